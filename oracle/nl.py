@@ -1,0 +1,193 @@
+"""
+Neighbour-list oracle (numpy) -- test infrastructure, never imported by the product.
+
+PARITY UNPINNED (values): the reference delegates this computation to the
+un-vendored third-party wheel ``vesin`` (pin ``>=0.6.1,<0.7``, reference
+``pyproject.toml:26``), called at ``src/metatrain/utils/neighbor_lists.py:131-135``
+as ``vesin.ase_neighbor_list("ijSD", atoms, cutoff)``. The reference's own tests
+only pin names/shape of the result (``tests/utils/test_neighbor_list.py:31-40``).
+This file restates the *contract* visible at that call site and in vesin's
+published description (a full, periodic, cell-list neighbour list):
+
+* full list: both (i, j, S) and (j, i, -S) are present;
+* self-images (i == j, S != 0) are present when the cell is smaller than the
+  cutoff; the pair (i, i, 0) never is;
+* ``D = r_j - r_i + S @ cell`` (``utils/neighbor_lists.py:179-201`` packs
+  ``first_atom, second_atom, cell_shift_a, cell_shift_b, cell_shift_c`` as int32);
+* a pair is kept when ``|D| < cutoff`` (strict; vesin and ASE both use ``<``).
+  PET re-filters with ``d <= cutoff`` (``pet/modules/structures.py:267``), so the
+  boundary convention cannot change energies.
+
+The output order of vesin is unspecified; "bit-exact" neighbour indices therefore
+means equality of the lexicographically sorted set of (i, j, Sa, Sb, Sc), which is
+the order this oracle returns.
+"""
+
+from typing import Tuple
+
+import numpy as np
+
+
+def _image_ranges(cell: np.ndarray, pbc: np.ndarray, cutoff: float) -> np.ndarray:
+    """Number of periodic images needed per lattice direction.
+
+    The height of the cell along direction a is ``V / |b x c|``; ``ceil(cutoff / h)``
+    images on each side are sufficient once positions are wrapped into the cell.
+    """
+    n = np.zeros(3, dtype=np.int64)
+    vol = abs(np.linalg.det(cell))
+    for a in range(3):
+        if not pbc[a]:
+            continue
+        b, c = cell[(a + 1) % 3], cell[(a + 2) % 3]
+        area = np.linalg.norm(np.cross(b, c))
+        height = vol / area
+        n[a] = int(np.ceil(cutoff / height))
+    return n
+
+
+def neighbor_list(
+    positions: np.ndarray,
+    cell: np.ndarray,
+    pbc: np.ndarray,
+    cutoff: float,
+) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+    """Full neighbour list ``(i, j, S, D)``, sorted by (i, j, Sa, Sb, Sc).
+
+    Works in float64 irrespective of the input dtype (the reference feeds vesin
+    float64 ASE positions, ``utils/neighbor_lists.py:128-135``).
+
+    :param positions: ``[N, 3]``.
+    :param cell: ``[3, 3]`` rows are lattice vectors; rows of non-periodic
+        directions may be zero (metatomic convention).
+    :param pbc: ``[3]`` bool.
+    :param cutoff: radial cutoff.
+    :return: ``i [E] int32, j [E] int32, S [E,3] int32, D [E,3] float64``.
+    """
+    pos = np.asarray(positions, dtype=np.float64)
+    cell = np.asarray(cell, dtype=np.float64)
+    pbc = np.asarray(pbc, dtype=bool)
+    n_atoms = pos.shape[0]
+    if n_atoms == 0:
+        z = np.zeros((0,), dtype=np.int32)
+        return z, z, np.zeros((0, 3), np.int32), np.zeros((0, 3), np.float64)
+
+    if pbc.any():
+        # wrap along periodic directions; remember the integer wrap so that shifts
+        # are reported relative to the *unwrapped* input positions
+        eff_cell = cell.copy()
+        for a in range(3):
+            if not pbc[a]:
+                # any vector completing the basis works: it is never used for
+                # shifts, only to make the matrix invertible
+                eff_cell[a] = 0.0
+        for a in range(3):
+            if not pbc[a]:
+                others = [eff_cell[b] for b in range(3) if b != a]
+                cand = np.cross(others[0], others[1])
+                if np.linalg.norm(cand) < 1e-12:
+                    for e in np.eye(3):
+                        trial = eff_cell.copy()
+                        trial[a] = e
+                        if abs(np.linalg.det(trial)) > 1e-12:
+                            cand = e
+                            break
+                eff_cell[a] = cand / np.linalg.norm(cand)
+        frac = pos @ np.linalg.inv(eff_cell)
+        wrap = np.zeros_like(frac)
+        wrap[:, pbc] = np.floor(frac[:, pbc])
+        wrapped = pos - wrap @ eff_cell
+        wrap = wrap.astype(np.int64)
+        n_img = _image_ranges(eff_cell, pbc, cutoff)
+    else:
+        eff_cell = np.zeros((3, 3))
+        wrapped = pos
+        wrap = np.zeros((n_atoms, 3), dtype=np.int64)
+        n_img = np.zeros(3, dtype=np.int64)
+
+    from scipy.spatial import cKDTree
+
+    tree = cKDTree(wrapped)
+    out_i, out_j, out_s = [], [], []
+    lo, hi = wrapped.min(axis=0) - cutoff, wrapped.max(axis=0) + cutoff
+    for sa in range(-n_img[0], n_img[0] + 1):
+        for sb in range(-n_img[1], n_img[1] + 1):
+            for sc in range(-n_img[2], n_img[2] + 1):
+                shift = np.array([sa, sb, sc], dtype=np.int64)
+                image = wrapped + shift @ eff_cell
+                keep = np.nonzero(np.all((image >= lo) & (image <= hi), axis=1))[0]
+                if keep.size == 0:
+                    continue
+                sub = cKDTree(image[keep])
+                pairs = tree.query_ball_tree(sub, cutoff * (1 + 1e-9) + 1e-9)
+                for i, js in enumerate(pairs):
+                    for jj in js:
+                        j = keep[jj]
+                        if i == j and sa == 0 and sb == 0 and sc == 0:
+                            continue
+                        out_i.append(i)
+                        out_j.append(j)
+                        out_s.append(shift)
+    if not out_i:
+        z = np.zeros((0,), dtype=np.int32)
+        return z, z, np.zeros((0, 3), np.int32), np.zeros((0, 3), np.float64)
+
+    i = np.asarray(out_i, dtype=np.int64)
+    j = np.asarray(out_j, dtype=np.int64)
+    s_wrapped = np.asarray(out_s, dtype=np.int64)
+    # shift relative to the unwrapped positions:
+    #   r_j + S cell - r_i = (w_j + wrap_j cell) + S cell - (w_i + wrap_i cell)
+    # with w = wrapped  =>  S = S_wrapped + wrap_i - wrap_j ... solved for S below
+    s = s_wrapped + wrap[i] - wrap[j]
+    d = pos[j] - pos[i] + s @ eff_cell
+    dist2 = np.einsum("ij,ij->i", d, d)
+    keep = dist2 < cutoff * cutoff
+    i, j, s, d = i[keep], j[keep], s[keep], d[keep]
+    order = np.lexsort((s[:, 2], s[:, 1], s[:, 0], j, i))
+    return (
+        i[order].astype(np.int32),
+        j[order].astype(np.int32),
+        s[order].astype(np.int32),
+        d[order],
+    )
+
+
+def neighbor_list_bruteforce(
+    positions: np.ndarray, cell: np.ndarray, pbc: np.ndarray, cutoff: float
+) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+    """O(N^2 * images) reference used to cross-check :func:`neighbor_list`
+    on small systems (no wrapping, no trees: the plainest statement)."""
+    pos = np.asarray(positions, dtype=np.float64)
+    cell = np.asarray(cell, dtype=np.float64)
+    pbc = np.asarray(pbc, dtype=bool)
+    n_atoms = pos.shape[0]
+    n_img = np.zeros(3, dtype=np.int64)
+    if pbc.any():
+        # generous image range: positions may be unwrapped by up to `span` cells
+        tmp = cell.copy()
+        for a in range(3):
+            if not pbc[a]:
+                tmp[a] = np.eye(3)[a] * 1e6
+        n_img = _image_ranges(tmp, pbc, cutoff)
+        frac = pos @ np.linalg.inv(tmp)
+        span = np.ceil(frac.max(axis=0) - frac.min(axis=0)).astype(np.int64)
+        n_img = np.where(pbc, n_img + span, 0)
+    rows = []
+    for sa in range(-n_img[0], n_img[0] + 1):
+        for sb in range(-n_img[1], n_img[1] + 1):
+            for sc in range(-n_img[2], n_img[2] + 1):
+                sh = np.array([sa, sb, sc])
+                d = pos[None, :, :] - pos[:, None, :] + (sh @ cell)[None, None, :]
+                dist2 = (d * d).sum(-1)
+                ii, jj = np.nonzero(dist2 < cutoff * cutoff)
+                for i, j in zip(ii, jj):
+                    if i == j and not sh.any():
+                        continue
+                    rows.append((i, j, sa, sb, sc))
+    if not rows:
+        z = np.zeros((0,), dtype=np.int32)
+        return z, z, np.zeros((0, 3), np.int32), np.zeros((0, 3), np.float64)
+    rows = np.array(sorted(rows), dtype=np.int64)
+    i, j, s = rows[:, 0], rows[:, 1], rows[:, 2:]
+    d = pos[j] - pos[i] + s @ cell
+    return i.astype(np.int32), j.astype(np.int32), s.astype(np.int32), d

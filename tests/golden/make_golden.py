@@ -1,0 +1,246 @@
+"""
+Generate the golden fixtures in this directory by IMPORTING the reference
+(`/root/reference`, read-only) in the build container. The reference never
+travels to the GPU box; only the ``*.npz`` files written here do.
+
+Run from the repo root:   python tests/golden/make_golden.py
+
+What is imported: the seven PET module files
+``/root/reference/src/metatrain/pet/modules/{utilities,nef,adaptive_cutoff,
+conditioning,transformer,structures,backend}.py`` are loaded UNCHANGED by path,
+after three stub modules provide the type-annotation-only names they import
+(``metatensor.torch.Labels``, ``metatomic.torch.{NeighborListOptions,System}``,
+``metatrain.pet.documentation.ModelHypers``). Recipe: SURVEY.md Appendix A.
+
+Fixtures written (all small):
+
+``qm9_first5.npz``         inputs of the first five frames of the reference's
+                           ``tests/resources/qm9_reduced_100.xyz`` + the five
+                           regression energies hard-coded in
+                           ``pet/tests/test_regression.py:66-74`` + the energies
+                           this import produced with ``torch.manual_seed(0)``.
+``batch_<case>.npz``       the 12 ``batch_data`` tensors of ``PETBackend.preprocess``
+                           for: ``co2cell`` (2-atom 3.5 A cubic C/O cell of
+                           ``pet/tests/test_backend.py:69-81``), ``box64``
+                           (64-atom random box, shuffled non-strict NL with rc+1),
+                           ``two_systems`` (two boxes with different cells).
+``pet_tiny_<dtype>.npz``   E, dE/dR, per-atom E for reduced hypers (d_pet=16, ...)
+                           with the synthetic weight generator, fp32 and fp64.
+``pet_default_box64.npz``  E, dE/dR, per-atom E, node/edge features for default
+                           hypers with the synthetic weight generator (seed 0).
+``pet_default_box1000.npz`` E, dE/dR for a 1000-atom box,
+                           fp32 and fp64 reference values.
+"""
+
+import importlib.util
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/src/metatrain"
+
+
+def import_reference_backend():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+
+    class _Placeholder:  # annotation-only names
+        pass
+
+    stub("metatensor")
+    stub("metatensor.torch", Labels=_Placeholder)
+    stub("metatomic")
+    stub("metatomic.torch", NeighborListOptions=_Placeholder, System=_Placeholder)
+    for pkg in ("metatrain", "metatrain.pet", "metatrain.pet.modules"):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+    stub("metatrain.pet.documentation", ModelHypers=dict)
+    for f in (
+        "utilities", "nef", "adaptive_cutoff", "conditioning", "transformer",
+        "structures", "backend",
+    ):
+        spec = importlib.util.spec_from_file_location(
+            f"metatrain.pet.modules.{f}", f"{REF}/pet/modules/{f}.py"
+        )
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = mod
+        spec.loader.exec_module(mod)
+    from metatrain.pet.modules.backend import PETBackend
+
+    return PETBackend
+
+
+def read_xyz_frames(path, n_frames):
+    """Minimal extended-xyz reader for species + positions (non-periodic QM9)."""
+    sym2z = {"H": 1, "C": 6, "N": 7, "O": 8, "F": 9}
+    frames = []
+    with open(path) as fh:
+        lines = fh.readlines()
+    k = 0
+    while len(frames) < n_frames:
+        n = int(lines[k])
+        body = lines[k + 2 : k + 2 + n]
+        z = [sym2z[ln.split()[0]] for ln in body]
+        xyz = [[float(x) for x in ln.split()[1:4]] for ln in body]
+        frames.append((np.array(z), np.array(xyz)))
+        k += 2 + n
+    return frames
+
+
+def run_reference(backend, name, pos, cells, centers, neighbors, shifts, species, sysidx,
+                  want_features=False):
+    pos = pos.detach().clone().requires_grad_(True)
+    batch = backend.preprocess(pos, centers, neighbors, species, cells, shifts, sysidx, 1.0)
+    nf, ef = backend.calculate_features(batch)
+    pred, _, _ = backend.predict(nf, ef, batch, cells, sysidx, [name])
+    atomic = pred[name][0]
+    n_sys = cells.shape[0]
+    energies = torch.zeros(n_sys, atomic.shape[1], dtype=atomic.dtype).index_add(
+        0, sysidx, atomic
+    )
+    (grad,) = torch.autograd.grad(energies.sum(), pos)
+    out = {
+        "energies": energies.detach().numpy(),
+        "atomic": atomic.detach().numpy(),
+        "grad": grad.numpy(),
+    }
+    if want_features:
+        out["node_features"] = nf[0].detach().numpy()
+        out["edge_features"] = ef[0].detach().numpy()
+    return out, batch
+
+
+def main():
+    from oracle import nl as onl
+    from oracle import pet as opet
+
+    PETBackend = import_reference_backend()
+    torch.set_num_threads(8)
+    hypers = dict(opet.DEFAULT_HYPERS)
+
+    # ------------------------------------------------------------------ regression pin
+    random.seed(0)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    backend = PETBackend(hypers, [1, 6, 7, 8])
+    backend.add_output("mtt::U0", {"mtt::U0": [1]})
+    backend.eval()
+    frames = read_xyz_frames("/root/reference/tests/resources/qm9_reduced_100.xyz", 5)
+    expected = np.array(  # pet/tests/test_regression.py:66-74
+        [1.146098375320, 0.171331465244, 0.539504408836, 0.861489117146, 0.177449733019]
+    )
+    got = []
+    store = {"expected_reference_test": expected}
+    for k, (z, xyz) in enumerate(frames):
+        i, j, s, _ = onl.neighbor_list(xyz, np.zeros((3, 3)), [False] * 3, hypers["cutoff"])
+        pos = torch.tensor(xyz, dtype=torch.float32)
+        res, _ = run_reference(
+            backend, "mtt::U0", pos, torch.zeros(1, 3, 3),
+            torch.tensor(i), torch.tensor(j), torch.tensor(s).long(),
+            torch.tensor(z), torch.zeros(len(z), dtype=torch.long),
+        )
+        got.append(float(res["energies"][0, 0]))
+        store[f"z{k}"] = z.astype(np.int32)
+        store[f"pos{k}"] = xyz
+    got = np.array(got)
+    print("regression energies: got", got, "\n expected", expected)
+    assert np.allclose(got, expected, rtol=1.3e-6, atol=1e-5), "reference import broken"
+    store["reference_import_seed0"] = got
+    np.savez(os.path.join(HERE, "qm9_first5.npz"), **store)
+
+    # ------------------------------------------------------------------ batch_data
+    def batch_case(tag, systems, cutoff_nl, shuffle_seed=None):
+        pos_l, z_l, cell_l, i_l, j_l, s_l, sys_l = [], [], [], [], [], [], []
+        off = 0
+        for k, (pos, z, cell, pbc) in enumerate(systems):
+            i, j, s, _ = onl.neighbor_list(pos.double().numpy(), cell.double().numpy(), pbc, cutoff_nl)
+            pos_l.append(pos); z_l.append(z); cell_l.append(cell)
+            i_l.append(torch.tensor(i) + off); j_l.append(torch.tensor(j) + off)
+            s_l.append(torch.tensor(s)); sys_l.append(torch.full((len(z),), k, dtype=torch.long))
+            off += len(z)
+        pos = torch.cat(pos_l); z = torch.cat(z_l); cells = torch.stack(cell_l)
+        i = torch.cat(i_l); j = torch.cat(j_l); s = torch.cat(s_l); sysidx = torch.cat(sys_l)
+        if shuffle_seed is not None:
+            perm = torch.randperm(len(i), generator=torch.Generator().manual_seed(shuffle_seed))
+            i, j, s = i[perm], j[perm], s[perm]
+        be = PETBackend(hypers, [1, 6, 7, 8])
+        batch = be.preprocess(pos, i, j, z, cells, s, sysidx, 1.0)
+        out = {"in_" + k: v.numpy() for k, v in dict(
+            positions=pos, species=z, cells=cells, centers=i, neighbors=j, cell_shifts=s,
+            system_indices=sysidx).items()}
+        out.update({k: v.numpy() for k, v in batch.items()})
+        np.savez(os.path.join(HERE, f"batch_{tag}.npz"), **out)
+        print(tag, "E =", len(i), "kept", len(batch["centers"]), "M =", batch["padding_mask"].shape[1])
+
+    pbc = [True] * 3
+    co = (torch.tensor([[0.0, 0.0, 0.0], [1.5, 1.5, 1.5]]), torch.tensor([6, 8], dtype=torch.int32),
+          3.5 * torch.eye(3), pbc)
+    batch_case("co2cell", [co], hypers["cutoff"])
+    p64, z64, c64 = opet.random_box(64, seed=1)
+    batch_case("box64", [(p64, z64, c64, pbc)], hypers["cutoff"] + 1.0, shuffle_seed=3)
+    p40, z40, c40 = opet.random_box(40, seed=2)
+    tri = c40.clone(); tri[1, 0] = 2.0; tri[2, 1] = -1.5
+    batch_case("two_systems", [(p64, z64, c64, pbc), (p40 + 30.0, z40, tri, pbc)],
+               hypers["cutoff"], shuffle_seed=4)
+
+    # ------------------------------------------------------------------ E / dE/dR
+    def pet_case(tag, hyp, systems, dtypes, seed=0, want_features=False, save_params=False):
+        store = {}
+        for dtype in dtypes:
+            params = opet.synthetic_params(hyp, [1, 6, 7, 8], {"energy": 1}, seed, dtype)
+            be = PETBackend(hyp, [1, 6, 7, 8])
+            be.add_output("energy", {"energy": [1]})
+            be = be.to(dtype).eval()
+            missing = be.load_state_dict(params, strict=True)
+            assert not missing.missing_keys and not missing.unexpected_keys
+            assert list(be.state_dict().keys()) == list(params.keys()), "schema order"
+            pos_l, z_l, cell_l, i_l, j_l, s_l, sys_l = [], [], [], [], [], [], []
+            off = 0
+            for k, (pos, z, cell) in enumerate(systems):
+                i, j, s, _ = onl.neighbor_list(pos.double().numpy(), cell.double().numpy(),
+                                               [True] * 3, hyp["cutoff"])
+                pos_l.append(pos.to(dtype)); z_l.append(z); cell_l.append(cell.to(dtype))
+                i_l.append(torch.tensor(i) + off); j_l.append(torch.tensor(j) + off)
+                s_l.append(torch.tensor(s)); sys_l.append(torch.full((len(z),), k, dtype=torch.long))
+                off += len(z)
+            args = (torch.cat(pos_l), torch.stack(cell_l), torch.cat(i_l), torch.cat(j_l),
+                    torch.cat(s_l).long(), torch.cat(z_l), torch.cat(sys_l))
+            res, _ = run_reference(be, "energy", *args, want_features=want_features)
+            sfx = {torch.float32: "f32", torch.float64: "f64"}[dtype]
+            for k, v in res.items():
+                store[f"{k}_{sfx}"] = v
+            if save_params and dtype == torch.float64:
+                for k, v in params.items():
+                    store["param::" + k] = v.numpy()
+            print(tag, sfx, "E =", res["energies"].ravel()[:4], "|grad|max =", np.abs(res["grad"]).max())
+        store["in_positions"] = args[0].double().numpy()
+        store["in_cells"] = args[1].double().numpy()
+        store["in_centers"] = args[2].numpy().astype(np.int32)
+        store["in_neighbors"] = args[3].numpy().astype(np.int32)
+        store["in_cell_shifts"] = args[4].numpy().astype(np.int32)
+        store["in_species"] = args[5].numpy().astype(np.int32)
+        store["in_system_indices"] = args[6].numpy()
+        np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **store)
+
+    tiny = dict(hypers, d_pet=16, d_node=32, d_head=16, d_feedforward=32, num_heads=2)
+    pet_case("pet_tiny", tiny, [(p64, z64, c64), (p40, z40, tri)],
+             [torch.float32, torch.float64], save_params=True)
+    pet_case("pet_default_box64", hypers, [(p64, z64, c64)],
+             [torch.float32, torch.float64], want_features=True)
+    p1k, z1k, c1k = opet.random_box(1000, seed=0)
+    pet_case("pet_default_box1000", hypers, [(p1k, z1k, c1k)], [torch.float32, torch.float64])
+
+
+if __name__ == "__main__":
+    main()

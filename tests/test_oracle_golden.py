@@ -1,0 +1,121 @@
+"""CPU tests: the oracle (``oracle/``) against the golden vectors generated from the
+reference (``tests/golden/make_golden.py``) and against the reference's own
+hard-coded regression energies (``pet/tests/test_regression.py:66-74``)."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nef as onef
+from oracle import nl as onl
+from oracle import pet as opet
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def test_oracle_reproduces_reference_regression_energies(golden_dir):
+    """Seed-0 default-init PET on the first five QM9 frames: the five numbers
+    hard-coded in the reference's test_regression.py."""
+    g = _load(golden_dir, "qm9_first5.npz")
+    hypers = dict(opet.DEFAULT_HYPERS)
+    params = opet.reference_init_params(hypers, [1, 6, 7, 8], "mtt::U0", seed=0)
+    got = []
+    for k in range(5):
+        z, xyz = g[f"z{k}"], g[f"pos{k}"]
+        i, j, s, _ = onl.neighbor_list(xyz, np.zeros((3, 3)), [False] * 3, hypers["cutoff"])
+        e, _, _ = opet.energy_and_gradient(
+            params, hypers, torch.tensor(xyz, dtype=torch.float32), torch.zeros(1, 3, 3),
+            torch.tensor(i), torch.tensor(j), torch.tensor(s).long(), torch.tensor(z),
+            torch.zeros(len(z), dtype=torch.long), target="mtt::U0",
+        )
+        got.append(float(e[0, 0]))
+    # the reference's own tolerance: torch.testing.assert_close fp32 defaults
+    np.testing.assert_allclose(got, g["expected_reference_test"], rtol=1.3e-6, atol=1e-5)
+    np.testing.assert_allclose(got, g["reference_import_seed0"], rtol=1.3e-6, atol=2e-6)
+
+
+INT_KEYS = [
+    "element_indices_nodes", "element_indices_neighbors", "padding_mask",
+    "reverse_neighbor_index", "centers", "neighbors", "nef_to_edges_neighbor", "cell_shifts",
+]
+FLOAT_KEYS = ["edge_vectors", "edge_distances", "cutoff_factors", "atomic_cutoffs_stats"]
+
+
+@pytest.mark.parametrize("case", ["co2cell", "box64", "two_systems"])
+def test_oracle_batch_tensors_match_reference(golden_dir, case):
+    g = _load(golden_dir, f"batch_{case}.npz")
+    hypers = dict(opet.DEFAULT_HYPERS)
+    idx = torch.full((9,), -1, dtype=torch.long)
+    for n, z in enumerate([1, 6, 7, 8]):
+        idx[z] = n
+    got = opet.batch_tensors(
+        hypers, idx, torch.tensor(g["in_positions"]), torch.tensor(g["in_cells"]),
+        torch.tensor(g["in_centers"]), torch.tensor(g["in_neighbors"]),
+        torch.tensor(g["in_cell_shifts"]), torch.tensor(g["in_species"]),
+        torch.tensor(g["in_system_indices"]),
+    )
+    for k in INT_KEYS:
+        assert got[k].shape == g[k].shape, k
+        assert np.array_equal(got[k], g[k]), f"integer key {k} not bit-exact"
+    for k in FLOAT_KEYS:
+        np.testing.assert_allclose(got[k], g[k], rtol=2e-6, atol=2e-6, err_msg=k)
+
+
+def _run_oracle(g, hypers, params, dtype):
+    return opet.energy_and_gradient(
+        params, hypers, torch.tensor(g["in_positions"], dtype=dtype),
+        torch.tensor(g["in_cells"], dtype=dtype), torch.tensor(g["in_centers"]),
+        torch.tensor(g["in_neighbors"]), torch.tensor(g["in_cell_shifts"]).long(),
+        torch.tensor(g["in_species"]), torch.tensor(g["in_system_indices"]),
+    )
+
+
+@pytest.mark.parametrize("dtype,sfx,tol", [(torch.float64, "f64", 1e-10), (torch.float32, "f32", 2e-5)])
+def test_oracle_tiny_energy_and_gradient(golden_dir, dtype, sfx, tol):
+    g = _load(golden_dir, "pet_tiny.npz")
+    hypers = dict(opet.DEFAULT_HYPERS, d_pet=16, d_node=32, d_head=16, d_feedforward=32, num_heads=2)
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, dtype)
+    for k, v in params.items():  # the committed state dict IS the generator's output
+        np.testing.assert_allclose(v.double().numpy(), g["param::" + k], rtol=1e-6 if dtype == torch.float32 else 0, atol=0)
+    e, grad, atomic = _run_oracle(g, hypers, params, dtype)
+    np.testing.assert_allclose(e.numpy(), g[f"energies_{sfx}"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(atomic.detach().numpy(), g[f"atomic_{sfx}"], rtol=tol, atol=tol)
+    scale = np.abs(g[f"grad_{sfx}"]).max()
+    assert np.abs(grad.numpy() - g[f"grad_{sfx}"]).max() / scale < tol
+
+
+@pytest.mark.parametrize("dtype,sfx,tol", [(torch.float64, "f64", 1e-10), (torch.float32, "f32", 1e-5)])
+def test_oracle_default_box64(golden_dir, dtype, sfx, tol):
+    g = _load(golden_dir, "pet_default_box64.npz")
+    hypers = dict(opet.DEFAULT_HYPERS)
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, dtype)
+    e, grad, atomic = _run_oracle(g, hypers, params, dtype)
+    np.testing.assert_allclose(e.numpy(), g[f"energies_{sfx}"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(atomic.detach().numpy(), g[f"atomic_{sfx}"], rtol=tol, atol=10 * tol)
+    scale = np.abs(g[f"grad_{sfx}"]).max()
+    assert np.abs(grad.numpy() - g[f"grad_{sfx}"]).max() / scale < tol
+
+
+def test_nl_oracle_tree_vs_bruteforce():
+    """The two statements of the NL contract agree (sorted (i,j,S) sets), including
+    self-images in a cell smaller than the cutoff and a triclinic cell."""
+    rng = np.random.default_rng(0)
+    cases = [
+        (np.array([[0.0, 0, 0], [1.5, 1.5, 1.5]]), 3.5 * np.eye(3), [True] * 3),
+        (rng.uniform(-3, 9, (30, 3)), np.array([[6.0, 0, 0], [1.5, 5.5, 0], [-1.0, 0.7, 7.0]]), [True] * 3),
+        (rng.uniform(0, 6, (25, 3)), np.array([[6.0, 0, 0], [0, 6.0, 0], [0, 0, 6.0]]), [True, True, False]),
+        (rng.uniform(0, 7, (20, 3)), np.zeros((3, 3)), [False] * 3),
+    ]
+    for pos, cell, pbc in cases:
+        a = onl.neighbor_list(pos, cell, pbc, 4.5)
+        b = onl.neighbor_list_bruteforce(pos, cell, pbc, 4.5)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.array_equal(a[2], b[2])
+        np.testing.assert_allclose(a[3], b[3], atol=1e-12)
+        # full list: every (i,j,S) has its (j,i,-S)
+        fwd = set(map(tuple, np.column_stack([a[0], a[1], a[2]]).tolist()))
+        assert all((j, i, -x, -y, -z) in fwd for (i, j, x, y, z) in fwd)
