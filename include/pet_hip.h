@@ -1,0 +1,169 @@
+/*
+ * pet_hip.h -- C ABI of libpet_hip.so: the MI355X (gfx950) hot path of metatrain's PET.
+ *
+ * Drop-in boundary: the plain-tensor L1 API of the reference,
+ *   PETBackend.preprocess          src/metatrain/pet/modules/backend.py:238-342
+ *   PETBackend.calculate_features  src/metatrain/pet/modules/backend.py:344-418
+ *   PETBackend.predict             src/metatrain/pet/modules/backend.py:420-494
+ *   compute_gradient (dE/dR)       src/metatrain/utils/output_gradient.py:7-63
+ *   vesin.ase_neighbor_list        src/metatrain/utils/neighbor_lists.py:131-135
+ * The reference is pure Python on torch; a maintainer binds this library with the
+ * ctypes stub shown in INTEGRATION.md (or torch.ops via a thin TORCH_LIBRARY shim).
+ *
+ * Conventions
+ *   - every pointer named d_* is DEVICE memory owned by the caller (e.g. a torch
+ *     tensor's data_ptr()); the library never frees or retains it beyond the call,
+ *     except for workspaces which the caller keeps alive while handles refer to them;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream);
+ *   - all calls return PET_OK (0) or a negative error code; pet_last_error() returns
+ *     a thread-local human-readable message for the last failure;
+ *   - float data is fp32, indices are int32 unless stated otherwise;
+ *   - no torch types, no host-side allocation of device memory on the hot path.
+ */
+#ifndef PET_HIP_H
+#define PET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PET_OK 0
+#define PET_ERR_HIP -1          /* a HIP runtime call failed                        */
+#define PET_ERR_UNSUPPORTED -2  /* hypers outside the compiled kernel instantiation */
+#define PET_ERR_ARGUMENT -3     /* bad argument / missing parameter / short buffer  */
+#define PET_ERR_GRAPH -4        /* neighbour list is not a full list (no ji for ij) */
+
+#define PET_CUTOFF_COSINE 0
+#define PET_CUTOFF_BUMP 1
+
+/* Mirrors the subset of ModelHypers that shapes the hot path
+ * (src/metatrain/pet/documentation.py:159-259). */
+typedef struct pet_hypers {
+    float cutoff;            /* 4.5   */
+    float cutoff_width;      /* 0.5   */
+    int32_t cutoff_function; /* PET_CUTOFF_BUMP */
+    int32_t d_pet;           /* 128   */
+    int32_t d_head;          /* 128   */
+    int32_t d_node;          /* 256   */
+    int32_t d_feedforward;   /* 256   */
+    int32_t num_heads;       /* 8     */
+    int32_t num_attention_layers; /* 2 */
+    int32_t num_gnn_layers;       /* 2 */
+    float attention_temperature;  /* 1.0 */
+    int32_t nl_is_strict;    /* = long_range.enable (backend.py:38); 0 => filter d <= cutoff */
+    int32_t n_species;       /* len(atomic_types) */
+    int32_t max_atomic_number; /* species_to_species_index has max+1 entries */
+} pet_hypers_t;
+
+typedef struct pet_model pet_model_t; /* packed weights on the device */
+typedef struct pet_graph pet_graph_t; /* CSR edge graph living in a caller workspace */
+
+/* ---- library ------------------------------------------------------------------ */
+const char* pet_last_error(void);
+const char* pet_version(void);
+/* 1 if the default hypers instantiation (d_pet=128, d_node=256, d_ff=256, d_head=128,
+ * heads=8) matches `h`, else 0. */
+int pet_hypers_supported(const pet_hypers_t* h);
+
+/* ---- model: owns device copies of the weights in MFMA fragment order ----------- */
+int pet_model_create(const pet_hypers_t* h, pet_model_t** out);
+void pet_model_destroy(pet_model_t* m);
+/* Upload one tensor of the reference state dict (SURVEY §8(b) key schema, e.g.
+ * "gnn_layers.0.trans.layers.1.mlp.w_in.weight"). `d_data` is a device pointer to
+ * `numel` contiguous fp32 values (int64 values for "species_to_species_index").
+ * Heads of ONE target are addressed with the literal target name "energy" replaced by
+ * the caller's target: keys "node_heads.<t>.0.0.weight" ... are passed with <t>
+ * stripped to "@" (e.g. "node_heads.@.0.0.weight", "node_last_layers.@.0.@.weight"). */
+int pet_model_set_param(pet_model_t* m, const char* key, const void* d_data,
+                        int64_t numel, void* stream);
+/* Pack / precompute derived tables once all parameters are set. */
+int pet_model_finalize(pet_model_t* m, void* stream);
+int64_t pet_model_num_params(const pet_model_t* m);
+
+/* ---- neighbour list (replaces vesin at utils/neighbor_lists.py:131-135) --------- */
+/* Full periodic neighbour list of ONE system within `cutoff` (strict: |D| < cutoff).
+ * Two-call protocol: pass d_pairs = NULL to count; then allocate n_pairs rows.
+ *   d_positions [n,3] fp32, h_cell[9] row-major lattice (host), h_pbc[3] (host)
+ *   d_pairs     [n_pairs,5] int32 rows (i, j, Sa, Sb, Sc), grouped by i (CSR order)
+ *   d_vectors   [n_pairs,3] fp32 D = r_j - r_i + S.cell   (may be NULL)
+ *   d_workspace: pet_nl_workspace_bytes(n) bytes. */
+int64_t pet_nl_workspace_bytes(int64_t n_atoms);
+int pet_nl_build(const float* d_positions, const float* h_cell, const int32_t* h_pbc,
+                 int64_t n_atoms, float cutoff, void* d_workspace, int32_t* d_pairs,
+                 float* d_vectors, int64_t capacity, int64_t* n_pairs, void* stream);
+
+/* ---- preprocess (replaces PETBackend.preprocess, backend.py:238) --------------- */
+int64_t pet_graph_workspace_bytes(int64_t n_nodes, int64_t n_edges_in);
+/* Builds edge vectors, the non-strict filter, cutoff factors, the CSR (= NEF slot)
+ * order and the ij->ji map.  Inputs as in compute_batch_tensors
+ * (pet/modules/structures.py:115-131): d_positions [N,3], d_cells [S,3,3],
+ * d_centers/d_neighbors [E] int32 (global atom indices), d_cell_shifts [E,3] int32,
+ * d_species [N] int32 atomic numbers, d_system_indices [N] int32.
+ * One device->host read-back of two integers (kept edges, max neighbours) happens
+ * here, like the reference's int(torch.max(num_neighbors)) (structures.py:292). */
+int pet_graph_build(const pet_model_t* m, const float* d_positions, const float* d_cells,
+                    const int32_t* d_centers, const int32_t* d_neighbors,
+                    const int32_t* d_cell_shifts, const int32_t* d_species,
+                    const int32_t* d_system_indices, int64_t n_nodes, int64_t n_edges_in,
+                    int64_t n_systems, void* d_workspace, int64_t workspace_bytes,
+                    pet_graph_t** out, void* stream);
+void pet_graph_destroy(pet_graph_t* g);
+int64_t pet_graph_num_edges(const pet_graph_t* g);     /* kept edges E            */
+int32_t pet_graph_max_neighbors(const pet_graph_t* g); /* M of the NEF grid       */
+/* The 12 batch_data tensors of backend.py:328-341 in the reference's padded NEF
+ * layout (pads replicate kept edge 0). int64 where the reference
+ * has int64, uint8 for the bool mask. Any output pointer may be NULL. */
+int pet_graph_export_batch(const pet_graph_t* g,
+                           int64_t* d_element_indices_nodes,     /* [N]     */
+                           int64_t* d_element_indices_neighbors, /* [N,M]   */
+                           float* d_edge_vectors,                /* [N,M,3] */
+                           float* d_edge_distances,              /* [N,M]   */
+                           uint8_t* d_padding_mask,              /* [N,M]   */
+                           int64_t* d_reverse_neighbor_index,    /* [N,M]   */
+                           float* d_cutoff_factors,              /* [N,M]   */
+                           float* d_atomic_cutoffs_stats,        /* [N]     */
+                           int64_t* d_centers,                   /* [E]     */
+                           int64_t* d_neighbors,                 /* [E]     */
+                           int64_t* d_nef_to_edges_neighbor,     /* [E]     */
+                           int64_t* d_cell_shifts,               /* [E,3]   */
+                           void* stream);
+/* CSR views for callers that want the unpadded layout (device pointers into the
+ * graph workspace): rowptr [N+1], ctr/nbr/rev [E] int32. */
+int pet_graph_csr(const pet_graph_t* g, const int32_t** d_rowptr, const int32_t** d_ctr,
+                  const int32_t** d_nbr, const int32_t** d_rev);
+
+/* ---- features + predict + gradient -------------------------------------------- */
+/* Activation workspace for one forward (+ saved tensors for the backward). */
+int64_t pet_forward_workspace_bytes(const pet_model_t* m, int64_t n_nodes, int64_t n_edges);
+/* calculate_features + predict for the single registered target:
+ *   d_atomic [N]       per-atom prediction (node + sum of cutoff-weighted edge terms)
+ *   d_node_features [N,d_node] / d_edge_features [E,d_pet] (CSR rows): optional copies
+ *   of the backbone features (backend.py:585-586) -- may be NULL.
+ * save_for_backward != 0 keeps what pet_backward needs in the workspace. */
+int pet_forward(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
+                int64_t workspace_bytes, int save_for_backward, float* d_atomic,
+                float* d_node_features, float* d_edge_features, void* stream);
+/* Reverse pass of the last pet_forward on (m, g, workspace):
+ *   d_grad_atomic [N] = dL/d(atomic prediction) (ones => L = total energy),
+ *   d_grad_positions [N,3] = dL/dR  (what compute_gradient returns; force = -grad),
+ *   d_grad_cells [S,3,3] = dL/dcell through the S.cell term (may be NULL). */
+int pet_backward(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
+                 int64_t workspace_bytes, const float* d_grad_atomic,
+                 float* d_grad_positions, float* d_grad_cells, void* stream);
+/* Per-system sum (utils/sum_over_atoms.py:10-48): d_out[S] = sum_{atoms of s} d_atomic. */
+int pet_sum_over_atoms(const pet_graph_t* g, const float* d_atomic, float* d_out, void* stream);
+
+/* ---- profiling hooks used by bench.py ------------------------------------------ */
+/* When enabled, every kernel launch of pet_forward/pet_backward is bracketed with HIP
+ * events on the launch stream; pet_profile_report fills name/ms/calls arrays. */
+int pet_profile_enable(int on);
+int pet_profile_reset(void);
+int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int64_t* calls,
+                       double* flops, int* n_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PET_HIP_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of libpet_hip.so (the C ABI declared in include/pet_hip.h).
+
+There is no CPU fallback anywhere in this package: if the shared library is missing
+or fails to load, importing/using the HIP path raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpet_hip.so")
+
+PET_OK = 0
+PET_CUTOFF_COSINE = 0
+PET_CUTOFF_BUMP = 1
+
+# every symbol include/pet_hip.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "pet_last_error", "pet_version", "pet_hypers_supported",
+    "pet_model_create", "pet_model_destroy", "pet_model_set_param", "pet_model_finalize",
+    "pet_model_num_params",
+    "pet_nl_workspace_bytes", "pet_nl_build",
+    "pet_graph_workspace_bytes", "pet_graph_build", "pet_graph_destroy", "pet_graph_num_edges",
+    "pet_graph_max_neighbors", "pet_graph_export_batch", "pet_graph_csr",
+    "pet_forward_workspace_bytes", "pet_forward", "pet_backward", "pet_sum_over_atoms",
+    "pet_profile_enable", "pet_profile_reset", "pet_profile_report",
+]
+
+
+class PetHypers(ctypes.Structure):
+    """Mirror of ``pet_hypers_t``."""
+
+    _fields_ = [
+        ("cutoff", c_float),
+        ("cutoff_width", c_float),
+        ("cutoff_function", c_int32),
+        ("d_pet", c_int32),
+        ("d_head", c_int32),
+        ("d_node", c_int32),
+        ("d_feedforward", c_int32),
+        ("num_heads", c_int32),
+        ("num_attention_layers", c_int32),
+        ("num_gnn_layers", c_int32),
+        ("attention_temperature", c_float),
+        ("nl_is_strict", c_int32),
+        ("n_species", c_int32),
+        ("max_atomic_number", c_int32),
+    ]
+
+
+class PetHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libpet_hip.so and declare the prototypes. Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PetHipError(
+            f"{LIB_PATH} not found: build it with `python -m metatrain_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    P = c_void_p
+    lib.pet_last_error.restype = c_char_p
+    lib.pet_version.restype = c_char_p
+    lib.pet_hypers_supported.argtypes = [POINTER(PetHypers)]
+    lib.pet_model_create.argtypes = [POINTER(PetHypers), POINTER(P)]
+    lib.pet_model_destroy.argtypes = [P]
+    lib.pet_model_destroy.restype = None
+    lib.pet_model_set_param.argtypes = [P, c_char_p, P, c_int64, P]
+    lib.pet_model_finalize.argtypes = [P, P]
+    lib.pet_model_num_params.argtypes = [P]
+    lib.pet_model_num_params.restype = c_int64
+    lib.pet_nl_workspace_bytes.argtypes = [c_int64]
+    lib.pet_nl_workspace_bytes.restype = c_int64
+    lib.pet_nl_build.argtypes = [P, POINTER(c_float), POINTER(c_int32), c_int64, c_float, P, P, P,
+                                 c_int64, POINTER(c_int64), P]
+    lib.pet_graph_workspace_bytes.argtypes = [c_int64, c_int64]
+    lib.pet_graph_workspace_bytes.restype = c_int64
+    lib.pet_graph_build.argtypes = [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, P, c_int64,
+                                    POINTER(P), P]
+    lib.pet_graph_destroy.argtypes = [P]
+    lib.pet_graph_destroy.restype = None
+    lib.pet_graph_num_edges.argtypes = [P]
+    lib.pet_graph_num_edges.restype = c_int64
+    lib.pet_graph_max_neighbors.argtypes = [P]
+    lib.pet_graph_max_neighbors.restype = c_int32
+    lib.pet_graph_export_batch.argtypes = [P] + [P] * 12 + [P]
+    lib.pet_graph_csr.argtypes = [P, POINTER(P), POINTER(P), POINTER(P), POINTER(P)]
+    lib.pet_forward_workspace_bytes.argtypes = [P, c_int64, c_int64]
+    lib.pet_forward_workspace_bytes.restype = c_int64
+    lib.pet_forward.argtypes = [P, P, P, c_int64, c_int, P, P, P, P]
+    lib.pet_backward.argtypes = [P, P, P, c_int64, P, P, P, P]
+    lib.pet_sum_over_atoms.argtypes = [P, P, P, P]
+    lib.pet_profile_enable.argtypes = [c_int]
+    lib.pet_profile_report.argtypes = [c_int, P, POINTER(c_double), POINTER(c_int64), POINTER(c_double),
+                                       POINTER(c_int)]
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != PET_OK:
+        msg = load().pet_last_error().decode(errors="replace")
+        raise PetHipError(f"libpet_hip error {code}: {msg}")

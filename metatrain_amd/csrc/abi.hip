@@ -1,0 +1,435 @@
+// extern "C" entry points of libpet_hip.so (see include/pet_hip.h) + model packing.
+#include <math.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "common.h"
+#include "model.h"
+
+namespace pet {
+
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+
+// ---------------------------------------------------------------------------------
+// profiling: HIP events on the launch stream around every stage
+// ---------------------------------------------------------------------------------
+struct ProfRec {
+    std::string name;
+    hipEvent_t e0, e1;
+    double flops;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;
+
+ProfScope::ProfScope(const char* n, hipStream_t s, double f) : name(n), st(s), flops(f) {
+    if (!g_prof_on) return;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, st);
+}
+ProfScope::~ProfScope() {
+    if (!e0) return;
+    (void)hipEventRecord(e1, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back({name, e0, e1, flops});
+}
+
+// ---------------------------------------------------------------------------------
+// weight packing into MFMA fragment order (tile.h)
+// ---------------------------------------------------------------------------------
+__global__ void k_pack(const float* __restrict__ W, int64_t s_n, int64_t s_k, int n_out, int k_in,
+                       float4* __restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int kgn = k_in / 8;
+    int64_t total = (int64_t)(n_out / 32) * kgn * 64;
+    if (idx >= total) return;
+    int l = idx & 63;
+    int kg = (idx >> 6) % kgn;
+    int t = (int)((idx >> 6) / kgn);
+    int64_t n = t * 32 + (l & 31), k = kg * 8 + (l >> 5) * 4;
+    const float* p = W + n * s_n + k * s_k;
+    out[idx] = make_float4(p[0], p[s_k], p[2 * s_k], p[3 * s_k]);
+}
+
+static int dev_alloc(Model& m, void** p, size_t bytes) {
+    PET_HIP_CHECK(hipMalloc(p, bytes > 0 ? bytes : 4));
+    m.owned.push_back(*p);
+    return PET_OK;
+}
+
+// pack the [n_out, k_in] sub-matrix starting at column col0 of a row-major matrix with
+// leading dimension ld
+static int pack_lin(Model& m, Lin& L, const float* w, const float* b, int n_out, int k_in, int ld,
+                    int col0, hipStream_t st) {
+    PET_REQUIRE(n_out % 32 == 0 && k_in % 32 == 0, PET_ERR_UNSUPPORTED, "linear shape not tileable");
+    L.w = w + col0;
+    L.b = b;
+    L.n_out = n_out;
+    L.k_in = k_in;
+    size_t n4 = (size_t)(n_out / 32) * (k_in / 8) * 64;
+    int rc;
+    if ((rc = dev_alloc(m, (void**)&L.fwd, n4 * sizeof(float4))) != PET_OK) return rc;
+    if ((rc = dev_alloc(m, (void**)&L.bwd, n4 * sizeof(float4))) != PET_OK) return rc;
+    k_pack<<<cdiv(n4, 256), 256, 0, st>>>(w + col0, ld, 1, n_out, k_in, L.fwd);
+    // transposed operand: rows = original columns, k = original rows
+    k_pack<<<cdiv(n4, 256), 256, 0, st>>>(w + col0, 1, ld, k_in, n_out, L.bwd);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
+static int get(const Model& m, const std::string& key, int64_t numel, const float** out) {
+    auto it = m.raw.find(key);
+    PET_REQUIRE(it != m.raw.end(), PET_ERR_ARGUMENT, "missing parameter '" + key + "'");
+    PET_REQUIRE(it->second.second == numel, PET_ERR_ARGUMENT,
+                "parameter '" + key + "' has " + std::to_string(it->second.second) + " elements, expected " +
+                    std::to_string(numel));
+    *out = it->second.first;
+    return PET_OK;
+}
+
+static int get_lin(Model& m, const std::string& key, int n_out, int k_in, Lin& L, hipStream_t st) {
+    const float *w, *b;
+    int rc;
+    if ((rc = get(m, key + ".weight", (int64_t)n_out * k_in, &w)) != PET_OK) return rc;
+    if ((rc = get(m, key + ".bias", n_out, &b)) != PET_OK) return rc;
+    return pack_lin(m, L, w, b, n_out, k_in, k_in, 0, st);
+}
+
+static int download(const float* d, size_t n, std::vector<double>& out, hipStream_t st) {
+    std::vector<float> tmp(n);
+    PET_HIP_CHECK(hipMemcpyAsync(tmp.data(), d, n * sizeof(float), hipMemcpyDeviceToHost, st));
+    PET_HIP_CHECK(hipStreamSynchronize(st));
+    out.assign(tmp.begin(), tmp.end());
+    return PET_OK;
+}
+
+static int upload(Model& m, const std::vector<double>& v, float** d, hipStream_t st) {
+    std::vector<float> tmp(v.begin(), v.end());
+    int rc = dev_alloc(m, (void**)d, tmp.size() * sizeof(float));
+    if (rc != PET_OK) return rc;
+    PET_HIP_CHECK(hipMemcpyAsync(*d, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    PET_HIP_CHECK(hipStreamSynchronize(st));
+    return PET_OK;
+}
+
+static int finalize(Model& m, hipStream_t st) {
+    const pet_hypers_t& h = m.h;
+    const int ns = h.n_species;
+    int rc;
+    m.gnn.clear();
+    m.gnn.resize(h.num_gnn_layers);
+    for (int g = 0; g < h.num_gnn_layers; g++) {
+        GnnLayerW& G = m.gnn[g];
+        const std::string pre = "gnn_layers." + std::to_string(g);
+        G.attn.resize(h.num_attention_layers);
+        for (int a = 0; a < h.num_attention_layers; a++) {
+            AttnLayerW& A = G.attn[a];
+            const std::string lp = pre + ".trans.layers." + std::to_string(a);
+            if ((rc = get_lin(m, lp + ".attention.input_linear", 3 * D, D, A.qkv, st))) return rc;
+            if ((rc = get_lin(m, lp + ".attention.output_linear", D, D, A.out, st))) return rc;
+            if ((rc = get(m, lp + ".norm_attention.weight", D, &A.g_attn))) return rc;
+            if ((rc = get(m, lp + ".norm_mlp.weight", D, &A.g_mlp))) return rc;
+            if ((rc = get_lin(m, lp + ".mlp.w_in", 2 * DFF, D, A.mlp_in, st))) return rc;
+            if ((rc = get_lin(m, lp + ".mlp.w_out", D, DFF, A.mlp_out, st))) return rc;
+            if ((rc = get_lin(m, lp + ".center_contraction", D, DN, A.cc, st))) return rc;
+            if ((rc = get_lin(m, lp + ".center_expansion", DN, D, A.ce, st))) return rc;
+            if ((rc = get(m, lp + ".norm_center_features.weight", DN, &A.g_center))) return rc;
+            if ((rc = get_lin(m, lp + ".center_mlp.w_in", 2 * DNF, DN, A.cmlp_in, st))) return rc;
+            if ((rc = get_lin(m, lp + ".center_mlp.w_out", DN, DNF, A.cmlp_out, st))) return rc;
+        }
+        // ---- compress.0 decomposition (transformer.py:499-521) -------------------
+        // tokens = [edge_embedder([v, d]) ; (g>0: neighbor_embedder[species]) ; message]
+        // compress.0 is linear in each block, so
+        //   a0 = [v,d] (W0a Wee)^T + (W0a bee + b0) + W0b emb[species] (+ W0c message, g>0)
+        // where for g == 0 the "message" block IS an embedding lookup (backend.py:516).
+        const int kin = (g == 0 ? 2 : 3) * D;
+        const float *w0, *b0, *wee, *bee, *emb;
+        if ((rc = get(m, pre + ".compress.0.weight", (int64_t)D * kin, &w0))) return rc;
+        if ((rc = get(m, pre + ".compress.0.bias", D, &b0))) return rc;
+        if ((rc = get(m, pre + ".edge_embedder.weight", D * 4, &wee))) return rc;
+        if ((rc = get(m, pre + ".edge_embedder.bias", D, &bee))) return rc;
+        if (g == 0) {
+            if ((rc = get(m, "edge_embedder.weight", (int64_t)ns * D, &emb))) return rc;
+        } else {
+            if ((rc = get(m, pre + ".neighbor_embedder.weight", (int64_t)ns * D, &emb))) return rc;
+        }
+        std::vector<double> W0, B0, Wee, Bee, Emb;
+        if ((rc = download(w0, (size_t)D * kin, W0, st))) return rc;
+        if ((rc = download(b0, D, B0, st))) return rc;
+        if ((rc = download(wee, D * 4, Wee, st))) return rc;
+        if ((rc = download(bee, D, Bee, st))) return rc;
+        if ((rc = download(emb, (size_t)ns * D, Emb, st))) return rc;
+        std::vector<double> Wc(D * 4), Wct(4 * D), Tbl((size_t)ns * D);
+        for (int o = 0; o < D; o++) {
+            double bc = B0[o];
+            for (int k = 0; k < D; k++) bc += W0[(size_t)o * kin + k] * Bee[k];
+            for (int c = 0; c < 4; c++) {
+                double s = 0;
+                for (int k = 0; k < D; k++) s += W0[(size_t)o * kin + k] * Wee[k * 4 + c];
+                Wc[o * 4 + c] = s;
+                Wct[c * D + o] = s;
+            }
+            for (int sidx = 0; sidx < ns; sidx++) {
+                double s = bc;
+                for (int k = 0; k < D; k++) s += W0[(size_t)o * kin + D + k] * Emb[(size_t)sidx * D + k];
+                Tbl[(size_t)sidx * D + o] = s;
+            }
+        }
+        if ((rc = upload(m, Wc, &G.wc, st))) return rc;
+        if ((rc = upload(m, Wct, &G.wct, st))) return rc;
+        if ((rc = upload(m, Tbl, &G.tbl, st))) return rc;
+        if (g > 0) {
+            if ((rc = pack_lin(m, G.compress0_msg, w0, nullptr, D, D, kin, 2 * D, st))) return rc;
+        }
+        if ((rc = get_lin(m, pre + ".compress.2", D, D, G.compress2, st))) return rc;
+        const std::string gs = std::to_string(g);
+        if ((rc = get(m, "combination_norms." + gs + ".weight", 2 * D, &G.ln_g))) return rc;
+        if ((rc = get(m, "combination_norms." + gs + ".bias", 2 * D, &G.ln_b))) return rc;
+        if ((rc = get_lin(m, "combination_mlps." + gs + ".0", 2 * D, 2 * D, G.comb0, st))) return rc;
+        if ((rc = get_lin(m, "combination_mlps." + gs + ".2", D, 2 * D, G.comb2, st))) return rc;
+    }
+    if ((rc = get(m, "node_embedders.0.weight", (int64_t)ns * DN, &m.node_emb))) return rc;
+    if ((rc = get(m, "edge_embedder.weight", (int64_t)ns * D, &m.edge_emb))) return rc;
+    if ((rc = get_lin(m, "node_heads.@.0.0", DH, DN, m.nh0, st))) return rc;
+    if ((rc = get_lin(m, "node_heads.@.0.2", DH, DH, m.nh2, st))) return rc;
+    if ((rc = get_lin(m, "edge_heads.@.0.0", DH, D, m.eh0, st))) return rc;
+    if ((rc = get_lin(m, "edge_heads.@.0.2", DH, DH, m.eh2, st))) return rc;
+    const float *nb, *eb;
+    if ((rc = get(m, "node_last_layers.@.0.@.weight", DH, &m.nll_w))) return rc;
+    if ((rc = get(m, "edge_last_layers.@.0.@.weight", DH, &m.ell_w))) return rc;
+    if ((rc = get(m, "node_last_layers.@.0.@.bias", 1, &nb))) return rc;
+    if ((rc = get(m, "edge_last_layers.@.0.@.bias", 1, &eb))) return rc;
+    PET_HIP_CHECK(hipMemcpyAsync(&m.nll_b, nb, sizeof(float), hipMemcpyDeviceToHost, st));
+    PET_HIP_CHECK(hipMemcpyAsync(&m.ell_b, eb, sizeof(float), hipMemcpyDeviceToHost, st));
+    PET_HIP_CHECK(hipStreamSynchronize(st));
+    PET_REQUIRE(m.species_table != nullptr, PET_ERR_ARGUMENT, "missing species_to_species_index");
+    m.finalized = true;
+    return PET_OK;
+}
+
+__global__ void k_i64_to_i32(const int64_t* __restrict__ in, int* __restrict__ out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int)in[i];
+}
+
+}  // namespace pet
+
+using namespace pet;
+
+struct pet_model {
+    Model m;
+};
+struct pet_graph {
+    Graph g;
+    float cutoff;
+};
+
+extern "C" {
+
+const char* pet_last_error(void) { return g_error.c_str(); }
+const char* pet_version(void) { return "pet_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+int pet_hypers_supported(const pet_hypers_t* h) {
+    return h && h->d_pet == D && h->d_node == DN && h->d_feedforward == DFF && h->d_head == DH &&
+           h->num_heads == NHEAD && h->num_gnn_layers >= 1 && h->num_attention_layers >= 1 &&
+           h->n_species >= 1 && h->n_species <= MAX_SPECIES;
+}
+
+int pet_model_create(const pet_hypers_t* h, pet_model_t** out) {
+    PET_REQUIRE(h && out, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(pet_hypers_supported(h), PET_ERR_UNSUPPORTED,
+                "hypers outside the compiled instantiation (d_pet=128, d_node=256, d_feedforward=256, "
+                "d_head=128, num_heads=8)");
+    PET_REQUIRE(h->cutoff_function == PET_CUTOFF_BUMP || h->cutoff_function == PET_CUTOFF_COSINE,
+                PET_ERR_UNSUPPORTED, "unknown cutoff function");
+    pet_model_t* pm = new pet_model_t();
+    pm->m.h = *h;
+    *out = pm;
+    return PET_OK;
+}
+
+void pet_model_destroy(pet_model_t* pm) {
+    if (!pm) return;
+    for (void* p : pm->m.owned) (void)hipFree(p);
+    delete pm;
+}
+
+int pet_model_set_param(pet_model_t* pm, const char* key, const void* d_data, int64_t numel, void* stream) {
+    PET_REQUIRE(pm && key && d_data && numel > 0, PET_ERR_ARGUMENT, "bad argument");
+    Model& m = pm->m;
+    hipStream_t st = (hipStream_t)stream;
+    std::string k(key);
+    if (k == "species_to_species_index") {
+        int* p;
+        int rc = dev_alloc(m, (void**)&p, numel * sizeof(int));
+        if (rc) return rc;
+        k_i64_to_i32<<<cdiv(numel, 256), 256, 0, st>>>((const int64_t*)d_data, p, (int)numel);
+        PET_HIP_CHECK(hipGetLastError());
+        m.species_table = p;
+        m.species_table_len = (int)numel;
+        return PET_OK;
+    }
+    float* p;
+    auto it = m.raw.find(k);
+    if (it != m.raw.end() && it->second.second == numel) {
+        p = it->second.first;  // overwrite in place (weights updated by an optimizer step)
+    } else {
+        int rc = dev_alloc(m, (void**)&p, numel * sizeof(float));
+        if (rc) return rc;
+        if (it == m.raw.end()) m.n_params += numel;
+        m.raw[k] = {p, numel};
+    }
+    PET_HIP_CHECK(hipMemcpyAsync(p, d_data, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+    m.finalized = false;
+    return PET_OK;
+}
+
+int pet_model_finalize(pet_model_t* pm, void* stream) {
+    PET_REQUIRE(pm, PET_ERR_ARGUMENT, "null model");
+    return finalize(pm->m, (hipStream_t)stream);
+}
+
+int64_t pet_model_num_params(const pet_model_t* pm) { return pm ? pm->m.n_params : 0; }
+
+int64_t pet_nl_workspace_bytes(int64_t n_atoms) { return nl_workspace_bytes(n_atoms); }
+
+int pet_nl_build(const float* d_positions, const float* h_cell, const int32_t* h_pbc, int64_t n_atoms,
+                 float cutoff, void* d_workspace, int32_t* d_pairs, float* d_vectors, int64_t capacity,
+                 int64_t* n_pairs, void* stream) {
+    PET_REQUIRE(h_cell && h_pbc && n_pairs && d_workspace, PET_ERR_ARGUMENT, "null argument");
+    return nl_build(d_positions, h_cell, h_pbc, n_atoms, cutoff, d_workspace, d_pairs, d_vectors, capacity,
+                    n_pairs, (hipStream_t)stream);
+}
+
+int64_t pet_graph_workspace_bytes(int64_t n_nodes, int64_t n_edges_in) {
+    return graph_workspace_bytes(n_nodes, n_edges_in);
+}
+
+int pet_graph_build(const pet_model_t* pm, const float* d_positions, const float* d_cells,
+                    const int32_t* d_centers, const int32_t* d_neighbors, const int32_t* d_cell_shifts,
+                    const int32_t* d_species, const int32_t* d_system_indices, int64_t n_nodes,
+                    int64_t n_edges_in, int64_t n_systems, void* d_workspace, int64_t workspace_bytes,
+                    pet_graph_t** out, void* stream) {
+    PET_REQUIRE(pm && out && d_workspace, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(pm->m.species_table != nullptr, PET_ERR_ARGUMENT, "species_to_species_index not set");
+    PET_REQUIRE(n_nodes < (int64_t(1) << 30) && n_edges_in < (int64_t(1) << 30), PET_ERR_ARGUMENT,
+                "graph too large for int32 indices");
+    pet_graph_t* pg = new pet_graph_t();
+    pg->cutoff = pm->m.h.cutoff;
+    int rc = graph_build(pm->m, d_positions, d_cells, d_centers, d_neighbors, d_cell_shifts, d_species,
+                         d_system_indices, n_nodes, n_edges_in, n_systems, d_workspace, workspace_bytes,
+                         pg->g, (hipStream_t)stream);
+    if (rc != PET_OK) {
+        delete pg;
+        return rc;
+    }
+    *out = pg;
+    return PET_OK;
+}
+
+void pet_graph_destroy(pet_graph_t* g) { delete g; }
+int64_t pet_graph_num_edges(const pet_graph_t* g) { return g ? g->g.n_edges : 0; }
+int32_t pet_graph_max_neighbors(const pet_graph_t* g) { return g ? g->g.max_nbr : 0; }
+
+int pet_graph_export_batch(const pet_graph_t* pg, int64_t* el_nodes, int64_t* el_nbr, float* ev, float* ed,
+                           uint8_t* mask, int64_t* rni, float* cf, float* stats, int64_t* centers,
+                           int64_t* neighbors, int64_t* slot, int64_t* shifts, void* stream) {
+    PET_REQUIRE(pg, PET_ERR_ARGUMENT, "null graph");
+    if (rni) {
+        int rc = graph_check_reverse(const_cast<Graph&>(pg->g), (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return graph_export(pg->g, pg->cutoff, el_nodes, el_nbr, ev, ed, mask, rni, cf, stats, centers, neighbors,
+                        slot, shifts, (hipStream_t)stream);
+}
+
+int pet_graph_csr(const pet_graph_t* pg, const int32_t** rowptr, const int32_t** ctr, const int32_t** nbr,
+                  const int32_t** rev) {
+    PET_REQUIRE(pg, PET_ERR_ARGUMENT, "null graph");
+    if (rowptr) *rowptr = pg->g.rowptr;
+    if (ctr) *ctr = pg->g.ctr;
+    if (nbr) *nbr = pg->g.nbr;
+    if (rev) *rev = pg->g.rev;
+    return PET_OK;
+}
+
+int64_t pet_forward_workspace_bytes(const pet_model_t* pm, int64_t n_nodes, int64_t n_edges) {
+    if (!pm) return -1;
+    return forward_workspace_bytes(pm->m, n_nodes, n_edges);
+}
+
+int pet_forward(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
+                int save_for_backward, float* d_atomic, float* d_node_features, float* d_edge_features,
+                void* stream) {
+    PET_REQUIRE(pm && pg && d_workspace && d_atomic, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
+    return forward(pm->m, pg->g, d_workspace, workspace_bytes, save_for_backward, d_atomic, d_node_features,
+                   d_edge_features, (hipStream_t)stream);
+}
+
+int pet_backward(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
+                 const float* d_grad_atomic, float* d_grad_positions, float* d_grad_cells, void* stream) {
+    PET_REQUIRE(pm && pg && d_workspace && d_grad_atomic && d_grad_positions, PET_ERR_ARGUMENT,
+                "null argument");
+    PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
+    return backward(pm->m, pg->g, d_workspace, workspace_bytes, d_grad_atomic, d_grad_positions, d_grad_cells,
+                    (hipStream_t)stream);
+}
+
+int pet_sum_over_atoms(const pet_graph_t* pg, const float* d_atomic, float* d_out, void* stream) {
+    PET_REQUIRE(pg && d_atomic && d_out, PET_ERR_ARGUMENT, "null argument");
+    return sum_over_atoms(pg->g, d_atomic, d_out, (hipStream_t)stream);
+}
+
+int pet_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return PET_OK;
+}
+
+int pet_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    return PET_OK;
+}
+
+int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int64_t* calls, double* flops,
+                       int* n_entries) {
+    PET_REQUIRE(names && total_ms && calls && flops && n_entries, PET_ERR_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::vector<std::string> order;
+    std::map<std::string, int> index;
+    for (auto& r : g_prof) {
+        PET_HIP_CHECK(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        PET_HIP_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        auto it = index.find(r.name);
+        int i;
+        if (it == index.end()) {
+            if ((int)order.size() >= max_entries) continue;
+            i = (int)order.size();
+            index[r.name] = i;
+            order.push_back(r.name);
+            strncpy(names[i], r.name.c_str(), 63);
+            names[i][63] = 0;
+            total_ms[i] = 0;
+            calls[i] = 0;
+            flops[i] = 0;
+        } else {
+            i = it->second;
+        }
+        total_ms[i] += ms;
+        calls[i] += 1;
+        flops[i] += r.flops;
+    }
+    *n_entries = (int)order.size();
+    return PET_OK;
+}
+
+}  // extern "C"

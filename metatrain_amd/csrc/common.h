@@ -1,0 +1,102 @@
+// Shared declarations for the MI355X (gfx950) PET hot-path library.
+// One process per GPU; every entry point launches on the caller's HIP stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/pet_hip.h"
+
+namespace pet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+void set_error(const std::string& msg);
+
+#define PET_HIP_CHECK(expr)                                                         \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            char _b[512];                                                           \
+            snprintf(_b, sizeof(_b), "%s:%d: %s failed: %s", __FILE__, __LINE__,    \
+                     #expr, hipGetErrorString(_e));                                 \
+            pet::set_error(_b);                                                     \
+            return PET_ERR_HIP;                                                     \
+        }                                                                           \
+    } while (0)
+
+#define PET_REQUIRE(cond, code, msg)                                                \
+    do {                                                                            \
+        if (!(cond)) {                                                              \
+            pet::set_error(std::string(__FILE__) + ":" + std::to_string(__LINE__) + \
+                           ": " + (msg));                                           \
+            return (code);                                                          \
+        }                                                                           \
+    } while (0)
+
+// bump allocator over a caller-provided device buffer (256-byte aligned carves);
+// with base == nullptr it only measures.
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base(static_cast<char*>(b)) {}
+    template <class T>
+    T* take(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+inline int cdiv(int64_t a, int64_t b) { return int((a + b - 1) / b); }
+
+// gfx950 has 160 KiB of LDS per CU; kernels asking for more than 64 KiB of dynamic LDS
+// must opt in once per function.
+template <class Kern>
+inline void allow_big_lds(Kern kern, size_t bytes) {
+    if (bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)bytes);
+}
+
+// --------------------------------------------------------------------------------
+// Edge graph in CSR order (edges stably sorted by centre; pet/modules/nef.py:63-70
+// defines exactly this order as the NEF slot order).
+// --------------------------------------------------------------------------------
+struct Graph {
+    int64_t n_nodes = 0, n_edges_in = 0, n_systems = 0;
+    int64_t n_edges = 0;  // kept edges (host copy, valid after build)
+    int max_nbr = 0;      // host copy
+    // per input edge
+    float4* vin = nullptr;     // [E0] (vx,vy,vz,d0 = |v| + 1e-15)
+    int* keep = nullptr;       // [E0] 0/1
+    int* kidx = nullptr;       // [E0] exclusive scan of keep: index among kept edges
+    int* sort_keys_in = nullptr;
+    int* sort_keys_out = nullptr;
+    int* sort_vals_in = nullptr;
+    int* perm = nullptr;       // [E0] sorted position -> input edge
+    // CSR
+    int* rowptr = nullptr;     // [N+1]
+    int* ctr = nullptr;        // [E]
+    int* nbr = nullptr;        // [E]
+    int* shift = nullptr;      // [E,3]
+    int* rev = nullptr;        // [E] CSR index of (j,i,-S)
+    int* sp = nullptr;         // [N] species index of the atom
+    int* sp_nbr = nullptr;     // [E] species index of the neighbour
+    float4* geo = nullptr;     // [E] (vx,vy,vz,dist = sqrt(v.v + 1e-15))
+    float* d0 = nullptr;       // [E] |v| + 1e-15
+    float* fc = nullptr;       // [E] cutoff factor
+    int* sys = nullptr;        // [N] system index
+    int* scalars = nullptr;    // [4] device: n_kept, max_nbr, n_bad_reverse, unused
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    void* scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+};
+
+}  // namespace pet

@@ -1,0 +1,374 @@
+// Preprocessing kernels: edge geometry, non-strict filter, CSR (= NEF slot) order,
+// ij -> ji map, NEF export.  HBM-bound integer/gather work: one thread per edge or
+// per atom, coalesced SoA reads, no atomics on floating point.
+//
+// Reference semantics: pet/modules/structures.py:115-378, pet/modules/nef.py:34-251,
+// pet/modules/utilities.py:4-39 (see include/pet_hip.h for the boundary).
+#include "common.h"
+#include "model.h"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace pet {
+
+// ----------------------------------------------------------------------------------
+// cutoff functions (pet/modules/utilities.py:4-39)
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ float cutoff_value(float d, float rc, float width, int fn) {
+    float s = (d - (rc - width)) / width;
+    if (fn == PET_CUTOFF_BUMP) {
+        s = fminf(fmaxf(s, 1e-6f), 1.0f - 1e-6f);
+        return 0.5f * (1.0f + tanhf(1.0f / tanf(3.14159274f * s)));
+    }
+    s = fminf(fmaxf(s, 0.0f), 1.0f);
+    return 0.5f * (1.0f + cosf(3.14159274f * s));
+}
+
+// d fc / d d0 (zero outside the taper because of the clamp)
+__device__ __forceinline__ float cutoff_deriv(float d, float rc, float width, int fn) {
+    float s = (d - (rc - width)) / width;
+    if (fn == PET_CUTOFF_BUMP) {
+        if (!(s >= 1e-6f && s <= 1.0f - 1e-6f)) return 0.0f;
+        float x = 3.14159274f * s;
+        float sn = sinf(x), cs = cosf(x);
+        float t = tanhf(cs / sn);
+        // d/ds [0.5 (1 + tanh(cot x))] = 0.5 (1 - t^2) * (-pi / sin^2 x)
+        return 0.5f * (1.0f - t * t) * (-3.14159274f / (sn * sn)) / width;
+    }
+    if (!(s >= 0.0f && s <= 1.0f)) return 0.0f;
+    return -0.5f * 3.14159274f * sinf(3.14159274f * s) / width;
+}
+
+float __device__ cutoff_deriv_dev(float d, float rc, float width, int fn) {
+    return cutoff_deriv(d, rc, width, fn);
+}
+
+// ----------------------------------------------------------------------------------
+// kernels
+// ----------------------------------------------------------------------------------
+__global__ void k_species_index(const int* __restrict__ species, const int* __restrict__ table,
+                                int table_len, int* __restrict__ sp, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int z = species[i];
+    sp[i] = (z >= 0 && z < table_len) ? table[z] : -1;
+}
+
+// structures.py:206-221 and the non-strict mask of :265-267
+__global__ void k_edge_geometry(const float* __restrict__ pos, const float* __restrict__ cells,
+                                const int* __restrict__ centers, const int* __restrict__ neighbors,
+                                const int* __restrict__ shifts, const int* __restrict__ sys,
+                                float4* __restrict__ vin, int* __restrict__ keep,
+                                int* __restrict__ sort_keys, int* __restrict__ sort_vals,
+                                int n_edges, int n_nodes, float cutoff, int strict) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    int i = centers[e], j = neighbors[e];
+    const float* c = cells + 9 * sys[i];
+    float sa = (float)shifts[3 * e], sb = (float)shifts[3 * e + 1], sc = (float)shifts[3 * e + 2];
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float contrib = fmaf(sc, c[6 + k], fmaf(sb, c[3 + k], sa * c[k]));
+        v[k] = (pos[3 * j + k] - pos[3 * i + k]) + contrib;
+    }
+    float d0 = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + 1e-15f;
+    int kp = strict ? 1 : (d0 <= cutoff ? 1 : 0);
+    vin[e] = make_float4(v[0], v[1], v[2], d0);
+    keep[e] = kp;
+    sort_keys[e] = kp ? i : n_nodes;  // dropped edges sort behind every real centre
+    sort_vals[e] = e;
+}
+
+// rowptr[i] = first sorted position whose key >= i
+__global__ void k_rowptr(const int* __restrict__ sorted_keys, int n_edges, int* __restrict__ rowptr,
+                         int n_nodes, int* __restrict__ scalars) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_nodes) return;
+    int lo = 0, hi = n_edges;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (sorted_keys[mid] < i) lo = mid + 1; else hi = mid;
+    }
+    rowptr[i] = lo;
+    if (i == n_nodes) scalars[0] = lo;
+}
+
+__global__ void k_max_nbr(const int* __restrict__ rowptr, int n_nodes, int* __restrict__ scalars) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int v = (i < n_nodes) ? rowptr[i + 1] - rowptr[i] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(&scalars[1], v);
+}
+
+__global__ void k_csr_fill(const int* __restrict__ perm, const float4* __restrict__ vin,
+                           const int* __restrict__ centers, const int* __restrict__ neighbors,
+                           const int* __restrict__ shifts, const int* __restrict__ sp,
+                           int* __restrict__ ctr, int* __restrict__ nbr, int* __restrict__ shift,
+                           int* __restrict__ sp_nbr, float4* __restrict__ geo,
+                           float* __restrict__ d0, float* __restrict__ fc, int n_kept,
+                           float cutoff, float width, int fn) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_kept) return;
+    int e = perm[p];
+    float4 v = vin[e];
+    int j = neighbors[e];
+    ctr[p] = centers[e];
+    nbr[p] = j;
+    shift[3 * p] = shifts[3 * e];
+    shift[3 * p + 1] = shifts[3 * e + 1];
+    shift[3 * p + 2] = shifts[3 * e + 2];
+    sp_nbr[p] = sp[j];
+    // structures.py:330: the network sees sqrt(sum v^2 + 1e-15), not |v| + 1e-15
+    geo[p] = make_float4(v.x, v.y, v.z, sqrtf(v.x * v.x + v.y * v.y + v.z * v.z + 1e-15f));
+    d0[p] = v.w;
+    fc[p] = cutoff_value(v.w, cutoff, width, fn);
+}
+
+// nef.py:88-166 restated as a search in row j (rows hold <= a few dozen edges)
+__global__ void k_reverse(const int* __restrict__ rowptr, const int* __restrict__ ctr,
+                          const int* __restrict__ nbr, const int* __restrict__ shift,
+                          int* __restrict__ rev, int n_kept, int* __restrict__ scalars) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_kept) return;
+    int i = ctr[p], j = nbr[p];
+    int sa = -shift[3 * p], sb = -shift[3 * p + 1], sc = -shift[3 * p + 2];
+    int found = -1;
+    for (int q = rowptr[j]; q < rowptr[j + 1]; q++) {
+        if (nbr[q] == i && shift[3 * q] == sa && shift[3 * q + 1] == sb && shift[3 * q + 2] == sc) {
+            found = q;
+            break;
+        }
+    }
+    rev[p] = found;
+    if (found < 0) atomicAdd(&scalars[2], 1);
+}
+
+// ---- NEF export (backend.py:328-341) ------------------------------------------------
+__global__ void k_export_nodes(const int* __restrict__ sp, int64_t* __restrict__ el_nodes,
+                               float* __restrict__ cut_stats, int n, float cutoff) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (el_nodes) el_nodes[i] = sp[i];
+    if (cut_stats) cut_stats[i] = cutoff;
+}
+
+__global__ void k_export_nef(const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                             const int* __restrict__ rev, const int* __restrict__ sp_nbr,
+                             const float4* __restrict__ geo, const float* __restrict__ fc,
+                             const int* __restrict__ perm, const int* __restrict__ kidx,
+                             int64_t* __restrict__ el_nbr, float* __restrict__ ev,
+                             float* __restrict__ ed, uint8_t* __restrict__ mask,
+                             int64_t* __restrict__ rni, float* __restrict__ cf, int n_nodes,
+                             int m, int pad_src /* CSR position of kept edge 0 */) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n_nodes * m) return;
+    int i = (int)(idx / m), k = (int)(idx % m);
+    int start = rowptr[i], n = rowptr[i + 1] - start;
+    bool real = k < n;
+    // nef.py:75-80: nef_indices is zero-initialised, so pads alias kept edge 0
+    int p = real ? start + k : pad_src;
+    if (el_nbr) el_nbr[idx] = (pad_src < 0 && !real) ? 0 : sp_nbr[p];
+    float4 g = (pad_src < 0 && !real) ? make_float4(0, 0, 0, 0) : geo[p];
+    if (ev) { ev[3 * idx] = g.x; ev[3 * idx + 1] = g.y; ev[3 * idx + 2] = g.z; }
+    if (ed) ed[idx] = g.w;
+    if (mask) mask[idx] = real ? 1 : 0;
+    if (cf) cf[idx] = real ? fc[p] : 0.0f;
+    if (rni) {
+        if (real) {
+            int q = rev[p];
+            int j = nbr[p];
+            rni[idx] = (int64_t)j * m + (q - rowptr[j]);
+        } else {
+            // structures.py:359-362: cumsum(~mask) - 1 in row-major order, closed form
+            rni[idx] = (int64_t)i * m - start + (k - n);
+        }
+    }
+}
+
+__global__ void k_export_edges(const int* __restrict__ perm, const int* __restrict__ kidx,
+                               const int* __restrict__ rowptr, const int* __restrict__ ctr,
+                               const int* __restrict__ nbr, const int* __restrict__ shift,
+                               int64_t* __restrict__ centers, int64_t* __restrict__ neighbors,
+                               int64_t* __restrict__ slot, int64_t* __restrict__ shifts_out,
+                               int n_kept) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_kept) return;
+    int k = kidx[perm[p]];  // position among kept edges in the caller's order
+    int i = ctr[p];
+    if (centers) centers[k] = i;
+    if (neighbors) neighbors[k] = nbr[p];
+    if (slot) slot[k] = p - rowptr[i];
+    if (shifts_out) {
+        shifts_out[3 * k] = shift[3 * p];
+        shifts_out[3 * k + 1] = shift[3 * p + 1];
+        shifts_out[3 * k + 2] = shift[3 * p + 2];
+    }
+}
+
+// CSR position of kept edge 0 (the edge every NEF pad aliases)
+__global__ void k_find_pad_src(const int* __restrict__ perm, const int* __restrict__ kidx,
+                               const int* __restrict__ keep, int n_kept, int* __restrict__ out) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_kept) return;
+    int e = perm[p];
+    if (keep[e] && kidx[e] == 0) *out = p;
+}
+
+__global__ void k_sum_over_atoms(const float* __restrict__ atomic, const int* __restrict__ sys,
+                                 float* __restrict__ out, int n) {
+    // systems are contiguous runs of atoms (concatenate_structures, structures.py:87-91);
+    // one thread per system start does a serial, deterministic sum.
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int s = sys[i];
+    if (i > 0 && sys[i - 1] == s) return;
+    float acc = 0.0f;
+    for (int k = i; k < n && sys[k] == s; k++) acc += atomic[k];
+    out[s] = acc;
+}
+
+// ----------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------
+static int sort_bits(int64_t n_nodes) {
+    int bits = 1;
+    while ((int64_t(1) << bits) <= n_nodes) bits++;
+    return bits;
+}
+
+static int carve_graph(Graph& g, void* ws, int64_t n_nodes, int64_t e0, size_t* total) {
+    Carver c(ws);
+    g.vin = c.take<float4>(e0);
+    g.keep = c.take<int>(e0);
+    g.kidx = c.take<int>(e0);
+    g.sort_keys_in = c.take<int>(e0);
+    g.sort_keys_out = c.take<int>(e0);
+    g.sort_vals_in = c.take<int>(e0);
+    g.perm = c.take<int>(e0);
+    g.rowptr = c.take<int>(n_nodes + 1);
+    g.ctr = c.take<int>(e0);
+    g.nbr = c.take<int>(e0);
+    g.shift = c.take<int>(3 * e0);
+    g.rev = c.take<int>(e0);
+    g.sp = c.take<int>(n_nodes);
+    g.sp_nbr = c.take<int>(e0);
+    g.geo = c.take<float4>(e0);
+    g.d0 = c.take<float>(e0);
+    g.fc = c.take<float>(e0);
+    g.sys = c.take<int>(n_nodes);
+    g.scalars = c.take<int>(8);
+    size_t sort_bytes = 0, scan_bytes = 0;
+    int* ni = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, sort_bytes, ni, ni, ni, ni, (size_t)e0, 0,
+                                  sort_bits(n_nodes)) != hipSuccess)
+        return PET_ERR_HIP;
+    if (rocprim::exclusive_scan(nullptr, scan_bytes, ni, ni, 0, (size_t)e0, rocprim::plus<int>()) !=
+        hipSuccess)
+        return PET_ERR_HIP;
+    g.sort_tmp_bytes = sort_bytes;
+    g.scan_tmp_bytes = scan_bytes;
+    g.sort_tmp = c.take<char>(sort_bytes + 256);
+    g.scan_tmp = c.take<char>(scan_bytes + 256);
+    *total = c.off;
+    return PET_OK;
+}
+
+int64_t graph_workspace_bytes(int64_t n_nodes, int64_t e0) {
+    Graph g;
+    size_t total = 0;
+    if (carve_graph(g, nullptr, n_nodes, e0 > 0 ? e0 : 1, &total) != PET_OK) return -1;
+    return (int64_t)total;
+}
+
+int graph_build(const Model& m, const float* pos, const float* cells, const int* centers,
+                const int* neighbors, const int* shifts, const int* species, const int* sys,
+                int64_t n_nodes, int64_t e0, int64_t n_systems, void* ws, int64_t ws_bytes,
+                Graph& g, hipStream_t st) {
+    size_t need = 0;
+    int rc = carve_graph(g, ws, n_nodes, e0 > 0 ? e0 : 1, &need);
+    if (rc != PET_OK) return rc;
+    PET_REQUIRE((int64_t)need <= ws_bytes, PET_ERR_ARGUMENT, "graph workspace too small");
+    g.n_nodes = n_nodes;
+    g.n_edges_in = e0;
+    g.n_systems = n_systems;
+    const int T = 256;
+    PET_HIP_CHECK(hipMemsetAsync(g.scalars, 0, 8 * sizeof(int), st));
+    if (n_nodes > 0) {
+        k_species_index<<<cdiv(n_nodes, T), T, 0, st>>>(species, m.species_table, m.species_table_len,
+                                                        g.sp, (int)n_nodes);
+        PET_HIP_CHECK(hipMemcpyAsync(g.sys, sys, n_nodes * sizeof(int), hipMemcpyDeviceToDevice, st));
+    }
+    if (e0 > 0) {
+        k_edge_geometry<<<cdiv(e0, T), T, 0, st>>>(pos, cells, centers, neighbors, shifts, g.sys, g.vin,
+                                                   g.keep, g.sort_keys_in, g.sort_vals_in, (int)e0,
+                                                   (int)n_nodes, m.h.cutoff, m.h.nl_is_strict);
+        size_t sb = g.sort_tmp_bytes, cb = g.scan_tmp_bytes;
+        PET_HIP_CHECK(rocprim::radix_sort_pairs(g.sort_tmp, sb, g.sort_keys_in, g.sort_keys_out,
+                                                g.sort_vals_in, g.perm, (size_t)e0, 0,
+                                                sort_bits(n_nodes), st));
+        PET_HIP_CHECK(rocprim::exclusive_scan(g.scan_tmp, cb, g.keep, g.kidx, 0, (size_t)e0,
+                                              rocprim::plus<int>(), st));
+    }
+    k_rowptr<<<cdiv(n_nodes + 1, T), T, 0, st>>>(g.sort_keys_out, (int)e0, g.rowptr, (int)n_nodes,
+                                                 g.scalars);
+    if (n_nodes > 0) k_max_nbr<<<cdiv(n_nodes, T), T, 0, st>>>(g.rowptr, (int)n_nodes, g.scalars);
+    int host_scalars[2] = {0, 0};
+    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    PET_HIP_CHECK(hipStreamSynchronize(st));
+    g.n_edges = host_scalars[0];
+    g.max_nbr = host_scalars[1];
+    if (g.n_edges > 0) {
+        int ne = (int)g.n_edges;
+        k_csr_fill<<<cdiv(ne, T), T, 0, st>>>(g.perm, g.vin, centers, neighbors, shifts, g.sp, g.ctr,
+                                              g.nbr, g.shift, g.sp_nbr, g.geo, g.d0, g.fc, ne,
+                                              m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function);
+        k_reverse<<<cdiv(ne, T), T, 0, st>>>(g.rowptr, g.ctr, g.nbr, g.shift, g.rev, ne, g.scalars);
+        k_find_pad_src<<<cdiv(ne, T), T, 0, st>>>(g.perm, g.kidx, g.keep, ne, g.scalars + 3);
+    }
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
+int graph_check_reverse(Graph& g, hipStream_t st) {
+    int bad = 0;
+    PET_HIP_CHECK(hipMemcpyAsync(&bad, g.scalars + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+    PET_HIP_CHECK(hipStreamSynchronize(st));
+    PET_REQUIRE(bad == 0, PET_ERR_GRAPH,
+                "neighbour list is not a full list: " + std::to_string(bad) +
+                    " edges have no reverse edge (j, i, -S)");
+    return PET_OK;
+}
+
+int graph_export(const Graph& g, float cutoff, int64_t* el_nodes, int64_t* el_nbr, float* ev,
+                 float* ed, uint8_t* mask, int64_t* rni, float* cf, float* stats, int64_t* centers,
+                 int64_t* neighbors, int64_t* slot, int64_t* shifts, hipStream_t st) {
+    const int T = 256;
+    if (g.n_nodes > 0)
+        k_export_nodes<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.sp, el_nodes, stats, (int)g.n_nodes, cutoff);
+    int64_t cells = g.n_nodes * (int64_t)g.max_nbr;
+    if (cells > 0) {
+        int pad_src = -1;
+        PET_HIP_CHECK(hipMemcpyAsync(&pad_src, g.scalars + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+        PET_HIP_CHECK(hipStreamSynchronize(st));
+        k_export_nef<<<cdiv(cells, T), T, 0, st>>>(g.rowptr, g.nbr, g.rev, g.sp_nbr, g.geo, g.fc, g.perm,
+                                                   g.kidx, el_nbr, ev, ed, mask, rni, cf, (int)g.n_nodes,
+                                                   g.max_nbr, pad_src);
+    }
+    if (g.n_edges > 0)
+        k_export_edges<<<cdiv(g.n_edges, T), T, 0, st>>>(g.perm, g.kidx, g.rowptr, g.ctr, g.nbr, g.shift,
+                                                         centers, neighbors, slot, shifts, (int)g.n_edges);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
+int sum_over_atoms(const Graph& g, const float* atomic, float* out, hipStream_t st) {
+    if (g.n_nodes > 0)
+        k_sum_over_atoms<<<cdiv(g.n_nodes, 256), 256, 0, st>>>(atomic, g.sys, out, (int)g.n_nodes);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
+}  // namespace pet

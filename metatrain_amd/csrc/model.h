@@ -1,0 +1,99 @@
+// Device-resident PET weights: raw copies keyed by the reference state-dict names
+//  plus the packed / derived forms the kernels consume.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace pet {
+
+// compiled instantiation (pet/documentation.py:159-259 defaults)
+constexpr int D = 128;        // d_pet
+constexpr int DN = 256;       // d_node
+constexpr int DFF = 256;      // d_feedforward (edge SwiGLU hidden; w_in has 2*DFF outputs)
+constexpr int DNF = 2 * DN;   // node SwiGLU hidden (transformer.py:188-190: 2 * dim_node_features)
+constexpr int DH = 128;       // d_head
+constexpr int NHEAD = 8;
+constexpr int HD = D / NHEAD; // 16
+constexpr int MAX_SPECIES = 128;
+
+// y = x W^T + b with W [n_out, k_in] (torch Linear). fwd: packed for x W^T;
+// bwd: packed W^T for dx = dy W.
+struct Lin {
+    const float* w = nullptr;  // raw [n_out, k_in]
+    const float* b = nullptr;  // raw [n_out]
+    float4* fwd = nullptr;
+    float4* bwd = nullptr;
+    int n_out = 0, k_in = 0;
+};
+
+struct AttnLayerW {
+    Lin qkv, out, mlp_in, mlp_out, cc, ce, cmlp_in, cmlp_out;
+    const float *g_attn = nullptr, *g_mlp = nullptr, *g_center = nullptr;
+};
+
+struct GnnLayerW {
+    std::vector<AttnLayerW> attn;
+    Lin compress2;      // [D, D]
+    Lin compress0_msg;  // columns of compress.0 that multiply the incoming message (g >= 1)
+    float* wc = nullptr;   // [D, 4]  compress.0[:, :D] @ edge_embedder.weight  (4 -> D composite)
+    float* wct = nullptr;  // [4, D]  transpose, for the backward dot products
+    float* tbl = nullptr;  // [n_species, D] species part of compress.0 (+ all biases)
+    Lin comb0, comb2;
+    const float *ln_g = nullptr, *ln_b = nullptr;
+};
+
+struct Model {
+    pet_hypers_t h;
+    std::map<std::string, std::pair<float*, int64_t>> raw;  // device copies
+    int* species_table = nullptr;
+    int species_table_len = 0;
+    std::vector<GnnLayerW> gnn;
+    const float* node_emb = nullptr;  // [ns, DN]
+    const float* edge_emb = nullptr;  // [ns, D]
+    Lin nh0, nh2, eh0, eh2;
+    const float *nll_w = nullptr, *ell_w = nullptr;  // [DH]
+    float nll_b = 0.f, ell_b = 0.f;
+    std::vector<void*> owned;  // device allocations to free
+    bool finalized = false;
+    int64_t n_params = 0;
+};
+
+// graph.hip
+int64_t graph_workspace_bytes(int64_t n_nodes, int64_t e0);
+int graph_build(const Model& m, const float* pos, const float* cells, const int* centers,
+                const int* neighbors, const int* shifts, const int* species, const int* sys,
+                int64_t n_nodes, int64_t e0, int64_t n_systems, void* ws, int64_t ws_bytes,
+                Graph& g, hipStream_t st);
+int graph_check_reverse(Graph& g, hipStream_t st);
+int graph_export(const Graph& g, float cutoff, int64_t* el_nodes, int64_t* el_nbr, float* ev,
+                 float* ed, uint8_t* mask, int64_t* rni, float* cf, float* stats, int64_t* centers,
+                 int64_t* neighbors, int64_t* slot, int64_t* shifts, hipStream_t st);
+int sum_over_atoms(const Graph& g, const float* atomic, float* out, hipStream_t st);
+
+// nl.hip
+int64_t nl_workspace_bytes(int64_t n_atoms);
+int nl_build(const float* d_pos, const float* h_cell, const int* h_pbc, int64_t n, float cutoff,
+             void* ws, int* d_pairs, float* d_vectors, int64_t capacity, int64_t* n_pairs,
+             hipStream_t st);
+
+// pet_fwd.hip / pet_bwd.hip
+int64_t forward_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges);
+int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
+            float* node_feat, float* edge_feat, hipStream_t st);
+int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* grad_atomic,
+             float* grad_pos, float* grad_cells, hipStream_t st);
+
+// profiling (abi.hip)
+struct ProfScope {
+    ProfScope(const char* name, hipStream_t st, double flops);
+    ~ProfScope();
+    const char* name;
+    hipStream_t st;
+    double flops;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
+}  // namespace pet

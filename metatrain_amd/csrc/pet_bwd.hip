@@ -1,0 +1,826 @@
+// PET reverse pass (dL/dR) on gfx950. Hand-written adjoint of every stage in pet_fwd.hip;
+// replaces torch.autograd.grad(E, positions) of utils/output_gradient.py:34-40 for the
+// inference / force path (activation gradients only, no weight gradients).
+//
+// Every dense adjoint is a row-tile GEMM against the TRANSPOSED weight (Lin::bwd packs
+// W^T in fragment order), so the same MFMA toolkit applies. Cross-atom terms are
+// gathers, never float atomics:
+//   * ji message gather   e_rev[p] = e[rev[p]]  ->  de[p] += dcat_hi[rev[p]]   (rev is an involution)
+//   * dE/dR_a = sum_{p in row a} (dv[rev[p]] - dv[p])                          (v_p = r_j - r_i + S.cell)
+// so the result is deterministic run to run.
+#include "common.h"
+#include "model.h"
+#include "pet_ws.h"
+#include "tile.h"
+
+namespace pet {
+
+constexpr int LD128 = lds_ld(128);
+constexpr int LD256 = lds_ld(256);
+
+float __device__ cutoff_deriv_dev(float d, float rc, float width, int fn);
+int attn_tiles(const Graph& g);
+
+__device__ __forceinline__ float sigmoid_grad_from(float s) { return s * (1.0f - s); }
+
+// RMSNorm adjoint on a tile: W holds w = gamma * dn (LDS [64][K+4]); x rows come from
+// global. dx = rstd * (w - xhat * mean(w * xhat)), xhat = x * rstd.
+// calls f(row_in_tile, col, dx) for the 4-thread-per-row decomposition.
+template <int K, class F>
+__device__ __forceinline__ void rmsnorm_bwd_rows(const float* Wt, const float* __restrict__ Xg, int64_t row0,
+                                                 int64_t n_rows, int ldx, F f) {
+    constexpr int LDW = lds_ld(K);
+    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const bool valid = row0 + r < n_rows;
+    const float* xrow = Xg + (row0 + r) * ldx;
+    float ss = 0.f, dot = 0.f;
+    for (int c = q * 4; c < K; c += 16) {
+        float4 x = valid ? *reinterpret_cast<const float4*>(xrow + c) : make_float4(0, 0, 0, 0);
+        float4 wv = *reinterpret_cast<const float4*>(Wt + r * LDW + c);
+        ss += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        dot += x.x * wv.x + x.y * wv.y + x.z * wv.z + x.w * wv.w;
+    }
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2);
+    dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2);
+    const float rstd = rsqrtf(ss * (1.0f / K) + 1.1920928955078125e-07f);
+    const float coef = dot * rstd * rstd * rstd * (1.0f / K);  // mean(w*xhat) * rstd / x-scale
+    if (!valid) return;
+    for (int c = q * 4; c < K; c += 16) {
+        float4 x = *reinterpret_cast<const float4*>(xrow + c);
+        float4 wv = *reinterpret_cast<const float4*>(Wt + r * LDW + c);
+        f(r, c, make_float4(rstd * wv.x - x.x * coef, rstd * wv.y - x.y * coef, rstd * wv.z - x.z * coef,
+                            rstd * wv.w - x.w * coef));
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// heads
+// ---------------------------------------------------------------------------------
+template <int K, bool EDGE>
+__global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__ Xin, const float4* __restrict__ w0f,
+                                                        const float* __restrict__ b0, const float4* __restrict__ w2f,
+                                                        const float* __restrict__ b2, const float4* __restrict__ w0b,
+                                                        const float4* __restrict__ w2b, const float* __restrict__ wl,
+                                                        const float* __restrict__ gA, const int* __restrict__ ctr,
+                                                        const float* __restrict__ fc, const float* __restrict__ ypred,
+                                                        float* __restrict__ dfc, float* __restrict__ dXout, int64_t R) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LDK = lds_ld(K);
+    float* A = smem;
+    float* S = smem + BM * LDK;
+    float* gy = S + BM * LD128;  // [64]
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<K>(A, Xin, row0, R, K);
+    if (threadIdx.x < BM) {
+        const int64_t row = row0 + threadIdx.x;
+        float g = 0.f;
+        if (row < R) {
+            if (EDGE) {
+                const float ga = gA[ctr[row]];
+                g = ga * fc[row];
+                dfc[row] = ga * ypred[row];  // d(y fc)/dfc
+            } else {
+                g = gA[row];
+            }
+        }
+        gy[threadIdx.x] = g;
+    }
+    __syncthreads();
+    f32x16 a1[2], acc[2];
+    acc_fill_bias<2>(a1, b0, 64 * w.ch, w.lane);
+    gemm_acc<K, 2>(A + w.rb * 32 * LDK, LDK, w0f, K / 8, 0, 2 * w.ch, a1, w.lane);
+    acc_foreach<2>(a1, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) { S[r * LD128 + c] = siluf_(v); });
+    __syncthreads();
+    acc_fill_bias<2>(acc, b2, 64 * w.ch, w.lane);
+    gemm_acc<128, 2>(S + w.rb * 32 * LD128, LD128, w2f, 16, 0, 2 * w.ch, acc, w.lane);
+    __syncthreads();
+    // da2 = gy * wl * silu'(a2)
+    acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane,
+                   [&](int r, int c, float v) { S[r * LD128 + c] = gy[r] * wl[c] * silu_grad_(v); });
+    __syncthreads();
+    acc_fill_bias<2>(acc, nullptr, 0, w.lane);
+    gemm_acc<128, 2>(S + w.rb * 32 * LD128, LD128, w2b, 16, 0, 2 * w.ch, acc, w.lane);  // ds1 = da2 W2
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int rr = w.rb * 32 + acc_row(r, w.lane), cc = 64 * w.ch + 32 * t + (w.lane & 31);
+            S[rr * LD128 + cc] = acc[t][r] * silu_grad_(a1[t][r]);  // da1
+        }
+    __syncthreads();
+    constexpr int NTO = K / 64;  // output columns K split over the two column halves
+    f32x16 dx[NTO];
+    acc_fill_bias<NTO>(dx, nullptr, 0, w.lane);
+    gemm_acc<128, NTO>(S + w.rb * 32 * LD128, LD128, w0b, 16, 0, NTO * w.ch, dx, w.lane);  // dx = da1 W0
+    acc_foreach<NTO>(dx, w.rb, (K / 2) * w.ch, w.lane, [&](int r, int c, float v) {
+        if (row0 + r < R) dXout[(row0 + r) * K + c] = v;
+    });
+}
+
+// ---------------------------------------------------------------------------------
+// combination MLP + LayerNorm adjoint -> dcat [E, 2D]
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_comb_bwd(const float* __restrict__ dM, const float* __restrict__ XF,
+                                                        const int* __restrict__ rev, const float* __restrict__ LNS,
+                                                        const float* __restrict__ CA, const float* __restrict__ ln_g,
+                                                        const float4* __restrict__ w2b, const float4* __restrict__ w0b,
+                                                        float* __restrict__ dcat, int64_t E) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Lo = smem;
+    float* Hi = smem + BM * LD128;
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<128>(Lo, dM, row0, E, D);
+    __syncthreads();
+    f32x16 t1[4];
+    acc_fill_bias<4>(t1, nullptr, 0, w.lane);
+    gemm_acc<128, 4>(Lo + w.rb * 32 * LD128, LD128, w2b, 16, 0, 4 * w.ch, t1, w.lane);  // [64,256] = dupd W2
+    __syncthreads();
+    float* Sdst = w.ch == 0 ? Lo : Hi;
+    acc_foreach<4>(t1, w.rb, 0, w.lane, [&](int r, int c, float v) {
+        const int64_t row = row0 + r;
+        const float a = row < E ? CA[row * (2 * D) + 128 * w.ch + c] : 0.f;
+        Sdst[r * LD128 + c] = v * silu_grad_(a);
+    });
+    __syncthreads();
+    acc_fill_bias<4>(t1, nullptr, 0, w.lane);
+    gemm_acc<128, 4>(Lo + w.rb * 32 * LD128, LD128, w0b, 32, 0, 4 * w.ch, t1, w.lane);  // dln = da W0
+    gemm_acc<128, 4>(Hi + w.rb * 32 * LD128, LD128, w0b, 32, 16, 4 * w.ch, t1, w.lane);
+    __syncthreads();
+    acc_foreach<4>(t1, w.rb, 0, w.lane,
+                   [&](int r, int c, float v) { Sdst[r * LD128 + c] = v * ln_g[128 * w.ch + c]; });  // dyhat
+    __syncthreads();
+    {   // LayerNorm adjoint: dx = rstd (dyh - mean(dyh) - xhat mean(dyh xhat))
+        const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const int64_t row = row0 + r;
+        const bool valid = row < E;
+        const float mean = valid ? LNS[row * 2] : 0.f, rstd = valid ? LNS[row * 2 + 1] : 0.f;
+        const float* xlo = XF + row * D;
+        const float* xhi = XF + (valid ? (int64_t)rev[row] : 0) * D;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = q * 4; c < 128; c += 16) {
+            float4 a = *reinterpret_cast<float4*>(Lo + r * LD128 + c);
+            float4 b = *reinterpret_cast<float4*>(Hi + r * LD128 + c);
+            float4 xa = valid ? *reinterpret_cast<const float4*>(xlo + c) : make_float4(0, 0, 0, 0);
+            float4 xb = valid ? *reinterpret_cast<const float4*>(xhi + c) : make_float4(0, 0, 0, 0);
+            s1 += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+            s2 += a.x * (xa.x - mean) + a.y * (xa.y - mean) + a.z * (xa.z - mean) + a.w * (xa.w - mean) +
+                  b.x * (xb.x - mean) + b.y * (xb.y - mean) + b.z * (xb.z - mean) + b.w * (xb.w - mean);
+        }
+        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+        const float m1 = s1 * (1.0f / 256.0f);
+        const float m2 = s2 * rstd * rstd * (1.0f / 256.0f);  // mean(dyh xhat) * rstd
+        if (valid) {
+            for (int c = q * 4; c < 128; c += 16) {
+                float4 a = *reinterpret_cast<float4*>(Lo + r * LD128 + c);
+                float4 b = *reinterpret_cast<float4*>(Hi + r * LD128 + c);
+                float4 xa = *reinterpret_cast<const float4*>(xlo + c);
+                float4 xb = *reinterpret_cast<const float4*>(xhi + c);
+                float4 oa = make_float4(rstd * (a.x - m1 - (xa.x - mean) * m2), rstd * (a.y - m1 - (xa.y - mean) * m2),
+                                        rstd * (a.z - m1 - (xa.z - mean) * m2), rstd * (a.w - m1 - (xa.w - mean) * m2));
+                float4 ob = make_float4(rstd * (b.x - m1 - (xb.x - mean) * m2), rstd * (b.y - m1 - (xb.y - mean) * m2),
+                                        rstd * (b.z - m1 - (xb.z - mean) * m2), rstd * (b.w - m1 - (xb.w - mean) * m2));
+                *reinterpret_cast<float4*>(dcat + row * (2 * D) + c) = oa;
+                *reinterpret_cast<float4*>(dcat + row * (2 * D) + 128 + c) = ob;
+            }
+        }
+    }
+}
+
+// dXF[p] = dM[p] + dcat[p][:D] + dcat[rev[p]][D:]
+__global__ void k_dxf(const float* __restrict__ dM, const float* __restrict__ dcat, const int* __restrict__ rev,
+                      float* __restrict__ dX, int64_t E) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * (D / 4)) return;
+    const int64_t p = idx / (D / 4);
+    const int c = (int)(idx % (D / 4));
+    float4 a = reinterpret_cast<const float4*>(dM)[idx];
+    float4 b = *reinterpret_cast<const float4*>(dcat + p * (2 * D) + 4 * c);
+    float4 d = *reinterpret_cast<const float4*>(dcat + (int64_t)rev[p] * (2 * D) + D + 4 * c);
+    reinterpret_cast<float4*>(dX)[idx] = make_float4(a.x + b.x + d.x, a.y + b.y + d.y, a.z + b.z + d.z, a.w + b.w + d.w);
+}
+
+// ---------------------------------------------------------------------------------
+// SwiGLU MLP adjoint (edge rows: K = 128, hidden 256; node rows: K = 256, hidden 512)
+//   y = x + Wout (v * sig(g)),  [v; g] = Win RMSNorm(x)
+//   dx = dy + RMSNorm^T( Win^T [du sig(g) ; du v sig'(g)] ),  du = Wout^T dy
+// ---------------------------------------------------------------------------------
+template <int K, int HID>
+__global__ __launch_bounds__(NTHREADS) void k_swiglu_bwd(const float* __restrict__ dY, const float* __restrict__ Xin,
+                                                          const float* __restrict__ VG, const float* __restrict__ gamma,
+                                                          const float4* __restrict__ woutb, const float4* __restrict__ winb,
+                                                          float* __restrict__ dXout, int64_t R) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LDK = lds_ld(K);
+    constexpr int NTO = K / 64;
+    float* A = smem;              // [64][K+4]: dY tile, later w = gamma * dn
+    float* U = smem + BM * LDK;   // [64][132]
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<K>(A, dY, row0, R, K);
+    __syncthreads();
+    f32x16 dn[NTO];
+    acc_fill_bias<NTO>(dn, nullptr, 0, w.lane);
+#pragma unroll 1
+    for (int hc = 0; hc < HID / 128; hc++) {
+        f32x16 du[2];
+        acc_fill_bias<2>(du, nullptr, 0, w.lane);
+        // du chunk = dY Wout[:, chunk]  (woutb: rows = hidden, k = K)
+        gemm_acc<K, 2>(A + w.rb * 32 * LDK, LDK, woutb, K / 8, 0, 4 * hc + 2 * w.ch, du, w.lane);
+        float sg[2][16], vv[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int64_t row = row0 + w.rb * 32 + acc_row(r, w.lane);
+                const int cc = 128 * hc + 64 * w.ch + 32 * t + (w.lane & 31);
+                float v = 0.f, g = 0.f;
+                if (row < R) {
+                    v = VG[row * (2 * HID) + cc];
+                    g = VG[row * (2 * HID) + HID + cc];
+                }
+                sg[t][r] = sigmoidf_(g);
+                vv[t][r] = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rr = w.rb * 32 + acc_row(r, w.lane), cc = 64 * w.ch + 32 * t + (w.lane & 31);
+                U[rr * LD128 + cc] = du[t][r] * sg[t][r];  // dv
+            }
+        __syncthreads();
+        gemm_acc<128, NTO>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, 16 * hc, NTO * w.ch, dn, w.lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rr = w.rb * 32 + acc_row(r, w.lane), cc = 64 * w.ch + 32 * t + (w.lane & 31);
+                U[rr * LD128 + cc] = du[t][r] * vv[t][r] * sigmoid_grad_from(sg[t][r]);  // dg
+            }
+        __syncthreads();
+        gemm_acc<128, NTO>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, HID / 8 + 16 * hc, NTO * w.ch, dn, w.lane);
+    }
+    __syncthreads();  // everyone is done with the dY tile in A
+    acc_foreach<NTO>(dn, w.rb, (K / 2) * w.ch, w.lane, [&](int r, int c, float v) { A[r * LDK + c] = v * gamma[c]; });
+    __syncthreads();
+    rmsnorm_bwd_rows<K>(A, Xin, row0, R, K, [&](int r, int c, float4 dx) {
+        const int64_t o = (row0 + r) * K + c;
+        float4 dy = *reinterpret_cast<const float4*>(dY + o);
+        *reinterpret_cast<float4*>(dXout + o) = make_float4(dy.x + dx.x, dy.y + dx.y, dy.z + dx.z, dy.w + dx.w);
+    });
+}
+
+// ---------------------------------------------------------------------------------
+// node chain adjoint, second half: dOC = dH1 Wce ; (dH_in = dH1 is finished by k_center_bwd)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_expand_bwd(const float* __restrict__ dH1, const float4* __restrict__ wceb,
+                                                          float* __restrict__ dOC, int64_t N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<256>(smem, dH1, row0, N, DN);
+    __syncthreads();
+    f32x16 acc[2];
+    acc_fill_bias<2>(acc, nullptr, 0, w.lane);
+    gemm_acc<256, 2>(smem + w.rb * 32 * LD256, LD256, wceb, 32, 0, 2 * w.ch, acc, w.lane);
+    acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
+        if (row0 + r < N) dOC[(row0 + r) * D + c] = v;
+    });
+}
+
+// dH_in = dH1 + dC Wcc   (centre contraction adjoint)
+__global__ __launch_bounds__(NTHREADS) void k_center_bwd(const float* __restrict__ dC, const float* __restrict__ dH1,
+                                                          const float4* __restrict__ wccb, float* __restrict__ dHin,
+                                                          int64_t N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<128>(smem, dC, row0, N, D);
+    __syncthreads();
+    f32x16 acc[4];
+    acc_fill_bias<4>(acc, nullptr, 0, w.lane);
+    gemm_acc<128, 4>(smem + w.rb * 32 * LD128, LD128, wccb, 16, 0, 4 * w.ch, acc, w.lane);
+    acc_foreach<4>(acc, w.rb, 128 * w.ch, w.lane, [&](int r, int c, float v) {
+        const int64_t row = row0 + r;
+        if (row < N) dHin[row * DN + c] = dH1[row * DN + c] + v;
+    });
+}
+
+// ---------------------------------------------------------------------------------
+// output_linear adjoint: dAO = dOut Wo, rows < E from dX1, rows >= E from dOC
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_oproj_bwd(const float* __restrict__ dX1, const float* __restrict__ dOC,
+                                                         const float4* __restrict__ wob, float* __restrict__ dAO,
+                                                         int64_t E, int64_t R) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    for (int idx = threadIdx.x; idx < BM * 32; idx += NTHREADS) {
+        const int r = idx >> 5, c = idx & 31;
+        const int64_t row = row0 + r;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (row < E) v = *reinterpret_cast<const float4*>(dX1 + row * D + 4 * c);
+        else if (row < R) v = *reinterpret_cast<const float4*>(dOC + (row - E) * D + 4 * c);
+        *reinterpret_cast<float4*>(smem + r * LD128 + 4 * c) = v;
+    }
+    __syncthreads();
+    f32x16 acc[2];
+    acc_fill_bias<2>(acc, nullptr, 0, w.lane);
+    gemm_acc<128, 2>(smem + w.rb * 32 * LD128, LD128, wob, 16, 0, 2 * w.ch, acc, w.lane);
+    acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
+        if (row0 + r < R) dAO[(row0 + r) * D + c] = v;
+    });
+}
+
+// ---------------------------------------------------------------------------------
+// attention adjoint: one wave per (atom, head). Pass A (query tiles, transposed scores)
+// gives dQ, delta, lse and the key-bias gradient; pass B (key tiles, plain scores)
+// gives dK and dV. 16x16x4 fp32 MFMA, no LDS, no atomics.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t token_row_b(int t, int T, int64_t E, int atom, int start) {
+    return (t == 0 || t >= T) ? E + atom : (int64_t)start + t - 1;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ QKV, const float* __restrict__ dAO,
+                                                   const int* __restrict__ rowptr, const float* __restrict__ fc,
+                                                   float* __restrict__ dQKV, float* __restrict__ dbias_h,
+                                                   int64_t E, int N, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int atom = gw / NHEAD, head = gw % NHEAD;
+    if (atom >= N) return;
+    const int start = rowptr[atom];
+    const int T = rowptr[atom + 1] - start + 1;
+    const int nt = (T + 15) >> 4;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head;
+    float4 kf[NT], vf[NT];
+    float bias_r[NT][4];  // bias of key 16kt + 4g4 + r (rows of the transposed tile)
+    float bias_c[NT];     // bias of key 16kt + c16   (columns of the plain tile)
+    float db[NT][4];
+    float lse[NT], delta[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+        lse[kt] = 0.f;
+        delta[kt] = 0.f;
+        if (kt < nt) {
+            const int64_t row = token_row_b(16 * kt + c16, T, E, atom, start);
+            kf[kt] = *reinterpret_cast<const float4*>(QKV + row * (3 * D) + ko + 4 * g4);
+            vf[kt] = *reinterpret_cast<const float4*>(QKV + row * (3 * D) + vo + 4 * g4);
+            const int kc = 16 * kt + c16;
+            bias_c[kt] = kc >= T ? -INFINITY : (kc == 0 ? 0.f : logf(fmaxf(fc[start + kc - 1], 1e-15f)));
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = 16 * kt + 4 * g4 + r;
+                bias_r[kt][r] = key >= T ? -INFINITY : (key == 0 ? 0.f : logf(fmaxf(fc[start + key - 1], 1e-15f)));
+                db[kt][r] = 0.f;
+            }
+        }
+    }
+    // ------------------------------ pass A ------------------------------
+#pragma unroll
+    for (int qt = 0; qt < NT; qt++) {
+        if (qt < nt) {
+            const int q = 16 * qt + c16;
+            const int64_t qrow = token_row_b(q, T, E, atom, start);
+            float4 qf = *reinterpret_cast<const float4*>(QKV + qrow * (3 * D) + qo + 4 * g4);
+            qf.x *= scale; qf.y *= scale; qf.z *= scale; qf.w *= scale;
+            float4 dof = make_float4(0, 0, 0, 0);
+            if (q < T) dof = *reinterpret_cast<const float4*>(dAO + qrow * D + qo + 4 * g4);
+            f32x4 s[NT], dp[NT];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++) {
+                if (kt < nt) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].x, qf.x, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].y, qf.y, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].z, qf.z, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].w, qf.w, a, 0, 0, 0);
+                    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                    b = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt].x, dof.x, b, 0, 0, 0);
+                    b = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt].y, dof.y, b, 0, 0, 0);
+                    b = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt].z, dof.z, b, 0, 0, 0);
+                    b = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt].w, dof.w, b, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        a[r] += bias_r[kt][r];
+                        mx = fmaxf(mx, a[r]);
+                    }
+                    s[kt] = a;
+                    dp[kt] = b;
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float p = expf(s[kt][r] - mx);
+                        s[kt][r] = p;
+                        sum += p;
+                    }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            float dl = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        s[kt][r] *= inv;
+                        dl += s[kt][r] * dp[kt][r];
+                    }
+            dl += __shfl_xor(dl, 16);
+            dl += __shfl_xor(dl, 32);
+            lse[qt] = mx + logf(sum);
+            delta[qt] = dl;
+            f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float ds = s[kt][r] * (dp[kt][r] - dl);  // dS^T[key][q]
+                        db[kt][r] += ds;  // padded queries have dO = 0 => dp = dl = 0 => ds = 0
+                        const int64_t krow = token_row_b(16 * kt + 4 * g4 + r, T, E, atom, start);
+                        const float kk = QKV[krow * (3 * D) + ko + c16];
+                        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kk, ds, dq, 0, 0, 0);
+                    }
+            if (q < T)
+                *reinterpret_cast<float4*>(dQKV + qrow * (3 * D) + qo + 4 * g4) =
+                    make_float4(dq[0] * scale, dq[1] * scale, dq[2] * scale, dq[3] * scale);
+        }
+    }
+    // key-bias gradient: sum over the 16 query columns, one writer per key
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+        if (kt < nt)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = db[kt][r];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                const int key = 16 * kt + 4 * g4 + r;
+                if (c16 == 0 && key >= 1 && key < T) dbias_h[(int64_t)(start + key - 1) * NHEAD + head] += v;
+            }
+    // ------------------------------ pass B ------------------------------
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+        if (kt < nt) {
+            f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dvv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qt = 0; qt < NT; qt++) {
+                if (qt < nt) {
+                    const int64_t qrow_c = token_row_b(16 * qt + c16, T, E, atom, start);
+                    float4 qf = *reinterpret_cast<const float4*>(QKV + qrow_c * (3 * D) + qo + 4 * g4);
+                    qf.x *= scale; qf.y *= scale; qf.z *= scale; qf.w *= scale;
+                    float4 dof = make_float4(0, 0, 0, 0);
+                    if (16 * qt + c16 < T) dof = *reinterpret_cast<const float4*>(dAO + qrow_c * D + qo + 4 * g4);
+                    // S[q][key]: A = Q (rows q), B = K (cols key)
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(qf.x, kf[kt].x, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(qf.y, kf[kt].y, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(qf.z, kf[kt].z, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(qf.w, kf[kt].w, a, 0, 0, 0);
+                    f32x4 b = {0.f, 0.f, 0.f, 0.f};  // dP[q][key] = dO V^T
+                    b = __builtin_amdgcn_mfma_f32_16x16x4f32(dof.x, vf[kt].x, b, 0, 0, 0);
+                    b = __builtin_amdgcn_mfma_f32_16x16x4f32(dof.y, vf[kt].y, b, 0, 0, 0);
+                    b = __builtin_amdgcn_mfma_f32_16x16x4f32(dof.z, vf[kt].z, b, 0, 0, 0);
+                    b = __builtin_amdgcn_mfma_f32_16x16x4f32(dof.w, vf[kt].w, b, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int qq = 16 * qt + 4 * g4 + r;  // row of the plain tile
+                        const float l = __shfl(lse[qt], 4 * g4 + r);
+                        const float dl = __shfl(delta[qt], 4 * g4 + r);
+                        float p = expf(a[r] + bias_c[kt] - l);
+                        if (qq >= T) p = 0.f;
+                        const float ds = p * (b[r] - dl);
+                        const int64_t qrow_r = token_row_b(qq, T, E, atom, start);
+                        float dov = 0.f;
+                        if (qq < T) dov = dAO[qrow_r * D + qo + c16];
+                        const float qv = QKV[qrow_r * (3 * D) + qo + c16];
+                        dvv = __builtin_amdgcn_mfma_f32_16x16x4f32(dov, p, dvv, 0, 0, 0);
+                        dk = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, ds, dk, 0, 0, 0);
+                    }
+                }
+            }
+            const int key = 16 * kt + c16;
+            if (key < T) {
+                const int64_t krow = token_row_b(key, T, E, atom, start);
+                *reinterpret_cast<float4*>(dQKV + krow * (3 * D) + ko + 4 * g4) =
+                    make_float4(dk[0] * scale, dk[1] * scale, dk[2] * scale, dk[3] * scale);
+                *reinterpret_cast<float4*>(dQKV + krow * (3 * D) + vo + 4 * g4) =
+                    make_float4(dvv[0], dvv[1], dvv[2], dvv[3]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// input_linear + RMSNorm adjoint: dXin = (rows<E ? dX1 : 0) + RMSNorm^T(dQKV Win)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_qkv_bwd(const float* __restrict__ dQKV, const float* __restrict__ X,
+                                                       const float* __restrict__ gamma, const float4* __restrict__ winb,
+                                                       const float* __restrict__ dX1, float* __restrict__ dXin,
+                                                       int64_t E, int64_t R) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    f32x16 dn[2];
+    acc_fill_bias<2>(dn, nullptr, 0, w.lane);
+#pragma unroll 1
+    for (int ks = 0; ks < 3; ks++) {
+        __syncthreads();
+        load_rows_to_lds<128>(smem, dQKV + 128 * ks, row0, R, 3 * D);
+        __syncthreads();
+        gemm_acc<128, 2>(smem + w.rb * 32 * LD128, LD128, winb, 48, 16 * ks, 2 * w.ch, dn, w.lane);
+    }
+    __syncthreads();
+    acc_foreach<2>(dn, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) { smem[r * LD128 + c] = v * gamma[c]; });
+    __syncthreads();
+    rmsnorm_bwd_rows<128>(smem, X, row0, R, D, [&](int r, int c, float4 dx) {
+        const int64_t row = row0 + r;
+        if (row < E) {
+            float4 d1 = *reinterpret_cast<const float4*>(dX1 + row * D + c);
+            dx.x += d1.x; dx.y += d1.y; dx.z += d1.z; dx.w += d1.w;
+        }
+        *reinterpret_cast<float4*>(dXin + row * D + c) = dx;
+    });
+}
+
+// ---------------------------------------------------------------------------------
+// compress adjoint: da0 = (dE W2) * silu'(a0); dgeo += da0 Wc; dM = dMpass + da0 W0c
+// ---------------------------------------------------------------------------------
+template <bool FIRST>
+__global__ __launch_bounds__(NTHREADS) void k_compress_bwd(const float* __restrict__ dXe, const float* __restrict__ a0,
+                                                            const float4* __restrict__ w2b, const float* __restrict__ wct,
+                                                            const float4* __restrict__ w0cb, float* __restrict__ dgeo,
+                                                            float* __restrict__ dM /* in/out, !FIRST */, int64_t E) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<128>(smem, dXe, row0, E, D);
+    __syncthreads();
+    f32x16 acc[2];
+    acc_fill_bias<2>(acc, nullptr, 0, w.lane);
+    gemm_acc<128, 2>(smem + w.rb * 32 * LD128, LD128, w2b, 16, 0, 2 * w.ch, acc, w.lane);
+    __syncthreads();
+    acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
+        const int64_t row = row0 + r;
+        smem[r * LD128 + c] = row < E ? v * silu_grad_(a0[row * D + c]) : 0.f;
+    });
+    __syncthreads();
+    {   // dgeo[row][k] += sum_c da0[row][c] * Wc[c][k]; 4 threads per row, thread q -> component q
+        const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const float* wrow = wct + q * D;
+        float s = 0.f;
+        for (int c = 0; c < 128; c += 4) {
+            float4 a = *reinterpret_cast<float4*>(smem + r * LD128 + c);
+            float4 ww = *reinterpret_cast<const float4*>(wrow + c);
+            s += a.x * ww.x + a.y * ww.y + a.z * ww.z + a.w * ww.w;
+        }
+        if (row0 + r < E) dgeo[(row0 + r) * 4 + q] += s;
+    }
+    if (!FIRST) {
+        acc_fill_bias<2>(acc, nullptr, 0, w.lane);
+        gemm_acc<128, 2>(smem + w.rb * 32 * LD128, LD128, w0cb, 16, 0, 2 * w.ch, acc, w.lane);
+        acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
+            const int64_t row = row0 + r;
+            if (row < E) dM[row * D + c] += v;
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// geometry adjoint
+// ---------------------------------------------------------------------------------
+__global__ void k_geom_bwd(const float4* __restrict__ geo, const float* __restrict__ d0, const float* __restrict__ fc,
+                           const float* __restrict__ dgeo, const float* __restrict__ dfc,
+                           const float* __restrict__ dbias_h, float4* __restrict__ dv, int64_t E, float cutoff,
+                           float width, int fn) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= E) return;
+    const float4 g = geo[p];
+    const float4 dg = reinterpret_cast<const float4*>(dgeo)[p];
+    float dbias = 0.f;
+#pragma unroll
+    for (int h = 0; h < NHEAD; h++) dbias += dbias_h[p * NHEAD + h];
+    const float f = fc[p];
+    // bias = log(clamp(fc, 1e-15)): gradient passes only where fc >= 1e-15 (transformer.py:109-110)
+    float dfc_t = dfc[p] + (f >= 1e-15f ? dbias / f : 0.f);
+    const float dd0 = dfc_t * cutoff_deriv_dev(d0[p], cutoff, width, fn);
+    const float nrm = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
+    const float c_dist = dg.w / g.w;                    // d sqrt(v.v + 1e-15) / dv = v / dist
+    const float c_d0 = nrm > 0.f ? dd0 / nrm : 0.f;     // d |v| / dv = v / |v|
+    const float c = c_dist + c_d0;
+    dv[p] = make_float4(dg.x + c * g.x, dg.y + c * g.y, dg.z + c * g.z, 0.f);
+}
+
+// dE/dR_a = sum_{p in row a} (dv[rev[p]] - dv[p]); one 16-lane group per atom
+__global__ void k_pos_grad(const float4* __restrict__ dv, const int* __restrict__ rowptr, const int* __restrict__ rev,
+                           float* __restrict__ gpos, int N) {
+    const int gid = blockIdx.x * (blockDim.x / 16) + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    const int a = gid < N ? gid : N - 1;
+    float x = 0.f, y = 0.f, z = 0.f;
+    for (int p = rowptr[a] + l; p < rowptr[a + 1]; p += 16) {
+        const float4 m = dv[p], q = dv[rev[p]];
+        x += q.x - m.x; y += q.y - m.y; z += q.z - m.z;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        x += __shfl_xor(x, o); y += __shfl_xor(y, o); z += __shfl_xor(z, o);
+    }
+    if (l == 0 && gid < N) {
+        gpos[3 * gid] = x; gpos[3 * gid + 1] = y; gpos[3 * gid + 2] = z;
+    }
+}
+
+// dE/dcell[s][a][k] = sum_{edges of system s} S_a dv_k (structures.py:212-219); one block per system
+__global__ void k_cell_grad(const float4* __restrict__ dv, const int* __restrict__ shift, const int* __restrict__ ctr,
+                            const int* __restrict__ sys, const int* __restrict__ rowptr, float* __restrict__ gcell,
+                            int N, int64_t E) {
+    // systems are contiguous atom ranges; find this system's atom range by scanning sys[] boundaries
+    const int s = blockIdx.x;
+    __shared__ float red[9][256];
+    __shared__ int range[2];
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = N;
+        // lower bound of s and of s+1 in the sorted sys[] array
+        int a = 0, b = N;
+        while (a < b) { int m = (a + b) >> 1; if (sys[m] < s) a = m + 1; else b = m; }
+        lo = a; b = N;
+        while (a < b) { int m = (a + b) >> 1; if (sys[m] < s + 1) a = m + 1; else b = m; }
+        hi = a;
+        range[0] = rowptr[lo];
+        range[1] = rowptr[hi];
+    }
+    __syncthreads();
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] = 0.f;
+    for (int p = range[0] + threadIdx.x; p < range[1]; p += blockDim.x) {
+        const float4 d = dv[p];
+        const float sa = (float)shift[3 * p], sb = (float)shift[3 * p + 1], sc = (float)shift[3 * p + 2];
+        acc[0] += sa * d.x; acc[1] += sa * d.y; acc[2] += sa * d.z;
+        acc[3] += sb * d.x; acc[4] += sb * d.y; acc[5] += sb * d.z;
+        acc[6] += sc * d.x; acc[7] += sc * d.y; acc[8] += sc * d.z;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+#pragma unroll
+            for (int k = 0; k < 9; k++) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 9) gcell[9 * s + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// ---------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------
+template <int NT>
+static void launch_attn_bwd(const float* QKV, const float* dAO, const Graph& g, float* dQKV, float* dbias_h,
+                            float scale, hipStream_t st) {
+    int waves = (int)g.n_nodes * NHEAD;
+    k_attn_bwd<NT><<<cdiv(waves, 4), 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges,
+                                                   (int)g.n_nodes, scale);
+}
+
+int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA, float* gpos,
+             float* gcell, hipStream_t st) {
+    Workspace w;
+    carve_workspace(m, g.n_nodes, g.n_edges, ws, w);
+    PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "workspace too small");
+    const int64_t N = g.n_nodes, E = g.n_edges, R = E + N;
+    if (N == 0) return PET_OK;
+    if (E == 0) {  // isolated atoms: no position dependence at all
+        PET_HIP_CHECK(hipMemsetAsync(gpos, 0, N * 3 * sizeof(float), st));
+        if (gcell) PET_HIP_CHECK(hipMemsetAsync(gcell, 0, g.n_systems * 9 * sizeof(float), st));
+        return PET_OK;
+    }
+    {
+        int bad = 0;
+        PET_HIP_CHECK(hipMemcpyAsync(&bad, g.scalars + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+        PET_HIP_CHECK(hipStreamSynchronize(st));
+        PET_REQUIRE(bad == 0, PET_ERR_GRAPH, "neighbour list is not a full list: edges without a reverse edge");
+    }
+    const int nt = attn_tiles(g);
+    PET_REQUIRE(nt <= 8, PET_ERR_UNSUPPORTED, "more than 127 neighbours per atom is not supported yet");
+    const float scale = 1.0f / (sqrtf((float)HD) * m.h.attention_temperature);
+    const int gE = cdiv(E, BM), gN = cdiv(N, BM), gR = cdiv(R, BM);
+    const size_t lds1 = BM * LD128 * 4, lds2 = 2 * BM * LD128 * 4;
+    const double fE = (double)E, fN = (double)N, fR = (double)R;
+    float* dbias_h = w.delta;  // [E, NHEAD] (reuses the delta carve)
+    PET_HIP_CHECK(hipMemsetAsync(w.dgeo, 0, E * 4 * sizeof(float), st));
+    PET_HIP_CHECK(hipMemsetAsync(dbias_h, 0, E * NHEAD * sizeof(float), st));
+
+    allow_big_lds(k_head_bwd<256, false>, (BM * LD256 + BM * LD128) * 4 + 256);
+    allow_big_lds(k_swiglu_bwd<256, DNF>, (BM * LD256 + BM * LD128) * 4);
+    allow_big_lds(k_expand_bwd, BM * LD256 * 4);
+    const GnnBufs& last = w.gnn.back();
+    {
+        ProfScope ps("head_edge_bwd", st, fE * 2.0 * (D * DH + DH * DH + DH));
+        k_head_bwd<128, true><<<gE, NTHREADS, lds2 + 256, st>>>(last.Mout, m.eh0.fwd, m.eh0.b, m.eh2.fwd, m.eh2.b,
+                                                               m.eh0.bwd, m.eh2.bwd, m.ell_w, gA, g.ctr, g.fc,
+                                                               w.ypred_e, w.dfc, w.dM, E);
+    }
+    {
+        ProfScope ps("head_node_bwd", st, fN * 2.0 * (DN * DH + DH * DH + DH));
+        k_head_bwd<256, false><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + 256, st>>>(
+            last.Hout, m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nh0.bwd, m.nh2.bwd, m.nll_w, gA, nullptr, nullptr,
+            nullptr, nullptr, w.dH, N);
+    }
+    float* dH = w.dH;
+    float* dH_alt = w.dH2;
+    float* dX = w.dX;
+    float* dX_alt = w.dX2;
+    for (int gi = m.h.num_gnn_layers - 1; gi >= 0; gi--) {
+        const GnnLayerW& G = m.gnn[gi];
+        const GnnBufs& B = w.gnn[gi];
+        {
+            ProfScope ps("comb_bwd", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D));
+            k_comb_bwd<<<gE, NTHREADS, lds2, st>>>(w.dM, B.XF, g.rev, B.LNS, B.CA, G.ln_g, G.comb2.bwd, G.comb0.bwd,
+                                                   w.dcat, E);
+        }
+        {
+            ProfScope ps("dxf", st, 0.0);
+            k_dxf<<<cdiv(E * (D / 4), 256), 256, 0, st>>>(w.dM, w.dcat, g.rev, dX, E);
+        }
+        for (int a = m.h.num_attention_layers - 1; a >= 0; a--) {
+            const AttnLayerW& A = G.attn[a];
+            const AttnBufs& Ab = B.attn[a];
+            // dX (edge rows) = grad wrt the edge MLP output; dH = grad wrt Hn
+            {
+                ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
+                k_swiglu_bwd<128, DFF><<<gE, NTHREADS, lds2, st>>>(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_out.bwd,
+                                                                   A.mlp_in.bwd, dX_alt, E);
+            }
+            {
+                ProfScope ps("node_bwd", st, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
+                k_swiglu_bwd<256, DNF><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, st>>>(
+                    dH, Ab.H1, Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N);
+                k_expand_bwd<<<gN, NTHREADS, BM * LD256 * 4, st>>>(dH_alt, A.ce.bwd, w.dOC, N);
+            }
+            // dX_alt (edge rows) = dX1, dH_alt = dH1
+            {
+                ProfScope ps("oproj_bwd", st, fR * 2.0 * D * D);
+                k_oproj_bwd<<<gR, NTHREADS, lds1, st>>>(dX_alt, w.dOC, A.out.bwd, w.dAO, E, R);
+            }
+            {
+                ProfScope ps("attn_bwd", st, 0.0);
+                switch (nt) {
+                    case 1: launch_attn_bwd<1>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;
+                    case 2: launch_attn_bwd<2>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;
+                    case 3: launch_attn_bwd<3>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;
+                    case 4: launch_attn_bwd<4>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;
+                    case 5: case 6: launch_attn_bwd<6>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;
+                    default: launch_attn_bwd<8>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;
+                }
+            }
+            {
+                ProfScope ps("qkv_bwd", st, fR * 2.0 * D * 3 * D);
+                k_qkv_bwd<<<gR, NTHREADS, lds1, st>>>(w.dQKV, Ab.X, A.g_attn, A.qkv.bwd, dX_alt, dX, E, R);
+            }
+            {
+                ProfScope ps("center_bwd", st, fN * 2.0 * DN * D);
+                k_center_bwd<<<gN, NTHREADS, lds1, st>>>(dX + E * D, dH_alt, A.cc.bwd, dH, N);
+            }
+            // now dX (edge rows) = grad wrt this layer's input edge tokens, dH = grad wrt its input h
+        }
+        {
+            ProfScope ps("compress_bwd", st, fE * 2.0 * (D * D * (gi == 0 ? 3 : 4) + 4 * D));
+            if (gi == 0)
+                k_compress_bwd<true><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct, nullptr, w.dgeo,
+                                                                 nullptr, E);
+            else
+                k_compress_bwd<false><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct,
+                                                                  G.compress0_msg.bwd, w.dgeo, w.dM, E);
+        }
+        // w.dM now holds d/dMout of layer gi-1 (pass-through + compress adjoint)
+    }
+    k_geom_bwd<<<cdiv(E, 256), 256, 0, st>>>(g.geo, g.d0, g.fc, w.dgeo, w.dfc, dbias_h,
+                                             reinterpret_cast<float4*>(w.dv), E, m.h.cutoff, m.h.cutoff_width,
+                                             m.h.cutoff_function);
+    k_pos_grad<<<cdiv(N, 16), 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.rowptr, g.rev, gpos, (int)N);
+    if (gcell)
+        k_cell_grad<<<(int)g.n_systems, 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.shift, g.ctr, g.sys,
+                                                      g.rowptr, gcell, (int)N, E);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
+}  // namespace pet

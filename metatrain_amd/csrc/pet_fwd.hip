@@ -1,0 +1,662 @@
+// PET forward on gfx950: fused row-tile kernels (fp32 MFMA) + per-atom attention.
+//
+// Token layout: one buffer X[(E+N), D]; rows 0..E-1 are the edges in CSR order
+// (edge p belongs to atom ctr[p], rows rowptr[i]..rowptr[i+1]-1), rows E..E+N-1
+// are the centre tokens. The reference pads every atom to max_neighbors and runs
+// [N, M+1, D] batches (pet/modules/transformer.py:463-562); here there are no pads.
+//
+// Reference map:
+//   k_compress   transformer.py:499-521 (edge_embedder, neighbor_embedder, compress MLP)
+//   k_center     transformer.py:211-214 (center_contraction)
+//   k_qkv        transformer.py:216-218 + 103-107 (norm_attention, input_linear)
+//   k_attn_fwd   transformer.py:108-151 / 565-589 (softmax(QK^T/sqrt(hd)/tau + log fc) V)
+//   k_oproj      transformer.py:151 + 229 (output_linear, edge residual)
+//   k_node       transformer.py:222-227 (center_expansion, center_mlp)
+//   k_emlp       transformer.py:230-232 (edge SwiGLU MLP)
+//   k_comb       backend.py:559-575 (ji gather, LayerNorm, combination MLP, residuals)
+//   k_head_*     backend.py:651-687, 726-777 (heads, last layers, cutoff-weighted sum)
+#include "common.h"
+#include "model.h"
+#include "pet_ws.h"
+#include "tile.h"
+
+namespace pet {
+
+constexpr int LD128 = lds_ld(128);
+constexpr int LD256 = lds_ld(256);
+
+// store this wave's NT accumulator tiles to a row-major global array
+template <int NT>
+__device__ __forceinline__ void store_acc(f32x16 (&acc)[NT], float* __restrict__ G, int64_t row0,
+                                          int64_t n_rows, int ld, int rb, int col0, int lane) {
+    acc_foreach<NT>(acc, rb, col0, lane, [&](int r, int c, float v) {
+        if (row0 + r < n_rows) G[(row0 + r) * ld + c] = v;
+    });
+}
+
+// ---------------------------------------------------------------------------------
+// node embedding lookup
+// ---------------------------------------------------------------------------------
+__global__ void k_node_embed(const int* __restrict__ sp, const float* __restrict__ emb,
+                             float* __restrict__ H, int n) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
+    if (idx >= (int64_t)n * (DN / 4)) return;
+    int i = (int)(idx / (DN / 4)), c = (int)(idx % (DN / 4));
+    reinterpret_cast<float4*>(H)[idx] = reinterpret_cast<const float4*>(emb + (size_t)sp[i] * DN)[c];
+}
+
+// ---------------------------------------------------------------------------------
+// compress: a0 = [v,d] Wc^T + Tbl[species] (+ M W0c^T);  e = SiLU(a0) W2^T + b2
+// ---------------------------------------------------------------------------------
+template <bool FIRST>
+__global__ __launch_bounds__(NTHREADS) void k_compress(const float4* __restrict__ geo,
+                                                        const int* __restrict__ sp_nbr,
+                                                        const float* __restrict__ wc,   // [D,4]
+                                                        const float* __restrict__ tbl,  // [ns,D]
+                                                        const float* __restrict__ Min,  // [E,D] (!FIRST)
+                                                        const float4* __restrict__ w0c,
+                                                        const float4* __restrict__ w2,
+                                                        const float* __restrict__ b2,
+                                                        float* __restrict__ a0_out,  // [E,D] or null
+                                                        float* __restrict__ Xout,    // [E,D]
+                                                        int64_t E) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* S = smem;                 // [64][132]
+    float* A = smem + BM * LD128;    // [64][132] (!FIRST)
+    float4* geo_s = reinterpret_cast<float4*>(smem + (FIRST ? 1 : 2) * BM * LD128);  // [64]
+    int* sp_s = reinterpret_cast<int*>(geo_s + BM);                                   // [64]
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    if (threadIdx.x < BM) {
+        int64_t p = row0 + threadIdx.x;
+        geo_s[threadIdx.x] = p < E ? geo[p] : make_float4(0, 0, 0, 0);
+        sp_s[threadIdx.x] = p < E ? sp_nbr[p] : 0;
+    }
+    if (!FIRST) load_rows_to_lds<128>(A, Min, row0, E, D);
+    __syncthreads();
+    if (FIRST) {
+        const int c = threadIdx.x & 127;
+        const float4 wv = reinterpret_cast<const float4*>(wc)[c];
+        for (int r = threadIdx.x >> 7; r < BM; r += 2) {
+            float4 g = geo_s[r];
+            float a = fmaf(g.w, wv.w, fmaf(g.z, wv.z, fmaf(g.y, wv.y, g.x * wv.x))) + tbl[sp_s[r] * D + c];
+            if (a0_out && row0 + r < E) a0_out[(row0 + r) * D + c] = a;
+            S[r * LD128 + c] = siluf_(a);
+        }
+    } else {
+        f32x16 acc[2];
+        const int col0 = 64 * w.ch;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int c = col0 + 32 * t + (w.lane & 31);
+            const float4 wv = reinterpret_cast<const float4*>(wc)[c];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = w.rb * 32 + acc_row(r, w.lane);
+                float4 g = geo_s[row];
+                acc[t][r] = fmaf(g.w, wv.w, fmaf(g.z, wv.z, fmaf(g.y, wv.y, g.x * wv.x))) + tbl[sp_s[row] * D + c];
+            }
+        }
+        gemm_acc<128, 2>(A + w.rb * 32 * LD128, LD128, w0c, 16, 0, 2 * w.ch, acc, w.lane);
+        acc_foreach<2>(acc, w.rb, col0, w.lane, [&](int r, int c, float v) {
+            if (a0_out && row0 + r < E) a0_out[(row0 + r) * D + c] = v;
+            S[r * LD128 + c] = siluf_(v);
+        });
+    }
+    __syncthreads();
+    f32x16 acc2[2];
+    acc_fill_bias<2>(acc2, b2, 64 * w.ch, w.lane);
+    gemm_acc<128, 2>(S + w.rb * 32 * LD128, LD128, w2, 16, 0, 2 * w.ch, acc2, w.lane);
+    store_acc<2>(acc2, Xout, row0, E, D, w.rb, 64 * w.ch, w.lane);
+}
+
+// ---------------------------------------------------------------------------------
+// centre contraction: X[E + i] = H[i] Wcc^T + b   (DN -> D)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_center(const float* __restrict__ H, const float4* __restrict__ wcc,
+                                                      const float* __restrict__ bcc, float* __restrict__ Xc,
+                                                      int64_t N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<256>(smem, H, row0, N, DN);
+    __syncthreads();
+    f32x16 acc[2];
+    acc_fill_bias<2>(acc, bcc, 64 * w.ch, w.lane);
+    gemm_acc<256, 2>(smem + w.rb * 32 * LD256, LD256, wcc, 32, 0, 2 * w.ch, acc, w.lane);
+    store_acc<2>(acc, Xc, row0, N, D, w.rb, 64 * w.ch, w.lane);
+}
+
+// ---------------------------------------------------------------------------------
+// QKV = RMSNorm(X) Win^T + b   (D -> 3D) over all E+N token rows
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_qkv(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                   const float4* __restrict__ win, const float* __restrict__ bin,
+                                                   float* __restrict__ QKV, int64_t R) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<128>(smem, X, row0, R, D);
+    __syncthreads();
+    rmsnorm_rows_inplace<128>(smem, gamma, nullptr);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
+        f32x16 acc[2];
+        const int col0 = 128 * c + 64 * w.ch;
+        acc_fill_bias<2>(acc, bin, col0, w.lane);
+        gemm_acc<128, 2>(smem + w.rb * 32 * LD128, LD128, win, 16, 0, 4 * c + 2 * w.ch, acc, w.lane);
+        store_acc<2>(acc, QKV, row0, R, 3 * D, w.rb, col0, w.lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// attention: one wave per (atom, head); 16x16x4 fp32 MFMA, no LDS.
+// Scores are produced transposed (keys x queries) so that the soft-maxed tile is
+// already in the B-operand layout of the PV product.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t token_row(int t, int T, int64_t E, int atom, int start) {
+    // token 0 = centre, token t >= 1 = edge start + t - 1; out-of-range tokens alias token 0
+    return (t == 0 || t >= T) ? E + atom : (int64_t)start + t - 1;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ QKV, const int* __restrict__ rowptr,
+                                                   const float* __restrict__ fc, float* __restrict__ AO,
+                                                   int64_t E, int N, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int atom = gw / NHEAD, head = gw % NHEAD;
+    if (atom >= N) return;
+    const int start = rowptr[atom];
+    const int T = rowptr[atom + 1] - start + 1;
+    const int nt = (T + 15) >> 4;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    // key fragments (A operand of S^T = K Q^T): K[key = 16 kt + c16][4 g4 .. 4 g4 + 3]
+    float4 kf[NT];
+    float bias[NT][4];
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+        if (kt < nt) {
+            const int64_t row = token_row(16 * kt + c16, T, E, atom, start);
+            kf[kt] = *reinterpret_cast<const float4*>(QKV + row * (3 * D) + D + HD * head + 4 * g4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = 16 * kt + 4 * g4 + r;  // C-layout row of the S^T tile
+                float b = 0.0f;
+                if (key >= T) b = -INFINITY;
+                else if (key > 0) b = logf(fmaxf(fc[start + key - 1], 1e-15f));  // transformer.py:109-110
+                bias[kt][r] = b;
+            }
+        }
+    }
+#pragma unroll 1
+    for (int qt = 0; qt < nt; qt++) {
+        const int q = 16 * qt + c16;
+        const int64_t qrow = token_row(q, T, E, atom, start);
+        float4 qf = *reinterpret_cast<const float4*>(QKV + qrow * (3 * D) + HD * head + 4 * g4);
+        qf.x *= scale; qf.y *= scale; qf.z *= scale; qf.w *= scale;
+        f32x4 s[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; kt++) {
+            if (kt < nt) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].x, qf.x, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].y, qf.y, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].z, qf.z, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].w, qf.w, a, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    a[r] += bias[kt][r];
+                    mx = fmaxf(mx, a[r]);
+                }
+                s[kt] = a;
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; kt++) {
+            if (kt < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float p = expf(s[kt][r] - mx);
+                    s[kt][r] = p;
+                    sum += p;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NT; kt++) {
+            if (kt < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int64_t vrow = token_row(16 * kt + 4 * g4 + r, T, E, atom, start);
+                    const float vv = QKV[vrow * (3 * D) + 2 * D + HD * head + c16];
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, s[kt][r], o, 0, 0, 0);
+                }
+            }
+        }
+        if (q < T) {
+            float4 ov = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+            *reinterpret_cast<float4*>(AO + qrow * D + HD * head + 4 * g4) = ov;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// output_linear + edge residual:  rows < E: X1 = X + AO Wo^T + b ; rows >= E: OC = AO Wo^T + b
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_oproj(const float* __restrict__ AO, const float* __restrict__ X,
+                                                     const float4* __restrict__ wo, const float* __restrict__ bo,
+                                                     float* __restrict__ X1, float* __restrict__ OC, int64_t E,
+                                                     int64_t R) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<128>(smem, AO, row0, R, D);
+    __syncthreads();
+    f32x16 acc[2];
+    acc_fill_bias<2>(acc, bo, 64 * w.ch, w.lane);
+    gemm_acc<128, 2>(smem + w.rb * 32 * LD128, LD128, wo, 16, 0, 2 * w.ch, acc, w.lane);
+    acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
+        const int64_t row = row0 + r;
+        if (row < E) X1[row * D + c] = X[row * D + c] + v;
+        else if (row < R) OC[(row - E) * D + c] = v;
+    });
+}
+
+// ---------------------------------------------------------------------------------
+// node update: h1 = h + OC Wce^T + b ; h2 = h1 + SwiGLU_MLP(RMSNorm(h1))
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_node(const float* __restrict__ H, const float* __restrict__ OC,
+                                                    const float4* __restrict__ wce, const float* __restrict__ bce,
+                                                    const float* __restrict__ gamma,
+                                                    const float4* __restrict__ win, const float* __restrict__ bin,
+                                                    const float4* __restrict__ wout, const float* __restrict__ bout,
+                                                    float* __restrict__ H1, float* __restrict__ VGn,
+                                                    float* __restrict__ Hn, int64_t N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;               // [64][260]
+    float* U = smem + BM * LD256;   // [64][132] (OC tile, then SwiGLU hidden chunk)
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<128>(U, OC, row0, N, D);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < 2; c++) {  // 256 output columns in two chunks of 128
+        f32x16 acc[2];
+        const int col0 = 128 * c + 64 * w.ch;
+        acc_fill_bias<2>(acc, bce, col0, w.lane);
+        gemm_acc<128, 2>(U + w.rb * 32 * LD128, LD128, wce, 16, 0, 4 * c + 2 * w.ch, acc, w.lane);
+        acc_foreach<2>(acc, w.rb, col0, w.lane, [&](int r, int cc, float v) {
+            const int64_t row = row0 + r;
+            float h1 = v + (row < N ? H[row * DN + cc] : 0.f);
+            Hs[r * LD256 + cc] = h1;
+            if (row < N) H1[row * DN + cc] = h1;
+        });
+    }
+    __syncthreads();
+    rmsnorm_rows_inplace<256>(Hs, gamma, nullptr);
+    __syncthreads();
+    f32x16 out[4];  // this wave: 32 rows x 128 columns (128 * ch ..)
+    acc_fill_bias<4>(out, bout, 128 * w.ch, w.lane);
+#pragma unroll 1
+    for (int hc = 0; hc < DNF / 128; hc++) {
+        f32x16 av[2], ag[2];
+        const int hcol0 = 128 * hc + 64 * w.ch;  // hidden columns of this wave
+        acc_fill_bias<2>(av, bin, hcol0, w.lane);
+        acc_fill_bias<2>(ag, bin, DNF + hcol0, w.lane);
+        gemm_acc<256, 2>(Hs + w.rb * 32 * LD256, LD256, win, 32, 0, hcol0 / 32, av, w.lane);
+        gemm_acc<256, 2>(Hs + w.rb * 32 * LD256, LD256, win, 32, 0, (DNF + hcol0) / 32, ag, w.lane);
+        __syncthreads();  // previous chunk's readers of U are done
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rr = w.rb * 32 + acc_row(r, w.lane);
+                const int cc = 64 * w.ch + 32 * t + (w.lane & 31);
+                const float v = av[t][r], gte = ag[t][r];
+                if (VGn && row0 + rr < N) {
+                    VGn[(row0 + rr) * (2 * DNF) + 128 * hc + cc] = v;
+                    VGn[(row0 + rr) * (2 * DNF) + DNF + 128 * hc + cc] = gte;
+                }
+                U[rr * LD128 + cc] = v * sigmoidf_(gte);  // transformer.py:42-43: value * sigmoid(gate)
+            }
+        }
+        __syncthreads();
+        gemm_acc<128, 4>(U + w.rb * 32 * LD128, LD128, wout, DNF / 8, 16 * hc, 4 * w.ch, out, w.lane);
+    }
+    acc_foreach<4>(out, w.rb, 128 * w.ch, w.lane, [&](int r, int c, float v) {
+        const int64_t row = row0 + r;
+        if (row < N) Hn[row * DN + c] = H1[row * DN + c] + v;
+    });
+}
+
+// ---------------------------------------------------------------------------------
+// edge MLP: X2 = X1 + SwiGLU_MLP(RMSNorm(X1))
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_emlp(const float* __restrict__ X1, const float* __restrict__ gamma,
+                                                    const float4* __restrict__ win, const float* __restrict__ bin,
+                                                    const float4* __restrict__ wout, const float* __restrict__ bout,
+                                                    float* __restrict__ VG, float* __restrict__ X2, int64_t E) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* A = smem;               // [64][132]
+    float* U = smem + BM * LD128;  // [64][132]
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<128>(A, X1, row0, E, D);
+    __syncthreads();
+    rmsnorm_rows_inplace<128>(A, gamma, nullptr);
+    __syncthreads();
+    f32x16 out[2];
+    acc_fill_bias<2>(out, bout, 64 * w.ch, w.lane);
+#pragma unroll 1
+    for (int hc = 0; hc < DFF / 128; hc++) {
+        f32x16 av[2], ag[2];
+        const int hcol0 = 128 * hc + 64 * w.ch;
+        acc_fill_bias<2>(av, bin, hcol0, w.lane);
+        acc_fill_bias<2>(ag, bin, DFF + hcol0, w.lane);
+        gemm_acc<128, 2>(A + w.rb * 32 * LD128, LD128, win, 16, 0, hcol0 / 32, av, w.lane);
+        gemm_acc<128, 2>(A + w.rb * 32 * LD128, LD128, win, 16, 0, (DFF + hcol0) / 32, ag, w.lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rr = w.rb * 32 + acc_row(r, w.lane);
+                const int cc = 64 * w.ch + 32 * t + (w.lane & 31);
+                const float v = av[t][r], gte = ag[t][r];
+                if (VG && row0 + rr < E) {
+                    VG[(row0 + rr) * (2 * DFF) + 128 * hc + cc] = v;
+                    VG[(row0 + rr) * (2 * DFF) + DFF + 128 * hc + cc] = gte;
+                }
+                U[rr * LD128 + cc] = v * sigmoidf_(gte);
+            }
+        }
+        __syncthreads();
+        gemm_acc<128, 2>(U + w.rb * 32 * LD128, LD128, wout, DFF / 8, 16 * hc, 2 * w.ch, out, w.lane);
+    }
+    acc_foreach<2>(out, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
+        const int64_t row = row0 + r;
+        if (row < E) X2[row * D + c] = X1[row * D + c] + v;
+    });
+}
+
+// ---------------------------------------------------------------------------------
+// message passing: Mout = Min + e + MLP(LayerNorm([e ; e[rev]]))   (backend.py:559-575)
+// ---------------------------------------------------------------------------------
+template <bool FIRST>
+__global__ __launch_bounds__(NTHREADS) void k_comb(const float* __restrict__ XF, const int* __restrict__ rev,
+                                                    const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                    const float4* __restrict__ w0, const float* __restrict__ b0,
+                                                    const float4* __restrict__ w2, const float* __restrict__ b2,
+                                                    const float* __restrict__ Min,       // [E,D]  (!FIRST)
+                                                    const float* __restrict__ edge_emb,  // [ns,D] (FIRST)
+                                                    const int* __restrict__ sp_nbr, float* __restrict__ CA,
+                                                    float* __restrict__ LNS, float* __restrict__ Mout, int64_t E) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Lo = smem;               // [64][132]  e rows
+    float* Hi = smem + BM * LD128;  // [64][132]  e[rev] rows
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<128>(Lo, XF, row0, E, D);
+    for (int idx = threadIdx.x; idx < BM * 32; idx += NTHREADS) {  // gathered rows: 512 B each
+        int r = idx >> 5, c = idx & 31;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (row0 + r < E) v = *reinterpret_cast<const float4*>(XF + (int64_t)rev[row0 + r] * D + 4 * c);
+        *reinterpret_cast<float4*>(Hi + r * LD128 + 4 * c) = v;
+    }
+    __syncthreads();
+    {   // LayerNorm over the 256 concatenated features, eps = 1e-5 (backend.py:95-97)
+        const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = q * 4; c < 128; c += 16) {
+            float4 a = *reinterpret_cast<float4*>(Lo + r * LD128 + c);
+            float4 b = *reinterpret_cast<float4*>(Hi + r * LD128 + c);
+            s1 += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+        }
+        s1 += __shfl_xor(s1, 1);
+        s1 += __shfl_xor(s1, 2);
+        const float mean = s1 * (1.0f / 256.0f);
+        for (int c = q * 4; c < 128; c += 16) {
+            float4 a = *reinterpret_cast<float4*>(Lo + r * LD128 + c);
+            float4 b = *reinterpret_cast<float4*>(Hi + r * LD128 + c);
+            float d;
+            d = a.x - mean; s2 += d * d; d = a.y - mean; s2 += d * d;
+            d = a.z - mean; s2 += d * d; d = a.w - mean; s2 += d * d;
+            d = b.x - mean; s2 += d * d; d = b.y - mean; s2 += d * d;
+            d = b.z - mean; s2 += d * d; d = b.w - mean; s2 += d * d;
+        }
+        s2 += __shfl_xor(s2, 1);
+        s2 += __shfl_xor(s2, 2);
+        const float rstd = rsqrtf(s2 * (1.0f / 256.0f) + 1e-5f);
+        if (LNS && q == 0 && row0 + r < E) {
+            LNS[(row0 + r) * 2] = mean;
+            LNS[(row0 + r) * 2 + 1] = rstd;
+        }
+        for (int c = q * 4; c < 128; c += 16) {
+            float4 a = *reinterpret_cast<float4*>(Lo + r * LD128 + c);
+            float4 b = *reinterpret_cast<float4*>(Hi + r * LD128 + c);
+            float4 ga = *reinterpret_cast<const float4*>(ln_g + c), ba = *reinterpret_cast<const float4*>(ln_b + c);
+            float4 gb = *reinterpret_cast<const float4*>(ln_g + 128 + c), bb = *reinterpret_cast<const float4*>(ln_b + 128 + c);
+            a.x = (a.x - mean) * rstd * ga.x + ba.x; a.y = (a.y - mean) * rstd * ga.y + ba.y;
+            a.z = (a.z - mean) * rstd * ga.z + ba.z; a.w = (a.w - mean) * rstd * ga.w + ba.w;
+            b.x = (b.x - mean) * rstd * gb.x + bb.x; b.y = (b.y - mean) * rstd * gb.y + bb.y;
+            b.z = (b.z - mean) * rstd * gb.z + bb.z; b.w = (b.w - mean) * rstd * gb.w + bb.w;
+            *reinterpret_cast<float4*>(Lo + r * LD128 + c) = a;
+            *reinterpret_cast<float4*>(Hi + r * LD128 + c) = b;
+        }
+    }
+    __syncthreads();
+    f32x16 a1[4];  // 32 rows x 128 hidden columns (128 * ch ..)
+    acc_fill_bias<4>(a1, b0, 128 * w.ch, w.lane);
+    gemm_acc<128, 4>(Lo + w.rb * 32 * LD128, LD128, w0, 32, 0, 4 * w.ch, a1, w.lane);
+    gemm_acc<128, 4>(Hi + w.rb * 32 * LD128, LD128, w0, 32, 16, 4 * w.ch, a1, w.lane);
+    __syncthreads();  // all waves finished reading Lo/Hi
+    float* Sdst = w.ch == 0 ? Lo : Hi;  // hidden columns 0..127 -> Lo, 128..255 -> Hi
+    acc_foreach<4>(a1, w.rb, 0, w.lane, [&](int r, int c, float v) {
+        if (CA && row0 + r < E) CA[(row0 + r) * (2 * D) + 128 * w.ch + c] = v;
+        Sdst[r * LD128 + c] = siluf_(v);
+    });
+    __syncthreads();
+    f32x16 out[2];
+    acc_fill_bias<2>(out, b2, 64 * w.ch, w.lane);
+    gemm_acc<128, 2>(Lo + w.rb * 32 * LD128, LD128, w2, 32, 0, 2 * w.ch, out, w.lane);
+    gemm_acc<128, 2>(Hi + w.rb * 32 * LD128, LD128, w2, 32, 16, 2 * w.ch, out, w.lane);
+    acc_foreach<2>(out, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
+        const int64_t row = row0 + r;
+        if (row < E) {
+            float m_in = FIRST ? edge_emb[sp_nbr[row] * D + c] : Min[row * D + c];
+            Mout[row * D + c] = m_in + XF[row * D + c] + v;
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------
+// heads: y = w . SiLU(W2 SiLU(W0 x + b0) + b2) + b     (backend.py:171-217, 726-777)
+// ---------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(NTHREADS) void k_head(const float* __restrict__ Xin, const float4* __restrict__ w0,
+                                                    const float* __restrict__ b0, const float4* __restrict__ w2,
+                                                    const float* __restrict__ b2, const float* __restrict__ wl,
+                                                    float bl, const float* __restrict__ fc /* or null */,
+                                                    float* __restrict__ ypred, float* __restrict__ yout,
+                                                    int64_t R) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LDK = lds_ld(K);
+    float* A = smem;              // [64][K+4]
+    float* S = smem + BM * LDK;   // [64][132]
+    const WaveId w;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<K>(A, Xin, row0, R, K);
+    __syncthreads();
+    f32x16 acc[2];
+    acc_fill_bias<2>(acc, b0, 64 * w.ch, w.lane);
+    gemm_acc<K, 2>(A + w.rb * 32 * LDK, LDK, w0, K / 8, 0, 2 * w.ch, acc, w.lane);
+    acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) { S[r * LD128 + c] = siluf_(v); });
+    __syncthreads();
+    acc_fill_bias<2>(acc, b2, 64 * w.ch, w.lane);
+    gemm_acc<128, 2>(S + w.rb * 32 * LD128, LD128, w2, 16, 0, 2 * w.ch, acc, w.lane);
+    __syncthreads();
+    acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) { S[r * LD128 + c] = siluf_(v) * wl[c]; });
+    __syncthreads();
+    {
+        const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+        float s = 0.f;
+        for (int c = q * 4; c < 128; c += 16) {
+            float4 v = *reinterpret_cast<float4*>(S + r * LD128 + c);
+            s += v.x + v.y + v.z + v.w;
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (q == 0 && row0 + r < R) {
+            const float y = s + bl;
+            if (ypred) ypred[row0 + r] = y;
+            yout[row0 + r] = fc ? y * fc[row0 + r] : y;
+        }
+    }
+}
+
+// atomic[i] = ynode[i] + sum_{edges of i} ye   (backend.py:768-772, 476)
+__global__ void k_atom_sum(const float* __restrict__ ynode, const float* __restrict__ ye,
+                           const int* __restrict__ rowptr, float* __restrict__ atomic, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = rowptr[i]; p < rowptr[i + 1]; p++) s += ye[p];
+    atomic[i] = ynode[i] + s;
+}
+
+// ---------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------
+int64_t forward_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges) {
+    Workspace w;
+    carve_workspace(m, n_nodes, n_edges, nullptr, w);
+    return (int64_t)w.bytes;
+}
+
+template <int NT>
+static void launch_attn_fwd(const float* QKV, const Graph& g, float* AO, float scale, hipStream_t st) {
+    int waves = (int)g.n_nodes * NHEAD;
+    k_attn_fwd<NT><<<cdiv(waves, 4), 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, (int)g.n_nodes, scale);
+}
+
+int attn_tiles(const Graph& g) { return (g.max_nbr + 1 + 15) / 16; }
+
+int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
+            float* node_feat, float* edge_feat, hipStream_t st) {
+    Workspace w;
+    carve_workspace(m, g.n_nodes, g.n_edges, ws, w);
+    PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "forward workspace too small");
+    const int64_t N = g.n_nodes, E = g.n_edges, R = E + N;
+    if (N == 0) return PET_OK;
+    (void)save;  // everything the backward needs is always kept (see pet_ws.h)
+    const int nt = attn_tiles(g);
+    PET_REQUIRE(nt <= 8, PET_ERR_UNSUPPORTED,
+                "more than 127 neighbours per atom (" + std::to_string(g.max_nbr) + ") is not supported yet");
+    const float scale = 1.0f / (sqrtf((float)HD) * m.h.attention_temperature);
+    const int gE = cdiv(E, BM), gN = cdiv(N, BM), gR = cdiv(R, BM);
+    const size_t lds1 = BM * LD128 * 4, lds2 = 2 * BM * LD128 * 4;
+    const size_t lds_c = lds2 + BM * 20;
+    const double fE = (double)E, fN = (double)N, fR = (double)R;
+
+    allow_big_lds(k_center, BM * LD256 * 4);
+    allow_big_lds(k_node, (BM * LD256 + BM * LD128) * 4);
+    allow_big_lds(k_head<256>, (BM * LD256 + BM * LD128) * 4);
+    k_node_embed<<<cdiv(N * (DN / 4), 256), 256, 0, st>>>(g.sp, m.node_emb, w.H0, (int)N);
+    for (int gi = 0; gi < m.h.num_gnn_layers; gi++) {
+        const GnnLayerW& G = m.gnn[gi];
+        GnnBufs& B = w.gnn[gi];
+        const float* Min = gi == 0 ? nullptr : w.gnn[gi - 1].Mout;
+        if (E > 0) {
+            ProfScope ps("compress", st, fE * 2.0 * (D * D * (gi == 0 ? 3 : 4) + 4 * D));
+            if (gi == 0)
+                k_compress<true><<<gE, NTHREADS, lds1 + BM * 20, st>>>(g.geo, g.sp_nbr, G.wc, G.tbl, nullptr, nullptr,
+                                                                        G.compress2.fwd, G.compress2.b, B.a0,
+                                                                        B.attn[0].X, E);
+            else
+                k_compress<false><<<gE, NTHREADS, lds_c, st>>>(g.geo, g.sp_nbr, G.wc, G.tbl, Min,
+                                                               G.compress0_msg.fwd, G.compress2.fwd, G.compress2.b,
+                                                               B.a0, B.attn[0].X, E);
+        }
+        for (int a = 0; a < m.h.num_attention_layers; a++) {
+            const AttnLayerW& A = G.attn[a];
+            AttnBufs& Ab = B.attn[a];
+            float* Xnext = (a + 1 < m.h.num_attention_layers) ? B.attn[a + 1].X : B.XF;
+            {
+                ProfScope ps("center", st, fN * 2.0 * DN * D);
+                k_center<<<gN, NTHREADS, BM * LD256 * 4, st>>>(Ab.H, A.cc.fwd, A.cc.b, Ab.X + E * D, N);
+            }
+            {
+                ProfScope ps("qkv", st, fR * 2.0 * D * 3 * D);
+                k_qkv<<<gR, NTHREADS, lds1, st>>>(Ab.X, A.g_attn, A.qkv.fwd, A.qkv.b, Ab.QKV, R);
+            }
+            {
+                ProfScope ps("attn_fwd", st, 0.0);
+                switch (nt) {
+                    case 1: launch_attn_fwd<1>(Ab.QKV, g, w.AO, scale, st); break;
+                    case 2: launch_attn_fwd<2>(Ab.QKV, g, w.AO, scale, st); break;
+                    case 3: launch_attn_fwd<3>(Ab.QKV, g, w.AO, scale, st); break;
+                    case 4: launch_attn_fwd<4>(Ab.QKV, g, w.AO, scale, st); break;
+                    case 5: case 6: launch_attn_fwd<6>(Ab.QKV, g, w.AO, scale, st); break;
+                    default: launch_attn_fwd<8>(Ab.QKV, g, w.AO, scale, st); break;
+                }
+            }
+            {
+                ProfScope ps("oproj", st, fR * 2.0 * D * D);
+                k_oproj<<<gR, NTHREADS, lds1, st>>>(w.AO, Ab.X, A.out.fwd, A.out.b, Ab.X1, w.OC, E, R);
+            }
+            {
+                ProfScope ps("node", st, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
+                k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, st>>>(
+                    Ab.H, w.OC, A.ce.fwd, A.ce.b, A.g_center, A.cmlp_in.fwd, A.cmlp_in.b, A.cmlp_out.fwd,
+                    A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
+            }
+            if (E > 0) {
+                ProfScope ps("emlp", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
+                k_emlp<<<gE, NTHREADS, lds2, st>>>(Ab.X1, A.g_mlp, A.mlp_in.fwd, A.mlp_in.b, A.mlp_out.fwd,
+                                                   A.mlp_out.b, Ab.VG, Xnext, E);
+            }
+        }
+        if (E > 0) {
+            ProfScope ps("comb", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D));
+            if (gi == 0)
+                k_comb<true><<<gE, NTHREADS, lds2, st>>>(B.XF, g.rev, G.ln_g, G.ln_b, G.comb0.fwd, G.comb0.b,
+                                                         G.comb2.fwd, G.comb2.b, nullptr, m.edge_emb, g.sp_nbr,
+                                                         B.CA, B.LNS, B.Mout, E);
+            else
+                k_comb<false><<<gE, NTHREADS, lds2, st>>>(B.XF, g.rev, G.ln_g, G.ln_b, G.comb0.fwd, G.comb0.b,
+                                                          G.comb2.fwd, G.comb2.b, Min, m.edge_emb, g.sp_nbr, B.CA,
+                                                          B.LNS, B.Mout, E);
+        }
+    }
+    const GnnBufs& last = w.gnn.back();
+    {
+        ProfScope ps("head_node", st, fN * 2.0 * (DN * DH + DH * DH + DH));
+        k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, st>>>(
+            last.Hout, m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nll_w, m.nll_b, nullptr, nullptr, w.ynode, N);
+    }
+    if (E > 0) {
+        ProfScope ps("head_edge", st, fE * 2.0 * (D * DH + DH * DH + DH));
+        k_head<128><<<gE, NTHREADS, lds2, st>>>(last.Mout, m.eh0.fwd, m.eh0.b, m.eh2.fwd, m.eh2.b, m.ell_w,
+                                                m.ell_b, g.fc, w.ypred_e, w.ye, E);
+    }
+    k_atom_sum<<<cdiv(N, 256), 256, 0, st>>>(w.ynode, w.ye, g.rowptr, atomic, (int)N);
+    if (node_feat)
+        PET_HIP_CHECK(hipMemcpyAsync(node_feat, last.Hout, N * DN * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (edge_feat && E > 0)
+        PET_HIP_CHECK(hipMemcpyAsync(edge_feat, last.Mout, E * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
+}  // namespace pet

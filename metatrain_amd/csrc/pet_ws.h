@@ -1,0 +1,118 @@
+// Activation workspace shared by the forward and backward passes. Everything the
+// reverse pass needs is kept (288 GB of HBM3E per GPU: ~24 KB per edge is cheap),
+// so the backward never recomputes a GEMM.
+#pragma once
+#include <vector>
+
+#include "common.h"
+#include "model.h"
+
+namespace pet {
+
+struct AttnBufs {
+    float* X = nullptr;    // [(E+N), D] tokens entering the layer (edges rows 0..E-1, centres E..)
+    float* QKV = nullptr;  // [(E+N), 3D]
+    float* X1 = nullptr;   // [E, D]  edges after attention residual (input of the edge MLP)
+    float* VG = nullptr;   // [E, 2*DFF] SwiGLU pre-activations (value | gate)
+    float* H = nullptr;    // [N, DN] node features entering the layer (alias of the producer)
+    float* Hn = nullptr;   // [N, DN] node features leaving the layer
+    float* H1 = nullptr;   // [N, DN] after centre expansion residual
+    float* VGn = nullptr;  // [N, 2*DNF]
+};
+
+struct GnnBufs {
+    std::vector<AttnBufs> attn;
+    float* a0 = nullptr;    // [E, D] compress.0 pre-activation
+    float* XF = nullptr;    // [E, D] edge tokens leaving the transformer
+    float* CA = nullptr;    // [E, 2D] combination MLP pre-activation
+    float* LNS = nullptr;   // [E, 2] LayerNorm (mean, rstd) of [e ; e_rev]
+    float* Mout = nullptr;  // [E, D] messages leaving the layer
+    float* Hout = nullptr;  // [N, DN]
+};
+
+struct Workspace {
+    std::vector<GnnBufs> gnn;
+    float* H0 = nullptr;     // [N, DN] node embedding
+    float* AO = nullptr;     // [(E+N), D] attention output before output_linear (temp)
+    float* OC = nullptr;     // [N, D] centre rows of output_linear (temp)
+    float* ypred_e = nullptr;  // [E] edge last-layer prediction before the cutoff weight
+    float* ye = nullptr;       // [E] fc * ypred_e
+    float* ynode = nullptr;    // [N]
+    // backward temporaries
+    float* dM = nullptr;      // [E, D]
+    float* dM2 = nullptr;     // [E, D]
+    float* dX = nullptr;      // [(E+N), D]
+    float* dX2 = nullptr;     // [(E+N), D]
+    float* dQKV = nullptr;    // [(E+N), 3D]
+    float* dAO = nullptr;     // [(E+N), D]
+    float* dcat = nullptr;    // [E, 2D]
+    float* dH = nullptr;      // [N, DN]
+    float* dH2 = nullptr;     // [N, DN]
+    float* dOC = nullptr;     // [N, D]
+    float* dgeo = nullptr;    // [E, 4] accumulated d/d(vx,vy,vz,dist)
+    float* dfc = nullptr;     // [E]
+    float* dbias = nullptr;   // [E] attention key-bias gradient (summed over heads/layers)
+    float* delta = nullptr;   // [(E+N), NHEAD]
+    float* lse = nullptr;     // [(E+N), NHEAD]
+    float* dv = nullptr;      // [E, 4] d/d(edge vector)
+    size_t bytes = 0;
+};
+
+inline void carve_workspace(const Model& m, int64_t N, int64_t E, void* base, Workspace& w) {
+    Carver c(base);
+    const int64_t R = E + N;
+    const int64_t Ea = E > 0 ? E : 1, Na = N > 0 ? N : 1, Ra = R > 0 ? R : 1;
+    w.gnn.resize(m.h.num_gnn_layers);
+    for (auto& G : w.gnn) {
+        G.attn.resize(m.h.num_attention_layers);
+        for (auto& A : G.attn) {
+            A.X = c.take<float>(Ra * D);
+            A.QKV = c.take<float>(Ra * 3 * D);
+            A.X1 = c.take<float>(Ea * D);
+            A.VG = c.take<float>(Ea * 2 * DFF);
+            A.H1 = c.take<float>(Na * DN);
+            A.VGn = c.take<float>(Na * 2 * DNF);
+        }
+        G.a0 = c.take<float>(Ea * D);
+        G.XF = c.take<float>(Ea * D);
+        G.CA = c.take<float>(Ea * 2 * D);
+        G.LNS = c.take<float>(Ea * 2);
+        G.Mout = c.take<float>(Ea * D);
+        G.Hout = nullptr;
+    }
+    // node feature chain: H0 plus one buffer per attention layer
+    w.H0 = c.take<float>(Na * DN);
+    float* prev = w.H0;
+    for (auto& G : w.gnn) {
+        for (auto& A : G.attn) {
+            A.H = prev;
+            A.Hn = c.take<float>(Na * DN);
+            prev = A.Hn;
+        }
+        G.Hout = prev;
+    }
+    w.AO = c.take<float>(Ra * D);
+    w.OC = c.take<float>(Na * D);
+    w.ypred_e = c.take<float>(Ea);
+    w.ye = c.take<float>(Ea);
+    w.ynode = c.take<float>(Na);
+    w.dM = c.take<float>(Ea * D);
+    w.dM2 = c.take<float>(Ea * D);
+    w.dX = c.take<float>(Ra * D);
+    w.dX2 = c.take<float>(Ra * D);
+    w.dQKV = c.take<float>(Ra * 3 * D);
+    w.dAO = c.take<float>(Ra * D);
+    w.dcat = c.take<float>(Ea * 2 * D);
+    w.dH = c.take<float>(Na * DN);
+    w.dH2 = c.take<float>(Na * DN);
+    w.dOC = c.take<float>(Na * D);
+    w.dgeo = c.take<float>(Ea * 4);
+    w.dfc = c.take<float>(Ea);
+    w.dbias = c.take<float>(Ea);
+    w.delta = c.take<float>(Ra * NHEAD);
+    w.lse = c.take<float>(Ra * NHEAD);
+    w.dv = c.take<float>(Ea * 4);
+    w.bytes = c.off;
+}
+
+}  // namespace pet

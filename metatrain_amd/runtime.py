@@ -1,0 +1,276 @@
+"""Thin host layer over the C ABI: torch owns device memory and streams, libpet_hip
+does the work. Nothing here computes on the CPU and nothing falls back to torch ops.
+"""
+import ctypes
+from ctypes import byref, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import PetHipError, PetHypers, check
+
+
+def _stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> c_void_p:
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def _require_cuda(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t.device.type != "cuda":
+            raise PetHipError(
+                "metatrain_amd runs on MI355X only: got a tensor on "
+                f"'{t.device}'. There is no CPU path in this package."
+            )
+
+
+def hypers_struct(hypers: dict, atomic_types: List[int]) -> PetHypers:
+    fn = hypers["cutoff_function"].lower()
+    if fn not in ("bump", "cosine"):
+        raise ValueError(f"Unknown cutoff function type: {hypers['cutoff_function']}")
+    for key, want in (("normalization", "RMSNorm"), ("activation", "SwiGLU"),
+                      ("transformer_type", "PreLN"), ("featurizer_type", "feedforward")):
+        if hypers[key] != want:
+            raise PetHipError(f"hypers['{key}'] = {hypers[key]!r} is not built into libpet_hip (only {want!r})")
+    if hypers["num_neighbors_adaptive"] is not None:
+        raise PetHipError("adaptive cutoff is not built into libpet_hip yet")
+    if hypers.get("system_conditioning", False):
+        raise PetHipError("system_conditioning is not built into libpet_hip yet")
+    return PetHypers(
+        cutoff=float(hypers["cutoff"]),
+        cutoff_width=float(hypers["cutoff_width"]),
+        cutoff_function=_lib.PET_CUTOFF_BUMP if fn == "bump" else _lib.PET_CUTOFF_COSINE,
+        d_pet=int(hypers["d_pet"]),
+        d_head=int(hypers["d_head"]),
+        d_node=int(hypers["d_node"]),
+        d_feedforward=int(hypers["d_feedforward"]),
+        num_heads=int(hypers["num_heads"]),
+        num_attention_layers=int(hypers["num_attention_layers"]),
+        num_gnn_layers=int(hypers["num_gnn_layers"]),
+        attention_temperature=float(hypers["attention_temperature"]),
+        nl_is_strict=int(bool(hypers["long_range"]["enable"])),
+        n_species=len(atomic_types),
+        max_atomic_number=max(atomic_types),
+    )
+
+
+class HipModel:
+    """Device-resident packed weights (``pet_model_t``)."""
+
+    def __init__(self, hypers: dict, atomic_types: List[int]):
+        self.lib = _lib.load()
+        self.hypers = dict(hypers)
+        self.atomic_types = list(atomic_types)
+        self._h = hypers_struct(hypers, atomic_types)
+        self._handle = c_void_p()
+        check(self.lib.pet_model_create(byref(self._h), byref(self._handle)))
+        self.target: Optional[str] = None
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            self.lib.pet_model_destroy(h)
+            self._handle = c_void_p()
+
+    @property
+    def handle(self) -> c_void_p:
+        return self._handle
+
+    def load(self, params: Dict[str, torch.Tensor], target: str, block: Optional[str] = None) -> None:
+        """Upload a reference-schema state dict for one target and pack it."""
+        block = block or target
+        self.target = target
+        for key, t in params.items():
+            _require_cuda(t)
+            parts = key.split(".")
+            if parts[0] in ("node_heads", "edge_heads", "node_last_layers", "edge_last_layers"):
+                if parts[1] != target:
+                    continue
+                parts[1] = "@"
+                if parts[0].endswith("last_layers"):
+                    if parts[3] != block:
+                        continue
+                    parts[3] = "@"
+            ckey = ".".join(parts)
+            if key == "species_to_species_index":
+                src = t.to(torch.int64).contiguous()
+            else:
+                src = t.detach().to(torch.float32).contiguous()
+            check(self.lib.pet_model_set_param(self._handle, ckey.encode(), _ptr(src), src.numel(), _stream()))
+            torch.cuda.current_stream().synchronize()  # src may be a temporary
+        check(self.lib.pet_model_finalize(self._handle, _stream()))
+
+    @property
+    def num_params(self) -> int:
+        return int(self.lib.pet_model_num_params(self._handle))
+
+
+class HipGraph:
+    """CSR edge graph (``pet_graph_t``) + the workspace it lives in."""
+
+    def __init__(self, model: HipModel, positions, cells, centers, neighbors, cell_shifts, species,
+                 system_indices):
+        _require_cuda(positions, cells, centers, neighbors, cell_shifts, species, system_indices)
+        self.lib = model.lib
+        self.model = model
+        dev = positions.device
+        self.n_nodes = int(positions.shape[0])
+        self.n_systems = int(cells.shape[0])
+        self.n_edges_in = int(centers.shape[0])
+        # keep the converted inputs alive: the graph build reads them asynchronously
+        self._pos = positions.detach().to(torch.float32).contiguous()
+        self._cells = cells.detach().to(torch.float32).contiguous()
+        self._ctr = centers.to(torch.int32).contiguous()
+        self._nbr = neighbors.to(torch.int32).contiguous()
+        self._shift = cell_shifts.to(torch.int32).contiguous()
+        self._species = species.to(torch.int32).contiguous()
+        self._sys = system_indices.to(torch.int32).contiguous()
+        nbytes = int(self.lib.pet_graph_workspace_bytes(self.n_nodes, self.n_edges_in))
+        if nbytes < 0:
+            raise PetHipError("pet_graph_workspace_bytes failed")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._handle = c_void_p()
+        check(self.lib.pet_graph_build(
+            model.handle, _ptr(self._pos), _ptr(self._cells), _ptr(self._ctr), _ptr(self._nbr),
+            _ptr(self._shift), _ptr(self._species), _ptr(self._sys), self.n_nodes, self.n_edges_in,
+            self.n_systems, _ptr(self.workspace), nbytes, byref(self._handle), _stream()))
+        self.n_edges = int(self.lib.pet_graph_num_edges(self._handle))
+        self.max_neighbors = int(self.lib.pet_graph_max_neighbors(self._handle))
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            self.lib.pet_graph_destroy(h)
+            self._handle = c_void_p()
+
+    @property
+    def handle(self) -> c_void_p:
+        return self._handle
+
+    def export_batch(self) -> Dict[str, torch.Tensor]:
+        """The 12 ``batch_data`` tensors of ``PETBackend.preprocess`` (backend.py:328-341)."""
+        dev = self.workspace.device
+        n, m, e = self.n_nodes, self.max_neighbors, self.n_edges
+        i64, f32 = torch.int64, torch.float32
+        out = {
+            "element_indices_nodes": torch.empty(n, dtype=i64, device=dev),
+            "element_indices_neighbors": torch.empty((n, m), dtype=i64, device=dev),
+            "edge_vectors": torch.empty((n, m, 3), dtype=f32, device=dev),
+            "edge_distances": torch.empty((n, m), dtype=f32, device=dev),
+            "padding_mask": torch.empty((n, m), dtype=torch.uint8, device=dev),
+            "reverse_neighbor_index": torch.empty((n, m), dtype=i64, device=dev),
+            "cutoff_factors": torch.empty((n, m), dtype=f32, device=dev),
+            "atomic_cutoffs_stats": torch.empty(n, dtype=f32, device=dev),
+            "centers": torch.empty(e, dtype=i64, device=dev),
+            "neighbors": torch.empty(e, dtype=i64, device=dev),
+            "nef_to_edges_neighbor": torch.empty(e, dtype=i64, device=dev),
+            "cell_shifts": torch.empty((e, 3), dtype=i64, device=dev),
+        }
+        order = ["element_indices_nodes", "element_indices_neighbors", "edge_vectors", "edge_distances",
+                 "padding_mask", "reverse_neighbor_index", "cutoff_factors", "atomic_cutoffs_stats",
+                 "centers", "neighbors", "nef_to_edges_neighbor", "cell_shifts"]
+        check(self.lib.pet_graph_export_batch(self._handle, *[_ptr(out[k]) for k in order], _stream()))
+        out["padding_mask"] = out["padding_mask"].to(torch.bool)
+        return out
+
+    def csr(self) -> Dict[str, torch.Tensor]:
+        """Copies of rowptr / ctr / nbr / rev (int32) for inspection."""
+        ptrs = [c_void_p() for _ in range(4)]
+        check(self.lib.pet_graph_csr(self._handle, *[byref(p) for p in ptrs]))
+        torch.cuda.current_stream().synchronize()
+        base = self.workspace.data_ptr()
+        sizes = [self.n_nodes + 1, self.n_edges, self.n_edges, self.n_edges]
+        out = {}
+        for name, p, sz in zip(["rowptr", "ctr", "nbr", "rev"], ptrs, sizes):
+            off = p.value - base
+            out[name] = self.workspace[off : off + 4 * sz].view(torch.int32).clone()
+        return out
+
+
+class HipForward:
+    """One forward pass' activations (kept for the backward)."""
+
+    def __init__(self, model: HipModel, graph: HipGraph):
+        self.model, self.graph = model, graph
+        self.lib = model.lib
+        nbytes = int(self.lib.pet_forward_workspace_bytes(model.handle, graph.n_nodes, graph.n_edges))
+        if nbytes < 0:
+            raise PetHipError("pet_forward_workspace_bytes failed")
+        self.nbytes = nbytes
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=graph.workspace.device)
+
+    def forward(self, want_features: bool = False):
+        g = self.graph
+        dev = self.workspace.device
+        atomic = torch.empty(g.n_nodes, dtype=torch.float32, device=dev)
+        nf = torch.empty((g.n_nodes, self.model.hypers["d_node"]), dtype=torch.float32, device=dev) if want_features else None
+        ef = torch.empty((g.n_edges, self.model.hypers["d_pet"]), dtype=torch.float32, device=dev) if want_features else None
+        check(self.lib.pet_forward(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes, 1,
+                                   _ptr(atomic), _ptr(nf), _ptr(ef), _stream()))
+        if want_features:
+            return atomic, nf, ef
+        return atomic
+
+    def backward(self, grad_atomic: torch.Tensor, want_cell_grad: bool = False):
+        g = self.graph
+        dev = self.workspace.device
+        _require_cuda(grad_atomic)
+        ga = grad_atomic.to(torch.float32).contiguous()
+        gpos = torch.empty((g.n_nodes, 3), dtype=torch.float32, device=dev)
+        gcell = torch.empty((g.n_systems, 3, 3), dtype=torch.float32, device=dev) if want_cell_grad else None
+        check(self.lib.pet_backward(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes, _ptr(ga),
+                                    _ptr(gpos), _ptr(gcell), _stream()))
+        if want_cell_grad:
+            return gpos, gcell
+        return gpos
+
+    def sum_over_atoms(self, atomic: torch.Tensor) -> torch.Tensor:
+        out = torch.zeros(self.graph.n_systems, dtype=torch.float32, device=atomic.device)
+        check(self.lib.pet_sum_over_atoms(self.graph.handle, _ptr(atomic), _ptr(out), _stream()))
+        return out
+
+
+def neighbor_list(positions: torch.Tensor, cell: torch.Tensor, pbc, cutoff: float):
+    """Device neighbour list of one system: ``(pairs [E,5] int32, vectors [E,3] fp32)`` with rows
+    ``(i, j, Sa, Sb, Sc)`` grouped by ``i`` (replaces vesin, utils/neighbor_lists.py:131-135)."""
+    _require_cuda(positions)
+    lib = _lib.load()
+    pos = positions.detach().to(torch.float32).contiguous()
+    n = int(pos.shape[0])
+    h_cell = (c_float * 9)(*[float(x) for x in cell.detach().cpu().reshape(-1).tolist()])
+    h_pbc = (c_int32 * 3)(*[int(bool(x)) for x in pbc])
+    ws = torch.empty(int(lib.pet_nl_workspace_bytes(n)), dtype=torch.uint8, device=pos.device)
+    count = c_int64(0)
+    check(lib.pet_nl_build(_ptr(pos), h_cell, h_pbc, n, float(cutoff), _ptr(ws), c_void_p(0), c_void_p(0), 0,
+                           byref(count), _stream()))
+    e = int(count.value)
+    pairs = torch.empty((e, 5), dtype=torch.int32, device=pos.device)
+    vectors = torch.empty((e, 3), dtype=torch.float32, device=pos.device)
+    check(lib.pet_nl_build(_ptr(pos), h_cell, h_pbc, n, float(cutoff), _ptr(ws), _ptr(pairs), _ptr(vectors), e,
+                           byref(count), _stream()))
+    return pairs, vectors
+
+
+def profile(enable: bool) -> None:
+    lib = _lib.load()
+    check(lib.pet_profile_reset())
+    check(lib.pet_profile_enable(1 if enable else 0))
+
+
+def profile_report() -> List[dict]:
+    lib = _lib.load()
+    n_max = 64
+    names = ((ctypes.c_char * 64) * n_max)()
+    ms = (c_double * n_max)()
+    calls = (c_int64 * n_max)()
+    flops = (c_double * n_max)()
+    n = c_int(0)
+    check(lib.pet_profile_report(n_max, names, ms, calls, flops, byref(n)))
+    return [
+        {"name": names[i].value.decode(), "total_ms": ms[i], "calls": calls[i], "flops": flops[i]}
+        for i in range(n.value)
+    ]
