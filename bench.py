@@ -1,0 +1,234 @@
+"""Headline benchmark: PET energy + forces on synthetic 10 000-atom periodic boxes.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (PETBackend.preprocess -> calculate_features ->
+predict -> dE/dR, i.e. what the reference's ``mtt eval`` times at cli/eval.py:246-256)
+over one batch of ``--boxes`` random periodic boxes per GPU (cubic,
+rho = 0.05 / A^3, U[0,L)^3 positions, species uniform over {1,6,7,8}, default PET hypers,
+fp32). The neighbour list is built once, before the clock starts, exactly like the
+reference (CPU collate, outside its timed region); its GPU build time is reported
+separately. Boxes are sharded over ranks with no data-path collective (weak scaling).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+ATOMS_PER_BOX = 10000
+
+
+def synthetic_params(hypers):
+    """Weights of the reference state-dict schema from the documented per-key generator
+    (random init; there are no checkpoints offline) -- the same weights the golden vectors use."""
+    from metatrain_amd.synthetic import synthetic_params as gen
+
+    return gen(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
+
+
+def cpu_baseline(hypers, params, seconds_budget=25.0):
+    """The CPU oracle (a torch-CPU restatement of the reference path, kind="port") timed on
+    this host on a bounded sample: forward + dE/dR of ONE 1000-atom box (BASELINE config 2
+    shape), as many repeats as fit the budget."""
+    from oracle import nl as onl
+    from oracle import pet as opet
+
+    n = 1000
+    pos, z, cell = opet.random_box(n, seed=0)
+    i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, hypers["cutoff"])
+    args = (params, hypers, pos, cell[None], torch.tensor(i), torch.tensor(j), torch.tensor(s).long(), z,
+            torch.zeros(n, dtype=torch.long))
+    opet.energy_and_gradient(*args)  # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 1 or (time.perf_counter() - t0 < seconds_budget and reps < 20):
+        opet.energy_and_gradient(*args)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {
+        "value": n / dt,
+        "unit": "atom-steps/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{reps} x (forward + dE/dR) of one 1000-atom box (rho=0.05/A^3, 4.5 A cutoff, fp32, "
+                  f"default hypers), {dt:.3f} s each; NL excluded",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--boxes", type=int, default=2, help="10k-atom boxes per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="print a per-stage table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.pet import default_hypers
+    from metatrain_amd.synthetic import random_box
+
+    hypers = default_hypers()
+    params = synthetic_params(hypers)
+    model = rt.HipModel(hypers, [1, 6, 7, 8])
+    model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+
+    # ---- inputs resident in HBM before the clock starts ---------------------------------
+    boxes = args.boxes
+    pos_l, z_l, cell_l, pair_l, sys_l = [], [], [], [], []
+    nl_ms = 0.0
+    for b in range(boxes):
+        pos, z, cell = random_box(ATOMS_PER_BOX, seed=rank * boxes + b)
+        posd = pos.to(dev)
+        rt.neighbor_list(posd[:64].contiguous(), cell, [True] * 3, hypers["cutoff"])  # warm the kernels
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pairs, _ = rt.neighbor_list(posd, cell, [True] * 3, hypers["cutoff"])
+        torch.cuda.synchronize()
+        nl_ms += (time.perf_counter() - t0) * 1e3
+        off = b * ATOMS_PER_BOX
+        pairs = pairs.clone()
+        pairs[:, 0:2] += off
+        pos_l.append(posd); z_l.append(z.to(dev)); cell_l.append(cell.to(dev)); pair_l.append(pairs)
+        sys_l.append(torch.full((ATOMS_PER_BOX,), b, dtype=torch.int32, device=dev))
+    positions, species, cells = torch.cat(pos_l), torch.cat(z_l), torch.stack(cell_l)
+    pairs, sysidx = torch.cat(pair_l), torch.cat(sys_l)
+    centers, neighbors = pairs[:, 0].contiguous(), pairs[:, 1].contiguous()
+    shifts = pairs[:, 2:5].contiguous()
+    n_atoms = boxes * ATOMS_PER_BOX
+    ones = torch.ones(n_atoms, dtype=torch.float32, device=dev)
+
+    state = {}
+
+    def step():
+        graph = rt.HipGraph(model, positions, cells, centers, neighbors, shifts, species, sysidx)
+        fw = state.get("fw")
+        if fw is None or fw.graph.n_edges != graph.n_edges:
+            fw = rt.HipForward(model, graph)   # activation workspace: allocated once, reused
+            state["fw"] = fw
+        fw.graph = graph
+        atomic = fw.forward()
+        grad = fw.backward(ones)
+        return atomic, grad, graph
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # ---- find the dominant stage (untimed), then time K steps with HIP events on it only ----
+    rt.profile(True)
+    step()
+    torch.cuda.synchronize()
+    table = rt.profile_report()
+    rt.profile(False)
+    dominant = max(table, key=lambda r: r["total_ms"])["name"]
+    if args.profile_all and rank == 0:
+        for r in sorted(table, key=lambda r: -r["total_ms"]):
+            tf = r["flops"] / max(r["total_ms"], 1e-9) / 1e9
+            print(f"  {r['name']:16s} {r['total_ms']:8.3f} ms x{r['calls']:<3d} {tf:8.1f} TFLOP/s", file=sys.stderr)
+
+    rt.profile(True, stage=dominant)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        atomic, grad, graph = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dom = [r for r in rt.profile_report() if r["name"] == dominant][0]
+    rt.profile(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_atoms = n_atoms * world
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_atoms * args.steps / elapsed
+
+    if rank == 0:
+        e_total = float(atomic.double().sum())
+        assert torch.isfinite(grad).all()
+        avg_ms = dom["total_ms"] / dom["calls"]
+        flops_per_launch = dom["flops"] / dom["calls"]
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        out = {
+            "metric": "atom-steps/sec (energy+forces) PET 10k-atom box",
+            "value": value,
+            "unit": "atom-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic random periodic boxes (rho=0.05/A^3, 4 species), weights from a seeded generator",
+            "config": {
+                "workload": f"PET forward + dE/dR (preprocess+features+predict+backward), {boxes} x "
+                            f"{ATOMS_PER_BOX}-atom boxes per GPU per step, default PET hypers (2.9M params), "
+                            f"4.5 A cutoff, {graph.n_edges // boxes} edges/box",
+                "atoms_per_gpu_per_step": n_atoms,
+                "edges_per_gpu_per_step": int(graph.n_edges),
+                "parallelism": f"boxes sharded over {world} rank(s), no data-path collective",
+                "neighbor_list_gpu_ms_per_box": nl_ms / boxes,
+                "total_energy_rank0": e_total,
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": dominant,
+                "achieved": achieved,
+                "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                "avg_launch_ms": avg_ms,
+                "algorithmic_flops_per_launch": flops_per_launch,
+                "traffic": None,
+                "whole_step_algorithmic_tflops": None,
+            },
+        }
+        # whole-step view: SURVEY §8(d) algorithmic GEMM FLOPs, forward x2 for forces
+        e, n = graph.n_edges, n_atoms
+        rowptr = graph.csr()["rowptr"].double()
+        t2 = float((((rowptr[1:] - rowptr[:-1]) + 1) ** 2).sum())
+        fwd_flops = 2001152.0 * e + 4292864.0 * n + 2048.0 * t2
+        out["roofline"]["whole_step_algorithmic_tflops"] = 2 * fwd_flops / (ms_per_step * 1e-3) / 1e12
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(hypers, params)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -159,6 +159,8 @@ int pet_sum_over_atoms(const pet_graph_t* g, const float* d_atomic, float* d_out
 /* When enabled, every kernel launch of pet_forward/pet_backward is bracketed with HIP
  * events on the launch stream; pet_profile_report fills name/ms/calls arrays. */
 int pet_profile_enable(int on);
+/* Restrict the event bracketing to one stage name (e.g. "emlp_bwd"); NULL or "" = all. */
+int pet_profile_select(const char* stage);
 int pet_profile_reset(void);
 int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int64_t* calls,
                        double* flops, int* n_entries);

@@ -23,7 +23,7 @@ SYMBOLS = [
     "pet_graph_workspace_bytes", "pet_graph_build", "pet_graph_destroy", "pet_graph_num_edges",
     "pet_graph_max_neighbors", "pet_graph_export_batch", "pet_graph_csr",
     "pet_forward_workspace_bytes", "pet_forward", "pet_backward", "pet_sum_over_atoms",
-    "pet_profile_enable", "pet_profile_reset", "pet_profile_report",
+    "pet_profile_enable", "pet_profile_select", "pet_profile_reset", "pet_profile_report",
 ]
 
 
@@ -99,6 +99,7 @@ def load() -> ctypes.CDLL:
     lib.pet_backward.argtypes = [P, P, P, c_int64, P, P, P, P]
     lib.pet_sum_over_atoms.argtypes = [P, P, P, P]
     lib.pet_profile_enable.argtypes = [c_int]
+    lib.pet_profile_select.argtypes = [c_char_p]
     lib.pet_profile_report.argtypes = [c_int, P, POINTER(c_double), POINTER(c_int64), POINTER(c_double),
                                        POINTER(c_int)]
     _lib = lib

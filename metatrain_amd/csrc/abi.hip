@@ -21,11 +21,12 @@ struct ProfRec {
     double flops;
 };
 static bool g_prof_on = false;
+static std::string g_prof_filter;  // empty = every stage
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;
 
 ProfScope::ProfScope(const char* n, hipStream_t s, double f) : name(n), st(s), flops(f) {
-    if (!g_prof_on) return;
+    if (!g_prof_on || (!g_prof_filter.empty() && g_prof_filter != n)) return;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, st);
@@ -386,6 +387,12 @@ int pet_sum_over_atoms(const pet_graph_t* pg, const float* d_atomic, float* d_ou
 
 int pet_profile_enable(int on) {
     g_prof_on = on != 0;
+    return PET_OK;
+}
+
+int pet_profile_select(const char* stage) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_filter = stage ? stage : "";
     return PET_OK;
 }
 

@@ -1,0 +1,1 @@
+from .hypers import DEFAULT_MODEL_HYPERS, default_hypers  # noqa: F401

@@ -72,9 +72,12 @@ class HipModel:
 
     def __del__(self):
         h = getattr(self, "_handle", None)
-        if h is not None and h.value:
-            self.lib.pet_model_destroy(h)
-            self._handle = c_void_p()
+        try:
+            if h is not None and h.value:
+                self.lib.pet_model_destroy(h)
+                self._handle = c_void_p()
+        except Exception:  # interpreter shutdown: ctypes may already be torn down
+            pass
 
     @property
     def handle(self) -> c_void_p:
@@ -143,9 +146,12 @@ class HipGraph:
 
     def __del__(self):
         h = getattr(self, "_handle", None)
-        if h is not None and h.value:
-            self.lib.pet_graph_destroy(h)
-            self._handle = c_void_p()
+        try:
+            if h is not None and h.value:
+                self.lib.pet_graph_destroy(h)
+                self._handle = c_void_p()
+        except Exception:
+            pass
 
     @property
     def handle(self) -> c_void_p:
@@ -255,9 +261,11 @@ def neighbor_list(positions: torch.Tensor, cell: torch.Tensor, pbc, cutoff: floa
     return pairs, vectors
 
 
-def profile(enable: bool) -> None:
+def profile(enable: bool, stage: Optional[str] = None) -> None:
+    """Bracket every stage (or only ``stage``) of forward/backward with HIP events."""
     lib = _lib.load()
     check(lib.pet_profile_reset())
+    check(lib.pet_profile_select((stage or "").encode()))
     check(lib.pet_profile_enable(1 if enable else 0))
 
 

@@ -1,0 +1,77 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/pet_hip.h declares, and its host-side argument checking behaves (no GPU calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from metatrain_amd import _lib
+from metatrain_amd import runtime as rt
+from oracle import pet as opet
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        from metatrain_amd import build
+
+        build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    header = open(os.path.join(ROOT, "include", "pet_hip.h")).read()
+    declared = set(re.findall(r"\b(pet_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in pet_hip.h but not exported"
+    assert b"gfx950" in lib.pet_version()
+
+
+def test_hypers_struct_and_supported(lib):
+    h = rt.hypers_struct(dict(opet.DEFAULT_HYPERS), [1, 6, 7, 8])
+    assert lib.pet_hypers_supported(ctypes.byref(h)) == 1
+    tiny = dict(opet.DEFAULT_HYPERS, d_pet=16, d_node=32, d_head=16, d_feedforward=32, num_heads=2)
+    assert lib.pet_hypers_supported(ctypes.byref(rt.hypers_struct(tiny, [1, 6]))) == 0
+    # unsupported instantiation fails loudly with a message, not silently
+    with pytest.raises(_lib.PetHipError, match="compiled instantiation"):
+        rt.HipModel(tiny, [1, 6])
+
+
+def test_model_create_destroy_without_gpu(lib):
+    m = rt.HipModel(dict(opet.DEFAULT_HYPERS), [1, 6, 7, 8])
+    assert m.num_params == 0
+    del m
+
+
+def test_variants_outside_the_build_fail_loudly():
+    for key, val in (("normalization", "LayerNorm"), ("activation", "SiLU"),
+                     ("transformer_type", "PostLN"), ("featurizer_type", "residual")):
+        with pytest.raises(_lib.PetHipError):
+            rt.hypers_struct(dict(opet.DEFAULT_HYPERS, **{key: val}), [1, 6])
+    with pytest.raises(ValueError, match="Unknown cutoff function type"):
+        rt.hypers_struct(dict(opet.DEFAULT_HYPERS, cutoff_function="Step"), [1, 6])
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    """The product has no CPU path: CPU tensors raise instead of falling back."""
+    m = rt.HipModel(dict(opet.DEFAULT_HYPERS), [1, 6, 7, 8])
+    params = opet.synthetic_params(dict(opet.DEFAULT_HYPERS), [1, 6, 7, 8], {"energy": 1})
+    with pytest.raises(_lib.PetHipError, match="no CPU path"):
+        m.load(params, "energy")
+    with pytest.raises(_lib.PetHipError, match="no CPU path"):
+        rt.neighbor_list(torch.zeros(4, 3), torch.eye(3), [True] * 3, 4.5)
+
+
+def test_product_does_not_import_the_oracle():
+    """oracle/ is test infrastructure; nothing under metatrain_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "metatrain_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f

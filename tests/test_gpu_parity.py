@@ -1,0 +1,232 @@
+"""GPU parity tests (``-m gpu``): the HIP path, called through the C ABI, against
+(1) golden vectors generated from the reference and (2) the CPU oracle on seeded inputs.
+
+Bars (BASELINE.json north_star): neighbour / NEF indices bit-exact; energies and forces
+within 1e-5 relative in fp32. "Relative" for forces is max|dF| / max|F| against the fp64
+reference (the reference's own fp32 path sits at 2.8e-6 .. 4.2e-6).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nl as onl
+from oracle import pet as opet
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+INT_KEYS = ["element_indices_nodes", "element_indices_neighbors", "padding_mask", "reverse_neighbor_index",
+            "centers", "neighbors", "nef_to_edges_neighbor", "cell_shifts"]
+FLOAT_KEYS = ["edge_vectors", "edge_distances", "cutoff_factors", "atomic_cutoffs_stats"]
+
+
+@pytest.fixture(scope="module")
+def rt():
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    from metatrain_amd import runtime
+
+    return runtime
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(rt, dev):
+    hypers = dict(opet.DEFAULT_HYPERS)
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
+    m = rt.HipModel(hypers, [1, 6, 7, 8])
+    m.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    assert m.num_params == sum(v.numel() for k, v in params.items() if k != "species_to_species_index")
+    return m
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def _graph_from_golden(rt, model, g, dev):
+    t = lambda k: torch.tensor(g[k]).to(dev)  # noqa: E731
+    return rt.HipGraph(model, t("in_positions").float(), t("in_cells").float(), t("in_centers"),
+                       t("in_neighbors"), t("in_cell_shifts"), t("in_species"), t("in_system_indices").int())
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+@pytest.mark.parametrize("case", ["co2cell", "box64", "two_systems"])
+def test_preprocess_matches_reference_batch_data(rt, model, dev, golden_dir, case):
+    """PETBackend.preprocess: all 12 batch_data tensors; integers bit-exact."""
+    g = _load(golden_dir, f"batch_{case}.npz")
+    out = _graph_from_golden(rt, model, g, dev).export_batch()
+    assert set(out) == set(INT_KEYS + FLOAT_KEYS)
+    for k in INT_KEYS:
+        got = out[k].cpu().numpy()
+        assert got.dtype == g[k].dtype and got.shape == g[k].shape, k
+        assert np.array_equal(got, g[k]), f"{k} is not bit-exact"
+    for k in FLOAT_KEYS:
+        np.testing.assert_allclose(out[k].cpu().numpy(), g[k], rtol=2e-6, atol=2e-6, err_msg=k)
+
+
+def test_energy_features_and_gradient_box64(rt, model, dev, golden_dir):
+    g = _load(golden_dir, "pet_default_box64.npz")
+    graph = _graph_from_golden(rt, model, g, dev)
+    fw = rt.HipForward(model, graph)
+    atomic, nf, ef = fw.forward(want_features=True)
+    grad = fw.backward(torch.ones_like(atomic))
+    e = fw.sum_over_atoms(atomic)
+    assert abs(float(e[0]) - g["energies_f64"][0, 0]) / abs(g["energies_f64"][0, 0]) < TOL
+    assert relmax(atomic.cpu().numpy(), g["atomic_f64"].ravel()) < TOL
+    assert relmax(nf.cpu().numpy(), g["node_features_f64"]) < TOL
+    rowptr = graph.csr()["rowptr"].cpu().numpy()
+    efn, ref = ef.cpu().numpy(), g["edge_features_f64"]
+    scale = np.abs(ref).max()
+    for i in range(graph.n_nodes):  # CSR rows vs the real slots of the reference's padded grid
+        n = rowptr[i + 1] - rowptr[i]
+        assert np.abs(efn[rowptr[i]:rowptr[i + 1]] - ref[i, :n]).max() / scale < TOL
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
+    # and against the reference's own fp32 numbers (same tolerance the reference uses for itself)
+    np.testing.assert_allclose(atomic.cpu().numpy(), g["atomic_f32"].ravel(), rtol=1e-4, atol=1e-5)
+
+
+def test_energy_and_forces_box1000(rt, model, dev, golden_dir):
+    """BASELINE config 2: 1000-atom periodic box, fp32, energy + forces vs the reference."""
+    g = _load(golden_dir, "pet_default_box1000.npz")
+    graph = _graph_from_golden(rt, model, g, dev)
+    fw = rt.HipForward(model, graph)
+    atomic = fw.forward()
+    grad = fw.backward(torch.ones_like(atomic))
+    e = float(atomic.double().sum())
+    assert abs(e - g["energies_f64"][0, 0]) / abs(g["energies_f64"][0, 0]) < TOL
+    assert relmax(atomic.cpu().numpy(), g["atomic_f64"].ravel()) < TOL
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
+    rms = np.sqrt(((grad.cpu().numpy() - g["grad_f64"]) ** 2).mean() / (g["grad_f64"] ** 2).mean())
+    assert rms < TOL
+
+
+@pytest.mark.parametrize("n_atoms,seed,pbc", [(1000, 5, (True, True, True)), (300, 6, (True, True, False)),
+                                               (40, 7, (False, False, False)), (17, 8, (True, True, True))])
+def test_neighbor_list_set_equals_oracle(rt, dev, n_atoms, seed, pbc):
+    pos, z, cell = opet.random_box(n_atoms, seed)
+    if n_atoms == 17:  # cell thinner than the cutoff along one axis: periodic self-images
+        cell = cell.clone()
+        cell[2, 2] = 3.1
+        cell[1, 0] = 1.3
+        pos = pos - 4.0  # unwrapped inputs
+    pairs, vec = rt.neighbor_list(pos.to(dev), cell, pbc, 4.5)
+    i, j, s, d = onl.neighbor_list(pos.numpy(), cell.numpy(), pbc, 4.5)
+    got = pairs.cpu().numpy()
+    assert np.all(np.diff(got[:, 0]) >= 0), "pairs must be grouped by centre"
+    order = np.lexsort((got[:, 4], got[:, 3], got[:, 2], got[:, 1], got[:, 0]))
+    assert np.array_equal(got[order], np.column_stack([i, j, s])), "neighbour set differs"
+    np.testing.assert_allclose(vec.cpu().numpy()[order], d, atol=2e-5)
+
+
+def test_empty_and_isolated_systems(rt, model, dev):
+    """Reference edge cases: isolated atoms (no edges) and a dissociated pair
+    (pet/tests/test_functionality.py:79-159)."""
+    pos = torch.tensor([[0.0, 0, 0], [30.0, 0, 0], [0, 30.0, 0]], device=dev)
+    z = torch.tensor([1, 6, 8], dtype=torch.int32, device=dev)
+    e0 = torch.zeros(0, dtype=torch.int32, device=dev)
+    graph = rt.HipGraph(model, pos, torch.zeros(1, 3, 3, device=dev), e0, e0,
+                        torch.zeros((0, 3), dtype=torch.int32, device=dev), z,
+                        torch.zeros(3, dtype=torch.int32, device=dev))
+    assert graph.n_edges == 0 and graph.max_neighbors == 0
+    fw = rt.HipForward(model, graph)
+    atomic = fw.forward()
+    grad = fw.backward(torch.ones_like(atomic))
+    assert torch.isfinite(atomic).all() and float(grad.abs().max()) == 0.0
+    hypers = model.hypers
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    ref = opet.pet_atomic_energies(params, hypers, pos.cpu().double(), torch.zeros(1, 3, 3, dtype=torch.float64),
+                                   torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long),
+                                   torch.zeros((0, 3), dtype=torch.long), z.cpu(), torch.zeros(3, dtype=torch.long))
+    assert relmax(atomic.cpu().numpy(), ref.numpy().ravel()) < TOL
+
+
+def test_batch_of_systems_vs_oracle_and_per_system_sum(rt, model, dev):
+    """Several systems in one call (concatenate_structures layout), triclinic + cubic cells,
+    a non-strict list (built with cutoff + 0.7) in shuffled edge order; checks energies per
+    system, dE/dR and dE/dcell against the fp64 oracle."""
+    hypers = model.hypers
+    systems = []
+    for k, (n, seed) in enumerate([(150, 21), (60, 22), (9, 23)]):
+        pos, z, cell = opet.random_box(n, seed)
+        if k == 1:
+            cell = cell.clone(); cell[1, 0] = 1.7; cell[2, 1] = -0.9
+        systems.append((pos, z, cell))
+    pos_l, z_l, cell_l, i_l, j_l, s_l, sys_l, off = [], [], [], [], [], [], [], 0
+    for k, (pos, z, cell) in enumerate(systems):
+        i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, hypers["cutoff"] + 0.7)
+        pos_l.append(pos); z_l.append(z); cell_l.append(cell)
+        i_l.append(torch.tensor(i) + off); j_l.append(torch.tensor(j) + off); s_l.append(torch.tensor(s))
+        sys_l.append(torch.full((len(z),), k, dtype=torch.int32)); off += len(z)
+    pos, z, cells = torch.cat(pos_l), torch.cat(z_l), torch.stack(cell_l)
+    i, j, s, sysidx = torch.cat(i_l), torch.cat(j_l), torch.cat(s_l), torch.cat(sys_l)
+    perm = torch.randperm(len(i), generator=torch.Generator().manual_seed(1))
+    i, j, s = i[perm], j[perm], s[perm]
+    graph = rt.HipGraph(model, pos.to(dev), cells.to(dev), i.to(dev), j.to(dev), s.to(dev), z.to(dev), sysidx.to(dev))
+    assert graph.n_edges < len(i)  # the d <= cutoff filter dropped the extra pairs
+    fw = rt.HipForward(model, graph)
+    atomic = fw.forward()
+    grad, gcell = fw.backward(torch.ones_like(atomic), want_cell_grad=True)
+    e = fw.sum_over_atoms(atomic).cpu().numpy()
+
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    p64 = pos.double().requires_grad_(True)
+    c64 = cells.double().requires_grad_(True)
+    ref_atomic = opet.pet_atomic_energies(params, hypers, p64, c64, i, j, s.long(), z, sysidx.long())
+    ref_e = torch.zeros(3, dtype=torch.float64).index_add(0, sysidx.long(), ref_atomic[:, 0])
+    gp, gc = torch.autograd.grad(ref_e.sum(), [p64, c64])
+    assert relmax(e, ref_e.detach().numpy()) < TOL
+    assert relmax(grad.cpu().numpy(), gp.numpy()) < TOL
+    assert relmax(gcell.cpu().numpy(), gc.numpy()) < 2 * TOL
+
+
+def test_weighted_seed_vector_backward(rt, model, dev):
+    """pet_backward with a non-trivial dL/d(atomic) seed (what autograd hands over when the
+    loss is not the plain energy sum): linearity check against two unit-seed calls."""
+    pos, z, cell = opet.random_box(120, 31)
+    pairs, _ = rt.neighbor_list(pos.to(dev), cell, [True] * 3, 4.5)
+    graph = rt.HipGraph(model, pos.to(dev), cell[None].to(dev), pairs[:, 0], pairs[:, 1], pairs[:, 2:5],
+                        z.to(dev), torch.zeros(120, dtype=torch.int32, device=dev))
+    fw = rt.HipForward(model, graph)
+    atomic = fw.forward()
+    w1 = torch.rand(120, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    w2 = torch.ones(120, device=dev) - w1
+    g1, g2 = fw.backward(w1), fw.backward(w2)
+    g = fw.backward(torch.ones(120, device=dev))
+    assert relmax((g1 + g2).cpu().numpy(), g.cpu().numpy()) < 5e-6
+    # determinism: identical bits run to run (no float atomics anywhere)
+    assert torch.equal(fw.backward(w1), g1)
+
+
+def test_rotation_and_permutation_consistency(rt, model, dev):
+    """Size-independent properties at a larger size (2000 atoms): permuting the atoms permutes
+    per-atom energies and gradients; translating by a lattice vector changes nothing."""
+    n = 2000
+    pos, z, cell = opet.random_box(n, 41)
+    sysidx = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def run(p, zz):
+        pairs, _ = rt.neighbor_list(p.to(dev), cell, [True] * 3, 4.5)
+        graph = rt.HipGraph(model, p.to(dev), cell[None].to(dev), pairs[:, 0], pairs[:, 1], pairs[:, 2:5],
+                            zz.to(dev), sysidx)
+        fw = rt.HipForward(model, graph)
+        a = fw.forward()
+        return a.cpu().numpy(), fw.backward(torch.ones_like(a)).cpu().numpy()
+
+    a0, g0 = run(pos, z)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(2))
+    a1, g1 = run(pos[perm], z[perm])
+    assert relmax(a1, a0[perm.numpy()]) < 5e-6 and relmax(g1, g0[perm.numpy()]) < 5e-6
+    a2, g2 = run(pos + cell[0] * 2 - cell[2], z)
+    assert relmax(a2, a0) < 2e-5 and relmax(g2, g0) < 2e-5
+    # Newton's third law: the net force on a periodic box vanishes
+    assert np.abs(g0.sum(0)).max() < 1e-3 * np.abs(g0).max()

@@ -119,3 +119,17 @@ def test_nl_oracle_tree_vs_bruteforce():
         # full list: every (i,j,S) has its (j,i,-S)
         fwd = set(map(tuple, np.column_stack([a[0], a[1], a[2]]).tolist()))
         assert all((j, i, -x, -y, -z) in fwd for (i, j, x, y, z) in fwd)
+
+
+def test_product_generators_equal_oracle_generators():
+    """metatrain_amd.synthetic / metatrain_amd.pet.hypers carry their own copies of the synthetic
+    input + weight generators (the product may not import the oracle): keep them identical."""
+    from metatrain_amd import synthetic
+    from metatrain_amd.pet import default_hypers
+
+    assert default_hypers() == opet.DEFAULT_HYPERS
+    a = synthetic.synthetic_params(opet.DEFAULT_HYPERS, [1, 6, 7, 8], {"energy": 1}, 3)
+    b = opet.synthetic_params(opet.DEFAULT_HYPERS, [1, 6, 7, 8], {"energy": 1}, 3)
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    for x, y in zip(synthetic.random_box(50, 9), opet.random_box(50, 9)):
+        assert torch.equal(x, y)
