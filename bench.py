@@ -49,17 +49,27 @@ def cpu_baseline(hypers, params, seconds_budget=25.0):
     i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, hypers["cutoff"])
     args = (params, hypers, pos, cell[None], torch.tensor(i), torch.tensor(j), torch.tensor(s).long(), z,
             torch.zeros(n, dtype=torch.long))
-    opet.energy_and_gradient(*args)  # warm-up
-    t0 = time.perf_counter()
-    reps = 0
-    while reps < 1 or (time.perf_counter() - t0 < seconds_budget and reps < 20):
-        opet.energy_and_gradient(*args)
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
+    # pick the thread count that serves this host best (many-core hosts oversubscribe on the
+    # small per-bucket ops); report the count actually used for the quoted number
+    ncpu = os.cpu_count() or 1
+    best = None
+    for nt in sorted({min(ncpu, t) for t in (8, 16, 32)}):
+        torch.set_num_threads(nt)
+        opet.energy_and_gradient(*args)  # warm-up
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 2 or (time.perf_counter() - t0 < seconds_budget / 3 and reps < 8):
+            opet.energy_and_gradient(*args)
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        if best is None or dt < best[0]:
+            best = (dt, nt, reps)
+    dt, nt, reps = best
+    torch.set_num_threads(nt)
     return {
         "value": n / dt,
         "unit": "atom-steps/s",
-        "cores": torch.get_num_threads(),
+        "cores": nt,
         "kind": "port",
         "sample": f"{reps} x (forward + dE/dR) of one 1000-atom box (rho=0.05/A^3, 4.5 A cutoff, fp32, "
                   f"default hypers), {dt:.3f} s each; NL excluded",

@@ -5,6 +5,12 @@ or fails to load, importing/using the HIP path raises.
 """
 import ctypes
 import os
+
+# torch MUST be imported before libpet_hip.so is loaded: device pointers and streams are
+# exchanged with torch, so both have to run on the ONE HIP runtime torch ships
+# (torch/lib/libamdhip64.so). Loading our library first would pull in /opt/rocm's copy and the
+# process would end up with two runtimes ("no ROCm-capable device is detected").
+import torch  # noqa: F401
 from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -125,6 +125,8 @@ class HipGraph:
         self.n_systems = int(cells.shape[0])
         self.n_edges_in = int(centers.shape[0])
         # keep the converted inputs alive: the graph build reads them asynchronously
+        self._index_dtype = centers.dtype      # batch_data keeps the caller's index dtypes
+        self._shift_dtype = cell_shifts.dtype  # (index_select of the inputs, structures.py:268-271)
         self._pos = positions.detach().to(torch.float32).contiguous()
         self._cells = cells.detach().to(torch.float32).contiguous()
         self._ctr = centers.to(torch.int32).contiguous()
@@ -181,6 +183,9 @@ class HipGraph:
                  "centers", "neighbors", "nef_to_edges_neighbor", "cell_shifts"]
         check(self.lib.pet_graph_export_batch(self._handle, *[_ptr(out[k]) for k in order], _stream()))
         out["padding_mask"] = out["padding_mask"].to(torch.bool)
+        out["centers"] = out["centers"].to(self._index_dtype)
+        out["neighbors"] = out["neighbors"].to(self._index_dtype)
+        out["cell_shifts"] = out["cell_shifts"].to(self._shift_dtype)
         return out
 
     def csr(self) -> Dict[str, torch.Tensor]:
