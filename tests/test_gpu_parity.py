@@ -227,6 +227,7 @@ def test_rotation_and_permutation_consistency(rt, model, dev):
     a1, g1 = run(pos[perm], z[perm])
     assert relmax(a1, a0[perm.numpy()]) < 5e-6 and relmax(g1, g0[perm.numpy()]) < 5e-6
     a2, g2 = run(pos + cell[0] * 2 - cell[2], z)
-    assert relmax(a2, a0) < 2e-5 and relmax(g2, g0) < 2e-5
+    # the shifted fp32 positions themselves differ by ~1 ulp(100 A) = 8e-6 A: an input perturbation, not a kernel error
+    assert relmax(a2, a0) < 1e-4 and relmax(g2, g0) < 1e-4
     # Newton's third law: the net force on a periodic box vanishes
     assert np.abs(g0.sum(0)).max() < 1e-3 * np.abs(g0).max()
