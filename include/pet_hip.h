@@ -152,6 +152,27 @@ int pet_forward(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
 int pet_backward(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
                  int64_t workspace_bytes, const float* d_grad_atomic,
                  float* d_grad_positions, float* d_grad_cells, void* stream);
+/* The same reverse pass split at the three PETBackend calls, so that torch autograd can chain
+ * preprocess -> calculate_features -> predict as three nodes (pet/tests/test_backend.py takes
+ * autograd.grad of the summed prediction w.r.t. positions and a strain tensor). Edge-shaped
+ * gradients are CSR rows (row p = slot p - rowptr[ctr[p]] of atom ctr[p]).
+ *   predict^T   : d_grad_atomic [N] -> d_grad_node_features [N,d_node], d_grad_edge_features
+ *                 [E,d_pet], d_grad_cutoff [E] (through the cutoff weight of backend.py:768-772)
+ *   features^T  : (d_grad_node_features, d_grad_edge_features) -> d_grad_geometry [E,4] =
+ *                 d/d(vx,vy,vz,dist) and d_grad_cutoff [E] (through the attention key bias)
+ *   preprocess^T: (d_grad_geometry, d_grad_cutoff) -> d_grad_positions [N,3], d_grad_cells */
+int pet_backward_predict(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
+                         int64_t workspace_bytes, const float* d_grad_atomic,
+                         float* d_grad_node_features, float* d_grad_edge_features,
+                         float* d_grad_cutoff, void* stream);
+int pet_backward_features(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
+                          int64_t workspace_bytes, const float* d_grad_node_features,
+                          const float* d_grad_edge_features, float* d_grad_geometry,
+                          float* d_grad_cutoff, void* stream);
+int pet_backward_geometry(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
+                          int64_t workspace_bytes, const float* d_grad_geometry,
+                          const float* d_grad_cutoff, float* d_grad_positions, float* d_grad_cells,
+                          void* stream);
 /* Per-system sum (utils/sum_over_atoms.py:10-48): d_out[S] = sum_{atoms of s} d_atomic. */
 int pet_sum_over_atoms(const pet_graph_t* g, const float* d_atomic, float* d_out, void* stream);
 

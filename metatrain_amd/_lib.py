@@ -28,7 +28,8 @@ SYMBOLS = [
     "pet_nl_workspace_bytes", "pet_nl_build",
     "pet_graph_workspace_bytes", "pet_graph_build", "pet_graph_destroy", "pet_graph_num_edges",
     "pet_graph_max_neighbors", "pet_graph_export_batch", "pet_graph_csr",
-    "pet_forward_workspace_bytes", "pet_forward", "pet_backward", "pet_sum_over_atoms",
+    "pet_forward_workspace_bytes", "pet_forward", "pet_backward", "pet_backward_predict",
+    "pet_backward_features", "pet_backward_geometry", "pet_sum_over_atoms",
     "pet_profile_enable", "pet_profile_select", "pet_profile_reset", "pet_profile_report",
 ]
 
@@ -103,6 +104,9 @@ def load() -> ctypes.CDLL:
     lib.pet_forward_workspace_bytes.restype = c_int64
     lib.pet_forward.argtypes = [P, P, P, c_int64, c_int, P, P, P, P]
     lib.pet_backward.argtypes = [P, P, P, c_int64, P, P, P, P]
+    lib.pet_backward_predict.argtypes = [P, P, P, c_int64, P, P, P, P, P]
+    lib.pet_backward_features.argtypes = [P, P, P, c_int64, P, P, P, P, P]
+    lib.pet_backward_geometry.argtypes = [P, P, P, c_int64, P, P, P, P, P]
     lib.pet_sum_over_atoms.argtypes = [P, P, P, P]
     lib.pet_profile_enable.argtypes = [c_int]
     lib.pet_profile_select.argtypes = [c_char_p]

@@ -380,6 +380,33 @@ int pet_backward(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace
                     (hipStream_t)stream);
 }
 
+int pet_backward_predict(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
+                         const float* d_grad_atomic, float* d_grad_node_features, float* d_grad_edge_features,
+                         float* d_grad_cutoff, void* stream) {
+    PET_REQUIRE(pm && pg && d_workspace && d_grad_atomic, PET_ERR_ARGUMENT, "null argument");
+    return backward_predict_abi(pm->m, pg->g, d_workspace, workspace_bytes, d_grad_atomic, d_grad_node_features,
+                                d_grad_edge_features, d_grad_cutoff, (hipStream_t)stream);
+}
+
+int pet_backward_features(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
+                          const float* d_grad_node_features, const float* d_grad_edge_features,
+                          float* d_grad_geometry, float* d_grad_cutoff, void* stream) {
+    PET_REQUIRE(pm && pg && d_workspace && d_grad_node_features && d_grad_geometry && d_grad_cutoff,
+                PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(d_grad_edge_features || pg->g.n_edges == 0, PET_ERR_ARGUMENT, "null argument");
+    return backward_features_abi(pm->m, pg->g, d_workspace, workspace_bytes, d_grad_node_features,
+                                 d_grad_edge_features, d_grad_geometry, d_grad_cutoff, (hipStream_t)stream);
+}
+
+int pet_backward_geometry(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
+                          const float* d_grad_geometry, const float* d_grad_cutoff, float* d_grad_positions,
+                          float* d_grad_cells, void* stream) {
+    PET_REQUIRE(pm && pg && d_workspace && d_grad_positions, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE((d_grad_geometry && d_grad_cutoff) || pg->g.n_edges == 0, PET_ERR_ARGUMENT, "null argument");
+    return backward_geometry_abi(pm->m, pg->g, d_workspace, workspace_bytes, d_grad_geometry, d_grad_cutoff,
+                                 d_grad_positions, d_grad_cells, (hipStream_t)stream);
+}
+
 int pet_sum_over_atoms(const pet_graph_t* pg, const float* d_atomic, float* d_out, void* stream) {
     PET_REQUIRE(pg && d_atomic && d_out, PET_ERR_ARGUMENT, "null argument");
     return sum_over_atoms(pg->g, d_atomic, d_out, (hipStream_t)stream);

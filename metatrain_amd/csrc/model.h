@@ -85,6 +85,12 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
             float* node_feat, float* edge_feat, hipStream_t st);
 int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* grad_atomic,
              float* grad_pos, float* grad_cells, hipStream_t st);
+int backward_predict_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* grad_atomic,
+                         float* g_node, float* g_edge, float* g_fc, hipStream_t st);
+int backward_features_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_node,
+                          const float* g_edge, float* g_geo, float* g_fc, hipStream_t st);
+int backward_geometry_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_geo,
+                          const float* g_fc, float* grad_pos, float* grad_cells, hipStream_t st);
 
 // profiling (abi.hip)
 struct ProfScope {

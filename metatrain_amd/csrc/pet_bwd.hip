@@ -605,20 +605,29 @@ __global__ __launch_bounds__(NTHREADS) void k_compress_bwd(const float* __restri
 // ---------------------------------------------------------------------------------
 // geometry adjoint
 // ---------------------------------------------------------------------------------
-__global__ void k_geom_bwd(const float4* __restrict__ geo, const float* __restrict__ d0, const float* __restrict__ fc,
-                           const float* __restrict__ dgeo, const float* __restrict__ dfc,
-                           const float* __restrict__ dbias_h, float4* __restrict__ dv, int64_t E, float cutoff,
+// key-bias adjoint -> cutoff-factor gradient: bias = log(clamp(fc, 1e-15)), so the gradient
+// passes only where fc >= 1e-15 (transformer.py:109-110); heads and layers are summed here.
+__global__ void k_dfc_attn(const float* __restrict__ fc, const float* __restrict__ dbias_h,
+                           float* __restrict__ dfc_attn, int64_t E) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= E) return;
+    float dbias = 0.f;
+#pragma unroll
+    for (int h = 0; h < NHEAD; h++) dbias += dbias_h[p * NHEAD + h];
+    const float f = fc[p];
+    dfc_attn[p] = f >= 1e-15f ? dbias / f : 0.f;
+}
+
+// dgeo = d/d(vx,vy,vz,dist), dfc_a + dfc_b = d/d(cutoff factor)  ->  d/d(edge vector)
+__global__ void k_geom_bwd(const float4* __restrict__ geo, const float* __restrict__ d0,
+                           const float* __restrict__ dgeo, const float* __restrict__ dfc_a,
+                           const float* __restrict__ dfc_b, float4* __restrict__ dv, int64_t E, float cutoff,
                            float width, int fn) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= E) return;
     const float4 g = geo[p];
     const float4 dg = reinterpret_cast<const float4*>(dgeo)[p];
-    float dbias = 0.f;
-#pragma unroll
-    for (int h = 0; h < NHEAD; h++) dbias += dbias_h[p * NHEAD + h];
-    const float f = fc[p];
-    // bias = log(clamp(fc, 1e-15)): gradient passes only where fc >= 1e-15 (transformer.py:109-110)
-    float dfc_t = dfc[p] + (f >= 1e-15f ? dbias / f : 0.f);
+    const float dfc_t = (dfc_a ? dfc_a[p] : 0.f) + (dfc_b ? dfc_b[p] : 0.f);
     const float dd0 = dfc_t * cutoff_deriv_dev(d0[p], cutoff, width, fn);
     const float nrm = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
     const float c_dist = dg.w / g.w;                    // d sqrt(v.v + 1e-15) / dv = v / dist
@@ -700,39 +709,23 @@ static void launch_attn_bwd(const float* QKV, const float* dAO, const Graph& g, 
                                                    (int)g.n_nodes, scale);
 }
 
-int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA, float* gpos,
-             float* gcell, hipStream_t st) {
-    Workspace w;
-    carve_workspace(m, g.n_nodes, g.n_edges, ws, w);
-    PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "workspace too small");
-    const int64_t N = g.n_nodes, E = g.n_edges, R = E + N;
-    if (N == 0) return PET_OK;
-    if (E == 0) {  // isolated atoms: no position dependence at all
-        PET_HIP_CHECK(hipMemsetAsync(gpos, 0, N * 3 * sizeof(float), st));
-        if (gcell) PET_HIP_CHECK(hipMemsetAsync(gcell, 0, g.n_systems * 9 * sizeof(float), st));
-        return PET_OK;
-    }
-    {
-        int bad = 0;
-        PET_HIP_CHECK(hipMemcpyAsync(&bad, g.scalars + 2, sizeof(int), hipMemcpyDeviceToHost, st));
-        PET_HIP_CHECK(hipStreamSynchronize(st));
-        PET_REQUIRE(bad == 0, PET_ERR_GRAPH, "neighbour list is not a full list: edges without a reverse edge");
-    }
-    const int nt = attn_tiles(g);
-    PET_REQUIRE(nt <= 8, PET_ERR_UNSUPPORTED, "more than 127 neighbours per atom is not supported yet");
-    const float scale = 1.0f / (sqrtf((float)HD) * m.h.attention_temperature);
-    const int gE = cdiv(E, BM), gN = cdiv(N, BM), gR = cdiv(R, BM);
-    const size_t lds1 = BM * LD128 * 4, lds2 = 2 * BM * LD128 * 4;
-    const double fE = (double)E, fN = (double)N, fR = (double)R;
-    float* dbias_h = w.delta;  // [E, NHEAD] (reuses the delta carve)
-    PET_HIP_CHECK(hipMemsetAsync(w.dgeo, 0, E * 4 * sizeof(float), st));
-    PET_HIP_CHECK(hipMemsetAsync(dbias_h, 0, E * NHEAD * sizeof(float), st));
+static int check_full_list(const Graph& g, hipStream_t st) {
+    int bad = 0;
+    PET_HIP_CHECK(hipMemcpyAsync(&bad, g.scalars + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+    PET_HIP_CHECK(hipStreamSynchronize(st));
+    PET_REQUIRE(bad == 0, PET_ERR_GRAPH, "neighbour list is not a full list: edges without a reverse edge");
+    return PET_OK;
+}
 
+// Stage P: adjoint of PETBackend.predict. seeds gA [N] -> w.dH [N,DN], w.dM [E,D], w.dfc [E]
+int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* gA, hipStream_t st) {
+    const int64_t N = g.n_nodes, E = g.n_edges;
+    const int gE = cdiv(E, BM), gN = cdiv(N, BM);
+    const size_t lds2 = 2 * BM * LD128 * 4;
+    const double fE = (double)E, fN = (double)N;
     allow_big_lds(k_head_bwd<256, false>, (BM * LD256 + BM * LD128) * 4 + 256);
-    allow_big_lds(k_swiglu_bwd<256, DNF>, (BM * LD256 + BM * LD128) * 4);
-    allow_big_lds(k_expand_bwd, BM * LD256 * 4);
     const GnnBufs& last = w.gnn.back();
-    {
+    if (E > 0) {
         ProfScope ps("head_edge_bwd", st, fE * 2.0 * (D * DH + DH * DH + DH));
         k_head_bwd<128, true><<<gE, NTHREADS, lds2 + 256, st>>>(last.Mout, m.eh0.fwd, m.eh0.b, m.eh2.fwd, m.eh2.b,
                                                                m.eh0.bwd, m.eh2.bwd, m.ell_w, gA, g.ctr, g.fc,
@@ -744,6 +737,27 @@ int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const f
             last.Hout, m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nh0.bwd, m.nh2.bwd, m.nll_w, gA, nullptr, nullptr,
             nullptr, nullptr, w.dH, N);
     }
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
+// Stage F: adjoint of PETBackend.calculate_features. (w.dH, w.dM) -> w.dgeo [E,4], w.dbias [E]
+int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t st) {
+    const int64_t N = g.n_nodes, E = g.n_edges, R = E + N;
+    if (E == 0) return PET_OK;
+    int rc = check_full_list(g, st);
+    if (rc) return rc;
+    const int nt = attn_tiles(g);
+    PET_REQUIRE(nt <= 8, PET_ERR_UNSUPPORTED, "more than 127 neighbours per atom is not supported yet");
+    const float scale = 1.0f / (sqrtf((float)HD) * m.h.attention_temperature);
+    const int gE = cdiv(E, BM), gN = cdiv(N, BM), gR = cdiv(R, BM);
+    const size_t lds1 = BM * LD128 * 4, lds2 = 2 * BM * LD128 * 4;
+    const double fE = (double)E, fN = (double)N, fR = (double)R;
+    float* dbias_h = w.delta;  // [E, NHEAD] (reuses the delta carve)
+    PET_HIP_CHECK(hipMemsetAsync(w.dgeo, 0, E * 4 * sizeof(float), st));
+    PET_HIP_CHECK(hipMemsetAsync(dbias_h, 0, E * NHEAD * sizeof(float), st));
+    allow_big_lds(k_swiglu_bwd<256, DNF>, (BM * LD256 + BM * LD128) * 4);
+    allow_big_lds(k_expand_bwd, BM * LD256 * 4);
     float* dH = w.dH;
     float* dH_alt = w.dH2;
     float* dX = w.dX;
@@ -812,15 +826,86 @@ int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const f
         }
         // w.dM now holds d/dMout of layer gi-1 (pass-through + compress adjoint)
     }
-    k_geom_bwd<<<cdiv(E, 256), 256, 0, st>>>(g.geo, g.d0, g.fc, w.dgeo, w.dfc, dbias_h,
-                                             reinterpret_cast<float4*>(w.dv), E, m.h.cutoff, m.h.cutoff_width,
-                                             m.h.cutoff_function);
+    k_dfc_attn<<<cdiv(E, 256), 256, 0, st>>>(g.fc, dbias_h, w.dbias, E);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
+// Stage G: adjoint of PETBackend.preprocess. (dgeo [E,4], dfc_a + dfc_b [E]) -> dL/dR, dL/dcell
+int backward_geometry(const Model& m, const Graph& g, Workspace& w, const float* dgeo, const float* dfc_a,
+                      const float* dfc_b, float* gpos, float* gcell, hipStream_t st) {
+    const int64_t N = g.n_nodes, E = g.n_edges;
+    if (E == 0) {  // isolated atoms: no position dependence at all
+        PET_HIP_CHECK(hipMemsetAsync(gpos, 0, N * 3 * sizeof(float), st));
+        if (gcell) PET_HIP_CHECK(hipMemsetAsync(gcell, 0, g.n_systems * 9 * sizeof(float), st));
+        return PET_OK;
+    }
+    int rc = check_full_list(g, st);
+    if (rc) return rc;
+    k_geom_bwd<<<cdiv(E, 256), 256, 0, st>>>(g.geo, g.d0, dgeo, dfc_a, dfc_b, reinterpret_cast<float4*>(w.dv), E,
+                                             m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function);
     k_pos_grad<<<cdiv(N, 16), 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.rowptr, g.rev, gpos, (int)N);
     if (gcell)
         k_cell_grad<<<(int)g.n_systems, 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.shift, g.ctr, g.sys,
                                                       g.rowptr, gcell, (int)N, E);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
+}
+
+#define PET_CARVE(w)                                                                      \
+    Workspace w;                                                                          \
+    carve_workspace(m, g.n_nodes, g.n_edges, ws, w);                                      \
+    PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "workspace too small")
+
+static int d2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes) PET_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+    return PET_OK;
+}
+
+int backward_predict_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA,
+                         float* g_node, float* g_edge, float* g_fc, hipStream_t st) {
+    PET_CARVE(w);
+    if (g.n_nodes == 0) return PET_OK;
+    int rc;
+    if ((rc = backward_predict(m, g, w, gA, st))) return rc;
+    if (g_node && (rc = d2d(g_node, w.dH, g.n_nodes * DN * sizeof(float), st))) return rc;
+    if (g_edge && (rc = d2d(g_edge, w.dM, g.n_edges * D * sizeof(float), st))) return rc;
+    if (g_fc && (rc = d2d(g_fc, w.dfc, g.n_edges * sizeof(float), st))) return rc;
+    return PET_OK;
+}
+
+int backward_features_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_node,
+                          const float* g_edge, float* g_geo, float* g_fc, hipStream_t st) {
+    PET_CARVE(w);
+    if (g.n_nodes == 0) return PET_OK;
+    int rc;
+    if ((rc = d2d(w.dH, g_node, g.n_nodes * DN * sizeof(float), st))) return rc;
+    if ((rc = d2d(w.dM, g_edge, g.n_edges * D * sizeof(float), st))) return rc;
+    if ((rc = backward_features(m, g, w, st))) return rc;
+    if ((rc = d2d(g_geo, w.dgeo, g.n_edges * 4 * sizeof(float), st))) return rc;
+    if ((rc = d2d(g_fc, w.dbias, g.n_edges * sizeof(float), st))) return rc;
+    return PET_OK;
+}
+
+int backward_geometry_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_geo,
+                          const float* g_fc, float* gpos, float* gcell, hipStream_t st) {
+    PET_CARVE(w);
+    if (g.n_nodes == 0) return PET_OK;
+    return backward_geometry(m, g, w, g_geo, g_fc, nullptr, gpos, gcell, st);
+}
+
+int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA, float* gpos,
+             float* gcell, hipStream_t st) {
+    Workspace w;
+    carve_workspace(m, g.n_nodes, g.n_edges, ws, w);
+    PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "workspace too small");
+    if (g.n_nodes == 0) return PET_OK;
+    int rc;
+    if (g.n_edges > 0) {
+        if ((rc = backward_predict(m, g, w, gA, st))) return rc;
+        if ((rc = backward_features(m, g, w, st))) return rc;
+    }
+    return backward_geometry(m, g, w, w.dgeo, w.dfc, w.dbias, gpos, gcell, st);
 }
 
 }  // namespace pet

@@ -1,0 +1,61 @@
+"""CPU tests of the host-side PETBackend mirror: state-dict schema / init parity with the
+reference (no GPU work: constructing the module owns parameters only)."""
+import pytest
+import torch
+
+from metatrain_amd._lib import PetHipError
+from metatrain_amd.pet import PETBackend, default_hypers
+from metatrain_amd.synthetic import state_dict_schema
+from oracle import pet as opet
+
+
+def test_state_dict_keys_shapes_and_order_match_reference_schema():
+    hypers = default_hypers()
+    be = PETBackend(hypers, [1, 6, 7, 8])
+    be.add_output("energy", {"energy": [1]})
+    sd = be.state_dict()
+    schema = state_dict_schema(hypers, [1, 6, 7, 8], {"energy": 1})
+    assert list(sd.keys()) == [k for k, _, _ in schema]
+    for k, shape, _ in schema:
+        assert tuple(sd[k].shape) == tuple(shape), k
+    # first entry is the integer buffer the reference's checkpoint dtype probe relies on
+    assert next(iter(sd)) == "species_to_species_index" and sd["species_to_species_index"].dtype == torch.int64
+    assert sum(p.numel() for p in be.parameters()) == 2903298  # default PET + energy head
+
+
+def test_seed0_init_equals_reference_init():
+    """torch.manual_seed(0) + the reference's construction order gives the reference's weights
+    (the oracle's reference_init_params reproduces pet/tests/test_regression.py:66-74 with them)."""
+    hypers = default_hypers()
+    ref = opet.reference_init_params(hypers, [1, 6, 7, 8], "mtt::U0", seed=0)
+    torch.manual_seed(0)
+    be = PETBackend(hypers, [1, 6, 7, 8])
+    be.add_output("mtt::U0", {"mtt::U0": [1]})
+    sd = be.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:
+        assert torch.equal(sd[k], ref[k]), k
+
+
+def test_reference_state_dict_loads_strictly():
+    hypers = default_hypers()
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1})
+    be = PETBackend(hypers, [1, 6, 7, 8])
+    be.add_output("energy", {"energy": [1]})
+    res = be.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    be.remove_output("energy")
+    assert not any(k.startswith(("node_heads", "edge_heads")) for k in be.state_dict())
+
+
+def test_unsupported_variants_and_cpu_inputs_raise():
+    with pytest.raises(PetHipError):
+        PETBackend(dict(default_hypers(), featurizer_type="residual"), [1, 6])
+    with pytest.raises(PetHipError):
+        PETBackend(dict(default_hypers(), num_neighbors_adaptive=16), [1, 6])
+    be = PETBackend(default_hypers(), [1, 6, 7, 8])
+    be.add_output("energy", {"energy": [1]})
+    z = torch.zeros
+    with pytest.raises(PetHipError, match="no CPU path"):
+        be.preprocess(z(2, 3), z(0, dtype=torch.int32), z(0, dtype=torch.int32), torch.tensor([1, 6]),
+                      z(1, 3, 3), z(0, 3, dtype=torch.int32), z(2, dtype=torch.long), 1.0)

@@ -1,0 +1,130 @@
+"""GPU tests of the drop-in boundary, written after the reference's own
+pet/tests/test_backend.py and pet/tests/test_regression.py: the backend consumes and returns
+plain tensors, and energy / forces / strain gradient come out of torch.autograd.grad."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nl as onl
+from oracle import pet as opet
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _backend(dev, target="energy", seed=None):
+    from metatrain_amd.pet import PETBackend, default_hypers
+
+    hypers = default_hypers()
+    if seed is not None:
+        torch.manual_seed(seed)
+    be = PETBackend(hypers, [1, 6, 7, 8])
+    be.add_output(target, {target: [1]})
+    if seed is None:
+        be.load_state_dict(opet.synthetic_params(hypers, [1, 6, 7, 8], {target: 1}))
+    return be.to(dev).eval(), hypers
+
+
+def _inputs(pos, z, cell, pbc, cutoff, dev):
+    i, j, s, _ = onl.neighbor_list(np.asarray(pos, dtype=np.float64), np.asarray(cell, dtype=np.float64), pbc, cutoff)
+    return (torch.tensor(i, device=dev), torch.tensor(j, device=dev), torch.tensor(s, device=dev),
+            torch.tensor(z, device=dev), torch.zeros(len(z), dtype=torch.long, device=dev))
+
+
+def test_backend_runs_on_plain_tensors(dev):
+    """pet/tests/test_backend.py:122-150 (water molecule, non-periodic)."""
+    be, hypers = _backend(dev)
+    pos = torch.tensor([[0.0, 0.0, 0.119], [0.0, 0.757, -0.477], [0.0, -0.757, -0.477]], device=dev)
+    cells = torch.zeros(1, 3, 3, device=dev)
+    i, j, s, z, sysidx = _inputs(pos.cpu().numpy(), [8, 1, 1], np.zeros((3, 3)), [False] * 3, hypers["cutoff"], dev)
+    batch = be.preprocess(pos, i, j, z, cells, s, sysidx, 1.0)
+    assert isinstance(batch, dict) and len(batch) == 12
+    assert all(isinstance(v, torch.Tensor) for v in batch.values())
+    nodes, edges = be.calculate_features(batch)
+    assert nodes[0].shape == (3, 256) and edges[0].shape == (3, 2, 128)
+    pred, node_ll, edge_ll = be.predict(nodes, edges, batch, cells, sysidx, ["energy"])
+    assert pred["energy"][0].shape == (3, 1)
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    ref = opet.pet_atomic_energies(params, hypers, pos.cpu().double(), cells.cpu().double(), i.cpu(), j.cpu(),
+                                   s.cpu().long(), z.cpu(), sysidx.cpu())
+    assert (pred["energy"][0].cpu().double() - ref).abs().max() / ref.abs().max() < TOL
+
+
+def test_energy_forces_and_strain_gradient_via_autograd(dev):
+    """pet/tests/test_backend.py:69-117: 2-atom 3.5 A cubic C/O cell with a 4.5 A cutoff (periodic
+    self images), energy / forces / strain gradient from torch.autograd.grad with the strain trick."""
+    be, hypers = _backend(dev)
+    base = torch.tensor([[0.0, 0.0, 0.0], [1.5, 1.5, 1.5]])
+    cell = 3.5 * torch.eye(3)
+    i, j, s, z, sysidx = _inputs(base.numpy(), [6, 8], cell.numpy(), [True] * 3, hypers["cutoff"], dev)
+
+    def energy(pos_leaf, strain, backend_like):
+        return backend_like(pos_leaf @ strain, (cell.to(pos_leaf) @ strain)[None])
+
+    def hip(pos, cells):
+        batch = be.preprocess(pos, i, j, z, cells, s, sysidx, 1.0)
+        nodes, edges = be.calculate_features(batch)
+        pred, _, _ = be.predict(nodes, edges, batch, cells, sysidx, ["energy"])
+        return pred["energy"][0].sum()
+
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+
+    def oracle(pos, cells):
+        return opet.pet_atomic_energies(params, hypers, pos, cells, i.cpu(), j.cpu(), s.cpu().long(), z.cpu(),
+                                        sysidx.cpu()).sum()
+
+    p = base.to(dev).requires_grad_(True)
+    st = torch.eye(3, device=dev).requires_grad_(True)
+    e = energy(p, st, hip)
+    gp, gs = torch.autograd.grad(e, [p, st])
+    p64 = base.double().requires_grad_(True)
+    st64 = torch.eye(3, dtype=torch.float64).requires_grad_(True)
+    e64 = energy(p64, st64, oracle)
+    gp64, gs64 = torch.autograd.grad(e64, [p64, st64])
+    assert abs(float(e) - float(e64)) / abs(float(e64)) < TOL
+    assert (gp.cpu().double() - gp64).abs().max() / gp64.abs().max() < TOL
+    assert (gs.cpu().double() - gs64).abs().max() / gs64.abs().max() < TOL
+
+
+def test_seed0_backend_reproduces_reference_regression_energies(dev, golden_dir):
+    """The reference's own golden numbers (pet/tests/test_regression.py:66-74): fresh model under
+    torch.manual_seed(0), first five QM9 frames, per-system energies."""
+    be, hypers = _backend(dev, target="mtt::U0", seed=0)
+    g = dict(np.load(os.path.join(golden_dir, "qm9_first5.npz")))
+    got = []
+    for k in range(5):
+        zk, xyz = g[f"z{k}"], g[f"pos{k}"]
+        i, j, s, z, sysidx = _inputs(xyz, zk, np.zeros((3, 3)), [False] * 3, hypers["cutoff"], dev)
+        pos = torch.tensor(xyz, dtype=torch.float32, device=dev)
+        cells = torch.zeros(1, 3, 3, device=dev)
+        batch = be.preprocess(pos, i, j, z, cells, s, sysidx, 1.0)
+        nodes, edges = be.calculate_features(batch)
+        pred, _, _ = be.predict(nodes, edges, batch, cells, sysidx, ["mtt::U0"])
+        got.append(float(pred["mtt::U0"][0].sum()))
+    # torch.testing.assert_close fp32 defaults, the tolerance the reference applies to itself
+    np.testing.assert_allclose(got, g["expected_reference_test"], rtol=1.3e-6, atol=1e-5)
+
+
+def test_parameter_update_is_picked_up(dev):
+    """Weights changed in place (optimizer step / load_state_dict) must reach the packed copy."""
+    be, hypers = _backend(dev)
+    pos, z, cell = opet.random_box(40, 3)
+    i, j, s, zz, sysidx = _inputs(pos.numpy(), z.numpy(), cell.numpy(), [True] * 3, hypers["cutoff"], dev)
+
+    def run():
+        batch = be.preprocess(pos.to(dev), i, j, zz, cell[None].to(dev), s, sysidx, 1.0)
+        n, e = be.calculate_features(batch)
+        return be.predict(n, e, batch, cell[None].to(dev), sysidx, ["energy"])[0]["energy"][0].sum().item()
+
+    e0 = run()
+    with torch.no_grad():
+        be.node_last_layers["energy"][0]["energy"].bias.add_(1.0)
+    assert abs(run() - (e0 + 40.0)) < 1e-3
