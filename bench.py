@@ -86,18 +86,16 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="print a per-stage table to stderr")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from metatrain_amd import distributed as pdist
+
+    rank, local_rank, world = pdist.env_rank()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        pdist.init("nccl", dev)  # "nccl" is RCCL on ROCm
 
     from metatrain_amd import runtime as rt
     from metatrain_amd.pet import default_hypers
@@ -112,8 +110,9 @@ def main():
     boxes = args.boxes
     pos_l, z_l, cell_l, pair_l, sys_l = [], [], [], [], []
     nl_ms = 0.0
+    seeds = pdist.box_seeds(boxes, rank)
     for b in range(boxes):
-        pos, z, cell = random_box(ATOMS_PER_BOX, seed=rank * boxes + b)
+        pos, z, cell = random_box(ATOMS_PER_BOX, seed=seeds[b])
         posd = pos.to(dev)
         rt.neighbor_list(posd[:64].contiguous(), cell, [True] * 3, hypers["cutoff"])  # warm the kernels
         torch.cuda.synchronize()
@@ -147,10 +146,7 @@ def main():
         return atomic, grad, graph
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        pdist.barrier(dev)
 
     for _ in range(args.warmup):
         step()
@@ -176,10 +172,7 @@ def main():
     dom = [r for r in rt.profile_report() if r["name"] == dominant][0]
     rt.profile(False)
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = pdist.max_over_ranks(elapsed, dev)
     total_atoms = n_atoms * world
     ms_per_step = elapsed / args.steps * 1e3
     value = total_atoms * args.steps / elapsed
@@ -236,8 +229,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(hypers, params)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        pdist.barrier(dev)
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
