@@ -1,5 +1,6 @@
 // extern "C" entry points of libpet_hip.so (see include/pet_hip.h) + model packing.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -10,7 +11,43 @@
 namespace pet {
 
 static thread_local std::string g_error;
+
+bool use_trr() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PET_HIP_TRR");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 void set_error(const std::string& msg) { g_error = msg; }
+
+const SideStream& side_stream() {
+    static SideStream ss;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        const char* e = getenv("PET_HIP_SIDE");
+        if (!(e && e[0] == '0')) {
+            if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.to_side, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.to_main, hipEventDisableTiming) == hipSuccess)
+                ss.enabled = true;
+        }
+    }
+    return ss;
+}
+void SideStream::fork(hipStream_t main) const {
+    if (!enabled) return;
+    (void)hipEventRecord(to_side, main);
+    (void)hipStreamWaitEvent(s, to_side, 0);
+}
+void SideStream::join(hipStream_t main) const {
+    if (!enabled) return;
+    (void)hipEventRecord(to_main, s);
+    (void)hipStreamWaitEvent(main, to_main, 0);
+}
 
 // ---------------------------------------------------------------------------------
 // profiling: HIP events on the launch stream around every stage

@@ -92,6 +92,32 @@ int backward_features_abi(const Model& m, const Graph& g, void* ws, int64_t ws_b
 int backward_geometry_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_geo,
                           const float* g_fc, float* grad_pos, float* grad_cells, hipStream_t st);
 
+// pet_trr.hip: transposed register-resident stages (default; PET_HIP_TRR=0 selects the LDS-tile kernels)
+bool use_trr();
+void trr_qkv(const float* X, const float* gamma, const Lin& qkv, float* QKV, int64_t R, hipStream_t st);
+void trr_qkv_bwd(const float* dQKV, const float* X, const float* gamma, const Lin& qkv, const float* dX1,
+                 float* dXin, int64_t E, int64_t R, hipStream_t st);
+void trr_oproj(const float* AO, const float* X, const Lin& out, float* X1, float* OC, int64_t E, int64_t R,
+               hipStream_t st);
+void trr_oproj_bwd(const float* dX1, const float* dOC, const Lin& out, float* dAO, int64_t E, int64_t R,
+                   hipStream_t st);
+void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wout, float* VG, float* X2,
+              int64_t E, hipStream_t st);
+void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
+                  const Lin& wout, float* dX1, int64_t E, hipStream_t st);
+
+// abi.hip: a second HIP stream for the node-feature chain, which is independent of the edge chain
+// between output_linear and the next attention layer (PET_HIP_SIDE=0 runs everything on one stream)
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t to_side = nullptr, to_main = nullptr;
+    bool enabled = false;
+    hipStream_t stream(hipStream_t main) const { return enabled ? s : main; }
+    void fork(hipStream_t main) const;  // side waits for everything issued on main so far
+    void join(hipStream_t main) const;  // main waits for everything issued on side so far
+};
+const SideStream& side_stream();
+
 // profiling (abi.hip)
 struct ProfScope {
     ProfScope(const char* name, hipStream_t st, double flops);

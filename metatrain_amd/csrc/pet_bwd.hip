@@ -732,10 +732,16 @@ int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* 
                                                                w.ypred_e, w.dfc, w.dM, E);
     }
     {
-        ProfScope ps("head_node_bwd", st, fN * 2.0 * (DN * DH + DH * DH + DH));
-        k_head_bwd<256, false><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + 256, st>>>(
-            last.Hout, m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nh0.bwd, m.nh2.bwd, m.nll_w, gA, nullptr, nullptr,
-            nullptr, nullptr, w.dH, N);
+        const SideStream& ss = side_stream();
+        const hipStream_t s2 = ss.stream(st);
+        ss.fork(st);
+        {
+            ProfScope ps("head_node_bwd", s2, fN * 2.0 * (DN * DH + DH * DH + DH));
+            k_head_bwd<256, false><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + 256, s2>>>(
+                last.Hout, m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nh0.bwd, m.nh2.bwd, m.nll_w, gA, nullptr,
+                nullptr, nullptr, nullptr, w.dH, N);
+        }
+        ss.join(st);
     }
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
@@ -754,6 +760,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     const size_t lds1 = BM * LD128 * 4, lds2 = 2 * BM * LD128 * 4;
     const double fE = (double)E, fN = (double)N, fR = (double)R;
     float* dbias_h = w.delta;  // [E, NHEAD] (reuses the delta carve)
+    const bool trr = use_trr();
     PET_HIP_CHECK(hipMemsetAsync(w.dgeo, 0, E * 4 * sizeof(float), st));
     PET_HIP_CHECK(hipMemsetAsync(dbias_h, 0, E * NHEAD * sizeof(float), st));
     allow_big_lds(k_swiglu_bwd<256, DNF>, (BM * LD256 + BM * LD128) * 4);
@@ -762,6 +769,11 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     float* dH_alt = w.dH2;
     float* dX = w.dX;
     float* dX_alt = w.dX2;
+    // node-feature adjoint chain on the side stream: it only meets the edge chain at output_linear^T
+    // (needs dOC) and at the centre rows of the token gradient (k_center_bwd)
+    const SideStream& ss = side_stream();
+    const hipStream_t s2 = ss.stream(st);
+    ss.fork(st);  // the seeds in w.dH / w.dM were produced on the main stream
     for (int gi = m.h.num_gnn_layers - 1; gi >= 0; gi--) {
         const GnnLayerW& G = m.gnn[gi];
         const GnnBufs& B = w.gnn[gi];
@@ -779,20 +791,23 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             const AttnBufs& Ab = B.attn[a];
             // dX (edge rows) = grad wrt the edge MLP output; dH = grad wrt Hn
             {
-                ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
-                k_swiglu_bwd<128, DFF><<<gE, NTHREADS, lds2, st>>>(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_out.bwd,
-                                                                   A.mlp_in.bwd, dX_alt, E);
+                ProfScope ps("node_bwd", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
+                k_swiglu_bwd<256, DNF><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
+                    dH, Ab.H1, Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N);
+                k_expand_bwd<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(dH_alt, A.ce.bwd, w.dOC, N);
             }
             {
-                ProfScope ps("node_bwd", st, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
-                k_swiglu_bwd<256, DNF><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, st>>>(
-                    dH, Ab.H1, Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N);
-                k_expand_bwd<<<gN, NTHREADS, BM * LD256 * 4, st>>>(dH_alt, A.ce.bwd, w.dOC, N);
+                ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
+                if (trr) trr_emlp_bwd(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_in, A.mlp_out, dX_alt, E, st);
+                else k_swiglu_bwd<128, DFF><<<gE, NTHREADS, lds2, st>>>(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_out.bwd,
+                                                                        A.mlp_in.bwd, dX_alt, E);
             }
+            ss.join(st);  // dOC ready
             // dX_alt (edge rows) = dX1, dH_alt = dH1
             {
                 ProfScope ps("oproj_bwd", st, fR * 2.0 * D * D);
-                k_oproj_bwd<<<gR, NTHREADS, lds1, st>>>(dX_alt, w.dOC, A.out.bwd, w.dAO, E, R);
+                if (trr) trr_oproj_bwd(dX_alt, w.dOC, A.out, w.dAO, E, R, st);
+                else k_oproj_bwd<<<gR, NTHREADS, lds1, st>>>(dX_alt, w.dOC, A.out.bwd, w.dAO, E, R);
             }
             {
                 ProfScope ps("attn_bwd", st, 0.0);
@@ -807,11 +822,13 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             }
             {
                 ProfScope ps("qkv_bwd", st, fR * 2.0 * D * 3 * D);
-                k_qkv_bwd<<<gR, NTHREADS, lds1, st>>>(w.dQKV, Ab.X, A.g_attn, A.qkv.bwd, dX_alt, dX, E, R);
+                if (trr) trr_qkv_bwd(w.dQKV, Ab.X, A.g_attn, A.qkv, dX_alt, dX, E, R, st);
+                else k_qkv_bwd<<<gR, NTHREADS, lds1, st>>>(w.dQKV, Ab.X, A.g_attn, A.qkv.bwd, dX_alt, dX, E, R);
             }
+            ss.fork(st);  // centre rows of dX ready
             {
-                ProfScope ps("center_bwd", st, fN * 2.0 * DN * D);
-                k_center_bwd<<<gN, NTHREADS, lds1, st>>>(dX + E * D, dH_alt, A.cc.bwd, dH, N);
+                ProfScope ps("center_bwd", s2, fN * 2.0 * DN * D);
+                k_center_bwd<<<gN, NTHREADS, lds1, s2>>>(dX + E * D, dH_alt, A.cc.bwd, dH, N);
             }
             // now dX (edge rows) = grad wrt this layer's input edge tokens, dH = grad wrt its input h
         }
@@ -826,6 +843,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         }
         // w.dM now holds d/dMout of layer gi-1 (pass-through + compress adjoint)
     }
+    ss.join(st);
     k_dfc_attn<<<cdiv(E, 256), 256, 0, st>>>(g.fc, dbias_h, w.dbias, E);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;

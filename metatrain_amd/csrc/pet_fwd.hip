@@ -568,11 +568,24 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
     const size_t lds1 = BM * LD128 * 4, lds2 = 2 * BM * LD128 * 4;
     const size_t lds_c = lds2 + BM * 20;
     const double fE = (double)E, fN = (double)N, fR = (double)R;
+    const bool trr = use_trr();
 
     allow_big_lds(k_center, BM * LD256 * 4);
     allow_big_lds(k_node, (BM * LD256 + BM * LD128) * 4);
     allow_big_lds(k_head<256>, (BM * LD256 + BM * LD128) * 4);
+    const SideStream& ss = side_stream();
+    const hipStream_t s2 = ss.stream(st);  // node-feature chain
+    bool side_busy = false;
+    auto launch_center = [&](int gi, int a) {
+        const AttnLayerW& A = m.gnn[gi].attn[a];
+        AttnBufs& Ab = w.gnn[gi].attn[a];
+        ProfScope ps("center", s2, fN * 2.0 * DN * D);
+        k_center<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(Ab.H, A.cc.fwd, A.cc.b, Ab.X + E * D, N);
+    };
     k_node_embed<<<cdiv(N * (DN / 4), 256), 256, 0, st>>>(g.sp, m.node_emb, w.H0, (int)N);
+    ss.fork(st);
+    launch_center(0, 0);
+    side_busy = true;
     for (int gi = 0; gi < m.h.num_gnn_layers; gi++) {
         const GnnLayerW& G = m.gnn[gi];
         GnnBufs& B = w.gnn[gi];
@@ -592,13 +605,14 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
             const AttnLayerW& A = G.attn[a];
             AttnBufs& Ab = B.attn[a];
             float* Xnext = (a + 1 < m.h.num_attention_layers) ? B.attn[a + 1].X : B.XF;
-            {
-                ProfScope ps("center", st, fN * 2.0 * DN * D);
-                k_center<<<gN, NTHREADS, BM * LD256 * 4, st>>>(Ab.H, A.cc.fwd, A.cc.b, Ab.X + E * D, N);
+            if (side_busy) {  // the centre rows of this layer's tokens come from the node chain
+                ss.join(st);
+                side_busy = false;
             }
             {
                 ProfScope ps("qkv", st, fR * 2.0 * D * 3 * D);
-                k_qkv<<<gR, NTHREADS, lds1, st>>>(Ab.X, A.g_attn, A.qkv.fwd, A.qkv.b, Ab.QKV, R);
+                if (trr) trr_qkv(Ab.X, A.g_attn, A.qkv, Ab.QKV, R, st);
+                else k_qkv<<<gR, NTHREADS, lds1, st>>>(Ab.X, A.g_attn, A.qkv.fwd, A.qkv.b, Ab.QKV, R);
             }
             {
                 ProfScope ps("attn_fwd", st, 0.0);
@@ -613,18 +627,25 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
             }
             {
                 ProfScope ps("oproj", st, fR * 2.0 * D * D);
-                k_oproj<<<gR, NTHREADS, lds1, st>>>(w.AO, Ab.X, A.out.fwd, A.out.b, Ab.X1, w.OC, E, R);
+                if (trr) trr_oproj(w.AO, Ab.X, A.out, Ab.X1, w.OC, E, R, st);
+                else k_oproj<<<gR, NTHREADS, lds1, st>>>(w.AO, Ab.X, A.out.fwd, A.out.b, Ab.X1, w.OC, E, R);
             }
+            // node chain (side stream): node update of this layer, then the centre token of the next
+            ss.fork(st);
             {
-                ProfScope ps("node", st, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
-                k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, st>>>(
+                ProfScope ps("node", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
+                k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
                     Ab.H, w.OC, A.ce.fwd, A.ce.b, A.g_center, A.cmlp_in.fwd, A.cmlp_in.b, A.cmlp_out.fwd,
                     A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
             }
+            if (a + 1 < m.h.num_attention_layers) launch_center(gi, a + 1);
+            else if (gi + 1 < m.h.num_gnn_layers) launch_center(gi + 1, 0);
+            side_busy = true;
             if (E > 0) {
                 ProfScope ps("emlp", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
-                k_emlp<<<gE, NTHREADS, lds2, st>>>(Ab.X1, A.g_mlp, A.mlp_in.fwd, A.mlp_in.b, A.mlp_out.fwd,
-                                                   A.mlp_out.b, Ab.VG, Xnext, E);
+                if (trr) trr_emlp(Ab.X1, A.g_mlp, A.mlp_in, A.mlp_out, Ab.VG, Xnext, E, st);
+                else k_emlp<<<gE, NTHREADS, lds2, st>>>(Ab.X1, A.g_mlp, A.mlp_in.fwd, A.mlp_in.b, A.mlp_out.fwd,
+                                                        A.mlp_out.b, Ab.VG, Xnext, E);
             }
         }
         if (E > 0) {
@@ -641,8 +662,8 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
     }
     const GnnBufs& last = w.gnn.back();
     {
-        ProfScope ps("head_node", st, fN * 2.0 * (DN * DH + DH * DH + DH));
-        k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, st>>>(
+        ProfScope ps("head_node", s2, fN * 2.0 * (DN * DH + DH * DH + DH));
+        k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
             last.Hout, m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nll_w, m.nll_b, nullptr, nullptr, w.ynode, N);
     }
     if (E > 0) {
@@ -650,6 +671,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
         k_head<128><<<gE, NTHREADS, lds2, st>>>(last.Mout, m.eh0.fwd, m.eh0.b, m.eh2.fwd, m.eh2.b, m.ell_w,
                                                 m.ell_b, g.fc, w.ypred_e, w.ye, E);
     }
+    ss.join(st);
     k_atom_sum<<<cdiv(N, 256), 256, 0, st>>>(w.ynode, w.ye, g.rowptr, atomic, (int)N);
     if (node_feat)
         PET_HIP_CHECK(hipMemcpyAsync(node_feat, last.Hout, N * DN * sizeof(float), hipMemcpyDeviceToDevice, st));

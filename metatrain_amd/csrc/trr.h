@@ -1,0 +1,174 @@
+// Transposed, register-resident row-tile toolkit (gfx950, wave64, fp32 MFMA 32x32x2).
+//
+// One WAVE owns 32 rows and runs a whole chain of dense layers on them without LDS and
+// without barriers. The product is computed transposed, Y^T = W X^T:
+//   A operand = weights  W[n0 + (lane&31)][k]     (packed fragment order, streamed from L2)
+//   B operand = rows     X[row = lane&31][k]      (registers)
+//   C/D       = Y^T tile: column = lane&31 = ROW, row-in-tile = feature
+// so lane (r = lane&31, h = lane>>5) holds, of row r, the features
+//   n = 32 t + 8 q + 4 h + j      (t tile, q = reg>>2, j = reg&3)
+// which is exactly the k-set  k = 8 kg + 4 h + j  (kg = 4 t + q)  that the same lane must
+// supply as B operand of the NEXT layer. A "row fragment" of a [32 x K] activation is
+// therefore K/8 float4 per lane, and the f32x16 accumulators of one GEMM *are* the row
+// fragment of its output: activations never leave the register file inside a chain.
+// Row statistics (RMSNorm, LayerNorm, dot-product heads) are a lane-local sum plus one
+// xor-32 shuffle.
+#pragma once
+#include "common.h"
+
+namespace pet {
+
+struct RowLane {
+    int lane, r, h;
+    __device__ RowLane() {
+        lane = threadIdx.x & 63;
+        r = lane & 31;
+        h = lane >> 5;
+    }
+};
+
+// rows handled per wave / per 256-thread workgroup
+constexpr int WROWS = 32;
+constexpr int WG_ROWS = 128;
+
+__device__ __forceinline__ int64_t wave_row0() {
+    return ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * WROWS;
+}
+
+// x[kg] = X[row][8 kg + 4 h .. + 3]
+template <int KG>
+__device__ __forceinline__ void load_rowfrag(float4 (&x)[KG], const float* __restrict__ X, int64_t row, int ld,
+                                             int h) {
+    const float4* p = reinterpret_cast<const float4*>(X + row * ld + 4 * h);
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) x[kg] = p[2 * kg];
+}
+
+template <int KG>
+__device__ __forceinline__ void store_rowfrag(const float4 (&y)[KG], float* __restrict__ Y, int64_t row, int ld,
+                                              int h) {
+    float4* p = reinterpret_cast<float4*>(Y + row * ld + 4 * h);
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) p[2 * kg] = y[kg];
+}
+
+// accumulator tile t <-> row-fragment entries 4t .. 4t+3
+__device__ __forceinline__ float4 acc_q(const f32x16& a, int q) {
+    return make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+}
+
+template <int NT>
+__device__ __forceinline__ void acc_to_frag(const f32x16 (&acc)[NT], float4* y) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) y[4 * t + q] = acc_q(acc[t], q);
+}
+
+template <int NT>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+}
+
+// acc[t] initialised with bias[n] at this lane's features; all loads are issued before the first
+// use so they cost one L2 round trip, not one per float4
+template <int NT>
+__device__ __forceinline__ void acc_bias(f32x16 (&acc)[NT], const float* __restrict__ bias, int col0, int h) {
+    float4 b[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) b[t][q] = *reinterpret_cast<const float4*>(bias + col0 + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            acc[t][4 * q] = b[t][q].x; acc[t][4 * q + 1] = b[t][q].y;
+            acc[t][4 * q + 2] = b[t][q].z; acc[t][4 * q + 3] = b[t][q].w;
+        }
+}
+
+// acc[t] += W[tiles tile0 .. tile0+NT)[k-groups kg0 .. kg0+KGS) . x[0 .. KGS)
+// Wp: packed [(tile * kg_total + kg) * 64 + lane] float4 (abi.hip k_pack). PF k-groups of weight
+// fragments are kept in flight ahead of the MFMAs that consume them.
+template <int KGS, int NT, int PF = 2>
+__device__ __forceinline__ void gemm_t(const float4* __restrict__ Wp, int kg_total, int kg0, int tile0,
+                                       const float4* x, f32x16 (&acc)[NT], int lane) {
+    const float4* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) wp[t] = Wp + ((size_t)(tile0 + t) * kg_total + kg0) * 64 + lane;
+    float4 wb[PF][NT];
+#pragma unroll
+    for (int s = 0; s < PF; s++)
+        if (s < KGS)
+#pragma unroll
+            for (int t = 0; t < NT; t++) wb[s][t] = wp[t][s * 64];
+#pragma unroll
+    for (int kg = 0; kg < KGS; kg++) {
+        const int cur = kg % PF;
+        const float4 xv = x[kg];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[cur][t].x, xv.x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[cur][t].y, xv.y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[cur][t].z, xv.z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[cur][t].w, xv.w, acc[t], 0, 0, 0);
+        if (kg + PF < KGS)
+#pragma unroll
+            for (int t = 0; t < NT; t++) wb[cur][t] = wp[t][(kg + PF) * 64];
+    }
+}
+
+// sum over the row: lane-local + the partner lane holding the other half of the features
+__device__ __forceinline__ float row_sum(float v) { return v + __shfl_xor(v, 32); }
+
+// RMSNorm in place on a row fragment (torch.nn.RMSNorm, eps = finfo(float32).eps)
+template <int KG>
+__device__ __forceinline__ float rmsnorm_frag(float4 (&x)[KG], const float* __restrict__ gamma, int h) {
+    float ss = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) ss += x[kg].x * x[kg].x + x[kg].y * x[kg].y + x[kg].z * x[kg].z + x[kg].w * x[kg].w;
+    ss = row_sum(ss);
+    const float rstd = rsqrtf(ss * (1.0f / (8 * KG)) + 1.1920928955078125e-07f);
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * h);
+        x[kg].x *= rstd * g.x; x[kg].y *= rstd * g.y; x[kg].z *= rstd * g.z; x[kg].w *= rstd * g.w;
+    }
+    return rstd;
+}
+
+// RMSNorm adjoint: given w = gamma * dn (fragment) and the un-normalised input x,
+// dx = rstd * w - x * rstd^3 * mean(w x)
+template <int KG>
+__device__ __forceinline__ void rmsnorm_bwd_frag(float4 (&w)[KG], const float4 (&x)[KG]) {
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) {
+        ss += x[kg].x * x[kg].x + x[kg].y * x[kg].y + x[kg].z * x[kg].z + x[kg].w * x[kg].w;
+        dot += x[kg].x * w[kg].x + x[kg].y * w[kg].y + x[kg].z * w[kg].z + x[kg].w * w[kg].w;
+    }
+    ss = row_sum(ss);
+    dot = row_sum(dot);
+    const float rstd = rsqrtf(ss * (1.0f / (8 * KG)) + 1.1920928955078125e-07f);
+    const float coef = dot * rstd * rstd * rstd * (1.0f / (8 * KG));
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) {
+        w[kg].x = rstd * w[kg].x - x[kg].x * coef; w[kg].y = rstd * w[kg].y - x[kg].y * coef;
+        w[kg].z = rstd * w[kg].z - x[kg].z * coef; w[kg].w = rstd * w[kg].w - x[kg].w * coef;
+    }
+}
+
+__device__ __forceinline__ float sigm_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_(float x) { return x * sigm_(x); }
+__device__ __forceinline__ float silu_g_(float x) {
+    float s = sigm_(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+
+}  // namespace pet
