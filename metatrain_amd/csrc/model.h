@@ -106,6 +106,11 @@ void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wo
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
                   const Lin& wout, float* dX1, int64_t E, hipStream_t st);
 
+// pet_attn.hip: preload variants of the attention kernels (NT <= 4); return false if not handled
+bool attn_fwd_preload(int nt, const float* QKV, const Graph& g, float* AO, float scale, hipStream_t st);
+bool attn_bwd_preload(int nt, const float* QKV, const float* dAO, const Graph& g, float* dQKV, float* dbias_h,
+                      float scale, hipStream_t st);
+
 // abi.hip: a second HIP stream for the node-feature chain, which is independent of the edge chain
 // between output_linear and the next attention layer (PET_HIP_SIDE=0 runs everything on one stream)
 struct SideStream {

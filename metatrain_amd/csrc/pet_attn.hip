@@ -1,0 +1,269 @@
+// Per-atom attention, forward and adjoint, "preload" variants for up to 63 neighbours (NT <= 4).
+//
+// Same math and same operand-layout trick as k_attn_fwd / k_attn_bwd in pet_fwd.hip / pet_bwd.hip
+// (one wave per (atom, head), transposed score tiles on v_mfma_f32_16x16x4_f32, no LDS), but every
+// global operand -- Q, K, V, dO fragments and the scalar re-reads used as A operands -- is loaded
+// into registers up front in ONE burst, so the wave pays one memory round trip instead of a chain
+// of dependent ones (the first version was latency-bound: MFMA busy 19 %, 58 % of wave time in
+// s_waitcnt). Reference: pet/modules/transformer.py:86-152, 565-589.
+#include "common.h"
+#include "model.h"
+
+namespace pet {
+
+__device__ __forceinline__ int64_t tok_row(int t, int T, int64_t E, int atom, int start) {
+    return (t == 0 || t >= T) ? E + atom : (int64_t)start + t - 1;
+}
+__device__ __forceinline__ float key_bias(int key, int T, const float* __restrict__ fc, int start) {
+    if (key >= T) return -INFINITY;
+    if (key == 0) return 0.f;
+    return logf(fmaxf(fc[start + key - 1], 1e-15f));  // transformer.py:109-110
+}
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_attn_fwd_p(const float* __restrict__ QKV, const int* __restrict__ rowptr,
+                                                     const float* __restrict__ fc, float* __restrict__ AO,
+                                                     int64_t E, int N, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int atom = gw / NHEAD, head = gw % NHEAD;
+    if (atom >= N) return;
+    const int start = rowptr[atom];
+    const int T = rowptr[atom + 1] - start + 1;
+    const int nt = (T + 15) >> 4;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head;
+    float4 kf[NT], qf[NT];
+    float vs[NT][4], bias[NT][4];
+    int64_t qrow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        if (t < nt) {
+            const int64_t rc = tok_row(16 * t + c16, T, E, atom, start);
+            qrow[t] = rc;
+            kf[t] = *reinterpret_cast<const float4*>(QKV + rc * (3 * D) + ko + 4 * g4);
+            qf[t] = *reinterpret_cast<const float4*>(QKV + rc * (3 * D) + qo + 4 * g4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = 16 * t + 4 * g4 + r;
+                vs[t][r] = QKV[tok_row(key, T, E, atom, start) * (3 * D) + vo + c16];
+                bias[t][r] = key_bias(key, T, fc, start);
+            }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < NT; qt++) {
+        if (qt < nt) {
+            const float4 q = make_float4(qf[qt].x * scale, qf[qt].y * scale, qf[qt].z * scale, qf[qt].w * scale);
+            f32x4 s[NT];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++) {
+                if (kt < nt) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    a = MFMA16(kf[kt].x, q.x, a); a = MFMA16(kf[kt].y, q.y, a);
+                    a = MFMA16(kf[kt].z, q.z, a); a = MFMA16(kf[kt].w, q.w, a);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { a[r] += bias[kt][r]; mx = fmaxf(mx, a[r]); }
+                    s[kt] = a;
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const float p = expf(s[kt][r] - mx); s[kt][r] = p; sum += p; }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o = MFMA16(vs[kt][r], s[kt][r], o);
+            if (16 * qt + c16 < T)
+                *reinterpret_cast<float4*>(AO + qrow[qt] * D + qo + 4 * g4) =
+                    make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QKV, const float* __restrict__ dAO,
+                                                     const int* __restrict__ rowptr, const float* __restrict__ fc,
+                                                     float* __restrict__ dQKV, float* __restrict__ dbias_h,
+                                                     int64_t E, int N, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int atom = gw / NHEAD, head = gw % NHEAD;
+    if (atom >= N) return;
+    const int start = rowptr[atom];
+    const int T = rowptr[atom + 1] - start + 1;
+    const int nt = (T + 15) >> 4;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head;
+    // fragments with the token on the 16-lane axis (rows 16t + c16) ...
+    float4 kf[NT], vf[NT], qf[NT], dof[NT];
+    // ... and scalars with the token on the (group, register) axis (rows 16t + 4 g4 + r)
+    float ks[NT][4], qs[NT][4], dos[NT][4];
+    float bias_r[NT][4], bias_c[NT], db[NT][4], lse[NT], delta[NT];
+    int64_t rowc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        lse[t] = 0.f;
+        delta[t] = 0.f;
+        if (t < nt) {
+            const int tc = 16 * t + c16;
+            const int64_t rc = tok_row(tc, T, E, atom, start);
+            rowc[t] = rc;
+            kf[t] = *reinterpret_cast<const float4*>(QKV + rc * (3 * D) + ko + 4 * g4);
+            vf[t] = *reinterpret_cast<const float4*>(QKV + rc * (3 * D) + vo + 4 * g4);
+            const float4 q = *reinterpret_cast<const float4*>(QKV + rc * (3 * D) + qo + 4 * g4);
+            qf[t] = make_float4(q.x * scale, q.y * scale, q.z * scale, q.w * scale);
+            dof[t] = tc < T ? *reinterpret_cast<const float4*>(dAO + rc * D + qo + 4 * g4) : make_float4(0, 0, 0, 0);
+            bias_c[t] = key_bias(tc, T, fc, start);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int tr = 16 * t + 4 * g4 + r;
+                const int64_t rr = tok_row(tr, T, E, atom, start);
+                ks[t][r] = QKV[rr * (3 * D) + ko + c16];
+                qs[t][r] = QKV[rr * (3 * D) + qo + c16];
+                dos[t][r] = tr < T ? dAO[rr * D + qo + c16] : 0.f;
+                bias_r[t][r] = key_bias(tr, T, fc, start);
+                db[t][r] = 0.f;
+            }
+        }
+    }
+    // ---- pass A: per query tile, transposed scores (keys x queries): dQ, delta, lse, key-bias grad
+#pragma unroll
+    for (int qt = 0; qt < NT; qt++) {
+        if (qt < nt) {
+            f32x4 s[NT], dp[NT];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++) {
+                if (kt < nt) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+                    a = MFMA16(kf[kt].x, qf[qt].x, a); a = MFMA16(kf[kt].y, qf[qt].y, a);
+                    a = MFMA16(kf[kt].z, qf[qt].z, a); a = MFMA16(kf[kt].w, qf[qt].w, a);
+                    b = MFMA16(vf[kt].x, dof[qt].x, b); b = MFMA16(vf[kt].y, dof[qt].y, b);
+                    b = MFMA16(vf[kt].z, dof[qt].z, b); b = MFMA16(vf[kt].w, dof[qt].w, b);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { a[r] += bias_r[kt][r]; mx = fmaxf(mx, a[r]); }
+                    s[kt] = a;
+                    dp[kt] = b;
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const float p = expf(s[kt][r] - mx); s[kt][r] = p; sum += p; }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            float dl = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { s[kt][r] *= inv; dl += s[kt][r] * dp[kt][r]; }
+            dl += __shfl_xor(dl, 16);
+            dl += __shfl_xor(dl, 32);
+            lse[qt] = mx + logf(sum);
+            delta[qt] = dl;
+            f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float ds = s[kt][r] * (dp[kt][r] - dl);  // dS^T[key][q]; 0 for padded queries
+                        db[kt][r] += ds;
+                        dq = MFMA16(ks[kt][r], ds, dq);
+                    }
+            if (16 * qt + c16 < T)
+                *reinterpret_cast<float4*>(dQKV + rowc[qt] * (3 * D) + qo + 4 * g4) =
+                    make_float4(dq[0] * scale, dq[1] * scale, dq[2] * scale, dq[3] * scale);
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+        if (kt < nt)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = db[kt][r];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                const int key = 16 * kt + 4 * g4 + r;
+                if (c16 == 0 && key >= 1 && key < T) dbias_h[(int64_t)(start + key - 1) * NHEAD + head] += v;
+            }
+    // ---- pass B: per key tile, plain scores (queries x keys): dK, dV
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+        if (kt < nt) {
+            f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dvv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qt = 0; qt < NT; qt++) {
+                if (qt < nt) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+                    a = MFMA16(qf[qt].x, kf[kt].x, a); a = MFMA16(qf[qt].y, kf[kt].y, a);
+                    a = MFMA16(qf[qt].z, kf[kt].z, a); a = MFMA16(qf[qt].w, kf[kt].w, a);
+                    b = MFMA16(dof[qt].x, vf[kt].x, b); b = MFMA16(dof[qt].y, vf[kt].y, b);
+                    b = MFMA16(dof[qt].z, vf[kt].z, b); b = MFMA16(dof[qt].w, vf[kt].w, b);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int qq = 16 * qt + 4 * g4 + r;
+                        const float l = __shfl(lse[qt], 4 * g4 + r);
+                        const float dl = __shfl(delta[qt], 4 * g4 + r);
+                        float p = expf(a[r] + bias_c[kt] - l);
+                        if (qq >= T) p = 0.f;
+                        const float ds = p * (b[r] - dl);
+                        dvv = MFMA16(dos[qt][r], p, dvv);
+                        dk = MFMA16(qs[qt][r], ds, dk);
+                    }
+                }
+            }
+            if (16 * kt + c16 < T) {
+                *reinterpret_cast<float4*>(dQKV + rowc[kt] * (3 * D) + ko + 4 * g4) =
+                    make_float4(dk[0] * scale, dk[1] * scale, dk[2] * scale, dk[3] * scale);
+                *reinterpret_cast<float4*>(dQKV + rowc[kt] * (3 * D) + vo + 4 * g4) =
+                    make_float4(dvv[0], dvv[1], dvv[2], dvv[3]);
+            }
+        }
+    }
+}
+
+// host launchers: true if this variant handled the launch (NT <= 4)
+bool attn_fwd_preload(int nt, const float* QKV, const Graph& g, float* AO, float scale, hipStream_t st) {
+    const int grid = cdiv((int64_t)g.n_nodes * NHEAD, 4);
+    const int N = (int)g.n_nodes;
+    switch (nt) {
+        case 1: k_attn_fwd_p<1><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale); return true;
+        case 2: k_attn_fwd_p<2><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale); return true;
+        case 3: k_attn_fwd_p<3><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale); return true;
+        case 4: k_attn_fwd_p<4><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale); return true;
+        default: return false;
+    }
+}
+bool attn_bwd_preload(int nt, const float* QKV, const float* dAO, const Graph& g, float* dQKV, float* dbias_h,
+                      float scale, hipStream_t st) {
+    const int grid = cdiv((int64_t)g.n_nodes * NHEAD, 4);
+    const int N = (int)g.n_nodes;
+    switch (nt) {
+        case 1: k_attn_bwd_p<1><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale); return true;
+        case 2: k_attn_bwd_p<2><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale); return true;
+        case 3: k_attn_bwd_p<3><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale); return true;
+        case 4: k_attn_bwd_p<4><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale); return true;
+        default: return false;
+    }
+}
+
+}  // namespace pet

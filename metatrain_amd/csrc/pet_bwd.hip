@@ -811,7 +811,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             }
             {
                 ProfScope ps("attn_bwd", st, 0.0);
-                switch (nt) {
+                if (!(trr && attn_bwd_preload(nt, Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st))) switch (nt) {
                     case 1: launch_attn_bwd<1>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;
                     case 2: launch_attn_bwd<2>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;
                     case 3: launch_attn_bwd<3>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;

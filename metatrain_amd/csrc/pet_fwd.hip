@@ -616,7 +616,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
             }
             {
                 ProfScope ps("attn_fwd", st, 0.0);
-                switch (nt) {
+                if (!(trr && attn_fwd_preload(nt, Ab.QKV, g, w.AO, scale, st))) switch (nt) {
                     case 1: launch_attn_fwd<1>(Ab.QKV, g, w.AO, scale, st); break;
                     case 2: launch_attn_fwd<2>(Ab.QKV, g, w.AO, scale, st); break;
                     case 3: launch_attn_fwd<3>(Ab.QKV, g, w.AO, scale, st); break;

@@ -19,7 +19,7 @@ namespace pet {
 // ---------------------------------------------------------------------------------
 // QKV = RMSNorm(X) Win^T + b
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_qkv_t(const float* __restrict__ X, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256, 3) void k_qkv_t(const float* __restrict__ X, const float* __restrict__ gamma,
                                                 const float4* __restrict__ win, const float* __restrict__ bin,
                                                 float* __restrict__ QKV, int64_t R) {
     TRR_PROLOGUE(R);
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_qkv_t(const float* __restrict__ X, cons
 }
 
 // dXin = (row < E ? dX1 : 0) + RMSNorm^T(dQKV Win)
-__global__ __launch_bounds__(256) void k_qkv_bwd_t(const float* __restrict__ dQKV, const float* __restrict__ X,
+__global__ __launch_bounds__(256, 2) void k_qkv_bwd_t(const float* __restrict__ dQKV, const float* __restrict__ X,
                                                     const float* __restrict__ gamma, const float4* __restrict__ winb,
                                                     const float* __restrict__ dX1, float* __restrict__ dXin,
                                                     int64_t E, int64_t R) {
@@ -64,11 +64,10 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_t(const float* __restrict__ dQK
     rmsnorm_bwd_frag<16>(w, x);
     if (valid) {
         if (row < E) {
-            float4 d1[16];
-            load_rowfrag<16>(d1, dX1, row, D, L.h);
+            load_rowfrag<16>(x, dX1, row, D, L.h);
 #pragma unroll
             for (int kg = 0; kg < 16; kg++) {
-                w[kg].x += d1[kg].x; w[kg].y += d1[kg].y; w[kg].z += d1[kg].z; w[kg].w += d1[kg].w;
+                w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
             }
         }
         store_rowfrag<16>(w, dXin, row, D, L.h);
@@ -78,7 +77,7 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_t(const float* __restrict__ dQK
 // ---------------------------------------------------------------------------------
 // output_linear (+ edge residual) and its adjoint
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_oproj_t(const float* __restrict__ AO, const float* __restrict__ X,
+__global__ __launch_bounds__(256, 3) void k_oproj_t(const float* __restrict__ AO, const float* __restrict__ X,
                                                   const float4* __restrict__ wo, const float* __restrict__ bo,
                                                   float* __restrict__ X1, float* __restrict__ OC, int64_t E,
                                                   int64_t R) {
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(256) void k_emlp_t(const float* __restrict__ X1, co
 }
 
 // dX1 = dY + RMSNorm^T( Win^T [du sig(g) ; du v sig'(g)] ),  du = Wout^T dY
-__global__ __launch_bounds__(256) void k_emlp_bwd_t(const float* __restrict__ dY, const float* __restrict__ X1,
+__global__ __launch_bounds__(256, 2) void k_emlp_bwd_t(const float* __restrict__ dY, const float* __restrict__ X1,
                                                      const float* __restrict__ VG, const float* __restrict__ gamma,
                                                      const float4* __restrict__ woutb, const float4* __restrict__ winb,
                                                      float* __restrict__ dX1, int64_t E) {
@@ -211,9 +210,10 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_t(const float* __restrict__ dY
     }
     rmsnorm_bwd_frag<16>(w, x);
     if (valid) {
+        load_rowfrag<16>(x, dY, row, D, L.h);  // residual: re-read dY (L2 hit) instead of keeping 64 registers live
 #pragma unroll
         for (int kg = 0; kg < 16; kg++) {
-            w[kg].x += dy[kg].x; w[kg].y += dy[kg].y; w[kg].z += dy[kg].z; w[kg].w += dy[kg].w;
+            w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
         }
         store_rowfrag<16>(w, dX1, row, D, L.h);
     }
