@@ -178,13 +178,18 @@ int pet_sum_over_atoms(const pet_graph_t* g, const float* d_atomic, float* d_out
 
 /* ---- profiling hooks used by bench.py ------------------------------------------ */
 /* When enabled, every kernel launch of pet_forward/pet_backward is bracketed with HIP
- * events on the launch stream; pet_profile_report fills name/ms/calls arrays. */
+ * events on the launch stream; pet_profile_report fills name / total ms / calls / algorithmic
+ * FLOPs / algorithmic HBM bytes per stage. */
 int pet_profile_enable(int on);
 /* Restrict the event bracketing to one stage name (e.g. "emlp_bwd"); NULL or "" = all. */
 int pet_profile_select(const char* stage);
 int pet_profile_reset(void);
 int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int64_t* calls,
-                       double* flops, int* n_entries);
+                       double* flops, double* bytes, int* n_entries);
+/* Runtime switches used by tests / the benchmark: "side_stream" (1 = node-feature chain on a
+ * second HIP stream, default), "trr" (1 = register-resident stage kernels, default; 0 = the
+ * LDS-tile kernels kept for A/B comparison). */
+int pet_config_set(const char* key, int value);
 
 #ifdef __cplusplus
 }

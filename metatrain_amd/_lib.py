@@ -30,7 +30,7 @@ SYMBOLS = [
     "pet_graph_max_neighbors", "pet_graph_export_batch", "pet_graph_csr",
     "pet_forward_workspace_bytes", "pet_forward", "pet_backward", "pet_backward_predict",
     "pet_backward_features", "pet_backward_geometry", "pet_sum_over_atoms",
-    "pet_profile_enable", "pet_profile_select", "pet_profile_reset", "pet_profile_report",
+    "pet_profile_enable", "pet_profile_select", "pet_profile_reset", "pet_profile_report", "pet_config_set",
 ]
 
 
@@ -111,7 +111,8 @@ def load() -> ctypes.CDLL:
     lib.pet_profile_enable.argtypes = [c_int]
     lib.pet_profile_select.argtypes = [c_char_p]
     lib.pet_profile_report.argtypes = [c_int, P, POINTER(c_double), POINTER(c_int64), POINTER(c_double),
-                                       POINTER(c_int)]
+                                       POINTER(c_double), POINTER(c_int)]
+    lib.pet_config_set.argtypes = [c_char_p, c_int]
     _lib = lib
     return lib
 

@@ -12,20 +12,25 @@ namespace pet {
 
 static thread_local std::string g_error;
 
+static int g_trr = -1;
 bool use_trr() {
-    static int v = -1;
-    if (v < 0) {
+    if (g_trr < 0) {
         const char* e = getenv("PET_HIP_TRR");
-        v = (e && e[0] == '0') ? 0 : 1;
+        g_trr = (e && e[0] == '0') ? 0 : 1;
     }
-    return v == 1;
+    return g_trr == 1;
 }
+void set_use_trr(int v) { g_trr = v ? 1 : 0; }
+static int g_side_override = -1;  // -1: environment default
+void set_side_stream(int v) { g_side_override = v ? 1 : 0; }
 
 void set_error(const std::string& msg) { g_error = msg; }
 
 const SideStream& side_stream() {
     static SideStream ss;
+    static SideStream off;  // enabled == false: everything on the caller's stream
     static bool init = false;
+    if (g_side_override == 0) return off;
     if (!init) {
         init = true;
         const char* e = getenv("PET_HIP_SIDE");
@@ -55,14 +60,14 @@ void SideStream::join(hipStream_t main) const {
 struct ProfRec {
     std::string name;
     hipEvent_t e0, e1;
-    double flops;
+    double flops, bytes;
 };
 static bool g_prof_on = false;
 static std::string g_prof_filter;  // empty = every stage
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;
 
-ProfScope::ProfScope(const char* n, hipStream_t s, double f) : name(n), st(s), flops(f) {
+ProfScope::ProfScope(const char* n, hipStream_t s, double f, double b) : name(n), st(s), flops(f), bytes(b) {
     if (!g_prof_on || (!g_prof_filter.empty() && g_prof_filter != n)) return;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
@@ -72,7 +77,7 @@ ProfScope::~ProfScope() {
     if (!e0) return;
     (void)hipEventRecord(e1, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof.push_back({name, e0, e1, flops});
+    g_prof.push_back({name, e0, e1, flops, bytes});
 }
 
 // ---------------------------------------------------------------------------------
@@ -470,9 +475,18 @@ int pet_profile_reset(void) {
     return PET_OK;
 }
 
+int pet_config_set(const char* key, int value) {
+    PET_REQUIRE(key, PET_ERR_ARGUMENT, "null key");
+    const std::string k(key);
+    if (k == "side_stream") set_side_stream(value);
+    else if (k == "trr") set_use_trr(value);
+    else PET_REQUIRE(false, PET_ERR_ARGUMENT, "unknown config key '" + k + "'");
+    return PET_OK;
+}
+
 int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int64_t* calls, double* flops,
-                       int* n_entries) {
-    PET_REQUIRE(names && total_ms && calls && flops && n_entries, PET_ERR_ARGUMENT, "null argument");
+                       double* bytes, int* n_entries) {
+    PET_REQUIRE(names && total_ms && calls && flops && bytes && n_entries, PET_ERR_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> lk(g_prof_mu);
     std::vector<std::string> order;
     std::map<std::string, int> index;
@@ -492,12 +506,14 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
             total_ms[i] = 0;
             calls[i] = 0;
             flops[i] = 0;
+            bytes[i] = 0;
         } else {
             i = it->second;
         }
         total_ms[i] += ms;
         calls[i] += 1;
         flops[i] += r.flops;
+        bytes[i] += r.bytes;
     }
     *n_entries = (int)order.size();
     return PET_OK;

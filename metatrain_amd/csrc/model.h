@@ -94,6 +94,8 @@ int backward_geometry_abi(const Model& m, const Graph& g, void* ws, int64_t ws_b
 
 // pet_trr.hip: transposed register-resident stages (default; PET_HIP_TRR=0 selects the LDS-tile kernels)
 bool use_trr();
+void set_use_trr(int v);
+void set_side_stream(int v);
 void trr_qkv(const float* X, const float* gamma, const Lin& qkv, float* QKV, int64_t R, hipStream_t st);
 void trr_qkv_bwd(const float* dQKV, const float* X, const float* gamma, const Lin& qkv, const float* dX1,
                  float* dXin, int64_t E, int64_t R, hipStream_t st);
@@ -125,11 +127,12 @@ const SideStream& side_stream();
 
 // profiling (abi.hip)
 struct ProfScope {
-    ProfScope(const char* name, hipStream_t st, double flops);
+    ProfScope(const char* name, hipStream_t st, double flops, double bytes = 0.0);
     ~ProfScope();
     const char* name;
     hipStream_t st;
     double flops;
+    double bytes = 0.0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 

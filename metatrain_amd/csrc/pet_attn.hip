@@ -21,6 +21,29 @@ __device__ __forceinline__ float key_bias(int key, int T, const float* __restric
 }
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Reductions across the four 16-lane groups (lanes l, l^16, l^32, l^48) with the gfx950 row swaps
+// (VALU speed; the first version used ds_bpermute and spent most of its time in lgkmcnt waits).
+__device__ __forceinline__ float g4_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float g4_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+// sum over the 16 lanes of a row with DPP (quad_perm, quad_perm, row_half_mirror, row_mirror)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, true));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, true));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xF, 0xF, true));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void k_attn_fwd_p(const float* __restrict__ QKV, const int* __restrict__ rowptr,
                                                      const float* __restrict__ fc, float* __restrict__ AO,
@@ -69,16 +92,14 @@ __global__ __launch_bounds__(256) void k_attn_fwd_p(const float* __restrict__ QK
                     s[kt] = a;
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = g4_max(mx);
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NT; kt++)
                 if (kt < nt)
 #pragma unroll
                     for (int r = 0; r < 4; r++) { const float p = expf(s[kt][r] - mx); s[kt][r] = p; sum += p; }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum = g4_sum(sum);
             const float inv = 1.0f / sum;
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -111,12 +132,12 @@ __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QK
     float4 kf[NT], vf[NT], qf[NT], dof[NT];
     // ... and scalars with the token on the (group, register) axis (rows 16t + 4 g4 + r)
     float ks[NT][4], qs[NT][4], dos[NT][4];
-    float bias_r[NT][4], bias_c[NT], db[NT][4], lse[NT], delta[NT];
+    float bias_r[NT][4], bias_c[NT], db[NT][4];
     int64_t rowc[NT];
+    __shared__ __attribute__((aligned(16))) float stat_all[4][2][NT * 16];
+    float (*stat)[NT * 16] = stat_all[threadIdx.x >> 6];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        lse[t] = 0.f;
-        delta[t] = 0.f;
         if (t < nt) {
             const int tc = 16 * t + c16;
             const int64_t rc = tok_row(tc, T, E, atom, start);
@@ -159,16 +180,14 @@ __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QK
                     dp[kt] = b;
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = g4_max(mx);
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NT; kt++)
                 if (kt < nt)
 #pragma unroll
                     for (int r = 0; r < 4; r++) { const float p = expf(s[kt][r] - mx); s[kt][r] = p; sum += p; }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum = g4_sum(sum);
             const float inv = 1.0f / sum;
             float dl = 0.f;
 #pragma unroll
@@ -176,10 +195,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QK
                 if (kt < nt)
 #pragma unroll
                     for (int r = 0; r < 4; r++) { s[kt][r] *= inv; dl += s[kt][r] * dp[kt][r]; }
-            dl += __shfl_xor(dl, 16);
-            dl += __shfl_xor(dl, 32);
-            lse[qt] = mx + logf(sum);
-            delta[qt] = dl;
+            dl = g4_sum(dl);
+            // per-query statistics cross over to pass B (queries on the (group, register) axis) through
+            // a wave-private LDS row: one masked write here, one ds_read_b128 per query tile there
+            if (g4 == 0) {
+                stat[0][16 * qt + c16] = mx + logf(sum);
+                stat[1][16 * qt + c16] = dl;
+            }
             f32x4 dq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NT; kt++)
@@ -200,8 +222,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QK
         if (kt < nt)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float v = db[kt][r];
-                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                const float v = row16_sum(db[kt][r]);
                 const int key = 16 * kt + 4 * g4 + r;
                 if (c16 == 0 && key >= 1 && key < T) dbias_h[(int64_t)(start + key - 1) * NHEAD + head] += v;
             }
@@ -218,11 +239,14 @@ __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QK
                     a = MFMA16(qf[qt].z, kf[kt].z, a); a = MFMA16(qf[qt].w, kf[kt].w, a);
                     b = MFMA16(dof[qt].x, vf[kt].x, b); b = MFMA16(dof[qt].y, vf[kt].y, b);
                     b = MFMA16(dof[qt].z, vf[kt].z, b); b = MFMA16(dof[qt].w, vf[kt].w, b);
+                    const float4 l4 = *reinterpret_cast<const float4*>(&stat[0][16 * qt + 4 * g4]);
+                    const float4 d4 = *reinterpret_cast<const float4*>(&stat[1][16 * qt + 4 * g4]);
+                    const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int qq = 16 * qt + 4 * g4 + r;
-                        const float l = __shfl(lse[qt], 4 * g4 + r);
-                        const float dl = __shfl(delta[qt], 4 * g4 + r);
+                        const float l = lr[r];
+                        const float dl = dr[r];
                         float p = expf(a[r] + bias_c[kt] - l);
                         if (qq >= T) p = 0.f;
                         const float ds = p * (b[r] - dl);

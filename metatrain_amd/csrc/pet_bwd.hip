@@ -20,6 +20,7 @@ constexpr int LD256 = lds_ld(256);
 
 float __device__ cutoff_deriv_dev(float d, float rc, float width, int fn);
 int attn_tiles(const Graph& g);
+double g_sum_t2(const Graph& g);
 
 __device__ __forceinline__ float sigmoid_grad_from(float s) { return s * (1.0f - s); }
 
@@ -810,7 +811,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 else k_oproj_bwd<<<gR, NTHREADS, lds1, st>>>(dX_alt, w.dOC, A.out.bwd, w.dAO, E, R);
             }
             {
-                ProfScope ps("attn_bwd", st, 0.0);
+                ProfScope ps("attn_bwd", st, 2.0 * 4.0 * D * g_sum_t2(g), fR * 4.0 * (3 * D + D + 3 * D));
                 if (!(trr && attn_bwd_preload(nt, Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st))) switch (nt) {
                     case 1: launch_attn_bwd<1>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;
                     case 2: launch_attn_bwd<2>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;

@@ -552,6 +552,13 @@ static void launch_attn_fwd(const float* QKV, const Graph& g, float* AO, float s
 
 int attn_tiles(const Graph& g) { return (g.max_nbr + 1 + 15) / 16; }
 
+// sum_i (n_i + 1)^2 estimated from the mean neighbour count (exact value is not needed on the hot path)
+double g_sum_t2(const Graph& g) {
+    if (g.n_nodes == 0) return 0.0;
+    const double t = (double)g.n_edges / (double)g.n_nodes + 1.0;
+    return (double)g.n_nodes * t * t;
+}
+
 int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
             float* node_feat, float* edge_feat, hipStream_t st) {
     Workspace w;
@@ -569,6 +576,8 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
     const size_t lds_c = lds2 + BM * 20;
     const double fE = (double)E, fN = (double)N, fR = (double)R;
     const bool trr = use_trr();
+    // attention: 4 T^2 d FLOPs per atom per layer; T^2 summed on the host side of the graph
+    const double attn_flops = 4.0 * D * g_sum_t2(g);
 
     allow_big_lds(k_center, BM * LD256 * 4);
     allow_big_lds(k_node, (BM * LD256 + BM * LD128) * 4);
@@ -615,7 +624,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
                 else k_qkv<<<gR, NTHREADS, lds1, st>>>(Ab.X, A.g_attn, A.qkv.fwd, A.qkv.b, Ab.QKV, R);
             }
             {
-                ProfScope ps("attn_fwd", st, 0.0);
+                ProfScope ps("attn_fwd", st, attn_flops, fR * 4.0 * (3 * D + D));
                 if (!(trr && attn_fwd_preload(nt, Ab.QKV, g, w.AO, scale, st))) switch (nt) {
                     case 1: launch_attn_fwd<1>(Ab.QKV, g, w.AO, scale, st); break;
                     case 2: launch_attn_fwd<2>(Ab.QKV, g, w.AO, scale, st); break;

@@ -281,9 +281,16 @@ def profile_report() -> List[dict]:
     ms = (c_double * n_max)()
     calls = (c_int64 * n_max)()
     flops = (c_double * n_max)()
+    nbytes = (c_double * n_max)()
     n = c_int(0)
-    check(lib.pet_profile_report(n_max, names, ms, calls, flops, byref(n)))
+    check(lib.pet_profile_report(n_max, names, ms, calls, flops, nbytes, byref(n)))
     return [
-        {"name": names[i].value.decode(), "total_ms": ms[i], "calls": calls[i], "flops": flops[i]}
+        {"name": names[i].value.decode(), "total_ms": ms[i], "calls": calls[i], "flops": flops[i],
+         "bytes": nbytes[i]}
         for i in range(n.value)
     ]
+
+
+def config_set(key: str, value: int) -> None:
+    """Runtime switches of the library ("side_stream", "trr")."""
+    check(_lib.load().pet_config_set(key.encode(), int(value)))
