@@ -164,7 +164,12 @@ __device__ __forceinline__ void rmsnorm_bwd_frag(float4 (&w)[KG], const float4 (
     }
 }
 
-__device__ __forceinline__ float sigm_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid on the hardware transcendentals: v_exp_f32 (2^x, ~1 ulp) and v_rcp_f32 (~1 ulp). The
+// argument scaling costs a relative error of ~1e-7 |x|, far inside the 1e-5 parity budget, and
+// saves ~15 VALU instructions per element over expf() + IEEE division in the gate-heavy stages.
+__device__ __forceinline__ float sigm_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 __device__ __forceinline__ float silu_(float x) { return x * sigm_(x); }
 __device__ __forceinline__ float silu_g_(float x) {
     float s = sigm_(x);
