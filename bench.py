@@ -37,6 +37,28 @@ def synthetic_params(hypers):
     return gen(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
 
 
+STAGE_KERNELS = {"attn_bwd": "k_attn_bwd_p", "attn_fwd": "k_attn_fwd_p", "emlp": "k_emlp_t", "emlp_bwd": "k_emlp_bwd_t",
+                 "qkv": "k_qkv_t", "qkv_bwd": "k_qkv_bwd_t", "comb": "k_comb", "comb_bwd": "k_comb_bwd"}
+
+
+def pmc_traffic(stage, n_edges):
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
+    same bench, corrected as MI355X_MICROARCH.md prescribes). Only quoted when the profiled run
+    had the same number of edges per launch; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path) or stage not in STAGE_KERNELS:
+        return None
+    with open(path) as fh:
+        data = json.load(fh)
+    if data.get("workload_edges") != n_edges:
+        return None
+    for name, rec in data["kernels"].items():
+        if name.startswith(STAGE_KERNELS[stage]):
+            return rec["hbm_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(hypers, params, seconds_budget=25.0):
     """The CPU oracle (a torch-CPU restatement of the reference path, kind="port") timed on
     this host on a bounded sample: forward + dE/dR of ONE 1000-atom box (BASELINE config 2
@@ -81,7 +103,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--boxes", type=int, default=2, help="10k-atom boxes per GPU per step")
+    ap.add_argument("--boxes", type=int, default=2, help="10k-atom boxes per GPU per step")  # 4: +4 %, 8: see DESIGN
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print a per-stage table to stderr")
     args = ap.parse_args()
@@ -201,6 +223,7 @@ def main():
             roof = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "avg_launch_ms": avg_ms,
                     "algorithmic_flops_per_launch": flops_per_launch, "traffic": None}
+        roof["traffic"] = pmc_traffic(dominant, int(graph.n_edges))
         roof["whole_step_algorithmic_tflops"] = None
         roof["stages_single_stream_ms"] = {r["name"]: round(r["total_ms"], 3)
                                            for r in sorted(table, key=lambda r: -r["total_ms"])[:8]}
