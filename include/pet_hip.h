@@ -173,6 +173,22 @@ int pet_backward_geometry(const pet_model_t* m, const pet_graph_t* g, void* d_wo
                           int64_t workspace_bytes, const float* d_grad_geometry,
                           const float* d_grad_cutoff, float* d_grad_positions, float* d_grad_cells,
                           void* stream);
+
+/* ---- training step (trainer.py:391-480) ---------------- */
+/* The model owns one gradient slot per uploaded parameter (same numel, fp32).
+ * pet_model_zero_grad allocates (first call) and clears them -- optimizer.zero_grad(). */
+int pet_model_zero_grad(pet_model_t* m, void* stream);
+/* Copy the accumulated gradient of parameter `key` (same key as pet_model_set_param) into d_dst. */
+int pet_model_get_grad(const pet_model_t* m, const char* key, float* d_dst, int64_t numel,
+                       void* stream);
+/* Workspace for pet_forward(save_for_backward = 2) + pet_backward_train. */
+int64_t pet_train_workspace_bytes(const pet_model_t* m, int64_t n_nodes, int64_t n_edges);
+/* Reverse pass of loss.backward() for L with dL/d(atomic prediction) = d_grad_atomic [N]:
+ * accumulates dL/dtheta into the model's gradient slots; d_grad_positions [N,3] (and d_grad_cells)
+ * may be NULL. Needs pet_forward(save_for_backward = 2) on a training workspace. */
+int pet_backward_train(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
+                       int64_t workspace_bytes, const float* d_grad_atomic,
+                       float* d_grad_positions, float* d_grad_cells, void* stream);
 /* Per-system sum (utils/sum_over_atoms.py:10-48): d_out[S] = sum_{atoms of s} d_atomic. */
 int pet_sum_over_atoms(const pet_graph_t* g, const float* d_atomic, float* d_out, void* stream);
 

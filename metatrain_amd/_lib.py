@@ -29,7 +29,9 @@ SYMBOLS = [
     "pet_graph_workspace_bytes", "pet_graph_build", "pet_graph_destroy", "pet_graph_num_edges",
     "pet_graph_max_neighbors", "pet_graph_export_batch", "pet_graph_csr",
     "pet_forward_workspace_bytes", "pet_forward", "pet_backward", "pet_backward_predict",
-    "pet_backward_features", "pet_backward_geometry", "pet_sum_over_atoms",
+    "pet_backward_features", "pet_backward_geometry",
+    "pet_model_zero_grad", "pet_model_get_grad", "pet_train_workspace_bytes", "pet_backward_train",
+    "pet_sum_over_atoms",
     "pet_profile_enable", "pet_profile_select", "pet_profile_reset", "pet_profile_report", "pet_config_set",
 ]
 
@@ -107,6 +109,11 @@ def load() -> ctypes.CDLL:
     lib.pet_backward_predict.argtypes = [P, P, P, c_int64, P, P, P, P, P]
     lib.pet_backward_features.argtypes = [P, P, P, c_int64, P, P, P, P, P]
     lib.pet_backward_geometry.argtypes = [P, P, P, c_int64, P, P, P, P, P]
+    lib.pet_model_zero_grad.argtypes = [P, P]
+    lib.pet_model_get_grad.argtypes = [P, c_char_p, P, c_int64, P]
+    lib.pet_train_workspace_bytes.argtypes = [P, c_int64, c_int64]
+    lib.pet_train_workspace_bytes.restype = c_int64
+    lib.pet_backward_train.argtypes = [P, P, P, c_int64, P, P, P, P]
     lib.pet_sum_over_atoms.argtypes = [P, P, P, P]
     lib.pet_profile_enable.argtypes = [c_int]
     lib.pet_profile_select.argtypes = [c_char_p]

@@ -322,7 +322,10 @@ int pet_model_set_param(pet_model_t* pm, const char* key, const void* d_data, in
     } else {
         int rc = dev_alloc(m, (void**)&p, numel * sizeof(float));
         if (rc) return rc;
-        if (it == m.raw.end()) m.n_params += numel;
+        if (it == m.raw.end()) {
+            m.grad_off[k] = m.n_params;
+            m.n_params += numel;
+        }
         m.raw[k] = {p, numel};
     }
     PET_HIP_CHECK(hipMemcpyAsync(p, d_data, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -336,6 +339,43 @@ int pet_model_finalize(pet_model_t* pm, void* stream) {
 }
 
 int64_t pet_model_num_params(const pet_model_t* pm) { return pm ? pm->m.n_params : 0; }
+
+int pet_model_zero_grad(pet_model_t* pm, void* stream) {
+    PET_REQUIRE(pm, PET_ERR_ARGUMENT, "null model");
+    Model& m = pm->m;
+    PET_REQUIRE(m.n_params > 0, PET_ERR_ARGUMENT, "model has no parameters");
+    if (!m.grad_flat) {
+        int rc = dev_alloc(m, (void**)&m.grad_flat, m.n_params * sizeof(float));
+        if (rc) return rc;
+    }
+    PET_HIP_CHECK(hipMemsetAsync(m.grad_flat, 0, m.n_params * sizeof(float), (hipStream_t)stream));
+    return PET_OK;
+}
+
+int pet_model_get_grad(const pet_model_t* pm, const char* key, float* d_dst, int64_t numel, void* stream) {
+    PET_REQUIRE(pm && key && d_dst, PET_ERR_ARGUMENT, "null argument");
+    const Model& m = pm->m;
+    PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
+    auto it = m.raw.find(key);
+    PET_REQUIRE(it != m.raw.end() && it->second.second == numel, PET_ERR_ARGUMENT,
+                std::string("unknown parameter or size mismatch: ") + key);
+    PET_HIP_CHECK(hipMemcpyAsync(d_dst, m.grad_flat + m.grad_off.at(key), numel * sizeof(float),
+                                 hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PET_OK;
+}
+
+int64_t pet_train_workspace_bytes(const pet_model_t* pm, int64_t n_nodes, int64_t n_edges) {
+    if (!pm) return -1;
+    return forward_workspace_bytes(pm->m, n_nodes, n_edges, true);
+}
+
+int pet_backward_train(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
+                       const float* d_grad_atomic, float* d_grad_positions, float* d_grad_cells, void* stream) {
+    PET_REQUIRE(pm && pg && d_workspace && d_grad_atomic, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
+    return backward_train(pm->m, pg->g, d_workspace, workspace_bytes, d_grad_atomic, d_grad_positions, d_grad_cells,
+                          (hipStream_t)stream);
+}
 
 int64_t pet_nl_workspace_bytes(int64_t n_atoms) { return nl_workspace_bytes(n_atoms); }
 

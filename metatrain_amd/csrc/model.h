@@ -59,6 +59,9 @@ struct Model {
     std::vector<void*> owned;  // device allocations to free
     bool finalized = false;
     int64_t n_params = 0;
+    // training (row a16): one flat gradient buffer, parameter `key` at grad_off[key] (upload order)
+    std::map<std::string, int64_t> grad_off;
+    float* grad_flat = nullptr;
 };
 
 // graph.hip
@@ -80,11 +83,13 @@ int nl_build(const float* d_pos, const float* h_cell, const int* h_pbc, int64_t 
              hipStream_t st);
 
 // pet_fwd.hip / pet_bwd.hip
-int64_t forward_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges);
+int64_t forward_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges, bool train = false);
 int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
             float* node_feat, float* edge_feat, hipStream_t st);
 int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* grad_atomic,
              float* grad_pos, float* grad_cells, hipStream_t st);
+int backward_train(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* grad_atomic,
+                   float* grad_pos, float* grad_cells, hipStream_t st);
 int backward_predict_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* grad_atomic,
                          float* g_node, float* g_edge, float* g_fc, hipStream_t st);
 int backward_features_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_node,
@@ -106,7 +111,7 @@ void trr_oproj_bwd(const float* dX1, const float* dOC, const Lin& out, float* dA
 void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wout, float* VG, float* X2,
               int64_t E, hipStream_t st);
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
-                  const Lin& wout, float* dX1, int64_t E, hipStream_t st);
+                  const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg = nullptr);
 
 // pet_attn.hip: preload variants of the attention kernels (NT <= 4); return false if not handled
 bool attn_fwd_preload(int nt, const float* QKV, const Graph& g, float* AO, float scale, hipStream_t st);

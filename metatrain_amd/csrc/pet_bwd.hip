@@ -11,6 +11,7 @@
 #include "common.h"
 #include "model.h"
 #include "pet_ws.h"
+#include "train.h"
 #include "tile.h"
 
 namespace pet {
@@ -64,7 +65,9 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
                                                         const float4* __restrict__ w2b, const float* __restrict__ wl,
                                                         const float* __restrict__ gA, const int* __restrict__ ctr,
                                                         const float* __restrict__ fc, const float* __restrict__ ypred,
-                                                        float* __restrict__ dfc, float* __restrict__ dXout, int64_t R) {
+                                                        float* __restrict__ dfc, float* __restrict__ dXout, int64_t R,
+                                                        float* __restrict__ t_s1, float* __restrict__ t_da2,
+                                                        float* __restrict__ t_da1, float* __restrict__ t_s2y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDK = lds_ld(K);
     float* A = smem;
@@ -91,14 +94,24 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
     f32x16 a1[2], acc[2];
     acc_fill_bias<2>(a1, b0, 64 * w.ch, w.lane);
     gemm_acc<K, 2>(A + w.rb * 32 * LDK, LDK, w0f, K / 8, 0, 2 * w.ch, a1, w.lane);
-    acc_foreach<2>(a1, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) { S[r * LD128 + c] = siluf_(v); });
+    acc_foreach<2>(a1, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
+        const float s1 = siluf_(v);
+        S[r * LD128 + c] = s1;
+        if (t_s1 && row0 + r < R) t_s1[(row0 + r) * DH + c] = s1;
+    });
     __syncthreads();
     acc_fill_bias<2>(acc, b2, 64 * w.ch, w.lane);
     gemm_acc<128, 2>(S + w.rb * 32 * LD128, LD128, w2f, 16, 0, 2 * w.ch, acc, w.lane);
     __syncthreads();
     // da2 = gy * wl * silu'(a2)
-    acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane,
-                   [&](int r, int c, float v) { S[r * LD128 + c] = gy[r] * wl[c] * silu_grad_(v); });
+    acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
+        const float d2 = gy[r] * wl[c] * silu_grad_(v);
+        S[r * LD128 + c] = d2;
+        if (t_da2 && row0 + r < R) {
+            t_da2[(row0 + r) * DH + c] = d2;
+            t_s2y[(row0 + r) * DH + c] = gy[r] * siluf_(v);
+        }
+    });
     __syncthreads();
     acc_fill_bias<2>(acc, nullptr, 0, w.lane);
     gemm_acc<128, 2>(S + w.rb * 32 * LD128, LD128, w2b, 16, 0, 2 * w.ch, acc, w.lane);  // ds1 = da2 W2
@@ -108,7 +121,9 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int rr = w.rb * 32 + acc_row(r, w.lane), cc = 64 * w.ch + 32 * t + (w.lane & 31);
-            S[rr * LD128 + cc] = acc[t][r] * silu_grad_(a1[t][r]);  // da1
+            const float d1 = acc[t][r] * silu_grad_(a1[t][r]);
+            S[rr * LD128 + cc] = d1;  // da1
+            if (t_da1 && row0 + rr < R) t_da1[(row0 + rr) * DH + cc] = d1;
         }
     __syncthreads();
     constexpr int NTO = K / 64;  // output columns K split over the two column halves
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(NTHREADS) void k_comb_bwd(const float* __restrict__
                                                         const int* __restrict__ rev, const float* __restrict__ LNS,
                                                         const float* __restrict__ CA, const float* __restrict__ ln_g,
                                                         const float4* __restrict__ w2b, const float4* __restrict__ w0b,
-                                                        float* __restrict__ dcat, int64_t E) {
+                                                        float* __restrict__ dcat, int64_t E, float* __restrict__ t_da) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Lo = smem;
     float* Hi = smem + BM * LD128;
@@ -143,7 +158,9 @@ __global__ __launch_bounds__(NTHREADS) void k_comb_bwd(const float* __restrict__
     acc_foreach<4>(t1, w.rb, 0, w.lane, [&](int r, int c, float v) {
         const int64_t row = row0 + r;
         const float a = row < E ? CA[row * (2 * D) + 128 * w.ch + c] : 0.f;
-        Sdst[r * LD128 + c] = v * silu_grad_(a);
+        const float da = v * silu_grad_(a);
+        Sdst[r * LD128 + c] = da;
+        if (t_da && row < E) t_da[row * (2 * D) + 128 * w.ch + c] = da;
     });
     __syncthreads();
     acc_fill_bias<4>(t1, nullptr, 0, w.lane);
@@ -213,7 +230,7 @@ template <int K, int HID>
 __global__ __launch_bounds__(NTHREADS) void k_swiglu_bwd(const float* __restrict__ dY, const float* __restrict__ Xin,
                                                           const float* __restrict__ VG, const float* __restrict__ gamma,
                                                           const float4* __restrict__ woutb, const float4* __restrict__ winb,
-                                                          float* __restrict__ dXout, int64_t R) {
+                                                          float* __restrict__ dXout, int64_t R, float* __restrict__ t_dvg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDK = lds_ld(K);
     constexpr int NTO = K / 64;
@@ -252,7 +269,9 @@ __global__ __launch_bounds__(NTHREADS) void k_swiglu_bwd(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int rr = w.rb * 32 + acc_row(r, w.lane), cc = 64 * w.ch + 32 * t + (w.lane & 31);
-                U[rr * LD128 + cc] = du[t][r] * sg[t][r];  // dv
+                const float dvv = du[t][r] * sg[t][r];
+                U[rr * LD128 + cc] = dvv;  // dv
+                if (t_dvg && row0 + rr < R) t_dvg[(row0 + rr) * (2 * HID) + 128 * hc + cc] = dvv;
             }
         __syncthreads();
         gemm_acc<128, NTO>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, 16 * hc, NTO * w.ch, dn, w.lane);
@@ -262,7 +281,9 @@ __global__ __launch_bounds__(NTHREADS) void k_swiglu_bwd(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int rr = w.rb * 32 + acc_row(r, w.lane), cc = 64 * w.ch + 32 * t + (w.lane & 31);
-                U[rr * LD128 + cc] = du[t][r] * vv[t][r] * sigmoid_grad_from(sg[t][r]);  // dg
+                const float dgv = du[t][r] * vv[t][r] * sigmoid_grad_from(sg[t][r]);
+                U[rr * LD128 + cc] = dgv;  // dg
+                if (t_dvg && row0 + rr < R) t_dvg[(row0 + rr) * (2 * HID) + HID + 128 * hc + cc] = dgv;
             }
         __syncthreads();
         gemm_acc<128, NTO>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, HID / 8 + 16 * hc, NTO * w.ch, dn, w.lane);
@@ -567,7 +588,8 @@ template <bool FIRST>
 __global__ __launch_bounds__(NTHREADS) void k_compress_bwd(const float* __restrict__ dXe, const float* __restrict__ a0,
                                                             const float4* __restrict__ w2b, const float* __restrict__ wct,
                                                             const float4* __restrict__ w0cb, float* __restrict__ dgeo,
-                                                            float* __restrict__ dM /* in/out, !FIRST */, int64_t E) {
+                                                            float* __restrict__ dM /* in/out, !FIRST */, int64_t E,
+                                                            float* __restrict__ t_da0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const WaveId w;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
@@ -579,7 +601,9 @@ __global__ __launch_bounds__(NTHREADS) void k_compress_bwd(const float* __restri
     __syncthreads();
     acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
         const int64_t row = row0 + r;
-        smem[r * LD128 + c] = row < E ? v * silu_grad_(a0[row * D + c]) : 0.f;
+        const float d0v = row < E ? v * silu_grad_(a0[row * D + c]) : 0.f;
+        smem[r * LD128 + c] = d0v;
+        if (t_da0 && row < E) t_da0[row * D + c] = d0v;
     });
     __syncthreads();
     {   // dgeo[row][k] += sum_c da0[row][c] * Wc[c][k]; 4 threads per row, thread q -> component q
@@ -719,7 +743,8 @@ static int check_full_list(const Graph& g, hipStream_t st) {
 }
 
 // Stage P: adjoint of PETBackend.predict. seeds gA [N] -> w.dH [N,DN], w.dM [E,D], w.dfc [E]
-int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* gA, hipStream_t st) {
+int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* gA, hipStream_t st,
+                     Trainer* tr = nullptr) {
     const int64_t N = g.n_nodes, E = g.n_edges;
     const int gE = cdiv(E, BM), gN = cdiv(N, BM);
     const size_t lds2 = 2 * BM * LD128 * 4;
@@ -730,17 +755,23 @@ int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* 
         ProfScope ps("head_edge_bwd", st, fE * 2.0 * (D * DH + DH * DH + DH));
         k_head_bwd<128, true><<<gE, NTHREADS, lds2 + 256, st>>>(last.Mout, m.eh0.fwd, m.eh0.b, m.eh2.fwd, m.eh2.b,
                                                                m.eh0.bwd, m.eh2.bwd, m.ell_w, gA, g.ctr, g.fc,
-                                                               w.ypred_e, w.dfc, w.dM, E);
+                                                               w.ypred_e, w.dfc, w.dM, E, tr ? w.hs1 : nullptr,
+                                                               tr ? w.hda2 : nullptr, tr ? w.hda1 : nullptr,
+                                                               tr ? w.hs2y : nullptr);
+        if (tr) tr->heads(true, last.Mout, D, E, gA);
     }
     {
-        const SideStream& ss = side_stream();
+        SideStream ss = side_stream();
+        if (tr) ss.enabled = false;  // the weight-gradient scratch is shared: one stream
         const hipStream_t s2 = ss.stream(st);
         ss.fork(st);
         {
             ProfScope ps("head_node_bwd", s2, fN * 2.0 * (DN * DH + DH * DH + DH));
             k_head_bwd<256, false><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + 256, s2>>>(
                 last.Hout, m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nh0.bwd, m.nh2.bwd, m.nll_w, gA, nullptr,
-                nullptr, nullptr, nullptr, w.dH, N);
+                nullptr, nullptr, nullptr, w.dH, N, tr ? w.hs1 : nullptr, tr ? w.hda2 : nullptr,
+                tr ? w.hda1 : nullptr, tr ? w.hs2y : nullptr);
+            if (tr) tr->heads(false, last.Hout, DN, N, gA);
         }
         ss.join(st);
     }
@@ -749,7 +780,7 @@ int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* 
 }
 
 // Stage F: adjoint of PETBackend.calculate_features. (w.dH, w.dM) -> w.dgeo [E,4], w.dbias [E]
-int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t st) {
+int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t st, Trainer* tr = nullptr) {
     const int64_t N = g.n_nodes, E = g.n_edges, R = E + N;
     if (E == 0) return PET_OK;
     int rc = check_full_list(g, st);
@@ -772,7 +803,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     float* dX_alt = w.dX2;
     // node-feature adjoint chain on the side stream: it only meets the edge chain at output_linear^T
     // (needs dOC) and at the centre rows of the token gradient (k_center_bwd)
-    const SideStream& ss = side_stream();
+    SideStream ss = side_stream();
+    if (tr) ss.enabled = false;
     const hipStream_t s2 = ss.stream(st);
     ss.fork(st);  // the seeds in w.dH / w.dM were produced on the main stream
     for (int gi = m.h.num_gnn_layers - 1; gi >= 0; gi--) {
@@ -781,7 +813,16 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         {
             ProfScope ps("comb_bwd", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D));
             k_comb_bwd<<<gE, NTHREADS, lds2, st>>>(w.dM, B.XF, g.rev, B.LNS, B.CA, G.ln_g, G.comb2.bwd, G.comb0.bwd,
-                                                   w.dcat, E);
+                                                   w.dcat, E, tr ? w.dCA : nullptr);
+            if (tr) {
+                const std::string gs = std::to_string(gi);
+                tr->linear("combination_mlps." + gs + ".2", D, 2 * D, {w.dM, nullptr, 0, D},
+                           {B.CA, 2 * D, 0, nullptr, nullptr}, 3, E);
+                tr->linear_after_norm("combination_mlps." + gs + ".0", G.comb0.w, 2 * D, 2 * D,
+                                      {w.dCA, nullptr, 0, 2 * D}, {B.XF, D, 0, g.rev, B.LNS}, 4, E,
+                                      "combination_norms." + gs + ".weight", G.ln_g,
+                                      "combination_norms." + gs + ".bias", G.ln_b);
+            }
         }
         {
             ProfScope ps("dxf", st, 0.0);
@@ -790,18 +831,34 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         for (int a = m.h.num_attention_layers - 1; a >= 0; a--) {
             const AttnLayerW& A = G.attn[a];
             const AttnBufs& Ab = B.attn[a];
+            const std::string lp = "gnn_layers." + std::to_string(gi) + ".trans.layers." + std::to_string(a);
             // dX (edge rows) = grad wrt the edge MLP output; dH = grad wrt Hn
             {
                 ProfScope ps("node_bwd", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
                 k_swiglu_bwd<256, DNF><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
-                    dH, Ab.H1, Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N);
+                    dH, Ab.H1, Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N, tr ? w.dVGn : nullptr);
                 k_expand_bwd<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(dH_alt, A.ce.bwd, w.dOC, N);
+                if (tr) {
+                    tr->linear(lp + ".center_mlp.w_out", DN, DNF, {dH, nullptr, 0, DN},
+                               {Ab.VGn, 2 * DNF, DNF, nullptr, nullptr}, 2, N);
+                    tr->linear_after_norm(lp + ".center_mlp.w_in", A.cmlp_in.w, 2 * DNF, DN,
+                                          {w.dVGn, nullptr, 0, 2 * DNF}, {Ab.H1, DN, 0, nullptr, nullptr}, 1, N,
+                                          lp + ".norm_center_features.weight", A.g_center);
+                    tr->linear(lp + ".center_expansion", DN, D, {dH_alt, nullptr, 0, DN},
+                               {Ab.OC, D, 0, nullptr, nullptr}, 0, N);
+                }
             }
             {
                 ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
-                if (trr) trr_emlp_bwd(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_in, A.mlp_out, dX_alt, E, st);
+                if (trr) trr_emlp_bwd(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_in, A.mlp_out, dX_alt, E, st, tr ? w.dVG : nullptr);
                 else k_swiglu_bwd<128, DFF><<<gE, NTHREADS, lds2, st>>>(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_out.bwd,
-                                                                        A.mlp_in.bwd, dX_alt, E);
+                                                                        A.mlp_in.bwd, dX_alt, E, tr ? w.dVG : nullptr);
+                if (tr) {
+                    tr->linear(lp + ".mlp.w_out", D, DFF, {dX, nullptr, 0, D}, {Ab.VG, 2 * DFF, DFF, nullptr, nullptr},
+                               2, E);
+                    tr->linear_after_norm(lp + ".mlp.w_in", A.mlp_in.w, 2 * DFF, D, {w.dVG, nullptr, 0, 2 * DFF},
+                                          {Ab.X1, D, 0, nullptr, nullptr}, 1, E, lp + ".norm_mlp.weight", A.g_mlp);
+                }
             }
             ss.join(st);  // dOC ready
             // dX_alt (edge rows) = dX1, dH_alt = dH1
@@ -809,6 +866,9 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 ProfScope ps("oproj_bwd", st, fR * 2.0 * D * D);
                 if (trr) trr_oproj_bwd(dX_alt, w.dOC, A.out, w.dAO, E, R, st);
                 else k_oproj_bwd<<<gR, NTHREADS, lds1, st>>>(dX_alt, w.dOC, A.out.bwd, w.dAO, E, R);
+                if (tr)
+                    tr->linear(lp + ".attention.output_linear", D, D, {dX_alt, w.dOC, E, D},
+                               {Ab.AO, D, 0, nullptr, nullptr}, 0, R);
             }
             {
                 ProfScope ps("attn_bwd", st, 2.0 * 4.0 * D * g_sum_t2(g), fR * 4.0 * (3 * D + D + 3 * D));
@@ -821,6 +881,9 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                     default: launch_attn_bwd<8>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;
                 }
             }
+            if (tr)
+                tr->linear_after_norm(lp + ".attention.input_linear", A.qkv.w, 3 * D, D, {w.dQKV, nullptr, 0, 3 * D},
+                                      {Ab.X, D, 0, nullptr, nullptr}, 1, R, lp + ".norm_attention.weight", A.g_attn);
             {
                 ProfScope ps("qkv_bwd", st, fR * 2.0 * D * 3 * D);
                 if (trr) trr_qkv_bwd(w.dQKV, Ab.X, A.g_attn, A.qkv, dX_alt, dX, E, R, st);
@@ -830,6 +893,9 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             {
                 ProfScope ps("center_bwd", s2, fN * 2.0 * DN * D);
                 k_center_bwd<<<gN, NTHREADS, lds1, s2>>>(dX + E * D, dH_alt, A.cc.bwd, dH, N);
+                if (tr)
+                    tr->linear(lp + ".center_contraction", D, DN, {dX + E * D, nullptr, 0, D},
+                               {Ab.H, DN, 0, nullptr, nullptr}, 0, N);
             }
             // now dX (edge rows) = grad wrt this layer's input edge tokens, dH = grad wrt its input h
         }
@@ -837,14 +903,24 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             ProfScope ps("compress_bwd", st, fE * 2.0 * (D * D * (gi == 0 ? 3 : 4) + 4 * D));
             if (gi == 0)
                 k_compress_bwd<true><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct, nullptr, w.dgeo,
-                                                                 nullptr, E);
+                                                                 nullptr, E, tr ? w.da0 : nullptr);
             else
                 k_compress_bwd<false><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct,
-                                                                  G.compress0_msg.bwd, w.dgeo, w.dM, E);
+                                                                  G.compress0_msg.bwd, w.dgeo, w.dM, E,
+                                                                  tr ? w.da0 : nullptr);
+            if (tr) {
+                const std::string pre = "gnn_layers." + std::to_string(gi);
+                tr->linear(pre + ".compress.2", D, D, {dX, nullptr, 0, D}, {B.a0, D, 0, nullptr, nullptr}, 3, E);
+                tr->compress0(gi, w.da0, gi > 0 ? w.gnn[gi - 1].Mout : nullptr);
+            }
         }
         // w.dM now holds d/dMout of layer gi-1 (pass-through + compress adjoint)
     }
     ss.join(st);
+    if (tr) {
+        tr->embeddings(dH, w.dM);
+        if (tr->err) return tr->err;
+    }
     k_dfc_attn<<<cdiv(E, 256), 256, 0, st>>>(g.fc, dbias_h, w.dbias, E);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
@@ -925,6 +1001,26 @@ int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const f
         if ((rc = backward_features(m, g, w, st))) return rc;
     }
     return backward_geometry(m, g, w, w.dgeo, w.dfc, w.dbias, gpos, gcell, st);
+}
+
+// Training reverse pass (energy term): dL/dtheta accumulated into the model's flat gradient
+// buffer for the seeds gA = dL/d(atomic prediction), plus dL/dR (and dL/dcell) when requested.
+// Needs a forward run with save_for_backward = 2 on a training workspace.
+int backward_train(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA, float* gpos,
+                   float* gcell, hipStream_t st) {
+    PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
+    Workspace w;
+    carve_workspace(m, g.n_nodes, g.n_edges, ws, w, true);
+    PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "workspace too small for training");
+    if (g.n_nodes == 0) return PET_OK;
+    PET_REQUIRE(g.n_edges > 0, PET_ERR_UNSUPPORTED, "training on a batch without any edge is not supported");
+    Trainer tr{m, g, w, m.grad_flat, st};
+    int rc;
+    if ((rc = backward_predict(m, g, w, gA, st, &tr))) return rc;
+    if ((rc = backward_features(m, g, w, st, &tr))) return rc;
+    if (tr.err) return tr.err;
+    if (gpos) return backward_geometry(m, g, w, w.dgeo, w.dfc, w.dbias, gpos, gcell, st);
+    return PET_OK;
 }
 
 }  // namespace pet

@@ -538,9 +538,9 @@ __global__ void k_atom_sum(const float* __restrict__ ynode, const float* __restr
 // ---------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------
-int64_t forward_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges) {
+int64_t forward_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges, bool train) {
     Workspace w;
-    carve_workspace(m, n_nodes, n_edges, nullptr, w);
+    carve_workspace(m, n_nodes, n_edges, nullptr, w, train);
     return (int64_t)w.bytes;
 }
 
@@ -562,11 +562,10 @@ double g_sum_t2(const Graph& g) {
 int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
             float* node_feat, float* edge_feat, hipStream_t st) {
     Workspace w;
-    carve_workspace(m, g.n_nodes, g.n_edges, ws, w);
+    carve_workspace(m, g.n_nodes, g.n_edges, ws, w, save == 2);
     PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "forward workspace too small");
     const int64_t N = g.n_nodes, E = g.n_edges, R = E + N;
     if (N == 0) return PET_OK;
-    (void)save;  // everything the backward needs is always kept (see pet_ws.h)
     const int nt = attn_tiles(g);
     PET_REQUIRE(nt <= 8, PET_ERR_UNSUPPORTED,
                 "more than 127 neighbours per atom (" + std::to_string(g.max_nbr) + ") is not supported yet");
@@ -625,26 +624,26 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
             }
             {
                 ProfScope ps("attn_fwd", st, attn_flops, fR * 4.0 * (3 * D + D));
-                if (!(trr && attn_fwd_preload(nt, Ab.QKV, g, w.AO, scale, st))) switch (nt) {
-                    case 1: launch_attn_fwd<1>(Ab.QKV, g, w.AO, scale, st); break;
-                    case 2: launch_attn_fwd<2>(Ab.QKV, g, w.AO, scale, st); break;
-                    case 3: launch_attn_fwd<3>(Ab.QKV, g, w.AO, scale, st); break;
-                    case 4: launch_attn_fwd<4>(Ab.QKV, g, w.AO, scale, st); break;
-                    case 5: case 6: launch_attn_fwd<6>(Ab.QKV, g, w.AO, scale, st); break;
-                    default: launch_attn_fwd<8>(Ab.QKV, g, w.AO, scale, st); break;
+                if (!(trr && attn_fwd_preload(nt, Ab.QKV, g, Ab.AO, scale, st))) switch (nt) {
+                    case 1: launch_attn_fwd<1>(Ab.QKV, g, Ab.AO, scale, st); break;
+                    case 2: launch_attn_fwd<2>(Ab.QKV, g, Ab.AO, scale, st); break;
+                    case 3: launch_attn_fwd<3>(Ab.QKV, g, Ab.AO, scale, st); break;
+                    case 4: launch_attn_fwd<4>(Ab.QKV, g, Ab.AO, scale, st); break;
+                    case 5: case 6: launch_attn_fwd<6>(Ab.QKV, g, Ab.AO, scale, st); break;
+                    default: launch_attn_fwd<8>(Ab.QKV, g, Ab.AO, scale, st); break;
                 }
             }
             {
                 ProfScope ps("oproj", st, fR * 2.0 * D * D);
-                if (trr) trr_oproj(w.AO, Ab.X, A.out, Ab.X1, w.OC, E, R, st);
-                else k_oproj<<<gR, NTHREADS, lds1, st>>>(w.AO, Ab.X, A.out.fwd, A.out.b, Ab.X1, w.OC, E, R);
+                if (trr) trr_oproj(Ab.AO, Ab.X, A.out, Ab.X1, Ab.OC, E, R, st);
+                else k_oproj<<<gR, NTHREADS, lds1, st>>>(Ab.AO, Ab.X, A.out.fwd, A.out.b, Ab.X1, Ab.OC, E, R);
             }
             // node chain (side stream): node update of this layer, then the centre token of the next
             ss.fork(st);
             {
                 ProfScope ps("node", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
                 k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
-                    Ab.H, w.OC, A.ce.fwd, A.ce.b, A.g_center, A.cmlp_in.fwd, A.cmlp_in.b, A.cmlp_out.fwd,
+                    Ab.H, Ab.OC, A.ce.fwd, A.ce.b, A.g_center, A.cmlp_in.fwd, A.cmlp_in.b, A.cmlp_out.fwd,
                     A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
             }
             if (a + 1 < m.h.num_attention_layers) launch_center(gi, a + 1);

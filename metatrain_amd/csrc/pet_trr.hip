@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_emlp_t(const float* __restrict__ X1, co
 __global__ __launch_bounds__(256, 2) void k_emlp_bwd_t(const float* __restrict__ dY, const float* __restrict__ X1,
                                                      const float* __restrict__ VG, const float* __restrict__ gamma,
                                                      const float4* __restrict__ woutb, const float4* __restrict__ winb,
-                                                     float* __restrict__ dX1, int64_t E) {
+                                                     float* __restrict__ dX1, int64_t E, float* __restrict__ t_dvg) {
     TRR_PROLOGUE(E);
     float4 dy[16];
     load_rowfrag<16>(dy, dY, row, D, L.h);
@@ -196,6 +196,10 @@ __global__ __launch_bounds__(256, 2) void k_emlp_bwd_t(const float* __restrict__
             dv[q] = make_float4(d.x * sx, d.y * sy, d.z * sz, d.w * sw);
             dg[q] = make_float4(d.x * vv.x * sx * (1.f - sx), d.y * vv.y * sy * (1.f - sy),
                                 d.z * vv.z * sz * (1.f - sz), d.w * vv.w * sw * (1.f - sw));
+            if (t_dvg && valid) {
+                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) = dv[q];
+                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) = dg[q];
+            }
         }
         gemm_t<4, 4>(winb, 2 * DFF / 8, 4 * hc, 0, dv, dn, L.lane);
         gemm_t<4, 4>(winb, 2 * DFF / 8, DFF / 8 + 4 * hc, 0, dg, dn, L.lane);
@@ -244,8 +248,8 @@ void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wo
     k_emlp_t<<<grid_rows(E), 256, 0, st>>>(X1, gamma, win.fwd, win.b, wout.fwd, wout.b, VG, X2, E);
 }
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
-                  const Lin& wout, float* dX1, int64_t E, hipStream_t st) {
-    k_emlp_bwd_t<<<grid_rows(E), 256, 0, st>>>(dY, X1, VG, gamma, wout.bwd, win.bwd, dX1, E);
+                  const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg) {
+    k_emlp_bwd_t<<<grid_rows(E), 256, 0, st>>>(dY, X1, VG, gamma, wout.bwd, win.bwd, dX1, E, t_dvg);
 }
 
 }  // namespace pet

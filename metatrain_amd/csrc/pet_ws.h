@@ -18,6 +18,8 @@ struct AttnBufs {
     float* Hn = nullptr;   // [N, DN] node features leaving the layer
     float* H1 = nullptr;   // [N, DN] after centre expansion residual
     float* VGn = nullptr;  // [N, 2*DNF]
+    float* AO = nullptr;   // [(E+N), D] attention output before output_linear (shared temp unless training)
+    float* OC = nullptr;   // [N, D] centre rows of output_linear (shared temp unless training)
 };
 
 struct GnnBufs {
@@ -55,10 +57,23 @@ struct Workspace {
     float* delta = nullptr;   // [(E+N), NHEAD]
     float* lse = nullptr;     // [(E+N), NHEAD]
     float* dv = nullptr;      // [E, 4] d/d(edge vector)
+    // training only (row a16): adjoint operands the weight-gradient GEMMs need
+    float* dVG = nullptr;     // [E, 2*DFF]  d(value | gate) of the edge MLP
+    float* dVGn = nullptr;    // [N, 2*DNF]
+    float* dCA = nullptr;     // [E, 2D]     d(combination MLP pre-activation)
+    float* da0 = nullptr;     // [E, D]      d(compress.0 pre-activation)
+    float* hs1 = nullptr;     // [max(E,N), DH] head temporaries: silu(a1), d a2, d a1, gy * silu(a2)
+    float* hda2 = nullptr;
+    float* hda1 = nullptr;
+    float* hs2y = nullptr;
+    float* gmat = nullptr;    // [1024 x 256] reduced weight-gradient block
+    float* gvec = nullptr;    // [32768]
+    float* partial = nullptr; // split-K partials
+    size_t partial_floats = 0;
     size_t bytes = 0;
 };
 
-inline void carve_workspace(const Model& m, int64_t N, int64_t E, void* base, Workspace& w) {
+inline void carve_workspace(const Model& m, int64_t N, int64_t E, void* base, Workspace& w, bool train = false) {
     Carver c(base);
     const int64_t R = E + N;
     const int64_t Ea = E > 0 ? E : 1, Na = N > 0 ? N : 1, Ra = R > 0 ? R : 1;
@@ -112,6 +127,28 @@ inline void carve_workspace(const Model& m, int64_t N, int64_t E, void* base, Wo
     w.delta = c.take<float>(Ra * NHEAD);
     w.lse = c.take<float>(Ra * NHEAD);
     w.dv = c.take<float>(Ea * 4);
+    // everything above is identical with and without `train`, so an inference backward can run on
+    // a workspace carved for training
+    for (auto& G : w.gnn)
+        for (auto& A : G.attn) {
+            A.AO = train ? c.take<float>(Ra * D) : w.AO;
+            A.OC = train ? c.take<float>(Na * D) : w.OC;
+        }
+    if (train) {
+        const int64_t Ma = Ea > Na ? Ea : Na;
+        w.dVG = c.take<float>(Ea * 2 * DFF);
+        w.dVGn = c.take<float>(Na * 2 * DNF);
+        w.dCA = c.take<float>(Ea * 2 * D);
+        w.da0 = c.take<float>(Ea * D);
+        w.hs1 = c.take<float>(Ma * DH);
+        w.hda2 = c.take<float>(Ma * DH);
+        w.hda1 = c.take<float>(Ma * DH);
+        w.hs2y = c.take<float>(Ma * DH);
+        w.gmat = c.take<float>(1024 * 256);
+        w.gvec = c.take<float>(32768);
+        w.partial_floats = (size_t)48 << 20;  // 192 MB of split-K partials
+        w.partial = c.take<float>(w.partial_floats);
+    }
     w.bytes = c.off;
 }
 

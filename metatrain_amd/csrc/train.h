@@ -1,0 +1,38 @@
+// Parameter gradients (first order) for the training row: the reverse pass of
+// pet_bwd.hip calls these hooks while the adjoint operands of each stage are still in its
+// temporaries; every hook is one or a few split-K weight-gradient GEMMs (wgrad.h).
+#pragma once
+#include <string>
+
+#include "common.h"
+#include "model.h"
+#include "pet_ws.h"
+
+namespace pet {
+
+struct Trainer {
+    const Model& m;
+    const Graph& g;
+    Workspace& w;
+    float* grads;  // flat, laid out like Model::grad_off
+    hipStream_t st;
+    int err = PET_OK;
+
+    float* gp(const std::string& key) const;  // destination of one parameter's gradient
+
+    // generic y = x W^T + b: dW [n_out, k_in] (+ db) from dY rows and rebuilt X rows
+    struct Y { const float* p0; const float* p1; int64_t split; int ld; };
+    struct X { const float* p; int ld; int hid; const int* rev; const float* lns; };
+    // xmode: 0 plain, 1 rms-hat, 2 swiglu(v|g), 3 silu, 4 layernorm-hat([x; x[rev]])
+    void linear(const std::string& key, int n_out, int k_in, Y y, X x, int xmode, int64_t n_rows);
+    // same, X normalised by a norm with weight `gamma_key` (and bias `beta_key` for LayerNorm)
+    void linear_after_norm(const std::string& key, const float* W, int n_out, int k_in, Y y, X x, int xmode,
+                           int64_t n_rows, const std::string& gamma_key, const float* gamma,
+                           const std::string& beta_key = "", const float* beta = nullptr);
+
+    void heads(bool edge, const float* Xin, int k_in, int64_t n_rows, const float* gA);
+    void embeddings(const float* dH0, const float* dM0);
+    void compress0(int gi, const float* da0, const float* Min);
+};
+
+}  // namespace pet

@@ -1,0 +1,292 @@
+// First-order parameter gradients of the PET backend (training row a16, energy term):
+// weight-gradient GEMMs and the small reductions around them. See train.h / wgrad.h.
+#include "train.h"
+
+#include <vector>
+
+#include "wgrad.h"
+
+namespace pet {
+
+float* Trainer::gp(const std::string& key) const {
+    auto it = m.grad_off.find(key);
+    return it == m.grad_off.end() ? nullptr : grads + it->second;
+}
+
+#define TR_CHECK(expr)                                         \
+    do {                                                       \
+        hipError_t _e = (expr);                                \
+        if (_e != hipSuccess && err == PET_OK) {               \
+            err = PET_ERR_HIP;                                 \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+        }                                                      \
+    } while (0)
+
+// out[n * ldo + col0 + k] (+)= sum_s partial[s][n][k]
+__global__ void k_reduce_2d(const float* __restrict__ partial, int nsplit, int n_out, int kb, float* __restrict__ out,
+                            int ldo, int col0, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tot = (int64_t)n_out * kb;
+    if (i >= tot) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; k++) s += partial[(size_t)k * tot + i];
+    float* o = out + (i / kb) * ldo + col0 + (i % kb);
+    *o = accumulate ? *o + s : s;
+}
+
+// norm feeding a Linear (y = xhat gamma + beta):  dW = G gamma + db (x) beta,  dgamma[k] = sum_n W[n][k] G[n][k],
+// LayerNorm only: dbeta[k] = sum_n W[n][k] db[n].   One thread per column k.
+__global__ void k_norm_fixup(const float* __restrict__ G, const float* __restrict__ W, const float* __restrict__ gamma,
+                             const float* __restrict__ beta, const float* __restrict__ db, int n_out, int k_in, float* __restrict__ dW,
+                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= k_in) return;
+    const float gk = gamma[k], bk = dbeta ? beta[k] : 0.f;
+    float sg = 0.f, sb = 0.f;
+    for (int n = 0; n < n_out; n++) {
+        const float gv = G[(size_t)n * k_in + k], wv = W[(size_t)n * k_in + k];
+        dW[(size_t)n * k_in + k] += gv * gk + (dbeta ? db[n] * bk : 0.f);
+        sg += wv * gv;
+        if (dbeta) sb += wv * db[n];
+    }
+    dgamma[k] += sg;
+    if (dbeta) dbeta[k] += sb;
+}
+
+// column sums of a row-major [R, C] buffer, two stages; also sums with a per-row species index
+__global__ void k_colsum_partial(const float* __restrict__ buf, int64_t n_rows, int C, float* __restrict__ partial) {
+    const int c = threadIdx.x;
+    const int nsplit = gridDim.x;
+    const int64_t per = (n_rows + nsplit - 1) / nsplit;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(n_rows, r0 + per);
+    float s = 0.f;
+    if (c < C)
+        for (int64_t r = r0; r < r1; r++) s += buf[r * C + c];
+    if (c < C) partial[(size_t)blockIdx.x * C + c] = s;
+}
+
+// partial[split][species][c] = sum over the split's rows with idx[row] == species
+__global__ void k_species_sum_partial(const float* __restrict__ buf, const int* __restrict__ idx, int64_t n_rows,
+                                      int C, int ns, float* __restrict__ partial) {
+    extern __shared__ float acc[];  // [ns][C]
+    const int c = threadIdx.x;
+    for (int i = threadIdx.x; i < ns * C; i += blockDim.x) acc[i] = 0.f;
+    __syncthreads();
+    const int nsplit = gridDim.x;
+    const int64_t per = (n_rows + nsplit - 1) / nsplit;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(n_rows, r0 + per);
+    if (c < C)
+        for (int64_t r = r0; r < r1; r++) acc[idx[r] * C + c] += buf[r * C + c];  // column c is private to this thread
+    __syncthreads();
+    for (int i = threadIdx.x; i < ns * C; i += blockDim.x) partial[(size_t)blockIdx.x * ns * C + i] = acc[i];
+}
+
+// dWc[n][c] = sum_rows da0[row][n] * geo[row][c]   (c < 4), partial per split
+__global__ void k_geo_wgrad_partial(const float* __restrict__ da0, const float4* __restrict__ geo, int64_t n_rows,
+                                    float* __restrict__ partial) {
+    const int n = threadIdx.x;  // 128 threads
+    const int nsplit = gridDim.x;
+    const int64_t per = (n_rows + nsplit - 1) / nsplit;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(n_rows, r0 + per);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t r = r0; r < r1; r++) {
+        const float d = da0[r * D + n];
+        const float4 gv = geo[r];
+        s.x += d * gv.x; s.y += d * gv.y; s.z += d * gv.z; s.w += d * gv.w;
+    }
+    reinterpret_cast<float4*>(partial)[(size_t)blockIdx.x * D + n] = s;
+}
+
+__global__ void k_edge_gy_sum_partial(const float* __restrict__ gA, const int* __restrict__ ctr,
+                                      const float* __restrict__ fc, int64_t n_rows, float* __restrict__ partial) {
+    // sum_p gA[ctr[p]] * fc[p]  (edge last-layer bias gradient); one block = one split, LDS tree
+    __shared__ float red[256];
+    const int nsplit = gridDim.x;
+    const int64_t per = (n_rows + nsplit - 1) / nsplit;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(n_rows, r0 + per);
+    float s = 0.f;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) s += ctr ? gA[ctr[r]] * fc[r] : gA[r];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+template <int KB, int XMODE>
+static void launch_k_wgrad(const WgradArgs& a, int nb, int nsplit, hipStream_t st) {
+    const size_t lds = (size_t)WG_RB * (132 + KB + 4) * sizeof(float);
+    k_wgrad<KB, XMODE><<<dim3(nb, nsplit), NTHREADS, lds, st>>>(a);
+}
+
+// dW block [n_out, k_in] into dst (row stride ldw) and, if db_dst, the bias gradient
+static void wgrad_core(Trainer& t, int n_out, int k_in, Trainer::Y y, Trainer::X x, int xmode, int64_t n_rows,
+                       float* dst, int ldw, float* db_dst, bool accumulate) {
+    if (n_rows <= 0 || t.err) return;
+    const int nb = n_out / 128;
+    const int KB = (xmode == 1 || xmode == 4) ? k_in : 128;
+    int nsplit = 1024 / nb;
+    const int64_t max_by_rows = (n_rows + WG_RB - 1) / WG_RB;
+    if (nsplit > max_by_rows) nsplit = (int)max_by_rows;
+    while ((size_t)nsplit * n_out * (KB + 1) > t.w.partial_floats && nsplit > 1) nsplit /= 2;
+    float* pb = t.w.partial + (size_t)nsplit * n_out * KB;
+    for (int k0 = 0; k0 < k_in; k0 += KB) {
+        WgradArgs a;
+        a.y0 = y.p0; a.y1 = y.p1; a.y_split = y.split; a.y_ld = y.ld; a.y_col0 = 0;
+        a.x0 = x.p; a.x_ld = x.ld; a.x_col0 = k0; a.x_hid = x.hid; a.rev = x.rev; a.lns = x.lns;
+        a.n_rows = n_rows; a.partial = t.w.partial; a.partial_b = (k0 == 0 && db_dst) ? pb : nullptr; a.n_out = n_out;
+        if (KB == 128) {
+            switch (xmode) {
+                case 0: launch_k_wgrad<128, 0>(a, nb, nsplit, t.st); break;
+                case 1: launch_k_wgrad<128, 1>(a, nb, nsplit, t.st); break;
+                case 2: launch_k_wgrad<128, 2>(a, nb, nsplit, t.st); break;
+                case 3: launch_k_wgrad<128, 3>(a, nb, nsplit, t.st); break;
+                default: t.err = PET_ERR_ARGUMENT; return;
+            }
+        } else {
+            if (xmode == 1) launch_k_wgrad<256, 1>(a, nb, nsplit, t.st);
+            else if (xmode == 4) launch_k_wgrad<256, 4>(a, nb, nsplit, t.st);
+            else { t.err = PET_ERR_ARGUMENT; return; }
+        }
+        const int64_t tot = (int64_t)n_out * KB;
+        k_reduce_2d<<<cdiv(tot, 256), 256, 0, t.st>>>(t.w.partial, nsplit, n_out, KB, dst, ldw, k0, accumulate ? 1 : 0);
+        if (k0 == 0 && db_dst)
+            k_reduce_2d<<<cdiv(n_out, 256), 256, 0, t.st>>>(pb, nsplit, n_out, 1, db_dst, 1, 0, accumulate ? 1 : 0);
+    }
+}
+
+void Trainer::linear(const std::string& key, int n_out, int k_in, Y y, X x, int xmode, int64_t n_rows) {
+    float* dW = gp(key + ".weight");
+    float* db = gp(key + ".bias");
+    if (!dW) { err = PET_ERR_ARGUMENT; set_error("no gradient slot for " + key); return; }
+    wgrad_core(*this, n_out, k_in, y, x, xmode, n_rows, dW, k_in, db, true);
+}
+
+void Trainer::linear_after_norm(const std::string& key, const float* W, int n_out, int k_in, Y y, X x, int xmode,
+                                int64_t n_rows, const std::string& gamma_key, const float* gamma,
+                                const std::string& beta_key, const float* beta) {
+    if (n_rows <= 0 || err) return;
+    float* dW = gp(key + ".weight");
+    float* db = gp(key + ".bias");
+    float* dgamma = gp(gamma_key);
+    float* dbeta = beta_key.empty() ? nullptr : gp(beta_key);
+    if (!dW || !db || !dgamma) { err = PET_ERR_ARGUMENT; set_error("no gradient slot for " + key); return; }
+    // G = dY^T xhat into scratch, bias gradient of THIS call into gvec (needed un-accumulated for dbeta)
+    wgrad_core(*this, n_out, k_in, y, x, xmode, n_rows, w.gmat, k_in, w.gvec, false);
+    k_norm_fixup<<<cdiv(k_in, 128), 128, 0, st>>>(w.gmat, W, gamma, beta, w.gvec, n_out, k_in, dW, dgamma, dbeta);
+    k_reduce_2d<<<cdiv(n_out, 256), 256, 0, st>>>(w.gvec, 1, n_out, 1, db, 1, 0, 1);
+}
+
+void Trainer::heads(bool edge, const float* Xin, int k_in, int64_t n_rows, const float* gA) {
+    if (n_rows <= 0 || err) return;
+    const std::string h = edge ? "edge_heads.@.0" : "node_heads.@.0";
+    const std::string l = edge ? "edge_last_layers.@.0.@" : "node_last_layers.@.0.@";
+    linear(h + ".0", DH, k_in, {w.hda1, nullptr, 0, DH}, {Xin, k_in, 0, nullptr, nullptr}, 0, n_rows);
+    linear(h + ".2", DH, DH, {w.hda2, nullptr, 0, DH}, {w.hs1, DH, 0, nullptr, nullptr}, 0, n_rows);
+    // last layer: d w = colsum(gy * s2), d b = sum gy
+    const int nsplit = 256;
+    k_colsum_partial<<<nsplit, 128, 0, st>>>(w.hs2y, n_rows, DH, w.partial);
+    k_reduce_2d<<<1, 256, 0, st>>>(w.partial, nsplit, DH, 1, gp(l + ".weight"), 1, 0, 1);
+    k_edge_gy_sum_partial<<<nsplit, 256, 0, st>>>(gA, edge ? g.ctr : nullptr, g.fc, n_rows, w.partial);
+    k_reduce_2d<<<1, 256, 0, st>>>(w.partial, nsplit, 1, 1, gp(l + ".bias"), 1, 0, 1);
+}
+
+static void species_sum(Trainer& t, const float* buf, const int* idx, int64_t n_rows, int C, float* dst /*[ns,C]*/) {
+    if (n_rows <= 0 || t.err) return;
+    const int ns = t.m.h.n_species;
+    const int nsplit = 256;
+    const size_t lds = (size_t)ns * C * sizeof(float);
+    if (lds > 64 * 1024) { t.err = PET_ERR_UNSUPPORTED; set_error("too many species for the embedding gradient"); return; }
+    k_species_sum_partial<<<nsplit, 256, lds, t.st>>>(buf, idx, n_rows, C, ns, t.w.partial);
+    k_reduce_2d<<<cdiv((int64_t)ns * C, 256), 256, 0, t.st>>>(t.w.partial, nsplit, ns * C, 1, dst, 1, 0, 1);
+}
+
+void Trainer::embeddings(const float* dH0, const float* dM0) {
+    species_sum(*this, dH0, g.sp, g.n_nodes, DN, gp("node_embedders.0.weight"));
+    // layer-0 messages are edge_embedder[species of the neighbour] (backend.py:516): residual path
+    species_sum(*this, dM0, g.sp_nbr, g.n_edges, D, gp("edge_embedder.weight"));
+}
+
+// compress.0 was folded at load time (abi.hip finalize):
+//   a0 = geo Wc^T + Tbl[species] (+ M W0c^T),  Wc = W0a Wee,  Tbl[s] = W0a bee + b0 + W0b emb[s]
+// un-fold the gradients on the host in fp64 (a few hundred KB once per step).
+void Trainer::compress0(int gi, const float* da0, const float* Min) {
+    if (g.n_edges <= 0 || err) return;
+    const int64_t E = g.n_edges;
+    const int ns = m.h.n_species;
+    const int kin = (gi == 0 ? 2 : 3) * D;
+    const std::string pre = "gnn_layers." + std::to_string(gi);
+    const int nsplit = 256;
+    // dWc [D,4]
+    k_geo_wgrad_partial<<<nsplit, 128, 0, st>>>(da0, g.geo, E, w.partial);
+    k_reduce_2d<<<cdiv(D * 4, 256), 256, 0, st>>>(w.partial, nsplit, D * 4, 1, w.gvec, 1, 0, 0);
+    // dTbl [ns, D] into gvec + 512
+    float* dTbl_d = w.gvec + 512;
+    TR_CHECK(hipMemsetAsync(dTbl_d, 0, (size_t)ns * D * sizeof(float), st));
+    species_sum(*this, da0, g.sp_nbr, E, D, dTbl_d);
+    if (gi > 0) {  // message block of compress.0: columns 2D..3D
+        float* dW0 = gp(pre + ".compress.0.weight");
+        wgrad_core(*this, D, D, {da0, nullptr, 0, D}, {Min, D, 0, nullptr, nullptr}, 0, E, dW0 + 2 * D, kin, nullptr, true);
+    }
+    std::vector<float> hWc(D * 4), hTbl((size_t)ns * D), hW0((size_t)D * kin), hWee(D * 4), hBee(D), hEmb((size_t)ns * D);
+    const std::string emb_key = gi == 0 ? "edge_embedder.weight" : pre + ".neighbor_embedder.weight";
+    auto raw = [&](const std::string& k) { return m.raw.at(k).first; };
+    TR_CHECK(hipMemcpyAsync(hWc.data(), w.gvec, hWc.size() * 4, hipMemcpyDeviceToHost, st));
+    TR_CHECK(hipMemcpyAsync(hTbl.data(), dTbl_d, hTbl.size() * 4, hipMemcpyDeviceToHost, st));
+    TR_CHECK(hipMemcpyAsync(hW0.data(), raw(pre + ".compress.0.weight"), hW0.size() * 4, hipMemcpyDeviceToHost, st));
+    TR_CHECK(hipMemcpyAsync(hWee.data(), raw(pre + ".edge_embedder.weight"), hWee.size() * 4, hipMemcpyDeviceToHost, st));
+    TR_CHECK(hipMemcpyAsync(hBee.data(), raw(pre + ".edge_embedder.bias"), hBee.size() * 4, hipMemcpyDeviceToHost, st));
+    TR_CHECK(hipMemcpyAsync(hEmb.data(), raw(emb_key), hEmb.size() * 4, hipMemcpyDeviceToHost, st));
+    TR_CHECK(hipStreamSynchronize(st));
+    if (err) return;
+    std::vector<double> dbc(D, 0.0);
+    for (int s = 0; s < ns; s++)
+        for (int o = 0; o < D; o++) dbc[o] += hTbl[(size_t)s * D + o];
+    std::vector<float> gW0a((size_t)D * D), gW0b((size_t)D * D), gWee(D * 4), gBee(D), gB0(D), gEmb((size_t)ns * D);
+    for (int o = 0; o < D; o++) {
+        gB0[o] = (float)dbc[o];
+        for (int k = 0; k < D; k++) {
+            double a = dbc[o] * hBee[k];  // d(W0a bee)/dW0a
+            for (int c = 0; c < 4; c++) a += (double)hWc[o * 4 + c] * hWee[k * 4 + c];  // dWc Wee^T
+            gW0a[(size_t)o * D + k] = (float)a;
+            double b = 0.0;
+            for (int s = 0; s < ns; s++) b += (double)hTbl[(size_t)s * D + o] * hEmb[(size_t)s * D + k];
+            gW0b[(size_t)o * D + k] = (float)b;
+        }
+    }
+    for (int k = 0; k < D; k++) {
+        double bb = 0.0;
+        for (int o = 0; o < D; o++) bb += (double)hW0[(size_t)o * kin + k] * dbc[o];
+        gBee[k] = (float)bb;
+        for (int c = 0; c < 4; c++) {
+            double a = 0.0;
+            for (int o = 0; o < D; o++) a += (double)hW0[(size_t)o * kin + k] * hWc[o * 4 + c];
+            gWee[k * 4 + c] = (float)a;
+        }
+    }
+    for (int s = 0; s < ns; s++)
+        for (int k = 0; k < D; k++) {
+            double a = 0.0;
+            for (int o = 0; o < D; o++) a += (double)hW0[(size_t)o * kin + D + k] * hTbl[(size_t)s * D + o];
+            gEmb[(size_t)s * D + k] = (float)a;
+        }
+    // upload into scratch and add into the flat gradient (device-side add keeps stream order)
+    float* scratch = w.gmat;
+    auto add_block = [&](const std::vector<float>& h, float* dst, int rows, int cols, int ld) {
+        if (!dst) { err = PET_ERR_ARGUMENT; return; }
+        TR_CHECK(hipMemcpyAsync(scratch, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));
+        k_reduce_2d<<<cdiv((int64_t)rows * cols, 256), 256, 0, st>>>(scratch, 1, rows, cols, dst, ld, 0, 1);
+        TR_CHECK(hipStreamSynchronize(st));  // scratch / host vector reuse
+    };
+    float* dW0 = gp(pre + ".compress.0.weight");
+    add_block(gW0a, dW0, D, D, kin);
+    add_block(gW0b, dW0 ? dW0 + D : nullptr, D, D, kin);
+    add_block(gB0, gp(pre + ".compress.0.bias"), D, 1, 1);
+    add_block(gWee, gp(pre + ".edge_embedder.weight"), D, 4, 4);
+    add_block(gBee, gp(pre + ".edge_embedder.bias"), D, 1, 1);
+    add_block(gEmb, gp(emb_key), ns, D, D);
+}
+
+}  // namespace pet

@@ -1,0 +1,181 @@
+// Weight-gradient GEMM for the training row: for y = x W^T + b,
+//   dW[n][k] = sum_rows dY[row][n] * X[row][k],   db[n] = sum_rows dY[row][n].
+// M = n_out, N = k_in are small (<= 1024 x 512), the reduction runs over 10^5..10^6 rows, so the
+// rows are split over workgroups (split-K); every workgroup accumulates a [128 x KB] block in fp32
+// MFMA registers over its row range and writes ONE partial; a second kernel sums the partials in a
+// fixed order (deterministic, no float atomics).
+//
+// Operand layout: v_mfma_f32_32x32x2_f32 with the row index as the MFMA k dimension,
+//   A[i = n][kk = row] = dY tile, B[kk = row][j = k] = X tile, both staged in LDS as [32 rows][cols]
+// so that a lane reads 32 consecutive floats of one row (conflict-free ds_read_b32).
+// X rows are produced by a prologue functor (identity / RMSNorm-hat / SwiGLU / SiLU / LayerNorm-hat),
+// i.e. the forward activation is rebuilt from what the forward pass saved; dY rows come from the
+// reverse pass' own buffers.
+#pragma once
+#include "common.h"
+#include "tile.h"
+
+namespace pet {
+
+constexpr int WG_RB = 32;  // rows per staging block
+
+// ---- row sources ----------------------------------------------------------------------------
+// Each provides: static constexpr int COLS; fill(float* dst /*[32][COLS+4]*/, row0, n_rows): cooperative
+struct SrcPlain {  // rows of a row-major buffer, columns [col0, col0 + COLS)
+    const float* p; int ld; int col0;
+};
+struct SrcSplit {  // rows < e from a, rows >= e from b (token streams: edges then centres)
+    const float* a; const float* b; int64_t e; int ld;
+};
+
+template <int COLS>
+__device__ __forceinline__ void fill_plain(float* dst, const float* __restrict__ p, int ld, int col0, int64_t row0,
+                                           int64_t n_rows) {
+    constexpr int C4 = COLS / 4, LDS = COLS + 4;
+    for (int idx = threadIdx.x; idx < WG_RB * C4; idx += NTHREADS) {
+        const int r = idx / C4, c = idx % C4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < n_rows) v = *reinterpret_cast<const float4*>(p + (row0 + r) * ld + col0 + 4 * c);
+        *reinterpret_cast<float4*>(dst + r * LDS + 4 * c) = v;
+    }
+}
+
+// in-place transforms on a staged [32][COLS+4] tile; 8 threads per row
+template <int COLS>
+__device__ __forceinline__ void tile_rms_hat(float* t) {  // x -> x * rsqrt(mean x^2 + eps)
+    constexpr int LDS = COLS + 4;
+    const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
+    float ss = 0.f;
+    for (int c = q * 4; c < COLS; c += 32) {
+        const float4 v = *reinterpret_cast<float4*>(t + r * LDS + c);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+    const float rstd = rsqrtf(ss * (1.0f / COLS) + 1.1920928955078125e-07f);
+    for (int c = q * 4; c < COLS; c += 32) {
+        float4 v = *reinterpret_cast<float4*>(t + r * LDS + c);
+        v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+        *reinterpret_cast<float4*>(t + r * LDS + c) = v;
+    }
+}
+
+// ---- the kernel -----------------------------------------------------------------------------
+// grid = (n_blocks of 128 output rows, splits). XMODE: 0 plain, 1 rms-hat, 2 swiglu(VG: v|g), 3 silu,
+// 4 layernorm-hat of [x ; x[rev]] (COLS = 256). YMODE: 0 plain, 1 split (edges | centres).
+struct WgradArgs {
+    const float* y0; const float* y1; int64_t y_split; int y_ld; int y_col0;
+    const float* x0; int x_ld; int x_col0; int x_hid;  // x_hid: SwiGLU hidden size (gate at +x_hid)
+    const int* rev; const float* lns;                  // XMODE 4
+    int64_t n_rows;
+    float* partial;  // [splits][n_out][KB]  (this launch's k-block only)
+    float* partial_b; // [splits][n_out] or null
+    int n_out;
+};
+
+template <int KB, int XMODE>
+__global__ __launch_bounds__(NTHREADS) void k_wgrad(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LDY = 128 + 4, LDX = KB + 4, KT = KB / 32;
+    float* Ys = smem;                 // [32][132]
+    float* Xs = smem + WG_RB * LDY;   // [32][KB+4]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    const int64_t rows_per = ((a.n_rows + nsplit - 1) / nsplit + WG_RB - 1) / WG_RB * WG_RB;
+    const int64_t r_begin = (int64_t)split * rows_per;
+    const int64_t r_end = min(a.n_rows, r_begin + rows_per);
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+    float bsum = 0.f;  // thread c < 128: column sum of dY (bias gradient)
+    for (int64_t row0 = r_begin; row0 < r_end; row0 += WG_RB) {
+        __syncthreads();
+        // ---- stage dY block: columns [128 nb, 128 nb + 128)
+        for (int idx = threadIdx.x; idx < WG_RB * 32; idx += NTHREADS) {
+            const int r = idx >> 5, c = idx & 31;
+            const int64_t row = row0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < r_end) {
+                const float* src = (a.y1 && row >= a.y_split) ? a.y1 + (row - a.y_split) * a.y_ld
+                                                              : a.y0 + row * a.y_ld;
+                v = *reinterpret_cast<const float4*>(src + a.y_col0 + 128 * nb + 4 * c);
+            }
+            *reinterpret_cast<float4*>(Ys + r * LDY + 4 * c) = v;
+        }
+        // ---- stage X block
+        if (XMODE == 2) {
+            for (int idx = threadIdx.x; idx < WG_RB * (KB / 4); idx += NTHREADS) {
+                const int r = idx / (KB / 4), c = idx % (KB / 4);
+                float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row0 + r < r_end) {
+                    const float* base = a.x0 + (row0 + r) * a.x_ld + a.x_col0 + 4 * c;
+                    const float4 v = *reinterpret_cast<const float4*>(base);
+                    const float4 g = *reinterpret_cast<const float4*>(base + a.x_hid);
+                    u = make_float4(v.x * sigmoidf_(g.x), v.y * sigmoidf_(g.y), v.z * sigmoidf_(g.z), v.w * sigmoidf_(g.w));
+                }
+                *reinterpret_cast<float4*>(Xs + r * LDX + 4 * c) = u;
+            }
+        } else if (XMODE == 4) {  // [x ; x[rev]] then LayerNorm-hat with the saved (mean, rstd)
+            for (int idx = threadIdx.x; idx < WG_RB * 64; idx += NTHREADS) {
+                const int r = idx >> 6, c = idx & 63;
+                const int64_t row = row0 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < r_end) {
+                    const int64_t src = c < 32 ? row : (int64_t)a.rev[row];
+                    v = *reinterpret_cast<const float4*>(a.x0 + src * a.x_ld + 4 * (c & 31));
+                    const float mean = a.lns[2 * row], rstd = a.lns[2 * row + 1];
+                    v.x = (v.x - mean) * rstd; v.y = (v.y - mean) * rstd; v.z = (v.z - mean) * rstd; v.w = (v.w - mean) * rstd;
+                }
+                *reinterpret_cast<float4*>(Xs + r * LDX + 4 * c) = v;
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < WG_RB * (KB / 4); idx += NTHREADS) {
+                const int r = idx / (KB / 4), c = idx % (KB / 4);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row0 + r < r_end) v = *reinterpret_cast<const float4*>(a.x0 + (row0 + r) * a.x_ld + a.x_col0 + 4 * c);
+                if (XMODE == 3) { v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w); }
+                *reinterpret_cast<float4*>(Xs + r * LDX + 4 * c) = v;
+            }
+        }
+        __syncthreads();
+        if (XMODE == 1) {
+            tile_rms_hat<KB>(Xs);
+            __syncthreads();
+        }
+        if (a.partial_b && threadIdx.x < 128) {
+#pragma unroll 8
+            for (int r = 0; r < WG_RB; r++) bsum += Ys[r * LDY + threadIdx.x];
+        }
+        // ---- MFMA: wave w owns output rows 32 w .. 32 w + 31 of this 128-row block, all KB columns
+#pragma unroll 4
+        for (int s = 0; s < WG_RB / 2; s++) {
+            const int rr = 2 * s + (lane >> 5);
+            const float av = Ys[rr * LDY + 32 * wave + (lane & 31)];
+#pragma unroll
+            for (int t = 0; t < KT; t++) {
+                const float bv = Xs[rr * LDX + 32 * t + (lane & 31)];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- write this split's partial: out[n = 128 nb + 32 wave + acc_row][k = 32 t + lane&31]
+    float* P = a.partial + ((size_t)split * a.n_out + 128 * nb + 32 * wave) * KB;
+#pragma unroll
+    for (int t = 0; t < KT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) P[(size_t)acc_row(r, lane) * KB + 32 * t + (lane & 31)] = acc[t][r];
+    if (a.partial_b && threadIdx.x < 128) a.partial_b[(size_t)split * a.n_out + 128 * nb + threadIdx.x] = bsum;
+}
+
+// out[i] (+)= scale * sum_s partial[s][i]   (i < n); fixed summation order
+__global__ void k_reduce_partials(const float* __restrict__ partial, int nsplit, int64_t n, float* __restrict__ out,
+                                  int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; k++) s += partial[(size_t)k * n + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+}  // namespace pet

@@ -87,6 +87,7 @@ class HipModel:
         """Upload a reference-schema state dict for one target and pack it."""
         block = block or target
         self.target = target
+        self._ckeys: Dict[str, tuple] = {}
         for key, t in params.items():
             _require_cuda(t)
             parts = key.split(".")
@@ -103,6 +104,7 @@ class HipModel:
                 src = t.to(torch.int64).contiguous()
             else:
                 src = t.detach().to(torch.float32).contiguous()
+                self._ckeys[key] = (ckey, tuple(t.shape))
             check(self.lib.pet_model_set_param(self._handle, ckey.encode(), _ptr(src), src.numel(), _stream()))
             torch.cuda.current_stream().synchronize()  # src may be a temporary
         check(self.lib.pet_model_finalize(self._handle, _stream()))
@@ -110,6 +112,20 @@ class HipModel:
     @property
     def num_params(self) -> int:
         return int(self.lib.pet_model_num_params(self._handle))
+
+    # ---- training row (a16): gradient slots, one per uploaded parameter ----
+    def zero_grad(self) -> None:
+        check(self.lib.pet_model_zero_grad(self._handle, _stream()))
+
+    def grad(self, key: str) -> torch.Tensor:
+        """Accumulated dL/d(parameter ``key``) (state-dict key as passed to :meth:`load`)."""
+        ckey, shape = self._ckeys[key]
+        out = torch.empty(shape, dtype=torch.float32, device="cuda")
+        check(self.lib.pet_model_get_grad(self._handle, ckey.encode(), _ptr(out), out.numel(), _stream()))
+        return out
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        return {k: self.grad(k) for k in self._ckeys}
 
 
 class HipGraph:
@@ -205,10 +221,12 @@ class HipGraph:
 class HipForward:
     """One forward pass' activations (kept for the backward)."""
 
-    def __init__(self, model: HipModel, graph: HipGraph):
+    def __init__(self, model: HipModel, graph: HipGraph, train: bool = False):
         self.model, self.graph = model, graph
         self.lib = model.lib
-        nbytes = int(self.lib.pet_forward_workspace_bytes(model.handle, graph.n_nodes, graph.n_edges))
+        self.train = train
+        size_fn = self.lib.pet_train_workspace_bytes if train else self.lib.pet_forward_workspace_bytes
+        nbytes = int(size_fn(model.handle, graph.n_nodes, graph.n_edges))
         if nbytes < 0:
             raise PetHipError("pet_forward_workspace_bytes failed")
         self.nbytes = nbytes
@@ -220,8 +238,8 @@ class HipForward:
         atomic = torch.empty(g.n_nodes, dtype=torch.float32, device=dev)
         nf = torch.empty((g.n_nodes, self.model.hypers["d_node"]), dtype=torch.float32, device=dev) if want_features else None
         ef = torch.empty((g.n_edges, self.model.hypers["d_pet"]), dtype=torch.float32, device=dev) if want_features else None
-        check(self.lib.pet_forward(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes, 1,
-                                   _ptr(atomic), _ptr(nf), _ptr(ef), _stream()))
+        check(self.lib.pet_forward(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes,
+                                   2 if self.train else 1, _ptr(atomic), _ptr(nf), _ptr(ef), _stream()))
         if want_features:
             return atomic, nf, ef
         return atomic
@@ -237,6 +255,20 @@ class HipForward:
                                     _ptr(gpos), _ptr(gcell), _stream()))
         if want_cell_grad:
             return gpos, gcell
+        return gpos
+
+    def backward_train(self, grad_atomic: torch.Tensor, want_position_grad: bool = False):
+        """loss.backward() for dL/d(atomic prediction) = ``grad_atomic``: accumulates dL/dtheta into
+        the model's gradient slots (``HipModel.grad``); optionally also returns dL/dR."""
+        if not self.train:
+            raise PetHipError("backward_train needs HipForward(..., train=True)")
+        g = self.graph
+        _require_cuda(grad_atomic)
+        ga = grad_atomic.to(torch.float32).contiguous()
+        gpos = (torch.empty((g.n_nodes, 3), dtype=torch.float32, device=self.workspace.device)
+                if want_position_grad else None)
+        check(self.lib.pet_backward_train(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes,
+                                          _ptr(ga), _ptr(gpos), None, _stream()))
         return gpos
 
     def sum_over_atoms(self, atomic: torch.Tensor) -> torch.Tensor:
