@@ -181,6 +181,18 @@ int pet_model_zero_grad(pet_model_t* m, void* stream);
 /* Copy the accumulated gradient of parameter `key` (same key as pet_model_set_param) into d_dst. */
 int pet_model_get_grad(const pet_model_t* m, const char* key, float* d_dst, int64_t numel,
                        void* stream);
+/* Current value of parameter `key` (after optimizer steps). */
+int pet_model_get_param(const pet_model_t* m, const char* key, float* d_dst, int64_t numel,
+                        void* stream);
+/* The gradient slots as ONE flat fp32 buffer of pet_model_num_params elements (upload order):
+ * direction 0 copies it out to d_flat, 1 copies d_flat back in. This is the bucket the RCCL
+ * gradient all-reduce runs on (torch DDP's role, pet/trainer.py:344-345): 11.6 MB, one collective. */
+int pet_model_flat_grad(pet_model_t* m, float* d_flat, int64_t numel, int direction, void* stream);
+/* clip_grad_norm_(max_grad_norm; <= 0: off) + torch.optim.Adam (weight_decay < 0) or AdamW
+ * (weight_decay >= 0) on every parameter, `step` counted from 1 (pet/trainer.py:367-376,463-467),
+ * then re-packs the weights. d_grad_norm (device, may be NULL) receives the pre-clip total norm. */
+int pet_adam_step(pet_model_t* m, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float max_grad_norm, int64_t step, float* d_grad_norm, void* stream);
 /* Workspace for pet_forward(save_for_backward = 2) + pet_backward_train. */
 int64_t pet_train_workspace_bytes(const pet_model_t* m, int64_t n_nodes, int64_t n_edges);
 /* Reverse pass of loss.backward() for L with dL/d(atomic prediction) = d_grad_atomic [N]:

@@ -97,16 +97,30 @@ __global__ void k_pack(const float* __restrict__ W, int64_t s_n, int64_t s_k, in
     out[idx] = make_float4(p[0], p[s_k], p[2 * s_k], p[3 * s_k]);
 }
 
-static int dev_alloc(Model& m, void** p, size_t bytes) {
+int dev_alloc(Model& m, void** p, size_t bytes) {
     PET_HIP_CHECK(hipMalloc(p, bytes > 0 ? bytes : 4));
     m.owned.push_back(*p);
     return PET_OK;
 }
 
+// derived buffers (packed weights, folded tables) are allocated once per name, so that
+// pet_model_finalize can run after every optimizer step without growing the footprint
+static int named_alloc(Model& m, const std::string& name, void** p, size_t bytes) {
+    auto it = m.named.find(name);
+    if (it != m.named.end() && it->second.second == bytes) {
+        *p = it->second.first;
+        return PET_OK;
+    }
+    int rc = dev_alloc(m, p, bytes);
+    if (rc) return rc;
+    m.named[name] = {*p, bytes};
+    return PET_OK;
+}
+
 // pack the [n_out, k_in] sub-matrix starting at column col0 of a row-major matrix with
 // leading dimension ld
-static int pack_lin(Model& m, Lin& L, const float* w, const float* b, int n_out, int k_in, int ld,
-                    int col0, hipStream_t st) {
+static int pack_lin(Model& m, const std::string& name, Lin& L, const float* w, const float* b, int n_out,
+                    int k_in, int ld, int col0, hipStream_t st) {
     PET_REQUIRE(n_out % 32 == 0 && k_in % 32 == 0, PET_ERR_UNSUPPORTED, "linear shape not tileable");
     L.w = w + col0;
     L.b = b;
@@ -114,8 +128,8 @@ static int pack_lin(Model& m, Lin& L, const float* w, const float* b, int n_out,
     L.k_in = k_in;
     size_t n4 = (size_t)(n_out / 32) * (k_in / 8) * 64;
     int rc;
-    if ((rc = dev_alloc(m, (void**)&L.fwd, n4 * sizeof(float4))) != PET_OK) return rc;
-    if ((rc = dev_alloc(m, (void**)&L.bwd, n4 * sizeof(float4))) != PET_OK) return rc;
+    if ((rc = named_alloc(m, name + ":fwd", (void**)&L.fwd, n4 * sizeof(float4))) != PET_OK) return rc;
+    if ((rc = named_alloc(m, name + ":bwd", (void**)&L.bwd, n4 * sizeof(float4))) != PET_OK) return rc;
     k_pack<<<cdiv(n4, 256), 256, 0, st>>>(w + col0, ld, 1, n_out, k_in, L.fwd);
     // transposed operand: rows = original columns, k = original rows
     k_pack<<<cdiv(n4, 256), 256, 0, st>>>(w + col0, 1, ld, k_in, n_out, L.bwd);
@@ -138,27 +152,32 @@ static int get_lin(Model& m, const std::string& key, int n_out, int k_in, Lin& L
     int rc;
     if ((rc = get(m, key + ".weight", (int64_t)n_out * k_in, &w)) != PET_OK) return rc;
     if ((rc = get(m, key + ".bias", n_out, &b)) != PET_OK) return rc;
-    return pack_lin(m, L, w, b, n_out, k_in, k_in, 0, st);
+    return pack_lin(m, key, L, w, b, n_out, k_in, k_in, 0, st);
 }
 
-static int download(const float* d, size_t n, std::vector<double>& out, hipStream_t st) {
-    std::vector<float> tmp(n);
-    PET_HIP_CHECK(hipMemcpyAsync(tmp.data(), d, n * sizeof(float), hipMemcpyDeviceToHost, st));
-    PET_HIP_CHECK(hipStreamSynchronize(st));
-    out.assign(tmp.begin(), tmp.end());
-    return PET_OK;
+// compress.0 folded with the 4 -> D edge embedder and the species embeddings, accumulated in fp64:
+//   Wc[o][c] = sum_k W0[o][k] Wee[k][c],  Tbl[s][o] = b0[o] + sum_k W0[o][k] bee[k] + sum_k W0[o][D+k] emb[s][k]
+__global__ void k_fold_compress0(const float* __restrict__ W0, int kin, const float* __restrict__ b0,
+                                 const float* __restrict__ Wee, const float* __restrict__ bee,
+                                 const float* __restrict__ emb, int ns, float* __restrict__ Wc,
+                                 float* __restrict__ Wct, float* __restrict__ Tbl) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < D * 4) {
+        const int o = idx >> 2, c = idx & 3;
+        double s = 0.0;
+        for (int k = 0; k < D; k++) s += (double)W0[(size_t)o * kin + k] * (double)Wee[k * 4 + c];
+        Wc[o * 4 + c] = (float)s;
+        Wct[c * D + o] = (float)s;
+    } else if (idx < D * 4 + ns * D) {
+        const int t = idx - D * 4, sidx = t / D, o = t % D;
+        double s = (double)b0[o];
+        for (int k = 0; k < D; k++) s += (double)W0[(size_t)o * kin + k] * (double)bee[k];
+        for (int k = 0; k < D; k++) s += (double)W0[(size_t)o * kin + D + k] * (double)emb[(size_t)sidx * D + k];
+        Tbl[(size_t)sidx * D + o] = (float)s;
+    }
 }
 
-static int upload(Model& m, const std::vector<double>& v, float** d, hipStream_t st) {
-    std::vector<float> tmp(v.begin(), v.end());
-    int rc = dev_alloc(m, (void**)d, tmp.size() * sizeof(float));
-    if (rc != PET_OK) return rc;
-    PET_HIP_CHECK(hipMemcpyAsync(*d, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    PET_HIP_CHECK(hipStreamSynchronize(st));
-    return PET_OK;
-}
-
-static int finalize(Model& m, hipStream_t st) {
+int finalize(Model& m, hipStream_t st) {
     const pet_hypers_t& h = m.h;
     const int ns = h.n_species;
     int rc;
@@ -199,33 +218,12 @@ static int finalize(Model& m, hipStream_t st) {
         } else {
             if ((rc = get(m, pre + ".neighbor_embedder.weight", (int64_t)ns * D, &emb))) return rc;
         }
-        std::vector<double> W0, B0, Wee, Bee, Emb;
-        if ((rc = download(w0, (size_t)D * kin, W0, st))) return rc;
-        if ((rc = download(b0, D, B0, st))) return rc;
-        if ((rc = download(wee, D * 4, Wee, st))) return rc;
-        if ((rc = download(bee, D, Bee, st))) return rc;
-        if ((rc = download(emb, (size_t)ns * D, Emb, st))) return rc;
-        std::vector<double> Wc(D * 4), Wct(4 * D), Tbl((size_t)ns * D);
-        for (int o = 0; o < D; o++) {
-            double bc = B0[o];
-            for (int k = 0; k < D; k++) bc += W0[(size_t)o * kin + k] * Bee[k];
-            for (int c = 0; c < 4; c++) {
-                double s = 0;
-                for (int k = 0; k < D; k++) s += W0[(size_t)o * kin + k] * Wee[k * 4 + c];
-                Wc[o * 4 + c] = s;
-                Wct[c * D + o] = s;
-            }
-            for (int sidx = 0; sidx < ns; sidx++) {
-                double s = bc;
-                for (int k = 0; k < D; k++) s += W0[(size_t)o * kin + D + k] * Emb[(size_t)sidx * D + k];
-                Tbl[(size_t)sidx * D + o] = s;
-            }
-        }
-        if ((rc = upload(m, Wc, &G.wc, st))) return rc;
-        if ((rc = upload(m, Wct, &G.wct, st))) return rc;
-        if ((rc = upload(m, Tbl, &G.tbl, st))) return rc;
+        if ((rc = named_alloc(m, pre + ":wc", (void**)&G.wc, D * 4 * sizeof(float)))) return rc;
+        if ((rc = named_alloc(m, pre + ":wct", (void**)&G.wct, 4 * D * sizeof(float)))) return rc;
+        if ((rc = named_alloc(m, pre + ":tbl", (void**)&G.tbl, (size_t)ns * D * sizeof(float)))) return rc;
+        k_fold_compress0<<<cdiv(D * 4 + ns * D, 128), 128, 0, st>>>(w0, kin, b0, wee, bee, emb, ns, G.wc, G.wct, G.tbl);
         if (g > 0) {
-            if ((rc = pack_lin(m, G.compress0_msg, w0, nullptr, D, D, kin, 2 * D, st))) return rc;
+            if ((rc = pack_lin(m, pre + ".compress.0:msg", G.compress0_msg, w0, nullptr, D, D, kin, 2 * D, st))) return rc;
         }
         if ((rc = get_lin(m, pre + ".compress.2", D, D, G.compress2, st))) return rc;
         const std::string gs = std::to_string(g);
@@ -362,6 +360,37 @@ int pet_model_get_grad(const pet_model_t* pm, const char* key, float* d_dst, int
     PET_HIP_CHECK(hipMemcpyAsync(d_dst, m.grad_flat + m.grad_off.at(key), numel * sizeof(float),
                                  hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PET_OK;
+}
+
+int pet_model_get_param(const pet_model_t* pm, const char* key, float* d_dst, int64_t numel, void* stream) {
+    PET_REQUIRE(pm && key && d_dst, PET_ERR_ARGUMENT, "null argument");
+    auto it = pm->m.raw.find(key);
+    PET_REQUIRE(it != pm->m.raw.end() && it->second.second == numel, PET_ERR_ARGUMENT,
+                std::string("unknown parameter or size mismatch: ") + key);
+    PET_HIP_CHECK(hipMemcpyAsync(d_dst, it->second.first, numel * sizeof(float), hipMemcpyDeviceToDevice,
+                                 (hipStream_t)stream));
+    return PET_OK;
+}
+
+int pet_model_flat_grad(pet_model_t* pm, float* d_flat, int64_t numel, int direction, void* stream) {
+    PET_REQUIRE(pm && d_flat, PET_ERR_ARGUMENT, "null argument");
+    Model& m = pm->m;
+    PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
+    PET_REQUIRE(numel == m.n_params, PET_ERR_ARGUMENT, "flat gradient has pet_model_num_params elements");
+    if (direction == 0)
+        PET_HIP_CHECK(hipMemcpyAsync(d_flat, m.grad_flat, numel * sizeof(float), hipMemcpyDeviceToDevice,
+                                     (hipStream_t)stream));
+    else
+        PET_HIP_CHECK(hipMemcpyAsync(m.grad_flat, d_flat, numel * sizeof(float), hipMemcpyDeviceToDevice,
+                                     (hipStream_t)stream));
+    return PET_OK;
+}
+
+int pet_adam_step(pet_model_t* pm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float max_grad_norm, int64_t step, float* d_grad_norm, void* stream) {
+    PET_REQUIRE(pm, PET_ERR_ARGUMENT, "null model");
+    return adam_step(pm->m, lr, beta1, beta2, eps, weight_decay, max_grad_norm, step, d_grad_norm,
+                     (hipStream_t)stream);
 }
 
 int64_t pet_train_workspace_bytes(const pet_model_t* pm, int64_t n_nodes, int64_t n_edges) {

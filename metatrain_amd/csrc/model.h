@@ -57,12 +57,27 @@ struct Model {
     const float *nll_w = nullptr, *ell_w = nullptr;  // [DH]
     float nll_b = 0.f, ell_b = 0.f;
     std::vector<void*> owned;  // device allocations to free
+    std::map<std::string, std::pair<void*, size_t>> named;  // derived buffers, reused across finalize calls
     bool finalized = false;
     int64_t n_params = 0;
     // training (row a16): one flat gradient buffer, parameter `key` at grad_off[key] (upload order)
     std::map<std::string, int64_t> grad_off;
     float* grad_flat = nullptr;
+    float* adam_m = nullptr;   // first / second moments, same layout as grad_flat
+    float* adam_v = nullptr;
+    float** seg_ptr = nullptr; // device table: parameter storage of segment i
+    int64_t* seg_off = nullptr;  // device table: first flat index of segment i (n_seg + 1 entries)
+    int n_seg = 0;
+    float* opt_scalars = nullptr;  // [4] sum of squares, clip coefficient
 };
+
+// abi.hip
+int dev_alloc(Model& m, void** p, size_t bytes);
+int finalize(Model& m, hipStream_t st);
+
+// optim.hip: fused clip_grad_norm_ + Adam/AdamW over the flat gradient buffer, then re-pack
+int adam_step(Model& m, float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+              int64_t step, float* d_grad_norm, hipStream_t st);
 
 // graph.hip
 int64_t graph_workspace_bytes(int64_t n_nodes, int64_t e0);

@@ -2,8 +2,9 @@
 
 The inference / force path shards independent structures over ranks and needs NO data-path
 collective; the only communication is the benchmark's barrier and the
-max-over-ranks of the elapsed time. (The gradient all-reduce of the training row a16 will live
-here when that row is built.)
+max-over-ranks of the elapsed time. The training row (a16/a19) adds ONE collective per step:
+the mean all-reduce of the flat 11.6 MB gradient bucket (torch DDP's role in the reference,
+utils/distributed/distributed_data_parallel.py:7-15, pet/trainer.py:344-345).
 """
 import os
 from typing import List, Tuple
@@ -62,3 +63,15 @@ def sum_over_ranks(value: float, device: torch.device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def all_reduce_gradients(model) -> None:
+    """Mean of the gradient slots over ranks, as ONE collective on the flat bucket (2 903 298 fp32 =
+    11.6 MB: a single ring all-reduce is per-link bound on xGMI, and one bucket keeps it at one
+    launch). ``model`` exposes ``flat_grad()`` / ``set_flat_grad(t)`` (runtime.HipModel)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    flat = model.flat_grad()
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    model.set_flat_grad(flat)

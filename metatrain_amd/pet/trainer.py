@@ -1,0 +1,75 @@
+"""Host side of the PET training step, mirroring the reference's loop body
+``pet/trainer.py:417-472``:
+
+    optimizer.zero_grad() -> evaluate_model(is_training=True) -> average_by_num_atoms -> loss
+    -> loss.backward() -> clip_grad_norm_ -> optimizer.step() -> lr_scheduler.step()
+
+Everything that touches activations or weights runs in libpet_hip (forward, reverse pass, weight
+gradients, clip + Adam, re-pack); torch only does the per-structure loss arithmetic on ``[S]`` /
+``[N,3]`` tensors and the RCCL all-reduce of the flat gradient bucket.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+
+from .. import distributed as D
+from ..runtime import HipForward, HipGraph, HipModel
+
+DEFAULT_TRAINER_HYPERS = {  # pet/documentation.py TrainerHypers defaults that the step depends on
+    "learning_rate": 1e-4,
+    "weight_decay": None,
+    "grad_clip_norm": 1.0,
+    "num_epochs": 1000,
+    "warmup_fraction": 0.01,
+    "loss_weights": {"energy": 1.0, "forces": 1.0},
+}
+
+
+def lr_lambda(step: int, total_steps: int, warmup_fraction: float, min_lr_ratio: float = 0.0) -> float:
+    """Linear warm-up then cosine decay (``pet/trainer.py:56-86``, ``get_scheduler``)."""
+    warmup_steps = int(warmup_fraction * total_steps)
+    if step < warmup_steps:
+        return float(step) / float(max(1, warmup_steps))
+    progress = (step - warmup_steps) / float(max(1, total_steps - warmup_steps))
+    return min_lr_ratio + (1.0 - min_lr_ratio) * 0.5 * (1.0 + math.cos(math.pi * progress))
+
+
+def energy_loss_and_seeds(energies: torch.Tensor, targets: torch.Tensor, n_atoms: torch.Tensor,
+                          system_of_atom: torch.Tensor, weight: float = 1.0):
+    """MSE (mean over structures) of per-atom-averaged energies (``utils/per_atom.py``,
+    ``utils/loss.py`` "mse"/"mean") and dL/dE_i for every atom i (the seed of the reverse pass)."""
+    diff = (energies - targets) / n_atoms
+    loss = weight * (diff * diff).mean()
+    d_energy = weight * 2.0 * diff / (n_atoms * energies.numel())  # dL/dE_s
+    return loss, d_energy[system_of_atom]
+
+
+class TrainStep:
+    """One optimizer step on one batch (a ``HipGraph`` of several structures)."""
+
+    def __init__(self, model: HipModel, hypers: Optional[dict] = None, steps_per_epoch: int = 1):
+        self.model = model
+        self.hypers = dict(DEFAULT_TRAINER_HYPERS)
+        self.hypers.update(hypers or {})
+        self.total_steps = int(self.hypers["num_epochs"]) * int(steps_per_epoch)
+        self.step_index = 0  # optimizer steps taken so far (LambdaLR's last_epoch)
+
+    def current_lr(self) -> float:
+        h = self.hypers
+        return h["learning_rate"] * lr_lambda(self.step_index, self.total_steps, h["warmup_fraction"])
+
+    def __call__(self, graph: HipGraph, fw: HipForward, target_energies: torch.Tensor,
+                 n_atoms: torch.Tensor) -> Dict[str, torch.Tensor]:
+        m = self.model
+        m.zero_grad()
+        atomic = fw.forward()
+        energies = fw.sum_over_atoms(atomic)
+        loss, seeds = energy_loss_and_seeds(energies, target_energies, n_atoms, graph.system_of_atom(),
+                                            self.hypers["loss_weights"]["energy"])
+        fw.backward_train(seeds)
+        D.all_reduce_gradients(m)
+        norm = m.adam_step(self.current_lr(), self.step_index + 1, weight_decay=self.hypers["weight_decay"],
+                           max_grad_norm=self.hypers["grad_clip_norm"] or 0.0)
+        self.step_index += 1
+        return {"loss": loss, "grad_norm": norm, "energies": energies}

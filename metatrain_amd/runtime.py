@@ -127,6 +127,36 @@ class HipModel:
     def grads(self) -> Dict[str, torch.Tensor]:
         return {k: self.grad(k) for k in self._ckeys}
 
+    def param(self, key: str) -> torch.Tensor:
+        ckey, shape = self._ckeys[key]
+        out = torch.empty(shape, dtype=torch.float32, device="cuda")
+        check(self.lib.pet_model_get_param(self._handle, ckey.encode(), _ptr(out), out.numel(), _stream()))
+        return out
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """Current weights under the reference state-dict keys they were loaded with."""
+        return {k: self.param(k) for k in self._ckeys}
+
+    def flat_grad(self) -> torch.Tensor:
+        out = torch.empty(self.num_params, dtype=torch.float32, device="cuda")
+        check(self.lib.pet_model_flat_grad(self._handle, _ptr(out), out.numel(), 0, _stream()))
+        return out
+
+    def set_flat_grad(self, flat: torch.Tensor) -> None:
+        _require_cuda(flat)
+        flat = flat.to(torch.float32).contiguous()
+        check(self.lib.pet_model_flat_grad(self._handle, _ptr(flat), flat.numel(), 1, _stream()))
+        torch.cuda.current_stream().synchronize()  # `flat` may be a temporary
+
+    def adam_step(self, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-8,
+                  weight_decay: Optional[float] = None, max_grad_norm: float = 0.0) -> torch.Tensor:
+        """clip_grad_norm_ + Adam/AdamW + re-pack; returns the pre-clip gradient norm (device scalar)."""
+        norm = torch.empty(1, dtype=torch.float32, device="cuda")
+        wd = -1.0 if weight_decay is None else float(weight_decay)
+        check(self.lib.pet_adam_step(self._handle, float(lr), float(betas[0]), float(betas[1]), float(eps), wd,
+                                     float(max_grad_norm), int(step), _ptr(norm), _stream()))
+        return norm
+
 
 class HipGraph:
     """CSR edge graph (``pet_graph_t``) + the workspace it lives in."""
@@ -203,6 +233,10 @@ class HipGraph:
         out["neighbors"] = out["neighbors"].to(self._index_dtype)
         out["cell_shifts"] = out["cell_shifts"].to(self._shift_dtype)
         return out
+
+    def system_of_atom(self) -> torch.Tensor:
+        """``[N]`` int64 structure index of every atom (the batch's ``system_indices``)."""
+        return self._sys.long()
 
     def csr(self) -> Dict[str, torch.Tensor]:
         """Copies of rowptr / ctr / nbr / rev (int32) for inspection."""

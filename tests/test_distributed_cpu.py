@@ -48,3 +48,61 @@ def test_two_rank_sharding_and_timing_reduce():
     assert sorted(seeds) == [0, 1, 2, 3]                  # globally unique boxes
     shards = res[0][4] + res[1][4]
     assert sorted(shards) == list(range(7))               # a partition, nothing dropped or doubled
+
+
+class _FakeModel:
+    """Stands in for runtime.HipModel's flat gradient bucket (no GPU in the CPU suite)."""
+
+    def __init__(self, flat):
+        self.flat = flat
+
+    def flat_grad(self):
+        return self.flat.clone()
+
+    def set_flat_grad(self, t):
+        self.flat = t.clone()
+
+
+def _grad_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from metatrain_amd import distributed as d
+
+    d.init("gloo")
+    n = 2903298  # the PET default parameter count: one 11.6 MB bucket
+    g = torch.full((n,), float(rank + 1))
+    g[rank] = 100.0
+    model = _FakeModel(g)
+    d.all_reduce_gradients(model)
+    out.put((rank, model.flat[:3].tolist(), float(model.flat[5])))
+    d.barrier(torch.device("cpu"))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce_is_the_mean_of_one_flat_bucket():
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, head, mid in res:  # identical on both ranks: mean over ranks (DDP semantics)
+        assert head == [(100.0 + 2.0) / 2, (1.0 + 100.0) / 2, 1.5]
+        assert mid == 1.5
+
+
+def test_lr_schedule_matches_reference_formula():
+    """Linear warm-up then cosine (pet/trainer.py:56-86): known points of the closed form."""
+    from metatrain_amd.pet.trainer import lr_lambda
+
+    total, wf = 1000, 0.01  # 10 warm-up steps
+    assert lr_lambda(0, total, wf) == 0.0
+    assert lr_lambda(5, total, wf) == 0.5
+    assert lr_lambda(10, total, wf) == 1.0
+    assert abs(lr_lambda(505, total, wf) - 0.5) < 1e-12
+    assert abs(lr_lambda(1000, total, wf)) < 1e-12

@@ -86,3 +86,77 @@ def test_parameter_gradients_match_oracle_autograd(golden_dir, case):
     fw.backward_train(seed_w.to(dev))
     k0 = "gnn_layers.1.trans.layers.0.attention.input_linear.weight"
     np.testing.assert_allclose(model.grad(k0).cpu().numpy(), 2 * got[k0].cpu().numpy(), rtol=1e-5, atol=1e-9)
+
+
+def _energy_loss_ref(p, hypers, inp, targets, n_atoms, dtype):
+    atomic = opet.pet_atomic_energies(
+        p, hypers, inp["positions"].to(dtype), inp["cells"].to(dtype), inp["centers"], inp["neighbors"],
+        inp["cell_shifts"], inp["species"], inp["system_indices"].long(), "energy")
+    s = inp["system_indices"].long()
+    e = torch.zeros(len(n_atoms), dtype=dtype).index_add(0, s, atomic[:, 0])
+    return (((e - targets.to(dtype)) / n_atoms.to(dtype)) ** 2).mean()
+
+
+def test_training_steps_match_torch_adam(golden_dir):
+    """zero_grad -> forward -> energy MSE -> backward -> clip_grad_norm_(1.0) -> Adam, three steps,
+    against torch.optim.Adam driving the CPU oracle (pet/trainer.py:417-467)."""
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.pet.trainer import TrainStep
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS)
+    types = [1, 6, 7, 8]
+    params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    inp = _inputs(golden_dir, "batch_two_systems.npz")
+    s = inp["system_indices"].long()
+    n_sys = int(s.max()) + 1
+    n_atoms = torch.bincount(s, minlength=n_sys).float()
+    targets = torch.tensor([1.5, -2.0])[:n_sys] * n_atoms
+    lr, steps = 1e-3, 3
+
+    # reference trajectory: fp64 oracle + torch Adam + clip
+    p64 = {k: (v if k == "species_to_species_index" else v.double().clone().requires_grad_(True))
+           for k, v in params.items()}
+    leaves = [v for k, v in p64.items() if k != "species_to_species_index"]
+    opt = torch.optim.Adam(leaves, lr=lr)
+    ref_losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        loss = _energy_loss_ref(p64, hypers, inp, targets, n_atoms, torch.float64)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(leaves, 1.0)
+        if not ref_losses:
+            g0 = {k: v.grad.clone() for k, v in p64.items() if k != "species_to_species_index"}
+        opt.step()
+        ref_losses.append(float(loss.detach()))
+
+    model = rt.HipModel(hypers, types)
+    model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    graph = rt.HipGraph(model, inp["positions"].float().to(dev), inp["cells"].float().to(dev),
+                        inp["centers"].to(dev), inp["neighbors"].to(dev), inp["cell_shifts"].to(dev),
+                        inp["species"].to(dev), inp["system_indices"].int().to(dev))
+    fw = rt.HipForward(model, graph, train=True)
+    # constant learning rate for the comparison: no warm-up, one "epoch" far longer than the test
+    step = TrainStep(model, {"learning_rate": lr, "warmup_fraction": 0.0, "num_epochs": 10**9})
+    losses = []
+    for _ in range(steps):
+        out = step(graph, fw, targets.to(dev), n_atoms.to(dev))
+        losses.append(float(out["loss"]))
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    got = model.state_dict()
+    worst = 0.0
+    for k, v in p64.items():
+        if k == "species_to_species_index":
+            continue
+        delta_ref = (v.detach() - params[k].double()).numpy()
+        delta = got[k].cpu().double().numpy() - params[k].double().numpy()
+        assert np.abs(delta_ref).max() <= lr * steps * 1.01
+        # Adam moves every weight by ~lr per step whatever the gradient's size (m / sqrt(v) ~ +-1), so an
+        # element whose gradient is at the fp32 noise floor of its tensor can legitimately step the other
+        # way; compare the elements that carry signal, in units of lr
+        g = g0[k].abs().numpy()
+        signal = g > 1e-3 * g.max()
+        if signal.any():
+            worst = max(worst, np.abs(delta - delta_ref)[signal].max() / (lr * steps))
+        assert np.abs(delta - delta_ref).max() <= 2.01 * lr * steps
+    assert worst < 0.02, worst
