@@ -201,6 +201,19 @@ int64_t pet_train_workspace_bytes(const pet_model_t* m, int64_t n_nodes, int64_t
 int pet_backward_train(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
                        int64_t workspace_bytes, const float* d_grad_atomic,
                        float* d_grad_positions, float* d_grad_cells, void* stream);
+/* Second-order reverse pass for losses on dE/dR (forces), i.e. what loss.backward() does through the
+ * create_graph=True gradient of evaluate_model(is_training=True) (pet/trainer.py:417-462):
+ *   d_lambda_atomic [N]  seeds the force pass used (grad_outputs of autograd.grad: ones),
+ *   d_nu_atomic [N]      dL/d(atomic prediction) of the energy term (may be NULL = 0),
+ *   d_u [N,3]            dL/d(dE/dR),
+ *   d_tangent_atomic [N] optional out: directional derivative of every atomic prediction along dR = u.
+ * Accumulates dL/dtheta into the gradient slots. Needs pet_forward(save_for_backward = 2) on a
+ * training workspace plus a second workspace of pet_train2_workspace_bytes. */
+int64_t pet_train2_workspace_bytes(const pet_model_t* m, int64_t n_nodes, int64_t n_edges);
+int pet_backward_train2(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
+                        int64_t workspace_bytes, void* d_workspace2, int64_t workspace2_bytes,
+                        const float* d_lambda_atomic, const float* d_nu_atomic, const float* d_u,
+                        float* d_tangent_atomic, void* stream);
 /* Per-system sum (utils/sum_over_atoms.py:10-48): d_out[S] = sum_{atoms of s} d_atomic. */
 int pet_sum_over_atoms(const pet_graph_t* g, const float* d_atomic, float* d_out, void* stream);
 

@@ -24,15 +24,22 @@ struct Trainer {
     struct Y { const float* p0; const float* p1; int64_t split; int ld; };
     struct X { const float* p; int ld; int hid; const int* rev; const float* lns; };
     // xmode: 0 plain, 1 rms-hat, 2 swiglu(v|g), 3 silu, 4 layernorm-hat([x; x[rev]])
-    void linear(const std::string& key, int n_out, int k_in, Y y, X x, int xmode, int64_t n_rows);
+    void linear(const std::string& key, int n_out, int k_in, Y y, X x, int xmode, int64_t n_rows,
+                bool with_bias = true);
     // same, X normalised by a norm with weight `gamma_key` (and bias `beta_key` for LayerNorm)
     void linear_after_norm(const std::string& key, const float* W, int n_out, int k_in, Y y, X x, int xmode,
                            int64_t n_rows, const std::string& gamma_key, const float* gamma,
-                           const std::string& beta_key = "", const float* beta = nullptr);
+                           const std::string& beta_key = "", const float* beta = nullptr,
+                           bool tangent_pair = false);
+    void colsum(const float* buf, int64_t n_rows, int C, float* dst);  // dst[c] += sum_rows buf[row][c]
+    void vecsum(const float* vec, int64_t n_rows, float* dst);         // dst[0] += sum_rows vec[row]
+    void species_rows(const float* buf, const int* idx, int64_t n_rows, int C, float* dst);
 
     void heads(bool edge, const float* Xin, int k_in, int64_t n_rows, const float* gA);
     void embeddings(const float* dH0, const float* dM0);
-    void compress0(int gi, const float* da0, const float* Min);
+    // (la0, Tgeo, TMin): second-order pair lambda_a0 with the tangents of the compress.0 inputs
+    void compress0(int gi, const float* da0, const float* Min, const float* la0 = nullptr,
+                   const float4* Tgeo = nullptr, const float* TMin = nullptr);
 };
 
 }  // namespace pet

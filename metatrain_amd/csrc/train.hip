@@ -125,6 +125,7 @@ static void launch_k_wgrad(const WgradArgs& a, int nb, int nsplit, hipStream_t s
 static void wgrad_core(Trainer& t, int n_out, int k_in, Trainer::Y y, Trainer::X x, int xmode, int64_t n_rows,
                        float* dst, int ldw, float* db_dst, bool accumulate) {
     if (n_rows <= 0 || t.err) return;
+    ProfScope ps("wgrad", t.st, 2.0 * (double)n_rows * n_out * k_in, 4.0 * (double)n_rows * (n_out + k_in));
     const int nb = n_out / 128;
     const int KB = (xmode == 1 || xmode == 4) ? k_in : 128;
     int nsplit = 1024 / nb;
@@ -157,26 +158,28 @@ static void wgrad_core(Trainer& t, int n_out, int k_in, Trainer::Y y, Trainer::X
     }
 }
 
-void Trainer::linear(const std::string& key, int n_out, int k_in, Y y, X x, int xmode, int64_t n_rows) {
+void Trainer::linear(const std::string& key, int n_out, int k_in, Y y, X x, int xmode, int64_t n_rows,
+                     bool with_bias) {
     float* dW = gp(key + ".weight");
-    float* db = gp(key + ".bias");
+    float* db = with_bias ? gp(key + ".bias") : nullptr;
     if (!dW) { err = PET_ERR_ARGUMENT; set_error("no gradient slot for " + key); return; }
     wgrad_core(*this, n_out, k_in, y, x, xmode, n_rows, dW, k_in, db, true);
 }
 
 void Trainer::linear_after_norm(const std::string& key, const float* W, int n_out, int k_in, Y y, X x, int xmode,
                                 int64_t n_rows, const std::string& gamma_key, const float* gamma,
-                                const std::string& beta_key, const float* beta) {
+                                const std::string& beta_key, const float* beta, bool tangent_pair) {
     if (n_rows <= 0 || err) return;
     float* dW = gp(key + ".weight");
     float* db = gp(key + ".bias");
     float* dgamma = gp(gamma_key);
-    float* dbeta = beta_key.empty() ? nullptr : gp(beta_key);
+    float* dbeta = (beta_key.empty() || tangent_pair) ? nullptr : gp(beta_key);
     if (!dW || !db || !dgamma) { err = PET_ERR_ARGUMENT; set_error("no gradient slot for " + key); return; }
     // G = dY^T xhat into scratch, bias gradient of THIS call into gvec (needed un-accumulated for dbeta)
-    wgrad_core(*this, n_out, k_in, y, x, xmode, n_rows, w.gmat, k_in, w.gvec, false);
+    // a tangent pair (lambda_y, d xhat) has no bias / beta term: d(y) = W (gamma * d xhat)
+    wgrad_core(*this, n_out, k_in, y, x, xmode, n_rows, w.gmat, k_in, tangent_pair ? nullptr : w.gvec, false);
     k_norm_fixup<<<cdiv(k_in, 128), 128, 0, st>>>(w.gmat, W, gamma, beta, w.gvec, n_out, k_in, dW, dgamma, dbeta);
-    k_reduce_2d<<<cdiv(n_out, 256), 256, 0, st>>>(w.gvec, 1, n_out, 1, db, 1, 0, 1);
+    if (!tangent_pair) k_reduce_2d<<<cdiv(n_out, 256), 256, 0, st>>>(w.gvec, 1, n_out, 1, db, 1, 0, 1);
 }
 
 void Trainer::heads(bool edge, const float* Xin, int k_in, int64_t n_rows, const float* gA) {
@@ -193,6 +196,20 @@ void Trainer::heads(bool edge, const float* Xin, int k_in, int64_t n_rows, const
     k_reduce_2d<<<1, 256, 0, st>>>(w.partial, nsplit, 1, 1, gp(l + ".bias"), 1, 0, 1);
 }
 
+void Trainer::colsum(const float* buf, int64_t n_rows, int C, float* dst) {
+    if (n_rows <= 0 || err) return;
+    const int nsplit = 256;
+    k_colsum_partial<<<nsplit, 256, 0, st>>>(buf, n_rows, C, w.partial);
+    k_reduce_2d<<<cdiv(C, 256), 256, 0, st>>>(w.partial, nsplit, C, 1, dst, 1, 0, 1);
+}
+
+void Trainer::vecsum(const float* vec, int64_t n_rows, float* dst) {
+    if (n_rows <= 0 || err) return;
+    const int nsplit = 256;
+    k_edge_gy_sum_partial<<<nsplit, 256, 0, st>>>(vec, nullptr, nullptr, n_rows, w.partial);
+    k_reduce_2d<<<1, 256, 0, st>>>(w.partial, nsplit, 1, 1, dst, 1, 0, 1);
+}
+
 static void species_sum(Trainer& t, const float* buf, const int* idx, int64_t n_rows, int C, float* dst /*[ns,C]*/) {
     if (n_rows <= 0 || t.err) return;
     const int ns = t.m.h.n_species;
@@ -201,6 +218,10 @@ static void species_sum(Trainer& t, const float* buf, const int* idx, int64_t n_
     if (lds > 64 * 1024) { t.err = PET_ERR_UNSUPPORTED; set_error("too many species for the embedding gradient"); return; }
     k_species_sum_partial<<<nsplit, 256, lds, t.st>>>(buf, idx, n_rows, C, ns, t.w.partial);
     k_reduce_2d<<<cdiv((int64_t)ns * C, 256), 256, 0, t.st>>>(t.w.partial, nsplit, ns * C, 1, dst, 1, 0, 1);
+}
+
+void Trainer::species_rows(const float* buf, const int* idx, int64_t n_rows, int C, float* dst) {
+    species_sum(*this, buf, idx, n_rows, C, dst);
 }
 
 void Trainer::embeddings(const float* dH0, const float* dM0) {
@@ -212,7 +233,8 @@ void Trainer::embeddings(const float* dH0, const float* dM0) {
 // compress.0 was folded at load time (abi.hip finalize):
 //   a0 = geo Wc^T + Tbl[species] (+ M W0c^T),  Wc = W0a Wee,  Tbl[s] = W0a bee + b0 + W0b emb[s]
 // un-fold the gradients on the host in fp64 (a few hundred KB once per step).
-void Trainer::compress0(int gi, const float* da0, const float* Min) {
+void Trainer::compress0(int gi, const float* da0, const float* Min, const float* la0, const float4* Tgeo,
+                        const float* TMin) {
     if (g.n_edges <= 0 || err) return;
     const int64_t E = g.n_edges;
     const int ns = m.h.n_species;
@@ -222,6 +244,10 @@ void Trainer::compress0(int gi, const float* da0, const float* Min) {
     // dWc [D,4]
     k_geo_wgrad_partial<<<nsplit, 128, 0, st>>>(da0, g.geo, E, w.partial);
     k_reduce_2d<<<cdiv(D * 4, 256), 256, 0, st>>>(w.partial, nsplit, D * 4, 1, w.gvec, 1, 0, 0);
+    if (la0) {  // second-order pair: lambda_a0^T (d geo)
+        k_geo_wgrad_partial<<<nsplit, 128, 0, st>>>(la0, Tgeo, E, w.partial);
+        k_reduce_2d<<<cdiv(D * 4, 256), 256, 0, st>>>(w.partial, nsplit, D * 4, 1, w.gvec, 1, 0, 1);
+    }
     // dTbl [ns, D] into gvec + 512
     float* dTbl_d = w.gvec + 512;
     TR_CHECK(hipMemsetAsync(dTbl_d, 0, (size_t)ns * D * sizeof(float), st));
@@ -229,6 +255,9 @@ void Trainer::compress0(int gi, const float* da0, const float* Min) {
     if (gi > 0) {  // message block of compress.0: columns 2D..3D
         float* dW0 = gp(pre + ".compress.0.weight");
         wgrad_core(*this, D, D, {da0, nullptr, 0, D}, {Min, D, 0, nullptr, nullptr}, 0, E, dW0 + 2 * D, kin, nullptr, true);
+        if (la0)
+            wgrad_core(*this, D, D, {la0, nullptr, 0, D}, {TMin, D, 0, nullptr, nullptr}, 0, E, dW0 + 2 * D, kin, nullptr,
+                       true);
     }
     std::vector<float> hWc(D * 4), hTbl((size_t)ns * D), hW0((size_t)D * kin), hWee(D * 4), hBee(D), hEmb((size_t)ns * D);
     const std::string emb_key = gi == 0 ? "edge_embedder.weight" : pre + ".neighbor_embedder.weight";

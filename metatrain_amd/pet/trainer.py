@@ -45,6 +45,14 @@ def energy_loss_and_seeds(energies: torch.Tensor, targets: torch.Tensor, n_atoms
     return loss, d_energy[system_of_atom]
 
 
+def force_loss_and_seeds(grad_positions: torch.Tensor, target_gradients: torch.Tensor, weight: float = 1.0):
+    """MSE (mean over the N*3 components) on the position gradient dE/dR = -forces, which the per-atom
+    averaging leaves untouched (``utils/per_atom.py``: samples carry "atom"), and u = dL/d(dE/dR)."""
+    diff = grad_positions - target_gradients
+    loss = weight * (diff * diff).mean()
+    return loss, weight * 2.0 * diff / diff.numel()
+
+
 class TrainStep:
     """One optimizer step on one batch (a ``HipGraph`` of several structures)."""
 
@@ -60,14 +68,22 @@ class TrainStep:
         return h["learning_rate"] * lr_lambda(self.step_index, self.total_steps, h["warmup_fraction"])
 
     def __call__(self, graph: HipGraph, fw: HipForward, target_energies: torch.Tensor,
-                 n_atoms: torch.Tensor) -> Dict[str, torch.Tensor]:
+                 n_atoms: torch.Tensor, target_gradients: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """``target_gradients`` [N,3] = dE/dR targets (-forces); None trains on energies only."""
         m = self.model
         m.zero_grad()
         atomic = fw.forward()
         energies = fw.sum_over_atoms(atomic)
         loss, seeds = energy_loss_and_seeds(energies, target_energies, n_atoms, graph.system_of_atom(),
                                             self.hypers["loss_weights"]["energy"])
-        fw.backward_train(seeds)
+        if target_gradients is None:
+            fw.backward_train(seeds)
+        else:
+            ones = torch.ones_like(atomic)
+            grad_positions = fw.backward(ones)  # evaluate_model: autograd.grad(E.sum(), R, create_graph=True)
+            loss_f, u = force_loss_and_seeds(grad_positions, target_gradients, self.hypers["loss_weights"]["forces"])
+            loss = loss + loss_f
+            fw.backward_train2(ones, seeds, u)
         D.all_reduce_gradients(m)
         norm = m.adam_step(self.current_lr(), self.step_index + 1, weight_decay=self.hypers["weight_decay"],
                            max_grad_norm=self.hypers["grad_clip_norm"] or 0.0)

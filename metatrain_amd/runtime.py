@@ -305,6 +305,27 @@ class HipForward:
                                           _ptr(ga), _ptr(gpos), None, _stream()))
         return gpos
 
+    def backward_train2(self, lambda_atomic: torch.Tensor, nu_atomic: Optional[torch.Tensor], u: torch.Tensor,
+                        want_tangent: bool = False):
+        """Second-order reverse pass (loss on dE/dR): accumulates d/dtheta [ sum_i nu_i E_i + <u, dE/dR> ]
+        where dE/dR was taken with seeds ``lambda_atomic``; optionally returns dE_i/d(eps) along dR = u."""
+        if not self.train:
+            raise PetHipError("backward_train2 needs HipForward(..., train=True)")
+        g = self.graph
+        dev = self.workspace.device
+        _require_cuda(lambda_atomic, u)
+        if getattr(self, "workspace2", None) is None:
+            n2 = int(self.lib.pet_train2_workspace_bytes(self.model.handle, g.n_nodes, g.n_edges))
+            self.workspace2 = torch.empty(n2, dtype=torch.uint8, device=dev)
+        la = lambda_atomic.to(torch.float32).contiguous()
+        nu = None if nu_atomic is None else nu_atomic.to(torch.float32).contiguous()
+        uu = u.to(torch.float32).contiguous()
+        tan = torch.empty(g.n_nodes, dtype=torch.float32, device=dev) if want_tangent else None
+        check(self.lib.pet_backward_train2(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes,
+                                           _ptr(self.workspace2), self.workspace2.numel(), _ptr(la), _ptr(nu),
+                                           _ptr(uu), _ptr(tan), _stream()))
+        return tan
+
     def sum_over_atoms(self, atomic: torch.Tensor) -> torch.Tensor:
         out = torch.zeros(self.graph.n_systems, dtype=torch.float32, device=atomic.device)
         check(self.lib.pet_sum_over_atoms(self.graph.handle, _ptr(atomic), _ptr(out), _stream()))

@@ -160,3 +160,134 @@ def test_training_steps_match_torch_adam(golden_dir):
             worst = max(worst, np.abs(delta - delta_ref)[signal].max() / (lr * steps))
         assert np.abs(delta - delta_ref).max() <= 2.01 * lr * steps
     assert worst < 0.02, worst
+
+
+def _oracle_second_order(params, hypers, inp, nu, u):
+    """fp64 autograd reference of d/dtheta [ sum_i nu_i E_i + <u, dE_tot/dR> ] and of dE_i/d(eps) along u."""
+    p64 = {k: (v if k == "species_to_species_index" else v.double().clone().requires_grad_(True))
+           for k, v in params.items()}
+    pos = inp["positions"].double().clone().requires_grad_(True)
+
+    def atomic_of(pos_):
+        return opet.pet_atomic_energies(p64, hypers, pos_, inp["cells"].double(), inp["centers"], inp["neighbors"],
+                                        inp["cell_shifts"], inp["species"], inp["system_indices"].long(), "energy")[:, 0]
+
+    atomic = atomic_of(pos)
+    (g,) = torch.autograd.grad(atomic.sum(), pos, create_graph=True)
+    phi = (nu.double() * atomic).sum() + (u.double() * g).sum()
+    keys = [k for k in p64 if k != "species_to_species_index"]
+    grads = torch.autograd.grad(phi, [p64[k] for k in keys], allow_unused=True)
+    eps = 1e-6
+    with torch.no_grad():
+        tan = (atomic_of(pos + eps * u.double()) - atomic_of(pos - eps * u.double())) / (2 * eps)
+    return {k: (torch.zeros_like(p64[k]) if gr is None else gr) for k, gr in zip(keys, grads)}, tan, g.detach()
+
+
+@pytest.mark.parametrize("case", ["pet_default_box64.npz", "batch_two_systems.npz"])
+def test_force_loss_parameter_gradients_match_oracle_double_backward(golden_dir, case):
+    """The second-order pass (loss on dE/dR) against torch's double backward through the fp64 oracle."""
+    from metatrain_amd import runtime as rt
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS)
+    types = [1, 6, 7, 8]
+    params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    inp = _inputs(golden_dir, case)
+    n = inp["positions"].shape[0]
+    gen = torch.Generator().manual_seed(11)
+    nu = torch.rand(n, generator=gen) - 0.5
+    u = torch.randn(n, 3, generator=gen)
+    ref, tan_ref, g_ref = _oracle_second_order(params, hypers, inp, nu, u)
+
+    model = rt.HipModel(hypers, types)
+    model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    graph = rt.HipGraph(model, inp["positions"].float().to(dev), inp["cells"].float().to(dev),
+                        inp["centers"].to(dev), inp["neighbors"].to(dev), inp["cell_shifts"].to(dev),
+                        inp["species"].to(dev), inp["system_indices"].int().to(dev))
+    fw = rt.HipForward(model, graph, train=True)
+    model.zero_grad()
+    fw.forward()
+    ones = torch.ones(n, device=dev)
+    gpos = fw.backward(ones)
+    tan = fw.backward_train2(ones, nu.to(dev), u.to(dev), want_tangent=True)
+    # tangent sweep: per-atom directional derivative, and the identity sum_i E_i' = <u, dE/dR>
+    assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < TOL
+    lhs, rhs = float(tan.double().sum()), float((u.to(dev).double() * gpos.double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(rhs))
+    got = model.grads()
+    worst = {}
+    for k, r in ref.items():
+        r = r.numpy()
+        g = got[k].cpu().numpy().astype(np.float64)
+        scale = np.abs(r).max()
+        err = np.abs(g - r).max()
+        worst[k] = err / scale if scale > 1e-12 else err
+    for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:12]:
+        print(f"{v:.3e}  {k}")
+    bad = {k: v for k, v in worst.items() if not v < TOL}  # measured worst 6e-6
+    assert not bad, f"second-order parameter gradients off: {bad}"
+
+
+def test_energy_and_force_training_steps_match_torch_adam(golden_dir):
+    """The reference step with forces (pet/trainer.py:417-467): evaluate_model builds dE/dR with
+    create_graph=True, MSE on energies per atom + MSE on dE/dR, loss.backward() (double backward),
+    clip_grad_norm_(1.0), Adam. Three steps against torch driving the fp64 oracle."""
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.pet.trainer import TrainStep
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS)
+    types = [1, 6, 7, 8]
+    params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    inp = _inputs(golden_dir, "batch_two_systems.npz")
+    s = inp["system_indices"].long()
+    n_sys = int(s.max()) + 1
+    n = len(s)
+    n_atoms = torch.bincount(s, minlength=n_sys).float()
+    targets = torch.tensor([1.5, -2.0])[:n_sys] * n_atoms
+    gen = torch.Generator().manual_seed(3)
+    target_grads = 0.3 * torch.randn(n, 3, generator=gen)
+    lr, steps = 1e-4, 3
+
+    p64 = {k: (v if k == "species_to_species_index" else v.double().clone().requires_grad_(True))
+           for k, v in params.items()}
+    leaves = [v for k, v in p64.items() if k != "species_to_species_index"]
+    opt = torch.optim.Adam(leaves, lr=lr)
+    ref_losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        pos = inp["positions"].double().clone().requires_grad_(True)
+        atomic = opet.pet_atomic_energies(p64, hypers, pos, inp["cells"].double(), inp["centers"], inp["neighbors"],
+                                          inp["cell_shifts"], inp["species"], s, "energy")[:, 0]
+        e = torch.zeros(n_sys, dtype=torch.float64).index_add(0, s, atomic)
+        (g,) = torch.autograd.grad(e.sum(), pos, create_graph=True)
+        loss = (((e - targets.double()) / n_atoms.double()) ** 2).mean() + ((g - target_grads.double()) ** 2).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(leaves, 1.0)
+        if not ref_losses:
+            g0 = {k: v.grad.clone() for k, v in p64.items() if k != "species_to_species_index"}
+        opt.step()
+        ref_losses.append(float(loss.detach()))
+
+    model = rt.HipModel(hypers, types)
+    model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    graph = rt.HipGraph(model, inp["positions"].float().to(dev), inp["cells"].float().to(dev),
+                        inp["centers"].to(dev), inp["neighbors"].to(dev), inp["cell_shifts"].to(dev),
+                        inp["species"].to(dev), inp["system_indices"].int().to(dev))
+    fw = rt.HipForward(model, graph, train=True)
+    step = TrainStep(model, {"learning_rate": lr, "warmup_fraction": 0.0, "num_epochs": 10**9})
+    losses = [float(step(graph, fw, targets.to(dev), n_atoms.to(dev), target_grads.to(dev))["loss"]) for _ in range(steps)]
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    got = model.state_dict()
+    worst = 0.0
+    for k, v in p64.items():
+        if k == "species_to_species_index":
+            continue
+        delta_ref = (v.detach() - params[k].double()).numpy()
+        delta = got[k].cpu().double().numpy() - params[k].double().numpy()
+        gabs = g0[k].abs().numpy()
+        signal = gabs > 1e-3 * gabs.max()
+        if signal.any():
+            worst = max(worst, np.abs(delta - delta_ref)[signal].max() / (lr * steps))
+        assert np.abs(delta - delta_ref).max() <= 2.01 * lr * steps
+    assert worst < 0.02, worst
