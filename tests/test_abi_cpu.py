@@ -25,7 +25,7 @@ def lib():
 
 def test_header_symbols_are_exported(lib):
     header = open(os.path.join(ROOT, "include", "pet_hip.h")).read()
-    declared = set(re.findall(r"\b(pet_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(pet_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in pet_hip.h but not exported"
