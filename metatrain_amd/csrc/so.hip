@@ -77,12 +77,14 @@ struct Ctx {
 static void mm_fwd(const Ctx& c, const Lin& L, const float* X, float* Y, int64_t R, bool bias, const float* cs = nullptr,
                    bool acc = false) {
     if (R <= 0) return;
+    ProfScope ps("so_gemm", c.st, 2.0 * (double)R * L.k_in * L.n_out, 4.0 * (double)R * (L.k_in + L.n_out));
     k_gemm<<<cdiv(R, BM), NTHREADS, BM * LD128 * 4, c.st>>>(X, L.k_in, L.k_in, cs, L.fwd, bias ? L.b : nullptr, Y,
                                                            L.n_out, L.n_out, R, acc ? 1 : 0);
 }
 // x_adj = y_adj W: transposed orientation
 static void mm_bwd(const Ctx& c, const Lin& L, const float* Yadj, float* Xadj, int64_t R, bool acc = false) {
     if (R <= 0) return;
+    ProfScope ps("so_gemm", c.st, 2.0 * (double)R * L.k_in * L.n_out, 4.0 * (double)R * (L.k_in + L.n_out));
     k_gemm<<<cdiv(R, BM), NTHREADS, BM * LD128 * 4, c.st>>>(Yadj, L.n_out, L.n_out, nullptr, L.bwd, nullptr, Xadj,
                                                            L.k_in, L.k_in, R, acc ? 1 : 0);
 }
@@ -819,6 +821,7 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
             mm_fwd(c, A.cc, Sa.TH, Sa.TX + E * D, N, false);                 // centre tokens
             rms_jvp(c, D, Ab.X, Sa.TX, Sa.Txh, R);
             mm_fwd(c, A.qkv, Sa.Txh, Sa.TQKV, R, false, A.g_attn);
+            ProfScope psj("so_attn_jvp", st, 0.0);
             k_attn_jvp<<<(int)N * NHEAD, 64, lds_jvp, st>>>(Ab.QKV, Sa.TQKV, g.rowptr, g.fc, s.Tkb, Sa.TAO, E, (int)N,
                                                            scale);
             float* TO = s.tmp[0];                                            // [R,D] output_linear tangent
@@ -933,6 +936,7 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
             mm_bwd(c, A.out, s.NX, t1, R);
             PET_HIP_CHECK(hipMemsetAsync(s.LX + E * D, 0, N * D * sizeof(float), st));  // centre tokens: norm path only
             PET_HIP_CHECK(hipMemsetAsync(s.NX + E * D, 0, N * D * sizeof(float), st));
+            ProfScope psr("so_attn_rev", st, 0.0);
             k_attn_rev<<<(int)N * NHEAD, 64, lds_rev, st>>>(Ab.QKV, Sa.TQKV, g.rowptr, g.fc, s.Tkb, t0, t1, t2, t3, E,
                                                            (int)N, scale);  // (l_QKV, n_QKV) [R,3D]
             tr.linear_after_norm(lp + ".attention.input_linear", A.qkv.w, 3 * D, D, {t3, nullptr, 0, 3 * D},

@@ -23,34 +23,56 @@ float* Trainer::gp(const std::string& key) const {
     } while (0)
 
 // out[n * ldo + col0 + k] (+)= sum_s partial[s][n][k]
-__global__ void k_reduce_2d(const float* __restrict__ partial, int nsplit, int n_out, int kb, float* __restrict__ out,
-                            int ldo, int col0, int accumulate) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// 64 outputs per block, the splits dealt over 4 thread groups (fixed order -> deterministic), LDS combine
+__global__ __launch_bounds__(256) void k_reduce_2d(const float* __restrict__ partial, int nsplit, int n_out, int kb,
+                                                   float* __restrict__ out, int ldo, int col0, int accumulate) {
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + o;
     const int64_t tot = (int64_t)n_out * kb;
-    if (i >= tot) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; k++) s += partial[(size_t)k * tot + i];
-    float* o = out + (i / kb) * ldo + col0 + (i % kb);
-    *o = accumulate ? *o + s : s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < tot) {
+        const float* p = partial + i;
+        int k = sg;
+        for (; k + 12 < nsplit; k += 16) {
+            s0 += p[(size_t)k * tot];
+            s1 += p[(size_t)(k + 4) * tot];
+            s2 += p[(size_t)(k + 8) * tot];
+            s3 += p[(size_t)(k + 12) * tot];
+        }
+        for (; k < nsplit; k += 4) s0 += p[(size_t)k * tot];
+    }
+    red[sg][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sg == 0 && i < tot) {
+        const float s = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+        float* dst = out + (i / kb) * ldo + col0 + (i % kb);
+        *dst = accumulate ? *dst + s : s;
+    }
+}
+static void reduce_2d(const float* partial, int nsplit, int n_out, int kb, float* out, int ldo, int col0, int accumulate,
+                      hipStream_t st) {
+    k_reduce_2d<<<cdiv((int64_t)n_out * kb, 64), 256, 0, st>>>(partial, nsplit, n_out, kb, out, ldo, col0, accumulate);
 }
 
-// norm feeding a Linear (y = xhat gamma + beta):  dW = G gamma + db (x) beta,  dgamma[k] = sum_n W[n][k] G[n][k],
-// LayerNorm only: dbeta[k] = sum_n W[n][k] db[n].   One thread per column k.
-__global__ void k_norm_fixup(const float* __restrict__ G, const float* __restrict__ W, const float* __restrict__ gamma,
-                             const float* __restrict__ beta, const float* __restrict__ db, int n_out, int k_in, float* __restrict__ dW,
-                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= k_in) return;
-    const float gk = gamma[k], bk = dbeta ? beta[k] : 0.f;
-    float sg = 0.f, sb = 0.f;
-    for (int n = 0; n < n_out; n++) {
-        const float gv = G[(size_t)n * k_in + k], wv = W[(size_t)n * k_in + k];
-        dW[(size_t)n * k_in + k] += gv * gk + (dbeta ? db[n] * bk : 0.f);
-        sg += wv * gv;
-        if (dbeta) sb += wv * db[n];
+// norm feeding a Linear (y = xhat gamma + beta):  dW += G gamma + db (x) beta,
+//   dgamma[k] = sum_n W[n][k] G[n][k],   LayerNorm only: dbeta[k] = sum_n W[n][k] db[n].
+// Elementwise part; G is overwritten with W.G and G2 (LayerNorm) with W[n][k] db[n] for the column sums.
+__global__ void k_norm_fixup(float* __restrict__ G, float* __restrict__ G2, const float* __restrict__ W,
+                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                             const float* __restrict__ db, int n_out, int k_in, float* __restrict__ dW) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_out * k_in) return;
+    const int n = (int)(i / k_in), k = (int)(i % k_in);
+    const float gv = G[i], wv = W[i];
+    float upd = gv * gamma[k];
+    if (G2) {
+        const float dbn = db[n];
+        upd += dbn * beta[k];
+        G2[i] = wv * dbn;
     }
-    dgamma[k] += sg;
-    if (dbeta) dbeta[k] += sb;
+    dW[i] += upd;
+    G[i] = wv * gv;
 }
 
 // column sums of a row-major [R, C] buffer, two stages; also sums with a per-row species index
@@ -128,7 +150,7 @@ static void wgrad_core(Trainer& t, int n_out, int k_in, Trainer::Y y, Trainer::X
     ProfScope ps("wgrad", t.st, 2.0 * (double)n_rows * n_out * k_in, 4.0 * (double)n_rows * (n_out + k_in));
     const int nb = n_out / 128;
     const int KB = (xmode == 1 || xmode == 4) ? k_in : 128;
-    int nsplit = 1024 / nb;
+    int nsplit = 768 / nb;  // three workgroups per CU (LDS: 34 - 50 KB each)
     const int64_t max_by_rows = (n_rows + WG_RB - 1) / WG_RB;
     if (nsplit > max_by_rows) nsplit = (int)max_by_rows;
     while ((size_t)nsplit * n_out * (KB + 1) > t.w.partial_floats && nsplit > 1) nsplit /= 2;
@@ -152,9 +174,9 @@ static void wgrad_core(Trainer& t, int n_out, int k_in, Trainer::Y y, Trainer::X
             else { t.err = PET_ERR_ARGUMENT; return; }
         }
         const int64_t tot = (int64_t)n_out * KB;
-        k_reduce_2d<<<cdiv(tot, 256), 256, 0, t.st>>>(t.w.partial, nsplit, n_out, KB, dst, ldw, k0, accumulate ? 1 : 0);
+        reduce_2d(t.w.partial, nsplit, n_out, KB, dst, ldw, k0, accumulate ? 1 : 0, t.st);
         if (k0 == 0 && db_dst)
-            k_reduce_2d<<<cdiv(n_out, 256), 256, 0, t.st>>>(pb, nsplit, n_out, 1, db_dst, 1, 0, accumulate ? 1 : 0);
+            reduce_2d(pb, nsplit, n_out, 1, db_dst, 1, 0, accumulate ? 1 : 0, t.st);
     }
 }
 
@@ -178,8 +200,11 @@ void Trainer::linear_after_norm(const std::string& key, const float* W, int n_ou
     // G = dY^T xhat into scratch, bias gradient of THIS call into gvec (needed un-accumulated for dbeta)
     // a tangent pair (lambda_y, d xhat) has no bias / beta term: d(y) = W (gamma * d xhat)
     wgrad_core(*this, n_out, k_in, y, x, xmode, n_rows, w.gmat, k_in, tangent_pair ? nullptr : w.gvec, false);
-    k_norm_fixup<<<cdiv(k_in, 128), 128, 0, st>>>(w.gmat, W, gamma, beta, w.gvec, n_out, k_in, dW, dgamma, dbeta);
-    if (!tangent_pair) k_reduce_2d<<<cdiv(n_out, 256), 256, 0, st>>>(w.gvec, 1, n_out, 1, db, 1, 0, 1);
+    float* G2 = dbeta ? w.gmat + 1024 * 256 : nullptr;
+    k_norm_fixup<<<cdiv((int64_t)n_out * k_in, 256), 256, 0, st>>>(w.gmat, G2, W, gamma, beta, w.gvec, n_out, k_in, dW);
+    colsum(w.gmat, n_out, k_in, dgamma);
+    if (dbeta) colsum(G2, n_out, k_in, dbeta);
+    if (!tangent_pair) reduce_2d(w.gvec, 1, n_out, 1, db, 1, 0, 1, st);
 }
 
 void Trainer::heads(bool edge, const float* Xin, int k_in, int64_t n_rows, const float* gA) {
@@ -191,33 +216,33 @@ void Trainer::heads(bool edge, const float* Xin, int k_in, int64_t n_rows, const
     // last layer: d w = colsum(gy * s2), d b = sum gy
     const int nsplit = 256;
     k_colsum_partial<<<nsplit, 128, 0, st>>>(w.hs2y, n_rows, DH, w.partial);
-    k_reduce_2d<<<1, 256, 0, st>>>(w.partial, nsplit, DH, 1, gp(l + ".weight"), 1, 0, 1);
+    reduce_2d(w.partial, nsplit, DH, 1, gp(l + ".weight"), 1, 0, 1, st);
     k_edge_gy_sum_partial<<<nsplit, 256, 0, st>>>(gA, edge ? g.ctr : nullptr, g.fc, n_rows, w.partial);
-    k_reduce_2d<<<1, 256, 0, st>>>(w.partial, nsplit, 1, 1, gp(l + ".bias"), 1, 0, 1);
+    reduce_2d(w.partial, nsplit, 1, 1, gp(l + ".bias"), 1, 0, 1, st);
 }
 
 void Trainer::colsum(const float* buf, int64_t n_rows, int C, float* dst) {
     if (n_rows <= 0 || err) return;
     const int nsplit = 256;
     k_colsum_partial<<<nsplit, 256, 0, st>>>(buf, n_rows, C, w.partial);
-    k_reduce_2d<<<cdiv(C, 256), 256, 0, st>>>(w.partial, nsplit, C, 1, dst, 1, 0, 1);
+    reduce_2d(w.partial, nsplit, C, 1, dst, 1, 0, 1, st);
 }
 
 void Trainer::vecsum(const float* vec, int64_t n_rows, float* dst) {
     if (n_rows <= 0 || err) return;
     const int nsplit = 256;
     k_edge_gy_sum_partial<<<nsplit, 256, 0, st>>>(vec, nullptr, nullptr, n_rows, w.partial);
-    k_reduce_2d<<<1, 256, 0, st>>>(w.partial, nsplit, 1, 1, dst, 1, 0, 1);
+    reduce_2d(w.partial, nsplit, 1, 1, dst, 1, 0, 1, st);
 }
 
 static void species_sum(Trainer& t, const float* buf, const int* idx, int64_t n_rows, int C, float* dst /*[ns,C]*/) {
     if (n_rows <= 0 || t.err) return;
     const int ns = t.m.h.n_species;
-    const int nsplit = 256;
+    const int nsplit = 2048;
     const size_t lds = (size_t)ns * C * sizeof(float);
     if (lds > 64 * 1024) { t.err = PET_ERR_UNSUPPORTED; set_error("too many species for the embedding gradient"); return; }
     k_species_sum_partial<<<nsplit, 256, lds, t.st>>>(buf, idx, n_rows, C, ns, t.w.partial);
-    k_reduce_2d<<<cdiv((int64_t)ns * C, 256), 256, 0, t.st>>>(t.w.partial, nsplit, ns * C, 1, dst, 1, 0, 1);
+    reduce_2d(t.w.partial, nsplit, ns * C, 1, dst, 1, 0, 1, t.st);
 }
 
 void Trainer::species_rows(const float* buf, const int* idx, int64_t n_rows, int C, float* dst) {
@@ -240,13 +265,13 @@ void Trainer::compress0(int gi, const float* da0, const float* Min, const float*
     const int ns = m.h.n_species;
     const int kin = (gi == 0 ? 2 : 3) * D;
     const std::string pre = "gnn_layers." + std::to_string(gi);
-    const int nsplit = 256;
+    const int nsplit = 2048;
     // dWc [D,4]
     k_geo_wgrad_partial<<<nsplit, 128, 0, st>>>(da0, g.geo, E, w.partial);
-    k_reduce_2d<<<cdiv(D * 4, 256), 256, 0, st>>>(w.partial, nsplit, D * 4, 1, w.gvec, 1, 0, 0);
+    reduce_2d(w.partial, nsplit, D * 4, 1, w.gvec, 1, 0, 0, st);
     if (la0) {  // second-order pair: lambda_a0^T (d geo)
         k_geo_wgrad_partial<<<nsplit, 128, 0, st>>>(la0, Tgeo, E, w.partial);
-        k_reduce_2d<<<cdiv(D * 4, 256), 256, 0, st>>>(w.partial, nsplit, D * 4, 1, w.gvec, 1, 0, 1);
+        reduce_2d(w.partial, nsplit, D * 4, 1, w.gvec, 1, 0, 1, st);
     }
     // dTbl [ns, D] into gvec + 512
     float* dTbl_d = w.gvec + 512;
@@ -306,7 +331,7 @@ void Trainer::compress0(int gi, const float* da0, const float* Min, const float*
     auto add_block = [&](const std::vector<float>& h, float* dst, int rows, int cols, int ld) {
         if (!dst) { err = PET_ERR_ARGUMENT; return; }
         TR_CHECK(hipMemcpyAsync(scratch, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));
-        k_reduce_2d<<<cdiv((int64_t)rows * cols, 256), 256, 0, st>>>(scratch, 1, rows, cols, dst, ld, 0, 1);
+        reduce_2d(scratch, 1, rows, cols, dst, ld, 0, 1, st);
         TR_CHECK(hipStreamSynchronize(st));  // scratch / host vector reuse
     };
     float* dW0 = gp(pre + ".compress.0.weight");

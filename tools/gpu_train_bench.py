@@ -56,9 +56,12 @@ def adam():
     model.adam_step(1e-4, step[0], max_grad_norm=1.0)
 
 
+u = torch.randn(boxes * natoms, 3, device=dev) * 1e-3
+print("backward_train2    %.2f ms" % timeit(lambda: fw.backward_train2(seeds, seeds, u), 3))
+print("workspace2 GB", fw.workspace2.numel() / 1e9)
 print("clip+adam+repack   %.2f ms" % timeit(adam))
 rt.profile(True)
-fw.forward(); fw.backward_train(seeds)
+fw.forward(); fw.backward(seeds); fw.backward_train2(seeds, seeds, u)
 torch.cuda.synchronize()
-for r in sorted(rt.profile_report(), key=lambda r: -r["total_ms"])[:12]:
+for r in sorted(rt.profile_report(), key=lambda r: -r["total_ms"])[:16]:
     print("  %-16s %8.3f ms x%-3d %8.1f TF/s" % (r["name"], r["total_ms"], r["calls"], r["flops"] / max(r["total_ms"], 1e-9) / 1e9))
