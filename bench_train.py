@@ -1,0 +1,159 @@
+"""Secondary benchmark (BASELINE.json configs[2] / configs[3]): one PET TRAINING step on synthetic boxes.
+
+  python bench_train.py --gpus N --steps K --warmup W [--boxes 64 --atoms 1000]
+
+One "step" = the body of the reference's training loop (pet/trainer.py:417-467) on one batch per GPU:
+zero_grad -> forward -> dE/dR (create_graph in the reference) -> MSE(E/atom) + MSE(dE/dR) ->
+loss.backward() (second order) -> [N > 1: mean all-reduce of the flat 11.6 MB gradient bucket over RCCL]
+-> clip_grad_norm_(1.0) -> Adam -> weights re-packed. Neighbour lists are built before the clock starts.
+bench.py (inference, energy + forces) stays the headline metric; this script prints ONE JSON line of the
+same shape for the training row.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(hypers, params, n=1000):
+    """The CPU oracle's training step (fp32, autograd double backward + torch Adam) on ONE n-atom box."""
+    from oracle import nl as onl
+    from oracle import pet as opet
+
+    pos, z, cell = opet.random_box(n, seed=0)
+    i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, hypers["cutoff"])
+    p = {k: (v if k == "species_to_species_index" else v.clone().requires_grad_(True)) for k, v in params.items()}
+    leaves = [v for k, v in p.items() if k != "species_to_species_index"]
+    opt = torch.optim.Adam(leaves, lr=1e-4)
+    sysidx = torch.zeros(n, dtype=torch.long)
+    nt = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(nt)
+
+    def step():
+        opt.zero_grad()
+        r = pos.clone().requires_grad_(True)
+        atomic = opet.pet_atomic_energies(p, hypers, r, cell[None], torch.tensor(i), torch.tensor(j),
+                                          torch.tensor(s).long(), z, sysidx, "energy")[:, 0]
+        e = atomic.sum()
+        (g,) = torch.autograd.grad(e, r, create_graph=True)
+        loss = (e / n) ** 2 + (g ** 2).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(leaves, 1.0)
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        step()
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": n / dt, "unit": "atom-steps/s", "cores": nt, "kind": "port",
+            "sample": f"{reps} x training step (fwd, dE/dR with create_graph, backward, clip, Adam) of one {n}-atom "
+                      f"box, {dt:.2f} s each"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--boxes", type=int, default=64, help="boxes per GPU per step")
+    ap.add_argument("--atoms", type=int, default=1000, help="atoms per box")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from metatrain_amd import distributed as pdist
+
+    rank, local_rank, world = pdist.env_rank()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench_train.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        pdist.init("nccl", dev)
+
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.pet import default_hypers
+    from metatrain_amd.pet.trainer import TrainStep
+    from metatrain_amd.synthetic import random_box, synthetic_params
+
+    hypers = default_hypers()
+    params = synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
+    model = rt.HipModel(hypers, [1, 6, 7, 8])
+    model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+
+    pos_l, z_l, cell_l, pair_l, sys_l = [], [], [], [], []
+    for b, seed in enumerate(pdist.box_seeds(args.boxes, rank)):
+        pos, z, cell = random_box(args.atoms, seed=seed)
+        posd = pos.to(dev)
+        pairs, _ = rt.neighbor_list(posd, cell, [True] * 3, hypers["cutoff"])
+        pairs = pairs.clone()
+        pairs[:, 0:2] += b * args.atoms
+        pos_l.append(posd); z_l.append(z.to(dev)); cell_l.append(cell.to(dev)); pair_l.append(pairs)
+        sys_l.append(torch.full((args.atoms,), b, dtype=torch.int32, device=dev))
+    positions, species, cells = torch.cat(pos_l), torch.cat(z_l), torch.stack(cell_l)
+    pairs, sysidx = torch.cat(pair_l), torch.cat(sys_l)
+    n_atoms = args.boxes * args.atoms
+    graph = rt.HipGraph(model, positions, cells, pairs[:, 0].contiguous(), pairs[:, 1].contiguous(),
+                        pairs[:, 2:5].contiguous(), species, sysidx)
+    fw = rt.HipForward(model, graph, train=True)
+    gen = torch.Generator().manual_seed(1234 + rank)
+    per_box = torch.full((args.boxes,), float(args.atoms), device=dev)
+    target_e = (torch.randn(args.boxes, generator=gen) * 0.1).to(dev) * per_box
+    target_g = (torch.randn(n_atoms, 3, generator=gen) * 0.1).to(dev)
+    step = TrainStep(model, {"warmup_fraction": 0.0, "num_epochs": 10**6})
+
+    losses = []
+    for _ in range(args.warmup):
+        step(graph, fw, target_e, per_box, target_g)
+    pdist.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(step(graph, fw, target_e, per_box, target_g)["loss"])
+    pdist.barrier(dev)
+    elapsed = pdist.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        ls = [float(x) for x in losses]
+        assert all(l == l for l in ls), "training diverged to NaN"
+        out = {
+            "metric": "atom-steps/sec (training step: energy+forces loss, double backward, Adam) PET",
+            "value": n_atoms * world * args.steps / elapsed,
+            "unit": "atom-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic random periodic boxes and random targets, weights from a seeded generator",
+            "config": {
+                "workload": f"PET training step, {args.boxes} x {args.atoms}-atom boxes per GPU per step, default PET "
+                            f"hypers (2.9M params), MSE(E/atom)+MSE(dE/dR), clip 1.0, Adam lr 1e-4",
+                "atoms_per_gpu_per_step": n_atoms,
+                "edges_per_gpu_per_step": int(graph.n_edges),
+                "parallelism": f"boxes sharded over {world} rank(s); one 11.6 MB gradient all-reduce per step"
+                               if world > 1 else "single GPU",
+                "loss_first_last": [ls[0], ls[-1]],
+                "workspace_gb": (fw.nbytes + fw.workspace2.numel()) / 1e9,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(hypers, params)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        pdist.barrier(dev)
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
