@@ -38,6 +38,30 @@ SYMBOLS = [
 ]
 
 
+SOAP_SYMBOLS = [
+    "soap_model_create", "soap_model_destroy", "soap_model_feature_size", "soap_model_set_radial_table",
+    "soap_model_set_param", "soap_model_finalize", "soap_workspace_bytes", "soap_forward", "soap_backward",
+]
+SOAP_MAX_L = 8
+
+
+class SoapHypers(ctypes.Structure):
+    """Mirror of ``soap_hypers_t`` (include/soap_hip.h)."""
+
+    _fields_ = [
+        ("cutoff", c_float),
+        ("cutoff_width", c_float),
+        ("max_angular", c_int32),
+        ("n_per_l", c_int32 * (SOAP_MAX_L + 1)),
+        ("n_species", c_int32),
+        ("n_channels", c_int32),
+        ("legacy", c_int32),
+        ("layernorm", c_int32),
+        ("num_hidden_layers", c_int32),
+        ("num_neurons_per_layer", c_int32),
+    ]
+
+
 class PetHypers(ctypes.Structure):
     """Mirror of ``pet_hypers_t``."""
 
@@ -128,6 +152,18 @@ def load() -> ctypes.CDLL:
     lib.pet_profile_report.argtypes = [c_int, P, POINTER(c_double), POINTER(c_int64), POINTER(c_double),
                                        POINTER(c_double), POINTER(c_int)]
     lib.pet_config_set.argtypes = [c_char_p, c_int]
+    lib.soap_model_create.argtypes = [POINTER(SoapHypers), POINTER(P)]
+    lib.soap_model_destroy.argtypes = [P]
+    lib.soap_model_destroy.restype = None
+    lib.soap_model_feature_size.argtypes = [P]
+    lib.soap_model_feature_size.restype = c_int64
+    lib.soap_model_set_radial_table.argtypes = [P, P, c_int32, P]
+    lib.soap_model_set_param.argtypes = [P, c_char_p, P, c_int64, P]
+    lib.soap_model_finalize.argtypes = [P, P]
+    lib.soap_workspace_bytes.argtypes = [P, c_int64, c_int64]
+    lib.soap_workspace_bytes.restype = c_int64
+    lib.soap_forward.argtypes = [P, P, P, c_int64, P, P, P]
+    lib.soap_backward.argtypes = [P, P, P, c_int64, P, P, P, P]
     _lib = lib
     return lib
 

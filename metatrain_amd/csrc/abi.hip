@@ -263,10 +263,6 @@ using namespace pet;
 struct pet_model {
     Model m;
 };
-struct pet_graph {
-    Graph g;
-    float cutoff;
-};
 
 extern "C" {
 

@@ -162,3 +162,9 @@ struct ProfScope {
 };
 
 }  // namespace pet
+
+// opaque handle behind pet_graph_t (shared by abi.hip and soap.hip)
+struct pet_graph {
+    pet::Graph g;
+    float cutoff;
+};

@@ -1,0 +1,704 @@
+// SOAP-BPNN hot path for gfx950: spherical expansion, power spectrum,
+// LayerNorm + MLP tail, and the hand-written reverse pass for dE/dR. See include/soap_hip.h.
+//
+//   c[i][l][m][n][a] = sum_{p in row i} Y_lm(r_p / |r_p|) R_nl(|r_p|) fc(|r_p|) w_a(species of neighbour)   (a17, spex)
+//   ps[i][l][(n a), (n' a')] = sum_m c[i][l][m][n a] c[i][l][m][n' a']        power_spectrum.py:125-136
+//   e_i = w3 . silu(W2 silu(W1 LN(ps_i * enc[s_i])))                           model.py:553-595, 1204-1219
+//
+// Everything is HBM / latency bound (a few hundred FLOP per byte only in the tail's first Linear);
+// one workgroup per atom, per-pair quantities staged in LDS, CSR rows give coalesced per-atom reads,
+// reductions are fixed-order (no float atomics): bit-reproducible.
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/soap_hip.h"
+#include "common.h"
+#include "model.h"
+
+namespace pet {
+
+// pet_bwd.hip (shared geometry adjoint: dE/dR_a = sum_{p in row a} (dv[rev p] - dv[p]), dE/dcell)
+__global__ void k_pos_grad(const float4* __restrict__ dv, const int* __restrict__ rowptr, const int* __restrict__ rev,
+                           float* __restrict__ gpos, int N);
+__global__ void k_cell_grad(const float4* __restrict__ dv, const int* __restrict__ shift, const int* __restrict__ ctr,
+                            const int* __restrict__ sys, const int* __restrict__ rowptr, float* __restrict__ gcell,
+                            int N, int64_t E);
+
+constexpr int MAXL = SOAP_MAX_L;
+constexpr int PC = 32;  // pairs per LDS chunk
+
+struct SoapDims {
+    int L, C, F, NLM, NCOEF, ITEMS, S, H, NH, ns, legacy, layernorm, n_grid;
+    int n_per_l[MAXL + 1], rad_off[MAXL + 1], coef_off[MAXL + 2], feat_off[MAXL + 2];
+    float rc, width, inv_h;
+};
+
+struct SoapSet {  // weights of one (centre-species) set
+    const float *ln_w = nullptr, *ln_b = nullptr, *W1 = nullptr, *W2 = nullptr, *w3 = nullptr;
+};
+
+struct SoapModel {
+    soap_hypers_t h;
+    SoapDims d;
+    std::map<std::string, std::pair<float*, int64_t>> raw;
+    std::vector<void*> owned;
+    float* table = nullptr;      // [n_grid][F][2]
+    float* shnorm = nullptr;     // [(L+1)*(L+1)] normalisation (sqrt 2 folded in for m > 0)
+    int* coef_lut = nullptr;     // [NCOEF] lm | rn << 8 | a << 16
+    int* item_lut = nullptr;     // [ITEMS] lm | rn << 8 | base << 16
+    float* species_w = nullptr;  // [ns, C]
+    const float* enc = nullptr;  // [ns, S] or null
+    SoapSet* sets = nullptr;     // device array [n_sets]
+    int n_sets = 0;
+    bool finalized = false;
+};
+
+static int salloc(SoapModel& m, void** p, size_t bytes) {
+    PET_HIP_CHECK(hipMalloc(p, bytes > 0 ? bytes : 4));
+    m.owned.push_back(*p);
+    return PET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-pair building blocks
+// ---------------------------------------------------------------------------------------------
+// Orthonormal real spherical harmonics of a unit vector (x, y, z) and, optionally, the gradient of
+// their polynomial extension; Y[l*l + l + m]. shn[l*(L+1)+m] carries sqrt(2) for m > 0.
+__device__ __forceinline__ void sh_eval(float x, float y, float z, int L, const float* __restrict__ shn, float* Y,
+                                        float* Gx, float* Gy, float* Gz) {
+    float c[MAXL + 1], s[MAXL + 1];
+    c[0] = 1.f; s[0] = 0.f;
+    for (int m = 1; m <= L; m++) {
+        c[m] = x * c[m - 1] - y * s[m - 1];
+        s[m] = x * s[m - 1] + y * c[m - 1];
+    }
+    float qmm = 1.f;
+    for (int m = 0; m <= L; m++) {
+        if (m > 0) qmm *= -(2 * m - 1);
+        float q2 = 0.f, dq2 = 0.f;   // Q_{l-2}^m and derivative
+        float q1 = qmm, dq1 = 0.f;   // Q_{l-1}^m (starts as Q_m^m)
+        for (int l = m; l <= L; l++) {
+            float q, dq;
+            if (l == m) { q = qmm; dq = 0.f; }
+            else if (l == m + 1) { q = (2 * m + 1) * z * q1; dq = (2 * m + 1) * q1; }
+            else {
+                const float inv = 1.0f / (l - m);
+                q = ((2 * l - 1) * z * q1 - (l + m - 1) * q2) * inv;
+                dq = ((2 * l - 1) * (q1 + z * dq1) - (l + m - 1) * dq2) * inv;
+            }
+            const float f = shn[l * (L + 1) + m];
+            const int ip = l * l + l + m, im = l * l + l - m;
+            if (m == 0) {
+                Y[ip] = f * q;
+                if (Gx) { Gx[ip] = 0.f; Gy[ip] = 0.f; Gz[ip] = f * dq; }
+            } else {
+                Y[ip] = f * q * c[m];
+                Y[im] = f * q * s[m];
+                if (Gx) {
+                    const float fm = f * q * m;
+                    Gx[ip] = fm * c[m - 1];  Gy[ip] = -fm * s[m - 1]; Gz[ip] = f * dq * c[m];
+                    Gx[im] = fm * s[m - 1];  Gy[im] = fm * c[m - 1];  Gz[im] = f * dq * s[m];
+                }
+            }
+            if (l > m) { q2 = q1; dq2 = dq1; }
+            q1 = q; dq1 = dq;
+            if (l == m) { q2 = 0.f; dq2 = 0.f; }
+        }
+    }
+}
+
+// Hermite spline: R[f] * fc and (optionally) d(R fc)/dr for all F radial functions
+__device__ __forceinline__ void radial_eval(const SoapDims& d, const float* __restrict__ table, float r, float fc,
+                                            float dfc, float* R, float* dR) {
+    float t = r * d.inv_h;
+    int k = (int)t;
+    if (k > d.n_grid - 2) k = d.n_grid - 2;
+    const float s = t - k, h = 1.0f / d.inv_h;
+    const float s2 = s * s, om = 1.f - s;
+    const float h00 = (1.f + 2.f * s) * om * om, h10 = s * om * om, h01 = s2 * (3.f - 2.f * s), h11 = s2 * (s - 1.f);
+    const float g00 = 6.f * s2 - 6.f * s, g10 = 3.f * s2 - 4.f * s + 1.f, g01 = -g00, g11 = 3.f * s2 - 2.f * s;
+    const float2* t0 = reinterpret_cast<const float2*>(table) + (size_t)k * d.F;
+    const float2* t1 = t0 + d.F;
+    for (int f = 0; f < d.F; f++) {
+        const float2 a = t0[f], b = t1[f];
+        const float v = h00 * a.x + h10 * h * a.y + h01 * b.x + h11 * h * b.y;
+        R[f] = v * fc;
+        if (dR) {
+            const float dv = (g00 * a.x + g01 * b.x) * d.inv_h + g10 * a.y + g11 * b.y;
+            dR[f] = dv * fc + v * dfc;
+        }
+    }
+}
+
+__device__ __forceinline__ float shifted_cosine(float r, float rc, float w, float* dfc) {
+    float s = (r - (rc - w)) / w;
+    if (r >= rc) { if (dfc) *dfc = 0.f; return 0.f; }
+    if (s <= 0.f) { if (dfc) *dfc = 0.f; return 1.f; }
+    if (dfc) *dfc = -0.5f * 3.14159274f * sinf(3.14159274f * s) / w;
+    return 0.5f * (1.0f + cosf(3.14159274f * s));
+}
+
+// ---------------------------------------------------------------------------------------------
+// a17: spherical expansion, one workgroup per atom
+// ---------------------------------------------------------------------------------------------
+constexpr int MAXK = 12;  // coefficients per thread (NCOEF <= 256 * MAXK)
+
+__global__ __launch_bounds__(256) void k_soap_expand(SoapDims d, const float4* __restrict__ geo,
+                                                     const int* __restrict__ rowptr, const int* __restrict__ sp_nbr,
+                                                     const float* __restrict__ table, const float* __restrict__ shn,
+                                                     const int* __restrict__ lut, const float* __restrict__ spw,
+                                                     float* __restrict__ Cf) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ys = smem;                     // [PC][NLM]
+    float* Rs = Ys + PC * d.NLM;          // [PC][F]
+    int* sps = reinterpret_cast<int*>(Rs + PC * d.F);
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int p0 = rowptr[i], p1 = rowptr[i + 1];
+    float acc[MAXK];
+    int code[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) {
+        acc[k] = 0.f;
+        const int idx = tid + 256 * k;
+        code[k] = idx < d.NCOEF ? lut[idx] : -1;
+    }
+    for (int base = p0; base < p1; base += PC) {
+        const int npc = min(PC, p1 - base);
+        __syncthreads();
+        if (tid < npc) {
+            const float4 g = geo[base + tid];
+            const float r = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
+            const float ir = r > 0.f ? 1.0f / r : 0.f;
+            sh_eval(g.x * ir, g.y * ir, g.z * ir, d.L, shn, Ys + tid * d.NLM, nullptr, nullptr, nullptr);
+            const float fc = shifted_cosine(r, d.rc, d.width, nullptr);
+            radial_eval(d, table, r, fc, 0.f, Rs + tid * d.F, nullptr);
+            sps[tid] = sp_nbr[base + tid];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MAXK; k++) {
+            if (code[k] < 0) continue;
+            const int lm = code[k] & 255, rn = (code[k] >> 8) & 255, a = code[k] >> 16;
+            float s = acc[k];
+            for (int pp = 0; pp < npc; pp++) s += Ys[pp * d.NLM + lm] * Rs[pp * d.F + rn] * spw[sps[pp] * d.C + a];
+            acc[k] = s;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXK; k++)
+        if (code[k] >= 0) Cf[(size_t)i * d.NCOEF + tid + 256 * k] = acc[k];
+}
+
+// power spectrum (+ centre encoding): feats[i][feat_off[l] + p1 * nc + p2] = sum_m c[l][m][p1] c[l][m][p2]
+__global__ __launch_bounds__(256) void k_soap_ps(SoapDims d, const float* __restrict__ Cf, const int* __restrict__ sp,
+                                                 const float* __restrict__ enc, float* __restrict__ feats) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int i = blockIdx.x;
+    for (int k = threadIdx.x; k < d.NCOEF; k += 256) smem[k] = Cf[(size_t)i * d.NCOEF + k];
+    __syncthreads();
+    const float* e = enc ? enc + (size_t)sp[i] * d.S : nullptr;
+    for (int idx = threadIdx.x; idx < d.S; idx += 256) {
+        int l = 0;
+        while (idx >= d.feat_off[l + 1]) l++;
+        const int nc = d.n_per_l[l] * d.C, q = idx - d.feat_off[l];
+        const int a = q / nc, b = q % nc;
+        const float* base = smem + d.coef_off[l];
+        float s = 0.f;
+        for (int m = 0; m < 2 * l + 1; m++) s += base[m * nc + a] * base[m * nc + b];
+        feats[(size_t)i * d.S + idx] = e ? s * e[idx] : s;
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red /*[8]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu(float x) { return x * sigm(x); }
+__device__ __forceinline__ float dsilu(float x) { const float s = sigm(x); return s * (1.0f + x * (1.0f - s)); }
+
+// ---------------------------------------------------------------------------------------------
+// a18: LayerNorm + MLP + last layer, one workgroup per atom. tail[i] = {mean, rstd, a1[H], a2[H]}
+// ---------------------------------------------------------------------------------------------
+constexpr int MAXH = 32;
+
+__global__ __launch_bounds__(256) void k_soap_tail(SoapDims d, const float* __restrict__ feats,
+                                                   const int* __restrict__ sp, const SoapSet* __restrict__ sets,
+                                                   float* __restrict__ tail, float* __restrict__ atomic) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                 // [S] normalised input
+    float* part = xs + d.S;           // [256][H+1]
+    float* red = part + 256 * (d.H + 1);  // [8]
+    float* hs = red + 8;              // [2*H]
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const SoapSet W = sets[d.legacy ? sp[i] : 0];
+    const float* x = feats + (size_t)i * d.S;
+    float mean = 0.f, rstd = 1.f;
+    if (d.layernorm) {
+        float s = 0.f;
+        for (int k = tid; k < d.S; k += 256) s += x[k];
+        mean = block_sum(s, red) / d.S;
+        float v = 0.f;
+        for (int k = tid; k < d.S; k += 256) { const float c = x[k] - mean; v += c * c; }
+        rstd = rsqrtf(block_sum(v, red) / d.S + 1e-5f);
+        for (int k = tid; k < d.S; k += 256) xs[k] = (x[k] - mean) * rstd * W.ln_w[k] + W.ln_b[k];
+    } else {
+        for (int k = tid; k < d.S; k += 256) xs[k] = x[k];
+    }
+    __syncthreads();
+    float acc[MAXH];
+#pragma unroll
+    for (int j = 0; j < MAXH; j++) acc[j] = 0.f;
+    for (int k = tid; k < d.S; k += 256) {
+        const float xv = xs[k];
+#pragma unroll
+        for (int j = 0; j < MAXH; j++)
+            if (j < d.H) acc[j] += W.W1[(size_t)j * d.S + k] * xv;
+    }
+#pragma unroll
+    for (int j = 0; j < MAXH; j++)
+        if (j < d.H) part[tid * (d.H + 1) + j] = acc[j];
+    __syncthreads();
+    if (tid < d.H) {
+        float s = 0.f;
+        for (int t = 0; t < 256; t++) s += part[t * (d.H + 1) + tid];
+        hs[tid] = s;  // a1
+    }
+    __syncthreads();
+    float a2 = 0.f;
+    if (tid < d.H && d.NH > 1) {
+        for (int q = 0; q < d.H; q++) a2 += W.W2[tid * d.H + q] * silu(hs[q]);
+        hs[d.H + tid] = a2;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float e = 0.f;
+        if (tid < d.H) e = W.w3[tid] * silu(d.NH > 1 ? hs[d.H + tid] : hs[tid]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+        if (tid == 0) atomic[i] = e;
+    }
+    float* tl = tail + (size_t)i * (2 + 2 * d.H);
+    if (tid == 0) { tl[0] = mean; tl[1] = rstd; }
+    if (tid < 2 * d.H) tl[2 + tid] = hs[tid];
+}
+
+// reverse of the tail: dF[i][k] = d e_i / d ps_i[k] * gA[i]
+__global__ __launch_bounds__(256) void k_soap_tail_bwd(SoapDims d, const float* __restrict__ feats,
+                                                       const int* __restrict__ sp, const SoapSet* __restrict__ sets,
+                                                       const float* __restrict__ enc, const float* __restrict__ tail,
+                                                       const float* __restrict__ gA, float* __restrict__ dF) {
+    __shared__ float da1[MAXH], da2[MAXH], red[8];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const SoapSet W = sets[d.legacy ? sp[i] : 0];
+    const float* tl = tail + (size_t)i * (2 + 2 * d.H);
+    const float mean = tl[0], rstd = tl[1], g = gA[i];
+    if (tid < d.H) {
+        if (d.NH > 1) da2[tid] = g * W.w3[tid] * dsilu(tl[2 + d.H + tid]);
+        else da1[tid] = g * W.w3[tid] * dsilu(tl[2 + tid]);
+    }
+    __syncthreads();
+    if (tid < d.H && d.NH > 1) {
+        float s = 0.f;
+        for (int j = 0; j < d.H; j++) s += W.W2[j * d.H + tid] * da2[j];
+        da1[tid] = s * dsilu(tl[2 + tid]);
+    }
+    __syncthreads();
+    const float* x = feats + (size_t)i * d.S;
+    // pass 1: dxn gamma and the two LayerNorm means
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = tid; k < d.S; k += 256) {
+        float dx = 0.f;
+        for (int q = 0; q < d.H; q++) dx += W.W1[(size_t)q * d.S + k] * da1[q];
+        if (d.layernorm) {
+            dx *= W.ln_w[k];
+            s1 += dx;
+            s2 += dx * (x[k] - mean) * rstd;
+        }
+        dF[(size_t)i * d.S + k] = dx;
+    }
+    if (d.layernorm) {
+        const float m1 = block_sum(s1, red) / d.S;
+        const float m2 = block_sum(s2, red) / d.S;
+        for (int k = tid; k < d.S; k += 256) {
+            const float xh = (x[k] - mean) * rstd;
+            dF[(size_t)i * d.S + k] = rstd * (dF[(size_t)i * d.S + k] - m1 - xh * m2);
+        }
+    }
+    if (enc) {
+        const float* e = enc + (size_t)sp[i] * d.S;
+        for (int k = tid; k < d.S; k += 256) dF[(size_t)i * d.S + k] *= e[k];
+    }
+}
+
+// dC[l][m][a] = sum_b (dF[l][a][b] + dF[l][b][a]) c[l][m][b]
+__global__ __launch_bounds__(256) void k_soap_ps_bwd(SoapDims d, const float* __restrict__ Cf,
+                                                     const float* __restrict__ dF, const int* __restrict__ lut,
+                                                     float* __restrict__ dCf) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int i = blockIdx.x;
+    for (int k = threadIdx.x; k < d.NCOEF; k += 256) smem[k] = Cf[(size_t)i * d.NCOEF + k];
+    __syncthreads();
+    const float* dFi = dF + (size_t)i * d.S;
+    for (int idx = threadIdx.x; idx < d.NCOEF; idx += 256) {
+        int l = 0;
+        while (idx >= d.coef_off[l + 1]) l++;
+        const int nc = d.n_per_l[l] * d.C, q = idx - d.coef_off[l];
+        const int m = q / nc, a = q % nc;
+        const float* crow = smem + d.coef_off[l] + m * nc;
+        const float* fb = dFi + d.feat_off[l];
+        float s = 0.f;
+        for (int b = 0; b < nc; b++) s += (fb[a * nc + b] + fb[b * nc + a]) * crow[b];
+        dCf[(size_t)i * d.NCOEF + idx] = s;
+    }
+}
+
+// reverse of the expansion: dv[p] = d/d(edge vector) for every pair of the row
+__global__ __launch_bounds__(256) void k_soap_expand_bwd(SoapDims d, const float4* __restrict__ geo,
+                                                         const int* __restrict__ rowptr,
+                                                         const int* __restrict__ sp_nbr,
+                                                         const float* __restrict__ table,
+                                                         const float* __restrict__ shn, const int* __restrict__ ilut,
+                                                         const float* __restrict__ spw,
+                                                         const float* __restrict__ dCf, float4* __restrict__ dv) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dCs = smem;                       // [NCOEF]
+    float* Ys = dCs + d.NCOEF;               // [PC][NLM] and three gradient components w.r.t. the edge vector
+    float* Gx = Ys + PC * d.NLM;
+    float* Gy = Gx + PC * d.NLM;
+    float* Gz = Gy + PC * d.NLM;
+    float* Rs = Gz + PC * d.NLM;             // [PC][F] R fc, d(R fc)/dr
+    float* dRs = Rs + PC * d.F;
+    float* us = dRs + PC * d.F;              // [PC][4] unit vector
+    int* sps = reinterpret_cast<int*>(us + PC * 4);
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < d.NCOEF; k += 256) dCs[k] = dCf[(size_t)i * d.NCOEF + k];
+    const int p0 = rowptr[i], p1 = rowptr[i + 1];
+    for (int base = p0; base < p1; base += PC) {
+        const int npc = min(PC, p1 - base);
+        __syncthreads();
+        if (tid < npc) {
+            const float4 g = geo[base + tid];
+            const float r = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
+            const float ir = r > 0.f ? 1.0f / r : 0.f;
+            const float ux = g.x * ir, uy = g.y * ir, uz = g.z * ir;
+            float* Y = Ys + tid * d.NLM; float* gx = Gx + tid * d.NLM; float* gy = Gy + tid * d.NLM; float* gz = Gz + tid * d.NLM;
+            sh_eval(ux, uy, uz, d.L, shn, Y, gx, gy, gz);
+            for (int k = 0; k < d.NLM; k++) {  // chain through u = v / r: (I - u u^T) / r
+                const float dot = ux * gx[k] + uy * gy[k] + uz * gz[k];
+                gx[k] = (gx[k] - ux * dot) * ir; gy[k] = (gy[k] - uy * dot) * ir; gz[k] = (gz[k] - uz * dot) * ir;
+            }
+            float dfc;
+            const float fc = shifted_cosine(r, d.rc, d.width, &dfc);
+            radial_eval(d, table, r, fc, dfc, Rs + tid * d.F, dRs + tid * d.F);
+            us[tid * 4] = ux; us[tid * 4 + 1] = uy; us[tid * 4 + 2] = uz;
+            sps[tid] = sp_nbr[base + tid];
+        }
+        __syncthreads();
+        for (int pp = wave; pp < npc; pp += 4) {
+            const float* w = spw + sps[pp] * d.C;
+            const float ux = us[pp * 4], uy = us[pp * 4 + 1], uz = us[pp * 4 + 2];
+            float ax = 0.f, ay = 0.f, az = 0.f;
+            for (int it = lane; it < d.ITEMS; it += 64) {
+                const int code = ilut[it];
+                const int lm = code & 255, rn = (code >> 8) & 255, cb = code >> 16;
+                float A = 0.f;
+                for (int a = 0; a < d.C; a++) A += dCs[cb + a] * w[a];
+                const float y = Ys[pp * d.NLM + lm], rf = Rs[pp * d.F + rn], drf = dRs[pp * d.F + rn];
+                const float radial = A * drf * y;   // along the unit vector
+                const float ang = A * rf;
+                ax += radial * ux + ang * Gx[pp * d.NLM + lm];
+                ay += radial * uy + ang * Gy[pp * d.NLM + lm];
+                az += radial * uz + ang * Gz[pp * d.NLM + lm];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                ax += __shfl_xor(ax, o); ay += __shfl_xor(ay, o); az += __shfl_xor(az, o);
+            }
+            if (lane == 0) dv[base + pp] = make_float4(ax, ay, az, 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct SoapWs {
+    float *Cf, *feats, *tail, *dF, *dCf, *dv;
+    size_t bytes;
+};
+static void carve_soap(const SoapDims& d, int64_t N, int64_t E, void* base, SoapWs& w) {
+    Carver c(base);
+    const int64_t Na = N > 0 ? N : 1, Ea = E > 0 ? E : 1;
+    w.Cf = c.take<float>(Na * d.NCOEF);
+    w.feats = c.take<float>(Na * d.S);
+    w.tail = c.take<float>(Na * (2 + 2 * d.H));
+    w.dF = c.take<float>(Na * d.S);
+    w.dCf = c.take<float>(Na * d.NCOEF);
+    w.dv = c.take<float>(Ea * 4);
+    w.bytes = c.off;
+}
+
+static int soap_get(const SoapModel& m, const std::string& key, int64_t numel, const float** out) {
+    auto it = m.raw.find(key);
+    PET_REQUIRE(it != m.raw.end(), PET_ERR_ARGUMENT, "missing parameter '" + key + "'");
+    PET_REQUIRE(it->second.second == numel, PET_ERR_ARGUMENT, "parameter '" + key + "' has the wrong size");
+    *out = it->second.first;
+    return PET_OK;
+}
+
+static int soap_finalize(SoapModel& m, hipStream_t st) {
+    const SoapDims& d = m.d;
+    PET_REQUIRE(m.table != nullptr, PET_ERR_ARGUMENT, "soap_model_set_radial_table has not been called");
+    int rc;
+    // normalisation of the real spherical harmonics: sqrt((2l+1)/(4 pi) (l-m)!/(l+m)!) [* sqrt 2]
+    std::vector<float> shn((d.L + 1) * (d.L + 1), 0.f);
+    for (int l = 0; l <= d.L; l++)
+        for (int mm = 0; mm <= l; mm++) {
+            double f = (2 * l + 1) / (4.0 * M_PI);
+            for (int k = l - mm + 1; k <= l + mm; k++) f /= k;
+            shn[l * (d.L + 1) + mm] = (float)(sqrt(f) * (mm > 0 ? sqrt(2.0) : 1.0));
+        }
+    std::vector<int> clut(d.NCOEF), ilut(d.ITEMS);
+    int idx = 0, it = 0;
+    for (int l = 0; l <= d.L; l++)
+        for (int mi = 0; mi < 2 * l + 1; mi++)
+            for (int n = 0; n < d.n_per_l[l]; n++) {
+                const int lm = l * l + mi, rn = d.rad_off[l] + n;
+                ilut[it++] = lm | (rn << 8) | (idx << 16);
+                for (int a = 0; a < d.C; a++) clut[idx++] = lm | (rn << 8) | (a << 16);
+            }
+    if (!m.shnorm) {
+        if ((rc = salloc(m, (void**)&m.shnorm, shn.size() * 4))) return rc;
+        if ((rc = salloc(m, (void**)&m.coef_lut, clut.size() * 4))) return rc;
+        if ((rc = salloc(m, (void**)&m.item_lut, ilut.size() * 4))) return rc;
+        if ((rc = salloc(m, (void**)&m.species_w, (size_t)d.ns * d.C * 4))) return rc;
+        if ((rc = salloc(m, (void**)&m.sets, sizeof(SoapSet) * m.n_sets))) return rc;
+    }
+    PET_HIP_CHECK(hipMemcpyAsync(m.shnorm, shn.data(), shn.size() * 4, hipMemcpyHostToDevice, st));
+    PET_HIP_CHECK(hipMemcpyAsync(m.coef_lut, clut.data(), clut.size() * 4, hipMemcpyHostToDevice, st));
+    PET_HIP_CHECK(hipMemcpyAsync(m.item_lut, ilut.data(), ilut.size() * 4, hipMemcpyHostToDevice, st));
+    if (d.legacy) {
+        std::vector<float> eye((size_t)d.ns * d.C, 0.f);
+        for (int s = 0; s < d.ns; s++) eye[s * d.C + s] = 1.f;
+        PET_HIP_CHECK(hipMemcpyAsync(m.species_w, eye.data(), eye.size() * 4, hipMemcpyHostToDevice, st));
+        m.enc = nullptr;
+    } else {
+        const float* emb;
+        if ((rc = soap_get(m, "species_embedding.weight", (int64_t)d.ns * d.C, &emb))) return rc;
+        PET_HIP_CHECK(hipMemcpyAsync(m.species_w, emb, (size_t)d.ns * d.C * 4, hipMemcpyDeviceToDevice, st));
+        if ((rc = soap_get(m, "center_encoding.weight", (int64_t)d.ns * d.S, &m.enc))) return rc;
+    }
+    std::vector<SoapSet> sets(m.n_sets);
+    for (int s = 0; s < m.n_sets; s++) {
+        const std::string ss = std::to_string(s);
+        if (d.layernorm) {
+            if ((rc = soap_get(m, "layernorm." + ss + ".weight", d.S, &sets[s].ln_w))) return rc;
+            if ((rc = soap_get(m, "layernorm." + ss + ".bias", d.S, &sets[s].ln_b))) return rc;
+        }
+        if ((rc = soap_get(m, "bpnn." + ss + ".0.weight", (int64_t)d.H * d.S, &sets[s].W1))) return rc;
+        if (d.NH > 1 && (rc = soap_get(m, "bpnn." + ss + ".2.weight", (int64_t)d.H * d.H, &sets[s].W2))) return rc;
+        if ((rc = soap_get(m, "last_layers.energy." + ss + ".weight", d.H, &sets[s].w3))) return rc;
+    }
+    PET_HIP_CHECK(hipMemcpyAsync(m.sets, sets.data(), sizeof(SoapSet) * m.n_sets, hipMemcpyHostToDevice, st));
+    PET_HIP_CHECK(hipStreamSynchronize(st));  // host vectors go out of scope
+    m.finalized = true;
+    return PET_OK;
+}
+
+static size_t lds_expand(const SoapDims& d) { return (size_t)PC * (d.NLM + d.F + 1) * 4; }
+static size_t lds_expand_bwd(const SoapDims& d) {
+    return ((size_t)d.NCOEF + (size_t)PC * (4 * d.NLM + 2 * d.F + 4 + 1)) * 4;
+}
+static size_t lds_tail(const SoapDims& d) { return ((size_t)d.S + 256 * (d.H + 1) + 8 + 2 * d.H) * 4; }
+
+static int soap_fwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_bytes, float* atomic, float* features,
+                    hipStream_t st) {
+    const SoapDims& d = m.d;
+    SoapWs w;
+    carve_soap(d, g.n_nodes, g.n_edges, ws, w);
+    PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "soap workspace too small");
+    const int N = (int)g.n_nodes;
+    if (N == 0) return PET_OK;
+    allow_big_lds(k_soap_tail, lds_tail(d));
+    {
+        ProfScope ps("soap_expand", st, 2.0 * (double)g.n_edges * d.NCOEF, (double)g.n_edges * 20 + (double)N * d.NCOEF * 4);
+        k_soap_expand<<<N, 256, lds_expand(d), st>>>(d, g.geo, g.rowptr, g.sp_nbr, m.table, m.shnorm, m.coef_lut,
+                                                     m.species_w, w.Cf);
+    }
+    {
+        ProfScope ps("soap_ps", st, 2.0 * (double)N * d.S * (d.L + 1), (double)N * (d.NCOEF + d.S) * 4);
+        k_soap_ps<<<N, 256, (size_t)d.NCOEF * 4, st>>>(d, w.Cf, g.sp, m.enc, w.feats);
+    }
+    {
+        ProfScope ps("soap_tail", st, 2.0 * (double)N * d.S * d.H, (double)N * d.S * 4);
+        k_soap_tail<<<N, 256, lds_tail(d), st>>>(d, w.feats, g.sp, m.sets, w.tail, atomic);
+    }
+    if (features)
+        PET_HIP_CHECK(hipMemcpyAsync(features, w.feats, (size_t)N * d.S * 4, hipMemcpyDeviceToDevice, st));
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
+static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA, float* gpos,
+                    float* gcell, hipStream_t st) {
+    const SoapDims& d = m.d;
+    SoapWs w;
+    carve_soap(d, g.n_nodes, g.n_edges, ws, w);
+    PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "soap workspace too small");
+    const int N = (int)g.n_nodes;
+    if (N == 0) return PET_OK;
+    if (g.n_edges == 0) {
+        PET_HIP_CHECK(hipMemsetAsync(gpos, 0, (size_t)N * 3 * 4, st));
+        if (gcell) PET_HIP_CHECK(hipMemsetAsync(gcell, 0, g.n_systems * 9 * 4, st));
+        return PET_OK;
+    }
+    int bad = 0;
+    PET_HIP_CHECK(hipMemcpyAsync(&bad, g.scalars + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+    PET_HIP_CHECK(hipStreamSynchronize(st));
+    PET_REQUIRE(bad == 0, PET_ERR_GRAPH, "neighbour list is not a full list: edges without a reverse edge");
+    allow_big_lds(k_soap_expand_bwd, lds_expand_bwd(d));
+    {
+        ProfScope ps("soap_tail_bwd", st, 2.0 * (double)N * d.S * d.H, (double)N * d.S * 8);
+        k_soap_tail_bwd<<<N, 256, 0, st>>>(d, w.feats, g.sp, m.sets, m.enc, w.tail, gA, w.dF);
+    }
+    {
+        ProfScope ps("soap_ps_bwd", st, 4.0 * (double)N * d.S * (d.L + 1), (double)N * (2 * d.NCOEF + d.S) * 4);
+        k_soap_ps_bwd<<<N, 256, (size_t)d.NCOEF * 4, st>>>(d, w.Cf, w.dF, m.coef_lut, w.dCf);
+    }
+    {
+        ProfScope ps("soap_expand_bwd", st, 2.0 * (double)g.n_edges * (d.NCOEF + 8.0 * d.ITEMS),
+                     (double)g.n_edges * 36 + (double)N * d.NCOEF * 4);
+        k_soap_expand_bwd<<<N, 256, lds_expand_bwd(d), st>>>(d, g.geo, g.rowptr, g.sp_nbr, m.table, m.shnorm,
+                                                             m.item_lut, m.species_w, w.dCf,
+                                                             reinterpret_cast<float4*>(w.dv));
+    }
+    k_pos_grad<<<cdiv(N, 16), 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.rowptr, g.rev, gpos, N);
+    if (gcell)
+        k_cell_grad<<<(int)g.n_systems, 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.shift, g.ctr, g.sys,
+                                                      g.rowptr, gcell, N, g.n_edges);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
+}  // namespace pet
+
+using namespace pet;
+
+struct soap_model {
+    SoapModel m;
+};
+
+extern "C" {
+
+int soap_model_create(const soap_hypers_t* h, soap_model_t** out) {
+    PET_REQUIRE(h && out, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(h->max_angular >= 0 && h->max_angular <= SOAP_MAX_L, PET_ERR_UNSUPPORTED, "max_angular out of range");
+    PET_REQUIRE(h->num_neurons_per_layer >= 1 && h->num_neurons_per_layer <= MAXH, PET_ERR_UNSUPPORTED,
+                "num_neurons_per_layer > 32 is not built");
+    PET_REQUIRE(h->num_hidden_layers == 1 || h->num_hidden_layers == 2, PET_ERR_UNSUPPORTED,
+                "num_hidden_layers must be 1 or 2");
+    PET_REQUIRE(h->n_species >= 1 && h->n_channels >= 1 && h->n_channels <= 255, PET_ERR_ARGUMENT, "bad species counts");
+    PET_REQUIRE(!h->legacy || h->n_channels == h->n_species, PET_ERR_ARGUMENT,
+                "legacy (Orthogonal species): n_channels must equal n_species");
+    soap_model_t* sm = new soap_model_t();
+    SoapModel& m = sm->m;
+    m.h = *h;
+    SoapDims& d = m.d;
+    memset(&d, 0, sizeof(d));
+    d.L = h->max_angular; d.C = h->n_channels; d.ns = h->n_species; d.legacy = h->legacy; d.layernorm = h->layernorm;
+    d.H = h->num_neurons_per_layer; d.NH = h->num_hidden_layers; d.rc = h->cutoff; d.width = h->cutoff_width;
+    d.NLM = (d.L + 1) * (d.L + 1);
+    int f = 0, co = 0, fo = 0, items = 0;
+    for (int l = 0; l <= d.L; l++) {
+        const int n = h->n_per_l[l];
+        if (n < 0 || n > 64) { delete sm; set_error("bad n_per_l"); return PET_ERR_ARGUMENT; }
+        d.n_per_l[l] = n; d.rad_off[l] = f; d.coef_off[l] = co; d.feat_off[l] = fo;
+        f += n; co += (2 * l + 1) * n * d.C; fo += (n * d.C) * (n * d.C); items += (2 * l + 1) * n;
+    }
+    d.coef_off[d.L + 1] = co; d.feat_off[d.L + 1] = fo;
+    d.F = f; d.NCOEF = co; d.S = fo; d.ITEMS = items;
+    m.n_sets = h->legacy ? h->n_species : 1;
+    if (d.F > 255 || d.NLM > 255 || d.NCOEF > 256 * MAXK || d.NCOEF >= 65536) {
+        delete sm;
+        set_error("SOAP basis too large for the compiled limits");
+        return PET_ERR_UNSUPPORTED;
+    }
+    *out = sm;
+    return PET_OK;
+}
+
+void soap_model_destroy(soap_model_t* sm) {
+    if (!sm) return;
+    for (void* p : sm->m.owned) (void)hipFree(p);
+    delete sm;
+}
+
+int64_t soap_model_feature_size(const soap_model_t* sm) { return sm ? sm->m.d.S : -1; }
+
+int soap_model_set_radial_table(soap_model_t* sm, const float* d_table, int32_t n_grid, void* stream) {
+    PET_REQUIRE(sm && d_table && n_grid >= 4, PET_ERR_ARGUMENT, "bad argument");
+    SoapModel& m = sm->m;
+    const size_t bytes = (size_t)n_grid * m.d.F * 2 * sizeof(float);
+    int rc = salloc(m, (void**)&m.table, bytes);
+    if (rc) return rc;
+    PET_HIP_CHECK(hipMemcpyAsync(m.table, d_table, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    m.d.n_grid = n_grid;
+    m.d.inv_h = (float)(n_grid - 1) / m.d.rc;
+    m.finalized = false;
+    return PET_OK;
+}
+
+int soap_model_set_param(soap_model_t* sm, const char* key, const float* d_data, int64_t numel, void* stream) {
+    PET_REQUIRE(sm && key && d_data && numel > 0, PET_ERR_ARGUMENT, "bad argument");
+    SoapModel& m = sm->m;
+    float* p;
+    auto it = m.raw.find(key);
+    if (it != m.raw.end() && it->second.second == numel) {
+        p = it->second.first;
+    } else {
+        int rc = salloc(m, (void**)&p, numel * sizeof(float));
+        if (rc) return rc;
+        m.raw[key] = {p, numel};
+    }
+    PET_HIP_CHECK(hipMemcpyAsync(p, d_data, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    m.finalized = false;
+    return PET_OK;
+}
+
+int soap_model_finalize(soap_model_t* sm, void* stream) {
+    PET_REQUIRE(sm, PET_ERR_ARGUMENT, "null model");
+    return soap_finalize(sm->m, (hipStream_t)stream);
+}
+
+int64_t soap_workspace_bytes(const soap_model_t* sm, int64_t n_nodes, int64_t n_edges) {
+    if (!sm) return -1;
+    SoapWs w;
+    carve_soap(sm->m.d, n_nodes, n_edges, nullptr, w);
+    return (int64_t)w.bytes;
+}
+
+int soap_forward(const soap_model_t* sm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
+                 float* d_atomic, float* d_features, void* stream) {
+    PET_REQUIRE(sm && pg && d_workspace && d_atomic, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(sm->m.finalized, PET_ERR_ARGUMENT, "soap_model_finalize has not been called");
+    return soap_fwd(sm->m, pg->g, d_workspace, workspace_bytes, d_atomic, d_features, (hipStream_t)stream);
+}
+
+int soap_backward(const soap_model_t* sm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
+                  const float* d_grad_atomic, float* d_grad_positions, float* d_grad_cells, void* stream) {
+    PET_REQUIRE(sm && pg && d_workspace && d_grad_atomic && d_grad_positions, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(sm->m.finalized, PET_ERR_ARGUMENT, "soap_model_finalize has not been called");
+    return soap_bwd(sm->m, pg->g, d_workspace, workspace_bytes, d_grad_atomic, d_grad_positions, d_grad_cells,
+                    (hipStream_t)stream);
+}
+
+}  // extern "C"

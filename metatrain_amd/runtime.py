@@ -109,6 +109,16 @@ class HipModel:
             torch.cuda.current_stream().synchronize()  # src may be a temporary
         check(self.lib.pet_model_finalize(self._handle, _stream()))
 
+    def load_species_table(self) -> None:
+        """Upload only ``species_to_species_index`` (enough for graph building: the SOAP path shares the
+        PET graph kernels but none of the PET weights)."""
+        table = torch.full((max(self.atomic_types) + 1,), -1, dtype=torch.int64)
+        for i, z in enumerate(self.atomic_types):
+            table[z] = i
+        src = table.cuda().contiguous()
+        check(self.lib.pet_model_set_param(self._handle, b"species_to_species_index", _ptr(src), src.numel(), _stream()))
+        torch.cuda.current_stream().synchronize()
+
     @property
     def num_params(self) -> int:
         return int(self.lib.pet_model_num_params(self._handle))

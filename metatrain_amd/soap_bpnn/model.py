@@ -1,0 +1,99 @@
+"""``SoapBpnnHip``: the plain-tensor SOAP-BPNN path on MI355X behind ``include/soap_hip.h``.
+
+Mirrors what ``SoapBpnn.forward`` computes below its metatensor wrapping (``soap_bpnn/model.py:540-595``
+and the scalar last layer ``:1204-1219``): power spectrum -> (centre encoding) -> LayerNorm -> MLP ->
+bias-free linear last layer, per centre species when ``legacy``; dE/dR through the hand-written reverse pass.
+**Parity unpinned** against torch-spex (not shipped with the reference); checked against ``oracle/soap.py``.
+"""
+from ctypes import byref, c_void_p
+from typing import Dict, List, Optional
+
+import torch
+
+from .. import _lib
+from .. import runtime as rt
+from .._lib import PetHipError, check
+from ..pet.hypers import default_hypers as pet_default_hypers
+from . import radial
+
+
+class SoapBpnnHip:
+    def __init__(self, hypers: dict, atomic_types: List[int], n_grid: int = 2049):
+        self.lib = _lib.load()
+        self.hypers = hypers
+        self.atomic_types = list(atomic_types)
+        so = hypers["soap"]
+        self.cutoff, self.width = float(so["cutoff"]["radius"]), float(so["cutoff"]["width"])
+        self.n_per_l, zeros, norms = radial.laplacian_eigenstates(self.cutoff, so["max_radial"], so["max_angular"])
+        ns = len(atomic_types)
+        self.legacy = bool(hypers["legacy"])
+        h = _lib.SoapHypers()
+        h.cutoff, h.cutoff_width, h.max_angular = self.cutoff, self.width, so["max_angular"]
+        for l, n in enumerate(self.n_per_l):
+            h.n_per_l[l] = n
+        h.n_species = ns
+        h.n_channels = ns if self.legacy else 4
+        h.legacy = int(self.legacy)
+        h.layernorm = int(bool(hypers["bpnn"]["layernorm"]))
+        h.num_hidden_layers = hypers["bpnn"]["num_hidden_layers"]
+        h.num_neurons_per_layer = hypers["bpnn"]["num_neurons_per_layer"]
+        self._handle = c_void_p()
+        check(self.lib.soap_model_create(byref(h), byref(self._handle)))
+        self.feature_size = int(self.lib.soap_model_feature_size(self._handle))
+        table = torch.from_numpy(radial.spline_table(self.cutoff, zeros, norms, n_grid)).cuda().contiguous()
+        check(self.lib.soap_model_set_radial_table(self._handle, rt._ptr(table), n_grid, rt._stream()))
+        torch.cuda.current_stream().synchronize()
+        # the graph (CSR order, edge vectors, ij->ji map) is the PET path's, built with the SOAP cutoff
+        gh = pet_default_hypers()
+        gh.update(cutoff=self.cutoff, cutoff_width=self.width, cutoff_function="Cosine")
+        self._graph_model = rt.HipModel(gh, self.atomic_types)
+        self._graph_model.load_species_table()
+        self._ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        try:
+            if h is not None and h.value:
+                self.lib.soap_model_destroy(h)
+                self._handle = c_void_p()
+        except Exception:
+            pass
+
+    def load(self, params: Dict[str, torch.Tensor]) -> None:
+        for key, t in params.items():
+            rt._require_cuda(t)
+            src = t.detach().to(torch.float32).contiguous()
+            check(self.lib.soap_model_set_param(self._handle, key.encode(), rt._ptr(src), src.numel(), rt._stream()))
+            torch.cuda.current_stream().synchronize()
+        check(self.lib.soap_model_finalize(self._handle, rt._stream()))
+
+    def graph(self, positions, cells, centers, neighbors, cell_shifts, species, system_indices) -> rt.HipGraph:
+        return rt.HipGraph(self._graph_model, positions, cells, centers, neighbors, cell_shifts, species,
+                           system_indices)
+
+    def _workspace(self, g: rt.HipGraph) -> torch.Tensor:
+        n = int(self.lib.soap_workspace_bytes(self._handle, g.n_nodes, g.n_edges))
+        if n < 0:
+            raise PetHipError("soap_workspace_bytes failed")
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = torch.empty(n, dtype=torch.uint8, device=g.workspace.device)
+        return self._ws
+
+    def forward(self, g: rt.HipGraph, want_features: bool = False):
+        ws = self._workspace(g)
+        dev = ws.device
+        atomic = torch.empty(g.n_nodes, dtype=torch.float32, device=dev)
+        feats = torch.empty((g.n_nodes, self.feature_size), dtype=torch.float32, device=dev) if want_features else None
+        check(self.lib.soap_forward(self._handle, g.handle, rt._ptr(ws), ws.numel(), rt._ptr(atomic), rt._ptr(feats),
+                                    rt._stream()))
+        return (atomic, feats) if want_features else atomic
+
+    def backward(self, g: rt.HipGraph, grad_atomic: torch.Tensor, want_cell_grad: bool = False):
+        ws = self._workspace(g)
+        dev = ws.device
+        ga = grad_atomic.to(torch.float32).contiguous()
+        gpos = torch.empty((g.n_nodes, 3), dtype=torch.float32, device=dev)
+        gcell = torch.empty((g.n_systems, 3, 3), dtype=torch.float32, device=dev) if want_cell_grad else None
+        check(self.lib.soap_backward(self._handle, g.handle, rt._ptr(ws), ws.numel(), rt._ptr(ga), rt._ptr(gpos),
+                                     rt._ptr(gcell), rt._stream()))
+        return (gpos, gcell) if want_cell_grad else gpos

@@ -32,6 +32,14 @@ def test_header_symbols_are_exported(lib):
     assert b"gfx950" in lib.pet_version()
 
 
+def test_soap_header_symbols_are_exported(lib):
+    header = open(os.path.join(ROOT, "include", "soap_hip.h")).read()
+    declared = set(re.findall(r"\b(soap_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SOAP_SYMBOLS), declared ^ set(_lib.SOAP_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in soap_hip.h but not exported"
+
+
 def test_hypers_struct_and_supported(lib):
     h = rt.hypers_struct(dict(opet.DEFAULT_HYPERS), [1, 6, 7, 8])
     assert lib.pet_hypers_supported(ctypes.byref(h)) == 1

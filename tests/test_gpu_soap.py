@@ -1,0 +1,56 @@
+"""GPU parity tests of the SOAP-BPNN path against oracle/soap.py on seeded inputs,
+through the C ABI (include/soap_hip.h). Bar: energies / forces within 1e-5 relative in fp32.
+Parity against torch-spex itself is UNPINNED (oracle/soap.py header)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nl as onl
+from oracle import pet as opet
+from oracle import soap as osoap
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _box(n, seed, dtype=torch.float64):
+    pos, z, cell = opet.random_box(n, seed=seed, dtype=dtype)
+    i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, 5.0)
+    return pos, z, cell[None], torch.tensor(i), torch.tensor(j), torch.tensor(s).long(), torch.zeros(n, dtype=torch.long)
+
+
+def _relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+@pytest.mark.parametrize("legacy", [True, False])
+def test_soap_bpnn_energy_features_and_forces(legacy):
+    from metatrain_amd.soap_bpnn import SoapBpnnHip
+
+    dev = torch.device("cuda:0")
+    hypers = dict(osoap.DEFAULT_HYPERS, legacy=legacy)
+    types = [1, 6, 7, 8]
+    n_per_l = osoap.basis(hypers)[0]
+    params = osoap.synthetic_params(hypers, 4, n_per_l, 0, torch.float32)
+    pos, z, cells, ci, cj, cs, sysidx = _box(96, seed=5)
+    p64 = {k: v.double() for k, v in params.items()}
+    e_ref, g_ref, a_ref = osoap.energy_and_gradient(p64, hypers, types, pos, cells, ci, cj, cs, z, sysidx)
+    _, f_ref = osoap.soap_bpnn_atomic_energies(p64, hypers, types, pos, cells, ci, cj, cs, z, sysidx, return_features=True)
+
+    model = SoapBpnnHip(hypers, types)
+    assert model.n_per_l == n_per_l and model.feature_size == osoap.soap_size(n_per_l, 4)
+    model.load({k: v.to(dev) for k, v in params.items()})
+    g = model.graph(pos.float().to(dev), cells.float().to(dev), ci.to(dev), cj.to(dev), cs.to(dev), z.to(dev),
+                    sysidx.int().to(dev))
+    atomic, feats = model.forward(g, want_features=True)
+    grad = model.backward(g, torch.ones_like(atomic))
+    assert _relmax(feats.cpu().numpy(), f_ref.detach().numpy()) < TOL
+    assert _relmax(atomic.cpu().numpy(), a_ref.numpy()) < TOL
+    assert abs(float(atomic.double().sum()) - float(e_ref[0])) / abs(float(e_ref[0])) < TOL
+    assert _relmax(grad.cpu().numpy(), g_ref.numpy()) < TOL
+    # seed-vector linearity of the reverse pass and Newton's third law (sum of forces = 0)
+    w = torch.rand(96, generator=torch.Generator().manual_seed(1)).to(dev)
+    g2 = model.backward(g, w) + model.backward(g, 1 - w)
+    np.testing.assert_allclose(g2.cpu().numpy(), grad.cpu().numpy(), atol=2e-6 * float(grad.abs().max()))
+    assert float(grad.sum(0).abs().max()) < 1e-4 * float(grad.abs().max())
