@@ -1,0 +1,156 @@
+"""Secondary benchmark (BASELINE.json configs[4]): SOAP-BPNN energy + forces on one large synthetic box.
+
+  python bench_soap.py --gpus N --steps K --warmup W [--atoms 100000] [--alchemical]
+
+One "step" = graph build (edge vectors, CSR, ij->ji) + spherical expansion + power spectrum + LayerNorm/MLP
+tail + the reverse pass to dE/dR for one random periodic box per GPU (rho = 0.05 / A^3, 5 A cutoff, default
+SOAP-BPNN hypers: max_angular 6, max_radial 7 -> 4544 power-spectrum features per atom). Boxes are
+independent per rank (weak scaling, no data-path collective). Prints ONE JSON line with the roofline of the
+dominant kernel and the CPU oracle timed beside it. Parity of this row is unpinned against torch-spex
+(oracle/soap.py header); the GPU path is checked against the oracle in tests/test_gpu_soap.py.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(hypers, n=500):
+    from oracle import nl as onl
+    from oracle import pet as opet
+    from oracle import soap as osoap
+
+    types = [1, 6, 7, 8]
+    n_per_l = osoap.basis(hypers)[0]
+    params = osoap.synthetic_params(hypers, 4, n_per_l, 0, torch.float32)
+    pos, z, cell = opet.random_box(n, seed=0)
+    i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, 5.0)
+    args = (params, hypers, types, pos, cell[None], torch.tensor(i), torch.tensor(j), torch.tensor(s).long(), z,
+            torch.zeros(n, dtype=torch.long))
+    nt = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(nt)
+    osoap.energy_and_gradient(*args)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        osoap.energy_and_gradient(*args)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": n / dt, "unit": "atom-steps/s", "cores": nt, "kind": "port",
+            "sample": f"{reps} x (forward + dE/dR) of one {n}-atom box with the torch-CPU oracle, {dt:.2f} s each"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--atoms", type=int, default=100000)
+    ap.add_argument("--alchemical", action="store_true", help="non-legacy: 4 pseudo-species + centre encoding")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from metatrain_amd import distributed as pdist
+
+    rank, local_rank, world = pdist.env_rank()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench_soap.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        pdist.init("nccl", dev)
+
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.soap_bpnn import SoapBpnnHip, default_hypers
+    from metatrain_amd.synthetic import random_box
+
+    hypers = default_hypers()
+    hypers["legacy"] = not args.alchemical
+    model = SoapBpnnHip(hypers, [1, 6, 7, 8])
+    S, H = model.feature_size, hypers["bpnn"]["num_neurons_per_layer"]
+    gen = torch.Generator().manual_seed(0)
+    params = {}
+    if args.alchemical:
+        params["species_embedding.weight"] = torch.randn(4, 4, generator=gen)
+        params["center_encoding.weight"] = torch.randn(4, S, generator=gen)
+    for s in range(1 if args.alchemical else 4):
+        params[f"layernorm.{s}.weight"] = 1 + 0.1 * torch.randn(S, generator=gen)
+        params[f"layernorm.{s}.bias"] = 0.1 * torch.randn(S, generator=gen)
+        params[f"bpnn.{s}.0.weight"] = torch.randn(H, S, generator=gen) / S**0.5
+        params[f"bpnn.{s}.2.weight"] = torch.randn(H, H, generator=gen) / H**0.5
+        params[f"last_layers.energy.{s}.weight"] = torch.randn(1, H, generator=gen) / H**0.5
+    model.load({k: v.to(dev) for k, v in params.items()})
+
+    pos, z, cell = random_box(args.atoms, seed=pdist.box_seeds(1, rank)[0])
+    posd = pos.to(dev)
+    pairs, _ = rt.neighbor_list(posd, cell, [True] * 3, model.cutoff)
+    gargs = (posd, cell[None].to(dev), pairs[:, 0].contiguous(), pairs[:, 1].contiguous(), pairs[:, 2:5].contiguous(),
+             z.to(dev), torch.zeros(args.atoms, dtype=torch.int32, device=dev))
+    ones = torch.ones(args.atoms, device=dev)
+
+    def step():
+        g = model.graph(*gargs)
+        a = model.forward(g)
+        return a, model.backward(g, ones), g
+
+    for _ in range(args.warmup):
+        step()
+    rt.profile(True)
+    step()
+    torch.cuda.synchronize()
+    table = rt.profile_report()
+    rt.profile(False)
+    dominant = max(table, key=lambda r: r["total_ms"])
+    pdist.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        atomic, grad, g = step()
+    pdist.barrier(dev)
+    elapsed = pdist.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        assert torch.isfinite(grad).all()
+        ach = dominant["bytes"] / (dominant["total_ms"] * 1e-3) / 1e9
+        out = {
+            "metric": "atom-steps/sec (energy+forces) SOAP-BPNN",
+            "value": args.atoms * world * args.steps / elapsed,
+            "unit": "atom-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic random periodic box, random weights (parity unpinned vs torch-spex)",
+            "config": {
+                "workload": f"SOAP-BPNN forward + dE/dR, one {args.atoms}-atom box per GPU per step, 5 A cutoff, "
+                            f"max_angular 6 / max_radial 7 ({S} features/atom), "
+                            f"{'alchemical (4 pseudo-species)' if args.alchemical else 'legacy (per-species heads)'}",
+                "pairs_per_gpu_per_step": int(g.n_edges),
+                "total_energy_rank0": float(atomic.double().sum()),
+            },
+            "roofline": {"bound": "hbm", "kernel": dominant["name"], "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": dominant["total_ms"],
+                         "algorithmic_bytes_per_launch": dominant["bytes"], "traffic": None,
+                         "stages_ms": {r["name"]: round(r["total_ms"], 3) for r in table}},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(hypers)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        pdist.barrier(dev)
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
