@@ -18,6 +18,7 @@
 #include "../../include/soap_hip.h"
 #include "common.h"
 #include "model.h"
+#include "tile.h"
 
 namespace pet {
 
@@ -27,6 +28,12 @@ __global__ void k_pos_grad(const float4* __restrict__ dv, const int* __restrict_
 __global__ void k_cell_grad(const float4* __restrict__ dv, const int* __restrict__ shift, const int* __restrict__ ctr,
                             const int* __restrict__ sys, const int* __restrict__ rowptr, float* __restrict__ gcell,
                             int N, int64_t E);
+
+// abi.hip
+__global__ void k_pack(const float* __restrict__ W, int64_t s_n, int64_t s_k, int n_out, int k_in,
+                       float4* __restrict__ out);
+static int g_soap_mfma = 1;  // pet_config_set("soap_mfma", 0) selects the per-atom tail kernels
+void set_soap_mfma(int v) { g_soap_mfma = v ? 1 : 0; }
 
 constexpr int MAXL = SOAP_MAX_L;
 constexpr int PC = 32;  // pairs per LDS chunk
@@ -54,6 +61,11 @@ struct SoapModel {
     const float* enc = nullptr;  // [ns, S] or null
     SoapSet* sets = nullptr;     // device array [n_sets]
     int n_sets = 0;
+    // MFMA tail: all sets' first Linear stacked (LayerNorm weight folded in), zero padded to [NOUTP][Kp]
+    int NT = 0, NOUTP = 0, Kp = 0;
+    float* wall = nullptr;       // [NOUTP][Kp]
+    float4 *wall_fwd = nullptr, *wall_bwd = nullptr;
+    float *wall_rs = nullptr, *wall_b = nullptr;  // [NOUTP] row sums, W1 beta
     bool finalized = false;
 };
 
@@ -194,12 +206,17 @@ __global__ __launch_bounds__(256) void k_soap_expand(SoapDims d, const float4* _
 }
 
 // power spectrum (+ centre encoding): feats[i][feat_off[l] + p1 * nc + p2] = sum_m c[l][m][p1] c[l][m][p2]
+__device__ __forceinline__ float block_sum(float v, float* red /*[8]*/);
+
 __global__ __launch_bounds__(256) void k_soap_ps(SoapDims d, const float* __restrict__ Cf, const int* __restrict__ sp,
-                                                 const float* __restrict__ enc, float* __restrict__ feats) {
+                                                 const float* __restrict__ enc, float* __restrict__ feats,
+                                                 float* __restrict__ tail) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float red[8];
     const int i = blockIdx.x;
     for (int k = threadIdx.x; k < d.NCOEF; k += 256) smem[k] = Cf[(size_t)i * d.NCOEF + k];
     __syncthreads();
+    float sum = 0.f;
     const float* e = enc ? enc + (size_t)sp[i] * d.S : nullptr;
     for (int idx = threadIdx.x; idx < d.S; idx += 256) {
         int l = 0;
@@ -209,11 +226,27 @@ __global__ __launch_bounds__(256) void k_soap_ps(SoapDims d, const float* __rest
         const float* base = smem + d.coef_off[l];
         float s = 0.f;
         for (int m = 0; m < 2 * l + 1; m++) s += base[m * nc + a] * base[m * nc + b];
-        feats[(size_t)i * d.S + idx] = e ? s * e[idx] : s;
+        const float v = e ? s * e[idx] : s;
+        feats[(size_t)i * d.S + idx] = v;
+        sum += v;
+    }
+    if (!d.layernorm) return;
+    // LayerNorm statistics (two passes: mean, then centred variance) for the tail
+    const float mean = block_sum(sum, red) / d.S;
+    float var = 0.f;
+    for (int idx = threadIdx.x; idx < d.S; idx += 256) {
+        const float c = feats[(size_t)i * d.S + idx] - mean;  // this thread's own writes
+        var += c * c;
+    }
+    const float rstd = rsqrtf(block_sum(var, red) / d.S + 1e-5f);
+    if (threadIdx.x == 0) {
+        tail[(size_t)i * (2 + 2 * d.H)] = mean;
+        tail[(size_t)i * (2 + 2 * d.H) + 1] = rstd;
     }
 }
 
 __device__ __forceinline__ float block_sum(float v, float* red /*[8]*/) {
+    __syncthreads();
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     __syncthreads();
@@ -289,6 +322,184 @@ __global__ __launch_bounds__(256) void k_soap_tail(SoapDims d, const float* __re
     float* tl = tail + (size_t)i * (2 + 2 * d.H);
     if (tid == 0) { tl[0] = mean; tl[1] = rstd; }
     if (tid < 2 * d.H) tl[2 + tid] = hs[tid];
+}
+
+// ---- MFMA tail: 64 atoms per workgroup, first Linear of ALL sets as one [64 x Kp] x [Kp x NOUTP] GEMM ----
+__global__ void k_soap_prep_wall(SoapDims d, const SoapSet* __restrict__ sets, int n_sets, int NOUTP, int Kp,
+                                 float* __restrict__ wall) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)NOUTP * Kp) return;
+    const int o = (int)(idx / Kp), k = (int)(idx % Kp);
+    float v = 0.f;
+    if (o < n_sets * d.H && k < d.S) {
+        const SoapSet W = sets[o / d.H];
+        v = W.W1[(size_t)(o % d.H) * d.S + k];
+        if (d.layernorm) v *= W.ln_w[k];
+    }
+    wall[idx] = v;
+}
+__global__ void k_soap_prep_rows(SoapDims d, const SoapSet* __restrict__ sets, int n_sets, int NOUTP, int Kp,
+                                 const float* __restrict__ wall, float* __restrict__ rs, float* __restrict__ bs) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= NOUTP) return;
+    double s = 0.0, b = 0.0;
+    if (o < n_sets * d.H) {
+        const SoapSet W = sets[o / d.H];
+        for (int k = 0; k < d.S; k++) {
+            s += wall[(size_t)o * Kp + k];
+            if (d.layernorm) b += (double)W.W1[(size_t)(o % d.H) * d.S + k] * W.ln_b[k];
+        }
+    }
+    rs[o] = (float)s;
+    bs[o] = (float)b;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NTHREADS) void k_soap_tail_fwd_mfma(SoapDims d, const float* __restrict__ feats,
+                                                                 const int* __restrict__ sp,
+                                                                 const SoapSet* __restrict__ sets,
+                                                                 const float4* __restrict__ Wp, int Kp,
+                                                                 const float* __restrict__ rs,
+                                                                 const float* __restrict__ bs, float* __restrict__ tail,
+                                                                 float* __restrict__ atomic, int N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NOUTP = 64 * NT, LDO = NOUTP + 1, LDA = lds_ld(128);
+    float* As = smem;                    // [64][132], later out [64][NOUTP + 1]
+    float* out = smem;
+    float* a1s = smem + BM * (LDO > LDA ? LDO : LDA);  // [64][32] silu(a1)
+    const WaveId w;
+    const int row0 = blockIdx.x * BM;
+    f32x16 acc[NT];
+    acc_fill_bias<NT>(acc, nullptr, 0, w.lane);
+    for (int kc = 0; kc < Kp / 128; kc++) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < BM * 32; idx += NTHREADS) {
+            const int r = idx >> 5, c = idx & 31, col = 128 * kc + 4 * c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r < N && col < d.S) v = *reinterpret_cast<const float4*>(feats + (size_t)(row0 + r) * d.S + col);
+            *reinterpret_cast<float4*>(As + r * LDA + 4 * c) = v;
+        }
+        __syncthreads();
+        gemm_acc<128, NT>(As + w.rb * 32 * LDA, LDA, Wp, Kp / 8, 16 * kc, NT * w.ch, acc, w.lane);
+    }
+    __syncthreads();
+    acc_foreach<NT>(acc, w.rb, 32 * NT * w.ch, w.lane, [&](int r, int c, float v) { out[r * LDO + c] = v; });
+    __syncthreads();
+    const int H = 32, TS = 2 + 2 * H;
+    for (int item = threadIdx.x; item < BM * H; item += NTHREADS) {
+        const int r = item >> 5, j = item & 31, atom = row0 + r;
+        float a1 = 0.f;
+        if (atom < N) {
+            const int s = d.legacy ? sp[atom] : 0;
+            const float mu = d.layernorm ? tail[(size_t)atom * TS] : 0.f;
+            const float rstd = d.layernorm ? tail[(size_t)atom * TS + 1] : 1.f;
+            a1 = rstd * (out[r * LDO + s * H + j] - mu * rs[s * H + j]) + bs[s * H + j];
+            tail[(size_t)atom * TS + 2 + j] = a1;
+        }
+        a1s[r * H + j] = silu(a1);
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < BM * H; item += NTHREADS) {
+        const int r = item >> 5, j = item & 31, atom = row0 + r;
+        float e = 0.f;
+        if (atom < N) {
+            const SoapSet W = sets[d.legacy ? sp[atom] : 0];
+            if (d.NH > 1) {
+                float a2 = 0.f;
+                for (int q = 0; q < H; q++) a2 += W.W2[j * H + q] * a1s[r * H + q];
+                tail[(size_t)atom * TS + 2 + H + j] = a2;
+                e = W.w3[j] * silu(a2);
+            } else {
+                e = W.w3[j] * a1s[r * H + j];
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) e += __shfl_xor(e, o);
+        if (j == 0 && atom < N) atomic[atom] = e;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_mfma(SoapDims d, const float* __restrict__ feats,
+                                                                 const int* __restrict__ sp,
+                                                                 const SoapSet* __restrict__ sets,
+                                                                 const float4* __restrict__ Wpb, int Kp,
+                                                                 const float* __restrict__ rs,
+                                                                 const float* __restrict__ bs,
+                                                                 const float* __restrict__ enc,
+                                                                 const float* __restrict__ tail,
+                                                                 const float* __restrict__ gA, float* __restrict__ dF,
+                                                                 int N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NOUTP = 64 * NT, LDD = lds_ld(NOUTP);
+    float* Ds = smem;                 // [64][NOUTP + 4] d a1, zero outside the atom's own set
+    float* d2 = Ds + BM * LDD;        // [64][32] d a2
+    float* st = d2 + BM * 32;         // [64][4] mean, rstd, m1, m2
+    const WaveId w;
+    const int row0 = blockIdx.x * BM;
+    const int H = 32, TS = 2 + 2 * H;
+    for (int idx = threadIdx.x; idx < BM * LDD; idx += NTHREADS) Ds[idx] = 0.f;
+    for (int item = threadIdx.x; item < BM * H; item += NTHREADS) {
+        const int r = item >> 5, j = item & 31, atom = row0 + r;
+        float v = 0.f;
+        if (atom < N && d.NH > 1) {
+            const SoapSet W = sets[d.legacy ? sp[atom] : 0];
+            v = gA[atom] * W.w3[j] * dsilu(tail[(size_t)atom * TS + 2 + H + j]);
+        }
+        d2[r * H + j] = v;
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < BM * H; item += NTHREADS) {
+        const int r = item >> 5, j = item & 31, atom = row0 + r;
+        float da1 = 0.f, t1 = 0.f, t2 = 0.f;
+        float mu = 0.f, rstd = 1.f;
+        if (atom < N) {
+            const int s = d.legacy ? sp[atom] : 0;
+            const SoapSet W = sets[s];
+            const float a1 = tail[(size_t)atom * TS + 2 + j];
+            if (d.NH > 1) {
+                float acc = 0.f;
+                for (int q = 0; q < H; q++) acc += W.W2[q * H + j] * d2[r * H + q];
+                da1 = acc * dsilu(a1);
+            } else {
+                da1 = gA[atom] * W.w3[j] * dsilu(a1);
+            }
+            Ds[r * LDD + s * H + j] = da1;
+            if (d.layernorm) {
+                mu = tail[(size_t)atom * TS];
+                rstd = tail[(size_t)atom * TS + 1];
+                const float rsj = rs[s * H + j];
+                const float raw = (a1 - bs[s * H + j]) / rstd + mu * rsj;  // Wall_s[j] . x
+                t1 = da1 * rsj;
+                t2 = da1 * raw;
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+        if (j == 0) {
+            st[r * 4] = mu; st[r * 4 + 1] = rstd;
+            st[r * 4 + 2] = t1 / d.S;                        // m1 = mean(dxn gamma)
+            st[r * 4 + 3] = rstd * (t2 - mu * t1) / d.S;     // m2 = mean(dxn gamma xhat)
+        }
+    }
+    __syncthreads();
+    for (int nblk = 0; nblk < Kp / 128; nblk++) {
+        f32x16 acc[2];
+        acc_fill_bias<2>(acc, nullptr, 0, w.lane);
+        gemm_acc<NOUTP, 2>(Ds + w.rb * 32 * LDD, LDD, Wpb, NOUTP / 8, 0, 4 * nblk + 2 * w.ch, acc, w.lane);
+        acc_foreach<2>(acc, w.rb, 128 * nblk + 64 * w.ch, w.lane, [&](int r, int k, float v) {
+            const int atom = row0 + r;
+            if (atom < N && k < d.S) {
+                float val = v;
+                if (d.layernorm) {
+                    const float xh = (feats[(size_t)atom * d.S + k] - st[r * 4]) * st[r * 4 + 1];
+                    val = st[r * 4 + 1] * (v - st[r * 4 + 2] - xh * st[r * 4 + 3]);
+                }
+                if (enc) val *= enc[(size_t)sp[atom] * d.S + k];
+                dF[(size_t)atom * d.S + k] = val;
+            }
+        });
+    }
 }
 
 // reverse of the tail: dF[i][k] = d e_i / d ps_i[k] * gA[i]
@@ -509,6 +720,26 @@ static int soap_finalize(SoapModel& m, hipStream_t st) {
         if ((rc = soap_get(m, "last_layers.energy." + ss + ".weight", d.H, &sets[s].w3))) return rc;
     }
     PET_HIP_CHECK(hipMemcpyAsync(m.sets, sets.data(), sizeof(SoapSet) * m.n_sets, hipMemcpyHostToDevice, st));
+    // stacked first Linear for the MFMA tail
+    m.NT = 0;
+    if (d.H == 32 && m.n_sets <= 8 && d.S % 4 == 0) {
+        const int NT = (m.n_sets + 1) / 2, NOUTP = 64 * NT, Kp = (d.S + 127) / 128 * 128;
+        if (!m.wall || m.NOUTP != NOUTP || m.Kp != Kp) {
+            const size_t n4 = (size_t)NOUTP * Kp / 4;
+            if ((rc = salloc(m, (void**)&m.wall, (size_t)NOUTP * Kp * 4))) return rc;
+            if ((rc = salloc(m, (void**)&m.wall_fwd, n4 * sizeof(float4)))) return rc;
+            if ((rc = salloc(m, (void**)&m.wall_bwd, n4 * sizeof(float4)))) return rc;
+            if ((rc = salloc(m, (void**)&m.wall_rs, NOUTP * 4))) return rc;
+            if ((rc = salloc(m, (void**)&m.wall_b, NOUTP * 4))) return rc;
+        }
+        m.NT = NT; m.NOUTP = NOUTP; m.Kp = Kp;
+        const size_t n4 = (size_t)NOUTP * Kp / 4;
+        k_soap_prep_wall<<<cdiv((int64_t)NOUTP * Kp, 256), 256, 0, st>>>(d, m.sets, m.n_sets, NOUTP, Kp, m.wall);
+        k_soap_prep_rows<<<cdiv(NOUTP, 64), 64, 0, st>>>(d, m.sets, m.n_sets, NOUTP, Kp, m.wall, m.wall_rs, m.wall_b);
+        k_pack<<<cdiv(n4, 256), 256, 0, st>>>(m.wall, Kp, 1, NOUTP, Kp, m.wall_fwd);   // x W^T: tiles over NOUTP
+        k_pack<<<cdiv(n4, 256), 256, 0, st>>>(m.wall, 1, Kp, Kp, NOUTP, m.wall_bwd);   // dy W: tiles over Kp
+        PET_HIP_CHECK(hipGetLastError());
+    }
     PET_HIP_CHECK(hipStreamSynchronize(st));  // host vectors go out of scope
     m.finalized = true;
     return PET_OK;
@@ -536,11 +767,25 @@ static int soap_fwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
     }
     {
         ProfScope ps("soap_ps", st, 2.0 * (double)N * d.S * (d.L + 1), (double)N * (d.NCOEF + d.S) * 4);
-        k_soap_ps<<<N, 256, (size_t)d.NCOEF * 4, st>>>(d, w.Cf, g.sp, m.enc, w.feats);
+        k_soap_ps<<<N, 256, (size_t)d.NCOEF * 4, st>>>(d, w.Cf, g.sp, m.enc, w.feats, w.tail);
     }
     {
         ProfScope ps("soap_tail", st, 2.0 * (double)N * d.S * d.H, (double)N * d.S * 4);
-        k_soap_tail<<<N, 256, lds_tail(d), st>>>(d, w.feats, g.sp, m.sets, w.tail, atomic);
+        if (m.NT > 0 && g_soap_mfma) {
+            const int NOUTP = m.NOUTP, lda = lds_ld(128);
+            const size_t lds = ((size_t)BM * (NOUTP + 1 > lda ? NOUTP + 1 : lda) + BM * 32) * 4;
+            const int grid = cdiv(N, BM);
+#define SOAP_TAIL_FWD(NTV)                                                                                        \
+    case NTV:                                                                                                     \
+        allow_big_lds(k_soap_tail_fwd_mfma<NTV>, lds);                                                            \
+        k_soap_tail_fwd_mfma<NTV><<<grid, NTHREADS, lds, st>>>(d, w.feats, g.sp, m.sets, m.wall_fwd, m.Kp,        \
+                                                                m.wall_rs, m.wall_b, w.tail, atomic, N);           \
+        break;
+            switch (m.NT) { SOAP_TAIL_FWD(1) SOAP_TAIL_FWD(2) SOAP_TAIL_FWD(3) SOAP_TAIL_FWD(4) }
+#undef SOAP_TAIL_FWD
+        } else {
+            k_soap_tail<<<N, 256, lds_tail(d), st>>>(d, w.feats, g.sp, m.sets, w.tail, atomic);
+        }
     }
     if (features)
         PET_HIP_CHECK(hipMemcpyAsync(features, w.feats, (size_t)N * d.S * 4, hipMemcpyDeviceToDevice, st));
@@ -568,7 +813,20 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
     allow_big_lds(k_soap_expand_bwd, lds_expand_bwd(d));
     {
         ProfScope ps("soap_tail_bwd", st, 2.0 * (double)N * d.S * d.H, (double)N * d.S * 8);
-        k_soap_tail_bwd<<<N, 256, 0, st>>>(d, w.feats, g.sp, m.sets, m.enc, w.tail, gA, w.dF);
+        if (m.NT > 0 && g_soap_mfma) {
+            const size_t lds = ((size_t)BM * lds_ld(m.NOUTP) + BM * 32 + BM * 4) * 4;
+            const int grid = cdiv(N, BM);
+#define SOAP_TAIL_BWD(NTV)                                                                                        \
+    case NTV:                                                                                                     \
+        allow_big_lds(k_soap_tail_bwd_mfma<NTV>, lds);                                                            \
+        k_soap_tail_bwd_mfma<NTV><<<grid, NTHREADS, lds, st>>>(d, w.feats, g.sp, m.sets, m.wall_bwd, m.Kp,        \
+                                                                m.wall_rs, m.wall_b, m.enc, w.tail, gA, w.dF, N);  \
+        break;
+            switch (m.NT) { SOAP_TAIL_BWD(1) SOAP_TAIL_BWD(2) SOAP_TAIL_BWD(3) SOAP_TAIL_BWD(4) }
+#undef SOAP_TAIL_BWD
+        } else {
+            k_soap_tail_bwd<<<N, 256, 0, st>>>(d, w.feats, g.sp, m.sets, m.enc, w.tail, gA, w.dF);
+        }
     }
     {
         ProfScope ps("soap_ps_bwd", st, 4.0 * (double)N * d.S * (d.L + 1), (double)N * (2 * d.NCOEF + d.S) * 4);

@@ -24,9 +24,13 @@ def _relmax(a, b):
     return np.abs(a - b).max() / np.abs(b).max()
 
 
+@pytest.mark.parametrize("mfma_tail", [1, 0])
 @pytest.mark.parametrize("legacy", [True, False])
-def test_soap_bpnn_energy_features_and_forces(legacy):
+def test_soap_bpnn_energy_features_and_forces(legacy, mfma_tail):
+    from metatrain_amd import runtime as rt
     from metatrain_amd.soap_bpnn import SoapBpnnHip
+
+    rt.config_set("soap_mfma", mfma_tail)  # both tail implementations: MFMA GEMM over 64 atoms / per-atom kernels
 
     dev = torch.device("cuda:0")
     hypers = dict(osoap.DEFAULT_HYPERS, legacy=legacy)
@@ -54,3 +58,4 @@ def test_soap_bpnn_energy_features_and_forces(legacy):
     g2 = model.backward(g, w) + model.backward(g, 1 - w)
     np.testing.assert_allclose(g2.cpu().numpy(), grad.cpu().numpy(), atol=2e-6 * float(grad.abs().max()))
     assert float(grad.sum(0).abs().max()) < 1e-4 * float(grad.abs().max())
+    rt.config_set("soap_mfma", 1)
