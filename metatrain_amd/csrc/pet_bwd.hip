@@ -58,7 +58,7 @@ __device__ __forceinline__ void rmsnorm_bwd_rows(const float* Wt, const float* _
 // ---------------------------------------------------------------------------------
 // heads
 // ---------------------------------------------------------------------------------
-template <int K, bool EDGE>
+template <int K, bool EDGE, bool TRAIN>
 __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__ Xin, const float4* __restrict__ w0f,
                                                         const float* __restrict__ b0, const float4* __restrict__ w2f,
                                                         const float* __restrict__ b2, const float4* __restrict__ w0b,
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
     acc_foreach<2>(a1, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
         const float s1 = siluf_(v);
         S[r * LD128 + c] = s1;
-        if (t_s1 && row0 + r < R) t_s1[(row0 + r) * DH + c] = s1;
+        if (TRAIN && row0 + r < R) t_s1[(row0 + r) * DH + c] = s1;
     });
     __syncthreads();
     acc_fill_bias<2>(acc, b2, 64 * w.ch, w.lane);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
     acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
         const float d2 = gy[r] * wl[c] * silu_grad_(v);
         S[r * LD128 + c] = d2;
-        if (t_da2 && row0 + r < R) {
+        if (TRAIN && row0 + r < R) {
             t_da2[(row0 + r) * DH + c] = d2;
             t_s2y[(row0 + r) * DH + c] = gy[r] * siluf_(v);
         }
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
             const int rr = w.rb * 32 + acc_row(r, w.lane), cc = 64 * w.ch + 32 * t + (w.lane & 31);
             const float d1 = acc[t][r] * silu_grad_(a1[t][r]);
             S[rr * LD128 + cc] = d1;  // da1
-            if (t_da1 && row0 + rr < R) t_da1[(row0 + rr) * DH + cc] = d1;
+            if (TRAIN && row0 + rr < R) t_da1[(row0 + rr) * DH + cc] = d1;
         }
     __syncthreads();
     constexpr int NTO = K / 64;  // output columns K split over the two column halves
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
 // ---------------------------------------------------------------------------------
 // combination MLP + LayerNorm adjoint -> dcat [E, 2D]
 // ---------------------------------------------------------------------------------
+template <bool TRAIN>
 __global__ __launch_bounds__(NTHREADS) void k_comb_bwd(const float* __restrict__ dM, const float* __restrict__ XF,
                                                         const int* __restrict__ rev, const float* __restrict__ LNS,
                                                         const float* __restrict__ CA, const float* __restrict__ ln_g,
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(NTHREADS) void k_comb_bwd(const float* __restrict__
         const float a = row < E ? CA[row * (2 * D) + 128 * w.ch + c] : 0.f;
         const float da = v * silu_grad_(a);
         Sdst[r * LD128 + c] = da;
-        if (t_da && row < E) t_da[row * (2 * D) + 128 * w.ch + c] = da;
+        if (TRAIN && row < E) t_da[row * (2 * D) + 128 * w.ch + c] = da;
     });
     __syncthreads();
     acc_fill_bias<4>(t1, nullptr, 0, w.lane);
@@ -226,7 +227,7 @@ __global__ void k_dxf(const float* __restrict__ dM, const float* __restrict__ dc
 //   y = x + Wout (v * sig(g)),  [v; g] = Win RMSNorm(x)
 //   dx = dy + RMSNorm^T( Win^T [du sig(g) ; du v sig'(g)] ),  du = Wout^T dy
 // ---------------------------------------------------------------------------------
-template <int K, int HID>
+template <int K, int HID, bool TRAIN>
 __global__ __launch_bounds__(NTHREADS) void k_swiglu_bwd(const float* __restrict__ dY, const float* __restrict__ Xin,
                                                           const float* __restrict__ VG, const float* __restrict__ gamma,
                                                           const float4* __restrict__ woutb, const float4* __restrict__ winb,
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(NTHREADS) void k_swiglu_bwd(const float* __restrict
                 const int rr = w.rb * 32 + acc_row(r, w.lane), cc = 64 * w.ch + 32 * t + (w.lane & 31);
                 const float dvv = du[t][r] * sg[t][r];
                 U[rr * LD128 + cc] = dvv;  // dv
-                if (t_dvg && row0 + rr < R) t_dvg[(row0 + rr) * (2 * HID) + 128 * hc + cc] = dvv;
+                if (TRAIN && row0 + rr < R) t_dvg[(row0 + rr) * (2 * HID) + 128 * hc + cc] = dvv;
             }
         __syncthreads();
         gemm_acc<128, NTO>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, 16 * hc, NTO * w.ch, dn, w.lane);
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(NTHREADS) void k_swiglu_bwd(const float* __restrict
                 const int rr = w.rb * 32 + acc_row(r, w.lane), cc = 64 * w.ch + 32 * t + (w.lane & 31);
                 const float dgv = du[t][r] * vv[t][r] * sigmoid_grad_from(sg[t][r]);
                 U[rr * LD128 + cc] = dgv;  // dg
-                if (t_dvg && row0 + rr < R) t_dvg[(row0 + rr) * (2 * HID) + HID + 128 * hc + cc] = dgv;
+                if (TRAIN && row0 + rr < R) t_dvg[(row0 + rr) * (2 * HID) + HID + 128 * hc + cc] = dgv;
             }
         __syncthreads();
         gemm_acc<128, NTO>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, HID / 8 + 16 * hc, NTO * w.ch, dn, w.lane);
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(NTHREADS) void k_qkv_bwd(const float* __restrict__ 
 // ---------------------------------------------------------------------------------
 // compress adjoint: da0 = (dE W2) * silu'(a0); dgeo += da0 Wc; dM = dMpass + da0 W0c
 // ---------------------------------------------------------------------------------
-template <bool FIRST>
+template <bool FIRST, bool TRAIN>
 __global__ __launch_bounds__(NTHREADS) void k_compress_bwd(const float* __restrict__ dXe, const float* __restrict__ a0,
                                                             const float4* __restrict__ w2b, const float* __restrict__ wct,
                                                             const float4* __restrict__ w0cb, float* __restrict__ dgeo,
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(NTHREADS) void k_compress_bwd(const float* __restri
         const int64_t row = row0 + r;
         const float d0v = row < E ? v * silu_grad_(a0[row * D + c]) : 0.f;
         smem[r * LD128 + c] = d0v;
-        if (t_da0 && row < E) t_da0[row * D + c] = d0v;
+        if (TRAIN && row < E) t_da0[row * D + c] = d0v;
     });
     __syncthreads();
     {   // dgeo[row][k] += sum_c da0[row][c] * Wc[c][k]; 4 threads per row, thread q -> component q
@@ -749,15 +750,20 @@ int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* 
     const int gE = cdiv(E, BM), gN = cdiv(N, BM);
     const size_t lds2 = 2 * BM * LD128 * 4;
     const double fE = (double)E, fN = (double)N;
-    allow_big_lds(k_head_bwd<256, false>, (BM * LD256 + BM * LD128) * 4 + 256);
+    allow_big_lds(k_head_bwd<256, false, false>, (BM * LD256 + BM * LD128) * 4 + 256);
+    allow_big_lds(k_head_bwd<256, false, true>, (BM * LD256 + BM * LD128) * 4 + 256);
     const GnnBufs& last = w.gnn.back();
     if (E > 0) {
         ProfScope ps("head_edge_bwd", st, fE * 2.0 * (D * DH + DH * DH + DH));
-        k_head_bwd<128, true><<<gE, NTHREADS, lds2 + 256, st>>>(last.Mout, m.eh0.fwd, m.eh0.b, m.eh2.fwd, m.eh2.b,
+        { if (tr) k_head_bwd<128, true, true><<<gE, NTHREADS, lds2 + 256, st>>>(last.Mout, m.eh0.fwd, m.eh0.b, m.eh2.fwd, m.eh2.b,
                                                                m.eh0.bwd, m.eh2.bwd, m.ell_w, gA, g.ctr, g.fc,
                                                                w.ypred_e, w.dfc, w.dM, E, tr ? w.hs1 : nullptr,
                                                                tr ? w.hda2 : nullptr, tr ? w.hda1 : nullptr,
-                                                               tr ? w.hs2y : nullptr);
+                                                               tr ? w.hs2y : nullptr); else k_head_bwd<128, true, false><<<gE, NTHREADS, lds2 + 256, st>>>(last.Mout, m.eh0.fwd, m.eh0.b, m.eh2.fwd, m.eh2.b,
+                                                               m.eh0.bwd, m.eh2.bwd, m.ell_w, gA, g.ctr, g.fc,
+                                                               w.ypred_e, w.dfc, w.dM, E, tr ? w.hs1 : nullptr,
+                                                               tr ? w.hda2 : nullptr, tr ? w.hda1 : nullptr,
+                                                               tr ? w.hs2y : nullptr); }
         if (tr) tr->heads(true, last.Mout, D, E, gA);
     }
     {
@@ -767,10 +773,13 @@ int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* 
         ss.fork(st);
         {
             ProfScope ps("head_node_bwd", s2, fN * 2.0 * (DN * DH + DH * DH + DH));
-            k_head_bwd<256, false><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + 256, s2>>>(
+            { if (tr) k_head_bwd<256, false, true><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + 256, s2>>>(
                 last.Hout, m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nh0.bwd, m.nh2.bwd, m.nll_w, gA, nullptr,
                 nullptr, nullptr, nullptr, w.dH, N, tr ? w.hs1 : nullptr, tr ? w.hda2 : nullptr,
-                tr ? w.hda1 : nullptr, tr ? w.hs2y : nullptr);
+                tr ? w.hda1 : nullptr, tr ? w.hs2y : nullptr); else k_head_bwd<256, false, false><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + 256, s2>>>(
+                last.Hout, m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nh0.bwd, m.nh2.bwd, m.nll_w, gA, nullptr,
+                nullptr, nullptr, nullptr, w.dH, N, tr ? w.hs1 : nullptr, tr ? w.hda2 : nullptr,
+                tr ? w.hda1 : nullptr, tr ? w.hs2y : nullptr); }
             if (tr) tr->heads(false, last.Hout, DN, N, gA);
         }
         ss.join(st);
@@ -795,7 +804,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     const bool trr = use_trr();
     PET_HIP_CHECK(hipMemsetAsync(w.dgeo, 0, E * 4 * sizeof(float), st));
     PET_HIP_CHECK(hipMemsetAsync(dbias_h, 0, E * NHEAD * sizeof(float), st));
-    allow_big_lds(k_swiglu_bwd<256, DNF>, (BM * LD256 + BM * LD128) * 4);
+    allow_big_lds(k_swiglu_bwd<256, DNF, false>, (BM * LD256 + BM * LD128) * 4);
+    allow_big_lds(k_swiglu_bwd<256, DNF, true>, (BM * LD256 + BM * LD128) * 4);
     allow_big_lds(k_expand_bwd, BM * LD256 * 4);
     float* dH = w.dH;
     float* dH_alt = w.dH2;
@@ -812,8 +822,9 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         const GnnBufs& B = w.gnn[gi];
         {
             ProfScope ps("comb_bwd", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D));
-            k_comb_bwd<<<gE, NTHREADS, lds2, st>>>(w.dM, B.XF, g.rev, B.LNS, B.CA, G.ln_g, G.comb2.bwd, G.comb0.bwd,
-                                                   w.dcat, E, tr ? w.dCA : nullptr);
+            { if (tr) k_comb_bwd<true><<<gE, NTHREADS, lds2, st>>>(w.dM, B.XF, g.rev, B.LNS, B.CA, G.ln_g, G.comb2.bwd, G.comb0.bwd,
+                                                   w.dcat, E, tr ? w.dCA : nullptr); else k_comb_bwd<false><<<gE, NTHREADS, lds2, st>>>(w.dM, B.XF, g.rev, B.LNS, B.CA, G.ln_g, G.comb2.bwd, G.comb0.bwd,
+                                                   w.dcat, E, tr ? w.dCA : nullptr); }
             if (tr) {
                 const std::string gs = std::to_string(gi);
                 tr->linear("combination_mlps." + gs + ".2", D, 2 * D, {w.dM, nullptr, 0, D},
@@ -835,8 +846,9 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             // dX (edge rows) = grad wrt the edge MLP output; dH = grad wrt Hn
             {
                 ProfScope ps("node_bwd", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
-                k_swiglu_bwd<256, DNF><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
-                    dH, Ab.H1, Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N, tr ? w.dVGn : nullptr);
+                { if (tr) k_swiglu_bwd<256, DNF, true><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
+                    dH, Ab.H1, Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N, tr ? w.dVGn : nullptr); else k_swiglu_bwd<256, DNF, false><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
+                    dH, Ab.H1, Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N, tr ? w.dVGn : nullptr); }
                 k_expand_bwd<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(dH_alt, A.ce.bwd, w.dOC, N);
                 if (tr) {
                     tr->linear(lp + ".center_mlp.w_out", DN, DNF, {dH, nullptr, 0, DN},
@@ -851,8 +863,9 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             {
                 ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
                 if (trr) trr_emlp_bwd(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_in, A.mlp_out, dX_alt, E, st, tr ? w.dVG : nullptr);
-                else k_swiglu_bwd<128, DFF><<<gE, NTHREADS, lds2, st>>>(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_out.bwd,
-                                                                        A.mlp_in.bwd, dX_alt, E, tr ? w.dVG : nullptr);
+                else { if (tr) k_swiglu_bwd<128, DFF, true><<<gE, NTHREADS, lds2, st>>>(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_out.bwd,
+                                                                        A.mlp_in.bwd, dX_alt, E, tr ? w.dVG : nullptr); else k_swiglu_bwd<128, DFF, false><<<gE, NTHREADS, lds2, st>>>(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_out.bwd,
+                                                                        A.mlp_in.bwd, dX_alt, E, tr ? w.dVG : nullptr); }
                 if (tr) {
                     tr->linear(lp + ".mlp.w_out", D, DFF, {dX, nullptr, 0, D}, {Ab.VG, 2 * DFF, DFF, nullptr, nullptr},
                                2, E);
@@ -902,12 +915,15 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         {
             ProfScope ps("compress_bwd", st, fE * 2.0 * (D * D * (gi == 0 ? 3 : 4) + 4 * D));
             if (gi == 0)
-                k_compress_bwd<true><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct, nullptr, w.dgeo,
-                                                                 nullptr, E, tr ? w.da0 : nullptr);
+                { if (tr) k_compress_bwd<true, true><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct, nullptr, w.dgeo,
+                                                                 nullptr, E, tr ? w.da0 : nullptr); else k_compress_bwd<true, false><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct, nullptr, w.dgeo,
+                                                                 nullptr, E, tr ? w.da0 : nullptr); }
             else
-                k_compress_bwd<false><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct,
+                { if (tr) k_compress_bwd<false, true><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct,
                                                                   G.compress0_msg.bwd, w.dgeo, w.dM, E,
-                                                                  tr ? w.da0 : nullptr);
+                                                                  tr ? w.da0 : nullptr); else k_compress_bwd<false, false><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct,
+                                                                  G.compress0_msg.bwd, w.dgeo, w.dM, E,
+                                                                  tr ? w.da0 : nullptr); }
             if (tr) {
                 const std::string pre = "gnn_layers." + std::to_string(gi);
                 tr->linear(pre + ".compress.2", D, D, {dX, nullptr, 0, D}, {B.a0, D, 0, nullptr, nullptr}, 3, E);

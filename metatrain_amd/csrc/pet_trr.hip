@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void k_emlp_t(const float* __restrict__ X1, co
 }
 
 // dX1 = dY + RMSNorm^T( Win^T [du sig(g) ; du v sig'(g)] ),  du = Wout^T dY
+template <bool TRAIN>
 __global__ __launch_bounds__(256, 2) void k_emlp_bwd_t(const float* __restrict__ dY, const float* __restrict__ X1,
                                                      const float* __restrict__ VG, const float* __restrict__ gamma,
                                                      const float4* __restrict__ woutb, const float4* __restrict__ winb,
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void k_emlp_bwd_t(const float* __restrict__
             dv[q] = make_float4(d.x * sx, d.y * sy, d.z * sz, d.w * sw);
             dg[q] = make_float4(d.x * vv.x * sx * (1.f - sx), d.y * vv.y * sy * (1.f - sy),
                                 d.z * vv.z * sz * (1.f - sz), d.w * vv.w * sw * (1.f - sw));
-            if (t_dvg && valid) {
+            if (TRAIN && valid) {
                 *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) = dv[q];
                 *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) = dg[q];
             }
@@ -249,7 +250,8 @@ void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wo
 }
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
                   const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg) {
-    k_emlp_bwd_t<<<grid_rows(E), 256, 0, st>>>(dY, X1, VG, gamma, wout.bwd, win.bwd, dX1, E, t_dvg);
+    if (t_dvg) k_emlp_bwd_t<true><<<grid_rows(E), 256, 0, st>>>(dY, X1, VG, gamma, wout.bwd, win.bwd, dX1, E, t_dvg);
+    else k_emlp_bwd_t<false><<<grid_rows(E), 256, 0, st>>>(dY, X1, VG, gamma, wout.bwd, win.bwd, dX1, E, nullptr);
 }
 
 }  // namespace pet
