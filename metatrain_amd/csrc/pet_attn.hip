@@ -47,7 +47,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <int NT>
 __global__ __launch_bounds__(256) void k_attn_fwd_p(const float* __restrict__ QKV, const int* __restrict__ rowptr,
                                                      const float* __restrict__ fc, float* __restrict__ AO,
-                                                     int64_t E, int N, float scale) {
+                                                     int64_t E, int N, float scale, int only_nt) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int atom = gw / NHEAD, head = gw % NHEAD;
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_p(const float* __restrict__ QK
     const int start = rowptr[atom];
     const int T = rowptr[atom + 1] - start + 1;
     const int nt = (T + 15) >> 4;
+    if (only_nt && nt != only_nt) return;  // bucketed launch: this instantiation serves one tile count
     const int c16 = lane & 15, g4 = lane >> 4;
     const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head;
     float4 kf[NT], qf[NT];
@@ -118,7 +119,7 @@ template <int NT>
 __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QKV, const float* __restrict__ dAO,
                                                      const int* __restrict__ rowptr, const float* __restrict__ fc,
                                                      float* __restrict__ dQKV, float* __restrict__ dbias_h,
-                                                     int64_t E, int N, float scale) {
+                                                     int64_t E, int N, float scale, int only_nt) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int atom = gw / NHEAD, head = gw % NHEAD;
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QK
     const int start = rowptr[atom];
     const int T = rowptr[atom + 1] - start + 1;
     const int nt = (T + 15) >> 4;
+    if (only_nt && nt != only_nt) return;  // bucketed launch: this instantiation serves one tile count
     const int c16 = lane & 15, g4 = lane >> 4;
     const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head;
     // fragments with the token on the 16-lane axis (rows 16t + c16) ...
@@ -266,28 +268,30 @@ __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QK
 }
 
 // host launchers: true if this variant handled the launch (NT <= 4)
+// Atoms are served by the instantiation that matches their own tile count (registers, hence waves in
+// flight, scale with NT): one launch per tile count up to the batch maximum, waves of other atoms exit at once.
 bool attn_fwd_preload(int nt, const float* QKV, const Graph& g, float* AO, float scale, hipStream_t st) {
+    if (nt > 4) return false;
     const int grid = cdiv((int64_t)g.n_nodes * NHEAD, 4);
     const int N = (int)g.n_nodes;
-    switch (nt) {
-        case 1: k_attn_fwd_p<1><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale); return true;
-        case 2: k_attn_fwd_p<2><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale); return true;
-        case 3: k_attn_fwd_p<3><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale); return true;
-        case 4: k_attn_fwd_p<4><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale); return true;
-        default: return false;
-    }
+    const int only = nt > 1 ? 1 : 0;
+    k_attn_fwd_p<1><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale, only);
+    if (nt >= 2) k_attn_fwd_p<2><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale, 2);
+    if (nt >= 3) k_attn_fwd_p<3><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale, 3);
+    if (nt >= 4) k_attn_fwd_p<4><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale, 4);
+    return true;
 }
 bool attn_bwd_preload(int nt, const float* QKV, const float* dAO, const Graph& g, float* dQKV, float* dbias_h,
                       float scale, hipStream_t st) {
+    if (nt > 4) return false;
     const int grid = cdiv((int64_t)g.n_nodes * NHEAD, 4);
     const int N = (int)g.n_nodes;
-    switch (nt) {
-        case 1: k_attn_bwd_p<1><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale); return true;
-        case 2: k_attn_bwd_p<2><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale); return true;
-        case 3: k_attn_bwd_p<3><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale); return true;
-        case 4: k_attn_bwd_p<4><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale); return true;
-        default: return false;
-    }
+    const int only = nt > 1 ? 1 : 0;
+    k_attn_bwd_p<1><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, only);
+    if (nt >= 2) k_attn_bwd_p<2><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, 2);
+    if (nt >= 3) k_attn_bwd_p<3><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, 3);
+    if (nt >= 4) k_attn_bwd_p<4><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, 4);
+    return true;
 }
 
 }  // namespace pet
