@@ -1,0 +1,35 @@
+"""profiles/<tag>_rocprofv3_summary.txt (FETCH_SIZE / WRITE_SIZE sections) -> profiles/r01_traffic.json.
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: FETCH_SIZE counts 64 B units
+reported in KiB on gfx950, i.e. half the bytes; WRITE_SIZE in KiB)."""
+import json
+import re
+import sys
+
+src, edges = sys.argv[1], int(sys.argv[2])
+text = open(src).read()
+sections = text.split("# counters")
+vals = {}
+for sec in sections[1:]:
+    lines = sec.splitlines()
+    header = lines[1].split()
+    if header[-1] not in ("FETCH_SIZE", "WRITE_SIZE"):
+        continue
+    for l in lines[2:]:
+        parts = l.split()
+        if len(parts) < 3:
+            continue
+        try:
+            v = float(parts[-1]); int(parts[-2])
+        except ValueError:
+            continue
+        name = " ".join(parts[:-2])
+        vals.setdefault(name, {})[header[-1]] = v
+out = {"source": f"{src} (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --boxes 2); "
+                 "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md",
+       "workload_edges": edges, "kernels": {}}
+for name, v in vals.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v and name.startswith("k_"):
+        out["kernels"][name] = {"fetch_kib_raw": v["FETCH_SIZE"], "write_kib_raw": v["WRITE_SIZE"],
+                                "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024}
+json.dump(out, open("profiles/r01_traffic.json", "w"), indent=1)
+print(len(out["kernels"]), "kernels")
