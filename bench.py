@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--boxes", type=int, default=2, help="10k-atom boxes per GPU per step")  # 4: +4 %, 8: see DESIGN
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print a per-stage table to stderr")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=INT",
+                    help="library switch for A/B runs, e.g. --set attn_lds=0 (pet_config_set)")
     args = ap.parse_args()
 
     from metatrain_amd import distributed as pdist
@@ -123,6 +125,9 @@ def main():
     from metatrain_amd.pet import default_hypers
     from metatrain_amd.synthetic import random_box
 
+    for kv in args.set:
+        key, val = kv.split("=")
+        rt.config_set(key, int(val))
     hypers = default_hypers()
     params = synthetic_params(hypers)
     model = rt.HipModel(hypers, [1, 6, 7, 8])

@@ -55,6 +55,9 @@ typedef struct pet_hypers {
     int32_t nl_is_strict;    /* = long_range.enable (backend.py:38); 0 => filter d <= cutoff */
     int32_t n_species;       /* len(atomic_types) */
     int32_t max_atomic_number; /* species_to_species_index has max+1 entries */
+    float num_neighbors_adaptive; /* target neighbour count of the adaptive cutoff ("solver" method,
+                                     pet/modules/adaptive_cutoff.py:110-229); <= 0: fixed cutoff */
+    float cutoff_width_adaptive;  /* taper width of the adaptive-cutoff probe */
 } pet_hypers_t;
 
 typedef struct pet_model pet_model_t; /* packed weights on the device */

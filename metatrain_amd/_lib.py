@@ -80,6 +80,8 @@ class PetHypers(ctypes.Structure):
         ("nl_is_strict", c_int32),
         ("n_species", c_int32),
         ("max_atomic_number", c_int32),
+        ("num_neighbors_adaptive", c_float),
+        ("cutoff_width_adaptive", c_float),
     ]
 
 

@@ -560,6 +560,7 @@ int pet_config_set(const char* key, int value) {
     if (k == "side_stream") set_side_stream(value);
     else if (k == "trr") set_use_trr(value);
     else if (k == "soap_mfma") set_soap_mfma(value);
+    else if (k == "attn_lds") set_attn_lds(value);
     else PET_REQUIRE(false, PET_ERR_ARGUMENT, "unknown config key '" + k + "'");
     return PET_OK;
 }

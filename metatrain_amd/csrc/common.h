@@ -93,6 +93,21 @@ struct Graph {
     float* fc = nullptr;       // [E] cutoff factor
     int* sys = nullptr;        // [N] system index
     int* scalars = nullptr;    // [4] device: n_kept, max_nbr, n_bad_reverse, unused
+    // adaptive cutoff (structures.py:225-263): CSR over ALL input edges (the root finder and its
+    // implicit-function gradient see every edge within the maximum cutoff, kept or not)
+    bool adaptive = false;
+    int* rowptr0 = nullptr;    // [N+1]
+    int* perm0 = nullptr;      // [E0] sorted-by-centre position -> input edge
+    int* nbr0 = nullptr;       // [E0]
+    int* shift0 = nullptr;     // [E0,3]
+    int* rev0 = nullptr;       // [E0] position of the reverse edge in the all-edge CSR
+    float* r_atom = nullptr;   // [N] adapted cutoff (after the IFT step and the clamp)
+    float* r_newton = nullptr; // [N] root of the Newton-bisection loop
+    float* inv_dn = nullptr;   // [N] 1 / max(dn_total/dr, 1e-6) at the root; 0 if the clamp is active
+    float* pc = nullptr;       // [E] pair cutoff of every kept edge
+    float* ad_gc = nullptr;    // [E] scratch: dL/d(pair cutoff)
+    float* ad_gr = nullptr;    // [N] scratch: dL/d(atomic cutoff)
+    float4* ad_dv = nullptr;   // [E0] scratch: adaptive part of dL/d(edge vector), all-edge CSR order
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     void* scan_tmp = nullptr;

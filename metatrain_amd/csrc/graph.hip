@@ -45,6 +45,93 @@ float __device__ cutoff_deriv_dev(float d, float rc, float width, int fn) {
 }
 
 // ----------------------------------------------------------------------------------
+// adaptive cutoff (pet/modules/adaptive_cutoff.py:46-229, "solver" method)
+// ----------------------------------------------------------------------------------
+// bump(d; r, w) and d bump / d r in closed form (adaptive_cutoff.py:74-93)
+__device__ __forceinline__ void adaptive_term(float d, float r, float w, float& f, float& df) {
+    const float scaled = (d - (r - w)) / w;
+    const bool active = scaled > 0.0f && scaled < 1.0f;
+    const float safe = fminf(fmaxf(scaled, 1e-6f), 1.0f - 1e-6f);
+    const float s = 3.14159274f * safe;
+    const float sn = sinf(s);
+    const float t = tanhf(cosf(s) / sn);
+    f = active ? 0.5f * (1.0f + t) : (scaled <= 0.0f ? 1.0f : 0.0f);
+    df = active ? (0.5f * 3.14159274f / w) * (1.0f - t * t) / (sn * sn) : 0.0f;
+}
+
+// one 16-lane group per atom over its row of the all-edge CSR: ten Newton-bisection steps, then the
+// implicit-function-theorem step and the clamp to [rc/16, rc]
+__global__ void k_adaptive_solve(const int* __restrict__ rowptr0, const int* __restrict__ perm0,
+                                 const float4* __restrict__ vin, float* __restrict__ r_atom,
+                                 float* __restrict__ r_newton, float* __restrict__ inv_dn, int N, float rc, float w,
+                                 float target) {
+    const int gid = blockIdx.x * (blockDim.x / 16) + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    const int a = gid < N ? gid : N - 1;
+    const int p0 = rowptr0[a], p1 = rowptr0[a + 1];
+    const float inv_rc = 1.0f / rc;
+    float r_lo = 0.f, r_hi = rc, r = 0.5f * rc;
+    float n = 0.f, dn = 0.f;
+    for (int it = 0; it <= 10; it++) {
+        float fs = 0.f, dfs = 0.f;
+        for (int p = p0 + l; p < p1; p += 16) {
+            float f, df;
+            adaptive_term(vin[perm0[p]].w, r, w, f, df);
+            fs += f;
+            dfs += df;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { fs += __shfl_xor(fs, o); dfs += __shfl_xor(dfs, o); }
+        const float x = r * inv_rc;
+        n = fs + target * x * x * x;
+        dn = dfs + 3.0f * target * x * x * inv_rc;
+        if (it == 10) break;  // the eleventh evaluation is at the root: dn_root and the residual
+        const float f = n - target;
+        const bool below = f <= 0.f;
+        r_lo = below ? r : r_lo;
+        r_hi = below ? r_hi : r;
+        const float r_nt = r - f / fmaxf(dn, 1e-6f);
+        r = (r_nt >= r_lo && r_nt <= r_hi) ? r_nt : 0.5f * (r_lo + r_hi);
+    }
+    const float idn = 1.0f / fmaxf(dn, 1e-6f);
+    const float r_ift = r - (n - target) * idn;
+    const float lo = rc * (1.0f / 16.0f);
+    const bool clamped = r_ift < lo || r_ift > rc;
+    if (l == 0 && gid < N) {
+        r_atom[gid] = fminf(fmaxf(r_ift, lo), rc);
+        r_newton[gid] = r;
+        inv_dn[gid] = clamped ? 0.f : idn;
+    }
+}
+
+// pair cutoffs (r_i + r_j) / 2 and the mask d <= pair cutoff (structures.py:248-252)
+__global__ void k_adaptive_keep(const int* __restrict__ centers, const int* __restrict__ neighbors,
+                                const float4* __restrict__ vin, const float* __restrict__ r_atom,
+                                int* __restrict__ keep, int* __restrict__ sort_keys, int* __restrict__ sort_vals,
+                                int n_edges, int n_nodes) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    const int i = centers[e], j = neighbors[e];
+    const float pc = (r_atom[i] + r_atom[j]) / 2.0f;
+    const int kp = vin[e].w <= pc ? 1 : 0;
+    keep[e] = kp;
+    sort_keys[e] = kp ? i : n_nodes;
+    sort_vals[e] = e;
+}
+
+__global__ void k_gather_all(const int* __restrict__ perm0, const int* __restrict__ neighbors,
+                             const int* __restrict__ shifts, int* __restrict__ nbr0, int* __restrict__ shift0,
+                             int n) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const int e = perm0[q];
+    nbr0[q] = neighbors[e];
+    shift0[3 * q] = shifts[3 * e];
+    shift0[3 * q + 1] = shifts[3 * e + 1];
+    shift0[3 * q + 2] = shifts[3 * e + 2];
+}
+
+// ----------------------------------------------------------------------------------
 // kernels
 // ----------------------------------------------------------------------------------
 __global__ void k_species_index(const int* __restrict__ species, const int* __restrict__ table,
@@ -74,7 +161,7 @@ __global__ void k_edge_geometry(const float* __restrict__ pos, const float* __re
         v[k] = (pos[3 * j + k] - pos[3 * i + k]) + contrib;
     }
     float d0 = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + 1e-15f;
-    int kp = strict ? 1 : (d0 <= cutoff ? 1 : 0);
+    int kp = strict ? 1 : (d0 <= cutoff ? 1 : 0);  // strict == 2: adaptive first pass, every edge
     vin[e] = make_float4(v[0], v[1], v[2], d0);
     keep[e] = kp;
     sort_keys[e] = kp ? i : n_nodes;  // dropped edges sort behind every real centre
@@ -109,7 +196,8 @@ __global__ void k_csr_fill(const int* __restrict__ perm, const float4* __restric
                            int* __restrict__ ctr, int* __restrict__ nbr, int* __restrict__ shift,
                            int* __restrict__ sp_nbr, float4* __restrict__ geo,
                            float* __restrict__ d0, float* __restrict__ fc, int n_kept,
-                           float cutoff, float width, int fn) {
+                           float cutoff, float width, int fn, const float* __restrict__ r_atom,
+                           float* __restrict__ pc) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_kept) return;
     int e = perm[p];
@@ -124,7 +212,12 @@ __global__ void k_csr_fill(const int* __restrict__ perm, const float4* __restric
     // structures.py:330: the network sees sqrt(sum v^2 + 1e-15), not |v| + 1e-15
     geo[p] = make_float4(v.x, v.y, v.z, sqrtf(v.x * v.x + v.y * v.y + v.z * v.z + 1e-15f));
     d0[p] = v.w;
-    fc[p] = cutoff_value(v.w, cutoff, width, fn);
+    float c = cutoff;
+    if (r_atom) {
+        c = (r_atom[centers[e]] + r_atom[j]) / 2.0f;
+        pc[p] = c;
+    }
+    fc[p] = cutoff_value(v.w, c, width, fn);
 }
 
 // nef.py:88-166 restated as a search in row j (rows hold <= a few dozen edges)
@@ -146,13 +239,32 @@ __global__ void k_reverse(const int* __restrict__ rowptr, const int* __restrict_
     if (found < 0) atomicAdd(&scalars[2], 1);
 }
 
+// reverse edges inside the all-edge CSR (ctr0 = the sorted keys of the first pass)
+__global__ void k_reverse_all(const int* __restrict__ rowptr0, const int* __restrict__ ctr0,
+                              const int* __restrict__ nbr0, const int* __restrict__ shift0, int* __restrict__ rev0,
+                              int n) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const int i = ctr0[q], j = nbr0[q];
+    const int sa = -shift0[3 * q], sb = -shift0[3 * q + 1], sc = -shift0[3 * q + 2];
+    int found = -1;
+    for (int t = rowptr0[j]; t < rowptr0[j + 1]; t++) {
+        if (nbr0[t] == i && shift0[3 * t] == sa && shift0[3 * t + 1] == sb && shift0[3 * t + 2] == sc) {
+            found = t;
+            break;
+        }
+    }
+    rev0[q] = found;
+}
+
 // ---- NEF export (backend.py:328-341) ------------------------------------------------
 __global__ void k_export_nodes(const int* __restrict__ sp, int64_t* __restrict__ el_nodes,
-                               float* __restrict__ cut_stats, int n, float cutoff) {
+                               float* __restrict__ cut_stats, int n, float cutoff,
+                               const float* __restrict__ r_atom) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (el_nodes) el_nodes[i] = sp[i];
-    if (cut_stats) cut_stats[i] = cutoff;
+    if (cut_stats) cut_stats[i] = r_atom ? r_atom[i] : cutoff;
 }
 
 __global__ void k_export_nef(const int* __restrict__ rowptr, const int* __restrict__ nbr,
@@ -260,6 +372,18 @@ static int carve_graph(Graph& g, void* ws, int64_t n_nodes, int64_t e0, size_t* 
     g.fc = c.take<float>(e0);
     g.sys = c.take<int>(n_nodes);
     g.scalars = c.take<int>(8);
+    g.rowptr0 = c.take<int>(n_nodes + 1);
+    g.perm0 = c.take<int>(e0);
+    g.nbr0 = c.take<int>(e0);
+    g.shift0 = c.take<int>(3 * e0);
+    g.rev0 = c.take<int>(e0);
+    g.r_atom = c.take<float>(n_nodes);
+    g.r_newton = c.take<float>(n_nodes);
+    g.inv_dn = c.take<float>(n_nodes);
+    g.pc = c.take<float>(e0);
+    g.ad_gc = c.take<float>(e0);
+    g.ad_gr = c.take<float>(n_nodes);
+    g.ad_dv = c.take<float4>(e0);
     size_t sort_bytes = 0, scan_bytes = 0;
     int* ni = nullptr;
     if (rocprim::radix_sort_pairs(nullptr, sort_bytes, ni, ni, ni, ni, (size_t)e0, 0,
@@ -301,11 +425,29 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
                                                         g.sp, (int)n_nodes);
         PET_HIP_CHECK(hipMemcpyAsync(g.sys, sys, n_nodes * sizeof(int), hipMemcpyDeviceToDevice, st));
     }
+    g.adaptive = m.h.num_neighbors_adaptive > 0.f;
     if (e0 > 0) {
         k_edge_geometry<<<cdiv(e0, T), T, 0, st>>>(pos, cells, centers, neighbors, shifts, g.sys, g.vin,
                                                    g.keep, g.sort_keys_in, g.sort_vals_in, (int)e0,
-                                                   (int)n_nodes, m.h.cutoff, m.h.nl_is_strict);
+                                                   (int)n_nodes, m.h.cutoff, g.adaptive ? 2 : m.h.nl_is_strict);
         size_t sb = g.sort_tmp_bytes, cb = g.scan_tmp_bytes;
+        if (g.adaptive) {
+            // all-edge CSR -> per-atom cutoffs -> pair mask; then the usual kept-edge CSR below
+            PET_HIP_CHECK(rocprim::radix_sort_pairs(g.sort_tmp, sb, g.sort_keys_in, g.sort_keys_out,
+                                                    g.sort_vals_in, g.perm0, (size_t)e0, 0,
+                                                    sort_bits(n_nodes), st));
+            k_rowptr<<<cdiv(n_nodes + 1, T), T, 0, st>>>(g.sort_keys_out, (int)e0, g.rowptr0, (int)n_nodes,
+                                                         g.scalars + 4);
+            k_gather_all<<<cdiv(e0, T), T, 0, st>>>(g.perm0, neighbors, shifts, g.nbr0, g.shift0, (int)e0);
+            k_adaptive_solve<<<cdiv(n_nodes, 16), 256, 0, st>>>(g.rowptr0, g.perm0, g.vin, g.r_atom, g.r_newton,
+                                                                g.inv_dn, (int)n_nodes, m.h.cutoff,
+                                                                m.h.cutoff_width_adaptive,
+                                                                m.h.num_neighbors_adaptive);
+            k_reverse_all<<<cdiv(e0, T), T, 0, st>>>(g.rowptr0, g.sort_keys_out, g.nbr0, g.shift0, g.rev0, (int)e0);
+            k_adaptive_keep<<<cdiv(e0, T), T, 0, st>>>(centers, neighbors, g.vin, g.r_atom, g.keep,
+                                                       g.sort_keys_in, g.sort_vals_in, (int)e0, (int)n_nodes);
+            sb = g.sort_tmp_bytes;
+        }
         PET_HIP_CHECK(rocprim::radix_sort_pairs(g.sort_tmp, sb, g.sort_keys_in, g.sort_keys_out,
                                                 g.sort_vals_in, g.perm, (size_t)e0, 0,
                                                 sort_bits(n_nodes), st));
@@ -324,7 +466,8 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
         int ne = (int)g.n_edges;
         k_csr_fill<<<cdiv(ne, T), T, 0, st>>>(g.perm, g.vin, centers, neighbors, shifts, g.sp, g.ctr,
                                               g.nbr, g.shift, g.sp_nbr, g.geo, g.d0, g.fc, ne,
-                                              m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function);
+                                              m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function,
+                                              g.adaptive ? g.r_atom : nullptr, g.pc);
         k_reverse<<<cdiv(ne, T), T, 0, st>>>(g.rowptr, g.ctr, g.nbr, g.shift, g.rev, ne, g.scalars);
         k_find_pad_src<<<cdiv(ne, T), T, 0, st>>>(g.perm, g.kidx, g.keep, ne, g.scalars + 3);
     }
@@ -347,7 +490,8 @@ int graph_export(const Graph& g, float cutoff, int64_t* el_nodes, int64_t* el_nb
                  int64_t* neighbors, int64_t* slot, int64_t* shifts, hipStream_t st) {
     const int T = 256;
     if (g.n_nodes > 0)
-        k_export_nodes<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.sp, el_nodes, stats, (int)g.n_nodes, cutoff);
+        k_export_nodes<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.sp, el_nodes, stats, (int)g.n_nodes, cutoff,
+                                                         g.adaptive ? g.r_atom : nullptr);
     int64_t cells = g.n_nodes * (int64_t)g.max_nbr;
     if (cells > 0) {
         int pad_src = -1;

@@ -121,6 +121,7 @@ int backward_geometry_abi(const Model& m, const Graph& g, void* ws, int64_t ws_b
 bool use_trr();
 void set_use_trr(int v);
 void set_side_stream(int v);
+void set_attn_lds(int v);   // pet_attn.hip: 1 = LDS-staged attention (default), 0 = wave-per-head from global
 void set_soap_mfma(int v);  // soap.hip: 1 = MFMA tail (default), 0 = per-atom tail kernels
 void trr_qkv(const float* X, const float* gamma, const Lin& qkv, float* QKV, int64_t R, hipStream_t st);
 void trr_qkv_bwd(const float* dQKV, const float* X, const float* gamma, const Lin& qkv, const float* dX1,

@@ -648,13 +648,15 @@ __global__ void k_dfc_attn(const float* __restrict__ fc, const float* __restrict
 __global__ void k_geom_bwd(const float4* __restrict__ geo, const float* __restrict__ d0,
                            const float* __restrict__ dgeo, const float* __restrict__ dfc_a,
                            const float* __restrict__ dfc_b, float4* __restrict__ dv, int64_t E, float cutoff,
-                           float width, int fn) {
+                           float width, int fn, const float* __restrict__ pc, float* __restrict__ gc) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= E) return;
     const float4 g = geo[p];
     const float4 dg = reinterpret_cast<const float4*>(dgeo)[p];
     const float dfc_t = (dfc_a ? dfc_a[p] : 0.f) + (dfc_b ? dfc_b[p] : 0.f);
-    const float dd0 = dfc_t * cutoff_deriv_dev(d0[p], cutoff, width, fn);
+    // adaptive cutoff: fc = f(d - c) with the pair cutoff c, so df/dc = -df/dd
+    const float dd0 = dfc_t * cutoff_deriv_dev(d0[p], pc ? pc[p] : cutoff, width, fn);
+    if (gc) gc[p] = -dd0;
     const float nrm = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
     const float c_dist = dg.w / g.w;                    // d sqrt(v.v + 1e-15) / dv = v / dist
     const float c_d0 = nrm > 0.f ? dd0 / nrm : 0.f;     // d |v| / dv = v / |v|
@@ -679,6 +681,60 @@ __global__ void k_pos_grad(const float4* __restrict__ dv, const int* __restrict_
     }
     if (l == 0 && gid < N) {
         gpos[3 * gid] = x; gpos[3 * gid + 1] = y; gpos[3 * gid + 2] = z;
+    }
+}
+
+// ---- adaptive cutoff adjoint (adaptive_cutoff.py:196-229: the implicit-function step carries the gradient)
+// g_r[i] = dL/d r_i = sum over kept edges touching i of dL/dc / 2 = 1/2 sum_{p in row i} (gc[p] + gc[rev p])
+__global__ void k_adapt_gr(const float* __restrict__ gc, const int* __restrict__ rowptr, const int* __restrict__ rev,
+                           float* __restrict__ gr, int N) {
+    const int gid = blockIdx.x * (blockDim.x / 16) + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    const int a = gid < N ? gid : N - 1;
+    float s = 0.f;
+    for (int p = rowptr[a] + l; p < rowptr[a + 1]; p += 16) s += gc[p] + gc[rev[p]];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (l == 0 && gid < N) gr[gid] = 0.5f * s;
+}
+// every input edge q of atom i (all-edge CSR): d r_i / d d_q = -(d bump(d_q; r, w)/d d_q) / dn_root,
+// d bump / d d = -(d bump / d r); the edge vector gets (v / |v|) times that
+__global__ void k_adapt_dv(const int* __restrict__ rowptr0, const int* __restrict__ perm0,
+                           const float4* __restrict__ vin, const float* __restrict__ gr,
+                           const float* __restrict__ r_newton, const float* __restrict__ inv_dn,
+                           float4* __restrict__ dvA, int N, float w) {
+    const int gid = blockIdx.x * (blockDim.x / 16) + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    if (gid >= N) return;
+    const float coef = gr[gid] * inv_dn[gid], r = r_newton[gid];
+    for (int q = rowptr0[gid] + l; q < rowptr0[gid + 1]; q += 16) {
+        const float4 v = vin[perm0[q]];
+        // d r_adapt / d d_q = -(d bump/d d)(d_q; r) * inv_dn  (bump derivative w.r.t. d, bump taper = BUMP)
+        const float dd = -coef * cutoff_deriv_dev(v.w, r, w, PET_CUTOFF_BUMP);
+        const float nrm = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+        const float c = nrm > 0.f ? dd / nrm : 0.f;
+        dvA[q] = make_float4(c * v.x, c * v.y, c * v.z, 0.f);
+    }
+}
+// gpos[a] += sum_{q in row0 a} (dvA[rev0 q] - dvA[q])
+__global__ void k_pos_grad_acc(const float4* __restrict__ dv, const int* __restrict__ rowptr,
+                               const int* __restrict__ rev, float* __restrict__ gpos, int N) {
+    const int gid = blockIdx.x * (blockDim.x / 16) + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    const int a = gid < N ? gid : N - 1;
+    float x = 0.f, y = 0.f, z = 0.f;
+    for (int p = rowptr[a] + l; p < rowptr[a + 1]; p += 16) {
+        const float4 m = dv[p];
+        const int rp = rev[p];
+        const float4 q = rp >= 0 ? dv[rp] : make_float4(0.f, 0.f, 0.f, 0.f);
+        x += q.x - m.x; y += q.y - m.y; z += q.z - m.z;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        x += __shfl_xor(x, o); y += __shfl_xor(y, o); z += __shfl_xor(z, o);
+    }
+    if (l == 0 && gid < N) {
+        gpos[3 * gid] += x; gpos[3 * gid + 1] += y; gpos[3 * gid + 2] += z;
     }
 }
 
@@ -954,8 +1010,16 @@ int backward_geometry(const Model& m, const Graph& g, Workspace& w, const float*
     int rc = check_full_list(g, st);
     if (rc) return rc;
     k_geom_bwd<<<cdiv(E, 256), 256, 0, st>>>(g.geo, g.d0, dgeo, dfc_a, dfc_b, reinterpret_cast<float4*>(w.dv), E,
-                                             m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function);
+                                             m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function,
+                                             g.adaptive ? g.pc : nullptr, g.adaptive ? g.ad_gc : nullptr);
     k_pos_grad<<<cdiv(N, 16), 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.rowptr, g.rev, gpos, (int)N);
+    if (g.adaptive) {
+        PET_REQUIRE(gcell == nullptr, PET_ERR_UNSUPPORTED, "dE/dcell with the adaptive cutoff is not built yet");
+        k_adapt_gr<<<cdiv(N, 16), 256, 0, st>>>(g.ad_gc, g.rowptr, g.rev, g.ad_gr, (int)N);
+        k_adapt_dv<<<cdiv(N, 16), 256, 0, st>>>(g.rowptr0, g.perm0, g.vin, g.ad_gr, g.r_newton, g.inv_dn, g.ad_dv,
+                                                (int)N, m.h.cutoff_width_adaptive);
+        k_pos_grad_acc<<<cdiv(N, 16), 256, 0, st>>>(g.ad_dv, g.rowptr0, g.rev0, gpos, (int)N);
+    }
     if (gcell)
         k_cell_grad<<<(int)g.n_systems, 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.shift, g.ctr, g.sys,
                                                       g.rowptr, gcell, (int)N, E);

@@ -790,6 +790,8 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
     if (N == 0) return PET_OK;
     PET_REQUIRE(E > 0, PET_ERR_UNSUPPORTED, "training on a batch without any edge is not supported");
     PET_REQUIRE(g.max_nbr + 1 <= 128, PET_ERR_UNSUPPORTED, "more than 127 neighbours per atom is not supported yet");
+    PET_REQUIRE(!g.adaptive, PET_ERR_UNSUPPORTED,
+                "the second-order (force-loss) pass with the adaptive cutoff is not built yet");
     const float scale = 1.0f / (sqrtf((float)HD) * m.h.attention_temperature);
     const int T_max = g.max_nbr + 1;
     const size_t lds_jvp = (size_t)T_max * (4 * HD + 2) * sizeof(float);

@@ -199,7 +199,9 @@ class PETBackend(torch.nn.Module):
         self.cutoff = float(hypers["cutoff"])
         self.cutoff_function = hypers["cutoff_function"]
         self.cutoff_width = float(hypers["cutoff_width"])
-        self.num_neighbors_adaptive = None
+        self.num_neighbors_adaptive = (float(hypers["num_neighbors_adaptive"])
+                                       if hypers["num_neighbors_adaptive"] is not None else None)
+        self.adaptive_cutoff_method = hypers.get("adaptive_cutoff_method", "solver")
         self.d_pet, self.d_node = hypers["d_pet"], hypers["d_node"]
         self.d_head, self.d_feedforward = hypers["d_head"], hypers["d_feedforward"]
         self.num_heads = hypers["num_heads"]
@@ -289,6 +291,10 @@ class PETBackend(torch.nn.Module):
                    cutoff_width_adaptive: float) -> Dict[str, torch.Tensor]:
         """``PETBackend.preprocess`` (backend.py:238-342): the 12 ``batch_data`` tensors."""
         model = self._any_model()
+        if self.num_neighbors_adaptive is not None and abs(
+                float(cutoff_width_adaptive) - float(self.hypers.get("cutoff_width_adaptive", 1.0))) > 1e-12:
+            raise PetHipError("cutoff_width_adaptive differs from the value in the model hypers (it is part of "
+                              "the packed model here)")
         graph = rt.HipGraph(model, positions, cells, centers, neighbors, cell_shifts, species, system_indices)
         batch = graph.export_batch()
         hctx = _Ctx(graph, model)

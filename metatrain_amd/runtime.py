@@ -36,8 +36,8 @@ def hypers_struct(hypers: dict, atomic_types: List[int]) -> PetHypers:
                       ("transformer_type", "PreLN"), ("featurizer_type", "feedforward")):
         if hypers[key] != want:
             raise PetHipError(f"hypers['{key}'] = {hypers[key]!r} is not built into libpet_hip (only {want!r})")
-    if hypers["num_neighbors_adaptive"] is not None:
-        raise PetHipError("adaptive cutoff is not built into libpet_hip yet")
+    if hypers["num_neighbors_adaptive"] is not None and hypers["adaptive_cutoff_method"].lower() != "solver":
+        raise PetHipError("adaptive_cutoff_method = 'grid' is not built into libpet_hip (only 'solver')")
     if hypers.get("system_conditioning", False):
         raise PetHipError("system_conditioning is not built into libpet_hip yet")
     return PetHypers(
@@ -55,6 +55,8 @@ def hypers_struct(hypers: dict, atomic_types: List[int]) -> PetHypers:
         nl_is_strict=int(bool(hypers["long_range"]["enable"])),
         n_species=len(atomic_types),
         max_atomic_number=max(atomic_types),
+        num_neighbors_adaptive=float(hypers["num_neighbors_adaptive"] or 0.0),
+        cutoff_width_adaptive=float(hypers.get("cutoff_width_adaptive", 1.0)),
     )
 
 

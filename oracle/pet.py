@@ -65,14 +65,53 @@ DEFAULT_HYPERS = {
 }
 
 
-def cutoff_bump(d: torch.Tensor, cutoff: float, width: float) -> torch.Tensor:
+def _adaptive_n_and_dn(r, d, centers, n_nodes, width, inv_rc, target):
+    """``adaptive_cutoff.py:46-107``: smoothed neighbour count + cubic baseline and d/dr, closed form."""
+    scaled = (d - (r[centers] - width)) / width
+    active = (scaled > 0.0) & (scaled < 1.0)
+    smaller = scaled <= 0.0
+    s = math.pi * scaled.clamp(1e-6, 1.0 - 1e-6)
+    sin_s = torch.sin(s)
+    t = torch.tanh(torch.cos(s) / sin_s)
+    f = torch.where(active, 0.5 * (1.0 + t), smaller.to(d.dtype))
+    df = (0.5 * math.pi / width) * (1.0 - t * t) / (sin_s * sin_s) * active.to(d.dtype)
+    n = torch.zeros(n_nodes, dtype=d.dtype).index_add(0, centers, f)
+    dn = torch.zeros(n_nodes, dtype=d.dtype).index_add(0, centers, df)
+    x = r * inv_rc
+    return n + target * x**3, dn + 3.0 * target * x**2 * inv_rc
+
+
+def adaptive_cutoffs_solver(centers, d, target: float, n_nodes: int, max_cutoff: float, width: float):
+    """``adaptive_cutoff.py:110-229`` (``get_adaptive_cutoffs_solver``): ten Newton-bisection steps on the
+    detached distances, then one implicit-function-theorem step that carries the gradient."""
+    dd = d.detach()
+    inv_rc = 1.0 / max_cutoff
+    r_lo = torch.zeros(n_nodes, dtype=d.dtype)
+    r_hi = torch.full((n_nodes,), max_cutoff, dtype=d.dtype)
+    r = 0.5 * r_hi
+    for _ in range(10):
+        n, dn = _adaptive_n_and_dn(r, dd, centers, n_nodes, width, inv_rc, target)
+        f = n - target
+        below = f <= 0
+        r_lo = torch.where(below, r, r_lo)
+        r_hi = torch.where(below, r_hi, r)
+        r_newton = r - f / dn.clamp_min(1e-6)
+        inside = (r_newton >= r_lo) & (r_newton <= r_hi)
+        r = torch.where(inside, r_newton, 0.5 * (r_lo + r_hi))
+    _, dn_root = _adaptive_n_and_dn(r, dd, centers, n_nodes, width, inv_rc, target)
+    per_edge = cutoff_bump(d, r[centers], width)  # the reference's cutoff_func with a per-edge cutoff
+    n_res = torch.zeros(n_nodes, dtype=d.dtype).index_add(0, centers, per_edge) + target * (r * inv_rc) ** 3 - target
+    return (r - n_res / dn_root.clamp_min(1e-6)).clamp(max_cutoff / 16.0, max_cutoff)
+
+
+def cutoff_bump(d: torch.Tensor, cutoff, width: float) -> torch.Tensor:
     """``pet/modules/utilities.py:4-22``."""
     s = (d - (cutoff - width)) / width
     s = s.clamp(1e-6, 1.0 - 1e-6)
     return 0.5 * (1.0 + torch.tanh(1.0 / torch.tan(math.pi * s)))
 
 
-def cutoff_cosine(d: torch.Tensor, cutoff: float, width: float) -> torch.Tensor:
+def cutoff_cosine(d: torch.Tensor, cutoff, width: float) -> torch.Tensor:
     """``pet/modules/utilities.py:25-39``."""
     s = ((d - (cutoff - width)) / width).clamp(0.0, 1.0)
     return 0.5 * (1.0 + torch.cos(math.pi * s))
@@ -190,7 +229,7 @@ def pet_atomic_energies(
     assert hypers["activation"] == "SwiGLU"
     assert hypers["transformer_type"] == "PreLN"
     assert hypers["featurizer_type"] == "feedforward"
-    assert hypers["num_neighbors_adaptive"] is None
+    assert hypers["num_neighbors_adaptive"] is None or hypers["adaptive_cutoff_method"] == "solver"
     block = block or target
     cutoff, width = float(hypers["cutoff"]), float(hypers["cutoff_width"])
     n_heads = hypers["num_heads"]
@@ -201,7 +240,14 @@ def pet_atomic_energies(
     v_all, d_all = edge_geometry(
         positions, cells, centers.long(), neighbors.long(), cell_shifts, system_indices
     )
-    if not bool(hypers["long_range"]["enable"]):
+    pair_cut_all = None
+    if hypers["num_neighbors_adaptive"] is not None:
+        # structures.py:225-263: per-atom adaptive cutoffs, symmetrised per pair, then the mask
+        r_atom = adaptive_cutoffs_solver(centers.long(), d_all, float(hypers["num_neighbors_adaptive"]), n_nodes,
+                                         cutoff, float(hypers["cutoff_width_adaptive"]))
+        pair_cut_all = 0.5 * (r_atom[centers.long()] + r_atom[neighbors.long()])
+        keep = torch.nonzero(d_all.detach() <= pair_cut_all.detach()).squeeze(-1)
+    elif not bool(hypers["long_range"]["enable"]):
         # non-strict NL filter, structures.py:265-272
         keep = torch.nonzero(d_all.detach() <= cutoff).squeeze(-1)
     else:
@@ -212,10 +258,11 @@ def pet_atomic_energies(
     sel = keep[torch.as_tensor(graph.order)]
     v = v_all[sel]
     d0 = d_all[sel]
+    pair_cut = cutoff if pair_cut_all is None else pair_cut_all[sel]
     if hypers["cutoff_function"].lower() == "bump":
-        fc = cutoff_bump(d0, cutoff, width)
+        fc = cutoff_bump(d0, pair_cut, width)
     else:
-        fc = cutoff_cosine(d0, cutoff, width)
+        fc = cutoff_cosine(d0, pair_cut, width)
     dist = torch.sqrt((v * v).sum(-1) + 1e-15)  # structures.py:330
     nbr = torch.as_tensor(graph.neighbors)
     ctr = torch.as_tensor(graph.centers)
@@ -321,17 +368,26 @@ def batch_tensors(
     v, d0 = edge_geometry(
         pos, cells, centers.long(), neighbors.long(), cell_shifts, system_indices
     )
-    if not bool(hypers["long_range"]["enable"]):
+    n_nodes = pos.shape[0]
+    pair_cut = None
+    stats = np.full((n_nodes,), cutoff, dtype=pos.numpy().dtype)
+    if hypers["num_neighbors_adaptive"] is not None:
+        r_atom = adaptive_cutoffs_solver(centers.long(), d0, float(hypers["num_neighbors_adaptive"]), n_nodes, cutoff,
+                                         float(hypers["cutoff_width_adaptive"]))
+        stats = r_atom.numpy()
+        pair_cut = 0.5 * (r_atom[centers.long()] + r_atom[neighbors.long()])
+        keep = torch.nonzero(d0 <= pair_cut).squeeze(-1)
+        pair_cut = pair_cut[keep]
+    elif not bool(hypers["long_range"]["enable"]):
         keep = torch.nonzero(d0 <= cutoff).squeeze(-1)
     else:
         keep = torch.arange(len(d0))
     centers_k, neighbors_k = centers[keep], neighbors[keep]
     shifts_k, v, d0 = cell_shifts[keep], v[keep], d0[keep]
     if hypers["cutoff_function"].lower() == "bump":
-        fc = cutoff_bump(d0, cutoff, width)
+        fc = cutoff_bump(d0, cutoff if pair_cut is None else pair_cut, width)
     else:
-        fc = cutoff_cosine(d0, cutoff, width)
-    n_nodes = pos.shape[0]
+        fc = cutoff_cosine(d0, cutoff if pair_cut is None else pair_cut, width)
     idx = _nef.reverse_neighbor_index(
         centers_k.numpy(), neighbors_k.numpy(), shifts_k.numpy(), n_nodes
     )
@@ -356,7 +412,7 @@ def batch_tensors(
         "padding_mask": idx["padding_mask"],
         "reverse_neighbor_index": idx["reverse_neighbor_index"],
         "cutoff_factors": fcn.numpy(),
-        "atomic_cutoffs_stats": np.full((n_nodes,), cutoff, dtype=ev.numpy().dtype),
+        "atomic_cutoffs_stats": stats,
         "centers": centers_k.numpy(),
         "neighbors": neighbors_k.numpy(),
         "nef_to_edges_neighbor": idx["nef_to_edges_neighbor"],

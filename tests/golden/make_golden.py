@@ -121,6 +121,67 @@ def run_reference(backend, name, pos, cells, centers, neighbors, shifts, species
     return out, batch
 
 
+def main_adaptive():
+    """Adaptive-cutoff fixtures (``num_neighbors_adaptive``, solver method):
+    ``batch_adaptive_<case>.npz`` (12 ``batch_data`` tensors) and ``pet_adaptive_<case>.npz``
+    (E, per-atom E, dE/dR in fp32 / fp64) from the reference modules."""
+    from oracle import nl as onl
+    from oracle import pet as opet
+
+    PETBackend = import_reference_backend()
+    torch.set_num_threads(8)
+    hypers = dict(opet.DEFAULT_HYPERS, num_neighbors_adaptive=12, adaptive_cutoff_method="solver",
+                  cutoff_width_adaptive=1.0)
+    p64, z64, c64 = opet.random_box(64, seed=1)
+    p40, z40, c40 = opet.random_box(40, seed=2)
+    tri = c40.clone(); tri[1, 0] = 2.0; tri[2, 1] = -1.5
+    cases = {"box64": [(p64, z64, c64)], "two_systems": [(p64, z64, c64), (p40 + 30.0, z40, tri)]}
+    for tag, systems in cases.items():
+        pos_l, z_l, cell_l, i_l, j_l, s_l, sys_l = [], [], [], [], [], [], []
+        off = 0
+        for k, (pos, z, cell) in enumerate(systems):
+            i, j, s, _ = onl.neighbor_list(pos.double().numpy(), cell.double().numpy(), [True] * 3, hypers["cutoff"])
+            pos_l.append(pos); z_l.append(z); cell_l.append(cell)
+            i_l.append(torch.tensor(i) + off); j_l.append(torch.tensor(j) + off)
+            s_l.append(torch.tensor(s)); sys_l.append(torch.full((len(z),), k, dtype=torch.long))
+            off += len(z)
+        pos = torch.cat(pos_l); z = torch.cat(z_l); cells = torch.stack(cell_l)
+        i = torch.cat(i_l); j = torch.cat(j_l); s = torch.cat(s_l).long(); sysidx = torch.cat(sys_l)
+        perm = torch.randperm(len(i), generator=torch.Generator().manual_seed(5))
+        i, j, s = i[perm], j[perm], s[perm]
+        inputs = {"in_" + k: v.numpy() for k, v in dict(
+            positions=pos.double(), species=z, cells=cells.double(), centers=i.int(), neighbors=j.int(),
+            cell_shifts=s.int(), system_indices=sysidx).items()}
+        be = PETBackend(hypers, [1, 6, 7, 8])
+        batch = be.preprocess(pos, i, j, z, cells, s, sysidx, hypers["cutoff_width_adaptive"])
+        out = dict(inputs)
+        out.update({k: v.numpy() for k, v in batch.items()})
+        np.savez(os.path.join(HERE, f"batch_adaptive_{tag}.npz"), **out)
+        print(tag, "E0 =", len(i), "kept", len(batch["centers"]), "M =", batch["padding_mask"].shape[1],
+              "cutoffs", batch["atomic_cutoffs_stats"].min().item(), batch["atomic_cutoffs_stats"].max().item())
+        store = dict(inputs)
+        for dtype in (torch.float32, torch.float64):
+            params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, dtype)
+            be = PETBackend(hypers, [1, 6, 7, 8])
+            be.add_output("energy", {"energy": [1]})
+            be = be.to(dtype).eval()
+            be.load_state_dict(params, strict=True)
+            p = pos.to(dtype).clone().requires_grad_(True)
+            b = be.preprocess(p, i, j, z, cells.to(dtype), s, sysidx, hypers["cutoff_width_adaptive"])
+            nf, ef = be.calculate_features(b)
+            pred, _, _ = be.predict(nf, ef, b, cells.to(dtype), sysidx, ["energy"])
+            atomic = pred["energy"][0]
+            energies = torch.zeros(cells.shape[0], 1, dtype=dtype).index_add(0, sysidx, atomic)
+            (grad,) = torch.autograd.grad(energies.sum(), p)
+            sfx = {torch.float32: "f32", torch.float64: "f64"}[dtype]
+            store[f"energies_{sfx}"] = energies.detach().numpy()
+            store[f"atomic_{sfx}"] = atomic.detach().numpy()
+            store[f"grad_{sfx}"] = grad.numpy()
+            store[f"atomic_cutoffs_{sfx}"] = b["atomic_cutoffs_stats"].numpy()
+            print(tag, sfx, "E =", energies.detach().numpy().ravel(), "|grad|max =", grad.abs().max().item())
+        np.savez_compressed(os.path.join(HERE, f"pet_adaptive_{tag}.npz"), **store)
+
+
 def main():
     from oracle import nl as onl
     from oracle import pet as opet
@@ -243,4 +304,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--adaptive" in sys.argv:
+        main_adaptive()
+    else:
+        main()

@@ -231,3 +231,41 @@ def test_rotation_and_permutation_consistency(rt, model, dev):
     assert relmax(a2, a0) < 1e-4 and relmax(g2, g0) < 1e-4
     # Newton's third law: the net force on a periodic box vanishes
     assert np.abs(g0.sum(0)).max() < 1e-3 * np.abs(g0).max()
+
+
+@pytest.fixture(scope="module")
+def adaptive_model(rt, dev):
+    hypers = dict(opet.DEFAULT_HYPERS, num_neighbors_adaptive=12, adaptive_cutoff_method="solver",
+                  cutoff_width_adaptive=1.0)
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
+    m = rt.HipModel(hypers, [1, 6, 7, 8])
+    m.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    return m
+
+
+@pytest.mark.parametrize("case", ["box64", "two_systems"])
+def test_adaptive_cutoff_matches_reference(rt, adaptive_model, dev, golden_dir, case):
+    """num_neighbors_adaptive = 12 (solver): batch_data with integers bit-exact, per-atom
+    cutoffs, then E / per-atom E / dE/dR including the implicit-function gradient of the cutoffs."""
+    b = _load(golden_dir, f"batch_adaptive_{case}.npz")
+    graph = _graph_from_golden(rt, adaptive_model, b, dev)
+    out = graph.export_batch()
+    for k in INT_KEYS:
+        got = out[k].cpu().numpy()
+        assert got.shape == b[k].shape, k
+        assert np.array_equal(got, b[k]), f"{k} is not bit-exact"
+    np.testing.assert_allclose(out["atomic_cutoffs_stats"].cpu().numpy(), b["atomic_cutoffs_stats"], rtol=3e-6)
+    assert b["atomic_cutoffs_stats"].max() < 4.2  # the adaptive cutoffs really are below the 4.5 A maximum
+    np.testing.assert_allclose(out["cutoff_factors"].cpu().numpy(), b["cutoff_factors"], rtol=2e-4, atol=3e-6)
+    for k in ("edge_vectors", "edge_distances"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), b[k], rtol=2e-6, atol=2e-6, err_msg=k)
+    g = _load(golden_dir, f"pet_adaptive_{case}.npz")
+    fw = rt.HipForward(adaptive_model, graph)
+    atomic = fw.forward()
+    grad = fw.backward(torch.ones_like(atomic))
+    e = fw.sum_over_atoms(atomic).cpu().numpy()
+    assert np.abs(e - g["energies_f64"].ravel()).max() / np.abs(g["energies_f64"]).max() < TOL
+    assert relmax(atomic.cpu().numpy(), g["atomic_f64"].ravel()) < TOL
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < 2e-5  # the reference's own fp32 path: see below
+    ref32 = relmax(g["grad_f32"], g["grad_f64"])
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < max(TOL, 3 * ref32)

@@ -133,3 +133,30 @@ def test_product_generators_equal_oracle_generators():
     assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
     for x, y in zip(synthetic.random_box(50, 9), opet.random_box(50, 9)):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("case", ["box64", "two_systems"])
+def test_oracle_adaptive_cutoff_matches_reference(golden_dir, case):
+    """num_neighbors_adaptive (solver) -- the oracle's restatement of
+    adaptive_cutoff.py:110-229 + structures.py:225-263 against fixtures generated from the reference."""
+    hypers = dict(opet.DEFAULT_HYPERS, num_neighbors_adaptive=12, adaptive_cutoff_method="solver",
+                  cutoff_width_adaptive=1.0)
+    g = dict(np.load(os.path.join(golden_dir, f"pet_adaptive_{case}.npz")))
+    b = dict(np.load(os.path.join(golden_dir, f"batch_adaptive_{case}.npz")))
+    t = lambda k: torch.tensor(g[k])  # noqa: E731
+    table = torch.full((9,), -1, dtype=torch.long)
+    table[torch.tensor([1, 6, 7, 8])] = torch.arange(4)
+    out = opet.batch_tensors(hypers, table, t("in_positions").float(), t("in_cells").float(), t("in_centers"),
+                             t("in_neighbors"), t("in_cell_shifts"), t("in_species"), t("in_system_indices"))
+    for k in ("padding_mask", "reverse_neighbor_index", "centers", "neighbors", "cell_shifts",
+              "element_indices_neighbors", "nef_to_edges_neighbor"):
+        assert np.array_equal(out[k], b[k]), k
+    np.testing.assert_allclose(out["atomic_cutoffs_stats"], b["atomic_cutoffs_stats"], rtol=2e-6)
+    np.testing.assert_allclose(out["cutoff_factors"], b["cutoff_factors"], rtol=1e-4, atol=2e-6)
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    e, grad, atomic = opet.energy_and_gradient(
+        params, hypers, t("in_positions"), t("in_cells"), t("in_centers"), t("in_neighbors"), t("in_cell_shifts"),
+        t("in_species"), t("in_system_indices"))
+    np.testing.assert_allclose(e.numpy(), g["energies_f64"], rtol=1e-10)
+    np.testing.assert_allclose(atomic.numpy(), g["atomic_f64"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(grad.numpy(), g["grad_f64"], rtol=1e-8, atol=1e-11)
