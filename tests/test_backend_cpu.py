@@ -52,7 +52,8 @@ def test_unsupported_variants_and_cpu_inputs_raise():
     with pytest.raises(PetHipError):
         PETBackend(dict(default_hypers(), featurizer_type="residual"), [1, 6])
     with pytest.raises(PetHipError):
-        PETBackend(dict(default_hypers(), num_neighbors_adaptive=16), [1, 6])
+        PETBackend(dict(default_hypers(), num_neighbors_adaptive=16, adaptive_cutoff_method="grid"), [1, 6])
+    PETBackend(dict(default_hypers(), num_neighbors_adaptive=16), [1, 6])  # the "solver" method is built
     be = PETBackend(default_hypers(), [1, 6, 7, 8])
     be.add_output("energy", {"energy": [1]})
     z = torch.zeros
