@@ -142,15 +142,20 @@ __global__ __launch_bounds__(256) void k_emlp_t(const float* __restrict__ X1, co
     acc_bias<4>(out, bout, 0, L.h);
 #pragma unroll 1
     for (int hc = 0; hc < DFF / 32; hc++) {
-        f32x16 v[1], g[1];
-        acc_bias<1>(v, bin, 32 * hc, L.h);
-        acc_bias<1>(g, bin, DFF + 32 * hc, L.h);
-        gemm_t<16, 1, 4>(win, 16, 0, hc, x, v, L.lane);
-        gemm_t<16, 1, 4>(win, 16, 0, DFF / 32 + hc, x, g, L.lane);
+        // value and gate tiles as two interleaved MFMA chains (tiles hc and DFF/32 + hc of w_in)
+        f32x16 vg[2];
+        {
+            f32x16 v[1], g[1];
+            acc_bias<1>(v, bin, 32 * hc, L.h);
+            acc_bias<1>(g, bin, DFF + 32 * hc, L.h);
+            vg[0] = v[0];
+            vg[1] = g[0];
+        }
+        gemm_t<16, 2, 2>(win, 16, 0, hc, x, vg, L.lane, DFF / 32);
         float4 u[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const float4 vv = acc_q(v[0], q), gg = acc_q(g[0], q);
+            const float4 vv = acc_q(vg[0], q), gg = acc_q(vg[1], q);
             if (VG && valid) {
                 *reinterpret_cast<float4*>(VG + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) = vv;
                 *reinterpret_cast<float4*>(VG + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) = gg;

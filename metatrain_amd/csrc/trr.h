@@ -96,10 +96,10 @@ __device__ __forceinline__ void acc_bias(f32x16 (&acc)[NT], const float* __restr
 // fragments are kept in flight ahead of the MFMAs that consume them.
 template <int KGS, int NT, int PF = 2>
 __device__ __forceinline__ void gemm_t(const float4* __restrict__ Wp, int kg_total, int kg0, int tile0,
-                                       const float4* x, f32x16 (&acc)[NT], int lane) {
+                                       const float4* x, f32x16 (&acc)[NT], int lane, int tile_stride = 1) {
     const float4* wp[NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++) wp[t] = Wp + ((size_t)(tile0 + t) * kg_total + kg0) * 64 + lane;
+    for (int t = 0; t < NT; t++) wp[t] = Wp + ((size_t)(tile0 + t * tile_stride) * kg_total + kg0) * 64 + lane;
     float4 wb[PF][NT];
 #pragma unroll
     for (int s = 0; s < PF; s++)
