@@ -15,10 +15,17 @@ pet/tests/test_backend.py and utils/output_gradient.py:34-40.
 
 There is no CPU path: CPU tensors raise ``PetHipError``.
 
-Not built in round 1 (raise loudly): normalization != RMSNorm, activation != SwiGLU,
-transformer_type != PreLN, featurizer_type != feedforward, adaptive cutoff, system
-conditioning, more than one property per block, last-layer-feature outputs (the two extra
-dicts are returned empty), and double backward (training with forces).
+Training (``pet/trainer.py:417-467`` through this mirror): in ``train()`` mode with parameters that
+require grad, ``predict`` routes the target through ONE fused autograd node ``_EnergyFn(positions, cells, *parameters)`` whose
+backward is itself differentiable (``_EnergyGradFn``): ``autograd.grad(E, positions, create_graph=True)``
+followed by ``loss.backward()`` fills ``parameter.grad`` -- first-order term from ``pet_backward_train``,
+force-loss term from the forward-over-reverse pass ``pet_backward_train2`` -- so torch optimizers and DDP work
+on the mirror unchanged. (``metatrain_amd.pet.trainer.TrainStep`` is the faster, fully native step.)
+
+Not built (raise loudly): normalization != RMSNorm, activation != SwiGLU, transformer_type != PreLN,
+featurizer_type != feedforward, the "grid" adaptive-cutoff method, system conditioning, more than one
+property per block, last-layer-feature outputs (the two extra dicts are returned empty), double backward
+through the three staged inference nodes, and stress (strain) terms in a training loss.
 """
 from math import prod
 from typing import Dict, List, Optional, Tuple
@@ -88,6 +95,8 @@ class _Ctx:
         self.slot = torch.arange(graph.n_edges, device=self.ctr.device) - csr["rowptr"].long()[self.ctr]
         self.fwd: Optional[rt.HipForward] = None
         self.atomic: Optional[torch.Tensor] = None
+        self.positions: Optional[torch.Tensor] = None  # the caller's tensors (training node inputs)
+        self.cells: Optional[torch.Tensor] = None
 
     def to_csr(self, nef: torch.Tensor) -> torch.Tensor:
         return nef[self.ctr, self.slot].contiguous()
@@ -101,8 +110,68 @@ class _Ctx:
 
 def _no_double_backward(*grads):
     if any(g is not None and g.requires_grad for g in grads):
-        raise PetHipError("double backward (training with conservative forces) is not built into "
-                          "libpet_hip yet: call autograd.grad without create_graph")
+        raise PetHipError("double backward through the staged inference nodes is not built: make the model "
+                          "parameters require grad so that predict() uses the fused training node")
+
+
+# ---------------------------------------------------------------------------------------------
+# fused training nodes: E(positions, cells, theta) with a differentiable backward
+# ---------------------------------------------------------------------------------------------
+class _EnergyGradFn(torch.autograd.Function):
+    """(g_atomic, positions, cells, *theta) -> (dL/dR, dL/dcell, *dL/dtheta) for L = <g_atomic, E_atomic>.
+    Its own backward is the second-order pass: grads w.r.t. g_atomic (the JVP of the atomic energies) and
+    w.r.t. theta for incoming dL/d(dL/dR); second derivatives w.r.t. positions / cells are not computed."""
+
+    @staticmethod
+    def forward(ctx, hctx, keys, g_atomic, positions, cells, *params):
+        fw, model = hctx.train_fwd, hctx.model
+        ga = g_atomic.detach().reshape(-1).float().contiguous()
+        want_theta = any(ctx.needs_input_grad[5:])
+        g = hctx.graph
+        if want_theta:
+            model.zero_grad()
+            gpos, gcell = fw.backward_train(ga, want_cell_grad=True)
+            grads = model.grads()
+            gtheta = tuple(grads[k].to(p.dtype) for k, p in zip(keys, params))
+        else:
+            gpos, gcell = fw.backward(ga, want_cell_grad=True)
+            gtheta = tuple(torch.zeros_like(p) for p in params)
+        ctx.hctx, ctx.keys, ctx.ga = hctx, keys, ga
+        ctx.param_dtypes = [p.dtype for p in params]
+        return (gpos.to(positions.dtype), gcell.to(cells.dtype)) + gtheta
+
+    @staticmethod
+    def backward(ctx, u_pos, u_cell, *u_theta):
+        if any(u is not None and bool((u != 0).any()) for u in u_theta):
+            raise PetHipError("differentiating through parameter gradients is not built into libpet_hip")
+        h = ctx.hctx
+        model, fw = h.model, h.train_fwd
+        n_in = 5 + len(ctx.keys)
+        if u_cell is not None and bool((u_cell != 0).any()):
+            raise PetHipError("a training loss on dE/dcell (stress) needs the strain second-order terms: not built")
+        if u_pos is None:
+            return (None,) * n_in
+        model.zero_grad()
+        tan = fw.backward_train2(ctx.ga, None, u_pos.detach().float().contiguous(), want_tangent=True)
+        grads = model.grads()
+        gtheta = tuple(grads[k].to(dt) for k, dt in zip(ctx.keys, ctx.param_dtypes))
+        return (None, None, tan[:, None], None, None) + gtheta
+
+
+class _EnergyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hctx, keys, positions, cells, *params):
+        hctx.train_fwd = rt.HipForward(hctx.model, hctx.graph, train=True)
+        atomic = hctx.train_fwd.forward()
+        ctx.hctx, ctx.keys = hctx, keys
+        ctx.save_for_backward(positions, cells, *params)
+        return atomic[:, None].to(positions.dtype)
+
+    @staticmethod
+    def backward(ctx, g_atomic):
+        positions, cells, *params = ctx.saved_tensors
+        out = _EnergyGradFn.apply(ctx.hctx, ctx.keys, g_atomic, positions, cells, *params)
+        return (None, None) + tuple(out)
 
 
 class _PreprocessFn(torch.autograd.Function):
@@ -279,6 +348,13 @@ class PETBackend(torch.nn.Module):
             self._hip[key], self._hip_version[key] = model, version
         return self._hip[key]
 
+    def _training_params(self, target: str, block: str):
+        """State-dict keys and tensors of the parameters the packed model of (target, block) was loaded with."""
+        model = self._hip[(target, block)]
+        named = dict(self.named_parameters())
+        keys = [k for k in model._ckeys if k in named]
+        return tuple(keys), [named[k] for k in keys]
+
     def _any_model(self) -> rt.HipModel:
         """preprocess() needs hypers + the species table only; any target's packed model will do."""
         for target in self.node_heads:
@@ -298,6 +374,7 @@ class PETBackend(torch.nn.Module):
         graph = rt.HipGraph(model, positions, cells, centers, neighbors, cell_shifts, species, system_indices)
         batch = graph.export_batch()
         hctx = _Ctx(graph, model)
+        hctx.positions, hctx.cells = positions, cells
         if positions.requires_grad or cells.requires_grad:
             ev, ed, cf = _PreprocessFn.apply(positions, cells, hctx, batch["edge_vectors"],
                                              batch["edge_distances"], batch["cutoff_factors"])
@@ -346,6 +423,13 @@ class PETBackend(torch.nn.Module):
             if len(blocks) != 1:
                 raise PetHipError("only single-block targets are built into libpet_hip for now")
             model = self._hip_model(name, blocks[0])
+            if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                # training: one fused node over (positions, cells, parameters of this target)
+                keys, params = self._training_params(name, blocks[0])
+                h2 = _Ctx(h.graph, model)
+                pred = _EnergyFn.apply(h2, keys, h.positions, h.cells, *params)
+                out[name] = [pred.to(node_features_list[0].dtype)]
+                continue
             if model is not h.model:
                 # another target than the one the features were computed with: re-run the fused
                 # forward with that target's heads (the backbone weights are identical)

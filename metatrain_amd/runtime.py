@@ -303,7 +303,8 @@ class HipForward:
             return gpos, gcell
         return gpos
 
-    def backward_train(self, grad_atomic: torch.Tensor, want_position_grad: bool = False):
+    def backward_train(self, grad_atomic: torch.Tensor, want_position_grad: bool = False,
+                       want_cell_grad: bool = False):
         """loss.backward() for dL/d(atomic prediction) = ``grad_atomic``: accumulates dL/dtheta into
         the model's gradient slots (``HipModel.grad``); optionally also returns dL/dR."""
         if not self.train:
@@ -311,10 +312,13 @@ class HipForward:
         g = self.graph
         _require_cuda(grad_atomic)
         ga = grad_atomic.to(torch.float32).contiguous()
-        gpos = (torch.empty((g.n_nodes, 3), dtype=torch.float32, device=self.workspace.device)
-                if want_position_grad else None)
+        dev = self.workspace.device
+        gpos = torch.empty((g.n_nodes, 3), dtype=torch.float32, device=dev) if want_position_grad or want_cell_grad else None
+        gcell = torch.empty((g.n_systems, 3, 3), dtype=torch.float32, device=dev) if want_cell_grad else None
         check(self.lib.pet_backward_train(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes,
-                                          _ptr(ga), _ptr(gpos), None, _stream()))
+                                          _ptr(ga), _ptr(gpos), _ptr(gcell), _stream()))
+        if want_cell_grad:
+            return gpos, gcell
         return gpos
 
     def backward_train2(self, lambda_atomic: torch.Tensor, nu_atomic: Optional[torch.Tensor], u: torch.Tensor,

@@ -128,3 +128,58 @@ def test_parameter_update_is_picked_up(dev):
     with torch.no_grad():
         be.node_last_layers["energy"][0]["energy"].bias.add_(1.0)
     assert abs(run() - (e0 + 40.0)) < 1e-3
+
+
+def test_training_through_the_mirror_fills_parameter_grads(golden_dir):
+    """pet/trainer.py:417-462 through the torch mirror: autograd.grad(E, R, create_graph=True), a loss on
+    energies and dE/dR, loss.backward() -> parameter.grad; against torch's double backward through the fp64
+    oracle with the same weights."""
+    from metatrain_amd.pet import PETBackend, default_hypers
+
+    dev = torch.device("cuda:0")
+    g = dict(np.load(os.path.join(golden_dir, "batch_two_systems.npz")))
+    t = lambda k: torch.tensor(g[k])  # noqa: E731
+    hypers = default_hypers()
+    types = [1, 6, 7, 8]
+    params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    be = PETBackend(hypers, types)
+    be.add_output("energy", {"energy": [1]})
+    be.load_state_dict(params, strict=True)
+    be = be.to(dev)
+    pos = t("in_positions").float().to(dev).requires_grad_(True)
+    cells, sysidx = t("in_cells").float().to(dev), t("in_system_indices").to(dev)
+    n = pos.shape[0]
+    gen = torch.Generator().manual_seed(5)
+    w_e = torch.rand(n, generator=gen) - 0.5
+    tgt_g = 0.3 * torch.randn(n, 3, generator=gen)
+    batch = be.preprocess(pos, t("in_centers").to(dev), t("in_neighbors").to(dev), t("in_species").to(dev), cells,
+                          t("in_cell_shifts").to(dev), sysidx, 1.0)
+    nf, ef = be.calculate_features(batch)
+    pred, _, _ = be.predict(nf, ef, batch, cells, sysidx, ["energy"])
+    atomic = pred["energy"][0][:, 0]
+    (grad,) = torch.autograd.grad(atomic.sum(), pos, create_graph=True)
+    loss = (w_e.to(dev) * atomic).sum() + ((grad - tgt_g.to(dev)) ** 2).sum()
+    loss.backward()
+
+    p64 = {k: (v if k == "species_to_species_index" else v.double().clone().requires_grad_(True))
+           for k, v in params.items()}
+    rpos = t("in_positions").double().clone().requires_grad_(True)
+    a_ref = opet.pet_atomic_energies(p64, hypers, rpos, t("in_cells").double(), t("in_centers"), t("in_neighbors"),
+                                     t("in_cell_shifts"), t("in_species"), t("in_system_indices").long(), "energy")[:, 0]
+    (g_ref,) = torch.autograd.grad(a_ref.sum(), rpos, create_graph=True)
+    l_ref = (w_e.double() * a_ref).sum() + ((g_ref - tgt_g.double()) ** 2).sum()
+    keys = [k for k in p64 if k != "species_to_species_index"]
+    ref = dict(zip(keys, torch.autograd.grad(l_ref, [p64[k] for k in keys], allow_unused=True)))
+    assert abs(float(loss) - float(l_ref)) / abs(float(l_ref)) < 1e-5
+    named = dict(be.named_parameters())
+    worst = 0.0
+    for k in keys:
+        r = ref[k]
+        got = named[k].grad
+        if r is None:
+            continue
+        assert got is not None, k
+        scale = float(r.abs().max())
+        if scale > 1e-12:
+            worst = max(worst, float((got.cpu().double() - r).abs().max()) / scale)
+    assert worst < 1e-5, worst
