@@ -783,6 +783,19 @@ __global__ void k_cell_grad(const float4* __restrict__ dv, const int* __restrict
 // ---------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------
+// The adjoint kernels are templated on TRAIN (export of the operands the weight-gradient GEMMs need):
+// launch KERN<..., true> when the training hooks are active, KERN<..., false> otherwise.
+#define PET_TA(...) __VA_ARGS__
+#define PET_LAUNCH_TR(tr, KERN, TARGS, GRID, LDS, STREAM, ...)                         \
+    do {                                                                               \
+        if (tr) KERN<TARGS, true><<<GRID, NTHREADS, LDS, STREAM>>>(__VA_ARGS__);       \
+        else KERN<TARGS, false><<<GRID, NTHREADS, LDS, STREAM>>>(__VA_ARGS__);         \
+    } while (0)
+#define PET_LAUNCH_TR1(tr, KERN, GRID, LDS, STREAM, ...)                               \
+    do {                                                                               \
+        if (tr) KERN<true><<<GRID, NTHREADS, LDS, STREAM>>>(__VA_ARGS__);              \
+        else KERN<false><<<GRID, NTHREADS, LDS, STREAM>>>(__VA_ARGS__);                \
+    } while (0)
 template <int NT>
 static void launch_attn_bwd(const float* QKV, const float* dAO, const Graph& g, float* dQKV, float* dbias_h,
                             float scale, hipStream_t st) {
@@ -811,15 +824,9 @@ int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* 
     const GnnBufs& last = w.gnn.back();
     if (E > 0) {
         ProfScope ps("head_edge_bwd", st, fE * 2.0 * (D * DH + DH * DH + DH));
-        { if (tr) k_head_bwd<128, true, true><<<gE, NTHREADS, lds2 + 256, st>>>(last.Mout, m.eh0.fwd, m.eh0.b, m.eh2.fwd, m.eh2.b,
-                                                               m.eh0.bwd, m.eh2.bwd, m.ell_w, gA, g.ctr, g.fc,
-                                                               w.ypred_e, w.dfc, w.dM, E, tr ? w.hs1 : nullptr,
-                                                               tr ? w.hda2 : nullptr, tr ? w.hda1 : nullptr,
-                                                               tr ? w.hs2y : nullptr); else k_head_bwd<128, true, false><<<gE, NTHREADS, lds2 + 256, st>>>(last.Mout, m.eh0.fwd, m.eh0.b, m.eh2.fwd, m.eh2.b,
-                                                               m.eh0.bwd, m.eh2.bwd, m.ell_w, gA, g.ctr, g.fc,
-                                                               w.ypred_e, w.dfc, w.dM, E, tr ? w.hs1 : nullptr,
-                                                               tr ? w.hda2 : nullptr, tr ? w.hda1 : nullptr,
-                                                               tr ? w.hs2y : nullptr); }
+        PET_LAUNCH_TR(tr, k_head_bwd, PET_TA(128, true), gE, lds2 + 256, st, last.Mout, m.eh0.fwd, m.eh0.b, m.eh2.fwd,
+            m.eh2.b, m.eh0.bwd, m.eh2.bwd, m.ell_w, gA, g.ctr, g.fc, w.ypred_e, w.dfc, w.dM, E, tr ? w.hs1 : nullptr,
+            tr ? w.hda2 : nullptr, tr ? w.hda1 : nullptr, tr ? w.hs2y : nullptr);
         if (tr) tr->heads(true, last.Mout, D, E, gA);
     }
     {
@@ -829,13 +836,10 @@ int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* 
         ss.fork(st);
         {
             ProfScope ps("head_node_bwd", s2, fN * 2.0 * (DN * DH + DH * DH + DH));
-            { if (tr) k_head_bwd<256, false, true><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + 256, s2>>>(
-                last.Hout, m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nh0.bwd, m.nh2.bwd, m.nll_w, gA, nullptr,
-                nullptr, nullptr, nullptr, w.dH, N, tr ? w.hs1 : nullptr, tr ? w.hda2 : nullptr,
-                tr ? w.hda1 : nullptr, tr ? w.hs2y : nullptr); else k_head_bwd<256, false, false><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + 256, s2>>>(
-                last.Hout, m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nh0.bwd, m.nh2.bwd, m.nll_w, gA, nullptr,
-                nullptr, nullptr, nullptr, w.dH, N, tr ? w.hs1 : nullptr, tr ? w.hda2 : nullptr,
-                tr ? w.hda1 : nullptr, tr ? w.hs2y : nullptr); }
+            PET_LAUNCH_TR(tr, k_head_bwd, PET_TA(256, false), gN, (BM * LD256 + BM * LD128) * 4 + 256, s2,  last.Hout,
+                m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nh0.bwd, m.nh2.bwd, m.nll_w, gA, nullptr, nullptr, nullptr,
+                nullptr, w.dH, N, tr ? w.hs1 : nullptr, tr ? w.hda2 : nullptr, tr ? w.hda1 : nullptr,
+                tr ? w.hs2y : nullptr);
             if (tr) tr->heads(false, last.Hout, DN, N, gA);
         }
         ss.join(st);
@@ -878,9 +882,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         const GnnBufs& B = w.gnn[gi];
         {
             ProfScope ps("comb_bwd", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D));
-            { if (tr) k_comb_bwd<true><<<gE, NTHREADS, lds2, st>>>(w.dM, B.XF, g.rev, B.LNS, B.CA, G.ln_g, G.comb2.bwd, G.comb0.bwd,
-                                                   w.dcat, E, tr ? w.dCA : nullptr); else k_comb_bwd<false><<<gE, NTHREADS, lds2, st>>>(w.dM, B.XF, g.rev, B.LNS, B.CA, G.ln_g, G.comb2.bwd, G.comb0.bwd,
-                                                   w.dcat, E, tr ? w.dCA : nullptr); }
+            PET_LAUNCH_TR1(tr, k_comb_bwd, gE, lds2, st, w.dM, B.XF, g.rev, B.LNS, B.CA, G.ln_g, G.comb2.bwd,
+                G.comb0.bwd, w.dcat, E, tr ? w.dCA : nullptr);
             if (tr) {
                 const std::string gs = std::to_string(gi);
                 tr->linear("combination_mlps." + gs + ".2", D, 2 * D, {w.dM, nullptr, 0, D},
@@ -902,9 +905,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             // dX (edge rows) = grad wrt the edge MLP output; dH = grad wrt Hn
             {
                 ProfScope ps("node_bwd", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
-                { if (tr) k_swiglu_bwd<256, DNF, true><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
-                    dH, Ab.H1, Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N, tr ? w.dVGn : nullptr); else k_swiglu_bwd<256, DNF, false><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
-                    dH, Ab.H1, Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N, tr ? w.dVGn : nullptr); }
+                PET_LAUNCH_TR(tr, k_swiglu_bwd, PET_TA(256, DNF), gN, (BM * LD256 + BM * LD128) * 4, s2,  dH, Ab.H1,
+                    Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N, tr ? w.dVGn : nullptr);
                 k_expand_bwd<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(dH_alt, A.ce.bwd, w.dOC, N);
                 if (tr) {
                     tr->linear(lp + ".center_mlp.w_out", DN, DNF, {dH, nullptr, 0, DN},
@@ -919,9 +921,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             {
                 ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
                 if (trr) trr_emlp_bwd(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_in, A.mlp_out, dX_alt, E, st, tr ? w.dVG : nullptr);
-                else { if (tr) k_swiglu_bwd<128, DFF, true><<<gE, NTHREADS, lds2, st>>>(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_out.bwd,
-                                                                        A.mlp_in.bwd, dX_alt, E, tr ? w.dVG : nullptr); else k_swiglu_bwd<128, DFF, false><<<gE, NTHREADS, lds2, st>>>(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_out.bwd,
-                                                                        A.mlp_in.bwd, dX_alt, E, tr ? w.dVG : nullptr); }
+                else PET_LAUNCH_TR(tr, k_swiglu_bwd, PET_TA(128, DFF), gE, lds2, st, dX, Ab.X1, Ab.VG, A.g_mlp,
+                    A.mlp_out.bwd, A.mlp_in.bwd, dX_alt, E, tr ? w.dVG : nullptr);
                 if (tr) {
                     tr->linear(lp + ".mlp.w_out", D, DFF, {dX, nullptr, 0, D}, {Ab.VG, 2 * DFF, DFF, nullptr, nullptr},
                                2, E);
@@ -971,15 +972,11 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         {
             ProfScope ps("compress_bwd", st, fE * 2.0 * (D * D * (gi == 0 ? 3 : 4) + 4 * D));
             if (gi == 0)
-                { if (tr) k_compress_bwd<true, true><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct, nullptr, w.dgeo,
-                                                                 nullptr, E, tr ? w.da0 : nullptr); else k_compress_bwd<true, false><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct, nullptr, w.dgeo,
-                                                                 nullptr, E, tr ? w.da0 : nullptr); }
+                PET_LAUNCH_TR(tr, k_compress_bwd, PET_TA(true), gE, lds1, st, dX, B.a0, G.compress2.bwd, G.wct,
+                    nullptr, w.dgeo, nullptr, E, tr ? w.da0 : nullptr);
             else
-                { if (tr) k_compress_bwd<false, true><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct,
-                                                                  G.compress0_msg.bwd, w.dgeo, w.dM, E,
-                                                                  tr ? w.da0 : nullptr); else k_compress_bwd<false, false><<<gE, NTHREADS, lds1, st>>>(dX, B.a0, G.compress2.bwd, G.wct,
-                                                                  G.compress0_msg.bwd, w.dgeo, w.dM, E,
-                                                                  tr ? w.da0 : nullptr); }
+                PET_LAUNCH_TR(tr, k_compress_bwd, PET_TA(false), gE, lds1, st, dX, B.a0, G.compress2.bwd, G.wct,
+                    G.compress0_msg.bwd, w.dgeo, w.dM, E, tr ? w.da0 : nullptr);
             if (tr) {
                 const std::string pre = "gnn_layers." + std::to_string(gi);
                 tr->linear(pre + ".compress.2", D, D, {dX, nullptr, 0, D}, {B.a0, D, 0, nullptr, nullptr}, 3, E);
