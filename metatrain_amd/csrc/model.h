@@ -140,6 +140,12 @@ bool attn_fwd_preload(int nt, const float* QKV, const Graph& g, float* AO, float
 bool attn_bwd_preload(int nt, const float* QKV, const float* dAO, const Graph& g, float* dQKV, float* dbias_h,
                       float scale, hipStream_t st);
 
+// second-order attention on MFMA (training pass); false if the tile count is not served
+bool attn_jvp_mfma(int nt, const float* QKV, const float* QKVd, const Graph& g, const float* Tkb, float* AOd,
+                   float scale, hipStream_t st);
+bool attn_rev_mfma(int nt, const float* QKV, const float* QKVd, const Graph& g, const float* Tkb, const float* LO,
+                   const float* NO, float* lQKV, float* nQKV, float scale, hipStream_t st);
+
 // abi.hip: a second HIP stream for the node-feature chain, which is independent of the edge chain
 // between output_linear and the next attention layer (PET_HIP_SIDE=0 runs everything on one stream)
 struct SideStream {

@@ -270,6 +270,344 @@ __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QK
 // host launchers: true if this variant handled the launch (NT <= 4)
 
 // ---------------------------------------------------------------------------------------------
+// Second-order attention for the training pass (so.hip), same tile conventions as k_attn_*_p.
+//   tangent:  o' = sum_j [ P_ij v'_j + P_ij (s'_ij - a_i) v_j ],  s' = scale (q'.k + q.k') + b',  a_i = <P_i, s'_i>
+//   joint reverse for (lambda_o, nu_o) -> (lambda, nu) of q, k, v:
+//     lambda_P = lambda_o.v,  nu_P = nu_o.v + lambda_o.v',  delta = <P, lambda_P>,  c = <P, lambda_P s'>,  e = <P, nu_P>
+//     lambda_s = P (lambda_P - delta),   nu_s = P (nu_P - e) + P [ (lambda_P - delta)(s' - a) - (c - a delta) ]
+//     lambda_q = scale lambda_s K          nu_q = scale (nu_s K + lambda_s K')
+//     lambda_k = scale lambda_s^T Q        nu_k = scale (nu_s^T Q + lambda_s^T Q')
+//     lambda_v = P^T lambda_o              nu_v = P^T nu_o + P'^T lambda_o,   P' = P (s' - a)
+// (identities checked against torch.autograd in fp64)
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_attn_jvp_p(const float* __restrict__ QKV, const float* __restrict__ QKVd,
+                                                     const int* __restrict__ rowptr, const float* __restrict__ fc,
+                                                     const float* __restrict__ Tkb, float* __restrict__ AOd,
+                                                     int64_t E, int N, float scale, int only_nt) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int atom = gw / NHEAD, head = gw % NHEAD;
+    if (atom >= N) return;
+    const int start = rowptr[atom];
+    const int T = rowptr[atom + 1] - start + 1;
+    const int nt = (T + 15) >> 4;
+    if (only_nt && nt != only_nt) return;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head;
+    float4 kf[NT], kdf[NT], qf[NT], qdf[NT];
+    float vs[NT][4], vds[NT][4], bias[NT][4], biasd[NT][4];
+    int64_t qrow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        if (t < nt) {
+            const int64_t rc = tok_row(16 * t + c16, T, E, atom, start);
+            qrow[t] = rc;
+            kf[t] = *reinterpret_cast<const float4*>(QKV + rc * (3 * D) + ko + 4 * g4);
+            kdf[t] = *reinterpret_cast<const float4*>(QKVd + rc * (3 * D) + ko + 4 * g4);
+            const float4 q = *reinterpret_cast<const float4*>(QKV + rc * (3 * D) + qo + 4 * g4);
+            const float4 qd = *reinterpret_cast<const float4*>(QKVd + rc * (3 * D) + qo + 4 * g4);
+            qf[t] = make_float4(q.x * scale, q.y * scale, q.z * scale, q.w * scale);
+            qdf[t] = make_float4(qd.x * scale, qd.y * scale, qd.z * scale, qd.w * scale);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = 16 * t + 4 * g4 + r;
+                const int64_t rr = tok_row(key, T, E, atom, start);
+                vs[t][r] = QKV[rr * (3 * D) + vo + c16];
+                vds[t][r] = QKVd[rr * (3 * D) + vo + c16];
+                bias[t][r] = key_bias(key, T, fc, start);
+                biasd[t][r] = (key >= 1 && key < T) ? Tkb[start + key - 1] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < NT; qt++) {
+        if (qt < nt) {
+            f32x4 s[NT], sd[NT];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++) {
+                if (kt < nt) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+                    a = MFMA16(kf[kt].x, qf[qt].x, a); a = MFMA16(kf[kt].y, qf[qt].y, a);
+                    a = MFMA16(kf[kt].z, qf[qt].z, a); a = MFMA16(kf[kt].w, qf[qt].w, a);
+                    b = MFMA16(kf[kt].x, qdf[qt].x, b); b = MFMA16(kf[kt].y, qdf[qt].y, b);
+                    b = MFMA16(kf[kt].z, qdf[qt].z, b); b = MFMA16(kf[kt].w, qdf[qt].w, b);
+                    b = MFMA16(kdf[kt].x, qf[qt].x, b); b = MFMA16(kdf[kt].y, qf[qt].y, b);
+                    b = MFMA16(kdf[kt].z, qf[qt].z, b); b = MFMA16(kdf[kt].w, qf[qt].w, b);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        a[r] += bias[kt][r];
+                        b[r] += biasd[kt][r];
+                        mx = fmaxf(mx, a[r]);
+                    }
+                    s[kt] = a;
+                    sd[kt] = b;
+                }
+            }
+            mx = g4_max(mx);
+            float sum = 0.f, an = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float p = expf(s[kt][r] - mx);
+                        s[kt][r] = p;
+                        sum += p;
+                        an += p * sd[kt][r];
+                    }
+            sum = g4_sum(sum);
+            an = g4_sum(an);
+            const float inv = 1.0f / sum, av = an * inv;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float p = s[kt][r];               // un-normalised; 1/sum applied at the end
+                        o = MFMA16(vds[kt][r], p, o);
+                        o = MFMA16(vs[kt][r], p * (sd[kt][r] - av), o);
+                    }
+            if (16 * qt + c16 < T)
+                *reinterpret_cast<float4*>(AOd + qrow[qt] * D + qo + 4 * g4) =
+                    make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_attn_rev_p(const float* __restrict__ QKV, const float* __restrict__ QKVd,
+                                                     const int* __restrict__ rowptr, const float* __restrict__ fc,
+                                                     const float* __restrict__ Tkb, const float* __restrict__ LO,
+                                                     const float* __restrict__ NO, float* __restrict__ lQKV,
+                                                     float* __restrict__ nQKV, int64_t E, int N, float scale,
+                                                     int only_nt) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int atom = gw / NHEAD, head = gw % NHEAD;
+    if (atom >= N) return;
+    const int start = rowptr[atom];
+    const int T = rowptr[atom + 1] - start + 1;
+    const int nt = (T + 15) >> 4;
+    if (only_nt && nt != only_nt) return;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head;
+    // fragments: token on the 16-lane axis (rows 16t + c16), 4 features per lane group
+    float4 kf[NT], vf[NT], qf[NT], lof[NT], kdf[NT], vdf[NT], qdf[NT], nof[NT];
+    // scalars: token on the (group, register) axis (rows 16t + 4 g4 + r), feature c16
+    float ks[NT][4], qs[NT][4], los[NT][4], kds[NT][4], qds[NT][4], nos[NT][4];
+    float bias_r[NT][4], biasd_r[NT][4], bias_c[NT], biasd_c[NT];
+    int64_t rowc[NT];
+    __shared__ __attribute__((aligned(16))) float stat_all[4][5][NT * 16];
+    float (*stat)[NT * 16] = stat_all[threadIdx.x >> 6];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        if (t < nt) {
+            const int tc = 16 * t + c16;
+            const int64_t rc = tok_row(tc, T, E, atom, start);
+            rowc[t] = rc;
+            const bool real = tc < T;
+            kf[t] = *reinterpret_cast<const float4*>(QKV + rc * (3 * D) + ko + 4 * g4);
+            vf[t] = *reinterpret_cast<const float4*>(QKV + rc * (3 * D) + vo + 4 * g4);
+            kdf[t] = *reinterpret_cast<const float4*>(QKVd + rc * (3 * D) + ko + 4 * g4);
+            vdf[t] = *reinterpret_cast<const float4*>(QKVd + rc * (3 * D) + vo + 4 * g4);
+            const float4 q = *reinterpret_cast<const float4*>(QKV + rc * (3 * D) + qo + 4 * g4);
+            const float4 qd = *reinterpret_cast<const float4*>(QKVd + rc * (3 * D) + qo + 4 * g4);
+            qf[t] = make_float4(q.x * scale, q.y * scale, q.z * scale, q.w * scale);
+            qdf[t] = make_float4(qd.x * scale, qd.y * scale, qd.z * scale, qd.w * scale);
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            lof[t] = real ? *reinterpret_cast<const float4*>(LO + rc * D + qo + 4 * g4) : z4;
+            nof[t] = real ? *reinterpret_cast<const float4*>(NO + rc * D + qo + 4 * g4) : z4;
+            bias_c[t] = key_bias(tc, T, fc, start);
+            biasd_c[t] = (tc >= 1 && real) ? Tkb[start + tc - 1] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int tr = 16 * t + 4 * g4 + r;
+                const int64_t rr = tok_row(tr, T, E, atom, start);
+                const bool rl = tr < T;
+                ks[t][r] = QKV[rr * (3 * D) + ko + c16];
+                qs[t][r] = QKV[rr * (3 * D) + qo + c16];
+                kds[t][r] = QKVd[rr * (3 * D) + ko + c16];
+                qds[t][r] = QKVd[rr * (3 * D) + qo + c16];
+                los[t][r] = rl ? LO[rr * D + qo + c16] : 0.f;
+                nos[t][r] = rl ? NO[rr * D + qo + c16] : 0.f;
+                bias_r[t][r] = key_bias(tr, T, fc, start);
+                biasd_r[t][r] = (tr >= 1 && rl) ? Tkb[start + tr - 1] : 0.f;
+            }
+        }
+    }
+    // ---- pass A: per query tile, transposed tiles (keys x queries): lambda_q, nu_q and the row statistics
+#pragma unroll
+    for (int qt = 0; qt < NT; qt++) {
+        if (qt < nt) {
+            f32x4 s[NT], lp[NT], sd[NT], np[NT];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++) {
+                if (kt < nt) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f},
+                          d = {0.f, 0.f, 0.f, 0.f};
+                    a = MFMA16(kf[kt].x, qf[qt].x, a); a = MFMA16(kf[kt].y, qf[qt].y, a);
+                    a = MFMA16(kf[kt].z, qf[qt].z, a); a = MFMA16(kf[kt].w, qf[qt].w, a);
+                    b = MFMA16(vf[kt].x, lof[qt].x, b); b = MFMA16(vf[kt].y, lof[qt].y, b);
+                    b = MFMA16(vf[kt].z, lof[qt].z, b); b = MFMA16(vf[kt].w, lof[qt].w, b);
+                    c = MFMA16(kf[kt].x, qdf[qt].x, c); c = MFMA16(kf[kt].y, qdf[qt].y, c);
+                    c = MFMA16(kf[kt].z, qdf[qt].z, c); c = MFMA16(kf[kt].w, qdf[qt].w, c);
+                    c = MFMA16(kdf[kt].x, qf[qt].x, c); c = MFMA16(kdf[kt].y, qf[qt].y, c);
+                    c = MFMA16(kdf[kt].z, qf[qt].z, c); c = MFMA16(kdf[kt].w, qf[qt].w, c);
+                    d = MFMA16(vf[kt].x, nof[qt].x, d); d = MFMA16(vf[kt].y, nof[qt].y, d);
+                    d = MFMA16(vf[kt].z, nof[qt].z, d); d = MFMA16(vf[kt].w, nof[qt].w, d);
+                    d = MFMA16(vdf[kt].x, lof[qt].x, d); d = MFMA16(vdf[kt].y, lof[qt].y, d);
+                    d = MFMA16(vdf[kt].z, lof[qt].z, d); d = MFMA16(vdf[kt].w, lof[qt].w, d);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        a[r] += bias_r[kt][r];
+                        c[r] += biasd_r[kt][r];
+                        mx = fmaxf(mx, a[r]);
+                    }
+                    s[kt] = a; lp[kt] = b; sd[kt] = c; np[kt] = d;
+                }
+            }
+            mx = g4_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const float p = expf(s[kt][r] - mx); s[kt][r] = p; sum += p; }
+            sum = g4_sum(sum);
+            const float inv = 1.0f / sum;
+            float de = 0.f, av = 0.f, cv = 0.f, ev = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float p = s[kt][r] * inv;
+                        s[kt][r] = p;
+                        de += p * lp[kt][r];
+                        av += p * sd[kt][r];
+                        cv += p * lp[kt][r] * sd[kt][r];
+                        ev += p * np[kt][r];
+                    }
+            de = g4_sum(de); av = g4_sum(av); cv = g4_sum(cv); ev = g4_sum(ev);
+            if (g4 == 0) {
+                stat[0][16 * qt + c16] = mx + logf(sum);
+                stat[1][16 * qt + c16] = de;
+                stat[2][16 * qt + c16] = av;
+                stat[3][16 * qt + c16] = cv - av * de;
+                stat[4][16 * qt + c16] = ev;
+            }
+            f32x4 lq = {0.f, 0.f, 0.f, 0.f}, nq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float p = s[kt][r];
+                        const float ls = p * (lp[kt][r] - de);
+                        const float ns = p * (np[kt][r] - ev) + p * ((lp[kt][r] - de) * (sd[kt][r] - av) - (cv - av * de));
+                        lq = MFMA16(ks[kt][r], ls, lq);
+                        nq = MFMA16(ks[kt][r], ns, nq);
+                        nq = MFMA16(kds[kt][r], ls, nq);
+                    }
+            if (16 * qt + c16 < T) {
+                *reinterpret_cast<float4*>(lQKV + rowc[qt] * (3 * D) + qo + 4 * g4) =
+                    make_float4(lq[0] * scale, lq[1] * scale, lq[2] * scale, lq[3] * scale);
+                *reinterpret_cast<float4*>(nQKV + rowc[qt] * (3 * D) + qo + 4 * g4) =
+                    make_float4(nq[0] * scale, nq[1] * scale, nq[2] * scale, nq[3] * scale);
+            }
+        }
+    }
+    // ---- pass B: per key tile, plain tiles (queries x keys): lambda / nu of k and v
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+        if (kt < nt) {
+            f32x4 lk = {0.f, 0.f, 0.f, 0.f}, nk = {0.f, 0.f, 0.f, 0.f}, lv = {0.f, 0.f, 0.f, 0.f},
+                  nv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qt = 0; qt < NT; qt++) {
+                if (qt < nt) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f},
+                          d = {0.f, 0.f, 0.f, 0.f};
+                    a = MFMA16(qf[qt].x, kf[kt].x, a); a = MFMA16(qf[qt].y, kf[kt].y, a);
+                    a = MFMA16(qf[qt].z, kf[kt].z, a); a = MFMA16(qf[qt].w, kf[kt].w, a);
+                    b = MFMA16(lof[qt].x, vf[kt].x, b); b = MFMA16(lof[qt].y, vf[kt].y, b);
+                    b = MFMA16(lof[qt].z, vf[kt].z, b); b = MFMA16(lof[qt].w, vf[kt].w, b);
+                    c = MFMA16(qdf[qt].x, kf[kt].x, c); c = MFMA16(qdf[qt].y, kf[kt].y, c);
+                    c = MFMA16(qdf[qt].z, kf[kt].z, c); c = MFMA16(qdf[qt].w, kf[kt].w, c);
+                    c = MFMA16(qf[qt].x, kdf[kt].x, c); c = MFMA16(qf[qt].y, kdf[kt].y, c);
+                    c = MFMA16(qf[qt].z, kdf[kt].z, c); c = MFMA16(qf[qt].w, kdf[kt].w, c);
+                    d = MFMA16(nof[qt].x, vf[kt].x, d); d = MFMA16(nof[qt].y, vf[kt].y, d);
+                    d = MFMA16(nof[qt].z, vf[kt].z, d); d = MFMA16(nof[qt].w, vf[kt].w, d);
+                    d = MFMA16(lof[qt].x, vdf[kt].x, d); d = MFMA16(lof[qt].y, vdf[kt].y, d);
+                    d = MFMA16(lof[qt].z, vdf[kt].z, d); d = MFMA16(lof[qt].w, vdf[kt].w, d);
+                    const float4 s0 = *reinterpret_cast<const float4*>(&stat[0][16 * qt + 4 * g4]);
+                    const float4 s1 = *reinterpret_cast<const float4*>(&stat[1][16 * qt + 4 * g4]);
+                    const float4 s2 = *reinterpret_cast<const float4*>(&stat[2][16 * qt + 4 * g4]);
+                    const float4 s3 = *reinterpret_cast<const float4*>(&stat[3][16 * qt + 4 * g4]);
+                    const float4 s4 = *reinterpret_cast<const float4*>(&stat[4][16 * qt + 4 * g4]);
+                    const float lse[4] = {s0.x, s0.y, s0.z, s0.w}, der[4] = {s1.x, s1.y, s1.z, s1.w},
+                                avr[4] = {s2.x, s2.y, s2.z, s2.w}, ccr[4] = {s3.x, s3.y, s3.z, s3.w},
+                                evr[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int qq = 16 * qt + 4 * g4 + r;
+                        float p = expf(a[r] + bias_c[kt] - lse[r]);
+                        if (qq >= T) p = 0.f;
+                        const float sdv = c[r] + biasd_c[kt];
+                        const float ls = p * (b[r] - der[r]);
+                        const float pd = p * (sdv - avr[r]);
+                        const float ns = p * (d[r] - evr[r]) + p * ((b[r] - der[r]) * (sdv - avr[r]) - ccr[r]);
+                        lk = MFMA16(qs[qt][r], ls, lk);
+                        nk = MFMA16(qs[qt][r], ns, nk);
+                        nk = MFMA16(qds[qt][r], ls, nk);
+                        lv = MFMA16(los[qt][r], p, lv);
+                        nv = MFMA16(nos[qt][r], p, nv);
+                        nv = MFMA16(los[qt][r], pd, nv);
+                    }
+                }
+            }
+            if (16 * kt + c16 < T) {
+                float* lrow = lQKV + rowc[kt] * (3 * D);
+                float* nrow = nQKV + rowc[kt] * (3 * D);
+                *reinterpret_cast<float4*>(lrow + ko + 4 * g4) = make_float4(lk[0] * scale, lk[1] * scale, lk[2] * scale, lk[3] * scale);
+                *reinterpret_cast<float4*>(nrow + ko + 4 * g4) = make_float4(nk[0] * scale, nk[1] * scale, nk[2] * scale, nk[3] * scale);
+                *reinterpret_cast<float4*>(lrow + vo + 4 * g4) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+                *reinterpret_cast<float4*>(nrow + vo + 4 * g4) = make_float4(nv[0], nv[1], nv[2], nv[3]);
+            }
+        }
+    }
+}
+
+bool attn_jvp_mfma(int nt, const float* QKV, const float* QKVd, const Graph& g, const float* Tkb, float* AOd,
+                   float scale, hipStream_t st) {
+    if (nt > 4) return false;
+    const int grid = cdiv((int64_t)g.n_nodes * NHEAD, 4);
+    const int N = (int)g.n_nodes;
+    k_attn_jvp_p<1><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, AOd, g.n_edges, N, scale, nt > 1 ? 1 : 0);
+    if (nt >= 2) k_attn_jvp_p<2><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, AOd, g.n_edges, N, scale, 2);
+    if (nt >= 3) k_attn_jvp_p<3><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, AOd, g.n_edges, N, scale, 3);
+    if (nt >= 4) k_attn_jvp_p<4><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, AOd, g.n_edges, N, scale, 4);
+    return true;
+}
+bool attn_rev_mfma(int nt, const float* QKV, const float* QKVd, const Graph& g, const float* Tkb, const float* LO,
+                   const float* NO, float* lQKV, float* nQKV, float scale, hipStream_t st) {
+    if (nt > 3) return false;  // NT = 4 exceeds the register file; the VALU kernel in so.hip serves those batches
+    const int grid = cdiv((int64_t)g.n_nodes * NHEAD, 4);
+    const int N = (int)g.n_nodes;
+    k_attn_rev_p<1><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, LO, NO, lQKV, nQKV, g.n_edges, N, scale,
+                                          nt > 1 ? 1 : 0);
+    if (nt >= 2)
+        k_attn_rev_p<2><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, LO, NO, lQKV, nQKV, g.n_edges, N, scale, 2);
+    if (nt >= 3)
+        k_attn_rev_p<3><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, LO, NO, lQKV, nQKV, g.n_edges, N, scale, 3);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // LDS-staged variants: ONE workgroup (8 waves = 8 heads) per atom. The atom's token rows (QKV, and dO in
 // the adjoint) are fetched once as full coalesced rows into LDS, every wave builds its fragments from LDS,
 // results overwrite the head's own Q / K / V slots and leave as full rows again. Same arithmetic, in the

@@ -794,6 +794,7 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
                 "the second-order (force-loss) pass with the adaptive cutoff is not built yet");
     const float scale = 1.0f / (sqrtf((float)HD) * m.h.attention_temperature);
     const int T_max = g.max_nbr + 1;
+    const int nt_attn = (T_max + 15) / 16;
     const size_t lds_jvp = (size_t)T_max * (4 * HD + 2) * sizeof(float);
     const size_t lds_rev = (size_t)T_max * (8 * HD + 2 + 6) * sizeof(float);
     allow_big_lds(k_attn_rev, lds_rev);
@@ -823,9 +824,12 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
             mm_fwd(c, A.cc, Sa.TH, Sa.TX + E * D, N, false);                 // centre tokens
             rms_jvp(c, D, Ab.X, Sa.TX, Sa.Txh, R);
             mm_fwd(c, A.qkv, Sa.Txh, Sa.TQKV, R, false, A.g_attn);
-            ProfScope psj("so_attn_jvp", st, 0.0);
-            k_attn_jvp<<<(int)N * NHEAD, 64, lds_jvp, st>>>(Ab.QKV, Sa.TQKV, g.rowptr, g.fc, s.Tkb, Sa.TAO, E, (int)N,
-                                                           scale);
+            {
+                ProfScope psj("so_attn_jvp", st, 0.0);
+                if (!attn_jvp_mfma(nt_attn, Ab.QKV, Sa.TQKV, g, s.Tkb, Sa.TAO, scale, st))
+                    k_attn_jvp<<<(int)N * NHEAD, 64, lds_jvp, st>>>(Ab.QKV, Sa.TQKV, g.rowptr, g.fc, s.Tkb, Sa.TAO, E,
+                                                                   (int)N, scale);
+            }
             float* TO = s.tmp[0];                                            // [R,D] output_linear tangent
             mm_fwd(c, A.out, Sa.TAO, TO, R, false);
             add3(c, Sa.TX, TO, nullptr, Sa.TX1, E * D);                      // edge residual
@@ -938,9 +942,12 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
             mm_bwd(c, A.out, s.NX, t1, R);
             PET_HIP_CHECK(hipMemsetAsync(s.LX + E * D, 0, N * D * sizeof(float), st));  // centre tokens: norm path only
             PET_HIP_CHECK(hipMemsetAsync(s.NX + E * D, 0, N * D * sizeof(float), st));
-            ProfScope psr("so_attn_rev", st, 0.0);
-            k_attn_rev<<<(int)N * NHEAD, 64, lds_rev, st>>>(Ab.QKV, Sa.TQKV, g.rowptr, g.fc, s.Tkb, t0, t1, t2, t3, E,
-                                                           (int)N, scale);  // (l_QKV, n_QKV) [R,3D]
+            {   // (l_QKV, n_QKV) [R,3D]
+                ProfScope psr("so_attn_rev", st, 0.0);
+                if (!attn_rev_mfma(nt_attn, Ab.QKV, Sa.TQKV, g, s.Tkb, t0, t1, t2, t3, scale, st))
+                    k_attn_rev<<<(int)N * NHEAD, 64, lds_rev, st>>>(Ab.QKV, Sa.TQKV, g.rowptr, g.fc, s.Tkb, t0, t1, t2,
+                                                                   t3, E, (int)N, scale);
+            }
             tr.linear_after_norm(lp + ".attention.input_linear", A.qkv.w, 3 * D, D, {t3, nullptr, 0, 3 * D},
                                  {Ab.X, D, 0, nullptr, nullptr}, 1, R, lp + ".norm_attention.weight", A.g_attn);
             tr.linear_after_norm(lp + ".attention.input_linear", A.qkv.w, 3 * D, D, {t2, nullptr, 0, 3 * D},
