@@ -78,71 +78,74 @@ static int salloc(SoapModel& m, void** p, size_t bytes) {
 // ---------------------------------------------------------------------------------------------
 // per-pair building blocks
 // ---------------------------------------------------------------------------------------------
-// Orthonormal real spherical harmonics of a unit vector (x, y, z) and, optionally, the gradient of
-// their polynomial extension; Y[l*l + l + m]. shn[l*(L+1)+m] carries sqrt(2) for m > 0.
-__device__ __forceinline__ void sh_eval(float x, float y, float z, int L, const float* __restrict__ shn, float* Y,
-                                        float* Gx, float* Gy, float* Gz) {
-    float c[MAXL + 1], s[MAXL + 1];
-    c[0] = 1.f; s[0] = 0.f;
-    for (int m = 1; m <= L; m++) {
-        c[m] = x * c[m - 1] - y * s[m - 1];
-        s[m] = x * s[m - 1] + y * c[m - 1];
-    }
+// Orthonormal real spherical harmonics of a unit vector (x, y, z), Y[l*l + l + m], by the standard recurrences
+//   c_m + i s_m = (x + i y)^m,   Q_m^m = (-1)^m (2m-1)!!,   Q_{m+1}^m = (2m+1) z Q_m^m,
+//   Q_l^m = ((2l-1) z Q_{l-1}^m - (l+m-1) Q_{l-2}^m) / (l-m),     Y_l^{+-m} = F_lm Q_l^m {c_m | s_m}
+// (shn[l*(L+1)+m] = F_lm, with sqrt(2) folded in for m > 0), and the gradient of their polynomial extension
+// by differentiating the recurrences.
+// One m-chain (all l >= m for one pair): the per-pair work is split over (pair, m) threads.
+__device__ __forceinline__ void sh_chain(float x, float y, float z, int m, int L, const float* __restrict__ shn,
+                                         float* Y, float* Gx, float* Gy, float* Gz, float ir) {
+    float cm = 1.f, sm = 0.f, cp = 1.f, sp_ = 0.f;  // (c_m, s_m) and (c_{m-1}, s_{m-1})
     float qmm = 1.f;
-    for (int m = 0; m <= L; m++) {
-        if (m > 0) qmm *= -(2 * m - 1);
-        float q2 = 0.f, dq2 = 0.f;   // Q_{l-2}^m and derivative
-        float q1 = qmm, dq1 = 0.f;   // Q_{l-1}^m (starts as Q_m^m)
-        for (int l = m; l <= L; l++) {
-            float q, dq;
-            if (l == m) { q = qmm; dq = 0.f; }
-            else if (l == m + 1) { q = (2 * m + 1) * z * q1; dq = (2 * m + 1) * q1; }
-            else {
-                const float inv = 1.0f / (l - m);
-                q = ((2 * l - 1) * z * q1 - (l + m - 1) * q2) * inv;
-                dq = ((2 * l - 1) * (q1 + z * dq1) - (l + m - 1) * dq2) * inv;
-            }
-            const float f = shn[l * (L + 1) + m];
-            const int ip = l * l + l + m, im = l * l + l - m;
-            if (m == 0) {
-                Y[ip] = f * q;
-                if (Gx) { Gx[ip] = 0.f; Gy[ip] = 0.f; Gz[ip] = f * dq; }
-            } else {
-                Y[ip] = f * q * c[m];
-                Y[im] = f * q * s[m];
-                if (Gx) {
-                    const float fm = f * q * m;
-                    Gx[ip] = fm * c[m - 1];  Gy[ip] = -fm * s[m - 1]; Gz[ip] = f * dq * c[m];
-                    Gx[im] = fm * s[m - 1];  Gy[im] = fm * c[m - 1];  Gz[im] = f * dq * s[m];
-                }
-            }
-            if (l > m) { q2 = q1; dq2 = dq1; }
-            q1 = q; dq1 = dq;
-            if (l == m) { q2 = 0.f; dq2 = 0.f; }
+    for (int k = 1; k <= m; k++) {
+        cp = cm; sp_ = sm;
+        cm = x * cp - y * sp_;
+        sm = x * sp_ + y * cp;
+        qmm *= -(2 * k - 1);
+    }
+    float q2 = 0.f, dq2 = 0.f, q1 = qmm, dq1 = 0.f;
+    for (int l = m; l <= L; l++) {
+        float q, dq;
+        if (l == m) { q = qmm; dq = 0.f; }
+        else if (l == m + 1) { q = (2 * m + 1) * z * q1; dq = (2 * m + 1) * q1; }
+        else {
+            const float inv = 1.0f / (l - m);
+            q = ((2 * l - 1) * z * q1 - (l + m - 1) * q2) * inv;
+            dq = ((2 * l - 1) * (q1 + z * dq1) - (l + m - 1) * dq2) * inv;
         }
+        const float f = shn[l * (L + 1) + m];
+        const int ip = l * l + l + m, im = l * l + l - m;
+        // value and gradient of the polynomial extension, then the chain through u = v / r: (I - u u^T) / r
+        float yv[2], gx[2], gy[2], gz[2];
+        if (m == 0) {
+            yv[0] = f * q; gx[0] = 0.f; gy[0] = 0.f; gz[0] = f * dq;
+        } else {
+            const float fm = f * q * m;
+            yv[0] = f * q * cm; gx[0] = fm * cp;  gy[0] = -fm * sp_; gz[0] = f * dq * cm;
+            yv[1] = f * q * sm; gx[1] = fm * sp_; gy[1] = fm * cp;   gz[1] = f * dq * sm;
+        }
+        for (int k = 0; k < (m == 0 ? 1 : 2); k++) {
+            const int idx = k == 0 ? ip : im;
+            Y[idx] = yv[k];
+            if (Gx) {
+                const float dot = x * gx[k] + y * gy[k] + z * gz[k];
+                Gx[idx] = (gx[k] - x * dot) * ir; Gy[idx] = (gy[k] - y * dot) * ir; Gz[idx] = (gz[k] - z * dot) * ir;
+            }
+        }
+        if (l > m) { q2 = q1; dq2 = dq1; }
+        q1 = q; dq1 = dq;
+        if (l == m) { q2 = 0.f; dq2 = 0.f; }
     }
 }
 
-// Hermite spline: R[f] * fc and (optionally) d(R fc)/dr for all F radial functions
-__device__ __forceinline__ void radial_eval(const SoapDims& d, const float* __restrict__ table, float r, float fc,
-                                            float dfc, float* R, float* dR) {
+// Hermite spline of radial function f at distance r: R fc and (optionally) d(R fc)/dr
+__device__ __forceinline__ void radial_one(const SoapDims& d, const float* __restrict__ table, int f, float r, float fc,
+                                           float dfc, float* R, float* dR) {
     float t = r * d.inv_h;
     int k = (int)t;
     if (k > d.n_grid - 2) k = d.n_grid - 2;
     const float s = t - k, h = 1.0f / d.inv_h;
     const float s2 = s * s, om = 1.f - s;
     const float h00 = (1.f + 2.f * s) * om * om, h10 = s * om * om, h01 = s2 * (3.f - 2.f * s), h11 = s2 * (s - 1.f);
-    const float g00 = 6.f * s2 - 6.f * s, g10 = 3.f * s2 - 4.f * s + 1.f, g01 = -g00, g11 = 3.f * s2 - 2.f * s;
-    const float2* t0 = reinterpret_cast<const float2*>(table) + (size_t)k * d.F;
-    const float2* t1 = t0 + d.F;
-    for (int f = 0; f < d.F; f++) {
-        const float2 a = t0[f], b = t1[f];
-        const float v = h00 * a.x + h10 * h * a.y + h01 * b.x + h11 * h * b.y;
-        R[f] = v * fc;
-        if (dR) {
-            const float dv = (g00 * a.x + g01 * b.x) * d.inv_h + g10 * a.y + g11 * b.y;
-            dR[f] = dv * fc + v * dfc;
-        }
+    const float2 a = reinterpret_cast<const float2*>(table)[(size_t)k * d.F + f];
+    const float2 b = reinterpret_cast<const float2*>(table)[(size_t)(k + 1) * d.F + f];
+    const float v = h00 * a.x + h10 * h * a.y + h01 * b.x + h11 * h * b.y;
+    *R = v * fc;
+    if (dR) {
+        const float g00 = 6.f * s2 - 6.f * s, g10 = 3.f * s2 - 4.f * s + 1.f, g11 = 3.f * s2 - 2.f * s;
+        const float dv = (g00 * a.x - g00 * b.x) * d.inv_h + g10 * a.y + g11 * b.y;
+        *dR = dv * fc + v * dfc;
     }
 }
 
@@ -167,7 +170,8 @@ __global__ __launch_bounds__(256) void k_soap_expand(SoapDims d, const float4* _
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ys = smem;                     // [PC][NLM]
     float* Rs = Ys + PC * d.NLM;          // [PC][F]
-    int* sps = reinterpret_cast<int*>(Rs + PC * d.F);
+    float* us = Rs + PC * d.F;            // [PC][8] unit vector, r, 1/r, fc, dfc
+    int* sps = reinterpret_cast<int*>(us + PC * 8);
     const int i = blockIdx.x, tid = threadIdx.x;
     const int p0 = rowptr[i], p1 = rowptr[i + 1];
     float acc[MAXK];
@@ -185,10 +189,21 @@ __global__ __launch_bounds__(256) void k_soap_expand(SoapDims d, const float4* _
             const float4 g = geo[base + tid];
             const float r = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
             const float ir = r > 0.f ? 1.0f / r : 0.f;
-            sh_eval(g.x * ir, g.y * ir, g.z * ir, d.L, shn, Ys + tid * d.NLM, nullptr, nullptr, nullptr);
-            const float fc = shifted_cosine(r, d.rc, d.width, nullptr);
-            radial_eval(d, table, r, fc, 0.f, Rs + tid * d.F, nullptr);
+            float* u = us + tid * 8;
+            u[0] = g.x * ir; u[1] = g.y * ir; u[2] = g.z * ir; u[3] = r; u[4] = ir;
+            u[5] = shifted_cosine(r, d.rc, d.width, nullptr);
             sps[tid] = sp_nbr[base + tid];
+        }
+        __syncthreads();
+        // per-pair quantities, spread over the workgroup: (pair, m) chains of Y_lm and (pair, f) spline values
+        for (int idx = tid; idx < npc * (d.L + 1); idx += 256) {
+            const int pp = idx / (d.L + 1), mm = idx % (d.L + 1);
+            const float* u = us + pp * 8;
+            sh_chain(u[0], u[1], u[2], mm, d.L, shn, Ys + pp * d.NLM, nullptr, nullptr, nullptr, 0.f);
+        }
+        for (int idx = tid; idx < npc * d.F; idx += 256) {
+            const int pp = idx / d.F, f = idx % d.F;
+            radial_one(d, table, f, us[pp * 8 + 3], us[pp * 8 + 5], 0.f, Rs + pp * d.F + f, nullptr);
         }
         __syncthreads();
 #pragma unroll
@@ -435,6 +450,7 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_mfma(SoapDims d, con
     float* Ds = smem;                 // [64][NOUTP + 4] d a1, zero outside the atom's own set
     float* d2 = Ds + BM * LDD;        // [64][32] d a2
     float* st = d2 + BM * 32;         // [64][4] mean, rstd, m1, m2
+    float* ot = st + BM * 4;          // [64][132] output tile staging: full-row (512 B) reads / writes below
     const WaveId w;
     const int row0 = blockIdx.x * BM;
     const int H = 32, TS = 2 + 2 * H;
@@ -487,18 +503,27 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_mfma(SoapDims d, con
         f32x16 acc[2];
         acc_fill_bias<2>(acc, nullptr, 0, w.lane);
         gemm_acc<NOUTP, 2>(Ds + w.rb * 32 * LDD, LDD, Wpb, NOUTP / 8, 0, 4 * nblk + 2 * w.ch, acc, w.lane);
-        acc_foreach<2>(acc, w.rb, 128 * nblk + 64 * w.ch, w.lane, [&](int r, int k, float v) {
-            const int atom = row0 + r;
-            if (atom < N && k < d.S) {
-                float val = v;
-                if (d.layernorm) {
-                    const float xh = (feats[(size_t)atom * d.S + k] - st[r * 4]) * st[r * 4 + 1];
-                    val = st[r * 4 + 1] * (v - st[r * 4 + 2] - xh * st[r * 4 + 3]);
-                }
-                if (enc) val *= enc[(size_t)sp[atom] * d.S + k];
-                dF[(size_t)atom * d.S + k] = val;
+        __syncthreads();  // the previous block's staging tile has been consumed
+        acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) { ot[r * lds_ld(128) + c] = v; });
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < BM * 32; idx += NTHREADS) {
+            const int r = idx >> 5, c4 = idx & 31, k = 128 * nblk + 4 * c4, atom = row0 + r;
+            if (atom >= N || k >= d.S) continue;
+            float4 v = *reinterpret_cast<const float4*>(ot + r * lds_ld(128) + 4 * c4);
+            if (d.layernorm) {
+                const float4 x = *reinterpret_cast<const float4*>(feats + (size_t)atom * d.S + k);
+                const float mu = st[r * 4], rs_ = st[r * 4 + 1], m1 = st[r * 4 + 2], m2 = st[r * 4 + 3];
+                v.x = rs_ * (v.x - m1 - (x.x - mu) * rs_ * m2);
+                v.y = rs_ * (v.y - m1 - (x.y - mu) * rs_ * m2);
+                v.z = rs_ * (v.z - m1 - (x.z - mu) * rs_ * m2);
+                v.w = rs_ * (v.w - m1 - (x.w - mu) * rs_ * m2);
             }
-        });
+            if (enc) {
+                const float4 e = *reinterpret_cast<const float4*>(enc + (size_t)sp[atom] * d.S + k);
+                v.x *= e.x; v.y *= e.y; v.z *= e.z; v.w *= e.w;
+            }
+            *reinterpret_cast<float4*>(dF + (size_t)atom * d.S + k) = v;
+        }
     }
 }
 
@@ -588,8 +613,8 @@ __global__ __launch_bounds__(256) void k_soap_expand_bwd(SoapDims d, const float
     float* Gz = Gy + PC * d.NLM;
     float* Rs = Gz + PC * d.NLM;             // [PC][F] R fc, d(R fc)/dr
     float* dRs = Rs + PC * d.F;
-    float* us = dRs + PC * d.F;              // [PC][4] unit vector
-    int* sps = reinterpret_cast<int*>(us + PC * 4);
+    float* us = dRs + PC * d.F;              // [PC][8] unit vector, r, 1/r, fc, dfc
+    int* sps = reinterpret_cast<int*>(us + PC * 8);
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < d.NCOEF; k += 256) dCs[k] = dCf[(size_t)i * d.NCOEF + k];
     const int p0 = rowptr[i], p1 = rowptr[i + 1];
@@ -600,23 +625,29 @@ __global__ __launch_bounds__(256) void k_soap_expand_bwd(SoapDims d, const float
             const float4 g = geo[base + tid];
             const float r = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
             const float ir = r > 0.f ? 1.0f / r : 0.f;
-            const float ux = g.x * ir, uy = g.y * ir, uz = g.z * ir;
-            float* Y = Ys + tid * d.NLM; float* gx = Gx + tid * d.NLM; float* gy = Gy + tid * d.NLM; float* gz = Gz + tid * d.NLM;
-            sh_eval(ux, uy, uz, d.L, shn, Y, gx, gy, gz);
-            for (int k = 0; k < d.NLM; k++) {  // chain through u = v / r: (I - u u^T) / r
-                const float dot = ux * gx[k] + uy * gy[k] + uz * gz[k];
-                gx[k] = (gx[k] - ux * dot) * ir; gy[k] = (gy[k] - uy * dot) * ir; gz[k] = (gz[k] - uz * dot) * ir;
-            }
+            float* u = us + tid * 8;
+            u[0] = g.x * ir; u[1] = g.y * ir; u[2] = g.z * ir; u[3] = r; u[4] = ir;
             float dfc;
-            const float fc = shifted_cosine(r, d.rc, d.width, &dfc);
-            radial_eval(d, table, r, fc, dfc, Rs + tid * d.F, dRs + tid * d.F);
-            us[tid * 4] = ux; us[tid * 4 + 1] = uy; us[tid * 4 + 2] = uz;
+            u[5] = shifted_cosine(r, d.rc, d.width, &dfc);
+            u[6] = dfc;
             sps[tid] = sp_nbr[base + tid];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < npc * (d.L + 1); idx += 256) {
+            const int pp = idx / (d.L + 1), mm = idx % (d.L + 1);
+            const float* u = us + pp * 8;
+            sh_chain(u[0], u[1], u[2], mm, d.L, shn, Ys + pp * d.NLM, Gx + pp * d.NLM, Gy + pp * d.NLM, Gz + pp * d.NLM,
+                     u[4]);
+        }
+        for (int idx = tid; idx < npc * d.F; idx += 256) {
+            const int pp = idx / d.F, f = idx % d.F;
+            const float* u = us + pp * 8;
+            radial_one(d, table, f, u[3], u[5], u[6], Rs + pp * d.F + f, dRs + pp * d.F + f);
         }
         __syncthreads();
         for (int pp = wave; pp < npc; pp += 4) {
             const float* w = spw + sps[pp] * d.C;
-            const float ux = us[pp * 4], uy = us[pp * 4 + 1], uz = us[pp * 4 + 2];
+            const float ux = us[pp * 8], uy = us[pp * 8 + 1], uz = us[pp * 8 + 2];
             float ax = 0.f, ay = 0.f, az = 0.f;
             for (int it = lane; it < d.ITEMS; it += 64) {
                 const int code = ilut[it];
@@ -745,9 +776,9 @@ static int soap_finalize(SoapModel& m, hipStream_t st) {
     return PET_OK;
 }
 
-static size_t lds_expand(const SoapDims& d) { return (size_t)PC * (d.NLM + d.F + 1) * 4; }
+static size_t lds_expand(const SoapDims& d) { return (size_t)PC * (d.NLM + d.F + 8 + 1) * 4; }
 static size_t lds_expand_bwd(const SoapDims& d) {
-    return ((size_t)d.NCOEF + (size_t)PC * (4 * d.NLM + 2 * d.F + 4 + 1)) * 4;
+    return ((size_t)d.NCOEF + (size_t)PC * (4 * d.NLM + 2 * d.F + 8 + 1)) * 4;
 }
 static size_t lds_tail(const SoapDims& d) { return ((size_t)d.S + 256 * (d.H + 1) + 8 + 2 * d.H) * 4; }
 
@@ -814,7 +845,7 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
     {
         ProfScope ps("soap_tail_bwd", st, 2.0 * (double)N * d.S * d.H, (double)N * d.S * 8);
         if (m.NT > 0 && g_soap_mfma) {
-            const size_t lds = ((size_t)BM * lds_ld(m.NOUTP) + BM * 32 + BM * 4) * 4;
+            const size_t lds = ((size_t)BM * lds_ld(m.NOUTP) + BM * 32 + BM * 4 + BM * lds_ld(128)) * 4;
             const int grid = cdiv(N, BM);
 #define SOAP_TAIL_BWD(NTV)                                                                                        \
     case NTV:                                                                                                     \
