@@ -103,7 +103,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--boxes", type=int, default=2, help="10k-atom boxes per GPU per step")  # 4: +4 %, 8: see DESIGN
+    ap.add_argument("--boxes", type=int, default=8,
+                    help="10k-atom boxes per GPU per step (1: 710k, 2: 757k, 4: 799k, 8: 816k atom-steps/s, DESIGN.md 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print a per-stage table to stderr")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=INT",

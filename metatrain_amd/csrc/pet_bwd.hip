@@ -741,7 +741,7 @@ __global__ void k_pos_grad_acc(const float4* __restrict__ dv, const int* __restr
 // dE/dcell[s][a][k] = sum_{edges of system s} S_a dv_k (structures.py:212-219); one block per system
 __global__ void k_cell_grad(const float4* __restrict__ dv, const int* __restrict__ shift, const int* __restrict__ ctr,
                             const int* __restrict__ sys, const int* __restrict__ rowptr, float* __restrict__ gcell,
-                            int N, int64_t E) {
+                            int N, int64_t E, int accumulate) {
     // systems are contiguous atom ranges; find this system's atom range by scanning sys[] boundaries
     const int s = blockIdx.x;
     __shared__ float red[9][256];
@@ -777,7 +777,8 @@ __global__ void k_cell_grad(const float4* __restrict__ dv, const int* __restrict
             for (int k = 0; k < 9; k++) red[k][threadIdx.x] += red[k][threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x < 9) gcell[9 * s + threadIdx.x] = red[threadIdx.x][0];
+    if (threadIdx.x < 9)
+        gcell[9 * s + threadIdx.x] = (accumulate ? gcell[9 * s + threadIdx.x] : 0.f) + red[threadIdx.x][0];
 }
 
 // ---------------------------------------------------------------------------------
@@ -1010,16 +1011,18 @@ int backward_geometry(const Model& m, const Graph& g, Workspace& w, const float*
                                              m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function,
                                              g.adaptive ? g.pc : nullptr, g.adaptive ? g.ad_gc : nullptr);
     k_pos_grad<<<cdiv(N, 16), 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.rowptr, g.rev, gpos, (int)N);
+    if (gcell)
+        k_cell_grad<<<(int)g.n_systems, 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.shift, g.ctr, g.sys,
+                                                      g.rowptr, gcell, (int)N, E, 0);
     if (g.adaptive) {
-        PET_REQUIRE(gcell == nullptr, PET_ERR_UNSUPPORTED, "dE/dcell with the adaptive cutoff is not built yet");
         k_adapt_gr<<<cdiv(N, 16), 256, 0, st>>>(g.ad_gc, g.rowptr, g.rev, g.ad_gr, (int)N);
         k_adapt_dv<<<cdiv(N, 16), 256, 0, st>>>(g.rowptr0, g.perm0, g.vin, g.ad_gr, g.r_newton, g.inv_dn, g.ad_dv,
                                                 (int)N, m.h.cutoff_width_adaptive);
         k_pos_grad_acc<<<cdiv(N, 16), 256, 0, st>>>(g.ad_dv, g.rowptr0, g.rev0, gpos, (int)N);
+        if (gcell)  // the adaptive term reaches the cell through the shift vectors of ALL input edges
+            k_cell_grad<<<(int)g.n_systems, 256, 0, st>>>(g.ad_dv, g.shift0, g.ctr, g.sys, g.rowptr0, gcell, (int)N,
+                                                          g.n_edges_in, 1);
     }
-    if (gcell)
-        k_cell_grad<<<(int)g.n_systems, 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.shift, g.ctr, g.sys,
-                                                      g.rowptr, gcell, (int)N, E);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }

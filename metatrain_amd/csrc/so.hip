@@ -122,10 +122,36 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
 // ---------------------------------------------------------------------------------------------
 // geometry tangent along dR = u:  v' = u[nbr] - u[ctr];  (v, dist)' , fc' , (log fc)'
 // ---------------------------------------------------------------------------------------------
+// adaptive cutoff: tangent of the per-atom cutoff through the implicit-function step,
+//   r_i' = -(1 / dn_root_i) sum_{q in all-edge row i} (d bump / d d)(d_q; r_i) d_q',   d_q' = v_q . (u_j - u_i) / |v_q|
+__global__ void k_adapt_rdot(const float* __restrict__ u, const int* __restrict__ rowptr0,
+                             const int* __restrict__ perm0, const int* __restrict__ nbr0,
+                             const float4* __restrict__ vin, const float* __restrict__ r_newton,
+                             const float* __restrict__ inv_dn, float* __restrict__ rdot, int N, float w) {
+    const int gid = blockIdx.x * (blockDim.x / 16) + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    const int a = gid < N ? gid : N - 1;
+    const float r = r_newton[a];
+    float s = 0.f;
+    for (int q = rowptr0[a] + l; q < rowptr0[a + 1]; q += 16) {
+        const float4 v = vin[perm0[q]];
+        const int j = nbr0[q];
+        const float nrm = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+        const float dd = nrm > 0.f
+            ? (v.x * (u[3 * j] - u[3 * a]) + v.y * (u[3 * j + 1] - u[3 * a + 1]) + v.z * (u[3 * j + 2] - u[3 * a + 2])) / nrm
+            : 0.f;
+        s += cutoff_deriv_dev(v.w, r, w, PET_CUTOFF_BUMP) * dd;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (l == 0 && gid < N) rdot[gid] = -inv_dn[gid] * s;
+}
+
 __global__ void k_geom_jvp(const float* __restrict__ u, const int* __restrict__ ctr, const int* __restrict__ nbr,
                            const float4* __restrict__ geo, const float* __restrict__ d0, const float* __restrict__ fc,
                            float4* __restrict__ Tgeo, float* __restrict__ Tfc, float* __restrict__ Tkb, int64_t E,
-                           float cutoff, float width, int fn) {
+                           float cutoff, float width, int fn, const float* __restrict__ pc,
+                           const float* __restrict__ rdot) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= E) return;
     const int i = ctr[p], j = nbr[p];
@@ -135,7 +161,9 @@ __global__ void k_geom_jvp(const float* __restrict__ u, const int* __restrict__ 
     const float nrm = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
     Tgeo[p] = make_float4(vx, vy, vz, vd / g.w);
     const float dd0 = nrm > 0.f ? vd / nrm : 0.f;
-    const float dfc = cutoff_deriv_dev(d0[p], cutoff, width, fn) * dd0;
+    // fc = f(d - c): with the adaptive pair cutoff c = (r_i + r_j) / 2 the tangent is f_d (d' - c')
+    const float cd = pc ? 0.5f * (rdot[i] + rdot[j]) : 0.f;
+    const float dfc = cutoff_deriv_dev(d0[p], pc ? pc[p] : cutoff, width, fn) * (dd0 - cd);
     Tfc[p] = dfc;
     const float f = fc[p];
     Tkb[p] = f >= 1e-15f ? dfc / f : 0.f;
@@ -790,8 +818,7 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
     if (N == 0) return PET_OK;
     PET_REQUIRE(E > 0, PET_ERR_UNSUPPORTED, "training on a batch without any edge is not supported");
     PET_REQUIRE(g.max_nbr + 1 <= 128, PET_ERR_UNSUPPORTED, "more than 127 neighbours per atom is not supported yet");
-    PET_REQUIRE(!g.adaptive, PET_ERR_UNSUPPORTED,
-                "the second-order (force-loss) pass with the adaptive cutoff is not built yet");
+
     const float scale = 1.0f / (sqrtf((float)HD) * m.h.attention_temperature);
     const int T_max = g.max_nbr + 1;
     const int nt_attn = (T_max + 15) / 16;
@@ -803,8 +830,12 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
     const int nG = m.h.num_gnn_layers, nA_ = m.h.num_attention_layers;
 
     // =========================== tangent sweep ===========================
+    if (g.adaptive)  // g.ad_gr doubles as the tangent of the atomic cutoffs
+        k_adapt_rdot<<<cdiv(N, 16), 256, 0, st>>>(u, g.rowptr0, g.perm0, g.nbr0, g.vin, g.r_newton, g.inv_dn, g.ad_gr,
+                                                  (int)N, m.h.cutoff_width_adaptive);
     k_geom_jvp<<<grid1(E), 256, 0, st>>>(u, g.ctr, g.nbr, g.geo, g.d0, g.fc, reinterpret_cast<float4*>(s.Tgeo), s.Tfc,
-                                        s.Tkb, E, m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function);
+                                        s.Tkb, E, m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function,
+                                        g.adaptive ? g.pc : nullptr, g.adaptive ? g.ad_gr : nullptr);
     PET_HIP_CHECK(hipMemsetAsync(s.TH0, 0, N * DN * sizeof(float), st));  // embeddings do not move with R
     PET_HIP_CHECK(hipMemsetAsync(s.TM0, 0, E * D * sizeof(float), st));
     for (int gi = 0; gi < nG; gi++) {

@@ -27,7 +27,7 @@ __global__ void k_pos_grad(const float4* __restrict__ dv, const int* __restrict_
                            float* __restrict__ gpos, int N);
 __global__ void k_cell_grad(const float4* __restrict__ dv, const int* __restrict__ shift, const int* __restrict__ ctr,
                             const int* __restrict__ sys, const int* __restrict__ rowptr, float* __restrict__ gcell,
-                            int N, int64_t E);
+                            int N, int64_t E, int accumulate);
 
 // abi.hip
 __global__ void k_pack(const float* __restrict__ W, int64_t s_n, int64_t s_k, int n_out, int k_in,
@@ -873,7 +873,7 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
     k_pos_grad<<<cdiv(N, 16), 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.rowptr, g.rev, gpos, N);
     if (gcell)
         k_cell_grad<<<(int)g.n_systems, 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.shift, g.ctr, g.sys,
-                                                      g.rowptr, gcell, N, g.n_edges);
+                                                      g.rowptr, gcell, N, g.n_edges, 0);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }

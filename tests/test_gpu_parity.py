@@ -269,3 +269,46 @@ def test_adaptive_cutoff_matches_reference(rt, adaptive_model, dev, golden_dir, 
     assert relmax(grad.cpu().numpy(), g["grad_f64"]) < 2e-5  # the reference's own fp32 path: see below
     ref32 = relmax(g["grad_f32"], g["grad_f64"])
     assert relmax(grad.cpu().numpy(), g["grad_f64"]) < max(TOL, 3 * ref32)
+
+
+def test_adaptive_cutoff_cell_gradient_and_second_order(rt, adaptive_model, dev, golden_dir):
+    """Adaptive cutoffs: dE/dcell (the implicit-function term reaches the cell through the shifts of ALL
+    input edges) and the force-loss parameter gradients (tangent of the cutoffs in the second-order pass)
+    against autograd through the fp64 oracle."""
+    hypers = adaptive_model.hypers
+    g = _load(golden_dir, "pet_adaptive_two_systems.npz")
+    t = lambda k: torch.tensor(g[k])  # noqa: E731
+    graph = _graph_from_golden(rt, adaptive_model, g, dev)
+    n = graph.n_nodes
+    fw = rt.HipForward(adaptive_model, graph, train=True)
+    atomic = fw.forward()
+    ones = torch.ones(n, device=dev)
+    grad, gcell = fw.backward(ones, want_cell_grad=True)
+    gen = torch.Generator().manual_seed(2)
+    u = torch.randn(n, 3, generator=gen)
+    adaptive_model.zero_grad()
+    tan = fw.backward_train2(ones, None, u.to(dev), want_tangent=True)
+    got = adaptive_model.grads()
+
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
+    p64 = {k: (v if k == "species_to_species_index" else v.double().clone().requires_grad_(True))
+           for k, v in params.items()}
+    pos = t("in_positions").double().clone().requires_grad_(True)
+    cells = t("in_cells").double().clone().requires_grad_(True)
+    a_ref = opet.pet_atomic_energies(p64, hypers, pos, cells, t("in_centers"), t("in_neighbors"), t("in_cell_shifts"),
+                                     t("in_species"), t("in_system_indices").long(), "energy")[:, 0]
+    gp, gc = torch.autograd.grad(a_ref.sum(), [pos, cells], create_graph=True)
+    assert relmax(grad.cpu().numpy(), gp.detach().numpy()) < 2e-5
+    assert relmax(gcell.cpu().numpy(), gc.detach().numpy()) < 2e-5
+    keys = [k for k in p64 if k != "species_to_species_index"]
+    ref = dict(zip(keys, torch.autograd.grad((u.double() * gp).sum(), [p64[k] for k in keys], allow_unused=True)))
+    lhs, rhs = float(tan.double().sum()), float((u.to(dev).double() * grad.double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(rhs))
+    worst = 0.0
+    for k, r in ref.items():
+        if r is None:
+            continue
+        scale = float(r.abs().max())
+        if scale > 1e-12:
+            worst = max(worst, float((got[k].cpu().double() - r).abs().max()) / scale)
+    assert worst < 2e-5, worst
