@@ -135,11 +135,16 @@ __global__ void k_gather_all(const int* __restrict__ perm0, const int* __restric
 // kernels
 // ----------------------------------------------------------------------------------
 __global__ void k_species_index(const int* __restrict__ species, const int* __restrict__ table,
-                                int table_len, int* __restrict__ sp, int n) {
+                                int table_len, int* __restrict__ sp, int n, int* __restrict__ n_unknown) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int z = species[i];
-    sp[i] = (z >= 0 && z < table_len) ? table[z] : -1;
+    int s = (z >= 0 && z < table_len) ? table[z] : -1;
+    if (s < 0) {  // not one of the model's atomic_types: reported by the host, index 0 keeps the kernels in bounds
+        atomicAdd(n_unknown, 1);
+        s = 0;
+    }
+    sp[i] = s;
 }
 
 // structures.py:206-221 and the non-strict mask of :265-267
@@ -422,7 +427,7 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
     PET_HIP_CHECK(hipMemsetAsync(g.scalars, 0, 8 * sizeof(int), st));
     if (n_nodes > 0) {
         k_species_index<<<cdiv(n_nodes, T), T, 0, st>>>(species, m.species_table, m.species_table_len,
-                                                        g.sp, (int)n_nodes);
+                                                        g.sp, (int)n_nodes, g.scalars + 5);
         PET_HIP_CHECK(hipMemcpyAsync(g.sys, sys, n_nodes * sizeof(int), hipMemcpyDeviceToDevice, st));
     }
     g.adaptive = m.h.num_neighbors_adaptive > 0.f;
@@ -457,11 +462,13 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
     k_rowptr<<<cdiv(n_nodes + 1, T), T, 0, st>>>(g.sort_keys_out, (int)e0, g.rowptr, (int)n_nodes,
                                                  g.scalars);
     if (n_nodes > 0) k_max_nbr<<<cdiv(n_nodes, T), T, 0, st>>>(g.rowptr, (int)n_nodes, g.scalars);
-    int host_scalars[2] = {0, 0};
-    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    int host_scalars[6] = {0, 0, 0, 0, 0, 0};
+    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 6 * sizeof(int), hipMemcpyDeviceToHost, st));
     PET_HIP_CHECK(hipStreamSynchronize(st));
     g.n_edges = host_scalars[0];
     g.max_nbr = host_scalars[1];
+    PET_REQUIRE(host_scalars[5] == 0, PET_ERR_ARGUMENT,
+                std::to_string(host_scalars[5]) + " atom(s) have an atomic number that is not in the model's atomic_types");
     if (g.n_edges > 0) {
         int ne = (int)g.n_edges;
         k_csr_fill<<<cdiv(ne, T), T, 0, st>>>(g.perm, g.vin, centers, neighbors, shifts, g.sp, g.ctr,

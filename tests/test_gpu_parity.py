@@ -312,3 +312,13 @@ def test_adaptive_cutoff_cell_gradient_and_second_order(rt, adaptive_model, dev,
         if scale > 1e-12:
             worst = max(worst, float((got[k].cpu().double() - r).abs().max()) / scale)
     assert worst < 2e-5, worst
+
+
+def test_unknown_species_is_an_error_not_an_out_of_bounds_read(rt, model, dev):
+    pos, z, cell = opet.random_box(32, 3)
+    z = z.clone()
+    z[5] = 14  # silicon is not one of the model's atomic_types [1, 6, 7, 8]
+    pairs, _ = rt.neighbor_list(pos.to(dev), cell, [True] * 3, 4.5)
+    with pytest.raises(Exception, match="atomic_types"):
+        rt.HipGraph(model, pos.to(dev), cell[None].to(dev), pairs[:, 0], pairs[:, 1], pairs[:, 2:5], z.to(dev),
+                    torch.zeros(32, dtype=torch.int32, device=dev))
