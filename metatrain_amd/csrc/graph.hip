@@ -112,8 +112,9 @@ __global__ void k_adaptive_keep(const int* __restrict__ centers, const int* __re
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
     const int i = centers[e], j = neighbors[e];
-    const float pc = (r_atom[i] + r_atom[j]) / 2.0f;
-    const int kp = vin[e].w <= pc ? 1 : 0;
+    const bool ok = i >= 0 && i < n_nodes && j >= 0 && j < n_nodes;  // bad indices were counted by k_edge_geometry
+    const float pc = ok ? (r_atom[i] + r_atom[j]) / 2.0f : -1.0f;
+    const int kp = (ok && vin[e].w <= pc) ? 1 : 0;
     keep[e] = kp;
     sort_keys[e] = kp ? i : n_nodes;
     sort_vals[e] = e;
@@ -153,10 +154,18 @@ __global__ void k_edge_geometry(const float* __restrict__ pos, const float* __re
                                 const int* __restrict__ shifts, const int* __restrict__ sys,
                                 float4* __restrict__ vin, int* __restrict__ keep,
                                 int* __restrict__ sort_keys, int* __restrict__ sort_vals,
-                                int n_edges, int n_nodes, float cutoff, int strict) {
+                                int n_edges, int n_nodes, float cutoff, int strict, int* __restrict__ n_bad) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
     int i = centers[e], j = neighbors[e];
+    if (i < 0 || i >= n_nodes || j < 0 || j >= n_nodes) {  // reported by the host; the edge is dropped
+        atomicAdd(n_bad, 1);
+        vin[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        keep[e] = 0;
+        sort_keys[e] = n_nodes;
+        sort_vals[e] = e;
+        return;
+    }
     const float* c = cells + 9 * sys[i];
     float sa = (float)shifts[3 * e], sb = (float)shifts[3 * e + 1], sc = (float)shifts[3 * e + 2];
     float v[3];
@@ -434,7 +443,8 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
     if (e0 > 0) {
         k_edge_geometry<<<cdiv(e0, T), T, 0, st>>>(pos, cells, centers, neighbors, shifts, g.sys, g.vin,
                                                    g.keep, g.sort_keys_in, g.sort_vals_in, (int)e0,
-                                                   (int)n_nodes, m.h.cutoff, g.adaptive ? 2 : m.h.nl_is_strict);
+                                                   (int)n_nodes, m.h.cutoff, g.adaptive ? 2 : m.h.nl_is_strict,
+                                                   g.scalars + 6);
         size_t sb = g.sort_tmp_bytes, cb = g.scan_tmp_bytes;
         if (g.adaptive) {
             // all-edge CSR -> per-atom cutoffs -> pair mask; then the usual kept-edge CSR below
@@ -462,11 +472,13 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
     k_rowptr<<<cdiv(n_nodes + 1, T), T, 0, st>>>(g.sort_keys_out, (int)e0, g.rowptr, (int)n_nodes,
                                                  g.scalars);
     if (n_nodes > 0) k_max_nbr<<<cdiv(n_nodes, T), T, 0, st>>>(g.rowptr, (int)n_nodes, g.scalars);
-    int host_scalars[6] = {0, 0, 0, 0, 0, 0};
-    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 6 * sizeof(int), hipMemcpyDeviceToHost, st));
+    int host_scalars[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     PET_HIP_CHECK(hipStreamSynchronize(st));
     g.n_edges = host_scalars[0];
     g.max_nbr = host_scalars[1];
+    PET_REQUIRE(host_scalars[6] == 0, PET_ERR_ARGUMENT,
+                std::to_string(host_scalars[6]) + " neighbour-list entries index atoms outside [0, n_nodes)");
     PET_REQUIRE(host_scalars[5] == 0, PET_ERR_ARGUMENT,
                 std::to_string(host_scalars[5]) + " atom(s) have an atomic number that is not in the model's atomic_types");
     if (g.n_edges > 0) {
