@@ -42,5 +42,31 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+TORCH_LIB = os.path.join(HERE, "lib", "libpet_hip_torch.so")
+
+
+def build_torch_ops(force: bool = False, verbose: bool = True) -> str:
+    """TorchScript-visible wrapper (csrc/torch_ops.cpp): plain C++ against the torch headers, linked to
+    libpet_hip.so. g++ only -- there is no device code in it."""
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    src = os.path.join(CSRC, "torch_ops.cpp")
+    hdr = os.path.join(os.path.dirname(HERE), "include", "pet_hip.h")
+    if not (force or _newer(src, TORCH_LIB) or _newer(hdr, TORCH_LIB) or _newer(LIB, TORCH_LIB)):
+        return TORCH_LIB
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", src, "-o", TORCH_LIB,
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           *[f"-I{p}" for p in ce.include_paths()], "-I/opt/rocm/include",
+           f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip",
+           f"-L{os.path.dirname(LIB)}", "-lpet_hip", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TORCH_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_torch_ops(force="--force" in sys.argv)

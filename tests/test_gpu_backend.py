@@ -183,3 +183,31 @@ def test_training_through_the_mirror_fills_parameter_grads(golden_dir):
         if scale > 1e-12:
             worst = max(worst, float((got.cpu().double() - r).abs().max()) / scale)
     assert worst < 1e-5, worst
+
+
+def test_torchscript_module_energy_and_forces(golden_dir):
+    """the TorchScript custom class (csrc/torch_ops.cpp), scripted, saved, re-loaded, then run:
+    energies and forces (autograd inside TorchScript) against the golden fp64 reference values."""
+    import io
+
+    from metatrain_amd.pet import default_hypers, script
+
+    dev = torch.device("cuda:0")
+    hypers = default_hypers()
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
+    core = script.make_core(hypers, [1, 6, 7, 8], params, "energy")
+    buf = io.BytesIO()
+    torch.jit.save(torch.jit.script(script.EnergyAndForces(core)), buf)
+    buf.seek(0)
+    mod = torch.jit.load(buf)
+    g = dict(np.load(os.path.join(golden_dir, "pet_default_box64.npz")))
+    t = lambda k: torch.tensor(g[k]).to(dev)  # noqa: E731
+    energies, forces = mod(t("in_positions").float(), t("in_cells").float(), t("in_centers"), t("in_neighbors"),
+                           t("in_cell_shifts"), t("in_species"), t("in_system_indices"))
+    e_ref, g_ref = g["energies_f64"].ravel(), g["grad_f64"]
+    assert abs(float(energies[0]) - e_ref[0]) / abs(e_ref[0]) < TOL
+    assert np.abs(-forces.cpu().numpy() - g_ref).max() / np.abs(g_ref).max() < TOL
+    # second call on the same module (packed weights are cached on the device)
+    e2, _ = mod(t("in_positions").float(), t("in_cells").float(), t("in_centers"), t("in_neighbors"),
+                t("in_cell_shifts"), t("in_species"), t("in_system_indices"))
+    assert torch.equal(e2, energies)

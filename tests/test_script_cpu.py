@@ -1,0 +1,47 @@
+"""CPU tests of the TorchScript surface (csrc/torch_ops.cpp): the op library loads, the custom class scripts,
+pickles through torch.jit.save / load with its weights, and refuses CPU tensors (no compute without a GPU)."""
+import io
+import os
+
+import pytest
+import torch
+
+from metatrain_amd import build
+from metatrain_amd.pet import default_hypers
+from metatrain_amd.synthetic import synthetic_params
+
+
+@pytest.fixture(scope="module")
+def core():
+    if not os.path.exists(build.TORCH_LIB):
+        build.build(verbose=False)
+        build.build_torch_ops(verbose=False)
+    from metatrain_amd.pet import script
+
+    hypers = default_hypers()
+    params = synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
+    return script.make_core(hypers, [1, 6, 7, 8], params, "energy"), len(params)
+
+
+def test_scripts_and_round_trips_through_jit_save(core):
+    from metatrain_amd.pet import script
+
+    c, n_tensors = core
+    assert c.num_tensors() == n_tensors
+    mod = torch.jit.script(script.EnergyAndForces(c))
+    buf = io.BytesIO()
+    torch.jit.save(mod, buf)
+    buf.seek(0)
+    back = torch.jit.load(buf)
+    assert back.pet.core.num_tensors() == n_tensors
+    assert "atomic_energies" in str(back.pet.graph)
+
+
+def test_cpu_tensors_are_refused(core):
+    from metatrain_amd.pet import script
+
+    mod = script.PETScriptModule(core[0])
+    z = torch.zeros
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        mod(z(2, 3), z(1, 3, 3), z(0, dtype=torch.int32), z(0, dtype=torch.int32), z(0, 3, dtype=torch.int32),
+            torch.tensor([1, 6]), z(2, dtype=torch.int32))
