@@ -59,3 +59,37 @@ def test_soap_bpnn_energy_features_and_forces(legacy, mfma_tail):
     np.testing.assert_allclose(g2.cpu().numpy(), grad.cpu().numpy(), atol=2e-6 * float(grad.abs().max()))
     assert float(grad.sum(0).abs().max()) < 1e-4 * float(grad.abs().max())
     rt.config_set("soap_mfma", 1)
+
+
+def test_soap_properties_at_10k_atoms():
+    """Size-independent properties on a 10 000-atom box: sum of forces = 0, permuting the atoms permutes the
+    per-atom energies and gradients, run-to-run bit determinism."""
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.soap_bpnn import SoapBpnnHip
+
+    dev = torch.device("cuda:0")
+    hypers = dict(osoap.DEFAULT_HYPERS)
+    n_per_l = [8, 7, 7, 6, 6, 5, 5]
+    params = osoap.synthetic_params(hypers, 4, n_per_l, 0, torch.float32)
+    model = SoapBpnnHip(hypers, [1, 6, 7, 8])
+    assert model.n_per_l == n_per_l
+    model.load({k: v.to(dev) for k, v in params.items()})
+    n = 10000
+    pos, z, cell = opet.random_box(n, seed=4)
+    sysidx = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def run(p, zz):
+        pairs, _ = rt.neighbor_list(p.to(dev), cell, [True] * 3, 5.0)
+        g = model.graph(p.to(dev), cell[None].to(dev), pairs[:, 0].contiguous(), pairs[:, 1].contiguous(),
+                        pairs[:, 2:5].contiguous(), zz.to(dev), sysidx)
+        a = model.forward(g)
+        return a, model.backward(g, torch.ones_like(a))
+
+    a, f = run(pos, z)
+    assert float(f.sum(0).abs().max()) < 1e-3 * float(f.abs().max())
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(1))
+    a2, f2 = run(pos[perm], z[perm])
+    assert float((a2 - a[perm.to(dev)]).abs().max()) < 2e-5 * float(a.abs().max())
+    assert float((f2 - f[perm.to(dev)]).abs().max()) < 2e-5 * float(f.abs().max())
+    a3, f3 = run(pos, z)
+    assert torch.equal(a, a3) and torch.equal(f, f3)

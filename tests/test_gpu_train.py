@@ -291,3 +291,44 @@ def test_energy_and_force_training_steps_match_torch_adam(golden_dir):
             worst = max(worst, np.abs(delta - delta_ref)[signal].max() / (lr * steps))
         assert np.abs(delta - delta_ref).max() <= 2.01 * lr * steps
     assert worst < 0.02, worst
+
+
+def test_second_order_pass_properties_at_1000_atoms():
+    """Size-independent properties of the training passes on a 1000-atom box (BASELINE configs[2] box size):
+    sum_i E_i' = <u, dE/dR>; the parameter gradient is linear in (nu, u); repeated runs are bit-identical."""
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.pet import default_hypers
+    from metatrain_amd.synthetic import random_box, synthetic_params
+
+    dev = torch.device("cuda:0")
+    hypers = default_hypers()
+    params = synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
+    model = rt.HipModel(hypers, [1, 6, 7, 8])
+    model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    n = 1000
+    pos, z, cell = random_box(n, seed=9)
+    pairs, _ = rt.neighbor_list(pos.to(dev), cell, [True] * 3, hypers["cutoff"])
+    graph = rt.HipGraph(model, pos.to(dev), cell[None].to(dev), pairs[:, 0].contiguous(), pairs[:, 1].contiguous(),
+                        pairs[:, 2:5].contiguous(), z.to(dev), torch.zeros(n, dtype=torch.int32, device=dev))
+    fw = rt.HipForward(model, graph, train=True)
+    fw.forward()
+    ones = torch.ones(n, device=dev)
+    gpos = fw.backward(ones)
+    gen = torch.Generator().manual_seed(0)
+    u1, u2 = torch.randn(n, 3, generator=gen).to(dev), torch.randn(n, 3, generator=gen).to(dev)
+    nu1, nu2 = torch.rand(n, generator=gen).to(dev), torch.rand(n, generator=gen).to(dev)
+
+    def run(nu, u):
+        model.zero_grad()
+        tan = fw.backward_train2(ones, nu, u, want_tangent=True)
+        return tan, model.flat_grad()
+
+    t1, g1 = run(nu1, u1)
+    t2, g2 = run(nu2, u2)
+    t12, g12 = run(nu1 + nu2, u1 + u2)
+    assert abs(float(t1.double().sum()) - float((u1.double() * gpos.double()).sum())) < 1e-4 * float(gpos.abs().sum())
+    scale = float(g12.abs().max())
+    assert float((g1 + g2 - g12).abs().max()) < 2e-5 * scale
+    assert float((t1 + t2 - t12).abs().max()) < 2e-5 * float(t12.abs().max())
+    _, g1b = run(nu1, u1)
+    assert torch.equal(g1, g1b)  # fixed-order reductions everywhere: bit-reproducible
