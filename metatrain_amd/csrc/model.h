@@ -26,6 +26,9 @@ struct Lin {
     const float* b = nullptr;  // raw [n_out]
     float4* fwd = nullptr;
     float4* bwd = nullptr;
+    // the same two operands split three ways into bf16 for the bf16x6 GEMMs (trr.h): [3][n4 * 2] bf16x8
+    void* fwd3 = nullptr;
+    void* bwd3 = nullptr;
     int n_out = 0, k_in = 0;
 };
 
@@ -121,6 +124,7 @@ int backward_geometry_abi(const Model& m, const Graph& g, void* ws, int64_t ws_b
 bool use_trr();
 void set_use_trr(int v);
 void set_side_stream(int v);
+void set_bf16x6(int v);     // pet_trr.hip: 1 = GEMM stages on the bf16 matrix cores with 3-way split operands
 void set_attn_lds(int v);   // pet_attn.hip: 1 = LDS-staged attention (default), 0 = wave-per-head from global
 void set_soap_mfma(int v);  // soap.hip: 1 = MFMA tail (default), 0 = per-atom tail kernels
 void trr_qkv(const float* X, const float* gamma, const Lin& qkv, float* QKV, int64_t R, hipStream_t st);

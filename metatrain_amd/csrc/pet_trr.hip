@@ -176,6 +176,72 @@ __global__ __launch_bounds__(256) void k_emlp_t(const float* __restrict__ X1, co
     }
 }
 
+// bf16x6 operands of a Lin (abi.hip k_pack3): three consecutive arrays of n8 fragments
+static inline W3 w3_fwd(const Lin& L) {
+    const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
+    const bf16x8* b = reinterpret_cast<const bf16x8*>(L.fwd3);
+    W3 w; w.h = b; w.m = b + n8; w.l = b + 2 * n8;
+    return w;
+}
+static inline W3 w3_bwd(const Lin& L) {
+    const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
+    const bf16x8* b = reinterpret_cast<const bf16x8*>(L.bwd3);
+    W3 w; w.h = b; w.m = b + n8; w.l = b + 2 * n8;
+    return w;
+}
+
+// same stage with the GEMMs on the bf16 matrix cores (bf16x6, trr.h)
+__global__ __launch_bounds__(256) void k_emlp_b(const float* __restrict__ X1, const float* __restrict__ gamma, W3 win,
+                                                 const float* __restrict__ bin, W3 wout,
+                                                 const float* __restrict__ bout, float* __restrict__ VG,
+                                                 float* __restrict__ X2, int64_t E) {
+    TRR_PROLOGUE(E);
+    Split3<8> xs;
+    {
+        float4 x[16];
+        load_rowfrag<16>(x, X1, row, D, L.h);
+        rmsnorm_frag<16>(x, gamma, L.h);
+        split_frag<8>(x, xs);
+    }
+    f32x16 out[4];
+    acc_bias<4>(out, bout, 0, L.h);
+#pragma unroll 1
+    for (int hc = 0; hc < DFF / 32; hc++) {
+        f32x16 vg[2];
+        {
+            f32x16 v[1], g[1];
+            acc_bias<1>(v, bin, 32 * hc, L.h);
+            acc_bias<1>(g, bin, DFF + 32 * hc, L.h);
+            vg[0] = v[0];
+            vg[1] = g[0];
+        }
+        gemm_b<8, 2, 2>(win, 8, 0, hc, xs, 0, vg, L.lane, DFF / 32);
+        float4 u[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 vv = acc_q(vg[0], q), gg = acc_q(vg[1], q);
+            if (VG && valid) {
+                *reinterpret_cast<float4*>(VG + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) = vv;
+                *reinterpret_cast<float4*>(VG + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) = gg;
+            }
+            u[q] = make_float4(vv.x * sigm_(gg.x), vv.y * sigm_(gg.y), vv.z * sigm_(gg.z), vv.w * sigm_(gg.w));
+        }
+        Split3<2> us;
+        split_frag<2>(u, us);
+        gemm_b<2, 4, 2>(wout, DFF / 16, 2 * hc, 0, us, 0, out, L.lane);
+    }
+    if (valid) {
+        float4 y[16], xr[16];
+        acc_to_frag<4>(out, y);
+        load_rowfrag<16>(xr, X1, row, D, L.h);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            y[k].x += xr[k].x; y[k].y += xr[k].y; y[k].z += xr[k].z; y[k].w += xr[k].w;
+        }
+        store_rowfrag<16>(y, X2, row, D, L.h);
+    }
+}
+
 // dX1 = dY + RMSNorm^T( Win^T [du sig(g) ; du v sig'(g)] ),  du = Wout^T dY
 template <bool TRAIN>
 __global__ __launch_bounds__(256, 2) void k_emlp_bwd_t(const float* __restrict__ dY, const float* __restrict__ X1,
@@ -249,9 +315,19 @@ void trr_oproj_bwd(const float* dX1, const float* dOC, const Lin& out, float* dA
                    hipStream_t st) {
     k_oproj_bwd_t<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, out.bwd, dAO, E, R);
 }
+// pet_config_set("bf16x6", 1): edge MLP GEMMs on the bf16 matrix cores (3-way split operands). Off by default:
+// as accurate as the fp32 MFMA path (tools/ubench/bf16x3.hip: 3.7e-7 vs 4.5e-7 against fp64) and 1.85x faster as
+// a plain GEMM, but in this fused stage the split fragments cost 96 VGPRs, occupancy drops to one wave per SIMD
+// and the exposed weight-load latency at each small GEMM outweighs the shorter MFMA time (4.3 vs 3.2 ms / step).
+static int g_bf16x6 = 0;
+void set_bf16x6(int v) { g_bf16x6 = v ? 1 : 0; }
+
 void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wout, float* VG, float* X2,
               int64_t E, hipStream_t st) {
-    k_emlp_t<<<grid_rows(E), 256, 0, st>>>(X1, gamma, win.fwd, win.b, wout.fwd, wout.b, VG, X2, E);
+    if (g_bf16x6 && win.fwd3 && wout.fwd3)
+        k_emlp_b<<<grid_rows(E), 256, 0, st>>>(X1, gamma, w3_fwd(win), win.b, w3_fwd(wout), wout.b, VG, X2, E);
+    else
+        k_emlp_t<<<grid_rows(E), 256, 0, st>>>(X1, gamma, win.fwd, win.b, wout.fwd, wout.b, VG, X2, E);
 }
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
                   const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg) {

@@ -124,6 +124,88 @@ __device__ __forceinline__ void gemm_t(const float4* __restrict__ Wp, int kg_tot
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix cores ("bf16x6"): every fp32 operand is split three ways,
+//   x = h + m + l   (8 + 8 + 8 mantissa bits, each piece a bf16, exact),
+// and the product keeps the six terms h.h + h.m + m.h + h.l + l.h + m.m (the dropped ones are below
+// 2^-24 relative). v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32, so six of
+// them per K = 16 cost 192 cycles against 512 for the eight fp32 MFMAs they replace; the measured error
+// against fp64 is 3.7e-7 (the fp32 MFMA path: 4.5e-7; tools/ubench/bf16x3.hip). Operand layout: a lane
+// holds the k-set {16 kb + 4 h + j, 16 kb + 8 + 4 h + j} of its row, i.e. exactly row-fragment entries
+// 2 kb and 2 kb + 1, so the TRR fragments and the C/D tiles are unchanged.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct W3 {  // weight fragments, one array per split piece, [(tile * kb_total + kb) * 64 + lane]
+    const bf16x8 *h = nullptr, *m = nullptr, *l = nullptr;
+};
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r = x - (float)h;
+    m = (__bf16)r;
+    l = (__bf16)(r - (float)m);
+}
+// row-fragment entries x[2 kb], x[2 kb + 1] -> the three bf16x8 operands of K block kb
+template <int KB>
+struct Split3 {
+    bf16x8 h[KB], m[KB], l[KB];
+};
+template <int KB>
+__device__ __forceinline__ void split_frag(const float4* x, Split3<KB>& s) {
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        const float v[8] = {x[2 * kb].x, x[2 * kb].y, x[2 * kb].z, x[2 * kb].w,
+                            x[2 * kb + 1].x, x[2 * kb + 1].y, x[2 * kb + 1].z, x[2 * kb + 1].w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            __bf16 a, b, c;
+            split3(v[j], a, b, c);
+            s.h[kb][j] = a; s.m[kb][j] = b; s.l[kb][j] = c;
+        }
+    }
+}
+#define PET_MFMA_B(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
+// acc[t] += W[tiles tile0 + t * tile_stride][K blocks kb0 .. kb0+KBS) . x[0 .. KBS)   (six bf16 MFMAs per block)
+template <int KBS, int NT, int PF = 2, int KBX>
+__device__ __forceinline__ void gemm_b(const W3& w, int kb_total, int kb0, int tile0, const Split3<KBX>& x, int xk0,
+                                       f32x16 (&acc)[NT], int lane, int tile_stride = 1) {
+    size_t base[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) base[t] = ((size_t)(tile0 + t * tile_stride) * kb_total + kb0) * 64 + lane;
+    bf16x8 wh[PF][NT], wm[PF][NT], wl[PF][NT];
+#pragma unroll
+    for (int s = 0; s < PF; s++)
+        if (s < KBS)
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                wh[s][t] = w.h[base[t] + s * 64]; wm[s][t] = w.m[base[t] + s * 64]; wl[s][t] = w.l[base[t] + s * 64];
+            }
+#pragma unroll
+    for (int kb = 0; kb < KBS; kb++) {
+        const int cur = kb % PF;
+        const bf16x8 xh = x.h[xk0 + kb], xm = x.m[xk0 + kb], xl = x.l[xk0 + kb];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(wl[cur][t], xh, acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(wh[cur][t], xl, acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(wm[cur][t], xm, acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(wm[cur][t], xh, acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(wh[cur][t], xm, acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(wh[cur][t], xh, acc[t]);
+        if (kb + PF < KBS)
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                wh[cur][t] = w.h[base[t] + (kb + PF) * 64]; wm[cur][t] = w.m[base[t] + (kb + PF) * 64];
+                wl[cur][t] = w.l[base[t] + (kb + PF) * 64];
+            }
+    }
+}
+
 // sum over the row: lane-local + the partner lane holding the other half of the features
 __device__ __forceinline__ float row_sum(float v) { return v + __shfl_xor(v, 32); }
 

@@ -324,19 +324,20 @@ def test_unknown_species_is_an_error_not_an_out_of_bounds_read(rt, model, dev):
                     torch.zeros(32, dtype=torch.int32, device=dev))
 
 
-@pytest.mark.parametrize("switch", ["trr", "attn_lds", "side_stream"])
+@pytest.mark.parametrize("switch", ["trr", "attn_lds", "side_stream", "bf16x6"])
 def test_alternative_kernel_paths_agree(rt, model, dev, golden_dir, switch):
     """The library keeps its earlier kernel generations selectable (pet_config_set): LDS-tile GEMM stages
     (trr=0), wave-per-head attention straight from global memory (attn_lds=0), single stream (side_stream=0).
     Each must meet the same parity bar."""
     g = _load(golden_dir, "pet_default_box64.npz")
     graph = _graph_from_golden(rt, model, g, dev)
-    rt.config_set(switch, 0)
+    default = 0 if switch == "bf16x6" else 1  # bf16x6 (split-bf16 GEMMs in the edge MLP) is the opt-in one
+    rt.config_set(switch, 1 - default)
     try:
         fw = rt.HipForward(model, graph)
         atomic = fw.forward()
         grad = fw.backward(torch.ones_like(atomic))
     finally:
-        rt.config_set(switch, 1)
+        rt.config_set(switch, default)
     assert relmax(atomic.cpu().numpy(), g["atomic_f64"].ravel()) < TOL
     assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
