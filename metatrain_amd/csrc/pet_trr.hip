@@ -128,6 +128,155 @@ __global__ __launch_bounds__(256) void k_oproj_bwd_t(const float* __restrict__ d
 }
 
 // ---------------------------------------------------------------------------------
+// bf16x6 versions of the three stages above (trr.h): one wave per SIMD, weight fragments through a 4-deep
+// ring that keeps running across the column chunks, biases one chunk ahead.
+// ---------------------------------------------------------------------------------
+// y[:, 64 c .. 64 c + 63] for c < NC2 from a 128-wide row fragment: shared by qkv (NC2 = 6) and output_linear (2)
+template <int NC2, class Epilogue>
+__device__ __forceinline__ void row_gemm128_b(const W3& w, const float* __restrict__ bias, const Split3<8>& xs,
+                                              const RowLane& L, Epilogue epi) {
+    auto widx = [&](int b) { return ((size_t)(2 * (b >> 3)) * 8 + (b & 7)) * 64 + L.lane; };
+    WBlk<2> ring[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) ld_blk<2>(ring[b], w, widx(b), 8 * 64);
+    float4 bnext[8];
+    if (bias) ld_bias<2>(bnext, bias, 0, L.h);
+#pragma unroll 1
+    for (int c = 0; c < NC2; c++) {
+        f32x16 acc[2];
+        if (bias) {
+            acc_from<2>(acc, bnext);
+            if (c + 1 < NC2) ld_bias<2>(bnext, bias, 64 * (c + 1), L.h);
+        } else {
+            acc_zero<2>(acc);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            WBlk<2>& wb = ring[kb & 3];
+            mfma6<2>(acc, wb, xs.h[kb], xs.m[kb], xs.l[kb]);
+            const int nb = 8 * c + kb + 4;
+            if (nb < 8 * NC2) ld_blk<2>(wb, w, widx(nb), 8 * 64);
+        }
+        epi(c, acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_qkv_b(const float* __restrict__ X, const float* __restrict__ gamma, W3 win,
+                                                const float* __restrict__ bin, float* __restrict__ QKV, int64_t R) {
+    TRR_PROLOGUE(R);
+    Split3<8> xs;
+    {
+        float4 x[16];
+        load_rowfrag<16>(x, X, row, D, L.h);
+        rmsnorm_frag<16>(x, gamma, L.h);
+        split_frag<8>(x, xs);
+    }
+    row_gemm128_b<6>(win, bin, xs, L, [&](int c, f32x16 (&acc)[2]) {
+        if (valid) {
+            float4 y[8];
+            acc_to_frag<2>(acc, y);
+            store_rowfrag<8>(y, QKV + 64 * c, row, 3 * D, L.h);
+        }
+    });
+}
+
+__global__ __launch_bounds__(256) void k_oproj_b(const float* __restrict__ AO, const float* __restrict__ X, W3 wo,
+                                                  const float* __restrict__ bo, float* __restrict__ X1,
+                                                  float* __restrict__ OC, int64_t E, int64_t R) {
+    TRR_PROLOGUE(R);
+    Split3<8> xs;
+    {
+        float4 a[16];
+        load_rowfrag<16>(a, AO, row, D, L.h);
+        split_frag<8>(a, xs);
+    }
+    row_gemm128_b<2>(wo, bo, xs, L, [&](int c, f32x16 (&acc)[2]) {
+        if (!valid) return;
+        float4 y[8];
+        acc_to_frag<2>(acc, y);
+        if (row < E) {
+            float4 xr[8];
+            load_rowfrag<8>(xr, X + 64 * c, row, D, L.h);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                y[k].x += xr[k].x; y[k].y += xr[k].y; y[k].z += xr[k].z; y[k].w += xr[k].w;
+            }
+            store_rowfrag<8>(y, X1 + 64 * c, row, D, L.h);
+        } else {
+            store_rowfrag<8>(y, OC + 64 * c, row - E, D, L.h);
+        }
+    });
+}
+
+__global__ __launch_bounds__(256) void k_oproj_bwd_b(const float* __restrict__ dX1, const float* __restrict__ dOC,
+                                                      W3 wob, float* __restrict__ dAO, int64_t E, int64_t R) {
+    TRR_PROLOGUE(R);
+    Split3<8> xs;
+    {
+        float4 d[16];
+        if (row < E) load_rowfrag<16>(d, dX1, row, D, L.h);
+        else load_rowfrag<16>(d, dOC, row - E, D, L.h);
+        split_frag<8>(d, xs);
+    }
+    row_gemm128_b<2>(wob, nullptr, xs, L, [&](int c, f32x16 (&acc)[2]) {
+        if (valid) {
+            float4 y[8];
+            acc_to_frag<2>(acc, y);
+            store_rowfrag<8>(y, dAO + 64 * c, row, D, L.h);
+        }
+    });
+}
+
+// dXin = (row < E ? dX1 : 0) + RMSNorm^T(dQKV Win): K = 384 as 24 blocks streamed through the ring, the three
+// 128-wide slices of dQKV are loaded one slice ahead of their use
+__global__ __launch_bounds__(256) void k_qkv_bwd_b(const float* __restrict__ dQKV, const float* __restrict__ X,
+                                                    const float* __restrict__ gamma, W3 winb,
+                                                    const float* __restrict__ dX1, float* __restrict__ dXin, int64_t E,
+                                                    int64_t R) {
+    TRR_PROLOGUE(R);
+    auto widx = [&](int b) { return (size_t)b * 64 + L.lane; };  // tile 0; tile t at + t * 24 * 64
+    WBlk<4> ring[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) ld_blk<4>(ring[b], winb, widx(b), 24 * 64);
+    f32x16 dn[4];
+    acc_zero<4>(dn);
+    float4 d[16];
+    load_rowfrag<16>(d, dQKV, row, 3 * D, L.h);
+#pragma unroll 1
+    for (int ks = 0; ks < 3; ks++) {
+        Split3<8> xs;
+        split_frag<8>(d, xs);
+        if (ks + 1 < 3) load_rowfrag<16>(d, dQKV + 128 * (ks + 1), row, 3 * D, L.h);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            WBlk<4>& wb = ring[kb & 3];
+            mfma6<4>(dn, wb, xs.h[kb], xs.m[kb], xs.l[kb]);
+            const int nb = 8 * ks + kb + 4;
+            if (nb < 24) ld_blk<4>(wb, winb, widx(nb), 24 * 64);
+        }
+    }
+    float4 w[16], x[16];
+    acc_to_frag<4>(dn, w);
+    load_rowfrag<16>(x, X, row, D, L.h);
+#pragma unroll
+    for (int kg = 0; kg < 16; kg++) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
+        w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
+    }
+    rmsnorm_bwd_frag<16>(w, x);
+    if (valid) {
+        if (row < E) {
+            load_rowfrag<16>(x, dX1, row, D, L.h);
+#pragma unroll
+            for (int kg = 0; kg < 16; kg++) {
+                w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
+            }
+        }
+        store_rowfrag<16>(w, dXin, row, D, L.h);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // edge SwiGLU MLP: X2 = X1 + Wout (v * sig(g)) + b,  [v; g] = Win RMSNorm(X1) + b
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_emlp_t(const float* __restrict__ X1, const float* __restrict__ gamma,
@@ -190,12 +339,22 @@ static inline W3 w3_bwd(const Lin& L) {
     return w;
 }
 
-// same stage with the GEMMs on the bf16 matrix cores (bf16x6, trr.h)
+// The same stage with its GEMMs on the bf16 matrix cores (bf16x6, trr.h).
+// One wave per SIMD (the split operands take the registers of two), so the wave hides its own latencies:
+// the w_in fragments run through a 4-deep ring that is refilled across chunk boundaries, the w_out
+// fragments and the biases of a chunk are requested before its first MFMA.
 __global__ __launch_bounds__(256) void k_emlp_b(const float* __restrict__ X1, const float* __restrict__ gamma, W3 win,
-                                                 const float* __restrict__ bin, W3 wout,
-                                                 const float* __restrict__ bout, float* __restrict__ VG,
-                                                 float* __restrict__ X2, int64_t E) {
+                                                  const float* __restrict__ bin, W3 wout,
+                                                  const float* __restrict__ bout, float* __restrict__ VG,
+                                                  float* __restrict__ X2, int64_t E) {
     TRR_PROLOGUE(E);
+    constexpr int NC = DFF / 32;  // hidden chunks
+    // ring of w_in blocks: stream index b = 8 hc + kb, tiles (hc, NC + hc), kb_total = 8
+    auto widx = [&](int b) { return ((size_t)(b >> 3) * 8 + (b & 7)) * 64 + L.lane; };
+    constexpr size_t TS = (size_t)NC * 8 * 64;  // from the value tile to the gate tile
+    WBlk<2> ring[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) ld_blk<2>(ring[b], win, widx(b), TS);
     Split3<8> xs;
     {
         float4 x[16];
@@ -205,17 +364,43 @@ __global__ __launch_bounds__(256) void k_emlp_b(const float* __restrict__ X1, co
     }
     f32x16 out[4];
     acc_bias<4>(out, bout, 0, L.h);
+    float4 bv[4], bg[4];  // biases of the current chunk (this lane's features)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        bv[q] = *reinterpret_cast<const float4*>(bin + 8 * q + 4 * L.h);
+        bg[q] = *reinterpret_cast<const float4*>(bin + DFF + 8 * q + 4 * L.h);
+    }
 #pragma unroll 1
-    for (int hc = 0; hc < DFF / 32; hc++) {
+    for (int hc = 0; hc < NC; hc++) {
+        // w_out fragments of this chunk (K blocks 2 hc, 2 hc + 1 of the four output tiles) and the next biases
+        bf16x8 oh[2][4], om[2][4], ol[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const size_t i = ((size_t)t * (DFF / 16) + 2 * hc + kb) * 64 + L.lane;
+                oh[kb][t] = wout.h[i]; om[kb][t] = wout.m[i]; ol[kb][t] = wout.l[i];
+            }
         f32x16 vg[2];
-        {
-            f32x16 v[1], g[1];
-            acc_bias<1>(v, bin, 32 * hc, L.h);
-            acc_bias<1>(g, bin, DFF + 32 * hc, L.h);
-            vg[0] = v[0];
-            vg[1] = g[0];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            vg[0][4 * q] = bv[q].x; vg[0][4 * q + 1] = bv[q].y; vg[0][4 * q + 2] = bv[q].z; vg[0][4 * q + 3] = bv[q].w;
+            vg[1][4 * q] = bg[q].x; vg[1][4 * q + 1] = bg[q].y; vg[1][4 * q + 2] = bg[q].z; vg[1][4 * q + 3] = bg[q].w;
         }
-        gemm_b<8, 2, 2>(win, 8, 0, hc, xs, 0, vg, L.lane, DFF / 32);
+        if (hc + 1 < NC) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                bv[q] = *reinterpret_cast<const float4*>(bin + 32 * (hc + 1) + 8 * q + 4 * L.h);
+                bg[q] = *reinterpret_cast<const float4*>(bin + DFF + 32 * (hc + 1) + 8 * q + 4 * L.h);
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            WBlk<2>& wb = ring[kb & 3];
+            mfma6<2>(vg, wb, xs.h[kb], xs.m[kb], xs.l[kb]);
+            const int nb = 8 * hc + kb + 4;  // refill this slot with the block four steps ahead (may be next chunk's)
+            if (nb < 8 * NC) ld_blk<2>(wb, win, widx(nb), TS);
+        }
         float4 u[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -228,7 +413,17 @@ __global__ __launch_bounds__(256) void k_emlp_b(const float* __restrict__ X1, co
         }
         Split3<2> us;
         split_frag<2>(u, us);
-        gemm_b<2, 4, 2>(wout, DFF / 16, 2 * hc, 0, us, 0, out, L.lane);
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                out[t] = PET_MFMA_B(ol[kb][t], us.h[kb], out[t]);
+                out[t] = PET_MFMA_B(oh[kb][t], us.l[kb], out[t]);
+                out[t] = PET_MFMA_B(om[kb][t], us.m[kb], out[t]);
+                out[t] = PET_MFMA_B(om[kb][t], us.h[kb], out[t]);
+                out[t] = PET_MFMA_B(oh[kb][t], us.m[kb], out[t]);
+                out[t] = PET_MFMA_B(oh[kb][t], us.h[kb], out[t]);
+            }
     }
     if (valid) {
         float4 y[16], xr[16];
@@ -295,33 +490,131 @@ __global__ __launch_bounds__(256, 2) void k_emlp_bwd_t(const float* __restrict__
     }
 }
 
+// bf16x6 version: two weight streams, both ring-prefetched across the hidden chunks --
+//   A: Wout^T blocks for du (tile hc of the [DFF x D] operand, 8 K blocks per chunk, one tile);
+//   B: Win^T blocks for dn += [dv | dg] Win (four output tiles; per chunk K blocks 2hc, 2hc+1 of the value half
+//      and 16 + 2hc, 16 + 2hc + 1 of the gate half).
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void k_emlp_bwd_b(const float* __restrict__ dY, const float* __restrict__ X1,
+                                                     const float* __restrict__ VG, const float* __restrict__ gamma,
+                                                     W3 woutb, W3 winb, float* __restrict__ dX1, int64_t E,
+                                                     float* __restrict__ t_dvg) {
+    TRR_PROLOGUE(E);
+    constexpr int NC = DFF / 32;
+    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };  // b = 8 hc + kb: tile hc, kb_total = 8
+    auto bkb = [&](int b) { const int hc = b >> 2, j = b & 3; return (j < 2 ? 2 * hc + j : 16 + 2 * hc + (j - 2)); };
+    auto bidx = [&](int b) { return (size_t)bkb(b) * 64 + L.lane; };  // tile 0; tile t at + t * 32 * 64
+    WBlk<1> ra[4];
+    WBlk<4> rb[2];
+#pragma unroll
+    for (int b = 0; b < 4; b++) ld_blk<1>(ra[b], woutb, aidx(b), 0);
+#pragma unroll
+    for (int b = 0; b < 2; b++) ld_blk<4>(rb[b], winb, bidx(b), 32 * 64);
+    Split3<8> ys;
+    {
+        float4 dy[16];
+        load_rowfrag<16>(dy, dY, row, D, L.h);
+        split_frag<8>(dy, ys);
+    }
+    f32x16 dn[4];
+    acc_zero<4>(dn);
+    float4 vv[4], gg[4];  // saved pre-activations of the current chunk
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        vv[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + 8 * q + 4 * L.h);
+        gg[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + DFF + 8 * q + 4 * L.h);
+    }
+#pragma unroll 1
+    for (int hc = 0; hc < NC; hc++) {
+        f32x16 du[1];
+        acc_zero<1>(du);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            WBlk<1>& wb = ra[kb & 3];
+            mfma6<1>(du, wb, ys.h[kb], ys.m[kb], ys.l[kb]);
+            const int nb = 8 * hc + kb + 4;
+            if (nb < 8 * NC) ld_blk<1>(wb, woutb, aidx(nb), 0);
+        }
+        float4 dvg[8];  // dv (4) then dg (4): the K = 64 operand of stream B
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 d = acc_q(du[0], q);
+            const float sx = sigm_(gg[q].x), sy = sigm_(gg[q].y), sz = sigm_(gg[q].z), sw = sigm_(gg[q].w);
+            dvg[q] = make_float4(d.x * sx, d.y * sy, d.z * sz, d.w * sw);
+            dvg[4 + q] = make_float4(d.x * vv[q].x * sx * (1.f - sx), d.y * vv[q].y * sy * (1.f - sy),
+                                     d.z * vv[q].z * sz * (1.f - sz), d.w * vv[q].w * sw * (1.f - sw));
+            if (TRAIN && valid) {
+                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) = dvg[q];
+                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) = dvg[4 + q];
+            }
+        }
+        if (hc + 1 < NC) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                vv[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + 32 * (hc + 1) + 8 * q + 4 * L.h);
+                gg[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + DFF + 32 * (hc + 1) + 8 * q + 4 * L.h);
+            }
+        }
+        Split3<4> ds;
+        split_frag<4>(dvg, ds);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            WBlk<4>& wb = rb[j & 1];
+            mfma6<4>(dn, wb, ds.h[j], ds.m[j], ds.l[j]);
+            const int nb = 4 * hc + j + 2;
+            if (nb < 4 * NC) ld_blk<4>(wb, winb, bidx(nb), 32 * 64);
+        }
+    }
+    float4 w[16], x[16];
+    acc_to_frag<4>(dn, w);
+    load_rowfrag<16>(x, X1, row, D, L.h);
+#pragma unroll
+    for (int kg = 0; kg < 16; kg++) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
+        w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
+    }
+    rmsnorm_bwd_frag<16>(w, x);
+    if (valid) {
+        load_rowfrag<16>(x, dY, row, D, L.h);
+#pragma unroll
+        for (int kg = 0; kg < 16; kg++) {
+            w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
+        }
+        store_rowfrag<16>(w, dX1, row, D, L.h);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // host launchers (declared in model.h)
 // ---------------------------------------------------------------------------------
 static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
 
+// pet_config_set("bf16x6", 0) puts the TRR stages back on the fp32 MFMA. Default: GEMMs on the bf16 matrix cores
+// with 3-way split operands -- as accurate as the fp32 MFMA (3.7e-7 vs 4.5e-7 against fp64, tools/ubench/bf16x3.hip)
+// at 0.375x the matrix-core time. The split fragments cost registers (one wave per SIMD), so these kernels
+// prefetch their weight fragments through rings that run across the GEMM boundaries.
+static int g_bf16x6 = 1;
+void set_bf16x6(int v) { g_bf16x6 = v ? 1 : 0; }
+
 void trr_qkv(const float* X, const float* gamma, const Lin& qkv, float* QKV, int64_t R, hipStream_t st) {
-    k_qkv_t<<<grid_rows(R), 256, 0, st>>>(X, gamma, qkv.fwd, qkv.b, QKV, R);
+    if (g_bf16x6 && qkv.fwd3) k_qkv_b<<<grid_rows(R), 256, 0, st>>>(X, gamma, w3_fwd(qkv), qkv.b, QKV, R);
+    else k_qkv_t<<<grid_rows(R), 256, 0, st>>>(X, gamma, qkv.fwd, qkv.b, QKV, R);
 }
 void trr_qkv_bwd(const float* dQKV, const float* X, const float* gamma, const Lin& qkv, const float* dX1,
                  float* dXin, int64_t E, int64_t R, hipStream_t st) {
-    k_qkv_bwd_t<<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, qkv.bwd, dX1, dXin, E, R);
+    if (g_bf16x6 && qkv.bwd3) k_qkv_bwd_b<<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, w3_bwd(qkv), dX1, dXin, E, R);
+    else k_qkv_bwd_t<<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, qkv.bwd, dX1, dXin, E, R);
 }
 void trr_oproj(const float* AO, const float* X, const Lin& out, float* X1, float* OC, int64_t E, int64_t R,
                hipStream_t st) {
-    k_oproj_t<<<grid_rows(R), 256, 0, st>>>(AO, X, out.fwd, out.b, X1, OC, E, R);
+    if (g_bf16x6 && out.fwd3) k_oproj_b<<<grid_rows(R), 256, 0, st>>>(AO, X, w3_fwd(out), out.b, X1, OC, E, R);
+    else k_oproj_t<<<grid_rows(R), 256, 0, st>>>(AO, X, out.fwd, out.b, X1, OC, E, R);
 }
 void trr_oproj_bwd(const float* dX1, const float* dOC, const Lin& out, float* dAO, int64_t E, int64_t R,
                    hipStream_t st) {
-    k_oproj_bwd_t<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, out.bwd, dAO, E, R);
+    if (g_bf16x6 && out.bwd3) k_oproj_bwd_b<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, w3_bwd(out), dAO, E, R);
+    else k_oproj_bwd_t<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, out.bwd, dAO, E, R);
 }
-// pet_config_set("bf16x6", 1): edge MLP GEMMs on the bf16 matrix cores (3-way split operands). Off by default:
-// as accurate as the fp32 MFMA path (tools/ubench/bf16x3.hip: 3.7e-7 vs 4.5e-7 against fp64) and 1.85x faster as
-// a plain GEMM, but in this fused stage the split fragments cost 96 VGPRs, occupancy drops to one wave per SIMD
-// and the exposed weight-load latency at each small GEMM outweighs the shorter MFMA time (4.3 vs 3.2 ms / step).
-static int g_bf16x6 = 0;
-void set_bf16x6(int v) { g_bf16x6 = v ? 1 : 0; }
-
 void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wout, float* VG, float* X2,
               int64_t E, hipStream_t st) {
     if (g_bf16x6 && win.fwd3 && wout.fwd3)
@@ -331,8 +624,14 @@ void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wo
 }
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
                   const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg) {
-    if (t_dvg) k_emlp_bwd_t<true><<<grid_rows(E), 256, 0, st>>>(dY, X1, VG, gamma, wout.bwd, win.bwd, dX1, E, t_dvg);
-    else k_emlp_bwd_t<false><<<grid_rows(E), 256, 0, st>>>(dY, X1, VG, gamma, wout.bwd, win.bwd, dX1, E, nullptr);
+    const int grid = grid_rows(E);
+    if (g_bf16x6 && win.bwd3 && wout.bwd3) {
+        if (t_dvg) k_emlp_bwd_b<true><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w3_bwd(wout), w3_bwd(win), dX1, E, t_dvg);
+        else k_emlp_bwd_b<false><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w3_bwd(wout), w3_bwd(win), dX1, E, nullptr);
+    } else {
+        if (t_dvg) k_emlp_bwd_t<true><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, wout.bwd, win.bwd, dX1, E, t_dvg);
+        else k_emlp_bwd_t<false><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, wout.bwd, win.bwd, dX1, E, nullptr);
+    }
 }
 
 }  // namespace pet

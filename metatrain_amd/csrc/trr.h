@@ -206,6 +206,54 @@ __device__ __forceinline__ void gemm_b(const W3& w, int kb_total, int kb0, int t
     }
 }
 
+// Building blocks of the ring-prefetched bf16x6 kernels (pet_trr.hip): one K block of NT tiles, its load and
+// the six MFMAs per tile.
+template <int NT>
+struct WBlk {
+    bf16x8 h[NT], m[NT], l[NT];
+};
+template <int NT>
+__device__ __forceinline__ void ld_blk(WBlk<NT>& b, const W3& w, size_t i0, size_t tile_stride) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        b.h[t] = w.h[i0 + t * tile_stride]; b.m[t] = w.m[i0 + t * tile_stride]; b.l[t] = w.l[i0 + t * tile_stride];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void mfma6(f32x16 (&acc)[NT], const WBlk<NT>& b, const bf16x8& xh, const bf16x8& xm,
+                                      const bf16x8& xl) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(b.l[t], xh, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(b.h[t], xl, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(b.m[t], xm, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(b.m[t], xh, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(b.h[t], xm, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(b.h[t], xh, acc[t]);
+}
+// accumulator tiles initialised from a prefetched bias fragment (float4 per (tile, q))
+template <int NT>
+__device__ __forceinline__ void acc_from(f32x16 (&acc)[NT], const float4 (&b)[4 * NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            acc[t][4 * q] = b[4 * t + q].x; acc[t][4 * q + 1] = b[4 * t + q].y;
+            acc[t][4 * q + 2] = b[4 * t + q].z; acc[t][4 * q + 3] = b[4 * t + q].w;
+        }
+}
+template <int NT>
+__device__ __forceinline__ void ld_bias(float4 (&b)[4 * NT], const float* __restrict__ bias, int col0, int h) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) b[4 * t + q] = *reinterpret_cast<const float4*>(bias + col0 + 32 * t + 8 * q + 4 * h);
+}
+
 // sum over the row: lane-local + the partner lane holding the other half of the features
 __device__ __forceinline__ float row_sum(float v) { return v + __shfl_xor(v, 32); }
 

@@ -331,7 +331,7 @@ def test_alternative_kernel_paths_agree(rt, model, dev, golden_dir, switch):
     Each must meet the same parity bar."""
     g = _load(golden_dir, "pet_default_box64.npz")
     graph = _graph_from_golden(rt, model, g, dev)
-    default = 0 if switch == "bf16x6" else 1  # bf16x6 (split-bf16 GEMMs in the edge MLP) is the opt-in one
+    default = 1
     rt.config_set(switch, 1 - default)
     try:
         fw = rt.HipForward(model, graph)
