@@ -140,6 +140,13 @@ void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wo
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
                   const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg = nullptr);
 
+// pet_comb.hip: combination stage and adjoint on the bf16 matrix cores; false if the split operands are missing
+bool use_bf16x6();
+bool comb_bf16(bool first, const float* XF, const Graph& g, const GnnLayerW& G, const float* Min,
+               const float* edge_emb, float* CA, float* LNS, float* Mout, int64_t E, hipStream_t st);
+bool comb_bwd_bf16(const float* dM, const float* XF, const Graph& g, const GnnLayerW& G, const float* LNS,
+                   const float* CA, float* dcat, int64_t E, float* t_da, hipStream_t st);
+
 // pet_attn.hip: preload variants of the attention kernels (NT <= 4); return false if not handled
 bool attn_fwd_preload(int nt, const float* QKV, const Graph& g, float* AO, float scale, hipStream_t st);
 bool attn_bwd_preload(int nt, const float* QKV, const float* dAO, const Graph& g, float* dQKV, float* dbias_h,

@@ -658,7 +658,9 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
         }
         if (E > 0) {
             ProfScope ps("comb", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D));
-            if (gi == 0)
+            if (trr && use_bf16x6() && comb_bf16(gi == 0, B.XF, g, G, Min, m.edge_emb, B.CA, B.LNS, B.Mout, E, st)) {
+                // TRR kernel on the bf16 matrix cores (pet_comb.hip)
+            } else if (gi == 0)
                 k_comb<true><<<gE, NTHREADS, lds2, st>>>(B.XF, g.rev, G.ln_g, G.ln_b, G.comb0.fwd, G.comb0.b,
                                                          G.comb2.fwd, G.comb2.b, nullptr, m.edge_emb, g.sp_nbr,
                                                          B.CA, B.LNS, B.Mout, E);

@@ -595,6 +595,7 @@ static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
 // prefetch their weight fragments through rings that run across the GEMM boundaries.
 static int g_bf16x6 = 1;
 void set_bf16x6(int v) { g_bf16x6 = v ? 1 : 0; }
+bool use_bf16x6() { return g_bf16x6 != 0; }
 
 void trr_qkv(const float* X, const float* gamma, const Lin& qkv, float* QKV, int64_t R, hipStream_t st) {
     if (g_bf16x6 && qkv.fwd3) k_qkv_b<<<grid_rows(R), 256, 0, st>>>(X, gamma, w3_fwd(qkv), qkv.b, QKV, R);
