@@ -856,15 +856,18 @@ __global__ __launch_bounds__(512) void k_attn_bwd_l(const float* __restrict__ QK
     }
 }
 
-static int g_attn_lds = 1;  // pet_config_set("attn_lds", 0): one wave per (atom, head) straight from global memory
-void set_attn_lds(int v) { g_attn_lds = v ? 1 : 0; }
+// pet_config_set("attn_lds", v): 0 = one wave per (atom, head) straight from global memory for both passes,
+// 1 (default) = LDS-staged adjoint, global-memory forward (measured best: 1.16 / 3.13 ms vs 1.36 / 3.22 per step),
+// 2 = LDS-staged for both
+static int g_attn_lds = 1;
+void set_attn_lds(int v) { g_attn_lds = v < 0 ? 0 : (v > 2 ? 2 : v); }
 
 // Atoms are served by the instantiation that matches their own tile count (registers / LDS, hence waves in
 // flight, scale with NT): one launch per tile count up to the batch maximum, the others exit at once.
 bool attn_fwd_preload(int nt, const float* QKV, const Graph& g, float* AO, float scale, hipStream_t st) {
     if (nt > 4) return false;
     const int N = (int)g.n_nodes;
-    if (g_attn_lds) {
+    if (g_attn_lds == 2) {
 #define PET_ATTN_FWD_L(K)                                                                                      \
     if (nt >= K) {                                                                                             \
         const size_t lds = (size_t)16 * K * LDF * sizeof(float);                                               \

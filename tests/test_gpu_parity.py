@@ -324,7 +324,7 @@ def test_unknown_species_is_an_error_not_an_out_of_bounds_read(rt, model, dev):
                     torch.zeros(32, dtype=torch.int32, device=dev))
 
 
-@pytest.mark.parametrize("switch", ["trr", "attn_lds", "side_stream", "bf16x6"])
+@pytest.mark.parametrize("switch", ["trr", "attn_lds", "attn_lds=2", "side_stream", "bf16x6"])
 def test_alternative_kernel_paths_agree(rt, model, dev, golden_dir, switch):
     """The library keeps its earlier kernel generations selectable (pet_config_set): LDS-tile GEMM stages
     (trr=0), wave-per-head attention straight from global memory (attn_lds=0), single stream (side_stream=0).
@@ -332,12 +332,13 @@ def test_alternative_kernel_paths_agree(rt, model, dev, golden_dir, switch):
     g = _load(golden_dir, "pet_default_box64.npz")
     graph = _graph_from_golden(rt, model, g, dev)
     default = 1
-    rt.config_set(switch, 1 - default)
+    key, _, val = switch.partition("=")
+    rt.config_set(key, int(val or 0))
     try:
         fw = rt.HipForward(model, graph)
         atomic = fw.forward()
         grad = fw.backward(torch.ones_like(atomic))
     finally:
-        rt.config_set(switch, default)
+        rt.config_set(key, default)
     assert relmax(atomic.cpu().numpy(), g["atomic_f64"].ravel()) < TOL
     assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
