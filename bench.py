@@ -37,8 +37,12 @@ def synthetic_params(hypers):
     return gen(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
 
 
-STAGE_KERNELS = {"attn_bwd": "k_attn_bwd_p", "attn_fwd": "k_attn_fwd_p", "emlp": "k_emlp_t", "emlp_bwd": "k_emlp_bwd_t",
-                 "qkv": "k_qkv_t", "qkv_bwd": "k_qkv_bwd_t", "comb": "k_comb", "comb_bwd": "k_comb_bwd"}
+# ProfScope stage -> the kernels it launches (base names, template arguments stripped). The attention stages
+# launch one kernel per neighbour-count bucket (NT = 1, 2, 3 ...): their traffic is the sum over the buckets.
+STAGE_KERNELS = {"attn_bwd": ("k_attn_bwd_l", "k_attn_bwd_p"), "attn_fwd": ("k_attn_fwd_p", "k_attn_fwd_l"),
+                 "emlp": ("k_emlp_b", "k_emlp_t"), "emlp_bwd": ("k_emlp_bwd_b", "k_emlp_bwd_t"),
+                 "qkv": ("k_qkv_b", "k_qkv_t"), "qkv_bwd": ("k_qkv_bwd_b", "k_qkv_bwd_t"),
+                 "comb": ("k_comb_b", "k_comb"), "comb_bwd": ("k_comb_bwd_b", "k_comb_bwd")}
 
 
 def pmc_traffic(stage, n_edges):
@@ -53,10 +57,13 @@ def pmc_traffic(stage, n_edges):
         data = json.load(fh)
     if data.get("workload_edges") != n_edges:
         return None
-    for name, rec in data["kernels"].items():
-        if name.startswith(STAGE_KERNELS[stage]):
-            return rec["hbm_bytes_per_launch"]
-    return None
+    recs = [rec for name, rec in data["kernels"].items() if name.split("<")[0] in STAGE_KERNELS[stage]]
+    if not recs:
+        return None
+    if stage.startswith("attn"):   # every bucket kernel runs once per stage call
+        return sum(r["hbm_bytes_per_launch"] for r in recs)
+    calls = sum(r.get("calls", 1) for r in recs)   # template variants are alternatives (first / later GNN layer)
+    return sum(r["hbm_bytes_per_launch"] * r.get("calls", 1) for r in recs) / calls
 
 
 def cpu_baseline(hypers, params, seconds_budget=25.0):

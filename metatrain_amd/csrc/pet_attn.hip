@@ -19,6 +19,15 @@ __device__ __forceinline__ float key_bias(int key, int T, const float* __restric
     if (key == 0) return 0.f;
     return logf(fmaxf(fc[start + key - 1], 1e-15f));  // transformer.py:109-110
 }
+// log2-domain softmax: scores carry a factor log2(e) (folded into the query scale and the key bias), so the
+// exponential is the bare v_exp_f32 (exp2) instead of the 13-instruction expf expansion; the kernels below are
+// VALU-issue bound, not MFMA bound, so instruction count is what matters.
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float key_bias2(int key, int T, const float* __restrict__ fc, int start) {
+    if (key >= T) return -INFINITY;
+    if (key == 0) return 0.f;
+    return __builtin_amdgcn_logf(fmaxf(fc[start + key - 1], 1e-15f));  // v_log_f32 = log2
+}
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // Reductions across the four 16-lane groups (lanes l, l^16, l^32, l^48) with the gfx950 row swaps
@@ -72,24 +81,25 @@ __global__ __launch_bounds__(256) void k_attn_fwd_p(const float* __restrict__ QK
             for (int r = 0; r < 4; r++) {
                 const int key = 16 * t + 4 * g4 + r;
                 vs[t][r] = QKV[tok_row(key, T, E, atom, start) * (3 * D) + vo + c16];
-                bias[t][r] = key_bias(key, T, fc, start);
+                bias[t][r] = key_bias2(key, T, fc, start);
             }
         }
     }
 #pragma unroll
     for (int qt = 0; qt < NT; qt++) {
         if (qt < nt) {
-            const float4 q = make_float4(qf[qt].x * scale, qf[qt].y * scale, qf[qt].z * scale, qf[qt].w * scale);
+            const float s2 = scale * LOG2E;
+            const float4 q = make_float4(qf[qt].x * s2, qf[qt].y * s2, qf[qt].z * s2, qf[qt].w * s2);
             f32x4 s[NT];
             float mx = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < NT; kt++) {
                 if (kt < nt) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 a = {bias[kt][0], bias[kt][1], bias[kt][2], bias[kt][3]};  // the bias rides in the accumulator
                     a = MFMA16(kf[kt].x, q.x, a); a = MFMA16(kf[kt].y, q.y, a);
                     a = MFMA16(kf[kt].z, q.z, a); a = MFMA16(kf[kt].w, q.w, a);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { a[r] += bias[kt][r]; mx = fmaxf(mx, a[r]); }
+                    for (int r = 0; r < 4; r++) mx = fmaxf(mx, a[r]);
                     s[kt] = a;
                 }
             }
@@ -99,9 +109,9 @@ __global__ __launch_bounds__(256) void k_attn_fwd_p(const float* __restrict__ QK
             for (int kt = 0; kt < NT; kt++)
                 if (kt < nt)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { const float p = expf(s[kt][r] - mx); s[kt][r] = p; sum += p; }
+                    for (int r = 0; r < 4; r++) { const float p = __builtin_amdgcn_exp2f(s[kt][r] - mx); s[kt][r] = p; sum += p; }
             sum = g4_sum(sum);
-            const float inv = 1.0f / sum;
+            const float inv = __builtin_amdgcn_rcpf(sum);
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NT; kt++)
@@ -698,18 +708,24 @@ __global__ __launch_bounds__(512) void k_attn_fwd_l(const float* __restrict__ QK
     }
 }
 
+// Adjoint, single pass over the query tiles. The score tile is formed once, transposed (keys x queries), which is
+// the layout the softmax reductions and dQ want; P and dS are then turned into the (queries x keys) operand
+// layout dK / dV need through a wave-private 16x16 LDS scratch (4 ds_write_b32 + 1 ds_read_b128 per matrix)
+// instead of recomputing scores and exponentials in a second pass: 20 MFMA and 4 exp2 per tile pair instead of
+// 28 and 8. The scratch lives in columns of the staged rows that the wave has already consumed into registers
+// (P in its dO columns, dS in its K columns of rows 0..15; row pitch 516 floats = 4 mod 64 banks, so both the
+// scalar writes and the float4 reads are conflict-free); dK lands in the K columns only after the last tile.
 template <int NT>
 __global__ __launch_bounds__(512) void k_attn_bwd_l(const float* __restrict__ QKV, const float* __restrict__ dAO,
                                                      const int* __restrict__ rowptr, const float* __restrict__ fc,
                                                      float* __restrict__ dQKV, float* __restrict__ dbias_h,
-                                                     int64_t E, int N, float scale, int only_nt) {
+                                                     int64_t E, int N, float scale, int only_nt, int t_skip) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ __attribute__((aligned(16))) float stat_all[8][2][NT * 16];
     const int atom = blockIdx.x;
     const int start = rowptr[atom];
     const int T = rowptr[atom + 1] - start + 1;
     const int nt = (T + 15) >> 4;
-    if (only_nt && nt != only_nt) return;
+    if ((only_nt && nt != only_nt) || T <= t_skip) return;  // t_skip: atoms the persistent kernel already served
     const int TP = 16 * nt;
     for (int idx = threadIdx.x; idx < TP * D; idx += 512) {  // D float4 per row: 96 of QKV + 32 of dO
         const int t = idx / D, c = idx % D;
@@ -725,10 +741,11 @@ __global__ __launch_bounds__(512) void k_attn_bwd_l(const float* __restrict__ QK
     const int lane = threadIdx.x & 63, head = threadIdx.x >> 6;
     const int c16 = lane & 15, g4 = lane >> 4;
     const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head, doo = 3 * D + HD * head;
+    const float s2 = scale * LOG2E;
     float4 kf[NT], vf[NT], qf[NT], dof[NT];
     float ks[NT][4], qs[NT][4], dos[NT][4];
-    float bias_r[NT][4], bias_c[NT], db[NT][4];
-    float (*stat)[NT * 16] = stat_all[head];
+    float bias_r[NT][4], db[NT][4];
+    f32x4 dk[NT], dv[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         if (t < nt) {
@@ -737,9 +754,8 @@ __global__ __launch_bounds__(512) void k_attn_bwd_l(const float* __restrict__ QK
             kf[t] = *reinterpret_cast<const float4*>(row + ko + 4 * g4);
             vf[t] = *reinterpret_cast<const float4*>(row + vo + 4 * g4);
             const float4 q = *reinterpret_cast<const float4*>(row + qo + 4 * g4);
-            qf[t] = make_float4(q.x * scale, q.y * scale, q.z * scale, q.w * scale);
+            qf[t] = make_float4(q.x * s2, q.y * s2, q.z * s2, q.w * s2);
             dof[t] = *reinterpret_cast<const float4*>(row + doo + 4 * g4);  // zero rows beyond T
-            bias_c[t] = key_bias(tc, T, fc, start);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int tr = 16 * t + 4 * g4 + r;
@@ -747,12 +763,15 @@ __global__ __launch_bounds__(512) void k_attn_bwd_l(const float* __restrict__ QK
                 ks[t][r] = rr[ko + c16];
                 qs[t][r] = rr[qo + c16];
                 dos[t][r] = rr[doo + c16];
-                bias_r[t][r] = key_bias(tr, T, fc, start);
+                bias_r[t][r] = key_bias2(tr, T, fc, start);
                 db[t][r] = 0.f;
+                dk[t][r] = 0.f;
+                dv[t][r] = 0.f;
             }
         }
     }
-    // ---- pass A: per query tile, transposed scores (keys x queries): dQ, delta, lse, key-bias grad
+    float* sc_p = sm + doo;  // [16 keys][16 queries] scratch, row pitch LDB
+    float* sc_s = sm + ko;
 #pragma unroll
     for (int qt = 0; qt < NT; qt++) {
         if (qt < nt) {
@@ -761,93 +780,74 @@ __global__ __launch_bounds__(512) void k_attn_bwd_l(const float* __restrict__ QK
 #pragma unroll
             for (int kt = 0; kt < NT; kt++) {
                 if (kt < nt) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-                    a = MFMA16(kf[kt].x, qf[qt].x, a); a = MFMA16(kf[kt].y, qf[qt].y, a);
-                    a = MFMA16(kf[kt].z, qf[qt].z, a); a = MFMA16(kf[kt].w, qf[qt].w, a);
-                    b = MFMA16(vf[kt].x, dof[qt].x, b); b = MFMA16(vf[kt].y, dof[qt].y, b);
-                    b = MFMA16(vf[kt].z, dof[qt].z, b); b = MFMA16(vf[kt].w, dof[qt].w, b);
+                    f32x4 a = {bias_r[kt][0], bias_r[kt][1], bias_r[kt][2], bias_r[kt][3]};
+                    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                    a = MFMA16(kf[kt].x, qf[qt].x, a); b = MFMA16(vf[kt].x, dof[qt].x, b);
+                    a = MFMA16(kf[kt].y, qf[qt].y, a); b = MFMA16(vf[kt].y, dof[qt].y, b);
+                    a = MFMA16(kf[kt].z, qf[qt].z, a); b = MFMA16(vf[kt].z, dof[qt].z, b);
+                    a = MFMA16(kf[kt].w, qf[qt].w, a); b = MFMA16(vf[kt].w, dof[qt].w, b);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { a[r] += bias_r[kt][r]; mx = fmaxf(mx, a[r]); }
+                    for (int r = 0; r < 4; r++) mx = fmaxf(mx, a[r]);
                     s[kt] = a;
                     dp[kt] = b;
                 }
             }
             mx = g4_max(mx);
-            float sum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < NT; kt++)
-                if (kt < nt)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) { const float p = expf(s[kt][r] - mx); s[kt][r] = p; sum += p; }
-            sum = g4_sum(sum);
-            const float inv = 1.0f / sum;
-            float dl = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < NT; kt++)
-                if (kt < nt)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) { s[kt][r] *= inv; dl += s[kt][r] * dp[kt][r]; }
-            dl = g4_sum(dl);
-            if (g4 == 0) {
-                stat[0][16 * qt + c16] = mx + logf(sum);
-                stat[1][16 * qt + c16] = dl;
-            }
-            f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+            float sum = 0.f, dl = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NT; kt++)
                 if (kt < nt)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const float ds = s[kt][r] * (dp[kt][r] - dl);
-                        db[kt][r] += ds;
-                        dq = MFMA16(ks[kt][r], ds, dq);
+                        const float p = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+                        s[kt][r] = p;
+                        sum += p;
+                        dl += p * dp[kt][r];
                     }
+            sum = g4_sum(sum);
+            const float inv = __builtin_amdgcn_rcpf(sum);
+            dl = g4_sum(dl) * inv;
+            f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NT; kt++)
+                if (kt < nt) {
+                    float ds[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float pn = s[kt][r] * inv;
+                        ds[r] = pn * (dp[kt][r] - dl);
+                        db[kt][r] += ds[r];
+                        sc_p[(4 * g4 + r) * LDB + c16] = pn;
+                        sc_s[(4 * g4 + r) * LDB + c16] = ds[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) dq = MFMA16(ks[kt][r], ds[r], dq);
+                    // same wave wrote it; LDS serves one wave's requests in order
+                    const float4 pb = *reinterpret_cast<const float4*>(sc_p + c16 * LDB + 4 * g4);
+                    const float4 sb = *reinterpret_cast<const float4*>(sc_s + c16 * LDB + 4 * g4);
+                    dv[kt] = MFMA16(dos[qt][0], pb.x, dv[kt]); dk[kt] = MFMA16(qs[qt][0], sb.x, dk[kt]);
+                    dv[kt] = MFMA16(dos[qt][1], pb.y, dv[kt]); dk[kt] = MFMA16(qs[qt][1], sb.y, dk[kt]);
+                    dv[kt] = MFMA16(dos[qt][2], pb.z, dv[kt]); dk[kt] = MFMA16(qs[qt][2], sb.z, dk[kt]);
+                    dv[kt] = MFMA16(dos[qt][3], pb.w, dv[kt]); dk[kt] = MFMA16(qs[qt][3], sb.w, dk[kt]);
+                }
             *reinterpret_cast<float4*>(sm + (16 * qt + c16) * LDB + qo + 4 * g4) =
                 make_float4(dq[0] * scale, dq[1] * scale, dq[2] * scale, dq[3] * scale);
         }
     }
 #pragma unroll
     for (int kt = 0; kt < NT; kt++)
-        if (kt < nt)
+        if (kt < nt) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const float v = row16_sum(db[kt][r]);
                 const int key = 16 * kt + 4 * g4 + r;
                 if (c16 == 0 && key >= 1 && key < T) dbias_h[(int64_t)(start + key - 1) * NHEAD + head] += v;
             }
-    // ---- pass B: per key tile, plain scores (queries x keys): dK, dV
-#pragma unroll
-    for (int kt = 0; kt < NT; kt++) {
-        if (kt < nt) {
-            f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dvv = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int qt = 0; qt < NT; qt++) {
-                if (qt < nt) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-                    a = MFMA16(qf[qt].x, kf[kt].x, a); a = MFMA16(qf[qt].y, kf[kt].y, a);
-                    a = MFMA16(qf[qt].z, kf[kt].z, a); a = MFMA16(qf[qt].w, kf[kt].w, a);
-                    b = MFMA16(dof[qt].x, vf[kt].x, b); b = MFMA16(dof[qt].y, vf[kt].y, b);
-                    b = MFMA16(dof[qt].z, vf[kt].z, b); b = MFMA16(dof[qt].w, vf[kt].w, b);
-                    const float4 l4 = *reinterpret_cast<const float4*>(&stat[0][16 * qt + 4 * g4]);
-                    const float4 d4 = *reinterpret_cast<const float4*>(&stat[1][16 * qt + 4 * g4]);
-                    const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int qq = 16 * qt + 4 * g4 + r;
-                        float p = expf(a[r] + bias_c[kt] - lr[r]);
-                        if (qq >= T) p = 0.f;
-                        const float ds = p * (b[r] - dr[r]);
-                        dvv = MFMA16(dos[qt][r], p, dvv);
-                        dk = MFMA16(qs[qt][r], ds, dk);
-                    }
-                }
-            }
             float* row = sm + (16 * kt + c16) * LDB;
             *reinterpret_cast<float4*>(row + ko + 4 * g4) =
-                make_float4(dk[0] * scale, dk[1] * scale, dk[2] * scale, dk[3] * scale);
-            *reinterpret_cast<float4*>(row + vo + 4 * g4) = make_float4(dvv[0], dvv[1], dvv[2], dvv[3]);
+                make_float4(dk[kt][0] * scale, dk[kt][1] * scale, dk[kt][2] * scale, dk[kt][3] * scale);
+            *reinterpret_cast<float4*>(row + vo + 4 * g4) = make_float4(dv[kt][0], dv[kt][1], dv[kt][2], dv[kt][3]);
         }
-    }
     __syncthreads();
     for (int idx = threadIdx.x; idx < T * (3 * D / 4); idx += 512) {
         const int t = idx / (3 * D / 4), c = idx % (3 * D / 4);
@@ -856,11 +856,216 @@ __global__ __launch_bounds__(512) void k_attn_bwd_l(const float* __restrict__ QK
     }
 }
 
-// pet_config_set("attn_lds", v): 0 = one wave per (atom, head) straight from global memory for both passes,
-// 1 (default) = LDS-staged adjoint, global-memory forward (measured best: 1.16 / 3.13 ms vs 1.36 / 3.22 per step),
-// 2 = LDS-staged for both
-static int g_attn_lds = 1;
-void set_attn_lds(int v) { g_attn_lds = v < 0 ? 0 : (v > 2 ? 2 : v); }
+// ---- persistent adjoint with LDS-DMA prefetch ----------------------------------------------------------------
+// k_attn_bwd_l is bound by bytes in flight, not by HBM or issue slots: each workgroup loads (~40 KB), computes,
+// stores, and only ~1/4 of the resident workgroups are in their load phase at any time (measured 2.3 TB/s with
+// FETCH+WRITE = algorithmic bytes). Here a workgroup walks a strided list of atoms and, as soon as the current
+// atom's operand fragments are in registers, refills the SAME staging rows with the next atom's Q/K/V/dO rows
+// by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, no registers, not counted by the compiler's
+// s_waitcnt bookkeeping), so the next load is in flight for the whole compute phase. dQ/dK/dV leave straight
+// from the accumulator registers (64 B segments per lane quad). Serves atoms with at most `cap` tokens
+// (cap = 32: two 32-row staging buffers + the transpose scratch = 149 KB, one workgroup of 8 waves per CU; the
+// compiler may then use up to 256 registers, which the preloaded fragments need); the rest fall to k_attn_bwd_l.
+constexpr int SCP = 20;  // scratch row pitch: (4 g4 + r) * 20 + c16 hits 64 distinct banks
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ int attn_next_atom(int a, int step, int N, int cap, const int* __restrict__ rowptr) {
+    while (a < N && rowptr[a + 1] - rowptr[a] + 1 > cap) a += step;
+    return a;
+}
+__device__ __forceinline__ void attn_issue_rows(const float* __restrict__ QKV, const float* __restrict__ dAO,
+                                                const float* sm, int atom, int start, int T, int64_t E) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned base = (unsigned)(uintptr_t)sm;
+    for (int h = wave; h < 2 * T; h += 8) {  // one wave-instruction per half row (64 float4)
+        const int t = h >> 1;
+        const int64_t row = tok_row(t, T, E, atom, start);
+        const float* src = (h & 1) == 0 ? QKV + row * (3 * D) + 4 * lane
+                           : lane < 32  ? QKV + row * (3 * D) + 256 + 4 * lane
+                                        : dAO + row * D + 4 * (lane - 32);
+        glds16(src, __builtin_amdgcn_readfirstlane(base + (unsigned)(t * LDB + (h & 1) * 256) * 4u));
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void k_attn_bwd_a(const float* __restrict__ QKV, const float* __restrict__ dAO,
+                                                     const int* __restrict__ rowptr, const float* __restrict__ fc,
+                                                     float* __restrict__ dQKV, float* __restrict__ dbias_h,
+                                                     int64_t E, int N, float scale, int cap) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // 2 x [cap][LDB] rows, then [8 waves][2][16][SCP]
+    __shared__ float sbias_all[2][16 * NT];                     // log2 of the cutoff factor per key, per buffer
+    const int head = threadIdx.x >> 6;
+    const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head, doo = 3 * D + HD * head;
+    const float s2 = scale * LOG2E;
+    const int step = gridDim.x;
+    int atom = attn_next_atom(blockIdx.x, step, N, cap, rowptr);
+    float fc_pre = 1.f;  // thread t holds the cutoff factor of key t of the atom in flight
+    int it = 0;
+    if (atom < N) {
+        const int st0 = rowptr[atom], T0 = rowptr[atom + 1] - st0 + 1;
+        attn_issue_rows(QKV, dAO, sm, atom, st0, T0, E);
+        if (threadIdx.x >= 1 && (int)threadIdx.x < T0) fc_pre = fc[st0 + threadIdx.x - 1];
+    }
+    while (atom < N) {
+        const int start = rowptr[atom];
+        const int T = rowptr[atom + 1] - start + 1;
+        const int nt = (T + 15) >> 4;
+        const int lane = threadIdx.x & 63;
+        const int c16 = lane & 15, g4 = lane >> 4;
+        const float* buf = sm + (it & 1) * cap * LDB;  // this atom's rows; the other buffer takes the next atom's
+        float* sc_p = sm + 2 * cap * LDB + head * (2 * 16 * SCP);
+        float* sc_s = sc_p + 16 * SCP;
+        float* sbias = sbias_all[it & 1];
+        if (threadIdx.x < 16 * NT)
+            sbias[threadIdx.x] = (int)threadIdx.x >= T ? -INFINITY
+                                 : threadIdx.x == 0    ? 0.f
+                                                       : __builtin_amdgcn_logf(fmaxf(fc_pre, 1e-15f));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces (and last atom's stores) landed
+        __syncthreads();                                  // ... and everybody else's
+        // everyone is also done with the other buffer (read in the previous iteration's prologue): refill it now,
+        // so the next atom's rows are in flight during this atom's whole compute phase
+        const int nxt = attn_next_atom(atom + step, step, N, cap, rowptr);
+        fc_pre = 1.f;
+        if (nxt < N) {
+            const int st1 = rowptr[nxt], T1 = rowptr[nxt + 1] - st1 + 1;
+            attn_issue_rows(QKV, dAO, sm + ((it + 1) & 1) * cap * LDB, nxt, st1, T1, E);
+            if (threadIdx.x >= 1 && (int)threadIdx.x < T1) fc_pre = fc[st1 + threadIdx.x - 1];
+        }
+        float4 kf[NT], vf[NT], qf[NT], dof[NT];
+        float ks[NT][4], qs[NT][4], dos[NT][4];
+        float bias_r[NT][4], db[NT][4];
+        f32x4 dk[NT], dv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (t < nt) {
+                const int tc = 16 * t + c16;
+                const float* row = buf + tc * LDB;
+                const bool in = tc < T;  // rows beyond T hold stale data: read them anyway, select afterwards
+                const float4 k4 = *reinterpret_cast<const float4*>(row + ko + 4 * g4);
+                const float4 v4 = *reinterpret_cast<const float4*>(row + vo + 4 * g4);
+                const float4 q4 = *reinterpret_cast<const float4*>(row + qo + 4 * g4);
+                const float4 d4 = *reinterpret_cast<const float4*>(row + doo + 4 * g4);
+                kf[t] = make_float4(in ? k4.x : 0.f, in ? k4.y : 0.f, in ? k4.z : 0.f, in ? k4.w : 0.f);
+                vf[t] = make_float4(in ? v4.x : 0.f, in ? v4.y : 0.f, in ? v4.z : 0.f, in ? v4.w : 0.f);
+                qf[t] = make_float4(in ? q4.x * s2 : 0.f, in ? q4.y * s2 : 0.f, in ? q4.z * s2 : 0.f,
+                                    in ? q4.w * s2 : 0.f);
+                dof[t] = make_float4(in ? d4.x : 0.f, in ? d4.y : 0.f, in ? d4.z : 0.f, in ? d4.w : 0.f);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int tr = 16 * t + 4 * g4 + r;
+                    const float* rr = buf + tr * LDB;
+                    const bool inr = tr < T;
+                    const float k1 = rr[ko + c16], q1 = rr[qo + c16], d1 = rr[doo + c16];
+                    ks[t][r] = inr ? k1 : 0.f;
+                    qs[t][r] = inr ? q1 : 0.f;
+                    dos[t][r] = inr ? d1 : 0.f;
+                    bias_r[t][r] = sbias[tr];
+                    db[t][r] = 0.f;
+                    dk[t][r] = 0.f;
+                    dv[t][r] = 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < NT; qt++) {
+            if (qt < nt) {
+                f32x4 s[NT], dp[NT];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NT; kt++) {
+                    if (kt < nt) {
+                        f32x4 a = {bias_r[kt][0], bias_r[kt][1], bias_r[kt][2], bias_r[kt][3]};
+                        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                        a = MFMA16(kf[kt].x, qf[qt].x, a); b = MFMA16(vf[kt].x, dof[qt].x, b);
+                        a = MFMA16(kf[kt].y, qf[qt].y, a); b = MFMA16(vf[kt].y, dof[qt].y, b);
+                        a = MFMA16(kf[kt].z, qf[qt].z, a); b = MFMA16(vf[kt].z, dof[qt].z, b);
+                        a = MFMA16(kf[kt].w, qf[qt].w, a); b = MFMA16(vf[kt].w, dof[qt].w, b);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) mx = fmaxf(mx, a[r]);
+                        s[kt] = a;
+                        dp[kt] = b;
+                    }
+                }
+                mx = g4_max(mx);
+                float sum = 0.f, dl = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NT; kt++)
+                    if (kt < nt)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float p = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+                            s[kt][r] = p;
+                            sum += p;
+                            dl += p * dp[kt][r];
+                        }
+                sum = g4_sum(sum);
+                const float inv = __builtin_amdgcn_rcpf(sum);
+                dl = g4_sum(dl) * inv;
+                f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < NT; kt++)
+                    if (kt < nt) {
+                        float ds[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float pn = s[kt][r] * inv;
+                            ds[r] = pn * (dp[kt][r] - dl);
+                            db[kt][r] += ds[r];
+                            sc_p[(4 * g4 + r) * SCP + c16] = pn;
+                            sc_s[(4 * g4 + r) * SCP + c16] = ds[r];
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; r++) dq = MFMA16(ks[kt][r], ds[r], dq);
+                        const float4 pb = *reinterpret_cast<const float4*>(sc_p + c16 * SCP + 4 * g4);
+                        const float4 sb = *reinterpret_cast<const float4*>(sc_s + c16 * SCP + 4 * g4);
+                        dv[kt] = MFMA16(dos[qt][0], pb.x, dv[kt]); dk[kt] = MFMA16(qs[qt][0], sb.x, dk[kt]);
+                        dv[kt] = MFMA16(dos[qt][1], pb.y, dv[kt]); dk[kt] = MFMA16(qs[qt][1], sb.y, dk[kt]);
+                        dv[kt] = MFMA16(dos[qt][2], pb.z, dv[kt]); dk[kt] = MFMA16(qs[qt][2], sb.z, dk[kt]);
+                        dv[kt] = MFMA16(dos[qt][3], pb.w, dv[kt]); dk[kt] = MFMA16(qs[qt][3], sb.w, dk[kt]);
+                    }
+                const int tq = 16 * qt + c16;
+                if (tq < T)
+                    *reinterpret_cast<float4*>(dQKV + tok_row(tq, T, E, atom, start) * (3 * D) + qo + 4 * g4) =
+                        make_float4(dq[0] * scale, dq[1] * scale, dq[2] * scale, dq[3] * scale);
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < NT; kt++)
+            if (kt < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float v = row16_sum(db[kt][r]);
+                    const int key = 16 * kt + 4 * g4 + r;
+                    // sole owner of this (edge, head); the no-return atomic keeps a load (and its vmcnt wait, which
+                    // would also wait for the DMA) out of the compute phase
+                    if (c16 == 0 && key >= 1 && key < T)
+                        __hip_atomic_fetch_add(dbias_h + (int64_t)(start + key - 1) * NHEAD + head, v,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const int tk = 16 * kt + c16;
+                if (tk < T) {
+                    float* out = dQKV + tok_row(tk, T, E, atom, start) * (3 * D);
+                    *reinterpret_cast<float4*>(out + ko + 4 * g4) =
+                        make_float4(dk[kt][0] * scale, dk[kt][1] * scale, dk[kt][2] * scale, dk[kt][3] * scale);
+                    *reinterpret_cast<float4*>(out + vo + 4 * g4) = make_float4(dv[kt][0], dv[kt][1], dv[kt][2], dv[kt][3]);
+                }
+            }
+        atom = nxt;
+        it++;
+    }
+}
+
+// pet_config_set("attn_lds", v) selects the attention kernels:
+//   0 = one wave per (atom, head) straight from global memory, forward and adjoint
+//   1 = adjoint staged through LDS per atom (k_attn_bwd_l), global-memory forward
+//   2 = LDS-staged forward and adjoint
+//   3 (default) = persistent adjoint with LDS-DMA prefetch (k_attn_bwd_a), global-memory forward
+// measured per launch on 8 x 10k-atom boxes: adjoint 3.2 (0, two-pass) / 2.5 (1) / 2.0 ms (3); forward 1.0 (0) / 1.2 (2)
+static int g_attn_lds = 3;
+void set_attn_lds(int v) { g_attn_lds = v < 0 ? 0 : (v > 3 ? 3 : v); }
 
 // Atoms are served by the instantiation that matches their own tile count (registers / LDS, hence waves in
 // flight, scale with NT): one launch per tile count up to the batch maximum, the others exit at once.
@@ -891,12 +1096,28 @@ bool attn_bwd_preload(int nt, const float* QKV, const float* dAO, const Graph& g
     if (nt > 4) return false;
     const int N = (int)g.n_nodes;
     if (g_attn_lds) {
+        int t_skip = 0, first = 1;
+        if (g_attn_lds == 3) {  // persistent LDS-DMA kernel for every atom with at most `cap` tokens
+            constexpr int cap = 32;
+            static int n_cu = 0;
+            if (!n_cu) {
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+            }
+            const size_t lds = ((size_t)2 * cap * LDB + 8 * 2 * 16 * SCP) * sizeof(float);  // 149 KB: one per CU
+            allow_big_lds(k_attn_bwd_a<2>, lds);
+            const int grid = N < n_cu ? N : n_cu;
+            k_attn_bwd_a<2><<<grid, 512, lds, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, cap);
+            t_skip = cap;
+            first = 3;
+        }
 #define PET_ATTN_BWD_L(K)                                                                                      \
-    if (nt >= K) {                                                                                             \
+    if (nt >= K && K >= first) {                                                                               \
         const size_t lds = (size_t)16 * K * LDB * sizeof(float);                                               \
         allow_big_lds(k_attn_bwd_l<K>, lds);                                                                   \
         k_attn_bwd_l<K><<<N, 512, lds, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale,     \
-                                              nt > 1 ? K : 0);                                                 \
+                                              nt > 1 ? K : 0, t_skip);                                         \
     }
         PET_ATTN_BWD_L(1) PET_ATTN_BWD_L(2) PET_ATTN_BWD_L(3) PET_ATTN_BWD_L(4)
 #undef PET_ATTN_BWD_L

@@ -19,17 +19,18 @@ for sec in sections[1:]:
         if len(parts) < 3:
             continue
         try:
-            v = float(parts[-1]); int(parts[-2])
+            v = float(parts[-1]); ncalls = int(parts[-2])
         except ValueError:
             continue
         name = " ".join(parts[:-2])
         vals.setdefault(name, {})[header[-1]] = v
-out = {"source": f"{src} (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --boxes 2); "
+        vals[name]["calls"] = ncalls
+out = {"source": f"{src} (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py, default workload); "
                  "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md",
        "workload_edges": edges, "kernels": {}}
 for name, v in vals.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v and name.startswith("k_"):
-        out["kernels"][name] = {"fetch_kib_raw": v["FETCH_SIZE"], "write_kib_raw": v["WRITE_SIZE"],
+        out["kernels"][name] = {"calls": v["calls"], "fetch_kib_raw": v["FETCH_SIZE"], "write_kib_raw": v["WRITE_SIZE"],
                                 "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024}
 json.dump(out, open("profiles/r01_traffic.json", "w"), indent=1)
 print(len(out["kernels"]), "kernels")
