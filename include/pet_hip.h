@@ -230,9 +230,15 @@ int pet_profile_select(const char* stage);
 int pet_profile_reset(void);
 int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int64_t* calls,
                        double* flops, double* bytes, int* n_entries);
-/* Runtime switches used by tests / the benchmark: "side_stream" (1 = node-feature chain on a
- * second HIP stream, default), "trr" (1 = register-resident stage kernels, default; 0 = the
- * LDS-tile kernels kept for A/B comparison). */
+/* Runtime switches used by tests / the benchmark (every setting meets the same parity bar):
+ *   "side_stream" 1 = node-feature chain on a second HIP stream (default)
+ *   "trr"         1 = register-resident stage kernels (default); 0 = the LDS-tile kernels
+ *   "bf16x6"      1 = TRR / combination GEMMs as 3-way-split bf16 MFMA, fp32 accuracy (default); 0 = fp32 MFMA
+ *   "so_bf16x6"   the same choice for the generic GEMM of the second-order (training) pass
+ *   "attn_lds"    attention kernels: 0 global-memory, 1 per-atom LDS-staged adjoint, 2 LDS-staged forward and
+ *                 adjoint, 3 persistent LDS-DMA adjoint (default)
+ *   "soap_mfma"   1 = SOAP-BPNN LayerNorm + MLP tail on MFMA (default)
+ * Unknown keys return PET_ERR_ARGUMENT. */
 int pet_config_set(const char* key, int value);
 
 #ifdef __cplusplus

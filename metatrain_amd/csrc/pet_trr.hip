@@ -387,22 +387,19 @@ __global__ __launch_bounds__(256) void k_emlp_b(const float* __restrict__ X1, co
             vg[0][4 * q] = bv[q].x; vg[0][4 * q + 1] = bv[q].y; vg[0][4 * q + 2] = bv[q].z; vg[0][4 * q + 3] = bv[q].w;
             vg[1][4 * q] = bg[q].x; vg[1][4 * q + 1] = bg[q].y; vg[1][4 * q + 2] = bg[q].z; vg[1][4 * q + 3] = bg[q].w;
         }
-        {   // unconditional (the last chunk re-reads its own): a guarded load turns the carried registers into
-            // phi copies, ~100 v_accvgpr_mov per chunk in a kernel whose limit is VALU issue slots
-            const int hn = hc + 1 < NC ? hc + 1 : hc;
+        if (hc + 1 < NC) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                bv[q] = *reinterpret_cast<const float4*>(bin + 32 * hn + 8 * q + 4 * L.h);
-                bg[q] = *reinterpret_cast<const float4*>(bin + DFF + 32 * hn + 8 * q + 4 * L.h);
+                bv[q] = *reinterpret_cast<const float4*>(bin + 32 * (hc + 1) + 8 * q + 4 * L.h);
+                bg[q] = *reinterpret_cast<const float4*>(bin + DFF + 32 * (hc + 1) + 8 * q + 4 * L.h);
             }
         }
 #pragma unroll
         for (int kb = 0; kb < 8; kb++) {
             WBlk<2>& wb = ring[kb & 3];
             mfma6<2>(vg, wb, xs.h[kb], xs.m[kb], xs.l[kb]);
-            int nb = 8 * hc + kb + 4;  // refill this slot with the block four steps ahead (may be next chunk's)
-            nb = nb < 8 * NC ? nb : nb - 8;  // past the end: any valid block, never used
-            ld_blk<2>(wb, win, widx(nb), TS);
+            const int nb = 8 * hc + kb + 4;  // refill this slot with the block four steps ahead (may be next chunk's)
+            if (nb < 8 * NC) ld_blk<2>(wb, win, widx(nb), TS);
         }
         float4 u[4];
 #pragma unroll
