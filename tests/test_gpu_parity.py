@@ -189,6 +189,39 @@ def test_batch_of_systems_vs_oracle_and_per_system_sum(rt, model, dev):
     assert relmax(gcell.cpu().numpy(), gc.numpy()) < 2 * TOL
 
 
+@pytest.mark.parametrize("spacing,above63", [(1.9, False), (1.62, True)])
+def test_neighbour_count_buckets_against_oracle(rt, model, dev, spacing, above63):
+    """One open-boundary system whose neighbour counts run from 4 to 57 (every bucketed attention
+    instantiation -- 1..4 key tiles, the persistent LDS-DMA adjoint for <= 32 tokens and the per-atom staged one
+    above -- serves some atoms of the same call) or to 80 (more than 63 neighbours: the general kernels)."""
+    hypers = model.hypers
+    gen = torch.Generator().manual_seed(11)
+    grid = torch.stack(torch.meshgrid(*[torch.arange(5.0)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    dense = spacing * grid + 0.25 * (torch.rand(grid.shape, generator=gen) - 0.5)       # 125 atoms, 0.15 - 0.23 / A^3
+    dilute = 10.0 + 2.9 * grid[:64 + 16] + 0.4 * (torch.rand((80, 3), generator=gen) - 0.5)
+    pos = torch.cat([dense, dilute]).float()
+    z = torch.tensor([1, 6, 7, 8])[torch.randint(0, 4, (len(pos),), generator=gen)].int()
+    cell = torch.zeros(3, 3)
+    i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [False] * 3, hypers["cutoff"])
+    i, j, s = torch.tensor(i), torch.tensor(j), torch.tensor(s)
+    counts = torch.bincount(i, minlength=len(pos))
+    assert (counts.max() > 63) == above63 and counts.min() < 15 and ((counts > 31) & (counts < 48)).any()
+    assert above63 or (counts >= 48).any()
+    sysidx = torch.zeros(len(pos), dtype=torch.int32)
+    graph = rt.HipGraph(model, pos.to(dev), cell[None].to(dev), i.to(dev), j.to(dev), s.to(dev), z.to(dev),
+                        sysidx.to(dev))
+    assert graph.max_neighbors == int(counts.max())
+    fw = rt.HipForward(model, graph)
+    atomic = fw.forward()
+    grad = fw.backward(torch.ones_like(atomic))
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    p64 = pos.double().requires_grad_(True)
+    ref = opet.pet_atomic_energies(params, hypers, p64, cell[None].double(), i, j, s.long(), z, sysidx.long())
+    (gp,) = torch.autograd.grad(ref.sum(), p64)
+    assert relmax(atomic.cpu().numpy(), ref.detach().numpy().ravel()) < TOL
+    assert relmax(grad.cpu().numpy(), gp.numpy()) < TOL
+
+
 def test_weighted_seed_vector_backward(rt, model, dev):
     """pet_backward with a non-trivial dL/d(atomic) seed (what autograd hands over when the
     loss is not the plain energy sum): linearity check against two unit-seed calls."""
