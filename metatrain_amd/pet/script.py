@@ -87,3 +87,65 @@ class EnergyAndForces(torch.nn.Module):
         g = grads[0]
         assert g is not None
         return energies, -g
+
+
+class ExportedEnergyModel(torch.nn.Module):
+    """Tensor-level equivalent of what ``PET.forward`` does around the backbone at evaluation time
+    (``pet/model.py:592-660``), scriptable end to end:
+
+    * ``scale``: the scaler's per-target factor (``utils/scaler``: prediction * scale),
+    * ``composition``: the additive composition model's per-species energies, indexed by atomic number
+      (``utils/additive/composition.py``: + sum_i w[Z_i]); not differentiated (it does not depend on positions),
+    * ``selected_atoms``: optional bool / index mask of the atoms that contribute to the per-system sums and that
+      are returned per atom (metatomic's ``selected_atoms``); forces are still returned for every atom,
+    * forces ``-dE/dR`` and, on request, the stress ``(1/V) dE/d(strain)`` assembled from ``dE/dR`` and
+      ``dE/dcell`` of the HIP backward (``utils/evaluate_model.py`` strain trick, done analytically:
+      ``dE/deps = R^T dE/dR + h^T dE/dh``).
+
+    ``forward`` returns ``(energies [S], forces [N, 3], stress [S, 3, 3] or empty, per_atom [n_selected])``."""
+
+    def __init__(self, core, scale: float = 1.0, composition: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.pet = PETScriptModule(core)
+        self.scale = float(scale)
+        self.register_buffer("composition", composition.detach().clone().to(torch.float32)
+                             if composition is not None else torch.zeros(0, dtype=torch.float32))
+
+    def forward(self, positions: torch.Tensor, cells: torch.Tensor, centers: torch.Tensor, neighbors: torch.Tensor,
+                cell_shifts: torch.Tensor, species: torch.Tensor, system_indices: torch.Tensor,
+                selected_atoms: Optional[torch.Tensor] = None, with_stress: bool = False):
+        positions = positions.detach().requires_grad_(True)
+        cells = cells.detach().requires_grad_(with_stress)
+        atomic = self.pet(positions, cells, centers, neighbors, cell_shifts, species, system_indices)[:, 0]
+        atomic = atomic * self.scale
+        keep = torch.ones(positions.shape[0], dtype=torch.bool, device=positions.device)
+        if selected_atoms is not None:
+            if selected_atoms.dtype == torch.bool:
+                keep = selected_atoms.to(positions.device)
+            else:
+                keep = torch.zeros_like(keep).index_fill(0, selected_atoms.to(positions.device, torch.long), True)
+        masked = torch.where(keep, atomic, torch.zeros_like(atomic))
+        sysl = system_indices.to(torch.long)
+        energies = torch.zeros(cells.shape[0], dtype=atomic.dtype, device=atomic.device).index_add(0, sysl, masked)
+        wrt = [positions, cells] if with_stress else [positions]
+        grads = torch.autograd.grad([energies.sum()], wrt)
+        g_pos = grads[0]
+        assert g_pos is not None
+        stress = torch.zeros((0, 3, 3), dtype=atomic.dtype, device=atomic.device)
+        if with_stress:
+            g_cell = grads[1]
+            assert g_cell is not None
+            outer = positions.detach().unsqueeze(2) * g_pos.unsqueeze(1)  # [N, 3, 3]: R_a dE/dR_b per atom
+            virial = torch.zeros((cells.shape[0], 3, 3), dtype=atomic.dtype, device=atomic.device).index_add(
+                0, sysl, outer)
+            virial = virial + torch.matmul(cells.detach().transpose(1, 2), g_cell)
+            volume = torch.abs(torch.linalg.det(cells.detach()))
+            stress = virial / volume.clamp_min(1e-30).reshape(-1, 1, 1)
+        per_atom = atomic.detach()
+        energies = energies.detach()
+        if self.composition.numel() > 0:
+            base = self.composition[species.to(torch.long)].to(atomic.dtype)
+            per_atom = per_atom + base
+            energies = energies + torch.zeros_like(energies).index_add(
+                0, sysl, torch.where(keep, base, torch.zeros_like(base)))
+        return energies, -g_pos, stress, per_atom[keep]

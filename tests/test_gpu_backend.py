@@ -14,6 +14,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
+def relmax(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max() / np.abs(b).max())
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available()
@@ -211,3 +215,46 @@ def test_torchscript_module_energy_and_forces(golden_dir):
     e2, _ = mod(t("in_positions").float(), t("in_cells").float(), t("in_centers"), t("in_neighbors"),
                 t("in_cell_shifts"), t("in_species"), t("in_system_indices"))
     assert torch.equal(e2, energies)
+
+
+def test_exported_model_scaler_composition_selected_atoms_and_stress():
+    """SURVEY §8(f)-2, the evaluation-time wrapper (pet/model.py:592-660): scaler factor, composition energies,
+    selected_atoms, forces and the strain derivative, scripted, against the fp64 oracle with the strain trick."""
+    from metatrain_amd.pet import default_hypers, script
+
+    dev = torch.device("cuda:0")
+    hypers = default_hypers()
+    types = [1, 6, 7, 8]
+    p32 = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    p64 = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float64)
+    pos, z, cell = opet.random_box(48, seed=31)
+    cell = cell.clone(); cell[1, 0] = 0.8; cell[2, 0] = -0.5
+    i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, hypers["cutoff"])
+    i, j, s = torch.tensor(i), torch.tensor(j), torch.tensor(s)
+    sysidx = torch.zeros(48, dtype=torch.int32)
+    comp = torch.zeros(9); comp[[1, 6, 7, 8]] = torch.tensor([-0.5, -37.8, -54.6, -75.1])
+    scale = 2.5
+    keep = torch.arange(48) % 3 != 0
+    mod = torch.jit.script(script.ExportedEnergyModel(script.make_core(hypers, types, p32, "energy"), scale, comp)).to(dev)
+    args = (pos.to(dev), cell[None].to(dev), i.to(dev), j.to(dev), s.to(dev), z.to(dev), sysidx.to(dev))
+    e_all, f_all, stress, per_atom = mod(*args, None, True)
+    e_sel, f_sel, none_stress, per_sel = mod(*args, keep.to(dev), False)
+    assert none_stress.shape[0] == 0 and per_sel.shape[0] == int(keep.sum())
+
+    eps = torch.zeros(3, 3, dtype=torch.float64, requires_grad=True)
+    r64 = pos.double().requires_grad_(True)
+    strain = torch.eye(3, dtype=torch.float64) + eps
+    atomic = opet.pet_atomic_energies(p64, hypers, r64 @ strain, (cell.double() @ strain)[None], i, j, s.long(), z,
+                                      sysidx.long())[:, 0] * scale
+    g_r, g_eps = torch.autograd.grad(atomic.sum(), [r64, eps], retain_graph=True)
+    base = comp.double()[z.long()]
+    vol = float(torch.det(cell.double()).abs())
+    assert abs(float(e_all[0]) - float(atomic.sum() + base.sum())) / abs(float(atomic.sum() + base.sum())) < TOL
+    assert relmax(-f_all.cpu().numpy(), g_r.numpy()) < TOL
+    assert relmax(stress[0].cpu().numpy(), (g_eps / vol).numpy()) < 2 * TOL
+    assert relmax(per_atom.cpu().numpy(), (atomic + base).detach().numpy()) < TOL
+    (g_sel,) = torch.autograd.grad(atomic[keep].sum(), [r64])
+    e_ref = float(atomic[keep].sum() + base[keep].sum())
+    assert abs(float(e_sel[0]) - e_ref) / abs(e_ref) < TOL
+    assert relmax(-f_sel.cpu().numpy(), g_sel.numpy()) < TOL
+    assert relmax(per_sel.cpu().numpy(), (atomic + base)[keep].detach().numpy()) < TOL

@@ -37,6 +37,20 @@ def test_scripts_and_round_trips_through_jit_save(core):
     assert "atomic_energies" in str(back.pet.graph)
 
 
+def test_exported_energy_model_scripts_with_optional_arguments(core):
+    from metatrain_amd.pet import script
+
+    comp = torch.zeros(9)
+    comp[[1, 6, 7, 8]] = torch.tensor([-0.5, -37.8, -54.6, -75.1])
+    mod = torch.jit.script(script.ExportedEnergyModel(core[0], 2.5, comp))
+    buf = io.BytesIO()
+    torch.jit.save(mod, buf)
+    buf.seek(0)
+    back = torch.jit.load(buf)
+    assert float(back.scale) == 2.5 and torch.equal(back.composition, comp)
+    assert "selected_atoms" in str(back.forward.schema)
+
+
 def test_cpu_tensors_are_refused(core):
     from metatrain_amd.pet import script
 
