@@ -671,6 +671,199 @@ __global__ __launch_bounds__(256) void k_soap_expand_bwd(SoapDims d, const float
 }
 
 // ---------------------------------------------------------------------------------------------
+// a17, second generation: no workgroup barriers, every lane busy.
+//   k_soap_expand_w      one WAVE per atom: lanes 0..31 run the spherical-harmonic levels of one pair each, lanes
+//                        32..63 that pair's radial splines, into wave-private LDS; then every lane owns up to
+//                        MAXI (lm, n) items and sums them over the pairs with the C = 4 species channels as one
+//                        float4 accumulator (the first generation looped 1120 scalar coefficients x pairs behind
+//                        three __syncthreads, one workgroup per atom, and re-read the species weight from global).
+//   k_soap_expand_bwd_p  one LANE per pair, flat over the CSR: the pair's Y_lm levels (with gradients) and splines
+//                        stay in registers, dC rows of the centre atom come through L1 (the ~26 pairs of an atom
+//                        sit in the same one or two waves), no LDS, no reduction, no barrier.
+// Both need C == 4 (float4 channels; Alchemical default and 4-species legacy) and at most 64 * MAXI items;
+// otherwise soap_fwd / soap_bwd fall back to the first-generation kernels (pet_config_set("soap_pair", 0) too).
+// ---------------------------------------------------------------------------------------------
+constexpr int MAXI = 8;
+static int g_soap_pair = 1;
+void set_soap_pair(int v) { g_soap_pair = v ? 1 : 0; }
+
+template <int LMAX>
+struct ShLevels {  // the recurrences of sh_chain, all m-chains advanced one l at a time
+    float x, y, z, ir;
+    float cm[LMAX + 1], sm[LMAX + 1], q1[LMAX + 1], q2[LMAX + 1], dq1[LMAX + 1], dq2[LMAX + 1];
+    __device__ __forceinline__ void init(float x_, float y_, float z_, float ir_) {
+        x = x_; y = y_; z = z_; ir = ir_;
+        cm[0] = 1.f; sm[0] = 0.f;
+        float qmm = 1.f;
+#pragma unroll
+        for (int m = 0; m <= LMAX; m++) {
+            if (m > 0) {
+                cm[m] = x * cm[m - 1] - y * sm[m - 1];
+                sm[m] = x * sm[m - 1] + y * cm[m - 1];
+                qmm *= -(2 * m - 1);
+            }
+            q1[m] = qmm; q2[m] = 0.f; dq1[m] = 0.f; dq2[m] = 0.f;
+        }
+    }
+    // level l (compile-time after unrolling): Y / G[mi], mi = l + m (cos) and l - m (sin)
+    template <bool GRAD>
+    __device__ __forceinline__ void level(int l, const float* __restrict__ shn, int L, float* Y, float* Gx, float* Gy,
+                                          float* Gz) {
+#pragma unroll
+        for (int m = 0; m <= LMAX; m++) {
+            if (m > l) continue;
+            float q, dq;
+            if (l == m) { q = q1[m]; dq = 0.f; }
+            else if (l == m + 1) { q = (2 * m + 1) * z * q1[m]; dq = (2 * m + 1) * q1[m]; }
+            else {
+                const float inv = 1.0f / (l - m);
+                q = ((2 * l - 1) * z * q1[m] - (l + m - 1) * q2[m]) * inv;
+                dq = ((2 * l - 1) * (q1[m] + z * dq1[m]) - (l + m - 1) * dq2[m]) * inv;
+            }
+            const float f = shn[l * (L + 1) + m];
+            if (m == 0) {
+                Y[l] = f * q;
+                if (GRAD) {
+                    const float gz = f * dq, dot = z * gz;
+                    Gx[l] = (-x * dot) * ir; Gy[l] = (-y * dot) * ir; Gz[l] = (gz - z * dot) * ir;
+                }
+            } else {
+                const float fq = f * q, fm = fq * m, cp = cm[m - 1], sp = sm[m - 1];
+                Y[l + m] = fq * cm[m];
+                Y[l - m] = fq * sm[m];
+                if (GRAD) {
+                    float gx = fm * cp, gy = -fm * sp, gz = f * dq * cm[m];
+                    float dot = x * gx + y * gy + z * gz;
+                    Gx[l + m] = (gx - x * dot) * ir; Gy[l + m] = (gy - y * dot) * ir; Gz[l + m] = (gz - z * dot) * ir;
+                    gx = fm * sp; gy = fm * cp; gz = f * dq * sm[m];
+                    dot = x * gx + y * gy + z * gz;
+                    Gx[l - m] = (gx - x * dot) * ir; Gy[l - m] = (gy - y * dot) * ir; Gz[l - m] = (gz - z * dot) * ir;
+                }
+            }
+            if (l > m) { q2[m] = q1[m]; dq2[m] = dq1[m]; }
+            q1[m] = q; dq1[m] = dq;
+            if (l == m) { q2[m] = 0.f; dq2[m] = 0.f; }
+        }
+    }
+};
+
+template <int LMAX>
+__global__ __launch_bounds__(256) void k_soap_expand_w(SoapDims d, const float4* __restrict__ geo,
+                                                       const int* __restrict__ rowptr, const int* __restrict__ sp_nbr,
+                                                       const float* __restrict__ table, const float* __restrict__ shn,
+                                                       const int* __restrict__ ilut, const float* __restrict__ spw,
+                                                       float* __restrict__ Cf, int N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= N) return;
+    const int ld = (d.NLM + d.F + 4 + 3) & ~3;   // row: Y[NLM] | R fc [F] | species weights [4], 16 B aligned
+    float* rows = smem + (size_t)wave * 32 * ld;
+    const int wo = ld - 4;
+    const int p0 = rowptr[i], p1 = rowptr[i + 1];
+    float4 acc[MAXI];
+    int code[MAXI];
+#pragma unroll
+    for (int k = 0; k < MAXI; k++) {
+        acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int it = lane + 64 * k;
+        code[k] = it < d.ITEMS ? ilut[it] : -1;
+    }
+    for (int base = p0; base < p1; base += 32) {
+        const int npc = min(32, p1 - base);
+        const int pp = lane & 31;
+        if (pp < npc) {
+            const float4 g = geo[base + pp];
+            const float r = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
+            const float ir = r > 0.f ? 1.0f / r : 0.f;
+            float* row = rows + pp * ld;
+            if (lane < 32) {
+                ShLevels<LMAX> sh;
+                sh.init(g.x * ir, g.y * ir, g.z * ir, ir);
+#pragma unroll
+                for (int l = 0; l <= LMAX; l++) {
+                    if (l > d.L) break;
+                    float Y[2 * LMAX + 1];
+                    sh.template level<false>(l, shn, d.L, Y, nullptr, nullptr, nullptr);
+#pragma unroll
+                    for (int mi = 0; mi < 2 * LMAX + 1; mi++)
+                        if (mi <= 2 * l) row[l * l + mi] = Y[mi];
+                }
+                *reinterpret_cast<float4*>(row + wo) = *reinterpret_cast<const float4*>(spw + sp_nbr[base + pp] * 4);
+            } else {
+                const float fc = shifted_cosine(r, d.rc, d.width, nullptr);
+                for (int f = 0; f < d.F; f++) radial_one(d, table, f, r, fc, 0.f, row + d.NLM + f, nullptr);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // same wave wrote the rows; LDS serves a wave's requests in order
+        for (int q = 0; q < npc; q++) {
+            const float* row = rows + q * ld;
+            const float4 w4 = *reinterpret_cast<const float4*>(row + wo);
+#pragma unroll
+            for (int k = 0; k < MAXI; k++) {
+                if (code[k] < 0) continue;
+                const float yr = row[code[k] & 255] * row[d.NLM + ((code[k] >> 8) & 255)];
+                acc[k].x += yr * w4.x; acc[k].y += yr * w4.y; acc[k].z += yr * w4.z; acc[k].w += yr * w4.w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int k = 0; k < MAXI; k++)
+        if (code[k] >= 0) *reinterpret_cast<float4*>(Cf + (size_t)i * d.NCOEF + (code[k] >> 16)) = acc[k];
+}
+
+template <int LMAX>
+__global__ __launch_bounds__(256) void k_soap_expand_bwd_p(SoapDims d, const float4* __restrict__ geo,
+                                                           const int* __restrict__ ctr, const int* __restrict__ sp_nbr,
+                                                           const float* __restrict__ table,
+                                                           const float* __restrict__ shn, const float* __restrict__ spw,
+                                                           const float* __restrict__ dCf, float4* __restrict__ dv,
+                                                           int64_t E) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= E) return;
+    const float4 g = geo[p];
+    const float r = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
+    const float ir = r > 0.f ? 1.0f / r : 0.f;
+    const float ux = g.x * ir, uy = g.y * ir, uz = g.z * ir;
+    float dfc;
+    const float fc = shifted_cosine(r, d.rc, d.width, &dfc);
+    const float4 w4 = *reinterpret_cast<const float4*>(spw + sp_nbr[p] * 4);
+    const float* dC = dCf + (size_t)ctr[p] * d.NCOEF;
+    ShLevels<LMAX> sh;
+    sh.init(ux, uy, uz, ir);
+    float ax = 0.f, ay = 0.f, az = 0.f, along = 0.f;  // `along` multiplies the unit vector
+#pragma unroll
+    for (int l = 0; l <= LMAX; l++) {
+        if (l > d.L) break;
+        float Y[2 * LMAX + 1], Gx[2 * LMAX + 1], Gy[2 * LMAX + 1], Gz[2 * LMAX + 1], T[2 * LMAX + 1];
+        sh.template level<true>(l, shn, d.L, Y, Gx, Gy, Gz);
+#pragma unroll
+        for (int mi = 0; mi < 2 * LMAX + 1; mi++) T[mi] = 0.f;
+        const int nl = d.n_per_l[l];
+        const float* dCl = dC + d.coef_off[l];
+        for (int n = 0; n < nl; n++) {
+            float R, dR;
+            radial_one(d, table, d.rad_off[l] + n, r, fc, dfc, &R, &dR);
+#pragma unroll
+            for (int mi = 0; mi < 2 * LMAX + 1; mi++) {
+                if (mi > 2 * l) continue;
+                const float4 c = *reinterpret_cast<const float4*>(dCl + (size_t)(mi * nl + n) * 4);
+                const float A = c.x * w4.x + c.y * w4.y + c.z * w4.z + c.w * w4.w;
+                along += A * dR * Y[mi];
+                T[mi] += A * R;
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2 * LMAX + 1; mi++) {
+            if (mi > 2 * l) continue;
+            ax += T[mi] * Gx[mi]; ay += T[mi] * Gy[mi]; az += T[mi] * Gz[mi];
+        }
+    }
+    dv[p] = make_float4(ax + along * ux, ay + along * uy, az + along * uz, 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 struct SoapWs {
@@ -776,6 +969,9 @@ static int soap_finalize(SoapModel& m, hipStream_t st) {
     return PET_OK;
 }
 
+static bool soap_pair_ok(const SoapDims& d) {
+    return g_soap_pair && d.C == 4 && d.ITEMS <= 64 * MAXI && d.NLM <= 255 && d.F <= 255 && d.NCOEF < 32768;
+}
 static size_t lds_expand(const SoapDims& d) { return (size_t)PC * (d.NLM + d.F + 8 + 1) * 4; }
 static size_t lds_expand_bwd(const SoapDims& d) {
     return ((size_t)d.NCOEF + (size_t)PC * (4 * d.NLM + 2 * d.F + 8 + 1)) * 4;
@@ -793,8 +989,20 @@ static int soap_fwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
     allow_big_lds(k_soap_tail, lds_tail(d));
     {
         ProfScope ps("soap_expand", st, 2.0 * (double)g.n_edges * d.NCOEF, (double)g.n_edges * 20 + (double)N * d.NCOEF * 4);
-        k_soap_expand<<<N, 256, lds_expand(d), st>>>(d, g.geo, g.rowptr, g.sp_nbr, m.table, m.shnorm, m.coef_lut,
-                                                     m.species_w, w.Cf);
+        if (soap_pair_ok(d)) {
+            const size_t lds = (size_t)4 * 32 * ((d.NLM + d.F + 4 + 3) & ~3) * 4;
+            allow_big_lds(k_soap_expand_w<6>, lds);
+            allow_big_lds(k_soap_expand_w<MAXL>, lds);
+            if (d.L <= 6)
+                k_soap_expand_w<6><<<cdiv(N, 4), 256, lds, st>>>(d, g.geo, g.rowptr, g.sp_nbr, m.table, m.shnorm,
+                                                                  m.item_lut, m.species_w, w.Cf, N);
+            else
+                k_soap_expand_w<MAXL><<<cdiv(N, 4), 256, lds, st>>>(d, g.geo, g.rowptr, g.sp_nbr, m.table, m.shnorm,
+                                                                     m.item_lut, m.species_w, w.Cf, N);
+        } else {
+            k_soap_expand<<<N, 256, lds_expand(d), st>>>(d, g.geo, g.rowptr, g.sp_nbr, m.table, m.shnorm, m.coef_lut,
+                                                         m.species_w, w.Cf);
+        }
     }
     {
         ProfScope ps("soap_ps", st, 2.0 * (double)N * d.S * (d.L + 1), (double)N * (d.NCOEF + d.S) * 4);
@@ -866,9 +1074,20 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
     {
         ProfScope ps("soap_expand_bwd", st, 2.0 * (double)g.n_edges * (d.NCOEF + 8.0 * d.ITEMS),
                      (double)g.n_edges * 36 + (double)N * d.NCOEF * 4);
-        k_soap_expand_bwd<<<N, 256, lds_expand_bwd(d), st>>>(d, g.geo, g.rowptr, g.sp_nbr, m.table, m.shnorm,
-                                                             m.item_lut, m.species_w, w.dCf,
-                                                             reinterpret_cast<float4*>(w.dv));
+        if (soap_pair_ok(d)) {
+            const int grid = (int)cdiv(g.n_edges, 256);
+            if (d.L <= 6)
+                k_soap_expand_bwd_p<6><<<grid, 256, 0, st>>>(d, g.geo, g.ctr, g.sp_nbr, m.table, m.shnorm, m.species_w,
+                                                              w.dCf, reinterpret_cast<float4*>(w.dv), g.n_edges);
+            else
+                k_soap_expand_bwd_p<MAXL><<<grid, 256, 0, st>>>(d, g.geo, g.ctr, g.sp_nbr, m.table, m.shnorm,
+                                                                 m.species_w, w.dCf, reinterpret_cast<float4*>(w.dv),
+                                                                 g.n_edges);
+        } else {
+            k_soap_expand_bwd<<<N, 256, lds_expand_bwd(d), st>>>(d, g.geo, g.rowptr, g.sp_nbr, m.table, m.shnorm,
+                                                                 m.item_lut, m.species_w, w.dCf,
+                                                                 reinterpret_cast<float4*>(w.dv));
+        }
     }
     k_pos_grad<<<cdiv(N, 16), 256, 0, st>>>(reinterpret_cast<const float4*>(w.dv), g.rowptr, g.rev, gpos, N);
     if (gcell)
