@@ -238,6 +238,7 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *   "attn_lds"    attention kernels: 0 global-memory, 1 per-atom LDS-staged adjoint, 2 LDS-staged forward and
  *                 adjoint, 3 persistent LDS-DMA adjoint (default)
  *   "soap_mfma"   1 = SOAP-BPNN LayerNorm + MLP tail on MFMA (default)
+ *   "soap_fused"  1 = SOAP power spectrum + LayerNorm + first Linear in one kernel, features never stored (default 0: slower, saves memory)
  *   "soap_pair"   1 = SOAP expansion one wave per atom, its adjoint one lane per pair (default); 0 = first generation
  * Unknown keys return PET_ERR_ARGUMENT. */
 int pet_config_set(const char* key, int value);
