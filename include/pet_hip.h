@@ -239,6 +239,7 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *                 adjoint, 3 persistent LDS-DMA adjoint (default)
  *   "soap_mfma"   1 = SOAP-BPNN LayerNorm + MLP tail on MFMA (default)
  *   "soap_fused"  1 = SOAP power spectrum + LayerNorm + first Linear in one kernel, features never stored (default 0: slower, saves memory)
+ *   "soap_sorted" 1 = SOAP-BPNN tail GEMM on species-sorted atom tiles, one network per tile (default)
  *   "soap_pair"   1 = SOAP expansion one wave per atom, its adjoint one lane per pair (default); 0 = first generation
  * Unknown keys return PET_ERR_ARGUMENT. */
 int pet_config_set(const char* key, int value);

@@ -70,6 +70,7 @@ struct SoapModel {
     float* wall = nullptr;       // [NOUTP][Kp]
     float4 *wall_fwd = nullptr, *wall_bwd = nullptr;
     float *wall_rs = nullptr, *wall_b = nullptr;  // [NOUTP] row sums, W1 beta
+    float4 *wall_fwd_set = nullptr, *wall_bwd_set = nullptr;  // per network: [n_sets][1][Kp/8][64], [n_sets][Kp/32][4][64]
     // fused power-spectrum + tail kernels: the same matrix over the padded K layout (SoapDims::kp_off), and its
     // (a, b) <-> (b, a) transpose for the symmetrised power-spectrum adjoint
     int Kp2 = 0;
@@ -921,6 +922,249 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_ps_tail_bwd(SoapDims d, int c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// a18, species-sorted tiles (pet_config_set("soap_sorted", 1), default): in legacy mode every atom uses ONE of the
+// per-species networks, so the stacked GEMM above does n_species times the needed MFMA work. Here the atoms are
+// bucketed by network once per forward (counting sort, k_sp_*), a 64-atom tile holds atoms of one network only and
+// multiplies with that network's [32 x Kp] weight: one 32-column tile, the two column-half waves split K instead
+// and their accumulators are summed through LDS. Per-atom results do not depend on tile mates, so the (atomic)
+// order inside a bucket does not show in the output.
+// ---------------------------------------------------------------------------------------------
+constexpr int SP_MAXSETS = 8;
+struct SpInfo {  // device-side bucket table
+    int count[SP_MAXSETS], cursor[SP_MAXSETS], offs[SP_MAXSETS + 1], tstart[SP_MAXSETS + 1];
+};
+__global__ void k_sp_count(const int* __restrict__ sp, int legacy, int N, SpInfo* __restrict__ info) {
+    __shared__ int hist[SP_MAXSETS];
+    if (threadIdx.x < SP_MAXSETS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) atomicAdd(&hist[legacy ? sp[i] : 0], 1);
+    __syncthreads();
+    if (threadIdx.x < SP_MAXSETS && hist[threadIdx.x]) atomicAdd(&info->count[threadIdx.x], hist[threadIdx.x]);
+}
+__global__ void k_sp_scan(int n_sets, SpInfo* __restrict__ info) {
+    info->offs[0] = 0;
+    info->tstart[0] = 0;
+    for (int s = 0; s < n_sets; s++) {
+        info->offs[s + 1] = info->offs[s] + info->count[s];
+        info->tstart[s + 1] = info->tstart[s] + (info->count[s] + BM - 1) / BM;
+        info->cursor[s] = 0;
+    }
+}
+__global__ void k_sp_fill(const int* __restrict__ sp, int legacy, int N, SpInfo* __restrict__ info,
+                          int* __restrict__ perm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int s = legacy ? sp[i] : 0;
+    perm[info->offs[s] + atomicAdd(&info->cursor[s], 1)] = i;
+}
+// tile -> (network, first slot in perm, number of atoms); false if the tile index is past the last bucket
+__device__ __forceinline__ bool sp_tile(const SpInfo* __restrict__ info, int n_sets, int t, int& s, int& base, int& cnt) {
+    if (t >= info->tstart[n_sets]) return false;
+    s = 0;
+    while (t >= info->tstart[s + 1]) s++;
+    base = info->offs[s] + BM * (t - info->tstart[s]);
+    cnt = min(BM, info->offs[s + 1] - base);
+    return true;
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_soap_tail_fwd_set(SoapDims d, const float* __restrict__ feats,
+                                                                const int* __restrict__ perm,
+                                                                const SpInfo* __restrict__ info, int n_sets,
+                                                                const SoapSet* __restrict__ sets,
+                                                                const float4* __restrict__ Wps, int Kp,
+                                                                const float* __restrict__ rs,
+                                                                const float* __restrict__ bs, float* __restrict__ tail,
+                                                                float* __restrict__ atomic) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = 32, LDO = H + 1, LDA = lds_ld(128), TS = 2 + 2 * H;
+    float* As = smem;                    // [64][132]; later the K-split partial sums [64][33] + out [64][33]
+    float* a1s = smem + BM * LDA;        // [64][32] silu(a1)
+    int* rows = reinterpret_cast<int*>(a1s + BM * H);  // [64] atom of each row, -1 beyond the bucket
+    int sidx, base, cnt;
+    if (!sp_tile(info, n_sets, blockIdx.x, sidx, base, cnt)) return;
+    const WaveId w;
+    if (threadIdx.x < BM) rows[threadIdx.x] = (int)threadIdx.x < cnt ? perm[base + threadIdx.x] : -1;
+    const float4* Wp = Wps + (size_t)sidx * (Kp / 8) * 64;
+    f32x16 acc[1];
+    acc_fill_bias<1>(acc, nullptr, 0, w.lane);
+    // this thread's 8 float4 of a chunk: rows r0 + 8 q (q = 0..7), column group c; the next chunk is requested
+    // before the MFMAs of the current one, so its HBM latency hides behind them and the barriers
+    __syncthreads();
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    int64_t rowoff[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) rowoff[q] = rows[r0 + 8 * q] >= 0 ? (int64_t)rows[r0 + 8 * q] * d.S : -1;
+    float4 pre[8];
+    auto fetch = [&](int kc) {
+        const int col = 128 * kc + 4 * c;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            pre[q] = rowoff[q] >= 0 && col < d.S ? *reinterpret_cast<const float4*>(feats + rowoff[q] + col)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(0);
+    for (int kc = 0; kc < Kp / 128; kc++) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; q++) *reinterpret_cast<float4*>(As + (r0 + 8 * q) * LDA + 4 * c) = pre[q];
+        __syncthreads();
+        if (kc + 1 < Kp / 128) fetch(kc + 1);
+        // the column-half index splits K: this wave takes 64 of the chunk's 128 k
+        gemm_acc<64, 1>(As + w.rb * 32 * LDA + 64 * w.ch, LDA, Wp, Kp / 8, 16 * kc + 8 * w.ch, 0, acc, w.lane);
+    }
+    __syncthreads();
+    float* part = smem;                  // [64][33] partial sums of the second K half
+    float* out = smem + BM * LDO;        // [64][33]
+    if (w.ch == 1) acc_foreach<1>(acc, w.rb, 0, w.lane, [&](int r, int c, float v) { part[r * LDO + c] = v; });
+    __syncthreads();
+    if (w.ch == 0) acc_foreach<1>(acc, w.rb, 0, w.lane, [&](int r, int c, float v) { out[r * LDO + c] = v + part[r * LDO + c]; });
+    __syncthreads();
+    const SoapSet W = sets[sidx];
+    for (int item = threadIdx.x; item < BM * H; item += NTHREADS) {
+        const int r = item >> 5, j = item & 31, at = rows[r];
+        float a1 = 0.f;
+        if (at >= 0) {
+            const float mu = d.layernorm ? tail[(size_t)at * TS] : 0.f;
+            const float rstd = d.layernorm ? tail[(size_t)at * TS + 1] : 1.f;
+            a1 = rstd * (out[r * LDO + j] - mu * rs[sidx * H + j]) + bs[sidx * H + j];
+            tail[(size_t)at * TS + 2 + j] = a1;
+        }
+        a1s[r * H + j] = silu(a1);
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < BM * H; item += NTHREADS) {
+        const int r = item >> 5, j = item & 31, at = rows[r];
+        float e = 0.f;
+        if (at >= 0) {
+            if (d.NH > 1) {
+                float a2 = 0.f;
+                for (int q = 0; q < H; q++) a2 += W.W2[j * H + q] * a1s[r * H + q];
+                tail[(size_t)at * TS + 2 + H + j] = a2;
+                e = W.w3[j] * silu(a2);
+            } else {
+                e = W.w3[j] * a1s[r * H + j];
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) e += __shfl_xor(e, o);
+        if (j == 0 && at >= 0) atomic[at] = e;
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_set(SoapDims d, const float* __restrict__ feats,
+                                                                const int* __restrict__ perm,
+                                                                const SpInfo* __restrict__ info, int n_sets,
+                                                                const int* __restrict__ sp,
+                                                                const SoapSet* __restrict__ sets,
+                                                                const float4* __restrict__ Wpbs, int Kp,
+                                                                const float* __restrict__ rs,
+                                                                const float* __restrict__ bs,
+                                                                const float* __restrict__ enc,
+                                                                const float* __restrict__ tail,
+                                                                const float* __restrict__ gA, float* __restrict__ dF) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = 32, LDD = lds_ld(H), TS = 2 + 2 * H;
+    float* Ds = smem;                 // [64][36] d a1
+    float* d2 = Ds + BM * LDD;        // [64][32] d a2
+    float* st = d2 + BM * H;          // [64][4] mean, rstd, m1, m2
+    float* ot = st + BM * 4;          // [64][132] output tile staging
+    int* rows = reinterpret_cast<int*>(ot + BM * lds_ld(128));  // [64]
+    int sidx, base, cnt;
+    if (!sp_tile(info, n_sets, blockIdx.x, sidx, base, cnt)) return;
+    const WaveId w;
+    if (threadIdx.x < BM) rows[threadIdx.x] = (int)threadIdx.x < cnt ? perm[base + threadIdx.x] : -1;
+    const SoapSet W = sets[sidx];
+    const float4* Wpb = Wpbs + (size_t)sidx * (Kp / 32) * 4 * 64;
+    __syncthreads();
+    for (int item = threadIdx.x; item < BM * H; item += NTHREADS) {
+        const int r = item >> 5, j = item & 31, at = rows[r];
+        float v = 0.f;
+        if (at >= 0 && d.NH > 1) v = gA[at] * W.w3[j] * dsilu(tail[(size_t)at * TS + 2 + H + j]);
+        d2[r * H + j] = v;
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < BM * H; item += NTHREADS) {
+        const int r = item >> 5, j = item & 31, at = rows[r];
+        float da1 = 0.f, t1 = 0.f, t2 = 0.f;
+        float mu = 0.f, rstd = 1.f;
+        if (at >= 0) {
+            const float a1 = tail[(size_t)at * TS + 2 + j];
+            if (d.NH > 1) {
+                float acc = 0.f;
+                for (int q = 0; q < H; q++) acc += W.W2[q * H + j] * d2[r * H + q];
+                da1 = acc * dsilu(a1);
+            } else {
+                da1 = gA[at] * W.w3[j] * dsilu(a1);
+            }
+            if (d.layernorm) {
+                mu = tail[(size_t)at * TS];
+                rstd = tail[(size_t)at * TS + 1];
+                const float rsj = rs[sidx * H + j];
+                const float raw = (a1 - bs[sidx * H + j]) / rstd + mu * rsj;  // Wall_s[j] . x
+                t1 = da1 * rsj;
+                t2 = da1 * raw;
+            }
+        }
+        Ds[r * LDD + j] = da1;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+        if (j == 0) {
+            st[r * 4] = mu; st[r * 4 + 1] = rstd;
+            st[r * 4 + 2] = t1 / d.S;
+            st[r * 4 + 3] = rstd * (t2 - mu * t1) / d.S;
+        }
+    }
+    __syncthreads();
+    // the feature values the LayerNorm adjoint needs are requested one block ahead (8 float4 per thread)
+    const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    int64_t rowoff[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) rowoff[q] = rows[r0 + 8 * q] >= 0 ? (int64_t)rows[r0 + 8 * q] * d.S : -1;
+    float4 xpre[8];
+    auto fetch = [&](int nblk) {
+        const int k = 128 * nblk + 4 * c4;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            xpre[q] = d.layernorm && rowoff[q] >= 0 && k < d.S ? *reinterpret_cast<const float4*>(feats + rowoff[q] + k)
+                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(0);
+    for (int nblk = 0; nblk < Kp / 128; nblk++) {
+        f32x16 acc[2];
+        acc_fill_bias<2>(acc, nullptr, 0, w.lane);
+        gemm_acc<H, 2>(Ds + w.rb * 32 * LDD, LDD, Wpb, H / 8, 0, 4 * nblk + 2 * w.ch, acc, w.lane);
+        __syncthreads();  // the previous block's staging tile has been consumed
+        acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) { ot[r * lds_ld(128) + c] = v; });
+        __syncthreads();
+        float4 xcur[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) xcur[q] = xpre[q];
+        if (nblk + 1 < Kp / 128) fetch(nblk + 1);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int r = r0 + 8 * q, k = 128 * nblk + 4 * c4;
+            const int at = rows[r];
+            if (at < 0 || k >= d.S) continue;
+            float4 v = *reinterpret_cast<const float4*>(ot + r * lds_ld(128) + 4 * c4);
+            if (d.layernorm) {
+                const float4 x = xcur[q];
+                const float mu = st[r * 4], rs_ = st[r * 4 + 1], m1 = st[r * 4 + 2], m2 = st[r * 4 + 3];
+                v.x = rs_ * (v.x - m1 - (x.x - mu) * rs_ * m2);
+                v.y = rs_ * (v.y - m1 - (x.y - mu) * rs_ * m2);
+                v.z = rs_ * (v.z - m1 - (x.z - mu) * rs_ * m2);
+                v.w = rs_ * (v.w - m1 - (x.w - mu) * rs_ * m2);
+            }
+            if (enc) {
+                const float4 e = *reinterpret_cast<const float4*>(enc + (size_t)sp[at] * d.S + k);
+                v.x *= e.x; v.y *= e.y; v.z *= e.z; v.w *= e.w;
+            }
+            *reinterpret_cast<float4*>(dF + (size_t)at * d.S + k) = v;
+        }
+    }
+}
+
 // reverse of the tail: dF[i][k] = d e_i / d ps_i[k] * gA[i]
 __global__ __launch_bounds__(256) void k_soap_tail_bwd(SoapDims d, const float* __restrict__ feats,
                                                        const int* __restrict__ sp, const SoapSet* __restrict__ sets,
@@ -1262,6 +1506,8 @@ __global__ __launch_bounds__(256) void k_soap_expand_bwd_p(SoapDims d, const flo
 // ---------------------------------------------------------------------------------------------
 struct SoapWs {
     float *Cf, *feats, *tail, *dF, *dCf, *dv;
+    int* perm;     // [N] atoms bucketed by network (species-sorted tail tiles)
+    SpInfo* info;
     size_t bytes;
 };
 static void carve_soap(const SoapDims& d, int64_t N, int64_t E, void* base, SoapWs& w) {
@@ -1273,6 +1519,8 @@ static void carve_soap(const SoapDims& d, int64_t N, int64_t E, void* base, Soap
     w.dF = c.take<float>(Na * d.S);
     w.dCf = c.take<float>(Na * d.NCOEF);
     w.dv = c.take<float>(Ea * 4);
+    w.perm = c.take<int>(Na);
+    w.info = reinterpret_cast<SpInfo*>(c.take<int>((sizeof(SpInfo) + 3) / 4));
     w.bytes = c.off;
 }
 
@@ -1370,6 +1618,18 @@ static int soap_finalize(SoapModel& m, hipStream_t st) {
         k_soap_prep_rows<<<cdiv(NOUTP, 64), 64, 0, st>>>(d, m.sets, m.n_sets, NOUTP, Kp, m.wall, m.wall_rs, m.wall_b);
         k_pack<<<cdiv(n4, 256), 256, 0, st>>>(m.wall, Kp, 1, NOUTP, Kp, m.wall_fwd);   // x W^T: tiles over NOUTP
         k_pack<<<cdiv(n4, 256), 256, 0, st>>>(m.wall, 1, Kp, Kp, NOUTP, m.wall_bwd);   // dy W: tiles over Kp
+        {   // the same weights network by network, for the species-sorted tiles
+            const size_t per = (size_t)(Kp / 8) * 64;  // float4 per network, both orientations
+            if (!m.wall_fwd_set) {
+                if ((rc = salloc(m, (void**)&m.wall_fwd_set, m.n_sets * per * sizeof(float4)))) return rc;
+                if ((rc = salloc(m, (void**)&m.wall_bwd_set, m.n_sets * per * sizeof(float4)))) return rc;
+            }
+            for (int sset = 0; sset < m.n_sets; sset++) {
+                const float* ws = m.wall + (size_t)sset * d.H * Kp;
+                k_pack<<<cdiv(per, 256), 256, 0, st>>>(ws, Kp, 1, d.H, Kp, m.wall_fwd_set + sset * per);
+                k_pack<<<cdiv(per, 256), 256, 0, st>>>(ws, 1, Kp, Kp, d.H, m.wall_bwd_set + sset * per);
+            }
+        }
         if (d.ncmax <= 32) {  // fused power-spectrum + tail kernels: W1 over the padded K layout, and its transpose
             const int Kp2 = d.kp_off[d.L + 1];
             const size_t n42 = (size_t)NOUTP * Kp2 / 4;
@@ -1397,6 +1657,11 @@ static int soap_finalize(SoapModel& m, hipStream_t st) {
 
 static bool soap_pair_ok(const SoapDims& d) {
     return g_soap_pair && d.C == 4 && d.ITEMS <= 64 * MAXI && d.NLM <= 255 && d.F <= 255 && d.NCOEF < 32768;
+}
+static int g_soap_sorted = 1;
+void set_soap_sorted(int v) { g_soap_sorted = v ? 1 : 0; }
+static bool soap_sorted_ok(const SoapModel& m) {
+    return g_soap_sorted && g_soap_mfma && m.NT > 0 && m.wall_fwd_set != nullptr && m.n_sets <= SP_MAXSETS;
 }
 static bool soap_fused_ok(const SoapModel& m) {
     return g_soap_fused && g_soap_mfma && m.NT > 0 && m.wall2_fwd != nullptr && m.d.ncmax <= 32 && m.d.L <= MAXL;
@@ -1465,7 +1730,16 @@ static int soap_fwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
         }
         {
             ProfScope ps("soap_tail", st, 2.0 * (double)N * d.S * d.H, (double)N * d.S * 4);
-            if (m.NT > 0 && g_soap_mfma) {
+            if (soap_sorted_ok(m)) {
+                PET_HIP_CHECK(hipMemsetAsync(w.info, 0, sizeof(SpInfo), st));
+                k_sp_count<<<cdiv(N, 256), 256, 0, st>>>(g.sp, d.legacy, N, w.info);
+                k_sp_scan<<<1, 1, 0, st>>>(m.n_sets, w.info);
+                k_sp_fill<<<cdiv(N, 256), 256, 0, st>>>(g.sp, d.legacy, N, w.info, w.perm);
+                const size_t lds = ((size_t)BM * lds_ld(128) + BM * 32 + BM) * 4;
+                k_soap_tail_fwd_set<<<cdiv(N, BM) + m.n_sets, NTHREADS, lds, st>>>(
+                    d, w.feats, w.perm, w.info, m.n_sets, m.sets, m.wall_fwd_set, m.Kp, m.wall_rs, m.wall_b, w.tail,
+                    atomic);
+            } else if (m.NT > 0 && g_soap_mfma) {
                 const int NOUTP = m.NOUTP, lda = lds_ld(128);
                 const size_t lds = ((size_t)BM * (NOUTP + 1 > lda ? NOUTP + 1 : lda) + BM * 32) * 4;
                 const int grid = cdiv(N, BM);
@@ -1522,7 +1796,12 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
     } else {
     {
         ProfScope ps("soap_tail_bwd", st, 2.0 * (double)N * d.S * d.H, (double)N * d.S * 8);
-        if (m.NT > 0 && g_soap_mfma) {
+        if (soap_sorted_ok(m)) {  // perm / info were filled by the forward pass on this workspace
+            const size_t lds = ((size_t)BM * lds_ld(32) + BM * 32 + BM * 4 + BM * lds_ld(128) + BM) * 4;
+            k_soap_tail_bwd_set<<<cdiv(N, BM) + m.n_sets, NTHREADS, lds, st>>>(
+                d, w.feats, w.perm, w.info, m.n_sets, g.sp, m.sets, m.wall_bwd_set, m.Kp, m.wall_rs, m.wall_b, m.enc,
+                w.tail, gA, w.dF);
+        } else if (m.NT > 0 && g_soap_mfma) {
             const size_t lds = ((size_t)BM * lds_ld(m.NOUTP) + BM * 32 + BM * 4 + BM * lds_ld(128)) * 4;
             const int grid = cdiv(N, BM);
 #define SOAP_TAIL_BWD(NTV)                                                                                        \

@@ -24,15 +24,17 @@ def _relmax(a, b):
     return np.abs(a - b).max() / np.abs(b).max()
 
 
-@pytest.mark.parametrize("mfma_tail,pair_kernels,fused", [(1, 1, 1), (1, 1, 0), (0, 1, 1), (1, 0, 0)])
+@pytest.mark.parametrize("mfma_tail,pair_kernels,fused,sorted_tiles",
+                         [(1, 1, 0, 1), (1, 1, 0, 0), (1, 1, 1, 0), (0, 1, 0, 0), (1, 0, 0, 1)])
 @pytest.mark.parametrize("legacy", [True, False])
-def test_soap_bpnn_energy_features_and_forces(legacy, mfma_tail, pair_kernels, fused):
+def test_soap_bpnn_energy_features_and_forces(legacy, mfma_tail, pair_kernels, fused, sorted_tiles):
     from metatrain_amd import runtime as rt
     from metatrain_amd.soap_bpnn import SoapBpnnHip
 
     rt.config_set("soap_mfma", mfma_tail)  # both tail implementations: MFMA GEMM over 64 atoms / per-atom kernels
     rt.config_set("soap_pair", pair_kernels)  # wave-per-atom expansion + lane-per-pair adjoint / first generation
     rt.config_set("soap_fused", fused)  # power spectrum + LayerNorm + first Linear in one kernel / separate kernels
+    rt.config_set("soap_sorted", sorted_tiles)  # tail GEMM per network on species-sorted tiles / all networks stacked
 
     dev = torch.device("cuda:0")
     hypers = dict(osoap.DEFAULT_HYPERS, legacy=legacy)
@@ -63,6 +65,7 @@ def test_soap_bpnn_energy_features_and_forces(legacy, mfma_tail, pair_kernels, f
     rt.config_set("soap_mfma", 1)
     rt.config_set("soap_pair", 1)
     rt.config_set("soap_fused", 0)
+    rt.config_set("soap_sorted", 1)
 
 
 def test_soap_properties_at_10k_atoms():
