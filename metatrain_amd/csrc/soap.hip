@@ -603,9 +603,9 @@ __global__ __launch_bounds__(256) void k_soap_ps_bwd_s(SoapDims d, const float* 
     for (int o = threadIdx.x; o < d.NCOEF; o += 256) {
         const int2 code = olut[o];
         const int g0 = code.x, c0 = code.y & 0xffff, nc = code.y >> 16;
-        float v = 0.f;
-        for (int b = 0; b < nc; b++) v += G[g0 + b * nc] * cs[c0 + b];
-        dCf[(size_t)i * d.NCOEF + o] = v;
+        double v = 0.0;
+        for (int b = 0; b < nc; b++) v += (double)(G[g0 + b * nc] * cs[c0 + b]);
+        dCf[(size_t)i * d.NCOEF + o] = (float)v;
     }
 }
 
@@ -993,16 +993,27 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_fwd_set(SoapDims d, cons
     // before the MFMAs of the current one, so its HBM latency hides behind them and the barriers
     __syncthreads();
     const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    // the GEMM runs on CENTRED features (x - mean): a1 = rstd W~(x - mu) + W beta without the large, cancelling
+    // terms W~x and mu rowsum(W~) of the stacked kernel
     int64_t rowoff[8];
+    float rowmu[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) rowoff[q] = rows[r0 + 8 * q] >= 0 ? (int64_t)rows[r0 + 8 * q] * d.S : -1;
+    for (int q = 0; q < 8; q++) {
+        const int at = rows[r0 + 8 * q];
+        rowoff[q] = at >= 0 ? (int64_t)at * d.S : -1;
+        rowmu[q] = at >= 0 && d.layernorm ? tail[(size_t)at * TS] : 0.f;
+    }
     float4 pre[8];
     auto fetch = [&](int kc) {
         const int col = 128 * kc + 4 * c;
 #pragma unroll
-        for (int q = 0; q < 8; q++)
-            pre[q] = rowoff[q] >= 0 && col < d.S ? *reinterpret_cast<const float4*>(feats + rowoff[q] + col)
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 8; q++) {
+            pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rowoff[q] >= 0 && col < d.S) {
+                const float4 x = *reinterpret_cast<const float4*>(feats + rowoff[q] + col);
+                pre[q] = make_float4(x.x - rowmu[q], x.y - rowmu[q], x.z - rowmu[q], x.w - rowmu[q]);
+            }
+        }
     };
     fetch(0);
     for (int kc = 0; kc < Kp / 128; kc++) {
@@ -1026,9 +1037,8 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_fwd_set(SoapDims d, cons
         const int r = item >> 5, j = item & 31, at = rows[r];
         float a1 = 0.f;
         if (at >= 0) {
-            const float mu = d.layernorm ? tail[(size_t)at * TS] : 0.f;
             const float rstd = d.layernorm ? tail[(size_t)at * TS + 1] : 1.f;
-            a1 = rstd * (out[r * LDO + j] - mu * rs[sidx * H + j]) + bs[sidx * H + j];
+            a1 = rstd * out[r * LDO + j] + bs[sidx * H + j];
             tail[(size_t)at * TS + 2 + j] = a1;
         }
         a1s[r * H + j] = silu(a1);
@@ -1101,10 +1111,8 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_set(SoapDims d, cons
             if (d.layernorm) {
                 mu = tail[(size_t)at * TS];
                 rstd = tail[(size_t)at * TS + 1];
-                const float rsj = rs[sidx * H + j];
-                const float raw = (a1 - bs[sidx * H + j]) / rstd + mu * rsj;  // Wall_s[j] . x
-                t1 = da1 * rsj;
-                t2 = da1 * raw;
+                t1 = da1 * rs[sidx * H + j];
+                t2 = da1 * (a1 - bs[sidx * H + j]) / rstd;  // da1 * Wall_s[j] . (x - mu)
             }
         }
         Ds[r * LDD + j] = da1;
@@ -1112,8 +1120,8 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_set(SoapDims d, cons
         for (int o = 16; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
         if (j == 0) {
             st[r * 4] = mu; st[r * 4 + 1] = rstd;
-            st[r * 4 + 2] = t1 / d.S;
-            st[r * 4 + 3] = rstd * (t2 - mu * t1) / d.S;
+            st[r * 4 + 2] = t1 / d.S;          // m1 = mean(dxn gamma)
+            st[r * 4 + 3] = rstd * t2 / d.S;   // m2 = mean(dxn gamma xhat)
         }
     }
     __syncthreads();
@@ -1470,7 +1478,7 @@ __global__ __launch_bounds__(256) void k_soap_expand_bwd_p(SoapDims d, const flo
     const float* dC = dCf + (size_t)ctr[p] * d.NCOEF;
     ShLevels<LMAX> sh;
     sh.init(ux, uy, uz, ir);
-    float ax = 0.f, ay = 0.f, az = 0.f, along = 0.f;  // `along` multiplies the unit vector
+    double ax = 0.0, ay = 0.0, az = 0.0, along = 0.0;  // `along` multiplies the unit vector; fp64 sums (280 items)
 #pragma unroll
     for (int l = 0; l <= LMAX; l++) {
         if (l > d.L) break;
@@ -1488,17 +1496,17 @@ __global__ __launch_bounds__(256) void k_soap_expand_bwd_p(SoapDims d, const flo
                 if (mi > 2 * l) continue;
                 const float4 c = *reinterpret_cast<const float4*>(dCl + (size_t)(mi * nl + n) * 4);
                 const float A = c.x * w4.x + c.y * w4.y + c.z * w4.z + c.w * w4.w;
-                along += A * dR * Y[mi];
+                along += (double)(A * dR * Y[mi]);
                 T[mi] += A * R;
             }
         }
 #pragma unroll
         for (int mi = 0; mi < 2 * LMAX + 1; mi++) {
             if (mi > 2 * l) continue;
-            ax += T[mi] * Gx[mi]; ay += T[mi] * Gy[mi]; az += T[mi] * Gz[mi];
+            ax += (double)(T[mi] * Gx[mi]); ay += (double)(T[mi] * Gy[mi]); az += (double)(T[mi] * Gz[mi]);
         }
     }
-    dv[p] = make_float4(ax + along * ux, ay + along * uy, az + along * uz, 0.f);
+    dv[p] = make_float4((float)(ax + along * ux), (float)(ay + along * uy), (float)(az + along * uz), 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------
