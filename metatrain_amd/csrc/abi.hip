@@ -596,6 +596,7 @@ int pet_config_set(const char* key, int value) {
     else if (k == "soap_sorted") set_soap_sorted(value);
     else if (k == "attn_lds") set_attn_lds(value);
     else if (k == "bf16x6") set_bf16x6(value);
+    else if (k == "trr_persist") set_trr_persist(value);
     else if (k == "so_bf16x6") set_so_bf16x6(value);
     else PET_REQUIRE(false, PET_ERR_ARGUMENT, "unknown config key '" + k + "'");
     return PET_OK;
