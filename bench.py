@@ -40,7 +40,7 @@ def synthetic_params(hypers):
 # ProfScope stage -> the kernels it launches (base names, template arguments stripped). The attention stages
 # launch one kernel per neighbour-count bucket (NT = 1, 2, 3 ...): their traffic is the sum over the buckets.
 STAGE_KERNELS = {"attn_bwd": ("k_attn_bwd_a", "k_attn_bwd_l", "k_attn_bwd_p"), "attn_fwd": ("k_attn_fwd_p", "k_attn_fwd_l"),
-                 "emlp": ("k_emlp_b", "k_emlp_t"), "emlp_bwd": ("k_emlp_bwd_b", "k_emlp_bwd_t"),
+                 "emlp": ("k_emlp_p", "k_emlp_b", "k_emlp_t"), "emlp_bwd": ("k_emlp_bwd_b", "k_emlp_bwd_t"),
                  "qkv": ("k_qkv_b", "k_qkv_t"), "qkv_bwd": ("k_qkv_bwd_b", "k_qkv_bwd_t"),
                  "comb": ("k_comb_b", "k_comb"), "comb_bwd": ("k_comb_bwd_b", "k_comb_bwd")}
 
