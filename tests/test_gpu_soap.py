@@ -68,6 +68,31 @@ def test_soap_bpnn_energy_features_and_forces(legacy, mfma_tail, pair_kernels, f
     rt.config_set("soap_sorted", 1)
 
 
+def test_soap_max_angular_8():
+    """The second instantiation of the expansion kernels (max_angular 7..8: 81 Y_lm, 17-wide m blocks)."""
+    from metatrain_amd.soap_bpnn import SoapBpnnHip
+
+    dev = torch.device("cuda:0")
+    hypers = dict(osoap.DEFAULT_HYPERS, legacy=True)
+    hypers["soap"] = dict(hypers["soap"], max_angular=8, max_radial=5)
+    types = [1, 6, 7, 8]
+    n_per_l = osoap.basis(hypers)[0]
+    assert len(n_per_l) == 9
+    params = osoap.synthetic_params(hypers, 4, n_per_l, 0, torch.float32)
+    pos, z, cells, ci, cj, cs, sysidx = _box(64, seed=9)
+    p64 = {k: v.double() for k, v in params.items()}
+    e_ref, g_ref, a_ref = osoap.energy_and_gradient(p64, hypers, types, pos, cells, ci, cj, cs, z, sysidx)
+    model = SoapBpnnHip(hypers, types)
+    assert model.n_per_l == n_per_l
+    model.load({k: v.to(dev) for k, v in params.items()})
+    g = model.graph(pos.float().to(dev), cells.float().to(dev), ci.to(dev), cj.to(dev), cs.to(dev), z.to(dev),
+                    sysidx.int().to(dev))
+    atomic = model.forward(g)
+    grad = model.backward(g, torch.ones_like(atomic))
+    assert _relmax(atomic.cpu().numpy(), a_ref.numpy()) < TOL
+    assert _relmax(grad.cpu().numpy(), g_ref.numpy()) < TOL
+
+
 def test_soap_properties_at_10k_atoms():
     """Size-independent properties on a 10 000-atom box: sum of forces = 0, permuting the atoms permutes the
     per-atom energies and gradients, run-to-run bit determinism."""
