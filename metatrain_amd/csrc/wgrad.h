@@ -89,34 +89,50 @@ __global__ __launch_bounds__(NTHREADS) void k_wgrad(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
     float bsum = 0.f;  // thread c < 128: column sum of dY (bias gradient)
-    for (int64_t row0 = r_begin; row0 < r_end; row0 += WG_RB) {
-        __syncthreads();
-        // ---- stage dY block: columns [128 nb, 128 nb + 128)
-        for (int idx = threadIdx.x; idx < WG_RB * 32; idx += NTHREADS) {
-            const int r = idx >> 5, c = idx & 31;
+    // Register prefetch: the global loads of block i + 1 are issued before the MFMAs of block i (the kernel is
+    // otherwise load -> barrier -> MFMA with nothing in flight during the MFMAs). Per thread: 4 float4 of dY and
+    // KB / 32 float4 of X (twice that for the SwiGLU source, which reads v and g). XMODE 4 gathers through `rev`
+    // and keeps the direct path.
+    constexpr int YQ = WG_RB * 32 / NTHREADS;             // 4
+    constexpr int XQ = WG_RB * (KB / 4) / NTHREADS;       // KB / 32
+    float4 ypre[YQ], xpre[XMODE == 4 ? 1 : XQ], gpre[XMODE == 2 ? XQ : 1];
+    auto fetch = [&](int64_t row0) {
+#pragma unroll
+        for (int q = 0; q < YQ; q++) {
+            const int idx = threadIdx.x + q * NTHREADS, r = idx >> 5, c = idx & 31;
             const int64_t row = row0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            ypre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < r_end) {
                 const float* src = (a.y1 && row >= a.y_split) ? a.y1 + (row - a.y_split) * a.y_ld
                                                               : a.y0 + row * a.y_ld;
-                v = *reinterpret_cast<const float4*>(src + a.y_col0 + 128 * nb + 4 * c);
+                ypre[q] = *reinterpret_cast<const float4*>(src + a.y_col0 + 128 * nb + 4 * c);
             }
-            *reinterpret_cast<float4*>(Ys + r * LDY + 4 * c) = v;
         }
-        // ---- stage X block
-        if (XMODE == 2) {
-            for (int idx = threadIdx.x; idx < WG_RB * (KB / 4); idx += NTHREADS) {
-                const int r = idx / (KB / 4), c = idx % (KB / 4);
-                float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (XMODE != 4) {
+#pragma unroll
+            for (int q = 0; q < XQ; q++) {
+                const int idx = threadIdx.x + q * NTHREADS, r = idx / (KB / 4), c = idx % (KB / 4);
+                xpre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (XMODE == 2) gpre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (row0 + r < r_end) {
                     const float* base = a.x0 + (row0 + r) * a.x_ld + a.x_col0 + 4 * c;
-                    const float4 v = *reinterpret_cast<const float4*>(base);
-                    const float4 g = *reinterpret_cast<const float4*>(base + a.x_hid);
-                    u = make_float4(v.x * sigmoidf_(g.x), v.y * sigmoidf_(g.y), v.z * sigmoidf_(g.z), v.w * sigmoidf_(g.w));
+                    xpre[q] = *reinterpret_cast<const float4*>(base);
+                    if (XMODE == 2) gpre[q] = *reinterpret_cast<const float4*>(base + a.x_hid);
                 }
-                *reinterpret_cast<float4*>(Xs + r * LDX + 4 * c) = u;
             }
-        } else if (XMODE == 4) {  // [x ; x[rev]] then LayerNorm-hat with the saved (mean, rstd)
+        }
+    };
+    if (r_begin < r_end) fetch(r_begin);
+    for (int64_t row0 = r_begin; row0 < r_end; row0 += WG_RB) {
+        __syncthreads();
+        // ---- stage dY block: columns [128 nb, 128 nb + 128)
+#pragma unroll
+        for (int q = 0; q < YQ; q++) {
+            const int idx = threadIdx.x + q * NTHREADS, r = idx >> 5, c = idx & 31;
+            *reinterpret_cast<float4*>(Ys + r * LDY + 4 * c) = ypre[q];
+        }
+        // ---- stage X block
+        if (XMODE == 4) {  // [x ; x[rev]] then LayerNorm-hat with the saved (mean, rstd)
             for (int idx = threadIdx.x; idx < WG_RB * 64; idx += NTHREADS) {
                 const int r = idx >> 6, c = idx & 63;
                 const int64_t row = row0 + r;
@@ -130,14 +146,19 @@ __global__ __launch_bounds__(NTHREADS) void k_wgrad(WgradArgs a) {
                 *reinterpret_cast<float4*>(Xs + r * LDX + 4 * c) = v;
             }
         } else {
-            for (int idx = threadIdx.x; idx < WG_RB * (KB / 4); idx += NTHREADS) {
-                const int r = idx / (KB / 4), c = idx % (KB / 4);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row0 + r < r_end) v = *reinterpret_cast<const float4*>(a.x0 + (row0 + r) * a.x_ld + a.x_col0 + 4 * c);
+#pragma unroll
+            for (int q = 0; q < XQ; q++) {
+                const int idx = threadIdx.x + q * NTHREADS, r = idx / (KB / 4), c = idx % (KB / 4);
+                float4 v = xpre[q];
+                if (XMODE == 2) {
+                    const float4 g = gpre[q];
+                    v = make_float4(v.x * sigmoidf_(g.x), v.y * sigmoidf_(g.y), v.z * sigmoidf_(g.z), v.w * sigmoidf_(g.w));
+                }
                 if (XMODE == 3) { v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w); }
                 *reinterpret_cast<float4*>(Xs + r * LDX + 4 * c) = v;
             }
         }
+        if (row0 + WG_RB < r_end) fetch(row0 + WG_RB);
         __syncthreads();
         if (XMODE == 1) {
             tile_rms_hat<KB>(Xs);
