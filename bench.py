@@ -284,7 +284,7 @@ def main():
         t2 = float((((rowptr[1:] - rowptr[:-1]) + 1) ** 2).sum())
         fwd_flops = 2001152.0 * e + 4292864.0 * n + 2048.0 * t2
         out["roofline"]["whole_step_algorithmic_tflops"] = 2 * fwd_flops / (ms_per_step * 1e-3) / 1e12
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the reported CPU leg runs at N = 1 only
             out["cpu_baseline"] = cpu_baseline(hypers, params)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -144,7 +144,7 @@ def main():
                          "algorithmic_bytes_per_launch": dominant["bytes"], "traffic": None,
                          "stages_ms": {r["name"]: round(r["total_ms"], 3) for r in table}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(hypers)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -147,7 +147,7 @@ def main():
                 "workspace_gb": (fw.nbytes + fw.workspace2.numel()) / 1e9,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(hypers, params)
         print(json.dumps(out), flush=True)
     if world > 1:
