@@ -80,6 +80,26 @@ ProfScope::~ProfScope() {
     g_prof.push_back({name, e0, e1, flops, bytes});
 }
 
+// two-way fp16 split of the same fragments (trr.h, f16x3 GEMMs): out[plane][(t * kbn + kb) * 64 + l][8]
+__global__ void k_pack2h(const float* __restrict__ W, int64_t s_n, int64_t s_k, int n_out, int k_in,
+                         _Float16* __restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int kbn = k_in / 16;
+    int64_t total = (int64_t)(n_out / 32) * kbn * 64;
+    if (idx >= total) return;
+    int l = idx & 63;
+    int kb = (idx >> 6) % kbn;
+    int t = (int)((idx >> 6) / kbn);
+    int64_t n = t * 32 + (l & 31);
+    for (int j = 0; j < 8; j++) {
+        const int64_t k = kb * 16 + (j < 4 ? 4 * (l >> 5) + j : 8 + 4 * (l >> 5) + (j - 4));
+        const float x = W[n * s_n + k * s_k];
+        const _Float16 h = (_Float16)x;
+        out[(0 * total + idx) * 8 + j] = h;
+        out[(1 * total + idx) * 8 + j] = (_Float16)((x - (float)h) * 2048.0f);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // weight packing into MFMA fragment order (tile.h)
 // ---------------------------------------------------------------------------------
@@ -163,6 +183,10 @@ static int pack_lin(Model& m, const std::string& name, Lin& L, const float* w, c
         if ((rc = named_alloc(m, name + ":bwd3", &L.bwd3, 3 * n8 * 16)) != PET_OK) return rc;
         k_pack3<<<cdiv(n8, 256), 256, 0, st>>>(w + col0, ld, 1, n_out, k_in, (__bf16*)L.fwd3);
         k_pack3<<<cdiv(n8, 256), 256, 0, st>>>(w + col0, 1, ld, k_in, n_out, (__bf16*)L.bwd3);
+        if ((rc = named_alloc(m, name + ":fwd2", &L.fwd2, 2 * n8 * 16)) != PET_OK) return rc;
+        if ((rc = named_alloc(m, name + ":bwd2", &L.bwd2, 2 * n8 * 16)) != PET_OK) return rc;
+        k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(w + col0, ld, 1, n_out, k_in, (_Float16*)L.fwd2);
+        k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(w + col0, 1, ld, k_in, n_out, (_Float16*)L.bwd2);
     }
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
@@ -597,6 +621,7 @@ int pet_config_set(const char* key, int value) {
     else if (k == "attn_lds") set_attn_lds(value);
     else if (k == "bf16x6") set_bf16x6(value);
     else if (k == "trr_persist") set_trr_persist(value);
+    else if (k == "f16x3") set_f16x3(value);
     else if (k == "so_bf16x6") set_so_bf16x6(value);
     else PET_REQUIRE(false, PET_ERR_ARGUMENT, "unknown config key '" + k + "'");
     return PET_OK;

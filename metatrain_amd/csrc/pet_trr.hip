@@ -332,6 +332,18 @@ static inline W3 w3_fwd(const Lin& L) {
     W3 w; w.h = b; w.m = b + n8; w.l = b + 2 * n8;
     return w;
 }
+static inline W2 w2_fwd(const Lin& L) {
+    const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
+    const f16x8* b = reinterpret_cast<const f16x8*>(L.fwd2);
+    W2 w; w.h = b; w.l = b + n8;
+    return w;
+}
+static inline W2 w2_bwd(const Lin& L) {
+    const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
+    const f16x8* b = reinterpret_cast<const f16x8*>(L.bwd2);
+    W2 w; w.h = b; w.l = b + n8;
+    return w;
+}
 static inline W3 w3_bwd(const Lin& L) {
     const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
     const bf16x8* b = reinterpret_cast<const bf16x8*>(L.bwd3);
@@ -566,6 +578,127 @@ __global__ __launch_bounds__(256) void k_emlp_p(const float* __restrict__ X1, co
     }
 }
 
+// f16x3 form of the persistent edge MLP (trr.h): two fp16 planes, three MFMAs per K block on a high and a cross
+// accumulator; RMSNorm output and SwiGLU output are O(1) rows, so no row scaling is needed here.
+__global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, const float* __restrict__ gamma, W2 win,
+                                                  const float* __restrict__ bin, W2 wout,
+                                                  const float* __restrict__ bout, float* __restrict__ VG,
+                                                  float* __restrict__ X2, int64_t E) {
+    extern __shared__ __attribute__((aligned(16))) float4 xstage[];  // [4 waves][2 buffers][16][64]
+    const RowLane L;
+    const int wave = threadIdx.x >> 6;
+    float4* mybuf = xstage + (size_t)wave * 2 * 16 * 64;
+    const int64_t ntiles = (E + WROWS - 1) / WROWS, nw = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    auto issue_rows = [&](int64_t t, int buf) {
+        int64_t rr = t * WROWS + L.r;
+        if (rr >= E) rr = E - 1;
+        const float* src = X1 + rr * D + 4 * L.h;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(mybuf + (size_t)buf * 16 * 64));
+#pragma unroll
+        for (int kg = 0; kg < 16; kg++) glds16_trr(src + 8 * kg, dst + kg * 1024);
+    };
+    issue_rows(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only the first tile waits for its own rows
+    constexpr int NC = DFF / 32;
+    auto widx = [&](int b) { return ((size_t)(b >> 3) * 8 + (b & 7)) * 64 + L.lane; };
+    constexpr size_t TS = (size_t)NC * 8 * 64;
+    WBlk2<2> ring[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) ld_blk2<2>(ring[b], win, widx(b), TS);
+    float4 bv[4], bg[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        bv[q] = *reinterpret_cast<const float4*>(bin + 8 * q + 4 * L.h);
+        bg[q] = *reinterpret_cast<const float4*>(bin + DFF + 8 * q + 4 * L.h);
+    }
+    for (int it = 0; tile < ntiles; it++, tile += nw) {
+        const int64_t row0 = tile * WROWS;
+        const bool valid = row0 + L.r < E;
+        const int64_t row = valid ? row0 + L.r : E - 1;
+        const float4* xb = mybuf + (size_t)(it & 1) * 16 * 64;
+        if (tile + nw < ntiles) issue_rows(tile + nw, (it + 1) & 1);
+        Split2<8> xs;
+        {
+            float4 x[16];
+#pragma unroll
+            for (int kg = 0; kg < 16; kg++) x[kg] = xb[kg * 64 + L.lane];
+            rmsnorm_frag<16>(x, gamma, L.h);
+            split_frag2<8>(x, xs);
+        }
+        f32x16 out[4], outl[4];
+        acc_bias<4>(out, bout, 0, L.h);
+        acc_zero<4>(outl);
+#pragma unroll 1
+        for (int hc = 0; hc < NC; hc++) {
+            f16x8 oh[2][4], ol[2][4];
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const size_t i = ((size_t)t * (DFF / 16) + 2 * hc + kb) * 64 + L.lane;
+                    oh[kb][t] = wout.h[i]; ol[kb][t] = wout.l[i];
+                }
+            f32x16 vg[2], vgl[2];
+            acc_zero<2>(vgl);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                vg[0][4 * q] = bv[q].x; vg[0][4 * q + 1] = bv[q].y; vg[0][4 * q + 2] = bv[q].z; vg[0][4 * q + 3] = bv[q].w;
+                vg[1][4 * q] = bg[q].x; vg[1][4 * q + 1] = bg[q].y; vg[1][4 * q + 2] = bg[q].z; vg[1][4 * q + 3] = bg[q].w;
+            }
+            {
+                const int hn = hc + 1 < NC ? hc + 1 : 0;  // wraps to the next tile's first chunk
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    bv[q] = *reinterpret_cast<const float4*>(bin + 32 * hn + 8 * q + 4 * L.h);
+                    bg[q] = *reinterpret_cast<const float4*>(bin + DFF + 32 * hn + 8 * q + 4 * L.h);
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < 8; kb++) {
+                WBlk2<2>& wb = ring[kb & 3];
+                mfma3<2>(vg, vgl, wb, xs.h[kb], xs.l[kb]);
+                int nb = 8 * hc + kb + 4;  // four steps ahead; past the end = the next tile's first blocks
+                nb = nb < 8 * NC ? nb : nb - 8 * NC;
+                ld_blk2<2>(wb, win, widx(nb), TS);
+            }
+            fold_low<2>(vg, vgl);
+            float4 u[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 vv = acc_q(vg[0], q), gg = acc_q(vg[1], q);
+                if (VG && valid) {
+                    *reinterpret_cast<float4*>(VG + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) = vv;
+                    *reinterpret_cast<float4*>(VG + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) = gg;
+                }
+                u[q] = make_float4(vv.x * sigm_(gg.x), vv.y * sigm_(gg.y), vv.z * sigm_(gg.z), vv.w * sigm_(gg.w));
+            }
+            Split2<2> us;
+            split_frag2<2>(u, us);
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    outl[t] = PET_MFMA_H(ol[kb][t], us.h[kb], outl[t]);
+                    out[t] = PET_MFMA_H(oh[kb][t], us.h[kb], out[t]);
+                    outl[t] = PET_MFMA_H(oh[kb][t], us.l[kb], outl[t]);
+                }
+        }
+        fold_low<4>(out, outl);
+        if (valid) {
+            float4 y[16];
+            acc_to_frag<4>(out, y);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float4 xr = xb[k * 64 + L.lane];
+                y[k].x += xr.x; y[k].y += xr.y; y[k].z += xr.z; y[k].w += xr.w;
+            }
+            store_rowfrag<16>(y, X2, row, D, L.h);
+        }
+    }
+}
+
 // dX1 = dY + RMSNorm^T( Win^T [du sig(g) ; du v sig'(g)] ),  du = Wout^T dY
 template <bool TRAIN>
 __global__ __launch_bounds__(256, 2) void k_emlp_bwd_t(const float* __restrict__ dY, const float* __restrict__ X1,
@@ -722,6 +855,8 @@ static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
 // with 3-way split operands -- as accurate as the fp32 MFMA (3.7e-7 vs 4.5e-7 against fp64, tools/ubench/bf16x3.hip)
 // at 0.375x the matrix-core time. The split fragments cost registers (one wave per SIMD), so these kernels
 // prefetch their weight fragments through rings that run across the GEMM boundaries.
+static int g_f16x3 = 1;  // pet_config_set("f16x3", 0): the bf16x6 kernels everywhere
+void set_f16x3(int v) { g_f16x3 = v ? 1 : 0; }
 static int g_trr_persist = 1;
 void set_trr_persist(int v) { g_trr_persist = v ? 1 : 0; }
 static int num_cus() {
@@ -758,7 +893,12 @@ void trr_oproj_bwd(const float* dX1, const float* dOC, const Lin& out, float* dA
 }
 void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wout, float* VG, float* X2,
               int64_t E, hipStream_t st) {
-    if (g_bf16x6 && win.fwd3 && wout.fwd3 && g_trr_persist && E > 0) {
+    if (g_bf16x6 && g_f16x3 && win.fwd2 && wout.fwd2 && g_trr_persist && E > 0) {
+        const size_t lds = (size_t)4 * 2 * 16 * 64 * sizeof(float4);  // 128 KB: two row buffers per wave
+        allow_big_lds(k_emlp_h, lds);
+        const int grid = std::min(grid_rows(E), num_cus());
+        k_emlp_h<<<grid, 256, lds, st>>>(X1, gamma, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
+    } else if (g_bf16x6 && win.fwd3 && wout.fwd3 && g_trr_persist && E > 0) {
         const size_t lds = (size_t)4 * 2 * 16 * 64 * sizeof(float4);  // 128 KB: two row buffers per wave
         allow_big_lds(k_emlp_p, lds);
         const int grid = std::min(grid_rows(E), num_cus());

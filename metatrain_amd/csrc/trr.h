@@ -254,6 +254,73 @@ __device__ __forceinline__ void ld_bias(float4 (&b)[4 * NT], const float* __rest
         for (int q = 0; q < 4; q++) b[4 * t + q] = *reinterpret_cast<const float4*>(bias + col0 + 32 * t + 8 * q + 4 * h);
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 GEMM on the fp16 matrix cores ("f16x3"): a TWO-way split whose low piece is pre-scaled,
+//   x = h + l,  h = fp16(x) (11 significant bits),  l' = fp16((x - h) * 2^11)   (the next 11 bits, stored at x's
+//   own magnitude so that it never falls into fp16's subnormal range),
+//   x w = h_x h_w + 2^-11 (h_x l'_w + l'_x h_w) + 2^-22 l'_x l'_w   (last term dropped: 2^-22 relative),
+// i.e. THREE v_mfma_f32_32x32x16_f16 per K block on two accumulators (the high-high sum and the cross sum, combined
+// as acc + 2^-11 acl at the end) instead of bf16x6's six on one, and two weight planes instead of three (the
+// L2 -> CU weight stream is a quarter of those kernels). Measured against fp64 (tools/ubench/f16x3.hip): 1.7e-7,
+// bf16x6 3.7e-7, fp32 MFMA 4.5e-7. fp16's range: |x| up to 65504; elements below 6e-5 keep 6e-8 ABSOLUTE accuracy,
+// which is what fp32 gives relative to an O(1) row; rows that are small as a whole (adjoints) are scaled by a
+// power of two first (row_scale_pow2), exactly, and the result scaled back.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct W2 {  // weight fragments, high and (scaled) low plane, [(tile * kb_total + kb) * 64 + lane]
+    const f16x8 *h = nullptr, *l = nullptr;
+};
+__device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
+    h = (_Float16)x;
+    l = (_Float16)((x - (float)h) * 2048.0f);
+}
+template <int KB>
+struct Split2 {
+    f16x8 h[KB], l[KB];
+};
+template <int KB>
+__device__ __forceinline__ void split_frag2(const float4* x, Split2<KB>& s) {
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        const float v[8] = {x[2 * kb].x, x[2 * kb].y, x[2 * kb].z, x[2 * kb].w,
+                            x[2 * kb + 1].x, x[2 * kb + 1].y, x[2 * kb + 1].z, x[2 * kb + 1].w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            _Float16 a, b;
+            split2(v[j], a, b);
+            s.h[kb][j] = a; s.l[kb][j] = b;
+        }
+    }
+}
+#define PET_MFMA_H(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16((A), (B), (C), 0, 0, 0)
+template <int NT>
+struct WBlk2 {
+    f16x8 h[NT], l[NT];
+};
+template <int NT>
+__device__ __forceinline__ void ld_blk2(WBlk2<NT>& b, const W2& w, size_t i0, size_t tile_stride) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) { b.h[t] = w.h[i0 + t * tile_stride]; b.l[t] = w.l[i0 + t * tile_stride]; }
+}
+// acc += W_h x_h ; acl += W_l' x_h + W_h x_l'
+template <int NT>
+__device__ __forceinline__ void mfma3(f32x16 (&acc)[NT], f32x16 (&acl)[NT], const WBlk2<NT>& b, const f16x8& xh,
+                                      const f16x8& xl) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) acl[t] = PET_MFMA_H(b.l[t], xh, acl[t]);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_H(b.h[t], xh, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acl[t] = PET_MFMA_H(b.h[t], xl, acl[t]);
+}
+template <int NT>
+__device__ __forceinline__ void fold_low(f32x16 (&acc)[NT], const f32x16 (&acl)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] += acl[t][r] * (1.0f / 2048.0f);
+}
+
 // sum over the row: lane-local + the partner lane holding the other half of the features
 __device__ __forceinline__ float row_sum(float v) { return v + __shfl_xor(v, 32); }
 
