@@ -277,6 +277,181 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_b(const float* __restrict__ dQK
 }
 
 // ---------------------------------------------------------------------------------
+// f16x3 versions (trr.h) of the 128-wide row GEMM and the stages built on it. `oscale` multiplies the finished
+// accumulators (the inverse of a row_scale_pow2 applied to an adjoint input; 1 for forward activations).
+// ---------------------------------------------------------------------------------
+template <int NC2, class Epilogue>
+__device__ __forceinline__ void row_gemm128_h(const W2& w, const float* __restrict__ bias, const Split2<8>& xs,
+                                              const RowLane& L, float oscale, Epilogue epi) {
+    auto widx = [&](int b) { return ((size_t)(2 * (b >> 3)) * 8 + (b & 7)) * 64 + L.lane; };
+    WBlk2<2> ring[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) ld_blk2<2>(ring[b], w, widx(b), 8 * 64);
+    float4 bnext[8];
+    if (bias) ld_bias<2>(bnext, bias, 0, L.h);
+#pragma unroll 1
+    for (int c = 0; c < NC2; c++) {
+        f32x16 acc[2], acl[2];
+        acc_zero<2>(acl);
+        if (bias) {
+            acc_from<2>(acc, bnext);
+            if (c + 1 < NC2) ld_bias<2>(bnext, bias, 64 * (c + 1), L.h);
+        } else {
+            acc_zero<2>(acc);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            WBlk2<2>& wb = ring[kb & 3];
+            mfma3<2>(acc, acl, wb, xs.h[kb], xs.l[kb]);
+            const int nb = 8 * c + kb + 4;
+            if (nb < 8 * NC2) ld_blk2<2>(wb, w, widx(nb), 8 * 64);
+        }
+        fold_low<2>(acc, acl);
+        if (oscale != 1.0f) acc_scale<2>(acc, oscale);
+        epi(c, acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_qkv_h(const float* __restrict__ X, const float* __restrict__ gamma, W2 win,
+                                                const float* __restrict__ bin, float* __restrict__ QKV, int64_t R) {
+    TRR_PROLOGUE(R);
+    Split2<8> xs;
+    {
+        float4 x[16];
+        load_rowfrag<16>(x, X, row, D, L.h);
+        rmsnorm_frag<16>(x, gamma, L.h);
+        split_frag2<8>(x, xs);
+    }
+    row_gemm128_h<6>(win, bin, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+        if (valid) {
+            float4 y[8];
+            acc_to_frag<2>(acc, y);
+            store_rowfrag<8>(y, QKV + 64 * c, row, 3 * D, L.h);
+        }
+    });
+}
+
+__global__ __launch_bounds__(256) void k_oproj_h(const float* __restrict__ AO, const float* __restrict__ X, W2 wo,
+                                                  const float* __restrict__ bo, float* __restrict__ X1,
+                                                  float* __restrict__ OC, int64_t E, int64_t R) {
+    TRR_PROLOGUE(R);
+    Split2<8> xs;
+    {
+        float4 a[16];
+        load_rowfrag<16>(a, AO, row, D, L.h);
+        split_frag2<8>(a, xs);
+    }
+    row_gemm128_h<2>(wo, bo, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+        if (!valid) return;
+        float4 y[8];
+        acc_to_frag<2>(acc, y);
+        if (row < E) {
+            float4 xr[8];
+            load_rowfrag<8>(xr, X + 64 * c, row, D, L.h);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                y[k].x += xr[k].x; y[k].y += xr[k].y; y[k].z += xr[k].z; y[k].w += xr[k].w;
+            }
+            store_rowfrag<8>(y, X1 + 64 * c, row, D, L.h);
+        } else {
+            store_rowfrag<8>(y, OC + 64 * c, row - E, D, L.h);
+        }
+    });
+}
+
+__global__ __launch_bounds__(256) void k_oproj_bwd_h(const float* __restrict__ dX1, const float* __restrict__ dOC,
+                                                      W2 wob, float* __restrict__ dAO, int64_t E, int64_t R) {
+    TRR_PROLOGUE(R);
+    Split2<8> xs;
+    float inv;
+    {
+        float4 d[16];
+        if (row < E) load_rowfrag<16>(d, dX1, row, D, L.h);
+        else load_rowfrag<16>(d, dOC, row - E, D, L.h);
+        float sc;
+        inv = row_scale_pow2<16>(d, sc);
+        split_frag2<8>(d, xs);
+    }
+    row_gemm128_h<2>(wob, nullptr, xs, L, inv, [&](int c, f32x16 (&acc)[2]) {
+        if (valid) {
+            float4 y[8];
+            acc_to_frag<2>(acc, y);
+            store_rowfrag<8>(y, dAO + 64 * c, row, D, L.h);
+        }
+    });
+}
+
+// dXin = (row < E ? dX1 : 0) + RMSNorm^T(dQKV Win): K = 384 in three 128-wide slices. One power-of-two scale per
+// row: it only ever shrinks (a later slice with larger entries rescales the accumulators, exactly).
+__global__ __launch_bounds__(256) void k_qkv_bwd_h(const float* __restrict__ dQKV, const float* __restrict__ X,
+                                                    const float* __restrict__ gamma, W2 winb,
+                                                    const float* __restrict__ dX1, float* __restrict__ dXin, int64_t E,
+                                                    int64_t R) {
+    TRR_PROLOGUE(R);
+    auto widx = [&](int b) { return (size_t)b * 64 + L.lane; };  // tile 0; tile t at + t * 24 * 64
+    WBlk2<4> ring[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) ld_blk2<4>(ring[b], winb, widx(b), 24 * 64);
+    f32x16 dn[4], dnl[4];
+    acc_zero<4>(dn);
+    acc_zero<4>(dnl);
+    float4 d[16];
+    load_rowfrag<16>(d, dQKV, row, 3 * D, L.h);
+    float scale = 0.f, inv = 0.f;  // scale applied to what the accumulators hold, and its inverse
+#pragma unroll 1
+    for (int ks = 0; ks < 3; ks++) {
+        Split2<8> xs;
+        {
+            float sc;
+            const float iv = row_scale_pow2<16>(d, sc);  // d is now scaled by sc
+            if (ks == 0 || sc < scale) {
+                if (ks > 0) {  // larger entries than before: bring the running sums to the new scale
+                    const float f = sc * inv;
+                    acc_scale<4>(dn, f);
+                    acc_scale<4>(dnl, f);
+                }
+                scale = sc;
+                inv = iv;
+            } else if (sc > scale) {  // smaller slice: use the scale already in force
+                const float f = scale * iv;
+#pragma unroll
+                for (int kg = 0; kg < 16; kg++) { d[kg].x *= f; d[kg].y *= f; d[kg].z *= f; d[kg].w *= f; }
+            }
+            split_frag2<8>(d, xs);
+        }
+        if (ks + 1 < 3) load_rowfrag<16>(d, dQKV + 128 * (ks + 1), row, 3 * D, L.h);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            WBlk2<4>& wb = ring[kb & 3];
+            mfma3<4>(dn, dnl, wb, xs.h[kb], xs.l[kb]);
+            const int nb = 8 * ks + kb + 4;
+            if (nb < 24) ld_blk2<4>(wb, winb, widx(nb), 24 * 64);
+        }
+    }
+    fold_low<4>(dn, dnl);
+    acc_scale<4>(dn, inv);
+    float4 w[16], x[16];
+    acc_to_frag<4>(dn, w);
+    load_rowfrag<16>(x, X, row, D, L.h);
+#pragma unroll
+    for (int kg = 0; kg < 16; kg++) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
+        w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
+    }
+    rmsnorm_bwd_frag<16>(w, x);
+    if (valid) {
+        if (row < E) {
+            load_rowfrag<16>(x, dX1, row, D, L.h);
+#pragma unroll
+            for (int kg = 0; kg < 16; kg++) {
+                w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
+            }
+        }
+        store_rowfrag<16>(w, dXin, row, D, L.h);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // edge SwiGLU MLP: X2 = X1 + Wout (v * sig(g)) + b,  [v; g] = Win RMSNorm(X1) + b
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_emlp_t(const float* __restrict__ X1, const float* __restrict__ gamma,
@@ -873,22 +1048,27 @@ void set_bf16x6(int v) { g_bf16x6 = v ? 1 : 0; }
 bool use_bf16x6() { return g_bf16x6 != 0; }
 
 void trr_qkv(const float* X, const float* gamma, const Lin& qkv, float* QKV, int64_t R, hipStream_t st) {
-    if (g_bf16x6 && qkv.fwd3) k_qkv_b<<<grid_rows(R), 256, 0, st>>>(X, gamma, w3_fwd(qkv), qkv.b, QKV, R);
+    if (g_bf16x6 && g_f16x3 && qkv.fwd2) k_qkv_h<<<grid_rows(R), 256, 0, st>>>(X, gamma, w2_fwd(qkv), qkv.b, QKV, R);
+    else if (g_bf16x6 && qkv.fwd3) k_qkv_b<<<grid_rows(R), 256, 0, st>>>(X, gamma, w3_fwd(qkv), qkv.b, QKV, R);
     else k_qkv_t<<<grid_rows(R), 256, 0, st>>>(X, gamma, qkv.fwd, qkv.b, QKV, R);
 }
 void trr_qkv_bwd(const float* dQKV, const float* X, const float* gamma, const Lin& qkv, const float* dX1,
                  float* dXin, int64_t E, int64_t R, hipStream_t st) {
-    if (g_bf16x6 && qkv.bwd3) k_qkv_bwd_b<<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, w3_bwd(qkv), dX1, dXin, E, R);
+    if (g_bf16x6 && g_f16x3 && qkv.bwd2)
+        k_qkv_bwd_h<<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, w2_bwd(qkv), dX1, dXin, E, R);
+    else if (g_bf16x6 && qkv.bwd3) k_qkv_bwd_b<<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, w3_bwd(qkv), dX1, dXin, E, R);
     else k_qkv_bwd_t<<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, qkv.bwd, dX1, dXin, E, R);
 }
 void trr_oproj(const float* AO, const float* X, const Lin& out, float* X1, float* OC, int64_t E, int64_t R,
                hipStream_t st) {
-    if (g_bf16x6 && out.fwd3) k_oproj_b<<<grid_rows(R), 256, 0, st>>>(AO, X, w3_fwd(out), out.b, X1, OC, E, R);
+    if (g_bf16x6 && g_f16x3 && out.fwd2) k_oproj_h<<<grid_rows(R), 256, 0, st>>>(AO, X, w2_fwd(out), out.b, X1, OC, E, R);
+    else if (g_bf16x6 && out.fwd3) k_oproj_b<<<grid_rows(R), 256, 0, st>>>(AO, X, w3_fwd(out), out.b, X1, OC, E, R);
     else k_oproj_t<<<grid_rows(R), 256, 0, st>>>(AO, X, out.fwd, out.b, X1, OC, E, R);
 }
 void trr_oproj_bwd(const float* dX1, const float* dOC, const Lin& out, float* dAO, int64_t E, int64_t R,
                    hipStream_t st) {
-    if (g_bf16x6 && out.bwd3) k_oproj_bwd_b<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, w3_bwd(out), dAO, E, R);
+    if (g_bf16x6 && g_f16x3 && out.bwd2) k_oproj_bwd_h<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, w2_bwd(out), dAO, E, R);
+    else if (g_bf16x6 && out.bwd3) k_oproj_bwd_b<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, w3_bwd(out), dAO, E, R);
     else k_oproj_bwd_t<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, out.bwd, dAO, E, R);
 }
 void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wout, float* VG, float* X2,

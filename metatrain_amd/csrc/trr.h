@@ -321,6 +321,31 @@ __device__ __forceinline__ void fold_low(f32x16 (&acc)[NT], const f32x16 (&acl)[
         for (int r = 0; r < 16; r++) acc[t][r] += acl[t][r] * (1.0f / 2048.0f);
 }
 
+// Adjoint rows can be small as a whole (loss-dependent seeds): scale the row by the power of two that puts its
+// largest element in [1, 2) before an f16x3 split, and the result back afterwards (both exact).
+// Returns the inverse scale; `sc` receives the scale that was applied.
+template <int KG>
+__device__ __forceinline__ float row_scale_pow2(float4 (&x)[KG], float& sc) {
+    float m = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++)
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(x[kg].x), fabsf(x[kg].y))), fmaxf(fabsf(x[kg].z), fabsf(x[kg].w)));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    int e = (__float_as_int(m) >> 23) & 0xff;
+    e = e > 253 ? 253 : e;
+    sc = __int_as_float((254 - e) << 23);  // 2^(127 - e)
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) { x[kg].x *= sc; x[kg].y *= sc; x[kg].z *= sc; x[kg].w *= sc; }
+    return __int_as_float(e << 23);        // 2^(e - 127); 0 for an all-zero row, whose outputs are 0 anyway
+}
+template <int NT>
+__device__ __forceinline__ void acc_scale(f32x16 (&acc)[NT], float f) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] *= f;
+}
+
 // sum over the row: lane-local + the partner lane holding the other half of the features
 __device__ __forceinline__ float row_sum(float v) { return v + __shfl_xor(v, 32); }
 
