@@ -1024,6 +1024,109 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_b(const float* __restrict__ dY
 // ---------------------------------------------------------------------------------
 // host launchers (declared in model.h)
 // ---------------------------------------------------------------------------------
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void k_emlp_bwd_h(const float* __restrict__ dY, const float* __restrict__ X1,
+                                                     const float* __restrict__ VG, const float* __restrict__ gamma,
+                                                     W2 woutb, W2 winb, float* __restrict__ dX1, int64_t E,
+                                                     float* __restrict__ t_dvg) {
+    TRR_PROLOGUE(E);
+    constexpr int NC = DFF / 32;
+    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };  // b = 8 hc + kb: tile hc, kb_total = 8
+    auto bkb = [&](int b) { const int hc = b >> 2, j = b & 3; return (j < 2 ? 2 * hc + j : 16 + 2 * hc + (j - 2)); };
+    auto bidx = [&](int b) { return (size_t)bkb(b) * 64 + L.lane; };  // tile 0; tile t at + t * 32 * 64
+    WBlk2<1> ra[4];
+    WBlk2<4> rb[2];
+#pragma unroll
+    for (int b = 0; b < 4; b++) ld_blk2<1>(ra[b], woutb, aidx(b), 0);
+#pragma unroll
+    for (int b = 0; b < 2; b++) ld_blk2<4>(rb[b], winb, bidx(b), 32 * 64);
+    Split2<8> ys;
+    float inv;  // dY is an adjoint: one power-of-two scale per row, undone on everything that leaves the kernel
+    {
+        float4 dy[16];
+        load_rowfrag<16>(dy, dY, row, D, L.h);
+        float sc;
+        inv = row_scale_pow2<16>(dy, sc);
+        split_frag2<8>(dy, ys);
+    }
+    f32x16 dn[4], dnl[4];
+    acc_zero<4>(dn);
+    acc_zero<4>(dnl);
+    float4 vv[4], gg[4];  // saved pre-activations of the current chunk
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        vv[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + 8 * q + 4 * L.h);
+        gg[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + DFF + 8 * q + 4 * L.h);
+    }
+#pragma unroll 1
+    for (int hc = 0; hc < NC; hc++) {
+        f32x16 du[1], dul[1];
+        acc_zero<1>(du);
+        acc_zero<1>(dul);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            WBlk2<1>& wb = ra[kb & 3];
+            mfma3<1>(du, dul, wb, ys.h[kb], ys.l[kb]);
+            const int nb = 8 * hc + kb + 4;
+            if (nb < 8 * NC) ld_blk2<1>(wb, woutb, aidx(nb), 0);
+        }
+        fold_low<1>(du, dul);
+        float4 dvg[8];  // dv (4) then dg (4): the K = 64 operand of stream B
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 d = acc_q(du[0], q);
+            const float sx = sigm_(gg[q].x), sy = sigm_(gg[q].y), sz = sigm_(gg[q].z), sw = sigm_(gg[q].w);
+            dvg[q] = make_float4(d.x * sx, d.y * sy, d.z * sz, d.w * sw);
+            dvg[4 + q] = make_float4(d.x * vv[q].x * sx * (1.f - sx), d.y * vv[q].y * sy * (1.f - sy),
+                                     d.z * vv[q].z * sz * (1.f - sz), d.w * vv[q].w * sw * (1.f - sw));
+            if (TRAIN && valid) {
+                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) =
+                    make_float4(dvg[q].x * inv, dvg[q].y * inv, dvg[q].z * inv, dvg[q].w * inv);
+                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) =
+                    make_float4(dvg[4 + q].x * inv, dvg[4 + q].y * inv, dvg[4 + q].z * inv, dvg[4 + q].w * inv);
+            }
+        }
+        if (hc + 1 < NC) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                vv[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + 32 * (hc + 1) + 8 * q + 4 * L.h);
+                gg[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + DFF + 32 * (hc + 1) + 8 * q + 4 * L.h);
+            }
+        }
+        Split2<4> ds;
+        split_frag2<4>(dvg, ds);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            WBlk2<4>& wb = rb[j & 1];
+            mfma3<4>(dn, dnl, wb, ds.h[j], ds.l[j]);
+            const int nb = 4 * hc + j + 2;
+            if (nb < 4 * NC) ld_blk2<4>(wb, winb, bidx(nb), 32 * 64);
+        }
+    }
+    fold_low<4>(dn, dnl);
+    acc_scale<4>(dn, inv);
+    float4 w[16], x[16];
+    acc_to_frag<4>(dn, w);
+    load_rowfrag<16>(x, X1, row, D, L.h);
+#pragma unroll
+    for (int kg = 0; kg < 16; kg++) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
+        w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
+    }
+    rmsnorm_bwd_frag<16>(w, x);
+    if (valid) {
+        load_rowfrag<16>(x, dY, row, D, L.h);
+#pragma unroll
+        for (int kg = 0; kg < 16; kg++) {
+            w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
+        }
+        store_rowfrag<16>(w, dX1, row, D, L.h);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// host launchers (declared in model.h)
+// ---------------------------------------------------------------------------------
 static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
 
 // pet_config_set("bf16x6", 0) puts the TRR stages back on the fp32 MFMA. Default: GEMMs on the bf16 matrix cores
@@ -1091,7 +1194,10 @@ void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wo
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
                   const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg) {
     const int grid = grid_rows(E);
-    if (g_bf16x6 && win.bwd3 && wout.bwd3) {
+    if (g_bf16x6 && g_f16x3 && win.bwd2 && wout.bwd2) {
+        if (t_dvg) k_emlp_bwd_h<true><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, t_dvg);
+        else k_emlp_bwd_h<false><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, nullptr);
+    } else if (g_bf16x6 && win.bwd3 && wout.bwd3) {
         if (t_dvg) k_emlp_bwd_b<true><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w3_bwd(wout), w3_bwd(win), dX1, E, t_dvg);
         else k_emlp_bwd_b<false><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w3_bwd(wout), w3_bwd(win), dX1, E, nullptr);
     } else {
