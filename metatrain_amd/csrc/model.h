@@ -131,6 +131,7 @@ void set_bf16x6(int v);     // pet_trr.hip: 1 = GEMM stages on the bf16 matrix c
 void set_attn_lds(int v);   // pet_attn.hip: 1 = LDS-staged attention (default), 0 = wave-per-head from global
 void set_soap_mfma(int v);  // soap.hip: 1 = MFMA tail (default), 0 = per-atom tail kernels
 void set_soap_fused(int v);  // soap.hip: 1 = power spectrum + LayerNorm + first Linear fused, features never stored (default 0)
+bool use_f16x3();
 void set_f16x3(int v);        // pet_trr.hip: 1 = f16x3 GEMMs where built (default), 0 = bf16x6
 void set_trr_persist(int v);  // pet_trr.hip: 1 = persistent emlp kernel with LDS-DMA row prefetch (default)
 void set_soap_sorted(int v);  // soap.hip: 1 = tail GEMM on species-sorted tiles, one network per tile (default)

@@ -336,12 +336,26 @@ __global__ __launch_bounds__(256) void k_oproj_h(const float* __restrict__ AO, c
                                                   float* __restrict__ OC, int64_t E, int64_t R) {
     TRR_PROLOGUE(R);
     Split2<8> xs;
+    float inv;  // attention outputs are not normalised rows: scale them like an adjoint (the bias is added after)
     {
         float4 a[16];
         load_rowfrag<16>(a, AO, row, D, L.h);
+        float sc;
+        inv = row_scale_pow2<16>(a, sc);
         split_frag2<8>(a, xs);
     }
-    row_gemm128_h<2>(wo, bo, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2>(wo, nullptr, xs, L, inv, [&](int c, f32x16 (&acc)[2]) {
+        {   // + bias, which must not be scaled with the row
+            float4 bb[8];
+            ld_bias<2>(bb, bo, 64 * c, L.h);
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    acc[t][4 * q] += bb[4 * t + q].x; acc[t][4 * q + 1] += bb[4 * t + q].y;
+                    acc[t][4 * q + 2] += bb[4 * t + q].z; acc[t][4 * q + 3] += bb[4 * t + q].w;
+                }
+        }
         if (!valid) return;
         float4 y[8];
         acc_to_frag<2>(acc, y);
@@ -1135,6 +1149,7 @@ static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
 // prefetch their weight fragments through rings that run across the GEMM boundaries.
 static int g_f16x3 = 1;  // pet_config_set("f16x3", 0): the bf16x6 kernels everywhere
 void set_f16x3(int v) { g_f16x3 = v ? 1 : 0; }
+bool use_f16x3() { return g_f16x3 != 0; }
 static int g_trr_persist = 1;
 void set_trr_persist(int v) { g_trr_persist = v ? 1 : 0; }
 static int num_cus() {
