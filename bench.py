@@ -26,10 +26,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-# The default GEMM stages compute fp32 products as six bf16 MFMA terms (bf16x6): their FLOP/s
+# The default GEMM stages compute fp32 products as three fp16 MFMA terms (f16x3): their FLOP/s
 # are fp32-equivalent (2 M N K / time). `peak` stays the fp32 MFMA figure (the roof of the arithmetic the path
-# delivers); the bf16 pipe's own ceiling for this scheme, 2.5 PFLOP/s / 6 terms, is reported next to it.
-MFMA_BF16X6_EQUIV_PEAK_TFLOPS = 2500.0 / 6.0
+# delivers); the 16-bit pipe's own ceiling for this scheme, 2.5 PFLOP/s / 3 terms, is reported next to it.
+MFMA_SPLIT_EQUIV_PEAK_TFLOPS = 2500.0 / 3.0
 ATOMS_PER_BOX = 10000
 
 
@@ -44,9 +44,10 @@ def synthetic_params(hypers):
 # ProfScope stage -> the kernels it launches (base names, template arguments stripped). The attention stages
 # launch one kernel per neighbour-count bucket (NT = 1, 2, 3 ...): their traffic is the sum over the buckets.
 STAGE_KERNELS = {"attn_bwd": ("k_attn_bwd_a", "k_attn_bwd_l", "k_attn_bwd_p"), "attn_fwd": ("k_attn_fwd_p", "k_attn_fwd_l"),
-                 "emlp": ("k_emlp_p", "k_emlp_b", "k_emlp_t"), "emlp_bwd": ("k_emlp_bwd_b", "k_emlp_bwd_t"),
-                 "qkv": ("k_qkv_b", "k_qkv_t"), "qkv_bwd": ("k_qkv_bwd_b", "k_qkv_bwd_t"),
-                 "comb": ("k_comb_b", "k_comb"), "comb_bwd": ("k_comb_bwd_b", "k_comb_bwd")}
+                 "emlp": ("k_emlp_h", "k_emlp_p", "k_emlp_b", "k_emlp_t"),
+                 "emlp_bwd": ("k_emlp_bwd_h", "k_emlp_bwd_b", "k_emlp_bwd_t"),
+                 "qkv": ("k_qkv_h", "k_qkv_b", "k_qkv_t"), "qkv_bwd": ("k_qkv_bwd_h", "k_qkv_bwd_b", "k_qkv_bwd_t"),
+                 "comb": ("k_comb_h", "k_comb_b", "k_comb"), "comb_bwd": ("k_comb_bwd_h", "k_comb_bwd_b", "k_comb_bwd")}
 
 
 BF16X6_STAGES = {"emlp", "emlp_bwd", "qkv", "qkv_bwd", "oproj", "oproj_bwd", "comb", "comb_bwd"}
@@ -245,11 +246,11 @@ def main():
                     "algorithmic_flops_per_launch": flops_per_launch, "traffic": None}
         roof["traffic"] = pmc_traffic(dominant, int(graph.n_edges))
         if not hbm_bound:
-            roof["arithmetic"] = ("fp32 via 3-way-split bf16 MFMA (six products per term, fp32 accumulate)"
+            roof["arithmetic"] = ("fp32 via 2-way-split fp16 MFMA (f16x3: three products per term, fp32 accumulate)"
                                   if dominant in BF16X6_STAGES else "fp32 MFMA")
             if dominant in BF16X6_STAGES:
-                roof["peak_bf16x6_equivalent"] = MFMA_BF16X6_EQUIV_PEAK_TFLOPS
-                roof["frac_of_bf16x6_equivalent"] = achieved / MFMA_BF16X6_EQUIV_PEAK_TFLOPS
+                roof["peak_f16x3_equivalent"] = MFMA_SPLIT_EQUIV_PEAK_TFLOPS
+                roof["frac_of_f16x3_equivalent"] = achieved / MFMA_SPLIT_EQUIV_PEAK_TFLOPS
         roof["whole_step_algorithmic_tflops"] = None
         roof["stages_single_stream_ms"] = {r["name"]: round(r["total_ms"], 3)
                                            for r in sorted(table, key=lambda r: -r["total_ms"])[:8]}

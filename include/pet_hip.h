@@ -233,7 +233,9 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
 /* Runtime switches used by tests / the benchmark (every setting meets the same parity bar):
  *   "side_stream" 1 = node-feature chain on a second HIP stream (default)
  *   "trr"         1 = register-resident stage kernels (default); 0 = the LDS-tile kernels
- *   "bf16x6"      1 = TRR / combination GEMMs as 3-way-split bf16 MFMA, fp32 accuracy (default); 0 = fp32 MFMA
+ *   "bf16x6"      1 = TRR / combination GEMMs as split-operand products on the 16-bit matrix cores, fp32 accuracy
+ *                 (default); 0 = fp32 MFMA
+ *   "f16x3"       1 = 2-way fp16 split, three MFMAs per K block (default); 0 = 3-way bf16 split, six MFMAs
  *   "trr_persist" 1 = persistent edge-MLP kernel with LDS-DMA prefetch of the next tile's rows (default)
  *   "so_bf16x6"   the same choice for the generic GEMM of the second-order (training) pass
  *   "attn_lds"    attention kernels: 0 global-memory, 1 per-atom LDS-staged adjoint, 2 LDS-staged forward and
