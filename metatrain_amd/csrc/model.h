@@ -132,6 +132,10 @@ void set_attn_lds(int v);   // pet_attn.hip: 1 = LDS-staged attention (default),
 void set_soap_mfma(int v);  // soap.hip: 1 = MFMA tail (default), 0 = per-atom tail kernels
 void set_soap_fused(int v);  // soap.hip: 1 = power spectrum + LayerNorm + first Linear fused, features never stored (default 0)
 bool use_f16x3();
+bool use_tile_f16x3();
+void set_tile_f16x3(int v);
+void set_tile_mask(int v);
+int tile_mask();
 void set_f16x3(int v);        // pet_trr.hip: 1 = f16x3 GEMMs where built (default), 0 = bf16x6
 void set_trr_persist(int v);  // pet_trr.hip: 1 = persistent emlp kernel with LDS-DMA row prefetch (default)
 void set_soap_sorted(int v);  // soap.hip: 1 = tail GEMM on species-sorted tiles, one network per tile (default)

@@ -54,8 +54,7 @@ __global__ __launch_bounds__(NTHREADS) void k_compress(const float4* __restrict_
                                                         const float* __restrict__ wc,   // [D,4]
                                                         const float* __restrict__ tbl,  // [ns,D]
                                                         const float* __restrict__ Min,  // [E,D] (!FIRST)
-                                                        const float4* __restrict__ w0c,
-                                                        const float4* __restrict__ w2,
+                                                        WX w0c, WX w2,
                                                         const float* __restrict__ b2,
                                                         float* __restrict__ a0_out,  // [E,D] or null
                                                         float* __restrict__ Xout,    // [E,D]
@@ -65,6 +64,7 @@ __global__ __launch_bounds__(NTHREADS) void k_compress(const float4* __restrict_
     float* A = smem + BM * LD128;    // [64][132] (!FIRST)
     float4* geo_s = reinterpret_cast<float4*>(smem + (FIRST ? 1 : 2) * BM * LD128);  // [64]
     int* sp_s = reinterpret_cast<int*>(geo_s + BM);                                   // [64]
+    float* rs = reinterpret_cast<float*>(sp_s + BM);  // [64][2] power-of-two row scales for the f16x3 GEMMs
     const WaveId w;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     if (threadIdx.x < BM) {
@@ -86,6 +86,11 @@ __global__ __launch_bounds__(NTHREADS) void k_compress(const float4* __restrict_
     } else {
         f32x16 acc[2];
         const int col0 = 64 * w.ch;
+        acc_fill_bias<2>(acc, nullptr, 0, w.lane);
+        gemm_acc_x<128, 2>(A + w.rb * 32 * LD128, LD128, w0c, 16, 0, 2 * w.ch, acc, w.lane);
+        // The geometry / species terms are added AFTER the GEMM. With them pre-filled into `acc` and live across
+        // gemm_acc_x, a few (row, 16-column) groups of the result came out different from launch to launch
+        // (same inputs, same weights; lanes 48..63 of one wave): not understood, avoided by this order.
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const int c = col0 + 32 * t + (w.lane & 31);
@@ -94,10 +99,9 @@ __global__ __launch_bounds__(NTHREADS) void k_compress(const float4* __restrict_
             for (int r = 0; r < 16; r++) {
                 const int row = w.rb * 32 + acc_row(r, w.lane);
                 float4 g = geo_s[row];
-                acc[t][r] = fmaf(g.w, wv.w, fmaf(g.z, wv.z, fmaf(g.y, wv.y, g.x * wv.x))) + tbl[sp_s[row] * D + c];
+                acc[t][r] += fmaf(g.w, wv.w, fmaf(g.z, wv.z, fmaf(g.y, wv.y, g.x * wv.x))) + tbl[sp_s[row] * D + c];
             }
         }
-        gemm_acc<128, 2>(A + w.rb * 32 * LD128, LD128, w0c, 16, 0, 2 * w.ch, acc, w.lane);
         acc_foreach<2>(acc, w.rb, col0, w.lane, [&](int r, int c, float v) {
             if (a0_out && row0 + r < E) a0_out[(row0 + r) * D + c] = v;
             S[r * LD128 + c] = siluf_(v);
@@ -106,14 +110,14 @@ __global__ __launch_bounds__(NTHREADS) void k_compress(const float4* __restrict_
     __syncthreads();
     f32x16 acc2[2];
     acc_fill_bias<2>(acc2, b2, 64 * w.ch, w.lane);
-    gemm_acc<128, 2>(S + w.rb * 32 * LD128, LD128, w2, 16, 0, 2 * w.ch, acc2, w.lane);
+    gemm_acc_x<128, 2>(S + w.rb * 32 * LD128, LD128, w2, 16, 0, 2 * w.ch, acc2, w.lane);
     store_acc<2>(acc2, Xout, row0, E, D, w.rb, 64 * w.ch, w.lane);
 }
 
 // ---------------------------------------------------------------------------------
 // centre contraction: X[E + i] = H[i] Wcc^T + b   (DN -> D)
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHREADS) void k_center(const float* __restrict__ H, const float4* __restrict__ wcc,
+__global__ __launch_bounds__(NTHREADS) void k_center(const float* __restrict__ H, WX wcc,
                                                       const float* __restrict__ bcc, float* __restrict__ Xc,
                                                       int64_t N) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(NTHREADS) void k_center(const float* __restrict__ H
     __syncthreads();
     f32x16 acc[2];
     acc_fill_bias<2>(acc, bcc, 64 * w.ch, w.lane);
-    gemm_acc<256, 2>(smem + w.rb * 32 * LD256, LD256, wcc, 32, 0, 2 * w.ch, acc, w.lane);
+    gemm_acc_x<256, 2>(smem + w.rb * 32 * LD256, LD256, wcc, 32, 0, 2 * w.ch, acc, w.lane);
     store_acc<2>(acc, Xc, row0, N, D, w.rb, 64 * w.ch, w.lane);
 }
 
@@ -277,10 +281,10 @@ __global__ __launch_bounds__(NTHREADS) void k_oproj(const float* __restrict__ AO
 // node update: h1 = h + OC Wce^T + b ; h2 = h1 + SwiGLU_MLP(RMSNorm(h1))
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(NTHREADS) void k_node(const float* __restrict__ H, const float* __restrict__ OC,
-                                                    const float4* __restrict__ wce, const float* __restrict__ bce,
-                                                    const float* __restrict__ gamma,
-                                                    const float4* __restrict__ win, const float* __restrict__ bin,
-                                                    const float4* __restrict__ wout, const float* __restrict__ bout,
+                                                    WX wce, const float* __restrict__ bce,
+                                                    const float* __restrict__ gamma, WX win,
+                                                    const float* __restrict__ bin, WX wout,
+                                                    const float* __restrict__ bout,
                                                     float* __restrict__ H1, float* __restrict__ VGn,
                                                     float* __restrict__ Hn, int64_t N) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(NTHREADS) void k_node(const float* __restrict__ H, 
         f32x16 acc[2];
         const int col0 = 128 * c + 64 * w.ch;
         acc_fill_bias<2>(acc, bce, col0, w.lane);
-        gemm_acc<128, 2>(U + w.rb * 32 * LD128, LD128, wce, 16, 0, 4 * c + 2 * w.ch, acc, w.lane);
+        gemm_acc_x<128, 2>(U + w.rb * 32 * LD128, LD128, wce, 16, 0, 4 * c + 2 * w.ch, acc, w.lane);
         acc_foreach<2>(acc, w.rb, col0, w.lane, [&](int r, int cc, float v) {
             const int64_t row = row0 + r;
             float h1 = v + (row < N ? H[row * DN + cc] : 0.f);
@@ -314,8 +318,8 @@ __global__ __launch_bounds__(NTHREADS) void k_node(const float* __restrict__ H, 
         const int hcol0 = 128 * hc + 64 * w.ch;  // hidden columns of this wave
         acc_fill_bias<2>(av, bin, hcol0, w.lane);
         acc_fill_bias<2>(ag, bin, DNF + hcol0, w.lane);
-        gemm_acc<256, 2>(Hs + w.rb * 32 * LD256, LD256, win, 32, 0, hcol0 / 32, av, w.lane);
-        gemm_acc<256, 2>(Hs + w.rb * 32 * LD256, LD256, win, 32, 0, (DNF + hcol0) / 32, ag, w.lane);
+        gemm_acc_x<256, 2>(Hs + w.rb * 32 * LD256, LD256, win, 32, 0, hcol0 / 32, av, w.lane);
+        gemm_acc_x<256, 2>(Hs + w.rb * 32 * LD256, LD256, win, 32, 0, (DNF + hcol0) / 32, ag, w.lane);
         __syncthreads();  // previous chunk's readers of U are done
 #pragma unroll
         for (int t = 0; t < 2; t++) {
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(NTHREADS) void k_node(const float* __restrict__ H, 
             }
         }
         __syncthreads();
-        gemm_acc<128, 4>(U + w.rb * 32 * LD128, LD128, wout, DNF / 8, 16 * hc, 4 * w.ch, out, w.lane);
+        gemm_acc_x<128, 4>(U + w.rb * 32 * LD128, LD128, wout, DNF / 8, 16 * hc, 4 * w.ch, out, w.lane);
     }
     acc_foreach<4>(out, w.rb, 128 * w.ch, w.lane, [&](int r, int c, float v) {
         const int64_t row = row0 + r;
@@ -484,8 +488,8 @@ __global__ __launch_bounds__(NTHREADS) void k_comb(const float* __restrict__ XF,
 // heads: y = w . SiLU(W2 SiLU(W0 x + b0) + b2) + b     (backend.py:171-217, 726-777)
 // ---------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(NTHREADS) void k_head(const float* __restrict__ Xin, const float4* __restrict__ w0,
-                                                    const float* __restrict__ b0, const float4* __restrict__ w2,
+__global__ __launch_bounds__(NTHREADS) void k_head(const float* __restrict__ Xin, WX w0,
+                                                    const float* __restrict__ b0, WX w2,
                                                     const float* __restrict__ b2, const float* __restrict__ wl,
                                                     float bl, const float* __restrict__ fc /* or null */,
                                                     float* __restrict__ ypred, float* __restrict__ yout,
@@ -500,11 +504,11 @@ __global__ __launch_bounds__(NTHREADS) void k_head(const float* __restrict__ Xin
     __syncthreads();
     f32x16 acc[2];
     acc_fill_bias<2>(acc, b0, 64 * w.ch, w.lane);
-    gemm_acc<K, 2>(A + w.rb * 32 * LDK, LDK, w0, K / 8, 0, 2 * w.ch, acc, w.lane);
+    gemm_acc_x<K, 2>(A + w.rb * 32 * LDK, LDK, w0, K / 8, 0, 2 * w.ch, acc, w.lane);
     acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) { S[r * LD128 + c] = siluf_(v); });
     __syncthreads();
     acc_fill_bias<2>(acc, b2, 64 * w.ch, w.lane);
-    gemm_acc<128, 2>(S + w.rb * 32 * LD128, LD128, w2, 16, 0, 2 * w.ch, acc, w.lane);
+    gemm_acc_x<128, 2>(S + w.rb * 32 * LD128, LD128, w2, 16, 0, 2 * w.ch, acc, w.lane);
     __syncthreads();
     acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) { S[r * LD128 + c] = siluf_(v) * wl[c]; });
     __syncthreads();
@@ -559,6 +563,18 @@ double g_sum_t2(const Graph& g) {
     return (double)g.n_nodes * t * t;
 }
 
+// both operand forms of a Linear for the LDS-tile kernels: fp16 planes when f16x3 is on and the weight was packed
+static inline WX wx_fwd(const Lin& L, int bit = 0) {
+    WX w;
+    w.f = L.fwd;
+    if (use_tile_f16x3() && L.fwd2 && !(tile_mask() & bit)) {
+        const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
+        w.h = reinterpret_cast<const f16x8_t*>(L.fwd2);
+        w.l = w.h + n8;
+    }
+    return w;
+}
+
 int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
             float* node_feat, float* edge_feat, hipStream_t st) {
     Workspace w;
@@ -572,7 +588,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
     const float scale = 1.0f / (sqrtf((float)HD) * m.h.attention_temperature);
     const int gE = cdiv(E, BM), gN = cdiv(N, BM), gR = cdiv(R, BM);
     const size_t lds1 = BM * LD128 * 4, lds2 = 2 * BM * LD128 * 4;
-    const size_t lds_c = lds2 + BM * 20;
+    const size_t lds_c = lds2 + BM * 20 + BM * 8;
     const double fE = (double)E, fN = (double)N, fR = (double)R;
     const bool trr = use_trr();
     // attention: 4 T^2 d FLOPs per atom per layer; T^2 summed on the host side of the graph
@@ -588,7 +604,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
         const AttnLayerW& A = m.gnn[gi].attn[a];
         AttnBufs& Ab = w.gnn[gi].attn[a];
         ProfScope ps("center", s2, fN * 2.0 * DN * D);
-        k_center<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(Ab.H, A.cc.fwd, A.cc.b, Ab.X + E * D, N);
+        k_center<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(Ab.H, wx_fwd(A.cc, 2), A.cc.b, Ab.X + E * D, N);
     };
     k_node_embed<<<cdiv(N * (DN / 4), 256), 256, 0, st>>>(g.sp, m.node_emb, w.H0, (int)N);
     ss.fork(st);
@@ -601,12 +617,12 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
         if (E > 0) {
             ProfScope ps("compress", st, fE * 2.0 * (D * D * (gi == 0 ? 3 : 4) + 4 * D));
             if (gi == 0)
-                k_compress<true><<<gE, NTHREADS, lds1 + BM * 20, st>>>(g.geo, g.sp_nbr, G.wc, G.tbl, nullptr, nullptr,
-                                                                        G.compress2.fwd, G.compress2.b, B.a0,
+                k_compress<true><<<gE, NTHREADS, lds1 + BM * 20 + BM * 8, st>>>(g.geo, g.sp_nbr, G.wc, G.tbl, nullptr, WX(),
+                                                                        wx_fwd(G.compress2, 1), G.compress2.b, B.a0,
                                                                         B.attn[0].X, E);
             else
                 k_compress<false><<<gE, NTHREADS, lds_c, st>>>(g.geo, g.sp_nbr, G.wc, G.tbl, Min,
-                                                               G.compress0_msg.fwd, G.compress2.fwd, G.compress2.b,
+                                                               wx_fwd(G.compress0_msg, 128), wx_fwd(G.compress2, 256), G.compress2.b,
                                                                B.a0, B.attn[0].X, E);
         }
         for (int a = 0; a < m.h.num_attention_layers; a++) {
@@ -643,7 +659,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
             {
                 ProfScope ps("node", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
                 k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
-                    Ab.H, Ab.OC, A.ce.fwd, A.ce.b, A.g_center, A.cmlp_in.fwd, A.cmlp_in.b, A.cmlp_out.fwd,
+                    Ab.H, Ab.OC, wx_fwd(A.ce, 4), A.ce.b, A.g_center, wx_fwd(A.cmlp_in, 8), A.cmlp_in.b, wx_fwd(A.cmlp_out, 16),
                     A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
             }
             if (a + 1 < m.h.num_attention_layers) launch_center(gi, a + 1);
@@ -674,11 +690,11 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
     {
         ProfScope ps("head_node", s2, fN * 2.0 * (DN * DH + DH * DH + DH));
         k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
-            last.Hout, m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nll_w, m.nll_b, nullptr, nullptr, w.ynode, N);
+            last.Hout, wx_fwd(m.nh0, 32), m.nh0.b, wx_fwd(m.nh2, 32), m.nh2.b, m.nll_w, m.nll_b, nullptr, nullptr, w.ynode, N);
     }
     if (E > 0) {
         ProfScope ps("head_edge", st, fE * 2.0 * (D * DH + DH * DH + DH));
-        k_head<128><<<gE, NTHREADS, lds2, st>>>(last.Mout, m.eh0.fwd, m.eh0.b, m.eh2.fwd, m.eh2.b, m.ell_w,
+        k_head<128><<<gE, NTHREADS, lds2, st>>>(last.Mout, wx_fwd(m.eh0, 64), m.eh0.b, wx_fwd(m.eh2, 64), m.eh2.b, m.ell_w,
                                                 m.ell_b, g.fc, w.ypred_e, w.ye, E);
     }
     ss.join(st);

@@ -1147,9 +1147,16 @@ static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
 // with 3-way split operands -- as accurate as the fp32 MFMA (3.7e-7 vs 4.5e-7 against fp64, tools/ubench/bf16x3.hip)
 // at 0.375x the matrix-core time. The split fragments cost registers (one wave per SIMD), so these kernels
 // prefetch their weight fragments through rings that run across the GEMM boundaries.
+static int g_bf16x6 = 1;
 static int g_f16x3 = 1;  // pet_config_set("f16x3", 0): the bf16x6 kernels everywhere
 void set_f16x3(int v) { g_f16x3 = v ? 1 : 0; }
 bool use_f16x3() { return g_f16x3 != 0; }
+static int g_tile_f16x3 = 1;  // pet_config_set("tile_f16x3", 0): LDS-tile kernels (compress, heads, node chain) on fp32 MFMA
+void set_tile_f16x3(int v) { g_tile_f16x3 = v ? 1 : 0; }
+static int g_tile_mask = 0;  // debugging aid: bits switch individual LDS-tile GEMMs back to fp32 MFMA
+void set_tile_mask(int v) { g_tile_mask = v; }
+int tile_mask() { return g_tile_mask; }
+bool use_tile_f16x3() { return g_f16x3 != 0 && g_tile_f16x3 != 0 && g_bf16x6 != 0; }
 static int g_trr_persist = 1;
 void set_trr_persist(int v) { g_trr_persist = v ? 1 : 0; }
 static int num_cus() {
@@ -1161,7 +1168,6 @@ static int num_cus() {
     }
     return n;
 }
-static int g_bf16x6 = 1;
 void set_bf16x6(int v) { g_bf16x6 = v ? 1 : 0; }
 bool use_bf16x6() { return g_bf16x6 != 0; }
 

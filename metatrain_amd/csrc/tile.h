@@ -71,6 +71,96 @@ __device__ __forceinline__ void gemm_acc(const float* As, int lda, const float4*
     }
 }
 
+// ---- the same GEMM on the fp16 matrix cores (f16x3, see trr.h): the A tile stays fp32 in LDS and is split on
+// the fly as its fragments are read (two ds_read_b128 and ~30 VALU per K block of 16, against three 32-cycle MFMAs
+// per tile instead of eight 64-cycle ones); the weights come as two fp16 planes (abi.hip k_pack2h).
+// WX carries both operand forms; h == nullptr selects the fp32 MFMA path above.
+// rscale (optional, LDS [32][2] for this wave's row block: power-of-two scale and its inverse per row): for adjoint
+// tiles whose rows can be small as a whole; the contribution is accumulated locally and added as (hi + lo/2048)/scale.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+struct WX {
+    const float4* f = nullptr;
+    const f16x8_t* h = nullptr;
+    const f16x8_t* l = nullptr;
+};
+template <int KS, int NT>
+__device__ __forceinline__ void gemm_acc_x(const float* As, int lda, const WX& w, int kg_total, int kg0, int tile0,
+                                           f32x16 (&acc)[NT], int lane, const float* rscale = nullptr) {
+    if (w.h == nullptr) {
+        gemm_acc<KS, NT>(As, lda, w.f, kg_total, kg0, tile0, acc, lane);
+        return;
+    }
+    constexpr int KB = KS / 16;
+    const int kb_total = kg_total / 2, kb0 = kg0 / 2;
+    const float* arow = As + (lane & 31) * lda + (lane >> 5) * 4;
+    const float sc = rscale ? rscale[2 * (lane & 31)] : 1.0f;
+    size_t base[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) base[t] = ((size_t)(tile0 + t) * kb_total + kb0) * 64 + lane;
+    f16x8_t wh[2][NT], wl[2][NT];
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+        if (s < KB)
+#pragma unroll
+            for (int t = 0; t < NT; t++) { wh[s][t] = w.h[base[t] + s * 64]; wl[s][t] = w.l[base[t] + s * 64]; }
+    f32x16 ah[NT], al[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { ah[t][r] = 0.f; al[t][r] = 0.f; }
+#pragma unroll 2
+    for (int kb = 0; kb < KB; kb++) {
+        const int cur = kb & 1;
+        const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * kb);
+        const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * kb + 8);
+        const float v[8] = {a0.x * sc, a0.y * sc, a0.z * sc, a0.w * sc, a1.x * sc, a1.y * sc, a1.z * sc, a1.w * sc};
+        f16x8_t xh, xl;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const _Float16 hj = (_Float16)v[j];
+            xh[j] = hj;
+            xl[j] = (_Float16)((v[j] - (float)hj) * 2048.0f);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) al[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl[cur][t], al[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) ah[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh[cur][t], ah[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) al[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh[cur][t], al[t], 0, 0, 0);
+        if (kb + 2 < KB)
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                wh[cur][t] = w.h[base[t] + (kb + 2) * 64];
+                wl[cur][t] = w.l[base[t] + (kb + 2) * 64];
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float v = ah[t][r] + al[t][r] * (1.0f / 2048.0f);
+            acc[t][r] += rscale ? v * rscale[2 * acc_row(r, lane) + 1] : v;
+        }
+}
+// per-row power-of-two scales of a staged [64][K] tile: rs[2 r] = scale (row maximum into [1, 2)), rs[2 r + 1] = inverse
+template <int K>
+__device__ __forceinline__ void tile_row_scales(const float* As, int lda, float* rs) {
+    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    float m = 0.f;
+    for (int c = q * 4; c < K; c += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(As + r * lda + c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    m = fmaxf(m, __shfl_xor(m, 1));
+    m = fmaxf(m, __shfl_xor(m, 2));
+    int e = (__float_as_int(m) >> 23) & 0xff;
+    e = e > 253 ? 253 : e;
+    if (q == 0) {
+        rs[2 * r] = __int_as_float((254 - e) << 23);
+        rs[2 * r + 1] = __int_as_float(e << 23);
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void acc_fill_bias(f32x16 (&acc)[NT], const float* __restrict__ bias, int col0,
                                               int lane) {
