@@ -59,10 +59,10 @@ __device__ __forceinline__ void rmsnorm_bwd_rows(const float* Wt, const float* _
 // heads
 // ---------------------------------------------------------------------------------
 template <int K, bool EDGE, bool TRAIN>
-__global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__ Xin, const float4* __restrict__ w0f,
-                                                        const float* __restrict__ b0, const float4* __restrict__ w2f,
-                                                        const float* __restrict__ b2, const float4* __restrict__ w0b,
-                                                        const float4* __restrict__ w2b, const float* __restrict__ wl,
+__global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__ Xin, WX w0f,
+                                                        const float* __restrict__ b0, WX w2f,
+                                                        const float* __restrict__ b2, WX w0b,
+                                                        WX w2b, const float* __restrict__ wl,
                                                         const float* __restrict__ gA, const int* __restrict__ ctr,
                                                         const float* __restrict__ fc, const float* __restrict__ ypred,
                                                         float* __restrict__ dfc, float* __restrict__ dXout, int64_t R,
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
     float* A = smem;
     float* S = smem + BM * LDK;
     float* gy = S + BM * LD128;  // [64]
+    float* rs = gy + BM;         // [64][2] power-of-two row scales of the adjoint tiles (f16x3 GEMMs)
     const WaveId w;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     load_rows_to_lds<K>(A, Xin, row0, R, K);
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
     __syncthreads();
     f32x16 a1[2], acc[2];
     acc_fill_bias<2>(a1, b0, 64 * w.ch, w.lane);
-    gemm_acc<K, 2>(A + w.rb * 32 * LDK, LDK, w0f, K / 8, 0, 2 * w.ch, a1, w.lane);
+    gemm_acc_x<K, 2>(A + w.rb * 32 * LDK, LDK, w0f, K / 8, 0, 2 * w.ch, a1, w.lane);
     acc_foreach<2>(a1, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
         const float s1 = siluf_(v);
         S[r * LD128 + c] = s1;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
     });
     __syncthreads();
     acc_fill_bias<2>(acc, b2, 64 * w.ch, w.lane);
-    gemm_acc<128, 2>(S + w.rb * 32 * LD128, LD128, w2f, 16, 0, 2 * w.ch, acc, w.lane);
+    gemm_acc_x<128, 2>(S + w.rb * 32 * LD128, LD128, w2f, 16, 0, 2 * w.ch, acc, w.lane);
     __syncthreads();
     // da2 = gy * wl * silu'(a2)
     acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
@@ -114,7 +115,12 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
     });
     __syncthreads();
     acc_fill_bias<2>(acc, nullptr, 0, w.lane);
-    gemm_acc<128, 2>(S + w.rb * 32 * LD128, LD128, w2b, 16, 0, 2 * w.ch, acc, w.lane);  // ds1 = da2 W2
+    if (w2b.h) {
+        tile_row_scales<128>(S, LD128, rs);
+        __syncthreads();
+    }
+    gemm_acc_x<128, 2>(S + w.rb * 32 * LD128, LD128, w2b, 16, 0, 2 * w.ch, acc, w.lane,
+                       w2b.h ? rs + 64 * w.rb : nullptr);  // ds1 = da2 W2
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; t++)
@@ -129,7 +135,12 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
     constexpr int NTO = K / 64;  // output columns K split over the two column halves
     f32x16 dx[NTO];
     acc_fill_bias<NTO>(dx, nullptr, 0, w.lane);
-    gemm_acc<128, NTO>(S + w.rb * 32 * LD128, LD128, w0b, 16, 0, NTO * w.ch, dx, w.lane);  // dx = da1 W0
+    if (w0b.h) {
+        tile_row_scales<128>(S, LD128, rs);
+        __syncthreads();
+    }
+    gemm_acc_x<128, NTO>(S + w.rb * 32 * LD128, LD128, w0b, 16, 0, NTO * w.ch, dx, w.lane,
+                         w0b.h ? rs + 64 * w.rb : nullptr);  // dx = da1 W0
     acc_foreach<NTO>(dx, w.rb, (K / 2) * w.ch, w.lane, [&](int r, int c, float v) {
         if (row0 + r < R) dXout[(row0 + r) * K + c] = v;
     });
@@ -805,6 +816,28 @@ static void launch_attn_bwd(const float* QKV, const float* dAO, const Graph& g, 
                                                    (int)g.n_nodes, scale);
 }
 
+// both operand forms of a Linear for the LDS-tile kernels (tile.h gemm_acc_x); fwd: x W^T, bwd: dy W
+static inline WX wx_f(const Lin& L) {
+    WX w;
+    w.f = L.fwd;
+    if (use_tile_f16x3() && L.fwd2) {
+        const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
+        w.h = reinterpret_cast<const f16x8_t*>(L.fwd2);
+        w.l = w.h + n8;
+    }
+    return w;
+}
+static inline WX wx_b(const Lin& L) {
+    WX w;
+    w.f = L.bwd;
+    if (use_tile_f16x3() && L.bwd2) {
+        const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
+        w.h = reinterpret_cast<const f16x8_t*>(L.bwd2);
+        w.l = w.h + n8;
+    }
+    return w;
+}
+
 static int check_full_list(const Graph& g, hipStream_t st) {
     int bad = 0;
     PET_HIP_CHECK(hipMemcpyAsync(&bad, g.scalars + 2, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -820,13 +853,15 @@ int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* 
     const int gE = cdiv(E, BM), gN = cdiv(N, BM);
     const size_t lds2 = 2 * BM * LD128 * 4;
     const double fE = (double)E, fN = (double)N;
-    allow_big_lds(k_head_bwd<256, false, false>, (BM * LD256 + BM * LD128) * 4 + 256);
-    allow_big_lds(k_head_bwd<256, false, true>, (BM * LD256 + BM * LD128) * 4 + 256);
+    allow_big_lds(k_head_bwd<256, false, false>, (BM * LD256 + BM * LD128) * 4 + 768);
+    allow_big_lds(k_head_bwd<256, false, true>, (BM * LD256 + BM * LD128) * 4 + 768);
+    allow_big_lds(k_head_bwd<128, true, false>, lds2 + 768);
+    allow_big_lds(k_head_bwd<128, true, true>, lds2 + 768);
     const GnnBufs& last = w.gnn.back();
     if (E > 0) {
         ProfScope ps("head_edge_bwd", st, fE * 2.0 * (D * DH + DH * DH + DH));
-        PET_LAUNCH_TR(tr, k_head_bwd, PET_TA(128, true), gE, lds2 + 256, st, last.Mout, m.eh0.fwd, m.eh0.b, m.eh2.fwd,
-            m.eh2.b, m.eh0.bwd, m.eh2.bwd, m.ell_w, gA, g.ctr, g.fc, w.ypred_e, w.dfc, w.dM, E, tr ? w.hs1 : nullptr,
+        PET_LAUNCH_TR(tr, k_head_bwd, PET_TA(128, true), gE, lds2 + 768, st, last.Mout, wx_f(m.eh0), m.eh0.b, wx_f(m.eh2),
+            m.eh2.b, wx_b(m.eh0), wx_b(m.eh2), m.ell_w, gA, g.ctr, g.fc, w.ypred_e, w.dfc, w.dM, E, tr ? w.hs1 : nullptr,
             tr ? w.hda2 : nullptr, tr ? w.hda1 : nullptr, tr ? w.hs2y : nullptr);
         if (tr) tr->heads(true, last.Mout, D, E, gA);
     }
@@ -837,8 +872,8 @@ int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* 
         ss.fork(st);
         {
             ProfScope ps("head_node_bwd", s2, fN * 2.0 * (DN * DH + DH * DH + DH));
-            PET_LAUNCH_TR(tr, k_head_bwd, PET_TA(256, false), gN, (BM * LD256 + BM * LD128) * 4 + 256, s2,  last.Hout,
-                m.nh0.fwd, m.nh0.b, m.nh2.fwd, m.nh2.b, m.nh0.bwd, m.nh2.bwd, m.nll_w, gA, nullptr, nullptr, nullptr,
+            PET_LAUNCH_TR(tr, k_head_bwd, PET_TA(256, false), gN, (BM * LD256 + BM * LD128) * 4 + 768, s2,  last.Hout,
+                wx_f(m.nh0), m.nh0.b, wx_f(m.nh2), m.nh2.b, wx_b(m.nh0), wx_b(m.nh2), m.nll_w, gA, nullptr, nullptr, nullptr,
                 nullptr, w.dH, N, tr ? w.hs1 : nullptr, tr ? w.hda2 : nullptr, tr ? w.hda1 : nullptr,
                 tr ? w.hs2y : nullptr);
             if (tr) tr->heads(false, last.Hout, DN, N, gA);
