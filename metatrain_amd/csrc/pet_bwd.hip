@@ -958,7 +958,10 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             }
             {
                 ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
-                if (trr) trr_emlp_bwd(dX, Ab.X1, Ab.VG, A.g_mlp, A.mlp_in, A.mlp_out, dX_alt, E, st, tr ? w.dVG : nullptr);
+                if (trr) {
+                    const float* vg = (!tr && emlp_recompute_ok(A.mlp_in, A.mlp_out)) ? nullptr : Ab.VG;
+                    trr_emlp_bwd(dX, Ab.X1, vg, A.g_mlp, A.mlp_in, A.mlp_out, dX_alt, E, st, tr ? w.dVG : nullptr);
+                }
                 else PET_LAUNCH_TR(tr, k_swiglu_bwd, PET_TA(128, DFF), gE, lds2, st, dX, Ab.X1, Ab.VG, A.g_mlp,
                     A.mlp_out.bwd, A.mlp_in.bwd, dX_alt, E, tr ? w.dVG : nullptr);
                 if (tr) {

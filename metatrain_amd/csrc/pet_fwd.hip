@@ -667,7 +667,11 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
             side_busy = true;
             if (E > 0) {
                 ProfScope ps("emlp", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
-                if (trr) trr_emlp(Ab.X1, A.g_mlp, A.mlp_in, A.mlp_out, Ab.VG, Xnext, E, st);
+                if (trr) {
+                    // [v; g] is stored for the adjoint unless no adjoint follows (save == 0) or it recomputes them
+                    float* vg = (save == 0 || (save != 2 && emlp_recompute_ok(A.mlp_in, A.mlp_out))) ? nullptr : Ab.VG;
+                    trr_emlp(Ab.X1, A.g_mlp, A.mlp_in, A.mlp_out, vg, Xnext, E, st);
+                }
                 else k_emlp<<<gE, NTHREADS, lds2, st>>>(Ab.X1, A.g_mlp, A.mlp_in.fwd, A.mlp_in.b, A.mlp_out.fwd,
                                                         A.mlp_out.b, Ab.VG, Xnext, E);
             }

@@ -1141,6 +1141,139 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_h(const float* __restrict__ dY
 // ---------------------------------------------------------------------------------
 // host launchers (declared in model.h)
 // ---------------------------------------------------------------------------------
+// Edge-MLP adjoint WITHOUT the saved pre-activations (inference: pet_forward stores no VG for this stage). [v; g] is
+// recomputed per hidden chunk from RMSNorm(X1) with the forward weight planes: one more f16x3 GEMM per chunk (the
+// matrix pipe has room: the stored-VG form moves 6.4 GB per launch at ~3.2 TB/s with the MFMAs ~20 % busy), against
+// 4 KB per edge and layer less written by the forward and 4 KB less read here, i.e. a quarter of the step's HBM
+// traffic. The two split row operands (dY, scaled; RMSNorm(X1)) live in wave-private LDS, 32 KB per wave.
+__global__ __launch_bounds__(256) void k_emlp_bwd_r(const float* __restrict__ dY, const float* __restrict__ X1,
+                                                     const float* __restrict__ gamma, W2 winf,
+                                                     const float* __restrict__ bin, W2 woutb, W2 winb,
+                                                     float* __restrict__ dX1, int64_t E) {
+    extern __shared__ __attribute__((aligned(16))) f16x8 opark[];  // [4 waves][ys: 8 x 2][xs: 8 x 2][64]
+    TRR_PROLOGUE(E);
+    constexpr int NC = DFF / 32;
+    f16x8* ysp = opark + (size_t)(threadIdx.x >> 6) * 32 * 64;
+    f16x8* xsp = ysp + 16 * 64;
+    auto fidx = [&](int b) { return ((size_t)(b >> 3) * 8 + (b & 7)) * 64 + L.lane; };  // forward W_in: tile hc, +TS = gate
+    constexpr size_t TS = (size_t)NC * 8 * 64;
+    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
+    auto bkb = [&](int b) { const int hc = b >> 2, j = b & 3; return (j < 2 ? 2 * hc + j : 16 + 2 * hc + (j - 2)); };
+    auto bidx = [&](int b) { return (size_t)bkb(b) * 64 + L.lane; };
+    constexpr int RD = 2;  // ring depth of the two K = 128 streams (registers: 512 are all used)
+    WBlk2<2> rf[RD];
+    WBlk2<1> ra[RD];
+    WBlk2<2> rb[2];  // W_in^T blocks, two output tiles at a time: stream index j2 = 8 hc + 4 half + j
+#pragma unroll
+    for (int b = 0; b < RD; b++) ld_blk2<2>(rf[b], winf, fidx(b), TS);
+#pragma unroll
+    for (int b = 0; b < RD; b++) ld_blk2<1>(ra[b], woutb, aidx(b), 0);
+    auto b2idx = [&](int j2) {  // half 1: tiles 2, 3
+        return bidx(4 * (j2 >> 3) + (j2 & 3)) + (size_t)((j2 >> 2) & 1) * 2 * 32 * 64;
+    };
+#pragma unroll
+    for (int b = 0; b < 2; b++) ld_blk2<2>(rb[b], winb, b2idx(b), 32 * 64);
+    float inv;
+    {
+        float4 dy[16];
+        load_rowfrag<16>(dy, dY, row, D, L.h);
+        float sc;
+        inv = row_scale_pow2<16>(dy, sc);
+        Split2<8> t;
+        split_frag2<8>(dy, t);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { ysp[(2 * k) * 64 + L.lane] = t.h[k]; ysp[(2 * k + 1) * 64 + L.lane] = t.l[k]; }
+    }
+    {
+        float4 x[16];
+        load_rowfrag<16>(x, X1, row, D, L.h);
+        rmsnorm_frag<16>(x, gamma, L.h);
+        Split2<8> t;
+        split_frag2<8>(x, t);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { xsp[(2 * k) * 64 + L.lane] = t.h[k]; xsp[(2 * k + 1) * 64 + L.lane] = t.l[k]; }
+    }
+    f32x16 dn[4];
+    acc_zero<4>(dn);
+#pragma unroll 1
+    for (int hc = 0; hc < NC; hc++) {
+        f32x16 vg[2], vgl[2];  // the bias is added after the GEMM (no prefetch registers to spare)
+        acc_zero<2>(vg);
+        acc_zero<2>(vgl);
+        f32x16 du[1], dul[1];
+        acc_zero<1>(du);
+        acc_zero<1>(dul);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            const f16x8 xh = xsp[(2 * kb) * 64 + L.lane], xl = xsp[(2 * kb + 1) * 64 + L.lane];
+            const f16x8 yh = ysp[(2 * kb) * 64 + L.lane], yl = ysp[(2 * kb + 1) * 64 + L.lane];
+            WBlk2<2>& wf = rf[kb % RD];
+            WBlk2<1>& wa = ra[kb % RD];
+            mfma3<2>(vg, vgl, wf, xh, xl);
+            mfma3<1>(du, dul, wa, yh, yl);
+            const int nb = 8 * hc + kb + RD;
+            if (nb < 8 * NC) {
+                ld_blk2<2>(wf, winf, fidx(nb), TS);
+                ld_blk2<1>(wa, woutb, aidx(nb), 0);
+            }
+        }
+        fold_low<2>(vg, vgl);
+        fold_low<1>(du, dul);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bin + 32 * hc + 8 * q + 4 * L.h);
+            const float4 b1 = *reinterpret_cast<const float4*>(bin + DFF + 32 * hc + 8 * q + 4 * L.h);
+            vg[0][4 * q] += b0.x; vg[0][4 * q + 1] += b0.y; vg[0][4 * q + 2] += b0.z; vg[0][4 * q + 3] += b0.w;
+            vg[1][4 * q] += b1.x; vg[1][4 * q + 1] += b1.y; vg[1][4 * q + 2] += b1.z; vg[1][4 * q + 3] += b1.w;
+        }
+        float4 dvg[8];  // dv (4) then dg (4): the K = 64 operand of stream B
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 d = acc_q(du[0], q), vv = acc_q(vg[0], q), gg = acc_q(vg[1], q);
+            const float sx = sigm_(gg.x), sy = sigm_(gg.y), sz = sigm_(gg.z), sw = sigm_(gg.w);
+            dvg[q] = make_float4(d.x * sx, d.y * sy, d.z * sz, d.w * sw);
+            dvg[4 + q] = make_float4(d.x * vv.x * sx * (1.f - sx), d.y * vv.y * sy * (1.f - sy),
+                                     d.z * vv.z * sz * (1.f - sz), d.w * vv.w * sw * (1.f - sw));
+        }
+        Split2<4> ds;
+        split_frag2<4>(dvg, ds);
+        // dn += [dv; dg] W_in, two output tiles at a time; the cross sums are folded in per chunk so that only one
+        // pair of them is live (registers)
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            f32x16 lo[2];
+            acc_zero<2>(lo);
+            f32x16(&dh)[2] = *reinterpret_cast<f32x16(*)[2]>(&dn[2 * half]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                WBlk2<2>& wb = rb[j & 1];
+                mfma3<2>(dh, lo, wb, ds.h[j], ds.l[j]);
+                const int nb = 8 * hc + 4 * half + j + 2;
+                if (nb < 8 * NC) ld_blk2<2>(wb, winb, b2idx(nb), 32 * 64);
+            }
+            fold_low<2>(dh, lo);
+        }
+    }
+    acc_scale<4>(dn, inv);
+    float4 w[16], x[16];
+    acc_to_frag<4>(dn, w);
+    load_rowfrag<16>(x, X1, row, D, L.h);
+#pragma unroll
+    for (int kg = 0; kg < 16; kg++) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
+        w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
+    }
+    rmsnorm_bwd_frag<16>(w, x);
+    if (valid) {
+        load_rowfrag<16>(x, dY, row, D, L.h);
+#pragma unroll
+        for (int kg = 0; kg < 16; kg++) {
+            w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
+        }
+        store_rowfrag<16>(w, dX1, row, D, L.h);
+    }
+}
+
 static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
 
 // pet_config_set("bf16x6", 0) puts the TRR stages back on the fp32 MFMA. Default: GEMMs on the bf16 matrix cores
@@ -1157,6 +1290,16 @@ static int g_tile_mask = 0;  // debugging aid: bits switch individual LDS-tile G
 void set_tile_mask(int v) { g_tile_mask = v; }
 int tile_mask() { return g_tile_mask; }
 bool use_tile_f16x3() { return g_f16x3 != 0 && g_tile_f16x3 != 0 && g_bf16x6 != 0; }
+// pet_config_set("emlp_recompute", 1): the inference adjoint of the edge MLP rebuilds the SwiGLU pre-activations
+// instead of reading them back. Saves 16 KB of workspace traffic per edge and makes the forward stage 21 % faster
+// (6.4 -> 5.1 ms per step), but the recomputing adjoint is out of registers (ring depth 2, both split operands parked
+// in LDS, 44 B of scratch) and takes 17.1 ms against 7.8: OFF by default, kept as the memory-lean variant.
+static int g_emlp_recompute = 0;
+void set_emlp_recompute(int v) { g_emlp_recompute = v ? 1 : 0; }
+// inference only: the edge-MLP adjoint rebuilds [v; g] instead of reading them back (k_emlp_bwd_r)
+bool emlp_recompute_ok(const Lin& win, const Lin& wout) {
+    return g_emlp_recompute && use_trr() && g_bf16x6 && g_f16x3 && win.fwd2 && win.bwd2 && wout.bwd2 && wout.fwd2;
+}
 static int g_trr_persist = 1;
 void set_trr_persist(int v) { g_trr_persist = v ? 1 : 0; }
 static int num_cus() {
@@ -1215,7 +1358,11 @@ void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wo
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
                   const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg) {
     const int grid = grid_rows(E);
-    if (g_bf16x6 && g_f16x3 && win.bwd2 && wout.bwd2) {
+    if (g_bf16x6 && g_f16x3 && win.bwd2 && wout.bwd2 && win.fwd2 && VG == nullptr && !t_dvg) {
+        const size_t lds = (size_t)4 * 32 * 64 * sizeof(f16x8);  // 128 KB: both split row operands of 4 waves
+        allow_big_lds(k_emlp_bwd_r, lds);
+        k_emlp_bwd_r<<<grid, 256, lds, st>>>(dY, X1, gamma, w2_fwd(win), win.b, w2_bwd(wout), w2_bwd(win), dX1, E);
+    } else if (g_bf16x6 && g_f16x3 && win.bwd2 && wout.bwd2) {
         if (t_dvg) k_emlp_bwd_h<true><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, t_dvg);
         else k_emlp_bwd_h<false><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, nullptr);
     } else if (g_bf16x6 && win.bwd3 && wout.bwd3) {
