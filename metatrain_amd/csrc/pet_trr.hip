@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_r(const float* __restrict__ dY
     auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
     auto bkb = [&](int b) { const int hc = b >> 2, j = b & 3; return (j < 2 ? 2 * hc + j : 16 + 2 * hc + (j - 2)); };
     auto bidx = [&](int b) { return (size_t)bkb(b) * 64 + L.lane; };
-    constexpr int RD = 2;  // ring depth of the two K = 128 streams (registers: 512 are all used)
+    constexpr int RD = 4;  // ring depth of the two K = 128 streams
     WBlk2<2> rf[RD];
     WBlk2<1> ra[RD];
     WBlk2<2> rb[2];  // W_in^T blocks, two output tiles at a time: stream index j2 = 8 hc + 4 half + j
@@ -1203,10 +1203,15 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_r(const float* __restrict__ dY
         f32x16 du[1], dul[1];
         acc_zero<1>(du);
         acc_zero<1>(dul);
+        // the parked operands are loop-invariant: without this the compiler hoists all 32 fragment reads (128
+        // registers) out of the chunk loop and spills
+        const f16x8* xq = xsp + L.lane;
+        const f16x8* yq = ysp + L.lane;
+        asm volatile("" : "+v"(xq), "+v"(yq));
 #pragma unroll
         for (int kb = 0; kb < 8; kb++) {
-            const f16x8 xh = xsp[(2 * kb) * 64 + L.lane], xl = xsp[(2 * kb + 1) * 64 + L.lane];
-            const f16x8 yh = ysp[(2 * kb) * 64 + L.lane], yl = ysp[(2 * kb + 1) * 64 + L.lane];
+            const f16x8 xh = xq[(2 * kb) * 64], xl = xq[(2 * kb + 1) * 64];
+            const f16x8 yh = yq[(2 * kb) * 64], yl = yq[(2 * kb + 1) * 64];
             WBlk2<2>& wf = rf[kb % RD];
             WBlk2<1>& wa = ra[kb % RD];
             mfma3<2>(vg, vgl, wf, xh, xl);
@@ -1292,8 +1297,9 @@ int tile_mask() { return g_tile_mask; }
 bool use_tile_f16x3() { return g_f16x3 != 0 && g_tile_f16x3 != 0 && g_bf16x6 != 0; }
 // pet_config_set("emlp_recompute", 1): the inference adjoint of the edge MLP rebuilds the SwiGLU pre-activations
 // instead of reading them back. Saves 16 KB of workspace traffic per edge and makes the forward stage 21 % faster
-// (6.4 -> 5.1 ms per step), but the recomputing adjoint is out of registers (ring depth 2, both split operands parked
-// in LDS, 44 B of scratch) and takes 17.1 ms against 7.8: OFF by default, kept as the memory-lean variant.
+// (6.4 -> 5.1 ms per step), but the recomputing adjoint issues 120 instead of 72 MFMAs per chunk at the same ~20 %
+// pipe utilisation (these kernels are issue / latency bound, not HBM bound) and takes 13.1 ms against 7.9: OFF by
+// default, kept as the memory-lean variant.
 static int g_emlp_recompute = 0;
 void set_emlp_recompute(int v) { g_emlp_recompute = v ? 1 : 0; }
 // inference only: the edge-MLP adjoint rebuilds [v; g] instead of reading them back (k_emlp_bwd_r)
