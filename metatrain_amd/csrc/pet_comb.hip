@@ -390,10 +390,10 @@ __global__ __launch_bounds__(256) void k_comb_bwd_h(const float* __restrict__ dM
     auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
     // stream B: W0^T, output tiles over the 256 cat columns (half: four tiles), K = 256 hidden: blocks 2 hc, 2 hc + 1
     auto bidx = [&](int b, int half) { return ((size_t)(4 * half) * 16 + b) * 64 + L.lane; };  // tile t at + t * 16 * 64
-    WBlk2<1> ra[4];
+    WBlk2<1> ra[8];  // 3 MFMAs per block: eight in flight to cover the L2 round trip
     WBlk2<4> rb[2];
 #pragma unroll
-    for (int b = 0; b < 4; b++) ld_blk2<1>(ra[b], w2b, aidx(b), 0);
+    for (int b = 0; b < 8; b++) ld_blk2<1>(ra[b], w2b, aidx(b), 0);
 #pragma unroll
     for (int b = 0; b < 2; b++) ld_blk2<4>(rb[b], w0b, bidx(b, 0), 16 * 64);
     f32x16 dl[4], dll[4];
@@ -419,9 +419,9 @@ __global__ __launch_bounds__(256) void k_comb_bwd_h(const float* __restrict__ dM
             acc_zero<1>(t1l);
 #pragma unroll
             for (int kb = 0; kb < 8; kb++) {
-                WBlk2<1>& wb = ra[kb & 3];
+                WBlk2<1>& wb = ra[kb];
                 mfma3<1>(t1, t1l, wb, ms.h[kb], ms.l[kb]);
-                const int nb = 8 * hc + kb + 4;
+                const int nb = 8 * hc + kb + 8;
                 if (nb < 8 * NC) ld_blk2<1>(wb, w2b, aidx(nb), 0);
             }
             fold_low<1>(t1, t1l);

@@ -1048,10 +1048,11 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_h(const float* __restrict__ dY
     auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };  // b = 8 hc + kb: tile hc, kb_total = 8
     auto bkb = [&](int b) { const int hc = b >> 2, j = b & 3; return (j < 2 ? 2 * hc + j : 16 + 2 * hc + (j - 2)); };
     auto bidx = [&](int b) { return (size_t)bkb(b) * 64 + L.lane; };  // tile 0; tile t at + t * 32 * 64
-    WBlk2<1> ra[4];
+    // a one-tile f16x3 block is only 3 MFMAs (96 cycles): eight of them in flight to cover the L2 round trip
+    WBlk2<1> ra[8];
     WBlk2<4> rb[2];
 #pragma unroll
-    for (int b = 0; b < 4; b++) ld_blk2<1>(ra[b], woutb, aidx(b), 0);
+    for (int b = 0; b < 8; b++) ld_blk2<1>(ra[b], woutb, aidx(b), 0);
 #pragma unroll
     for (int b = 0; b < 2; b++) ld_blk2<4>(rb[b], winb, bidx(b), 32 * 64);
     Split2<8> ys;
@@ -1079,9 +1080,9 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_h(const float* __restrict__ dY
         acc_zero<1>(dul);
 #pragma unroll
         for (int kb = 0; kb < 8; kb++) {
-            WBlk2<1>& wb = ra[kb & 3];
+            WBlk2<1>& wb = ra[kb];
             mfma3<1>(du, dul, wb, ys.h[kb], ys.l[kb]);
-            const int nb = 8 * hc + kb + 4;
+            const int nb = 8 * hc + kb + 8;
             if (nb < 8 * NC) ld_blk2<1>(wb, woutb, aidx(nb), 0);
         }
         fold_low<1>(du, dul);
