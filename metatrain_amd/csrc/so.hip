@@ -157,8 +157,121 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_b(const float* __restrict__ X
     }
 }
 
+// The same GEMM as f16x3 (trr.h): two fp16 planes, three MFMAs per K block on a high and a cross accumulator.
+// The operands here are tangents and adjoints of arbitrary magnitude, so every staged 64 x 128 chunk is scaled row by
+// row with a power of two (row maximum into [1, 2); the 32 threads that stage a row are consecutive lanes, so the
+// maximum is five shuffles), its products are accumulated in chunk-local accumulators and added to the running sum
+// with the inverse scale.
+__global__ __launch_bounds__(NTHREADS) void k_gemm_h(const float* __restrict__ X, int ldx, int K,
+                                                     const float* __restrict__ cs, W2 w, const float* __restrict__ bias,
+                                                     float* __restrict__ Y, int ldy, int n_out, int64_t R,
+                                                     int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 ph[];  // [2][64][LDB16], then float rinv[64]
+    float* rinv = reinterpret_cast<float*>(ph + 2 * BM * LDB16);
+    const WaveId wv;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int nk = K / 128, kbt = K / 16;
+    const int g = wv.lane >> 5;
+    for (int nblk = 0; nblk < n_out / 128; nblk++) {
+        f32x16 acc[2];
+        acc_fill_bias<2>(acc, bias, 128 * nblk + 64 * wv.ch, wv.lane);
+        for (int kc = 0; kc < nk; kc++) {
+            if (nk > 1 || nblk == 0) {
+                __syncthreads();
+                float4 v[BM * 32 / NTHREADS];
+                float mx[BM * 32 / NTHREADS];
+#pragma unroll
+                for (int q = 0; q < BM * 32 / NTHREADS; q++) {
+                    const int idx = threadIdx.x + q * NTHREADS, r = idx >> 5, c = idx & 31;
+                    v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row0 + r < R) v[q] = *reinterpret_cast<const float4*>(X + (row0 + r) * ldx + 128 * kc + 4 * c);
+                    if (cs) {
+                        const float4 sc = *reinterpret_cast<const float4*>(cs + 128 * kc + 4 * c);
+                        v[q].x *= sc.x; v[q].y *= sc.y; v[q].z *= sc.z; v[q].w *= sc.w;
+                    }
+                    float m = fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w)));
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                    mx[q] = m;
+                }
+#pragma unroll
+                for (int q = 0; q < BM * 32 / NTHREADS; q++) {
+                    const int idx = threadIdx.x + q * NTHREADS, r = idx >> 5, c = idx & 31;
+                    int e = (__float_as_int(mx[q]) >> 23) & 0xff;
+                    e = e > 253 ? 253 : e;
+                    const float sc = __int_as_float((254 - e) << 23);
+                    if (c == 0) rinv[r] = __int_as_float(e << 23);
+                    const int qq = c & 3, slot = 16 * (c >> 2) + (qq & 1) * 8 + (qq >> 1) * 4;
+                    const float f[4] = {v[q].x * sc, v[q].y * sc, v[q].z * sc, v[q].w * sc};
+                    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                    f16x4 h, l;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        _Float16 a, b;
+                        split2(f[j], a, b);
+                        h[j] = a; l[j] = b;
+                    }
+                    _Float16* d = ph + r * LDB16 + slot;
+                    *reinterpret_cast<f16x4*>(d) = h;
+                    *reinterpret_cast<f16x4*>(d + BM * LDB16) = l;
+                }
+                __syncthreads();
+            }
+            const _Float16* arow = ph + (wv.rb * 32 + (wv.lane & 31)) * LDB16 + 8 * g;
+            size_t base[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) base[t] = ((size_t)(4 * nblk + 2 * wv.ch + t) * kbt + 8 * kc) * 64 + wv.lane;
+            f16x8 wh[2][2], wl[2][2];
+#pragma unroll
+            for (int sidx = 0; sidx < 2; sidx++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) { wh[sidx][t] = w.h[base[t] + sidx * 64]; wl[sidx][t] = w.l[base[t] + sidx * 64]; }
+            f32x16 ah[2], al[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) { ah[t][r] = 0.f; al[t][r] = 0.f; }
+#pragma unroll
+            for (int kb = 0; kb < 8; kb++) {
+                const int cur = kb & 1;
+                const f16x8 xh = *reinterpret_cast<const f16x8*>(arow + 16 * kb);
+                const f16x8 xl = *reinterpret_cast<const f16x8*>(arow + BM * LDB16 + 16 * kb);
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    al[t] = PET_MFMA_H(xh, wl[cur][t], al[t]);
+                    ah[t] = PET_MFMA_H(xh, wh[cur][t], ah[t]);
+                    al[t] = PET_MFMA_H(xl, wh[cur][t], al[t]);
+                }
+                if (kb + 2 < 8)
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        wh[cur][t] = w.h[base[t] + (kb + 2) * 64];
+                        wl[cur][t] = w.l[base[t] + (kb + 2) * 64];
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    acc[t][r] += (ah[t][r] + al[t][r] * (1.0f / 2048.0f)) * rinv[wv.rb * 32 + acc_row(r, wv.lane)];
+        }
+        acc_foreach<2>(acc, wv.rb, 128 * nblk + 64 * wv.ch, wv.lane, [&](int r, int c, float v) {
+            if (row0 + r < R) {
+                float* y = Y + (row0 + r) * ldy + c;
+                *y = accumulate ? *y + v : v;
+            }
+        });
+    }
+}
+
 static int g_so_bf16x6 = 1;  // pet_config_set("so_bf16x6", 0): generic training GEMMs on the fp32 MFMA
 void set_so_bf16x6(int v) { g_so_bf16x6 = v ? 1 : 0; }
+static inline W2 w2_at(const void* base, int n_out, int k_in) {
+    const size_t n8 = (size_t)(n_out / 32) * (k_in / 16) * 64;
+    const f16x8* b = reinterpret_cast<const f16x8*>(base);
+    W2 w; w.h = b; w.l = b + n8;
+    return w;
+}
 static inline W3 w3_at(const void* base, int n_out, int k_in) {
     const size_t n8 = (size_t)(n_out / 32) * (k_in / 16) * 64;
     const bf16x8* b = reinterpret_cast<const bf16x8*>(base);
@@ -177,7 +290,12 @@ static void mm_fwd(const Ctx& c, const Lin& L, const float* X, float* Y, int64_t
                    bool acc = false) {
     if (R <= 0) return;
     ProfScope ps("so_gemm", c.st, 2.0 * (double)R * L.k_in * L.n_out, 4.0 * (double)R * (L.k_in + L.n_out));
-    if (g_so_bf16x6 && L.fwd3)
+    if (g_so_bf16x6 && use_f16x3() && L.fwd2)
+        k_gemm_h<<<cdiv(R, BM), NTHREADS, 2 * BM * LDB16 * 2 + BM * 4, c.st>>>(X, L.k_in, L.k_in, cs,
+                                                                               w2_at(L.fwd2, L.n_out, L.k_in),
+                                                                               bias ? L.b : nullptr, Y, L.n_out, L.n_out, R,
+                                                                               acc ? 1 : 0);
+    else if (g_so_bf16x6 && L.fwd3)
         k_gemm_b<<<cdiv(R, BM), NTHREADS, 3 * BM * LDB16 * 2, c.st>>>(X, L.k_in, L.k_in, cs, w3_at(L.fwd3, L.n_out, L.k_in),
                                                                      bias ? L.b : nullptr, Y, L.n_out, L.n_out, R,
                                                                      acc ? 1 : 0);
@@ -189,7 +307,11 @@ static void mm_fwd(const Ctx& c, const Lin& L, const float* X, float* Y, int64_t
 static void mm_bwd(const Ctx& c, const Lin& L, const float* Yadj, float* Xadj, int64_t R, bool acc = false) {
     if (R <= 0) return;
     ProfScope ps("so_gemm", c.st, 2.0 * (double)R * L.k_in * L.n_out, 4.0 * (double)R * (L.k_in + L.n_out));
-    if (g_so_bf16x6 && L.bwd3)  // the transposed operand: tiles over k_in, K = n_out
+    if (g_so_bf16x6 && use_f16x3() && L.bwd2)  // the transposed operand: tiles over k_in, K = n_out
+        k_gemm_h<<<cdiv(R, BM), NTHREADS, 2 * BM * LDB16 * 2 + BM * 4, c.st>>>(Yadj, L.n_out, L.n_out, nullptr,
+                                                                               w2_at(L.bwd2, L.k_in, L.n_out), nullptr, Xadj,
+                                                                               L.k_in, L.k_in, R, acc ? 1 : 0);
+    else if (g_so_bf16x6 && L.bwd3)
         k_gemm_b<<<cdiv(R, BM), NTHREADS, 3 * BM * LDB16 * 2, c.st>>>(Yadj, L.n_out, L.n_out, nullptr,
                                                                      w3_at(L.bwd3, L.k_in, L.n_out), nullptr, Xadj,
                                                                      L.k_in, L.k_in, R, acc ? 1 : 0);
