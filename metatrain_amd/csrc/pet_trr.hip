@@ -312,7 +312,7 @@ __device__ __forceinline__ void row_gemm128_h(const W2& w, const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void k_qkv_h(const float* __restrict__ X, const float* __restrict__ gamma, W2 win,
+__global__ __launch_bounds__(256, 2) void k_qkv_h(const float* __restrict__ X, const float* __restrict__ gamma, W2 win,
                                                 const float* __restrict__ bin, float* __restrict__ QKV, int64_t R) {
     TRR_PROLOGUE(R);
     Split2<8> xs;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void k_qkv_h(const float* __restrict__ X, cons
     });
 }
 
-__global__ __launch_bounds__(256) void k_oproj_h(const float* __restrict__ AO, const float* __restrict__ X, W2 wo,
+__global__ __launch_bounds__(256, 2) void k_oproj_h(const float* __restrict__ AO, const float* __restrict__ X, W2 wo,
                                                   const float* __restrict__ bo, float* __restrict__ X1,
                                                   float* __restrict__ OC, int64_t E, int64_t R) {
     TRR_PROLOGUE(R);
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void k_oproj_h(const float* __restrict__ AO, c
     });
 }
 
-__global__ __launch_bounds__(256) void k_oproj_bwd_h(const float* __restrict__ dX1, const float* __restrict__ dOC,
+__global__ __launch_bounds__(256, 2) void k_oproj_bwd_h(const float* __restrict__ dX1, const float* __restrict__ dOC,
                                                       W2 wob, float* __restrict__ dAO, int64_t E, int64_t R) {
     TRR_PROLOGUE(R);
     Split2<8> xs;
