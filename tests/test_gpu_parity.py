@@ -285,6 +285,13 @@ def test_weighted_seed_vector_backward(rt, model, dev):
     assert relmax((g1 + g2).cpu().numpy(), g.cpu().numpy()) < 5e-6
     # determinism: identical bits run to run (no float atomics anywhere)
     assert torch.equal(fw.backward(w1), g1)
+    # seeds of any magnitude (a loss can hand over 1e-8 or 1e+6): the split-operand GEMMs scale adjoint rows by a
+    # power of two, so the gradient is exactly homogeneous
+    for scale in (2.0 ** -27, 2.0 ** 20):
+        gs = fw.backward(w1 * scale)
+        assert torch.equal(gs, g1 * scale), scale
+    gs = fw.backward(w1 * 3.7e-9)
+    assert relmax((gs / 3.7e-9).cpu().numpy(), g1.cpu().numpy()) < 2e-6
 
 
 def test_rotation_and_permutation_consistency(rt, model, dev):
