@@ -139,6 +139,12 @@ void set_tile_f16x3(int v);
 void set_tile_mask(int v);
 int tile_mask();
 void set_f16x3(int v);        // pet_trr.hip: 1 = f16x3 GEMMs where built (default), 0 = bf16x6
+void set_trr_compress(int v);
+struct Graph;
+bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* Min, float* a0_out, float* Xout, int64_t E,
+                  hipStream_t st);
+bool trr_compress_bwd(bool first, const float* dXe, const float* a0, const GnnLayerW& G, float* dgeo, float* dM, int64_t E,
+                      float* t_da0, hipStream_t st);
 void set_trr_persist(int v);  // pet_trr.hip: 1 = persistent emlp kernel with LDS-DMA row prefetch (default)
 void set_soap_sorted(int v);  // soap.hip: 1 = tail GEMM on species-sorted tiles, one network per tile (default)
 void set_soap_pair(int v);  // soap.hip: 1 = wave-per-atom expansion / lane-per-pair adjoint (default), 0 = first generation

@@ -1012,7 +1012,9 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         }
         {
             ProfScope ps("compress_bwd", st, fE * 2.0 * (D * D * (gi == 0 ? 3 : 4) + 4 * D));
-            if (gi == 0)
+            if (trr && trr_compress_bwd(gi == 0, dX, B.a0, G, w.dgeo, w.dM, E, tr ? w.da0 : nullptr, st)) {
+                // TRR kernel on f16x3 (pet_trr.hip)
+            } else if (gi == 0)
                 PET_LAUNCH_TR(tr, k_compress_bwd, PET_TA(true), gE, lds1, st, dX, B.a0, G.compress2.bwd, G.wct,
                     nullptr, w.dgeo, nullptr, E, tr ? w.da0 : nullptr);
             else

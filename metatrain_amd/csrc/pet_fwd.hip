@@ -616,7 +616,9 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
         const float* Min = gi == 0 ? nullptr : w.gnn[gi - 1].Mout;
         if (E > 0) {
             ProfScope ps("compress", st, fE * 2.0 * (D * D * (gi == 0 ? 3 : 4) + 4 * D));
-            if (gi == 0)
+            if (trr && trr_compress(gi == 0, g, G, Min, B.a0, B.attn[0].X, E, st)) {
+                // TRR kernel on f16x3 (pet_trr.hip)
+            } else if (gi == 0)
                 k_compress<true><<<gE, NTHREADS, lds1 + BM * 20 + BM * 8, st>>>(g.geo, g.sp_nbr, G.wc, G.tbl, nullptr, WX(),
                                                                         wx_fwd(G.compress2, 1), G.compress2.b, B.a0,
                                                                         B.attn[0].X, E);

@@ -1280,6 +1280,138 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_r(const float* __restrict__ dY
     }
 }
 
+// ---------------------------------------------------------------------------------
+// compress stage (transformer.py:499-521) and its adjoint as TRR kernels on f16x3. One wave = 32 edges:
+//   forward:  a0 = [v,d] Wc^T + Tbl[species] (+ M W0c^T);  e = SiLU(a0) W2^T + b2
+//   adjoint:  da0 = (dE W2) . silu'(a0);  dgeo += da0 Wc;  dM += da0 W0c
+// Same arithmetic as k_compress / k_compress_bwd (pet_fwd.hip / pet_bwd.hip), which stay selectable.
+// ---------------------------------------------------------------------------------
+template <bool FIRST>
+__global__ __launch_bounds__(256, 2) void k_compress_h(const float4* __restrict__ geo, const int* __restrict__ sp_nbr,
+                                                     const float* __restrict__ wc /*[D][4]*/,
+                                                     const float* __restrict__ tbl /*[ns][D]*/,
+                                                     const float* __restrict__ Min, W2 w0c, W2 w2,
+                                                     const float* __restrict__ b2, float* __restrict__ a0_out,
+                                                     float* __restrict__ Xout, int64_t E) {
+    TRR_PROLOGUE(E);
+    float4 a0[16];  // row fragment of the pre-activation: entries a0[kg] = features 8 kg + 4 h .. + 3
+    {
+        const float4 g = geo[row];
+        const float* trow = tbl + (size_t)sp_nbr[row] * D;
+#pragma unroll
+        for (int kg = 0; kg < 16; kg++) {
+            const int c = 8 * kg + 4 * L.h;
+            const float4 t = *reinterpret_cast<const float4*>(trow + c);
+            const float4 w0 = *reinterpret_cast<const float4*>(wc + 4 * c), w1 = *reinterpret_cast<const float4*>(wc + 4 * c + 4),
+                         w2v = *reinterpret_cast<const float4*>(wc + 4 * c + 8), w3 = *reinterpret_cast<const float4*>(wc + 4 * c + 12);
+            a0[kg].x = fmaf(g.w, w0.w, fmaf(g.z, w0.z, fmaf(g.y, w0.y, g.x * w0.x))) + t.x;
+            a0[kg].y = fmaf(g.w, w1.w, fmaf(g.z, w1.z, fmaf(g.y, w1.y, g.x * w1.x))) + t.y;
+            a0[kg].z = fmaf(g.w, w2v.w, fmaf(g.z, w2v.z, fmaf(g.y, w2v.y, g.x * w2v.x))) + t.z;
+            a0[kg].w = fmaf(g.w, w3.w, fmaf(g.z, w3.z, fmaf(g.y, w3.y, g.x * w3.x))) + t.w;
+        }
+    }
+    if (!FIRST) {
+        Split2<8> ms;
+        {
+            float4 mrow[16];
+            load_rowfrag<16>(mrow, Min, row, D, L.h);
+            split_frag2<8>(mrow, ms);  // messages: an O(1) residual stream
+        }
+        row_gemm128_h<2>(w0c, nullptr, ms, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+            float4 y[8];
+            acc_to_frag<2>(acc, y);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                a0[8 * c + k].x += y[k].x; a0[8 * c + k].y += y[k].y; a0[8 * c + k].z += y[k].z; a0[8 * c + k].w += y[k].w;
+            }
+        });
+    }
+    if (a0_out && valid) store_rowfrag<16>(a0, a0_out, row, D, L.h);
+    Split2<8> ss;
+    {
+#pragma unroll
+        for (int kg = 0; kg < 16; kg++)
+            a0[kg] = make_float4(silu_(a0[kg].x), silu_(a0[kg].y), silu_(a0[kg].z), silu_(a0[kg].w));
+        split_frag2<8>(a0, ss);
+    }
+    row_gemm128_h<2>(w2, b2, ss, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+        if (valid) {
+            float4 y[8];
+            acc_to_frag<2>(acc, y);
+            store_rowfrag<8>(y, Xout + 64 * c, row, D, L.h);
+        }
+    });
+}
+
+template <bool FIRST, bool TRAIN>
+__global__ __launch_bounds__(256, 2) void k_compress_bwd_h(const float* __restrict__ dXe, const float* __restrict__ a0,
+                                                         W2 w2b, const float* __restrict__ wct /*[4][D]*/, W2 w0cb,
+                                                         float* __restrict__ dgeo, float* __restrict__ dM, int64_t E,
+                                                         float* __restrict__ t_da0) {
+    TRR_PROLOGUE(E);
+    Split2<8> ys;
+    float inv;
+    {
+        float4 d[16];
+        load_rowfrag<16>(d, dXe, row, D, L.h);
+        float sc;
+        inv = row_scale_pow2<16>(d, sc);
+        split_frag2<8>(d, ys);
+    }
+    float4 da0[16];
+    load_rowfrag<16>(da0, a0, row, D, L.h);  // holds a0 until the chunk's product arrives
+    row_gemm128_h<2>(w2b, nullptr, ys, L, inv, [&](int c, f32x16 (&acc)[2]) {
+        float4 y[8];
+        acc_to_frag<2>(acc, y);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float4& a = da0[8 * c + k];
+            a = make_float4(y[k].x * silu_g_(a.x), y[k].y * silu_g_(a.y), y[k].z * silu_g_(a.z), y[k].w * silu_g_(a.w));
+        }
+    });
+    if (TRAIN && valid) store_rowfrag<16>(da0, t_da0, row, D, L.h);
+    {   // dgeo[row][q] += sum_c da0[c] Wc[c][q]: this lane's 64 features, then the partner lane
+        float sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kg = 0; kg < 16; kg++) {
+            const int c = 8 * kg + 4 * L.h;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 ww = *reinterpret_cast<const float4*>(wct + q * D + c);
+                sq[q] += da0[kg].x * ww.x + da0[kg].y * ww.y + da0[kg].z * ww.z + da0[kg].w * ww.w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) sq[q] = row_sum(sq[q]);
+        if (valid && L.h == 0) {
+            float4* dg = reinterpret_cast<float4*>(dgeo + row * 4);
+            const float4 old = *dg;
+            *dg = make_float4(old.x + sq[0], old.y + sq[1], old.z + sq[2], old.w + sq[3]);
+        }
+    }
+    if (!FIRST) {
+        Split2<8> ds;
+        float inv2;
+        {
+            float sc;
+            inv2 = row_scale_pow2<16>(da0, sc);
+            split_frag2<8>(da0, ds);
+        }
+        row_gemm128_h<2>(w0cb, nullptr, ds, L, inv2, [&](int c, f32x16 (&acc)[2]) {
+            if (valid) {
+                float4 y[8], old[8];
+                acc_to_frag<2>(acc, y);
+                load_rowfrag<8>(old, dM + 64 * c, row, D, L.h);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    y[k].x += old[k].x; y[k].y += old[k].y; y[k].z += old[k].z; y[k].w += old[k].w;
+                }
+                store_rowfrag<8>(y, dM + 64 * c, row, D, L.h);
+            }
+        });
+    }
+}
+
 static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
 
 // pet_config_set("bf16x6", 0) puts the TRR stages back on the fp32 MFMA. Default: GEMMs on the bf16 matrix cores
@@ -1301,6 +1433,8 @@ bool use_tile_f16x3() { return g_f16x3 != 0 && g_tile_f16x3 != 0 && g_bf16x6 != 
 // (6.4 -> 5.1 ms per step), but the recomputing adjoint issues 120 instead of 72 MFMAs per chunk at the same ~20 %
 // pipe utilisation (these kernels are issue / latency bound, not HBM bound) and takes 13.1 ms against 7.9: OFF by
 // default, kept as the memory-lean variant.
+static int g_trr_tilek = 1;  // pet_config_set("trr_compress", 0): the LDS-tile compress kernels
+void set_trr_compress(int v) { g_trr_tilek = v ? 1 : 0; }
 static int g_emlp_recompute = 0;
 void set_emlp_recompute(int v) { g_emlp_recompute = v ? 1 : 0; }
 // inference only: the edge-MLP adjoint rebuilds [v; g] instead of reading them back (k_emlp_bwd_r)
@@ -1379,6 +1513,31 @@ void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float
         if (t_dvg) k_emlp_bwd_t<true><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, wout.bwd, win.bwd, dX1, E, t_dvg);
         else k_emlp_bwd_t<false><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, wout.bwd, win.bwd, dX1, E, nullptr);
     }
+}
+
+bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* Min, float* a0_out, float* Xout,
+                  int64_t E, hipStream_t st) {
+    if (!(g_bf16x6 && g_f16x3 && g_trr_tilek && G.compress2.fwd2 && (first || G.compress0_msg.fwd2))) return false;
+    if (first)
+        k_compress_h<true><<<grid_rows(E), 256, 0, st>>>(g.geo, g.sp_nbr, G.wc, G.tbl, nullptr, W2(), w2_fwd(G.compress2),
+                                                       G.compress2.b, a0_out, Xout, E);
+    else
+        k_compress_h<false><<<grid_rows(E), 256, 0, st>>>(g.geo, g.sp_nbr, G.wc, G.tbl, Min, w2_fwd(G.compress0_msg),
+                                                        w2_fwd(G.compress2), G.compress2.b, a0_out, Xout, E);
+    return true;
+}
+bool trr_compress_bwd(bool first, const float* dXe, const float* a0, const GnnLayerW& G, float* dgeo, float* dM,
+                      int64_t E, float* t_da0, hipStream_t st) {
+    if (!(g_bf16x6 && g_f16x3 && g_trr_tilek && G.compress2.bwd2 && (first || G.compress0_msg.bwd2))) return false;
+    const int grid = grid_rows(E);
+    if (first) {
+        if (t_da0) k_compress_bwd_h<true, true><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), G.wct, W2(), dgeo, nullptr, E, t_da0);
+        else k_compress_bwd_h<true, false><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), G.wct, W2(), dgeo, nullptr, E, nullptr);
+    } else {
+        if (t_da0) k_compress_bwd_h<false, true><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), G.wct, w2_bwd(G.compress0_msg), dgeo, dM, E, t_da0);
+        else k_compress_bwd_h<false, false><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), G.wct, w2_bwd(G.compress0_msg), dgeo, dM, E, nullptr);
+    }
+    return true;
 }
 
 }  // namespace pet

@@ -411,7 +411,7 @@ def test_unknown_species_is_an_error_not_an_out_of_bounds_read(rt, model, dev):
                     torch.zeros(32, dtype=torch.int32, device=dev))
 
 
-@pytest.mark.parametrize("switch", ["trr", "attn_lds", "attn_lds=1", "attn_lds=2", "side_stream", "bf16x6", "trr_persist", "f16x3", "tile_f16x3", "emlp_recompute=1"])
+@pytest.mark.parametrize("switch", ["trr", "attn_lds", "attn_lds=1", "attn_lds=2", "side_stream", "bf16x6", "trr_persist", "f16x3", "tile_f16x3", "emlp_recompute=1", "trr_compress"])
 def test_alternative_kernel_paths_agree(rt, model, dev, golden_dir, switch):
     """The library keeps its earlier kernel generations selectable (pet_config_set): LDS-tile GEMM stages
     (trr=0), attention straight from global memory / staged per atom (attn_lds=0/1/2; the default 3 is the
