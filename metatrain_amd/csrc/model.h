@@ -145,6 +145,11 @@ bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* M
                   hipStream_t st);
 bool trr_compress_bwd(bool first, const float* dXe, const float* a0, const GnnLayerW& G, float* dgeo, float* dM, int64_t E,
                       float* t_da0, hipStream_t st);
+struct Model;
+bool trr_head_edge(const Model& m, const float* Xin, const float* fc, float* ypred, float* yout, int64_t E, hipStream_t st);
+bool trr_head_edge_bwd(const Model& m, const float* Xin, const float* gA, const int* ctr, const float* fc,
+                       const float* ypred, float* dfc, float* dXout, int64_t E, float* t_s1, float* t_da2, float* t_da1,
+                       float* t_s2y, hipStream_t st);
 void set_trr_persist(int v);  // pet_trr.hip: 1 = persistent emlp kernel with LDS-DMA row prefetch (default)
 void set_soap_sorted(int v);  // soap.hip: 1 = tail GEMM on species-sorted tiles, one network per tile (default)
 void set_soap_pair(int v);  // soap.hip: 1 = wave-per-atom expansion / lane-per-pair adjoint (default), 0 = first generation

@@ -860,6 +860,8 @@ int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* 
     const GnnBufs& last = w.gnn.back();
     if (E > 0) {
         ProfScope ps("head_edge_bwd", st, fE * 2.0 * (D * DH + DH * DH + DH));
+        if (!(use_trr() && trr_head_edge_bwd(m, last.Mout, gA, g.ctr, g.fc, w.ypred_e, w.dfc, w.dM, E, tr ? w.hs1 : nullptr,
+                                              tr ? w.hda2 : nullptr, tr ? w.hda1 : nullptr, tr ? w.hs2y : nullptr, st)))
         PET_LAUNCH_TR(tr, k_head_bwd, PET_TA(128, true), gE, lds2 + 768, st, last.Mout, wx_f(m.eh0), m.eh0.b, wx_f(m.eh2),
             m.eh2.b, wx_b(m.eh0), wx_b(m.eh2), m.ell_w, gA, g.ctr, g.fc, w.ypred_e, w.dfc, w.dM, E, tr ? w.hs1 : nullptr,
             tr ? w.hda2 : nullptr, tr ? w.hda1 : nullptr, tr ? w.hs2y : nullptr);

@@ -700,6 +700,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
     }
     if (E > 0) {
         ProfScope ps("head_edge", st, fE * 2.0 * (D * DH + DH * DH + DH));
+        if (!(trr && trr_head_edge(m, last.Mout, g.fc, w.ypred_e, w.ye, E, st)))
         k_head<128><<<gE, NTHREADS, lds2, st>>>(last.Mout, wx_fwd(m.eh0, 64), m.eh0.b, wx_fwd(m.eh2, 64), m.eh2.b, m.ell_w,
                                                 m.ell_b, g.fc, w.ypred_e, w.ye, E);
     }

@@ -1515,6 +1515,150 @@ void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float
     }
 }
 
+// ---------------------------------------------------------------------------------
+// edge head (backend.py:171-217, 726-777) and its adjoint as TRR kernels on f16x3:
+//   y = wl . SiLU(W2 SiLU(W0 x + b0) + b2) + bl;   yout = y * fc
+// The adjoint recomputes a1 / a2 (as k_head_bwd does) and keeps them in registers.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_head_h(const float* __restrict__ Xin, W2 w0, const float* __restrict__ b0,
+                                                    W2 w2, const float* __restrict__ b2, const float* __restrict__ wl,
+                                                    float bl, const float* __restrict__ fc, float* __restrict__ ypred,
+                                                    float* __restrict__ yout, int64_t R) {
+    TRR_PROLOGUE(R);
+    Split2<8> xs;
+    {
+        float4 x[16];
+        load_rowfrag<16>(x, Xin, row, D, L.h);
+        split_frag2<8>(x, xs);
+    }
+    float4 s1[16];
+    row_gemm128_h<2>(w0, b0, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+        float4 y[8];
+        acc_to_frag<2>(acc, y);
+#pragma unroll
+        for (int k = 0; k < 8; k++) s1[8 * c + k] = make_float4(silu_(y[k].x), silu_(y[k].y), silu_(y[k].z), silu_(y[k].w));
+    });
+    split_frag2<8>(s1, xs);
+    float part = 0.f;
+    row_gemm128_h<2>(w2, b2, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+        float4 y[8];
+        acc_to_frag<2>(acc, y);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float4 ww = *reinterpret_cast<const float4*>(wl + 64 * c + 8 * k + 4 * L.h);
+            part += silu_(y[k].x) * ww.x + silu_(y[k].y) * ww.y + silu_(y[k].z) * ww.z + silu_(y[k].w) * ww.w;
+        }
+    });
+    const float y = row_sum(part) + bl;
+    if (valid && L.h == 0) {
+        if (ypred) ypred[row] = y;
+        yout[row] = fc ? y * fc[row] : y;
+    }
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void k_head_bwd_h(const float* __restrict__ Xin, W2 w0f, const float* __restrict__ b0,
+                                                     W2 w2f, const float* __restrict__ b2, W2 w0b, W2 w2b,
+                                                     const float* __restrict__ wl, const float* __restrict__ gA,
+                                                     const int* __restrict__ ctr, const float* __restrict__ fc,
+                                                     const float* __restrict__ ypred, float* __restrict__ dfc,
+                                                     float* __restrict__ dXout, int64_t R, float* __restrict__ t_s1,
+                                                     float* __restrict__ t_da2, float* __restrict__ t_da1,
+                                                     float* __restrict__ t_s2y) {
+    TRR_PROLOGUE(R);
+    float gy;  // dL/dy of this edge: the centre atom's seed times the cutoff factor
+    {
+        const float ga = gA[ctr[row]];
+        gy = ga * fc[row];
+        if (valid && L.h == 0) dfc[row] = ga * ypred[row];  // d(y fc)/dfc
+    }
+    Split2<8> xs;
+    {
+        float4 x[16];
+        load_rowfrag<16>(x, Xin, row, D, L.h);
+        split_frag2<8>(x, xs);
+    }
+    float4 a1[16], t[16];
+    row_gemm128_h<2>(w0f, b0, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+        float4 y[8];
+        acc_to_frag<2>(acc, y);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            a1[8 * c + k] = y[k];
+            t[8 * c + k] = make_float4(silu_(y[k].x), silu_(y[k].y), silu_(y[k].z), silu_(y[k].w));
+        }
+    });
+    if (TRAIN && valid) store_rowfrag<16>(t, t_s1, row, DH, L.h);
+    split_frag2<8>(t, xs);
+    // a2 = W2 s1 + b2  ->  da2 = gy wl silu'(a2)   (t is reused for da2)
+    row_gemm128_h<2>(w2f, b2, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+        float4 y[8];
+        acc_to_frag<2>(acc, y);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float4 ww = *reinterpret_cast<const float4*>(wl + 64 * c + 8 * k + 4 * L.h);
+            if (TRAIN && valid)
+                *reinterpret_cast<float4*>(t_s2y + row * DH + 64 * c + 8 * k + 4 * L.h) =
+                    make_float4(gy * silu_(y[k].x), gy * silu_(y[k].y), gy * silu_(y[k].z), gy * silu_(y[k].w));
+            t[8 * c + k] = make_float4(gy * ww.x * silu_g_(y[k].x), gy * ww.y * silu_g_(y[k].y),
+                                       gy * ww.z * silu_g_(y[k].z), gy * ww.w * silu_g_(y[k].w));
+        }
+    });
+    if (TRAIN && valid) store_rowfrag<16>(t, t_da2, row, DH, L.h);
+    float inv;
+    {
+        float sc;
+        inv = row_scale_pow2<16>(t, sc);
+        split_frag2<8>(t, xs);
+    }
+    // ds1 = da2 W2  ->  da1 = ds1 silu'(a1)
+    row_gemm128_h<2>(w2b, nullptr, xs, L, inv, [&](int c, f32x16 (&acc)[2]) {
+        float4 y[8];
+        acc_to_frag<2>(acc, y);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float4 a = a1[8 * c + k];
+            t[8 * c + k] = make_float4(y[k].x * silu_g_(a.x), y[k].y * silu_g_(a.y), y[k].z * silu_g_(a.z), y[k].w * silu_g_(a.w));
+        }
+    });
+    if (TRAIN && valid) store_rowfrag<16>(t, t_da1, row, DH, L.h);
+    {
+        float sc;
+        inv = row_scale_pow2<16>(t, sc);
+        split_frag2<8>(t, xs);
+    }
+    row_gemm128_h<2>(w0b, nullptr, xs, L, inv, [&](int c, f32x16 (&acc)[2]) {  // dx = da1 W0
+        if (valid) {
+            float4 y[8];
+            acc_to_frag<2>(acc, y);
+            store_rowfrag<8>(y, dXout + 64 * c, row, D, L.h);
+        }
+    });
+}
+
+bool trr_head_edge(const Model& m, const float* Xin, const float* fc, float* ypred, float* yout, int64_t E,
+                   hipStream_t st) {
+    if (!(g_bf16x6 && g_f16x3 && g_trr_tilek && m.eh0.fwd2 && m.eh2.fwd2)) return false;
+    k_head_h<<<grid_rows(E), 256, 0, st>>>(Xin, w2_fwd(m.eh0), m.eh0.b, w2_fwd(m.eh2), m.eh2.b, m.ell_w, m.ell_b, fc, ypred,
+                                           yout, E);
+    return true;
+}
+bool trr_head_edge_bwd(const Model& m, const float* Xin, const float* gA, const int* ctr, const float* fc,
+                       const float* ypred, float* dfc, float* dXout, int64_t E, float* t_s1, float* t_da2, float* t_da1,
+                       float* t_s2y, hipStream_t st) {
+    if (!(g_bf16x6 && g_f16x3 && g_trr_tilek && m.eh0.fwd2 && m.eh2.fwd2 && m.eh0.bwd2 && m.eh2.bwd2)) return false;
+    const int grid = grid_rows(E);
+    if (t_s1)
+        k_head_bwd_h<true><<<grid, 256, 0, st>>>(Xin, w2_fwd(m.eh0), m.eh0.b, w2_fwd(m.eh2), m.eh2.b, w2_bwd(m.eh0),
+                                                 w2_bwd(m.eh2), m.ell_w, gA, ctr, fc, ypred, dfc, dXout, E, t_s1, t_da2,
+                                                 t_da1, t_s2y);
+    else
+        k_head_bwd_h<false><<<grid, 256, 0, st>>>(Xin, w2_fwd(m.eh0), m.eh0.b, w2_fwd(m.eh2), m.eh2.b, w2_bwd(m.eh0),
+                                                  w2_bwd(m.eh2), m.ell_w, gA, ctr, fc, ypred, dfc, dXout, E, nullptr, nullptr,
+                                                  nullptr, nullptr);
+    return true;
+}
+
 bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* Min, float* a0_out, float* Xout,
                   int64_t E, hipStream_t st) {
     if (!(g_bf16x6 && g_f16x3 && g_trr_tilek && G.compress2.fwd2 && (first || G.compress0_msg.fwd2))) return false;
