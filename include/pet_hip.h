@@ -240,7 +240,8 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *                 (default); 0 = fp32 MFMA. "tile_mask" (debug): bits switch single GEMMs of those kernels back.
  *   "emlp_recompute" 1 = the inference adjoint of the edge MLP rebuilds the SwiGLU pre-activations instead of reading
  *                 them back (less workspace traffic, slower adjoint); default 0
- *   "trr_compress" 1 = compress stage, edge head and their adjoints as TRR kernels on f16x3 (default); 0 = LDS-tile kernels
+ *   "trr_compress" bit mask of f16x3 TRR kernels replacing LDS-tile ones: 1 compress (+adjoint), 2 edge head (+adjoint),
+ *                  4 node update (slower, off); default 3; 0 = LDS-tile kernels
  *   "trr_persist" 1 = persistent edge-MLP kernel with LDS-DMA prefetch of the next tile's rows (default)
  *   "so_bf16x6"   the same choice for the generic GEMM of the second-order (training) pass
  *   "attn_lds"    attention kernels: 0 global-memory, 1 per-atom LDS-staged adjoint, 2 LDS-staged forward and

@@ -150,6 +150,8 @@ bool trr_head_edge(const Model& m, const float* Xin, const float* fc, float* ypr
 bool trr_head_edge_bwd(const Model& m, const float* Xin, const float* gA, const int* ctr, const float* fc,
                        const float* ypred, float* dfc, float* dXout, int64_t E, float* t_s1, float* t_da2, float* t_da1,
                        float* t_s2y, hipStream_t st);
+bool trr_node(const AttnLayerW& A, const float* H, const float* OC, float* H1, float* VGn, float* Hn, int64_t N,
+              hipStream_t st);
 void set_trr_persist(int v);  // pet_trr.hip: 1 = persistent emlp kernel with LDS-DMA row prefetch (default)
 void set_soap_sorted(int v);  // soap.hip: 1 = tail GEMM on species-sorted tiles, one network per tile (default)
 void set_soap_pair(int v);  // soap.hip: 1 = wave-per-atom expansion / lane-per-pair adjoint (default), 0 = first generation

@@ -660,6 +660,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
             ss.fork(st);
             {
                 ProfScope ps("node", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
+                if (!(trr && trr_node(A, Ab.H, Ab.OC, Ab.H1, Ab.VGn, Ab.Hn, N, s2)))
                 k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
                     Ab.H, Ab.OC, wx_fwd(A.ce, 4), A.ce.b, A.g_center, wx_fwd(A.cmlp_in, 8), A.cmlp_in.b, wx_fwd(A.cmlp_out, 16),
                     A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);

@@ -280,7 +280,9 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_b(const float* __restrict__ dQK
 // f16x3 versions (trr.h) of the 128-wide row GEMM and the stages built on it. `oscale` multiplies the finished
 // accumulators (the inverse of a row_scale_pow2 applied to an adjoint input; 1 for forward activations).
 // ---------------------------------------------------------------------------------
-template <int NC2, class Epilogue>
+// UNROLLED: the column-group loop is fully unrolled, for epilogues that index register arrays with the group number
+// (a runtime index would send those arrays to scratch memory)
+template <int NC2, bool UNROLLED = false, class Epilogue>
 __device__ __forceinline__ void row_gemm128_h(const W2& w, const float* __restrict__ bias, const Split2<8>& xs,
                                               const RowLane& L, float oscale, Epilogue epi) {
     auto widx = [&](int b) { return ((size_t)(2 * (b >> 3)) * 8 + (b & 7)) * 64 + L.lane; };
@@ -289,7 +291,7 @@ __device__ __forceinline__ void row_gemm128_h(const W2& w, const float* __restri
     for (int b = 0; b < 4; b++) ld_blk2<2>(ring[b], w, widx(b), 8 * 64);
     float4 bnext[8];
     if (bias) ld_bias<2>(bnext, bias, 0, L.h);
-#pragma unroll 1
+#pragma unroll UNROLLED ? NC2 : 1
     for (int c = 0; c < NC2; c++) {
         f32x16 acc[2], acl[2];
         acc_zero<2>(acl);
@@ -307,7 +309,9 @@ __device__ __forceinline__ void row_gemm128_h(const W2& w, const float* __restri
             if (nb < 8 * NC2) ld_blk2<2>(wb, w, widx(nb), 8 * 64);
         }
         fold_low<2>(acc, acl);
-        if (oscale != 1.0f) acc_scale<2>(acc, oscale);
+        // forward callers pass the literal 1 and the multiply folds away; adjoint callers pass a per-row value and
+        // always multiply: a test on it would be a divergent branch around spill code ("exec hazards")
+        if (!(__builtin_constant_p(oscale) && oscale == 1.0f)) acc_scale<2>(acc, oscale);
         epi(c, acc);
     }
 }
@@ -1317,7 +1321,7 @@ __global__ __launch_bounds__(256, 2) void k_compress_h(const float4* __restrict_
             load_rowfrag<16>(mrow, Min, row, D, L.h);
             split_frag2<8>(mrow, ms);  // messages: an O(1) residual stream
         }
-        row_gemm128_h<2>(w0c, nullptr, ms, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+        row_gemm128_h<2, true>(w0c, nullptr, ms, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
             float4 y[8];
             acc_to_frag<2>(acc, y);
 #pragma unroll
@@ -1334,7 +1338,7 @@ __global__ __launch_bounds__(256, 2) void k_compress_h(const float4* __restrict_
             a0[kg] = make_float4(silu_(a0[kg].x), silu_(a0[kg].y), silu_(a0[kg].z), silu_(a0[kg].w));
         split_frag2<8>(a0, ss);
     }
-    row_gemm128_h<2>(w2, b2, ss, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true>(w2, b2, ss, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
         if (valid) {
             float4 y[8];
             acc_to_frag<2>(acc, y);
@@ -1360,7 +1364,7 @@ __global__ __launch_bounds__(256, 2) void k_compress_bwd_h(const float* __restri
     }
     float4 da0[16];
     load_rowfrag<16>(da0, a0, row, D, L.h);  // holds a0 until the chunk's product arrives
-    row_gemm128_h<2>(w2b, nullptr, ys, L, inv, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true>(w2b, nullptr, ys, L, inv, [&](int c, f32x16 (&acc)[2]) {
         float4 y[8];
         acc_to_frag<2>(acc, y);
 #pragma unroll
@@ -1397,17 +1401,15 @@ __global__ __launch_bounds__(256, 2) void k_compress_bwd_h(const float* __restri
             inv2 = row_scale_pow2<16>(da0, sc);
             split_frag2<8>(da0, ds);
         }
-        row_gemm128_h<2>(w0cb, nullptr, ds, L, inv2, [&](int c, f32x16 (&acc)[2]) {
-            if (valid) {
-                float4 y[8], old[8];
-                acc_to_frag<2>(acc, y);
-                load_rowfrag<8>(old, dM + 64 * c, row, D, L.h);
+        row_gemm128_h<2, true>(w0cb, nullptr, ds, L, inv2, [&](int c, f32x16 (&acc)[2]) {
+            float4 y[8], old[8];
+            acc_to_frag<2>(acc, y);
+            load_rowfrag<8>(old, dM + 64 * c, row, D, L.h);
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    y[k].x += old[k].x; y[k].y += old[k].y; y[k].z += old[k].z; y[k].w += old[k].w;
-                }
-                store_rowfrag<8>(y, dM + 64 * c, row, D, L.h);
+            for (int k = 0; k < 8; k++) {
+                y[k].x += old[k].x; y[k].y += old[k].y; y[k].z += old[k].z; y[k].w += old[k].w;
             }
+            if (valid) store_rowfrag<8>(y, dM + 64 * c, row, D, L.h);
         });
     }
 }
@@ -1433,8 +1435,10 @@ bool use_tile_f16x3() { return g_f16x3 != 0 && g_tile_f16x3 != 0 && g_bf16x6 != 
 // (6.4 -> 5.1 ms per step), but the recomputing adjoint issues 120 instead of 72 MFMAs per chunk at the same ~20 %
 // pipe utilisation (these kernels are issue / latency bound, not HBM bound) and takes 13.1 ms against 7.9: OFF by
 // default, kept as the memory-lean variant.
-static int g_trr_tilek = 1;  // pet_config_set("trr_compress", 0): the LDS-tile compress kernels
-void set_trr_compress(int v) { g_trr_tilek = v ? 1 : 0; }
+// pet_config_set("trr_compress", bits): 1 compress (+adjoint), 2 edge head (+adjoint), 4 node update (k_node_h: 5.8 ms
+// against 3.0 ms for the LDS-tile k_node at 80k atoms, so off by default); 0 = the LDS-tile kernels everywhere
+static int g_trr_tilek = 3;
+void set_trr_compress(int v) { g_trr_tilek = v; }
 static int g_emlp_recompute = 0;
 void set_emlp_recompute(int v) { g_emlp_recompute = v ? 1 : 0; }
 // inference only: the edge-MLP adjoint rebuilds [v; g] instead of reading them back (k_emlp_bwd_r)
@@ -1532,7 +1536,7 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const float* __restrict__ Xin
         split_frag2<8>(x, xs);
     }
     float4 s1[16];
-    row_gemm128_h<2>(w0, b0, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true>(w0, b0, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
         float4 y[8];
         acc_to_frag<2>(acc, y);
 #pragma unroll
@@ -1540,7 +1544,7 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const float* __restrict__ Xin
     });
     split_frag2<8>(s1, xs);
     float part = 0.f;
-    row_gemm128_h<2>(w2, b2, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true>(w2, b2, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
         float4 y[8];
         acc_to_frag<2>(acc, y);
 #pragma unroll
@@ -1579,7 +1583,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_h(const float* __restrict__ Xi
         split_frag2<8>(x, xs);
     }
     float4 a1[16], t[16];
-    row_gemm128_h<2>(w0f, b0, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true>(w0f, b0, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
         float4 y[8];
         acc_to_frag<2>(acc, y);
 #pragma unroll
@@ -1591,7 +1595,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_h(const float* __restrict__ Xi
     if (TRAIN && valid) store_rowfrag<16>(t, t_s1, row, DH, L.h);
     split_frag2<8>(t, xs);
     // a2 = W2 s1 + b2  ->  da2 = gy wl silu'(a2)   (t is reused for da2)
-    row_gemm128_h<2>(w2f, b2, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true>(w2f, b2, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
         float4 y[8];
         acc_to_frag<2>(acc, y);
 #pragma unroll
@@ -1612,7 +1616,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_h(const float* __restrict__ Xi
         split_frag2<8>(t, xs);
     }
     // ds1 = da2 W2  ->  da1 = ds1 silu'(a1)
-    row_gemm128_h<2>(w2b, nullptr, xs, L, inv, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true>(w2b, nullptr, xs, L, inv, [&](int c, f32x16 (&acc)[2]) {
         float4 y[8];
         acc_to_frag<2>(acc, y);
 #pragma unroll
@@ -1627,7 +1631,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_h(const float* __restrict__ Xi
         inv = row_scale_pow2<16>(t, sc);
         split_frag2<8>(t, xs);
     }
-    row_gemm128_h<2>(w0b, nullptr, xs, L, inv, [&](int c, f32x16 (&acc)[2]) {  // dx = da1 W0
+    row_gemm128_h<2, true>(w0b, nullptr, xs, L, inv, [&](int c, f32x16 (&acc)[2]) {  // dx = da1 W0
         if (valid) {
             float4 y[8];
             acc_to_frag<2>(acc, y);
@@ -1638,7 +1642,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_h(const float* __restrict__ Xi
 
 bool trr_head_edge(const Model& m, const float* Xin, const float* fc, float* ypred, float* yout, int64_t E,
                    hipStream_t st) {
-    if (!(g_bf16x6 && g_f16x3 && g_trr_tilek && m.eh0.fwd2 && m.eh2.fwd2)) return false;
+    if (!(g_bf16x6 && g_f16x3 && (g_trr_tilek & 2) && m.eh0.fwd2 && m.eh2.fwd2)) return false;
     k_head_h<<<grid_rows(E), 256, 0, st>>>(Xin, w2_fwd(m.eh0), m.eh0.b, w2_fwd(m.eh2), m.eh2.b, m.ell_w, m.ell_b, fc, ypred,
                                            yout, E);
     return true;
@@ -1646,7 +1650,7 @@ bool trr_head_edge(const Model& m, const float* Xin, const float* fc, float* ypr
 bool trr_head_edge_bwd(const Model& m, const float* Xin, const float* gA, const int* ctr, const float* fc,
                        const float* ypred, float* dfc, float* dXout, int64_t E, float* t_s1, float* t_da2, float* t_da1,
                        float* t_s2y, hipStream_t st) {
-    if (!(g_bf16x6 && g_f16x3 && g_trr_tilek && m.eh0.fwd2 && m.eh2.fwd2 && m.eh0.bwd2 && m.eh2.bwd2)) return false;
+    if (!(g_bf16x6 && g_f16x3 && (g_trr_tilek & 2) && m.eh0.fwd2 && m.eh2.fwd2 && m.eh0.bwd2 && m.eh2.bwd2)) return false;
     const int grid = grid_rows(E);
     if (t_s1)
         k_head_bwd_h<true><<<grid, 256, 0, st>>>(Xin, w2_fwd(m.eh0), m.eh0.b, w2_fwd(m.eh2), m.eh2.b, w2_bwd(m.eh0),
@@ -1659,9 +1663,164 @@ bool trr_head_edge_bwd(const Model& m, const float* Xin, const float* gA, const 
     return true;
 }
 
+// ---------------------------------------------------------------------------------
+// node update (transformer.py:222-227) as a TRR kernel on f16x3: one wave = 32 atoms,
+//   h1 = h + OC Wce^T + b;   hn = h1 + Wout (v sig(g)) + b,  [v; g] = Win RMSNorm(h1) + b
+// The 256-wide normalised row (16 K blocks x 2 planes) is parked in wave-private LDS (32 KB per wave); the 256
+// output columns of the second GEMM are eight accumulator tiles, their cross sums are folded in pair by pair so
+// that only one pair of them is live.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_node_h(const float* __restrict__ H, const float* __restrict__ OC, W2 wce,
+                                                 const float* __restrict__ bce, const float* __restrict__ gamma, W2 win,
+                                                 const float* __restrict__ bin, W2 wout, const float* __restrict__ bout,
+                                                 float* __restrict__ H1, float* __restrict__ VGn,
+                                                 float* __restrict__ Hn, int64_t N) {
+    extern __shared__ __attribute__((aligned(16))) f16x8 npark[];  // [4 waves][16 blocks][2 planes][64]
+    TRR_PROLOGUE(N);
+    f16x8* xp = npark + (size_t)(threadIdx.x >> 6) * 32 * 64;
+    constexpr int NC = DNF / 32;  // hidden chunks
+    {
+        float4 h1[32];
+        Split2<8> ocs;
+        {
+            float4 oc[16];
+            load_rowfrag<16>(oc, OC, row, D, L.h);
+            split_frag2<8>(oc, ocs);
+        }
+        float ss = 0.f;
+        row_gemm128_h<4, true>(wce, bce, ocs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+            float4 y[8], hin[8];
+            acc_to_frag<2>(acc, y);
+            load_rowfrag<8>(hin, H + 64 * c, row, DN, L.h);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float4 v = make_float4(y[k].x + hin[k].x, y[k].y + hin[k].y, y[k].z + hin[k].z, y[k].w + hin[k].w);
+                h1[8 * c + k] = v;
+                y[k] = v;
+                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+            if (valid) store_rowfrag<8>(y, H1 + 64 * c, row, DN, L.h);
+        });
+        const float rstd = rsqrtf(row_sum(ss) * (1.0f / DN) + 1.1920928955078125e-07f);
+#pragma unroll
+        for (int kg = 0; kg < 32; kg++) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
+            h1[kg].x *= rstd * g.x; h1[kg].y *= rstd * g.y; h1[kg].z *= rstd * g.z; h1[kg].w *= rstd * g.w;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            Split2<8> t;
+            split_frag2<8>(h1 + 16 * half, t);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                xp[(2 * (8 * half + k)) * 64 + L.lane] = t.h[k];
+                xp[(2 * (8 * half + k) + 1) * 64 + L.lane] = t.l[k];
+            }
+        }
+    }
+    // stream A: W_in, tile hc (value) and 16 + hc (gate), 16 K blocks each: b = 16 hc + kb
+    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
+    constexpr size_t TS = (size_t)NC * 16 * 64;
+    // stream B: W_out, K blocks 2 hc, 2 hc + 1 of the tile pairs (0,1) (2,3) (4,5) (6,7): j = 8 hc + 2 tp + kb
+    auto bidx = [&](int j) {
+        const int hc = j >> 3, tp = (j >> 1) & 3, kb = j & 1;
+        return ((size_t)(2 * tp) * (DNF / 16) + 2 * hc + kb) * 64 + L.lane;  // second tile of the pair at + (DNF / 16) * 64
+    };
+    WBlk2<2> ra[4], rb[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) ld_blk2<2>(ra[b], win, aidx(b), TS);
+#pragma unroll
+    for (int b = 0; b < 4; b++) ld_blk2<2>(rb[b], wout, bidx(b), (size_t)(DNF / 16) * 64);
+    f32x16 out[8];
+    acc_bias<8>(out, bout, 0, L.h);
+    float4 bv[4], bg[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        bv[q] = *reinterpret_cast<const float4*>(bin + 8 * q + 4 * L.h);
+        bg[q] = *reinterpret_cast<const float4*>(bin + DNF + 8 * q + 4 * L.h);
+    }
+#pragma unroll 1
+    for (int hc = 0; hc < NC; hc++) {
+        f32x16 vg[2], vgl[2];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            vg[0][4 * q] = bv[q].x; vg[0][4 * q + 1] = bv[q].y; vg[0][4 * q + 2] = bv[q].z; vg[0][4 * q + 3] = bv[q].w;
+            vg[1][4 * q] = bg[q].x; vg[1][4 * q + 1] = bg[q].y; vg[1][4 * q + 2] = bg[q].z; vg[1][4 * q + 3] = bg[q].w;
+        }
+        acc_zero<2>(vgl);
+        if (hc + 1 < NC) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                bv[q] = *reinterpret_cast<const float4*>(bin + 32 * (hc + 1) + 8 * q + 4 * L.h);
+                bg[q] = *reinterpret_cast<const float4*>(bin + DNF + 32 * (hc + 1) + 8 * q + 4 * L.h);
+            }
+        }
+        const f16x8* xq = xp + L.lane;
+        asm volatile("" : "+v"(xq));  // keep the parked fragments out of hoisted registers
+#pragma unroll
+        for (int kb = 0; kb < 16; kb++) {
+            const f16x8 xh = xq[(2 * kb) * 64], xl = xq[(2 * kb + 1) * 64];
+            WBlk2<2>& wb = ra[kb & 3];
+            mfma3<2>(vg, vgl, wb, xh, xl);
+            const int nb = 16 * hc + kb + 4;
+            if (nb < 16 * NC) ld_blk2<2>(wb, win, aidx(nb), TS);
+        }
+        fold_low<2>(vg, vgl);
+        float4 u[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 vv = acc_q(vg[0], q), gg = acc_q(vg[1], q);
+            if (VGn && valid) {
+                *reinterpret_cast<float4*>(VGn + row * (2 * DNF) + 32 * hc + 8 * q + 4 * L.h) = vv;
+                *reinterpret_cast<float4*>(VGn + row * (2 * DNF) + DNF + 32 * hc + 8 * q + 4 * L.h) = gg;
+            }
+            u[q] = make_float4(vv.x * sigm_(gg.x), vv.y * sigm_(gg.y), vv.z * sigm_(gg.z), vv.w * sigm_(gg.w));
+        }
+        Split2<2> us;
+        split_frag2<2>(u, us);
+#pragma unroll
+        for (int tp = 0; tp < 4; tp++) {
+            f32x16 lo[2];
+            acc_zero<2>(lo);
+            f32x16(&op)[2] = *reinterpret_cast<f32x16(*)[2]>(&out[2 * tp]);
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+                WBlk2<2>& wb = rb[(2 * tp + kb) & 3];
+                mfma3<2>(op, lo, wb, us.h[kb], us.l[kb]);
+                const int nb = 8 * hc + 2 * tp + kb + 4;
+                if (nb < 8 * NC) ld_blk2<2>(wb, wout, bidx(nb), (size_t)(DNF / 16) * 64);
+            }
+            fold_low<2>(op, lo);
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float4 y[8], hr[8];
+            acc_to_frag<2>(*reinterpret_cast<f32x16(*)[2]>(&out[2 * c]), y);
+            load_rowfrag<8>(hr, H1 + 64 * c, row, DN, L.h);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                y[k].x += hr[k].x; y[k].y += hr[k].y; y[k].z += hr[k].z; y[k].w += hr[k].w;
+            }
+            store_rowfrag<8>(y, Hn + 64 * c, row, DN, L.h);
+        }
+    }
+}
+
+bool trr_node(const AttnLayerW& A, const float* H, const float* OC, float* H1, float* VGn, float* Hn, int64_t N,
+              hipStream_t st) {
+    if (!(g_bf16x6 && g_f16x3 && (g_trr_tilek & 4) && A.ce.fwd2 && A.cmlp_in.fwd2 && A.cmlp_out.fwd2) || N <= 0) return false;
+    const size_t lds = (size_t)4 * 32 * 64 * sizeof(f16x8);  // 128 KB
+    allow_big_lds(k_node_h, lds);
+    k_node_h<<<grid_rows(N), 256, lds, st>>>(H, OC, w2_fwd(A.ce), A.ce.b, A.g_center, w2_fwd(A.cmlp_in), A.cmlp_in.b,
+                                              w2_fwd(A.cmlp_out), A.cmlp_out.b, H1, VGn, Hn, N);
+    return true;
+}
+
 bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* Min, float* a0_out, float* Xout,
                   int64_t E, hipStream_t st) {
-    if (!(g_bf16x6 && g_f16x3 && g_trr_tilek && G.compress2.fwd2 && (first || G.compress0_msg.fwd2))) return false;
+    if (!(g_bf16x6 && g_f16x3 && (g_trr_tilek & 1) && G.compress2.fwd2 && (first || G.compress0_msg.fwd2))) return false;
     if (first)
         k_compress_h<true><<<grid_rows(E), 256, 0, st>>>(g.geo, g.sp_nbr, G.wc, G.tbl, nullptr, W2(), w2_fwd(G.compress2),
                                                        G.compress2.b, a0_out, Xout, E);
@@ -1672,7 +1831,7 @@ bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* M
 }
 bool trr_compress_bwd(bool first, const float* dXe, const float* a0, const GnnLayerW& G, float* dgeo, float* dM,
                       int64_t E, float* t_da0, hipStream_t st) {
-    if (!(g_bf16x6 && g_f16x3 && g_trr_tilek && G.compress2.bwd2 && (first || G.compress0_msg.bwd2))) return false;
+    if (!(g_bf16x6 && g_f16x3 && (g_trr_tilek & 1) && G.compress2.bwd2 && (first || G.compress0_msg.bwd2))) return false;
     const int grid = grid_rows(E);
     if (first) {
         if (t_da0) k_compress_bwd_h<true, true><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), G.wct, W2(), dgeo, nullptr, E, t_da0);
