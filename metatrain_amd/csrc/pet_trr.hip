@@ -282,13 +282,13 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_b(const float* __restrict__ dQK
 // ---------------------------------------------------------------------------------
 // UNROLLED: the column-group loop is fully unrolled, for epilogues that index register arrays with the group number
 // (a runtime index would send those arrays to scratch memory)
-template <int NC2, bool UNROLLED = false, class Epilogue>
+template <int NC2, bool UNROLLED = false, int RING = 4, class Epilogue>
 __device__ __forceinline__ void row_gemm128_h(const W2& w, const float* __restrict__ bias, const Split2<8>& xs,
                                               const RowLane& L, float oscale, Epilogue epi) {
     auto widx = [&](int b) { return ((size_t)(2 * (b >> 3)) * 8 + (b & 7)) * 64 + L.lane; };
-    WBlk2<2> ring[4];
+    WBlk2<2> ring[RING];  // RING (a power of two) weight blocks in flight
 #pragma unroll
-    for (int b = 0; b < 4; b++) ld_blk2<2>(ring[b], w, widx(b), 8 * 64);
+    for (int b = 0; b < RING; b++) ld_blk2<2>(ring[b], w, widx(b), 8 * 64);
     float4 bnext[8];
     if (bias) ld_bias<2>(bnext, bias, 0, L.h);
 #pragma unroll UNROLLED ? NC2 : 1
@@ -303,9 +303,9 @@ __device__ __forceinline__ void row_gemm128_h(const W2& w, const float* __restri
         }
 #pragma unroll
         for (int kb = 0; kb < 8; kb++) {
-            WBlk2<2>& wb = ring[kb & 3];
+            WBlk2<2>& wb = ring[kb & (RING - 1)];
             mfma3<2>(acc, acl, wb, xs.h[kb], xs.l[kb]);
-            const int nb = 8 * c + kb + 4;
+            const int nb = 8 * c + kb + RING;
             if (nb < 8 * NC2) ld_blk2<2>(wb, w, widx(nb), 8 * 64);
         }
         fold_low<2>(acc, acl);
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void k_qkv_h(const float* __restrict__ X, c
         rmsnorm_frag<16>(x, gamma, L.h);
         split_frag2<8>(x, xs);
     }
-    row_gemm128_h<6>(win, bin, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<6, false, 2>(win, bin, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
         if (valid) {
             float4 y[8];
             acc_to_frag<2>(acc, y);
@@ -1299,6 +1299,20 @@ __global__ __launch_bounds__(256, 2) void k_compress_h(const float4* __restrict_
                                                      float* __restrict__ Xout, int64_t E) {
     TRR_PROLOGUE(E);
     float4 a0[16];  // row fragment of the pre-activation: entries a0[kg] = features 8 kg + 4 h .. + 3
+    if (!FIRST) {   // message term first: the geometry terms below then need no registers during the GEMM
+        Split2<8> ms;
+        {
+            float4 mrow[16];
+            load_rowfrag<16>(mrow, Min, row, D, L.h);
+            split_frag2<8>(mrow, ms);  // messages: an O(1) residual stream
+        }
+        row_gemm128_h<2, true, 2>(w0c, nullptr, ms, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+            acc_to_frag<2>(acc, &a0[8 * c]);
+        });
+    } else {
+#pragma unroll
+        for (int kg = 0; kg < 16; kg++) a0[kg] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     {
         const float4 g = geo[row];
         const float* trow = tbl + (size_t)sp_nbr[row] * D;
@@ -1308,27 +1322,12 @@ __global__ __launch_bounds__(256, 2) void k_compress_h(const float4* __restrict_
             const float4 t = *reinterpret_cast<const float4*>(trow + c);
             const float4 w0 = *reinterpret_cast<const float4*>(wc + 4 * c), w1 = *reinterpret_cast<const float4*>(wc + 4 * c + 4),
                          w2v = *reinterpret_cast<const float4*>(wc + 4 * c + 8), w3 = *reinterpret_cast<const float4*>(wc + 4 * c + 12);
-            a0[kg].x = fmaf(g.w, w0.w, fmaf(g.z, w0.z, fmaf(g.y, w0.y, g.x * w0.x))) + t.x;
-            a0[kg].y = fmaf(g.w, w1.w, fmaf(g.z, w1.z, fmaf(g.y, w1.y, g.x * w1.x))) + t.y;
-            a0[kg].z = fmaf(g.w, w2v.w, fmaf(g.z, w2v.z, fmaf(g.y, w2v.y, g.x * w2v.x))) + t.z;
-            a0[kg].w = fmaf(g.w, w3.w, fmaf(g.z, w3.z, fmaf(g.y, w3.y, g.x * w3.x))) + t.w;
+            a0[kg].x += fmaf(g.w, w0.w, fmaf(g.z, w0.z, fmaf(g.y, w0.y, g.x * w0.x))) + t.x;
+            a0[kg].y += fmaf(g.w, w1.w, fmaf(g.z, w1.z, fmaf(g.y, w1.y, g.x * w1.x))) + t.y;
+            a0[kg].z += fmaf(g.w, w2v.w, fmaf(g.z, w2v.z, fmaf(g.y, w2v.y, g.x * w2v.x))) + t.z;
+            a0[kg].w += fmaf(g.w, w3.w, fmaf(g.z, w3.z, fmaf(g.y, w3.y, g.x * w3.x))) + t.w;
+            if ((kg & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // 20 float4 loads in flight, not 80
         }
-    }
-    if (!FIRST) {
-        Split2<8> ms;
-        {
-            float4 mrow[16];
-            load_rowfrag<16>(mrow, Min, row, D, L.h);
-            split_frag2<8>(mrow, ms);  // messages: an O(1) residual stream
-        }
-        row_gemm128_h<2, true>(w0c, nullptr, ms, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
-            float4 y[8];
-            acc_to_frag<2>(acc, y);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                a0[8 * c + k].x += y[k].x; a0[8 * c + k].y += y[k].y; a0[8 * c + k].z += y[k].z; a0[8 * c + k].w += y[k].w;
-            }
-        });
     }
     if (a0_out && valid) store_rowfrag<16>(a0, a0_out, row, D, L.h);
     Split2<8> ss;
@@ -1338,7 +1337,7 @@ __global__ __launch_bounds__(256, 2) void k_compress_h(const float4* __restrict_
             a0[kg] = make_float4(silu_(a0[kg].x), silu_(a0[kg].y), silu_(a0[kg].z), silu_(a0[kg].w));
         split_frag2<8>(a0, ss);
     }
-    row_gemm128_h<2, true>(w2, b2, ss, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true, 2>(w2, b2, ss, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
         if (valid) {
             float4 y[8];
             acc_to_frag<2>(acc, y);
@@ -1536,7 +1535,7 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const float* __restrict__ Xin
         split_frag2<8>(x, xs);
     }
     float4 s1[16];
-    row_gemm128_h<2, true>(w0, b0, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true, 2>(w0, b0, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
         float4 y[8];
         acc_to_frag<2>(acc, y);
 #pragma unroll
@@ -1544,7 +1543,7 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const float* __restrict__ Xin
     });
     split_frag2<8>(s1, xs);
     float part = 0.f;
-    row_gemm128_h<2, true>(w2, b2, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true, 2>(w2, b2, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
         float4 y[8];
         acc_to_frag<2>(acc, y);
 #pragma unroll
