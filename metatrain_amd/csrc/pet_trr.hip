@@ -419,22 +419,20 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_h(const float* __restrict__ dQK
 #pragma unroll 1
     for (int ks = 0; ks < 3; ks++) {
         Split2<8> xs;
-        {
+        {   // branch-free per row (a divergent branch around accumulator code costs more than the multiplies)
             float sc;
-            const float iv = row_scale_pow2<16>(d, sc);  // d is now scaled by sc
-            if (ks == 0 || sc < scale) {
-                if (ks > 0) {  // larger entries than before: bring the running sums to the new scale
-                    const float f = sc * inv;
-                    acc_scale<4>(dn, f);
-                    acc_scale<4>(dnl, f);
-                }
-                scale = sc;
-                inv = iv;
-            } else if (sc > scale) {  // smaller slice: use the scale already in force
-                const float f = scale * iv;
-#pragma unroll
-                for (int kg = 0; kg < 16; kg++) { d[kg].x *= f; d[kg].y *= f; d[kg].z *= f; d[kg].w *= f; }
+            const float iv = row_pow2<16>(d, sc);
+            const bool shrink = ks == 0 || sc < scale;
+            const float sc_eff = shrink ? sc : scale;
+            if (ks > 0) {  // larger entries than before: bring the running sums to the new scale (factor 1 otherwise)
+                const float f = sc_eff * inv;
+                acc_scale<4>(dn, f);
+                acc_scale<4>(dnl, f);
             }
+            scale = sc_eff;
+            inv = shrink ? iv : inv;
+#pragma unroll
+            for (int kg = 0; kg < 16; kg++) { d[kg].x *= sc_eff; d[kg].y *= sc_eff; d[kg].z *= sc_eff; d[kg].w *= sc_eff; }
             split_frag2<8>(d, xs);
         }
         if (ks + 1 < 3) load_rowfrag<16>(d, dQKV + 128 * (ks + 1), row, 3 * D, L.h);

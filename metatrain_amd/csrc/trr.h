@@ -325,7 +325,7 @@ __device__ __forceinline__ void fold_low(f32x16 (&acc)[NT], const f32x16 (&acl)[
 // largest element in [1, 2) before an f16x3 split, and the result back afterwards (both exact).
 // Returns the inverse scale; `sc` receives the scale that was applied.
 template <int KG>
-__device__ __forceinline__ float row_scale_pow2(float4 (&x)[KG], float& sc) {
+__device__ __forceinline__ float row_pow2(const float4 (&x)[KG], float& sc) {  // the scale and its inverse, not applied
     float m = 0.f;
 #pragma unroll
     for (int kg = 0; kg < KG; kg++)
@@ -334,9 +334,14 @@ __device__ __forceinline__ float row_scale_pow2(float4 (&x)[KG], float& sc) {
     int e = (__float_as_int(m) >> 23) & 0xff;
     e = e > 253 ? 253 : e;
     sc = __int_as_float((254 - e) << 23);  // 2^(127 - e)
+    return __int_as_float(e << 23);        // 2^(e - 127); 0 for an all-zero row, whose outputs are 0 anyway
+}
+template <int KG>
+__device__ __forceinline__ float row_scale_pow2(float4 (&x)[KG], float& sc) {
+    const float inv = row_pow2<KG>(x, sc);
 #pragma unroll
     for (int kg = 0; kg < KG; kg++) { x[kg].x *= sc; x[kg].y *= sc; x[kg].z *= sc; x[kg].w *= sc; }
-    return __int_as_float(e << 23);        // 2^(e - 127); 0 for an all-zero row, whose outputs are 0 anyway
+    return inv;
 }
 template <int NT>
 __device__ __forceinline__ void acc_scale(f32x16 (&acc)[NT], float f) {
