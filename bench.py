@@ -285,6 +285,38 @@ def main():
         t2 = float((((rowptr[1:] - rowptr[:-1]) + 1) ** 2).sum())
         fwd_flops = 2001152.0 * e + 4292864.0 * n + 2048.0 * t2
         out["roofline"]["whole_step_algorithmic_tflops"] = 2 * fwd_flops / (ms_per_step * 1e-3) / 1e12
+        if world == 1:
+            # not `value`: the same step started from HOST-resident systems (what an MD driver or a DataLoader hands
+            # over) -- H2D of positions / species / cells, device neighbour lists + collate (metatrain_amd.data), graph
+            # build, forward, dE/dR, D2H of per-atom energies and gradients. DESIGN.md section 5 quotes it.
+            from metatrain_amd import data as pdata
+            host = [(pos_l[b].cpu().pin_memory(), z_l[b].cpu().pin_memory(), cell_l[b].cpu(), [True] * 3)
+                    for b in range(boxes)]
+
+            def host_step():
+                systems = [(p.to(dev, non_blocking=True), z.to(dev, non_blocking=True), c.to(dev), pbc)
+                           for p, z, c, pbc in host]
+                batch = pdata.collate(systems, hypers["cutoff"])
+                g = pdata.graph_of(model, batch)
+                fw = state["fw"]
+                if fw.graph.n_edges != g.n_edges:
+                    fw = state["fw"] = rt.HipForward(model, g)
+                fw.graph = g
+                a = fw.forward()
+                return a.cpu(), fw.backward(ones).cpu()
+
+            host_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                host_step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            out["host_resident_inputs"] = {
+                "value": n_atoms / dt, "unit": "atom-steps/s", "ms_per_step": dt * 1e3,
+                "includes": "H2D positions/species/cells (pinned), device neighbour lists + collate, graph build, "
+                            "forward, dE/dR, D2H per-atom energies + gradients"}
         if not args.no_cpu_baseline and world == 1:  # the reported CPU leg runs at N = 1 only
             out["cpu_baseline"] = cpu_baseline(hypers, params)
         print(json.dumps(out), flush=True)
