@@ -222,6 +222,33 @@ def test_neighbour_count_buckets_against_oracle(rt, model, dev, spacing, above63
     assert relmax(grad.cpu().numpy(), gp.numpy()) < TOL
 
 
+@pytest.mark.parametrize("n_atoms,seed", [(257, 5), (389, 6), (515, 7), (1031, 8)])
+def test_ragged_tail_tiles_against_oracle(rt, model, dev, n_atoms, seed):
+    """Edge and token counts that leave partially filled 32-row wave tiles and 128-row workgroups at the end of
+    every row kernel (E mod 128 differs per case), with a non-uniform seed vector so that adjoint rows span several
+    orders of magnitude (per-row power-of-two scaling of the f16x3 kernels): energies and dE/dR against the fp64
+    oracle evaluated here. (An exec-mask problem in a tail tile of the compress adjoint was once only visible
+    through an atom permutation; this test looks at the tails directly.)"""
+    hypers = model.hypers
+    pos, z, cell = opet.random_box(n_atoms, seed)
+    i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, hypers["cutoff"])
+    i, j, s = torch.tensor(i), torch.tensor(j), torch.tensor(s)
+    sysidx = torch.zeros(n_atoms, dtype=torch.int32)
+    graph = rt.HipGraph(model, pos.to(dev), cell[None].to(dev), i.to(dev), j.to(dev), s.to(dev), z.to(dev),
+                        sysidx.to(dev))
+    gen = torch.Generator().manual_seed(seed)
+    w = (10.0 ** (4.0 * torch.rand(n_atoms, generator=gen) - 3.0)).float()  # 1e-3 .. 10
+    fw = rt.HipForward(model, graph)
+    atomic = fw.forward()
+    grad = fw.backward(w.to(dev))
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    p64 = pos.double().requires_grad_(True)
+    ref = opet.pet_atomic_energies(params, hypers, p64, cell[None].double(), i, j, s.long(), z, sysidx.long())
+    (gp,) = torch.autograd.grad((ref.ravel() * w.double()).sum(), p64)
+    assert relmax(atomic.cpu().numpy(), ref.detach().numpy().ravel()) < TOL
+    assert relmax(grad.cpu().numpy(), gp.numpy()) < TOL
+
+
 def test_device_collate_matches_cpu_batching(rt, model, dev):
     """neighbour lists + batching on the device (metatrain_amd.data.collate) against the CPU
     route (oracle NL per system, offsets added as concatenate_structures does): same pair set, same energies and
