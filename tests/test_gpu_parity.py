@@ -227,8 +227,8 @@ def test_ragged_tail_tiles_against_oracle(rt, model, dev, n_atoms, seed):
     """Edge and token counts that leave partially filled 32-row wave tiles and 128-row workgroups at the end of
     every row kernel (E mod 128 differs per case), with a non-uniform seed vector so that adjoint rows span several
     orders of magnitude (per-row power-of-two scaling of the f16x3 kernels): energies and dE/dR against the fp64
-    oracle evaluated here. (An exec-mask problem in a tail tile of the compress adjoint was once only visible
-    through an atom permutation; this test looks at the tails directly.)"""
+    oracle evaluated here. (Complements test_rotation_and_permutation_consistency, which is the test that caught a
+    per-lane branch around spill code in the compress adjoint)"""
     hypers = model.hypers
     pos, z, cell = opet.random_box(n_atoms, seed)
     i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, hypers["cutoff"])
