@@ -289,15 +289,17 @@ __device__ __forceinline__ void row_gemm128_h(const W2& w, const float* __restri
     WBlk2<2> ring[RING];  // RING (a power of two) weight blocks in flight
 #pragma unroll
     for (int b = 0; b < RING; b++) ld_blk2<2>(ring[b], w, widx(b), 8 * 64);
+    constexpr bool BIAS_AHEAD = RING >= 4;  // the two-waves-per-SIMD callers (RING 2) have no registers for it
     float4 bnext[8];
-    if (bias) ld_bias<2>(bnext, bias, 0, L.h);
+    if (bias && BIAS_AHEAD) ld_bias<2>(bnext, bias, 0, L.h);
 #pragma unroll UNROLLED ? NC2 : 1
     for (int c = 0; c < NC2; c++) {
         f32x16 acc[2], acl[2];
         acc_zero<2>(acl);
         if (bias) {
+            if (!BIAS_AHEAD) ld_bias<2>(bnext, bias, 64 * c, L.h);
             acc_from<2>(acc, bnext);
-            if (c + 1 < NC2) ld_bias<2>(bnext, bias, 64 * (c + 1), L.h);
+            if (BIAS_AHEAD && c + 1 < NC2) ld_bias<2>(bnext, bias, 64 * (c + 1), L.h);
         } else {
             acc_zero<2>(acc);
         }
