@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_p(const float* __restrict__ QK
                                                      const float* __restrict__ fc, float* __restrict__ AO,
                                                      int64_t E, int N, float scale, int only_nt) {
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and the compiler knows it
     const int atom = gw / NHEAD, head = gw % NHEAD;
     if (atom >= N) return;
     const int start = rowptr[atom];
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QK
                                                      float* __restrict__ dQKV, float* __restrict__ dbias_h,
                                                      int64_t E, int N, float scale, int only_nt) {
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and the compiler knows it
     const int atom = gw / NHEAD, head = gw % NHEAD;
     if (atom >= N) return;
     const int start = rowptr[atom];
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QK
     float bias_r[NT][4], bias_c[NT], db[NT][4];
     int64_t rowc[NT];
     __shared__ __attribute__((aligned(16))) float stat_all[4][2][NT * 16];
-    float (*stat)[NT * 16] = stat_all[threadIdx.x >> 6];
+    float (*stat)[NT * 16] = stat_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         if (t < nt) {
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_attn_jvp_p(const float* __restrict__ QK
                                                      const float* __restrict__ Tkb, float* __restrict__ AOd,
                                                      int64_t E, int N, float scale, int only_nt) {
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and the compiler knows it
     const int atom = gw / NHEAD, head = gw % NHEAD;
     if (atom >= N) return;
     const int start = rowptr[atom];
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_attn_rev_p(const float* __restrict__ QK
                                                      float* __restrict__ nQKV, int64_t E, int N, float scale,
                                                      int only_nt) {
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and the compiler knows it
     const int atom = gw / NHEAD, head = gw % NHEAD;
     if (atom >= N) return;
     const int start = rowptr[atom];
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void k_attn_rev_p(const float* __restrict__ QK
     float bias_r[NT][4], biasd_r[NT][4], bias_c[NT], biasd_c[NT];
     int64_t rowc[NT];
     __shared__ __attribute__((aligned(16))) float stat_all[4][5][NT * 16];
-    float (*stat)[NT * 16] = stat_all[threadIdx.x >> 6];
+    float (*stat)[NT * 16] = stat_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         if (t < nt) {
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd_l(const float* __restrict__ QK
         *reinterpret_cast<float4*>(sm + t * LDF + 4 * c) = v;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, head = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c16 = lane & 15, g4 = lane >> 4;
     const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head;
     float4 kf[NT], qf[NT];
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_l(const float* __restrict__ QK
         *reinterpret_cast<float4*>(sm + t * LDB + 4 * c) = v;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, head = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c16 = lane & 15, g4 = lane >> 4;
     const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head, doo = 3 * D + HD * head;
     const float s2 = scale * LOG2E;
@@ -878,7 +878,7 @@ __device__ __forceinline__ int attn_next_atom(int a, int step, int N, int cap, c
 }
 __device__ __forceinline__ void attn_issue_rows(const float* __restrict__ QKV, const float* __restrict__ dAO,
                                                 const float* sm, int atom, int start, int T, int64_t E) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned base = (unsigned)(uintptr_t)sm;
     for (int h = wave; h < 2 * T; h += 8) {  // one wave-instruction per half row (64 float4)
         const int t = h >> 1;
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_a(const float* __restrict__ QK
                                                      int64_t E, int N, float scale, int cap) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // 2 x [cap][LDB] rows, then [8 waves][2][16][SCP]
     __shared__ float sbias_all[2][16 * NT];                     // log2 of the cutoff factor per key, per buffer
-    const int head = threadIdx.x >> 6;
+    const int head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head, doo = 3 * D + HD * head;
     const float s2 = scale * LOG2E;
     const int step = gridDim.x;

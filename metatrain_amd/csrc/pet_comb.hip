@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_comb_b(const float* __restrict__ XF, co
     TRR_PROLOGUE(E);
     constexpr int NC = 2 * D / 32;  // hidden chunks of 32
     constexpr int RD = 8;           // ring depth: a one-tile block is only 192 MFMA cycles, L2 is ~1.5k away
-    bf16x8* xpark = xpark_all + (size_t)(threadIdx.x >> 6) * 8 * 3 * 64;
+    bf16x8* xpark = xpark_all + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 8 * 3 * 64;
     // stream A: W0 tile hc, K blocks 0..15 (kb_total = 16): linear index b = 16 hc + kb
     auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
     WBlk<1> ra[RD];
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_comb_bwd_b(const float* __restrict__ dM
     extern __shared__ __attribute__((aligned(16))) float4 park_all[];  // [4 waves][NC * 4][64] float4
     TRR_PROLOGUE(E);
     constexpr int NC = 2 * D / 32;
-    float4* park = park_all + (size_t)(threadIdx.x >> 6) * NC * 4 * 64;
+    float4* park = park_all + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * NC * 4 * 64;
     // stream A: W2^T tile hc (tiles over the 256 hidden columns), K = 128: b = 8 hc + kb
     auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
     // stream B: W0^T, output tiles over the 256 cat columns (half: four tiles), K = 256 hidden: blocks 2 hc, 2 hc + 1
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_comb_h(const float* __restrict__ XF, co
     TRR_PROLOGUE(E);
     constexpr int NC = 2 * D / 32;  // hidden chunks of 32
     constexpr int RD = 8;           // ring depth: a one-tile block is only 192 MFMA cycles, L2 is ~1.5k away
-    f16x8* xpark = xpark2_all + (size_t)(threadIdx.x >> 6) * 8 * 2 * 64;
+    f16x8* xpark = xpark2_all + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 8 * 2 * 64;
     // stream A: W0 tile hc, K blocks 0..15 (kb_total = 16): linear index b = 16 hc + kb
     auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
     WBlk2<1> ra[RD];
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_comb_bwd_h(const float* __restrict__ dM
     extern __shared__ __attribute__((aligned(16))) float4 park_all[];  // [4 waves][NC * 4][64] float4
     TRR_PROLOGUE(E);
     constexpr int NC = 2 * D / 32;
-    float4* park = park_all + (size_t)(threadIdx.x >> 6) * NC * 4 * 64;
+    float4* park = park_all + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * NC * 4 * 64;
     // stream A: W2^T tile hc (tiles over the 256 hidden columns), K = 128: b = 8 hc + kb
     auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
     // stream B: W0^T, output tiles over the 256 cat columns (half: four tiles), K = 256 hidden: blocks 2 hc, 2 hc + 1

@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void k_emlp_p(const float* __restrict__ X1, co
                                                   float* __restrict__ X2, int64_t E) {
     extern __shared__ __attribute__((aligned(16))) float4 xstage[];  // [4 waves][2 buffers][16][64]
     const RowLane L;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4* mybuf = xstage + (size_t)wave * 2 * 16 * 64;
     const int64_t ntiles = (E + WROWS - 1) / WROWS, nw = (int64_t)gridDim.x * 4;
     int64_t tile = (int64_t)blockIdx.x * 4 + wave;
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, co
                                                   float* __restrict__ X2, int64_t E) {
     extern __shared__ __attribute__((aligned(16))) float4 xstage[];  // [4 waves][2 buffers][16][64]
     const RowLane L;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4* mybuf = xstage + (size_t)wave * 2 * 16 * 64;
     const int64_t ntiles = (E + WROWS - 1) / WROWS, nw = (int64_t)gridDim.x * 4;
     int64_t tile = (int64_t)blockIdx.x * 4 + wave;
@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_r(const float* __restrict__ dY
     extern __shared__ __attribute__((aligned(16))) f16x8 opark[];  // [4 waves][ys: 8 x 2][xs: 8 x 2][64]
     TRR_PROLOGUE(E);
     constexpr int NC = DFF / 32;
-    f16x8* ysp = opark + (size_t)(threadIdx.x >> 6) * 32 * 64;
+    f16x8* ysp = opark + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 32 * 64;
     f16x8* xsp = ysp + 16 * 64;
     auto fidx = [&](int b) { return ((size_t)(b >> 3) * 8 + (b & 7)) * 64 + L.lane; };  // forward W_in: tile hc, +TS = gate
     constexpr size_t TS = (size_t)NC * 8 * 64;
@@ -1676,7 +1676,7 @@ __global__ __launch_bounds__(256) void k_node_h(const float* __restrict__ H, con
                                                  float* __restrict__ Hn, int64_t N) {
     extern __shared__ __attribute__((aligned(16))) f16x8 npark[];  // [4 waves][16 blocks][2 planes][64]
     TRR_PROLOGUE(N);
-    f16x8* xp = npark + (size_t)(threadIdx.x >> 6) * 32 * 64;
+    f16x8* xp = npark + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 32 * 64;
     constexpr int NC = DNF / 32;  // hidden chunks
     {
         float4 h1[32];

@@ -32,7 +32,7 @@ constexpr int WROWS = 32;
 constexpr int WG_ROWS = 128;
 
 __device__ __forceinline__ int64_t wave_row0() {
-    return ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * WROWS;
+    return ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * WROWS;  // wave-uniform (SGPR)
 }
 
 // x[kg] = X[row][8 kg + 4 h .. + 3]
