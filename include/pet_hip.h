@@ -148,6 +148,17 @@ int64_t pet_forward_workspace_bytes(const pet_model_t* m, int64_t n_nodes, int64
 int pet_forward(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
                 int64_t workspace_bytes, int save_for_backward, float* d_atomic,
                 float* d_node_features, float* d_edge_features, void* stream);
+
+/* Auxiliary per-atom outputs of pet/model.py:730-875 ("feature" and "mtt::aux::<target>_last_layer_features"),
+ * from the backbone features pet_forward returned (same graph):
+ *   d_feature [N, d_node + d_pet]          = [ node features | sum over edges of cutoff_factor * edge features ]
+ *                                            (model.py:750-755; feedforward featuriser: the last GNN layer)
+ *   d_last_layer_features [N, 2 * d_head]  = [ node-head hidden | sum over edges of cutoff_factor * edge-head hidden ]
+ *                                            (model.py:795-812): the inputs of the target's last Linear layers
+ * Either may be NULL. d_scratch: n_edges * d_head + max(n_edges, n_nodes) floats, needed for d_last_layer_features. */
+int pet_aux_outputs(const pet_model_t* m, const pet_graph_t* g, const float* d_node_features,
+                    const float* d_edge_features, float* d_feature, float* d_last_layer_features, float* d_scratch,
+                    void* stream);
 /* Reverse pass of the last pet_forward on (m, g, workspace):
  *   d_grad_atomic [N] = dL/d(atomic prediction) (ones => L = total energy),
  *   d_grad_positions [N,3] = dL/dR  (what compute_gradient returns; force = -grad),

@@ -28,7 +28,7 @@ SYMBOLS = [
     "pet_nl_workspace_bytes", "pet_nl_build",
     "pet_graph_workspace_bytes", "pet_graph_build", "pet_graph_destroy", "pet_graph_num_edges",
     "pet_graph_max_neighbors", "pet_graph_export_batch", "pet_graph_csr",
-    "pet_forward_workspace_bytes", "pet_forward", "pet_backward", "pet_backward_predict",
+    "pet_forward_workspace_bytes", "pet_forward", "pet_aux_outputs", "pet_backward", "pet_backward_predict",
     "pet_backward_features", "pet_backward_geometry",
     "pet_model_zero_grad", "pet_model_get_grad", "pet_train_workspace_bytes", "pet_backward_train",
     "pet_model_get_param", "pet_model_flat_grad", "pet_adam_step",
@@ -133,6 +133,7 @@ def load() -> ctypes.CDLL:
     lib.pet_forward_workspace_bytes.argtypes = [P, c_int64, c_int64]
     lib.pet_forward_workspace_bytes.restype = c_int64
     lib.pet_forward.argtypes = [P, P, P, c_int64, c_int, P, P, P, P]
+    lib.pet_aux_outputs.argtypes = [P, P, P, P, P, P, P, P]
     lib.pet_backward.argtypes = [P, P, P, c_int64, P, P, P, P]
     lib.pet_backward_predict.argtypes = [P, P, P, c_int64, P, P, P, P, P]
     lib.pet_backward_features.argtypes = [P, P, P, c_int64, P, P, P, P, P]

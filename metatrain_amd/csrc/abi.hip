@@ -547,6 +547,16 @@ int pet_forward(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace,
                    d_edge_features, (hipStream_t)stream);
 }
 
+int pet_aux_outputs(const pet_model_t* pm, const pet_graph_t* pg, const float* d_node_features,
+                    const float* d_edge_features, float* d_feature, float* d_last_layer_features, float* d_scratch,
+                    void* stream) {
+    PET_REQUIRE(pm && pg && d_node_features, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(d_edge_features || pg->g.n_edges == 0, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
+    return aux_outputs(pm->m, pg->g, d_node_features, d_edge_features, d_feature, d_last_layer_features, d_scratch,
+                       (hipStream_t)stream);
+}
+
 int pet_backward(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                  const float* d_grad_atomic, float* d_grad_positions, float* d_grad_cells, void* stream) {
     PET_REQUIRE(pm && pg && d_workspace && d_grad_atomic && d_grad_positions, PET_ERR_ARGUMENT,

@@ -108,6 +108,8 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
             float* node_feat, float* edge_feat, hipStream_t st);
 int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* grad_atomic,
              float* grad_pos, float* grad_cells, hipStream_t st);
+int aux_outputs(const Model& m, const Graph& g, const float* node_feat, const float* edge_feat, float* feature,
+                float* last_layer, float* scratch, hipStream_t st);
 int backward_train(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* grad_atomic,
                    float* grad_pos, float* grad_cells, hipStream_t st);
 // so.hip: second-order (force-loss) reverse pass

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(NTHREADS) void k_head(const float* __restrict__ Xin
                                                     const float* __restrict__ b2, const float* __restrict__ wl,
                                                     float bl, const float* __restrict__ fc /* or null */,
                                                     float* __restrict__ ypred, float* __restrict__ yout,
-                                                    int64_t R) {
+                                                    int64_t R, float* __restrict__ hidden = nullptr, int ldh = 0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDK = lds_ld(K);
     float* A = smem;              // [64][K+4]
@@ -510,7 +510,11 @@ __global__ __launch_bounds__(NTHREADS) void k_head(const float* __restrict__ Xin
     acc_fill_bias<2>(acc, b2, 64 * w.ch, w.lane);
     gemm_acc_x<128, 2>(S + w.rb * 32 * LD128, LD128, w2, 16, 0, 2 * w.ch, acc, w.lane);
     __syncthreads();
-    acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) { S[r * LD128 + c] = siluf_(v) * wl[c]; });
+    acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
+        const float a = siluf_(v);
+        if (hidden && row0 + r < R) hidden[(row0 + r) * ldh + c] = a;  // last-layer features (pet_aux_outputs)
+        S[r * LD128 + c] = a * wl[c];
+    });
     __syncthreads();
     {
         const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
@@ -537,6 +541,27 @@ __global__ void k_atom_sum(const float* __restrict__ ynode, const float* __restr
     float s = 0.f;
     for (int p = rowptr[i]; p < rowptr[i + 1]; p++) s += ye[p];
     atomic[i] = ynode[i] + s;
+}
+
+// out[i][c] = sum_{edges p of i} fc[p] X[p][c], c < 128: one wave per atom, two columns per lane
+// (the cutoff-weighted edge sums of pet/model.py:753 and :797-799)
+__global__ void k_edge_sum_fc(const float* __restrict__ X, const float* __restrict__ fc, const int* __restrict__ rowptr,
+                              float* __restrict__ out, int ldo, int n) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    float2 s = make_float2(0.f, 0.f);
+    for (int p = rowptr[i]; p < rowptr[i + 1]; p++) {
+        const float f = fc[p];
+        const float2 x = *reinterpret_cast<const float2*>(X + (int64_t)p * D + 2 * lane);
+        s.x = fmaf(f, x.x, s.x);
+        s.y = fmaf(f, x.y, s.y);
+    }
+    *reinterpret_cast<float2*>(out + (int64_t)i * ldo + 2 * lane) = s;
+}
+__global__ void k_copy_rows(const float* __restrict__ X, int w, float* __restrict__ out, int ldo, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * w) return;
+    out[(idx / w) * ldo + idx % w] = X[idx];
 }
 
 // ---------------------------------------------------------------------------------
@@ -714,5 +739,37 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }
+
+// Auxiliary per-atom outputs (pet/model.py:730-875) from the backbone features pet_forward returned:
+//   feature    [N, DN + D]  = [ node features | sum_e fc_e edge features ]
+//   last_layer [N, 2 DH]    = [ node-head hidden | sum_e fc_e edge-head hidden ]   (the inputs of the last Linear)
+// scratch: E DH + max(E, N) floats, needed for last_layer
+int aux_outputs(const Model& m, const Graph& g, const float* node_feat, const float* edge_feat, float* feature,
+                float* last_layer, float* scratch, hipStream_t st) {
+    const int64_t N = g.n_nodes, E = g.n_edges;
+    if (N == 0) return PET_OK;
+    const int gN = (int)cdiv(N, BM), gE = (int)cdiv(E, BM);
+    if (feature) {
+        k_copy_rows<<<cdiv(N * DN, 256), 256, 0, st>>>(node_feat, DN, feature, DN + D, N);
+        k_edge_sum_fc<<<cdiv(N, 4), 256, 0, st>>>(edge_feat, g.fc, g.rowptr, feature + DN, DN + D, (int)N);
+    }
+    if (last_layer) {
+        allow_big_lds(k_head<256>, (BM * LD256 + BM * LD128) * 4);
+        const size_t lds2 = (size_t)(BM * LD128 * 2) * 4;
+        PET_REQUIRE(scratch, PET_ERR_ARGUMENT, "last-layer features need the scratch buffer");
+        float* hid_e = scratch;             // [E, DH] edge-head hidden rows
+        float* ytmp = scratch + E * DH;     // [max(E, N)] the heads' scalar predictions, not wanted here
+        k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, st>>>(
+            node_feat, wx_fwd(m.nh0, 32), m.nh0.b, wx_fwd(m.nh2, 32), m.nh2.b, m.nll_w, m.nll_b, nullptr, nullptr,
+            ytmp, N, last_layer, 2 * DH);
+        if (E > 0)
+            k_head<128><<<gE, NTHREADS, lds2, st>>>(edge_feat, wx_fwd(m.eh0, 64), m.eh0.b, wx_fwd(m.eh2, 64), m.eh2.b,
+                                                    m.ell_w, m.ell_b, nullptr, nullptr, ytmp, E, hid_e, DH);
+        k_edge_sum_fc<<<cdiv(N, 4), 256, 0, st>>>(hid_e, g.fc, g.rowptr, last_layer + DH, 2 * DH, (int)N);
+    }
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
 
 }  // namespace pet

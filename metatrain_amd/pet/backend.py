@@ -407,9 +407,27 @@ class PETBackend(torch.nn.Module):
         dt = batch_data["edge_vectors"].dtype
         return [nf.to(dt)], [ef.to(dt)]
 
+    def auxiliary_outputs(self, node_features_list, edge_features_list, batch_data, target: str = "energy",
+                          feature: bool = True, last_layer_features: bool = True):
+        """Per-atom ``feature`` ``[N, d_node + d_pet]`` and ``mtt::aux::<target>_last_layer_features``
+        ``[N, 2 d_head]`` as ``PET._get_output_features`` / ``_get_output_last_layer_features`` assemble them
+        (``pet/model.py:730-875``: cutoff-weighted edge sums next to the node parts), computed by
+        ``pet_aux_outputs`` from the features of ``calculate_features`` (values only: no autograd node)."""
+        h = self._ctx_of(batch_data)
+        if h.fwd is None:
+            raise PetHipError("auxiliary_outputs() needs calculate_features() on the same batch_data")
+        blocks = list(self.node_last_layers[target][0].keys())
+        model = self._hip_model(target, blocks[0])
+        fw = h.fwd if model is h.model else rt.HipForward(model, h.graph)
+        nf = node_features_list[-1].detach().float()
+        ef = h.to_csr(edge_features_list[-1].detach()).float()
+        return fw.aux_outputs(nf, ef, feature=feature, last_layer_features=last_layer_features)
+
     def predict(self, node_features_list, edge_features_list, batch_data, cells, system_indices,
                 requested_output_names: List[str]):
-        """``PETBackend.predict`` (backend.py:420-494): per-block atomic predictions ``[N, 1]``."""
+        """``PETBackend.predict`` (backend.py:420-494): per-block atomic predictions ``[N, 1]``. The two last-layer
+        feature dictionaries come back empty: the fused heads never store their hidden rows; the per-atom sums the
+        model wrapper builds from them are served by ``auxiliary_outputs``."""
         h = self._ctx_of(batch_data)
         if h.fwd is None:
             raise PetHipError("predict() needs the features of calculate_features() on the same batch_data")

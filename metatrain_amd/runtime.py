@@ -290,6 +290,22 @@ class HipForward:
             return atomic, nf, ef
         return atomic
 
+    def aux_outputs(self, node_features: torch.Tensor, edge_features: torch.Tensor, feature: bool = True,
+                    last_layer_features: bool = True):
+        """The per-atom auxiliary outputs of ``pet/model.py:730-875`` from the features ``forward(want_features=True)``
+        returned: ``feature`` ``[N, d_node + d_pet]`` (node features | cutoff-weighted sum of edge features) and the
+        target's last-layer features ``[N, 2 d_head]`` (node-head hidden | cutoff-weighted sum of edge-head hidden)."""
+        g = self.graph
+        dev = self.workspace.device
+        hy = self.model.hypers
+        n, e = g.n_nodes, g.n_edges
+        feat = torch.empty((n, hy["d_node"] + hy["d_pet"]), dtype=torch.float32, device=dev) if feature else None
+        llf = torch.empty((n, 2 * hy["d_head"]), dtype=torch.float32, device=dev) if last_layer_features else None
+        scratch = torch.empty(e * hy["d_head"] + max(e, n, 1), dtype=torch.float32, device=dev) if last_layer_features else None
+        check(self.lib.pet_aux_outputs(self.model.handle, g.handle, _ptr(node_features.contiguous()),
+                                       _ptr(edge_features.contiguous()), _ptr(feat), _ptr(llf), _ptr(scratch), _stream()))
+        return feat, llf
+
     def backward(self, grad_atomic: torch.Tensor, want_cell_grad: bool = False):
         g = self.graph
         dev = self.workspace.device

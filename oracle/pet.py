@@ -217,8 +217,14 @@ def pet_atomic_energies(
     target: str = "energy",
     block: Optional[str] = None,
     return_features: bool = False,
+    return_aux: bool = False,
 ):
     """Per-atom predictions ``[N, P]`` of the PET backend for one target.
+
+    ``return_aux``: also the auxiliary per-atom outputs of ``pet/model.py:730-875`` -- ``feature``
+    (``_get_output_features``, :750-755: node features | sum over edges of cutoff factor x edge features) and the
+    target's last-layer features (``_get_output_last_layer_features``, :795-812: node-head hidden | cutoff-weighted
+    sum of the edge-head hidden).
 
     Mirrors ``PETBackend.preprocess -> calculate_features -> predict``
     (``pet/modules/backend.py:238,344,420``) for the default variants
@@ -330,6 +336,10 @@ def pet_atomic_energies(
     node_pred = _linear(nl, p, f"node_last_layers.{target}.0.{block}")
     edge_pred = _linear(el, p, f"edge_last_layers.{target}.0.{block}") * fc[:, None]
     atomic = node_pred.index_add(0, ctr, edge_pred)
+    if return_aux:
+        def esum(x):
+            return torch.zeros((n_nodes, x.shape[1]), dtype=x.dtype).index_add(0, ctr, x * fc[:, None])
+        return atomic, torch.cat([h, esum(m)], dim=1), torch.cat([nl, esum(el)], dim=1)
     if return_features:
         return atomic, h, m, graph
     return atomic

@@ -60,6 +60,12 @@ def test_backend_runs_on_plain_tensors(dev):
     ref = opet.pet_atomic_energies(params, hypers, pos.cpu().double(), cells.cpu().double(), i.cpu(), j.cpu(),
                                    s.cpu().long(), z.cpu(), sysidx.cpu())
     assert (pred["energy"][0].cpu().double() - ref).abs().max() / ref.abs().max() < TOL
+    # the per-atom "feature" and last-layer-feature outputs of the model wrapper (pet/model.py:730-875)
+    feat, llf = be.auxiliary_outputs(nodes, edges, batch, "energy")
+    _, feat64, llf64 = opet.pet_atomic_energies(params, hypers, pos.cpu().double(), cells.cpu().double(), i.cpu(),
+                                                j.cpu(), s.cpu().long(), z.cpu(), sysidx.cpu(), return_aux=True)
+    assert feat.shape == (3, 384) and llf.shape == (3, 256)
+    assert relmax(feat.cpu().numpy(), feat64.numpy()) < TOL and relmax(llf.cpu().numpy(), llf64.numpy()) < TOL
 
 
 def test_energy_forces_and_strain_gradient_via_autograd(dev):

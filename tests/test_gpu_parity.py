@@ -249,6 +249,30 @@ def test_ragged_tail_tiles_against_oracle(rt, model, dev, n_atoms, seed):
     assert relmax(grad.cpu().numpy(), gp.numpy()) < TOL
 
 
+def test_feature_and_last_layer_feature_outputs(rt, model, dev):
+    """the "feature" and "mtt::aux::energy_last_layer_features" outputs (pet/model.py:730-875),
+    per atom, against the fp64 oracle."""
+    hypers = model.hypers
+    pos, z, cell = opet.random_box(203, 17)
+    i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, hypers["cutoff"])
+    i, j, s = torch.tensor(i), torch.tensor(j), torch.tensor(s)
+    sysidx = torch.zeros(len(pos), dtype=torch.int32)
+    graph = rt.HipGraph(model, pos.to(dev), cell[None].to(dev), i.to(dev), j.to(dev), s.to(dev), z.to(dev),
+                        sysidx.to(dev))
+    fw = rt.HipForward(model, graph)
+    atomic, nf, ef = fw.forward(want_features=True)
+    feat, llf = fw.aux_outputs(nf, ef)
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    ref, feat64, llf64 = opet.pet_atomic_energies(params, hypers, pos.double(), cell[None].double(), i, j, s.long(), z,
+                                                  sysidx.long(), return_aux=True)
+    assert feat.shape == (203, hypers["d_node"] + hypers["d_pet"]) and llf.shape == (203, 2 * hypers["d_head"])
+    assert relmax(atomic.cpu().numpy(), ref.numpy().ravel()) < TOL
+    assert relmax(feat.cpu().numpy(), feat64.numpy()) < TOL
+    assert relmax(llf.cpu().numpy(), llf64.numpy()) < TOL
+    only_feat, none = fw.aux_outputs(nf, ef, last_layer_features=False)
+    assert none is None and torch.equal(only_feat, feat)
+
+
 def test_device_collate_matches_cpu_batching(rt, model, dev):
     """neighbour lists + batching on the device (metatrain_amd.data.collate) against the CPU
     route (oracle NL per system, offsets added as concatenate_structures does): same pair set, same energies and
