@@ -78,7 +78,10 @@ void pet_model_destroy(pet_model_t* m);
  * `numel` contiguous fp32 values (int64 values for "species_to_species_index").
  * Heads of ONE target are addressed with the literal target name "energy" replaced by
  * the caller's target: keys "node_heads.<t>.0.0.weight" ... are passed with <t>
- * stripped to "@" (e.g. "node_heads.@.0.0.weight", "node_last_layers.@.0.@.weight"). */
+ * stripped to "@" (e.g. "node_heads.@.0.0.weight", "node_last_layers.@.0.@.weight").
+ * activation = "SiLU" (transformer.py:32-49): upload every "...w_in.weight" / "...w_in.bias" as the tensor stacked on
+ * itself ([W; W], [b; b]): with equal value and gate halves the SwiGLU stage computes silu(W x + b) exactly; the
+ * gradient of W is the sum of the two halves' gradients (metatrain_amd/runtime.py does both). */
 int pet_model_set_param(pet_model_t* m, const char* key, const void* d_data,
                         int64_t numel, void* stream);
 /* Pack / precompute derived tables once all parameters are set. */

@@ -22,9 +22,11 @@ followed by ``loss.backward()`` fills ``parameter.grad`` -- first-order term fro
 force-loss term from the forward-over-reverse pass ``pet_backward_train2`` -- so torch optimizers and DDP work
 on the mirror unchanged. (``metatrain_amd.pet.trainer.TrainStep`` is the faster, fully native step.)
 
-Not built (raise loudly): normalization != RMSNorm, activation != SwiGLU, transformer_type != PreLN,
+``activation = "SiLU"`` runs on the SwiGLU kernels with the projection uploaded as both halves (exact, see
+``runtime.HipModel.load``). Not built (raise loudly): normalization != RMSNorm, transformer_type != PreLN,
 featurizer_type != feedforward, the "grid" adaptive-cutoff method, system conditioning, more than one
-property per block, last-layer-feature outputs (the two extra dicts are returned empty), double backward
+property per block, per-edge last-layer-feature dicts (returned empty; ``auxiliary_outputs`` gives the per-atom
+sums), double backward
 through the three staged inference nodes, and stress (strain) terms in a training loss.
 """
 from math import prod
@@ -43,14 +45,15 @@ class _ParamsOnly(torch.nn.Module):
         raise PetHipError("parameter container: compute happens in libpet_hip, not in torch modules")
 
 
-def _feed_forward(d_model: int, dim_ff: int) -> torch.nn.Module:
+def _feed_forward(d_model: int, dim_ff: int, activation: str = "SwiGLU") -> torch.nn.Module:
     m = _ParamsOnly()
-    m.w_in = torch.nn.Linear(d_model, 2 * dim_ff)  # SwiGLU: value | gate (transformer.py:28-31)
+    # SwiGLU: value | gate (transformer.py:28-31); SiLU: one projection (:34-36)
+    m.w_in = torch.nn.Linear(d_model, (2 if activation.lower() == "swiglu" else 1) * dim_ff)
     m.w_out = torch.nn.Linear(dim_ff, d_model)
     return m
 
 
-def _transformer_layer(d: int, dn: int, dff: int) -> torch.nn.Module:
+def _transformer_layer(d: int, dn: int, dff: int, activation: str = "SwiGLU") -> torch.nn.Module:
     # creation order == reference (transformer.py:169-201) so torch.manual_seed reproduces its init
     m = _ParamsOnly()
     att = _ParamsOnly()
@@ -59,18 +62,19 @@ def _transformer_layer(d: int, dn: int, dff: int) -> torch.nn.Module:
     m.attention = att
     m.norm_attention = torch.nn.RMSNorm(d)
     m.norm_mlp = torch.nn.RMSNorm(d)
-    m.mlp = _feed_forward(d, dff)
+    m.mlp = _feed_forward(d, dff, activation)
     m.center_contraction = torch.nn.Linear(dn, d)
     m.center_expansion = torch.nn.Linear(d, dn)
     m.norm_center_features = torch.nn.RMSNorm(dn)
-    m.center_mlp = _feed_forward(dn, 2 * dn)
+    m.center_mlp = _feed_forward(dn, 2 * dn, activation)
     return m
 
 
-def _cartesian_transformer(d: int, dn: int, dff: int, n_layers: int, n_species: int, is_first: bool):
+def _cartesian_transformer(d: int, dn: int, dff: int, n_layers: int, n_species: int, is_first: bool,
+                           activation: str = "SwiGLU"):
     m = _ParamsOnly()
     trans = _ParamsOnly()
-    trans.layers = torch.nn.ModuleList([_transformer_layer(d, dn, dff) for _ in range(n_layers)])
+    trans.layers = torch.nn.ModuleList([_transformer_layer(d, dn, dff, activation) for _ in range(n_layers)])
     m.trans = trans
     m.edge_embedder = torch.nn.Linear(4, d)
     m.compress = torch.nn.Sequential(
@@ -286,7 +290,7 @@ class PETBackend(torch.nn.Module):
             self.species_to_species_index[species] = i
         self.gnn_layers = torch.nn.ModuleList([
             _cartesian_transformer(self.d_pet, self.d_node, self.d_feedforward, self.num_attention_layers,
-                                   n_species, g == 0)
+                                   n_species, g == 0, hypers["activation"])
             for g in range(self.num_gnn_layers)
         ])
         self.combination_norms = torch.nn.ModuleList(

@@ -32,10 +32,11 @@ def hypers_struct(hypers: dict, atomic_types: List[int]) -> PetHypers:
     fn = hypers["cutoff_function"].lower()
     if fn not in ("bump", "cosine"):
         raise ValueError(f"Unknown cutoff function type: {hypers['cutoff_function']}")
-    for key, want in (("normalization", "RMSNorm"), ("activation", "SwiGLU"),
-                      ("transformer_type", "PreLN"), ("featurizer_type", "feedforward")):
+    for key, want in (("normalization", "RMSNorm"), ("transformer_type", "PreLN"), ("featurizer_type", "feedforward")):
         if hypers[key] != want:
             raise PetHipError(f"hypers['{key}'] = {hypers[key]!r} is not built into libpet_hip (only {want!r})")
+    if hypers["activation"] not in ("SwiGLU", "SiLU"):
+        raise ValueError(f"Unknown activation flag: {hypers['activation']}")  # transformer.py:342-346
     if hypers["num_neighbors_adaptive"] is not None and hypers["adaptive_cutoff_method"].lower() != "solver":
         raise PetHipError("adaptive_cutoff_method = 'grid' is not built into libpet_hip (only 'solver')")
     if hypers.get("system_conditioning", False):
@@ -90,6 +91,7 @@ class HipModel:
         block = block or target
         self.target = target
         self._ckeys: Dict[str, tuple] = {}
+        self._tied = set()  # SiLU variant: w_in parameters uploaded twice (value half = gate half)
         for key, t in params.items():
             _require_cuda(t)
             parts = key.split(".")
@@ -106,7 +108,13 @@ class HipModel:
                 src = t.to(torch.int64).contiguous()
             else:
                 src = t.detach().to(torch.float32).contiguous()
-                self._ckeys[key] = (ckey, tuple(t.shape))
+                if self.hypers["activation"] == "SiLU" and ".w_in." in key:
+                    # activation = "SiLU" (transformer.py:32-49) on the SwiGLU kernels, exactly: with the value and
+                    # gate halves both equal to W x + b, v * sigmoid(g) IS silu(W x + b), and the adjoint
+                    # W^T (dv + dg) is W^T (d * silu'(a)). The packed model holds [W; W]; the tie is kept here.
+                    src = torch.cat([src, src], dim=0).contiguous()
+                    self._tied.add(key)
+                self._ckeys[key] = (ckey, tuple(src.shape))
             check(self.lib.pet_model_set_param(self._handle, ckey.encode(), _ptr(src), src.numel(), _stream()))
             torch.cuda.current_stream().synchronize()  # src may be a temporary
         check(self.lib.pet_model_finalize(self._handle, _stream()))
@@ -134,6 +142,8 @@ class HipModel:
         ckey, shape = self._ckeys[key]
         out = torch.empty(shape, dtype=torch.float32, device="cuda")
         check(self.lib.pet_model_get_grad(self._handle, ckey.encode(), _ptr(out), out.numel(), _stream()))
+        if key in self._tied:  # d/dW of a weight used as both halves
+            return out[: shape[0] // 2] + out[shape[0] // 2:]
         return out
 
     def grads(self) -> Dict[str, torch.Tensor]:
@@ -143,6 +153,8 @@ class HipModel:
         ckey, shape = self._ckeys[key]
         out = torch.empty(shape, dtype=torch.float32, device="cuda")
         check(self.lib.pet_model_get_param(self._handle, ckey.encode(), _ptr(out), out.numel(), _stream()))
+        if key in self._tied:
+            return out[: shape[0] // 2].clone()
         return out
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
@@ -163,6 +175,10 @@ class HipModel:
     def adam_step(self, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-8,
                   weight_decay: Optional[float] = None, max_grad_norm: float = 0.0) -> torch.Tensor:
         """clip_grad_norm_ + Adam/AdamW + re-pack; returns the pre-clip gradient norm (device scalar)."""
+        if self._tied:
+            raise PetHipError("the fused Adam step updates the two halves of a tied (activation = 'SiLU') w_in "
+                              "independently: train this variant through the torch mirror (PETBackend + a torch "
+                              "optimizer), which re-uploads the weights")
         norm = torch.empty(1, dtype=torch.float32, device="cuda")
         wd = -1.0 if weight_decay is None else float(weight_decay)
         check(self.lib.pet_adam_step(self._handle, float(lr), float(betas[0]), float(betas[1]), float(eps), wd,

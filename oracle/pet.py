@@ -128,10 +128,13 @@ def _rmsnorm(x, weight):
 
 
 def _swiglu_ff(x, p, prefix):
-    # transformer.py:39-44: value first, gate second, sigmoid gate
     y = _linear(x, p, prefix + ".w_in")
-    v, g = y.chunk(2, dim=-1)
-    return _linear(v * torch.sigmoid(g), p, prefix + ".w_out")
+    if p[prefix + ".w_in.weight"].shape[0] == 2 * p[prefix + ".w_out.weight"].shape[1]:
+        # activation = "SwiGLU", transformer.py:39-44: value first, gate second, sigmoid gate
+        v, g = y.chunk(2, dim=-1)
+        return _linear(v * torch.sigmoid(g), p, prefix + ".w_out")
+    # activation = "SiLU", transformer.py:45-49
+    return _linear(torch.nn.functional.silu(y), p, prefix + ".w_out")
 
 
 class EdgeGraph:
@@ -232,7 +235,7 @@ def pet_atomic_energies(
     no adaptive cutoff, non-strict neighbour list).
     """
     assert hypers["normalization"] == "RMSNorm"
-    assert hypers["activation"] == "SwiGLU"
+    assert hypers["activation"] in ("SwiGLU", "SiLU")
     assert hypers["transformer_type"] == "PreLN"
     assert hypers["featurizer_type"] == "feedforward"
     assert hypers["num_neighbors_adaptive"] is None or hypers["adaptive_cutoff_method"] == "solver"
@@ -458,12 +461,12 @@ def state_dict_schema(hypers: dict, atomic_types: List[int], targets: Dict[str, 
             lin(lp + ".attention.output_linear", d, d)
             out.append((lp + ".norm_attention.weight", (d,), "norm_w"))
             out.append((lp + ".norm_mlp.weight", (d,), "norm_w"))
-            lin(lp + ".mlp.w_in", 2 * dff, d)
+            lin(lp + ".mlp.w_in", (2 if hypers["activation"] == "SwiGLU" else 1) * dff, d)
             lin(lp + ".mlp.w_out", d, dff)
             lin(lp + ".center_contraction", d, dn)
             lin(lp + ".center_expansion", dn, d)
             out.append((lp + ".norm_center_features.weight", (dn,), "norm_w"))
-            lin(lp + ".center_mlp.w_in", 4 * dn, dn)
+            lin(lp + ".center_mlp.w_in", (4 if hypers["activation"] == "SwiGLU" else 2) * dn, dn)
             lin(lp + ".center_mlp.w_out", dn, 2 * dn)
         lin(f"gnn_layers.{g}.edge_embedder", d, 4)
         lin(f"gnn_layers.{g}.compress.0", d, (2 if g == 0 else 3) * d)
@@ -579,12 +582,12 @@ def reference_init_params(
             lin(lp + ".attention.output_linear", d, d)
             p[lp + ".norm_attention.weight"] = torch.ones(d)
             p[lp + ".norm_mlp.weight"] = torch.ones(d)
-            lin(lp + ".mlp.w_in", 2 * dff, d)
+            lin(lp + ".mlp.w_in", (2 if hypers["activation"] == "SwiGLU" else 1) * dff, d)
             lin(lp + ".mlp.w_out", d, dff)
             lin(lp + ".center_contraction", d, dn)
             lin(lp + ".center_expansion", dn, d)
             p[lp + ".norm_center_features.weight"] = torch.ones(dn)
-            lin(lp + ".center_mlp.w_in", 4 * dn, dn)
+            lin(lp + ".center_mlp.w_in", (4 if hypers["activation"] == "SwiGLU" else 2) * dn, dn)
             lin(lp + ".center_mlp.w_out", dn, 2 * dn)
         lin(f"gnn_layers.{g}.edge_embedder", d, 4)
         lin(f"gnn_layers.{g}.compress.0", d, (2 if g == 0 else 3) * d)

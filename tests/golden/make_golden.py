@@ -303,8 +303,46 @@ def main():
     pet_case("pet_default_box1000", hypers, [(p1k, z1k, c1k)], [torch.float32, torch.float64])
 
 
+def main_silu():
+    """``activation = "SiLU"`` variant (transformer.py:32-49): E, per-atom E and dE/dR of the reference
+    in fp32 / fp64 -> ``pet_silu_box64.npz``."""
+    from oracle import nl as onl
+    from oracle import pet as opet
+
+    PETBackend = import_reference_backend()
+    torch.set_num_threads(8)
+    hyp = dict(opet.DEFAULT_HYPERS, activation="SiLU")
+    p64, z64, c64 = opet.random_box(64, seed=1)
+    store = {}
+    for dtype in (torch.float32, torch.float64):
+        params = opet.synthetic_params(hyp, [1, 6, 7, 8], {"energy": 1}, 0, dtype)
+        be = PETBackend(hyp, [1, 6, 7, 8])
+        be.add_output("energy", {"energy": [1]})
+        be = be.to(dtype).eval()
+        be.load_state_dict(params, strict=True)
+        assert list(be.state_dict().keys()) == list(params.keys()), "schema order"
+        i, j, s, _ = onl.neighbor_list(p64.double().numpy(), c64.double().numpy(), [True] * 3, hyp["cutoff"])
+        args = (p64.to(dtype), c64.to(dtype)[None], torch.tensor(i), torch.tensor(j), torch.tensor(s).long(), z64,
+                torch.zeros(64, dtype=torch.long))
+        res, _ = run_reference(be, "energy", *args)
+        sfx = {torch.float32: "f32", torch.float64: "f64"}[dtype]
+        for k, v in res.items():
+            store[f"{k}_{sfx}"] = v
+        print("pet_silu_box64", sfx, "E =", res["energies"].ravel()[:4], "|grad|max =", np.abs(res["grad"]).max())
+    store["in_positions"] = args[0].double().numpy()
+    store["in_cells"] = args[1].double().numpy()
+    store["in_centers"] = args[2].numpy().astype(np.int32)
+    store["in_neighbors"] = args[3].numpy().astype(np.int32)
+    store["in_cell_shifts"] = args[4].numpy().astype(np.int32)
+    store["in_species"] = args[5].numpy().astype(np.int32)
+    store["in_system_indices"] = args[6].numpy()
+    np.savez_compressed(os.path.join(HERE, "pet_silu_box64.npz"), **store)
+
+
 if __name__ == "__main__":
-    if "--adaptive" in sys.argv:
+    if "--silu" in sys.argv:
+        main_silu()
+    elif "--adaptive" in sys.argv:
         main_adaptive()
     else:
         main()

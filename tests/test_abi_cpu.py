@@ -57,10 +57,12 @@ def test_model_create_destroy_without_gpu(lib):
 
 
 def test_variants_outside_the_build_fail_loudly():
-    for key, val in (("normalization", "LayerNorm"), ("activation", "SiLU"),
-                     ("transformer_type", "PostLN"), ("featurizer_type", "residual")):
+    for key, val in (("normalization", "LayerNorm"), ("transformer_type", "PostLN"), ("featurizer_type", "residual")):
         with pytest.raises(_lib.PetHipError):
             rt.hypers_struct(dict(opet.DEFAULT_HYPERS, **{key: val}), [1, 6])
+    rt.hypers_struct(dict(opet.DEFAULT_HYPERS, activation="SiLU"), [1, 6])  # built: SwiGLU kernels, tied halves
+    with pytest.raises(ValueError, match="Unknown activation flag"):  # transformer.py:342-346
+        rt.hypers_struct(dict(opet.DEFAULT_HYPERS, activation="GELU"), [1, 6])
     with pytest.raises(ValueError, match="Unknown cutoff function type"):
         rt.hypers_struct(dict(opet.DEFAULT_HYPERS, cutoff_function="Step"), [1, 6])
 

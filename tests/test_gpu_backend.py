@@ -140,16 +140,17 @@ def test_parameter_update_is_picked_up(dev):
     assert abs(run() - (e0 + 40.0)) < 1e-3
 
 
-def test_training_through_the_mirror_fills_parameter_grads(golden_dir):
+@pytest.mark.parametrize("activation", ["SwiGLU", "SiLU"])
+def test_training_through_the_mirror_fills_parameter_grads(golden_dir, activation):
     """pet/trainer.py:417-462 through the torch mirror: autograd.grad(E, R, create_graph=True), a loss on
     energies and dE/dR, loss.backward() -> parameter.grad; against torch's double backward through the fp64
-    oracle with the same weights."""
+    oracle with the same weights. With activation = "SiLU" the w_in gradients are those of the tied projection."""
     from metatrain_amd.pet import PETBackend, default_hypers
 
     dev = torch.device("cuda:0")
     g = dict(np.load(os.path.join(golden_dir, "batch_two_systems.npz")))
     t = lambda k: torch.tensor(g[k])  # noqa: E731
-    hypers = default_hypers()
+    hypers = dict(default_hypers(), activation=activation)
     types = [1, 6, 7, 8]
     params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
     be = PETBackend(hypers, types)

@@ -249,6 +249,29 @@ def test_ragged_tail_tiles_against_oracle(rt, model, dev, n_atoms, seed):
     assert relmax(grad.cpu().numpy(), gp.numpy()) < TOL
 
 
+def test_silu_activation_variant_against_reference_golden(rt, dev, golden_dir):
+    """SURVEY §8(f)-4, activation = "SiLU" (transformer.py:32-49): the state dict has the reference's shapes (one
+    projection, [d_ff, d]); energies and dE/dR against the reference's own fp64 output (make_golden.py --silu)."""
+    from metatrain_amd.pet import default_hypers
+
+    g = _load(golden_dir, "pet_silu_box64.npz")
+    hypers = dict(default_hypers(), activation="SiLU")
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
+    key = "gnn_layers.0.trans.layers.0.mlp.w_in.weight"
+    assert params[key].shape == (hypers["d_feedforward"], hypers["d_pet"])
+    m = rt.HipModel(hypers, [1, 6, 7, 8])
+    m.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    graph = _graph_from_golden(rt, m, g, dev)
+    fw = rt.HipForward(m, graph)
+    atomic = fw.forward()
+    grad = fw.backward(torch.ones_like(atomic))
+    assert relmax(atomic.cpu().numpy(), g["atomic_f64"].ravel()) < TOL
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
+    assert torch.equal(m.param(key).cpu(), params[key])  # the tie is invisible at the state-dict level
+    with pytest.raises(rt.PetHipError):
+        m.adam_step(1e-3, 1)
+
+
 def test_feature_and_last_layer_feature_outputs(rt, model, dev):
     """the "feature" and "mtt::aux::energy_last_layer_features" outputs (pet/model.py:730-875),
     per atom, against the fp64 oracle."""

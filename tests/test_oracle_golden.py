@@ -100,6 +100,20 @@ def test_oracle_default_box64(golden_dir, dtype, sfx, tol):
     assert np.abs(grad.numpy() - g[f"grad_{sfx}"]).max() / scale < tol
 
 
+@pytest.mark.parametrize("dtype,sfx,tol", [(torch.float64, "f64", 1e-10), (torch.float32, "f32", 1e-5)])
+def test_oracle_silu_activation_box64(golden_dir, dtype, sfx, tol):
+    """activation = "SiLU" (transformer.py:32-49) against the reference's own output (make_golden.py --silu)."""
+    g = _load(golden_dir, "pet_silu_box64.npz")
+    hypers = dict(opet.DEFAULT_HYPERS, activation="SiLU")
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, dtype)
+    assert params["gnn_layers.0.trans.layers.0.mlp.w_in.weight"].shape == (hypers["d_feedforward"], hypers["d_pet"])
+    e, grad, atomic = _run_oracle(g, hypers, params, dtype)
+    np.testing.assert_allclose(e.numpy(), g[f"energies_{sfx}"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(atomic.detach().numpy(), g[f"atomic_{sfx}"], rtol=tol, atol=10 * tol)
+    scale = np.abs(g[f"grad_{sfx}"]).max()
+    assert np.abs(grad.numpy() - g[f"grad_{sfx}"]).max() / scale < tol
+
+
 def test_nl_oracle_tree_vs_bruteforce():
     """The two statements of the NL contract agree (sorted (i,j,S) sets), including
     self-images in a cell smaller than the cutoff and a triclinic cell."""
