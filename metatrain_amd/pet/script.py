@@ -52,7 +52,10 @@ def make_core(hypers: dict, atomic_types: List[int], state_dict: Dict[str, torch
                     continue
                 parts[3] = "@"
         keys.append(".".join(parts))
-        tensors.append(t.detach().cpu().contiguous())
+        t = t.detach().cpu()
+        if hypers["activation"] == "SiLU" and ".w_in." in key:
+            t = torch.cat([t, t], dim=0)  # silu(W x + b) on the SwiGLU stage: value half = gate half (runtime.py)
+        tensors.append(t.contiguous())
     return torch.classes.pet_hip.PetHipModule(numbers, [int(z) for z in atomic_types], keys, tensors)
 
 

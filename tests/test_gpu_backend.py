@@ -196,7 +196,8 @@ def test_training_through_the_mirror_fills_parameter_grads(golden_dir, activatio
     assert worst < 1e-5, worst
 
 
-def test_torchscript_module_energy_and_forces(golden_dir):
+@pytest.mark.parametrize("activation,fixture", [("SwiGLU", "pet_default_box64.npz"), ("SiLU", "pet_silu_box64.npz")])
+def test_torchscript_module_energy_and_forces(golden_dir, activation, fixture):
     """the TorchScript custom class (csrc/torch_ops.cpp), scripted, saved, re-loaded, then run:
     energies and forces (autograd inside TorchScript) against the golden fp64 reference values."""
     import io
@@ -204,14 +205,14 @@ def test_torchscript_module_energy_and_forces(golden_dir):
     from metatrain_amd.pet import default_hypers, script
 
     dev = torch.device("cuda:0")
-    hypers = default_hypers()
+    hypers = dict(default_hypers(), activation=activation)
     params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
     core = script.make_core(hypers, [1, 6, 7, 8], params, "energy")
     buf = io.BytesIO()
     torch.jit.save(torch.jit.script(script.EnergyAndForces(core)), buf)
     buf.seek(0)
     mod = torch.jit.load(buf)
-    g = dict(np.load(os.path.join(golden_dir, "pet_default_box64.npz")))
+    g = dict(np.load(os.path.join(golden_dir, fixture)))
     t = lambda k: torch.tensor(g[k]).to(dev)  # noqa: E731
     energies, forces = mod(t("in_positions").float(), t("in_cells").float(), t("in_centers"), t("in_neighbors"),
                            t("in_cell_shifts"), t("in_species"), t("in_system_indices"))
