@@ -146,6 +146,14 @@ def main():
                          "algorithmic_bytes_per_launch": dominant["bytes"], "traffic": None,
                          "stages_ms": {r["name"]: round(r["total_ms"], 3) for r in table}},
         }
+        if dominant["name"] in ("soap_expand", "soap_expand_bwd"):
+            # the descriptor kernels are VALU work (spherical-harmonic recurrences per pair, fp64 adjoint accumulators,
+            # no matrix product): neither the HBM nor the MFMA roof describes them; the HBM figure is kept as the
+            # lower of the two fractions, the stage that IS an HBM stream is soap_tail (feature matrix read once)
+            tail = [r for r in table if r["name"] == "soap_tail"]
+            out["roofline"]["note"] = "VALU-bound stage (no matrix product); HBM-streaming stage for comparison: soap_tail"
+            if tail:
+                out["roofline"]["soap_tail_hbm_frac"] = tail[0]["bytes"] / (tail[0]["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(hypers)
         print(json.dumps(out), flush=True)

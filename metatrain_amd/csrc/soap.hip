@@ -954,10 +954,18 @@ __global__ void k_sp_scan(int n_sets, SpInfo* __restrict__ info) {
 }
 __global__ void k_sp_fill(const int* __restrict__ sp, int legacy, int N, SpInfo* __restrict__ info,
                           int* __restrict__ perm) {
+    // one atomic per (wave, network) instead of one per atom: 100 k atoms on 4 cursors serialised in L2 (0.63 ms)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const int s = legacy ? sp[i] : 0;
-    perm[info->offs[s] + atomicAdd(&info->cursor[s], 1)] = i;
+    const int lane = threadIdx.x & 63;
+    const int s = i < N ? (legacy ? sp[i] : 0) : -1;
+    for (int t = 0; t < SP_MAXSETS; t++) {
+        const unsigned long long m = __ballot(s == t);
+        if (m == 0) continue;
+        int base = 0;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&info->cursor[t], __popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (s == t) perm[info->offs[t] + base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    }
 }
 // tile -> (network, first slot in perm, number of atoms); false if the tile index is past the last bucket
 __device__ __forceinline__ bool sp_tile(const SpInfo* __restrict__ info, int n_sets, int t, int& s, int& base, int& cnt) {
