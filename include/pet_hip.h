@@ -252,6 +252,7 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *   "f16x3"       1 = 2-way fp16 split, three MFMAs per K block (default); 0 = 3-way bf16 split, six MFMAs
  *   "tile_f16x3"  1 = the LDS-tile forward kernels (compress, centre, node update, heads) and the head adjoint on f16x3
  *                 (default); 0 = fp32 MFMA. "tile_mask" (debug): bits switch single GEMMs of those kernels back.
+ *   "so_trr"       1 = generic training GEMMs with K = 128 or n_out = 128 as TRR kernels (default); 0 = LDS-tile k_gemm_h
  *   "emlp_recompute" 1 = the inference adjoint of the edge MLP rebuilds the SwiGLU pre-activations instead of reading
  *                 them back (less workspace traffic, slower adjoint); default 0
  *   "trr_compress" bit mask of f16x3 TRR kernels replacing LDS-tile ones: 1 compress (+adjoint), 2 edge head (+adjoint),

@@ -129,6 +129,7 @@ bool use_trr();
 void set_use_trr(int v);
 void set_side_stream(int v);
 void set_so_bf16x6(int v);  // so.hip: 1 = generic training GEMMs on the bf16 matrix cores (default)
+void set_so_trr(int v);     // so.hip: 1 = K = 128 / n_out = 128 generic GEMMs as TRR kernels (default)
 void set_bf16x6(int v);     // pet_trr.hip: 1 = GEMM stages on the bf16 matrix cores with 3-way split operands
 void set_attn_lds(int v);   // pet_attn.hip: 1 = LDS-staged attention (default), 0 = wave-per-head from global
 void set_soap_mfma(int v);  // soap.hip: 1 = MFMA tail (default), 0 = per-atom tail kernels

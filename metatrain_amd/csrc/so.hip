@@ -264,6 +264,171 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_h(const float* __restrict__ X
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// TRR forms (trr.h: one wave = 32 rows, no LDS, no barrier) of the generic f16x3 GEMM for the two shape families that
+// make up most of the second-order pass: K = 128 with any n_out (a multiple of 64), and n_out = 128 with any K (a
+// multiple of 128). Same products and the same power-of-two row scaling as k_gemm_h (one scale per row and per 128-wide
+// K slice; with several slices a running scale that only shrinks, applied with selects, as in k_qkv_bwd_h).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_rowgemm_k128(const float* __restrict__ X, int ldx,
+                                                         const float* __restrict__ cs, W2 w,
+                                                         const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+                                                         int n_out, int64_t R, int accumulate) {
+    const RowLane L;
+    const int64_t row0 = wave_row0();
+    if (row0 >= R) return;
+    const bool valid = row0 + L.r < R;
+    const int64_t row = valid ? row0 + L.r : R - 1;
+    Split2<8> xs;
+    float inv;
+    {
+        float4 x[16];
+        load_rowfrag<16>(x, X, row, ldx, L.h);
+        if (cs) {
+#pragma unroll
+            for (int kg = 0; kg < 16; kg++) {
+                const float4 c4 = *reinterpret_cast<const float4*>(cs + 8 * kg + 4 * L.h);
+                x[kg].x *= c4.x; x[kg].y *= c4.y; x[kg].z *= c4.z; x[kg].w *= c4.w;
+            }
+        }
+        float sc;
+        inv = row_scale_pow2<16>(x, sc);
+        split_frag2<8>(x, xs);
+    }
+    const int nc = n_out / 64;  // 64-wide column groups = pairs of 32-wide weight tiles
+    auto widx = [&](int b) { return ((size_t)(2 * (b >> 3)) * 8 + (b & 7)) * 64 + L.lane; };
+    WBlk2<2> ring[2];
+#pragma unroll
+    for (int b = 0; b < 2; b++) ld_blk2<2>(ring[b], w, widx(b), 8 * 64);
+#pragma unroll 1
+    for (int c = 0; c < nc; c++) {
+        f32x16 acc[2], acl[2];
+        acc_zero<2>(acc);
+        acc_zero<2>(acl);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            WBlk2<2>& wb = ring[kb & 1];
+            mfma3<2>(acc, acl, wb, xs.h[kb], xs.l[kb]);
+            int nb = 8 * c + kb + 2;
+            nb = nb < 8 * nc ? nb : 8 * nc - 1;  // past the end: a harmless reload of the last block
+            ld_blk2<2>(wb, w, widx(nb), 8 * 64);
+        }
+        fold_low<2>(acc, acl);
+        acc_scale<2>(acc, inv);
+        float4 y[8];
+        acc_to_frag<2>(acc, y);
+        if (bias) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bias + 64 * c + 8 * k + 4 * L.h);
+                y[k].x += b4.x; y[k].y += b4.y; y[k].z += b4.z; y[k].w += b4.w;
+            }
+        }
+        if (accumulate) {
+            float4 old[8];
+            load_rowfrag<8>(old, Y + 64 * c, row, ldy, L.h);
+#pragma unroll
+            for (int k = 0; k < 8; k++) { y[k].x += old[k].x; y[k].y += old[k].y; y[k].z += old[k].z; y[k].w += old[k].w; }
+        }
+        if (valid) store_rowfrag<8>(y, Y + 64 * c, row, ldy, L.h);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rowgemm_n128(const float* __restrict__ X, int ldx, int K,
+                                                      const float* __restrict__ cs, W2 w,
+                                                      const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+                                                      int64_t R, int accumulate) {
+    const RowLane L;
+    const int64_t row0 = wave_row0();
+    if (row0 >= R) return;
+    const bool valid = row0 + L.r < R;
+    const int64_t row = valid ? row0 + L.r : R - 1;
+    const int kbt = K / 16, nks = K / 128;
+    const size_t ts = (size_t)kbt * 64;  // tile stride: 32 output columns
+    auto widx = [&](int b) { return (size_t)b * 64 + L.lane; };
+    WBlk2<4> ring[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) ld_blk2<4>(ring[b], w, widx(b), ts);
+    f32x16 dn[4], dnl[4];
+    acc_zero<4>(dn);
+    acc_zero<4>(dnl);
+    float4 d[16];
+    load_rowfrag<16>(d, X, row, ldx, L.h);
+    float scale = 0.f, inv = 0.f;  // scale applied to what the accumulators hold, and its inverse
+#pragma unroll 1
+    for (int ks = 0; ks < nks; ks++) {
+        Split2<8> xs;
+        {
+            if (cs) {
+#pragma unroll
+                for (int kg = 0; kg < 16; kg++) {
+                    const float4 c4 = *reinterpret_cast<const float4*>(cs + 128 * ks + 8 * kg + 4 * L.h);
+                    d[kg].x *= c4.x; d[kg].y *= c4.y; d[kg].z *= c4.z; d[kg].w *= c4.w;
+                }
+            }
+            float sc;
+            const float iv = row_pow2<16>(d, sc);
+            const bool shrink = ks == 0 || sc < scale;
+            const float sc_eff = shrink ? sc : scale;
+            if (ks > 0) {
+                const float f = sc_eff * inv;  // 1 unless this slice is larger than everything before it
+                acc_scale<4>(dn, f);
+                acc_scale<4>(dnl, f);
+            }
+            scale = sc_eff;
+            inv = shrink ? iv : inv;
+#pragma unroll
+            for (int kg = 0; kg < 16; kg++) { d[kg].x *= sc_eff; d[kg].y *= sc_eff; d[kg].z *= sc_eff; d[kg].w *= sc_eff; }
+            split_frag2<8>(d, xs);
+        }
+        if (ks + 1 < nks) load_rowfrag<16>(d, X + 128 * (ks + 1), row, ldx, L.h);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            WBlk2<4>& wb = ring[kb & 3];
+            mfma3<4>(dn, dnl, wb, xs.h[kb], xs.l[kb]);
+            int nb = 8 * ks + kb + 4;
+            nb = nb < kbt ? nb : kbt - 1;
+            ld_blk2<4>(wb, w, widx(nb), ts);
+        }
+    }
+    fold_low<4>(dn, dnl);
+    acc_scale<4>(dn, inv);
+    float4 y[16];
+    acc_to_frag<4>(dn, y);
+    if (bias) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + 8 * k + 4 * L.h);
+            y[k].x += b4.x; y[k].y += b4.y; y[k].z += b4.z; y[k].w += b4.w;
+        }
+    }
+    if (accumulate) {
+        float4 old[16];
+        load_rowfrag<16>(old, Y, row, ldy, L.h);
+#pragma unroll
+        for (int k = 0; k < 16; k++) { y[k].x += old[k].x; y[k].y += old[k].y; y[k].z += old[k].z; y[k].w += old[k].w; }
+    }
+    if (valid) store_rowfrag<16>(y, Y, row, ldy, L.h);
+}
+
+static int g_so_trr = 1;  // pet_config_set("so_trr", 0): every generic GEMM through the LDS-tile k_gemm_h
+void set_so_trr(int v) { g_so_trr = v ? 1 : 0; }
+// Y[R, n_out] (=|+=) (X[R, K] * cs) W^T + bias on the TRR kernels when the shape allows; false otherwise
+static bool rowgemm_trr(hipStream_t st, const float* X, int K, const float* cs, W2 w, const float* bias, float* Y,
+                        int n_out, int64_t R, bool acc) {
+    if (!g_so_trr) return false;
+    const int grid = (int)cdiv(R, WG_ROWS);
+    if (K == 128 && n_out % 64 == 0) {
+        k_rowgemm_k128<<<grid, 256, 0, st>>>(X, K, cs, w, bias, Y, n_out, n_out, R, acc ? 1 : 0);
+        return true;
+    }
+    if (n_out == 128 && K % 128 == 0) {
+        k_rowgemm_n128<<<grid, 256, 0, st>>>(X, K, K, cs, w, bias, Y, n_out, R, acc ? 1 : 0);
+        return true;
+    }
+    return false;
+}
+
 static int g_so_bf16x6 = 1;  // pet_config_set("so_bf16x6", 0): generic training GEMMs on the fp32 MFMA
 void set_so_bf16x6(int v) { g_so_bf16x6 = v ? 1 : 0; }
 static inline W2 w2_at(const void* base, int n_out, int k_in) {
@@ -290,7 +455,9 @@ static void mm_fwd(const Ctx& c, const Lin& L, const float* X, float* Y, int64_t
                    bool acc = false) {
     if (R <= 0) return;
     ProfScope ps("so_gemm", c.st, 2.0 * (double)R * L.k_in * L.n_out, 4.0 * (double)R * (L.k_in + L.n_out));
-    if (g_so_bf16x6 && use_f16x3() && L.fwd2)
+    if (g_so_bf16x6 && use_f16x3() && L.fwd2 &&
+        rowgemm_trr(c.st, X, L.k_in, cs, w2_at(L.fwd2, L.n_out, L.k_in), bias ? L.b : nullptr, Y, L.n_out, R, acc)) {
+    } else if (g_so_bf16x6 && use_f16x3() && L.fwd2)
         k_gemm_h<<<cdiv(R, BM), NTHREADS, 2 * BM * LDB16 * 2 + BM * 4, c.st>>>(X, L.k_in, L.k_in, cs,
                                                                                w2_at(L.fwd2, L.n_out, L.k_in),
                                                                                bias ? L.b : nullptr, Y, L.n_out, L.n_out, R,
@@ -307,7 +474,9 @@ static void mm_fwd(const Ctx& c, const Lin& L, const float* X, float* Y, int64_t
 static void mm_bwd(const Ctx& c, const Lin& L, const float* Yadj, float* Xadj, int64_t R, bool acc = false) {
     if (R <= 0) return;
     ProfScope ps("so_gemm", c.st, 2.0 * (double)R * L.k_in * L.n_out, 4.0 * (double)R * (L.k_in + L.n_out));
-    if (g_so_bf16x6 && use_f16x3() && L.bwd2)  // the transposed operand: tiles over k_in, K = n_out
+    if (g_so_bf16x6 && use_f16x3() && L.bwd2 &&
+        rowgemm_trr(c.st, Yadj, L.n_out, nullptr, w2_at(L.bwd2, L.k_in, L.n_out), nullptr, Xadj, L.k_in, R, acc)) {
+    } else if (g_so_bf16x6 && use_f16x3() && L.bwd2)  // the transposed operand: tiles over k_in, K = n_out
         k_gemm_h<<<cdiv(R, BM), NTHREADS, 2 * BM * LDB16 * 2 + BM * 4, c.st>>>(Yadj, L.n_out, L.n_out, nullptr,
                                                                                w2_at(L.bwd2, L.k_in, L.n_out), nullptr, Xadj,
                                                                                L.k_in, L.k_in, R, acc ? 1 : 0);
