@@ -266,8 +266,8 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_h(const float* __restrict__ X
 
 // ---------------------------------------------------------------------------------------------
 // TRR forms (trr.h: one wave = 32 rows, no LDS, no barrier) of the generic f16x3 GEMM for the two shape families that
-// make up most of the second-order pass: K = 128 with any n_out (a multiple of 64), and n_out = 128 with any K (a
-// multiple of 128). Same products and the same power-of-two row scaling as k_gemm_h (one scale per row and per 128-wide
+// make up most of the second-order pass: K = 128 with any n_out (a multiple of 64), and 128 output columns with any K (a
+// multiple of 128; wider outputs take one launch per 128 columns). Same products and the same power-of-two row scaling as k_gemm_h (one scale per row and per 128-wide
 // K slice; with several slices a running scale that only shrinks, applied with selects, as in k_qkv_bwd_h).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_rowgemm_k128(const float* __restrict__ X, int ldx,
@@ -422,8 +422,13 @@ static bool rowgemm_trr(hipStream_t st, const float* X, int K, const float* cs, 
         k_rowgemm_k128<<<grid, 256, 0, st>>>(X, K, cs, w, bias, Y, n_out, n_out, R, acc ? 1 : 0);
         return true;
     }
-    if (n_out == 128 && K % 128 == 0) {
-        k_rowgemm_n128<<<grid, 256, 0, st>>>(X, K, K, cs, w, bias, Y, n_out, R, acc ? 1 : 0);
+    if (n_out % 128 == 0 && K % 128 == 0) {  // 128 output columns per launch (k_gemm_h re-stages X per column block too)
+        const size_t ts4 = (size_t)4 * (K / 16) * 64;  // four 32-column weight tiles
+        for (int nb = 0; nb < n_out / 128; nb++) {
+            W2 wn; wn.h = w.h + nb * ts4; wn.l = w.l + nb * ts4;
+            k_rowgemm_n128<<<grid, 256, 0, st>>>(X, K, K, cs, wn, bias ? bias + 128 * nb : nullptr, Y + 128 * nb, n_out, R,
+                                                 acc ? 1 : 0);
+        }
         return true;
     }
     return false;
