@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QK
             for (int kt = 0; kt < NT; kt++)
                 if (kt < nt)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { const float p = expf(s[kt][r] - mx); s[kt][r] = p; sum += p; }
+                    for (int r = 0; r < 4; r++) { const float p = __builtin_amdgcn_exp2f(LOG2E * (s[kt][r] - mx)); s[kt][r] = p; sum += p; }
             sum = g4_sum(sum);
             const float inv = 1.0f / sum;
             float dl = 0.f;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QK
                         const int qq = 16 * qt + 4 * g4 + r;
                         const float l = lr[r];
                         const float dl = dr[r];
-                        float p = expf(a[r] + bias_c[kt] - l);
+                        float p = __builtin_amdgcn_exp2f(LOG2E * (a[r] + bias_c[kt] - l));
                         if (qq >= T) p = 0.f;
                         const float ds = p * (b[r] - dl);
                         dvv = MFMA16(dos[qt][r], p, dvv);
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_attn_jvp_p(const float* __restrict__ QK
                 if (kt < nt)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const float p = expf(s[kt][r] - mx);
+                        const float p = __builtin_amdgcn_exp2f(LOG2E * (s[kt][r] - mx));
                         s[kt][r] = p;
                         sum += p;
                         an += p * sd[kt][r];
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_attn_rev_p(const float* __restrict__ QK
             for (int kt = 0; kt < NT; kt++)
                 if (kt < nt)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { const float p = expf(s[kt][r] - mx); s[kt][r] = p; sum += p; }
+                    for (int r = 0; r < 4; r++) { const float p = __builtin_amdgcn_exp2f(LOG2E * (s[kt][r] - mx)); s[kt][r] = p; sum += p; }
             sum = g4_sum(sum);
             const float inv = 1.0f / sum;
             float de = 0.f, av = 0.f, cv = 0.f, ev = 0.f;
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void k_attn_rev_p(const float* __restrict__ QK
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int qq = 16 * qt + 4 * g4 + r;
-                        float p = expf(a[r] + bias_c[kt] - lse[r]);
+                        float p = __builtin_amdgcn_exp2f(LOG2E * (a[r] + bias_c[kt] - lse[r]));
                         if (qq >= T) p = 0.f;
                         const float sdv = c[r] + biasd_c[kt];
                         const float ls = p * (b[r] - der[r]);
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd_l(const float* __restrict__ QK
             for (int kt = 0; kt < NT; kt++)
                 if (kt < nt)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { const float p = expf(s[kt][r] - mx); s[kt][r] = p; sum += p; }
+                    for (int r = 0; r < 4; r++) { const float p = __builtin_amdgcn_exp2f(LOG2E * (s[kt][r] - mx)); s[kt][r] = p; sum += p; }
             sum = g4_sum(sum);
             const float inv = 1.0f / sum;
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
