@@ -107,8 +107,14 @@ int64_t pet_graph_workspace_bytes(int64_t n_nodes, int64_t n_edges_in);
  * (pet/modules/structures.py:115-131): d_positions [N,3], d_cells [S,3,3],
  * d_centers/d_neighbors [E] int32 (global atom indices), d_cell_shifts [E,3] int32,
  * d_species [N] int32 atomic numbers, d_system_indices [N] int32.
- * One device->host read-back of two integers (kept edges, max neighbours) happens
- * here, like the reference's int(torch.max(num_neighbors)) (structures.py:292). */
+ * ONE device->host read-back (kept edges, max neighbours, validation counters) happens
+ * here, like the reference's int(torch.max(num_neighbors)) (structures.py:292); nothing
+ * downstream (forward, reverse passes) synchronises with the host.
+ * Errors: PET_ERR_GRAPH if a kept edge (i, j, S) has no partner (j, i, -S) -- every consumer
+ * gathers through the ij->ji map, the reference's get_corresponding_edges (nef.py:88-166)
+ * has the same precondition; PET_ERR_ARGUMENT for indices outside [0, N), atomic numbers
+ * outside the model's atomic_types, or system_indices that are not non-decreasing runs
+ * inside [0, n_systems). */
 int pet_graph_build(const pet_model_t* m, const float* d_positions, const float* d_cells,
                     const int32_t* d_centers, const int32_t* d_neighbors,
                     const int32_t* d_cell_shifts, const int32_t* d_species,

@@ -355,9 +355,11 @@ int pet_model_set_param(pet_model_t* pm, const char* key, const void* d_data, in
     hipStream_t st = (hipStream_t)stream;
     std::string k(key);
     if (k == "species_to_species_index") {
-        int* p;
-        int rc = dev_alloc(m, (void**)&p, numel * sizeof(int));
-        if (rc) return rc;
+        int* p = m.species_table;
+        if (!p || m.species_table_len != (int)numel) {  // re-uploads (one per optimizer step through the mirror) reuse it
+            int rc = dev_alloc(m, (void**)&p, numel * sizeof(int));
+            if (rc) return rc;
+        }
         k_i64_to_i32<<<cdiv(numel, 256), 256, 0, st>>>((const int64_t*)d_data, p, (int)numel);
         PET_HIP_CHECK(hipGetLastError());
         m.species_table = p;
@@ -369,12 +371,15 @@ int pet_model_set_param(pet_model_t* pm, const char* key, const void* d_data, in
     if (it != m.raw.end() && it->second.second == numel) {
         p = it->second.first;  // overwrite in place (weights updated by an optimizer step)
     } else {
+        // the flat gradient / Adam buffers and their segment table are laid out by upload order and size: a parameter
+        // cannot change its size once it has a slot
+        PET_REQUIRE(it == m.raw.end(), PET_ERR_ARGUMENT,
+                    "parameter '" + k + "' was uploaded with " + std::to_string(it->second.second) +
+                        " elements before and cannot be re-set with " + std::to_string(numel) + ": create a new model");
         int rc = dev_alloc(m, (void**)&p, numel * sizeof(float));
         if (rc) return rc;
-        if (it == m.raw.end()) {
-            m.grad_off[k] = m.n_params;
-            m.n_params += numel;
-        }
+        m.grad_off[k] = m.n_params;
+        m.n_params += numel;
         m.raw[k] = {p, numel};
     }
     PET_HIP_CHECK(hipMemcpyAsync(p, d_data, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -515,10 +520,6 @@ int pet_graph_export_batch(const pet_graph_t* pg, int64_t* el_nodes, int64_t* el
                            uint8_t* mask, int64_t* rni, float* cf, float* stats, int64_t* centers,
                            int64_t* neighbors, int64_t* slot, int64_t* shifts, void* stream) {
     PET_REQUIRE(pg, PET_ERR_ARGUMENT, "null graph");
-    if (rni) {
-        int rc = graph_check_reverse(const_cast<Graph&>(pg->g), (hipStream_t)stream);
-        if (rc) return rc;
-    }
     return graph_export(pg->g, pg->cutoff, el_nodes, el_nbr, ev, ed, mask, rni, cf, stats, centers, neighbors,
                         slot, shifts, (hipStream_t)stream);
 }

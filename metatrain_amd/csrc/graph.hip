@@ -136,9 +136,18 @@ __global__ void k_gather_all(const int* __restrict__ perm0, const int* __restric
 // kernels
 // ----------------------------------------------------------------------------------
 __global__ void k_species_index(const int* __restrict__ species, const int* __restrict__ table,
-                                int table_len, int* __restrict__ sp, int n, int* __restrict__ n_unknown) {
+                                int table_len, int* __restrict__ sp, int n, int* __restrict__ n_unknown,
+                                const int* __restrict__ sys_in, int* __restrict__ sys_out, int n_systems,
+                                int* __restrict__ n_bad_sys) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    {   // system_indices must be non-decreasing runs inside [0, n_systems) (concatenate_structures, structures.py:87-91):
+        // the per-system sums and the cell lookup rely on it. Violations are reported by the host; the stored index
+        // is clamped so that the kernels stay in bounds.
+        const int sy = sys_in[i];
+        if (sy < 0 || sy >= n_systems || (i > 0 && sys_in[i - 1] > sy)) atomicAdd(n_bad_sys, 1);
+        sys_out[i] = min(max(sy, 0), n_systems - 1);
+    }
     int z = species[i];
     int s = (z >= 0 && z < table_len) ? table[z] : -1;
     if (s < 0) {  // not one of the model's atomic_types: reported by the host, index 0 keeps the kernels in bounds
@@ -209,11 +218,12 @@ __global__ void k_csr_fill(const int* __restrict__ perm, const float4* __restric
                            const int* __restrict__ shifts, const int* __restrict__ sp,
                            int* __restrict__ ctr, int* __restrict__ nbr, int* __restrict__ shift,
                            int* __restrict__ sp_nbr, float4* __restrict__ geo,
-                           float* __restrict__ d0, float* __restrict__ fc, int n_kept,
+                           float* __restrict__ d0, float* __restrict__ fc, const int* __restrict__ n_kept_dev,
                            float cutoff, float width, int fn, const float* __restrict__ r_atom,
                            float* __restrict__ pc) {
+    // launched over all input edges: the kept count stays on the device until the single read-back of graph_build
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_kept) return;
+    if (p >= *n_kept_dev) return;
     int e = perm[p];
     float4 v = vin[e];
     int j = neighbors[e];
@@ -237,9 +247,9 @@ __global__ void k_csr_fill(const int* __restrict__ perm, const float4* __restric
 // nef.py:88-166 restated as a search in row j (rows hold <= a few dozen edges)
 __global__ void k_reverse(const int* __restrict__ rowptr, const int* __restrict__ ctr,
                           const int* __restrict__ nbr, const int* __restrict__ shift,
-                          int* __restrict__ rev, int n_kept, int* __restrict__ scalars) {
+                          int* __restrict__ rev, int* __restrict__ scalars) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_kept) return;
+    if (p >= scalars[0]) return;
     int i = ctr[p], j = nbr[p];
     int sa = -shift[3 * p], sb = -shift[3 * p + 1], sc = -shift[3 * p + 2];
     int found = -1;
@@ -249,7 +259,9 @@ __global__ void k_reverse(const int* __restrict__ rowptr, const int* __restrict_
             break;
         }
     }
-    rev[p] = found;
+    // an edge without its (j, i, -S) partner makes graph_build fail (PET_ERR_GRAPH); pointing it at itself keeps every
+    // later gather in bounds whatever the caller does with the error
+    rev[p] = found < 0 ? p : found;
     if (found < 0) atomicAdd(&scalars[2], 1);
 }
 
@@ -336,24 +348,37 @@ __global__ void k_export_edges(const int* __restrict__ perm, const int* __restri
 
 // CSR position of kept edge 0 (the edge every NEF pad aliases)
 __global__ void k_find_pad_src(const int* __restrict__ perm, const int* __restrict__ kidx,
-                               const int* __restrict__ keep, int n_kept, int* __restrict__ out) {
+                               const int* __restrict__ keep, const int* __restrict__ n_kept_dev,
+                               int* __restrict__ out) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_kept) return;
+    if (p >= *n_kept_dev) return;
     int e = perm[p];
     if (keep[e] && kidx[e] == 0) *out = p;
 }
 
-__global__ void k_sum_over_atoms(const float* __restrict__ atomic, const int* __restrict__ sys,
-                                 float* __restrict__ out, int n) {
-    // systems are contiguous runs of atoms (concatenate_structures, structures.py:87-91);
-    // one thread per system start does a serial, deterministic sum.
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int s = sys[i];
-    if (i > 0 && sys[i - 1] == s) return;
-    float acc = 0.0f;
-    for (int k = i; k < n && sys[k] == s; k++) acc += atomic[k];
-    out[s] = acc;
+__global__ __launch_bounds__(256) void k_sum_over_atoms(const float* __restrict__ atomic, const int* __restrict__ sys,
+                                                        float* __restrict__ out, int n) {
+    // One workgroup per system. system_indices is non-decreasing (validated by graph_build), so the atoms of system s
+    // are the run [lower_bound(s), lower_bound(s + 1)); strided fp64 partial sums and a fixed-order LDS tree make the
+    // result deterministic and independent of the run length (a 10 k-atom box is 40 coalesced loads per lane, not
+    // 10 k dependent ones).
+    __shared__ double red[256];
+    const int s = blockIdx.x;
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (sys[mid] < s) lo = mid + 1; else hi = mid; }
+    const int begin = lo;
+    hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (sys[mid] < s + 1) lo = mid + 1; else hi = mid; }
+    const int end = lo;
+    double acc = 0.0;
+    for (int k = begin + threadIdx.x; k < end; k += 256) acc += (double)atomic[k];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[s] = (float)red[0];
 }
 
 // ----------------------------------------------------------------------------------
@@ -436,8 +461,8 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
     PET_HIP_CHECK(hipMemsetAsync(g.scalars, 0, 8 * sizeof(int), st));
     if (n_nodes > 0) {
         k_species_index<<<cdiv(n_nodes, T), T, 0, st>>>(species, m.species_table, m.species_table_len,
-                                                        g.sp, (int)n_nodes, g.scalars + 5);
-        PET_HIP_CHECK(hipMemcpyAsync(g.sys, sys, n_nodes * sizeof(int), hipMemcpyDeviceToDevice, st));
+                                                        g.sp, (int)n_nodes, g.scalars + 5, sys, g.sys,
+                                                        (int)(n_systems > 0 ? n_systems : 1), g.scalars + 7);
     }
     g.adaptive = m.h.num_neighbors_adaptive > 0.f;
     if (e0 > 0) {
@@ -472,6 +497,16 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
     k_rowptr<<<cdiv(n_nodes + 1, T), T, 0, st>>>(g.sort_keys_out, (int)e0, g.rowptr, (int)n_nodes,
                                                  g.scalars);
     if (n_nodes > 0) k_max_nbr<<<cdiv(n_nodes, T), T, 0, st>>>(g.rowptr, (int)n_nodes, g.scalars);
+    if (e0 > 0) {
+        // sized by the input edge count; the kernels read the kept count from the device (scalars[0]), so the whole
+        // build needs ONE device -> host read-back (below), like the reference's int(torch.max(num_neighbors))
+        k_csr_fill<<<cdiv(e0, T), T, 0, st>>>(g.perm, g.vin, centers, neighbors, shifts, g.sp, g.ctr,
+                                              g.nbr, g.shift, g.sp_nbr, g.geo, g.d0, g.fc, g.scalars,
+                                              m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function,
+                                              g.adaptive ? g.r_atom : nullptr, g.pc);
+        k_reverse<<<cdiv(e0, T), T, 0, st>>>(g.rowptr, g.ctr, g.nbr, g.shift, g.rev, g.scalars);
+        k_find_pad_src<<<cdiv(e0, T), T, 0, st>>>(g.perm, g.kidx, g.keep, g.scalars, g.scalars + 3);
+    }
     int host_scalars[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     PET_HIP_CHECK(hipStreamSynchronize(st));
@@ -481,15 +516,13 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
                 std::to_string(host_scalars[6]) + " neighbour-list entries index atoms outside [0, n_nodes)");
     PET_REQUIRE(host_scalars[5] == 0, PET_ERR_ARGUMENT,
                 std::to_string(host_scalars[5]) + " atom(s) have an atomic number that is not in the model's atomic_types");
-    if (g.n_edges > 0) {
-        int ne = (int)g.n_edges;
-        k_csr_fill<<<cdiv(ne, T), T, 0, st>>>(g.perm, g.vin, centers, neighbors, shifts, g.sp, g.ctr,
-                                              g.nbr, g.shift, g.sp_nbr, g.geo, g.d0, g.fc, ne,
-                                              m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function,
-                                              g.adaptive ? g.r_atom : nullptr, g.pc);
-        k_reverse<<<cdiv(ne, T), T, 0, st>>>(g.rowptr, g.ctr, g.nbr, g.shift, g.rev, ne, g.scalars);
-        k_find_pad_src<<<cdiv(ne, T), T, 0, st>>>(g.perm, g.kidx, g.keep, ne, g.scalars + 3);
-    }
+    PET_REQUIRE(host_scalars[7] == 0, PET_ERR_ARGUMENT,
+                std::to_string(host_scalars[7]) + " entries of system_indices are outside [0, n_systems) or decreasing");
+    // every consumer (the ji gather of the forward pass included) needs the (j, i, -S) partner of every kept edge: the
+    // reference's get_corresponding_edges (nef.py:88-166) has the same precondition
+    PET_REQUIRE(host_scalars[2] == 0, PET_ERR_GRAPH,
+                "neighbour list is not a full list: " + std::to_string(host_scalars[2]) +
+                    " kept edges have no reverse edge (j, i, -S)");
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }
@@ -528,8 +561,8 @@ int graph_export(const Graph& g, float cutoff, int64_t* el_nodes, int64_t* el_nb
 }
 
 int sum_over_atoms(const Graph& g, const float* atomic, float* out, hipStream_t st) {
-    if (g.n_nodes > 0)
-        k_sum_over_atoms<<<cdiv(g.n_nodes, 256), 256, 0, st>>>(atomic, g.sys, out, (int)g.n_nodes);
+    if (g.n_systems > 0)  // systems without atoms get 0
+        k_sum_over_atoms<<<(int)g.n_systems, 256, 0, st>>>(atomic, g.sys, out, (int)g.n_nodes);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }

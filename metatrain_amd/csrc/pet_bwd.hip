@@ -838,14 +838,8 @@ static inline WX wx_b(const Lin& L) {
     return w;
 }
 
-static int check_full_list(const Graph& g, hipStream_t st) {
-    int bad = 0;
-    PET_HIP_CHECK(hipMemcpyAsync(&bad, g.scalars + 2, sizeof(int), hipMemcpyDeviceToHost, st));
-    PET_HIP_CHECK(hipStreamSynchronize(st));
-    PET_REQUIRE(bad == 0, PET_ERR_GRAPH, "neighbour list is not a full list: edges without a reverse edge");
-    return PET_OK;
-}
-
+// (pet_graph_build refuses a list with an edge that has no (j, i, -S) partner, so the reverse pass needs no check
+//  and no host synchronisation of its own.)
 // Stage P: adjoint of PETBackend.predict. seeds gA [N] -> w.dH [N,DN], w.dM [E,D], w.dfc [E]
 int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* gA, hipStream_t st,
                      Trainer* tr = nullptr) {
@@ -890,8 +884,6 @@ int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* 
 int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t st, Trainer* tr = nullptr) {
     const int64_t N = g.n_nodes, E = g.n_edges, R = E + N;
     if (E == 0) return PET_OK;
-    int rc = check_full_list(g, st);
-    if (rc) return rc;
     const int nt = attn_tiles(g);
     PET_REQUIRE(nt <= 8, PET_ERR_UNSUPPORTED, "more than 127 neighbours per atom is not supported yet");
     const float scale = 1.0f / (sqrtf((float)HD) * m.h.attention_temperature);
@@ -1049,8 +1041,6 @@ int backward_geometry(const Model& m, const Graph& g, Workspace& w, const float*
         if (gcell) PET_HIP_CHECK(hipMemsetAsync(gcell, 0, g.n_systems * 9 * sizeof(float), st));
         return PET_OK;
     }
-    int rc = check_full_list(g, st);
-    if (rc) return rc;
     k_geom_bwd<<<cdiv(E, 256), 256, 0, st>>>(g.geo, g.d0, dgeo, dfc_a, dfc_b, reinterpret_cast<float4*>(w.dv), E,
                                              m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function,
                                              g.adaptive ? g.pc : nullptr, g.adaptive ? g.ad_gc : nullptr);

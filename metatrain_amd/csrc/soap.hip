@@ -1791,10 +1791,6 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
         if (gcell) PET_HIP_CHECK(hipMemsetAsync(gcell, 0, g.n_systems * 9 * 4, st));
         return PET_OK;
     }
-    int bad = 0;
-    PET_HIP_CHECK(hipMemcpyAsync(&bad, g.scalars + 2, sizeof(int), hipMemcpyDeviceToHost, st));
-    PET_HIP_CHECK(hipStreamSynchronize(st));
-    PET_REQUIRE(bad == 0, PET_ERR_GRAPH, "neighbour list is not a full list: edges without a reverse edge");
     allow_big_lds(k_soap_expand_bwd, lds_expand_bwd(d));
     if (soap_fused_ok(m)) {
         ProfScope ps("soap_ps_tail_bwd", st, 4.0 * (double)N * d.S * (d.L + 1 + d.H), (double)N * d.NCOEF * 8);

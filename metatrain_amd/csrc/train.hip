@@ -88,8 +88,9 @@ __global__ void k_colsum_partial(const float* __restrict__ buf, int64_t n_rows, 
 }
 
 // partial[split][species][c] = sum over the split's rows with idx[row] == species
+// (species s0 .. s0 + ns - 1 only: the host walks the species axis in chunks that fit 64 KB of LDS)
 __global__ void k_species_sum_partial(const float* __restrict__ buf, const int* __restrict__ idx, int64_t n_rows,
-                                      int C, int ns, float* __restrict__ partial) {
+                                      int C, int ns, int s0, float* __restrict__ partial) {
     extern __shared__ float acc[];  // [ns][C]
     const int c = threadIdx.x;
     for (int i = threadIdx.x; i < ns * C; i += blockDim.x) acc[i] = 0.f;
@@ -98,7 +99,10 @@ __global__ void k_species_sum_partial(const float* __restrict__ buf, const int* 
     const int64_t per = (n_rows + nsplit - 1) / nsplit;
     const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(n_rows, r0 + per);
     if (c < C)
-        for (int64_t r = r0; r < r1; r++) acc[idx[r] * C + c] += buf[r * C + c];  // column c is private to this thread
+        for (int64_t r = r0; r < r1; r++) {
+            const int sp = idx[r] - s0;
+            if (sp >= 0 && sp < ns) acc[sp * C + c] += buf[r * C + c];  // column c is private to this thread
+        }
     __syncthreads();
     for (int i = threadIdx.x; i < ns * C; i += blockDim.x) partial[(size_t)blockIdx.x * ns * C + i] = acc[i];
 }
@@ -239,10 +243,13 @@ static void species_sum(Trainer& t, const float* buf, const int* idx, int64_t n_
     if (n_rows <= 0 || t.err) return;
     const int ns = t.m.h.n_species;
     const int nsplit = 2048;
-    const size_t lds = (size_t)ns * C * sizeof(float);
-    if (lds > 64 * 1024) { t.err = PET_ERR_UNSUPPORTED; set_error("too many species for the embedding gradient"); return; }
-    k_species_sum_partial<<<nsplit, 256, lds, t.st>>>(buf, idx, n_rows, C, ns, t.w.partial);
-    reduce_2d(t.w.partial, nsplit, ns * C, 1, dst, 1, 0, 1, t.st);
+    // the species axis in chunks of 64 KB / (4 C): 64 species for the node embedding (C = 256), 128 for the edge ones
+    const int chunk = (64 * 1024) / (C * (int)sizeof(float));
+    for (int s0 = 0; s0 < ns; s0 += chunk) {
+        const int nc = ns - s0 < chunk ? ns - s0 : chunk;
+        k_species_sum_partial<<<nsplit, 256, (size_t)nc * C * sizeof(float), t.st>>>(buf, idx, n_rows, C, nc, s0, t.w.partial);
+        reduce_2d(t.w.partial, nsplit, nc * C, 1, dst + (size_t)s0 * C, 1, 0, 1, t.st);
+    }
 }
 
 void Trainer::species_rows(const float* buf, const int* idx, int64_t n_rows, int C, float* dst) {

@@ -339,8 +339,185 @@ def main_silu():
     np.savez_compressed(os.path.join(HERE, "pet_silu_box64.npz"), **store)
 
 
+def _store_inputs(store, args):
+    store["in_positions"] = args[0].double().numpy()
+    store["in_cells"] = args[1].double().numpy()
+    store["in_centers"] = args[2].numpy().astype(np.int32)
+    store["in_neighbors"] = args[3].numpy().astype(np.int32)
+    store["in_cell_shifts"] = args[4].numpy().astype(np.int32)
+    store["in_species"] = args[5].numpy().astype(np.int32)
+    store["in_system_indices"] = args[6].numpy()
+
+
+def _reference_backend(PETBackend, hyp, dtype, targets=None, seed=0):
+    from oracle import pet as opet
+
+    targets = targets or {"energy": 1}
+    params = opet.synthetic_params(hyp, [1, 6, 7, 8], targets, seed, dtype)
+    be = PETBackend(hyp, [1, 6, 7, 8])
+    for t, nprop in targets.items():
+        be.add_output(t, {t: [nprop]})
+    be = be.to(dtype)
+    be.load_state_dict(params, strict=True)
+    assert list(be.state_dict().keys()) == list(params.keys()), "schema order"
+    return be, params
+
+
+def main_box10000():
+    """BASELINE.json's metric size: one 10 000-atom box (rho = 0.05 / A^3, seed 0), default hypers,
+    synthetic weights (seed 0) -> ``pet_default_box10000.npz``:
+
+    * ``atomic_ref_f32`` / ``grad_ref_f32``: the REFERENCE in fp32, eval mode (its own SDPA path);
+    * ``atomic_ref_f64``: the REFERENCE in fp64, energies only (no autograd graph: the fp64 graph of the padded
+      [N, 41, ...] layout does not fit this container's 62 GB);
+    * ``atomic_f64`` / ``grad_f64``: the fp64 ORACLE (``oracle/pet.py``, unpadded CSR), asserted here to agree with
+      the reference's fp64 per-atom energies to 1e-10 and with its fp32 gradient to the fp32 noise floor.
+
+    The neighbour list is not stored (191 044 pairs): the tests rebuild it from the stored positions."""
+    import time
+
+    from oracle import nl as onl
+    from oracle import pet as opet
+
+    PETBackend = import_reference_backend()
+    torch.set_num_threads(8)
+    hyp = dict(opet.DEFAULT_HYPERS)
+    pos, z, cell = opet.random_box(10000, seed=0)
+    i, j, s, _ = onl.neighbor_list(pos.double().numpy(), cell.double().numpy(), [True] * 3, hyp["cutoff"])
+    i, j, s = torch.tensor(i), torch.tensor(j), torch.tensor(s).long()
+    sysidx = torch.zeros(10000, dtype=torch.long)
+    store = {"in_positions": pos.numpy(), "in_species": z.numpy().astype(np.int32), "in_cell": cell.numpy(),
+             "n_pairs": np.array(len(i))}
+    t0 = time.time()
+    be, _ = _reference_backend(PETBackend, hyp, torch.float32)
+    res, _ = run_reference(be.eval(), "energy", pos, cell[None], i, j, s, z, sysidx)
+    store["atomic_ref_f32"], store["grad_ref_f32"] = res["atomic"].ravel(), res["grad"]
+    print("reference fp32:", time.time() - t0, "s; E =", res["energies"].ravel())
+    del be, res
+    t0 = time.time()
+    be, p64 = _reference_backend(PETBackend, hyp, torch.float64)
+    with torch.no_grad():
+        b = be.eval().preprocess(pos.double(), i, j, z, cell[None].double(), s, sysidx, 1.0)
+        nf, ef = be.calculate_features(b)
+        pred, _, _ = be.predict(nf, ef, b, cell[None].double(), sysidx, ["energy"])
+    store["atomic_ref_f64"] = pred["energy"][0].numpy().ravel()
+    print("reference fp64 (energies):", time.time() - t0, "s; E =", store["atomic_ref_f64"].sum())
+    del be, b, nf, ef, pred
+    t0 = time.time()
+    e, grad, atomic = opet.energy_and_gradient(p64, hyp, pos.double(), cell[None].double(), i, j, s, z, sysidx)
+    store["atomic_f64"], store["grad_f64"] = atomic.numpy().ravel(), grad.numpy()
+    print("oracle fp64:", time.time() - t0, "s; E =", float(e))
+    err_e = np.abs(store["atomic_f64"] - store["atomic_ref_f64"]).max() / np.abs(store["atomic_ref_f64"]).max()
+    err_g = np.abs(store["grad_f64"] - store["grad_ref_f32"]).max() / np.abs(store["grad_f64"]).max()
+    print("oracle vs reference: per-atom E (fp64)", err_e, " dE/dR (fp64 oracle vs fp32 reference)", err_g)
+    assert err_e < 1e-10 and err_g < 2e-5
+    np.savez_compressed(os.path.join(HERE, "pet_default_box10000.npz"), **store)
+
+
+def main_cosine():
+    """``cutoff_function = "Cosine"`` (``pet/modules/utilities.py:25-39``): ``batch_cosine_box64.npz`` (12 ``batch_data``
+    tensors) and ``pet_cosine_box64.npz`` (E, per-atom E, dE/dR in fp32 / fp64) from the reference."""
+    from oracle import nl as onl
+    from oracle import pet as opet
+
+    PETBackend = import_reference_backend()
+    torch.set_num_threads(8)
+    hyp = dict(opet.DEFAULT_HYPERS, cutoff_function="Cosine")
+    p64, z64, c64 = opet.random_box(64, seed=1)
+    i, j, s, _ = onl.neighbor_list(p64.double().numpy(), c64.double().numpy(), [True] * 3, hyp["cutoff"] + 1.0)
+    perm = torch.randperm(len(i), generator=torch.Generator().manual_seed(3))
+    i, j, s = torch.tensor(i)[perm], torch.tensor(j)[perm], torch.tensor(s).long()[perm]
+    sysidx = torch.zeros(64, dtype=torch.long)
+    be = PETBackend(hyp, [1, 6, 7, 8])
+    batch = be.preprocess(p64, i, j, z64, c64[None], s, sysidx, 1.0)
+    out = {"in_" + k: v.numpy() for k, v in dict(positions=p64, species=z64, cells=c64[None], centers=i, neighbors=j,
+                                                 cell_shifts=s, system_indices=sysidx).items()}
+    out.update({k: v.numpy() for k, v in batch.items()})
+    np.savez(os.path.join(HERE, "batch_cosine_box64.npz"), **out)
+    store = {}
+    for dtype in (torch.float32, torch.float64):
+        be, _ = _reference_backend(PETBackend, hyp, dtype)
+        args = (p64.to(dtype), c64.to(dtype)[None], i, j, s, z64, sysidx)
+        res, _ = run_reference(be.eval(), "energy", *args)
+        sfx = {torch.float32: "f32", torch.float64: "f64"}[dtype]
+        for k, v in res.items():
+            store[f"{k}_{sfx}"] = v
+        print("pet_cosine_box64", sfx, "E =", res["energies"].ravel(), "|grad|max =", np.abs(res["grad"]).max())
+    _store_inputs(store, args)
+    np.savez_compressed(os.path.join(HERE, "pet_cosine_box64.npz"), **store)
+
+
+def main_train():
+    """SURVEY §8(c) fixture (iv): ONE training step's loss and parameter gradients from the REFERENCE in ``train()``
+    mode -- manual attention (``backend.py:380-384``), ``autograd.grad(E, positions, create_graph=True)``
+    (``utils/output_gradient.py:34-40``), loss = MSE(E / n_atoms) + MSE(dE/dR) (``pet/trainer.py:432-452``,
+    ``utils/loss.py:144-217``: mean reduction over the flattened batch, weights 1), ``loss.backward()`` -- on two
+    periodic systems (64 + 40 atoms), fp64 and fp32 -> ``pet_train_two_systems.npz``: loss, energy / force loss
+    terms, total gradient norm, the norm of every parameter's gradient and four full gradient tensors."""
+    from oracle import nl as onl
+    from oracle import pet as opet
+
+    PETBackend = import_reference_backend()
+    torch.set_num_threads(8)
+    hyp = dict(opet.DEFAULT_HYPERS)
+    p64, z64, c64 = opet.random_box(64, seed=1)
+    p40, z40, c40 = opet.random_box(40, seed=2)
+    tri = c40.clone(); tri[1, 0] = 2.0; tri[2, 1] = -1.5
+    systems = [(p64, z64, c64), (p40, z40, tri)]
+    pos_l, z_l, cell_l, i_l, j_l, s_l, sys_l, off = [], [], [], [], [], [], [], 0
+    for k, (pos, z, cell) in enumerate(systems):
+        i, j, s, _ = onl.neighbor_list(pos.double().numpy(), cell.double().numpy(), [True] * 3, hyp["cutoff"])
+        pos_l.append(pos); z_l.append(z); cell_l.append(cell)
+        i_l.append(torch.tensor(i) + off); j_l.append(torch.tensor(j) + off); s_l.append(torch.tensor(s))
+        sys_l.append(torch.full((len(z),), k, dtype=torch.long)); off += len(z)
+    pos, z, cells = torch.cat(pos_l), torch.cat(z_l), torch.stack(cell_l)
+    i, j, s, sysidx = torch.cat(i_l), torch.cat(j_l), torch.cat(s_l).long(), torch.cat(sys_l)
+    gen = torch.Generator().manual_seed(7)
+    e_target = torch.randn(2, generator=gen, dtype=torch.float64) * 5.0
+    g_target = torch.randn(len(z), 3, generator=gen, dtype=torch.float64) * 0.3
+    n_atoms = torch.tensor([64.0, 40.0], dtype=torch.float64)
+    store = {"e_target": e_target.numpy(), "g_target": g_target.numpy()}
+    full = ["gnn_layers.1.trans.layers.0.norm_attention.weight", "gnn_layers.0.edge_embedder.weight",
+            "node_last_layers.energy.0.energy.weight", "combination_norms.1.bias"]
+    for dtype in (torch.float64, torch.float32):
+        be, _ = _reference_backend(PETBackend, hyp, dtype)
+        be.train()
+        p = pos.to(dtype).clone().requires_grad_(True)
+        b = be.preprocess(p, i, j, z, cells.to(dtype), s, sysidx, 1.0)
+        assert b["edge_vectors"].requires_grad and be.training  # => manual attention
+        nf, ef = be.calculate_features(b)
+        pred, _, _ = be.predict(nf, ef, b, cells.to(dtype), sysidx, ["energy"])
+        atomic = pred["energy"][0]
+        energies = torch.zeros(2, 1, dtype=dtype).index_add(0, sysidx, atomic)[:, 0]
+        (grad,) = torch.autograd.grad(energies.sum(), p, create_graph=True)
+        loss_e = ((energies / n_atoms.to(dtype) - (e_target / n_atoms).to(dtype)) ** 2).mean()
+        loss_f = ((grad - g_target.to(dtype)) ** 2).mean()
+        loss = loss_e + loss_f
+        loss.backward()
+        named = dict(be.named_parameters())
+        sfx = {torch.float32: "f32", torch.float64: "f64"}[dtype]
+        store[f"loss_{sfx}"] = np.array([loss.item(), loss_e.item(), loss_f.item()])
+        store[f"energies_{sfx}"] = energies.detach().numpy()
+        store[f"grad_{sfx}"] = grad.detach().numpy()
+        norms = np.array([named[k].grad.norm().item() for k in named])
+        store[f"grad_norms_{sfx}"] = norms
+        store[f"total_grad_norm_{sfx}"] = np.array(np.sqrt((norms ** 2).sum()))
+        for k in full:
+            store[f"dparam_{sfx}::{k}"] = named[k].grad.numpy()
+        print("train", sfx, "loss", store[f"loss_{sfx}"], "total grad norm", store[f"total_grad_norm_{sfx}"])
+    store["param_keys"] = np.array(list(named.keys()))
+    _store_inputs(store, (pos, cells, i, j, s, z, sysidx))
+    np.savez_compressed(os.path.join(HERE, "pet_train_two_systems.npz"), **store)
+
+
 if __name__ == "__main__":
-    if "--silu" in sys.argv:
+    if "--box10000" in sys.argv:
+        main_box10000()
+    elif "--cosine" in sys.argv:
+        main_cosine()
+    elif "--train" in sys.argv:
+        main_train()
+    elif "--silu" in sys.argv:
         main_silu()
     elif "--adaptive" in sys.argv:
         main_adaptive()

@@ -174,3 +174,69 @@ def test_oracle_adaptive_cutoff_matches_reference(golden_dir, case):
     np.testing.assert_allclose(e.numpy(), g["energies_f64"], rtol=1e-10)
     np.testing.assert_allclose(atomic.numpy(), g["atomic_f64"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(grad.numpy(), g["grad_f64"], rtol=1e-8, atol=1e-11)
+
+
+def test_oracle_cosine_cutoff_matches_reference(golden_dir):
+    """cutoff_function = "Cosine" (pet/modules/utilities.py:25-39): batch_data and E / dE/dR of the reference."""
+    hypers = dict(opet.DEFAULT_HYPERS, cutoff_function="Cosine")
+    b = _load(golden_dir, "batch_cosine_box64.npz")
+    table = torch.full((9,), -1, dtype=torch.long)
+    table[torch.tensor([1, 6, 7, 8])] = torch.arange(4)
+    t = lambda d, k: torch.tensor(d[k])  # noqa: E731
+    out = opet.batch_tensors(hypers, table, t(b, "in_positions"), t(b, "in_cells"), t(b, "in_centers"),
+                             t(b, "in_neighbors"), t(b, "in_cell_shifts"), t(b, "in_species"), t(b, "in_system_indices"))
+    for k in INT_KEYS:
+        assert np.array_equal(out[k], b[k]), k
+    np.testing.assert_allclose(out["cutoff_factors"], b["cutoff_factors"], rtol=2e-6, atol=2e-6)
+    g = _load(golden_dir, "pet_cosine_box64.npz")
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    e, grad, atomic = _run_oracle(g, hypers, params, torch.float64)
+    np.testing.assert_allclose(e.numpy(), g["energies_f64"], rtol=1e-10)
+    np.testing.assert_allclose(atomic.numpy(), g["atomic_f64"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(grad.numpy(), g["grad_f64"], rtol=1e-8, atol=1e-11)
+
+
+def test_oracle_training_step_matches_reference_fixture(golden_dir):
+    """SURVEY §8(c) fixture (iv): the oracle's double backward (loss on E / atom and on dE/dR) against what the reference
+    produced in train() mode with manual attention (make_golden.py --train): loss terms, every parameter's gradient
+    norm, four full gradient tensors -- fp64, 1e-9."""
+    g = _load(golden_dir, "pet_train_two_systems.npz")
+    hypers = dict(opet.DEFAULT_HYPERS)
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    p64 = {k: (v if k == "species_to_species_index" else v.clone().requires_grad_(True)) for k, v in params.items()}
+    t = lambda k: torch.tensor(g[k])  # noqa: E731
+    pos = t("in_positions").clone().requires_grad_(True)
+    s = t("in_system_indices")
+    atomic = opet.pet_atomic_energies(p64, hypers, pos, t("in_cells"), t("in_centers"), t("in_neighbors"),
+                                      t("in_cell_shifts"), t("in_species"), s)[:, 0]
+    e = torch.zeros(2, dtype=torch.float64).index_add(0, s, atomic)
+    (grad,) = torch.autograd.grad(e.sum(), pos, create_graph=True)
+    n_atoms = torch.tensor([64.0, 40.0], dtype=torch.float64)
+    loss_e = (((e - t("e_target")) / n_atoms) ** 2).mean()
+    loss_f = ((grad - t("g_target")) ** 2).mean()
+    (loss_e + loss_f).backward()
+    np.testing.assert_allclose([float(loss_e + loss_f), float(loss_e), float(loss_f)], g["loss_f64"], rtol=1e-10)
+    keys = [str(k) for k in g["param_keys"]]
+    assert keys == [k for k in p64 if k != "species_to_species_index"]
+    norms = np.array([float(p64[k].grad.norm()) for k in keys])
+    np.testing.assert_allclose(norms, g["grad_norms_f64"], rtol=1e-8, atol=1e-12)
+    for k in [k[len("dparam_f64::"):] for k in g if k.startswith("dparam_f64::")]:
+        ref = g["dparam_f64::" + k]
+        assert np.abs(p64[k].grad.numpy() - ref).max() < 1e-9 * np.abs(ref).max(), k
+    # the reference's own fp32 training pass sits this far from its fp64 one (context for the GPU tolerance)
+    assert np.abs(g["grad_norms_f32"] - g["grad_norms_f64"]).max() < 1e-4 * g["grad_norms_f64"].max()
+
+
+def test_box10000_golden_is_consistent(golden_dir):
+    """The 10 000-atom fixture (BASELINE.json's metric size): the fp64 oracle's per-atom energies equal the
+    reference's fp64 ones to 1e-12, its gradient equals the reference's fp32 gradient to the fp32 noise floor, the
+    stored inputs are the documented generator's output."""
+    g = _load(golden_dir, "pet_default_box10000.npz")
+    pos, z, cell = opet.random_box(10000, seed=0)
+    assert np.array_equal(pos.numpy(), g["in_positions"]) and np.array_equal(z.numpy(), g["in_species"])
+    assert np.array_equal(cell.numpy(), g["in_cell"])
+    scale = np.abs(g["atomic_ref_f64"]).max()
+    assert np.abs(g["atomic_f64"] - g["atomic_ref_f64"]).max() < 1e-12 * scale
+    assert np.abs(g["atomic_ref_f32"] - g["atomic_ref_f64"]).max() < 1e-5 * scale
+    assert np.abs(g["grad_f64"] - g["grad_ref_f32"]).max() < 1e-5 * np.abs(g["grad_f64"]).max()
+    assert abs(g["grad_f64"].sum(0)).max() < 1e-9  # Newton's third law in fp64
