@@ -277,6 +277,14 @@ int finalize(Model& m, hipStream_t st) {
         if ((rc = named_alloc(m, pre + ":wct", (void**)&G.wct, 4 * D * sizeof(float)))) return rc;
         if ((rc = named_alloc(m, pre + ":tbl", (void**)&G.tbl, (size_t)ns * D * sizeof(float)))) return rc;
         k_fold_compress0<<<cdiv(D * 4 + ns * D, 128), 128, 0, st>>>(w0, kin, b0, wee, bee, emb, ns, G.wc, G.wct, G.tbl);
+        {   // the 4 -> D composite once more as one 32-row MFMA tile (rows 4..31 zero), f16x3 planes, for the TRR adjoint
+            const size_t n8 = (size_t)(D / 16) * 64;
+            if ((rc = named_alloc(m, pre + ":wcp", (void**)&G.wcp, 32 * D * sizeof(float)))) return rc;
+            if ((rc = named_alloc(m, pre + ":wc2", &G.wc2, 2 * n8 * 16))) return rc;
+            PET_HIP_CHECK(hipMemsetAsync(G.wcp, 0, 32 * D * sizeof(float), st));
+            PET_HIP_CHECK(hipMemcpyAsync(G.wcp, G.wct, 4 * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+            k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(G.wcp, D, 1, 32, D, (_Float16*)G.wc2);
+        }
         if (g > 0) {
             if ((rc = pack_lin(m, pre + ".compress.0:msg", G.compress0_msg, w0, nullptr, D, D, kin, 2 * D, st))) return rc;
         }

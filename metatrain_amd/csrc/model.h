@@ -45,6 +45,8 @@ struct GnnLayerW {
     Lin compress0_msg;  // columns of compress.0 that multiply the incoming message (g >= 1)
     float* wc = nullptr;   // [D, 4]  compress.0[:, :D] @ edge_embedder.weight  (4 -> D composite)
     float* wct = nullptr;  // [4, D]  transpose, for the backward dot products
+    float* wcp = nullptr;  // [32, D] wct padded with zero rows to one MFMA tile
+    void* wc2 = nullptr;   // f16x3 planes of wcp in fragment order (dgeo = da0 Wc as a 32-wide GEMM tile, pet_trr.hip)
     float* tbl = nullptr;  // [n_species, D] species part of compress.0 (+ all biases)
     Lin comb0, comb2;
     const float *ln_g = nullptr, *ln_b = nullptr;

@@ -92,17 +92,25 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
         gy[threadIdx.x] = g;
     }
     __syncthreads();
+    if (w0f.h) {  // the forward kernel's row scales (k_head): un-normalised backbone features and hidden rows
+        tile_row_scales<K>(A, LDK, rs);
+        __syncthreads();
+    }
     f32x16 a1[2], acc[2];
     acc_fill_bias<2>(a1, b0, 64 * w.ch, w.lane);
-    gemm_acc_x<K, 2>(A + w.rb * 32 * LDK, LDK, w0f, K / 8, 0, 2 * w.ch, a1, w.lane);
+    gemm_acc_x<K, 2>(A + w.rb * 32 * LDK, LDK, w0f, K / 8, 0, 2 * w.ch, a1, w.lane, w0f.h ? rs + 64 * w.rb : nullptr);
     acc_foreach<2>(a1, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
         const float s1 = siluf_(v);
         S[r * LD128 + c] = s1;
         if (TRAIN && row0 + r < R) t_s1[(row0 + r) * DH + c] = s1;
     });
     __syncthreads();
+    if (w2f.h) {
+        tile_row_scales<128>(S, LD128, rs);
+        __syncthreads();
+    }
     acc_fill_bias<2>(acc, b2, 64 * w.ch, w.lane);
-    gemm_acc_x<128, 2>(S + w.rb * 32 * LD128, LD128, w2f, 16, 0, 2 * w.ch, acc, w.lane);
+    gemm_acc_x<128, 2>(S + w.rb * 32 * LD128, LD128, w2f, 16, 0, 2 * w.ch, acc, w.lane, w2f.h ? rs + 64 * w.rb : nullptr);
     __syncthreads();
     // da2 = gy * wl * silu'(a2)
     acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {

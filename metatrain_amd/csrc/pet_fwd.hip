@@ -74,6 +74,10 @@ __global__ __launch_bounds__(NTHREADS) void k_compress(const float4* __restrict_
     }
     if (!FIRST) load_rows_to_lds<128>(A, Min, row0, E, D);
     __syncthreads();
+    if (!FIRST && w0c.h) {  // messages: un-normalised rows
+        tile_row_scales<128>(A, LD128, rs);
+        __syncthreads();
+    }
     if (FIRST) {
         const int c = threadIdx.x & 127;
         const float4 wv = reinterpret_cast<const float4*>(wc)[c];
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(NTHREADS) void k_compress(const float4* __restrict_
         f32x16 acc[2];
         const int col0 = 64 * w.ch;
         acc_fill_bias<2>(acc, nullptr, 0, w.lane);
-        gemm_acc_x<128, 2>(A + w.rb * 32 * LD128, LD128, w0c, 16, 0, 2 * w.ch, acc, w.lane);
+        gemm_acc_x<128, 2>(A + w.rb * 32 * LD128, LD128, w0c, 16, 0, 2 * w.ch, acc, w.lane, w0c.h ? rs + 64 * w.rb : nullptr);
         // The geometry / species terms are added AFTER the GEMM. With them pre-filled into `acc` and live across
         // gemm_acc_x, a few (row, 16-column) groups of the result came out different from launch to launch
         // (same inputs, same weights; lanes 48..63 of one wave): not understood, avoided by this order.
@@ -108,9 +112,13 @@ __global__ __launch_bounds__(NTHREADS) void k_compress(const float4* __restrict_
         });
     }
     __syncthreads();
+    if (w2.h) {
+        tile_row_scales<128>(S, LD128, rs);
+        __syncthreads();
+    }
     f32x16 acc2[2];
     acc_fill_bias<2>(acc2, b2, 64 * w.ch, w.lane);
-    gemm_acc_x<128, 2>(S + w.rb * 32 * LD128, LD128, w2, 16, 0, 2 * w.ch, acc2, w.lane);
+    gemm_acc_x<128, 2>(S + w.rb * 32 * LD128, LD128, w2, 16, 0, 2 * w.ch, acc2, w.lane, w2.h ? rs + 64 * w.rb : nullptr);
     store_acc<2>(acc2, Xout, row0, E, D, w.rb, 64 * w.ch, w.lane);
 }
 
@@ -123,11 +131,16 @@ __global__ __launch_bounds__(NTHREADS) void k_center(const float* __restrict__ H
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const WaveId w;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
+    float* rs = smem + BM * LD256;  // [64][2] power-of-two row scales: node features are un-normalised rows
     load_rows_to_lds<256>(smem, H, row0, N, DN);
     __syncthreads();
+    if (wcc.h) {
+        tile_row_scales<256>(smem, LD256, rs);
+        __syncthreads();
+    }
     f32x16 acc[2];
     acc_fill_bias<2>(acc, bcc, 64 * w.ch, w.lane);
-    gemm_acc_x<256, 2>(smem + w.rb * 32 * LD256, LD256, wcc, 32, 0, 2 * w.ch, acc, w.lane);
+    gemm_acc_x<256, 2>(smem + w.rb * 32 * LD256, LD256, wcc, 32, 0, 2 * w.ch, acc, w.lane, wcc.h ? rs + 64 * w.rb : nullptr);
     store_acc<2>(acc, Xc, row0, N, D, w.rb, 64 * w.ch, w.lane);
 }
 
@@ -290,16 +303,22 @@ __global__ __launch_bounds__(NTHREADS) void k_node(const float* __restrict__ H, 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;               // [64][260]
     float* U = smem + BM * LD256;   // [64][132] (OC tile, then SwiGLU hidden chunk)
+    float* rs = U + BM * LD128;     // [64][2] row scales of the OC tile (un-normalised attention output)
     const WaveId w;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     load_rows_to_lds<128>(U, OC, row0, N, D);
     __syncthreads();
+    if (wce.h) {
+        tile_row_scales<128>(U, LD128, rs);
+        __syncthreads();
+    }
 #pragma unroll 1
     for (int c = 0; c < 2; c++) {  // 256 output columns in two chunks of 128
         f32x16 acc[2];
         const int col0 = 128 * c + 64 * w.ch;
         acc_fill_bias<2>(acc, bce, col0, w.lane);
-        gemm_acc_x<128, 2>(U + w.rb * 32 * LD128, LD128, wce, 16, 0, 4 * c + 2 * w.ch, acc, w.lane);
+        gemm_acc_x<128, 2>(U + w.rb * 32 * LD128, LD128, wce, 16, 0, 4 * c + 2 * w.ch, acc, w.lane,
+                           wce.h ? rs + 64 * w.rb : nullptr);
         acc_foreach<2>(acc, w.rb, col0, w.lane, [&](int r, int cc, float v) {
             const int64_t row = row0 + r;
             float h1 = v + (row < N ? H[row * DN + cc] : 0.f);
@@ -498,17 +517,26 @@ __global__ __launch_bounds__(NTHREADS) void k_head(const float* __restrict__ Xin
     constexpr int LDK = lds_ld(K);
     float* A = smem;              // [64][K+4]
     float* S = smem + BM * LDK;   // [64][132]
+    float* rs = S + BM * LD128;   // [64][2] row scales: backbone features and the hidden rows are un-normalised
     const WaveId w;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     load_rows_to_lds<K>(A, Xin, row0, R, K);
     __syncthreads();
+    if (w0.h) {
+        tile_row_scales<K>(A, LDK, rs);
+        __syncthreads();
+    }
     f32x16 acc[2];
     acc_fill_bias<2>(acc, b0, 64 * w.ch, w.lane);
-    gemm_acc_x<K, 2>(A + w.rb * 32 * LDK, LDK, w0, K / 8, 0, 2 * w.ch, acc, w.lane);
+    gemm_acc_x<K, 2>(A + w.rb * 32 * LDK, LDK, w0, K / 8, 0, 2 * w.ch, acc, w.lane, w0.h ? rs + 64 * w.rb : nullptr);
     acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) { S[r * LD128 + c] = siluf_(v); });
     __syncthreads();
+    if (w2.h) {
+        tile_row_scales<128>(S, LD128, rs);
+        __syncthreads();
+    }
     acc_fill_bias<2>(acc, b2, 64 * w.ch, w.lane);
-    gemm_acc_x<128, 2>(S + w.rb * 32 * LD128, LD128, w2, 16, 0, 2 * w.ch, acc, w.lane);
+    gemm_acc_x<128, 2>(S + w.rb * 32 * LD128, LD128, w2, 16, 0, 2 * w.ch, acc, w.lane, w2.h ? rs + 64 * w.rb : nullptr);
     __syncthreads();
     acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
         const float a = siluf_(v);
@@ -619,9 +647,9 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
     // attention: 4 T^2 d FLOPs per atom per layer; T^2 summed on the host side of the graph
     const double attn_flops = 4.0 * D * g_sum_t2(g);
 
-    allow_big_lds(k_center, BM * LD256 * 4);
-    allow_big_lds(k_node, (BM * LD256 + BM * LD128) * 4);
-    allow_big_lds(k_head<256>, (BM * LD256 + BM * LD128) * 4);
+    allow_big_lds(k_center, BM * LD256 * 4 + BM * 8);
+    allow_big_lds(k_node, (BM * LD256 + BM * LD128) * 4 + BM * 8);
+    allow_big_lds(k_head<256>, (BM * LD256 + BM * LD128) * 4 + BM * 8);
     const SideStream& ss = side_stream();
     const hipStream_t s2 = ss.stream(st);  // node-feature chain
     bool side_busy = false;
@@ -629,7 +657,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
         const AttnLayerW& A = m.gnn[gi].attn[a];
         AttnBufs& Ab = w.gnn[gi].attn[a];
         ProfScope ps("center", s2, fN * 2.0 * DN * D);
-        k_center<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(Ab.H, wx_fwd(A.cc, 2), A.cc.b, Ab.X + E * D, N);
+        k_center<<<gN, NTHREADS, BM * LD256 * 4 + BM * 8, s2>>>(Ab.H, wx_fwd(A.cc, 2), A.cc.b, Ab.X + E * D, N);
     };
     k_node_embed<<<cdiv(N * (DN / 4), 256), 256, 0, st>>>(g.sp, m.node_emb, w.H0, (int)N);
     ss.fork(st);
@@ -686,7 +714,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
             {
                 ProfScope ps("node", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
                 if (!(trr && trr_node(A, Ab.H, Ab.OC, Ab.H1, Ab.VGn, Ab.Hn, N, s2)))
-                k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
+                k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, s2>>>(
                     Ab.H, Ab.OC, wx_fwd(A.ce, 4), A.ce.b, A.g_center, wx_fwd(A.cmlp_in, 8), A.cmlp_in.b, wx_fwd(A.cmlp_out, 16),
                     A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
             }
@@ -721,13 +749,13 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
     const GnnBufs& last = w.gnn.back();
     {
         ProfScope ps("head_node", s2, fN * 2.0 * (DN * DH + DH * DH + DH));
-        k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, s2>>>(
+        k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, s2>>>(
             last.Hout, wx_fwd(m.nh0, 32), m.nh0.b, wx_fwd(m.nh2, 32), m.nh2.b, m.nll_w, m.nll_b, nullptr, nullptr, w.ynode, N);
     }
     if (E > 0) {
         ProfScope ps("head_edge", st, fE * 2.0 * (D * DH + DH * DH + DH));
         if (!(trr && trr_head_edge(m, last.Mout, g.fc, w.ypred_e, w.ye, E, st)))
-        k_head<128><<<gE, NTHREADS, lds2, st>>>(last.Mout, wx_fwd(m.eh0, 64), m.eh0.b, wx_fwd(m.eh2, 64), m.eh2.b, m.ell_w,
+        k_head<128><<<gE, NTHREADS, lds2 + BM * 8, st>>>(last.Mout, wx_fwd(m.eh0, 64), m.eh0.b, wx_fwd(m.eh2, 64), m.eh2.b, m.ell_w,
                                                 m.ell_b, g.fc, w.ypred_e, w.ye, E);
     }
     ss.join(st);
@@ -754,12 +782,12 @@ int aux_outputs(const Model& m, const Graph& g, const float* node_feat, const fl
         k_edge_sum_fc<<<cdiv(N, 4), 256, 0, st>>>(edge_feat, g.fc, g.rowptr, feature + DN, DN + D, (int)N);
     }
     if (last_layer) {
-        allow_big_lds(k_head<256>, (BM * LD256 + BM * LD128) * 4);
-        const size_t lds2 = (size_t)(BM * LD128 * 2) * 4;
+        allow_big_lds(k_head<256>, (BM * LD256 + BM * LD128) * 4 + BM * 8);
+        const size_t lds2 = (size_t)(BM * LD128 * 2) * 4 + BM * 8;
         PET_REQUIRE(scratch, PET_ERR_ARGUMENT, "last-layer features need the scratch buffer");
         float* hid_e = scratch;             // [E, DH] edge-head hidden rows
         float* ytmp = scratch + E * DH;     // [max(E, N)] the heads' scalar predictions, not wanted here
-        k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4, st>>>(
+        k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, st>>>(
             node_feat, wx_fwd(m.nh0, 32), m.nh0.b, wx_fwd(m.nh2, 32), m.nh2.b, m.nll_w, m.nll_b, nullptr, nullptr,
             ytmp, N, last_layer, 2 * DH);
         if (E > 0)

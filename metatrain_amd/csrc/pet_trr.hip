@@ -290,17 +290,20 @@ __device__ __forceinline__ void row_gemm128_h(const W2& w, const float* __restri
 #pragma unroll
     for (int b = 0; b < RING; b++) ld_blk2<2>(ring[b], w, widx(b), 8 * 64);
     constexpr bool BIAS_AHEAD = RING >= 4;  // the two-waves-per-SIMD callers (RING 2) have no registers for it
+    // a run-time `oscale` undoes a power-of-two scale of the INPUT rows: the bias must then be added after it
+    const bool unit_scale = __builtin_constant_p(oscale) && oscale == 1.0f;
     float4 bnext[8];
-    if (bias && BIAS_AHEAD) ld_bias<2>(bnext, bias, 0, L.h);
+    if (bias && BIAS_AHEAD && unit_scale) ld_bias<2>(bnext, bias, 0, L.h);
 #pragma unroll UNROLLED ? NC2 : 1
     for (int c = 0; c < NC2; c++) {
         f32x16 acc[2], acl[2];
         acc_zero<2>(acl);
-        if (bias) {
+        if (bias && unit_scale) {
             if (!BIAS_AHEAD) ld_bias<2>(bnext, bias, 64 * c, L.h);
             acc_from<2>(acc, bnext);
             if (BIAS_AHEAD && c + 1 < NC2) ld_bias<2>(bnext, bias, 64 * (c + 1), L.h);
         } else {
+            if (bias) ld_bias<2>(bnext, bias, 64 * c, L.h);
             acc_zero<2>(acc);
         }
 #pragma unroll
@@ -313,7 +316,18 @@ __device__ __forceinline__ void row_gemm128_h(const W2& w, const float* __restri
         fold_low<2>(acc, acl);
         // forward callers pass the literal 1 and the multiply folds away; adjoint callers pass a per-row value and
         // always multiply: a test on it would be a divergent branch around spill code ("exec hazards")
-        if (!(__builtin_constant_p(oscale) && oscale == 1.0f)) acc_scale<2>(acc, oscale);
+        if (!unit_scale) {
+            acc_scale<2>(acc, oscale);
+            if (bias) {
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        acc[t][4 * q] += bnext[4 * t + q].x; acc[t][4 * q + 1] += bnext[4 * t + q].y;
+                        acc[t][4 * q + 2] += bnext[4 * t + q].z; acc[t][4 * q + 3] += bnext[4 * t + q].w;
+                    }
+            }
+        }
         epi(c, acc);
     }
 }
@@ -535,6 +549,11 @@ static inline W2 w2_bwd(const Lin& L) {
     const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
     const f16x8* b = reinterpret_cast<const f16x8*>(L.bwd2);
     W2 w; w.h = b; w.l = b + n8;
+    return w;
+}
+static inline W2 w2_wc(const GnnLayerW& G) {  // one 32-row tile, K = D
+    const f16x8* b = reinterpret_cast<const f16x8*>(G.wc2);
+    W2 w; w.h = b; w.l = b + (size_t)(D / 16) * 64;
     return w;
 }
 static inline W3 w3_bwd(const Lin& L) {
@@ -1301,12 +1320,16 @@ __global__ __launch_bounds__(256, 2) void k_compress_h(const float4* __restrict_
     float4 a0[16];  // row fragment of the pre-activation: entries a0[kg] = features 8 kg + 4 h .. + 3
     if (!FIRST) {   // message term first: the geometry terms below then need no registers during the GEMM
         Split2<8> ms;
-        {
+        float minv;
+        {   // messages are an UN-normalised residual stream: a checkpoint may carry them at 1e-4 or 1e+4, outside the
+            // range in which fp16 pieces keep fp32 accuracy, so the row goes in scaled by a power of two (exact)
             float4 mrow[16];
             load_rowfrag<16>(mrow, Min, row, D, L.h);
-            split_frag2<8>(mrow, ms);  // messages: an O(1) residual stream
+            float sc;
+            minv = row_scale_pow2<16>(mrow, sc);
+            split_frag2<8>(mrow, ms);
         }
-        row_gemm128_h<2, true, 2>(w0c, nullptr, ms, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+        row_gemm128_h<2, true, 2>(w0c, nullptr, ms, L, minv, [&](int c, f32x16 (&acc)[2]) {
             acc_to_frag<2>(acc, &a0[8 * c]);
         });
     } else {
@@ -1331,13 +1354,16 @@ __global__ __launch_bounds__(256, 2) void k_compress_h(const float4* __restrict_
     }
     if (a0_out && valid) store_rowfrag<16>(a0, a0_out, row, D, L.h);
     Split2<8> ss;
+    float sinv;
     {
 #pragma unroll
         for (int kg = 0; kg < 16; kg++)
             a0[kg] = make_float4(silu_(a0[kg].x), silu_(a0[kg].y), silu_(a0[kg].z), silu_(a0[kg].w));
+        float sc;
+        sinv = row_scale_pow2<16>(a0, sc);  // silu(a0) is as large as a0
         split_frag2<8>(a0, ss);
     }
-    row_gemm128_h<2, true, 2>(w2, b2, ss, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true, 2>(w2, b2, ss, L, sinv, [&](int c, f32x16 (&acc)[2]) {
         if (valid) {
             float4 y[8];
             acc_to_frag<2>(acc, y);
@@ -1348,7 +1374,7 @@ __global__ __launch_bounds__(256, 2) void k_compress_h(const float4* __restrict_
 
 template <bool FIRST, bool TRAIN>
 __global__ __launch_bounds__(256, 2) void k_compress_bwd_h(const float* __restrict__ dXe, const float* __restrict__ a0,
-                                                         W2 w2b, const float* __restrict__ wct /*[4][D]*/, W2 w0cb,
+                                                         W2 w2b, W2 wcp /* Wc^T padded to [32][D] */, W2 w0cb,
                                                          float* __restrict__ dgeo, float* __restrict__ dM, int64_t E,
                                                          float* __restrict__ t_da0) {
     TRR_PROLOGUE(E);
@@ -1373,33 +1399,39 @@ __global__ __launch_bounds__(256, 2) void k_compress_bwd_h(const float* __restri
         }
     });
     if (TRAIN && valid) store_rowfrag<16>(da0, t_da0, row, D, L.h);
-    {   // dgeo[row][q] += sum_c da0[c] Wc[c][q]: this lane's 64 features, then the partner lane
-        float sq[4] = {0.f, 0.f, 0.f, 0.f};
+    // dgeo[row][q] += sum_c da0[c] Wc[c][q] as ONE more MFMA tile: Wc^T padded to 32 rows is the A operand, the split
+    // da0 row fragment the B operand, and the tile's first four rows -- registers 0..3 of the lanes with h = 0 -- are
+    // dgeo[row][0..3]. (Until round 2 this was 64 float4 loads of Wc^T and 256 packed FMAs per lane plus a cross-lane
+    // sum; that block returned sums with ONE product missing -- upper half-wave, second element of a packed pair --
+    // for a few waves of every launch of more than 512 workgroups, differently from run to run:
+    // tools/debug/dbg10k*.py, DESIGN.md section 7. The matrix-core form has no weight loads in VALU code at all.)
+    Split2<8> ds;
+    float inv2;
+    {
+        float sc;
+        inv2 = row_scale_pow2<16>(da0, sc);
+        split_frag2<8>(da0, ds);
+    }
+    {
+        f32x16 g[1], gl[1];
+        acc_zero<1>(g);
+        acc_zero<1>(gl);
+        WBlk2<1> wb[2];
+        ld_blk2<1>(wb[0], wcp, L.lane, 0);
 #pragma unroll
-        for (int kg = 0; kg < 16; kg++) {
-            const int c = 8 * kg + 4 * L.h;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 ww = *reinterpret_cast<const float4*>(wct + q * D + c);
-                sq[q] += da0[kg].x * ww.x + da0[kg].y * ww.y + da0[kg].z * ww.z + da0[kg].w * ww.w;
-            }
+        for (int kb = 0; kb < 8; kb++) {
+            if (kb + 1 < 8) ld_blk2<1>(wb[(kb + 1) & 1], wcp, (size_t)(kb + 1) * 64 + L.lane, 0);
+            mfma3<1>(g, gl, wb[kb & 1], ds.h[kb], ds.l[kb]);
         }
-#pragma unroll
-        for (int q = 0; q < 4; q++) sq[q] = row_sum(sq[q]);
+        fold_low<1>(g, gl);
         if (valid && L.h == 0) {
             float4* dg = reinterpret_cast<float4*>(dgeo + row * 4);
             const float4 old = *dg;
-            *dg = make_float4(old.x + sq[0], old.y + sq[1], old.z + sq[2], old.w + sq[3]);
+            *dg = make_float4(fmaf(g[0][0], inv2, old.x), fmaf(g[0][1], inv2, old.y), fmaf(g[0][2], inv2, old.z),
+                              fmaf(g[0][3], inv2, old.w));
         }
     }
     if (!FIRST) {
-        Split2<8> ds;
-        float inv2;
-        {
-            float sc;
-            inv2 = row_scale_pow2<16>(da0, sc);
-            split_frag2<8>(da0, ds);
-        }
         row_gemm128_h<2, true>(w0cb, nullptr, ds, L, inv2, [&](int c, f32x16 (&acc)[2]) {
             float4 y[8], old[8];
             acc_to_frag<2>(acc, y);
@@ -1529,21 +1561,28 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const float* __restrict__ Xin
                                                     float* __restrict__ yout, int64_t R) {
     TRR_PROLOGUE(R);
     Split2<8> xs;
-    {
+    float xinv;
+    {   // backbone features are un-normalised rows: power-of-two row scale (see k_compress_h)
         float4 x[16];
         load_rowfrag<16>(x, Xin, row, D, L.h);
+        float sc;
+        xinv = row_scale_pow2<16>(x, sc);
         split_frag2<8>(x, xs);
     }
     float4 s1[16];
-    row_gemm128_h<2, true, 2>(w0, b0, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true, 2>(w0, b0, xs, L, xinv, [&](int c, f32x16 (&acc)[2]) {
         float4 y[8];
         acc_to_frag<2>(acc, y);
 #pragma unroll
         for (int k = 0; k < 8; k++) s1[8 * c + k] = make_float4(silu_(y[k].x), silu_(y[k].y), silu_(y[k].z), silu_(y[k].w));
     });
-    split_frag2<8>(s1, xs);
+    {
+        float sc;
+        xinv = row_scale_pow2<16>(s1, sc);
+        split_frag2<8>(s1, xs);
+    }
     float part = 0.f;
-    row_gemm128_h<2, true, 2>(w2, b2, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true, 2>(w2, b2, xs, L, xinv, [&](int c, f32x16 (&acc)[2]) {
         float4 y[8];
         acc_to_frag<2>(acc, y);
 #pragma unroll
@@ -1576,13 +1615,16 @@ __global__ __launch_bounds__(256) void k_head_bwd_h(const float* __restrict__ Xi
         if (valid && L.h == 0) dfc[row] = ga * ypred[row];  // d(y fc)/dfc
     }
     Split2<8> xs;
-    {
+    float xinv;
+    {   // the same power-of-two row scales as the forward kernel (k_head_h)
         float4 x[16];
         load_rowfrag<16>(x, Xin, row, D, L.h);
+        float sc;
+        xinv = row_scale_pow2<16>(x, sc);
         split_frag2<8>(x, xs);
     }
     float4 a1[16], t[16];
-    row_gemm128_h<2, true>(w0f, b0, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true>(w0f, b0, xs, L, xinv, [&](int c, f32x16 (&acc)[2]) {
         float4 y[8];
         acc_to_frag<2>(acc, y);
 #pragma unroll
@@ -1592,9 +1634,13 @@ __global__ __launch_bounds__(256) void k_head_bwd_h(const float* __restrict__ Xi
         }
     });
     if (TRAIN && valid) store_rowfrag<16>(t, t_s1, row, DH, L.h);
-    split_frag2<8>(t, xs);
+    {
+        float sc;
+        xinv = row_scale_pow2<16>(t, sc);
+        split_frag2<8>(t, xs);
+    }
     // a2 = W2 s1 + b2  ->  da2 = gy wl silu'(a2)   (t is reused for da2)
-    row_gemm128_h<2, true>(w2f, b2, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+    row_gemm128_h<2, true>(w2f, b2, xs, L, xinv, [&](int c, f32x16 (&acc)[2]) {
         float4 y[8];
         acc_to_frag<2>(acc, y);
 #pragma unroll
@@ -1830,14 +1876,14 @@ bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* M
 }
 bool trr_compress_bwd(bool first, const float* dXe, const float* a0, const GnnLayerW& G, float* dgeo, float* dM,
                       int64_t E, float* t_da0, hipStream_t st) {
-    if (!(g_bf16x6 && g_f16x3 && (g_trr_tilek & 1) && G.compress2.bwd2 && (first || G.compress0_msg.bwd2))) return false;
+    if (!(g_bf16x6 && g_f16x3 && (g_trr_tilek & 1) && G.compress2.bwd2 && G.wc2 && (first || G.compress0_msg.bwd2))) return false;
     const int grid = grid_rows(E);
     if (first) {
-        if (t_da0) k_compress_bwd_h<true, true><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), G.wct, W2(), dgeo, nullptr, E, t_da0);
-        else k_compress_bwd_h<true, false><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), G.wct, W2(), dgeo, nullptr, E, nullptr);
+        if (t_da0) k_compress_bwd_h<true, true><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), w2_wc(G), W2(), dgeo, nullptr, E, t_da0);
+        else k_compress_bwd_h<true, false><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), w2_wc(G), W2(), dgeo, nullptr, E, nullptr);
     } else {
-        if (t_da0) k_compress_bwd_h<false, true><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), G.wct, w2_bwd(G.compress0_msg), dgeo, dM, E, t_da0);
-        else k_compress_bwd_h<false, false><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), G.wct, w2_bwd(G.compress0_msg), dgeo, dM, E, nullptr);
+        if (t_da0) k_compress_bwd_h<false, true><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), w2_wc(G), w2_bwd(G.compress0_msg), dgeo, dM, E, t_da0);
+        else k_compress_bwd_h<false, false><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), w2_wc(G), w2_bwd(G.compress0_msg), dgeo, dM, E, nullptr);
     }
     return true;
 }
