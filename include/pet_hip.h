@@ -76,9 +76,11 @@ void pet_model_destroy(pet_model_t* m);
 /* Upload one tensor of the reference state dict (SURVEY §8(b) key schema, e.g.
  * "gnn_layers.0.trans.layers.1.mlp.w_in.weight"). `d_data` is a device pointer to
  * `numel` contiguous fp32 values (int64 values for "species_to_species_index").
- * Heads of ONE target are addressed with the literal target name "energy" replaced by
- * the caller's target: keys "node_heads.<t>.0.0.weight" ... are passed with <t>
- * stripped to "@" (e.g. "node_heads.@.0.0.weight", "node_last_layers.@.0.@.weight").
+ * The FUSED target (what pet_forward / the native training step evaluate; one property) is
+ * uploaded with its target and block names replaced by "@" ("node_heads.@.0.0.weight" ...,
+ * "node_last_layers.@.0.@.weight"); any further heads / last layers (other targets, blocks with
+ * P > 1 properties, other readout layers) are uploaded under their own names and served by
+ * pet_predict.
  * activation = "SiLU" (transformer.py:32-49): upload every "...w_in.weight" / "...w_in.bias" as the tensor stacked on
  * itself ([W; W], [b; b]): with equal value and gate halves the SwiGLU stage computes silu(W x + b) exactly; the
  * gradient of W is the sum of the two halves' gradients (metatrain_amd/runtime.py does both). */
@@ -149,14 +151,55 @@ int pet_graph_csr(const pet_graph_t* g, const int32_t** d_rowptr, const int32_t*
 /* ---- features + predict + gradient -------------------------------------------- */
 /* Activation workspace for one forward (+ saved tensors for the backward). */
 int64_t pet_forward_workspace_bytes(const pet_model_t* m, int64_t n_nodes, int64_t n_edges);
-/* calculate_features + predict for the single registered target:
- *   d_atomic [N]       per-atom prediction (node + sum of cutoff-weighted edge terms)
+/* calculate_features + predict for the fused target (the heads uploaded under the name "@", one property):
+ *   d_atomic [N]       per-atom prediction (node + sum of cutoff-weighted edge terms); NULL = features only
  *   d_node_features [N,d_node] / d_edge_features [E,d_pet] (CSR rows): optional copies
  *   of the backbone features (backend.py:585-586) -- may be NULL.
  * save_for_backward != 0 keeps what pet_backward needs in the workspace. */
 int pet_forward(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
                 int64_t workspace_bytes, int save_for_backward, float* d_atomic,
                 float* d_node_features, float* d_edge_features, void* stream);
+
+/* ---- the three PETBackend calls as functions of their arguments ---------------------------------
+ * pet_graph_build + pet_graph_export_batch is preprocess (backend.py:238). The two calls below take a
+ * batch_data dictionary as the reference's calculate_features / predict do (backend.py:344, :420): a graph handle
+ * made FROM the padded NEF tensors, whoever produced them -- this library's preprocess, the reference's, or a caller
+ * that edited them in between (pet/tests/test_backend.py:122-150 is the executable spec).
+ *   d_element_indices_nodes [N] i64, d_element_indices_neighbors [N,M] i64, d_edge_vectors [N,M,3] f32,
+ *   d_edge_distances [N,M] f32, d_padding_mask [N,M] u8, d_reverse_neighbor_index [N,M] i64, d_cutoff_factors [N,M] f32.
+ * Real slots are a prefix of each row (nef.py:63-85); CSR row of (i, slot) = rowptr[i] + slot. The handle holds
+ * what features / heads and their adjoints read (rowptr, ctr, nbr, rev, species, geometry, cutoff factors); it has
+ * no positions, so the geometry adjoint needs the pet_graph_build handle. One device->host read-back.
+ * predict only reads the row structure and the cutoff factors: every pointer except d_padding_mask and
+ * d_cutoff_factors may be NULL for a handle that is only passed to pet_predict / pet_predict_backward. */
+int64_t pet_graph_from_batch_workspace_bytes(int64_t n_nodes, int64_t max_neighbors);
+int pet_graph_from_batch(const int64_t* d_element_indices_nodes, const int64_t* d_element_indices_neighbors,
+                         const float* d_edge_vectors, const float* d_edge_distances, const uint8_t* d_padding_mask,
+                         const int64_t* d_reverse_neighbor_index, const float* d_cutoff_factors, int64_t n_nodes,
+                         int64_t max_neighbors, void* d_workspace, int64_t workspace_bytes, pet_graph_t** out,
+                         void* stream);
+/* calculate_features alone: pet_forward with d_atomic = NULL (no heads), d_node_features / d_edge_features out.
+ *
+ * predict (backend.py:420-494) for ONE (target, readout layer, block) on the features the caller passes:
+ *   heads node_heads.<target>.<layer> / edge_heads.<target>.<layer> (backend.py:651-687), last layers
+ *   node_last_layers.<target>.<layer>.<block> / edge_... with P properties (:689-777), edge predictions weighted by the
+ *   cutoff factor and summed per atom (:762-772), node + edge (:468-476). Summing over readout layers and blocks is
+ *   the caller's loop, as in the reference.
+ *   target / block: the names the heads were uploaded with ("@" for the fused target of pet_forward);
+ *   d_node_features [N, d_node], d_edge_features [E, d_pet] (CSR rows), d_cutoff_factors [E] (NULL = the graph's),
+ *   d_atomic [N, P] out; d_node_hidden [N, d_head] / d_edge_hidden [E, d_head] optional outs: the last-layer features
+ *   predict returns as its 2nd / 3rd value; d_scratch: pet_predict_scratch_floats(N, E) floats. */
+int32_t pet_model_block_properties(const pet_model_t* m, const char* target, int32_t readout_layer, const char* block);
+int64_t pet_predict_scratch_floats(int64_t n_nodes, int64_t n_edges);
+int pet_predict(const pet_model_t* m, const pet_graph_t* g, const char* target, int32_t readout_layer, const char* block,
+                const float* d_node_features, const float* d_edge_features, const float* d_cutoff_factors,
+                float* d_atomic, float* d_node_hidden, float* d_edge_hidden, float* d_scratch, void* stream);
+/* Its adjoint, from the same inputs (the head MLPs are recomputed; nothing is read from a forward workspace):
+ *   d_grad_atomic [N, P] -> d_grad_node_features [N, d_node], d_grad_edge_features [E, d_pet], d_grad_cutoff [E]. */
+int pet_predict_backward(const pet_model_t* m, const pet_graph_t* g, const char* target, int32_t readout_layer,
+                         const char* block, const float* d_node_features, const float* d_edge_features,
+                         const float* d_cutoff_factors, const float* d_grad_atomic, float* d_grad_node_features,
+                         float* d_grad_edge_features, float* d_grad_cutoff, float* d_scratch, void* stream);
 
 /* Auxiliary per-atom outputs of pet/model.py:730-875 ("feature" and "mtt::aux::<target>_last_layer_features"),
  * from the backbone features pet_forward returned (same graph):
@@ -195,6 +238,12 @@ int pet_backward_features(const pet_model_t* m, const pet_graph_t* g, void* d_wo
 int pet_backward_geometry(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
                           int64_t workspace_bytes, const float* d_grad_geometry,
                           const float* d_grad_cutoff, float* d_grad_positions, float* d_grad_cells,
+                          void* stream);
+
+/* preprocess^T without a forward workspace (the autograd node of preprocess on its own):
+ * d_scratch: 4 * n_edges floats. Needs the pet_graph_build handle (positions, shifts). */
+int pet_geometry_backward(const pet_model_t* m, const pet_graph_t* g, const float* d_grad_geometry,
+                          const float* d_grad_cutoff, float* d_grad_positions, float* d_grad_cells, float* d_scratch,
                           void* stream);
 
 /* ---- training step (trainer.py:391-480) ---------------- */

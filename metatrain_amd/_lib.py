@@ -28,6 +28,8 @@ SYMBOLS = [
     "pet_nl_workspace_bytes", "pet_nl_build",
     "pet_graph_workspace_bytes", "pet_graph_build", "pet_graph_destroy", "pet_graph_num_edges",
     "pet_graph_max_neighbors", "pet_graph_export_batch", "pet_graph_csr",
+    "pet_graph_from_batch_workspace_bytes", "pet_graph_from_batch", "pet_model_block_properties",
+    "pet_predict_scratch_floats", "pet_predict", "pet_predict_backward", "pet_geometry_backward",
     "pet_forward_workspace_bytes", "pet_forward", "pet_aux_outputs", "pet_backward", "pet_backward_predict",
     "pet_backward_features", "pet_backward_geometry",
     "pet_model_zero_grad", "pet_model_get_grad", "pet_train_workspace_bytes", "pet_backward_train",
@@ -130,6 +132,16 @@ def load() -> ctypes.CDLL:
     lib.pet_graph_max_neighbors.restype = c_int32
     lib.pet_graph_export_batch.argtypes = [P] + [P] * 12 + [P]
     lib.pet_graph_csr.argtypes = [P, POINTER(P), POINTER(P), POINTER(P), POINTER(P)]
+    lib.pet_graph_from_batch_workspace_bytes.argtypes = [c_int64, c_int64]
+    lib.pet_graph_from_batch_workspace_bytes.restype = c_int64
+    lib.pet_graph_from_batch.argtypes = [P] * 7 + [c_int64, c_int64, P, c_int64, POINTER(P), P]
+    lib.pet_model_block_properties.argtypes = [P, c_char_p, c_int32, c_char_p]
+    lib.pet_model_block_properties.restype = c_int32
+    lib.pet_predict_scratch_floats.argtypes = [c_int64, c_int64]
+    lib.pet_predict_scratch_floats.restype = c_int64
+    lib.pet_predict.argtypes = [P, P, c_char_p, c_int32, c_char_p, P, P, P, P, P, P, P, P]
+    lib.pet_predict_backward.argtypes = [P, P, c_char_p, c_int32, c_char_p, P, P, P, P, P, P, P, P, P]
+    lib.pet_geometry_backward.argtypes = [P, P, P, P, P, P, P, P]
     lib.pet_forward_workspace_bytes.argtypes = [P, c_int64, c_int64]
     lib.pet_forward_workspace_bytes.restype = c_int64
     lib.pet_forward.argtypes = [P, P, P, c_int64, c_int, P, P, P, P]

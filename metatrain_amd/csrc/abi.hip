@@ -297,18 +297,58 @@ int finalize(Model& m, hipStream_t st) {
     }
     if ((rc = get(m, "node_embedders.0.weight", (int64_t)ns * DN, &m.node_emb))) return rc;
     if ((rc = get(m, "edge_embedder.weight", (int64_t)ns * D, &m.edge_emb))) return rc;
-    if ((rc = get_lin(m, "node_heads.@.0.0", DH, DN, m.nh0, st))) return rc;
-    if ((rc = get_lin(m, "node_heads.@.0.2", DH, DH, m.nh2, st))) return rc;
-    if ((rc = get_lin(m, "edge_heads.@.0.0", DH, D, m.eh0, st))) return rc;
-    if ((rc = get_lin(m, "edge_heads.@.0.2", DH, DH, m.eh2, st))) return rc;
-    const float *nb, *eb;
-    if ((rc = get(m, "node_last_layers.@.0.@.weight", DH, &m.nll_w))) return rc;
-    if ((rc = get(m, "edge_last_layers.@.0.@.weight", DH, &m.ell_w))) return rc;
-    if ((rc = get(m, "node_last_layers.@.0.@.bias", 1, &nb))) return rc;
-    if ((rc = get(m, "edge_last_layers.@.0.@.bias", 1, &eb))) return rc;
-    PET_HIP_CHECK(hipMemcpyAsync(&m.nll_b, nb, sizeof(float), hipMemcpyDeviceToHost, st));
-    PET_HIP_CHECK(hipMemcpyAsync(&m.ell_b, eb, sizeof(float), hipMemcpyDeviceToHost, st));
-    PET_HIP_CHECK(hipStreamSynchronize(st));
+    // every head that was uploaded: "node_heads.<t>.<l>.0.weight" names a (target, readout layer); "node_last_layers.
+    // <t>.<l>.<block>.weight" a block of P = numel / DH properties (backend.py:171-217). "@" is the fused target.
+    m.heads.clear();
+    m.lasts.clear();
+    std::vector<std::pair<std::string, std::string>> head_ids, last_ids;
+    for (const auto& kv : m.raw) {
+        const std::string& k = kv.first;
+        auto field = [&](int i) {  // i-th dot-separated field
+            size_t a = 0;
+            for (int n = 0; n < i; n++) a = k.find('.', a) + 1;
+            return k.substr(a, k.find('.', a) - a);
+        };
+        if (k.rfind("node_heads.", 0) == 0 && k.size() > 9 && k.compare(k.size() - 9, 9, ".0.weight") == 0)
+            head_ids.push_back({field(1), field(2)});
+        if (k.rfind("node_last_layers.", 0) == 0 && k.compare(k.size() - 7, 7, ".weight") == 0) {
+            // the block name may itself contain dots: everything between the layer field and ".weight"
+            const size_t a = std::string("node_last_layers.").size() + field(1).size() + 1 + field(2).size() + 1;
+            last_ids.push_back({field(1) + "." + field(2), k.substr(a, k.size() - 7 - a)});
+        }
+    }
+    for (const auto& id : head_ids) {
+        HeadW& H = m.heads[id.first + "|" + id.second];
+        const std::string tl = id.first + "." + id.second;
+        if ((rc = get_lin(m, "node_heads." + tl + ".0", DH, DN, H.nh0, st))) return rc;
+        if ((rc = get_lin(m, "node_heads." + tl + ".2", DH, DH, H.nh2, st))) return rc;
+        if ((rc = get_lin(m, "edge_heads." + tl + ".0", DH, D, H.eh0, st))) return rc;
+        if ((rc = get_lin(m, "edge_heads." + tl + ".2", DH, DH, H.eh2, st))) return rc;
+    }
+    for (const auto& id : last_ids) {
+        const std::string key = id.first + "." + id.second;  // <t>.<l>.<block>
+        LastW Lw;
+        const auto it = m.raw.find("node_last_layers." + key + ".weight");
+        Lw.P = (int)(it->second.second / DH);
+        PET_REQUIRE(Lw.P >= 1 && (int64_t)Lw.P * DH == it->second.second, PET_ERR_ARGUMENT, "bad last-layer shape: " + key);
+        if ((rc = get(m, "node_last_layers." + key + ".weight", (int64_t)Lw.P * DH, &Lw.nw))) return rc;
+        if ((rc = get(m, "node_last_layers." + key + ".bias", Lw.P, &Lw.nb))) return rc;
+        if ((rc = get(m, "edge_last_layers." + key + ".weight", (int64_t)Lw.P * DH, &Lw.ew))) return rc;
+        if ((rc = get(m, "edge_last_layers." + key + ".bias", Lw.P, &Lw.eb))) return rc;
+        std::string tl = id.first;
+        tl[tl.rfind('.')] = '|';
+        m.lasts[tl + "|" + id.second] = Lw;
+    }
+    m.has_fused_head = m.heads.count("@|0") && m.lasts.count("@|0|@") && m.lasts["@|0|@"].P == 1;
+    if (m.has_fused_head) {
+        const HeadW& H = m.heads["@|0"];
+        const LastW& Lw = m.lasts["@|0|@"];
+        m.nh0 = H.nh0; m.nh2 = H.nh2; m.eh0 = H.eh0; m.eh2 = H.eh2;
+        m.nll_w = Lw.nw; m.ell_w = Lw.ew;
+        PET_HIP_CHECK(hipMemcpyAsync(&m.nll_b, Lw.nb, sizeof(float), hipMemcpyDeviceToHost, st));
+        PET_HIP_CHECK(hipMemcpyAsync(&m.ell_b, Lw.eb, sizeof(float), hipMemcpyDeviceToHost, st));
+        PET_HIP_CHECK(hipStreamSynchronize(st));
+    }
     PET_REQUIRE(m.species_table != nullptr, PET_ERR_ARGUMENT, "missing species_to_species_index");
     m.finalized = true;
     return PET_OK;
@@ -550,10 +590,105 @@ int64_t pet_forward_workspace_bytes(const pet_model_t* pm, int64_t n_nodes, int6
 int pet_forward(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                 int save_for_backward, float* d_atomic, float* d_node_features, float* d_edge_features,
                 void* stream) {
-    PET_REQUIRE(pm && pg && d_workspace && d_atomic, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(pm && pg && d_workspace, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(d_atomic || d_node_features || save_for_backward, PET_ERR_ARGUMENT,
+                "nothing to compute: d_atomic and d_node_features are both NULL");
     PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
     return forward(pm->m, pg->g, d_workspace, workspace_bytes, save_for_backward, d_atomic, d_node_features,
                    d_edge_features, (hipStream_t)stream);
+}
+
+// ---- predict as a function of its arguments ---------------------------------------------------------------------
+static int find_head(const Model& m, const char* target, int32_t layer, const char* block, const HeadW** H, const LastW** Lw) {
+    PET_REQUIRE(target && block, PET_ERR_ARGUMENT, "null target / block name");
+    const std::string hk = std::string(target) + "|" + std::to_string(layer);
+    const auto hi = m.heads.find(hk);
+    PET_REQUIRE(hi != m.heads.end(), PET_ERR_ARGUMENT, "no heads were uploaded for target '" + std::string(target) +
+                                                           "', readout layer " + std::to_string(layer));
+    const auto li = m.lasts.find(hk + "|" + block);
+    PET_REQUIRE(li != m.lasts.end(), PET_ERR_ARGUMENT, "no last layer was uploaded for block '" + std::string(block) + "' of target '" +
+                                                           std::string(target) + "'");
+    *H = &hi->second;
+    *Lw = &li->second;
+    return PET_OK;
+}
+
+int32_t pet_model_block_properties(const pet_model_t* pm, const char* target, int32_t readout_layer, const char* block) {
+    if (!pm || !pm->m.finalized) return -1;
+    const HeadW* H;
+    const LastW* Lw;
+    if (find_head(pm->m, target, readout_layer, block, &H, &Lw) != PET_OK) return -1;
+    return Lw->P;
+}
+
+int64_t pet_predict_scratch_floats(int64_t n_nodes, int64_t n_edges) { return predict_scratch_floats(n_nodes, n_edges); }
+
+int pet_predict(const pet_model_t* pm, const pet_graph_t* pg, const char* target, int32_t readout_layer, const char* block,
+                const float* d_node_features, const float* d_edge_features, const float* d_cutoff_factors, float* d_atomic,
+                float* d_node_hidden, float* d_edge_hidden, float* d_scratch, void* stream) {
+    PET_REQUIRE(pm && pg && d_node_features && d_atomic && d_scratch, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(d_edge_features || pg->g.n_edges == 0, PET_ERR_ARGUMENT, "null edge features");
+    PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
+    const HeadW* H;
+    const LastW* Lw;
+    int rc = find_head(pm->m, target, readout_layer, block, &H, &Lw);
+    if (rc) return rc;
+    return predict(pm->m, pg->g, *H, *Lw, d_node_features, d_edge_features, d_cutoff_factors, d_atomic, d_node_hidden,
+                   d_edge_hidden, d_scratch, (hipStream_t)stream);
+}
+
+int pet_predict_backward(const pet_model_t* pm, const pet_graph_t* pg, const char* target, int32_t readout_layer,
+                         const char* block, const float* d_node_features, const float* d_edge_features,
+                         const float* d_cutoff_factors, const float* d_grad_atomic, float* d_grad_node_features,
+                         float* d_grad_edge_features, float* d_grad_cutoff, float* d_scratch, void* stream) {
+    PET_REQUIRE(pm && pg && d_node_features && d_grad_atomic && d_grad_node_features && d_scratch, PET_ERR_ARGUMENT,
+                "null argument");
+    PET_REQUIRE((d_edge_features && d_grad_edge_features && d_grad_cutoff) || pg->g.n_edges == 0, PET_ERR_ARGUMENT,
+                "null edge argument");
+    PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
+    const HeadW* H;
+    const LastW* Lw;
+    int rc = find_head(pm->m, target, readout_layer, block, &H, &Lw);
+    if (rc) return rc;
+    return predict_backward(pm->m, pg->g, *H, *Lw, d_node_features, d_edge_features, d_cutoff_factors, d_grad_atomic,
+                            d_grad_node_features, d_grad_edge_features, d_grad_cutoff, d_scratch, (hipStream_t)stream);
+}
+
+int pet_geometry_backward(const pet_model_t* pm, const pet_graph_t* pg, const float* d_grad_geometry,
+                          const float* d_grad_cutoff, float* d_grad_positions, float* d_grad_cells, float* d_scratch,
+                          void* stream) {
+    PET_REQUIRE(pm && pg && d_grad_positions, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(pg->g.n_edges == 0 || (d_grad_geometry && d_grad_cutoff && d_scratch), PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(pg->g.d0 != nullptr, PET_ERR_ARGUMENT,
+                "this graph was made from batch_data and has no positions: use the pet_graph_build handle");
+    return geometry_backward(pm->m, pg->g, d_grad_geometry, d_grad_cutoff, d_grad_positions, d_grad_cells, d_scratch,
+                             (hipStream_t)stream);
+}
+
+int64_t pet_graph_from_batch_workspace_bytes(int64_t n_nodes, int64_t max_neighbors) {
+    return graph_from_batch_workspace_bytes(n_nodes, max_neighbors);
+}
+
+int pet_graph_from_batch(const int64_t* d_element_indices_nodes, const int64_t* d_element_indices_neighbors,
+                         const float* d_edge_vectors, const float* d_edge_distances, const uint8_t* d_padding_mask,
+                         const int64_t* d_reverse_neighbor_index, const float* d_cutoff_factors, int64_t n_nodes,
+                         int64_t max_neighbors, void* d_workspace, int64_t workspace_bytes, pet_graph_t** out, void* stream) {
+    PET_REQUIRE(out && d_workspace && n_nodes >= 0 && max_neighbors >= 0, PET_ERR_ARGUMENT, "bad argument");
+    PET_REQUIRE(n_nodes * max_neighbors == 0 || (d_padding_mask && d_cutoff_factors), PET_ERR_ARGUMENT,
+                "padding_mask and cutoff_factors are required");
+    PET_REQUIRE((d_edge_vectors == nullptr) == (d_edge_distances == nullptr), PET_ERR_ARGUMENT,
+                "edge_vectors and edge_distances come together");
+    pet_graph_t* pg = new pet_graph_t();
+    pg->cutoff = 0.f;
+    int rc = graph_from_batch(d_element_indices_nodes, d_element_indices_neighbors, d_edge_vectors, d_edge_distances,
+                              d_padding_mask, d_reverse_neighbor_index, d_cutoff_factors, n_nodes, max_neighbors,
+                              d_workspace, workspace_bytes, pg->g, (hipStream_t)stream);
+    if (rc != PET_OK) {
+        delete pg;
+        return rc;
+    }
+    *out = pg;
+    return PET_OK;
 }
 
 int pet_aux_outputs(const pet_model_t* pm, const pet_graph_t* pg, const float* d_node_features,

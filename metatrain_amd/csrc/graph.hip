@@ -560,6 +560,131 @@ int graph_export(const Graph& g, float cutoff, int64_t* el_nodes, int64_t* el_nb
     return PET_OK;
 }
 
+// ----------------------------------------------------------------------------------
+// CSR graph FROM the reference's padded batch_data tensors (backend.py:328-341): what calculate_features / predict
+// need of a batch_data dictionary they are handed -- whoever built it (this library's preprocess, the reference's,
+// or a caller that edited it). Real slots are a prefix of every row (nef.py:63-85), so
+//   rowptr = exclusive scan of the row counts of padding_mask, CSR row p = rowptr[i] + slot,
+//   reverse_neighbor_index[i][slot] = j * M + slot_j  ->  rev[p] = rowptr[j] + slot_j, nbr[p] = j.
+// Only what the feature / head kernels and their adjoints read is filled: rowptr, ctr, nbr, rev, sp, sp_nbr, geo, fc.
+// ----------------------------------------------------------------------------------
+__global__ void k_mask_counts(const uint8_t* __restrict__ mask, int n, int M, int* __restrict__ counts,
+                              int* __restrict__ scalars) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0;
+    if (i < n) {
+        for (int k = 0; k < M; k++) c += mask[(int64_t)i * M + k] ? 1 : 0;
+        // a real slot after a pad would break the prefix layout: counted, reported by the host
+        int prefix = 0;
+        while (prefix < M && mask[(int64_t)i * M + prefix]) prefix++;
+        if (prefix != c) atomicAdd(&scalars[2], 1);
+        counts[i] = c;
+    }
+    int v = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(&scalars[1], v);
+}
+__global__ void k_from_batch_fill(const int64_t* __restrict__ el_nodes, const int64_t* __restrict__ el_nbr,
+                                  const float* __restrict__ ev, const float* __restrict__ ed,
+                                  const int64_t* __restrict__ rni, const float* __restrict__ cf,
+                                  const int* __restrict__ rowptr, int n, int M, int* __restrict__ ctr,
+                                  int* __restrict__ nbr, int* __restrict__ rev, int* __restrict__ sp,
+                                  int* __restrict__ sp_nbr, float4* __restrict__ geo, float* __restrict__ fc,
+                                  int* __restrict__ scalars) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n * M) return;
+    const int i = (int)(idx / M), k = (int)(idx % M);
+    // any of el_nodes / el_nbr / ev + ed / rni may be NULL: predict only needs the row structure and the cutoff factors
+    if (k == 0) sp[i] = el_nodes ? (int)el_nodes[i] : 0;
+    const int cnt = rowptr[i + 1] - rowptr[i];
+    if (k >= cnt) return;
+    const int p = rowptr[i] + k;
+    ctr[p] = i;
+    if (rni) {
+        const int64_t r = rni[idx];
+        const int j = (int)(r / M), kj = (int)(r % M);
+        const bool ok = r >= 0 && j < n && kj < rowptr[j + 1] - rowptr[j];
+        if (!ok) atomicAdd(&scalars[2], 1);
+        nbr[p] = ok ? j : i;
+        rev[p] = ok ? rowptr[j] + kj : p;
+    } else {
+        nbr[p] = i;
+        rev[p] = p;
+    }
+    sp_nbr[p] = el_nbr ? (int)el_nbr[idx] : 0;
+    geo[p] = ev ? make_float4(ev[3 * idx], ev[3 * idx + 1], ev[3 * idx + 2], ed[idx]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    fc[p] = cf[idx];
+}
+
+static int carve_from_batch(Graph& g, void* ws, int64_t n_nodes, int64_t M, size_t* total) {
+    Carver c(ws);
+    const int64_t cap = n_nodes * M > 0 ? n_nodes * M : 1;
+    g.rowptr = c.take<int>(n_nodes + 1);
+    g.kidx = c.take<int>(n_nodes + 1);  // row counts (scan input)
+    g.ctr = c.take<int>(cap);
+    g.nbr = c.take<int>(cap);
+    g.rev = c.take<int>(cap);
+    g.sp = c.take<int>(n_nodes > 0 ? n_nodes : 1);
+    g.sp_nbr = c.take<int>(cap);
+    g.geo = c.take<float4>(cap);
+    g.fc = c.take<float>(cap);
+    g.scalars = c.take<int>(8);
+    size_t scan_bytes = 0;
+    int* ni = nullptr;
+    if (rocprim::exclusive_scan(nullptr, scan_bytes, ni, ni, 0, (size_t)(n_nodes + 1), rocprim::plus<int>()) != hipSuccess)
+        return PET_ERR_HIP;
+    g.scan_tmp_bytes = scan_bytes;
+    g.scan_tmp = c.take<char>(scan_bytes + 256);
+    *total = c.off;
+    return PET_OK;
+}
+
+int64_t graph_from_batch_workspace_bytes(int64_t n_nodes, int64_t max_nbr) {
+    Graph g;
+    size_t total = 0;
+    if (carve_from_batch(g, nullptr, n_nodes, max_nbr, &total) != PET_OK) return -1;
+    return (int64_t)total;
+}
+
+int graph_from_batch(const int64_t* el_nodes, const int64_t* el_nbr, const float* ev, const float* ed, const uint8_t* mask,
+                     const int64_t* rni, const float* cf, int64_t n_nodes, int64_t M, void* ws, int64_t ws_bytes, Graph& g,
+                     hipStream_t st) {
+    size_t need = 0;
+    int rc = carve_from_batch(g, ws, n_nodes, M, &need);
+    if (rc != PET_OK) return rc;
+    PET_REQUIRE((int64_t)need <= ws_bytes, PET_ERR_ARGUMENT, "graph-from-batch workspace too small");
+    g.n_nodes = n_nodes;
+    g.n_edges_in = n_nodes * M;
+    g.n_systems = 0;
+    g.adaptive = false;
+    const int T = 256;
+    PET_HIP_CHECK(hipMemsetAsync(g.scalars, 0, 8 * sizeof(int), st));
+    PET_HIP_CHECK(hipMemsetAsync(g.kidx, 0, (n_nodes + 1) * sizeof(int), st));
+    if (n_nodes > 0 && M > 0)
+        k_mask_counts<<<cdiv(n_nodes, T), T, 0, st>>>(mask, (int)n_nodes, (int)M, g.kidx, g.scalars);
+    size_t cb = g.scan_tmp_bytes;
+    PET_HIP_CHECK(rocprim::exclusive_scan(g.scan_tmp, cb, g.kidx, g.rowptr, 0, (size_t)(n_nodes + 1), rocprim::plus<int>(), st));
+    if (n_nodes > 0 && M > 0)
+        k_from_batch_fill<<<cdiv(n_nodes * M, T), T, 0, st>>>(el_nodes, el_nbr, ev, ed, rni, cf, g.rowptr, (int)n_nodes, (int)M,
+                                                              g.ctr, g.nbr, g.rev, g.sp, g.sp_nbr, g.geo, g.fc, g.scalars);
+    else if (n_nodes > 0)
+        k_from_batch_fill<<<cdiv(n_nodes, T), T, 0, st>>>(el_nodes, el_nbr, ev, ed, rni, cf, g.rowptr, (int)n_nodes, 1, g.ctr,
+                                                          g.nbr, g.rev, g.sp, g.sp_nbr, g.geo, g.fc, g.scalars);
+    int host_scalars[8] = {0};
+    int n_edges = 0;
+    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+    PET_HIP_CHECK(hipMemcpyAsync(&n_edges, g.rowptr + n_nodes, sizeof(int), hipMemcpyDeviceToHost, st));
+    PET_HIP_CHECK(hipStreamSynchronize(st));
+    g.n_edges = n_edges;
+    g.max_nbr = host_scalars[1];
+    PET_REQUIRE(host_scalars[2] == 0, PET_ERR_GRAPH,
+                "batch_data is not a NEF batch: " + std::to_string(host_scalars[2]) +
+                    " rows with a real slot behind a pad, or reverse_neighbor_index entries that do not point at a real slot");
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
 int sum_over_atoms(const Graph& g, const float* atomic, float* out, hipStream_t st) {
     if (g.n_systems > 0)  // systems without atoms get 0
         k_sum_over_atoms<<<(int)g.n_systems, 256, 0, st>>>(atomic, g.sys, out, (int)g.n_nodes);

@@ -52,6 +52,16 @@ struct GnnLayerW {
     const float *ln_g = nullptr, *ln_b = nullptr;
 };
 
+// Heads of one (target, readout layer): node_heads.<t>.<l>.{0,2}, edge_heads.<t>.<l>.{0,2} (backend.py:171-217);
+// last layers of one (target, readout layer, block): [P, DH] weights + [P] biases, node and edge (P = properties).
+struct HeadW {
+    Lin nh0, nh2, eh0, eh2;
+};
+struct LastW {
+    const float *nw = nullptr, *nb = nullptr, *ew = nullptr, *eb = nullptr;
+    int P = 0;
+};
+
 struct Model {
     pet_hypers_t h;
     std::map<std::string, std::pair<float*, int64_t>> raw;  // device copies
@@ -60,9 +70,14 @@ struct Model {
     std::vector<GnnLayerW> gnn;
     const float* node_emb = nullptr;  // [ns, DN]
     const float* edge_emb = nullptr;  // [ns, D]
+    // the FUSED target (keys with "@" for target and block: pet_forward / the native training step): one property
+    bool has_fused_head = false;
     Lin nh0, nh2, eh0, eh2;
     const float *nll_w = nullptr, *ell_w = nullptr;  // [DH]
     float nll_b = 0.f, ell_b = 0.f;
+    // every head uploaded (the fused one included, under "@"), for pet_predict: key "<target>|<layer>" / "...|<block>"
+    std::map<std::string, HeadW> heads;
+    std::map<std::string, LastW> lasts;
     std::vector<void*> owned;  // device allocations to free
     std::map<std::string, std::pair<void*, size_t>> named;  // derived buffers, reused across finalize calls
     bool finalized = false;
@@ -93,6 +108,10 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
                 int64_t n_nodes, int64_t e0, int64_t n_systems, void* ws, int64_t ws_bytes,
                 Graph& g, hipStream_t st);
 int graph_check_reverse(Graph& g, hipStream_t st);
+int64_t graph_from_batch_workspace_bytes(int64_t n_nodes, int64_t max_nbr);
+int graph_from_batch(const int64_t* el_nodes, const int64_t* el_nbr, const float* ev, const float* ed, const uint8_t* mask,
+                     const int64_t* rni, const float* cf, int64_t n_nodes, int64_t max_nbr, void* ws, int64_t ws_bytes,
+                     Graph& g, hipStream_t st);
 int graph_export(const Graph& g, float cutoff, int64_t* el_nodes, int64_t* el_nbr, float* ev,
                  float* ed, uint8_t* mask, int64_t* rni, float* cf, float* stats, int64_t* centers,
                  int64_t* neighbors, int64_t* slot, int64_t* shifts, hipStream_t st);
@@ -110,6 +129,12 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
             float* node_feat, float* edge_feat, hipStream_t st);
 int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* grad_atomic,
              float* grad_pos, float* grad_cells, hipStream_t st);
+int64_t predict_scratch_floats(int64_t n_nodes, int64_t n_edges);
+int predict(const Model& m, const Graph& g, const HeadW& H, const LastW& Lw, const float* node_feat, const float* edge_feat,
+            const float* fc, float* atomic, float* node_hidden, float* edge_hidden, float* scratch, hipStream_t st);
+int predict_backward(const Model& m, const Graph& g, const HeadW& H, const LastW& Lw, const float* node_feat,
+                     const float* edge_feat, const float* fc, const float* grad_atomic, float* g_node, float* g_edge,
+                     float* g_fc, float* scratch, hipStream_t st);
 int aux_outputs(const Model& m, const Graph& g, const float* node_feat, const float* edge_feat, float* feature,
                 float* last_layer, float* scratch, hipStream_t st);
 int backward_train(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* grad_atomic,
@@ -123,6 +148,8 @@ int backward_predict_abi(const Model& m, const Graph& g, void* ws, int64_t ws_by
                          float* g_node, float* g_edge, float* g_fc, hipStream_t st);
 int backward_features_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_node,
                           const float* g_edge, float* g_geo, float* g_fc, hipStream_t st);
+int geometry_backward(const Model& m, const Graph& g, const float* g_geo, const float* g_fc, float* gpos, float* gcell,
+                      float* scratch, hipStream_t st);
 int backward_geometry_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_geo,
                           const float* g_fc, float* grad_pos, float* grad_cells, hipStream_t st);
 

@@ -58,7 +58,10 @@ __device__ __forceinline__ void rmsnorm_bwd_rows(const float* Wt, const float* _
 // ---------------------------------------------------------------------------------
 // heads
 // ---------------------------------------------------------------------------------
-template <int K, bool EDGE, bool TRAIN>
+// GEN (pet_predict_backward: any number of properties, features given by the caller): the gradient w.r.t. the head's
+// hidden row arrives as a per-atom row Gd[atom][DH] = sum_p gA[atom][p] Wl[p][:] (instead of gA[atom] * wl), and the
+// cutoff-factor gradient is dfc = Gd[atom] . hidden + gb[atom] (gb = sum_p gA[atom][p] bl[p]) from the recomputed hidden row.
+template <int K, bool EDGE, bool TRAIN, bool GEN = false>
 __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__ Xin, WX w0f,
                                                         const float* __restrict__ b0, WX w2f,
                                                         const float* __restrict__ b2, WX w0b,
@@ -67,13 +70,16 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
                                                         const float* __restrict__ fc, const float* __restrict__ ypred,
                                                         float* __restrict__ dfc, float* __restrict__ dXout, int64_t R,
                                                         float* __restrict__ t_s1, float* __restrict__ t_da2,
-                                                        float* __restrict__ t_da1, float* __restrict__ t_s2y) {
+                                                        float* __restrict__ t_da1, float* __restrict__ t_s2y,
+                                                        const float* __restrict__ Gd = nullptr,
+                                                        const float* __restrict__ gb = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDK = lds_ld(K);
     float* A = smem;
     float* S = smem + BM * LDK;
     float* gy = S + BM * LD128;  // [64]
     float* rs = gy + BM;         // [64][2] power-of-two row scales of the adjoint tiles (f16x3 GEMMs)
+    int* at = reinterpret_cast<int*>(rs + 2 * BM);  // [64] GEN: atom of the row (Gd / gb row index)
     const WaveId w;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     load_rows_to_lds<K>(A, Xin, row0, R, K);
@@ -81,13 +87,18 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
         const int64_t row = row0 + threadIdx.x;
         float g = 0.f;
         if (row < R) {
-            if (EDGE) {
+            if (GEN) {
+                g = EDGE ? fc[row] : 1.0f;
+                at[threadIdx.x] = EDGE ? ctr[row] : (int)row;
+            } else if (EDGE) {
                 const float ga = gA[ctr[row]];
                 g = ga * fc[row];
                 dfc[row] = ga * ypred[row];  // d(y fc)/dfc
             } else {
                 g = gA[row];
             }
+        } else if (GEN) {
+            at[threadIdx.x] = 0;
         }
         gy[threadIdx.x] = g;
     }
@@ -112,9 +123,27 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
     acc_fill_bias<2>(acc, b2, 64 * w.ch, w.lane);
     gemm_acc_x<128, 2>(S + w.rb * 32 * LD128, LD128, w2f, 16, 0, 2 * w.ch, acc, w.lane, w2f.h ? rs + 64 * w.rb : nullptr);
     __syncthreads();
+    if (GEN && EDGE) {  // dfc[row] = Gd[atom] . silu(a2) + gb[atom]
+        acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
+            S[r * LD128 + c] = siluf_(v) * Gd[(int64_t)at[r] * DH + c];
+        });
+        __syncthreads();
+        {
+            const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+            float sum = 0.f;
+            for (int c = q * 4; c < 128; c += 16) {
+                const float4 v = *reinterpret_cast<float4*>(S + r * LD128 + c);
+                sum += v.x + v.y + v.z + v.w;
+            }
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            if (q == 0 && row0 + r < R) dfc[row0 + r] = sum + gb[at[r]];
+        }
+        __syncthreads();
+    }
     // da2 = gy * wl * silu'(a2)
     acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
-        const float d2 = gy[r] * wl[c] * silu_grad_(v);
+        const float d2 = gy[r] * (GEN ? Gd[(int64_t)at[r] * DH + c] : wl[c]) * silu_grad_(v);
         S[r * LD128 + c] = d2;
         if (TRAIN && row0 + r < R) {
             t_da2[(row0 + r) * DH + c] = d2;
@@ -1069,6 +1098,51 @@ int backward_geometry(const Model& m, const Graph& g, Workspace& w, const float*
     return PET_OK;
 }
 
+// Gn[i][c] = sum_p gA[i][p] Wn[p][c], Ge likewise with We, gb[i] = sum_p gA[i][p] be[p]
+__global__ void k_last_bwd(const float* __restrict__ gA, const float* __restrict__ nw, const float* __restrict__ ew,
+                           const float* __restrict__ eb, int P, float* __restrict__ Gn, float* __restrict__ Ge,
+                           float* __restrict__ gbv, int n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n * DH) return;
+    const int i = (int)(idx / DH), c = (int)(idx % DH);
+    float a = 0.f, b = 0.f, s = 0.f;
+    for (int p = 0; p < P; p++) {
+        const float gv = gA[(int64_t)i * P + p];
+        a = fmaf(gv, nw[(int64_t)p * DH + c], a);
+        b = fmaf(gv, ew[(int64_t)p * DH + c], b);
+        s = fmaf(gv, eb[p], s);
+    }
+    Gn[idx] = a;
+    Ge[idx] = b;
+    if (c == 0) gbv[i] = s;
+}
+
+// adjoint of predict() (pet_fwd.hip) for the features the caller passes in
+int predict_backward(const Model& m, const Graph& g, const HeadW& H, const LastW& Lw, const float* node_feat,
+                     const float* edge_feat, const float* fc, const float* gA, float* g_node, float* g_edge, float* g_fc,
+                     float* scratch, hipStream_t st) {
+    const int64_t N = g.n_nodes, E = g.n_edges;
+    if (N == 0) return PET_OK;
+    float* Gn = scratch;
+    float* Ge = scratch + N * DH;
+    float* gbv = Ge + N * DH;
+    if (!fc) fc = g.fc;
+    const int gE = cdiv(E, BM), gN = cdiv(N, BM);
+    const size_t ldsn = (BM * LD256 + BM * LD128) * 4 + 768 + BM * 4, ldse = 2 * BM * LD128 * 4 + 768 + BM * 4;
+    allow_big_lds(k_head_bwd<256, false, false, true>, ldsn);
+    allow_big_lds(k_head_bwd<128, true, false, true>, ldse);
+    k_last_bwd<<<cdiv(N * DH, 256), 256, 0, st>>>(gA, Lw.nw, Lw.ew, Lw.eb, Lw.P, Gn, Ge, gbv, (int)N);
+    k_head_bwd<256, false, false, true><<<gN, NTHREADS, ldsn, st>>>(
+        node_feat, wx_f(H.nh0), H.nh0.b, wx_f(H.nh2), H.nh2.b, wx_b(H.nh0), wx_b(H.nh2), nullptr, nullptr, nullptr, nullptr,
+        nullptr, nullptr, g_node, N, nullptr, nullptr, nullptr, nullptr, Gn, gbv);
+    if (E > 0)
+        k_head_bwd<128, true, false, true><<<gE, NTHREADS, ldse, st>>>(
+            edge_feat, wx_f(H.eh0), H.eh0.b, wx_f(H.eh2), H.eh2.b, wx_b(H.eh0), wx_b(H.eh2), nullptr, nullptr, g.ctr, fc,
+            nullptr, g_fc, g_edge, E, nullptr, nullptr, nullptr, nullptr, Ge, gbv);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
 #define PET_CARVE(w)                                                                      \
     Workspace w;                                                                          \
     carve_workspace(m, g.n_nodes, g.n_edges, ws, w);                                      \
@@ -1107,6 +1181,15 @@ int backward_features_abi(const Model& m, const Graph& g, void* ws, int64_t ws_b
 int backward_geometry_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_geo,
                           const float* g_fc, float* gpos, float* gcell, hipStream_t st) {
     PET_CARVE(w);
+    if (g.n_nodes == 0) return PET_OK;
+    return backward_geometry(m, g, w, g_geo, g_fc, nullptr, gpos, gcell, st);
+}
+
+// preprocess^T on its own: only the d/d(edge vector) buffer is needed, not a forward workspace
+int geometry_backward(const Model& m, const Graph& g, const float* g_geo, const float* g_fc, float* gpos, float* gcell,
+                      float* scratch, hipStream_t st) {
+    Workspace w;
+    w.dv = scratch;
     if (g.n_nodes == 0) return PET_OK;
     return backward_geometry(m, g, w, g_geo, g_fc, nullptr, gpos, gcell, st);
 }

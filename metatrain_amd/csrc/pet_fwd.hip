@@ -747,19 +747,24 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
         }
     }
     const GnnBufs& last = w.gnn.back();
-    {
+    if (atomic) {
+        PET_REQUIRE(m.has_fused_head, PET_ERR_ARGUMENT,
+                    "pet_forward with d_atomic needs the fused single-property target (keys 'node_heads.@...'); use "
+                    "pet_predict for other heads");
+    }
+    if (atomic) {
         ProfScope ps("head_node", s2, fN * 2.0 * (DN * DH + DH * DH + DH));
         k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, s2>>>(
             last.Hout, wx_fwd(m.nh0, 32), m.nh0.b, wx_fwd(m.nh2, 32), m.nh2.b, m.nll_w, m.nll_b, nullptr, nullptr, w.ynode, N);
     }
-    if (E > 0) {
+    if (atomic && E > 0) {
         ProfScope ps("head_edge", st, fE * 2.0 * (D * DH + DH * DH + DH));
         if (!(trr && trr_head_edge(m, last.Mout, g.fc, w.ypred_e, w.ye, E, st)))
         k_head<128><<<gE, NTHREADS, lds2 + BM * 8, st>>>(last.Mout, wx_fwd(m.eh0, 64), m.eh0.b, wx_fwd(m.eh2, 64), m.eh2.b, m.ell_w,
                                                 m.ell_b, g.fc, w.ypred_e, w.ye, E);
     }
     ss.join(st);
-    k_atom_sum<<<cdiv(N, 256), 256, 0, st>>>(w.ynode, w.ye, g.rowptr, atomic, (int)N);
+    if (atomic) k_atom_sum<<<cdiv(N, 256), 256, 0, st>>>(w.ynode, w.ye, g.rowptr, atomic, (int)N);
     if (node_feat)
         PET_HIP_CHECK(hipMemcpyAsync(node_feat, last.Hout, N * DN * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (edge_feat && E > 0)
@@ -799,5 +804,70 @@ int aux_outputs(const Model& m, const Graph& g, const float* node_feat, const fl
     return PET_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// PETBackend.predict as a function of its arguments (backend.py:420-494): heads of ONE (target, readout layer) on the
+// GIVEN node / edge features, the last layers of ONE block with P properties, cutoff-weighted edge sum:
+//   atomic[i][p] = Wn[p] . hn_i + bn[p] + We[p] . (sum_e fc_e he_e) + be[p] sum_e fc_e        (backend.py:726-777)
+// (the edge sum commutes with the last Linear, so it is taken on the 128 hidden columns once, not on P outputs).
+// ---------------------------------------------------------------------------------
+__global__ void k_fc_sum(const float* __restrict__ fc, const int* __restrict__ rowptr, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = rowptr[i]; p < rowptr[i + 1]; p++) s += fc[p];
+    out[i] = s;
+}
+// one wave per atom: lane l owns hidden columns 2 l, 2 l + 1 of both halves; P outputs by wave reductions
+__global__ void k_last_layers(const float* __restrict__ hn, const float* __restrict__ hes, const float* __restrict__ csum,
+                              const float* __restrict__ nw, const float* __restrict__ nb, const float* __restrict__ ew,
+                              const float* __restrict__ eb, int P, float* __restrict__ atomic, int n) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const float2 a = *reinterpret_cast<const float2*>(hn + (int64_t)i * DH + 2 * lane);
+    const float2 b = *reinterpret_cast<const float2*>(hes + (int64_t)i * DH + 2 * lane);
+    const float cs = csum[i];
+    for (int p = 0; p < P; p++) {
+        const float2 wn = *reinterpret_cast<const float2*>(nw + (int64_t)p * DH + 2 * lane);
+        const float2 we = *reinterpret_cast<const float2*>(ew + (int64_t)p * DH + 2 * lane);
+        float v = a.x * wn.x + a.y * wn.y + b.x * we.x + b.y * we.y;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) atomic[(int64_t)i * P + p] = v + nb[p] + eb[p] * cs;
+    }
+}
+
+// floats: node hidden [N, DH] | edge hidden [E, DH] | edge sums [N, DH] | fc sums [N] | scalar scratch [max(E, N)]
+// (+ the adjoint's per-atom rows Gn, Ge [N, DH] each and gb [N])
+int64_t predict_scratch_floats(int64_t N, int64_t E) {
+    const int64_t Na = N > 0 ? N : 1, Ea = E > 0 ? E : 1;
+    return 4 * Na * DH + Ea * DH + 2 * Na + (Ea > Na ? Ea : Na) + 1024;
+}
+
+int predict(const Model& m, const Graph& g, const HeadW& H, const LastW& Lw, const float* node_feat, const float* edge_feat,
+            const float* fc, float* atomic, float* node_hidden, float* edge_hidden, float* scratch, hipStream_t st) {
+    const int64_t N = g.n_nodes, E = g.n_edges;
+    if (N == 0) return PET_OK;
+    const int64_t Ea = E > 0 ? E : 1;
+    float* hid_n = node_hidden ? node_hidden : scratch;
+    float* hid_e = edge_hidden ? edge_hidden : scratch + N * DH;
+    float* sums = scratch + N * DH + Ea * DH;
+    float* csum = sums + N * DH;
+    float* ytmp = csum + N;
+    if (!fc) fc = g.fc;
+    const int gN = (int)cdiv(N, BM), gE = (int)cdiv(E, BM);
+    allow_big_lds(k_head<256>, (BM * LD256 + BM * LD128) * 4 + BM * 8);
+    const size_t lds2 = (size_t)(BM * LD128 * 2) * 4 + BM * 8;
+    // the heads' own dot-product output is not wanted here (P properties follow): any DH-vector serves as `wl`
+    k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, st>>>(
+        node_feat, wx_fwd(H.nh0, 32), H.nh0.b, wx_fwd(H.nh2, 32), H.nh2.b, Lw.nw, 0.f, nullptr, nullptr, ytmp, N, hid_n, DH);
+    if (E > 0)
+        k_head<128><<<gE, NTHREADS, lds2, st>>>(edge_feat, wx_fwd(H.eh0, 64), H.eh0.b, wx_fwd(H.eh2, 64), H.eh2.b, Lw.ew,
+                                                0.f, nullptr, nullptr, ytmp, E, hid_e, DH);
+    k_edge_sum_fc<<<cdiv(N, 4), 256, 0, st>>>(hid_e, fc, g.rowptr, sums, DH, (int)N);
+    k_fc_sum<<<cdiv(N, 256), 256, 0, st>>>(fc, g.rowptr, csum, (int)N);
+    k_last_layers<<<cdiv(N, 4), 256, 0, st>>>(hid_n, sums, csum, Lw.nw, Lw.nb, Lw.ew, Lw.eb, Lw.P, atomic, (int)N);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
 
 }  // namespace pet

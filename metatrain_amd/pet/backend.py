@@ -1,33 +1,35 @@
 """Host-side mirror of the reference's ``PETBackend`` (src/metatrain/pet/modules/backend.py:12)
 for MI355X: same constructor, same state-dict keys, same three calls
 
-    preprocess(...)            -> Dict[str, Tensor]        (backend.py:238)
-    calculate_features(batch)  -> (List[node], List[edge]) (backend.py:344)
-    predict(...)               -> (Dict[name, List[Tensor]], {}, {})  (backend.py:420)
+    preprocess(...)            -> Dict[str, Tensor]                         (backend.py:238)
+    calculate_features(batch)  -> (List[node], List[edge])                  (backend.py:344)
+    predict(...)               -> (Dict[name, List[Tensor]], node_ll, edge_ll)  (backend.py:420)
 
-but every FLOP runs in libpet_hip (hand-written HIP for gfx950) through the C ABI of
-include/pet_hip.h. torch is used for what the reference's callers expect from it: parameter
-ownership (``state_dict`` interop with reference checkpoints), device memory, streams, and
-the autograd *graph* -- the three calls are three ``torch.autograd.Function`` nodes whose
-backward methods call ``pet_backward_{predict,features,geometry}``, so
-``torch.autograd.grad(energy, [positions, strain])`` works exactly as in
-pet/tests/test_backend.py and utils/output_gradient.py:34-40.
+Every FLOP runs in libpet_hip (hand-written HIP for gfx950) behind the C ABI of include/pet_hip.h. The three calls
+are **functions of their arguments**: ``calculate_features`` and ``predict`` rebuild what they need from the
+``batch_data`` / feature tensors they are handed (``pet_graph_from_batch``), so a caller that edits features or
+``batch_data`` between the calls (LoRA / finetune hooks, diagnostics) gets the edited result, exactly as with the
+reference. Each call is one TorchScript-visible method of ``torch.classes.pet_hip.PetHipBackend``
+(csrc/torch_ops.cpp) with a C++ autograd node, so this module is ``torch.jit.script``-able
+(utils/testing/torchscript.py:39-75) and ``torch.autograd.grad(energy, [positions, strain])`` works as in
+pet/tests/test_backend.py and utils/output_gradient.py:34-40. torch supplies parameter ownership (state-dict interop
+with reference checkpoints), device memory, streams and the autograd graph -- nothing else.
 
-There is no CPU path: CPU tensors raise ``PetHipError``.
+There is no CPU path: CPU tensors raise.
 
-Training (``pet/trainer.py:417-467`` through this mirror): in ``train()`` mode with parameters that
-require grad, ``predict`` routes the target through ONE fused autograd node ``_EnergyFn(positions, cells, *parameters)`` whose
-backward is itself differentiable (``_EnergyGradFn``): ``autograd.grad(E, positions, create_graph=True)``
-followed by ``loss.backward()`` fills ``parameter.grad`` -- first-order term from ``pet_backward_train``,
-force-loss term from the forward-over-reverse pass ``pet_backward_train2`` -- so torch optimizers and DDP work
-on the mirror unchanged. (``metatrain_amd.pet.trainer.TrainStep`` is the faster, fully native step.)
+Training (``pet/trainer.py:417-467`` through this mirror, eager mode): in ``train()`` mode with parameters that
+require grad, ``predict`` routes a single-property target through ONE fused autograd node ``_EnergyFn(positions,
+cells, *parameters)`` whose backward is itself differentiable (``_EnergyGradFn``): ``autograd.grad(E, positions,
+create_graph=True)`` followed by ``loss.backward()`` fills ``parameter.grad`` -- first-order term from
+``pet_backward_train``, force-loss term from the forward-over-reverse pass ``pet_backward_train2`` -- so torch
+optimizers and DDP work on the mirror unchanged. (``metatrain_amd.pet.trainer.TrainStep`` is the faster, fully native
+step.) That node evaluates the batch ``preprocess`` saw, not edited features.
 
-``activation = "SiLU"`` runs on the SwiGLU kernels with the projection uploaded as both halves (exact, see
-``runtime.HipModel.load``). Not built (raise loudly): normalization != RMSNorm, transformer_type != PreLN,
-featurizer_type != feedforward, the "grid" adaptive-cutoff method, system conditioning, more than one
-property per block, per-edge last-layer-feature dicts (returned empty; ``auxiliary_outputs`` gives the per-atom
-sums), double backward
-through the three staged inference nodes, and stress (strain) terms in a training loss.
+``activation = "SiLU"`` runs on the SwiGLU kernels with the projection uploaded as both halves (exact). Several
+properties per block, several blocks per target and several targets are served by ``pet_predict``. Not built (raise
+loudly): normalization != RMSNorm, transformer_type != PreLN, featurizer_type != feedforward, the "grid"
+adaptive-cutoff method, system conditioning, diagnostic capture, double backward through the three inference nodes,
+stress (strain) terms in a training loss.
 """
 from math import prod
 from typing import Dict, List, Optional, Tuple
@@ -37,90 +39,139 @@ import torch
 from .. import runtime as rt
 from .._lib import PetHipError
 
-
-class _ParamsOnly(torch.nn.Module):
-    """Container whose sub-modules exist only to own parameters under the reference's names."""
-
-    def forward(self, *args, **kwargs):  # pragma: no cover
-        raise PetHipError("parameter container: compute happens in libpet_hip, not in torch modules")
-
-
-def _feed_forward(d_model: int, dim_ff: int, activation: str = "SwiGLU") -> torch.nn.Module:
-    m = _ParamsOnly()
-    # SwiGLU: value | gate (transformer.py:28-31); SiLU: one projection (:34-36)
-    m.w_in = torch.nn.Linear(d_model, (2 if activation.lower() == "swiglu" else 1) * dim_ff)
-    m.w_out = torch.nn.Linear(dim_ff, d_model)
-    return m
-
-
-def _transformer_layer(d: int, dn: int, dff: int, activation: str = "SwiGLU") -> torch.nn.Module:
-    # creation order == reference (transformer.py:169-201) so torch.manual_seed reproduces its init
-    m = _ParamsOnly()
-    att = _ParamsOnly()
-    att.input_linear = torch.nn.Linear(d, 3 * d)
-    att.output_linear = torch.nn.Linear(d, d)
-    m.attention = att
-    m.norm_attention = torch.nn.RMSNorm(d)
-    m.norm_mlp = torch.nn.RMSNorm(d)
-    m.mlp = _feed_forward(d, dff, activation)
-    m.center_contraction = torch.nn.Linear(dn, d)
-    m.center_expansion = torch.nn.Linear(d, dn)
-    m.norm_center_features = torch.nn.RMSNorm(dn)
-    m.center_mlp = _feed_forward(dn, 2 * dn, activation)
-    return m
-
-
-def _cartesian_transformer(d: int, dn: int, dff: int, n_layers: int, n_species: int, is_first: bool,
-                           activation: str = "SwiGLU"):
-    m = _ParamsOnly()
-    trans = _ParamsOnly()
-    trans.layers = torch.nn.ModuleList([_transformer_layer(d, dn, dff, activation) for _ in range(n_layers)])
-    m.trans = trans
-    m.edge_embedder = torch.nn.Linear(4, d)
-    m.compress = torch.nn.Sequential(
-        torch.nn.Linear((2 if is_first else 3) * d, d), torch.nn.SiLU(), torch.nn.Linear(d, d)
-    )
-    if not is_first:
-        m.neighbor_embedder = torch.nn.Embedding(n_species, d)
-    return m
+BATCH_KEYS = ["element_indices_nodes", "element_indices_neighbors", "edge_vectors", "edge_distances", "padding_mask",
+              "reverse_neighbor_index", "cutoff_factors", "atomic_cutoffs_stats", "centers", "neighbors",
+              "nef_to_edges_neighbor", "cell_shifts"]
 
 
 # ---------------------------------------------------------------------------------------------
-# autograd nodes (first order)
+# parameter containers under the reference's names (creation order == reference, transformer.py:169-201,414-461,
+# so that torch.manual_seed reproduces its initialisation); each lists its parameters for the kernels
 # ---------------------------------------------------------------------------------------------
-class _Ctx:
-    """What the three nodes share for one preprocess() call."""
+class _FeedForward(torch.nn.Module):
+    def __init__(self, d_model: int, dim_ff: int, activation: str):
+        super().__init__()
+        # SwiGLU: value | gate (transformer.py:28-31); SiLU: one projection (:34-36)
+        self.w_in = torch.nn.Linear(d_model, (2 if activation.lower() == "swiglu" else 1) * dim_ff)
+        self.w_out = torch.nn.Linear(dim_ff, d_model)
 
-    def __init__(self, graph: rt.HipGraph, model: rt.HipModel):
-        self.graph = graph
-        self.model = model
-        csr = graph.csr()
-        self.ctr = csr["ctr"].long()
-        self.slot = torch.arange(graph.n_edges, device=self.ctr.device) - csr["rowptr"].long()[self.ctr]
-        self.fwd: Optional[rt.HipForward] = None
-        self.atomic: Optional[torch.Tensor] = None
-        self.positions: Optional[torch.Tensor] = None  # the caller's tensors (training node inputs)
-        self.cells: Optional[torch.Tensor] = None
+    @torch.jit.export
+    def params(self) -> List[torch.Tensor]:
+        return [self.w_in.weight, self.w_in.bias, self.w_out.weight, self.w_out.bias]
 
-    def to_csr(self, nef: torch.Tensor) -> torch.Tensor:
-        return nef[self.ctr, self.slot].contiguous()
 
-    def to_nef(self, csr: torch.Tensor) -> torch.Tensor:
-        shape = (self.graph.n_nodes, self.graph.max_neighbors) + tuple(csr.shape[1:])
-        out = torch.zeros(shape, dtype=csr.dtype, device=csr.device)
-        out[self.ctr, self.slot] = csr
+class _Attention(torch.nn.Module):
+    def __init__(self, d: int):
+        super().__init__()
+        self.input_linear = torch.nn.Linear(d, 3 * d)
+        self.output_linear = torch.nn.Linear(d, d)
+
+    @torch.jit.export
+    def params(self) -> List[torch.Tensor]:
+        return [self.input_linear.weight, self.input_linear.bias, self.output_linear.weight, self.output_linear.bias]
+
+
+class _TransformerLayer(torch.nn.Module):
+    def __init__(self, d: int, dn: int, dff: int, activation: str):
+        super().__init__()
+        self.attention = _Attention(d)
+        self.norm_attention = torch.nn.RMSNorm(d)
+        self.norm_mlp = torch.nn.RMSNorm(d)
+        self.mlp = _FeedForward(d, dff, activation)
+        self.center_contraction = torch.nn.Linear(dn, d)
+        self.center_expansion = torch.nn.Linear(d, dn)
+        self.norm_center_features = torch.nn.RMSNorm(dn)
+        self.center_mlp = _FeedForward(dn, 2 * dn, activation)
+
+    @torch.jit.export
+    def params(self) -> List[torch.Tensor]:
+        out = self.attention.params()
+        out += [self.norm_attention.weight, self.norm_mlp.weight]
+        out += self.mlp.params()
+        out += [self.center_contraction.weight, self.center_contraction.bias, self.center_expansion.weight,
+                self.center_expansion.bias, self.norm_center_features.weight]
+        out += self.center_mlp.params()
         return out
 
 
-def _no_double_backward(*grads):
-    if any(g is not None and g.requires_grad for g in grads):
-        raise PetHipError("double backward through the staged inference nodes is not built: make the model "
-                          "parameters require grad so that predict() uses the fused training node")
+class _Transformer(torch.nn.Module):
+    def __init__(self, d: int, dn: int, dff: int, n_layers: int, activation: str):
+        super().__init__()
+        self.layers = torch.nn.ModuleList([_TransformerLayer(d, dn, dff, activation) for _ in range(n_layers)])
+
+    @torch.jit.export
+    def params(self) -> List[torch.Tensor]:
+        out: List[torch.Tensor] = []
+        for layer in self.layers:
+            out += layer.params()
+        return out
+
+
+class _CartesianTransformerFirst(torch.nn.Module):
+    def __init__(self, d: int, dn: int, dff: int, n_layers: int, n_species: int, activation: str):
+        super().__init__()
+        self.trans = _Transformer(d, dn, dff, n_layers, activation)
+        self.edge_embedder = torch.nn.Linear(4, d)
+        # a ModuleList where the reference has a Sequential: the same "compress.0 / compress.2" keys, indexable in TorchScript
+        self.compress = torch.nn.ModuleList([torch.nn.Linear(2 * d, d), torch.nn.SiLU(), torch.nn.Linear(d, d)])
+
+    @torch.jit.export
+    def params(self) -> List[torch.Tensor]:
+        out = self.trans.params()
+        out += [self.edge_embedder.weight, self.edge_embedder.bias]
+        out += [self.compress[0].weight, self.compress[0].bias, self.compress[2].weight, self.compress[2].bias]
+        return out
+
+
+class _CartesianTransformerLater(torch.nn.Module):
+    def __init__(self, d: int, dn: int, dff: int, n_layers: int, n_species: int, activation: str):
+        super().__init__()
+        self.trans = _Transformer(d, dn, dff, n_layers, activation)
+        self.edge_embedder = torch.nn.Linear(4, d)
+        self.compress = torch.nn.ModuleList([torch.nn.Linear(3 * d, d), torch.nn.SiLU(), torch.nn.Linear(d, d)])
+        self.neighbor_embedder = torch.nn.Embedding(n_species, d)
+
+    @torch.jit.export
+    def params(self) -> List[torch.Tensor]:
+        out = self.trans.params()
+        out += [self.edge_embedder.weight, self.edge_embedder.bias]
+        out += [self.compress[0].weight, self.compress[0].bias, self.compress[2].weight, self.compress[2].bias]
+        out += [self.neighbor_embedder.weight]
+        return out
+
+
+def _flat_head(d_in: int, d_head: int) -> torch.nn.ModuleList:
+    """The head as a ModuleList [Linear, SiLU, Linear, SiLU]: keys "0.weight" / "2.weight" like the reference's
+    Sequential, and indexable with constants in TorchScript."""
+    return torch.nn.ModuleList([torch.nn.Linear(d_in, d_head), torch.nn.SiLU(), torch.nn.Linear(d_head, d_head),
+                                torch.nn.SiLU()])
+
+
+def process_non_conservative_stress(tensor: torch.Tensor, cells: torch.Tensor, system_indices: torch.Tensor,
+                                    num_properties: int) -> torch.Tensor:
+    """backend.py:780-813: reshape to 3 x 3 per atom, divide by the cell volume (zero volume = non-periodic: +inf),
+    symmetrise. A handful of element-wise ops on [N, 9 P]: plain torch, as in the reference."""
+    t = tensor.reshape(-1, 3, 3, num_properties)
+    volumes = torch.abs(torch.det(cells))
+    volumes = torch.where(volumes == 0.0, torch.full_like(volumes, float("inf")), volumes)
+    t = t / volumes[system_indices].unsqueeze(1).unsqueeze(2).unsqueeze(3)
+    return (t + t.transpose(1, 2)) / 2.0
 
 
 # ---------------------------------------------------------------------------------------------
-# fused training nodes: E(positions, cells, theta) with a differentiable backward
+# fused training nodes (eager): E(positions, cells, theta) with a differentiable backward
 # ---------------------------------------------------------------------------------------------
+class _TrainCtx:
+    """What the fused training node needs of one preprocess() call (eager mode only)."""
+
+    def __init__(self, positions, cells, centers, neighbors, cell_shifts, species, system_indices):
+        self.positions, self.cells = positions, cells
+        self.args = (centers, neighbors, cell_shifts, species, system_indices)
+        self.model: Optional[rt.HipModel] = None
+        self.graph: Optional[rt.HipGraph] = None
+        self.train_fwd: Optional[rt.HipForward] = None
+
+
 class _EnergyGradFn(torch.autograd.Function):
     """(g_atomic, positions, cells, *theta) -> (dL/dR, dL/dcell, *dL/dtheta) for L = <g_atomic, E_atomic>.
     Its own backward is the second-order pass: grads w.r.t. g_atomic (the JVP of the atomic energies) and
@@ -131,7 +182,6 @@ class _EnergyGradFn(torch.autograd.Function):
         fw, model = hctx.train_fwd, hctx.model
         ga = g_atomic.detach().reshape(-1).float().contiguous()
         want_theta = any(ctx.needs_input_grad[5:])
-        g = hctx.graph
         if want_theta:
             model.zero_grad()
             gpos, gcell = fw.backward_train(ga, want_cell_grad=True)
@@ -178,81 +228,6 @@ class _EnergyFn(torch.autograd.Function):
         return (None, None) + tuple(out)
 
 
-class _PreprocessFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, positions, cells, hctx, ev, ed, cf):
-        ctx.hctx = hctx
-        return ev.clone(), ed.clone(), cf.clone()
-
-    @staticmethod
-    def backward(ctx, g_ev, g_ed, g_cf):
-        _no_double_backward(g_ev, g_ed, g_cf)
-        h = ctx.hctx
-        g, lib = h.graph, h.graph.lib
-        dev = g.workspace.device
-        gpos = torch.zeros((g.n_nodes, 3), dtype=torch.float32, device=dev)
-        gcell = torch.zeros((g.n_systems, 3, 3), dtype=torch.float32, device=dev)
-        if g.n_edges > 0:
-            geo = torch.cat([h.to_csr(g_ev), h.to_csr(g_ed)[:, None]], dim=1).float().contiguous()
-            gfc = h.to_csr(g_cf).float().contiguous()
-            fw = h.fwd or rt.HipForward(h.model, g)
-            rt.check(lib.pet_backward_geometry(h.model.handle, g.handle, rt._ptr(fw.workspace), fw.nbytes,
-                                               rt._ptr(geo), rt._ptr(gfc), rt._ptr(gpos), rt._ptr(gcell),
-                                               rt._stream()))
-        return gpos, gcell, None, None, None, None
-
-
-class _FeaturesFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, ev, ed, cf, hctx):
-        ctx.hctx = hctx
-        h = hctx
-        h.fwd = rt.HipForward(h.model, h.graph)
-        atomic, nf, ef = h.fwd.forward(want_features=True)
-        h.atomic = atomic
-        return nf, h.to_nef(ef)
-
-    @staticmethod
-    def backward(ctx, g_nf, g_ef):
-        _no_double_backward(g_nf, g_ef)
-        h = ctx.hctx
-        g, lib, fw = h.graph, h.graph.lib, h.fwd
-        dev = g.workspace.device
-        n, m = g.n_nodes, g.max_neighbors
-        if g.n_edges == 0:
-            z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)  # noqa: E731
-            return z(n, m, 3), z(n, m), z(n, m), None
-        g_nf = g_nf.float().contiguous()
-        g_ef_csr = h.to_csr(g_ef).float().contiguous()
-        geo = torch.empty((g.n_edges, 4), dtype=torch.float32, device=dev)
-        gfc = torch.empty(g.n_edges, dtype=torch.float32, device=dev)
-        rt.check(lib.pet_backward_features(h.model.handle, g.handle, rt._ptr(fw.workspace), fw.nbytes,
-                                           rt._ptr(g_nf), rt._ptr(g_ef_csr), rt._ptr(geo), rt._ptr(gfc),
-                                           rt._stream()))
-        return h.to_nef(geo[:, :3].contiguous()), h.to_nef(geo[:, 3].contiguous()), h.to_nef(gfc), None
-
-
-class _PredictFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, nf, ef, cf, hctx):
-        ctx.hctx = hctx
-        return hctx.atomic[:, None].clone()
-
-    @staticmethod
-    def backward(ctx, g_atomic):
-        _no_double_backward(g_atomic)
-        h = ctx.hctx
-        g, lib, fw = h.graph, h.graph.lib, h.fwd
-        dev = g.workspace.device
-        ga = g_atomic.reshape(-1).float().contiguous()
-        g_nf = torch.empty((g.n_nodes, h.model.hypers["d_node"]), dtype=torch.float32, device=dev)
-        g_ef = torch.zeros((g.n_edges, h.model.hypers["d_pet"]), dtype=torch.float32, device=dev)
-        g_fc = torch.zeros(g.n_edges, dtype=torch.float32, device=dev)
-        rt.check(lib.pet_backward_predict(h.model.handle, g.handle, rt._ptr(fw.workspace), fw.nbytes, rt._ptr(ga),
-                                          rt._ptr(g_nf), rt._ptr(g_ef), rt._ptr(g_fc), rt._stream()))
-        return g_nf, h.to_nef(g_ef), h.to_nef(g_fc), None
-
-
 # ---------------------------------------------------------------------------------------------
 class PETBackend(torch.nn.Module):
     """MI355X drop-in for ``metatrain.pet.modules.backend.PETBackend`` (plain tensors in / out).
@@ -265,39 +240,45 @@ class PETBackend(torch.nn.Module):
 
     def __init__(self, hypers: dict, atomic_types: List[int]) -> None:
         super().__init__()
-        rt.hypers_struct(hypers, atomic_types)  # validates; unsupported variants raise here
+        h = rt.hypers_struct(hypers, atomic_types)  # validates; unsupported variants raise here
+        self._numbers: List[float] = [float(getattr(h, name)) for name, _ in h._fields_] + [
+            1.0 if hypers["activation"] == "SiLU" else 0.0]
         self.hypers = dict(hypers)
-        self.atomic_types = list(atomic_types)
+        self.atomic_types: List[int] = [int(z) for z in atomic_types]
         self.nl_is_strict = bool(hypers["long_range"]["enable"])
         self.cutoff = float(hypers["cutoff"])
-        self.cutoff_function = hypers["cutoff_function"]
+        self.cutoff_function: str = hypers["cutoff_function"]
         self.cutoff_width = float(hypers["cutoff_width"])
-        self.num_neighbors_adaptive = (float(hypers["num_neighbors_adaptive"])
-                                       if hypers["num_neighbors_adaptive"] is not None else None)
-        self.adaptive_cutoff_method = hypers.get("adaptive_cutoff_method", "solver")
-        self.d_pet, self.d_node = hypers["d_pet"], hypers["d_node"]
-        self.d_head, self.d_feedforward = hypers["d_head"], hypers["d_feedforward"]
-        self.num_heads = hypers["num_heads"]
-        self.num_gnn_layers = hypers["num_gnn_layers"]
-        self.num_attention_layers = hypers["num_attention_layers"]
-        self.featurizer_type = hypers["featurizer_type"]
-        self.num_readout_layers = 1
+        self.num_neighbors_adaptive: Optional[float] = (float(hypers["num_neighbors_adaptive"])
+                                                        if hypers["num_neighbors_adaptive"] is not None else None)
+        self.adaptive_cutoff_method: str = hypers.get("adaptive_cutoff_method", "solver")
+        self.cutoff_width_adaptive = float(hypers.get("cutoff_width_adaptive", 1.0))
+        self.d_pet: int = hypers["d_pet"]
+        self.d_node: int = hypers["d_node"]
+        self.d_head: int = hypers["d_head"]
+        self.d_feedforward: int = hypers["d_feedforward"]
+        self.num_heads: int = hypers["num_heads"]
+        self.num_gnn_layers: int = hypers["num_gnn_layers"]
+        self.num_attention_layers: int = hypers["num_attention_layers"]
+        self.featurizer_type: str = hypers["featurizer_type"]
+        self.num_readout_layers: int = 1
         n_species = len(atomic_types)
+        act = hypers["activation"]
 
         # first state-dict entry, like the reference (backend.py:63-71)
         self.register_buffer("species_to_species_index", torch.full((max(atomic_types) + 1,), -1))
         for i, species in enumerate(atomic_types):
             self.species_to_species_index[species] = i
-        self.gnn_layers = torch.nn.ModuleList([
-            _cartesian_transformer(self.d_pet, self.d_node, self.d_feedforward, self.num_attention_layers,
-                                   n_species, g == 0, hypers["activation"])
-            for g in range(self.num_gnn_layers)
-        ])
+        layers: List[torch.nn.Module] = []
+        for g in range(self.num_gnn_layers):
+            cls = _CartesianTransformerFirst if g == 0 else _CartesianTransformerLater
+            layers.append(cls(self.d_pet, self.d_node, self.d_feedforward, self.num_attention_layers, n_species, act))
+        self.gnn_layers = torch.nn.ModuleList(layers)
         self.combination_norms = torch.nn.ModuleList(
             [torch.nn.LayerNorm(2 * self.d_pet) for _ in range(self.num_gnn_layers)])
         self.combination_mlps = torch.nn.ModuleList([
-            torch.nn.Sequential(torch.nn.Linear(2 * self.d_pet, 2 * self.d_pet), torch.nn.SiLU(),
-                                torch.nn.Linear(2 * self.d_pet, self.d_pet))
+            torch.nn.ModuleList([torch.nn.Linear(2 * self.d_pet, 2 * self.d_pet), torch.nn.SiLU(),
+                                 torch.nn.Linear(2 * self.d_pet, self.d_pet)])
             for _ in range(self.num_gnn_layers)
         ])
         self.node_embedders = torch.nn.ModuleList([torch.nn.Embedding(n_species, self.d_node)])
@@ -306,161 +287,213 @@ class PETBackend(torch.nn.Module):
         self.edge_heads = torch.nn.ModuleDict()
         self.node_last_layers = torch.nn.ModuleDict()
         self.edge_last_layers = torch.nn.ModuleDict()
-
-        self._hip: Dict[Tuple[str, str], rt.HipModel] = {}
-        self._hip_version: Dict[Tuple[str, str], int] = {}
-        self._ctx: Dict[int, _Ctx] = {}
+        self._train_models: Dict[Tuple[str, str], rt.HipModel] = {}
+        self._train_versions: Dict[Tuple[str, str], int] = {}
+        self._refresh_core()
 
     # ---- outputs (backend.py:157-236) ----------------------------------------------------------
     def add_output(self, target_name: str, output_shapes: Dict[str, List[int]]) -> None:
-        def head(d_in):
-            return torch.nn.ModuleList([torch.nn.Sequential(
-                torch.nn.Linear(d_in, self.d_head), torch.nn.SiLU(),
-                torch.nn.Linear(self.d_head, self.d_head), torch.nn.SiLU())])
-
         def last():
             return torch.nn.ModuleList([torch.nn.ModuleDict(
-                {key: torch.nn.Linear(self.d_head, prod(shape), bias=True) for key, shape in output_shapes.items()})])
+                {key: torch.nn.Linear(self.d_head, prod(shape), bias=True) for key, shape in output_shapes.items()})
+                for _ in range(self.num_readout_layers)])
 
-        self.node_heads[target_name] = head(self.d_node)
-        self.edge_heads[target_name] = head(self.d_pet)
+        self.node_heads[target_name] = torch.nn.ModuleList(
+            [_flat_head(self.d_node, self.d_head) for _ in range(self.num_readout_layers)])
+        self.edge_heads[target_name] = torch.nn.ModuleList(
+            [_flat_head(self.d_pet, self.d_head) for _ in range(self.num_readout_layers)])
         self.node_last_layers[target_name] = last()
         self.edge_last_layers[target_name] = last()
+        self._refresh_core()
 
     def remove_output(self, target_name: str) -> None:
         for d in (self.node_heads, self.edge_heads, self.node_last_layers, self.edge_last_layers):
             if target_name in d:
                 del d[target_name]
-        for key in [k for k in self._hip if k[0] == target_name]:
-            del self._hip[key], self._hip_version[key]
+        for key in [k for k in self._train_models if k[0] == target_name]:
+            del self._train_models[key], self._train_versions[key]
+        self._refresh_core()
 
-    # ---- packed weights on the device, refreshed when parameters change -------------------------
+    def _refresh_core(self) -> None:
+        """(Re)create the TorchScript-visible kernel front end for the current parameter list. The keys are the
+        state-dict names in the order ``_params()`` lists the tensors."""
+        from .script import load_ops
+
+        load_ops()
+        named = {id(p): k for k, p in self.named_parameters()}
+        keys = [named[id(p)] for p in self._params()]
+        assert len(keys) == len(named) == len(set(keys)), "every parameter exactly once"
+        self.core = torch.classes.pet_hip.PetHipBackend(self._numbers, self.atomic_types, keys)
+
+    # ---- the parameters, in one fixed order ----------------------------------------------------
+    @torch.jit.export
+    def _params(self) -> List[torch.Tensor]:
+        out: List[torch.Tensor] = []
+        for layer in self.gnn_layers:
+            out += layer.params()
+        for norm in self.combination_norms:
+            out += [norm.weight, norm.bias]
+        for mlp in self.combination_mlps:
+            out += [mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias]
+        for emb in self.node_embedders:
+            out += [emb.weight]
+        out += [self.edge_embedder.weight]
+        for _, heads in self.node_heads.items():
+            for head in heads:
+                out += [head[0].weight, head[0].bias, head[2].weight, head[2].bias]
+        for _, heads in self.edge_heads.items():
+            for head in heads:
+                out += [head[0].weight, head[0].bias, head[2].weight, head[2].bias]
+        for _, layers in self.node_last_layers.items():
+            for blocks in layers:
+                for _, lin in blocks.items():
+                    out += [lin.weight, lin.bias]
+        for _, layers in self.edge_last_layers.items():
+            for blocks in layers:
+                for _, lin in blocks.items():
+                    out += [lin.weight, lin.bias]
+        return out
+
+    # ---- the three calls -----------------------------------------------------------------------
+    @torch.jit.export
+    def preprocess(self, positions: torch.Tensor, centers: torch.Tensor, neighbors: torch.Tensor,
+                   species: torch.Tensor, cells: torch.Tensor, cell_shifts: torch.Tensor,
+                   system_indices: torch.Tensor, cutoff_width_adaptive: float) -> Dict[str, torch.Tensor]:
+        """``PETBackend.preprocess`` (backend.py:238-342): the 12 ``batch_data`` tensors."""
+        if self.num_neighbors_adaptive is not None and abs(cutoff_width_adaptive - self.cutoff_width_adaptive) > 1e-12:
+            raise RuntimeError("cutoff_width_adaptive differs from the value in the model hypers (it is part of the "
+                               "packed model here)")
+        outs = self.core.preprocess(self._params(), positions, centers, neighbors, species, cells, cell_shifts,
+                                    system_indices)
+        batch: Dict[str, torch.Tensor] = {
+            "element_indices_nodes": outs[0], "element_indices_neighbors": outs[1], "edge_vectors": outs[2],
+            "edge_distances": outs[3], "padding_mask": outs[4], "reverse_neighbor_index": outs[5],
+            "cutoff_factors": outs[6], "atomic_cutoffs_stats": outs[7], "centers": outs[8], "neighbors": outs[9],
+            "nef_to_edges_neighbor": outs[10], "cell_shifts": outs[11],
+        }
+        if not torch.jit.is_scripting():
+            self._stash_training_inputs(batch, positions, cells, centers, neighbors, cell_shifts, species, system_indices)
+        return batch
+
+    @torch.jit.unused
+    def _stash_training_inputs(self, batch: Dict[str, torch.Tensor], positions, cells, centers, neighbors, cell_shifts,
+                               species, system_indices) -> None:
+        # the fused training node (eager train() mode) differentiates E w.r.t. the positions themselves
+        batch["reverse_neighbor_index"]._pet_hip_train = _TrainCtx(positions, cells, centers, neighbors, cell_shifts,
+                                                                    species, system_indices)
+
+    @torch.jit.export
+    def calculate_features(self, batch_data: Dict[str, torch.Tensor], capture_diagnostics: bool = False
+                           ) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+        """``PETBackend.calculate_features`` (backend.py:344-418): node [N, d_node] and edge [N, M, d_pet] features of
+        the last GNN layer (feedforward featuriser), computed FROM ``batch_data`` as given."""
+        if capture_diagnostics:
+            raise RuntimeError("diagnostic feature capture is not built into libpet_hip")
+        outs = self.core.calculate_features(
+            self._params(), batch_data["element_indices_nodes"], batch_data["element_indices_neighbors"],
+            batch_data["edge_vectors"], batch_data["edge_distances"], batch_data["padding_mask"],
+            batch_data["reverse_neighbor_index"], batch_data["cutoff_factors"])
+        return [outs[0]], [outs[1]]
+
+    @torch.jit.export
+    def predict(self, node_features_list: List[torch.Tensor], edge_features_list: List[torch.Tensor],
+                batch_data: Dict[str, torch.Tensor], cells: torch.Tensor, system_indices: torch.Tensor,
+                requested_output_names: List[str]
+                ) -> Tuple[Dict[str, List[torch.Tensor]], Dict[str, List[torch.Tensor]], Dict[str, List[torch.Tensor]]]:
+        """``PETBackend.predict`` (backend.py:420-494): per-block atomic predictions ``[N, P_block]`` and the node /
+        edge last-layer features of every requested output, from the features and ``batch_data`` passed in."""
+        atomic: Dict[str, List[torch.Tensor]] = {}
+        node_ll: Dict[str, List[torch.Tensor]] = {}
+        edge_ll: Dict[str, List[torch.Tensor]] = {}
+        if not torch.jit.is_scripting():
+            if self.training and torch.is_grad_enabled():
+                requested_output_names = self._predict_training(node_features_list, batch_data,
+                                                                requested_output_names, atomic)
+        params = self._params()
+        mask = batch_data["padding_mask"]
+        cf = batch_data["cutoff_factors"]
+        for name, layers in self.node_last_layers.items():
+            if name in requested_output_names:  # (no `continue`: TorchScript unrolls loops over ModuleDicts)
+                node_ll[name] = []
+                edge_ll[name] = []
+                block_sums: List[torch.Tensor] = []
+                layer_index = 0
+                for blocks in layers:
+                    block_index = 0
+                    for block, _ in blocks.items():
+                        outs = self.core.predict(params, name, layer_index, block, node_features_list[layer_index],
+                                                 edge_features_list[layer_index], mask, cf)
+                        if layer_index == 0:
+                            block_sums.append(outs[0])
+                        else:
+                            block_sums[block_index] = block_sums[block_index] + outs[0]
+                        if block_index == 0:
+                            node_ll[name].append(outs[1])
+                            edge_ll[name].append(outs[2])
+                        block_index += 1
+                    layer_index += 1
+                if name == "non_conservative_stress":
+                    num_properties = block_sums[0].shape[1] // 9
+                    block_sums[0] = process_non_conservative_stress(block_sums[0], cells, system_indices.to(torch.long),
+                                                                    num_properties)
+                atomic[name] = block_sums
+        return atomic, node_ll, edge_ll
+
+    # ---- eager-only: training through the mirror -------------------------------------------------
     def _version(self) -> int:
         return sum(p._version for p in self.parameters()) + sum(id(p) & 0xFFFF for p in self.parameters())
 
-    def _hip_model(self, target: str, block: str) -> rt.HipModel:
-        key = (target, block)
-        version = self._version()
-        if key not in self._hip or self._hip_version[key] != version:
-            if target not in self.node_heads:
-                raise PetHipError(f"output '{target}' was never registered with add_output")
-            w = self.node_last_layers[target][0][block].weight
-            if w.shape[0] != 1:
-                raise PetHipError("only one property per block is built into libpet_hip for now")
-            model = self._hip.get(key) or rt.HipModel(self.hypers, self.atomic_types)
-            model.load(dict(self.state_dict()), target, block)
-            self._hip[key], self._hip_version[key] = model, version
-        return self._hip[key]
+    @torch.jit.unused
+    def _predict_training(self, node_features_list: List[torch.Tensor], batch_data: Dict[str, torch.Tensor],
+                          requested_output_names: List[str], out: Dict[str, List[torch.Tensor]]) -> List[str]:
+        """train() mode with parameters that require grad: single-property targets go through the fused node
+        (double-differentiable); returns the names that are still to be served."""
+        if not any(p.requires_grad for p in self.parameters()):
+            return requested_output_names
+        tctx = getattr(batch_data["reverse_neighbor_index"], "_pet_hip_train", None)
+        done: List[str] = []
+        for name in self.node_last_layers.keys():
+            if name not in requested_output_names:
+                continue
+            blocks = list(self.node_last_layers[name][0].keys())
+            if len(blocks) != 1 or self.node_last_layers[name][0][blocks[0]].weight.shape[0] != 1:
+                continue  # several blocks / properties: served (first order) by pet_predict below
+            if tctx is None:
+                raise PetHipError("training through the mirror needs the batch_data of this backend's preprocess()")
+            key = (name, blocks[0])
+            version = self._version()
+            if key not in self._train_models or self._train_versions[key] != version:
+                model = self._train_models.get(key) or rt.HipModel(self.hypers, self.atomic_types)
+                model.load(dict(self.state_dict()), name, blocks[0])
+                self._train_models[key], self._train_versions[key] = model, version
+            model = self._train_models[key]
+            named = dict(self.named_parameters())
+            keys = tuple(k for k in model._ckeys if k in named)
+            params = [named[k] for k in keys]
+            h = _TrainCtx(tctx.positions, tctx.cells, *tctx.args)
+            h.model = model
+            c, n, s, z, sysidx = tctx.args
+            h.graph = rt.HipGraph(model, tctx.positions, tctx.cells, c, n, s, z, sysidx)
+            pred = _EnergyFn.apply(h, keys, tctx.positions, tctx.cells, *params)
+            out[name] = [pred.to(node_features_list[0].dtype)]
+            done.append(name)
+        return [n for n in requested_output_names if n not in done]
 
-    def _training_params(self, target: str, block: str):
-        """State-dict keys and tensors of the parameters the packed model of (target, block) was loaded with."""
-        model = self._hip[(target, block)]
-        named = dict(self.named_parameters())
-        keys = [k for k in model._ckeys if k in named]
-        return tuple(keys), [named[k] for k in keys]
-
-    def _any_model(self) -> rt.HipModel:
-        """preprocess() needs hypers + the species table only; any target's packed model will do."""
-        for target in self.node_heads:
-            block = next(iter(self.node_last_layers[target][0].keys()))
-            return self._hip_model(target, block)
-        raise PetHipError("register an output with add_output() before calling preprocess()")
-
-    # ---- the three calls -----------------------------------------------------------------------
-    def preprocess(self, positions, centers, neighbors, species, cells, cell_shifts, system_indices,
-                   cutoff_width_adaptive: float) -> Dict[str, torch.Tensor]:
-        """``PETBackend.preprocess`` (backend.py:238-342): the 12 ``batch_data`` tensors."""
-        model = self._any_model()
-        if self.num_neighbors_adaptive is not None and abs(
-                float(cutoff_width_adaptive) - float(self.hypers.get("cutoff_width_adaptive", 1.0))) > 1e-12:
-            raise PetHipError("cutoff_width_adaptive differs from the value in the model hypers (it is part of "
-                              "the packed model here)")
-        graph = rt.HipGraph(model, positions, cells, centers, neighbors, cell_shifts, species, system_indices)
-        batch = graph.export_batch()
-        hctx = _Ctx(graph, model)
-        hctx.positions, hctx.cells = positions, cells
-        if positions.requires_grad or cells.requires_grad:
-            ev, ed, cf = _PreprocessFn.apply(positions, cells, hctx, batch["edge_vectors"],
-                                             batch["edge_distances"], batch["cutoff_factors"])
-            batch["edge_vectors"], batch["edge_distances"], batch["cutoff_factors"] = ev, ed, cf
-        dt = positions.dtype
-        for k in ("edge_vectors", "edge_distances", "cutoff_factors", "atomic_cutoffs_stats"):
-            if batch[k].dtype != dt:
-                batch[k] = batch[k].to(dt)
-        if len(self._ctx) > 8:  # graphs of stale batches
-            self._ctx.pop(next(iter(self._ctx)))
-        self._ctx[id(batch["reverse_neighbor_index"])] = hctx
-        batch["reverse_neighbor_index"]._pet_hip_ctx = hctx  # keeps the graph alive with the batch
-        return batch
-
-    def _ctx_of(self, batch_data: Dict[str, torch.Tensor]) -> _Ctx:
-        h = getattr(batch_data["reverse_neighbor_index"], "_pet_hip_ctx", None)
-        if h is None:
-            raise PetHipError("batch_data does not come from this backend's preprocess()")
-        return h
-
-    def calculate_features(self, batch_data: Dict[str, torch.Tensor], capture_diagnostics: bool = False
-                           ) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
-        """``PETBackend.calculate_features`` (backend.py:344-418): node [N,d_node] and edge
-        [N,M,d_pet] features of the last GNN layer (feedforward featuriser)."""
-        if capture_diagnostics:
-            raise PetHipError("diagnostic feature capture is not built into libpet_hip")
-        h = self._ctx_of(batch_data)
-        nf, ef = _FeaturesFn.apply(batch_data["edge_vectors"], batch_data["edge_distances"],
-                                   batch_data["cutoff_factors"], h)
-        dt = batch_data["edge_vectors"].dtype
-        return [nf.to(dt)], [ef.to(dt)]
-
+    # ---- auxiliary per-atom outputs (values only) -------------------------------------------------
+    @torch.jit.unused
     def auxiliary_outputs(self, node_features_list, edge_features_list, batch_data, target: str = "energy",
                           feature: bool = True, last_layer_features: bool = True):
         """Per-atom ``feature`` ``[N, d_node + d_pet]`` and ``mtt::aux::<target>_last_layer_features``
         ``[N, 2 d_head]`` as ``PET._get_output_features`` / ``_get_output_last_layer_features`` assemble them
-        (``pet/model.py:730-875``: cutoff-weighted edge sums next to the node parts), computed by
-        ``pet_aux_outputs`` from the features of ``calculate_features`` (values only: no autograd node)."""
-        h = self._ctx_of(batch_data)
-        if h.fwd is None:
-            raise PetHipError("auxiliary_outputs() needs calculate_features() on the same batch_data")
-        blocks = list(self.node_last_layers[target][0].keys())
-        model = self._hip_model(target, blocks[0])
-        fw = h.fwd if model is h.model else rt.HipForward(model, h.graph)
-        nf = node_features_list[-1].detach().float()
-        ef = h.to_csr(edge_features_list[-1].detach()).float()
-        return fw.aux_outputs(nf, ef, feature=feature, last_layer_features=last_layer_features)
-
-    def predict(self, node_features_list, edge_features_list, batch_data, cells, system_indices,
-                requested_output_names: List[str]):
-        """``PETBackend.predict`` (backend.py:420-494): per-block atomic predictions ``[N, 1]``. The two last-layer
-        feature dictionaries come back empty: the fused heads never store their hidden rows; the per-atom sums the
-        model wrapper builds from them are served by ``auxiliary_outputs``."""
-        h = self._ctx_of(batch_data)
-        if h.fwd is None:
-            raise PetHipError("predict() needs the features of calculate_features() on the same batch_data")
-        out: Dict[str, List[torch.Tensor]] = {}
-        for name in self.node_last_layers.keys():
-            if name not in requested_output_names:
-                continue
-            if name == "non_conservative_stress":
-                raise PetHipError("non_conservative_stress is not built into libpet_hip")
-            blocks = list(self.node_last_layers[name][0].keys())
-            if len(blocks) != 1:
-                raise PetHipError("only single-block targets are built into libpet_hip for now")
-            model = self._hip_model(name, blocks[0])
-            if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                # training: one fused node over (positions, cells, parameters of this target)
-                keys, params = self._training_params(name, blocks[0])
-                h2 = _Ctx(h.graph, model)
-                pred = _EnergyFn.apply(h2, keys, h.positions, h.cells, *params)
-                out[name] = [pred.to(node_features_list[0].dtype)]
-                continue
-            if model is not h.model:
-                # another target than the one the features were computed with: re-run the fused
-                # forward with that target's heads (the backbone weights are identical)
-                h2 = _Ctx(h.graph, model)
-                nf, ef = _FeaturesFn.apply(batch_data["edge_vectors"], batch_data["edge_distances"],
-                                           batch_data["cutoff_factors"], h2)
-                pred = _PredictFn.apply(nf, ef, batch_data["cutoff_factors"], h2)
-            else:
-                pred = _PredictFn.apply(node_features_list[0].float(), edge_features_list[0].float(),
-                                        batch_data["cutoff_factors"], h)
-            out[name] = [pred.to(node_features_list[0].dtype)]
-        return out, {}, {}
+        (``pet/model.py:730-875``: cutoff-weighted edge sums next to the node parts), from the given features."""
+        # (this is wrapper-level assembly -- pet/model.py:750-755, :795-812 -- on tensors the kernels produced)
+        cf = batch_data["cutoff_factors"].detach()[..., None]
+        nf, ef = node_features_list[-1].detach(), edge_features_list[-1].detach()
+        feat = torch.cat([nf, (ef * cf).sum(1)], dim=1) if feature else None
+        llf = None
+        if last_layer_features:
+            _, node_ll, edge_ll = self.predict(node_features_list, edge_features_list, batch_data,
+                                               torch.zeros((1, 3, 3), device=nf.device), torch.zeros(1, device=nf.device),
+                                               [target])
+            llf = torch.cat([node_ll[target][-1], (edge_ll[target][-1] * cf).sum(1)], dim=1)
+        return feat, llf

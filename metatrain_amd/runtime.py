@@ -86,23 +86,30 @@ class HipModel:
     def handle(self) -> c_void_p:
         return self._handle
 
-    def load(self, params: Dict[str, torch.Tensor], target: str, block: Optional[str] = None) -> None:
-        """Upload a reference-schema state dict for one target and pack it."""
+    def load(self, params: Dict[str, torch.Tensor], target: Optional[str], block: Optional[str] = None) -> None:
+        """Upload a reference-schema state dict and pack it. ``target`` / ``block`` name the FUSED head
+        (what ``pet_forward`` and the native training step evaluate; its last layers must have one property): its keys
+        are uploaded with both names replaced by "@". Every other head / last layer of the state dict (other targets,
+        blocks with several properties, further readout layers) is uploaded under its own name and served by
+        :meth:`HipForward.predict`. ``target=None``: no fused head (features + ``predict`` only)."""
         block = block or target
         self.target = target
+        self._fused_block = block
         self._ckeys: Dict[str, tuple] = {}
         self._tied = set()  # SiLU variant: w_in parameters uploaded twice (value half = gate half)
+        last_w = params.get(f"node_last_layers.{target}.0.{block}.weight") if target is not None else None
+        fused = last_w is not None and last_w.shape[0] == 1  # the fused kernels serve one property
+        if not fused:
+            self.target = self._fused_block = None
         for key, t in params.items():
             _require_cuda(t)
             parts = key.split(".")
-            if parts[0] in ("node_heads", "edge_heads", "node_last_layers", "edge_last_layers"):
-                if parts[1] != target:
-                    continue
+            if fused and parts[0] in ("node_heads", "edge_heads") and parts[1] == target and parts[2] == "0":
                 parts[1] = "@"
-                if parts[0].endswith("last_layers"):
-                    if parts[3] != block:
-                        continue
-                    parts[3] = "@"
+            elif fused and parts[0] in ("node_last_layers", "edge_last_layers") and parts[1] == target \
+                    and parts[2] == "0" and ".".join(parts[3:-1]) == block:
+                parts[1] = "@"
+                parts[3:-1] = ["@"]
             ckey = ".".join(parts)
             if key == "species_to_species_index":
                 src = t.to(torch.int64).contiguous()
@@ -266,6 +273,35 @@ class HipGraph:
         """``[N]`` int64 structure index of every atom (the batch's ``system_indices``)."""
         return self._sys.long()
 
+    @classmethod
+    def from_batch(cls, model: "HipModel", batch_data: Dict[str, torch.Tensor]) -> "HipGraph":
+        """CSR graph from a ``batch_data`` dictionary (the padded NEF tensors of ``PETBackend.preprocess``,
+        backend.py:328-341), whoever produced it: what ``calculate_features`` / ``predict`` need of their argument."""
+        self = cls.__new__(cls)
+        self.lib, self.model = model.lib, model
+        mask = batch_data["padding_mask"]
+        _require_cuda(mask)
+        dev = mask.device
+        self.n_nodes, m = int(mask.shape[0]), int(mask.shape[1])
+        self.n_systems, self.n_edges_in = 0, self.n_nodes * m
+        i64, f32 = torch.int64, torch.float32
+        self._keep = [batch_data["element_indices_nodes"].to(i64).contiguous(),
+                      batch_data["element_indices_neighbors"].to(i64).contiguous(),
+                      batch_data["edge_vectors"].detach().to(f32).contiguous(),
+                      batch_data["edge_distances"].detach().to(f32).contiguous(),
+                      mask.to(torch.uint8).contiguous(),
+                      batch_data["reverse_neighbor_index"].to(i64).contiguous(),
+                      batch_data["cutoff_factors"].detach().to(f32).contiguous()]
+        nbytes = int(self.lib.pet_graph_from_batch_workspace_bytes(self.n_nodes, m))
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._handle = c_void_p()
+        check(self.lib.pet_graph_from_batch(*[_ptr(t) for t in self._keep], self.n_nodes, m, _ptr(self.workspace), nbytes,
+                                            byref(self._handle), _stream()))
+        self.n_edges = int(self.lib.pet_graph_num_edges(self._handle))
+        self.max_neighbors = m  # the width of the caller's NEF grid (what the NEF views of this graph must have)
+        self._sys = None
+        return self
+
     def csr(self) -> Dict[str, torch.Tensor]:
         """Copies of rowptr / ctr / nbr / rev (int32) for inspection."""
         ptrs = [c_void_p() for _ in range(4)]
@@ -293,6 +329,17 @@ class HipForward:
             raise PetHipError("pet_forward_workspace_bytes failed")
         self.nbytes = nbytes
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=graph.workspace.device)
+
+    def features(self):
+        """``calculate_features`` alone (no heads): node ``[N, d_node]`` and edge ``[E, d_pet]`` (CSR rows) features,
+        saved for :meth:`backward_features`."""
+        g = self.graph
+        dev = self.workspace.device
+        nf = torch.empty((g.n_nodes, self.model.hypers["d_node"]), dtype=torch.float32, device=dev)
+        ef = torch.empty((g.n_edges, self.model.hypers["d_pet"]), dtype=torch.float32, device=dev)
+        check(self.lib.pet_forward(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes, 2 if self.train else 1,
+                                   c_void_p(0), _ptr(nf), _ptr(ef), _stream()))
+        return nf, ef
 
     def forward(self, want_features: bool = False):
         g = self.graph
@@ -378,6 +425,60 @@ class HipForward:
         out = torch.zeros(self.graph.n_systems, dtype=torch.float32, device=atomic.device)
         check(self.lib.pet_sum_over_atoms(self.graph.handle, _ptr(atomic), _ptr(out), _stream()))
         return out
+
+
+def _head_names(model: HipModel, target: str, block: Optional[str], readout_zero: bool = True):
+    block = block or target
+    if model.target is not None and target == model.target and block == model._fused_block and readout_zero:
+        return b"@", b"@"
+    return target.encode(), block.encode()
+
+
+def predict(model: HipModel, graph: HipGraph, node_features: torch.Tensor, edge_features: torch.Tensor,
+            target: str, block: Optional[str] = None, readout_layer: int = 0,
+            cutoff_factors: Optional[torch.Tensor] = None, want_hidden: bool = False):
+    """``PETBackend.predict`` for one (target, readout layer, block) as a function of its arguments (``pet_predict``):
+    per-atom predictions ``[N, P]`` from the GIVEN node ``[N, d_node]`` / edge ``[E, d_pet]`` (CSR rows) features."""
+    _require_cuda(node_features)
+    lib = model.lib
+    tname, bname = _head_names(model, target, block, readout_layer == 0)
+    p = int(lib.pet_model_block_properties(model.handle, tname, readout_layer, bname))
+    if p < 1:
+        raise PetHipError(f"no head / last layer uploaded for target '{target}', readout layer {readout_layer}, block "
+                          f"'{block or target}'")
+    dev = node_features.device
+    n, e, dh = graph.n_nodes, graph.n_edges, model.hypers["d_head"]
+    nf = node_features.detach().to(torch.float32).contiguous()
+    ef = edge_features.detach().to(torch.float32).contiguous()
+    fc = None if cutoff_factors is None else cutoff_factors.detach().to(torch.float32).contiguous()
+    atomic = torch.empty((n, p), dtype=torch.float32, device=dev)
+    hn = torch.empty((n, dh), dtype=torch.float32, device=dev) if want_hidden else None
+    he = torch.empty((e, dh), dtype=torch.float32, device=dev) if want_hidden else None
+    scratch = torch.empty(int(lib.pet_predict_scratch_floats(n, e)), dtype=torch.float32, device=dev)
+    check(lib.pet_predict(model.handle, graph.handle, tname, readout_layer, bname, _ptr(nf), _ptr(ef), _ptr(fc), _ptr(atomic),
+                          _ptr(hn), _ptr(he), _ptr(scratch), _stream()))
+    return (atomic, hn, he) if want_hidden else atomic
+
+
+def predict_backward(model: HipModel, graph: HipGraph, node_features: torch.Tensor, edge_features: torch.Tensor,
+                     grad_atomic: torch.Tensor, target: str, block: Optional[str] = None, readout_layer: int = 0,
+                     cutoff_factors: Optional[torch.Tensor] = None):
+    """Adjoint of :func:`predict` from the same inputs: ``(d node features, d edge features (CSR), d cutoff factors)``."""
+    lib = model.lib
+    tname, bname = _head_names(model, target, block, readout_layer == 0)
+    dev = node_features.device
+    n, e = graph.n_nodes, graph.n_edges
+    nf = node_features.detach().to(torch.float32).contiguous()
+    ef = edge_features.detach().to(torch.float32).contiguous()
+    fc = None if cutoff_factors is None else cutoff_factors.detach().to(torch.float32).contiguous()
+    ga = grad_atomic.detach().to(torch.float32).reshape(n, -1).contiguous()
+    g_nf = torch.empty((n, model.hypers["d_node"]), dtype=torch.float32, device=dev)
+    g_ef = torch.zeros((e, model.hypers["d_pet"]), dtype=torch.float32, device=dev)
+    g_fc = torch.zeros(e, dtype=torch.float32, device=dev)
+    scratch = torch.empty(int(lib.pet_predict_scratch_floats(n, e)), dtype=torch.float32, device=dev)
+    check(lib.pet_predict_backward(model.handle, graph.handle, tname, readout_layer, bname, _ptr(nf), _ptr(ef), _ptr(fc),
+                                   _ptr(ga), _ptr(g_nf), _ptr(g_ef), _ptr(g_fc), _ptr(scratch), _stream()))
+    return g_nf, g_ef, g_fc
 
 
 def neighbor_list(positions: torch.Tensor, cell: torch.Tensor, pbc, cutoff: float):

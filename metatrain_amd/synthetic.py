@@ -66,10 +66,13 @@ def state_dict_schema(hypers: dict, atomic_types: List[int], targets: Dict[str, 
     for t in targets:
         lin(f"edge_heads.{t}.0.0", dh, d)
         lin(f"edge_heads.{t}.0.2", dh, dh)
+    # a target maps to its number of properties (one block named like the target) or to {block: properties}
     for t, nprop in targets.items():
-        lin(f"node_last_layers.{t}.0.{t}", nprop, dh)
+        for b, n in (nprop.items() if isinstance(nprop, dict) else [(t, nprop)]):
+            lin(f"node_last_layers.{t}.0.{b}", n, dh)
     for t, nprop in targets.items():
-        lin(f"edge_last_layers.{t}.0.{t}", nprop, dh)
+        for b, n in (nprop.items() if isinstance(nprop, dict) else [(t, nprop)]):
+            lin(f"edge_last_layers.{t}.0.{b}", n, dh)
     return out
 
 

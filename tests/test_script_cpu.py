@@ -59,3 +59,30 @@ def test_cpu_tensors_are_refused(core):
     with pytest.raises(RuntimeError, match="no CPU path"):
         mod(z(2, 3), z(1, 3, 3), z(0, dtype=torch.int32), z(0, dtype=torch.int32), z(0, 3, dtype=torch.int32),
             torch.tensor([1, 6]), z(2, dtype=torch.int32))
+
+
+def test_backend_mirror_scripts_like_the_reference_module():
+    """utils/testing/torchscript.py:39-75 at the backend level: ``torch.jit.script(PETBackend)`` compiles the three
+    calls (each one a method of torch.classes.pet_hip.PetHipBackend), survives torch.jit.save / load with its
+    parameters and a (target with several blocks and properties), and refuses CPU tensors."""
+    from metatrain_amd.pet import PETBackend
+
+    be = PETBackend(default_hypers(), [1, 6, 7, 8])
+    be.add_output("energy", {"energy": [1]})
+    be.add_output("multi", {"a": [3], "b": [3, 2]})
+    n_params = len(list(be.parameters()))
+    mod = torch.jit.script(be)
+    for name in ("preprocess", "calculate_features", "predict"):
+        assert hasattr(mod, name)
+    assert "Dict(str, Tensor)" in str(mod.preprocess.schema) and "cutoff_width_adaptive" in str(mod.preprocess.schema)
+    assert "requested_output_names" in str(mod.predict.schema)
+    buf = io.BytesIO()
+    torch.jit.save(mod, buf)
+    buf.seek(0)
+    back = torch.jit.load(buf)
+    assert len(back._params()) == n_params
+    assert [tuple(a.shape) for a in back._params()] == [tuple(a.shape) for a in be._params()]
+    z = torch.zeros
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        back.preprocess(z(2, 3), z(0, dtype=torch.int32), z(0, dtype=torch.int32), torch.tensor([1, 6]), z(1, 3, 3),
+                        z(0, 3, dtype=torch.int32), z(2, dtype=torch.long), 1.0)
