@@ -102,6 +102,17 @@ int pet_nl_build(const float* d_positions, const float* h_cell, const int32_t* h
                  int64_t n_atoms, float cutoff, void* d_workspace, int32_t* d_pairs,
                  float* d_vectors, int64_t capacity, int64_t* n_pairs, void* stream);
 
+/* All systems of a batch in one set of launches (what the reference does per system inside DataLoader workers,
+ * utils/neighbor_lists.py:13-46): positions concatenated, system s owning atoms h_first_atom[s] .. h_first_atom[s+1]-1,
+ * h_cells [S,9] / h_pbc [S,3] on the host. Pairs carry GLOBAL atom indices (the offsets concatenate_structures adds,
+ * structures.py:81-85), grouped by centre. d_pairs = NULL counts only. With d_pairs: one call does everything when
+ * `capacity` suffices; otherwise PET_ERR_ARGUMENT and *n_pairs tells the size to retry with. One device->host
+ * read-back per call (two when a system has an open boundary: its bounding box). */
+int64_t pet_nl_batch_workspace_bytes(int64_t n_atoms, int64_t n_systems);
+int pet_nl_build_batch(const float* d_positions, const float* h_cells, const int32_t* h_pbc, const int64_t* h_first_atom,
+                       int64_t n_systems, float cutoff, void* d_workspace, int32_t* d_pairs, float* d_vectors,
+                       int64_t capacity, int64_t* n_pairs, void* stream);
+
 /* ---- preprocess (replaces PETBackend.preprocess, backend.py:238) --------------- */
 int64_t pet_graph_workspace_bytes(int64_t n_nodes, int64_t n_edges_in);
 /* Builds edge vectors, the non-strict filter, cutoff factors, the CSR (= NEF slot)

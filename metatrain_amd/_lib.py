@@ -25,7 +25,7 @@ SYMBOLS = [
     "pet_last_error", "pet_version", "pet_hypers_supported",
     "pet_model_create", "pet_model_destroy", "pet_model_set_param", "pet_model_finalize",
     "pet_model_num_params",
-    "pet_nl_workspace_bytes", "pet_nl_build",
+    "pet_nl_workspace_bytes", "pet_nl_build", "pet_nl_batch_workspace_bytes", "pet_nl_build_batch",
     "pet_graph_workspace_bytes", "pet_graph_build", "pet_graph_destroy", "pet_graph_num_edges",
     "pet_graph_max_neighbors", "pet_graph_export_batch", "pet_graph_csr",
     "pet_graph_from_batch_workspace_bytes", "pet_graph_from_batch", "pet_model_block_properties",
@@ -120,6 +120,10 @@ def load() -> ctypes.CDLL:
     lib.pet_nl_workspace_bytes.restype = c_int64
     lib.pet_nl_build.argtypes = [P, POINTER(c_float), POINTER(c_int32), c_int64, c_float, P, P, P,
                                  c_int64, POINTER(c_int64), P]
+    lib.pet_nl_batch_workspace_bytes.argtypes = [c_int64, c_int64]
+    lib.pet_nl_batch_workspace_bytes.restype = c_int64
+    lib.pet_nl_build_batch.argtypes = [P, POINTER(c_float), POINTER(c_int32), POINTER(c_int64), c_int64, c_float, P, P, P,
+                                       c_int64, POINTER(c_int64), P]
     lib.pet_graph_workspace_bytes.argtypes = [c_int64, c_int64]
     lib.pet_graph_workspace_bytes.restype = c_int64
     lib.pet_graph_build.argtypes = [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, P, c_int64,

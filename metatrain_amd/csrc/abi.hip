@@ -534,6 +534,16 @@ int pet_nl_build(const float* d_positions, const float* h_cell, const int32_t* h
                     n_pairs, (hipStream_t)stream);
 }
 
+int64_t pet_nl_batch_workspace_bytes(int64_t n_atoms, int64_t n_systems) { return nl_batch_workspace_bytes(n_atoms, n_systems); }
+
+int pet_nl_build_batch(const float* d_positions, const float* h_cells, const int32_t* h_pbc, const int64_t* h_first_atom,
+                       int64_t n_systems, float cutoff, void* d_workspace, int32_t* d_pairs, float* d_vectors,
+                       int64_t capacity, int64_t* n_pairs, void* stream) {
+    PET_REQUIRE(d_positions && h_cells && h_pbc && h_first_atom && d_workspace && n_pairs, PET_ERR_ARGUMENT, "null argument");
+    return nl_build_batch(d_positions, h_cells, h_pbc, h_first_atom, n_systems, cutoff, d_workspace, d_pairs, d_vectors,
+                          capacity, n_pairs, (hipStream_t)stream);
+}
+
 int64_t pet_graph_workspace_bytes(int64_t n_nodes, int64_t n_edges_in) {
     return graph_workspace_bytes(n_nodes, n_edges_in);
 }

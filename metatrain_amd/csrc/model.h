@@ -119,6 +119,10 @@ int sum_over_atoms(const Graph& g, const float* atomic, float* out, hipStream_t 
 
 // nl.hip
 int64_t nl_workspace_bytes(int64_t n_atoms);
+int64_t nl_batch_workspace_bytes(int64_t n_atoms, int64_t n_systems);
+int nl_build_batch(const float* d_pos, const float* h_cells, const int* h_pbc, const int64_t* h_first_atom, int64_t n_sys,
+                   float cutoff, void* ws, int* d_pairs, float* d_vectors, int64_t capacity, int64_t* n_pairs,
+                   hipStream_t st);
 int nl_build(const float* d_pos, const float* h_cell, const int* h_pbc, int64_t n, float cutoff,
              void* ws, int* d_pairs, float* d_vectors, int64_t capacity, int64_t* n_pairs,
              hipStream_t st);

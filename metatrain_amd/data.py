@@ -25,25 +25,22 @@ def collate(systems: List[System], cutoff: float, targets: Optional[Dict[str, Li
     if not systems:
         raise ValueError("collate needs at least one system")
     dev = systems[0][0].device
-    pos_l, z_l, cell_l, pair_l, sys_l = [], [], [], [], []
-    offset = 0
+    pos_l, z_l, cell_l, sys_l, first = [], [], [], [], [0]
     for k, (pos, z, cell, pbc) in enumerate(systems):
         pos = pos.detach().to(dev, torch.float32)
-        n = int(pos.shape[0])
-        pairs, _ = rt.neighbor_list(pos, cell, pbc, cutoff)  # [e,5] rows (i, j, Sa, Sb, Sc), grouped by i
-        if offset:
-            pairs = pairs.clone()
-            pairs[:, 0:2] += offset
         pos_l.append(pos)
         z_l.append(z.to(dev, torch.int32))
-        cell_l.append(cell.detach().to(dev, torch.float32))
-        pair_l.append(pairs)
-        sys_l.append(torch.full((n,), k, dtype=torch.int32, device=dev))
-        offset += n
-    pairs = torch.cat(pair_l)
+        cell_l.append(cell.detach().to(torch.float32))
+        sys_l.append(torch.full((int(pos.shape[0]),), k, dtype=torch.int32, device=dev))
+        first.append(first[-1] + int(pos.shape[0]))
+    positions = torch.cat(pos_l)
+    cells = torch.stack([c.to(dev) for c in cell_l])
+    # every system's neighbour list in ONE set of launches, global atom indices (pet_nl_build_batch)
+    pairs, _ = rt.neighbor_list_batch(positions, torch.stack([c.cpu() for c in cell_l]), [s[3] for s in systems], first,
+                                      cutoff, want_vectors=False)
     batch = {
-        "positions": torch.cat(pos_l),
-        "cells": torch.stack(cell_l),
+        "positions": positions,
+        "cells": cells,
         "centers": pairs[:, 0].contiguous(),
         "neighbors": pairs[:, 1].contiguous(),
         "cell_shifts": pairs[:, 2:5].contiguous(),

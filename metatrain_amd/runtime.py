@@ -481,25 +481,48 @@ def predict_backward(model: HipModel, graph: HipGraph, node_features: torch.Tens
     return g_nf, g_ef, g_fc
 
 
-def neighbor_list(positions: torch.Tensor, cell: torch.Tensor, pbc, cutoff: float):
-    """Device neighbour list of one system: ``(pairs [E,5] int32, vectors [E,3] fp32)`` with rows
-    ``(i, j, Sa, Sb, Sc)`` grouped by ``i`` (replaces vesin, utils/neighbor_lists.py:131-135)."""
+_nl_guess: Dict[int, int] = {}  # atoms in the batch -> pairs found last time (sizes the next optimistic call)
+
+
+def neighbor_list_batch(positions: torch.Tensor, cells, pbcs, first_atom: List[int], cutoff: float,
+                        want_vectors: bool = True):
+    """Device neighbour lists of all systems of a batch in one set of launches (``pet_nl_build_batch``):
+    ``positions [N,3]`` concatenated, system ``s`` owning atoms ``first_atom[s] .. first_atom[s+1]-1``; ``cells``
+    ``[S,3,3]`` (host or device tensor, or list), ``pbcs`` ``[S][3]`` booleans. Returns ``(pairs [E,5] int32, vectors
+    [E,3] fp32 or None)`` with GLOBAL atom indices, rows ``(i, j, Sa, Sb, Sc)`` grouped by ``i``.
+    One call when the pair buffer sized from the previous call of this size suffices, else a second one."""
     _require_cuda(positions)
     lib = _lib.load()
     pos = positions.detach().to(torch.float32).contiguous()
-    n = int(pos.shape[0])
-    h_cell = (c_float * 9)(*[float(x) for x in cell.detach().cpu().reshape(-1).tolist()])
-    h_pbc = (c_int32 * 3)(*[int(bool(x)) for x in pbc])
-    ws = torch.empty(int(lib.pet_nl_workspace_bytes(n)), dtype=torch.uint8, device=pos.device)
+    n, n_sys = int(pos.shape[0]), len(first_atom) - 1
+    cells_t = torch.as_tensor(cells) if not isinstance(cells, torch.Tensor) else cells
+    flat = [float(x) for x in cells_t.detach().cpu().reshape(-1).tolist()]
+    h_cells = (c_float * (9 * n_sys))(*flat)
+    h_pbc = (c_int32 * (3 * n_sys))(*[int(bool(x)) for p in pbcs for x in p])
+    h_first = (c_int64 * (n_sys + 1))(*[int(x) for x in first_atom])
+    ws = torch.empty(int(lib.pet_nl_batch_workspace_bytes(n, n_sys)), dtype=torch.uint8, device=pos.device)
     count = c_int64(0)
-    check(lib.pet_nl_build(_ptr(pos), h_cell, h_pbc, n, float(cutoff), _ptr(ws), c_void_p(0), c_void_p(0), 0,
-                           byref(count), _stream()))
-    e = int(count.value)
-    pairs = torch.empty((e, 5), dtype=torch.int32, device=pos.device)
-    vectors = torch.empty((e, 3), dtype=torch.float32, device=pos.device)
-    check(lib.pet_nl_build(_ptr(pos), h_cell, h_pbc, n, float(cutoff), _ptr(ws), _ptr(pairs), _ptr(vectors), e,
-                           byref(count), _stream()))
-    return pairs, vectors
+    cap = max(1024, int(1.1 * _nl_guess.get(n, 32 * n)))
+    for _ in range(2):
+        pairs = torch.empty((cap, 5), dtype=torch.int32, device=pos.device)
+        vectors = torch.empty((cap, 3), dtype=torch.float32, device=pos.device) if want_vectors else None
+        rc = lib.pet_nl_build_batch(_ptr(pos), h_cells, h_pbc, h_first, n_sys, float(cutoff), _ptr(ws), _ptr(pairs),
+                                    _ptr(vectors), cap, byref(count), _stream())
+        e = int(count.value)
+        if rc == 0:
+            _nl_guess[n] = e
+            return pairs[:e], (vectors[:e] if want_vectors else None)
+        if e <= cap:  # a real error, not a short buffer
+            check(rc)
+        cap = e
+    check(rc)
+
+
+def neighbor_list(positions: torch.Tensor, cell: torch.Tensor, pbc, cutoff: float):
+    """Device neighbour list of one system: ``(pairs [E,5] int32, vectors [E,3] fp32)`` with rows
+    ``(i, j, Sa, Sb, Sc)`` grouped by ``i`` (replaces vesin, utils/neighbor_lists.py:131-135)."""
+    return neighbor_list_batch(positions, torch.as_tensor(cell).reshape(1, 3, 3), [pbc], [0, int(positions.shape[0])],
+                               cutoff)
 
 
 def profile(enable: bool, stage: Optional[str] = None) -> None:
