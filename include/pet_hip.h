@@ -276,6 +276,14 @@ int pet_model_flat_grad(pet_model_t* m, float* d_flat, int64_t numel, int direct
  * then re-packs the weights. d_grad_norm (device, may be NULL) receives the pre-clip total norm. */
 int pet_adam_step(pet_model_t* m, float lr, float beta1, float beta2, float eps, float weight_decay,
                   float max_grad_norm, int64_t step, float* d_grad_norm, void* stream);
+/* Adam's first / second moments as two flat fp32 buffers of pet_model_num_params elements in upload order (the layout
+ * of pet_model_flat_grad): direction 0 copies them out, 1 copies them in. With the step counter this is the
+ * optimizer_state_dict a checkpoint keeps (pet/trainer.py:697-717, trainer checkpoint v15). */
+int pet_optimizer_state(pet_model_t* m, float* d_m, float* d_v, int64_t numel, int direction, void* stream);
+/* Declare parameter `key` (uploaded as a tensor stacked on itself, see pet_model_set_param) TIED: pet_adam_step sums
+ * the gradient slots of its two halves, counts the parameter once in the clipping norm and gives both halves the same
+ * update, so that they stay equal. */
+int pet_model_tie_halves(pet_model_t* m, const char* key);
 /* Workspace for pet_forward(save_for_backward = 2) + pet_backward_train. */
 int64_t pet_train_workspace_bytes(const pet_model_t* m, int64_t n_nodes, int64_t n_edges);
 /* Reverse pass of loss.backward() for L with dL/d(atomic prediction) = d_grad_atomic [N]:

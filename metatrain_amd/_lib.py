@@ -33,7 +33,7 @@ SYMBOLS = [
     "pet_forward_workspace_bytes", "pet_forward", "pet_aux_outputs", "pet_backward", "pet_backward_predict",
     "pet_backward_features", "pet_backward_geometry",
     "pet_model_zero_grad", "pet_model_get_grad", "pet_train_workspace_bytes", "pet_backward_train",
-    "pet_model_get_param", "pet_model_flat_grad", "pet_adam_step",
+    "pet_model_get_param", "pet_model_flat_grad", "pet_adam_step", "pet_optimizer_state", "pet_model_tie_halves",
     "pet_train2_workspace_bytes", "pet_backward_train2",
     "pet_sum_over_atoms",
     "pet_profile_enable", "pet_profile_select", "pet_profile_reset", "pet_profile_report", "pet_config_set",
@@ -159,6 +159,8 @@ def load() -> ctypes.CDLL:
     lib.pet_model_get_param.argtypes = [P, c_char_p, P, c_int64, P]
     lib.pet_model_flat_grad.argtypes = [P, P, c_int64, c_int, P]
     lib.pet_adam_step.argtypes = [P, c_float, c_float, c_float, c_float, c_float, c_float, c_int64, P, P]
+    lib.pet_optimizer_state.argtypes = [P, P, P, c_int64, c_int, P]
+    lib.pet_model_tie_halves.argtypes = [P, c_char_p]
     lib.pet_train2_workspace_bytes.argtypes = [P, c_int64, c_int64]
     lib.pet_train2_workspace_bytes.restype = c_int64
     lib.pet_backward_train2.argtypes = [P, P, P, c_int64, P, c_int64, P, P, P, P, P]

@@ -435,6 +435,16 @@ int pet_model_set_param(pet_model_t* pm, const char* key, const void* d_data, in
     return PET_OK;
 }
 
+int pet_model_tie_halves(pet_model_t* pm, const char* key) {
+    PET_REQUIRE(pm && key, PET_ERR_ARGUMENT, "null argument");
+    return tie_halves(pm->m, key);
+}
+
+int pet_optimizer_state(pet_model_t* pm, float* d_m, float* d_v, int64_t numel, int direction, void* stream) {
+    PET_REQUIRE(pm && d_m && d_v, PET_ERR_ARGUMENT, "null argument");
+    return optimizer_state(pm->m, d_m, d_v, numel, direction, (hipStream_t)stream);
+}
+
 int pet_model_finalize(pet_model_t* pm, void* stream) {
     PET_REQUIRE(pm, PET_ERR_ARGUMENT, "null model");
     return finalize(pm->m, (hipStream_t)stream);

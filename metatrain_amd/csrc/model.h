@@ -91,6 +91,12 @@ struct Model {
     int64_t* seg_off = nullptr;  // device table: first flat index of segment i (n_seg + 1 entries)
     int n_seg = 0;
     float* opt_scalars = nullptr;  // [4] sum of squares, clip coefficient
+    // tied parameters (activation = "SiLU": w_in held as [W; W]): (flat offset, half length) pairs
+    std::vector<int64_t> ties;
+    bool ties_dirty = false;
+    int64_t* d_ties = nullptr;
+    uint8_t* d_dup = nullptr;  // [n_params] 1 on the second copy of a tied parameter
+    int64_t max_tie_half = 0;
 };
 
 // abi.hip
@@ -100,6 +106,9 @@ int finalize(Model& m, hipStream_t st);
 // optim.hip: fused clip_grad_norm_ + Adam/AdamW over the flat gradient buffer, then re-pack
 int adam_step(Model& m, float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
               int64_t step, float* d_grad_norm, hipStream_t st);
+
+int tie_halves(Model& m, const std::string& key);
+int optimizer_state(Model& m, float* d_m, float* d_v, int64_t numel, int direction, hipStream_t st);
 
 // graph.hip
 int64_t graph_workspace_bytes(int64_t n_nodes, int64_t e0);

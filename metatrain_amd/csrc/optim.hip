@@ -15,12 +15,16 @@ namespace pet {
 // ---- global L2 norm of the flat gradient (deterministic two-stage sum, fp64 accumulate) -------
 constexpr int NORM_BLOCKS = 256;
 
-__global__ void k_sumsq_partial(const float* __restrict__ g, int64_t n, double* __restrict__ partial) {
+// `dup` (optional) marks the second copy of a tied parameter (activation = "SiLU": w_in is held as [W; W]): the norm is
+// that of the reference's parameter list, which has W once
+__global__ void k_sumsq_partial(const float* __restrict__ g, int64_t n, double* __restrict__ partial,
+                                const uint8_t* __restrict__ dup) {
     __shared__ double red[256];
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * per, i1 = min(n, i0 + per);
     double s = 0.0;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) s += (double)g[i] * (double)g[i];
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
+        if (!dup || !dup[i]) s += (double)g[i] * (double)g[i];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -71,6 +75,56 @@ __global__ void k_adam(float* const* __restrict__ seg_ptr, const int64_t* __rest
     *p = w - (lr / bc1) * (m1 / denom);
 }
 
+// tied halves: the gradient of W used as both the value and the gate projection is the sum of the two halves' slots;
+// both slots get that sum, so that the two copies receive the same Adam update and stay equal
+__global__ void k_tie_grads(float* __restrict__ g, const int64_t* __restrict__ ties /*[n_ties][2] offset, half*/, int n_ties) {
+    const int t = blockIdx.y;
+    if (t >= n_ties) return;
+    const int64_t off = ties[2 * t], half = ties[2 * t + 1];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    const float s = g[off + i] + g[off + half + i];
+    g[off + i] = s;
+    g[off + half + i] = s;
+}
+
+int tie_halves(Model& m, const std::string& key) {
+    const auto it = m.grad_off.find(key);
+    PET_REQUIRE(it != m.grad_off.end(), PET_ERR_ARGUMENT, "unknown parameter '" + key + "'");
+    const int64_t numel = m.raw.at(key).second;
+    PET_REQUIRE(numel % 2 == 0, PET_ERR_ARGUMENT, "a tied parameter has an even number of elements");
+    for (size_t k = 0; k + 1 < m.ties.size(); k += 2)
+        if (m.ties[k] == it->second) return PET_OK;  // already registered
+    m.ties.push_back(it->second);
+    m.ties.push_back(numel / 2);
+    m.ties_dirty = true;
+    return PET_OK;
+}
+
+static int ensure_ties(Model& m, hipStream_t st) {
+    if (!m.ties_dirty) return PET_OK;
+    int rc;
+    if ((rc = dev_alloc(m, (void**)&m.d_ties, m.ties.size() * sizeof(int64_t)))) return rc;
+    if (!m.d_dup && (rc = dev_alloc(m, (void**)&m.d_dup, m.n_params))) return rc;
+    std::vector<uint8_t> dup(m.n_params, 0);
+    int64_t max_half = 0;
+    for (size_t k = 0; k + 1 < m.ties.size(); k += 2) {
+        for (int64_t i = 0; i < m.ties[k + 1]; i++) dup[m.ties[k] + m.ties[k + 1] + i] = 1;
+        max_half = std::max(max_half, m.ties[k + 1]);
+    }
+    m.max_tie_half = max_half;
+    PET_HIP_CHECK(hipMemcpyAsync(m.d_ties, m.ties.data(), m.ties.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    PET_HIP_CHECK(hipMemcpyAsync(m.d_dup, dup.data(), dup.size(), hipMemcpyHostToDevice, st));
+    PET_HIP_CHECK(hipStreamSynchronize(st));
+    m.ties_dirty = false;
+    return PET_OK;
+}
+
+// Adam's first / second moments as flat buffers in upload order (the layout of pet_model_flat_grad): direction 0
+// copies them out, 1 copies them in (checkpoint / resume of the native step; pet/trainer.py:697-717 saves
+// optimizer_state_dict)
+int optimizer_state(Model& m, float* d_m, float* d_v, int64_t numel, int direction, hipStream_t st);
+
 static int ensure_state(Model& m, hipStream_t st) {
     if (m.adam_m) return PET_OK;
     int rc;
@@ -106,8 +160,12 @@ int adam_step(Model& m, float lr, float beta1, float beta2, float eps, float wei
     PET_REQUIRE(step >= 1, PET_ERR_ARGUMENT, "optimizer steps are counted from 1");
     int rc;
     if ((rc = ensure_state(m, st))) return rc;
+    if ((rc = ensure_ties(m, st))) return rc;
+    const int n_ties = (int)(m.ties.size() / 2);
+    if (n_ties > 0)
+        k_tie_grads<<<dim3(cdiv(m.max_tie_half, 256), n_ties), 256, 0, st>>>(m.grad_flat, m.d_ties, n_ties);
     double* partial = reinterpret_cast<double*>(m.opt_scalars + 4);
-    k_sumsq_partial<<<NORM_BLOCKS, 256, 0, st>>>(m.grad_flat, m.n_params, partial);
+    k_sumsq_partial<<<NORM_BLOCKS, 256, 0, st>>>(m.grad_flat, m.n_params, partial, n_ties > 0 ? m.d_dup : nullptr);
     k_clip_coef<<<1, 1, 0, st>>>(partial, NORM_BLOCKS, max_grad_norm, m.opt_scalars);
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
@@ -118,6 +176,21 @@ int adam_step(Model& m, float lr, float beta1, float beta2, float eps, float wei
     if (d_grad_norm)
         PET_HIP_CHECK(hipMemcpyAsync(d_grad_norm, m.opt_scalars, sizeof(float), hipMemcpyDeviceToDevice, st));
     return finalize(m, st);  // the packed / folded forms follow the updated raw weights
+}
+
+int optimizer_state(Model& m, float* d_m, float* d_v, int64_t numel, int direction, hipStream_t st) {
+    PET_REQUIRE(numel == m.n_params, PET_ERR_ARGUMENT, "optimizer state has pet_model_num_params elements per moment");
+    int rc;
+    if ((rc = ensure_state(m, st))) return rc;
+    const size_t bytes = m.n_params * sizeof(float);
+    if (direction == 0) {
+        PET_HIP_CHECK(hipMemcpyAsync(d_m, m.adam_m, bytes, hipMemcpyDeviceToDevice, st));
+        PET_HIP_CHECK(hipMemcpyAsync(d_v, m.adam_v, bytes, hipMemcpyDeviceToDevice, st));
+    } else {
+        PET_HIP_CHECK(hipMemcpyAsync(m.adam_m, d_m, bytes, hipMemcpyDeviceToDevice, st));
+        PET_HIP_CHECK(hipMemcpyAsync(m.adam_v, d_v, bytes, hipMemcpyDeviceToDevice, st));
+    }
+    return PET_OK;
 }
 
 }  // namespace pet

@@ -19,6 +19,70 @@ def env_rank() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def expand_hostlist(nodelist: str) -> List[str]:
+    """SLURM's compressed node list (``nid[001-003,007],login1``) as host names -- what ``hostlist.expand_hostlist`` gives
+    the reference (``utils/distributed/slurm.py:65``); python-hostlist is not a dependency here."""
+    hosts: List[str] = []
+    depth, start = 0, 0
+    parts = []
+    for k, ch in enumerate(nodelist):  # split on commas outside brackets
+        depth += ch == "["
+        depth -= ch == "]"
+        if ch == "," and depth == 0:
+            parts.append(nodelist[start:k])
+            start = k + 1
+    parts.append(nodelist[start:])
+    for part in parts:
+        if "[" not in part:
+            if part:
+                hosts.append(part)
+            continue
+        head, rest = part.split("[", 1)
+        body, tail = rest.split("]", 1)
+        for item in body.split(","):
+            if "-" in item:
+                lo, hi = item.split("-")
+                for v in range(int(lo), int(hi) + 1):
+                    hosts.append(f"{head}{v:0{len(lo)}d}{tail}")
+            else:
+                hosts.append(f"{head}{item}{tail}")
+    return hosts
+
+
+def is_slurm() -> bool:
+    """``utils/distributed/slurm.py:10-16``."""
+    return ("SLURM_JOB_ID" in os.environ) and ("SLURM_PROCID" in os.environ)
+
+
+def resolve_distributed(distributed) -> bool:
+    """``utils/distributed/slurm.py:28-41``: unset = on exactly when inside a SLURM job with more than one task."""
+    if distributed is None:
+        return is_slurm() and int(os.environ.get("SLURM_NTASKS", "1")) > 1
+    return bool(distributed)
+
+
+def slurm_environment(port: int) -> Tuple[int, int, int]:
+    """SLURM variables -> ``MASTER_ADDR / MASTER_PORT / WORLD_SIZE / RANK / LOCAL_RANK`` (``DistributedEnvironment``,
+    ``utils/distributed/slurm.py:44-79``): first node of the job is the master. Returns (rank, local_rank, world)."""
+    hostnames = expand_hostlist(os.environ["SLURM_JOB_NODELIST"])
+    os.environ["MASTER_ADDR"] = hostnames[0]
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["WORLD_SIZE"] = os.environ["SLURM_NTASKS"]
+    os.environ["RANK"] = os.environ["SLURM_PROCID"]
+    os.environ["LOCAL_RANK"] = os.environ["SLURM_LOCALID"]
+    return env_rank()
+
+
+def initialize_slurm_nccl_process_group(port: int) -> Tuple[torch.device, int, int]:
+    """``utils/distributed/slurm.py:82-102``: one process per GPU under ``srun``; device = local rank modulo the
+    visible device count; ``backend="nccl"`` is RCCL on ROCm. Returns (device, world_size, rank)."""
+    _, local_rank, _ = slurm_environment(port)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    dist.init_process_group(backend="nccl", device_id=device)
+    return device, dist.get_world_size(), dist.get_rank()
+
+
 def init(backend: str, device: torch.device = None) -> None:
     if dist.is_initialized():
         return

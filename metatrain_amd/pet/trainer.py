@@ -63,6 +63,19 @@ class TrainStep:
         self.total_steps = int(self.hypers["num_epochs"]) * int(steps_per_epoch)
         self.step_index = 0  # optimizer steps taken so far (LambdaLR's last_epoch)
 
+    def state_dict(self) -> Dict[str, object]:
+        """What the reference's trainer checkpoint keeps of the optimizer and scheduler (``pet/trainer.py:697-717``:
+        ``optimizer_state_dict``, ``scheduler_state_dict``, epoch): Adam's moments, the step counter that drives both
+        the bias correction and the LambdaLR schedule, and the hypers the schedule was built from."""
+        return {"step_index": self.step_index, "total_steps": self.total_steps, "hypers": dict(self.hypers),
+                "optimizer": {k: v.cpu() for k, v in self.model.optimizer_state().items()}}
+
+    def load_state_dict(self, state: Dict[str, object]) -> None:
+        self.step_index = int(state["step_index"])
+        self.total_steps = int(state["total_steps"])
+        self.hypers.update(state["hypers"])
+        self.model.load_optimizer_state(state["optimizer"])
+
     def current_lr(self) -> float:
         h = self.hypers
         return h["learning_rate"] * lr_lambda(self.step_index, self.total_steps, h["warmup_fraction"])

@@ -125,6 +125,8 @@ class HipModel:
             check(self.lib.pet_model_set_param(self._handle, ckey.encode(), _ptr(src), src.numel(), _stream()))
             torch.cuda.current_stream().synchronize()  # src may be a temporary
         check(self.lib.pet_model_finalize(self._handle, _stream()))
+        for key in self._tied:  # the fused Adam step keeps the two copies of a tied projection equal
+            check(self.lib.pet_model_tie_halves(self._handle, self._ckeys[key][0].encode()))
 
     def load_species_table(self) -> None:
         """Upload only ``species_to_species_index`` (enough for graph building: the SOAP path shares the
@@ -164,6 +166,13 @@ class HipModel:
             return out[: shape[0] // 2].clone()
         return out
 
+    def param_as_uploaded(self, key: str) -> torch.Tensor:
+        """The device copy exactly as uploaded (a tied parameter: both copies, stacked)."""
+        ckey, shape = self._ckeys[key]
+        out = torch.empty(shape, dtype=torch.float32, device="cuda")
+        check(self.lib.pet_model_get_param(self._handle, ckey.encode(), _ptr(out), out.numel(), _stream()))
+        return out
+
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """Current weights under the reference state-dict keys they were loaded with."""
         return {k: self.param(k) for k in self._ckeys}
@@ -179,13 +188,22 @@ class HipModel:
         check(self.lib.pet_model_flat_grad(self._handle, _ptr(flat), flat.numel(), 1, _stream()))
         torch.cuda.current_stream().synchronize()  # `flat` may be a temporary
 
+    def optimizer_state(self) -> Dict[str, torch.Tensor]:
+        """Adam's moments as flat buffers in upload order (``pet_optimizer_state``): what a checkpoint keeps."""
+        m = torch.empty(self.num_params, dtype=torch.float32, device="cuda")
+        v = torch.empty_like(m)
+        check(self.lib.pet_optimizer_state(self._handle, _ptr(m), _ptr(v), m.numel(), 0, _stream()))
+        return {"exp_avg": m, "exp_avg_sq": v}
+
+    def load_optimizer_state(self, state: Dict[str, torch.Tensor]) -> None:
+        m = state["exp_avg"].to("cuda", torch.float32).contiguous()
+        v = state["exp_avg_sq"].to("cuda", torch.float32).contiguous()
+        check(self.lib.pet_optimizer_state(self._handle, _ptr(m), _ptr(v), m.numel(), 1, _stream()))
+        torch.cuda.current_stream().synchronize()  # m / v may be temporaries
+
     def adam_step(self, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-8,
                   weight_decay: Optional[float] = None, max_grad_norm: float = 0.0) -> torch.Tensor:
         """clip_grad_norm_ + Adam/AdamW + re-pack; returns the pre-clip gradient norm (device scalar)."""
-        if self._tied:
-            raise PetHipError("the fused Adam step updates the two halves of a tied (activation = 'SiLU') w_in "
-                              "independently: train this variant through the torch mirror (PETBackend + a torch "
-                              "optimizer), which re-uploads the weights")
         norm = torch.empty(1, dtype=torch.float32, device="cuda")
         wd = -1.0 if weight_decay is None else float(weight_decay)
         check(self.lib.pet_adam_step(self._handle, float(lr), float(betas[0]), float(betas[1]), float(eps), wd,

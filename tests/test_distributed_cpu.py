@@ -106,3 +106,31 @@ def test_lr_schedule_matches_reference_formula():
     assert lr_lambda(10, total, wf) == 1.0
     assert abs(lr_lambda(505, total, wf) - 0.5) < 1e-12
     assert abs(lr_lambda(1000, total, wf)) < 1e-12
+
+
+def test_slurm_environment_and_process_group_call_sequence(monkeypatch):
+    """tests/utils/test_slurm.py:81-117 of the reference, on this package's rendezvous: SLURM variables become the
+    env:// variables (first node of the compressed node list is the master), the device is the local rank modulo
+    the device count, and the NCCL (= RCCL) group is initialised on that device -- all calls faked, no communication."""
+    from metatrain_amd import distributed as d
+
+    assert d.expand_hostlist("nid[001-003,007],login1") == ["nid001", "nid002", "nid003", "nid007", "login1"]
+    assert d.expand_hostlist("node12") == ["node12"]
+    for k, v in {"SLURM_JOB_ID": "7", "SLURM_JOB_NODELIST": "gpu[05-06]", "SLURM_NTASKS": "16", "SLURM_PROCID": "11",
+                 "SLURM_LOCALID": "3"}.items():
+        monkeypatch.setenv(k, v)
+    assert d.is_slurm() and d.resolve_distributed(None) and not d.resolve_distributed(False)
+    calls = []
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda dev: calls.append(("set_device", str(dev))))
+    monkeypatch.setattr(torch.distributed, "init_process_group",
+                        lambda backend, device_id=None: calls.append(("init", backend, str(device_id))))
+    monkeypatch.setattr(torch.distributed, "get_world_size", lambda: 16)
+    monkeypatch.setattr(torch.distributed, "get_rank", lambda: 11)
+    dev, world, rank = d.initialize_slurm_nccl_process_group(39591)
+    assert (str(dev), world, rank) == ("cuda:1", 16, 11)          # 3 % 2
+    assert calls == [("set_device", "cuda:1"), ("init", "nccl", "cuda:1")]
+    assert os.environ["MASTER_ADDR"] == "gpu05" and os.environ["MASTER_PORT"] == "39591"
+    assert (os.environ["WORLD_SIZE"], os.environ["RANK"], os.environ["LOCAL_RANK"]) == ("16", "11", "3")
+    for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)

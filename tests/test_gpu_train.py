@@ -232,15 +232,18 @@ def test_force_loss_parameter_gradients_match_oracle_double_backward(golden_dir,
     assert not bad, f"second-order parameter gradients off: {bad}"
 
 
-def test_energy_and_force_training_steps_match_torch_adam(golden_dir):
+@pytest.mark.parametrize("activation", ["SwiGLU", "SiLU"])
+def test_energy_and_force_training_steps_match_torch_adam(golden_dir, activation):
     """The reference step with forces (pet/trainer.py:417-467): evaluate_model builds dE/dR with
     create_graph=True, MSE on energies per atom + MSE on dE/dR, loss.backward() (double backward),
-    clip_grad_norm_(1.0), Adam. Three steps against torch driving the fp64 oracle."""
+    clip_grad_norm_(1.0), Adam. Three steps against torch driving the fp64 oracle. activation = "SiLU": the projection
+    is held twice on the device (value half = gate half); the fused step sums the two gradient slots, counts the
+    parameter once in the clipping norm and keeps the copies equal (pet_model_tie_halves)."""
     from metatrain_amd import runtime as rt
     from metatrain_amd.pet.trainer import TrainStep
 
     dev = torch.device("cuda:0")
-    hypers = dict(opet.DEFAULT_HYPERS)
+    hypers = dict(opet.DEFAULT_HYPERS, activation=activation)
     types = [1, 6, 7, 8]
     params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
     inp = _inputs(golden_dir, "batch_two_systems.npz")
@@ -295,6 +298,10 @@ def test_energy_and_force_training_steps_match_torch_adam(golden_dir):
             worst = max(worst, np.abs(delta - delta_ref)[signal].max() / (lr * steps))
         assert np.abs(delta - delta_ref).max() <= 2.01 * lr * steps
     assert worst < 0.02, worst
+    if activation == "SiLU":  # the two device copies of every tied projection are still one parameter
+        for k in model._tied:
+            both = model.param_as_uploaded(k)
+            assert torch.equal(both[: both.shape[0] // 2], both[both.shape[0] // 2:]), k
 
 
 def test_second_order_pass_properties_at_1000_atoms():
@@ -336,3 +343,48 @@ def test_second_order_pass_properties_at_1000_atoms():
     assert float((t1 + t2 - t12).abs().max()) < 2e-5 * float(t12.abs().max())
     _, g1b = run(nu1, u1)
     assert torch.equal(g1, g1b)  # fixed-order reductions everywhere: bit-reproducible
+
+
+def test_optimizer_state_round_trip_resumes_bit_identically(golden_dir):
+    """Checkpoint / resume of the native step (pet/trainer.py:697-717 keeps optimizer and scheduler state): two steps,
+    ``TrainStep.state_dict()`` + the weights, a FRESH model and step object loaded from them, then the third step --
+    bit-identical to the third step of the uninterrupted run (moments, step counter, learning-rate schedule)."""
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.pet.trainer import TrainStep
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS)
+    types = [1, 6, 7, 8]
+    params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    inp = _inputs(golden_dir, "batch_two_systems.npz")
+    s = inp["system_indices"].long()
+    n_atoms = torch.bincount(s).float().to(dev)
+    targets = (torch.tensor([1.5, -2.0]) * n_atoms.cpu()).to(dev)
+    tg = (0.3 * torch.randn(len(s), 3, generator=torch.Generator().manual_seed(3))).to(dev)
+    th = {"learning_rate": 1e-3, "warmup_fraction": 0.5, "num_epochs": 6}  # a schedule that moves every step
+
+    def fresh(weights):
+        model = rt.HipModel(hypers, types)
+        model.load({k: v.to(dev) for k, v in weights.items()}, "energy")
+        graph = rt.HipGraph(model, inp["positions"].float().to(dev), inp["cells"].float().to(dev), inp["centers"].to(dev),
+                            inp["neighbors"].to(dev), inp["cell_shifts"].to(dev), inp["species"].to(dev),
+                            inp["system_indices"].int().to(dev))
+        return model, graph, rt.HipForward(model, graph, train=True), TrainStep(model, th)
+
+    model, graph, fw, step = fresh(params)
+    for _ in range(2):
+        step(graph, fw, targets, n_atoms, tg)
+    ckpt = {"trainer": step.state_dict(), "weights": {k: v.cpu() for k, v in model.state_dict().items()}}
+    assert ckpt["trainer"]["step_index"] == 2 and float(ckpt["trainer"]["optimizer"]["exp_avg_sq"].abs().max()) > 0
+    out_a = step(graph, fw, targets, n_atoms, tg)
+    final_a = model.state_dict()
+
+    weights = dict(params)
+    weights.update(ckpt["weights"])
+    model_b, graph_b, fw_b, step_b = fresh(weights)
+    step_b.load_state_dict(ckpt["trainer"])
+    assert step_b.current_lr() == pytest.approx(1e-3 * (2 / 3))  # warm-up over 3 of 6 steps
+    out_b = step_b(graph_b, fw_b, targets, n_atoms, tg)
+    final_b = model_b.state_dict()
+    assert float(out_a["loss"]) == float(out_b["loss"]) and torch.equal(out_a["grad_norm"], out_b["grad_norm"])
+    assert all(torch.equal(final_a[k], final_b[k]) for k in final_a)

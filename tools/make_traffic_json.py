@@ -1,4 +1,4 @@
-"""profiles/<tag>_rocprofv3_summary.txt (FETCH_SIZE / WRITE_SIZE sections) -> profiles/r01_traffic.json.
+"""profiles/<tag>_rocprofv3_summary.txt (FETCH_SIZE / WRITE_SIZE sections) -> profiles/r0N_traffic.json (argv[3]).
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: FETCH_SIZE counts 64 B units
 reported in KiB on gfx950, i.e. half the bytes; WRITE_SIZE in KiB)."""
 import json
@@ -6,6 +6,7 @@ import re
 import sys
 
 src, edges = sys.argv[1], int(sys.argv[2])
+dst = sys.argv[3] if len(sys.argv) > 3 else "profiles/r02_traffic.json"
 text = open(src).read()
 sections = text.split("# counters")
 vals = {}
@@ -32,5 +33,9 @@ for name, v in vals.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v and name.startswith("k_"):
         out["kernels"][name] = {"calls": v["calls"], "fetch_kib_raw": v["FETCH_SIZE"], "write_kib_raw": v["WRITE_SIZE"],
                                 "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024}
-json.dump(out, open("profiles/r01_traffic.json", "w"), indent=1)
+# whole-step traffic over ALL kernels: the edge head runs once per step, so its call count is the number of steps profiled
+steps = max([v["calls"] for k, v in out["kernels"].items() if k.startswith("k_head_h")] or [1])
+out["steps_profiled"] = steps
+out["step_hbm_bytes"] = sum(v["hbm_bytes_per_launch"] * v["calls"] for v in out["kernels"].values()) / steps
+json.dump(out, open(dst, "w"), indent=1)
 print(len(out["kernels"]), "kernels")
