@@ -33,18 +33,27 @@ def state_dict_schema(hypers: dict, atomic_types: List[int], targets: Dict[str, 
         out.append((key + ".weight", (o, i), "linear_w"))
         out.append((key + ".bias", (o,), "linear_b"))
 
+    layer_norm = hypers.get("normalization", "RMSNorm") == "LayerNorm"
+    residual = hypers.get("featurizer_type", "feedforward") == "residual"
+    n_readout = hypers["num_gnn_layers"] if residual else 1  # backend.py:93-119
+
+    def norm(key, n):  # torch.nn.RMSNorm: weight; torch.nn.LayerNorm: weight, bias
+        out.append((key + ".weight", (n,), "norm_w"))
+        if layer_norm:
+            out.append((key + ".bias", (n,), "norm_b"))
+
     for g in range(hypers["num_gnn_layers"]):
         for a in range(hypers["num_attention_layers"]):
             lp = f"gnn_layers.{g}.trans.layers.{a}"
             lin(lp + ".attention.input_linear", 3 * d, d)
             lin(lp + ".attention.output_linear", d, d)
-            out.append((lp + ".norm_attention.weight", (d,), "norm_w"))
-            out.append((lp + ".norm_mlp.weight", (d,), "norm_w"))
+            norm(lp + ".norm_attention", d)
+            norm(lp + ".norm_mlp", d)
             lin(lp + ".mlp.w_in", 2 * dff, d)
             lin(lp + ".mlp.w_out", d, dff)
             lin(lp + ".center_contraction", d, dn)
             lin(lp + ".center_expansion", dn, d)
-            out.append((lp + ".norm_center_features.weight", (dn,), "norm_w"))
+            norm(lp + ".norm_center_features", dn)
             lin(lp + ".center_mlp.w_in", 4 * dn, dn)
             lin(lp + ".center_mlp.w_out", dn, 2 * dn)
         lin(f"gnn_layers.{g}.edge_embedder", d, 4)
@@ -52,27 +61,34 @@ def state_dict_schema(hypers: dict, atomic_types: List[int], targets: Dict[str, 
         lin(f"gnn_layers.{g}.compress.2", d, d)
         if g > 0:
             out.append((f"gnn_layers.{g}.neighbor_embedder.weight", (ns, d), "embedding"))
-    for g in range(hypers["num_gnn_layers"]):
-        out.append((f"combination_norms.{g}.weight", (2 * d,), "norm_w"))
-        out.append((f"combination_norms.{g}.bias", (2 * d,), "norm_b"))
-    for g in range(hypers["num_gnn_layers"]):
-        lin(f"combination_mlps.{g}.0", 2 * d, 2 * d)
-        lin(f"combination_mlps.{g}.2", d, 2 * d)
-    out.append(("node_embedders.0.weight", (ns, dn), "embedding"))
+    if not residual:
+        for g in range(hypers["num_gnn_layers"]):
+            out.append((f"combination_norms.{g}.weight", (2 * d,), "norm_w"))
+            out.append((f"combination_norms.{g}.bias", (2 * d,), "norm_b"))
+        for g in range(hypers["num_gnn_layers"]):
+            lin(f"combination_mlps.{g}.0", 2 * d, 2 * d)
+            lin(f"combination_mlps.{g}.2", d, 2 * d)
+    for l in range(n_readout):
+        out.append((f"node_embedders.{l}.weight", (ns, dn), "embedding"))
     out.append(("edge_embedder.weight", (ns, d), "embedding"))
+    # a target maps to its number of properties (one block named like the target) or to {block: properties};
+    # heads and last layers exist once per readout layer (backend.py:171-217)
     for t in targets:
-        lin(f"node_heads.{t}.0.0", dh, dn)
-        lin(f"node_heads.{t}.0.2", dh, dh)
+        for l in range(n_readout):
+            lin(f"node_heads.{t}.{l}.0", dh, dn)
+            lin(f"node_heads.{t}.{l}.2", dh, dh)
     for t in targets:
-        lin(f"edge_heads.{t}.0.0", dh, d)
-        lin(f"edge_heads.{t}.0.2", dh, dh)
-    # a target maps to its number of properties (one block named like the target) or to {block: properties}
+        for l in range(n_readout):
+            lin(f"edge_heads.{t}.{l}.0", dh, d)
+            lin(f"edge_heads.{t}.{l}.2", dh, dh)
     for t, nprop in targets.items():
-        for b, n in (nprop.items() if isinstance(nprop, dict) else [(t, nprop)]):
-            lin(f"node_last_layers.{t}.0.{b}", n, dh)
+        for l in range(n_readout):
+            for b, n in (nprop.items() if isinstance(nprop, dict) else [(t, nprop)]):
+                lin(f"node_last_layers.{t}.{l}.{b}", n, dh)
     for t, nprop in targets.items():
-        for b, n in (nprop.items() if isinstance(nprop, dict) else [(t, nprop)]):
-            lin(f"edge_last_layers.{t}.0.{b}", n, dh)
+        for l in range(n_readout):
+            for b, n in (nprop.items() if isinstance(nprop, dict) else [(t, nprop)]):
+                lin(f"edge_last_layers.{t}.{l}.{b}", n, dh)
     return out
 
 

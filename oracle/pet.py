@@ -127,6 +127,14 @@ def _rmsnorm(x, weight):
     return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * weight
 
 
+def _norm(x, p, key):
+    """norm_attention / norm_mlp / norm_center_features: torch.nn.RMSNorm (weight) or torch.nn.LayerNorm (weight, bias,
+    eps 1e-5) -- ``getattr(nn, norm)(d)`` at transformer.py:176-186."""
+    if key + ".bias" in p:
+        return torch.nn.functional.layer_norm(x, (x.shape[-1],), p[key + ".weight"], p[key + ".bias"], 1e-5)
+    return _rmsnorm(x, p[key + ".weight"])
+
+
 def _swiglu_ff(x, p, prefix):
     y = _linear(x, p, prefix + ".w_in")
     if p[prefix + ".w_in.weight"].shape[0] == 2 * p[prefix + ".w_out.weight"].shape[1]:
@@ -234,10 +242,12 @@ def pet_atomic_energies(
     (RMSNorm, SwiGLU, PreLN, feedforward featuriser, Bump/Cosine cutoff,
     no adaptive cutoff, non-strict neighbour list).
     """
-    assert hypers["normalization"] == "RMSNorm"
+    assert hypers["normalization"] in ("RMSNorm", "LayerNorm")
     assert hypers["activation"] in ("SwiGLU", "SiLU")
-    assert hypers["transformer_type"] == "PreLN"
-    assert hypers["featurizer_type"] == "feedforward"
+    assert hypers["transformer_type"] in ("PreLN", "PostLN")
+    assert hypers["featurizer_type"] in ("feedforward", "residual")
+    post_ln = hypers["transformer_type"] == "PostLN"
+    residual = hypers["featurizer_type"] == "residual"
     assert hypers["num_neighbors_adaptive"] is None or hypers["adaptive_cutoff_method"] == "solver"
     block = block or target
     cutoff, width = float(hypers["cutoff"]), float(hypers["cutoff_width"])
@@ -285,8 +295,11 @@ def pet_atomic_energies(
     key_bias = torch.log(torch.clamp(fc, min=1e-15))  # transformer.py:109-110
     scale = 1.0 / (math.sqrt(d_pet // n_heads) * hypers["attention_temperature"])
 
+    node_feats, edge_feats = [], []
     for g in range(hypers["num_gnn_layers"]):
         pre = f"gnn_layers.{g}"
+        if residual:  # backend.py:617: every GNN layer starts from its own node embedding
+            h = p[f"node_embedders.{g}.weight"][sp]
         geo = torch.cat([v, dist[:, None]], dim=1)
         e = _linear(geo, p, pre + ".edge_embedder")
         if g == 0:
@@ -301,23 +314,33 @@ def pet_atomic_energies(
         for a in range(hypers["num_attention_layers"]):
             lp = f"{pre}.trans.layers.{a}"
             c = _linear(h, p, lp + ".center_contraction")
-            xn = _rmsnorm(c, p[lp + ".norm_attention.weight"])
-            xe = _rmsnorm(e, p[lp + ".norm_attention.weight"])
-            qkv_n = _linear(xn, p, lp + ".attention.input_linear")
-            qkv_e = _linear(xe, p, lp + ".attention.input_linear")
-            qn, kn, vn = qkv_n.split(d_pet, dim=-1)
-            qe, ke, ve = qkv_e.split(d_pet, dim=-1)
-            on, oe = _attention_bucketed(
-                (qn, qe), (kn, ke), (vn, ve), key_bias, graph, n_heads, scale
-            )
-            on = _linear(on, p, lp + ".attention.output_linear")
-            oe = _linear(oe, p, lp + ".attention.output_linear")
+
+            def attention(tn, te):
+                qkv_n = _linear(tn, p, lp + ".attention.input_linear")
+                qkv_e = _linear(te, p, lp + ".attention.input_linear")
+                qn, kn, vn = qkv_n.split(d_pet, dim=-1)
+                qe, ke, ve = qkv_e.split(d_pet, dim=-1)
+                on, oe = _attention_bucketed((qn, qe), (kn, ke), (vn, ve), key_bias, graph, n_heads, scale)
+                return (_linear(on, p, lp + ".attention.output_linear"), _linear(oe, p, lp + ".attention.output_linear"))
+
+            if post_ln:  # transformer.py:236-262: norm AFTER each residual sum, the MLP on every token
+                on, oe = attention(c, e)
+                tn, te = _norm(c + on, p, lp + ".norm_attention"), _norm(e + oe, p, lp + ".norm_attention")
+                tn = _norm(tn + _swiglu_ff(tn, p, lp + ".mlp"), p, lp + ".norm_mlp")
+                e = _norm(te + _swiglu_ff(te, p, lp + ".mlp"), p, lp + ".norm_mlp")
+                on = tn
+            else:        # transformer.py:203-234
+                on, oe = attention(_norm(c, p, lp + ".norm_attention"), _norm(e, p, lp + ".norm_attention"))
             h = h + _linear(on, p, lp + ".center_expansion")
-            h = h + _swiglu_ff(
-                _rmsnorm(h, p[lp + ".norm_center_features.weight"]), p, lp + ".center_mlp"
-            )
-            e = e + oe
-            e = e + _swiglu_ff(_rmsnorm(e, p[lp + ".norm_mlp.weight"]), p, lp + ".mlp")
+            h = h + _swiglu_ff(_norm(h, p, lp + ".norm_center_features"), p, lp + ".center_mlp")
+            if not post_ln:
+                e = e + oe
+                e = e + _swiglu_ff(_norm(e, p, lp + ".norm_mlp"), p, lp + ".mlp")
+        if residual:     # backend.py:621-647: features of every layer are read out; messages are averaged with the
+            node_feats.append(h)  # reversed ones, no combination MLP
+            edge_feats.append(e)
+            m = 0.5 * (m + e[rev])
+            continue
         cat = torch.cat([e, e[rev]], dim=1)  # backend.py:559-570
         cat = torch.nn.functional.layer_norm(
             cat,
@@ -332,17 +355,24 @@ def pet_atomic_energies(
             f"combination_mlps.{g}.2",
         )
         m = m + e + upd
+    if not residual:
+        node_feats, edge_feats = [h], [m]
 
     silu = torch.nn.functional.silu
-    nl = silu(_linear(silu(_linear(h, p, f"node_heads.{target}.0.0")), p, f"node_heads.{target}.0.2"))
-    el = silu(_linear(silu(_linear(m, p, f"edge_heads.{target}.0.0")), p, f"edge_heads.{target}.0.2"))
-    node_pred = _linear(nl, p, f"node_last_layers.{target}.0.{block}")
-    edge_pred = _linear(el, p, f"edge_last_layers.{target}.0.{block}") * fc[:, None]
-    atomic = node_pred.index_add(0, ctr, edge_pred)
+    atomic = None
+    for l, (h, m) in enumerate(zip(node_feats, edge_feats)):  # backend.py:468-481: summed over readout layers
+        nl = silu(_linear(silu(_linear(h, p, f"node_heads.{target}.{l}.0")), p, f"node_heads.{target}.{l}.2"))
+        el = silu(_linear(silu(_linear(m, p, f"edge_heads.{target}.{l}.0")), p, f"edge_heads.{target}.{l}.2"))
+        node_pred = _linear(nl, p, f"node_last_layers.{target}.{l}.{block}")
+        edge_pred = _linear(el, p, f"edge_last_layers.{target}.{l}.{block}") * fc[:, None]
+        contrib = node_pred.index_add(0, ctr, edge_pred)
+        atomic = contrib if atomic is None else atomic + contrib
     if return_aux:
         def esum(x):
             return torch.zeros((n_nodes, x.shape[1]), dtype=x.dtype).index_add(0, ctr, x * fc[:, None])
         return atomic, torch.cat([h, esum(m)], dim=1), torch.cat([nl, esum(el)], dim=1)
+    if return_features == "all":  # every readout layer (residual featuriser: one per GNN layer)
+        return atomic, node_feats, edge_feats, graph
     if return_features:
         return atomic, h, m, graph
     return atomic
@@ -454,18 +484,27 @@ def state_dict_schema(hypers: dict, atomic_types: List[int], targets: Dict[str, 
         out.append((key + ".weight", (o, i), "linear_w"))
         out.append((key + ".bias", (o,), "linear_b"))
 
+    layer_norm = hypers.get("normalization", "RMSNorm") == "LayerNorm"
+    residual = hypers.get("featurizer_type", "feedforward") == "residual"
+    n_readout = hypers["num_gnn_layers"] if residual else 1  # backend.py:93-119
+
+    def norm(key, n):  # torch.nn.RMSNorm: weight; torch.nn.LayerNorm: weight, bias
+        out.append((key + ".weight", (n,), "norm_w"))
+        if layer_norm:
+            out.append((key + ".bias", (n,), "norm_b"))
+
     for g in range(hypers["num_gnn_layers"]):
         for a in range(hypers["num_attention_layers"]):
             lp = f"gnn_layers.{g}.trans.layers.{a}"
             lin(lp + ".attention.input_linear", 3 * d, d)
             lin(lp + ".attention.output_linear", d, d)
-            out.append((lp + ".norm_attention.weight", (d,), "norm_w"))
-            out.append((lp + ".norm_mlp.weight", (d,), "norm_w"))
+            norm(lp + ".norm_attention", d)
+            norm(lp + ".norm_mlp", d)
             lin(lp + ".mlp.w_in", (2 if hypers["activation"] == "SwiGLU" else 1) * dff, d)
             lin(lp + ".mlp.w_out", d, dff)
             lin(lp + ".center_contraction", d, dn)
             lin(lp + ".center_expansion", dn, d)
-            out.append((lp + ".norm_center_features.weight", (dn,), "norm_w"))
+            norm(lp + ".norm_center_features", dn)
             lin(lp + ".center_mlp.w_in", (4 if hypers["activation"] == "SwiGLU" else 2) * dn, dn)
             lin(lp + ".center_mlp.w_out", dn, 2 * dn)
         lin(f"gnn_layers.{g}.edge_embedder", d, 4)
@@ -473,27 +512,34 @@ def state_dict_schema(hypers: dict, atomic_types: List[int], targets: Dict[str, 
         lin(f"gnn_layers.{g}.compress.2", d, d)
         if g > 0:
             out.append((f"gnn_layers.{g}.neighbor_embedder.weight", (ns, d), "embedding"))
-    for g in range(hypers["num_gnn_layers"]):
-        out.append((f"combination_norms.{g}.weight", (2 * d,), "norm_w"))
-        out.append((f"combination_norms.{g}.bias", (2 * d,), "norm_b"))
-    for g in range(hypers["num_gnn_layers"]):
-        lin(f"combination_mlps.{g}.0", 2 * d, 2 * d)
-        lin(f"combination_mlps.{g}.2", d, 2 * d)
-    out.append(("node_embedders.0.weight", (ns, dn), "embedding"))
+    if not residual:
+        for g in range(hypers["num_gnn_layers"]):
+            out.append((f"combination_norms.{g}.weight", (2 * d,), "norm_w"))
+            out.append((f"combination_norms.{g}.bias", (2 * d,), "norm_b"))
+        for g in range(hypers["num_gnn_layers"]):
+            lin(f"combination_mlps.{g}.0", 2 * d, 2 * d)
+            lin(f"combination_mlps.{g}.2", d, 2 * d)
+    for l in range(n_readout):
+        out.append((f"node_embedders.{l}.weight", (ns, dn), "embedding"))
     out.append(("edge_embedder.weight", (ns, d), "embedding"))
+    # a target maps to its number of properties (one block named like the target) or to {block: properties};
+    # heads and last layers exist once per readout layer (backend.py:171-217)
+    for t in targets:
+        for l in range(n_readout):
+            lin(f"node_heads.{t}.{l}.0", dh, dn)
+            lin(f"node_heads.{t}.{l}.2", dh, dh)
+    for t in targets:
+        for l in range(n_readout):
+            lin(f"edge_heads.{t}.{l}.0", dh, d)
+            lin(f"edge_heads.{t}.{l}.2", dh, dh)
     for t, nprop in targets.items():
-        lin(f"node_heads.{t}.0.0", dh, dn)
-        lin(f"node_heads.{t}.0.2", dh, dh)
+        for l in range(n_readout):
+            for b, n in (nprop.items() if isinstance(nprop, dict) else [(t, nprop)]):
+                lin(f"node_last_layers.{t}.{l}.{b}", n, dh)
     for t, nprop in targets.items():
-        lin(f"edge_heads.{t}.0.0", dh, d)
-        lin(f"edge_heads.{t}.0.2", dh, dh)
-    # a target maps to its number of properties (one block named like the target) or to {block: properties}
-    for t, nprop in targets.items():
-        for b, n in (nprop.items() if isinstance(nprop, dict) else [(t, nprop)]):
-            lin(f"node_last_layers.{t}.0.{b}", n, dh)
-    for t, nprop in targets.items():
-        for b, n in (nprop.items() if isinstance(nprop, dict) else [(t, nprop)]):
-            lin(f"edge_last_layers.{t}.0.{b}", n, dh)
+        for l in range(n_readout):
+            for b, n in (nprop.items() if isinstance(nprop, dict) else [(t, nprop)]):
+                lin(f"edge_last_layers.{t}.{l}.{b}", n, dh)
     return out
 
 

@@ -510,8 +510,61 @@ def main_train():
     np.savez_compressed(os.path.join(HERE, "pet_train_two_systems.npz"), **store)
 
 
+VARIANTS = {
+    # tag: hypers that differ from the defaults (pet/documentation.py:159-259)
+    "legacy": dict(normalization="LayerNorm", activation="SiLU", transformer_type="PostLN", featurizer_type="residual"),
+    "layernorm": dict(normalization="LayerNorm"),
+    "postln": dict(transformer_type="PostLN"),
+    "residual": dict(featurizer_type="residual"),
+}
+
+
+def main_variants():
+    """the variants older / production checkpoints use (pet/checkpoints.py:190-205 upgrades them to
+    LayerNorm + SiLU + PostLN + residual featuriser = "legacy" here) and each switch on its own -- E, per-atom E, dE/dR
+    and (legacy) the features of every readout layer, from the reference in fp32 / fp64 on the 64-atom box ->
+    ``pet_variant_<tag>_box64.npz``."""
+    from oracle import nl as onl
+    from oracle import pet as opet
+
+    PETBackend = import_reference_backend()
+    torch.set_num_threads(8)
+    p64, z64, c64 = opet.random_box(64, seed=1)
+    for tag, delta in VARIANTS.items():
+        hyp = dict(opet.DEFAULT_HYPERS, **delta)
+        i, j, s, _ = onl.neighbor_list(p64.double().numpy(), c64.double().numpy(), [True] * 3, hyp["cutoff"])
+        store = {}
+        for dtype in (torch.float32, torch.float64):
+            be, _ = _reference_backend(PETBackend, hyp, dtype)
+            args = (p64.to(dtype), c64.to(dtype)[None], torch.tensor(i), torch.tensor(j), torch.tensor(s).long(), z64,
+                    torch.zeros(64, dtype=torch.long))
+            pos = args[0].clone().requires_grad_(True)
+            be = be.eval()
+            batch = be.preprocess(pos, args[2], args[3], args[5], args[1], args[4], args[6], 1.0)
+            nf, ef = be.calculate_features(batch)
+            pred, _, _ = be.predict(nf, ef, batch, args[1], args[6], ["energy"])
+            atomic = pred["energy"][0]
+            (grad,) = torch.autograd.grad(atomic.sum(), pos)
+            sfx = {torch.float32: "f32", torch.float64: "f64"}[dtype]
+            store[f"energies_{sfx}"] = atomic.sum(0, keepdim=True).detach().numpy()
+            store[f"atomic_{sfx}"] = atomic.detach().numpy()
+            store[f"grad_{sfx}"] = grad.numpy()
+            if dtype == torch.float64:
+                store["n_readout"] = np.array(len(nf))
+                for l in range(len(nf)):
+                    store[f"node_features_{l}_f64"] = nf[l].detach().numpy()
+                    if tag == "legacy":  # [64, M, 128] per layer: kept for one variant, in fp32, to bound the fixture size
+                        store[f"edge_features_{l}_f64_as_f32"] = ef[l].detach().float().numpy()
+                store["padding_mask"] = batch["padding_mask"].numpy()
+            print(tag, sfx, "E =", float(atomic.sum()), "|grad|max =", float(grad.abs().max()), "readout layers", len(nf))
+        _store_inputs(store, args)
+        np.savez_compressed(os.path.join(HERE, f"pet_variant_{tag}_box64.npz"), **store)
+
+
 if __name__ == "__main__":
-    if "--box10000" in sys.argv:
+    if "--variants" in sys.argv:
+        main_variants()
+    elif "--box10000" in sys.argv:
         main_box10000()
     elif "--cosine" in sys.argv:
         main_cosine()

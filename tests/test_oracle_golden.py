@@ -240,3 +240,27 @@ def test_box10000_golden_is_consistent(golden_dir):
     assert np.abs(g["atomic_ref_f32"] - g["atomic_ref_f64"]).max() < 1e-5 * scale
     assert np.abs(g["grad_f64"] - g["grad_ref_f32"]).max() < 1e-5 * np.abs(g["grad_f64"]).max()
     assert abs(g["grad_f64"].sum(0)).max() < 1e-9  # Newton's third law in fp64
+
+
+@pytest.mark.parametrize("tag", ["legacy", "layernorm", "postln", "residual"])
+def test_oracle_variants_match_reference(golden_dir, tag):
+    """LayerNorm normalisation (transformer.py:176-186), PostLN layers (:236-262), the residual
+    featuriser (backend.py:589-649) -- alone and combined with activation = "SiLU" as the reference's checkpoint
+    upgrade leaves older models (pet/checkpoints.py:190-205, "legacy") -- against make_golden.py --variants."""
+    delta = {"legacy": dict(normalization="LayerNorm", activation="SiLU", transformer_type="PostLN", featurizer_type="residual"),
+             "layernorm": dict(normalization="LayerNorm"), "postln": dict(transformer_type="PostLN"),
+             "residual": dict(featurizer_type="residual")}[tag]
+    hypers = dict(opet.DEFAULT_HYPERS, **delta)
+    g = _load(golden_dir, f"pet_variant_{tag}_box64.npz")
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    e, grad, atomic = _run_oracle(g, hypers, params, torch.float64)
+    np.testing.assert_allclose(e.numpy(), g["energies_f64"], rtol=1e-10)
+    np.testing.assert_allclose(atomic.numpy(), g["atomic_f64"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(grad.numpy(), g["grad_f64"], rtol=1e-8, atol=1e-11)
+    t = lambda k: torch.tensor(g[k])  # noqa: E731
+    _, nfs, efs, graph = opet.pet_atomic_energies(params, hypers, t("in_positions"), t("in_cells"), t("in_centers"),
+                                                  t("in_neighbors"), t("in_cell_shifts").long(), t("in_species"),
+                                                  t("in_system_indices"), return_features="all")
+    assert len(nfs) == int(g["n_readout"])
+    for l, nf in enumerate(nfs):
+        np.testing.assert_allclose(nf.numpy(), g[f"node_features_{l}_f64"], rtol=1e-8, atol=1e-11)
