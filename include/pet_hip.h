@@ -38,6 +38,13 @@ extern "C" {
 #define PET_CUTOFF_COSINE 0
 #define PET_CUTOFF_BUMP 1
 
+#define PET_NORM_RMS 0
+#define PET_NORM_LAYER 1
+#define PET_PRE_LN 0
+#define PET_POST_LN 1
+#define PET_FEATURIZER_FEEDFORWARD 0
+#define PET_FEATURIZER_RESIDUAL 1
+
 /* Mirrors the subset of ModelHypers that shapes the hot path
  * (src/metatrain/pet/documentation.py:159-259). */
 typedef struct pet_hypers {
@@ -58,6 +65,11 @@ typedef struct pet_hypers {
     float num_neighbors_adaptive; /* target neighbour count of the adaptive cutoff ("solver" method,
                                      pet/modules/adaptive_cutoff.py:110-229); <= 0: fixed cutoff */
     float cutoff_width_adaptive;  /* taper width of the adaptive-cutoff probe */
+    /* the architecture variants older checkpoints use (pet/checkpoints.py:190-205 upgrades them to
+     * LayerNorm + PostLN + residual); all 0 = the current defaults */
+    int32_t normalization;    /* PET_NORM_RMS | PET_NORM_LAYER (transformer.py:170-176; LayerNorm: eps 1e-5, weight + bias) */
+    int32_t transformer_type; /* PET_PRE_LN (transformer.py:203-234) | PET_POST_LN (transformer.py:236-262) */
+    int32_t featurizer_type;  /* PET_FEATURIZER_FEEDFORWARD (backend.py:496-587) | PET_FEATURIZER_RESIDUAL (backend.py:589-649) */
 } pet_hypers_t;
 
 typedef struct pet_model pet_model_t; /* packed weights on the device */
@@ -250,6 +262,19 @@ int pet_backward_geometry(const pet_model_t* m, const pet_graph_t* g, void* d_wo
                           int64_t workspace_bytes, const float* d_grad_geometry,
                           const float* d_grad_cutoff, float* d_grad_positions, float* d_grad_cells,
                           void* stream);
+
+/* Every readout layer at once (backend.py:93-119: the residual featuriser reads out the features of EVERY GNN layer,
+ * the feedforward one only the last: pet_model_num_readout_layers = num_gnn_layers or 1).
+ *   pet_forward_layers: h_node_features[l] -> device [N,d_node], h_edge_features[l] -> device [E,d_pet] (CSR rows), two
+ *     HOST arrays of n_layers device pointers (calculate_features' two lists, backend.py:344-418); no heads.
+ *   pet_backward_features_layers: its adjoint for one gradient per returned tensor (NULL entries = zero). */
+int32_t pet_model_num_readout_layers(const pet_model_t* m);
+int pet_forward_layers(const pet_model_t* m, const pet_graph_t* g, void* d_workspace, int64_t workspace_bytes,
+                       int save_for_backward, float* const* h_node_features, float* const* h_edge_features,
+                       int32_t n_layers, void* stream);
+int pet_backward_features_layers(const pet_model_t* m, const pet_graph_t* g, void* d_workspace, int64_t workspace_bytes,
+                                 const float* const* h_grad_node_features, const float* const* h_grad_edge_features,
+                                 int32_t n_layers, float* d_grad_geometry, float* d_grad_cutoff, void* stream);
 
 /* preprocess^T without a forward workspace (the autograd node of preprocess on its own):
  * d_scratch: 4 * n_edges floats. Needs the pet_graph_build handle (positions, shifts). */

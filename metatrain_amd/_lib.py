@@ -32,6 +32,7 @@ SYMBOLS = [
     "pet_predict_scratch_floats", "pet_predict", "pet_predict_backward", "pet_geometry_backward",
     "pet_forward_workspace_bytes", "pet_forward", "pet_aux_outputs", "pet_backward", "pet_backward_predict",
     "pet_backward_features", "pet_backward_geometry",
+    "pet_model_num_readout_layers", "pet_forward_layers", "pet_backward_features_layers",
     "pet_model_zero_grad", "pet_model_get_grad", "pet_train_workspace_bytes", "pet_backward_train",
     "pet_model_get_param", "pet_model_flat_grad", "pet_adam_step", "pet_optimizer_state", "pet_model_tie_halves",
     "pet_train2_workspace_bytes", "pet_backward_train2",
@@ -84,6 +85,9 @@ class PetHypers(ctypes.Structure):
         ("max_atomic_number", c_int32),
         ("num_neighbors_adaptive", c_float),
         ("cutoff_width_adaptive", c_float),
+        ("normalization", c_int32),
+        ("transformer_type", c_int32),
+        ("featurizer_type", c_int32),
     ]
 
 
@@ -154,6 +158,10 @@ def load() -> ctypes.CDLL:
     lib.pet_backward_predict.argtypes = [P, P, P, c_int64, P, P, P, P, P]
     lib.pet_backward_features.argtypes = [P, P, P, c_int64, P, P, P, P, P]
     lib.pet_backward_geometry.argtypes = [P, P, P, c_int64, P, P, P, P, P]
+    lib.pet_model_num_readout_layers.argtypes = [P]
+    lib.pet_model_num_readout_layers.restype = c_int32
+    lib.pet_forward_layers.argtypes = [P, P, P, c_int64, c_int, P, P, c_int32, P]
+    lib.pet_backward_features_layers.argtypes = [P, P, P, c_int64, P, P, c_int32, P, P, P]
     lib.pet_model_zero_grad.argtypes = [P, P]
     lib.pet_model_get_grad.argtypes = [P, c_char_p, P, c_int64, P]
     lib.pet_model_get_param.argtypes = [P, c_char_p, P, c_int64, P]

@@ -254,6 +254,11 @@ int finalize(Model& m, hipStream_t st) {
             if ((rc = get_lin(m, lp + ".center_contraction", D, DN, A.cc, st))) return rc;
             if ((rc = get_lin(m, lp + ".center_expansion", DN, D, A.ce, st))) return rc;
             if ((rc = get(m, lp + ".norm_center_features.weight", DN, &A.g_center))) return rc;
+            if (m.layer_norm()) {  // torch.nn.LayerNorm: weight + bias (transformer.py:170-176)
+                if ((rc = get(m, lp + ".norm_attention.bias", D, &A.b_attn))) return rc;
+                if ((rc = get(m, lp + ".norm_mlp.bias", D, &A.b_mlp))) return rc;
+                if ((rc = get(m, lp + ".norm_center_features.bias", DN, &A.b_center))) return rc;
+            }
             if ((rc = get_lin(m, lp + ".center_mlp.w_in", 2 * DNF, DN, A.cmlp_in, st))) return rc;
             if ((rc = get_lin(m, lp + ".center_mlp.w_out", DN, DNF, A.cmlp_out, st))) return rc;
         }
@@ -290,12 +295,16 @@ int finalize(Model& m, hipStream_t st) {
         }
         if ((rc = get_lin(m, pre + ".compress.2", D, D, G.compress2, st))) return rc;
         const std::string gs = std::to_string(g);
+        if (m.residual()) continue;  // backend.py:589-649: no combination modules, messages are averaged
         if ((rc = get(m, "combination_norms." + gs + ".weight", 2 * D, &G.ln_g))) return rc;
         if ((rc = get(m, "combination_norms." + gs + ".bias", 2 * D, &G.ln_b))) return rc;
         if ((rc = get_lin(m, "combination_mlps." + gs + ".0", 2 * D, 2 * D, G.comb0, st))) return rc;
         if ((rc = get_lin(m, "combination_mlps." + gs + ".2", D, 2 * D, G.comb2, st))) return rc;
     }
-    if ((rc = get(m, "node_embedders.0.weight", (int64_t)ns * DN, &m.node_emb))) return rc;
+    m.node_embs.assign(m.residual() ? h.num_gnn_layers : 1, nullptr);  // backend.py:93-119: one per readout layer
+    for (size_t l = 0; l < m.node_embs.size(); l++)
+        if ((rc = get(m, "node_embedders." + std::to_string(l) + ".weight", (int64_t)ns * DN, &m.node_embs[l]))) return rc;
+    m.node_emb = m.node_embs[0];
     if ((rc = get(m, "edge_embedder.weight", (int64_t)ns * D, &m.edge_emb))) return rc;
     // every head that was uploaded: "node_heads.<t>.<l>.0.weight" names a (target, readout layer); "node_last_layers.
     // <t>.<l>.<block>.weight" a block of P = numel / DH properties (backend.py:171-217). "@" is the fused target.
@@ -385,6 +394,10 @@ int pet_model_create(const pet_hypers_t* h, pet_model_t** out) {
                 "d_head=128, num_heads=8)");
     PET_REQUIRE(h->cutoff_function == PET_CUTOFF_BUMP || h->cutoff_function == PET_CUTOFF_COSINE,
                 PET_ERR_UNSUPPORTED, "unknown cutoff function");
+    PET_REQUIRE((h->normalization == PET_NORM_RMS || h->normalization == PET_NORM_LAYER) &&
+                    (h->transformer_type == PET_PRE_LN || h->transformer_type == PET_POST_LN) &&
+                    (h->featurizer_type == PET_FEATURIZER_FEEDFORWARD || h->featurizer_type == PET_FEATURIZER_RESIDUAL),
+                PET_ERR_UNSUPPORTED, "unknown normalization / transformer_type / featurizer_type");
     pet_model_t* pm = new pet_model_t();
     pm->m.h = *h;
     *out = pm;
@@ -616,6 +629,28 @@ int pet_forward(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace,
     PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
     return forward(pm->m, pg->g, d_workspace, workspace_bytes, save_for_backward, d_atomic, d_node_features,
                    d_edge_features, (hipStream_t)stream);
+}
+
+int32_t pet_model_num_readout_layers(const pet_model_t* pm) { return pm ? pm->m.num_readout_layers() : -1; }
+
+int pet_forward_layers(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
+                       int save_for_backward, float* const* h_node_features, float* const* h_edge_features, int32_t n_layers,
+                       void* stream) {
+    PET_REQUIRE(pm && pg && d_workspace && h_node_features && h_edge_features, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
+    PET_REQUIRE(n_layers == pm->m.num_readout_layers(), PET_ERR_ARGUMENT,
+                "expected one feature pair per readout layer (" + std::to_string(pm->m.num_readout_layers()) + ")");
+    return forward_layers(pm->m, pg->g, d_workspace, workspace_bytes, save_for_backward, nullptr, h_node_features,
+                          h_edge_features, n_layers, (hipStream_t)stream);
+}
+
+int pet_backward_features_layers(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
+                                 const float* const* h_grad_node_features, const float* const* h_grad_edge_features,
+                                 int32_t n_layers, float* d_grad_geometry, float* d_grad_cutoff, void* stream) {
+    PET_REQUIRE(pm && pg && d_workspace && h_grad_node_features && h_grad_edge_features && d_grad_geometry && d_grad_cutoff,
+                PET_ERR_ARGUMENT, "null argument");
+    return backward_features_layers_abi(pm->m, pg->g, d_workspace, workspace_bytes, h_grad_node_features,
+                                        h_grad_edge_features, n_layers, d_grad_geometry, d_grad_cutoff, (hipStream_t)stream);
 }
 
 // ---- predict as a function of its arguments ---------------------------------------------------------------------

@@ -37,6 +37,7 @@ struct Lin {
 struct AttnLayerW {
     Lin qkv, out, mlp_in, mlp_out, cc, ce, cmlp_in, cmlp_out;
     const float *g_attn = nullptr, *g_mlp = nullptr, *g_center = nullptr;
+    const float *b_attn = nullptr, *b_mlp = nullptr, *b_center = nullptr;  // LayerNorm biases (nullptr: RMSNorm)
 };
 
 struct GnnLayerW {
@@ -68,7 +69,15 @@ struct Model {
     int* species_table = nullptr;
     int species_table_len = 0;
     std::vector<GnnLayerW> gnn;
-    const float* node_emb = nullptr;  // [ns, DN]
+    const float* node_emb = nullptr;  // [ns, DN]  node_embedders.0
+    std::vector<const float*> node_embs;  // node_embedders.<l>: one per GNN layer for the residual featuriser, else [0]
+    // architecture variants (pet_hypers_t): the TRR kernels serve RMSNorm + PreLN transformer layers only
+    bool layer_norm() const { return h.normalization == PET_NORM_LAYER; }
+    bool post_ln() const { return h.transformer_type == PET_POST_LN; }
+    bool residual() const { return h.featurizer_type == PET_FEATURIZER_RESIDUAL; }
+    bool plain_layers() const { return !layer_norm() && !post_ln(); }
+    bool plain() const { return plain_layers() && !residual(); }
+    int num_readout_layers() const { return residual() ? h.num_gnn_layers : 1; }
     const float* edge_emb = nullptr;  // [ns, D]
     // the FUSED target (keys with "@" for target and block: pet_forward / the native training step): one property
     bool has_fused_head = false;
@@ -140,6 +149,10 @@ int nl_build(const float* d_pos, const float* h_cell, const int* h_pbc, int64_t 
 int64_t forward_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges, bool train = false);
 int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
             float* node_feat, float* edge_feat, hipStream_t st);
+int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
+                   float* const* node_feats, float* const* edge_feats, int n_layers, hipStream_t st);
+int backward_features_layers_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* const* g_node,
+                                 const float* const* g_edge, int n_layers, float* g_geo, float* g_fc, hipStream_t st);
 int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* grad_atomic,
              float* grad_pos, float* grad_cells, hipStream_t st);
 int64_t predict_scratch_floats(int64_t n_nodes, int64_t n_edges);

@@ -55,6 +55,49 @@ __device__ __forceinline__ void rmsnorm_bwd_rows(const float* Wt, const float* _
     }
 }
 
+// The same with LayerNorm (ln): xhat = (x - mean) rstd, dx = rstd (w - mean(w) - xhat mean(w xhat)).
+template <int K, class F>
+__device__ __forceinline__ void norm_bwd_rows(const float* Wt, const float* __restrict__ Xg, int64_t row0,
+                                              int64_t n_rows, int ldx, bool ln, F f) {
+    if (!ln) {
+        rmsnorm_bwd_rows<K>(Wt, Xg, row0, n_rows, ldx, f);
+        return;
+    }
+    constexpr int LDW = lds_ld(K);
+    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const bool valid = row0 + r < n_rows;
+    const float* xrow = Xg + (row0 + r) * ldx;
+    float s = 0.f, sw = 0.f;
+    for (int c = q * 4; c < K; c += 16) {
+        float4 x = valid ? *reinterpret_cast<const float4*>(xrow + c) : make_float4(0, 0, 0, 0);
+        float4 wv = *reinterpret_cast<const float4*>(Wt + r * LDW + c);
+        s += (x.x + x.y) + (x.z + x.w);
+        sw += (wv.x + wv.y) + (wv.z + wv.w);
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+    sw += __shfl_xor(sw, 1); sw += __shfl_xor(sw, 2);
+    const float mean = s * (1.0f / K), mw = sw * (1.0f / K);
+    float ss = 0.f, dot = 0.f;
+    for (int c = q * 4; c < K; c += 16) {
+        float4 x = valid ? *reinterpret_cast<const float4*>(xrow + c) : make_float4(0, 0, 0, 0);
+        float4 wv = *reinterpret_cast<const float4*>(Wt + r * LDW + c);
+        x.x -= mean; x.y -= mean; x.z -= mean; x.w -= mean;
+        ss += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        dot += x.x * wv.x + x.y * wv.y + x.z * wv.z + x.w * wv.w;
+    }
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2);
+    dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2);
+    const float rstd = rsqrtf(ss * (1.0f / K) + 1e-5f);
+    const float coef = dot * rstd * rstd * rstd * (1.0f / K);
+    if (!valid) return;
+    for (int c = q * 4; c < K; c += 16) {
+        float4 x = *reinterpret_cast<const float4*>(xrow + c);
+        float4 wv = *reinterpret_cast<const float4*>(Wt + r * LDW + c);
+        f(r, c, make_float4(rstd * (wv.x - mw) - (x.x - mean) * coef, rstd * (wv.y - mw) - (x.y - mean) * coef,
+                            rstd * (wv.z - mw) - (x.z - mean) * coef, rstd * (wv.w - mw) - (x.w - mean) * coef));
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // heads
 // ---------------------------------------------------------------------------------
@@ -275,11 +318,13 @@ __global__ void k_dxf(const float* __restrict__ dM, const float* __restrict__ dc
 //   y = x + Wout (v * sig(g)),  [v; g] = Win RMSNorm(x)
 //   dx = dy + RMSNorm^T( Win^T [du sig(g) ; du v sig'(g)] ),  du = Wout^T dy
 // ---------------------------------------------------------------------------------
-template <int K, int HID, bool TRAIN>
+// NORM = false (PostLN, transformer.py:246-247: the MLP reads already-normalised tokens): dx = dy + Win^T [..]; ln: LayerNorm
+template <int K, int HID, bool TRAIN, bool NORM = true>
 __global__ __launch_bounds__(NTHREADS) void k_swiglu_bwd(const float* __restrict__ dY, const float* __restrict__ Xin,
                                                           const float* __restrict__ VG, const float* __restrict__ gamma,
                                                           const float4* __restrict__ woutb, const float4* __restrict__ winb,
-                                                          float* __restrict__ dXout, int64_t R, float* __restrict__ t_dvg) {
+                                                          float* __restrict__ dXout, int64_t R, float* __restrict__ t_dvg,
+                                                          bool ln = false) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDK = lds_ld(K);
     constexpr int NTO = K / 64;
@@ -337,10 +382,17 @@ __global__ __launch_bounds__(NTHREADS) void k_swiglu_bwd(const float* __restrict
         __syncthreads();
         gemm_acc<128, NTO>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, HID / 8 + 16 * hc, NTO * w.ch, dn, w.lane);
     }
+    if (!NORM) {
+        acc_foreach<NTO>(dn, w.rb, (K / 2) * w.ch, w.lane, [&](int r, int c, float v) {
+            const int64_t row = row0 + r;
+            if (row < R) dXout[row * K + c] = dY[row * K + c] + v;
+        });
+        return;
+    }
     __syncthreads();  // everyone is done with the dY tile in A
     acc_foreach<NTO>(dn, w.rb, (K / 2) * w.ch, w.lane, [&](int r, int c, float v) { A[r * LDK + c] = v * gamma[c]; });
     __syncthreads();
-    rmsnorm_bwd_rows<K>(A, Xin, row0, R, K, [&](int r, int c, float4 dx) {
+    norm_bwd_rows<K>(A, Xin, row0, R, K, ln, [&](int r, int c, float4 dx) {
         const int64_t o = (row0 + r) * K + c;
         float4 dy = *reinterpret_cast<const float4*>(dY + o);
         *reinterpret_cast<float4*>(dXout + o) = make_float4(dy.x + dx.x, dy.y + dx.y, dy.z + dx.z, dy.w + dx.w);
@@ -601,10 +653,12 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ QKV,
 // ---------------------------------------------------------------------------------
 // input_linear + RMSNorm adjoint: dXin = (rows<E ? dX1 : 0) + RMSNorm^T(dQKV Win)
 // ---------------------------------------------------------------------------------
+// POST (transformer.py:243-245): no norm in front of input_linear and every token row carries the residual gradient dX1
+template <bool POST>
 __global__ __launch_bounds__(NTHREADS) void k_qkv_bwd(const float* __restrict__ dQKV, const float* __restrict__ X,
                                                        const float* __restrict__ gamma, const float4* __restrict__ winb,
                                                        const float* __restrict__ dX1, float* __restrict__ dXin,
-                                                       int64_t E, int64_t R) {
+                                                       int64_t E, int64_t R, bool ln) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const WaveId w;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
@@ -617,10 +671,17 @@ __global__ __launch_bounds__(NTHREADS) void k_qkv_bwd(const float* __restrict__ 
         __syncthreads();
         gemm_acc<128, 2>(smem + w.rb * 32 * LD128, LD128, winb, 48, 16 * ks, 2 * w.ch, dn, w.lane);
     }
+    if (POST) {
+        acc_foreach<2>(dn, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
+            const int64_t row = row0 + r;
+            if (row < R) dXin[row * D + c] = dX1[row * D + c] + v;
+        });
+        return;
+    }
     __syncthreads();
     acc_foreach<2>(dn, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) { smem[r * LD128 + c] = v * gamma[c]; });
     __syncthreads();
-    rmsnorm_bwd_rows<128>(smem, X, row0, R, D, [&](int r, int c, float4 dx) {
+    norm_bwd_rows<128>(smem, X, row0, R, D, ln, [&](int r, int c, float4 dx) {
         const int64_t row = row0 + r;
         if (row < E) {
             float4 d1 = *reinterpret_cast<const float4*>(dX1 + row * D + c);
@@ -628,6 +689,49 @@ __global__ __launch_bounds__(NTHREADS) void k_qkv_bwd(const float* __restrict__ 
         }
         *reinterpret_cast<float4*>(dXin + row * D + c) = dx;
     });
+}
+
+// ---------------------------------------------------------------------------------
+// PostLN: adjoint of Y = Norm(S) (k_rownorm): rows < E of dY from dYe, rows >= E from dYc; dS on all E+N rows
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_rownorm_bwd(const float* __restrict__ dYe, const float* __restrict__ dYc,
+                                                           const float* __restrict__ S, const float* __restrict__ gamma,
+                                                           bool ln, float* __restrict__ dS, int64_t E, int64_t R) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    for (int idx = threadIdx.x; idx < BM * 32; idx += NTHREADS) {
+        const int r = idx >> 5, c = idx & 31;
+        const int64_t row = row0 + r;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (row < E) v = *reinterpret_cast<const float4*>(dYe + row * D + 4 * c);
+        else if (row < R) v = *reinterpret_cast<const float4*>(dYc + (row - E) * D + 4 * c);
+        const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c);
+        *reinterpret_cast<float4*>(smem + r * LD128 + 4 * c) = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
+    }
+    __syncthreads();
+    norm_bwd_rows<128>(smem, S, row0, R, D, ln, [&](int r, int c, float4 dx) {
+        *reinterpret_cast<float4*>(dS + (row0 + r) * D + c) = dx;
+    });
+}
+
+// residual featuriser adjoint (k_resmix): Mout[p] = 0.5 (Min[p] + e[rev[p]]) with rev an involution, so
+//   de[p] = ge[p] + 0.5 dMout[rev[p]],  dMin[p] = 0.5 dMout[p];  dMout == nullptr (last layer): de = ge, dMin = 0
+__global__ void k_resmix_bwd(const float* __restrict__ ge, const float* __restrict__ dMout, const int* __restrict__ rev,
+                             float* __restrict__ de, float* __restrict__ dMin, int64_t E) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * (D / 4)) return;
+    const int64_t p = idx / (D / 4);
+    const int c = (int)(idx % (D / 4));
+    float4 a = ge ? reinterpret_cast<const float4*>(ge)[idx] : make_float4(0, 0, 0, 0);
+    float4 mp = make_float4(0, 0, 0, 0);
+    if (dMout) {
+        const float4 b = *reinterpret_cast<const float4*>(dMout + (int64_t)rev[p] * D + 4 * c);
+        a.x += 0.5f * b.x; a.y += 0.5f * b.y; a.z += 0.5f * b.z; a.w += 0.5f * b.w;
+        const float4 q = reinterpret_cast<const float4*>(dMout)[idx];
+        mp = make_float4(0.5f * q.x, 0.5f * q.y, 0.5f * q.z, 0.5f * q.w);
+    }
+    reinterpret_cast<float4*>(de)[idx] = a;
+    reinterpret_cast<float4*>(dMin)[idx] = mp;
 }
 
 // ---------------------------------------------------------------------------------
@@ -918,54 +1022,78 @@ int backward_predict(const Model& m, const Graph& g, Workspace& w, const float* 
 }
 
 // Stage F: adjoint of PETBackend.calculate_features. (w.dH, w.dM) -> w.dgeo [E,4], w.dbias [E]
-int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t st, Trainer* tr = nullptr) {
+// Residual featuriser: one (node, edge) gradient pair per readout layer in g_node / g_edge (null entries = zero) instead
+// of the seeds in w.dH / w.dM.
+int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t st, Trainer* tr = nullptr,
+                      const float* const* g_node = nullptr, const float* const* g_edge = nullptr) {
     const int64_t N = g.n_nodes, E = g.n_edges, R = E + N;
     if (E == 0) return PET_OK;
     const int nt = attn_tiles(g);
     PET_REQUIRE(nt <= 8, PET_ERR_UNSUPPORTED, "more than 127 neighbours per atom is not supported yet");
+    const bool post = m.post_ln(), res = m.residual(), ln = m.layer_norm();
+    PET_REQUIRE(!tr || m.plain(), PET_ERR_UNSUPPORTED,
+                "training is built for normalization=RMSNorm, transformer_type=PreLN, featurizer_type=feedforward only");
+    PET_REQUIRE(!res || (g_node && g_edge), PET_ERR_ARGUMENT,
+                "residual featuriser: the reverse pass starts from one gradient pair per readout layer "
+                "(pet_backward_features_layers)");
     const float scale = 1.0f / (sqrtf((float)HD) * m.h.attention_temperature);
     const int gE = cdiv(E, BM), gN = cdiv(N, BM), gR = cdiv(R, BM);
     const size_t lds1 = BM * LD128 * 4, lds2 = 2 * BM * LD128 * 4;
     const double fE = (double)E, fN = (double)N, fR = (double)R;
     float* dbias_h = w.delta;  // [E, NHEAD] (reuses the delta carve)
     const bool trr = use_trr();
+    const bool trr_l = trr && m.plain_layers();  // the TRR transformer-layer kernels are RMSNorm + PreLN
     PET_HIP_CHECK(hipMemsetAsync(w.dgeo, 0, E * 4 * sizeof(float), st));
     PET_HIP_CHECK(hipMemsetAsync(dbias_h, 0, E * NHEAD * sizeof(float), st));
-    allow_big_lds(k_swiglu_bwd<256, DNF, false>, (BM * LD256 + BM * LD128) * 4);
-    allow_big_lds(k_swiglu_bwd<256, DNF, true>, (BM * LD256 + BM * LD128) * 4);
+    allow_big_lds(k_swiglu_bwd<256, DNF, false, true>, (BM * LD256 + BM * LD128) * 4);
+    allow_big_lds(k_swiglu_bwd<256, DNF, true, true>, (BM * LD256 + BM * LD128) * 4);
     allow_big_lds(k_expand_bwd, BM * LD256 * 4);
     float* dH = w.dH;
     float* dH_alt = w.dH2;
     float* dX = w.dX;
     float* dX_alt = w.dX2;
+    float* dM = w.dM;      // gradient w.r.t. the messages leaving the layer below the one being processed
+    float* dM_alt = w.dM2;
+    bool have_dM = !res;   // residual: no message gradient enters the last layer
     // node-feature adjoint chain on the side stream: it only meets the edge chain at output_linear^T
     // (needs dOC) and at the centre rows of the token gradient (k_center_bwd)
     SideStream ss = side_stream();
-    if (tr) ss.enabled = false;
+    if (tr || post || res) ss.enabled = false;
     const hipStream_t s2 = ss.stream(st);
     ss.fork(st);  // the seeds in w.dH / w.dM were produced on the main stream
     for (int gi = m.h.num_gnn_layers - 1; gi >= 0; gi--) {
         const GnnLayerW& G = m.gnn[gi];
         const GnnBufs& B = w.gnn[gi];
-        {
-            ProfScope ps("comb_bwd", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D));
-            if (!(trr && use_bf16x6() &&
-                  comb_bwd_bf16(w.dM, B.XF, g, G, B.LNS, B.CA, w.dcat, E, tr ? w.dCA : nullptr, st)))
-                PET_LAUNCH_TR1(tr, k_comb_bwd, gE, lds2, st, w.dM, B.XF, g.rev, B.LNS, B.CA, G.ln_g, G.comb2.bwd,
-                G.comb0.bwd, w.dcat, E, tr ? w.dCA : nullptr);
-            if (tr) {
-                const std::string gs = std::to_string(gi);
-                tr->linear("combination_mlps." + gs + ".2", D, 2 * D, {w.dM, nullptr, 0, D},
-                           {B.CA, 2 * D, 0, nullptr, nullptr}, 3, E);
-                tr->linear_after_norm("combination_mlps." + gs + ".0", G.comb0.w, 2 * D, 2 * D,
-                                      {w.dCA, nullptr, 0, 2 * D}, {B.XF, D, 0, g.rev, B.LNS}, 4, E,
-                                      "combination_norms." + gs + ".weight", G.ln_g,
-                                      "combination_norms." + gs + ".bias", G.ln_b);
+        if (res) {
+            // backend.py:621-647: this layer's features were read out (seeds g_node / g_edge), its edge features were
+            // averaged into the next layer's messages, and its node features started from a fresh embedding
+            if (g_node[gi]) PET_HIP_CHECK(hipMemcpyAsync(dH, g_node[gi], N * DN * sizeof(float), hipMemcpyDeviceToDevice, st));
+            else PET_HIP_CHECK(hipMemsetAsync(dH, 0, N * DN * sizeof(float), st));
+            ProfScope ps("comb_bwd", st, 0.0, fE * 4.0 * 4 * D);
+            k_resmix_bwd<<<cdiv(E * (D / 4), 256), 256, 0, st>>>(g_edge[gi], have_dM ? dM : nullptr, g.rev, dX, dM_alt, E);
+            std::swap(dM, dM_alt);
+            have_dM = true;
+        } else {
+            {
+                ProfScope ps("comb_bwd", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D));
+                if (!(trr && use_bf16x6() &&
+                      comb_bwd_bf16(dM, B.XF, g, G, B.LNS, B.CA, w.dcat, E, tr ? w.dCA : nullptr, st)))
+                    PET_LAUNCH_TR1(tr, k_comb_bwd, gE, lds2, st, dM, B.XF, g.rev, B.LNS, B.CA, G.ln_g, G.comb2.bwd,
+                    G.comb0.bwd, w.dcat, E, tr ? w.dCA : nullptr);
+                if (tr) {
+                    const std::string gs = std::to_string(gi);
+                    tr->linear("combination_mlps." + gs + ".2", D, 2 * D, {dM, nullptr, 0, D},
+                               {B.CA, 2 * D, 0, nullptr, nullptr}, 3, E);
+                    tr->linear_after_norm("combination_mlps." + gs + ".0", G.comb0.w, 2 * D, 2 * D,
+                                          {w.dCA, nullptr, 0, 2 * D}, {B.XF, D, 0, g.rev, B.LNS}, 4, E,
+                                          "combination_norms." + gs + ".weight", G.ln_g,
+                                          "combination_norms." + gs + ".bias", G.ln_b);
+                }
             }
-        }
-        {
-            ProfScope ps("dxf", st, 0.0);
-            k_dxf<<<cdiv(E * (D / 4), 256), 256, 0, st>>>(w.dM, w.dcat, g.rev, dX, E);
+            {
+                ProfScope ps("dxf", st, 0.0);
+                k_dxf<<<cdiv(E * (D / 4), 256), 256, 0, st>>>(dM, w.dcat, g.rev, dX, E);
+            }
         }
         for (int a = m.h.num_attention_layers - 1; a >= 0; a--) {
             const AttnLayerW& A = G.attn[a];
@@ -975,7 +1103,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             {
                 ProfScope ps("node_bwd", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
                 PET_LAUNCH_TR(tr, k_swiglu_bwd, PET_TA(256, DNF), gN, (BM * LD256 + BM * LD128) * 4, s2,  dH, Ab.H1,
-                    Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N, tr ? w.dVGn : nullptr);
+                    Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N, tr ? w.dVGn : nullptr, ln);
                 k_expand_bwd<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(dH_alt, A.ce.bwd, w.dOC, N);
                 if (tr) {
                     tr->linear(lp + ".center_mlp.w_out", DN, DNF, {dH, nullptr, 0, DN},
@@ -987,14 +1115,22 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                                {Ab.OC, D, 0, nullptr, nullptr}, 0, N);
                 }
             }
-            {
+            if (post) {
+                // transformer.py:245-247 backwards on every token: norm_mlp^T of [dX edge rows ; dOC], the MLP residual
+                // block on normalised tokens, norm_attention^T; dX_alt = gradient of (tokens + attention output)
+                ProfScope ps("emlp_bwd", st, fR * 2.0 * (D * 2 * DFF + DFF * D));
+                k_rownorm_bwd<<<gR, NTHREADS, lds1, st>>>(dX, w.dOC, Ab.S2, A.g_mlp, ln, dX_alt, E, R);
+                k_swiglu_bwd<128, DFF, false, false><<<gR, NTHREADS, lds2, st>>>(dX_alt, nullptr, Ab.VG, nullptr, A.mlp_out.bwd,
+                                                                                 A.mlp_in.bwd, dX, R, nullptr, false);
+                k_rownorm_bwd<<<gR, NTHREADS, lds1, st>>>(dX, dX + E * D, Ab.X1, A.g_attn, ln, dX_alt, E, R);
+            } else {
                 ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
-                if (trr) {
+                if (trr_l) {
                     const float* vg = (!tr && emlp_recompute_ok(A.mlp_in, A.mlp_out)) ? nullptr : Ab.VG;
                     trr_emlp_bwd(dX, Ab.X1, vg, A.g_mlp, A.mlp_in, A.mlp_out, dX_alt, E, st, tr ? w.dVG : nullptr);
                 }
                 else PET_LAUNCH_TR(tr, k_swiglu_bwd, PET_TA(128, DFF), gE, lds2, st, dX, Ab.X1, Ab.VG, A.g_mlp,
-                    A.mlp_out.bwd, A.mlp_in.bwd, dX_alt, E, tr ? w.dVG : nullptr);
+                    A.mlp_out.bwd, A.mlp_in.bwd, dX_alt, E, tr ? w.dVG : nullptr, ln);
                 if (tr) {
                     tr->linear(lp + ".mlp.w_out", D, DFF, {dX, nullptr, 0, D}, {Ab.VG, 2 * DFF, DFF, nullptr, nullptr},
                                2, E);
@@ -1003,11 +1139,12 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 }
             }
             ss.join(st);  // dOC ready
-            // dX_alt (edge rows) = dX1, dH_alt = dH1
+            // dX_alt (edge rows) = dX1, dH_alt = dH1; PostLN: dX_alt holds all E+N rows of d(tokens + attention output)
+            const float* dOCr = post ? dX_alt + E * D : w.dOC;
             {
                 ProfScope ps("oproj_bwd", st, fR * 2.0 * D * D);
-                if (trr) trr_oproj_bwd(dX_alt, w.dOC, A.out, w.dAO, E, R, st);
-                else k_oproj_bwd<<<gR, NTHREADS, lds1, st>>>(dX_alt, w.dOC, A.out.bwd, w.dAO, E, R);
+                if (trr_l) trr_oproj_bwd(dX_alt, w.dOC, A.out, w.dAO, E, R, st);
+                else k_oproj_bwd<<<gR, NTHREADS, lds1, st>>>(dX_alt, dOCr, A.out.bwd, w.dAO, E, R);
                 if (tr)
                     tr->linear(lp + ".attention.output_linear", D, D, {dX_alt, w.dOC, E, D},
                                {Ab.AO, D, 0, nullptr, nullptr}, 0, R);
@@ -1028,8 +1165,9 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                                       {Ab.X, D, 0, nullptr, nullptr}, 1, R, lp + ".norm_attention.weight", A.g_attn);
             {
                 ProfScope ps("qkv_bwd", st, fR * 2.0 * D * 3 * D);
-                if (trr) trr_qkv_bwd(w.dQKV, Ab.X, A.g_attn, A.qkv, dX_alt, dX, E, R, st);
-                else k_qkv_bwd<<<gR, NTHREADS, lds1, st>>>(w.dQKV, Ab.X, A.g_attn, A.qkv.bwd, dX_alt, dX, E, R);
+                if (trr_l) trr_qkv_bwd(w.dQKV, Ab.X, A.g_attn, A.qkv, dX_alt, dX, E, R, st);
+                else if (post) k_qkv_bwd<true><<<gR, NTHREADS, lds1, st>>>(w.dQKV, nullptr, nullptr, A.qkv.bwd, dX_alt, dX, E, R, false);
+                else k_qkv_bwd<false><<<gR, NTHREADS, lds1, st>>>(w.dQKV, Ab.X, A.g_attn, A.qkv.bwd, dX_alt, dX, E, R, ln);
             }
             ss.fork(st);  // centre rows of dX ready
             {
@@ -1043,25 +1181,25 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         }
         {
             ProfScope ps("compress_bwd", st, fE * 2.0 * (D * D * (gi == 0 ? 3 : 4) + 4 * D));
-            if (trr && trr_compress_bwd(gi == 0, dX, B.a0, G, w.dgeo, w.dM, E, tr ? w.da0 : nullptr, st)) {
+            if (trr && trr_compress_bwd(gi == 0, dX, B.a0, G, w.dgeo, dM, E, tr ? w.da0 : nullptr, st)) {
                 // TRR kernel on f16x3 (pet_trr.hip)
             } else if (gi == 0)
                 PET_LAUNCH_TR(tr, k_compress_bwd, PET_TA(true), gE, lds1, st, dX, B.a0, G.compress2.bwd, G.wct,
                     nullptr, w.dgeo, nullptr, E, tr ? w.da0 : nullptr);
             else
                 PET_LAUNCH_TR(tr, k_compress_bwd, PET_TA(false), gE, lds1, st, dX, B.a0, G.compress2.bwd, G.wct,
-                    G.compress0_msg.bwd, w.dgeo, w.dM, E, tr ? w.da0 : nullptr);
+                    G.compress0_msg.bwd, w.dgeo, dM, E, tr ? w.da0 : nullptr);
             if (tr) {
                 const std::string pre = "gnn_layers." + std::to_string(gi);
                 tr->linear(pre + ".compress.2", D, D, {dX, nullptr, 0, D}, {B.a0, D, 0, nullptr, nullptr}, 3, E);
                 tr->compress0(gi, w.da0, gi > 0 ? w.gnn[gi - 1].Mout : nullptr);
             }
         }
-        // w.dM now holds d/dMout of layer gi-1 (pass-through + compress adjoint)
+        // dM now holds d/dMout of layer gi-1 (pass-through + compress adjoint)
     }
     ss.join(st);
     if (tr) {
-        tr->embeddings(dH, w.dM);
+        tr->embeddings(dH, dM);
         if (tr->err) return tr->err;
     }
     k_dfc_attn<<<cdiv(E, 256), 256, 0, st>>>(g.fc, dbias_h, w.dbias, E);
@@ -1173,6 +1311,25 @@ int backward_features_abi(const Model& m, const Graph& g, void* ws, int64_t ws_b
     if ((rc = d2d(w.dH, g_node, g.n_nodes * DN * sizeof(float), st))) return rc;
     if ((rc = d2d(w.dM, g_edge, g.n_edges * D * sizeof(float), st))) return rc;
     if ((rc = backward_features(m, g, w, st))) return rc;
+    if ((rc = d2d(g_geo, w.dgeo, g.n_edges * 4 * sizeof(float), st))) return rc;
+    if ((rc = d2d(g_fc, w.dbias, g.n_edges * sizeof(float), st))) return rc;
+    return PET_OK;
+}
+
+int backward_features_layers_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* const* g_node,
+                                 const float* const* g_edge, int n_layers, float* g_geo, float* g_fc, hipStream_t st) {
+    PET_CARVE(w);
+    PET_REQUIRE(n_layers == m.num_readout_layers(), PET_ERR_ARGUMENT,
+                "expected one gradient pair per readout layer (" + std::to_string(m.num_readout_layers()) + ")");
+    if (g.n_nodes == 0) return PET_OK;
+    int rc;
+    if (!m.residual()) {
+        if (g_node[0]) { if ((rc = d2d(w.dH, g_node[0], g.n_nodes * DN * sizeof(float), st))) return rc; }
+        else PET_HIP_CHECK(hipMemsetAsync(w.dH, 0, g.n_nodes * DN * sizeof(float), st));
+        if (g_edge[0]) { if ((rc = d2d(w.dM, g_edge[0], g.n_edges * D * sizeof(float), st))) return rc; }
+        else if (g.n_edges) PET_HIP_CHECK(hipMemsetAsync(w.dM, 0, g.n_edges * D * sizeof(float), st));
+        if ((rc = backward_features(m, g, w, st))) return rc;
+    } else if ((rc = backward_features(m, g, w, st, nullptr, g_node, g_edge))) return rc;
     if ((rc = d2d(g_geo, w.dgeo, g.n_edges * 4 * sizeof(float), st))) return rc;
     if ((rc = d2d(g_fc, w.dbias, g.n_edges * sizeof(float), st))) return rc;
     return PET_OK;

@@ -145,9 +145,12 @@ __global__ __launch_bounds__(NTHREADS) void k_center(const float* __restrict__ H
 }
 
 // ---------------------------------------------------------------------------------
-// QKV = RMSNorm(X) Win^T + b   (D -> 3D) over all E+N token rows
+// QKV = Norm(X) Win^T + b   (D -> 3D) over all E+N token rows; Norm = RMSNorm, LayerNorm (beta) or, for PostLN
+// (transformer.py:243: attention on the raw tokens), nothing
 // ---------------------------------------------------------------------------------
+template <bool NORM>
 __global__ __launch_bounds__(NTHREADS) void k_qkv(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta,
                                                    const float4* __restrict__ win, const float* __restrict__ bin,
                                                    float* __restrict__ QKV, int64_t R) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -155,8 +158,10 @@ __global__ __launch_bounds__(NTHREADS) void k_qkv(const float* __restrict__ X, c
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     load_rows_to_lds<128>(smem, X, row0, R, D);
     __syncthreads();
-    rmsnorm_rows_inplace<128>(smem, gamma, nullptr);
-    __syncthreads();
+    if (NORM) {
+        norm_rows_inplace<128>(smem, gamma, beta);
+        __syncthreads();
+    }
 #pragma unroll 1
     for (int c = 0; c < 3; c++) {
         f32x16 acc[2];
@@ -270,7 +275,9 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ QKV,
 
 // ---------------------------------------------------------------------------------
 // output_linear + edge residual:  rows < E: X1 = X + AO Wo^T + b ; rows >= E: OC = AO Wo^T + b
+// POST (transformer.py:243-245): every token keeps its residual, X1 = X + AO Wo^T + b on all E+N rows
 // ---------------------------------------------------------------------------------
+template <bool POST>
 __global__ __launch_bounds__(NTHREADS) void k_oproj(const float* __restrict__ AO, const float* __restrict__ X,
                                                      const float4* __restrict__ wo, const float* __restrict__ bo,
                                                      float* __restrict__ X1, float* __restrict__ OC, int64_t E,
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(NTHREADS) void k_oproj(const float* __restrict__ AO
     gemm_acc<128, 2>(smem + w.rb * 32 * LD128, LD128, wo, 16, 0, 2 * w.ch, acc, w.lane);
     acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
         const int64_t row = row0 + r;
-        if (row < E) X1[row * D + c] = X[row * D + c] + v;
+        if (row < E || (POST && row < R)) X1[row * D + c] = X[row * D + c] + v;
         else if (row < R) OC[(row - E) * D + c] = v;
     });
 }
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(NTHREADS) void k_oproj(const float* __restrict__ AO
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(NTHREADS) void k_node(const float* __restrict__ H, const float* __restrict__ OC,
                                                     WX wce, const float* __restrict__ bce,
-                                                    const float* __restrict__ gamma, WX win,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta, WX win,
                                                     const float* __restrict__ bin, WX wout,
                                                     const float* __restrict__ bout,
                                                     float* __restrict__ H1, float* __restrict__ VGn,
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(NTHREADS) void k_node(const float* __restrict__ H, 
         });
     }
     __syncthreads();
-    rmsnorm_rows_inplace<256>(Hs, gamma, nullptr);
+    norm_rows_inplace<256>(Hs, gamma, beta);
     __syncthreads();
     f32x16 out[4];  // this wave: 32 rows x 128 columns (128 * ch ..)
     acc_fill_bias<4>(out, bout, 128 * w.ch, w.lane);
@@ -364,9 +371,12 @@ __global__ __launch_bounds__(NTHREADS) void k_node(const float* __restrict__ H, 
 }
 
 // ---------------------------------------------------------------------------------
-// edge MLP: X2 = X1 + SwiGLU_MLP(RMSNorm(X1))
+// edge MLP: X2 = X1 + SwiGLU_MLP(Norm(X1)); PostLN (NORM = false, transformer.py:246-247): X2 = X1 + SwiGLU_MLP(X1) on
+// already-normalised tokens, centre rows included (E = the row count)
 // ---------------------------------------------------------------------------------
+template <bool NORM>
 __global__ __launch_bounds__(NTHREADS) void k_emlp(const float* __restrict__ X1, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta,
                                                     const float4* __restrict__ win, const float* __restrict__ bin,
                                                     const float4* __restrict__ wout, const float* __restrict__ bout,
                                                     float* __restrict__ VG, float* __restrict__ X2, int64_t E) {
@@ -377,8 +387,10 @@ __global__ __launch_bounds__(NTHREADS) void k_emlp(const float* __restrict__ X1,
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     load_rows_to_lds<128>(A, X1, row0, E, D);
     __syncthreads();
-    rmsnorm_rows_inplace<128>(A, gamma, nullptr);
-    __syncthreads();
+    if (NORM) {
+        norm_rows_inplace<128>(A, gamma, beta);
+        __syncthreads();
+    }
     f32x16 out[2];
     acc_fill_bias<2>(out, bout, 64 * w.ch, w.lane);
 #pragma unroll 1
@@ -411,6 +423,44 @@ __global__ __launch_bounds__(NTHREADS) void k_emlp(const float* __restrict__ X1,
         const int64_t row = row0 + r;
         if (row < E) X2[row * D + c] = X1[row * D + c] + v;
     });
+}
+
+// ---------------------------------------------------------------------------------
+// PostLN: Y = Norm(S) row by row (transformer.py:245,247); rows < E go to Ye, rows >= E (the centre tokens) to Yc
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_rownorm(const float* __restrict__ S, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ Ye,
+                                                       float* __restrict__ Yc, int64_t E, int64_t R) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    load_rows_to_lds<128>(smem, S, row0, R, D);
+    __syncthreads();
+    norm_rows_inplace<128>(smem, gamma, beta);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < BM * 32; idx += NTHREADS) {
+        const int r = idx >> 5, c = idx & 31;
+        const int64_t row = row0 + r;
+        if (row >= R) continue;
+        const float4 v = *reinterpret_cast<const float4*>(smem + r * LD128 + 4 * c);
+        if (row < E) *reinterpret_cast<float4*>(Ye + row * D + 4 * c) = v;
+        else *reinterpret_cast<float4*>(Yc + (row - E) * D + 4 * c) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// residual featuriser (backend.py:621-647): Mout[p] = 0.5 (Min[p] + e[rev[p]]); layer 0: Min = edge_embedder[species]
+// ---------------------------------------------------------------------------------
+__global__ void k_resmix(const float* __restrict__ Min, const float* __restrict__ emb, const int* __restrict__ sp_nbr,
+                         const float* __restrict__ XF, const int* __restrict__ rev, float* __restrict__ Mout, int64_t E) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * (D / 4)) return;
+    const int64_t p = idx / (D / 4);
+    const int c = (int)(idx % (D / 4));
+    const float4 a = Min ? reinterpret_cast<const float4*>(Min)[idx]
+                         : *reinterpret_cast<const float4*>(emb + (int64_t)sp_nbr[p] * D + 4 * c);
+    const float4 b = *reinterpret_cast<const float4*>(XF + (int64_t)rev[p] * D + 4 * c);
+    reinterpret_cast<float4*>(Mout)[idx] = make_float4(0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z),
+                                                       0.5f * (a.w + b.w));
 }
 
 // ---------------------------------------------------------------------------------
@@ -630,9 +680,25 @@ static inline WX wx_fwd(const Lin& L, int bit = 0) {
 
 int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
             float* node_feat, float* edge_feat, hipStream_t st) {
+    PET_REQUIRE(!m.residual() || (!node_feat && !edge_feat), PET_ERR_ARGUMENT,
+                "residual featuriser: one feature pair per GNN layer, use pet_forward_layers");
+    return forward_layers(m, g, ws, ws_bytes, save, atomic, &node_feat, &edge_feat, 1, st);
+}
+
+// node_feats / edge_feats: n_layers = num_readout_layers() output pointers each (entries may be null)
+int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
+                   float* const* node_feats, float* const* edge_feats, int n_layers, hipStream_t st) {
     Workspace w;
     carve_workspace(m, g.n_nodes, g.n_edges, ws, w, save == 2);
     PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "forward workspace too small");
+    const bool post = m.post_ln(), res = m.residual();
+    PET_REQUIRE(res ? (n_layers == m.h.num_gnn_layers || (n_layers == 1 && !node_feats[0] && !edge_feats[0])) : n_layers == 1,
+                PET_ERR_ARGUMENT, "expected one feature pair per readout layer (" + std::to_string(m.num_readout_layers()) + ")");
+    PET_REQUIRE(!(atomic && res), PET_ERR_UNSUPPORTED,
+                "the fused head reads one readout layer; with the residual featuriser use pet_forward_layers and "
+                "pet_predict per readout layer");
+    PET_REQUIRE(save != 2 || m.plain(), PET_ERR_UNSUPPORTED,
+                "training is built for normalization=RMSNorm, transformer_type=PreLN, featurizer_type=feedforward only");
     const int64_t N = g.n_nodes, E = g.n_edges, R = E + N;
     if (N == 0) return PET_OK;
     const int nt = attn_tiles(g);
@@ -644,18 +710,23 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
     const size_t lds_c = lds2 + BM * 20 + BM * 8;
     const double fE = (double)E, fN = (double)N, fR = (double)R;
     const bool trr = use_trr();
+    const bool trr_l = trr && m.plain_layers();  // the TRR transformer-layer kernels are RMSNorm + PreLN
     // attention: 4 T^2 d FLOPs per atom per layer; T^2 summed on the host side of the graph
     const double attn_flops = 4.0 * D * g_sum_t2(g);
+    const int L = m.h.num_gnn_layers, AL = m.h.num_attention_layers;
 
     allow_big_lds(k_center, BM * LD256 * 4 + BM * 8);
     allow_big_lds(k_node, (BM * LD256 + BM * LD128) * 4 + BM * 8);
     allow_big_lds(k_head<256>, (BM * LD256 + BM * LD128) * 4 + BM * 8);
-    const SideStream& ss = side_stream();
+    SideStream ss = side_stream();
+    if (post) ss.enabled = false;  // PostLN: the node update needs the MLP output of the centre token, one chain
     const hipStream_t s2 = ss.stream(st);  // node-feature chain
     bool side_busy = false;
     auto launch_center = [&](int gi, int a) {
         const AttnLayerW& A = m.gnn[gi].attn[a];
         AttnBufs& Ab = w.gnn[gi].attn[a];
+        if (a == 0 && res && gi > 0)  // backend.py:617: every GNN layer starts from its own node embedding
+            k_node_embed<<<cdiv(N * (DN / 4), 256), 256, 0, s2>>>(g.sp, m.node_embs[gi], w.gnn[gi].Hin, (int)N);
         ProfScope ps("center", s2, fN * 2.0 * DN * D);
         k_center<<<gN, NTHREADS, BM * LD256 * 4 + BM * 8, s2>>>(Ab.H, wx_fwd(A.cc, 2), A.cc.b, Ab.X + E * D, N);
     };
@@ -663,7 +734,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
     ss.fork(st);
     launch_center(0, 0);
     side_busy = true;
-    for (int gi = 0; gi < m.h.num_gnn_layers; gi++) {
+    for (int gi = 0; gi < L; gi++) {
         const GnnLayerW& G = m.gnn[gi];
         GnnBufs& B = w.gnn[gi];
         const float* Min = gi == 0 ? nullptr : w.gnn[gi - 1].Mout;
@@ -680,18 +751,19 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
                                                                wx_fwd(G.compress0_msg, 128), wx_fwd(G.compress2, 256), G.compress2.b,
                                                                B.a0, B.attn[0].X, E);
         }
-        for (int a = 0; a < m.h.num_attention_layers; a++) {
+        for (int a = 0; a < AL; a++) {
             const AttnLayerW& A = G.attn[a];
             AttnBufs& Ab = B.attn[a];
-            float* Xnext = (a + 1 < m.h.num_attention_layers) ? B.attn[a + 1].X : B.XF;
+            float* Xnext = (a + 1 < AL) ? B.attn[a + 1].X : B.XF;
             if (side_busy) {  // the centre rows of this layer's tokens come from the node chain
                 ss.join(st);
                 side_busy = false;
             }
             {
                 ProfScope ps("qkv", st, fR * 2.0 * D * 3 * D);
-                if (trr) trr_qkv(Ab.X, A.g_attn, A.qkv, Ab.QKV, R, st);
-                else k_qkv<<<gR, NTHREADS, lds1, st>>>(Ab.X, A.g_attn, A.qkv.fwd, A.qkv.b, Ab.QKV, R);
+                if (trr_l) trr_qkv(Ab.X, A.g_attn, A.qkv, Ab.QKV, R, st);
+                else if (post) k_qkv<false><<<gR, NTHREADS, lds1, st>>>(Ab.X, nullptr, nullptr, A.qkv.fwd, A.qkv.b, Ab.QKV, R);
+                else k_qkv<true><<<gR, NTHREADS, lds1, st>>>(Ab.X, A.g_attn, A.b_attn, A.qkv.fwd, A.qkv.b, Ab.QKV, R);
             }
             {
                 ProfScope ps("attn_fwd", st, attn_flops, fR * 4.0 * (3 * D + D));
@@ -706,33 +778,48 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
             }
             {
                 ProfScope ps("oproj", st, fR * 2.0 * D * D);
-                if (trr) trr_oproj(Ab.AO, Ab.X, A.out, Ab.X1, Ab.OC, E, R, st);
-                else k_oproj<<<gR, NTHREADS, lds1, st>>>(Ab.AO, Ab.X, A.out.fwd, A.out.b, Ab.X1, Ab.OC, E, R);
+                if (trr_l) trr_oproj(Ab.AO, Ab.X, A.out, Ab.X1, Ab.OC, E, R, st);
+                else if (post) k_oproj<true><<<gR, NTHREADS, lds1, st>>>(Ab.AO, Ab.X, A.out.fwd, A.out.b, Ab.X1, nullptr, E, R);
+                else k_oproj<false><<<gR, NTHREADS, lds1, st>>>(Ab.AO, Ab.X, A.out.fwd, A.out.b, Ab.X1, Ab.OC, E, R);
+            }
+            if (post) {
+                // transformer.py:245-247 on every token (edges and centre): norm_attention, + MLP, norm_mlp; the edge rows
+                // of the result are the next layer's tokens, the centre row feeds center_expansion
+                ProfScope ps("emlp", st, fR * 2.0 * (D * 2 * DFF + DFF * D));
+                k_rownorm<<<gR, NTHREADS, lds1, st>>>(Ab.X1, A.g_attn, A.b_attn, w.T1, w.T1 + E * D, E, R);
+                k_emlp<false><<<gR, NTHREADS, lds2, st>>>(w.T1, nullptr, nullptr, A.mlp_in.fwd, A.mlp_in.b, A.mlp_out.fwd,
+                                                           A.mlp_out.b, Ab.VG, Ab.S2, R);
+                k_rownorm<<<gR, NTHREADS, lds1, st>>>(Ab.S2, A.g_mlp, A.b_mlp, Xnext, Ab.OC, E, R);
             }
             // node chain (side stream): node update of this layer, then the centre token of the next
             ss.fork(st);
             {
                 ProfScope ps("node", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
-                if (!(trr && trr_node(A, Ab.H, Ab.OC, Ab.H1, Ab.VGn, Ab.Hn, N, s2)))
+                if (!(trr_l && trr_node(A, Ab.H, Ab.OC, Ab.H1, Ab.VGn, Ab.Hn, N, s2)))
                 k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, s2>>>(
-                    Ab.H, Ab.OC, wx_fwd(A.ce, 4), A.ce.b, A.g_center, wx_fwd(A.cmlp_in, 8), A.cmlp_in.b, wx_fwd(A.cmlp_out, 16),
-                    A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
+                    Ab.H, Ab.OC, wx_fwd(A.ce, 4), A.ce.b, A.g_center, A.b_center, wx_fwd(A.cmlp_in, 8), A.cmlp_in.b,
+                    wx_fwd(A.cmlp_out, 16), A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
             }
-            if (a + 1 < m.h.num_attention_layers) launch_center(gi, a + 1);
-            else if (gi + 1 < m.h.num_gnn_layers) launch_center(gi + 1, 0);
+            if (a + 1 < AL) launch_center(gi, a + 1);
+            else if (gi + 1 < L) launch_center(gi + 1, 0);
             side_busy = true;
-            if (E > 0) {
+            if (E > 0 && !post) {
                 ProfScope ps("emlp", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
-                if (trr) {
+                if (trr_l) {
                     // [v; g] is stored for the adjoint unless no adjoint follows (save == 0) or it recomputes them
                     float* vg = (save == 0 || (save != 2 && emlp_recompute_ok(A.mlp_in, A.mlp_out))) ? nullptr : Ab.VG;
                     trr_emlp(Ab.X1, A.g_mlp, A.mlp_in, A.mlp_out, vg, Xnext, E, st);
                 }
-                else k_emlp<<<gE, NTHREADS, lds2, st>>>(Ab.X1, A.g_mlp, A.mlp_in.fwd, A.mlp_in.b, A.mlp_out.fwd,
-                                                        A.mlp_out.b, Ab.VG, Xnext, E);
+                else k_emlp<true><<<gE, NTHREADS, lds2, st>>>(Ab.X1, A.g_mlp, A.b_mlp, A.mlp_in.fwd, A.mlp_in.b, A.mlp_out.fwd,
+                                                              A.mlp_out.b, Ab.VG, Xnext, E);
             }
         }
-        if (E > 0) {
+        if (E > 0 && res) {
+            if (gi + 1 < L) {  // the messages of the next layer (backend.py:640-647); the last layer's are never read
+                ProfScope ps("comb", st, 0.0, fE * 4.0 * 3 * D);
+                k_resmix<<<cdiv(E * (D / 4), 256), 256, 0, st>>>(Min, m.edge_emb, g.sp_nbr, B.XF, g.rev, B.Mout, E);
+            }
+        } else if (E > 0) {
             ProfScope ps("comb", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D));
             if (trr && use_bf16x6() && comb_bf16(gi == 0, B.XF, g, G, Min, m.edge_emb, B.CA, B.LNS, B.Mout, E, st)) {
                 // TRR kernel on the bf16 matrix cores (pet_comb.hip)
@@ -765,10 +852,13 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
     }
     ss.join(st);
     if (atomic) k_atom_sum<<<cdiv(N, 256), 256, 0, st>>>(w.ynode, w.ye, g.rowptr, atomic, (int)N);
-    if (node_feat)
-        PET_HIP_CHECK(hipMemcpyAsync(node_feat, last.Hout, N * DN * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (edge_feat && E > 0)
-        PET_HIP_CHECK(hipMemcpyAsync(edge_feat, last.Mout, E * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    for (int l = 0; l < n_layers; l++) {  // backend.py:585-586 / :621-625: (node, edge) features of every readout layer
+        const GnnBufs& Bl = res ? w.gnn[l] : last;
+        if (node_feats[l])
+            PET_HIP_CHECK(hipMemcpyAsync(node_feats[l], Bl.Hout, N * DN * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (edge_feats[l] && E > 0)
+            PET_HIP_CHECK(hipMemcpyAsync(edge_feats[l], res ? Bl.XF : Bl.Mout, E * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }

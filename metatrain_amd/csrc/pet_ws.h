@@ -13,7 +13,9 @@ struct AttnBufs {
     float* X = nullptr;    // [(E+N), D] tokens entering the layer (edges rows 0..E-1, centres E..)
     float* QKV = nullptr;  // [(E+N), 3D]
     float* X1 = nullptr;   // [E, D]  edges after attention residual (input of the edge MLP)
-    float* VG = nullptr;   // [E, 2*DFF] SwiGLU pre-activations (value | gate)
+                           // PostLN: [(E+N), D] tokens + attention output BEFORE norm_attention (transformer.py:245)
+    float* S2 = nullptr;   // PostLN only: [(E+N), D] tokens + MLP output before norm_mlp (transformer.py:247)
+    float* VG = nullptr;   // [E, 2*DFF] SwiGLU pre-activations (value | gate); PostLN: (E+N) rows, the MLP sees every token
     float* H = nullptr;    // [N, DN] node features entering the layer (alias of the producer)
     float* Hn = nullptr;   // [N, DN] node features leaving the layer
     float* H1 = nullptr;   // [N, DN] after centre expansion residual
@@ -30,6 +32,7 @@ struct GnnBufs {
     float* LNS = nullptr;   // [E, 2] LayerNorm (mean, rstd) of [e ; e_rev]
     float* Mout = nullptr;  // [E, D] messages leaving the layer
     float* Hout = nullptr;  // [N, DN]
+    float* Hin = nullptr;   // [N, DN] node features entering the layer (residual featuriser: its own embedding)
 };
 
 struct Workspace {
@@ -37,6 +40,7 @@ struct Workspace {
     float* H0 = nullptr;     // [N, DN] node embedding
     float* AO = nullptr;     // [(E+N), D] attention output before output_linear (temp)
     float* OC = nullptr;     // [N, D] centre rows of output_linear (temp)
+    float* T1 = nullptr;     // PostLN only: [(E+N), D] norm_attention output (temp)
     float* ypred_e = nullptr;  // [E] edge last-layer prediction before the cutoff weight
     float* ye = nullptr;       // [E] fc * ypred_e
     float* ynode = nullptr;    // [N]
@@ -83,8 +87,9 @@ inline void carve_workspace(const Model& m, int64_t N, int64_t E, void* base, Wo
         for (auto& A : G.attn) {
             A.X = c.take<float>(Ra * D);
             A.QKV = c.take<float>(Ra * 3 * D);
-            A.X1 = c.take<float>(Ea * D);
-            A.VG = c.take<float>(Ea * 2 * DFF);
+            A.X1 = c.take<float>((m.post_ln() ? Ra : Ea) * D);
+            A.VG = c.take<float>((m.post_ln() ? Ra : Ea) * 2 * DFF);
+            if (m.post_ln()) A.S2 = c.take<float>(Ra * D);
             A.H1 = c.take<float>(Na * DN);
             A.VGn = c.take<float>(Na * 2 * DNF);
         }
@@ -98,7 +103,10 @@ inline void carve_workspace(const Model& m, int64_t N, int64_t E, void* base, Wo
     // node feature chain: H0 plus one buffer per attention layer
     w.H0 = c.take<float>(Na * DN);
     float* prev = w.H0;
-    for (auto& G : w.gnn) {
+    for (size_t gi = 0; gi < w.gnn.size(); gi++) {
+        GnnBufs& G = w.gnn[gi];
+        if (m.residual() && gi > 0) prev = c.take<float>(Na * DN);  // backend.py:617: a fresh embedding per layer
+        G.Hin = prev;
         for (auto& A : G.attn) {
             A.H = prev;
             A.Hn = c.take<float>(Na * DN);
@@ -108,6 +116,7 @@ inline void carve_workspace(const Model& m, int64_t N, int64_t E, void* base, Wo
     }
     w.AO = c.take<float>(Ra * D);
     w.OC = c.take<float>(Na * D);
+    if (m.post_ln()) w.T1 = c.take<float>(Ra * D);
     w.ypred_e = c.take<float>(Ea);
     w.ye = c.take<float>(Ea);
     w.ynode = c.take<float>(Na);

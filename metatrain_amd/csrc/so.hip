@@ -1213,6 +1213,8 @@ static void head_reverse(const Ctx& c, Trainer& tr, SoWs& s, bool edge, const Li
 int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, void* ws2, int64_t ws2_bytes,
                     const float* lA, const float* nA, const float* u, float* tangent_atomic, hipStream_t st) {
     PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
+    PET_REQUIRE(m.plain(), PET_ERR_UNSUPPORTED,
+                "training is built for normalization=RMSNorm, transformer_type=PreLN, featurizer_type=feedforward only");
     Workspace w;
     carve_workspace(m, g.n_nodes, g.n_edges, ws, w, true);
     PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "workspace too small for training");

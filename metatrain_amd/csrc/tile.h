@@ -226,6 +226,44 @@ __device__ __forceinline__ void rmsnorm_rows_inplace(float* As, const float* __r
     }
 }
 
+// RMSNorm (beta == nullptr) or torch.nn.LayerNorm(K) (eps 1e-5, biased variance, weight + bias; transformer.py:170-176)
+template <int K>
+__device__ __forceinline__ void norm_rows_inplace(float* As, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta) {
+    if (beta == nullptr) {
+        rmsnorm_rows_inplace<K>(As, gamma, nullptr);
+        return;
+    }
+    constexpr int LDA = lds_ld(K);
+    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    float* row = As + r * LDA;
+    float s = 0.f;
+    for (int c = q * 4; c < K; c += 16) {
+        float4 v = *reinterpret_cast<float4*>(row + c);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    const float mean = s * (1.0f / K);
+    float ss = 0.f;
+    for (int c = q * 4; c < K; c += 16) {
+        float4 v = *reinterpret_cast<float4*>(row + c);
+        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    const float rstd = rsqrtf(ss * (1.0f / K) + 1e-5f);
+    for (int c = q * 4; c < K; c += 16) {
+        float4 v = *reinterpret_cast<float4*>(row + c);
+        float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        float4 b = *reinterpret_cast<const float4*>(beta + c);
+        v.x = (v.x - mean) * rstd * g.x + b.x; v.y = (v.y - mean) * rstd * g.y + b.y;
+        v.z = (v.z - mean) * rstd * g.z + b.z; v.w = (v.w - mean) * rstd * g.w + b.w;
+        *reinterpret_cast<float4*>(row + c) = v;
+    }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 // d silu / dx = s (1 + x (1 - s))

@@ -47,7 +47,7 @@ struct PetHipModule : torch::CustomClassHolder {
                  std::vector<at::Tensor> tensors_)
         : hypers(std::move(hypers_)), atomic_types(std::move(atomic_types_)), keys(std::move(keys_)),
           tensors(std::move(tensors_)) {
-        TORCH_CHECK(hypers.size() == 16, "pet_hip: expected the 16 fields of pet_hypers_t");
+        TORCH_CHECK(hypers.size() == 16 || hypers.size() == 19, "pet_hip: expected the 16 or all 19 fields of pet_hypers_t");
         TORCH_CHECK(keys.size() == tensors.size(), "pet_hip: keys / tensors length mismatch");
     }
     ~PetHipModule() override {
@@ -55,7 +55,7 @@ struct PetHipModule : torch::CustomClassHolder {
     }
 
     pet_hypers_t hypers_struct() const {
-        pet_hypers_t h;
+        pet_hypers_t h{};
         h.cutoff = (float)hypers[0]; h.cutoff_width = (float)hypers[1]; h.cutoff_function = (int32_t)hypers[2];
         h.d_pet = (int32_t)hypers[3]; h.d_head = (int32_t)hypers[4]; h.d_node = (int32_t)hypers[5];
         h.d_feedforward = (int32_t)hypers[6]; h.num_heads = (int32_t)hypers[7];
@@ -63,6 +63,10 @@ struct PetHipModule : torch::CustomClassHolder {
         h.attention_temperature = (float)hypers[10]; h.nl_is_strict = (int32_t)hypers[11];
         h.n_species = (int32_t)hypers[12]; h.max_atomic_number = (int32_t)hypers[13];
         h.num_neighbors_adaptive = (float)hypers[14]; h.cutoff_width_adaptive = (float)hypers[15];
+        if (hypers.size() == 19) {
+            h.normalization = (int32_t)hypers[16]; h.transformer_type = (int32_t)hypers[17];
+            h.featurizer_type = (int32_t)hypers[18];
+        }
         return h;
     }
 
@@ -171,14 +175,16 @@ struct PetHipBackend : torch::CustomClassHolder {
 
     PetHipBackend(std::vector<double> hypers_, std::vector<int64_t> atomic_types_, std::vector<std::string> keys_)
         : hypers(std::move(hypers_)), atomic_types(std::move(atomic_types_)), keys(std::move(keys_)) {
-        TORCH_CHECK(hypers.size() == 17, "pet_hip: expected the 16 fields of pet_hypers_t + the SiLU flag");
+        TORCH_CHECK(hypers.size() == 17 || hypers.size() == 20,
+                    "pet_hip: expected the first 16 fields of pet_hypers_t, the SiLU flag and (optionally) normalization, "
+                    "transformer_type, featurizer_type");
     }
     ~PetHipBackend() override {
         if (model) pet_model_destroy(model);
     }
 
     pet_hypers_t hypers_struct() const {
-        pet_hypers_t h;
+        pet_hypers_t h{};
         h.cutoff = (float)hypers[0]; h.cutoff_width = (float)hypers[1]; h.cutoff_function = (int32_t)hypers[2];
         h.d_pet = (int32_t)hypers[3]; h.d_head = (int32_t)hypers[4]; h.d_node = (int32_t)hypers[5];
         h.d_feedforward = (int32_t)hypers[6]; h.num_heads = (int32_t)hypers[7];
@@ -186,6 +192,10 @@ struct PetHipBackend : torch::CustomClassHolder {
         h.attention_temperature = (float)hypers[10]; h.nl_is_strict = (int32_t)hypers[11];
         h.n_species = (int32_t)hypers[12]; h.max_atomic_number = (int32_t)hypers[13];
         h.num_neighbors_adaptive = (float)hypers[14]; h.cutoff_width_adaptive = (float)hypers[15];
+        if (hypers.size() == 20) {
+            h.normalization = (int32_t)hypers[17]; h.transformer_type = (int32_t)hypers[18];
+            h.featurizer_type = (int32_t)hypers[19];
+        }
         return h;
     }
 
@@ -384,16 +394,28 @@ struct FeaturesFn : torch::autograd::Function<FeaturesFn> {
         auto dev = mask.device();
         auto bytes = at::TensorOptions().dtype(at::kByte).device(dev), f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
         bg->fwd_ws = at::empty({pet_forward_workspace_bytes(be->model, n, e)}, bytes);
-        at::Tensor nf = at::empty({n, h.d_node}, f32), ef = at::empty({e, h.d_pet}, f32);
-        check(pet_forward(be->model, bg->g, bg->fwd_ws.data_ptr(), bg->fwd_ws.numel(), 1, nullptr, nf.data_ptr<float>(),
-                          ef.data_ptr<float>(), stream_of(mask)),
-              "pet_forward (features)");
+        // backend.py:344-418 returns two lists, one entry per readout layer: here [node_0 .. node_{L-1}, edge_0 .. edge_{L-1}]
+        const int64_t L = pet_model_num_readout_layers(be->model);
+        std::vector<at::Tensor> nf, ef;
+        std::vector<float*> pn, pe;
+        for (int64_t l = 0; l < L; l++) {
+            nf.push_back(at::empty({n, h.d_node}, f32));
+            ef.push_back(at::empty({e, h.d_pet}, f32));
+            pn.push_back(nf[l].data_ptr<float>());
+            pe.push_back(ef[l].data_ptr<float>());
+        }
+        check(pet_forward_layers(be->model, bg->g, bg->fwd_ws.data_ptr(), bg->fwd_ws.numel(), 1, pn.data(), pe.data(), (int32_t)L,
+                                 stream_of(mask)),
+              "pet_forward_layers");
         ctx->saved_data["graph"] = bg;
         ctx->saved_data["backend"] = be;
         ctx->saved_data["dtype"] = (int64_t)ev.scalar_type();
         const auto dt = ev.scalar_type();
-        at::Tensor ef_nef = e > 0 ? to_nef(ef, bg->ix, n, bg->m) : at::zeros({n, bg->m, h.d_pet}, f32);
-        return {nf.to(dt), ef_nef.to(dt)};
+        torch::autograd::variable_list out;
+        for (int64_t l = 0; l < L; l++) out.push_back(nf[l].to(dt));
+        for (int64_t l = 0; l < L; l++)
+            out.push_back((e > 0 ? to_nef(ef[l], bg->ix, n, bg->m) : at::zeros({n, bg->m, h.d_pet}, f32)).to(dt));
+        return out;
     }
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
                                                    torch::autograd::variable_list go) {
@@ -405,16 +427,21 @@ struct FeaturesFn : torch::autograd::Function<FeaturesFn> {
         auto f32 = at::TensorOptions().dtype(at::kFloat).device(bg->ws.device());
         at::Tensor g_ev = at::zeros({n, m, 3}, f32), g_ed = at::zeros({n, m}, f32), g_cf = at::zeros({n, m}, f32);
         if (e > 0) {
-            for (int k : {0, 1})
+            const int64_t L = (int64_t)go.size() / 2;
+            std::vector<at::Tensor> keep;
+            std::vector<const float*> pn(L, nullptr), pe(L, nullptr);
+            for (int64_t k = 0; k < 2 * L; k++) {
                 TORCH_CHECK(!go[k].defined() || !go[k].requires_grad(),
                             "pet_hip: double backward through calculate_features is not built (train through "
                             "metatrain_amd.pet.PETBackend in train() mode or TrainStep)");
-            at::Tensor g_nf = go[0].defined() ? as_f32(go[0]) : at::zeros({n, h.d_node}, f32);
-            at::Tensor g_ef = go[1].defined() ? to_csr(as_f32(go[1]), bg->ix) : at::zeros({e, h.d_pet}, f32);
+                if (!go[k].defined()) continue;
+                keep.push_back(k < L ? as_f32(go[k]) : to_csr(as_f32(go[k]), bg->ix));
+                (k < L ? pn[k] : pe[k - L]) = keep.back().data_ptr<float>();
+            }
             at::Tensor geo = at::empty({e, 4}, f32), gfc = at::empty({e}, f32);
-            check(pet_backward_features(be->model, bg->g, bg->fwd_ws.data_ptr(), bg->fwd_ws.numel(), g_nf.data_ptr<float>(),
-                                        g_ef.data_ptr<float>(), geo.data_ptr<float>(), gfc.data_ptr<float>(), stream_of(geo)),
-                  "pet_backward_features");
+            check(pet_backward_features_layers(be->model, bg->g, bg->fwd_ws.data_ptr(), bg->fwd_ws.numel(), pn.data(), pe.data(),
+                                               (int32_t)L, geo.data_ptr<float>(), gfc.data_ptr<float>(), stream_of(geo)),
+                  "pet_backward_features_layers");
             g_ev = to_nef(geo.narrow(1, 0, 3).contiguous(), bg->ix, n, m);
             g_ed = to_nef(geo.select(1, 3).contiguous(), bg->ix, n, m);
             g_cf = to_nef(gfc, bg->ix, n, m);

@@ -26,10 +26,12 @@ optimizers and DDP work on the mirror unchanged. (``metatrain_amd.pet.trainer.Tr
 step.) That node evaluates the batch ``preprocess`` saw, not edited features.
 
 ``activation = "SiLU"`` runs on the SwiGLU kernels with the projection uploaded as both halves (exact). Several
-properties per block, several blocks per target and several targets are served by ``pet_predict``. Not built (raise
-loudly): normalization != RMSNorm, transformer_type != PreLN, featurizer_type != feedforward, the "grid"
-adaptive-cutoff method, system conditioning, diagnostic capture, double backward through the three inference nodes,
-stress (strain) terms in a training loss.
+properties per block, several blocks per target and several targets are served by ``pet_predict``. The architecture
+variants older checkpoints use -- ``normalization = "LayerNorm"``, ``transformer_type = "PostLN"``, ``featurizer_type =
+"residual"`` (``pet/checkpoints.py:190-205``) -- run for inference and forces; training is built for the default
+architecture only. Not built (raise loudly): the "grid" adaptive-cutoff method, system conditioning, diagnostic
+capture, double backward through the three inference nodes, stress (strain) terms in a training loss, training of the
+variants.
 """
 from math import prod
 from typing import Dict, List, Optional, Tuple
@@ -71,33 +73,55 @@ class _Attention(torch.nn.Module):
         return [self.input_linear.weight, self.input_linear.bias, self.output_linear.weight, self.output_linear.bias]
 
 
+class _RMSNorm(torch.nn.RMSNorm):
+    """torch.nn.RMSNorm's parameter (same state-dict key: "weight"), listable from TorchScript."""
+
+    @torch.jit.export
+    def params(self) -> List[torch.Tensor]:
+        return [self.weight]
+
+
+class _LayerNorm(torch.nn.LayerNorm):
+    """torch.nn.LayerNorm's parameters ("weight", "bias": transformer.py:170-176 with norm = "LayerNorm")."""
+
+    @torch.jit.export
+    def params(self) -> List[torch.Tensor]:
+        return [self.weight, self.bias]
+
+
+def _norm(kind: str, d: int) -> torch.nn.Module:
+    return _LayerNorm(d) if kind == "LayerNorm" else _RMSNorm(d)
+
+
 class _TransformerLayer(torch.nn.Module):
-    def __init__(self, d: int, dn: int, dff: int, activation: str):
+    def __init__(self, d: int, dn: int, dff: int, activation: str, norm: str):
         super().__init__()
         self.attention = _Attention(d)
-        self.norm_attention = torch.nn.RMSNorm(d)
-        self.norm_mlp = torch.nn.RMSNorm(d)
+        self.norm_attention = _norm(norm, d)
+        self.norm_mlp = _norm(norm, d)
         self.mlp = _FeedForward(d, dff, activation)
         self.center_contraction = torch.nn.Linear(dn, d)
         self.center_expansion = torch.nn.Linear(d, dn)
-        self.norm_center_features = torch.nn.RMSNorm(dn)
+        self.norm_center_features = _norm(norm, dn)
         self.center_mlp = _FeedForward(dn, 2 * dn, activation)
 
     @torch.jit.export
     def params(self) -> List[torch.Tensor]:
         out = self.attention.params()
-        out += [self.norm_attention.weight, self.norm_mlp.weight]
+        out += self.norm_attention.params()
+        out += self.norm_mlp.params()
         out += self.mlp.params()
         out += [self.center_contraction.weight, self.center_contraction.bias, self.center_expansion.weight,
-                self.center_expansion.bias, self.norm_center_features.weight]
+                self.center_expansion.bias]
+        out += self.norm_center_features.params()
         out += self.center_mlp.params()
         return out
 
 
 class _Transformer(torch.nn.Module):
-    def __init__(self, d: int, dn: int, dff: int, n_layers: int, activation: str):
+    def __init__(self, d: int, dn: int, dff: int, n_layers: int, activation: str, norm: str):
         super().__init__()
-        self.layers = torch.nn.ModuleList([_TransformerLayer(d, dn, dff, activation) for _ in range(n_layers)])
+        self.layers = torch.nn.ModuleList([_TransformerLayer(d, dn, dff, activation, norm) for _ in range(n_layers)])
 
     @torch.jit.export
     def params(self) -> List[torch.Tensor]:
@@ -108,9 +132,9 @@ class _Transformer(torch.nn.Module):
 
 
 class _CartesianTransformerFirst(torch.nn.Module):
-    def __init__(self, d: int, dn: int, dff: int, n_layers: int, n_species: int, activation: str):
+    def __init__(self, d: int, dn: int, dff: int, n_layers: int, n_species: int, activation: str, norm: str):
         super().__init__()
-        self.trans = _Transformer(d, dn, dff, n_layers, activation)
+        self.trans = _Transformer(d, dn, dff, n_layers, activation, norm)
         self.edge_embedder = torch.nn.Linear(4, d)
         # a ModuleList where the reference has a Sequential: the same "compress.0 / compress.2" keys, indexable in TorchScript
         self.compress = torch.nn.ModuleList([torch.nn.Linear(2 * d, d), torch.nn.SiLU(), torch.nn.Linear(d, d)])
@@ -124,9 +148,9 @@ class _CartesianTransformerFirst(torch.nn.Module):
 
 
 class _CartesianTransformerLater(torch.nn.Module):
-    def __init__(self, d: int, dn: int, dff: int, n_layers: int, n_species: int, activation: str):
+    def __init__(self, d: int, dn: int, dff: int, n_layers: int, n_species: int, activation: str, norm: str):
         super().__init__()
-        self.trans = _Transformer(d, dn, dff, n_layers, activation)
+        self.trans = _Transformer(d, dn, dff, n_layers, activation, norm)
         self.edge_embedder = torch.nn.Linear(4, d)
         self.compress = torch.nn.ModuleList([torch.nn.Linear(3 * d, d), torch.nn.SiLU(), torch.nn.Linear(d, d)])
         self.neighbor_embedder = torch.nn.Embedding(n_species, d)
@@ -241,8 +265,10 @@ class PETBackend(torch.nn.Module):
     def __init__(self, hypers: dict, atomic_types: List[int]) -> None:
         super().__init__()
         h = rt.hypers_struct(hypers, atomic_types)  # validates; unsupported variants raise here
-        self._numbers: List[float] = [float(getattr(h, name)) for name, _ in h._fields_] + [
-            1.0 if hypers["activation"] == "SiLU" else 0.0]
+        fields = [float(getattr(h, name)) for name, _ in h._fields_]
+        # PetHipBackend(hypers): the first 16 fields of pet_hypers_t, the SiLU flag, then normalization / transformer_type /
+        # featurizer_type (csrc/torch_ops.cpp)
+        self._numbers: List[float] = fields[:16] + [1.0 if hypers["activation"] == "SiLU" else 0.0] + fields[16:]
         self.hypers = dict(hypers)
         self.atomic_types: List[int] = [int(z) for z in atomic_types]
         self.nl_is_strict = bool(hypers["long_range"]["enable"])
@@ -261,7 +287,8 @@ class PETBackend(torch.nn.Module):
         self.num_gnn_layers: int = hypers["num_gnn_layers"]
         self.num_attention_layers: int = hypers["num_attention_layers"]
         self.featurizer_type: str = hypers["featurizer_type"]
-        self.num_readout_layers: int = 1
+        # backend.py:93-119: the residual featuriser reads out the features of every GNN layer
+        self.num_readout_layers: int = self.num_gnn_layers if self.featurizer_type == "residual" else 1
         n_species = len(atomic_types)
         act = hypers["activation"]
 
@@ -272,16 +299,18 @@ class PETBackend(torch.nn.Module):
         layers: List[torch.nn.Module] = []
         for g in range(self.num_gnn_layers):
             cls = _CartesianTransformerFirst if g == 0 else _CartesianTransformerLater
-            layers.append(cls(self.d_pet, self.d_node, self.d_feedforward, self.num_attention_layers, n_species, act))
+            layers.append(cls(self.d_pet, self.d_node, self.d_feedforward, self.num_attention_layers, n_species, act,
+                              hypers["normalization"]))
         self.gnn_layers = torch.nn.ModuleList(layers)
-        self.combination_norms = torch.nn.ModuleList(
-            [torch.nn.LayerNorm(2 * self.d_pet) for _ in range(self.num_gnn_layers)])
+        n_comb = self.num_gnn_layers if self.featurizer_type == "feedforward" else 0  # backend.py:93-119
+        self.combination_norms = torch.nn.ModuleList([torch.nn.LayerNorm(2 * self.d_pet) for _ in range(n_comb)])
         self.combination_mlps = torch.nn.ModuleList([
             torch.nn.ModuleList([torch.nn.Linear(2 * self.d_pet, 2 * self.d_pet), torch.nn.SiLU(),
                                  torch.nn.Linear(2 * self.d_pet, self.d_pet)])
-            for _ in range(self.num_gnn_layers)
+            for _ in range(n_comb)
         ])
-        self.node_embedders = torch.nn.ModuleList([torch.nn.Embedding(n_species, self.d_node)])
+        self.node_embedders = torch.nn.ModuleList(
+            [torch.nn.Embedding(n_species, self.d_node) for _ in range(self.num_readout_layers)])
         self.edge_embedder = torch.nn.Embedding(n_species, self.d_pet)
         self.node_heads = torch.nn.ModuleDict()
         self.edge_heads = torch.nn.ModuleDict()
@@ -386,14 +415,15 @@ class PETBackend(torch.nn.Module):
     def calculate_features(self, batch_data: Dict[str, torch.Tensor], capture_diagnostics: bool = False
                            ) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
         """``PETBackend.calculate_features`` (backend.py:344-418): node [N, d_node] and edge [N, M, d_pet] features of
-        the last GNN layer (feedforward featuriser), computed FROM ``batch_data`` as given."""
+        every readout layer -- the last GNN layer (feedforward featuriser) or each of them (residual) -- computed FROM
+        ``batch_data`` as given."""
         if capture_diagnostics:
             raise RuntimeError("diagnostic feature capture is not built into libpet_hip")
         outs = self.core.calculate_features(
             self._params(), batch_data["element_indices_nodes"], batch_data["element_indices_neighbors"],
             batch_data["edge_vectors"], batch_data["edge_distances"], batch_data["padding_mask"],
             batch_data["reverse_neighbor_index"], batch_data["cutoff_factors"])
-        return [outs[0]], [outs[1]]
+        return outs[: self.num_readout_layers], outs[self.num_readout_layers:]
 
     @torch.jit.export
     def predict(self, node_features_list: List[torch.Tensor], edge_features_list: List[torch.Tensor],

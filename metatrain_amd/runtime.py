@@ -32,9 +32,12 @@ def hypers_struct(hypers: dict, atomic_types: List[int]) -> PetHypers:
     fn = hypers["cutoff_function"].lower()
     if fn not in ("bump", "cosine"):
         raise ValueError(f"Unknown cutoff function type: {hypers['cutoff_function']}")
-    for key, want in (("normalization", "RMSNorm"), ("transformer_type", "PreLN"), ("featurizer_type", "feedforward")):
-        if hypers[key] != want:
-            raise PetHipError(f"hypers['{key}'] = {hypers[key]!r} is not built into libpet_hip (only {want!r})")
+    variants = {}
+    for key, choices in (("normalization", ("RMSNorm", "LayerNorm")), ("transformer_type", ("PreLN", "PostLN")),
+                         ("featurizer_type", ("feedforward", "residual"))):
+        if hypers[key] not in choices:  # transformer.py:170-176, :336-341, backend.py:76-81
+            raise ValueError(f"Unknown {key}: {hypers[key]!r} (expected one of {choices})")
+        variants[key] = choices.index(hypers[key])
     if hypers["activation"] not in ("SwiGLU", "SiLU"):
         raise ValueError(f"Unknown activation flag: {hypers['activation']}")  # transformer.py:342-346
     if hypers["num_neighbors_adaptive"] is not None and hypers["adaptive_cutoff_method"].lower() != "solver":
@@ -58,6 +61,7 @@ def hypers_struct(hypers: dict, atomic_types: List[int]) -> PetHypers:
         max_atomic_number=max(atomic_types),
         num_neighbors_adaptive=float(hypers["num_neighbors_adaptive"] or 0.0),
         cutoff_width_adaptive=float(hypers.get("cutoff_width_adaptive", 1.0)),
+        **variants,
     )
 
 
@@ -98,7 +102,8 @@ class HipModel:
         self._ckeys: Dict[str, tuple] = {}
         self._tied = set()  # SiLU variant: w_in parameters uploaded twice (value half = gate half)
         last_w = params.get(f"node_last_layers.{target}.0.{block}.weight") if target is not None else None
-        fused = last_w is not None and last_w.shape[0] == 1  # the fused kernels serve one property
+        # the fused kernels serve one property of one readout layer (the residual featuriser reads out every GNN layer)
+        fused = last_w is not None and last_w.shape[0] == 1 and self.hypers["featurizer_type"] != "residual"
         if not fused:
             self.target = self._fused_block = None
         for key, t in params.items():
@@ -358,6 +363,50 @@ class HipForward:
         check(self.lib.pet_forward(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes, 2 if self.train else 1,
                                    c_void_p(0), _ptr(nf), _ptr(ef), _stream()))
         return nf, ef
+
+    def features_layers(self):
+        """``calculate_features`` for every readout layer (``pet_forward_layers``): two lists of
+        ``num_readout_layers`` tensors (node ``[N, d_node]``, edge ``[E, d_pet]`` CSR rows), as ``backend.py:344-418``
+        returns them (residual featuriser: one pair per GNN layer)."""
+        g = self.graph
+        dev = self.workspace.device
+        n_l = int(self.lib.pet_model_num_readout_layers(self.model.handle))
+        nfs = [torch.empty((g.n_nodes, self.model.hypers["d_node"]), dtype=torch.float32, device=dev) for _ in range(n_l)]
+        efs = [torch.empty((g.n_edges, self.model.hypers["d_pet"]), dtype=torch.float32, device=dev) for _ in range(n_l)]
+        pn = (c_void_p * n_l)(*[t.data_ptr() for t in nfs])
+        pe = (c_void_p * n_l)(*[t.data_ptr() for t in efs])
+        check(self.lib.pet_forward_layers(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes, 1, pn, pe, n_l,
+                                          _stream()))
+        return nfs, efs
+
+    def backward_features_layers(self, grad_node_features, grad_edge_features):
+        """Adjoint of :meth:`features_layers`: lists of gradients (``None`` = zero) -> ``(d geometry [E,4], d cutoff
+        factors [E])`` (``pet_backward_features_layers``)."""
+        g = self.graph
+        dev = self.workspace.device
+        n_l = len(grad_node_features)
+        gn = [None if t is None else t.detach().to(torch.float32).contiguous() for t in grad_node_features]
+        ge = [None if t is None else t.detach().to(torch.float32).contiguous() for t in grad_edge_features]
+        pn = (c_void_p * n_l)(*[0 if t is None else t.data_ptr() for t in gn])
+        pe = (c_void_p * n_l)(*[0 if t is None else t.data_ptr() for t in ge])
+        geo = torch.zeros((g.n_edges, 4), dtype=torch.float32, device=dev)
+        gfc = torch.zeros(g.n_edges, dtype=torch.float32, device=dev)
+        check(self.lib.pet_backward_features_layers(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes, pn, pe,
+                                                    n_l, _ptr(geo), _ptr(gfc), _stream()))
+        return geo, gfc
+
+    def backward_geometry(self, grad_geometry: torch.Tensor, grad_cutoff: torch.Tensor, want_cell_grad: bool = False):
+        """``preprocess^T`` (``pet_backward_geometry``): ``(d geometry [E,4], d cutoff factors [E])`` -> dL/dR ``[N,3]``
+        (and dL/dcell ``[S,3,3]``)."""
+        g = self.graph
+        dev = self.workspace.device
+        geo = grad_geometry.detach().to(torch.float32).contiguous()
+        gfc = grad_cutoff.detach().to(torch.float32).contiguous()
+        gpos = torch.zeros((g.n_nodes, 3), dtype=torch.float32, device=dev)
+        gcell = torch.zeros((g.n_systems, 3, 3), dtype=torch.float32, device=dev) if want_cell_grad else None
+        check(self.lib.pet_backward_geometry(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes, _ptr(geo),
+                                             _ptr(gfc), _ptr(gpos), _ptr(gcell), _stream()))
+        return (gpos, gcell) if want_cell_grad else gpos
 
     def forward(self, want_features: bool = False):
         g = self.graph

@@ -1,0 +1,111 @@
+"""GPU parity of the architecture variants older checkpoints use (``-m gpu``): LayerNorm normalisation
+(``transformer.py:170-176``), PostLN transformer layers (``:236-262``), the residual featuriser (``backend.py:589-649``),
+each on its own and all together with ``activation = "SiLU"`` -- what ``pet/checkpoints.py:190-205`` turns a legacy
+checkpoint into -- against goldens the REFERENCE produced (``tests/golden/make_golden.py --variants``): per-atom
+energies, the features of every readout layer and dE/dR through the three calls' adjoints."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pet as opet
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+TYPES = [1, 6, 7, 8]
+VARIANTS = {
+    "legacy": dict(normalization="LayerNorm", activation="SiLU", transformer_type="PostLN", featurizer_type="residual"),
+    "layernorm": dict(normalization="LayerNorm"),
+    "postln": dict(transformer_type="PostLN"),
+    "residual": dict(featurizer_type="residual"),
+}
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+@pytest.fixture(scope="module")
+def rt():
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    from metatrain_amd import runtime
+
+    return runtime
+
+
+def _setup(rt, golden_dir, tag, extra=None):
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS, **VARIANTS[tag], **(extra or {}))
+    g = dict(np.load(os.path.join(golden_dir, f"pet_variant_{tag}_box64.npz")))
+    params = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    m = rt.HipModel(hypers, TYPES)
+    m.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    t = lambda k, dt=None: torch.tensor(g[k]).to(dev) if dt is None else torch.tensor(g[k]).to(dev, dt)  # noqa: E731
+    graph = rt.HipGraph(m, t("in_positions", torch.float32), t("in_cells", torch.float32), t("in_centers"), t("in_neighbors"),
+                        t("in_cell_shifts"), t("in_species"), t("in_system_indices", torch.int32))
+    return m, graph, g, hypers
+
+
+def _energy_and_gradient(rt, m, graph):
+    """predict summed over readout layers on the features of calculate_features, and dE/dR through the adjoints of
+    the three calls (what autograd does with the mirror's three nodes)."""
+    fw = rt.HipForward(m, graph)
+    nfs, efs = fw.features_layers()
+    atomic = sum(rt.predict(m, graph, nfs[l], efs[l], "energy", readout_layer=l) for l in range(len(nfs)))
+    ones = torch.ones_like(atomic)
+    g_nf, g_ef, g_fc = [], [], None
+    for l in range(len(nfs)):
+        a, b, c = rt.predict_backward(m, graph, nfs[l], efs[l], ones, "energy", readout_layer=l)
+        g_nf.append(a)
+        g_ef.append(b)
+        g_fc = c if g_fc is None else g_fc + c
+    geo, gfc = fw.backward_features_layers(g_nf, g_ef)
+    grad = fw.backward_geometry(geo, gfc + g_fc)
+    return atomic, grad, nfs, efs
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_variant_against_reference_golden(rt, golden_dir, tag):
+    m, graph, g, hypers = _setup(rt, golden_dir, tag)
+    atomic, grad, nfs, efs = _energy_and_gradient(rt, m, graph)
+    assert len(nfs) == int(g["n_readout"]) == (hypers["num_gnn_layers"] if hypers["featurizer_type"] == "residual" else 1)
+    for l, nf in enumerate(nfs):
+        assert relmax(nf.cpu().numpy(), g[f"node_features_{l}_f64"]) < TOL, f"node features of readout layer {l}"
+        key = f"edge_features_{l}_f64_as_f32"
+        if key in g:  # [N, M, d_pet] NEF grid of the reference -> CSR rows
+            mask = g["padding_mask"]
+            assert relmax(efs[l].cpu().numpy(), g[key][mask]) < TOL, f"edge features of readout layer {l}"
+    assert relmax(atomic.cpu().numpy(), g["atomic_f64"]) < TOL
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_variant_on_lds_tile_kernels_only(rt, golden_dir, tag):
+    """The same with the TRR kernels switched off everywhere (PET_HIP_TRR=0 path): the variant switches live in the
+    LDS-tile kernels, which then also serve compress / attention / heads."""
+    from metatrain_amd import _lib
+
+    lib = _lib.load()
+    _lib.check(lib.pet_config_set(b"trr", 0))
+    try:
+        m, graph, g, _ = _setup(rt, golden_dir, tag)
+        atomic, grad, _, _ = _energy_and_gradient(rt, m, graph)
+    finally:
+        _lib.check(lib.pet_config_set(b"trr", 1))
+    assert relmax(atomic.cpu().numpy(), g["atomic_f64"]) < TOL
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
+
+
+def test_fused_entry_points_refuse_what_they_do_not_serve(rt, golden_dir):
+    """pet_forward's fused head reads ONE readout layer and the native training step is built for the default
+    architecture: both say so instead of computing something else."""
+    m, graph, _, _ = _setup(rt, golden_dir, "residual")
+    fw = rt.HipForward(m, graph)
+    with pytest.raises(rt.PetHipError, match="fused"):
+        fw.forward()
+    m, graph, _, _ = _setup(rt, golden_dir, "layernorm")
+    fw = rt.HipForward(m, graph, train=True)
+    with pytest.raises(rt.PetHipError, match="training is built"):
+        fw.forward()
