@@ -513,17 +513,22 @@ class PETBackend(torch.nn.Module):
     @torch.jit.unused
     def auxiliary_outputs(self, node_features_list, edge_features_list, batch_data, target: str = "energy",
                           feature: bool = True, last_layer_features: bool = True):
-        """Per-atom ``feature`` ``[N, d_node + d_pet]`` and ``mtt::aux::<target>_last_layer_features``
-        ``[N, 2 d_head]`` as ``PET._get_output_features`` / ``_get_output_last_layer_features`` assemble them
-        (``pet/model.py:730-875``: cutoff-weighted edge sums next to the node parts), from the given features."""
-        # (this is wrapper-level assembly -- pet/model.py:750-755, :795-812 -- on tensors the kernels produced)
+        """Per-atom ``feature`` ``[N, L (d_node + d_pet)]`` and ``mtt::aux::<target>_last_layer_features``
+        ``[N, 2 L d_head]`` (L readout layers) as ``PET._get_output_features`` / ``_get_output_last_layer_features``
+        assemble them (``pet/model.py:730-875``: node parts of all layers, then the cutoff-weighted edge sums; last-layer
+        features interleaved node, edge per layer), from the given features."""
+        # (this is wrapper-level assembly -- pet/model.py:754-757, :813-823 -- on tensors the kernels produced)
         cf = batch_data["cutoff_factors"].detach()[..., None]
-        nf, ef = node_features_list[-1].detach(), edge_features_list[-1].detach()
+        nf = torch.cat([t.detach() for t in node_features_list], dim=1)
+        ef = torch.cat([t.detach() for t in edge_features_list], dim=2)
         feat = torch.cat([nf, (ef * cf).sum(1)], dim=1) if feature else None
         llf = None
         if last_layer_features:
             _, node_ll, edge_ll = self.predict(node_features_list, edge_features_list, batch_data,
                                                torch.zeros((1, 3, 3), device=nf.device), torch.zeros(1, device=nf.device),
                                                [target])
-            llf = torch.cat([node_ll[target][-1], (edge_ll[target][-1] * cf).sum(1)], dim=1)
+            parts = []
+            for a, b in zip(node_ll[target], edge_ll[target]):
+                parts += [a, (b * cf).sum(1)]
+            llf = torch.cat(parts, dim=1)
         return feat, llf

@@ -48,9 +48,47 @@ def test_reference_state_dict_loads_strictly():
     assert not any(k.startswith(("node_heads", "edge_heads")) for k in be.state_dict())
 
 
+VARIANTS = {
+    "legacy": dict(normalization="LayerNorm", activation="SiLU", transformer_type="PostLN", featurizer_type="residual"),
+    "layernorm": dict(normalization="LayerNorm"),
+    "postln": dict(transformer_type="PostLN"),
+    "residual": dict(featurizer_type="residual"),
+}
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_variant_state_dicts_match_reference_schema_and_script(tag):
+    """LayerNorm adds the norm biases, the residual featuriser drops the combination modules and has one node embedder,
+    head and last layer per GNN layer (backend.py:93-119, transformer.py:170-176); keys, shapes and order as the
+    reference's (the synthetic schema is pinned to it by tests/test_oracle_golden.py), strict loading, and the module
+    still scripts and round-trips through torch.jit.save."""
+    import io
+
+    hypers = dict(default_hypers(), **VARIANTS[tag])
+    be = PETBackend(hypers, [1, 6, 7, 8])
+    be.add_output("energy", {"energy": [1]})
+    sd = be.state_dict()
+    schema = state_dict_schema(hypers, [1, 6, 7, 8], {"energy": 1})
+    assert list(sd.keys()) == [k for k, _, _ in schema]
+    for k, shape, _ in schema:
+        assert tuple(sd[k].shape) == tuple(shape), k
+    res = be.load_state_dict(opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert be.num_readout_layers == (hypers["num_gnn_layers"] if hypers["featurizer_type"] == "residual" else 1)
+    mod = torch.jit.script(be)
+    buf = io.BytesIO()
+    torch.jit.save(mod, buf)
+    buf.seek(0)
+    back = torch.jit.load(buf)
+    assert [tuple(a.shape) for a in back._params()] == [tuple(a.shape) for a in be._params()]
+    assert len(be._params()) == len(list(be.parameters()))
+
+
 def test_unsupported_variants_and_cpu_inputs_raise():
-    with pytest.raises(PetHipError):
-        PETBackend(dict(default_hypers(), featurizer_type="residual"), [1, 6])
+    with pytest.raises(ValueError, match="featurizer_type"):
+        PETBackend(dict(default_hypers(), featurizer_type="convolutional"), [1, 6])
+    with pytest.raises(ValueError, match="normalization"):
+        PETBackend(dict(default_hypers(), normalization="BatchNorm"), [1, 6])
     with pytest.raises(PetHipError):
         PETBackend(dict(default_hypers(), num_neighbors_adaptive=16, adaptive_cutoff_method="grid"), [1, 6])
     PETBackend(dict(default_hypers(), num_neighbors_adaptive=16), [1, 6])  # the "solver" method is built

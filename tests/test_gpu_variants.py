@@ -109,3 +109,67 @@ def test_fused_entry_points_refuse_what_they_do_not_serve(rt, golden_dir):
     fw = rt.HipForward(m, graph, train=True)
     with pytest.raises(rt.PetHipError, match="training is built"):
         fw.forward()
+
+
+@pytest.mark.parametrize("scripted", [False, True])
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_variant_through_the_three_backend_calls(golden_dir, tag, scripted):
+    """The drop-in boundary for a legacy checkpoint: ``PETBackend(hypers)`` with the reference's state-dict keys,
+    ``preprocess -> calculate_features -> predict`` (lists with one entry per readout layer, backend.py:344-494) and
+    ``torch.autograd.grad`` of the summed energy w.r.t. positions, eager and as a scripted / saved / re-loaded module."""
+    import io
+
+    from metatrain_amd.pet import PETBackend
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS, **VARIANTS[tag])
+    g = dict(np.load(os.path.join(golden_dir, f"pet_variant_{tag}_box64.npz")))
+    be = PETBackend(hypers, TYPES)
+    be.add_output("energy", {"energy": [1]})
+    res = be.load_state_dict(opet.synthetic_params(hypers, TYPES, {"energy": 1}), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    be = be.to(dev).eval()
+    if scripted:
+        buf = io.BytesIO()
+        torch.jit.save(torch.jit.script(be), buf)
+        buf.seek(0)
+        be = torch.jit.load(buf, map_location=dev)
+    t = lambda k: torch.tensor(g[k]).to(dev)  # noqa: E731
+    pos = t("in_positions").float().requires_grad_(True)
+    cells = t("in_cells").float()
+    batch = be.preprocess(pos, t("in_centers"), t("in_neighbors"), t("in_species"), cells, t("in_cell_shifts"),
+                          t("in_system_indices"), 1.0)
+    nodes, edges = be.calculate_features(batch)
+    n_readout = hypers["num_gnn_layers"] if hypers["featurizer_type"] == "residual" else 1
+    assert len(nodes) == len(edges) == n_readout
+    for l in range(n_readout):
+        assert relmax(nodes[l].detach().cpu().numpy(), g[f"node_features_{l}_f64"]) < TOL
+        key = f"edge_features_{l}_f64_as_f32"
+        if key in g:
+            mask = g["padding_mask"]
+            assert relmax(edges[l].detach().cpu().numpy()[mask], g[key][mask]) < TOL
+    pred, node_ll, edge_ll = be.predict(nodes, edges, batch, cells, t("in_system_indices"), ["energy"])
+    assert len(node_ll["energy"]) == len(edge_ll["energy"]) == n_readout
+    atomic = pred["energy"][0]
+    (grad,) = torch.autograd.grad(atomic.sum(), pos)
+    assert relmax(atomic.detach().cpu().numpy(), g["atomic_f64"]) < TOL
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
+
+
+def test_variant_training_through_the_mirror_says_it_is_not_built(golden_dir):
+    from metatrain_amd._lib import PetHipError
+    from metatrain_amd.pet import PETBackend
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS, **VARIANTS["postln"])
+    g = dict(np.load(os.path.join(golden_dir, "pet_variant_postln_box64.npz")))
+    be = PETBackend(hypers, TYPES)
+    be.add_output("energy", {"energy": [1]})
+    be = be.to(dev).train()
+    t = lambda k: torch.tensor(g[k]).to(dev)  # noqa: E731
+    pos = t("in_positions").float().requires_grad_(True)
+    batch = be.preprocess(pos, t("in_centers"), t("in_neighbors"), t("in_species"), t("in_cells").float(),
+                          t("in_cell_shifts"), t("in_system_indices"), 1.0)
+    nodes, edges = be.calculate_features(batch)
+    with pytest.raises((PetHipError, RuntimeError), match="training is built"):
+        be.predict(nodes, edges, batch, t("in_cells").float(), t("in_system_indices"), ["energy"])
