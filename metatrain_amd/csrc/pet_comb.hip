@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void k_comb_bwd_h(const float* __restrict__ dM
     }
     const float m1 = row_sum(s1) * (1.0f / 256.0f);
     const float m2 = row_sum(s2) * rstd * rstd * (1.0f / 256.0f);
-    if (valid) {
+    {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             wlo[k] = make_float4(rstd * (wlo[k].x - m1 - (xo[k].x - mean) * m2), rstd * (wlo[k].y - m1 - (xo[k].y - mean) * m2),
@@ -503,8 +503,10 @@ __global__ __launch_bounds__(256) void k_comb_bwd_h(const float* __restrict__ dM
             whi[k] = make_float4(rstd * (whi[k].x - m1 - (xr[k].x - mean) * m2), rstd * (whi[k].y - m1 - (xr[k].y - mean) * m2),
                                  rstd * (whi[k].z - m1 - (xr[k].z - mean) * m2), rstd * (whi[k].w - m1 - (xr[k].w - mean) * m2));
         }
-        store_rowfrag<16>(wlo, dcat, row, 2 * D, L.h);
-        store_rowfrag<16>(whi, dcat + D, row, 2 * D, L.h);
+        // the parked chunks are consumed: the wave's park region is its staging tile for full-line stores (trr.h)
+        float* otile = reinterpret_cast<float*>(park);
+        store_rows_lines<16>(wlo, otile, L, [&](int r) { return row0 + r < E ? dcat + (row0 + r) * (2 * D) : nullptr; });
+        store_rows_lines<16>(whi, otile, L, [&](int r) { return row0 + r < E ? dcat + (row0 + r) * (2 * D) + D : nullptr; });
     }
 }
 

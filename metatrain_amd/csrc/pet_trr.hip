@@ -351,9 +351,30 @@ __global__ __launch_bounds__(256, 2) void k_qkv_h(const float* __restrict__ X, c
     });
 }
 
+// the same with full-line stores through a wave-private LDS tile (trr.h store_tile64_lines)
+__global__ __launch_bounds__(256, 2) void k_qkv_hl(const float* __restrict__ X, const float* __restrict__ gamma, W2 win,
+                                                 const float* __restrict__ bin, float* __restrict__ QKV, int64_t R) {
+    __shared__ __attribute__((aligned(16))) float tiles[4][32 * TILE_LD];
+    TRR_PROLOGUE(R);
+    float* lds = tiles[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    Split2<8> xs;
+    {
+        float4 x[16];
+        load_rowfrag<16>(x, X, row, D, L.h);
+        rmsnorm_frag<16>(x, gamma, L.h);
+        split_frag2<8>(x, xs);
+    }
+    row_gemm128_h<6, false, 2>(win, bin, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
+        float4 y[8];
+        acc_to_frag<2>(acc, y);
+        store_tile64_lines(y, lds, QKV + 64 * c, row0, R, 3 * D, L);
+    });
+}
+
 __global__ __launch_bounds__(256, 2) void k_oproj_h(const float* __restrict__ AO, const float* __restrict__ X, W2 wo,
                                                   const float* __restrict__ bo, float* __restrict__ X1,
                                                   float* __restrict__ OC, int64_t E, int64_t R) {
+    PET_TRR_TILE_LDS();
     TRR_PROLOGUE(R);
     Split2<8> xs;
     float inv;  // attention outputs are not normalised rows: scale them like an adjoint (the bias is added after)
@@ -376,25 +397,26 @@ __global__ __launch_bounds__(256, 2) void k_oproj_h(const float* __restrict__ AO
                     acc[t][4 * q + 2] += bb[4 * t + q].z; acc[t][4 * q + 3] += bb[4 * t + q].w;
                 }
         }
-        if (!valid) return;
         float4 y[8];
         acc_to_frag<2>(acc, y);
-        if (row < E) {
+        if (valid && row < E) {
             float4 xr[8];
             load_rowfrag<8>(xr, X + 64 * c, row, D, L.h);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 y[k].x += xr[k].x; y[k].y += xr[k].y; y[k].z += xr[k].z; y[k].w += xr[k].w;
             }
-            store_rowfrag<8>(y, X1 + 64 * c, row, D, L.h);
-        } else {
-            store_rowfrag<8>(y, OC + 64 * c, row - E, D, L.h);
         }
+        store_rows_lines<8>(y, lds_tile, L, [&](int r) -> float* {
+            const int64_t rw = row0 + r;
+            return rw < E ? X1 + rw * D + 64 * c : (rw < R ? OC + (rw - E) * D + 64 * c : nullptr);
+        });
     });
 }
 
 __global__ __launch_bounds__(256, 2) void k_oproj_bwd_h(const float* __restrict__ dX1, const float* __restrict__ dOC,
                                                       W2 wob, float* __restrict__ dAO, int64_t E, int64_t R) {
+    PET_TRR_TILE_LDS();
     TRR_PROLOGUE(R);
     Split2<8> xs;
     float inv;
@@ -407,11 +429,9 @@ __global__ __launch_bounds__(256, 2) void k_oproj_bwd_h(const float* __restrict_
         split_frag2<8>(d, xs);
     }
     row_gemm128_h<2>(wob, nullptr, xs, L, inv, [&](int c, f32x16 (&acc)[2]) {
-        if (valid) {
-            float4 y[8];
-            acc_to_frag<2>(acc, y);
-            store_rowfrag<8>(y, dAO + 64 * c, row, D, L.h);
-        }
+        float4 y[8];
+        acc_to_frag<2>(acc, y);
+        store_tile64_lines(y, lds_tile, dAO + 64 * c, row0, R, D, L);
     });
 }
 
@@ -421,6 +441,7 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_h(const float* __restrict__ dQK
                                                     const float* __restrict__ gamma, W2 winb,
                                                     const float* __restrict__ dX1, float* __restrict__ dXin, int64_t E,
                                                     int64_t R) {
+    PET_TRR_TILE_LDS();
     TRR_PROLOGUE(R);
     auto widx = [&](int b) { return (size_t)b * 64 + L.lane; };  // tile 0; tile t at + t * 24 * 64
     WBlk2<4> ring[4];
@@ -471,16 +492,14 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_h(const float* __restrict__ dQK
         w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
     }
     rmsnorm_bwd_frag<16>(w, x);
-    if (valid) {
-        if (row < E) {
-            load_rowfrag<16>(x, dX1, row, D, L.h);
+    if (valid && row < E) {
+        load_rowfrag<16>(x, dX1, row, D, L.h);
 #pragma unroll
-            for (int kg = 0; kg < 16; kg++) {
-                w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
-            }
+        for (int kg = 0; kg < 16; kg++) {
+            w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
         }
-        store_rowfrag<16>(w, dXin, row, D, L.h);
     }
+    store_rows_lines<16>(w, lds_tile, L, [&](int r) { return row0 + r < R ? dXin + (row0 + r) * D : nullptr; });
 }
 
 // ---------------------------------------------------------------------------------
@@ -792,6 +811,7 @@ __global__ __launch_bounds__(256) void k_emlp_p(const float* __restrict__ X1, co
 
 // f16x3 form of the persistent edge MLP (trr.h): two fp16 planes, three MFMAs per K block on a high and a cross
 // accumulator; RMSNorm output and SwiGLU output are O(1) rows, so no row scaling is needed here.
+template <bool LINES>
 __global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, const float* __restrict__ gamma, W2 win,
                                                   const float* __restrict__ bin, W2 wout,
                                                   const float* __restrict__ bout, float* __restrict__ VG,
@@ -800,6 +820,8 @@ __global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, co
     const RowLane L;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4* mybuf = xstage + (size_t)wave * 2 * 16 * 64;
+    // LINES: outputs leave as whole 128-B lines through a wave-private [32][36] tile behind the row buffers (trr.h)
+    float* otile = reinterpret_cast<float*>(xstage + (size_t)4 * 2 * 16 * 64) + wave * 32 * TILE32_LD;
     const int64_t ntiles = (E + WROWS - 1) / WROWS, nw = (int64_t)gridDim.x * 4;
     int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     if (tile >= ntiles) return;
@@ -877,10 +899,19 @@ __global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, co
             }
             fold_low<2>(vg, vgl);
             float4 u[4];
+            if (LINES && VG) {
+                float4 t4[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) t4[q] = acc_q(vg[0], q);
+                store_tile32_lines(t4, otile, VG + 32 * hc, row0, E, 2 * DFF, L);
+#pragma unroll
+                for (int q = 0; q < 4; q++) t4[q] = acc_q(vg[1], q);
+                store_tile32_lines(t4, otile, VG + DFF + 32 * hc, row0, E, 2 * DFF, L);
+            }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const float4 vv = acc_q(vg[0], q), gg = acc_q(vg[1], q);
-                if (VG && valid) {
+                if (!LINES && VG && valid) {
                     *reinterpret_cast<float4*>(VG + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) = vv;
                     *reinterpret_cast<float4*>(VG + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) = gg;
                 }
@@ -898,7 +929,7 @@ __global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, co
                 }
         }
         fold_low<4>(out, outl);
-        if (valid) {
+        {
             float4 y[16];
             acc_to_frag<4>(out, y);
 #pragma unroll
@@ -906,7 +937,13 @@ __global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, co
                 const float4 xr = xb[k * 64 + L.lane];
                 y[k].x += xr.x; y[k].y += xr.y; y[k].z += xr.z; y[k].w += xr.w;
             }
-            store_rowfrag<16>(y, X2, row, D, L.h);
+            if (LINES) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const float4 t4[4] = {y[4 * t], y[4 * t + 1], y[4 * t + 2], y[4 * t + 3]};
+                    store_tile32_lines(t4, otile, X2 + 32 * t, row0, E, D, L);
+                }
+            } else if (valid) store_rowfrag<16>(y, X2, row, D, L.h);
         }
     }
 }
@@ -1316,6 +1353,7 @@ __global__ __launch_bounds__(256, 2) void k_compress_h(const float4* __restrict_
                                                      const float* __restrict__ Min, W2 w0c, W2 w2,
                                                      const float* __restrict__ b2, float* __restrict__ a0_out,
                                                      float* __restrict__ Xout, int64_t E) {
+    PET_TRR_TILE_LDS();
     TRR_PROLOGUE(E);
     float4 a0[16];  // row fragment of the pre-activation: entries a0[kg] = features 8 kg + 4 h .. + 3
     if (!FIRST) {   // message term first: the geometry terms below then need no registers during the GEMM
@@ -1352,7 +1390,7 @@ __global__ __launch_bounds__(256, 2) void k_compress_h(const float4* __restrict_
             if ((kg & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // 20 float4 loads in flight, not 80
         }
     }
-    if (a0_out && valid) store_rowfrag<16>(a0, a0_out, row, D, L.h);
+    if (a0_out) store_rows_lines<16>(a0, lds_tile, L, [&](int r) { return row0 + r < E ? a0_out + (row0 + r) * D : nullptr; });
     Split2<8> ss;
     float sinv;
     {
@@ -1364,11 +1402,9 @@ __global__ __launch_bounds__(256, 2) void k_compress_h(const float4* __restrict_
         split_frag2<8>(a0, ss);
     }
     row_gemm128_h<2, true, 2>(w2, b2, ss, L, sinv, [&](int c, f32x16 (&acc)[2]) {
-        if (valid) {
-            float4 y[8];
-            acc_to_frag<2>(acc, y);
-            store_rowfrag<8>(y, Xout + 64 * c, row, D, L.h);
-        }
+        float4 y[8];
+        acc_to_frag<2>(acc, y);
+        store_tile64_lines(y, lds_tile, Xout + 64 * c, row0, E, D, L);
     });
 }
 
@@ -1377,6 +1413,7 @@ __global__ __launch_bounds__(256, 2) void k_compress_bwd_h(const float* __restri
                                                          W2 w2b, W2 wcp /* Wc^T padded to [32][D] */, W2 w0cb,
                                                          float* __restrict__ dgeo, float* __restrict__ dM, int64_t E,
                                                          float* __restrict__ t_da0) {
+    PET_TRR_TILE_LDS();
     TRR_PROLOGUE(E);
     Split2<8> ys;
     float inv;
@@ -1440,12 +1477,16 @@ __global__ __launch_bounds__(256, 2) void k_compress_bwd_h(const float* __restri
             for (int k = 0; k < 8; k++) {
                 y[k].x += old[k].x; y[k].y += old[k].y; y[k].z += old[k].z; y[k].w += old[k].w;
             }
-            if (valid) store_rowfrag<8>(y, dM + 64 * c, row, D, L.h);
+            store_tile64_lines(y, lds_tile, dM + 64 * c, row0, E, D, L);
         });
     }
 }
 
 static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
+// full-line stores through a wave-private LDS tile (trr.h store_rows_lines): bit 0 qkv, bit 1 edge MLP (A/B switches;
+// oproj_bwd, qkv_bwd, compress, compress_bwd, comb_bwd and head_bwd always store this way)
+static int g_line_stores = 3;
+void set_line_stores(int v) { g_line_stores = v; }
 
 // pet_config_set("bf16x6", 0) puts the TRR stages back on the fp32 MFMA. Default: GEMMs on the bf16 matrix cores
 // with 3-way split operands -- as accurate as the fp32 MFMA (3.7e-7 vs 4.5e-7 against fp64, tools/ubench/bf16x3.hip)
@@ -1491,7 +1532,9 @@ void set_bf16x6(int v) { g_bf16x6 = v ? 1 : 0; }
 bool use_bf16x6() { return g_bf16x6 != 0; }
 
 void trr_qkv(const float* X, const float* gamma, const Lin& qkv, float* QKV, int64_t R, hipStream_t st) {
-    if (g_bf16x6 && g_f16x3 && qkv.fwd2) k_qkv_h<<<grid_rows(R), 256, 0, st>>>(X, gamma, w2_fwd(qkv), qkv.b, QKV, R);
+    if (g_bf16x6 && g_f16x3 && qkv.fwd2 && (g_line_stores & 1))
+        k_qkv_hl<<<grid_rows(R), 256, 0, st>>>(X, gamma, w2_fwd(qkv), qkv.b, QKV, R);
+    else if (g_bf16x6 && g_f16x3 && qkv.fwd2) k_qkv_h<<<grid_rows(R), 256, 0, st>>>(X, gamma, w2_fwd(qkv), qkv.b, QKV, R);
     else if (g_bf16x6 && qkv.fwd3) k_qkv_b<<<grid_rows(R), 256, 0, st>>>(X, gamma, w3_fwd(qkv), qkv.b, QKV, R);
     else k_qkv_t<<<grid_rows(R), 256, 0, st>>>(X, gamma, qkv.fwd, qkv.b, QKV, R);
 }
@@ -1517,10 +1560,16 @@ void trr_oproj_bwd(const float* dX1, const float* dOC, const Lin& out, float* dA
 void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wout, float* VG, float* X2,
               int64_t E, hipStream_t st) {
     if (g_bf16x6 && g_f16x3 && win.fwd2 && wout.fwd2 && g_trr_persist && E > 0) {
-        const size_t lds = (size_t)4 * 2 * 16 * 64 * sizeof(float4);  // 128 KB: two row buffers per wave
-        allow_big_lds(k_emlp_h, lds);
+        const size_t rows_lds = (size_t)4 * 2 * 16 * 64 * sizeof(float4);  // 128 KB: two row buffers per wave
         const int grid = std::min(grid_rows(E), num_cus());
-        k_emlp_h<<<grid, 256, lds, st>>>(X1, gamma, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
+        if (g_line_stores & 2) {
+            const size_t lds = rows_lds + (size_t)4 * 32 * TILE32_LD * sizeof(float);  // + one output tile per wave
+            allow_big_lds(k_emlp_h<true>, lds);
+            k_emlp_h<true><<<grid, 256, lds, st>>>(X1, gamma, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
+        } else {
+            allow_big_lds(k_emlp_h<false>, rows_lds);
+            k_emlp_h<false><<<grid, 256, rows_lds, st>>>(X1, gamma, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
+        }
     } else if (g_bf16x6 && win.fwd3 && wout.fwd3 && g_trr_persist && E > 0) {
         const size_t lds = (size_t)4 * 2 * 16 * 64 * sizeof(float4);  // 128 KB: two row buffers per wave
         allow_big_lds(k_emlp_p, lds);
@@ -1607,6 +1656,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_h(const float* __restrict__ Xi
                                                      float* __restrict__ dXout, int64_t R, float* __restrict__ t_s1,
                                                      float* __restrict__ t_da2, float* __restrict__ t_da1,
                                                      float* __restrict__ t_s2y) {
+    PET_TRR_TILE_LDS();
     TRR_PROLOGUE(R);
     float gy;  // dL/dy of this edge: the centre atom's seed times the cutoff factor
     {
@@ -1677,11 +1727,9 @@ __global__ __launch_bounds__(256) void k_head_bwd_h(const float* __restrict__ Xi
         split_frag2<8>(t, xs);
     }
     row_gemm128_h<2, true>(w0b, nullptr, xs, L, inv, [&](int c, f32x16 (&acc)[2]) {  // dx = da1 W0
-        if (valid) {
-            float4 y[8];
-            acc_to_frag<2>(acc, y);
-            store_rowfrag<8>(y, dXout + 64 * c, row, D, L.h);
-        }
+        float4 y[8];
+        acc_to_frag<2>(acc, y);
+        store_tile64_lines(y, lds_tile, dXout + 64 * c, row0, R, D, L);
     });
 }
 

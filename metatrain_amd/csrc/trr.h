@@ -274,6 +274,59 @@ __device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
     h = (_Float16)x;
     l = (_Float16)((x - (float)h) * 2048.0f);
 }
+// Full-line stores of a [32 rows x 8 KG columns] output fragment. A row fragment gives each row 32 contiguous bytes
+// per store instruction (its two lanes), i.e. four separate partial writes per 128-B line on the way to L2. Staged
+// through a wave-private LDS tile instead, every store instruction writes four rows x 256 B (16 lanes per row): whole
+// lines. lds: this wave's [32][TILE_LD] floats; rowptr(r) = where columns 0.. of tile row r go, or nullptr to skip it.
+constexpr int TILE_LD = 68;
+template <int KG, class RowPtr>
+__device__ __forceinline__ void store_rows_lines(const float4 (&y)[KG], float* lds, const RowLane& L, RowPtr rowptr) {
+    static_assert(KG % 8 == 0, "whole 64-column groups");
+    float* wr = lds + L.r * TILE_LD + 4 * L.h;
+    const int rr = L.lane >> 4, cc = 4 * (L.lane & 15);
+#pragma unroll
+    for (int g = 0; g < KG / 8; g++) {
+#pragma unroll
+        for (int kg = 0; kg < 8; kg++) *reinterpret_cast<float4*>(wr + 8 * kg) = y[8 * g + kg];
+        __builtin_amdgcn_wave_barrier();  // same wave: the LDS serves its requests in order
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int r = 4 * j + rr;
+            const float4 v = *reinterpret_cast<const float4*>(lds + r * TILE_LD + cc);
+            float* p = rowptr(r);
+            if (p) *reinterpret_cast<float4*>(p + 64 * g + cc) = v;
+        }
+        __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next group
+    }
+}
+// rows row0 .. row0 + 31 of a row-major matrix Y (leading dimension ld), rows >= n_rows not written
+__device__ __forceinline__ void store_tile64_lines(const float4 (&y)[8], float* lds, float* __restrict__ Y, int64_t row0,
+                                                   int64_t n_rows, int ld, const RowLane& L) {
+    store_rows_lines<8>(y, lds, L, [&](int r) { return row0 + r < n_rows ? Y + (row0 + r) * ld : nullptr; });
+}
+#define PET_TRR_TILE_LDS()                                                          \
+    __shared__ __attribute__((aligned(16))) float trr_tiles_[4][32 * TILE_LD];      \
+    float* const lds_tile = trr_tiles_[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)]
+
+// The same for a [32 rows x 32 columns] tile (y[q] = columns 8 q + 4 h ..): 8 lanes per row, one full 128-B line each.
+// lds: this wave's [32][TILE32_LD] floats.
+constexpr int TILE32_LD = 36;
+__device__ __forceinline__ void store_tile32_lines(const float4 (&y)[4], float* lds, float* __restrict__ Y, int64_t row0,
+                                                   int64_t n_rows, int ld, const RowLane& L) {
+    float* wr = lds + L.r * TILE32_LD + 4 * L.h;
+#pragma unroll
+    for (int q = 0; q < 4; q++) *reinterpret_cast<float4*>(wr + 8 * q) = y[q];
+    __builtin_amdgcn_wave_barrier();
+    const int rr = L.lane >> 3, cc = 4 * (L.lane & 7);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = 8 * j + rr;
+        const float4 v = *reinterpret_cast<const float4*>(lds + r * TILE32_LD + cc);
+        if (row0 + r < n_rows) *reinterpret_cast<float4*>(Y + (row0 + r) * ld + cc) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int KB>
 struct Split2 {
     f16x8 h[KB], l[KB];
