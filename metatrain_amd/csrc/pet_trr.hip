@@ -354,13 +354,13 @@ __global__ __launch_bounds__(256, 2) void k_qkv_h(const float* __restrict__ X, c
 // the same with full-line stores through a wave-private LDS tile (trr.h store_tile64_lines)
 __global__ __launch_bounds__(256, 2) void k_qkv_hl(const float* __restrict__ X, const float* __restrict__ gamma, W2 win,
                                                  const float* __restrict__ bin, float* __restrict__ QKV, int64_t R) {
-    __shared__ __attribute__((aligned(16))) float tiles[4][32 * TILE_LD];
+    __shared__ __attribute__((aligned(16))) float tiles[4][32 * ROWS_LD];
     TRR_PROLOGUE(R);
     float* lds = tiles[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
     Split2<8> xs;
     {
         float4 x[16];
-        load_rowfrag<16>(x, X, row, D, L.h);
+        load_rows_lines128(x, lds, X, row0, R, L);
         rmsnorm_frag<16>(x, gamma, L.h);
         split_frag2<8>(x, xs);
     }
@@ -374,13 +374,13 @@ __global__ __launch_bounds__(256, 2) void k_qkv_hl(const float* __restrict__ X, 
 __global__ __launch_bounds__(256, 2) void k_oproj_h(const float* __restrict__ AO, const float* __restrict__ X, W2 wo,
                                                   const float* __restrict__ bo, float* __restrict__ X1,
                                                   float* __restrict__ OC, int64_t E, int64_t R) {
-    PET_TRR_TILE_LDS();
+    PET_TRR_ROWS_LDS();
     TRR_PROLOGUE(R);
     Split2<8> xs;
     float inv;  // attention outputs are not normalised rows: scale them like an adjoint (the bias is added after)
     {
         float4 a[16];
-        load_rowfrag<16>(a, AO, row, D, L.h);
+        load_rows_lines128(a, lds_tile, AO, row0, R, L);
         float sc;
         inv = row_scale_pow2<16>(a, sc);
         split_frag2<8>(a, xs);
@@ -416,14 +416,16 @@ __global__ __launch_bounds__(256, 2) void k_oproj_h(const float* __restrict__ AO
 
 __global__ __launch_bounds__(256, 2) void k_oproj_bwd_h(const float* __restrict__ dX1, const float* __restrict__ dOC,
                                                       W2 wob, float* __restrict__ dAO, int64_t E, int64_t R) {
-    PET_TRR_TILE_LDS();
+    PET_TRR_ROWS_LDS();
     TRR_PROLOGUE(R);
     Split2<8> xs;
     float inv;
     {
         float4 d[16];
-        if (row < E) load_rowfrag<16>(d, dX1, row, D, L.h);
-        else load_rowfrag<16>(d, dOC, row - E, D, L.h);
+        load_rows_lines(d, lds_tile, L, [&](int r) {
+            const int64_t rw = row0 + r < R ? row0 + r : R - 1;
+            return rw < E ? dX1 + rw * D : dOC + (rw - E) * D;
+        });
         float sc;
         inv = row_scale_pow2<16>(d, sc);
         split_frag2<8>(d, xs);
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_h(const float* __restrict__ dQK
                                                     const float* __restrict__ gamma, W2 winb,
                                                     const float* __restrict__ dX1, float* __restrict__ dXin, int64_t E,
                                                     int64_t R) {
-    PET_TRR_TILE_LDS();
+    PET_TRR_ROWS_LDS();
     TRR_PROLOGUE(R);
     auto widx = [&](int b) { return (size_t)b * 64 + L.lane; };  // tile 0; tile t at + t * 24 * 64
     WBlk2<4> ring[4];
@@ -1353,7 +1355,7 @@ __global__ __launch_bounds__(256, 2) void k_compress_h(const float4* __restrict_
                                                      const float* __restrict__ Min, W2 w0c, W2 w2,
                                                      const float* __restrict__ b2, float* __restrict__ a0_out,
                                                      float* __restrict__ Xout, int64_t E) {
-    PET_TRR_TILE_LDS();
+    PET_TRR_ROWS_LDS();
     TRR_PROLOGUE(E);
     float4 a0[16];  // row fragment of the pre-activation: entries a0[kg] = features 8 kg + 4 h .. + 3
     if (!FIRST) {   // message term first: the geometry terms below then need no registers during the GEMM
@@ -1413,7 +1415,7 @@ __global__ __launch_bounds__(256, 2) void k_compress_bwd_h(const float* __restri
                                                          W2 w2b, W2 wcp /* Wc^T padded to [32][D] */, W2 w0cb,
                                                          float* __restrict__ dgeo, float* __restrict__ dM, int64_t E,
                                                          float* __restrict__ t_da0) {
-    PET_TRR_TILE_LDS();
+    PET_TRR_ROWS_LDS();
     TRR_PROLOGUE(E);
     Split2<8> ys;
     float inv;
@@ -1608,12 +1610,13 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const float* __restrict__ Xin
                                                     W2 w2, const float* __restrict__ b2, const float* __restrict__ wl,
                                                     float bl, const float* __restrict__ fc, float* __restrict__ ypred,
                                                     float* __restrict__ yout, int64_t R) {
+    PET_TRR_ROWS_LDS();
     TRR_PROLOGUE(R);
     Split2<8> xs;
     float xinv;
     {   // backbone features are un-normalised rows: power-of-two row scale (see k_compress_h)
         float4 x[16];
-        load_rowfrag<16>(x, Xin, row, D, L.h);
+        load_rows_lines128(x, lds_tile, Xin, row0, R, L);
         float sc;
         xinv = row_scale_pow2<16>(x, sc);
         split_frag2<8>(x, xs);
@@ -1656,7 +1659,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_h(const float* __restrict__ Xi
                                                      float* __restrict__ dXout, int64_t R, float* __restrict__ t_s1,
                                                      float* __restrict__ t_da2, float* __restrict__ t_da1,
                                                      float* __restrict__ t_s2y) {
-    PET_TRR_TILE_LDS();
+    PET_TRR_ROWS_LDS();
     TRR_PROLOGUE(R);
     float gy;  // dL/dy of this edge: the centre atom's seed times the cutoff factor
     {

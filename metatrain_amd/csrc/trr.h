@@ -304,9 +304,62 @@ __device__ __forceinline__ void store_tile64_lines(const float4 (&y)[8], float* 
                                                    int64_t n_rows, int ld, const RowLane& L) {
     store_rows_lines<8>(y, lds, L, [&](int r) { return row0 + r < n_rows ? Y + (row0 + r) * ld : nullptr; });
 }
-#define PET_TRR_TILE_LDS()                                                          \
-    __shared__ __attribute__((aligned(16))) float trr_tiles_[4][32 * TILE_LD];      \
+// Full-line loads of a [32 rows x 128 columns] row tile: 32 lanes read one row's 512 B (two rows per instruction), the
+// fragments are then picked up from the wave-private LDS tile [32][ROWS_LD]. load_rowfrag touches 32 different lines
+// per instruction (32 B of each); this touches 8. rowptr(r) = first of the 128 floats of tile row r (never null: clamp).
+constexpr int ROWS_LD = 132;
+// Two halves so that the global loads can be in flight across other work: request (coalesced mapping, 16 registers) ...
+template <class RowPtr>
+__device__ __forceinline__ void request_rows_lines(float4 (&t)[16], const RowLane& L, RowPtr rowptr) {
+    const int rr = L.lane >> 5, cc = 4 * (L.lane & 31);
+#pragma unroll
+    for (int j = 0; j < 16; j++) t[j] = *reinterpret_cast<const float4*>(rowptr(2 * j + rr) + cc);
+}
+// ... and turn into row fragments through the LDS tile
+__device__ __forceinline__ void rows_lines_to_frag(float4 (&x)[16], const float4 (&t)[16], float* lds, const RowLane& L) {
+    const int rr = L.lane >> 5, cc = 4 * (L.lane & 31);
+#pragma unroll
+    for (int j = 0; j < 16; j++) *reinterpret_cast<float4*>(lds + (2 * j + rr) * ROWS_LD + cc) = t[j];
+    __builtin_amdgcn_wave_barrier();
+    const float* rd = lds + L.r * ROWS_LD + 4 * L.h;
+#pragma unroll
+    for (int kg = 0; kg < 16; kg++) x[kg] = *reinterpret_cast<const float4*>(rd + 8 * kg);
+    __builtin_amdgcn_wave_barrier();
+}
+template <class RowPtr>
+__device__ __forceinline__ void load_rows_lines(float4 (&x)[16], float* lds, const RowLane& L, RowPtr rowptr) {
+    float4 t[16];
+    request_rows_lines(t, L, rowptr);
+    rows_lines_to_frag(x, t, lds, L);
+}
+// rows row0 .. row0 + 31 of a row-major [n_rows][128] matrix (rows past the end read the last row)
+__device__ __forceinline__ void load_rows_lines128(float4 (&x)[16], float* lds, const float* __restrict__ X, int64_t row0,
+                                                   int64_t n_rows, const RowLane& L) {
+    load_rows_lines(x, lds, L, [&](int r) { return X + (row0 + r < n_rows ? row0 + r : n_rows - 1) * 128; });
+}
+// one LDS tile per wave for both directions: [32][ROWS_LD] floats (the store helpers use its first [32][TILE_LD])
+#define PET_TRR_ROWS_LDS()                                                          \
+    __shared__ __attribute__((aligned(16))) float trr_tiles_[4][32 * ROWS_LD];      \
     float* const lds_tile = trr_tiles_[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)]
+
+// [32 rows x 32 columns] chunk as whole lines (8 lanes per row, 8 rows per instruction), in two halves like above;
+// lds: [32][TILE32_LD] floats. rowptr(r) = first of the 32 floats of tile row r.
+template <class RowPtr>
+__device__ __forceinline__ void request_tile32_lines(float4 (&t)[4], const RowLane& L, RowPtr rowptr) {
+    const int rr = L.lane >> 3, cc = 4 * (L.lane & 7);
+#pragma unroll
+    for (int j = 0; j < 4; j++) t[j] = *reinterpret_cast<const float4*>(rowptr(8 * j + rr) + cc);
+}
+__device__ __forceinline__ void tile32_lines_to_frag(float4 (&x)[4], const float4 (&t)[4], float* lds, const RowLane& L) {
+    const int rr = L.lane >> 3, cc = 4 * (L.lane & 7);
+#pragma unroll
+    for (int j = 0; j < 4; j++) *reinterpret_cast<float4*>(lds + (8 * j + rr) * 36 + cc) = t[j];
+    __builtin_amdgcn_wave_barrier();
+    const float* rd = lds + L.r * 36 + 4 * L.h;
+#pragma unroll
+    for (int q = 0; q < 4; q++) x[q] = *reinterpret_cast<const float4*>(rd + 8 * q);
+    __builtin_amdgcn_wave_barrier();
+}
 
 // The same for a [32 rows x 32 columns] tile (y[q] = columns 8 q + 4 h ..): 8 lanes per row, one full 128-B line each.
 // lds: this wave's [32][TILE32_LD] floats.
