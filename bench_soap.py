@@ -58,10 +58,24 @@ def main():
     ap.add_argument("--atoms", type=int, default=100000)
     ap.add_argument("--alchemical", action="store_true", help="non-legacy: 4 pseudo-species + centre encoding")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--partition", action="store_true",
+                    help="strong scaling: ONE box for all ranks, cut into slabs + halos, one all-reduce of energy and "
+                         "gradient per step (metatrain_amd/soap_bpnn/partition.py; BASELINE configs[4] at 8 GPUs)")
     args = ap.parse_args()
 
     from metatrain_amd import distributed as pdist
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: start the ranks ourselves (as bench.py does)
+        import socket
+        import subprocess
+
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        raise SystemExit(subprocess.call(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+             "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]))
     rank, local_rank, world = pdist.env_rank()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -92,6 +106,8 @@ def main():
         params[f"last_layers.energy.{s}.weight"] = torch.randn(1, H, generator=gen) / H**0.5
     model.load({k: v.to(dev) for k, v in params.items()})
 
+    if args.partition:
+        return partitioned(args, model, S, rank, world, dev)
     pos, z, cell = random_box(args.atoms, seed=pdist.box_seeds(1, rank)[0])
     posd = pos.to(dev)
     pairs, _ = rt.neighbor_list(posd, cell, [True] * 3, model.cutoff)
@@ -157,6 +173,47 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(hypers)
         print(json.dumps(out), flush=True)
+    if world > 1:
+        pdist.barrier(dev)
+        torch.distributed.destroy_process_group()
+
+
+def partitioned(args, model, S, rank, world, dev):
+    """One box, all ranks: positions replicated, centres partitioned, ONE all-reduce(sum) of [gradient | energy]."""
+    from metatrain_amd import distributed as pdist
+    from metatrain_amd.soap_bpnn import partition
+    from metatrain_amd.synthetic import random_box
+
+    pos, z, cell = random_box(args.atoms, seed=0)  # the same box on every rank
+    posd, zd = pos.to(dev), z.to(dev)
+    reduce = (lambda t: torch.distributed.all_reduce(t)) if world > 1 else None
+
+    def step():
+        return partition.energy_and_gradient(model, posd, zd, cell, [True] * 3, world, rank, all_reduce=reduce)
+
+    for _ in range(args.warmup):
+        step()
+    pdist.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        e, grad, n_sub, n_owned = step()
+    pdist.barrier(dev)
+    elapsed = pdist.max_over_ranks(time.perf_counter() - t0, dev)
+    n_sub_max = int(pdist.max_over_ranks(float(n_sub), dev))
+    if rank == 0:
+        assert torch.isfinite(grad).all()
+        print(json.dumps({
+            "metric": "atom-steps/sec (energy+forces) SOAP-BPNN, one box over all GPUs",
+            "value": args.atoms * args.steps / elapsed, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic random periodic box, random weights (parity unpinned vs torch-spex)",
+            "config": {"workload": f"SOAP-BPNN forward + dE/dR of ONE {args.atoms}-atom box, centres partitioned into "
+                                   f"{world} slab(s) + 5 A halos, device neighbour list per step, one all-reduce of "
+                                   f"[gradient | energy] ({(3 * args.atoms + 1) * 4 / 1e6:.1f} MB)",
+                       "atoms_on_the_busiest_rank": n_sub_max, "atoms_owned_rank0": n_owned,
+                       "total_energy": float(e)},
+        }), flush=True)
     if world > 1:
         pdist.barrier(dev)
         torch.distributed.destroy_process_group()

@@ -125,3 +125,37 @@ def test_soap_properties_at_10k_atoms():
     assert float((f2 - f[perm.to(dev)]).abs().max()) < 2e-5 * float(f.abs().max())
     a3, f3 = run(pos, z)
     assert torch.equal(a, a3) and torch.equal(f, f3)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_single_box_partition_adds_up_to_the_whole_box(world):
+    """SURVEY §8(e) row 2 (BASELINE configs[4]: one 100 000-atom box on 8 GPUs), the ranks run one after the other on
+    this GPU: slab + halo sub-systems through the ordinary kernels, partial energies and [N, 3] gradients summed (what
+    the one all-reduce does) equal the whole box; each rank works on a fraction of the atoms."""
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.soap_bpnn import SoapBpnnHip, partition
+
+    dev = torch.device("cuda:0")
+    hypers = dict(osoap.DEFAULT_HYPERS)
+    params = osoap.synthetic_params(hypers, 4, [8, 7, 7, 6, 6, 5, 5], 0, torch.float32)
+    model = SoapBpnnHip(hypers, [1, 6, 7, 8])
+    model.load({k: v.to(dev) for k, v in params.items()})
+    n = 40000
+    pos, z, cell = opet.random_box(n, seed=6)
+    tri = cell.clone()
+    tri[1, 0], tri[2, 1] = 9.0, -7.0  # triclinic: the slabs are cut along a lattice direction, not a Cartesian axis
+    for c, p in ((cell, pos), (tri, pos @ torch.linalg.inv(cell) @ tri)):
+        pd, zd = p.to(dev), z.to(dev)
+        pairs, _ = rt.neighbor_list(pd, c, [True] * 3, 5.0)
+        g = model.graph(pd, c[None].to(dev), pairs[:, 0].contiguous(), pairs[:, 1].contiguous(), pairs[:, 2:5].contiguous(),
+                        zd, torch.zeros(n, dtype=torch.int32, device=dev))
+        atomic = model.forward(g)
+        e_ref, g_ref = atomic.double().sum(), model.backward(g, torch.ones_like(atomic))
+        e, grad, owned_total, sub_max = 0.0, torch.zeros(n, 3, device=dev), 0, 0
+        for rank in range(world):
+            er, gr, n_sub, n_owned = partition.energy_and_gradient(model, pd, zd, c, [True] * 3, world, rank)
+            e, grad, owned_total, sub_max = e + float(er), grad + gr, owned_total + n_owned, max(sub_max, n_sub)
+        assert owned_total == n
+        assert sub_max < (0.8 if world == 2 else 0.35) * n  # slab + two 5 A halos of a 93 A box
+        assert abs(e - float(e_ref)) < TOL * abs(float(e_ref))
+        assert _relmax(grad.cpu().numpy(), g_ref.cpu().numpy()) < TOL
