@@ -104,6 +104,24 @@ def adaptive_cutoffs_solver(centers, d, target: float, n_nodes: int, max_cutoff:
     return (r - n_res / dn_root.clamp_min(1e-6)).clamp(max_cutoff / 16.0, max_cutoff)
 
 
+def adaptive_cutoffs_grid(centers, d, target: float, n_nodes: int, max_cutoff: float, width: float,
+                          min_cutoff: float = 0.5):
+    """``adaptive_cutoff.py:232-294,297-395`` (``get_adaptive_cutoffs_grid``, the legacy method): smoothed neighbour
+    counts on a grid of probe cutoffs (spacing width / 4), Gaussian weights around the target count with a width taken
+    from the slope of the count along the grid, cutoff = weighted mean of the probes. Plain autograd for the gradient."""
+    probes = torch.arange(min_cutoff, max_cutoff, width / 4.0, dtype=d.dtype)
+    weights = cutoff_bump(d.unsqueeze(0), probes.unsqueeze(1), width)  # [K, E]
+    n_eff = torch.zeros((len(probes), n_nodes), dtype=d.dtype).index_add(1, centers, weights).T  # [N, K]
+    x = torch.linspace(0, 1, len(probes), dtype=d.dtype)
+    diff = n_eff - target + (target * x**3).unsqueeze(0)
+    (slope,) = torch.gradient(diff, dim=-1)
+    width_t = slope.abs().clamp_min(1e-12)
+    logw = -0.5 * (diff / width_t) ** 2
+    w = torch.exp(logw - logw.max())
+    w = w / w.sum(dim=1, keepdim=True)
+    return probes @ w.T
+
+
 def cutoff_bump(d: torch.Tensor, cutoff, width: float) -> torch.Tensor:
     """``pet/modules/utilities.py:4-22``."""
     s = (d - (cutoff - width)) / width
@@ -248,7 +266,7 @@ def pet_atomic_energies(
     assert hypers["featurizer_type"] in ("feedforward", "residual")
     post_ln = hypers["transformer_type"] == "PostLN"
     residual = hypers["featurizer_type"] == "residual"
-    assert hypers["num_neighbors_adaptive"] is None or hypers["adaptive_cutoff_method"] == "solver"
+    assert hypers["num_neighbors_adaptive"] is None or hypers["adaptive_cutoff_method"] in ("solver", "grid")
     block = block or target
     cutoff, width = float(hypers["cutoff"]), float(hypers["cutoff_width"])
     n_heads = hypers["num_heads"]
@@ -262,8 +280,9 @@ def pet_atomic_energies(
     pair_cut_all = None
     if hypers["num_neighbors_adaptive"] is not None:
         # structures.py:225-263: per-atom adaptive cutoffs, symmetrised per pair, then the mask
-        r_atom = adaptive_cutoffs_solver(centers.long(), d_all, float(hypers["num_neighbors_adaptive"]), n_nodes,
-                                         cutoff, float(hypers["cutoff_width_adaptive"]))
+        solve = adaptive_cutoffs_grid if hypers["adaptive_cutoff_method"] == "grid" else adaptive_cutoffs_solver
+        r_atom = solve(centers.long(), d_all, float(hypers["num_neighbors_adaptive"]), n_nodes, cutoff,
+                       float(hypers["cutoff_width_adaptive"]))
         pair_cut_all = 0.5 * (r_atom[centers.long()] + r_atom[neighbors.long()])
         keep = torch.nonzero(d_all.detach() <= pair_cut_all.detach()).squeeze(-1)
     elif not bool(hypers["long_range"]["enable"]):
@@ -415,8 +434,9 @@ def batch_tensors(
     pair_cut = None
     stats = np.full((n_nodes,), cutoff, dtype=pos.numpy().dtype)
     if hypers["num_neighbors_adaptive"] is not None:
-        r_atom = adaptive_cutoffs_solver(centers.long(), d0, float(hypers["num_neighbors_adaptive"]), n_nodes, cutoff,
-                                         float(hypers["cutoff_width_adaptive"]))
+        solve = adaptive_cutoffs_grid if hypers["adaptive_cutoff_method"] == "grid" else adaptive_cutoffs_solver
+        r_atom = solve(centers.long(), d0, float(hypers["num_neighbors_adaptive"]), n_nodes, cutoff,
+                       float(hypers["cutoff_width_adaptive"]))
         stats = r_atom.numpy()
         pair_cut = 0.5 * (r_atom[centers.long()] + r_atom[neighbors.long()])
         keep = torch.nonzero(d0 <= pair_cut).squeeze(-1)

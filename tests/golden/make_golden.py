@@ -121,8 +121,9 @@ def run_reference(backend, name, pos, cells, centers, neighbors, shifts, species
     return out, batch
 
 
-def main_adaptive():
-    """Adaptive-cutoff fixtures (``num_neighbors_adaptive``, solver method):
+def main_adaptive(method="solver"):
+    """Adaptive-cutoff fixtures (``num_neighbors_adaptive``, "solver" method, or with
+    ``--adaptive-grid`` the legacy "grid" method, files ``*_adaptive_grid_<case>.npz``):
     ``batch_adaptive_<case>.npz`` (12 ``batch_data`` tensors) and ``pet_adaptive_<case>.npz``
     (E, per-atom E, dE/dR in fp32 / fp64) from the reference modules."""
     from oracle import nl as onl
@@ -130,8 +131,9 @@ def main_adaptive():
 
     PETBackend = import_reference_backend()
     torch.set_num_threads(8)
-    hypers = dict(opet.DEFAULT_HYPERS, num_neighbors_adaptive=12, adaptive_cutoff_method="solver",
+    hypers = dict(opet.DEFAULT_HYPERS, num_neighbors_adaptive=12, adaptive_cutoff_method=method,
                   cutoff_width_adaptive=1.0)
+    name = "adaptive" if method == "solver" else f"adaptive_{method}"
     p64, z64, c64 = opet.random_box(64, seed=1)
     p40, z40, c40 = opet.random_box(40, seed=2)
     tri = c40.clone(); tri[1, 0] = 2.0; tri[2, 1] = -1.5
@@ -156,7 +158,7 @@ def main_adaptive():
         batch = be.preprocess(pos, i, j, z, cells, s, sysidx, hypers["cutoff_width_adaptive"])
         out = dict(inputs)
         out.update({k: v.numpy() for k, v in batch.items()})
-        np.savez(os.path.join(HERE, f"batch_adaptive_{tag}.npz"), **out)
+        np.savez(os.path.join(HERE, f"batch_{name}_{tag}.npz"), **out)
         print(tag, "E0 =", len(i), "kept", len(batch["centers"]), "M =", batch["padding_mask"].shape[1],
               "cutoffs", batch["atomic_cutoffs_stats"].min().item(), batch["atomic_cutoffs_stats"].max().item())
         store = dict(inputs)
@@ -179,7 +181,7 @@ def main_adaptive():
             store[f"grad_{sfx}"] = grad.numpy()
             store[f"atomic_cutoffs_{sfx}"] = b["atomic_cutoffs_stats"].numpy()
             print(tag, sfx, "E =", energies.detach().numpy().ravel(), "|grad|max =", grad.abs().max().item())
-        np.savez_compressed(os.path.join(HERE, f"pet_adaptive_{tag}.npz"), **store)
+        np.savez_compressed(os.path.join(HERE, f"pet_{name}_{tag}.npz"), **store)
 
 
 def main():
@@ -572,6 +574,8 @@ if __name__ == "__main__":
         main_train()
     elif "--silu" in sys.argv:
         main_silu()
+    elif "--adaptive-grid" in sys.argv:
+        main_adaptive("grid")
     elif "--adaptive" in sys.argv:
         main_adaptive()
     else:

@@ -149,14 +149,17 @@ def test_product_generators_equal_oracle_generators():
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("method", ["solver", "grid"])
 @pytest.mark.parametrize("case", ["box64", "two_systems"])
-def test_oracle_adaptive_cutoff_matches_reference(golden_dir, case):
-    """num_neighbors_adaptive (solver) -- the oracle's restatement of
-    adaptive_cutoff.py:110-229 + structures.py:225-263 against fixtures generated from the reference."""
-    hypers = dict(opet.DEFAULT_HYPERS, num_neighbors_adaptive=12, adaptive_cutoff_method="solver",
+def test_oracle_adaptive_cutoff_matches_reference(golden_dir, case, method):
+    """num_neighbors_adaptive -- the oracle's restatement of adaptive_cutoff.py:110-229 ("solver") and
+    :232-395 ("grid", the legacy method older checkpoints keep) + structures.py:225-263 against fixtures generated from
+    the reference."""
+    hypers = dict(opet.DEFAULT_HYPERS, num_neighbors_adaptive=12, adaptive_cutoff_method=method,
                   cutoff_width_adaptive=1.0)
-    g = dict(np.load(os.path.join(golden_dir, f"pet_adaptive_{case}.npz")))
-    b = dict(np.load(os.path.join(golden_dir, f"batch_adaptive_{case}.npz")))
+    name = "adaptive" if method == "solver" else "adaptive_grid"
+    g = dict(np.load(os.path.join(golden_dir, f"pet_{name}_{case}.npz")))
+    b = dict(np.load(os.path.join(golden_dir, f"batch_{name}_{case}.npz")))
     t = lambda k: torch.tensor(g[k])  # noqa: E731
     table = torch.full((9,), -1, dtype=torch.long)
     table[torch.tensor([1, 6, 7, 8])] = torch.arange(4)
