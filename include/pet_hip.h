@@ -44,6 +44,8 @@ extern "C" {
 #define PET_POST_LN 1
 #define PET_FEATURIZER_FEEDFORWARD 0
 #define PET_FEATURIZER_RESIDUAL 1
+#define PET_ADAPTIVE_SOLVER 0
+#define PET_ADAPTIVE_GRID 1
 
 /* Mirrors the subset of ModelHypers that shapes the hot path
  * (src/metatrain/pet/documentation.py:159-259). */
@@ -70,6 +72,7 @@ typedef struct pet_hypers {
     int32_t normalization;    /* PET_NORM_RMS | PET_NORM_LAYER (transformer.py:170-176; LayerNorm: eps 1e-5, weight + bias) */
     int32_t transformer_type; /* PET_PRE_LN (transformer.py:203-234) | PET_POST_LN (transformer.py:236-262) */
     int32_t featurizer_type;  /* PET_FEATURIZER_FEEDFORWARD (backend.py:496-587) | PET_FEATURIZER_RESIDUAL (backend.py:589-649) */
+    int32_t adaptive_cutoff_method; /* PET_ADAPTIVE_SOLVER (adaptive_cutoff.py:110-229) | PET_ADAPTIVE_GRID (:232-395, legacy) */
 } pet_hypers_t;
 
 typedef struct pet_model pet_model_t; /* packed weights on the device */

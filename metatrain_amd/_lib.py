@@ -88,6 +88,7 @@ class PetHypers(ctypes.Structure):
         ("normalization", c_int32),
         ("transformer_type", c_int32),
         ("featurizer_type", c_int32),
+        ("adaptive_cutoff_method", c_int32),
     ]
 
 

@@ -398,6 +398,8 @@ int pet_model_create(const pet_hypers_t* h, pet_model_t** out) {
                     (h->transformer_type == PET_PRE_LN || h->transformer_type == PET_POST_LN) &&
                     (h->featurizer_type == PET_FEATURIZER_FEEDFORWARD || h->featurizer_type == PET_FEATURIZER_RESIDUAL),
                 PET_ERR_UNSUPPORTED, "unknown normalization / transformer_type / featurizer_type");
+    PET_REQUIRE(h->adaptive_cutoff_method == PET_ADAPTIVE_SOLVER || h->adaptive_cutoff_method == PET_ADAPTIVE_GRID,
+                PET_ERR_UNSUPPORTED, "unknown adaptive_cutoff_method");
     pet_model_t* pm = new pet_model_t();
     pm->m.h = *h;
     *out = pm;

@@ -68,6 +68,8 @@ inline void allow_big_lds(Kern kern, size_t bytes) {
 // Edge graph in CSR order (edges stably sorted by centre; pet/modules/nef.py:63-70
 // defines exactly this order as the NEF slot order).
 // --------------------------------------------------------------------------------
+constexpr int GRID_MAX_PROBES = 64;  // adaptive_cutoff_method = "grid": probe cutoffs 0.5, 0.5 + w/4, .. < cutoff
+
 struct Graph {
     int64_t n_nodes = 0, n_edges_in = 0, n_systems = 0;
     int64_t n_edges = 0;  // kept edges (host copy, valid after build)
@@ -104,6 +106,8 @@ struct Graph {
     float* r_atom = nullptr;   // [N] adapted cutoff (after the IFT step and the clamp)
     float* r_newton = nullptr; // [N] root of the Newton-bisection loop
     float* inv_dn = nullptr;   // [N] 1 / max(dn_total/dr, 1e-6) at the root; 0 if the clamp is active
+    float* grid_drdn = nullptr; // [N, GRID_MAX_PROBES] "grid" method: d(atomic cutoff) / d(smoothed count at probe k)
+    int grid_probes = 0;        // number of probe cutoffs of the "grid" method (0: "solver")
     float* pc = nullptr;       // [E] pair cutoff of every kept edge
     float* ad_gc = nullptr;    // [E] scratch: dL/d(pair cutoff)
     float* ad_gr = nullptr;    // [N] scratch: dL/d(atomic cutoff)

@@ -104,6 +104,83 @@ __global__ void k_adaptive_solve(const int* __restrict__ rowptr0, const int* __r
     }
 }
 
+// The legacy "grid" method (adaptive_cutoff.py:232-395), one 16-lane group per atom over its row of the all-edge CSR:
+//   n_k    = sum over the atom's edges of bump(d; p_k, w) on the probe grid p_k = 0.5 + k w / 4 < rc      (:297-327)
+//   diff_k = n_k - target + target x_k^3, x = linspace(0, 1, K)                                          (:349-365)
+//   wd_k   = max(|torch.gradient(diff)_k|, 1e-12); logw_k = -(diff_k / wd_k)^2 / 2; w = softmax(logw)    (:366-393)
+//   r      = sum_k p_k w_k                                                                               (:291-293)
+// and, for the reverse pass, dr / dn_k through all of that (written out by hand below). The reference subtracts the
+// GLOBAL maximum of logw before the exponential; the row maximum used here gives the same weights wherever the
+// reference's do not underflow.
+__global__ void k_adaptive_grid(const int* __restrict__ rowptr0, const int* __restrict__ perm0,
+                                const float4* __restrict__ vin, float* __restrict__ r_atom, float* __restrict__ drdn,
+                                int N, float w, float target, int K, float pmin, float dp) {
+    __shared__ float s_diff[16][GRID_MAX_PROBES], s_w[16][GRID_MAX_PROBES], s_e[16][GRID_MAX_PROBES];
+    const int grp = threadIdx.x >> 4;
+    const int gid = blockIdx.x * (blockDim.x / 16) + grp;
+    const int l = threadIdx.x & 15;
+    const int a = gid < N ? gid : N - 1;
+    const int p0 = rowptr0[a], p1 = rowptr0[a + 1];
+    for (int k = 0; k < K; k++) {
+        const float pk = pmin + (float)k * dp;
+        float fs = 0.f;
+        for (int p = p0 + l; p < p1; p += 16) {
+            float f, df;
+            adaptive_term(vin[perm0[p]].w, pk, w, f, df);
+            fs += f;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) fs += __shfl_xor(fs, o);
+        const float x = (float)k / (float)(K - 1);
+        if (l == 0) s_diff[grp][k] = fs - target + target * x * x * x;
+    }
+    if (l != 0 || gid >= N) return;
+    float* diff = s_diff[grp];
+    float* wt = s_w[grp];
+    float* ev = s_e[grp];
+    // logw (kept in wt), u and the slope sign (packed into ev for now)
+    float mx = -INFINITY;
+    for (int k = 0; k < K; k++) {
+        const float gk = k == 0 ? diff[1] - diff[0] : (k == K - 1 ? diff[K - 1] - diff[K - 2] : 0.5f * (diff[k + 1] - diff[k - 1]));
+        const float wd = fmaxf(fabsf(gk), 1e-12f);
+        const float u = diff[k] / wd;
+        wt[k] = -0.5f * u * u;
+        mx = fmaxf(mx, wt[k]);
+    }
+    float sum = 0.f;
+    for (int k = 0; k < K; k++) {
+        wt[k] = expf(wt[k] - mx);
+        sum += wt[k];
+    }
+    const float isum = 1.0f / sum;
+    float r = 0.f;
+    for (int k = 0; k < K; k++) {
+        wt[k] *= isum;
+        r += (pmin + (float)k * dp) * wt[k];
+    }
+    r_atom[gid] = r;
+    // reverse: c_k = dr/du_k = -w_k (p_k - r) u_k; dr/ddiff_j = c_j / wd_j + sum_k e_k G_kj with
+    // e_k = dr/dg_k = -c_k u_k sign(g_k) / wd_k where |g_k| > 1e-12, and G the finite-difference stencil of torch.gradient
+    for (int k = 0; k < K; k++) {
+        const float gk = k == 0 ? diff[1] - diff[0] : (k == K - 1 ? diff[K - 1] - diff[K - 2] : 0.5f * (diff[k + 1] - diff[k - 1]));
+        const float ag = fabsf(gk);
+        const float wd = fmaxf(ag, 1e-12f);
+        const float u = diff[k] / wd;
+        const float c = -wt[k] * ((pmin + (float)k * dp) - r) * u;
+        ev[k] = ag > 1e-12f ? -c * u * (gk > 0.f ? 1.0f : -1.0f) / wd : 0.f;
+        wt[k] = c / wd;  // the direct term (the weights themselves are not needed any more)
+    }
+    for (int j = 0; j < K; j++) {
+        float v = wt[j];
+        // column j of the stencil: rows j - 1 and j + 1 (interior rows: +-1/2), the two one-sided boundary rows
+        if (j >= 1) v += ev[j - 1] * (j - 1 == 0 ? 1.0f : 0.5f);           // G[j-1][j]
+        if (j + 1 <= K - 1) v -= ev[j + 1] * (j + 1 == K - 1 ? 1.0f : 0.5f);  // G[j+1][j]
+        if (j == 0) v -= ev[0];                                             // G[0][0] = -1
+        if (j == K - 1) v += ev[K - 1];                                     // G[K-1][K-1] = +1
+        drdn[(int64_t)gid * GRID_MAX_PROBES + j] = v;
+    }
+}
+
 // pair cutoffs (r_i + r_j) / 2 and the mask d <= pair cutoff (structures.py:248-252)
 __global__ void k_adaptive_keep(const int* __restrict__ centers, const int* __restrict__ neighbors,
                                 const float4* __restrict__ vin, const float* __restrict__ r_atom,
@@ -419,6 +496,7 @@ static int carve_graph(Graph& g, void* ws, int64_t n_nodes, int64_t e0, size_t* 
     g.r_atom = c.take<float>(n_nodes);
     g.r_newton = c.take<float>(n_nodes);
     g.inv_dn = c.take<float>(n_nodes);
+    g.grid_drdn = c.take<float>(n_nodes * GRID_MAX_PROBES);
     g.pc = c.take<float>(e0);
     g.ad_gc = c.take<float>(e0);
     g.ad_gr = c.take<float>(n_nodes);
@@ -479,6 +557,18 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
             k_rowptr<<<cdiv(n_nodes + 1, T), T, 0, st>>>(g.sort_keys_out, (int)e0, g.rowptr0, (int)n_nodes,
                                                          g.scalars + 4);
             k_gather_all<<<cdiv(e0, T), T, 0, st>>>(g.perm0, neighbors, shifts, g.nbr0, g.shift0, (int)e0);
+            if (m.h.adaptive_cutoff_method == PET_ADAPTIVE_GRID) {
+                // probe grid = torch.arange(0.5, cutoff, width / 4) (adaptive_cutoff.py:266-277)
+                const double dp = (double)m.h.cutoff_width_adaptive / 4.0;
+                const int K = (int)std::ceil(((double)m.h.cutoff - 0.5) / dp);
+                PET_REQUIRE(K >= 2 && K <= GRID_MAX_PROBES, PET_ERR_UNSUPPORTED,
+                            "adaptive_cutoff_method = 'grid': " + std::to_string(K) + " probe cutoffs (2 .. " +
+                                std::to_string(GRID_MAX_PROBES) + " are built)");
+                g.grid_probes = K;
+                k_adaptive_grid<<<cdiv(n_nodes, 16), 256, 0, st>>>(g.rowptr0, g.perm0, g.vin, g.r_atom, g.grid_drdn,
+                                                                   (int)n_nodes, m.h.cutoff_width_adaptive,
+                                                                   m.h.num_neighbors_adaptive, K, 0.5f, (float)dp);
+            } else
             k_adaptive_solve<<<cdiv(n_nodes, 16), 256, 0, st>>>(g.rowptr0, g.perm0, g.vin, g.r_atom, g.r_newton,
                                                                 g.inv_dn, (int)n_nodes, m.h.cutoff,
                                                                 m.h.cutoff_width_adaptive,

@@ -868,6 +868,29 @@ __global__ void k_adapt_dv(const int* __restrict__ rowptr0, const int* __restric
         dvA[q] = make_float4(c * v.x, c * v.y, c * v.z, 0.f);
     }
 }
+// "grid" method: r_i = sum_k p_k w_k(n_i1 .. n_iK), n_ik = sum_q bump(d_q; p_k, w): every input edge q of atom i gets
+//   d r_i / d d_q = sum_k (d r_i / d n_ik) (d bump / d d)(d_q; p_k, w)   with the per-atom row drdn of k_adaptive_grid
+__global__ void k_adapt_dv_grid(const int* __restrict__ rowptr0, const int* __restrict__ perm0,
+                                const float4* __restrict__ vin, const float* __restrict__ gr,
+                                const float* __restrict__ drdn, float4* __restrict__ dvA, int N, float w, int K,
+                                float pmin, float dp) {
+    __shared__ float s_c[16][GRID_MAX_PROBES];
+    const int grp = threadIdx.x >> 4;
+    const int gid = blockIdx.x * (blockDim.x / 16) + grp;
+    const int l = threadIdx.x & 15;
+    const int a = gid < N ? gid : N - 1;
+    for (int k = l; k < K; k += 16) s_c[grp][k] = gr[a] * drdn[(int64_t)a * GRID_MAX_PROBES + k];
+    __syncthreads();
+    if (gid >= N) return;
+    for (int q = rowptr0[gid] + l; q < rowptr0[gid + 1]; q += 16) {
+        const float4 v = vin[perm0[q]];
+        float dd = 0.f;
+        for (int k = 0; k < K; k++) dd += s_c[grp][k] * cutoff_deriv_dev(v.w, pmin + (float)k * dp, w, PET_CUTOFF_BUMP);
+        const float nrm = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+        const float c = nrm > 0.f ? dd / nrm : 0.f;
+        dvA[q] = make_float4(c * v.x, c * v.y, c * v.z, 0.f);
+    }
+}
 // gpos[a] += sum_{q in row0 a} (dvA[rev0 q] - dvA[q])
 __global__ void k_pos_grad_acc(const float4* __restrict__ dv, const int* __restrict__ rowptr,
                                const int* __restrict__ rev, float* __restrict__ gpos, int N) {
@@ -1225,6 +1248,11 @@ int backward_geometry(const Model& m, const Graph& g, Workspace& w, const float*
                                                       g.rowptr, gcell, (int)N, E, 0);
     if (g.adaptive) {
         k_adapt_gr<<<cdiv(N, 16), 256, 0, st>>>(g.ad_gc, g.rowptr, g.rev, g.ad_gr, (int)N);
+        if (g.grid_probes > 0)
+            k_adapt_dv_grid<<<cdiv(N, 16), 256, 0, st>>>(g.rowptr0, g.perm0, g.vin, g.ad_gr, g.grid_drdn, g.ad_dv, (int)N,
+                                                         m.h.cutoff_width_adaptive, g.grid_probes, 0.5f,
+                                                         m.h.cutoff_width_adaptive / 4.0f);
+        else
         k_adapt_dv<<<cdiv(N, 16), 256, 0, st>>>(g.rowptr0, g.perm0, g.vin, g.ad_gr, g.r_newton, g.inv_dn, g.ad_dv,
                                                 (int)N, m.h.cutoff_width_adaptive);
         k_pos_grad_acc<<<cdiv(N, 16), 256, 0, st>>>(g.ad_dv, g.rowptr0, g.rev0, gpos, (int)N);

@@ -1215,6 +1215,8 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
     PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
     PET_REQUIRE(m.plain(), PET_ERR_UNSUPPORTED,
                 "training is built for normalization=RMSNorm, transformer_type=PreLN, featurizer_type=feedforward only");
+    PET_REQUIRE(g.grid_probes == 0, PET_ERR_UNSUPPORTED,
+                "the force-loss (second-order) pass carries the cutoff tangents of the 'solver' adaptive-cutoff method only");
     Workspace w;
     carve_workspace(m, g.n_nodes, g.n_edges, ws, w, true);
     PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "workspace too small for training");

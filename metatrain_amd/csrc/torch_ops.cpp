@@ -47,7 +47,8 @@ struct PetHipModule : torch::CustomClassHolder {
                  std::vector<at::Tensor> tensors_)
         : hypers(std::move(hypers_)), atomic_types(std::move(atomic_types_)), keys(std::move(keys_)),
           tensors(std::move(tensors_)) {
-        TORCH_CHECK(hypers.size() == 16 || hypers.size() == 19, "pet_hip: expected the 16 or all 19 fields of pet_hypers_t");
+        TORCH_CHECK(hypers.size() == 16 || hypers.size() == 19 || hypers.size() == 20,
+                    "pet_hip: expected the first 16, 19 or all 20 fields of pet_hypers_t");
         TORCH_CHECK(keys.size() == tensors.size(), "pet_hip: keys / tensors length mismatch");
     }
     ~PetHipModule() override {
@@ -63,10 +64,11 @@ struct PetHipModule : torch::CustomClassHolder {
         h.attention_temperature = (float)hypers[10]; h.nl_is_strict = (int32_t)hypers[11];
         h.n_species = (int32_t)hypers[12]; h.max_atomic_number = (int32_t)hypers[13];
         h.num_neighbors_adaptive = (float)hypers[14]; h.cutoff_width_adaptive = (float)hypers[15];
-        if (hypers.size() == 19) {
+        if (hypers.size() >= 19) {
             h.normalization = (int32_t)hypers[16]; h.transformer_type = (int32_t)hypers[17];
             h.featurizer_type = (int32_t)hypers[18];
         }
+        if (hypers.size() >= 20) h.adaptive_cutoff_method = (int32_t)hypers[19];
         return h;
     }
 
@@ -175,9 +177,9 @@ struct PetHipBackend : torch::CustomClassHolder {
 
     PetHipBackend(std::vector<double> hypers_, std::vector<int64_t> atomic_types_, std::vector<std::string> keys_)
         : hypers(std::move(hypers_)), atomic_types(std::move(atomic_types_)), keys(std::move(keys_)) {
-        TORCH_CHECK(hypers.size() == 17 || hypers.size() == 20,
+        TORCH_CHECK(hypers.size() == 17 || hypers.size() == 20 || hypers.size() == 21,
                     "pet_hip: expected the first 16 fields of pet_hypers_t, the SiLU flag and (optionally) normalization, "
-                    "transformer_type, featurizer_type");
+                    "transformer_type, featurizer_type, adaptive_cutoff_method");
     }
     ~PetHipBackend() override {
         if (model) pet_model_destroy(model);
@@ -192,10 +194,11 @@ struct PetHipBackend : torch::CustomClassHolder {
         h.attention_temperature = (float)hypers[10]; h.nl_is_strict = (int32_t)hypers[11];
         h.n_species = (int32_t)hypers[12]; h.max_atomic_number = (int32_t)hypers[13];
         h.num_neighbors_adaptive = (float)hypers[14]; h.cutoff_width_adaptive = (float)hypers[15];
-        if (hypers.size() == 20) {
+        if (hypers.size() >= 20) {
             h.normalization = (int32_t)hypers[17]; h.transformer_type = (int32_t)hypers[18];
             h.featurizer_type = (int32_t)hypers[19];
         }
+        if (hypers.size() >= 21) h.adaptive_cutoff_method = (int32_t)hypers[20];
         return h;
     }
 

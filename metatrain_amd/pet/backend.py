@@ -29,7 +29,8 @@ step.) That node evaluates the batch ``preprocess`` saw, not edited features.
 properties per block, several blocks per target and several targets are served by ``pet_predict``. The architecture
 variants older checkpoints use -- ``normalization = "LayerNorm"``, ``transformer_type = "PostLN"``, ``featurizer_type =
 "residual"`` (``pet/checkpoints.py:190-205``) -- run for inference and forces; training is built for the default
-architecture only. Not built (raise loudly): the "grid" adaptive-cutoff method, system conditioning, diagnostic
+architecture only; both adaptive-cutoff methods ("solver", and the legacy "grid" for inference / forces / energy-only
+training). Not built (raise loudly): system conditioning, diagnostic
 capture, double backward through the three inference nodes, stress (strain) terms in a training loss, training of the
 variants.
 """

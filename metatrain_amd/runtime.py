@@ -40,8 +40,10 @@ def hypers_struct(hypers: dict, atomic_types: List[int]) -> PetHypers:
         variants[key] = choices.index(hypers[key])
     if hypers["activation"] not in ("SwiGLU", "SiLU"):
         raise ValueError(f"Unknown activation flag: {hypers['activation']}")  # transformer.py:342-346
-    if hypers["num_neighbors_adaptive"] is not None and hypers["adaptive_cutoff_method"].lower() != "solver":
-        raise PetHipError("adaptive_cutoff_method = 'grid' is not built into libpet_hip (only 'solver')")
+    method = str(hypers.get("adaptive_cutoff_method", "solver")).lower()
+    if method not in ("solver", "grid"):  # structures.py:229-251
+        raise ValueError(f"adaptive_cutoff_method must be 'grid' or 'solver', got {hypers['adaptive_cutoff_method']}")
+    variants["adaptive_cutoff_method"] = 1 if method == "grid" else 0
     if hypers.get("system_conditioning", False):
         raise PetHipError("system_conditioning is not built into libpet_hip yet")
     return PetHypers(

@@ -57,14 +57,32 @@ def test_model_create_destroy_without_gpu(lib):
 
 
 def test_variants_outside_the_build_fail_loudly():
-    for key, val in (("normalization", "LayerNorm"), ("transformer_type", "PostLN"), ("featurizer_type", "residual")):
-        with pytest.raises(_lib.PetHipError):
-            rt.hypers_struct(dict(opet.DEFAULT_HYPERS, **{key: val}), [1, 6])
+    """The variants of the reference's hypers are mapped onto pet_hypers_t (all built since round 2); a value the
+    reference does not know raises like the reference does, and the C side refuses an enum it does not know."""
+    for key, val, field in (("normalization", "LayerNorm", "normalization"), ("transformer_type", "PostLN", "transformer_type"),
+                            ("featurizer_type", "residual", "featurizer_type")):
+        assert getattr(rt.hypers_struct(dict(opet.DEFAULT_HYPERS, **{key: val}), [1, 6]), field) == 1
+        with pytest.raises(ValueError, match=key):
+            rt.hypers_struct(dict(opet.DEFAULT_HYPERS, **{key: "something else"}), [1, 6])
+    grid = rt.hypers_struct(dict(opet.DEFAULT_HYPERS, num_neighbors_adaptive=12, adaptive_cutoff_method="grid"), [1, 6])
+    assert grid.adaptive_cutoff_method == 1
+    with pytest.raises(ValueError, match="adaptive_cutoff_method"):
+        rt.hypers_struct(dict(opet.DEFAULT_HYPERS, adaptive_cutoff_method="bisection"), [1, 6])
     rt.hypers_struct(dict(opet.DEFAULT_HYPERS, activation="SiLU"), [1, 6])  # built: SwiGLU kernels, tied halves
     with pytest.raises(ValueError, match="Unknown activation flag"):  # transformer.py:342-346
         rt.hypers_struct(dict(opet.DEFAULT_HYPERS, activation="GELU"), [1, 6])
     with pytest.raises(ValueError, match="Unknown cutoff function type"):
         rt.hypers_struct(dict(opet.DEFAULT_HYPERS, cutoff_function="Step"), [1, 6])
+    import ctypes
+
+    lib = _lib.load()
+    for field in ("normalization", "transformer_type", "featurizer_type", "adaptive_cutoff_method"):
+        h = rt.hypers_struct(dict(opet.DEFAULT_HYPERS), [1, 6])
+        setattr(h, field, 7)
+        handle = ctypes.c_void_p()
+        assert lib.pet_model_create(ctypes.byref(h), ctypes.byref(handle)) == -2, field  # PET_ERR_UNSUPPORTED
+    with pytest.raises(_lib.PetHipError):  # system conditioning is not built
+        rt.hypers_struct(dict(opet.DEFAULT_HYPERS, system_conditioning=True), [1, 6])
 
 
 def test_cpu_tensors_are_rejected_not_silently_computed():

@@ -89,9 +89,10 @@ def test_unsupported_variants_and_cpu_inputs_raise():
         PETBackend(dict(default_hypers(), featurizer_type="convolutional"), [1, 6])
     with pytest.raises(ValueError, match="normalization"):
         PETBackend(dict(default_hypers(), normalization="BatchNorm"), [1, 6])
-    with pytest.raises(PetHipError):
-        PETBackend(dict(default_hypers(), num_neighbors_adaptive=16, adaptive_cutoff_method="grid"), [1, 6])
-    PETBackend(dict(default_hypers(), num_neighbors_adaptive=16), [1, 6])  # the "solver" method is built
+    with pytest.raises(ValueError, match="adaptive_cutoff_method"):
+        PETBackend(dict(default_hypers(), num_neighbors_adaptive=16, adaptive_cutoff_method="bisection"), [1, 6])
+    PETBackend(dict(default_hypers(), num_neighbors_adaptive=16), [1, 6])  # "solver"
+    PETBackend(dict(default_hypers(), num_neighbors_adaptive=16, adaptive_cutoff_method="grid"), [1, 6])  # legacy method
     be = PETBackend(default_hypers(), [1, 6, 7, 8])
     be.add_output("energy", {"energy": [1]})
     z = torch.zeros

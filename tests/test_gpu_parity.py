@@ -392,14 +392,50 @@ def test_rotation_and_permutation_consistency(rt, model, dev):
     assert np.abs(g0.sum(0)).max() < 1e-3 * np.abs(g0).max()
 
 
-@pytest.fixture(scope="module")
-def adaptive_model(rt, dev):
-    hypers = dict(opet.DEFAULT_HYPERS, num_neighbors_adaptive=12, adaptive_cutoff_method="solver",
+def _adaptive_model(rt, dev, method):
+    hypers = dict(opet.DEFAULT_HYPERS, num_neighbors_adaptive=12, adaptive_cutoff_method=method,
                   cutoff_width_adaptive=1.0)
     params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
     m = rt.HipModel(hypers, [1, 6, 7, 8])
     m.load({k: v.to(dev) for k, v in params.items()}, "energy")
     return m
+
+
+@pytest.fixture(scope="module")
+def adaptive_model(rt, dev):
+    return _adaptive_model(rt, dev, "solver")
+
+
+@pytest.mark.parametrize("case", ["box64", "two_systems"])
+def test_adaptive_cutoff_grid_method_matches_reference(rt, dev, golden_dir, case):
+    """The legacy "grid" method (adaptive_cutoff.py:232-395: probe-cutoff grid, Gaussian weights around the target count),
+    kept by the reference so that existing checkpoints reload with their original behaviour: batch_data with integers
+    bit-exact, per-atom cutoffs, E / per-atom E / dE/dR (the gradient runs through the weights of every probe) and
+    dE/dcell against the oracle's autograd."""
+    model = _adaptive_model(rt, dev, "grid")
+    b = _load(golden_dir, f"batch_adaptive_grid_{case}.npz")
+    graph = _graph_from_golden(rt, model, b, dev)
+    out = graph.export_batch()
+    for k in INT_KEYS:
+        assert np.array_equal(out[k].cpu().numpy(), b[k]), f"{k} is not bit-exact"
+    np.testing.assert_allclose(out["atomic_cutoffs_stats"].cpu().numpy(), b["atomic_cutoffs_stats"], rtol=5e-6)
+    assert 3.0 < b["atomic_cutoffs_stats"].min() and b["atomic_cutoffs_stats"].max() < 4.2
+    np.testing.assert_allclose(out["cutoff_factors"].cpu().numpy(), b["cutoff_factors"], rtol=3e-4, atol=3e-6)
+    g = _load(golden_dir, f"pet_adaptive_grid_{case}.npz")
+    fw = rt.HipForward(model, graph)
+    atomic = fw.forward()
+    grad, gcell = fw.backward(torch.ones_like(atomic), want_cell_grad=True)
+    assert relmax(atomic.cpu().numpy(), g["atomic_f64"].ravel()) < TOL
+    ref32 = relmax(g["grad_f32"], g["grad_f64"])
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < max(TOL, 3 * ref32)
+    # dE/dcell from the oracle's autograd (fp64) on the same inputs
+    t = lambda k: torch.tensor(g[k])  # noqa: E731
+    params = opet.synthetic_params(model.hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    cells = t("in_cells").clone().requires_grad_(True)
+    a64 = opet.pet_atomic_energies(params, model.hypers, t("in_positions"), cells, t("in_centers"), t("in_neighbors"),
+                                   t("in_cell_shifts").long(), t("in_species"), t("in_system_indices"))
+    (gc64,) = torch.autograd.grad(a64.sum(), cells)
+    assert relmax(gcell.cpu().numpy(), gc64.numpy()) < max(TOL, 3 * ref32)
 
 
 @pytest.mark.parametrize("case", ["box64", "two_systems"])
