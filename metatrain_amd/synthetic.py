@@ -71,6 +71,11 @@ def state_dict_schema(hypers: dict, atomic_types: List[int], targets: Dict[str, 
     for l in range(n_readout):
         out.append((f"node_embedders.{l}.weight", (ns, dn), "embedding"))
     out.append(("edge_embedder.weight", (ns, d), "embedding"))
+    if hypers.get("system_conditioning", False):  # conditioning.py:38-52 (created after the embedders, backend.py:121-130)
+        out.append(("system_conditioning.charge_embedding.weight", (2 * hypers["max_charge"] + 1, dn), "embedding"))
+        out.append(("system_conditioning.spin_multiplicity_embedding.weight", (hypers["max_spin_multiplicity"], dn), "embedding"))
+        lin("system_conditioning.project.0", dn, 2 * dn)
+        lin("system_conditioning.project.2", dn, dn)
     # a target maps to its number of properties (one block named like the target) or to {block: properties};
     # heads and last layers exist once per readout layer (backend.py:171-217)
     for t in targets:

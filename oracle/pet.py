@@ -247,6 +247,8 @@ def pet_atomic_energies(
     block: Optional[str] = None,
     return_features: bool = False,
     return_aux: bool = False,
+    charge: Optional[torch.Tensor] = None,
+    spin_multiplicity: Optional[torch.Tensor] = None,
 ):
     """Per-atom predictions ``[N, P]`` of the PET backend for one target.
 
@@ -314,6 +316,18 @@ def pet_atomic_energies(
     key_bias = torch.log(torch.clamp(fc, min=1e-15))  # transformer.py:109-110
     scale = 1.0 / (math.sqrt(d_pet // n_heads) * hypers["attention_temperature"])
 
+    cond = None
+    if hypers.get("system_conditioning", False):
+        # conditioning.py:82-100: per-system embedding of charge and spin multiplicity, added to the node features
+        # leaving every GNN layer (backend.py:517-545, :607-630); systems without the data: charge 0, multiplicity 1
+        n_sys = cells.shape[0]
+        q = torch.zeros(n_sys, dtype=torch.long) if charge is None else charge.long()
+        sm = torch.ones(n_sys, dtype=torch.long) if spin_multiplicity is None else spin_multiplicity.long()
+        x = torch.cat([p["system_conditioning.charge_embedding.weight"][q + hypers["max_charge"]],
+                       p["system_conditioning.spin_multiplicity_embedding.weight"][sm - 1]], dim=-1)
+        x = torch.nn.functional.silu(_linear(x, p, "system_conditioning.project.0"))
+        cond = _linear(x, p, "system_conditioning.project.2")[system_indices.long()]
+
     node_feats, edge_feats = [], []
     for g in range(hypers["num_gnn_layers"]):
         pre = f"gnn_layers.{g}"
@@ -355,6 +369,8 @@ def pet_atomic_energies(
             if not post_ln:
                 e = e + oe
                 e = e + _swiglu_ff(_norm(e, p, lp + ".norm_mlp"), p, lp + ".mlp")
+        if cond is not None:
+            h = h + cond
         if residual:     # backend.py:621-647: features of every layer are read out; messages are averaged with the
             node_feats.append(h)  # reversed ones, no combination MLP
             edge_feats.append(e)
@@ -399,13 +415,13 @@ def pet_atomic_energies(
 
 def energy_and_gradient(
     params, hypers, positions, cells, centers, neighbors, cell_shifts, species,
-    system_indices, target="energy", create_graph=False,
+    system_indices, target="energy", create_graph=False, charge=None, spin_multiplicity=None,
 ):
     """Total energies per system and dE/dR (``utils/evaluate_model.py:128-133``)."""
     pos = positions.detach().clone().requires_grad_(True)
     atomic = pet_atomic_energies(
         params, hypers, pos, cells, centers, neighbors, cell_shifts, species,
-        system_indices, target,
+        system_indices, target, charge=charge, spin_multiplicity=spin_multiplicity,
     )
     n_sys = cells.shape[0]
     energies = torch.zeros(n_sys, atomic.shape[1], dtype=atomic.dtype).index_add(
@@ -542,6 +558,11 @@ def state_dict_schema(hypers: dict, atomic_types: List[int], targets: Dict[str, 
     for l in range(n_readout):
         out.append((f"node_embedders.{l}.weight", (ns, dn), "embedding"))
     out.append(("edge_embedder.weight", (ns, d), "embedding"))
+    if hypers.get("system_conditioning", False):  # conditioning.py:38-52 (created after the embedders, backend.py:121-130)
+        out.append(("system_conditioning.charge_embedding.weight", (2 * hypers["max_charge"] + 1, dn), "embedding"))
+        out.append(("system_conditioning.spin_multiplicity_embedding.weight", (hypers["max_spin_multiplicity"], dn), "embedding"))
+        lin("system_conditioning.project.0", dn, 2 * dn)
+        lin("system_conditioning.project.2", dn, dn)
     # a target maps to its number of properties (one block named like the target) or to {block: properties};
     # heads and last layers exist once per readout layer (backend.py:171-217)
     for t in targets:

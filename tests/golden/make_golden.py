@@ -521,6 +521,52 @@ VARIANTS = {
 }
 
 
+def main_conditioning():
+    """``system_conditioning = True`` (conditioning.py, backend.py:121-130,517-545): two systems with different total
+    charge and spin multiplicity, for the feedforward and the residual featuriser -> ``pet_conditioning_<tag>.npz``
+    (per-atom E, the node features of every readout layer, dE/dR, in fp32 / fp64)."""
+    from oracle import nl as onl
+    from oracle import pet as opet
+
+    PETBackend = import_reference_backend()
+    torch.set_num_threads(8)
+    p64, z64, c64 = opet.random_box(64, seed=1)
+    p40, z40, c40 = opet.random_box(40, seed=2)
+    pos_l, i_l, j_l, s_l, off = [], [], [], [], 0
+    for pos, cell in ((p64, c64), (p40, c40)):
+        i, j, s, _ = onl.neighbor_list(pos.double().numpy(), cell.double().numpy(), [True] * 3, 4.5)
+        i_l.append(torch.tensor(i) + off); j_l.append(torch.tensor(j) + off); s_l.append(torch.tensor(s))
+        off += len(pos)
+    pos, z = torch.cat([p64, p40]), torch.cat([z64, z40])
+    cells = torch.stack([c64, c40])
+    i, j, s = torch.cat(i_l), torch.cat(j_l), torch.cat(s_l).long()
+    sysidx = torch.cat([torch.zeros(64, dtype=torch.long), torch.ones(40, dtype=torch.long)])
+    charge, spin = torch.tensor([-2, 3]), torch.tensor([1, 4])
+    for tag, delta in (("feedforward", {}), ("residual", {"featurizer_type": "residual"})):
+        hyp = dict(opet.DEFAULT_HYPERS, system_conditioning=True, **delta)
+        store = {"in_charge": charge.numpy(), "in_spin_multiplicity": spin.numpy()}
+        for dtype in (torch.float32, torch.float64):
+            be, _ = _reference_backend(PETBackend, hyp, dtype)
+            be = be.eval()
+            p = pos.to(dtype).clone().requires_grad_(True)
+            batch = be.preprocess(p, i, j, z, cells.to(dtype), s, sysidx, 1.0)
+            batch["charge"], batch["spin_multiplicity"], batch["system_indices"] = charge, spin, sysidx
+            nf, ef = be.calculate_features(batch)
+            pred, _, _ = be.predict(nf, ef, batch, cells.to(dtype), sysidx, ["energy"])
+            atomic = pred["energy"][0]
+            (grad,) = torch.autograd.grad(atomic.sum(), p)
+            sfx = {torch.float32: "f32", torch.float64: "f64"}[dtype]
+            store[f"atomic_{sfx}"] = atomic.detach().numpy()
+            store[f"grad_{sfx}"] = grad.numpy()
+            if dtype == torch.float64:
+                store["n_readout"] = np.array(len(nf))
+                for l in range(len(nf)):
+                    store[f"node_features_{l}_f64"] = nf[l].detach().numpy()
+            print(tag, sfx, "E =", float(atomic.sum()), "|grad|max =", float(grad.abs().max()))
+        _store_inputs(store, (pos.double(), cells.double(), i, j, s, z, sysidx))
+        np.savez_compressed(os.path.join(HERE, f"pet_conditioning_{tag}.npz"), **store)
+
+
 def main_variants():
     """the variants older / production checkpoints use (pet/checkpoints.py:190-205 upgrades them to
     LayerNorm + SiLU + PostLN + residual featuriser = "legacy" here) and each switch on its own -- E, per-atom E, dE/dR
@@ -564,7 +610,9 @@ def main_variants():
 
 
 if __name__ == "__main__":
-    if "--variants" in sys.argv:
+    if "--conditioning" in sys.argv:
+        main_conditioning()
+    elif "--variants" in sys.argv:
         main_variants()
     elif "--box10000" in sys.argv:
         main_box10000()

@@ -267,3 +267,32 @@ def test_oracle_variants_match_reference(golden_dir, tag):
     assert len(nfs) == int(g["n_readout"])
     for l, nf in enumerate(nfs):
         np.testing.assert_allclose(nf.numpy(), g[f"node_features_{l}_f64"], rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("tag", ["feedforward", "residual"])
+def test_oracle_system_conditioning_matches_reference(golden_dir, tag):
+    """system_conditioning = True (conditioning.py; backend.py:121-130, 517-545, 607-630): charge / spin-multiplicity
+    embedding added to the node features leaving every GNN layer -- two systems with different charge and multiplicity,
+    against make_golden.py --conditioning."""
+    hypers = dict(opet.DEFAULT_HYPERS, system_conditioning=True,
+                  featurizer_type="residual" if tag == "residual" else "feedforward")
+    g = _load(golden_dir, f"pet_conditioning_{tag}.npz")
+    t = lambda k: torch.tensor(g[k])  # noqa: E731
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    e, grad, atomic = opet.energy_and_gradient(
+        params, hypers, t("in_positions"), t("in_cells"), t("in_centers"), t("in_neighbors"), t("in_cell_shifts").long(),
+        t("in_species"), t("in_system_indices"), charge=t("in_charge"), spin_multiplicity=t("in_spin_multiplicity"))
+    np.testing.assert_allclose(atomic.numpy(), g["atomic_f64"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(grad.numpy(), g["grad_f64"], rtol=1e-8, atol=1e-11)
+    _, nfs, _, _ = opet.pet_atomic_energies(
+        params, hypers, t("in_positions"), t("in_cells"), t("in_centers"), t("in_neighbors"), t("in_cell_shifts").long(),
+        t("in_species"), t("in_system_indices"), return_features="all", charge=t("in_charge"),
+        spin_multiplicity=t("in_spin_multiplicity"))
+    assert len(nfs) == int(g["n_readout"])
+    for l, nf in enumerate(nfs):
+        np.testing.assert_allclose(nf.numpy(), g[f"node_features_{l}_f64"], rtol=1e-8, atol=1e-11)
+    # the conditioning really acts: without it the energies differ
+    e0, _, _ = opet.energy_and_gradient(
+        params, hypers, t("in_positions"), t("in_cells"), t("in_centers"), t("in_neighbors"), t("in_cell_shifts").long(),
+        t("in_species"), t("in_system_indices"))
+    assert float((e0 - e).abs().max()) > 1e-3
