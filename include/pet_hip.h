@@ -73,6 +73,10 @@ typedef struct pet_hypers {
     int32_t transformer_type; /* PET_PRE_LN (transformer.py:203-234) | PET_POST_LN (transformer.py:236-262) */
     int32_t featurizer_type;  /* PET_FEATURIZER_FEEDFORWARD (backend.py:496-587) | PET_FEATURIZER_RESIDUAL (backend.py:589-649) */
     int32_t adaptive_cutoff_method; /* PET_ADAPTIVE_SOLVER (adaptive_cutoff.py:110-229) | PET_ADAPTIVE_GRID (:232-395, legacy) */
+    int32_t system_conditioning;    /* 1: charge / spin-multiplicity embedding added to the node features leaving every
+                                       GNN layer (conditioning.py, backend.py:121-130,517-545); needs pet_graph_set_conditioning */
+    int32_t max_charge;             /* charges in [-max_charge, max_charge]   (10) */
+    int32_t max_spin_multiplicity;  /* multiplicities in [1, max]             (10) */
 } pet_hypers_t;
 
 typedef struct pet_model pet_model_t; /* packed weights on the device */
@@ -173,6 +177,14 @@ int pet_graph_export_batch(const pet_graph_t* g,
  * graph workspace): rowptr [N+1], ctr/nbr/rev [E] int32. */
 int pet_graph_csr(const pet_graph_t* g, const int32_t** d_rowptr, const int32_t** d_ctr,
                   const int32_t** d_nbr, const int32_t** d_rev);
+
+/* system_conditioning (backend.py:375-378: batch_data["charge"], ["spin_multiplicity"], ["system_indices"]): per-system
+ * total charge and spin multiplicity (2S + 1) for the forward passes on this graph handle. d_system_indices [N] may be
+ * NULL for a pet_graph_build handle (it has them); the three device arrays must stay alive while the handle is used.
+ * Values outside [-max_charge, max_charge] / [1, max_spin_multiplicity] are the caller's to reject (conditioning.py:54-80
+ * does it on the host); the kernels clamp them. */
+int pet_graph_set_conditioning(pet_graph_t* g, const int64_t* d_charge, const int64_t* d_spin_multiplicity,
+                               const int64_t* d_system_indices, int64_t n_systems);
 
 /* ---- features + predict + gradient -------------------------------------------- */
 /* Activation workspace for one forward (+ saved tensors for the backward). */

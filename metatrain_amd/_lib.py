@@ -32,7 +32,7 @@ SYMBOLS = [
     "pet_predict_scratch_floats", "pet_predict", "pet_predict_backward", "pet_geometry_backward",
     "pet_forward_workspace_bytes", "pet_forward", "pet_aux_outputs", "pet_backward", "pet_backward_predict",
     "pet_backward_features", "pet_backward_geometry",
-    "pet_model_num_readout_layers", "pet_forward_layers", "pet_backward_features_layers",
+    "pet_model_num_readout_layers", "pet_forward_layers", "pet_backward_features_layers", "pet_graph_set_conditioning",
     "pet_model_zero_grad", "pet_model_get_grad", "pet_train_workspace_bytes", "pet_backward_train",
     "pet_model_get_param", "pet_model_flat_grad", "pet_adam_step", "pet_optimizer_state", "pet_model_tie_halves",
     "pet_train2_workspace_bytes", "pet_backward_train2",
@@ -89,6 +89,9 @@ class PetHypers(ctypes.Structure):
         ("transformer_type", c_int32),
         ("featurizer_type", c_int32),
         ("adaptive_cutoff_method", c_int32),
+        ("system_conditioning", c_int32),
+        ("max_charge", c_int32),
+        ("max_spin_multiplicity", c_int32),
     ]
 
 
@@ -159,6 +162,7 @@ def load() -> ctypes.CDLL:
     lib.pet_backward_predict.argtypes = [P, P, P, c_int64, P, P, P, P, P]
     lib.pet_backward_features.argtypes = [P, P, P, c_int64, P, P, P, P, P]
     lib.pet_backward_geometry.argtypes = [P, P, P, c_int64, P, P, P, P, P]
+    lib.pet_graph_set_conditioning.argtypes = [P, P, P, P, c_int64]
     lib.pet_model_num_readout_layers.argtypes = [P]
     lib.pet_model_num_readout_layers.restype = c_int32
     lib.pet_forward_layers.argtypes = [P, P, P, c_int64, c_int, P, P, c_int32, P]

@@ -306,6 +306,15 @@ int finalize(Model& m, hipStream_t st) {
         if ((rc = get(m, "node_embedders." + std::to_string(l) + ".weight", (int64_t)ns * DN, &m.node_embs[l]))) return rc;
     m.node_emb = m.node_embs[0];
     if ((rc = get(m, "edge_embedder.weight", (int64_t)ns * D, &m.edge_emb))) return rc;
+    if (h.system_conditioning) {
+        const std::string sc = "system_conditioning.";
+        if ((rc = get(m, sc + "charge_embedding.weight", (int64_t)(2 * h.max_charge + 1) * DN, &m.cond_qe))) return rc;
+        if ((rc = get(m, sc + "spin_multiplicity_embedding.weight", (int64_t)h.max_spin_multiplicity * DN, &m.cond_se))) return rc;
+        if ((rc = get(m, sc + "project.0.weight", (int64_t)DN * 2 * DN, &m.cond_w0))) return rc;
+        if ((rc = get(m, sc + "project.0.bias", DN, &m.cond_b0))) return rc;
+        if ((rc = get(m, sc + "project.2.weight", (int64_t)DN * DN, &m.cond_w2))) return rc;
+        if ((rc = get(m, sc + "project.2.bias", DN, &m.cond_b2))) return rc;
+    }
     // every head that was uploaded: "node_heads.<t>.<l>.0.weight" names a (target, readout layer); "node_last_layers.
     // <t>.<l>.<block>.weight" a block of P = numel / DH properties (backend.py:171-217). "@" is the fused target.
     m.heads.clear();
@@ -400,6 +409,8 @@ int pet_model_create(const pet_hypers_t* h, pet_model_t** out) {
                 PET_ERR_UNSUPPORTED, "unknown normalization / transformer_type / featurizer_type");
     PET_REQUIRE(h->adaptive_cutoff_method == PET_ADAPTIVE_SOLVER || h->adaptive_cutoff_method == PET_ADAPTIVE_GRID,
                 PET_ERR_UNSUPPORTED, "unknown adaptive_cutoff_method");
+    PET_REQUIRE(!h->system_conditioning || (h->max_charge >= 0 && h->max_spin_multiplicity >= 1), PET_ERR_ARGUMENT,
+                "system_conditioning needs max_charge >= 0 and max_spin_multiplicity >= 1");
     pet_model_t* pm = new pet_model_t();
     pm->m.h = *h;
     *out = pm;
@@ -614,6 +625,18 @@ int pet_graph_csr(const pet_graph_t* pg, const int32_t** rowptr, const int32_t**
     if (ctr) *ctr = pg->g.ctr;
     if (nbr) *nbr = pg->g.nbr;
     if (rev) *rev = pg->g.rev;
+    return PET_OK;
+}
+
+int pet_graph_set_conditioning(pet_graph_t* pg, const int64_t* d_charge, const int64_t* d_spin_multiplicity,
+                               const int64_t* d_system_indices, int64_t n_systems) {
+    PET_REQUIRE(pg && d_charge && d_spin_multiplicity && n_systems >= 1, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(d_system_indices || pg->g.sys, PET_ERR_ARGUMENT,
+                "this graph handle has no system indices (pet_graph_from_batch): pass d_system_indices");
+    pg->g.cond_charge = d_charge;
+    pg->g.cond_spin = d_spin_multiplicity;
+    pg->g.cond_sys = d_system_indices;
+    pg->g.n_cond_systems = n_systems;
     return PET_OK;
 }
 

@@ -108,6 +108,11 @@ struct Graph {
     float* inv_dn = nullptr;   // [N] 1 / max(dn_total/dr, 1e-6) at the root; 0 if the clamp is active
     float* grid_drdn = nullptr; // [N, GRID_MAX_PROBES] "grid" method: d(atomic cutoff) / d(smoothed count at probe k)
     int grid_probes = 0;        // number of probe cutoffs of the "grid" method (0: "solver")
+    // system conditioning (pet_graph_set_conditioning): caller-owned device arrays
+    const int64_t* cond_charge = nullptr;  // [n_cond_systems]
+    const int64_t* cond_spin = nullptr;    // [n_cond_systems]
+    const int64_t* cond_sys = nullptr;     // [N] or nullptr: use `sys`
+    int64_t n_cond_systems = 0;
     float* pc = nullptr;       // [E] pair cutoff of every kept edge
     float* ad_gc = nullptr;    // [E] scratch: dL/d(pair cutoff)
     float* ad_gr = nullptr;    // [N] scratch: dL/d(atomic cutoff)

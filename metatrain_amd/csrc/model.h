@@ -79,6 +79,10 @@ struct Model {
     bool plain() const { return plain_layers() && !residual(); }
     int num_readout_layers() const { return residual() ? h.num_gnn_layers : 1; }
     const float* edge_emb = nullptr;  // [ns, D]
+    // system conditioning (conditioning.py:38-52): embeddings [2 max_charge + 1, DN], [max_spin, DN]; project.0 [DN, 2 DN],
+    // project.2 [DN, DN] as raw torch Linear weights (a per-SYSTEM MLP: a few rows, evaluated by one small kernel)
+    const float *cond_qe = nullptr, *cond_se = nullptr, *cond_w0 = nullptr, *cond_b0 = nullptr, *cond_w2 = nullptr,
+                *cond_b2 = nullptr;
     // the FUSED target (keys with "@" for target and block: pet_forward / the native training step): one property
     bool has_fused_head = false;
     Lin nh0, nh2, eh0, eh2;

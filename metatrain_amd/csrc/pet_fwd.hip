@@ -46,6 +46,44 @@ __global__ void k_node_embed(const int* __restrict__ sp, const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------
+// system conditioning (conditioning.py:82-100): cond[s] = W2 silu(W0 [emb_q[charge_s + max_charge] ; emb_m[mult_s - 1]] + b0) + b2,
+// one 256-thread block per SYSTEM (a handful of rows: plain fp32 dot products), then h_i += cond[system of i] after every
+// GNN layer (backend.py:543-545, :628-629)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(DN) void k_system_cond(const int64_t* __restrict__ charge, const int64_t* __restrict__ spin,
+                                                   const float* __restrict__ emb_q, const float* __restrict__ emb_m,
+                                                   const float* __restrict__ w0, const float* __restrict__ b0,
+                                                   const float* __restrict__ w2, const float* __restrict__ b2,
+                                                   float* __restrict__ cond, int max_charge, int max_spin) {
+    __shared__ float x[2 * DN], hid[DN];
+    const int s = blockIdx.x, t = threadIdx.x;
+    int q = (int)charge[s] + max_charge, mi = (int)spin[s] - 1;
+    q = q < 0 ? 0 : (q > 2 * max_charge ? 2 * max_charge : q);  // the caller validates (conditioning.py:54-80); stay in bounds
+    mi = mi < 0 ? 0 : (mi > max_spin - 1 ? max_spin - 1 : mi);
+    x[t] = emb_q[(size_t)q * DN + t];
+    x[DN + t] = emb_m[(size_t)mi * DN + t];
+    __syncthreads();
+    float a = b0[t];
+    for (int k = 0; k < 2 * DN; k++) a = fmaf(w0[(size_t)t * 2 * DN + k], x[k], a);
+    hid[t] = siluf_(a);
+    __syncthreads();
+    float o = b2[t];
+    for (int k = 0; k < DN; k++) o = fmaf(w2[(size_t)t * DN + k], hid[k], o);
+    cond[(size_t)s * DN + t] = o;
+}
+__global__ void k_add_cond(float* __restrict__ H, const float* __restrict__ cond, const int* __restrict__ sys32,
+                           const int64_t* __restrict__ sys64, int n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
+    if (idx >= (int64_t)n * (DN / 4)) return;
+    const int i = (int)(idx / (DN / 4)), c = (int)(idx % (DN / 4));
+    const int64_t s = sys64 ? sys64[i] : (int64_t)sys32[i];
+    float4 h = reinterpret_cast<float4*>(H)[idx];
+    const float4 a = reinterpret_cast<const float4*>(cond + s * DN)[c];
+    h.x += a.x; h.y += a.y; h.z += a.z; h.w += a.w;
+    reinterpret_cast<float4*>(H)[idx] = h;
+}
+
+// ---------------------------------------------------------------------------------
 // compress: a0 = [v,d] Wc^T + Tbl[species] (+ M W0c^T);  e = SiLU(a0) W2^T + b2
 // ---------------------------------------------------------------------------------
 template <bool FIRST>
@@ -697,8 +735,9 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
     PET_REQUIRE(!(atomic && res), PET_ERR_UNSUPPORTED,
                 "the fused head reads one readout layer; with the residual featuriser use pet_forward_layers and "
                 "pet_predict per readout layer");
-    PET_REQUIRE(save != 2 || m.plain(), PET_ERR_UNSUPPORTED,
-                "training is built for normalization=RMSNorm, transformer_type=PreLN, featurizer_type=feedforward only");
+    PET_REQUIRE(save != 2 || (m.plain() && !m.h.system_conditioning), PET_ERR_UNSUPPORTED,
+                "training is built for normalization=RMSNorm, transformer_type=PreLN, featurizer_type=feedforward only, "
+                "without system conditioning");
     const int64_t N = g.n_nodes, E = g.n_edges, R = E + N;
     if (N == 0) return PET_OK;
     const int nt = attn_tiles(g);
@@ -731,6 +770,14 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
         k_center<<<gN, NTHREADS, BM * LD256 * 4 + BM * 8, s2>>>(Ab.H, wx_fwd(A.cc, 2), A.cc.b, Ab.X + E * D, N);
     };
     k_node_embed<<<cdiv(N * (DN / 4), 256), 256, 0, st>>>(g.sp, m.node_emb, w.H0, (int)N);
+    const bool conditioned = m.h.system_conditioning != 0;
+    if (conditioned) {
+        PET_REQUIRE(g.cond_charge && g.n_cond_systems >= 1 && g.n_cond_systems <= N, PET_ERR_ARGUMENT,
+                    "system_conditioning: call pet_graph_set_conditioning (charge, spin multiplicity, system indices) first");
+        k_system_cond<<<(int)g.n_cond_systems, DN, 0, st>>>(g.cond_charge, g.cond_spin, m.cond_qe, m.cond_se, m.cond_w0,
+                                                             m.cond_b0, m.cond_w2, m.cond_b2, w.cond, m.h.max_charge,
+                                                             m.h.max_spin_multiplicity);
+    }
     ss.fork(st);
     launch_center(0, 0);
     side_busy = true;
@@ -800,6 +847,8 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                     Ab.H, Ab.OC, wx_fwd(A.ce, 4), A.ce.b, A.g_center, A.b_center, wx_fwd(A.cmlp_in, 8), A.cmlp_in.b,
                     wx_fwd(A.cmlp_out, 16), A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
             }
+            if (a + 1 == AL && conditioned)  // backend.py:543-545: the node features LEAVING the GNN layer
+                k_add_cond<<<cdiv(N * (DN / 4), 256), 256, 0, s2>>>(Ab.Hn, w.cond, g.sys, g.cond_sys, (int)N);
             if (a + 1 < AL) launch_center(gi, a + 1);
             else if (gi + 1 < L) launch_center(gi + 1, 0);
             side_busy = true;

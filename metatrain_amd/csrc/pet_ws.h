@@ -41,6 +41,7 @@ struct Workspace {
     float* AO = nullptr;     // [(E+N), D] attention output before output_linear (temp)
     float* OC = nullptr;     // [N, D] centre rows of output_linear (temp)
     float* T1 = nullptr;     // PostLN only: [(E+N), D] norm_attention output (temp)
+    float* cond = nullptr;   // system conditioning only: [n_systems <= N, DN] per-system embedding
     float* ypred_e = nullptr;  // [E] edge last-layer prediction before the cutoff weight
     float* ye = nullptr;       // [E] fc * ypred_e
     float* ynode = nullptr;    // [N]
@@ -117,6 +118,7 @@ inline void carve_workspace(const Model& m, int64_t N, int64_t E, void* base, Wo
     w.AO = c.take<float>(Ra * D);
     w.OC = c.take<float>(Na * D);
     if (m.post_ln()) w.T1 = c.take<float>(Ra * D);
+    if (m.h.system_conditioning) w.cond = c.take<float>(Na * DN);
     w.ypred_e = c.take<float>(Ea);
     w.ye = c.take<float>(Ea);
     w.ynode = c.take<float>(Na);

@@ -47,8 +47,8 @@ struct PetHipModule : torch::CustomClassHolder {
                  std::vector<at::Tensor> tensors_)
         : hypers(std::move(hypers_)), atomic_types(std::move(atomic_types_)), keys(std::move(keys_)),
           tensors(std::move(tensors_)) {
-        TORCH_CHECK(hypers.size() == 16 || hypers.size() == 19 || hypers.size() == 20,
-                    "pet_hip: expected the first 16, 19 or all 20 fields of pet_hypers_t");
+        TORCH_CHECK(hypers.size() == 16 || hypers.size() == 19 || hypers.size() == 20 || hypers.size() == 23,
+                    "pet_hip: expected the first 16, 19, 20 or all 23 fields of pet_hypers_t");
         TORCH_CHECK(keys.size() == tensors.size(), "pet_hip: keys / tensors length mismatch");
     }
     ~PetHipModule() override {
@@ -69,6 +69,8 @@ struct PetHipModule : torch::CustomClassHolder {
             h.featurizer_type = (int32_t)hypers[18];
         }
         if (hypers.size() >= 20) h.adaptive_cutoff_method = (int32_t)hypers[19];
+        TORCH_CHECK(hypers.size() < 23 || hypers[20] == 0.0,
+                    "pet_hip: system conditioning needs the three PETBackend calls (batch_data carries charge / spin)");
         return h;
     }
 
@@ -177,7 +179,7 @@ struct PetHipBackend : torch::CustomClassHolder {
 
     PetHipBackend(std::vector<double> hypers_, std::vector<int64_t> atomic_types_, std::vector<std::string> keys_)
         : hypers(std::move(hypers_)), atomic_types(std::move(atomic_types_)), keys(std::move(keys_)) {
-        TORCH_CHECK(hypers.size() == 17 || hypers.size() == 20 || hypers.size() == 21,
+        TORCH_CHECK(hypers.size() == 17 || hypers.size() == 20 || hypers.size() == 21 || hypers.size() == 24,
                     "pet_hip: expected the first 16 fields of pet_hypers_t, the SiLU flag and (optionally) normalization, "
                     "transformer_type, featurizer_type, adaptive_cutoff_method");
     }
@@ -199,6 +201,10 @@ struct PetHipBackend : torch::CustomClassHolder {
             h.featurizer_type = (int32_t)hypers[19];
         }
         if (hypers.size() >= 21) h.adaptive_cutoff_method = (int32_t)hypers[20];
+        if (hypers.size() >= 24) {
+            h.system_conditioning = (int32_t)hypers[21]; h.max_charge = (int32_t)hypers[22];
+            h.max_spin_multiplicity = (int32_t)hypers[23];
+        }
         return h;
     }
 
@@ -245,7 +251,8 @@ struct PetHipBackend : torch::CustomClassHolder {
     std::vector<at::Tensor> calculate_features(std::vector<at::Tensor> params, const at::Tensor& element_indices_nodes,
                                                const at::Tensor& element_indices_neighbors, const at::Tensor& edge_vectors,
                                                const at::Tensor& edge_distances, const at::Tensor& padding_mask,
-                                               const at::Tensor& reverse_neighbor_index, const at::Tensor& cutoff_factors);
+                                               const at::Tensor& reverse_neighbor_index, const at::Tensor& cutoff_factors,
+                                               std::vector<at::Tensor> conditioning);
     std::vector<at::Tensor> predict(std::vector<at::Tensor> params, std::string target, int64_t readout_layer,
                                     std::string block, const at::Tensor& node_features, const at::Tensor& edge_features,
                                     const at::Tensor& padding_mask, const at::Tensor& cutoff_factors);
@@ -390,8 +397,21 @@ struct FeaturesFn : torch::autograd::Function<FeaturesFn> {
     static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const at::Tensor& ev,
                                                   const at::Tensor& ed, const at::Tensor& cf,
                                                   c10::intrusive_ptr<PetHipBackend> be, const at::Tensor& el_nodes,
-                                                  const at::Tensor& el_nbr, const at::Tensor& mask, const at::Tensor& rni) {
+                                                  const at::Tensor& el_nbr, const at::Tensor& mask, const at::Tensor& rni,
+                                                  const at::Tensor& charge, const at::Tensor& spin,
+                                                  const at::Tensor& system_indices) {
         auto bg = graph_from_batch(el_nodes, el_nbr, ev, ed, mask, rni, cf, false);
+        if (be->hypers_struct().system_conditioning) {
+            // batch_data["charge"], ["spin_multiplicity"], ["system_indices"] (backend.py:375-378)
+            TORCH_CHECK(charge.numel() > 0 && spin.numel() == charge.numel() && system_indices.numel() == mask.size(0),
+                        "pet_hip: system_conditioning needs batch_data['charge'], ['spin_multiplicity'] and ['system_indices']");
+            auto i64 = [&](const at::Tensor& t) { return t.to(mask.device(), at::kLong).contiguous(); };
+            bg->keep.push_back(i64(charge)); bg->keep.push_back(i64(spin)); bg->keep.push_back(i64(system_indices));
+            const size_t k = bg->keep.size();
+            check(pet_graph_set_conditioning(bg->g, bg->keep[k - 3].data_ptr<int64_t>(), bg->keep[k - 2].data_ptr<int64_t>(),
+                                             bg->keep[k - 1].data_ptr<int64_t>(), bg->keep[k - 3].numel()),
+                  "pet_graph_set_conditioning");
+        }
         const int64_t n = bg->n_nodes, e = pet_graph_num_edges(bg->g);
         const pet_hypers_t h = be->hypers_struct();
         auto dev = mask.device();
@@ -449,7 +469,8 @@ struct FeaturesFn : torch::autograd::Function<FeaturesFn> {
             g_ed = to_nef(geo.select(1, 3).contiguous(), bg->ix, n, m);
             g_cf = to_nef(gfc, bg->ix, n, m);
         }
-        return {g_ev.to(dt), g_ed.to(dt), g_cf.to(dt), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+        return {g_ev.to(dt), g_ed.to(dt), g_cf.to(dt), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+                at::Tensor(), at::Tensor(), at::Tensor()};
     }
 };
 
@@ -522,9 +543,15 @@ std::vector<at::Tensor> PetHipBackend::preprocess(std::vector<at::Tensor> params
 }
 std::vector<at::Tensor> PetHipBackend::calculate_features(std::vector<at::Tensor> params, const at::Tensor& el_nodes,
                                                           const at::Tensor& el_nbr, const at::Tensor& ev, const at::Tensor& ed,
-                                                          const at::Tensor& mask, const at::Tensor& rni, const at::Tensor& cf) {
+                                                          const at::Tensor& mask, const at::Tensor& rni, const at::Tensor& cf,
+                                                          std::vector<at::Tensor> conditioning) {
     ensure_model(params, ev);
-    return FeaturesFn::apply(ev, ed, cf, c10::intrusive_ptr<PetHipBackend>::reclaim_copy(this), el_nodes, el_nbr, mask, rni);
+    TORCH_CHECK(conditioning.empty() || conditioning.size() == 3,
+                "pet_hip: conditioning = [] or [charge, spin_multiplicity, system_indices]");
+    const at::Tensor none = at::empty({0}, mask.options().dtype(at::kLong));  // (autograd wants defined tensors)
+    return FeaturesFn::apply(ev, ed, cf, c10::intrusive_ptr<PetHipBackend>::reclaim_copy(this), el_nodes, el_nbr, mask, rni,
+                             conditioning.empty() ? none : conditioning[0], conditioning.empty() ? none : conditioning[1],
+                             conditioning.empty() ? none : conditioning[2]);
 }
 std::vector<at::Tensor> PetHipBackend::predict(std::vector<at::Tensor> params, std::string target, int64_t readout_layer,
                                                std::string block, const at::Tensor& nf, const at::Tensor& ef,

@@ -30,7 +30,7 @@ properties per block, several blocks per target and several targets are served b
 variants older checkpoints use -- ``normalization = "LayerNorm"``, ``transformer_type = "PostLN"``, ``featurizer_type =
 "residual"`` (``pet/checkpoints.py:190-205``) -- run for inference and forces; training is built for the default
 architecture only; both adaptive-cutoff methods ("solver", and the legacy "grid" for inference / forces / energy-only
-training). Not built (raise loudly): system conditioning, diagnostic
+training); system conditioning (charge / spin multiplicity, inference + forces). Not built (raise loudly): diagnostic
 capture, double backward through the three inference nodes, stress (strain) terms in a training loss, training of the
 variants.
 """
@@ -165,6 +165,52 @@ class _CartesianTransformerLater(torch.nn.Module):
         return out
 
 
+class _SystemConditioning(torch.nn.Module):
+    """Parameters of ``SystemConditioningEmbedding`` (conditioning.py:8-52) under the same names: charge and
+    spin-multiplicity embeddings, ``project`` = Linear, SiLU, zero-initialised gate Linear."""
+
+    required_data_keys: List[str] = ["charge", "spin_multiplicity"]
+
+    def __init__(self, d_out: int, max_charge: int, max_spin_multiplicity: int):
+        super().__init__()
+        self.max_charge = max_charge
+        self.max_spin_multiplicity = max_spin_multiplicity
+        self.charge_embedding = torch.nn.Embedding(2 * max_charge + 1, d_out)
+        self.spin_multiplicity_embedding = torch.nn.Embedding(max_spin_multiplicity, d_out)
+        gate = torch.nn.Linear(d_out, d_out)
+        torch.nn.init.zeros_(gate.weight)
+        torch.nn.init.zeros_(gate.bias)
+        self.project = torch.nn.ModuleList([torch.nn.Linear(2 * d_out, d_out), torch.nn.SiLU(), gate])
+
+    @torch.jit.export
+    def params(self) -> List[torch.Tensor]:
+        return [self.charge_embedding.weight, self.spin_multiplicity_embedding.weight, self.project[0].weight,
+                self.project[0].bias, self.project[2].weight, self.project[2].bias]
+
+    @torch.jit.export
+    def validate(self, charge: torch.Tensor, spin_multiplicity: torch.Tensor) -> None:
+        """conditioning.py:54-80."""
+        if bool((charge < -self.max_charge).any()) or bool((charge > self.max_charge).any()):
+            raise ValueError("charge values must be in [-max_charge, max_charge]. Increase max_charge in model hypers to "
+                             "support wider charge ranges.")
+        if bool((spin_multiplicity < 1).any()) or bool((spin_multiplicity > self.max_spin_multiplicity).any()):
+            raise ValueError("spin_multiplicity values must be in [1, max_spin_multiplicity]. Increase "
+                             "max_spin_multiplicity in model hypers to support higher spin multiplicities.")
+
+
+class _NoConditioning(torch.nn.Module):
+    """``system_conditioning = False`` (the reference holds None): no parameters, nothing to validate."""
+
+    @torch.jit.export
+    def params(self) -> List[torch.Tensor]:
+        out: List[torch.Tensor] = []
+        return out
+
+    @torch.jit.export
+    def validate(self, charge: torch.Tensor, spin_multiplicity: torch.Tensor) -> None:
+        pass
+
+
 def _flat_head(d_in: int, d_head: int) -> torch.nn.ModuleList:
     """The head as a ModuleList [Linear, SiLU, Linear, SiLU]: keys "0.weight" / "2.weight" like the reference's
     Sequential, and indexable with constants in TorchScript."""
@@ -267,8 +313,8 @@ class PETBackend(torch.nn.Module):
         super().__init__()
         h = rt.hypers_struct(hypers, atomic_types)  # validates; unsupported variants raise here
         fields = [float(getattr(h, name)) for name, _ in h._fields_]
-        # PetHipBackend(hypers): the first 16 fields of pet_hypers_t, the SiLU flag, then normalization / transformer_type /
-        # featurizer_type (csrc/torch_ops.cpp)
+        # PetHipBackend(hypers): the first 16 fields of pet_hypers_t, the SiLU flag, then the remaining fields (normalization,
+        # transformer_type, featurizer_type, adaptive_cutoff_method, system_conditioning, max_charge, max_spin_multiplicity)
         self._numbers: List[float] = fields[:16] + [1.0 if hypers["activation"] == "SiLU" else 0.0] + fields[16:]
         self.hypers = dict(hypers)
         self.atomic_types: List[int] = [int(z) for z in atomic_types]
@@ -313,6 +359,11 @@ class PETBackend(torch.nn.Module):
         self.node_embedders = torch.nn.ModuleList(
             [torch.nn.Embedding(n_species, self.d_node) for _ in range(self.num_readout_layers)])
         self.edge_embedder = torch.nn.Embedding(n_species, self.d_pet)
+        # backend.py:121-130 (None in the reference when off; an empty ModuleList here so that TorchScript sees one type)
+        self.has_system_conditioning: bool = bool(hypers.get("system_conditioning", False))
+        self.system_conditioning = (_SystemConditioning(self.d_node, int(hypers["max_charge"]),
+                                                        int(hypers["max_spin_multiplicity"]))
+                                    if self.has_system_conditioning else _NoConditioning())
         self.node_heads = torch.nn.ModuleDict()
         self.edge_heads = torch.nn.ModuleDict()
         self.node_last_layers = torch.nn.ModuleDict()
@@ -368,6 +419,7 @@ class PETBackend(torch.nn.Module):
         for emb in self.node_embedders:
             out += [emb.weight]
         out += [self.edge_embedder.weight]
+        out += self.system_conditioning.params()
         for _, heads in self.node_heads.items():
             for head in heads:
                 out += [head[0].weight, head[0].bias, head[2].weight, head[2].bias]
@@ -420,10 +472,14 @@ class PETBackend(torch.nn.Module):
         ``batch_data`` as given."""
         if capture_diagnostics:
             raise RuntimeError("diagnostic feature capture is not built into libpet_hip")
+        conditioning: List[torch.Tensor] = []
+        if self.has_system_conditioning:  # backend.py:375-378; the model wrapper puts the three keys into batch_data
+            self.system_conditioning.validate(batch_data["charge"], batch_data["spin_multiplicity"])
+            conditioning = [batch_data["charge"], batch_data["spin_multiplicity"], batch_data["system_indices"]]
         outs = self.core.calculate_features(
             self._params(), batch_data["element_indices_nodes"], batch_data["element_indices_neighbors"],
             batch_data["edge_vectors"], batch_data["edge_distances"], batch_data["padding_mask"],
-            batch_data["reverse_neighbor_index"], batch_data["cutoff_factors"])
+            batch_data["reverse_neighbor_index"], batch_data["cutoff_factors"], conditioning)
         return outs[: self.num_readout_layers], outs[self.num_readout_layers:]
 
     @torch.jit.export

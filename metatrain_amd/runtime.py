@@ -45,7 +45,8 @@ def hypers_struct(hypers: dict, atomic_types: List[int]) -> PetHypers:
         raise ValueError(f"adaptive_cutoff_method must be 'grid' or 'solver', got {hypers['adaptive_cutoff_method']}")
     variants["adaptive_cutoff_method"] = 1 if method == "grid" else 0
     if hypers.get("system_conditioning", False):
-        raise PetHipError("system_conditioning is not built into libpet_hip yet")
+        variants.update(system_conditioning=1, max_charge=int(hypers["max_charge"]),
+                        max_spin_multiplicity=int(hypers["max_spin_multiplicity"]))
     return PetHypers(
         cutoff=float(hypers["cutoff"]),
         cutoff_width=float(hypers["cutoff_width"]),
@@ -297,6 +298,25 @@ class HipGraph:
     def system_of_atom(self) -> torch.Tensor:
         """``[N]`` int64 structure index of every atom (the batch's ``system_indices``)."""
         return self._sys.long()
+
+    def set_conditioning(self, charge: torch.Tensor, spin_multiplicity: torch.Tensor,
+                         system_indices: Optional[torch.Tensor] = None) -> None:
+        """``system_conditioning``: per-system total charge and spin multiplicity of this batch
+        (``batch_data["charge"]``, ``["spin_multiplicity"]``, ``["system_indices"]``; ``pet_graph_set_conditioning``).
+        Range check on the host like ``SystemConditioningEmbedding.validate`` (conditioning.py:54-80)."""
+        h = self.model.hypers
+        q = charge.detach().to(self.workspace.device, torch.int64).contiguous()
+        sm = spin_multiplicity.detach().to(self.workspace.device, torch.int64).contiguous()
+        if q.numel() and (int(q.min()) < -h["max_charge"] or int(q.max()) > h["max_charge"]):
+            raise ValueError(f"charge values must be in [{-h['max_charge']}, {h['max_charge']}], got min={int(q.min())}, "
+                             f"max={int(q.max())}. Increase max_charge in model hypers to support wider charge ranges.")
+        if sm.numel() and (int(sm.min()) < 1 or int(sm.max()) > h["max_spin_multiplicity"]):
+            raise ValueError(f"spin_multiplicity values must be in [1, {h['max_spin_multiplicity']}], got "
+                             f"min={int(sm.min())}, max={int(sm.max())}. Increase max_spin_multiplicity in model hypers to "
+                             f"support higher spin multiplicities.")
+        si = None if system_indices is None else system_indices.detach().to(self.workspace.device, torch.int64).contiguous()
+        self._conditioning = (q, sm, si)  # the handle keeps the pointers: keep the tensors alive with it
+        check(self.lib.pet_graph_set_conditioning(self.handle, _ptr(q), _ptr(sm), _ptr(si), int(q.numel())))
 
     @classmethod
     def from_batch(cls, model: "HipModel", batch_data: Dict[str, torch.Tensor]) -> "HipGraph":

@@ -81,8 +81,8 @@ def test_variants_outside_the_build_fail_loudly():
         setattr(h, field, 7)
         handle = ctypes.c_void_p()
         assert lib.pet_model_create(ctypes.byref(h), ctypes.byref(handle)) == -2, field  # PET_ERR_UNSUPPORTED
-    with pytest.raises(_lib.PetHipError):  # system conditioning is not built
-        rt.hypers_struct(dict(opet.DEFAULT_HYPERS, system_conditioning=True), [1, 6])
+    cond = rt.hypers_struct(dict(opet.DEFAULT_HYPERS, system_conditioning=True, max_charge=4), [1, 6])
+    assert (cond.system_conditioning, cond.max_charge, cond.max_spin_multiplicity) == (1, 4, 10)
 
 
 def test_cpu_tensors_are_rejected_not_silently_computed():

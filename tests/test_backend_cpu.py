@@ -49,6 +49,7 @@ def test_reference_state_dict_loads_strictly():
 
 
 VARIANTS = {
+    "conditioned": dict(system_conditioning=True),
     "legacy": dict(normalization="LayerNorm", activation="SiLU", transformer_type="PostLN", featurizer_type="residual"),
     "layernorm": dict(normalization="LayerNorm"),
     "postln": dict(transformer_type="PostLN"),

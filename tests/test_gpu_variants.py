@@ -173,3 +173,82 @@ def test_variant_training_through_the_mirror_says_it_is_not_built(golden_dir):
     nodes, edges = be.calculate_features(batch)
     with pytest.raises((PetHipError, RuntimeError), match="training is built"):
         be.predict(nodes, edges, batch, t("in_cells").float(), t("in_system_indices"), ["energy"])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# system conditioning (conditioning.py; backend.py:121-130, 517-545, 607-630)
+# ---------------------------------------------------------------------------------------------------------
+def _conditioning_case(golden_dir, tag):
+    hypers = dict(opet.DEFAULT_HYPERS, system_conditioning=True,
+                  featurizer_type="residual" if tag == "residual" else "feedforward")
+    g = dict(np.load(os.path.join(golden_dir, f"pet_conditioning_{tag}.npz")))
+    return hypers, g
+
+
+@pytest.mark.parametrize("tag", ["feedforward", "residual"])
+def test_system_conditioning_through_the_c_abi(rt, golden_dir, tag):
+    """Two systems with different total charge and spin multiplicity: per-atom energies, the node features of every
+    readout layer and dE/dR against the reference; the fused pet_forward / pet_backward pair serves it too."""
+    dev = torch.device("cuda:0")
+    hypers, g = _conditioning_case(golden_dir, tag)
+    params = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    m = rt.HipModel(hypers, TYPES)
+    m.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    t = lambda k, dt=None: torch.tensor(g[k]).to(dev) if dt is None else torch.tensor(g[k]).to(dev, dt)  # noqa: E731
+    graph = rt.HipGraph(m, t("in_positions", torch.float32), t("in_cells", torch.float32), t("in_centers"), t("in_neighbors"),
+                        t("in_cell_shifts"), t("in_species"), t("in_system_indices", torch.int32))
+    with pytest.raises(rt.PetHipError, match="pet_graph_set_conditioning"):
+        rt.HipForward(m, graph).features_layers()  # the model expects charge / spin
+    graph.set_conditioning(t("in_charge"), t("in_spin_multiplicity"))
+    atomic, grad, nfs, _ = _energy_and_gradient(rt, m, graph)
+    assert len(nfs) == int(g["n_readout"])
+    for l, nf in enumerate(nfs):
+        assert relmax(nf.cpu().numpy(), g[f"node_features_{l}_f64"]) < TOL
+    assert relmax(atomic.cpu().numpy(), g["atomic_f64"]) < TOL
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
+    if tag == "feedforward":
+        fw = rt.HipForward(m, graph)
+        a2 = fw.forward()
+        g2 = fw.backward(torch.ones_like(a2))
+        assert relmax(a2.cpu().numpy(), g["atomic_f64"].ravel()) < TOL and relmax(g2.cpu().numpy(), g["grad_f64"]) < TOL
+    with pytest.raises(ValueError, match="charge values"):
+        graph.set_conditioning(torch.tensor([11, 0]), t("in_spin_multiplicity"))
+    with pytest.raises(ValueError, match="spin_multiplicity values"):
+        graph.set_conditioning(t("in_charge"), torch.tensor([0, 1]))
+
+
+@pytest.mark.parametrize("scripted", [False, True])
+def test_system_conditioning_through_the_backend_calls(golden_dir, scripted):
+    """batch_data carries "charge", "spin_multiplicity" and "system_indices" (put there by the model wrapper,
+    pet/model.py:465-470) into calculate_features, eager and scripted."""
+    import io
+
+    from metatrain_amd.pet import PETBackend
+
+    dev = torch.device("cuda:0")
+    hypers, g = _conditioning_case(golden_dir, "residual")
+    be = PETBackend(hypers, TYPES)
+    be.add_output("energy", {"energy": [1]})
+    be.load_state_dict(opet.synthetic_params(hypers, TYPES, {"energy": 1}), strict=True)
+    be = be.to(dev).eval()
+    if scripted:
+        buf = io.BytesIO()
+        torch.jit.save(torch.jit.script(be), buf)
+        buf.seek(0)
+        be = torch.jit.load(buf, map_location=dev)
+    t = lambda k: torch.tensor(g[k]).to(dev)  # noqa: E731
+    pos = t("in_positions").float().requires_grad_(True)
+    cells = t("in_cells").float()
+    batch = be.preprocess(pos, t("in_centers"), t("in_neighbors"), t("in_species"), cells, t("in_cell_shifts"),
+                          t("in_system_indices"), 1.0)
+    batch["charge"], batch["spin_multiplicity"] = t("in_charge"), t("in_spin_multiplicity")
+    batch["system_indices"] = t("in_system_indices")
+    nodes, edges = be.calculate_features(batch)
+    pred, _, _ = be.predict(nodes, edges, batch, cells, t("in_system_indices"), ["energy"])
+    atomic = pred["energy"][0]
+    (grad,) = torch.autograd.grad(atomic.sum(), pos)
+    assert relmax(atomic.detach().cpu().numpy(), g["atomic_f64"]) < TOL
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
+    batch["charge"] = torch.tensor([0, 42], device=dev)
+    with pytest.raises((ValueError, RuntimeError, torch.jit.Error), match="charge values"):
+        be.calculate_features(batch)
