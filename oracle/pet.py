@@ -104,21 +104,31 @@ def adaptive_cutoffs_solver(centers, d, target: float, n_nodes: int, max_cutoff:
     return (r - n_res / dn_root.clamp_min(1e-6)).clamp(max_cutoff / 16.0, max_cutoff)
 
 
-def adaptive_cutoffs_grid(centers, d, target: float, n_nodes: int, max_cutoff: float, width: float,
-                          min_cutoff: float = 0.5):
-    """``adaptive_cutoff.py:232-294,297-395`` (``get_adaptive_cutoffs_grid``, the legacy method): smoothed neighbour
-    counts on a grid of probe cutoffs (spacing width / 4), Gaussian weights around the target count with a width taken
-    from the slope of the count along the grid, cutoff = weighted mean of the probes. Plain autograd for the gradient."""
-    probes = torch.arange(min_cutoff, max_cutoff, width / 4.0, dtype=d.dtype)
+def grid_effective_num_neighbors(d, probes, centers, n_nodes: int, width: float):
+    """``adaptive_cutoff.py:297-327``: smoothed neighbour count of every atom at every probe cutoff, ``[N, K]``."""
     weights = cutoff_bump(d.unsqueeze(0), probes.unsqueeze(1), width)  # [K, E]
-    n_eff = torch.zeros((len(probes), n_nodes), dtype=d.dtype).index_add(1, centers, weights).T  # [N, K]
-    x = torch.linspace(0, 1, len(probes), dtype=d.dtype)
+    return torch.zeros((len(probes), n_nodes), dtype=d.dtype).index_add(1, centers, weights).T
+
+
+def grid_gaussian_weights(n_eff, target: float):
+    """``adaptive_cutoff.py:331-395`` with ``width=None``: Gaussian weights of the probes around the target count
+    (+ the cubic baseline), width from the slope of the count along the probe axis, rows normalised."""
+    x = torch.linspace(0, 1, n_eff.shape[1], dtype=n_eff.dtype)
     diff = n_eff - target + (target * x**3).unsqueeze(0)
     (slope,) = torch.gradient(diff, dim=-1)
     width_t = slope.abs().clamp_min(1e-12)
     logw = -0.5 * (diff / width_t) ** 2
     w = torch.exp(logw - logw.max())
-    w = w / w.sum(dim=1, keepdim=True)
+    return w / w.sum(dim=1, keepdim=True)
+
+
+def adaptive_cutoffs_grid(centers, d, target: float, n_nodes: int, max_cutoff: float, width: float,
+                          min_cutoff: float = 0.5):
+    """``adaptive_cutoff.py:232-294`` (``get_adaptive_cutoffs_grid``, the legacy method): smoothed neighbour counts on
+    a grid of probe cutoffs (spacing width / 4), Gaussian weights around the target count, cutoff = weighted mean of the
+    probes. Plain autograd for the gradient."""
+    probes = torch.arange(min_cutoff, max_cutoff, width / 4.0, dtype=d.dtype)
+    w = grid_gaussian_weights(grid_effective_num_neighbors(d, probes, centers, n_nodes, width), target)
     return probes @ w.T
 
 

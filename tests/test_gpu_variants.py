@@ -252,3 +252,23 @@ def test_system_conditioning_through_the_backend_calls(golden_dir, scripted):
     batch["charge"] = torch.tensor([0, 42], device=dev)
     with pytest.raises((ValueError, RuntimeError, torch.jit.Error), match="charge values"):
         be.calculate_features(batch)
+
+
+def test_system_conditioning_batch_independence(rt, golden_dir):
+    """pet/tests/test_conditioning.py:195-218: changing the charge / multiplicity of one system of a batch does not
+    touch the other system's atoms (bit for bit here) and does change its own."""
+    dev = torch.device("cuda:0")
+    hypers, g = _conditioning_case(golden_dir, "feedforward")
+    params = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    m = rt.HipModel(hypers, TYPES)
+    m.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    t = lambda k, dt=None: torch.tensor(g[k]).to(dev) if dt is None else torch.tensor(g[k]).to(dev, dt)  # noqa: E731
+    graph = rt.HipGraph(m, t("in_positions", torch.float32), t("in_cells", torch.float32), t("in_centers"), t("in_neighbors"),
+                        t("in_cell_shifts"), t("in_species"), t("in_system_indices", torch.int32))
+    out = []
+    for charge, spin in (([0, 1], [1, 1]), ([0, 3], [1, 2])):
+        graph.set_conditioning(torch.tensor(charge), torch.tensor(spin))
+        out.append(rt.HipForward(m, graph).forward())
+    first = (t("in_system_indices") == 0)
+    assert torch.equal(out[0][first], out[1][first])
+    assert float((out[0][~first] - out[1][~first]).abs().max()) > 1e-4

@@ -296,3 +296,18 @@ def test_oracle_system_conditioning_matches_reference(golden_dir, tag):
         params, hypers, t("in_positions"), t("in_cells"), t("in_centers"), t("in_neighbors"), t("in_cell_shifts").long(),
         t("in_species"), t("in_system_indices"))
     assert float((e0 - e).abs().max()) > 1e-3
+
+
+def test_oracle_reproduces_the_reference_tests_hand_tables_of_the_grid_method(golden_dir):
+    """The two known-answer tables of the reference's own adaptive-cutoff tests (pet/tests/test_adaptive_cutoff.py:
+    232-292: smoothed neighbour counts on a probe grid, Gaussian probe weights), torch.allclose as there."""
+    import json
+
+    kat = json.load(open(os.path.join(golden_dir, "reference_known_answers.json")))
+    a = kat["effective_num_neighbors"]
+    n_eff = opet.grid_effective_num_neighbors(torch.tensor(a["edge_distances"]), torch.tensor(a["probe_cutoffs"]),
+                                              torch.tensor(a["centers"]), a["num_nodes"], a["width"])
+    assert torch.allclose(n_eff, torch.tensor(a["expected"]))
+    b = kat["gaussian_cutoff_weights"]
+    w = opet.grid_gaussian_weights(torch.tensor(b["effective_num_neighbors"]), b["num_neighbors_adaptive"])
+    assert torch.allclose(w, torch.tensor(b["expected"]))
