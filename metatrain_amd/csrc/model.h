@@ -202,6 +202,8 @@ void set_tile_mask(int v);
 int tile_mask();
 void set_f16x3(int v);        // pet_trr.hip: 1 = f16x3 GEMMs where built (default), 0 = bf16x6
 void set_trr_compress(int v);
+void set_node_planes(int v);  // pet_fwd.hip / pet_bwd.hip: node-row kernels on pre-split fp16 planes (default 1)
+bool node_planes();
 void set_line_stores(int v);  // pet_trr.hip: bit 0 qkv, bit 1 edge MLP store whole 128-B lines through LDS (default 3)
 struct Graph;
 bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* Min, float* a0_out, float* Xout, int64_t E,

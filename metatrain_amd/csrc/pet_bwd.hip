@@ -399,6 +399,87 @@ __global__ __launch_bounds__(NTHREADS) void k_swiglu_bwd(const float* __restrict
     });
 }
 
+// The node-row instance (K = 256, hidden 512) rebuilt like k_node2 (pet_fwd.hip): the dY tile is scaled per row by a
+// power of two (adjoint rows have any magnitude) and split ONCE into fp16 planes for the four du chunk GEMMs, all products
+// on the 16-bit matrix cores (the fp32-MFMA form above spends 46 % of its time in the matrix pipe: 64 cycles per 2 k),
+// everything between the two scalings stays in scaled units; the saved pre-activations arrive as float4 rows through
+// wave-private staging tiles. Inference only (no weight-gradient exports).
+__global__ __launch_bounds__(NTHREADS) void k_node_bwd2(const float* __restrict__ dY, const float* __restrict__ Xin,
+                                                         const float* __restrict__ VG, const float* __restrict__ gamma,
+                                                         WX woutb, WX winb, float* __restrict__ dXout, int64_t R, bool ln) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int K = 256, HID = DNF, LDK = lds_ld(K), LDH = plane_ld(K);
+    float* A = smem;                                               // [64][260] dY tile; at the end w = gamma * dn
+    float* U = smem;                                               // [64][132] dv / dg chunk (aliases A while A is dead)
+    float* stage = smem + BM * LD128;                              // 4 x [32][64] staging tiles (behind U, inside A)
+    _Float16* Ph = reinterpret_cast<_Float16*>(smem + BM * LDK);   // [64][264] planes of the scaled dY rows
+    _Float16* Pl = Ph + BM * LDH;
+    float* rs = smem + BM * LDK + BM * LDH;                        // [64][2] scale, inverse
+    const WaveId w;
+    float* my_stage = stage + w.wave * (32 * 64);
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int64_t wrow0 = row0 + 32 * w.rb;
+    load_rows_to_lds<K>(A, dY, row0, R, K);
+    __syncthreads();
+    tile_row_scales<K>(A, LDK, rs);
+    __syncthreads();
+    split_tile_planes_scaled<K>(A, LDK, rs, Ph, Pl);
+    __syncthreads();  // A is dead until the epilogue
+    f32x16 dn[4];
+    acc_fill_bias<4>(dn, nullptr, 0, w.lane);
+#pragma unroll 1
+    for (int hc = 0; hc < HID / 128; hc++) {
+        f32x16 du[2];
+        acc_fill_bias<2>(du, nullptr, 0, w.lane);
+        gemm_acc_hs<K, 2, 8>(Ph + w.rb * 32 * LDH, Pl + w.rb * 32 * LDH, LDH, woutb, K / 8, 0, 4 * hc + 2 * w.ch, du, w.lane);
+        const int hcol0 = 128 * hc + 64 * w.ch;
+        float sg[2][16], vv[2][16];
+        auto vg_rows = [&](int off) {
+            return [&, off](int r, int cc, float4& v) {
+                v = wrow0 + r < R ? *reinterpret_cast<const float4*>(VG + (wrow0 + r) * (2 * HID) + off + hcol0 + cc)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            };
+        };
+        wave_load_rows64(my_stage, w.lane, vg_rows(0));
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) vv[t][r] = my_stage[acc_row(r, w.lane) * 64 + 32 * t + (w.lane & 31)];
+        __builtin_amdgcn_wave_barrier();
+        wave_load_rows64(my_stage, w.lane, vg_rows(HID));
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) sg[t][r] = sigmoidf_(my_stage[acc_row(r, w.lane) * 64 + 32 * t + (w.lane & 31)]);
+        __builtin_amdgcn_wave_barrier();
+        __syncthreads();  // the previous chunk's readers of U are done
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                U[(w.rb * 32 + acc_row(r, w.lane)) * LD128 + 64 * w.ch + 32 * t + (w.lane & 31)] = du[t][r] * sg[t][r];  // dv
+        __syncthreads();
+        gemm_acc_x<128, 4>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, 16 * hc, 4 * w.ch, dn, w.lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                U[(w.rb * 32 + acc_row(r, w.lane)) * LD128 + 64 * w.ch + 32 * t + (w.lane & 31)] =
+                    du[t][r] * vv[t][r] * sigmoid_grad_from(sg[t][r]);  // dg
+        __syncthreads();
+        gemm_acc_x<128, 4>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, HID / 8 + 16 * hc, 4 * w.ch, dn, w.lane);
+    }
+    __syncthreads();  // everyone is done with U: A takes w = gamma * dn (back in true units)
+    acc_foreach<4>(dn, w.rb, 128 * w.ch, w.lane, [&](int r, int c, float v) { A[r * LDK + c] = v * rs[2 * r + 1] * gamma[c]; });
+    __syncthreads();
+    norm_bwd_rows<K>(A, Xin, row0, R, K, ln, [&](int r, int c, float4 dx) {
+        const int64_t o = (row0 + r) * K + c;
+        const float4 dy = *reinterpret_cast<const float4*>(dY + o);
+        *reinterpret_cast<float4*>(dXout + o) = make_float4(dy.x + dx.x, dy.y + dx.y, dy.z + dx.z, dy.w + dx.w);
+    });
+}
+
 // ---------------------------------------------------------------------------------
 // node chain adjoint, second half: dOC = dH1 Wce ; (dH_in = dH1 is finished by k_center_bwd)
 // ---------------------------------------------------------------------------------
@@ -1125,6 +1206,12 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             // dX (edge rows) = grad wrt the edge MLP output; dH = grad wrt Hn
             {
                 ProfScope ps("node_bwd", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
+                const WX wob = wx_b(A.cmlp_out), wib = wx_b(A.cmlp_in);
+                if (!tr && node_planes() && wob.h && wib.h) {
+                    const size_t lds_nb = (size_t)BM * LD256 * 4 + (size_t)2 * BM * plane_ld(256) * 2 + BM * 8;
+                    allow_big_lds(k_node_bwd2, lds_nb);
+                    k_node_bwd2<<<gN, NTHREADS, lds_nb, s2>>>(dH, Ab.H1, Ab.VGn, A.g_center, wob, wib, dH_alt, N, ln);
+                } else
                 PET_LAUNCH_TR(tr, k_swiglu_bwd, PET_TA(256, DNF), gN, (BM * LD256 + BM * LD128) * 4, s2,  dH, Ab.H1,
                     Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N, tr ? w.dVGn : nullptr, ln);
                 k_expand_bwd<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(dH_alt, A.ce.bwd, w.dOC, N);

@@ -142,6 +142,84 @@ __device__ __forceinline__ void gemm_acc_x(const float* As, int lda, const WX& w
             acc[t][r] += rscale ? v * rscale[2 * acc_row(r, lane) + 1] : v;
         }
 }
+// ---- the same product with the A tile ALREADY split: two fp16 planes [64][K + 8] in LDS, written once by
+// split_tile_planes (or directly by the stage that produces the tile). A stage that runs several GEMMs on one tile
+// (the node MLP: 16 column-chunk GEMMs on the same [64 x 256] rows) then splits each element once instead of once per
+// GEMM and per wave; the K loop is two ds_read_b128 and the MFMAs. Within every block of 16 k the planes hold k in the
+// order a lane consumes it (lane group g of gemm_acc_x takes k = 4 g + j and 8 + 4 g + j): plane_pos().
+__host__ __device__ constexpr int plane_ld(int K) { return K + 8; }
+__device__ __forceinline__ int plane_pos(int k) {
+    const int b = k & 15;
+    return (k & ~15) + (b < 4 ? b : (b < 8 ? b + 4 : (b < 12 ? b - 4 : b)));
+}
+// DEPTH weight blocks (K = 16 each) are in flight: at one wave per SIMD the L2 round trip (~1.5k cycles) has to be
+// covered by this wave's own MFMAs (96 cycles per block and tile).
+template <int KS, int NT, int DEPTH = 2>
+__device__ __forceinline__ void gemm_acc_hs(const _Float16* Ah, const _Float16* Al, int ldh, const WX& w, int kg_total,
+                                            int kg0, int tile0, f32x16 (&acc)[NT], int lane) {
+    constexpr int KB = KS / 16;
+    static_assert(KB % DEPTH == 0, "the ring index must be static");
+    const int kb_total = kg_total / 2, kb0 = kg0 / 2;
+    const int roff = (lane & 31) * ldh + (lane >> 5) * 8;
+    size_t base[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) base[t] = ((size_t)(tile0 + t) * kb_total + kb0) * 64 + lane;
+    f16x8_t wh[DEPTH][NT], wl[DEPTH][NT];
+#pragma unroll
+    for (int s = 0; s < DEPTH; s++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) { wh[s][t] = w.h[base[t] + s * 64]; wl[s][t] = w.l[base[t] + s * 64]; }
+    f32x16 ah[NT], al[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { ah[t][r] = 0.f; al[t][r] = 0.f; }
+#pragma unroll 1
+    for (int kb0i = 0; kb0i < KB; kb0i += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const int kb = kb0i + d;
+            const f16x8_t xh = *reinterpret_cast<const f16x8_t*>(Ah + roff + 16 * kb);
+            const f16x8_t xl = *reinterpret_cast<const f16x8_t*>(Al + roff + 16 * kb);
+#pragma unroll
+            for (int t = 0; t < NT; t++) al[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl[d][t], al[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) ah[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh[d][t], ah[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) al[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh[d][t], al[t], 0, 0, 0);
+            if (kb + DEPTH < KB)
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    wh[d][t] = w.h[base[t] + (kb + DEPTH) * 64];
+                    wl[d][t] = w.l[base[t] + (kb + DEPTH) * 64];
+                }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] += ah[t][r] + al[t][r] * (1.0f / 2048.0f);
+}
+// split one value into its two fp16 pieces (high piece, and the remainder scaled by 2^11: trr.h split2)
+__device__ __forceinline__ void split_hl(float v, _Float16& h, _Float16& l) {
+    h = (_Float16)v;
+    l = (_Float16)((v - (float)h) * 2048.0f);
+}
+// [64][K] fp32 tile (leading dimension lda) -> the two planes; 256 threads, four per row
+template <int K>
+__device__ __forceinline__ void split_tile_planes(const float* As, int lda, _Float16* Ah, _Float16* Al) {
+    constexpr int LDH = plane_ld(K);
+    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    for (int c = 4 * q; c < K; c += 16) {  // this thread: columns c .. c + 3, a run of four inside one block of 16
+        const float4 v = *reinterpret_cast<const float4*>(As + r * lda + c);
+        const int p = r * LDH + plane_pos(c);
+        _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
+        split_hl(v.x, h0, l0); split_hl(v.y, h1, l1); split_hl(v.z, h2, l2); split_hl(v.w, h3, l3);
+        Ah[p] = h0; Ah[p + 1] = h1; Ah[p + 2] = h2; Ah[p + 3] = h3;
+        Al[p] = l0; Al[p + 1] = l1; Al[p + 2] = l2; Al[p + 3] = l3;
+    }
+}
+
 // per-row power-of-two scales of a staged [64][K] tile: rs[2 r] = scale (row maximum into [1, 2)), rs[2 r + 1] = inverse
 template <int K>
 __device__ __forceinline__ void tile_row_scales(const float* As, int lda, float* rs) {
@@ -197,6 +275,71 @@ __device__ __forceinline__ void load_rows_to_lds(float* As, const float* __restr
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row0 + r < n_rows) v = *reinterpret_cast<const float4*>(G + (row0 + r) * ld_g + 4 * c);
         *reinterpret_cast<float4*>(As + r * LDA + 4 * c) = v;
+    }
+}
+
+// Cooperative store of a [64][K] fp32 LDS tile to global rows (the inverse of load_rows_to_lds): 512-B row segments.
+template <int K>
+__device__ __forceinline__ void store_rows_from_lds(const float* As, float* __restrict__ G, int64_t row0, int64_t n_rows,
+                                                    int ld_g) {
+    constexpr int C4 = K / 4;
+    constexpr int LDA = lds_ld(K);
+    for (int idx = threadIdx.x; idx < BM * C4; idx += NTHREADS) {
+        const int r = idx / C4, c = idx % C4;
+        if (row0 + r < n_rows)
+            *reinterpret_cast<float4*>(G + (row0 + r) * ld_g + 4 * c) = *reinterpret_cast<const float4*>(As + r * LDA + 4 * c);
+    }
+}
+
+// A wave's [32 rows x 64 columns] accumulator pair leaves through a wave-private [32][64] fp32 staging tile so that
+// the global stores are float4 rows (16 lanes per row, 4 rows per instruction) instead of one float per lane; f(row in
+// the wave's block, column offset 0..60 step 4, float4) does the store (and may add a residual it loads the same way).
+// No workgroup barrier: the LDS serves one wave's requests in order.
+template <class F>
+__device__ __forceinline__ void wave_rows64(const f32x16 (&acc)[2], float* stage, int lane, F f) {
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) stage[acc_row(r, lane) * 64 + 32 * t + (lane & 31)] = acc[t][r];
+    __builtin_amdgcn_wave_barrier();
+    const int rr = lane >> 4, cc = 4 * (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int r = 4 * j + rr;
+        f(r, cc, *reinterpret_cast<const float4*>(stage + r * 64 + cc));
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The inverse: f(row in the wave's block, column offset, float4&) LOADS whole float4 rows of a [32 x 64] block, which
+// then sit in the staging tile in row-major order; read element (acc_row(r, lane), 32 t + (lane & 31)) afterwards and
+// call __builtin_amdgcn_wave_barrier() before the tile is reused.
+template <class F>
+__device__ __forceinline__ void wave_load_rows64(float* stage, int lane, F f) {
+    const int rr = lane >> 4, cc = 4 * (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int r = 4 * j + rr;
+        float4 v;
+        f(r, cc, v);
+        *reinterpret_cast<float4*>(stage + r * 64 + cc) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// [64][K] fp32 tile -> planes, every row multiplied by its power-of-two scale rs[2 r] first (adjoint rows)
+template <int K>
+__device__ __forceinline__ void split_tile_planes_scaled(const float* As, int lda, const float* rs, _Float16* Ah,
+                                                         _Float16* Al) {
+    constexpr int LDH = plane_ld(K);
+    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const float sc = rs[2 * r];
+    for (int c = 4 * q; c < K; c += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(As + r * lda + c);
+        const int p = r * LDH + plane_pos(c);
+        _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
+        split_hl(v.x * sc, h0, l0); split_hl(v.y * sc, h1, l1); split_hl(v.z * sc, h2, l2); split_hl(v.w * sc, h3, l3);
+        Ah[p] = h0; Ah[p + 1] = h1; Ah[p + 2] = h2; Ah[p + 3] = h3;
+        Al[p] = l0; Al[p + 1] = l1; Al[p + 2] = l2; Al[p + 3] = l3;
     }
 }
 
