@@ -493,8 +493,10 @@ __global__ __launch_bounds__(NTHREADS) void k_expand_bwd(const float* __restrict
     f32x16 acc[2];
     acc_fill_bias<2>(acc, nullptr, 0, w.lane);
     gemm_acc<256, 2>(smem + w.rb * 32 * LD256, LD256, wceb, 32, 0, 2 * w.ch, acc, w.lane);
-    acc_foreach<2>(acc, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
-        if (row0 + r < N) dOC[(row0 + r) * D + c] = v;
+    __syncthreads();  // the dH1 tile is consumed: its memory stages the float4 row stores (tile.h wave_rows64)
+    const int64_t wrow0 = row0 + 32 * w.rb;
+    wave_rows64(acc, smem + w.wave * (32 * 64), w.lane, [&](int r, int cc, float4 v) {
+        if (wrow0 + r < N) *reinterpret_cast<float4*>(dOC + (wrow0 + r) * D + 64 * w.ch + cc) = v;
     });
 }
 
@@ -510,10 +512,19 @@ __global__ __launch_bounds__(NTHREADS) void k_center_bwd(const float* __restrict
     f32x16 acc[4];
     acc_fill_bias<4>(acc, nullptr, 0, w.lane);
     gemm_acc<128, 4>(smem + w.rb * 32 * LD128, LD128, wccb, 16, 0, 4 * w.ch, acc, w.lane);
-    acc_foreach<4>(acc, w.rb, 128 * w.ch, w.lane, [&](int r, int c, float v) {
-        const int64_t row = row0 + r;
-        if (row < N) dHin[row * DN + c] = dH1[row * DN + c] + v;
-    });
+    __syncthreads();  // the dC tile is consumed: its memory stages float4 row traffic (tile.h wave_rows64)
+    const int64_t wrow0 = row0 + 32 * w.rb;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const f32x16 pair[2] = {acc[2 * half], acc[2 * half + 1]};
+        wave_rows64(pair, smem + w.wave * (32 * 64), w.lane, [&](int r, int cc, float4 v) {
+            const int64_t row = wrow0 + r;
+            if (row >= N) return;
+            const int64_t o = row * DN + 128 * w.ch + 64 * half + cc;
+            const float4 d1 = *reinterpret_cast<const float4*>(dH1 + o);
+            *reinterpret_cast<float4*>(dHin + o) = make_float4(d1.x + v.x, d1.y + v.y, d1.z + v.z, d1.w + v.w);
+        });
+    }
 }
 
 // ---------------------------------------------------------------------------------
