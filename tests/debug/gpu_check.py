@@ -2,7 +2,7 @@
 import os, sys, time
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from metatrain_amd import runtime as rt
 from oracle import pet as opet, nl as onl
