@@ -272,3 +272,39 @@ def test_system_conditioning_batch_independence(rt, golden_dir):
     first = (t("in_system_indices") == 0)
     assert torch.equal(out[0][first], out[1][first])
     assert float((out[0][~first] - out[1][~first]).abs().max()) > 1e-4
+
+
+@pytest.mark.parametrize("tag", ["legacy", "conditioned"])
+def test_variants_beyond_65536_token_rows_against_the_oracle(rt, tag):
+    """The variant kernels at a size where row indices pass 2^16 (the compress-adjoint fault of DESIGN.md section 4a only
+    showed there): a 5 000-atom box, E + N > 100 000 token rows, energies and dE/dR against the fp64 oracle."""
+    from oracle import nl as onl
+
+    dev = torch.device("cuda:0")
+    delta = VARIANTS["legacy"] if tag == "legacy" else dict(system_conditioning=True, transformer_type="PostLN")
+    hypers = dict(opet.DEFAULT_HYPERS, **delta)
+    n = 5000
+    pos, z, cell = opet.random_box(n, seed=8)
+    i, j, s, _ = onl.neighbor_list(pos.double().numpy(), cell.double().numpy(), [True] * 3, hypers["cutoff"])
+    assert len(i) + n > 65536
+    sysidx = torch.zeros(n, dtype=torch.long)
+    charge, spin = torch.tensor([2]), torch.tensor([3])
+    p64 = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float64)
+    torch.set_num_threads(16)
+    _, g_ref, a_ref = opet.energy_and_gradient(p64, hypers, pos.double(), cell[None].double(), torch.tensor(i), torch.tensor(j),
+                                               torch.tensor(s).long(), z, sysidx, charge=charge, spin_multiplicity=spin)
+    m = rt.HipModel(hypers, TYPES)
+    m.load({k: v.to(dev) for k, v in opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32).items()}, "energy")
+    graph = rt.HipGraph(m, pos.to(dev), cell[None].to(dev), torch.tensor(i, device=dev), torch.tensor(j, device=dev),
+                        torch.tensor(s, device=dev), z.to(dev), sysidx.to(dev, torch.int32))
+    if hypers["system_conditioning"]:
+        graph.set_conditioning(charge, spin)
+    atomic, grad, _, _ = _energy_and_gradient(rt, m, graph)
+    ea, eg = relmax(atomic.cpu().numpy(), a_ref.numpy()), relmax(grad.cpu().numpy(), g_ref.numpy())
+    # yardstick: the same model evaluated by torch in fp32 (what the reference's own fp32 path delivers at this size)
+    p32 = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    _, g32, a32 = opet.energy_and_gradient(p32, hypers, pos, cell[None], torch.tensor(i), torch.tensor(j),
+                                           torch.tensor(s).long(), z, sysidx, charge=charge, spin_multiplicity=spin)
+    ra, rg = relmax(a32.numpy(), a_ref.numpy()), relmax(g32.numpy(), g_ref.numpy())
+    print(f"{tag}: per-atom energies {ea:.2e} (torch fp32: {ra:.2e}), gradient {eg:.2e} (torch fp32: {rg:.2e})")
+    assert ea < max(TOL, 2 * ra) and eg < max(TOL, 2 * rg), (ea, eg, ra, rg)
