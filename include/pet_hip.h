@@ -372,6 +372,9 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *   "trr_compress" bit mask of f16x3 TRR kernels replacing LDS-tile ones: 1 compress (+adjoint), 2 edge head (+adjoint),
  *                  4 node update (slower, off); default 3; 0 = LDS-tile kernels
  *   "trr_persist" 1 = persistent edge-MLP kernel with LDS-DMA prefetch of the next tile's rows (default)
+ *   "line_stores" bit mask: 1 = QKV projection, 2 = edge MLP write whole 128-B lines through a wave-private LDS tile
+ *                 (default 3; the other row kernels always do)
+ *   "node_planes" 1 = node-row kernels k_node2 / k_node_bwd2 (coalesced tiles, fp16 planes; default), 0 = k_node / k_swiglu_bwd
  *   "so_bf16x6"   the same choice for the generic GEMM of the second-order (training) pass
  *   "attn_lds"    attention kernels: 0 global-memory, 1 per-atom LDS-staged adjoint, 2 LDS-staged forward and
  *                 adjoint, 3 persistent LDS-DMA adjoint (default)
