@@ -345,6 +345,13 @@ int pet_backward_train2(const pet_model_t* m, const pet_graph_t* g, void* d_work
                         int64_t workspace_bytes, void* d_workspace2, int64_t workspace2_bytes,
                         const float* d_lambda_atomic, const float* d_nu_atomic, const float* d_u,
                         float* d_tangent_atomic, void* stream);
+/* The same with a tangent of the CELLS as well (a stress / strain-gradient term in the loss, utils/evaluate_model.py:
+ * 305-321: positions @ strain, cell @ strain under create_graph): the sweep runs along (dR, dcell) = (d_u [N,3],
+ * d_u_cell [S,3,3]) with u = dL/d(dE/dR), u_cell = dL/d(dE/dcell); d_u_cell = NULL is pet_backward_train2. */
+int pet_backward_train2_cell(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
+                             int64_t workspace_bytes, void* d_workspace2, int64_t workspace2_bytes,
+                             const float* d_lambda_atomic, const float* d_nu_atomic, const float* d_u,
+                             const float* d_u_cell, float* d_tangent_atomic, void* stream);
 /* Per-system sum (utils/sum_over_atoms.py:10-48): d_out[S] = sum_{atoms of s} d_atomic. */
 int pet_sum_over_atoms(const pet_graph_t* g, const float* d_atomic, float* d_out, void* stream);
 

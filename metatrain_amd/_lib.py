@@ -35,7 +35,7 @@ SYMBOLS = [
     "pet_model_num_readout_layers", "pet_forward_layers", "pet_backward_features_layers", "pet_graph_set_conditioning",
     "pet_model_zero_grad", "pet_model_get_grad", "pet_train_workspace_bytes", "pet_backward_train",
     "pet_model_get_param", "pet_model_flat_grad", "pet_adam_step", "pet_optimizer_state", "pet_model_tie_halves",
-    "pet_train2_workspace_bytes", "pet_backward_train2",
+    "pet_train2_workspace_bytes", "pet_backward_train2", "pet_backward_train2_cell",
     "pet_sum_over_atoms",
     "pet_profile_enable", "pet_profile_select", "pet_profile_reset", "pet_profile_report", "pet_config_set",
 ]
@@ -177,6 +177,7 @@ def load() -> ctypes.CDLL:
     lib.pet_train2_workspace_bytes.argtypes = [P, c_int64, c_int64]
     lib.pet_train2_workspace_bytes.restype = c_int64
     lib.pet_backward_train2.argtypes = [P, P, P, c_int64, P, c_int64, P, P, P, P, P]
+    lib.pet_backward_train2_cell.argtypes = [P, P, P, c_int64, P, c_int64, P, P, P, P, P, P]
     lib.pet_train_workspace_bytes.argtypes = [P, c_int64, c_int64]
     lib.pet_train_workspace_bytes.restype = c_int64
     lib.pet_backward_train.argtypes = [P, P, P, c_int64, P, P, P, P]

@@ -560,6 +560,17 @@ int pet_backward_train2(const pet_model_t* pm, const pet_graph_t* pg, void* d_wo
                            d_lambda_atomic, d_nu_atomic, d_u, d_tangent_atomic, (hipStream_t)stream);
 }
 
+int pet_backward_train2_cell(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
+                             void* d_workspace2, int64_t workspace2_bytes, const float* d_lambda_atomic,
+                             const float* d_nu_atomic, const float* d_u, const float* d_u_cell, float* d_tangent_atomic,
+                             void* stream) {
+    PET_REQUIRE(pm && pg && d_workspace && d_workspace2 && d_lambda_atomic && d_u, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
+    PET_REQUIRE(!d_u_cell || pg->g.shift, PET_ERR_ARGUMENT, "a cell tangent needs a pet_graph_build handle (cell shifts)");
+    return backward_train2(pm->m, pg->g, d_workspace, workspace_bytes, d_workspace2, workspace2_bytes,
+                           d_lambda_atomic, d_nu_atomic, d_u, d_tangent_atomic, (hipStream_t)stream, d_u_cell);
+}
+
 int64_t pet_nl_workspace_bytes(int64_t n_atoms) { return nl_workspace_bytes(n_atoms); }
 
 int pet_nl_build(const float* d_positions, const float* h_cell, const int32_t* h_pbc, int64_t n_atoms,

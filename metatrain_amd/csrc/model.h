@@ -173,7 +173,7 @@ int backward_train(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, c
 int64_t so_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges);
 int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, void* ws2, int64_t ws2_bytes,
                     const float* lambda_atomic, const float* nu_atomic, const float* u, float* tangent_atomic,
-                    hipStream_t st);
+                    hipStream_t st, const float* u_cell = nullptr);
 int backward_predict_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* grad_atomic,
                          float* g_node, float* g_edge, float* g_fc, hipStream_t st);
 int backward_features_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_node,

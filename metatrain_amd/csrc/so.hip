@@ -532,7 +532,9 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
 __global__ void k_adapt_rdot(const float* __restrict__ u, const int* __restrict__ rowptr0,
                              const int* __restrict__ perm0, const int* __restrict__ nbr0,
                              const float4* __restrict__ vin, const float* __restrict__ r_newton,
-                             const float* __restrict__ inv_dn, float* __restrict__ rdot, int N, float w) {
+                             const float* __restrict__ inv_dn, float* __restrict__ rdot, int N, float w,
+                             const float* __restrict__ ucell, const int* __restrict__ shift0,
+                             const int* __restrict__ sys) {
     const int gid = blockIdx.x * (blockDim.x / 16) + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
     const int a = gid < N ? gid : N - 1;
@@ -542,9 +544,15 @@ __global__ void k_adapt_rdot(const float* __restrict__ u, const int* __restrict_
         const float4 v = vin[perm0[q]];
         const int j = nbr0[q];
         const float nrm = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
-        const float dd = nrm > 0.f
-            ? (v.x * (u[3 * j] - u[3 * a]) + v.y * (u[3 * j + 1] - u[3 * a + 1]) + v.z * (u[3 * j + 2] - u[3 * a + 2])) / nrm
-            : 0.f;
+        float tx = u[3 * j] - u[3 * a], ty = u[3 * j + 1] - u[3 * a + 1], tz = u[3 * j + 2] - u[3 * a + 2];
+        if (ucell) {  // the cell moves too: v' += S . cell'
+            const float* c = ucell + 9 * sys[a];
+            const float sa = (float)shift0[3 * q], sb = (float)shift0[3 * q + 1], sc = (float)shift0[3 * q + 2];
+            tx += sa * c[0] + sb * c[3] + sc * c[6];
+            ty += sa * c[1] + sb * c[4] + sc * c[7];
+            tz += sa * c[2] + sb * c[5] + sc * c[8];
+        }
+        const float dd = nrm > 0.f ? (v.x * tx + v.y * ty + v.z * tz) / nrm : 0.f;
         s += cutoff_deriv_dev(v.w, r, w, PET_CUTOFF_BUMP) * dd;
     }
 #pragma unroll
@@ -556,11 +564,19 @@ __global__ void k_geom_jvp(const float* __restrict__ u, const int* __restrict__ 
                            const float4* __restrict__ geo, const float* __restrict__ d0, const float* __restrict__ fc,
                            float4* __restrict__ Tgeo, float* __restrict__ Tfc, float* __restrict__ Tkb, int64_t E,
                            float cutoff, float width, int fn, const float* __restrict__ pc,
-                           const float* __restrict__ rdot) {
+                           const float* __restrict__ rdot, const float* __restrict__ ucell,
+                           const int* __restrict__ shift, const int* __restrict__ sys) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= E) return;
     const int i = ctr[p], j = nbr[p];
-    const float vx = u[3 * j] - u[3 * i], vy = u[3 * j + 1] - u[3 * i + 1], vz = u[3 * j + 2] - u[3 * i + 2];
+    float vx = u[3 * j] - u[3 * i], vy = u[3 * j + 1] - u[3 * i + 1], vz = u[3 * j + 2] - u[3 * i + 2];
+    if (ucell) {  // tangent of the cell (a stress term in the loss): v = r_j - r_i + S . cell, so v' += S . cell'
+        const float* c = ucell + 9 * sys[i];
+        const float sa = (float)shift[3 * p], sb = (float)shift[3 * p + 1], sc = (float)shift[3 * p + 2];
+        vx += sa * c[0] + sb * c[3] + sc * c[6];
+        vy += sa * c[1] + sb * c[4] + sc * c[7];
+        vz += sa * c[2] + sb * c[5] + sc * c[8];
+    }
     const float4 g = geo[p];
     const float vd = g.x * vx + g.y * vy + g.z * vz;
     const float nrm = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
@@ -1211,7 +1227,8 @@ static void head_reverse(const Ctx& c, Trainer& tr, SoWs& s, bool edge, const Li
 // driver
 // ---------------------------------------------------------------------------------------------
 int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, void* ws2, int64_t ws2_bytes,
-                    const float* lA, const float* nA, const float* u, float* tangent_atomic, hipStream_t st) {
+                    const float* lA, const float* nA, const float* u, float* tangent_atomic, hipStream_t st,
+                    const float* ucell) {
     PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
     PET_REQUIRE(m.plain(), PET_ERR_UNSUPPORTED,
                 "training is built for normalization=RMSNorm, transformer_type=PreLN, featurizer_type=feedforward only");
@@ -1241,10 +1258,10 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
     // =========================== tangent sweep ===========================
     if (g.adaptive)  // g.ad_gr doubles as the tangent of the atomic cutoffs
         k_adapt_rdot<<<cdiv(N, 16), 256, 0, st>>>(u, g.rowptr0, g.perm0, g.nbr0, g.vin, g.r_newton, g.inv_dn, g.ad_gr,
-                                                  (int)N, m.h.cutoff_width_adaptive);
+                                                  (int)N, m.h.cutoff_width_adaptive, ucell, g.shift0, g.sys);
     k_geom_jvp<<<grid1(E), 256, 0, st>>>(u, g.ctr, g.nbr, g.geo, g.d0, g.fc, reinterpret_cast<float4*>(s.Tgeo), s.Tfc,
                                         s.Tkb, E, m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function,
-                                        g.adaptive ? g.pc : nullptr, g.adaptive ? g.ad_gr : nullptr);
+                                        g.adaptive ? g.pc : nullptr, g.adaptive ? g.ad_gr : nullptr, ucell, g.shift, g.sys);
     PET_HIP_CHECK(hipMemsetAsync(s.TH0, 0, N * DN * sizeof(float), st));  // embeddings do not move with R
     PET_HIP_CHECK(hipMemsetAsync(s.TM0, 0, E * D * sizeof(float), st));
     for (int gi = 0; gi < nG; gi++) {

@@ -31,8 +31,7 @@ variants older checkpoints use -- ``normalization = "LayerNorm"``, ``transformer
 "residual"`` (``pet/checkpoints.py:190-205``) -- run for inference and forces; training is built for the default
 architecture only; both adaptive-cutoff methods ("solver", and the legacy "grid" for inference / forces / energy-only
 training); system conditioning (charge / spin multiplicity, inference + forces). Not built (raise loudly): diagnostic
-capture, double backward through the three inference nodes, stress (strain) terms in a training loss, training of the
-variants.
+capture, double backward through the three inference nodes, training of the variants.
 """
 from math import prod
 from typing import Dict, List, Optional, Tuple
@@ -272,12 +271,15 @@ class _EnergyGradFn(torch.autograd.Function):
         h = ctx.hctx
         model, fw = h.model, h.train_fwd
         n_in = 5 + len(ctx.keys)
-        if u_cell is not None and bool((u_cell != 0).any()):
-            raise PetHipError("a training loss on dE/dcell (stress) needs the strain second-order terms: not built")
-        if u_pos is None:
+        if u_pos is None and u_cell is None:
             return (None,) * n_in
         model.zero_grad()
-        tan = fw.backward_train2(ctx.ga, None, u_pos.detach().float().contiguous(), want_tangent=True)
+        up = (torch.zeros((fw.graph.n_nodes, 3), device=ctx.ga.device) if u_pos is None
+              else u_pos.detach().float().contiguous())
+        # a loss on dE/dcell (the stress / strain-gradient term of utils/evaluate_model.py:305-321) rides along as the
+        # tangent of the cells
+        uc = None if u_cell is None else u_cell.detach().float().contiguous()
+        tan = fw.backward_train2(ctx.ga, None, up, want_tangent=True, u_cell=uc)
         grads = model.grads()
         gtheta = tuple(grads[k].to(dt) for k, dt in zip(ctx.keys, ctx.param_dtypes))
         return (None, None, tan[:, None], None, None) + gtheta

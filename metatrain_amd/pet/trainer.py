@@ -53,6 +53,24 @@ def force_loss_and_seeds(grad_positions: torch.Tensor, target_gradients: torch.T
     return loss, weight * 2.0 * diff / diff.numel()
 
 
+def strain_loss_and_seeds(positions: torch.Tensor, cells: torch.Tensor, system_of_atom: torch.Tensor,
+                          grad_positions: torch.Tensor, grad_cells: torch.Tensor, target_strain_gradients: torch.Tensor,
+                          weight: float = 1.0):
+    """The strain derivative of ``utils/evaluate_model.py:305-321`` (``positions @ strain``, ``cell @ strain``, gradient at
+    strain = 1) from dE/dR and dE/dcell: ``dE/deps[s] = R_s^T dE/dR_s + cell_s^T dE/dcell_s`` ``[S,3,3]``; MSE (mean over
+    the 9 S components) against the targets and the seeds ``u = dL/d(dE/dR)`` ``[N,3]``, ``u_cell = dL/d(dE/dcell)``
+    ``[S,3,3]`` of the second-order pass. ``[S]``-sized torch arithmetic."""
+    n_sys = cells.shape[0]
+    virial = torch.zeros((n_sys, 3, 3), dtype=grad_positions.dtype, device=grad_positions.device)
+    virial.index_add_(0, system_of_atom, positions[:, :, None] * grad_positions[:, None, :])
+    virial = virial + cells.transpose(1, 2) @ grad_cells
+    diff = virial - target_strain_gradients
+    loss = weight * (diff * diff).mean()
+    g = weight * 2.0 * diff / diff.numel()                       # dL/d(dE/deps)
+    u = (positions[:, None, :] @ g[system_of_atom]).squeeze(1)    # d(dE/deps_ab)/d(gR_ib) = R_ia
+    return loss, u, cells @ g
+
+
 class TrainStep:
     """One optimizer step on one batch (a ``HipGraph`` of several structures)."""
 
@@ -81,22 +99,38 @@ class TrainStep:
         return h["learning_rate"] * lr_lambda(self.step_index, self.total_steps, h["warmup_fraction"])
 
     def __call__(self, graph: HipGraph, fw: HipForward, target_energies: torch.Tensor,
-                 n_atoms: torch.Tensor, target_gradients: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        """``target_gradients`` [N,3] = dE/dR targets (-forces); None trains on energies only."""
+                 n_atoms: torch.Tensor, target_gradients: Optional[torch.Tensor] = None,
+                 target_strain_gradients: Optional[torch.Tensor] = None, positions: Optional[torch.Tensor] = None,
+                 cells: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """``target_gradients`` [N,3] = dE/dR targets (-forces); None trains on energies only.
+        ``target_strain_gradients`` [S,3,3] = dE/dstrain targets (stress x volume; needs ``positions`` and ``cells``,
+        weight ``loss_weights["strain"]``, default 1)."""
         m = self.model
         m.zero_grad()
         atomic = fw.forward()
         energies = fw.sum_over_atoms(atomic)
         loss, seeds = energy_loss_and_seeds(energies, target_energies, n_atoms, graph.system_of_atom(),
                                             self.hypers["loss_weights"]["energy"])
-        if target_gradients is None:
+        if target_gradients is None and target_strain_gradients is None:
             fw.backward_train(seeds)
         else:
             ones = torch.ones_like(atomic)
-            grad_positions = fw.backward(ones)  # evaluate_model: autograd.grad(E.sum(), R, create_graph=True)
-            loss_f, u = force_loss_and_seeds(grad_positions, target_gradients, self.hypers["loss_weights"]["forces"])
-            loss = loss + loss_f
-            fw.backward_train2(ones, seeds, u)
+            # evaluate_model: autograd.grad(E.sum(), [R, strain], create_graph=True)
+            grad_positions, grad_cells = fw.backward(ones, want_cell_grad=True)
+            u = torch.zeros_like(grad_positions)
+            u_cell = None
+            if target_gradients is not None:
+                loss_f, u = force_loss_and_seeds(grad_positions, target_gradients, self.hypers["loss_weights"]["forces"])
+                loss = loss + loss_f
+            if target_strain_gradients is not None:
+                if positions is None or cells is None:
+                    raise ValueError("a strain-gradient (stress) target needs `positions` and `cells`")
+                loss_s, u_s, u_cell = strain_loss_and_seeds(
+                    positions.to(torch.float32), cells.to(torch.float32), graph.system_of_atom().long(), grad_positions,
+                    grad_cells, target_strain_gradients, self.hypers["loss_weights"].get("strain", 1.0))
+                loss = loss + loss_s
+                u = u + u_s
+            fw.backward_train2(ones, seeds, u, u_cell=u_cell)
         D.all_reduce_gradients(m)
         norm = m.adam_step(self.current_lr(), self.step_index + 1, weight_decay=self.hypers["weight_decay"],
                            max_grad_norm=self.hypers["grad_clip_norm"] or 0.0)

@@ -490,9 +490,10 @@ class HipForward:
         return gpos
 
     def backward_train2(self, lambda_atomic: torch.Tensor, nu_atomic: Optional[torch.Tensor], u: torch.Tensor,
-                        want_tangent: bool = False):
-        """Second-order reverse pass (loss on dE/dR): accumulates d/dtheta [ sum_i nu_i E_i + <u, dE/dR> ]
-        where dE/dR was taken with seeds ``lambda_atomic``; optionally returns dE_i/d(eps) along dR = u."""
+                        want_tangent: bool = False, u_cell: Optional[torch.Tensor] = None):
+        """Second-order reverse pass (loss on dE/dR, and with ``u_cell`` [S,3,3] on dE/dcell: the stress term):
+        accumulates d/dtheta [ sum_i nu_i E_i + <u, dE/dR> + <u_cell, dE/dcell> ] where the gradients were taken with
+        seeds ``lambda_atomic``; optionally returns dE_i/d(eps) along (dR, dcell) = (u, u_cell)."""
         if not self.train:
             raise PetHipError("backward_train2 needs HipForward(..., train=True)")
         g = self.graph
@@ -505,9 +506,10 @@ class HipForward:
         nu = None if nu_atomic is None else nu_atomic.to(torch.float32).contiguous()
         uu = u.to(torch.float32).contiguous()
         tan = torch.empty(g.n_nodes, dtype=torch.float32, device=dev) if want_tangent else None
-        check(self.lib.pet_backward_train2(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes,
-                                           _ptr(self.workspace2), self.workspace2.numel(), _ptr(la), _ptr(nu),
-                                           _ptr(uu), _ptr(tan), _stream()))
+        uc = None if u_cell is None else u_cell.to(dev, torch.float32).reshape(g.n_systems, 3, 3).contiguous()
+        check(self.lib.pet_backward_train2_cell(self.model.handle, g.handle, _ptr(self.workspace), self.nbytes,
+                                                _ptr(self.workspace2), self.workspace2.numel(), _ptr(la), _ptr(nu),
+                                                _ptr(uu), _ptr(uc), _ptr(tan), _stream()))
         return tan
 
     def sum_over_atoms(self, atomic: torch.Tensor) -> torch.Tensor:

@@ -409,3 +409,64 @@ def test_scripted_backend_equals_eager_and_survives_save_load(dev):
     ref = opet.pet_atomic_energies(params, hypers, r, cell[None].double(), i.cpu(), j.cpu(), s.cpu().long(), z, sysidx.cpu())
     (gr,) = torch.autograd.grad(ref.sum(), r)
     assert relmax(e1.cpu().numpy(), ref.detach().numpy()) < TOL and relmax(g1.cpu().numpy(), gr.numpy()) < TOL
+
+
+def test_training_through_the_mirror_with_a_stress_term(golden_dir):
+    """The reference's strain trick under create_graph (utils/evaluate_model.py:305-321: positions @ strain, cell @ strain,
+    gradient w.r.t. strain) through the mirror in train() mode, a loss on energies, dE/dR and dE/dstrain,
+    loss.backward() -> parameter.grad; against the fp64 oracle's double backward."""
+    from metatrain_amd.pet import PETBackend, default_hypers
+
+    dev = torch.device("cuda:0")
+    g = dict(np.load(os.path.join(golden_dir, "batch_two_systems.npz")))
+    t = lambda k: torch.tensor(g[k])  # noqa: E731
+    hypers, types = default_hypers(), [1, 6, 7, 8]
+    params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    sys_cpu = t("in_system_indices").long()
+    n, n_sys = len(sys_cpu), int(sys_cpu.max()) + 1
+    gen = torch.Generator().manual_seed(9)
+    tgt_g, tgt_s = 0.3 * torch.randn(n, 3, generator=gen), torch.randn(n_sys, 3, 3, generator=gen)
+
+    def loss_of(backend_like, dtype, device):
+        pos0 = t("in_positions").to(device, dtype).requires_grad_(True)
+        strain = torch.eye(3, dtype=dtype, device=device).repeat(n_sys, 1, 1).requires_grad_(True)
+        sysidx = sys_cpu.to(device)
+        pos = (pos0[:, None, :] @ strain[sysidx]).squeeze(1)
+        cells = t("in_cells").to(device, dtype) @ strain
+        atomic = backend_like(pos, cells, sysidx)
+        g_pos, g_strain = torch.autograd.grad(atomic.sum(), [pos0, strain], create_graph=True)
+        return (atomic.sum() ** 2 * 1e-3 + ((g_pos - tgt_g.to(device, dtype)) ** 2).sum()
+                + ((g_strain - tgt_s.to(device, dtype)) ** 2).sum())
+
+    be = PETBackend(hypers, types)
+    be.add_output("energy", {"energy": [1]})
+    be.load_state_dict(params, strict=True)
+    be = be.to(dev)
+
+    def hip(pos, cells, sysidx):
+        batch = be.preprocess(pos, t("in_centers").to(dev), t("in_neighbors").to(dev), t("in_species").to(dev), cells,
+                              t("in_cell_shifts").to(dev), sysidx, 1.0)
+        nf, ef = be.calculate_features(batch)
+        return be.predict(nf, ef, batch, cells, sysidx, ["energy"])[0]["energy"][0][:, 0]
+
+    loss = loss_of(hip, torch.float32, dev)
+    loss.backward()
+    p64 = {k: (v if k == "species_to_species_index" else v.double().clone().requires_grad_(True)) for k, v in params.items()}
+
+    def oracle(pos, cells, sysidx):
+        return opet.pet_atomic_energies(p64, hypers, pos, cells, t("in_centers"), t("in_neighbors"), t("in_cell_shifts"),
+                                        t("in_species"), sysidx, "energy")[:, 0]
+
+    l_ref = loss_of(oracle, torch.float64, torch.device("cpu"))
+    keys = [k for k in p64 if k != "species_to_species_index"]
+    ref = dict(zip(keys, torch.autograd.grad(l_ref, [p64[k] for k in keys], allow_unused=True)))
+    assert abs(float(loss) - float(l_ref)) / abs(float(l_ref)) < 1e-5
+    named = dict(be.named_parameters())
+    worst = 0.0
+    for k in keys:
+        if ref[k] is None:
+            continue
+        scale = float(ref[k].abs().max())
+        if scale > 1e-12:
+            worst = max(worst, float((named[k].grad.cpu().double() - ref[k]).abs().max()) / scale)
+    assert worst < 2e-5, worst

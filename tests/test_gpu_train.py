@@ -388,3 +388,71 @@ def test_optimizer_state_round_trip_resumes_bit_identically(golden_dir):
     final_b = model_b.state_dict()
     assert float(out_a["loss"]) == float(out_b["loss"]) and torch.equal(out_a["grad_norm"], out_b["grad_norm"])
     assert all(torch.equal(final_a[k], final_b[k]) for k in final_a)
+
+
+def test_strain_loss_parameter_gradients_match_oracle_double_backward(golden_dir):
+    """A stress term in the training loss (utils/evaluate_model.py:305-321: positions @ strain, cell @ strain under
+    create_graph; MSE on dE/dstrain): the second-order pass with a tangent of the cells, and the step assembled by
+    TrainStep (energies + dE/dR + dE/dstrain), against torch's double backward through the fp64 oracle on a batch of two
+    systems (one triclinic)."""
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.pet.trainer import (energy_loss_and_seeds, force_loss_and_seeds, strain_loss_and_seeds)
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS)
+    types = [1, 6, 7, 8]
+    params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    inp = _inputs(golden_dir, "batch_two_systems.npz")
+    n, n_sys = inp["positions"].shape[0], inp["cells"].shape[0]
+    sysidx = inp["system_indices"].long()
+    n_atoms = torch.bincount(sysidx, minlength=n_sys).double()
+    gen = torch.Generator().manual_seed(5)
+    t_e = torch.randn(n_sys, generator=gen).double()
+    t_f = 0.3 * torch.randn(n, 3, generator=gen).double()
+    t_s = 2.0 * torch.randn(n_sys, 3, 3, generator=gen).double()
+
+    # ---- fp64 oracle: the reference's strain trick and loss.backward()
+    p64 = {k: (v if k == "species_to_species_index" else v.double().clone().requires_grad_(True)) for k, v in params.items()}
+    pos0, cells0 = inp["positions"].double(), inp["cells"].double()
+    strain = torch.eye(3, dtype=torch.float64).repeat(n_sys, 1, 1).requires_grad_(True)
+    posl = pos0.clone().requires_grad_(True)
+    pos_s = (posl[:, None, :] @ strain[sysidx]).squeeze(1)
+    cells_s = cells0 @ strain
+    atomic = opet.pet_atomic_energies(p64, hypers, pos_s, cells_s, inp["centers"], inp["neighbors"], inp["cell_shifts"],
+                                      inp["species"], sysidx, "energy")[:, 0]
+    energies = torch.zeros(n_sys, dtype=torch.float64).index_add(0, sysidx, atomic)
+    g_pos, g_strain = torch.autograd.grad(energies.sum(), [posl, strain], create_graph=True)
+    loss_ref = ((((energies - t_e) / n_atoms) ** 2).mean() + ((g_pos - t_f) ** 2).mean() + ((g_strain - t_s) ** 2).mean())
+    keys = [k for k in p64 if k != "species_to_species_index"]
+    grads = torch.autograd.grad(loss_ref, [p64[k] for k in keys], allow_unused=True)
+    ref = {k: (torch.zeros_like(p64[k]) if gr is None else gr) for k, gr in zip(keys, grads)}
+
+    # ---- HIP
+    model = rt.HipModel(hypers, types)
+    model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    posd, cellsd = pos0.float().to(dev), cells0.float().to(dev)
+    graph = rt.HipGraph(model, posd, cellsd, inp["centers"].to(dev), inp["neighbors"].to(dev), inp["cell_shifts"].to(dev),
+                        inp["species"].to(dev), inp["system_indices"].int().to(dev))
+    fw = rt.HipForward(model, graph, train=True)
+    model.zero_grad()
+    atomic_h = fw.forward()
+    e_h = fw.sum_over_atoms(atomic_h)
+    ones = torch.ones(n, device=dev)
+    gpos, gcell = fw.backward(ones, want_cell_grad=True)
+    soa = graph.system_of_atom()
+    loss_e, seeds = energy_loss_and_seeds(e_h, t_e.float().to(dev), n_atoms.float().to(dev), soa)
+    loss_f, u_f = force_loss_and_seeds(gpos, t_f.float().to(dev))
+    loss_s, u_s, u_cell = strain_loss_and_seeds(posd, cellsd, soa.long(), gpos, gcell, t_s.float().to(dev))
+    assert abs(float(loss_e + loss_f + loss_s) - float(loss_ref)) < 2e-5 * abs(float(loss_ref))
+    fw.backward_train2(ones, seeds, u_f + u_s, u_cell=u_cell)
+    got = model.grads()
+    worst = {}
+    for k, r in ref.items():
+        r = r.numpy()
+        scale = np.abs(r).max()
+        err = np.abs(got[k].cpu().numpy().astype(np.float64) - r).max()
+        worst[k] = err / scale if scale > 1e-12 else err
+    for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]:
+        print(f"{v:.3e}  {k}")
+    bad = {k: v for k, v in worst.items() if not v < 2e-5}
+    assert not bad, f"strain-loss parameter gradients off: {bad}"
