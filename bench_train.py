@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--boxes", type=int, default=64, help="boxes per GPU per step")
     ap.add_argument("--atoms", type=int, default=1000, help="atoms per box")
+    ap.add_argument("--micro", type=int, default=0,
+                    help="boxes per micro-batch (gradient accumulation, TrainStep.microbatched); 0 = the whole batch at once. "
+                         "BASELINE configs[3] per GPU: --boxes 64 --atoms 10000 --micro 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -92,26 +95,41 @@ def main():
     model = rt.HipModel(hypers, [1, 6, 7, 8])
     model.load({k: v.to(dev) for k, v in params.items()}, "energy")
 
-    pos_l, z_l, cell_l, pair_l, sys_l = [], [], [], [], []
-    for b, seed in enumerate(pdist.box_seeds(args.boxes, rank)):
-        pos, z, cell = random_box(args.atoms, seed=seed)
-        posd = pos.to(dev)
-        pairs, _ = rt.neighbor_list(posd, cell, [True] * 3, hypers["cutoff"])
-        pairs = pairs.clone()
-        pairs[:, 0:2] += b * args.atoms
-        pos_l.append(posd); z_l.append(z.to(dev)); cell_l.append(cell.to(dev)); pair_l.append(pairs)
-        sys_l.append(torch.full((args.atoms,), b, dtype=torch.int32, device=dev))
-    positions, species, cells = torch.cat(pos_l), torch.cat(z_l), torch.stack(cell_l)
-    pairs, sysidx = torch.cat(pair_l), torch.cat(sys_l)
-    n_atoms = args.boxes * args.atoms
-    graph = rt.HipGraph(model, positions, cells, pairs[:, 0].contiguous(), pairs[:, 1].contiguous(),
-                        pairs[:, 2:5].contiguous(), species, sysidx)
-    fw = rt.HipForward(model, graph, train=True)
     gen = torch.Generator().manual_seed(1234 + rank)
-    per_box = torch.full((args.boxes,), float(args.atoms), device=dev)
-    target_e = (torch.randn(args.boxes, generator=gen) * 0.1).to(dev) * per_box
-    target_g = (torch.randn(n_atoms, 3, generator=gen) * 0.1).to(dev)
-    step = TrainStep(model, {"warmup_fraction": 0.0, "num_epochs": 10**6})
+    micro = args.micro if args.micro > 0 else args.boxes
+    seeds = pdist.box_seeds(args.boxes, rank)
+    batches, n_edges = [], 0
+    for m0 in range(0, args.boxes, micro):
+        pos_l, z_l, cell_l, pair_l, sys_l = [], [], [], [], []
+        for b, seed in enumerate(seeds[m0:m0 + micro]):
+            pos, z, cell = random_box(args.atoms, seed=seed)
+            posd = pos.to(dev)
+            pairs, _ = rt.neighbor_list(posd, cell, [True] * 3, hypers["cutoff"])
+            pairs = pairs.clone()
+            pairs[:, 0:2] += b * args.atoms
+            pos_l.append(posd); z_l.append(z.to(dev)); cell_l.append(cell.to(dev)); pair_l.append(pairs)
+            sys_l.append(torch.full((args.atoms,), b, dtype=torch.int32, device=dev))
+        nb = len(pos_l)
+        pairs = torch.cat(pair_l)
+        graph = rt.HipGraph(model, torch.cat(pos_l), torch.stack(cell_l), pairs[:, 0].contiguous(), pairs[:, 1].contiguous(),
+                            pairs[:, 2:5].contiguous(), torch.cat(z_l), torch.cat(sys_l))
+        per_box = torch.full((nb,), float(args.atoms), device=dev)
+        batches.append(dict(graph=graph, target_energies=(torch.randn(nb, generator=gen) * 0.1).to(dev) * per_box,
+                            n_atoms=per_box, target_gradients=(torch.randn(nb * args.atoms, 3, generator=gen) * 0.1).to(dev)))
+        n_edges += int(graph.n_edges)
+    n_atoms = args.boxes * args.atoms
+    # ONE training workspace, sized for the largest micro-batch, walked by all of them
+    fw = rt.HipForward(model, max(batches, key=lambda b: b["graph"].n_edges)["graph"], train=True)
+    for b in batches:
+        b["fw"] = fw
+    train = TrainStep(model, {"warmup_fraction": 0.0, "num_epochs": 10**6})
+
+    def step(*_):
+        return train.microbatched(batches) if len(batches) > 1 else train(
+            batches[0]["graph"], fw, batches[0]["target_energies"], batches[0]["n_atoms"], batches[0]["target_gradients"])
+
+    target_e = per_box = target_g = None
+    graph = batches[0]["graph"]
 
     losses = []
     for _ in range(args.warmup):
@@ -139,10 +157,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic random periodic boxes and random targets, weights from a seeded generator",
             "config": {
-                "workload": f"PET training step, {args.boxes} x {args.atoms}-atom boxes per GPU per step, default PET "
+                "workload": f"PET training step, {args.boxes} x {args.atoms}-atom boxes per GPU per step"
+                            f"{f' in micro-batches of {micro} (gradient accumulation)' if len(batches) > 1 else ''}, default PET "
                             f"hypers (2.9M params), MSE(E/atom)+MSE(dE/dR), clip 1.0, Adam lr 1e-4",
                 "atoms_per_gpu_per_step": n_atoms,
-                "edges_per_gpu_per_step": int(graph.n_edges),
+                "edges_per_gpu_per_step": n_edges,
+                "micro_batches": len(batches),
                 "parallelism": f"boxes sharded over {world} rank(s); one 11.6 MB gradient all-reduce per step"
                                if world > 1 else "single GPU",
                 "loss_first_last": [ls[0], ls[-1]],

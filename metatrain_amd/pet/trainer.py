@@ -105,12 +105,53 @@ class TrainStep:
         """``target_gradients`` [N,3] = dE/dR targets (-forces); None trains on energies only.
         ``target_strain_gradients`` [S,3,3] = dE/dstrain targets (stress x volume; needs ``positions`` and ``cells``,
         weight ``loss_weights["strain"]``, default 1)."""
+        self.model.zero_grad()
+        loss, energies = self._accumulate(graph, fw, target_energies, n_atoms, target_gradients, target_strain_gradients,
+                                          positions, cells, 1.0, 1.0, 1.0)
+        norm = self._finish()
+        return {"loss": loss, "grad_norm": norm, "energies": energies}
+
+    def microbatched(self, batches) -> Dict[str, torch.Tensor]:
+        """ONE optimizer step over several micro-batches (gradient accumulation): the training workspace holds every
+        tangent of a batch (100 KB per edge), so a rank's share of a large batch -- BASELINE
+        ``configs[3]``: 64 x 10 000-atom boxes per GPU -- is walked a few boxes at a time. Each element of ``batches`` is a
+        dict with the arguments of :meth:`__call__` (``graph, fw, target_energies, n_atoms`` and optionally
+        ``target_gradients, target_strain_gradients, positions, cells``); the losses are the full batch's means
+        (``utils/loss.py`` "mean" reduction over ALL structures / components), so the result equals the one-batch step up
+        to fp32 summation order."""
+        batches = list(batches)
+        s_tot = float(sum(int(b["target_energies"].numel()) for b in batches))
+        n_tot = float(sum(int(b["graph"].n_nodes) for b in batches))
+        self.model.zero_grad()
+        loss, energies = None, []
+        for b in batches:
+            s_b, n_b = float(b["target_energies"].numel()), float(b["graph"].n_nodes)
+            l_b, e_b = self._accumulate(b["graph"], b["fw"], b["target_energies"], b["n_atoms"], b.get("target_gradients"),
+                                        b.get("target_strain_gradients"), b.get("positions"), b.get("cells"),
+                                        s_b / s_tot, n_b / n_tot, s_b / s_tot)
+            loss = l_b if loss is None else loss + l_b
+            energies.append(e_b)
+        norm = self._finish()
+        return {"loss": loss, "grad_norm": norm, "energies": torch.cat(energies)}
+
+    def _finish(self) -> torch.Tensor:
         m = self.model
-        m.zero_grad()
+        D.all_reduce_gradients(m)
+        norm = m.adam_step(self.current_lr(), self.step_index + 1, weight_decay=self.hypers["weight_decay"],
+                           max_grad_norm=self.hypers["grad_clip_norm"] or 0.0)
+        self.step_index += 1
+        return norm
+
+    def _accumulate(self, graph, fw, target_energies, n_atoms, target_gradients, target_strain_gradients, positions, cells,
+                    share_e: float, share_f: float, share_s: float):
+        """Forward + reverse passes of one (micro-)batch, parameter gradients ADDED to the model's slots; ``share_*`` =
+        this batch's fraction of the structures / force components / strain components of the whole step."""
+        w = self.hypers["loss_weights"]
+        if fw.graph is not graph:  # micro-batches may share one workspace allocation
+            fw.rebind(graph)
         atomic = fw.forward()
         energies = fw.sum_over_atoms(atomic)
-        loss, seeds = energy_loss_and_seeds(energies, target_energies, n_atoms, graph.system_of_atom(),
-                                            self.hypers["loss_weights"]["energy"])
+        loss, seeds = energy_loss_and_seeds(energies, target_energies, n_atoms, graph.system_of_atom(), w["energy"] * share_e)
         if target_gradients is None and target_strain_gradients is None:
             fw.backward_train(seeds)
         else:
@@ -120,19 +161,15 @@ class TrainStep:
             u = torch.zeros_like(grad_positions)
             u_cell = None
             if target_gradients is not None:
-                loss_f, u = force_loss_and_seeds(grad_positions, target_gradients, self.hypers["loss_weights"]["forces"])
+                loss_f, u = force_loss_and_seeds(grad_positions, target_gradients, w["forces"] * share_f)
                 loss = loss + loss_f
             if target_strain_gradients is not None:
                 if positions is None or cells is None:
                     raise ValueError("a strain-gradient (stress) target needs `positions` and `cells`")
                 loss_s, u_s, u_cell = strain_loss_and_seeds(
                     positions.to(torch.float32), cells.to(torch.float32), graph.system_of_atom().long(), grad_positions,
-                    grad_cells, target_strain_gradients, self.hypers["loss_weights"].get("strain", 1.0))
+                    grad_cells, target_strain_gradients, w.get("strain", 1.0) * share_s)
                 loss = loss + loss_s
                 u = u + u_s
             fw.backward_train2(ones, seeds, u, u_cell=u_cell)
-        D.all_reduce_gradients(m)
-        norm = m.adam_step(self.current_lr(), self.step_index + 1, weight_decay=self.hypers["weight_decay"],
-                           max_grad_norm=self.hypers["grad_clip_norm"] or 0.0)
-        self.step_index += 1
-        return {"loss": loss, "grad_norm": norm, "energies": energies}
+        return loss, energies

@@ -375,6 +375,15 @@ class HipForward:
         self.nbytes = nbytes
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=graph.workspace.device)
 
+    def rebind(self, graph: "HipGraph") -> "HipForward":
+        """Use this object's workspaces for another graph of the same model (micro-batches walk one allocation)."""
+        size_fn = self.lib.pet_train_workspace_bytes if self.train else self.lib.pet_forward_workspace_bytes
+        need = int(size_fn(self.model.handle, graph.n_nodes, graph.n_edges))
+        if need > self.nbytes:
+            raise PetHipError(f"workspace of {self.nbytes} bytes is too small for this graph ({need} bytes)")
+        self.graph = graph
+        return self
+
     def features(self):
         """``calculate_features`` alone (no heads): node ``[N, d_node]`` and edge ``[E, d_pet]`` (CSR rows) features,
         saved for :meth:`backward_features`."""
@@ -499,8 +508,8 @@ class HipForward:
         g = self.graph
         dev = self.workspace.device
         _require_cuda(lambda_atomic, u)
-        if getattr(self, "workspace2", None) is None:
-            n2 = int(self.lib.pet_train2_workspace_bytes(self.model.handle, g.n_nodes, g.n_edges))
+        n2 = int(self.lib.pet_train2_workspace_bytes(self.model.handle, g.n_nodes, g.n_edges))
+        if getattr(self, "workspace2", None) is None or self.workspace2.numel() < n2:
             self.workspace2 = torch.empty(n2, dtype=torch.uint8, device=dev)
         la = lambda_atomic.to(torch.float32).contiguous()
         nu = None if nu_atomic is None else nu_atomic.to(torch.float32).contiguous()

@@ -456,3 +456,57 @@ def test_strain_loss_parameter_gradients_match_oracle_double_backward(golden_dir
         print(f"{v:.3e}  {k}")
     bad = {k: v for k, v in worst.items() if not v < 2e-5}
     assert not bad, f"strain-loss parameter gradients off: {bad}"
+
+
+def test_microbatched_step_equals_the_one_batch_step(golden_dir):
+    """Gradient accumulation (TrainStep.microbatched; what lets a rank walk BASELINE configs[3]'s 64 x 10 000-atom share
+    a few boxes at a time): one optimizer step over the two systems of a batch taken one at a time gives the loss,
+    the pre-clip gradient norm and the updated weights of the step on the whole batch."""
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.pet.trainer import TrainStep
+
+    dev = torch.device("cuda:0")
+    hypers, types = dict(opet.DEFAULT_HYPERS), [1, 6, 7, 8]
+    params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    inp = _inputs(golden_dir, "batch_two_systems.npz")
+    sysidx = inp["system_indices"].long()
+    n = len(sysidx)
+    gen = torch.Generator().manual_seed(3)
+    t_e, t_f = torch.randn(2, generator=gen), 0.3 * torch.randn(n, 3, generator=gen)
+    t_s = torch.randn(2, 3, 3, generator=gen)
+
+    def graph_of(model, atoms):
+        """the sub-batch holding the atoms of `atoms` (a boolean mask over the batch), renumbered from zero"""
+        idx = torch.nonzero(atoms).squeeze(1)
+        remap = torch.full((n,), -1, dtype=torch.long)
+        remap[idx] = torch.arange(len(idx))
+        keep = atoms[inp["centers"].long()]
+        systems = torch.unique(sysidx[idx])
+        smap = torch.full((2,), -1, dtype=torch.long)
+        smap[systems] = torch.arange(len(systems))
+        pos, cells = inp["positions"].float()[idx].to(dev), inp["cells"].float()[systems].to(dev)
+        g = rt.HipGraph(model, pos, cells, remap[inp["centers"].long()[keep]].int().to(dev),
+                        remap[inp["neighbors"].long()[keep]].int().to(dev), inp["cell_shifts"][keep].to(dev),
+                        inp["species"][idx].to(dev), smap[sysidx[idx]].int().to(dev))
+        return dict(graph=g, fw=rt.HipForward(model, g, train=True), target_energies=t_e[systems].to(dev),
+                    n_atoms=torch.bincount(smap[sysidx[idx]]).float().to(dev), target_gradients=t_f[idx].to(dev),
+                    target_strain_gradients=t_s[systems].to(dev), positions=pos, cells=cells)
+
+    results = []
+    for split in (False, True):
+        model = rt.HipModel(hypers, types)
+        model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+        step = TrainStep(model, {"learning_rate": 1e-3, "warmup_fraction": 0.0, "num_epochs": 10**9})
+        if split:
+            out = step.microbatched([graph_of(model, sysidx == 0), graph_of(model, sysidx == 1)])
+        else:
+            b = graph_of(model, torch.ones(n, dtype=torch.bool))
+            out = step(b["graph"], b["fw"], b["target_energies"], b["n_atoms"], b["target_gradients"],
+                       b["target_strain_gradients"], b["positions"], b["cells"])
+        results.append((float(out["loss"]), float(out["grad_norm"]), out["energies"].cpu(), model.state_dict()))
+    (l0, g0, e0, w0), (l1, g1, e1, w1) = results
+    assert abs(l0 - l1) < 1e-5 * abs(l0) and abs(g0 - g1) < 1e-4 * g0
+    assert torch.allclose(e0, e1, rtol=1e-6, atol=1e-6)
+    for k in w0:
+        delta = (w0[k].cpu() - params[k]).abs().max()
+        assert float((w0[k] - w1[k]).abs().max()) <= 0.02 * float(delta) + 1e-9, k  # the two steps moved the weights alike
