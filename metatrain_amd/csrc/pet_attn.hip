@@ -53,6 +53,17 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Key-bias gradient of one 16-key tile. After the row sums every lane of a 16-lane row holds the four key values of
+// its g4 group; lanes c16 < 4 store one key each, so a wave writes the tile's 16 keys as one 64-byte run of the
+// attention layer's head-major slice [NHEAD, E]. Plain stores: each (layer, head, edge) has exactly one writer,
+// and k_dfc_attn sums the slices.
+__device__ __forceinline__ void store_key_bias(float* __restrict__ dbh, int64_t E, int head, int start, int T,
+                                               int kt, int g4, int c16, float v0, float v1, float v2, float v3) {
+    const float v = c16 == 0 ? v0 : c16 == 1 ? v1 : c16 == 2 ? v2 : v3;
+    const int key = 16 * kt + 4 * g4 + c16;
+    if (c16 < 4 && key >= 1 && key < T) dbh[(int64_t)head * E + start + key - 1] = v;
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void k_attn_fwd_p(const float* __restrict__ QKV, const int* __restrict__ rowptr,
                                                      const float* __restrict__ fc, float* __restrict__ AO,
@@ -232,12 +243,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QK
 #pragma unroll
     for (int kt = 0; kt < NT; kt++)
         if (kt < nt)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float v = row16_sum(db[kt][r]);
-                const int key = 16 * kt + 4 * g4 + r;
-                if (c16 == 0 && key >= 1 && key < T) dbias_h[(int64_t)(start + key - 1) * NHEAD + head] += v;
-            }
+            store_key_bias(dbias_h, E, head, start, T, kt, g4, c16, row16_sum(db[kt][0]), row16_sum(db[kt][1]),
+                           row16_sum(db[kt][2]), row16_sum(db[kt][3]));
     // ---- pass B: per key tile, plain scores (queries x keys): dK, dV
 #pragma unroll
     for (int kt = 0; kt < NT; kt++) {
@@ -837,12 +844,8 @@ __global__ __launch_bounds__(512) void k_attn_bwd_l(const float* __restrict__ QK
 #pragma unroll
     for (int kt = 0; kt < NT; kt++)
         if (kt < nt) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float v = row16_sum(db[kt][r]);
-                const int key = 16 * kt + 4 * g4 + r;
-                if (c16 == 0 && key >= 1 && key < T) dbias_h[(int64_t)(start + key - 1) * NHEAD + head] += v;
-            }
+            store_key_bias(dbias_h, E, head, start, T, kt, g4, c16, row16_sum(db[kt][0]), row16_sum(db[kt][1]),
+                           row16_sum(db[kt][2]), row16_sum(db[kt][3]));
             float* row = sm + (16 * kt + c16) * LDB;
             *reinterpret_cast<float4*>(row + ko + 4 * g4) =
                 make_float4(dk[kt][0] * scale, dk[kt][1] * scale, dk[kt][2] * scale, dk[kt][3] * scale);
@@ -1035,16 +1038,8 @@ __global__ __launch_bounds__(512) void k_attn_bwd_a(const float* __restrict__ QK
 #pragma unroll
         for (int kt = 0; kt < NT; kt++)
             if (kt < nt) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float v = row16_sum(db[kt][r]);
-                    const int key = 16 * kt + 4 * g4 + r;
-                    // sole owner of this (edge, head); the no-return atomic keeps a load (and its vmcnt wait, which
-                    // would also wait for the DMA) out of the compute phase
-                    if (c16 == 0 && key >= 1 && key < T)
-                        __hip_atomic_fetch_add(dbias_h + (int64_t)(start + key - 1) * NHEAD + head, v,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                store_key_bias(dbias_h, E, head, start, T, kt, g4, c16, row16_sum(db[kt][0]), row16_sum(db[kt][1]),
+                               row16_sum(db[kt][2]), row16_sum(db[kt][3]));
                 const int tk = 16 * kt + c16;
                 if (tk < T) {
                     float* out = dQKV + tok_row(tk, T, E, atom, start) * (3 * D);

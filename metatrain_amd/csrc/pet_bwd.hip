@@ -678,17 +678,22 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ QKV,
                     make_float4(dq[0] * scale, dq[1] * scale, dq[2] * scale, dq[3] * scale);
         }
     }
-    // key-bias gradient: sum over the 16 query columns, one writer per key
+    // key-bias gradient: sum over the 16 query columns; lanes c16 < 4 write one key each into the attention
+    // layer's head-major slice [NHEAD, E] (one writer per (layer, head, edge): plain stores, k_dfc_attn sums)
 #pragma unroll
     for (int kt = 0; kt < NT; kt++)
-        if (kt < nt)
+        if (kt < nt) {
+            float v4[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 float v = db[kt][r];
                 v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                const int key = 16 * kt + 4 * g4 + r;
-                if (c16 == 0 && key >= 1 && key < T) dbias_h[(int64_t)(start + key - 1) * NHEAD + head] += v;
+                v4[r] = v;
             }
+            const float v = c16 == 0 ? v4[0] : c16 == 1 ? v4[1] : c16 == 2 ? v4[2] : v4[3];
+            const int key = 16 * kt + 4 * g4 + c16;
+            if (c16 < 4 && key >= 1 && key < T) dbias_h[(int64_t)head * E + start + key - 1] = v;
+        }
     // ------------------------------ pass B ------------------------------
 #pragma unroll
     for (int kt = 0; kt < NT; kt++) {
@@ -877,13 +882,13 @@ __global__ __launch_bounds__(NTHREADS) void k_compress_bwd(const float* __restri
 // ---------------------------------------------------------------------------------
 // key-bias adjoint -> cutoff-factor gradient: bias = log(clamp(fc, 1e-15)), so the gradient
 // passes only where fc >= 1e-15 (transformer.py:109-110); heads and layers are summed here.
-__global__ void k_dfc_attn(const float* __restrict__ fc, const float* __restrict__ dbias_h,
+// dbias_l: one head-major slice [NHEAD, E] per attention layer, each written once by that layer's adjoint
+__global__ void k_dfc_attn(const float* __restrict__ fc, const float* __restrict__ dbias_l, int slices,
                            float* __restrict__ dfc_attn, int64_t E) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= E) return;
     float dbias = 0.f;
-#pragma unroll
-    for (int h = 0; h < NHEAD; h++) dbias += dbias_h[p * NHEAD + h];
+    for (int h = 0; h < slices * NHEAD; h++) dbias += dbias_l[(int64_t)h * E + p];
     const float f = fc[p];
     dfc_attn[p] = f >= 1e-15f ? dbias / f : 0.f;
 }
@@ -1155,11 +1160,9 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     const int gE = cdiv(E, BM), gN = cdiv(N, BM), gR = cdiv(R, BM);
     const size_t lds1 = BM * LD128 * 4, lds2 = 2 * BM * LD128 * 4;
     const double fE = (double)E, fN = (double)N, fR = (double)R;
-    float* dbias_h = w.delta;  // [E, NHEAD] (reuses the delta carve)
     const bool trr = use_trr();
     const bool trr_l = trr && m.plain_layers();  // the TRR transformer-layer kernels are RMSNorm + PreLN
     PET_HIP_CHECK(hipMemsetAsync(w.dgeo, 0, E * 4 * sizeof(float), st));
-    PET_HIP_CHECK(hipMemsetAsync(dbias_h, 0, E * NHEAD * sizeof(float), st));
     allow_big_lds(k_swiglu_bwd<256, DNF, false, true>, (BM * LD256 + BM * LD128) * 4);
     allow_big_lds(k_swiglu_bwd<256, DNF, true, true>, (BM * LD256 + BM * LD128) * 4);
     allow_big_lds(k_expand_bwd, BM * LD256 * 4);
@@ -1272,6 +1275,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             }
             {
                 ProfScope ps("attn_bwd", st, 2.0 * 4.0 * D * g_sum_t2(g), fR * 4.0 * (3 * D + D + 3 * D));
+                float* dbias_h = w.dbias_l + ((int64_t)gi * m.h.num_attention_layers + a) * NHEAD * E;
                 if (!(trr && attn_bwd_preload(nt, Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st))) switch (nt) {
                     case 1: launch_attn_bwd<1>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;
                     case 2: launch_attn_bwd<2>(Ab.QKV, w.dAO, g, w.dQKV, dbias_h, scale, st); break;
@@ -1323,7 +1327,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         tr->embeddings(dH, dM);
         if (tr->err) return tr->err;
     }
-    k_dfc_attn<<<cdiv(E, 256), 256, 0, st>>>(g.fc, dbias_h, w.dbias, E);
+    k_dfc_attn<<<cdiv(E, 256), 256, 0, st>>>(g.fc, w.dbias_l, m.h.num_gnn_layers * m.h.num_attention_layers, w.dbias, E);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }

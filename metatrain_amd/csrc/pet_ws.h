@@ -59,6 +59,7 @@ struct Workspace {
     float* dgeo = nullptr;    // [E, 4] accumulated d/d(vx,vy,vz,dist)
     float* dfc = nullptr;     // [E]
     float* dbias = nullptr;   // [E] attention key-bias gradient (summed over heads/layers)
+    float* dbias_l = nullptr; // [layers, NHEAD, E] key-bias gradient per attention layer, head-major
     float* delta = nullptr;   // [(E+N), NHEAD]
     float* lse = nullptr;     // [(E+N), NHEAD]
     float* dv = nullptr;      // [E, 4] d/d(edge vector)
@@ -138,6 +139,7 @@ inline void carve_workspace(const Model& m, int64_t N, int64_t E, void* base, Wo
     w.delta = c.take<float>(Ra * NHEAD);
     w.lse = c.take<float>(Ra * NHEAD);
     w.dv = c.take<float>(Ea * 4);
+    w.dbias_l = c.take<float>((int64_t)m.h.num_gnn_layers * m.h.num_attention_layers * NHEAD * Ea);
     // everything above is identical with and without `train`, so an inference backward can run on
     // a workspace carved for training
     for (auto& G : w.gnn)
