@@ -368,23 +368,21 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
 /* Runtime switches used by tests / the benchmark (every setting meets the same parity bar):
  *   "side_stream" 1 = node-feature chain on a second HIP stream (default)
  *   "trr"         1 = register-resident stage kernels (default); 0 = the LDS-tile kernels
- *   "bf16x6"      1 = TRR / combination GEMMs as split-operand products on the 16-bit matrix cores, fp32 accuracy
- *                 (default); 0 = fp32 MFMA
- *   "f16x3"       1 = 2-way fp16 split, three MFMAs per K block (default); 0 = 3-way bf16 split, six MFMAs
+ *                 (the one fallback generation; the TRR GEMMs are f16x3 split-operand products on the 16-bit matrix
+ *                 cores, fp32 accuracy; round 1's fp32-MFMA and bf16x6 TRR generations were removed in round 2)
  *   "tile_f16x3"  1 = the LDS-tile forward kernels (compress, centre, node update, heads) and the head adjoint on f16x3
  *                 (default); 0 = fp32 MFMA. "tile_mask" (debug): bits switch single GEMMs of those kernels back.
  *   "so_trr"       1 = generic training GEMMs with K = 128 or n_out = 128 as TRR kernels (default); 0 = LDS-tile k_gemm_h
  *   "emlp_recompute" 1 = the inference adjoint of the edge MLP rebuilds the SwiGLU pre-activations instead of reading
  *                 them back (less workspace traffic, slower adjoint); default 0
- *   "trr_compress" bit mask of f16x3 TRR kernels replacing LDS-tile ones: 1 compress (+adjoint), 2 edge head (+adjoint),
- *                  4 node update (slower, off); default 3; 0 = LDS-tile kernels
- *   "trr_persist" 1 = persistent edge-MLP kernel with LDS-DMA prefetch of the next tile's rows (default)
+ *   "trr_compress" bit mask of f16x3 TRR kernels replacing LDS-tile ones: 1 compress (+adjoint), 2 edge head (+adjoint);
+ *                  default 3; 0 = LDS-tile kernels
  *   "line_stores" bit mask: 1 = QKV projection, 2 = edge MLP write whole 128-B lines through a wave-private LDS tile
  *                 (default 3; the other row kernels always do)
  *   "node_planes" 1 = node-row kernels k_node2 / k_node_bwd2 (coalesced tiles, fp16 planes; default), 0 = k_node / k_swiglu_bwd
- *   "so_bf16x6"   the same choice for the generic GEMM of the second-order (training) pass
- *   "attn_lds"    attention kernels: 0 global-memory, 1 per-atom LDS-staged adjoint, 2 LDS-staged forward and
- *                 adjoint, 3 persistent LDS-DMA adjoint (default)
+ *   "so_f16x3"    1 = generic GEMMs of the second-order (training) pass as f16x3 (default); 0 = fp32 MFMA
+ *   "attn_lds"    attention adjoint: 1 per-atom LDS-staged for every atom, 3 persistent LDS-DMA kernel for atoms of at
+ *                 most 32 tokens (default)
  *   "soap_mfma"   1 = SOAP-BPNN LayerNorm + MLP tail on MFMA (default)
  *   "soap_fused"  1 = SOAP power spectrum + LayerNorm + first Linear in one kernel, features never stored (default 0: slower, saves memory)
  *   "soap_sorted" 1 = SOAP-BPNN tail GEMM on species-sorted atom tiles, one network per tile (default)

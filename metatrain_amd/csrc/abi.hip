@@ -117,30 +117,6 @@ __global__ void k_pack(const float* __restrict__ W, int64_t s_n, int64_t s_k, in
     out[idx] = make_float4(p[0], p[s_k], p[2 * s_k], p[3 * s_k]);
 }
 
-// three-way bf16 split of the same fragments (trr.h, bf16x6 GEMMs): out[piece][(t * kbn + kb) * 64 + l][8]
-__global__ void k_pack3(const float* __restrict__ W, int64_t s_n, int64_t s_k, int n_out, int k_in,
-                        __bf16* __restrict__ out) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int kbn = k_in / 16;
-    int64_t total = (int64_t)(n_out / 32) * kbn * 64;
-    if (idx >= total) return;
-    int l = idx & 63;
-    int kb = (idx >> 6) % kbn;
-    int t = (int)((idx >> 6) / kbn);
-    int64_t n = t * 32 + (l & 31);
-    for (int j = 0; j < 8; j++) {
-        const int64_t k = kb * 16 + (j < 4 ? 4 * (l >> 5) + j : 8 + 4 * (l >> 5) + (j - 4));
-        const float x = W[n * s_n + k * s_k];
-        const __bf16 h = (__bf16)x;
-        const float r = x - (float)h;
-        const __bf16 mm = (__bf16)r;
-        const __bf16 ll = (__bf16)(r - (float)mm);
-        out[(0 * total + idx) * 8 + j] = h;
-        out[(1 * total + idx) * 8 + j] = mm;
-        out[(2 * total + idx) * 8 + j] = ll;
-    }
-}
-
 int dev_alloc(Model& m, void** p, size_t bytes) {
     PET_HIP_CHECK(hipMalloc(p, bytes > 0 ? bytes : 4));
     m.owned.push_back(*p);
@@ -177,12 +153,8 @@ static int pack_lin(Model& m, const std::string& name, Lin& L, const float* w, c
     k_pack<<<cdiv(n4, 256), 256, 0, st>>>(w + col0, ld, 1, n_out, k_in, L.fwd);
     // transposed operand: rows = original columns, k = original rows
     k_pack<<<cdiv(n4, 256), 256, 0, st>>>(w + col0, 1, ld, k_in, n_out, L.bwd);
-    if (n_out % 32 == 0 && k_in % 32 == 0) {  // bf16x6 operands: fwd tiles over n_out (K = k_in), bwd over k_in (K = n_out)
+    {  // f16x3 operand planes: fwd tiles over n_out (K = k_in), bwd over k_in (K = n_out)
         const size_t n8 = (size_t)(n_out / 32) * (k_in / 16) * 64;  // == (k_in / 32) * (n_out / 16) * 64
-        if ((rc = named_alloc(m, name + ":fwd3", &L.fwd3, 3 * n8 * 16)) != PET_OK) return rc;
-        if ((rc = named_alloc(m, name + ":bwd3", &L.bwd3, 3 * n8 * 16)) != PET_OK) return rc;
-        k_pack3<<<cdiv(n8, 256), 256, 0, st>>>(w + col0, ld, 1, n_out, k_in, (__bf16*)L.fwd3);
-        k_pack3<<<cdiv(n8, 256), 256, 0, st>>>(w + col0, 1, ld, k_in, n_out, (__bf16*)L.bwd3);
         if ((rc = named_alloc(m, name + ":fwd2", &L.fwd2, 2 * n8 * 16)) != PET_OK) return rc;
         if ((rc = named_alloc(m, name + ":bwd2", &L.bwd2, 2 * n8 * 16)) != PET_OK) return rc;
         k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(w + col0, ld, 1, n_out, k_in, (_Float16*)L.fwd2);
@@ -864,9 +836,6 @@ int pet_config_set(const char* key, int value) {
     else if (k == "soap_fused") set_soap_fused(value);
     else if (k == "soap_sorted") set_soap_sorted(value);
     else if (k == "attn_lds") set_attn_lds(value);
-    else if (k == "bf16x6") set_bf16x6(value);
-    else if (k == "trr_persist") set_trr_persist(value);
-    else if (k == "f16x3") set_f16x3(value);
     else if (k == "emlp_recompute") set_emlp_recompute(value);
     else if (k == "tile_f16x3") set_tile_f16x3(value);
     else if (k == "trr_compress") set_trr_compress(value);
@@ -874,7 +843,7 @@ int pet_config_set(const char* key, int value) {
     else if (k == "node_planes") set_node_planes(value);
     else if (k == "so_trr") set_so_trr(value);
     else if (k == "tile_mask") set_tile_mask(value);
-    else if (k == "so_bf16x6") set_so_bf16x6(value);
+    else if (k == "so_f16x3") set_so_f16x3(value);
     else PET_REQUIRE(false, PET_ERR_ARGUMENT, "unknown config key '" + k + "'");
     return PET_OK;
 }

@@ -26,9 +26,6 @@ struct Lin {
     const float* b = nullptr;  // raw [n_out]
     float4* fwd = nullptr;
     float4* bwd = nullptr;
-    // the same two operands split three ways into bf16 for the bf16x6 GEMMs (trr.h): [3][n4 * 2] bf16x8
-    void* fwd3 = nullptr;
-    void* bwd3 = nullptr;
     void* fwd2 = nullptr;  // f16x3 operands (trr.h): two fp16 planes, fragment order
     void* bwd2 = nullptr;
     int n_out = 0, k_in = 0;
@@ -187,20 +184,17 @@ int backward_geometry_abi(const Model& m, const Graph& g, void* ws, int64_t ws_b
 bool use_trr();
 void set_use_trr(int v);
 void set_side_stream(int v);
-void set_so_bf16x6(int v);  // so.hip: 1 = generic training GEMMs on the bf16 matrix cores (default)
+void set_so_f16x3(int v);   // so.hip: 1 = generic training GEMMs as f16x3 on the 16-bit matrix cores (default), 0 = fp32 MFMA
 void set_so_trr(int v);     // so.hip: 1 = K = 128 / n_out = 128 generic GEMMs as TRR kernels (default)
-void set_bf16x6(int v);     // pet_trr.hip: 1 = GEMM stages on the bf16 matrix cores with 3-way split operands
 void set_attn_lds(int v);   // pet_attn.hip: 1 = LDS-staged attention (default), 0 = wave-per-head from global
 void set_soap_mfma(int v);  // soap.hip: 1 = MFMA tail (default), 0 = per-atom tail kernels
 void set_soap_fused(int v);  // soap.hip: 1 = power spectrum + LayerNorm + first Linear fused, features never stored (default 0)
-bool use_f16x3();
 bool emlp_recompute_ok(const Lin& win, const Lin& wout);
 void set_emlp_recompute(int v);
 bool use_tile_f16x3();
 void set_tile_f16x3(int v);
 void set_tile_mask(int v);
 int tile_mask();
-void set_f16x3(int v);        // pet_trr.hip: 1 = f16x3 GEMMs where built (default), 0 = bf16x6
 void set_trr_compress(int v);
 void set_node_planes(int v);  // pet_fwd.hip / pet_bwd.hip: node-row kernels on pre-split fp16 planes (default 1)
 bool node_planes();
@@ -215,9 +209,6 @@ bool trr_head_edge(const Model& m, const float* Xin, const float* fc, float* ypr
 bool trr_head_edge_bwd(const Model& m, const float* Xin, const float* gA, const int* ctr, const float* fc,
                        const float* ypred, float* dfc, float* dXout, int64_t E, float* t_s1, float* t_da2, float* t_da1,
                        float* t_s2y, hipStream_t st);
-bool trr_node(const AttnLayerW& A, const float* H, const float* OC, float* H1, float* VGn, float* Hn, int64_t N,
-              hipStream_t st);
-void set_trr_persist(int v);  // pet_trr.hip: 1 = persistent emlp kernel with LDS-DMA row prefetch (default)
 void set_soap_sorted(int v);  // soap.hip: 1 = tail GEMM on species-sorted tiles, one network per tile (default)
 void set_soap_pair(int v);  // soap.hip: 1 = wave-per-atom expansion / lane-per-pair adjoint (default), 0 = first generation
 void trr_qkv(const float* X, const float* gamma, const Lin& qkv, float* QKV, int64_t R, hipStream_t st);
@@ -232,12 +223,11 @@ void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wo
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
                   const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg = nullptr);
 
-// pet_comb.hip: combination stage and adjoint on the bf16 matrix cores; false if the split operands are missing
-bool use_bf16x6();
-bool comb_bf16(bool first, const float* XF, const Graph& g, const GnnLayerW& G, const float* Min,
-               const float* edge_emb, float* CA, float* LNS, float* Mout, int64_t E, hipStream_t st);
-bool comb_bwd_bf16(const float* dM, const float* XF, const Graph& g, const GnnLayerW& G, const float* LNS,
-                   const float* CA, float* dcat, int64_t E, float* t_da, hipStream_t st);
+// pet_comb.hip: combination stage and adjoint as TRR kernels (f16x3); false if the split operands are missing
+bool trr_comb(bool first, const float* XF, const Graph& g, const GnnLayerW& G, const float* Min,
+              const float* edge_emb, float* CA, float* LNS, float* Mout, int64_t E, hipStream_t st);
+bool trr_comb_bwd(const float* dM, const float* XF, const Graph& g, const GnnLayerW& G, const float* LNS,
+                  const float* CA, float* dcat, int64_t E, float* t_da, hipStream_t st);
 
 // pet_attn.hip: preload variants of the attention kernels (NT <= 4); return false if not handled
 bool attn_fwd_preload(int nt, const float* QKV, const Graph& g, float* AO, float scale, hipStream_t st);

@@ -136,156 +136,6 @@ __global__ __launch_bounds__(256) void k_attn_fwd_p(const float* __restrict__ QK
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void k_attn_bwd_p(const float* __restrict__ QKV, const float* __restrict__ dAO,
-                                                     const int* __restrict__ rowptr, const float* __restrict__ fc,
-                                                     float* __restrict__ dQKV, float* __restrict__ dbias_h,
-                                                     int64_t E, int N, float scale, int only_nt) {
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and the compiler knows it
-    const int atom = gw / NHEAD, head = gw % NHEAD;
-    if (atom >= N) return;
-    const int start = rowptr[atom];
-    const int T = rowptr[atom + 1] - start + 1;
-    const int nt = (T + 15) >> 4;
-    if (only_nt && nt != only_nt) return;  // bucketed launch: this instantiation serves one tile count
-    const int c16 = lane & 15, g4 = lane >> 4;
-    const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head;
-    // fragments with the token on the 16-lane axis (rows 16t + c16) ...
-    float4 kf[NT], vf[NT], qf[NT], dof[NT];
-    // ... and scalars with the token on the (group, register) axis (rows 16t + 4 g4 + r)
-    float ks[NT][4], qs[NT][4], dos[NT][4];
-    float bias_r[NT][4], bias_c[NT], db[NT][4];
-    int64_t rowc[NT];
-    __shared__ __attribute__((aligned(16))) float stat_all[4][2][NT * 16];
-    float (*stat)[NT * 16] = stat_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        if (t < nt) {
-            const int tc = 16 * t + c16;
-            const int64_t rc = tok_row(tc, T, E, atom, start);
-            rowc[t] = rc;
-            kf[t] = *reinterpret_cast<const float4*>(QKV + rc * (3 * D) + ko + 4 * g4);
-            vf[t] = *reinterpret_cast<const float4*>(QKV + rc * (3 * D) + vo + 4 * g4);
-            const float4 q = *reinterpret_cast<const float4*>(QKV + rc * (3 * D) + qo + 4 * g4);
-            qf[t] = make_float4(q.x * scale, q.y * scale, q.z * scale, q.w * scale);
-            dof[t] = tc < T ? *reinterpret_cast<const float4*>(dAO + rc * D + qo + 4 * g4) : make_float4(0, 0, 0, 0);
-            bias_c[t] = key_bias(tc, T, fc, start);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int tr = 16 * t + 4 * g4 + r;
-                const int64_t rr = tok_row(tr, T, E, atom, start);
-                ks[t][r] = QKV[rr * (3 * D) + ko + c16];
-                qs[t][r] = QKV[rr * (3 * D) + qo + c16];
-                dos[t][r] = tr < T ? dAO[rr * D + qo + c16] : 0.f;
-                bias_r[t][r] = key_bias(tr, T, fc, start);
-                db[t][r] = 0.f;
-            }
-        }
-    }
-    // ---- pass A: per query tile, transposed scores (keys x queries): dQ, delta, lse, key-bias grad
-#pragma unroll
-    for (int qt = 0; qt < NT; qt++) {
-        if (qt < nt) {
-            f32x4 s[NT], dp[NT];
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < NT; kt++) {
-                if (kt < nt) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-                    a = MFMA16(kf[kt].x, qf[qt].x, a); a = MFMA16(kf[kt].y, qf[qt].y, a);
-                    a = MFMA16(kf[kt].z, qf[qt].z, a); a = MFMA16(kf[kt].w, qf[qt].w, a);
-                    b = MFMA16(vf[kt].x, dof[qt].x, b); b = MFMA16(vf[kt].y, dof[qt].y, b);
-                    b = MFMA16(vf[kt].z, dof[qt].z, b); b = MFMA16(vf[kt].w, dof[qt].w, b);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) { a[r] += bias_r[kt][r]; mx = fmaxf(mx, a[r]); }
-                    s[kt] = a;
-                    dp[kt] = b;
-                }
-            }
-            mx = g4_max(mx);
-            float sum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < NT; kt++)
-                if (kt < nt)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) { const float p = __builtin_amdgcn_exp2f(LOG2E * (s[kt][r] - mx)); s[kt][r] = p; sum += p; }
-            sum = g4_sum(sum);
-            const float inv = 1.0f / sum;
-            float dl = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < NT; kt++)
-                if (kt < nt)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) { s[kt][r] *= inv; dl += s[kt][r] * dp[kt][r]; }
-            dl = g4_sum(dl);
-            // per-query statistics cross over to pass B (queries on the (group, register) axis) through
-            // a wave-private LDS row: one masked write here, one ds_read_b128 per query tile there
-            if (g4 == 0) {
-                stat[0][16 * qt + c16] = mx + logf(sum);
-                stat[1][16 * qt + c16] = dl;
-            }
-            f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < NT; kt++)
-                if (kt < nt)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float ds = s[kt][r] * (dp[kt][r] - dl);  // dS^T[key][q]; 0 for padded queries
-                        db[kt][r] += ds;
-                        dq = MFMA16(ks[kt][r], ds, dq);
-                    }
-            if (16 * qt + c16 < T)
-                *reinterpret_cast<float4*>(dQKV + rowc[qt] * (3 * D) + qo + 4 * g4) =
-                    make_float4(dq[0] * scale, dq[1] * scale, dq[2] * scale, dq[3] * scale);
-        }
-    }
-#pragma unroll
-    for (int kt = 0; kt < NT; kt++)
-        if (kt < nt)
-            store_key_bias(dbias_h, E, head, start, T, kt, g4, c16, row16_sum(db[kt][0]), row16_sum(db[kt][1]),
-                           row16_sum(db[kt][2]), row16_sum(db[kt][3]));
-    // ---- pass B: per key tile, plain scores (queries x keys): dK, dV
-#pragma unroll
-    for (int kt = 0; kt < NT; kt++) {
-        if (kt < nt) {
-            f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dvv = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int qt = 0; qt < NT; qt++) {
-                if (qt < nt) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-                    a = MFMA16(qf[qt].x, kf[kt].x, a); a = MFMA16(qf[qt].y, kf[kt].y, a);
-                    a = MFMA16(qf[qt].z, kf[kt].z, a); a = MFMA16(qf[qt].w, kf[kt].w, a);
-                    b = MFMA16(dof[qt].x, vf[kt].x, b); b = MFMA16(dof[qt].y, vf[kt].y, b);
-                    b = MFMA16(dof[qt].z, vf[kt].z, b); b = MFMA16(dof[qt].w, vf[kt].w, b);
-                    const float4 l4 = *reinterpret_cast<const float4*>(&stat[0][16 * qt + 4 * g4]);
-                    const float4 d4 = *reinterpret_cast<const float4*>(&stat[1][16 * qt + 4 * g4]);
-                    const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int qq = 16 * qt + 4 * g4 + r;
-                        const float l = lr[r];
-                        const float dl = dr[r];
-                        float p = __builtin_amdgcn_exp2f(LOG2E * (a[r] + bias_c[kt] - l));
-                        if (qq >= T) p = 0.f;
-                        const float ds = p * (b[r] - dl);
-                        dvv = MFMA16(dos[qt][r], p, dvv);
-                        dk = MFMA16(qs[qt][r], ds, dk);
-                    }
-                }
-            }
-            if (16 * kt + c16 < T) {
-                *reinterpret_cast<float4*>(dQKV + rowc[kt] * (3 * D) + ko + 4 * g4) =
-                    make_float4(dk[0] * scale, dk[1] * scale, dk[2] * scale, dk[3] * scale);
-                *reinterpret_cast<float4*>(dQKV + rowc[kt] * (3 * D) + vo + 4 * g4) =
-                    make_float4(dvv[0], dvv[1], dvv[2], dvv[3]);
-            }
-        }
-    }
-}
-
-// host launchers: true if this variant handled the launch (NT <= 4)
-
 // ---------------------------------------------------------------------------------------------
 // Second-order attention for the training pass (so.hip), same tile conventions as k_attn_*_p.
 //   tangent:  o' = sum_j [ P_ij v'_j + P_ij (s'_ij - a_i) v_j ],  s' = scale (q'.k + q.k') + b',  a_i = <P_i, s'_i>
@@ -625,95 +475,12 @@ bool attn_rev_mfma(int nt, const float* QKV, const float* QKVd, const Graph& g, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-staged variants: ONE workgroup (8 waves = 8 heads) per atom. The atom's token rows (QKV, and dO in
-// the adjoint) are fetched once as full coalesced rows into LDS, every wave builds its fragments from LDS,
-// results overwrite the head's own Q / K / V slots and leave as full rows again. Same arithmetic, in the
-// same order, as k_attn_*_p: only the memory path differs (64 B slices per (row, head) -> 1.5 KB rows).
+// LDS-staged adjoint: ONE workgroup (8 waves = 8 heads) per atom. The atom's token rows (QKV and dO) are fetched
+// once as full coalesced rows into LDS, every wave builds its fragments from LDS, results overwrite the head's own
+// Q / K / V slots and leave as full rows again (64 B slices per (row, head) -> 1.5 KB rows). A forward of the same
+// form was slower than k_attn_fwd_p (1.2 against 1.0 ms per launch) and was removed.
 // ---------------------------------------------------------------------------------------------
-constexpr int LDF = 3 * D + 4;   // forward staging row: q | k | v (+4 floats: b128 reads of 16 rows 2-way at most)
 constexpr int LDB = 4 * D + 4;   // adjoint staging row: q | k | v | dO
-
-template <int NT>
-__global__ __launch_bounds__(512) void k_attn_fwd_l(const float* __restrict__ QKV, const int* __restrict__ rowptr,
-                                                     const float* __restrict__ fc, float* __restrict__ AO,
-                                                     int64_t E, int N, float scale, int only_nt) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int atom = blockIdx.x;
-    const int start = rowptr[atom];
-    const int T = rowptr[atom + 1] - start + 1;
-    const int nt = (T + 15) >> 4;
-    if (only_nt && nt != only_nt) return;
-    const int TP = 16 * nt;
-    for (int idx = threadIdx.x; idx < TP * (3 * D / 4); idx += 512) {
-        const int t = idx / (3 * D / 4), c = idx % (3 * D / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < T) v = *reinterpret_cast<const float4*>(QKV + tok_row(t, T, E, atom, start) * (3 * D) + 4 * c);
-        *reinterpret_cast<float4*>(sm + t * LDF + 4 * c) = v;
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c16 = lane & 15, g4 = lane >> 4;
-    const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head;
-    float4 kf[NT], qf[NT];
-    float vs[NT][4], bias[NT][4];
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        if (t < nt) {
-            const float* row = sm + (16 * t + c16) * LDF;
-            kf[t] = *reinterpret_cast<const float4*>(row + ko + 4 * g4);
-            qf[t] = *reinterpret_cast<const float4*>(row + qo + 4 * g4);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int key = 16 * t + 4 * g4 + r;
-                vs[t][r] = sm[key * LDF + vo + c16];
-                bias[t][r] = key_bias(key, T, fc, start);
-            }
-        }
-    }
-#pragma unroll
-    for (int qt = 0; qt < NT; qt++) {
-        if (qt < nt) {
-            const float4 q = make_float4(qf[qt].x * scale, qf[qt].y * scale, qf[qt].z * scale, qf[qt].w * scale);
-            f32x4 s[NT];
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < NT; kt++) {
-                if (kt < nt) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                    a = MFMA16(kf[kt].x, q.x, a); a = MFMA16(kf[kt].y, q.y, a);
-                    a = MFMA16(kf[kt].z, q.z, a); a = MFMA16(kf[kt].w, q.w, a);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) { a[r] += bias[kt][r]; mx = fmaxf(mx, a[r]); }
-                    s[kt] = a;
-                }
-            }
-            mx = g4_max(mx);
-            float sum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < NT; kt++)
-                if (kt < nt)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) { const float p = __builtin_amdgcn_exp2f(LOG2E * (s[kt][r] - mx)); s[kt][r] = p; sum += p; }
-            sum = g4_sum(sum);
-            const float inv = 1.0f / sum;
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < NT; kt++)
-                if (kt < nt)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o = MFMA16(vs[kt][r], s[kt][r], o);
-            // the head's own Q slot is free (its fragments are in registers): park the output there
-            *reinterpret_cast<float4*>(sm + (16 * qt + c16) * LDF + qo + 4 * g4) =
-                make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
-        }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < T * (D / 4); idx += 512) {
-        const int t = idx / (D / 4), c = idx % (D / 4);
-        *reinterpret_cast<float4*>(AO + tok_row(t, T, E, atom, start) * D + 4 * c) =
-            *reinterpret_cast<const float4*>(sm + t * LDF + 4 * c);
-    }
-}
 
 // Adjoint, single pass over the query tiles. The score tile is formed once, transposed (keys x queries), which is
 // the layout the softmax reductions and dQ want; P and dS are then turned into the (queries x keys) operand
@@ -1053,31 +820,22 @@ __global__ __launch_bounds__(512) void k_attn_bwd_a(const float* __restrict__ QK
     }
 }
 
-// pet_config_set("attn_lds", v) selects the attention kernels:
-//   0 = one wave per (atom, head) straight from global memory, forward and adjoint
-//   1 = adjoint staged through LDS per atom (k_attn_bwd_l), global-memory forward
-//   2 = LDS-staged forward and adjoint
-//   3 (default) = persistent adjoint with LDS-DMA prefetch (k_attn_bwd_a), global-memory forward
-// measured per launch on 8 x 10k-atom boxes: adjoint 3.2 (0, two-pass) / 2.5 (1) / 2.0 ms (3); forward 1.0 (0) / 1.2 (2)
+// pet_config_set("attn_lds", v) selects the attention adjoint (the forward is always k_attn_fwd_p, one wave per
+// (atom, head) straight from global memory):
+//   1 = staged through LDS per atom for every atom (k_attn_bwd_l)
+//   3 (default) = persistent kernel with LDS-DMA prefetch (k_attn_bwd_a) for atoms of at most 32 tokens, k_attn_bwd_l
+//       for the rest
+// (0 and 2 of round 1 -- a two-pass global-memory adjoint and an LDS-staged forward -- were slower and were removed:
+// measured per launch on 8 x 10k-atom boxes: adjoint 3.2 (two-pass) / 2.5 (1) / 1.8 ms (3); forward 1.0 / 1.2 (staged).)
+// The generic wave-per-head kernels of pet_fwd.hip / pet_bwd.hip serve more than 64 tokens per atom and trr = 0.
 static int g_attn_lds = 3;
-void set_attn_lds(int v) { g_attn_lds = v < 0 ? 0 : (v > 3 ? 3 : v); }
+void set_attn_lds(int v) { g_attn_lds = v >= 2 ? 3 : 1; }
 
 // Atoms are served by the instantiation that matches their own tile count (registers / LDS, hence waves in
 // flight, scale with NT): one launch per tile count up to the batch maximum, the others exit at once.
 bool attn_fwd_preload(int nt, const float* QKV, const Graph& g, float* AO, float scale, hipStream_t st) {
     if (nt > 4) return false;
     const int N = (int)g.n_nodes;
-    if (g_attn_lds == 2) {
-#define PET_ATTN_FWD_L(K)                                                                                      \
-    if (nt >= K) {                                                                                             \
-        const size_t lds = (size_t)16 * K * LDF * sizeof(float);                                               \
-        allow_big_lds(k_attn_fwd_l<K>, lds);                                                                   \
-        k_attn_fwd_l<K><<<N, 512, lds, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale, nt > 1 ? K : 0);    \
-    }
-        PET_ATTN_FWD_L(1) PET_ATTN_FWD_L(2) PET_ATTN_FWD_L(3) PET_ATTN_FWD_L(4)
-#undef PET_ATTN_FWD_L
-        return true;
-    }
     const int grid = cdiv((int64_t)g.n_nodes * NHEAD, 4);
     const int only = nt > 1 ? 1 : 0;
     k_attn_fwd_p<1><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale, only);
@@ -1090,23 +848,22 @@ bool attn_bwd_preload(int nt, const float* QKV, const float* dAO, const Graph& g
                       float scale, hipStream_t st) {
     if (nt > 4) return false;
     const int N = (int)g.n_nodes;
-    if (g_attn_lds) {
-        int t_skip = 0, first = 1;
-        if (g_attn_lds == 3) {  // persistent LDS-DMA kernel for every atom with at most `cap` tokens
-            constexpr int cap = 32;
-            static int n_cu = 0;
-            if (!n_cu) {
-                int dev = 0;
-                (void)hipGetDevice(&dev);
-                (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-            }
-            const size_t lds = ((size_t)2 * cap * LDB + 8 * 2 * 16 * SCP) * sizeof(float);  // 149 KB: one per CU
-            allow_big_lds(k_attn_bwd_a<2>, lds);
-            const int grid = N < n_cu ? N : n_cu;
-            k_attn_bwd_a<2><<<grid, 512, lds, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, cap);
-            t_skip = cap;
-            first = 3;
+    int t_skip = 0, first = 1;
+    if (g_attn_lds == 3) {  // persistent LDS-DMA kernel for every atom with at most `cap` tokens
+        constexpr int cap = 32;
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
         }
+        const size_t lds = ((size_t)2 * cap * LDB + 8 * 2 * 16 * SCP) * sizeof(float);  // 149 KB: one per CU
+        allow_big_lds(k_attn_bwd_a<2>, lds);
+        const int grid = N < n_cu ? N : n_cu;
+        k_attn_bwd_a<2><<<grid, 512, lds, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, cap);
+        t_skip = cap;
+        first = 3;
+    }
 #define PET_ATTN_BWD_L(K)                                                                                      \
     if (nt >= K && K >= first) {                                                                               \
         const size_t lds = (size_t)16 * K * LDB * sizeof(float);                                               \
@@ -1114,16 +871,8 @@ bool attn_bwd_preload(int nt, const float* QKV, const float* dAO, const Graph& g
         k_attn_bwd_l<K><<<N, 512, lds, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale,     \
                                               nt > 1 ? K : 0, t_skip);                                         \
     }
-        PET_ATTN_BWD_L(1) PET_ATTN_BWD_L(2) PET_ATTN_BWD_L(3) PET_ATTN_BWD_L(4)
+    PET_ATTN_BWD_L(1) PET_ATTN_BWD_L(2) PET_ATTN_BWD_L(3) PET_ATTN_BWD_L(4)
 #undef PET_ATTN_BWD_L
-        return true;
-    }
-    const int grid = cdiv((int64_t)g.n_nodes * NHEAD, 4);
-    const int only = nt > 1 ? 1 : 0;
-    k_attn_bwd_p<1><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, only);
-    if (nt >= 2) k_attn_bwd_p<2><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, 2);
-    if (nt >= 3) k_attn_bwd_p<3><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, 3);
-    if (nt >= 4) k_attn_bwd_p<4><<<grid, 256, 0, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, 4);
     return true;
 }
 

@@ -1194,8 +1194,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         } else {
             {
                 ProfScope ps("comb_bwd", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D));
-                if (!(trr && use_bf16x6() &&
-                      comb_bwd_bf16(dM, B.XF, g, G, B.LNS, B.CA, w.dcat, E, tr ? w.dCA : nullptr, st)))
+                if (!(trr && trr_comb_bwd(dM, B.XF, g, G, B.LNS, B.CA, w.dcat, E, tr ? w.dCA : nullptr, st)))
                     PET_LAUNCH_TR1(tr, k_comb_bwd, gE, lds2, st, dM, B.XF, g.rev, B.LNS, B.CA, G.ln_g, G.comb2.bwd,
                     G.comb0.bwd, w.dcat, E, tr ? w.dCA : nullptr);
                 if (tr) {

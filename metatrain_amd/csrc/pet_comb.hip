@@ -1,9 +1,9 @@
-// Message-passing combination stage (backend.py:559-575) and its adjoint as TRR kernels on the bf16 matrix cores
-// (bf16x6, trr.h): one wave = 32 edges, one wave per SIMD, weight fragments through rings that run across the
+// Message-passing combination stage (backend.py:559-575) and its adjoint as TRR kernels on the 16-bit matrix cores
+// (f16x3, trr.h): one wave = 32 edges, one wave per SIMD, weight fragments through rings that run across the
 // hidden chunks.
 //   forward:  cat = [e ; e[rev]] (256) -> LayerNorm -> W0 (256 -> 256) -> SiLU -> W2 (256 -> 128);  M' = M + e + out
 //   adjoint:  dM -> dcat [E, 256] (the ji scatter of its second half is k_dxf's gather)
-// Same arithmetic as k_comb / k_comb_bwd (pet_fwd.hip / pet_bwd.hip), which stay selectable (bf16x6 = 0).
+// Same arithmetic as k_comb / k_comb_bwd (pet_fwd.hip / pet_bwd.hip), which stay selectable (trr = 0).
 #include "common.h"
 #include "model.h"
 #include "trr.h"
@@ -17,245 +17,8 @@ namespace pet {
     const bool valid = row0 + L.r < (NROWS);                  \
     const int64_t row = valid ? row0 + L.r : (NROWS) - 1
 
-template <bool FIRST>
-__global__ __launch_bounds__(256) void k_comb_b(const float* __restrict__ XF, const int* __restrict__ rev,
-                                                 const float* __restrict__ ln_g, const float* __restrict__ ln_b, W3 w0,
-                                                 const float* __restrict__ b0, W3 w2, const float* __restrict__ b2,
-                                                 const float* __restrict__ Min, const float* __restrict__ edge_emb,
-                                                 const int* __restrict__ sp_nbr, float* __restrict__ CA,
-                                                 float* __restrict__ LNS, float* __restrict__ Mout, int64_t E) {
-    extern __shared__ __attribute__((aligned(16))) bf16x8 xpark_all[];  // [4 waves][8 blocks][3 pieces][64]
-    TRR_PROLOGUE(E);
-    constexpr int NC = 2 * D / 32;  // hidden chunks of 32
-    constexpr int RD = 8;           // ring depth: a one-tile block is only 192 MFMA cycles, L2 is ~1.5k away
-    bf16x8* xpark = xpark_all + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 8 * 3 * 64;
-    // stream A: W0 tile hc, K blocks 0..15 (kb_total = 16): linear index b = 16 hc + kb
-    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
-    WBlk<1> ra[RD];
-#pragma unroll
-    for (int b = 0; b < RD; b++) ld_blk<1>(ra[b], w0, aidx(b), 0);
-    Split3<8> xs;  // the e[p] half (K blocks 0..7) in registers; the e[rev[p]] half (blocks 8..15) in wave-private LDS
-    {
-        float4 xo[16], xr[16];
-        load_rowfrag<16>(xo, XF, row, D, L.h);
-        load_rowfrag<16>(xr, XF, (int64_t)rev[row], D, L.h);
-        float s1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            s1 += xo[k].x + xo[k].y + xo[k].z + xo[k].w + xr[k].x + xr[k].y + xr[k].z + xr[k].w;
-        const float mean = row_sum(s1) * (1.0f / 256.0f);
-        float s2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            float d;
-            d = xo[k].x - mean; s2 += d * d; d = xo[k].y - mean; s2 += d * d;
-            d = xo[k].z - mean; s2 += d * d; d = xo[k].w - mean; s2 += d * d;
-            d = xr[k].x - mean; s2 += d * d; d = xr[k].y - mean; s2 += d * d;
-            d = xr[k].z - mean; s2 += d * d; d = xr[k].w - mean; s2 += d * d;
-        }
-        const float rstd = rsqrtf(row_sum(s2) * (1.0f / 256.0f) + 1e-5f);  // LayerNorm eps (backend.py:95-97)
-        if (LNS && valid && L.h == 0) {
-            LNS[row * 2] = mean;
-            LNS[row * 2 + 1] = rstd;
-        }
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const float4 ga = *reinterpret_cast<const float4*>(ln_g + 8 * k + 4 * L.h);
-            const float4 ba = *reinterpret_cast<const float4*>(ln_b + 8 * k + 4 * L.h);
-            const float4 gb = *reinterpret_cast<const float4*>(ln_g + D + 8 * k + 4 * L.h);
-            const float4 bb = *reinterpret_cast<const float4*>(ln_b + D + 8 * k + 4 * L.h);
-            xo[k].x = (xo[k].x - mean) * rstd * ga.x + ba.x; xo[k].y = (xo[k].y - mean) * rstd * ga.y + ba.y;
-            xo[k].z = (xo[k].z - mean) * rstd * ga.z + ba.z; xo[k].w = (xo[k].w - mean) * rstd * ga.w + ba.w;
-            xr[k].x = (xr[k].x - mean) * rstd * gb.x + bb.x; xr[k].y = (xr[k].y - mean) * rstd * gb.y + bb.y;
-            xr[k].z = (xr[k].z - mean) * rstd * gb.z + bb.z; xr[k].w = (xr[k].w - mean) * rstd * gb.w + bb.w;
-        }
-        split_frag<8>(xo, xs);
-        Split3<8> t;
-        split_frag<8>(xr, t);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            xpark[(k * 3 + 0) * 64 + L.lane] = t.h[k];
-            xpark[(k * 3 + 1) * 64 + L.lane] = t.m[k];
-            xpark[(k * 3 + 2) * 64 + L.lane] = t.l[k];
-        }
-    }
-    f32x16 out[4];
-    acc_bias<4>(out, b2, 0, L.h);
-    float4 bnext[4];
-    ld_bias<1>(bnext, b0, 0, L.h);
-#pragma unroll 1
-    for (int hc = 0; hc < NC; hc++) {
-        // W2 fragments of this chunk: K blocks 2 hc, 2 hc + 1 of the four output tiles (kb_total = 16)
-        WBlk<4> wo[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++) ld_blk<4>(wo[kb], w2, (size_t)(2 * hc + kb) * 64 + L.lane, 16 * 64);
-        f32x16 a1[1];
-        acc_from<1>(a1, bnext);
-        if (hc + 1 < NC) ld_bias<1>(bnext, b0, 32 * (hc + 1), L.h);
-#pragma unroll
-        for (int kb = 0; kb < 16; kb++) {
-            WBlk<1>& wb = ra[kb % RD];
-            if (kb < 8) {
-                mfma6<1>(a1, wb, xs.h[kb], xs.m[kb], xs.l[kb]);
-            } else {
-                const bf16x8 ph = xpark[((kb - 8) * 3 + 0) * 64 + L.lane], pm = xpark[((kb - 8) * 3 + 1) * 64 + L.lane],
-                             pl = xpark[((kb - 8) * 3 + 2) * 64 + L.lane];
-                mfma6<1>(a1, wb, ph, pm, pl);
-            }
-            const int nb = 16 * hc + kb + RD;
-            if (nb < 16 * NC) ld_blk<1>(wb, w0, aidx(nb), 0);
-        }
-        float4 u[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 a = acc_q(a1[0], q);
-            if (CA && valid) *reinterpret_cast<float4*>(CA + row * (2 * D) + 32 * hc + 8 * q + 4 * L.h) = a;
-            u[q] = make_float4(silu_(a.x), silu_(a.y), silu_(a.z), silu_(a.w));
-        }
-        Split3<2> us;
-        split_frag<2>(u, us);
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++) mfma6<4>(out, wo[kb], us.h[kb], us.m[kb], us.l[kb]);
-    }
-    if (valid) {
-        float4 y[16], e[16], mi[16];
-        acc_to_frag<4>(out, y);
-        load_rowfrag<16>(e, XF, row, D, L.h);
-        if (FIRST) load_rowfrag<16>(mi, edge_emb, (int64_t)sp_nbr[row], D, L.h);
-        else load_rowfrag<16>(mi, Min, row, D, L.h);
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            y[k].x += e[k].x + mi[k].x; y[k].y += e[k].y + mi[k].y;
-            y[k].z += e[k].z + mi[k].z; y[k].w += e[k].w + mi[k].w;
-        }
-        store_rowfrag<16>(y, Mout, row, D, L.h);
-    }
-}
-
-// Adjoint. Phase 1 streams the hidden chunks: da = (dM W2)[chunk] . silu'(CA[chunk]) and accumulates the first
-// half of dln = da W0 (the e[p] columns); the da chunks are parked in wave-private LDS (32 KB per wave) and phase 2
-// re-reads them for the second half (the e[rev[p]] columns), so the 256-wide result never needs 8 accumulator tiles.
-template <bool TRAIN>
-__global__ __launch_bounds__(256) void k_comb_bwd_b(const float* __restrict__ dM, const float* __restrict__ XF,
-                                                     const int* __restrict__ rev, const float* __restrict__ LNS,
-                                                     const float* __restrict__ CA, const float* __restrict__ ln_g,
-                                                     W3 w2b, W3 w0b, float* __restrict__ dcat, int64_t E,
-                                                     float* __restrict__ t_da) {
-    extern __shared__ __attribute__((aligned(16))) float4 park_all[];  // [4 waves][NC * 4][64] float4
-    TRR_PROLOGUE(E);
-    constexpr int NC = 2 * D / 32;
-    float4* park = park_all + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * NC * 4 * 64;
-    // stream A: W2^T tile hc (tiles over the 256 hidden columns), K = 128: b = 8 hc + kb
-    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
-    // stream B: W0^T, output tiles over the 256 cat columns (half: four tiles), K = 256 hidden: blocks 2 hc, 2 hc + 1
-    auto bidx = [&](int b, int half) { return ((size_t)(4 * half) * 16 + b) * 64 + L.lane; };  // tile t at + t * 16 * 64
-    WBlk<1> ra[4];
-    WBlk<4> rb[2];
-#pragma unroll
-    for (int b = 0; b < 4; b++) ld_blk<1>(ra[b], w2b, aidx(b), 0);
-#pragma unroll
-    for (int b = 0; b < 2; b++) ld_blk<4>(rb[b], w0b, bidx(b, 0), 16 * 64);
-    f32x16 dl[4];
-    acc_zero<4>(dl);
-    {
-        Split3<8> ms;
-        {
-            float4 d[16];
-            load_rowfrag<16>(d, dM, row, D, L.h);
-            split_frag<8>(d, ms);
-        }
-        float4 ca[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) ca[q] = *reinterpret_cast<const float4*>(CA + row * (2 * D) + 8 * q + 4 * L.h);
-#pragma unroll 1
-        for (int hc = 0; hc < NC; hc++) {
-            f32x16 t1[1];
-            acc_zero<1>(t1);
-#pragma unroll
-            for (int kb = 0; kb < 8; kb++) {
-                WBlk<1>& wb = ra[kb & 3];
-                mfma6<1>(t1, wb, ms.h[kb], ms.m[kb], ms.l[kb]);
-                const int nb = 8 * hc + kb + 4;
-                if (nb < 8 * NC) ld_blk<1>(wb, w2b, aidx(nb), 0);
-            }
-            float4 da[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 v = acc_q(t1[0], q);
-                da[q] = make_float4(v.x * silu_g_(ca[q].x), v.y * silu_g_(ca[q].y), v.z * silu_g_(ca[q].z),
-                                    v.w * silu_g_(ca[q].w));
-                park[(4 * hc + q) * 64 + L.lane] = da[q];
-                if (TRAIN && valid) *reinterpret_cast<float4*>(t_da + row * (2 * D) + 32 * hc + 8 * q + 4 * L.h) = da[q];
-            }
-            if (hc + 1 < NC) {
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    ca[q] = *reinterpret_cast<const float4*>(CA + row * (2 * D) + 32 * (hc + 1) + 8 * q + 4 * L.h);
-            }
-            Split3<2> ds;
-            split_frag<2>(da, ds);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                WBlk<4>& wb = rb[j];
-                mfma6<4>(dl, wb, ds.h[j], ds.m[j], ds.l[j]);
-                const int nb = 2 * hc + j + 2;  // next chunk's block, or the first blocks of the second half
-                if (nb < 2 * NC) ld_blk<4>(wb, w0b, bidx(nb, 0), 16 * 64);
-                else ld_blk<4>(wb, w0b, bidx(nb - 2 * NC, 1), 16 * 64);
-            }
-        }
-    }
-    float4 wlo[16];
-    acc_to_frag<4>(dl, wlo);
-    acc_zero<4>(dl);
-#pragma unroll 1
-    for (int hc = 0; hc < NC; hc++) {
-        float4 da[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) da[q] = park[(4 * hc + q) * 64 + L.lane];
-        Split3<2> ds;
-        split_frag<2>(da, ds);
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            WBlk<4>& wb = rb[j];
-            mfma6<4>(dl, wb, ds.h[j], ds.m[j], ds.l[j]);
-            const int nb = 2 * hc + j + 2;
-            if (nb < 2 * NC) ld_blk<4>(wb, w0b, bidx(nb, 1), 16 * 64);
-        }
-    }
-    float4 whi[16], xo[16], xr[16];
-    acc_to_frag<4>(dl, whi);
-    load_rowfrag<16>(xo, XF, row, D, L.h);
-    load_rowfrag<16>(xr, XF, (int64_t)rev[row], D, L.h);
-    const float mean = LNS[row * 2], rstd = LNS[row * 2 + 1];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {  // dyhat = dln * gamma; LayerNorm adjoint sums
-        const float4 ga = *reinterpret_cast<const float4*>(ln_g + 8 * k + 4 * L.h);
-        const float4 gb = *reinterpret_cast<const float4*>(ln_g + D + 8 * k + 4 * L.h);
-        wlo[k].x *= ga.x; wlo[k].y *= ga.y; wlo[k].z *= ga.z; wlo[k].w *= ga.w;
-        whi[k].x *= gb.x; whi[k].y *= gb.y; whi[k].z *= gb.z; whi[k].w *= gb.w;
-        s1 += wlo[k].x + wlo[k].y + wlo[k].z + wlo[k].w + whi[k].x + whi[k].y + whi[k].z + whi[k].w;
-        s2 += wlo[k].x * (xo[k].x - mean) + wlo[k].y * (xo[k].y - mean) + wlo[k].z * (xo[k].z - mean) +
-              wlo[k].w * (xo[k].w - mean) + whi[k].x * (xr[k].x - mean) + whi[k].y * (xr[k].y - mean) +
-              whi[k].z * (xr[k].z - mean) + whi[k].w * (xr[k].w - mean);
-    }
-    const float m1 = row_sum(s1) * (1.0f / 256.0f);
-    const float m2 = row_sum(s2) * rstd * rstd * (1.0f / 256.0f);
-    if (valid) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            wlo[k] = make_float4(rstd * (wlo[k].x - m1 - (xo[k].x - mean) * m2), rstd * (wlo[k].y - m1 - (xo[k].y - mean) * m2),
-                                 rstd * (wlo[k].z - m1 - (xo[k].z - mean) * m2), rstd * (wlo[k].w - m1 - (xo[k].w - mean) * m2));
-            whi[k] = make_float4(rstd * (whi[k].x - m1 - (xr[k].x - mean) * m2), rstd * (whi[k].y - m1 - (xr[k].y - mean) * m2),
-                                 rstd * (whi[k].z - m1 - (xr[k].z - mean) * m2), rstd * (whi[k].w - m1 - (xr[k].w - mean) * m2));
-        }
-        store_rowfrag<16>(wlo, dcat, row, 2 * D, L.h);
-        store_rowfrag<16>(whi, dcat + D, row, 2 * D, L.h);
-    }
-}
-
-// ---- f16x3 versions (trr.h): two fp16 planes, three MFMAs per K block on a high and a cross accumulator; the
-// adjoint scales its input row by a power of two first (row_scale_pow2) ----
+// f16x3 (trr.h): two fp16 planes, three MFMAs per K block on a high and a cross accumulator; the adjoint scales its
+// input row by a power of two first (row_scale_pow2)
 template <bool FIRST>
 __global__ __launch_bounds__(256) void k_comb_h(const float* __restrict__ XF, const int* __restrict__ rev,
                                                  const float* __restrict__ ln_g, const float* __restrict__ ln_b, W2 w0,
@@ -510,13 +273,6 @@ __global__ __launch_bounds__(256) void k_comb_bwd_h(const float* __restrict__ dM
     }
 }
 
-static inline W3 w3_of(const void* base, int n_tiles_dim, int k_dim) {
-    const size_t n8 = (size_t)(n_tiles_dim / 32) * (k_dim / 16) * 64;
-    const bf16x8* b = reinterpret_cast<const bf16x8*>(base);
-    W3 w; w.h = b; w.m = b + n8; w.l = b + 2 * n8;
-    return w;
-}
-
 static inline W2 w2_of(const void* base, int n_tiles_dim, int k_dim) {
     const size_t n8 = (size_t)(n_tiles_dim / 32) * (k_dim / 16) * 64;
     const f16x8* b = reinterpret_cast<const f16x8*>(base);
@@ -524,63 +280,36 @@ static inline W2 w2_of(const void* base, int n_tiles_dim, int k_dim) {
     return w;
 }
 
-bool comb_bf16(bool first, const float* XF, const Graph& g, const GnnLayerW& G, const float* Min,
-               const float* edge_emb, float* CA, float* LNS, float* Mout, int64_t E, hipStream_t st) {
-    if (use_f16x3() && G.comb0.fwd2 && G.comb2.fwd2) {
-        const W2 w0 = w2_of(G.comb0.fwd2, G.comb0.n_out, G.comb0.k_in), w2 = w2_of(G.comb2.fwd2, G.comb2.n_out, G.comb2.k_in);
-        const int grid = cdiv(E, WG_ROWS);
-        const size_t lds = (size_t)4 * 8 * 2 * 64 * sizeof(f16x8);  // 64 KB: the split e[rev] halves of 4 waves
-        allow_big_lds(k_comb_h<true>, lds);
-        allow_big_lds(k_comb_h<false>, lds);
-        if (first)
-            k_comb_h<true><<<grid, 256, lds, st>>>(XF, g.rev, G.ln_g, G.ln_b, w0, G.comb0.b, w2, G.comb2.b, nullptr,
-                                                 edge_emb, g.sp_nbr, CA, LNS, Mout, E);
-        else
-            k_comb_h<false><<<grid, 256, lds, st>>>(XF, g.rev, G.ln_g, G.ln_b, w0, G.comb0.b, w2, G.comb2.b, Min, edge_emb,
-                                                  g.sp_nbr, CA, LNS, Mout, E);
-        return true;
-    }
-    if (!G.comb0.fwd3 || !G.comb2.fwd3) return false;
-    const W3 w0 = w3_of(G.comb0.fwd3, G.comb0.n_out, G.comb0.k_in), w2 = w3_of(G.comb2.fwd3, G.comb2.n_out, G.comb2.k_in);
+bool trr_comb(bool first, const float* XF, const Graph& g, const GnnLayerW& G, const float* Min,
+              const float* edge_emb, float* CA, float* LNS, float* Mout, int64_t E, hipStream_t st) {
+    if (!G.comb0.fwd2 || !G.comb2.fwd2 || E <= 0) return false;
+    const W2 w0 = w2_of(G.comb0.fwd2, G.comb0.n_out, G.comb0.k_in), w2 = w2_of(G.comb2.fwd2, G.comb2.n_out, G.comb2.k_in);
     const int grid = cdiv(E, WG_ROWS);
-    const size_t lds = (size_t)4 * 8 * 3 * 64 * sizeof(bf16x8);  // 96 KB: the split e[rev] halves of 4 waves
-    allow_big_lds(k_comb_b<true>, lds);
-    allow_big_lds(k_comb_b<false>, lds);
+    const size_t lds = (size_t)4 * 8 * 2 * 64 * sizeof(f16x8);  // 64 KB: the split e[rev] halves of 4 waves
+    allow_big_lds(k_comb_h<true>, lds);
+    allow_big_lds(k_comb_h<false>, lds);
     if (first)
-        k_comb_b<true><<<grid, 256, lds, st>>>(XF, g.rev, G.ln_g, G.ln_b, w0, G.comb0.b, w2, G.comb2.b, nullptr, edge_emb,
-                                             g.sp_nbr, CA, LNS, Mout, E);
+        k_comb_h<true><<<grid, 256, lds, st>>>(XF, g.rev, G.ln_g, G.ln_b, w0, G.comb0.b, w2, G.comb2.b, nullptr,
+                                             edge_emb, g.sp_nbr, CA, LNS, Mout, E);
     else
-        k_comb_b<false><<<grid, 256, lds, st>>>(XF, g.rev, G.ln_g, G.ln_b, w0, G.comb0.b, w2, G.comb2.b, Min, edge_emb,
+        k_comb_h<false><<<grid, 256, lds, st>>>(XF, g.rev, G.ln_g, G.ln_b, w0, G.comb0.b, w2, G.comb2.b, Min, edge_emb,
                                               g.sp_nbr, CA, LNS, Mout, E);
     return true;
 }
 
-bool comb_bwd_bf16(const float* dM, const float* XF, const Graph& g, const GnnLayerW& G, const float* LNS,
-                   const float* CA, float* dcat, int64_t E, float* t_da, hipStream_t st) {
-    if (use_f16x3() && G.comb0.bwd2 && G.comb2.bwd2) {
-        const W2 w2b = w2_of(G.comb2.bwd2, G.comb2.k_in, G.comb2.n_out), w0b = w2_of(G.comb0.bwd2, G.comb0.k_in, G.comb0.n_out);
-        const int grid = cdiv(E, WG_ROWS);
-        const size_t lds = (size_t)4 * (2 * D / 32) * 4 * 64 * sizeof(float4);
-        if (t_da) {
-            allow_big_lds(k_comb_bwd_h<true>, lds);
-            k_comb_bwd_h<true><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, t_da);
-        } else {
-            allow_big_lds(k_comb_bwd_h<false>, lds);
-            k_comb_bwd_h<false><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, nullptr);
-        }
-        return true;
-    }
-    if (!G.comb0.bwd3 || !G.comb2.bwd3) return false;
-    // bwd3 operands: tiles over k_in, K = n_out
-    const W3 w2b = w3_of(G.comb2.bwd3, G.comb2.k_in, G.comb2.n_out), w0b = w3_of(G.comb0.bwd3, G.comb0.k_in, G.comb0.n_out);
+bool trr_comb_bwd(const float* dM, const float* XF, const Graph& g, const GnnLayerW& G, const float* LNS,
+                  const float* CA, float* dcat, int64_t E, float* t_da, hipStream_t st) {
+    if (!G.comb0.bwd2 || !G.comb2.bwd2 || E <= 0) return false;
+    // bwd2 operands: tiles over k_in, K = n_out
+    const W2 w2b = w2_of(G.comb2.bwd2, G.comb2.k_in, G.comb2.n_out), w0b = w2_of(G.comb0.bwd2, G.comb0.k_in, G.comb0.n_out);
     const int grid = cdiv(E, WG_ROWS);
     const size_t lds = (size_t)4 * (2 * D / 32) * 4 * 64 * sizeof(float4);  // 128 KB: the parked da chunks of 4 waves
     if (t_da) {
-        allow_big_lds(k_comb_bwd_b<true>, lds);
-        k_comb_bwd_b<true><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, t_da);
+        allow_big_lds(k_comb_bwd_h<true>, lds);
+        k_comb_bwd_h<true><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, t_da);
     } else {
-        allow_big_lds(k_comb_bwd_b<false>, lds);
-        k_comb_bwd_b<false><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, nullptr);
+        allow_big_lds(k_comb_bwd_h<false>, lds);
+        k_comb_bwd_h<false><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, nullptr);
     }
     return true;
 }

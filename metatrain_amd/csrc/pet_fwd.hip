@@ -932,9 +932,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
             {
                 ProfScope ps("node", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
                 const WX wci = wx_fwd(A.cmlp_in, 8), wce_ = wx_fwd(A.ce, 4), wco = wx_fwd(A.cmlp_out, 16);
-                if (trr_l && trr_node(A, Ab.H, Ab.OC, Ab.H1, Ab.VGn, Ab.Hn, N, s2)) {
-                    // TRR kernel (off by default)
-                } else if (node_planes() && wci.h && wce_.h && wco.h) {
+                if (node_planes() && wci.h && wce_.h && wco.h) {
                     const size_t lds_n2 = (size_t)BM * LD256 * 4 + (size_t)2 * BM * plane_ld(256) * 2 + BM * 8;
                     allow_big_lds(k_node2, lds_n2);
                     k_node2<<<gN, NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci, A.cmlp_in.b,
@@ -967,7 +965,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
             }
         } else if (E > 0) {
             ProfScope ps("comb", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D));
-            if (trr && use_bf16x6() && comb_bf16(gi == 0, B.XF, g, G, Min, m.edge_emb, B.CA, B.LNS, B.Mout, E, st)) {
+            if (trr && trr_comb(gi == 0, B.XF, g, G, Min, m.edge_emb, B.CA, B.LNS, B.Mout, E, st)) {
                 // TRR kernel on the bf16 matrix cores (pet_comb.hip)
             } else if (gi == 0)
                 k_comb<true><<<gE, NTHREADS, lds2, st>>>(B.XF, g.rev, G.ln_g, G.ln_b, G.comb0.fwd, G.comb0.b,

@@ -17,266 +17,6 @@ namespace pet {
     const int64_t row = valid ? row0 + L.r : (NROWS) - 1
 
 // ---------------------------------------------------------------------------------
-// QKV = RMSNorm(X) Win^T + b
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void k_qkv_t(const float* __restrict__ X, const float* __restrict__ gamma,
-                                                const float4* __restrict__ win, const float* __restrict__ bin,
-                                                float* __restrict__ QKV, int64_t R) {
-    TRR_PROLOGUE(R);
-    float4 x[16];
-    load_rowfrag<16>(x, X, row, D, L.h);
-    rmsnorm_frag<16>(x, gamma, L.h);
-#pragma unroll 1
-    for (int c = 0; c < 6; c++) {
-        f32x16 acc[2];
-        acc_bias<2>(acc, bin, 64 * c, L.h);
-        gemm_t<16, 2>(win, 16, 0, 2 * c, x, acc, L.lane);
-        if (valid) {
-            float4 y[8];
-            acc_to_frag<2>(acc, y);
-            store_rowfrag<8>(y, QKV + 64 * c, row, 3 * D, L.h);
-        }
-    }
-}
-
-// dXin = (row < E ? dX1 : 0) + RMSNorm^T(dQKV Win)
-__global__ __launch_bounds__(256, 2) void k_qkv_bwd_t(const float* __restrict__ dQKV, const float* __restrict__ X,
-                                                    const float* __restrict__ gamma, const float4* __restrict__ winb,
-                                                    const float* __restrict__ dX1, float* __restrict__ dXin,
-                                                    int64_t E, int64_t R) {
-    TRR_PROLOGUE(R);
-    f32x16 dn[4];
-    acc_zero<4>(dn);
-#pragma unroll 1
-    for (int ks = 0; ks < 3; ks++) {
-        float4 d[16];
-        load_rowfrag<16>(d, dQKV + 128 * ks, row, 3 * D, L.h);
-        gemm_t<16, 4>(winb, 48, 16 * ks, 0, d, dn, L.lane);
-    }
-    float4 w[16], x[16];
-    acc_to_frag<4>(dn, w);
-    load_rowfrag<16>(x, X, row, D, L.h);
-#pragma unroll
-    for (int kg = 0; kg < 16; kg++) {
-        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
-        w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
-    }
-    rmsnorm_bwd_frag<16>(w, x);
-    if (valid) {
-        if (row < E) {
-            load_rowfrag<16>(x, dX1, row, D, L.h);
-#pragma unroll
-            for (int kg = 0; kg < 16; kg++) {
-                w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
-            }
-        }
-        store_rowfrag<16>(w, dXin, row, D, L.h);
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// output_linear (+ edge residual) and its adjoint
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void k_oproj_t(const float* __restrict__ AO, const float* __restrict__ X,
-                                                  const float4* __restrict__ wo, const float* __restrict__ bo,
-                                                  float* __restrict__ X1, float* __restrict__ OC, int64_t E,
-                                                  int64_t R) {
-    TRR_PROLOGUE(R);
-    float4 a[16];
-    load_rowfrag<16>(a, AO, row, D, L.h);
-#pragma unroll 1
-    for (int c = 0; c < 2; c++) {
-        f32x16 acc[2];
-        acc_bias<2>(acc, bo, 64 * c, L.h);
-        gemm_t<16, 2>(wo, 16, 0, 2 * c, a, acc, L.lane);
-        if (valid) {
-            float4 y[8];
-            acc_to_frag<2>(acc, y);
-            if (row < E) {
-                float4 xr[8];
-                load_rowfrag<8>(xr, X + 64 * c, row, D, L.h);
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    y[k].x += xr[k].x; y[k].y += xr[k].y; y[k].z += xr[k].z; y[k].w += xr[k].w;
-                }
-                store_rowfrag<8>(y, X1 + 64 * c, row, D, L.h);
-            } else {
-                store_rowfrag<8>(y, OC + 64 * c, row - E, D, L.h);
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_oproj_bwd_t(const float* __restrict__ dX1, const float* __restrict__ dOC,
-                                                      const float4* __restrict__ wob, float* __restrict__ dAO,
-                                                      int64_t E, int64_t R) {
-    TRR_PROLOGUE(R);
-    float4 d[16];
-    if (row < E) load_rowfrag<16>(d, dX1, row, D, L.h);
-    else load_rowfrag<16>(d, dOC, row - E, D, L.h);
-#pragma unroll 1
-    for (int c = 0; c < 2; c++) {
-        f32x16 acc[2];
-        acc_zero<2>(acc);
-        gemm_t<16, 2>(wob, 16, 0, 2 * c, d, acc, L.lane);
-        if (valid) {
-            float4 y[8];
-            acc_to_frag<2>(acc, y);
-            store_rowfrag<8>(y, dAO + 64 * c, row, D, L.h);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// bf16x6 versions of the three stages above (trr.h): one wave per SIMD, weight fragments through a 4-deep
-// ring that keeps running across the column chunks, biases one chunk ahead.
-// ---------------------------------------------------------------------------------
-// y[:, 64 c .. 64 c + 63] for c < NC2 from a 128-wide row fragment: shared by qkv (NC2 = 6) and output_linear (2)
-template <int NC2, class Epilogue>
-__device__ __forceinline__ void row_gemm128_b(const W3& w, const float* __restrict__ bias, const Split3<8>& xs,
-                                              const RowLane& L, Epilogue epi) {
-    auto widx = [&](int b) { return ((size_t)(2 * (b >> 3)) * 8 + (b & 7)) * 64 + L.lane; };
-    WBlk<2> ring[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) ld_blk<2>(ring[b], w, widx(b), 8 * 64);
-    float4 bnext[8];
-    if (bias) ld_bias<2>(bnext, bias, 0, L.h);
-#pragma unroll 1
-    for (int c = 0; c < NC2; c++) {
-        f32x16 acc[2];
-        if (bias) {
-            acc_from<2>(acc, bnext);
-            if (c + 1 < NC2) ld_bias<2>(bnext, bias, 64 * (c + 1), L.h);
-        } else {
-            acc_zero<2>(acc);
-        }
-#pragma unroll
-        for (int kb = 0; kb < 8; kb++) {
-            WBlk<2>& wb = ring[kb & 3];
-            mfma6<2>(acc, wb, xs.h[kb], xs.m[kb], xs.l[kb]);
-            const int nb = 8 * c + kb + 4;
-            if (nb < 8 * NC2) ld_blk<2>(wb, w, widx(nb), 8 * 64);
-        }
-        epi(c, acc);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_qkv_b(const float* __restrict__ X, const float* __restrict__ gamma, W3 win,
-                                                const float* __restrict__ bin, float* __restrict__ QKV, int64_t R) {
-    TRR_PROLOGUE(R);
-    Split3<8> xs;
-    {
-        float4 x[16];
-        load_rowfrag<16>(x, X, row, D, L.h);
-        rmsnorm_frag<16>(x, gamma, L.h);
-        split_frag<8>(x, xs);
-    }
-    row_gemm128_b<6>(win, bin, xs, L, [&](int c, f32x16 (&acc)[2]) {
-        if (valid) {
-            float4 y[8];
-            acc_to_frag<2>(acc, y);
-            store_rowfrag<8>(y, QKV + 64 * c, row, 3 * D, L.h);
-        }
-    });
-}
-
-__global__ __launch_bounds__(256) void k_oproj_b(const float* __restrict__ AO, const float* __restrict__ X, W3 wo,
-                                                  const float* __restrict__ bo, float* __restrict__ X1,
-                                                  float* __restrict__ OC, int64_t E, int64_t R) {
-    TRR_PROLOGUE(R);
-    Split3<8> xs;
-    {
-        float4 a[16];
-        load_rowfrag<16>(a, AO, row, D, L.h);
-        split_frag<8>(a, xs);
-    }
-    row_gemm128_b<2>(wo, bo, xs, L, [&](int c, f32x16 (&acc)[2]) {
-        if (!valid) return;
-        float4 y[8];
-        acc_to_frag<2>(acc, y);
-        if (row < E) {
-            float4 xr[8];
-            load_rowfrag<8>(xr, X + 64 * c, row, D, L.h);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                y[k].x += xr[k].x; y[k].y += xr[k].y; y[k].z += xr[k].z; y[k].w += xr[k].w;
-            }
-            store_rowfrag<8>(y, X1 + 64 * c, row, D, L.h);
-        } else {
-            store_rowfrag<8>(y, OC + 64 * c, row - E, D, L.h);
-        }
-    });
-}
-
-__global__ __launch_bounds__(256) void k_oproj_bwd_b(const float* __restrict__ dX1, const float* __restrict__ dOC,
-                                                      W3 wob, float* __restrict__ dAO, int64_t E, int64_t R) {
-    TRR_PROLOGUE(R);
-    Split3<8> xs;
-    {
-        float4 d[16];
-        if (row < E) load_rowfrag<16>(d, dX1, row, D, L.h);
-        else load_rowfrag<16>(d, dOC, row - E, D, L.h);
-        split_frag<8>(d, xs);
-    }
-    row_gemm128_b<2>(wob, nullptr, xs, L, [&](int c, f32x16 (&acc)[2]) {
-        if (valid) {
-            float4 y[8];
-            acc_to_frag<2>(acc, y);
-            store_rowfrag<8>(y, dAO + 64 * c, row, D, L.h);
-        }
-    });
-}
-
-// dXin = (row < E ? dX1 : 0) + RMSNorm^T(dQKV Win): K = 384 as 24 blocks streamed through the ring, the three
-// 128-wide slices of dQKV are loaded one slice ahead of their use
-__global__ __launch_bounds__(256) void k_qkv_bwd_b(const float* __restrict__ dQKV, const float* __restrict__ X,
-                                                    const float* __restrict__ gamma, W3 winb,
-                                                    const float* __restrict__ dX1, float* __restrict__ dXin, int64_t E,
-                                                    int64_t R) {
-    TRR_PROLOGUE(R);
-    auto widx = [&](int b) { return (size_t)b * 64 + L.lane; };  // tile 0; tile t at + t * 24 * 64
-    WBlk<4> ring[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) ld_blk<4>(ring[b], winb, widx(b), 24 * 64);
-    f32x16 dn[4];
-    acc_zero<4>(dn);
-    float4 d[16];
-    load_rowfrag<16>(d, dQKV, row, 3 * D, L.h);
-#pragma unroll 1
-    for (int ks = 0; ks < 3; ks++) {
-        Split3<8> xs;
-        split_frag<8>(d, xs);
-        if (ks + 1 < 3) load_rowfrag<16>(d, dQKV + 128 * (ks + 1), row, 3 * D, L.h);
-#pragma unroll
-        for (int kb = 0; kb < 8; kb++) {
-            WBlk<4>& wb = ring[kb & 3];
-            mfma6<4>(dn, wb, xs.h[kb], xs.m[kb], xs.l[kb]);
-            const int nb = 8 * ks + kb + 4;
-            if (nb < 24) ld_blk<4>(wb, winb, widx(nb), 24 * 64);
-        }
-    }
-    float4 w[16], x[16];
-    acc_to_frag<4>(dn, w);
-    load_rowfrag<16>(x, X, row, D, L.h);
-#pragma unroll
-    for (int kg = 0; kg < 16; kg++) {
-        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
-        w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
-    }
-    rmsnorm_bwd_frag<16>(w, x);
-    if (valid) {
-        if (row < E) {
-            load_rowfrag<16>(x, dX1, row, D, L.h);
-#pragma unroll
-            for (int kg = 0; kg < 16; kg++) {
-                w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
-            }
-        }
-        store_rowfrag<16>(w, dXin, row, D, L.h);
-    }
-}
-
-// ---------------------------------------------------------------------------------
 // f16x3 versions (trr.h) of the 128-wide row GEMM and the stages built on it. `oscale` multiplies the finished
 // accumulators (the inverse of a row_scale_pow2 applied to an adjoint input; 1 for forward activations).
 // ---------------------------------------------------------------------------------
@@ -504,62 +244,7 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_h(const float* __restrict__ dQK
     store_rows_lines<16>(w, lds_tile, L, [&](int r) { return row0 + r < R ? dXin + (row0 + r) * D : nullptr; });
 }
 
-// ---------------------------------------------------------------------------------
-// edge SwiGLU MLP: X2 = X1 + Wout (v * sig(g)) + b,  [v; g] = Win RMSNorm(X1) + b
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_emlp_t(const float* __restrict__ X1, const float* __restrict__ gamma,
-                                                 const float4* __restrict__ win, const float* __restrict__ bin,
-                                                 const float4* __restrict__ wout, const float* __restrict__ bout,
-                                                 float* __restrict__ VG, float* __restrict__ X2, int64_t E) {
-    TRR_PROLOGUE(E);
-    float4 x[16];
-    load_rowfrag<16>(x, X1, row, D, L.h);
-    rmsnorm_frag<16>(x, gamma, L.h);
-    f32x16 out[4];
-    acc_bias<4>(out, bout, 0, L.h);
-#pragma unroll 1
-    for (int hc = 0; hc < DFF / 32; hc++) {
-        // value and gate tiles as two interleaved MFMA chains (tiles hc and DFF/32 + hc of w_in)
-        f32x16 vg[2];
-        {
-            f32x16 v[1], g[1];
-            acc_bias<1>(v, bin, 32 * hc, L.h);
-            acc_bias<1>(g, bin, DFF + 32 * hc, L.h);
-            vg[0] = v[0];
-            vg[1] = g[0];
-        }
-        gemm_t<16, 2, 2>(win, 16, 0, hc, x, vg, L.lane, DFF / 32);
-        float4 u[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 vv = acc_q(vg[0], q), gg = acc_q(vg[1], q);
-            if (VG && valid) {
-                *reinterpret_cast<float4*>(VG + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) = vv;
-                *reinterpret_cast<float4*>(VG + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) = gg;
-            }
-            u[q] = make_float4(vv.x * sigm_(gg.x), vv.y * sigm_(gg.y), vv.z * sigm_(gg.z), vv.w * sigm_(gg.w));
-        }
-        gemm_t<4, 4>(wout, DFF / 8, 4 * hc, 0, u, out, L.lane);
-    }
-    if (valid) {
-        float4 y[16], xr[16];
-        acc_to_frag<4>(out, y);
-        load_rowfrag<16>(xr, X1, row, D, L.h);
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            y[k].x += xr[k].x; y[k].y += xr[k].y; y[k].z += xr[k].z; y[k].w += xr[k].w;
-        }
-        store_rowfrag<16>(y, X2, row, D, L.h);
-    }
-}
-
-// bf16x6 operands of a Lin (abi.hip k_pack3): three consecutive arrays of n8 fragments
-static inline W3 w3_fwd(const Lin& L) {
-    const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
-    const bf16x8* b = reinterpret_cast<const bf16x8*>(L.fwd3);
-    W3 w; w.h = b; w.m = b + n8; w.l = b + 2 * n8;
-    return w;
-}
+// f16x2 planes of a Lin (abi.hip k_pack2h): two consecutive arrays of n8 fragments
 static inline W2 w2_fwd(const Lin& L) {
     const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
     const f16x8* b = reinterpret_cast<const f16x8*>(L.fwd2);
@@ -577,242 +262,21 @@ static inline W2 w2_wc(const GnnLayerW& G) {  // one 32-row tile, K = D
     W2 w; w.h = b; w.l = b + (size_t)(D / 16) * 64;
     return w;
 }
-static inline W3 w3_bwd(const Lin& L) {
-    const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
-    const bf16x8* b = reinterpret_cast<const bf16x8*>(L.bwd3);
-    W3 w; w.h = b; w.m = b + n8; w.l = b + 2 * n8;
-    return w;
-}
-
-// The same stage with its GEMMs on the bf16 matrix cores (bf16x6, trr.h).
-// One wave per SIMD (the split operands take the registers of two), so the wave hides its own latencies:
-// the w_in fragments run through a 4-deep ring that is refilled across chunk boundaries, the w_out
-// fragments and the biases of a chunk are requested before its first MFMA.
-__global__ __launch_bounds__(256) void k_emlp_b(const float* __restrict__ X1, const float* __restrict__ gamma, W3 win,
-                                                  const float* __restrict__ bin, W3 wout,
-                                                  const float* __restrict__ bout, float* __restrict__ VG,
-                                                  float* __restrict__ X2, int64_t E) {
-    TRR_PROLOGUE(E);
-    constexpr int NC = DFF / 32;  // hidden chunks
-    // ring of w_in blocks: stream index b = 8 hc + kb, tiles (hc, NC + hc), kb_total = 8
-    auto widx = [&](int b) { return ((size_t)(b >> 3) * 8 + (b & 7)) * 64 + L.lane; };
-    constexpr size_t TS = (size_t)NC * 8 * 64;  // from the value tile to the gate tile
-    WBlk<2> ring[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) ld_blk<2>(ring[b], win, widx(b), TS);
-    Split3<8> xs;
-    {
-        float4 x[16];
-        load_rowfrag<16>(x, X1, row, D, L.h);
-        rmsnorm_frag<16>(x, gamma, L.h);
-        split_frag<8>(x, xs);
-    }
-    f32x16 out[4];
-    acc_bias<4>(out, bout, 0, L.h);
-    float4 bv[4], bg[4];  // biases of the current chunk (this lane's features)
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        bv[q] = *reinterpret_cast<const float4*>(bin + 8 * q + 4 * L.h);
-        bg[q] = *reinterpret_cast<const float4*>(bin + DFF + 8 * q + 4 * L.h);
-    }
-#pragma unroll 1
-    for (int hc = 0; hc < NC; hc++) {
-        // w_out fragments of this chunk (K blocks 2 hc, 2 hc + 1 of the four output tiles) and the next biases
-        bf16x8 oh[2][4], om[2][4], ol[2][4];
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const size_t i = ((size_t)t * (DFF / 16) + 2 * hc + kb) * 64 + L.lane;
-                oh[kb][t] = wout.h[i]; om[kb][t] = wout.m[i]; ol[kb][t] = wout.l[i];
-            }
-        f32x16 vg[2];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            vg[0][4 * q] = bv[q].x; vg[0][4 * q + 1] = bv[q].y; vg[0][4 * q + 2] = bv[q].z; vg[0][4 * q + 3] = bv[q].w;
-            vg[1][4 * q] = bg[q].x; vg[1][4 * q + 1] = bg[q].y; vg[1][4 * q + 2] = bg[q].z; vg[1][4 * q + 3] = bg[q].w;
-        }
-        if (hc + 1 < NC) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                bv[q] = *reinterpret_cast<const float4*>(bin + 32 * (hc + 1) + 8 * q + 4 * L.h);
-                bg[q] = *reinterpret_cast<const float4*>(bin + DFF + 32 * (hc + 1) + 8 * q + 4 * L.h);
-            }
-        }
-#pragma unroll
-        for (int kb = 0; kb < 8; kb++) {
-            WBlk<2>& wb = ring[kb & 3];
-            mfma6<2>(vg, wb, xs.h[kb], xs.m[kb], xs.l[kb]);
-            const int nb = 8 * hc + kb + 4;  // refill this slot with the block four steps ahead (may be next chunk's)
-            if (nb < 8 * NC) ld_blk<2>(wb, win, widx(nb), TS);
-        }
-        float4 u[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 vv = acc_q(vg[0], q), gg = acc_q(vg[1], q);
-            if (VG && valid) {
-                *reinterpret_cast<float4*>(VG + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) = vv;
-                *reinterpret_cast<float4*>(VG + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) = gg;
-            }
-            u[q] = make_float4(vv.x * sigm_(gg.x), vv.y * sigm_(gg.y), vv.z * sigm_(gg.z), vv.w * sigm_(gg.w));
-        }
-        Split3<2> us;
-        split_frag<2>(u, us);
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                out[t] = PET_MFMA_B(ol[kb][t], us.h[kb], out[t]);
-                out[t] = PET_MFMA_B(oh[kb][t], us.l[kb], out[t]);
-                out[t] = PET_MFMA_B(om[kb][t], us.m[kb], out[t]);
-                out[t] = PET_MFMA_B(om[kb][t], us.h[kb], out[t]);
-                out[t] = PET_MFMA_B(oh[kb][t], us.m[kb], out[t]);
-                out[t] = PET_MFMA_B(oh[kb][t], us.h[kb], out[t]);
-            }
-    }
-    if (valid) {
-        float4 y[16], xr[16];
-        acc_to_frag<4>(out, y);
-        load_rowfrag<16>(xr, X1, row, D, L.h);
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            y[k].x += xr[k].x; y[k].y += xr[k].y; y[k].z += xr[k].z; y[k].w += xr[k].w;
-        }
-        store_rowfrag<16>(y, X2, row, D, L.h);
-    }
-}
-
-// Persistent form of k_emlp_b: one workgroup per CU walks a strided list of 32-row tiles. What the one-tile-per-wave
-// kernel pays at every tile -- the HBM round trip of its input rows before the first MFMA, and the cold weight ring --
-// is paid once per wave here: the NEXT tile's rows are fetched into wave-private LDS by LDS-DMA while this tile
-// computes (same lane mapping as load_rowfrag, so every lane reads back exactly the 16 B pieces it requested), the
-// residual re-read comes from the same buffer, and the w_in ring simply keeps running into the next tile's first
-// blocks. pet_config_set("trr_persist", 0) selects the one-shot kernel.
+// ---------------------------------------------------------------------------------
+// edge SwiGLU MLP: X2 = X1 + Wout (v * sig(g)) + b,  [v; g] = Win RMSNorm(X1) + b
+// Persistent: one workgroup per CU walks a strided list of 32-row tiles. What a one-tile-per-wave kernel pays at
+// every tile -- the HBM round trip of its input rows before the first MFMA, and the cold weight ring -- is paid
+// once per wave here: the NEXT tile's rows are fetched into wave-private LDS by LDS-DMA while this tile computes
+// (same lane mapping as load_rowfrag, so every lane reads back exactly the 16 B pieces it requested), the residual
+// re-read comes from the same buffer, and the w_in ring keeps running into the next tile's first blocks.
+// ---------------------------------------------------------------------------------
 __device__ __forceinline__ void glds16_trr(const float* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-__global__ __launch_bounds__(256) void k_emlp_p(const float* __restrict__ X1, const float* __restrict__ gamma, W3 win,
-                                                  const float* __restrict__ bin, W3 wout,
-                                                  const float* __restrict__ bout, float* __restrict__ VG,
-                                                  float* __restrict__ X2, int64_t E) {
-    extern __shared__ __attribute__((aligned(16))) float4 xstage[];  // [4 waves][2 buffers][16][64]
-    const RowLane L;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4* mybuf = xstage + (size_t)wave * 2 * 16 * 64;
-    const int64_t ntiles = (E + WROWS - 1) / WROWS, nw = (int64_t)gridDim.x * 4;
-    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    if (tile >= ntiles) return;
-    auto issue_rows = [&](int64_t t, int buf) {
-        int64_t rr = t * WROWS + L.r;
-        if (rr >= E) rr = E - 1;
-        const float* src = X1 + rr * D + 4 * L.h;
-        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(mybuf + (size_t)buf * 16 * 64));
-#pragma unroll
-        for (int kg = 0; kg < 16; kg++) glds16_trr(src + 8 * kg, dst + kg * 1024);
-    };
-    issue_rows(tile, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only the first tile waits for its own rows
-    constexpr int NC = DFF / 32;
-    auto widx = [&](int b) { return ((size_t)(b >> 3) * 8 + (b & 7)) * 64 + L.lane; };
-    constexpr size_t TS = (size_t)NC * 8 * 64;
-    WBlk<2> ring[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) ld_blk<2>(ring[b], win, widx(b), TS);
-    float4 bv[4], bg[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        bv[q] = *reinterpret_cast<const float4*>(bin + 8 * q + 4 * L.h);
-        bg[q] = *reinterpret_cast<const float4*>(bin + DFF + 8 * q + 4 * L.h);
-    }
-    for (int it = 0; tile < ntiles; it++, tile += nw) {
-        const int64_t row0 = tile * WROWS;
-        const bool valid = row0 + L.r < E;
-        const int64_t row = valid ? row0 + L.r : E - 1;
-        const float4* xb = mybuf + (size_t)(it & 1) * 16 * 64;
-        if (tile + nw < ntiles) issue_rows(tile + nw, (it + 1) & 1);
-        Split3<8> xs;
-        {
-            float4 x[16];
-#pragma unroll
-            for (int kg = 0; kg < 16; kg++) x[kg] = xb[kg * 64 + L.lane];
-            rmsnorm_frag<16>(x, gamma, L.h);
-            split_frag<8>(x, xs);
-        }
-        f32x16 out[4];
-        acc_bias<4>(out, bout, 0, L.h);
-#pragma unroll 1
-        for (int hc = 0; hc < NC; hc++) {
-            bf16x8 oh[2][4], om[2][4], ol[2][4];
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const size_t i = ((size_t)t * (DFF / 16) + 2 * hc + kb) * 64 + L.lane;
-                    oh[kb][t] = wout.h[i]; om[kb][t] = wout.m[i]; ol[kb][t] = wout.l[i];
-                }
-            f32x16 vg[2];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                vg[0][4 * q] = bv[q].x; vg[0][4 * q + 1] = bv[q].y; vg[0][4 * q + 2] = bv[q].z; vg[0][4 * q + 3] = bv[q].w;
-                vg[1][4 * q] = bg[q].x; vg[1][4 * q + 1] = bg[q].y; vg[1][4 * q + 2] = bg[q].z; vg[1][4 * q + 3] = bg[q].w;
-            }
-            {
-                const int hn = hc + 1 < NC ? hc + 1 : 0;  // wraps to the next tile's first chunk
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    bv[q] = *reinterpret_cast<const float4*>(bin + 32 * hn + 8 * q + 4 * L.h);
-                    bg[q] = *reinterpret_cast<const float4*>(bin + DFF + 32 * hn + 8 * q + 4 * L.h);
-                }
-            }
-#pragma unroll
-            for (int kb = 0; kb < 8; kb++) {
-                WBlk<2>& wb = ring[kb & 3];
-                mfma6<2>(vg, wb, xs.h[kb], xs.m[kb], xs.l[kb]);
-                int nb = 8 * hc + kb + 4;  // four steps ahead; past the end = the next tile's first blocks
-                nb = nb < 8 * NC ? nb : nb - 8 * NC;
-                ld_blk<2>(wb, win, widx(nb), TS);
-            }
-            float4 u[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 vv = acc_q(vg[0], q), gg = acc_q(vg[1], q);
-                if (VG && valid) {
-                    *reinterpret_cast<float4*>(VG + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) = vv;
-                    *reinterpret_cast<float4*>(VG + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) = gg;
-                }
-                u[q] = make_float4(vv.x * sigm_(gg.x), vv.y * sigm_(gg.y), vv.z * sigm_(gg.z), vv.w * sigm_(gg.w));
-            }
-            Split3<2> us;
-            split_frag<2>(u, us);
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    out[t] = PET_MFMA_B(ol[kb][t], us.h[kb], out[t]);
-                    out[t] = PET_MFMA_B(oh[kb][t], us.l[kb], out[t]);
-                    out[t] = PET_MFMA_B(om[kb][t], us.m[kb], out[t]);
-                    out[t] = PET_MFMA_B(om[kb][t], us.h[kb], out[t]);
-                    out[t] = PET_MFMA_B(oh[kb][t], us.m[kb], out[t]);
-                    out[t] = PET_MFMA_B(oh[kb][t], us.h[kb], out[t]);
-                }
-        }
-        if (valid) {
-            float4 y[16];
-            acc_to_frag<4>(out, y);
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const float4 xr = xb[k * 64 + L.lane];
-                y[k].x += xr.x; y[k].y += xr.y; y[k].z += xr.z; y[k].w += xr.w;
-            }
-            store_rowfrag<16>(y, X2, row, D, L.h);
-        }
-    }
-}
-
-// f16x3 form of the persistent edge MLP (trr.h): two fp16 planes, three MFMAs per K block on a high and a cross
-// accumulator; RMSNorm output and SwiGLU output are O(1) rows, so no row scaling is needed here.
+// f16x3 (trr.h): two fp16 planes, three MFMAs per K block on a high and a cross accumulator; RMSNorm output and
+// SwiGLU output are O(1) rows, so no row scaling is needed here.
 template <bool LINES>
 __global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, const float* __restrict__ gamma, W2 win,
                                                   const float* __restrict__ bin, W2 wout,
@@ -950,155 +414,12 @@ __global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, co
     }
 }
 
+// ---------------------------------------------------------------------------------
 // dX1 = dY + RMSNorm^T( Win^T [du sig(g) ; du v sig'(g)] ),  du = Wout^T dY
-template <bool TRAIN>
-__global__ __launch_bounds__(256, 2) void k_emlp_bwd_t(const float* __restrict__ dY, const float* __restrict__ X1,
-                                                     const float* __restrict__ VG, const float* __restrict__ gamma,
-                                                     const float4* __restrict__ woutb, const float4* __restrict__ winb,
-                                                     float* __restrict__ dX1, int64_t E, float* __restrict__ t_dvg) {
-    TRR_PROLOGUE(E);
-    float4 dy[16];
-    load_rowfrag<16>(dy, dY, row, D, L.h);
-    f32x16 dn[4];
-    acc_zero<4>(dn);
-#pragma unroll 1
-    for (int hc = 0; hc < DFF / 32; hc++) {
-        f32x16 du[1];
-        acc_zero<1>(du);
-        gemm_t<16, 1, 4>(woutb, 16, 0, hc, dy, du, L.lane);  // du[:, chunk] = dY Wout[:, chunk]
-        float4 dv[4], dg[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 vv = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h);
-            const float4 gg = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h);
-            const float4 d = acc_q(du[0], q);
-            const float sx = sigm_(gg.x), sy = sigm_(gg.y), sz = sigm_(gg.z), sw = sigm_(gg.w);
-            dv[q] = make_float4(d.x * sx, d.y * sy, d.z * sz, d.w * sw);
-            dg[q] = make_float4(d.x * vv.x * sx * (1.f - sx), d.y * vv.y * sy * (1.f - sy),
-                                d.z * vv.z * sz * (1.f - sz), d.w * vv.w * sw * (1.f - sw));
-            if (TRAIN && valid) {
-                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) = dv[q];
-                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) = dg[q];
-            }
-        }
-        gemm_t<4, 4>(winb, 2 * DFF / 8, 4 * hc, 0, dv, dn, L.lane);
-        gemm_t<4, 4>(winb, 2 * DFF / 8, DFF / 8 + 4 * hc, 0, dg, dn, L.lane);
-    }
-    float4 w[16], x[16];
-    acc_to_frag<4>(dn, w);
-    load_rowfrag<16>(x, X1, row, D, L.h);
-#pragma unroll
-    for (int kg = 0; kg < 16; kg++) {
-        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
-        w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
-    }
-    rmsnorm_bwd_frag<16>(w, x);
-    if (valid) {
-        load_rowfrag<16>(x, dY, row, D, L.h);  // residual: re-read dY (L2 hit) instead of keeping 64 registers live
-#pragma unroll
-        for (int kg = 0; kg < 16; kg++) {
-            w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
-        }
-        store_rowfrag<16>(w, dX1, row, D, L.h);
-    }
-}
-
-// bf16x6 version: two weight streams, both ring-prefetched across the hidden chunks --
+// two weight streams, both ring-prefetched across the hidden chunks --
 //   A: Wout^T blocks for du (tile hc of the [DFF x D] operand, 8 K blocks per chunk, one tile);
 //   B: Win^T blocks for dn += [dv | dg] Win (four output tiles; per chunk K blocks 2hc, 2hc+1 of the value half
 //      and 16 + 2hc, 16 + 2hc + 1 of the gate half).
-template <bool TRAIN>
-__global__ __launch_bounds__(256) void k_emlp_bwd_b(const float* __restrict__ dY, const float* __restrict__ X1,
-                                                     const float* __restrict__ VG, const float* __restrict__ gamma,
-                                                     W3 woutb, W3 winb, float* __restrict__ dX1, int64_t E,
-                                                     float* __restrict__ t_dvg) {
-    TRR_PROLOGUE(E);
-    constexpr int NC = DFF / 32;
-    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };  // b = 8 hc + kb: tile hc, kb_total = 8
-    auto bkb = [&](int b) { const int hc = b >> 2, j = b & 3; return (j < 2 ? 2 * hc + j : 16 + 2 * hc + (j - 2)); };
-    auto bidx = [&](int b) { return (size_t)bkb(b) * 64 + L.lane; };  // tile 0; tile t at + t * 32 * 64
-    WBlk<1> ra[4];
-    WBlk<4> rb[2];
-#pragma unroll
-    for (int b = 0; b < 4; b++) ld_blk<1>(ra[b], woutb, aidx(b), 0);
-#pragma unroll
-    for (int b = 0; b < 2; b++) ld_blk<4>(rb[b], winb, bidx(b), 32 * 64);
-    Split3<8> ys;
-    {
-        float4 dy[16];
-        load_rowfrag<16>(dy, dY, row, D, L.h);
-        split_frag<8>(dy, ys);
-    }
-    f32x16 dn[4];
-    acc_zero<4>(dn);
-    float4 vv[4], gg[4];  // saved pre-activations of the current chunk
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        vv[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + 8 * q + 4 * L.h);
-        gg[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + DFF + 8 * q + 4 * L.h);
-    }
-#pragma unroll 1
-    for (int hc = 0; hc < NC; hc++) {
-        f32x16 du[1];
-        acc_zero<1>(du);
-#pragma unroll
-        for (int kb = 0; kb < 8; kb++) {
-            WBlk<1>& wb = ra[kb & 3];
-            mfma6<1>(du, wb, ys.h[kb], ys.m[kb], ys.l[kb]);
-            const int nb = 8 * hc + kb + 4;
-            if (nb < 8 * NC) ld_blk<1>(wb, woutb, aidx(nb), 0);
-        }
-        float4 dvg[8];  // dv (4) then dg (4): the K = 64 operand of stream B
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 d = acc_q(du[0], q);
-            const float sx = sigm_(gg[q].x), sy = sigm_(gg[q].y), sz = sigm_(gg[q].z), sw = sigm_(gg[q].w);
-            dvg[q] = make_float4(d.x * sx, d.y * sy, d.z * sz, d.w * sw);
-            dvg[4 + q] = make_float4(d.x * vv[q].x * sx * (1.f - sx), d.y * vv[q].y * sy * (1.f - sy),
-                                     d.z * vv[q].z * sz * (1.f - sz), d.w * vv[q].w * sw * (1.f - sw));
-            if (TRAIN && valid) {
-                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) = dvg[q];
-                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) = dvg[4 + q];
-            }
-        }
-        if (hc + 1 < NC) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                vv[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + 32 * (hc + 1) + 8 * q + 4 * L.h);
-                gg[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + DFF + 32 * (hc + 1) + 8 * q + 4 * L.h);
-            }
-        }
-        Split3<4> ds;
-        split_frag<4>(dvg, ds);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            WBlk<4>& wb = rb[j & 1];
-            mfma6<4>(dn, wb, ds.h[j], ds.m[j], ds.l[j]);
-            const int nb = 4 * hc + j + 2;
-            if (nb < 4 * NC) ld_blk<4>(wb, winb, bidx(nb), 32 * 64);
-        }
-    }
-    float4 w[16], x[16];
-    acc_to_frag<4>(dn, w);
-    load_rowfrag<16>(x, X1, row, D, L.h);
-#pragma unroll
-    for (int kg = 0; kg < 16; kg++) {
-        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
-        w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
-    }
-    rmsnorm_bwd_frag<16>(w, x);
-    if (valid) {
-        load_rowfrag<16>(x, dY, row, D, L.h);
-#pragma unroll
-        for (int kg = 0; kg < 16; kg++) {
-            w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
-        }
-        store_rowfrag<16>(w, dX1, row, D, L.h);
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// host launchers (declared in model.h)
 // ---------------------------------------------------------------------------------
 template <bool TRAIN>
 __global__ __launch_bounds__(256) void k_emlp_bwd_h(const float* __restrict__ dY, const float* __restrict__ X1,
@@ -1201,9 +522,6 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_h(const float* __restrict__ dY
     }
 }
 
-// ---------------------------------------------------------------------------------
-// host launchers (declared in model.h)
-// ---------------------------------------------------------------------------------
 // Edge-MLP adjoint WITHOUT the saved pre-activations (inference: pet_forward stores no VG for this stage). [v; g] is
 // recomputed per hidden chunk from RMSNorm(X1) with the forward weight planes: one more f16x3 GEMM per chunk (the
 // matrix pipe has room: the stored-VG form moves 6.4 GB per launch at ~3.2 TB/s with the MFMAs ~20 % busy), against
@@ -1484,43 +802,39 @@ __global__ __launch_bounds__(256, 2) void k_compress_bwd_h(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------
+// host launchers (declared in model.h)
+// ---------------------------------------------------------------------------------
 static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
 // full-line stores through a wave-private LDS tile (trr.h store_rows_lines): bit 0 qkv, bit 1 edge MLP (A/B switches;
 // oproj_bwd, qkv_bwd, compress, compress_bwd, comb_bwd and head_bwd always store this way)
 static int g_line_stores = 3;
 void set_line_stores(int v) { g_line_stores = v; }
 
-// pet_config_set("bf16x6", 0) puts the TRR stages back on the fp32 MFMA. Default: GEMMs on the bf16 matrix cores
-// with 3-way split operands -- as accurate as the fp32 MFMA (3.7e-7 vs 4.5e-7 against fp64, tools/ubench/bf16x3.hip)
-// at 0.375x the matrix-core time. The split fragments cost registers (one wave per SIMD), so these kernels
-// prefetch their weight fragments through rings that run across the GEMM boundaries.
-static int g_bf16x6 = 1;
-static int g_f16x3 = 1;  // pet_config_set("f16x3", 0): the bf16x6 kernels everywhere
-void set_f16x3(int v) { g_f16x3 = v ? 1 : 0; }
-bool use_f16x3() { return g_f16x3 != 0; }
+// The GEMMs of these kernels are split-operand products on the 16-bit matrix cores (f16x3: 2-way fp16 split, three
+// MFMAs per K block; 1.7e-7 product error against fp64, tools/ubench). The fp32-MFMA and 3-way bf16 (bf16x6)
+// generations of round 1 were removed in round 2; pet_config_set("trr", 0) selects the LDS-tile kernels of
+// pet_fwd.hip / pet_bwd.hip, which are the one fallback (and the path of the LayerNorm / PostLN / residual variants).
 static int g_tile_f16x3 = 1;  // pet_config_set("tile_f16x3", 0): LDS-tile kernels (compress, heads, node chain) on fp32 MFMA
 void set_tile_f16x3(int v) { g_tile_f16x3 = v ? 1 : 0; }
 static int g_tile_mask = 0;  // debugging aid: bits switch individual LDS-tile GEMMs back to fp32 MFMA
 void set_tile_mask(int v) { g_tile_mask = v; }
 int tile_mask() { return g_tile_mask; }
-bool use_tile_f16x3() { return g_f16x3 != 0 && g_tile_f16x3 != 0 && g_bf16x6 != 0; }
+bool use_tile_f16x3() { return g_tile_f16x3 != 0; }
 // pet_config_set("emlp_recompute", 1): the inference adjoint of the edge MLP rebuilds the SwiGLU pre-activations
 // instead of reading them back. Saves 16 KB of workspace traffic per edge and makes the forward stage 21 % faster
 // (6.4 -> 5.1 ms per step), but the recomputing adjoint issues 120 instead of 72 MFMAs per chunk at the same ~20 %
 // pipe utilisation (these kernels are issue / latency bound, not HBM bound) and takes 13.1 ms against 7.9: OFF by
 // default, kept as the memory-lean variant.
-// pet_config_set("trr_compress", bits): 1 compress (+adjoint), 2 edge head (+adjoint), 4 node update (k_node_h: 5.8 ms
-// against 3.0 ms for the LDS-tile k_node at 80k atoms, so off by default); 0 = the LDS-tile kernels everywhere
+// pet_config_set("trr_compress", bits): 1 compress (+adjoint), 2 edge head (+adjoint); 0 = the LDS-tile kernels
 static int g_trr_tilek = 3;
 void set_trr_compress(int v) { g_trr_tilek = v; }
 static int g_emlp_recompute = 0;
 void set_emlp_recompute(int v) { g_emlp_recompute = v ? 1 : 0; }
 // inference only: the edge-MLP adjoint rebuilds [v; g] instead of reading them back (k_emlp_bwd_r)
 bool emlp_recompute_ok(const Lin& win, const Lin& wout) {
-    return g_emlp_recompute && use_trr() && g_bf16x6 && g_f16x3 && win.fwd2 && win.bwd2 && wout.bwd2 && wout.fwd2;
+    return g_emlp_recompute && use_trr() && win.fwd2 && win.bwd2 && wout.bwd2 && wout.fwd2;
 }
-static int g_trr_persist = 1;
-void set_trr_persist(int v) { g_trr_persist = v ? 1 : 0; }
 static int num_cus() {
     static int n = 0;
     if (!n) {
@@ -1530,74 +844,53 @@ static int num_cus() {
     }
     return n;
 }
-void set_bf16x6(int v) { g_bf16x6 = v ? 1 : 0; }
-bool use_bf16x6() { return g_bf16x6 != 0; }
 
 void trr_qkv(const float* X, const float* gamma, const Lin& qkv, float* QKV, int64_t R, hipStream_t st) {
-    if (g_bf16x6 && g_f16x3 && qkv.fwd2 && (g_line_stores & 1))
-        k_qkv_hl<<<grid_rows(R), 256, 0, st>>>(X, gamma, w2_fwd(qkv), qkv.b, QKV, R);
-    else if (g_bf16x6 && g_f16x3 && qkv.fwd2) k_qkv_h<<<grid_rows(R), 256, 0, st>>>(X, gamma, w2_fwd(qkv), qkv.b, QKV, R);
-    else if (g_bf16x6 && qkv.fwd3) k_qkv_b<<<grid_rows(R), 256, 0, st>>>(X, gamma, w3_fwd(qkv), qkv.b, QKV, R);
-    else k_qkv_t<<<grid_rows(R), 256, 0, st>>>(X, gamma, qkv.fwd, qkv.b, QKV, R);
+    if (R <= 0) return;
+    if (g_line_stores & 1) k_qkv_hl<<<grid_rows(R), 256, 0, st>>>(X, gamma, w2_fwd(qkv), qkv.b, QKV, R);
+    else k_qkv_h<<<grid_rows(R), 256, 0, st>>>(X, gamma, w2_fwd(qkv), qkv.b, QKV, R);
 }
 void trr_qkv_bwd(const float* dQKV, const float* X, const float* gamma, const Lin& qkv, const float* dX1,
                  float* dXin, int64_t E, int64_t R, hipStream_t st) {
-    if (g_bf16x6 && g_f16x3 && qkv.bwd2)
-        k_qkv_bwd_h<<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, w2_bwd(qkv), dX1, dXin, E, R);
-    else if (g_bf16x6 && qkv.bwd3) k_qkv_bwd_b<<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, w3_bwd(qkv), dX1, dXin, E, R);
-    else k_qkv_bwd_t<<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, qkv.bwd, dX1, dXin, E, R);
+    if (R <= 0) return;
+    k_qkv_bwd_h<<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, w2_bwd(qkv), dX1, dXin, E, R);
 }
 void trr_oproj(const float* AO, const float* X, const Lin& out, float* X1, float* OC, int64_t E, int64_t R,
                hipStream_t st) {
-    if (g_bf16x6 && g_f16x3 && out.fwd2) k_oproj_h<<<grid_rows(R), 256, 0, st>>>(AO, X, w2_fwd(out), out.b, X1, OC, E, R);
-    else if (g_bf16x6 && out.fwd3) k_oproj_b<<<grid_rows(R), 256, 0, st>>>(AO, X, w3_fwd(out), out.b, X1, OC, E, R);
-    else k_oproj_t<<<grid_rows(R), 256, 0, st>>>(AO, X, out.fwd, out.b, X1, OC, E, R);
+    if (R <= 0) return;
+    k_oproj_h<<<grid_rows(R), 256, 0, st>>>(AO, X, w2_fwd(out), out.b, X1, OC, E, R);
 }
 void trr_oproj_bwd(const float* dX1, const float* dOC, const Lin& out, float* dAO, int64_t E, int64_t R,
                    hipStream_t st) {
-    if (g_bf16x6 && g_f16x3 && out.bwd2) k_oproj_bwd_h<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, w2_bwd(out), dAO, E, R);
-    else if (g_bf16x6 && out.bwd3) k_oproj_bwd_b<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, w3_bwd(out), dAO, E, R);
-    else k_oproj_bwd_t<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, out.bwd, dAO, E, R);
+    if (R <= 0) return;
+    k_oproj_bwd_h<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, w2_bwd(out), dAO, E, R);
 }
 void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wout, float* VG, float* X2,
               int64_t E, hipStream_t st) {
-    if (g_bf16x6 && g_f16x3 && win.fwd2 && wout.fwd2 && g_trr_persist && E > 0) {
-        const size_t rows_lds = (size_t)4 * 2 * 16 * 64 * sizeof(float4);  // 128 KB: two row buffers per wave
-        const int grid = std::min(grid_rows(E), num_cus());
-        if (g_line_stores & 2) {
-            const size_t lds = rows_lds + (size_t)4 * 32 * TILE32_LD * sizeof(float);  // + one output tile per wave
-            allow_big_lds(k_emlp_h<true>, lds);
-            k_emlp_h<true><<<grid, 256, lds, st>>>(X1, gamma, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
-        } else {
-            allow_big_lds(k_emlp_h<false>, rows_lds);
-            k_emlp_h<false><<<grid, 256, rows_lds, st>>>(X1, gamma, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
-        }
-    } else if (g_bf16x6 && win.fwd3 && wout.fwd3 && g_trr_persist && E > 0) {
-        const size_t lds = (size_t)4 * 2 * 16 * 64 * sizeof(float4);  // 128 KB: two row buffers per wave
-        allow_big_lds(k_emlp_p, lds);
-        const int grid = std::min(grid_rows(E), num_cus());
-        k_emlp_p<<<grid, 256, lds, st>>>(X1, gamma, w3_fwd(win), win.b, w3_fwd(wout), wout.b, VG, X2, E);
-    } else if (g_bf16x6 && win.fwd3 && wout.fwd3)
-        k_emlp_b<<<grid_rows(E), 256, 0, st>>>(X1, gamma, w3_fwd(win), win.b, w3_fwd(wout), wout.b, VG, X2, E);
-    else
-        k_emlp_t<<<grid_rows(E), 256, 0, st>>>(X1, gamma, win.fwd, win.b, wout.fwd, wout.b, VG, X2, E);
+    if (E <= 0) return;
+    const size_t rows_lds = (size_t)4 * 2 * 16 * 64 * sizeof(float4);  // 128 KB: two row buffers per wave
+    const int grid = std::min(grid_rows(E), num_cus());
+    if (g_line_stores & 2) {
+        const size_t lds = rows_lds + (size_t)4 * 32 * TILE32_LD * sizeof(float);  // + one output tile per wave
+        allow_big_lds(k_emlp_h<true>, lds);
+        k_emlp_h<true><<<grid, 256, lds, st>>>(X1, gamma, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
+    } else {
+        allow_big_lds(k_emlp_h<false>, rows_lds);
+        k_emlp_h<false><<<grid, 256, rows_lds, st>>>(X1, gamma, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
+    }
 }
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
                   const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg) {
+    if (E <= 0) return;
     const int grid = grid_rows(E);
-    if (g_bf16x6 && g_f16x3 && win.bwd2 && wout.bwd2 && win.fwd2 && VG == nullptr && !t_dvg) {
+    if (VG == nullptr && !t_dvg) {
         const size_t lds = (size_t)4 * 32 * 64 * sizeof(f16x8);  // 128 KB: both split row operands of 4 waves
         allow_big_lds(k_emlp_bwd_r, lds);
         k_emlp_bwd_r<<<grid, 256, lds, st>>>(dY, X1, gamma, w2_fwd(win), win.b, w2_bwd(wout), w2_bwd(win), dX1, E);
-    } else if (g_bf16x6 && g_f16x3 && win.bwd2 && wout.bwd2) {
-        if (t_dvg) k_emlp_bwd_h<true><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, t_dvg);
-        else k_emlp_bwd_h<false><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, nullptr);
-    } else if (g_bf16x6 && win.bwd3 && wout.bwd3) {
-        if (t_dvg) k_emlp_bwd_b<true><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w3_bwd(wout), w3_bwd(win), dX1, E, t_dvg);
-        else k_emlp_bwd_b<false><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w3_bwd(wout), w3_bwd(win), dX1, E, nullptr);
+    } else if (t_dvg) {
+        k_emlp_bwd_h<true><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, t_dvg);
     } else {
-        if (t_dvg) k_emlp_bwd_t<true><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, wout.bwd, win.bwd, dX1, E, t_dvg);
-        else k_emlp_bwd_t<false><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, wout.bwd, win.bwd, dX1, E, nullptr);
+        k_emlp_bwd_h<false><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, nullptr);
     }
 }
 
@@ -1738,7 +1031,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_h(const float* __restrict__ Xi
 
 bool trr_head_edge(const Model& m, const float* Xin, const float* fc, float* ypred, float* yout, int64_t E,
                    hipStream_t st) {
-    if (!(g_bf16x6 && g_f16x3 && (g_trr_tilek & 2) && m.eh0.fwd2 && m.eh2.fwd2)) return false;
+    if (!((g_trr_tilek & 2) && m.eh0.fwd2 && m.eh2.fwd2)) return false;
     k_head_h<<<grid_rows(E), 256, 0, st>>>(Xin, w2_fwd(m.eh0), m.eh0.b, w2_fwd(m.eh2), m.eh2.b, m.ell_w, m.ell_b, fc, ypred,
                                            yout, E);
     return true;
@@ -1746,7 +1039,7 @@ bool trr_head_edge(const Model& m, const float* Xin, const float* fc, float* ypr
 bool trr_head_edge_bwd(const Model& m, const float* Xin, const float* gA, const int* ctr, const float* fc,
                        const float* ypred, float* dfc, float* dXout, int64_t E, float* t_s1, float* t_da2, float* t_da1,
                        float* t_s2y, hipStream_t st) {
-    if (!(g_bf16x6 && g_f16x3 && (g_trr_tilek & 2) && m.eh0.fwd2 && m.eh2.fwd2 && m.eh0.bwd2 && m.eh2.bwd2)) return false;
+    if (!((g_trr_tilek & 2) && m.eh0.fwd2 && m.eh2.fwd2 && m.eh0.bwd2 && m.eh2.bwd2)) return false;
     const int grid = grid_rows(E);
     if (t_s1)
         k_head_bwd_h<true><<<grid, 256, 0, st>>>(Xin, w2_fwd(m.eh0), m.eh0.b, w2_fwd(m.eh2), m.eh2.b, w2_bwd(m.eh0),
@@ -1759,164 +1052,9 @@ bool trr_head_edge_bwd(const Model& m, const float* Xin, const float* gA, const 
     return true;
 }
 
-// ---------------------------------------------------------------------------------
-// node update (transformer.py:222-227) as a TRR kernel on f16x3: one wave = 32 atoms,
-//   h1 = h + OC Wce^T + b;   hn = h1 + Wout (v sig(g)) + b,  [v; g] = Win RMSNorm(h1) + b
-// The 256-wide normalised row (16 K blocks x 2 planes) is parked in wave-private LDS (32 KB per wave); the 256
-// output columns of the second GEMM are eight accumulator tiles, their cross sums are folded in pair by pair so
-// that only one pair of them is live.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_node_h(const float* __restrict__ H, const float* __restrict__ OC, W2 wce,
-                                                 const float* __restrict__ bce, const float* __restrict__ gamma, W2 win,
-                                                 const float* __restrict__ bin, W2 wout, const float* __restrict__ bout,
-                                                 float* __restrict__ H1, float* __restrict__ VGn,
-                                                 float* __restrict__ Hn, int64_t N) {
-    extern __shared__ __attribute__((aligned(16))) f16x8 npark[];  // [4 waves][16 blocks][2 planes][64]
-    TRR_PROLOGUE(N);
-    f16x8* xp = npark + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 32 * 64;
-    constexpr int NC = DNF / 32;  // hidden chunks
-    {
-        float4 h1[32];
-        Split2<8> ocs;
-        {
-            float4 oc[16];
-            load_rowfrag<16>(oc, OC, row, D, L.h);
-            split_frag2<8>(oc, ocs);
-        }
-        float ss = 0.f;
-        row_gemm128_h<4, true>(wce, bce, ocs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
-            float4 y[8], hin[8];
-            acc_to_frag<2>(acc, y);
-            load_rowfrag<8>(hin, H + 64 * c, row, DN, L.h);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const float4 v = make_float4(y[k].x + hin[k].x, y[k].y + hin[k].y, y[k].z + hin[k].z, y[k].w + hin[k].w);
-                h1[8 * c + k] = v;
-                y[k] = v;
-                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-            }
-            if (valid) store_rowfrag<8>(y, H1 + 64 * c, row, DN, L.h);
-        });
-        const float rstd = rsqrtf(row_sum(ss) * (1.0f / DN) + 1.1920928955078125e-07f);
-#pragma unroll
-        for (int kg = 0; kg < 32; kg++) {
-            const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
-            h1[kg].x *= rstd * g.x; h1[kg].y *= rstd * g.y; h1[kg].z *= rstd * g.z; h1[kg].w *= rstd * g.w;
-        }
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            Split2<8> t;
-            split_frag2<8>(h1 + 16 * half, t);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                xp[(2 * (8 * half + k)) * 64 + L.lane] = t.h[k];
-                xp[(2 * (8 * half + k) + 1) * 64 + L.lane] = t.l[k];
-            }
-        }
-    }
-    // stream A: W_in, tile hc (value) and 16 + hc (gate), 16 K blocks each: b = 16 hc + kb
-    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
-    constexpr size_t TS = (size_t)NC * 16 * 64;
-    // stream B: W_out, K blocks 2 hc, 2 hc + 1 of the tile pairs (0,1) (2,3) (4,5) (6,7): j = 8 hc + 2 tp + kb
-    auto bidx = [&](int j) {
-        const int hc = j >> 3, tp = (j >> 1) & 3, kb = j & 1;
-        return ((size_t)(2 * tp) * (DNF / 16) + 2 * hc + kb) * 64 + L.lane;  // second tile of the pair at + (DNF / 16) * 64
-    };
-    WBlk2<2> ra[4], rb[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) ld_blk2<2>(ra[b], win, aidx(b), TS);
-#pragma unroll
-    for (int b = 0; b < 4; b++) ld_blk2<2>(rb[b], wout, bidx(b), (size_t)(DNF / 16) * 64);
-    f32x16 out[8];
-    acc_bias<8>(out, bout, 0, L.h);
-    float4 bv[4], bg[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        bv[q] = *reinterpret_cast<const float4*>(bin + 8 * q + 4 * L.h);
-        bg[q] = *reinterpret_cast<const float4*>(bin + DNF + 8 * q + 4 * L.h);
-    }
-#pragma unroll 1
-    for (int hc = 0; hc < NC; hc++) {
-        f32x16 vg[2], vgl[2];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            vg[0][4 * q] = bv[q].x; vg[0][4 * q + 1] = bv[q].y; vg[0][4 * q + 2] = bv[q].z; vg[0][4 * q + 3] = bv[q].w;
-            vg[1][4 * q] = bg[q].x; vg[1][4 * q + 1] = bg[q].y; vg[1][4 * q + 2] = bg[q].z; vg[1][4 * q + 3] = bg[q].w;
-        }
-        acc_zero<2>(vgl);
-        if (hc + 1 < NC) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                bv[q] = *reinterpret_cast<const float4*>(bin + 32 * (hc + 1) + 8 * q + 4 * L.h);
-                bg[q] = *reinterpret_cast<const float4*>(bin + DNF + 32 * (hc + 1) + 8 * q + 4 * L.h);
-            }
-        }
-        const f16x8* xq = xp + L.lane;
-        asm volatile("" : "+v"(xq));  // keep the parked fragments out of hoisted registers
-#pragma unroll
-        for (int kb = 0; kb < 16; kb++) {
-            const f16x8 xh = xq[(2 * kb) * 64], xl = xq[(2 * kb + 1) * 64];
-            WBlk2<2>& wb = ra[kb & 3];
-            mfma3<2>(vg, vgl, wb, xh, xl);
-            const int nb = 16 * hc + kb + 4;
-            if (nb < 16 * NC) ld_blk2<2>(wb, win, aidx(nb), TS);
-        }
-        fold_low<2>(vg, vgl);
-        float4 u[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 vv = acc_q(vg[0], q), gg = acc_q(vg[1], q);
-            if (VGn && valid) {
-                *reinterpret_cast<float4*>(VGn + row * (2 * DNF) + 32 * hc + 8 * q + 4 * L.h) = vv;
-                *reinterpret_cast<float4*>(VGn + row * (2 * DNF) + DNF + 32 * hc + 8 * q + 4 * L.h) = gg;
-            }
-            u[q] = make_float4(vv.x * sigm_(gg.x), vv.y * sigm_(gg.y), vv.z * sigm_(gg.z), vv.w * sigm_(gg.w));
-        }
-        Split2<2> us;
-        split_frag2<2>(u, us);
-#pragma unroll
-        for (int tp = 0; tp < 4; tp++) {
-            f32x16 lo[2];
-            acc_zero<2>(lo);
-            f32x16(&op)[2] = *reinterpret_cast<f32x16(*)[2]>(&out[2 * tp]);
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
-                WBlk2<2>& wb = rb[(2 * tp + kb) & 3];
-                mfma3<2>(op, lo, wb, us.h[kb], us.l[kb]);
-                const int nb = 8 * hc + 2 * tp + kb + 4;
-                if (nb < 8 * NC) ld_blk2<2>(wb, wout, bidx(nb), (size_t)(DNF / 16) * 64);
-            }
-            fold_low<2>(op, lo);
-        }
-    }
-    if (valid) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            float4 y[8], hr[8];
-            acc_to_frag<2>(*reinterpret_cast<f32x16(*)[2]>(&out[2 * c]), y);
-            load_rowfrag<8>(hr, H1 + 64 * c, row, DN, L.h);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                y[k].x += hr[k].x; y[k].y += hr[k].y; y[k].z += hr[k].z; y[k].w += hr[k].w;
-            }
-            store_rowfrag<8>(y, Hn + 64 * c, row, DN, L.h);
-        }
-    }
-}
-
-bool trr_node(const AttnLayerW& A, const float* H, const float* OC, float* H1, float* VGn, float* Hn, int64_t N,
-              hipStream_t st) {
-    if (!(g_bf16x6 && g_f16x3 && (g_trr_tilek & 4) && A.ce.fwd2 && A.cmlp_in.fwd2 && A.cmlp_out.fwd2) || N <= 0) return false;
-    const size_t lds = (size_t)4 * 32 * 64 * sizeof(f16x8);  // 128 KB
-    allow_big_lds(k_node_h, lds);
-    k_node_h<<<grid_rows(N), 256, lds, st>>>(H, OC, w2_fwd(A.ce), A.ce.b, A.g_center, w2_fwd(A.cmlp_in), A.cmlp_in.b,
-                                              w2_fwd(A.cmlp_out), A.cmlp_out.b, H1, VGn, Hn, N);
-    return true;
-}
-
 bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* Min, float* a0_out, float* Xout,
                   int64_t E, hipStream_t st) {
-    if (!(g_bf16x6 && g_f16x3 && (g_trr_tilek & 1) && G.compress2.fwd2 && (first || G.compress0_msg.fwd2))) return false;
+    if (!((g_trr_tilek & 1) && G.compress2.fwd2 && (first || G.compress0_msg.fwd2)) || E <= 0) return false;
     if (first)
         k_compress_h<true><<<grid_rows(E), 256, 0, st>>>(g.geo, g.sp_nbr, G.wc, G.tbl, nullptr, W2(), w2_fwd(G.compress2),
                                                        G.compress2.b, a0_out, Xout, E);
@@ -1927,7 +1065,7 @@ bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* M
 }
 bool trr_compress_bwd(bool first, const float* dXe, const float* a0, const GnnLayerW& G, float* dgeo, float* dM,
                       int64_t E, float* t_da0, hipStream_t st) {
-    if (!(g_bf16x6 && g_f16x3 && (g_trr_tilek & 1) && G.compress2.bwd2 && G.wc2 && (first || G.compress0_msg.bwd2))) return false;
+    if (!((g_trr_tilek & 1) && G.compress2.bwd2 && G.wc2 && (first || G.compress0_msg.bwd2)) || E <= 0) return false;
     const int grid = grid_rows(E);
     if (first) {
         if (t_da0) k_compress_bwd_h<true, true><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), w2_wc(G), W2(), dgeo, nullptr, E, t_da0);

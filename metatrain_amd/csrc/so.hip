@@ -68,94 +68,9 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(const float* __restrict__ X, 
     }
 }
 
-// The same GEMM on the bf16 matrix cores (bf16x6, trr.h): the 64 x 128 activation chunk is split three ways
-// while it is staged, into three bf16 planes whose 16-element K blocks are stored in fragment order
-// (slot 8 g + j  <->  k = 4 g + j | 8 + 4 g + j - 4), so that a lane's A operand is one ds_read_b128 per plane.
-constexpr int LDB16 = 128 + 8;  // bf16 elements per LDS row (272 B: rows shift by 4 banks)
-
-__global__ __launch_bounds__(NTHREADS) void k_gemm_b(const float* __restrict__ X, int ldx, int K,
-                                                     const float* __restrict__ cs, W3 w, const float* __restrict__ bias,
-                                                     float* __restrict__ Y, int ldy, int n_out, int64_t R,
-                                                     int accumulate) {
-    extern __shared__ __attribute__((aligned(16))) __bf16 pl[];  // [3][64][LDB16]
-    const WaveId wv;
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
-    const int nk = K / 128, kbt = K / 16;
-    const int g = wv.lane >> 5;
-    for (int nblk = 0; nblk < n_out / 128; nblk++) {
-        f32x16 acc[2];
-        acc_fill_bias<2>(acc, bias, 128 * nblk + 64 * wv.ch, wv.lane);
-        for (int kc = 0; kc < nk; kc++) {
-            if (nk > 1 || nblk == 0) {
-                __syncthreads();
-                for (int idx = threadIdx.x; idx < BM * 32; idx += NTHREADS) {
-                    const int r = idx >> 5, c = idx & 31;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (row0 + r < R) v = *reinterpret_cast<const float4*>(X + (row0 + r) * ldx + 128 * kc + 4 * c);
-                    if (cs) {
-                        const float4 sc = *reinterpret_cast<const float4*>(cs + 128 * kc + 4 * c);
-                        v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
-                    }
-                    const int q = c & 3, slot = 16 * (c >> 2) + (q & 1) * 8 + (q >> 1) * 4;
-                    const float f[4] = {v.x, v.y, v.z, v.w};
-                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                    bf16x4 h, m, l;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        __bf16 a, b, cc;
-                        split3(f[j], a, b, cc);
-                        h[j] = a; m[j] = b; l[j] = cc;
-                    }
-                    __bf16* d = pl + r * LDB16 + slot;  // slot is a multiple of 4: one 8-byte store per plane
-                    *reinterpret_cast<bf16x4*>(d) = h;
-                    *reinterpret_cast<bf16x4*>(d + BM * LDB16) = m;
-                    *reinterpret_cast<bf16x4*>(d + 2 * BM * LDB16) = l;
-                }
-                __syncthreads();
-            }
-            const __bf16* arow = pl + (wv.rb * 32 + (wv.lane & 31)) * LDB16 + 8 * g;
-            size_t base[2];
-#pragma unroll
-            for (int t = 0; t < 2; t++) base[t] = ((size_t)(4 * nblk + 2 * wv.ch + t) * kbt + 8 * kc) * 64 + wv.lane;
-            bf16x8 wh[2][2], wm[2][2], wl[2][2];
-#pragma unroll
-            for (int sidx = 0; sidx < 2; sidx++)
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    wh[sidx][t] = w.h[base[t] + sidx * 64]; wm[sidx][t] = w.m[base[t] + sidx * 64];
-                    wl[sidx][t] = w.l[base[t] + sidx * 64];
-                }
-#pragma unroll
-            for (int kb = 0; kb < 8; kb++) {
-                const int cur = kb & 1;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(arow + 16 * kb);
-                const bf16x8 am = *reinterpret_cast<const bf16x8*>(arow + BM * LDB16 + 16 * kb);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(arow + 2 * BM * LDB16 + 16 * kb);
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    acc[t] = PET_MFMA_B(al, wh[cur][t], acc[t]);
-                    acc[t] = PET_MFMA_B(ah, wl[cur][t], acc[t]);
-                    acc[t] = PET_MFMA_B(am, wm[cur][t], acc[t]);
-                    acc[t] = PET_MFMA_B(am, wh[cur][t], acc[t]);
-                    acc[t] = PET_MFMA_B(ah, wm[cur][t], acc[t]);
-                    acc[t] = PET_MFMA_B(ah, wh[cur][t], acc[t]);
-                }
-                if (kb + 2 < 8)
-#pragma unroll
-                    for (int t = 0; t < 2; t++) {
-                        wh[cur][t] = w.h[base[t] + (kb + 2) * 64]; wm[cur][t] = w.m[base[t] + (kb + 2) * 64];
-                        wl[cur][t] = w.l[base[t] + (kb + 2) * 64];
-                    }
-            }
-        }
-        acc_foreach<2>(acc, wv.rb, 128 * nblk + 64 * wv.ch, wv.lane, [&](int r, int c, float v) {
-            if (row0 + r < R) {
-                float* y = Y + (row0 + r) * ldy + c;
-                *y = accumulate ? *y + v : v;
-            }
-        });
-    }
-}
+// 16-bit planes are staged in fragment order (slot 8 g + j  <->  k = 4 g + j | 8 + 4 g + j - 4), so that a lane's
+// A operand is one ds_read_b128 per plane.
+constexpr int LDB16 = 128 + 8;  // 16-bit elements per LDS row (272 B: rows shift by 4 banks)
 
 // The same GEMM as f16x3 (trr.h): two fp16 planes, three MFMAs per K block on a high and a cross accumulator.
 // The operands here are tangents and adjoints of arbitrary magnitude, so every staged 64 x 128 chunk is scaled row by
@@ -434,21 +349,14 @@ static bool rowgemm_trr(hipStream_t st, const float* X, int K, const float* cs, 
     return false;
 }
 
-static int g_so_bf16x6 = 1;  // pet_config_set("so_bf16x6", 0): generic training GEMMs on the fp32 MFMA
-void set_so_bf16x6(int v) { g_so_bf16x6 = v ? 1 : 0; }
+static int g_so_f16x3 = 1;  // pet_config_set("so_f16x3", 0): generic training GEMMs on the fp32 MFMA
+void set_so_f16x3(int v) { g_so_f16x3 = v ? 1 : 0; }
 static inline W2 w2_at(const void* base, int n_out, int k_in) {
     const size_t n8 = (size_t)(n_out / 32) * (k_in / 16) * 64;
     const f16x8* b = reinterpret_cast<const f16x8*>(base);
     W2 w; w.h = b; w.l = b + n8;
     return w;
 }
-static inline W3 w3_at(const void* base, int n_out, int k_in) {
-    const size_t n8 = (size_t)(n_out / 32) * (k_in / 16) * 64;
-    const bf16x8* b = reinterpret_cast<const bf16x8*>(base);
-    W3 w; w.h = b; w.m = b + n8; w.l = b + 2 * n8;
-    return w;
-}
-
 struct Ctx {
     const Model& m;
     const Graph& g;
@@ -460,17 +368,13 @@ static void mm_fwd(const Ctx& c, const Lin& L, const float* X, float* Y, int64_t
                    bool acc = false) {
     if (R <= 0) return;
     ProfScope ps("so_gemm", c.st, 2.0 * (double)R * L.k_in * L.n_out, 4.0 * (double)R * (L.k_in + L.n_out));
-    if (g_so_bf16x6 && use_f16x3() && L.fwd2 &&
+    if (g_so_f16x3 && L.fwd2 &&
         rowgemm_trr(c.st, X, L.k_in, cs, w2_at(L.fwd2, L.n_out, L.k_in), bias ? L.b : nullptr, Y, L.n_out, R, acc)) {
-    } else if (g_so_bf16x6 && use_f16x3() && L.fwd2)
+    } else if (g_so_f16x3 && L.fwd2)
         k_gemm_h<<<cdiv(R, BM), NTHREADS, 2 * BM * LDB16 * 2 + BM * 4, c.st>>>(X, L.k_in, L.k_in, cs,
                                                                                w2_at(L.fwd2, L.n_out, L.k_in),
                                                                                bias ? L.b : nullptr, Y, L.n_out, L.n_out, R,
                                                                                acc ? 1 : 0);
-    else if (g_so_bf16x6 && L.fwd3)
-        k_gemm_b<<<cdiv(R, BM), NTHREADS, 3 * BM * LDB16 * 2, c.st>>>(X, L.k_in, L.k_in, cs, w3_at(L.fwd3, L.n_out, L.k_in),
-                                                                     bias ? L.b : nullptr, Y, L.n_out, L.n_out, R,
-                                                                     acc ? 1 : 0);
     else
         k_gemm<<<cdiv(R, BM), NTHREADS, BM * LD128 * 4, c.st>>>(X, L.k_in, L.k_in, cs, L.fwd, bias ? L.b : nullptr, Y,
                                                                L.n_out, L.n_out, R, acc ? 1 : 0);
@@ -479,16 +383,12 @@ static void mm_fwd(const Ctx& c, const Lin& L, const float* X, float* Y, int64_t
 static void mm_bwd(const Ctx& c, const Lin& L, const float* Yadj, float* Xadj, int64_t R, bool acc = false) {
     if (R <= 0) return;
     ProfScope ps("so_gemm", c.st, 2.0 * (double)R * L.k_in * L.n_out, 4.0 * (double)R * (L.k_in + L.n_out));
-    if (g_so_bf16x6 && use_f16x3() && L.bwd2 &&
+    if (g_so_f16x3 && L.bwd2 &&
         rowgemm_trr(c.st, Yadj, L.n_out, nullptr, w2_at(L.bwd2, L.k_in, L.n_out), nullptr, Xadj, L.k_in, R, acc)) {
-    } else if (g_so_bf16x6 && use_f16x3() && L.bwd2)  // the transposed operand: tiles over k_in, K = n_out
+    } else if (g_so_f16x3 && L.bwd2)  // the transposed operand: tiles over k_in, K = n_out
         k_gemm_h<<<cdiv(R, BM), NTHREADS, 2 * BM * LDB16 * 2 + BM * 4, c.st>>>(Yadj, L.n_out, L.n_out, nullptr,
                                                                                w2_at(L.bwd2, L.k_in, L.n_out), nullptr, Xadj,
                                                                                L.k_in, L.k_in, R, acc ? 1 : 0);
-    else if (g_so_bf16x6 && L.bwd3)
-        k_gemm_b<<<cdiv(R, BM), NTHREADS, 3 * BM * LDB16 * 2, c.st>>>(Yadj, L.n_out, L.n_out, nullptr,
-                                                                     w3_at(L.bwd3, L.k_in, L.n_out), nullptr, Xadj,
-                                                                     L.k_in, L.k_in, R, acc ? 1 : 0);
     else
         k_gemm<<<cdiv(R, BM), NTHREADS, BM * LD128 * 4, c.st>>>(Yadj, L.n_out, L.n_out, nullptr, L.bwd, nullptr, Xadj,
                                                                L.k_in, L.k_in, R, acc ? 1 : 0);

@@ -1,4 +1,4 @@
-// Transposed, register-resident row-tile toolkit (gfx950, wave64, fp32 MFMA 32x32x2).
+// Transposed, register-resident row-tile toolkit (gfx950, wave64, v_mfma_f32_32x32x16_f16 on split operands).
 //
 // One WAVE owns 32 rows and runs a whole chain of dense layers on them without LDS and
 // without barriers. The product is computed transposed, Y^T = W X^T:
@@ -91,150 +91,6 @@ __device__ __forceinline__ void acc_bias(f32x16 (&acc)[NT], const float* __restr
         }
 }
 
-// acc[t] += W[tiles tile0 .. tile0+NT)[k-groups kg0 .. kg0+KGS) . x[0 .. KGS)
-// Wp: packed [(tile * kg_total + kg) * 64 + lane] float4 (abi.hip k_pack). PF k-groups of weight
-// fragments are kept in flight ahead of the MFMAs that consume them.
-template <int KGS, int NT, int PF = 2>
-__device__ __forceinline__ void gemm_t(const float4* __restrict__ Wp, int kg_total, int kg0, int tile0,
-                                       const float4* x, f32x16 (&acc)[NT], int lane, int tile_stride = 1) {
-    const float4* wp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) wp[t] = Wp + ((size_t)(tile0 + t * tile_stride) * kg_total + kg0) * 64 + lane;
-    float4 wb[PF][NT];
-#pragma unroll
-    for (int s = 0; s < PF; s++)
-        if (s < KGS)
-#pragma unroll
-            for (int t = 0; t < NT; t++) wb[s][t] = wp[t][s * 64];
-#pragma unroll
-    for (int kg = 0; kg < KGS; kg++) {
-        const int cur = kg % PF;
-        const float4 xv = x[kg];
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[cur][t].x, xv.x, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[cur][t].y, xv.y, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[cur][t].z, xv.z, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[cur][t].w, xv.w, acc[t], 0, 0, 0);
-        if (kg + PF < KGS)
-#pragma unroll
-            for (int t = 0; t < NT; t++) wb[cur][t] = wp[t][(kg + PF) * 64];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// fp32 GEMM on the bf16 matrix cores ("bf16x6"): every fp32 operand is split three ways,
-//   x = h + m + l   (8 + 8 + 8 mantissa bits, each piece a bf16, exact),
-// and the product keeps the six terms h.h + h.m + m.h + h.l + l.h + m.m (the dropped ones are below
-// 2^-24 relative). v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32, so six of
-// them per K = 16 cost 192 cycles against 512 for the eight fp32 MFMAs they replace; the measured error
-// against fp64 is 3.7e-7 (the fp32 MFMA path: 4.5e-7; tools/ubench/bf16x3.hip). Operand layout: a lane
-// holds the k-set {16 kb + 4 h + j, 16 kb + 8 + 4 h + j} of its row, i.e. exactly row-fragment entries
-// 2 kb and 2 kb + 1, so the TRR fragments and the C/D tiles are unchanged.
-// ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct W3 {  // weight fragments, one array per split piece, [(tile * kb_total + kb) * 64 + lane]
-    const bf16x8 *h = nullptr, *m = nullptr, *l = nullptr;
-};
-
-__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)x;
-    const float r = x - (float)h;
-    m = (__bf16)r;
-    l = (__bf16)(r - (float)m);
-}
-// row-fragment entries x[2 kb], x[2 kb + 1] -> the three bf16x8 operands of K block kb
-template <int KB>
-struct Split3 {
-    bf16x8 h[KB], m[KB], l[KB];
-};
-template <int KB>
-__device__ __forceinline__ void split_frag(const float4* x, Split3<KB>& s) {
-#pragma unroll
-    for (int kb = 0; kb < KB; kb++) {
-        const float v[8] = {x[2 * kb].x, x[2 * kb].y, x[2 * kb].z, x[2 * kb].w,
-                            x[2 * kb + 1].x, x[2 * kb + 1].y, x[2 * kb + 1].z, x[2 * kb + 1].w};
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            __bf16 a, b, c;
-            split3(v[j], a, b, c);
-            s.h[kb][j] = a; s.m[kb][j] = b; s.l[kb][j] = c;
-        }
-    }
-}
-#define PET_MFMA_B(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
-// acc[t] += W[tiles tile0 + t * tile_stride][K blocks kb0 .. kb0+KBS) . x[0 .. KBS)   (six bf16 MFMAs per block)
-template <int KBS, int NT, int PF = 2, int KBX>
-__device__ __forceinline__ void gemm_b(const W3& w, int kb_total, int kb0, int tile0, const Split3<KBX>& x, int xk0,
-                                       f32x16 (&acc)[NT], int lane, int tile_stride = 1) {
-    size_t base[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) base[t] = ((size_t)(tile0 + t * tile_stride) * kb_total + kb0) * 64 + lane;
-    bf16x8 wh[PF][NT], wm[PF][NT], wl[PF][NT];
-#pragma unroll
-    for (int s = 0; s < PF; s++)
-        if (s < KBS)
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                wh[s][t] = w.h[base[t] + s * 64]; wm[s][t] = w.m[base[t] + s * 64]; wl[s][t] = w.l[base[t] + s * 64];
-            }
-#pragma unroll
-    for (int kb = 0; kb < KBS; kb++) {
-        const int cur = kb % PF;
-        const bf16x8 xh = x.h[xk0 + kb], xm = x.m[xk0 + kb], xl = x.l[xk0 + kb];
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(wl[cur][t], xh, acc[t]);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(wh[cur][t], xl, acc[t]);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(wm[cur][t], xm, acc[t]);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(wm[cur][t], xh, acc[t]);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(wh[cur][t], xm, acc[t]);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(wh[cur][t], xh, acc[t]);
-        if (kb + PF < KBS)
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                wh[cur][t] = w.h[base[t] + (kb + PF) * 64]; wm[cur][t] = w.m[base[t] + (kb + PF) * 64];
-                wl[cur][t] = w.l[base[t] + (kb + PF) * 64];
-            }
-    }
-}
-
-// Building blocks of the ring-prefetched bf16x6 kernels (pet_trr.hip): one K block of NT tiles, its load and
-// the six MFMAs per tile.
-template <int NT>
-struct WBlk {
-    bf16x8 h[NT], m[NT], l[NT];
-};
-template <int NT>
-__device__ __forceinline__ void ld_blk(WBlk<NT>& b, const W3& w, size_t i0, size_t tile_stride) {
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        b.h[t] = w.h[i0 + t * tile_stride]; b.m[t] = w.m[i0 + t * tile_stride]; b.l[t] = w.l[i0 + t * tile_stride];
-    }
-}
-template <int NT>
-__device__ __forceinline__ void mfma6(f32x16 (&acc)[NT], const WBlk<NT>& b, const bf16x8& xh, const bf16x8& xm,
-                                      const bf16x8& xl) {
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(b.l[t], xh, acc[t]);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(b.h[t], xl, acc[t]);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(b.m[t], xm, acc[t]);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(b.m[t], xh, acc[t]);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(b.h[t], xm, acc[t]);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_B(b.h[t], xh, acc[t]);
-}
 // accumulator tiles initialised from a prefetched bias fragment (float4 per (tile, q))
 template <int NT>
 __device__ __forceinline__ void acc_from(f32x16 (&acc)[NT], const float4 (&b)[4 * NT]) {
@@ -260,9 +116,9 @@ __device__ __forceinline__ void ld_bias(float4 (&b)[4 * NT], const float* __rest
 //   own magnitude so that it never falls into fp16's subnormal range),
 //   x w = h_x h_w + 2^-11 (h_x l'_w + l'_x h_w) + 2^-22 l'_x l'_w   (last term dropped: 2^-22 relative),
 // i.e. THREE v_mfma_f32_32x32x16_f16 per K block on two accumulators (the high-high sum and the cross sum, combined
-// as acc + 2^-11 acl at the end) instead of bf16x6's six on one, and two weight planes instead of three (the
-// L2 -> CU weight stream is a quarter of those kernels). Measured against fp64 (tools/ubench/f16x3.hip): 1.7e-7,
-// bf16x6 3.7e-7, fp32 MFMA 4.5e-7. fp16's range: |x| up to 65504; elements below 6e-5 keep 6e-8 ABSOLUTE accuracy,
+// as acc + 2^-11 acl at the end) and two weight planes (round 1's 3-way bf16 split, "bf16x6", needed six MFMAs on
+// three planes and was removed in round 2). Measured against fp64 (tools/ubench/f16x3.hip): 1.7e-7 (bf16x6 3.7e-7,
+// fp32 MFMA 4.5e-7). fp16's range: |x| up to 65504; elements below 6e-5 keep 6e-8 ABSOLUTE accuracy,
 // which is what fp32 gives relative to an O(1) row; rows that are small as a whole (adjoints) are scaled by a
 // power of two first (row_scale_pow2), exactly, and the result scaled back.
 // ---------------------------------------------------------------------------------------------

@@ -25,8 +25,7 @@ def run(tag):
 g0 = run("default")
 g1 = run("default again")
 print("run-to-run identical:", np.array_equal(g0, g1))
-for sw, val, dflt in [("attn_lds", 0, 3), ("attn_lds", 1, 3), ("attn_lds", 2, 3), ("trr", 0, 1), ("side_stream", 0, 1), ("f16x3", 0, 1), ("bf16x6", 0, 1),
-                      ("trr_persist", 0, 1), ("trr_compress", 0, 3), ("tile_f16x3", 0, 1)]:
+for sw, val, dflt in [("attn_lds", 1, 3), ("trr", 0, 1), ("side_stream", 0, 1), ("trr_compress", 0, 3), ("tile_f16x3", 0, 1)]:
     rt.config_set(sw, val)
     try:
         run(f"{sw}={val}")

@@ -519,16 +519,16 @@ def test_unknown_species_is_an_error_not_an_out_of_bounds_read(rt, model, dev):
                     torch.zeros(32, dtype=torch.int32, device=dev))
 
 
-@pytest.mark.parametrize("switch", ["trr", "attn_lds", "attn_lds=1", "attn_lds=2", "side_stream", "bf16x6", "trr_persist", "f16x3", "tile_f16x3", "emlp_recompute=1", "trr_compress", "trr_compress=7"])
+@pytest.mark.parametrize("switch", ["trr", "attn_lds=1", "side_stream", "tile_f16x3", "emlp_recompute=1", "trr_compress", "line_stores", "node_planes"])
 def test_alternative_kernel_paths_agree(rt, model, dev, golden_dir, switch):
-    """The library keeps its earlier kernel generations selectable (pet_config_set): LDS-tile GEMM stages
-    (trr=0), attention straight from global memory / staged per atom (attn_lds=0/1/2; the default 3 is the
-    persistent LDS-DMA adjoint), single stream (side_stream=0), fp32 MFMA instead of bf16x6 (bf16x6=0).
-    Each must meet the same parity bar."""
+    """The library keeps ONE fallback generation of its GEMM stages selectable (pet_config_set): the LDS-tile kernels
+    (trr=0, also the path of the variants; on fp32 MFMA with tile_f16x3=0), plus the per-atom staged attention adjoint (attn_lds=1;
+    the default 3 is the persistent LDS-DMA adjoint), a single stream (side_stream=0), the recomputing edge-MLP adjoint
+    and the A/B switches of the round-2 kernels. Each must meet the same parity bar."""
     g = _load(golden_dir, "pet_default_box64.npz")
     graph = _graph_from_golden(rt, model, g, dev)
     key, _, val = switch.partition("=")
-    default = {"attn_lds": 3, "trr_compress": 3, "emlp_recompute": 0}.get(key, 1)
+    default = {"attn_lds": 3, "trr_compress": 3, "emlp_recompute": 0, "line_stores": 3}.get(key, 1)
     rt.config_set(key, int(val or 0))
     try:
         fw = rt.HipForward(model, graph)
