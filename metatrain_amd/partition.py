@@ -1,0 +1,58 @@
+"""Slab + halo partition of ONE box over several ranks: the host-side plumbing shared by the
+SOAP-BPNN (`soap_bpnn/partition.py`, halo = one cutoff) and PET (`pet/partition.py`, halo = num_gnn_layers cutoffs)
+single-box paths. Positions are replicated, centres are cut into slabs along the lattice direction with the largest
+plane spacing, a rank works on its slab plus every atom within `halo` of it."""
+from typing import Sequence, Tuple
+
+import torch
+
+
+def slab_partition(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bool], halo: float, world: int,
+                   rank: int) -> Tuple[torch.Tensor, torch.Tensor, int]:
+    """``(index [n_sub] int64, owned [n_sub] bool, axis)``: the atoms rank ``rank`` of ``world`` works on (slab + halo,
+    ascending global index; the halo holds every atom within ``halo`` of the slab) and which of them it owns. Every atom is owned by exactly one rank. Element-wise tensor
+    work on the device (plumbing of the exchange, not the hot path)."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world size {world}")
+    dev = positions.device
+    n = positions.shape[0]
+    if world == 1:
+        return torch.arange(n, device=dev), torch.ones(n, dtype=torch.bool, device=dev), 0
+    c = cell.detach().to("cpu", torch.float64).reshape(3, 3)
+    periodic_cell = bool(abs(torch.det(c)) > 1e-12)
+    pos = positions.detach()
+    if periodic_cell:
+        # plane spacing of lattice direction a: V / |b x c|; cut along the direction with the largest one
+        vol = abs(float(torch.det(c)))
+        heights = []
+        for a in range(3):
+            b1, b2 = c[(a + 1) % 3], c[(a + 2) % 3]
+            heights.append(vol / float(torch.linalg.norm(torch.linalg.cross(b1, b2))))
+        axis = max(range(3), key=lambda a: heights[a])
+        inv = torch.linalg.inv(c).to(dev, pos.dtype)
+        f = (pos @ inv)[:, axis]
+        wrap = bool(pbc[axis])
+        if wrap:
+            f = f - torch.floor(f)
+            f = torch.where(f >= 1.0, f - 1.0, f)  # guard the rounding of values just below an integer
+            lo_all, width = 0.0, 1.0
+        else:
+            lo_all, width = float(f.min()), max(float(f.max() - f.min()), 1e-12) * (1.0 + 1e-6)
+        h = halo / heights[axis] * 1.0001
+    else:  # open system without a cell: slabs of the bounding box along the longest Cartesian extent
+        ext = pos.max(0).values - pos.min(0).values
+        axis = int(torch.argmax(ext))
+        f = pos[:, axis]
+        wrap = False
+        lo_all, width = float(f.min()), max(float(ext[axis]), 1e-12) * (1.0 + 1e-6)
+        h = halo * 1.0001
+    lo, hi = lo_all + width * rank / world, lo_all + width * (rank + 1) / world
+    owned = (f >= lo) & (f < hi)
+    below, above = lo - f, f - hi  # > 0 on the respective outside
+    if wrap:
+        below, above = torch.remainder(below, 1.0), torch.remainder(above, 1.0)
+        near = torch.minimum(below, above) < h
+    else:
+        near = ((below > 0) & (below < h)) | ((above >= 0) & (above < h))
+    index = torch.nonzero(owned | near).squeeze(1)
+    return index, owned[index], axis

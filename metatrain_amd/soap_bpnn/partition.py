@@ -9,63 +9,13 @@ energies of owned atoms are complete, halo atoms are only neighbours (their own,
 and seeded with zero) -- and the partial results are combined by ONE exchange: an all-reduce(sum) of the energy and of
 the ``[N, 3]`` gradient (1.2 MB), as SURVEY §8(e) prescribes. No kernel changes, no halo exchange of features.
 
-PET needs ``num_gnn_layers x r_c`` = 9 A halos and an exchange of edge messages per GNN layer; for PET a single box
-stays "replicas only" (DESIGN.md §6).
+PET uses the same scheme with ``num_gnn_layers x r_c`` halos (``metatrain_amd/pet/partition.py``).
 """
-from typing import Callable, Optional, Sequence, Tuple
+from typing import Callable, Optional, Sequence
 
 import torch
 
-
-def slab_partition(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bool], cutoff: float, world: int,
-                   rank: int) -> Tuple[torch.Tensor, torch.Tensor, int]:
-    """``(index [n_sub] int64, owned [n_sub] bool, axis)``: the atoms rank ``rank`` of ``world`` works on (slab + halo,
-    ascending global index) and which of them it owns. Every atom is owned by exactly one rank. Element-wise tensor
-    work on the device (plumbing of the exchange, not the hot path)."""
-    if not 0 <= rank < world:
-        raise ValueError(f"rank {rank} outside world size {world}")
-    dev = positions.device
-    n = positions.shape[0]
-    if world == 1:
-        return torch.arange(n, device=dev), torch.ones(n, dtype=torch.bool, device=dev), 0
-    c = cell.detach().to("cpu", torch.float64).reshape(3, 3)
-    periodic_cell = bool(abs(torch.det(c)) > 1e-12)
-    pos = positions.detach()
-    if periodic_cell:
-        # plane spacing of lattice direction a: V / |b x c|; cut along the direction with the largest one
-        vol = abs(float(torch.det(c)))
-        heights = []
-        for a in range(3):
-            b1, b2 = c[(a + 1) % 3], c[(a + 2) % 3]
-            heights.append(vol / float(torch.linalg.norm(torch.linalg.cross(b1, b2))))
-        axis = max(range(3), key=lambda a: heights[a])
-        inv = torch.linalg.inv(c).to(dev, pos.dtype)
-        f = (pos @ inv)[:, axis]
-        wrap = bool(pbc[axis])
-        if wrap:
-            f = f - torch.floor(f)
-            f = torch.where(f >= 1.0, f - 1.0, f)  # guard the rounding of values just below an integer
-            lo_all, width = 0.0, 1.0
-        else:
-            lo_all, width = float(f.min()), max(float(f.max() - f.min()), 1e-12) * (1.0 + 1e-6)
-        h = cutoff / heights[axis] * 1.0001
-    else:  # open system without a cell: slabs of the bounding box along the longest Cartesian extent
-        ext = pos.max(0).values - pos.min(0).values
-        axis = int(torch.argmax(ext))
-        f = pos[:, axis]
-        wrap = False
-        lo_all, width = float(f.min()), max(float(ext[axis]), 1e-12) * (1.0 + 1e-6)
-        h = cutoff * 1.0001
-    lo, hi = lo_all + width * rank / world, lo_all + width * (rank + 1) / world
-    owned = (f >= lo) & (f < hi)
-    below, above = lo - f, f - hi  # > 0 on the respective outside
-    if wrap:
-        below, above = torch.remainder(below, 1.0), torch.remainder(above, 1.0)
-        near = torch.minimum(below, above) < h
-    else:
-        near = ((below > 0) & (below < h)) | ((above >= 0) & (above < h))
-    index = torch.nonzero(owned | near).squeeze(1)
-    return index, owned[index], axis
+from ..partition import slab_partition  # noqa: F401  (re-exported: the partition itself is shared with PET)
 
 
 def energy_and_gradient(model, positions: torch.Tensor, species: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bool],
