@@ -380,6 +380,7 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *   "line_stores" bit mask: 1 = QKV projection, 2 = edge MLP write whole 128-B lines through a wave-private LDS tile
  *                 (default 3; the other row kernels always do)
  *   "node_planes" 1 = node-row kernels k_node2 / k_node_bwd2 (coalesced tiles, fp16 planes; default), 0 = k_node / k_swiglu_bwd
+ *   "wgrad_bf16"  1 = weight-gradient GEMMs of the training passes as bf16x3 split-operand products (default); 0 = fp32 MFMA
  *   "so_f16x3"    1 = generic GEMMs of the second-order (training) pass as f16x3 (default); 0 = fp32 MFMA
  *   "attn_lds"    attention adjoint: 1 per-atom LDS-staged for every atom, 3 persistent LDS-DMA kernel for atoms of at
  *                 most 32 tokens (default)

@@ -146,6 +146,15 @@ static void launch_k_wgrad(const WgradArgs& a, int nb, int nsplit, hipStream_t s
     const size_t lds = (size_t)WG_RB * (132 + KB + 4) * sizeof(float);
     k_wgrad<KB, XMODE><<<dim3(nb, nsplit), NTHREADS, lds, st>>>(a);
 }
+template <int XMODE>
+static void launch_k_wgrad_b(const WgradArgs& a, int nb, int nsplit, hipStream_t st) {
+    const size_t lds = (size_t)6 * 128 * WB_LDW * sizeof(unsigned);  // 60 KB: two workgroups per CU
+    k_wgrad_b<XMODE><<<nb * nsplit, NTHREADS, lds, st>>>(a, nb, nsplit);
+}
+
+// pet_config_set("wgrad_bf16", 0): weight gradients on the fp32 MFMA (k_wgrad) instead of bf16x3 (k_wgrad_b, default)
+static int g_wgrad_bf16 = 1;
+void set_wgrad_bf16(int v) { g_wgrad_bf16 = v ? 1 : 0; }
 
 // dW block [n_out, k_in] into dst (row stride ldw) and, if db_dst, the bias gradient
 static void wgrad_core(Trainer& t, int n_out, int k_in, Trainer::Y y, Trainer::X x, int xmode, int64_t n_rows,
@@ -153,18 +162,30 @@ static void wgrad_core(Trainer& t, int n_out, int k_in, Trainer::Y y, Trainer::X
     if (n_rows <= 0 || t.err) return;
     ProfScope ps("wgrad", t.st, 2.0 * (double)n_rows * n_out * k_in, 4.0 * (double)n_rows * (n_out + k_in));
     const int nb = n_out / 128;
-    const int KB = (xmode == 1 || xmode == 4) ? k_in : 128;
-    int nsplit = 768 / nb;  // three workgroups per CU (LDS: 34 - 50 KB each)
+    // bf16x3 kernel: 128 x columns per launch; the RMSNorm-hat source needs its whole row in one launch
+    const bool b16 = g_wgrad_bf16 && !(xmode == 1 && k_in != 128);
+    const int KB = b16 ? 128 : ((xmode == 1 || xmode == 4) ? k_in : 128);
+    int nsplit = (b16 ? 512 : 768) / nb;  // two (bf16x3: 60 KB of LDS) / three (fp32: 34 - 50 KB) workgroups per CU
     const int64_t max_by_rows = (n_rows + WG_RB - 1) / WG_RB;
     if (nsplit > max_by_rows) nsplit = (int)max_by_rows;
     while ((size_t)nsplit * n_out * (KB + 1) > t.w.partial_floats && nsplit > 1) nsplit /= 2;
+    if (b16 && nsplit > 8) nsplit &= ~7;  // XCD-aware workgroup numbering wants a multiple of 8
     float* pb = t.w.partial + (size_t)nsplit * n_out * KB;
     for (int k0 = 0; k0 < k_in; k0 += KB) {
         WgradArgs a;
         a.y0 = y.p0; a.y1 = y.p1; a.y_split = y.split; a.y_ld = y.ld; a.y_col0 = 0;
         a.x0 = x.p; a.x_ld = x.ld; a.x_col0 = k0; a.x_hid = x.hid; a.rev = x.rev; a.lns = x.lns;
         a.n_rows = n_rows; a.partial = t.w.partial; a.partial_b = (k0 == 0 && db_dst) ? pb : nullptr; a.n_out = n_out;
-        if (KB == 128) {
+        if (b16) {
+            switch (xmode) {
+                case 0: launch_k_wgrad_b<0>(a, nb, nsplit, t.st); break;
+                case 1: launch_k_wgrad_b<1>(a, nb, nsplit, t.st); break;
+                case 2: launch_k_wgrad_b<2>(a, nb, nsplit, t.st); break;
+                case 3: launch_k_wgrad_b<3>(a, nb, nsplit, t.st); break;
+                case 4: launch_k_wgrad_b<4>(a, nb, nsplit, t.st); break;
+                default: t.err = PET_ERR_ARGUMENT; return;
+            }
+        } else if (KB == 128) {
             switch (xmode) {
                 case 0: launch_k_wgrad<128, 0>(a, nb, nsplit, t.st); break;
                 case 1: launch_k_wgrad<128, 1>(a, nb, nsplit, t.st); break;
@@ -177,7 +198,6 @@ static void wgrad_core(Trainer& t, int n_out, int k_in, Trainer::Y y, Trainer::X
             else if (xmode == 4) launch_k_wgrad<256, 4>(a, nb, nsplit, t.st);
             else { t.err = PET_ERR_ARGUMENT; return; }
         }
-        const int64_t tot = (int64_t)n_out * KB;
         reduce_2d(t.w.partial, nsplit, n_out, KB, dst, ldw, k0, accumulate ? 1 : 0, t.st);
         if (k0 == 0 && db_dst)
             reduce_2d(pb, nsplit, n_out, 1, db_dst, 1, 0, accumulate ? 1 : 0, t.st);

@@ -183,14 +183,16 @@ def _oracle_second_order(params, hypers, inp, nu, u):
     return {k: (torch.zeros_like(p64[k]) if gr is None else gr) for k, gr in zip(keys, grads)}, tan, g.detach()
 
 
-@pytest.mark.parametrize("case,so_trr", [("pet_default_box64.npz", 1), ("batch_two_systems.npz", 1),
-                                         ("batch_two_systems.npz", 0)])
-def test_force_loss_parameter_gradients_match_oracle_double_backward(golden_dir, case, so_trr):
+@pytest.mark.parametrize("case,so_trr,wgrad_bf16", [("pet_default_box64.npz", 1, 1), ("batch_two_systems.npz", 1, 1),
+                                                    ("batch_two_systems.npz", 0, 1), ("batch_two_systems.npz", 1, 0)])
+def test_force_loss_parameter_gradients_match_oracle_double_backward(golden_dir, case, so_trr, wgrad_bf16):
     """The second-order pass (loss on dE/dR) against torch's double backward through the fp64 oracle; with the
-    generic GEMMs on the TRR kernels (default) and on the LDS-tile kernel (so_trr = 0)."""
+    generic GEMMs on the TRR kernels (default) and on the LDS-tile kernel (so_trr = 0), and with the weight-gradient
+    GEMMs as bf16x3 products (default) and on the fp32 MFMA (wgrad_bf16 = 0)."""
     from metatrain_amd import runtime as rt
 
     rt.config_set("so_trr", so_trr)
+    rt.config_set("wgrad_bf16", wgrad_bf16)
     dev = torch.device("cuda:0")
     hypers = dict(opet.DEFAULT_HYPERS)
     types = [1, 6, 7, 8]
@@ -228,6 +230,7 @@ def test_force_loss_parameter_gradients_match_oracle_double_backward(golden_dir,
     for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:12]:
         print(f"{v:.3e}  {k}")
     rt.config_set("so_trr", 1)
+    rt.config_set("wgrad_bf16", 1)
     bad = {k: v for k, v in worst.items() if not v < TOL}  # measured worst 6e-6
     assert not bad, f"second-order parameter gradients off: {bad}"
 
