@@ -94,7 +94,12 @@ struct Graph {
     float* d0 = nullptr;       // [E] |v| + 1e-15
     float* fc = nullptr;       // [E] cutoff factor
     int* sys = nullptr;        // [N] system index
-    int* scalars = nullptr;    // [4] device: n_kept, max_nbr, n_bad_reverse, unused
+    int* scalars = nullptr;    // [24] device: n_kept, max_nbr, n_bad_reverse, pad source, input checks; [8..12] atoms per
+                               // attention tile count (1, 2, 3, 4, more), [13..17] fill cursors
+    // atoms listed by attention tile count nt = ceil((neighbours + 1) / 16): the attention kernels are launched per
+    // tile count over exactly their own atoms (pet_attn.hip); bucket_start[k] = first entry of tile count k + 1
+    int* atom_order = nullptr; // [N]
+    int bucket_start[6] = {0, 0, 0, 0, 0, 0};  // host copy
     // adaptive cutoff (structures.py:225-263): CSR over ALL input edges (the root finder and its
     // implicit-function gradient see every edge within the maximum cutoff, kept or not)
     bool adaptive = false;

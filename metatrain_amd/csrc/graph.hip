@@ -282,6 +282,46 @@ __global__ void k_rowptr(const int* __restrict__ sorted_keys, int n_edges, int* 
     if (i == n_nodes) scalars[0] = lo;
 }
 
+// Atoms by attention tile count (bucket b = min(ceil((deg + 1) / 16), 5) - 1): counts, then a fill whose order inside a
+// bucket is whatever the atomics give -- every atom's attention is independent, so results do not depend on it.
+__global__ void k_bucket_count(const int* __restrict__ rowptr, int n_nodes, int* __restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = i < n_nodes ? min((rowptr[i + 1] - rowptr[i] + 1 + 15) >> 4, 5) - 1 : -1;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const unsigned long long m = __ballot(b == k);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[k], __popcll(m));
+    }
+}
+__global__ void k_bucket_fill(const int* __restrict__ rowptr, int n_nodes, const int* __restrict__ counts,
+                              int* __restrict__ cursors, int* __restrict__ order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = i < n_nodes ? min((rowptr[i + 1] - rowptr[i] + 1 + 15) >> 4, 5) - 1 : -1;
+    const int lane = threadIdx.x & 63;
+    int start = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const unsigned long long m = __ballot(b == k);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&cursors[k], __popcll(m));
+        base = __shfl(base, 0);
+        if (b == k) order[start + base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        start += counts[k];
+    }
+}
+static int bucket_atoms_by_tile_count(Graph& g, hipStream_t st) {  // scalars[8..17] were zeroed with the rest
+    if (g.n_nodes <= 0) return PET_OK;
+    const int T = 256;
+    k_bucket_count<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8);
+    k_bucket_fill<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8, g.scalars + 13, g.atom_order);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+static void set_bucket_starts(Graph& g, const int* counts) {
+    g.bucket_start[0] = 0;
+    for (int k = 0; k < 5; k++) g.bucket_start[k + 1] = g.bucket_start[k] + counts[k];
+}
+
 __global__ void k_max_nbr(const int* __restrict__ rowptr, int n_nodes, int* __restrict__ scalars) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int v = (i < n_nodes) ? rowptr[i + 1] - rowptr[i] : 0;
@@ -487,7 +527,8 @@ static int carve_graph(Graph& g, void* ws, int64_t n_nodes, int64_t e0, size_t* 
     g.d0 = c.take<float>(e0);
     g.fc = c.take<float>(e0);
     g.sys = c.take<int>(n_nodes);
-    g.scalars = c.take<int>(8);
+    g.scalars = c.take<int>(24);
+    g.atom_order = c.take<int>(n_nodes > 0 ? n_nodes : 1);
     g.rowptr0 = c.take<int>(n_nodes + 1);
     g.perm0 = c.take<int>(e0);
     g.nbr0 = c.take<int>(e0);
@@ -536,7 +577,7 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
     g.n_edges_in = e0;
     g.n_systems = n_systems;
     const int T = 256;
-    PET_HIP_CHECK(hipMemsetAsync(g.scalars, 0, 8 * sizeof(int), st));
+    PET_HIP_CHECK(hipMemsetAsync(g.scalars, 0, 24 * sizeof(int), st));
     if (n_nodes > 0) {
         k_species_index<<<cdiv(n_nodes, T), T, 0, st>>>(species, m.species_table, m.species_table_len,
                                                         g.sp, (int)n_nodes, g.scalars + 5, sys, g.sys,
@@ -597,11 +638,13 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
         k_reverse<<<cdiv(e0, T), T, 0, st>>>(g.rowptr, g.ctr, g.nbr, g.shift, g.rev, g.scalars);
         k_find_pad_src<<<cdiv(e0, T), T, 0, st>>>(g.perm, g.kidx, g.keep, g.scalars, g.scalars + 3);
     }
-    int host_scalars[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (int rcb = bucket_atoms_by_tile_count(g, st)) return rcb;
+    int host_scalars[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 13 * sizeof(int), hipMemcpyDeviceToHost, st));
     PET_HIP_CHECK(hipStreamSynchronize(st));
     g.n_edges = host_scalars[0];
     g.max_nbr = host_scalars[1];
+    set_bucket_starts(g, host_scalars + 8);
     PET_REQUIRE(host_scalars[6] == 0, PET_ERR_ARGUMENT,
                 std::to_string(host_scalars[6]) + " neighbour-list entries index atoms outside [0, n_nodes)");
     PET_REQUIRE(host_scalars[5] == 0, PET_ERR_ARGUMENT,
@@ -719,7 +762,8 @@ static int carve_from_batch(Graph& g, void* ws, int64_t n_nodes, int64_t M, size
     g.sp_nbr = c.take<int>(cap);
     g.geo = c.take<float4>(cap);
     g.fc = c.take<float>(cap);
-    g.scalars = c.take<int>(8);
+    g.scalars = c.take<int>(24);
+    g.atom_order = c.take<int>(n_nodes > 0 ? n_nodes : 1);
     size_t scan_bytes = 0;
     int* ni = nullptr;
     if (rocprim::exclusive_scan(nullptr, scan_bytes, ni, ni, 0, (size_t)(n_nodes + 1), rocprim::plus<int>()) != hipSuccess)
@@ -749,7 +793,7 @@ int graph_from_batch(const int64_t* el_nodes, const int64_t* el_nbr, const float
     g.n_systems = 0;
     g.adaptive = false;
     const int T = 256;
-    PET_HIP_CHECK(hipMemsetAsync(g.scalars, 0, 8 * sizeof(int), st));
+    PET_HIP_CHECK(hipMemsetAsync(g.scalars, 0, 24 * sizeof(int), st));
     PET_HIP_CHECK(hipMemsetAsync(g.kidx, 0, (n_nodes + 1) * sizeof(int), st));
     if (n_nodes > 0 && M > 0)
         k_mask_counts<<<cdiv(n_nodes, T), T, 0, st>>>(mask, (int)n_nodes, (int)M, g.kidx, g.scalars);
@@ -761,13 +805,15 @@ int graph_from_batch(const int64_t* el_nodes, const int64_t* el_nbr, const float
     else if (n_nodes > 0)
         k_from_batch_fill<<<cdiv(n_nodes, T), T, 0, st>>>(el_nodes, el_nbr, ev, ed, rni, cf, g.rowptr, (int)n_nodes, 1, g.ctr,
                                                           g.nbr, g.rev, g.sp, g.sp_nbr, g.geo, g.fc, g.scalars);
-    int host_scalars[8] = {0};
+    if (int rcb = bucket_atoms_by_tile_count(g, st)) return rcb;
+    int host_scalars[13] = {0};
     int n_edges = 0;
-    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 13 * sizeof(int), hipMemcpyDeviceToHost, st));
     PET_HIP_CHECK(hipMemcpyAsync(&n_edges, g.rowptr + n_nodes, sizeof(int), hipMemcpyDeviceToHost, st));
     PET_HIP_CHECK(hipStreamSynchronize(st));
     g.n_edges = n_edges;
     g.max_nbr = host_scalars[1];
+    set_bucket_starts(g, host_scalars + 8);
     PET_REQUIRE(host_scalars[2] == 0, PET_ERR_GRAPH,
                 "batch_data is not a NEF batch: " + std::to_string(host_scalars[2]) +
                     " rows with a real slot behind a pad, or reverse_neighbor_index entries that do not point at a real slot");

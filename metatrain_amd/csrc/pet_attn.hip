@@ -67,15 +67,16 @@ __device__ __forceinline__ void store_key_bias(float* __restrict__ dbh, int64_t 
 template <int NT>
 __global__ __launch_bounds__(256) void k_attn_fwd_p(const float* __restrict__ QKV, const int* __restrict__ rowptr,
                                                      const float* __restrict__ fc, float* __restrict__ AO,
-                                                     int64_t E, int N, float scale, int only_nt) {
+                                                     int64_t E, int N, float scale, const int* __restrict__ atoms,
+                                                     int n_list) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and the compiler knows it
-    const int atom = gw / NHEAD, head = gw % NHEAD;
-    if (atom >= N) return;
+    const int li = gw / NHEAD, head = gw % NHEAD;
+    if (li >= n_list) return;
+    const int atom = atoms[li];  // bucketed launch: the graph's list of the atoms with this tile count (graph.hip)
     const int start = rowptr[atom];
     const int T = rowptr[atom + 1] - start + 1;
     const int nt = (T + 15) >> 4;
-    if (only_nt && nt != only_nt) return;  // bucketed launch: this instantiation serves one tile count
     const int c16 = lane & 15, g4 = lane >> 4;
     const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head;
     float4 kf[NT], qf[NT];
@@ -151,15 +152,16 @@ template <int NT>
 __global__ __launch_bounds__(256) void k_attn_jvp_p(const float* __restrict__ QKV, const float* __restrict__ QKVd,
                                                      const int* __restrict__ rowptr, const float* __restrict__ fc,
                                                      const float* __restrict__ Tkb, float* __restrict__ AOd,
-                                                     int64_t E, int N, float scale, int only_nt) {
+                                                     int64_t E, int N, float scale, const int* __restrict__ atoms,
+                                                     int n_list) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and the compiler knows it
-    const int atom = gw / NHEAD, head = gw % NHEAD;
-    if (atom >= N) return;
+    const int li = gw / NHEAD, head = gw % NHEAD;
+    if (li >= n_list) return;
+    const int atom = atoms[li];
     const int start = rowptr[atom];
     const int T = rowptr[atom + 1] - start + 1;
     const int nt = (T + 15) >> 4;
-    if (only_nt && nt != only_nt) return;
     const int c16 = lane & 15, g4 = lane >> 4;
     const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head;
     float4 kf[NT], kdf[NT], qf[NT], qdf[NT];
@@ -250,15 +252,16 @@ __global__ __launch_bounds__(256) void k_attn_rev_p(const float* __restrict__ QK
                                                      const float* __restrict__ Tkb, const float* __restrict__ LO,
                                                      const float* __restrict__ NO, float* __restrict__ lQKV,
                                                      float* __restrict__ nQKV, int64_t E, int N, float scale,
-                                                     int only_nt) {
+                                                     const int* __restrict__ atoms,
+                                                     int n_list) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and the compiler knows it
-    const int atom = gw / NHEAD, head = gw % NHEAD;
-    if (atom >= N) return;
+    const int li = gw / NHEAD, head = gw % NHEAD;
+    if (li >= n_list) return;
+    const int atom = atoms[li];
     const int start = rowptr[atom];
     const int T = rowptr[atom + 1] - start + 1;
     const int nt = (T + 15) >> 4;
-    if (only_nt && nt != only_nt) return;
     const int c16 = lane & 15, g4 = lane >> 4;
     const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head;
     // fragments: token on the 16-lane axis (rows 16t + c16), 4 features per lane group
@@ -449,28 +452,34 @@ __global__ __launch_bounds__(256) void k_attn_rev_p(const float* __restrict__ QK
     }
 }
 
+// Bucketed launches: the graph build lists the atoms by tile count (Graph::atom_order, bucket_start), so every
+// instantiation is launched over exactly its own atoms (no early-exit workgroups).
+static inline int bucket_count(const Graph& g, int K) { return g.bucket_start[K] - g.bucket_start[K - 1]; }
+static inline const int* bucket_atoms(const Graph& g, int K) { return g.atom_order + g.bucket_start[K - 1]; }
+
 bool attn_jvp_mfma(int nt, const float* QKV, const float* QKVd, const Graph& g, const float* Tkb, float* AOd,
                    float scale, hipStream_t st) {
     if (nt > 4) return false;
-    const int grid = cdiv((int64_t)g.n_nodes * NHEAD, 4);
     const int N = (int)g.n_nodes;
-    k_attn_jvp_p<1><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, AOd, g.n_edges, N, scale, nt > 1 ? 1 : 0);
-    if (nt >= 2) k_attn_jvp_p<2><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, AOd, g.n_edges, N, scale, 2);
-    if (nt >= 3) k_attn_jvp_p<3><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, AOd, g.n_edges, N, scale, 3);
-    if (nt >= 4) k_attn_jvp_p<4><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, AOd, g.n_edges, N, scale, 4);
+#define PET_ATTN_JVP(K)                                                                                            \
+    if (nt >= K && bucket_count(g, K) > 0)                                                                         \
+        k_attn_jvp_p<K><<<cdiv((int64_t)bucket_count(g, K) * NHEAD, 4), 256, 0, st>>>(                             \
+            QKV, QKVd, g.rowptr, g.fc, Tkb, AOd, g.n_edges, N, scale, bucket_atoms(g, K), bucket_count(g, K));
+    PET_ATTN_JVP(1) PET_ATTN_JVP(2) PET_ATTN_JVP(3) PET_ATTN_JVP(4)
+#undef PET_ATTN_JVP
     return true;
 }
 bool attn_rev_mfma(int nt, const float* QKV, const float* QKVd, const Graph& g, const float* Tkb, const float* LO,
                    const float* NO, float* lQKV, float* nQKV, float scale, hipStream_t st) {
     if (nt > 3) return false;  // NT = 4 exceeds the register file; the VALU kernel in so.hip serves those batches
-    const int grid = cdiv((int64_t)g.n_nodes * NHEAD, 4);
     const int N = (int)g.n_nodes;
-    k_attn_rev_p<1><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, LO, NO, lQKV, nQKV, g.n_edges, N, scale,
-                                          nt > 1 ? 1 : 0);
-    if (nt >= 2)
-        k_attn_rev_p<2><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, LO, NO, lQKV, nQKV, g.n_edges, N, scale, 2);
-    if (nt >= 3)
-        k_attn_rev_p<3><<<grid, 256, 0, st>>>(QKV, QKVd, g.rowptr, g.fc, Tkb, LO, NO, lQKV, nQKV, g.n_edges, N, scale, 3);
+#define PET_ATTN_REV(K)                                                                                            \
+    if (nt >= K && bucket_count(g, K) > 0)                                                                         \
+        k_attn_rev_p<K><<<cdiv((int64_t)bucket_count(g, K) * NHEAD, 4), 256, 0, st>>>(                             \
+            QKV, QKVd, g.rowptr, g.fc, Tkb, LO, NO, lQKV, nQKV, g.n_edges, N, scale, bucket_atoms(g, K),           \
+            bucket_count(g, K));
+    PET_ATTN_REV(1) PET_ATTN_REV(2) PET_ATTN_REV(3)
+#undef PET_ATTN_REV
     return true;
 }
 
@@ -493,13 +502,12 @@ template <int NT>
 __global__ __launch_bounds__(512) void k_attn_bwd_l(const float* __restrict__ QKV, const float* __restrict__ dAO,
                                                      const int* __restrict__ rowptr, const float* __restrict__ fc,
                                                      float* __restrict__ dQKV, float* __restrict__ dbias_h,
-                                                     int64_t E, int N, float scale, int only_nt, int t_skip) {
+                                                     int64_t E, int N, float scale, const int* __restrict__ atoms) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int atom = blockIdx.x;
+    const int atom = atoms[blockIdx.x];  // one workgroup per atom of this tile count's list
     const int start = rowptr[atom];
     const int T = rowptr[atom + 1] - start + 1;
     const int nt = (T + 15) >> 4;
-    if ((only_nt && nt != only_nt) || T <= t_skip) return;  // t_skip: atoms the persistent kernel already served
     const int TP = 16 * nt;
     for (int idx = threadIdx.x; idx < TP * D; idx += 512) {  // D float4 per row: 96 of QKV + 32 of dO
         const int t = idx / D, c = idx % D;
@@ -642,10 +650,6 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ int attn_next_atom(int a, int step, int N, int cap, const int* __restrict__ rowptr) {
-    while (a < N && rowptr[a + 1] - rowptr[a] + 1 > cap) a += step;
-    return a;
-}
 __device__ __forceinline__ void attn_issue_rows(const float* __restrict__ QKV, const float* __restrict__ dAO,
                                                 const float* sm, int atom, int start, int T, int64_t E) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -664,14 +668,16 @@ template <int NT>
 __global__ __launch_bounds__(512) void k_attn_bwd_a(const float* __restrict__ QKV, const float* __restrict__ dAO,
                                                      const int* __restrict__ rowptr, const float* __restrict__ fc,
                                                      float* __restrict__ dQKV, float* __restrict__ dbias_h,
-                                                     int64_t E, int N, float scale, int cap) {
+                                                     int64_t E, int N, float scale, int cap,
+                                                     const int* __restrict__ atoms, int n_list) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // 2 x [cap][LDB] rows, then [8 waves][2][16][SCP]
     __shared__ float sbias_all[2][16 * NT];                     // log2 of the cutoff factor per key, per buffer
     const int head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qo = HD * head, ko = D + HD * head, vo = 2 * D + HD * head, doo = 3 * D + HD * head;
     const float s2 = scale * LOG2E;
     const int step = gridDim.x;
-    int atom = attn_next_atom(blockIdx.x, step, N, cap, rowptr);
+    int li = blockIdx.x;  // walks the graph's list of the atoms with at most `cap` tokens
+    int atom = li < n_list ? atoms[li] : N;
     float fc_pre = 1.f;  // thread t holds the cutoff factor of key t of the atom in flight
     int it = 0;
     if (atom < N) {
@@ -697,7 +703,8 @@ __global__ __launch_bounds__(512) void k_attn_bwd_a(const float* __restrict__ QK
         __syncthreads();                                  // ... and everybody else's
         // everyone is also done with the other buffer (read in the previous iteration's prologue): refill it now,
         // so the next atom's rows are in flight during this atom's whole compute phase
-        const int nxt = attn_next_atom(atom + step, step, N, cap, rowptr);
+        li += step;
+        const int nxt = li < n_list ? atoms[li] : N;
         fc_pre = 1.f;
         if (nxt < N) {
             const int st1 = rowptr[nxt], T1 = rowptr[nxt + 1] - st1 + 1;
@@ -832,24 +839,24 @@ static int g_attn_lds = 3;
 void set_attn_lds(int v) { g_attn_lds = v >= 2 ? 3 : 1; }
 
 // Atoms are served by the instantiation that matches their own tile count (registers / LDS, hence waves in
-// flight, scale with NT): one launch per tile count up to the batch maximum, the others exit at once.
+// flight, scale with NT): one launch per tile count, over the graph's list of the atoms that have it.
 bool attn_fwd_preload(int nt, const float* QKV, const Graph& g, float* AO, float scale, hipStream_t st) {
     if (nt > 4) return false;
     const int N = (int)g.n_nodes;
-    const int grid = cdiv((int64_t)g.n_nodes * NHEAD, 4);
-    const int only = nt > 1 ? 1 : 0;
-    k_attn_fwd_p<1><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale, only);
-    if (nt >= 2) k_attn_fwd_p<2><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale, 2);
-    if (nt >= 3) k_attn_fwd_p<3><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale, 3);
-    if (nt >= 4) k_attn_fwd_p<4><<<grid, 256, 0, st>>>(QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale, 4);
+#define PET_ATTN_FWD(K)                                                                                            \
+    if (nt >= K && bucket_count(g, K) > 0)                                                                         \
+        k_attn_fwd_p<K><<<cdiv((int64_t)bucket_count(g, K) * NHEAD, 4), 256, 0, st>>>(                             \
+            QKV, g.rowptr, g.fc, AO, g.n_edges, N, scale, bucket_atoms(g, K), bucket_count(g, K));
+    PET_ATTN_FWD(1) PET_ATTN_FWD(2) PET_ATTN_FWD(3) PET_ATTN_FWD(4)
+#undef PET_ATTN_FWD
     return true;
 }
 bool attn_bwd_preload(int nt, const float* QKV, const float* dAO, const Graph& g, float* dQKV, float* dbias_h,
                       float scale, hipStream_t st) {
     if (nt > 4) return false;
     const int N = (int)g.n_nodes;
-    int t_skip = 0, first = 1;
-    if (g_attn_lds == 3) {  // persistent LDS-DMA kernel for every atom with at most `cap` tokens
+    int first = 1;
+    if (g_attn_lds == 3) {  // persistent LDS-DMA kernel for every atom with at most `cap` tokens (tile counts 1 and 2)
         constexpr int cap = 32;
         static int n_cu = 0;
         if (!n_cu) {
@@ -857,19 +864,22 @@ bool attn_bwd_preload(int nt, const float* QKV, const float* dAO, const Graph& g
             (void)hipGetDevice(&dev);
             (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
         }
-        const size_t lds = ((size_t)2 * cap * LDB + 8 * 2 * 16 * SCP) * sizeof(float);  // 149 KB: one per CU
-        allow_big_lds(k_attn_bwd_a<2>, lds);
-        const int grid = N < n_cu ? N : n_cu;
-        k_attn_bwd_a<2><<<grid, 512, lds, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, cap);
-        t_skip = cap;
+        const int n_list = g.bucket_start[2];
+        if (n_list > 0) {
+            const size_t lds = ((size_t)2 * cap * LDB + 8 * 2 * 16 * SCP) * sizeof(float);  // 149 KB: one per CU
+            allow_big_lds(k_attn_bwd_a<2>, lds);
+            const int grid = n_list < n_cu ? n_list : n_cu;
+            k_attn_bwd_a<2><<<grid, 512, lds, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, cap,
+                                                    g.atom_order, n_list);
+        }
         first = 3;
     }
 #define PET_ATTN_BWD_L(K)                                                                                      \
-    if (nt >= K && K >= first) {                                                                               \
+    if (nt >= K && K >= first && bucket_count(g, K) > 0) {                                                     \
         const size_t lds = (size_t)16 * K * LDB * sizeof(float);                                               \
         allow_big_lds(k_attn_bwd_l<K>, lds);                                                                   \
-        k_attn_bwd_l<K><<<N, 512, lds, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale,     \
-                                              nt > 1 ? K : 0, t_skip);                                         \
+        k_attn_bwd_l<K><<<bucket_count(g, K), 512, lds, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h,         \
+                                                              g.n_edges, N, scale, bucket_atoms(g, K));        \
     }
     PET_ATTN_BWD_L(1) PET_ATTN_BWD_L(2) PET_ATTN_BWD_L(3) PET_ATTN_BWD_L(4)
 #undef PET_ATTN_BWD_L
