@@ -189,16 +189,18 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_k128(const float* __restrict
                                                          const float* __restrict__ cs, W2 w,
                                                          const float* __restrict__ bias, float* __restrict__ Y, int ldy,
                                                          int n_out, int64_t R, int accumulate) {
+    __shared__ __attribute__((aligned(16))) float tiles[4][32 * ROWS_LD];  // wave-private: whole-line loads / stores (trr.h)
     const RowLane L;
     const int64_t row0 = wave_row0();
     if (row0 >= R) return;
     const bool valid = row0 + L.r < R;
     const int64_t row = valid ? row0 + L.r : R - 1;
+    float* lds = tiles[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
     Split2<8> xs;
     float inv;
     {
         float4 x[16];
-        load_rowfrag<16>(x, X, row, ldx, L.h);
+        load_rows_lines(x, lds, L, [&](int r) { return X + (row0 + r < R ? row0 + r : R - 1) * ldx; });
         if (cs) {
 #pragma unroll
             for (int kg = 0; kg < 16; kg++) {
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_k128(const float* __restrict
 #pragma unroll
             for (int k = 0; k < 8; k++) { y[k].x += old[k].x; y[k].y += old[k].y; y[k].z += old[k].z; y[k].w += old[k].w; }
         }
-        if (valid) store_rowfrag<8>(y, Y + 64 * c, row, ldy, L.h);
+        store_tile64_lines(y, lds, Y + 64 * c, row0, R, ldy, L);
     }
 }
 
@@ -253,11 +255,13 @@ __global__ __launch_bounds__(256) void k_rowgemm_n128(const float* __restrict__ 
                                                       const float* __restrict__ cs, W2 w,
                                                       const float* __restrict__ bias, float* __restrict__ Y, int ldy,
                                                       int64_t R, int accumulate) {
+    __shared__ __attribute__((aligned(16))) float tiles[4][32 * TILE_LD];  // wave-private: whole-line stores (trr.h)
     const RowLane L;
     const int64_t row0 = wave_row0();
     if (row0 >= R) return;
     const bool valid = row0 + L.r < R;
     const int64_t row = valid ? row0 + L.r : R - 1;
+    float* lds = tiles[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
     const int kbt = K / 16, nks = K / 128;
     const size_t ts = (size_t)kbt * 64;  // tile stride: 32 output columns
     auto widx = [&](int b) { return (size_t)b * 64 + L.lane; };
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) void k_rowgemm_n128(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 16; k++) { y[k].x += old[k].x; y[k].y += old[k].y; y[k].z += old[k].z; y[k].w += old[k].w; }
     }
-    if (valid) store_rowfrag<16>(y, Y, row, ldy, L.h);
+    store_rows_lines<16>(y, lds, L, [&](int r) { return row0 + r < R ? Y + (row0 + r) * ldy : nullptr; });
 }
 
 static int g_so_trr = 1;  // pet_config_set("so_trr", 0): every generic GEMM through the LDS-tile k_gemm_h
