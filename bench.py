@@ -45,14 +45,13 @@ def synthetic_params(hypers):
 
 # ProfScope stage -> the kernels it launches (base names, template arguments stripped). The attention stages
 # launch one kernel per neighbour-count bucket (NT = 1, 2, 3 ...): their traffic is the sum over the buckets.
-STAGE_KERNELS = {"attn_bwd": ("k_attn_bwd_a", "k_attn_bwd_l", "k_attn_bwd_p"), "attn_fwd": ("k_attn_fwd_p", "k_attn_fwd_l"),
-                 "emlp": ("k_emlp_h", "k_emlp_p", "k_emlp_b", "k_emlp_t"),
-                 "emlp_bwd": ("k_emlp_bwd_h", "k_emlp_bwd_b", "k_emlp_bwd_t"),
-                 "qkv": ("k_qkv_h", "k_qkv_b", "k_qkv_t"), "qkv_bwd": ("k_qkv_bwd_h", "k_qkv_bwd_b", "k_qkv_bwd_t"),
-                 "comb": ("k_comb_h", "k_comb_b", "k_comb"), "comb_bwd": ("k_comb_bwd_h", "k_comb_bwd_b", "k_comb_bwd")}
+STAGE_KERNELS = {"attn_bwd": ("k_attn_bwd_a", "k_attn_bwd_l"), "attn_fwd": ("k_attn_fwd_p",),
+                 "emlp": ("k_emlp_h",), "emlp_bwd": ("k_emlp_bwd_h",),
+                 "qkv": ("k_qkv_h", "k_qkv_hl"), "qkv_bwd": ("k_qkv_bwd_h",),
+                 "comb": ("k_comb_h", "k_comb"), "comb_bwd": ("k_comb_bwd_h", "k_comb_bwd")}
 
 
-BF16X6_STAGES = {"emlp", "emlp_bwd", "qkv", "qkv_bwd", "oproj", "oproj_bwd", "comb", "comb_bwd", "compress",
+SPLIT_MFMA_STAGES = {"emlp", "emlp_bwd", "qkv", "qkv_bwd", "oproj", "oproj_bwd", "comb", "comb_bwd", "compress",
                  "compress_bwd", "head_edge", "head_edge_bwd", "node", "center", "head_node"}
 ARITHMETIC = ("f32 results: every dense stage computes its fp32 products as three fp16 MFMA terms on 2-way split "
               "operands (f16x3, fp32 accumulate, 1.7e-7 product error vs fp64); attention soft-max, norms and "
@@ -168,7 +167,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print a per-stage table to stderr")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=INT",
-                    help="library switch for A/B runs, e.g. --set attn_lds=0 (pet_config_set)")
+                    help="library switch for A/B runs, e.g. --set attn_lds=1 (pet_config_set)")
     args = ap.parse_args()
 
     from metatrain_amd import distributed as pdist
@@ -294,7 +293,7 @@ def main():
         roof["traffic"] = pmc_traffic(dominant, int(graph.n_edges))
         roof["arithmetic"] = ("fp32 MFMA soft-max attention kernel; the surrounding projections: " + ARITHMETIC
                               if dominant.startswith("attn") else ARITHMETIC)
-        if not hbm_bound and dominant in BF16X6_STAGES:
+        if not hbm_bound and dominant in SPLIT_MFMA_STAGES:
             roof["peak_f16x3_equivalent"] = MFMA_SPLIT_EQUIV_PEAK_TFLOPS
             roof["frac_of_f16x3_equivalent"] = achieved / MFMA_SPLIT_EQUIV_PEAK_TFLOPS
         roof["whole_step_algorithmic_tflops"] = None
