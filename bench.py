@@ -278,8 +278,12 @@ def main():
         avg_ms = dom["total_ms"] / dom["calls"]
         flops_per_launch = dom["flops"] / dom["calls"]
         bytes_per_launch = dom["bytes"] / dom["calls"]
-        # which roof bounds this stage: algorithmic FLOPs at the fp32 MFMA peak vs algorithmic bytes at HBM peak
-        hbm_bound = bytes_per_launch / (HBM_PEAK_GBS * 1e9) > flops_per_launch / (MFMA_F32_PEAK_TFLOPS * 1e12)
+        # which roof bounds this stage: algorithmic bytes at HBM peak vs algorithmic FLOPs at the peak of the matrix pipe
+        # the stage RUNS on -- the fp32 MFMA for attention, the 16-bit MFMA at three terms per product (f16x3:
+        # 2500 / 3 TFLOP/s fp32-equivalent) for the GEMM stages
+        split = dominant in SPLIT_MFMA_STAGES
+        mfma_peak = MFMA_SPLIT_EQUIV_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+        hbm_bound = bytes_per_launch / (HBM_PEAK_GBS * 1e9) > flops_per_launch / (mfma_peak * 1e12)
         if hbm_bound:
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -287,18 +291,30 @@ def main():
                     "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": None}
         else:
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "avg_launch_ms": avg_ms,
+            roof = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": mfma_peak,
+                    "unit": "TFLOP/s", "frac": achieved / mfma_peak, "avg_launch_ms": avg_ms,
                     "algorithmic_flops_per_launch": flops_per_launch, "traffic": None}
         roof["traffic"] = pmc_traffic(dominant, int(graph.n_edges))
         roof["arithmetic"] = ("fp32 MFMA soft-max attention kernel; the surrounding projections: " + ARITHMETIC
                               if dominant.startswith("attn") else ARITHMETIC)
-        if not hbm_bound and dominant in SPLIT_MFMA_STAGES:
-            roof["peak_f16x3_equivalent"] = MFMA_SPLIT_EQUIV_PEAK_TFLOPS
-            roof["frac_of_f16x3_equivalent"] = achieved / MFMA_SPLIT_EQUIV_PEAK_TFLOPS
+        if split:  # both roofs of a split-operand GEMM stage, whichever one "bound" names
+            tf = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            roof["fp32_equivalent_tflops"] = tf
+            roof["frac_of_f16x3_mfma_peak"] = tf / MFMA_SPLIT_EQUIV_PEAK_TFLOPS
+            roof["frac_of_hbm_peak"] = bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         roof["whole_step_algorithmic_tflops"] = None
         roof["stages_single_stream_ms"] = {r["name"]: round(r["total_ms"], 3)
                                            for r in sorted(table, key=lambda r: -r["total_ms"])[:8]}
+        # both roofs of every large stage, from the untimed single-stream step (per launch; the matrix roof is the one of
+        # the pipe the stage runs on): the dominant stage changes hands between attn_bwd and emlp_bwd from run to run
+        roof["stage_roofs_single_stream"] = {
+            r["name"]: {
+                "ms_per_launch": round(r["total_ms"] / r["calls"], 4),
+                "frac_of_hbm_peak": round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if r["bytes"] else None,
+                "frac_of_mfma_peak": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12 /
+                                           (MFMA_SPLIT_EQUIV_PEAK_TFLOPS if r["name"] in SPLIT_MFMA_STAGES
+                                            else MFMA_F32_PEAK_TFLOPS), 4) if r["flops"] else None,
+            } for r in sorted(table, key=lambda r: -r["total_ms"])[:8]}
         out = {
             "metric": "atom-steps/sec (energy+forces) PET 10k-atom box",
             "value": value,

@@ -1193,7 +1193,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             have_dM = true;
         } else {
             {
-                ProfScope ps("comb_bwd", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D));
+                ProfScope ps("comb_bwd", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D), fE * 4.0 * (3 * D + 2 * D + 2 * D));  // dM, e, e[rev], CA in; dcat out
                 if (!(trr && trr_comb_bwd(dM, B.XF, g, G, B.LNS, B.CA, w.dcat, E, tr ? w.dCA : nullptr, st)))
                     PET_LAUNCH_TR1(tr, k_comb_bwd, gE, lds2, st, dM, B.XF, g.rev, B.LNS, B.CA, G.ln_g, G.comb2.bwd,
                     G.comb0.bwd, w.dcat, E, tr ? w.dCA : nullptr);
@@ -1247,7 +1247,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                                                                                  A.mlp_in.bwd, dX, R, nullptr, false);
                 k_rownorm_bwd<<<gR, NTHREADS, lds1, st>>>(dX, dX + E * D, Ab.X1, A.g_attn, ln, dX_alt, E, R);
             } else {
-                ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
+                ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D), fE * 4.0 * (3 * D + 2 * DFF));  // dY, X1, VG in; dX1 out
                 if (trr_l) {
                     const float* vg = (!tr && emlp_recompute_ok(A.mlp_in, A.mlp_out)) ? nullptr : Ab.VG;
                     trr_emlp_bwd(dX, Ab.X1, vg, A.g_mlp, A.mlp_in, A.mlp_out, dX_alt, E, st, tr ? w.dVG : nullptr);
@@ -1265,7 +1265,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             // dX_alt (edge rows) = dX1, dH_alt = dH1; PostLN: dX_alt holds all E+N rows of d(tokens + attention output)
             const float* dOCr = post ? dX_alt + E * D : w.dOC;
             {
-                ProfScope ps("oproj_bwd", st, fR * 2.0 * D * D);
+                ProfScope ps("oproj_bwd", st, fR * 2.0 * D * D, fR * 4.0 * 2 * D);  // dX1 (| dOC) in; dAO out
                 if (trr_l) trr_oproj_bwd(dX_alt, w.dOC, A.out, w.dAO, E, R, st);
                 else k_oproj_bwd<<<gR, NTHREADS, lds1, st>>>(dX_alt, dOCr, A.out.bwd, w.dAO, E, R);
                 if (tr)
@@ -1288,7 +1288,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 tr->linear_after_norm(lp + ".attention.input_linear", A.qkv.w, 3 * D, D, {w.dQKV, nullptr, 0, 3 * D},
                                       {Ab.X, D, 0, nullptr, nullptr}, 1, R, lp + ".norm_attention.weight", A.g_attn);
             {
-                ProfScope ps("qkv_bwd", st, fR * 2.0 * D * 3 * D);
+                ProfScope ps("qkv_bwd", st, fR * 2.0 * D * 3 * D, fR * 4.0 * (3 * D + 3 * D));  // dQKV, X, dX1 in; dX out
                 if (trr_l) trr_qkv_bwd(w.dQKV, Ab.X, A.g_attn, A.qkv, dX_alt, dX, E, R, st);
                 else if (post) k_qkv_bwd<true><<<gR, NTHREADS, lds1, st>>>(w.dQKV, nullptr, nullptr, A.qkv.bwd, dX_alt, dX, E, R, false);
                 else k_qkv_bwd<false><<<gR, NTHREADS, lds1, st>>>(w.dQKV, Ab.X, A.g_attn, A.qkv.bwd, dX_alt, dX, E, R, ln);

@@ -896,7 +896,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                 side_busy = false;
             }
             {
-                ProfScope ps("qkv", st, fR * 2.0 * D * 3 * D);
+                ProfScope ps("qkv", st, fR * 2.0 * D * 3 * D, fR * 4.0 * (D + 3 * D));  // X in, QKV out
                 if (trr_l) trr_qkv(Ab.X, A.g_attn, A.qkv, Ab.QKV, R, st);
                 else if (post) k_qkv<false><<<gR, NTHREADS, lds1, st>>>(Ab.X, nullptr, nullptr, A.qkv.fwd, A.qkv.b, Ab.QKV, R);
                 else k_qkv<true><<<gR, NTHREADS, lds1, st>>>(Ab.X, A.g_attn, A.b_attn, A.qkv.fwd, A.qkv.b, Ab.QKV, R);
@@ -913,7 +913,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                 }
             }
             {
-                ProfScope ps("oproj", st, fR * 2.0 * D * D);
+                ProfScope ps("oproj", st, fR * 2.0 * D * D, fR * 4.0 * 3 * D);  // AO, X in; X1 (| OC) out
                 if (trr_l) trr_oproj(Ab.AO, Ab.X, A.out, Ab.X1, Ab.OC, E, R, st);
                 else if (post) k_oproj<true><<<gR, NTHREADS, lds1, st>>>(Ab.AO, Ab.X, A.out.fwd, A.out.b, Ab.X1, nullptr, E, R);
                 else k_oproj<false><<<gR, NTHREADS, lds1, st>>>(Ab.AO, Ab.X, A.out.fwd, A.out.b, Ab.X1, Ab.OC, E, R);
@@ -948,7 +948,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
             else if (gi + 1 < L) launch_center(gi + 1, 0);
             side_busy = true;
             if (E > 0 && !post) {
-                ProfScope ps("emlp", st, fE * 2.0 * (D * 2 * DFF + DFF * D));
+                ProfScope ps("emlp", st, fE * 2.0 * (D * 2 * DFF + DFF * D), fE * 4.0 * (2 * D + 2 * DFF));  // X1 in; VG, X2 out
                 if (trr_l) {
                     // [v; g] is stored for the adjoint unless no adjoint follows (save == 0) or it recomputes them
                     float* vg = (save == 0 || (save != 2 && emlp_recompute_ok(A.mlp_in, A.mlp_out))) ? nullptr : Ab.VG;
@@ -964,7 +964,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                 k_resmix<<<cdiv(E * (D / 4), 256), 256, 0, st>>>(Min, m.edge_emb, g.sp_nbr, B.XF, g.rev, B.Mout, E);
             }
         } else if (E > 0) {
-            ProfScope ps("comb", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D));
+            ProfScope ps("comb", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D), fE * 4.0 * (3 * D + 2 * D + D));  // e, e[rev], M in; CA, M out
             if (trr && trr_comb(gi == 0, B.XF, g, G, Min, m.edge_emb, B.CA, B.LNS, B.Mout, E, st)) {
                 // TRR kernel on the bf16 matrix cores (pet_comb.hip)
             } else if (gi == 0)
