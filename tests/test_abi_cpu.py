@@ -103,3 +103,14 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+
+
+def test_config_switches_of_removed_kernel_generations_are_rejected(lib):
+    """Round 2 dropped the fp32-MFMA / bf16x6 TRR generations and two attention forms: their switches are unknown keys
+    (PET_ERR_ARGUMENT), the documented ones (include/pet_hip.h) are accepted."""
+    for key in (b"bf16x6", b"f16x3", b"trr_persist", b"so_bf16x6", b"no_such_switch"):
+        assert lib.pet_config_set(key, 0) == -3, key
+    for key, default in ((b"trr", 1), (b"attn_lds", 3), (b"tile_f16x3", 1), (b"trr_compress", 3), (b"line_stores", 3),
+                         (b"node_planes", 1), (b"so_trr", 1), (b"so_f16x3", 1), (b"wgrad_bf16", 1), (b"emlp_recompute", 0),
+                         (b"side_stream", 1)):
+        assert lib.pet_config_set(key, default) == 0, key
