@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--partition", action="store_true",
                     help="strong scaling: ONE box for all ranks, cut into slabs + halos, one all-reduce of energy and "
                          "gradient per step (metatrain_amd/soap_bpnn/partition.py; BASELINE configs[4] at 8 GPUs)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="with --partition on ONE GPU: time every rank's share of a W-rank partition one after the other "
+                         "and report the busiest rank (a W-GPU step without its 1.2 MB all-reduce)")
     args = ap.parse_args()
 
     from metatrain_amd import distributed as pdist
@@ -187,6 +190,34 @@ def partitioned(args, model, S, rank, world, dev):
     pos, z, cell = random_box(args.atoms, seed=0)  # the same box on every rank
     posd, zd = pos.to(dev), z.to(dev)
     reduce = (lambda t: torch.distributed.all_reduce(t)) if world > 1 else None
+    if args.emulate_world > 1 and world == 1:
+        W, per_rank, subs = args.emulate_world, [], []
+        for r in range(W):
+            for _ in range(args.warmup):
+                partition.energy_and_gradient(model, posd, zd, cell, [True] * 3, W, r)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                e, grad, n_sub, n_owned = partition.energy_and_gradient(model, posd, zd, cell, [True] * 3, W, r)
+            torch.cuda.synchronize()
+            per_rank.append((time.perf_counter() - t0) / args.steps * 1e3)
+            subs.append(n_sub)
+        partition.energy_and_gradient(model, posd, zd, cell, [True] * 3, 1, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        partition.energy_and_gradient(model, posd, zd, cell, [True] * 3, 1, 0)
+        torch.cuda.synchronize()
+        whole = (time.perf_counter() - t0) * 1e3
+        print(json.dumps({
+            "metric": "ms per step of the busiest rank, SOAP-BPNN one box partitioned (ranks emulated one after the other on 1 GPU)",
+            "value": max(per_rank), "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": False,
+            "config": {"workload": f"ONE {args.atoms}-atom box cut into {W} slabs + 5 A halos",
+                       "ms_per_rank": [round(t, 2) for t in per_rank], "atoms_per_rank": subs,
+                       "whole_box_on_one_gpu_ms": round(whole, 2),
+                       "projected_speedup_over_one_gpu": round(whole / max(per_rank), 2),
+                       "not_included": "the all-reduce of [gradient | energy]"}}), flush=True)
+        return
 
     def step():
         return partition.energy_and_gradient(model, posd, zd, cell, [True] * 3, world, rank, all_reduce=reduce)
