@@ -18,6 +18,11 @@ published description (a full, periodic, cell-list neighbour list):
   PET re-filters with ``d <= cutoff`` (``pet/modules/structures.py:267``), so the
   boundary convention cannot change energies.
 
+Mixed periodicity: any subset of the three directions may be periodic (two, one -- wires / chains -- or none); the
+rows of the effective cell that belong to non-periodic directions are completed with unit vectors orthogonal to the
+rest (round 2 fixed the one-periodic-direction case, which produced a singular cell; checked against the brute-force
+statement in tests/test_oracle_golden.py).
+
 The output order of vesin is unspecified; "bit-exact" neighbour indices therefore
 means equality of the lexicographically sorted set of (i, j, Sa, Sb, Sc), which is
 the order this oracle returns.
@@ -83,15 +88,16 @@ def neighbor_list(
                 eff_cell[a] = 0.0
         for a in range(3):
             if not pbc[a]:
-                others = [eff_cell[b] for b in range(3) if b != a]
-                cand = np.cross(others[0], others[1])
-                if np.linalg.norm(cand) < 1e-12:
-                    for e in np.eye(3):
-                        trial = eff_cell.copy()
-                        trial[a] = e
-                        if abs(np.linalg.det(trial)) > 1e-12:
-                            cand = e
-                            break
+                # a unit vector orthogonal to the rows that are already fixed (the periodic ones, then the
+                # non-periodic ones completed so far): cross product of two, Gram-Schmidt against one, any axis for none
+                fixed = [eff_cell[b] for b in range(3) if b != a and np.linalg.norm(eff_cell[b]) > 1e-12]
+                if len(fixed) == 2:
+                    cand = np.cross(fixed[0], fixed[1])
+                elif len(fixed) == 1:
+                    u = fixed[0] / np.linalg.norm(fixed[0])
+                    cand = max((e - (e @ u) * u for e in np.eye(3)), key=np.linalg.norm)
+                else:
+                    cand = np.eye(3)[a]
                 eff_cell[a] = cand / np.linalg.norm(cand)
         frac = pos @ np.linalg.inv(eff_cell)
         wrap = np.zeros_like(frac)

@@ -1,0 +1,64 @@
+"""One-off randomized parity sweep (uses the oracle: lives under tests/): random sizes, densities, triclinic cells,
+mixed periodicity, several systems per batch; per-atom energies and dE/dR against the fp64 oracle."""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from metatrain_amd import runtime as rt
+from oracle import nl as onl
+from oracle import pet as opet
+
+dev = torch.device("cuda:0")
+hypers = dict(opet.DEFAULT_HYPERS)
+types = [1, 6, 7, 8]
+p32 = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+p64 = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float64)
+model = rt.HipModel(hypers, types)
+model.load({k: v.to(dev) for k, v in p32.items()}, "energy")
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+worst = (0.0, 0.0)
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
+    n_sys = int(rng.integers(1, 4))
+    pos_l, z_l, cell_l, i_l, j_l, s_l, sys_l, off = [], [], [], [], [], [], [], 0
+    desc = []
+    for k in range(n_sys):
+        n = int(rng.integers(2, 220))
+        rho = float(10 ** rng.uniform(-2.6, -0.95))
+        L = max((n / rho) ** (1 / 3), 3.0)
+        cell = np.eye(3) * L + (rng.uniform(-0.25, 0.25, (3, 3)) * L if rng.random() < 0.5 else 0.0)
+        pbc = [bool(b) for b in rng.random(3) < 0.7]
+        pos = rng.random((n, 3)) @ cell
+        z = rng.choice(types, n)
+        i, j, s, _ = onl.neighbor_list(pos, cell, pbc, hypers["cutoff"])
+        if len(i) and np.bincount(i, minlength=n).max() > 120:
+            continue
+        desc.append((n, round(rho, 4), pbc))
+        pos_l.append(torch.tensor(pos)); z_l.append(torch.tensor(z)); cell_l.append(torch.tensor(cell))
+        i_l.append(torch.tensor(i, dtype=torch.int64) + off); j_l.append(torch.tensor(j, dtype=torch.int64) + off)
+        s_l.append(torch.tensor(s, dtype=torch.int64).reshape(-1, 3)); sys_l.append(torch.full((n,), len(pos_l) - 1))
+        off += n
+    if not pos_l:
+        continue
+    pos, z, cells = torch.cat(pos_l), torch.cat(z_l), torch.stack(cell_l)
+    i, j, s, sysidx = torch.cat(i_l), torch.cat(j_l), torch.cat(s_l), torch.cat(sys_l)
+    graph = rt.HipGraph(model, pos.float().to(dev), cells.float().to(dev), i.to(dev), j.to(dev), s.to(dev), z.to(dev),
+                        sysidx.int().to(dev))
+    fw = rt.HipForward(model, graph)
+    atomic = fw.forward().cpu().double().ravel()
+    w = torch.tensor(rng.uniform(0.2, 2.0, off))
+    grad = fw.backward(w.float().to(dev)).cpu().double()
+    q = pos.float().double().requires_grad_(True)
+    ref = opet.pet_atomic_energies(p64, hypers, q, cells.float().double(), i, j, s, z, sysidx.long()).ravel()
+    (gp,) = torch.autograd.grad((ref * w).sum(), q)
+    ea = float((atomic - ref.detach()).abs().max() / ref.detach().abs().max())
+    eg = float((grad - gp).abs().max() / max(float(gp.abs().max()), 1e-30)) if len(i) else 0.0
+    worst = (max(worst[0], ea), max(worst[1], eg))
+    flag = "" if ea < 1e-5 and eg < 1e-5 else "   <-- ABOVE 1e-5"
+    if flag:  # yardstick: the same model evaluated by torch in fp32 on the CPU
+        q32 = pos.float().requires_grad_(True)
+        r32 = opet.pet_atomic_energies(p32, hypers, q32, cells.float(), i, j, s, z, sysidx.long()).ravel()
+        (g32,) = torch.autograd.grad((r32 * w.float()).sum(), q32)
+        flag += f" (torch fp32: E {float((r32.detach().double() - ref.detach()).abs().max() / ref.detach().abs().max()):.2e}" \
+                f" grad {float((g32.double() - gp).abs().max() / gp.abs().max()):.2e}; max|grad| {float(gp.abs().max()):.3e})"
+    print(f"trial {trial:3d} systems {desc} edges {len(i)}: E {ea:.2e} grad {eg:.2e}{flag}", flush=True)
+print("worst", worst)

@@ -111,7 +111,8 @@ def test_energy_and_forces_box1000(rt, model, dev, golden_dir):
 
 
 @pytest.mark.parametrize("n_atoms,seed,pbc", [(1000, 5, (True, True, True)), (300, 6, (True, True, False)),
-                                               (40, 7, (False, False, False)), (17, 8, (True, True, True))])
+                                               (40, 7, (False, False, False)), (17, 8, (True, True, True)),
+                                               (200, 9, (True, False, False)), (200, 10, (False, False, True))])
 def test_neighbor_list_set_equals_oracle(rt, dev, n_atoms, seed, pbc):
     pos, z, cell = opet.random_box(n_atoms, seed)
     if n_atoms == 17:  # cell thinner than the cutoff along one axis: periodic self-images

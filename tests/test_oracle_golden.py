@@ -123,6 +123,10 @@ def test_nl_oracle_tree_vs_bruteforce():
         (rng.uniform(-3, 9, (30, 3)), np.array([[6.0, 0, 0], [1.5, 5.5, 0], [-1.0, 0.7, 7.0]]), [True] * 3),
         (rng.uniform(0, 6, (25, 3)), np.array([[6.0, 0, 0], [0, 6.0, 0], [0, 0, 6.0]]), [True, True, False]),
         (rng.uniform(0, 7, (20, 3)), np.zeros((3, 3)), [False] * 3),
+        # ONE periodic direction (wires, chains): two rows of the effective cell have to be completed
+        (rng.uniform(-2, 8, (30, 3)), np.array([[5.0, 0.4, 0], [0.3, 6.0, 0.2], [0, 0.5, 7.0]]), [True, False, False]),
+        (rng.uniform(-2, 8, (30, 3)), np.array([[5.0, 0.4, 0], [0.3, 6.0, 0.2], [0, 0.5, 7.0]]), [False, True, False]),
+        (rng.uniform(-2, 8, (30, 3)), np.array([[5.0, 0.4, 0], [0.3, 6.0, 0.2], [0, 0.5, 3.0]]), [False, False, True]),
     ]
     for pos, cell, pbc in cases:
         a = onl.neighbor_list(pos, cell, pbc, 4.5)
