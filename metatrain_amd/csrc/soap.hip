@@ -148,13 +148,17 @@ __device__ __forceinline__ void radial_one(const SoapDims& d, const float* __res
     const float s = t - k, h = 1.0f / d.inv_h;
     const float s2 = s * s, om = 1.f - s;
     const float h00 = (1.f + 2.f * s) * om * om, h10 = s * om * om, h01 = s2 * (3.f - 2.f * s), h11 = s2 * (s - 1.f);
-    const float2 a = reinterpret_cast<const float2*>(table)[(size_t)k * d.F + f];
-    const float2 b = reinterpret_cast<const float2*>(table)[(size_t)(k + 1) * d.F + f];
+    // table entry: (R, dR/dr, chord slope (R[k+1] - R[k]) / h, 0). The derivative of the Hermite cubic needs the chord
+    // slope; taken from the fp32 node values it is a difference of two numbers 2e-3 relative apart times 1 / h = 410:
+    // 4e-5 |R| of rounding noise in dR/dr, which showed as 1.1e-5 .. 1.5e-5 in dE/dR of dilute systems (round-2 sweep,
+    // tests/debug/fuzz_soap.py). The host computes it in fp64.
+    const float4 a = reinterpret_cast<const float4*>(table)[(size_t)k * d.F + f];
+    const float4 b = reinterpret_cast<const float4*>(table)[(size_t)(k + 1) * d.F + f];
     const float v = h00 * a.x + h10 * h * a.y + h01 * b.x + h11 * h * b.y;
     *R = v * fc;
     if (dR) {
         const float g00 = 6.f * s2 - 6.f * s, g10 = 3.f * s2 - 4.f * s + 1.f, g11 = 3.f * s2 - 2.f * s;
-        const float dv = (g00 * a.x - g00 * b.x) * d.inv_h + g10 * a.y + g11 * b.y;
+        const float dv = g10 * a.y + g11 * b.y - g00 * a.z;
         *dR = dv * fc + v * dfc;
     }
 }
@@ -1924,7 +1928,7 @@ int64_t soap_model_feature_size(const soap_model_t* sm) { return sm ? sm->m.d.S 
 int soap_model_set_radial_table(soap_model_t* sm, const float* d_table, int32_t n_grid, void* stream) {
     PET_REQUIRE(sm && d_table && n_grid >= 4, PET_ERR_ARGUMENT, "bad argument");
     SoapModel& m = sm->m;
-    const size_t bytes = (size_t)n_grid * m.d.F * 2 * sizeof(float);
+    const size_t bytes = (size_t)n_grid * m.d.F * 4 * sizeof(float);
     int rc = salloc(m, (void**)&m.table, bytes);
     if (rc) return rc;
     PET_HIP_CHECK(hipMemcpyAsync(m.table, d_table, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));

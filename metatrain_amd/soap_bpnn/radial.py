@@ -1,6 +1,6 @@
 """Host-side construction of the radial basis, as the reference does it (torch-spex builds the
 Laplacian-eigenstate basis with scipy and hands a spline to the device code; ``soap_bpnn/model.py:251-264``
-selects ``LaplacianEigenstates(max_radial)``). The device evaluates a cubic Hermite spline on a uniform grid.
+selects ``LaplacianEigenstates(max_radial)``). The device evaluates a cubic Hermite spline on a uniform grid (node values, node derivatives and fp64-made chord slopes).
 
 Published definition (Bigi et al., J. Chem. Phys. 157, 234101 (2022)):
     R_nl(r) = N_nl j_l(z_nl r / r_c),   N_nl = [ r_c^3 / 2 * j_{l+1}(z_nl)^2 ]^(-1/2),
@@ -32,12 +32,17 @@ def laplacian_eigenstates(cutoff: float, max_radial: int, max_angular: int) -> T
 
 
 def spline_table(cutoff: float, zeros, norms, n_grid: int = 2049) -> np.ndarray:
-    """``[n_grid, F, 2]`` float32: (R(r), dR/dr) on a uniform grid over [0, cutoff], functions l-major."""
+    """``[n_grid, F, 4]`` float32: (R(r_k), dR/dr(r_k), chord slope (R(r_k+1) - R(r_k)) / h, 0) on a uniform grid over
+    [0, cutoff], functions l-major. The chord slope is formed here in fp64: from the fp32 node values it would carry
+    4e-5 |R| of rounding noise (two numbers 2e-3 apart, times 1 / h)."""
     r = np.linspace(0.0, cutoff, n_grid)
+    h = cutoff / (n_grid - 1)
     cols = []
     for l, (zl, nl) in enumerate(zip(zeros, norms)):
         for zn, nn in zip(zl, nl):
             k = zn / cutoff
-            cols.append(np.stack([nn * special.spherical_jn(l, k * r),
-                                  nn * k * special.spherical_jn(l, k * r, derivative=True)], axis=1))
+            val = nn * special.spherical_jn(l, k * r)
+            chord = np.concatenate([(val[1:] - val[:-1]) / h, [0.0]])
+            cols.append(np.stack([val, nn * k * special.spherical_jn(l, k * r, derivative=True), chord,
+                                  np.zeros_like(val)], axis=1))
     return np.stack(cols, axis=1).astype(np.float32)

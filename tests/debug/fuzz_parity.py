@@ -10,6 +10,16 @@ from oracle import pet as opet
 
 dev = torch.device("cuda:0")
 hypers = dict(opet.DEFAULT_HYPERS)
+mode = sys.argv[3] if len(sys.argv) > 3 else "default"
+if mode == "adaptive":
+    hypers.update(num_neighbors_adaptive=10, adaptive_cutoff_method="solver", cutoff_width_adaptive=1.0)
+elif mode == "grid":
+    hypers.update(num_neighbors_adaptive=10, adaptive_cutoff_method="grid", cutoff_width_adaptive=1.0)
+elif mode == "legacy":
+    hypers.update(normalization="LayerNorm", transformer_type="PostLN", activation="SiLU")  # (residual: layered API, own tests)
+elif mode == "cosine":
+    hypers.update(cutoff_function="Cosine")
+print("mode", mode)
 types = [1, 6, 7, 8]
 p32 = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
 p64 = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float64)

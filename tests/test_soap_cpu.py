@@ -53,7 +53,10 @@ def test_product_radial_tables_match_the_oracle(basis):
     for a, b in zip(norms, basis[2]):
         np.testing.assert_allclose(a, b, rtol=1e-10)
     table = radial.spline_table(5.0, zeros, norms, 513)
-    assert table.shape == (513, 44, 2) and table.dtype == np.float32
+    assert table.shape == (513, 44, 4) and table.dtype == np.float32
+    # third component: chord slope of the interval that starts at the node (made in fp64 on the host)
+    np.testing.assert_allclose(table[:-1, :, 2], np.diff(table[:, :, 0].astype(np.float64), axis=0) / (5.0 / 512), atol=2e-4)
+    assert np.all(table[-1, :, 2] == 0) and np.all(table[:, :, 3] == 0)
     r = torch.linspace(0, 5, 513, dtype=torch.float64).requires_grad_(True)
     rad = torch.cat(osoap.radial_basis(r, 5.0, basis[1], basis[2]), dim=1)
     np.testing.assert_allclose(table[:, :, 0], rad.detach().numpy(), atol=2e-6)
