@@ -26,7 +26,7 @@ p64 = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float64)
 model = rt.HipModel(hypers, types)
 model.load({k: v.to(dev) for k, v in p32.items()}, "energy")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-worst = (0.0, 0.0)
+worst = (0.0, 0.0, 0.0)
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     n_sys = int(rng.integers(1, 4))
     pos_l, z_l, cell_l, i_l, j_l, s_l, sys_l, off = [], [], [], [], [], [], [], 0
@@ -56,14 +56,18 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     fw = rt.HipForward(model, graph)
     atomic = fw.forward().cpu().double().ravel()
     w = torch.tensor(rng.uniform(0.2, 2.0, off))
-    grad = fw.backward(w.float().to(dev)).cpu().double()
+    grad, gcell = fw.backward(w.float().to(dev), want_cell_grad=True)
+    grad, gcell = grad.cpu().double(), gcell.cpu().double()
     q = pos.float().double().requires_grad_(True)
-    ref = opet.pet_atomic_energies(p64, hypers, q, cells.float().double(), i, j, s, z, sysidx.long()).ravel()
-    (gp,) = torch.autograd.grad((ref * w).sum(), q)
+    c64 = cells.float().double().requires_grad_(True)
+    ref = opet.pet_atomic_energies(p64, hypers, q, c64, i, j, s, z, sysidx.long()).ravel()
+    gp, gc = torch.autograd.grad((ref * w).sum(), [q, c64], allow_unused=True)
+    gc = torch.zeros_like(c64) if gc is None else gc
+    ec = float((gcell - gc).abs().max() / max(float(gc.abs().max()), 1e-30)) if float(gc.abs().max()) > 0 else 0.0
     ea = float((atomic - ref.detach()).abs().max() / ref.detach().abs().max())
     eg = float((grad - gp).abs().max() / max(float(gp.abs().max()), 1e-30)) if len(i) else 0.0
-    worst = (max(worst[0], ea), max(worst[1], eg))
-    flag = "" if ea < 1e-5 and eg < 1e-5 else "   <-- ABOVE 1e-5"
+    worst = (max(worst[0], ea), max(worst[1], eg), max(worst[2], ec))
+    flag = "" if ea < 1e-5 and eg < 1e-5 and ec < 1e-5 else f"   <-- ABOVE 1e-5 (cell {ec:.2e})"
     if flag:  # yardstick: the same model evaluated by torch in fp32 on the CPU
         q32 = pos.float().requires_grad_(True)
         r32 = opet.pet_atomic_energies(p32, hypers, q32, cells.float(), i, j, s, z, sysidx.long()).ravel()
