@@ -108,7 +108,8 @@ def radial_basis(r: torch.Tensor, cutoff: float, zeros, norms) -> List[torch.Ten
     out = []
     for l, (zl, nl) in enumerate(zip(zeros, norms)):
         cols = [float(nl[n]) * _sph_jn(l, r * (float(zl[n]) / cutoff)) for n in range(len(zl))]
-        out.append(torch.stack(cols, dim=1))
+        # an l without radial functions (small max_radial, large max_angular) contributes no features
+        out.append(torch.stack(cols, dim=1) if cols else r.new_zeros((r.shape[0], 0)))
     return out
 
 
@@ -146,7 +147,8 @@ def spherical_harmonics(u: torch.Tensor, max_l: int) -> List[torch.Tensor]:
                 cols.append(math.sqrt(2.0) * f * q[(l, am)] * c[am])
             else:
                 cols.append(math.sqrt(2.0) * f * q[(l, am)] * s[am])
-        out.append(torch.stack(cols, dim=1))
+        # an l without radial functions (small max_radial, large max_angular) contributes no features
+        out.append(torch.stack(cols, dim=1) if cols else r.new_zeros((r.shape[0], 0)))
     return out
 
 
