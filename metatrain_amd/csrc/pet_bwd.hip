@@ -1016,7 +1016,7 @@ __global__ void k_cell_grad(const float4* __restrict__ dv, const int* __restrict
                             int N, int64_t E, int accumulate) {
     // systems are contiguous atom ranges; find this system's atom range by scanning sys[] boundaries
     const int s = blockIdx.x;
-    __shared__ float red[9][256];
+    __shared__ double red[9][256];  // fp64 sums: a system's edges with a shift are a signed sum with heavy cancellation
     __shared__ int range[2];
     if (threadIdx.x == 0) {
         int lo = 0, hi = N;
@@ -1030,15 +1030,17 @@ __global__ void k_cell_grad(const float4* __restrict__ dv, const int* __restrict
         range[1] = rowptr[hi];
     }
     __syncthreads();
-    float acc[9];
+    double acc[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) acc[k] = 0.f;
+    for (int k = 0; k < 9; k++) acc[k] = 0.0;
     for (int p = range[0] + threadIdx.x; p < range[1]; p += blockDim.x) {
+        const int ia = shift[3 * p], ib = shift[3 * p + 1], ic = shift[3 * p + 2];
+        if ((ia | ib | ic) == 0) continue;  // most edges stay inside the cell
         const float4 d = dv[p];
-        const float sa = (float)shift[3 * p], sb = (float)shift[3 * p + 1], sc = (float)shift[3 * p + 2];
-        acc[0] += sa * d.x; acc[1] += sa * d.y; acc[2] += sa * d.z;
-        acc[3] += sb * d.x; acc[4] += sb * d.y; acc[5] += sb * d.z;
-        acc[6] += sc * d.x; acc[7] += sc * d.y; acc[8] += sc * d.z;
+        const double sa = ia, sb = ib, sc = ic, dx = d.x, dy = d.y, dz = d.z;
+        acc[0] += sa * dx; acc[1] += sa * dy; acc[2] += sa * dz;
+        acc[3] += sb * dx; acc[4] += sb * dy; acc[5] += sb * dz;
+        acc[6] += sc * dx; acc[7] += sc * dy; acc[8] += sc * dz;
     }
 #pragma unroll
     for (int k = 0; k < 9; k++) red[k][threadIdx.x] = acc[k];
@@ -1050,7 +1052,7 @@ __global__ void k_cell_grad(const float4* __restrict__ dv, const int* __restrict
         __syncthreads();
     }
     if (threadIdx.x < 9)
-        gcell[9 * s + threadIdx.x] = (accumulate ? gcell[9 * s + threadIdx.x] : 0.f) + red[threadIdx.x][0];
+        gcell[9 * s + threadIdx.x] = (accumulate ? gcell[9 * s + threadIdx.x] : 0.f) + (float)red[threadIdx.x][0];
 }
 
 // ---------------------------------------------------------------------------------

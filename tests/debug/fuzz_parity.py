@@ -19,6 +19,14 @@ elif mode == "legacy":
     hypers.update(normalization="LayerNorm", transformer_type="PostLN", activation="SiLU")  # (residual: layered API, own tests)
 elif mode == "cosine":
     hypers.update(cutoff_function="Cosine")
+elif mode == "hypers":  # the size-independent hyper-parameters (the kernels are one instantiation of the sizes)
+    _r = np.random.default_rng(int(sys.argv[1]) + 1000)
+    hypers.update(num_gnn_layers=int(_r.integers(1, 4)), num_attention_layers=int(_r.integers(1, 4)),
+                  cutoff=float(_r.choice([3.5, 4.5, 5.5])), cutoff_width=float(_r.choice([0.2, 0.5, 1.0])),
+                  attention_temperature=float(_r.choice([0.5, 1.0, 2.0])),
+                  cutoff_function=str(_r.choice(["Bump", "Cosine"])), activation=str(_r.choice(["SwiGLU", "SiLU"])))
+    print({k: hypers[k] for k in ("num_gnn_layers", "num_attention_layers", "cutoff", "cutoff_width",
+                                  "attention_temperature", "cutoff_function", "activation")})
 print("mode", mode)
 types = [1, 6, 7, 8]
 p32 = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
