@@ -29,6 +29,10 @@ elif mode == "hypers":  # the size-independent hyper-parameters (the kernels are
                                   "attention_temperature", "cutoff_function", "activation")})
 print("mode", mode)
 types = [1, 6, 7, 8]
+if len(sys.argv) > 3 and sys.argv[3] == "species":  # many atomic types, random atomic numbers up to 118
+    _r = np.random.default_rng(int(sys.argv[1]) + 2000)
+    types = sorted(int(t) for t in _r.choice(np.arange(1, 119), int(_r.integers(2, 41)), replace=False))
+    print("atomic_types", types)
 p32 = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
 p64 = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float64)
 model = rt.HipModel(hypers, types)
