@@ -178,10 +178,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PET_BENCH_BACKEND=gloo: a debugging aid for boxes with fewer GPUs than ranks (the ranks then share devices and
+    # the barrier / max-over-ranks go through gloo); the measured configuration is one rank per GPU over RCCL
+    backend = os.environ.get("PET_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        pdist.init("nccl", dev)  # "nccl" is RCCL on ROCm
+        pdist.init(backend, dev)  # "nccl" is RCCL on ROCm
 
     from metatrain_amd import runtime as rt
     from metatrain_amd.pet import default_hypers
