@@ -51,10 +51,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench_pet_box.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("PET_BENCH_BACKEND", "nccl")  # "gloo": debugging aid, ranks may share a GPU (bench.py)
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        pdist.init("nccl", dev)
+        pdist.init(backend, dev)
 
     from metatrain_amd import runtime as rt
     from metatrain_amd.pet import default_hypers, partition

@@ -76,14 +76,27 @@ def main():
 
     from metatrain_amd import distributed as pdist
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: start the ranks ourselves (as bench.py does)
+        import socket
+        import subprocess
+
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        raise SystemExit(subprocess.call(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+             "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]))
     rank, local_rank, world = pdist.env_rank()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench_train.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("PET_BENCH_BACKEND", "nccl")  # "gloo": debugging aid, ranks may share a GPU (bench.py)
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        pdist.init("nccl", dev)
+        pdist.init(backend, dev)
 
     from metatrain_amd import runtime as rt
     from metatrain_amd.pet import default_hypers
