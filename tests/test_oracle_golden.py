@@ -315,3 +315,27 @@ def test_oracle_reproduces_the_reference_tests_hand_tables_of_the_grid_method(go
     b = kat["gaussian_cutoff_weights"]
     w = opet.grid_gaussian_weights(torch.tensor(b["effective_num_neighbors"]), b["num_neighbors_adaptive"])
     assert torch.allclose(w, torch.tensor(b["expected"]))
+
+
+def test_energy_reads_one_cutoff_further_than_the_declared_interaction_range(golden_dir):
+    """``tests/golden/check_interaction_range.py`` ran the imported REFERENCE on a four-atom chain A-B-C-D (4 A spacing,
+    4.5 A cutoff, two GNN layers): dE_A/dR_D is not zero although D is 12 A from A, beyond the ``num_gnn_layers x cutoff``
+    = 9 A of ``pet/model.py:1004`` (the reversed-edge term of the last combination, ``backend.py:559-575``, reads one hop
+    further). The oracle reproduces the reference's numbers; ``metatrain_amd/pet/partition.py`` sizes its halos by it."""
+    import json
+
+    ref = json.load(open(os.path.join(golden_dir, "reference_interaction_range.json")))
+    hyp = dict(opet.DEFAULT_HYPERS)
+    params = opet.synthetic_params(hyp, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    pos = torch.tensor([[0.0, 0, 0], [4.0, 0.3, 0], [8.0, -0.2, 0.4], [12.0, 0.1, -0.3]], dtype=torch.float64,
+                       requires_grad=True)
+    z = torch.tensor([6, 1, 8, 7])
+    cell = torch.zeros(1, 3, 3, dtype=torch.float64)
+    i, j, s, _ = onl.neighbor_list(pos.detach().numpy(), cell[0].numpy(), [False] * 3, hyp["cutoff"])
+    atomic = opet.pet_atomic_energies(params, hyp, pos, cell, torch.tensor(i), torch.tensor(j), torch.tensor(s),
+                                      z, torch.zeros(4, dtype=torch.long))
+    (g,) = torch.autograd.grad(atomic[0, 0], pos)
+    assert ref["distance_A_to_D"] > ref["declared_interaction_range_A"] + 2.9
+    for n, k in enumerate("ABCD"):
+        np.testing.assert_allclose(g[n].numpy(), ref["dE_A_dR"][k], rtol=1e-9, atol=1e-14)
+    assert float(g[3].abs().max()) > 1e-3 * float(g[1].abs().max())  # far above rounding: a real dependence
