@@ -567,6 +567,47 @@ def main_conditioning():
         np.savez_compressed(os.path.join(HERE, f"pet_conditioning_{tag}.npz"), **store)
 
 
+def main_multitarget():
+    """Several targets, blocks and properties (backend.py:171-217, :689-777) and the non-conservative stress
+    post-processing (:780-813): energy + a target with two blocks of 3 and 6 properties + a 3x3 stress target on a
+    50-atom box -> ``pet_multitarget_box50.npz`` (every block's per-atom predictions, dE/dR of a weighted sum; fp64)."""
+    from oracle import nl as onl
+    from oracle import pet as opet
+
+    PETBackend = import_reference_backend()
+    torch.set_num_threads(8)
+    hyp = dict(opet.DEFAULT_HYPERS)
+    targets = {"energy": 1, "multi": {"a": 3, "b": 6}, "non_conservative_stress": 9}
+    params = opet.synthetic_params(hyp, [1, 6, 7, 8], targets, 0, torch.float64)
+    be = PETBackend(hyp, [1, 6, 7, 8])
+    be.add_output("energy", {"energy": [1]})
+    be.add_output("multi", {"a": [3], "b": [3, 2]})
+    be.add_output("non_conservative_stress", {"non_conservative_stress": [3, 3, 1]})
+    be = be.to(torch.float64)
+    be.load_state_dict(params, strict=True)
+    assert list(be.state_dict().keys()) == list(params.keys()), "schema order"
+    be = be.eval()
+    pos, z, cell = opet.random_box(50, 9)
+    i, j, s, _ = onl.neighbor_list(pos.double().numpy(), cell.double().numpy(), [True] * 3, hyp["cutoff"])
+    i, j, s = torch.tensor(i), torch.tensor(j), torch.tensor(s).long()
+    sysidx = torch.zeros(50, dtype=torch.long)
+    cells = cell[None].double()
+    p = pos.double().clone().requires_grad_(True)
+    batch = be.preprocess(p, i, j, z, cells, s, sysidx, 1.0)
+    nf, ef = be.calculate_features(batch)
+    pred, _, _ = be.predict(nf, ef, batch, cells, sysidx, ["energy", "multi", "non_conservative_stress"])
+    gen = torch.Generator().manual_seed(1)
+    wa, wb = torch.randn(50, 3, generator=gen).double(), torch.randn(50, 6, generator=gen).double()
+    (grad,) = torch.autograd.grad((pred["multi"][0] * wa).sum() + (pred["multi"][1] * wb).sum() + pred["energy"][0].sum(), p)
+    store = {"energy": pred["energy"][0].detach().numpy(), "multi_a": pred["multi"][0].detach().numpy(),
+             "multi_b": pred["multi"][1].detach().numpy(),
+             "non_conservative_stress": pred["non_conservative_stress"][0].detach().numpy(),
+             "wa": wa.numpy(), "wb": wb.numpy(), "grad": grad.numpy()}
+    print({k: v.shape for k, v in store.items()})
+    _store_inputs(store, (pos.double(), cells, i, j, s, z, sysidx))
+    np.savez_compressed(os.path.join(HERE, "pet_multitarget_box50.npz"), **store)
+
+
 def main_variants():
     """the variants older / production checkpoints use (pet/checkpoints.py:190-205 upgrades them to
     LayerNorm + SiLU + PostLN + residual featuriser = "legacy" here) and each switch on its own -- E, per-atom E, dE/dR
@@ -610,7 +651,9 @@ def main_variants():
 
 
 if __name__ == "__main__":
-    if "--conditioning" in sys.argv:
+    if "--multitarget" in sys.argv:
+        main_multitarget()
+    elif "--conditioning" in sys.argv:
         main_conditioning()
     elif "--variants" in sys.argv:
         main_variants()

@@ -470,3 +470,33 @@ def test_training_through_the_mirror_with_a_stress_term(golden_dir):
         if scale > 1e-12:
             worst = max(worst, float((named[k].grad.cpu().double() - ref[k]).abs().max()) / scale)
     assert worst < 2e-5, worst
+
+
+def test_several_targets_against_the_reference_golden(dev, golden_dir):
+    """The same three targets against what the imported REFERENCE produced (``make_golden.py --multitarget``,
+    ``pet_multitarget_box50.npz``): every block's per-atom predictions, the processed non-conservative stress and dE/dR
+    of the weighted sum, through the mirror's three calls."""
+    from metatrain_amd.pet import PETBackend, default_hypers
+
+    g = dict(np.load(os.path.join(golden_dir, "pet_multitarget_box50.npz")))
+    hypers = default_hypers()
+    targets = {"energy": 1, "multi": {"a": 3, "b": 6}, "non_conservative_stress": 9}
+    be = PETBackend(hypers, [1, 6, 7, 8])
+    be.add_output("energy", {"energy": [1]})
+    be.add_output("multi", {"a": [3], "b": [3, 2]})
+    be.add_output("non_conservative_stress", {"non_conservative_stress": [3, 3, 1]})
+    be.load_state_dict(opet.synthetic_params(hypers, [1, 6, 7, 8], targets), strict=True)
+    be = be.to(dev).eval()
+    t = lambda k: torch.tensor(g[k]).to(dev)  # noqa: E731
+    p = t("in_positions").float().requires_grad_(True)
+    cells, sysidx = t("in_cells").float(), t("in_system_indices")
+    batch = be.preprocess(p, t("in_centers"), t("in_neighbors"), t("in_species"), cells, t("in_cell_shifts"), sysidx, 1.0)
+    nodes, edges = be.calculate_features(batch)
+    pred, _, _ = be.predict(nodes, edges, batch, cells, sysidx, ["energy", "multi", "non_conservative_stress"])
+    (gp,) = torch.autograd.grad((pred["multi"][0] * t("wa").float()).sum() + (pred["multi"][1] * t("wb").float()).sum()
+                                + pred["energy"][0].sum(), p)
+    assert relmax(pred["energy"][0].detach().cpu().numpy(), g["energy"]) < TOL
+    assert relmax(pred["multi"][0].detach().cpu().numpy(), g["multi_a"]) < TOL
+    assert relmax(pred["multi"][1].detach().cpu().numpy(), g["multi_b"]) < TOL
+    assert relmax(pred["non_conservative_stress"][0].detach().cpu().numpy(), g["non_conservative_stress"]) < TOL
+    assert relmax(gp.cpu().numpy(), g["grad"]) < TOL

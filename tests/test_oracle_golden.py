@@ -339,3 +339,28 @@ def test_energy_reads_one_cutoff_further_than_the_declared_interaction_range(gol
     for n, k in enumerate("ABCD"):
         np.testing.assert_allclose(g[n].numpy(), ref["dE_A_dR"][k], rtol=1e-9, atol=1e-14)
     assert float(g[3].abs().max()) > 1e-3 * float(g[1].abs().max())  # far above rounding: a real dependence
+
+
+def test_oracle_matches_reference_on_several_targets_blocks_and_properties(golden_dir):
+    """``make_golden.py --multitarget``: the reference's predictions for an energy, a target with two blocks (3 and 6
+    properties) and the non-conservative stress (symmetrised, divided by the volume: backend.py:780-813), and dE/dR of a
+    weighted sum of them -- the oracle's per-block restatement against it."""
+    g = dict(np.load(os.path.join(golden_dir, "pet_multitarget_box50.npz")))
+    hyp = dict(opet.DEFAULT_HYPERS)
+    targets = {"energy": 1, "multi": {"a": 3, "b": 6}, "non_conservative_stress": 9}
+    p64 = opet.synthetic_params(hyp, [1, 6, 7, 8], targets, 0, torch.float64)
+    r = torch.tensor(g["in_positions"]).requires_grad_(True)
+    cells = torch.tensor(g["in_cells"])
+    args = (hyp, r, cells, torch.tensor(g["in_centers"]), torch.tensor(g["in_neighbors"]),
+            torch.tensor(g["in_cell_shifts"]), torch.tensor(g["in_species"]), torch.tensor(g["in_system_indices"]))
+    ra = opet.pet_atomic_energies(p64, *args, "multi", "a")
+    rb = opet.pet_atomic_energies(p64, *args, "multi", "b")
+    re = opet.pet_atomic_energies(p64, *args, "energy")
+    rs = opet.pet_atomic_energies(p64, *args, "non_conservative_stress")
+    (gr,) = torch.autograd.grad((ra * torch.tensor(g["wa"])).sum() + (rb * torch.tensor(g["wb"])).sum() + re.sum(), r)
+    np.testing.assert_allclose(re.detach().numpy(), g["energy"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(ra.detach().numpy(), g["multi_a"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(rb.detach().numpy(), g["multi_b"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(gr.numpy(), g["grad"], rtol=1e-9, atol=1e-12)
+    t = rs.detach().reshape(-1, 3, 3, 1) / float(torch.det(cells[0]).abs())
+    np.testing.assert_allclose(((t + t.transpose(1, 2)) / 2).numpy(), g["non_conservative_stress"], rtol=1e-10, atol=1e-14)
