@@ -183,6 +183,8 @@ int pet_graph_csr(const pet_graph_t* g, const int32_t** d_rowptr, const int32_t*
  * NULL for a pet_graph_build handle (it has them); the three device arrays must stay alive while the handle is used.
  * Values outside [-max_charge, max_charge] / [1, max_spin_multiplicity] are the caller's to reject (conditioning.py:54-80
  * does it on the host); the kernels clamp them. */
+/* Training (pet_backward_train / pet_backward_train2) sums the node-feature adjoints per system for the conditioning
+ * parameters: the system indices must then be non-decreasing (what concatenate_structures produces). */
 int pet_graph_set_conditioning(pet_graph_t* g, const int64_t* d_charge, const int64_t* d_spin_multiplicity,
                                const int64_t* d_system_indices, int64_t n_systems);
 

@@ -1184,6 +1184,9 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     for (int gi = m.h.num_gnn_layers - 1; gi >= 0; gi--) {
         const GnnLayerW& G = m.gnn[gi];
         const GnnBufs& B = w.gnn[gi];
+        // dH is the adjoint of the node features LEAVING this layer, where the system embedding was added (training:
+        // the side stream is off, so dH is complete on this stream)
+        if (tr) tr->cond_accumulate(dH, gi == m.h.num_gnn_layers - 1);
         if (res) {
             // backend.py:621-647: this layer's features were read out (seeds g_node / g_edge), its edge features were
             // averaged into the next layer's messages, and its node features started from a fresh embedding
@@ -1326,6 +1329,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     ss.join(st);
     if (tr) {
         tr->embeddings(dH, dM);
+        tr->cond_finish();
         if (tr->err) return tr->err;
     }
     k_dfc_attn<<<cdiv(E, 256), 256, 0, st>>>(g.fc, w.dbias_l, m.h.num_gnn_layers * m.h.num_attention_layers, w.dbias, E);

@@ -72,6 +72,7 @@ struct Workspace {
     float* hda2 = nullptr;
     float* hda1 = nullptr;
     float* hs2y = nullptr;
+    float* dcond = nullptr;   // system conditioning only: [n_systems <= N, DN] adjoint of the per-system embedding
     float* gmat = nullptr;    // [2][1024 x 256] reduced weight-gradient block (+ LayerNorm beta scratch)
     float* gvec = nullptr;    // [32768]
     float* partial = nullptr; // split-K partials
@@ -157,6 +158,7 @@ inline void carve_workspace(const Model& m, int64_t N, int64_t E, void* base, Wo
         w.hda2 = c.take<float>(Ma * DH);
         w.hda1 = c.take<float>(Ma * DH);
         w.hs2y = c.take<float>(Ma * DH);
+        if (m.h.system_conditioning) w.dcond = c.take<float>(Na * DN);
         w.gmat = c.take<float>(2 * 1024 * 256);
         w.gvec = c.take<float>(32768);
         w.partial_floats = (size_t)48 << 20;  // 192 MB of split-K partials

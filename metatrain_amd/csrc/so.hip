@@ -1237,6 +1237,9 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
         const std::string pre = "gnn_layers." + gs;
         const float* Min = gi == 0 ? nullptr : w.gnn[gi - 1].Mout;
         const float* TMin = gi == 0 ? s.TM0 : s.gnn[gi - 1].TMout;
+        // system conditioning: the embedding enters additively where the node features leave the layer and has no
+        // tangent, so its parameters see the second-order adjoint nu of those features only
+        tr.cond_accumulate(s.NH, gi == nG - 1);
         // ---- M_out = M_in + XF + comb2(silu(comb0(LN(cat))))
         tr.linear("combination_mlps." + gs + ".2", D, 2 * D, {s.NM, nullptr, 0, D}, {B.CA, 2 * D, 0, nullptr, nullptr}, 3, E);
         tr.linear("combination_mlps." + gs + ".2", D, 2 * D, {s.LM, nullptr, 0, D}, {S.TS, 2 * D, 0, nullptr, nullptr}, 0, E,
@@ -1340,6 +1343,7 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
     // embeddings: H0 = node_emb[species], M0 = edge_emb[neighbour species] (their tangents are zero)
     tr.species_rows(s.NH, g.sp, N, DN, tr.gp("node_embedders.0.weight"));
     tr.species_rows(s.NM, g.sp_nbr, E, D, tr.gp("edge_embedder.weight"));
+    tr.cond_finish();
     PET_HIP_CHECK(hipGetLastError());
     return tr.err;
 }

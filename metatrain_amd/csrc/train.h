@@ -37,6 +37,11 @@ struct Trainer {
 
     void heads(bool edge, const float* Xin, int k_in, int64_t n_rows, const float* gA);
     void embeddings(const float* dH0, const float* dM0);
+    // system conditioning (conditioning.py:82-100; backend.py:543-545 adds the per-system embedding to the node features
+    // LEAVING every GNN layer): cond_accumulate sums that layer's node-feature adjoint over the atoms of each system
+    // into w.dcond, cond_finish back-propagates the sum through the two-layer projection and the two embeddings
+    void cond_accumulate(const float* dHout, bool first);
+    void cond_finish();
     // (la0, Tgeo, TMin): second-order pair lambda_a0 with the tangents of the compress.0 inputs
     void compress0(int gi, const float* da0, const float* Min, const float* la0 = nullptr,
                    const float4* Tgeo = nullptr, const float* TMin = nullptr);

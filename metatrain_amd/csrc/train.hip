@@ -231,6 +231,119 @@ void Trainer::linear_after_norm(const std::string& key, const float* W, int n_ou
     if (!tangent_pair) reduce_2d(w.gvec, 1, n_out, 1, db, 1, 0, 1, st);
 }
 
+// ---------------------------------------------------------------------------------------------
+// system conditioning: parameter gradients of  cond_s = W2 silu(W0 [emb_q(charge_s) ; emb_m(spin_s)] + b0) + b2
+// ---------------------------------------------------------------------------------------------
+// dcond[s][c] (=|+=) sum over the atoms of system s of dH[i][c]: one block per system, the system's atoms are a
+// contiguous run of the (non-decreasing) system indices, fixed summation order
+__global__ __launch_bounds__(DN) void k_cond_accum(const float* __restrict__ dH, const int* __restrict__ sys32,
+                                                   const int64_t* __restrict__ sys64, int N, float* __restrict__ dcond,
+                                                   int accumulate) {
+    const int s = blockIdx.x, c = threadIdx.x;
+    __shared__ int range[2];
+    if (c == 0) {
+        auto at = [&](int i) { return sys64 ? sys64[i] : (int64_t)sys32[i]; };
+        int a = 0, b = N;
+        while (a < b) { const int mid = (a + b) >> 1; if (at(mid) < s) a = mid + 1; else b = mid; }
+        range[0] = a; b = N;
+        while (a < b) { const int mid = (a + b) >> 1; if (at(mid) < s + 1) a = mid + 1; else b = mid; }
+        range[1] = a;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    for (int i = range[0]; i < range[1]; i++) acc += dH[(size_t)i * DN + c];
+    dcond[(size_t)s * DN + c] = accumulate ? dcond[(size_t)s * DN + c] + acc : acc;
+}
+// per system: the projection's hidden row and the adjoints that the weight gradients need; scr [n_sys][5 DN] =
+// (x [2 DN] | hid [DN] | da [DN] | -- ) and dx [n_sys][2 DN]
+__global__ __launch_bounds__(DN) void k_cond_bwd_rows(const int64_t* __restrict__ charge, const int64_t* __restrict__ spin,
+                                                      const float* __restrict__ emb_q, const float* __restrict__ emb_m,
+                                                      const float* __restrict__ w0, const float* __restrict__ b0,
+                                                      const float* __restrict__ w2, const float* __restrict__ dcond,
+                                                      float* __restrict__ scr, float* __restrict__ dx, int max_charge,
+                                                      int max_spin) {
+    __shared__ float x[2 * DN], da[DN], dc[DN];
+    const int s = blockIdx.x, t = threadIdx.x;
+    int q = (int)charge[s] + max_charge, mi = (int)spin[s] - 1;
+    q = q < 0 ? 0 : (q > 2 * max_charge ? 2 * max_charge : q);
+    mi = mi < 0 ? 0 : (mi > max_spin - 1 ? max_spin - 1 : mi);
+    x[t] = emb_q[(size_t)q * DN + t];
+    x[DN + t] = emb_m[(size_t)mi * DN + t];
+    dc[t] = dcond[(size_t)s * DN + t];
+    __syncthreads();
+    float a = b0[t];
+    for (int k = 0; k < 2 * DN; k++) a = fmaf(w0[(size_t)t * 2 * DN + k], x[k], a);
+    const float sg = 1.0f / (1.0f + expf(-a));
+    float dh = 0.f;  // d hidden[t] = sum_o W2[o][t] dcond[o]
+    for (int o = 0; o < DN; o++) dh = fmaf(w2[(size_t)o * DN + t], dc[o], dh);
+    const float dat = dh * sg * (1.0f + a * (1.0f - sg));  // silu'(a)
+    da[t] = dat;
+    float* row = scr + (size_t)s * 5 * DN;
+    row[t] = x[t]; row[DN + t] = x[DN + t];
+    row[2 * DN + t] = a * sg;
+    row[3 * DN + t] = dat;
+    __syncthreads();
+    float d0 = 0.f, d1 = 0.f;  // dx[k] = sum_o W0[o][k] da[o]
+    for (int o = 0; o < DN; o++) {
+        d0 = fmaf(w0[(size_t)o * 2 * DN + t], da[o], d0);
+        d1 = fmaf(w0[(size_t)o * 2 * DN + DN + t], da[o], d1);
+    }
+    dx[(size_t)s * 2 * DN + t] = d0;
+    dx[(size_t)s * 2 * DN + DN + t] = d1;
+}
+// one block per output row t of the two weight matrices: sums over the systems in order (deterministic)
+__global__ __launch_bounds__(2 * DN) void k_cond_bwd_weights(const float* __restrict__ scr, const float* __restrict__ dcond,
+                                                             int n_sys, float* __restrict__ gw0, float* __restrict__ gb0,
+                                                             float* __restrict__ gw2, float* __restrict__ gb2) {
+    const int t = blockIdx.x, k = threadIdx.x;  // k < 2 DN
+    float a0 = 0.f, a2 = 0.f, s0 = 0.f, s2 = 0.f;
+    for (int s = 0; s < n_sys; s++) {
+        const float* row = scr + (size_t)s * 5 * DN;
+        const float dat = row[3 * DN + t], dct = dcond[(size_t)s * DN + t];
+        a0 = fmaf(dat, row[k], a0);
+        if (k < DN) a2 = fmaf(dct, row[2 * DN + k], a2);
+        s0 += dat; s2 += dct;
+    }
+    gw0[(size_t)t * 2 * DN + k] += a0;
+    if (k < DN) gw2[(size_t)t * DN + k] += a2;
+    if (k == 0) { gb0[t] += s0; gb2[t] += s2; }
+}
+// embedding rows: one block, the systems in order (several systems may share a charge or a multiplicity)
+__global__ __launch_bounds__(DN) void k_cond_bwd_emb(const int64_t* __restrict__ charge, const int64_t* __restrict__ spin,
+                                                     const float* __restrict__ dx, int n_sys, int max_charge, int max_spin,
+                                                     float* __restrict__ gq, float* __restrict__ gm) {
+    const int c = threadIdx.x;
+    for (int s = 0; s < n_sys; s++) {
+        int q = (int)charge[s] + max_charge, mi = (int)spin[s] - 1;
+        q = q < 0 ? 0 : (q > 2 * max_charge ? 2 * max_charge : q);
+        mi = mi < 0 ? 0 : (mi > max_spin - 1 ? max_spin - 1 : mi);
+        gq[(size_t)q * DN + c] += dx[(size_t)s * 2 * DN + c];
+        gm[(size_t)mi * DN + c] += dx[(size_t)s * 2 * DN + DN + c];
+    }
+}
+
+void Trainer::cond_accumulate(const float* dHout, bool first) {
+    if (!m.h.system_conditioning || err) return;
+    if (!g.cond_charge || g.n_cond_systems < 1 || !w.dcond) { err = PET_ERR_ARGUMENT; set_error("system conditioning: no charges / multiplicities on this graph"); return; }
+    k_cond_accum<<<(int)g.n_cond_systems, DN, 0, st>>>(dHout, g.sys, g.cond_sys, (int)g.n_nodes, w.dcond, first ? 0 : 1);
+}
+void Trainer::cond_finish() {
+    if (!m.h.system_conditioning || err) return;
+    const std::string sc = "system_conditioning.";
+    float *gq = gp(sc + "charge_embedding.weight"), *gm = gp(sc + "spin_multiplicity_embedding.weight");
+    float *gw0 = gp(sc + "project.0.weight"), *gb0 = gp(sc + "project.0.bias");
+    float *gw2 = gp(sc + "project.2.weight"), *gb2 = gp(sc + "project.2.bias");
+    if (!gq || !gm || !gw0 || !gb0 || !gw2 || !gb2) { err = PET_ERR_ARGUMENT; set_error("no gradient slot for the conditioning parameters"); return; }
+    const int ns = (int)g.n_cond_systems;
+    float* scr = w.partial;                    // [ns][5 DN]
+    float* dx = w.partial + (size_t)ns * 5 * DN;  // [ns][2 DN]
+    if ((size_t)ns * 7 * DN > w.partial_floats) { err = PET_ERR_UNSUPPORTED; set_error("too many systems for the conditioning scratch"); return; }
+    k_cond_bwd_rows<<<ns, DN, 0, st>>>(g.cond_charge, g.cond_spin, m.cond_qe, m.cond_se, m.cond_w0, m.cond_b0, m.cond_w2,
+                                       w.dcond, scr, dx, m.h.max_charge, m.h.max_spin_multiplicity);
+    k_cond_bwd_weights<<<DN, 2 * DN, 0, st>>>(scr, w.dcond, ns, gw0, gb0, gw2, gb2);
+    k_cond_bwd_emb<<<1, DN, 0, st>>>(g.cond_charge, g.cond_spin, dx, ns, m.h.max_charge, m.h.max_spin_multiplicity, gq, gm);
+}
+
 void Trainer::heads(bool edge, const float* Xin, int k_in, int64_t n_rows, const float* gA) {
     if (n_rows <= 0 || err) return;
     const std::string h = edge ? "edge_heads.@.0" : "node_heads.@.0";
