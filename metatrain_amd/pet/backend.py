@@ -30,7 +30,7 @@ properties per block, several blocks per target and several targets are served b
 variants older checkpoints use -- ``normalization = "LayerNorm"``, ``transformer_type = "PostLN"``, ``featurizer_type =
 "residual"`` (``pet/checkpoints.py:190-205``) -- run for inference and forces; training is built for the default
 architecture only; both adaptive-cutoff methods ("solver", and the legacy "grid" for inference / forces / energy-only
-training); system conditioning (charge / spin multiplicity, inference + forces). Not built (raise loudly): diagnostic
+training); system conditioning (charge / spin multiplicity; inference, forces and training). Not built (raise loudly): diagnostic
 capture, double backward through the three inference nodes, training of the variants.
 """
 from math import prod
@@ -563,6 +563,10 @@ class PETBackend(torch.nn.Module):
             h.model = model
             c, n, s, z, sysidx = tctx.args
             h.graph = rt.HipGraph(model, tctx.positions, tctx.cells, c, n, s, z, sysidx)
+            if self.has_system_conditioning:  # backend.py:375-378: the model wrapper put the three keys into batch_data
+                self.system_conditioning.validate(batch_data["charge"], batch_data["spin_multiplicity"])
+                h.graph.set_conditioning(batch_data["charge"], batch_data["spin_multiplicity"],
+                                         batch_data["system_indices"])
             pred = _EnergyFn.apply(h, keys, tctx.positions, tctx.cells, *params)
             out[name] = [pred.to(node_features_list[0].dtype)]
             done.append(name)
