@@ -315,6 +315,8 @@ class HipGraph:
                              f"min={int(sm.min())}, max={int(sm.max())}. Increase max_spin_multiplicity in model hypers to "
                              f"support higher spin multiplicities.")
         si = None if system_indices is None else system_indices.detach().to(self.workspace.device, torch.int64).contiguous()
+        # the training passes sum node-feature adjoints per system over contiguous runs of atoms (train.hip k_cond_accum)
+        self._conditioning_sorted = si is None or si.numel() < 2 or bool((si[1:] >= si[:-1]).all())
         self._conditioning = (q, sm, si)  # the handle keeps the pointers: keep the tensors alive with it
         check(self.lib.pet_graph_set_conditioning(self.handle, _ptr(q), _ptr(sm), _ptr(si), int(q.numel())))
 
@@ -480,12 +482,18 @@ class HipForward:
             return gpos, gcell
         return gpos
 
+    def _check_conditioning_for_training(self) -> None:
+        if self.model.hypers.get("system_conditioning") and not getattr(self.graph, "_conditioning_sorted", True):
+            raise ValueError("system conditioning: training needs non-decreasing system_indices (concatenate_structures "
+                             "order); the per-system sums of the conditioning gradients run over contiguous atoms")
+
     def backward_train(self, grad_atomic: torch.Tensor, want_position_grad: bool = False,
                        want_cell_grad: bool = False):
         """loss.backward() for dL/d(atomic prediction) = ``grad_atomic``: accumulates dL/dtheta into
         the model's gradient slots (``HipModel.grad``); optionally also returns dL/dR."""
         if not self.train:
             raise PetHipError("backward_train needs HipForward(..., train=True)")
+        self._check_conditioning_for_training()
         g = self.graph
         _require_cuda(grad_atomic)
         ga = grad_atomic.to(torch.float32).contiguous()
@@ -505,6 +513,7 @@ class HipForward:
         seeds ``lambda_atomic``; optionally returns dE_i/d(eps) along (dR, dcell) = (u, u_cell)."""
         if not self.train:
             raise PetHipError("backward_train2 needs HipForward(..., train=True)")
+        self._check_conditioning_for_training()
         g = self.graph
         dev = self.workspace.device
         _require_cuda(lambda_atomic, u)
