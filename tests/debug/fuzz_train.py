@@ -13,6 +13,9 @@ from oracle import pet as opet
 
 dev = torch.device("cuda:0")
 hypers = dict(opet.DEFAULT_HYPERS)
+COND = len(sys.argv) > 3 and sys.argv[3] == "cond"  # system conditioning: random charges / multiplicities (with repeats)
+if COND:
+    hypers["system_conditioning"] = True
 types = [1, 6, 7, 8]
 params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
 model = rt.HipModel(hypers, types)
@@ -42,6 +45,10 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
     inp = {"positions": torch.cat(pos_l), "cells": torch.stack(cell_l), "centers": torch.cat(i_l),
            "neighbors": torch.cat(j_l), "cell_shifts": torch.cat(s_l), "species": torch.cat(z_l),
            "system_indices": torch.cat(sys_l)}
+    if COND:
+        ns = len(pos_l)
+        inp["charge"] = torch.tensor(rng.integers(-1, 2, ns))
+        inp["spin_multiplicity"] = torch.tensor(rng.integers(1, 3, ns))
     n = off
     nu = torch.tensor(rng.uniform(-0.5, 0.5, n), dtype=torch.float32)
     u = torch.tensor(rng.normal(size=(n, 3)), dtype=torch.float32)
@@ -49,6 +56,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
     graph = rt.HipGraph(model, inp["positions"].to(dev), inp["cells"].to(dev), inp["centers"].to(dev),
                         inp["neighbors"].to(dev), inp["cell_shifts"].to(dev), inp["species"].to(dev),
                         inp["system_indices"].int().to(dev))
+    if COND:
+        graph.set_conditioning(inp["charge"].to(dev), inp["spin_multiplicity"].to(dev), inp["system_indices"].to(dev))
     fw = rt.HipForward(model, graph, train=True)
     model.zero_grad()
     fw.forward()
