@@ -300,6 +300,9 @@ int pet_geometry_backward(const pet_model_t* m, const pet_graph_t* g, const floa
                           void* stream);
 
 /* ---- training step (trainer.py:391-480) ---------------- */
+/* Served architectures: transformer_type = PreLN with the feed-forward featuriser; normalization RMSNorm or LayerNorm,
+ * activation SwiGLU or SiLU, system conditioning on or off. PostLN / residual models: PET_ERR_UNSUPPORTED from
+ * pet_forward(save_for_backward = 2) and from the two training reverse passes. */
 /* The model owns one gradient slot per uploaded parameter (same numel, fp32).
  * pet_model_zero_grad allocates (first call) and clears them -- optimizer.zero_grad(). */
 int pet_model_zero_grad(pet_model_t* m, void* stream);

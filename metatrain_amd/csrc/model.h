@@ -74,6 +74,7 @@ struct Model {
     bool residual() const { return h.featurizer_type == PET_FEATURIZER_RESIDUAL; }
     bool plain_layers() const { return !layer_norm() && !post_ln(); }
     bool plain() const { return plain_layers() && !residual(); }
+    bool trainable() const { return !post_ln() && !residual(); }  // RMSNorm or LayerNorm, PreLN, feedforward featuriser
     int num_readout_layers() const { return residual() ? h.num_gnn_layers : 1; }
     const float* edge_emb = nullptr;  // [ns, D]
     // system conditioning (conditioning.py:38-52): embeddings [2 max_charge + 1, DN], [max_spin, DN]; project.0 [DN, 2 DN],

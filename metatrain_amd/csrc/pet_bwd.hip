@@ -1153,8 +1153,9 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     const int nt = attn_tiles(g);
     PET_REQUIRE(nt <= 8, PET_ERR_UNSUPPORTED, "more than 127 neighbours per atom is not supported yet");
     const bool post = m.post_ln(), res = m.residual(), ln = m.layer_norm();
-    PET_REQUIRE(!tr || m.plain(), PET_ERR_UNSUPPORTED,
-                "training is built for normalization=RMSNorm, transformer_type=PreLN, featurizer_type=feedforward only");
+    PET_REQUIRE(!tr || m.trainable(), PET_ERR_UNSUPPORTED,
+                "training is built for transformer_type=PreLN, featurizer_type=feedforward only");
+    const int nxm = ln ? 5 : 1;  // weight-gradient row source: LayerNorm-hat / RMSNorm-hat of the saved input
     PET_REQUIRE(!res || (g_node && g_edge), PET_ERR_ARGUMENT,
                 "residual featuriser: the reverse pass starts from one gradient pair per readout layer "
                 "(pet_backward_features_layers)");
@@ -1237,8 +1238,9 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                     tr->linear(lp + ".center_mlp.w_out", DN, DNF, {dH, nullptr, 0, DN},
                                {Ab.VGn, 2 * DNF, DNF, nullptr, nullptr}, 2, N);
                     tr->linear_after_norm(lp + ".center_mlp.w_in", A.cmlp_in.w, 2 * DNF, DN,
-                                          {w.dVGn, nullptr, 0, 2 * DNF}, {Ab.H1, DN, 0, nullptr, nullptr}, 1, N,
-                                          lp + ".norm_center_features.weight", A.g_center);
+                                          {w.dVGn, nullptr, 0, 2 * DNF}, {Ab.H1, DN, 0, nullptr, nullptr}, nxm, N,
+                                          lp + ".norm_center_features.weight", A.g_center,
+                                          ln ? lp + ".norm_center_features.bias" : std::string(), ln ? A.b_center : nullptr);
                     tr->linear(lp + ".center_expansion", DN, D, {dH_alt, nullptr, 0, DN},
                                {Ab.OC, D, 0, nullptr, nullptr}, 0, N);
                 }
@@ -1263,7 +1265,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                     tr->linear(lp + ".mlp.w_out", D, DFF, {dX, nullptr, 0, D}, {Ab.VG, 2 * DFF, DFF, nullptr, nullptr},
                                2, E);
                     tr->linear_after_norm(lp + ".mlp.w_in", A.mlp_in.w, 2 * DFF, D, {w.dVG, nullptr, 0, 2 * DFF},
-                                          {Ab.X1, D, 0, nullptr, nullptr}, 1, E, lp + ".norm_mlp.weight", A.g_mlp);
+                                          {Ab.X1, D, 0, nullptr, nullptr}, nxm, E, lp + ".norm_mlp.weight", A.g_mlp,
+                                          ln ? lp + ".norm_mlp.bias" : std::string(), ln ? A.b_mlp : nullptr);
                 }
             }
             ss.join(st);  // dOC ready
@@ -1291,7 +1294,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             }
             if (tr)
                 tr->linear_after_norm(lp + ".attention.input_linear", A.qkv.w, 3 * D, D, {w.dQKV, nullptr, 0, 3 * D},
-                                      {Ab.X, D, 0, nullptr, nullptr}, 1, R, lp + ".norm_attention.weight", A.g_attn);
+                                      {Ab.X, D, 0, nullptr, nullptr}, nxm, R, lp + ".norm_attention.weight", A.g_attn,
+                                      ln ? lp + ".norm_attention.bias" : std::string(), ln ? A.b_attn : nullptr);
             {
                 ProfScope ps("qkv_bwd", st, fR * 2.0 * D * 3 * D, fR * 4.0 * (3 * D + 3 * D));  // dQKV, X, dX1 in; dX out
                 if (trr_l) trr_qkv_bwd(w.dQKV, Ab.X, A.g_attn, A.qkv, dX_alt, dX, E, R, st);

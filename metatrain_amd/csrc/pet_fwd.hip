@@ -824,8 +824,8 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
     PET_REQUIRE(!(atomic && res), PET_ERR_UNSUPPORTED,
                 "the fused head reads one readout layer; with the residual featuriser use pet_forward_layers and "
                 "pet_predict per readout layer");
-    PET_REQUIRE(save != 2 || m.plain(), PET_ERR_UNSUPPORTED,
-                "training is built for normalization=RMSNorm, transformer_type=PreLN, featurizer_type=feedforward only");
+    PET_REQUIRE(save != 2 || m.trainable(), PET_ERR_UNSUPPORTED,
+                "training is built for transformer_type=PreLN, featurizer_type=feedforward only");
     const int64_t N = g.n_nodes, E = g.n_edges, R = E + N;
     if (N == 0) return PET_OK;
     const int nt = attn_tiles(g);

@@ -571,7 +571,17 @@ __global__ void k_swiglu_rev(const float* __restrict__ VG, const float* __restri
 //   xhat' = r (x' - xhat A),  A = mean(xhat x')
 // one float4 per lane, K/4 lanes per row
 // ---------------------------------------------------------------------------------------------
-template <int K>
+// LN = true: LayerNorm-hat. (x - mean) / sqrt(var + eps) is the RMS-hat of the CENTRED row, and centring is a linear,
+// symmetric projection P = I - 11^T / K: the tangent is the RMS tangent of (P x, P x'), the reverse sweep is the RMS
+// reverse sweep on the centred row followed by P on both adjoints (a linear map adds no second-order term).
+constexpr float LN_EPS = 1e-5f;
+__device__ __forceinline__ float sum4(const float4& v) { return (v.x + v.y) + (v.z + v.w); }
+template <int LPR, int K>
+__device__ __forceinline__ void centre_row(float4& v) {
+    const float mu = group_sum<LPR>(sum4(v)) * (1.0f / K);
+    v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
+}
+template <int K, bool LN>
 __global__ void k_rms_jvp(const float* __restrict__ X, const float* __restrict__ Xd, float* __restrict__ XHd,
                           int64_t R) {
     constexpr int LPR = K / 4;
@@ -583,9 +593,10 @@ __global__ void k_rms_jvp(const float* __restrict__ X, const float* __restrict__
         x = *reinterpret_cast<const float4*>(X + row * K + 4 * c);
         xd = *reinterpret_cast<const float4*>(Xd + row * K + 4 * c);
     }
+    if (LN) { centre_row<LPR, K>(x); centre_row<LPR, K>(xd); }
     const float ss = group_sum<LPR>(dot4(x, x));
     const float xxd = group_sum<LPR>(dot4(x, xd));
-    const float r = rsqrtf(ss * (1.0f / K) + RMS_EPS);
+    const float r = rsqrtf(ss * (1.0f / K) + (LN ? LN_EPS : RMS_EPS));
     const float rA = r * r * r * xxd * (1.0f / K);  // r * A / (x -> xhat scale): xhat A r = x r^2 A, A = r mean(x x')
     if (valid)
         *reinterpret_cast<float4*>(XHd + row * K + 4 * c) =
@@ -595,7 +606,7 @@ __global__ void k_rms_jvp(const float* __restrict__ X, const float* __restrict__
 //   lambda_x += r (l - xhat B)
 //   nu_x     += r (n - xhat m(xhat, n)) - r^2 [ (C - 3AB) xhat + B x' + A l ],   l = gamma*lin_l, n = gamma*lin_n,
 //   A = m(xhat, x'), B = m(xhat, l), C = m(l, x')
-template <int K>
+template <int K, bool LN>
 __global__ void k_rms_rev(const float* __restrict__ X, const float* __restrict__ Xd, const float* __restrict__ lin_l,
                           const float* __restrict__ lin_n, const float* __restrict__ gamma, float* __restrict__ LX,
                           float* __restrict__ NX, int64_t R) {
@@ -613,23 +624,27 @@ __global__ void k_rms_rev(const float* __restrict__ X, const float* __restrict__
         l.x *= gm.x; l.y *= gm.y; l.z *= gm.z; l.w *= gm.w;
         n.x *= gm.x; n.y *= gm.y; n.z *= gm.z; n.w *= gm.w;
     }
+    if (LN) { centre_row<LPR, K>(x); centre_row<LPR, K>(xd); }
     const float ss = group_sum<LPR>(dot4(x, x));
-    const float r = rsqrtf(ss * (1.0f / K) + RMS_EPS);
+    const float r = rsqrtf(ss * (1.0f / K) + (LN ? LN_EPS : RMS_EPS));
     const float4 xh = make_float4(x.x * r, x.y * r, x.z * r, x.w * r);
     const float A = group_sum<LPR>(dot4(xh, xd)) * (1.0f / K);
     const float B = group_sum<LPR>(dot4(xh, l)) * (1.0f / K);
     const float C = group_sum<LPR>(dot4(l, xd)) * (1.0f / K);
     const float Mn = group_sum<LPR>(dot4(xh, n)) * (1.0f / K);
-    if (!valid) return;
     const float r2 = r * r, k3 = C - 3.0f * A * B;
+    float4 da = make_float4(r * (l.x - xh.x * B), r * (l.y - xh.y * B), r * (l.z - xh.z * B), r * (l.w - xh.w * B));
+    float4 db = make_float4(r * (n.x - xh.x * Mn) - r2 * (k3 * xh.x + B * xd.x + A * l.x),
+                            r * (n.y - xh.y * Mn) - r2 * (k3 * xh.y + B * xd.y + A * l.y),
+                            r * (n.z - xh.z * Mn) - r2 * (k3 * xh.z + B * xd.z + A * l.z),
+                            r * (n.w - xh.w * Mn) - r2 * (k3 * xh.w + B * xd.w + A * l.w));
+    if (LN) { centre_row<LPR, K>(da); centre_row<LPR, K>(db); }  // P^T = P on both adjoints
+    if (!valid) return;
     float4* lx = reinterpret_cast<float4*>(LX + row * K + 4 * c);
     float4* nx = reinterpret_cast<float4*>(NX + row * K + 4 * c);
     float4 a = *lx, b = *nx;
-    a.x += r * (l.x - xh.x * B); a.y += r * (l.y - xh.y * B); a.z += r * (l.z - xh.z * B); a.w += r * (l.w - xh.w * B);
-    b.x += r * (n.x - xh.x * Mn) - r2 * (k3 * xh.x + B * xd.x + A * l.x);
-    b.y += r * (n.y - xh.y * Mn) - r2 * (k3 * xh.y + B * xd.y + A * l.y);
-    b.z += r * (n.z - xh.z * Mn) - r2 * (k3 * xh.z + B * xd.z + A * l.z);
-    b.w += r * (n.w - xh.w * Mn) - r2 * (k3 * xh.w + B * xd.w + A * l.w);
+    a.x += da.x; a.y += da.y; a.z += da.z; a.w += da.w;
+    b.x += db.x; b.y += db.y; b.z += db.z; b.w += db.w;
     *lx = a;
     *nx = b;
 }
@@ -1081,14 +1096,20 @@ static inline int grid1(int64_t n) { return cdiv(n, 256); }
 
 static void rms_jvp(const Ctx& c, int K, const float* X, const float* Xd, float* XHd, int64_t R) {
     if (R <= 0) return;
-    if (K == 128) k_rms_jvp<128><<<cdiv(R, 8), 256, 0, c.st>>>(X, Xd, XHd, R);
-    else k_rms_jvp<256><<<cdiv(R, 4), 256, 0, c.st>>>(X, Xd, XHd, R);
+    const bool ln = c.m.layer_norm();
+    if (K == 128 && ln) k_rms_jvp<128, true><<<cdiv(R, 8), 256, 0, c.st>>>(X, Xd, XHd, R);
+    else if (K == 128) k_rms_jvp<128, false><<<cdiv(R, 8), 256, 0, c.st>>>(X, Xd, XHd, R);
+    else if (ln) k_rms_jvp<256, true><<<cdiv(R, 4), 256, 0, c.st>>>(X, Xd, XHd, R);
+    else k_rms_jvp<256, false><<<cdiv(R, 4), 256, 0, c.st>>>(X, Xd, XHd, R);
 }
 static void rms_rev(const Ctx& c, int K, const float* X, const float* Xd, const float* ll, const float* ln,
                     const float* gamma, float* LX, float* NX, int64_t R) {
     if (R <= 0) return;
-    if (K == 128) k_rms_rev<128><<<cdiv(R, 8), 256, 0, c.st>>>(X, Xd, ll, ln, gamma, LX, NX, R);
-    else k_rms_rev<256><<<cdiv(R, 4), 256, 0, c.st>>>(X, Xd, ll, ln, gamma, LX, NX, R);
+    const bool lnorm = c.m.layer_norm();
+    if (K == 128 && lnorm) k_rms_rev<128, true><<<cdiv(R, 8), 256, 0, c.st>>>(X, Xd, ll, ln, gamma, LX, NX, R);
+    else if (K == 128) k_rms_rev<128, false><<<cdiv(R, 8), 256, 0, c.st>>>(X, Xd, ll, ln, gamma, LX, NX, R);
+    else if (lnorm) k_rms_rev<256, true><<<cdiv(R, 4), 256, 0, c.st>>>(X, Xd, ll, ln, gamma, LX, NX, R);
+    else k_rms_rev<256, false><<<cdiv(R, 4), 256, 0, c.st>>>(X, Xd, ll, ln, gamma, LX, NX, R);
 }
 
 // heads: primal recompute + tangent (forward part)
@@ -1134,8 +1155,8 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
                     const float* lA, const float* nA, const float* u, float* tangent_atomic, hipStream_t st,
                     const float* ucell) {
     PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
-    PET_REQUIRE(m.plain(), PET_ERR_UNSUPPORTED,
-                "training is built for normalization=RMSNorm, transformer_type=PreLN, featurizer_type=feedforward only");
+    PET_REQUIRE(m.trainable(), PET_ERR_UNSUPPORTED,
+                "training is built for transformer_type=PreLN, featurizer_type=feedforward only");
     PET_REQUIRE(g.grid_probes == 0, PET_ERR_UNSUPPORTED,
                 "the force-loss (second-order) pass carries the cutoff tangents of the 'solver' adaptive-cutoff method only");
     Workspace w;
@@ -1229,6 +1250,8 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
                  s.NH, N);
     if (tangent_atomic) k_tangent_atom_sum<<<grid1(N), 256, 0, st>>>(s.tan_n, s.tan_e, g.rowptr, tangent_atomic, (int)N);
     float *t0 = s.tmp[0], *t1 = s.tmp[1], *t2 = s.tmp[2], *t3 = s.tmp[3], *t4 = s.tmp[4], *t5 = s.tmp[5];
+    const bool lnm = m.layer_norm();
+    const int nx = lnm ? 5 : 1;  // weight-gradient row source: LayerNorm-hat / RMSNorm-hat of the saved input
     for (int gi = nG - 1; gi >= 0; gi--) {
         const GnnLayerW& G = m.gnn[gi];
         const GnnBufs& B = w.gnn[gi];
@@ -1270,7 +1293,8 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
             mm_bwd(c, A.mlp_out, s.NX, t1, E);
             k_swiglu_rev<<<grid1(E * DFF), 256, 0, st>>>(Ab.VG, Sa.TVG, t0, t1, t2, t3, E, DFF);  // (l_VG, n_VG)
             tr.linear_after_norm(lp + ".mlp.w_in", A.mlp_in.w, 2 * DFF, D, {t3, nullptr, 0, 2 * DFF},
-                                 {Ab.X1, D, 0, nullptr, nullptr}, 1, E, lp + ".norm_mlp.weight", A.g_mlp);
+                                 {Ab.X1, D, 0, nullptr, nullptr}, nx, E, lp + ".norm_mlp.weight", A.g_mlp,
+                                 lnm ? lp + ".norm_mlp.bias" : std::string(), lnm ? A.b_mlp : nullptr);
             tr.linear_after_norm(lp + ".mlp.w_in", A.mlp_in.w, 2 * DFF, D, {t2, nullptr, 0, 2 * DFF},
                                  {Sa.Tx1h, D, 0, nullptr, nullptr}, 0, E, lp + ".norm_mlp.weight", A.g_mlp, "", nullptr,
                                  true);
@@ -1286,7 +1310,8 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
             mm_bwd(c, A.cmlp_out, s.NH, t1, N);
             k_swiglu_rev<<<grid1(N * DNF), 256, 0, st>>>(Ab.VGn, Sa.TVGn, t0, t1, t2, t3, N, DNF);
             tr.linear_after_norm(lp + ".center_mlp.w_in", A.cmlp_in.w, 2 * DNF, DN, {t3, nullptr, 0, 2 * DNF},
-                                 {Ab.H1, DN, 0, nullptr, nullptr}, 1, N, lp + ".norm_center_features.weight", A.g_center);
+                                 {Ab.H1, DN, 0, nullptr, nullptr}, nx, N, lp + ".norm_center_features.weight", A.g_center,
+                                 lnm ? lp + ".norm_center_features.bias" : std::string(), lnm ? A.b_center : nullptr);
             tr.linear_after_norm(lp + ".center_mlp.w_in", A.cmlp_in.w, 2 * DNF, DN, {t2, nullptr, 0, 2 * DNF},
                                  {Sa.Th1h, DN, 0, nullptr, nullptr}, 0, N, lp + ".norm_center_features.weight",
                                  A.g_center, "", nullptr, true);
@@ -1313,7 +1338,8 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
                                                                    t3, E, (int)N, scale);
             }
             tr.linear_after_norm(lp + ".attention.input_linear", A.qkv.w, 3 * D, D, {t3, nullptr, 0, 3 * D},
-                                 {Ab.X, D, 0, nullptr, nullptr}, 1, R, lp + ".norm_attention.weight", A.g_attn);
+                                 {Ab.X, D, 0, nullptr, nullptr}, nx, R, lp + ".norm_attention.weight", A.g_attn,
+                                 lnm ? lp + ".norm_attention.bias" : std::string(), lnm ? A.b_attn : nullptr);
             tr.linear_after_norm(lp + ".attention.input_linear", A.qkv.w, 3 * D, D, {t2, nullptr, 0, 3 * D},
                                  {Sa.Txh, D, 0, nullptr, nullptr}, 0, R, lp + ".norm_attention.weight", A.g_attn, "",
                                  nullptr, true);

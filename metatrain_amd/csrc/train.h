@@ -23,7 +23,7 @@ struct Trainer {
     // generic y = x W^T + b: dW [n_out, k_in] (+ db) from dY rows and rebuilt X rows
     struct Y { const float* p0; const float* p1; int64_t split; int ld; };
     struct X { const float* p; int ld; int hid; const int* rev; const float* lns; };
-    // xmode: 0 plain, 1 rms-hat, 2 swiglu(v|g), 3 silu, 4 layernorm-hat([x; x[rev]])
+    // xmode: 0 plain, 1 rms-hat, 2 swiglu(v|g), 3 silu, 4 layernorm-hat([x; x[rev]]), 5 layernorm-hat(x)
     void linear(const std::string& key, int n_out, int k_in, Y y, X x, int xmode, int64_t n_rows,
                 bool with_bias = true);
     // same, X normalised by a norm with weight `gamma_key` (and bias `beta_key` for LayerNorm)

@@ -163,8 +163,9 @@ static void wgrad_core(Trainer& t, int n_out, int k_in, Trainer::Y y, Trainer::X
     ProfScope ps("wgrad", t.st, 2.0 * (double)n_rows * n_out * k_in, 4.0 * (double)n_rows * (n_out + k_in));
     const int nb = n_out / 128;
     // bf16x3 kernel: 128 x columns per launch; the RMSNorm-hat source needs its whole row in one launch
-    const bool b16 = g_wgrad_bf16 && !(xmode == 1 && k_in != 128);
-    const int KB = b16 ? 128 : ((xmode == 1 || xmode == 4) ? k_in : 128);
+    const bool whole_row = xmode == 1 || xmode == 5;  // the norm-hat sources need the whole row in one launch
+    const bool b16 = g_wgrad_bf16 && !(whole_row && k_in != 128);
+    const int KB = b16 ? 128 : ((whole_row || xmode == 4) ? k_in : 128);
     int nsplit = (b16 ? 512 : 768) / nb;  // two (bf16x3: 60 KB of LDS) / three (fp32: 34 - 50 KB) workgroups per CU
     const int64_t max_by_rows = (n_rows + WG_RB - 1) / WG_RB;
     if (nsplit > max_by_rows) nsplit = (int)max_by_rows;
@@ -183,6 +184,7 @@ static void wgrad_core(Trainer& t, int n_out, int k_in, Trainer::Y y, Trainer::X
                 case 2: launch_k_wgrad_b<2>(a, nb, nsplit, t.st); break;
                 case 3: launch_k_wgrad_b<3>(a, nb, nsplit, t.st); break;
                 case 4: launch_k_wgrad_b<4>(a, nb, nsplit, t.st); break;
+                case 5: launch_k_wgrad_b<5>(a, nb, nsplit, t.st); break;
                 default: t.err = PET_ERR_ARGUMENT; return;
             }
         } else if (KB == 128) {
@@ -191,11 +193,13 @@ static void wgrad_core(Trainer& t, int n_out, int k_in, Trainer::Y y, Trainer::X
                 case 1: launch_k_wgrad<128, 1>(a, nb, nsplit, t.st); break;
                 case 2: launch_k_wgrad<128, 2>(a, nb, nsplit, t.st); break;
                 case 3: launch_k_wgrad<128, 3>(a, nb, nsplit, t.st); break;
+                case 5: launch_k_wgrad<128, 5>(a, nb, nsplit, t.st); break;
                 default: t.err = PET_ERR_ARGUMENT; return;
             }
         } else {
             if (xmode == 1) launch_k_wgrad<256, 1>(a, nb, nsplit, t.st);
             else if (xmode == 4) launch_k_wgrad<256, 4>(a, nb, nsplit, t.st);
+            else if (xmode == 5) launch_k_wgrad<256, 5>(a, nb, nsplit, t.st);
             else { t.err = PET_ERR_ARGUMENT; return; }
         }
         reduce_2d(t.w.partial, nsplit, n_out, KB, dst, ldw, k0, accumulate ? 1 : 0, t.st);

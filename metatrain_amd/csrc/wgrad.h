@@ -59,9 +59,36 @@ __device__ __forceinline__ void tile_rms_hat(float* t) {  // x -> x * rsqrt(mean
     }
 }
 
+template <int COLS>
+__device__ __forceinline__ void tile_ln_hat(float* t) {  // x -> (x - mean) * rsqrt(var + 1e-5)
+    constexpr int LDS = COLS + 4;
+    const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
+    float sm = 0.f;
+    for (int c = q * 4; c < COLS; c += 32) {
+        const float4 v = *reinterpret_cast<float4*>(t + r * LDS + c);
+        sm += (v.x + v.y) + (v.z + v.w);
+    }
+    sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4);
+    const float mean = sm * (1.0f / COLS);
+    float ss = 0.f;
+    for (int c = q * 4; c < COLS; c += 32) {
+        const float4 v = *reinterpret_cast<float4*>(t + r * LDS + c);
+        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+        ss += a * a + b * b + cc * cc + d * d;
+    }
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+    const float rstd = rsqrtf(ss * (1.0f / COLS) + 1e-5f);
+    for (int c = q * 4; c < COLS; c += 32) {
+        float4 v = *reinterpret_cast<float4*>(t + r * LDS + c);
+        v.x = (v.x - mean) * rstd; v.y = (v.y - mean) * rstd; v.z = (v.z - mean) * rstd; v.w = (v.w - mean) * rstd;
+        *reinterpret_cast<float4*>(t + r * LDS + c) = v;
+    }
+}
+
 // ---- the kernel -----------------------------------------------------------------------------
 // grid = (n_blocks of 128 output rows, splits). XMODE: 0 plain, 1 rms-hat, 2 swiglu(VG: v|g), 3 silu,
-// 4 layernorm-hat of [x ; x[rev]] (COLS = 256). YMODE: 0 plain, 1 split (edges | centres).
+// 4 layernorm-hat of [x ; x[rev]] (COLS = 256), 5 layernorm-hat of the row itself (statistics recomputed).
+// YMODE: 0 plain, 1 split (edges | centres).
 struct WgradArgs {
     const float* y0; const float* y1; int64_t y_split; int y_ld; int y_col0;
     const float* x0; int x_ld; int x_col0; int x_hid;  // x_hid: SwiGLU hidden size (gate at +x_hid)
@@ -162,6 +189,10 @@ __global__ __launch_bounds__(NTHREADS) void k_wgrad(WgradArgs a) {
         __syncthreads();
         if (XMODE == 1) {
             tile_rms_hat<KB>(Xs);
+            __syncthreads();
+        }
+        if (XMODE == 5) {
+            tile_ln_hat<KB>(Xs);
             __syncthreads();
         }
         if (a.partial_b && threadIdx.x < 128) {
@@ -308,6 +339,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_wgrad_b(WgradArgs a, int nb_tot
                 ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
                 ss += __shfl_xor(ss, 8); ss += __shfl_xor(ss, 16);
                 const float rstd = rsqrtf(ss * (1.0f / KB) + 1.1920928955078125e-07f);
+                v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+            }
+            if (XMODE == 5) {  // LayerNorm-hat of the row itself, same half-wave layout
+                float sm = (v.x + v.y) + (v.z + v.w);
+                sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4);
+                sm += __shfl_xor(sm, 8); sm += __shfl_xor(sm, 16);
+                const float mean = sm * (1.0f / KB);
+                v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+                float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+                ss += __shfl_xor(ss, 8); ss += __shfl_xor(ss, 16);
+                const float rstd = rsqrtf(ss * (1.0f / KB) + 1e-5f);
                 v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
             }
             if (XMODE == 2) {

@@ -28,10 +28,10 @@ step.) That node evaluates the batch ``preprocess`` saw, not edited features.
 ``activation = "SiLU"`` runs on the SwiGLU kernels with the projection uploaded as both halves (exact). Several
 properties per block, several blocks per target and several targets are served by ``pet_predict``. The architecture
 variants older checkpoints use -- ``normalization = "LayerNorm"``, ``transformer_type = "PostLN"``, ``featurizer_type =
-"residual"`` (``pet/checkpoints.py:190-205``) -- run for inference and forces; training is built for the default
-architecture only; both adaptive-cutoff methods ("solver", and the legacy "grid" for inference / forces / energy-only
+"residual"`` (``pet/checkpoints.py:190-205``) -- run for inference and forces; training is built for PreLN + feedforward
+models (RMSNorm or LayerNorm); both adaptive-cutoff methods ("solver", and the legacy "grid" for inference / forces / energy-only
 training); system conditioning (charge / spin multiplicity; inference, forces and training). Not built (raise loudly): diagnostic
-capture, double backward through the three inference nodes, training of the variants.
+capture, double backward through the three inference nodes, training of PostLN / residual models.
 """
 from math import prod
 from typing import Dict, List, Optional, Tuple

@@ -16,8 +16,16 @@ hypers = dict(opet.DEFAULT_HYPERS)
 COND = len(sys.argv) > 3 and sys.argv[3] == "cond"  # system conditioning: random charges / multiplicities (with repeats)
 if COND:
     hypers["system_conditioning"] = True
+LN = len(sys.argv) > 3 and sys.argv[3] == "layernorm"  # normalization = LayerNorm with random norm weights / biases
+if LN:
+    hypers["normalization"] = "LayerNorm"
 types = [1, 6, 7, 8]
 params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+if LN:
+    gen = torch.Generator().manual_seed(1)
+    for k in params:
+        if ".norm_" in k:
+            params[k] = params[k] + 0.3 * torch.randn(params[k].shape, generator=gen)
 model = rt.HipModel(hypers, types)
 model.load({k: v.to(dev) for k, v in params.items()}, "energy")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)

@@ -140,22 +140,29 @@ def test_parameter_update_is_picked_up(dev):
     assert abs(run() - (e0 + 40.0)) < 1e-3
 
 
-@pytest.mark.parametrize("activation,conditioned", [("SwiGLU", False), ("SiLU", False), ("SwiGLU", True)])
-def test_training_through_the_mirror_fills_parameter_grads(golden_dir, activation, conditioned):
+@pytest.mark.parametrize("activation,conditioned,normalization", [
+    ("SwiGLU", False, "RMSNorm"), ("SiLU", False, "RMSNorm"), ("SwiGLU", True, "RMSNorm"), ("SiLU", True, "LayerNorm")])
+def test_training_through_the_mirror_fills_parameter_grads(golden_dir, activation, conditioned, normalization):
     """pet/trainer.py:417-462 through the torch mirror: autograd.grad(E, R, create_graph=True), a loss on
     energies and dE/dR, loss.backward() -> parameter.grad; against torch's double backward through the fp64
     oracle with the same weights. With activation = "SiLU" the w_in gradients are those of the tied projection; with
-    system conditioning the charge / spin embeddings and their projection are trained too."""
+    system conditioning the charge / spin embeddings and their projection are trained too; with normalization =
+    "LayerNorm" the norm biases are."""
     from metatrain_amd.pet import PETBackend, default_hypers
 
     dev = torch.device("cuda:0")
     g = dict(np.load(os.path.join(golden_dir, "batch_two_systems.npz")))
     t = lambda k: torch.tensor(g[k])  # noqa: E731
-    hypers = dict(default_hypers(), activation=activation, system_conditioning=conditioned)
+    hypers = dict(default_hypers(), activation=activation, system_conditioning=conditioned, normalization=normalization)
     charge, spin = torch.tensor([2, -1]), torch.tensor([3, 1])
     kw = dict(charge=charge, spin_multiplicity=spin) if conditioned else {}
     types = [1, 6, 7, 8]
     params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    gen = torch.Generator().manual_seed(5)
+    if normalization == "LayerNorm":  # norm parameters start at (1, 0): move them
+        for k in params:
+            if ".norm_" in k:
+                params[k] = params[k] + 0.3 * torch.randn(params[k].shape, generator=gen)
     be = PETBackend(hypers, types)
     be.add_output("energy", {"energy": [1]})
     be.load_state_dict(params, strict=True)
@@ -163,7 +170,6 @@ def test_training_through_the_mirror_fills_parameter_grads(golden_dir, activatio
     pos = t("in_positions").float().to(dev).requires_grad_(True)
     cells, sysidx = t("in_cells").float().to(dev), t("in_system_indices").to(dev)
     n = pos.shape[0]
-    gen = torch.Generator().manual_seed(5)
     w_e = torch.rand(n, generator=gen) - 0.5
     tgt_g = 0.3 * torch.randn(n, 3, generator=gen)
     batch = be.preprocess(pos, t("in_centers").to(dev), t("in_neighbors").to(dev), t("in_species").to(dev), cells,

@@ -652,3 +652,64 @@ def _oracle_param_grads_cond(params, hypers, inp, seed_w):
     keys = [k for k in p64 if k != "species_to_species_index"]
     grads = torch.autograd.grad(loss, [p64[k] for k in keys], allow_unused=True)
     return {k: (torch.zeros_like(p64[k]) if g is None else g) for k, g in zip(keys, grads)}
+
+
+@pytest.mark.parametrize("activation", ["SwiGLU", "SiLU"])
+@pytest.mark.parametrize("wgrad_bf16", [1, 0])
+def test_training_gradients_of_a_layernorm_model(golden_dir, activation, wgrad_bf16):
+    """normalization = LayerNorm (modules/transformer.py:181-186, PreLN, feed-forward featuriser): the energy-loss and the
+    force-loss parameter gradients -- norm weights AND biases -- against autograd / double backward through the fp64
+    oracle. LayerNorm-hat is the RMSNorm-hat of the centred row, which is how the second-order kernels compute it."""
+    from metatrain_amd import runtime as rt
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS, normalization="LayerNorm", activation=activation)
+    types = [1, 6, 7, 8]
+    params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    gen = torch.Generator().manual_seed(3)
+    for k in params:  # synthetic norm parameters start at (1, 0): move them so that every term is exercised
+        if ".norm_" in k:
+            params[k] = params[k] + 0.3 * torch.randn(params[k].shape, generator=gen)
+    inp = _inputs(golden_dir, "batch_two_systems.npz")
+    n = inp["positions"].shape[0]
+    seed_w = torch.rand(n, generator=gen) + 0.5
+    nu = torch.rand(n, generator=gen) - 0.5
+    u = torch.randn(n, 3, generator=gen)
+    ref1 = _oracle_param_grads(params, hypers, inp, seed_w)
+    ref2, tan_ref, _ = _oracle_second_order(params, hypers, inp, nu, u)
+    assert any(k.endswith("norm_attention.bias") for k in ref1)
+
+    rt.config_set("wgrad_bf16", wgrad_bf16)
+    try:
+        model = rt.HipModel(hypers, types)
+        model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+        graph = rt.HipGraph(model, inp["positions"].float().to(dev), inp["cells"].float().to(dev),
+                            inp["centers"].to(dev), inp["neighbors"].to(dev), inp["cell_shifts"].to(dev),
+                            inp["species"].to(dev), inp["system_indices"].int().to(dev))
+        fw = rt.HipForward(model, graph, train=True)
+        model.zero_grad()
+        fw.forward()
+        fw.backward_train(seed_w.to(dev))
+        got1 = {k: v.clone() for k, v in model.grads().items()}
+        model.zero_grad()
+        fw.forward()
+        ones = torch.ones(n, device=dev)
+        fw.backward(ones)
+        tan = fw.backward_train2(ones, nu.to(dev), u.to(dev), want_tangent=True)
+        got2 = model.grads()
+    finally:
+        rt.config_set("wgrad_bf16", 1)
+    assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < TOL
+    for name, ref, got in (("energy loss", ref1, got1), ("force loss", ref2, got2)):
+        assert set(got) == set(ref)
+        worst = {}
+        for k, r in ref.items():
+            r = r.numpy()
+            g = got[k].cpu().numpy().astype(np.float64)
+            scale = np.abs(r).max()
+            err = np.abs(g - r).max()
+            worst[k] = err / scale if scale > 1e-12 else err
+        for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]:
+            print(f"{name}: {v:.3e}  {k}")
+        bad = {k: v for k, v in worst.items() if not v < (5 * TOL if ref[k].numel() == 1 else TOL)}
+        assert not bad, f"{name}: parameter gradients off: {bad}"

@@ -105,7 +105,7 @@ def test_fused_entry_points_refuse_what_they_do_not_serve(rt, golden_dir):
     fw = rt.HipForward(m, graph)
     with pytest.raises(rt.PetHipError, match="fused"):
         fw.forward()
-    m, graph, _, _ = _setup(rt, golden_dir, "layernorm")
+    m, graph, _, _ = _setup(rt, golden_dir, "postln")
     fw = rt.HipForward(m, graph, train=True)
     with pytest.raises(rt.PetHipError, match="training is built"):
         fw.forward()
