@@ -72,6 +72,8 @@ def main():
                     help="boxes per micro-batch (gradient accumulation, TrainStep.microbatched); 0 = the whole batch at once. "
                          "BASELINE configs[3] per GPU: --boxes 64 --atoms 10000 --micro 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--normalization", default="RMSNorm", choices=["RMSNorm", "LayerNorm"],
+                    help="LayerNorm: the legacy-checkpoint norm (LDS-tile layer kernels instead of the TRR ones)")
     args = ap.parse_args()
 
     from metatrain_amd import distributed as pdist
@@ -103,7 +105,7 @@ def main():
     from metatrain_amd.pet.trainer import TrainStep
     from metatrain_amd.synthetic import random_box, synthetic_params
 
-    hypers = default_hypers()
+    hypers = dict(default_hypers(), normalization=args.normalization)
     params = synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)
     model = rt.HipModel(hypers, [1, 6, 7, 8])
     model.load({k: v.to(dev) for k, v in params.items()}, "energy")
@@ -172,7 +174,7 @@ def main():
             "config": {
                 "workload": f"PET training step, {args.boxes} x {args.atoms}-atom boxes per GPU per step"
                             f"{f' in micro-batches of {micro} (gradient accumulation)' if len(batches) > 1 else ''}, default PET "
-                            f"hypers (2.9M params), MSE(E/atom)+MSE(dE/dR), clip 1.0, Adam lr 1e-4",
+                            f"hypers{'' if args.normalization == 'RMSNorm' else ' with normalization=' + args.normalization} (2.9M params), MSE(E/atom)+MSE(dE/dR), clip 1.0, Adam lr 1e-4",
                 "atoms_per_gpu_per_step": n_atoms,
                 "edges_per_gpu_per_step": n_edges,
                 "micro_batches": len(batches),
