@@ -166,6 +166,8 @@ def main():
                     help="10k-atom boxes per GPU per step (1: 710k, 2: 757k, 4: 799k, 8: 816k atom-steps/s, DESIGN.md 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print a per-stage table to stderr")
+    ap.add_argument("--normalization", default="RMSNorm", choices=["RMSNorm", "LayerNorm"],
+                    help="side runs only: the legacy-checkpoint norm; the headline metric is the default (RMSNorm)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=INT",
                     help="library switch for A/B runs, e.g. --set attn_lds=1 (pet_config_set)")
     args = ap.parse_args()
@@ -194,7 +196,7 @@ def main():
     for kv in args.set:
         key, val = kv.split("=")
         rt.config_set(key, int(val))
-    hypers = default_hypers()
+    hypers = dict(default_hypers(), normalization=args.normalization)
     params = synthetic_params(hypers)
     model = rt.HipModel(hypers, [1, 6, 7, 8])
     model.load({k: v.to(dev) for k, v in params.items()}, "energy")
@@ -334,7 +336,8 @@ def main():
             "data": "synthetic random periodic boxes (rho=0.05/A^3, 4 species), weights from a seeded generator",
             "config": {
                 "workload": f"PET forward + dE/dR (preprocess+features+predict+backward), {boxes} x "
-                            f"{ATOMS_PER_BOX}-atom boxes per GPU per step, default PET hypers (2.9M params), "
+                            f"{ATOMS_PER_BOX}-atom boxes per GPU per step, default PET hypers"
+                            f"{'' if args.normalization == 'RMSNorm' else ' with normalization=' + args.normalization} (2.9M params), "
                             f"4.5 A cutoff, {graph.n_edges // boxes} edges/box",
                 "atoms_per_gpu_per_step": n_atoms,
                 "edges_per_gpu_per_step": int(graph.n_edges),

@@ -73,7 +73,7 @@ def main():
                          "BASELINE configs[3] per GPU: --boxes 64 --atoms 10000 --micro 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--normalization", default="RMSNorm", choices=["RMSNorm", "LayerNorm"],
-                    help="LayerNorm: the legacy-checkpoint norm (LDS-tile layer kernels instead of the TRR ones)")
+                    help="LayerNorm: the legacy-checkpoint norm")
     args = ap.parse_args()
 
     from metatrain_amd import distributed as pdist

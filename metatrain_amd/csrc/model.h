@@ -72,7 +72,7 @@ struct Model {
     bool layer_norm() const { return h.normalization == PET_NORM_LAYER; }
     bool post_ln() const { return h.transformer_type == PET_POST_LN; }
     bool residual() const { return h.featurizer_type == PET_FEATURIZER_RESIDUAL; }
-    bool plain_layers() const { return !layer_norm() && !post_ln(); }
+    bool plain_layers() const { return !post_ln(); }  // PreLN (either norm): what the TRR transformer-layer kernels serve
     bool plain() const { return plain_layers() && !residual(); }
     bool trainable() const { return !post_ln() && !residual(); }  // RMSNorm or LayerNorm, PreLN, feedforward featuriser
     int num_readout_layers() const { return residual() ? h.num_gnn_layers : 1; }
@@ -213,17 +213,19 @@ bool trr_head_edge_bwd(const Model& m, const float* Xin, const float* gA, const 
                        float* t_s2y, hipStream_t st);
 void set_soap_sorted(int v);  // soap.hip: 1 = tail GEMM on species-sorted tiles, one network per tile (default)
 void set_soap_pair(int v);  // soap.hip: 1 = wave-per-atom expansion / lane-per-pair adjoint (default), 0 = first generation
-void trr_qkv(const float* X, const float* gamma, const Lin& qkv, float* QKV, int64_t R, hipStream_t st);
-void trr_qkv_bwd(const float* dQKV, const float* X, const float* gamma, const Lin& qkv, const float* dX1,
-                 float* dXin, int64_t E, int64_t R, hipStream_t st);
+// beta: the LayerNorm bias of the layer's norm, nullptr = RMSNorm
+void trr_qkv(const float* X, const float* gamma, const float* beta, const Lin& qkv, float* QKV, int64_t R,
+             hipStream_t st);
+void trr_qkv_bwd(const float* dQKV, const float* X, const float* gamma, bool layer_norm, const Lin& qkv,
+                 const float* dX1, float* dXin, int64_t E, int64_t R, hipStream_t st);
 void trr_oproj(const float* AO, const float* X, const Lin& out, float* X1, float* OC, int64_t E, int64_t R,
                hipStream_t st);
 void trr_oproj_bwd(const float* dX1, const float* dOC, const Lin& out, float* dAO, int64_t E, int64_t R,
                    hipStream_t st);
-void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wout, float* VG, float* X2,
-              int64_t E, hipStream_t st);
-void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
-                  const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg = nullptr);
+void trr_emlp(const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout, float* VG,
+              float* X2, int64_t E, hipStream_t st);
+void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const float* beta,
+                  const Lin& win, const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg = nullptr);
 
 // pet_comb.hip: combination stage and adjoint as TRR kernels (f16x3); false if the split operands are missing
 bool trr_comb(bool first, const float* XF, const Graph& g, const GnnLayerW& G, const float* Min,

@@ -1164,7 +1164,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     const size_t lds1 = BM * LD128 * 4, lds2 = 2 * BM * LD128 * 4;
     const double fE = (double)E, fN = (double)N, fR = (double)R;
     const bool trr = use_trr();
-    const bool trr_l = trr && m.plain_layers();  // the TRR transformer-layer kernels are RMSNorm + PreLN
+    const bool trr_l = trr && m.plain_layers();  // the TRR transformer-layer kernels are PreLN (RMSNorm or LayerNorm)
     PET_HIP_CHECK(hipMemsetAsync(w.dgeo, 0, E * 4 * sizeof(float), st));
     allow_big_lds(k_swiglu_bwd<256, DNF, false, true>, (BM * LD256 + BM * LD128) * 4);
     allow_big_lds(k_swiglu_bwd<256, DNF, true, true>, (BM * LD256 + BM * LD128) * 4);
@@ -1257,7 +1257,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D), fE * 4.0 * (3 * D + 2 * DFF));  // dY, X1, VG in; dX1 out
                 if (trr_l) {
                     const float* vg = (!tr && emlp_recompute_ok(A.mlp_in, A.mlp_out)) ? nullptr : Ab.VG;
-                    trr_emlp_bwd(dX, Ab.X1, vg, A.g_mlp, A.mlp_in, A.mlp_out, dX_alt, E, st, tr ? w.dVG : nullptr);
+                    trr_emlp_bwd(dX, Ab.X1, vg, A.g_mlp, ln ? A.b_mlp : nullptr, A.mlp_in, A.mlp_out, dX_alt, E, st,
+                                 tr ? w.dVG : nullptr);
                 }
                 else PET_LAUNCH_TR(tr, k_swiglu_bwd, PET_TA(128, DFF), gE, lds2, st, dX, Ab.X1, Ab.VG, A.g_mlp,
                     A.mlp_out.bwd, A.mlp_in.bwd, dX_alt, E, tr ? w.dVG : nullptr, ln);
@@ -1298,7 +1299,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                                       ln ? lp + ".norm_attention.bias" : std::string(), ln ? A.b_attn : nullptr);
             {
                 ProfScope ps("qkv_bwd", st, fR * 2.0 * D * 3 * D, fR * 4.0 * (3 * D + 3 * D));  // dQKV, X, dX1 in; dX out
-                if (trr_l) trr_qkv_bwd(w.dQKV, Ab.X, A.g_attn, A.qkv, dX_alt, dX, E, R, st);
+                if (trr_l) trr_qkv_bwd(w.dQKV, Ab.X, A.g_attn, ln, A.qkv, dX_alt, dX, E, R, st);
                 else if (post) k_qkv_bwd<true><<<gR, NTHREADS, lds1, st>>>(w.dQKV, nullptr, nullptr, A.qkv.bwd, dX_alt, dX, E, R, false);
                 else k_qkv_bwd<false><<<gR, NTHREADS, lds1, st>>>(w.dQKV, Ab.X, A.g_attn, A.qkv.bwd, dX_alt, dX, E, R, ln);
             }

@@ -837,7 +837,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
     const size_t lds_c = lds2 + BM * 20 + BM * 8;
     const double fE = (double)E, fN = (double)N, fR = (double)R;
     const bool trr = use_trr();
-    const bool trr_l = trr && m.plain_layers();  // the TRR transformer-layer kernels are RMSNorm + PreLN
+    const bool trr_l = trr && m.plain_layers();  // the TRR transformer-layer kernels are PreLN (RMSNorm or LayerNorm)
     // attention: 4 T^2 d FLOPs per atom per layer; T^2 summed on the host side of the graph
     const double attn_flops = 4.0 * D * g_sum_t2(g);
     const int L = m.h.num_gnn_layers, AL = m.h.num_attention_layers;
@@ -896,7 +896,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
             }
             {
                 ProfScope ps("qkv", st, fR * 2.0 * D * 3 * D, fR * 4.0 * (D + 3 * D));  // X in, QKV out
-                if (trr_l) trr_qkv(Ab.X, A.g_attn, A.qkv, Ab.QKV, R, st);
+                if (trr_l) trr_qkv(Ab.X, A.g_attn, m.layer_norm() ? A.b_attn : nullptr, A.qkv, Ab.QKV, R, st);
                 else if (post) k_qkv<false><<<gR, NTHREADS, lds1, st>>>(Ab.X, nullptr, nullptr, A.qkv.fwd, A.qkv.b, Ab.QKV, R);
                 else k_qkv<true><<<gR, NTHREADS, lds1, st>>>(Ab.X, A.g_attn, A.b_attn, A.qkv.fwd, A.qkv.b, Ab.QKV, R);
             }
@@ -951,7 +951,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                 if (trr_l) {
                     // [v; g] is stored for the adjoint unless no adjoint follows (save == 0) or it recomputes them
                     float* vg = (save == 0 || (save != 2 && emlp_recompute_ok(A.mlp_in, A.mlp_out))) ? nullptr : Ab.VG;
-                    trr_emlp(Ab.X1, A.g_mlp, A.mlp_in, A.mlp_out, vg, Xnext, E, st);
+                    trr_emlp(Ab.X1, A.g_mlp, m.layer_norm() ? A.b_mlp : nullptr, A.mlp_in, A.mlp_out, vg, Xnext, E, st);
                 }
                 else k_emlp<true><<<gE, NTHREADS, lds2, st>>>(Ab.X1, A.g_mlp, A.b_mlp, A.mlp_in.fwd, A.mlp_in.b, A.mlp_out.fwd,
                                                               A.mlp_out.b, Ab.VG, Xnext, E);

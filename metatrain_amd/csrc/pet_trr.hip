@@ -72,14 +72,16 @@ __device__ __forceinline__ void row_gemm128_h(const W2& w, const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_qkv_h(const float* __restrict__ X, const float* __restrict__ gamma, W2 win,
+template <bool LN>
+__global__ __launch_bounds__(256, 2) void k_qkv_h(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, W2 win,
                                                 const float* __restrict__ bin, float* __restrict__ QKV, int64_t R) {
     TRR_PROLOGUE(R);
     Split2<8> xs;
     {
         float4 x[16];
         load_rowfrag<16>(x, X, row, D, L.h);
-        rmsnorm_frag<16>(x, gamma, L.h);
+        norm_frag<16, LN>(x, gamma, beta, L.h);
         split_frag2<8>(x, xs);
     }
     row_gemm128_h<6, false, 2>(win, bin, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
@@ -92,7 +94,9 @@ __global__ __launch_bounds__(256, 2) void k_qkv_h(const float* __restrict__ X, c
 }
 
 // the same with full-line stores through a wave-private LDS tile (trr.h store_tile64_lines)
-__global__ __launch_bounds__(256, 2) void k_qkv_hl(const float* __restrict__ X, const float* __restrict__ gamma, W2 win,
+template <bool LN>
+__global__ __launch_bounds__(256, 2) void k_qkv_hl(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, W2 win,
                                                  const float* __restrict__ bin, float* __restrict__ QKV, int64_t R) {
     __shared__ __attribute__((aligned(16))) float tiles[4][32 * ROWS_LD];
     TRR_PROLOGUE(R);
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void k_qkv_hl(const float* __restrict__ X, 
     {
         float4 x[16];
         load_rows_lines128(x, lds, X, row0, R, L);
-        rmsnorm_frag<16>(x, gamma, L.h);
+        norm_frag<16, LN>(x, gamma, beta, L.h);
         split_frag2<8>(x, xs);
     }
     row_gemm128_h<6, false, 2>(win, bin, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void k_oproj_bwd_h(const float* __restrict_
 
 // dXin = (row < E ? dX1 : 0) + RMSNorm^T(dQKV Win): K = 384 in three 128-wide slices. One power-of-two scale per
 // row: it only ever shrinks (a later slice with larger entries rescales the accumulators, exactly).
+template <bool LN>
 __global__ __launch_bounds__(256) void k_qkv_bwd_h(const float* __restrict__ dQKV, const float* __restrict__ X,
                                                     const float* __restrict__ gamma, W2 winb,
                                                     const float* __restrict__ dX1, float* __restrict__ dXin, int64_t E,
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_h(const float* __restrict__ dQK
         const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
         w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
     }
-    rmsnorm_bwd_frag<16>(w, x);
+    norm_bwd_frag<16, LN>(w, x);
     if (valid && row < E) {
         load_rowfrag<16>(x, dX1, row, D, L.h);
 #pragma unroll
@@ -277,8 +282,9 @@ __device__ __forceinline__ void glds16_trr(const float* gsrc, unsigned lds_dst) 
 }
 // f16x3 (trr.h): two fp16 planes, three MFMAs per K block on a high and a cross accumulator; RMSNorm output and
 // SwiGLU output are O(1) rows, so no row scaling is needed here.
-template <bool LINES>
-__global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, const float* __restrict__ gamma, W2 win,
+template <bool LINES, bool LN>
+__global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, W2 win,
                                                   const float* __restrict__ bin, W2 wout,
                                                   const float* __restrict__ bout, float* __restrict__ VG,
                                                   float* __restrict__ X2, int64_t E) {
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, co
             float4 x[16];
 #pragma unroll
             for (int kg = 0; kg < 16; kg++) x[kg] = xb[kg * 64 + L.lane];
-            rmsnorm_frag<16>(x, gamma, L.h);
+            norm_frag<16, LN>(x, gamma, beta, L.h);
             split_frag2<8>(x, xs);
         }
         f32x16 out[4], outl[4];
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, co
 //   B: Win^T blocks for dn += [dv | dg] Win (four output tiles; per chunk K blocks 2hc, 2hc+1 of the value half
 //      and 16 + 2hc, 16 + 2hc + 1 of the gate half).
 // ---------------------------------------------------------------------------------
-template <bool TRAIN>
+template <bool TRAIN, bool LN>
 __global__ __launch_bounds__(256) void k_emlp_bwd_h(const float* __restrict__ dY, const float* __restrict__ X1,
                                                      const float* __restrict__ VG, const float* __restrict__ gamma,
                                                      W2 woutb, W2 winb, float* __restrict__ dX1, int64_t E,
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_h(const float* __restrict__ dY
         const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
         w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
     }
-    rmsnorm_bwd_frag<16>(w, x);
+    norm_bwd_frag<16, LN>(w, x);
     if (valid) {
         load_rowfrag<16>(x, dY, row, D, L.h);
 #pragma unroll
@@ -527,8 +533,10 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_h(const float* __restrict__ dY
 // matrix pipe has room: the stored-VG form moves 6.4 GB per launch at ~3.2 TB/s with the MFMAs ~20 % busy), against
 // 4 KB per edge and layer less written by the forward and 4 KB less read here, i.e. a quarter of the step's HBM
 // traffic. The two split row operands (dY, scaled; RMSNorm(X1)) live in wave-private LDS, 32 KB per wave.
+template <bool LN>
 __global__ __launch_bounds__(256) void k_emlp_bwd_r(const float* __restrict__ dY, const float* __restrict__ X1,
-                                                     const float* __restrict__ gamma, W2 winf,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     W2 winf,
                                                      const float* __restrict__ bin, W2 woutb, W2 winb,
                                                      float* __restrict__ dX1, int64_t E) {
     extern __shared__ __attribute__((aligned(16))) f16x8 opark[];  // [4 waves][ys: 8 x 2][xs: 8 x 2][64]
@@ -568,7 +576,7 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_r(const float* __restrict__ dY
     {
         float4 x[16];
         load_rowfrag<16>(x, X1, row, D, L.h);
-        rmsnorm_frag<16>(x, gamma, L.h);
+        norm_frag<16, LN>(x, gamma, beta, L.h);
         Split2<8> t;
         split_frag2<8>(x, t);
 #pragma unroll
@@ -649,7 +657,7 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_r(const float* __restrict__ dY
         const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
         w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
     }
-    rmsnorm_bwd_frag<16>(w, x);
+    norm_bwd_frag<16, LN>(w, x);
     if (valid) {
         load_rowfrag<16>(x, dY, row, D, L.h);
 #pragma unroll
@@ -845,15 +853,24 @@ static int num_cus() {
     return n;
 }
 
-void trr_qkv(const float* X, const float* gamma, const Lin& qkv, float* QKV, int64_t R, hipStream_t st) {
+// beta: the LayerNorm bias, nullptr = RMSNorm (here and below)
+void trr_qkv(const float* X, const float* gamma, const float* beta, const Lin& qkv, float* QKV, int64_t R,
+             hipStream_t st) {
     if (R <= 0) return;
-    if (g_line_stores & 1) k_qkv_hl<<<grid_rows(R), 256, 0, st>>>(X, gamma, w2_fwd(qkv), qkv.b, QKV, R);
-    else k_qkv_h<<<grid_rows(R), 256, 0, st>>>(X, gamma, w2_fwd(qkv), qkv.b, QKV, R);
+    const int grid = grid_rows(R);
+    if (g_line_stores & 1) {
+        if (beta) k_qkv_hl<true><<<grid, 256, 0, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R);
+        else k_qkv_hl<false><<<grid, 256, 0, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R);
+    } else {
+        if (beta) k_qkv_h<true><<<grid, 256, 0, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R);
+        else k_qkv_h<false><<<grid, 256, 0, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R);
+    }
 }
-void trr_qkv_bwd(const float* dQKV, const float* X, const float* gamma, const Lin& qkv, const float* dX1,
-                 float* dXin, int64_t E, int64_t R, hipStream_t st) {
+void trr_qkv_bwd(const float* dQKV, const float* X, const float* gamma, bool layer_norm, const Lin& qkv,
+                 const float* dX1, float* dXin, int64_t E, int64_t R, hipStream_t st) {
     if (R <= 0) return;
-    k_qkv_bwd_h<<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, w2_bwd(qkv), dX1, dXin, E, R);
+    if (layer_norm) k_qkv_bwd_h<true><<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, w2_bwd(qkv), dX1, dXin, E, R);
+    else k_qkv_bwd_h<false><<<grid_rows(R), 256, 0, st>>>(dQKV, X, gamma, w2_bwd(qkv), dX1, dXin, E, R);
 }
 void trr_oproj(const float* AO, const float* X, const Lin& out, float* X1, float* OC, int64_t E, int64_t R,
                hipStream_t st) {
@@ -865,33 +882,46 @@ void trr_oproj_bwd(const float* dX1, const float* dOC, const Lin& out, float* dA
     if (R <= 0) return;
     k_oproj_bwd_h<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, w2_bwd(out), dAO, E, R);
 }
-void trr_emlp(const float* X1, const float* gamma, const Lin& win, const Lin& wout, float* VG, float* X2,
-              int64_t E, hipStream_t st) {
+template <bool LINES, bool LN>
+static void launch_emlp(int grid, size_t lds, hipStream_t st, const float* X1, const float* gamma, const float* beta,
+                        const Lin& win, const Lin& wout, float* VG, float* X2, int64_t E) {
+    allow_big_lds(k_emlp_h<LINES, LN>, lds);
+    k_emlp_h<LINES, LN><<<grid, 256, lds, st>>>(X1, gamma, beta, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
+}
+void trr_emlp(const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout, float* VG,
+              float* X2, int64_t E, hipStream_t st) {
     if (E <= 0) return;
     const size_t rows_lds = (size_t)4 * 2 * 16 * 64 * sizeof(float4);  // 128 KB: two row buffers per wave
     const int grid = std::min(grid_rows(E), num_cus());
     if (g_line_stores & 2) {
         const size_t lds = rows_lds + (size_t)4 * 32 * TILE32_LD * sizeof(float);  // + one output tile per wave
-        allow_big_lds(k_emlp_h<true>, lds);
-        k_emlp_h<true><<<grid, 256, lds, st>>>(X1, gamma, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
+        if (beta) launch_emlp<true, true>(grid, lds, st, X1, gamma, beta, win, wout, VG, X2, E);
+        else launch_emlp<true, false>(grid, lds, st, X1, gamma, beta, win, wout, VG, X2, E);
     } else {
-        allow_big_lds(k_emlp_h<false>, rows_lds);
-        k_emlp_h<false><<<grid, 256, rows_lds, st>>>(X1, gamma, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
+        if (beta) launch_emlp<false, true>(grid, rows_lds, st, X1, gamma, beta, win, wout, VG, X2, E);
+        else launch_emlp<false, false>(grid, rows_lds, st, X1, gamma, beta, win, wout, VG, X2, E);
     }
 }
-void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const Lin& win,
-                  const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg) {
-    if (E <= 0) return;
+template <bool LN>
+static void launch_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const float* beta,
+                            const Lin& win, const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg) {
     const int grid = grid_rows(E);
     if (VG == nullptr && !t_dvg) {
         const size_t lds = (size_t)4 * 32 * 64 * sizeof(f16x8);  // 128 KB: both split row operands of 4 waves
-        allow_big_lds(k_emlp_bwd_r, lds);
-        k_emlp_bwd_r<<<grid, 256, lds, st>>>(dY, X1, gamma, w2_fwd(win), win.b, w2_bwd(wout), w2_bwd(win), dX1, E);
+        allow_big_lds(k_emlp_bwd_r<LN>, lds);
+        k_emlp_bwd_r<LN><<<grid, 256, lds, st>>>(dY, X1, gamma, beta, w2_fwd(win), win.b, w2_bwd(wout), w2_bwd(win), dX1,
+                                                 E);
     } else if (t_dvg) {
-        k_emlp_bwd_h<true><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, t_dvg);
+        k_emlp_bwd_h<true, LN><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, t_dvg);
     } else {
-        k_emlp_bwd_h<false><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, nullptr);
+        k_emlp_bwd_h<false, LN><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, nullptr);
     }
+}
+void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const float* beta,
+                  const Lin& win, const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg) {
+    if (E <= 0) return;
+    if (beta) launch_emlp_bwd<true>(dY, X1, VG, gamma, beta, win, wout, dX1, E, st, t_dvg);
+    else launch_emlp_bwd<false>(dY, X1, VG, gamma, beta, win, wout, dX1, E, st, t_dvg);
 }
 
 // ---------------------------------------------------------------------------------

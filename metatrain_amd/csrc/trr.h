@@ -353,6 +353,69 @@ __device__ __forceinline__ void rmsnorm_bwd_frag(float4 (&w)[KG], const float4 (
     }
 }
 
+// The norm of a transformer layer as a template switch: LN = false is torch.nn.RMSNorm (above), LN = true is
+// torch.nn.LayerNorm (eps 1e-5, weight + bias; transformer.py:170-176): the RMS formulas on the centred row.
+template <int KG, bool LN>
+__device__ __forceinline__ void norm_frag(float4 (&x)[KG], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          int h) {
+    if (!LN) {
+        rmsnorm_frag<KG>(x, gamma, h);
+        return;
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) sm += (x[kg].x + x[kg].y) + (x[kg].z + x[kg].w);
+    const float mean = row_sum(sm) * (1.0f / (8 * KG));
+    float ss = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) {
+        x[kg].x -= mean; x[kg].y -= mean; x[kg].z -= mean; x[kg].w -= mean;
+        ss += x[kg].x * x[kg].x + x[kg].y * x[kg].y + x[kg].z * x[kg].z + x[kg].w * x[kg].w;
+    }
+    ss = row_sum(ss);
+    const float rstd = rsqrtf(ss * (1.0f / (8 * KG)) + 1e-5f);
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * h);
+        const float4 b = *reinterpret_cast<const float4*>(beta + 8 * kg + 4 * h);
+        x[kg].x = x[kg].x * (rstd * g.x) + b.x; x[kg].y = x[kg].y * (rstd * g.y) + b.y;
+        x[kg].z = x[kg].z * (rstd * g.z) + b.z; x[kg].w = x[kg].w * (rstd * g.w) + b.w;
+    }
+}
+// adjoint: w = gamma * dn on entry, dx on exit; x (the un-normalised input) is centred in place when LN
+template <int KG, bool LN>
+__device__ __forceinline__ void norm_bwd_frag(float4 (&w)[KG], float4 (&x)[KG]) {
+    if (!LN) {
+        rmsnorm_bwd_frag<KG>(w, x);
+        return;
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) sm += (x[kg].x + x[kg].y) + (x[kg].z + x[kg].w);
+    const float mean = row_sum(sm) * (1.0f / (8 * KG));
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) {
+        x[kg].x -= mean; x[kg].y -= mean; x[kg].z -= mean; x[kg].w -= mean;
+        ss += x[kg].x * x[kg].x + x[kg].y * x[kg].y + x[kg].z * x[kg].z + x[kg].w * x[kg].w;
+        dot += x[kg].x * w[kg].x + x[kg].y * w[kg].y + x[kg].z * w[kg].z + x[kg].w * w[kg].w;
+    }
+    ss = row_sum(ss);
+    dot = row_sum(dot);
+    const float rstd = rsqrtf(ss * (1.0f / (8 * KG)) + 1e-5f);
+    const float coef = dot * rstd * rstd * rstd * (1.0f / (8 * KG));
+    float sw = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) {
+        w[kg].x = rstd * w[kg].x - x[kg].x * coef; w[kg].y = rstd * w[kg].y - x[kg].y * coef;
+        w[kg].z = rstd * w[kg].z - x[kg].z * coef; w[kg].w = rstd * w[kg].w - x[kg].w * coef;
+        sw += (w[kg].x + w[kg].y) + (w[kg].z + w[kg].w);
+    }
+    const float mw = row_sum(sw) * (1.0f / (8 * KG));
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) { w[kg].x -= mw; w[kg].y -= mw; w[kg].z -= mw; w[kg].w -= mw; }
+}
+
 // sigmoid on the hardware transcendentals: v_exp_f32 (2^x, ~1 ulp) and v_rcp_f32 (~1 ulp). The
 // argument scaling costs a relative error of ~1e-7 |x|, far inside the 1e-5 parity budget, and
 // saves ~15 VALU instructions per element over expf() + IEEE division in the gate-heavy stages.
