@@ -654,12 +654,13 @@ def _oracle_param_grads_cond(params, hypers, inp, seed_w):
     return {k: (torch.zeros_like(p64[k]) if g is None else g) for k, g in zip(keys, grads)}
 
 
-@pytest.mark.parametrize("activation", ["SwiGLU", "SiLU"])
-@pytest.mark.parametrize("wgrad_bf16", [1, 0])
-def test_training_gradients_of_a_layernorm_model(golden_dir, activation, wgrad_bf16):
+@pytest.mark.parametrize("activation,wgrad_bf16,trr", [("SwiGLU", 1, 1), ("SiLU", 1, 1), ("SwiGLU", 0, 1), ("SiLU", 0, 0),
+                                                       ("SwiGLU", 1, 0)])
+def test_training_gradients_of_a_layernorm_model(golden_dir, activation, wgrad_bf16, trr):
     """normalization = LayerNorm (modules/transformer.py:181-186, PreLN, feed-forward featuriser): the energy-loss and the
     force-loss parameter gradients -- norm weights AND biases -- against autograd / double backward through the fp64
-    oracle. LayerNorm-hat is the RMSNorm-hat of the centred row, which is how the second-order kernels compute it."""
+    oracle. LayerNorm-hat is the RMSNorm-hat of the centred row, which is how the second-order kernels compute it. With
+    the layer kernels of the first-order passes as TRR kernels (default) and as LDS-tile kernels (trr = 0)."""
     from metatrain_amd import runtime as rt
 
     dev = torch.device("cuda:0")
@@ -680,6 +681,7 @@ def test_training_gradients_of_a_layernorm_model(golden_dir, activation, wgrad_b
     assert any(k.endswith("norm_attention.bias") for k in ref1)
 
     rt.config_set("wgrad_bf16", wgrad_bf16)
+    rt.config_set("trr", trr)
     try:
         model = rt.HipModel(hypers, types)
         model.load({k: v.to(dev) for k, v in params.items()}, "energy")
@@ -699,6 +701,7 @@ def test_training_gradients_of_a_layernorm_model(golden_dir, activation, wgrad_b
         got2 = model.grads()
     finally:
         rt.config_set("wgrad_bf16", 1)
+        rt.config_set("trr", 1)
     assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < TOL
     for name, ref, got in (("energy loss", ref1, got1), ("force loss", ref2, got2)):
         assert set(got) == set(ref)
