@@ -1,6 +1,6 @@
 """Slab + halo partition of ONE box over several ranks: the host-side plumbing shared by the
-SOAP-BPNN (`soap_bpnn/partition.py`, halo = one cutoff) and PET (`pet/partition.py`, halo = num_gnn_layers cutoffs)
-single-box paths. Positions are replicated, centres are cut into slabs along the lattice direction with the largest
+SOAP-BPNN (`soap_bpnn/partition.py`, halo = one cutoff) and PET (`pet/partition.py`, halo = num_gnn_layers + 1
+cutoffs) single-box paths. Positions are replicated, centres are cut into slabs along the lattice direction with the largest
 plane spacing, a rank works on its slab plus every atom within `halo` of it."""
 from typing import Sequence, Tuple
 
@@ -10,8 +10,9 @@ import torch
 def slab_partition(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bool], halo: float, world: int,
                    rank: int) -> Tuple[torch.Tensor, torch.Tensor, int]:
     """``(index [n_sub] int64, owned [n_sub] bool, axis)``: the atoms rank ``rank`` of ``world`` works on (slab + halo,
-    ascending global index; the halo holds every atom within ``halo`` of the slab) and which of them it owns. Every atom is owned by exactly one rank. Element-wise tensor
-    work on the device (plumbing of the exchange, not the hot path)."""
+    ascending global index; the halo holds every atom within ``halo`` of the slab) and which of them it owns. Every atom
+    is owned by exactly one rank. Element-wise tensor work on the device (plumbing of the exchange, not the hot
+    path)."""
     if not 0 <= rank < world:
         raise ValueError(f"rank {rank} outside world size {world}")
     dev = positions.device
