@@ -17,6 +17,8 @@ elif mode == "grid":
     hypers.update(num_neighbors_adaptive=10, adaptive_cutoff_method="grid", cutoff_width_adaptive=1.0)
 elif mode == "legacy":
     hypers.update(normalization="LayerNorm", transformer_type="PostLN", activation="SiLU")  # (residual: layered API, own tests)
+elif mode == "layernorm":  # PreLN LayerNorm: the TRR layer kernels' LayerNorm instantiation, random norm weights / biases
+    hypers.update(normalization="LayerNorm", activation=("SiLU" if int(sys.argv[1]) % 2 else "SwiGLU"))
 elif mode == "cosine":
     hypers.update(cutoff_function="Cosine")
 elif mode == "hypers":  # the size-independent hyper-parameters (the kernels are one instantiation of the sizes)
@@ -35,6 +37,12 @@ if len(sys.argv) > 3 and sys.argv[3] == "species":  # many atomic types, random 
     print("atomic_types", types)
 p32 = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
 p64 = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float64)
+if mode == "layernorm":
+    _g = torch.Generator().manual_seed(int(sys.argv[1]))
+    for k in p64:
+        if ".norm_" in k:
+            p64[k] = p64[k] + 0.3 * torch.randn(p64[k].shape, generator=_g, dtype=torch.float64)
+            p32[k] = p64[k].float()
 model = rt.HipModel(hypers, types)
 model.load({k: v.to(dev) for k, v in p32.items()}, "energy")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)

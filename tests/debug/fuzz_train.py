@@ -19,6 +19,9 @@ if COND:
 LN = len(sys.argv) > 3 and sys.argv[3] == "layernorm"  # normalization = LayerNorm with random norm weights / biases
 if LN:
     hypers["normalization"] = "LayerNorm"
+import os
+for kv in filter(None, os.environ.get("PET_FUZZ_SET", "").split(",")):  # e.g. PET_FUZZ_SET=so_f16x3=0,wgrad_bf16=0
+    rt.config_set(kv.split("=")[0], int(kv.split("=")[1]))
 types = [1, 6, 7, 8]
 params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
 if LN:
