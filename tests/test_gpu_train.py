@@ -716,3 +716,56 @@ def test_training_gradients_of_a_layernorm_model(golden_dir, activation, wgrad_b
             print(f"{name}: {v:.3e}  {k}")
         bad = {k: v for k, v in worst.items() if not v < (5 * TOL if ref[k].numel() == 1 else TOL)}
         assert not bad, f"{name}: parameter gradients off: {bad}"
+
+
+def test_parameter_gradients_with_more_than_64_atomic_types(golden_dir):
+    """A universal-model-sized species table (100 atomic types; the embedding gradients are per-species row sums staged
+    in LDS in chunks of 64 species for the 256-wide node embedding, train.hip species_sum): energy-loss and
+    force-loss parameter gradients against the oracle, every species row of both embedding tables included."""
+    from metatrain_amd import runtime as rt
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS)
+    types = list(range(1, 101))
+    params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    inp = _inputs(golden_dir, "batch_two_systems.npz")
+    n = inp["positions"].shape[0]
+    gen = torch.Generator().manual_seed(13)
+    # every chunk of the species axis is hit: types 1..100 spread over the atoms, the last ones included
+    inp["species"] = torch.tensor(types)[torch.randint(0, 100, (n,), generator=gen)]
+    inp["species"][:4] = torch.tensor([1, 64, 65, 100])
+    seed_w = torch.rand(n, generator=gen) + 0.5
+    nu = torch.rand(n, generator=gen) - 0.5
+    u = torch.randn(n, 3, generator=gen)
+    ref1 = _oracle_param_grads(params, hypers, inp, seed_w)
+    ref2, _, _ = _oracle_second_order(params, hypers, inp, nu, u)
+
+    model = rt.HipModel(hypers, types)
+    model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    graph = rt.HipGraph(model, inp["positions"].float().to(dev), inp["cells"].float().to(dev),
+                        inp["centers"].to(dev), inp["neighbors"].to(dev), inp["cell_shifts"].to(dev),
+                        inp["species"].to(dev), inp["system_indices"].int().to(dev))
+    fw = rt.HipForward(model, graph, train=True)
+    model.zero_grad()
+    fw.forward()
+    fw.backward_train(seed_w.to(dev))
+    got1 = {k: v.clone() for k, v in model.grads().items()}
+    model.zero_grad()
+    fw.forward()
+    ones = torch.ones(n, device=dev)
+    fw.backward(ones)
+    fw.backward_train2(ones, nu.to(dev), u.to(dev))
+    got2 = model.grads()
+    for name, ref, got in (("energy loss", ref1, got1), ("force loss", ref2, got2)):
+        assert set(got) == set(ref)
+        for k in ("node_embedders.0.weight", "edge_embedder.weight"):
+            assert ref[k].shape[0] == 100 and float(ref[k][64:].abs().max()) > 0, k
+        bad = {}
+        for k, r in ref.items():
+            r = r.numpy()
+            g = got[k].cpu().numpy().astype(np.float64)
+            scale = np.abs(r).max()
+            err = np.abs(g - r).max() / scale if scale > 1e-12 else np.abs(g - r).max()
+            if not err < (5 * TOL if r.size == 1 else TOL):
+                bad[k] = err
+        assert not bad, f"{name}: parameter gradients off: {bad}"
