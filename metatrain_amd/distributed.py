@@ -32,20 +32,25 @@ def expand_hostlist(nodelist: str) -> List[str]:
             parts.append(nodelist[start:k])
             start = k + 1
     parts.append(nodelist[start:])
-    for part in parts:
+    def expand(part: str) -> List[str]:  # every bracket group of the part: cartesian product, left to right
         if "[" not in part:
-            if part:
-                hosts.append(part)
-            continue
+            return [part]
         head, rest = part.split("[", 1)
         body, tail = rest.split("]", 1)
+        tails = expand(tail)
+        out: List[str] = []
         for item in body.split(","):
             if "-" in item:
                 lo, hi = item.split("-")
-                for v in range(int(lo), int(hi) + 1):
-                    hosts.append(f"{head}{v:0{len(lo)}d}{tail}")
+                mids = [f"{v:0{len(lo)}d}" for v in range(int(lo), int(hi) + 1)]
             else:
-                hosts.append(f"{head}{item}{tail}")
+                mids = [item]
+            out += [f"{head}{mid}{t}" for mid in mids for t in tails]
+        return out
+
+    for part in parts:
+        if part:
+            hosts += expand(part)
     return hosts
 
 

@@ -7,6 +7,38 @@ from typing import Sequence, Tuple
 import torch
 
 
+def complete_lattice(cell: torch.Tensor, pbc: Sequence[bool]) -> torch.Tensor:
+    """The 3 x 3 fp64 lattice with the rows of non-periodic directions replaced by unit vectors orthogonal to the
+    periodic ones (metatomic stores zero vectors there). Raises if the periodic rows are linearly dependent."""
+    c = cell.detach().to("cpu", torch.float64).reshape(3, 3).clone()
+    basis = []
+
+    def residual(v):
+        r = v.clone()
+        for b in basis:
+            r = r - torch.dot(r, b) * b
+        return r
+
+    for a in range(3):
+        if pbc[a]:
+            r = residual(c[a])
+            n = float(torch.linalg.norm(r))
+            if n <= 1e-9:
+                raise ValueError("singular cell: the lattice vectors of the periodic directions are linearly dependent")
+            basis.append(r / n)
+    for a in range(3):
+        if pbc[a]:
+            continue
+        cand = [residual(torch.eye(3, dtype=torch.float64)[e]) for e in range(3)]
+        best = max(cand, key=lambda r: float(torch.linalg.norm(r)))
+        best = best / torch.linalg.norm(best)
+        c[a] = best
+        basis.append(best)
+    if abs(float(torch.det(c))) <= 1e-12:
+        raise ValueError("singular cell")
+    return c
+
+
 def slab_partition(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bool], halo: float, world: int,
                    rank: int) -> Tuple[torch.Tensor, torch.Tensor, int]:
     """``(index [n_sub] int64, owned [n_sub] bool, axis)``: the atoms rank ``rank`` of ``world`` works on (slab + halo,
@@ -19,20 +51,25 @@ def slab_partition(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bo
     n = positions.shape[0]
     if world == 1:
         return torch.arange(n, device=dev), torch.ones(n, dtype=torch.bool, device=dev), 0
-    c = cell.detach().to("cpu", torch.float64).reshape(3, 3)
-    periodic_cell = bool(abs(torch.det(c)) > 1e-12)
     pos = positions.detach()
-    if periodic_cell:
-        # plane spacing of lattice direction a: V / |b x c|; cut along the direction with the largest one
+    periodic = [bool(p) for p in pbc]
+    if any(periodic):
+        # lattice completed for the non-periodic rows (metatomic: zero vectors there) exactly as the neighbour list does
+        # (csrc/nl.hip::lattice_params): a surface / wire keeps its wrap-around halo along the periodic directions
+        c = complete_lattice(cell, periodic)
         vol = abs(float(torch.det(c)))
+        # plane spacing of lattice direction a: V / |b x c|; cut along the direction with the largest extent in planes
         heights = []
         for a in range(3):
             b1, b2 = c[(a + 1) % 3], c[(a + 2) % 3]
             heights.append(vol / float(torch.linalg.norm(torch.linalg.cross(b1, b2))))
-        axis = max(range(3), key=lambda a: heights[a])
         inv = torch.linalg.inv(c).to(dev, pos.dtype)
-        f = (pos @ inv)[:, axis]
-        wrap = bool(pbc[axis])
+        frac = pos @ inv
+        # thickness of the system along every direction, in length units (open directions: bounding box of the atoms)
+        span = [heights[a] if periodic[a] else float(frac[:, a].max() - frac[:, a].min()) * heights[a] for a in range(3)]
+        axis = max(range(3), key=lambda a: span[a])
+        f = frac[:, axis]
+        wrap = periodic[axis]
         if wrap:
             f = f - torch.floor(f)
             f = torch.where(f >= 1.0, f - 1.0, f)  # guard the rounding of values just below an integer
@@ -40,7 +77,7 @@ def slab_partition(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bo
         else:
             lo_all, width = float(f.min()), max(float(f.max() - f.min()), 1e-12) * (1.0 + 1e-6)
         h = halo / heights[axis] * 1.0001
-    else:  # open system without a cell: slabs of the bounding box along the longest Cartesian extent
+    else:  # open system: slabs of the bounding box along the longest Cartesian extent
         ext = pos.max(0).values - pos.min(0).values
         axis = int(torch.argmax(ext))
         f = pos[:, axis]

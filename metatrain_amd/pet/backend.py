@@ -546,7 +546,17 @@ class PETBackend(torch.nn.Module):
                 continue
             blocks = list(self.node_last_layers[name][0].keys())
             if len(blocks) != 1 or self.node_last_layers[name][0][blocks[0]].weight.shape[0] != 1:
-                continue  # several blocks / properties: served (first order) by pet_predict below
+                # several blocks / properties: pet_predict serves them, but its autograd node returns no PARAMETER
+                # gradients (the parameters reach it as a plain list), so a loss.backward() would silently leave these
+                # heads -- and the backbone's share from them -- without gradients
+                heads = [self.node_heads[name], self.edge_heads[name], self.node_last_layers[name],
+                         self.edge_last_layers[name]]
+                if any(p.requires_grad for h in heads for p in h.parameters()):
+                    raise PetHipError(
+                        f"training target '{name}' has several blocks or properties: libpet_hip computes parameter "
+                        "gradients only for single-property targets (the fused training node); freeze this target's "
+                        "heads (requires_grad_(False)) or evaluate it in eval() mode")
+                continue
             if tctx is None:
                 raise PetHipError("training through the mirror needs the batch_data of this backend's preprocess()")
             key = (name, blocks[0])

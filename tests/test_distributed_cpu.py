@@ -116,6 +116,7 @@ def test_slurm_environment_and_process_group_call_sequence(monkeypatch):
 
     assert d.expand_hostlist("nid[001-003,007],login1") == ["nid001", "nid002", "nid003", "nid007", "login1"]
     assert d.expand_hostlist("node12") == ["node12"]
+    assert d.expand_hostlist("rack[1-2]n[01-02],x") == ["rack1n01", "rack1n02", "rack2n01", "rack2n02", "x"]
     for k, v in {"SLURM_JOB_ID": "7", "SLURM_JOB_NODELIST": "gpu[05-06]", "SLURM_NTASKS": "16", "SLURM_PROCID": "11",
                  "SLURM_LOCALID": "3"}.items():
         monkeypatch.setenv(k, v)

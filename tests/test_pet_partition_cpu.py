@@ -76,6 +76,10 @@ def _boxes():
         ("long cell", frac @ long_cell, z, long_cell, [True] * 3),
         ("triclinic", frac @ tri, z, tri, [True] * 3),
         ("mixed pbc", frac @ long_cell, z, long_cell, [False, True, True]),
+        # metatomic convention for a surface: ZERO lattice vector along the open direction (such a cell
+        # was treated as fully open and cut along a periodic axis without a wrap-around halo)
+        ("surface, zero row", frac @ long_cell, z, torch.diag(torch.tensor([60.0, 14.0, 0.0])), [True, True, False]),
+        ("wire, two zero rows", frac @ long_cell, z, torch.diag(torch.tensor([60.0, 0.0, 0.0])), [True, False, False]),
     ]
 
 

@@ -27,6 +27,9 @@ def _boxes():
         ("triclinic", pos @ torch.linalg.inv(cell) @ tri, z, tri, [True] * 3),
         ("mixed pbc", pos @ torch.linalg.inv(cell) @ slab, z, slab, [False, True, True]),
         ("open cluster", pos, z, torch.zeros(3, 3), [False] * 3),
+        # metatomic's surface convention: zero lattice vector along the open direction; the longest direction is periodic
+        ("surface, zero row", pos @ torch.linalg.inv(cell) @ slab, z, torch.diag(torch.tensor([40.0, 12.0, 0.0])),
+         [True, True, False]),
     ]
 
 
