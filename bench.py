@@ -9,7 +9,11 @@ over one batch of ``--boxes`` random periodic boxes per GPU (cubi
 rho = 0.05 / A^3, U[0,L)^3 positions, species uniform over {1,6,7,8}, default PET hypers,
 fp32). The neighbour list is built once, before the clock starts, exactly like the
 reference (CPU collate, outside its timed region); its GPU build time is reported
-separately. Boxes are sharded over ranks with no data-path collective (weak scaling).
+separately. Boxes are sharded over ranks with no data-path collective. Default: ``--boxes`` per
+GPU per step whatever N is ("scaling": "weak"). ``--total-boxes B`` fixes the GLOBAL batch instead: the
+B boxes of a step are split over the N ranks ("scaling": "strong"; north_star's 8-GPU target is a
+strong-scaling one) and every rank walks its share in chunks of at most ``--boxes`` boxes that reuse one
+activation workspace (64 boxes = 352 GB of activations do not fit one GPU at once).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -60,7 +64,7 @@ SURVEY_8D_BYTES_PER_ATOM = 150e3  # forward + forces with a
 
 
 def _traffic_file():
-    for name in ("r02_traffic.json", "r01_traffic.json"):   # newest round first
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # newest round first
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as fh:
@@ -163,7 +167,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--boxes", type=int, default=8,
-                    help="10k-atom boxes per GPU per step (1: 710k, 2: 757k, 4: 799k, 8: 816k atom-steps/s, DESIGN.md 5)")
+                    help="10k-atom boxes per GPU per step (round 2: 1 box 1.26 M, 8 boxes 1.47 M atom-steps/s, DESIGN.md 5); "
+                         "with --total-boxes: the chunk size a rank walks its share in")
+    ap.add_argument("--total-boxes", type=int, default=0,
+                    help="strong-scaling mode: this many boxes per step in the WHOLE job, split over the ranks and "
+                         "walked in chunks of --boxes (0 = weak scaling, --boxes per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print a per-stage table to stderr")
     ap.add_argument("--normalization", default="RMSNorm", choices=["RMSNorm", "LayerNorm"],
@@ -202,43 +210,61 @@ def main():
     model.load({k: v.to(dev) for k, v in params.items()}, "energy")
 
     # ---- inputs resident in HBM before the clock starts ---------------------------------
-    boxes = args.boxes
-    pos_l, z_l, cell_l, pair_l, sys_l = [], [], [], [], []
+    strong = args.total_boxes > 0
+    if strong:  # rank r takes boxes r, r + world, ... of the global batch
+        my_ids = list(range(rank, args.total_boxes, world))
+        if args.total_boxes < world:
+            raise SystemExit(f"--total-boxes {args.total_boxes} < {world} ranks")
+    else:
+        my_ids = pdist.box_seeds(args.boxes, rank)
+    chunks = []   # per chunk of <= --boxes boxes: the concatenated inputs, resident in HBM
     nl_ms = 0.0
-    seeds = pdist.box_seeds(boxes, rank)
-    for b in range(boxes):
-        pos, z, cell = random_box(ATOMS_PER_BOX, seed=seeds[b])
-        posd = pos.to(dev)
-        rt.neighbor_list(posd[:64].contiguous(), cell, [True] * 3, hypers["cutoff"])  # warm the kernels
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pairs, _ = rt.neighbor_list(posd, cell, [True] * 3, hypers["cutoff"])
-        torch.cuda.synchronize()
-        nl_ms += (time.perf_counter() - t0) * 1e3
-        off = b * ATOMS_PER_BOX
-        pairs = pairs.clone()
-        pairs[:, 0:2] += off
-        pos_l.append(posd); z_l.append(z.to(dev)); cell_l.append(cell.to(dev)); pair_l.append(pairs)
-        sys_l.append(torch.full((ATOMS_PER_BOX,), b, dtype=torch.int32, device=dev))
-    positions, species, cells = torch.cat(pos_l), torch.cat(z_l), torch.stack(cell_l)
-    pairs, sysidx = torch.cat(pair_l), torch.cat(sys_l)
-    centers, neighbors = pairs[:, 0].contiguous(), pairs[:, 1].contiguous()
-    shifts = pairs[:, 2:5].contiguous()
-    n_atoms = boxes * ATOMS_PER_BOX
-    ones = torch.ones(n_atoms, dtype=torch.float32, device=dev)
+    pos_l, z_l, cell_l = [], [], []
+    for c0 in range(0, len(my_ids), args.boxes):
+        ids = my_ids[c0:c0 + args.boxes]
+        cp, cz, cc, cpair, csys = [], [], [], [], []
+        for b, seed in enumerate(ids):
+            pos, z, cell = random_box(ATOMS_PER_BOX, seed=seed)
+            posd = pos.to(dev)
+            rt.neighbor_list(posd[:64].contiguous(), cell, [True] * 3, hypers["cutoff"])  # warm the kernels
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pairs, _ = rt.neighbor_list(posd, cell, [True] * 3, hypers["cutoff"])
+            torch.cuda.synchronize()
+            nl_ms += (time.perf_counter() - t0) * 1e3
+            pairs = pairs.clone()
+            pairs[:, 0:2] += b * ATOMS_PER_BOX
+            cp.append(posd); cz.append(z.to(dev)); cc.append(cell.to(dev)); cpair.append(pairs)
+            csys.append(torch.full((ATOMS_PER_BOX,), b, dtype=torch.int32, device=dev))
+        if c0 == 0:
+            pos_l, z_l, cell_l = cp, cz, cc
+        pairs = torch.cat(cpair)
+        chunks.append({"positions": torch.cat(cp), "species": torch.cat(cz), "cells": torch.stack(cc),
+                       "centers": pairs[:, 0].contiguous(), "neighbors": pairs[:, 1].contiguous(),
+                       "shifts": pairs[:, 2:5].contiguous(), "sysidx": torch.cat(csys),
+                       "ones": torch.ones(len(ids) * ATOMS_PER_BOX, dtype=torch.float32, device=dev)})
+    boxes = len(chunks[0]["ones"]) // ATOMS_PER_BOX   # boxes of the first (largest) chunk
+    n_atoms = len(my_ids) * ATOMS_PER_BOX             # atoms this rank processes per step
+    ones = chunks[0]["ones"]
 
     state = {}
 
     def step():
-        graph = rt.HipGraph(model, positions, cells, centers, neighbors, shifts, species, sysidx)
-        fw = state.get("fw")
-        if fw is None or fw.graph.n_edges != graph.n_edges:
-            fw = rt.HipForward(model, graph)   # activation workspace: allocated once, reused
+        out = None
+        for ch in chunks:
+            graph = rt.HipGraph(model, ch["positions"], ch["cells"], ch["centers"], ch["neighbors"], ch["shifts"],
+                                ch["species"], ch["sysidx"])
+            fw = state.get("fw")
+            try:   # activation workspace: allocated once (for the largest chunk seen), reused by every chunk and step
+                fw = fw.rebind(graph) if fw is not None else rt.HipForward(model, graph)
+            except rt.PetHipError:
+                state["fw"] = fw = None
+                fw = rt.HipForward(model, graph)
             state["fw"] = fw
-        fw.graph = graph
-        atomic = fw.forward()
-        grad = fw.backward(ones)
-        return atomic, grad, graph
+            atomic = fw.forward()
+            grad = fw.backward(ch["ones"])
+            out = out or (atomic, grad, graph)
+        return out
 
     def barrier():
         pdist.barrier(dev)
@@ -274,7 +300,7 @@ def main():
     rt.profile(False)
 
     elapsed = pdist.max_over_ranks(elapsed, dev)
-    total_atoms = n_atoms * world
+    total_atoms = args.total_boxes * ATOMS_PER_BOX if strong else n_atoms * world
     ms_per_step = elapsed / args.steps * 1e3
     value = total_atoms * args.steps / elapsed
 
@@ -330,18 +356,21 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic random periodic boxes (rho=0.05/A^3, 4 species), weights from a seeded generator",
             "config": {
-                "workload": f"PET forward + dE/dR (preprocess+features+predict+backward), {boxes} x "
-                            f"{ATOMS_PER_BOX}-atom boxes per GPU per step, default PET hypers"
+                "workload": f"PET forward + dE/dR (preprocess+features+predict+backward), "
+                            + (f"{args.total_boxes} x {ATOMS_PER_BOX}-atom boxes per step in the whole job "
+                               f"({len(my_ids)} per GPU, chunks of {boxes})" if strong else
+                               f"{boxes} x {ATOMS_PER_BOX}-atom boxes per GPU per step") + ", default PET hypers"
                             f"{'' if args.normalization == 'RMSNorm' else ' with normalization=' + args.normalization} (2.9M params), "
                             f"4.5 A cutoff, {graph.n_edges // boxes} edges/box",
                 "atoms_per_gpu_per_step": n_atoms,
                 "edges_per_gpu_per_step": int(graph.n_edges),
                 "parallelism": f"boxes sharded over {world} rank(s), no data-path collective",
+                "chunks_per_step_per_gpu": len(chunks),
                 "arithmetic": ARITHMETIC,
                 "neighbor_list_gpu_ms_per_box": nl_ms / boxes,
                 "total_energy_rank0": e_total,
@@ -349,21 +378,23 @@ def main():
             "roofline": roof,
         }
         # whole-step view: SURVEY §8(d) algorithmic GEMM FLOPs, forward x2 for forces
-        e, n = graph.n_edges, n_atoms
+        # (`graph` is the step's first chunk; the other chunks are boxes of the same size and density)
+        chunk_atoms = boxes * ATOMS_PER_BOX
+        e, n = graph.n_edges, chunk_atoms
         rowptr = graph.csr()["rowptr"].double()
         t2 = float((((rowptr[1:] - rowptr[:-1]) + 1) ** 2).sum())
-        fwd_flops = 2001152.0 * e + 4292864.0 * n + 2048.0 * t2
+        fwd_flops = (2001152.0 * e + 4292864.0 * n + 2048.0 * t2) * (n_atoms / chunk_atoms)
         out["roofline"]["whole_step_algorithmic_tflops"] = 2 * fwd_flops / (ms_per_step * 1e-3) / 1e12
         # step-level traffic: what this design moves per step (sum of the stages' own byte counts; the PMC total
         # of the committed profile when it is the same workload) against SURVEY 8(d)'s 150 KB/atom
         step_alg = SURVEY_8D_BYTES_PER_ATOM * n_atoms
-        design = sum(r["bytes"] for r in table)
-        pmc_step = pmc_step_traffic(int(graph.n_edges))
+        design = sum(r["bytes"] for r in table)   # the untimed profiled step walks every chunk
+        pmc_step = pmc_step_traffic(int(graph.n_edges)) if len(chunks) == 1 else None
         out["roofline"]["step_traffic"] = {
             "survey_8d_algorithmic_bytes": step_alg, "design_bytes_counted_by_stages": design or None,
             "pmc_bytes": pmc_step, "ratio_to_survey_8d": (pmc_step or design or 0.0) / step_alg or None,
             "hbm_frac_whole_step": (pmc_step or design or 0.0) / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9) or None}
-        if world == 1:
+        if world == 1 and not strong:
             # not `value`: the same step started from HOST-resident systems (what an MD driver or a DataLoader hands
             # over) -- H2D of positions / species / cells, device neighbour lists + collate (metatrain_amd.data), graph
             # build, forward, dE/dR, D2H of per-atom energies and gradients. DESIGN.md section 5 quotes it.
@@ -376,10 +407,10 @@ def main():
                            for p, z, c, pbc in host]
                 batch = pdata.collate(systems, hypers["cutoff"])
                 g = pdata.graph_of(model, batch)
-                fw = state["fw"]
-                if fw.graph.n_edges != g.n_edges:
+                try:
+                    fw = state["fw"].rebind(g)
+                except rt.PetHipError:
                     fw = state["fw"] = rt.HipForward(model, g)
-                fw.graph = g
                 a = fw.forward()
                 return a.cpu(), fw.backward(ones).cpu()
 

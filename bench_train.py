@@ -71,10 +71,19 @@ def main():
     ap.add_argument("--micro", type=int, default=0,
                     help="boxes per micro-batch (gradient accumulation, TrainStep.microbatched); 0 = the whole batch at once. "
                          "BASELINE configs[3] per GPU: --boxes 64 --atoms 10000 --micro 8")
+    ap.add_argument("--total-boxes", type=int, default=0,
+                    help="strong-scaling mode: boxes per step in the WHOLE job, split over the ranks (0 = weak: --boxes "
+                         "per GPU)")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE configs[3]: 512 x 10 000-atom boxes per step in the whole job (64 per GPU at N = 8), "
+                         "micro-batches of 4 = --total-boxes 512 --atoms 10000 --micro 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--normalization", default="RMSNorm", choices=["RMSNorm", "LayerNorm"],
                     help="LayerNorm: the legacy-checkpoint norm")
     args = ap.parse_args()
+    if args.config4:
+        args.total_boxes, args.atoms = args.total_boxes or 512, 10000
+        args.micro = args.micro or 4
 
     from metatrain_amd import distributed as pdist
 
@@ -112,7 +121,15 @@ def main():
 
     gen = torch.Generator().manual_seed(1234 + rank)
     micro = args.micro if args.micro > 0 else args.boxes
-    seeds = pdist.box_seeds(args.boxes, rank)
+    strong = args.total_boxes > 0
+    if strong:  # the global batch is fixed; rank r takes boxes r, r + world, ...
+        if args.total_boxes % world:
+            raise SystemExit(f"--total-boxes {args.total_boxes} is not a multiple of {world} ranks (DDP semantics: equal shards)")
+        seeds = list(range(rank, args.total_boxes, world))
+        args.boxes = len(seeds)
+        micro = min(args.micro, args.boxes) if args.micro > 0 else args.boxes
+    else:
+        seeds = pdist.box_seeds(args.boxes, rank)
     batches, n_edges = [], 0
     for m0 in range(0, args.boxes, micro):
         pos_l, z_l, cell_l, pair_l, sys_l = [], [], [], [], []
@@ -138,6 +155,7 @@ def main():
     for b in batches:
         b["fw"] = fw
     train = TrainStep(model, {"warmup_fraction": 0.0, "num_epochs": 10**6})
+    comm_events = []
 
     def step(*_):
         return train.microbatched(batches) if len(batches) > 1 else train(
@@ -150,11 +168,14 @@ def main():
     for _ in range(args.warmup):
         step(graph, fw, target_e, per_box, target_g)
     pdist.barrier(dev)
+    train.comm_events = comm_events   # (start, end) events around each step's gradient all-reduce (N > 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses.append(step(graph, fw, target_e, per_box, target_g)["loss"])
     pdist.barrier(dev)
     elapsed = pdist.max_over_ranks(time.perf_counter() - t0, dev)
+    train.comm_events = None
+    comm_ms = (sum(a.elapsed_time(b) for a, b in comm_events) / len(comm_events)) if comm_events else 0.0
     if rank == 0:
         ls = [float(x) for x in losses]
         assert all(l == l for l in ls), "training diverged to NaN"
@@ -167,12 +188,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic random periodic boxes and random targets, weights from a seeded generator",
             "config": {
-                "workload": f"PET training step, {args.boxes} x {args.atoms}-atom boxes per GPU per step"
+                "workload": f"PET training step, "
+                            + (f"{args.total_boxes} x {args.atoms}-atom boxes per step in the whole job ({args.boxes} per GPU)"
+                               if strong else f"{args.boxes} x {args.atoms}-atom boxes per GPU per step") +
                             f"{f' in micro-batches of {micro} (gradient accumulation)' if len(batches) > 1 else ''}, default PET "
                             f"hypers{'' if args.normalization == 'RMSNorm' else ' with normalization=' + args.normalization} (2.9M params), MSE(E/atom)+MSE(dE/dR), clip 1.0, Adam lr 1e-4",
                 "atoms_per_gpu_per_step": n_atoms,
@@ -180,6 +203,8 @@ def main():
                 "micro_batches": len(batches),
                 "parallelism": f"boxes sharded over {world} rank(s); one 11.6 MB gradient all-reduce per step"
                                if world > 1 else "single GPU",
+                "gradient_all_reduce_ms_per_step": comm_ms,
+                "gradient_all_reduce_backend": backend if world > 1 else None,
                 "loss_first_last": [ls[0], ls[-1]],
                 "workspace_gb": (fw.nbytes + fw.workspace2.numel()) / 1e9,
             },

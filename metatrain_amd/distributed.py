@@ -7,7 +7,7 @@ the mean all-reduce of the flat 11.6 MB gradient bucket (torch DDP's role in the
 utils/distributed/distributed_data_parallel.py:7-15, pet/trainer.py:344-345).
 """
 import os
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -134,13 +134,25 @@ def sum_over_ranks(value: float, device: torch.device) -> float:
     return float(t.item())
 
 
-def all_reduce_gradients(model) -> None:
+def all_reduce_gradients(model, timing: Optional[list] = None) -> None:
     """Mean of the gradient slots over ranks, as ONE collective on the flat bucket (2 903 298 fp32 =
     11.6 MB: a single ring all-reduce is per-link bound on xGMI, and one bucket keeps it at one
-    launch). ``model`` exposes ``flat_grad()`` / ``set_flat_grad(t)`` (runtime.HipModel)."""
+    launch). ``model`` exposes ``flat_grad()`` / ``set_flat_grad(t)`` (runtime.HipModel). RCCL takes the mean itself
+    (``ReduceOp.AVG``); gloo (CPU tests, debugging) sums and divides. ``timing``: a list that receives a pair of
+    recorded events around copy-out + collective + copy-in (the benches read ``elapsed_time`` after the step)."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return
+    ev = None
+    if timing is not None and torch.cuda.is_available():
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     flat = model.flat_grad()
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat /= dist.get_world_size()
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= dist.get_world_size()
     model.set_flat_grad(flat)
+    if ev is not None:
+        ev[1].record()
+        timing.append(ev)

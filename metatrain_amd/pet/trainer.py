@@ -80,6 +80,7 @@ class TrainStep:
         self.hypers.update(hypers or {})
         self.total_steps = int(self.hypers["num_epochs"]) * int(steps_per_epoch)
         self.step_index = 0  # optimizer steps taken so far (LambdaLR's last_epoch)
+        self.comm_events: Optional[list] = None  # a list here collects (start, end) events around every gradient all-reduce
 
     def state_dict(self) -> Dict[str, object]:
         """What the reference's trainer checkpoint keeps of the optimizer and scheduler (``pet/trainer.py:697-717``:
@@ -136,7 +137,7 @@ class TrainStep:
 
     def _finish(self) -> torch.Tensor:
         m = self.model
-        D.all_reduce_gradients(m)
+        D.all_reduce_gradients(m, self.comm_events)
         norm = m.adam_step(self.current_lr(), self.step_index + 1, weight_decay=self.hypers["weight_decay"],
                            max_grad_norm=self.hypers["grad_clip_norm"] or 0.0)
         self.step_index += 1
