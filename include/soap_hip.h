@@ -69,6 +69,27 @@ int soap_forward(const soap_model_t* m, const pet_graph_t* g, void* d_workspace,
 int soap_backward(const soap_model_t* m, const pet_graph_t* g, void* d_workspace, int64_t workspace_bytes,
                   const float* d_grad_atomic, float* d_grad_positions, float* d_grad_cells, void* stream);
 
+/* ---- training step (reference loop body soap_bpnn/trainer.py:344-391: zero_grad, evaluate_model(is_training=True),
+ * loss.backward(), Adam lr 1e-3 without clipping, soap_bpnn/documentation.py TrainerHypers) -------------------------------
+ * Trainable: layernorm.<s>.{weight,bias}, bpnn.<s>.{0,2}.weight, last_layers.energy.<s>.weight (every parameter of a
+ * legacy = True model; legacy = False models are refused with PET_ERR_UNSUPPORTED: their species embedding / centre
+ * encoding have no gradient kernels). */
+/* Allocates (first call) and zeroes the gradient slot of every trainable parameter (optimizer.zero_grad()). */
+int soap_model_zero_grad(soap_model_t* m, void* stream);
+int64_t soap_train_workspace_bytes(const soap_model_t* m, int64_t n_nodes, int64_t n_edges);
+/* What loss.backward() leaves in parameter.grad for  L = L_E(E) + L_F(dE/dR):  ADDS  d/d theta [ sum_i gA_i e_i + <u, dE/dR> ]
+ * to the slots, with d_grad_atomic [N] = dL_E/d e_i and d_u [N,3] = dL_F/d(dE/dR) (NULL: energy-only loss). The double
+ * backward of utils/output_gradient.py:34-40 (create_graph=True) is done as forward-over-reverse: d_tangent_atomic [N]
+ * receives the tangent of every atomic energy along u (its sum equals <u, dE/dR>, a self-check). soap_forward must have
+ * run on d_workspace for this graph. */
+int soap_train_gradients(soap_model_t* m, const pet_graph_t* g, void* d_workspace, int64_t workspace_bytes,
+                         void* d_train_workspace, int64_t train_workspace_bytes, const float* d_grad_atomic,
+                         const float* d_u, float* d_tangent_atomic, void* stream);
+int soap_model_get_grad(const soap_model_t* m, const char* key, float* d_out, int64_t numel, void* stream);
+int soap_model_get_param(const soap_model_t* m, const char* key, float* d_out, int64_t numel, void* stream);
+/* torch.optim.Adam step (no weight decay; `step` counted from 1) on every trainable parameter, then soap_model_finalize. */
+int soap_adam_step(soap_model_t* m, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

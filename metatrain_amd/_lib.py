@@ -44,6 +44,8 @@ SYMBOLS = [
 SOAP_SYMBOLS = [
     "soap_model_create", "soap_model_destroy", "soap_model_feature_size", "soap_model_set_radial_table",
     "soap_model_set_param", "soap_model_finalize", "soap_workspace_bytes", "soap_forward", "soap_backward",
+    "soap_model_zero_grad", "soap_train_workspace_bytes", "soap_train_gradients", "soap_model_get_grad",
+    "soap_model_get_param", "soap_adam_step",
 ]
 SOAP_MAX_L = 8
 
@@ -199,6 +201,13 @@ def load() -> ctypes.CDLL:
     lib.soap_workspace_bytes.restype = c_int64
     lib.soap_forward.argtypes = [P, P, P, c_int64, P, P, P]
     lib.soap_backward.argtypes = [P, P, P, c_int64, P, P, P, P]
+    lib.soap_model_zero_grad.argtypes = [P, P]
+    lib.soap_train_workspace_bytes.argtypes = [P, c_int64, c_int64]
+    lib.soap_train_workspace_bytes.restype = c_int64
+    lib.soap_train_gradients.argtypes = [P, P, P, c_int64, P, c_int64, P, P, P, P]
+    lib.soap_model_get_grad.argtypes = [P, c_char_p, P, c_int64, P]
+    lib.soap_model_get_param.argtypes = [P, c_char_p, P, c_int64, P]
+    lib.soap_adam_step.argtypes = [P, c_float, c_float, c_float, c_float, c_int64, P]
     _lib = lib
     return lib
 

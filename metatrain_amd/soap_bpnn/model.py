@@ -97,3 +97,88 @@ class SoapBpnnHip:
         check(self.lib.soap_backward(self._handle, g.handle, rt._ptr(ws), ws.numel(), rt._ptr(ga), rt._ptr(gpos),
                                      rt._ptr(gcell), rt._stream()))
         return (gpos, gcell) if want_cell_grad else gpos
+
+    # ---- training (soap_bpnn/trainer.py:344-391) ---------------------------------------------------------------
+    def sum_over_atoms(self, g: rt.HipGraph, atomic: torch.Tensor) -> torch.Tensor:
+        out = torch.zeros(g.n_systems, dtype=torch.float32, device=atomic.device)
+        check(self.lib.pet_sum_over_atoms(g.handle, rt._ptr(atomic), rt._ptr(out), rt._stream()))
+        return out
+
+    def zero_grad(self) -> None:
+        check(self.lib.soap_model_zero_grad(self._handle, rt._stream()))
+
+    def train_gradients(self, g: rt.HipGraph, grad_atomic: torch.Tensor, u: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ADDS ``d/d theta [sum_i grad_atomic_i e_i + <u, dE/dR>]`` to the gradient slots (``soap_train_gradients``;
+        ``forward(g)`` must have run) and returns the tangent of the atomic energies along ``u`` ``[N]``."""
+        ws = self._workspace(g)
+        n = int(self.lib.soap_train_workspace_bytes(self._handle, g.n_nodes, g.n_edges))
+        if n < 0:
+            raise PetHipError("soap_train_workspace_bytes failed")
+        if getattr(self, "_tws", None) is None or self._tws.numel() < n:
+            self._tws = torch.empty(n, dtype=torch.uint8, device=ws.device)
+        ga = grad_atomic.detach().to(torch.float32).contiguous()
+        uu = None if u is None else u.detach().to(torch.float32).contiguous()
+        tangent = torch.zeros(g.n_nodes, dtype=torch.float32, device=ws.device)
+        check(self.lib.soap_train_gradients(self._handle, g.handle, rt._ptr(ws), ws.numel(), rt._ptr(self._tws),
+                                            self._tws.numel(), rt._ptr(ga), rt._ptr(uu), rt._ptr(tangent), rt._stream()))
+        return tangent
+
+    def _copy_out(self, fn, keys_shapes) -> Dict[str, torch.Tensor]:
+        out = {}
+        for key, shape in keys_shapes:
+            t = torch.empty(shape, dtype=torch.float32, device="cuda")
+            check(fn(self._handle, key.encode(), rt._ptr(t), t.numel(), rt._stream()))
+            out[key] = t
+        return out
+
+    def trainable(self) -> List:
+        """``(key, shape)`` of every trainable parameter (all parameters of a ``legacy = True`` model)."""
+        nn_, nh = self.hypers["bpnn"]["num_neurons_per_layer"], self.hypers["bpnn"]["num_hidden_layers"]
+        size, out = self.feature_size, []
+        for s in range(len(self.atomic_types) if self.legacy else 1):
+            if self.hypers["bpnn"]["layernorm"]:
+                out += [(f"layernorm.{s}.weight", (size,)), (f"layernorm.{s}.bias", (size,))]
+            out += [(f"bpnn.{s}.{2 * k}.weight", (nn_, size if k == 0 else nn_)) for k in range(nh)]
+            out.append((f"last_layers.energy.{s}.weight", (1, nn_)))
+        return out
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        return self._copy_out(self.lib.soap_model_get_grad, self.trainable())
+
+    def params(self) -> Dict[str, torch.Tensor]:
+        return self._copy_out(self.lib.soap_model_get_param, self.trainable())
+
+    def adam_step(self, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+        check(self.lib.soap_adam_step(self._handle, lr, betas[0], betas[1], eps, step, rt._stream()))
+
+
+class SoapTrainStep:
+    """One optimizer step of SOAP-BPNN on one batch, the body of the reference's loop (``soap_bpnn/trainer.py:344-391``):
+    ``zero_grad -> evaluate_model(is_training=True) -> per-atom average -> MSE(E/atom) + MSE(dE/dR) -> backward -> Adam``
+    (lr 1e-3, no gradient clipping, ``soap_bpnn/documentation.py`` TrainerHypers). Descriptor, tail, reverse and
+    second-order passes, weight gradients and Adam run in libpet_hip; torch does the ``[S]`` / ``[N, 3]`` loss arithmetic
+    (shared with the PET step, ``metatrain_amd/pet/trainer.py``) and, for N > 1 ranks, the gradient all-reduce."""
+
+    def __init__(self, model: SoapBpnnHip, learning_rate: float = 1e-3, loss_weights: Optional[dict] = None):
+        self.model, self.lr = model, learning_rate
+        self.weights = {"energy": 1.0, "forces": 1.0, **(loss_weights or {})}
+        self.step_index = 0
+
+    def __call__(self, g: rt.HipGraph, target_energies: torch.Tensor, n_atoms: torch.Tensor,
+                 target_gradients: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        from ..pet.trainer import energy_loss_and_seeds, force_loss_and_seeds
+
+        m = self.model
+        m.zero_grad()
+        atomic = m.forward(g)
+        energies = m.sum_over_atoms(g, atomic)
+        loss, seeds = energy_loss_and_seeds(energies, target_energies, n_atoms, g.system_of_atom(), self.weights["energy"])
+        u = None
+        if target_gradients is not None:
+            grad_positions = m.backward(g, torch.ones_like(atomic))   # evaluate_model: autograd.grad(E.sum(), R, create_graph)
+            loss_f, u = force_loss_and_seeds(grad_positions, target_gradients, self.weights["forces"])
+            loss = loss + loss_f
+        tangent = m.train_gradients(g, seeds, u)
+        self.step_index += 1
+        m.adam_step(self.lr, self.step_index)
+        return {"loss": loss, "energies": energies, "tangent_atomic": tangent}

@@ -1,0 +1,196 @@
+"""GPU tests of BASELINE config 1's architecture beyond inference: SOAP-BPNN on the first frames of the reference's own
+ethanol data set (``tests/resources/ethanol_reduced_100.xyz`` -> ``tests/golden/ethanol_first10.npz``, a data fixture)
+and the SOAP-BPNN TRAINING step (``soap_bpnn/trainer.py:344-391``: MSE(E/atom) + MSE(dE/dR), ``loss.backward()`` = a
+double backward through the descriptor, Adam lr 1e-3 without clipping) -- every parameter gradient against the
+oracle's autograd in fp64, through the C ABI (``soap_train_gradients`` / ``soap_adam_step``)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nl as onl
+from oracle import pet as opet
+from oracle import soap as osoap
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _ethanol(n_frames=10):
+    d = np.load(os.path.join(GOLD, "ethanol_first10.npz"))
+    pos_l, z_l, i_l, j_l, sys_l, off = [], [], [], [], [], 0
+    for k in range(n_frames):
+        xyz = d["positions"][k]
+        i, j, s, _ = onl.neighbor_list(xyz, np.zeros((3, 3)), [False] * 3, 5.0)
+        pos_l.append(torch.tensor(xyz)); z_l.append(torch.tensor(d["species"][k]))
+        i_l.append(torch.tensor(i) + off); j_l.append(torch.tensor(j) + off)
+        sys_l.append(torch.full((len(xyz),), k, dtype=torch.long))
+        off += len(xyz)
+    pos, z = torch.cat(pos_l), torch.cat(z_l)
+    ci, cj = torch.cat(i_l), torch.cat(j_l)
+    cells = torch.zeros((n_frames, 3, 3), dtype=torch.float64)
+    e = torch.tensor(d["energies"][:n_frames])
+    targets_e = e - e.mean()                       # what the composition baseline leaves for the network
+    targets_g = -torch.tensor(d["forces"][:n_frames]).reshape(-1, 3)   # datasets store -forces as the position gradient
+    return pos, z, cells, ci, cj, torch.zeros((len(ci), 3), dtype=torch.long), torch.cat(sys_l), targets_e, targets_g
+
+
+def _random_batch(n_atoms=(150, 90), seed=3):
+    pos_l, z_l, cell_l, i_l, j_l, s_l, sys_l, off = [], [], [], [], [], [], [], 0
+    for k, n in enumerate(n_atoms):
+        pos, z, cell = opet.random_box(n, seed=seed + k, dtype=torch.float64)
+        i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, 5.0)
+        pos_l.append(pos); z_l.append(z); cell_l.append(cell)
+        i_l.append(torch.tensor(i) + off); j_l.append(torch.tensor(j) + off); s_l.append(torch.tensor(s).long())
+        sys_l.append(torch.full((n,), k, dtype=torch.long))
+        off += n
+    gen = torch.Generator().manual_seed(seed)
+    n_tot = sum(n_atoms)
+    te = torch.randn(len(n_atoms), generator=gen, dtype=torch.float64) * 3
+    tg = torch.randn(n_tot, 3, generator=gen, dtype=torch.float64) * 0.3
+    return (torch.cat(pos_l), torch.cat(z_l), torch.stack(cell_l), torch.cat(i_l), torch.cat(j_l), torch.cat(s_l),
+            torch.cat(sys_l), te, tg)
+
+
+def _oracle_loss_and_grads(params64, hypers, types, batch, with_forces=True):
+    """The reference's step in torch autograd, fp64: E, dE/dR with create_graph, MSE(E/atom) + MSE(dE/dR), backward."""
+    pos, z, cells, ci, cj, cs, sysidx, te, tg = batch
+    p = {k: v.clone().requires_grad_(True) for k, v in params64.items()}
+    r = pos.clone().requires_grad_(True)
+    atomic = osoap.soap_bpnn_atomic_energies(p, hypers, types, r, cells, ci, cj, cs, z, sysidx)
+    n_sys = cells.shape[0]
+    energies = torch.zeros(n_sys, dtype=torch.float64).index_add(0, sysidx, atomic)
+    n_atoms = torch.bincount(sysidx, minlength=n_sys).double()
+    loss = (((energies - te) / n_atoms) ** 2).mean()
+    g = None
+    if with_forces:
+        (g,) = torch.autograd.grad(energies.sum(), r, create_graph=True)
+        loss = loss + ((g - tg) ** 2).mean()
+    loss.backward()
+    return float(loss.detach()), {k: v.grad for k, v in p.items()}, energies.detach(), None if g is None else g.detach()
+
+
+def _model(dev, types, hypers, params):
+    from metatrain_amd.soap_bpnn import SoapBpnnHip
+
+    m = SoapBpnnHip(hypers, types)
+    m.load({k: v.to(dev) for k, v in params.items()})
+    return m
+
+
+def _graph(m, dev, batch):
+    pos, z, cells, ci, cj, cs, sysidx = batch[:7]
+    return m.graph(pos.float().to(dev), cells.float().to(dev), ci.to(dev), cj.to(dev), cs.to(dev), z.to(dev),
+                   sysidx.int().to(dev))
+
+
+def test_ethanol_frames_energy_and_forces():
+    """BASELINE config 1's data: ten 9-atom ethanol molecules (open boundaries, three atomic types -> the
+    three-channel Orthogonal species basis), default SOAP-BPNN hypers, per-structure energies and dE/dR."""
+    dev = torch.device("cuda:0")
+    types, hypers = [1, 6, 8], dict(osoap.DEFAULT_HYPERS)
+    n_per_l = osoap.basis(hypers)[0]
+    params = osoap.synthetic_params(hypers, 3, n_per_l, 0, torch.float32)
+    batch = _ethanol()
+    pos, z, cells, ci, cj, cs, sysidx = batch[:7]
+    e_ref, g_ref, a_ref = osoap.energy_and_gradient({k: v.double() for k, v in params.items()}, hypers, types, pos, cells,
+                                                    ci, cj, cs, z, sysidx)
+    m = _model(dev, types, hypers, params)
+    g = _graph(m, dev, batch)
+    atomic = m.forward(g)
+    grad = m.backward(g, torch.ones_like(atomic))
+    energies = m.sum_over_atoms(g, atomic)
+    assert _relmax(atomic.cpu().numpy(), a_ref.numpy()) < TOL
+    assert _relmax(energies.cpu().numpy(), e_ref.numpy()) < TOL
+    assert _relmax(grad.cpu().numpy(), g_ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("case", ["ethanol", "boxes", "boxes_no_layernorm", "boxes_one_hidden_layer", "energy_only"])
+def test_training_gradients_against_the_oracles_double_backward(case):
+    dev = torch.device("cuda:0")
+    hypers = dict(osoap.DEFAULT_HYPERS)
+    if case == "boxes_no_layernorm":
+        hypers["bpnn"] = dict(hypers["bpnn"], layernorm=False)
+    if case == "boxes_one_hidden_layer":
+        hypers["bpnn"] = dict(hypers["bpnn"], num_hidden_layers=1)
+    types = [1, 6, 8] if case == "ethanol" else [1, 6, 7, 8]
+    batch = _ethanol() if case == "ethanol" else _random_batch()
+    with_forces = case != "energy_only"
+    n_per_l = osoap.basis(hypers)[0]
+    params = osoap.synthetic_params(hypers, len(types), n_per_l, 1, torch.float32)
+    loss_ref, g_ref, e_ref, gr_ref = _oracle_loss_and_grads({k: v.double() for k, v in params.items()}, hypers, types,
+                                                            batch, with_forces)
+    m = _model(dev, types, hypers, params)
+    g = _graph(m, dev, batch)
+    from metatrain_amd.pet.trainer import energy_loss_and_seeds, force_loss_and_seeds
+
+    te, tg = batch[7].float().to(dev), batch[8].float().to(dev)
+    n_atoms = torch.bincount(batch[6], minlength=len(te)).float().to(dev)
+    m.zero_grad()
+    atomic = m.forward(g)
+    energies = m.sum_over_atoms(g, atomic)
+    loss, seeds = energy_loss_and_seeds(energies, te, n_atoms, g.system_of_atom())
+    u = None
+    if with_forces:
+        grad_pos = m.backward(g, torch.ones_like(atomic))
+        assert _relmax(grad_pos.cpu().numpy(), gr_ref.numpy()) < TOL
+        loss_f, u = force_loss_and_seeds(grad_pos, tg)
+        loss = loss + loss_f
+    tangent = m.train_gradients(g, seeds, u)
+    assert abs(float(loss) - loss_ref) < 2e-5 * abs(loss_ref)
+    if with_forces:   # the tangent sweep's self-check: sum_i e'_i = <u, dE/dR>
+        lhs, rhs = float(tangent.double().sum()), float((u.double() * grad_pos.double()).sum())
+        assert abs(lhs - rhs) < 2e-5 * max(abs(rhs), float((u.double().abs() * grad_pos.double().abs()).sum()) * 1e-2)
+    got = m.grads()
+    assert set(got) == set(g_ref), (sorted(got), sorted(g_ref))
+    worst = {}
+    for key, ref in g_ref.items():
+        err = _relmax(got[key].cpu().numpy().reshape(ref.shape), ref.numpy())
+        worst[key] = err
+    bad = {k: v for k, v in worst.items() if not v < 2e-5}
+    print(case, "worst parameter-gradient error", max(worst.values()))
+    assert not bad, bad
+
+
+def test_three_adam_steps_follow_torch():
+    """``SoapTrainStep`` (zero_grad, forward, dE/dR, losses, gradients, Adam lr 1e-3) against the same three steps of
+    torch.optim.Adam on the oracle: losses and every parameter after the third step."""
+    from metatrain_amd.soap_bpnn import SoapTrainStep
+
+    dev = torch.device("cuda:0")
+    types, hypers = [1, 6, 8], dict(osoap.DEFAULT_HYPERS)
+    n_per_l = osoap.basis(hypers)[0]
+    params = osoap.synthetic_params(hypers, 3, n_per_l, 2, torch.float32)
+    batch = _ethanol(6)
+    pos, z, cells, ci, cj, cs, sysidx, te, tg = batch
+    p = {k: v.double().clone().requires_grad_(True) for k, v in params.items()}
+    opt = torch.optim.Adam(list(p.values()), lr=1e-3)
+    n_atoms64 = torch.bincount(sysidx, minlength=len(te)).double()
+    ref_losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        r = pos.clone().requires_grad_(True)
+        atomic = osoap.soap_bpnn_atomic_energies(p, hypers, types, r, cells, ci, cj, cs, z, sysidx)
+        energies = torch.zeros(len(te), dtype=torch.float64).index_add(0, sysidx, atomic)
+        (gr,) = torch.autograd.grad(energies.sum(), r, create_graph=True)
+        loss = (((energies - te) / n_atoms64) ** 2).mean() + ((gr - tg) ** 2).mean()
+        loss.backward()
+        opt.step()
+        ref_losses.append(float(loss.detach()))
+    m = _model(dev, types, hypers, params)
+    g = _graph(m, dev, batch)
+    step = SoapTrainStep(m)
+    losses = [float(step(g, te.float().to(dev), n_atoms64.float().to(dev), tg.float().to(dev))["loss"]) for _ in range(3)]
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    assert losses[2] < losses[0]
+    after = m.params()
+    for key, ref in p.items():
+        # three Adam steps move every entry by at most 3e-3; agreement to a small fraction of that
+        assert float((after[key].cpu().double().reshape(ref.shape) - ref.detach()).abs().max()) < 3e-5, key
