@@ -191,6 +191,13 @@ int pet_graph_set_conditioning(pet_graph_t* g, const int64_t* d_charge, const in
 /* ---- features + predict + gradient -------------------------------------------- */
 /* Activation workspace for one forward (+ saved tensors for the backward). */
 int64_t pet_forward_workspace_bytes(const pet_model_t* m, int64_t n_nodes, int64_t n_edges);
+/* The same for a built graph. The tuned kernels are one compiled model size (d_pet=128, d_node=256, d_feedforward=256,
+ * d_head=128, num_heads=8) with at most 127 neighbours per atom; every other model size (the reference is size-generic,
+ * pet/documentation.py:196-213; d_node == d_pet follows transformer.py:189-201) AND any graph with a denser atom (the
+ * reference pads to any max(num_neighbors), pet/modules/structures.py:292-294) runs on a size-generic path with its own,
+ * larger workspace layout. pet_forward_workspace_bytes answers for the model alone; a caller that may meet dense graphs
+ * sizes the workspace with this function. Inference + dE/dR only on that path (training entry points refuse it). */
+int64_t pet_forward_workspace_bytes_for(const pet_model_t* m, const pet_graph_t* g);
 /* calculate_features + predict for the fused target (the heads uploaded under the name "@", one property):
  *   d_atomic [N]       per-atom prediction (node + sum of cutoff-weighted edge terms); NULL = features only
  *   d_node_features [N,d_node] / d_edge_features [E,d_pet] (CSR rows): optional copies

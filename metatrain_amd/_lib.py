@@ -30,7 +30,7 @@ SYMBOLS = [
     "pet_graph_max_neighbors", "pet_graph_export_batch", "pet_graph_csr",
     "pet_graph_from_batch_workspace_bytes", "pet_graph_from_batch", "pet_model_block_properties",
     "pet_predict_scratch_floats", "pet_predict", "pet_predict_backward", "pet_geometry_backward",
-    "pet_forward_workspace_bytes", "pet_forward", "pet_aux_outputs", "pet_backward", "pet_backward_predict",
+    "pet_forward_workspace_bytes", "pet_forward_workspace_bytes_for", "pet_forward", "pet_aux_outputs", "pet_backward", "pet_backward_predict",
     "pet_backward_features", "pet_backward_geometry",
     "pet_model_num_readout_layers", "pet_forward_layers", "pet_backward_features_layers", "pet_graph_set_conditioning",
     "pet_model_zero_grad", "pet_model_get_grad", "pet_train_workspace_bytes", "pet_backward_train",
@@ -158,6 +158,8 @@ def load() -> ctypes.CDLL:
     lib.pet_geometry_backward.argtypes = [P, P, P, P, P, P, P, P]
     lib.pet_forward_workspace_bytes.argtypes = [P, c_int64, c_int64]
     lib.pet_forward_workspace_bytes.restype = c_int64
+    lib.pet_forward_workspace_bytes_for.argtypes = [P, P]
+    lib.pet_forward_workspace_bytes_for.restype = c_int64
     lib.pet_forward.argtypes = [P, P, P, c_int64, c_int, P, P, P, P]
     lib.pet_aux_outputs.argtypes = [P, P, P, P, P, P, P, P]
     lib.pet_backward.argtypes = [P, P, P, c_int64, P, P, P, P]

@@ -141,11 +141,12 @@ static int named_alloc(Model& m, const std::string& name, void** p, size_t bytes
 // leading dimension ld
 static int pack_lin(Model& m, const std::string& name, Lin& L, const float* w, const float* b, int n_out,
                     int k_in, int ld, int col0, hipStream_t st) {
-    PET_REQUIRE(n_out % 32 == 0 && k_in % 32 == 0, PET_ERR_UNSUPPORTED, "linear shape not tileable");
     L.w = w + col0;
     L.b = b;
     L.n_out = n_out;
     L.k_in = k_in;
+    if (m.generic()) return PET_OK;  // gen.hip reads the raw torch layout; no MFMA fragment forms
+    PET_REQUIRE(n_out % 32 == 0 && k_in % 32 == 0, PET_ERR_UNSUPPORTED, "linear shape not tileable");
     size_t n4 = (size_t)(n_out / 32) * (k_in / 8) * 64;
     int rc;
     if ((rc = named_alloc(m, name + ":fwd", (void**)&L.fwd, n4 * sizeof(float4))) != PET_OK) return rc;
@@ -208,6 +209,9 @@ int finalize(Model& m, hipStream_t st) {
     const pet_hypers_t& h = m.h;
     const int ns = h.n_species;
     int rc;
+    // the model's own sizes (they shadow the compiled instantiation's constants, which only the tuned kernels use)
+    const int D = h.d_pet, DN = h.d_node, DFF = h.d_feedforward, DNF = 2 * h.d_node, DH = h.d_head;
+    const bool generic = m.generic(), expanded = DN != D;
     m.gnn.clear();
     m.gnn.resize(h.num_gnn_layers);
     for (int g = 0; g < h.num_gnn_layers; g++) {
@@ -223,14 +227,15 @@ int finalize(Model& m, hipStream_t st) {
             if ((rc = get(m, lp + ".norm_mlp.weight", D, &A.g_mlp))) return rc;
             if ((rc = get_lin(m, lp + ".mlp.w_in", 2 * DFF, D, A.mlp_in, st))) return rc;
             if ((rc = get_lin(m, lp + ".mlp.w_out", D, DFF, A.mlp_out, st))) return rc;
-            if ((rc = get_lin(m, lp + ".center_contraction", D, DN, A.cc, st))) return rc;
-            if ((rc = get_lin(m, lp + ".center_expansion", DN, D, A.ce, st))) return rc;
-            if ((rc = get(m, lp + ".norm_center_features.weight", DN, &A.g_center))) return rc;
             if (m.layer_norm()) {  // torch.nn.LayerNorm: weight + bias (transformer.py:170-176)
                 if ((rc = get(m, lp + ".norm_attention.bias", D, &A.b_attn))) return rc;
                 if ((rc = get(m, lp + ".norm_mlp.bias", D, &A.b_mlp))) return rc;
-                if ((rc = get(m, lp + ".norm_center_features.bias", DN, &A.b_center))) return rc;
             }
+            if (!expanded) continue;  // d_node == d_pet: Identity modules, no parameters (transformer.py:196-201)
+            if ((rc = get_lin(m, lp + ".center_contraction", D, DN, A.cc, st))) return rc;
+            if ((rc = get_lin(m, lp + ".center_expansion", DN, D, A.ce, st))) return rc;
+            if ((rc = get(m, lp + ".norm_center_features.weight", DN, &A.g_center))) return rc;
+            if (m.layer_norm() && (rc = get(m, lp + ".norm_center_features.bias", DN, &A.b_center))) return rc;
             if ((rc = get_lin(m, lp + ".center_mlp.w_in", 2 * DNF, DN, A.cmlp_in, st))) return rc;
             if ((rc = get_lin(m, lp + ".center_mlp.w_out", DN, DNF, A.cmlp_out, st))) return rc;
         }
@@ -249,6 +254,19 @@ int finalize(Model& m, hipStream_t st) {
             if ((rc = get(m, "edge_embedder.weight", (int64_t)ns * D, &emb))) return rc;
         } else {
             if ((rc = get(m, pre + ".neighbor_embedder.weight", (int64_t)ns * D, &emb))) return rc;
+        }
+        G.eemb.w = wee; G.eemb.b = bee; G.eemb.n_out = D; G.eemb.k_in = 4;
+        G.c0.w = w0; G.c0.b = b0; G.c0.n_out = D; G.c0.k_in = kin;
+        G.nbr_emb = g == 0 ? nullptr : emb;
+        if (generic) {   // no folded / packed forms: gen.hip evaluates edge_embedder and compress.0 as uploaded
+            if ((rc = get_lin(m, pre + ".compress.2", D, D, G.compress2, st))) return rc;
+            if (m.residual()) continue;
+            const std::string gs_ = std::to_string(g);
+            if ((rc = get(m, "combination_norms." + gs_ + ".weight", 2 * D, &G.ln_g))) return rc;
+            if ((rc = get(m, "combination_norms." + gs_ + ".bias", 2 * D, &G.ln_b))) return rc;
+            if ((rc = get_lin(m, "combination_mlps." + gs_ + ".0", 2 * D, 2 * D, G.comb0, st))) return rc;
+            if ((rc = get_lin(m, "combination_mlps." + gs_ + ".2", D, 2 * D, G.comb2, st))) return rc;
+            continue;
         }
         if ((rc = named_alloc(m, pre + ":wc", (void**)&G.wc, D * 4 * sizeof(float)))) return rc;
         if ((rc = named_alloc(m, pre + ":wct", (void**)&G.wct, 4 * D * sizeof(float)))) return rc;
@@ -362,17 +380,19 @@ extern "C" {
 const char* pet_last_error(void) { return g_error.c_str(); }
 const char* pet_version(void) { return "pet_hip 0.1 (gfx950, fp32 MFMA)"; }
 
+// any size is served: the compiled instantiation (d_pet=128, d_node=256, d_feedforward=256, d_head=128, num_heads=8) by the
+// tuned kernels, everything else by the size-generic path (gen.hip; head dimension up to 128)
 int pet_hypers_supported(const pet_hypers_t* h) {
-    return h && h->d_pet == D && h->d_node == DN && h->d_feedforward == DFF && h->d_head == DH &&
-           h->num_heads == NHEAD && h->num_gnn_layers >= 1 && h->num_attention_layers >= 1 &&
-           h->n_species >= 1 && h->n_species <= MAX_SPECIES;
+    return h && h->d_pet >= 1 && h->d_node >= 1 && h->d_feedforward >= 1 && h->d_head >= 1 && h->num_heads >= 1 &&
+           h->d_pet % h->num_heads == 0 && h->d_pet / h->num_heads <= 128 && h->num_gnn_layers >= 1 &&
+           h->num_attention_layers >= 1 && h->n_species >= 1 && h->n_species <= MAX_SPECIES;
 }
 
 int pet_model_create(const pet_hypers_t* h, pet_model_t** out) {
     PET_REQUIRE(h && out, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(pet_hypers_supported(h), PET_ERR_UNSUPPORTED,
-                "hypers outside the compiled instantiation (d_pet=128, d_node=256, d_feedforward=256, "
-                "d_head=128, num_heads=8)");
+                "unsupported sizes: d_pet must be a multiple of num_heads with a head dimension of at most 128, at most "
+                "128 species");
     PET_REQUIRE(h->cutoff_function == PET_CUTOFF_BUMP || h->cutoff_function == PET_CUTOFF_COSINE,
                 PET_ERR_UNSUPPORTED, "unknown cutoff function");
     PET_REQUIRE((h->normalization == PET_NORM_RMS || h->normalization == PET_NORM_LAYER) &&
@@ -626,6 +646,12 @@ int pet_graph_set_conditioning(pet_graph_t* pg, const int64_t* d_charge, const i
 int64_t pet_forward_workspace_bytes(const pet_model_t* pm, int64_t n_nodes, int64_t n_edges) {
     if (!pm) return -1;
     return forward_workspace_bytes(pm->m, n_nodes, n_edges);
+}
+
+int64_t pet_forward_workspace_bytes_for(const pet_model_t* pm, const pet_graph_t* pg) {
+    if (!pm || !pg) return -1;
+    if (use_generic(pm->m, pg->g)) return gen_workspace_bytes(pm->m, pg->g.n_nodes, pg->g.n_edges);
+    return forward_workspace_bytes(pm->m, pg->g.n_nodes, pg->g.n_edges, false);
 }
 
 int pet_forward(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,

@@ -48,6 +48,9 @@ struct GnnLayerW {
     float* tbl = nullptr;  // [n_species, D] species part of compress.0 (+ all biases)
     Lin comb0, comb2;
     const float *ln_g = nullptr, *ln_b = nullptr;
+    // raw forms for the size-generic path (gen.hip): edge_embedder (4 -> d_pet), compress.0 as uploaded, neighbor_embedder
+    Lin eemb, c0;
+    const float* nbr_emb = nullptr;
 };
 
 // Heads of one (target, readout layer): node_heads.<t>.<l>.{0,2}, edge_heads.<t>.<l>.{0,2} (backend.py:171-217);
@@ -60,8 +63,14 @@ struct LastW {
     int P = 0;
 };
 
+// the tuned kernels are ONE instantiation; every other size runs on the generic path (gen.hip)
+inline bool compiled_size(const pet_hypers_t& h) {
+    return h.d_pet == D && h.d_node == DN && h.d_feedforward == DFF && h.d_head == DH && h.num_heads == NHEAD;
+}
+
 struct Model {
     pet_hypers_t h;
+    bool generic() const { return !compiled_size(h); }
     std::map<std::string, std::pair<float*, int64_t>> raw;  // device copies
     int* species_table = nullptr;
     int species_table_len = 0;
@@ -146,6 +155,33 @@ int nl_build_batch(const float* d_pos, const float* h_cells, const int* h_pbc, c
 int nl_build(const float* d_pos, const float* h_cell, const int* h_pbc, int64_t n, float cutoff,
              void* ws, int* d_pairs, float* d_vectors, int64_t capacity, int64_t* n_pairs,
              hipStream_t st);
+
+// A graph with an atom of more than 127 neighbours (attention tiles of 16 tokens, at most 8 per atom in the tuned kernels)
+// runs on the size-generic path too, whatever the model size: its attention walks keys one by one, without a tile limit.
+bool use_generic(const Model& m, const Graph& g);  // pet_fwd.hip
+
+// gen.hip: the size-generic path (any d_pet / d_node / d_feedforward / d_head / num_heads; inference + dE/dR)
+int64_t gen_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges);
+int gen_forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
+                       float* const* node_feats, float* const* edge_feats, int n_layers, hipStream_t st);
+int gen_backward_features(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* const* g_node,
+                          const float* const* g_edge, int n_layers, float* g_geo, float* g_fc, hipStream_t st);
+int gen_backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA, float* gpos, float* gcell,
+                 hipStream_t st);
+int gen_predict(const Model& m, const Graph& g, const HeadW& H, const LastW& Lw, const float* node_feat,
+                const float* edge_feat, const float* fc, float* atomic, float* node_hidden, float* edge_hidden,
+                hipStream_t st);
+int gen_predict_backward(const Model& m, const Graph& g, const HeadW& H, const LastW& Lw, const float* node_feat,
+                         const float* edge_feat, const float* fc, const float* gA, float* g_node, float* g_edge, float* g_fc,
+                         hipStream_t st);
+int gen_aux_outputs(const Model& m, const Graph& g, const float* node_feat, const float* edge_feat, float* feature,
+                    float* last_layer, float* scratch, hipStream_t st);
+int gen_backward_predict(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA, float* g_node,
+                         float* g_edge, float* g_fc, hipStream_t st);
+int gen_backward_geometry(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_geo, const float* g_fc,
+                          float* gpos, float* gcell, hipStream_t st);
+int backward_geometry_generic(const Model& m, const Graph& g, float* dv_scratch, const float* dgeo, const float* dfc_a,
+                              const float* dfc_b, float* gpos, float* gcell, hipStream_t st);
 
 // pet_fwd.hip / pet_bwd.hip
 int64_t forward_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges, bool train = false);

@@ -1399,6 +1399,7 @@ __global__ void k_last_bwd(const float* __restrict__ gA, const float* __restrict
 int predict_backward(const Model& m, const Graph& g, const HeadW& H, const LastW& Lw, const float* node_feat,
                      const float* edge_feat, const float* fc, const float* gA, float* g_node, float* g_edge, float* g_fc,
                      float* scratch, hipStream_t st) {
+    if (m.generic()) return gen_predict_backward(m, g, H, Lw, node_feat, edge_feat, fc, gA, g_node, g_edge, g_fc, st);
     const int64_t N = g.n_nodes, E = g.n_edges;
     if (N == 0) return PET_OK;
     float* Gn = scratch;
@@ -1433,6 +1434,7 @@ static int d2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
 
 int backward_predict_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA,
                          float* g_node, float* g_edge, float* g_fc, hipStream_t st) {
+    if (use_generic(m, g)) return gen_backward_predict(m, g, ws, ws_bytes, gA, g_node, g_edge, g_fc, st);
     PET_CARVE(w);
     if (g.n_nodes == 0) return PET_OK;
     int rc;
@@ -1445,6 +1447,7 @@ int backward_predict_abi(const Model& m, const Graph& g, void* ws, int64_t ws_by
 
 int backward_features_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_node,
                           const float* g_edge, float* g_geo, float* g_fc, hipStream_t st) {
+    if (use_generic(m, g)) return gen_backward_features(m, g, ws, ws_bytes, &g_node, &g_edge, 1, g_geo, g_fc, st);
     PET_CARVE(w);
     if (g.n_nodes == 0) return PET_OK;
     int rc;
@@ -1458,6 +1461,7 @@ int backward_features_abi(const Model& m, const Graph& g, void* ws, int64_t ws_b
 
 int backward_features_layers_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* const* g_node,
                                  const float* const* g_edge, int n_layers, float* g_geo, float* g_fc, hipStream_t st) {
+    if (use_generic(m, g)) return gen_backward_features(m, g, ws, ws_bytes, g_node, g_edge, n_layers, g_geo, g_fc, st);
     PET_CARVE(w);
     PET_REQUIRE(n_layers == m.num_readout_layers(), PET_ERR_ARGUMENT,
                 "expected one gradient pair per readout layer (" + std::to_string(m.num_readout_layers()) + ")");
@@ -1477,6 +1481,7 @@ int backward_features_layers_abi(const Model& m, const Graph& g, void* ws, int64
 
 int backward_geometry_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_geo,
                           const float* g_fc, float* gpos, float* gcell, hipStream_t st) {
+    if (use_generic(m, g)) return gen_backward_geometry(m, g, ws, ws_bytes, g_geo, g_fc, gpos, gcell, st);
     PET_CARVE(w);
     if (g.n_nodes == 0) return PET_OK;
     return backward_geometry(m, g, w, g_geo, g_fc, nullptr, gpos, gcell, st);
@@ -1491,8 +1496,17 @@ int geometry_backward(const Model& m, const Graph& g, const float* g_geo, const 
     return backward_geometry(m, g, w, g_geo, g_fc, nullptr, gpos, gcell, st);
 }
 
+// shared by the size-generic path (gen.hip): only the d/d(edge vector) buffer is needed
+int backward_geometry_generic(const Model& m, const Graph& g, float* dv_scratch, const float* dgeo, const float* dfc_a,
+                              const float* dfc_b, float* gpos, float* gcell, hipStream_t st) {
+    Workspace w;
+    w.dv = dv_scratch;
+    return backward_geometry(m, g, w, dgeo, dfc_a, dfc_b, gpos, gcell, st);
+}
+
 int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA, float* gpos,
              float* gcell, hipStream_t st) {
+    if (use_generic(m, g)) return gen_backward(m, g, ws, ws_bytes, gA, gpos, gcell, st);
     Workspace w;
     carve_workspace(m, g.n_nodes, g.n_edges, ws, w);
     PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "workspace too small");
@@ -1510,6 +1524,9 @@ int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const f
 // Needs a forward run with save_for_backward = 2 on a training workspace.
 int backward_train(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA, float* gpos,
                    float* gcell, hipStream_t st) {
+    PET_REQUIRE(!use_generic(m, g), PET_ERR_UNSUPPORTED,
+                "training is built for the compiled model size (d_pet=128, d_node=256, d_feedforward=256, d_head=128, "
+                "num_heads=8) and at most 127 neighbours per atom");
     PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
     Workspace w;
     carve_workspace(m, g.n_nodes, g.n_edges, ws, w, true);

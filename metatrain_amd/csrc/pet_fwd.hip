@@ -769,6 +769,7 @@ __global__ void k_copy_rows(const float* __restrict__ X, int w, float* __restric
 // host driver
 // ---------------------------------------------------------------------------------
 int64_t forward_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges, bool train) {
+    if (m.generic()) return gen_workspace_bytes(m, n_nodes, n_edges);  // any other size: gen.hip
     Workspace w;
     carve_workspace(m, n_nodes, n_edges, nullptr, w, train);
     return (int64_t)w.bytes;
@@ -781,6 +782,7 @@ static void launch_attn_fwd(const float* QKV, const Graph& g, float* AO, float s
 }
 
 int attn_tiles(const Graph& g) { return (g.max_nbr + 1 + 15) / 16; }
+bool use_generic(const Model& m, const Graph& g) { return m.generic() || attn_tiles(g) > 8; }
 
 static int g_node_planes = 1;  // k_node2 / k_node_bwd2: A tiles pre-split into fp16 planes (pet_config_set("node_planes", 0): k_node)
 void set_node_planes(int v) { g_node_planes = v; }
@@ -815,6 +817,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
 // node_feats / edge_feats: n_layers = num_readout_layers() output pointers each (entries may be null)
 int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
                    float* const* node_feats, float* const* edge_feats, int n_layers, hipStream_t st) {
+    if (use_generic(m, g)) return gen_forward_layers(m, g, ws, ws_bytes, save, atomic, node_feats, edge_feats, n_layers, st);
     Workspace w;
     carve_workspace(m, g.n_nodes, g.n_edges, ws, w, save == 2);
     PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "forward workspace too small");
@@ -829,8 +832,6 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
     const int64_t N = g.n_nodes, E = g.n_edges, R = E + N;
     if (N == 0) return PET_OK;
     const int nt = attn_tiles(g);
-    PET_REQUIRE(nt <= 8, PET_ERR_UNSUPPORTED,
-                "more than 127 neighbours per atom (" + std::to_string(g.max_nbr) + ") is not supported yet");
     const float scale = 1.0f / (sqrtf((float)HD) * m.h.attention_temperature);
     const int gE = cdiv(E, BM), gN = cdiv(N, BM), gR = cdiv(R, BM);
     const size_t lds1 = BM * LD128 * 4, lds2 = 2 * BM * LD128 * 4;
@@ -1012,6 +1013,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
 // scratch: E DH + max(E, N) floats, needed for last_layer
 int aux_outputs(const Model& m, const Graph& g, const float* node_feat, const float* edge_feat, float* feature,
                 float* last_layer, float* scratch, hipStream_t st) {
+    if (m.generic()) return gen_aux_outputs(m, g, node_feat, edge_feat, feature, last_layer, scratch, st);
     const int64_t N = g.n_nodes, E = g.n_edges;
     if (N == 0) return PET_OK;
     const int gN = (int)cdiv(N, BM), gE = (int)cdiv(E, BM);
@@ -1078,6 +1080,7 @@ int64_t predict_scratch_floats(int64_t N, int64_t E) {
 
 int predict(const Model& m, const Graph& g, const HeadW& H, const LastW& Lw, const float* node_feat, const float* edge_feat,
             const float* fc, float* atomic, float* node_hidden, float* edge_hidden, float* scratch, hipStream_t st) {
+    if (m.generic()) return gen_predict(m, g, H, Lw, node_feat, edge_feat, fc, atomic, node_hidden, edge_hidden, st);
     const int64_t N = g.n_nodes, E = g.n_edges;
     if (N == 0) return PET_OK;
     const int64_t Ea = E > 0 ? E : 1;

@@ -1154,6 +1154,9 @@ static void head_reverse(const Ctx& c, Trainer& tr, SoWs& s, bool edge, const Li
 int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, void* ws2, int64_t ws2_bytes,
                     const float* lA, const float* nA, const float* u, float* tangent_atomic, hipStream_t st,
                     const float* ucell) {
+    PET_REQUIRE(!use_generic(m, g), PET_ERR_UNSUPPORTED,
+                "training is built for the compiled model size (d_pet=128, d_node=256, d_feedforward=256, d_head=128, "
+                "num_heads=8) and at most 127 neighbours per atom");
     PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
     PET_REQUIRE(m.trainable(), PET_ERR_UNSUPPORTED,
                 "training is built for transformer_type=PreLN, featurizer_type=feedforward only");

@@ -121,7 +121,7 @@ struct EnergyFn : torch::autograd::Function<EnergyFn> {
                               gh->keep_alive[6].data_ptr<int32_t>(), gh->n_nodes, e0, gh->n_systems,
                               gh->graph_ws.data_ptr(), gh->graph_ws.numel(), &gh->g, st),
               "pet_graph_build");
-        gh->fwd_ws = at::empty({pet_forward_workspace_bytes(mod->model, gh->n_nodes, pet_graph_num_edges(gh->g))}, bytes);
+        gh->fwd_ws = at::empty({pet_forward_workspace_bytes_for(mod->model, gh->g)}, bytes);
         at::Tensor atomic = at::empty({gh->n_nodes}, positions.options().dtype(at::kFloat));
         check(pet_forward(mod->model, gh->g, gh->fwd_ws.data_ptr(), gh->fwd_ws.numel(), 1, atomic.data_ptr<float>(),
                           nullptr, nullptr, st),
@@ -416,7 +416,7 @@ struct FeaturesFn : torch::autograd::Function<FeaturesFn> {
         const pet_hypers_t h = be->hypers_struct();
         auto dev = mask.device();
         auto bytes = at::TensorOptions().dtype(at::kByte).device(dev), f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
-        bg->fwd_ws = at::empty({pet_forward_workspace_bytes(be->model, n, e)}, bytes);
+        bg->fwd_ws = at::empty({pet_forward_workspace_bytes_for(be->model, bg->g)}, bytes);
         // backend.py:344-418 returns two lists, one entry per readout layer: here [node_0 .. node_{L-1}, edge_0 .. edge_{L-1}]
         const int64_t L = pet_model_num_readout_layers(be->model);
         std::vector<at::Tensor> nf, ef;

@@ -118,10 +118,33 @@ class _TransformerLayer(torch.nn.Module):
         return out
 
 
+class _TransformerLayerFlat(torch.nn.Module):
+    """``d_node == d_pet`` (transformer.py:189-201): centre contraction / expansion / norm / MLP are ``Identity`` in the
+    reference -- no parameters, no state-dict keys; the node features leaving the layer are the centre token."""
+
+    def __init__(self, d: int, dff: int, activation: str, norm: str):
+        super().__init__()
+        self.attention = _Attention(d)
+        self.norm_attention = _norm(norm, d)
+        self.norm_mlp = _norm(norm, d)
+        self.mlp = _FeedForward(d, dff, activation)
+
+    @torch.jit.export
+    def params(self) -> List[torch.Tensor]:
+        out = self.attention.params()
+        out += self.norm_attention.params()
+        out += self.norm_mlp.params()
+        out += self.mlp.params()
+        return out
+
+
 class _Transformer(torch.nn.Module):
     def __init__(self, d: int, dn: int, dff: int, n_layers: int, activation: str, norm: str):
         super().__init__()
-        self.layers = torch.nn.ModuleList([_TransformerLayer(d, dn, dff, activation, norm) for _ in range(n_layers)])
+        if dn != d:
+            self.layers = torch.nn.ModuleList([_TransformerLayer(d, dn, dff, activation, norm) for _ in range(n_layers)])
+        else:
+            self.layers = torch.nn.ModuleList([_TransformerLayerFlat(d, dff, activation, norm) for _ in range(n_layers)])
 
     @torch.jit.export
     def params(self) -> List[torch.Tensor]:

@@ -370,8 +370,10 @@ class HipForward:
         self.model, self.graph = model, graph
         self.lib = model.lib
         self.train = train
-        size_fn = self.lib.pet_train_workspace_bytes if train else self.lib.pet_forward_workspace_bytes
-        nbytes = int(size_fn(model.handle, graph.n_nodes, graph.n_edges))
+        if train:
+            nbytes = int(self.lib.pet_train_workspace_bytes(model.handle, graph.n_nodes, graph.n_edges))
+        else:  # graph-aware: a graph with an atom of more than 127 neighbours runs on the size-generic path
+            nbytes = int(self.lib.pet_forward_workspace_bytes_for(model.handle, graph.handle))
         if nbytes < 0:
             raise PetHipError("pet_forward_workspace_bytes failed")
         self.nbytes = nbytes
@@ -379,8 +381,10 @@ class HipForward:
 
     def rebind(self, graph: "HipGraph") -> "HipForward":
         """Use this object's workspaces for another graph of the same model (micro-batches walk one allocation)."""
-        size_fn = self.lib.pet_train_workspace_bytes if self.train else self.lib.pet_forward_workspace_bytes
-        need = int(size_fn(self.model.handle, graph.n_nodes, graph.n_edges))
+        if self.train:
+            need = int(self.lib.pet_train_workspace_bytes(self.model.handle, graph.n_nodes, graph.n_edges))
+        else:
+            need = int(self.lib.pet_forward_workspace_bytes_for(self.model.handle, graph.handle))
         if need > self.nbytes:
             raise PetHipError(f"workspace of {self.nbytes} bytes is too small for this graph ({need} bytes)")
         self.graph = graph

@@ -51,11 +51,12 @@ def state_dict_schema(hypers: dict, atomic_types: List[int], targets: Dict[str, 
             norm(lp + ".norm_mlp", d)
             lin(lp + ".mlp.w_in", (2 if hypers.get("activation", "SwiGLU") == "SwiGLU" else 1) * dff, d)
             lin(lp + ".mlp.w_out", d, dff)
-            lin(lp + ".center_contraction", d, dn)
-            lin(lp + ".center_expansion", dn, d)
-            norm(lp + ".norm_center_features", dn)
-            lin(lp + ".center_mlp.w_in", (4 if hypers.get("activation", "SwiGLU") == "SwiGLU" else 2) * dn, dn)
-            lin(lp + ".center_mlp.w_out", dn, 2 * dn)
+            if dn != d:  # transformer.py:189-201: d_node == d_pet holds Identity modules (no parameters) instead
+                lin(lp + ".center_contraction", d, dn)
+                lin(lp + ".center_expansion", dn, d)
+                norm(lp + ".norm_center_features", dn)
+                lin(lp + ".center_mlp.w_in", (4 if hypers.get("activation", "SwiGLU") == "SwiGLU" else 2) * dn, dn)
+                lin(lp + ".center_mlp.w_out", dn, 2 * dn)
         lin(f"gnn_layers.{g}.edge_embedder", d, 4)
         lin(f"gnn_layers.{g}.compress.0", d, (2 if g == 0 else 3) * d)
         lin(f"gnn_layers.{g}.compress.2", d, d)

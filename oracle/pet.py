@@ -356,7 +356,8 @@ def pet_atomic_energies(
         )
         for a in range(hypers["num_attention_layers"]):
             lp = f"{pre}.trans.layers.{a}"
-            c = _linear(h, p, lp + ".center_contraction")
+            expanded = hypers["d_node"] != d_pet  # transformer.py:189-201
+            c = _linear(h, p, lp + ".center_contraction") if expanded else h
 
             def attention(tn, te):
                 qkv_n = _linear(tn, p, lp + ".attention.input_linear")
@@ -374,8 +375,11 @@ def pet_atomic_energies(
                 on = tn
             else:        # transformer.py:203-234
                 on, oe = attention(_norm(c, p, lp + ".norm_attention"), _norm(e, p, lp + ".norm_attention"))
-            h = h + _linear(on, p, lp + ".center_expansion")
-            h = h + _swiglu_ff(_norm(h, p, lp + ".norm_center_features"), p, lp + ".center_mlp")
+            if expanded:
+                h = h + _linear(on, p, lp + ".center_expansion")
+                h = h + _swiglu_ff(_norm(h, p, lp + ".norm_center_features"), p, lp + ".center_mlp")
+            else:  # the node features leaving the layer ARE the centre token (transformer.py:221-227 skipped)
+                h = on
             if not post_ln:
                 e = e + oe
                 e = e + _swiglu_ff(_norm(e, p, lp + ".norm_mlp"), p, lp + ".mlp")
@@ -548,11 +552,12 @@ def state_dict_schema(hypers: dict, atomic_types: List[int], targets: Dict[str, 
             norm(lp + ".norm_mlp", d)
             lin(lp + ".mlp.w_in", (2 if hypers["activation"] == "SwiGLU" else 1) * dff, d)
             lin(lp + ".mlp.w_out", d, dff)
-            lin(lp + ".center_contraction", d, dn)
-            lin(lp + ".center_expansion", dn, d)
-            norm(lp + ".norm_center_features", dn)
-            lin(lp + ".center_mlp.w_in", (4 if hypers["activation"] == "SwiGLU" else 2) * dn, dn)
-            lin(lp + ".center_mlp.w_out", dn, 2 * dn)
+            if dn != d:  # transformer.py:189-201: d_node == d_pet holds Identity modules (no parameters) instead
+                lin(lp + ".center_contraction", d, dn)
+                lin(lp + ".center_expansion", dn, d)
+                norm(lp + ".norm_center_features", dn)
+                lin(lp + ".center_mlp.w_in", (4 if hypers["activation"] == "SwiGLU" else 2) * dn, dn)
+                lin(lp + ".center_mlp.w_out", dn, 2 * dn)
         lin(f"gnn_layers.{g}.edge_embedder", d, 4)
         lin(f"gnn_layers.{g}.compress.0", d, (2 if g == 0 else 3) * d)
         lin(f"gnn_layers.{g}.compress.2", d, d)
@@ -684,11 +689,12 @@ def reference_init_params(
             p[lp + ".norm_mlp.weight"] = torch.ones(d)
             lin(lp + ".mlp.w_in", (2 if hypers["activation"] == "SwiGLU" else 1) * dff, d)
             lin(lp + ".mlp.w_out", d, dff)
-            lin(lp + ".center_contraction", d, dn)
-            lin(lp + ".center_expansion", dn, d)
-            p[lp + ".norm_center_features.weight"] = torch.ones(dn)
-            lin(lp + ".center_mlp.w_in", (4 if hypers["activation"] == "SwiGLU" else 2) * dn, dn)
-            lin(lp + ".center_mlp.w_out", dn, 2 * dn)
+            if dn != d:  # transformer.py:189-201
+                lin(lp + ".center_contraction", d, dn)
+                lin(lp + ".center_expansion", dn, d)
+                p[lp + ".norm_center_features.weight"] = torch.ones(dn)
+                lin(lp + ".center_mlp.w_in", (4 if hypers["activation"] == "SwiGLU" else 2) * dn, dn)
+                lin(lp + ".center_mlp.w_out", dn, 2 * dn)
         lin(f"gnn_layers.{g}.edge_embedder", d, 4)
         lin(f"gnn_layers.{g}.compress.0", d, (2 if g == 0 else 3) * d)
         lin(f"gnn_layers.{g}.compress.2", d, d)

@@ -650,8 +650,61 @@ def main_variants():
         np.savez_compressed(os.path.join(HERE, f"pet_variant_{tag}_box64.npz"), **store)
 
 
+SIZES = {
+    # tag: model sizes that differ from the defaults (pet/documentation.py:196-213); the tuned kernels of the build are ONE
+    # instantiation (128 / 256 / 256 / 128 / 8), every other size runs on its size-generic path
+    "s64": dict(d_pet=64, d_node=128, d_feedforward=128, d_head=64, num_heads=4),
+    "flat32": dict(d_pet=32, d_node=32, d_feedforward=48, d_head=24, num_heads=2),   # d_node == d_pet: transformer.py:189-201
+    "flat32_legacy": dict(d_pet=32, d_node=32, d_feedforward=48, d_head=24, num_heads=2, normalization="LayerNorm",
+                          activation="SiLU", transformer_type="PostLN", featurizer_type="residual"),  # what
+    # pet/checkpoints.py:190-205 upgrades pre-d_node checkpoints to
+    "wide256": dict(d_pet=256, d_node=512, d_feedforward=320, d_head=96, num_heads=4),  # head dimension 64
+    "minimal": dict(d_pet=1, d_node=1, d_feedforward=1, d_head=1, num_heads=1, num_attention_layers=1,
+                    num_gnn_layers=1),   # pet/tests/test_basic.py:22-32 (minimal_model_hypers)
+}
+
+
+def main_sizes():
+    """The reference at other model sizes -> ``pet_size_<tag>_box64.npz``: per-atom E, dE/dR (fp32 / fp64), the node
+    features of every readout layer (fp64), on the 64-atom box with the synthetic weight generator."""
+    from oracle import nl as onl
+    from oracle import pet as opet
+
+    PETBackend = import_reference_backend()
+    torch.set_num_threads(8)
+    p64, z64, c64 = opet.random_box(64, seed=1)
+    for tag, delta in SIZES.items():
+        hyp = dict(opet.DEFAULT_HYPERS, **delta)
+        i, j, s, _ = onl.neighbor_list(p64.double().numpy(), c64.double().numpy(), [True] * 3, hyp["cutoff"])
+        store = {}
+        for dtype in (torch.float32, torch.float64):
+            be, _ = _reference_backend(PETBackend, hyp, dtype)
+            args = (p64.to(dtype), c64.to(dtype)[None], torch.tensor(i), torch.tensor(j), torch.tensor(s).long(), z64,
+                    torch.zeros(64, dtype=torch.long))
+            pos = args[0].clone().requires_grad_(True)
+            be = be.eval()
+            batch = be.preprocess(pos, args[2], args[3], args[5], args[1], args[4], args[6], 1.0)
+            nf, ef = be.calculate_features(batch)
+            pred, _, _ = be.predict(nf, ef, batch, args[1], args[6], ["energy"])
+            atomic = pred["energy"][0]
+            (grad,) = torch.autograd.grad(atomic.sum(), pos)
+            sfx = {torch.float32: "f32", torch.float64: "f64"}[dtype]
+            store[f"energies_{sfx}"] = atomic.sum(0, keepdim=True).detach().numpy()
+            store[f"atomic_{sfx}"] = atomic.detach().numpy()
+            store[f"grad_{sfx}"] = grad.numpy()
+            if dtype == torch.float64:
+                store["n_readout"] = np.array(len(nf))
+                for l in range(len(nf)):
+                    store[f"node_features_{l}_f64"] = nf[l].detach().numpy()
+            print(tag, sfx, "E =", float(atomic.sum()), "|grad|max =", float(grad.abs().max()), "readout layers", len(nf))
+        _store_inputs(store, args)
+        np.savez_compressed(os.path.join(HERE, f"pet_size_{tag}_box64.npz"), **store)
+
+
 if __name__ == "__main__":
-    if "--multitarget" in sys.argv:
+    if "--sizes" in sys.argv:
+        main_sizes()
+    elif "--multitarget" in sys.argv:
         main_multitarget()
     elif "--conditioning" in sys.argv:
         main_conditioning()

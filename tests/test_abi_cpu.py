@@ -43,11 +43,21 @@ def test_soap_header_symbols_are_exported(lib):
 def test_hypers_struct_and_supported(lib):
     h = rt.hypers_struct(dict(opet.DEFAULT_HYPERS), [1, 6, 7, 8])
     assert lib.pet_hypers_supported(ctypes.byref(h)) == 1
-    tiny = dict(opet.DEFAULT_HYPERS, d_pet=16, d_node=32, d_head=16, d_feedforward=32, num_heads=2)
-    assert lib.pet_hypers_supported(ctypes.byref(rt.hypers_struct(tiny, [1, 6]))) == 0
-    # unsupported instantiation fails loudly with a message, not silently
-    with pytest.raises(_lib.PetHipError, match="compiled instantiation"):
-        rt.HipModel(tiny, [1, 6])
+    # any size is served since round 3 (the size-generic path, csrc/gen.hip): the reference's own minimal hypers
+    # (pet/tests/test_basic.py:22-32), d_node == d_pet, sizes that are no multiple of a tile
+    for sizes in (dict(d_pet=16, d_node=32, d_head=16, d_feedforward=32, num_heads=2),
+                  dict(d_pet=1, d_node=1, d_head=1, d_feedforward=1, num_heads=1),
+                  dict(d_pet=48, d_node=48, d_head=20, d_feedforward=72, num_heads=3)):
+        hy = dict(opet.DEFAULT_HYPERS, **sizes)
+        assert lib.pet_hypers_supported(ctypes.byref(rt.hypers_struct(hy, [1, 6]))) == 1
+        m = rt.HipModel(hy, [1, 6])
+        del m
+    # what stays unsupported fails loudly with a message: d_pet not a multiple of num_heads, head dimension > 128
+    for sizes in (dict(d_pet=100, num_heads=8), dict(d_pet=512, num_heads=2)):
+        hy = dict(opet.DEFAULT_HYPERS, **sizes)
+        assert lib.pet_hypers_supported(ctypes.byref(rt.hypers_struct(hy, [1, 6]))) == 0
+        with pytest.raises(_lib.PetHipError, match="unsupported sizes"):
+            rt.HipModel(hy, [1, 6])
 
 
 def test_model_create_destroy_without_gpu(lib):

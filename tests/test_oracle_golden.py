@@ -273,6 +273,44 @@ def test_oracle_variants_match_reference(golden_dir, tag):
         np.testing.assert_allclose(nf.numpy(), g[f"node_features_{l}_f64"], rtol=1e-8, atol=1e-11)
 
 
+SIZES = {   # = tests/golden/make_golden.py::SIZES
+    "s64": dict(d_pet=64, d_node=128, d_feedforward=128, d_head=64, num_heads=4),
+    "flat32": dict(d_pet=32, d_node=32, d_feedforward=48, d_head=24, num_heads=2),
+    "flat32_legacy": dict(d_pet=32, d_node=32, d_feedforward=48, d_head=24, num_heads=2, normalization="LayerNorm",
+                          activation="SiLU", transformer_type="PostLN", featurizer_type="residual"),
+    "wide256": dict(d_pet=256, d_node=512, d_feedforward=320, d_head=96, num_heads=4),
+    "minimal": dict(d_pet=1, d_node=1, d_feedforward=1, d_head=1, num_heads=1, num_attention_layers=1, num_gnn_layers=1),
+}
+
+
+@pytest.mark.parametrize("tag", list(SIZES))
+def test_oracle_other_model_sizes_match_reference(golden_dir, tag):
+    """The reference is size-generic (pet/documentation.py:196-213); with d_node == d_pet it holds Identity modules in
+    place of centre contraction / expansion / MLP (transformer.py:189-201), and its architecture suites run at
+    d_pet = 1 (pet/tests/test_basic.py:22-32) -- against make_golden.py --sizes."""
+    hypers = dict(opet.DEFAULT_HYPERS, **SIZES[tag])
+    g = _load(golden_dir, f"pet_size_{tag}_box64.npz")
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    if hypers["d_node"] == hypers["d_pet"]:
+        assert not any("center_" in k for k in params)
+    e, grad, atomic = _run_oracle(g, hypers, params, torch.float64)
+    np.testing.assert_allclose(atomic.numpy(), g["atomic_f64"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(grad.numpy(), g["grad_f64"], rtol=1e-8, atol=1e-11)
+    t = lambda k: torch.tensor(g[k])  # noqa: E731
+    _, nfs, _, _ = opet.pet_atomic_energies(params, hypers, t("in_positions"), t("in_cells"), t("in_centers"),
+                                            t("in_neighbors"), t("in_cell_shifts").long(), t("in_species"),
+                                            t("in_system_indices"), return_features="all")
+    assert len(nfs) == int(g["n_readout"])
+    for l, nf in enumerate(nfs):
+        np.testing.assert_allclose(nf.numpy(), g[f"node_features_{l}_f64"], rtol=1e-8, atol=1e-11)
+    # the product's own generator knows the schema of these sizes too
+    from metatrain_amd import synthetic
+
+    a = synthetic.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0)
+    b = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0)
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+
+
 @pytest.mark.parametrize("tag", ["feedforward", "residual"])
 def test_oracle_system_conditioning_matches_reference(golden_dir, tag):
     """system_conditioning = True (conditioning.py; backend.py:121-130, 517-545, 607-630): charge / spin-multiplicity
