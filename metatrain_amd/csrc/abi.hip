@@ -866,6 +866,7 @@ int pet_config_set(const char* key, int value) {
     else if (k == "tile_f16x3") set_tile_f16x3(value);
     else if (k == "trr_compress") set_trr_compress(value);
     else if (k == "line_stores") set_line_stores(value);
+    else if (k == "lds_w") set_lds_w(value);
     else if (k == "node_planes") set_node_planes(value);
     else if (k == "so_trr") set_so_trr(value);
     else if (k == "wgrad_bf16") set_wgrad_bf16(value);

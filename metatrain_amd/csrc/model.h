@@ -236,6 +236,7 @@ int tile_mask();
 void set_trr_compress(int v);
 void set_node_planes(int v);  // pet_fwd.hip / pet_bwd.hip: node-row kernels on pre-split fp16 planes (default 1)
 bool node_planes();
+void set_lds_w(int v);       // pet_trr.hip: shared weight stream kernels (weights once per 256-row workgroup through LDS)
 void set_line_stores(int v);  // pet_trr.hip: bit 0 qkv, bit 1 edge MLP store whole 128-B lines through LDS (default 3)
 struct Graph;
 bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* Min, float* a0_out, float* Xout, int64_t E,

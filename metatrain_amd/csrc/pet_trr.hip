@@ -2,6 +2,8 @@
 // 32 rows through a whole stage, no LDS, no barriers, weights streamed from L2 in fragment order.
 // Same math and same saved tensors as the LDS-tile kernels in pet_fwd.hip / pet_bwd.hip (kept for
 // A/B comparison, PET_HIP_TRR=0); reference line map in pet_fwd.hip.
+#include <stdlib.h>
+
 #include "common.h"
 #include "model.h"
 #include "pet_ws.h"
@@ -113,6 +115,82 @@ __global__ __launch_bounds__(256, 2) void k_qkv_hl(const float* __restrict__ X, 
         acc_to_frag<2>(acc, y);
         store_tile64_lines(y, lds, QKV + 64 * c, row0, R, 3 * D, L);
     });
+}
+
+// ---------------------------------------------------------------------------------
+// "Shared weight stream" kernels (round 3; pet_config_set("lds_w", bits)). The TRR kernels above give every 32-row WAVE
+// its own copy of the weight stream from L2: 196 KB of fragments against 64 KB of rows per tile in the QKV stage, i.e.
+// three quarters of what passes the CU's vector-memory path (64 B / clk) is the same weights over and over, and that
+// path is what the stage spends ~40 % of its time on. Here ONE workgroup of eight waves
+// (256 rows, two waves per SIMD) streams each weight chunk ONCE, by LDS-DMA (global_load_lds_dwordx4: no registers, the
+// lane-linear fragment order of the packed weights is exactly the LDS image), into a double buffer; the waves read
+// their A fragments with ds_read_b128 (conflict-free: 16 B per lane, consecutive lanes) and meet at one barrier per
+// chunk. Row fragments, split operands and accumulators stay in registers as in the TRR kernels: same arithmetic,
+// bit-identical results.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16_w(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+constexpr int SW_WAVES = 8;                       // waves per workgroup = 256 rows
+constexpr int SW_CHUNK = 2 * 8 * 64;              // f16x8 entries of one plane of a 64-column x 128-K weight chunk (16 KB)
+constexpr size_t SW_WBYTES = (size_t)2 * 2 * SW_CHUNK * 16;   // two buffers x two planes
+template <bool LN>
+__global__ __launch_bounds__(512) void k_qkv_s(const float* __restrict__ X, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, W2 win, const float* __restrict__ bin,
+                                               float* __restrict__ QKV, int64_t R) {
+    extern __shared__ __attribute__((aligned(16))) char smem_sw[];
+    const f16x8* wb = reinterpret_cast<const f16x8*>(smem_sw);  // [buffer][plane][tile 0..1][kb 0..7][lane]
+    const RowLane L;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* lds = reinterpret_cast<float*>(smem_sw + SW_WBYTES) + wave * 32 * TILE_LD;
+    const int64_t row0 = ((int64_t)blockIdx.x * SW_WAVES + wave) * WROWS;
+    const int64_t rowc = row0 + L.r < R ? row0 + L.r : R - 1;   // waves past the end run along and store nothing
+    const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem_sw);
+    auto dma = [&](int c, int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const f16x8* src = (p ? win.l : win.h) + (size_t)c * SW_CHUNK + threadIdx.x;
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                glds16_w(src + r * 512, wbase + (unsigned)(((buf * 2 + p) * SW_CHUNK + r * 512 + wave * 64) * 16));
+        }
+    };
+    dma(0, 0);
+    Split2<8> xs;
+    {
+        float4 x[16];
+        load_rowfrag<16>(x, X, rowc, D, L.h);
+        norm_frag<16, LN>(x, gamma, beta, L.h);
+        split_frag2<8>(x, xs);
+    }
+    float4 yprev[8];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < 6; c++) {
+        if (c + 1 < 6) dma(c + 1, (c + 1) & 1);
+        // the previous chunk's 64 columns leave while this chunk's MFMAs run
+        if (c > 0) store_tile64_lines(yprev, lds, QKV + 64 * (c - 1), row0, R, 3 * D, L);
+        const f16x8* bh = wb + (size_t)((c & 1) * 2) * SW_CHUNK + L.lane;
+        const f16x8* bl = bh + SW_CHUNK;
+        f32x16 acc[2], acl[2];
+        acc_bias<2>(acc, bin, 64 * c, L.h);
+        acc_zero<2>(acl);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            WBlk2<2> w;
+#pragma unroll
+            for (int t = 0; t < 2; t++) { w.h[t] = bh[(t * 8 + kb) * 64]; w.l[t] = bl[(t * 8 + kb) * 64]; }
+            mfma3<2>(acc, acl, w, xs.h[kb], xs.l[kb]);
+        }
+        fold_low<2>(acc, acl);
+        acc_to_frag<2>(acc, yprev);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk has landed (and this wave's stores are out)
+        __syncthreads();                                    // ... for every wave; and every wave is done with this buffer
+    }
+    store_tile64_lines(yprev, lds, QKV + 64 * 5, row0, R, 3 * D, L);
 }
 
 __global__ __launch_bounds__(256, 2) void k_oproj_h(const float* __restrict__ AO, const float* __restrict__ X, W2 wo,
@@ -818,6 +896,15 @@ static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
 // oproj_bwd, qkv_bwd, compress, compress_bwd, comb_bwd and head_bwd always store this way)
 static int g_line_stores = 3;
 void set_line_stores(int v) { g_line_stores = v; }
+static int g_lds_w = -1;   // shared weight stream kernels: bit 0 qkv (PET_HIP_LDS_W sets the start value)
+void set_lds_w(int v) { g_lds_w = v; }
+static int lds_w() {
+    if (g_lds_w < 0) {
+        const char* e = getenv("PET_HIP_LDS_W");
+        g_lds_w = e ? atoi(e) : 1;   // qkv: 3.39 -> 3.16 ms per step (8 x 10k-atom boxes), bit-identical results
+    }
+    return g_lds_w;
+}
 
 // The GEMMs of these kernels are split-operand products on the 16-bit matrix cores (f16x3: 2-way fp16 split, three
 // MFMAs per K block; 1.7e-7 product error against fp64, tools/ubench). The fp32-MFMA and 3-way bf16 (bf16x6)
@@ -858,7 +945,12 @@ void trr_qkv(const float* X, const float* gamma, const float* beta, const Lin& q
              hipStream_t st) {
     if (R <= 0) return;
     const int grid = grid_rows(R);
-    if (g_line_stores & 1) {
+    if (lds_w() & 1) {
+        const size_t lds = SW_WBYTES + (size_t)SW_WAVES * 32 * TILE_LD * 4;
+        const int g8 = (int)cdiv(R, SW_WAVES * WROWS);
+        if (beta) { allow_big_lds(k_qkv_s<true>, lds); k_qkv_s<true><<<g8, 512, lds, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R); }
+        else { allow_big_lds(k_qkv_s<false>, lds); k_qkv_s<false><<<g8, 512, lds, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R); }
+    } else if (g_line_stores & 1) {
         if (beta) k_qkv_hl<true><<<grid, 256, 0, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R);
         else k_qkv_hl<false><<<grid, 256, 0, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R);
     } else {
