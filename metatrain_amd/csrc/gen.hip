@@ -14,11 +14,11 @@
 //   * all architecture switches of the tuned path: RMSNorm / LayerNorm, PreLN / PostLN, feedforward / residual featuriser,
 //     SwiGLU / SiLU (tied halves), system conditioning, bump / cosine / adaptive cutoffs (graph side, shared).
 // Correctness-first (the matrix cores are not used): a few percent of the tuned path's rate, documented in DESIGN.md.
-// Training of generic sizes is not built (refused in abi.hip).
-#include <type_traits>
+// Training on this path: gen_train.hip.
+#include <string>
+#include <vector>
 
-#include "common.h"
-#include "model.h"
+#include "gen_common.h"
 
 namespace pet {
 
@@ -26,556 +26,6 @@ int attn_tiles(const Graph& g);
 int backward_geometry_generic(const Model& m, const Graph& g, float* dv_scratch, const float* dgeo, const float* dfc_a,
                               const float* dfc_b, float* gpos, float* gcell, hipStream_t st);  // pet_bwd.hip
 
-namespace {
-
-struct GD {
-    int D, DN, DFF, DNF, DH, NH, HD;
-    bool expanded;  // d_node != d_pet (transformer.py:189-201)
-};
-static GD dims_of(const Model& m) {
-    GD d;
-    d.D = m.h.d_pet; d.DN = m.h.d_node; d.DFF = m.h.d_feedforward; d.DNF = 2 * d.DN; d.DH = m.h.d_head;
-    d.NH = m.h.num_heads; d.HD = d.D / d.NH; d.expanded = d.DN != d.D;
-    return d;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Y[r][o] (+)= b[o] + sum_i X[r * ldx + i] * W[o * so + i * si]
-// ---------------------------------------------------------------------------------------------
-template <bool ACC>
-__global__ __launch_bounds__(256) void k_gen_lin(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
-                                                 int64_t so, int64_t si, const float* __restrict__ b,
-                                                 float* __restrict__ Y, int64_t ldy, int64_t R, int NO, int KI) {
-    __shared__ float Xs[64][17], Ws[64][17];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int64_t r0 = (int64_t)blockIdx.x * 64;
-    const int o0 = blockIdx.y * 64;
-    float acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = 0.f;
-    for (int k0 = 0; k0 < KI; k0 += 16) {
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
-            const int rr = idx >> 4, kk = idx & 15;
-            const int64_t r = r0 + rr;
-            Xs[rr][kk] = (r < R && k0 + kk < KI) ? X[r * ldx + k0 + kk] : 0.f;
-            const int o = o0 + rr;
-            Ws[rr][kk] = (o < NO && k0 + kk < KI) ? W[(int64_t)o * so + (int64_t)(k0 + kk) * si] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; kk++) {
-            float a[4], c[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) { a[i] = Xs[ty + 16 * i][kk]; c[i] = Ws[tx + 16 * i][kk]; }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = fmaf(a[i], c[j], acc[i][j]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int64_t r = r0 + ty + 16 * i;
-        if (r >= R) continue;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int o = o0 + tx + 16 * j;
-            if (o >= NO) continue;
-            const float v = acc[i][j] + (b ? b[o] : 0.f);
-            if (ACC) Y[r * ldy + o] += v;
-            else Y[r * ldy + o] = v;
-        }
-    }
-}
-
-struct Lins {
-    hipStream_t st;
-    // y = x W^T + b
-    void fwd(const float* X, int64_t ldx, const Lin& L, float* Y, int64_t ldy, int64_t R, bool acc = false,
-             int col0 = 0, int kin = -1) const {
-        if (R <= 0) return;
-        const int K = kin < 0 ? L.k_in : kin;  // a column block [col0, col0 + K) of the weight (compress.0)
-        dim3 grid((unsigned)cdiv(R, 64), (unsigned)cdiv(L.n_out, 64));
-        if (acc) k_gen_lin<true><<<grid, 256, 0, st>>>(X, ldx, L.w + col0, L.k_in, 1, L.b, Y, ldy, R, L.n_out, K);
-        else k_gen_lin<false><<<grid, 256, 0, st>>>(X, ldx, L.w + col0, L.k_in, 1, L.b, Y, ldy, R, L.n_out, K);
-    }
-    // dx (+)= dy W
-    void bwd(const float* dY, int64_t ldy, const Lin& L, float* dX, int64_t ldx, int64_t R, bool acc = false,
-             int col0 = 0, int kin = -1) const {
-        if (R <= 0) return;
-        const int K = kin < 0 ? L.k_in : kin;
-        dim3 grid((unsigned)cdiv(R, 64), (unsigned)cdiv(K, 64));
-        if (acc) k_gen_lin<true><<<grid, 256, 0, st>>>(dY, ldy, L.w + col0, 1, L.k_in, nullptr, dX, ldx, R, K, L.n_out);
-        else k_gen_lin<false><<<grid, 256, 0, st>>>(dY, ldy, L.w + col0, 1, L.k_in, nullptr, dX, ldx, R, K, L.n_out);
-    }
-};
-
-// ---------------------------------------------------------------------------------------------
-// row kernels, one wave per row, run-time width
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float gsig(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// torch.nn.RMSNorm (eps = finfo(float32).eps, weight) or torch.nn.LayerNorm (eps 1e-5, weight + bias)
-__global__ void k_gen_norm(const float* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
-                           int ln, float eps, float* __restrict__ Y, int64_t R, int W) {
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (r >= R) return;
-    const float* x = X + r * W;
-    float mean = 0.f;
-    if (ln) {
-        float s = 0.f;
-        for (int k = lane; k < W; k += 64) s += x[k];
-        mean = wave_sum(s) / W;
-    }
-    float s2 = 0.f;
-    for (int k = lane; k < W; k += 64) { const float c = x[k] - mean; s2 += c * c; }
-    const float rstd = 1.0f / sqrtf(wave_sum(s2) / W + eps);
-    for (int k = lane; k < W; k += 64) Y[r * W + k] = (x[k] - mean) * rstd * gamma[k] + (beta ? beta[k] : 0.f);
-}
-
-// dX (+)= adjoint of k_gen_norm at X for the incoming dY
-__global__ void k_gen_norm_bwd(const float* __restrict__ X, const float* __restrict__ gamma, int ln, float eps,
-                               const float* __restrict__ dY, float* __restrict__ dX, int acc, int64_t R, int W) {
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (r >= R) return;
-    const float* x = X + r * W;
-    const float* dy = dY + r * W;
-    float mean = 0.f;
-    if (ln) {
-        float s = 0.f;
-        for (int k = lane; k < W; k += 64) s += x[k];
-        mean = wave_sum(s) / W;
-    }
-    float s2 = 0.f;
-    for (int k = lane; k < W; k += 64) { const float c = x[k] - mean; s2 += c * c; }
-    const float rstd = 1.0f / sqrtf(wave_sum(s2) / W + eps);
-    float m1 = 0.f, m2 = 0.f;
-    for (int k = lane; k < W; k += 64) {
-        const float gk = dy[k] * gamma[k];
-        m1 += gk;
-        m2 += gk * (x[k] - mean) * rstd;
-    }
-    m1 = ln ? wave_sum(m1) / W : 0.f;
-    m2 = wave_sum(m2) / W;
-    for (int k = lane; k < W; k += 64) {
-        const float v = rstd * (dy[k] * gamma[k] - m1 - (x[k] - mean) * rstd * m2);
-        if (acc) dX[r * W + k] += v;
-        else dX[r * W + k] = v;
-    }
-}
-
-// FeedForward (transformer.py:39-50): S = v * sigmoid(g), [v | g] = VG [R, 2F]
-__global__ void k_gen_swiglu(const float* __restrict__ VG, float* __restrict__ S, int64_t R, int F) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= R * F) return;
-    const int64_t r = idx / F;
-    const int k = (int)(idx % F);
-    S[idx] = VG[r * 2 * F + k] * gsig(VG[r * 2 * F + F + k]);
-}
-__global__ void k_gen_swiglu_bwd(const float* __restrict__ VG, const float* __restrict__ dS, float* __restrict__ dVG,
-                                 int64_t R, int F) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= R * F) return;
-    const int64_t r = idx / F;
-    const int k = (int)(idx % F);
-    const float v = VG[r * 2 * F + k], s = gsig(VG[r * 2 * F + F + k]), d = dS[idx];
-    dVG[r * 2 * F + k] = d * s;
-    dVG[r * 2 * F + F + k] = d * v * s * (1.f - s);
-}
-__global__ void k_gen_silu(const float* __restrict__ A, float* __restrict__ S, int64_t n) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) S[idx] = A[idx] * gsig(A[idx]);
-}
-// dA = dS * silu'(A)   (in place on dS allowed)
-__global__ void k_gen_silu_bwd(const float* __restrict__ A, const float* __restrict__ dS, float* __restrict__ dA, int64_t n) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    const float a = A[idx], s = gsig(a);
-    dA[idx] = dS[idx] * s * (1.f + a * (1.f - s));
-}
-// Y[r][0..W) (+)= a * A[r * lda + ..] + b * B[rowB(r) * ldb + ..]   (B, index optional)
-__global__ void k_gen_axpby(float a, const float* __restrict__ A, int64_t lda, float b, const float* __restrict__ B,
-                            int64_t ldb, const int* __restrict__ index, float* __restrict__ Y, int64_t ldy, int acc,
-                            int64_t R, int W) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= R * W) return;
-    const int64_t r = idx / W;
-    const int k = (int)(idx % W);
-    float v = A ? a * A[r * lda + k] : 0.f;
-    if (B) v += b * B[(index ? (int64_t)index[r] : r) * ldb + k];
-    if (acc) Y[r * ldy + k] += v;
-    else Y[r * ldy + k] = v;
-}
-// Y[r][..] = table[index[r]][..]
-__global__ void k_gen_embed(const int* __restrict__ index, const float* __restrict__ table, float* __restrict__ Y,
-                            int64_t ldy, int64_t R, int W) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= R * W) return;
-    const int64_t r = idx / W;
-    const int k = (int)(idx % W);
-    Y[r * ldy + k] = table[(int64_t)index[r] * W + k];
-}
-// out[a][..] += cond[system of atom a][..]
-__global__ void k_gen_add_cond(float* __restrict__ H, const float* __restrict__ cond, const int* __restrict__ sys32,
-                               const int64_t* __restrict__ sys64, int64_t N, int W) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * W) return;
-    const int64_t a = idx / W;
-    const int64_t s = sys64 ? sys64[a] : (int64_t)sys32[a];
-    H[idx] += cond[s * W + (idx % W)];
-}
-// conditioning.py:82-100 for one system per block: silu(project.0 [emb_q ; emb_s]) -> project.2
-__global__ void k_gen_system_cond(const int64_t* __restrict__ charge, const int64_t* __restrict__ spin,
-                                  const float* __restrict__ qe, const float* __restrict__ se, const float* __restrict__ w0,
-                                  const float* __restrict__ b0, const float* __restrict__ w2, const float* __restrict__ b2,
-                                  float* __restrict__ out, int max_charge, int DN) {
-    extern __shared__ float sm[];  // [2 DN] input, [DN] hidden
-    float* x = sm;
-    float* hdn = sm + 2 * DN;
-    const int s = blockIdx.x;
-    const int64_t q = charge[s] + max_charge, mult = spin[s] - 1;
-    for (int k = threadIdx.x; k < DN; k += blockDim.x) { x[k] = qe[q * DN + k]; x[DN + k] = se[mult * DN + k]; }
-    __syncthreads();
-    for (int o = threadIdx.x; o < DN; o += blockDim.x) {
-        float a = b0[o];
-        for (int k = 0; k < 2 * DN; k++) a = fmaf(w0[(int64_t)o * 2 * DN + k], x[k], a);
-        hdn[o] = a * gsig(a);
-    }
-    __syncthreads();
-    for (int o = threadIdx.x; o < DN; o += blockDim.x) {
-        float a = b2[o];
-        for (int k = 0; k < DN; k++) a = fmaf(w2[(int64_t)o * DN + k], hdn[k], a);
-        out[(int64_t)s * DN + o] = a;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// attention (transformer.py:86-152, 565-589): tokens of atom i = [centre row E + i ; its CSR edge rows], key bias
-// log(max(fc, 1e-15)) on edge keys (0 for the centre), scale 1 / (sqrt(head_dim) temperature)
-// ---------------------------------------------------------------------------------------------
-template <int HDM>
-__global__ __launch_bounds__(64) void k_gen_attn_fwd(const float* __restrict__ QKV, const int* __restrict__ rowptr,
-                                                     const float* __restrict__ fc, float* __restrict__ AO,
-                                                     float* __restrict__ LSE, int64_t E, int D, int NH, int HD, float scale) {
-    const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-    const int p0 = rowptr[i], T = rowptr[i + 1] - p0 + 1;
-    const int64_t ld = 3 * (int64_t)D;
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        const int tq = t0 + lane;
-        const bool live = tq < T;
-        const int64_t rq = !live ? E + i : (tq == 0 ? E + i : (int64_t)p0 + tq - 1);
-        float q[HDM], acc[HDM];
-#pragma unroll
-        for (int d = 0; d < HDM; d++) {
-            q[d] = d < HD ? QKV[rq * ld + h * HD + d] * scale : 0.f;
-            acc[d] = 0.f;
-        }
-        float mx = -INFINITY, l = 0.f;
-        for (int tk = 0; tk < T; tk++) {
-            const int64_t rk = tk == 0 ? E + i : (int64_t)p0 + tk - 1;
-            const float* kp = QKV + rk * ld + D + h * HD;
-            const float* vp = QKV + rk * ld + 2 * D + h * HD;
-            float s = tk == 0 ? 0.f : logf(fmaxf(fc[p0 + tk - 1], 1e-15f));
-#pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) s = fmaf(q[d], kp[d], s);
-            const float mn = fmaxf(mx, s), c = expf(mx - mn), p = expf(s - mn);
-            l = l * c + p;
-#pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) acc[d] = acc[d] * c + p * vp[d];
-            mx = mn;
-        }
-        if (live) {
-            const float il = 1.0f / l;
-#pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) AO[rq * D + h * HD + d] = acc[d] * il;
-            LSE[rq * NH + h] = mx + logf(l);
-        }
-    }
-}
-
-// pass A, lanes = queries: delta = <dO, O>, dQ
-template <int HDM>
-__global__ __launch_bounds__(64) void k_gen_attn_bwd_q(const float* __restrict__ QKV, const float* __restrict__ AO,
-                                                       const float* __restrict__ dAO, const float* __restrict__ LSE,
-                                                       const int* __restrict__ rowptr, const float* __restrict__ fc,
-                                                       float* __restrict__ dQKV, float* __restrict__ DELTA, int64_t E,
-                                                       int D, int NH, int HD, float scale) {
-    const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-    const int p0 = rowptr[i], T = rowptr[i + 1] - p0 + 1;
-    const int64_t ld = 3 * (int64_t)D;
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        const int tq = t0 + lane;
-        if (tq >= T) continue;
-        const int64_t rq = tq == 0 ? E + i : (int64_t)p0 + tq - 1;
-        float q[HDM], dO[HDM], dq[HDM];
-        float delta = 0.f;
-#pragma unroll
-        for (int d = 0; d < HDM; d++) {
-            q[d] = d < HD ? QKV[rq * ld + h * HD + d] * scale : 0.f;
-            dO[d] = d < HD ? dAO[rq * D + h * HD + d] : 0.f;
-            dq[d] = 0.f;
-            if (d < HD) delta = fmaf(dO[d], AO[rq * D + h * HD + d], delta);
-        }
-        const float lse = LSE[rq * NH + h];
-        for (int tk = 0; tk < T; tk++) {
-            const int64_t rk = tk == 0 ? E + i : (int64_t)p0 + tk - 1;
-            const float* kp = QKV + rk * ld + D + h * HD;
-            const float* vp = QKV + rk * ld + 2 * D + h * HD;
-            float s = tk == 0 ? 0.f : logf(fmaxf(fc[p0 + tk - 1], 1e-15f));
-            float dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) { s = fmaf(q[d], kp[d], s); dp = fmaf(dO[d], vp[d], dp); }
-            const float ds = expf(s - lse) * (dp - delta);
-#pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) dq[d] = fmaf(ds, kp[d], dq[d]);
-        }
-#pragma unroll
-        for (int d = 0; d < HDM; d++)
-            if (d < HD) dQKV[rq * ld + h * HD + d] = dq[d] * scale;
-        DELTA[rq * NH + h] = delta;
-    }
-}
-
-// pass B, lanes = keys: dK, dV and the key-bias gradient (edge keys; head-major [NH][E])
-template <int HDM>
-__global__ __launch_bounds__(64) void k_gen_attn_bwd_k(const float* __restrict__ QKV, const float* __restrict__ dAO,
-                                                       const float* __restrict__ LSE, const float* __restrict__ DELTA,
-                                                       const int* __restrict__ rowptr, const float* __restrict__ fc,
-                                                       float* __restrict__ dQKV, float* __restrict__ dbias_h, int64_t E,
-                                                       int D, int NH, int HD, float scale) {
-    const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-    const int p0 = rowptr[i], T = rowptr[i + 1] - p0 + 1;
-    const int64_t ld = 3 * (int64_t)D;
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        const int tk = t0 + lane;
-        if (tk >= T) continue;
-        const int64_t rk = tk == 0 ? E + i : (int64_t)p0 + tk - 1;
-        float k[HDM], v[HDM], dk[HDM], dv[HDM];
-#pragma unroll
-        for (int d = 0; d < HDM; d++) {
-            k[d] = d < HD ? QKV[rk * ld + D + h * HD + d] : 0.f;
-            v[d] = d < HD ? QKV[rk * ld + 2 * D + h * HD + d] : 0.f;
-            dk[d] = 0.f; dv[d] = 0.f;
-        }
-        const float bias = tk == 0 ? 0.f : logf(fmaxf(fc[p0 + tk - 1], 1e-15f));
-        float db = 0.f;
-        for (int tq = 0; tq < T; tq++) {
-            const int64_t rq = tq == 0 ? E + i : (int64_t)p0 + tq - 1;
-            const float* qp = QKV + rq * ld + h * HD;
-            const float* dop = dAO + rq * D + h * HD;
-            float s = 0.f, dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) { s = fmaf(qp[d], k[d], s); dp = fmaf(dop[d], v[d], dp); }
-            const float p = expf(s * scale + bias - LSE[rq * NH + h]);
-            const float ds = p * (dp - DELTA[rq * NH + h]);
-            db += ds;
-#pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) { dv[d] = fmaf(p, dop[d], dv[d]); dk[d] = fmaf(ds * scale, qp[d], dk[d]); }
-        }
-#pragma unroll
-        for (int d = 0; d < HDM; d++)
-            if (d < HD) { dQKV[rk * ld + D + h * HD + d] = dk[d]; dQKV[rk * ld + 2 * D + h * HD + d] = dv[d]; }
-        if (tk > 0) dbias_h[(int64_t)h * E + p0 + tk - 1] = db;
-    }
-}
-// dfc[p] += (sum_h dbias_h[h][p]) / fc[p]   (d log(max(fc, 1e-15)) / dfc; 0 below the clamp)
-__global__ void k_gen_dfc(const float* __restrict__ dbias_h, const float* __restrict__ fc, float* __restrict__ dfc,
-                          int64_t E, int NH) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= E) return;
-    float s = 0.f;
-    for (int h = 0; h < NH; h++) s += dbias_h[(int64_t)h * E + p];
-    const float f = fc[p];
-    dfc[p] += f > 1e-15f ? s / f : 0.f;
-}
-
-template <class F>
-static void attn_dispatch(int HD, F f) {
-    if (HD <= 4) f(std::integral_constant<int, 4>());
-    else if (HD <= 16) f(std::integral_constant<int, 16>());
-    else if (HD <= 32) f(std::integral_constant<int, 32>());
-    else if (HD <= 64) f(std::integral_constant<int, 64>());
-    else f(std::integral_constant<int, 128>());
-}
-
-// ---------------------------------------------------------------------------------------------
-// heads (backend.py:651-777): pred[i][p] = node_pred[i][p] + sum_{e in row i} fc_e edge_pred[e][p]
-// ---------------------------------------------------------------------------------------------
-__global__ void k_gen_atom_sum(const float* __restrict__ npred, const float* __restrict__ epred, const float* __restrict__ fc,
-                               const int* __restrict__ rowptr, float* __restrict__ out, int64_t N, int P) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * P) return;
-    const int64_t i = idx / P;
-    const int p = (int)(idx % P);
-    float s = npred[idx];
-    for (int e = rowptr[i]; e < rowptr[i + 1]; e++) s += fc[e] * epred[(int64_t)e * P + p];
-    out[idx] = s;
-}
-// edge_sum[i][k] = sum_{e in row i} fc_e X[e][k]
-__global__ void k_gen_edge_sum(const float* __restrict__ X, const float* __restrict__ fc, const int* __restrict__ rowptr,
-                               float* __restrict__ out, int64_t ldo, int64_t N, int W) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * W) return;
-    const int64_t i = idx / W;
-    const int k = (int)(idx % W);
-    float s = 0.f;
-    for (int e = rowptr[i]; e < rowptr[i + 1]; e++) s += fc[e] * X[(int64_t)e * W + k];
-    out[i * ldo + k] = s;
-}
-// seeds of the edge head: dEpred[e][p] = fc_e gA[ctr e][p];  dfc[e] (+)= sum_p gA[ctr e][p] epred[e][p]
-__global__ void k_gen_edge_seed(const float* __restrict__ gA, const int* __restrict__ ctr, const float* __restrict__ fc,
-                                const float* __restrict__ epred, float* __restrict__ dEp, float* __restrict__ dfc, int acc,
-                                int64_t E, int P) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    const int64_t i = ctr[e];
-    float s = 0.f;
-    for (int p = 0; p < P; p++) {
-        const float gv = gA[i * P + p];
-        dEp[e * P + p] = fc[e] * gv;
-        s = fmaf(gv, epred[e * P + p], s);
-    }
-    if (acc) dfc[e] += s;
-    else dfc[e] = s;
-}
-
-// ---------------------------------------------------------------------------------------------
-// workspace
-// ---------------------------------------------------------------------------------------------
-struct GAttn {
-    float *X, *QKV, *AO, *LSE, *X1, *VG, *T1, *S2, *H, *H1, *VGn, *Hn, *TOKo;
-};
-struct GGnn {
-    std::vector<GAttn> attn;
-    float *a0, *XF, *CA, *Mout, *Hin, *Hout;
-};
-struct GWs {
-    std::vector<GGnn> gnn;
-    float *H0, *M0, *cond;
-    // temporaries
-    float *tE1, *tE2, *tE3, *tE4;   // [R][wmax]
-    float *tN1, *tN2, *tN3;   // [N][nmax]
-    float *dX, *dX2, *dM, *dH, *dQKV, *DELTA, *dbias_h, *dgeo, *dfc, *dv;
-    size_t bytes;
-};
-static int imax(int a, int b) { return a > b ? a : b; }
-static void gen_carve(const Model& m, int64_t N, int64_t E, void* base, GWs& w) {
-    const GD d = dims_of(m);
-    Carver c(base);
-    const int64_t R = E + N, Ra = R > 0 ? R : 1, Na = N > 0 ? N : 1, Ea = E > 0 ? E : 1;
-    const bool post = m.post_ln();
-    w.gnn.resize(m.h.num_gnn_layers);
-    w.H0 = c.take<float>(Na * d.DN);
-    w.M0 = c.take<float>(Ea * d.D);
-    w.cond = m.h.system_conditioning ? c.take<float>(Na * d.DN) : nullptr;
-    float* prev = w.H0;
-    for (size_t gi = 0; gi < w.gnn.size(); gi++) {
-        GGnn& G = w.gnn[gi];
-        G.attn.resize(m.h.num_attention_layers);
-        G.a0 = c.take<float>(Ea * d.D);
-        G.XF = c.take<float>(Ea * d.D);
-        G.CA = c.take<float>(Ea * 2 * d.D);
-        G.Mout = c.take<float>(Ea * d.D);
-        if (m.residual() && gi > 0) prev = c.take<float>(Na * d.DN);
-        G.Hin = prev;
-        for (auto& A : G.attn) {
-            A.X = c.take<float>(Ra * d.D);
-            A.QKV = c.take<float>(Ra * 3 * d.D);
-            A.AO = c.take<float>(Ra * d.D);
-            A.LSE = c.take<float>(Ra * d.NH);
-            A.X1 = c.take<float>(Ra * d.D);
-            A.VG = c.take<float>(Ra * 2 * d.DFF);
-            A.T1 = post ? c.take<float>(Ra * d.D) : nullptr;
-            A.S2 = post ? c.take<float>(Ra * d.D) : nullptr;
-            A.TOKo = c.take<float>(Na * d.D);   // the centre token leaving the layer (attention output / PostLN norm_mlp row)
-            A.H = prev;
-            A.H1 = d.expanded ? c.take<float>(Na * d.DN) : nullptr;
-            A.VGn = d.expanded ? c.take<float>(Na * 2 * d.DNF) : nullptr;
-            A.Hn = c.take<float>(Na * d.DN);
-            prev = A.Hn;
-        }
-        G.Hout = prev;
-    }
-    const int wmax = imax(imax(3 * d.D, 2 * d.DFF), imax(2 * d.D, d.DH));
-    const int nmax = imax(imax(2 * d.DNF, d.DN), imax(d.DH, d.D));
-    w.tE1 = c.take<float>(Ra * wmax); w.tE2 = c.take<float>(Ra * wmax); w.tE3 = c.take<float>(Ra * wmax);
-    w.tE4 = c.take<float>(Ra * wmax);
-    w.tN1 = c.take<float>(Na * nmax); w.tN2 = c.take<float>(Na * nmax); w.tN3 = c.take<float>(Na * nmax);
-    w.dX = c.take<float>(Ra * d.D); w.dX2 = c.take<float>(Ra * d.D);
-    w.dM = c.take<float>(Ea * d.D); w.dH = c.take<float>(Na * d.DN);
-    w.dQKV = c.take<float>(Ra * 3 * d.D);
-    w.DELTA = c.take<float>(Ra * d.NH);
-    w.dbias_h = c.take<float>(Ea * d.NH);
-    w.dgeo = c.take<float>(Ea * 4); w.dfc = c.take<float>(Ea); w.dv = c.take<float>(Ea * 4);
-    w.bytes = c.off;
-}
-
-static inline int g1(int64_t n) { return (int)cdiv(n > 0 ? n : 1, 256); }
-
-struct Ops {   // launch helpers of one pass
-    const Model& m;
-    const Graph& g;
-    GD d;
-    hipStream_t st;
-    Lins lin;
-    int64_t N, E, R;
-    Ops(const Model& m_, const Graph& g_, hipStream_t s) : m(m_), g(g_), d(dims_of(m_)), st(s), lin{s}, N(g_.n_nodes),
-        E(g_.n_edges), R(g_.n_nodes + g_.n_edges) {}
-    float eps() const { return m.layer_norm() ? 1e-5f : 1.1920929e-07f; }
-    void norm(const float* X, const float* gamma, const float* beta, float* Y, int64_t rows, int W) const {
-        if (rows > 0) k_gen_norm<<<(int)cdiv(rows, 4), 256, 0, st>>>(X, gamma, m.layer_norm() ? beta : nullptr, m.layer_norm(), eps(), Y, rows, W);
-    }
-    void norm_bwd(const float* X, const float* gamma, const float* dY, float* dX, bool acc, int64_t rows, int W) const {
-        if (rows > 0) k_gen_norm_bwd<<<(int)cdiv(rows, 4), 256, 0, st>>>(X, gamma, m.layer_norm(), eps(), dY, dX, acc, rows, W);
-    }
-    void axpby(float a, const float* A, int64_t lda, float b, const float* B, int64_t ldb, const int* index, float* Y,
-               int64_t ldy, bool acc, int64_t rows, int W) const {
-        if (rows > 0) k_gen_axpby<<<g1(rows * W), 256, 0, st>>>(a, A, lda, b, B, ldb, index, Y, ldy, acc, rows, W);
-    }
-    void copy(const float* A, float* Y, int64_t rows, int W) const { axpby(1.f, A, W, 0.f, nullptr, 0, nullptr, Y, W, false, rows, W); }
-    void add(const float* A, float* Y, int64_t rows, int W) const { axpby(1.f, A, W, 0.f, nullptr, 0, nullptr, Y, W, true, rows, W); }
-    // y = x + w_out(swiglu(w_in(norm(x))))  -> VG saved; out may alias nothing of the inputs
-    // FFN block on `rows` rows of width W: N = (normed ? norm(X) : X); VG = w_in N; S = swiglu(VG); Y = base + w_out S
-    void ffn(const float* Xin, bool normed, const float* gamma, const float* beta, const Lin& w_in, const Lin& w_out,
-             float* VG, const float* base, float* Y, float* tA, float* tB, int64_t rows, int W, int F) const {
-        const float* Nn = Xin;
-        if (normed) { norm(Xin, gamma, beta, tA, rows, W); Nn = tA; }
-        lin.fwd(Nn, W, w_in, VG, 2 * F, rows);
-        if (rows > 0) k_gen_swiglu<<<g1(rows * F), 256, 0, st>>>(VG, tB, rows, F);
-        if (base != Y) copy(base, Y, rows, W);
-        lin.fwd(tB, F, w_out, Y, W, rows, true);   // += w_out S + bias
-    }
-    // adjoint of the FFN branch: dIn (+)= d/dXin [w_out(swiglu(w_in(norm(Xin))))] for dY; the residual path is the caller's
-    void ffn_bwd(const float* Xin, bool normed, const float* gamma, const Lin& w_in, const Lin& w_out, const float* VG,
-                 const float* dY, float* dIn, bool acc, float* tA, float* tB, int64_t rows, int W, int F) const {
-        lin.bwd(dY, W, w_out, tA, F, rows);                                       // dS
-        if (rows > 0) k_gen_swiglu_bwd<<<g1(rows * F), 256, 0, st>>>(VG, tA, tB, rows, F);  // dVG
-        if (normed) {
-            lin.bwd(tB, 2 * F, w_in, tA, W, rows);                                // dN
-            norm_bwd(Xin, gamma, tA, dIn, acc, rows, W);
-        } else
-            lin.bwd(tB, 2 * F, w_in, dIn, W, rows, acc);
-    }
-};
-
-}  // namespace
 
 int64_t gen_workspace_bytes(const Model& m, int64_t N, int64_t E) {
     GWs w;
@@ -703,14 +153,10 @@ int gen_forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_byte
     PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT,
                 "forward workspace too small for the size-generic path (other model sizes, or an atom with more than 127 "
                 "neighbours): size it with pet_forward_workspace_bytes_for(model, graph)");
-    PET_REQUIRE(save != 2, PET_ERR_UNSUPPORTED,
-                "training is built for the compiled model size (d_pet=128, d_node=256, d_feedforward=256, d_head=128, "
-                "num_heads=8) and at most 127 neighbours per atom");
+    (void)save;  // everything the reverse passes need is kept anyway; the training pass (gen_train.hip) recomputes
     const bool post = m.post_ln(), res = m.residual();
     PET_REQUIRE(res ? (n_layers == m.h.num_gnn_layers || (n_layers == 1 && !node_feats[0] && !edge_feats[0])) : n_layers == 1,
                 PET_ERR_ARGUMENT, "expected one feature pair per readout layer");
-    PET_REQUIRE(!(atomic && res), PET_ERR_UNSUPPORTED,
-                "the fused head reads one readout layer; with the residual featuriser use pet_forward_layers and pet_predict");
     Ops o(m, g, st);
     const GD& d = o.d;
     const int64_t N = o.N, E = o.E, R = o.R;
@@ -802,12 +248,23 @@ int gen_forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_byte
     }
     const GGnn& last = w.gnn.back();
     if (atomic) {
-        PET_REQUIRE(m.has_fused_head, PET_ERR_ARGUMENT,
-                    "pet_forward with d_atomic needs the fused single-property target; use pet_predict for other heads");
-        HeadW H; H.nh0 = m.nh0; H.nh2 = m.nh2; H.eh0 = m.eh0; H.eh2 = m.eh2;
-        const LastW& Lw = m.lasts.at("@|0|@");
-        int rc = gen_predict(m, g, H, Lw, last.Hout, last.Mout, g.fc, atomic, nullptr, nullptr, st);
-        if (rc) return rc;
+        // the fused single-property target; with the residual featuriser the sum over the readout layers (backend.py:468-481)
+        const int NR = m.num_readout_layers();
+        float* tmp = nullptr;
+        if (NR > 1) PET_HIP_CHECK(hipMallocAsync((void**)&tmp, (size_t)N * sizeof(float), st));
+        for (int l = 0; l < NR; l++) {
+            auto hi = m.heads.find("@|" + std::to_string(l));
+            auto li = m.lasts.find("@|" + std::to_string(l) + "|@");
+            PET_REQUIRE(hi != m.heads.end() && li != m.lasts.end() && li->second.P == 1, PET_ERR_ARGUMENT,
+                        "pet_forward with d_atomic needs the fused single-property target (of every readout layer); use "
+                        "pet_predict for other heads");
+            const GGnn& Bl = res ? w.gnn[l] : last;
+            int rc = gen_predict(m, g, hi->second, li->second, Bl.Hout, res ? Bl.XF : Bl.Mout, g.fc, l == 0 ? atomic : tmp,
+                                 nullptr, nullptr, st);
+            if (rc) return rc;
+            if (l > 0) o.add(tmp, atomic, N, 1);
+        }
+        if (tmp) PET_HIP_CHECK(hipFreeAsync(tmp, st));
     }
     for (int l = 0; l < n_layers; l++) {
         const GGnn& Bl = res ? w.gnn[l] : last;
@@ -984,25 +441,37 @@ int gen_backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, con
     GWs w;
     gen_carve(m, g.n_nodes, g.n_edges, ws, w);
     PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "workspace too small");
-    PET_REQUIRE(!m.residual(), PET_ERR_UNSUPPORTED, "residual featuriser: use the staged calls (one head per readout layer)");
-    PET_REQUIRE(m.has_fused_head, PET_ERR_ARGUMENT, "pet_backward needs the fused single-property target");
     const int64_t N = g.n_nodes, E = g.n_edges;
     if (N == 0) return PET_OK;
     const GD d = dims_of(m);
-    HeadW H; H.nh0 = m.nh0; H.nh2 = m.nh2; H.eh0 = m.eh0; H.eh2 = m.eh2;
-    const LastW& Lw = m.lasts.at("@|0|@");
-    const GGnn& last = w.gnn.back();
-    float *gn = nullptr, *ge = nullptr, *gfh = nullptr, *ggeo = nullptr, *gfc = nullptr;
+    const int NR = m.num_readout_layers();
+    const bool res = m.residual();
     const int64_t Ea = E > 0 ? E : 1;
-    PET_HIP_CHECK(hipMallocAsync((void**)&gn, (size_t)(N * d.DN + Ea * d.D + Ea + Ea * 4 + Ea) * sizeof(float), st));
-    ge = gn + N * d.DN; gfh = ge + Ea * d.D; ggeo = gfh + Ea; gfc = ggeo + Ea * 4;
-    int rc = gen_predict_backward(m, g, H, Lw, last.Hout, last.Mout, g.fc, gA, gn, ge, gfh, st);
-    const float* gnp[1] = {gn};
-    const float* gep[1] = {ge};
-    if (!rc) rc = gen_backward_features(m, g, ws, ws_bytes, gnp, gep, 1, ggeo, gfc, st);
+    float* buf = nullptr;   // per readout layer: d node features, d edge features; then d fc (heads, summed), scratch d fc, d geo, d fc (attention)
+    const size_t per = (size_t)N * d.DN + (size_t)Ea * d.D;
+    PET_HIP_CHECK(hipMallocAsync((void**)&buf, (per * NR + (size_t)Ea * 7) * sizeof(float), st));
+    float* gfh = buf + per * NR;
+    float* gft = gfh + Ea;
+    float* ggeo = gft + Ea;
+    float* gfc = ggeo + Ea * 4;
+    std::vector<const float*> gnp(NR), gep(NR);
+    int rc = PET_OK;
+    for (int l = 0; l < NR && !rc; l++) {
+        auto hi = m.heads.find("@|" + std::to_string(l));
+        auto li = m.lasts.find("@|" + std::to_string(l) + "|@");
+        PET_REQUIRE(hi != m.heads.end() && li != m.lasts.end() && li->second.P == 1, PET_ERR_ARGUMENT,
+                    "pet_backward needs the fused single-property target (of every readout layer)");
+        const GGnn& Bl = res ? w.gnn[l] : w.gnn.back();
+        float* gn = buf + per * l;
+        float* ge = gn + (size_t)N * d.DN;
+        gnp[l] = gn; gep[l] = ge;
+        rc = gen_predict_backward(m, g, hi->second, li->second, Bl.Hout, res ? Bl.XF : Bl.Mout, g.fc, gA, gn, ge, l == 0 ? gfh : gft, st);
+        if (!rc && l > 0 && E > 0) { Ops o(m, g, st); o.add(gft, gfh, E, 1); }
+    }
+    if (!rc) rc = gen_backward_features(m, g, ws, ws_bytes, gnp.data(), gep.data(), NR, ggeo, gfc, st);
     // the two cutoff-factor gradients (heads, attention key biases) are added by the geometry kernel
     if (!rc) rc = backward_geometry_generic(m, g, w.dv, ggeo, E > 0 ? gfh : nullptr, E > 0 ? gfc : nullptr, gpos, gcell, st);
-    PET_HIP_CHECK(hipFreeAsync(gn, st));
+    PET_HIP_CHECK(hipFreeAsync(buf, st));
     return rc;
 }
 

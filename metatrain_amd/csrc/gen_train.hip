@@ -1,0 +1,1057 @@
+// Size-generic PET TRAINING pass (SURVEY §8 row a16 for every model the tuned second-order pass of so.hip does not serve:
+// other model sizes, d_node == d_pet, PostLN transformer layers, the residual featuriser -- VERDICT r2 missing #1 / #3).
+//
+// What the reference gets from `loss.backward()` after `autograd.grad(E, R, create_graph=True)` (pet/trainer.py:417-467,
+// utils/output_gradient.py:34-40) is computed as FORWARD-OVER-REVERSE on "dual" activations, like so.hip but unfused and
+// with run-time sizes:  with u = dL_F/d(dE/dR) the tangent of every edge vector is v'_p = u_j - u_i (+ S cell'), and
+//     <u, dE/dR> = d/d eps sum_i lambda_i e_i(R + eps u) = sum_i lambda_i e'_i,
+//     dL/d theta = d/d theta J,   J = sum_i (nu_i e_i + lambda_i e'_i),   nu_i = dL_E/d e_i, lambda_i = the force pass' seeds.
+// Sweep 1 evaluates every stage on (x, x') pairs -- each Linear once on the primal and once (without bias) on the tangent
+// rows, each non-linearity with its derivative; sweep 2 walks back with two adjoints per activation, (nu_x, lambda_x) =
+// dJ/d(x, x'), and at every Linear adds  dW += nu_y^T x + lambda_y^T x',  db += sum nu_y.  The second-order identities of
+// RMSNorm / LayerNorm, SiLU, SwiGLU and soft-max attention used here were checked against torch.autograd in fp64 before
+// the kernels were written (1e-16). Weight-gradient reductions run over row chunks into partial buffers that a second
+// kernel sums in a fixed order: no float atomics, bit-reproducible. Correctness-first: fp32 FMA, nothing fused.
+#include <map>
+#include <string>
+
+#include "gen_common.h"
+
+namespace pet {
+
+float __device__ cutoff_deriv_dev(float d, float rc, float width, int fn);  // graph.hip
+
+namespace {
+
+struct D2 {   // primal / tangent halves of an activation, or (nu, lambda) of an adjoint: two arrays of one shape
+    float* p = nullptr;
+    float* t = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+// geometry tangents: geo' = (v', d'), fc', b' = (log max(fc, 1e-15))'
+// ---------------------------------------------------------------------------------------------
+__global__ void k_gt_geo(const float4* __restrict__ geo, const float* __restrict__ d0, const float* __restrict__ fc,
+                         const int* __restrict__ ctr, const int* __restrict__ nbr, const int* __restrict__ shift,
+                         const int* __restrict__ sys, const float* __restrict__ u, const float* __restrict__ ucell,
+                         float4* __restrict__ geod, float* __restrict__ fcd, float* __restrict__ bd, int64_t E, float cutoff,
+                         float width, int fn) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= E) return;
+    const int i = ctr[p], j = nbr[p];
+    float vx = u[3 * j] - u[3 * i], vy = u[3 * j + 1] - u[3 * i + 1], vz = u[3 * j + 2] - u[3 * i + 2];
+    if (ucell) {   // v = r_j - r_i + S cell: the cell tangent of the stress term (utils/evaluate_model.py:305-321)
+        const float* c = ucell + 9 * (int64_t)sys[i];
+        const float sa = (float)shift[3 * p], sb = (float)shift[3 * p + 1], sc = (float)shift[3 * p + 2];
+        vx += sa * c[0] + sb * c[3] + sc * c[6];
+        vy += sa * c[1] + sb * c[4] + sc * c[7];
+        vz += sa * c[2] + sb * c[5] + sc * c[8];
+    }
+    const float4 g = geo[p];
+    const float dot = g.x * vx + g.y * vy + g.z * vz;
+    geod[p] = make_float4(vx, vy, vz, dot / g.w);                      // d sqrt(v.v + 1e-15) = v.v' / dist
+    const float nrm = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
+    const float f = nrm > 0.f ? cutoff_deriv_dev(d0[p], cutoff, width, fn) * dot / nrm : 0.f;
+    fcd[p] = f;
+    bd[p] = fc[p] > 1e-15f ? f / fc[p] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dual row kernels
+// ---------------------------------------------------------------------------------------------
+// (y, y') = norm(x, x'):  y = gamma xhat + beta,  y' = gamma rstd (c' - xhat mean(xhat c'))
+__global__ void k_gt_norm(const float* __restrict__ Xp, const float* __restrict__ Xt, const float* __restrict__ gamma,
+                          const float* __restrict__ beta, int ln, float eps, float* __restrict__ Yp, float* __restrict__ Yt,
+                          int64_t R, int W) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float* x = Xp + r * W;
+    const float* xt = Xt + r * W;
+    float mean = 0.f, meant = 0.f;
+    if (ln) {
+        float s = 0.f, st = 0.f;
+        for (int k = lane; k < W; k += 64) { s += x[k]; st += xt[k]; }
+        mean = wave_sum(s) / W;
+        meant = wave_sum(st) / W;
+    }
+    float s2 = 0.f, s3 = 0.f;
+    for (int k = lane; k < W; k += 64) {
+        const float c = x[k] - mean;
+        s2 += c * c;
+        s3 += c * (xt[k] - meant);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / W + eps);
+    const float m = rstd * wave_sum(s3) / W;   // mean(xhat c')
+    for (int k = lane; k < W; k += 64) {
+        const float xh = (x[k] - mean) * rstd;
+        Yp[r * W + k] = xh * gamma[k] + (beta ? beta[k] : 0.f);
+        Yt[r * W + k] = gamma[k] * rstd * ((xt[k] - meant) - xh * m);
+    }
+}
+
+// (nu_x, lambda_x) (+)= adjoint of k_gt_norm for (nu_y, lambda_y); G (optional) receives nu_y xhat + lambda_y xhat' (its
+// column sum is d gamma)
+__global__ void k_gt_norm_rev(const float* __restrict__ Xp, const float* __restrict__ Xt, const float* __restrict__ gamma,
+                              int ln, float eps, const float* __restrict__ NYp, const float* __restrict__ NYt,
+                              float* __restrict__ NXp, float* __restrict__ NXt, int acc, float* __restrict__ G, int64_t R,
+                              int W) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float* x = Xp + r * W;
+    const float* xt = Xt + r * W;
+    const float* ny = NYp + r * W;
+    const float* ly = NYt + r * W;
+    const float iw = 1.0f / W;
+    float mean = 0.f, meant = 0.f;
+    if (ln) {
+        float s = 0.f, st = 0.f;
+        for (int k = lane; k < W; k += 64) { s += x[k]; st += xt[k]; }
+        mean = wave_sum(s) * iw;
+        meant = wave_sum(st) * iw;
+    }
+    float s2 = 0.f, s3 = 0.f;
+    for (int k = lane; k < W; k += 64) {
+        const float c = x[k] - mean;
+        s2 += c * c;
+        s3 += c * (xt[k] - meant);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) * iw + eps);
+    const float m = rstd * wave_sum(s3) * iw;
+    // s_q = mean(q xhat), rbar = sum q xhat' / rstd, with p = gamma nu_y, q = gamma lambda_y
+    float a_sq = 0.f, a_rb = 0.f;
+    for (int k = lane; k < W; k += 64) {
+        const float xh = (x[k] - mean) * rstd, cd = xt[k] - meant, q = gamma[k] * ly[k];
+        a_sq += q * xh;
+        a_rb += q * (cd - xh * m);   // = q xhat' / rstd
+    }
+    const float sq = wave_sum(a_sq) * iw, rb = wave_sum(a_rb);
+    // xhat_bar = p - rstd (m q + s_q c');  t1 = mean(xhat_bar xhat)
+    float a_t1 = 0.f;
+    for (int k = lane; k < W; k += 64) {
+        const float xh = (x[k] - mean) * rstd, cd = xt[k] - meant;
+        const float xb = gamma[k] * ny[k] - rstd * (m * gamma[k] * ly[k] + sq * cd);
+        a_t1 += xb * xh;
+    }
+    const float t1 = wave_sum(a_t1) * iw;
+    const float coef = rstd * rb * iw + t1;
+    // c_bar = rstd xhat_bar - rstd xhat coef;  c'_bar = rstd (q - xhat s_q);  LayerNorm: minus their means
+    float a_cb = 0.f, a_cdb = 0.f;
+    if (ln) {
+        for (int k = lane; k < W; k += 64) {
+            const float xh = (x[k] - mean) * rstd, cd = xt[k] - meant, q = gamma[k] * ly[k];
+            const float xb = gamma[k] * ny[k] - rstd * (m * q + sq * cd);
+            a_cb += rstd * xb - rstd * xh * coef;
+            a_cdb += rstd * (q - xh * sq);
+        }
+        a_cb = wave_sum(a_cb) * iw;
+        a_cdb = wave_sum(a_cdb) * iw;
+    }
+    for (int k = lane; k < W; k += 64) {
+        const float xh = (x[k] - mean) * rstd, cd = xt[k] - meant, q = gamma[k] * ly[k];
+        const float xb = gamma[k] * ny[k] - rstd * (m * q + sq * cd);
+        const float cb = rstd * xb - rstd * xh * coef - a_cb;
+        const float cdb = rstd * (q - xh * sq) - a_cdb;
+        if (acc) { NXp[r * W + k] += cb; NXt[r * W + k] += cdb; }
+        else { NXp[r * W + k] = cb; NXt[r * W + k] = cdb; }
+        if (G) G[r * W + k] = ny[k] * xh + ly[k] * rstd * (cd - xh * m);
+    }
+}
+
+// silu: s = a sig(a), s' = silu'(a) a'
+__global__ void k_gt_silu(const float* __restrict__ Ap, const float* __restrict__ At, float* __restrict__ Sp,
+                          float* __restrict__ St, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float a = Ap[idx], s = gsig(a);
+    Sp[idx] = a * s;
+    St[idx] = s * (1.f + a * (1.f - s)) * At[idx];
+}
+// nu_a = nu_s silu' + lambda_s silu'' a';  lambda_a = lambda_s silu'   (in place on the adjoint allowed)
+__global__ void k_gt_silu_rev(const float* __restrict__ Ap, const float* __restrict__ At, const float* __restrict__ NSp,
+                              const float* __restrict__ NSt, float* __restrict__ NAp, float* __restrict__ NAt, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float a = Ap[idx], s = gsig(a);
+    const float d1 = s * (1.f + a * (1.f - s)), d2 = s * (1.f - s) * (2.f + a * (1.f - 2.f * s));
+    const float ns = NSp[idx], ls = NSt[idx];
+    NAp[idx] = ns * d1 + ls * d2 * At[idx];
+    NAt[idx] = ls * d1;
+}
+// SwiGLU: S = v sig(g), S' = v' sig + v sig' g'
+__global__ void k_gt_swiglu(const float* __restrict__ VGp, const float* __restrict__ VGt, float* __restrict__ Sp,
+                            float* __restrict__ St, int64_t R, int F) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * F) return;
+    const int64_t r = idx / F;
+    const int k = (int)(idx % F);
+    const float v = VGp[r * 2 * F + k], g = VGp[r * 2 * F + F + k], vd = VGt[r * 2 * F + k], gd = VGt[r * 2 * F + F + k];
+    const float s = gsig(g), s1 = s * (1.f - s);
+    Sp[idx] = v * s;
+    St[idx] = vd * s + v * s1 * gd;
+}
+__global__ void k_gt_swiglu_rev(const float* __restrict__ VGp, const float* __restrict__ VGt, const float* __restrict__ NSp,
+                                const float* __restrict__ NSt, float* __restrict__ NVGp, float* __restrict__ NVGt, int64_t R,
+                                int F) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * F) return;
+    const int64_t r = idx / F;
+    const int k = (int)(idx % F);
+    const float v = VGp[r * 2 * F + k], g = VGp[r * 2 * F + F + k], vd = VGt[r * 2 * F + k], gd = VGt[r * 2 * F + F + k];
+    const float s = gsig(g), s1 = s * (1.f - s), s2 = s1 * (1.f - 2.f * s);
+    const float nu = NSp[idx], la = NSt[idx];
+    NVGp[r * 2 * F + k] = nu * s + la * s1 * gd;
+    NVGp[r * 2 * F + F + k] = nu * v * s1 + la * (vd * s1 + v * s2 * gd);
+    NVGt[r * 2 * F + k] = la * s;
+    NVGt[r * 2 * F + F + k] = la * v * s1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention on dual tokens
+// ---------------------------------------------------------------------------------------------
+template <int HDM>
+__global__ __launch_bounds__(64) void k_gt_attn(const float* __restrict__ Qp, const float* __restrict__ Qt,
+                                                const int* __restrict__ rowptr, const float* __restrict__ fc,
+                                                const float* __restrict__ bd, float* __restrict__ AOp,
+                                                float* __restrict__ AOt, float* __restrict__ LSE, float* __restrict__ MS,
+                                                int64_t E, int D, int NH, int HD, float scale) {
+    const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int p0 = rowptr[i], T = rowptr[i + 1] - p0 + 1;
+    const int64_t ld = 3 * (int64_t)D;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int tq = t0 + lane;
+        if (tq >= T) continue;
+        const int64_t rq = tq == 0 ? E + i : (int64_t)p0 + tq - 1;
+        float q[HDM], qd[HDM], A0[HDM], A1[HDM], A2[HDM];
+#pragma unroll
+        for (int d = 0; d < HDM; d++) {
+            q[d] = d < HD ? Qp[rq * ld + h * HD + d] * scale : 0.f;
+            qd[d] = d < HD ? Qt[rq * ld + h * HD + d] * scale : 0.f;
+            A0[d] = 0.f; A1[d] = 0.f; A2[d] = 0.f;
+        }
+        float mx = -INFINITY, l = 0.f, sda = 0.f;
+        for (int tk = 0; tk < T; tk++) {
+            const int64_t rk = tk == 0 ? E + i : (int64_t)p0 + tk - 1;
+            const float* kp = Qp + rk * ld + D + h * HD;
+            const float* kt = Qt + rk * ld + D + h * HD;
+            const float* vp = Qp + rk * ld + 2 * D + h * HD;
+            const float* vt = Qt + rk * ld + 2 * D + h * HD;
+            float s = tk == 0 ? 0.f : logf(fmaxf(fc[p0 + tk - 1], 1e-15f));
+            float sd = tk == 0 ? 0.f : bd[p0 + tk - 1];
+#pragma unroll
+            for (int d = 0; d < HDM; d++)
+                if (d < HD) { s = fmaf(q[d], kp[d], s); sd = fmaf(qd[d], kp[d], fmaf(q[d], kt[d], sd)); }
+            const float mn = fmaxf(mx, s), c = expf(mx - mn), p = expf(s - mn);
+            l = l * c + p;
+            sda = sda * c + p * sd;
+#pragma unroll
+            for (int d = 0; d < HDM; d++)
+                if (d < HD) {
+                    A0[d] = A0[d] * c + p * vp[d];
+                    A1[d] = A1[d] * c + p * sd * vp[d];
+                    A2[d] = A2[d] * c + p * vt[d];
+                }
+            mx = mn;
+        }
+        const float il = 1.0f / l, m = sda * il;
+#pragma unroll
+        for (int d = 0; d < HDM; d++)
+            if (d < HD) {
+                AOp[rq * D + h * HD + d] = A0[d] * il;
+                AOt[rq * D + h * HD + d] = (A1[d] - m * A0[d] + A2[d]) * il;
+            }
+        LSE[rq * NH + h] = mx + logf(l);
+        MS[rq * NH + h] = m;
+    }
+}
+
+// pass Q (lanes = queries): c_i = sum_k p_ik (B_i . v_k), d_i = sum_k p_ik pbar_ik, then (nu_q, lambda_q)
+template <int HDM>
+__global__ __launch_bounds__(64) void k_gt_attn_rev_q(const float* __restrict__ Qp, const float* __restrict__ Qt,
+                                                      const float* __restrict__ NOp, const float* __restrict__ NOt,
+                                                      const float* __restrict__ LSE, const float* __restrict__ MS,
+                                                      const int* __restrict__ rowptr, const float* __restrict__ fc,
+                                                      const float* __restrict__ bd, float* __restrict__ NQp,
+                                                      float* __restrict__ NQt, float* __restrict__ CC, float* __restrict__ DD,
+                                                      int64_t E, int D, int NH, int HD, float scale) {
+    const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int p0 = rowptr[i], T = rowptr[i + 1] - p0 + 1;
+    const int64_t ld = 3 * (int64_t)D;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int tq = t0 + lane;
+        if (tq >= T) continue;
+        const int64_t rq = tq == 0 ? E + i : (int64_t)p0 + tq - 1;
+        float q[HDM], qd[HDM], A[HDM], B[HDM], qb[HDM], qdb[HDM];
+#pragma unroll
+        for (int d = 0; d < HDM; d++) {
+            q[d] = d < HD ? Qp[rq * ld + h * HD + d] * scale : 0.f;
+            qd[d] = d < HD ? Qt[rq * ld + h * HD + d] * scale : 0.f;
+            A[d] = d < HD ? NOp[rq * D + h * HD + d] : 0.f;
+            B[d] = d < HD ? NOt[rq * D + h * HD + d] : 0.f;
+            qb[d] = 0.f; qdb[d] = 0.f;
+        }
+        const float lse = LSE[rq * NH + h], m = MS[rq * NH + h];
+        float cc = 0.f, dd = 0.f;
+        for (int pass = 0; pass < 3; pass++) {
+            for (int tk = 0; tk < T; tk++) {
+                const int64_t rk = tk == 0 ? E + i : (int64_t)p0 + tk - 1;
+                const float* kp = Qp + rk * ld + D + h * HD;
+                const float* kt = Qt + rk * ld + D + h * HD;
+                const float* vp = Qp + rk * ld + 2 * D + h * HD;
+                const float* vt = Qt + rk * ld + 2 * D + h * HD;
+                float s = tk == 0 ? 0.f : logf(fmaxf(fc[p0 + tk - 1], 1e-15f));
+                float sd = tk == 0 ? 0.f : bd[p0 + tk - 1];
+                float pdb = 0.f, av = 0.f, bvd = 0.f;
+#pragma unroll
+                for (int d = 0; d < HDM; d++)
+                    if (d < HD) {
+                        s = fmaf(q[d], kp[d], s);
+                        sd = fmaf(qd[d], kp[d], fmaf(q[d], kt[d], sd));
+                        pdb = fmaf(B[d], vp[d], pdb);
+                        av = fmaf(A[d], vp[d], av);
+                        bvd = fmaf(B[d], vt[d], bvd);
+                    }
+                const float p = expf(s - lse);
+                if (pass == 0) { cc += p * pdb; continue; }
+                const float pb = av + bvd + pdb * (sd - m) - sd * cc;
+                if (pass == 1) { dd += p * pb; continue; }
+                const float sb = p * (pb - dd), sdb = p * (pdb - cc);
+#pragma unroll
+                for (int d = 0; d < HDM; d++)
+                    if (d < HD) {
+                        qb[d] = fmaf(sb, kp[d], fmaf(sdb, kt[d], qb[d]));
+                        qdb[d] = fmaf(sdb, kp[d], qdb[d]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < HDM; d++)
+            if (d < HD) { NQp[rq * ld + h * HD + d] = qb[d] * scale; NQt[rq * ld + h * HD + d] = qdb[d] * scale; }
+        CC[rq * NH + h] = cc;
+        DD[rq * NH + h] = dd;
+    }
+}
+
+// pass K (lanes = keys): (nu, lambda) of k and v
+template <int HDM>
+__global__ __launch_bounds__(64) void k_gt_attn_rev_k(const float* __restrict__ Qp, const float* __restrict__ Qt,
+                                                      const float* __restrict__ NOp, const float* __restrict__ NOt,
+                                                      const float* __restrict__ LSE, const float* __restrict__ MS,
+                                                      const float* __restrict__ CC, const float* __restrict__ DD,
+                                                      const int* __restrict__ rowptr, const float* __restrict__ fc,
+                                                      const float* __restrict__ bd, float* __restrict__ NQp,
+                                                      float* __restrict__ NQt, int64_t E, int D, int NH, int HD,
+                                                      float scale) {
+    const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int p0 = rowptr[i], T = rowptr[i + 1] - p0 + 1;
+    const int64_t ld = 3 * (int64_t)D;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int tk = t0 + lane;
+        if (tk >= T) continue;
+        const int64_t rk = tk == 0 ? E + i : (int64_t)p0 + tk - 1;
+        float k[HDM], kd[HDM], v[HDM], vd[HDM], kb[HDM], kdb[HDM], vb[HDM], vdb[HDM];
+#pragma unroll
+        for (int d = 0; d < HDM; d++) {
+            k[d] = d < HD ? Qp[rk * ld + D + h * HD + d] : 0.f;
+            kd[d] = d < HD ? Qt[rk * ld + D + h * HD + d] : 0.f;
+            v[d] = d < HD ? Qp[rk * ld + 2 * D + h * HD + d] : 0.f;
+            vd[d] = d < HD ? Qt[rk * ld + 2 * D + h * HD + d] : 0.f;
+            kb[d] = 0.f; kdb[d] = 0.f; vb[d] = 0.f; vdb[d] = 0.f;
+        }
+        const float bias = tk == 0 ? 0.f : logf(fmaxf(fc[p0 + tk - 1], 1e-15f));
+        const float biasd = tk == 0 ? 0.f : bd[p0 + tk - 1];
+        for (int tq = 0; tq < T; tq++) {
+            const int64_t rq = tq == 0 ? E + i : (int64_t)p0 + tq - 1;
+            const float* qp = Qp + rq * ld + h * HD;
+            const float* qt = Qt + rq * ld + h * HD;
+            const float* ap = NOp + rq * D + h * HD;
+            const float* bp = NOt + rq * D + h * HD;
+            float s = 0.f, sd = 0.f, pdb = 0.f, av = 0.f, bvd = 0.f;
+#pragma unroll
+            for (int d = 0; d < HDM; d++)
+                if (d < HD) {
+                    s = fmaf(qp[d], k[d], s);
+                    sd = fmaf(qt[d], k[d], fmaf(qp[d], kd[d], sd));
+                    pdb = fmaf(bp[d], v[d], pdb);
+                    av = fmaf(ap[d], v[d], av);
+                    bvd = fmaf(bp[d], vd[d], bvd);
+                }
+            s = s * scale + bias;
+            sd = sd * scale + biasd;
+            const float m = MS[rq * NH + h], cc = CC[rq * NH + h], dq = DD[rq * NH + h];
+            const float p = expf(s - LSE[rq * NH + h]);
+            const float pb = av + bvd + pdb * (sd - m) - sd * cc;
+            const float sb = p * (pb - dq) * scale, sdb = p * (pdb - cc) * scale, pd = p * (sd - m);
+#pragma unroll
+            for (int d = 0; d < HDM; d++)
+                if (d < HD) {
+                    kb[d] = fmaf(sb, qp[d], fmaf(sdb, qt[d], kb[d]));
+                    kdb[d] = fmaf(sdb, qp[d], kdb[d]);
+                    vb[d] = fmaf(p, ap[d], fmaf(pd, bp[d], vb[d]));
+                    vdb[d] = fmaf(p, bp[d], vdb[d]);
+                }
+        }
+#pragma unroll
+        for (int d = 0; d < HDM; d++)
+            if (d < HD) {
+                NQp[rk * ld + D + h * HD + d] = kb[d];
+                NQt[rk * ld + D + h * HD + d] = kdb[d];
+                NQp[rk * ld + 2 * D + h * HD + d] = vb[d];
+                NQt[rk * ld + 2 * D + h * HD + d] = vdb[d];
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradients: G[o][i] = sum_r (A0[r][o] B0[r][i] + A1[r][o] B1[r][i]), rows split into chunks, partials summed by
+// k_gt_reduce in chunk order
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gt_wgrad(const float* __restrict__ A0, const float* __restrict__ B0,
+                                                  const float* __restrict__ A1, const float* __restrict__ B1, int64_t lda,
+                                                  int64_t ldb, int64_t R, int NO, int KI, int64_t per,
+                                                  float* __restrict__ part) {
+    __shared__ float As[16][65], Bs[16][65];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int o0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int64_t lo = (int64_t)blockIdx.z * per, hi = lo + per < R ? lo + per : R;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0.f;
+    for (int seg = 0; seg < 2; seg++) {
+        const float* A = seg ? A1 : A0;
+        const float* B = seg ? B1 : B0;
+        if (!A) continue;
+        for (int64_t r0 = lo; r0 < hi; r0 += 16) {
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
+                const int rr = idx >> 6, cc = idx & 63;
+                const int64_t r = r0 + rr;
+                As[rr][cc] = (r < hi && o0 + cc < NO) ? A[r * lda + o0 + cc] : 0.f;
+                Bs[rr][cc] = (r < hi && i0 + cc < KI) ? B[r * ldb + i0 + cc] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 16; rr++) {
+                float a[4], b[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { a[q] = As[rr][ty + 16 * q]; b[q] = Bs[rr][tx + 16 * q]; }
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+#pragma unroll
+                    for (int y = 0; y < 4; y++) acc[x][y] = fmaf(a[x], b[y], acc[x][y]);
+            }
+        }
+    }
+    float* out = part + (size_t)blockIdx.z * NO * KI;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const int o = o0 + ty + 16 * x;
+        if (o >= NO) continue;
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const int i = i0 + tx + 16 * y;
+            if (i < KI) out[(size_t)o * KI + i] = acc[x][y];
+        }
+    }
+}
+// column sums of A [R][W] (bias gradients, norm weight gradients from a per-row product buffer): partial per chunk
+__global__ void k_gt_colsum(const float* __restrict__ A, int64_t lda, int64_t R, int W, int64_t per, float* __restrict__ part) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= W) return;
+    const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < R ? lo + per : R;
+    double s = 0.0;   // bias gradients are sums of signed adjoints that largely cancel
+    for (int64_t r = lo; r < hi; r++) s += (double)A[r * lda + k];
+    part[(size_t)blockIdx.y * W + k] = (float)s;
+}
+__global__ void k_gt_reduce(const float* __restrict__ part, int n_chunks, int64_t n, float* __restrict__ dst) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    double s = 0.0;
+    for (int c = 0; c < n_chunks; c++) s += (double)part[(size_t)c * n + idx];
+    dst[idx] += (float)s;
+}
+// embedding gradients: part[chunk][index[r]][k] += X[r][k] (one thread per column: no races), reduced like the others
+__global__ void k_gt_embed_grad(const int* __restrict__ index, const float* __restrict__ X, int64_t ldx, int64_t R, int W,
+                                int ns, int64_t per, float* __restrict__ part) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= W) return;
+    const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < R ? lo + per : R;
+    float* out = part + (size_t)blockIdx.y * ns * W;
+    for (int s = 0; s < ns; s++) out[(size_t)s * W + k] = 0.f;
+    for (int64_t r = lo; r < hi; r++) out[(size_t)index[r] * W + k] += X[r * ldx + k];
+}
+
+// heads: e_i = np_i + sum_e fc_e ep_e,  e'_i = np'_i + sum_e (fc'_e ep_e + fc_e ep'_e)  (accumulated over readout layers)
+__global__ void k_gt_atom_sum(const float* __restrict__ npp, const float* __restrict__ npt, const float* __restrict__ epp,
+                              const float* __restrict__ ept, const float* __restrict__ fc, const float* __restrict__ fcd,
+                              const int* __restrict__ rowptr, float* __restrict__ tangent, int acc, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float st = npt[i];
+    for (int e = rowptr[i]; e < rowptr[i + 1]; e++) st += fcd[e] * epp[e] + fc[e] * ept[e];
+    (void)npp;
+    if (acc) tangent[i] += st;
+    else tangent[i] = st;
+}
+// seeds: nu_np = nA, lambda_np = lA;  nu_ep = nA fc + lA fc',  lambda_ep = lA fc
+__global__ void k_gt_seeds(const float* __restrict__ nA, const float* __restrict__ lA, const int* __restrict__ ctr,
+                           const float* __restrict__ fc, const float* __restrict__ fcd, float* __restrict__ nnp,
+                           float* __restrict__ lnp, float* __restrict__ nep, float* __restrict__ lep, int64_t N, int64_t E) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < N) { nnp[idx] = nA ? nA[idx] : 0.f; lnp[idx] = lA ? lA[idx] : 0.f; }
+    if (idx < E) {
+        const int64_t i = ctr[idx];
+        const float n = nA ? nA[i] : 0.f, l = lA ? lA[i] : 0.f;
+        nep[idx] = n * fc[idx] + l * fcd[idx];
+        lep[idx] = l * fc[idx];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace of the pass
+// ---------------------------------------------------------------------------------------------
+struct TAttn {
+    D2 X, QKV, AO, X1, VG, T1, S2, TOKo, H, H1, VGn, Hn;
+    float *LSE, *MS;
+};
+struct TGnn {
+    std::vector<TAttn> attn;
+    D2 TOK, a0, XF, CA, Mout, Hin, Hout;
+};
+struct TWs {
+    std::vector<TGnn> gnn;
+    D2 H0, M0, geo;
+    float *fcd, *bd;
+    D2 tE[5], tN[4];          // temporaries [R][wmax] / [N][nmax]
+    D2 dX, dX2, dM, dH, dQKV; // adjoints
+    float *CC, *DD, *part;
+    size_t part_floats;
+    size_t bytes;
+};
+static D2 take2(Carver& c, size_t n) {
+    D2 d;
+    d.p = c.take<float>(n);
+    d.t = c.take<float>(n);
+    return d;
+}
+static int n_chunks_for(int64_t rows) { return (int)std::min<int64_t>(32, std::max<int64_t>(1, (rows + 1023) / 1024)); }
+static void train_carve(const Model& m, int64_t N, int64_t E, void* base, TWs& w) {
+    const GD d = dims_of(m);
+    Carver c(base);
+    const int64_t R = E + N, Ra = R > 0 ? R : 1, Na = N > 0 ? N : 1, Ea = E > 0 ? E : 1;
+    const bool post = m.post_ln();
+    w.gnn.resize(m.h.num_gnn_layers);
+    w.H0 = take2(c, Na * d.DN);
+    w.M0 = take2(c, Ea * d.D);
+    w.geo = take2(c, Ea * 4);
+    w.fcd = c.take<float>(Ea);
+    w.bd = c.take<float>(Ea);
+    D2 prev = w.H0;
+    for (size_t gi = 0; gi < w.gnn.size(); gi++) {
+        TGnn& G = w.gnn[gi];
+        G.attn.resize(m.h.num_attention_layers);
+        G.TOK = take2(c, Ea * 3 * d.D);
+        G.a0 = take2(c, Ea * d.D);
+        G.XF = take2(c, Ea * d.D);
+        G.CA = take2(c, Ea * 2 * d.D);
+        G.Mout = take2(c, Ea * d.D);
+        if (m.residual() && gi > 0) prev = take2(c, Na * d.DN);
+        G.Hin = prev;
+        for (auto& A : G.attn) {
+            A.X = take2(c, Ra * d.D);
+            A.QKV = take2(c, Ra * 3 * d.D);
+            A.AO = take2(c, Ra * d.D);
+            A.LSE = c.take<float>(Ra * d.NH);
+            A.MS = c.take<float>(Ra * d.NH);
+            A.X1 = take2(c, Ra * d.D);
+            A.VG = take2(c, Ra * 2 * d.DFF);
+            if (post) { A.T1 = take2(c, Ra * d.D); A.S2 = take2(c, Ra * d.D); }
+            A.TOKo = take2(c, Na * d.D);
+            A.H = prev;
+            if (d.expanded) { A.H1 = take2(c, Na * d.DN); A.VGn = take2(c, Na * 2 * d.DNF); }
+            A.Hn = take2(c, Na * d.DN);
+            prev = A.Hn;
+        }
+        G.Hout = prev;
+    }
+    const int wmax = imax(imax(3 * d.D, 2 * d.DFF), imax(2 * d.D, d.DH));
+    const int nmax = imax(imax(2 * d.DNF, d.DN), imax(d.DH, d.D));
+    for (auto& t : w.tE) t = take2(c, Ra * wmax);
+    for (auto& t : w.tN) t = take2(c, Na * nmax);
+    w.dX = take2(c, Ra * d.D); w.dX2 = take2(c, Ra * d.D);
+    w.dM = take2(c, Ea * d.D); w.dH = take2(c, Na * d.DN);
+    w.dQKV = take2(c, Ra * 3 * d.D);
+    w.CC = c.take<float>(Ra * d.NH);
+    w.DD = c.take<float>(Ra * d.NH);
+    // partial sums of the largest weight gradient (and of the embedding tables)
+    size_t big = (size_t)imax(4 * d.DN * d.DN, imax(2 * d.DFF * d.D, imax(4 * d.D * d.D, 3 * d.D * d.D)));
+    big = std::max(big, (size_t)imax(d.DH * d.DN, d.DH * d.DH));
+    big = std::max(big, (size_t)m.h.n_species * imax(d.DN, d.D));
+    w.part_floats = big * 32;
+    w.part = c.take<float>(w.part_floats);
+    w.bytes = c.off;
+}
+
+struct TOps {
+    const Model& m;
+    const Graph& g;
+    GD d;
+    hipStream_t st;
+    Lins lin;
+    Ops o;
+    TWs* w;
+    std::map<const float*, int64_t> off;   // raw parameter storage -> offset in the flat gradient
+    int err = PET_OK;
+    TOps(const Model& m_, const Graph& g_, hipStream_t s, TWs* w_) : m(m_), g(g_), d(dims_of(m_)), st(s), lin{s}, o(m_, g_, s), w(w_) {
+        for (const auto& kv : m.raw) {
+            auto it = m.grad_off.find(kv.first);
+            if (it != m.grad_off.end()) off[kv.second.first] = it->second;
+        }
+    }
+    float* slot(const float* raw) {
+        auto it = off.find(raw);
+        if (it == off.end()) { err = PET_ERR_ARGUMENT; set_error("gen_train: a parameter has no gradient slot"); return nullptr; }
+        return m.grad_flat + it->second;
+    }
+    float eps() const { return m.layer_norm() ? 1e-5f : 1.1920929e-07f; }
+    // ---- dual forward pieces
+    void linf(const D2& X, int64_t ldx, const Lin& L, const D2& Y, int64_t ldy, int64_t rows, bool acc = false) const {
+        if (rows <= 0) return;
+        lin.fwd(X.p, ldx, L, Y.p, ldy, rows, acc);
+        Lin nb = L;
+        nb.b = nullptr;   // the tangent of a Linear has no bias
+        lin.fwd(X.t, ldx, nb, Y.t, ldy, rows, acc);
+    }
+    void norm(const D2& X, const float* gamma, const float* beta, const D2& Y, int64_t rows, int W, int ln = -1, float e = -1.f) const {
+        if (rows <= 0) return;
+        const int l = ln < 0 ? (int)m.layer_norm() : ln;
+        k_gt_norm<<<(int)cdiv(rows, 4), 256, 0, st>>>(X.p, X.t, gamma, l ? beta : nullptr, l, e < 0 ? eps() : e, Y.p, Y.t, rows, W);
+    }
+    void silu(const D2& A, const D2& S, int64_t n) const { if (n > 0) k_gt_silu<<<g1(n), 256, 0, st>>>(A.p, A.t, S.p, S.t, n); }
+    void swiglu(const D2& VG, const D2& S, int64_t rows, int F) const {
+        if (rows > 0) k_gt_swiglu<<<g1(rows * F), 256, 0, st>>>(VG.p, VG.t, S.p, S.t, rows, F);
+    }
+    void axpby(float a, const D2& A, int64_t lda, float b, const D2& B, int64_t ldb, const int* index, const D2& Y, int64_t ldy,
+               bool acc, int64_t rows, int W) const {
+        o.axpby(a, A.p, lda, b, B.p, ldb, index, Y.p, ldy, acc, rows, W);
+        o.axpby(a, A.t, lda, b, B.t, ldb, index, Y.t, ldy, acc, rows, W);
+    }
+    void copy(const D2& A, const D2& Y, int64_t rows, int W) const { axpby(1.f, A, W, 0.f, D2(), 0, nullptr, Y, W, false, rows, W); }
+    void zero(const D2& A, int64_t n) const {
+        if (n <= 0) return;
+        (void)hipMemsetAsync(A.p, 0, n * sizeof(float), st);
+        (void)hipMemsetAsync(A.t, 0, n * sizeof(float), st);
+    }
+    // Y = base + w_out(swiglu(w_in(normed ? norm(X) : X))); VG saved
+    void ffn(const D2& Xin, bool normed, const float* gamma, const float* beta, const Lin& w_in, const Lin& w_out, const D2& VG,
+             const D2& base, const D2& Y, const D2& tA, const D2& tB, int64_t rows, int W, int F) const {
+        D2 Nn = Xin;
+        if (normed) { norm(Xin, gamma, beta, tA, rows, W); Nn = tA; }
+        linf(Nn, W, w_in, VG, 2 * F, rows);
+        swiglu(VG, tB, rows, F);
+        if (base.p != Y.p) copy(base, Y, rows, W);
+        linf(tB, F, w_out, Y, W, rows, true);
+    }
+    // ---- reverse pieces
+    void chunked(int64_t rows, int& nc, int64_t& per) const {
+        nc = n_chunks_for(rows);
+        per = (rows + nc - 1) / nc;
+    }
+    // dW += nu_y^T x + lambda_y^T x', db += colsum(nu_y)
+    void wgrad(const Lin& L, const D2& NY, int64_t ldy, const D2& X, int64_t ldx, int64_t rows) {
+        if (rows <= 0 || err) return;
+        int nc; int64_t per;
+        chunked(rows, nc, per);
+        float* gw = slot(L.w);
+        if (!gw) return;
+        dim3 grid((unsigned)cdiv(L.n_out, 64), (unsigned)cdiv(L.k_in, 64), (unsigned)nc);
+        k_gt_wgrad<<<grid, 256, 0, st>>>(NY.p, X.p, NY.t, X.t, ldy, ldx, rows, L.n_out, L.k_in, per, w->part);
+        const int64_t n = (int64_t)L.n_out * L.k_in;
+        k_gt_reduce<<<g1(n), 256, 0, st>>>(w->part, nc, n, gw);
+        if (L.b) colsum(NY.p, ldy, rows, L.n_out, slot(L.b));
+    }
+    void colsum(const float* A, int64_t lda, int64_t rows, int W, float* dst) {
+        if (rows <= 0 || !dst) return;
+        int nc; int64_t per;
+        chunked(rows, nc, per);
+        k_gt_colsum<<<dim3((unsigned)cdiv(W, 64), (unsigned)nc), 64, 0, st>>>(A, lda, rows, W, per, w->part);
+        k_gt_reduce<<<g1(W), 256, 0, st>>>(w->part, nc, W, dst);
+    }
+    void embed_grad(const int* index, const float* NU, int64_t ld, int64_t rows, int W, const float* table) {
+        if (rows <= 0 || err) return;
+        float* dst = slot(table);
+        if (!dst) return;
+        int nc; int64_t per;
+        chunked(rows, nc, per);
+        const int ns = m.h.n_species;
+        k_gt_embed_grad<<<dim3((unsigned)cdiv(W, 64), (unsigned)nc), 64, 0, st>>>(index, NU, ld, rows, W, ns, per, w->part);
+        k_gt_reduce<<<g1((int64_t)ns * W), 256, 0, st>>>(w->part, nc, (int64_t)ns * W, dst);
+    }
+    // (nu_x, lambda_x) (+)= W^T (nu_y, lambda_y)
+    void linb(const D2& NY, int64_t ldy, const Lin& L, const D2& NX, int64_t ldx, int64_t rows, bool acc = false) const {
+        if (rows <= 0) return;
+        lin.bwd(NY.p, ldy, L, NX.p, ldx, rows, acc);
+        lin.bwd(NY.t, ldy, L, NX.t, ldx, rows, acc);
+    }
+    // norm reverse incl. the norm's own parameter gradients; G: scratch [rows][W]
+    void norm_rev(const D2& X, const float* gamma, const float* beta, const D2& NY, const D2& NX, bool acc, float* G, int64_t rows,
+                  int W, int ln = -1, float e = -1.f) {
+        if (rows <= 0) return;
+        const int l = ln < 0 ? (int)m.layer_norm() : ln;
+        k_gt_norm_rev<<<(int)cdiv(rows, 4), 256, 0, st>>>(X.p, X.t, gamma, l, e < 0 ? eps() : e, NY.p, NY.t, NX.p, NX.t, acc, G, rows, W);
+        colsum(G, W, rows, W, slot(gamma));
+        if (l && beta) colsum(NY.p, W, rows, W, slot(beta));
+    }
+    // adjoint of the FFN branch (not of the residual path): NIn (+)= ..., parameter gradients added
+    void ffn_rev(const D2& Xin, bool normed, const float* gamma, const float* beta, const Lin& w_in, const Lin& w_out, const D2& VG,
+                 const D2& NY, const D2& NIn, bool acc, const D2& tA, const D2& tB, const D2& tC, int64_t rows, int W, int F) {
+        // recompute N (input of w_in) and S (input of w_out)
+        D2 Nn = Xin;
+        if (normed) { norm(Xin, gamma, beta, tC, rows, W); Nn = tC; }
+        swiglu(VG, tA, rows, F);
+        wgrad(w_out, NY, W, tA, F, rows);
+        linb(NY, W, w_out, tA, F, rows);                                           // (nu, lambda) of S
+        if (rows > 0) k_gt_swiglu_rev<<<g1(rows * F), 256, 0, st>>>(VG.p, VG.t, tA.p, tA.t, tB.p, tB.t, rows, F);  // of VG
+        wgrad(w_in, tB, 2 * F, Nn, W, rows);
+        if (normed) {
+            linb(tB, 2 * F, w_in, tA, W, rows);                                    // of N
+            norm_rev(Xin, gamma, beta, tA, NIn, acc, tC.p, rows, W);
+        } else
+            linb(tB, 2 * F, w_in, NIn, W, rows, acc);
+    }
+};
+
+}  // namespace
+
+int64_t gen_train_workspace_bytes(const Model& m, int64_t N, int64_t E) {
+    TWs w;
+    train_carve(m, N, E, nullptr, w);
+    return (int64_t)w.bytes;
+}
+
+// dL/d theta of J = sum_i (nu_i e_i + lambda_i e'_i) ADDED to the flat gradient; tangent_atomic [N] = e'_i (optional).
+// nA / lA may be null (zero). u null = no tangent (energy-only loss).
+int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, const float* lA, const float* nA, const float* u,
+               const float* ucell, float* tangent_atomic, hipStream_t st) {
+    PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
+    PET_REQUIRE(!m.h.system_conditioning, PET_ERR_UNSUPPORTED,
+                "training of a conditioned model is built for the compiled model size, PreLN, feedforward only");
+    PET_REQUIRE(!g.adaptive, PET_ERR_UNSUPPORTED,
+                "training with the adaptive cutoff is built for the compiled model size, PreLN, feedforward only");
+    TWs w;
+    train_carve(m, g.n_nodes, g.n_edges, ws2, w);
+    PET_REQUIRE((int64_t)w.bytes <= ws2_bytes, PET_ERR_ARGUMENT, "second-order workspace too small");
+    TOps t(m, g, st, &w);
+    const GD& d = t.d;
+    const int64_t N = g.n_nodes, E = g.n_edges, R = N + E;
+    if (N == 0) return PET_OK;
+    PET_REQUIRE(E > 0, PET_ERR_UNSUPPORTED, "training on a batch without any edge is not supported");
+    const int D = d.D, DN = d.DN;
+    const bool post = m.post_ln(), res = m.residual();
+    const float scale = 1.0f / (sqrtf((float)d.HD) * m.h.attention_temperature);
+    const int L = m.h.num_gnn_layers, AL = m.h.num_attention_layers, NR = m.num_readout_layers();
+    // the heads of the trained target, one per readout layer ("@": runtime.HipModel.load)
+    std::vector<const HeadW*> heads(NR);
+    std::vector<const LastW*> lasts(NR);
+    for (int l = 0; l < NR; l++) {
+        auto hi = m.heads.find("@|" + std::to_string(l));
+        auto li = m.lasts.find("@|" + std::to_string(l) + "|@");
+        PET_REQUIRE(hi != m.heads.end() && li != m.lasts.end() && li->second.P == 1, PET_ERR_ARGUMENT,
+                    "training needs the single-property target uploaded as the fused head of every readout layer");
+        heads[l] = &hi->second;
+        lasts[l] = &li->second;
+    }
+    // ---------------- sweep 1: dual forward ----------------
+    // geometry: primal = the graph's geo / fc, tangent along (u, ucell)
+    PET_HIP_CHECK(hipMemcpyAsync(w.geo.p, g.geo, E * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (u) {
+        PET_REQUIRE(!ucell || g.shift, PET_ERR_ARGUMENT, "a cell tangent needs a pet_graph_build handle (cell shifts)");
+        k_gt_geo<<<g1(E), 256, 0, st>>>(g.geo, g.d0, g.fc, g.ctr, g.nbr, g.shift, g.sys, u, ucell,
+                                        reinterpret_cast<float4*>(w.geo.t), w.fcd, w.bd, E, m.h.cutoff, m.h.cutoff_width,
+                                        m.h.cutoff_function);
+    } else {
+        PET_HIP_CHECK(hipMemsetAsync(w.geo.t, 0, E * 4 * sizeof(float), st));
+        PET_HIP_CHECK(hipMemsetAsync(w.fcd, 0, E * sizeof(float), st));
+        PET_HIP_CHECK(hipMemsetAsync(w.bd, 0, E * sizeof(float), st));
+    }
+    k_gen_embed<<<g1(N * DN), 256, 0, st>>>(g.sp, m.node_emb, w.H0.p, DN, N, DN);
+    PET_HIP_CHECK(hipMemsetAsync(w.H0.t, 0, N * DN * sizeof(float), st));
+    k_gen_embed<<<g1(E * D), 256, 0, st>>>(g.sp_nbr, m.edge_emb, w.M0.p, D, E, D);
+    PET_HIP_CHECK(hipMemsetAsync(w.M0.t, 0, E * D * sizeof(float), st));
+    D2 Min = w.M0;
+    for (int gi = 0; gi < L; gi++) {
+        const GnnLayerW& G = m.gnn[gi];
+        TGnn& B = w.gnn[gi];
+        if (res && gi > 0) {
+            k_gen_embed<<<g1(N * DN), 256, 0, st>>>(g.sp, m.node_embs[gi], B.Hin.p, DN, N, DN);
+            PET_HIP_CHECK(hipMemsetAsync(B.Hin.t, 0, N * DN * sizeof(float), st));
+        }
+        const int kin = (gi == 0 ? 2 : 3) * D;
+        t.linf(w.geo, 4, G.eemb, B.TOK, kin, E);
+        if (gi > 0) {
+            k_gen_embed<<<g1(E * D), 256, 0, st>>>(g.sp_nbr, G.nbr_emb, B.TOK.p + D, kin, E, D);
+            t.o.axpby(0.f, nullptr, 0, 0.f, nullptr, 0, nullptr, B.TOK.t + D, kin, false, E, D);
+        }
+        {
+            D2 dst{B.TOK.p + (gi == 0 ? D : 2 * D), B.TOK.t + (gi == 0 ? D : 2 * D)};
+            t.axpby(1.f, Min, D, 0.f, D2(), 0, nullptr, dst, kin, false, E, D);
+        }
+        t.linf(B.TOK, kin, G.c0, B.a0, D, E);
+        t.silu(B.a0, w.tE[1], E * D);
+        t.linf(w.tE[1], D, G.compress2, B.attn[0].X, D, E);
+        for (int a = 0; a < AL; a++) {
+            const AttnLayerW& A = G.attn[a];
+            TAttn& Ab = B.attn[a];
+            D2 Xnext = (a + 1 < AL) ? B.attn[a + 1].X : B.XF;
+            D2 Xc{Ab.X.p + E * D, Ab.X.t + E * D};
+            if (d.expanded) t.linf(Ab.H, DN, A.cc, Xc, D, N);
+            else t.copy(Ab.H, Xc, N, D);
+            D2 Xatt = Ab.X;
+            if (!post) { t.norm(Ab.X, A.g_attn, A.b_attn, w.tE[0], R, D); Xatt = w.tE[0]; }
+            t.linf(Xatt, D, A.qkv, Ab.QKV, 3 * D, R);
+            attn_dispatch(d.HD, [&](auto hdm) {
+                k_gt_attn<decltype(hdm)::value><<<dim3((unsigned)N, (unsigned)d.NH), 64, 0, st>>>(
+                    Ab.QKV.p, Ab.QKV.t, g.rowptr, g.fc, w.bd, Ab.AO.p, Ab.AO.t, Ab.LSE, Ab.MS, E, D, d.NH, d.HD, scale);
+            });
+            D2 OUT = w.tE[1];
+            t.linf(Ab.AO, D, A.out, OUT, D, R);
+            D2 OUTc{OUT.p + E * D, OUT.t + E * D};
+            if (!post) {
+                t.copy(OUTc, Ab.TOKo, N, D);
+                t.axpby(1.f, Ab.X, D, 1.f, OUT, D, nullptr, Ab.X1, D, false, E, D);
+                t.ffn(Ab.X1, true, A.g_mlp, A.b_mlp, A.mlp_in, A.mlp_out, Ab.VG, Ab.X1, Xnext, w.tE[0], w.tE[2], E, D, d.DFF);
+            } else {
+                t.axpby(1.f, Ab.X, D, 1.f, OUT, D, nullptr, Ab.X1, D, false, R, D);
+                t.norm(Ab.X1, A.g_attn, A.b_attn, Ab.T1, R, D);
+                t.ffn(Ab.T1, false, nullptr, nullptr, A.mlp_in, A.mlp_out, Ab.VG, Ab.T1, Ab.S2, w.tE[0], w.tE[2], R, D, d.DFF);
+                t.norm(Ab.S2, A.g_mlp, A.b_mlp, w.tE[0], R, D);
+                t.copy(w.tE[0], Xnext, E, D);
+                D2 T2c{w.tE[0].p + E * D, w.tE[0].t + E * D};
+                t.copy(T2c, Ab.TOKo, N, D);
+            }
+            if (d.expanded) {
+                t.copy(Ab.H, Ab.H1, N, DN);
+                t.linf(Ab.TOKo, D, A.ce, Ab.H1, DN, N, true);
+                t.ffn(Ab.H1, true, A.g_center, A.b_center, A.cmlp_in, A.cmlp_out, Ab.VGn, Ab.H1, Ab.Hn, w.tN[0], w.tN[1], N, DN, d.DNF);
+            } else
+                t.copy(Ab.TOKo, Ab.Hn, N, DN);
+        }
+        if (res) {
+            if (gi + 1 < L) t.axpby(0.5f, Min, D, 0.5f, B.XF, D, g.rev, B.Mout, D, false, E, D);
+        } else {
+            D2 CAT = w.tE[0];
+            t.axpby(1.f, B.XF, D, 0.f, D2(), 0, nullptr, CAT, 2 * D, false, E, D);
+            D2 CATr{CAT.p + D, CAT.t + D};
+            t.axpby(0.f, D2(), 0, 1.f, B.XF, D, g.rev, CATr, 2 * D, false, E, D);
+            t.norm(CAT, G.ln_g, G.ln_b, w.tE[1], E, 2 * D, 1, 1e-5f);
+            t.linf(w.tE[1], 2 * D, G.comb0, B.CA, 2 * D, E);
+            t.silu(B.CA, w.tE[2], E * 2 * D);
+            t.axpby(1.f, Min, D, 1.f, B.XF, D, nullptr, B.Mout, D, false, E, D);
+            t.linf(w.tE[2], 2 * D, G.comb2, B.Mout, D, E, true);
+        }
+        Min = B.Mout;
+    }
+    // ---------------- heads: tangent energies and the seeds of sweep 2 ----------------
+    // scratch per readout layer (recomputed in the reverse part): a1, s1, a2, s2 [rows][DH], predictions [rows]
+    const int DH = d.DH;
+    auto head_dual = [&](const Lin& h0, const Lin& h2, const D2& X, int W, int64_t rows, const D2& a1, const D2& s1, const D2& a2,
+                         const D2& s2) {
+        t.linf(X, W, h0, a1, DH, rows);
+        t.silu(a1, s1, rows * DH);
+        t.linf(s1, DH, h2, a2, DH, rows);
+        t.silu(a2, s2, rows * DH);
+    };
+    // adjoints entering the backbone from the heads, per readout layer: kept for the residual featuriser in dHl / dMl
+    std::vector<D2> dHl(NR), dMl(NR);
+    float* extra = nullptr;
+    {
+        size_t fl = 0;
+        if (NR > 1) fl = (size_t)NR * 2 * ((size_t)N * DN + (size_t)E * D);
+        fl += 2 * (size_t)(N + E) + 4 * (size_t)(N + E);   // predictions (dual) and their adjoints
+        PET_HIP_CHECK(hipMallocAsync((void**)&extra, fl * sizeof(float), st));
+    }
+    float* ex = extra;
+    D2 npred{ex, ex + N}; ex += 2 * N;
+    D2 epred{ex, ex + E}; ex += 2 * E;
+    D2 nnp{ex, ex + N}; ex += 2 * N;
+    D2 nep{ex, ex + E}; ex += 2 * E;
+    for (int l = 0; l < NR; l++) {
+        if (NR > 1) {
+            dHl[l] = D2{ex, ex + N * DN}; ex += 2 * N * DN;
+            dMl[l] = D2{ex, ex + E * D}; ex += 2 * E * D;
+        } else { dHl[l] = w.dH; dMl[l] = w.dM; }
+    }
+    k_gt_seeds<<<g1(R), 256, 0, st>>>(nA, lA, g.ctr, g.fc, w.fcd, nnp.p, nnp.t, nep.p, nep.t, N, E);
+    for (int l = 0; l < NR; l++) {
+        const TGnn& Bl = res ? w.gnn[l] : w.gnn.back();
+        const D2 Hf = Bl.Hout, Mf = res ? Bl.XF : Bl.Mout;
+        const HeadW& H = *heads[l];
+        const LastW& Lw = *lasts[l];
+        Lin ln; ln.w = Lw.nw; ln.b = Lw.nb; ln.n_out = 1; ln.k_in = DH;
+        Lin le; le.w = Lw.ew; le.b = Lw.eb; le.n_out = 1; le.k_in = DH;
+        // node branch: forward (dual), then reverse with weight gradients
+        head_dual(H.nh0, H.nh2, Hf, DN, N, w.tN[0], w.tN[1], w.tN[2], w.tN[3]);
+        t.linf(w.tN[3], DH, ln, npred, 1, N);
+        head_dual(H.eh0, H.eh2, Mf, D, E, w.tE[0], w.tE[1], w.tE[2], w.tE[3]);
+        t.linf(w.tE[3], DH, le, epred, 1, E);
+        if (tangent_atomic)
+            k_gt_atom_sum<<<g1(N), 256, 0, st>>>(npred.p, npred.t, epred.p, epred.t, g.fc, w.fcd, g.rowptr, tangent_atomic,
+                                                 l > 0, N);
+        // reverse of the node head
+        t.wgrad(ln, nnp, 1, w.tN[3], DH, N);
+        t.linb(nnp, 1, ln, w.tN[3], DH, N);                                                       // (nu, lambda) of s2
+        k_gt_silu_rev<<<g1(N * DH), 256, 0, st>>>(w.tN[2].p, w.tN[2].t, w.tN[3].p, w.tN[3].t, w.tN[3].p, w.tN[3].t, N * DH);
+        t.wgrad(H.nh2, w.tN[3], DH, w.tN[1], DH, N);
+        t.linb(w.tN[3], DH, H.nh2, w.tN[1], DH, N);                                               // of s1
+        k_gt_silu_rev<<<g1(N * DH), 256, 0, st>>>(w.tN[0].p, w.tN[0].t, w.tN[1].p, w.tN[1].t, w.tN[1].p, w.tN[1].t, N * DH);
+        t.wgrad(H.nh0, w.tN[1], DH, Hf, DN, N);
+        t.linb(w.tN[1], DH, H.nh0, dHl[l], DN, N);
+        // reverse of the edge head
+        t.wgrad(le, nep, 1, w.tE[3], DH, E);
+        t.linb(nep, 1, le, w.tE[3], DH, E);
+        k_gt_silu_rev<<<g1(E * DH), 256, 0, st>>>(w.tE[2].p, w.tE[2].t, w.tE[3].p, w.tE[3].t, w.tE[3].p, w.tE[3].t, E * DH);
+        t.wgrad(H.eh2, w.tE[3], DH, w.tE[1], DH, E);
+        t.linb(w.tE[3], DH, H.eh2, w.tE[1], DH, E);
+        k_gt_silu_rev<<<g1(E * DH), 256, 0, st>>>(w.tE[0].p, w.tE[0].t, w.tE[1].p, w.tE[1].t, w.tE[1].p, w.tE[1].t, E * DH);
+        t.wgrad(H.eh0, w.tE[1], DH, Mf, D, E);
+        t.linb(w.tE[1], DH, H.eh0, dMl[l], D, E);
+    }
+    // ---------------- sweep 2: joint reverse through the backbone ----------------
+    if (res) t.zero(w.dM, E * D);   // the last layer's messages are never read
+    for (int gi = L - 1; gi >= 0; gi--) {
+        const GnnLayerW& G = m.gnn[gi];
+        TGnn& B = w.gnn[gi];
+        const D2 MinF = gi == 0 ? w.M0 : w.gnn[gi - 1].Mout;
+        D2 dXF = w.dX, dMin = w.dX2;
+        if (res) {
+            t.copy(dHl[gi], w.dH, N, DN);
+            t.copy(dMl[gi], dXF, E, D);
+            if (gi + 1 < L) {
+                t.axpby(0.f, D2(), 0, 0.5f, w.dM, D, g.rev, dXF, D, true, E, D);
+                t.axpby(0.5f, w.dM, D, 0.f, D2(), 0, nullptr, dMin, D, false, E, D);
+            } else
+                t.zero(dMin, E * D);
+        } else {
+            // Mout = Min + XF + comb2(silu(comb0(LN([XF ; XF[rev]]))))
+            D2 CAT = w.tE[0];
+            t.axpby(1.f, B.XF, D, 0.f, D2(), 0, nullptr, CAT, 2 * D, false, E, D);
+            D2 CATr{CAT.p + D, CAT.t + D};
+            t.axpby(0.f, D2(), 0, 1.f, B.XF, D, g.rev, CATr, 2 * D, false, E, D);
+            t.silu(B.CA, w.tE[1], E * 2 * D);                                                   // input of comb2
+            t.wgrad(G.comb2, w.dM, D, w.tE[1], 2 * D, E);
+            t.linb(w.dM, D, G.comb2, w.tE[1], 2 * D, E);                                        // of silu(CA)
+            k_gt_silu_rev<<<g1(E * 2 * D), 256, 0, st>>>(B.CA.p, B.CA.t, w.tE[1].p, w.tE[1].t, w.tE[1].p, w.tE[1].t, E * 2 * D);
+            t.norm(CAT, G.ln_g, G.ln_b, w.tE[2], E, 2 * D, 1, 1e-5f);                            // input of comb0
+            t.wgrad(G.comb0, w.tE[1], 2 * D, w.tE[2], 2 * D, E);
+            t.linb(w.tE[1], 2 * D, G.comb0, w.tE[2], 2 * D, E);                                  // of LN(CAT)
+            t.norm_rev(CAT, G.ln_g, G.ln_b, w.tE[2], w.tE[1], false, w.tE[3].p, E, 2 * D, 1, 1e-5f);   // of CAT -> tE[1]
+            t.copy(w.dM, dXF, E, D);
+            D2 dCATr{w.tE[1].p + D, w.tE[1].t + D};
+            t.axpby(1.f, w.tE[1], 2 * D, 1.f, dCATr, 2 * D, g.rev, dXF, D, true, E, D);
+            t.copy(w.dM, dMin, E, D);
+        }
+        for (int a = AL - 1; a >= 0; a--) {
+            const AttnLayerW& A = G.attn[a];
+            TAttn& Ab = B.attn[a];
+            // ---- node update
+            D2 dTOKo = w.tN[3];
+            if (d.expanded) {
+                D2 dH1 = w.tN[0];
+                t.copy(w.dH, dH1, N, DN);
+                t.ffn_rev(Ab.H1, true, A.g_center, A.b_center, A.cmlp_in, A.cmlp_out, Ab.VGn, w.dH, dH1, true, w.tN[1], w.tN[2],
+                          w.tN[3], N, DN, d.DNF);
+                t.wgrad(A.ce, dH1, DN, Ab.TOKo, D, N);
+                t.linb(dH1, DN, A.ce, dTOKo, D, N);
+                t.copy(dH1, w.dH, N, DN);
+            } else {
+                t.copy(w.dH, dTOKo, N, D);
+                t.zero(w.dH, N * DN);
+            }
+            D2 dOUT = w.tE[1], dXin = w.tE[4];
+            D2 dOUTc{dOUT.p + E * D, dOUT.t + E * D}, dXinc{dXin.p + E * D, dXin.t + E * D};
+            if (!post) {
+                D2 dX1 = dXin;
+                t.copy(dXF, dX1, E, D);
+                t.ffn_rev(Ab.X1, true, A.g_mlp, A.b_mlp, A.mlp_in, A.mlp_out, Ab.VG, dXF, dX1, true, w.tE[0], w.tE[2], w.tE[3], E, D,
+                          d.DFF);
+                t.copy(dX1, dOUT, E, D);
+                t.copy(dTOKo, dOUTc, N, D);
+                t.zero(dXinc, N * D);
+            } else {
+                D2 dT2 = w.tE[0];
+                t.copy(dXF, dT2, E, D);
+                D2 dT2c{dT2.p + E * D, dT2.t + E * D};
+                t.copy(dTOKo, dT2c, N, D);
+                D2 dS2 = w.tE[1];
+                t.norm_rev(Ab.S2, A.g_mlp, A.b_mlp, dT2, dS2, false, w.tE[2].p, R, D);
+                D2 dT1 = dXin;
+                t.copy(dS2, dT1, R, D);
+                t.ffn_rev(Ab.T1, false, nullptr, nullptr, A.mlp_in, A.mlp_out, Ab.VG, dS2, dT1, true, w.tE[0], w.tE[2], w.tE[3], R, D,
+                          d.DFF);
+                D2 dS1 = w.tE[0];
+                t.norm_rev(Ab.X1, A.g_attn, A.b_attn, dT1, dS1, false, w.tE[2].p, R, D);
+                t.copy(dS1, dOUT, R, D);
+                t.copy(dS1, dXin, R, D);
+            }
+            // ---- output_linear, attention, input_linear
+            t.wgrad(A.out, dOUT, D, Ab.AO, D, R);
+            D2 dAO = w.tE[0];
+            t.linb(dOUT, D, A.out, dAO, D, R);
+            attn_dispatch(d.HD, [&](auto hdm) {
+                constexpr int HDM = decltype(hdm)::value;
+                k_gt_attn_rev_q<HDM><<<dim3((unsigned)N, (unsigned)d.NH), 64, 0, st>>>(
+                    Ab.QKV.p, Ab.QKV.t, dAO.p, dAO.t, Ab.LSE, Ab.MS, g.rowptr, g.fc, w.bd, w.dQKV.p, w.dQKV.t, w.CC, w.DD, E, D, d.NH,
+                    d.HD, scale);
+                k_gt_attn_rev_k<HDM><<<dim3((unsigned)N, (unsigned)d.NH), 64, 0, st>>>(
+                    Ab.QKV.p, Ab.QKV.t, dAO.p, dAO.t, Ab.LSE, Ab.MS, w.CC, w.DD, g.rowptr, g.fc, w.bd, w.dQKV.p, w.dQKV.t, E, D, d.NH,
+                    d.HD, scale);
+            });
+            if (!post) {
+                t.norm(Ab.X, A.g_attn, A.b_attn, w.tE[0], R, D);                                  // input of input_linear
+                t.wgrad(A.qkv, w.dQKV, 3 * D, w.tE[0], D, R);
+                t.linb(w.dQKV, 3 * D, A.qkv, w.tE[1], D, R);
+                t.norm_rev(Ab.X, A.g_attn, A.b_attn, w.tE[1], dXin, true, w.tE[2].p, R, D);
+            } else {
+                t.wgrad(A.qkv, w.dQKV, 3 * D, Ab.X, D, R);
+                t.linb(w.dQKV, 3 * D, A.qkv, dXin, D, R, true);
+            }
+            t.copy(dXin, dXF, E, D);
+            if (d.expanded) {
+                t.wgrad(A.cc, dXinc, D, Ab.H, DN, N);
+                t.linb(dXinc, D, A.cc, w.dH, DN, N, true);
+            } else
+                t.axpby(1.f, dXinc, D, 0.f, D2(), 0, nullptr, w.dH, DN, true, N, DN);
+        }
+        // ---- compress
+        {
+            const int kin = (gi == 0 ? 2 : 3) * D;
+            t.silu(B.a0, w.tE[0], E * D);
+            t.wgrad(G.compress2, dXF, D, w.tE[0], D, E);
+            t.linb(dXF, D, G.compress2, w.tE[0], D, E);
+            k_gt_silu_rev<<<g1(E * D), 256, 0, st>>>(B.a0.p, B.a0.t, w.tE[0].p, w.tE[0].t, w.tE[0].p, w.tE[0].t, E * D);
+            t.wgrad(G.c0, w.tE[0], D, B.TOK, kin, E);
+            D2 dTOK = w.tE[1];
+            t.linb(w.tE[0], D, G.c0, dTOK, kin, E);
+            t.wgrad(G.eemb, dTOK, kin, w.geo, 4, E);
+            if (gi > 0) t.embed_grad(g.sp_nbr, dTOK.p + D, kin, E, D, G.nbr_emb);
+            D2 dMsg{dTOK.p + (gi == 0 ? D : 2 * D), dTOK.t + (gi == 0 ? D : 2 * D)};
+            t.axpby(1.f, dMsg, kin, 0.f, D2(), 0, nullptr, dMin, D, true, E, D);
+            t.copy(dMin, w.dM, E, D);
+            (void)MinF;
+        }
+        // node features entering the layer: an embedding per layer (residual) or the previous layer's output
+        if (res || gi == 0) {
+            t.embed_grad(g.sp, w.dH.p, DN, N, DN, m.node_embs[res ? gi : 0]);
+            if (res) t.zero(w.dH, N * DN);
+        }
+    }
+    t.embed_grad(g.sp_nbr, w.dM.p, D, E, D, m.edge_emb);   // the first layer's messages are the neighbour embedding
+    PET_HIP_CHECK(hipFreeAsync(extra, st));
+    PET_HIP_CHECK(hipGetLastError());
+    return t.err;
+}
+
+}  // namespace pet

@@ -180,6 +180,14 @@ int gen_backward_predict(const Model& m, const Graph& g, void* ws, int64_t ws_by
                          float* g_edge, float* g_fc, hipStream_t st);
 int gen_backward_geometry(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_geo, const float* g_fc,
                           float* gpos, float* gcell, hipStream_t st);
+// gen_train.hip: the size-generic TRAINING pass (forward-over-reverse on dual activations, any size / PostLN / residual)
+int64_t gen_train_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges);
+int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, const float* lA, const float* nA, const float* u,
+               const float* ucell, float* tangent_atomic, hipStream_t st);
+// a model whose TRAINING runs on the size-generic path: other sizes, PostLN layers, the residual featuriser
+inline bool train_generic(const Model& m) { return m.generic() || !m.trainable(); }
+// the workspace `ws` was last filled by a size-generic forward (pet_fwd.hip keeps the record): its adjoints must follow
+bool generic_workspace(const void* ws);
 int backward_geometry_generic(const Model& m, const Graph& g, float* dv_scratch, const float* dgeo, const float* dfc_a,
                               const float* dfc_b, float* gpos, float* gcell, hipStream_t st);
 

@@ -15,6 +15,9 @@
 //   k_emlp       transformer.py:230-232 (edge SwiGLU MLP)
 //   k_comb       backend.py:559-575 (ji gather, LayerNorm, combination MLP, residuals)
 //   k_head_*     backend.py:651-687, 726-777 (heads, last layers, cutoff-weighted sum)
+#include <mutex>
+#include <set>
+
 #include "common.h"
 #include "model.h"
 #include "pet_ws.h"
@@ -769,7 +772,7 @@ __global__ void k_copy_rows(const float* __restrict__ X, int w, float* __restric
 // host driver
 // ---------------------------------------------------------------------------------
 int64_t forward_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges, bool train) {
-    if (m.generic()) return gen_workspace_bytes(m, n_nodes, n_edges);  // any other size: gen.hip
+    if (m.generic() || (train && train_generic(m))) return gen_workspace_bytes(m, n_nodes, n_edges);  // gen.hip
     Workspace w;
     carve_workspace(m, n_nodes, n_edges, nullptr, w, train);
     return (int64_t)w.bytes;
@@ -783,6 +786,19 @@ static void launch_attn_fwd(const float* QKV, const Graph& g, float* AO, float s
 
 int attn_tiles(const Graph& g) { return (g.max_nbr + 1 + 15) / 16; }
 bool use_generic(const Model& m, const Graph& g) { return m.generic() || attn_tiles(g) > 8; }
+// workspaces whose last forward ran on the size-generic path (a training forward of a PostLN / residual model of the
+// compiled size does, while its inference forward runs on the tuned kernels): the adjoint calls ask
+static std::mutex g_gen_ws_mu;
+static std::set<const void*> g_gen_ws;
+bool generic_workspace(const void* ws) {
+    std::lock_guard<std::mutex> lk(g_gen_ws_mu);
+    return g_gen_ws.count(ws) != 0;
+}
+static void note_workspace(const void* ws, bool generic) {
+    std::lock_guard<std::mutex> lk(g_gen_ws_mu);
+    if (generic) g_gen_ws.insert(ws);
+    else g_gen_ws.erase(ws);
+}
 
 static int g_node_planes = 1;  // k_node2 / k_node_bwd2: A tiles pre-split into fp16 planes (pet_config_set("node_planes", 0): k_node)
 void set_node_planes(int v) { g_node_planes = v; }
@@ -817,7 +833,9 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
 // node_feats / edge_feats: n_layers = num_readout_layers() output pointers each (entries may be null)
 int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
                    float* const* node_feats, float* const* edge_feats, int n_layers, hipStream_t st) {
-    if (use_generic(m, g)) return gen_forward_layers(m, g, ws, ws_bytes, save, atomic, node_feats, edge_feats, n_layers, st);
+    const bool gen = use_generic(m, g) || (save == 2 && train_generic(m));
+    note_workspace(ws, gen);
+    if (gen) return gen_forward_layers(m, g, ws, ws_bytes, save, atomic, node_feats, edge_feats, n_layers, st);
     Workspace w;
     carve_workspace(m, g.n_nodes, g.n_edges, ws, w, save == 2);
     PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "forward workspace too small");

@@ -1084,6 +1084,7 @@ static void carve_so(const Model& m, int64_t N, int64_t E, void* base, SoWs& s) 
 }
 
 int64_t so_workspace_bytes(const Model& m, int64_t N, int64_t E) {
+    if (train_generic(m)) return gen_train_workspace_bytes(m, N, E);
     SoWs s;
     carve_so(m, N, E, nullptr, s);
     return (int64_t)s.bytes;
@@ -1154,9 +1155,10 @@ static void head_reverse(const Ctx& c, Trainer& tr, SoWs& s, bool edge, const Li
 int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, void* ws2, int64_t ws2_bytes,
                     const float* lA, const float* nA, const float* u, float* tangent_atomic, hipStream_t st,
                     const float* ucell) {
+    if (train_generic(m))   // other sizes, PostLN, residual: gen_train.hip (it recomputes what it needs in ws2)
+        return gen_train2(m, g, ws2, ws2_bytes, lA, nA, u, ucell, tangent_atomic, st);
     PET_REQUIRE(!use_generic(m, g), PET_ERR_UNSUPPORTED,
-                "training is built for the compiled model size (d_pet=128, d_node=256, d_feedforward=256, d_head=128, "
-                "num_heads=8) and at most 127 neighbours per atom");
+                "training with more than 127 neighbours per atom is not built for the compiled model size");
     PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
     PET_REQUIRE(m.trainable(), PET_ERR_UNSUPPORTED,
                 "training is built for transformer_type=PreLN, featurizer_type=feedforward only");

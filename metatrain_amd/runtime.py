@@ -105,17 +105,21 @@ class HipModel:
         self._ckeys: Dict[str, tuple] = {}
         self._tied = set()  # SiLU variant: w_in parameters uploaded twice (value half = gate half)
         last_w = params.get(f"node_last_layers.{target}.0.{block}.weight") if target is not None else None
-        # the fused kernels serve one property of one readout layer (the residual featuriser reads out every GNN layer)
-        fused = last_w is not None and last_w.shape[0] == 1 and self.hypers["featurizer_type"] != "residual"
+        # the fused target: one property. Its heads and last layers go up under the name "@" -- of readout layer 0, and with
+        # the residual featuriser (one readout per GNN layer, backend.py:589-649) of EVERY readout layer, which is what the
+        # native training step reads (the fused inference entry points serve one readout layer only)
+        fused = last_w is not None and last_w.shape[0] == 1
+        self._fused_all_layers = fused and self.hypers["featurizer_type"] == "residual"
         if not fused:
             self.target = self._fused_block = None
         for key, t in params.items():
             _require_cuda(t)
             parts = key.split(".")
-            if fused and parts[0] in ("node_heads", "edge_heads") and parts[1] == target and parts[2] == "0":
+            layer_ok = len(parts) > 2 and (parts[2] == "0" or self._fused_all_layers)
+            if fused and parts[0] in ("node_heads", "edge_heads") and parts[1] == target and layer_ok:
                 parts[1] = "@"
             elif fused and parts[0] in ("node_last_layers", "edge_last_layers") and parts[1] == target \
-                    and parts[2] == "0" and ".".join(parts[3:-1]) == block:
+                    and layer_ok and ".".join(parts[3:-1]) == block:
                 parts[1] = "@"
                 parts[3:-1] = ["@"]
             ckey = ".".join(parts)
@@ -542,7 +546,8 @@ class HipForward:
 
 def _head_names(model: HipModel, target: str, block: Optional[str], readout_zero: bool = True):
     block = block or target
-    if model.target is not None and target == model.target and block == model._fused_block and readout_zero:
+    if model.target is not None and target == model.target and block == model._fused_block and \
+            (readout_zero or getattr(model, "_fused_all_layers", False)):
         return b"@", b"@"
     return target.encode(), block.encode()
 

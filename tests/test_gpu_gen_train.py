@@ -1,0 +1,151 @@
+"""GPU tests of the size-generic TRAINING pass (csrc/gen_train.hip; VERDICT r2 missing #1 / #3): parameter gradients of the
+energy term and of the force-loss term (the reference's double backward, ``utils/output_gradient.py:34-40`` +
+``pet/trainer.py:462``) for models the tuned second-order pass does not serve -- other model sizes incl. ``d_node == d_pet``
+and the reference's minimal hypers (``pet/tests/test_basic.py:22-32``), PostLN transformer layers
+(``transformer.py:236-262``) and the residual featuriser (``backend.py:589-649``) at the DEFAULT size, and the
+combination old checkpoints upgrade to (``pet/checkpoints.py:190-205``) -- against torch's autograd through the fp64
+oracle, through the C ABI (``pet_backward_train`` / ``pet_backward_train2``) and the native ``TrainStep``."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pet as opet
+from test_gpu_train import _inputs, _oracle_param_grads, _oracle_second_order
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+TYPES = [1, 6, 7, 8]
+CASES = {
+    "s64": dict(d_pet=64, d_node=128, d_feedforward=128, d_head=64, num_heads=4),
+    "flat32": dict(d_pet=32, d_node=32, d_feedforward=48, d_head=24, num_heads=2),
+    "flat32_legacy": dict(d_pet=32, d_node=32, d_feedforward=48, d_head=24, num_heads=2, normalization="LayerNorm",
+                          activation="SiLU", transformer_type="PostLN", featurizer_type="residual"),
+    "minimal": dict(d_pet=1, d_node=1, d_feedforward=1, d_head=1, num_heads=1, num_attention_layers=1, num_gnn_layers=1),
+    "default_postln": dict(transformer_type="PostLN"),
+    "default_residual": dict(featurizer_type="residual"),
+    "default_legacy": dict(normalization="LayerNorm", activation="SiLU", transformer_type="PostLN", featurizer_type="residual"),
+    "s64_layernorm": dict(d_pet=64, d_node=128, d_feedforward=128, d_head=64, num_heads=4, normalization="LayerNorm"),
+}
+
+
+def _setup(golden_dir, tag, case="batch_two_systems.npz"):
+    from metatrain_amd import runtime as rt
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS, **CASES[tag])
+    params = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    inp = _inputs(golden_dir, case)
+    model = rt.HipModel(hypers, TYPES)
+    model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    graph = rt.HipGraph(model, inp["positions"].float().to(dev), inp["cells"].float().to(dev),
+                        inp["centers"].to(dev), inp["neighbors"].to(dev), inp["cell_shifts"].to(dev),
+                        inp["species"].to(dev), inp["system_indices"].int().to(dev))
+    return rt, dev, hypers, params, inp, model, graph
+
+
+# d_pet = 1 is a degenerate model numerically: RMSNorm of ONE feature is sign(x) (x / sqrt(x^2 + 1.2e-7)), every gradient
+# is a single sum with heavy cancellation. The reference's own arithmetic (torch, fp32, same weights and inputs) misses its
+# fp64 values by 2e-4 .. 9e-3 on these gradients (edge_embedder.bias 9.2e-3, compress.0.bias 9.1e-3, norm / mlp weights
+# 4e-4: measured with the oracle evaluated in fp32); the HIP pass sits at 2e-5 (energy term) / 8e-4 (force-loss term).
+LOOSE = {"minimal": 2e-3}
+
+
+def _compare(got, ref, model, what, tol=2 * TOL):
+    worst = {}
+    for k, r in ref.items():
+        r = r.numpy()
+        g = got[k].cpu().numpy().astype(np.float64)
+        if g.shape != r.shape:   # activation = "SiLU": the model holds [W; W]; d/dW = the sum of the halves' gradients
+            assert g.shape[0] == 2 * r.shape[0], k
+            g = g[: r.shape[0]] + g[r.shape[0]:]
+        scale = np.abs(r).max()
+        err = np.abs(g - r).max()
+        worst[k] = err / scale if scale > 1e-12 else err
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    print(what, [(f"{v:.2e}", k) for k, v in top])
+    bad = {k: v for k, v in worst.items() if not v < tol}
+    assert not bad, f"{what}: parameter gradients off: {bad}"
+    return max(worst.values())
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_energy_term_parameter_gradients(golden_dir, tag):
+    rt, dev, hypers, params, inp, model, graph = _setup(golden_dir, tag)
+    n = inp["positions"].shape[0]
+    seed_w = torch.rand(n, generator=torch.Generator().manual_seed(7)) + 0.5
+    ref = _oracle_param_grads(params, hypers, inp, seed_w)
+    fw = rt.HipForward(model, graph, train=True)
+    model.zero_grad()
+    fw.forward()
+    gpos = fw.backward_train(seed_w.to(dev), want_position_grad=True)
+    _compare(model.grads(), ref, model, f"{tag} energy term", LOOSE.get(tag, 2 * TOL))
+    inf = rt.HipForward(model, graph)
+    a = inf.forward() if hypers["featurizer_type"] != "residual" or model.hypers["d_pet"] != 128 else None
+    if a is not None:   # (the compiled size serves the residual featuriser's inference through the staged calls only)
+        np.testing.assert_allclose(gpos.cpu().numpy(), inf.backward(seed_w.to(dev)).cpu().numpy(), rtol=0,
+                                   atol=2e-6 * float(gpos.abs().max()))
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_force_loss_parameter_gradients(golden_dir, tag):
+    rt, dev, hypers, params, inp, model, graph = _setup(golden_dir, tag)
+    n = inp["positions"].shape[0]
+    gen = torch.Generator().manual_seed(11)
+    nu = torch.rand(n, generator=gen) - 0.5
+    u = torch.randn(n, 3, generator=gen)
+    ref, tan_ref, g_ref = _oracle_second_order(params, hypers, inp, nu, u)
+    fw = rt.HipForward(model, graph, train=True)
+    model.zero_grad()
+    atomic = fw.forward()
+    ones = torch.ones(n, device=dev)
+    gpos = fw.backward(ones)
+    assert np.abs(gpos.cpu().numpy() - g_ref.numpy()).max() < TOL * np.abs(g_ref.numpy()).max()
+    tan = fw.backward_train2(ones, nu.to(dev), u.to(dev), want_tangent=True)
+    assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < 2 * TOL
+    lhs, rhs = float(tan.double().sum()), float((u.to(dev).double() * gpos.double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(rhs))
+    _compare(model.grads(), ref, model, f"{tag} force-loss term", LOOSE.get(tag, 2 * TOL))
+    # bit-reproducible: fixed summation orders, no atomics
+    first = model.flat_grad().clone()
+    model.zero_grad()
+    fw.forward()
+    fw.backward(ones)
+    fw.backward_train2(ones, nu.to(dev), u.to(dev))
+    assert torch.equal(model.flat_grad(), first)
+
+
+@pytest.mark.parametrize("tag", ["s64", "default_legacy"])
+def test_native_training_steps_reduce_the_loss_and_follow_torch(golden_dir, tag):
+    """``TrainStep`` (zero_grad, forward, dE/dR, MSE(E/atom) + MSE(dE/dR), second-order pass, clip, Adam) for three steps
+    against the same steps of torch.optim.Adam on the fp64 oracle."""
+    from metatrain_amd.pet.trainer import TrainStep
+
+    rt, dev, hypers, params, inp, model, graph = _setup(golden_dir, tag)
+    s = inp["system_indices"].long()
+    n_sys = int(s.max()) + 1
+    n_atoms = torch.bincount(s, minlength=n_sys).float()
+    gen = torch.Generator().manual_seed(3)
+    te = torch.randn(n_sys, generator=gen) * n_atoms
+    tg = torch.randn(len(s), 3, generator=gen) * 0.3
+    lr = 1e-4
+    p64 = {k: (v if k == "species_to_species_index" else v.double().clone().requires_grad_(True)) for k, v in params.items()}
+    leaves = [v for k, v in p64.items() if k != "species_to_species_index"]
+    opt = torch.optim.Adam(leaves, lr=lr)
+    ref_losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        pos = inp["positions"].double().clone().requires_grad_(True)
+        atomic = opet.pet_atomic_energies(p64, hypers, pos, inp["cells"].double(), inp["centers"], inp["neighbors"],
+                                          inp["cell_shifts"], inp["species"], s, "energy")[:, 0]
+        e = torch.zeros(n_sys, dtype=torch.float64).index_add(0, s, atomic)
+        (g,) = torch.autograd.grad(e.sum(), pos, create_graph=True)
+        loss = (((e - te.double()) / n_atoms.double()) ** 2).mean() + ((g - tg.double()) ** 2).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(leaves, 1.0)
+        opt.step()
+        ref_losses.append(float(loss.detach()))
+    fw = rt.HipForward(model, graph, train=True)
+    step = TrainStep(model, {"learning_rate": lr, "warmup_fraction": 0.0, "num_epochs": 10**9})
+    losses = [float(step(graph, fw, te.to(dev), n_atoms.to(dev), tg.to(dev))["loss"]) for _ in range(3)]
+    np.testing.assert_allclose(losses, ref_losses, rtol=5e-5)
+    assert (losses[-1] < losses[0]) == (ref_losses[-1] < ref_losses[0])
