@@ -167,6 +167,13 @@ def main():
     losses = []
     for _ in range(args.warmup):
         step(graph, fw, target_e, per_box, target_g)
+    # per-stage durations of one untimed step (HIP events around every instrumented stage of the three sweeps): the stage
+    # with the largest share is the roofline's kernel; the generic GEMMs of the second-order pass report FLOPs and bytes
+    rt.profile(True)
+    step(graph, fw, target_e, per_box, target_g)
+    torch.cuda.synchronize()
+    table = rt.profile_report()
+    rt.profile(False)
     pdist.barrier(dev)
     train.comm_events = comm_events   # (start, end) events around each step's gradient all-reduce (N > 1)
     t0 = time.perf_counter()
@@ -209,6 +216,27 @@ def main():
                 "workspace_gb": (fw.nbytes + fw.workspace2.numel()) / 1e9,
             },
         }
+        # roofline: the stage group with the largest share of the step (instrumented stages only), its algorithmic FLOPs
+        # against the pipe it runs on (f16x3: 2500 / 3 TFLOP/s fp32-equivalent) and its bytes against HBM; plus the whole
+        # step against SURVEY 8(d)'s training FLOPs (6 x the forward's GEMM FLOPs)
+        if table:
+            dom = max(table, key=lambda r: r["total_ms"])
+            tf = dom["flops"] / max(dom["total_ms"], 1e-9) / 1e9
+            gb = dom["bytes"] / max(dom["total_ms"], 1e-9) / 1e6
+            hbm_bound = gb / 8000.0 > tf / (2500.0 / 3.0)
+            out["roofline"] = {
+                "bound": "hbm" if hbm_bound else "mfma", "kernel": dom["name"],
+                "achieved": gb if hbm_bound else tf, "peak": 8000.0 if hbm_bound else 2500.0 / 3.0,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": (gb / 8000.0) if hbm_bound else tf / (2500.0 / 3.0),
+                "stage_ms_per_step": round(dom["total_ms"], 3), "stage_calls_per_step": dom["calls"], "traffic": None,
+                "frac_of_hbm_peak": gb / 8000.0, "frac_of_f16x3_mfma_peak": tf / (2500.0 / 3.0),
+                "stages_ms": {r["name"]: round(r["total_ms"], 3) for r in sorted(table, key=lambda r: -r["total_ms"])[:10]},
+            }
+            g0 = batches[0]["graph"]
+            rowptr = g0.csr()["rowptr"].double()
+            t2 = float((((rowptr[1:] - rowptr[:-1]) + 1) ** 2).sum())
+            fwd = (2001152.0 * g0.n_edges + 4292864.0 * g0.n_nodes + 2048.0 * t2) * (n_edges / max(g0.n_edges, 1))
+            out["roofline"]["whole_step_algorithmic_tflops"] = 6.0 * fwd / (elapsed / args.steps) / 1e12
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(hypers, params)
         print(json.dumps(out), flush=True)

@@ -176,6 +176,7 @@ struct PetHipBackend : torch::CustomClassHolder {
     pet_model_t* model = nullptr;
     int64_t model_device = -1;
     std::vector<std::pair<void*, int64_t>> stamp;
+    int64_t generation = 0;  // bumped by every re-upload: a backward checks that its forward saw the same weights
 
     PetHipBackend(std::vector<double> hypers_, std::vector<int64_t> atomic_types_, std::vector<std::string> keys_)
         : hypers(std::move(hypers_)), atomic_types(std::move(atomic_types_)), keys(std::move(keys_)) {
@@ -243,6 +244,13 @@ struct PetHipBackend : torch::CustomClassHolder {
         model_device = like.device().index();
         stamp.clear();
         for (const auto& p : params) stamp.push_back({p.data_ptr(), (int64_t)p._version()});
+        generation++;
+    }
+    // a backward that runs after a parameter update / another forward would pair the new weights with the
+    // activations its forward saved: refuse instead of returning a silently inconsistent gradient
+    void check_generation(int64_t seen) const {
+        TORCH_CHECK(seen == generation, "pet_hip: the parameters were re-uploaded (optimizer step or device change) between "
+                    "this node's forward and its backward; run the forward again before differentiating");
     }
 
     std::vector<at::Tensor> preprocess(std::vector<at::Tensor> params, const at::Tensor& positions, const at::Tensor& centers,
@@ -334,6 +342,7 @@ struct PreprocessFn : torch::autograd::Function<PreprocessFn> {
         if (e > 0) bg->ix = csr_index(bg->g, n, positions);
         ctx->saved_data["graph"] = bg;
         ctx->saved_data["backend"] = be;
+        ctx->saved_data["generation"] = be->generation;
         ctx->saved_data["pos_dtype"] = (int64_t)positions.scalar_type();
         ctx->saved_data["cell_dtype"] = (int64_t)cells.scalar_type();
         const auto dt = positions.scalar_type();
@@ -348,6 +357,7 @@ struct PreprocessFn : torch::autograd::Function<PreprocessFn> {
                                                    torch::autograd::variable_list go) {
         auto bg = ctx->saved_data["graph"].toCustomClass<BatchGraph>();
         auto be = ctx->saved_data["backend"].toCustomClass<PetHipBackend>();
+        be->check_generation(ctx->saved_data["generation"].toInt());
         const auto pd = (at::ScalarType)ctx->saved_data["pos_dtype"].toInt();
         const auto cd = (at::ScalarType)ctx->saved_data["cell_dtype"].toInt();
         const int64_t n = bg->n_nodes, e = pet_graph_num_edges(bg->g);
@@ -432,6 +442,7 @@ struct FeaturesFn : torch::autograd::Function<FeaturesFn> {
               "pet_forward_layers");
         ctx->saved_data["graph"] = bg;
         ctx->saved_data["backend"] = be;
+        ctx->saved_data["generation"] = be->generation;
         ctx->saved_data["dtype"] = (int64_t)ev.scalar_type();
         const auto dt = ev.scalar_type();
         torch::autograd::variable_list out;
@@ -444,6 +455,7 @@ struct FeaturesFn : torch::autograd::Function<FeaturesFn> {
                                                    torch::autograd::variable_list go) {
         auto bg = ctx->saved_data["graph"].toCustomClass<BatchGraph>();
         auto be = ctx->saved_data["backend"].toCustomClass<PetHipBackend>();
+        be->check_generation(ctx->saved_data["generation"].toInt());
         const auto dt = (at::ScalarType)ctx->saved_data["dtype"].toInt();
         const int64_t n = bg->n_nodes, m = bg->m, e = pet_graph_num_edges(bg->g);
         const pet_hypers_t h = be->hypers_struct();
@@ -496,6 +508,7 @@ struct PredictFn : torch::autograd::Function<PredictFn> {
               "pet_predict");
         ctx->saved_data["graph"] = bg;
         ctx->saved_data["backend"] = be;
+        ctx->saved_data["generation"] = be->generation;
         ctx->saved_data["nf"] = nfc;
         ctx->saved_data["ef"] = efc;
         ctx->saved_data["target"] = target;
@@ -512,6 +525,7 @@ struct PredictFn : torch::autograd::Function<PredictFn> {
                                                    torch::autograd::variable_list go) {
         auto bg = ctx->saved_data["graph"].toCustomClass<BatchGraph>();
         auto be = ctx->saved_data["backend"].toCustomClass<PetHipBackend>();
+        be->check_generation(ctx->saved_data["generation"].toInt());
         const auto dt = (at::ScalarType)ctx->saved_data["dtype"].toInt();
         const std::string target = ctx->saved_data["target"].toStringRef(), block = ctx->saved_data["block"].toStringRef();
         const int64_t layer = ctx->saved_data["layer"].toInt();

@@ -87,7 +87,7 @@ class TrainStep:
         ``optimizer_state_dict``, ``scheduler_state_dict``, epoch): Adam's moments, the step counter that drives both
         the bias correction and the LambdaLR schedule, and the hypers the schedule was built from."""
         return {"step_index": self.step_index, "total_steps": self.total_steps, "hypers": dict(self.hypers),
-                "optimizer": {k: v.cpu() for k, v in self.model.optimizer_state().items()}}
+                "optimizer": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self.model.optimizer_state().items()}}
 
     def load_state_dict(self, state: Dict[str, object]) -> None:
         self.step_index = int(state["step_index"])

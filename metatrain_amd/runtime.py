@@ -205,9 +205,19 @@ class HipModel:
         m = torch.empty(self.num_params, dtype=torch.float32, device="cuda")
         v = torch.empty_like(m)
         check(self.lib.pet_optimizer_state(self._handle, _ptr(m), _ptr(v), m.numel(), 0, _stream()))
-        return {"exp_avg": m, "exp_avg_sq": v}
+        return {"exp_avg": m, "exp_avg_sq": v, "layout": self.flat_layout()}
+
+    def flat_layout(self):
+        """``[(state-dict key, numel)]`` in the order of the flat gradient / Adam buffers (= upload order). Saved with the
+        optimizer state and checked on load: two state dicts with another key order or target set have the same total size."""
+        import math
+
+        return [(k, int(math.prod(shape))) for k, (_, shape) in self._ckeys.items()]
 
     def load_optimizer_state(self, state: Dict[str, torch.Tensor]) -> None:
+        if "layout" in state and [tuple(x) for x in state["layout"]] != self.flat_layout():
+            raise PetHipError("optimizer state was saved for another parameter layout (key order / targets differ): the flat "
+                              "Adam moments would be misaligned")
         m = state["exp_avg"].to("cuda", torch.float32).contiguous()
         v = state["exp_avg_sq"].to("cuda", torch.float32).contiguous()
         check(self.lib.pet_optimizer_state(self._handle, _ptr(m), _ptr(v), m.numel(), 1, _stream()))

@@ -207,3 +207,136 @@ def test_variant_training_through_the_mirror(golden_dir, tag):
         err = float((got.cpu().double() - ref[k]).abs().max())
         worst = max(worst, err / scale if scale > 1e-12 else err)
     assert worst < 2e-5, worst
+
+
+def _conditioning_case(golden_dir, tag):
+    hypers = dict(opet.DEFAULT_HYPERS, system_conditioning=True,
+                  featurizer_type="residual" if tag == "residual" else "feedforward")
+    g = dict(np.load(os.path.join(golden_dir, f"pet_conditioning_{tag}.npz")))
+    return hypers, g
+
+
+
+@pytest.mark.parametrize("tag", ["feedforward", "residual"])
+def test_system_conditioning_through_the_c_abi(rt, golden_dir, tag):
+    """Two systems with different total charge and spin multiplicity: per-atom energies, the node features of every
+    readout layer and dE/dR against the reference; the fused pet_forward / pet_backward pair serves it too."""
+    dev = torch.device("cuda:0")
+    hypers, g = _conditioning_case(golden_dir, tag)
+    params = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    m = rt.HipModel(hypers, TYPES)
+    m.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    t = lambda k, dt=None: torch.tensor(g[k]).to(dev) if dt is None else torch.tensor(g[k]).to(dev, dt)  # noqa: E731
+    graph = rt.HipGraph(m, t("in_positions", torch.float32), t("in_cells", torch.float32), t("in_centers"), t("in_neighbors"),
+                        t("in_cell_shifts"), t("in_species"), t("in_system_indices", torch.int32))
+    with pytest.raises(rt.PetHipError, match="pet_graph_set_conditioning"):
+        rt.HipForward(m, graph).features_layers()  # the model expects charge / spin
+    graph.set_conditioning(t("in_charge"), t("in_spin_multiplicity"))
+    atomic, grad, nfs, _ = _energy_and_gradient(rt, m, graph)
+    assert len(nfs) == int(g["n_readout"])
+    for l, nf in enumerate(nfs):
+        assert relmax(nf.cpu().numpy(), g[f"node_features_{l}_f64"]) < TOL
+    assert relmax(atomic.cpu().numpy(), g["atomic_f64"]) < TOL
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
+    if tag == "feedforward":
+        fw = rt.HipForward(m, graph)
+        a2 = fw.forward()
+        g2 = fw.backward(torch.ones_like(a2))
+        assert relmax(a2.cpu().numpy(), g["atomic_f64"].ravel()) < TOL and relmax(g2.cpu().numpy(), g["grad_f64"]) < TOL
+    with pytest.raises(ValueError, match="charge values"):
+        graph.set_conditioning(torch.tensor([11, 0]), t("in_spin_multiplicity"))
+    with pytest.raises(ValueError, match="spin_multiplicity values"):
+        graph.set_conditioning(t("in_charge"), torch.tensor([0, 1]))
+
+
+@pytest.mark.parametrize("scripted", [False, True])
+def test_system_conditioning_through_the_backend_calls(golden_dir, scripted):
+    """batch_data carries "charge", "spin_multiplicity" and "system_indices" (put there by the model wrapper,
+    pet/model.py:465-470) into calculate_features, eager and scripted."""
+    import io
+
+    from metatrain_amd.pet import PETBackend
+
+    dev = torch.device("cuda:0")
+    hypers, g = _conditioning_case(golden_dir, "residual")
+    be = PETBackend(hypers, TYPES)
+    be.add_output("energy", {"energy": [1]})
+    be.load_state_dict(opet.synthetic_params(hypers, TYPES, {"energy": 1}), strict=True)
+    be = be.to(dev).eval()
+    if scripted:
+        buf = io.BytesIO()
+        torch.jit.save(torch.jit.script(be), buf)
+        buf.seek(0)
+        be = torch.jit.load(buf, map_location=dev)
+    t = lambda k: torch.tensor(g[k]).to(dev)  # noqa: E731
+    pos = t("in_positions").float().requires_grad_(True)
+    cells = t("in_cells").float()
+    batch = be.preprocess(pos, t("in_centers"), t("in_neighbors"), t("in_species"), cells, t("in_cell_shifts"),
+                          t("in_system_indices"), 1.0)
+    batch["charge"], batch["spin_multiplicity"] = t("in_charge"), t("in_spin_multiplicity")
+    batch["system_indices"] = t("in_system_indices")
+    nodes, edges = be.calculate_features(batch)
+    pred, _, _ = be.predict(nodes, edges, batch, cells, t("in_system_indices"), ["energy"])
+    atomic = pred["energy"][0]
+    (grad,) = torch.autograd.grad(atomic.sum(), pos)
+    assert relmax(atomic.detach().cpu().numpy(), g["atomic_f64"]) < TOL
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
+    batch["charge"] = torch.tensor([0, 42], device=dev)
+    with pytest.raises((ValueError, RuntimeError, torch.jit.Error), match="charge values"):
+        be.calculate_features(batch)
+
+
+def test_system_conditioning_batch_independence(rt, golden_dir):
+    """pet/tests/test_conditioning.py:195-218: changing the charge / multiplicity of one system of a batch does not
+    touch the other system's atoms (bit for bit here) and does change its own."""
+    dev = torch.device("cuda:0")
+    hypers, g = _conditioning_case(golden_dir, "feedforward")
+    params = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    m = rt.HipModel(hypers, TYPES)
+    m.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    t = lambda k, dt=None: torch.tensor(g[k]).to(dev) if dt is None else torch.tensor(g[k]).to(dev, dt)  # noqa: E731
+    graph = rt.HipGraph(m, t("in_positions", torch.float32), t("in_cells", torch.float32), t("in_centers"), t("in_neighbors"),
+                        t("in_cell_shifts"), t("in_species"), t("in_system_indices", torch.int32))
+    out = []
+    for charge, spin in (([0, 1], [1, 1]), ([0, 3], [1, 2])):
+        graph.set_conditioning(torch.tensor(charge), torch.tensor(spin))
+        out.append(rt.HipForward(m, graph).forward())
+    first = (t("in_system_indices") == 0)
+    assert torch.equal(out[0][first], out[1][first])
+    assert float((out[0][~first] - out[1][~first]).abs().max()) > 1e-4
+
+
+@pytest.mark.parametrize("tag", ["legacy", "conditioned"])
+def test_variants_beyond_65536_token_rows_against_the_oracle(rt, tag):
+    """The variant kernels at a size where row indices pass 2^16 (the compress-adjoint fault of DESIGN.md section 4a only
+    showed there): a 5 000-atom box, E + N > 100 000 token rows, energies and dE/dR against the fp64 oracle."""
+    from oracle import nl as onl
+
+    dev = torch.device("cuda:0")
+    delta = VARIANTS["legacy"] if tag == "legacy" else dict(system_conditioning=True, transformer_type="PostLN")
+    hypers = dict(opet.DEFAULT_HYPERS, **delta)
+    n = 5000
+    pos, z, cell = opet.random_box(n, seed=8)
+    i, j, s, _ = onl.neighbor_list(pos.double().numpy(), cell.double().numpy(), [True] * 3, hypers["cutoff"])
+    assert len(i) + n > 65536
+    sysidx = torch.zeros(n, dtype=torch.long)
+    charge, spin = torch.tensor([2]), torch.tensor([3])
+    p64 = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float64)
+    torch.set_num_threads(16)
+    _, g_ref, a_ref = opet.energy_and_gradient(p64, hypers, pos.double(), cell[None].double(), torch.tensor(i), torch.tensor(j),
+                                               torch.tensor(s).long(), z, sysidx, charge=charge, spin_multiplicity=spin)
+    m = rt.HipModel(hypers, TYPES)
+    m.load({k: v.to(dev) for k, v in opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32).items()}, "energy")
+    graph = rt.HipGraph(m, pos.to(dev), cell[None].to(dev), torch.tensor(i, device=dev), torch.tensor(j, device=dev),
+                        torch.tensor(s, device=dev), z.to(dev), sysidx.to(dev, torch.int32))
+    if hypers["system_conditioning"]:
+        graph.set_conditioning(charge, spin)
+    atomic, grad, _, _ = _energy_and_gradient(rt, m, graph)
+    ea, eg = relmax(atomic.cpu().numpy(), a_ref.numpy()), relmax(grad.cpu().numpy(), g_ref.numpy())
+    # yardstick: the same model evaluated by torch in fp32 (what the reference's own fp32 path delivers at this size)
+    p32 = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    _, g32, a32 = opet.energy_and_gradient(p32, hypers, pos, cell[None], torch.tensor(i), torch.tensor(j),
+                                           torch.tensor(s).long(), z, sysidx, charge=charge, spin_multiplicity=spin)
+    ra, rg = relmax(a32.numpy(), a_ref.numpy()), relmax(g32.numpy(), g_ref.numpy())
+    print(f"{tag}: per-atom energies {ea:.2e} (torch fp32: {ra:.2e}), gradient {eg:.2e} (torch fp32: {rg:.2e})")
+    assert ea < max(TOL, 2 * ra) and eg < max(TOL, 2 * rg), (ea, eg, ra, rg)
