@@ -54,7 +54,7 @@ def test_hip_error_against_the_fp32_yardstick(case):
     model.load({k: v.to(dev) for k, v in params.items()}, "energy")
     rng = np.random.default_rng(101 if case == "steep_cosine_flank" else 7)
     worst = []
-    for _ in range(6):
+    for _ in range(4):
         b = _batch(rng, dilute=(case == "dilute"))
         if len(b[2]) == 0:
             continue
