@@ -178,12 +178,25 @@ int pet_graph_export_batch(const pet_graph_t* g,
 int pet_graph_csr(const pet_graph_t* g, const int32_t** d_rowptr, const int32_t** d_ctr,
                   const int32_t** d_nbr, const int32_t** d_rev);
 
+/* ONE box over several GPUs with a per-layer exchange (not in the reference, which leaves large systems to the MD engine's
+ * domain decomposition, pet/model.py:1004-1017). A rank's graph holds its OWNED centres with all
+ * their edges plus, for every foreign neighbour j of an owned atom i, the reverse edge (j -> i) as a "ghost" row. After the
+ * transformer layers of each GNN layer the library gathers the "export" rows (owned centre, foreign neighbour) of the edge
+ * tokens into d_export_buf, calls fn(user, 0, layer) -- the caller's all-to-all, which must fill d_ghost_buf with the
+ * owners' rows, stream-ordered on the call's stream -- and scatters d_ghost_buf into the ghost rows before the combination
+ * stage reads e[reversed] (backend.py:559-575). In the reverse pass the adjoints that land on ghost rows are gathered into
+ * d_ghost_buf, zeroed locally, fn(user, 1, layer) carries them home and d_export_buf is ADDED to the export rows. Halo
+ * atoms need no complete neighbourhood: one cutoff of halo instead of (layers + 1). Buffers [n, d_pet] fp32; row lists are
+ * CSR rows of this graph (pet_graph_csr). Default model size, PreLN + feedforward, inference + forces. fn == NULL: off. */
+typedef int (*pet_exchange_fn)(void* user, int direction, int layer);
+int pet_graph_set_exchange(pet_graph_t* g, const int32_t* d_export_rows, int64_t n_export, const int32_t* d_ghost_rows,
+                           int64_t n_ghost, float* d_export_buf, float* d_ghost_buf, pet_exchange_fn fn, void* user);
 /* system_conditioning (backend.py:375-378: batch_data["charge"], ["spin_multiplicity"], ["system_indices"]): per-system
  * total charge and spin multiplicity (2S + 1) for the forward passes on this graph handle. d_system_indices [N] may be
  * NULL for a pet_graph_build handle (it has them); the three device arrays must stay alive while the handle is used.
  * Values outside [-max_charge, max_charge] / [1, max_spin_multiplicity] are the caller's to reject (conditioning.py:54-80
- * does it on the host); the kernels clamp them. */
-/* Training (pet_backward_train / pet_backward_train2) sums the node-feature adjoints per system for the conditioning
+ * does it on the host); the kernels clamp them.
+ * Training (pet_backward_train / pet_backward_train2) sums the node-feature adjoints per system for the conditioning
  * parameters: the system indices must then be non-decreasing (what concatenate_structures produces). */
 int pet_graph_set_conditioning(pet_graph_t* g, const int64_t* d_charge, const int64_t* d_spin_multiplicity,
                                const int64_t* d_system_indices, int64_t n_systems);
@@ -196,7 +209,8 @@ int64_t pet_forward_workspace_bytes(const pet_model_t* m, int64_t n_nodes, int64
  * pet/documentation.py:196-213; d_node == d_pet follows transformer.py:189-201) AND any graph with a denser atom (the
  * reference pads to any max(num_neighbors), pet/modules/structures.py:292-294) runs on a size-generic path with its own,
  * larger workspace layout. pet_forward_workspace_bytes answers for the model alone; a caller that may meet dense graphs
- * sizes the workspace with this function. Inference + dE/dR only on that path (training entry points refuse it). */
+ * sizes the workspace with this function. Training of other sizes / PostLN / residual models runs on that path too
+ * (pet_train_workspace_bytes answers for the model); training on graphs with more than 127 neighbours per atom is refused. */
 int64_t pet_forward_workspace_bytes_for(const pet_model_t* m, const pet_graph_t* g);
 /* calculate_features + predict for the fused target (the heads uploaded under the name "@", one property):
  *   d_atomic [N]       per-atom prediction (node + sum of cutoff-weighted edge terms); NULL = features only

@@ -32,7 +32,7 @@ SYMBOLS = [
     "pet_predict_scratch_floats", "pet_predict", "pet_predict_backward", "pet_geometry_backward",
     "pet_forward_workspace_bytes", "pet_forward_workspace_bytes_for", "pet_forward", "pet_aux_outputs", "pet_backward", "pet_backward_predict",
     "pet_backward_features", "pet_backward_geometry",
-    "pet_model_num_readout_layers", "pet_forward_layers", "pet_backward_features_layers", "pet_graph_set_conditioning",
+    "pet_model_num_readout_layers", "pet_forward_layers", "pet_backward_features_layers", "pet_graph_set_conditioning", "pet_graph_set_exchange",
     "pet_model_zero_grad", "pet_model_get_grad", "pet_train_workspace_bytes", "pet_backward_train",
     "pet_model_get_param", "pet_model_flat_grad", "pet_adam_step", "pet_optimizer_state", "pet_model_tie_halves",
     "pet_train2_workspace_bytes", "pet_backward_train2", "pet_backward_train2_cell",
@@ -48,6 +48,10 @@ SOAP_SYMBOLS = [
     "soap_model_get_param", "soap_adam_step",
 ]
 SOAP_MAX_L = 8
+
+
+# pet_exchange_fn (include/pet_hip.h): the caller's collective of the per-layer exchange
+EXCHANGE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_int)
 
 
 class SoapHypers(ctypes.Structure):
@@ -167,6 +171,7 @@ def load() -> ctypes.CDLL:
     lib.pet_backward_features.argtypes = [P, P, P, c_int64, P, P, P, P, P]
     lib.pet_backward_geometry.argtypes = [P, P, P, c_int64, P, P, P, P, P]
     lib.pet_graph_set_conditioning.argtypes = [P, P, P, P, c_int64]
+    lib.pet_graph_set_exchange.argtypes = [P, P, c_int64, P, c_int64, P, P, EXCHANGE_FN, P]
     lib.pet_model_num_readout_layers.argtypes = [P]
     lib.pet_model_num_readout_layers.restype = c_int32
     lib.pet_forward_layers.argtypes = [P, P, P, c_int64, c_int, P, P, c_int32, P]

@@ -631,6 +631,18 @@ int pet_graph_csr(const pet_graph_t* pg, const int32_t** rowptr, const int32_t**
     return PET_OK;
 }
 
+int pet_graph_set_exchange(pet_graph_t* pg, const int32_t* d_export_rows, int64_t n_export, const int32_t* d_ghost_rows,
+                           int64_t n_ghost, float* d_export_buf, float* d_ghost_buf, pet_exchange_fn fn, void* user) {
+    PET_REQUIRE(pg, PET_ERR_ARGUMENT, "null graph");
+    PET_REQUIRE(n_export >= 0 && n_ghost >= 0 && (n_export == 0 || (d_export_rows && d_export_buf)) &&
+                    (n_ghost == 0 || (d_ghost_rows && d_ghost_buf)), PET_ERR_ARGUMENT, "bad exchange lists");
+    Graph& g = pg->g;
+    g.x_export = d_export_rows; g.n_export = n_export; g.x_export_buf = d_export_buf;
+    g.x_ghost = d_ghost_rows; g.n_ghost = n_ghost; g.x_ghost_buf = d_ghost_buf;
+    g.x_fn = fn; g.x_user = user;
+    return PET_OK;
+}
+
 int pet_graph_set_conditioning(pet_graph_t* pg, const int64_t* d_charge, const int64_t* d_spin_multiplicity,
                                const int64_t* d_system_indices, int64_t n_systems) {
     PET_REQUIRE(pg && d_charge && d_spin_multiplicity && n_systems >= 1, PET_ERR_ARGUMENT, "null argument");

@@ -118,6 +118,16 @@ struct Graph {
     const int64_t* cond_spin = nullptr;    // [n_cond_systems]
     const int64_t* cond_sys = nullptr;     // [N] or nullptr: use `sys`
     int64_t n_cond_systems = 0;
+    // per-layer exchange of edge tokens for ONE box over several ranks (pet_graph_set_exchange; pet/partition.py): rows whose
+    // centre another rank owns ("ghost") receive their transformer output from that rank before the combination stage, rows
+    // with an owned centre and a foreign neighbour ("export") are sent; the adjoints travel the other way
+    const int* x_export = nullptr;   // [n_export] CSR rows, grouped by destination rank
+    const int* x_ghost = nullptr;    // [n_ghost] CSR rows, grouped by source rank
+    int64_t n_export = 0, n_ghost = 0;
+    float* x_export_buf = nullptr;   // [n_export, d_pet] caller-owned staging (what the collective reads / writes)
+    float* x_ghost_buf = nullptr;    // [n_ghost, d_pet]
+    int (*x_fn)(void* user, int direction, int layer) = nullptr;  // the collective: 0 = export -> ghost, 1 = ghost -> export
+    void* x_user = nullptr;
     float* pc = nullptr;       // [E] pair cutoff of every kept edge
     float* ad_gc = nullptr;    // [E] scratch: dL/d(pair cutoff)
     float* ad_gr = nullptr;    // [N] scratch: dL/d(atomic cutoff)

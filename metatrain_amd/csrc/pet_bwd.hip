@@ -21,6 +21,7 @@ constexpr int LD256 = lds_ld(256);
 
 float __device__ cutoff_deriv_dev(float d, float rc, float width, int fn);
 int attn_tiles(const Graph& g);
+int exchange_backward(const Graph& g, float* dXF, int layer, hipStream_t st);  // pet_fwd.hip
 double g_sum_t2(const Graph& g);
 
 __device__ __forceinline__ float sigmoid_grad_from(float s) { return s * (1.0f - s); }
@@ -1216,6 +1217,10 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             {
                 ProfScope ps("dxf", st, 0.0);
                 k_dxf<<<cdiv(E * (D / 4), 256), 256, 0, st>>>(dM, w.dcat, g.rev, dX, E);
+            }
+            if (g.x_fn) {   // one box over several ranks: the adjoints on ghost rows go home to their owners
+                int rc = exchange_backward(g, dX, gi, st);
+                if (rc) return rc;
             }
         }
         for (int a = m.h.num_attention_layers - 1; a >= 0; a--) {

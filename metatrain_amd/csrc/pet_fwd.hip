@@ -771,6 +771,53 @@ __global__ void k_copy_rows(const float* __restrict__ X, int w, float* __restric
 // ---------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------
+// ---- per-layer exchange of edge tokens (one box over several ranks): staging kernels around the caller's collective
+__global__ void k_rows_gather(const float* __restrict__ X, const int* __restrict__ rows, int64_t n, float* __restrict__ buf) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 per thread, D / 4 per row
+    if (idx >= n * (D / 4)) return;
+    const int64_t r = idx / (D / 4);
+    const int c = (int)(idx % (D / 4));
+    reinterpret_cast<float4*>(buf)[idx] = reinterpret_cast<const float4*>(X + (int64_t)rows[r] * D)[c];
+}
+// mode 0: X[rows] = buf; 1: X[rows] += buf; 2: X[rows] = 0
+__global__ void k_rows_scatter(const float* __restrict__ buf, const int* __restrict__ rows, int64_t n, float* __restrict__ X,
+                               int mode) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * (D / 4)) return;
+    const int64_t r = idx / (D / 4);
+    const int c = (int)(idx % (D / 4));
+    float4* dst = reinterpret_cast<float4*>(X + (int64_t)rows[r] * D) + c;
+    if (mode == 2) { *dst = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const float4 v = reinterpret_cast<const float4*>(buf)[idx];
+    if (mode == 0) *dst = v;
+    else { float4 o = *dst; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; *dst = o; }
+}
+// forward: XF[ghost rows] <- the owners' XF[export rows]   (before the combination stage reads e[rev])
+int exchange_forward(const Graph& g, float* XF, int layer, hipStream_t st) {
+    if (!g.x_fn) return PET_OK;
+    if (g.n_export > 0)
+        k_rows_gather<<<cdiv(g.n_export * (D / 4), 256), 256, 0, st>>>(XF, g.x_export, g.n_export, g.x_export_buf);
+    PET_REQUIRE(g.x_fn(g.x_user, 0, layer) == 0, PET_ERR_ARGUMENT, "the exchange callback failed (forward)");
+    if (g.n_ghost > 0)
+        k_rows_scatter<<<cdiv(g.n_ghost * (D / 4), 256), 256, 0, st>>>(g.x_ghost_buf, g.x_ghost, g.n_ghost, XF, 0);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+// reverse: the adjoint that landed on ghost rows belongs to their owners: send it, zero it here, add what arrives to the
+// export rows
+int exchange_backward(const Graph& g, float* dXF, int layer, hipStream_t st) {
+    if (!g.x_fn) return PET_OK;
+    if (g.n_ghost > 0) {
+        k_rows_gather<<<cdiv(g.n_ghost * (D / 4), 256), 256, 0, st>>>(dXF, g.x_ghost, g.n_ghost, g.x_ghost_buf);
+        k_rows_scatter<<<cdiv(g.n_ghost * (D / 4), 256), 256, 0, st>>>(nullptr, g.x_ghost, g.n_ghost, dXF, 2);
+    }
+    PET_REQUIRE(g.x_fn(g.x_user, 1, layer) == 0, PET_ERR_ARGUMENT, "the exchange callback failed (reverse)");
+    if (g.n_export > 0)
+        k_rows_scatter<<<cdiv(g.n_export * (D / 4), 256), 256, 0, st>>>(g.x_export_buf, g.x_export, g.n_export, dXF, 1);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
 int64_t forward_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges, bool train) {
     if (m.generic() || (train && train_generic(m))) return gen_workspace_bytes(m, n_nodes, n_edges);  // gen.hip
     Workspace w;
@@ -834,6 +881,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
 int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
                    float* const* node_feats, float* const* edge_feats, int n_layers, hipStream_t st) {
     const bool gen = use_generic(m, g) || (save == 2 && train_generic(m));
+    PET_REQUIRE(!(gen && g.x_fn), PET_ERR_UNSUPPORTED, "the per-layer exchange is built for the tuned path (default model size)");
     note_workspace(ws, gen);
     if (gen) return gen_forward_layers(m, g, ws, ws_bytes, save, atomic, node_feats, edge_feats, n_layers, st);
     Workspace w;
@@ -975,6 +1023,12 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                 else k_emlp<true><<<gE, NTHREADS, lds2, st>>>(Ab.X1, A.g_mlp, A.b_mlp, A.mlp_in.fwd, A.mlp_in.b, A.mlp_out.fwd,
                                                               A.mlp_out.b, Ab.VG, Xnext, E);
             }
+        }
+        if (g.x_fn) {   // one box over several ranks: the transformer outputs of foreign centres arrive from their owners
+            PET_REQUIRE(m.plain() && save != 2, PET_ERR_UNSUPPORTED,
+                        "the per-layer exchange is built for PreLN + feedforward models, inference and forces");
+            int rc = exchange_forward(g, B.XF, gi, st);
+            if (rc) return rc;
         }
         if (E > 0 && res) {
             if (gi + 1 < L) {  // the messages of the next layer (backend.py:640-647); the last layer's are never read

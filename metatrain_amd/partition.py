@@ -39,6 +39,54 @@ def complete_lattice(cell: torch.Tensor, pbc: Sequence[bool]) -> torch.Tensor:
     return c
 
 
+def _slab_coordinate(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bool]):
+    """``(f [N], wrap, lo_all, width, unit, axis)``: the coordinate the slabs cut (fractional along the lattice direction
+    with the largest extent, or Cartesian for an open system), whether it wraps, its range and the length of one unit."""
+    dev = positions.device
+    pos = positions.detach()
+    periodic = [bool(p) for p in pbc]
+    if any(periodic):
+        # lattice completed for the non-periodic rows (metatomic: zero vectors there) exactly as the neighbour list does
+        # (csrc/nl.hip::lattice_params): a surface / wire keeps its wrap-around halo along the periodic directions
+        c = complete_lattice(cell, periodic)
+        vol = abs(float(torch.det(c)))
+        heights = []
+        for a in range(3):
+            b1, b2 = c[(a + 1) % 3], c[(a + 2) % 3]
+            heights.append(vol / float(torch.linalg.norm(torch.linalg.cross(b1, b2))))
+        inv = torch.linalg.inv(c).to(dev, pos.dtype)
+        frac = pos @ inv
+        span = [heights[a] if periodic[a] else float(frac[:, a].max() - frac[:, a].min()) * heights[a] for a in range(3)]
+        axis = max(range(3), key=lambda a: span[a])
+        f = frac[:, axis]
+        wrap = periodic[axis]
+        if wrap:
+            f = f - torch.floor(f)
+            f = torch.where(f >= 1.0, f - 1.0, f)  # guard the rounding of values just below an integer
+            lo_all, width = 0.0, 1.0
+        else:
+            lo_all, width = float(f.min()), max(float(f.max() - f.min()), 1e-12) * (1.0 + 1e-6)
+        unit = heights[axis]
+    else:  # open system: slabs of the bounding box along the longest Cartesian extent
+        ext = pos.max(0).values - pos.min(0).values
+        axis = int(torch.argmax(ext))
+        f = pos[:, axis]
+        wrap = False
+        lo_all, width = float(f.min()), max(float(ext[axis]), 1e-12) * (1.0 + 1e-6)
+        unit = 1.0
+    return f, wrap, lo_all, width, unit, axis
+
+
+def slab_owner(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bool], world: int) -> torch.Tensor:
+    """``[N]`` int64: the rank that owns every atom -- the same intervals, bound for bound, as :func:`slab_partition`."""
+    f, _, lo_all, width, _, _ = _slab_coordinate(positions, cell, pbc)
+    owner = torch.full((positions.shape[0],), -1, dtype=torch.long, device=positions.device)
+    for rank in range(world):
+        lo, hi = lo_all + width * rank / world, lo_all + width * (rank + 1) / world
+        owner[(f >= lo) & (f < hi)] = rank
+    return owner
+
+
 def slab_partition(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bool], halo: float, world: int,
                    rank: int) -> Tuple[torch.Tensor, torch.Tensor, int]:
     """``(index [n_sub] int64, owned [n_sub] bool, axis)``: the atoms rank ``rank`` of ``world`` works on (slab + halo,
@@ -51,39 +99,8 @@ def slab_partition(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bo
     n = positions.shape[0]
     if world == 1:
         return torch.arange(n, device=dev), torch.ones(n, dtype=torch.bool, device=dev), 0
-    pos = positions.detach()
-    periodic = [bool(p) for p in pbc]
-    if any(periodic):
-        # lattice completed for the non-periodic rows (metatomic: zero vectors there) exactly as the neighbour list does
-        # (csrc/nl.hip::lattice_params): a surface / wire keeps its wrap-around halo along the periodic directions
-        c = complete_lattice(cell, periodic)
-        vol = abs(float(torch.det(c)))
-        # plane spacing of lattice direction a: V / |b x c|; cut along the direction with the largest extent in planes
-        heights = []
-        for a in range(3):
-            b1, b2 = c[(a + 1) % 3], c[(a + 2) % 3]
-            heights.append(vol / float(torch.linalg.norm(torch.linalg.cross(b1, b2))))
-        inv = torch.linalg.inv(c).to(dev, pos.dtype)
-        frac = pos @ inv
-        # thickness of the system along every direction, in length units (open directions: bounding box of the atoms)
-        span = [heights[a] if periodic[a] else float(frac[:, a].max() - frac[:, a].min()) * heights[a] for a in range(3)]
-        axis = max(range(3), key=lambda a: span[a])
-        f = frac[:, axis]
-        wrap = periodic[axis]
-        if wrap:
-            f = f - torch.floor(f)
-            f = torch.where(f >= 1.0, f - 1.0, f)  # guard the rounding of values just below an integer
-            lo_all, width = 0.0, 1.0
-        else:
-            lo_all, width = float(f.min()), max(float(f.max() - f.min()), 1e-12) * (1.0 + 1e-6)
-        h = halo / heights[axis] * 1.0001
-    else:  # open system: slabs of the bounding box along the longest Cartesian extent
-        ext = pos.max(0).values - pos.min(0).values
-        axis = int(torch.argmax(ext))
-        f = pos[:, axis]
-        wrap = False
-        lo_all, width = float(f.min()), max(float(ext[axis]), 1e-12) * (1.0 + 1e-6)
-        h = halo * 1.0001
+    f, wrap, lo_all, width, unit, axis = _slab_coordinate(positions, cell, pbc)
+    h = halo / unit * 1.0001
     lo, hi = lo_all + width * rank / world, lo_all + width * (rank + 1) / world
     owned = (f >= lo) & (f < hi)
     below, above = lo - f, f - hi  # > 0 on the respective outside

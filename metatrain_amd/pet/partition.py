@@ -70,3 +70,113 @@ def energy_and_gradient(model, positions: torch.Tensor, species: torch.Tensor, c
     if all_reduce is not None:
         all_reduce(buf)
     return buf[3 * n:], buf[: 3 * n].view(n, 3), int(index.numel()), int(owned.sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 3: ONE box over several GPUs with a PER-LAYER exchange of edge tokens (one-cutoff halos)
+# ---------------------------------------------------------------------------------------------------------------------
+class ExchangePlan:
+    """Who sends which edge rows to whom (``pet_graph_set_exchange``). Built from the rank's sub-system alone: positions
+    are replicated, so every rank knows the owner of every atom (``slab_owner``); the rows a rank exports to rank ``q`` --
+    edges ``(i -> j)`` with ``i`` its own and ``j`` owned by ``q`` -- are exactly the rows rank ``q`` holds as ghosts, and both
+    sides order them by the global pair ``(i, j)``, so no negotiation is needed."""
+
+    def __init__(self, graph, index: torch.Tensor, owned: torch.Tensor, owner: torch.Tensor, world: int, d_pet: int):
+        csr = graph.csr()
+        ctr, nbr = csr["ctr"].long(), csr["nbr"].long()
+        gi, gj = index[ctr], index[nbr]                      # global atom numbers of every CSR row's centre / neighbour
+        own_c, own_n = owned[ctr], owned[nbr]
+        n_glob = int(owner.numel())
+
+        def ordered(mask, peer_of, first, second):
+            rows = torch.nonzero(mask).squeeze(1)
+            peer = peer_of[rows]
+            key = (peer * n_glob + first[rows]) * n_glob + second[rows]
+            order = torch.argsort(key)
+            rows, peer = rows[order], peer[order]
+            if rows.numel() > 1 and bool((key[order][1:] == key[order][:-1]).any()):
+                raise ValueError("a pair of atoms is connected by more than one image: the per-layer exchange needs a cell "
+                                 "wider than two cutoffs in every periodic direction")
+            return rows.to(torch.int32).contiguous(), torch.bincount(peer, minlength=world).tolist()
+
+        # export: own centre, foreign neighbour -> to the neighbour's owner; ghost: foreign centre -> from the centre's owner
+        self.export_rows, self.send_splits = ordered(own_c & ~own_n, owner[gj], gi, gj)
+        self.ghost_rows, self.recv_splits = ordered(~own_c, owner[gi], gi, gj)
+        dev = ctr.device
+        self.export_buf = torch.empty((self.export_rows.numel(), d_pet), dtype=torch.float32, device=dev)
+        self.ghost_buf = torch.empty((self.ghost_rows.numel(), d_pet), dtype=torch.float32, device=dev)
+
+
+def energy_and_gradient_exchange(model, positions: torch.Tensor, species: torch.Tensor, cell: torch.Tensor,
+                                 pbc: Sequence[bool], world: int, rank: int, all_to_all: Callable,
+                                 all_reduce: Optional[Callable[[torch.Tensor], None]] = None,
+                                 neighbor_list: Optional[Callable] = None, runtime=None):
+    """Energy and dE/dR of one box with ONE-cutoff halos: rank ``rank`` runs the transformer layers on the atoms it owns; the
+    edge tokens its combination stage needs from foreign centres arrive by ``all_to_all(out, inp, out_splits, in_splits)``
+    once per GNN layer (and their adjoints go back once per layer in the reverse pass) -- ``torch.distributed.
+    all_to_all_single`` on RCCL: one message per peer over its xGMI link. Then ONE all-reduce(sum) of ``[gradient | energy]``
+    as in :func:`energy_and_gradient`. Default model size, PreLN + feedforward, fixed cutoff.
+    Returns ``(energy [1], gradient [N, 3], n_sub, n_owned, n_rows, n_ghost_rows)``."""
+    import ctypes
+
+    from ..partition import slab_owner
+
+    if runtime is None:
+        from .. import runtime
+    if neighbor_list is None:
+        neighbor_list = runtime.neighbor_list
+    if model.hypers.get("num_neighbors_adaptive") is not None:
+        raise ValueError("the per-layer exchange is built for the fixed cutoff")
+    cutoff = float(model.hypers["cutoff"])
+    dev = positions.device
+    n = positions.shape[0]
+    index, owned, _ = slab_partition(positions, cell, pbc, cutoff, world, rank)
+    owner = slab_owner(positions, cell, pbc, world)
+    buf = torch.zeros(3 * n + 1, dtype=torch.float32, device=dev)
+    n_rows = n_ghost = 0
+    sub_pos = positions.detach()[index].to(torch.float32).contiguous()
+    sub_z = species[index].to(torch.int32).contiguous()
+    pairs, _ = neighbor_list(sub_pos, cell, pbc, cutoff)
+    if pairs.numel():   # halo-halo edges are nobody's business here: every kept edge touches an owned atom
+        keep = owned[pairs[:, 0].long()] | owned[pairs[:, 1].long()]
+        pairs = pairs[keep]
+    graph = runtime.HipGraph(model, sub_pos, cell.reshape(1, 3, 3).to(dev, torch.float32), pairs[:, 0].contiguous(),
+                             pairs[:, 1].contiguous(), pairs[:, 2:5].contiguous(), sub_z,
+                             torch.zeros(index.numel(), dtype=torch.int32, device=dev))
+    plan = ExchangePlan(graph, index, owned, owner, world, int(model.hypers["d_pet"]))
+    n_rows, n_ghost = int(graph.n_edges), int(plan.ghost_rows.numel())
+
+    def hook(_user, direction, _layer):
+        try:
+            if direction == 0:
+                all_to_all(plan.ghost_buf, plan.export_buf, plan.recv_splits, plan.send_splits)
+            else:
+                all_to_all(plan.export_buf, plan.ghost_buf, plan.send_splits, plan.recv_splits)
+            return 0
+        except Exception as exc:  # a Python exception must not unwind through the C frames
+            plan.error = exc
+            return 1
+
+    from .._lib import EXCHANGE_FN
+
+    cb = EXCHANGE_FN(hook)
+    rt_check = runtime.check
+    rt_check(model.lib.pet_graph_set_exchange(graph.handle, runtime._ptr(plan.export_rows), plan.export_rows.numel(),
+                                              runtime._ptr(plan.ghost_rows), plan.ghost_rows.numel(),
+                                              runtime._ptr(plan.export_buf), runtime._ptr(plan.ghost_buf), cb, None))
+    try:
+        fw = runtime.HipForward(model, graph)
+        seeds = owned.to(torch.float32)
+        atomic = fw.forward()
+        grad_sub = fw.backward(seeds)
+    except Exception:
+        if getattr(plan, "error", None) is not None:
+            raise plan.error
+        raise
+    finally:
+        model.lib.pet_graph_set_exchange(graph.handle, None, 0, None, 0, None, None, EXCHANGE_FN(), None)
+    buf[: 3 * n].view(n, 3)[index] = grad_sub
+    buf[3 * n] = (atomic.reshape(-1) * seeds).sum()
+    if all_reduce is not None:
+        all_reduce(buf)
+    return buf[3 * n:], buf[: 3 * n].view(n, 3), int(index.numel()), int(owned.sum()), n_rows, n_ghost
