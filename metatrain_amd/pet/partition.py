@@ -24,8 +24,18 @@ per atom), with the ordinary kernels and the cell unchanged (periodic images sta
 The price is redundant work in the halo: a slab of thickness ``L / world`` computes ``L / world + 2 hops r_c``, so the
 scheme pays off for boxes whose slabs are thick against 27 A (a 1 M-atom box at 0.05 atoms / A^3 on 8 GPUs: 34 A
 slabs, 56 % efficiency; the 100 k-atom box: 16 A slabs, 37 %; ``hops = num_gnn_layers`` reproduces the reference's
-declared range at ~1e-4 accuracy and 47 %). A per-layer exchange of edge messages would cut the halo to one cutoff; it
-is not built.
+declared range at ~1e-4 accuracy and 47 %).
+
+The per-layer exchange cuts the halo to ONE cutoff (:func:`energy_and_gradient_exchange`, round 3). A rank then runs the
+transformers only on the centres it owns; what it lacks is, per GNN layer, the edge tokens of the edges ``j -> i`` whose
+centre ``j`` is foreign and whose neighbour ``i`` is its own (the reversed-edge operand of its combination stage). Those
+rows exist in its CSR layout as GHOST rows (the halo atom's edges towards owned atoms; halo-halo edges are dropped), the
+owner of ``j`` holds the same edges as EXPORT rows, and the library calls the host between the edge transformer and the
+combination stage of every layer (``pet_graph_set_exchange``, include/pet_hip.h): export rows are gathered into one send
+buffer ordered by (peer, i, j), the host runs ONE all-to-all (``all_to_all_single`` on RCCL: one message per peer and
+xGMI link), the received rows are scattered over the ghost rows. The reverse pass sends the ghost rows' adjoints back
+the same way and ADDS them to the export rows' adjoints. Needs a cell wider than two cutoffs in every periodic
+direction (a pair connected by two images has no unique (i, j) key), the fixed cutoff and the compiled default size.
 """
 from typing import Callable, Optional, Sequence
 
@@ -103,8 +113,8 @@ class ExchangePlan:
         self.export_rows, self.send_splits = ordered(own_c & ~own_n, owner[gj], gi, gj)
         self.ghost_rows, self.recv_splits = ordered(~own_c, owner[gi], gi, gj)
         dev = ctr.device
-        self.export_buf = torch.empty((self.export_rows.numel(), d_pet), dtype=torch.float32, device=dev)
-        self.ghost_buf = torch.empty((self.ghost_rows.numel(), d_pet), dtype=torch.float32, device=dev)
+        self.export_buf = torch.zeros((self.export_rows.numel(), d_pet), dtype=torch.float32, device=dev)
+        self.ghost_buf = torch.zeros((self.ghost_rows.numel(), d_pet), dtype=torch.float32, device=dev)
 
 
 def energy_and_gradient_exchange(model, positions: torch.Tensor, species: torch.Tensor, cell: torch.Tensor,

@@ -146,3 +146,49 @@ def test_one_all_reduce_over_two_ranks(tmp_path):
     e_ref, g_ref = _whole(_ToyModel(2, True), pos, z, cell, pbc)
     assert abs(float(e) - float(e_ref)) < 1e-5 * abs(float(e_ref))
     assert float((grad - g_ref).abs().max()) < 1e-5 * float(g_ref.abs().max())
+
+
+class _CsrGraph:
+    """What ExchangePlan reads of a HipGraph: the CSR rows (sorted by centre) of the kept pairs."""
+
+    def __init__(self, pairs):
+        order = torch.argsort(pairs[:, 0].long(), stable=True)
+        self.ctr, self.nbr = pairs[order, 0].int(), pairs[order, 1].int()
+
+    def csr(self):
+        return {"ctr": self.ctr, "nbr": self.nbr}
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_exchange_plans_of_the_ranks_agree_without_negotiation(world):
+    """Per-layer exchange (energy_and_gradient_exchange): what rank a exports to rank b is, row for row and in the same
+    order, what rank b holds as ghost rows from a; every edge of the box is computed by exactly one rank."""
+    gen = torch.Generator().manual_seed(3)
+    cell = torch.diag(torch.tensor([30.0, 11.0, 12.0]))
+    cell[1, 0] = 3.0
+    n = 700
+    pos = torch.rand(n, 3, generator=gen) @ cell
+    pbc = [True] * 3
+    owner = generic.slab_owner(pos, cell, pbc, world)
+    whole, _ = _ToyRuntime.neighbor_list(pos, cell, pbc, CUTOFF)
+    plans, keys, own_edges = [], [], 0
+    for rank in range(world):
+        index, owned, _ = generic.slab_partition(pos, cell, pbc, CUTOFF, world, rank)
+        assert bool((owner[index][owned] == rank).all()) and int(owned.sum()) == int((owner == rank).sum())
+        pairs, _ = _ToyRuntime.neighbor_list(pos[index], cell, pbc, CUTOFF)
+        pairs = pairs[owned[pairs[:, 0].long()] | owned[pairs[:, 1].long()]]
+        own_edges += int(owned[pairs[:, 0].long()].sum())
+        g = _CsrGraph(pairs)
+        plan = partition.ExchangePlan(g, index, owned, owner, world, 4)
+        gi, gj = index[g.ctr.long()], index[g.nbr.long()]
+        plans.append(plan)
+        keys.append((torch.stack([gi[plan.export_rows.long()], gj[plan.export_rows.long()]], 1),
+                     torch.stack([gi[plan.ghost_rows.long()], gj[plan.ghost_rows.long()]], 1)))
+        assert plan.send_splits[rank] == 0 and plan.recv_splits[rank] == 0
+    assert own_edges == whole.shape[0]
+    for a in range(world):
+        for b in range(world):
+            assert plans[a].send_splits[b] == plans[b].recv_splits[a]
+            sa, sb = sum(plans[a].send_splits[:b]), sum(plans[b].recv_splits[:a])
+            cnt = plans[a].send_splits[b]
+            assert torch.equal(keys[a][0][sa:sa + cnt], keys[b][1][sb:sb + cnt])
