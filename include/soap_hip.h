@@ -38,7 +38,7 @@ typedef struct {
     int32_t n_channels;       /* species channels: n_species (Orthogonal, legacy) or 4 (Alchemical) */
     int32_t legacy;           /* 1: per-centre-species LayerNorm / MLP / last layer, identity species weights */
     int32_t layernorm;        /* bpnn.layernorm */
-    int32_t num_hidden_layers;      /* bpnn.num_hidden_layers (1 or 2) */
+    int32_t num_hidden_layers;      /* bpnn.num_hidden_layers (1 .. 8) */
     int32_t num_neurons_per_layer;  /* bpnn.num_neurons_per_layer (32) */
 } soap_hypers_t;
 

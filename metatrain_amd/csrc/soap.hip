@@ -46,8 +46,10 @@ struct SoapDims {
     float rc, width, inv_h;
 };
 
+constexpr int MAXNH = 8;  // hidden layers of the tail (soap_bpnn/documentation.py: num_hidden_layers, default 2)
 struct SoapSet {  // weights of one (centre-species) set
     const float *ln_w = nullptr, *ln_b = nullptr, *W1 = nullptr, *W2 = nullptr, *w3 = nullptr;
+    const float* Wh[MAXNH - 1] = {};  // hidden Linear k + 2 of the stack ("bpnn.<s>.<2 (k + 1)>.weight"); Wh[0] == W2
 };
 
 struct SoapModel {
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_mfma(SoapDims d, con
                                                                  const float* __restrict__ enc,
                                                                  const float* __restrict__ tail,
                                                                  const float* __restrict__ gA, float* __restrict__ dF,
-                                                                 int N) {
+                                                                 int N, const float* __restrict__ da2x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NOUTP = 64 * NT, LDD = lds_ld(NOUTP);
     float* Ds = smem;                 // [64][NOUTP + 4] d a1, zero outside the atom's own set
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_mfma(SoapDims d, con
         float v = 0.f;
         if (atom < N && d.NH > 1) {
             const SoapSet W = sets[d.legacy ? sp[atom] : 0];
-            v = gA[atom] * W.w3[j] * dsilu(tail[(size_t)atom * TS + 2 + H + j]);
+            v = da2x ? da2x[(size_t)atom * H + j] : gA[atom] * W.w3[j] * dsilu(tail[(size_t)atom * TS + 2 + H + j]);
         }
         d2[r * H + j] = v;
     }
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_ps_tail_bwd(SoapDims d, int c
                                                                const float* __restrict__ enc,
                                                                const float* __restrict__ tail,
                                                                const float* __restrict__ gA, float* __restrict__ dCf,
-                                                               int N) {
+                                                               int N, const float* __restrict__ da2x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NOUTP = 64 * NT, LDD = lds_ld(NOUTP), LDT = lds_ld(256);
     float* Ds = smem;                 // [32][NOUTP + 4] d a1, zero outside the atom's own set
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_ps_tail_bwd(SoapDims d, int c
         float v = 0.f;
         if (at < N && d.NH > 1) {
             const SoapSet W = sets[d.legacy ? sp[at] : 0];
-            v = gA[at] * W.w3[j] * dsilu(tail[(size_t)at * TS + 2 + H + j]);
+            v = da2x ? da2x[(size_t)at * H + j] : gA[at] * W.w3[j] * dsilu(tail[(size_t)at * TS + 2 + H + j]);
         }
         d2[rr * H + j] = v;
     }
@@ -1107,7 +1109,8 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_set(SoapDims d, cons
                                                                 const float* __restrict__ bs,
                                                                 const float* __restrict__ enc,
                                                                 const float* __restrict__ tail,
-                                                                const float* __restrict__ gA, float* __restrict__ dF) {
+                                                                const float* __restrict__ gA, float* __restrict__ dF,
+                                                                const float* __restrict__ da2x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int H = 32, LDD = lds_ld(H), TS = 2 + 2 * H;
     float* Ds = smem;                 // [64][36] d a1
@@ -1125,7 +1128,8 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_set(SoapDims d, cons
     for (int item = threadIdx.x; item < BM * H; item += NTHREADS) {
         const int r = item >> 5, j = item & 31, at = rows[r];
         float v = 0.f;
-        if (at >= 0 && d.NH > 1) v = gA[at] * W.w3[j] * dsilu(tail[(size_t)at * TS + 2 + H + j]);
+        if (at >= 0 && d.NH > 1)
+            v = da2x ? da2x[(size_t)at * H + j] : gA[at] * W.w3[j] * dsilu(tail[(size_t)at * TS + 2 + H + j]);
         d2[r * H + j] = v;
     }
     __syncthreads();
@@ -1211,14 +1215,15 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_set(SoapDims d, cons
 __global__ __launch_bounds__(256) void k_soap_tail_bwd(SoapDims d, const float* __restrict__ feats,
                                                        const int* __restrict__ sp, const SoapSet* __restrict__ sets,
                                                        const float* __restrict__ enc, const float* __restrict__ tail,
-                                                       const float* __restrict__ gA, float* __restrict__ dF) {
+                                                       const float* __restrict__ gA, float* __restrict__ dF,
+                                                       const float* __restrict__ da2x) {
     __shared__ float da1[MAXH], da2[MAXH], red[8];
     const int i = blockIdx.x, tid = threadIdx.x;
     const SoapSet W = sets[d.legacy ? sp[i] : 0];
     const float* tl = tail + (size_t)i * (2 + 2 * d.H);
     const float mean = tl[0], rstd = tl[1], g = gA[i];
     if (tid < d.H) {
-        if (d.NH > 1) da2[tid] = g * W.w3[tid] * dsilu(tl[2 + d.H + tid]);
+        if (d.NH > 1) da2[tid] = da2x ? da2x[(size_t)i * d.H + tid] : g * W.w3[tid] * dsilu(tl[2 + d.H + tid]);
         else da1[tid] = g * W.w3[tid] * dsilu(tl[2 + tid]);
     }
     __syncthreads();
@@ -1253,6 +1258,67 @@ __global__ __launch_bounds__(256) void k_soap_tail_bwd(SoapDims d, const float* 
         const float* e = enc + (size_t)sp[i] * d.S;
         for (int k = tid; k < d.S; k += 256) dF[(size_t)i * d.S + k] *= e[k];
     }
+}
+
+// Hidden layers beyond the second (num_hidden_layers > 2; the reference's MLPMap stacks Linear + SiLU per layer,
+// soap_bpnn/model.py). Every tail kernel above keeps a1, a2 and the 4 544-wide first Linear, which is all of the work; one
+// wave per atom continues from a2: a_{k+3} = Wh[k+1] silu(a_{k+2}) -> ext[atom][k][H], and replaces the atom's energy.
+__global__ __launch_bounds__(256) void k_soap_tail_extra_fwd(SoapDims d, const int* __restrict__ sp,
+                                                             const SoapSet* __restrict__ sets,
+                                                             const float* __restrict__ tail, float* __restrict__ ext,
+                                                             float* __restrict__ atomic, int N) {
+    __shared__ float hs[4][MAXH];
+    const int wave = threadIdx.x >> 6, j = threadIdx.x & 63;
+    const int at = blockIdx.x * 4 + wave;
+    if (at >= N) return;  // whole waves leave; no workgroup barrier below
+    const int H = d.H, TS = 2 + 2 * H, NX = d.NH - 2;
+    const SoapSet* W = sets + (d.legacy ? sp[at] : 0);
+    float a = j < H ? tail[(size_t)at * TS + 2 + H + j] : 0.f;
+    for (int k = 0; k < NX; k++) {
+        if (j < H) hs[wave][j] = silu(a);
+        __builtin_amdgcn_wave_barrier();
+        float s = 0.f;
+        if (j < H) {
+            const float* w = W->Wh[k + 1] + (size_t)j * H;
+            for (int q = 0; q < H; q++) s += w[q] * hs[wave][q];
+            ext[((size_t)at * NX + k) * H + j] = s;
+        }
+        a = s;
+        __builtin_amdgcn_wave_barrier();
+    }
+    float e = j < H ? W->w3[j] * silu(a) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+    if (j == 0) atomic[at] = e;
+}
+
+// ... and its reverse down to d a2 [N, H], which the tail adjoints then start from instead of gA w3 silu'(a2)
+__global__ __launch_bounds__(256) void k_soap_tail_extra_bwd(SoapDims d, const int* __restrict__ sp,
+                                                             const SoapSet* __restrict__ sets,
+                                                             const float* __restrict__ tail,
+                                                             const float* __restrict__ ext, const float* __restrict__ gA,
+                                                             float* __restrict__ da2, int N) {
+    __shared__ float ds[4][MAXH];
+    const int wave = threadIdx.x >> 6, j = threadIdx.x & 63;
+    const int at = blockIdx.x * 4 + wave;
+    if (at >= N) return;
+    const int H = d.H, TS = 2 + 2 * H, NX = d.NH - 2;
+    const SoapSet* W = sets + (d.legacy ? sp[at] : 0);
+    float da = j < H ? gA[at] * W->w3[j] * dsilu(ext[((size_t)at * NX + NX - 1) * H + j]) : 0.f;
+    for (int k = NX - 1; k >= 0; k--) {  // through a_{k+3} = Wh[k+1] silu(a_{k+2})
+        if (j < H) ds[wave][j] = da;
+        __builtin_amdgcn_wave_barrier();
+        float s = 0.f;
+        if (j < H) {
+            const float* w = W->Wh[k + 1];
+            for (int q = 0; q < H; q++) s += w[(size_t)q * H + j] * ds[wave][q];
+            const float aprev = k > 0 ? ext[((size_t)at * NX + k - 1) * H + j] : tail[(size_t)at * TS + 2 + H + j];
+            s *= dsilu(aprev);
+        }
+        da = s;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (j < H) da2[(size_t)at * H + j] = da;
 }
 
 // dC[l][m][a] = sum_b (dF[l][a][b] + dF[l][b][a]) c[l][m][b]
@@ -1548,6 +1614,7 @@ __global__ __launch_bounds__(256) void k_soap_expand_bwd_p(SoapDims d, const flo
 // ---------------------------------------------------------------------------------------------
 struct SoapWs {
     float *Cf, *feats, *tail, *dF, *dCf, *dv;
+    float *tail_ext, *da2;  // num_hidden_layers > 2: a3 .. a_NH [N][NH - 2][H] and the adjoint of a2 [N][H]
     int* perm;     // [N] atoms bucketed by network (species-sorted tail tiles)
     SpInfo* info;
     size_t bytes;
@@ -1563,6 +1630,8 @@ static void carve_soap(const SoapDims& d, int64_t N, int64_t E, void* base, Soap
     w.dv = c.take<float>(Ea * 4);
     w.perm = c.take<int>(Na);
     w.info = reinterpret_cast<SpInfo*>(c.take<int>((sizeof(SpInfo) + 3) / 4));
+    w.tail_ext = c.take<float>(d.NH > 2 ? Na * (d.NH - 2) * d.H : 1);
+    w.da2 = c.take<float>(d.NH > 2 ? Na * d.H : 1);
     w.bytes = c.off;
 }
 
@@ -1638,7 +1707,11 @@ static int soap_finalize(SoapModel& m, hipStream_t st) {
             if ((rc = soap_get(m, "layernorm." + ss + ".bias", d.S, &sets[s].ln_b))) return rc;
         }
         if ((rc = soap_get(m, "bpnn." + ss + ".0.weight", (int64_t)d.H * d.S, &sets[s].W1))) return rc;
-        if (d.NH > 1 && (rc = soap_get(m, "bpnn." + ss + ".2.weight", (int64_t)d.H * d.H, &sets[s].W2))) return rc;
+        for (int k = 1; k < d.NH; k++)
+            if ((rc = soap_get(m, "bpnn." + ss + "." + std::to_string(2 * k) + ".weight", (int64_t)d.H * d.H,
+                               &sets[s].Wh[k - 1])))
+                return rc;
+        sets[s].W2 = sets[s].Wh[0];
         if ((rc = soap_get(m, "last_layers.energy." + ss + ".weight", d.H, &sets[s].w3))) return rc;
     }
     PET_HIP_CHECK(hipMemcpyAsync(m.sets, sets.data(), sizeof(SoapSet) * m.n_sets, hipMemcpyHostToDevice, st));
@@ -1798,6 +1871,7 @@ static int soap_fwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
             }
         }
     }
+    if (d.NH > 2) k_soap_tail_extra_fwd<<<cdiv(N, 4), 256, 0, st>>>(d, g.sp, m.sets, w.tail, w.tail_ext, atomic, N);
     if (features)
         PET_HIP_CHECK(hipMemcpyAsync(features, w.feats, (size_t)N * d.S * 4, hipMemcpyDeviceToDevice, st));
     PET_HIP_CHECK(hipGetLastError());
@@ -1818,6 +1892,11 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
         return PET_OK;
     }
     allow_big_lds(k_soap_expand_bwd, lds_expand_bwd(d));
+    const float* da2x = nullptr;
+    if (d.NH > 2) {
+        k_soap_tail_extra_bwd<<<cdiv(N, 4), 256, 0, st>>>(d, g.sp, m.sets, w.tail, w.tail_ext, gA, w.da2, N);
+        da2x = w.da2;
+    }
     if (soap_fused_ok(m)) {
         ProfScope ps("soap_ps_tail_bwd", st, 4.0 * (double)N * d.S * (d.L + 1 + d.H), (double)N * d.NCOEF * 8);
         const int cld = soap_cld(d), grid = cdiv(N, BMB);
@@ -1827,7 +1906,8 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
                             (size_t)2 * BMB * cld) * 4;                                                           \
         allow_big_lds(k_soap_ps_tail_bwd<NTV>, lds);                                                              \
         k_soap_ps_tail_bwd<NTV><<<grid, NTHREADS, lds, st>>>(d, cld, w.Cf, g.sp, m.sets, m.wall2_bwd, m.wall2t_bwd, \
-                                                             m.wall_rs, m.wall_b, m.enc, w.tail, gA, w.dCf, N);   \
+                                                             m.wall_rs, m.wall_b, m.enc, w.tail, gA, w.dCf, N,    \
+                                                             da2x);                                               \
     } break;
         switch (m.NT) { SOAP_FUSED_BWD(1) SOAP_FUSED_BWD(2) SOAP_FUSED_BWD(3) SOAP_FUSED_BWD(4) }
 #undef SOAP_FUSED_BWD
@@ -1838,7 +1918,7 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
             const size_t lds = ((size_t)BM * lds_ld(32) + BM * 32 + BM * 4 + BM * lds_ld(128) + BM) * 4;
             k_soap_tail_bwd_set<<<cdiv(N, BM) + m.n_sets, NTHREADS, lds, st>>>(
                 d, w.feats, w.perm, w.info, m.n_sets, g.sp, m.sets, m.wall_bwd_set, m.Kp, m.wall_rs, m.wall_b, m.enc,
-                w.tail, gA, w.dF);
+                w.tail, gA, w.dF, da2x);
         } else if (m.NT > 0 && g_soap_mfma) {
             const size_t lds = ((size_t)BM * lds_ld(m.NOUTP) + BM * 32 + BM * 4 + BM * lds_ld(128)) * 4;
             const int grid = cdiv(N, BM);
@@ -1846,12 +1926,13 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
     case NTV:                                                                                                     \
         allow_big_lds(k_soap_tail_bwd_mfma<NTV>, lds);                                                            \
         k_soap_tail_bwd_mfma<NTV><<<grid, NTHREADS, lds, st>>>(d, w.feats, g.sp, m.sets, m.wall_bwd, m.Kp,        \
-                                                                m.wall_rs, m.wall_b, m.enc, w.tail, gA, w.dF, N);  \
+                                                                m.wall_rs, m.wall_b, m.enc, w.tail, gA, w.dF, N,   \
+                                                                da2x);                                             \
         break;
             switch (m.NT) { SOAP_TAIL_BWD(1) SOAP_TAIL_BWD(2) SOAP_TAIL_BWD(3) SOAP_TAIL_BWD(4) }
 #undef SOAP_TAIL_BWD
         } else {
-            k_soap_tail_bwd<<<N, 256, 0, st>>>(d, w.feats, g.sp, m.sets, m.enc, w.tail, gA, w.dF);
+            k_soap_tail_bwd<<<N, 256, 0, st>>>(d, w.feats, g.sp, m.sets, m.enc, w.tail, gA, w.dF, da2x);
         }
     }
     {
@@ -1906,8 +1987,8 @@ int soap_model_create(const soap_hypers_t* h, soap_model_t** out) {
     PET_REQUIRE(h->max_angular >= 0 && h->max_angular <= SOAP_MAX_L, PET_ERR_UNSUPPORTED, "max_angular out of range");
     PET_REQUIRE(h->num_neurons_per_layer >= 1 && h->num_neurons_per_layer <= MAXH, PET_ERR_UNSUPPORTED,
                 "num_neurons_per_layer > 32 is not built");
-    PET_REQUIRE(h->num_hidden_layers == 1 || h->num_hidden_layers == 2, PET_ERR_UNSUPPORTED,
-                "num_hidden_layers must be 1 or 2");
+    PET_REQUIRE(h->num_hidden_layers >= 1 && h->num_hidden_layers <= MAXNH, PET_ERR_UNSUPPORTED,
+                "num_hidden_layers must be 1 .. 8");
     PET_REQUIRE(h->n_species >= 1 && h->n_channels >= 1 && h->n_channels <= 255, PET_ERR_ARGUMENT, "bad species counts");
     PET_REQUIRE(!h->legacy || h->n_channels == h->n_species, PET_ERR_ARGUMENT,
                 "legacy (Orthogonal species): n_channels must equal n_species");

@@ -160,9 +160,11 @@ __global__ __launch_bounds__(256) void k_soap_tail_train(SoapDims d, const float
     __shared__ double red[4];
     __shared__ float sa[2 * MAXH], sb[2 * MAXH], hbar[2 * MAXH];
     __shared__ float part[4][2 * MAXH];
+    __shared__ float sak[MAXNH][2 * MAXH];  // [a_k | a'_k] of every hidden layer (lane j writes and reads its own entries)
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = d.H, NH = d.NH, PK = soap_pack_size(H, NH);
-    const SoapSet W = sets[d.legacy ? sp[i] : 0];
+    const SoapSet* Wp = sets + (d.legacy ? sp[i] : 0);
+    const SoapSet W = *Wp;
     const float* x = feats + (size_t)i * d.S;
     const float* xt = xd ? xd + (size_t)i * d.S : nullptr;
     float mu = 0.f, rstd = 1.f, mud = 0.f, mm = 0.f;
@@ -215,16 +217,16 @@ __global__ __launch_bounds__(256) void k_soap_tail_train(SoapDims d, const float
     if (wave != 0) return;
     // one wave from here: lane j < H owns row j of every hidden layer (LDS serves a wave's requests in order)
     const int j = lane;
-    float ak[2] = {0.f, 0.f}, adk[2] = {0.f, 0.f};  // NH <= 2 (soap_model_create)
     for (int k = 0; k < NH; k++) {
         float a = 0.f, ad = 0.f;
         if (j < H) {
             if (k == 0) { a = sa[j]; ad = sa[MAXH + j]; }
             else {
-                for (int q = 0; q < H; q++) { a += W.W2[j * H + q] * sb[q]; ad += W.W2[j * H + q] * sb[MAXH + q]; }
+                const float* wk = Wp->Wh[k - 1] + (size_t)j * H;
+                for (int q = 0; q < H; q++) { a += wk[q] * sb[q]; ad += wk[q] * sb[MAXH + q]; }
             }
+            sak[k][j] = a; sak[k][MAXH + j] = ad;
         }
-        ak[k] = a; adk[k] = ad;
         __builtin_amdgcn_wave_barrier();
         if (j < H) {
             const float h = silu(a), hd = dsilu(a) * ad;
@@ -248,17 +250,19 @@ __global__ __launch_bounds__(256) void k_soap_tail_train(SoapDims d, const float
     for (int k = NH - 1; k >= 0; k--) {
         float ab = 0.f, adb = 0.f;
         if (j < H) {
-            const float s1 = dsilu(ak[k]);
-            ab = hbar[j] * s1 + hbar[MAXH + j] * d2silu(ak[k]) * adk[k];
+            const float akk = sak[k][j], adkk = sak[k][MAXH + j];
+            const float s1 = dsilu(akk);
+            ab = hbar[j] * s1 + hbar[MAXH + j] * d2silu(akk) * adkk;
             adb = hbar[MAXH + j] * s1;
             pk[4 + 4 * H * k + j] = ab;
             pk[4 + 4 * H * k + H + j] = adb;
             sa[j] = ab; sa[MAXH + j] = adb;
         }
         __builtin_amdgcn_wave_barrier();
-        if (k > 0 && j < H) {   // through a_k = W2 h_{k-1}
+        if (k > 0 && j < H) {   // through a_k = W_k h_{k-1}
+            const float* wk = Wp->Wh[k - 1];
             float hb = 0.f, hdb = 0.f;
-            for (int q = 0; q < H; q++) { hb += W.W2[q * H + j] * sa[q]; hdb += W.W2[q * H + j] * sa[MAXH + q]; }
+            for (int q = 0; q < H; q++) { hb += wk[q * H + j] * sa[q]; hdb += wk[q * H + j] * sa[MAXH + q]; }
             hbar[j] = hb; hbar[MAXH + j] = hdb;
         }
         __builtin_amdgcn_wave_barrier();
@@ -352,27 +356,33 @@ __global__ void k_soap_wgrad1_reduce(SoapDims d, const float* __restrict__ part,
     else if (gB) gB[k] += v;
 }
 
-// hidden layers k >= 2 and the last layer: one workgroup per network, elements strided over the threads, atoms in order
-//   dW_k[j][q] = sum_i (abar_k[i][j] h_{k-1}[i][q] + adbar_k[i][j] h'_{k-1}[i][q]),  dw3[j] = sum_i (gA_i h_NH[i][j] + st h'_NH[i][j])
+// hidden layer kk (1 <= kk < NH) or the last layer (kk == NH): one workgroup per (network, layer), elements strided over the
+// threads, atoms in order
+//   dW_kk[j][q] = sum_i (abar_kk[i][j] h_{kk-1}[i][q] + adbar_kk[i][j] h'_{kk-1}[i][q]),  dw3[j] = sum_i (gA_i h_NH[i][j] + st h'_NH[i][j])
 __global__ __launch_bounds__(256) void k_soap_wgrad2(SoapDims d, const int* __restrict__ perm, const SpInfo* __restrict__ info,
                                                      const float* __restrict__ pack, const float* __restrict__ gA,
-                                                     float seed_tangent, int s, float* __restrict__ gW2,
-                                                     float* __restrict__ gw3) {
-    extern __shared__ float sp_[];   // [WG_ATOMS][PK + 1]
-    const int H = d.H, NH = d.NH, PK = soap_pack_size(H, NH), LD = PK + 1;
+                                                     float seed_tangent, int s, int kk, float* __restrict__ gout) {
+    extern __shared__ float sp_[];   // [WG_ATOMS][4 H + 1]: abar_kk | adbar_kk | h_{kk-1} | h'_{kk-1} | gA
+    const int H = d.H, NH = d.NH, PK = soap_pack_size(H, NH), LD = 4 * H + 1;
+    const bool last = kk == NH;
     const int a0 = info->offs[s], a1 = info->offs[s + 1];
-    constexpr int MAXE = (MAXH * MAXH + MAXH + 255) / 256;
+    constexpr int MAXE = (MAXH * MAXH + 255) / 256;
     double acc[MAXE];
 #pragma unroll
     for (int e = 0; e < MAXE; e++) acc[e] = 0.0;
-    const int n_el = (NH > 1 ? H * H : 0) + H;
+    const int n_el = last ? H : H * H;
     for (int b0 = a0; b0 < a1; b0 += WG_ATOMS) {
         const int nb = min(WG_ATOMS, a1 - b0);
         __syncthreads();
         for (int idx = threadIdx.x; idx < nb * LD; idx += 256) {
             const int a = idx / LD, c = idx % LD;
             const int at = perm[b0 + a];
-            sp_[idx] = c < PK ? pack[(size_t)at * PK + c] : gA[at];
+            const float* pk = pack + (size_t)at * PK + 4;
+            float v;
+            if (c == 4 * H) v = gA[at];
+            else if (c < 2 * H) v = last ? 0.f : pk[4 * H * kk + c];
+            else v = pk[4 * H * (kk - 1) + c];
+            sp_[idx] = v;
         }
         __syncthreads();
 #pragma unroll
@@ -380,17 +390,16 @@ __global__ __launch_bounds__(256) void k_soap_wgrad2(SoapDims d, const int* __re
             const int el = threadIdx.x + 256 * e;
             if (el >= n_el) continue;
             float v = 0.f;
-            if (NH > 1 && el < H * H) {
+            if (!last) {
                 const int j = el / H, q = el % H;
                 for (int a = 0; a < nb; a++) {
-                    const float* p = sp_ + a * LD + 4;
-                    v += p[4 * H + j] * p[2 * H + q] + p[4 * H + H + j] * p[3 * H + q];
+                    const float* p = sp_ + a * LD;
+                    v += p[j] * p[2 * H + q] + p[H + j] * p[3 * H + q];
                 }
             } else {
-                const int j = el - (NH > 1 ? H * H : 0);
                 for (int a = 0; a < nb; a++) {
-                    const float* p = sp_ + a * LD + 4 + 4 * H * (NH - 1);
-                    v += sp_[a * LD + PK] * p[2 * H + j] + seed_tangent * p[3 * H + j];
+                    const float* p = sp_ + a * LD;
+                    v += p[4 * H] * p[2 * H + el] + seed_tangent * p[3 * H + el];
                 }
             }
             acc[e] += (double)v;
@@ -399,9 +408,7 @@ __global__ __launch_bounds__(256) void k_soap_wgrad2(SoapDims d, const int* __re
 #pragma unroll
     for (int e = 0; e < MAXE; e++) {
         const int el = threadIdx.x + 256 * e;
-        if (el >= n_el) continue;
-        if (NH > 1 && el < H * H) gW2[el] += (float)acc[e];
-        else gw3[el - (NH > 1 ? H * H : 0)] += (float)acc[e];
+        if (el < n_el) gout[el] += (float)acc[e];
     }
 }
 
@@ -476,7 +483,7 @@ static int soap_train_grads(SoapModel& m, const Graph& g, void* ws, int64_t ws_b
     PET_REQUIRE(d.legacy, PET_ERR_UNSUPPORTED,
                 "SOAP-BPNN training is built for legacy = True models (the species embedding and centre encoding of "
                 "legacy = False have no gradient kernels)");
-    PET_REQUIRE(d.H <= MAXH && d.NH <= 2, PET_ERR_UNSUPPORTED, "tail size outside the compiled limits");
+    PET_REQUIRE(d.H <= MAXH && d.NH <= MAXNH, PET_ERR_UNSUPPORTED, "tail size outside the compiled limits");
     PET_REQUIRE(!m.grad.empty(), PET_ERR_ARGUMENT, "soap_model_zero_grad has not been called");
     PET_REQUIRE(!soap_fused_ok(m), PET_ERR_UNSUPPORTED,
                 "training reads the stored power spectrum: switch pet_config_set(\"soap_fused\", 0)");
@@ -508,7 +515,6 @@ static int soap_train_grads(SoapModel& m, const Graph& g, void* ws, int64_t ws_b
     k_sp_fill<<<cdiv(N, 256), 256, 0, st>>>(g.sp, d.legacy, N, t.info, t.perm);
     k_soap_wgrad1<<<dim3(cdiv(d.S, 64), m.n_sets, t.n_chunks), 64, 0, st>>>(d, w.feats, xd, t.perm, t.info, m.sets, t.pack,
                                                                           t.n_chunks, t.part);
-    const int PK = soap_pack_size(d.H, d.NH);
     for (int s = 0; s < m.n_sets; s++) {
         const std::string ss = std::to_string(s);
         float* gW1 = m.grad.at("bpnn." + ss + ".0.weight").first;
@@ -516,9 +522,12 @@ static int soap_train_grads(SoapModel& m, const Graph& g, void* ws, int64_t ws_b
         float* gB = d.layernorm ? m.grad.at("layernorm." + ss + ".bias").first : nullptr;
         k_soap_wgrad1_reduce<<<cdiv((int64_t)(d.H + 2) * d.S, 256), 256, 0, st>>>(d, t.part, t.n_chunks, m.n_sets, s, gW1,
                                                                                gG, gB);
-        float* gW2 = d.NH > 1 ? m.grad.at("bpnn." + ss + ".2.weight").first : nullptr;
-        float* gw3 = m.grad.at("last_layers.energy." + ss + ".weight").first;
-        k_soap_wgrad2<<<1, 256, (size_t)WG_ATOMS * (PK + 1) * 4, st>>>(d, t.perm, t.info, t.pack, gA, seed_t, s, gW2, gw3);
+        const size_t lds2 = (size_t)WG_ATOMS * (4 * d.H + 1) * 4;
+        for (int kk = 1; kk < d.NH; kk++)
+            k_soap_wgrad2<<<1, 256, lds2, st>>>(d, t.perm, t.info, t.pack, gA, seed_t, s, kk,
+                                                m.grad.at("bpnn." + ss + "." + std::to_string(2 * kk) + ".weight").first);
+        k_soap_wgrad2<<<1, 256, lds2, st>>>(d, t.perm, t.info, t.pack, gA, seed_t, s, d.NH,
+                                            m.grad.at("last_layers.energy." + ss + ".weight").first);
     }
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;

@@ -112,7 +112,8 @@ def test_ethanol_frames_energy_and_forces():
     assert _relmax(grad.cpu().numpy(), g_ref.numpy()) < TOL
 
 
-@pytest.mark.parametrize("case", ["ethanol", "boxes", "boxes_no_layernorm", "boxes_one_hidden_layer", "energy_only"])
+@pytest.mark.parametrize("case", ["ethanol", "boxes", "boxes_no_layernorm", "boxes_one_hidden_layer",
+                                  "boxes_four_hidden_layers", "energy_only"])
 def test_training_gradients_against_the_oracles_double_backward(case):
     dev = torch.device("cuda:0")
     hypers = dict(osoap.DEFAULT_HYPERS)
@@ -120,6 +121,8 @@ def test_training_gradients_against_the_oracles_double_backward(case):
         hypers["bpnn"] = dict(hypers["bpnn"], layernorm=False)
     if case == "boxes_one_hidden_layer":
         hypers["bpnn"] = dict(hypers["bpnn"], num_hidden_layers=1)
+    if case == "boxes_four_hidden_layers":
+        hypers["bpnn"] = dict(hypers["bpnn"], num_hidden_layers=4)
     types = [1, 6, 8] if case == "ethanol" else [1, 6, 7, 8]
     batch = _ethanol() if case == "ethanol" else _random_batch()
     with_forces = case != "energy_only"
