@@ -210,7 +210,8 @@ int64_t pet_forward_workspace_bytes(const pet_model_t* m, int64_t n_nodes, int64
  * reference pads to any max(num_neighbors), pet/modules/structures.py:292-294) runs on a size-generic path with its own,
  * larger workspace layout. pet_forward_workspace_bytes answers for the model alone; a caller that may meet dense graphs
  * sizes the workspace with this function. Training of other sizes / PostLN / residual models runs on that path too
- * (pet_train_workspace_bytes answers for the model); training on graphs with more than 127 neighbours per atom is refused. */
+ * (pet_train_workspace_bytes answers for the model, pet_train_workspace_bytes_for / pet_train2_workspace_bytes_for for a
+ * built graph: a model of the compiled size trains on a graph with a denser atom through that path as well). */
 int64_t pet_forward_workspace_bytes_for(const pet_model_t* m, const pet_graph_t* g);
 /* calculate_features + predict for the fused target (the heads uploaded under the name "@", one property):
  *   d_atomic [N]       per-atom prediction (node + sum of cutoff-weighted edge terms); NULL = features only
@@ -352,6 +353,7 @@ int pet_optimizer_state(pet_model_t* m, float* d_m, float* d_v, int64_t numel, i
 int pet_model_tie_halves(pet_model_t* m, const char* key);
 /* Workspace for pet_forward(save_for_backward = 2) + pet_backward_train. */
 int64_t pet_train_workspace_bytes(const pet_model_t* m, int64_t n_nodes, int64_t n_edges);
+int64_t pet_train_workspace_bytes_for(const pet_model_t* m, const pet_graph_t* g);   /* graph-aware (dense atoms) */
 /* Reverse pass of loss.backward() for L with dL/d(atomic prediction) = d_grad_atomic [N]:
  * accumulates dL/dtheta into the model's gradient slots; d_grad_positions [N,3] (and d_grad_cells)
  * may be NULL. Needs pet_forward(save_for_backward = 2) on a training workspace. */
@@ -367,6 +369,7 @@ int pet_backward_train(const pet_model_t* m, const pet_graph_t* g, void* d_works
  * Accumulates dL/dtheta into the gradient slots. Needs pet_forward(save_for_backward = 2) on a
  * training workspace plus a second workspace of pet_train2_workspace_bytes. */
 int64_t pet_train2_workspace_bytes(const pet_model_t* m, int64_t n_nodes, int64_t n_edges);
+int64_t pet_train2_workspace_bytes_for(const pet_model_t* m, const pet_graph_t* g);  /* graph-aware (dense atoms) */
 int pet_backward_train2(const pet_model_t* m, const pet_graph_t* g, void* d_workspace,
                         int64_t workspace_bytes, void* d_workspace2, int64_t workspace2_bytes,
                         const float* d_lambda_atomic, const float* d_nu_atomic, const float* d_u,

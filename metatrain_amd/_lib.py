@@ -33,7 +33,8 @@ SYMBOLS = [
     "pet_forward_workspace_bytes", "pet_forward_workspace_bytes_for", "pet_forward", "pet_aux_outputs", "pet_backward", "pet_backward_predict",
     "pet_backward_features", "pet_backward_geometry",
     "pet_model_num_readout_layers", "pet_forward_layers", "pet_backward_features_layers", "pet_graph_set_conditioning", "pet_graph_set_exchange",
-    "pet_model_zero_grad", "pet_model_get_grad", "pet_train_workspace_bytes", "pet_backward_train",
+    "pet_model_zero_grad", "pet_model_get_grad", "pet_train_workspace_bytes", "pet_train_workspace_bytes_for",
+    "pet_train2_workspace_bytes_for", "pet_backward_train",
     "pet_model_get_param", "pet_model_flat_grad", "pet_adam_step", "pet_optimizer_state", "pet_model_tie_halves",
     "pet_train2_workspace_bytes", "pet_backward_train2", "pet_backward_train2_cell",
     "pet_sum_over_atoms",
@@ -189,6 +190,9 @@ def load() -> ctypes.CDLL:
     lib.pet_backward_train2_cell.argtypes = [P, P, P, c_int64, P, c_int64, P, P, P, P, P, P]
     lib.pet_train_workspace_bytes.argtypes = [P, c_int64, c_int64]
     lib.pet_train_workspace_bytes.restype = c_int64
+    for fn in (lib.pet_train_workspace_bytes_for, lib.pet_train2_workspace_bytes_for):
+        fn.argtypes = [P, P]
+        fn.restype = c_int64
     lib.pet_backward_train.argtypes = [P, P, P, c_int64, P, P, P, P]
     lib.pet_sum_over_atoms.argtypes = [P, P, P, P]
     lib.pet_profile_enable.argtypes = [c_int]

@@ -530,6 +530,18 @@ int64_t pet_train_workspace_bytes(const pet_model_t* pm, int64_t n_nodes, int64_
     return forward_workspace_bytes(pm->m, n_nodes, n_edges, true);
 }
 
+int64_t pet_train_workspace_bytes_for(const pet_model_t* pm, const pet_graph_t* pg) {
+    if (!pm || !pg) return -1;
+    if (use_generic(pm->m, pg->g)) return gen_workspace_bytes(pm->m, pg->g.n_nodes, pg->g.n_edges);
+    return forward_workspace_bytes(pm->m, pg->g.n_nodes, pg->g.n_edges, true);
+}
+
+int64_t pet_train2_workspace_bytes_for(const pet_model_t* pm, const pet_graph_t* pg) {
+    if (!pm || !pg) return -1;
+    if (use_generic(pm->m, pg->g)) return gen_train_workspace_bytes(pm->m, pg->g.n_nodes, pg->g.n_edges);
+    return so_workspace_bytes(pm->m, pg->g.n_nodes, pg->g.n_edges);
+}
+
 int pet_backward_train(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                        const float* d_grad_atomic, float* d_grad_positions, float* d_grad_cells, void* stream) {
     PET_REQUIRE(pm && pg && d_workspace && d_grad_atomic, PET_ERR_ARGUMENT, "null argument");

@@ -724,6 +724,81 @@ struct TOps {
     }
 };
 
+// ---- system conditioning (conditioning.py:82-100; backend.py:543-545, :628-629): cond_s = W2 silu(W0 [emb_q ; emb_m] + b0)
+// + b2 is added to the node features LEAVING every GNN layer. It does not move with the positions (no tangent), so its
+// parameters see the nu-adjoint of those features only, summed over the atoms of each system.
+__global__ void k_gt_cond_accum(const float* __restrict__ dH, const int* __restrict__ sys32, const int64_t* __restrict__ sys64,
+                                int N, int W, float* __restrict__ dcond, int accumulate) {
+    // one block per system; its atoms are a contiguous run of the non-decreasing system indices; fixed summation order
+    __shared__ int range[2];
+    const int s = blockIdx.x;
+    if (threadIdx.x == 0) {
+        auto at = [&](int i) { return sys64 ? sys64[i] : (int64_t)sys32[i]; };
+        int a = 0, b = N;
+        while (a < b) { const int mid = (a + b) >> 1; if (at(mid) < s) a = mid + 1; else b = mid; }
+        range[0] = a; b = N;
+        while (a < b) { const int mid = (a + b) >> 1; if (at(mid) < s + 1) a = mid + 1; else b = mid; }
+        range[1] = a;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < W; c += blockDim.x) {
+        float acc = 0.f;
+        for (int i = range[0]; i < range[1]; i++) acc += dH[(size_t)i * W + c];
+        dcond[(size_t)s * W + c] = accumulate ? dcond[(size_t)s * W + c] + acc : acc;
+    }
+}
+// ONE block walks the systems in order (a handful of rows; deterministic): every thread owns whole rows / columns of the
+// gradient slots it adds to, so nothing races
+__global__ __launch_bounds__(256) void k_gt_cond_bwd(const int64_t* __restrict__ charge, const int64_t* __restrict__ spin,
+                                                     const float* __restrict__ qe, const float* __restrict__ se,
+                                                     const float* __restrict__ w0, const float* __restrict__ b0,
+                                                     const float* __restrict__ w2, const float* __restrict__ dcond, int n_sys,
+                                                     int max_charge, int max_spin, int DN, float* __restrict__ gq,
+                                                     float* __restrict__ gm, float* __restrict__ gw0, float* __restrict__ gb0,
+                                                     float* __restrict__ gw2, float* __restrict__ gb2) {
+    extern __shared__ float sm[];  // x [2 DN] | a [DN] | hid [DN] | da [DN] | dc [DN]
+    float *x = sm, *a = sm + 2 * DN, *hid = a + DN, *da = hid + DN, *dc = da + DN;
+    for (int s = 0; s < n_sys; s++) {
+        int q = (int)charge[s] + max_charge, mi = (int)spin[s] - 1;
+        q = q < 0 ? 0 : (q > 2 * max_charge ? 2 * max_charge : q);
+        mi = mi < 0 ? 0 : (mi > max_spin - 1 ? max_spin - 1 : mi);
+        __syncthreads();
+        for (int k = threadIdx.x; k < DN; k += blockDim.x) {
+            x[k] = qe[(size_t)q * DN + k];
+            x[DN + k] = se[(size_t)mi * DN + k];
+            dc[k] = dcond[(size_t)s * DN + k];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < DN; t += blockDim.x) {
+            float v = b0[t];
+            for (int k = 0; k < 2 * DN; k++) v = fmaf(w0[(size_t)t * 2 * DN + k], x[k], v);
+            a[t] = v;
+            hid[t] = v * gsig(v);
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < DN; t += blockDim.x) {
+            float dh = 0.f;
+            for (int o = 0; o < DN; o++) dh = fmaf(w2[(size_t)o * DN + t], dc[o], dh);
+            const float sg = gsig(a[t]);
+            da[t] = dh * sg * (1.0f + a[t] * (1.0f - sg));
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < DN; t += blockDim.x) {   // rows t of project.0 / project.2 and their biases
+            const float dat = da[t], dct = dc[t];
+            for (int k = 0; k < 2 * DN; k++) gw0[(size_t)t * 2 * DN + k] += dat * x[k];
+            for (int k = 0; k < DN; k++) gw2[(size_t)t * DN + k] += dct * hid[k];
+            gb0[t] += dat;
+            gb2[t] += dct;
+        }
+        for (int k = threadIdx.x; k < 2 * DN; k += blockDim.x) {   // columns k of the two embedding rows
+            float dx = 0.f;
+            for (int o = 0; o < DN; o++) dx = fmaf(w0[(size_t)o * 2 * DN + k], da[o], dx);
+            if (k < DN) gq[(size_t)q * DN + k] += dx;
+            else gm[(size_t)mi * DN + (k - DN)] += dx;
+        }
+    }
+}
+
 }  // namespace
 
 int64_t gen_train_workspace_bytes(const Model& m, int64_t N, int64_t E) {
@@ -737,8 +812,10 @@ int64_t gen_train_workspace_bytes(const Model& m, int64_t N, int64_t E) {
 int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, const float* lA, const float* nA, const float* u,
                const float* ucell, float* tangent_atomic, hipStream_t st) {
     PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
-    PET_REQUIRE(!m.h.system_conditioning, PET_ERR_UNSUPPORTED,
-                "training of a conditioned model is built for the compiled model size, PreLN, feedforward only");
+    const bool conditioned = m.h.system_conditioning != 0;
+    if (conditioned)
+        PET_REQUIRE(g.cond_charge && g.n_cond_systems >= 1 && g.n_cond_systems <= g.n_nodes, PET_ERR_ARGUMENT,
+                    "system_conditioning: call pet_graph_set_conditioning (charge, spin multiplicity, system indices) first");
     PET_REQUIRE(!g.adaptive, PET_ERR_UNSUPPORTED,
                 "training with the adaptive cutoff is built for the compiled model size, PreLN, feedforward only");
     TWs w;
@@ -763,6 +840,15 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
                     "training needs the single-property target uploaded as the fused head of every readout layer");
         heads[l] = &hi->second;
         lasts[l] = &li->second;
+    }
+    float *cond = nullptr, *dcond = nullptr;   // [n_systems][DN] per-system embedding and its nu-adjoint
+    if (conditioned) {
+        const size_t nc = (size_t)g.n_cond_systems * DN;
+        PET_HIP_CHECK(hipMallocAsync((void**)&cond, 2 * nc * sizeof(float), st));
+        dcond = cond + nc;
+        k_gen_system_cond<<<(int)g.n_cond_systems, 128, 3 * DN * sizeof(float), st>>>(
+            g.cond_charge, g.cond_spin, m.cond_qe, m.cond_se, m.cond_w0, m.cond_b0, m.cond_w2, m.cond_b2, cond, m.h.max_charge,
+            DN);
     }
     // ---------------- sweep 1: dual forward ----------------
     // geometry: primal = the graph's geo / fc, tangent along (u, ucell)
@@ -839,6 +925,8 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
             } else
                 t.copy(Ab.TOKo, Ab.Hn, N, DN);
         }
+        if (conditioned)   // backend.py:543-545: the node features LEAVING the GNN layer (primal only: no tangent)
+            k_gen_add_cond<<<g1(N * DN), 256, 0, st>>>(B.Hout.p, cond, g.sys, g.cond_sys, N, DN);
         if (res) {
             if (gi + 1 < L) t.axpby(0.5f, Min, D, 0.5f, B.XF, D, g.rev, B.Mout, D, false, E, D);
         } else {
@@ -869,7 +957,7 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
     float* extra = nullptr;
     {
         size_t fl = 0;
-        if (NR > 1) fl = (size_t)NR * 2 * ((size_t)N * DN + (size_t)E * D);
+        if (NR > 1 || res) fl = (size_t)NR * 2 * ((size_t)N * DN + (size_t)E * D);   // (residual, one layer: dM is zeroed below)
         fl += 2 * (size_t)(N + E) + 4 * (size_t)(N + E);   // predictions (dual) and their adjoints
         PET_HIP_CHECK(hipMallocAsync((void**)&extra, fl * sizeof(float), st));
     }
@@ -879,7 +967,7 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
     D2 nnp{ex, ex + N}; ex += 2 * N;
     D2 nep{ex, ex + E}; ex += 2 * E;
     for (int l = 0; l < NR; l++) {
-        if (NR > 1) {
+        if (NR > 1 || res) {
             dHl[l] = D2{ex, ex + N * DN}; ex += 2 * N * DN;
             dMl[l] = D2{ex, ex + E * D}; ex += 2 * E * D;
         } else { dHl[l] = w.dH; dMl[l] = w.dM; }
@@ -953,6 +1041,8 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
             t.axpby(1.f, w.tE[1], 2 * D, 1.f, dCATr, 2 * D, g.rev, dXF, D, true, E, D);
             t.copy(w.dM, dMin, E, D);
         }
+        if (conditioned)
+            k_gt_cond_accum<<<(int)g.n_cond_systems, 256, 0, st>>>(w.dH.p, g.sys, g.cond_sys, (int)N, DN, dcond, gi == L - 1 ? 0 : 1);
         for (int a = AL - 1; a >= 0; a--) {
             const AttnLayerW& A = G.attn[a];
             TAttn& Ab = B.attn[a];
@@ -1049,6 +1139,16 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
         }
     }
     t.embed_grad(g.sp_nbr, w.dM.p, D, E, D, m.edge_emb);   // the first layer's messages are the neighbour embedding
+    if (conditioned) {
+        float *gq = t.slot(m.cond_qe), *gm = t.slot(m.cond_se), *gw0 = t.slot(m.cond_w0), *gb0 = t.slot(m.cond_b0),
+              *gw2 = t.slot(m.cond_w2), *gb2 = t.slot(m.cond_b2);
+        if (!t.err)
+            k_gt_cond_bwd<<<1, 256, 6 * DN * sizeof(float), st>>>(g.cond_charge, g.cond_spin, m.cond_qe, m.cond_se, m.cond_w0,
+                                                                  m.cond_b0, m.cond_w2, dcond, (int)g.n_cond_systems,
+                                                                  m.h.max_charge, m.h.max_spin_multiplicity, DN, gq, gm, gw0,
+                                                                  gb0, gw2, gb2);
+        PET_HIP_CHECK(hipFreeAsync(cond, st));
+    }
     PET_HIP_CHECK(hipFreeAsync(extra, st));
     PET_HIP_CHECK(hipGetLastError());
     return t.err;

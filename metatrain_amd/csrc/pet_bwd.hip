@@ -1529,7 +1529,9 @@ int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const f
 // Needs a forward run with save_for_backward = 2 on a training workspace.
 int backward_train(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA, float* gpos,
                    float* gcell, hipStream_t st) {
-    if (train_generic(m)) {   // other sizes, PostLN, residual: the energy term alone = the second-order pass without a tangent
+    // other sizes, PostLN, residual, and any graph with an atom of more than 127 neighbours: the energy term alone = the
+    // size-generic second-order pass without a tangent
+    if (train_generic(m) || use_generic(m, g)) {
         PET_REQUIRE(generic_workspace(ws), PET_ERR_ARGUMENT, "pet_forward with save_for_backward = 2 has not run on this workspace");
         void* ws2 = nullptr;
         const int64_t n2 = gen_train_workspace_bytes(m, g.n_nodes, g.n_edges);
@@ -1539,8 +1541,6 @@ int backward_train(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, c
         if (!rc && gpos) rc = gen_backward(m, g, ws, ws_bytes, gA, gpos, gcell, st);
         return rc;
     }
-    PET_REQUIRE(!use_generic(m, g), PET_ERR_UNSUPPORTED,
-                "training with more than 127 neighbours per atom is not built for the compiled model size");
     PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
     Workspace w;
     carve_workspace(m, g.n_nodes, g.n_edges, ws, w, true);

@@ -385,7 +385,7 @@ class HipForward:
         self.lib = model.lib
         self.train = train
         if train:
-            nbytes = int(self.lib.pet_train_workspace_bytes(model.handle, graph.n_nodes, graph.n_edges))
+            nbytes = int(self.lib.pet_train_workspace_bytes_for(model.handle, graph.handle))
         else:  # graph-aware: a graph with an atom of more than 127 neighbours runs on the size-generic path
             nbytes = int(self.lib.pet_forward_workspace_bytes_for(model.handle, graph.handle))
         if nbytes < 0:
@@ -396,7 +396,7 @@ class HipForward:
     def rebind(self, graph: "HipGraph") -> "HipForward":
         """Use this object's workspaces for another graph of the same model (micro-batches walk one allocation)."""
         if self.train:
-            need = int(self.lib.pet_train_workspace_bytes(self.model.handle, graph.n_nodes, graph.n_edges))
+            need = int(self.lib.pet_train_workspace_bytes_for(self.model.handle, graph.handle))
         else:
             need = int(self.lib.pet_forward_workspace_bytes_for(self.model.handle, graph.handle))
         if need > self.nbytes:
@@ -535,7 +535,7 @@ class HipForward:
         g = self.graph
         dev = self.workspace.device
         _require_cuda(lambda_atomic, u)
-        n2 = int(self.lib.pet_train2_workspace_bytes(self.model.handle, g.n_nodes, g.n_edges))
+        n2 = int(self.lib.pet_train2_workspace_bytes_for(self.model.handle, g.handle))
         if getattr(self, "workspace2", None) is None or self.workspace2.numel() < n2:
             self.workspace2 = torch.empty(n2, dtype=torch.uint8, device=dev)
         la = lambda_atomic.to(torch.float32).contiguous()

@@ -149,3 +149,98 @@ def test_native_training_steps_reduce_the_loss_and_follow_torch(golden_dir, tag)
     losses = [float(step(graph, fw, te.to(dev), n_atoms.to(dev), tg.to(dev))["loss"]) for _ in range(3)]
     np.testing.assert_allclose(losses, ref_losses, rtol=5e-5)
     assert (losses[-1] < losses[0]) == (ref_losses[-1] < ref_losses[0])
+
+
+@pytest.mark.parametrize("tag,extra", [
+    ("cond8_flat", dict(d_pet=8, d_head=8, d_node=8, d_feedforward=8, num_heads=1, num_attention_layers=1, num_gnn_layers=1)),
+    ("cond8_residual", dict(d_pet=8, d_head=8, d_node=8, d_feedforward=8, num_heads=1, num_attention_layers=1, num_gnn_layers=1,
+                            featurizer_type="residual")),
+    ("cond8_16", dict(d_pet=8, d_head=8, d_node=16, d_feedforward=8, num_heads=1, num_attention_layers=1, num_gnn_layers=1)),
+    ("cond_default_residual", dict(featurizer_type="residual")),
+])
+def test_conditioned_models_train_on_the_size_generic_path(golden_dir, tag, extra):
+    """``pet/tests/test_conditioning.py:28-40, 106-147`` trains conditioned models of d_pet = 8 (d_node 8 and 16, both
+    featurisers) before looking at their outputs: every parameter gradient, the six conditioning tensors included, of the
+    energy-only pass and of the force-loss pass against torch's (double) backward through the fp64 oracle."""
+    from metatrain_amd import runtime as rt
+    from test_gpu_train import _oracle_param_grads_cond
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS, system_conditioning=True, **extra)
+    params = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    inp = _inputs(golden_dir, "batch_two_systems.npz")
+    inp["charge"], inp["spin_multiplicity"] = torch.tensor([-2, 3]), torch.tensor([1, 4])
+    n = inp["positions"].shape[0]
+    gen = torch.Generator().manual_seed(17)
+    nu = torch.rand(n, generator=gen) - 0.5
+    u = torch.randn(n, 3, generator=gen)
+    model = rt.HipModel(hypers, TYPES)
+    model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    graph = rt.HipGraph(model, inp["positions"].float().to(dev), inp["cells"].float().to(dev),
+                        inp["centers"].to(dev), inp["neighbors"].to(dev), inp["cell_shifts"].to(dev),
+                        inp["species"].to(dev), inp["system_indices"].int().to(dev))
+    graph.set_conditioning(inp["charge"].to(dev), inp["spin_multiplicity"].to(dev), inp["system_indices"].to(dev))
+    fw = rt.HipForward(model, graph, train=True)
+    cond_keys = [k for k in params if k.startswith("system_conditioning.")]
+    assert len(cond_keys) == 6
+    w = torch.rand(n, generator=gen) + 0.5
+    ref1 = _oracle_param_grads_cond(params, hypers, inp, w)
+    model.zero_grad()
+    fw.forward()
+    fw.backward_train(w.to(dev))
+    got = model.grads()
+    _compare(got, ref1, model, f"{tag} energy term")
+    assert all(float(got[k].abs().max()) > 0 for k in cond_keys)
+    ref2, tan_ref, g_ref = _oracle_second_order(params, hypers, inp, nu, u)
+    model.zero_grad()
+    fw.forward()
+    ones = torch.ones(n, device=dev)
+    gpos = fw.backward(ones)
+    assert np.abs(gpos.cpu().numpy() - g_ref.numpy()).max() < TOL * np.abs(g_ref.numpy()).max()
+    tan = fw.backward_train2(ones, nu.to(dev), u.to(dev), want_tangent=True)
+    assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < 2 * TOL
+    _compare(model.grads(), ref2, model, f"{tag} force-loss term")
+
+
+def test_default_size_trains_on_a_graph_with_more_than_127_neighbours():
+    """structures.py:292-294 pads to any max(num_neighbors); the tuned second-order pass serves 127. A graph with a denser
+    atom runs its training forward, both reverse passes and the weight gradients on the size-generic path: parameter
+    gradients of the energy term and of the force-loss term against the oracle's (double) backward."""
+    from metatrain_amd import runtime as rt
+    from oracle import nl as onl
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS)
+    params = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    gen = torch.Generator().manual_seed(4)
+    n = 150
+    pos = torch.rand(n, 3, generator=gen, dtype=torch.float64) * 2.4   # every pair within the 4.5 A cutoff
+    cell = torch.eye(3, dtype=torch.float64) * 30.0
+    z = torch.tensor(TYPES)[torch.randint(0, 4, (n,), generator=gen)]
+    i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [False] * 3, hypers["cutoff"])
+    assert np.bincount(i, minlength=n).max() > 127
+    inp = {"positions": pos, "cells": cell[None], "centers": torch.tensor(i).long(), "neighbors": torch.tensor(j).long(),
+           "cell_shifts": torch.tensor(s).long(), "species": z, "system_indices": torch.zeros(n, dtype=torch.long)}
+    nu = torch.rand(n, generator=gen) - 0.5
+    u = torch.randn(n, 3, generator=gen)
+    w = torch.rand(n, generator=gen) + 0.5
+    model = rt.HipModel(hypers, TYPES)
+    model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    graph = rt.HipGraph(model, pos.float().to(dev), inp["cells"].float().to(dev), inp["centers"].to(dev),
+                        inp["neighbors"].to(dev), inp["cell_shifts"].to(dev), z.to(dev),
+                        inp["system_indices"].int().to(dev))
+    fw = rt.HipForward(model, graph, train=True)
+    ref1 = _oracle_param_grads(params, hypers, inp, w)
+    model.zero_grad()
+    fw.forward()
+    fw.backward_train(w.to(dev))
+    _compare(model.grads(), ref1, model, "dense graph, energy term")
+    ref2, tan_ref, g_ref = _oracle_second_order(params, hypers, inp, nu, u)
+    model.zero_grad()
+    fw.forward()
+    ones = torch.ones(n, device=dev)
+    gpos = fw.backward(ones)
+    assert np.abs(gpos.cpu().numpy() - g_ref.numpy()).max() < TOL * np.abs(g_ref.numpy()).max()
+    tan = fw.backward_train2(ones, nu.to(dev), u.to(dev), want_tangent=True)
+    assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < 2 * TOL
+    _compare(model.grads(), ref2, model, "dense graph, force-loss term")

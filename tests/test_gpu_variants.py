@@ -209,6 +209,64 @@ def test_variant_training_through_the_mirror(golden_dir, tag):
     assert worst < 2e-5, worst
 
 
+@pytest.mark.parametrize("featurizer", ["feedforward", "residual"])
+def test_small_conditioned_model_takes_gradient_steps_through_the_mirror(golden_dir, featurizer):
+    """The reference's own conditioning suite trains its d_pet = 8 models before it looks at them
+    (``pet/tests/test_conditioning.py:28-40, 119-135``: ``loss = energy.sum(); loss.backward(); p -= 0.01 p.grad``): the same
+    loop through the mirror in train() mode -- parameter.grad of every tensor, the conditioning ones included, against the
+    fp64 oracle at the same parameters, for three consecutive plain gradient steps (re-uploads included)."""
+    from metatrain_amd.pet import PETBackend
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS, system_conditioning=True, d_pet=8, d_head=8, d_node=8, d_feedforward=8, num_heads=1,
+                  num_attention_layers=1, num_gnn_layers=1, featurizer_type=featurizer)
+    g = dict(np.load(os.path.join(golden_dir, "batch_two_systems.npz")))
+    t = lambda k: torch.tensor(g[k])  # noqa: E731
+    params = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    charge, spin = torch.tensor([2, -1]), torch.tensor([3, 1])
+    be = PETBackend(hypers, TYPES)
+    be.add_output("energy", {"energy": [1]})
+    be.load_state_dict(params, strict=True)
+    be = be.to(dev).train()
+    keys = [k for k in params if k != "species_to_species_index"]
+    named = dict(be.named_parameters())
+    cells, sysidx = t("in_cells").float().to(dev), t("in_system_indices").to(dev)
+    for step in range(3):
+        # the oracle starts every step from the mirror's current fp32 parameters
+        p64 = {k: (params[k] if k == "species_to_species_index" else named[k].detach().cpu().double().requires_grad_(True))
+               for k in params}
+        pos = t("in_positions").float().to(dev)
+        batch = be.preprocess(pos, t("in_centers").to(dev), t("in_neighbors").to(dev), t("in_species").to(dev), cells,
+                              t("in_cell_shifts").to(dev), sysidx, 1.0)
+        batch["charge"], batch["spin_multiplicity"], batch["system_indices"] = charge.to(dev), spin.to(dev), sysidx
+        nodes, edges = be.calculate_features(batch)
+        pred, _, _ = be.predict(nodes, edges, batch, cells, sysidx, ["energy"])
+        loss = pred["energy"][0].sum()
+        loss.backward()
+        a_ref = opet.pet_atomic_energies(p64, hypers, t("in_positions").double(), t("in_cells").double(), t("in_centers"),
+                                         t("in_neighbors"), t("in_cell_shifts"), t("in_species"),
+                                         t("in_system_indices").long(), "energy", charge=charge, spin_multiplicity=spin)
+        l_ref = a_ref.sum()
+        ref = dict(zip(keys, torch.autograd.grad(l_ref, [p64[k] for k in keys], allow_unused=True)))
+        assert abs(float(loss) - float(l_ref)) < 1e-5 * max(1.0, abs(float(l_ref))), step
+        worst = 0.0
+        for k in keys:
+            if ref[k] is None:
+                continue
+            got = named[k].grad
+            assert got is not None, k
+            scale = float(ref[k].abs().max())
+            err = float((got.cpu().double() - ref[k]).abs().max())
+            worst = max(worst, err / scale if scale > 1e-12 else err)
+        assert worst < 2e-5, (step, worst)
+        assert all(float(named[k].grad.abs().max()) > 0 for k in keys if k.startswith("system_conditioning."))
+        with torch.no_grad():
+            for k in keys:
+                if named[k].grad is not None:
+                    named[k] -= 1e-5 * named[k].grad   # (0.01 x the gradients of these synthetic weights blows the model up)
+                    named[k].grad.zero_()
+
+
 def _conditioning_case(golden_dir, tag):
     hypers = dict(opet.DEFAULT_HYPERS, system_conditioning=True,
                   featurizer_type="residual" if tag == "residual" else "feedforward")
