@@ -739,13 +739,15 @@ int64_t pet_predict_scratch_floats(int64_t n_nodes, int64_t n_edges) { return pr
 int pet_predict(const pet_model_t* pm, const pet_graph_t* pg, const char* target, int32_t readout_layer, const char* block,
                 const float* d_node_features, const float* d_edge_features, const float* d_cutoff_factors, float* d_atomic,
                 float* d_node_hidden, float* d_edge_hidden, float* d_scratch, void* stream) {
-    PET_REQUIRE(pm && pg && d_node_features && d_atomic && d_scratch, PET_ERR_ARGUMENT, "null argument");
-    PET_REQUIRE(d_edge_features || pg->g.n_edges == 0, PET_ERR_ARGUMENT, "null edge features");
+    PET_REQUIRE(pm && pg, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
     const HeadW* H;
     const LastW* Lw;
     int rc = find_head(pm->m, target, readout_layer, block, &H, &Lw);
     if (rc) return rc;
+    if (pg->g.n_nodes == 0) return PET_OK;  // an empty system (pet/tests/test_functionality.py:79-103): nothing to write
+    PET_REQUIRE(d_node_features && d_atomic && d_scratch, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(d_edge_features || pg->g.n_edges == 0, PET_ERR_ARGUMENT, "null edge features");
     return predict(pm->m, pg->g, *H, *Lw, d_node_features, d_edge_features, d_cutoff_factors, d_atomic, d_node_hidden,
                    d_edge_hidden, d_scratch, (hipStream_t)stream);
 }
@@ -754,15 +756,16 @@ int pet_predict_backward(const pet_model_t* pm, const pet_graph_t* pg, const cha
                          const char* block, const float* d_node_features, const float* d_edge_features,
                          const float* d_cutoff_factors, const float* d_grad_atomic, float* d_grad_node_features,
                          float* d_grad_edge_features, float* d_grad_cutoff, float* d_scratch, void* stream) {
-    PET_REQUIRE(pm && pg && d_node_features && d_grad_atomic && d_grad_node_features && d_scratch, PET_ERR_ARGUMENT,
-                "null argument");
-    PET_REQUIRE((d_edge_features && d_grad_edge_features && d_grad_cutoff) || pg->g.n_edges == 0, PET_ERR_ARGUMENT,
-                "null edge argument");
+    PET_REQUIRE(pm && pg, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
     const HeadW* H;
     const LastW* Lw;
     int rc = find_head(pm->m, target, readout_layer, block, &H, &Lw);
     if (rc) return rc;
+    if (pg->g.n_nodes == 0) return PET_OK;
+    PET_REQUIRE(d_node_features && d_grad_atomic && d_grad_node_features && d_scratch, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE((d_edge_features && d_grad_edge_features && d_grad_cutoff) || pg->g.n_edges == 0, PET_ERR_ARGUMENT,
+                "null edge argument");
     return predict_backward(pm->m, pg->g, *H, *Lw, d_node_features, d_edge_features, d_cutoff_factors, d_grad_atomic,
                             d_grad_node_features, d_grad_edge_features, d_grad_cutoff, d_scratch, (hipStream_t)stream);
 }

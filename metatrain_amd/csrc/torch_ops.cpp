@@ -514,6 +514,7 @@ struct PredictFn : torch::autograd::Function<PredictFn> {
         ctx->saved_data["target"] = target;
         ctx->saved_data["block"] = block;
         ctx->saved_data["layer"] = layer;
+        ctx->saved_data["P"] = (int64_t)P;
         ctx->saved_data["dtype"] = (int64_t)nf.scalar_type();
         const auto dt = nf.scalar_type();
         at::Tensor he_nef = e > 0 ? to_nef(he, bg->ix, n, bg->m) : at::zeros({n, bg->m, h.d_head}, f32);
@@ -534,7 +535,7 @@ struct PredictFn : torch::autograd::Function<PredictFn> {
         const pet_hypers_t h = be->hypers_struct();
         TORCH_CHECK(!go[0].requires_grad(), "pet_hip: double backward through predict is not built");
         auto f32 = at::TensorOptions().dtype(at::kFloat).device(bg->ws.device());
-        at::Tensor ga = as_f32(go[0]).reshape({n, -1}).contiguous();
+        at::Tensor ga = as_f32(go[0]).reshape({n, ctx->saved_data["P"].toInt()}).contiguous();  // (n may be 0: empty system)
         at::Tensor g_nf = at::empty({n, h.d_node}, f32), g_ef = at::zeros({e, h.d_pet}, f32), g_fc = at::zeros({e}, f32);
         at::Tensor scratch = at::empty({pet_predict_scratch_floats(n, e)}, f32);
         check(pet_predict_backward(be->model, bg->g, target.c_str(), (int32_t)layer, block.c_str(), nf.data_ptr<float>(),

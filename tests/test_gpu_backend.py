@@ -104,6 +104,104 @@ def test_energy_forces_and_strain_gradient_via_autograd(dev):
     assert (gs.cpu().double() - gs64).abs().max() / gs64.abs().max() < TOL
 
 
+@pytest.mark.parametrize("variant", ["default", "small", "adaptive_solver", "adaptive_grid", "small_adaptive"])
+def test_empty_isolated_and_dissociated_systems_through_the_mirror(dev, variant):
+    """pet/tests/test_functionality.py:79-159 and test_adaptive_cutoff.py:408-500: an EMPTY system (zero-sized outputs, and a
+    backward that returns a [0, 3] gradient), one isolated atom, two atoms 100 A apart and a bonded pair -- tuned and
+    size-generic kernels, fixed and adaptive cutoffs (both methods): finite, equal to the oracle."""
+    from metatrain_amd.pet import PETBackend
+
+    extra = {"default": {}, "small": dict(d_pet=8, d_head=8, d_node=16, d_feedforward=8, num_heads=2),
+             "adaptive_solver": dict(num_neighbors_adaptive=5.0),
+             "adaptive_grid": dict(num_neighbors_adaptive=5.0, adaptive_cutoff_method="grid"),
+             "small_adaptive": dict(d_pet=8, d_head=8, d_node=16, d_feedforward=8, num_heads=2, num_neighbors_adaptive=5.0)}[variant]
+    hypers = dict(opet.DEFAULT_HYPERS, **extra)
+    types = [1, 6, 7, 8]
+    params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    be = PETBackend(hypers, types)
+    be.add_output("energy", {"energy": [1]})
+    be.load_state_dict(params, strict=True)
+    be = be.to(dev).eval()
+    p64 = {k: (v if k == "species_to_species_index" else v.double()) for k, v in params.items()}
+    systems = {"empty": (np.zeros((0, 3)), []), "isolated": (np.zeros((1, 3)), [6]),
+               "dissociated": (np.array([[0, 0, 0], [0, 0, 100.0]]), [6, 6]), "pair": (np.array([[0, 0, 0], [0, 0, 1.2]]), [6, 8])}
+    for name, (pos, z) in systems.items():
+        i, j, s, _ = onl.neighbor_list(pos, np.zeros((3, 3)), [False] * 3, hypers["cutoff"])
+        ti = lambda a: torch.tensor(np.asarray(a), dtype=torch.long, device=dev)  # noqa: E731
+        p = torch.tensor(pos, dtype=torch.float32, device=dev).reshape(-1, 3).requires_grad_(True)
+        cells = torch.zeros(1, 3, 3, device=dev)
+        sysidx = torch.zeros(len(z), dtype=torch.long, device=dev)
+        batch = be.preprocess(p, ti(i), ti(j), ti(z), cells, ti(s).reshape(-1, 3), sysidx, float(hypers["cutoff_width_adaptive"]))
+        nodes, edges = be.calculate_features(batch)
+        pred, _, _ = be.predict(nodes, edges, batch, cells, sysidx, ["energy"])
+        atomic = pred["energy"][0]
+        (grad,) = torch.autograd.grad(atomic.sum(), p)
+        assert atomic.shape == (len(z), 1) and grad.shape == (len(z), 3), name
+        assert torch.isfinite(atomic).all() and torch.isfinite(grad).all(), name
+        if len(z):
+            ref = opet.pet_atomic_energies(p64, hypers, torch.tensor(pos).double().reshape(-1, 3),
+                                           torch.zeros(1, 3, 3, dtype=torch.float64), torch.tensor(i).long(),
+                                           torch.tensor(j).long(), torch.tensor(s).long().reshape(-1, 3), torch.tensor(z),
+                                           torch.zeros(len(z), dtype=torch.long))
+            assert float((atomic.detach().cpu().double() - ref).abs().max() / ref.abs().max()) < TOL, name
+
+
+@pytest.mark.parametrize("fullgraph", [False, True])
+def test_backend_torch_compile(dev, fullgraph):
+    """pet/tests/test_backend.py:177-330: ``torch.compile`` of the three backend calls (under the Dynamo flags the reference
+    sets) matches eager execution on the adaptive-cutoff path and a periodic system: ``preprocess``'s twelve tensors,
+    energy, forces and the strain gradient -- and the eager values are the oracle's."""
+    from metatrain_amd.pet import PETBackend, default_hypers
+
+    hypers = dict(default_hypers(), num_neighbors_adaptive=5.0)
+
+    def make():
+        be = PETBackend(hypers, [1, 6, 7, 8])
+        be.add_output("energy", {"energy": [1]})
+        be.load_state_dict(opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}))
+        return be.to(dev).eval()
+
+    base = torch.tensor([[0.0, 0.0, 0.0], [1.5, 1.5, 1.5]])
+    cell = 3.5 * torch.eye(3)
+    i, j, s, z, sysidx = _inputs(base.numpy(), [6, 8], cell.numpy(), [True] * 3, hypers["cutoff"], dev)
+    cwa = float(hypers["cutoff_width_adaptive"]) if "cutoff_width_adaptive" in hypers else 1.0
+
+    def results(be):
+        p = base.to(dev).requires_grad_(True)
+        st = torch.eye(3, device=dev).requires_grad_(True)
+        cells = (cell.to(dev) @ st)[None]
+        batch = be.preprocess(p @ st, i, j, z, cells, s, sysidx, cwa)
+        nodes, edges = be.calculate_features(batch)
+        pred, _, _ = be.predict(nodes, edges, batch, cells, sysidx, ["energy"])
+        e = pred["energy"][0].sum()
+        gp, gs = torch.autograd.grad(e, [p, st])
+        return {k: v.detach() for k, v in batch.items()}, e.detach(), gp, gs
+
+    batch_e, e_e, gp_e, gs_e = results(make())
+    be = make()
+    with torch._dynamo.config.patch(capture_scalar_outputs=True, capture_dynamic_output_shape_ops=True, specialize_int=True):
+        be.preprocess = torch.compile(be.preprocess, fullgraph=fullgraph)
+        be.calculate_features = torch.compile(be.calculate_features, fullgraph=fullgraph)
+        be.predict = torch.compile(be.predict, fullgraph=fullgraph)
+        batch_c, e_c, gp_c, gs_c = results(be)
+    assert set(batch_c) == set(batch_e)
+    for key in batch_e:
+        assert batch_e[key].shape == batch_c[key].shape, key
+        torch.testing.assert_close(batch_e[key], batch_c[key])
+    torch.testing.assert_close(e_c, e_e)
+    torch.testing.assert_close(gp_c, gp_e)
+    torch.testing.assert_close(gs_c, gs_e)
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float64)
+    p64 = base.double().requires_grad_(True)
+    st64 = torch.eye(3, dtype=torch.float64).requires_grad_(True)
+    e64 = opet.pet_atomic_energies(params, hypers, p64 @ st64, (cell.double() @ st64)[None], i.cpu(), j.cpu(), s.cpu().long(),
+                                   z.cpu(), sysidx.cpu()).sum()
+    gp64, gs64 = torch.autograd.grad(e64, [p64, st64])
+    assert abs(float(e_c) - float(e64)) / abs(float(e64)) < TOL
+    assert (gp_c.cpu().double() - gp64).abs().max() / gp64.abs().max() < TOL
+    assert (gs_c.cpu().double() - gs64).abs().max() / gs64.abs().max() < TOL
+
+
 def test_seed0_backend_reproduces_reference_regression_energies(dev, golden_dir):
     """The reference's own golden numbers (pet/tests/test_regression.py:66-74): fresh model under
     torch.manual_seed(0), first five QM9 frames, per-system energies."""
