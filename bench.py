@@ -201,7 +201,10 @@ def main():
     from metatrain_amd.pet import default_hypers
     from metatrain_amd.synthetic import random_box
 
+    side_stream = 1   # the production configuration (csrc default); `--set side_stream=0` keeps the step on one stream
     for kv in args.set:
+        if kv.split("=")[0] == "side_stream":
+            side_stream = int(kv.split("=")[1])
         key, val = kv.split("=")
         rt.config_set(key, int(val))
     hypers = dict(default_hypers(), normalization=args.normalization)
@@ -279,7 +282,7 @@ def main():
     torch.cuda.synchronize()
     table = rt.profile_report()
     rt.profile(False)
-    rt.config_set("side_stream", 1)
+    rt.config_set("side_stream", side_stream)
     dominant = max(table, key=lambda r: r["total_ms"])["name"]
     if args.profile_all and rank == 0:
         for r in sorted(table, key=lambda r: -r["total_ms"]):

@@ -71,6 +71,15 @@ ProfScope::ProfScope(const char* n, hipStream_t s, double f, double b) : name(n)
     if (!g_prof_on || (!g_prof_filter.empty() && g_prof_filter != n)) return;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
+    // The start stamp must not be taken while the previous kernel of the stream is still draining (a marker is stamped
+    // when the command processor reaches it: measured 2.22 ms for a kernel whose rocprofv3 duration is 1.82 ms): make the
+    // stream wait for everything before the scope first, then stamp.
+    hipEvent_t fence = nullptr;
+    if (hipEventCreateWithFlags(&fence, hipEventDisableTiming) == hipSuccess) {
+        (void)hipEventRecord(fence, st);
+        (void)hipStreamWaitEvent(st, fence, 0);
+        (void)hipEventDestroy(fence);
+    }
     (void)hipEventRecord(e0, st);
 }
 ProfScope::~ProfScope() {
