@@ -816,8 +816,6 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
     if (conditioned)
         PET_REQUIRE(g.cond_charge && g.n_cond_systems >= 1 && g.n_cond_systems <= g.n_nodes, PET_ERR_ARGUMENT,
                     "system_conditioning: call pet_graph_set_conditioning (charge, spin multiplicity, system indices) first");
-    PET_REQUIRE(!g.adaptive, PET_ERR_UNSUPPORTED,
-                "training with the adaptive cutoff is built for the compiled model size, PreLN, feedforward only");
     TWs w;
     train_carve(m, g.n_nodes, g.n_edges, ws2, w);
     PET_REQUIRE((int64_t)w.bytes <= ws2_bytes, PET_ERR_ARGUMENT, "second-order workspace too small");
@@ -855,9 +853,13 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
     PET_HIP_CHECK(hipMemcpyAsync(w.geo.p, g.geo, E * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (u) {
         PET_REQUIRE(!ucell || g.shift, PET_ERR_ARGUMENT, "a cell tangent needs a pet_graph_build handle (cell shifts)");
-        k_gt_geo<<<g1(E), 256, 0, st>>>(g.geo, g.d0, g.fc, g.ctr, g.nbr, g.shift, g.sys, u, ucell,
-                                        reinterpret_cast<float4*>(w.geo.t), w.fcd, w.bd, E, m.h.cutoff, m.h.cutoff_width,
-                                        m.h.cutoff_function);
+        if (g.adaptive) {   // the pair cutoffs move with the positions too (so.hip: implicit-function tangent of the solver)
+            int rc = geometry_tangent(m, g, u, ucell, w.geo.t, w.fcd, w.bd, st);
+            if (rc) return rc;
+        } else
+            k_gt_geo<<<g1(E), 256, 0, st>>>(g.geo, g.d0, g.fc, g.ctr, g.nbr, g.shift, g.sys, u, ucell,
+                                            reinterpret_cast<float4*>(w.geo.t), w.fcd, w.bd, E, m.h.cutoff, m.h.cutoff_width,
+                                            m.h.cutoff_function);
     } else {
         PET_HIP_CHECK(hipMemsetAsync(w.geo.t, 0, E * 4 * sizeof(float), st));
         PET_HIP_CHECK(hipMemsetAsync(w.fcd, 0, E * sizeof(float), st));

@@ -213,6 +213,9 @@ int backward_train(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, c
                    float* grad_pos, float* grad_cells, hipStream_t st);
 // so.hip: second-order (force-loss) reverse pass
 int64_t so_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges);
+// tangents of (edge vector, distance), cutoff factor and key bias along (u, ucell), adaptive cutoffs ('solver') included
+int geometry_tangent(const Model& m, const Graph& g, const float* u, const float* ucell, float* Tgeo, float* Tfc, float* Tkb,
+                     hipStream_t st);
 int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, void* ws2, int64_t ws2_bytes,
                     const float* lambda_atomic, const float* nu_atomic, const float* u, float* tangent_atomic,
                     hipStream_t st, const float* u_cell = nullptr);

@@ -494,6 +494,22 @@ __global__ void k_geom_jvp(const float* __restrict__ u, const int* __restrict__ 
     Tkb[p] = f >= 1e-15f ? dfc / f : 0.f;
 }
 
+// the two kernels above for any caller (gen_train.hip: the size-generic pass with the adaptive cutoff)
+int geometry_tangent(const Model& m, const Graph& g, const float* u, const float* ucell, float* Tgeo, float* Tfc, float* Tkb,
+                     hipStream_t st) {
+    PET_REQUIRE(g.grid_probes == 0, PET_ERR_UNSUPPORTED,
+                "the force-loss (second-order) pass carries the cutoff tangents of the 'solver' adaptive-cutoff method only");
+    const int64_t N = g.n_nodes, E = g.n_edges;
+    if (g.adaptive)  // g.ad_gr doubles as the tangent of the atomic cutoffs
+        k_adapt_rdot<<<cdiv(N, 16), 256, 0, st>>>(u, g.rowptr0, g.perm0, g.nbr0, g.vin, g.r_newton, g.inv_dn, g.ad_gr, (int)N,
+                                                  m.h.cutoff_width_adaptive, ucell, g.shift0, g.sys);
+    k_geom_jvp<<<cdiv(E, 256), 256, 0, st>>>(u, g.ctr, g.nbr, g.geo, g.d0, g.fc, reinterpret_cast<float4*>(Tgeo), Tfc, Tkb, E,
+                                            m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function, g.adaptive ? g.pc : nullptr,
+                                            g.adaptive ? g.ad_gr : nullptr, ucell, g.shift, g.sys);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
 // Ta0[p][c] = Tgeo[p] . Wc[c]   (4 -> D)
 __global__ void k_geo_lin(const float4* __restrict__ Tgeo, const float* __restrict__ wc, float* __restrict__ out,
                           int64_t E) {

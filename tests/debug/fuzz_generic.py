@@ -31,7 +31,7 @@ for trial in range(ntrial):
               cutoff_function=str(rng.choice(["Bump", "Cosine"])), cutoff=float(rng.choice([3.5, 4.5, 5.5])),
               cutoff_width=float(rng.choice([0.2, 0.5, 1.0])), attention_temperature=float(rng.choice([0.5, 1.0, 2.0])),
               system_conditioning=bool(rng.random() < 0.35))
-    adaptive = rng.random() < 0.2
+    adaptive = rng.random() < 0.3
     if adaptive:
         hy.update(num_neighbors_adaptive=float(rng.choice([4.0, 8.0])), adaptive_cutoff_method=str(rng.choice(["solver", "grid"])))
     tag = {k: hy[k] for k in ("d_pet", "num_heads", "d_node", "d_feedforward", "d_head", "num_gnn_layers", "num_attention_layers",
@@ -104,8 +104,8 @@ for trial in range(ntrial):
         a64, g64 = oracle(torch.float64, "infer")
         a32, g32 = oracle(torch.float32, "infer")
         flagged = check("E", a, a64, a32, 1e-5) + check("dE/dR", g, g64, g32, 1e-5)
-        # training (the generic pass refuses the adaptive cutoff)
-        trainable = not adaptive or (hy["d_pet"] == 128 and False)
+        # training (the force-loss pass carries the cutoff tangents of the 'solver' method only)
+        trainable = not adaptive or hy["adaptive_cutoff_method"] == "solver"
         if trainable:
             ft = rt.HipForward(model, graph, train=True)
             for what in ("energy", "force"):

@@ -18,7 +18,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 16):
     hy["soap"]["max_radial"] = int(rng.integers(2, 10))
     hy["soap"]["cutoff"] = {"radius": float(rng.choice([3.5, 5.0, 6.0])), "width": float(rng.choice([0.25, 0.5, 1.0]))}
     hy["legacy"] = bool(rng.random() < 0.5)
-    hy["bpnn"]["num_hidden_layers"] = int(rng.integers(1, 3))
+    hy["bpnn"]["num_hidden_layers"] = int(rng.integers(1, 7))
     hy["bpnn"]["layernorm"] = bool(rng.random() < 0.7)
     tag = f"L={hy['soap']['max_angular']} N={hy['soap']['max_radial']} rc={hy['soap']['cutoff']} legacy={hy['legacy']} " \
           f"hidden={hy['bpnn']['num_hidden_layers']} ln={hy['bpnn']['layernorm']}"

@@ -25,6 +25,10 @@ CASES = {
     "default_residual": dict(featurizer_type="residual"),
     "default_legacy": dict(normalization="LayerNorm", activation="SiLU", transformer_type="PostLN", featurizer_type="residual"),
     "s64_layernorm": dict(d_pet=64, d_node=128, d_feedforward=128, d_head=64, num_heads=4, normalization="LayerNorm"),
+    # adaptive cutoff ('solver', structures.py:225-263): the pair cutoffs move with the positions, so the force-loss term
+    # needs the implicit-function tangent of the atomic cutoffs (so.hip geometry_tangent) on the generic pass too
+    "s64_adaptive": dict(d_pet=64, d_node=128, d_feedforward=128, d_head=64, num_heads=4, num_neighbors_adaptive=6.0),
+    "default_residual_adaptive": dict(featurizer_type="residual", num_neighbors_adaptive=6.0),
 }
 
 
