@@ -39,7 +39,7 @@ typedef struct {
     int32_t legacy;           /* 1: per-centre-species LayerNorm / MLP / last layer, identity species weights */
     int32_t layernorm;        /* bpnn.layernorm */
     int32_t num_hidden_layers;      /* bpnn.num_hidden_layers (1 .. 8) */
-    int32_t num_neurons_per_layer;  /* bpnn.num_neurons_per_layer (32) */
+    int32_t num_neurons_per_layer;  /* bpnn.num_neurons_per_layer (1 .. 64; 32 = the MFMA tails) */
 } soap_hypers_t;
 
 int soap_model_create(const soap_hypers_t* hypers, soap_model_t** out);

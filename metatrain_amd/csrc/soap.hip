@@ -295,7 +295,7 @@ __device__ __forceinline__ float dsilu(float x) { const float s = sigm(x); retur
 // ---------------------------------------------------------------------------------------------
 // a18: LayerNorm + MLP + last layer, one workgroup per atom. tail[i] = {mean, rstd, a1[H], a2[H]}
 // ---------------------------------------------------------------------------------------------
-constexpr int MAXH = 32;
+constexpr int MAXH = 64;  // neurons per hidden layer; the MFMA tails serve 32 (the default), other widths the per-atom kernels
 
 __global__ __launch_bounds__(256) void k_soap_tail(SoapDims d, const float* __restrict__ feats,
                                                    const int* __restrict__ sp, const SoapSet* __restrict__ sets,
@@ -1986,7 +1986,7 @@ int soap_model_create(const soap_hypers_t* h, soap_model_t** out) {
     PET_REQUIRE(h && out, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(h->max_angular >= 0 && h->max_angular <= SOAP_MAX_L, PET_ERR_UNSUPPORTED, "max_angular out of range");
     PET_REQUIRE(h->num_neurons_per_layer >= 1 && h->num_neurons_per_layer <= MAXH, PET_ERR_UNSUPPORTED,
-                "num_neurons_per_layer > 32 is not built");
+                "num_neurons_per_layer > 64 is not built");
     PET_REQUIRE(h->num_hidden_layers >= 1 && h->num_hidden_layers <= MAXNH, PET_ERR_UNSUPPORTED,
                 "num_hidden_layers must be 1 .. 8");
     PET_REQUIRE(h->n_species >= 1 && h->n_channels >= 1 && h->n_channels <= 255, PET_ERR_ARGUMENT, "bad species counts");

@@ -110,6 +110,30 @@ def test_more_than_two_hidden_layers(legacy, layers, mfma_tail, fused, sorted_ti
         rt.config_set("soap_sorted", 1)
 
 
+@pytest.mark.parametrize("legacy,neurons,layers", [(True, 48, 2), (False, 64, 3), (True, 7, 1), (False, 16, 2)])
+def test_other_layer_widths(legacy, neurons, layers):
+    """``bpnn.num_neurons_per_layer`` other than 32 (soap_bpnn/documentation.py): the per-atom tail kernels, up to 64."""
+    from metatrain_amd.soap_bpnn import SoapBpnnHip
+
+    dev = torch.device("cuda:0")
+    hypers = dict(osoap.DEFAULT_HYPERS, legacy=legacy)
+    hypers["bpnn"] = dict(hypers["bpnn"], num_hidden_layers=layers, num_neurons_per_layer=neurons)
+    types = [1, 6, 7, 8]
+    n_per_l = osoap.basis(hypers)[0]
+    params = osoap.synthetic_params(hypers, 4, n_per_l, 5, torch.float32)
+    pos, z, cells, ci, cj, cs, sysidx = _box(70, seed=9)
+    p64 = {k: v.double() for k, v in params.items()}
+    e_ref, g_ref, a_ref = osoap.energy_and_gradient(p64, hypers, types, pos, cells, ci, cj, cs, z, sysidx)
+    model = SoapBpnnHip(hypers, types)
+    model.load({k: v.to(dev) for k, v in params.items()})
+    g = model.graph(pos.float().to(dev), cells.float().to(dev), ci.to(dev), cj.to(dev), cs.to(dev), z.to(dev),
+                    sysidx.int().to(dev))
+    atomic = model.forward(g)
+    grad = model.backward(g, torch.ones_like(atomic))
+    assert _relmax(atomic.cpu().numpy(), a_ref.numpy()) < TOL
+    assert _relmax(grad.cpu().numpy(), g_ref.numpy()) < TOL
+
+
 def test_soap_max_angular_8():
     """The second instantiation of the expansion kernels (max_angular 7..8: 81 Y_lm, 17-wide m blocks)."""
     from metatrain_amd.soap_bpnn import SoapBpnnHip

@@ -113,7 +113,7 @@ def test_ethanol_frames_energy_and_forces():
 
 
 @pytest.mark.parametrize("case", ["ethanol", "boxes", "boxes_no_layernorm", "boxes_one_hidden_layer",
-                                  "boxes_four_hidden_layers", "energy_only"])
+                                  "boxes_four_hidden_layers", "boxes_48_neurons", "energy_only"])
 def test_training_gradients_against_the_oracles_double_backward(case):
     dev = torch.device("cuda:0")
     hypers = dict(osoap.DEFAULT_HYPERS)
@@ -123,6 +123,8 @@ def test_training_gradients_against_the_oracles_double_backward(case):
         hypers["bpnn"] = dict(hypers["bpnn"], num_hidden_layers=1)
     if case == "boxes_four_hidden_layers":
         hypers["bpnn"] = dict(hypers["bpnn"], num_hidden_layers=4)
+    if case == "boxes_48_neurons":
+        hypers["bpnn"] = dict(hypers["bpnn"], num_hidden_layers=3, num_neurons_per_layer=48)
     types = [1, 6, 8] if case == "ethanol" else [1, 6, 7, 8]
     batch = _ethanol() if case == "ethanol" else _random_batch()
     with_forces = case != "energy_only"
