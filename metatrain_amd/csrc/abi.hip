@@ -541,13 +541,13 @@ int64_t pet_train_workspace_bytes(const pet_model_t* pm, int64_t n_nodes, int64_
 
 int64_t pet_train_workspace_bytes_for(const pet_model_t* pm, const pet_graph_t* pg) {
     if (!pm || !pg) return -1;
-    if (use_generic(pm->m, pg->g)) return gen_workspace_bytes(pm->m, pg->g.n_nodes, pg->g.n_edges);
+    if (train_generic_for(pm->m, pg->g)) return gen_workspace_bytes(pm->m, pg->g.n_nodes, pg->g.n_edges);
     return forward_workspace_bytes(pm->m, pg->g.n_nodes, pg->g.n_edges, true);
 }
 
 int64_t pet_train2_workspace_bytes_for(const pet_model_t* pm, const pet_graph_t* pg) {
     if (!pm || !pg) return -1;
-    if (use_generic(pm->m, pg->g)) return gen_train_workspace_bytes(pm->m, pg->g.n_nodes, pg->g.n_edges);
+    if (train_generic_for(pm->m, pg->g)) return gen_train_workspace_bytes(pm->m, pg->g.n_nodes, pg->g.n_edges);
     return so_workspace_bytes(pm->m, pg->g.n_nodes, pg->g.n_edges);
 }
 

@@ -823,7 +823,8 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
     const GD& d = t.d;
     const int64_t N = g.n_nodes, E = g.n_edges, R = N + E;
     if (N == 0) return PET_OK;
-    PET_REQUIRE(E > 0, PET_ERR_UNSUPPORTED, "training on a batch without any edge is not supported");
+    // E == 0 (a batch of isolated atoms): every helper below skips zero-row work, the raw E-row launches are guarded; what
+    // remains is the node path -- embeddings, centre tokens attending to themselves, centre MLPs, node heads
     const int D = d.D, DN = d.DN;
     const bool post = m.post_ln(), res = m.residual();
     const float scale = 1.0f / (sqrtf((float)d.HD) * m.h.attention_temperature);
@@ -853,7 +854,8 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
     PET_HIP_CHECK(hipMemcpyAsync(w.geo.p, g.geo, E * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (u) {
         PET_REQUIRE(!ucell || g.shift, PET_ERR_ARGUMENT, "a cell tangent needs a pet_graph_build handle (cell shifts)");
-        if (g.adaptive) {   // the pair cutoffs move with the positions too (so.hip: implicit-function tangent of the solver)
+        if (E == 0) {
+        } else if (g.adaptive) {   // the pair cutoffs move with the positions too (so.hip: implicit-function tangent of the solver)
             int rc = geometry_tangent(m, g, u, ucell, w.geo.t, w.fcd, w.bd, st);
             if (rc) return rc;
         } else
@@ -867,7 +869,7 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
     }
     k_gen_embed<<<g1(N * DN), 256, 0, st>>>(g.sp, m.node_emb, w.H0.p, DN, N, DN);
     PET_HIP_CHECK(hipMemsetAsync(w.H0.t, 0, N * DN * sizeof(float), st));
-    k_gen_embed<<<g1(E * D), 256, 0, st>>>(g.sp_nbr, m.edge_emb, w.M0.p, D, E, D);
+    if (E > 0) k_gen_embed<<<g1(E * D), 256, 0, st>>>(g.sp_nbr, m.edge_emb, w.M0.p, D, E, D);
     PET_HIP_CHECK(hipMemsetAsync(w.M0.t, 0, E * D * sizeof(float), st));
     D2 Min = w.M0;
     for (int gi = 0; gi < L; gi++) {
@@ -880,7 +882,7 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
         const int kin = (gi == 0 ? 2 : 3) * D;
         t.linf(w.geo, 4, G.eemb, B.TOK, kin, E);
         if (gi > 0) {
-            k_gen_embed<<<g1(E * D), 256, 0, st>>>(g.sp_nbr, G.nbr_emb, B.TOK.p + D, kin, E, D);
+            if (E > 0) k_gen_embed<<<g1(E * D), 256, 0, st>>>(g.sp_nbr, G.nbr_emb, B.TOK.p + D, kin, E, D);
             t.o.axpby(0.f, nullptr, 0, 0.f, nullptr, 0, nullptr, B.TOK.t + D, kin, false, E, D);
         }
         {
@@ -1002,10 +1004,10 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
         // reverse of the edge head
         t.wgrad(le, nep, 1, w.tE[3], DH, E);
         t.linb(nep, 1, le, w.tE[3], DH, E);
-        k_gt_silu_rev<<<g1(E * DH), 256, 0, st>>>(w.tE[2].p, w.tE[2].t, w.tE[3].p, w.tE[3].t, w.tE[3].p, w.tE[3].t, E * DH);
+        if (E > 0) k_gt_silu_rev<<<g1(E * DH), 256, 0, st>>>(w.tE[2].p, w.tE[2].t, w.tE[3].p, w.tE[3].t, w.tE[3].p, w.tE[3].t, E * DH);
         t.wgrad(H.eh2, w.tE[3], DH, w.tE[1], DH, E);
         t.linb(w.tE[3], DH, H.eh2, w.tE[1], DH, E);
-        k_gt_silu_rev<<<g1(E * DH), 256, 0, st>>>(w.tE[0].p, w.tE[0].t, w.tE[1].p, w.tE[1].t, w.tE[1].p, w.tE[1].t, E * DH);
+        if (E > 0) k_gt_silu_rev<<<g1(E * DH), 256, 0, st>>>(w.tE[0].p, w.tE[0].t, w.tE[1].p, w.tE[1].t, w.tE[1].p, w.tE[1].t, E * DH);
         t.wgrad(H.eh0, w.tE[1], DH, Mf, D, E);
         t.linb(w.tE[1], DH, H.eh0, dMl[l], D, E);
     }
@@ -1033,7 +1035,7 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
             t.silu(B.CA, w.tE[1], E * 2 * D);                                                   // input of comb2
             t.wgrad(G.comb2, w.dM, D, w.tE[1], 2 * D, E);
             t.linb(w.dM, D, G.comb2, w.tE[1], 2 * D, E);                                        // of silu(CA)
-            k_gt_silu_rev<<<g1(E * 2 * D), 256, 0, st>>>(B.CA.p, B.CA.t, w.tE[1].p, w.tE[1].t, w.tE[1].p, w.tE[1].t, E * 2 * D);
+            if (E > 0) k_gt_silu_rev<<<g1(E * 2 * D), 256, 0, st>>>(B.CA.p, B.CA.t, w.tE[1].p, w.tE[1].t, w.tE[1].p, w.tE[1].t, E * 2 * D);
             t.norm(CAT, G.ln_g, G.ln_b, w.tE[2], E, 2 * D, 1, 1e-5f);                            // input of comb0
             t.wgrad(G.comb0, w.tE[1], 2 * D, w.tE[2], 2 * D, E);
             t.linb(w.tE[1], 2 * D, G.comb0, w.tE[2], 2 * D, E);                                  // of LN(CAT)
@@ -1123,7 +1125,7 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
             t.silu(B.a0, w.tE[0], E * D);
             t.wgrad(G.compress2, dXF, D, w.tE[0], D, E);
             t.linb(dXF, D, G.compress2, w.tE[0], D, E);
-            k_gt_silu_rev<<<g1(E * D), 256, 0, st>>>(B.a0.p, B.a0.t, w.tE[0].p, w.tE[0].t, w.tE[0].p, w.tE[0].t, E * D);
+            if (E > 0) k_gt_silu_rev<<<g1(E * D), 256, 0, st>>>(B.a0.p, B.a0.t, w.tE[0].p, w.tE[0].t, w.tE[0].p, w.tE[0].t, E * D);
             t.wgrad(G.c0, w.tE[0], D, B.TOK, kin, E);
             D2 dTOK = w.tE[1];
             t.linb(w.tE[0], D, G.c0, dTOK, kin, E);

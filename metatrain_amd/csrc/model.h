@@ -186,6 +186,9 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
                const float* ucell, float* tangent_atomic, hipStream_t st);
 // a model whose TRAINING runs on the size-generic path: other sizes, PostLN layers, the residual featuriser
 inline bool train_generic(const Model& m) { return m.generic() || !m.trainable(); }
+// ... and for a built graph: an atom of more than 127 neighbours, or NO edge at all (a batch of isolated atoms -- reference
+// structures of a dataset -- trains the node path alone; the tuned passes launch over E rows)
+inline bool train_generic_for(const Model& m, const Graph& g) { return train_generic(m) || use_generic(m, g) || g.n_edges == 0; }
 // the workspace `ws` was last filled by a size-generic forward (pet_fwd.hip keeps the record): its adjoints must follow
 bool generic_workspace(const void* ws);
 int backward_geometry_generic(const Model& m, const Graph& g, float* dv_scratch, const float* dgeo, const float* dfc_a,

@@ -1531,7 +1531,7 @@ int backward_train(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, c
                    float* gcell, hipStream_t st) {
     // other sizes, PostLN, residual, and any graph with an atom of more than 127 neighbours: the energy term alone = the
     // size-generic second-order pass without a tangent
-    if (train_generic(m) || use_generic(m, g)) {
+    if (train_generic_for(m, g)) {
         PET_REQUIRE(generic_workspace(ws), PET_ERR_ARGUMENT, "pet_forward with save_for_backward = 2 has not run on this workspace");
         void* ws2 = nullptr;
         const int64_t n2 = gen_train_workspace_bytes(m, g.n_nodes, g.n_edges);

@@ -880,7 +880,7 @@ int forward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save
 // node_feats / edge_feats: n_layers = num_readout_layers() output pointers each (entries may be null)
 int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, int save, float* atomic,
                    float* const* node_feats, float* const* edge_feats, int n_layers, hipStream_t st) {
-    const bool gen = use_generic(m, g) || (save == 2 && train_generic(m));
+    const bool gen = use_generic(m, g) || (save == 2 && train_generic_for(m, g));
     PET_REQUIRE(!(gen && g.x_fn), PET_ERR_UNSUPPORTED, "the per-layer exchange is built for the tuned path (default model size)");
     note_workspace(ws, gen);
     if (gen) return gen_forward_layers(m, g, ws, ws_bytes, save, atomic, node_feats, edge_feats, n_layers, st);

@@ -1172,7 +1172,7 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
                     const float* lA, const float* nA, const float* u, float* tangent_atomic, hipStream_t st,
                     const float* ucell) {
     // other sizes, PostLN, residual, more than 127 neighbours per atom: gen_train.hip (it recomputes what it needs in ws2)
-    if (train_generic(m) || use_generic(m, g)) return gen_train2(m, g, ws2, ws2_bytes, lA, nA, u, ucell, tangent_atomic, st);
+    if (train_generic_for(m, g)) return gen_train2(m, g, ws2, ws2_bytes, lA, nA, u, ucell, tangent_atomic, st);
     PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
     PET_REQUIRE(m.trainable(), PET_ERR_UNSUPPORTED,
                 "training is built for transformer_type=PreLN, featurizer_type=feedforward only");

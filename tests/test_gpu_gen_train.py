@@ -248,3 +248,84 @@ def test_default_size_trains_on_a_graph_with_more_than_127_neighbours():
     tan = fw.backward_train2(ones, nu.to(dev), u.to(dev), want_tangent=True)
     assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < 2 * TOL
     _compare(model.grads(), ref2, model, "dense graph, force-loss term")
+
+
+@pytest.mark.parametrize("tag", ["default", "s64", "default_legacy"])
+def test_training_on_a_batch_of_isolated_atoms(tag):
+    """A batch WITHOUT ANY EDGE (the isolated-atom reference structures of a dataset falling into one batch): the node path
+    alone carries the gradients -- embeddings, centre tokens attending to themselves, centre MLPs, node heads -- every edge
+    parameter gets exactly zero, dE/dR and the tangent energies are zero. Against the oracle's backward."""
+    from metatrain_amd import runtime as rt
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS, **({} if tag == "default" else CASES[tag]))
+    params = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    n = 5
+    pos = torch.tensor([[0.0, 0, 0], [40.0, 0, 0], [0, 40.0, 0], [0, 0, 40.0], [40.0, 40.0, 0]])
+    z = torch.tensor([1, 6, 7, 8, 6])
+    sysidx = torch.tensor([0, 0, 1, 2, 2])
+    e0 = torch.zeros(0, dtype=torch.long)
+    inp = {"positions": pos, "cells": torch.zeros(3, 3, 3), "centers": e0, "neighbors": e0,
+           "cell_shifts": torch.zeros((0, 3), dtype=torch.long), "species": z, "system_indices": sysidx}
+    model = rt.HipModel(hypers, TYPES)
+    model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+    graph = rt.HipGraph(model, pos.to(dev), inp["cells"].to(dev), e0.to(dev), e0.to(dev), inp["cell_shifts"].to(dev), z.to(dev),
+                        sysidx.int().to(dev))
+    assert graph.n_edges == 0
+    w = torch.tensor([0.7, -1.3, 0.4, 2.0, 1.1])
+    ref = _oracle_param_grads(params, hypers, inp, w)
+    fw = rt.HipForward(model, graph, train=True)
+    model.zero_grad()
+    atomic = fw.forward()
+    gpos = fw.backward_train(w.to(dev), want_position_grad=True)
+    assert float(gpos.abs().max()) == 0.0
+    got = model.grads()
+    _compare(got, ref, model, f"{tag} isolated atoms, energy term")
+    edge_keys = [k for k in ref if float(ref[k].abs().max()) == 0.0]
+    assert edge_keys and all(float(got[k].abs().max()) == 0.0 for k in edge_keys)
+    # the force-loss pass: no geometry to differentiate, the nu term alone
+    model.zero_grad()
+    fw.forward()
+    ones = torch.ones(n, device=dev)
+    assert float(fw.backward(ones).abs().max()) == 0.0
+    tan = fw.backward_train2(ones, w.to(dev), torch.randn(n, 3, generator=torch.Generator().manual_seed(1)).to(dev),
+                             want_tangent=True)
+    assert float(tan.abs().max()) == 0.0
+    _compare(model.grads(), ref, model, f"{tag} isolated atoms, force-loss pass")
+    a_ref = opet.pet_atomic_energies({k: (v if k == "species_to_species_index" else v.double()) for k, v in params.items()},
+                                     hypers, pos.double(), inp["cells"].double(), e0, e0, inp["cell_shifts"], z, sysidx,
+                                     "energy")[:, 0]
+    assert float((atomic.cpu().double() - a_ref).abs().max() / a_ref.abs().max()) < TOL
+
+
+def test_mirror_trains_on_isolated_atoms():
+    """The same through the mirror in train() mode: ``loss.backward()`` with an energy and a force term on an edge-free batch."""
+    from metatrain_amd.pet import PETBackend
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS)
+    params = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    be = PETBackend(hypers, TYPES)
+    be.add_output("energy", {"energy": [1]})
+    be.load_state_dict(params, strict=True)
+    be = be.to(dev).train()
+    pos = torch.tensor([[0.0, 0, 0], [40.0, 0, 0], [0, 40.0, 0]], device=dev, requires_grad=True)
+    z = torch.tensor([1, 8, 6], device=dev)
+    sysidx = torch.tensor([0, 0, 1], device=dev)
+    e0 = torch.zeros(0, dtype=torch.long, device=dev)
+    cells = torch.zeros(2, 3, 3, device=dev)
+    batch = be.preprocess(pos, e0, e0, z, cells, torch.zeros((0, 3), dtype=torch.long, device=dev), sysidx, 1.0)
+    nodes, edges = be.calculate_features(batch)
+    pred, _, _ = be.predict(nodes, edges, batch, cells, sysidx, ["energy"])
+    atomic = pred["energy"][0][:, 0]
+    (grad,) = torch.autograd.grad(atomic.sum(), pos, create_graph=True)
+    w = torch.tensor([0.5, -1.0, 2.0], device=dev)
+    loss = (w * atomic).sum() + ((grad - 0.1) ** 2).sum()
+    loss.backward()
+    inp = {"positions": pos.detach().cpu(), "cells": cells.cpu(), "centers": e0.cpu(), "neighbors": e0.cpu(),
+           "cell_shifts": torch.zeros((0, 3), dtype=torch.long), "species": z.cpu(), "system_indices": sysidx.cpu()}
+    ref = _oracle_param_grads(params, hypers, inp, w.cpu())
+    named = dict(be.named_parameters())
+    got = {k: (named[k].grad if named[k].grad is not None else torch.zeros_like(named[k])) for k in ref}
+    _compare(got, ref, None, "mirror, isolated atoms")
+    assert float(grad.abs().max()) == 0.0
