@@ -2074,15 +2074,19 @@ int64_t soap_workspace_bytes(const soap_model_t* sm, int64_t n_nodes, int64_t n_
 
 int soap_forward(const soap_model_t* sm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                  float* d_atomic, float* d_features, void* stream) {
-    PET_REQUIRE(sm && pg && d_workspace && d_atomic, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(sm && pg, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(sm->m.finalized, PET_ERR_ARGUMENT, "soap_model_finalize has not been called");
+    if (pg->g.n_nodes == 0) return PET_OK;   // an empty system: nothing to write (zero-sized buffers may be null)
+    PET_REQUIRE(d_workspace && d_atomic, PET_ERR_ARGUMENT, "null argument");
     return soap_fwd(sm->m, pg->g, d_workspace, workspace_bytes, d_atomic, d_features, (hipStream_t)stream);
 }
 
 int soap_backward(const soap_model_t* sm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                   const float* d_grad_atomic, float* d_grad_positions, float* d_grad_cells, void* stream) {
-    PET_REQUIRE(sm && pg && d_workspace && d_grad_atomic && d_grad_positions, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(sm && pg, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(sm->m.finalized, PET_ERR_ARGUMENT, "soap_model_finalize has not been called");
+    if (pg->g.n_nodes == 0) return PET_OK;
+    PET_REQUIRE(d_workspace && d_grad_atomic && d_grad_positions, PET_ERR_ARGUMENT, "null argument");
     return soap_bwd(sm->m, pg->g, d_workspace, workspace_bytes, d_grad_atomic, d_grad_positions, d_grad_cells,
                     (hipStream_t)stream);
 }
@@ -2102,9 +2106,10 @@ int64_t soap_train_workspace_bytes(const soap_model_t* sm, int64_t n_nodes, int6
 int soap_train_gradients(soap_model_t* sm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                          void* d_train_workspace, int64_t train_workspace_bytes, const float* d_grad_atomic,
                          const float* d_u, float* d_tangent_atomic, void* stream) {
-    PET_REQUIRE(sm && pg && d_workspace && d_train_workspace && d_grad_atomic && d_tangent_atomic, PET_ERR_ARGUMENT,
-                "null argument");
+    PET_REQUIRE(sm && pg, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(sm->m.finalized, PET_ERR_ARGUMENT, "soap_model_finalize has not been called");
+    if (pg->g.n_nodes == 0) return PET_OK;
+    PET_REQUIRE(d_workspace && d_train_workspace && d_grad_atomic && d_tangent_atomic, PET_ERR_ARGUMENT, "null argument");
     return soap_train_grads(sm->m, pg->g, d_workspace, workspace_bytes, d_train_workspace, train_workspace_bytes,
                             d_grad_atomic, d_u, d_tangent_atomic, (hipStream_t)stream);
 }

@@ -134,6 +134,40 @@ def test_other_layer_widths(legacy, neurons, layers):
     assert _relmax(grad.cpu().numpy(), g_ref.numpy()) < TOL
 
 
+@pytest.mark.parametrize("legacy", [True, False])
+def test_empty_and_isolated_systems(legacy):
+    """An EMPTY system (zero-sized outputs) and a batch of isolated atoms (no pair): finite, the oracle's energies, zero
+    dE/dR; the training pass runs on the edge-free batch."""
+    from metatrain_amd.soap_bpnn import SoapBpnnHip
+
+    dev = torch.device("cuda:0")
+    hypers = dict(osoap.DEFAULT_HYPERS, legacy=legacy)
+    types = [1, 6, 7, 8]
+    params = osoap.synthetic_params(hypers, 4, osoap.basis(hypers)[0], 0, torch.float32)
+    model = SoapBpnnHip(hypers, types)
+    model.load({k: v.to(dev) for k, v in params.items()})
+    e0 = torch.zeros(0, dtype=torch.long, device=dev)
+    s0 = torch.zeros((0, 3), dtype=torch.long, device=dev)
+    g = model.graph(torch.zeros((0, 3), device=dev), torch.zeros(1, 3, 3, device=dev), e0, e0, s0, e0,
+                    torch.zeros(0, dtype=torch.int32, device=dev))
+    a = model.forward(g)
+    assert a.shape == (0,) and model.backward(g, torch.ones_like(a)).shape == (0, 3)
+    pos = torch.tensor([[0.0, 0, 0], [50.0, 0, 0], [0, 50.0, 0]])
+    z, sysidx = torch.tensor([1, 6, 8]), torch.tensor([0, 0, 1])
+    g = model.graph(pos.to(dev), torch.zeros(2, 3, 3, device=dev), e0, e0, s0, z.to(dev), sysidx.int().to(dev))
+    a = model.forward(g)
+    grad = model.backward(g, torch.ones_like(a))
+    _, _, a_ref = osoap.energy_and_gradient({k: v.double() for k, v in params.items()}, hypers, types, pos.double(),
+                                            torch.zeros(2, 3, 3, dtype=torch.float64), e0.cpu(), e0.cpu(), s0.cpu(), z, sysidx)
+    assert _relmax(a.cpu().numpy(), a_ref.numpy()) < TOL and float(grad.abs().max()) == 0.0
+    if legacy:
+        model.zero_grad()
+        a = model.forward(g)
+        tan = model.train_gradients(g, torch.ones_like(a), torch.ones(3, 3, device=dev))
+        assert float(tan.abs().max()) == 0.0
+        assert all(bool(torch.isfinite(v).all()) for v in model.grads().values())
+
+
 def test_soap_max_angular_8():
     """The second instantiation of the expansion kernels (max_angular 7..8: 81 Y_lm, 17-wide m blocks)."""
     from metatrain_amd.soap_bpnn import SoapBpnnHip
