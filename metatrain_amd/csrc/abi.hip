@@ -553,6 +553,7 @@ int64_t pet_train2_workspace_bytes_for(const pet_model_t* pm, const pet_graph_t*
 
 int pet_backward_train(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                        const float* d_grad_atomic, float* d_grad_positions, float* d_grad_cells, void* stream) {
+    if (pg && pg->g.n_nodes == 0) return PET_OK;  // an empty system: nothing to compute, zero-sized buffers may be null
     PET_REQUIRE(pm && pg && d_workspace && d_grad_atomic, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
     return backward_train(pm->m, pg->g, d_workspace, workspace_bytes, d_grad_atomic, d_grad_positions, d_grad_cells,
@@ -567,6 +568,7 @@ int64_t pet_train2_workspace_bytes(const pet_model_t* pm, int64_t n_nodes, int64
 int pet_backward_train2(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                         void* d_workspace2, int64_t workspace2_bytes, const float* d_lambda_atomic,
                         const float* d_nu_atomic, const float* d_u, float* d_tangent_atomic, void* stream) {
+    if (pg && pg->g.n_nodes == 0) return PET_OK;  // an empty system: nothing to compute, zero-sized buffers may be null
     PET_REQUIRE(pm && pg && d_workspace && d_workspace2 && d_lambda_atomic && d_u, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
     return backward_train2(pm->m, pg->g, d_workspace, workspace_bytes, d_workspace2, workspace2_bytes,
@@ -577,6 +579,7 @@ int pet_backward_train2_cell(const pet_model_t* pm, const pet_graph_t* pg, void*
                              void* d_workspace2, int64_t workspace2_bytes, const float* d_lambda_atomic,
                              const float* d_nu_atomic, const float* d_u, const float* d_u_cell, float* d_tangent_atomic,
                              void* stream) {
+    if (pg && pg->g.n_nodes == 0) return PET_OK;  // an empty system: nothing to compute, zero-sized buffers may be null
     PET_REQUIRE(pm && pg && d_workspace && d_workspace2 && d_lambda_atomic && d_u, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
     PET_REQUIRE(!d_u_cell || pg->g.shift, PET_ERR_ARGUMENT, "a cell tangent needs a pet_graph_build handle (cell shifts)");
@@ -589,7 +592,9 @@ int64_t pet_nl_workspace_bytes(int64_t n_atoms) { return nl_workspace_bytes(n_at
 int pet_nl_build(const float* d_positions, const float* h_cell, const int32_t* h_pbc, int64_t n_atoms,
                  float cutoff, void* d_workspace, int32_t* d_pairs, float* d_vectors, int64_t capacity,
                  int64_t* n_pairs, void* stream) {
-    PET_REQUIRE(h_cell && h_pbc && n_pairs && d_workspace, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(h_cell && h_pbc && n_pairs, PET_ERR_ARGUMENT, "null argument");
+    if (n_atoms == 0) { *n_pairs = 0; return PET_OK; }
+    PET_REQUIRE(d_workspace, PET_ERR_ARGUMENT, "null argument");
     return nl_build(d_positions, h_cell, h_pbc, n_atoms, cutoff, d_workspace, d_pairs, d_vectors, capacity,
                     n_pairs, (hipStream_t)stream);
 }
@@ -599,7 +604,9 @@ int64_t pet_nl_batch_workspace_bytes(int64_t n_atoms, int64_t n_systems) { retur
 int pet_nl_build_batch(const float* d_positions, const float* h_cells, const int32_t* h_pbc, const int64_t* h_first_atom,
                        int64_t n_systems, float cutoff, void* d_workspace, int32_t* d_pairs, float* d_vectors,
                        int64_t capacity, int64_t* n_pairs, void* stream) {
-    PET_REQUIRE(d_positions && h_cells && h_pbc && h_first_atom && d_workspace && n_pairs, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(h_cells && h_pbc && h_first_atom && n_pairs, PET_ERR_ARGUMENT, "null argument");
+    if (n_systems <= 0 || h_first_atom[n_systems] == 0) { *n_pairs = 0; return PET_OK; }   // no atom at all
+    PET_REQUIRE(d_positions && d_workspace, PET_ERR_ARGUMENT, "null argument");
     return nl_build_batch(d_positions, h_cells, h_pbc, h_first_atom, n_systems, cutoff, d_workspace, d_pairs, d_vectors,
                           capacity, n_pairs, (hipStream_t)stream);
 }
@@ -690,6 +697,7 @@ int64_t pet_forward_workspace_bytes_for(const pet_model_t* pm, const pet_graph_t
 int pet_forward(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                 int save_for_backward, float* d_atomic, float* d_node_features, float* d_edge_features,
                 void* stream) {
+    if (pg && pg->g.n_nodes == 0) return PET_OK;  // an empty system: nothing to compute, zero-sized buffers may be null
     PET_REQUIRE(pm && pg && d_workspace, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(d_atomic || d_node_features || save_for_backward, PET_ERR_ARGUMENT,
                 "nothing to compute: d_atomic and d_node_features are both NULL");
@@ -703,6 +711,7 @@ int32_t pet_model_num_readout_layers(const pet_model_t* pm) { return pm ? pm->m.
 int pet_forward_layers(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                        int save_for_backward, float* const* h_node_features, float* const* h_edge_features, int32_t n_layers,
                        void* stream) {
+    if (pg && pg->g.n_nodes == 0) return PET_OK;  // an empty system: nothing to compute, zero-sized buffers may be null
     PET_REQUIRE(pm && pg && d_workspace && h_node_features && h_edge_features, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
     PET_REQUIRE(n_layers == pm->m.num_readout_layers(), PET_ERR_ARGUMENT,
@@ -714,6 +723,7 @@ int pet_forward_layers(const pet_model_t* pm, const pet_graph_t* pg, void* d_wor
 int pet_backward_features_layers(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                                  const float* const* h_grad_node_features, const float* const* h_grad_edge_features,
                                  int32_t n_layers, float* d_grad_geometry, float* d_grad_cutoff, void* stream) {
+    if (pg && pg->g.n_nodes == 0) return PET_OK;  // an empty system: nothing to compute, zero-sized buffers may be null
     PET_REQUIRE(pm && pg && d_workspace && h_grad_node_features && h_grad_edge_features && d_grad_geometry && d_grad_cutoff,
                 PET_ERR_ARGUMENT, "null argument");
     return backward_features_layers_abi(pm->m, pg->g, d_workspace, workspace_bytes, h_grad_node_features,
@@ -819,6 +829,7 @@ int pet_graph_from_batch(const int64_t* d_element_indices_nodes, const int64_t* 
 int pet_aux_outputs(const pet_model_t* pm, const pet_graph_t* pg, const float* d_node_features,
                     const float* d_edge_features, float* d_feature, float* d_last_layer_features, float* d_scratch,
                     void* stream) {
+    if (pg && pg->g.n_nodes == 0) return PET_OK;  // an empty system: nothing to compute, zero-sized buffers may be null
     PET_REQUIRE(pm && pg && d_node_features, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(d_edge_features || pg->g.n_edges == 0, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
@@ -828,6 +839,7 @@ int pet_aux_outputs(const pet_model_t* pm, const pet_graph_t* pg, const float* d
 
 int pet_backward(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                  const float* d_grad_atomic, float* d_grad_positions, float* d_grad_cells, void* stream) {
+    if (pg && pg->g.n_nodes == 0) return PET_OK;  // an empty system: nothing to compute, zero-sized buffers may be null
     PET_REQUIRE(pm && pg && d_workspace && d_grad_atomic && d_grad_positions, PET_ERR_ARGUMENT,
                 "null argument");
     PET_REQUIRE(pm->m.finalized, PET_ERR_ARGUMENT, "pet_model_finalize has not been called");
@@ -838,6 +850,7 @@ int pet_backward(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace
 int pet_backward_predict(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                          const float* d_grad_atomic, float* d_grad_node_features, float* d_grad_edge_features,
                          float* d_grad_cutoff, void* stream) {
+    if (pg && pg->g.n_nodes == 0) return PET_OK;  // an empty system: nothing to compute, zero-sized buffers may be null
     PET_REQUIRE(pm && pg && d_workspace && d_grad_atomic, PET_ERR_ARGUMENT, "null argument");
     return backward_predict_abi(pm->m, pg->g, d_workspace, workspace_bytes, d_grad_atomic, d_grad_node_features,
                                 d_grad_edge_features, d_grad_cutoff, (hipStream_t)stream);
@@ -846,6 +859,7 @@ int pet_backward_predict(const pet_model_t* pm, const pet_graph_t* pg, void* d_w
 int pet_backward_features(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                           const float* d_grad_node_features, const float* d_grad_edge_features,
                           float* d_grad_geometry, float* d_grad_cutoff, void* stream) {
+    if (pg && pg->g.n_nodes == 0) return PET_OK;  // an empty system: nothing to compute, zero-sized buffers may be null
     PET_REQUIRE(pm && pg && d_workspace && d_grad_node_features && d_grad_geometry && d_grad_cutoff,
                 PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE(d_grad_edge_features || pg->g.n_edges == 0, PET_ERR_ARGUMENT, "null argument");
@@ -856,6 +870,7 @@ int pet_backward_features(const pet_model_t* pm, const pet_graph_t* pg, void* d_
 int pet_backward_geometry(const pet_model_t* pm, const pet_graph_t* pg, void* d_workspace, int64_t workspace_bytes,
                           const float* d_grad_geometry, const float* d_grad_cutoff, float* d_grad_positions,
                           float* d_grad_cells, void* stream) {
+    if (pg && pg->g.n_nodes == 0) return PET_OK;  // an empty system: nothing to compute, zero-sized buffers may be null
     PET_REQUIRE(pm && pg && d_workspace && d_grad_positions, PET_ERR_ARGUMENT, "null argument");
     PET_REQUIRE((d_grad_geometry && d_grad_cutoff) || pg->g.n_edges == 0, PET_ERR_ARGUMENT, "null argument");
     return backward_geometry_abi(pm->m, pg->g, d_workspace, workspace_bytes, d_grad_geometry, d_grad_cutoff,
@@ -863,7 +878,13 @@ int pet_backward_geometry(const pet_model_t* pm, const pet_graph_t* pg, void* d_
 }
 
 int pet_sum_over_atoms(const pet_graph_t* pg, const float* d_atomic, float* d_out, void* stream) {
-    PET_REQUIRE(pg && d_atomic && d_out, PET_ERR_ARGUMENT, "null argument");
+    PET_REQUIRE(pg && d_out, PET_ERR_ARGUMENT, "null argument");
+    if (pg->g.n_nodes == 0) {
+        PET_HIP_CHECK(hipMemsetAsync(d_out, 0, (size_t)(pg->g.n_systems > 0 ? pg->g.n_systems : 0) * sizeof(float),
+                                     (hipStream_t)stream));
+        return PET_OK;
+    }
+    PET_REQUIRE(d_atomic, PET_ERR_ARGUMENT, "null argument");
     return sum_over_atoms(pg->g, d_atomic, d_out, (hipStream_t)stream);
 }
 

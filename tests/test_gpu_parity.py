@@ -151,6 +151,41 @@ def test_empty_and_isolated_systems(rt, model, dev):
     assert relmax(atomic.cpu().numpy(), ref.numpy().ravel()) < TOL
 
 
+def test_zero_atoms_through_the_runtime(rt, model, dev):
+    """No atom at all (pet/tests/test_functionality.py:79-103 at the C ABI): neighbour lists (single and batched, an empty
+    system between two others), graph, forward, backward, per-system sums and the training reverse pass return zero-sized
+    results instead of failing on null buffers; an empty system in the middle of a batch sums to zero."""
+    hypers = model.hypers
+    cell = torch.eye(3) * 10
+    pairs, _ = rt.neighbor_list(torch.zeros((0, 3), device=dev), cell, [True] * 3, hypers["cutoff"])
+    assert tuple(pairs.shape) == (0, 5)
+    boxes = [opet.random_box(30, seed) for seed in (1, 2)]
+    pos = torch.cat([boxes[0][0], boxes[1][0]]).to(dev)
+    cells = torch.stack([boxes[0][2], torch.eye(3) * 5, boxes[1][2]])
+    batched, _ = rt.neighbor_list_batch(pos, cells, [[True] * 3] * 3, [0, 30, 30, 60], hypers["cutoff"])
+    single = sum(rt.neighbor_list(b[0].to(dev), b[2], [True] * 3, hypers["cutoff"])[0].shape[0] for b in boxes)
+    assert batched.shape[0] == single
+    e0 = torch.zeros(0, dtype=torch.int32, device=dev)
+    graph = rt.HipGraph(model, torch.zeros((0, 3), device=dev), torch.zeros(1, 3, 3, device=dev), e0, e0,
+                        torch.zeros((0, 3), dtype=torch.int32, device=dev), e0, e0)
+    fw = rt.HipForward(model, graph)
+    atomic = fw.forward()
+    assert atomic.shape == (0,) and fw.backward(torch.ones_like(atomic)).shape == (0, 3)
+    assert fw.sum_over_atoms(atomic).tolist() == [0.0]
+    ft = rt.HipForward(model, graph, train=True)
+    model.zero_grad()
+    ft.backward_train(torch.ones_like(ft.forward()))
+    assert float(model.flat_grad().abs().max()) == 0.0
+    # systems 0 and 2 hold the atoms, system 1 none
+    sysidx = torch.cat([torch.zeros(30), torch.full((30,), 2)]).int().to(dev)
+    z = torch.cat([boxes[0][1], boxes[1][1]]).to(dev)
+    graph = rt.HipGraph(model, pos, cells.to(dev), batched[:, 0].contiguous(), batched[:, 1].contiguous(),
+                        batched[:, 2:5].contiguous(), z, sysidx)
+    fw = rt.HipForward(model, graph)
+    energies = fw.sum_over_atoms(fw.forward())
+    assert float(energies[1]) == 0.0 and float(energies[0]) != 0.0 and float(energies[2]) != 0.0
+
+
 def test_batch_of_systems_vs_oracle_and_per_system_sum(rt, model, dev):
     """Several systems in one call (concatenate_structures layout), triclinic + cubic cells,
     a non-strict list (built with cutoff + 0.7) in shuffled edge order; checks energies per
