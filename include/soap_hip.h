@@ -71,9 +71,8 @@ int soap_backward(const soap_model_t* m, const pet_graph_t* g, void* d_workspace
 
 /* ---- training step (reference loop body soap_bpnn/trainer.py:344-391: zero_grad, evaluate_model(is_training=True),
  * loss.backward(), Adam lr 1e-3 without clipping, soap_bpnn/documentation.py TrainerHypers) -------------------------------
- * Trainable: layernorm.<s>.{weight,bias}, bpnn.<s>.{0,2}.weight, last_layers.energy.<s>.weight (every parameter of a
- * legacy = True model; legacy = False models are refused with PET_ERR_UNSUPPORTED: their species embedding / centre
- * encoding have no gradient kernels). */
+ * Trainable: layernorm.<s>.{weight,bias}, bpnn.<s>.<2k>.weight, last_layers.energy.<s>.weight (every parameter of a
+ * legacy = True model) and, for legacy = False models, species_embedding.weight and center_encoding.weight. */
 /* Allocates (first call) and zeroes the gradient slot of every trainable parameter (optimizer.zero_grad()). */
 int soap_model_zero_grad(soap_model_t* m, void* stream);
 int64_t soap_train_workspace_bytes(const soap_model_t* m, int64_t n_nodes, int64_t n_edges);

@@ -801,6 +801,16 @@ __global__ __launch_bounds__(256) void k_gt_cond_bwd(const int64_t* __restrict__
 
 }  // namespace
 
+// (nu_x, lambda_x) = adjoint of (y, y') = norm(x, x') on rows of any width (k_gt_norm_rev) for another caller: the
+// SOAP-BPNN training pass of legacy = False models takes its LayerNorm adjoints here (soap_train.h)
+int norm_rev_rows(const float* Xp, const float* Xt, const float* gamma, int ln, float eps, const float* NYp, const float* NYt,
+                  float* NXp, float* NXt, int64_t R, int W, hipStream_t st) {
+    if (R <= 0) return PET_OK;
+    k_gt_norm_rev<<<(int)cdiv(R, 4), 256, 0, st>>>(Xp, Xt, gamma, ln, eps, NYp, NYt, NXp, NXt, 0, nullptr, R, W);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
 int64_t gen_train_workspace_bytes(const Model& m, int64_t N, int64_t E) {
     TWs w;
     train_carve(m, N, E, nullptr, w);

@@ -182,6 +182,8 @@ int gen_backward_geometry(const Model& m, const Graph& g, void* ws, int64_t ws_b
                           float* gpos, float* gcell, hipStream_t st);
 // gen_train.hip: the size-generic TRAINING pass (forward-over-reverse on dual activations, any size / PostLN / residual)
 int64_t gen_train_workspace_bytes(const Model& m, int64_t n_nodes, int64_t n_edges);
+int norm_rev_rows(const float* Xp, const float* Xt, const float* gamma, int ln, float eps, const float* NYp, const float* NYt,
+                  float* NXp, float* NXt, int64_t R, int W, hipStream_t st);
 int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, const float* lA, const float* nA, const float* u,
                const float* ucell, float* tangent_atomic, hipStream_t st);
 // a model whose TRAINING runs on the size-generic path: other sizes, PostLN layers, the residual featuriser

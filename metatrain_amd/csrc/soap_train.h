@@ -12,10 +12,10 @@
 // atoms of each network for the weight gradients (k_soap_wgrad1 / k_soap_wgrad2: fixed summation order, no float
 // atomics), then Adam (torch.optim.Adam semantics, soap_bpnn/trainer.py:279-291: lr 1e-3, no clipping).
 //
-// Trainable here: layernorm.<s>.{weight,bias}, bpnn.<s>.{0,2}.weight, last_layers.energy.<s>.weight -- every
-// parameter of the default (legacy = True) model. The Alchemical species embedding and the centre encoding of
-// legacy = False models sit in front of the descriptor; their gradients need the reverse sweep through the power
-// spectrum as well and are not built (soap_train_gradients refuses such a model).
+// Trainable here: layernorm.<s>.{weight,bias}, bpnn.<s>.<2k>.weight, last_layers.energy.<s>.weight -- every
+// parameter of the default (legacy = True) model -- and, for legacy = False models, the centre encoding and the
+// Alchemical species embedding, which sit in FRONT of the tail: J is carried back through LayerNorm, the encoding, the
+// power spectrum and the expansion (k_soap_ybar ... k_soap_embed_reduce below).
 #pragma once
 
 // ---------------------------------------------------------------------------------------------
@@ -412,6 +412,208 @@ __global__ __launch_bounds__(256) void k_soap_wgrad2(SoapDims d, const int* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// legacy = False: the centre encoding and the Alchemical species embedding sit in FRONT of the tail, so J has to be carried
+// back through LayerNorm, the encoding, the power spectrum and the expansion:
+//   (nu_y, lambda_y) = W1^T (abar_1, adbar_1)          adjoints of the first Linear's input y and of its tangent y'
+//   (nu_x, lambda_x) = LayerNorm^T (second order)       gen_train.hip norm_rev_rows
+//   x = p enc[species], x' = p' enc:  d enc = sum_i (nu_x p + lambda_x p'),  (nu_p, lambda_p) = (nu_x, lambda_x) enc
+//   p = sum_m c c, p' = sum_m (c' c + c c'):  nu_c = P(c, nu_p) + P(c', lambda_p),  lambda_c = P(c, lambda_p),
+//       P(c, f)[m][a] = sum_b (f[a][b] + f[b][a]) c[m][b]
+//   c[lm n a] = sum_pairs B_{lm n} w[species of the neighbour][a]:  d w[s][a] = sum_{pairs with neighbour species s}
+//       sum_{lm n} (nu_c B + lambda_c B'),  B = Y_lm R_n, B' = Y'_lm R_n + Y_lm R'_n
+// All sums over atoms / pairs run in a fixed order (chunk partials, then the chunks in order).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_soap_ybar(SoapDims d, const SoapSet* __restrict__ sets, const float* __restrict__ pack,
+                                                   float* __restrict__ NY, float* __restrict__ LY) {
+    __shared__ float ab[2 * MAXH];
+    const int i = blockIdx.x, H = d.H, PK = soap_pack_size(H, d.NH);
+    const float* pk = pack + (size_t)i * PK + 4;
+    if ((int)threadIdx.x < H) { ab[threadIdx.x] = pk[threadIdx.x]; ab[MAXH + threadIdx.x] = pk[H + threadIdx.x]; }
+    __syncthreads();
+    const float* W1 = sets[0].W1;
+    for (int k = threadIdx.x; k < d.S; k += 256) {
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < H; j++) {
+            const float w = W1[(size_t)j * d.S + k];
+            a += w * ab[j];
+            b += w * ab[MAXH + j];
+        }
+        NY[(size_t)i * d.S + k] = a;
+        LY[(size_t)i * d.S + k] = b;
+    }
+}
+
+// T = nu_x p + lambda_x p' (its sum over the atoms of a species is d enc); (nu_x, lambda_x) *= enc -> (nu_p, lambda_p)
+__global__ __launch_bounds__(256) void k_soap_enc_rev(SoapDims d, const float* __restrict__ Cf, const float* __restrict__ Cd,
+                                                      const int* __restrict__ sp, const float* __restrict__ enc,
+                                                      const int2* __restrict__ flut, float* __restrict__ NX,
+                                                      float* __restrict__ LX, float* __restrict__ T) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cs = smem;
+    float* cd = smem + d.NCOEF;
+    const int i = blockIdx.x;
+    for (int k = threadIdx.x; k < d.NCOEF; k += 256) {
+        cs[k] = Cf[(size_t)i * d.NCOEF + k];
+        cd[k] = Cd[(size_t)i * d.NCOEF + k];
+    }
+    __syncthreads();
+    const float* e = enc + (size_t)sp[i] * d.S;
+    for (int idx = threadIdx.x; idx < d.S; idx += 256) {
+        const int2 code = flut[idx];
+        const int pa = code.x, pb = code.y & 0xffff, M = (code.y >> 16) & 0xff, nc = code.y >> 24;
+        float p = 0.f, pd = 0.f;
+        for (int m = 0; m < M; m++) {
+            p += cs[pa + m * nc] * cs[pb + m * nc];
+            pd += cd[pa + m * nc] * cs[pb + m * nc] + cs[pa + m * nc] * cd[pb + m * nc];
+        }
+        const size_t o = (size_t)i * d.S + idx;
+        const float nx = NX[o], lx = LX[o];
+        T[o] = nx * p + lx * pd;
+        NX[o] = nx * e[idx];
+        LX[o] = lx * e[idx];
+    }
+}
+
+// partial[(chunk, s)][k] = sum over the atoms i of the chunk with species s of T[i][k]
+__global__ __launch_bounds__(256) void k_soap_colsum_species(const float* __restrict__ T, const int* __restrict__ sp, int N,
+                                                             int S, int n_chunks, float* __restrict__ partial) {
+    const int k = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y, s = blockIdx.z;
+    if (k >= S) return;
+    const int per = (N + n_chunks - 1) / n_chunks, lo = chunk * per, hi = min(N, lo + per);
+    float acc = 0.f;
+    for (int i = lo; i < hi; i++)
+        if (sp[i] == s) acc += T[(size_t)i * S + k];
+    partial[((size_t)chunk * gridDim.z + s) * S + k] = acc;
+}
+__global__ void k_soap_reduce_add(const float* __restrict__ partial, int n_chunks, int64_t n, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float v = 0.f;
+    for (int c = 0; c < n_chunks; c++) v += partial[(size_t)c * n + idx];
+    out[idx] += v;
+}
+
+__global__ __launch_bounds__(256) void k_soap_ps_rev2(SoapDims d, const float* __restrict__ Cf, const float* __restrict__ Cd,
+                                                      const float* __restrict__ NP, const float* __restrict__ LP,
+                                                      float* __restrict__ NC, float* __restrict__ LC) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cs = smem;
+    float* cd = smem + d.NCOEF;
+    const int i = blockIdx.x;
+    for (int k = threadIdx.x; k < d.NCOEF; k += 256) {
+        cs[k] = Cf[(size_t)i * d.NCOEF + k];
+        cd[k] = Cd[(size_t)i * d.NCOEF + k];
+    }
+    __syncthreads();
+    const float* np = NP + (size_t)i * d.S;
+    const float* lp = LP + (size_t)i * d.S;
+    for (int idx = threadIdx.x; idx < d.NCOEF; idx += 256) {
+        int l = 0;
+        while (idx >= d.coef_off[l + 1]) l++;
+        const int nc = d.n_per_l[l] * d.C, q = idx - d.coef_off[l];
+        const int m = q / nc, a = q % nc;
+        const float* crow = cs + d.coef_off[l] + m * nc;
+        const float* drow = cd + d.coef_off[l] + m * nc;
+        const float* fn = np + d.feat_off[l];
+        const float* fl = lp + d.feat_off[l];
+        float vn = 0.f, vl = 0.f;
+        for (int b = 0; b < nc; b++) {
+            const float sn = fn[a * nc + b] + fn[b * nc + a], sl = fl[a * nc + b] + fl[b * nc + a];
+            vn += sn * crow[b] + sl * drow[b];
+            vl += sl * crow[b];
+        }
+        NC[(size_t)i * d.NCOEF + idx] = vn;
+        LC[(size_t)i * d.NCOEF + idx] = vl;
+    }
+}
+
+// q[p][a] = sum_{lm n} (nu_c[i][lm n a] B_{lm n}(p) + lambda_c[i][lm n a] B'_{lm n}(p)) for every pair p of atom i
+__global__ __launch_bounds__(256) void k_soap_embed_pairs(SoapDims d, const float4* __restrict__ geo,
+                                                          const float4* __restrict__ vdot, const int* __restrict__ rowptr,
+                                                          const float* __restrict__ table, const float* __restrict__ shn,
+                                                          const int* __restrict__ lut, const float* __restrict__ NC,
+                                                          const float* __restrict__ LC, float* __restrict__ q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ys = smem;                     // [PC][NLM]
+    float* Yd = Ys + PC * d.NLM;          // [PC][NLM]
+    float* Gs = Yd + PC * d.NLM;          // [PC][3][NLM]
+    float* Rs = Gs + PC * 3 * d.NLM;      // [PC][F]
+    float* Rd = Rs + PC * d.F;            // [PC][F]
+    float* us = Rd + PC * d.F;            // [PC][12]
+    float* ncs = us + PC * 12;            // [NCOEF] nu_c of this atom
+    float* lcs = ncs + d.NCOEF;           // [NCOEF] lambda_c
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int p0 = rowptr[i], p1 = rowptr[i + 1];
+    for (int k = tid; k < d.NCOEF; k += 256) {
+        ncs[k] = NC[(size_t)i * d.NCOEF + k];
+        lcs[k] = LC[(size_t)i * d.NCOEF + k];
+    }
+    for (int base = p0; base < p1; base += PC) {
+        const int npc = min(PC, p1 - base);
+        __syncthreads();
+        if (tid < npc) {
+            const float4 g = geo[base + tid], t = vdot[base + tid];
+            const float r = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
+            const float ir = r > 0.f ? 1.0f / r : 0.f;
+            float* u = us + tid * 12;
+            u[0] = g.x * ir; u[1] = g.y * ir; u[2] = g.z * ir; u[3] = r; u[4] = ir;
+            float dfc;
+            u[5] = shifted_cosine(r, d.rc, d.width, &dfc);
+            u[6] = dfc;
+            u[7] = t.x; u[8] = t.y; u[9] = t.z;
+            u[10] = u[0] * t.x + u[1] * t.y + u[2] * t.z;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < npc * (d.L + 1); idx += 256) {
+            const int pp = idx / (d.L + 1), mm = idx % (d.L + 1);
+            const float* u = us + pp * 12;
+            float* G = Gs + pp * 3 * d.NLM;
+            sh_chain(u[0], u[1], u[2], mm, d.L, shn, Ys + pp * d.NLM, G, G + d.NLM, G + 2 * d.NLM, u[4]);
+        }
+        for (int idx = tid; idx < npc * d.F; idx += 256) {
+            const int pp = idx / d.F, f = idx % d.F;
+            const float* u = us + pp * 12;
+            float dR;
+            radial_one(d, table, f, u[3], u[5], u[6], Rs + pp * d.F + f, &dR);
+            Rd[pp * d.F + f] = dR * u[10];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < npc * d.NLM; idx += 256) {
+            const int pp = idx / d.NLM, lm = idx % d.NLM;
+            const float* u = us + pp * 12;
+            const float* G = Gs + pp * 3 * d.NLM;
+            Yd[idx] = G[lm] * u[7] + G[d.NLM + lm] * u[8] + G[2 * d.NLM + lm] * u[9];
+        }
+        __syncthreads();
+        for (int out = tid; out < npc * d.C; out += 256) {
+            const int pp = out / d.C, a = out % d.C;
+            float s = 0.f;
+            for (int idx = 0; idx < d.NCOEF; idx++) {
+                const int code = lut[idx];
+                if ((code >> 16) != a) continue;
+                const int lm = code & 255, rn = (code >> 8) & 255;
+                const float y = Ys[pp * d.NLM + lm], yd = Yd[pp * d.NLM + lm], r = Rs[pp * d.F + rn], rd = Rd[pp * d.F + rn];
+                s += ncs[idx] * (y * r) + lcs[idx] * (yd * r + y * rd);
+            }
+            q[(size_t)(base + pp) * d.C + a] = s;
+        }
+    }
+}
+
+// partial[chunk][s][a] = sum over the pairs p of the chunk whose neighbour has species s of q[p][a]
+__global__ __launch_bounds__(256) void k_soap_embed_reduce(const float* __restrict__ q, const int* __restrict__ sp_nbr,
+                                                           int64_t E, int C, int ns, int n_chunks, float* __restrict__ partial) {
+    const int t = threadIdx.x, chunk = blockIdx.x;
+    if (t >= ns * C) return;
+    const int s = t / C, a = t % C;
+    const int64_t per = (E + n_chunks - 1) / n_chunks, lo = chunk * per, hi = min(E, lo + per);
+    float acc = 0.f;
+    for (int64_t p = lo; p < hi; p++)
+        if (sp_nbr[p] == s) acc += q[p * C + a];
+    partial[(size_t)chunk * ns * C + t] = acc;
+}
+
 // torch.optim.Adam (no weight decay, no amsgrad): bias-corrected moments, step counted from 1
 __global__ void k_soap_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             int64_t n, float lr, float b1, float b2, float eps, float c1, float c2) {
@@ -429,11 +631,13 @@ __global__ void k_soap_adam(float* __restrict__ p, const float* __restrict__ g, 
 struct SoapTrainWs {
     float4* vd;
     float *Cd, *xd, *pack, *part;
+    float *NY, *LY, *NX, *LX, *NC, *LC, *q, *part2;   // legacy = False only (see k_soap_ybar)
     int* perm;
     SpInfo* info;
     int n_chunks;
     size_t bytes;
 };
+constexpr int SOAP_EMBED_CHUNKS = 64;   // chunk partials of the centre-encoding / species-embedding reductions
 static int soap_train_chunks(int64_t N) { return (int)std::min<int64_t>(32, std::max<int64_t>(1, (N + 1023) / 1024)); }
 static void carve_soap_train(const SoapModel& m, int64_t N, int64_t E, void* base, SoapTrainWs& w) {
     const SoapDims& d = m.d;
@@ -447,10 +651,18 @@ static void carve_soap_train(const SoapModel& m, int64_t N, int64_t E, void* bas
     w.part = c.take<float>((size_t)w.n_chunks * m.n_sets * (d.H + 2) * d.S);
     w.perm = c.take<int>(Na);
     w.info = reinterpret_cast<SpInfo*>(c.take<int>((sizeof(SpInfo) + 3) / 4));
+    const bool front = !d.legacy;
+    const int64_t ns_s = front ? Na * d.S : 1, nc_s = front ? Na * d.NCOEF : 1;
+    w.NY = c.take<float>(ns_s); w.LY = c.take<float>(ns_s);
+    w.NX = c.take<float>(ns_s); w.LX = c.take<float>(ns_s);
+    w.NC = c.take<float>(nc_s); w.LC = c.take<float>(nc_s);
+    w.q = c.take<float>(front ? Ea * d.C : 1);
+    w.part2 = c.take<float>(front ? (size_t)SOAP_EMBED_CHUNKS * d.ns * (d.S > d.C ? d.S : d.C) : 1);
     w.bytes = c.off;
 }
 
 static bool soap_trainable_key(const SoapModel& m, const std::string& key) {
+    if (!m.d.legacy && (key == "species_embedding.weight" || key == "center_encoding.weight")) return true;
     return key.rfind("layernorm.", 0) == 0 || key.rfind("bpnn.", 0) == 0 || key.rfind("last_layers.", 0) == 0;
 }
 
@@ -480,9 +692,7 @@ static int soap_zero_grad(SoapModel& m, hipStream_t st) {
 static int soap_train_grads(SoapModel& m, const Graph& g, void* ws, int64_t ws_bytes, void* tws, int64_t tws_bytes,
                             const float* gA, const float* u, float* tangent_atomic, hipStream_t st) {
     const SoapDims& d = m.d;
-    PET_REQUIRE(d.legacy, PET_ERR_UNSUPPORTED,
-                "SOAP-BPNN training is built for legacy = True models (the species embedding and centre encoding of "
-                "legacy = False have no gradient kernels)");
+    PET_REQUIRE(d.legacy || d.ns * d.C <= 256, PET_ERR_UNSUPPORTED, "more than 64 species with the Alchemical embedding");
     PET_REQUIRE(d.H <= MAXH && d.NH <= MAXNH, PET_ERR_UNSUPPORTED, "tail size outside the compiled limits");
     PET_REQUIRE(!m.grad.empty(), PET_ERR_ARGUMENT, "soap_model_zero_grad has not been called");
     PET_REQUIRE(!soap_fused_ok(m), PET_ERR_UNSUPPORTED,
@@ -496,6 +706,11 @@ static int soap_train_grads(SoapModel& m, const Graph& g, void* ws, int64_t ws_b
     const int N = (int)g.n_nodes;
     if (N == 0) return PET_OK;
     const bool tangent = u != nullptr && g.n_edges > 0;
+    if (!tangent && !d.legacy) {   // the front-of-the-tail pass reads the tangents: zeros for an energy-only loss
+        PET_HIP_CHECK(hipMemsetAsync(t.vd, 0, (size_t)(g.n_edges > 0 ? g.n_edges : 1) * sizeof(float4), st));
+        PET_HIP_CHECK(hipMemsetAsync(t.Cd, 0, (size_t)N * d.NCOEF * 4, st));
+        PET_HIP_CHECK(hipMemsetAsync(t.xd, 0, (size_t)N * d.S * 4, st));
+    }
     if (tangent) {
         k_edge_tangent<<<cdiv(g.n_edges, 256), 256, 0, st>>>(u, g.ctr, g.nbr, t.vd, g.n_edges);
         const size_t lds = (size_t)PC * (5 * d.NLM + 2 * d.F + 12 + 1) * 4;
@@ -528,6 +743,33 @@ static int soap_train_grads(SoapModel& m, const Graph& g, void* ws, int64_t ws_b
                                                 m.grad.at("bpnn." + ss + "." + std::to_string(2 * kk) + ".weight").first);
         k_soap_wgrad2<<<1, 256, lds2, st>>>(d, t.perm, t.info, t.pack, gA, seed_t, s, d.NH,
                                             m.grad.at("last_layers.energy." + ss + ".weight").first);
+    }
+    if (!d.legacy) {   // centre encoding and species embedding (k_soap_ybar ...)
+        const float* ln_w = d.layernorm ? m.raw.at("layernorm.0.weight").first : nullptr;
+        k_soap_ybar<<<N, 256, 0, st>>>(d, m.sets, t.pack, t.NY, t.LY);
+        float *NX = t.NY, *LX = t.LY, *T = t.NX;
+        if (d.layernorm) {
+            int rc = norm_rev_rows(w.feats, t.xd, ln_w, 1, 1e-5f, t.NY, t.LY, t.NX, t.LX, N, d.S, st);
+            if (rc) return rc;
+            NX = t.NX; LX = t.LX; T = t.NY;
+        }
+        allow_big_lds(k_soap_enc_rev, (size_t)2 * d.NCOEF * 4);
+        k_soap_enc_rev<<<N, 256, (size_t)2 * d.NCOEF * 4, st>>>(d, w.Cf, t.Cd, g.sp, m.enc, m.feat_lut, NX, LX, T);
+        const int nch = (int)std::min<int64_t>(SOAP_EMBED_CHUNKS, N);
+        k_soap_colsum_species<<<dim3(cdiv(d.S, 256), nch, d.ns), 256, 0, st>>>(T, g.sp, N, d.S, nch, t.part2);
+        k_soap_reduce_add<<<cdiv((int64_t)d.ns * d.S, 256), 256, 0, st>>>(t.part2, nch, (int64_t)d.ns * d.S,
+                                                                        m.grad.at("center_encoding.weight").first);
+        allow_big_lds(k_soap_ps_rev2, (size_t)2 * d.NCOEF * 4);
+        k_soap_ps_rev2<<<N, 256, (size_t)2 * d.NCOEF * 4, st>>>(d, w.Cf, t.Cd, NX, LX, t.NC, t.LC);
+        if (g.n_edges > 0) {
+            const size_t lds = ((size_t)PC * (5 * d.NLM + 2 * d.F + 12) + 2 * d.NCOEF) * 4;
+            allow_big_lds(k_soap_embed_pairs, lds);
+            k_soap_embed_pairs<<<N, 256, lds, st>>>(d, g.geo, t.vd, g.rowptr, m.table, m.shnorm, m.coef_lut, t.NC, t.LC, t.q);
+            const int nce = (int)std::min<int64_t>(SOAP_EMBED_CHUNKS, g.n_edges);
+            k_soap_embed_reduce<<<nce, 256, 0, st>>>(t.q, g.sp_nbr, g.n_edges, d.C, d.ns, nce, t.part2);
+            k_soap_reduce_add<<<cdiv((int64_t)d.ns * d.C, 256), 256, 0, st>>>(t.part2, nce, (int64_t)d.ns * d.C,
+                                                                            m.grad.at("species_embedding.weight").first);
+        }
     }
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;

@@ -132,9 +132,13 @@ class SoapBpnnHip:
         return out
 
     def trainable(self) -> List:
-        """``(key, shape)`` of every trainable parameter (all parameters of a ``legacy = True`` model)."""
+        """``(key, shape)`` of every trainable parameter: the tail's, and for ``legacy = False`` models the Alchemical species
+        embedding and the centre encoding in front of it."""
         nn_, nh = self.hypers["bpnn"]["num_neurons_per_layer"], self.hypers["bpnn"]["num_hidden_layers"]
         size, out = self.feature_size, []
+        if not self.legacy:
+            ns = len(self.atomic_types)
+            out += [("species_embedding.weight", (ns, 4)), ("center_encoding.weight", (ns, size))]
         for s in range(len(self.atomic_types) if self.legacy else 1):
             if self.hypers["bpnn"]["layernorm"]:
                 out += [(f"layernorm.{s}.weight", (size,)), (f"layernorm.{s}.bias", (size,))]

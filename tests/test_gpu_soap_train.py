@@ -113,7 +113,8 @@ def test_ethanol_frames_energy_and_forces():
 
 
 @pytest.mark.parametrize("case", ["ethanol", "boxes", "boxes_no_layernorm", "boxes_one_hidden_layer",
-                                  "boxes_four_hidden_layers", "boxes_48_neurons", "energy_only"])
+                                  "boxes_four_hidden_layers", "boxes_48_neurons", "energy_only", "alchemical", "alchemical_ethanol",
+                                  "alchemical_no_layernorm", "alchemical_energy_only"])
 def test_training_gradients_against_the_oracles_double_backward(case):
     dev = torch.device("cuda:0")
     hypers = dict(osoap.DEFAULT_HYPERS)
@@ -123,11 +124,15 @@ def test_training_gradients_against_the_oracles_double_backward(case):
         hypers["bpnn"] = dict(hypers["bpnn"], num_hidden_layers=1)
     if case == "boxes_four_hidden_layers":
         hypers["bpnn"] = dict(hypers["bpnn"], num_hidden_layers=4)
+    if case.startswith("alchemical"):   # legacy = False: species embedding + centre encoding in front of one shared tail
+        hypers["legacy"] = False
+    if case == "alchemical_no_layernorm":
+        hypers["bpnn"] = dict(hypers["bpnn"], layernorm=False)
     if case == "boxes_48_neurons":
         hypers["bpnn"] = dict(hypers["bpnn"], num_hidden_layers=3, num_neurons_per_layer=48)
-    types = [1, 6, 8] if case == "ethanol" else [1, 6, 7, 8]
-    batch = _ethanol() if case == "ethanol" else _random_batch()
-    with_forces = case != "energy_only"
+    types = [1, 6, 8] if case.endswith("ethanol") else [1, 6, 7, 8]
+    batch = _ethanol() if case.endswith("ethanol") else _random_batch()
+    with_forces = not case.endswith("energy_only")
     n_per_l = osoap.basis(hypers)[0]
     params = osoap.synthetic_params(hypers, len(types), n_per_l, 1, torch.float32)
     loss_ref, g_ref, e_ref, gr_ref = _oracle_loss_and_grads({k: v.double() for k, v in params.items()}, hypers, types,
@@ -164,13 +169,15 @@ def test_training_gradients_against_the_oracles_double_backward(case):
     assert not bad, bad
 
 
-def test_three_adam_steps_follow_torch():
+@pytest.mark.parametrize("legacy", [True, False])
+def test_three_adam_steps_follow_torch(legacy):
     """``SoapTrainStep`` (zero_grad, forward, dE/dR, losses, gradients, Adam lr 1e-3) against the same three steps of
-    torch.optim.Adam on the oracle: losses and every parameter after the third step."""
+    torch.optim.Adam on the oracle: losses and every parameter after the third step (legacy = False: the species
+    embedding and the centre encoding move too, and the forward's derived tables follow them)."""
     from metatrain_amd.soap_bpnn import SoapTrainStep
 
     dev = torch.device("cuda:0")
-    types, hypers = [1, 6, 8], dict(osoap.DEFAULT_HYPERS)
+    types, hypers = [1, 6, 8], dict(osoap.DEFAULT_HYPERS, legacy=legacy)
     n_per_l = osoap.basis(hypers)[0]
     params = osoap.synthetic_params(hypers, 3, n_per_l, 2, torch.float32)
     batch = _ethanol(6)
