@@ -464,6 +464,55 @@ __global__ void k_adapt_rdot(const float* __restrict__ u, const int* __restrict_
     if (l == 0 && gid < N) rdot[gid] = -inv_dn[gid] * s;
 }
 
+// "grid" method (adaptive_cutoff.py legacy path): r_i = sum_k p_k w_k(n_i1 .. n_iK), n_ik = sum_q bump(d_q; p_k, w), so
+//   r_i' = sum_q [ sum_k (d r_i / d n_ik) (d bump / d d)(d_q; p_k, w) ] d_q'   with the per-atom row drdn the graph build kept
+// (the transpose of pet_bwd.hip k_adapt_dv_grid)
+__global__ void k_adapt_rdot_grid(const float* __restrict__ u, const int* __restrict__ rowptr0, const int* __restrict__ perm0,
+                                  const int* __restrict__ nbr0, const float4* __restrict__ vin,
+                                  const float* __restrict__ drdn, float* __restrict__ rdot, int N, float w, int K, float pmin,
+                                  float dp, const float* __restrict__ ucell, const int* __restrict__ shift0,
+                                  const int* __restrict__ sys) {
+    __shared__ float s_c[16][GRID_MAX_PROBES];
+    const int grp = threadIdx.x >> 4;
+    const int gid = blockIdx.x * (blockDim.x / 16) + grp;
+    const int l = threadIdx.x & 15;
+    const int a = gid < N ? gid : N - 1;
+    for (int k = l; k < K; k += 16) s_c[grp][k] = drdn[(int64_t)a * GRID_MAX_PROBES + k];
+    __syncthreads();
+    float s = 0.f;
+    for (int q = rowptr0[a] + l; q < rowptr0[a + 1]; q += 16) {
+        const float4 v = vin[perm0[q]];
+        const int j = nbr0[q];
+        const float nrm = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+        float tx = u[3 * j] - u[3 * a], ty = u[3 * j + 1] - u[3 * a + 1], tz = u[3 * j + 2] - u[3 * a + 2];
+        if (ucell) {
+            const float* c = ucell + 9 * sys[a];
+            const float sa = (float)shift0[3 * q], sb = (float)shift0[3 * q + 1], sc = (float)shift0[3 * q + 2];
+            tx += sa * c[0] + sb * c[3] + sc * c[6];
+            ty += sa * c[1] + sb * c[4] + sc * c[7];
+            tz += sa * c[2] + sb * c[5] + sc * c[8];
+        }
+        const float dd = nrm > 0.f ? (v.x * tx + v.y * ty + v.z * tz) / nrm : 0.f;
+        float coef = 0.f;
+        for (int k = 0; k < K; k++) coef += s_c[grp][k] * cutoff_deriv_dev(v.w, pmin + (float)k * dp, w, PET_CUTOFF_BUMP);
+        s += coef * dd;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (l == 0 && gid < N) rdot[gid] = s;
+}
+// tangent of the atomic cutoffs into g.ad_gr (either method)
+static void adaptive_rdot(const Model& m, const Graph& g, const float* u, const float* ucell, hipStream_t st) {
+    const int N = (int)g.n_nodes;
+    if (g.grid_probes > 0)
+        k_adapt_rdot_grid<<<cdiv(N, 16), 256, 0, st>>>(u, g.rowptr0, g.perm0, g.nbr0, g.vin, g.grid_drdn, g.ad_gr, N,
+                                                       m.h.cutoff_width_adaptive, g.grid_probes, 0.5f,
+                                                       m.h.cutoff_width_adaptive / 4.0f, ucell, g.shift0, g.sys);
+    else
+        k_adapt_rdot<<<cdiv(N, 16), 256, 0, st>>>(u, g.rowptr0, g.perm0, g.nbr0, g.vin, g.r_newton, g.inv_dn, g.ad_gr, N,
+                                                  m.h.cutoff_width_adaptive, ucell, g.shift0, g.sys);
+}
+
 __global__ void k_geom_jvp(const float* __restrict__ u, const int* __restrict__ ctr, const int* __restrict__ nbr,
                            const float4* __restrict__ geo, const float* __restrict__ d0, const float* __restrict__ fc,
                            float4* __restrict__ Tgeo, float* __restrict__ Tfc, float* __restrict__ Tkb, int64_t E,
@@ -497,12 +546,8 @@ __global__ void k_geom_jvp(const float* __restrict__ u, const int* __restrict__ 
 // the two kernels above for any caller (gen_train.hip: the size-generic pass with the adaptive cutoff)
 int geometry_tangent(const Model& m, const Graph& g, const float* u, const float* ucell, float* Tgeo, float* Tfc, float* Tkb,
                      hipStream_t st) {
-    PET_REQUIRE(g.grid_probes == 0, PET_ERR_UNSUPPORTED,
-                "the force-loss (second-order) pass carries the cutoff tangents of the 'solver' adaptive-cutoff method only");
-    const int64_t N = g.n_nodes, E = g.n_edges;
-    if (g.adaptive)  // g.ad_gr doubles as the tangent of the atomic cutoffs
-        k_adapt_rdot<<<cdiv(N, 16), 256, 0, st>>>(u, g.rowptr0, g.perm0, g.nbr0, g.vin, g.r_newton, g.inv_dn, g.ad_gr, (int)N,
-                                                  m.h.cutoff_width_adaptive, ucell, g.shift0, g.sys);
+    const int64_t E = g.n_edges;
+    if (g.adaptive) adaptive_rdot(m, g, u, ucell, st);  // g.ad_gr doubles as the tangent of the atomic cutoffs
     k_geom_jvp<<<cdiv(E, 256), 256, 0, st>>>(u, g.ctr, g.nbr, g.geo, g.d0, g.fc, reinterpret_cast<float4*>(Tgeo), Tfc, Tkb, E,
                                             m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function, g.adaptive ? g.pc : nullptr,
                                             g.adaptive ? g.ad_gr : nullptr, ucell, g.shift, g.sys);
@@ -1176,8 +1221,6 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
     PET_REQUIRE(m.grad_flat, PET_ERR_ARGUMENT, "pet_model_zero_grad has not been called");
     PET_REQUIRE(m.trainable(), PET_ERR_UNSUPPORTED,
                 "training is built for transformer_type=PreLN, featurizer_type=feedforward only");
-    PET_REQUIRE(g.grid_probes == 0, PET_ERR_UNSUPPORTED,
-                "the force-loss (second-order) pass carries the cutoff tangents of the 'solver' adaptive-cutoff method only");
     Workspace w;
     carve_workspace(m, g.n_nodes, g.n_edges, ws, w, true);
     PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "workspace too small for training");
@@ -1200,9 +1243,7 @@ int backward_train2(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, 
     const int nG = m.h.num_gnn_layers, nA_ = m.h.num_attention_layers;
 
     // =========================== tangent sweep ===========================
-    if (g.adaptive)  // g.ad_gr doubles as the tangent of the atomic cutoffs
-        k_adapt_rdot<<<cdiv(N, 16), 256, 0, st>>>(u, g.rowptr0, g.perm0, g.nbr0, g.vin, g.r_newton, g.inv_dn, g.ad_gr,
-                                                  (int)N, m.h.cutoff_width_adaptive, ucell, g.shift0, g.sys);
+    if (g.adaptive) adaptive_rdot(m, g, u, ucell, st);  // g.ad_gr doubles as the tangent of the atomic cutoffs
     k_geom_jvp<<<grid1(E), 256, 0, st>>>(u, g.ctr, g.nbr, g.geo, g.d0, g.fc, reinterpret_cast<float4*>(s.Tgeo), s.Tfc,
                                         s.Tkb, E, m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function,
                                         g.adaptive ? g.pc : nullptr, g.adaptive ? g.ad_gr : nullptr, ucell, g.shift, g.sys);

@@ -26,12 +26,14 @@ optimizers and DDP work on the mirror unchanged. (``metatrain_amd.pet.trainer.Tr
 step.) That node evaluates the batch ``preprocess`` saw, not edited features.
 
 ``activation = "SiLU"`` runs on the SwiGLU kernels with the projection uploaded as both halves (exact). Several
-properties per block, several blocks per target and several targets are served by ``pet_predict``. The architecture
-variants older checkpoints use -- ``normalization = "LayerNorm"``, ``transformer_type = "PostLN"``, ``featurizer_type =
-"residual"`` (``pet/checkpoints.py:190-205``) -- run for inference and forces; training is built for PreLN + feedforward
-models (RMSNorm or LayerNorm); both adaptive-cutoff methods ("solver", and the legacy "grid" for inference / forces / energy-only
-training); system conditioning (charge / spin multiplicity; inference, forces and training). Not built (raise loudly): diagnostic
-capture, double backward through the three inference nodes, training of PostLN / residual models.
+properties per block, several blocks per target and several targets are served by ``pet_predict``. Every model size the
+reference accepts runs (the tuned kernels are the default size; anything else, ``d_node == d_pet`` included, and any graph
+with an atom of more than 127 neighbours takes the size-generic path), and so do the architecture variants older checkpoints
+use -- ``normalization = "LayerNorm"``, ``transformer_type = "PostLN"``, ``featurizer_type = "residual"``
+(``pet/checkpoints.py:190-205``) --, both adaptive-cutoff methods ("solver" and the legacy "grid") and system conditioning
+(charge / spin multiplicity): inference, forces AND training (energy and force loss) for all of them, edge-free batches of
+isolated atoms and empty systems included. Not built (raise loudly): diagnostic capture, double backward through the three
+inference nodes, long-range features.
 """
 from math import prod
 from typing import Dict, List, Optional, Tuple

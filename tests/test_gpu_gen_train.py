@@ -29,6 +29,8 @@ CASES = {
     # needs the implicit-function tangent of the atomic cutoffs (so.hip geometry_tangent) on the generic pass too
     "s64_adaptive": dict(d_pet=64, d_node=128, d_feedforward=128, d_head=64, num_heads=4, num_neighbors_adaptive=6.0),
     "default_residual_adaptive": dict(featurizer_type="residual", num_neighbors_adaptive=6.0),
+    "s64_adaptive_grid": dict(d_pet=64, d_node=128, d_feedforward=128, d_head=64, num_heads=4, num_neighbors_adaptive=6.0,
+                              adaptive_cutoff_method="grid"),
 }
 
 
