@@ -245,6 +245,8 @@ void set_soap_mfma(int v);  // soap.hip: 1 = MFMA tail (default), 0 = per-atom t
 void set_soap_fused(int v);  // soap.hip: 1 = power spectrum + LayerNorm + first Linear fused, features never stored (default 0)
 bool emlp_recompute_ok(const Lin& win, const Lin& wout);
 void set_emlp_recompute(int v);
+void set_emlp_bwd_pipe(int v);
+void set_emlp_pipe(int v);
 bool use_tile_f16x3();
 void set_tile_f16x3(int v);
 void set_tile_mask(int v);

@@ -2,6 +2,7 @@
 // 32 rows through a whole stage, no LDS, no barriers, weights streamed from L2 in fragment order.
 // Same math and same saved tensors as the LDS-tile kernels in pet_fwd.hip / pet_bwd.hip (kept for
 // A/B comparison, PET_HIP_TRR=0); reference line map in pet_fwd.hip.
+#include <type_traits>
 #include <stdlib.h>
 
 #include "common.h"
@@ -17,6 +18,48 @@ namespace pet {
     if (row0 >= (NROWS)) return;                              \
     const bool valid = row0 + L.r < (NROWS);                  \
     const int64_t row = valid ? row0 + L.r : (NROWS) - 1
+
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+// f16x3 split of two values into packed (high, pre-scaled low) pairs, computed where it stands in the instruction
+// stream (the pipelined kernels place it in a particular slot). The low piece is derived from the PINNED high pair:
+// pinning the finished pair alone let the compiler convert x -> fp16 twice, once for the pair (v_cvt_pk_f16_f32) and once
+// for the remainder (v_cvt_f16_f32), and the two instructions do not round every input alike (a handful of values in
+// 3e5 came out one fp16 ulp apart: rows off by 1e-4; tools/ubench/emlp_fwd_ab.hip).
+__device__ __forceinline__ void split_pair_pinned(float x0, float x1, h16x2& hp, h16x2& lp) {
+    hp[0] = (_Float16)x0; hp[1] = (_Float16)x1;
+    asm volatile("" : "+v"(hp));
+    lp[0] = (_Float16)((x0 - (float)hp[0]) * 2048.0f);
+    lp[1] = (_Float16)((x1 - (float)hp[1]) * 2048.0f);
+    asm volatile("" : "+v"(lp));
+}
+// LDS-DMA: 16 B per lane from global memory straight into LDS at lds_dst + 16 lane (no registers; counted by vmcnt,
+// invisible to the compiler's own wait bookkeeping)
+__device__ __forceinline__ void glds16_trr(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// whole-row LDS-DMA of a [32 x 128] fp32 tile: instruction j brings rows 2j, 2j + 1; row r, 16-B piece p lands at
+// byte 512 r + 16 (p ^ (r & 15)) of the tile
+__device__ __forceinline__ void dma_tile128(const float* __restrict__ X, int64_t row0, int64_t n_rows, unsigned lds_base,
+                                            const RowLane& L) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int r = 2 * j + (L.lane >> 5);
+        int64_t rr = row0 + r;
+        rr = rr < n_rows ? rr : n_rows - 1;
+        const int p = (L.lane & 31) ^ (r & 15);
+        glds16_trr(X + rr * 128 + 4 * p, lds_base + j * 1024);
+    }
+}
+// row fragment (trr.h) out of such a tile
+__device__ __forceinline__ void tile128_to_frag(float4 (&x)[16], const char* tile, const RowLane& L) {
+    const char* rowp = tile + 512 * L.r;
+    const int sw = L.r & 15;
+#pragma unroll
+    for (int kg = 0; kg < 16; kg++) x[kg] = *reinterpret_cast<const float4*>(rowp + 16 * ((2 * kg + L.h) ^ sw));
+}
 
 // ---------------------------------------------------------------------------------
 // f16x3 versions (trr.h) of the 128-wide row GEMM and the stages built on it. `oscale` multiplies the finished
@@ -353,11 +396,6 @@ static inline W2 w2_wc(const GnnLayerW& G) {  // one 32-row tile, K = D
 // (same lane mapping as load_rowfrag, so every lane reads back exactly the 16 B pieces it requested), the residual
 // re-read comes from the same buffer, and the w_in ring keeps running into the next tile's first blocks.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16_trr(const float* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
 // f16x3 (trr.h): two fp16 planes, three MFMAs per K block on a high and a cross accumulator; RMSNorm output and
 // SwiGLU output are O(1) rows, so no row scaling is needed here.
 template <bool LINES, bool LN>
@@ -499,6 +537,198 @@ __global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, co
 }
 
 // ---------------------------------------------------------------------------------
+// k_emlp_p2: the edge MLP as a software-pipelined kernel (default since round 3; pet_config_set("emlp_pipe", 0) restores
+// the persistent k_emlp_h). Same scheme as k_emlp_bwd_p2 below: the three stages of a hidden chunk -- [v; g] = Win xn
+// (48 MFMAs), u = v sigma(g) + operand split (VALU), out += Wout u (24 MFMAs) -- depend on each other and a wave issues
+// in order, so iteration hc is 24 slots of one f16x3 MFMA triple followed by VALU work that does not depend on it:
+//   slots  0..7   out GEMM of chunk hc - 1 (2 K blocks x 4 tiles)  | slot s: pre-activations 2s, 2s + 1 of chunk hc folded
+//   slots  8..23  [v; g] GEMM of chunk hc + 1 (8 K blocks x 2)      | slot a: u of element a; odd a: split of a pair;
+//                                                                   |         the saved [v; g] leave as whole 128-B lines
+// x arrives by LDS-DMA (whole rows) and is parked, normalised and split, over its own tile; the residual and the output
+// bias are the INITIAL VALUE of the out accumulators; the split u operand (2 K blocks) and a private copy of the
+// input bias live in LDS. Rings: Win blocks four K blocks (8 slots) ahead, the Wout fragments of a chunk requested in
+// slots 8..15 of the iteration in which its u is made (they are used in slots 0..7 of the next one).
+// LDS per wave: [x tile / split planes 16 KB | u operand 4 KB | store staging tile 4.5 KB | input bias 2 KB].
+// ---------------------------------------------------------------------------------
+constexpr int EP2_WAVE_LDS = 16384 + 4096 + 32 * TILE32_LD * 4 + 2 * DFF * 4;
+template <bool LN>
+__global__ __launch_bounds__(256) void k_emlp_p2(const float* __restrict__ X1, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, W2 win, const float* __restrict__ bin,
+                                                  W2 wout, const float* __restrict__ bout, float* __restrict__ VG,
+                                                  float* __restrict__ X2, int64_t E) {
+    extern __shared__ __attribute__((aligned(16))) char ep_lds[];
+    TRR_PROLOGUE(E);
+    constexpr int NC = DFF / 32;
+    static_assert(NC >= 3, "first and last iteration peeled");
+    char* const my = ep_lds + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * EP2_WAVE_LDS;
+    f16x8* const xsp = reinterpret_cast<f16x8*>(my);             // after the split: [8 K blocks x (h, l)][64]
+    f16x8* const usp = reinterpret_cast<f16x8*>(my + 16384);     // [2 K blocks x (h, l)][64]
+    float* const otile = reinterpret_cast<float*>(my + 16384 + 4096);
+    float* const bias = reinterpret_cast<float*>(my + 16384 + 4096 + 32 * TILE32_LD * 4);
+    dma_tile128(X1, row0, E, __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)my), L);
+    {   // private copy of the input bias [v 256 | g 256]
+        const float4* b4 = reinterpret_cast<const float4*>(bin);
+        reinterpret_cast<float4*>(bias)[L.lane] = b4[L.lane];
+        reinterpret_cast<float4*>(bias)[64 + L.lane] = b4[64 + L.lane];
+    }
+    auto widx = [&](int b) { return (size_t)b * 64 + L.lane; };  // Win: v tile hc, K block kb at b = 8 hc + kb; g tile at + TS
+    constexpr size_t TS = (size_t)NC * 8 * 64;
+    WBlk2<2> rw[4];  // Win ring: K blocks kb .. kb + 3
+#pragma unroll
+    for (int b = 0; b < 4; b++) ld_blk2<2>(rw[b], win, widx(b), TS);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA is not visible to the compiler's own bookkeeping
+    f32x16 out[4], outl[4];
+    {
+        float4 x[16];
+        tile128_to_frag(x, my, L);
+        acc_bias<4>(out, bout, 0, L.h);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {  // the residual rides in the accumulator
+                out[t][4 * q] += x[4 * t + q].x; out[t][4 * q + 1] += x[4 * t + q].y;
+                out[t][4 * q + 2] += x[4 * t + q].z; out[t][4 * q + 3] += x[4 * t + q].w;
+            }
+        norm_frag<16, LN>(x, gamma, beta, L.h);
+        Split2<8> t;
+        split_frag2<8>(x, t);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { xsp[(2 * k) * 64 + L.lane] = t.h[k]; xsp[(2 * k + 1) * 64 + L.lane] = t.l[k]; }
+    }
+    acc_zero<4>(outl);
+    __builtin_amdgcn_sched_barrier(0);
+    // Wout fragments of one chunk, one (K block, tile) pair per slot of the out GEMM: ring entry s = 4 kb2 + tile
+    f16x8 roh[8], rol[8];
+    auto ld_wout = [&](int c, int s) {
+        const size_t i = ((size_t)(s & 3) * (DFF / 16) + 2 * c + (s >> 2)) * 64 + L.lane;
+        roh[s] = wout.h[i];
+        rol[s] = wout.l[i];
+    };
+    f32x16 vg[2], vgl[2];  // [v; g] of the chunk the element slices work on; rebuilt for the next chunk in slots 8..23
+    // LDS operands are requested one slot ahead of the MFMAs that use them
+    f16x8 xh, xl;  // K block of the parked xn planes
+    f16x8 uh, ul;  // K block of the split u operand
+    auto rd_x = [&](int kb) {
+        unsigned o = L.lane;  // opaque offset: read here, not hoisted into registers
+        asm volatile("" : "+v"(o));
+        xh = xsp[o + (2 * kb) * 64];
+        xl = xsp[o + (2 * kb + 1) * 64];
+    };
+    auto rd_u = [&](int kb2) {
+        unsigned o = L.lane;
+        asm volatile("" : "+v"(o));
+        uh = usp[o + (2 * kb2) * 64];
+        ul = usp[o + (2 * kb2 + 1) * 64];
+    };
+    // slot a (0..15) of the [v; g] GEMM of chunk c: K block a >> 1, tile a & 1 (0: v, 1: g)
+    auto vg_slot = [&](int c, int a) {
+        const int kb = a >> 1, t = a & 1;
+        WBlk2<2>& wb = rw[kb & 3];
+        if (kb == 0) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; r++) z[r] = 0.f;
+            vgl[t] = PET_MFMA_H(wb.l[t], xh, z);
+            vg[t] = PET_MFMA_H(wb.h[t], xh, z);
+        } else {
+            vgl[t] = PET_MFMA_H(wb.l[t], xh, vgl[t]);
+            vg[t] = PET_MFMA_H(wb.h[t], xh, vg[t]);
+        }
+        vgl[t] = PET_MFMA_H(wb.h[t], xl, vgl[t]);
+        if (t == 1) {
+            if (kb < 7) rd_x(kb + 1);
+            int nb = 8 * c + kb + 4;
+            nb = nb < 8 * NC ? nb : 8 * NC - 1;
+            ld_blk2<2>(wb, win, widx(nb), TS);
+        }
+    };
+    // slot s (0..7) of the out GEMM: K block s >> 2 of the u operand, output tile s & 3
+    auto out_slot = [&](int s) {
+        const int t = s & 3;
+        outl[t] = PET_MFMA_H(rol[s], uh, outl[t]);
+        out[t] = PET_MFMA_H(roh[s], uh, out[t]);
+        outl[t] = PET_MFMA_H(roh[s], ul, outl[t]);
+        if (s == 3) rd_u(1);
+    };
+    // MODE 1: first iteration (no out GEMM of a previous chunk), 2: last (no [v; g] GEMM of a next chunk)
+    auto iteration = [&](auto mode, int hc) {
+        constexpr int MODE = decltype(mode)::value;
+        float vv[16], gg[16];  // pre-activations of the chunk: element e = 4 q + c is hidden unit 8 q + 4 h + c
+        float4 bv, bg;
+#pragma unroll
+        for (int sl = 0; sl < 8; sl++) {
+            if (MODE != 1) out_slot(sl);
+#pragma unroll
+            for (int e = 2 * sl; e < 2 * sl + 2; e++) {
+                if ((e & 3) == 0) {
+                    bv = *reinterpret_cast<const float4*>(bias + 32 * hc + 8 * (e >> 2) + 4 * L.h);
+                    bg = *reinterpret_cast<const float4*>(bias + DFF + 32 * hc + 8 * (e >> 2) + 4 * L.h);
+                }
+                vv[e] = vg[0][e] + vgl[0][e] * (1.0f / 2048.0f) + f4c(bv, e & 3);
+                gg[e] = vg[1][e] + vgl[1][e] * (1.0f / 2048.0f) + f4c(bg, e & 3);
+                asm volatile("" : "+v"(vv[e]), "+v"(gg[e]));  // computed in this slot
+            }
+            if (sl == 7 && MODE != 2) rd_x(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        h16x2 sh[4], sl4[4];  // the fragment pair under construction
+        float u0 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 16; a++) {
+            if (MODE != 2) vg_slot(hc + 1, a);
+            if (a < 8) ld_wout(hc, a);  // this chunk's fragments: its out GEMM runs in slots 0..7 of the next iteration
+            const float u = vv[a] * sigm_(gg[a]);
+            if (a & 1) {
+                h16x2 hp, lp;
+                split_pair_pinned(u0, u, hp, lp);
+                sh[(a & 7) >> 1] = hp;
+                sl4[(a & 7) >> 1] = lp;
+            } else {
+                u0 = u;
+                asm volatile("" : "+v"(u0));
+            }
+            if ((a & 7) == 7) {
+                f16x8 fh, fl;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    fh[2 * w] = sh[w][0]; fh[2 * w + 1] = sh[w][1];
+                    fl[2 * w] = sl4[w][0]; fl[2 * w + 1] = sl4[w][1];
+                }
+                usp[(2 * (a >> 3)) * 64 + L.lane] = fh;
+                usp[(2 * (a >> 3) + 1) * 64 + L.lane] = fl;
+            }
+            if (VG && (a == 3 || a == 11)) {  // the saved pre-activations: whole 128-B lines through the staging tile
+                float4 t4[4];
+                const float* src = a == 3 ? vv : gg;
+#pragma unroll
+                for (int q = 0; q < 4; q++) t4[q] = make_float4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
+                store_tile32_lines(t4, otile, VG + (a == 3 ? 0 : DFF) + 32 * hc, row0, E, 2 * DFF, L);
+            }
+            if (a == 15) rd_u(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    rd_x(0);
+#pragma unroll
+    for (int a = 0; a < 16; a++) {  // [v; g] of chunk 0
+        vg_slot(0, a);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    iteration(std::integral_constant<int, 1>{}, 0);
+#pragma unroll 1
+    for (int hc = 1; hc + 1 < NC; hc++) iteration(std::integral_constant<int, 0>{}, hc);
+    iteration(std::integral_constant<int, 2>{}, NC - 1);
+#pragma unroll
+    for (int sl = 0; sl < 8; sl++) out_slot(sl);
+    fold_low<4>(out, outl);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const float4 t4[4] = {acc_q(out[t], 0), acc_q(out[t], 1), acc_q(out[t], 2), acc_q(out[t], 3)};
+        store_tile32_lines(t4, otile, X2 + 32 * t, row0, E, D, L);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // dX1 = dY + RMSNorm^T( Win^T [du sig(g) ; du v sig'(g)] ),  du = Wout^T dY
 // two weight streams, both ring-prefetched across the hidden chunks --
 //   A: Wout^T blocks for du (tile hc of the [DFF x D] operand, 8 K blocks per chunk, one tile);
@@ -601,6 +831,274 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_h(const float* __restrict__ dY
 #pragma unroll
         for (int kg = 0; kg < 16; kg++) {
             w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
+        }
+        store_rowfrag<16>(w, dX1, row, D, L.h);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------
+// k_emlp_bwd_p2: the edge-MLP adjoint as a software-pipelined kernel (default since round 3;
+// pet_config_set("emlp_bwd_pipe", 0) restores k_emlp_bwd_h). Two things k_emlp_bwd_h paid for at one wave per SIMD:
+//  * vmcnt retires IN ORDER (loads and stores alike on gfx950), so the first wait for a weight block that was requested
+//    AFTER an HBM load also waits for that HBM load: with weight rings that reach ~24 MFMAs (0.3 us) ahead, the HBM
+//    latency of the VG chunk was exposed once per hidden chunk and that of X1 / the dY re-read once more each per tile
+//    (timing ablations, 8 x 10k atoms, ms per step: 7.36 full, 6.92 without the two epilogue loads, 6.01 without the VG
+//    loads, 5.41 without both);
+//  * the three stages of a hidden chunk depend on each other and a wave issues in order, so the matrix pipe idled
+//    during the VALU stage and the VALU during both GEMMs.
+// ---------------------------------------------------------------------------------
+// dY arrives by LDS-DMA as whole 512-B rows and is parked, split, over its own fp32 tile (the residual is rebuilt from
+// the planes: h + 2^-11 l', 22 bits of the scaled row); the VG chunks arrive by LDS-DMA as whole 128-B lines into two
+// 8 KB buffers, two chunks ahead; the X1 tile follows into the same buffers in the last two iterations, so the
+// epilogue makes no memory round trip. The chunk loop: the three stages of a hidden chunk are du = Wout^T dY (24
+// MFMAs), the SwiGLU adjoint + operand split (VALU), dn += [dv | dg] Win (48 MFMAs). Iteration hc is 24 "slots" of one
+// f16x3 MFMA triple (96 matrix-pipe cycles) FOLLOWED in the instruction stream by a slice of VALU work that does not
+// depend on it (sched_barrier after every slot: the order below is the issue order):
+//   slots  0..15  dn(hc - 1), four steps of four output tiles      | slot t: element t of the SwiGLU adjoint of chunk hc
+//   slots  8..15                                                    |         + two values of the split of its first half
+//   slots 16..23  du(hc + 1), eight K blocks                        |         two values of the split of the second half
+// The split [dv | dg] operand lives in LDS (one 8 KB buffer per wave: K blocks 0 / 2 are rewritten in slots 11 / 15,
+// K blocks 1 / 3 in 19 / 23, each after the dn step that reads the old one), du's accumulators are read directly by the
+// element slices (the next du starts from a literal zero at slot 16). The VG request for chunk hc + 2 sits between
+// slots 15 and 16: behind this iteration's last Win^T request, so the first wait that covers it is the one for the
+// Win^T block of slot 8 of the next iteration.
+template <bool TRAIN, bool LN>
+__global__ __launch_bounds__(256) void k_emlp_bwd_p2(const float* __restrict__ dY, const float* __restrict__ X1,
+                                                      const float* __restrict__ VG, const float* __restrict__ gamma,
+                                                      W2 woutb, W2 winb, float* __restrict__ dX1, int64_t E,
+                                                      float* __restrict__ t_dvg) {
+    extern __shared__ __attribute__((aligned(16))) char ebp_lds[];  // [4 waves][dY / split planes 16 KB | VG chunks 2 x 8 KB, X1 at the end | [dv | dg] 8 KB]
+    TRR_PROLOGUE(E);
+    constexpr int NC = DFF / 32;
+    static_assert(NC % 2 == 0 && NC >= 4, "two VG buffers, first and last iteration peeled");
+    char* const my = ebp_lds + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 40960;
+    f16x8* const ysp = reinterpret_cast<f16x8*>(my);
+    const char* const vgt = my + 16384;  // two chunk buffers [v 4 KB | g 4 KB]; the X1 tile in the last two iterations
+    f16x8* const dsp = reinterpret_cast<f16x8*>(my + 32768);  // [4 K blocks x (h, l)][64]
+    {
+        const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)my);
+        dma_tile128(dY, row0, E, base, L);
+    }
+    // VG chunk hc -> buffer: whole 128-B lines (8 lanes per row and half, 8 rows per instruction); row r, 16-B piece p
+    // of a half lands at byte 128 r + 16 (p ^ ((r >> 1) & 7)): conflict-free for the per-row reads below
+    const unsigned vgbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)vgt);
+    const float* vgsrc[4];
+#pragma unroll
+    for (int i4 = 0; i4 < 4; i4++) {
+        const int r = 8 * i4 + (L.lane >> 3);
+        int64_t rr = row0 + r;
+        rr = rr < E ? rr : E - 1;
+        vgsrc[i4] = VG + rr * (2 * DFF) + 4 * ((L.lane & 7) ^ ((r >> 1) & 7));
+    }
+    auto dma_vg = [&](int hc, int buf) {
+        hc = hc < NC ? hc : NC - 1;  // past the end: the last chunk again (no branch)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; i4++) {
+            glds16_trr(vgsrc[i4] + 32 * hc, vgbase + buf * 8192 + i4 * 1024);
+            glds16_trr(vgsrc[i4] + DFF + 32 * hc, vgbase + buf * 8192 + 4096 + i4 * 1024);
+        }
+    };
+    // rows 16 half .. of the X1 tile into chunk buffer `half` (the two buffers together are a tile128 layout)
+    auto dma_x1_half = [&](int half) {
+#pragma unroll
+        for (int j8 = 0; j8 < 8; j8++) {
+            const int r = 16 * half + 2 * j8 + (L.lane >> 5);
+            int64_t rr = row0 + r;
+            rr = rr < E ? rr : E - 1;
+            glds16_trr(X1 + rr * 128 + 4 * ((L.lane & 31) ^ (r & 15)), vgbase + half * 8192 + j8 * 1024);
+        }
+    };
+    dma_vg(0, 0);
+    dma_vg(1, 1);
+    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
+    // Win^T stream position b = 4 hc + s -> K block (s = 0: dv first half, 1: dg first half, 2: dv second, 3: dg second)
+    auto bkb = [&](int b) { const int hc = b >> 2, st = b & 3; return (st & 1 ? 16 : 0) + 2 * hc + (st >> 1); };
+    auto bidx = [&](int b) { return (size_t)bkb(b) * 64 + L.lane; };
+    constexpr int RA = 4;  // Wout^T ring: blocks kb .. kb + 3 (eight blocks do not fit the register file next to the rest)
+    WBlk2<1> ra[RA];
+    WBlk2<4> rb[2];
+#pragma unroll
+    for (int b = 0; b < RA; b++) ld_blk2<1>(ra[b], woutb, aidx(b), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float inv;
+    {
+        float4 dy[16];
+        tile128_to_frag(dy, my, L);
+        float sc;
+        inv = row_scale_pow2<16>(dy, sc);
+        Split2<8> t;
+        split_frag2<8>(dy, t);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { ysp[(2 * k) * 64 + L.lane] = t.h[k]; ysp[(2 * k + 1) * 64 + L.lane] = t.l[k]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the Win^T ring is requested only now: the split above needs the registers
+#pragma unroll
+    for (int b = 0; b < 2; b++) ld_blk2<4>(rb[b], winb, bidx(b), 32 * 64);
+    f32x16 dn[4], dnl[4];
+    acc_zero<4>(dn);
+    acc_zero<4>(dnl);
+    f32x16 du, dul;  // du of the chunk the element slices work on; rebuilt for the next chunk in slots 16..23
+    // LDS operands are requested one slot ahead of the MFMAs / elements that use them (the order inside a slot is
+    // fixed, so a read issued in its own slot would expose the LDS latency 24 times per iteration)
+    f16x8 yh, yl;   // K block of the parked dY planes
+    f16x8 dh, dl;   // K block of the split [dv | dg] operand
+    float4 vq, gq;  // saved pre-activations of four elements
+    auto rd_y = [&](int kb) {
+        unsigned yo = L.lane;  // opaque offset: read here, not hoisted into registers
+        asm volatile("" : "+v"(yo));
+        yh = ysp[yo + (2 * kb) * 64];
+        yl = ysp[yo + (2 * kb + 1) * 64];
+    };
+    auto rd_d = [&](int st) {  // step st of dn takes K block (0, 2, 1, 3)[st]
+        const int jj = ((st & 1) << 1) | (st >> 1);
+        unsigned o = L.lane;
+        asm volatile("" : "+v"(o));
+        dh = dsp[o + (2 * jj) * 64];
+        dl = dsp[o + (2 * jj + 1) * 64];
+    };
+    auto rd_vg = [&](int buf, int q) {
+        unsigned o = 128 * L.r + 16 * ((2 * q + L.h) ^ ((L.r >> 1) & 7));
+        asm volatile("" : "+v"(o));
+        const char* pv = vgt + buf * 8192 + o;
+        vq = *reinterpret_cast<const float4*>(pv);
+        gq = *reinterpret_cast<const float4*>(pv + 4096);
+    };
+    // one K block of du(c): block 8 c + kb of the Wout^T stream, ring slot kb % RA, refilled RA blocks ahead
+    auto du_slot = [&](int c, int kb) {
+        WBlk2<1>& wb = ra[kb % RA];
+        if (kb == 0) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; r++) z[r] = 0.f;
+            dul = PET_MFMA_H(wb.l[0], yh, z);
+            du = PET_MFMA_H(wb.h[0], yh, z);
+        } else {
+            dul = PET_MFMA_H(wb.l[0], yh, dul);
+            du = PET_MFMA_H(wb.h[0], yh, du);
+        }
+        dul = PET_MFMA_H(wb.h[0], yl, dul);
+        if (kb < 7) rd_y(kb + 1);
+        int nb = 8 * c + kb + RA;
+        nb = nb < 8 * NC ? nb : 8 * NC - 1;  // past the end: the last block again
+        ld_blk2<1>(wb, woutb, aidx(nb), 0);
+    };
+    // output tile t of step st of dn(c)
+    auto dn_slot = [&](int c, int st, int t) {
+        WBlk2<4>& wb = rb[st & 1];
+        dnl[t] = PET_MFMA_H(wb.l[t], dh, dnl[t]);
+        dn[t] = PET_MFMA_H(wb.h[t], dh, dn[t]);
+        dnl[t] = PET_MFMA_H(wb.h[t], dl, dnl[t]);
+        if (t == 3) {
+            if (st < 3) rd_d(st + 1);
+            int nb = 4 * c + st + 2;
+            nb = nb < 4 * NC ? nb : 4 * NC - 1;
+            ld_blk2<4>(wb, winb, bidx(nb), 32 * 64);
+        }
+    };
+    // MODE 1: first iteration (no dn of a previous chunk), 2: last (no du of a next chunk, no further VG request).
+    // On entry: (vq, gq) = elements 0..3 of this chunk, (dh, dl) = operand of dn step 0.
+    auto iteration = [&](auto mode, int hc, int buf) {
+        constexpr int MODE = decltype(mode)::value;
+        float dv[16], dg[16];  // element e = 4 q + c: hidden unit 8 q + 4 h + c of the chunk
+        h16x2 sh[4], sl[4];    // the fragment pair under construction
+        // values n, n + 1 (of 0..15) of half hf: n < 8: dv of elements 8 hf + n (K block hf), else dg (K block 2 + hf)
+        auto split_pair = [&](int hf, int n) {
+            const float x0 = n < 8 ? dv[8 * hf + n] : dg[8 * hf + n - 8];
+            const float x1 = n < 8 ? dv[8 * hf + n + 1] : dg[8 * hf + n - 7];
+            h16x2 hp, lp;
+            split_pair_pinned(x0, x1, hp, lp);
+            sh[(n & 7) >> 1] = hp;
+            sl[(n & 7) >> 1] = lp;
+            if ((n & 7) == 6) {
+                f16x8 fh, fl;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    fh[2 * u] = sh[u][0]; fh[2 * u + 1] = sh[u][1];
+                    fl[2 * u] = sl[u][0]; fl[2 * u + 1] = sl[u][1];
+                }
+                const int kbk = n < 8 ? hf : 2 + hf;
+                dsp[(2 * kbk) * 64 + L.lane] = fh;
+                dsp[(2 * kbk + 1) * 64 + L.lane] = fl;
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            if (MODE != 1) dn_slot(hc - 1, t >> 2, t & 3);
+            if (t == 15 && MODE != 2) rd_y(0);
+            {   // element t
+                const int q = t >> 2, c = t & 3;
+                const float d = du[t] + dul[t] * (1.0f / 2048.0f);
+                const float sg = sigm_(f4c(gq, c));
+                dv[t] = d * sg;
+                dg[t] = d * f4c(vq, c) * sg * (1.f - sg);
+                asm volatile("" : "+v"(dv[t]), "+v"(dg[t]));  // computed in this slot
+                if (c == 3 && q < 3) rd_vg(buf, q + 1);
+            }
+            if (t >= 8) split_pair(0, 2 * (t - 8));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (TRAIN && valid) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) =
+                    make_float4(dv[4 * q] * inv, dv[4 * q + 1] * inv, dv[4 * q + 2] * inv, dv[4 * q + 3] * inv);
+                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) =
+                    make_float4(dg[4 * q] * inv, dg[4 * q + 1] * inv, dg[4 * q + 2] * inv, dg[4 * q + 3] * inv);
+            }
+        }
+        // this buffer's next chunk; in the last two iterations the halves of the X1 tile for the epilogue instead
+        if (MODE == 2 || hc + 2 == NC) dma_x1_half(buf);  // (wave-uniform branch between two scheduling regions)
+        else dma_vg(hc + 2, buf);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            if (MODE != 2) du_slot(hc + 1, t);
+            if (t == 7) {
+                rd_d(0);
+                if (MODE != 2) rd_vg(buf ^ 1, 0);
+            }
+            split_pair(1, 2 * t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    rd_y(0);
+    rd_vg(0, 0);
+#pragma unroll
+    for (int kb = 0; kb < 8; kb++) {  // du(0)
+        du_slot(0, kb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    iteration(std::integral_constant<int, 1>{}, 0, 0);
+#pragma unroll 1
+    for (int hc = 1; hc + 1 < NC; hc += 2) {
+        iteration(std::integral_constant<int, 0>{}, hc, 1);
+        iteration(std::integral_constant<int, 0>{}, hc + 1, 0);
+    }
+    iteration(std::integral_constant<int, 2>{}, NC - 1, 1);
+#pragma unroll
+    for (int t = 0; t < 16; t++) dn_slot(NC - 1, t >> 2, t & 3);
+    fold_low<4>(dn, dnl);
+    acc_scale<4>(dn, inv);
+    float4 w[16], x[16];
+    acc_to_frag<4>(dn, w);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the second half of the X1 tile
+    tile128_to_frag(x, vgt, L);
+#pragma unroll
+    for (int kg = 0; kg < 16; kg++) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
+        w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
+    }
+    norm_bwd_frag<16, LN>(w, x);
+    if (valid) {
+        const float f = inv * (1.0f / 2048.0f);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {  // the residual: dY = inv (h + 2^-11 l')
+            const f16x8 yh = ysp[(2 * kb) * 64 + L.lane], yl = ysp[(2 * kb + 1) * 64 + L.lane];
+            w[2 * kb].x += (float)yh[0] * inv + (float)yl[0] * f; w[2 * kb].y += (float)yh[1] * inv + (float)yl[1] * f;
+            w[2 * kb].z += (float)yh[2] * inv + (float)yl[2] * f; w[2 * kb].w += (float)yh[3] * inv + (float)yl[3] * f;
+            w[2 * kb + 1].x += (float)yh[4] * inv + (float)yl[4] * f; w[2 * kb + 1].y += (float)yh[5] * inv + (float)yl[5] * f;
+            w[2 * kb + 1].z += (float)yh[6] * inv + (float)yl[6] * f; w[2 * kb + 1].w += (float)yh[7] * inv + (float)yl[7] * f;
         }
         store_rowfrag<16>(w, dX1, row, D, L.h);
     }
@@ -924,6 +1422,10 @@ bool use_tile_f16x3() { return g_tile_f16x3 != 0; }
 // pet_config_set("trr_compress", bits): 1 compress (+adjoint), 2 edge head (+adjoint); 0 = the LDS-tile kernels
 static int g_trr_tilek = 3;
 void set_trr_compress(int v) { g_trr_tilek = v; }
+static int g_emlp_pipe = 1;      // k_emlp_p2 (software-pipelined); 0 = the persistent k_emlp_h
+void set_emlp_pipe(int v) { g_emlp_pipe = v ? 1 : 0; }
+static int g_emlp_bwd_pipe = 1;  // k_emlp_bwd_p2 (software-pipelined, LDS-staged operands); 0 = k_emlp_bwd_h
+void set_emlp_bwd_pipe(int v) { g_emlp_bwd_pipe = v ? 1 : 0; }
 static int g_emlp_recompute = 0;
 void set_emlp_recompute(int v) { g_emlp_recompute = v ? 1 : 0; }
 // inference only: the edge-MLP adjoint rebuilds [v; g] instead of reading them back (k_emlp_bwd_r)
@@ -983,6 +1485,17 @@ static void launch_emlp(int grid, size_t lds, hipStream_t st, const float* X1, c
 void trr_emlp(const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout, float* VG,
               float* X2, int64_t E, hipStream_t st) {
     if (E <= 0) return;
+    if (g_emlp_pipe) {
+        const size_t lds = (size_t)4 * EP2_WAVE_LDS;
+        if (beta) {
+            allow_big_lds(k_emlp_p2<true>, lds);
+            k_emlp_p2<true><<<grid_rows(E), 256, lds, st>>>(X1, gamma, beta, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
+        } else {
+            allow_big_lds(k_emlp_p2<false>, lds);
+            k_emlp_p2<false><<<grid_rows(E), 256, lds, st>>>(X1, gamma, beta, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
+        }
+        return;
+    }
     const size_t rows_lds = (size_t)4 * 2 * 16 * 64 * sizeof(float4);  // 128 KB: two row buffers per wave
     const int grid = std::min(grid_rows(E), num_cus());
     if (g_line_stores & 2) {
@@ -1003,6 +1516,15 @@ static void launch_emlp_bwd(const float* dY, const float* X1, const float* VG, c
         allow_big_lds(k_emlp_bwd_r<LN>, lds);
         k_emlp_bwd_r<LN><<<grid, 256, lds, st>>>(dY, X1, gamma, beta, w2_fwd(win), win.b, w2_bwd(wout), w2_bwd(win), dX1,
                                                  E);
+    } else if (g_emlp_bwd_pipe) {
+        const size_t lds = (size_t)4 * 40960;  // per wave: dY tile / split planes 16 KB, VG chunks / X1 tile 16 KB, [dv | dg] 8 KB (all 160 KB of the CU)
+        if (t_dvg) {
+            allow_big_lds(k_emlp_bwd_p2<true, LN>, lds);
+            k_emlp_bwd_p2<true, LN><<<grid, 256, lds, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, t_dvg);
+        } else {
+            allow_big_lds(k_emlp_bwd_p2<false, LN>, lds);
+            k_emlp_bwd_p2<false, LN><<<grid, 256, lds, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, nullptr);
+        }
     } else if (t_dvg) {
         k_emlp_bwd_h<true, LN><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, t_dvg);
     } else {
