@@ -67,6 +67,24 @@ int main(int argc, char** argv) {
         allow_big_lds(k_emlp_p2<false>, lds);
         k_emlp_p2<false><<<(int)((E + 127) / 128), 256, lds>>>(d_X1, d_g, nullptr, win, d_bi, wout, d_bo, getenv("NOVG") ? nullptr : d_vg1, d_o1, E);
     }
+    if (getenv("TIME")) {   // launch times: old kernel, new kernel, new kernel without the [v; g] stores
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        auto timeit = [&](const char* what, auto fn) {
+            for (int i = 0; i < 3; i++) fn();
+            (void)hipEventRecord(e0);
+            for (int i = 0; i < 10; i++) fn();
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+            printf("%s: %.3f ms per launch\n", what, ms / 10);
+        };
+        const size_t lds0 = (size_t)4 * 2 * 16 * 64 * sizeof(float4) + (size_t)4 * 32 * TILE32_LD * sizeof(float);
+        const size_t lds1 = (size_t)4 * EP2_WAVE_LDS;
+        const int g1 = (int)((E + 127) / 128), g0 = std::min(g1, 256);
+        timeit("k_emlp_h", [&] { k_emlp_h<true, false><<<g0, 256, lds0>>>(d_X1, d_g, nullptr, win, d_bi, wout, d_bo, d_vg0, d_o0, E); });
+        timeit("k_emlp_p2", [&] { k_emlp_p2<false><<<g1, 256, lds1>>>(d_X1, d_g, nullptr, win, d_bi, wout, d_bo, d_vg1, d_o1, E); });
+        timeit("k_emlp_h, no VG", [&] { k_emlp_h<true, false><<<g0, 256, lds0>>>(d_X1, d_g, nullptr, win, d_bi, wout, d_bo, nullptr, d_o0, E); });
+        timeit("k_emlp_p2, no VG", [&] { k_emlp_p2<false><<<g1, 256, lds1>>>(d_X1, d_g, nullptr, win, d_bi, wout, d_bo, nullptr, d_o1, E); });
+    }
     hipError_t err = hipDeviceSynchronize();
     if (err != hipSuccess) { printf("error %s\n", hipGetErrorString(err)); return 1; }
     std::vector<float> o0(E * D), o1(E * D), v0(E * 2 * DFF), v1(E * 2 * DFF);
