@@ -19,48 +19,6 @@ namespace pet {
     const bool valid = row0 + L.r < (NROWS);                  \
     const int64_t row = valid ? row0 + L.r : (NROWS) - 1
 
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
-// f16x3 split of two values into packed (high, pre-scaled low) pairs, computed where it stands in the instruction
-// stream (the pipelined kernels place it in a particular slot). The low piece is derived from the PINNED high pair:
-// pinning the finished pair alone let the compiler convert x -> fp16 twice, once for the pair (v_cvt_pk_f16_f32) and once
-// for the remainder (v_cvt_f16_f32), and the two instructions do not round every input alike (a handful of values in
-// 3e5 came out one fp16 ulp apart: rows off by 1e-4; tools/ubench/emlp_fwd_ab.hip).
-__device__ __forceinline__ void split_pair_pinned(float x0, float x1, h16x2& hp, h16x2& lp) {
-    hp[0] = (_Float16)x0; hp[1] = (_Float16)x1;
-    asm volatile("" : "+v"(hp));
-    lp[0] = (_Float16)((x0 - (float)hp[0]) * 2048.0f);
-    lp[1] = (_Float16)((x1 - (float)hp[1]) * 2048.0f);
-    asm volatile("" : "+v"(lp));
-}
-// LDS-DMA: 16 B per lane from global memory straight into LDS at lds_dst + 16 lane (no registers; counted by vmcnt,
-// invisible to the compiler's own wait bookkeeping)
-__device__ __forceinline__ void glds16_trr(const float* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// whole-row LDS-DMA of a [32 x 128] fp32 tile: instruction j brings rows 2j, 2j + 1; row r, 16-B piece p lands at
-// byte 512 r + 16 (p ^ (r & 15)) of the tile
-__device__ __forceinline__ void dma_tile128(const float* __restrict__ X, int64_t row0, int64_t n_rows, unsigned lds_base,
-                                            const RowLane& L) {
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const int r = 2 * j + (L.lane >> 5);
-        int64_t rr = row0 + r;
-        rr = rr < n_rows ? rr : n_rows - 1;
-        const int p = (L.lane & 31) ^ (r & 15);
-        glds16_trr(X + rr * 128 + 4 * p, lds_base + j * 1024);
-    }
-}
-// row fragment (trr.h) out of such a tile
-__device__ __forceinline__ void tile128_to_frag(float4 (&x)[16], const char* tile, const RowLane& L) {
-    const char* rowp = tile + 512 * L.r;
-    const int sw = L.r & 15;
-#pragma unroll
-    for (int kg = 0; kg < 16; kg++) x[kg] = *reinterpret_cast<const float4*>(rowp + 16 * ((2 * kg + L.h) ^ sw));
-}
-
 // ---------------------------------------------------------------------------------
 // f16x3 versions (trr.h) of the 128-wide row GEMM and the stages built on it. `oscale` multiplies the finished
 // accumulators (the inverse of a row_scale_pow2 applied to an adjoint input; 1 for forward activations).
