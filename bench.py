@@ -52,7 +52,7 @@ def synthetic_params(hypers):
 STAGE_KERNELS = {"attn_bwd": ("k_attn_bwd_a", "k_attn_bwd_l"), "attn_fwd": ("k_attn_fwd_p",),
                  "emlp": ("k_emlp_p2", "k_emlp_h"), "emlp_bwd": ("k_emlp_bwd_p2", "k_emlp_bwd_h"),
                  "qkv": ("k_qkv_h", "k_qkv_hl", "k_qkv_s"), "qkv_bwd": ("k_qkv_bwd_h",),
-                 "comb": ("k_comb_p2", "k_comb_h", "k_comb"), "comb_bwd": ("k_comb_bwd_h", "k_comb_bwd")}
+                 "comb": ("k_comb_p2", "k_comb_h", "k_comb"), "comb_bwd": ("k_comb_bwd_p2", "k_comb_bwd_h", "k_comb_bwd")}
 
 
 SPLIT_MFMA_STAGES = {"emlp", "emlp_bwd", "qkv", "qkv_bwd", "oproj", "oproj_bwd", "comb", "comb_bwd", "compress",

@@ -404,10 +404,10 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *   "so_trr"       1 = generic training GEMMs with K = 128 or n_out = 128 as TRR kernels (default); 0 = LDS-tile k_gemm_h
  *   "emlp_recompute" 1 = the inference adjoint of the edge MLP rebuilds the SwiGLU pre-activations instead of reading
  *                 them back (less workspace traffic, slower adjoint); default 0
- *   "emlp_pipe", "emlp_bwd_pipe", "comb_pipe" 1 = the edge MLP, its adjoint and the combination stage as software-
- *                 pipelined kernels (k_emlp_p2 / k_emlp_bwd_p2 / k_comb_p2: one MFMA triple + one slice of VALU work per
- *                 slot, operands staged in LDS by LDS-DMA; default); 0 = k_emlp_h (persistent) / k_emlp_bwd_h / k_comb_h,
- *                 which walk the stages of a hidden chunk in turn
+ *   "emlp_pipe", "emlp_bwd_pipe", "comb_pipe", "comb_bwd_pipe" 1 = the edge MLP, the combination stage and their
+ *                 adjoints as software-pipelined kernels (k_emlp_p2 / k_emlp_bwd_p2 / k_comb_p2 / k_comb_bwd_p2: one MFMA
+ *                 triple + one slice of VALU work per slot, operands staged in LDS by LDS-DMA; default); 0 = k_emlp_h
+ *                 (persistent) / k_emlp_bwd_h / k_comb_h / k_comb_bwd_h, which walk the stages of a hidden chunk in turn
  *   "trr_compress" bit mask of f16x3 TRR kernels replacing LDS-tile ones: 1 compress (+adjoint), 2 edge head (+adjoint);
  *                  default 3; 0 = LDS-tile kernels
  *   "line_stores" bit mask: 1 = QKV projection, 2 = edge MLP write whole 128-B lines through a wave-private LDS tile

@@ -923,6 +923,7 @@ int pet_config_set(const char* key, int value) {
     else if (k == "emlp_bwd_pipe") set_emlp_bwd_pipe(value);
     else if (k == "emlp_pipe") set_emlp_pipe(value);
     else if (k == "comb_pipe") set_comb_pipe(value);
+    else if (k == "comb_bwd_pipe") set_comb_bwd_pipe(value);
     else if (k == "tile_f16x3") set_tile_f16x3(value);
     else if (k == "trr_compress") set_trr_compress(value);
     else if (k == "line_stores") set_line_stores(value);

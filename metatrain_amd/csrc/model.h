@@ -248,6 +248,7 @@ void set_emlp_recompute(int v);
 void set_emlp_bwd_pipe(int v);
 void set_emlp_pipe(int v);
 void set_comb_pipe(int v);
+void set_comb_bwd_pipe(int v);
 bool use_tile_f16x3();
 void set_tile_f16x3(int v);
 void set_tile_mask(int v);

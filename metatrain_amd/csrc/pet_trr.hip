@@ -818,9 +818,9 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_h(const float* __restrict__ dY
 //   slots 16..23  du(hc + 1), eight K blocks                        |         two values of the split of the second half
 // The split [dv | dg] operand lives in LDS (one 8 KB buffer per wave: K blocks 0 / 2 are rewritten in slots 11 / 15,
 // K blocks 1 / 3 in 19 / 23, each after the dn step that reads the old one), du's accumulators are read directly by the
-// element slices (the next du starts from a literal zero at slot 16). The VG request for chunk hc + 2 sits between
-// slots 15 and 16: behind this iteration's last Win^T request, so the first wait that covers it is the one for the
-// Win^T block of slot 8 of the next iteration.
+// element slices (the next du starts from a literal zero at slot 16). The VG request for chunk hc + 2 sits behind slot 19:
+// behind this iteration's last Win^T request and behind the Wout^T requests that are waited for in this iteration, so
+// the first wait that covers it is the one for the Win^T block of slot 8 of the next iteration.
 template <bool TRAIN, bool LN>
 __global__ __launch_bounds__(256) void k_emlp_bwd_p2(const float* __restrict__ dY, const float* __restrict__ X1,
                                                       const float* __restrict__ VG, const float* __restrict__ gamma,
@@ -1005,13 +1005,18 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_p2(const float* __restrict__ d
                     make_float4(dg[4 * q] * inv, dg[4 * q + 1] * inv, dg[4 * q + 2] * inv, dg[4 * q + 3] * inv);
             }
         }
-        // this buffer's next chunk; in the last two iterations the halves of the X1 tile for the epilogue instead
-        if (MODE == 2 || hc + 2 == NC) dma_x1_half(buf);  // (wave-uniform branch between two scheduling regions)
-        else dma_vg(hc + 2, buf);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 8; t++) {
             if (MODE != 2) du_slot(hc + 1, t);
+            if (t == 3) {
+                // this buffer's next chunk; in the last two iterations the halves of the X1 tile for the epilogue instead.
+                // Requested BEHIND the Wout^T requests that are waited for within this iteration (K blocks 4..7, made in
+                // slots 16..19): the first wait that covers it is the one for the Win^T block of slot 8 of the next
+                // iteration, twelve slots away (right after slot 15 it was the Wout^T wait of slot 20)
+                if (MODE == 2 || hc + 2 == NC) dma_x1_half(buf);  // (wave-uniform branch)
+                else dma_vg(hc + 2, buf);
+            }
             if (t == 7) {
                 rd_d(0);
                 if (MODE != 2) rd_vg(buf ^ 1, 0);

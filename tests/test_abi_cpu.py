@@ -122,5 +122,5 @@ def test_config_switches_of_removed_kernel_generations_are_rejected(lib):
         assert lib.pet_config_set(key, 0) == -3, key
     for key, default in ((b"trr", 1), (b"attn_lds", 3), (b"tile_f16x3", 1), (b"trr_compress", 3), (b"line_stores", 3),
                          (b"node_planes", 1), (b"so_trr", 1), (b"so_f16x3", 1), (b"wgrad_bf16", 1), (b"emlp_recompute", 0),
-                         (b"side_stream", 1), (b"emlp_pipe", 1), (b"emlp_bwd_pipe", 1), (b"comb_pipe", 1)):
+                         (b"side_stream", 1), (b"emlp_pipe", 1), (b"emlp_bwd_pipe", 1), (b"comb_pipe", 1), (b"comb_bwd_pipe", 1)):
         assert lib.pet_config_set(key, default) == 0, key

@@ -570,13 +570,13 @@ def test_unknown_species_is_an_error_not_an_out_of_bounds_read(rt, model, dev):
 
 
 @pytest.mark.parametrize("switch", ["trr", "attn_lds=1", "side_stream", "tile_f16x3", "emlp_recompute=1", "trr_compress", "line_stores", "node_planes",
-                                    "emlp_pipe", "emlp_bwd_pipe", "comb_pipe"])
+                                    "emlp_pipe", "emlp_bwd_pipe", "comb_pipe", "comb_bwd_pipe"])
 def test_alternative_kernel_paths_agree(rt, model, dev, golden_dir, switch):
     """The library keeps ONE fallback generation of its GEMM stages selectable (pet_config_set): the LDS-tile kernels
     (trr=0, also the path of the variants; on fp32 MFMA with tile_f16x3=0), plus the per-atom staged attention adjoint (attn_lds=1;
     the default 3 is the persistent LDS-DMA adjoint), a single stream (side_stream=0), the recomputing edge-MLP adjoint,
     the A/B switches of the round-2 kernels and the edge-MLP kernels without the software pipeline of round 3
-    (emlp_pipe = 0: the persistent k_emlp_h, emlp_bwd_pipe = 0: k_emlp_bwd_h, comb_pipe = 0: k_comb_h). Each must meet the same parity bar."""
+    (emlp_pipe = 0: the persistent k_emlp_h, emlp_bwd_pipe = 0: k_emlp_bwd_h, comb_pipe = 0: k_comb_h, comb_bwd_pipe = 0: k_comb_bwd_h). Each must meet the same parity bar."""
     g = _load(golden_dir, "pet_default_box64.npz")
     graph = _graph_from_golden(rt, model, g, dev)
     key, _, val = switch.partition("=")

@@ -46,6 +46,19 @@ int main(int argc, char** argv) {
     const size_t lds = (size_t)4 * 40960;
     allow_big_lds(k_emlp_bwd_p2<false, false>, lds);
     k_emlp_bwd_p2<false, false><<<grid, 256, lds>>>(d_dY, d_X1, d_VG, d_g, woutb, winb, d_o1, E, nullptr);
+    if (getenv("TIME")) {
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        auto timeit = [&](const char* what, auto fn) {
+            for (int i = 0; i < 3; i++) fn();
+            (void)hipEventRecord(e0);
+            for (int i = 0; i < 10; i++) fn();
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+            printf("%s: %.3f ms per launch\n", what, ms / 10);
+        };
+        timeit("k_emlp_bwd_h", [&] { k_emlp_bwd_h<false, false><<<grid, 256>>>(d_dY, d_X1, d_VG, d_g, woutb, winb, d_o0, E, nullptr); });
+        timeit("k_emlp_bwd_p2", [&] { k_emlp_bwd_p2<false, false><<<grid, 256, lds>>>(d_dY, d_X1, d_VG, d_g, woutb, winb, d_o1, E, nullptr); });
+    }
     hipError_t err = hipDeviceSynchronize();
     if (err != hipSuccess) { printf("error %s\n", hipGetErrorString(err)); return 1; }
     std::vector<float> o0(E * D), o1(E * D);
