@@ -91,7 +91,7 @@ ProfScope::~ProfScope() {
 
 // two-way fp16 split of the same fragments (trr.h, f16x3 GEMMs): out[plane][(t * kbn + kb) * 64 + l][8]
 __global__ void k_pack2h(const float* __restrict__ W, int64_t s_n, int64_t s_k, int n_out, int k_in,
-                         _Float16* __restrict__ out) {
+                         _Float16* __restrict__ out, float lscale = 2048.0f) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int kbn = k_in / 16;
     int64_t total = (int64_t)(n_out / 32) * kbn * 64;
@@ -105,7 +105,7 @@ __global__ void k_pack2h(const float* __restrict__ W, int64_t s_n, int64_t s_k, 
         const float x = W[n * s_n + k * s_k];
         const _Float16 h = (_Float16)x;
         out[(0 * total + idx) * 8 + j] = h;
-        out[(1 * total + idx) * 8 + j] = (_Float16)((x - (float)h) * 2048.0f);
+        out[(1 * total + idx) * 8 + j] = (_Float16)((x - (float)h) * lscale);
     }
 }
 
@@ -174,6 +174,19 @@ static int pack_lin(Model& m, const std::string& name, Lin& L, const float* w, c
     return PET_OK;
 }
 
+// planes for the single-accumulator products of pet_ablk.hip: the low piece scaled by 64 instead of 2048
+static int pack_lin_s(Model& m, const std::string& name, Lin& L, hipStream_t st) {
+    if (m.generic()) return PET_OK;
+    const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
+    int rc;
+    if ((rc = named_alloc(m, name + ":fwd2s", &L.fwd2s, 2 * n8 * 16)) != PET_OK) return rc;
+    if ((rc = named_alloc(m, name + ":bwd2s", &L.bwd2s, 2 * n8 * 16)) != PET_OK) return rc;
+    k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(L.w, L.k_in, 1, L.n_out, L.k_in, (_Float16*)L.fwd2s, 64.0f);
+    k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(L.w, 1, L.k_in, L.k_in, L.n_out, (_Float16*)L.bwd2s, 64.0f);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
+}
+
 static int get(const Model& m, const std::string& key, int64_t numel, const float** out) {
     auto it = m.raw.find(key);
     PET_REQUIRE(it != m.raw.end(), PET_ERR_ARGUMENT, "missing parameter '" + key + "'");
@@ -232,6 +245,8 @@ int finalize(Model& m, hipStream_t st) {
             const std::string lp = pre + ".trans.layers." + std::to_string(a);
             if ((rc = get_lin(m, lp + ".attention.input_linear", 3 * D, D, A.qkv, st))) return rc;
             if ((rc = get_lin(m, lp + ".attention.output_linear", D, D, A.out, st))) return rc;
+            if ((rc = pack_lin_s(m, lp + ".attention.input_linear", A.qkv, st))) return rc;
+            if ((rc = pack_lin_s(m, lp + ".attention.output_linear", A.out, st))) return rc;
             if ((rc = get(m, lp + ".norm_attention.weight", D, &A.g_attn))) return rc;
             if ((rc = get(m, lp + ".norm_mlp.weight", D, &A.g_mlp))) return rc;
             if ((rc = get_lin(m, lp + ".mlp.w_in", 2 * DFF, D, A.mlp_in, st))) return rc;
@@ -919,6 +934,7 @@ int pet_config_set(const char* key, int value) {
     else if (k == "soap_fused") set_soap_fused(value);
     else if (k == "soap_sorted") set_soap_sorted(value);
     else if (k == "attn_lds") set_attn_lds(value);
+    else if (k == "attn_fused") set_attn_fused(value);
     else if (k == "emlp_recompute") set_emlp_recompute(value);
     else if (k == "emlp_bwd_pipe") set_emlp_bwd_pipe(value);
     else if (k == "emlp_pipe") set_emlp_pipe(value);

@@ -28,6 +28,8 @@ struct Lin {
     float4* bwd = nullptr;
     void* fwd2 = nullptr;  // f16x3 operands (trr.h): two fp16 planes, fragment order
     void* bwd2 = nullptr;
+    void* fwd2s = nullptr;  // the same planes with the low piece scaled by 64 (single-accumulator products, pet_ablk.hip)
+    void* bwd2s = nullptr;
     int n_out = 0, k_in = 0;
 };
 
@@ -289,6 +291,16 @@ bool trr_comb(bool first, const float* XF, const Graph& g, const GnnLayerW& G, c
               const float* edge_emb, float* CA, float* LNS, float* Mout, int64_t E, hipStream_t st);
 bool trr_comb_bwd(const float* dM, const float* XF, const Graph& g, const GnnLayerW& G, const float* LNS,
                   const float* CA, float* dcat, int64_t E, float* t_da, hipStream_t st);
+
+// pet_ablk.hip: the per-atom fused attention block (norm -> QKV -> attention -> output projection in one kernel, the
+// adjoint recomputing Q, K, V); false = not served (an atom of more than 64 tokens, planes missing, switched off)
+void set_attn_fused(int v);
+int attn_fused();
+bool ablk_fwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* X, float* X1, float* OC, float scale,
+              hipStream_t st);
+bool ablk_bwd_on(const Graph& g);
+bool ablk_bwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* X, const float* dX1, const float* dOC,
+              float* dXin, float* dbias, float scale, hipStream_t st);
 
 // pet_attn.hip: preload variants of the attention kernels (NT <= 4); return false if not handled
 bool attn_fwd_preload(int nt, const float* QKV, const Graph& g, float* AO, float scale, hipStream_t st);

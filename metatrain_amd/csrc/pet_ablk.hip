@@ -1,0 +1,854 @@
+// Per-atom fused attention block (round 4): one WAVE owns the tokens of one atom (centre token + its neighbours, at most
+// 32 NQ) and runs  norm -> QKV -> soft-max attention -> output projection (+ residual)  on them without ever writing
+// Q, K, V or the attention output to HBM; the adjoint recomputes Q, K, V from the saved layer input in the same way and
+// emits only the gradient of the layer input. Reference: pet/modules/transformer.py:86-152 (AttentionBlock.forward),
+// :203-234 (the PreLN layer around it), :565-589 (manual_attention).
+//
+// Everything is v_mfma_f32_32x32x16_f16 on split operands (trr.h) and the C/D layout of one product IS the operand
+// layout of the next, so the chain needs no LDS exchange and no cross-lane traffic except the soft-max row statistics:
+//
+//   token form   (lane = token,   regs = features)  Q^T, K^T   = W x^T        A = weight fragment, B = row planes
+//   feature form (lane = feature, regs = tokens)    V          = x W^T        A = row planes,      B = weight fragment
+//   S^T [key, query]   = K Q^T   A = K (token form, one head = 8 regs),  B = Q (token form)     -> lane = query
+//   soft-max over the keys = over the 16 regs of a lane and its partner lane (xor 32)
+//   O^T [feature, query] = V^T P^T   A = V (feature form, K blocks = 8 regs of tokens),  B = P^T (the S^T registers)
+//                        -> lane = query = token, regs = features: the row fragment of the attention output,
+//                           i.e. directly the B operand of the output projection X1^T = Wo AO^T.
+//
+// Products are "f16x3" with ONE accumulator: x = h + l / S with h = fp16(x), l = fp16((x - h) S), S = 64, and
+//   S (a b) = a_h (S b_h) + a_l b_h + a_h b_l      (three MFMAs per K block; the S b_h plane is one v_pk_mul_f16 away)
+// so an accumulator holds S times the product. S = 64 keeps S b_h inside fp16 for |b| < 1023 (the H plane always sits
+// on the operand of known magnitude: normalised rows, soft-max weights, rows scaled to [1, 2)) and l normal for
+// |x| > 4e-3 (below that the low piece keeps 1e-9 absolute accuracy). The weight planes with that scale are packed
+// next to the 2048-scaled ones of the other TRR kernels (abi.hip, Lin::fwd2s / bwd2s).
+#include "common.h"
+#include "model.h"
+#include "pet_ws.h"
+#include "trr.h"
+
+namespace pet {
+
+constexpr float ABS = 64.0f;
+constexpr float ABS_INV = 1.0f / 64.0f;
+constexpr float AB_LOG2E = 1.4426950408889634f;
+
+union H8 {
+    f16x8 v;
+    h16x2 p[4];
+};
+// (h, l) planes of eight values; the low piece is derived from the PINNED high pair (trr.h split_pair_pinned)
+__device__ __forceinline__ void ab_split8(const float (&x)[8], f16x8& h, f16x8& l) {
+    H8 a, b;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        h16x2 hp, lp;
+        hp[0] = (_Float16)x[2 * j]; hp[1] = (_Float16)x[2 * j + 1];
+        asm volatile("" : "+v"(hp));
+        lp[0] = (_Float16)((x[2 * j] - (float)hp[0]) * ABS);
+        lp[1] = (_Float16)((x[2 * j + 1] - (float)hp[1]) * ABS);
+        a.p[j] = hp; b.p[j] = lp;
+    }
+    h = a.v; l = b.v;
+}
+__device__ __forceinline__ f16x8 ab_times_s(const f16x8& h) {
+    f16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = h[j] * (_Float16)ABS;
+    return r;
+}
+// acc += S (a b):  a = (h, l),  b = (H = S h, h, l)
+#define AB_MFMA3(acc, ah, al, bH, bh, bl)      \
+    do {                                       \
+        acc = PET_MFMA_H((ah), (bH), (acc));   \
+        acc = PET_MFMA_H((al), (bh), (acc));   \
+        acc = PET_MFMA_H((ah), (bl), (acc));   \
+    } while (0)
+// the same with the H plane on the A side
+#define AB_MFMA3A(acc, aH, ah, al, bh, bl)     \
+    do {                                       \
+        acc = PET_MFMA_H((aH), (bh), (acc));   \
+        acc = PET_MFMA_H((al), (bh), (acc));   \
+        acc = PET_MFMA_H((ah), (bl), (acc));   \
+    } while (0)
+
+__device__ __forceinline__ f32x16 ab_zero() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; r++) z[r] = 0.f;
+    return z;
+}
+// the eight registers 8 kb .. 8 kb + 7 of a C tile (K block kb of the NEXT product) scaled by f
+__device__ __forceinline__ void ab_regs8(const f32x16& a, int kb, float f, float (&o)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = a[8 * kb + j] * f;
+}
+
+// Q, K, V weight fragments (both planes) of head pair hp, K block kb
+struct AbW6 {
+    f16x8 qh, ql, kh, kl, vh, vl;
+};
+__device__ __forceinline__ void ab_ldw6(AbW6& w, const W2& wqkv, int hp, int kb, int lane) {
+    const size_t i = (size_t)(hp * 8 + kb) * 64 + lane;
+    constexpr size_t KOFF = (size_t)4 * 8 * 64, VOFF = (size_t)8 * 8 * 64;
+    w.qh = wqkv.h[i]; w.ql = wqkv.l[i];
+    w.kh = wqkv.h[KOFF + i]; w.kl = wqkv.l[KOFF + i];
+    w.vh = wqkv.h[VOFF + i]; w.vl = wqkv.l[VOFF + i];
+}
+
+// token slot s of the atom: 0 = the centre token (row E + atom of the token stream), s >= 1 neighbour s - 1; slots past
+// the atom's last token repeat it (their results are never stored and, as keys, are masked)
+struct AbAtom {
+    int atom, start, T;
+    int64_t E;
+    __device__ __forceinline__ int64_t row(int s) const {
+        s = s < T ? s : T - 1;
+        return s == 0 ? E + atom : (int64_t)start + s - 1;
+    }
+};
+
+// whole-row LDS-DMA of the atom's token rows into the wave's tile(s): tile tq holds slots 32 tq .. 32 tq + 31 in the
+// layout of trr.h dma_tile128 (row r, 16-B piece p at byte 512 r + 16 (p ^ (r & 15)))
+template <int NQ>
+__device__ __forceinline__ void ab_dma_rows(const float* __restrict__ X, const AbAtom& a, unsigned lds_base,
+                                            const RowLane& L) {
+#pragma unroll
+    for (int tq = 0; tq < NQ; tq++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int r = 2 * j + (L.lane >> 5);
+            const int p = (L.lane & 31) ^ (r & 15);
+            glds16_trr(X + a.row(32 * tq + r) * D + 4 * p, lds_base + tq * 16384 + j * 1024);
+        }
+}
+
+// planes of a normalised row tile in the wave's LDS: [kb 0..7][plane h, l][lane] f16x8
+__device__ __forceinline__ void ab_park_planes(const float4 (&x)[16], char* tile, const RowLane& L) {
+#pragma unroll
+    for (int kb = 0; kb < 8; kb++) {
+        const float v[8] = {x[2 * kb].x, x[2 * kb].y, x[2 * kb].z, x[2 * kb].w,
+                            x[2 * kb + 1].x, x[2 * kb + 1].y, x[2 * kb + 1].z, x[2 * kb + 1].w};
+        f16x8 h, l;
+        ab_split8(v, h, l);
+        *reinterpret_cast<f16x8*>(tile + ((kb * 2 + 0) * 64 + L.lane) * 16) = h;
+        *reinterpret_cast<f16x8*>(tile + ((kb * 2 + 1) * 64 + L.lane) * 16) = l;
+    }
+}
+
+// key bias (log2 of the cutoff factor, transformer.py:109-110) of the keys this lane's S^T registers hold; -inf masks
+// the slots past the atom's last token
+template <int NQ>
+__device__ __forceinline__ void ab_key_bias(float (&bias)[NQ][16], const AbAtom& a, const float* __restrict__ fc, int h) {
+#pragma unroll
+    for (int tk = 0; tk < NQ; tk++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int key = 32 * tk + 8 * (i >> 2) + 4 * h + (i & 3);
+            float b = -INFINITY;
+            if (key == 0) b = 0.f;
+            else if (key < a.T) b = __builtin_amdgcn_logf(fmaxf(fc[a.start + key - 1], 1e-15f));
+            bias[tk][i] = b;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int NQ, bool LN>
+__global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void k_ablk_fwd(
+    const float* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta, W2 wqkv,
+    const float* __restrict__ bqkv, W2 wo, const float* __restrict__ bo, const int* __restrict__ rowptr,
+    const float* __restrict__ fc, const int* __restrict__ atoms, int n_list, int64_t E, float qscale,
+    float* __restrict__ X1, float* __restrict__ OC) {
+    extern __shared__ __attribute__((aligned(16))) char ab_smem[];
+    const RowLane L;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = blockIdx.x * 4 + wave;
+    if (li >= n_list) return;
+    AbAtom a;
+    a.atom = atoms[li];
+    a.start = rowptr[a.atom];
+    a.T = rowptr[a.atom + 1] - a.start + 1;
+    a.E = E;
+    char* tile = ab_smem + wave * (NQ * 16384);
+    const unsigned tile_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile);
+    ab_dma_rows<NQ>(X, a, tile_u, L);
+    float bias[NQ][16];
+    ab_key_bias<NQ>(bias, a, fc, L.h);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // rows -> normalised -> (h, l) planes, parked over the fp32 tile they came from
+#pragma unroll
+    for (int tq = 0; tq < NQ; tq++) {
+        float4 x[16];
+        tile128_to_frag(x, tile + tq * 16384, L);
+        norm_frag<16, LN>(x, gamma, beta, L.h);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        ab_park_planes(x, tile + tq * 16384, L);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+
+    float4 ao[NQ][16];  // attention output, row fragment
+    AbW6 wr[2];         // weight fragments of two K blocks in flight
+    ab_ldw6(wr[0], wqkv, 0, 0, L.lane);
+#pragma unroll
+    for (int hp = 0; hp < 4; hp++) {  // unrolled: ao[] is indexed with hp (a run-time index would send it to scratch)
+        // ---- Q^T, K^T (token form) and V (feature form) of the head pair: 32 features each
+        f32x16 q[NQ], k[NQ], v[NQ];
+        {
+            float4 bq[4], bk[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bq[j] = *reinterpret_cast<const float4*>(bqkv + 32 * hp + 8 * j + 4 * L.h);
+                bk[j] = *reinterpret_cast<const float4*>(bqkv + D + 32 * hp + 8 * j + 4 * L.h);
+            }
+            const float bv = bqkv[2 * D + 32 * hp + L.r] * ABS;
+#pragma unroll
+            for (int tq = 0; tq < NQ; tq++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    q[tq][4 * j] = bq[j].x * ABS; q[tq][4 * j + 1] = bq[j].y * ABS;
+                    q[tq][4 * j + 2] = bq[j].z * ABS; q[tq][4 * j + 3] = bq[j].w * ABS;
+                    k[tq][4 * j] = bk[j].x * ABS; k[tq][4 * j + 1] = bk[j].y * ABS;
+                    k[tq][4 * j + 2] = bk[j].z * ABS; k[tq][4 * j + 3] = bk[j].w * ABS;
+                    v[tq][4 * j] = bv; v[tq][4 * j + 1] = bv; v[tq][4 * j + 2] = bv; v[tq][4 * j + 3] = bv;
+                }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            // the next K block's fragments (the next head pair's first block behind the last one) are requested before
+            // this block's MFMAs; left to itself the compiler requests a block right in front of its own MFMAs
+            const int nx = 8 * hp + kb + 1;
+            if (nx < 32) ab_ldw6(wr[nx & 1], wqkv, nx >> 3, nx & 7, L.lane);
+            __builtin_amdgcn_sched_barrier(0);
+            const AbW6& w6 = wr[kb & 1];
+#pragma unroll
+            for (int tq = 0; tq < NQ; tq++) {
+                const char* tp = tile + tq * 16384;
+                const f16x8 xh = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 0) * 64 + L.lane) * 16);
+                const f16x8 xl = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 1) * 64 + L.lane) * 16);
+                const f16x8 xH = ab_times_s(xh);
+                AB_MFMA3(q[tq], w6.qh, w6.ql, xH, xh, xl);
+                AB_MFMA3(k[tq], w6.kh, w6.kl, xH, xh, xl);
+                AB_MFMA3A(v[tq], xH, xh, xl, w6.vh, w6.vl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- operand planes of the attention products
+        f16x8 qH[NQ][2], qh[NQ][2], ql[NQ][2], kh[NQ][2], kl[NQ][2], vh[NQ][2], vl[NQ][2];
+#pragma unroll
+        for (int tq = 0; tq < NQ; tq++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                float t8[8];
+                ab_regs8(q[tq], b, qscale * ABS_INV, t8);
+                ab_split8(t8, qh[tq][b], ql[tq][b]);
+                qH[tq][b] = ab_times_s(qh[tq][b]);
+                ab_regs8(k[tq], b, ABS_INV, t8);
+                ab_split8(t8, kh[tq][b], kl[tq][b]);
+                ab_regs8(v[tq], b, ABS_INV, t8);
+                ab_split8(t8, vh[tq][b], vl[tq][b]);
+            }
+        // ---- the two heads of the pair
+#pragma unroll
+        for (int hd = 0; hd < 2; hd++)
+#pragma unroll
+            for (int tq = 0; tq < NQ; tq++) {
+                f32x16 s[NQ];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int tk = 0; tk < NQ; tk++) {
+                    s[tk] = ab_zero();
+                    AB_MFMA3(s[tk], kh[tk][hd], kl[tk][hd], qH[tq][hd], qh[tq][hd], ql[tq][hd]);
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        s[tk][i] = fmaf(s[tk][i], ABS_INV, bias[tk][i]);
+                        mx = fmaxf(mx, s[tk][i]);
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sum = 0.f;
+#pragma unroll
+                for (int tk = 0; tk < NQ; tk++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const float p = __builtin_amdgcn_exp2f(s[tk][i] - mx);
+                        s[tk][i] = p;
+                        sum += p;
+                    }
+                sum += __shfl_xor(sum, 32);
+                f32x16 o = ab_zero();
+#pragma unroll
+                for (int tk = 0; tk < NQ; tk++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++) {
+                        float t8[8];
+                        ab_regs8(s[tk], b, 1.0f, t8);
+                        f16x8 ph, pl;
+                        ab_split8(t8, ph, pl);
+                        const f16x8 pH = ab_times_s(ph);
+                        AB_MFMA3(o, vh[tk][b], vl[tk][b], pH, ph, pl);
+                    }
+                const float inv = ABS_INV * __builtin_amdgcn_rcpf(sum);
+                ao[tq][4 * hp + 2 * hd] = make_float4(o[8 * hd] * inv, o[8 * hd + 1] * inv, o[8 * hd + 2] * inv,
+                                                      o[8 * hd + 3] * inv);
+                ao[tq][4 * hp + 2 * hd + 1] = make_float4(o[8 * hd + 4] * inv, o[8 * hd + 5] * inv, o[8 * hd + 6] * inv,
+                                                          o[8 * hd + 7] * inv);
+            }
+    }
+    // ---- output projection, bias, residual: X1 = X + Wo AO + bo (edge rows); OC = Wo AO + bo (the centre token)
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    float* stg = reinterpret_cast<float*>(tile);  // [32][TILE_LD] staging for whole-line stores (the planes are dead)
+#pragma unroll
+    for (int tq = 0; tq < NQ; tq++) {
+        if (32 * tq >= a.T) continue;
+        float sc;
+        const float inv = row_scale_pow2<16>(ao[tq], sc) * ABS_INV;
+        f16x8 ah[8], al[8];
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            const float v8[8] = {ao[tq][2 * kb].x, ao[tq][2 * kb].y, ao[tq][2 * kb].z, ao[tq][2 * kb].w,
+                                 ao[tq][2 * kb + 1].x, ao[tq][2 * kb + 1].y, ao[tq][2 * kb + 1].z, ao[tq][2 * kb + 1].w};
+            ab_split8(v8, ah[kb], al[kb]);
+        }
+        f16x8 woh[2][2], wol[2][2];  // [ring slot][tile]
+#pragma unroll
+        for (int t = 0; t < 2; t++) { woh[0][t] = wo.h[(size_t)t * 8 * 64 + L.lane]; wol[0][t] = wo.l[(size_t)t * 8 * 64 + L.lane]; }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {  // 64 output features at a time
+            f32x16 y[2] = {ab_zero(), ab_zero()};
+#pragma unroll
+            for (int kb = 0; kb < 8; kb++) {
+                const int nx = 8 * c + kb + 1;
+                if (nx < 16) {
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const size_t wi = ((size_t)(2 * (nx >> 3) + t) * 8 + (nx & 7)) * 64 + L.lane;
+                        woh[nx & 1][t] = wo.h[wi]; wol[nx & 1][t] = wo.l[wi];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const f16x8 aH = ab_times_s(ah[kb]);
+#pragma unroll
+                for (int t = 0; t < 2; t++) AB_MFMA3(y[t], woh[kb & 1][t], wol[kb & 1][t], aH, ah[kb], al[kb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float4 bb[8];
+            ld_bias<2>(bb, bo, 64 * c, L.h);
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float4 o4;
+                    o4.x = fmaf(y[t][4 * j], inv, bb[4 * t + j].x); o4.y = fmaf(y[t][4 * j + 1], inv, bb[4 * t + j].y);
+                    o4.z = fmaf(y[t][4 * j + 2], inv, bb[4 * t + j].z); o4.w = fmaf(y[t][4 * j + 3], inv, bb[4 * t + j].w);
+                    *reinterpret_cast<float4*>(stg + L.r * TILE_LD + 8 * (4 * t + j) + 4 * L.h) = o4;
+                }
+            __builtin_amdgcn_wave_barrier();
+            // whole lines out: 16 lanes per row, four rows per instruction; the residual comes in the same shape
+            const int rr = L.lane >> 4, cc = 4 * (L.lane & 15);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int r = 4 * j + rr, s = 32 * tq + r;
+                if (s < a.T) {
+                    float4 o4 = *reinterpret_cast<const float4*>(stg + r * TILE_LD + cc);
+                    if (s == 0) {
+                        *reinterpret_cast<float4*>(OC + (int64_t)a.atom * D + 64 * c + cc) = o4;
+                    } else {
+                        const int64_t row = (int64_t)a.start + s - 1;
+                        const float4 xr = *reinterpret_cast<const float4*>(X + row * D + 64 * c + cc);
+                        o4.x += xr.x; o4.y += xr.y; o4.z += xr.z; o4.w += xr.w;
+                        *reinterpret_cast<float4*>(X1 + row * D + 64 * c + cc) = o4;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint: (dX1 | dOC) -> dXin, key-bias gradient. Q, K, V are recomputed from the layer input X.
+//
+//   dAO  = dY Wo                                  token form; its feature form by TRANSPOSITION ON THE MATRIX CORE:
+//   a token-form tile (lane = token, regs = features) fed as the A operand against a 0/1 selection matrix comes out as
+//   C[token][feature] = lane = feature, regs = tokens; the (h, l) planes are fp16 numbers, so two MFMAs per plane move
+//   them exactly (ab_transpose). The same turns Q, K, P^T and dS^T around.
+//   S^T  = K Q^T, P^T = soft-max over the keys    (as in the forward)
+//   dP^T = V dAO^T          A = V (token form),  B = dAO (token form)
+//   dS^T = P^T (dP^T - delta),  delta = sum_keys P^T dP^T
+//   dQ^T = K^T dS^T         A = K (feature form),  B = dS^T (the C registers)      -> token form
+//   dK^T = Q^T dS           A = Q (feature form),  B = dS (transposed tile)        -> token form
+//   dV^T = dAO^T P          A = dAO (feature form), B = P (transposed tile)        -> token form
+//   dXn^T += Wqkv^T [dQ; dK; dV]^T of the head pair, then the norm adjoint and the residual.
+// The incoming rows are scaled by ONE power of two per atom (their largest entry in [1, 2)): the sums over queries mix
+// rows, so a per-row scale as in the row kernels would not factor out. Slots past the atom's last token get a zero
+// adjoint row, which removes them from every sum over queries.
+// ---------------------------------------------------------------------------------------------
+struct AbSel {
+    f16x8 i0, i1;  // selection matrices of the two K blocks of a 32-wide tile, B-operand form
+};
+__device__ __forceinline__ AbSel ab_selectors(const RowLane& L) {
+    AbSel s;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int f = 8 * (j >> 2) + 4 * L.h + (j & 3);
+        s.i0[j] = (f == L.r) ? (_Float16)1.0f : (_Float16)0.0f;
+        s.i1[j] = (16 + f == L.r) ? (_Float16)1.0f : (_Float16)0.0f;
+    }
+    return s;
+}
+// planes (h[b], l[b], b = K block of the 32-wide tile) of a tile -> planes of its transpose, exactly
+__device__ __forceinline__ void ab_transpose(const f16x8 (&h)[2], const f16x8 (&l)[2], const AbSel& sel,
+                                             f16x8 (&th)[2], f16x8 (&tl)[2]) {
+    f32x16 ch = ab_zero(), cl = ab_zero();
+    ch = PET_MFMA_H(h[0], sel.i0, ch); ch = PET_MFMA_H(h[1], sel.i1, ch);
+    cl = PET_MFMA_H(l[0], sel.i0, cl); cl = PET_MFMA_H(l[1], sel.i1, cl);
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            th[b][j] = (_Float16)ch[8 * b + j];
+            tl[b][j] = (_Float16)cl[8 * b + j];
+        }
+}
+// the same, also returning the sum over the registers of the transposed VALUES (h + l / S): column sums of the tile
+__device__ __forceinline__ float ab_transpose_sum(const f16x8 (&h)[2], const f16x8 (&l)[2], const AbSel& sel,
+                                                  f16x8 (&th)[2], f16x8 (&tl)[2]) {
+    f32x16 ch = ab_zero(), cl = ab_zero();
+    ch = PET_MFMA_H(h[0], sel.i0, ch); ch = PET_MFMA_H(h[1], sel.i1, ch);
+    cl = PET_MFMA_H(l[0], sel.i0, cl); cl = PET_MFMA_H(l[1], sel.i1, cl);
+    float sh = 0.f, sl = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            th[b][j] = (_Float16)ch[8 * b + j];
+            tl[b][j] = (_Float16)cl[8 * b + j];
+            sh += ch[8 * b + j];
+            sl += cl[8 * b + j];
+        }
+    return fmaf(sl, ABS_INV, sh);
+}
+// (h, l) planes of the two K blocks of a C tile scaled by f
+__device__ __forceinline__ void ab_tile_planes(const f32x16& a, float f, f16x8 (&h)[2], f16x8 (&l)[2]) {
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        float t8[8];
+        ab_regs8(a, b, f, t8);
+        ab_split8(t8, h[b], l[b]);
+    }
+}
+
+template <int NQ, bool LN>
+__global__ __launch_bounds__(256) void k_ablk_bwd(
+    const float* __restrict__ X, const float* __restrict__ dX1, const float* __restrict__ dOC,
+    const float* __restrict__ gamma, const float* __restrict__ beta, W2 wqkv, const float* __restrict__ bqkv, W2 wot,
+    W2 wqkvt, const int* __restrict__ rowptr, const float* __restrict__ fc, const int* __restrict__ atoms, int n_list,
+    int64_t E, float qscale, float scale, float* __restrict__ dXin, float* __restrict__ dbias) {
+    extern __shared__ __attribute__((aligned(16))) char ab_smem[];
+    const RowLane L;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = blockIdx.x * (blockDim.x >> 6) + wave;  // NQ = 2: two waves per workgroup (64 KB of LDS per wave)
+    if (li >= n_list) return;
+    AbAtom a;
+    a.atom = atoms[li];
+    a.start = rowptr[a.atom];
+    a.T = rowptr[a.atom + 1] - a.start + 1;
+    a.E = E;
+    // per wave: NQ x 16 KB planes of the normalised rows | NQ x 16 KB incoming adjoint rows, then dAO (row fragments)
+    char* tile = ab_smem + wave * (NQ * 32768);
+    char* tileB = tile + NQ * 16384;
+    const unsigned tile_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile);
+    ab_dma_rows<NQ>(X, a, tile_u, L);
+    // incoming adjoint: dX1 rows of the neighbours, dOC row of the centre token
+#pragma unroll
+    for (int tq = 0; tq < NQ; tq++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int r = 2 * j + (L.lane >> 5);
+            const int p = (L.lane & 31) ^ (r & 15);
+            int s = 32 * tq + r;
+            s = s < a.T ? s : a.T - 1;
+            const float* src = s == 0 ? dOC + (int64_t)a.atom * D : dX1 + ((int64_t)a.start + s - 1) * D;
+            glds16_trr(src + 4 * p, tile_u + NQ * 16384 + tq * 16384 + j * 1024);
+        }
+    float bias[NQ][16];
+    ab_key_bias<NQ>(bias, a, fc, L.h);
+    const AbSel sel = ab_selectors(L);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int tq = 0; tq < NQ; tq++) {
+        float4 x[16];
+        tile128_to_frag(x, tile + tq * 16384, L);
+        norm_frag<16, LN>(x, gamma, beta, L.h);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        ab_park_planes(x, tile + tq * 16384, L);
+    }
+    // ---- dAO = dY Wo (token form), parked as row fragments [kg][lane] over the rows it came from
+    float inv_sc;  // inverse of the atom's power-of-two scale
+    {
+        float4 d[NQ][16];
+        float m = 0.f;
+#pragma unroll
+        for (int tq = 0; tq < NQ; tq++) {
+            tile128_to_frag(d[tq], tileB + tq * 16384, L);
+            const bool live = 32 * tq + L.r < a.T;
+#pragma unroll
+            for (int kg = 0; kg < 16; kg++) {
+                if (!live) d[tq][kg] = make_float4(0.f, 0.f, 0.f, 0.f);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(d[tq][kg].x), fabsf(d[tq][kg].y))),
+                          fmaxf(fabsf(d[tq][kg].z), fabsf(d[tq][kg].w)));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        int e = (__float_as_int(m) >> 23) & 0xff;
+        e = e > 253 ? 253 : e;
+        const float sc = __int_as_float((254 - e) << 23);
+        inv_sc = __int_as_float(e << 23);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int tq = 0; tq < NQ; tq++) {
+            f32x16 da[4] = {ab_zero(), ab_zero(), ab_zero(), ab_zero()};
+#pragma unroll
+            for (int kb = 0; kb < 8; kb++) {
+                const float v8[8] = {d[tq][2 * kb].x * sc, d[tq][2 * kb].y * sc, d[tq][2 * kb].z * sc, d[tq][2 * kb].w * sc,
+                                     d[tq][2 * kb + 1].x * sc, d[tq][2 * kb + 1].y * sc, d[tq][2 * kb + 1].z * sc,
+                                     d[tq][2 * kb + 1].w * sc};
+                f16x8 dh, dl;
+                ab_split8(v8, dh, dl);
+                const f16x8 dH = ab_times_s(dh);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const size_t wi = ((size_t)t * 8 + kb) * 64 + L.lane;
+                    const f16x8 wh = wot.h[wi], wl = wot.l[wi];
+                    AB_MFMA3(da[t], wh, wl, dH, dh, dl);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    *reinterpret_cast<float4*>(tileB + tq * 16384 + ((4 * t + j) * 64 + L.lane) * 16) =
+                        make_float4(da[t][4 * j] * ABS_INV, da[t][4 * j + 1] * ABS_INV, da[t][4 * j + 2] * ABS_INV,
+                                    da[t][4 * j + 3] * ABS_INV);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+
+    f32x16 dxn[NQ][4];
+#pragma unroll
+    for (int tq = 0; tq < NQ; tq++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) dxn[tq][t] = ab_zero();
+    float db[NQ];
+#pragma unroll
+    for (int tk = 0; tk < NQ; tk++) db[tk] = 0.f;
+    constexpr float LN2 = 0.6931471805599453f;
+
+#pragma unroll 1
+    for (int hp = 0; hp < 4; hp++) {
+        // ---- Q^T, K^T, V^T of the head pair (token form), as in the forward
+        f32x16 q[NQ], k[NQ], v[NQ];
+        {
+            float4 bq[4], bk[4], bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bq[j] = *reinterpret_cast<const float4*>(bqkv + 32 * hp + 8 * j + 4 * L.h);
+                bk[j] = *reinterpret_cast<const float4*>(bqkv + D + 32 * hp + 8 * j + 4 * L.h);
+                bv[j] = *reinterpret_cast<const float4*>(bqkv + 2 * D + 32 * hp + 8 * j + 4 * L.h);
+            }
+#pragma unroll
+            for (int tq = 0; tq < NQ; tq++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    q[tq][4 * j] = bq[j].x * ABS; q[tq][4 * j + 1] = bq[j].y * ABS;
+                    q[tq][4 * j + 2] = bq[j].z * ABS; q[tq][4 * j + 3] = bq[j].w * ABS;
+                    k[tq][4 * j] = bk[j].x * ABS; k[tq][4 * j + 1] = bk[j].y * ABS;
+                    k[tq][4 * j + 2] = bk[j].z * ABS; k[tq][4 * j + 3] = bk[j].w * ABS;
+                    v[tq][4 * j] = bv[j].x * ABS; v[tq][4 * j + 1] = bv[j].y * ABS;
+                    v[tq][4 * j + 2] = bv[j].z * ABS; v[tq][4 * j + 3] = bv[j].w * ABS;
+                }
+        }
+        {
+            const f16x8* wqh = wqkv.h + (size_t)(hp * 8) * 64 + L.lane;
+            const f16x8* wql = wqkv.l + (size_t)(hp * 8) * 64 + L.lane;
+            constexpr size_t KOFF = (size_t)4 * 8 * 64, VOFF = (size_t)8 * 8 * 64;
+#pragma unroll
+            for (int kb = 0; kb < 8; kb++) {
+                const f16x8 aqh = wqh[kb * 64], aql = wql[kb * 64];
+                const f16x8 akh = wqh[KOFF + kb * 64], akl = wql[KOFF + kb * 64];
+                const f16x8 avh = wqh[VOFF + kb * 64], avl = wql[VOFF + kb * 64];
+#pragma unroll
+                for (int tq = 0; tq < NQ; tq++) {
+                    const char* tp = tile + tq * 16384;
+                    const f16x8 xh = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 0) * 64 + L.lane) * 16);
+                    const f16x8 xl = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 1) * 64 + L.lane) * 16);
+                    const f16x8 xH = ab_times_s(xh);
+                    AB_MFMA3(q[tq], aqh, aql, xH, xh, xl);
+                    AB_MFMA3(k[tq], akh, akl, xH, xh, xl);
+                    AB_MFMA3(v[tq], avh, avl, xH, xh, xl);
+                }
+            }
+        }
+        // ---- operand planes: token form (index = head of the pair) and feature form (index = token K block)
+        f16x8 qh[NQ][2], ql[NQ][2], kh[NQ][2], kl[NQ][2], vh[NQ][2], vl[NQ][2], dah[NQ][2], dal[NQ][2];
+        f16x8 qfh[NQ][2], qfl[NQ][2], kfh[NQ][2], kfl[NQ][2], dfh[NQ][2], dfl[NQ][2];
+#pragma unroll
+        for (int tq = 0; tq < NQ; tq++) {
+            ab_tile_planes(q[tq], qscale * ABS_INV, qh[tq], ql[tq]);
+            ab_tile_planes(k[tq], ABS_INV, kh[tq], kl[tq]);
+            ab_tile_planes(v[tq], ABS_INV, vh[tq], vl[tq]);
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const float4 d0 = *reinterpret_cast<const float4*>(tileB + tq * 16384 + ((4 * hp + 2 * b) * 64 + L.lane) * 16);
+                const float4 d1 = *reinterpret_cast<const float4*>(tileB + tq * 16384 + ((4 * hp + 2 * b + 1) * 64 + L.lane) * 16);
+                const float v8[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                ab_split8(v8, dah[tq][b], dal[tq][b]);
+            }
+            ab_transpose(qh[tq], ql[tq], sel, qfh[tq], qfl[tq]);
+            ab_transpose(kh[tq], kl[tq], sel, kfh[tq], kfl[tq]);
+            ab_transpose(dah[tq], dal[tq], sel, dfh[tq], dfl[tq]);
+        }
+        f32x16 dq[NQ], dk[NQ], dv[NQ];  // token-form tiles of the pair: registers 8 hd .. 8 hd + 7 from head hd
+#pragma unroll
+        for (int hd = 0; hd < 2; hd++) {
+            f32x16 dkh[NQ], dvh[NQ];
+#pragma unroll
+            for (int tk = 0; tk < NQ; tk++) { dkh[tk] = ab_zero(); dvh[tk] = ab_zero(); }
+#pragma unroll
+            for (int tq = 0; tq < NQ; tq++) {
+                f32x16 s[NQ], dp[NQ];
+                float mx = -INFINITY;
+                const f16x8 qH = ab_times_s(qh[tq][hd]);
+#pragma unroll
+                for (int tk = 0; tk < NQ; tk++) {
+                    s[tk] = ab_zero();
+                    dp[tk] = ab_zero();
+                    AB_MFMA3(s[tk], kh[tk][hd], kl[tk][hd], qH, qh[tq][hd], ql[tq][hd]);
+                    const f16x8 vH = ab_times_s(vh[tk][hd]);
+                    AB_MFMA3A(dp[tk], vH, vh[tk][hd], vl[tk][hd], dah[tq][hd], dal[tq][hd]);
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        s[tk][i] = fmaf(s[tk][i], ABS_INV, bias[tk][i]);
+                        mx = fmaxf(mx, s[tk][i]);
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sum = 0.f, dl = 0.f;
+#pragma unroll
+                for (int tk = 0; tk < NQ; tk++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const float p = __builtin_amdgcn_exp2f(s[tk][i] - mx);
+                        s[tk][i] = p;
+                        sum += p;
+                        dl = fmaf(p, dp[tk][i], dl);
+                    }
+                sum += __shfl_xor(sum, 32);
+                dl += __shfl_xor(dl, 32);
+                const float inv = __builtin_amdgcn_rcpf(sum);
+                dl *= inv * ABS_INV;  // delta of this query
+                f32x16 dqh = ab_zero();
+#pragma unroll
+                for (int tk = 0; tk < NQ; tk++) {
+                    f32x16 ds;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const float pn = s[tk][i] * inv;
+                        s[tk][i] = pn;
+                        ds[i] = pn * fmaf(dp[tk][i], ABS_INV, -dl);
+                    }
+                    f16x8 pth[2], ptl[2], sth[2], stl[2];
+                    ab_tile_planes(s[tk], 1.0f, pth, ptl);
+                    ab_tile_planes(ds, 1.0f, sth, stl);
+                    // dQ^T += K^T dS^T (keys of tile tk)
+#pragma unroll
+                    for (int b = 0; b < 2; b++) {
+                        const f16x8 kH = ab_times_s(kfh[tk][b]);
+                        AB_MFMA3A(dqh, kH, kfh[tk][b], kfl[tk][b], sth[b], stl[b]);
+                    }
+                    // the (query, key) forms: P and dS with lane = key, registers = queries of tile tq
+                    f16x8 ph[2], pl[2], sh[2], sl[2];
+                    ab_transpose(pth, ptl, sel, ph, pl);
+                    db[tk] += ab_transpose_sum(sth, stl, sel, sh, sl);
+#pragma unroll
+                    for (int b = 0; b < 2; b++) {
+                        const f16x8 qH2 = ab_times_s(qfh[tq][b]);
+                        AB_MFMA3A(dkh[tk], qH2, qfh[tq][b], qfl[tq][b], sh[b], sl[b]);
+                        const f16x8 pH = ab_times_s(ph[b]);
+                        AB_MFMA3(dvh[tk], dfh[tq][b], dfl[tq][b], pH, ph[b], pl[b]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) dq[tq][8 * hd + j] = dqh[8 * hd + j];
+            }
+#pragma unroll
+            for (int tk = 0; tk < NQ; tk++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    dk[tk][8 * hd + j] = dkh[tk][8 * hd + j];
+                    dv[tk][8 * hd + j] = dvh[tk][8 * hd + j];
+                }
+        }
+        // ---- dXn^T += Wqkv^T [dQ; dK; dV]^T: K blocks 2 hp, 2 hp + 1 of each of the three parts
+#pragma unroll
+        for (int tq = 0; tq < NQ; tq++) {
+            f16x8 gh[3][2], gl[3][2];
+            ab_tile_planes(dq[tq], scale * ABS_INV, gh[0], gl[0]);
+            ab_tile_planes(dk[tq], LN2 * ABS_INV, gh[1], gl[1]);
+            ab_tile_planes(dv[tq], ABS_INV, gh[2], gl[2]);
+#pragma unroll
+            for (int part = 0; part < 3; part++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const int kb = 8 * part + 2 * hp + b;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const size_t wi = ((size_t)t * 24 + kb) * 64 + L.lane;
+                        const f16x8 wh = wqkvt.h[wi], wl = wqkvt.l[wi];
+                        const f16x8 wH = ab_times_s(wh);
+                        AB_MFMA3A(dxn[tq][t], wH, wh, wl, gh[part][b], gl[part][b]);
+                    }
+                }
+        }
+    }
+    // ---- key-bias gradient (summed over the heads; one writer per edge and layer)
+#pragma unroll
+    for (int tk = 0; tk < NQ; tk++) {
+        const float v = (db[tk] + __shfl_xor(db[tk], 32)) * inv_sc;
+        const int key = 32 * tk + L.r;
+        if (L.h == 0 && key >= 1 && key < a.T) dbias[a.start + key - 1] = v;
+    }
+    // ---- norm adjoint, residual, whole-line stores
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    float* stg = reinterpret_cast<float*>(tile);
+#pragma unroll
+    for (int tq = 0; tq < NQ; tq++) {
+        if (32 * tq >= a.T) continue;
+        float4 w[16], x[16];
+        const int64_t rw = a.row(32 * tq + L.r);
+        load_rowfrag<16>(x, X, rw, D, L.h);
+        const float f = ABS_INV * inv_sc;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + 32 * t + 8 * j + 4 * L.h);
+                w[4 * t + j] = make_float4(dxn[tq][t][4 * j] * f * g.x, dxn[tq][t][4 * j + 1] * f * g.y,
+                                           dxn[tq][t][4 * j + 2] * f * g.z, dxn[tq][t][4 * j + 3] * f * g.w);
+            }
+        norm_bwd_frag<16, LN>(w, x);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+#pragma unroll
+            for (int kg = 0; kg < 8; kg++)
+                *reinterpret_cast<float4*>(stg + L.r * TILE_LD + 8 * kg + 4 * L.h) = w[8 * c + kg];
+            __builtin_amdgcn_wave_barrier();
+            const int rr = L.lane >> 4, cc = 4 * (L.lane & 15);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int r = 4 * j + rr, s = 32 * tq + r;
+                if (s < a.T) {
+                    float4 o4 = *reinterpret_cast<const float4*>(stg + r * TILE_LD + cc);
+                    if (s == 0) {
+                        *reinterpret_cast<float4*>(dXin + (E + a.atom) * D + 64 * c + cc) = o4;
+                    } else {
+                        const int64_t row = (int64_t)a.start + s - 1;
+                        const float4 xr = *reinterpret_cast<const float4*>(dX1 + row * D + 64 * c + cc);
+                        o4.x += xr.x; o4.y += xr.y; o4.z += xr.z; o4.w += xr.w;
+                        *reinterpret_cast<float4*>(dXin + row * D + 64 * c + cc) = o4;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int g_attn_fused = 0;  // pet_config_set("attn_fused", bits): 1 = fused forward, 2 = fused adjoint; 0 = the three-kernel form
+void set_attn_fused(int v) { g_attn_fused = v; }
+int attn_fused() { return g_attn_fused; }
+
+static inline W2 w2s_fwd(const Lin& L) {
+    const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
+    const f16x8* b = reinterpret_cast<const f16x8*>(L.fwd2s);
+    W2 w; w.h = b; w.l = b + n8;
+    return w;
+}
+
+// atoms of at most 64 tokens (attention tile counts 1 .. 4 of the graph's bucket lists); false = not served
+bool ablk_fwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* X, float* X1, float* OC, float scale,
+              hipStream_t st) {
+    if (!(g_attn_fused & 1) || !A.qkv.fwd2s || !A.out.fwd2s) return false;
+    if (g.bucket_start[5] > g.bucket_start[4]) return false;  // an atom of more than 64 tokens
+    const bool ln = m.layer_norm();
+    const float qscale = scale * AB_LOG2E;
+    const W2 wq = w2s_fwd(A.qkv), wo = w2s_fwd(A.out);
+    const float* beta = ln ? A.b_attn : nullptr;
+    const int n1 = g.bucket_start[2], n2 = g.bucket_start[4] - g.bucket_start[2];
+#define PET_ABLK_FWD(NQ, LNF, LIST, CNT)                                                                            \
+    {                                                                                                               \
+        const size_t lds = (size_t)4 * NQ * 16384;                                                                  \
+        allow_big_lds(k_ablk_fwd<NQ, LNF>, lds);                                                                    \
+        k_ablk_fwd<NQ, LNF><<<cdiv(CNT, 4), 256, lds, st>>>(X, A.g_attn, beta, wq, A.qkv.b, wo, A.out.b, g.rowptr,  \
+                                                            g.fc, LIST, CNT, g.n_edges, qscale, X1, OC);            \
+    }
+    if (n1 > 0) {
+        if (ln) PET_ABLK_FWD(1, true, g.atom_order, n1) else PET_ABLK_FWD(1, false, g.atom_order, n1)
+    }
+    if (n2 > 0) {
+        if (ln) PET_ABLK_FWD(2, true, g.atom_order + n1, n2) else PET_ABLK_FWD(2, false, g.atom_order + n1, n2)
+    }
+#undef PET_ABLK_FWD
+    return true;
+}
+
+static inline W2 w2s_bwd(const Lin& L) {
+    const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
+    const f16x8* b = reinterpret_cast<const f16x8*>(L.bwd2s);
+    W2 w; w.h = b; w.l = b + n8;
+    return w;
+}
+
+// whether the adjoint of this graph's attention layers runs fused (the forward of the same call sequence did, then)
+bool ablk_bwd_on(const Graph& g) { return (g_attn_fused & 2) && !(g.bucket_start[5] > g.bucket_start[4]); }
+
+// dXin [E + N, D] = adjoint of the layer input; dbias [E] = key-bias gradient of this layer summed over the heads
+bool ablk_bwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* X, const float* dX1, const float* dOC,
+              float* dXin, float* dbias, float scale, hipStream_t st) {
+    if (!ablk_bwd_on(g) || !A.qkv.fwd2s || !A.qkv.bwd2s || !A.out.bwd2s) return false;
+    const bool ln = m.layer_norm();
+    const float qscale = scale * AB_LOG2E;
+    const W2 wq = w2s_fwd(A.qkv), wqt = w2s_bwd(A.qkv), wot = w2s_bwd(A.out);
+    const float* beta = ln ? A.b_attn : nullptr;
+    const int n1 = g.bucket_start[2], n2 = g.bucket_start[4] - g.bucket_start[2];
+#define PET_ABLK_BWD(NQ, LNF, LIST, CNT)                                                                             \
+    {                                                                                                                \
+        constexpr int WPB = 4 / NQ;                                                                                  \
+        const size_t lds = (size_t)WPB * NQ * 32768;                                                                 \
+        allow_big_lds(k_ablk_bwd<NQ, LNF>, lds);                                                                     \
+        k_ablk_bwd<NQ, LNF><<<cdiv(CNT, WPB), 64 * WPB, lds, st>>>(X, dX1, dOC, A.g_attn, beta, wq, A.qkv.b, wot, wqt,      \
+                                                            g.rowptr, g.fc, LIST, CNT, g.n_edges, qscale, scale,     \
+                                                            dXin, dbias);                                            \
+    }
+    if (n1 > 0) {
+        if (ln) PET_ABLK_BWD(1, true, g.atom_order, n1) else PET_ABLK_BWD(1, false, g.atom_order, n1)
+    }
+    if (n2 > 0) {
+        if (ln) PET_ABLK_BWD(2, true, g.atom_order + n1, n2) else PET_ABLK_BWD(2, false, g.atom_order + n1, n2)
+    }
+#undef PET_ABLK_BWD
+    return true;
+}
+
+}  // namespace pet

@@ -885,11 +885,11 @@ __global__ __launch_bounds__(NTHREADS) void k_compress_bwd(const float* __restri
 // passes only where fc >= 1e-15 (transformer.py:109-110); heads and layers are summed here.
 // dbias_l: one head-major slice [NHEAD, E] per attention layer, each written once by that layer's adjoint
 __global__ void k_dfc_attn(const float* __restrict__ fc, const float* __restrict__ dbias_l, int slices,
-                           float* __restrict__ dfc_attn, int64_t E) {
+                           float* __restrict__ dfc_attn, int64_t E, int hstep) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= E) return;
     float dbias = 0.f;
-    for (int h = 0; h < slices * NHEAD; h++) dbias += dbias_l[(int64_t)h * E + p];
+    for (int h = 0; h < slices * NHEAD; h += hstep) dbias += dbias_l[(int64_t)h * E + p];
     const float f = fc[p];
     dfc_attn[p] = f >= 1e-15f ? dbias / f : 0.f;
 }
@@ -1166,6 +1166,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     const double fE = (double)E, fN = (double)N, fR = (double)R;
     const bool trr = use_trr();
     const bool trr_l = trr && m.plain_layers();  // the TRR transformer-layer kernels are PreLN (RMSNorm or LayerNorm)
+    const bool fused_attn = trr_l && !tr && ablk_bwd_on(g) && m.gnn[0].attn[0].qkv.bwd2s;
     PET_HIP_CHECK(hipMemsetAsync(w.dgeo, 0, E * 4 * sizeof(float), st));
     allow_big_lds(k_swiglu_bwd<256, DNF, false, true>, (BM * LD256 + BM * LD128) * 4);
     allow_big_lds(k_swiglu_bwd<256, DNF, true, true>, (BM * LD256 + BM * LD128) * 4);
@@ -1278,6 +1279,14 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             ss.join(st);  // dOC ready
             // dX_alt (edge rows) = dX1, dH_alt = dH1; PostLN: dX_alt holds all E+N rows of d(tokens + attention output)
             const float* dOCr = post ? dX_alt + E * D : w.dOC;
+            // the per-atom fused adjoint (pet_ablk.hip): Q, K, V recomputed from X, only dX and the key-bias gradient leave
+            bool fusedb = false;
+            if (fused_attn) {
+                ProfScope ps("attn_blk_bwd", st, fR * 2.0 * D * 8 * D + 2.0 * 4.0 * D * g_sum_t2(g), fR * 4.0 * 3 * D);  // X, dX1 in; dX out
+                fusedb = ablk_bwd(m, g, A, Ab.X, dX_alt, w.dOC, dX,
+                                  w.dbias_l + ((int64_t)gi * m.h.num_attention_layers + a) * NHEAD * E, scale, st);
+            }
+            if (!fusedb) {
             {
                 ProfScope ps("oproj_bwd", st, fR * 2.0 * D * D, fR * 4.0 * 2 * D);  // dX1 (| dOC) in; dAO out
                 if (trr_l) trr_oproj_bwd(dX_alt, w.dOC, A.out, w.dAO, E, R, st);
@@ -1307,6 +1316,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 if (trr_l) trr_qkv_bwd(w.dQKV, Ab.X, A.g_attn, ln, A.qkv, dX_alt, dX, E, R, st);
                 else if (post) k_qkv_bwd<true><<<gR, NTHREADS, lds1, st>>>(w.dQKV, nullptr, nullptr, A.qkv.bwd, dX_alt, dX, E, R, false);
                 else k_qkv_bwd<false><<<gR, NTHREADS, lds1, st>>>(w.dQKV, Ab.X, A.g_attn, A.qkv.bwd, dX_alt, dX, E, R, ln);
+            }
             }
             ss.fork(st);  // centre rows of dX ready
             {
@@ -1342,7 +1352,9 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         tr->cond_finish();
         if (tr->err) return tr->err;
     }
-    k_dfc_attn<<<cdiv(E, 256), 256, 0, st>>>(g.fc, w.dbias_l, m.h.num_gnn_layers * m.h.num_attention_layers, w.dbias, E);
+    // fused adjoint: one slice per attention layer (the head sum), at the place of the layer's first head slice
+    k_dfc_attn<<<cdiv(E, 256), 256, 0, st>>>(g.fc, w.dbias_l, m.h.num_gnn_layers * m.h.num_attention_layers, w.dbias, E,
+                                             fused_attn ? NHEAD : 1);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }

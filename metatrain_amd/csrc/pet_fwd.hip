@@ -961,6 +961,14 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                 ss.join(st);
                 side_busy = false;
             }
+            // the per-atom fused block (pet_ablk.hip): QKV, attention output and nothing else of this stage reach HBM.
+            // Training keeps the three-kernel form (its second-order pass reads the saved QKV and AO).
+            bool fused = false;
+            if (trr_l && save != 2 && E > 0 && (save == 0 || ablk_bwd_on(g))) {
+                ProfScope ps("attn_blk", st, fR * 2.0 * D * 4 * D + attn_flops, fR * 4.0 * 2 * D);  // X in; X1 | OC out
+                fused = ablk_fwd(m, g, A, Ab.X, Ab.X1, Ab.OC, scale, st);
+            }
+            if (!fused) {
             {
                 ProfScope ps("qkv", st, fR * 2.0 * D * 3 * D, fR * 4.0 * (D + 3 * D));  // X in, QKV out
                 if (trr_l) trr_qkv(Ab.X, A.g_attn, m.layer_norm() ? A.b_attn : nullptr, A.qkv, Ab.QKV, R, st);
@@ -983,6 +991,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                 if (trr_l) trr_oproj(Ab.AO, Ab.X, A.out, Ab.X1, Ab.OC, E, R, st);
                 else if (post) k_oproj<true><<<gR, NTHREADS, lds1, st>>>(Ab.AO, Ab.X, A.out.fwd, A.out.b, Ab.X1, nullptr, E, R);
                 else k_oproj<false><<<gR, NTHREADS, lds1, st>>>(Ab.AO, Ab.X, A.out.fwd, A.out.b, Ab.X1, Ab.OC, E, R);
+            }
             }
             if (post) {
                 // transformer.py:245-247 on every token (edges and centre): norm_attention, + MLP, norm_mlp; the edge rows
