@@ -91,7 +91,7 @@ ProfScope::~ProfScope() {
 
 // two-way fp16 split of the same fragments (trr.h, f16x3 GEMMs): out[plane][(t * kbn + kb) * 64 + l][8]
 __global__ void k_pack2h(const float* __restrict__ W, int64_t s_n, int64_t s_k, int n_out, int k_in,
-                         _Float16* __restrict__ out, float lscale = 2048.0f) {
+                         _Float16* __restrict__ out, float lscale = 2048.0f, float hscale = 1.0f) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int kbn = k_in / 16;
     int64_t total = (int64_t)(n_out / 32) * kbn * 64;
@@ -104,7 +104,7 @@ __global__ void k_pack2h(const float* __restrict__ W, int64_t s_n, int64_t s_k, 
         const int64_t k = kb * 16 + (j < 4 ? 4 * (l >> 5) + j : 8 + 4 * (l >> 5) + (j - 4));
         const float x = W[n * s_n + k * s_k];
         const _Float16 h = (_Float16)x;
-        out[(0 * total + idx) * 8 + j] = h;
+        out[(0 * total + idx) * 8 + j] = (_Float16)((float)h * hscale);
         out[(1 * total + idx) * 8 + j] = (_Float16)((x - (float)h) * lscale);
     }
 }
@@ -174,15 +174,15 @@ static int pack_lin(Model& m, const std::string& name, Lin& L, const float* w, c
     return PET_OK;
 }
 
-// planes for the single-accumulator products of pet_ablk.hip: the low piece scaled by 64 instead of 2048
+// "scaled" planes for the single-accumulator products of pet_ablk.hip: H = fp16(64 w), L = fp16(64 w - H)
 static int pack_lin_s(Model& m, const std::string& name, Lin& L, hipStream_t st) {
     if (m.generic()) return PET_OK;
     const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
     int rc;
     if ((rc = named_alloc(m, name + ":fwd2s", &L.fwd2s, 2 * n8 * 16)) != PET_OK) return rc;
     if ((rc = named_alloc(m, name + ":bwd2s", &L.bwd2s, 2 * n8 * 16)) != PET_OK) return rc;
-    k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(L.w, L.k_in, 1, L.n_out, L.k_in, (_Float16*)L.fwd2s, 64.0f);
-    k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(L.w, 1, L.k_in, L.k_in, L.n_out, (_Float16*)L.bwd2s, 64.0f);
+    k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(L.w, L.k_in, 1, L.n_out, L.k_in, (_Float16*)L.fwd2s, 64.0f, 64.0f);
+    k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(L.w, 1, L.k_in, L.k_in, L.n_out, (_Float16*)L.bwd2s, 64.0f, 64.0f);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }

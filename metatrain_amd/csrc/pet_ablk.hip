@@ -4,8 +4,8 @@
 // emits only the gradient of the layer input. Reference: pet/modules/transformer.py:86-152 (AttentionBlock.forward),
 // :203-234 (the PreLN layer around it), :565-589 (manual_attention).
 //
-// Everything is v_mfma_f32_32x32x16_f16 on split operands (trr.h) and the C/D layout of one product IS the operand
-// layout of the next, so the chain needs no LDS exchange and no cross-lane traffic except the soft-max row statistics:
+// Everything is v_mfma_f32_32x32x16_f16 on split operands and the C/D layout of one product IS the operand layout of
+// the next, so the chain needs no LDS exchange and no cross-lane traffic except the soft-max row statistics:
 //
 //   token form   (lane = token,   regs = features)  Q^T, K^T   = W x^T        A = weight fragment, B = row planes
 //   feature form (lane = feature, regs = tokens)    V          = x W^T        A = row planes,      B = weight fragment
@@ -15,12 +15,16 @@
 //                        -> lane = query = token, regs = features: the row fragment of the attention output,
 //                           i.e. directly the B operand of the output projection X1^T = Wo AO^T.
 //
-// Products are "f16x3" with ONE accumulator: x = h + l / S with h = fp16(x), l = fp16((x - h) S), S = 64, and
-//   S (a b) = a_h (S b_h) + a_l b_h + a_h b_l      (three MFMAs per K block; the S b_h plane is one v_pk_mul_f16 away)
-// so an accumulator holds S times the product. S = 64 keeps S b_h inside fp16 for |b| < 1023 (the H plane always sits
-// on the operand of known magnitude: normalised rows, soft-max weights, rows scaled to [1, 2)) and l normal for
-// |x| > 4e-3 (below that the low piece keeps 1e-9 absolute accuracy). The weight planes with that scale are packed
-// next to the 2048-scaled ones of the other TRR kernels (abi.hip, Lin::fwd2s / bwd2s).
+// Split operands, ONE accumulator per product ("f16x3"): every tensor -- weights, activations, adjoints -- is held as
+// two fp16 planes of 64 x,
+//   H = fp16(64 x),    L = fp16(64 x - H)      (L is a normal fp16 number for |x| > 4e-3; below that the pair still
+//                                               carries x to 5e-10 absolute: the matrix cores honour fp16 subnormals,
+//                                               tools/debug/mfma_denorm.hip)
+// and a product is three MFMAs on one accumulator that then holds 4096 a b:
+//   4096 a b = a_H b_H + a_L b_H + a_H b_L          (+ a_L b_L: 2^-22 relative, dropped).
+// |64 x| must stay inside fp16: |x| < 1023, which holds for normalised rows, weights, Q / K / V (sums of normalised rows
+// times weights), soft-max weights and attention outputs; adjoint rows are scaled per atom by a power of two first.
+// The weight planes are packed by abi.hip (Lin::fwd2s / bwd2s).
 #include "common.h"
 #include "model.h"
 #include "pet_ws.h"
@@ -28,47 +32,37 @@
 
 namespace pet {
 
-constexpr float ABS = 64.0f;
+constexpr float ABS = 64.0f;             // plane scale
 constexpr float ABS_INV = 1.0f / 64.0f;
+constexpr float ABQ = 4096.0f;           // accumulator scale = ABS^2
+constexpr float ABQ_INV = 1.0f / 4096.0f;
 constexpr float AB_LOG2E = 1.4426950408889634f;
 
 union H8 {
     f16x8 v;
     h16x2 p[4];
 };
-// (h, l) planes of eight values; the low piece is derived from the PINNED high pair (trr.h split_pair_pinned)
-__device__ __forceinline__ void ab_split8(const float (&x)[8], f16x8& h, f16x8& l) {
+// the two planes of eight values v = 64 x: hi = fp16(v), lo = fp16(v - hi); the low piece is derived from the PINNED high pair
+// (trr.h split_pair_pinned: otherwise the compiler may convert twice with instructions that round differently)
+__device__ __forceinline__ void ab_split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
     H8 a, b;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         h16x2 hp, lp;
         hp[0] = (_Float16)x[2 * j]; hp[1] = (_Float16)x[2 * j + 1];
         asm volatile("" : "+v"(hp));
-        lp[0] = (_Float16)((x[2 * j] - (float)hp[0]) * ABS);
-        lp[1] = (_Float16)((x[2 * j + 1] - (float)hp[1]) * ABS);
+        lp[0] = (_Float16)(x[2 * j] - (float)hp[0]);
+        lp[1] = (_Float16)(x[2 * j + 1] - (float)hp[1]);
         a.p[j] = hp; b.p[j] = lp;
     }
-    h = a.v; l = b.v;
+    hi = a.v; lo = b.v;
 }
-__device__ __forceinline__ f16x8 ab_times_s(const f16x8& h) {
-    f16x8 r;
-#pragma unroll
-    for (int j = 0; j < 8; j++) r[j] = h[j] * (_Float16)ABS;
-    return r;
-}
-// acc += S (a b):  a = (h, l),  b = (H = S h, h, l)
-#define AB_MFMA3(acc, ah, al, bH, bh, bl)      \
+// acc += 4096 (a b) from the planes of a (A operand) and b (B operand)
+#define AB_MFMA3(acc, aH, aL, bH, bL)          \
     do {                                       \
-        acc = PET_MFMA_H((ah), (bH), (acc));   \
-        acc = PET_MFMA_H((al), (bh), (acc));   \
-        acc = PET_MFMA_H((ah), (bl), (acc));   \
-    } while (0)
-// the same with the H plane on the A side
-#define AB_MFMA3A(acc, aH, ah, al, bh, bl)     \
-    do {                                       \
-        acc = PET_MFMA_H((aH), (bh), (acc));   \
-        acc = PET_MFMA_H((al), (bh), (acc));   \
-        acc = PET_MFMA_H((ah), (bl), (acc));   \
+        acc = PET_MFMA_H((aH), (bH), (acc));   \
+        acc = PET_MFMA_H((aL), (bH), (acc));   \
+        acc = PET_MFMA_H((aH), (bL), (acc));   \
     } while (0)
 
 __device__ __forceinline__ f32x16 ab_zero() {
@@ -82,17 +76,53 @@ __device__ __forceinline__ void ab_regs8(const f32x16& a, int kb, float f, float
 #pragma unroll
     for (int j = 0; j < 8; j++) o[j] = a[8 * kb + j] * f;
 }
+__device__ __forceinline__ void ab_regs8(const f32x16& a, int kb, float (&o)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = a[8 * kb + j];
+}
+// planes of the two K blocks of a C tile (times f)
+__device__ __forceinline__ void ab_tile_planes(const f32x16& a, float f, f16x8 (&hi)[2], f16x8 (&lo)[2]) {
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        float t8[8];
+        ab_regs8(a, b, f, t8);
+        ab_split8(t8, hi[b], lo[b]);
+    }
+}
+__device__ __forceinline__ void ab_tile_planes(const f32x16& a, f16x8 (&hi)[2], f16x8 (&lo)[2]) {
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        float t8[8];
+        ab_regs8(a, b, t8);
+        ab_split8(t8, hi[b], lo[b]);
+    }
+}
+
+// weight fragment `idx` (in units of 64 lanes x 16 B) of a plane: scalar base + per-lane byte offset, so that the
+// address arithmetic stays on the scalar unit (saddr + voffset form of global_load)
+__device__ __forceinline__ f16x8 ab_ldw(const f16x8* plane, int idx, unsigned lane16) {
+    const char* base = reinterpret_cast<const char*>(plane + (size_t)idx * 64);
+    return *reinterpret_cast<const f16x8*>(base + lane16);
+}
 
 // Q, K, V weight fragments (both planes) of head pair hp, K block kb
 struct AbW6 {
     f16x8 qh, ql, kh, kl, vh, vl;
 };
-__device__ __forceinline__ void ab_ldw6(AbW6& w, const W2& wqkv, int hp, int kb, int lane) {
-    const size_t i = (size_t)(hp * 8 + kb) * 64 + lane;
-    constexpr size_t KOFF = (size_t)4 * 8 * 64, VOFF = (size_t)8 * 8 * 64;
-    w.qh = wqkv.h[i]; w.ql = wqkv.l[i];
-    w.kh = wqkv.h[KOFF + i]; w.kl = wqkv.l[KOFF + i];
-    w.vh = wqkv.h[VOFF + i]; w.vl = wqkv.l[VOFF + i];
+__device__ __forceinline__ void ab_ldw6(AbW6& w, const W2& wqkv, int hp, int kb, unsigned lane16) {
+    const int i = hp * 8 + kb;
+    w.qh = ab_ldw(wqkv.h, i, lane16); w.ql = ab_ldw(wqkv.l, i, lane16);
+    w.kh = ab_ldw(wqkv.h, 32 + i, lane16); w.kl = ab_ldw(wqkv.l, 32 + i, lane16);
+    w.vh = ab_ldw(wqkv.h, 64 + i, lane16); w.vl = ab_ldw(wqkv.l, 64 + i, lane16);
+}
+// fragments of four output tiles (both planes) at K block kb of a [128 x (16 KB)] weight
+struct AbW4 {
+    f16x8 h[4], l[4];
+};
+template <int KB>
+__device__ __forceinline__ void ab_ldw4(AbW4& w, const W2& wt, int kb, unsigned lane16) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) { w.h[t] = ab_ldw(wt.h, t * KB + kb, lane16); w.l[t] = ab_ldw(wt.l, t * KB + kb, lane16); }
 }
 
 // token slot s of the atom: 0 = the centre token (row E + atom of the token stream), s >= 1 neighbour s - 1; slots past
@@ -121,12 +151,12 @@ __device__ __forceinline__ void ab_dma_rows(const float* __restrict__ X, const A
         }
 }
 
-// planes of a normalised row tile in the wave's LDS: [kb 0..7][plane h, l][lane] f16x8
+// planes of a normalised row tile in the wave's LDS: [kb 0..7][plane H, L][lane] f16x8
 __device__ __forceinline__ void ab_park_planes(const float4 (&x)[16], char* tile, const RowLane& L) {
 #pragma unroll
     for (int kb = 0; kb < 8; kb++) {
-        const float v[8] = {x[2 * kb].x, x[2 * kb].y, x[2 * kb].z, x[2 * kb].w,
-                            x[2 * kb + 1].x, x[2 * kb + 1].y, x[2 * kb + 1].z, x[2 * kb + 1].w};
+        const float v[8] = {x[2 * kb].x * ABS, x[2 * kb].y * ABS, x[2 * kb].z * ABS, x[2 * kb].w * ABS,
+                            x[2 * kb + 1].x * ABS, x[2 * kb + 1].y * ABS, x[2 * kb + 1].z * ABS, x[2 * kb + 1].w * ABS};
         f16x8 h, l;
         ab_split8(v, h, l);
         *reinterpret_cast<f16x8*>(tile + ((kb * 2 + 0) * 64 + L.lane) * 16) = h;
@@ -150,6 +180,15 @@ __device__ __forceinline__ void ab_key_bias(float (&bias)[NQ][16], const AbAtom&
         }
 }
 
+// accumulators of a token-form tile initialised with 4096 x bias (features 8 j + 4 h .. + 3 of the tile at b)
+__device__ __forceinline__ void ab_bias_tile(f32x16& acc, const float* __restrict__ b, int h) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float4 v = *reinterpret_cast<const float4*>(b + 8 * j + 4 * h);
+        acc[4 * j] = v.x * ABQ; acc[4 * j + 1] = v.y * ABQ; acc[4 * j + 2] = v.z * ABQ; acc[4 * j + 3] = v.w * ABQ;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
@@ -161,6 +200,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void k_ablk_fwd(
     float* __restrict__ X1, float* __restrict__ OC) {
     extern __shared__ __attribute__((aligned(16))) char ab_smem[];
     const RowLane L;
+    const unsigned lane16 = (unsigned)L.lane * 16u;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = blockIdx.x * 4 + wave;
     if (li >= n_list) return;
@@ -172,10 +212,12 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void k_ablk_fwd(
     char* tile = ab_smem + wave * (NQ * 16384);
     const unsigned tile_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile);
     ab_dma_rows<NQ>(X, a, tile_u, L);
+    AbW6 wr[2];  // weight fragments of two K blocks in flight
+    ab_ldw6(wr[0], wqkv, 0, 0, lane16);
     float bias[NQ][16];
     ab_key_bias<NQ>(bias, a, fc, L.h);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // rows -> normalised -> (h, l) planes, parked over the fp32 tile they came from
+    // rows -> normalised -> plain planes, parked over the fp32 tile they came from
 #pragma unroll
     for (int tq = 0; tq < NQ; tq++) {
         float4 x[16];
@@ -188,38 +230,27 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void k_ablk_fwd(
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
 
-    float4 ao[NQ][16];  // attention output, row fragment
-    AbW6 wr[2];         // weight fragments of two K blocks in flight
-    ab_ldw6(wr[0], wqkv, 0, 0, L.lane);
+    f16x8 aoh[NQ][8], aol[NQ][8];  // attention output: planes of the row fragment, K block = head
 #pragma unroll
-    for (int hp = 0; hp < 4; hp++) {  // unrolled: ao[] is indexed with hp (a run-time index would send it to scratch)
+    for (int hp = 0; hp < 4; hp++) {  // unrolled: the planes are indexed with hp (a run-time index would go to scratch)
         // ---- Q^T, K^T (token form) and V (feature form) of the head pair: 32 features each
         f32x16 q[NQ], k[NQ], v[NQ];
         {
-            float4 bq[4], bk[4];
+            const float bv = bqkv[2 * D + 32 * hp + L.r] * ABQ;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                bq[j] = *reinterpret_cast<const float4*>(bqkv + 32 * hp + 8 * j + 4 * L.h);
-                bk[j] = *reinterpret_cast<const float4*>(bqkv + D + 32 * hp + 8 * j + 4 * L.h);
+            for (int tq = 0; tq < NQ; tq++) {
+                ab_bias_tile(q[tq], bqkv + 32 * hp, L.h);
+                ab_bias_tile(k[tq], bqkv + D + 32 * hp, L.h);
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[tq][i] = bv;
             }
-            const float bv = bqkv[2 * D + 32 * hp + L.r] * ABS;
-#pragma unroll
-            for (int tq = 0; tq < NQ; tq++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    q[tq][4 * j] = bq[j].x * ABS; q[tq][4 * j + 1] = bq[j].y * ABS;
-                    q[tq][4 * j + 2] = bq[j].z * ABS; q[tq][4 * j + 3] = bq[j].w * ABS;
-                    k[tq][4 * j] = bk[j].x * ABS; k[tq][4 * j + 1] = bk[j].y * ABS;
-                    k[tq][4 * j + 2] = bk[j].z * ABS; k[tq][4 * j + 3] = bk[j].w * ABS;
-                    v[tq][4 * j] = bv; v[tq][4 * j + 1] = bv; v[tq][4 * j + 2] = bv; v[tq][4 * j + 3] = bv;
-                }
         }
 #pragma unroll
         for (int kb = 0; kb < 8; kb++) {
             // the next K block's fragments (the next head pair's first block behind the last one) are requested before
             // this block's MFMAs; left to itself the compiler requests a block right in front of its own MFMAs
             const int nx = 8 * hp + kb + 1;
-            if (nx < 32) ab_ldw6(wr[nx & 1], wqkv, nx >> 3, nx & 7, L.lane);
+            if (nx < 32) ab_ldw6(wr[nx & 1], wqkv, nx >> 3, nx & 7, lane16);
             __builtin_amdgcn_sched_barrier(0);
             const AbW6& w6 = wr[kb & 1];
 #pragma unroll
@@ -227,124 +258,115 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void k_ablk_fwd(
                 const char* tp = tile + tq * 16384;
                 const f16x8 xh = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 0) * 64 + L.lane) * 16);
                 const f16x8 xl = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 1) * 64 + L.lane) * 16);
-                const f16x8 xH = ab_times_s(xh);
-                AB_MFMA3(q[tq], w6.qh, w6.ql, xH, xh, xl);
-                AB_MFMA3(k[tq], w6.kh, w6.kl, xH, xh, xl);
-                AB_MFMA3A(v[tq], xH, xh, xl, w6.vh, w6.vl);
+                AB_MFMA3(q[tq], w6.qh, w6.ql, xh, xl);
+                AB_MFMA3(k[tq], w6.kh, w6.kl, xh, xl);
+                AB_MFMA3(v[tq], xh, xl, w6.vh, w6.vl);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- operand planes of the attention products
-        f16x8 qH[NQ][2], qh[NQ][2], ql[NQ][2], kh[NQ][2], kl[NQ][2], vh[NQ][2], vl[NQ][2];
+        // ---- operand planes of the attention products (the accumulators hold 4096 x the value, the planes 64 x)
+        f16x8 qh[NQ][2], ql[NQ][2], kH[NQ][2], kL[NQ][2], vH[NQ][2], vL[NQ][2];
 #pragma unroll
-        for (int tq = 0; tq < NQ; tq++)
+        for (int tq = 0; tq < NQ; tq++) {
+            ab_tile_planes(q[tq], qscale * ABS_INV, qh[tq], ql[tq]);
+            ab_tile_planes(k[tq], ABS_INV, kH[tq], kL[tq]);
+            ab_tile_planes(v[tq], ABS_INV, vH[tq], vL[tq]);
+        }
+        // ---- the two heads of the pair, side by side (independent chains for the scheduler to interleave)
 #pragma unroll
-            for (int b = 0; b < 2; b++) {
-                float t8[8];
-                ab_regs8(q[tq], b, qscale * ABS_INV, t8);
-                ab_split8(t8, qh[tq][b], ql[tq][b]);
-                qH[tq][b] = ab_times_s(qh[tq][b]);
-                ab_regs8(k[tq], b, ABS_INV, t8);
-                ab_split8(t8, kh[tq][b], kl[tq][b]);
-                ab_regs8(v[tq], b, ABS_INV, t8);
-                ab_split8(t8, vh[tq][b], vl[tq][b]);
-            }
-        // ---- the two heads of the pair
+        for (int tq = 0; tq < NQ; tq++) {
+            f32x16 s[2][NQ];
 #pragma unroll
-        for (int hd = 0; hd < 2; hd++)
-#pragma unroll
-            for (int tq = 0; tq < NQ; tq++) {
-                f32x16 s[NQ];
-                float mx = -INFINITY;
+            for (int hd = 0; hd < 2; hd++)
 #pragma unroll
                 for (int tk = 0; tk < NQ; tk++) {
-                    s[tk] = ab_zero();
-                    AB_MFMA3(s[tk], kh[tk][hd], kl[tk][hd], qH[tq][hd], qh[tq][hd], ql[tq][hd]);
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        s[tk][i] = fmaf(s[tk][i], ABS_INV, bias[tk][i]);
-                        mx = fmaxf(mx, s[tk][i]);
-                    }
+                    s[hd][tk] = ab_zero();
+                    AB_MFMA3(s[hd][tk], kH[tk][hd], kL[tk][hd], qh[tq][hd], ql[tq][hd]);
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                float sum = 0.f;
+            float mx[2], sum[2];
+#pragma unroll
+            for (int hd = 0; hd < 2; hd++) {
+                mx[hd] = -INFINITY;
 #pragma unroll
                 for (int tk = 0; tk < NQ; tk++)
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
-                        const float p = __builtin_amdgcn_exp2f(s[tk][i] - mx);
-                        s[tk][i] = p;
-                        sum += p;
+                        s[hd][tk][i] = fmaf(s[hd][tk][i], ABQ_INV, bias[tk][i]);
+                        mx[hd] = fmaxf(mx[hd], s[hd][tk][i]);
                     }
-                sum += __shfl_xor(sum, 32);
-                f32x16 o = ab_zero();
+            }
+#pragma unroll
+            for (int hd = 0; hd < 2; hd++) mx[hd] = fmaxf(mx[hd], __shfl_xor(mx[hd], 32)) - 6.0f;  // p comes out as 64 p
+#pragma unroll
+            for (int hd = 0; hd < 2; hd++) {
+                sum[hd] = 0.f;
 #pragma unroll
                 for (int tk = 0; tk < NQ; tk++)
 #pragma unroll
-                    for (int b = 0; b < 2; b++) {
-                        float t8[8];
-                        ab_regs8(s[tk], b, 1.0f, t8);
-                        f16x8 ph, pl;
-                        ab_split8(t8, ph, pl);
-                        const f16x8 pH = ab_times_s(ph);
-                        AB_MFMA3(o, vh[tk][b], vl[tk][b], pH, ph, pl);
+                    for (int i = 0; i < 16; i++) {
+                        const float p = __builtin_amdgcn_exp2f(s[hd][tk][i] - mx[hd]);
+                        s[hd][tk][i] = p;
+                        sum[hd] += p;
                     }
-                const float inv = ABS_INV * __builtin_amdgcn_rcpf(sum);
-                ao[tq][4 * hp + 2 * hd] = make_float4(o[8 * hd] * inv, o[8 * hd + 1] * inv, o[8 * hd + 2] * inv,
-                                                      o[8 * hd + 3] * inv);
-                ao[tq][4 * hp + 2 * hd + 1] = make_float4(o[8 * hd + 4] * inv, o[8 * hd + 5] * inv, o[8 * hd + 6] * inv,
-                                                          o[8 * hd + 7] * inv);
             }
+#pragma unroll
+            for (int hd = 0; hd < 2; hd++) sum[hd] += __shfl_xor(sum[hd], 32);  // 64 x the soft-max denominator
+            f32x16 o[2];
+#pragma unroll
+            for (int hd = 0; hd < 2; hd++) {
+                o[hd] = ab_zero();
+#pragma unroll
+                for (int tk = 0; tk < NQ; tk++) {
+                    f16x8 ph[2], pl[2];
+                    ab_tile_planes(s[hd][tk], ph, pl);
+#pragma unroll
+                    for (int b = 0; b < 2; b++) AB_MFMA3(o[hd], vH[tk][b], vL[tk][b], ph[b], pl[b]);
+                }
+            }
+#pragma unroll
+            for (int hd = 0; hd < 2; hd++) {
+                const float inv = __builtin_amdgcn_rcpf(sum[hd]);  // o = 4096 sum(V 64 p): o / (64 denominator) = 64 AO
+                float t8[8];
+                ab_regs8(o[hd], hd, inv, t8);
+                ab_split8(t8, aoh[tq][2 * hp + hd], aol[tq][2 * hp + hd]);
+            }
+        }
     }
     // ---- output projection, bias, residual: X1 = X + Wo AO + bo (edge rows); OC = Wo AO + bo (the centre token)
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
     float* stg = reinterpret_cast<float*>(tile);  // [32][TILE_LD] staging for whole-line stores (the planes are dead)
+    f16x8 woh[2][2], wol[2][2];  // [ring slot][tile]
+#pragma unroll
+    for (int t = 0; t < 2; t++) { woh[0][t] = ab_ldw(wo.h, t * 8, lane16); wol[0][t] = ab_ldw(wo.l, t * 8, lane16); }
 #pragma unroll
     for (int tq = 0; tq < NQ; tq++) {
         if (32 * tq >= a.T) continue;
-        float sc;
-        const float inv = row_scale_pow2<16>(ao[tq], sc) * ABS_INV;
-        f16x8 ah[8], al[8];
-#pragma unroll
-        for (int kb = 0; kb < 8; kb++) {
-            const float v8[8] = {ao[tq][2 * kb].x, ao[tq][2 * kb].y, ao[tq][2 * kb].z, ao[tq][2 * kb].w,
-                                 ao[tq][2 * kb + 1].x, ao[tq][2 * kb + 1].y, ao[tq][2 * kb + 1].z, ao[tq][2 * kb + 1].w};
-            ab_split8(v8, ah[kb], al[kb]);
-        }
-        f16x8 woh[2][2], wol[2][2];  // [ring slot][tile]
-#pragma unroll
-        for (int t = 0; t < 2; t++) { woh[0][t] = wo.h[(size_t)t * 8 * 64 + L.lane]; wol[0][t] = wo.l[(size_t)t * 8 * 64 + L.lane]; }
 #pragma unroll
         for (int c = 0; c < 2; c++) {  // 64 output features at a time
-            f32x16 y[2] = {ab_zero(), ab_zero()};
+            f32x16 y[2];
+            ab_bias_tile(y[0], bo + 64 * c, L.h);
+            ab_bias_tile(y[1], bo + 64 * c + 32, L.h);
 #pragma unroll
             for (int kb = 0; kb < 8; kb++) {
-                const int nx = 8 * c + kb + 1;
-                if (nx < 16) {
+                const int nx = (8 * c + kb + 1) & 15;  // wraps to the first block for the next token tile
 #pragma unroll
-                    for (int t = 0; t < 2; t++) {
-                        const size_t wi = ((size_t)(2 * (nx >> 3) + t) * 8 + (nx & 7)) * 64 + L.lane;
-                        woh[nx & 1][t] = wo.h[wi]; wol[nx & 1][t] = wo.l[wi];
-                    }
+                for (int t = 0; t < 2; t++) {
+                    woh[(kb + 1) & 1][t] = ab_ldw(wo.h, (2 * (nx >> 3) + t) * 8 + (nx & 7), lane16);
+                    wol[(kb + 1) & 1][t] = ab_ldw(wo.l, (2 * (nx >> 3) + t) * 8 + (nx & 7), lane16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const f16x8 aH = ab_times_s(ah[kb]);
 #pragma unroll
-                for (int t = 0; t < 2; t++) AB_MFMA3(y[t], woh[kb & 1][t], wol[kb & 1][t], aH, ah[kb], al[kb]);
+                for (int t = 0; t < 2; t++) AB_MFMA3(y[t], woh[kb & 1][t], wol[kb & 1][t], aoh[tq][kb], aol[tq][kb]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            float4 bb[8];
-            ld_bias<2>(bb, bo, 64 * c, L.h);
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    float4 o4;
-                    o4.x = fmaf(y[t][4 * j], inv, bb[4 * t + j].x); o4.y = fmaf(y[t][4 * j + 1], inv, bb[4 * t + j].y);
-                    o4.z = fmaf(y[t][4 * j + 2], inv, bb[4 * t + j].z); o4.w = fmaf(y[t][4 * j + 3], inv, bb[4 * t + j].w);
-                    *reinterpret_cast<float4*>(stg + L.r * TILE_LD + 8 * (4 * t + j) + 4 * L.h) = o4;
-                }
+                for (int j = 0; j < 4; j++)
+                    *reinterpret_cast<float4*>(stg + L.r * TILE_LD + 8 * (4 * t + j) + 4 * L.h) =
+                        make_float4(y[t][4 * j] * ABQ_INV, y[t][4 * j + 1] * ABQ_INV, y[t][4 * j + 2] * ABQ_INV,
+                                    y[t][4 * j + 3] * ABQ_INV);
             __builtin_amdgcn_wave_barrier();
             // whole lines out: 16 lanes per row, four rows per instruction; the residual comes in the same shape
             const int rr = L.lane >> 4, cc = 4 * (L.lane & 15);
@@ -372,9 +394,9 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void k_ablk_fwd(
 // adjoint: (dX1 | dOC) -> dXin, key-bias gradient. Q, K, V are recomputed from the layer input X.
 //
 //   dAO  = dY Wo                                  token form; its feature form by TRANSPOSITION ON THE MATRIX CORE:
-//   a token-form tile (lane = token, regs = features) fed as the A operand against a 0/1 selection matrix comes out as
-//   C[token][feature] = lane = feature, regs = tokens; the (h, l) planes are fp16 numbers, so two MFMAs per plane move
-//   them exactly (ab_transpose). The same turns Q, K, P^T and dS^T around.
+//   a token-form tile (lane = token, regs = features) fed as the A operand against a selection matrix comes out as
+//   C[token][feature] = lane = feature, regs = tokens; the planes are fp16 numbers, so two MFMAs per plane move them
+//   exactly (ab_transpose).
 //   S^T  = K Q^T, P^T = soft-max over the keys    (as in the forward)
 //   dP^T = V dAO^T          A = V (token form),  B = dAO (token form)
 //   dS^T = P^T (dP^T - delta),  delta = sum_keys P^T dP^T
@@ -382,29 +404,29 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void k_ablk_fwd(
 //   dK^T = Q^T dS           A = Q (feature form),  B = dS (transposed tile)        -> token form
 //   dV^T = dAO^T P          A = dAO (feature form), B = P (transposed tile)        -> token form
 //   dXn^T += Wqkv^T [dQ; dK; dV]^T of the head pair, then the norm adjoint and the residual.
-// The incoming rows are scaled by ONE power of two per atom (their largest entry in [1, 2)): the sums over queries mix
+// The incoming rows are scaled by ONE power of two per atom (their largest entry in [0.25, 0.5)): the sums over queries mix
 // rows, so a per-row scale as in the row kernels would not factor out. Slots past the atom's last token get a zero
 // adjoint row, which removes them from every sum over queries.
 // ---------------------------------------------------------------------------------------------
 struct AbSel {
     f16x8 i0, i1;  // selection matrices of the two K blocks of a 32-wide tile, B-operand form
 };
-__device__ __forceinline__ AbSel ab_selectors(const RowLane& L) {
+__device__ __forceinline__ AbSel ab_selectors(const RowLane& L, float one) {
     AbSel s;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int f = 8 * (j >> 2) + 4 * L.h + (j & 3);
-        s.i0[j] = (f == L.r) ? (_Float16)1.0f : (_Float16)0.0f;
-        s.i1[j] = (16 + f == L.r) ? (_Float16)1.0f : (_Float16)0.0f;
+        s.i0[j] = (f == L.r) ? (_Float16)one : (_Float16)0.0f;
+        s.i1[j] = (16 + f == L.r) ? (_Float16)one : (_Float16)0.0f;
     }
     return s;
 }
-// planes (h[b], l[b], b = K block of the 32-wide tile) of a tile -> planes of its transpose, exactly
+// planes (index = K block of the 32-wide tile) of a tile -> planes of its transpose (times the selector's entry), exactly
 __device__ __forceinline__ void ab_transpose(const f16x8 (&h)[2], const f16x8 (&l)[2], const AbSel& sel,
                                              f16x8 (&th)[2], f16x8 (&tl)[2]) {
     f32x16 ch = ab_zero(), cl = ab_zero();
-    ch = PET_MFMA_H(h[0], sel.i0, ch); ch = PET_MFMA_H(h[1], sel.i1, ch);
-    cl = PET_MFMA_H(l[0], sel.i0, cl); cl = PET_MFMA_H(l[1], sel.i1, cl);
+    ch = PET_MFMA_H(h[0], sel.i0, ch); cl = PET_MFMA_H(l[0], sel.i0, cl);
+    ch = PET_MFMA_H(h[1], sel.i1, ch); cl = PET_MFMA_H(l[1], sel.i1, cl);
 #pragma unroll
     for (int b = 0; b < 2; b++)
 #pragma unroll
@@ -413,12 +435,12 @@ __device__ __forceinline__ void ab_transpose(const f16x8 (&h)[2], const f16x8 (&
             tl[b][j] = (_Float16)cl[8 * b + j];
         }
 }
-// the same, also returning the sum over the registers of the transposed VALUES (h + l / S): column sums of the tile
+// the same, also returning the sum over the registers of the transposed VALUES (h + l): column sums of the tile
 __device__ __forceinline__ float ab_transpose_sum(const f16x8 (&h)[2], const f16x8 (&l)[2], const AbSel& sel,
                                                   f16x8 (&th)[2], f16x8 (&tl)[2]) {
     f32x16 ch = ab_zero(), cl = ab_zero();
-    ch = PET_MFMA_H(h[0], sel.i0, ch); ch = PET_MFMA_H(h[1], sel.i1, ch);
-    cl = PET_MFMA_H(l[0], sel.i0, cl); cl = PET_MFMA_H(l[1], sel.i1, cl);
+    ch = PET_MFMA_H(h[0], sel.i0, ch); cl = PET_MFMA_H(l[0], sel.i0, cl);
+    ch = PET_MFMA_H(h[1], sel.i1, ch); cl = PET_MFMA_H(l[1], sel.i1, cl);
     float sh = 0.f, sl = 0.f;
 #pragma unroll
     for (int b = 0; b < 2; b++)
@@ -429,16 +451,7 @@ __device__ __forceinline__ float ab_transpose_sum(const f16x8 (&h)[2], const f16
             sh += ch[8 * b + j];
             sl += cl[8 * b + j];
         }
-    return fmaf(sl, ABS_INV, sh);
-}
-// (h, l) planes of the two K blocks of a C tile scaled by f
-__device__ __forceinline__ void ab_tile_planes(const f32x16& a, float f, f16x8 (&h)[2], f16x8 (&l)[2]) {
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-        float t8[8];
-        ab_regs8(a, b, f, t8);
-        ab_split8(t8, h[b], l[b]);
-    }
+    return sh + sl;
 }
 
 template <int NQ, bool LN>
@@ -449,6 +462,7 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
     int64_t E, float qscale, float scale, float* __restrict__ dXin, float* __restrict__ dbias) {
     extern __shared__ __attribute__((aligned(16))) char ab_smem[];
     const RowLane L;
+    const unsigned lane16 = (unsigned)L.lane * 16u;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = blockIdx.x * (blockDim.x >> 6) + wave;  // NQ = 2: two waves per workgroup (64 KB of LDS per wave)
     if (li >= n_list) return;
@@ -474,9 +488,11 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
             const float* src = s == 0 ? dOC + (int64_t)a.atom * D : dX1 + ((int64_t)a.start + s - 1) * D;
             glds16_trr(src + 4 * p, tile_u + NQ * 16384 + tq * 16384 + j * 1024);
         }
+    AbW4 wd[2];  // output-projection (transposed) fragments of two K blocks in flight
+    ab_ldw4<8>(wd[0], wot, 0, lane16);
     float bias[NQ][16];
     ab_key_bias<NQ>(bias, a, fc, L.h);
-    const AbSel sel = ab_selectors(L);
+    const AbSel sel1 = ab_selectors(L, 1.0f);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int tq = 0; tq < NQ; tq++) {
@@ -505,9 +521,10 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        int e = (__float_as_int(m) >> 23) & 0xff;
+        int e = ((__float_as_int(m) >> 23) & 0xff) + 2;  // largest entry of the scaled rows in [0.25, 0.5)
         e = e > 253 ? 253 : e;
-        const float sc = __int_as_float((254 - e) << 23);
+        e = e < 16 ? 16 : e;  // all-zero rows: keep the scale finite
+        const float sc = __int_as_float((254 - e) << 23) * ABS;  // ... and the planes hold 64 x that
         inv_sc = __int_as_float(e << 23);
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
@@ -516,18 +533,17 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
             f32x16 da[4] = {ab_zero(), ab_zero(), ab_zero(), ab_zero()};
 #pragma unroll
             for (int kb = 0; kb < 8; kb++) {
+                ab_ldw4<8>(wd[(kb + 1) & 1], wot, (kb + 1) & 7, lane16);
                 const float v8[8] = {d[tq][2 * kb].x * sc, d[tq][2 * kb].y * sc, d[tq][2 * kb].z * sc, d[tq][2 * kb].w * sc,
                                      d[tq][2 * kb + 1].x * sc, d[tq][2 * kb + 1].y * sc, d[tq][2 * kb + 1].z * sc,
                                      d[tq][2 * kb + 1].w * sc};
                 f16x8 dh, dl;
                 ab_split8(v8, dh, dl);
-                const f16x8 dH = ab_times_s(dh);
+                __builtin_amdgcn_sched_barrier(0);
+                const AbW4& w4 = wd[kb & 1];
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const size_t wi = ((size_t)t * 8 + kb) * 64 + L.lane;
-                    const f16x8 wh = wot.h[wi], wl = wot.l[wi];
-                    AB_MFMA3(da[t], wh, wl, dH, dh, dl);
-                }
+                for (int t = 0; t < 4; t++) AB_MFMA3(da[t], w4.h[t], w4.l[t], dh, dl);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int t = 0; t < 4; t++)
@@ -535,7 +551,7 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
                 for (int j = 0; j < 4; j++)
                     *reinterpret_cast<float4*>(tileB + tq * 16384 + ((4 * t + j) * 64 + L.lane) * 16) =
                         make_float4(da[t][4 * j] * ABS_INV, da[t][4 * j + 1] * ABS_INV, da[t][4 * j + 2] * ABS_INV,
-                                    da[t][4 * j + 3] * ABS_INV);
+                                    da[t][4 * j + 3] * ABS_INV);  // 64 dAO: what the planes are split from
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -550,60 +566,46 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
 #pragma unroll
     for (int tk = 0; tk < NQ; tk++) db[tk] = 0.f;
     constexpr float LN2 = 0.6931471805599453f;
+    AbW6 wr[2];
+    ab_ldw6(wr[0], wqkv, 0, 0, lane16);
 
 #pragma unroll 1
     for (int hp = 0; hp < 4; hp++) {
         // ---- Q^T, K^T, V^T of the head pair (token form), as in the forward
         f32x16 q[NQ], k[NQ], v[NQ];
-        {
-            float4 bq[4], bk[4], bv[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                bq[j] = *reinterpret_cast<const float4*>(bqkv + 32 * hp + 8 * j + 4 * L.h);
-                bk[j] = *reinterpret_cast<const float4*>(bqkv + D + 32 * hp + 8 * j + 4 * L.h);
-                bv[j] = *reinterpret_cast<const float4*>(bqkv + 2 * D + 32 * hp + 8 * j + 4 * L.h);
-            }
-#pragma unroll
-            for (int tq = 0; tq < NQ; tq++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    q[tq][4 * j] = bq[j].x * ABS; q[tq][4 * j + 1] = bq[j].y * ABS;
-                    q[tq][4 * j + 2] = bq[j].z * ABS; q[tq][4 * j + 3] = bq[j].w * ABS;
-                    k[tq][4 * j] = bk[j].x * ABS; k[tq][4 * j + 1] = bk[j].y * ABS;
-                    k[tq][4 * j + 2] = bk[j].z * ABS; k[tq][4 * j + 3] = bk[j].w * ABS;
-                    v[tq][4 * j] = bv[j].x * ABS; v[tq][4 * j + 1] = bv[j].y * ABS;
-                    v[tq][4 * j + 2] = bv[j].z * ABS; v[tq][4 * j + 3] = bv[j].w * ABS;
-                }
+        for (int tq = 0; tq < NQ; tq++) {
+            ab_bias_tile(q[tq], bqkv + 32 * hp, L.h);
+            ab_bias_tile(k[tq], bqkv + D + 32 * hp, L.h);
+            ab_bias_tile(v[tq], bqkv + 2 * D + 32 * hp, L.h);
         }
-        {
-            const f16x8* wqh = wqkv.h + (size_t)(hp * 8) * 64 + L.lane;
-            const f16x8* wql = wqkv.l + (size_t)(hp * 8) * 64 + L.lane;
-            constexpr size_t KOFF = (size_t)4 * 8 * 64, VOFF = (size_t)8 * 8 * 64;
+        AbW4 wx[2];  // Wqkv^T fragments of this pair's first K block, requested under the QKV products
 #pragma unroll
-            for (int kb = 0; kb < 8; kb++) {
-                const f16x8 aqh = wqh[kb * 64], aql = wql[kb * 64];
-                const f16x8 akh = wqh[KOFF + kb * 64], akl = wql[KOFF + kb * 64];
-                const f16x8 avh = wqh[VOFF + kb * 64], avl = wql[VOFF + kb * 64];
+        for (int kb = 0; kb < 8; kb++) {
+            const int nx = kb + 1;
+            if (nx < 8) ab_ldw6(wr[nx & 1], wqkv, hp, nx, lane16);
+            else ab_ldw4<24>(wx[0], wqkvt, 2 * hp, lane16);
+            __builtin_amdgcn_sched_barrier(0);
+            const AbW6& w6 = wr[kb & 1];
 #pragma unroll
-                for (int tq = 0; tq < NQ; tq++) {
-                    const char* tp = tile + tq * 16384;
-                    const f16x8 xh = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 0) * 64 + L.lane) * 16);
-                    const f16x8 xl = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 1) * 64 + L.lane) * 16);
-                    const f16x8 xH = ab_times_s(xh);
-                    AB_MFMA3(q[tq], aqh, aql, xH, xh, xl);
-                    AB_MFMA3(k[tq], akh, akl, xH, xh, xl);
-                    AB_MFMA3(v[tq], avh, avl, xH, xh, xl);
-                }
+            for (int tq = 0; tq < NQ; tq++) {
+                const char* tp = tile + tq * 16384;
+                const f16x8 xh = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 0) * 64 + L.lane) * 16);
+                const f16x8 xl = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 1) * 64 + L.lane) * 16);
+                AB_MFMA3(q[tq], w6.qh, w6.ql, xh, xl);
+                AB_MFMA3(k[tq], w6.kh, w6.kl, xh, xl);
+                AB_MFMA3(v[tq], w6.vh, w6.vl, xh, xl);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- operand planes: token form (index = head of the pair) and feature form (index = token K block)
-        f16x8 qh[NQ][2], ql[NQ][2], kh[NQ][2], kl[NQ][2], vh[NQ][2], vl[NQ][2], dah[NQ][2], dal[NQ][2];
-        f16x8 qfh[NQ][2], qfl[NQ][2], kfh[NQ][2], kfl[NQ][2], dfh[NQ][2], dfl[NQ][2];
+        f16x8 qh[NQ][2], ql[NQ][2], kH[NQ][2], kL[NQ][2], vH[NQ][2], vL[NQ][2], dah[NQ][2], dal[NQ][2];
+        f16x8 qfH[NQ][2], qfL[NQ][2], kfH[NQ][2], kfL[NQ][2], dfH[NQ][2], dfL[NQ][2];
 #pragma unroll
         for (int tq = 0; tq < NQ; tq++) {
             ab_tile_planes(q[tq], qscale * ABS_INV, qh[tq], ql[tq]);
-            ab_tile_planes(k[tq], ABS_INV, kh[tq], kl[tq]);
-            ab_tile_planes(v[tq], ABS_INV, vh[tq], vl[tq]);
+            ab_tile_planes(k[tq], ABS_INV, kH[tq], kL[tq]);
+            ab_tile_planes(v[tq], ABS_INV, vH[tq], vL[tq]);
 #pragma unroll
             for (int b = 0; b < 2; b++) {
                 const float4 d0 = *reinterpret_cast<const float4*>(tileB + tq * 16384 + ((4 * hp + 2 * b) * 64 + L.lane) * 16);
@@ -611,117 +613,135 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
                 const float v8[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
                 ab_split8(v8, dah[tq][b], dal[tq][b]);
             }
-            ab_transpose(qh[tq], ql[tq], sel, qfh[tq], qfl[tq]);
-            ab_transpose(kh[tq], kl[tq], sel, kfh[tq], kfl[tq]);
-            ab_transpose(dah[tq], dal[tq], sel, dfh[tq], dfl[tq]);
+            ab_transpose(qh[tq], ql[tq], sel1, qfH[tq], qfL[tq]);
+            ab_transpose(kH[tq], kL[tq], sel1, kfH[tq], kfL[tq]);
+            ab_transpose(dah[tq], dal[tq], sel1, dfH[tq], dfL[tq]);
         }
         f32x16 dq[NQ], dk[NQ], dv[NQ];  // token-form tiles of the pair: registers 8 hd .. 8 hd + 7 from head hd
+        f32x16 dkh[2][NQ], dvh[2][NQ];
 #pragma unroll
-        for (int hd = 0; hd < 2; hd++) {
-            f32x16 dkh[NQ], dvh[NQ];
+        for (int hd = 0; hd < 2; hd++)
 #pragma unroll
-            for (int tk = 0; tk < NQ; tk++) { dkh[tk] = ab_zero(); dvh[tk] = ab_zero(); }
+            for (int tk = 0; tk < NQ; tk++) { dkh[hd][tk] = ab_zero(); dvh[hd][tk] = ab_zero(); }
 #pragma unroll
-            for (int tq = 0; tq < NQ; tq++) {
-                f32x16 s[NQ], dp[NQ];
-                float mx = -INFINITY;
-                const f16x8 qH = ab_times_s(qh[tq][hd]);
+        for (int tq = 0; tq < NQ; tq++) {
+            // the two heads of the pair side by side
+            f32x16 s[2][NQ], dp[2][NQ];
+#pragma unroll
+            for (int hd = 0; hd < 2; hd++)
 #pragma unroll
                 for (int tk = 0; tk < NQ; tk++) {
-                    s[tk] = ab_zero();
-                    dp[tk] = ab_zero();
-                    AB_MFMA3(s[tk], kh[tk][hd], kl[tk][hd], qH, qh[tq][hd], ql[tq][hd]);
-                    const f16x8 vH = ab_times_s(vh[tk][hd]);
-                    AB_MFMA3A(dp[tk], vH, vh[tk][hd], vl[tk][hd], dah[tq][hd], dal[tq][hd]);
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        s[tk][i] = fmaf(s[tk][i], ABS_INV, bias[tk][i]);
-                        mx = fmaxf(mx, s[tk][i]);
-                    }
+                    s[hd][tk] = ab_zero();
+                    dp[hd][tk] = ab_zero();
+                    AB_MFMA3(s[hd][tk], kH[tk][hd], kL[tk][hd], qh[tq][hd], ql[tq][hd]);
+                    AB_MFMA3(dp[hd][tk], vH[tk][hd], vL[tk][hd], dah[tq][hd], dal[tq][hd]);
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                float sum = 0.f, dl = 0.f;
+            float mx[2], sum[2], dl[2];
+#pragma unroll
+            for (int hd = 0; hd < 2; hd++) {
+                mx[hd] = -INFINITY;
 #pragma unroll
                 for (int tk = 0; tk < NQ; tk++)
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
-                        const float p = __builtin_amdgcn_exp2f(s[tk][i] - mx);
-                        s[tk][i] = p;
-                        sum += p;
-                        dl = fmaf(p, dp[tk][i], dl);
+                        s[hd][tk][i] = fmaf(s[hd][tk][i], ABQ_INV, bias[tk][i]);
+                        mx[hd] = fmaxf(mx[hd], s[hd][tk][i]);
                     }
-                sum += __shfl_xor(sum, 32);
-                dl += __shfl_xor(dl, 32);
-                const float inv = __builtin_amdgcn_rcpf(sum);
-                dl *= inv * ABS_INV;  // delta of this query
-                f32x16 dqh = ab_zero();
+            }
 #pragma unroll
-                for (int tk = 0; tk < NQ; tk++) {
-                    f32x16 ds;
+            for (int hd = 0; hd < 2; hd++) mx[hd] = fmaxf(mx[hd], __shfl_xor(mx[hd], 32));
+#pragma unroll
+            for (int hd = 0; hd < 2; hd++) {
+                sum[hd] = 0.f;
+                dl[hd] = 0.f;
+#pragma unroll
+                for (int tk = 0; tk < NQ; tk++)
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
-                        const float pn = s[tk][i] * inv;
-                        s[tk][i] = pn;
-                        ds[i] = pn * fmaf(dp[tk][i], ABS_INV, -dl);
+                        const float p = __builtin_amdgcn_exp2f(s[hd][tk][i] - mx[hd]);
+                        s[hd][tk][i] = p;
+                        sum[hd] += p;
+                        dl[hd] = fmaf(p, dp[hd][tk][i], dl[hd]);
+                    }
+            }
+#pragma unroll
+            for (int hd = 0; hd < 2; hd++) {
+                sum[hd] += __shfl_xor(sum[hd], 32);
+                dl[hd] += __shfl_xor(dl[hd], 32);
+            }
+            f32x16 dqh[2];
+#pragma unroll
+            for (int hd = 0; hd < 2; hd++) {
+                const float inv = __builtin_amdgcn_rcpf(sum[hd]);
+                const float delta = dl[hd] * inv * ABQ_INV;
+                const float inv64 = inv * ABS;
+                dqh[hd] = ab_zero();
+#pragma unroll
+                for (int tk = 0; tk < NQ; tk++) {
+                    f32x16 ds;  // 64 dS^T
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const float pn = s[hd][tk][i] * inv64;  // 64 P^T
+                        s[hd][tk][i] = pn;
+                        ds[i] = pn * fmaf(dp[hd][tk][i], ABQ_INV, -delta);
                     }
                     f16x8 pth[2], ptl[2], sth[2], stl[2];
-                    ab_tile_planes(s[tk], 1.0f, pth, ptl);
-                    ab_tile_planes(ds, 1.0f, sth, stl);
+                    ab_tile_planes(s[hd][tk], pth, ptl);
+                    ab_tile_planes(ds, sth, stl);
                     // dQ^T += K^T dS^T (keys of tile tk)
 #pragma unroll
-                    for (int b = 0; b < 2; b++) {
-                        const f16x8 kH = ab_times_s(kfh[tk][b]);
-                        AB_MFMA3A(dqh, kH, kfh[tk][b], kfl[tk][b], sth[b], stl[b]);
-                    }
+                    for (int b = 0; b < 2; b++) AB_MFMA3(dqh[hd], kfH[tk][b], kfL[tk][b], sth[b], stl[b]);
                     // the (query, key) forms: P and dS with lane = key, registers = queries of tile tq
                     f16x8 ph[2], pl[2], sh[2], sl[2];
-                    ab_transpose(pth, ptl, sel, ph, pl);
-                    db[tk] += ab_transpose_sum(sth, stl, sel, sh, sl);
+                    ab_transpose(pth, ptl, sel1, ph, pl);
+                    db[tk] += ab_transpose_sum(sth, stl, sel1, sh, sl);
 #pragma unroll
                     for (int b = 0; b < 2; b++) {
-                        const f16x8 qH2 = ab_times_s(qfh[tq][b]);
-                        AB_MFMA3A(dkh[tk], qH2, qfh[tq][b], qfl[tq][b], sh[b], sl[b]);
-                        const f16x8 pH = ab_times_s(ph[b]);
-                        AB_MFMA3(dvh[tk], dfh[tq][b], dfl[tq][b], pH, ph[b], pl[b]);
+                        AB_MFMA3(dkh[hd][tk], qfH[tq][b], qfL[tq][b], sh[b], sl[b]);
+                        AB_MFMA3(dvh[hd][tk], dfH[tq][b], dfL[tq][b], ph[b], pl[b]);
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < 8; j++) dq[tq][8 * hd + j] = dqh[8 * hd + j];
             }
+#pragma unroll
+            for (int hd = 0; hd < 2; hd++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) dq[tq][8 * hd + j] = dqh[hd][8 * hd + j];
+        }
+#pragma unroll
+        for (int hd = 0; hd < 2; hd++)
 #pragma unroll
             for (int tk = 0; tk < NQ; tk++)
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    dk[tk][8 * hd + j] = dkh[tk][8 * hd + j];
-                    dv[tk][8 * hd + j] = dvh[tk][8 * hd + j];
+                    dk[tk][8 * hd + j] = dkh[hd][tk][8 * hd + j];
+                    dv[tk][8 * hd + j] = dvh[hd][tk][8 * hd + j];
                 }
-        }
         // ---- dXn^T += Wqkv^T [dQ; dK; dV]^T: K blocks 2 hp, 2 hp + 1 of each of the three parts
+        f16x8 gh[NQ][3][2], gl[NQ][3][2];
 #pragma unroll
         for (int tq = 0; tq < NQ; tq++) {
-            f16x8 gh[3][2], gl[3][2];
-            ab_tile_planes(dq[tq], scale * ABS_INV, gh[0], gl[0]);
-            ab_tile_planes(dk[tq], LN2 * ABS_INV, gh[1], gl[1]);
-            ab_tile_planes(dv[tq], ABS_INV, gh[2], gl[2]);
+            ab_tile_planes(dq[tq], scale * ABS_INV, gh[tq][0], gl[tq][0]);
+            ab_tile_planes(dk[tq], LN2 * ABS_INV, gh[tq][1], gl[tq][1]);
+            ab_tile_planes(dv[tq], ABS_INV, gh[tq][2], gl[tq][2]);
+        }
 #pragma unroll
-            for (int part = 0; part < 3; part++)
+        for (int st = 0; st < 6; st++) {
+            const int part = st >> 1, b = st & 1;
+            if (st + 1 < 6) ab_ldw4<24>(wx[(st + 1) & 1], wqkvt, 8 * ((st + 1) >> 1) + 2 * hp + ((st + 1) & 1), lane16);
+            else if (hp + 1 < 4) ab_ldw6(wr[0], wqkv, hp + 1, 0, lane16);
+            __builtin_amdgcn_sched_barrier(0);
+            const AbW4& w4 = wx[st & 1];
 #pragma unroll
-                for (int b = 0; b < 2; b++) {
-                    const int kb = 8 * part + 2 * hp + b;
+            for (int tq = 0; tq < NQ; tq++)
 #pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const size_t wi = ((size_t)t * 24 + kb) * 64 + L.lane;
-                        const f16x8 wh = wqkvt.h[wi], wl = wqkvt.l[wi];
-                        const f16x8 wH = ab_times_s(wh);
-                        AB_MFMA3A(dxn[tq][t], wH, wh, wl, gh[part][b], gl[part][b]);
-                    }
-                }
+                for (int t = 0; t < 4; t++) AB_MFMA3(dxn[tq][t], w4.h[t], w4.l[t], gh[tq][part][b], gl[tq][part][b]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // ---- key-bias gradient (summed over the heads; one writer per edge and layer)
 #pragma unroll
     for (int tk = 0; tk < NQ; tk++) {
-        const float v = (db[tk] + __shfl_xor(db[tk], 32)) * inv_sc;
+        const float v = (db[tk] + __shfl_xor(db[tk], 32)) * (inv_sc * ABS_INV);  // the transposed planes held 64 dS
         const int key = 32 * tk + L.r;
         if (L.h == 0 && key >= 1 && key < a.T) dbias[a.start + key - 1] = v;
     }
@@ -735,7 +755,7 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
         float4 w[16], x[16];
         const int64_t rw = a.row(32 * tq + L.r);
         load_rowfrag<16>(x, X, rw, D, L.h);
-        const float f = ABS_INV * inv_sc;
+        const float f = ABQ_INV * inv_sc;
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
@@ -785,6 +805,15 @@ static inline W2 w2s_fwd(const Lin& L) {
     W2 w; w.h = b; w.l = b + n8;
     return w;
 }
+static inline W2 w2s_bwd(const Lin& L) {
+    const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
+    const f16x8* b = reinterpret_cast<const f16x8*>(L.bwd2s);
+    W2 w; w.h = b; w.l = b + n8;
+    return w;
+}
+
+// whether the adjoint of this graph's attention layers runs fused (the forward of the same call sequence did, then)
+bool ablk_bwd_on(const Graph& g) { return (g_attn_fused & 2) && !(g.bucket_start[5] > g.bucket_start[4]); }
 
 // atoms of at most 64 tokens (attention tile counts 1 .. 4 of the graph's bucket lists); false = not served
 bool ablk_fwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* X, float* X1, float* OC, float scale,
@@ -813,16 +842,6 @@ bool ablk_fwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* 
     return true;
 }
 
-static inline W2 w2s_bwd(const Lin& L) {
-    const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
-    const f16x8* b = reinterpret_cast<const f16x8*>(L.bwd2s);
-    W2 w; w.h = b; w.l = b + n8;
-    return w;
-}
-
-// whether the adjoint of this graph's attention layers runs fused (the forward of the same call sequence did, then)
-bool ablk_bwd_on(const Graph& g) { return (g_attn_fused & 2) && !(g.bucket_start[5] > g.bucket_start[4]); }
-
 // dXin [E + N, D] = adjoint of the layer input; dbias [E] = key-bias gradient of this layer summed over the heads
 bool ablk_bwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* X, const float* dX1, const float* dOC,
               float* dXin, float* dbias, float scale, hipStream_t st) {
@@ -837,9 +856,9 @@ bool ablk_bwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* 
         constexpr int WPB = 4 / NQ;                                                                                  \
         const size_t lds = (size_t)WPB * NQ * 32768;                                                                 \
         allow_big_lds(k_ablk_bwd<NQ, LNF>, lds);                                                                     \
-        k_ablk_bwd<NQ, LNF><<<cdiv(CNT, WPB), 64 * WPB, lds, st>>>(X, dX1, dOC, A.g_attn, beta, wq, A.qkv.b, wot, wqt,      \
-                                                            g.rowptr, g.fc, LIST, CNT, g.n_edges, qscale, scale,     \
-                                                            dXin, dbias);                                            \
+        k_ablk_bwd<NQ, LNF><<<cdiv(CNT, WPB), 64 * WPB, lds, st>>>(X, dX1, dOC, A.g_attn, beta, wq, A.qkv.b, wot,    \
+                                                                   wqt, g.rowptr, g.fc, LIST, CNT, g.n_edges,        \
+                                                                   qscale, scale, dXin, dbias);                      \
     }
     if (n1 > 0) {
         if (ln) PET_ABLK_BWD(1, true, g.atom_order, n1) else PET_ABLK_BWD(1, false, g.atom_order, n1)
