@@ -935,6 +935,7 @@ int pet_config_set(const char* key, int value) {
     else if (k == "soap_sorted") set_soap_sorted(value);
     else if (k == "attn_lds") set_attn_lds(value);
     else if (k == "attn_fused") set_attn_fused(value);
+    else if (k == "attn_fused_prof") ablk_prof_dump();
     else if (k == "emlp_recompute") set_emlp_recompute(value);
     else if (k == "emlp_bwd_pipe") set_emlp_bwd_pipe(value);
     else if (k == "emlp_pipe") set_emlp_pipe(value);

@@ -99,6 +99,8 @@ struct Graph {
     // atoms listed by attention tile count nt = ceil((neighbours + 1) / 16): the attention kernels are launched per
     // tile count over exactly their own atoms (pet_attn.hip); bucket_start[k] = first entry of tile count k + 1
     int* atom_order = nullptr; // [N]
+    int4* atom_desc = nullptr; // [N] (atom, first CSR row, tokens = neighbours + 1, 0) in atom_order's order: one 16-B read per
+                               // attention tile instead of three dependent ones (pet_ablk.hip)
     int bucket_start[6] = {0, 0, 0, 0, 0, 0};  // host copy
     // adaptive cutoff (structures.py:225-263): CSR over ALL input edges (the root finder and its
     // implicit-function gradient see every edge within the maximum cutoff, kept or not)

@@ -294,9 +294,10 @@ __global__ void k_bucket_count(const int* __restrict__ rowptr, int n_nodes, int*
     }
 }
 __global__ void k_bucket_fill(const int* __restrict__ rowptr, int n_nodes, const int* __restrict__ counts,
-                              int* __restrict__ cursors, int* __restrict__ order) {
+                              int* __restrict__ cursors, int* __restrict__ order, int4* __restrict__ desc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = i < n_nodes ? min((rowptr[i + 1] - rowptr[i] + 1 + 15) >> 4, 5) - 1 : -1;
+    const int r0 = i < n_nodes ? rowptr[i] : 0, r1 = i < n_nodes ? rowptr[i + 1] : 0;
+    const int b = i < n_nodes ? min((r1 - r0 + 1 + 15) >> 4, 5) - 1 : -1;
     const int lane = threadIdx.x & 63;
     int start = 0;
 #pragma unroll
@@ -305,7 +306,11 @@ __global__ void k_bucket_fill(const int* __restrict__ rowptr, int n_nodes, const
         int base = 0;
         if (lane == 0 && m) base = atomicAdd(&cursors[k], __popcll(m));
         base = __shfl(base, 0);
-        if (b == k) order[start + base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        if (b == k) {
+            const int at = start + base + __popcll(m & ((1ull << lane) - 1ull));
+            order[at] = i;
+            desc[at] = make_int4(i, r0, r1 - r0 + 1, 0);
+        }
         start += counts[k];
     }
 }
@@ -313,7 +318,8 @@ static int bucket_atoms_by_tile_count(Graph& g, hipStream_t st) {  // scalars[8.
     if (g.n_nodes <= 0) return PET_OK;
     const int T = 256;
     k_bucket_count<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8);
-    k_bucket_fill<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8, g.scalars + 13, g.atom_order);
+    k_bucket_fill<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8, g.scalars + 13, g.atom_order,
+                                                     g.atom_desc);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }
@@ -529,6 +535,7 @@ static int carve_graph(Graph& g, void* ws, int64_t n_nodes, int64_t e0, size_t* 
     g.sys = c.take<int>(n_nodes);
     g.scalars = c.take<int>(24);
     g.atom_order = c.take<int>(n_nodes > 0 ? n_nodes : 1);
+    g.atom_desc = c.take<int4>(n_nodes > 0 ? n_nodes : 1);
     g.rowptr0 = c.take<int>(n_nodes + 1);
     g.perm0 = c.take<int>(e0);
     g.nbr0 = c.take<int>(e0);
@@ -764,6 +771,7 @@ static int carve_from_batch(Graph& g, void* ws, int64_t n_nodes, int64_t M, size
     g.fc = c.take<float>(cap);
     g.scalars = c.take<int>(24);
     g.atom_order = c.take<int>(n_nodes > 0 ? n_nodes : 1);
+    g.atom_desc = c.take<int4>(n_nodes > 0 ? n_nodes : 1);
     size_t scan_bytes = 0;
     int* ni = nullptr;
     if (rocprim::exclusive_scan(nullptr, scan_bytes, ni, ni, 0, (size_t)(n_nodes + 1), rocprim::plus<int>()) != hipSuccess)

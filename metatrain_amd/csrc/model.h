@@ -296,6 +296,7 @@ bool trr_comb_bwd(const float* dM, const float* XF, const Graph& g, const GnnLay
 // adjoint recomputing Q, K, V); false = not served (an atom of more than 64 tokens, planes missing, switched off)
 void set_attn_fused(int v);
 int attn_fused();
+void ablk_prof_dump();  // debugging aid: per-phase cycle sums of the fused kernels (library built with -DAB_PROFILE)
 bool ablk_fwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* X, float* X1, float* OC, float scale,
               hipStream_t st);
 bool ablk_bwd_on(const Graph& g);

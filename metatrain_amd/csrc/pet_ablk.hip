@@ -125,11 +125,31 @@ __device__ __forceinline__ void ab_ldw4(AbW4& w, const W2& wt, int kb, unsigned 
     for (int t = 0; t < 4; t++) { w.h[t] = ab_ldw(wt.h, t * KB + kb, lane16); w.l[t] = ab_ldw(wt.l, t * KB + kb, lane16); }
 }
 
+#ifdef AB_PROFILE
+// debugging aid (build with -DAB_PROFILE): shader cycles per phase, summed over the waves of every launch
+__device__ unsigned long long ab_prof[32];
+#define AB_T(i)                                                                              \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
+        if (threadIdx.x % 64 == 0) atomicAdd(&ab_prof[(i)], t_ - ab_t0);                     \
+        ab_t0 = __builtin_amdgcn_s_memtime();                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#define AB_T0() unsigned long long ab_t0 = __builtin_amdgcn_s_memtime()
+#else
+#define AB_T(i)
+#define AB_T0()
+#endif
+
 // token slot s of the atom: 0 = the centre token (row E + atom of the token stream), s >= 1 neighbour s - 1; slots past
 // the atom's last token repeat it (their results are never stored and, as keys, are masked)
 struct AbAtom {
     int atom, start, T;
     int64_t E;
+    __device__ __forceinline__ AbAtom(const int4 d, int64_t e)  // Graph::atom_desc entry: (atom, first CSR row, tokens, -)
+        : atom(__builtin_amdgcn_readfirstlane(d.x)), start(__builtin_amdgcn_readfirstlane(d.y)),
+          T(__builtin_amdgcn_readfirstlane(d.z)), E(e) {}
     __device__ __forceinline__ int64_t row(int s) const {
         s = s < T ? s : T - 1;
         return s == 0 ? E + atom : (int64_t)start + s - 1;
@@ -190,34 +210,118 @@ __device__ __forceinline__ void ab_bias_tile(f32x16& acc, const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// The weight stream, shared by the waves of a workgroup. Every wave needs the same weight fragments at (about) the
+// same time -- a tile is 32 token slots whatever the atom's size -- and a wave of its own streams 260 KB of them from
+// L2 per tile: measured, the forward's QKV phase took exactly as long with its MFMAs removed as with them (the L2 ->
+// CU path was the bound, 25 TB/s). So the workgroup fetches each "stage" (a few KB of fragments) ONCE, by LDS-DMA into
+// a two-slot ring; fragments are lane-linear 1-KB pieces, which is exactly the LDS image a ds_read_b128 per lane wants.
+//   stage g:  wait for the own pieces of stage g  ->  barrier (stage g landed for everybody, everybody is done with
+//             stage g - 1's slot)  ->  request stage g + 1 into that slot  ->  the products of stage g.
+// One barrier per 18 .. 24 MFMAs of a wave; waves whose tile index is past the list run along on the last tile (same
+// barrier count) and store nothing.
+// ---------------------------------------------------------------------------------------------
+constexpr int AB_SLOT = 12288;  // bytes of a ring slot: two QKV K blocks (2 x 6 fragments) or two Wo steps (2 x 4)
+__device__ __forceinline__ void ab_dma_piece(const f16x8* plane, int idx, unsigned lane16, unsigned lds_dst) {
+    const char* base = reinterpret_cast<const char*>(plane + (size_t)idx * 64);
+    glds16_trr(reinterpret_cast<const float*>(base + lane16), lds_dst);
+}
+// forward stages 0 .. 15: QKV blocks (hp = g / 4, kb = 2 (g % 4) + j), pieces j * 6 + {Qh, Ql, Kh, Kl, Vh, Vl};
+// stages 16 .. 23: Wo steps n = 2 (g - 16) + j (c = n / 8, kb = n % 8), pieces j * 4 + {tile 2c h, l, tile 2c + 1 h, l}
+template <int NW>
+__device__ __forceinline__ void ab_fwd_request(int g, const W2& wqkv, const W2& wo, unsigned ring_u, int wave,
+                                               unsigned lane16) {
+    const unsigned dst = ring_u + (unsigned)(g & 1) * AB_SLOT;
+    if (g < 16) {
+        const int hp = g >> 2, kb0 = 2 * (g & 3);
+#pragma unroll
+        for (int p0 = 0; p0 < 12; p0 += NW) {
+            const int p = p0 + wave;
+            if (p < 12) {
+                const int j = p / 6, f = p % 6;
+                ab_dma_piece((f & 1) ? wqkv.l : wqkv.h, 32 * (f >> 1) + hp * 8 + kb0 + j, lane16, dst + p * 1024);
+            }
+        }
+    } else {
+        const int n0 = 2 * (g - 16);
+        const int p = wave;  // 8 pieces
+        if (p < 8) {
+            const int n = n0 + (p >> 2), f = p & 3;
+            ab_dma_piece((f & 1) ? wo.l : wo.h, (2 * (n >> 3) + (f >> 1)) * 8 + (n & 7), lane16, dst + p * 1024);
+        }
+        if (NW < 8 && wave + 4 < 8) {
+            const int p2 = wave + 4;
+            const int n = n0 + (p2 >> 2), f = p2 & 3;
+            ab_dma_piece((f & 1) ? wo.l : wo.h, (2 * (n >> 3) + (f >> 1)) * 8 + (n & 7), lane16, dst + p2 * 1024);
+        }
+    }
+}
+// adjoint stages (slots of 16 KB): 0 .. 3 Wo^T blocks (kb = 2 g + j: 8 fragments each); then per head pair seven stages:
+// four QKV stages as in the forward, three Wqkv^T stages (steps st = 2 x + j: K block 8 (st / 2) + 2 hp + st % 2, 8 fragments)
+constexpr int AB_SLOT_B = 16384;
+template <int NW>
+__device__ __forceinline__ void ab_bwd_request(int g, const W2& wqkv, const W2& wot, const W2& wqkvt, unsigned ring_u,
+                                               int wave, unsigned lane16) {
+    const unsigned dst = ring_u + (unsigned)(g & 1) * AB_SLOT_B;
+    const int r = g < 4 ? -1 : (g - 4) % 7, hp = g < 4 ? 0 : (g - 4) / 7;
+    if (r >= 0 && r < 4) {  // QKV: 12 pieces
+        const int kb0 = 2 * r;
+#pragma unroll
+        for (int p0 = 0; p0 < 12; p0 += NW) {
+            const int p = p0 + wave;
+            if (p < 12) {
+                const int j = p / 6, f = p % 6;
+                ab_dma_piece((f & 1) ? wqkv.l : wqkv.h, 32 * (f >> 1) + hp * 8 + kb0 + j, lane16, dst + p * 1024);
+            }
+        }
+    } else {  // 16 pieces: j * 8 + 2 t + plane
+#pragma unroll
+        for (int p0 = 0; p0 < 16; p0 += NW) {
+            const int p = p0 + wave;
+            const int j = p >> 3, t = (p >> 1) & 3, pl = p & 1;
+            if (r < 0) {
+                ab_dma_piece(pl ? wot.l : wot.h, t * 8 + 2 * g + j, lane16, dst + p * 1024);
+            } else {
+                const int st = 2 * (r - 4) + j;
+                ab_dma_piece(pl ? wqkvt.l : wqkvt.h, t * 24 + 8 * (st >> 1) + 2 * hp + (st & 1), lane16, dst + p * 1024);
+            }
+        }
+    }
+}
+#define AB_STAGE_SYNC()                                   \
+    do {                                                  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
+        __syncthreads();                                  \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
 template <int NQ, bool LN>
-__global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void k_ablk_fwd(
+__global__ __launch_bounds__(NQ == 1 ? 512 : 256) void k_ablk_fwd(
     const float* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta, W2 wqkv,
-    const float* __restrict__ bqkv, W2 wo, const float* __restrict__ bo, const int* __restrict__ rowptr,
-    const float* __restrict__ fc, const int* __restrict__ atoms, int n_list, int64_t E, float qscale,
-    float* __restrict__ X1, float* __restrict__ OC) {
+    const float* __restrict__ bqkv, W2 wo, const float* __restrict__ bo, const float* __restrict__ fc,
+    const int4* __restrict__ desc, int n_list, int64_t E, float qscale, float* __restrict__ X1, float* __restrict__ OC) {
+    constexpr int NW = NQ == 1 ? 8 : 4;  // waves per workgroup: NW x NQ x 16 KB of row planes + the 24 KB ring
     extern __shared__ __attribute__((aligned(16))) char ab_smem[];
     const RowLane L;
     const unsigned lane16 = (unsigned)L.lane * 16u;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int li = blockIdx.x * 4 + wave;
-    if (li >= n_list) return;
-    AbAtom a;
-    a.atom = atoms[li];
-    a.start = rowptr[a.atom];
-    a.T = rowptr[a.atom + 1] - a.start + 1;
-    a.E = E;
+    int li = blockIdx.x * NW + wave;
+    const bool live = li < n_list;
+    li = live ? li : n_list - 1;
+    const AbAtom a(desc[li], E);
     char* tile = ab_smem + wave * (NQ * 16384);
+    const char* ring = ab_smem + NW * NQ * 16384;
     const unsigned tile_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile);
+    const unsigned ring_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+    AB_T0();
     ab_dma_rows<NQ>(X, a, tile_u, L);
-    AbW6 wr[2];  // weight fragments of two K blocks in flight
-    ab_ldw6(wr[0], wqkv, 0, 0, lane16);
+    ab_fwd_request<NW>(0, wqkv, wo, ring_u, wave, lane16);
     float bias[NQ][16];
     ab_key_bias<NQ>(bias, a, fc, L.h);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // rows -> normalised -> plain planes, parked over the fp32 tile they came from
+    AB_T(0);
+    // rows -> normalised -> planes, parked over the fp32 tile they came from
 #pragma unroll
     for (int tq = 0; tq < NQ; tq++) {
         float4 x[16];
@@ -230,6 +334,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void k_ablk_fwd(
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
 
+    AB_T(1);
     f16x8 aoh[NQ][8], aol[NQ][8];  // attention output: planes of the row fragment, K block = head
 #pragma unroll
     for (int hp = 0; hp < 4; hp++) {  // unrolled: the planes are indexed with hp (a run-time index would go to scratch)
@@ -246,24 +351,32 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void k_ablk_fwd(
             }
         }
 #pragma unroll
-        for (int kb = 0; kb < 8; kb++) {
-            // the next K block's fragments (the next head pair's first block behind the last one) are requested before
-            // this block's MFMAs; left to itself the compiler requests a block right in front of its own MFMAs
-            const int nx = 8 * hp + kb + 1;
-            if (nx < 32) ab_ldw6(wr[nx & 1], wqkv, nx >> 3, nx & 7, lane16);
-            __builtin_amdgcn_sched_barrier(0);
-            const AbW6& w6 = wr[kb & 1];
+        for (int sg = 0; sg < 4; sg++) {
+            const int g = 4 * hp + sg;
+            AB_STAGE_SYNC();
+            ab_fwd_request<NW>(g + 1, wqkv, wo, ring_u, wave, lane16);
+            const char* slot = ring + (g & 1) * AB_SLOT + lane16;
 #pragma unroll
-            for (int tq = 0; tq < NQ; tq++) {
-                const char* tp = tile + tq * 16384;
-                const f16x8 xh = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 0) * 64 + L.lane) * 16);
-                const f16x8 xl = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 1) * 64 + L.lane) * 16);
-                AB_MFMA3(q[tq], w6.qh, w6.ql, xh, xl);
-                AB_MFMA3(k[tq], w6.kh, w6.kl, xh, xl);
-                AB_MFMA3(v[tq], xh, xl, w6.vh, w6.vl);
+            for (int j = 0; j < 2; j++) {
+                const int kb = 2 * sg + j;
+                const f16x8 wqh = *reinterpret_cast<const f16x8*>(slot + (6 * j + 0) * 1024);
+                const f16x8 wql = *reinterpret_cast<const f16x8*>(slot + (6 * j + 1) * 1024);
+                const f16x8 wkh = *reinterpret_cast<const f16x8*>(slot + (6 * j + 2) * 1024);
+                const f16x8 wkl = *reinterpret_cast<const f16x8*>(slot + (6 * j + 3) * 1024);
+                const f16x8 wvh = *reinterpret_cast<const f16x8*>(slot + (6 * j + 4) * 1024);
+                const f16x8 wvl = *reinterpret_cast<const f16x8*>(slot + (6 * j + 5) * 1024);
+#pragma unroll
+                for (int tq = 0; tq < NQ; tq++) {
+                    const char* tp = tile + tq * 16384;
+                    const f16x8 xh = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 0) * 64 + L.lane) * 16);
+                    const f16x8 xl = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 1) * 64 + L.lane) * 16);
+                    AB_MFMA3(q[tq], wqh, wql, xh, xl);
+                    AB_MFMA3(k[tq], wkh, wkl, xh, xl);
+                    AB_MFMA3(v[tq], xh, xl, wvh, wvl);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
+        AB_T(2);
         // ---- operand planes of the attention products (the accumulators hold 4096 x the value, the planes 64 x)
         f16x8 qh[NQ][2], ql[NQ][2], kH[NQ][2], kL[NQ][2], vH[NQ][2], vL[NQ][2];
 #pragma unroll
@@ -272,6 +385,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void k_ablk_fwd(
             ab_tile_planes(k[tq], ABS_INV, kH[tq], kL[tq]);
             ab_tile_planes(v[tq], ABS_INV, vH[tq], vL[tq]);
         }
+        AB_T(3);
         // ---- the two heads of the pair, side by side (independent chains for the scheduler to interleave)
 #pragma unroll
         for (int tq = 0; tq < NQ; tq++) {
@@ -331,62 +445,76 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void k_ablk_fwd(
                 ab_split8(t8, aoh[tq][2 * hp + hd], aol[tq][2 * hp + hd]);
             }
         }
+        AB_T(4);
     }
-    // ---- output projection, bias, residual: X1 = X + Wo AO + bo (edge rows); OC = Wo AO + bo (the centre token)
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-    float* stg = reinterpret_cast<float*>(tile);  // [32][TILE_LD] staging for whole-line stores (the planes are dead)
-    f16x8 woh[2][2], wol[2][2];  // [ring slot][tile]
+    // ---- output projection, bias, residual: X1 = X + Wo AO + bo (edge rows); OC = Wo AO + bo (the centre token).
+    // Both token tiles share a stage's fragments; the staging tile for whole-line stores is the wave's own (dead) planes.
+    float* stg = reinterpret_cast<float*>(tile);  // [32][TILE_LD]
+    const int rr = L.lane >> 4, cc = 4 * (L.lane & 15);
 #pragma unroll
-    for (int t = 0; t < 2; t++) { woh[0][t] = ab_ldw(wo.h, t * 8, lane16); wol[0][t] = ab_ldw(wo.l, t * 8, lane16); }
+    for (int c = 0; c < 2; c++) {  // 64 output features at a time
+        float4 xr[NQ][8];  // the residual rows of this half in the store's shape, requested before the products
 #pragma unroll
-    for (int tq = 0; tq < NQ; tq++) {
-        if (32 * tq >= a.T) continue;
+        for (int tq = 0; tq < NQ; tq++)
 #pragma unroll
-        for (int c = 0; c < 2; c++) {  // 64 output features at a time
-            f32x16 y[2];
-            ab_bias_tile(y[0], bo + 64 * c, L.h);
-            ab_bias_tile(y[1], bo + 64 * c + 32, L.h);
+            for (int j = 0; j < 8; j++) {
+                const int s = 32 * tq + 4 * j + rr;
+                xr[tq][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (s >= 1 && s < a.T) xr[tq][j] = *reinterpret_cast<const float4*>(X + ((int64_t)a.start + s - 1) * D + 64 * c + cc);
+            }
+        f32x16 y[NQ][2];
 #pragma unroll
-            for (int kb = 0; kb < 8; kb++) {
-                const int nx = (8 * c + kb + 1) & 15;  // wraps to the first block for the next token tile
+        for (int tq = 0; tq < NQ; tq++) {
+            ab_bias_tile(y[tq][0], bo + 64 * c, L.h);
+            ab_bias_tile(y[tq][1], bo + 64 * c + 32, L.h);
+        }
+#pragma unroll
+        for (int sg = 0; sg < 4; sg++) {
+            const int g = 16 + 4 * c + sg;
+            AB_STAGE_SYNC();
+            if (g + 1 < 24) ab_fwd_request<NW>(g + 1, wqkv, wo, ring_u, wave, lane16);
+            const char* slot = ring + (g & 1) * AB_SLOT + lane16;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int kb = 2 * sg + j;
+                f16x8 wh[2], wl[2];
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
-                    woh[(kb + 1) & 1][t] = ab_ldw(wo.h, (2 * (nx >> 3) + t) * 8 + (nx & 7), lane16);
-                    wol[(kb + 1) & 1][t] = ab_ldw(wo.l, (2 * (nx >> 3) + t) * 8 + (nx & 7), lane16);
+                    wh[t] = *reinterpret_cast<const f16x8*>(slot + (4 * j + 2 * t) * 1024);
+                    wl[t] = *reinterpret_cast<const f16x8*>(slot + (4 * j + 2 * t + 1) * 1024);
                 }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 2; t++) AB_MFMA3(y[t], woh[kb & 1][t], wol[kb & 1][t], aoh[tq][kb], aol[tq][kb]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int tq = 0; tq < NQ; tq++)
+#pragma unroll
+                    for (int t = 0; t < 2; t++) AB_MFMA3(y[tq][t], wh[t], wl[t], aoh[tq][kb], aol[tq][kb]);
             }
+        }
+        AB_T(5);
+#pragma unroll
+        for (int tq = 0; tq < NQ; tq++) {
+            if (32 * tq >= a.T) continue;
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     *reinterpret_cast<float4*>(stg + L.r * TILE_LD + 8 * (4 * t + j) + 4 * L.h) =
-                        make_float4(y[t][4 * j] * ABQ_INV, y[t][4 * j + 1] * ABQ_INV, y[t][4 * j + 2] * ABQ_INV,
-                                    y[t][4 * j + 3] * ABQ_INV);
+                        make_float4(y[tq][t][4 * j] * ABQ_INV, y[tq][t][4 * j + 1] * ABQ_INV, y[tq][t][4 * j + 2] * ABQ_INV,
+                                    y[tq][t][4 * j + 3] * ABQ_INV);
             __builtin_amdgcn_wave_barrier();
-            // whole lines out: 16 lanes per row, four rows per instruction; the residual comes in the same shape
-            const int rr = L.lane >> 4, cc = 4 * (L.lane & 15);
+            // whole lines out: 16 lanes per row, four rows per instruction
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int r = 4 * j + rr, s = 32 * tq + r;
-                if (s < a.T) {
+                if (live && s < a.T) {
                     float4 o4 = *reinterpret_cast<const float4*>(stg + r * TILE_LD + cc);
-                    if (s == 0) {
-                        *reinterpret_cast<float4*>(OC + (int64_t)a.atom * D + 64 * c + cc) = o4;
-                    } else {
-                        const int64_t row = (int64_t)a.start + s - 1;
-                        const float4 xr = *reinterpret_cast<const float4*>(X + row * D + 64 * c + cc);
-                        o4.x += xr.x; o4.y += xr.y; o4.z += xr.z; o4.w += xr.w;
-                        *reinterpret_cast<float4*>(X1 + row * D + 64 * c + cc) = o4;
-                    }
+                    o4.x += xr[tq][j].x; o4.y += xr[tq][j].y; o4.z += xr[tq][j].z; o4.w += xr[tq][j].w;
+                    float* dst = s == 0 ? OC + (int64_t)a.atom * D : X1 + ((int64_t)a.start + s - 1) * D;
+                    *reinterpret_cast<float4*>(dst + 64 * c + cc) = o4;
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
+        AB_T(6);
     }
 }
 
@@ -458,23 +586,24 @@ template <int NQ, bool LN>
 __global__ __launch_bounds__(256) void k_ablk_bwd(
     const float* __restrict__ X, const float* __restrict__ dX1, const float* __restrict__ dOC,
     const float* __restrict__ gamma, const float* __restrict__ beta, W2 wqkv, const float* __restrict__ bqkv, W2 wot,
-    W2 wqkvt, const int* __restrict__ rowptr, const float* __restrict__ fc, const int* __restrict__ atoms, int n_list,
-    int64_t E, float qscale, float scale, float* __restrict__ dXin, float* __restrict__ dbias) {
+    W2 wqkvt, const float* __restrict__ fc, const int4* __restrict__ desc, int n_list, int64_t E, float qscale, float scale,
+    float* __restrict__ dXin, float* __restrict__ dbias) {
     extern __shared__ __attribute__((aligned(16))) char ab_smem[];
     const RowLane L;
     const unsigned lane16 = (unsigned)L.lane * 16u;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int li = blockIdx.x * (blockDim.x >> 6) + wave;  // NQ = 2: two waves per workgroup (64 KB of LDS per wave)
-    if (li >= n_list) return;
-    AbAtom a;
-    a.atom = atoms[li];
-    a.start = rowptr[a.atom];
-    a.T = rowptr[a.atom + 1] - a.start + 1;
-    a.E = E;
+    constexpr int NW = 4 / NQ;  // waves per workgroup: NW x NQ x 32 KB of tiles + the 32 KB ring = all of the CU's LDS
+    int li = blockIdx.x * NW + wave;
+    const bool live = li < n_list;
+    li = live ? li : n_list - 1;
+    const AbAtom a(desc[li], E);
     // per wave: NQ x 16 KB planes of the normalised rows | NQ x 16 KB incoming adjoint rows, then dAO (row fragments)
     char* tile = ab_smem + wave * (NQ * 32768);
     char* tileB = tile + NQ * 16384;
+    const char* ring = ab_smem + NW * NQ * 32768;
     const unsigned tile_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile);
+    const unsigned ring_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+    AB_T0();
     ab_dma_rows<NQ>(X, a, tile_u, L);
     // incoming adjoint: dX1 rows of the neighbours, dOC row of the centre token
 #pragma unroll
@@ -488,12 +617,12 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
             const float* src = s == 0 ? dOC + (int64_t)a.atom * D : dX1 + ((int64_t)a.start + s - 1) * D;
             glds16_trr(src + 4 * p, tile_u + NQ * 16384 + tq * 16384 + j * 1024);
         }
-    AbW4 wd[2];  // output-projection (transposed) fragments of two K blocks in flight
-    ab_ldw4<8>(wd[0], wot, 0, lane16);
+    ab_bwd_request<NW>(0, wqkv, wot, wqkvt, ring_u, wave, lane16);
     float bias[NQ][16];
     ab_key_bias<NQ>(bias, a, fc, L.h);
     const AbSel sel1 = ab_selectors(L, 1.0f);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AB_T(8);
 #pragma unroll
     for (int tq = 0; tq < NQ; tq++) {
         float4 x[16];
@@ -503,6 +632,7 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
         asm volatile("" ::: "memory");
         ab_park_planes(x, tile + tq * 16384, L);
     }
+    AB_T(9);
     // ---- dAO = dY Wo (token form), parked as row fragments [kg][lane] over the rows it came from
     float inv_sc;  // inverse of the atom's power-of-two scale
     {
@@ -528,35 +658,51 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
         inv_sc = __int_as_float(e << 23);
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
+        f32x16 da[NQ][4];
 #pragma unroll
-        for (int tq = 0; tq < NQ; tq++) {
-            f32x16 da[4] = {ab_zero(), ab_zero(), ab_zero(), ab_zero()};
+        for (int tq = 0; tq < NQ; tq++)
 #pragma unroll
-            for (int kb = 0; kb < 8; kb++) {
-                ab_ldw4<8>(wd[(kb + 1) & 1], wot, (kb + 1) & 7, lane16);
-                const float v8[8] = {d[tq][2 * kb].x * sc, d[tq][2 * kb].y * sc, d[tq][2 * kb].z * sc, d[tq][2 * kb].w * sc,
-                                     d[tq][2 * kb + 1].x * sc, d[tq][2 * kb + 1].y * sc, d[tq][2 * kb + 1].z * sc,
-                                     d[tq][2 * kb + 1].w * sc};
-                f16x8 dh, dl;
-                ab_split8(v8, dh, dl);
-                __builtin_amdgcn_sched_barrier(0);
-                const AbW4& w4 = wd[kb & 1];
+            for (int t = 0; t < 4; t++) da[tq][t] = ab_zero();
 #pragma unroll
-                for (int t = 0; t < 4; t++) AB_MFMA3(da[t], w4.h[t], w4.l[t], dh, dl);
-                __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < 4; g++) {
+            AB_STAGE_SYNC();
+            ab_bwd_request<NW>(g + 1, wqkv, wot, wqkvt, ring_u, wave, lane16);
+            const char* slot = ring + (g & 1) * AB_SLOT_B + lane16;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int kb = 2 * g + j;
+                f16x8 wh[4], wl[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    wh[t] = *reinterpret_cast<const f16x8*>(slot + (8 * j + 2 * t) * 1024);
+                    wl[t] = *reinterpret_cast<const f16x8*>(slot + (8 * j + 2 * t + 1) * 1024);
+                }
+#pragma unroll
+                for (int tq = 0; tq < NQ; tq++) {
+                    const float v8[8] = {d[tq][2 * kb].x * sc, d[tq][2 * kb].y * sc, d[tq][2 * kb].z * sc, d[tq][2 * kb].w * sc,
+                                         d[tq][2 * kb + 1].x * sc, d[tq][2 * kb + 1].y * sc, d[tq][2 * kb + 1].z * sc,
+                                         d[tq][2 * kb + 1].w * sc};
+                    f16x8 dh, dl;
+                    ab_split8(v8, dh, dl);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) AB_MFMA3(da[tq][t], wh[t], wl[t], dh, dl);
+                }
             }
+        }
+#pragma unroll
+        for (int tq = 0; tq < NQ; tq++)
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     *reinterpret_cast<float4*>(tileB + tq * 16384 + ((4 * t + j) * 64 + L.lane) * 16) =
-                        make_float4(da[t][4 * j] * ABS_INV, da[t][4 * j + 1] * ABS_INV, da[t][4 * j + 2] * ABS_INV,
-                                    da[t][4 * j + 3] * ABS_INV);  // 64 dAO: what the planes are split from
-        }
+                        make_float4(da[tq][t][4 * j] * ABS_INV, da[tq][t][4 * j + 1] * ABS_INV, da[tq][t][4 * j + 2] * ABS_INV,
+                                    da[tq][t][4 * j + 3] * ABS_INV);  // 64 dAO: what the planes are split from
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
 
+    AB_T(10);
     f32x16 dxn[NQ][4];
 #pragma unroll
     for (int tq = 0; tq < NQ; tq++)
@@ -566,11 +712,11 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
 #pragma unroll
     for (int tk = 0; tk < NQ; tk++) db[tk] = 0.f;
     constexpr float LN2 = 0.6931471805599453f;
-    AbW6 wr[2];
-    ab_ldw6(wr[0], wqkv, 0, 0, lane16);
+    float4 xin[NQ][16];
 
 #pragma unroll 1
     for (int hp = 0; hp < 4; hp++) {
+        const int gbase = 4 + 7 * hp;
         // ---- Q^T, K^T, V^T of the head pair (token form), as in the forward
         f32x16 q[NQ], k[NQ], v[NQ];
 #pragma unroll
@@ -579,25 +725,33 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
             ab_bias_tile(k[tq], bqkv + D + 32 * hp, L.h);
             ab_bias_tile(v[tq], bqkv + 2 * D + 32 * hp, L.h);
         }
-        AbW4 wx[2];  // Wqkv^T fragments of this pair's first K block, requested under the QKV products
 #pragma unroll
-        for (int kb = 0; kb < 8; kb++) {
-            const int nx = kb + 1;
-            if (nx < 8) ab_ldw6(wr[nx & 1], wqkv, hp, nx, lane16);
-            else ab_ldw4<24>(wx[0], wqkvt, 2 * hp, lane16);
-            __builtin_amdgcn_sched_barrier(0);
-            const AbW6& w6 = wr[kb & 1];
+        for (int sg = 0; sg < 4; sg++) {
+            const int g = gbase + sg;
+            AB_STAGE_SYNC();
+            ab_bwd_request<NW>(g + 1, wqkv, wot, wqkvt, ring_u, wave, lane16);
+            const char* slot = ring + (g & 1) * AB_SLOT_B + lane16;
 #pragma unroll
-            for (int tq = 0; tq < NQ; tq++) {
-                const char* tp = tile + tq * 16384;
-                const f16x8 xh = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 0) * 64 + L.lane) * 16);
-                const f16x8 xl = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 1) * 64 + L.lane) * 16);
-                AB_MFMA3(q[tq], w6.qh, w6.ql, xh, xl);
-                AB_MFMA3(k[tq], w6.kh, w6.kl, xh, xl);
-                AB_MFMA3(v[tq], w6.vh, w6.vl, xh, xl);
+            for (int j = 0; j < 2; j++) {
+                const int kb = 2 * sg + j;
+                const f16x8 wqh = *reinterpret_cast<const f16x8*>(slot + (6 * j + 0) * 1024);
+                const f16x8 wql = *reinterpret_cast<const f16x8*>(slot + (6 * j + 1) * 1024);
+                const f16x8 wkh = *reinterpret_cast<const f16x8*>(slot + (6 * j + 2) * 1024);
+                const f16x8 wkl = *reinterpret_cast<const f16x8*>(slot + (6 * j + 3) * 1024);
+                const f16x8 wvh = *reinterpret_cast<const f16x8*>(slot + (6 * j + 4) * 1024);
+                const f16x8 wvl = *reinterpret_cast<const f16x8*>(slot + (6 * j + 5) * 1024);
+#pragma unroll
+                for (int tq = 0; tq < NQ; tq++) {
+                    const char* tp = tile + tq * 16384;
+                    const f16x8 xh = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 0) * 64 + L.lane) * 16);
+                    const f16x8 xl = *reinterpret_cast<const f16x8*>(tp + ((kb * 2 + 1) * 64 + L.lane) * 16);
+                    AB_MFMA3(q[tq], wqh, wql, xh, xl);
+                    AB_MFMA3(k[tq], wkh, wkl, xh, xl);
+                    AB_MFMA3(v[tq], wvh, wvl, xh, xl);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
+        AB_T(11);
         // ---- operand planes: token form (index = head of the pair) and feature form (index = token K block)
         f16x8 qh[NQ][2], ql[NQ][2], kH[NQ][2], kL[NQ][2], vH[NQ][2], vL[NQ][2], dah[NQ][2], dal[NQ][2];
         f16x8 qfH[NQ][2], qfL[NQ][2], kfH[NQ][2], kfL[NQ][2], dfH[NQ][2], dfL[NQ][2];
@@ -617,6 +771,7 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
             ab_transpose(kH[tq], kL[tq], sel1, kfH[tq], kfL[tq]);
             ab_transpose(dah[tq], dal[tq], sel1, dfH[tq], dfL[tq]);
         }
+        AB_T(12);
         f32x16 dq[NQ], dk[NQ], dv[NQ];  // token-form tiles of the pair: registers 8 hd .. 8 hd + 7 from head hd
         f32x16 dkh[2][NQ], dvh[2][NQ];
 #pragma unroll
@@ -716,6 +871,11 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
                     dk[tk][8 * hd + j] = dkh[hd][tk][8 * hd + j];
                     dv[tk][8 * hd + j] = dvh[hd][tk][8 * hd + j];
                 }
+        AB_T(13);
+        if (hp == 3) {  // the norm adjoint's input rows: requested under the last products
+#pragma unroll
+            for (int tq = 0; tq < NQ; tq++) load_rowfrag<16>(xin[tq], X, a.row(32 * tq + L.r), D, L.h);
+        }
         // ---- dXn^T += Wqkv^T [dQ; dK; dV]^T: K blocks 2 hp, 2 hp + 1 of each of the three parts
         f16x8 gh[NQ][3][2], gl[NQ][3][2];
 #pragma unroll
@@ -725,25 +885,35 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
             ab_tile_planes(dv[tq], ABS_INV, gh[tq][2], gl[tq][2]);
         }
 #pragma unroll
-        for (int st = 0; st < 6; st++) {
-            const int part = st >> 1, b = st & 1;
-            if (st + 1 < 6) ab_ldw4<24>(wx[(st + 1) & 1], wqkvt, 8 * ((st + 1) >> 1) + 2 * hp + ((st + 1) & 1), lane16);
-            else if (hp + 1 < 4) ab_ldw6(wr[0], wqkv, hp + 1, 0, lane16);
-            __builtin_amdgcn_sched_barrier(0);
-            const AbW4& w4 = wx[st & 1];
+        for (int x = 0; x < 3; x++) {
+            const int g = gbase + 4 + x;
+            AB_STAGE_SYNC();
+            if (g + 1 < 32) ab_bwd_request<NW>(g + 1, wqkv, wot, wqkvt, ring_u, wave, lane16);
+            const char* slot = ring + (g & 1) * AB_SLOT_B + lane16;
 #pragma unroll
-            for (int tq = 0; tq < NQ; tq++)
+            for (int j = 0; j < 2; j++) {
+                const int st = 2 * x + j, part = st >> 1, b = st & 1;
+                f16x8 wh[4], wl[4];
 #pragma unroll
-                for (int t = 0; t < 4; t++) AB_MFMA3(dxn[tq][t], w4.h[t], w4.l[t], gh[tq][part][b], gl[tq][part][b]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < 4; t++) {
+                    wh[t] = *reinterpret_cast<const f16x8*>(slot + (8 * j + 2 * t) * 1024);
+                    wl[t] = *reinterpret_cast<const f16x8*>(slot + (8 * j + 2 * t + 1) * 1024);
+                }
+#pragma unroll
+                for (int tq = 0; tq < NQ; tq++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) AB_MFMA3(dxn[tq][t], wh[t], wl[t], gh[tq][part][b], gl[tq][part][b]);
+            }
         }
+        AB_T(14);
     }
     // ---- key-bias gradient (summed over the heads; one writer per edge and layer)
+    AB_T(15);
 #pragma unroll
     for (int tk = 0; tk < NQ; tk++) {
         const float v = (db[tk] + __shfl_xor(db[tk], 32)) * (inv_sc * ABS_INV);  // the transposed planes held 64 dS
         const int key = 32 * tk + L.r;
-        if (L.h == 0 && key >= 1 && key < a.T) dbias[a.start + key - 1] = v;
+        if (live && L.h == 0 && key >= 1 && key < a.T) dbias[a.start + key - 1] = v;
     }
     // ---- norm adjoint, residual, whole-line stores
     __builtin_amdgcn_wave_barrier();
@@ -752,9 +922,8 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
 #pragma unroll
     for (int tq = 0; tq < NQ; tq++) {
         if (32 * tq >= a.T) continue;
-        float4 w[16], x[16];
-        const int64_t rw = a.row(32 * tq + L.r);
-        load_rowfrag<16>(x, X, rw, D, L.h);
+        float4 w[16];
+        float4 (&x)[16] = xin[tq];
         const float f = ABQ_INV * inv_sc;
 #pragma unroll
         for (int t = 0; t < 4; t++)
@@ -764,6 +933,16 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
                 w[4 * t + j] = make_float4(dxn[tq][t][4 * j] * f * g.x, dxn[tq][t][4 * j + 1] * f * g.y,
                                            dxn[tq][t][4 * j + 2] * f * g.z, dxn[tq][t][4 * j + 3] * f * g.w);
             }
+        const int rr = L.lane >> 4, cc = 4 * (L.lane & 15);
+        float4 dr[2][8];  // the residual (dX1 rows) in the store's shape, requested before the norm adjoint's arithmetic
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int s = 32 * tq + 4 * j + rr;
+                dr[c][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (s >= 1 && s < a.T) dr[c][j] = *reinterpret_cast<const float4*>(dX1 + ((int64_t)a.start + s - 1) * D + 64 * c + cc);
+            }
         norm_bwd_frag<16, LN>(w, x);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -771,24 +950,19 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
             for (int kg = 0; kg < 8; kg++)
                 *reinterpret_cast<float4*>(stg + L.r * TILE_LD + 8 * kg + 4 * L.h) = w[8 * c + kg];
             __builtin_amdgcn_wave_barrier();
-            const int rr = L.lane >> 4, cc = 4 * (L.lane & 15);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int r = 4 * j + rr, s = 32 * tq + r;
-                if (s < a.T) {
+                if (live && s < a.T) {
                     float4 o4 = *reinterpret_cast<const float4*>(stg + r * TILE_LD + cc);
-                    if (s == 0) {
-                        *reinterpret_cast<float4*>(dXin + (E + a.atom) * D + 64 * c + cc) = o4;
-                    } else {
-                        const int64_t row = (int64_t)a.start + s - 1;
-                        const float4 xr = *reinterpret_cast<const float4*>(dX1 + row * D + 64 * c + cc);
-                        o4.x += xr.x; o4.y += xr.y; o4.z += xr.z; o4.w += xr.w;
-                        *reinterpret_cast<float4*>(dXin + row * D + 64 * c + cc) = o4;
-                    }
+                    o4.x += dr[c][j].x; o4.y += dr[c][j].y; o4.z += dr[c][j].z; o4.w += dr[c][j].w;
+                    float* dst = s == 0 ? dXin + (E + a.atom) * D : dXin + ((int64_t)a.start + s - 1) * D;
+                    *reinterpret_cast<float4*>(dst + 64 * c + cc) = o4;
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
+        AB_T(16);
     }
 }
 
@@ -798,6 +972,20 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
 static int g_attn_fused = 0;  // pet_config_set("attn_fused", bits): 1 = fused forward, 2 = fused adjoint; 0 = the three-kernel form
 void set_attn_fused(int v) { g_attn_fused = v; }
 int attn_fused() { return g_attn_fused; }
+
+#ifdef AB_PROFILE
+void ablk_prof_dump() {
+    unsigned long long h[32];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(ab_prof), sizeof(h));
+    for (int i = 0; i < 32; i++)
+        if (h[i]) fprintf(stderr, "ab_prof[%d] = %.3f Mcycles\n", i, h[i] * 1e-6);
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ab_prof), z, sizeof(z));
+}
+#else
+void ablk_prof_dump() {}
+#endif
 
 static inline W2 w2s_fwd(const Lin& L) {
     const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
@@ -810,6 +998,41 @@ static inline W2 w2s_bwd(const Lin& L) {
     const f16x8* b = reinterpret_cast<const f16x8*>(L.bwd2s);
     W2 w; w.h = b; w.l = b + n8;
     return w;
+}
+
+// The few atoms of 33 .. 64 tokens run the NQ = 2 instantiation: a grid of a few hundred waves whose run time is one
+// wave's latency (70 / 200 us). On the caller's stream it would stand in front of the NQ = 1 launch; on a stream of its
+// own it runs beside it (both only read the layer input and write disjoint rows).
+struct TailStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    bool ok = false;
+};
+static TailStream& tail_stream() {
+    static TailStream t;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        t.ok = hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&t.fork_ev, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&t.join_ev, hipEventDisableTiming) == hipSuccess;
+    }
+    return t;
+}
+// stream for the NQ = 2 launch (forked from st), or st itself
+static hipStream_t tail_fork(hipStream_t st, bool want) {
+    if (!want || !side_stream().enabled) return st;
+    TailStream& t = tail_stream();
+    if (!t.ok) return st;
+    (void)hipEventRecord(t.fork_ev, st);
+    (void)hipStreamWaitEvent(t.s, t.fork_ev, 0);
+    return t.s;
+}
+static void tail_join(hipStream_t st, hipStream_t ts) {
+    if (ts == st) return;
+    TailStream& t = tail_stream();
+    (void)hipEventRecord(t.join_ev, ts);
+    (void)hipStreamWaitEvent(st, t.join_ev, 0);
 }
 
 // whether the adjoint of this graph's attention layers runs fused (the forward of the same call sequence did, then)
@@ -827,17 +1050,23 @@ bool ablk_fwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* 
     const int n1 = g.bucket_start[2], n2 = g.bucket_start[4] - g.bucket_start[2];
 #define PET_ABLK_FWD(NQ, LNF, LIST, CNT)                                                                            \
     {                                                                                                               \
-        const size_t lds = (size_t)4 * NQ * 16384;                                                                  \
+        constexpr int NW = NQ == 1 ? 8 : 4;                                                                         \
+        const size_t lds = (size_t)NW * NQ * 16384 + 2 * AB_SLOT;                                                   \
         allow_big_lds(k_ablk_fwd<NQ, LNF>, lds);                                                                    \
-        k_ablk_fwd<NQ, LNF><<<cdiv(CNT, 4), 256, lds, st>>>(X, A.g_attn, beta, wq, A.qkv.b, wo, A.out.b, g.rowptr,  \
-                                                            g.fc, LIST, CNT, g.n_edges, qscale, X1, OC);            \
+        k_ablk_fwd<NQ, LNF><<<cdiv(CNT, NW), 64 * NW, lds, st>>>(X, A.g_attn, beta, wq, A.qkv.b, wo, A.out.b, g.fc,  \
+                                                                 LIST, CNT, g.n_edges, qscale, X1, OC);             \
+    }
+    const hipStream_t st1 = st;
+    const hipStream_t ts = tail_fork(st1, n1 > 0 && n2 > 0);
+    if (n2 > 0) {
+        st = ts;
+        if (ln) PET_ABLK_FWD(2, true, g.atom_desc + n1, n2) else PET_ABLK_FWD(2, false, g.atom_desc + n1, n2)
+        st = st1;
     }
     if (n1 > 0) {
-        if (ln) PET_ABLK_FWD(1, true, g.atom_order, n1) else PET_ABLK_FWD(1, false, g.atom_order, n1)
+        if (ln) PET_ABLK_FWD(1, true, g.atom_desc, n1) else PET_ABLK_FWD(1, false, g.atom_desc, n1)
     }
-    if (n2 > 0) {
-        if (ln) PET_ABLK_FWD(2, true, g.atom_order + n1, n2) else PET_ABLK_FWD(2, false, g.atom_order + n1, n2)
-    }
+    tail_join(st1, ts);
 #undef PET_ABLK_FWD
     return true;
 }
@@ -854,18 +1083,23 @@ bool ablk_bwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* 
 #define PET_ABLK_BWD(NQ, LNF, LIST, CNT)                                                                             \
     {                                                                                                                \
         constexpr int WPB = 4 / NQ;                                                                                  \
-        const size_t lds = (size_t)WPB * NQ * 32768;                                                                 \
+        const size_t lds = (size_t)WPB * NQ * 32768 + 2 * AB_SLOT_B;                                                 \
         allow_big_lds(k_ablk_bwd<NQ, LNF>, lds);                                                                     \
         k_ablk_bwd<NQ, LNF><<<cdiv(CNT, WPB), 64 * WPB, lds, st>>>(X, dX1, dOC, A.g_attn, beta, wq, A.qkv.b, wot,    \
-                                                                   wqt, g.rowptr, g.fc, LIST, CNT, g.n_edges,        \
-                                                                   qscale, scale, dXin, dbias);                      \
+                                                                   wqt, g.fc, LIST, CNT, g.n_edges, qscale, scale,   \
+                                                                   dXin, dbias);                                     \
+    }
+    const hipStream_t st1 = st;
+    const hipStream_t ts = tail_fork(st1, n1 > 0 && n2 > 0);
+    if (n2 > 0) {
+        st = ts;
+        if (ln) PET_ABLK_BWD(2, true, g.atom_desc + n1, n2) else PET_ABLK_BWD(2, false, g.atom_desc + n1, n2)
+        st = st1;
     }
     if (n1 > 0) {
-        if (ln) PET_ABLK_BWD(1, true, g.atom_order, n1) else PET_ABLK_BWD(1, false, g.atom_order, n1)
+        if (ln) PET_ABLK_BWD(1, true, g.atom_desc, n1) else PET_ABLK_BWD(1, false, g.atom_desc, n1)
     }
-    if (n2 > 0) {
-        if (ln) PET_ABLK_BWD(2, true, g.atom_order + n1, n2) else PET_ABLK_BWD(2, false, g.atom_order + n1, n2)
-    }
+    tail_join(st1, ts);
 #undef PET_ABLK_BWD
     return true;
 }
