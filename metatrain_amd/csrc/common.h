@@ -94,13 +94,18 @@ struct Graph {
     float* d0 = nullptr;       // [E] |v| + 1e-15
     float* fc = nullptr;       // [E] cutoff factor
     int* sys = nullptr;        // [N] system index
-    int* scalars = nullptr;    // [24] device: n_kept, max_nbr, n_bad_reverse, pad source, input checks; [8..12] atoms per
+    int* scalars = nullptr;    // [128] device ([24 + t] atoms of t <= 32 tokens, [64 + t] fill cursors of that sort): n_kept, max_nbr, n_bad_reverse, pad source, input checks; [8..12] atoms per
                                // attention tile count (1, 2, 3, 4, more), [13..17] fill cursors
     // atoms listed by attention tile count nt = ceil((neighbours + 1) / 16): the attention kernels are launched per
     // tile count over exactly their own atoms (pet_attn.hip); bucket_start[k] = first entry of tile count k + 1
     int* atom_order = nullptr; // [N]
-    int4* atom_desc = nullptr; // [N] (atom, first CSR row, tokens = neighbours + 1, 0) in atom_order's order: one 16-B read per
-                               // attention tile instead of three dependent ones (pet_ablk.hip)
+    // attention tiles of the per-atom fused block (pet_ablk.hip): a tile is 32 token slots holding ONE atom of at most 32
+    // tokens or TWO whose tokens add up to at most 32 (the plan pairs small atoms with the largest partners that fit);
+    // atoms of 33 .. 64 tokens get a 64-slot tile each. Two int4 per tile: (atom A, first CSR row A, tokens A, atom B),
+    // (first CSR row B, tokens B or 0, -, -).
+    int* atoms_by_t = nullptr; // [N] atoms of at most 32 tokens, grouped by token count
+    int4* tile_desc = nullptr; // [2 N]: the 32-slot tiles first (n_tiles1), then the 64-slot ones (n_tiles2)
+    int n_tiles1 = 0, n_tiles2 = 0;  // host copies
     int bucket_start[6] = {0, 0, 0, 0, 0, 0};  // host copy
     // adaptive cutoff (structures.py:225-263): CSR over ALL input edges (the root finder and its
     // implicit-function gradient see every edge within the maximum cutoff, kept or not)

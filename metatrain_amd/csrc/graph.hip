@@ -294,7 +294,7 @@ __global__ void k_bucket_count(const int* __restrict__ rowptr, int n_nodes, int*
     }
 }
 __global__ void k_bucket_fill(const int* __restrict__ rowptr, int n_nodes, const int* __restrict__ counts,
-                              int* __restrict__ cursors, int* __restrict__ order, int4* __restrict__ desc) {
+                              int* __restrict__ cursors, int* __restrict__ order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int r0 = i < n_nodes ? rowptr[i] : 0, r1 = i < n_nodes ? rowptr[i + 1] : 0;
     const int b = i < n_nodes ? min((r1 - r0 + 1 + 15) >> 4, 5) - 1 : -1;
@@ -306,26 +306,135 @@ __global__ void k_bucket_fill(const int* __restrict__ rowptr, int n_nodes, const
         int base = 0;
         if (lane == 0 && m) base = atomicAdd(&cursors[k], __popcll(m));
         base = __shfl(base, 0);
-        if (b == k) {
-            const int at = start + base + __popcll(m & ((1ull << lane) - 1ull));
-            order[at] = i;
-            desc[at] = make_int4(i, r0, r1 - r0 + 1, 0);
-        }
+        if (b == k) order[start + base + __popcll(m & ((1ull << lane) - 1ull))] = i;
         start += counts[k];
     }
+}
+// ---- attention tiles of the fused block (pet_ablk.hip; Graph::tile_desc) -------------------------------------------
+// atoms of at most 32 tokens counted and listed by token count t = neighbours + 1 (counts: hist[t], t = 1 .. 32)
+__global__ void k_thist(const int* __restrict__ rowptr, int n_nodes, int* __restrict__ hist) {
+    __shared__ int lh[33];
+    if (threadIdx.x < 33) lh[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = i < n_nodes ? rowptr[i + 1] - rowptr[i] + 1 : 0;
+    if (t >= 1 && t <= 32) atomicAdd(&lh[t], 1);
+    __syncthreads();
+    if (threadIdx.x < 33 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+__global__ void k_tsort(const int* __restrict__ rowptr, int n_nodes, const int* __restrict__ hist,
+                        int* __restrict__ cursors, int* __restrict__ out) {
+    __shared__ int lh[33], lbase[33];
+    if (threadIdx.x < 33) lh[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = i < n_nodes ? rowptr[i + 1] - rowptr[i] + 1 : 0;
+    int rank = 0;
+    if (t >= 1 && t <= 32) rank = atomicAdd(&lh[t], 1);
+    __syncthreads();
+    if (threadIdx.x < 33 && threadIdx.x >= 1) {
+        int start = 0;
+        for (int u = 1; u < (int)threadIdx.x; u++) start += hist[u];
+        lbase[threadIdx.x] = start + (lh[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], lh[threadIdx.x]) : 0);
+    }
+    __syncthreads();
+    if (t >= 1 && t <= 32) out[lbase[t] + rank] = i;
 }
 static int bucket_atoms_by_tile_count(Graph& g, hipStream_t st) {  // scalars[8..17] were zeroed with the rest
     if (g.n_nodes <= 0) return PET_OK;
     const int T = 256;
     k_bucket_count<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8);
-    k_bucket_fill<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8, g.scalars + 13, g.atom_order,
-                                                     g.atom_desc);
+    k_bucket_fill<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8, g.scalars + 13, g.atom_order);
+    k_thist<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 24);
+    k_tsort<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 24, g.scalars + 64, g.atoms_by_t);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }
 static void set_bucket_starts(Graph& g, const int* counts) {
     g.bucket_start[0] = 0;
     for (int k = 0; k < 5; k++) g.bucket_start[k + 1] = g.bucket_start[k] + counts[k];
+}
+
+// the plan: segments of tiles; a segment takes `n` tiles, atom A of tile k from bin ta at offset offa + k, atom B (tb > 0)
+// from bin tb at offset offb + k
+struct TilePlan {
+    int n_seg;
+    int first[72];  // first tile of the segment (first[n_seg] = number of tiles)
+    short ta[72], tb[72];
+    int offa[72], offb[72];
+    int binstart[34];
+};
+__global__ void k_tile_fill(TilePlan plan, const int* __restrict__ by_t, const int* __restrict__ rowptr,
+                            int4* __restrict__ desc) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= plan.first[plan.n_seg]) return;
+    int sgm = 0;
+    while (sgm + 1 < plan.n_seg && plan.first[sgm + 1] <= k) sgm++;
+    const int r = k - plan.first[sgm];
+    const int ta = plan.ta[sgm], tb = plan.tb[sgm];
+    const int A = by_t[plan.binstart[ta] + plan.offa[sgm] + r];
+    const int B = tb > 0 ? by_t[plan.binstart[tb] + plan.offb[sgm] + r] : 0;
+    desc[2 * k] = make_int4(A, rowptr[A], ta, B);
+    desc[2 * k + 1] = make_int4(tb > 0 ? rowptr[B] : 0, tb, 0, 0);
+}
+__global__ void k_tile_fill_big(const int* __restrict__ atoms, int n, const int* __restrict__ rowptr, int4* __restrict__ desc) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int A = atoms[k];
+    desc[2 * k] = make_int4(A, rowptr[A], rowptr[A + 1] - rowptr[A] + 1, 0);
+    desc[2 * k + 1] = make_int4(0, 0, 0, 0);
+}
+// host: pair the smallest atoms with the largest partners that still fit 32 slots (hist[t]: atoms of t tokens)
+static int plan_attention_tiles(Graph& g, const int* hist, hipStream_t st) {
+    g.n_tiles1 = g.n_tiles2 = 0;
+    if (g.n_nodes <= 0) return PET_OK;
+    static const bool pairing = !(getenv("PET_HIP_TILE_PAIRS") && getenv("PET_HIP_TILE_PAIRS")[0] == '0');
+    TilePlan plan;
+    int rem[33], off[33];
+    plan.binstart[0] = plan.binstart[1] = 0;
+    for (int t = 1; t <= 32; t++) {
+        rem[t] = hist[t];
+        off[t] = 0;
+        plan.binstart[t + 1] = plan.binstart[t] + hist[t];
+    }
+    int nseg = 0, ntile = 0;
+    auto add = [&](int ta, int oa, int tb, int ob, int n) {
+        plan.first[nseg] = ntile;
+        plan.ta[nseg] = (short)ta; plan.tb[nseg] = (short)tb;
+        plan.offa[nseg] = oa; plan.offb[nseg] = ob;
+        nseg++;
+        ntile += n;
+    };
+    for (int lo = 1; lo <= 32; lo++) {
+        while (pairing && rem[lo] > 0 && lo <= 16) {
+            int h = 32 - lo;
+            while (h >= lo && !(rem[h] > 0 && (h != lo || rem[lo] >= 2))) h--;
+            if (h < lo) break;
+            const int n = h == lo ? rem[lo] / 2 : (rem[lo] < rem[h] ? rem[lo] : rem[h]);
+            if (h == lo) {
+                add(lo, off[lo], lo, off[lo] + n, n);
+                off[lo] += 2 * n; rem[lo] -= 2 * n;
+            } else {
+                add(lo, off[lo], h, off[h], n);
+                off[lo] += n; rem[lo] -= n;
+                off[h] += n; rem[h] -= n;
+            }
+        }
+        if (rem[lo] > 0) {
+            add(lo, off[lo], 0, 0, rem[lo]);
+            off[lo] += rem[lo]; rem[lo] = 0;
+        }
+    }
+    plan.first[nseg] = ntile;
+    plan.n_seg = nseg;
+    g.n_tiles1 = ntile;
+    g.n_tiles2 = g.bucket_start[4] - g.bucket_start[2];
+    if (ntile > 0) k_tile_fill<<<cdiv(ntile, 256), 256, 0, st>>>(plan, g.atoms_by_t, g.rowptr, g.tile_desc);
+    if (g.n_tiles2 > 0)
+        k_tile_fill_big<<<cdiv(g.n_tiles2, 256), 256, 0, st>>>(g.atom_order + g.bucket_start[2], g.n_tiles2, g.rowptr,
+                                                               g.tile_desc + 2 * (size_t)ntile);
+    PET_HIP_CHECK(hipGetLastError());
+    return PET_OK;
 }
 
 __global__ void k_max_nbr(const int* __restrict__ rowptr, int n_nodes, int* __restrict__ scalars) {
@@ -533,9 +642,10 @@ static int carve_graph(Graph& g, void* ws, int64_t n_nodes, int64_t e0, size_t* 
     g.d0 = c.take<float>(e0);
     g.fc = c.take<float>(e0);
     g.sys = c.take<int>(n_nodes);
-    g.scalars = c.take<int>(24);
+    g.scalars = c.take<int>(128);
     g.atom_order = c.take<int>(n_nodes > 0 ? n_nodes : 1);
-    g.atom_desc = c.take<int4>(n_nodes > 0 ? n_nodes : 1);
+    g.atoms_by_t = c.take<int>(n_nodes > 0 ? n_nodes : 1);
+    g.tile_desc = c.take<int4>(2 * (n_nodes > 0 ? n_nodes : 1));
     g.rowptr0 = c.take<int>(n_nodes + 1);
     g.perm0 = c.take<int>(e0);
     g.nbr0 = c.take<int>(e0);
@@ -584,7 +694,7 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
     g.n_edges_in = e0;
     g.n_systems = n_systems;
     const int T = 256;
-    PET_HIP_CHECK(hipMemsetAsync(g.scalars, 0, 24 * sizeof(int), st));
+    PET_HIP_CHECK(hipMemsetAsync(g.scalars, 0, 128 * sizeof(int), st));
     if (n_nodes > 0) {
         k_species_index<<<cdiv(n_nodes, T), T, 0, st>>>(species, m.species_table, m.species_table_len,
                                                         g.sp, (int)n_nodes, g.scalars + 5, sys, g.sys,
@@ -646,12 +756,13 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
         k_find_pad_src<<<cdiv(e0, T), T, 0, st>>>(g.perm, g.kidx, g.keep, g.scalars, g.scalars + 3);
     }
     if (int rcb = bucket_atoms_by_tile_count(g, st)) return rcb;
-    int host_scalars[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 13 * sizeof(int), hipMemcpyDeviceToHost, st));
+    int host_scalars[57] = {0};
+    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 57 * sizeof(int), hipMemcpyDeviceToHost, st));
     PET_HIP_CHECK(hipStreamSynchronize(st));
     g.n_edges = host_scalars[0];
     g.max_nbr = host_scalars[1];
     set_bucket_starts(g, host_scalars + 8);
+    if (int rcp = plan_attention_tiles(g, host_scalars + 24, st)) return rcp;
     PET_REQUIRE(host_scalars[6] == 0, PET_ERR_ARGUMENT,
                 std::to_string(host_scalars[6]) + " neighbour-list entries index atoms outside [0, n_nodes)");
     PET_REQUIRE(host_scalars[5] == 0, PET_ERR_ARGUMENT,
@@ -769,9 +880,10 @@ static int carve_from_batch(Graph& g, void* ws, int64_t n_nodes, int64_t M, size
     g.sp_nbr = c.take<int>(cap);
     g.geo = c.take<float4>(cap);
     g.fc = c.take<float>(cap);
-    g.scalars = c.take<int>(24);
+    g.scalars = c.take<int>(128);
     g.atom_order = c.take<int>(n_nodes > 0 ? n_nodes : 1);
-    g.atom_desc = c.take<int4>(n_nodes > 0 ? n_nodes : 1);
+    g.atoms_by_t = c.take<int>(n_nodes > 0 ? n_nodes : 1);
+    g.tile_desc = c.take<int4>(2 * (n_nodes > 0 ? n_nodes : 1));
     size_t scan_bytes = 0;
     int* ni = nullptr;
     if (rocprim::exclusive_scan(nullptr, scan_bytes, ni, ni, 0, (size_t)(n_nodes + 1), rocprim::plus<int>()) != hipSuccess)
@@ -801,7 +913,7 @@ int graph_from_batch(const int64_t* el_nodes, const int64_t* el_nbr, const float
     g.n_systems = 0;
     g.adaptive = false;
     const int T = 256;
-    PET_HIP_CHECK(hipMemsetAsync(g.scalars, 0, 24 * sizeof(int), st));
+    PET_HIP_CHECK(hipMemsetAsync(g.scalars, 0, 128 * sizeof(int), st));
     PET_HIP_CHECK(hipMemsetAsync(g.kidx, 0, (n_nodes + 1) * sizeof(int), st));
     if (n_nodes > 0 && M > 0)
         k_mask_counts<<<cdiv(n_nodes, T), T, 0, st>>>(mask, (int)n_nodes, (int)M, g.kidx, g.scalars);
@@ -814,14 +926,15 @@ int graph_from_batch(const int64_t* el_nodes, const int64_t* el_nbr, const float
         k_from_batch_fill<<<cdiv(n_nodes, T), T, 0, st>>>(el_nodes, el_nbr, ev, ed, rni, cf, g.rowptr, (int)n_nodes, 1, g.ctr,
                                                           g.nbr, g.rev, g.sp, g.sp_nbr, g.geo, g.fc, g.scalars);
     if (int rcb = bucket_atoms_by_tile_count(g, st)) return rcb;
-    int host_scalars[13] = {0};
+    int host_scalars[57] = {0};
     int n_edges = 0;
-    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 13 * sizeof(int), hipMemcpyDeviceToHost, st));
+    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 57 * sizeof(int), hipMemcpyDeviceToHost, st));
     PET_HIP_CHECK(hipMemcpyAsync(&n_edges, g.rowptr + n_nodes, sizeof(int), hipMemcpyDeviceToHost, st));
     PET_HIP_CHECK(hipStreamSynchronize(st));
     g.n_edges = n_edges;
     g.max_nbr = host_scalars[1];
     set_bucket_starts(g, host_scalars + 8);
+    if (int rcp = plan_attention_tiles(g, host_scalars + 24, st)) return rcp;
     PET_REQUIRE(host_scalars[2] == 0, PET_ERR_GRAPH,
                 "batch_data is not a NEF batch: " + std::to_string(host_scalars[2]) +
                     " rows with a real slot behind a pad, or reverse_neighbor_index entries that do not point at a real slot");

@@ -142,17 +142,28 @@ __device__ unsigned long long ab_prof[32];
 #define AB_T0()
 #endif
 
-// token slot s of the atom: 0 = the centre token (row E + atom of the token stream), s >= 1 neighbour s - 1; slots past
-// the atom's last token repeat it (their results are never stored and, as keys, are masked)
+// A tile: 32 NQ token slots holding atom A (slot 0 = its centre token = row E + atom of the token stream, slots 1 .. TA - 1
+// its neighbours = CSR rows startA ..) and, in a 32-slot tile, possibly a second atom B behind it (Graph::tile_desc; the
+// graph build pairs small atoms with partners that fit). Tokens attend within their own atom only. Slots past the last
+// token repeat it (their results are never stored and, as keys, are masked).
 struct AbAtom {
-    int atom, start, T;
+    int atomA, startA, TA, atomB, startB, TB, T;
     int64_t E;
-    __device__ __forceinline__ AbAtom(const int4 d, int64_t e)  // Graph::atom_desc entry: (atom, first CSR row, tokens, -)
-        : atom(__builtin_amdgcn_readfirstlane(d.x)), start(__builtin_amdgcn_readfirstlane(d.y)),
-          T(__builtin_amdgcn_readfirstlane(d.z)), E(e) {}
-    __device__ __forceinline__ int64_t row(int s) const {
+    __device__ __forceinline__ AbAtom(const int4* __restrict__ d, int64_t e) : E(e) {
+        const int4 d0 = d[0], d1 = d[1];
+        atomA = __builtin_amdgcn_readfirstlane(d0.x); startA = __builtin_amdgcn_readfirstlane(d0.y);
+        TA = __builtin_amdgcn_readfirstlane(d0.z); atomB = __builtin_amdgcn_readfirstlane(d0.w);
+        startB = __builtin_amdgcn_readfirstlane(d1.x); TB = __builtin_amdgcn_readfirstlane(d1.y);
+        T = TA + TB;
+    }
+    __device__ __forceinline__ bool centre(int s) const { return s == 0 || s == TA; }
+    __device__ __forceinline__ int atom(int s) const { return s < TA ? atomA : atomB; }
+    __device__ __forceinline__ int64_t edge(int s) const {  // CSR row of a neighbour slot
+        return s < TA ? (int64_t)startA + s - 1 : (int64_t)startB + (s - TA) - 1;
+    }
+    __device__ __forceinline__ int64_t row(int s) const {  // row of the token stream [edges | centre tokens]
         s = s < T ? s : T - 1;
-        return s == 0 ? E + atom : (int64_t)start + s - 1;
+        return centre(s) ? E + atom(s) : edge(s);
     }
 };
 
@@ -185,17 +196,19 @@ __device__ __forceinline__ void ab_park_planes(const float4 (&x)[16], char* tile
 }
 
 // key bias (log2 of the cutoff factor, transformer.py:109-110) of the keys this lane's S^T registers hold; -inf masks
-// the slots past the atom's last token
+// the slots past the last token and the other atom of a paired tile (the lane is a QUERY: its atom decides)
 template <int NQ>
-__device__ __forceinline__ void ab_key_bias(float (&bias)[NQ][16], const AbAtom& a, const float* __restrict__ fc, int h) {
+__device__ __forceinline__ void ab_key_bias(float (&bias)[NQ][16], const AbAtom& a, const float* __restrict__ fc,
+                                            const RowLane& L) {
+    const bool qb = (L.r < a.T ? L.r : a.T - 1) >= a.TA;
 #pragma unroll
     for (int tk = 0; tk < NQ; tk++)
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const int key = 32 * tk + 8 * (i >> 2) + 4 * h + (i & 3);
+            const int key = 32 * tk + 8 * (i >> 2) + 4 * L.h + (i & 3);
             float b = -INFINITY;
-            if (key == 0) b = 0.f;
-            else if (key < a.T) b = __builtin_amdgcn_logf(fmaxf(fc[a.start + key - 1], 1e-15f));
+            if (key < a.T && (key >= a.TA) == qb)
+                b = a.centre(key) ? 0.f : __builtin_amdgcn_logf(fmaxf(fc[a.edge(key)], 1e-15f));
             bias[tk][i] = b;
         }
 }
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(NQ == 1 ? 512 : 256) void k_ablk_fwd(
     int li = blockIdx.x * NW + wave;
     const bool live = li < n_list;
     li = live ? li : n_list - 1;
-    const AbAtom a(desc[li], E);
+    const AbAtom a(desc + 2 * (size_t)li, E);
     char* tile = ab_smem + wave * (NQ * 16384);
     const char* ring = ab_smem + NW * NQ * 16384;
     const unsigned tile_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile);
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(NQ == 1 ? 512 : 256) void k_ablk_fwd(
     ab_dma_rows<NQ>(X, a, tile_u, L);
     ab_fwd_request<NW>(0, wqkv, wo, ring_u, wave, lane16);
     float bias[NQ][16];
-    ab_key_bias<NQ>(bias, a, fc, L.h);
+    ab_key_bias<NQ>(bias, a, fc, L);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     AB_T(0);
     // rows -> normalised -> planes, parked over the fp32 tile they came from
@@ -460,7 +473,7 @@ __global__ __launch_bounds__(NQ == 1 ? 512 : 256) void k_ablk_fwd(
             for (int j = 0; j < 8; j++) {
                 const int s = 32 * tq + 4 * j + rr;
                 xr[tq][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (s >= 1 && s < a.T) xr[tq][j] = *reinterpret_cast<const float4*>(X + ((int64_t)a.start + s - 1) * D + 64 * c + cc);
+                if (s < a.T && !a.centre(s)) xr[tq][j] = *reinterpret_cast<const float4*>(X + a.edge(s) * D + 64 * c + cc);
             }
         f32x16 y[NQ][2];
 #pragma unroll
@@ -508,7 +521,7 @@ __global__ __launch_bounds__(NQ == 1 ? 512 : 256) void k_ablk_fwd(
                 if (live && s < a.T) {
                     float4 o4 = *reinterpret_cast<const float4*>(stg + r * TILE_LD + cc);
                     o4.x += xr[tq][j].x; o4.y += xr[tq][j].y; o4.z += xr[tq][j].z; o4.w += xr[tq][j].w;
-                    float* dst = s == 0 ? OC + (int64_t)a.atom * D : X1 + ((int64_t)a.start + s - 1) * D;
+                    float* dst = a.centre(s) ? OC + (int64_t)a.atom(s) * D : X1 + a.edge(s) * D;
                     *reinterpret_cast<float4*>(dst + 64 * c + cc) = o4;
                 }
             }
@@ -596,7 +609,7 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
     int li = blockIdx.x * NW + wave;
     const bool live = li < n_list;
     li = live ? li : n_list - 1;
-    const AbAtom a(desc[li], E);
+    const AbAtom a(desc + 2 * (size_t)li, E);
     // per wave: NQ x 16 KB planes of the normalised rows | NQ x 16 KB incoming adjoint rows, then dAO (row fragments)
     char* tile = ab_smem + wave * (NQ * 32768);
     char* tileB = tile + NQ * 16384;
@@ -614,12 +627,12 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
             const int p = (L.lane & 31) ^ (r & 15);
             int s = 32 * tq + r;
             s = s < a.T ? s : a.T - 1;
-            const float* src = s == 0 ? dOC + (int64_t)a.atom * D : dX1 + ((int64_t)a.start + s - 1) * D;
+            const float* src = a.centre(s) ? dOC + (int64_t)a.atom(s) * D : dX1 + a.edge(s) * D;
             glds16_trr(src + 4 * p, tile_u + NQ * 16384 + tq * 16384 + j * 1024);
         }
     ab_bwd_request<NW>(0, wqkv, wot, wqkvt, ring_u, wave, lane16);
     float bias[NQ][16];
-    ab_key_bias<NQ>(bias, a, fc, L.h);
+    ab_key_bias<NQ>(bias, a, fc, L);
     const AbSel sel1 = ab_selectors(L, 1.0f);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     AB_T(8);
@@ -634,7 +647,7 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
     }
     AB_T(9);
     // ---- dAO = dY Wo (token form), parked as row fragments [kg][lane] over the rows it came from
-    float inv_sc;  // inverse of the atom's power-of-two scale
+    float inv_sc;  // inverse of the power-of-two scale of this lane's atom (the lane is a token in every place it is used)
     {
         float4 d[NQ][16];
         float m = 0.f;
@@ -649,9 +662,17 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
                           fmaxf(fabsf(d[tq][kg].z), fabsf(d[tq][kg].w)));
             }
         }
+        // one scale per ATOM: the sums over queries stay inside an atom, so the two atoms of a paired tile keep their own
+        // scale and an atom's arithmetic does not depend on what it was paired with
+        const bool gb = NQ == 1 && L.r >= a.TA;
+        float ma = gb ? 0.f : m, mb = gb ? m : 0.f;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        int e = ((__float_as_int(m) >> 23) & 0xff) + 2;  // largest entry of the scaled rows in [0.25, 0.5)
+        for (int o = 32; o >= 1; o >>= 1) {
+            ma = fmaxf(ma, __shfl_xor(ma, o));
+            mb = fmaxf(mb, __shfl_xor(mb, o));
+        }
+        m = gb ? mb : ma;
+        int e = ((__float_as_int(m) >> 23) & 0xff) + 2;  // largest entry of the atom's scaled rows in [0.25, 0.5)
         e = e > 253 ? 253 : e;
         e = e < 16 ? 16 : e;  // all-zero rows: keep the scale finite
         const float sc = __int_as_float((254 - e) << 23) * ABS;  // ... and the planes hold 64 x that
@@ -712,7 +733,6 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
 #pragma unroll
     for (int tk = 0; tk < NQ; tk++) db[tk] = 0.f;
     constexpr float LN2 = 0.6931471805599453f;
-    float4 xin[NQ][16];
 
 #pragma unroll 1
     for (int hp = 0; hp < 4; hp++) {
@@ -750,6 +770,11 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
                     AB_MFMA3(v[tq], wvh, wvl, xh, xl);
                 }
             }
+        }
+        if (hp == 3) {  // the norm adjoint's input rows come back by LDS-DMA over the row planes, which nobody reads any
+            __builtin_amdgcn_wave_barrier();  // more; the attention work of this pair covers the round trip
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ab_dma_rows<NQ>(X, a, tile_u, L);
         }
         AB_T(11);
         // ---- operand planes: token form (index = head of the pair) and feature form (index = token K block)
@@ -872,10 +897,6 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
                     dv[tk][8 * hd + j] = dvh[hd][tk][8 * hd + j];
                 }
         AB_T(13);
-        if (hp == 3) {  // the norm adjoint's input rows: requested under the last products
-#pragma unroll
-            for (int tq = 0; tq < NQ; tq++) load_rowfrag<16>(xin[tq], X, a.row(32 * tq + L.r), D, L.h);
-        }
         // ---- dXn^T += Wqkv^T [dQ; dK; dV]^T: K blocks 2 hp, 2 hp + 1 of each of the three parts
         f16x8 gh[NQ][3][2], gl[NQ][3][2];
 #pragma unroll
@@ -913,17 +934,17 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
     for (int tk = 0; tk < NQ; tk++) {
         const float v = (db[tk] + __shfl_xor(db[tk], 32)) * (inv_sc * ABS_INV);  // the transposed planes held 64 dS
         const int key = 32 * tk + L.r;
-        if (live && L.h == 0 && key >= 1 && key < a.T) dbias[a.start + key - 1] = v;
+        if (live && L.h == 0 && key < a.T && !a.centre(key)) dbias[a.edge(key)] = v;
     }
     // ---- norm adjoint, residual, whole-line stores
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
-    float* stg = reinterpret_cast<float*>(tile);
+    float* stg = reinterpret_cast<float*>(tileB);  // staging for whole-line stores: the dAO rows are dead
 #pragma unroll
     for (int tq = 0; tq < NQ; tq++) {
         if (32 * tq >= a.T) continue;
-        float4 w[16];
-        float4 (&x)[16] = xin[tq];
+        float4 w[16], x[16];
+        tile128_to_frag(x, tile + tq * 16384, L);  // landed: every stage sync since the request waited for vmcnt(0)
         const float f = ABQ_INV * inv_sc;
 #pragma unroll
         for (int t = 0; t < 4; t++)
@@ -941,7 +962,7 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
             for (int j = 0; j < 8; j++) {
                 const int s = 32 * tq + 4 * j + rr;
                 dr[c][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (s >= 1 && s < a.T) dr[c][j] = *reinterpret_cast<const float4*>(dX1 + ((int64_t)a.start + s - 1) * D + 64 * c + cc);
+                if (s < a.T && !a.centre(s)) dr[c][j] = *reinterpret_cast<const float4*>(dX1 + a.edge(s) * D + 64 * c + cc);
             }
         norm_bwd_frag<16, LN>(w, x);
 #pragma unroll
@@ -956,7 +977,7 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
                 if (live && s < a.T) {
                     float4 o4 = *reinterpret_cast<const float4*>(stg + r * TILE_LD + cc);
                     o4.x += dr[c][j].x; o4.y += dr[c][j].y; o4.z += dr[c][j].z; o4.w += dr[c][j].w;
-                    float* dst = s == 0 ? dXin + (E + a.atom) * D : dXin + ((int64_t)a.start + s - 1) * D;
+                    float* dst = dXin + (a.centre(s) ? E + a.atom(s) : a.edge(s)) * D;
                     *reinterpret_cast<float4*>(dst + 64 * c + cc) = o4;
                 }
             }
@@ -969,7 +990,11 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static int g_attn_fused = 0;  // pet_config_set("attn_fused", bits): 1 = fused forward, 2 = fused adjoint; 0 = the three-kernel form
+// pet_config_set("attn_fused", bits): 1 = fused forward, 2 = fused adjoint (the forward of a call sequence whose adjoint
+// follows is fused only together with it: the three-kernel adjoint reads the saved Q, K, V), 4 = also when many atoms
+// have more than 32 tokens (their 64-slot instantiation of the adjoint spills; above 5 % of the atoms the three-kernel
+// form is the faster one); 0 = the three-kernel form (QKV / attention / projection) everywhere
+static int g_attn_fused = 3;
 void set_attn_fused(int v) { g_attn_fused = v; }
 int attn_fused() { return g_attn_fused; }
 
@@ -1036,18 +1061,21 @@ static void tail_join(hipStream_t st, hipStream_t ts) {
 }
 
 // whether the adjoint of this graph's attention layers runs fused (the forward of the same call sequence did, then)
-bool ablk_bwd_on(const Graph& g) { return (g_attn_fused & 2) && !(g.bucket_start[5] > g.bucket_start[4]); }
+static bool ablk_serves(const Graph& g) {
+    if (g.bucket_start[5] > g.bucket_start[4]) return false;  // an atom of more than 64 tokens
+    return (g_attn_fused & 4) || (int64_t)g.n_tiles2 * 20 <= g.n_nodes;
+}
+bool ablk_bwd_on(const Graph& g) { return (g_attn_fused & 2) && ablk_serves(g); }
 
 // atoms of at most 64 tokens (attention tile counts 1 .. 4 of the graph's bucket lists); false = not served
 bool ablk_fwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* X, float* X1, float* OC, float scale,
               hipStream_t st) {
-    if (!(g_attn_fused & 1) || !A.qkv.fwd2s || !A.out.fwd2s) return false;
-    if (g.bucket_start[5] > g.bucket_start[4]) return false;  // an atom of more than 64 tokens
+    if (!(g_attn_fused & 1) || !A.qkv.fwd2s || !A.out.fwd2s || !ablk_serves(g)) return false;
     const bool ln = m.layer_norm();
     const float qscale = scale * AB_LOG2E;
     const W2 wq = w2s_fwd(A.qkv), wo = w2s_fwd(A.out);
     const float* beta = ln ? A.b_attn : nullptr;
-    const int n1 = g.bucket_start[2], n2 = g.bucket_start[4] - g.bucket_start[2];
+    const int n1 = g.n_tiles1, n2 = g.n_tiles2;
 #define PET_ABLK_FWD(NQ, LNF, LIST, CNT)                                                                            \
     {                                                                                                               \
         constexpr int NW = NQ == 1 ? 8 : 4;                                                                         \
@@ -1060,11 +1088,11 @@ bool ablk_fwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* 
     const hipStream_t ts = tail_fork(st1, n1 > 0 && n2 > 0);
     if (n2 > 0) {
         st = ts;
-        if (ln) PET_ABLK_FWD(2, true, g.atom_desc + n1, n2) else PET_ABLK_FWD(2, false, g.atom_desc + n1, n2)
+        if (ln) PET_ABLK_FWD(2, true, g.tile_desc + 2 * (size_t)n1, n2) else PET_ABLK_FWD(2, false, g.tile_desc + 2 * (size_t)n1, n2)
         st = st1;
     }
     if (n1 > 0) {
-        if (ln) PET_ABLK_FWD(1, true, g.atom_desc, n1) else PET_ABLK_FWD(1, false, g.atom_desc, n1)
+        if (ln) PET_ABLK_FWD(1, true, g.tile_desc, n1) else PET_ABLK_FWD(1, false, g.tile_desc, n1)
     }
     tail_join(st1, ts);
 #undef PET_ABLK_FWD
@@ -1079,7 +1107,7 @@ bool ablk_bwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* 
     const float qscale = scale * AB_LOG2E;
     const W2 wq = w2s_fwd(A.qkv), wqt = w2s_bwd(A.qkv), wot = w2s_bwd(A.out);
     const float* beta = ln ? A.b_attn : nullptr;
-    const int n1 = g.bucket_start[2], n2 = g.bucket_start[4] - g.bucket_start[2];
+    const int n1 = g.n_tiles1, n2 = g.n_tiles2;
 #define PET_ABLK_BWD(NQ, LNF, LIST, CNT)                                                                             \
     {                                                                                                                \
         constexpr int WPB = 4 / NQ;                                                                                  \
@@ -1093,11 +1121,11 @@ bool ablk_bwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* 
     const hipStream_t ts = tail_fork(st1, n1 > 0 && n2 > 0);
     if (n2 > 0) {
         st = ts;
-        if (ln) PET_ABLK_BWD(2, true, g.atom_desc + n1, n2) else PET_ABLK_BWD(2, false, g.atom_desc + n1, n2)
+        if (ln) PET_ABLK_BWD(2, true, g.tile_desc + 2 * (size_t)n1, n2) else PET_ABLK_BWD(2, false, g.tile_desc + 2 * (size_t)n1, n2)
         st = st1;
     }
     if (n1 > 0) {
-        if (ln) PET_ABLK_BWD(1, true, g.atom_desc, n1) else PET_ABLK_BWD(1, false, g.atom_desc, n1)
+        if (ln) PET_ABLK_BWD(1, true, g.tile_desc, n1) else PET_ABLK_BWD(1, false, g.tile_desc, n1)
     }
     tail_join(st1, ts);
 #undef PET_ABLK_BWD

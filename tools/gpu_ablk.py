@@ -61,7 +61,7 @@ graph = rt.HipGraph(model, pos.to(dev), cell[None].to(dev), pairs[:, 0].contiguo
                     pairs[:, 2:5].contiguous(), z.to(dev), torch.zeros(len(z), dtype=torch.int32, device=dev))
 res = {}
 for mode in (0, MODE):
-    rt.config_set("attn_fused", mode)
+    rt.config_set("attn_fused", mode | (4 if mode else 0))  # 4: fused although most atoms take the 64-slot tiles
     fw = rt.HipForward(model, graph)
     a = fw.forward()
     gp = fw.backward(torch.ones_like(a)) if (mode == 0 or mode & 2) else None
