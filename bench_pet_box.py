@@ -60,6 +60,7 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         pdist.init(backend, dev)
+        pdist.selftest(args.gpus, dev)  # the ranks the launch line names joined, and a collective works
 
     from metatrain_amd import runtime as rt
     from metatrain_amd.pet import default_hypers, partition

@@ -396,27 +396,26 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
                        double* flops, double* bytes, int* n_entries);
 /* Runtime switches used by tests / the benchmark (every setting meets the same parity bar):
  *   "side_stream" 1 = node-feature chain on a second HIP stream (default)
- *   "trr"         1 = register-resident stage kernels (default); 0 = the LDS-tile kernels
- *                 (the one fallback generation; the TRR GEMMs are f16x3 split-operand products on the 16-bit matrix
- *                 cores, fp32 accuracy; round 1's fp32-MFMA and bf16x6 TRR generations were removed in round 2)
+ *   "trr"         1 = transposed register-resident row kernels on f16x3 split-operand products (default); 0 = the LDS-tile
+ *                 kernels for the transformer layers (the one fallback generation, also the transformer-layer path of
+ *                 PostLN models). The combination stage has one implementation (the software-pipelined TRR kernel).
+ *   "attn_fused"  bits: 1 = the per-atom fused attention block in the forward (norm -> QKV -> soft-max attention -> output
+ *                 projection in one kernel; Q, K, V and the attention output never reach HBM; csrc/pet_ablk.hip), 2 = its
+ *                 adjoint (recomputes Q, K, V from the layer input), 4 = also for graphs in which more than 5 % of the
+ *                 atoms have more than 32 tokens; default 3. 0 = the three-kernel form everywhere (what training forwards,
+ *                 graphs with an atom of more than 64 tokens and PostLN models always run).
+ *   "attn_lds"    adjoint of the three-kernel attention form: 1 = staged per atom, 3 = persistent workgroups with LDS-DMA
+ *                 prefetch for atoms of at most 32 tokens (default)
  *   "tile_f16x3"  1 = the LDS-tile forward kernels (compress, centre, node update, heads) and the head adjoint on f16x3
  *                 (default); 0 = fp32 MFMA. "tile_mask" (debug): bits switch single GEMMs of those kernels back.
- *   "so_trr"       1 = generic training GEMMs with K = 128 or n_out = 128 as TRR kernels (default); 0 = LDS-tile k_gemm_h
- *   "emlp_recompute" 1 = the inference adjoint of the edge MLP rebuilds the SwiGLU pre-activations instead of reading
- *                 them back (less workspace traffic, slower adjoint); default 0
- *   "emlp_pipe", "emlp_bwd_pipe", "comb_pipe", "comb_bwd_pipe" 1 = the edge MLP, the combination stage and their
- *                 adjoints as software-pipelined kernels (k_emlp_p2 / k_emlp_bwd_p2 / k_comb_p2 / k_comb_bwd_p2: one MFMA
- *                 triple + one slice of VALU work per slot, operands staged in LDS by LDS-DMA; default); 0 = k_emlp_h
- *                 (persistent) / k_emlp_bwd_h / k_comb_h / k_comb_bwd_h, which walk the stages of a hidden chunk in turn
  *   "trr_compress" bit mask of f16x3 TRR kernels replacing LDS-tile ones: 1 compress (+adjoint), 2 edge head (+adjoint);
  *                  default 3; 0 = LDS-tile kernels
- *   "line_stores" bit mask: 1 = QKV projection, 2 = edge MLP write whole 128-B lines through a wave-private LDS tile
- *                 (default 3; the other row kernels always do)
  *   "node_planes" 1 = node-row kernels k_node2 / k_node_bwd2 (coalesced tiles, fp16 planes; default), 0 = k_node / k_swiglu_bwd
+ *   "so_trr"      1 = generic training GEMMs with K = 128 or n_out = 128 as TRR kernels (default); 0 = LDS-tile k_gemm_h
  *   "wgrad_bf16"  1 = weight-gradient GEMMs of the training passes as bf16x3 split-operand products (default); 0 = fp32 MFMA
  *   "so_f16x3"    1 = generic GEMMs of the second-order (training) pass as f16x3 (default); 0 = fp32 MFMA
- *   "attn_lds"    attention adjoint: 1 per-atom LDS-staged for every atom, 3 persistent LDS-DMA kernel for atoms of at
- *                 most 32 tokens (default)
+ *   (removed in round 4 with the kernels they selected: "emlp_pipe", "emlp_bwd_pipe", "comb_pipe", "comb_bwd_pipe",
+ *   "emlp_recompute", "line_stores", "lds_w")
  *   "soap_mfma"   1 = SOAP-BPNN LayerNorm + MLP tail on MFMA (default)
  *   "soap_fused"  1 = SOAP power spectrum + LayerNorm + first Linear in one kernel, features never stored (default 0: slower, saves memory)
  *   "soap_sorted" 1 = SOAP-BPNN tail GEMM on species-sorted atom tiles, one network per tile (default)

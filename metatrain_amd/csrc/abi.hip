@@ -936,15 +936,8 @@ int pet_config_set(const char* key, int value) {
     else if (k == "attn_lds") set_attn_lds(value);
     else if (k == "attn_fused") set_attn_fused(value);
     else if (k == "attn_fused_prof") ablk_prof_dump();
-    else if (k == "emlp_recompute") set_emlp_recompute(value);
-    else if (k == "emlp_bwd_pipe") set_emlp_bwd_pipe(value);
-    else if (k == "emlp_pipe") set_emlp_pipe(value);
-    else if (k == "comb_pipe") set_comb_pipe(value);
-    else if (k == "comb_bwd_pipe") set_comb_bwd_pipe(value);
     else if (k == "tile_f16x3") set_tile_f16x3(value);
     else if (k == "trr_compress") set_trr_compress(value);
-    else if (k == "line_stores") set_line_stores(value);
-    else if (k == "lds_w") set_lds_w(value);
     else if (k == "node_planes") set_node_planes(value);
     else if (k == "so_trr") set_so_trr(value);
     else if (k == "wgrad_bf16") set_wgrad_bf16(value);

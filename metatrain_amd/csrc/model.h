@@ -245,12 +245,6 @@ void set_so_trr(int v);     // so.hip: 1 = K = 128 / n_out = 128 generic GEMMs a
 void set_attn_lds(int v);   // pet_attn.hip: 1 = LDS-staged attention (default), 0 = wave-per-head from global
 void set_soap_mfma(int v);  // soap.hip: 1 = MFMA tail (default), 0 = per-atom tail kernels
 void set_soap_fused(int v);  // soap.hip: 1 = power spectrum + LayerNorm + first Linear fused, features never stored (default 0)
-bool emlp_recompute_ok(const Lin& win, const Lin& wout);
-void set_emlp_recompute(int v);
-void set_emlp_bwd_pipe(int v);
-void set_emlp_pipe(int v);
-void set_comb_pipe(int v);
-void set_comb_bwd_pipe(int v);
 bool use_tile_f16x3();
 void set_tile_f16x3(int v);
 void set_tile_mask(int v);
@@ -258,8 +252,6 @@ int tile_mask();
 void set_trr_compress(int v);
 void set_node_planes(int v);  // pet_fwd.hip / pet_bwd.hip: node-row kernels on pre-split fp16 planes (default 1)
 bool node_planes();
-void set_lds_w(int v);       // pet_trr.hip: shared weight stream kernels (weights once per 256-row workgroup through LDS)
-void set_line_stores(int v);  // pet_trr.hip: bit 0 qkv, bit 1 edge MLP store whole 128-B lines through LDS (default 3)
 struct Graph;
 bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* Min, float* a0_out, float* Xout, int64_t E,
                   hipStream_t st);

@@ -710,6 +710,27 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
                 }
             }
         }
+        // dAO = dY Wo can be far from dY's magnitude (a checkpoint with a large output projection): a second power of two
+        // per atom puts ITS largest entry in [0.25, 0.5) before it is split into fp16 planes and multiplied on
+        float m2 = 0.f;
+#pragma unroll
+        for (int tq = 0; tq < NQ; tq++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) m2 = fmaxf(m2, fabsf(da[tq][t][i]));
+        float m2a = gb ? 0.f : m2, m2b = gb ? m2 : 0.f;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            m2a = fmaxf(m2a, __shfl_xor(m2a, o));
+            m2b = fmaxf(m2b, __shfl_xor(m2b, o));
+        }
+        m2 = (gb ? m2b : m2a) * ABQ_INV;  // largest |dAO| of this lane's atom (in the first scale)
+        int e2 = ((__float_as_int(m2) >> 23) & 0xff) + 2;
+        e2 = e2 > 253 ? 253 : e2;
+        e2 = e2 < 16 ? 16 : e2;
+        const float s2 = __int_as_float((254 - e2) << 23) * ABS_INV;  // accumulator (4096 x) -> planes' source (64 x), rescaled
+        inv_sc *= __int_as_float(e2 << 23);
 #pragma unroll
         for (int tq = 0; tq < NQ; tq++)
 #pragma unroll
@@ -717,8 +738,8 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     *reinterpret_cast<float4*>(tileB + tq * 16384 + ((4 * t + j) * 64 + L.lane) * 16) =
-                        make_float4(da[tq][t][4 * j] * ABS_INV, da[tq][t][4 * j + 1] * ABS_INV, da[tq][t][4 * j + 2] * ABS_INV,
-                                    da[tq][t][4 * j + 3] * ABS_INV);  // 64 dAO: what the planes are split from
+                        make_float4(da[tq][t][4 * j] * s2, da[tq][t][4 * j + 1] * s2, da[tq][t][4 * j + 2] * s2,
+                                    da[tq][t][4 * j + 3] * s2);  // 64 dAO: what the planes are split from
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");

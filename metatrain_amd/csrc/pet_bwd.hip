@@ -227,80 +227,6 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
     });
 }
 
-// ---------------------------------------------------------------------------------
-// combination MLP + LayerNorm adjoint -> dcat [E, 2D]
-// ---------------------------------------------------------------------------------
-template <bool TRAIN>
-__global__ __launch_bounds__(NTHREADS) void k_comb_bwd(const float* __restrict__ dM, const float* __restrict__ XF,
-                                                        const int* __restrict__ rev, const float* __restrict__ LNS,
-                                                        const float* __restrict__ CA, const float* __restrict__ ln_g,
-                                                        const float4* __restrict__ w2b, const float4* __restrict__ w0b,
-                                                        float* __restrict__ dcat, int64_t E, float* __restrict__ t_da) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Lo = smem;
-    float* Hi = smem + BM * LD128;
-    const WaveId w;
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
-    load_rows_to_lds<128>(Lo, dM, row0, E, D);
-    __syncthreads();
-    f32x16 t1[4];
-    acc_fill_bias<4>(t1, nullptr, 0, w.lane);
-    gemm_acc<128, 4>(Lo + w.rb * 32 * LD128, LD128, w2b, 16, 0, 4 * w.ch, t1, w.lane);  // [64,256] = dupd W2
-    __syncthreads();
-    float* Sdst = w.ch == 0 ? Lo : Hi;
-    acc_foreach<4>(t1, w.rb, 0, w.lane, [&](int r, int c, float v) {
-        const int64_t row = row0 + r;
-        const float a = row < E ? CA[row * (2 * D) + 128 * w.ch + c] : 0.f;
-        const float da = v * silu_grad_(a);
-        Sdst[r * LD128 + c] = da;
-        if (TRAIN && row < E) t_da[row * (2 * D) + 128 * w.ch + c] = da;
-    });
-    __syncthreads();
-    acc_fill_bias<4>(t1, nullptr, 0, w.lane);
-    gemm_acc<128, 4>(Lo + w.rb * 32 * LD128, LD128, w0b, 32, 0, 4 * w.ch, t1, w.lane);  // dln = da W0
-    gemm_acc<128, 4>(Hi + w.rb * 32 * LD128, LD128, w0b, 32, 16, 4 * w.ch, t1, w.lane);
-    __syncthreads();
-    acc_foreach<4>(t1, w.rb, 0, w.lane,
-                   [&](int r, int c, float v) { Sdst[r * LD128 + c] = v * ln_g[128 * w.ch + c]; });  // dyhat
-    __syncthreads();
-    {   // LayerNorm adjoint: dx = rstd (dyh - mean(dyh) - xhat mean(dyh xhat))
-        const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
-        const int64_t row = row0 + r;
-        const bool valid = row < E;
-        const float mean = valid ? LNS[row * 2] : 0.f, rstd = valid ? LNS[row * 2 + 1] : 0.f;
-        const float* xlo = XF + row * D;
-        const float* xhi = XF + (valid ? (int64_t)rev[row] : 0) * D;
-        float s1 = 0.f, s2 = 0.f;
-        for (int c = q * 4; c < 128; c += 16) {
-            float4 a = *reinterpret_cast<float4*>(Lo + r * LD128 + c);
-            float4 b = *reinterpret_cast<float4*>(Hi + r * LD128 + c);
-            float4 xa = valid ? *reinterpret_cast<const float4*>(xlo + c) : make_float4(0, 0, 0, 0);
-            float4 xb = valid ? *reinterpret_cast<const float4*>(xhi + c) : make_float4(0, 0, 0, 0);
-            s1 += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
-            s2 += a.x * (xa.x - mean) + a.y * (xa.y - mean) + a.z * (xa.z - mean) + a.w * (xa.w - mean) +
-                  b.x * (xb.x - mean) + b.y * (xb.y - mean) + b.z * (xb.z - mean) + b.w * (xb.w - mean);
-        }
-        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
-        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
-        const float m1 = s1 * (1.0f / 256.0f);
-        const float m2 = s2 * rstd * rstd * (1.0f / 256.0f);  // mean(dyh xhat) * rstd
-        if (valid) {
-            for (int c = q * 4; c < 128; c += 16) {
-                float4 a = *reinterpret_cast<float4*>(Lo + r * LD128 + c);
-                float4 b = *reinterpret_cast<float4*>(Hi + r * LD128 + c);
-                float4 xa = *reinterpret_cast<const float4*>(xlo + c);
-                float4 xb = *reinterpret_cast<const float4*>(xhi + c);
-                float4 oa = make_float4(rstd * (a.x - m1 - (xa.x - mean) * m2), rstd * (a.y - m1 - (xa.y - mean) * m2),
-                                        rstd * (a.z - m1 - (xa.z - mean) * m2), rstd * (a.w - m1 - (xa.w - mean) * m2));
-                float4 ob = make_float4(rstd * (b.x - m1 - (xb.x - mean) * m2), rstd * (b.y - m1 - (xb.y - mean) * m2),
-                                        rstd * (b.z - m1 - (xb.z - mean) * m2), rstd * (b.w - m1 - (xb.w - mean) * m2));
-                *reinterpret_cast<float4*>(dcat + row * (2 * D) + c) = oa;
-                *reinterpret_cast<float4*>(dcat + row * (2 * D) + 128 + c) = ob;
-            }
-        }
-    }
-}
-
 // dXF[p] = dM[p] + dcat[p][:D] + dcat[rev[p]][D:]
 __global__ void k_dxf(const float* __restrict__ dM, const float* __restrict__ dcat, const int* __restrict__ rev,
                       float* __restrict__ dX, int64_t E) {
@@ -1067,11 +993,6 @@ __global__ void k_cell_grad(const float4* __restrict__ dv, const int* __restrict
         if (tr) KERN<TARGS, true><<<GRID, NTHREADS, LDS, STREAM>>>(__VA_ARGS__);       \
         else KERN<TARGS, false><<<GRID, NTHREADS, LDS, STREAM>>>(__VA_ARGS__);         \
     } while (0)
-#define PET_LAUNCH_TR1(tr, KERN, GRID, LDS, STREAM, ...)                               \
-    do {                                                                               \
-        if (tr) KERN<true><<<GRID, NTHREADS, LDS, STREAM>>>(__VA_ARGS__);              \
-        else KERN<false><<<GRID, NTHREADS, LDS, STREAM>>>(__VA_ARGS__);                \
-    } while (0)
 template <int NT>
 static void launch_attn_bwd(const float* QKV, const float* dAO, const Graph& g, float* dQKV, float* dbias_h,
                             float scale, hipStream_t st) {
@@ -1202,9 +1123,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         } else {
             {
                 ProfScope ps("comb_bwd", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D), fE * 4.0 * (3 * D + 2 * D + 2 * D));  // dM, e, e[rev], CA in; dcat out
-                if (!(trr && trr_comb_bwd(dM, B.XF, g, G, B.LNS, B.CA, w.dcat, E, tr ? w.dCA : nullptr, st)))
-                    PET_LAUNCH_TR1(tr, k_comb_bwd, gE, lds2, st, dM, B.XF, g.rev, B.LNS, B.CA, G.ln_g, G.comb2.bwd,
-                    G.comb0.bwd, w.dcat, E, tr ? w.dCA : nullptr);
+                PET_REQUIRE(trr_comb_bwd(dM, B.XF, g, G, B.LNS, B.CA, w.dcat, E, tr ? w.dCA : nullptr, st), PET_ERR_ARGUMENT,
+                            "combination adjoint: the split weight planes are missing (pet_model_finalize)");
                 if (tr) {
                     const std::string gs = std::to_string(gi);
                     tr->linear("combination_mlps." + gs + ".2", D, 2 * D, {dM, nullptr, 0, D},
@@ -1262,8 +1182,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             } else {
                 ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D), fE * 4.0 * (3 * D + 2 * DFF));  // dY, X1, VG in; dX1 out
                 if (trr_l) {
-                    const float* vg = (!tr && emlp_recompute_ok(A.mlp_in, A.mlp_out)) ? nullptr : Ab.VG;
-                    trr_emlp_bwd(dX, Ab.X1, vg, A.g_mlp, ln ? A.b_mlp : nullptr, A.mlp_in, A.mlp_out, dX_alt, E, st,
+                    trr_emlp_bwd(dX, Ab.X1, Ab.VG, A.g_mlp, ln ? A.b_mlp : nullptr, A.mlp_in, A.mlp_out, dX_alt, E, st,
                                  tr ? w.dVG : nullptr);
                 }
                 else PET_LAUNCH_TR(tr, k_swiglu_bwd, PET_TA(128, DFF), gE, lds2, st, dX, Ab.X1, Ab.VG, A.g_mlp,

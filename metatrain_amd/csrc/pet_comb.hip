@@ -18,125 +18,6 @@ namespace pet {
     const bool valid = row0 + L.r < (NROWS);                  \
     const int64_t row = valid ? row0 + L.r : (NROWS) - 1
 
-// f16x3 (trr.h): two fp16 planes, three MFMAs per K block on a high and a cross accumulator; the adjoint scales its
-// input row by a power of two first (row_scale_pow2)
-template <bool FIRST>
-__global__ __launch_bounds__(256) void k_comb_h(const float* __restrict__ XF, const int* __restrict__ rev,
-                                                 const float* __restrict__ ln_g, const float* __restrict__ ln_b, W2 w0,
-                                                 const float* __restrict__ b0, W2 w2, const float* __restrict__ b2,
-                                                 const float* __restrict__ Min, const float* __restrict__ edge_emb,
-                                                 const int* __restrict__ sp_nbr, float* __restrict__ CA,
-                                                 float* __restrict__ LNS, float* __restrict__ Mout, int64_t E) {
-    extern __shared__ __attribute__((aligned(16))) f16x8 xpark2_all[];  // [4 waves][8 blocks][2 pieces][64]
-    TRR_PROLOGUE(E);
-    constexpr int NC = 2 * D / 32;  // hidden chunks of 32
-    constexpr int RD = 8;           // ring depth: a one-tile block is only 192 MFMA cycles, L2 is ~1.5k away
-    f16x8* xpark = xpark2_all + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 8 * 2 * 64;
-    // stream A: W0 tile hc, K blocks 0..15 (kb_total = 16): linear index b = 16 hc + kb
-    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
-    WBlk2<1> ra[RD];
-#pragma unroll
-    for (int b = 0; b < RD; b++) ld_blk2<1>(ra[b], w0, aidx(b), 0);
-    Split2<8> xs;  // the e[p] half (K blocks 0..7) in registers; the e[rev[p]] half (blocks 8..15) in wave-private LDS
-    {
-        float4 xo[16], xr[16];
-        load_rowfrag<16>(xo, XF, row, D, L.h);
-        load_rowfrag<16>(xr, XF, (int64_t)rev[row], D, L.h);
-        float s1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            s1 += xo[k].x + xo[k].y + xo[k].z + xo[k].w + xr[k].x + xr[k].y + xr[k].z + xr[k].w;
-        const float mean = row_sum(s1) * (1.0f / 256.0f);
-        float s2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            float d;
-            d = xo[k].x - mean; s2 += d * d; d = xo[k].y - mean; s2 += d * d;
-            d = xo[k].z - mean; s2 += d * d; d = xo[k].w - mean; s2 += d * d;
-            d = xr[k].x - mean; s2 += d * d; d = xr[k].y - mean; s2 += d * d;
-            d = xr[k].z - mean; s2 += d * d; d = xr[k].w - mean; s2 += d * d;
-        }
-        const float rstd = rsqrtf(row_sum(s2) * (1.0f / 256.0f) + 1e-5f);  // LayerNorm eps (backend.py:95-97)
-        if (LNS && valid && L.h == 0) {
-            LNS[row * 2] = mean;
-            LNS[row * 2 + 1] = rstd;
-        }
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const float4 ga = *reinterpret_cast<const float4*>(ln_g + 8 * k + 4 * L.h);
-            const float4 ba = *reinterpret_cast<const float4*>(ln_b + 8 * k + 4 * L.h);
-            const float4 gb = *reinterpret_cast<const float4*>(ln_g + D + 8 * k + 4 * L.h);
-            const float4 bb = *reinterpret_cast<const float4*>(ln_b + D + 8 * k + 4 * L.h);
-            xo[k].x = (xo[k].x - mean) * rstd * ga.x + ba.x; xo[k].y = (xo[k].y - mean) * rstd * ga.y + ba.y;
-            xo[k].z = (xo[k].z - mean) * rstd * ga.z + ba.z; xo[k].w = (xo[k].w - mean) * rstd * ga.w + ba.w;
-            xr[k].x = (xr[k].x - mean) * rstd * gb.x + bb.x; xr[k].y = (xr[k].y - mean) * rstd * gb.y + bb.y;
-            xr[k].z = (xr[k].z - mean) * rstd * gb.z + bb.z; xr[k].w = (xr[k].w - mean) * rstd * gb.w + bb.w;
-        }
-        split_frag2<8>(xo, xs);
-        Split2<8> t;
-        split_frag2<8>(xr, t);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            xpark[(k * 2 + 0) * 64 + L.lane] = t.h[k];
-            xpark[(k * 2 + 1) * 64 + L.lane] = t.l[k];
-        }
-    }
-    f32x16 out[4], outl[4];
-    acc_bias<4>(out, b2, 0, L.h);
-    acc_zero<4>(outl);
-    float4 bnext[4];
-    ld_bias<1>(bnext, b0, 0, L.h);
-#pragma unroll 1
-    for (int hc = 0; hc < NC; hc++) {
-        // W2 fragments of this chunk: K blocks 2 hc, 2 hc + 1 of the four output tiles (kb_total = 16)
-        WBlk2<4> wo[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++) ld_blk2<4>(wo[kb], w2, (size_t)(2 * hc + kb) * 64 + L.lane, 16 * 64);
-        f32x16 a1[1], a1l[1];
-        acc_from<1>(a1, bnext);
-        acc_zero<1>(a1l);
-        if (hc + 1 < NC) ld_bias<1>(bnext, b0, 32 * (hc + 1), L.h);
-#pragma unroll
-        for (int kb = 0; kb < 16; kb++) {
-            WBlk2<1>& wb = ra[kb % RD];
-            if (kb < 8) {
-                mfma3<1>(a1, a1l, wb, xs.h[kb], xs.l[kb]);
-            } else {
-                const f16x8 ph = xpark[((kb - 8) * 2 + 0) * 64 + L.lane], pl = xpark[((kb - 8) * 2 + 1) * 64 + L.lane];
-                mfma3<1>(a1, a1l, wb, ph, pl);
-            }
-            const int nb = 16 * hc + kb + RD;
-            if (nb < 16 * NC) ld_blk2<1>(wb, w0, aidx(nb), 0);
-        }
-        fold_low<1>(a1, a1l);
-        float4 u[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 a = acc_q(a1[0], q);
-            if (CA && valid) *reinterpret_cast<float4*>(CA + row * (2 * D) + 32 * hc + 8 * q + 4 * L.h) = a;
-            u[q] = make_float4(silu_(a.x), silu_(a.y), silu_(a.z), silu_(a.w));
-        }
-        Split2<2> us;
-        split_frag2<2>(u, us);
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++) mfma3<4>(out, outl, wo[kb], us.h[kb], us.l[kb]);
-    }
-    fold_low<4>(out, outl);
-    if (valid) {
-        float4 y[16], e[16], mi[16];
-        acc_to_frag<4>(out, y);
-        load_rowfrag<16>(e, XF, row, D, L.h);
-        if (FIRST) load_rowfrag<16>(mi, edge_emb, (int64_t)sp_nbr[row], D, L.h);
-        else load_rowfrag<16>(mi, Min, row, D, L.h);
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            y[k].x += e[k].x + mi[k].x; y[k].y += e[k].y + mi[k].y;
-            y[k].z += e[k].z + mi[k].z; y[k].w += e[k].w + mi[k].w;
-        }
-        store_rowfrag<16>(y, Mout, row, D, L.h);
-    }
-}
-
 // ---------------------------------------------------------------------------------
 // k_comb_p2: the same stage as a software-pipelined kernel (default since round 3; pet_config_set("comb_pipe", 0) restores
 // k_comb_h), built like k_emlp_p2 (pet_trr.hip): the three stages of a hidden chunk -- a = W0 LayerNorm([e ; e[rev]]) (one
@@ -362,143 +243,6 @@ __global__ __launch_bounds__(256) void k_comb_p2(const float* __restrict__ XF, c
     for (int t = 0; t < 4; t++) {
         const float4 t4[4] = {acc_q(out[t], 0), acc_q(out[t], 1), acc_q(out[t], 2), acc_q(out[t], 3)};
         store_tile32_lines(t4, otile, Mout + 32 * t, row0, E, D, L);
-    }
-}
-
-// Adjoint. Phase 1 streams the hidden chunks: da = (dM W2)[chunk] . silu'(CA[chunk]) and accumulates the first
-// half of dln = da W0 (the e[p] columns); the da chunks are parked in wave-private LDS (32 KB per wave) and phase 2
-// re-reads them for the second half (the e[rev[p]] columns), so the 256-wide result never needs 8 accumulator tiles.
-template <bool TRAIN>
-__global__ __launch_bounds__(256) void k_comb_bwd_h(const float* __restrict__ dM, const float* __restrict__ XF,
-                                                     const int* __restrict__ rev, const float* __restrict__ LNS,
-                                                     const float* __restrict__ CA, const float* __restrict__ ln_g,
-                                                     W2 w2b, W2 w0b, float* __restrict__ dcat, int64_t E,
-                                                     float* __restrict__ t_da) {
-    extern __shared__ __attribute__((aligned(16))) float4 park_all[];  // [4 waves][NC * 4][64] float4
-    TRR_PROLOGUE(E);
-    constexpr int NC = 2 * D / 32;
-    float4* park = park_all + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * NC * 4 * 64;
-    // stream A: W2^T tile hc (tiles over the 256 hidden columns), K = 128: b = 8 hc + kb
-    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
-    // stream B: W0^T, output tiles over the 256 cat columns (half: four tiles), K = 256 hidden: blocks 2 hc, 2 hc + 1
-    auto bidx = [&](int b, int half) { return ((size_t)(4 * half) * 16 + b) * 64 + L.lane; };  // tile t at + t * 16 * 64
-    WBlk2<1> ra[8];  // 3 MFMAs per block: eight in flight to cover the L2 round trip
-    WBlk2<4> rb[2];
-#pragma unroll
-    for (int b = 0; b < 8; b++) ld_blk2<1>(ra[b], w2b, aidx(b), 0);
-#pragma unroll
-    for (int b = 0; b < 2; b++) ld_blk2<4>(rb[b], w0b, bidx(b, 0), 16 * 64);
-    f32x16 dl[4], dll[4];
-    acc_zero<4>(dl);
-    acc_zero<4>(dll);
-    float inv;  // dM is an adjoint: one power-of-two scale per row; da and dl carry it until they leave the kernel
-    {
-        Split2<8> ms;
-        {
-            float4 d[16];
-            load_rowfrag<16>(d, dM, row, D, L.h);
-            float sc;
-            inv = row_scale_pow2<16>(d, sc);
-            split_frag2<8>(d, ms);
-        }
-        float4 ca[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) ca[q] = *reinterpret_cast<const float4*>(CA + row * (2 * D) + 8 * q + 4 * L.h);
-#pragma unroll 1
-        for (int hc = 0; hc < NC; hc++) {
-            f32x16 t1[1], t1l[1];
-            acc_zero<1>(t1);
-            acc_zero<1>(t1l);
-#pragma unroll
-            for (int kb = 0; kb < 8; kb++) {
-                WBlk2<1>& wb = ra[kb];
-                mfma3<1>(t1, t1l, wb, ms.h[kb], ms.l[kb]);
-                const int nb = 8 * hc + kb + 8;
-                if (nb < 8 * NC) ld_blk2<1>(wb, w2b, aidx(nb), 0);
-            }
-            fold_low<1>(t1, t1l);
-            float4 da[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 v = acc_q(t1[0], q);
-                da[q] = make_float4(v.x * silu_g_(ca[q].x), v.y * silu_g_(ca[q].y), v.z * silu_g_(ca[q].z),
-                                    v.w * silu_g_(ca[q].w));
-                park[(4 * hc + q) * 64 + L.lane] = da[q];
-                if (TRAIN && valid)
-                    *reinterpret_cast<float4*>(t_da + row * (2 * D) + 32 * hc + 8 * q + 4 * L.h) =
-                        make_float4(da[q].x * inv, da[q].y * inv, da[q].z * inv, da[q].w * inv);
-            }
-            if (hc + 1 < NC) {
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    ca[q] = *reinterpret_cast<const float4*>(CA + row * (2 * D) + 32 * (hc + 1) + 8 * q + 4 * L.h);
-            }
-            Split2<2> ds;
-            split_frag2<2>(da, ds);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                WBlk2<4>& wb = rb[j];
-                mfma3<4>(dl, dll, wb, ds.h[j], ds.l[j]);
-                const int nb = 2 * hc + j + 2;  // next chunk's block, or the first blocks of the second half
-                if (nb < 2 * NC) ld_blk2<4>(wb, w0b, bidx(nb, 0), 16 * 64);
-                else ld_blk2<4>(wb, w0b, bidx(nb - 2 * NC, 1), 16 * 64);
-            }
-        }
-    }
-    fold_low<4>(dl, dll);
-    acc_scale<4>(dl, inv);
-    float4 wlo[16];
-    acc_to_frag<4>(dl, wlo);
-    acc_zero<4>(dl);
-    acc_zero<4>(dll);
-#pragma unroll 1
-    for (int hc = 0; hc < NC; hc++) {
-        float4 da[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) da[q] = park[(4 * hc + q) * 64 + L.lane];
-        Split2<2> ds;
-        split_frag2<2>(da, ds);
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            WBlk2<4>& wb = rb[j];
-            mfma3<4>(dl, dll, wb, ds.h[j], ds.l[j]);
-            const int nb = 2 * hc + j + 2;
-            if (nb < 2 * NC) ld_blk2<4>(wb, w0b, bidx(nb, 1), 16 * 64);
-        }
-    }
-    fold_low<4>(dl, dll);
-    acc_scale<4>(dl, inv);
-    float4 whi[16], xo[16], xr[16];
-    acc_to_frag<4>(dl, whi);
-    load_rowfrag<16>(xo, XF, row, D, L.h);
-    load_rowfrag<16>(xr, XF, (int64_t)rev[row], D, L.h);
-    const float mean = LNS[row * 2], rstd = LNS[row * 2 + 1];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {  // dyhat = dln * gamma; LayerNorm adjoint sums
-        const float4 ga = *reinterpret_cast<const float4*>(ln_g + 8 * k + 4 * L.h);
-        const float4 gb = *reinterpret_cast<const float4*>(ln_g + D + 8 * k + 4 * L.h);
-        wlo[k].x *= ga.x; wlo[k].y *= ga.y; wlo[k].z *= ga.z; wlo[k].w *= ga.w;
-        whi[k].x *= gb.x; whi[k].y *= gb.y; whi[k].z *= gb.z; whi[k].w *= gb.w;
-        s1 += wlo[k].x + wlo[k].y + wlo[k].z + wlo[k].w + whi[k].x + whi[k].y + whi[k].z + whi[k].w;
-        s2 += wlo[k].x * (xo[k].x - mean) + wlo[k].y * (xo[k].y - mean) + wlo[k].z * (xo[k].z - mean) +
-              wlo[k].w * (xo[k].w - mean) + whi[k].x * (xr[k].x - mean) + whi[k].y * (xr[k].y - mean) +
-              whi[k].z * (xr[k].z - mean) + whi[k].w * (xr[k].w - mean);
-    }
-    const float m1 = row_sum(s1) * (1.0f / 256.0f);
-    const float m2 = row_sum(s2) * rstd * rstd * (1.0f / 256.0f);
-    {
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            wlo[k] = make_float4(rstd * (wlo[k].x - m1 - (xo[k].x - mean) * m2), rstd * (wlo[k].y - m1 - (xo[k].y - mean) * m2),
-                                 rstd * (wlo[k].z - m1 - (xo[k].z - mean) * m2), rstd * (wlo[k].w - m1 - (xo[k].w - mean) * m2));
-            whi[k] = make_float4(rstd * (whi[k].x - m1 - (xr[k].x - mean) * m2), rstd * (whi[k].y - m1 - (xr[k].y - mean) * m2),
-                                 rstd * (whi[k].z - m1 - (xr[k].z - mean) * m2), rstd * (whi[k].w - m1 - (xr[k].w - mean) * m2));
-        }
-        // the parked chunks are consumed: the wave's park region is its staging tile for full-line stores (trr.h)
-        float* otile = reinterpret_cast<float*>(park);
-        store_rows_lines<16>(wlo, otile, L, [&](int r) { return row0 + r < E ? dcat + (row0 + r) * (2 * D) : nullptr; });
-        store_rows_lines<16>(whi, otile, L, [&](int r) { return row0 + r < E ? dcat + (row0 + r) * (2 * D) + D : nullptr; });
     }
 }
 
@@ -733,11 +477,6 @@ __global__ __launch_bounds__(256) void k_comb_bwd_p2(const float* __restrict__ d
     }
 }
 
-static int g_comb_bwd_pipe = 1;  // k_comb_bwd_p2 (software-pipelined); 0 = k_comb_bwd_h
-void set_comb_bwd_pipe(int v) { g_comb_bwd_pipe = v ? 1 : 0; }
-static int g_comb_pipe = 1;  // k_comb_p2 (software-pipelined); 0 = k_comb_h
-void set_comb_pipe(int v) { g_comb_pipe = v ? 1 : 0; }
-
 static inline W2 w2_of(const void* base, int n_tiles_dim, int k_dim) {
     const size_t n8 = (size_t)(n_tiles_dim / 32) * (k_dim / 16) * 64;
     const f16x8* b = reinterpret_cast<const f16x8*>(base);
@@ -750,28 +489,16 @@ bool trr_comb(bool first, const float* XF, const Graph& g, const GnnLayerW& G, c
     if (!G.comb0.fwd2 || !G.comb2.fwd2 || E <= 0) return false;
     const W2 w0 = w2_of(G.comb0.fwd2, G.comb0.n_out, G.comb0.k_in), w2 = w2_of(G.comb2.fwd2, G.comb2.n_out, G.comb2.k_in);
     const int grid = cdiv(E, WG_ROWS);
-    if (g_comb_pipe) {
-        const size_t lds = (size_t)4 * 32768;  // per wave: e tile (then operands / staging / bias), e[rev] tile (then its planes)
-        if (first) {
-            allow_big_lds(k_comb_p2<true>, lds);
-            k_comb_p2<true><<<grid, 256, lds, st>>>(XF, g.rev, G.ln_g, G.ln_b, w0, G.comb0.b, w2, G.comb2.b, nullptr, edge_emb,
-                                                    g.sp_nbr, CA, LNS, Mout, E);
-        } else {
-            allow_big_lds(k_comb_p2<false>, lds);
-            k_comb_p2<false><<<grid, 256, lds, st>>>(XF, g.rev, G.ln_g, G.ln_b, w0, G.comb0.b, w2, G.comb2.b, Min, edge_emb,
-                                                     g.sp_nbr, CA, LNS, Mout, E);
-        }
-        return true;
+    const size_t lds = (size_t)4 * 32768;  // per wave: e tile (then operands / staging / bias), e[rev] tile (then its planes)
+    if (first) {
+        allow_big_lds(k_comb_p2<true>, lds);
+        k_comb_p2<true><<<grid, 256, lds, st>>>(XF, g.rev, G.ln_g, G.ln_b, w0, G.comb0.b, w2, G.comb2.b, nullptr, edge_emb,
+                                                g.sp_nbr, CA, LNS, Mout, E);
+    } else {
+        allow_big_lds(k_comb_p2<false>, lds);
+        k_comb_p2<false><<<grid, 256, lds, st>>>(XF, g.rev, G.ln_g, G.ln_b, w0, G.comb0.b, w2, G.comb2.b, Min, edge_emb,
+                                                 g.sp_nbr, CA, LNS, Mout, E);
     }
-    const size_t lds = (size_t)4 * 8 * 2 * 64 * sizeof(f16x8);  // 64 KB: the split e[rev] halves of 4 waves
-    allow_big_lds(k_comb_h<true>, lds);
-    allow_big_lds(k_comb_h<false>, lds);
-    if (first)
-        k_comb_h<true><<<grid, 256, lds, st>>>(XF, g.rev, G.ln_g, G.ln_b, w0, G.comb0.b, w2, G.comb2.b, nullptr,
-                                             edge_emb, g.sp_nbr, CA, LNS, Mout, E);
-    else
-        k_comb_h<false><<<grid, 256, lds, st>>>(XF, g.rev, G.ln_g, G.ln_b, w0, G.comb0.b, w2, G.comb2.b, Min, edge_emb,
-                                              g.sp_nbr, CA, LNS, Mout, E);
     return true;
 }
 
@@ -781,24 +508,13 @@ bool trr_comb_bwd(const float* dM, const float* XF, const Graph& g, const GnnLay
     // bwd2 operands: tiles over k_in, K = n_out
     const W2 w2b = w2_of(G.comb2.bwd2, G.comb2.k_in, G.comb2.n_out), w0b = w2_of(G.comb0.bwd2, G.comb0.k_in, G.comb0.n_out);
     const int grid = cdiv(E, WG_ROWS);
-    if (g_comb_bwd_pipe) {
-        const size_t lds = (size_t)4 * 40960;  // per wave: parked da planes 32 KB, pre-activation chunks 2 x 4 KB
-        if (t_da) {
-            allow_big_lds(k_comb_bwd_p2<true>, lds);
-            k_comb_bwd_p2<true><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, t_da);
-        } else {
-            allow_big_lds(k_comb_bwd_p2<false>, lds);
-            k_comb_bwd_p2<false><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, nullptr);
-        }
-        return true;
-    }
-    const size_t lds = (size_t)4 * (2 * D / 32) * 4 * 64 * sizeof(float4);  // 128 KB: the parked da chunks of 4 waves
+    const size_t lds = (size_t)4 * 40960;  // per wave: parked da planes 32 KB, pre-activation chunks 2 x 4 KB
     if (t_da) {
-        allow_big_lds(k_comb_bwd_h<true>, lds);
-        k_comb_bwd_h<true><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, t_da);
+        allow_big_lds(k_comb_bwd_p2<true>, lds);
+        k_comb_bwd_p2<true><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, t_da);
     } else {
-        allow_big_lds(k_comb_bwd_h<false>, lds);
-        k_comb_bwd_h<false><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, nullptr);
+        allow_big_lds(k_comb_bwd_p2<false>, lds);
+        k_comb_bwd_p2<false><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, nullptr);
     }
     return true;
 }

@@ -13,7 +13,7 @@
 //   k_oproj      transformer.py:151 + 229 (output_linear, edge residual)
 //   k_node       transformer.py:222-227 (center_expansion, center_mlp)
 //   k_emlp       transformer.py:230-232 (edge SwiGLU MLP)
-//   k_comb       backend.py:559-575 (ji gather, LayerNorm, combination MLP, residuals)
+//   (combination stage backend.py:559-575: k_comb_p2 in pet_comb.hip)
 //   k_head_*     backend.py:651-687, 726-777 (heads, last layers, cutoff-weighted sum)
 #include <mutex>
 #include <set>
@@ -590,96 +590,6 @@ __global__ void k_resmix(const float* __restrict__ Min, const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------
-// message passing: Mout = Min + e + MLP(LayerNorm([e ; e[rev]]))   (backend.py:559-575)
-// ---------------------------------------------------------------------------------
-template <bool FIRST>
-__global__ __launch_bounds__(NTHREADS) void k_comb(const float* __restrict__ XF, const int* __restrict__ rev,
-                                                    const float* __restrict__ ln_g, const float* __restrict__ ln_b,
-                                                    const float4* __restrict__ w0, const float* __restrict__ b0,
-                                                    const float4* __restrict__ w2, const float* __restrict__ b2,
-                                                    const float* __restrict__ Min,       // [E,D]  (!FIRST)
-                                                    const float* __restrict__ edge_emb,  // [ns,D] (FIRST)
-                                                    const int* __restrict__ sp_nbr, float* __restrict__ CA,
-                                                    float* __restrict__ LNS, float* __restrict__ Mout, int64_t E) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Lo = smem;               // [64][132]  e rows
-    float* Hi = smem + BM * LD128;  // [64][132]  e[rev] rows
-    const WaveId w;
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
-    load_rows_to_lds<128>(Lo, XF, row0, E, D);
-    for (int idx = threadIdx.x; idx < BM * 32; idx += NTHREADS) {  // gathered rows: 512 B each
-        int r = idx >> 5, c = idx & 31;
-        float4 v = make_float4(0, 0, 0, 0);
-        if (row0 + r < E) v = *reinterpret_cast<const float4*>(XF + (int64_t)rev[row0 + r] * D + 4 * c);
-        *reinterpret_cast<float4*>(Hi + r * LD128 + 4 * c) = v;
-    }
-    __syncthreads();
-    {   // LayerNorm over the 256 concatenated features, eps = 1e-5 (backend.py:95-97)
-        const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
-        float s1 = 0.f, s2 = 0.f;
-        for (int c = q * 4; c < 128; c += 16) {
-            float4 a = *reinterpret_cast<float4*>(Lo + r * LD128 + c);
-            float4 b = *reinterpret_cast<float4*>(Hi + r * LD128 + c);
-            s1 += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
-        }
-        s1 += __shfl_xor(s1, 1);
-        s1 += __shfl_xor(s1, 2);
-        const float mean = s1 * (1.0f / 256.0f);
-        for (int c = q * 4; c < 128; c += 16) {
-            float4 a = *reinterpret_cast<float4*>(Lo + r * LD128 + c);
-            float4 b = *reinterpret_cast<float4*>(Hi + r * LD128 + c);
-            float d;
-            d = a.x - mean; s2 += d * d; d = a.y - mean; s2 += d * d;
-            d = a.z - mean; s2 += d * d; d = a.w - mean; s2 += d * d;
-            d = b.x - mean; s2 += d * d; d = b.y - mean; s2 += d * d;
-            d = b.z - mean; s2 += d * d; d = b.w - mean; s2 += d * d;
-        }
-        s2 += __shfl_xor(s2, 1);
-        s2 += __shfl_xor(s2, 2);
-        const float rstd = rsqrtf(s2 * (1.0f / 256.0f) + 1e-5f);
-        if (LNS && q == 0 && row0 + r < E) {
-            LNS[(row0 + r) * 2] = mean;
-            LNS[(row0 + r) * 2 + 1] = rstd;
-        }
-        for (int c = q * 4; c < 128; c += 16) {
-            float4 a = *reinterpret_cast<float4*>(Lo + r * LD128 + c);
-            float4 b = *reinterpret_cast<float4*>(Hi + r * LD128 + c);
-            float4 ga = *reinterpret_cast<const float4*>(ln_g + c), ba = *reinterpret_cast<const float4*>(ln_b + c);
-            float4 gb = *reinterpret_cast<const float4*>(ln_g + 128 + c), bb = *reinterpret_cast<const float4*>(ln_b + 128 + c);
-            a.x = (a.x - mean) * rstd * ga.x + ba.x; a.y = (a.y - mean) * rstd * ga.y + ba.y;
-            a.z = (a.z - mean) * rstd * ga.z + ba.z; a.w = (a.w - mean) * rstd * ga.w + ba.w;
-            b.x = (b.x - mean) * rstd * gb.x + bb.x; b.y = (b.y - mean) * rstd * gb.y + bb.y;
-            b.z = (b.z - mean) * rstd * gb.z + bb.z; b.w = (b.w - mean) * rstd * gb.w + bb.w;
-            *reinterpret_cast<float4*>(Lo + r * LD128 + c) = a;
-            *reinterpret_cast<float4*>(Hi + r * LD128 + c) = b;
-        }
-    }
-    __syncthreads();
-    f32x16 a1[4];  // 32 rows x 128 hidden columns (128 * ch ..)
-    acc_fill_bias<4>(a1, b0, 128 * w.ch, w.lane);
-    gemm_acc<128, 4>(Lo + w.rb * 32 * LD128, LD128, w0, 32, 0, 4 * w.ch, a1, w.lane);
-    gemm_acc<128, 4>(Hi + w.rb * 32 * LD128, LD128, w0, 32, 16, 4 * w.ch, a1, w.lane);
-    __syncthreads();  // all waves finished reading Lo/Hi
-    float* Sdst = w.ch == 0 ? Lo : Hi;  // hidden columns 0..127 -> Lo, 128..255 -> Hi
-    acc_foreach<4>(a1, w.rb, 0, w.lane, [&](int r, int c, float v) {
-        if (CA && row0 + r < E) CA[(row0 + r) * (2 * D) + 128 * w.ch + c] = v;
-        Sdst[r * LD128 + c] = siluf_(v);
-    });
-    __syncthreads();
-    f32x16 out[2];
-    acc_fill_bias<2>(out, b2, 64 * w.ch, w.lane);
-    gemm_acc<128, 2>(Lo + w.rb * 32 * LD128, LD128, w2, 32, 0, 2 * w.ch, out, w.lane);
-    gemm_acc<128, 2>(Hi + w.rb * 32 * LD128, LD128, w2, 32, 16, 2 * w.ch, out, w.lane);
-    acc_foreach<2>(out, w.rb, 64 * w.ch, w.lane, [&](int r, int c, float v) {
-        const int64_t row = row0 + r;
-        if (row < E) {
-            float m_in = FIRST ? edge_emb[sp_nbr[row] * D + c] : Min[row * D + c];
-            Mout[row * D + c] = m_in + XF[row * D + c] + v;
-        }
-    });
-}
-
-// ---------------------------------------------------------------------------------
 // heads: y = w . SiLU(W2 SiLU(W0 x + b0) + b2) + b     (backend.py:171-217, 726-777)
 // ---------------------------------------------------------------------------------
 template <int K>
@@ -1025,8 +935,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
             if (E > 0 && !post) {
                 ProfScope ps("emlp", st, fE * 2.0 * (D * 2 * DFF + DFF * D), fE * 4.0 * (2 * D + 2 * DFF));  // X1 in; VG, X2 out
                 if (trr_l) {
-                    // [v; g] is stored for the adjoint unless no adjoint follows (save == 0) or it recomputes them
-                    float* vg = (save == 0 || (save != 2 && emlp_recompute_ok(A.mlp_in, A.mlp_out))) ? nullptr : Ab.VG;
+                    float* vg = save == 0 ? nullptr : Ab.VG;  // [v; g] is stored for the adjoint unless none follows
                     trr_emlp(Ab.X1, A.g_mlp, m.layer_norm() ? A.b_mlp : nullptr, A.mlp_in, A.mlp_out, vg, Xnext, E, st);
                 }
                 else k_emlp<true><<<gE, NTHREADS, lds2, st>>>(Ab.X1, A.g_mlp, A.b_mlp, A.mlp_in.fwd, A.mlp_in.b, A.mlp_out.fwd,
@@ -1046,16 +955,9 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
             }
         } else if (E > 0) {
             ProfScope ps("comb", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D), fE * 4.0 * (3 * D + 2 * D + D));  // e, e[rev], M in; CA, M out
-            if (trr && trr_comb(gi == 0, B.XF, g, G, Min, m.edge_emb, B.CA, B.LNS, B.Mout, E, st)) {
-                // TRR kernel on the bf16 matrix cores (pet_comb.hip)
-            } else if (gi == 0)
-                k_comb<true><<<gE, NTHREADS, lds2, st>>>(B.XF, g.rev, G.ln_g, G.ln_b, G.comb0.fwd, G.comb0.b,
-                                                         G.comb2.fwd, G.comb2.b, nullptr, m.edge_emb, g.sp_nbr,
-                                                         B.CA, B.LNS, B.Mout, E);
-            else
-                k_comb<false><<<gE, NTHREADS, lds2, st>>>(B.XF, g.rev, G.ln_g, G.ln_b, G.comb0.fwd, G.comb0.b,
-                                                          G.comb2.fwd, G.comb2.b, Min, m.edge_emb, g.sp_nbr, B.CA,
-                                                          B.LNS, B.Mout, E);
+            // the software-pipelined TRR kernel (pet_comb.hip) is the one implementation of this stage
+            PET_REQUIRE(trr_comb(gi == 0, B.XF, g, G, Min, m.edge_emb, B.CA, B.LNS, B.Mout, E, st), PET_ERR_ARGUMENT,
+                        "combination stage: the split weight planes are missing (pet_model_finalize)");
         }
     }
     const GnnBufs& last = w.gnn.back();

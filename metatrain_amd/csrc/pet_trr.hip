@@ -75,49 +75,6 @@ __device__ __forceinline__ void row_gemm128_h(const W2& w, const float* __restri
     }
 }
 
-template <bool LN>
-__global__ __launch_bounds__(256, 2) void k_qkv_h(const float* __restrict__ X, const float* __restrict__ gamma,
-                                                const float* __restrict__ beta, W2 win,
-                                                const float* __restrict__ bin, float* __restrict__ QKV, int64_t R) {
-    TRR_PROLOGUE(R);
-    Split2<8> xs;
-    {
-        float4 x[16];
-        load_rowfrag<16>(x, X, row, D, L.h);
-        norm_frag<16, LN>(x, gamma, beta, L.h);
-        split_frag2<8>(x, xs);
-    }
-    row_gemm128_h<6, false, 2>(win, bin, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
-        if (valid) {
-            float4 y[8];
-            acc_to_frag<2>(acc, y);
-            store_rowfrag<8>(y, QKV + 64 * c, row, 3 * D, L.h);
-        }
-    });
-}
-
-// the same with full-line stores through a wave-private LDS tile (trr.h store_tile64_lines)
-template <bool LN>
-__global__ __launch_bounds__(256, 2) void k_qkv_hl(const float* __restrict__ X, const float* __restrict__ gamma,
-                                                 const float* __restrict__ beta, W2 win,
-                                                 const float* __restrict__ bin, float* __restrict__ QKV, int64_t R) {
-    __shared__ __attribute__((aligned(16))) float tiles[4][32 * ROWS_LD];
-    TRR_PROLOGUE(R);
-    float* lds = tiles[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-    Split2<8> xs;
-    {
-        float4 x[16];
-        load_rows_lines128(x, lds, X, row0, R, L);
-        norm_frag<16, LN>(x, gamma, beta, L.h);
-        split_frag2<8>(x, xs);
-    }
-    row_gemm128_h<6, false, 2>(win, bin, xs, L, 1.0f, [&](int c, f32x16 (&acc)[2]) {
-        float4 y[8];
-        acc_to_frag<2>(acc, y);
-        store_tile64_lines(y, lds, QKV + 64 * c, row0, R, 3 * D, L);
-    });
-}
-
 // ---------------------------------------------------------------------------------
 // "Shared weight stream" kernels (round 3; pet_config_set("lds_w", bits)). The TRR kernels above give every 32-row WAVE
 // its own copy of the weight stream from L2: 196 KB of fragments against 64 KB of rows per tile in the QKV stage, i.e.
@@ -347,154 +304,6 @@ static inline W2 w2_wc(const GnnLayerW& G) {  // one 32-row tile, K = D
     return w;
 }
 // ---------------------------------------------------------------------------------
-// edge SwiGLU MLP: X2 = X1 + Wout (v * sig(g)) + b,  [v; g] = Win RMSNorm(X1) + b
-// Persistent: one workgroup per CU walks a strided list of 32-row tiles. What a one-tile-per-wave kernel pays at
-// every tile -- the HBM round trip of its input rows before the first MFMA, and the cold weight ring -- is paid
-// once per wave here: the NEXT tile's rows are fetched into wave-private LDS by LDS-DMA while this tile computes
-// (same lane mapping as load_rowfrag, so every lane reads back exactly the 16 B pieces it requested), the residual
-// re-read comes from the same buffer, and the w_in ring keeps running into the next tile's first blocks.
-// ---------------------------------------------------------------------------------
-// f16x3 (trr.h): two fp16 planes, three MFMAs per K block on a high and a cross accumulator; RMSNorm output and
-// SwiGLU output are O(1) rows, so no row scaling is needed here.
-template <bool LINES, bool LN>
-__global__ __launch_bounds__(256) void k_emlp_h(const float* __restrict__ X1, const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta, W2 win,
-                                                  const float* __restrict__ bin, W2 wout,
-                                                  const float* __restrict__ bout, float* __restrict__ VG,
-                                                  float* __restrict__ X2, int64_t E) {
-    extern __shared__ __attribute__((aligned(16))) float4 xstage[];  // [4 waves][2 buffers][16][64]
-    const RowLane L;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4* mybuf = xstage + (size_t)wave * 2 * 16 * 64;
-    // LINES: outputs leave as whole 128-B lines through a wave-private [32][36] tile behind the row buffers (trr.h)
-    float* otile = reinterpret_cast<float*>(xstage + (size_t)4 * 2 * 16 * 64) + wave * 32 * TILE32_LD;
-    const int64_t ntiles = (E + WROWS - 1) / WROWS, nw = (int64_t)gridDim.x * 4;
-    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    if (tile >= ntiles) return;
-    auto issue_rows = [&](int64_t t, int buf) {
-        int64_t rr = t * WROWS + L.r;
-        if (rr >= E) rr = E - 1;
-        const float* src = X1 + rr * D + 4 * L.h;
-        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(mybuf + (size_t)buf * 16 * 64));
-#pragma unroll
-        for (int kg = 0; kg < 16; kg++) glds16_trr(src + 8 * kg, dst + kg * 1024);
-    };
-    issue_rows(tile, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only the first tile waits for its own rows
-    constexpr int NC = DFF / 32;
-    auto widx = [&](int b) { return ((size_t)(b >> 3) * 8 + (b & 7)) * 64 + L.lane; };
-    constexpr size_t TS = (size_t)NC * 8 * 64;
-    WBlk2<2> ring[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) ld_blk2<2>(ring[b], win, widx(b), TS);
-    float4 bv[4], bg[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        bv[q] = *reinterpret_cast<const float4*>(bin + 8 * q + 4 * L.h);
-        bg[q] = *reinterpret_cast<const float4*>(bin + DFF + 8 * q + 4 * L.h);
-    }
-    for (int it = 0; tile < ntiles; it++, tile += nw) {
-        const int64_t row0 = tile * WROWS;
-        const bool valid = row0 + L.r < E;
-        const int64_t row = valid ? row0 + L.r : E - 1;
-        const float4* xb = mybuf + (size_t)(it & 1) * 16 * 64;
-        if (tile + nw < ntiles) issue_rows(tile + nw, (it + 1) & 1);
-        Split2<8> xs;
-        {
-            float4 x[16];
-#pragma unroll
-            for (int kg = 0; kg < 16; kg++) x[kg] = xb[kg * 64 + L.lane];
-            norm_frag<16, LN>(x, gamma, beta, L.h);
-            split_frag2<8>(x, xs);
-        }
-        f32x16 out[4], outl[4];
-        acc_bias<4>(out, bout, 0, L.h);
-        acc_zero<4>(outl);
-#pragma unroll 1
-        for (int hc = 0; hc < NC; hc++) {
-            f16x8 oh[2][4], ol[2][4];
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const size_t i = ((size_t)t * (DFF / 16) + 2 * hc + kb) * 64 + L.lane;
-                    oh[kb][t] = wout.h[i]; ol[kb][t] = wout.l[i];
-                }
-            f32x16 vg[2], vgl[2];
-            acc_zero<2>(vgl);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                vg[0][4 * q] = bv[q].x; vg[0][4 * q + 1] = bv[q].y; vg[0][4 * q + 2] = bv[q].z; vg[0][4 * q + 3] = bv[q].w;
-                vg[1][4 * q] = bg[q].x; vg[1][4 * q + 1] = bg[q].y; vg[1][4 * q + 2] = bg[q].z; vg[1][4 * q + 3] = bg[q].w;
-            }
-            {
-                const int hn = hc + 1 < NC ? hc + 1 : 0;  // wraps to the next tile's first chunk
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    bv[q] = *reinterpret_cast<const float4*>(bin + 32 * hn + 8 * q + 4 * L.h);
-                    bg[q] = *reinterpret_cast<const float4*>(bin + DFF + 32 * hn + 8 * q + 4 * L.h);
-                }
-            }
-#pragma unroll
-            for (int kb = 0; kb < 8; kb++) {
-                WBlk2<2>& wb = ring[kb & 3];
-                mfma3<2>(vg, vgl, wb, xs.h[kb], xs.l[kb]);
-                int nb = 8 * hc + kb + 4;  // four steps ahead; past the end = the next tile's first blocks
-                nb = nb < 8 * NC ? nb : nb - 8 * NC;
-                ld_blk2<2>(wb, win, widx(nb), TS);
-            }
-            fold_low<2>(vg, vgl);
-            float4 u[4];
-            if (LINES && VG) {
-                float4 t4[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) t4[q] = acc_q(vg[0], q);
-                store_tile32_lines(t4, otile, VG + 32 * hc, row0, E, 2 * DFF, L);
-#pragma unroll
-                for (int q = 0; q < 4; q++) t4[q] = acc_q(vg[1], q);
-                store_tile32_lines(t4, otile, VG + DFF + 32 * hc, row0, E, 2 * DFF, L);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 vv = acc_q(vg[0], q), gg = acc_q(vg[1], q);
-                if (!LINES && VG && valid) {
-                    *reinterpret_cast<float4*>(VG + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) = vv;
-                    *reinterpret_cast<float4*>(VG + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) = gg;
-                }
-                u[q] = make_float4(vv.x * sigm_(gg.x), vv.y * sigm_(gg.y), vv.z * sigm_(gg.z), vv.w * sigm_(gg.w));
-            }
-            Split2<2> us;
-            split_frag2<2>(u, us);
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    outl[t] = PET_MFMA_H(ol[kb][t], us.h[kb], outl[t]);
-                    out[t] = PET_MFMA_H(oh[kb][t], us.h[kb], out[t]);
-                    outl[t] = PET_MFMA_H(oh[kb][t], us.l[kb], outl[t]);
-                }
-        }
-        fold_low<4>(out, outl);
-        {
-            float4 y[16];
-            acc_to_frag<4>(out, y);
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const float4 xr = xb[k * 64 + L.lane];
-                y[k].x += xr.x; y[k].y += xr.y; y[k].z += xr.z; y[k].w += xr.w;
-            }
-            if (LINES) {
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const float4 t4[4] = {y[4 * t], y[4 * t + 1], y[4 * t + 2], y[4 * t + 3]};
-                    store_tile32_lines(t4, otile, X2 + 32 * t, row0, E, D, L);
-                }
-            } else if (valid) store_rowfrag<16>(y, X2, row, D, L.h);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
 // k_emlp_p2: the edge MLP as a software-pipelined kernel (default since round 3; pet_config_set("emlp_pipe", 0) restores
 // the persistent k_emlp_h). Same scheme as k_emlp_bwd_p2 below: the three stages of a hidden chunk -- [v; g] = Win xn
 // (48 MFMAs), u = v sigma(g) + operand split (VALU), out += Wout u (24 MFMAs) -- depend on each other and a wave issues
@@ -683,114 +492,6 @@ __global__ __launch_bounds__(256) void k_emlp_p2(const float* __restrict__ X1, c
     for (int t = 0; t < 4; t++) {
         const float4 t4[4] = {acc_q(out[t], 0), acc_q(out[t], 1), acc_q(out[t], 2), acc_q(out[t], 3)};
         store_tile32_lines(t4, otile, X2 + 32 * t, row0, E, D, L);
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// dX1 = dY + RMSNorm^T( Win^T [du sig(g) ; du v sig'(g)] ),  du = Wout^T dY
-// two weight streams, both ring-prefetched across the hidden chunks --
-//   A: Wout^T blocks for du (tile hc of the [DFF x D] operand, 8 K blocks per chunk, one tile);
-//   B: Win^T blocks for dn += [dv | dg] Win (four output tiles; per chunk K blocks 2hc, 2hc+1 of the value half
-//      and 16 + 2hc, 16 + 2hc + 1 of the gate half).
-// ---------------------------------------------------------------------------------
-template <bool TRAIN, bool LN>
-__global__ __launch_bounds__(256) void k_emlp_bwd_h(const float* __restrict__ dY, const float* __restrict__ X1,
-                                                     const float* __restrict__ VG, const float* __restrict__ gamma,
-                                                     W2 woutb, W2 winb, float* __restrict__ dX1, int64_t E,
-                                                     float* __restrict__ t_dvg) {
-    TRR_PROLOGUE(E);
-    constexpr int NC = DFF / 32;
-    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };  // b = 8 hc + kb: tile hc, kb_total = 8
-    auto bkb = [&](int b) { const int hc = b >> 2, j = b & 3; return (j < 2 ? 2 * hc + j : 16 + 2 * hc + (j - 2)); };
-    auto bidx = [&](int b) { return (size_t)bkb(b) * 64 + L.lane; };  // tile 0; tile t at + t * 32 * 64
-    // a one-tile f16x3 block is only 3 MFMAs (96 cycles): eight of them in flight to cover the L2 round trip
-    WBlk2<1> ra[8];
-    WBlk2<4> rb[2];
-#pragma unroll
-    for (int b = 0; b < 8; b++) ld_blk2<1>(ra[b], woutb, aidx(b), 0);
-#pragma unroll
-    for (int b = 0; b < 2; b++) ld_blk2<4>(rb[b], winb, bidx(b), 32 * 64);
-    Split2<8> ys;
-    float inv;  // dY is an adjoint: one power-of-two scale per row, undone on everything that leaves the kernel
-    {
-        float4 dy[16];
-        load_rowfrag<16>(dy, dY, row, D, L.h);
-        float sc;
-        inv = row_scale_pow2<16>(dy, sc);
-        split_frag2<8>(dy, ys);
-    }
-    f32x16 dn[4], dnl[4];
-    acc_zero<4>(dn);
-    acc_zero<4>(dnl);
-    float4 vv[4], gg[4];  // saved pre-activations of the current chunk
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        vv[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + 8 * q + 4 * L.h);
-        gg[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + DFF + 8 * q + 4 * L.h);
-    }
-#pragma unroll 1
-    for (int hc = 0; hc < NC; hc++) {
-        f32x16 du[1], dul[1];
-        acc_zero<1>(du);
-        acc_zero<1>(dul);
-#pragma unroll
-        for (int kb = 0; kb < 8; kb++) {
-            WBlk2<1>& wb = ra[kb];
-            mfma3<1>(du, dul, wb, ys.h[kb], ys.l[kb]);
-            const int nb = 8 * hc + kb + 8;
-            if (nb < 8 * NC) ld_blk2<1>(wb, woutb, aidx(nb), 0);
-        }
-        fold_low<1>(du, dul);
-        float4 dvg[8];  // dv (4) then dg (4): the K = 64 operand of stream B
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 d = acc_q(du[0], q);
-            const float sx = sigm_(gg[q].x), sy = sigm_(gg[q].y), sz = sigm_(gg[q].z), sw = sigm_(gg[q].w);
-            dvg[q] = make_float4(d.x * sx, d.y * sy, d.z * sz, d.w * sw);
-            dvg[4 + q] = make_float4(d.x * vv[q].x * sx * (1.f - sx), d.y * vv[q].y * sy * (1.f - sy),
-                                     d.z * vv[q].z * sz * (1.f - sz), d.w * vv[q].w * sw * (1.f - sw));
-            if (TRAIN && valid) {
-                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + 32 * hc + 8 * q + 4 * L.h) =
-                    make_float4(dvg[q].x * inv, dvg[q].y * inv, dvg[q].z * inv, dvg[q].w * inv);
-                *reinterpret_cast<float4*>(t_dvg + row * (2 * DFF) + DFF + 32 * hc + 8 * q + 4 * L.h) =
-                    make_float4(dvg[4 + q].x * inv, dvg[4 + q].y * inv, dvg[4 + q].z * inv, dvg[4 + q].w * inv);
-            }
-        }
-        if (hc + 1 < NC) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                vv[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + 32 * (hc + 1) + 8 * q + 4 * L.h);
-                gg[q] = *reinterpret_cast<const float4*>(VG + row * (2 * DFF) + DFF + 32 * (hc + 1) + 8 * q + 4 * L.h);
-            }
-        }
-        Split2<4> ds;
-        split_frag2<4>(dvg, ds);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            WBlk2<4>& wb = rb[j & 1];
-            mfma3<4>(dn, dnl, wb, ds.h[j], ds.l[j]);
-            const int nb = 4 * hc + j + 2;
-            if (nb < 4 * NC) ld_blk2<4>(wb, winb, bidx(nb), 32 * 64);
-        }
-    }
-    fold_low<4>(dn, dnl);
-    acc_scale<4>(dn, inv);
-    float4 w[16], x[16];
-    acc_to_frag<4>(dn, w);
-    load_rowfrag<16>(x, X1, row, D, L.h);
-#pragma unroll
-    for (int kg = 0; kg < 16; kg++) {
-        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
-        w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
-    }
-    norm_bwd_frag<16, LN>(w, x);
-    if (valid) {
-        load_rowfrag<16>(x, dY, row, D, L.h);
-#pragma unroll
-        for (int kg = 0; kg < 16; kg++) {
-            w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
-        }
-        store_rowfrag<16>(w, dX1, row, D, L.h);
     }
 }
 
@@ -1067,146 +768,6 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_p2(const float* __restrict__ d
     }
 }
 
-// Edge-MLP adjoint WITHOUT the saved pre-activations (inference: pet_forward stores no VG for this stage). [v; g] is
-// recomputed per hidden chunk from RMSNorm(X1) with the forward weight planes: one more f16x3 GEMM per chunk (the
-// matrix pipe has room: the stored-VG form moves 6.4 GB per launch at ~3.2 TB/s with the MFMAs ~20 % busy), against
-// 4 KB per edge and layer less written by the forward and 4 KB less read here, i.e. a quarter of the step's HBM
-// traffic. The two split row operands (dY, scaled; RMSNorm(X1)) live in wave-private LDS, 32 KB per wave.
-template <bool LN>
-__global__ __launch_bounds__(256) void k_emlp_bwd_r(const float* __restrict__ dY, const float* __restrict__ X1,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     W2 winf,
-                                                     const float* __restrict__ bin, W2 woutb, W2 winb,
-                                                     float* __restrict__ dX1, int64_t E) {
-    extern __shared__ __attribute__((aligned(16))) f16x8 opark[];  // [4 waves][ys: 8 x 2][xs: 8 x 2][64]
-    TRR_PROLOGUE(E);
-    constexpr int NC = DFF / 32;
-    f16x8* ysp = opark + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 32 * 64;
-    f16x8* xsp = ysp + 16 * 64;
-    auto fidx = [&](int b) { return ((size_t)(b >> 3) * 8 + (b & 7)) * 64 + L.lane; };  // forward W_in: tile hc, +TS = gate
-    constexpr size_t TS = (size_t)NC * 8 * 64;
-    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
-    auto bkb = [&](int b) { const int hc = b >> 2, j = b & 3; return (j < 2 ? 2 * hc + j : 16 + 2 * hc + (j - 2)); };
-    auto bidx = [&](int b) { return (size_t)bkb(b) * 64 + L.lane; };
-    constexpr int RD = 4;  // ring depth of the two K = 128 streams
-    WBlk2<2> rf[RD];
-    WBlk2<1> ra[RD];
-    WBlk2<2> rb[2];  // W_in^T blocks, two output tiles at a time: stream index j2 = 8 hc + 4 half + j
-#pragma unroll
-    for (int b = 0; b < RD; b++) ld_blk2<2>(rf[b], winf, fidx(b), TS);
-#pragma unroll
-    for (int b = 0; b < RD; b++) ld_blk2<1>(ra[b], woutb, aidx(b), 0);
-    auto b2idx = [&](int j2) {  // half 1: tiles 2, 3
-        return bidx(4 * (j2 >> 3) + (j2 & 3)) + (size_t)((j2 >> 2) & 1) * 2 * 32 * 64;
-    };
-#pragma unroll
-    for (int b = 0; b < 2; b++) ld_blk2<2>(rb[b], winb, b2idx(b), 32 * 64);
-    float inv;
-    {
-        float4 dy[16];
-        load_rowfrag<16>(dy, dY, row, D, L.h);
-        float sc;
-        inv = row_scale_pow2<16>(dy, sc);
-        Split2<8> t;
-        split_frag2<8>(dy, t);
-#pragma unroll
-        for (int k = 0; k < 8; k++) { ysp[(2 * k) * 64 + L.lane] = t.h[k]; ysp[(2 * k + 1) * 64 + L.lane] = t.l[k]; }
-    }
-    {
-        float4 x[16];
-        load_rowfrag<16>(x, X1, row, D, L.h);
-        norm_frag<16, LN>(x, gamma, beta, L.h);
-        Split2<8> t;
-        split_frag2<8>(x, t);
-#pragma unroll
-        for (int k = 0; k < 8; k++) { xsp[(2 * k) * 64 + L.lane] = t.h[k]; xsp[(2 * k + 1) * 64 + L.lane] = t.l[k]; }
-    }
-    f32x16 dn[4];
-    acc_zero<4>(dn);
-#pragma unroll 1
-    for (int hc = 0; hc < NC; hc++) {
-        f32x16 vg[2], vgl[2];  // the bias is added after the GEMM (no prefetch registers to spare)
-        acc_zero<2>(vg);
-        acc_zero<2>(vgl);
-        f32x16 du[1], dul[1];
-        acc_zero<1>(du);
-        acc_zero<1>(dul);
-        // the parked operands are loop-invariant: without this the compiler hoists all 32 fragment reads (128
-        // registers) out of the chunk loop and spills
-        const f16x8* xq = xsp + L.lane;
-        const f16x8* yq = ysp + L.lane;
-        asm volatile("" : "+v"(xq), "+v"(yq));
-#pragma unroll
-        for (int kb = 0; kb < 8; kb++) {
-            const f16x8 xh = xq[(2 * kb) * 64], xl = xq[(2 * kb + 1) * 64];
-            const f16x8 yh = yq[(2 * kb) * 64], yl = yq[(2 * kb + 1) * 64];
-            WBlk2<2>& wf = rf[kb % RD];
-            WBlk2<1>& wa = ra[kb % RD];
-            mfma3<2>(vg, vgl, wf, xh, xl);
-            mfma3<1>(du, dul, wa, yh, yl);
-            const int nb = 8 * hc + kb + RD;
-            if (nb < 8 * NC) {
-                ld_blk2<2>(wf, winf, fidx(nb), TS);
-                ld_blk2<1>(wa, woutb, aidx(nb), 0);
-            }
-        }
-        fold_low<2>(vg, vgl);
-        fold_low<1>(du, dul);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 b0 = *reinterpret_cast<const float4*>(bin + 32 * hc + 8 * q + 4 * L.h);
-            const float4 b1 = *reinterpret_cast<const float4*>(bin + DFF + 32 * hc + 8 * q + 4 * L.h);
-            vg[0][4 * q] += b0.x; vg[0][4 * q + 1] += b0.y; vg[0][4 * q + 2] += b0.z; vg[0][4 * q + 3] += b0.w;
-            vg[1][4 * q] += b1.x; vg[1][4 * q + 1] += b1.y; vg[1][4 * q + 2] += b1.z; vg[1][4 * q + 3] += b1.w;
-        }
-        float4 dvg[8];  // dv (4) then dg (4): the K = 64 operand of stream B
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 d = acc_q(du[0], q), vv = acc_q(vg[0], q), gg = acc_q(vg[1], q);
-            const float sx = sigm_(gg.x), sy = sigm_(gg.y), sz = sigm_(gg.z), sw = sigm_(gg.w);
-            dvg[q] = make_float4(d.x * sx, d.y * sy, d.z * sz, d.w * sw);
-            dvg[4 + q] = make_float4(d.x * vv.x * sx * (1.f - sx), d.y * vv.y * sy * (1.f - sy),
-                                     d.z * vv.z * sz * (1.f - sz), d.w * vv.w * sw * (1.f - sw));
-        }
-        Split2<4> ds;
-        split_frag2<4>(dvg, ds);
-        // dn += [dv; dg] W_in, two output tiles at a time; the cross sums are folded in per chunk so that only one
-        // pair of them is live (registers)
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            f32x16 lo[2];
-            acc_zero<2>(lo);
-            f32x16(&dh)[2] = *reinterpret_cast<f32x16(*)[2]>(&dn[2 * half]);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                WBlk2<2>& wb = rb[j & 1];
-                mfma3<2>(dh, lo, wb, ds.h[j], ds.l[j]);
-                const int nb = 8 * hc + 4 * half + j + 2;
-                if (nb < 8 * NC) ld_blk2<2>(wb, winb, b2idx(nb), 32 * 64);
-            }
-            fold_low<2>(dh, lo);
-        }
-    }
-    acc_scale<4>(dn, inv);
-    float4 w[16], x[16];
-    acc_to_frag<4>(dn, w);
-    load_rowfrag<16>(x, X1, row, D, L.h);
-#pragma unroll
-    for (int kg = 0; kg < 16; kg++) {
-        const float4 g = *reinterpret_cast<const float4*>(gamma + 8 * kg + 4 * L.h);
-        w[kg].x *= g.x; w[kg].y *= g.y; w[kg].z *= g.z; w[kg].w *= g.w;
-    }
-    norm_bwd_frag<16, LN>(w, x);
-    if (valid) {
-        load_rowfrag<16>(x, dY, row, D, L.h);
-#pragma unroll
-        for (int kg = 0; kg < 16; kg++) {
-            w[kg].x += x[kg].x; w[kg].y += x[kg].y; w[kg].z += x[kg].z; w[kg].w += x[kg].w;
-        }
-        store_rowfrag<16>(w, dX1, row, D, L.h);
-    }
-}
-
 // ---------------------------------------------------------------------------------
 // compress stage (transformer.py:499-521) and its adjoint as TRR kernels on f16x3. One wave = 32 edges:
 //   forward:  a0 = [v,d] Wc^T + Tbl[species] (+ M W0c^T);  e = SiLU(a0) W2^T + b2
@@ -1353,20 +914,6 @@ __global__ __launch_bounds__(256, 2) void k_compress_bwd_h(const float* __restri
 // host launchers (declared in model.h)
 // ---------------------------------------------------------------------------------
 static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
-// full-line stores through a wave-private LDS tile (trr.h store_rows_lines): bit 0 qkv, bit 1 edge MLP (A/B switches;
-// oproj_bwd, qkv_bwd, compress, compress_bwd, comb_bwd and head_bwd always store this way)
-static int g_line_stores = 3;
-void set_line_stores(int v) { g_line_stores = v; }
-static int g_lds_w = -1;   // shared weight stream kernels: bit 0 qkv (PET_HIP_LDS_W sets the start value)
-void set_lds_w(int v) { g_lds_w = v; }
-static int lds_w() {
-    if (g_lds_w < 0) {
-        const char* e = getenv("PET_HIP_LDS_W");
-        g_lds_w = e ? atoi(e) : 1;   // qkv: 3.39 -> 3.16 ms per step (8 x 10k-atom boxes), bit-identical results
-    }
-    return g_lds_w;
-}
-
 // The GEMMs of these kernels are split-operand products on the 16-bit matrix cores (f16x3: 2-way fp16 split, three
 // MFMAs per K block; 1.7e-7 product error against fp64, tools/ubench). The fp32-MFMA and 3-way bf16 (bf16x6)
 // generations of round 1 were removed in round 2; pet_config_set("trr", 0) selects the LDS-tile kernels of
@@ -1377,51 +924,18 @@ static int g_tile_mask = 0;  // debugging aid: bits switch individual LDS-tile G
 void set_tile_mask(int v) { g_tile_mask = v; }
 int tile_mask() { return g_tile_mask; }
 bool use_tile_f16x3() { return g_tile_f16x3 != 0; }
-// pet_config_set("emlp_recompute", 1): the inference adjoint of the edge MLP rebuilds the SwiGLU pre-activations
-// instead of reading them back. Saves 16 KB of workspace traffic per edge and makes the forward stage 21 % faster
-// (6.4 -> 5.1 ms per step), but the recomputing adjoint issues 120 instead of 72 MFMAs per chunk at the same ~20 %
-// pipe utilisation (these kernels are issue / latency bound, not HBM bound) and takes 13.1 ms against 7.9: OFF by
-// default, kept as the memory-lean variant.
 // pet_config_set("trr_compress", bits): 1 compress (+adjoint), 2 edge head (+adjoint); 0 = the LDS-tile kernels
 static int g_trr_tilek = 3;
 void set_trr_compress(int v) { g_trr_tilek = v; }
-static int g_emlp_pipe = 1;      // k_emlp_p2 (software-pipelined); 0 = the persistent k_emlp_h
-void set_emlp_pipe(int v) { g_emlp_pipe = v ? 1 : 0; }
-static int g_emlp_bwd_pipe = 1;  // k_emlp_bwd_p2 (software-pipelined, LDS-staged operands); 0 = k_emlp_bwd_h
-void set_emlp_bwd_pipe(int v) { g_emlp_bwd_pipe = v ? 1 : 0; }
-static int g_emlp_recompute = 0;
-void set_emlp_recompute(int v) { g_emlp_recompute = v ? 1 : 0; }
-// inference only: the edge-MLP adjoint rebuilds [v; g] instead of reading them back (k_emlp_bwd_r)
-bool emlp_recompute_ok(const Lin& win, const Lin& wout) {
-    return g_emlp_recompute && use_trr() && win.fwd2 && win.bwd2 && wout.bwd2 && wout.fwd2;
-}
-static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    }
-    return n;
-}
 
 // beta: the LayerNorm bias, nullptr = RMSNorm (here and below)
 void trr_qkv(const float* X, const float* gamma, const float* beta, const Lin& qkv, float* QKV, int64_t R,
              hipStream_t st) {
     if (R <= 0) return;
-    const int grid = grid_rows(R);
-    if (lds_w() & 1) {
-        const size_t lds = SW_WBYTES + (size_t)SW_WAVES * 32 * TILE_LD * 4;
-        const int g8 = (int)cdiv(R, SW_WAVES * WROWS);
-        if (beta) { allow_big_lds(k_qkv_s<true>, lds); k_qkv_s<true><<<g8, 512, lds, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R); }
-        else { allow_big_lds(k_qkv_s<false>, lds); k_qkv_s<false><<<g8, 512, lds, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R); }
-    } else if (g_line_stores & 1) {
-        if (beta) k_qkv_hl<true><<<grid, 256, 0, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R);
-        else k_qkv_hl<false><<<grid, 256, 0, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R);
-    } else {
-        if (beta) k_qkv_h<true><<<grid, 256, 0, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R);
-        else k_qkv_h<false><<<grid, 256, 0, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R);
-    }
+    const size_t lds = SW_WBYTES + (size_t)SW_WAVES * 32 * TILE_LD * 4;
+    const int g8 = (int)cdiv(R, SW_WAVES * WROWS);
+    if (beta) { allow_big_lds(k_qkv_s<true>, lds); k_qkv_s<true><<<g8, 512, lds, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R); }
+    else { allow_big_lds(k_qkv_s<false>, lds); k_qkv_s<false><<<g8, 512, lds, st>>>(X, gamma, beta, w2_fwd(qkv), qkv.b, QKV, R); }
 }
 void trr_qkv_bwd(const float* dQKV, const float* X, const float* gamma, bool layer_norm, const Lin& qkv,
                  const float* dX1, float* dXin, int64_t E, int64_t R, hipStream_t st) {
@@ -1439,59 +953,29 @@ void trr_oproj_bwd(const float* dX1, const float* dOC, const Lin& out, float* dA
     if (R <= 0) return;
     k_oproj_bwd_h<<<grid_rows(R), 256, 0, st>>>(dX1, dOC, w2_bwd(out), dAO, E, R);
 }
-template <bool LINES, bool LN>
-static void launch_emlp(int grid, size_t lds, hipStream_t st, const float* X1, const float* gamma, const float* beta,
-                        const Lin& win, const Lin& wout, float* VG, float* X2, int64_t E) {
-    allow_big_lds(k_emlp_h<LINES, LN>, lds);
-    k_emlp_h<LINES, LN><<<grid, 256, lds, st>>>(X1, gamma, beta, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
-}
 void trr_emlp(const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout, float* VG,
               float* X2, int64_t E, hipStream_t st) {
     if (E <= 0) return;
-    if (g_emlp_pipe) {
-        const size_t lds = (size_t)4 * EP2_WAVE_LDS;
-        if (beta) {
-            allow_big_lds(k_emlp_p2<true>, lds);
-            k_emlp_p2<true><<<grid_rows(E), 256, lds, st>>>(X1, gamma, beta, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
-        } else {
-            allow_big_lds(k_emlp_p2<false>, lds);
-            k_emlp_p2<false><<<grid_rows(E), 256, lds, st>>>(X1, gamma, beta, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
-        }
-        return;
-    }
-    const size_t rows_lds = (size_t)4 * 2 * 16 * 64 * sizeof(float4);  // 128 KB: two row buffers per wave
-    const int grid = std::min(grid_rows(E), num_cus());
-    if (g_line_stores & 2) {
-        const size_t lds = rows_lds + (size_t)4 * 32 * TILE32_LD * sizeof(float);  // + one output tile per wave
-        if (beta) launch_emlp<true, true>(grid, lds, st, X1, gamma, beta, win, wout, VG, X2, E);
-        else launch_emlp<true, false>(grid, lds, st, X1, gamma, beta, win, wout, VG, X2, E);
+    const size_t lds = (size_t)4 * EP2_WAVE_LDS;
+    if (beta) {
+        allow_big_lds(k_emlp_p2<true>, lds);
+        k_emlp_p2<true><<<grid_rows(E), 256, lds, st>>>(X1, gamma, beta, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
     } else {
-        if (beta) launch_emlp<false, true>(grid, rows_lds, st, X1, gamma, beta, win, wout, VG, X2, E);
-        else launch_emlp<false, false>(grid, rows_lds, st, X1, gamma, beta, win, wout, VG, X2, E);
+        allow_big_lds(k_emlp_p2<false>, lds);
+        k_emlp_p2<false><<<grid_rows(E), 256, lds, st>>>(X1, gamma, beta, w2_fwd(win), win.b, w2_fwd(wout), wout.b, VG, X2, E);
     }
 }
 template <bool LN>
 static void launch_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const float* beta,
                             const Lin& win, const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg) {
     const int grid = grid_rows(E);
-    if (VG == nullptr && !t_dvg) {
-        const size_t lds = (size_t)4 * 32 * 64 * sizeof(f16x8);  // 128 KB: both split row operands of 4 waves
-        allow_big_lds(k_emlp_bwd_r<LN>, lds);
-        k_emlp_bwd_r<LN><<<grid, 256, lds, st>>>(dY, X1, gamma, beta, w2_fwd(win), win.b, w2_bwd(wout), w2_bwd(win), dX1,
-                                                 E);
-    } else if (g_emlp_bwd_pipe) {
-        const size_t lds = (size_t)4 * 40960;  // per wave: dY tile / split planes 16 KB, VG chunks / X1 tile 16 KB, [dv | dg] 8 KB (all 160 KB of the CU)
-        if (t_dvg) {
-            allow_big_lds(k_emlp_bwd_p2<true, LN>, lds);
-            k_emlp_bwd_p2<true, LN><<<grid, 256, lds, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, t_dvg);
-        } else {
-            allow_big_lds(k_emlp_bwd_p2<false, LN>, lds);
-            k_emlp_bwd_p2<false, LN><<<grid, 256, lds, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, nullptr);
-        }
-    } else if (t_dvg) {
-        k_emlp_bwd_h<true, LN><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, t_dvg);
+    const size_t lds = (size_t)4 * 40960;  // per wave: dY tile / split planes 16 KB, VG chunks / X1 tile 16 KB, [dv | dg] 8 KB (all 160 KB of the CU)
+    if (t_dvg) {
+        allow_big_lds(k_emlp_bwd_p2<true, LN>, lds);
+        k_emlp_bwd_p2<true, LN><<<grid, 256, lds, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, t_dvg);
     } else {
-        k_emlp_bwd_h<false, LN><<<grid, 256, 0, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, nullptr);
+        allow_big_lds(k_emlp_bwd_p2<false, LN>, lds);
+        k_emlp_bwd_p2<false, LN><<<grid, 256, lds, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, nullptr);
     }
 }
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const float* beta,

@@ -97,6 +97,27 @@ def init(backend: str, device: torch.device = None) -> None:
     dist.init_process_group(backend, **kwargs)
 
 
+def selftest(expected_world: int, device: torch.device = None) -> None:
+    """Fail loudly, before any timed work, if the job is not what the launcher line promised: the process group must
+    hold ``expected_world`` ranks and one all-reduce over it must work (sum of ones = world size on every rank). A bench
+    that silently ran on fewer ranks -- a rank that died at start-up, a launcher that fell back to one process -- would
+    report a number for the wrong job. Called by every ``bench*.py`` right after ``init`` when ``--gpus`` > 1."""
+    if not dist.is_initialized():
+        if expected_world > 1:
+            raise SystemExit(f"distributed self-test: --gpus {expected_world} but no process group was initialised")
+        return
+    world = dist.get_world_size()
+    if world != expected_world:
+        raise SystemExit(f"distributed self-test: {world} rank(s) joined, {expected_world} expected")
+    on_gpu = device is not None and device.type == "cuda"
+    t = torch.ones(1 << 16, dtype=torch.float32, device=device if on_gpu else "cpu")
+    dist.all_reduce(t)
+    if on_gpu:
+        torch.cuda.synchronize(device)
+    if float(t[0]) != float(world) or float(t[-1]) != float(world):
+        raise SystemExit(f"distributed self-test: all-reduce of ones over {world} rank(s) returned {float(t[0])}")
+
+
 def shard_structures(n_total: int, rank: int, world: int) -> List[int]:
     """Round-robin assignment of structure ids to ranks (identical synthetic boxes are balanced by
     construction; the reference's DistributedSampler does the same without shuffling for

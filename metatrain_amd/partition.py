@@ -80,11 +80,16 @@ def _slab_coordinate(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[
 def slab_owner(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bool], world: int) -> torch.Tensor:
     """``[N]`` int64: the rank that owns every atom -- the same intervals, bound for bound, as :func:`slab_partition`."""
     f, _, lo_all, width, _, _ = _slab_coordinate(positions, cell, pbc)
-    owner = torch.full((positions.shape[0],), -1, dtype=torch.long, device=positions.device)
-    for rank in range(world):
-        lo, hi = lo_all + width * rank / world, lo_all + width * (rank + 1) / world
-        owner[(f >= lo) & (f < hi)] = rank
-    return owner
+    return _owner_of(f, lo_all, width, world)
+
+
+def _owner_of(f: torch.Tensor, lo_all: float, width: float, world: int) -> torch.Tensor:
+    """Slab number of every coordinate: ``floor((f - lo) / width * world)`` clamped to ``[0, world)``, so that a value that
+    rounds onto the upper bound of the last slab still has an owner and NaN / inf positions are refused here
+    instead of surfacing as an opaque ``bincount`` error in the exchange plan."""
+    if not bool(torch.isfinite(f).all()):
+        raise ValueError("non-finite atom positions: the slab partition cannot place them")
+    return torch.clamp(torch.floor((f - lo_all) / width * world), 0, world - 1).to(torch.long)
 
 
 def slab_partition(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bool], halo: float, world: int,
@@ -102,12 +107,12 @@ def slab_partition(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bo
     f, wrap, lo_all, width, unit, axis = _slab_coordinate(positions, cell, pbc)
     h = halo / unit * 1.0001
     lo, hi = lo_all + width * rank / world, lo_all + width * (rank + 1) / world
-    owned = (f >= lo) & (f < hi)
+    owned = _owner_of(f, lo_all, width, world) == rank  # the same expression slab_owner uses: every atom has one owner
     below, above = lo - f, f - hi  # > 0 on the respective outside
     if wrap:
         below, above = torch.remainder(below, 1.0), torch.remainder(above, 1.0)
         near = torch.minimum(below, above) < h
     else:
-        near = ((below > 0) & (below < h)) | ((above >= 0) & (above < h))
+        near = ((below > -1e-12) & (below < h)) | ((above > -1e-12) & (above < h))
     index = torch.nonzero(owned | near).squeeze(1)
     return index, owned[index], axis

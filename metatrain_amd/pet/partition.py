@@ -140,53 +140,94 @@ def energy_and_gradient_exchange(model, positions: torch.Tensor, species: torch.
     cutoff = float(model.hypers["cutoff"])
     dev = positions.device
     n = positions.shape[0]
-    index, owned, _ = slab_partition(positions, cell, pbc, cutoff, world, rank)
-    owner = slab_owner(positions, cell, pbc, world)
+    n_layers = int(model.hypers["num_gnn_layers"])
     buf = torch.zeros(3 * n + 1, dtype=torch.float32, device=dev)
     n_rows = n_ghost = 0
-    sub_pos = positions.detach()[index].to(torch.float32).contiguous()
-    sub_z = species[index].to(torch.int32).contiguous()
-    pairs, _ = neighbor_list(sub_pos, cell, pbc, cutoff)
-    if pairs.numel():   # halo-halo edges are nobody's business here: every kept edge touches an owned atom
-        keep = owned[pairs[:, 0].long()] | owned[pairs[:, 1].long()]
-        pairs = pairs[keep]
-    graph = runtime.HipGraph(model, sub_pos, cell.reshape(1, 3, 3).to(dev, torch.float32), pairs[:, 0].contiguous(),
-                             pairs[:, 1].contiguous(), pairs[:, 2:5].contiguous(), sub_z,
-                             torch.zeros(index.numel(), dtype=torch.int32, device=dev))
-    plan = ExchangePlan(graph, index, owned, owner, world, int(model.hypers["d_pet"]))
-    n_rows, n_ghost = int(graph.n_edges), int(plan.ghost_rows.numel())
-
-    def hook(_user, direction, _layer):
-        try:
-            if direction == 0:
-                all_to_all(plan.ghost_buf, plan.export_buf, plan.recv_splits, plan.send_splits)
-            else:
-                all_to_all(plan.export_buf, plan.ghost_buf, plan.send_splits, plan.recv_splits)
-            return 0
-        except Exception as exc:  # a Python exception must not unwind through the C frames
-            plan.error = exc
-            return 1
-
-    from .._lib import EXCHANGE_FN
-
-    cb = EXCHANGE_FN(hook)
-    rt_check = runtime.check
-    rt_check(model.lib.pet_graph_set_exchange(graph.handle, runtime._ptr(plan.export_rows), plan.export_rows.numel(),
-                                              runtime._ptr(plan.ghost_rows), plan.ghost_rows.numel(),
-                                              runtime._ptr(plan.export_buf), runtime._ptr(plan.ghost_buf), cb, None))
+    # Every rank must enter the same collectives: 2 x num_gnn_layers all-to-alls and one all-reduce. A rank whose slab
+    # (plus halo) is empty has nothing to launch -- the library returns before any layer -- and a rank that fails while
+    # it sets up (neighbour list, graph, plan; an atom of more than 127 neighbours, which the exchange does not serve)
+    # would leave its peers waiting. So: set up under a guard, agree on an "everybody is fine" flag FIRST (one tiny
+    # all-reduce; every rank raises if any rank failed), then run, and top the all-to-all count up with zero-row calls.
+    index = owned = graph = plan = None
+    setup_error: Optional[BaseException] = None
     try:
-        fw = runtime.HipForward(model, graph)
-        seeds = owned.to(torch.float32)
-        atomic = fw.forward()
-        grad_sub = fw.backward(seeds)
-    except Exception:
-        if getattr(plan, "error", None) is not None:
-            raise plan.error
-        raise
-    finally:
-        model.lib.pet_graph_set_exchange(graph.handle, None, 0, None, 0, None, None, EXCHANGE_FN(), None)
-    buf[: 3 * n].view(n, 3)[index] = grad_sub
-    buf[3 * n] = (atomic.reshape(-1) * seeds).sum()
+        index, owned, _ = slab_partition(positions, cell, pbc, cutoff, world, rank)
+        owner = slab_owner(positions, cell, pbc, world)
+        if index.numel():
+            sub_pos = positions.detach()[index].to(torch.float32).contiguous()
+            sub_z = species[index].to(torch.int32).contiguous()
+            pairs, _ = neighbor_list(sub_pos, cell, pbc, cutoff)
+            if pairs.numel():   # halo-halo edges are nobody's business here: every kept edge touches an owned atom
+                keep = owned[pairs[:, 0].long()] | owned[pairs[:, 1].long()]
+                pairs = pairs[keep]
+            graph = runtime.HipGraph(model, sub_pos, cell.reshape(1, 3, 3).to(dev, torch.float32), pairs[:, 0].contiguous(),
+                                     pairs[:, 1].contiguous(), pairs[:, 2:5].contiguous(), sub_z,
+                                     torch.zeros(index.numel(), dtype=torch.int32, device=dev))
+            if int(getattr(graph, "max_neighbors", 0)) > 127:
+                raise ValueError("an atom has more than 127 neighbours: the per-layer exchange is built for the tuned kernels")
+            plan = ExchangePlan(graph, index, owned, owner, world, int(model.hypers["d_pet"]))
+            n_rows, n_ghost = int(graph.n_edges), int(plan.ghost_rows.numel())
+    except Exception as exc:  # noqa: BLE001 -- reported to every rank below
+        setup_error = exc
+    if all_reduce is not None:
+        flag = torch.tensor([0.0 if setup_error is None else 1.0], dtype=torch.float32, device=dev)
+        all_reduce(flag)
+        if float(flag) > 0 and setup_error is None:
+            raise RuntimeError("another rank failed while setting up the per-layer exchange; this rank stops with it")
+    if setup_error is not None:
+        raise setup_error
+    empty = torch.zeros((0, int(model.hypers["d_pet"])), dtype=torch.float32, device=dev)
+    zeros = [0] * world
+    calls = [0, 0]  # all-to-alls issued so far, per direction
+
+    def exchange(direction):
+        if plan is None:
+            all_to_all(empty, empty, zeros, zeros)
+        elif direction == 0:
+            all_to_all(plan.ghost_buf, plan.export_buf, plan.recv_splits, plan.send_splits)
+        else:
+            all_to_all(plan.export_buf, plan.ghost_buf, plan.send_splits, plan.recv_splits)
+        calls[direction] += 1
+
+    run_error: Optional[BaseException] = None
+    if plan is not None:
+        def hook(_user, direction, _layer):
+            try:
+                exchange(direction)
+                return 0
+            except Exception as exc:  # a Python exception must not unwind through the C frames
+                plan.error = exc
+                return 1
+
+        from .._lib import EXCHANGE_FN
+
+        cb = EXCHANGE_FN(hook)
+        rt_check = runtime.check
+        rt_check(model.lib.pet_graph_set_exchange(graph.handle, runtime._ptr(plan.export_rows), plan.export_rows.numel(),
+                                                  runtime._ptr(plan.ghost_rows), plan.ghost_rows.numel(),
+                                                  runtime._ptr(plan.export_buf), runtime._ptr(plan.ghost_buf), cb, None))
+        try:
+            fw = runtime.HipForward(model, graph)
+            seeds = owned.to(torch.float32)
+            atomic = fw.forward()
+            while calls[0] < n_layers:  # a sub-system without edges: the library had nothing to exchange
+                exchange(0)
+            grad_sub = fw.backward(seeds)
+            buf[: 3 * n].view(n, 3)[index] = grad_sub
+            buf[3 * n] = (atomic.reshape(-1) * seeds).sum()
+        except Exception as exc:  # noqa: BLE001 -- the peers still get their collectives below
+            run_error = getattr(plan, "error", None) or exc
+        finally:
+            model.lib.pet_graph_set_exchange(graph.handle, None, 0, None, 0, None, None, EXCHANGE_FN(), None)
+    if plan is not None and getattr(plan, "error", None) is not None:
+        raise plan.error  # the collective itself failed: nothing to keep in step with
+    for direction in (0, 1):  # keep in step with the peers: an empty slab, or a local failure after the agreement
+        while calls[direction] < n_layers:
+            exchange(direction)
     if all_reduce is not None:
         all_reduce(buf)
-    return buf[3 * n:], buf[: 3 * n].view(n, 3), int(index.numel()), int(owned.sum()), n_rows, n_ghost
+    if run_error is not None:
+        raise run_error
+    return (buf[3 * n:], buf[: 3 * n].view(n, 3), 0 if index is None else int(index.numel()),
+            0 if owned is None else int(owned.sum()), n_rows, n_ghost)
+

@@ -158,15 +158,38 @@ class SoapBpnnHip:
 
 class SoapTrainStep:
     """One optimizer step of SOAP-BPNN on one batch, the body of the reference's loop (``soap_bpnn/trainer.py:344-391``):
-    ``zero_grad -> evaluate_model(is_training=True) -> per-atom average -> MSE(E/atom) + MSE(dE/dR) -> backward -> Adam``
-    (lr 1e-3, no gradient clipping, ``soap_bpnn/documentation.py`` TrainerHypers). Descriptor, tail, reverse and
-    second-order passes, weight gradients and Adam run in libpet_hip; torch does the ``[S]`` / ``[N, 3]`` loss arithmetic
-    (shared with the PET step, ``metatrain_amd/pet/trainer.py``) and, for N > 1 ranks, the gradient all-reduce."""
+    ``zero_grad -> evaluate_model(is_training=True) -> per-atom average -> MSE(E/atom) + MSE(dE/dR) -> backward -> Adam ->
+    lr_scheduler.step()``. Adam's learning rate follows the reference's ``LambdaLR`` (``soap_bpnn/trainer.py:54-84``: linear
+    warm-up over ``warmup_fraction`` of ``num_epochs * steps_per_epoch`` steps -- so the very first step runs at lr 0 --
+    then a cosine to zero), stepped once per batch; no gradient clipping (``soap_bpnn/documentation.py`` TrainerHypers:
+    learning_rate 1e-3, num_epochs 100, warmup_fraction 0.01). Descriptor, tail, reverse and second-order passes, weight
+    gradients and Adam run in libpet_hip; torch does the ``[S]`` / ``[N, 3]`` loss arithmetic (shared with the PET step,
+    ``metatrain_amd/pet/trainer.py``). One rank: the gradients stay inside the library, there is no all-reduce hook."""
 
-    def __init__(self, model: SoapBpnnHip, learning_rate: float = 1e-3, loss_weights: Optional[dict] = None):
-        self.model, self.lr = model, learning_rate
+    DEFAULTS = {"learning_rate": 1e-3, "num_epochs": 100, "warmup_fraction": 0.01}
+
+    def __init__(self, model: SoapBpnnHip, hypers: Optional[dict] = None, steps_per_epoch: int = 1,
+                 loss_weights: Optional[dict] = None):
+        self.model = model
+        self.hypers = dict(self.DEFAULTS)
+        self.hypers.update(hypers or {})
+        self.total_steps = int(self.hypers["num_epochs"]) * int(steps_per_epoch)
         self.weights = {"energy": 1.0, "forces": 1.0, **(loss_weights or {})}
-        self.step_index = 0
+        self.step_index = 0  # optimizer steps taken so far (LambdaLR's last_epoch)
+
+    def current_lr(self) -> float:
+        from ..pet.trainer import lr_lambda
+
+        return self.hypers["learning_rate"] * lr_lambda(self.step_index, self.total_steps, self.hypers["warmup_fraction"])
+
+    def state_dict(self) -> Dict[str, object]:
+        """The scheduler's side of a trainer checkpoint: the step counter drives Adam's bias correction and the schedule."""
+        return {"step_index": self.step_index, "total_steps": self.total_steps, "hypers": dict(self.hypers)}
+
+    def load_state_dict(self, state: Dict[str, object]) -> None:
+        self.step_index = int(state["step_index"])
+        self.total_steps = int(state["total_steps"])
+        self.hypers.update(state["hypers"])
 
     def __call__(self, g: rt.HipGraph, target_energies: torch.Tensor, n_atoms: torch.Tensor,
                  target_gradients: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
@@ -183,6 +206,7 @@ class SoapTrainStep:
             loss_f, u = force_loss_and_seeds(grad_positions, target_gradients, self.weights["forces"])
             loss = loss + loss_f
         tangent = m.train_gradients(g, seeds, u)
+        lr = self.current_lr()  # the rate the scheduler set after the previous step
         self.step_index += 1
-        m.adam_step(self.lr, self.step_index)
-        return {"loss": loss, "energies": energies, "tangent_atomic": tangent}
+        m.adam_step(lr, self.step_index)
+        return {"loss": loss, "energies": energies, "tangent_atomic": tangent, "lr": lr}

@@ -701,8 +701,106 @@ def main_sizes():
         np.savez_compressed(os.path.join(HERE, f"pet_size_{tag}_box64.npz"), **store)
 
 
+def main_soap_ps():
+    """SOAP power spectrum: the REFERENCE's ``soap_bpnn/modules/power_spectrum.py`` imported unchanged and run on the
+    oracle's spherical expansion. torch-spex (the expansion itself) is not installable here, so ``spex.spherical_expansion.
+    SphericalExpansion`` is a stand-in that returns ``oracle.soap.spherical_expansion`` in spex's output format (a list over
+    l of ``[centre, 2l+1, n_l, channel]``); everything downstream of it -- the per-l ``einsum("smn,smN->snN")`` contraction,
+    the flattening and concatenation order over (l, n, channel, n', channel'), the split into ``center_type`` blocks of the
+    legacy model -- is reference code. Writes soap_ps_box24.npz (legacy / Orthogonal and Alchemical)."""
+    from oracle import nl as onl
+    from oracle import pet as opet
+    from oracle import soap as osoap
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class Labels:
+        def __init__(self, names, values):
+            self.names, self.values = names, values
+
+        def to(self, device):
+            return self
+
+    class TensorBlock:
+        def __init__(self, values, samples, components, properties):
+            self.values, self.samples, self.components, self.properties = values, samples, components, properties
+
+    class TensorMap:
+        def __init__(self, keys, blocks):
+            self.keys, self.blocks = keys, blocks
+
+    state = {}
+
+    class _Radial:
+        pass
+
+    class SphericalExpansion:  # spex's constructor signature as the reference calls it (power_spectrum.py:42)
+        def __init__(self, cutoff, max_angular, radial, angular, species, cutoff_function):
+            self.max_angular = max_angular
+            self.radial = _Radial()
+            self.radial.n_per_l = state["n_per_l"]
+
+        def forward(self, R_ij, i, j, species):
+            return osoap.spherical_expansion(R_ij, i, state["sp_index"][j], len(species), state["hypers"], state["weights"])
+
+    stub("metatensor")
+    stub("metatensor.torch", Labels=Labels, TensorBlock=TensorBlock, TensorMap=TensorMap)
+    stub("spex")
+    stub("spex.spherical_expansion", SphericalExpansion=SphericalExpansion)
+    spec = importlib.util.spec_from_file_location("ref_power_spectrum", f"{REF}/soap_bpnn/modules/power_spectrum.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    atomic_types = [1, 6, 7, 8]
+    n_at = 24  # 4 544 features per atom: kept small (the file holds two [n_at, 4544] fp32 arrays)
+    pos, z, cell = opet.random_box(n_at, seed=21)
+    out = {"in_positions": pos.numpy(), "in_species": z.numpy(), "in_cell": cell.numpy()}
+    for tag, legacy in (("legacy", True), ("alchemical", False)):
+        hypers = dict(osoap.DEFAULT_HYPERS, legacy=legacy)
+        so = hypers["soap"]
+        n_per_l = osoap.basis(hypers)[0]
+        i, j, sh, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, float(so["cutoff"]["radius"]))
+        i, j, sh = torch.tensor(i), torch.tensor(j), torch.tensor(sh)
+        p64 = pos.double()
+        v = p64[j] - p64[i] + sh.double() @ cell.double()
+        table = torch.full((max(atomic_types) + 1,), -1, dtype=torch.long)
+        table[torch.tensor(atomic_types)] = torch.arange(len(atomic_types))
+        params = osoap.synthetic_params(hypers, len(atomic_types), n_per_l, 3, torch.float64)
+        weights = torch.eye(4, dtype=torch.float64) if legacy else params["species_embedding.weight"].double()
+        state.update(n_per_l=n_per_l, hypers=hypers, weights=weights, sp_index=table[z.long()])
+        species_spec = ({"Orthogonal": {"species": atomic_types}} if legacy
+                        else {"Alchemical": {"pseudo_species": 4, "total_species": len(atomic_types)}})
+        ps = mod.SoapPowerSpectrum(float(so["cutoff"]["radius"]), so["max_angular"],
+                                   {"LaplacianEigenstates": {"max_radial": so["max_radial"]}}, "SphericalHarmonics",
+                                   species_spec, {"ShiftedCosine": {"width": so["cutoff"]["width"]}})
+        tmap = ps.forward(v, i, j, z.long(), torch.zeros(n_at, dtype=torch.long), torch.arange(n_at))
+        full = torch.zeros((n_at, ps.shape), dtype=torch.float64)
+        if legacy:
+            keys = tmap.keys.values.reshape(-1).tolist()
+            for key, block in zip(keys, tmap.blocks):
+                atoms = block.samples.values[:, 1]
+                assert bool((z[atoms].long() == key).all())
+                full[atoms] = block.values
+            out["legacy_center_types"] = np.array(keys)
+        else:
+            (block,) = tmap.blocks
+            full[block.samples.values[:, 1]] = block.values
+            out["alchemical_species_embedding"] = weights.numpy()
+        assert full.shape[1] == osoap.soap_size(n_per_l, 4)
+        out[f"{tag}_power_spectrum"] = full.numpy().astype(np.float32)
+        out[f"{tag}_pairs"] = torch.cat([i[:, None], j[:, None], sh], 1).numpy()
+        print(tag, "power spectrum", tuple(full.shape), "|max|", float(full.abs().max()))
+    np.savez_compressed(os.path.join(HERE, "soap_ps_box24.npz"), **out)
+
+
 if __name__ == "__main__":
-    if "--sizes" in sys.argv:
+    if "--soap-ps" in sys.argv:
+        main_soap_ps()
+    elif "--sizes" in sys.argv:
         main_sizes()
     elif "--multitarget" in sys.argv:
         main_multitarget()

@@ -116,11 +116,13 @@ def test_product_does_not_import_the_oracle():
 
 
 def test_config_switches_of_removed_kernel_generations_are_rejected(lib):
-    """Round 2 dropped the fp32-MFMA / bf16x6 TRR generations and two attention forms: their switches are unknown keys
+    """Round 2 dropped the fp32-MFMA / bf16x6 TRR generations and two attention forms, round 4 the kernels that the
+    software-pipelined edge-MLP / combination kernels and the shared-weight QKV kernel had superseded (k_emlp_h, k_emlp_bwd_h,
+    k_emlp_bwd_r, k_comb_h, k_comb_bwd_h, the LDS-tile k_comb pair, k_qkv_h, k_qkv_hl): their switches are unknown keys
     (PET_ERR_ARGUMENT), the documented ones (include/pet_hip.h) are accepted."""
-    for key in (b"bf16x6", b"f16x3", b"trr_persist", b"so_bf16x6", b"no_such_switch"):
+    for key in (b"bf16x6", b"f16x3", b"trr_persist", b"so_bf16x6", b"emlp_pipe", b"emlp_bwd_pipe", b"comb_pipe",
+                b"comb_bwd_pipe", b"emlp_recompute", b"line_stores", b"lds_w", b"no_such_switch"):
         assert lib.pet_config_set(key, 0) == -3, key
-    for key, default in ((b"trr", 1), (b"attn_lds", 3), (b"tile_f16x3", 1), (b"trr_compress", 3), (b"line_stores", 3),
-                         (b"node_planes", 1), (b"so_trr", 1), (b"so_f16x3", 1), (b"wgrad_bf16", 1), (b"emlp_recompute", 0),
-                         (b"side_stream", 1), (b"emlp_pipe", 1), (b"emlp_bwd_pipe", 1), (b"comb_pipe", 1), (b"comb_bwd_pipe", 1)):
+    for key, default in ((b"trr", 1), (b"attn_lds", 3), (b"attn_fused", 3), (b"tile_f16x3", 1), (b"trr_compress", 3),
+                         (b"node_planes", 1), (b"so_trr", 1), (b"so_f16x3", 1), (b"wgrad_bf16", 1), (b"side_stream", 1)):
         assert lib.pet_config_set(key, default) == 0, key

@@ -22,6 +22,12 @@ def _worker(rank, world, port, out):
     assert d.env_rank() == (rank, rank, world)
     d.init("gloo")
     dev = torch.device("cpu")
+    d.selftest(world, dev)                               # the benches' preamble: right rank count, a working collective
+    try:
+        d.selftest(world + 1, dev)                       # "--gpus 3" with two ranks in the group: refuse to measure
+        raise AssertionError("selftest accepted a smaller job than the launch line named")
+    except SystemExit as exc:
+        assert "2 rank(s) joined, 3 expected" in str(exc)
     d.barrier(dev)
     elapsed = d.max_over_ranks(1.0 + rank, dev)          # slowest rank defines the step time
     atoms = d.sum_over_ranks(10000.0 * len(d.box_seeds(2, rank)), dev)

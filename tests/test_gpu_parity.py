@@ -569,18 +569,17 @@ def test_unknown_species_is_an_error_not_an_out_of_bounds_read(rt, model, dev):
                     torch.zeros(32, dtype=torch.int32, device=dev))
 
 
-@pytest.mark.parametrize("switch", ["trr", "attn_lds=1", "side_stream", "tile_f16x3", "emlp_recompute=1", "trr_compress", "line_stores", "node_planes",
-                                    "emlp_pipe", "emlp_bwd_pipe", "comb_pipe", "comb_bwd_pipe"])
+@pytest.mark.parametrize("switch", ["trr", "attn_fused=0", "attn_lds=1", "side_stream", "tile_f16x3", "trr_compress", "node_planes"])
 def test_alternative_kernel_paths_agree(rt, model, dev, golden_dir, switch):
-    """The library keeps ONE fallback generation of its GEMM stages selectable (pet_config_set): the LDS-tile kernels
-    (trr=0, also the path of the variants; on fp32 MFMA with tile_f16x3=0), plus the per-atom staged attention adjoint (attn_lds=1;
-    the default 3 is the persistent LDS-DMA adjoint), a single stream (side_stream=0), the recomputing edge-MLP adjoint,
-    the A/B switches of the round-2 kernels and the edge-MLP kernels without the software pipeline of round 3
-    (emlp_pipe = 0: the persistent k_emlp_h, emlp_bwd_pipe = 0: k_emlp_bwd_h, comb_pipe = 0: k_comb_h, comb_bwd_pipe = 0: k_comb_bwd_h). Each must meet the same parity bar."""
+    """The fallbacks behind ``pet_config_set``: the LDS-tile kernels (trr=0, also the transformer-layer path of PostLN models;
+    on fp32 MFMA with tile_f16x3=0), the three-kernel attention form (attn_fused=0: QKV / attention / projection with Q, K, V
+    in HBM -- what the training forward and graphs with many atoms of more than 32 tokens run; with attn_lds=1 its
+    per-atom staged adjoint instead of the persistent LDS-DMA one), a single stream (side_stream=0) and the A/B switches
+    of the round-2 kernels. Each must meet the same parity bar."""
     g = _load(golden_dir, "pet_default_box64.npz")
     graph = _graph_from_golden(rt, model, g, dev)
     key, _, val = switch.partition("=")
-    default = {"attn_lds": 3, "trr_compress": 3, "emlp_recompute": 0, "line_stores": 3}.get(key, 1)
+    default = {"attn_lds": 3, "trr_compress": 3, "attn_fused": 3}.get(key, 1)
     rt.config_set(key, int(val or 0))
     try:
         fw = rt.HipForward(model, graph)
@@ -590,6 +589,36 @@ def test_alternative_kernel_paths_agree(rt, model, dev, golden_dir, switch):
         rt.config_set(key, default)
     assert relmax(atomic.cpu().numpy(), g["atomic_f64"].ravel()) < TOL
     assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
+
+
+def test_fused_attention_block_on_a_dense_box(rt, model, dev):
+    """The 64-slot instantiation of the fused attention block (pet_ablk.hip, atoms of 33 .. 64 tokens): by default a
+    graph in which more than 5 % of the atoms need it runs the three-kernel form, so it is forced here (attn_fused = 7)
+    on a box of 36 neighbours per atom; per-atom energies and dE/dR against the fp64 oracle and against the
+    three-kernel form."""
+    hypers = model.hypers
+    pos, z, cell = opet.random_box(400, seed=5, density=0.095)
+    i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, hypers["cutoff"])
+    counts = np.bincount(i, minlength=400)
+    assert counts.max() <= 63 and (counts >= 32).mean() > 0.5  # most atoms in 64-slot tiles, none beyond
+    sysidx = torch.zeros(400, dtype=torch.int32)
+    graph = rt.HipGraph(model, pos.to(dev), cell[None].to(dev), torch.tensor(i).int().to(dev), torch.tensor(j).int().to(dev),
+                        torch.tensor(s).int().to(dev), z.to(dev), sysidx.to(dev))
+    out = {}
+    try:
+        for mode in (7, 0):
+            rt.config_set("attn_fused", mode)
+            fw = rt.HipForward(model, graph)
+            atomic = fw.forward()
+            out[mode] = (atomic.cpu().numpy(), fw.backward(torch.ones_like(atomic)).cpu().numpy())
+    finally:
+        rt.config_set("attn_fused", 3)
+    assert relmax(out[7][0], out[0][0]) < 2e-6 and relmax(out[7][1], out[0][1]) < TOL
+    params = opet.synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0, torch.float32)  # the fixture model's weights
+    p64 = {k: (v.double() if v.is_floating_point() else v) for k, v in params.items()}
+    _, g_ref, a_ref = opet.energy_and_gradient(p64, hypers, pos.double(), cell[None].double(), torch.tensor(i),
+                                               torch.tensor(j), torch.tensor(s).long(), z, sysidx.long())
+    assert relmax(out[7][0], a_ref.numpy().ravel()) < TOL and relmax(out[7][1], g_ref.numpy()) < TOL
 
 
 @pytest.mark.parametrize("seed", [21, 22, 23])

@@ -294,3 +294,38 @@ def test_dilute_partly_periodic_system_gradient_accuracy():
         assert _relmax(atomic.cpu().numpy(), a_ref.numpy()) < TOL
         worst = max(worst, _relmax(grad.cpu().numpy(), g_ref.numpy()))
     assert worst < 8e-6, worst
+
+
+@pytest.mark.parametrize("legacy", [True, False])
+def test_power_spectrum_features_against_the_reference_module(legacy):
+    """The descriptor the HIP kernels produce against ``tests/golden/soap_ps_box24.npz``: power spectra computed by the
+    REFERENCE's ``soap_bpnn/modules/power_spectrum.py`` (imported unchanged, ``make_golden.py --soap-ps``) from the oracle's
+    spherical expansion. Pins the contraction, the feature order and the centre-type split on reference-run data; the
+    expansion under it remains the oracle's restatement of torch-spex (parity unpinned)."""
+    import os
+
+    from metatrain_amd.soap_bpnn import SoapBpnnHip
+
+    dev = torch.device("cuda:0")
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "soap_ps_box24.npz")))
+    tag = "legacy" if legacy else "alchemical"
+    hypers = dict(osoap.DEFAULT_HYPERS, legacy=legacy)
+    types = [1, 6, 7, 8]
+    n_per_l = osoap.basis(hypers)[0]
+    params = osoap.synthetic_params(hypers, 4, n_per_l, 3, torch.float32)  # seed 3: the fixture's species embedding
+    if not legacy:
+        np.testing.assert_allclose(params["species_embedding.weight"].numpy(), g["alchemical_species_embedding"], rtol=1e-6)
+    pos, z, cell = torch.tensor(g["in_positions"]), torch.tensor(g["in_species"]), torch.tensor(g["in_cell"])
+    pairs = torch.tensor(g[f"{tag}_pairs"])
+    model = SoapBpnnHip(hypers, types)
+    model.load({k: v.to(dev) for k, v in params.items()})
+    graph = model.graph(pos.float().to(dev), cell[None].float().to(dev), pairs[:, 0].contiguous().to(dev),
+                        pairs[:, 1].contiguous().to(dev), pairs[:, 2:5].contiguous().long().to(dev), z.to(dev),
+                        torch.zeros(len(z), dtype=torch.int32, device=dev))
+    _, feats = model.forward(graph, want_features=True)
+    ref = g[f"{tag}_power_spectrum"].astype(np.float64)
+    if not legacy:  # the features the tail sees carry the centre encoding (soap_bpnn/model.py:553-566)
+        table = torch.full((9,), -1, dtype=torch.long)
+        table[torch.tensor(types)] = torch.arange(4)
+        ref = ref * params["center_encoding.weight"].double().numpy()[table[z.long()].numpy()]
+    assert _relmax(feats.cpu().numpy(), ref) < TOL

@@ -171,9 +171,14 @@ def test_training_gradients_against_the_oracles_double_backward(case):
 
 @pytest.mark.parametrize("legacy", [True, False])
 def test_three_adam_steps_follow_torch(legacy):
-    """``SoapTrainStep`` (zero_grad, forward, dE/dR, losses, gradients, Adam lr 1e-3) against the same three steps of
-    torch.optim.Adam on the oracle: losses and every parameter after the third step (legacy = False: the species
-    embedding and the centre encoding move too, and the forward's derived tables follow them)."""
+    """``SoapTrainStep`` (zero_grad, forward, dE/dR, losses, gradients, Adam, warm-up + cosine LambdaLR stepped per batch
+    as in ``soap_bpnn/trainer.py:54-84, 344-391``) against the same steps of torch.optim.Adam + LambdaLR on the oracle:
+    losses, learning rates and every parameter after the last step (legacy = False: the species embedding and the centre
+    encoding move too, and the forward's derived tables follow them). Four steps of a 5 x 60-step schedule: the first runs
+    at lr 0 (warm-up), as in the reference."""
+    from torch.optim.lr_scheduler import LambdaLR
+
+    from metatrain_amd.pet.trainer import lr_lambda
     from metatrain_amd.soap_bpnn import SoapTrainStep
 
     dev = torch.device("cuda:0")
@@ -184,9 +189,11 @@ def test_three_adam_steps_follow_torch(legacy):
     pos, z, cells, ci, cj, cs, sysidx, te, tg = batch
     p = {k: v.double().clone().requires_grad_(True) for k, v in params.items()}
     opt = torch.optim.Adam(list(p.values()), lr=1e-3)
+    sched_hypers, steps_per_epoch, n_steps = {"num_epochs": 5, "warmup_fraction": 0.01}, 60, 4
+    sched = LambdaLR(opt, lr_lambda=lambda k: lr_lambda(k, 5 * 60, 0.01))
     n_atoms64 = torch.bincount(sysidx, minlength=len(te)).double()
-    ref_losses = []
-    for _ in range(3):
+    ref_losses, ref_lrs = [], []
+    for _ in range(n_steps):
         opt.zero_grad()
         r = pos.clone().requires_grad_(True)
         atomic = osoap.soap_bpnn_atomic_energies(p, hypers, types, r, cells, ci, cj, cs, z, sysidx)
@@ -194,15 +201,22 @@ def test_three_adam_steps_follow_torch(legacy):
         (gr,) = torch.autograd.grad(energies.sum(), r, create_graph=True)
         loss = (((energies - te) / n_atoms64) ** 2).mean() + ((gr - tg) ** 2).mean()
         loss.backward()
+        ref_lrs.append(opt.param_groups[0]["lr"])
         opt.step()
+        sched.step()
         ref_losses.append(float(loss.detach()))
     m = _model(dev, types, hypers, params)
     g = _graph(m, dev, batch)
-    step = SoapTrainStep(m)
-    losses = [float(step(g, te.float().to(dev), n_atoms64.float().to(dev), tg.float().to(dev))["loss"]) for _ in range(3)]
+    step = SoapTrainStep(m, sched_hypers, steps_per_epoch)
+    outs = [step(g, te.float().to(dev), n_atoms64.float().to(dev), tg.float().to(dev)) for _ in range(n_steps)]
+    losses = [float(o["loss"]) for o in outs]
+    np.testing.assert_allclose([o["lr"] for o in outs], ref_lrs, rtol=1e-12, atol=0)
+    assert ref_lrs[0] == 0.0 and ref_lrs[1] > 0.0
     np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
-    assert losses[2] < losses[0]
+    assert losses[1] == pytest.approx(losses[0], rel=1e-6) and losses[-1] < losses[0]  # step 0 ran at lr 0
+    state = step.state_dict()
+    assert state["step_index"] == n_steps and state["total_steps"] == 300
     after = m.params()
     for key, ref in p.items():
-        # three Adam steps move every entry by at most 3e-3; agreement to a small fraction of that
+        # the steps move every entry by at most 2e-3 (lr 0, 1/3, 2/3, 1 of 1e-3); agreement to a small fraction of that
         assert float((after[key].cpu().double().reshape(ref.shape) - ref.detach()).abs().max()) < 3e-5, key

@@ -192,3 +192,69 @@ def test_exchange_plans_of_the_ranks_agree_without_negotiation(world):
             sa, sb = sum(plans[a].send_splits[:b]), sum(plans[b].recv_splits[:a])
             cnt = plans[a].send_splits[b]
             assert torch.equal(keys[a][0][sa:sa + cnt], keys[b][1][sb:sb + cnt])
+
+
+def _clustered():
+    """All atoms between x = 20 and 25 A of a periodic 60 A cell: with four slabs only rank 1 owns (or sees) atoms."""
+    gen = torch.Generator().manual_seed(11)
+    cell = torch.diag(torch.tensor([60.0, 9.0, 9.0]))
+    pos = torch.rand(80, 3, generator=gen) * torch.tensor([5.0, 9.0, 9.0]) + torch.tensor([20.0, 0.0, 0.0])
+    return pos, torch.ones(80, dtype=torch.int32), cell, [True, True, True]
+
+
+class _ExchangeModel(_ToyModel):
+    def __init__(self, layers):
+        super().__init__(layers, False)
+        self.hypers["d_pet"] = 4
+
+
+@pytest.mark.parametrize("rank", [0, 2, 3])
+def test_exchange_rank_with_an_empty_slab_still_enters_every_collective(rank):
+    """a rank whose slab + halo holds no atom launches nothing (the library returns before any layer), but its
+    peers sit in 2 x num_gnn_layers all-to-alls and one all-reduce: it has to enter all of them, with zero rows."""
+    pos, z, cell, pbc = _clustered()
+    layers, log = 3, []
+
+    def all_to_all(out, inp, out_splits, in_splits):
+        log.append(("a2a", tuple(out.shape), tuple(inp.shape), list(out_splits), list(in_splits)))
+
+    def all_reduce(t):
+        log.append(("ar", t.numel()))
+
+    e, grad, n_sub, n_owned, n_rows, n_ghost = partition.energy_and_gradient_exchange(
+        _ExchangeModel(layers), pos, z, cell, pbc, 4, rank, all_to_all, all_reduce, runtime=_ToyRuntime)
+    assert (n_sub, n_owned, n_rows, n_ghost) == (0, 0, 0, 0) and float(e) == 0.0 and float(grad.abs().max()) == 0.0
+    assert [c[0] for c in log] == ["ar"] + ["a2a"] * (2 * layers) + ["ar"]
+    assert log[0] == ("ar", 1) and log[-1] == ("ar", 3 * len(pos) + 1)
+    assert all(c[1] == (0, 4) and c[2] == (0, 4) and c[3] == [0] * 4 and c[4] == [0] * 4 for c in log[1:-1])
+
+
+def test_exchange_setup_failure_reaches_every_rank_before_the_layer_loop():
+    """A rank that fails while it sets up (here: its neighbour list raises) says so in the first all-reduce and raises its
+    own error; a rank that was fine but reads a non-zero flag raises too, and neither enters an all-to-all."""
+    pos, z, cell, pbc = _clustered()
+    calls = []
+
+    class _Broken(_ToyRuntime):
+        @staticmethod
+        def neighbor_list(pos, cell, pbc, cutoff):
+            raise MemoryError("pair buffer")
+
+    def all_to_all(*a):
+        calls.append("a2a")
+
+    def flag_sum(extra):
+        def all_reduce(t):
+            calls.append(("ar", float(t.sum())))
+            t += extra
+        return all_reduce
+
+    with pytest.raises(MemoryError):  # rank 1 holds the atoms and fails
+        partition.energy_and_gradient_exchange(_ExchangeModel(2), pos, z, cell, pbc, 4, 1, all_to_all, flag_sum(0.0),
+                                               runtime=_Broken)
+    assert calls == [("ar", 1.0)]
+    calls.clear()
+    with pytest.raises(RuntimeError, match="another rank failed"):  # rank 2 is fine, but the summed flag says rank 1 is not
+        partition.energy_and_gradient_exchange(_ExchangeModel(2), pos, z, cell, pbc, 4, 2, all_to_all, flag_sum(1.0),
+                                               runtime=_ToyRuntime)
+    assert calls == [("ar", 0.0)]

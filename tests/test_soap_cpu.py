@@ -81,3 +81,29 @@ def test_oracle_energy_is_rotation_and_permutation_invariant():
     q, _ = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(1)))
     e1 = osoap.soap_bpnn_atomic_energies(params, hypers, types, pos @ q.T, *args)
     np.testing.assert_allclose(e0.numpy(), e1.numpy(), rtol=1e-9, atol=1e-12)
+
+
+def test_power_spectrum_against_the_reference_module():
+    """``tests/golden/soap_ps_box24.npz`` (``make_golden.py --soap-ps``): the reference's ``soap_bpnn/modules/power_spectrum.py``
+    imported unchanged and run on the oracle's spherical expansion (torch-spex itself is not installable: parity of the
+    EXPANSION stays unpinned). What this pins on reference-run data: the per-l contraction, the (l, n, channel, n',
+    channel') feature order and the ``center_type`` block split of the legacy model."""
+    import os
+
+    from oracle import nl as onl  # noqa: F401  (the fixture stores its own pair list)
+
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "soap_ps_box24.npz")))
+    pos, z, cell = torch.tensor(g["in_positions"]).double(), torch.tensor(g["in_species"]), torch.tensor(g["in_cell"]).double()
+    table = torch.full((9,), -1, dtype=torch.long)
+    table[torch.tensor([1, 6, 7, 8])] = torch.arange(4)
+    sp = table[z.long()]
+    for tag, legacy in (("legacy", True), ("alchemical", False)):
+        hypers = dict(osoap.DEFAULT_HYPERS, legacy=legacy)
+        pairs = torch.tensor(g[f"{tag}_pairs"]).long()
+        i, j, sh = pairs[:, 0], pairs[:, 1], pairs[:, 2:5].double()
+        v = pos[j] - pos[i] + sh @ cell
+        w = torch.eye(4, dtype=torch.float64) if legacy else torch.tensor(g["alchemical_species_embedding"])
+        feats = osoap.power_spectrum(osoap.spherical_expansion(v, i, sp[j], len(z), hypers, w))
+        ref = g[f"{tag}_power_spectrum"].astype(np.float64)
+        assert feats.shape == ref.shape == (len(z), 4544)
+        assert np.abs(feats.numpy() - ref).max() < 2e-7 * np.abs(ref).max()  # the fixture is stored in fp32
