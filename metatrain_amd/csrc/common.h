@@ -103,7 +103,8 @@ struct Graph {
     // tokens or TWO whose tokens add up to at most 32 (the plan pairs small atoms with the largest partners that fit);
     // atoms of 33 .. 64 tokens get a 64-slot tile each. Two int4 per tile: (atom A, first CSR row A, tokens A, atom B),
     // (first CSR row B, tokens B or 0, -, -).
-    int* atoms_by_t = nullptr; // [N] atoms of at most 32 tokens, grouped by token count
+    int* atoms_by_t = nullptr; // [N] atoms of at most 32 tokens, grouped by token count, ascending atom index inside a group
+    int* tsort_tmp = nullptr;  // [ceil(N / 256)][33] per-block counts / first positions of that sort
     int4* tile_desc = nullptr; // [2 N]: the 32-slot tiles first (n_tiles1), then the 64-slot ones (n_tiles2)
     int n_tiles1 = 0, n_tiles2 = 0;  // host copies
     int bucket_start[6] = {0, 0, 0, 0, 0, 0};  // host copy

@@ -312,41 +312,62 @@ __global__ void k_bucket_fill(const int* __restrict__ rowptr, int n_nodes, const
 }
 // ---- attention tiles of the fused block (pet_ablk.hip; Graph::tile_desc) -------------------------------------------
 // atoms of at most 32 tokens counted and listed by token count t = neighbours + 1 (counts: hist[t], t = 1 .. 32)
-__global__ void k_thist(const int* __restrict__ rowptr, int n_nodes, int* __restrict__ hist) {
+// Deterministic (every build of the same graph pairs the same atoms: an atom's position inside its tile decides the
+// summation order of its attention products, so the pairing must not depend on the order atomics happen to land in):
+// per-block counts, one scan over the blocks per bin, then ranks from ballots in thread order.
+__global__ void k_thist(const int* __restrict__ rowptr, int n_nodes, int* __restrict__ hist, int* __restrict__ blockhist) {
     __shared__ int lh[33];
     if (threadIdx.x < 33) lh[threadIdx.x] = 0;
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int t = i < n_nodes ? rowptr[i + 1] - rowptr[i] + 1 : 0;
-    if (t >= 1 && t <= 32) atomicAdd(&lh[t], 1);
+    if (t >= 1 && t <= 32) atomicAdd(&lh[t], 1);  // a count: the same whatever the order
     __syncthreads();
-    if (threadIdx.x < 33 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+    if (threadIdx.x < 33) {
+        blockhist[blockIdx.x * 33 + threadIdx.x] = lh[threadIdx.x];
+        if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+    }
 }
-__global__ void k_tsort(const int* __restrict__ rowptr, int n_nodes, const int* __restrict__ hist,
-                        int* __restrict__ cursors, int* __restrict__ out) {
-    __shared__ int lh[33], lbase[33];
-    if (threadIdx.x < 33) lh[threadIdx.x] = 0;
-    __syncthreads();
+// blockhist[b][t] <- first position of block b's atoms of t tokens (bins laid out one after the other)
+__global__ void k_tscan(int* __restrict__ blockhist, int n_blocks, const int* __restrict__ hist) {
+    const int t = threadIdx.x;
+    if (t < 1 || t > 32) return;
+    int run = 0;
+    for (int u = 1; u < t; u++) run += hist[u];
+    for (int b = 0; b < n_blocks; b++) {
+        const int c = blockhist[b * 33 + t];
+        blockhist[b * 33 + t] = run;
+        run += c;
+    }
+}
+__global__ void k_tsort(const int* __restrict__ rowptr, int n_nodes, const int* __restrict__ blockbase,
+                        int* __restrict__ out) {
+    __shared__ int wcount[4][33];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int t = i < n_nodes ? rowptr[i + 1] - rowptr[i] + 1 : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int rank = 0;
-    if (t >= 1 && t <= 32) rank = atomicAdd(&lh[t], 1);
-    __syncthreads();
-    if (threadIdx.x < 33 && threadIdx.x >= 1) {
-        int start = 0;
-        for (int u = 1; u < (int)threadIdx.x; u++) start += hist[u];
-        lbase[threadIdx.x] = start + (lh[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], lh[threadIdx.x]) : 0);
+    for (int u = 1; u <= 32; u++) {
+        const unsigned long long m = __ballot(t == u);
+        if (t == u) rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wcount[wave][u] = __popcll(m);
     }
     __syncthreads();
-    if (t >= 1 && t <= 32) out[lbase[t] + rank] = i;
+    if (t >= 1 && t <= 32) {
+        int base = blockbase[blockIdx.x * 33 + t];
+        for (int w = 0; w < wave; w++) base += wcount[w][t];
+        out[base + rank] = i;
+    }
 }
 static int bucket_atoms_by_tile_count(Graph& g, hipStream_t st) {  // scalars[8..17] were zeroed with the rest
     if (g.n_nodes <= 0) return PET_OK;
     const int T = 256;
     k_bucket_count<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8);
     k_bucket_fill<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8, g.scalars + 13, g.atom_order);
-    k_thist<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 24);
-    k_tsort<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 24, g.scalars + 64, g.atoms_by_t);
+    const int nb = cdiv(g.n_nodes, T);
+    k_thist<<<nb, T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 24, g.tsort_tmp);
+    k_tscan<<<1, 64, 0, st>>>(g.tsort_tmp, nb, g.scalars + 24);
+    k_tsort<<<nb, T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.tsort_tmp, g.atoms_by_t);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }
@@ -645,6 +666,7 @@ static int carve_graph(Graph& g, void* ws, int64_t n_nodes, int64_t e0, size_t* 
     g.scalars = c.take<int>(128);
     g.atom_order = c.take<int>(n_nodes > 0 ? n_nodes : 1);
     g.atoms_by_t = c.take<int>(n_nodes > 0 ? n_nodes : 1);
+    g.tsort_tmp = c.take<int>((size_t)(n_nodes / 256 + 2) * 33);
     g.tile_desc = c.take<int4>(2 * (n_nodes > 0 ? n_nodes : 1));
     g.rowptr0 = c.take<int>(n_nodes + 1);
     g.perm0 = c.take<int>(e0);
@@ -883,6 +905,7 @@ static int carve_from_batch(Graph& g, void* ws, int64_t n_nodes, int64_t M, size
     g.scalars = c.take<int>(128);
     g.atom_order = c.take<int>(n_nodes > 0 ? n_nodes : 1);
     g.atoms_by_t = c.take<int>(n_nodes > 0 ? n_nodes : 1);
+    g.tsort_tmp = c.take<int>((size_t)(n_nodes / 256 + 2) * 33);
     g.tile_desc = c.take<int4>(2 * (n_nodes > 0 ? n_nodes : 1));
     size_t scan_bytes = 0;
     int* ni = nullptr;

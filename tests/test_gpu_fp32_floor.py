@@ -9,6 +9,8 @@ import torch
 from oracle import nl as onl
 from oracle import pet as opet
 
+from _memo import memo_oracle
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
 TYPES = [1, 6, 7, 8]
@@ -32,6 +34,7 @@ def _batch(rng, dilute):
     return (torch.cat(pos_l), torch.stack(cell_l), torch.cat(i_l), torch.cat(j_l), torch.cat(s_l), torch.cat(z_l), torch.cat(sys_l))
 
 
+@memo_oracle
 def _oracle(params, hypers, b, dtype):
     p = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in params.items()}
     e, g, a = opet.energy_and_gradient(p, hypers, b[0].to(dtype), b[1].to(dtype), b[2], b[3], b[4], b[5], b[6])

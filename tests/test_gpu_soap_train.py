@@ -13,6 +13,8 @@ from oracle import nl as onl
 from oracle import pet as opet
 from oracle import soap as osoap
 
+from _memo import memo_oracle
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -59,6 +61,7 @@ def _random_batch(n_atoms=(150, 90), seed=3):
             torch.cat(sys_l), te, tg)
 
 
+@memo_oracle
 def _oracle_loss_and_grads(params64, hypers, types, batch, with_forces=True):
     """The reference's step in torch autograd, fp64: E, dE/dR with create_graph, MSE(E/atom) + MSE(dE/dR), backward."""
     pos, z, cells, ci, cj, cs, sysidx, te, tg = batch

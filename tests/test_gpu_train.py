@@ -13,6 +13,8 @@ import torch
 
 from oracle import pet as opet
 
+from _memo import memo_oracle
+
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5  # same bar as energies and forces (north_star); measured worst 2.3e-6
@@ -23,6 +25,7 @@ def _inputs(golden_dir, name):
     return {k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("in_")}
 
 
+@memo_oracle
 def _oracle_param_grads(params, hypers, inp, seed_w):
     p64 = {}
     for k, v in params.items():
@@ -162,6 +165,7 @@ def test_training_steps_match_torch_adam(golden_dir):
     assert worst < 0.02, worst
 
 
+@memo_oracle
 def _oracle_second_order(params, hypers, inp, nu, u):
     """fp64 autograd reference of d/dtheta [ sum_i nu_i E_i + <u, dE_tot/dR> ] and of dE_i/d(eps) along u."""
     p64 = {k: (v if k == "species_to_species_index" else v.double().clone().requires_grad_(True))
@@ -641,6 +645,7 @@ def test_training_gradients_of_a_conditioned_model(golden_dir):
     compare(ref2, "force-loss pass")
 
 
+@memo_oracle
 def _oracle_param_grads_cond(params, hypers, inp, seed_w):
     p64 = {k: (v if k == "species_to_species_index" else v.double().clone().requires_grad_(True))
            for k, v in params.items()}
