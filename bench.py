@@ -49,22 +49,22 @@ def synthetic_params(hypers):
 
 # ProfScope stage -> the kernels it launches (base names, template arguments stripped). The attention stages
 # launch one kernel per neighbour-count bucket (NT = 1, 2, 3 ...): their traffic is the sum over the buckets.
-STAGE_KERNELS = {"attn_bwd": ("k_attn_bwd_a", "k_attn_bwd_l"), "attn_fwd": ("k_attn_fwd_p",),
-                 "emlp": ("k_emlp_p2", "k_emlp_h"), "emlp_bwd": ("k_emlp_bwd_p2", "k_emlp_bwd_h"),
-                 "qkv": ("k_qkv_h", "k_qkv_hl", "k_qkv_s"), "qkv_bwd": ("k_qkv_bwd_h",),
-                 "comb": ("k_comb_p2", "k_comb_h", "k_comb"), "comb_bwd": ("k_comb_bwd_p2", "k_comb_bwd_h", "k_comb_bwd")}
+STAGE_KERNELS = {"attn_blk": ("k_ablk_fwd",), "attn_blk_bwd": ("k_ablk_bwd",),
+                 "attn_bwd": ("k_attn_bwd_a", "k_attn_bwd_l"), "attn_fwd": ("k_attn_fwd_p",),
+                 "emlp": ("k_emlp_p2",), "emlp_bwd": ("k_emlp_bwd_p2",), "qkv": ("k_qkv_s",), "qkv_bwd": ("k_qkv_bwd_h",),
+                 "comb": ("k_comb_p2",), "comb_bwd": ("k_comb_bwd_p2",)}
 
 
-SPLIT_MFMA_STAGES = {"emlp", "emlp_bwd", "qkv", "qkv_bwd", "oproj", "oproj_bwd", "comb", "comb_bwd", "compress",
+SPLIT_MFMA_STAGES = {"attn_blk", "attn_blk_bwd", "emlp", "emlp_bwd", "qkv", "qkv_bwd", "oproj", "oproj_bwd", "comb", "comb_bwd", "compress",
                  "compress_bwd", "head_edge", "head_edge_bwd", "node", "center", "head_node"}
 ARITHMETIC = ("f32 results: every dense stage computes its fp32 products as three fp16 MFMA terms on 2-way split "
-              "operands (f16x3, fp32 accumulate, 1.7e-7 product error vs fp64); attention soft-max, norms and "
-              "geometry in fp32")
+              "operands (f16x3, fp32 accumulate, 1.7e-7 product error vs fp64) -- the attention products of the fused "
+              "per-atom block included; soft-max, norms and geometry in fp32")
 SURVEY_8D_BYTES_PER_ATOM = 150e3  # forward + forces with activations recomputed in-tile
 
 
 def _traffic_file():
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # newest round first
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # newest round first
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as fh:
@@ -85,7 +85,7 @@ def pmc_traffic(stage, n_edges):
     recs = [rec for name, rec in data["kernels"].items() if name.split("<")[0] in STAGE_KERNELS[stage]]
     if not recs:
         return None
-    if stage.startswith("attn"):   # every bucket kernel runs once per stage call
+    if stage.startswith("attn"):   # every bucket / tile-size kernel runs once per stage call
         return sum(r["hbm_bytes_per_launch"] for r in recs)
     calls = sum(r.get("calls", 1) for r in recs)   # template variants are alternatives (first / later GNN layer)
     return sum(r["hbm_bytes_per_launch"] * r.get("calls", 1) for r in recs) / calls
@@ -332,7 +332,7 @@ def main():
                     "algorithmic_flops_per_launch": flops_per_launch, "traffic": None}
         roof["traffic"] = pmc_traffic(dominant, int(graph.n_edges))
         roof["arithmetic"] = ("fp32 MFMA soft-max attention kernel; the surrounding projections: " + ARITHMETIC
-                              if dominant.startswith("attn") else ARITHMETIC)
+                              if dominant in ("attn_fwd", "attn_bwd") else ARITHMETIC)
         if split:  # both roofs of a split-operand GEMM stage, whichever one "bound" names
             tf = flops_per_launch / (avg_ms * 1e-3) / 1e12
             roof["fp32_equivalent_tflops"] = tf

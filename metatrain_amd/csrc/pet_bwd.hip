@@ -1201,7 +1201,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             // the per-atom fused adjoint (pet_ablk.hip): Q, K, V recomputed from X, only dX and the key-bias gradient leave
             bool fusedb = false;
             if (fused_attn) {
-                ProfScope ps("attn_blk_bwd", st, fR * 2.0 * D * 8 * D + 2.0 * 4.0 * D * g_sum_t2(g), fR * 4.0 * 3 * D);  // X, dX1 in; dX out
+                ProfScope ps("attn_blk_bwd", st, fR * 2.0 * D * 4 * D + 2.0 * 4.0 * D * g_sum_t2(g), fR * 4.0 * 3 * D);  // algorithmic: the adjoint's own products (the Q, K, V recomputation is this design's choice, not counted); X, dX1 in; dX out
                 fusedb = ablk_bwd(m, g, A, Ab.X, dX_alt, w.dOC, dX,
                                   w.dbias_l + ((int64_t)gi * m.h.num_attention_layers + a) * NHEAD * E, scale, st);
             }
