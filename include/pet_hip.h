@@ -401,9 +401,10 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *                 PostLN models). The combination stage has one implementation (the software-pipelined TRR kernel).
  *   "attn_fused"  bits: 1 = the per-atom fused attention block in the forward (norm -> QKV -> soft-max attention -> output
  *                 projection in one kernel; Q, K, V and the attention output never reach HBM; csrc/pet_ablk.hip), 2 = its
- *                 adjoint (recomputes Q, K, V from the layer input), 4 = also for graphs in which more than 5 % of the
- *                 atoms have more than 32 tokens; default 3. 0 = the three-kernel form everywhere (what training forwards,
- *                 graphs with an atom of more than 64 tokens and PostLN models always run).
+ *                 adjoint (recomputes Q, K, V from the layer input), 4 = whatever the graph's size; default 3: graphs of
+ *                 fewer than 6 144 attention tiles (a few thousand atoms: latency-bound there) and graphs in which more
+ *                 than 5 % of the atoms have more than 32 tokens keep the three-kernel form, as do training forwards,
+ *                 graphs with an atom of more than 64 tokens and PostLN models. 0 = the three-kernel form everywhere.
  *   "attn_lds"    adjoint of the three-kernel attention form: 1 = staged per atom, 3 = persistent workgroups with LDS-DMA
  *                 prefetch for atoms of at most 32 tokens (default)
  *   "tile_f16x3"  1 = the LDS-tile forward kernels (compress, centre, node update, heads) and the head adjoint on f16x3

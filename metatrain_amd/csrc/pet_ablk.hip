@@ -1012,9 +1012,9 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
 // host side
 // ---------------------------------------------------------------------------------------------
 // pet_config_set("attn_fused", bits): 1 = fused forward, 2 = fused adjoint (the forward of a call sequence whose adjoint
-// follows is fused only together with it: the three-kernel adjoint reads the saved Q, K, V), 4 = also when many atoms
-// have more than 32 tokens (their 64-slot instantiation of the adjoint spills; above 5 % of the atoms the three-kernel
-// form is the faster one); 0 = the three-kernel form (QKV / attention / projection) everywhere
+// follows is fused only together with it: the three-kernel adjoint reads the saved Q, K, V), 4 = whatever the graph
+// (by default graphs of fewer than 6 144 tiles, and graphs in which more than 5 % of the atoms have more than 32 tokens,
+// take the three-kernel form: ablk_serves); 0 = the three-kernel form (QKV / attention / projection) everywhere
 static int g_attn_fused = 3;
 void set_attn_fused(int v) { g_attn_fused = v; }
 int attn_fused() { return g_attn_fused; }
@@ -1084,7 +1084,11 @@ static void tail_join(hipStream_t st, hipStream_t ts) {
 // whether the adjoint of this graph's attention layers runs fused (the forward of the same call sequence did, then)
 static bool ablk_serves(const Graph& g) {
     if (g.bucket_start[5] > g.bucket_start[4]) return false;  // an atom of more than 64 tokens
-    return (g_attn_fused & 4) || (int64_t)g.n_tiles2 * 20 <= g.n_nodes;
+    if (g_attn_fused & 4) return true;
+    // A tile is one wave's serial chain (40 us forward, 100 us adjoint): below a few waves per SIMD the launch costs that
+    // latency whatever its size, and the three row-parallel kernels are quicker (1 000 atoms: 2.5 against 3.1 ms per
+    // step, 3 000: 3.5 / 3.9, 10 000: 7.8 / 7.3). Many 64-slot tiles (the adjoint's instantiation for them spills): likewise.
+    return g.n_tiles1 >= 6144 && (int64_t)g.n_tiles2 * 20 <= g.n_nodes;
 }
 bool ablk_bwd_on(const Graph& g) { return (g_attn_fused & 2) && ablk_serves(g); }
 
