@@ -146,6 +146,44 @@ def cpu_baseline(hypers, params, seconds_budget=12.0):
     }
 
 
+def gpu_box1000(model, hypers, dev, reps=200):
+    """BASELINE configs[1] on the GPU (not `value`): ONE 1000-atom box per step -- graph build + forward + dE/dR from a
+    resident neighbour list, and the same step with the device neighbour list rebuilt every step (the MD regime). The CPU
+    oracle's rate on this box is `cpu_baseline.box1000`."""
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.synthetic import random_box
+    pos, z, cell = random_box(1000, 0)
+    pos, z, cell = pos.to(dev), z.to(dev), cell.to(dev)
+    sysidx = torch.zeros(1000, dtype=torch.int32, device=dev)
+    ones = torch.ones(1000, device=dev)
+    st = {}
+
+    def step(with_nl):
+        if with_nl or "pairs" not in st:
+            pr, _ = rt.neighbor_list(pos, cell, [True] * 3, hypers["cutoff"])
+            st["pairs"] = (pr[:, 0].contiguous(), pr[:, 1].contiguous(), pr[:, 2:5].contiguous())
+        i, j, s = st["pairs"]
+        g = rt.HipGraph(model, pos, cell[None], i, j, s, z, sysidx)
+        fw = st["fw"].rebind(g) if "fw" in st else st.setdefault("fw", rt.HipForward(model, g))
+        fw.forward()
+        return fw.backward(ones)
+
+    res = {}
+    for key, with_nl in (("graph+forward+backward_ms", False), ("nl+graph+forward+backward_ms", True)):
+        for _ in range(20):
+            step(with_nl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step(with_nl)
+        torch.cuda.synchronize()
+        res[key] = (time.perf_counter() - t0) / reps * 1e3
+    res["value"] = 1000.0 / (res["graph+forward+backward_ms"] * 1e-3)
+    res["unit"] = "atom-steps/s"
+    res["sample"] = f"{reps} x one 1000-atom box (BASELINE config 2 shape: rho=0.05/A^3, 4.5 A cutoff), one box per step"
+    return res
+
+
 def respawn_under_launcher(n_gpus):
     """`python bench.py --gpus N` without a launcher: start N ranks of this same script under torch.distributed.run
     (one process per GPU, rendezvous on 127.0.0.1) and hand its exit code back."""
@@ -167,7 +205,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--boxes", type=int, default=8,
-                    help="10k-atom boxes per GPU per step (round 2: 1 box 1.26 M, 8 boxes 1.47 M atom-steps/s, DESIGN.md 5); "
+                    help="10k-atom boxes per GPU per step (larger batches amortise wave quantisation and launch gaps; DESIGN.md 5); "
                          "with --total-boxes: the chunk size a rank walks its share in")
     ap.add_argument("--total-boxes", type=int, default=0,
                     help="strong-scaling mode: this many boxes per step in the WHOLE job, split over the ranks and "
@@ -430,6 +468,8 @@ def main():
                 "value": n_atoms / dt, "unit": "atom-steps/s", "ms_per_step": dt * 1e3,
                 "includes": "H2D positions/species/cells (pinned), device neighbour lists + collate, graph build, "
                             "forward, dE/dR, D2H per-atom energies + gradients"}
+        if world == 1 and not strong:
+            out["box1000"] = gpu_box1000(model, hypers, dev)
         if not args.no_cpu_baseline and world == 1:  # the reported CPU leg runs at N = 1 only
             out["cpu_baseline"] = cpu_baseline(hypers, params)
         print(json.dumps(out), flush=True)

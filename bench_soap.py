@@ -50,6 +50,27 @@ def cpu_baseline(hypers, n=10000):
             "sample": f"{reps} x (forward + dE/dR) of one {n}-atom box with the torch-CPU oracle, {dt:.2f} s each"}
 
 
+
+SOAP_STAGE_KERNELS = {"soap_expand": "k_soap_expand_w", "soap_ps": "k_soap_ps_w", "soap_tail": "k_soap_tail_fwd_set",
+                      "soap_tail_bwd": "k_soap_tail_bwd_set", "soap_ps_bwd": "k_soap_ps_bwd_s",
+                      "soap_expand_bwd": "k_soap_expand_bwd_p"}
+
+
+def pmc_traffic(stage, n_pairs):
+    """HBM bytes per launch of the stage's kernel and of a whole step from the committed rocprofv3 PMC passes of this bench
+    (profiles/r04_soap_traffic.json: --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, (2 FETCH + WRITE) x 1024); None
+    unless the profiled run had the same number of pairs."""
+    path = os.path.join(ROOT, "profiles", "r04_soap_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        data = json.load(fh)
+    if data.get("workload_edges") != n_pairs:
+        return None, None
+    recs = [v for k, v in data["kernels"].items() if k.startswith(SOAP_STAGE_KERNELS.get(stage, "-"))]
+    return (recs[0]["hbm_bytes_per_launch"] if recs else None), data.get("step_hbm_bytes")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +189,7 @@ def main():
                          "algorithmic_bytes_per_launch": dominant["bytes"], "traffic": None,
                          "stages_ms": {r["name"]: round(r["total_ms"], 3) for r in table}},
         }
+        out["roofline"]["traffic"], out["roofline"]["step_traffic_bytes"] = pmc_traffic(dominant["name"], int(g.n_edges))
         if dominant["name"] in ("soap_expand", "soap_expand_bwd"):
             # the descriptor kernels are VALU work (spherical-harmonic recurrences per pair, fp64 adjoint accumulators,
             # no matrix product): neither the HBM nor the MFMA roof describes them; the HBM figure is kept as the

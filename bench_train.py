@@ -61,6 +61,29 @@ def cpu_baseline(hypers, params, n=1000):
                       f"box, {dt:.2f} s each"}
 
 
+
+TRAIN_STAGE_KERNELS = {"so_gemm": ("k_rowgemm_n128", "k_rowgemm_k128", "k_gemm_h"), "wgrad": ("k_wgrad_b", "k_wgrad<"),
+                       "so_attn_rev": ("k_attn_rev_p",), "so_attn_jvp": ("k_attn_jvp_p",), "emlp": ("k_emlp_p2",),
+                       "emlp_bwd": ("k_emlp_bwd_p2",), "attn_blk_bwd": ("k_ablk_bwd",), "attn_blk": ("k_ablk_fwd",)}
+
+
+def pmc_traffic(stage, n_edges):
+    """HBM bytes PER STEP of the stage group's kernels and of the whole step from the committed rocprofv3 PMC passes of this
+    bench (profiles/r04_train_traffic.json: --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, (2 FETCH + WRITE) x 1024);
+    None unless the profiled run had the same number of edges."""
+    path = os.path.join(ROOT, "profiles", "r04_train_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        data = json.load(fh)
+    if data.get("workload_edges") != n_edges:
+        return None, None
+    steps = max(data.get("steps_profiled", 1), 1)
+    recs = [v for k, v in data["kernels"].items() if k.startswith(TRAIN_STAGE_KERNELS.get(stage, ("-",)))]
+    per_step = sum(v["hbm_bytes_per_launch"] * v["calls"] for v in recs) / steps if recs else None
+    return per_step, data.get("step_hbm_bytes")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,6 +256,9 @@ def main():
                 "frac_of_hbm_peak": gb / 8000.0, "frac_of_f16x3_mfma_peak": tf / (2500.0 / 3.0),
                 "stages_ms": {r["name"]: round(r["total_ms"], 3) for r in sorted(table, key=lambda r: -r["total_ms"])[:10]},
             }
+            # PMC bytes of the stage group per step (same unit as stage_ms_per_step) and of every kernel of the step
+            out["roofline"]["traffic"], out["roofline"]["step_traffic_bytes"] = pmc_traffic(dom["name"], n_edges) \
+                if len(batches) == 1 else (None, None)
             g0 = batches[0]["graph"]
             rowptr = g0.csr()["rowptr"].double()
             t2 = float((((rowptr[1:] - rowptr[:-1]) + 1) ** 2).sum())

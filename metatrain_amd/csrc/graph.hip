@@ -330,14 +330,19 @@ __global__ void k_thist(const int* __restrict__ rowptr, int n_nodes, int* __rest
 }
 // blockhist[b][t] <- first position of block b's atoms of t tokens (bins laid out one after the other)
 __global__ void k_tscan(int* __restrict__ blockhist, int n_blocks, const int* __restrict__ hist) {
-    const int t = threadIdx.x;
-    if (t < 1 || t > 32) return;
+    const int t = blockIdx.x + 1, lane = threadIdx.x;  // one wave per bin: 64 blocks per wave scan
     int run = 0;
     for (int u = 1; u < t; u++) run += hist[u];
-    for (int b = 0; b < n_blocks; b++) {
-        const int c = blockhist[b * 33 + t];
-        blockhist[b * 33 + t] = run;
-        run += c;
+    for (int b0 = 0; b0 < n_blocks; b0 += 64) {
+        const int b = b0 + lane;
+        const int c = b < n_blocks ? blockhist[b * 33 + t] : 0;
+        int incl = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (b < n_blocks) blockhist[b * 33 + t] = run + incl - c;
+        run += __shfl(incl, 63);
     }
 }
 __global__ void k_tsort(const int* __restrict__ rowptr, int n_nodes, const int* __restrict__ blockbase,
@@ -366,7 +371,7 @@ static int bucket_atoms_by_tile_count(Graph& g, hipStream_t st) {  // scalars[8.
     k_bucket_fill<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8, g.scalars + 13, g.atom_order);
     const int nb = cdiv(g.n_nodes, T);
     k_thist<<<nb, T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 24, g.tsort_tmp);
-    k_tscan<<<1, 64, 0, st>>>(g.tsort_tmp, nb, g.scalars + 24);
+    k_tscan<<<32, 64, 0, st>>>(g.tsort_tmp, nb, g.scalars + 24);
     k_tsort<<<nb, T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.tsort_tmp, g.atoms_by_t);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
