@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-# The default GEMM stages compute fp32 products as three fp16 MFMA terms (f16x3, DESIGN.md section 4): their FLOP/s
+# The default GEMM stages compute fp32 products as three fp16 MFMA terms (f16x3, DESIGN.md section 4.1): their FLOP/s
 # are fp32-equivalent (2 M N K / time). `peak` stays the fp32 MFMA figure (the roof of the arithmetic the path
 # delivers); the 16-bit pipe's own ceiling for this scheme, 2.5 PFLOP/s / 3 terms, is reported next to it.
 MFMA_SPLIT_EQUIV_PEAK_TFLOPS = 2500.0 / 3.0

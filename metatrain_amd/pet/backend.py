@@ -33,7 +33,7 @@ use -- ``normalization = "LayerNorm"``, ``transformer_type = "PostLN"``, ``featu
 (``pet/checkpoints.py:190-205``) --, both adaptive-cutoff methods ("solver" and the legacy "grid") and system conditioning
 (charge / spin multiplicity): inference, forces AND training (energy and force loss) for all of them, edge-free batches of
 isolated atoms and empty systems included. Not built (raise loudly): diagnostic capture, double backward through the three
-inference nodes (DESIGN.md section 6), long-range features.
+inference nodes (DESIGN.md section 7), long-range features.
 """
 from math import prod
 from typing import Dict, List, Optional, Tuple

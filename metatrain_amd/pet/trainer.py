@@ -114,7 +114,7 @@ class TrainStep:
 
     def microbatched(self, batches) -> Dict[str, torch.Tensor]:
         """ONE optimizer step over several micro-batches (gradient accumulation): the training workspace holds every
-        tangent of a batch (100 KB per edge, DESIGN.md section 4b), so a rank's share of a large batch -- BASELINE
+        tangent of a batch (100 KB per edge, DESIGN.md section 4.5), so a rank's share of a large batch -- BASELINE
         ``configs[3]``: 64 x 10 000-atom boxes per GPU -- is walked a few boxes at a time. Each element of ``batches`` is a
         dict with the arguments of :meth:`__call__` (``graph, fw, target_energies, n_atoms`` and optionally
         ``target_gradients, target_strain_gradients, positions, cells``); the losses are the full batch's means

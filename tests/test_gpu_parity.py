@@ -264,7 +264,7 @@ def test_ragged_tail_tiles_against_oracle(rt, model, dev, n_atoms, seed):
     every row kernel (E mod 128 differs per case), with a non-uniform seed vector so that adjoint rows span several
     orders of magnitude (per-row power-of-two scaling of the f16x3 kernels): energies and dE/dR against the fp64
     oracle evaluated here. (Complements test_rotation_and_permutation_consistency, which is the test that caught a
-    per-lane branch around spill code in the compress adjoint, DESIGN.md section 4.)"""
+    per-lane branch around spill code in the compress adjoint, DESIGN.md section 4.4.)"""
     hypers = model.hypers
     pos, z, cell = opet.random_box(n_atoms, seed)
     i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, hypers["cutoff"])

@@ -366,7 +366,7 @@ def test_system_conditioning_batch_independence(rt, golden_dir):
 
 @pytest.mark.parametrize("tag", ["legacy", "conditioned"])
 def test_variants_beyond_65536_token_rows_against_the_oracle(rt, tag):
-    """The variant kernels at a size where row indices pass 2^16 (the compress-adjoint fault of DESIGN.md section 4a only
+    """The variant kernels at a size where row indices pass 2^16 (the compress-adjoint fault of profiles/DESIGN_history_r1-r3.md section 4a only
     showed there): a 5 000-atom box, E + N > 100 000 token rows, energies and dE/dR against the fp64 oracle."""
     from oracle import nl as onl
 
