@@ -107,6 +107,7 @@ struct Graph {
     int* tsort_tmp = nullptr;  // [ceil(N / 256)][33] per-block counts / first positions of that sort
     int4* tile_desc = nullptr; // [2 N]: the 32-slot tiles first (n_tiles1), then the 64-slot ones (n_tiles2)
     int n_tiles1 = 0, n_tiles2 = 0;  // host copies
+    bool tiles_planned = false;      // the graph build made tile_desc (large graphs, or the fused block forced)
     int bucket_start[6] = {0, 0, 0, 0, 0, 0};  // host copy
     // adaptive cutoff (structures.py:225-263): CSR over ALL input edges (the root finder and its
     // implicit-function gradient see every edge within the maximum cutoff, kept or not)

@@ -369,6 +369,9 @@ static int bucket_atoms_by_tile_count(Graph& g, hipStream_t st) {  // scalars[8.
     const int T = 256;
     k_bucket_count<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8);
     k_bucket_fill<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8, g.scalars + 13, g.atom_order);
+    // the per-atom attention tiles serve the fused block only (pet_ablk.hip: graphs of at least 6 144 tiles, or forced)
+    g.tiles_planned = g.n_nodes >= 6144 || (attn_fused() & 4);
+    if (!g.tiles_planned) return PET_OK;
     const int nb = cdiv(g.n_nodes, T);
     k_thist<<<nb, T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 24, g.tsort_tmp);
     k_tscan<<<32, 64, 0, st>>>(g.tsort_tmp, nb, g.scalars + 24);
@@ -413,7 +416,7 @@ __global__ void k_tile_fill_big(const int* __restrict__ atoms, int n, const int*
 // host: pair the smallest atoms with the largest partners that still fit 32 slots (hist[t]: atoms of t tokens)
 static int plan_attention_tiles(Graph& g, const int* hist, hipStream_t st) {
     g.n_tiles1 = g.n_tiles2 = 0;
-    if (g.n_nodes <= 0) return PET_OK;
+    if (g.n_nodes <= 0 || !g.tiles_planned) return PET_OK;
     static const bool pairing = !(getenv("PET_HIP_TILE_PAIRS") && getenv("PET_HIP_TILE_PAIRS")[0] == '0');
     TilePlan plan;
     int rem[33], off[33];

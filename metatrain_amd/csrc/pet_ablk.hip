@@ -1084,6 +1084,7 @@ static void tail_join(hipStream_t st, hipStream_t ts) {
 // whether the adjoint of this graph's attention layers runs fused (the forward of the same call sequence did, then)
 static bool ablk_serves(const Graph& g) {
     if (g.bucket_start[5] > g.bucket_start[4]) return false;  // an atom of more than 64 tokens
+    if (!g.tiles_planned) return false;                       // a small graph built before the block was forced
     if (g_attn_fused & 4) return true;
     // A tile is one wave's serial chain (40 us forward, 100 us adjoint): below a few waves per SIMD the launch costs that
     // latency whatever its size, and the three row-parallel kernels are quicker (1 000 atoms: 2.5 against 3.1 ms per

@@ -29,26 +29,26 @@ __device__ __forceinline__ float sigmoid_grad_from(float s) { return s * (1.0f -
 // RMSNorm adjoint on a tile: W holds w = gamma * dn (LDS [64][K+4]); x rows come from
 // global. dx = rstd * (w - xhat * mean(w * xhat)), xhat = x * rstd.
 // calls f(row_in_tile, col, dx) for the 4-thread-per-row decomposition.
-template <int K, class F>
+template <int K, int ROWS = BM, class F>
 __device__ __forceinline__ void rmsnorm_bwd_rows(const float* Wt, const float* __restrict__ Xg, int64_t row0,
                                                  int64_t n_rows, int ldx, F f) {
-    constexpr int LDW = lds_ld(K);
-    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    constexpr int LDW = lds_ld(K), TPR = NTHREADS / ROWS;
+    const int r = threadIdx.x / TPR, q = threadIdx.x % TPR;
     const bool valid = row0 + r < n_rows;
     const float* xrow = Xg + (row0 + r) * ldx;
     float ss = 0.f, dot = 0.f;
-    for (int c = q * 4; c < K; c += 16) {
+    for (int c = q * 4; c < K; c += 4 * TPR) {
         float4 x = valid ? *reinterpret_cast<const float4*>(xrow + c) : make_float4(0, 0, 0, 0);
         float4 wv = *reinterpret_cast<const float4*>(Wt + r * LDW + c);
         ss += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
         dot += x.x * wv.x + x.y * wv.y + x.z * wv.z + x.w * wv.w;
     }
-    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2);
-    dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2);
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); if (TPR == 8) ss += __shfl_xor(ss, 4);
+    dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); if (TPR == 8) dot += __shfl_xor(dot, 4);
     const float rstd = rsqrtf(ss * (1.0f / K) + 1.1920928955078125e-07f);
     const float coef = dot * rstd * rstd * rstd * (1.0f / K);  // mean(w*xhat) * rstd / x-scale
     if (!valid) return;
-    for (int c = q * 4; c < K; c += 16) {
+    for (int c = q * 4; c < K; c += 4 * TPR) {
         float4 x = *reinterpret_cast<const float4*>(xrow + c);
         float4 wv = *reinterpret_cast<const float4*>(Wt + r * LDW + c);
         f(r, c, make_float4(rstd * wv.x - x.x * coef, rstd * wv.y - x.y * coef, rstd * wv.z - x.z * coef,
@@ -57,41 +57,41 @@ __device__ __forceinline__ void rmsnorm_bwd_rows(const float* Wt, const float* _
 }
 
 // The same with LayerNorm (ln): xhat = (x - mean) rstd, dx = rstd (w - mean(w) - xhat mean(w xhat)).
-template <int K, class F>
+template <int K, int ROWS = BM, class F>
 __device__ __forceinline__ void norm_bwd_rows(const float* Wt, const float* __restrict__ Xg, int64_t row0,
                                               int64_t n_rows, int ldx, bool ln, F f) {
     if (!ln) {
-        rmsnorm_bwd_rows<K>(Wt, Xg, row0, n_rows, ldx, f);
+        rmsnorm_bwd_rows<K, ROWS>(Wt, Xg, row0, n_rows, ldx, f);
         return;
     }
-    constexpr int LDW = lds_ld(K);
-    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    constexpr int LDW = lds_ld(K), TPR = NTHREADS / ROWS;
+    const int r = threadIdx.x / TPR, q = threadIdx.x % TPR;
     const bool valid = row0 + r < n_rows;
     const float* xrow = Xg + (row0 + r) * ldx;
     float s = 0.f, sw = 0.f;
-    for (int c = q * 4; c < K; c += 16) {
+    for (int c = q * 4; c < K; c += 4 * TPR) {
         float4 x = valid ? *reinterpret_cast<const float4*>(xrow + c) : make_float4(0, 0, 0, 0);
         float4 wv = *reinterpret_cast<const float4*>(Wt + r * LDW + c);
         s += (x.x + x.y) + (x.z + x.w);
         sw += (wv.x + wv.y) + (wv.z + wv.w);
     }
-    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
-    sw += __shfl_xor(sw, 1); sw += __shfl_xor(sw, 2);
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); if (TPR == 8) s += __shfl_xor(s, 4);
+    sw += __shfl_xor(sw, 1); sw += __shfl_xor(sw, 2); if (TPR == 8) sw += __shfl_xor(sw, 4);
     const float mean = s * (1.0f / K), mw = sw * (1.0f / K);
     float ss = 0.f, dot = 0.f;
-    for (int c = q * 4; c < K; c += 16) {
+    for (int c = q * 4; c < K; c += 4 * TPR) {
         float4 x = valid ? *reinterpret_cast<const float4*>(xrow + c) : make_float4(0, 0, 0, 0);
         float4 wv = *reinterpret_cast<const float4*>(Wt + r * LDW + c);
         x.x -= mean; x.y -= mean; x.z -= mean; x.w -= mean;
         ss += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
         dot += x.x * wv.x + x.y * wv.y + x.z * wv.z + x.w * wv.w;
     }
-    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2);
-    dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2);
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); if (TPR == 8) ss += __shfl_xor(ss, 4);
+    dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); if (TPR == 8) dot += __shfl_xor(dot, 4);
     const float rstd = rsqrtf(ss * (1.0f / K) + 1e-5f);
     const float coef = dot * rstd * rstd * rstd * (1.0f / K);
     if (!valid) return;
-    for (int c = q * 4; c < K; c += 16) {
+    for (int c = q * 4; c < K; c += 4 * TPR) {
         float4 x = *reinterpret_cast<const float4*>(xrow + c);
         float4 wv = *reinterpret_cast<const float4*>(Wt + r * LDW + c);
         f(r, c, make_float4(rstd * (wv.x - mw) - (x.x - mean) * coef, rstd * (wv.y - mw) - (x.y - mean) * coef,
@@ -331,76 +331,81 @@ __global__ __launch_bounds__(NTHREADS) void k_swiglu_bwd(const float* __restrict
 // on the 16-bit matrix cores (the fp32-MFMA form above spends 46 % of its time in the matrix pipe: 64 cycles per 2 k),
 // everything between the two scalings stays in scaled units; the saved pre-activations arrive as float4 rows through
 // wave-private staging tiles. Inference only (no weight-gradient exports).
+template <int RB>  // 32 RB rows per workgroup (see k_node2)
 __global__ __launch_bounds__(NTHREADS) void k_node_bwd2(const float* __restrict__ dY, const float* __restrict__ Xin,
                                                          const float* __restrict__ VG, const float* __restrict__ gamma,
                                                          WX woutb, WX winb, float* __restrict__ dXout, int64_t R, bool ln) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = 256, HID = DNF, LDK = lds_ld(K), LDH = plane_ld(K);
-    float* A = smem;                                               // [64][260] dY tile; at the end w = gamma * dn
-    float* U = smem;                                               // [64][132] dv / dg chunk (aliases A while A is dead)
-    float* stage = smem + BM * LD128;                              // 4 x [32][64] staging tiles (behind U, inside A)
-    _Float16* Ph = reinterpret_cast<_Float16*>(smem + BM * LDK);   // [64][264] planes of the scaled dY rows
-    _Float16* Pl = Ph + BM * LDH;
-    float* rs = smem + BM * LDK + BM * LDH;                        // [64][2] scale, inverse
-    const WaveId w;
-    float* my_stage = stage + w.wave * (32 * 64);
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    constexpr int ROWS = 32 * RB, NCH = 4 / RB, WC = 256 / NCH, HC = 128 / NCH, NTH = HC / 32, NTO = WC / 32;
+    float* A = smem;                                                 // [ROWS][260] dY tile; at the end w = gamma * dn
+    float* U = smem;                                                 // [ROWS][132] dv / dg chunk (aliases A while A is dead)
+    float* stage = smem + ROWS * LD128;                              // 4 staging tiles (behind U, inside A)
+    _Float16* Ph = reinterpret_cast<_Float16*>(smem + ROWS * LDK);   // [ROWS][264] planes of the scaled dY rows
+    _Float16* Pl = Ph + ROWS * LDH;
+    float* rs = smem + ROWS * LDK + ROWS * LDH;                      // [ROWS][2] scale, inverse
+    const WaveIdT<RB> w;
+    constexpr int SW = RB == 2 ? 64 : 32;                            // staging tile width
+    float* my_stage = stage + w.wave * (32 * SW);
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
     const int64_t wrow0 = row0 + 32 * w.rb;
-    load_rows_to_lds<K>(A, dY, row0, R, K);
+    load_rows_to_lds<K, ROWS>(A, dY, row0, R, K);
     __syncthreads();
-    tile_row_scales<K>(A, LDK, rs);
+    tile_row_scales<K, ROWS>(A, LDK, rs);
     __syncthreads();
-    split_tile_planes_scaled<K>(A, LDK, rs, Ph, Pl);
+    split_tile_planes_scaled<K, ROWS>(A, LDK, rs, Ph, Pl);
     __syncthreads();  // A is dead until the epilogue
-    f32x16 dn[4];
-    acc_fill_bias<4>(dn, nullptr, 0, w.lane);
+    f32x16 dn[NTO];
+    acc_fill_bias<NTO>(dn, nullptr, 0, w.lane);
 #pragma unroll 1
     for (int hc = 0; hc < HID / 128; hc++) {
-        f32x16 du[2];
-        acc_fill_bias<2>(du, nullptr, 0, w.lane);
-        gemm_acc_hs<K, 2, 8>(Ph + w.rb * 32 * LDH, Pl + w.rb * 32 * LDH, LDH, woutb, K / 8, 0, 4 * hc + 2 * w.ch, du, w.lane);
-        const int hcol0 = 128 * hc + 64 * w.ch;
-        float sg[2][16], vv[2][16];
+        f32x16 du[NTH];
+        acc_fill_bias<NTH>(du, nullptr, 0, w.lane);
+        const int hcol0 = 128 * hc + HC * w.ch;
+        gemm_acc_hs<K, NTH, 8>(Ph + w.rb * 32 * LDH, Pl + w.rb * 32 * LDH, LDH, woutb, K / 8, 0, hcol0 / 32, du, w.lane);
+        float sg[NTH][16], vv[NTH][16];
         auto vg_rows = [&](int off) {
             return [&, off](int r, int cc, float4& v) {
                 v = wrow0 + r < R ? *reinterpret_cast<const float4*>(VG + (wrow0 + r) * (2 * HID) + off + hcol0 + cc)
                                   : make_float4(0.f, 0.f, 0.f, 0.f);
             };
         };
-        wave_load_rows64(my_stage, w.lane, vg_rows(0));
+        if constexpr (RB == 2) wave_load_rows64(my_stage, w.lane, vg_rows(0));
+        else wave_load_rows32(my_stage, w.lane, vg_rows(0));
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+        for (int t = 0; t < NTH; t++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) vv[t][r] = my_stage[acc_row(r, w.lane) * 64 + 32 * t + (w.lane & 31)];
+            for (int r = 0; r < 16; r++) vv[t][r] = my_stage[acc_row(r, w.lane) * SW + 32 * t + (w.lane & 31)];
         __builtin_amdgcn_wave_barrier();
-        wave_load_rows64(my_stage, w.lane, vg_rows(HID));
+        if constexpr (RB == 2) wave_load_rows64(my_stage, w.lane, vg_rows(HID));
+        else wave_load_rows32(my_stage, w.lane, vg_rows(HID));
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+        for (int t = 0; t < NTH; t++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) sg[t][r] = sigmoidf_(my_stage[acc_row(r, w.lane) * 64 + 32 * t + (w.lane & 31)]);
+            for (int r = 0; r < 16; r++) sg[t][r] = sigmoidf_(my_stage[acc_row(r, w.lane) * SW + 32 * t + (w.lane & 31)]);
         __builtin_amdgcn_wave_barrier();
         __syncthreads();  // the previous chunk's readers of U are done
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+        for (int t = 0; t < NTH; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++)
-                U[(w.rb * 32 + acc_row(r, w.lane)) * LD128 + 64 * w.ch + 32 * t + (w.lane & 31)] = du[t][r] * sg[t][r];  // dv
+                U[(w.rb * 32 + acc_row(r, w.lane)) * LD128 + HC * w.ch + 32 * t + (w.lane & 31)] = du[t][r] * sg[t][r];  // dv
         __syncthreads();
-        gemm_acc_x<128, 4>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, 16 * hc, 4 * w.ch, dn, w.lane);
+        gemm_acc_x<128, NTO>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, 16 * hc, NTO * w.ch, dn, w.lane);
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+        for (int t = 0; t < NTH; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++)
-                U[(w.rb * 32 + acc_row(r, w.lane)) * LD128 + 64 * w.ch + 32 * t + (w.lane & 31)] =
+                U[(w.rb * 32 + acc_row(r, w.lane)) * LD128 + HC * w.ch + 32 * t + (w.lane & 31)] =
                     du[t][r] * vv[t][r] * sigmoid_grad_from(sg[t][r]);  // dg
         __syncthreads();
-        gemm_acc_x<128, 4>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, HID / 8 + 16 * hc, 4 * w.ch, dn, w.lane);
+        gemm_acc_x<128, NTO>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, HID / 8 + 16 * hc, NTO * w.ch, dn, w.lane);
     }
     __syncthreads();  // everyone is done with U: A takes w = gamma * dn (back in true units)
-    acc_foreach<4>(dn, w.rb, 128 * w.ch, w.lane, [&](int r, int c, float v) { A[r * LDK + c] = v * rs[2 * r + 1] * gamma[c]; });
+    acc_foreach<NTO>(dn, w.rb, WC * w.ch, w.lane, [&](int r, int c, float v) { A[r * LDK + c] = v * rs[2 * r + 1] * gamma[c]; });
     __syncthreads();
-    norm_bwd_rows<K>(A, Xin, row0, R, K, ln, [&](int r, int c, float4 dx) {
+    norm_bwd_rows<K, ROWS>(A, Xin, row0, R, K, ln, [&](int r, int c, float4 dx) {
         const int64_t o = (row0 + r) * K + c;
         const float4 dy = *reinterpret_cast<const float4*>(dY + o);
         *reinterpret_cast<float4*>(dXout + o) = make_float4(dy.x + dx.x, dy.y + dx.y, dy.z + dx.z, dy.w + dx.w);
@@ -1153,9 +1158,15 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 ProfScope ps("node_bwd", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
                 const WX wob = wx_b(A.cmlp_out), wib = wx_b(A.cmlp_in);
                 if (!tr && node_planes() && wob.h && wib.h) {
-                    const size_t lds_nb = (size_t)BM * LD256 * 4 + (size_t)2 * BM * plane_ld(256) * 2 + BM * 8;
-                    allow_big_lds(k_node_bwd2, lds_nb);
-                    k_node_bwd2<<<gN, NTHREADS, lds_nb, s2>>>(dH, Ab.H1, Ab.VGn, A.g_center, wob, wib, dH_alt, N, ln);
+                    const int nr = node_rows(N);
+                    const size_t lds_nb = (size_t)nr * LD256 * 4 + (size_t)2 * nr * plane_ld(256) * 2 + nr * 8;
+                    if (nr == 32) {
+                        allow_big_lds(k_node_bwd2<1>, lds_nb);
+                        k_node_bwd2<1><<<cdiv(N, 32), NTHREADS, lds_nb, s2>>>(dH, Ab.H1, Ab.VGn, A.g_center, wob, wib, dH_alt, N, ln);
+                    } else {
+                        allow_big_lds(k_node_bwd2<2>, lds_nb);
+                        k_node_bwd2<2><<<gN, NTHREADS, lds_nb, s2>>>(dH, Ab.H1, Ab.VGn, A.g_center, wob, wib, dH_alt, N, ln);
+                    }
                 } else
                 PET_LAUNCH_TR(tr, k_swiglu_bwd, PET_TA(256, DNF), gN, (BM * LD256 + BM * LD128) * 4, s2,  dH, Ab.H1,
                     Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N, tr ? w.dVGn : nullptr, ln);

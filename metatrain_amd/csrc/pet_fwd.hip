@@ -416,6 +416,11 @@ __global__ __launch_bounds__(NTHREADS) void k_node(const float* __restrict__ H, 
 // the SwiGLU pre-activations and the result leave through wave-private staging tiles as float4 rows (tile.h
 // wave_rows64); and the normalised rows are split ONCE into fp16 planes (gemm_acc_hs) for the 16 column-chunk GEMMs of
 // the centre MLP's first Linear. LDS: [ h tile fp32 -> (SwiGLU chunk | 4 staging tiles) ][ OC tile -> planes ][ scales ].
+// RB = 2: 64 rows per workgroup, waves = 2 row blocks x 2 column halves (1 workgroup per CU: 133 KB of LDS). RB = 1: 32 rows,
+// the four waves own a quarter of the columns each and two workgroups share a CU (67 KB): half the dependent chain per
+// wave and a second workgroup to fill its stalls -- the node chain sits on the critical path of a small box (one
+// k_node2 per attention layer between the output projection and the next layer's centre tokens).
+template <int RB>
 __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H, const float* __restrict__ OC,
                                                      WX wce, const float* __restrict__ bce,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, WX win,
@@ -424,75 +429,95 @@ __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H,
                                                      float* __restrict__ H1, float* __restrict__ VGn,
                                                      float* __restrict__ Hn, int64_t N) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 32 * RB, NCH = 4 / RB;      // rows per workgroup, column groups
+    constexpr int WC = 256 / NCH, HC = 128 / NCH;    // output columns / hidden columns (per 128-chunk) of one wave
+    constexpr int NTH = HC / 32, NTO = WC / 32;
     constexpr int LDH = plane_ld(256);
-    float* Hs = smem;                                                  // [64][260] h, then h1, then dead
-    float* U = smem;                                                   // [64][132] SwiGLU chunk (aliases Hs)
-    float* stage = smem + BM * LD128;                                  // 4 x [32][64] staging tiles (behind U, inside Hs)
-    _Float16* Ph = reinterpret_cast<_Float16*>(smem + BM * LD256);     // [64][264] high pieces of Norm(h1)
-    _Float16* Pl = Ph + BM * LDH;                                      // [64][264] low pieces
-    float* OCs = smem + BM * LD256;                                    // [64][132] OC tile (before the planes exist)
-    float* rs = smem + BM * LD256 + BM * LDH;                          // [64][2] row scales of the OC tile
-    const WaveId w;
-    float* my_stage = stage + w.wave * (32 * 64);
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
-    load_rows_to_lds<128>(OCs, OC, row0, N, D);
-    load_rows_to_lds<256>(Hs, H, row0, N, DN);
+    float* Hs = smem;                                                  // [ROWS][260] h, then h1, then dead
+    float* U = smem;                                                   // [ROWS][132] SwiGLU chunk (aliases Hs)
+    float* stage = smem + ROWS * LD128;                                // 4 staging tiles (behind U, inside Hs)
+    _Float16* Ph = reinterpret_cast<_Float16*>(smem + ROWS * LD256);   // [ROWS][264] high pieces of Norm(h1)
+    _Float16* Pl = Ph + ROWS * LDH;                                    // [ROWS][264] low pieces
+    float* OCs = smem + ROWS * LD256;                                  // [ROWS][132] OC tile (before the planes exist)
+    float* rs = smem + ROWS * LD256 + ROWS * LDH;                      // [ROWS][2] row scales of the OC tile
+    const WaveIdT<RB> w;
+    float* my_stage = stage + w.wave * (RB == 2 ? 32 * 64 : 32 * 32);
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    load_rows_to_lds<128, ROWS>(OCs, OC, row0, N, D);
+    load_rows_to_lds<256, ROWS>(Hs, H, row0, N, DN);
     __syncthreads();
-    tile_row_scales<128>(OCs, LD128, rs);
+    tile_row_scales<128, ROWS>(OCs, LD128, rs);
     __syncthreads();
 #pragma unroll 1
-    for (int c = 0; c < 2; c++) {  // 256 output columns in two chunks of 128
+    for (int c = 0; c < RB; c++) {  // this wave's WC output columns in groups of 64
         f32x16 acc[2];
-        const int col0 = 128 * c + 64 * w.ch;
+        const int col0 = 64 * (NCH * c + w.ch);
         acc_fill_bias<2>(acc, bce, col0, w.lane);
-        gemm_acc_x<128, 2>(OCs + w.rb * 32 * LD128, LD128, wce, 16, 0, 4 * c + 2 * w.ch, acc, w.lane, rs + 64 * w.rb);
+        gemm_acc_x<128, 2>(OCs + w.rb * 32 * LD128, LD128, wce, 16, 0, col0 / 32, acc, w.lane, rs + 64 * w.rb);
         acc_foreach<2>(acc, w.rb, col0, w.lane, [&](int r, int cc, float v) { Hs[r * LD256 + cc] += v; });  // h1 = h + ...
     }
     __syncthreads();
-    store_rows_from_lds<256>(Hs, H1, row0, N, DN);
+    store_rows_from_lds<256, ROWS>(Hs, H1, row0, N, DN);
     __syncthreads();
-    norm_rows_inplace<256>(Hs, gamma, beta);
+    norm_rows_inplace<256, ROWS>(Hs, gamma, beta);
     __syncthreads();
-    split_tile_planes<256>(Hs, LD256, Ph, Pl);
+    split_tile_planes<256, ROWS>(Hs, LD256, Ph, Pl);
     __syncthreads();  // Hs is dead from here on: U and the staging tiles reuse its memory
-    f32x16 out[4];  // this wave: 32 rows x 128 columns (128 * ch ..)
-    acc_fill_bias<4>(out, bout, 128 * w.ch, w.lane);
+    f32x16 out[NTO];  // this wave: 32 rows x WC columns (WC * ch ..)
+    acc_fill_bias<NTO>(out, bout, WC * w.ch, w.lane);
     const int64_t wrow0 = row0 + 32 * w.rb;  // first row of this wave's block
 #pragma unroll 1
     for (int hc = 0; hc < DNF / 128; hc++) {
-        f32x16 av[2], ag[2];
-        const int hcol0 = 128 * hc + 64 * w.ch;  // hidden columns of this wave
-        acc_fill_bias<2>(av, bin, hcol0, w.lane);
-        acc_fill_bias<2>(ag, bin, DNF + hcol0, w.lane);
-        gemm_acc_hs<256, 2, 8>(Ph + w.rb * 32 * LDH, Pl + w.rb * 32 * LDH, LDH, win, 32, 0, hcol0 / 32, av, w.lane);
-        gemm_acc_hs<256, 2, 8>(Ph + w.rb * 32 * LDH, Pl + w.rb * 32 * LDH, LDH, win, 32, 0, (DNF + hcol0) / 32, ag, w.lane);
+        f32x16 av[NTH], ag[NTH];
+        const int hcol0 = 128 * hc + HC * w.ch;  // hidden columns of this wave
+        acc_fill_bias<NTH>(av, bin, hcol0, w.lane);
+        acc_fill_bias<NTH>(ag, bin, DNF + hcol0, w.lane);
+        gemm_acc_hs<256, NTH, 8>(Ph + w.rb * 32 * LDH, Pl + w.rb * 32 * LDH, LDH, win, 32, 0, hcol0 / 32, av, w.lane);
+        gemm_acc_hs<256, NTH, 8>(Ph + w.rb * 32 * LDH, Pl + w.rb * 32 * LDH, LDH, win, 32, 0, (DNF + hcol0) / 32, ag, w.lane);
         if (VGn) {  // saved for the adjoint: [value | gate] pre-activations, whole float4 rows
-            wave_rows64(av, my_stage, w.lane, [&](int r, int cc, float4 v) {
-                if (wrow0 + r < N) *reinterpret_cast<float4*>(VGn + (wrow0 + r) * (2 * DNF) + hcol0 + cc) = v;
-            });
-            wave_rows64(ag, my_stage, w.lane, [&](int r, int cc, float4 v) {
-                if (wrow0 + r < N) *reinterpret_cast<float4*>(VGn + (wrow0 + r) * (2 * DNF) + DNF + hcol0 + cc) = v;
-            });
+            if constexpr (RB == 2) {
+                wave_rows64(av, my_stage, w.lane, [&](int r, int cc, float4 v) {
+                    if (wrow0 + r < N) *reinterpret_cast<float4*>(VGn + (wrow0 + r) * (2 * DNF) + hcol0 + cc) = v;
+                });
+                wave_rows64(ag, my_stage, w.lane, [&](int r, int cc, float4 v) {
+                    if (wrow0 + r < N) *reinterpret_cast<float4*>(VGn + (wrow0 + r) * (2 * DNF) + DNF + hcol0 + cc) = v;
+                });
+            } else {
+                wave_rows32(av[0], my_stage, w.lane, [&](int r, int cc, float4 v) {
+                    if (wrow0 + r < N) *reinterpret_cast<float4*>(VGn + (wrow0 + r) * (2 * DNF) + hcol0 + cc) = v;
+                });
+                wave_rows32(ag[0], my_stage, w.lane, [&](int r, int cc, float4 v) {
+                    if (wrow0 + r < N) *reinterpret_cast<float4*>(VGn + (wrow0 + r) * (2 * DNF) + DNF + hcol0 + cc) = v;
+                });
+            }
         }
         __syncthreads();  // previous chunk's readers of U are done
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+        for (int t = 0; t < NTH; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++)  // transformer.py:42-43: value * sigmoid(gate)
-                U[(w.rb * 32 + acc_row(r, w.lane)) * LD128 + 64 * w.ch + 32 * t + (w.lane & 31)] = av[t][r] * sigmoidf_(ag[t][r]);
+                U[(w.rb * 32 + acc_row(r, w.lane)) * LD128 + HC * w.ch + 32 * t + (w.lane & 31)] = av[t][r] * sigmoidf_(ag[t][r]);
         __syncthreads();
-        gemm_acc_x<128, 4>(U + w.rb * 32 * LD128, LD128, wout, DNF / 8, 16 * hc, 4 * w.ch, out, w.lane);
+        gemm_acc_x<128, NTO>(U + w.rb * 32 * LD128, LD128, wout, DNF / 8, 16 * hc, NTO * w.ch, out, w.lane);
     }
-#pragma unroll
-    for (int half = 0; half < 2; half++) {  // Hn = h1 + MLP: this wave's 128 columns in two groups of 64
-        const f32x16 pair[2] = {out[2 * half], out[2 * half + 1]};
-        wave_rows64(pair, my_stage, w.lane, [&](int r, int cc, float4 v) {
+    auto add_h1 = [&](int col) {  // Hn = h1 + MLP
+        return [&, col](int r, int cc, float4 v) {
             const int64_t row = wrow0 + r;
             if (row >= N) return;
-            const int64_t o = row * DN + 128 * w.ch + 64 * half + cc;
+            const int64_t o = row * DN + col + cc;
             const float4 h1 = *reinterpret_cast<const float4*>(H1 + o);
             *reinterpret_cast<float4*>(Hn + o) = make_float4(h1.x + v.x, h1.y + v.y, h1.z + v.z, h1.w + v.w);
-        });
+        };
+    };
+    if constexpr (RB == 2) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {  // this wave's 128 columns in two groups of 64
+            const f32x16 pair[2] = {out[2 * half], out[2 * half + 1]};
+            wave_rows64(pair, my_stage, w.lane, add_h1(WC * w.ch + 64 * half));
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NTO; t++) wave_rows32(out[t], my_stage, w.lane, add_h1(WC * w.ch + 32 * t));
     }
 }
 
@@ -760,6 +785,13 @@ static void note_workspace(const void* ws, bool generic) {
 static int g_node_planes = 1;  // k_node2 / k_node_bwd2: A tiles pre-split into fp16 planes (pet_config_set("node_planes", 0): k_node)
 void set_node_planes(int v) { g_node_planes = v; }
 bool node_planes() { return g_node_planes != 0; }
+// rows per workgroup of k_node2 / k_node_bwd2: node_planes = 2 / 3 force 32 / 64, 1 chooses by the number of atoms
+static int g_node_rows_threshold = 16384;  // measured: 1 000 / 3 000 / 10 000 atoms gain 14 / 8 / 2 %, 80 000 lose 8 % of the stage
+int node_rows(int64_t N) {
+    if (g_node_planes == 2) return 32;
+    if (g_node_planes == 3) return 64;
+    return N <= g_node_rows_threshold ? 32 : 64;
+}
 
 // sum_i (n_i + 1)^2 estimated from the mean neighbour count (exact value is not needed on the hot path)
 double g_sum_t2(const Graph& g) {
@@ -918,10 +950,17 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                 ProfScope ps("node", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
                 const WX wci = wx_fwd(A.cmlp_in, 8), wce_ = wx_fwd(A.ce, 4), wco = wx_fwd(A.cmlp_out, 16);
                 if (node_planes() && wci.h && wce_.h && wco.h) {
-                    const size_t lds_n2 = (size_t)BM * LD256 * 4 + (size_t)2 * BM * plane_ld(256) * 2 + BM * 8;
-                    allow_big_lds(k_node2, lds_n2);
-                    k_node2<<<gN, NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci, A.cmlp_in.b,
-                                                          wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
+                    const int nr = node_rows(N);
+                    const size_t lds_n2 = (size_t)nr * LD256 * 4 + (size_t)2 * nr * plane_ld(256) * 2 + nr * 8;
+                    if (nr == 32) {
+                        allow_big_lds(k_node2<1>, lds_n2);
+                        k_node2<1><<<cdiv(N, 32), NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci,
+                                                                         A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
+                    } else {
+                        allow_big_lds(k_node2<2>, lds_n2);
+                        k_node2<2><<<gN, NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci,
+                                                                 A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
+                    }
                 } else
                 k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, s2>>>(
                     Ab.H, Ab.OC, wx_fwd(A.ce, 4), A.ce.b, A.g_center, A.b_center, wx_fwd(A.cmlp_in, 8), A.cmlp_in.b,

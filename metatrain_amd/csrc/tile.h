@@ -33,6 +33,18 @@ struct WaveId {
     }
 };
 
+// RB row blocks of 32 rows per workgroup: 2 -> (row block, column half) as above; 1 -> one row block, four column quarters
+template <int RB>
+struct WaveIdT {
+    int lane, wave, rb, ch;
+    __device__ WaveIdT() {
+        lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        rb = RB == 2 ? (wave & 1) : 0;
+        ch = RB == 2 ? (wave >> 1) : wave;
+    }
+};
+
 // C/D layout of the 32x32 tile (cdna_hip_programming.md §3):
 //   col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), r in [0, 16)
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
@@ -206,11 +218,11 @@ __device__ __forceinline__ void split_hl(float v, _Float16& h, _Float16& l) {
     l = (_Float16)((v - (float)h) * 2048.0f);
 }
 // [64][K] fp32 tile (leading dimension lda) -> the two planes; 256 threads, four per row
-template <int K>
+template <int K, int ROWS = BM>
 __device__ __forceinline__ void split_tile_planes(const float* As, int lda, _Float16* Ah, _Float16* Al) {
-    constexpr int LDH = plane_ld(K);
-    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
-    for (int c = 4 * q; c < K; c += 16) {  // this thread: columns c .. c + 3, a run of four inside one block of 16
+    constexpr int LDH = plane_ld(K), TPR = NTHREADS / ROWS;
+    const int r = threadIdx.x / TPR, q = threadIdx.x % TPR;
+    for (int c = 4 * q; c < K; c += 4 * TPR) {  // this thread: columns c .. c + 3, a run of four inside one block of 16
         const float4 v = *reinterpret_cast<const float4*>(As + r * lda + c);
         const int p = r * LDH + plane_pos(c);
         _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
@@ -221,16 +233,18 @@ __device__ __forceinline__ void split_tile_planes(const float* As, int lda, _Flo
 }
 
 // per-row power-of-two scales of a staged [64][K] tile: rs[2 r] = scale (row maximum into [1, 2)), rs[2 r + 1] = inverse
-template <int K>
+template <int K, int ROWS = BM>
 __device__ __forceinline__ void tile_row_scales(const float* As, int lda, float* rs) {
-    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    constexpr int TPR = NTHREADS / ROWS;
+    const int r = threadIdx.x / TPR, q = threadIdx.x % TPR;
     float m = 0.f;
-    for (int c = q * 4; c < K; c += 16) {
+    for (int c = q * 4; c < K; c += 4 * TPR) {
         const float4 v = *reinterpret_cast<const float4*>(As + r * lda + c);
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
     m = fmaxf(m, __shfl_xor(m, 1));
     m = fmaxf(m, __shfl_xor(m, 2));
+    if (TPR == 8) m = fmaxf(m, __shfl_xor(m, 4));
     int e = (__float_as_int(m) >> 23) & 0xff;
     e = e > 253 ? 253 : e;
     if (q == 0) {
@@ -265,12 +279,12 @@ __device__ __forceinline__ void acc_foreach(f32x16 (&acc)[NT], int rb, int col0,
 // Cooperative load of a [64][K] fp32 row tile from global (row stride ld_g) into LDS
 // [64][K+4]; rows >= n_rows are zero-filled. 32 consecutive lanes read one row's
 // float4s (512 B contiguous).
-template <int K>
+template <int K, int ROWS = BM>
 __device__ __forceinline__ void load_rows_to_lds(float* As, const float* __restrict__ G, int64_t row0,
                                                  int64_t n_rows, int ld_g) {
     constexpr int C4 = K / 4;
     constexpr int LDA = lds_ld(K);
-    for (int idx = threadIdx.x; idx < BM * C4; idx += NTHREADS) {
+    for (int idx = threadIdx.x; idx < ROWS * C4; idx += NTHREADS) {
         int r = idx / C4, c = idx % C4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row0 + r < n_rows) v = *reinterpret_cast<const float4*>(G + (row0 + r) * ld_g + 4 * c);
@@ -279,12 +293,12 @@ __device__ __forceinline__ void load_rows_to_lds(float* As, const float* __restr
 }
 
 // Cooperative store of a [64][K] fp32 LDS tile to global rows (the inverse of load_rows_to_lds): 512-B row segments.
-template <int K>
+template <int K, int ROWS = BM>
 __device__ __forceinline__ void store_rows_from_lds(const float* As, float* __restrict__ G, int64_t row0, int64_t n_rows,
                                                     int ld_g) {
     constexpr int C4 = K / 4;
     constexpr int LDA = lds_ld(K);
-    for (int idx = threadIdx.x; idx < BM * C4; idx += NTHREADS) {
+    for (int idx = threadIdx.x; idx < ROWS * C4; idx += NTHREADS) {
         const int r = idx / C4, c = idx % C4;
         if (row0 + r < n_rows)
             *reinterpret_cast<float4*>(G + (row0 + r) * ld_g + 4 * c) = *reinterpret_cast<const float4*>(As + r * LDA + 4 * c);
@@ -326,14 +340,41 @@ __device__ __forceinline__ void wave_load_rows64(float* stage, int lane, F f) {
     }
     __builtin_amdgcn_wave_barrier();
 }
+// One accumulator ([32 rows x 32 columns]) through a wave-private [32][32] staging tile: float4 rows of 128 B, eight lanes
+// per row (the 32-row workgroups of the node kernels, whose waves own a quarter of the columns).
+template <class F>
+__device__ __forceinline__ void wave_rows32(const f32x16& acc, float* stage, int lane, F f) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) stage[acc_row(r, lane) * 32 + (lane & 31)] = acc[r];
+    __builtin_amdgcn_wave_barrier();
+    const int rr = lane >> 3, cc = 4 * (lane & 7);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = 8 * j + rr;
+        f(r, cc, *reinterpret_cast<const float4*>(stage + r * 32 + cc));
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+template <class F>
+__device__ __forceinline__ void wave_load_rows32(float* stage, int lane, F f) {
+    const int rr = lane >> 3, cc = 4 * (lane & 7);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = 8 * j + rr;
+        float4 v;
+        f(r, cc, v);
+        *reinterpret_cast<float4*>(stage + r * 32 + cc) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
 // [64][K] fp32 tile -> planes, every row multiplied by its power-of-two scale rs[2 r] first (adjoint rows)
-template <int K>
+template <int K, int ROWS = BM>
 __device__ __forceinline__ void split_tile_planes_scaled(const float* As, int lda, const float* rs, _Float16* Ah,
                                                          _Float16* Al) {
-    constexpr int LDH = plane_ld(K);
-    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    constexpr int LDH = plane_ld(K), TPR = NTHREADS / ROWS;
+    const int r = threadIdx.x / TPR, q = threadIdx.x % TPR;
     const float sc = rs[2 * r];
-    for (int c = 4 * q; c < K; c += 16) {
+    for (int c = 4 * q; c < K; c += 4 * TPR) {
         const float4 v = *reinterpret_cast<const float4*>(As + r * lda + c);
         const int p = r * LDH + plane_pos(c);
         _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
@@ -346,22 +387,23 @@ __device__ __forceinline__ void split_tile_planes_scaled(const float* As, int ld
 // ---- row-wise normalisations on an LDS tile [64][K+4] ------------------------------
 // Four threads per row (256 threads / 64 rows), strided columns, xor-shuffle reduce.
 // RMSNorm: torch.nn.RMSNorm(d), eps = finfo(float32).eps.
-template <int K>
+template <int K, int ROWS = BM>
 __device__ __forceinline__ void rmsnorm_rows_inplace(float* As, const float* __restrict__ gamma,
                                                      float* rstd_out /* LDS [64] or nullptr */) {
-    constexpr int LDA = lds_ld(K);
-    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    constexpr int LDA = lds_ld(K), TPR = NTHREADS / ROWS;
+    const int r = threadIdx.x / TPR, q = threadIdx.x % TPR;
     float* row = As + r * LDA;
     float ss = 0.f;
-    for (int c = q * 4; c < K; c += 16) {
+    for (int c = q * 4; c < K; c += 4 * TPR) {
         float4 v = *reinterpret_cast<float4*>(row + c);
         ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
     ss += __shfl_xor(ss, 1);
     ss += __shfl_xor(ss, 2);
+    if (TPR == 8) ss += __shfl_xor(ss, 4);
     const float rstd = rsqrtf(ss * (1.0f / K) + 1.1920928955078125e-07f);
     if (rstd_out && q == 0) rstd_out[r] = rstd;
-    for (int c = q * 4; c < K; c += 16) {
+    for (int c = q * 4; c < K; c += 4 * TPR) {
         float4 v = *reinterpret_cast<float4*>(row + c);
         float4 g = *reinterpret_cast<const float4*>(gamma + c);
         v.x *= rstd * g.x; v.y *= rstd * g.y; v.z *= rstd * g.z; v.w *= rstd * g.w;
@@ -370,34 +412,36 @@ __device__ __forceinline__ void rmsnorm_rows_inplace(float* As, const float* __r
 }
 
 // RMSNorm (beta == nullptr) or torch.nn.LayerNorm(K) (eps 1e-5, biased variance, weight + bias; transformer.py:170-176)
-template <int K>
+template <int K, int ROWS = BM>
 __device__ __forceinline__ void norm_rows_inplace(float* As, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta) {
     if (beta == nullptr) {
-        rmsnorm_rows_inplace<K>(As, gamma, nullptr);
+        rmsnorm_rows_inplace<K, ROWS>(As, gamma, nullptr);
         return;
     }
-    constexpr int LDA = lds_ld(K);
-    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    constexpr int LDA = lds_ld(K), TPR = NTHREADS / ROWS;
+    const int r = threadIdx.x / TPR, q = threadIdx.x % TPR;
     float* row = As + r * LDA;
     float s = 0.f;
-    for (int c = q * 4; c < K; c += 16) {
+    for (int c = q * 4; c < K; c += 4 * TPR) {
         float4 v = *reinterpret_cast<float4*>(row + c);
         s += (v.x + v.y) + (v.z + v.w);
     }
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
+    if (TPR == 8) s += __shfl_xor(s, 4);
     const float mean = s * (1.0f / K);
     float ss = 0.f;
-    for (int c = q * 4; c < K; c += 16) {
+    for (int c = q * 4; c < K; c += 4 * TPR) {
         float4 v = *reinterpret_cast<float4*>(row + c);
         v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
         ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
     ss += __shfl_xor(ss, 1);
     ss += __shfl_xor(ss, 2);
+    if (TPR == 8) ss += __shfl_xor(ss, 4);
     const float rstd = rsqrtf(ss * (1.0f / K) + 1e-5f);
-    for (int c = q * 4; c < K; c += 16) {
+    for (int c = q * 4; c < K; c += 4 * TPR) {
         float4 v = *reinterpret_cast<float4*>(row + c);
         float4 g = *reinterpret_cast<const float4*>(gamma + c);
         float4 b = *reinterpret_cast<const float4*>(beta + c);

@@ -62,8 +62,15 @@ def test_fused_block_against_reference_goldens(rt, dev, golden_dir, name):
     graph = _graph(rt, model, dev, t("in_positions"), t("in_cells"), g["in_centers"], g["in_neighbors"], g["in_cell_shifts"],
                    t("in_species"), t("in_system_indices"))
     fw = rt.HipForward(model, graph)
-    atomic = fw.forward()
-    grad = fw.backward(torch.ones_like(atomic))
+    rt.profile(True)  # the stage names say which kernels ran: the fused block, not the three-kernel form
+    try:
+        atomic = fw.forward()
+        grad = fw.backward(torch.ones_like(atomic))
+        torch.cuda.synchronize()
+        stages = {r["name"] for r in rt.profile_report()}
+    finally:
+        rt.profile(False)
+    assert {"attn_blk", "attn_blk_bwd"} <= stages and not stages & {"qkv", "attn_fwd", "oproj", "attn_bwd", "qkv_bwd"}, stages
     assert relmax(atomic.cpu().numpy(), g["atomic_f64"].ravel()) < TOL
     assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
     # a second build of the same graph pairs the same atoms: bit-identical results (the pairing decides the summation order)
