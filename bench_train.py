@@ -101,6 +101,10 @@ def main():
                     help="BASELINE configs[3]: 512 x 10 000-atom boxes per step in the whole job (64 per GPU at N = 8), "
                          "micro-batches of 4 = --total-boxes 512 --atoms 10000 --micro 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-bf16", action="store_true",
+                    help="pet_config_set('train_bf16', 1): ONE 16-bit MFMA term per product in the second-order and "
+                         "weight-gradient GEMMs (BASELINE configs[2]'s 'bf16 MFMA MLPs'; gradients to ~1e-3, not the parity "
+                         "mode; the default run reports it next to `value` as `train_bf16`)")
     ap.add_argument("--normalization", default="RMSNorm", choices=["RMSNorm", "LayerNorm"],
                     help="LayerNorm: the legacy-checkpoint norm")
     args = ap.parse_args()
@@ -143,6 +147,8 @@ def main():
     model = rt.HipModel(hypers, [1, 6, 7, 8])
     model.load({k: v.to(dev) for k, v in params.items()}, "energy")
 
+    if args.train_bf16:
+        rt.config_set("train_bf16", 1)
     gen = torch.Generator().manual_seed(1234 + rank)
     micro = args.micro if args.micro > 0 else args.boxes
     strong = args.total_boxes > 0
@@ -206,6 +212,21 @@ def main():
     pdist.barrier(dev)
     elapsed = pdist.max_over_ranks(time.perf_counter() - t0, dev)
     train.comm_events = None
+    one_term = None
+    if world == 1 and not args.train_bf16:  # not `value`: the same step in the single-term mode (a few more Adam steps)
+        rt.config_set("train_bf16", 1)
+        step(graph, fw, target_e, per_box, target_g)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step(graph, fw, target_e, per_box, target_g)
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t1) / 3
+        rt.config_set("train_bf16", 0)
+        one_term = {"value": n_atoms / dt1, "unit": "atom-steps/s", "ms_per_step": dt1 * 1e3,
+                    "what": "pet_config_set('train_bf16', 1): ONE 16-bit MFMA term per product in the second-order and "
+                            "weight-gradient GEMMs (gradients to ~1e-3: 20-step loss curve in tests/test_gpu_train.py); "
+                            "forward and force pass unchanged"}
     comm_ms = (sum(a.elapsed_time(b) for a, b in comm_events) / len(comm_events)) if comm_events else 0.0
     if rank == 0:
         ls = [float(x) for x in losses]
@@ -221,7 +242,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (single-term 16-bit MFMA training GEMMs: --train-bf16)" if args.train_bf16 else "f32",
             "data": "synthetic random periodic boxes and random targets, weights from a seeded generator",
             "config": {
                 "workload": f"PET training step, "
@@ -264,6 +285,8 @@ def main():
             t2 = float((((rowptr[1:] - rowptr[:-1]) + 1) ** 2).sum())
             fwd = (2001152.0 * g0.n_edges + 4292864.0 * g0.n_nodes + 2048.0 * t2) * (n_edges / max(g0.n_edges, 1))
             out["roofline"]["whole_step_algorithmic_tflops"] = 6.0 * fwd / (elapsed / args.steps) / 1e12
+        if one_term:
+            out["train_bf16"] = one_term
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(hypers, params)
         print(json.dumps(out), flush=True)

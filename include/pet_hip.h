@@ -413,6 +413,9 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *                  default 3; 0 = LDS-tile kernels
  *   "node_planes" 1 = node-row kernels k_node2 / k_node_bwd2 (coalesced tiles, fp16 planes; default), 0 = k_node / k_swiglu_bwd
  *   "so_trr"      1 = generic training GEMMs with K = 128 or n_out = 128 as TRR kernels (default); 0 = LDS-tile k_gemm_h
+ *   "train_bf16"  1 = the GEMMs of the second-order pass and the weight-gradient GEMMs keep ONE 16-bit MFMA term per product
+ *                 (fp16 / bf16 high planes, fp32 accumulation: BASELINE configs[2]'s "bf16 MFMA MLPs"; gradients within
+ *                 ~1e-3, NOT the 1e-5 parity mode; 20-step loss curve in tests/test_gpu_train.py); default 0
  *   "wgrad_bf16"  1 = weight-gradient GEMMs of the training passes as bf16x3 split-operand products (default); 0 = fp32 MFMA
  *   "so_f16x3"    1 = generic GEMMs of the second-order (training) pass as f16x3 (default); 0 = fp32 MFMA
  *   (removed in round 4 with the kernels they selected: "emlp_pipe", "emlp_bwd_pipe", "comb_pipe", "comb_bwd_pipe",

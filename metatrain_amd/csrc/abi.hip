@@ -941,6 +941,7 @@ int pet_config_set(const char* key, int value) {
     else if (k == "node_planes") set_node_planes(value);
     else if (k == "so_trr") set_so_trr(value);
     else if (k == "wgrad_bf16") set_wgrad_bf16(value);
+    else if (k == "train_bf16") set_train_bf16(value);
     else if (k == "tile_mask") set_tile_mask(value);
     else if (k == "so_f16x3") set_so_f16x3(value);
     else PET_REQUIRE(false, PET_ERR_ARGUMENT, "unknown config key '" + k + "'");

@@ -240,6 +240,8 @@ bool use_trr();
 void set_use_trr(int v);
 void set_side_stream(int v);
 void set_so_f16x3(int v);   // so.hip: 1 = generic training GEMMs as f16x3 on the 16-bit matrix cores (default), 0 = fp32 MFMA
+void set_train_bf16(int v);  // so.hip / train.hip: 1 = ONE 16-bit MFMA term per product in the training GEMMs (default 0: f16x3 / bf16x3)
+int train_bf16();
 void set_wgrad_bf16(int v);  // train.hip: 1 = weight gradients as bf16x3 products on the 16-bit matrix cores (default)
 void set_so_trr(int v);     // so.hip: 1 = K = 128 / n_out = 128 generic GEMMs as TRR kernels (default)
 void set_attn_lds(int v);   // pet_attn.hip: 1 = LDS-staged attention (default), 0 = wave-per-head from global

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_h(const float* __restrict__ X
 // multiple of 128; wider outputs take one launch per 128 columns). Same products and the same power-of-two row scaling as k_gemm_h (one scale per row and per 128-wide
 // K slice; with several slices a running scale that only shrinks, applied with selects, as in k_qkv_bwd_h).
 // ---------------------------------------------------------------------------------------------
+template <bool ONE>  // ONE: single fp16 term per product (train_bf16 mode), else f16x3
 __global__ __launch_bounds__(256, 2) void k_rowgemm_k128(const float* __restrict__ X, int ldx,
                                                          const float* __restrict__ cs, W2 w,
                                                          const float* __restrict__ bias, float* __restrict__ Y, int ldy,
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_k128(const float* __restrict
     const bool valid = row0 + L.r < R;
     const int64_t row = valid ? row0 + L.r : R - 1;
     float* lds = tiles[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-    Split2<8> xs;
+    Split2<ONE ? 1 : 8> xs;
+    f16x8 xh1[ONE ? 8 : 1];
     float inv;
     {
         float4 x[16];
@@ -210,13 +212,20 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_k128(const float* __restrict
         }
         float sc;
         inv = row_scale_pow2<16>(x, sc);
-        split_frag2<8>(x, xs);
+        if constexpr (ONE) high_frag<8>(x, xh1);
+        else split_frag2<8>(x, xs);
     }
     const int nc = n_out / 64;  // 64-wide column groups = pairs of 32-wide weight tiles
     auto widx = [&](int b) { return ((size_t)(2 * (b >> 3)) * 8 + (b & 7)) * 64 + L.lane; };
-    WBlk2<2> ring[2];
+    WBlk2<2> ring[ONE ? 1 : 2];
+    WBlk1<2> ring1[ONE ? 4 : 1];  // the single-term form has registers to spare: four blocks in flight
+    if constexpr (ONE) {
 #pragma unroll
-    for (int b = 0; b < 2; b++) ld_blk2<2>(ring[b], w, widx(b), 8 * 64);
+        for (int b = 0; b < 4; b++) ld_blk1<2>(ring1[b], w, widx(b < 8 * nc ? b : 8 * nc - 1), 8 * 64);
+    } else {
+#pragma unroll
+        for (int b = 0; b < 2; b++) ld_blk2<2>(ring[b], w, widx(b), 8 * 64);
+    }
 #pragma unroll 1
     for (int c = 0; c < nc; c++) {
         f32x16 acc[2], acl[2];
@@ -224,13 +233,21 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_k128(const float* __restrict
         acc_zero<2>(acl);
 #pragma unroll
         for (int kb = 0; kb < 8; kb++) {
-            WBlk2<2>& wb = ring[kb & 1];
-            mfma3<2>(acc, acl, wb, xs.h[kb], xs.l[kb]);
-            int nb = 8 * c + kb + 2;
-            nb = nb < 8 * nc ? nb : 8 * nc - 1;  // past the end: a harmless reload of the last block
-            ld_blk2<2>(wb, w, widx(nb), 8 * 64);
+            if constexpr (ONE) {
+                WBlk1<2>& wb = ring1[kb & 3];
+                mfma1<2>(acc, wb, xh1[kb]);
+                int nb = 8 * c + kb + 4;
+                nb = nb < 8 * nc ? nb : 8 * nc - 1;
+                ld_blk1<2>(wb, w, widx(nb), 8 * 64);
+            } else {
+                WBlk2<2>& wb = ring[kb & 1];
+                mfma3<2>(acc, acl, wb, xs.h[kb], xs.l[kb]);
+                int nb = 8 * c + kb + 2;
+                nb = nb < 8 * nc ? nb : 8 * nc - 1;  // past the end: a harmless reload of the last block
+                ld_blk2<2>(wb, w, widx(nb), 8 * 64);
+            }
         }
-        fold_low<2>(acc, acl);
+        if constexpr (!ONE) fold_low<2>(acc, acl);
         acc_scale<2>(acc, inv);
         float4 y[8];
         acc_to_frag<2>(acc, y);
@@ -251,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_k128(const float* __restrict
     }
 }
 
+template <bool ONE>
 __global__ __launch_bounds__(256) void k_rowgemm_n128(const float* __restrict__ X, int ldx, int K,
                                                       const float* __restrict__ cs, W2 w,
                                                       const float* __restrict__ bias, float* __restrict__ Y, int ldy,
@@ -265,9 +283,13 @@ __global__ __launch_bounds__(256) void k_rowgemm_n128(const float* __restrict__ 
     const int kbt = K / 16, nks = K / 128;
     const size_t ts = (size_t)kbt * 64;  // tile stride: 32 output columns
     auto widx = [&](int b) { return (size_t)b * 64 + L.lane; };
-    WBlk2<4> ring[4];
+    WBlk2<4> ring[ONE ? 1 : 4];
+    WBlk1<4> ring1[ONE ? 4 : 1];
 #pragma unroll
-    for (int b = 0; b < 4; b++) ld_blk2<4>(ring[b], w, widx(b), ts);
+    for (int b = 0; b < 4; b++) {
+        if constexpr (ONE) ld_blk1<4>(ring1[b], w, widx(b), ts);
+        else ld_blk2<4>(ring[b], w, widx(b), ts);
+    }
     f32x16 dn[4], dnl[4];
     acc_zero<4>(dn);
     acc_zero<4>(dnl);
@@ -276,7 +298,8 @@ __global__ __launch_bounds__(256) void k_rowgemm_n128(const float* __restrict__ 
     float scale = 0.f, inv = 0.f;  // scale applied to what the accumulators hold, and its inverse
 #pragma unroll 1
     for (int ks = 0; ks < nks; ks++) {
-        Split2<8> xs;
+        Split2<ONE ? 1 : 8> xs;
+        f16x8 xh1[ONE ? 8 : 1];
         {
             if (cs) {
 #pragma unroll
@@ -298,19 +321,26 @@ __global__ __launch_bounds__(256) void k_rowgemm_n128(const float* __restrict__ 
             inv = shrink ? iv : inv;
 #pragma unroll
             for (int kg = 0; kg < 16; kg++) { d[kg].x *= sc_eff; d[kg].y *= sc_eff; d[kg].z *= sc_eff; d[kg].w *= sc_eff; }
-            split_frag2<8>(d, xs);
+            if constexpr (ONE) high_frag<8>(d, xh1);
+            else split_frag2<8>(d, xs);
         }
         if (ks + 1 < nks) load_rowfrag<16>(d, X + 128 * (ks + 1), row, ldx, L.h);
 #pragma unroll
         for (int kb = 0; kb < 8; kb++) {
-            WBlk2<4>& wb = ring[kb & 3];
-            mfma3<4>(dn, dnl, wb, xs.h[kb], xs.l[kb]);
             int nb = 8 * ks + kb + 4;
             nb = nb < kbt ? nb : kbt - 1;
-            ld_blk2<4>(wb, w, widx(nb), ts);
+            if constexpr (ONE) {
+                WBlk1<4>& wb = ring1[kb & 3];
+                mfma1<4>(dn, wb, xh1[kb]);
+                ld_blk1<4>(wb, w, widx(nb), ts);
+            } else {
+                WBlk2<4>& wb = ring[kb & 3];
+                mfma3<4>(dn, dnl, wb, xs.h[kb], xs.l[kb]);
+                ld_blk2<4>(wb, w, widx(nb), ts);
+            }
         }
     }
-    fold_low<4>(dn, dnl);
+    if constexpr (!ONE) fold_low<4>(dn, dnl);
     acc_scale<4>(dn, inv);
     float4 y[16];
     acc_to_frag<4>(dn, y);
@@ -333,20 +363,28 @@ __global__ __launch_bounds__(256) void k_rowgemm_n128(const float* __restrict__ 
 static int g_so_trr = 1;  // pet_config_set("so_trr", 0): every generic GEMM through the LDS-tile k_gemm_h
 void set_so_trr(int v) { g_so_trr = v ? 1 : 0; }
 // Y[R, n_out] (=|+=) (X[R, K] * cs) W^T + bias on the TRR kernels when the shape allows; false otherwise
+static int g_train_bf16 = 0;  // pet_config_set("train_bf16", 1): ONE 16-bit MFMA term per product in the training GEMMs
+void set_train_bf16(int v) { g_train_bf16 = v ? 1 : 0; }
+int train_bf16() { return g_train_bf16; }
 static bool rowgemm_trr(hipStream_t st, const float* X, int K, const float* cs, W2 w, const float* bias, float* Y,
                         int n_out, int64_t R, bool acc) {
     if (!g_so_trr) return false;
     const int grid = (int)cdiv(R, WG_ROWS);
     if (K == 128 && n_out % 64 == 0) {
-        k_rowgemm_k128<<<grid, 256, 0, st>>>(X, K, cs, w, bias, Y, n_out, n_out, R, acc ? 1 : 0);
+        if (g_train_bf16) k_rowgemm_k128<true><<<grid, 256, 0, st>>>(X, K, cs, w, bias, Y, n_out, n_out, R, acc ? 1 : 0);
+        else k_rowgemm_k128<false><<<grid, 256, 0, st>>>(X, K, cs, w, bias, Y, n_out, n_out, R, acc ? 1 : 0);
         return true;
     }
     if (n_out % 128 == 0 && K % 128 == 0) {  // 128 output columns per launch (k_gemm_h re-stages X per column block too)
         const size_t ts4 = (size_t)4 * (K / 16) * 64;  // four 32-column weight tiles
         for (int nb = 0; nb < n_out / 128; nb++) {
             W2 wn; wn.h = w.h + nb * ts4; wn.l = w.l + nb * ts4;
-            k_rowgemm_n128<<<grid, 256, 0, st>>>(X, K, K, cs, wn, bias ? bias + 128 * nb : nullptr, Y + 128 * nb, n_out, R,
-                                                 acc ? 1 : 0);
+            if (g_train_bf16)
+                k_rowgemm_n128<true><<<grid, 256, 0, st>>>(X, K, K, cs, wn, bias ? bias + 128 * nb : nullptr, Y + 128 * nb,
+                                                           n_out, R, acc ? 1 : 0);
+            else
+                k_rowgemm_n128<false><<<grid, 256, 0, st>>>(X, K, K, cs, wn, bias ? bias + 128 * nb : nullptr, Y + 128 * nb,
+                                                            n_out, R, acc ? 1 : 0);
         }
         return true;
     }

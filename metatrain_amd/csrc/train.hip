@@ -148,6 +148,10 @@ static void launch_k_wgrad(const WgradArgs& a, int nb, int nsplit, hipStream_t s
 }
 template <int XMODE>
 static void launch_k_wgrad_b(const WgradArgs& a, int nb, int nsplit, hipStream_t st) {
+    if (train_bf16()) {  // single-term mode: one plane per operand (20 KB)
+        k_wgrad_b<XMODE, true><<<nb * nsplit, NTHREADS, (size_t)2 * 128 * WB_LDW * sizeof(unsigned), st>>>(a, nb, nsplit);
+        return;
+    }
     const size_t lds = (size_t)6 * 128 * WB_LDW * sizeof(unsigned);  // 60 KB: two workgroups per CU
     k_wgrad_b<XMODE><<<nb * nsplit, NTHREADS, lds, st>>>(a, nb, nsplit);
 }

@@ -275,6 +275,31 @@ __device__ __forceinline__ void mfma3(f32x16 (&acc)[NT], f32x16 (&acl)[NT], cons
 #pragma unroll
     for (int t = 0; t < NT; t++) acl[t] = PET_MFMA_H(b.h[t], xl, acl[t]);
 }
+// single-term training mode (pet_config_set("train_bf16", 1)): the high planes only
+template <int NT>
+struct WBlk1 {
+    f16x8 h[NT];
+};
+template <int NT>
+__device__ __forceinline__ void ld_blk1(WBlk1<NT>& b, const W2& w, size_t i0, size_t tile_stride) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) b.h[t] = w.h[i0 + t * tile_stride];
+}
+template <int NT>
+__device__ __forceinline__ void mfma1(f32x16 (&acc)[NT], const WBlk1<NT>& b, const f16x8& xh) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = PET_MFMA_H(b.h[t], xh, acc[t]);
+}
+template <int KB>
+__device__ __forceinline__ void high_frag(const float4* x, f16x8 (&h)[KB]) {
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        const float v[8] = {x[2 * kb].x, x[2 * kb].y, x[2 * kb].z, x[2 * kb].w,
+                            x[2 * kb + 1].x, x[2 * kb + 1].y, x[2 * kb + 1].z, x[2 * kb + 1].w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) h[kb][j] = (_Float16)v[j];
+    }
+}
 template <int NT>
 __device__ __forceinline__ void fold_low(f32x16 (&acc)[NT], const f32x16 (&acl)[NT]) {
 #pragma unroll

@@ -265,6 +265,11 @@ __device__ __forceinline__ void wb_store4(unsigned* plane_h, unsigned* plane_m, 
         plane_h[w] = h; plane_m[w] = m; plane_l[w] = l;
     }
 }
+__device__ __forceinline__ void wb_store4_high(unsigned* plane_h, int c0, int pp, const float4& a, const float4& b) {
+    const float va[4] = {a.x, a.y, a.z, a.w}, vb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) plane_h[wb_slot(c0 + e, pp)] = bf16_bits(va[e]) | (bf16_bits(vb[e]) << 16);
+}
 // eight rows of one column: the words are read as what they were stored as (no type punning across the barrier)
 __device__ __forceinline__ bf16x8 wb_load8(const unsigned* p) {
     const uint4 w = *reinterpret_cast<const uint4*>(p);
@@ -274,12 +279,14 @@ __device__ __forceinline__ bf16x8 wb_load8(const unsigned* p) {
 
 // grid = n_blocks * splits workgroups (1-D, XCD-aware numbering when splits % 8 == 0). 128 x-columns per launch
 // (x_col0 selects them). XMODE as in k_wgrad; XMODE 1 needs the whole row in the launch (k_in == 128).
-template <int XMODE>
+// ONE (pet_config_set("train_bf16", 1)): the high bf16 pieces only -- one plane per operand, one MFMA per tile and 16 rows
+template <int XMODE, bool ONE = false>
 __global__ __launch_bounds__(NTHREADS, 2) void k_wgrad_b(WgradArgs a, int nb_total, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned wsm[];
     constexpr int KB = 128, KT = 4, PLANE = 128 * WB_LDW;  // words per plane
-    unsigned* Yp = wsm;              // [3][128 columns][20 words]
-    unsigned* Xp = wsm + 3 * PLANE;  // [3][128 columns][20 words]
+    constexpr int NP = ONE ? 1 : 3;
+    unsigned* Yp = wsm;               // [NP][128 columns][20 words]
+    unsigned* Xp = wsm + NP * PLANE;  // [NP][128 columns][20 words]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int nb, split;
     if ((nsplit & 7) == 0) {  // ids L, L + 8, ... share an XCD: the nb_total readers of one row range are neighbours there
@@ -368,8 +375,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_wgrad_b(WgradArgs a, int nb_tot
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int pp = rg + 8 * h;
-            wb_store4(Yp, Yp + PLANE, Yp + 2 * PLANE, 4 * c4, pp, ypre[2 * h], ypre[2 * h + 1]);
-            wb_store4(Xp, Xp + PLANE, Xp + 2 * PLANE, 4 * c4, pp, xv[2 * h], xv[2 * h + 1]);
+            if constexpr (ONE) {
+                wb_store4_high(Yp, 4 * c4, pp, ypre[2 * h], ypre[2 * h + 1]);
+                wb_store4_high(Xp, 4 * c4, pp, xv[2 * h], xv[2 * h + 1]);
+            } else {
+                wb_store4(Yp, Yp + PLANE, Yp + 2 * PLANE, 4 * c4, pp, ypre[2 * h], ypre[2 * h + 1]);
+                wb_store4(Xp, Xp + PLANE, Xp + 2 * PLANE, 4 * c4, pp, xv[2 * h], xv[2 * h + 1]);
+            }
         }
         if (row0 + WG_RB < r_end) fetch(row0 + WG_RB);
         __syncthreads();
@@ -379,14 +391,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_wgrad_b(WgradArgs a, int nb_tot
             const int pp0 = 8 * ks + 4 * (lane >> 5);
             const int wy = wb_slot(32 * wave + (lane & 31), pp0);
             const bf16x8 ah = wb_load8(Yp + wy);
-            const bf16x8 am = wb_load8(Yp + PLANE + wy);
-            const bf16x8 al = wb_load8(Yp + 2 * PLANE + wy);
+            if constexpr (ONE) {
+#pragma unroll
+                for (int t = 0; t < KT; t++)
+                    acc[t] = PET_MFMA_BF(ah, wb_load8(Xp + wb_slot(32 * t + (lane & 31), pp0)), acc[t]);
+                continue;
+            }
+            const bf16x8 am = wb_load8(Yp + (NP - 2) * PLANE + wy);
+            const bf16x8 al = wb_load8(Yp + (NP - 1) * PLANE + wy);
 #pragma unroll
             for (int t = 0; t < KT; t++) {
                 const int wx = wb_slot(32 * t + (lane & 31), pp0);
                 const bf16x8 bh = wb_load8(Xp + wx);
-                const bf16x8 bm = wb_load8(Xp + PLANE + wx);
-                const bf16x8 bl = wb_load8(Xp + 2 * PLANE + wx);
+                const bf16x8 bm = wb_load8(Xp + (NP - 2) * PLANE + wx);
+                const bf16x8 bl = wb_load8(Xp + (NP - 1) * PLANE + wx);
                 acc[t] = PET_MFMA_BF(al, bh, acc[t]);
                 acc[t] = PET_MFMA_BF(ah, bl, acc[t]);
                 acc[t] = PET_MFMA_BF(am, bm, acc[t]);

@@ -774,3 +774,67 @@ def test_parameter_gradients_with_more_than_64_atomic_types(golden_dir):
             if not err < (5 * TOL if r.size == 1 else TOL):
                 bad[k] = err
         assert not bad, f"{name}: parameter gradients off: {bad}"
+
+
+def test_train_bf16_mode_follows_the_loss_curve_of_the_default_mode(golden_dir):
+    """``pet_config_set("train_bf16", 1)`` (BASELINE configs[2]: "bf16 MFMA MLPs"): the GEMMs of the second-order pass and the
+    weight-gradient GEMMs keep ONE 16-bit MFMA term per product instead of three / six. Not a parity mode -- its gradients
+    carry the 1e-3 of the 16-bit operands -- so it is checked the way a trainer would: 20 Adam steps of the energy + force
+    loss from the same start in both modes on a four-box batch (lr 1e-4, no warm-up): the loss curves agree to 1 % while the loss
+    falls (12 steps) and stay within a factor 1.6 on the noisy floor after it, the first-step gradient agrees in direction
+    (cosine > 0.999) and norm (1 %), and the 20-step parameter updates point the same way (cosine > 0.95)."""
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.pet.trainer import TrainStep
+
+    dev = torch.device("cuda:0")
+    hypers = dict(opet.DEFAULT_HYPERS)
+    types = [1, 6, 7, 8]
+    params = opet.synthetic_params(hypers, types, {"energy": 1}, 0, torch.float32)
+    pos_l, z_l, cell_l, pr_l, sys_l, off = [], [], [], [], [], 0
+    for b in range(4):
+        pos, z, cell = opet.random_box(250, seed=40 + b)
+        pr, _ = rt.neighbor_list(pos.to(dev), cell, [True] * 3, hypers["cutoff"])
+        pr = pr.clone(); pr[:, :2] += off
+        pos_l.append(pos.to(dev)); z_l.append(z.to(dev)); cell_l.append(cell.to(dev)); pr_l.append(pr)
+        sys_l.append(torch.full((250,), b, dtype=torch.int32, device=dev)); off += 250
+    pos, z, cells, pr, sysidx = torch.cat(pos_l), torch.cat(z_l), torch.stack(cell_l), torch.cat(pr_l), torch.cat(sys_l)
+    n_atoms = torch.full((4,), 250.0, device=dev)
+    gen = torch.Generator().manual_seed(7)
+    targets = (torch.randn(4, generator=gen) * 0.2 * 250).to(dev)
+    target_grads = (0.1 * torch.randn(1000, 3, generator=gen)).to(dev)
+    steps, lr = 20, 1e-4
+
+    def run(mode):
+        rt.config_set("train_bf16", mode)
+        try:
+            model = rt.HipModel(hypers, types)
+            model.load({k: v.to(dev) for k, v in params.items()}, "energy")
+            graph = rt.HipGraph(model, pos, cells, pr[:, 0].contiguous(), pr[:, 1].contiguous(), pr[:, 2:5].contiguous(), z, sysidx)
+            fw = rt.HipForward(model, graph, train=True)
+            step = TrainStep(model, {"learning_rate": lr, "warmup_fraction": 0.0, "num_epochs": 10**9})
+            losses, g0 = [], None
+            for k in range(steps):
+                out = step(graph, fw, targets, n_atoms, target_grads)
+                losses.append(float(out["loss"]))
+                if k == 0:
+                    g0 = model.flat_grad().double().cpu().clone()
+            return np.array(losses), g0, {k: v.cpu().double() for k, v in model.state_dict().items() if v.is_floating_point()}
+        finally:
+            rt.config_set("train_bf16", 0)
+
+    l_ref, g_ref, p_ref = run(0)
+    l_one, g_one, p_one = run(1)
+    print("default:", np.round(l_ref, 5).tolist(), "\ntrain_bf16:", np.round(l_one, 5).tolist())
+    assert np.isfinite(l_one).all() and l_ref[-1] < 0.3 * l_ref[0], l_ref
+    # Adam's first steps on these synthetic weights overshoot (0.25 -> 1.5 -> ... -> 0.04); while the loss falls the two curves
+    # agree to a percent, on the noisy floor they wander apart like any two roundings of the same run do
+    np.testing.assert_allclose(l_one[:12], l_ref[:12], rtol=1e-2)
+    assert np.all(l_one[12:] < 0.3 * l_one[0]) and np.all(np.abs(np.log(l_one[12:] / l_ref[12:])) < np.log(1.6))
+    cos = float((g_ref * g_one).sum() / (g_ref.norm() * g_one.norm()))
+    assert cos > 0.999 and abs(float(g_one.norm() / g_ref.norm()) - 1.0) < 1e-2, (cos, float(g_one.norm() / g_ref.norm()))
+    assert not torch.equal(g_ref, g_one)  # the switch did select other kernels
+    d_ref = torch.cat([(p_ref[k] - params[k].double()).ravel() for k in p_ref])
+    d_one = torch.cat([(p_one[k] - params[k].double()).ravel() for k in p_ref])
+    upd = float((d_ref * d_one).sum() / (d_ref.norm() * d_one.norm()))
+    print("first-step gradient cosine", cos, "cosine of the 20-step parameter updates", upd)
+    assert upd > 0.95, upd
