@@ -126,6 +126,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 struct W2 {  // weight fragments, high and (scaled) low plane, [(tile * kb_total + kb) * 64 + lane]
     const f16x8 *h = nullptr, *l = nullptr;
 };
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+// x - h with h read as the fp16 (low / high) half of a register: ONE mixed-precision fma instead of v_cvt_f32_f16 + v_sub
+// (the difference is exact in fp32 either way, so the result is the same bit for bit)
+__device__ __forceinline__ float sub_half_lo(float x, h16x2 hp) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
+    return r;
+}
+__device__ __forceinline__ float sub_half_hi(float x, h16x2 hp) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
+    return r;
+}
 __device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
     h = (_Float16)x;
     l = (_Float16)((x - (float)h) * 2048.0f);
@@ -456,7 +469,6 @@ __device__ __forceinline__ float silu_g_(float x) {
 // ---------------------------------------------------------------------------------------------
 // Pieces of the software-pipelined row kernels (k_emlp_p2 / k_emlp_bwd_p2 in pet_trr.hip, k_comb_p2 in pet_comb.hip)
 // ---------------------------------------------------------------------------------------------
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
 // f16x3 split of two values into packed (high, pre-scaled low) pairs, computed where it stands in the instruction
 // stream (the pipelined kernels place it in a particular slot). The low piece is derived from the PINNED high pair:
@@ -466,8 +478,8 @@ __device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v
 __device__ __forceinline__ void split_pair_pinned(float x0, float x1, h16x2& hp, h16x2& lp) {
     hp[0] = (_Float16)x0; hp[1] = (_Float16)x1;
     asm volatile("" : "+v"(hp));
-    lp[0] = (_Float16)((x0 - (float)hp[0]) * 2048.0f);
-    lp[1] = (_Float16)((x1 - (float)hp[1]) * 2048.0f);
+    lp[0] = (_Float16)(sub_half_lo(x0, hp) * 2048.0f);
+    lp[1] = (_Float16)(sub_half_hi(x1, hp) * 2048.0f);
     asm volatile("" : "+v"(lp));
 }
 // LDS-DMA: 16 B per lane from global memory straight into LDS at lds_dst + 16 lane (no registers; counted by vmcnt,
