@@ -25,52 +25,68 @@ static GD dims_of(const Model& m) {
 // ---------------------------------------------------------------------------------------------
 // Y[r][o] (+)= b[o] + sum_i X[r * ldx + i] * W[o * so + i * si]
 // ---------------------------------------------------------------------------------------------
+// 64 x 64 output tile per workgroup, one 32 x 32 quadrant per wave on the fp32 matrix core (v_mfma_f32_32x32x2_f32: exact fp32
+// products, fp32 accumulation -- no operand splitting, so adjoint rows of any magnitude need no scaling); K in chunks of 32
+// through LDS ([64][33] floats per operand: a lane reads row (lane & 31), column 2 s + (lane >> 5) -- stride 33, no bank
+// conflicts). Any R, NO, KI (tails are zero-filled) and either orientation of the raw torch weight (so, si).
 template <bool ACC>
 __global__ __launch_bounds__(256) void k_gen_lin(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
                                                  int64_t so, int64_t si, const float* __restrict__ b,
                                                  float* __restrict__ Y, int64_t ldy, int64_t R, int NO, int KI) {
-    __shared__ float Xs[64][17], Ws[64][17];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    constexpr int KC = 32, LD = KC + 1;
+    __shared__ float Xs[64 * LD], Ws[64 * LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rb = wave & 1, cb = wave >> 1;
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int o0 = blockIdx.y * 64;
-    float acc[4][4];
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    const float* xa = Xs + (rb * 32 + (lane & 31)) * LD + (lane >> 5);
+    const float* wa = Ws + (cb * 32 + (lane & 31)) * LD + (lane >> 5);
+    // register prefetch: the global loads of chunk k0 + KC are in flight during the MFMAs of chunk k0
+    float xr[8], wr[8];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = 0.f;
-    for (int k0 = 0; k0 < KI; k0 += 16) {
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
-            const int rr = idx >> 4, kk = idx & 15;
-            const int64_t r = r0 + rr;
-            Xs[rr][kk] = (r < R && k0 + kk < KI) ? X[r * ldx + k0 + kk] : 0.f;
+        for (int q = 0; q < 8; q++) {
+            const int idx = threadIdx.x + 256 * q;
+            {   // X rows: k fastest (a row's 128 B are contiguous)
+                const int rr = idx >> 5, kk = idx & 31;
+                const int64_t r = r0 + rr;
+                xr[q] = (r < R && k0 + kk < KI) ? X[r * ldx + k0 + kk] : 0.f;
+            }
+            // W: forward orientation W[o][k] (si == 1): k fastest; transposed (so == 1): o fastest
+            const int rr = si == 1 ? idx >> 5 : idx & 63, kk = si == 1 ? idx & 31 : idx >> 6;
             const int o = o0 + rr;
-            Ws[rr][kk] = (o < NO && k0 + kk < KI) ? W[(int64_t)o * so + (int64_t)(k0 + kk) * si] : 0.f;
+            wr[q] = (o < NO && k0 + kk < KI) ? W[(int64_t)o * so + (int64_t)(k0 + kk) * si] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < KI; k0 += KC) {
+        __syncthreads();  // the previous chunk's MFMAs have read the tiles
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int idx = threadIdx.x + 256 * q;
+            Xs[(idx >> 5) * LD + (idx & 31)] = xr[q];
+            const int rr = si == 1 ? idx >> 5 : idx & 63, kk = si == 1 ? idx & 31 : idx >> 6;
+            Ws[rr * LD + kk] = wr[q];
         }
         __syncthreads();
+        if (k0 + KC < KI) fetch(k0 + KC);
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) {
-            float a[4], c[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) { a[i] = Xs[ty + 16 * i][kk]; c[i] = Ws[tx + 16 * i][kk]; }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = fmaf(a[i], c[j], acc[i][j]);
-        }
+        for (int s2 = 0; s2 < KC / 2; s2++)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * s2], wa[2 * s2], acc, 0, 0, 0);
     }
+    const int o = o0 + cb * 32 + (lane & 31);
+    if (o >= NO) return;
+    const float bo = b ? b[o] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int64_t r = r0 + ty + 16 * i;
+    for (int i = 0; i < 16; i++) {
+        const int64_t r = r0 + rb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
         if (r >= R) continue;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int o = o0 + tx + 16 * j;
-            if (o >= NO) continue;
-            const float v = acc[i][j] + (b ? b[o] : 0.f);
-            if (ACC) Y[r * ldy + o] += v;
-            else Y[r * ldy + o] = v;
-        }
+        const float v = acc[i] + bo;
+        if (ACC) Y[r * ldy + o] += v;
+        else Y[r * ldy + o] = v;
     }
 }
 

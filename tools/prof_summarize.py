@@ -3,6 +3,7 @@ import csv, glob, os, re, sys
 from collections import defaultdict
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     name = name.replace("void ", "").replace("pet::", "")
     return name[:48]
