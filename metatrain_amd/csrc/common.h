@@ -107,6 +107,8 @@ struct Graph {
     int* tsort_tmp = nullptr;  // [ceil(N / 256)][33] per-block counts / first positions of that sort
     int4* tile_desc = nullptr; // [2 N]: the 32-slot tiles first (n_tiles1), then the 64-slot ones (n_tiles2)
     int n_tiles1 = 0, n_tiles2 = 0;  // host copies
+    mutable const void* fwd_ws = nullptr;  // the workspace this graph's last forward wrote, and whether it ran the
+    mutable bool fwd_generic = false;      // size-generic path there (pet_fwd.hip note_workspace)
     bool tiles_planned = false;      // the graph build made tile_desc (large graphs, or the fused block forced)
     int bucket_start[6] = {0, 0, 0, 0, 0, 0};  // host copy
     // adaptive cutoff (structures.py:225-263): CSR over ALL input edges (the root finder and its
@@ -145,6 +147,21 @@ struct Graph {
     size_t sort_tmp_bytes = 0;
     void* scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
+};
+
+// A temporary from the stream's memory pool, returned on EVERY exit of the scope (PET_REQUIRE / PET_HIP_CHECK return early).
+struct PoolBuf {
+    void* p = nullptr;
+    hipStream_t st = nullptr;
+    PoolBuf() = default;
+    PoolBuf(const PoolBuf&) = delete;
+    PoolBuf& operator=(const PoolBuf&) = delete;
+    hipError_t alloc(size_t bytes, hipStream_t s) {
+        st = s;
+        return hipMallocAsync(&p, bytes, s);
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+    ~PoolBuf() { if (p) (void)hipFreeAsync(p, st); }
 };
 
 }  // namespace pet

@@ -56,7 +56,9 @@ int gen_predict(const Model& m, const Graph& g, const HeadW& H, const LastW& Lw,
     // (the caller's scratch is sized for the compiled instantiation: this path takes its own from the stream's pool)
     const int64_t need = 4 * (N + E + 2) * (int64_t)DH + (N + E + 2) * (int64_t)P;
     float* scratch = nullptr;
-    PET_HIP_CHECK(hipMallocAsync((void**)&scratch, (size_t)need * sizeof(float), st));
+    PoolBuf scratch_pool;
+    PET_HIP_CHECK(scratch_pool.alloc((size_t)need * sizeof(float), st));
+    scratch = scratch_pool.as<float>();
     float* a1n = scratch; float* s1n = a1n + N * DH; float* a2n = s1n + N * DH; float* s2n = a2n + N * DH;
     float* a1e = s2n + N * DH; float* s1e = a1e + E * DH; float* a2e = s1e + E * DH; float* s2e = a2e + E * DH;
     float* np = s2e + E * DH; float* ep = np + N * P;
@@ -71,7 +73,6 @@ int gen_predict(const Model& m, const Graph& g, const HeadW& H, const LastW& Lw,
     k_gen_atom_sum<<<g1(N * P), 256, 0, st>>>(np, ep, fc, g.rowptr, atomic, N, P);
     if (node_hidden) o.copy(s2n, node_hidden, N, DH);
     if (edge_hidden && E > 0) o.copy(s2e, edge_hidden, E, DH);
-    PET_HIP_CHECK(hipFreeAsync(scratch, st));
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }
@@ -86,7 +87,9 @@ int gen_predict_backward(const Model& m, const Graph& g, const HeadW& H, const L
     if (!fc) fc = g.fc;
     const int64_t M = N > E ? N : E;
     float* scratch = nullptr;
-    PET_HIP_CHECK(hipMallocAsync((void**)&scratch, (size_t)(4 * M * DH + 2 * M * P) * sizeof(float), st));
+    PoolBuf scratch_pool;
+    PET_HIP_CHECK(scratch_pool.alloc((size_t)(4 * M * DH + 2 * M * P) * sizeof(float), st));
+    scratch = scratch_pool.as<float>();
     float* a1 = scratch; float* s1 = a1 + M * DH; float* a2 = s1 + M * DH; float* s2 = a2 + M * DH;
     float* pr = s2 + M * DH; float* dpr = pr + M * P;
     // node branch (recomputed from the features: nothing is read from a forward workspace)
@@ -108,7 +111,6 @@ int gen_predict_backward(const Model& m, const Graph& g, const HeadW& H, const L
         k_gen_silu_bwd<<<g1(E * DH), 256, 0, st>>>(a1, s1, s1, E * DH);
         o.lin.bwd(s1, DH, H.eh0, g_edge, o.d.D, E);
     }
-    PET_HIP_CHECK(hipFreeAsync(scratch, st));
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }
@@ -127,8 +129,9 @@ int gen_aux_outputs(const Model& m, const Graph& g, const float* node_feat, cons
         PET_REQUIRE(m.has_fused_head, PET_ERR_ARGUMENT, "last-layer features need the fused target's heads");
         const int64_t M = N > E ? N : E;
         (void)scratch;  // sized for the compiled instantiation: this path takes its temporaries from the stream's pool
-        float* tmp = nullptr;
-        PET_HIP_CHECK(hipMallocAsync((void**)&tmp, (size_t)4 * M * d.DH * sizeof(float), st));
+        PoolBuf tmp_pool;
+        PET_HIP_CHECK(tmp_pool.alloc((size_t)4 * M * d.DH * sizeof(float), st));
+        float* tmp = tmp_pool.as<float>();
         float* b1 = tmp; float* b2 = b1 + M * d.DH; float* b3 = b2 + M * d.DH; float* b4 = b3 + M * d.DH;
         gen_head_fwd(o, m.nh0, m.nh2, node_feat, d.DN, N, b1, b2, b3, b4);
         o.axpby(1.f, b4, d.DH, 0.f, nullptr, 0, nullptr, last_layer, 2 * d.DH, false, N, d.DH);
@@ -137,7 +140,6 @@ int gen_aux_outputs(const Model& m, const Graph& g, const float* node_feat, cons
             k_gen_edge_sum<<<g1(N * d.DH), 256, 0, st>>>(b4, g.fc, g.rowptr, last_layer + d.DH, 2 * d.DH, N, d.DH);
         } else
             o.axpby(0.f, b4, d.DH, 0.f, nullptr, 0, nullptr, last_layer + d.DH, 2 * d.DH, false, N, d.DH);
-        PET_HIP_CHECK(hipFreeAsync(tmp, st));
     }
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
@@ -250,8 +252,9 @@ int gen_forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_byte
     if (atomic) {
         // the fused single-property target; with the residual featuriser the sum over the readout layers (backend.py:468-481)
         const int NR = m.num_readout_layers();
-        float* tmp = nullptr;
-        if (NR > 1) PET_HIP_CHECK(hipMallocAsync((void**)&tmp, (size_t)N * sizeof(float), st));
+        PoolBuf tmp_pool;
+        if (NR > 1) PET_HIP_CHECK(tmp_pool.alloc((size_t)N * sizeof(float), st));
+        float* tmp = tmp_pool.as<float>();
         for (int l = 0; l < NR; l++) {
             auto hi = m.heads.find("@|" + std::to_string(l));
             auto li = m.lasts.find("@|" + std::to_string(l) + "|@");
@@ -264,7 +267,6 @@ int gen_forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_byte
             if (rc) return rc;
             if (l > 0) o.add(tmp, atomic, N, 1);
         }
-        if (tmp) PET_HIP_CHECK(hipFreeAsync(tmp, st));
     }
     for (int l = 0; l < n_layers; l++) {
         const GGnn& Bl = res ? w.gnn[l] : last;
@@ -449,7 +451,9 @@ int gen_backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, con
     const int64_t Ea = E > 0 ? E : 1;
     float* buf = nullptr;   // per readout layer: d node features, d edge features; then d fc (heads, summed), scratch d fc, d geo, d fc (attention)
     const size_t per = (size_t)N * d.DN + (size_t)Ea * d.D;
-    PET_HIP_CHECK(hipMallocAsync((void**)&buf, (per * NR + (size_t)Ea * 7) * sizeof(float), st));
+    PoolBuf buf_pool;
+    PET_HIP_CHECK(buf_pool.alloc((per * NR + (size_t)Ea * 7) * sizeof(float), st));
+    buf = buf_pool.as<float>();
     float* gfh = buf + per * NR;
     float* gft = gfh + Ea;
     float* ggeo = gft + Ea;
@@ -471,7 +475,6 @@ int gen_backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, con
     if (!rc) rc = gen_backward_features(m, g, ws, ws_bytes, gnp.data(), gep.data(), NR, ggeo, gfc, st);
     // the two cutoff-factor gradients (heads, attention key biases) are added by the geometry kernel
     if (!rc) rc = backward_geometry_generic(m, g, w.dv, ggeo, E > 0 ? gfh : nullptr, E > 0 ? gfc : nullptr, gpos, gcell, st);
-    PET_HIP_CHECK(hipFreeAsync(buf, st));
     return rc;
 }
 
@@ -488,10 +491,11 @@ int gen_backward_predict(const Model& m, const Graph& g, void* ws, int64_t ws_by
     const GGnn& last = w.gnn.back();
     const int64_t Ea = g.n_edges > 0 ? g.n_edges : 1;
     float* tmp = nullptr;   // outputs the caller did not ask for
-    PET_HIP_CHECK(hipMallocAsync((void**)&tmp, (size_t)(g.n_nodes * d.DN + Ea * d.D + Ea) * sizeof(float), st));
+    PoolBuf tmp_pool;
+    PET_HIP_CHECK(tmp_pool.alloc((size_t)(g.n_nodes * d.DN + Ea * d.D + Ea) * sizeof(float), st));
+    tmp = tmp_pool.as<float>();
     int rc = gen_predict_backward(m, g, H, m.lasts.at("@|0|@"), last.Hout, last.Mout, g.fc, gA, g_node ? g_node : tmp,
                                   g_edge ? g_edge : tmp + g.n_nodes * d.DN, g_fc ? g_fc : tmp + g.n_nodes * d.DN + Ea * d.D, st);
-    PET_HIP_CHECK(hipFreeAsync(tmp, st));
     return rc;
 }
 

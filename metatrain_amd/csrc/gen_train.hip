@@ -851,9 +851,11 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
         lasts[l] = &li->second;
     }
     float *cond = nullptr, *dcond = nullptr;   // [n_systems][DN] per-system embedding and its nu-adjoint
+    PoolBuf cond_pool, extra_pool;             // returned to the stream's pool on every exit
     if (conditioned) {
         const size_t nc = (size_t)g.n_cond_systems * DN;
-        PET_HIP_CHECK(hipMallocAsync((void**)&cond, 2 * nc * sizeof(float), st));
+        PET_HIP_CHECK(cond_pool.alloc(2 * nc * sizeof(float), st));
+        cond = cond_pool.as<float>();
         dcond = cond + nc;
         k_gen_system_cond<<<(int)g.n_cond_systems, 128, 3 * DN * sizeof(float), st>>>(
             g.cond_charge, g.cond_spin, m.cond_qe, m.cond_se, m.cond_w0, m.cond_b0, m.cond_w2, m.cond_b2, cond, m.h.max_charge,
@@ -973,7 +975,8 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
         size_t fl = 0;
         if (NR > 1 || res) fl = (size_t)NR * 2 * ((size_t)N * DN + (size_t)E * D);   // (residual, one layer: dM is zeroed below)
         fl += 2 * (size_t)(N + E) + 4 * (size_t)(N + E);   // predictions (dual) and their adjoints
-        PET_HIP_CHECK(hipMallocAsync((void**)&extra, fl * sizeof(float), st));
+        PET_HIP_CHECK(extra_pool.alloc(fl * sizeof(float), st));
+        extra = extra_pool.as<float>();
     }
     float* ex = extra;
     D2 npred{ex, ex + N}; ex += 2 * N;
@@ -1161,9 +1164,7 @@ int gen_train2(const Model& m, const Graph& g, void* ws2, int64_t ws2_bytes, con
                                                                   m.cond_b0, m.cond_w2, dcond, (int)g.n_cond_systems,
                                                                   m.h.max_charge, m.h.max_spin_multiplicity, DN, gq, gm, gw0,
                                                                   gb0, gw2, gb2);
-        PET_HIP_CHECK(hipFreeAsync(cond, st));
     }
-    PET_HIP_CHECK(hipFreeAsync(extra, st));
     PET_HIP_CHECK(hipGetLastError());
     return t.err;
 }

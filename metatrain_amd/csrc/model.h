@@ -194,7 +194,7 @@ inline bool train_generic(const Model& m) { return m.generic() || !m.trainable()
 // structures of a dataset -- trains the node path alone; the tuned passes launch over E rows)
 inline bool train_generic_for(const Model& m, const Graph& g) { return train_generic(m) || use_generic(m, g) || g.n_edges == 0; }
 // the workspace `ws` was last filled by a size-generic forward (pet_fwd.hip keeps the record): its adjoints must follow
-bool generic_workspace(const void* ws);
+bool generic_workspace(const Graph& g, const void* ws);
 int backward_geometry_generic(const Model& m, const Graph& g, float* dv_scratch, const float* dgeo, const float* dfc_a,
                               const float* dfc_b, float* gpos, float* gcell, hipStream_t st);
 

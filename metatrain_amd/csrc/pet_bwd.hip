@@ -1381,7 +1381,7 @@ static int d2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
 
 int backward_predict_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA,
                          float* g_node, float* g_edge, float* g_fc, hipStream_t st) {
-    if (use_generic(m, g) || generic_workspace(ws)) return gen_backward_predict(m, g, ws, ws_bytes, gA, g_node, g_edge, g_fc, st);
+    if (use_generic(m, g) || generic_workspace(g, ws)) return gen_backward_predict(m, g, ws, ws_bytes, gA, g_node, g_edge, g_fc, st);
     PET_CARVE(w);
     if (g.n_nodes == 0) return PET_OK;
     int rc;
@@ -1394,7 +1394,7 @@ int backward_predict_abi(const Model& m, const Graph& g, void* ws, int64_t ws_by
 
 int backward_features_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_node,
                           const float* g_edge, float* g_geo, float* g_fc, hipStream_t st) {
-    if (use_generic(m, g) || generic_workspace(ws)) return gen_backward_features(m, g, ws, ws_bytes, &g_node, &g_edge, 1, g_geo, g_fc, st);
+    if (use_generic(m, g) || generic_workspace(g, ws)) return gen_backward_features(m, g, ws, ws_bytes, &g_node, &g_edge, 1, g_geo, g_fc, st);
     PET_CARVE(w);
     if (g.n_nodes == 0) return PET_OK;
     int rc;
@@ -1408,7 +1408,7 @@ int backward_features_abi(const Model& m, const Graph& g, void* ws, int64_t ws_b
 
 int backward_features_layers_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* const* g_node,
                                  const float* const* g_edge, int n_layers, float* g_geo, float* g_fc, hipStream_t st) {
-    if (use_generic(m, g) || generic_workspace(ws)) return gen_backward_features(m, g, ws, ws_bytes, g_node, g_edge, n_layers, g_geo, g_fc, st);
+    if (use_generic(m, g) || generic_workspace(g, ws)) return gen_backward_features(m, g, ws, ws_bytes, g_node, g_edge, n_layers, g_geo, g_fc, st);
     PET_CARVE(w);
     PET_REQUIRE(n_layers == m.num_readout_layers(), PET_ERR_ARGUMENT,
                 "expected one gradient pair per readout layer (" + std::to_string(m.num_readout_layers()) + ")");
@@ -1428,7 +1428,7 @@ int backward_features_layers_abi(const Model& m, const Graph& g, void* ws, int64
 
 int backward_geometry_abi(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* g_geo,
                           const float* g_fc, float* gpos, float* gcell, hipStream_t st) {
-    if (use_generic(m, g) || generic_workspace(ws)) return gen_backward_geometry(m, g, ws, ws_bytes, g_geo, g_fc, gpos, gcell, st);
+    if (use_generic(m, g) || generic_workspace(g, ws)) return gen_backward_geometry(m, g, ws, ws_bytes, g_geo, g_fc, gpos, gcell, st);
     PET_CARVE(w);
     if (g.n_nodes == 0) return PET_OK;
     return backward_geometry(m, g, w, g_geo, g_fc, nullptr, gpos, gcell, st);
@@ -1453,7 +1453,7 @@ int backward_geometry_generic(const Model& m, const Graph& g, float* dv_scratch,
 
 int backward(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, const float* gA, float* gpos,
              float* gcell, hipStream_t st) {
-    if (use_generic(m, g) || generic_workspace(ws)) return gen_backward(m, g, ws, ws_bytes, gA, gpos, gcell, st);
+    if (use_generic(m, g) || generic_workspace(g, ws)) return gen_backward(m, g, ws, ws_bytes, gA, gpos, gcell, st);
     Workspace w;
     carve_workspace(m, g.n_nodes, g.n_edges, ws, w);
     PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "workspace too small");
@@ -1474,12 +1474,14 @@ int backward_train(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, c
     // other sizes, PostLN, residual, and any graph with an atom of more than 127 neighbours: the energy term alone = the
     // size-generic second-order pass without a tangent
     if (train_generic_for(m, g)) {
-        PET_REQUIRE(generic_workspace(ws), PET_ERR_ARGUMENT, "pet_forward with save_for_backward = 2 has not run on this workspace");
-        void* ws2 = nullptr;
+        PET_REQUIRE(generic_workspace(g, ws), PET_ERR_ARGUMENT, "pet_forward with save_for_backward = 2 has not run on this workspace");
+        // (the energy-only step has no second-order workspace of its own in the ABI: the dual activations come from the
+        // stream's pool and go back to it on every exit)
         const int64_t n2 = gen_train_workspace_bytes(m, g.n_nodes, g.n_edges);
-        PET_HIP_CHECK(hipMallocAsync(&ws2, (size_t)n2, st));
+        PoolBuf ws2_pool;
+        PET_HIP_CHECK(ws2_pool.alloc((size_t)n2, st));
+        void* ws2 = ws2_pool.p;
         int rc = gen_train2(m, g, ws2, n2, nullptr, gA, nullptr, nullptr, nullptr, st);
-        PET_HIP_CHECK(hipFreeAsync(ws2, st));
         if (!rc && gpos) rc = gen_backward(m, g, ws, ws_bytes, gA, gpos, gcell, st);
         return rc;
     }

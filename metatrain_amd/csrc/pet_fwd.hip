@@ -768,18 +768,14 @@ static void launch_attn_fwd(const float* QKV, const Graph& g, float* AO, float s
 
 int attn_tiles(const Graph& g) { return (g.max_nbr + 1 + 15) / 16; }
 bool use_generic(const Model& m, const Graph& g) { return m.generic() || attn_tiles(g) > 8; }
-// workspaces whose last forward ran on the size-generic path (a training forward of a PostLN / residual model of the
-// compiled size does, while its inference forward runs on the tuned kernels): the adjoint calls ask
-static std::mutex g_gen_ws_mu;
-static std::set<const void*> g_gen_ws;
-bool generic_workspace(const void* ws) {
-    std::lock_guard<std::mutex> lk(g_gen_ws_mu);
-    return g_gen_ws.count(ws) != 0;
-}
-static void note_workspace(const void* ws, bool generic) {
-    std::lock_guard<std::mutex> lk(g_gen_ws_mu);
-    if (generic) g_gen_ws.insert(ws);
-    else g_gen_ws.erase(ws);
+// Which layout the last forward of THIS graph left in a workspace: a training forward of a PostLN / residual model of the
+// compiled size runs on the size-generic path while its inference forward runs on the tuned kernels, and the adjoint calls
+// must follow. Recorded on the graph handle (host side, the caller owns its lifetime): no process-global table, and an
+// adjoint call on a workspace this graph's forward has not written falls back to what (model, graph) say.
+bool generic_workspace(const Graph& g, const void* ws) { return g.fwd_ws == ws && g.fwd_generic; }
+static void note_workspace(const Graph& g, const void* ws, bool generic) {
+    g.fwd_ws = ws;
+    g.fwd_generic = generic;
 }
 
 static int g_node_planes = 1;  // k_node2 / k_node_bwd2: A tiles pre-split into fp16 planes (pet_config_set("node_planes", 0): k_node)
@@ -824,7 +820,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                    float* const* node_feats, float* const* edge_feats, int n_layers, hipStream_t st) {
     const bool gen = use_generic(m, g) || (save == 2 && train_generic_for(m, g));
     PET_REQUIRE(!(gen && g.x_fn), PET_ERR_UNSUPPORTED, "the per-layer exchange is built for the tuned path (default model size)");
-    note_workspace(ws, gen);
+    note_workspace(g, ws, gen);
     if (gen) return gen_forward_layers(m, g, ws, ws_bytes, save, atomic, node_feats, edge_feats, n_layers, st);
     Workspace w;
     carve_workspace(m, g.n_nodes, g.n_edges, ws, w, save == 2);
