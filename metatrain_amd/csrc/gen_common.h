@@ -262,136 +262,182 @@ __global__ void k_gen_system_cond(const int64_t* __restrict__ charge, const int6
 // attention (transformer.py:86-152, 565-589): tokens of atom i = [centre row E + i ; its CSR edge rows], key bias
 // log(max(fc, 1e-15)) on edge keys (0 for the centre), scale 1 / (sqrt(head_dim) temperature)
 // ---------------------------------------------------------------------------------------------
+// One wave per (atom, head). A lane is (token, feature slice): the head's features are cut into SL slices of DS <= 16, so a
+// lane holds DS values of every row it touches (registers stay small at any head dimension) and a pass serves TPW = 64 / SL
+// tokens (head dimension 64: four slices, 16 tokens per pass -- with ~20 tokens per atom most lanes work, where one lane per
+// token with the whole row in registers left two thirds of them idle and ran at one wave per SIMD). Dot products are the
+// slices' partial sums added across the SL lanes of a token by xor shuffles.
+template <int HDM>
+struct GAttnLanes {
+    static constexpr int DS = HDM < 16 ? HDM : 16, SL = HDM / DS, TPW = 64 / SL;
+};
+// DS values of a row slice: float4 pieces when the layout allows it (v4), guarded scalars otherwise; zeros past nvalid
+template <int DS>
+__device__ __forceinline__ void gen_ld_slice(float (&o)[DS], const float* __restrict__ p, int nvalid, bool v4) {
+    if (v4) {
+#pragma unroll
+        for (int g = 0; g < DS / 4; g++) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * g < nvalid) t = *reinterpret_cast<const float4*>(p + 4 * g);
+            o[4 * g] = t.x; o[4 * g + 1] = t.y; o[4 * g + 2] = t.z; o[4 * g + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < DS; j++) o[j] = j < nvalid ? p[j] : 0.f;
+    }
+}
+template <int SL, int TPW>
+__device__ __forceinline__ float gen_slice_sum(float v) {
+#pragma unroll
+    for (int o = TPW; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 template <int HDM>
 __global__ __launch_bounds__(64) void k_gen_attn_fwd(const float* __restrict__ QKV, const int* __restrict__ rowptr,
                                                      const float* __restrict__ fc, float* __restrict__ AO,
                                                      float* __restrict__ LSE, int64_t E, int D, int NH, int HD, float scale) {
+    using GL = GAttnLanes<HDM>;
+    constexpr int DS = GL::DS, SL = GL::SL, TPW = GL::TPW;
     const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int tok = lane % TPW, d0 = DS * (lane / TPW);
+    const int nv = HD - d0 < 0 ? 0 : (HD - d0 < DS ? HD - d0 : DS);
+    const bool v4 = DS % 4 == 0 && (HD & 3) == 0 && (D & 3) == 0;
     const int p0 = rowptr[i], T = rowptr[i + 1] - p0 + 1;
     const int64_t ld = 3 * (int64_t)D;
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        const int tq = t0 + lane;
+    for (int t0 = 0; t0 < T; t0 += TPW) {
+        const int tq = t0 + tok;
         const bool live = tq < T;
         const int64_t rq = !live ? E + i : (tq == 0 ? E + i : (int64_t)p0 + tq - 1);
-        float q[HDM], acc[HDM];
+        float q[DS], acc[DS];
+        gen_ld_slice<DS>(q, QKV + rq * ld + h * HD + d0, nv, v4);
 #pragma unroll
-        for (int d = 0; d < HDM; d++) {
-            q[d] = d < HD ? QKV[rq * ld + h * HD + d] * scale : 0.f;
-            acc[d] = 0.f;
-        }
+        for (int j = 0; j < DS; j++) { q[j] *= scale; acc[j] = 0.f; }
         float mx = -INFINITY, l = 0.f;
         for (int tk = 0; tk < T; tk++) {
             const int64_t rk = tk == 0 ? E + i : (int64_t)p0 + tk - 1;
-            const float* kp = QKV + rk * ld + D + h * HD;
-            const float* vp = QKV + rk * ld + 2 * D + h * HD;
-            float s = tk == 0 ? 0.f : logf(fmaxf(fc[p0 + tk - 1], 1e-15f));
+            float kk[DS], vv[DS];
+            gen_ld_slice<DS>(kk, QKV + rk * ld + D + h * HD + d0, nv, v4);
+            gen_ld_slice<DS>(vv, QKV + rk * ld + 2 * D + h * HD + d0, nv, v4);
+            float s = 0.f;
 #pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) s = fmaf(q[d], kp[d], s);
+            for (int j = 0; j < DS; j++) s = fmaf(q[j], kk[j], s);
+            s = gen_slice_sum<SL, TPW>(s) + (tk == 0 ? 0.f : logf(fmaxf(fc[p0 + tk - 1], 1e-15f)));
             const float mn = fmaxf(mx, s), c = expf(mx - mn), p = expf(s - mn);
             l = l * c + p;
 #pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) acc[d] = acc[d] * c + p * vp[d];
+            for (int j = 0; j < DS; j++) acc[j] = acc[j] * c + p * vv[j];
             mx = mn;
         }
         if (live) {
             const float il = 1.0f / l;
 #pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) AO[rq * D + h * HD + d] = acc[d] * il;
-            LSE[rq * NH + h] = mx + logf(l);
+            for (int j = 0; j < DS; j++)
+                if (j < nv) AO[rq * D + h * HD + d0 + j] = acc[j] * il;
+            if (d0 == 0) LSE[rq * NH + h] = mx + logf(l);
         }
     }
 }
 
-// pass A, lanes = queries: delta = <dO, O>, dQ
+// pass A, lanes = (query, slice): delta = <dO, O>, dQ
 template <int HDM>
 __global__ __launch_bounds__(64) void k_gen_attn_bwd_q(const float* __restrict__ QKV, const float* __restrict__ AO,
                                                        const float* __restrict__ dAO, const float* __restrict__ LSE,
                                                        const int* __restrict__ rowptr, const float* __restrict__ fc,
                                                        float* __restrict__ dQKV, float* __restrict__ DELTA, int64_t E,
                                                        int D, int NH, int HD, float scale) {
+    using GL = GAttnLanes<HDM>;
+    constexpr int DS = GL::DS, SL = GL::SL, TPW = GL::TPW;
     const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int tok = lane % TPW, d0 = DS * (lane / TPW);
+    const int nv = HD - d0 < 0 ? 0 : (HD - d0 < DS ? HD - d0 : DS);
+    const bool v4 = DS % 4 == 0 && (HD & 3) == 0 && (D & 3) == 0;
     const int p0 = rowptr[i], T = rowptr[i + 1] - p0 + 1;
     const int64_t ld = 3 * (int64_t)D;
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        const int tq = t0 + lane;
-        if (tq >= T) continue;
-        const int64_t rq = tq == 0 ? E + i : (int64_t)p0 + tq - 1;
-        float q[HDM], dO[HDM], dq[HDM];
+    for (int t0 = 0; t0 < T; t0 += TPW) {
+        const int tq = t0 + tok;
+        const bool live = tq < T;
+        const int64_t rq = !live ? E + i : (tq == 0 ? E + i : (int64_t)p0 + tq - 1);
+        float q[DS], dO[DS], dq[DS], ao[DS];
+        gen_ld_slice<DS>(q, QKV + rq * ld + h * HD + d0, nv, v4);
+        gen_ld_slice<DS>(dO, dAO + rq * D + h * HD + d0, nv, v4);
+        gen_ld_slice<DS>(ao, AO + rq * D + h * HD + d0, nv, v4);
         float delta = 0.f;
 #pragma unroll
-        for (int d = 0; d < HDM; d++) {
-            q[d] = d < HD ? QKV[rq * ld + h * HD + d] * scale : 0.f;
-            dO[d] = d < HD ? dAO[rq * D + h * HD + d] : 0.f;
-            dq[d] = 0.f;
-            if (d < HD) delta = fmaf(dO[d], AO[rq * D + h * HD + d], delta);
-        }
+        for (int j = 0; j < DS; j++) { q[j] *= scale; dq[j] = 0.f; delta = fmaf(dO[j], ao[j], delta); }
+        delta = gen_slice_sum<SL, TPW>(delta);
         const float lse = LSE[rq * NH + h];
         for (int tk = 0; tk < T; tk++) {
             const int64_t rk = tk == 0 ? E + i : (int64_t)p0 + tk - 1;
-            const float* kp = QKV + rk * ld + D + h * HD;
-            const float* vp = QKV + rk * ld + 2 * D + h * HD;
-            float s = tk == 0 ? 0.f : logf(fmaxf(fc[p0 + tk - 1], 1e-15f));
-            float dp = 0.f;
+            float kk[DS], vv[DS];
+            gen_ld_slice<DS>(kk, QKV + rk * ld + D + h * HD + d0, nv, v4);
+            gen_ld_slice<DS>(vv, QKV + rk * ld + 2 * D + h * HD + d0, nv, v4);
+            float s = 0.f, dp = 0.f;
 #pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) { s = fmaf(q[d], kp[d], s); dp = fmaf(dO[d], vp[d], dp); }
+            for (int j = 0; j < DS; j++) { s = fmaf(q[j], kk[j], s); dp = fmaf(dO[j], vv[j], dp); }
+            s = gen_slice_sum<SL, TPW>(s) + (tk == 0 ? 0.f : logf(fmaxf(fc[p0 + tk - 1], 1e-15f)));
+            dp = gen_slice_sum<SL, TPW>(dp);
             const float ds = expf(s - lse) * (dp - delta);
 #pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) dq[d] = fmaf(ds, kp[d], dq[d]);
+            for (int j = 0; j < DS; j++) dq[j] = fmaf(ds, kk[j], dq[j]);
         }
+        if (live) {
 #pragma unroll
-        for (int d = 0; d < HDM; d++)
-            if (d < HD) dQKV[rq * ld + h * HD + d] = dq[d] * scale;
-        DELTA[rq * NH + h] = delta;
+            for (int j = 0; j < DS; j++)
+                if (j < nv) dQKV[rq * ld + h * HD + d0 + j] = dq[j] * scale;
+            if (d0 == 0) DELTA[rq * NH + h] = delta;
+        }
     }
 }
 
-// pass B, lanes = keys: dK, dV and the key-bias gradient (edge keys; head-major [NH][E])
+// pass B, lanes = (key, slice): dK, dV and the key-bias gradient (edge keys; head-major [NH][E])
 template <int HDM>
 __global__ __launch_bounds__(64) void k_gen_attn_bwd_k(const float* __restrict__ QKV, const float* __restrict__ dAO,
                                                        const float* __restrict__ LSE, const float* __restrict__ DELTA,
                                                        const int* __restrict__ rowptr, const float* __restrict__ fc,
                                                        float* __restrict__ dQKV, float* __restrict__ dbias_h, int64_t E,
                                                        int D, int NH, int HD, float scale) {
+    using GL = GAttnLanes<HDM>;
+    constexpr int DS = GL::DS, SL = GL::SL, TPW = GL::TPW;
     const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int tok = lane % TPW, d0 = DS * (lane / TPW);
+    const int nv = HD - d0 < 0 ? 0 : (HD - d0 < DS ? HD - d0 : DS);
+    const bool v4 = DS % 4 == 0 && (HD & 3) == 0 && (D & 3) == 0;
     const int p0 = rowptr[i], T = rowptr[i + 1] - p0 + 1;
     const int64_t ld = 3 * (int64_t)D;
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        const int tk = t0 + lane;
-        if (tk >= T) continue;
-        const int64_t rk = tk == 0 ? E + i : (int64_t)p0 + tk - 1;
-        float k[HDM], v[HDM], dk[HDM], dv[HDM];
+    for (int t0 = 0; t0 < T; t0 += TPW) {
+        const int tk = t0 + tok;
+        const bool live = tk < T;
+        const int64_t rk = !live ? E + i : (tk == 0 ? E + i : (int64_t)p0 + tk - 1);
+        float k[DS], v[DS], dk[DS], dv[DS];
+        gen_ld_slice<DS>(k, QKV + rk * ld + D + h * HD + d0, nv, v4);
+        gen_ld_slice<DS>(v, QKV + rk * ld + 2 * D + h * HD + d0, nv, v4);
 #pragma unroll
-        for (int d = 0; d < HDM; d++) {
-            k[d] = d < HD ? QKV[rk * ld + D + h * HD + d] : 0.f;
-            v[d] = d < HD ? QKV[rk * ld + 2 * D + h * HD + d] : 0.f;
-            dk[d] = 0.f; dv[d] = 0.f;
-        }
-        const float bias = tk == 0 ? 0.f : logf(fmaxf(fc[p0 + tk - 1], 1e-15f));
+        for (int j = 0; j < DS; j++) { dk[j] = 0.f; dv[j] = 0.f; }
+        const float bias = (!live || tk == 0) ? 0.f : logf(fmaxf(fc[p0 + tk - 1], 1e-15f));
         float db = 0.f;
         for (int tq = 0; tq < T; tq++) {
             const int64_t rq = tq == 0 ? E + i : (int64_t)p0 + tq - 1;
-            const float* qp = QKV + rq * ld + h * HD;
-            const float* dop = dAO + rq * D + h * HD;
+            float qq[DS], dO[DS];
+            gen_ld_slice<DS>(qq, QKV + rq * ld + h * HD + d0, nv, v4);
+            gen_ld_slice<DS>(dO, dAO + rq * D + h * HD + d0, nv, v4);
             float s = 0.f, dp = 0.f;
 #pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) { s = fmaf(qp[d], k[d], s); dp = fmaf(dop[d], v[d], dp); }
+            for (int j = 0; j < DS; j++) { s = fmaf(qq[j], k[j], s); dp = fmaf(dO[j], v[j], dp); }
+            s = gen_slice_sum<SL, TPW>(s);
+            dp = gen_slice_sum<SL, TPW>(dp);
             const float p = expf(s * scale + bias - LSE[rq * NH + h]);
             const float ds = p * (dp - DELTA[rq * NH + h]);
             db += ds;
 #pragma unroll
-            for (int d = 0; d < HDM; d++)
-                if (d < HD) { dv[d] = fmaf(p, dop[d], dv[d]); dk[d] = fmaf(ds * scale, qp[d], dk[d]); }
+            for (int j = 0; j < DS; j++) { dv[j] = fmaf(p, dO[j], dv[j]); dk[j] = fmaf(ds * scale, qq[j], dk[j]); }
         }
+        if (live) {
 #pragma unroll
-        for (int d = 0; d < HDM; d++)
-            if (d < HD) { dQKV[rk * ld + D + h * HD + d] = dk[d]; dQKV[rk * ld + 2 * D + h * HD + d] = dv[d]; }
-        if (tk > 0) dbias_h[(int64_t)h * E + p0 + tk - 1] = db;
+            for (int j = 0; j < DS; j++)
+                if (j < nv) { dQKV[rk * ld + D + h * HD + d0 + j] = dk[j]; dQKV[rk * ld + 2 * D + h * HD + d0 + j] = dv[j]; }
+            if (tk > 0 && d0 == 0) dbias_h[(int64_t)h * E + p0 + tk - 1] = db;
+        }
     }
 }
 // dfc[p] += (sum_h dbias_h[h][p]) / fc[p]   (d log(max(fc, 1e-15)) / dfc; 0 below the clamp)
