@@ -211,6 +211,8 @@ def main():
                     help="strong-scaling mode: this many boxes per step in the WHOLE job, split over the ranks and "
                          "walked in chunks of --boxes (0 = weak scaling, --boxes per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs that are not `value` (box1000, host_resident_inputs): what the rocprofv3 passes run")
     ap.add_argument("--profile-all", action="store_true", help="print a per-stage table to stderr")
     ap.add_argument("--normalization", default="RMSNorm", choices=["RMSNorm", "LayerNorm"],
                     help="side runs only: the legacy-checkpoint norm; the headline metric is the default (RMSNorm)")
@@ -436,7 +438,7 @@ def main():
             "survey_8d_algorithmic_bytes": step_alg, "design_bytes_counted_by_stages": design or None,
             "pmc_bytes": pmc_step, "ratio_to_survey_8d": (pmc_step or design or 0.0) / step_alg or None,
             "hbm_frac_whole_step": (pmc_step or design or 0.0) / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9) or None}
-        if world == 1 and not strong:
+        if world == 1 and not strong and not args.no_extras:
             # not `value`: the same step started from HOST-resident systems (what an MD driver or a DataLoader hands
             # over) -- H2D of positions / species / cells, device neighbour lists + collate (metatrain_amd.data), graph
             # build, forward, dE/dR, D2H of per-atom energies and gradients. DESIGN.md section 5 quotes it.
@@ -468,7 +470,7 @@ def main():
                 "value": n_atoms / dt, "unit": "atom-steps/s", "ms_per_step": dt * 1e3,
                 "includes": "H2D positions/species/cells (pinned), device neighbour lists + collate, graph build, "
                             "forward, dE/dR, D2H per-atom energies + gradients"}
-        if world == 1 and not strong:
+        if world == 1 and not strong and not args.no_extras:
             out["box1000"] = gpu_box1000(model, hypers, dev)
         if not args.no_cpu_baseline and world == 1:  # the reported CPU leg runs at N = 1 only
             out["cpu_baseline"] = cpu_baseline(hypers, params)

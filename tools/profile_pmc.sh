@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 RAW=/tmp/prof_raw
 OUT=$PWD/gpurun_out
 rm -rf $RAW; mkdir -p $RAW $OUT
-CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS"
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras $BENCH_ARGS"
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_WAVES -d $RAW/pmc1 -o pmc1 -- $CMD > $RAW/pmc1.log 2>&1
 python tools/prof_summarize.py $RAW $OUT/prof_pmc.txt > /dev/null
 python - <<'PY'

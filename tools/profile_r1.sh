@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 RAW=/tmp/prof_raw
 OUT=$PWD/gpurun_out
 rm -rf $RAW; mkdir -p $RAW $OUT
-CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o trace -- $CMD > $RAW/trace.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_WAVES -d $RAW/pmc1 -o pmc1 -- $CMD > $RAW/pmc1.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $RAW/pmc2 -o pmc2 -- $CMD > $RAW/pmc2.log 2>&1
