@@ -254,6 +254,7 @@ int tile_mask();
 void set_trr_compress(int v);
 void set_node_planes(int v);  // pet_fwd.hip / pet_bwd.hip: node-row kernels on pre-split fp16 planes (default 1)
 bool node_planes();
+void set_center_fused(int v);  // pet_fwd.hip: 1 = k_node2 also writes the next layer's centre tokens (default)
 int node_rows(int64_t N);   // rows per workgroup of the node-row kernels (32: two workgroups per CU; 64)
 struct Graph;
 bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* Min, float* a0_out, float* Xout, int64_t E,

@@ -427,7 +427,8 @@ __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H,
                                                      const float* __restrict__ bin, WX wout,
                                                      const float* __restrict__ bout,
                                                      float* __restrict__ H1, float* __restrict__ VGn,
-                                                     float* __restrict__ Hn, int64_t N) {
+                                                     float* __restrict__ Hn, int64_t N, WX wcn,
+                                                     const float* __restrict__ bcn, float* __restrict__ Xcn) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 32 * RB, NCH = 4 / RB;      // rows per workgroup, column groups
     constexpr int WC = 256 / NCH, HC = 128 / NCH;    // output columns / hidden columns (per 128-chunk) of one wave
@@ -500,13 +501,22 @@ __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H,
         __syncthreads();
         gemm_acc_x<128, NTO>(U + w.rb * 32 * LD128, LD128, wout, DNF / 8, 16 * hc, NTO * w.ch, out, w.lane);
     }
+    // Xcn: the NEXT attention layer's centre tokens = center_contraction(Hn) (transformer.py:211-214) from the Hn tile while
+    // it is on chip (k_center's arithmetic: power-of-two row scales, the same GEMM) -- one launch and one stream hand-over
+    // less per layer on the critical path of a small box
+    float* Hn_s = smem + ROWS * LD256;  // [ROWS][260]: over the planes, which nobody reads after the last hidden chunk
+    if (Xcn) __syncthreads();
     auto add_h1 = [&](int col) {  // Hn = h1 + MLP
         return [&, col](int r, int cc, float4 v) {
             const int64_t row = wrow0 + r;
-            if (row >= N) return;
-            const int64_t o = row * DN + col + cc;
-            const float4 h1 = *reinterpret_cast<const float4*>(H1 + o);
-            *reinterpret_cast<float4*>(Hn + o) = make_float4(h1.x + v.x, h1.y + v.y, h1.z + v.z, h1.w + v.w);
+            float4 hn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < N) {
+                const int64_t o = row * DN + col + cc;
+                const float4 h1 = *reinterpret_cast<const float4*>(H1 + o);
+                hn = make_float4(h1.x + v.x, h1.y + v.y, h1.z + v.z, h1.w + v.w);
+                *reinterpret_cast<float4*>(Hn + o) = hn;
+            }
+            if (Xcn) *reinterpret_cast<float4*>(Hn_s + (w.rb * 32 + r) * LD256 + col + cc) = hn;
         };
     };
     if constexpr (RB == 2) {
@@ -518,6 +528,16 @@ __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H,
     } else {
 #pragma unroll
         for (int t = 0; t < NTO; t++) wave_rows32(out[t], my_stage, w.lane, add_h1(WC * w.ch + 32 * t));
+    }
+    if (Xcn) {
+        constexpr int NTC = RB;  // 128 centre-token columns over the NCH column groups
+        __syncthreads();
+        tile_row_scales<256, ROWS>(Hn_s, LD256, rs);
+        __syncthreads();
+        f32x16 cacc[NTC];
+        acc_fill_bias<NTC>(cacc, bcn, 32 * NTC * w.ch, w.lane);
+        gemm_acc_x<256, NTC>(Hn_s + w.rb * 32 * LD256, LD256, wcn, 32, 0, NTC * w.ch, cacc, w.lane, rs + 64 * w.rb);
+        store_acc<NTC>(cacc, Xcn, row0, N, D, w.rb, 32 * NTC * w.ch, w.lane);
     }
 }
 
@@ -778,6 +798,8 @@ static void note_workspace(const Graph& g, const void* ws, bool generic) {
     g.fwd_generic = generic;
 }
 
+static int g_center_fused = 1;  // pet_config_set("center_fused", 0): the next layer's centre tokens by their own k_center launch
+void set_center_fused(int v) { g_center_fused = v ? 1 : 0; }
 static int g_node_planes = 1;  // k_node2 / k_node_bwd2: A tiles pre-split into fp16 planes (pet_config_set("node_planes", 0): k_node)
 void set_node_planes(int v) { g_node_planes = v; }
 bool node_planes() { return g_node_planes != 0; }
@@ -942,20 +964,35 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
             }
             // node chain (side stream): node update of this layer, then the centre token of the next
             ss.fork(st);
+            bool center_done = false;
             {
                 ProfScope ps("node", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
+                WX wcn;
+                const float* bcn = nullptr;
+                float* xcn = nullptr;
                 const WX wci = wx_fwd(A.cmlp_in, 8), wce_ = wx_fwd(A.ce, 4), wco = wx_fwd(A.cmlp_out, 16);
                 if (node_planes() && wci.h && wce_.h && wco.h) {
                     const int nr = node_rows(N);
                     const size_t lds_n2 = (size_t)nr * LD256 * 4 + (size_t)2 * nr * plane_ld(256) * 2 + nr * 8;
+                    // the next layer's centre tokens in the same launch when they are center_contraction(Hn) as it leaves this
+                    // kernel: not behind the conditioning add, not into a residual GNN layer (its own embedding), f16x3 weights
+                    const bool has_next = a + 1 < AL || gi + 1 < L;
+                    if (has_next && g_center_fused && nr == 32 && !(a + 1 == AL && (conditioned || res))) {  // (large graphs: k_center is quicker)
+                        const AttnLayerW& An = a + 1 < AL ? G.attn[a + 1] : m.gnn[gi + 1].attn[0];
+                        AttnBufs& Abn = a + 1 < AL ? B.attn[a + 1] : w.gnn[gi + 1].attn[0];
+                        wcn = wx_fwd(An.cc, 2);
+                        if (wcn.h && Abn.H == Ab.Hn) { bcn = An.cc.b; xcn = Abn.X + E * D; center_done = true; }
+                    }
                     if (nr == 32) {
                         allow_big_lds(k_node2<1>, lds_n2);
                         k_node2<1><<<cdiv(N, 32), NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci,
-                                                                         A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
+                                                                         A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N,
+                                                                         wcn, bcn, xcn);
                     } else {
                         allow_big_lds(k_node2<2>, lds_n2);
                         k_node2<2><<<gN, NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci,
-                                                                 A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
+                                                                 A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N, wcn, bcn,
+                                                                 xcn);
                     }
                 } else
                 k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, s2>>>(
@@ -964,7 +1001,8 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
             }
             if (a + 1 == AL && conditioned)  // backend.py:543-545: the node features LEAVING the GNN layer
                 k_add_cond<<<cdiv(N * (DN / 4), 256), 256, 0, s2>>>(Ab.Hn, w.cond, g.sys, g.cond_sys, (int)N);
-            if (a + 1 < AL) launch_center(gi, a + 1);
+            if (center_done) {
+            } else if (a + 1 < AL) launch_center(gi, a + 1);
             else if (gi + 1 < L) launch_center(gi + 1, 0);
             side_busy = true;
             if (E > 0 && !post) {
