@@ -3,17 +3,19 @@
 // d_pet = 1, pet/tests/test_basic.py:22-32) while the tuned kernels of pet_fwd / pet_trr / pet_attn / pet_comb are ONE
 // compiled instantiation (128 / 256 / 256 / 128 / 8). A model of any other size runs here, behind the same C ABI:
 //
-//   * every Linear is one fp32 FMA GEMM kernel over the RAW torch weights [n_out, k_in] (k_gen_lin: 64 x 64 output tiles,
-//     K chunks of 16 through LDS, run-time bounds everywhere), the adjoint dX = dY W is the same kernel with swapped strides;
+//   * every Linear is one GEMM kernel over the RAW torch weights [n_out, k_in] on the fp32 matrix core (k_gen_lin:
+//     v_mfma_f32_32x32x2_f32, 64 x 64 output tiles, K chunks of 32 through LDS, run-time bounds everywhere), the adjoint
+//     dX = dY W is the same kernel with swapped strides;
 //   * norms / SwiGLU / SiLU are row kernels with a run-time width (one wave per row);
-//   * attention is one wave per (atom, head): lanes own queries (forward, dQ) or keys (dK, dV, key-bias gradient) and walk
-//     the other index with an online soft-max, so any head dimension up to 128 and ANY number of neighbours is served
-//     (no 16-token tiles) -- no cross-lane reduction, fixed summation order, bit-reproducible;
+//   * attention is one wave per (atom, head): a lane is (query | key, 16-feature slice) -- queries for the forward and dQ, keys
+//     for dK, dV and the key-bias gradient -- and walks the other index with an online soft-max, so any head dimension up
+//     to 128 and ANY number of neighbours is served (no 16-token tiles); dot products are xor-shuffle sums over the slices:
+//     fixed summation order, bit-reproducible;
 //   * d_node == d_pet follows transformer.py:189-201: no centre contraction / expansion / centre MLP, the node features
 //     leaving a layer ARE the centre token;
 //   * all architecture switches of the tuned path: RMSNorm / LayerNorm, PreLN / PostLN, feedforward / residual featuriser,
 //     SwiGLU / SiLU (tied halves), system conditioning, bump / cosine / adaptive cutoffs (graph side, shared).
-// Correctness-first (the matrix cores are not used): a few percent of the tuned path's rate, documented in DESIGN.md.
+// Correctness-first: fp32 products throughout (no split operands, no tuned tiles); rates in DESIGN.md section 1.
 // Training on this path: gen_train.hip.
 #include <string>
 #include <vector>
