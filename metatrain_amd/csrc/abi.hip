@@ -35,7 +35,14 @@ const SideStream& side_stream() {
         init = true;
         const char* e = getenv("PET_HIP_SIDE");
         if (!(e && e[0] == '0')) {
-            if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
+            // The node chain runs BELOW the caller's stream: its result is needed one edge-MLP later, and at equal priority
+            // its 133 KB workgroups take whole CUs from the edge kernels they overlap with (measured: 51.0 -> 49.7 ms per
+            // step). PET_HIP_SIDE_PRIO = same | high overrides.
+            const char* pr = getenv("PET_HIP_SIDE_PRIO");
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            const int prio = pr && pr[0] == 's' ? 0 : (pr && pr[0] == 'h' ? greatest : least);
+            if (hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, prio) == hipSuccess &&
                 hipEventCreateWithFlags(&ss.to_side, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&ss.to_main, hipEventDisableTiming) == hipSuccess)
                 ss.enabled = true;

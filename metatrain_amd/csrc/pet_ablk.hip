@@ -1063,7 +1063,11 @@ static TailStream& tail_stream() {
     static bool init = false;
     if (!init) {
         init = true;
-        t.ok = hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) == hipSuccess &&
+        const char* pr = getenv("PET_HIP_TAIL_PRIO");  // low | high | (default) the caller's level
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const int prio = pr && pr[0] == 'l' ? least : (pr && pr[0] == 'h' ? greatest : 0);
+        t.ok = hipStreamCreateWithPriority(&t.s, hipStreamNonBlocking, prio) == hipSuccess &&
                hipEventCreateWithFlags(&t.fork_ev, hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&t.join_ev, hipEventDisableTiming) == hipSuccess;
     }
