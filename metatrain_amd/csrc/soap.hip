@@ -586,6 +586,61 @@ __global__ __launch_bounds__(256) void k_soap_ps_w(SoapDims d, const float* __re
     }
 }
 
+// The same on the fp32 matrix core (ncmax <= 32): p_l = C_l^T C_l is a [nc x (2l+1)] x [(2l+1) x nc] product and both MFMA
+// operands are the SAME register -- lane (a = lane & 31, m = 2 s + (lane >> 5)) holds c[l][m][a] as A[a][m] and as B[m][a] --
+// so an l block costs ceil((2l+1) / 2) v_mfma_f32_32x32x2_f32 and as many ds_read_b32 (exact fp32 products, fp32 sums, as
+// the scalar loop). One wave per atom; the 32 x 32 tile leaves as rows of nc consecutive floats; LayerNorm statistics in fp64.
+__global__ __launch_bounds__(256) void k_soap_ps_m(SoapDims d, const float* __restrict__ Cf, const int* __restrict__ sp,
+                                                   const float* __restrict__ enc, float* __restrict__ feats,
+                                                   float* __restrict__ tail, int N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= N) return;
+    float* cs = smem + (size_t)wave * d.NCOEF;
+    for (int k = lane; k < d.NCOEF; k += 64) cs[k] = Cf[(size_t)i * d.NCOEF + k];
+    __builtin_amdgcn_wave_barrier();
+    const float* e = enc ? enc + (size_t)sp[i] * d.S : nullptr;
+    float* out = feats + (size_t)i * d.S;
+    const int a = lane & 31, mh = lane >> 5;
+    double s1 = 0.0, s2 = 0.0;
+    for (int l = 0; l <= d.L; l++) {
+        const int nc = d.n_per_l[l] * d.C, M = 2 * l + 1;
+        const float* c = cs + d.coef_off[l];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        for (int m0 = 0; m0 < M; m0 += 2) {
+            const int m = m0 + mh;
+            const float v = (m < M && a < nc) ? c[m * nc + a] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, v, acc, 0, 0, 0);
+        }
+        if (a < nc) {  // this lane: column b = a of rows p1(r)
+            const int f0 = d.feat_off[l];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int p1 = (r & 3) + 8 * (r >> 2) + 4 * mh;
+                if (p1 < nc) {
+                    const int idx = f0 + p1 * nc + a;
+                    float v = acc[r];
+                    if (e) v *= e[idx];
+                    out[idx] = v;
+                    s1 += (double)v;
+                    s2 += (double)v * (double)v;
+                }
+            }
+        }
+    }
+    if (!d.layernorm) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) {
+        const double mean = s1 / d.S, var = s2 / d.S - mean * mean;
+        tail[(size_t)i * (2 + 2 * d.H)] = (float)mean;
+        tail[(size_t)i * (2 + 2 * d.H) + 1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + 1e-5));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_soap_ps_bwd_s(SoapDims d, const float* __restrict__ Cf,
                                                        const float* __restrict__ dF, const int2* __restrict__ olut,
                                                        float* __restrict__ dCf) {
@@ -597,24 +652,57 @@ __global__ __launch_bounds__(256) void k_soap_ps_bwd_s(SoapDims d, const float* 
     for (int k = threadIdx.x; k < d.S / 4; k += 256)
         reinterpret_cast<float4*>(G)[k] = reinterpret_cast<const float4*>(dF + (size_t)i * d.S)[k];
     __syncthreads();
-    for (int l = 0; l <= d.L; l++) {  // symmetrise each block in place: pairs a < b, the diagonal doubles
-        const int nc = d.n_per_l[l] * d.C;
-        float* g = G + d.feat_off[l];
-        for (int q = threadIdx.x; q < nc * nc; q += 256) {
-            const int a = q / nc, b = q - a * nc;
-            if (a > b) continue;
-            const float t = g[a * nc + b] + g[b * nc + a];
-            g[a * nc + b] = t;
-            g[b * nc + a] = t;
-        }
-    }
-    __syncthreads();
     for (int o = threadIdx.x; o < d.NCOEF; o += 256) {
         const int2 code = olut[o];
         const int g0 = code.x, c0 = code.y & 0xffff, nc = code.y >> 16;
         double v = 0.0;
         for (int b = 0; b < nc; b++) v += (double)(G[g0 + b * nc] * cs[c0 + b]);
         dCf[(size_t)i * d.NCOEF + o] = (float)v;
+    }
+}
+
+// The adjoint on the fp32 matrix core: dC_l [(2l+1) x nc] = C_l [(2l+1) x nc] (dF_l + dF_l^T) [nc x nc] as 16 x 16 x 4 tiles (m
+// is at most 2 L + 1 = 13 .. 17 rows: the 32-row tile would waste more than half of itself), two MFMAs per K step -- one
+// with dF[b][a], one with dF[a][b] -- instead of a symmetrisation pass over the staged row; the workgroup's four waves take
+// the l blocks in turn. fp32 products and sums (the scalar kernel summed its 28 terms in fp64).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_soap_ps_bwd_m(SoapDims d, const float* __restrict__ Cf,
+                                                       const float* __restrict__ dF, float* __restrict__ dCf) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cs = smem;             // [NCOEF]
+    float* G = smem + d.NCOEF;    // [S]
+    const int i = blockIdx.x;
+    for (int k = threadIdx.x; k < d.NCOEF; k += 256) cs[k] = Cf[(size_t)i * d.NCOEF + k];
+    for (int k = threadIdx.x; k < d.S / 4; k += 256)
+        reinterpret_cast<float4*>(G)[k] = reinterpret_cast<const float4*>(dF + (size_t)i * d.S)[k];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    float* out = dCf + (size_t)i * d.NCOEF;
+    for (int l = wave; l <= d.L; l += 4) {
+        const int nc = d.n_per_l[l] * d.C, M = 2 * l + 1;
+        const float* c = cs + d.coef_off[l];
+        const float* g = G + d.feat_off[l];
+        for (int m0 = 0; m0 < M; m0 += 16)
+            for (int a0 = 0; a0 < nc; a0 += 16) {
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                const int mi = m0 + li, aj = a0 + li;
+                for (int b0 = 0; b0 < nc; b0 += 4) {
+                    const int b = b0 + kq;
+                    const float av = (mi < M && b < nc) ? c[mi * nc + b] : 0.f;
+                    const bool ok = aj < nc && b < nc;
+                    const float bv = ok ? g[b * nc + aj] : 0.f, bt = ok ? g[aj * nc + b] : 0.f;  // dF[b][a], dF[a][b]
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bt, acc, 0, 0, 0);
+                }
+                if (aj < nc) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int mm = m0 + 4 * kq + r;
+                        if (mm < M) out[d.coef_off[l] + mm * nc + aj] = acc[r];
+                    }
+                }
+            }
     }
 }
 
@@ -636,6 +724,8 @@ __global__ __launch_bounds__(256) void k_soap_ps_bwd_s(SoapDims d, const float* 
 // (pet_config_set("soap_fused", 1) selects it; parity-tested); it wins memory (no [N][S] tensors), not time.
 static int g_soap_fused = 0;
 void set_soap_fused(int v) { g_soap_fused = v ? 1 : 0; }
+static int g_soap_ps_mfma = 1;  // pet_config_set("soap_ps_mfma", 0): the power spectrum (and its adjoint) on the VALU kernels
+void set_soap_ps_mfma(int v) { g_soap_ps_mfma = v ? 1 : 0; }
 
 __global__ void k_soap_prep_wall2(SoapDims d, const SoapSet* __restrict__ sets, int n_sets, int NOUTP, int Kp2,
                                   int transpose, float* __restrict__ wall2) {
@@ -1835,7 +1925,10 @@ static int soap_fwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
     } else {
     {
             ProfScope ps("soap_ps", st, 2.0 * (double)N * d.S * (d.L + 1), (double)N * (d.NCOEF + d.S) * 4);
-            if (g_soap_pair && d.ncmax < 128 && d.NCOEF < 65536) {
+            if (g_soap_pair && g_soap_ps_mfma && d.ncmax <= 32) {
+                allow_big_lds(k_soap_ps_m, (size_t)4 * d.NCOEF * 4);
+                k_soap_ps_m<<<cdiv(N, 4), 256, (size_t)4 * d.NCOEF * 4, st>>>(d, w.Cf, g.sp, m.enc, w.feats, w.tail, N);
+            } else if (g_soap_pair && d.ncmax < 128 && d.NCOEF < 65536) {
                 allow_big_lds(k_soap_ps_w, (size_t)4 * d.NCOEF * 4);
                 k_soap_ps_w<<<cdiv(N, 4), 256, (size_t)4 * d.NCOEF * 4, st>>>(d, w.Cf, g.sp, m.enc, m.feat_lut, w.feats,
                                                                             w.tail, N);
@@ -1937,7 +2030,9 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
     }
     {
         ProfScope ps("soap_ps_bwd", st, 4.0 * (double)N * d.S * (d.L + 1), (double)N * (2 * d.NCOEF + d.S) * 4);
-        if (g_soap_pair && d.S % 4 == 0 && d.NCOEF < 65536 && (size_t)(d.NCOEF + d.S) * 4 <= 64 * 1024) {
+        if (g_soap_pair && g_soap_ps_mfma && d.S % 4 == 0 && (size_t)(d.NCOEF + d.S) * 4 <= 64 * 1024) {
+            k_soap_ps_bwd_m<<<N, 256, (size_t)(d.NCOEF + d.S) * 4, st>>>(d, w.Cf, w.dF, w.dCf);
+        } else if (g_soap_pair && d.S % 4 == 0 && d.NCOEF < 65536 && (size_t)(d.NCOEF + d.S) * 4 <= 64 * 1024) {
             k_soap_ps_bwd_s<<<N, 256, (size_t)(d.NCOEF + d.S) * 4, st>>>(d, w.Cf, w.dF, m.out_lut, w.dCf);
         } else {
             k_soap_ps_bwd<<<N, 256, (size_t)d.NCOEF * 4, st>>>(d, w.Cf, w.dF, m.coef_lut, w.dCf);
