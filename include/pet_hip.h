@@ -413,6 +413,7 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *                  default 3; 0 = LDS-tile kernels
  *   "node_planes" 1 = node-row kernels k_node2 / k_node_bwd2 (coalesced tiles, fp16 planes; default), 0 = k_node / k_swiglu_bwd
  *   "so_trr"      1 = generic training GEMMs with K = 128 or n_out = 128 as TRR kernels (default); 0 = LDS-tile k_gemm_h
+ *   "soap_ps_mfma" 1 = SOAP-BPNN power spectrum and its adjoint on the fp32 matrix core (default); 0 = the VALU kernels
  *   "center_fused" 1 = the node-update kernel also writes the next attention layer's centre tokens (default); 0 = k_center
  *   "train_bf16"  1 = the GEMMs of the second-order pass and the weight-gradient GEMMs keep ONE 16-bit MFMA term per product
  *                 (fp16 / bf16 high planes, fp32 accumulation: BASELINE configs[2]'s "bf16 MFMA MLPs"; gradients within
