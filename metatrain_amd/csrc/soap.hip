@@ -652,6 +652,18 @@ __global__ __launch_bounds__(256) void k_soap_ps_bwd_s(SoapDims d, const float* 
     for (int k = threadIdx.x; k < d.S / 4; k += 256)
         reinterpret_cast<float4*>(G)[k] = reinterpret_cast<const float4*>(dF + (size_t)i * d.S)[k];
     __syncthreads();
+    for (int l = 0; l <= d.L; l++) {  // symmetrise each block in place: pairs a < b, the diagonal doubles
+        const int nc = d.n_per_l[l] * d.C;
+        float* g = G + d.feat_off[l];
+        for (int q = threadIdx.x; q < nc * nc; q += 256) {
+            const int a = q / nc, b = q - a * nc;
+            if (a > b) continue;
+            const float t = g[a * nc + b] + g[b * nc + a];
+            g[a * nc + b] = t;
+            g[b * nc + a] = t;
+        }
+    }
+    __syncthreads();
     for (int o = threadIdx.x; o < d.NCOEF; o += 256) {
         const int2 code = olut[o];
         const int g0 = code.x, c0 = code.y & 0xffff, nc = code.y >> 16;

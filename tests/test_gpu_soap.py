@@ -68,6 +68,39 @@ def test_soap_bpnn_energy_features_and_forces(legacy, mfma_tail, pair_kernels, f
     rt.config_set("soap_sorted", 1)
 
 
+@pytest.mark.parametrize("legacy", [True, False])
+def test_power_spectrum_on_the_matrix_core_and_on_the_valu_agree(legacy):
+    """``pet_config_set("soap_ps_mfma", 0)`` keeps the power spectrum and its adjoint on the VALU kernels (k_soap_ps_w,
+    k_soap_ps_bwd_s; also what more than 32 coefficient columns per l run): features, energies and dE/dR of both forms
+    against the fp64 oracle and against each other."""
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.soap_bpnn import SoapBpnnHip
+
+    dev = torch.device("cuda:0")
+    hypers = dict(osoap.DEFAULT_HYPERS, legacy=legacy)
+    types = [1, 6, 7, 8]
+    params = osoap.synthetic_params(hypers, 4, osoap.basis(hypers)[0], 0, torch.float32)
+    pos, z, cells, ci, cj, cs, sysidx = _box(150, seed=9)
+    p64 = {k: v.double() for k, v in params.items()}
+    _, g_ref, a_ref = osoap.energy_and_gradient(p64, hypers, types, pos, cells, ci, cj, cs, z, sysidx)
+    model = SoapBpnnHip(hypers, types)
+    model.load({k: v.to(dev) for k, v in params.items()})
+    g = model.graph(pos.float().to(dev), cells.float().to(dev), ci.to(dev), cj.to(dev), cs.to(dev), z.to(dev),
+                    sysidx.int().to(dev))
+    out = {}
+    try:
+        for mode in (1, 0):
+            rt.config_set("soap_ps_mfma", mode)
+            atomic, feats = model.forward(g, want_features=True)
+            out[mode] = (atomic.cpu().numpy(), feats.cpu().numpy(), model.backward(g, torch.ones_like(atomic)).cpu().numpy())
+    finally:
+        rt.config_set("soap_ps_mfma", 1)
+    for mode in (1, 0):
+        assert _relmax(out[mode][0], a_ref.numpy()) < TOL and _relmax(out[mode][2], g_ref.numpy()) < TOL
+    assert _relmax(out[1][1], out[0][1]) < 2e-6 and _relmax(out[1][2], out[0][2]) < 5e-6
+    assert not np.array_equal(out[1][1], out[0][1])  # the switch did select other kernels (other summation order)
+
+
 @pytest.mark.parametrize("mfma_tail,fused,sorted_tiles", [(1, 0, 1), (1, 0, 0), (1, 1, 0), (0, 0, 0)])
 @pytest.mark.parametrize("legacy,layers", [(True, 3), (False, 4), (True, 8)])
 def test_more_than_two_hidden_layers(legacy, layers, mfma_tail, fused, sorted_tiles):
