@@ -9,6 +9,9 @@ from oracle import nl as onl
 from oracle import pet as opet
 
 dev = torch.device("cuda:0")
+import os
+if os.environ.get("PET_FUZZ_FUSED"):  # the per-atom fused attention block on every graph (default: graphs of >= 6 144 tiles)
+    rt.config_set("attn_fused", 7)
 hypers = dict(opet.DEFAULT_HYPERS)
 mode = sys.argv[3] if len(sys.argv) > 3 else "default"
 if mode == "adaptive":
