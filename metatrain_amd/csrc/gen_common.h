@@ -29,7 +29,8 @@ static GD dims_of(const Model& m) {
 // products, fp32 accumulation -- no operand splitting, so adjoint rows of any magnitude need no scaling); K in chunks of 32
 // through LDS ([64][33] floats per operand: a lane reads row (lane & 31), column 2 s + (lane >> 5) -- stride 33, no bank
 // conflicts). Any R, NO, KI (tails are zero-filled) and either orientation of the raw torch weight (so, si).
-template <bool ACC>
+// V4: 16-byte global loads (K, the strides and NO multiples of 4, 16-byte aligned bases: every size but the odd ones)
+template <bool ACC, bool V4>
 __global__ __launch_bounds__(256) void k_gen_lin(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
                                                  int64_t so, int64_t si, const float* __restrict__ b,
                                                  float* __restrict__ Y, int64_t ldy, int64_t R, int NO, int KI) {
@@ -47,6 +48,29 @@ __global__ __launch_bounds__(256) void k_gen_lin(const float* __restrict__ X, in
     // register prefetch: the global loads of chunk k0 + KC are in flight during the MFMAs of chunk k0
     float xr[8], wr[8];
     auto fetch = [&](int k0) {
+        if constexpr (V4) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int idx = threadIdx.x + 256 * q;
+                {
+                    const int rr = idx >> 3, k4 = 4 * (idx & 7);
+                    const int64_t r = r0 + rr;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (r < R && k0 + k4 < KI) v = *reinterpret_cast<const float4*>(X + r * ldx + k0 + k4);
+                    xr[4 * q] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
+                }
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (si == 1) {  // W[o][k]: four k of one output row
+                    const int o = o0 + (idx >> 3), k4 = 4 * (idx & 7);
+                    if (o < NO && k0 + k4 < KI) v = *reinterpret_cast<const float4*>(W + (int64_t)o * so + k0 + k4);
+                } else {        // transposed: four output rows of one k
+                    const int o = o0 + 4 * (idx & 15), kk = idx >> 4;
+                    if (o < NO && k0 + kk < KI) v = *reinterpret_cast<const float4*>(W + (int64_t)(k0 + kk) * si + o);
+                }
+                wr[4 * q] = v.x; wr[4 * q + 1] = v.y; wr[4 * q + 2] = v.z; wr[4 * q + 3] = v.w;
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int idx = threadIdx.x + 256 * q;
@@ -64,12 +88,31 @@ __global__ __launch_bounds__(256) void k_gen_lin(const float* __restrict__ X, in
     fetch(0);
     for (int k0 = 0; k0 < KI; k0 += KC) {
         __syncthreads();  // the previous chunk's MFMAs have read the tiles
+        if constexpr (V4) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int idx = threadIdx.x + 256 * q;
-            Xs[(idx >> 5) * LD + (idx & 31)] = xr[q];
-            const int rr = si == 1 ? idx >> 5 : idx & 63, kk = si == 1 ? idx & 31 : idx >> 6;
-            Ws[rr * LD + kk] = wr[q];
+            for (int q = 0; q < 2; q++) {
+                const int idx = threadIdx.x + 256 * q;
+                float* xd = Xs + (idx >> 3) * LD + 4 * (idx & 7);
+#pragma unroll
+                for (int j = 0; j < 4; j++) xd[j] = xr[4 * q + j];
+                if (si == 1) {
+                    float* wd = Ws + (idx >> 3) * LD + 4 * (idx & 7);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) wd[j] = wr[4 * q + j];
+                } else {
+                    float* wd = Ws + 4 * (idx & 15) * LD + (idx >> 4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) wd[j * LD] = wr[4 * q + j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int idx = threadIdx.x + 256 * q;
+                Xs[(idx >> 5) * LD + (idx & 31)] = xr[q];
+                const int rr = si == 1 ? idx >> 5 : idx & 63, kk = si == 1 ? idx & 31 : idx >> 6;
+                Ws[rr * LD + kk] = wr[q];
+            }
         }
         __syncthreads();
         if (k0 + KC < KI) fetch(k0 + KC);
@@ -92,14 +135,25 @@ __global__ __launch_bounds__(256) void k_gen_lin(const float* __restrict__ X, in
 
 struct Lins {
     hipStream_t st;
+    void launch(dim3 grid, bool acc, const float* X, int64_t ldx, const float* W, int64_t so, int64_t si, const float* b,
+                float* Y, int64_t ldy, int64_t R, int NO, int KI) const {
+        const bool v4 = KI % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0 &&
+                        ((si == 1 && so % 4 == 0) || (so == 1 && si % 4 == 0 && NO % 4 == 0));
+        if (acc) {
+            if (v4) k_gen_lin<true, true><<<grid, 256, 0, st>>>(X, ldx, W, so, si, b, Y, ldy, R, NO, KI);
+            else k_gen_lin<true, false><<<grid, 256, 0, st>>>(X, ldx, W, so, si, b, Y, ldy, R, NO, KI);
+        } else {
+            if (v4) k_gen_lin<false, true><<<grid, 256, 0, st>>>(X, ldx, W, so, si, b, Y, ldy, R, NO, KI);
+            else k_gen_lin<false, false><<<grid, 256, 0, st>>>(X, ldx, W, so, si, b, Y, ldy, R, NO, KI);
+        }
+    }
     // y = x W^T + b
     void fwd(const float* X, int64_t ldx, const Lin& L, float* Y, int64_t ldy, int64_t R, bool acc = false,
              int col0 = 0, int kin = -1) const {
         if (R <= 0) return;
         const int K = kin < 0 ? L.k_in : kin;  // a column block [col0, col0 + K) of the weight (compress.0)
         dim3 grid((unsigned)cdiv(R, 64), (unsigned)cdiv(L.n_out, 64));
-        if (acc) k_gen_lin<true><<<grid, 256, 0, st>>>(X, ldx, L.w + col0, L.k_in, 1, L.b, Y, ldy, R, L.n_out, K);
-        else k_gen_lin<false><<<grid, 256, 0, st>>>(X, ldx, L.w + col0, L.k_in, 1, L.b, Y, ldy, R, L.n_out, K);
+        launch(grid, acc, X, ldx, L.w + col0, L.k_in, 1, L.b, Y, ldy, R, L.n_out, K);
     }
     // dx (+)= dy W
     void bwd(const float* dY, int64_t ldy, const Lin& L, float* dX, int64_t ldx, int64_t R, bool acc = false,
@@ -107,8 +161,7 @@ struct Lins {
         if (R <= 0) return;
         const int K = kin < 0 ? L.k_in : kin;
         dim3 grid((unsigned)cdiv(R, 64), (unsigned)cdiv(K, 64));
-        if (acc) k_gen_lin<true><<<grid, 256, 0, st>>>(dY, ldy, L.w + col0, 1, L.k_in, nullptr, dX, ldx, R, K, L.n_out);
-        else k_gen_lin<false><<<grid, 256, 0, st>>>(dY, ldy, L.w + col0, 1, L.k_in, nullptr, dX, ldx, R, K, L.n_out);
+        launch(grid, acc, dY, ldy, L.w + col0, 1, L.k_in, nullptr, dX, ldx, R, K, L.n_out);
     }
 };
 
