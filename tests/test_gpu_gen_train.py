@@ -52,11 +52,13 @@ def _setup(golden_dir, tag, case="batch_two_systems.npz"):
 # d_pet = 1 is a degenerate model numerically: RMSNorm of ONE feature is sign(x) (x / sqrt(x^2 + 1.2e-7)), every gradient
 # is a single sum with heavy cancellation. The reference's own arithmetic (torch, fp32, same weights and inputs) misses its
 # fp64 values by 2e-4 .. 9e-3 on these gradients (edge_embedder.bias 9.2e-3, compress.0.bias 9.1e-3, norm / mlp weights
-# 4e-4: measured with the oracle evaluated in fp32); the HIP pass sits at 2e-5 (energy term) / 8e-4 (force-loss term).
+# 4e-4: measured with the oracle evaluated in fp32); the HIP pass sits at 1e-5 (energy term) / 8e-4 (force-loss term).
 LOOSE = {"minimal": 2e-3}
+# the grid adaptive cutoff carries the tangent through a soft-max over probe cutoffs: its force-loss gradients sit at 1.3e-5
+LOOSE_FORCE = dict(LOOSE, s64_adaptive_grid=2 * TOL)
 
 
-def _compare(got, ref, model, what, tol=2 * TOL):
+def _compare(got, ref, model, what, tol=TOL):
     worst = {}
     for k, r in ref.items():
         r = r.numpy()
@@ -84,7 +86,7 @@ def test_energy_term_parameter_gradients(golden_dir, tag):
     model.zero_grad()
     fw.forward()
     gpos = fw.backward_train(seed_w.to(dev), want_position_grad=True)
-    _compare(model.grads(), ref, model, f"{tag} energy term", LOOSE.get(tag, 2 * TOL))
+    _compare(model.grads(), ref, model, f"{tag} energy term", LOOSE.get(tag, TOL))
     inf = rt.HipForward(model, graph)
     a = inf.forward() if hypers["featurizer_type"] != "residual" or model.hypers["d_pet"] != 128 else None
     if a is not None:   # (the compiled size serves the residual featuriser's inference through the staged calls only)
@@ -107,10 +109,10 @@ def test_force_loss_parameter_gradients(golden_dir, tag):
     gpos = fw.backward(ones)
     assert np.abs(gpos.cpu().numpy() - g_ref.numpy()).max() < TOL * np.abs(g_ref.numpy()).max()
     tan = fw.backward_train2(ones, nu.to(dev), u.to(dev), want_tangent=True)
-    assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < 2 * TOL
+    assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < TOL
     lhs, rhs = float(tan.double().sum()), float((u.to(dev).double() * gpos.double()).sum())
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(rhs))
-    _compare(model.grads(), ref, model, f"{tag} force-loss term", LOOSE.get(tag, 2 * TOL))
+    _compare(model.grads(), ref, model, f"{tag} force-loss term", LOOSE_FORCE.get(tag, TOL))
     # bit-reproducible: fixed summation orders, no atomics
     first = model.flat_grad().clone()
     model.zero_grad()
@@ -204,7 +206,7 @@ def test_conditioned_models_train_on_the_size_generic_path(golden_dir, tag, extr
     gpos = fw.backward(ones)
     assert np.abs(gpos.cpu().numpy() - g_ref.numpy()).max() < TOL * np.abs(g_ref.numpy()).max()
     tan = fw.backward_train2(ones, nu.to(dev), u.to(dev), want_tangent=True)
-    assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < 2 * TOL
+    assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < TOL
     _compare(model.grads(), ref2, model, f"{tag} force-loss term")
 
 
@@ -248,7 +250,7 @@ def test_default_size_trains_on_a_graph_with_more_than_127_neighbours():
     gpos = fw.backward(ones)
     assert np.abs(gpos.cpu().numpy() - g_ref.numpy()).max() < TOL * np.abs(g_ref.numpy()).max()
     tan = fw.backward_train2(ones, nu.to(dev), u.to(dev), want_tangent=True)
-    assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < 2 * TOL
+    assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < TOL
     _compare(model.grads(), ref2, model, "dense graph, force-loss term")
 
 

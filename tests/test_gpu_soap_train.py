@@ -157,17 +157,17 @@ def test_training_gradients_against_the_oracles_double_backward(case):
         loss_f, u = force_loss_and_seeds(grad_pos, tg)
         loss = loss + loss_f
     tangent = m.train_gradients(g, seeds, u)
-    assert abs(float(loss) - loss_ref) < 2e-5 * abs(loss_ref)
+    assert abs(float(loss) - loss_ref) < 1e-5 * abs(loss_ref)
     if with_forces:   # the tangent sweep's self-check: sum_i e'_i = <u, dE/dR>
         lhs, rhs = float(tangent.double().sum()), float((u.double() * grad_pos.double()).sum())
-        assert abs(lhs - rhs) < 2e-5 * max(abs(rhs), float((u.double().abs() * grad_pos.double().abs()).sum()) * 1e-2)
+        assert abs(lhs - rhs) < 1e-5 * max(abs(rhs), float((u.double().abs() * grad_pos.double().abs()).sum()) * 1e-2)
     got = m.grads()
     assert set(got) == set(g_ref), (sorted(got), sorted(g_ref))
     worst = {}
     for key, ref in g_ref.items():
         err = _relmax(got[key].cpu().numpy().reshape(ref.shape), ref.numpy())
         worst[key] = err
-    bad = {k: v for k, v in worst.items() if not v < 2e-5}
+    bad = {k: v for k, v in worst.items() if not v < 1e-5}
     print(case, "worst parameter-gradient error", max(worst.values()))
     assert not bad, bad
 
