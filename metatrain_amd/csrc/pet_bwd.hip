@@ -334,7 +334,8 @@ __global__ __launch_bounds__(NTHREADS) void k_swiglu_bwd(const float* __restrict
 template <int RB>  // 32 RB rows per workgroup (see k_node2)
 __global__ __launch_bounds__(NTHREADS) void k_node_bwd2(const float* __restrict__ dY, const float* __restrict__ Xin,
                                                          const float* __restrict__ VG, const float* __restrict__ gamma,
-                                                         WX woutb, WX winb, float* __restrict__ dXout, int64_t R, bool ln) {
+                                                         WX woutb, WX winb, float* __restrict__ dXout, int64_t R, bool ln,
+                                                         const float4* __restrict__ wceb, float* __restrict__ dOC) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = 256, HID = DNF, LDK = lds_ld(K), LDH = plane_ld(K);
     constexpr int ROWS = 32 * RB, NCH = 4 / RB, WC = 256 / NCH, HC = 128 / NCH, NTH = HC / 32, NTO = WC / 32;
@@ -405,11 +406,31 @@ __global__ __launch_bounds__(NTHREADS) void k_node_bwd2(const float* __restrict_
     __syncthreads();  // everyone is done with U: A takes w = gamma * dn (back in true units)
     acc_foreach<NTO>(dn, w.rb, WC * w.ch, w.lane, [&](int r, int c, float v) { A[r * LDK + c] = v * rs[2 * r + 1] * gamma[c]; });
     __syncthreads();
+    // dOC = dH1 Wce (k_expand_bwd's GEMM) from the dH1 tile while it is on chip, when the caller passes dOC: one launch less
+    // on the critical path of a small box. The tile goes over the planes, which nobody reads any more.
+    float* T = smem + ROWS * LDK;  // [ROWS][260]
+    if (dOC) {
+        for (int idx = threadIdx.x; idx < ROWS * (K / 4); idx += NTHREADS)  // rows past the end stay zero
+            *reinterpret_cast<float4*>(T + (idx / (K / 4)) * LDK + 4 * (idx % (K / 4))) = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+    }
     norm_bwd_rows<K, ROWS>(A, Xin, row0, R, K, ln, [&](int r, int c, float4 dx) {
         const int64_t o = (row0 + r) * K + c;
         const float4 dy = *reinterpret_cast<const float4*>(dY + o);
-        *reinterpret_cast<float4*>(dXout + o) = make_float4(dy.x + dx.x, dy.y + dx.y, dy.z + dx.z, dy.w + dx.w);
+        const float4 v = make_float4(dy.x + dx.x, dy.y + dx.y, dy.z + dx.z, dy.w + dx.w);
+        *reinterpret_cast<float4*>(dXout + o) = v;
+        if (dOC) *reinterpret_cast<float4*>(T + r * LDK + c) = v;
     });
+    if (dOC) {
+        constexpr int NTC = RB;  // 128 columns over the NCH column groups
+        __syncthreads();
+        f32x16 acc[NTC];
+        acc_fill_bias<NTC>(acc, nullptr, 0, w.lane);
+        gemm_acc<256, NTC>(T + w.rb * 32 * LDK, LDK, wceb, 32, 0, NTC * w.ch, acc, w.lane);
+        acc_foreach<NTC>(acc, w.rb, 32 * NTC * w.ch, w.lane, [&](int r, int c, float v) {
+            if (row0 + r < R) dOC[(row0 + r) * D + c] = v;
+        });
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1157,20 +1178,24 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             {
                 ProfScope ps("node_bwd", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
                 const WX wob = wx_b(A.cmlp_out), wib = wx_b(A.cmlp_in);
+                bool expand_done = false;
                 if (!tr && node_planes() && wob.h && wib.h) {
                     const int nr = node_rows(N);
                     const size_t lds_nb = (size_t)nr * LD256 * 4 + (size_t)2 * nr * plane_ld(256) * 2 + nr * 8;
-                    if (nr == 32) {
+                    if (nr == 32) {  // small graphs: the expansion adjoint in the same launch
                         allow_big_lds(k_node_bwd2<1>, lds_nb);
-                        k_node_bwd2<1><<<cdiv(N, 32), NTHREADS, lds_nb, s2>>>(dH, Ab.H1, Ab.VGn, A.g_center, wob, wib, dH_alt, N, ln);
+                        k_node_bwd2<1><<<cdiv(N, 32), NTHREADS, lds_nb, s2>>>(dH, Ab.H1, Ab.VGn, A.g_center, wob, wib, dH_alt, N, ln,
+                                                                             A.ce.bwd, w.dOC);
+                        expand_done = true;
                     } else {
                         allow_big_lds(k_node_bwd2<2>, lds_nb);
-                        k_node_bwd2<2><<<gN, NTHREADS, lds_nb, s2>>>(dH, Ab.H1, Ab.VGn, A.g_center, wob, wib, dH_alt, N, ln);
+                        k_node_bwd2<2><<<gN, NTHREADS, lds_nb, s2>>>(dH, Ab.H1, Ab.VGn, A.g_center, wob, wib, dH_alt, N, ln,
+                                                                     nullptr, nullptr);
                     }
                 } else
                 PET_LAUNCH_TR(tr, k_swiglu_bwd, PET_TA(256, DNF), gN, (BM * LD256 + BM * LD128) * 4, s2,  dH, Ab.H1,
                     Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N, tr ? w.dVGn : nullptr, ln);
-                k_expand_bwd<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(dH_alt, A.ce.bwd, w.dOC, N);
+                if (!expand_done) k_expand_bwd<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(dH_alt, A.ce.bwd, w.dOC, N);
                 if (tr) {
                     tr->linear(lp + ".center_mlp.w_out", DN, DNF, {dH, nullptr, 0, DN},
                                {Ab.VGn, 2 * DNF, DNF, nullptr, nullptr}, 2, N);
