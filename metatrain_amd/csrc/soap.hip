@@ -1143,14 +1143,32 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_fwd_set(SoapDims d, cons
 #pragma unroll
     for (int r = 0; r < 16; r++) tot[r] = 0.0;
     for (int kc = 0; kc < Kp / 128; kc++) {
+        // this wave's eight weight fragments of the chunk (the column-half index splits K: 64 of the chunk's 128 k) are
+        // requested together, ahead of the barriers: gemm_acc asks for one fragment per four MFMAs, i.e. eight dependent L2
+        // round trips per chunk, which is what this kernel waited for (20 k cycles per chunk against 2 k of MFMA)
+        float4 bw[8];
+        {
+            const float4* bp = Wp + ((size_t)16 * kc + 8 * w.ch) * 64 + w.lane;
+#pragma unroll
+            for (int kg = 0; kg < 8; kg++) bw[kg] = bp[kg * 64];
+        }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; q++) *reinterpret_cast<float4*>(As + (r0 + 8 * q) * LDA + 4 * c) = pre[q];
         __syncthreads();
         if (kc + 1 < Kp / 128) fetch(kc + 1);
-        // the column-half index splits K: this wave takes 64 of the chunk's 128 k
         acc_fill_bias<1>(acc, nullptr, 0, w.lane);
-        gemm_acc<64, 1>(As + w.rb * 32 * LDA + 64 * w.ch, LDA, Wp, Kp / 8, 16 * kc + 8 * w.ch, 0, acc, w.lane);
+        {
+            const float* arow = As + (w.rb * 32 + (w.lane & 31)) * LDA + 64 * w.ch + (w.lane >> 5) * 4;
+#pragma unroll
+            for (int kg = 0; kg < 8; kg++) {  // the same products in the same order as gemm_acc<64, 1>
+                const float4 av = *reinterpret_cast<const float4*>(arow + kg * 8);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bw[kg].x, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bw[kg].y, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bw[kg].z, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bw[kg].w, acc[0], 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; r++) tot[r] += (double)acc[0][r];
     }
