@@ -91,6 +91,26 @@ def pmc_traffic(stage, n_edges):
     return sum(r["hbm_bytes_per_launch"] * r.get("calls", 1) for r in recs) / calls
 
 
+def pmc_mfma_busy(stage):
+    """SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE of the stage's largest kernel from the committed SQ pass of this bench
+    (profiles/r04_sq_counters_table.txt, column mfma_util), or None."""
+    path = os.path.join(ROOT, "profiles", "r04_sq_counters_table.txt")
+    if stage not in STAGE_KERNELS or not os.path.exists(path):
+        return None
+    best = None
+    with open(path) as fh:
+        for line in fh:
+            if line.split("<")[0].strip() in STAGE_KERNELS[stage]:
+                parts = line.split()
+                try:
+                    us, util = float(parts[-7]), float(parts[-6])
+                except (ValueError, IndexError):
+                    continue
+                if best is None or us > best[0]:
+                    best = (us, util)
+    return best[1] if best else None
+
+
 def pmc_step_traffic(n_edges):
     """Total HBM bytes of one step over ALL kernels from the committed PMC passes, or None (other workload)."""
     data = _traffic_file()
@@ -371,6 +391,7 @@ def main():
                     "unit": "TFLOP/s", "frac": achieved / mfma_peak, "avg_launch_ms": avg_ms,
                     "algorithmic_flops_per_launch": flops_per_launch, "traffic": None}
         roof["traffic"] = pmc_traffic(dominant, int(graph.n_edges))
+        roof["mfma_busy_pmc"] = pmc_mfma_busy(dominant)  # what the matrix pipe was busy with, recompute and padding included
         roof["arithmetic"] = ("fp32 MFMA soft-max attention kernel; the surrounding projections: " + ARITHMETIC
                               if dominant in ("attn_fwd", "attn_bwd") else ARITHMETIC)
         if split:  # both roofs of a split-operand GEMM stage, whichever one "bound" names
