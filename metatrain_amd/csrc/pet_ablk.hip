@@ -102,33 +102,6 @@ __device__ __forceinline__ void ab_tile_planes(const f32x16& a, f16x8 (&hi)[2], 
     }
 }
 
-// weight fragment `idx` (in units of 64 lanes x 16 B) of a plane: scalar base + per-lane byte offset, so that the
-// address arithmetic stays on the scalar unit (saddr + voffset form of global_load)
-__device__ __forceinline__ f16x8 ab_ldw(const f16x8* plane, int idx, unsigned lane16) {
-    const char* base = reinterpret_cast<const char*>(plane + (size_t)idx * 64);
-    return *reinterpret_cast<const f16x8*>(base + lane16);
-}
-
-// Q, K, V weight fragments (both planes) of head pair hp, K block kb
-struct AbW6 {
-    f16x8 qh, ql, kh, kl, vh, vl;
-};
-__device__ __forceinline__ void ab_ldw6(AbW6& w, const W2& wqkv, int hp, int kb, unsigned lane16) {
-    const int i = hp * 8 + kb;
-    w.qh = ab_ldw(wqkv.h, i, lane16); w.ql = ab_ldw(wqkv.l, i, lane16);
-    w.kh = ab_ldw(wqkv.h, 32 + i, lane16); w.kl = ab_ldw(wqkv.l, 32 + i, lane16);
-    w.vh = ab_ldw(wqkv.h, 64 + i, lane16); w.vl = ab_ldw(wqkv.l, 64 + i, lane16);
-}
-// fragments of four output tiles (both planes) at K block kb of a [128 x (16 KB)] weight
-struct AbW4 {
-    f16x8 h[4], l[4];
-};
-template <int KB>
-__device__ __forceinline__ void ab_ldw4(AbW4& w, const W2& wt, int kb, unsigned lane16) {
-#pragma unroll
-    for (int t = 0; t < 4; t++) { w.h[t] = ab_ldw(wt.h, t * KB + kb, lane16); w.l[t] = ab_ldw(wt.l, t * KB + kb, lane16); }
-}
-
 #ifdef AB_PROFILE
 // debugging aid (build with -DAB_PROFILE): shader cycles per phase, summed over the waves of every launch
 __device__ unsigned long long ab_prof[32];
