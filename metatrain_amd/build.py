@@ -36,7 +36,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if failed:
         raise RuntimeError(f"hipcc failed for {failed}")
     if procs or not os.path.exists(LIB):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-fgpu-rdc", "-shared", "-fPIC", *objs, "-o", LIB]
+        # (-fgpu-rdc: the device code is generated at this step, so code-generation switches belong here too)
+        cmd = ["hipcc", "--offload-arch=gfx950", "-fgpu-rdc", "-shared", "-fPIC", *os.environ.get("PET_HIP_LINK_FLAGS", "").split(),
+               *objs, "-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
