@@ -1685,8 +1685,22 @@ __global__ __launch_bounds__(256) void k_soap_expand_bwd_p(SoapDims d, const flo
                                                            const float* __restrict__ table,
                                                            const float* __restrict__ shn, const float* __restrict__ spw,
                                                            const float* __restrict__ dCf, float4* __restrict__ dv,
-                                                           int64_t E) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                           int64_t E, int lds_floats) {
+    // The 256 pairs of a workgroup are consecutive in CSR order, i.e. they belong to ~10 consecutive centres: those
+    // centres' adjoint coefficient rows (NCOEF floats each) are staged in LDS once, and the 343 float4 a pair reads come
+    // from there (lanes of one centre read the same address: a broadcast) instead of as many dependent L1 round trips.
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int64_t p0 = (int64_t)blockIdx.x * 256;
+    const int64_t plast = (p0 + 255 < E ? p0 + 255 : E - 1);
+    const int c0 = ctr[p0], c1 = ctr[plast];
+    const bool staged = (int64_t)(c1 - c0 + 1) * d.NCOEF <= lds_floats;
+    if (staged) {
+        const float4* src = reinterpret_cast<const float4*>(dCf + (size_t)c0 * d.NCOEF);
+        const int n4 = (c1 - c0 + 1) * (d.NCOEF / 4);
+        for (int k = threadIdx.x; k < n4; k += 256) reinterpret_cast<float4*>(smem)[k] = src[k];
+        __syncthreads();
+    }
+    const int64_t p = p0 + threadIdx.x;
     if (p >= E) return;
     const float4 g = geo[p];
     const float r = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
@@ -1695,7 +1709,7 @@ __global__ __launch_bounds__(256) void k_soap_expand_bwd_p(SoapDims d, const flo
     float dfc;
     const float fc = shifted_cosine(r, d.rc, d.width, &dfc);
     const float4 w4 = *reinterpret_cast<const float4*>(spw + sp_nbr[p] * 4);
-    const float* dC = dCf + (size_t)ctr[p] * d.NCOEF;
+    const float* dC = staged ? smem + (size_t)(ctr[p] - c0) * d.NCOEF : dCf + (size_t)ctr[p] * d.NCOEF;
     ShLevels<LMAX> sh;
     sh.init(ux, uy, uz, ir);
     double ax = 0.0, ay = 0.0, az = 0.0, along = 0.0;  // `along` multiplies the unit vector; fp64 sums (280 items)
@@ -2074,13 +2088,20 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
                      (double)g.n_edges * 36 + (double)N * d.NCOEF * 4);
         if (soap_pair_ok(d)) {
             const int grid = (int)cdiv(g.n_edges, 256);
-            if (d.L <= 6)
-                k_soap_expand_bwd_p<6><<<grid, 256, 0, st>>>(d, g.geo, g.ctr, g.sp_nbr, m.table, m.shnorm, m.species_w,
-                                                              w.dCf, reinterpret_cast<float4*>(w.dv), g.n_edges);
-            else
-                k_soap_expand_bwd_p<MAXL><<<grid, 256, 0, st>>>(d, g.geo, g.ctr, g.sp_nbr, m.table, m.shnorm,
-                                                                 m.species_w, w.dCf, reinterpret_cast<float4*>(w.dv),
-                                                                 g.n_edges);
+            const int lds_floats = (d.NCOEF % 4 == 0) ? 16 * 1024 : 0;  // 64 KB: the rows of up to ~11 centres of the default basis
+            if (d.L <= 6) {
+                allow_big_lds(k_soap_expand_bwd_p<6>, (size_t)lds_floats * 4);
+                k_soap_expand_bwd_p<6><<<grid, 256, (size_t)lds_floats * 4, st>>>(d, g.geo, g.ctr, g.sp_nbr, m.table, m.shnorm,
+                                                                                 m.species_w, w.dCf,
+                                                                                 reinterpret_cast<float4*>(w.dv), g.n_edges,
+                                                                                 lds_floats);
+            } else {
+                allow_big_lds(k_soap_expand_bwd_p<MAXL>, (size_t)lds_floats * 4);
+                k_soap_expand_bwd_p<MAXL><<<grid, 256, (size_t)lds_floats * 4, st>>>(d, g.geo, g.ctr, g.sp_nbr, m.table,
+                                                                                    m.shnorm, m.species_w, w.dCf,
+                                                                                    reinterpret_cast<float4*>(w.dv),
+                                                                                    g.n_edges, lds_floats);
+            }
         } else {
             k_soap_expand_bwd<<<N, 256, lds_expand_bwd(d), st>>>(d, g.geo, g.rowptr, g.sp_nbr, m.table, m.shnorm,
                                                                  m.item_lut, m.species_w, w.dCf,
