@@ -1623,9 +1623,9 @@ __global__ __launch_bounds__(256) void k_soap_expand_w(SoapDims d, const float4*
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wave;
     if (i >= N) return;
-    const int ld = (d.NLM + d.F + 4 + 3) & ~3;   // row: Y[NLM] | R fc [F] | species weights [4], 16 B aligned
+    const int ld = ((d.NLM + d.F + 4 + 3) & ~3) + 4;   // row: Y[NLM] | R fc [F] | species weights [4] | r, fc (16 B aligned)
     float* rows = smem + (size_t)wave * 32 * ld;
-    const int wo = ld - 4;
+    const int wo = ld - 8;
     const int p0 = rowptr[i], p1 = rowptr[i + 1];
     float4 acc[MAXI];
     int code[MAXI];
@@ -1657,11 +1657,20 @@ __global__ __launch_bounds__(256) void k_soap_expand_w(SoapDims d, const float4*
                 }
                 *reinterpret_cast<float4*>(row + wo) = *reinterpret_cast<const float4*>(spw + sp_nbr[base + pp] * 4);
             } else {
-                const float fc = shifted_cosine(r, d.rc, d.width, nullptr);
-                for (int f = 0; f < d.F; f++) radial_one(d, table, f, r, fc, 0.f, row + d.NLM + f, nullptr);
+                row[wo + 4] = r;
+                row[wo + 5] = shifted_cosine(r, d.rc, d.width, nullptr);
             }
         }
         __builtin_amdgcn_wave_barrier();  // same wave wrote the rows; LDS serves a wave's requests in order
+        // the radial functions: (pair, function) items over ALL 64 lanes -- the two spline nodes of an item are independent
+        // loads, where 32 lanes walking the functions of their own pair waited for each pair of them in turn (and the
+        // spherical-harmonic half of the wave sat idle behind the same branch)
+        for (int it = lane; it < npc * d.F; it += 64) {
+            const int q = it / d.F, f = it - q * d.F;
+            float* rq = rows + q * ld;
+            radial_one(d, table, f, rq[wo + 4], rq[wo + 5], 0.f, rq + d.NLM + f, nullptr);
+        }
+        __builtin_amdgcn_wave_barrier();
         for (int q = 0; q < npc; q++) {
             const float* row = rows + q * ld;
             const float4 w4 = *reinterpret_cast<const float4*>(row + wo);
@@ -1938,7 +1947,7 @@ static int soap_fwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
     {
         ProfScope ps("soap_expand", st, 2.0 * (double)g.n_edges * d.NCOEF, (double)g.n_edges * 20 + (double)N * d.NCOEF * 4);
         if (soap_pair_ok(d)) {
-            const size_t lds = (size_t)4 * 32 * ((d.NLM + d.F + 4 + 3) & ~3) * 4;
+            const size_t lds = (size_t)4 * 32 * (((d.NLM + d.F + 4 + 3) & ~3) + 4) * 4;
             allow_big_lds(k_soap_expand_w<6>, lds);
             allow_big_lds(k_soap_expand_w<MAXL>, lds);
             if (d.L <= 6)
