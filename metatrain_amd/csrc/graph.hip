@@ -506,20 +506,26 @@ __global__ void k_csr_fill(const int* __restrict__ perm, const float4* __restric
 }
 
 // nef.py:88-166 restated as a search in row j (rows hold <= a few dozen edges)
+// Four lanes per edge walk row j in strides of four (a row holds ~20 - 30 edges: the one-lane scan was ten dependent loads).
 __global__ void k_reverse(const int* __restrict__ rowptr, const int* __restrict__ ctr,
                           const int* __restrict__ nbr, const int* __restrict__ shift,
                           int* __restrict__ rev, int* __restrict__ scalars) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= scalars[0]) return;
-    int i = ctr[p], j = nbr[p];
-    int sa = -shift[3 * p], sb = -shift[3 * p + 1], sc = -shift[3 * p + 2];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = t >> 2, sub = t & 3;
+    const bool live = p < scalars[0];
     int found = -1;
-    for (int q = rowptr[j]; q < rowptr[j + 1]; q++) {
-        if (nbr[q] == i && shift[3 * q] == sa && shift[3 * q + 1] == sb && shift[3 * q + 2] == sc) {
-            found = q;
-            break;
-        }
+    if (live) {
+        const int i = ctr[p], j = nbr[p];
+        const int sa = -shift[3 * p], sb = -shift[3 * p + 1], sc = -shift[3 * p + 2];
+        for (int q = rowptr[j] + sub; q < rowptr[j + 1]; q += 4)
+            if (nbr[q] == i && shift[3 * q] == sa && shift[3 * q + 1] == sb && shift[3 * q + 2] == sc) {
+                found = q;
+                break;
+            }
     }
+    found = max(found, __shfl_xor(found, 1));  // at most one lane of the four finds the partner (edges are unique)
+    found = max(found, __shfl_xor(found, 2));
+    if (!live || sub != 0) return;
     // an edge without its (j, i, -S) partner makes graph_build fail (PET_ERR_GRAPH); pointing it at itself keeps every
     // later gather in bounds whatever the caller does with the error
     rev[p] = found < 0 ? p : found;
@@ -782,7 +788,7 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
                                               g.nbr, g.shift, g.sp_nbr, g.geo, g.d0, g.fc, g.scalars,
                                               m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function,
                                               g.adaptive ? g.r_atom : nullptr, g.pc);
-        k_reverse<<<cdiv(e0, T), T, 0, st>>>(g.rowptr, g.ctr, g.nbr, g.shift, g.rev, g.scalars);
+        k_reverse<<<cdiv(4 * (int64_t)e0, T), T, 0, st>>>(g.rowptr, g.ctr, g.nbr, g.shift, g.rev, g.scalars);
         k_find_pad_src<<<cdiv(e0, T), T, 0, st>>>(g.perm, g.kidx, g.keep, g.scalars, g.scalars + 3);
     }
     if (int rcb = bucket_atoms_by_tile_count(g, st)) return rcb;

@@ -1734,14 +1734,16 @@ __global__ __launch_bounds__(256) void k_soap_expand_bwd_p(SoapDims d, const flo
         for (int n = 0; n < nl; n++) {
             float R, dR;
             radial_one(d, table, d.rad_off[l] + n, r, fc, dfc, &R, &dR);
+            float ay_ = 0.f;  // sum over m of A Y in fp32 (at most 2 l + 1 terms), then one fp64 add per radial function
 #pragma unroll
             for (int mi = 0; mi < 2 * LMAX + 1; mi++) {
                 if (mi > 2 * l) continue;
                 const float4 c = *reinterpret_cast<const float4*>(dCl + (size_t)(mi * nl + n) * 4);
                 const float A = c.x * w4.x + c.y * w4.y + c.z * w4.z + c.w * w4.w;
-                along += (double)(A * dR * Y[mi]);
+                ay_ = fmaf(A, Y[mi], ay_);
                 T[mi] += A * R;
             }
+            along += (double)(ay_ * dR);
         }
 #pragma unroll
         for (int mi = 0; mi < 2 * LMAX + 1; mi++) {
