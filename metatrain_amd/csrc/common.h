@@ -109,6 +109,7 @@ struct Graph {
     int n_tiles1 = 0, n_tiles2 = 0;  // host copies
     mutable const void* fwd_ws = nullptr;  // the workspace this graph's last forward wrote, and whether it ran the
     mutable bool fwd_generic = false;      // size-generic path there (pet_fwd.hip note_workspace)
+    bool attn_lists = false;         // atom_order / bucket_start (and the tile plan) exist (graph.hip graph_attention_lists)
     bool tiles_planned = false;      // the graph build made tile_desc (large graphs, or the fused block forced)
     int bucket_start[6] = {0, 0, 0, 0, 0, 0};  // host copy
     // adaptive cutoff (structures.py:225-263): CSR over ALL input edges (the root finder and its

@@ -718,6 +718,21 @@ int64_t graph_workspace_bytes(int64_t n_nodes, int64_t e0) {
     return (int64_t)total;
 }
 
+// The attention lists of a graph that was built before its model had weights (see graph_build): made on the first tuned
+// forward. The bucket / histogram slots of `scalars` are still zero: nothing has written them.
+int graph_attention_lists(const Graph& gc, hipStream_t st) {
+    Graph& g = const_cast<Graph&>(gc);
+    if (g.attn_lists || g.n_nodes <= 0) return PET_OK;
+    if (int rcb = bucket_atoms_by_tile_count(g, st)) return rcb;
+    int host_scalars[57] = {0};
+    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 57 * sizeof(int), hipMemcpyDeviceToHost, st));
+    PET_HIP_CHECK(hipStreamSynchronize(st));
+    set_bucket_starts(g, host_scalars + 8);
+    if (int rcp = plan_attention_tiles(g, host_scalars + 24, st)) return rcp;
+    g.attn_lists = true;
+    return PET_OK;
+}
+
 int graph_build(const Model& m, const float* pos, const float* cells, const int* centers,
                 const int* neighbors, const int* shifts, const int* species, const int* sys,
                 int64_t n_nodes, int64_t e0, int64_t n_systems, void* ws, int64_t ws_bytes,
@@ -791,14 +806,21 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
         k_reverse<<<cdiv(4 * (int64_t)e0, T), T, 0, st>>>(g.rowptr, g.ctr, g.nbr, g.shift, g.rev, g.scalars);
         k_find_pad_src<<<cdiv(e0, T), T, 0, st>>>(g.perm, g.kidx, g.keep, g.scalars, g.scalars + 3);
     }
-    if (int rcb = bucket_atoms_by_tile_count(g, st)) return rcb;
+    // the per-tile-count atom lists and the attention tile plan serve the PET layers only: a model handle without weights
+    // (what the SOAP-BPNN path builds its graphs with; a mirror that runs preprocess before its weights are uploaded)
+    // skips them here, and the first tuned forward on the graph makes them (graph_attention_lists)
+    g.attn_lists = m.finalized;
+    if (g.attn_lists)
+        if (int rcb = bucket_atoms_by_tile_count(g, st)) return rcb;
     int host_scalars[57] = {0};
     PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 57 * sizeof(int), hipMemcpyDeviceToHost, st));
     PET_HIP_CHECK(hipStreamSynchronize(st));
     g.n_edges = host_scalars[0];
     g.max_nbr = host_scalars[1];
-    set_bucket_starts(g, host_scalars + 8);
-    if (int rcp = plan_attention_tiles(g, host_scalars + 24, st)) return rcp;
+    if (g.attn_lists) {
+        set_bucket_starts(g, host_scalars + 8);
+        if (int rcp = plan_attention_tiles(g, host_scalars + 24, st)) return rcp;
+    }
     PET_REQUIRE(host_scalars[6] == 0, PET_ERR_ARGUMENT,
                 std::to_string(host_scalars[6]) + " neighbour-list entries index atoms outside [0, n_nodes)");
     PET_REQUIRE(host_scalars[5] == 0, PET_ERR_ARGUMENT,
@@ -962,6 +984,7 @@ int graph_from_batch(const int64_t* el_nodes, const int64_t* el_nbr, const float
     else if (n_nodes > 0)
         k_from_batch_fill<<<cdiv(n_nodes, T), T, 0, st>>>(el_nodes, el_nbr, ev, ed, rni, cf, g.rowptr, (int)n_nodes, 1, g.ctr,
                                                           g.nbr, g.rev, g.sp, g.sp_nbr, g.geo, g.fc, g.scalars);
+    g.attn_lists = true;
     if (int rcb = bucket_atoms_by_tile_count(g, st)) return rcb;
     int host_scalars[57] = {0};
     int n_edges = 0;

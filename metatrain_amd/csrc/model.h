@@ -134,6 +134,7 @@ int optimizer_state(Model& m, float* d_m, float* d_v, int64_t numel, int directi
 
 // graph.hip
 int64_t graph_workspace_bytes(int64_t n_nodes, int64_t e0);
+int graph_attention_lists(const Graph& g, hipStream_t st);  // graph.hip: lazily, for a graph built before pet_model_finalize
 int graph_build(const Model& m, const float* pos, const float* cells, const int* centers,
                 const int* neighbors, const int* shifts, const int* species, const int* sys,
                 int64_t n_nodes, int64_t e0, int64_t n_systems, void* ws, int64_t ws_bytes,

@@ -844,6 +844,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
     PET_REQUIRE(!(gen && g.x_fn), PET_ERR_UNSUPPORTED, "the per-layer exchange is built for the tuned path (default model size)");
     note_workspace(g, ws, gen);
     if (gen) return gen_forward_layers(m, g, ws, ws_bytes, save, atomic, node_feats, edge_feats, n_layers, st);
+    if (int rcl = graph_attention_lists(g, st)) return rcl;
     Workspace w;
     carve_workspace(m, g.n_nodes, g.n_edges, ws, w, save == 2);
     PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "forward workspace too small");
