@@ -1127,11 +1127,10 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_fwd_set(SoapDims d, cons
         const int col = 128 * kc + 4 * c;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rowoff[q] >= 0 && col < d.S) {
-                const float4 x = *reinterpret_cast<const float4*>(feats + rowoff[q] + col);
-                pre[q] = make_float4(x.x - rowmu[q], x.y - rowmu[q], x.z - rowmu[q], x.w - rowmu[q]);
-            }
+            // raw values: the centring waits until the tile is written (a subtraction here makes the load's latency part of
+            // this trip instead of hiding it behind the MFMAs)
+            pre[q] = make_float4(rowmu[q], rowmu[q], rowmu[q], rowmu[q]);  // (x - mu = 0 in the padding)
+            if (rowoff[q] >= 0 && col < d.S) pre[q] = *reinterpret_cast<const float4*>(feats + rowoff[q] + col);
         }
     };
     fetch(0);
@@ -1154,7 +1153,9 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_fwd_set(SoapDims d, cons
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 8; q++) *reinterpret_cast<float4*>(As + (r0 + 8 * q) * LDA + 4 * c) = pre[q];
+        for (int q = 0; q < 8; q++)
+            *reinterpret_cast<float4*>(As + (r0 + 8 * q) * LDA + 4 * c) =
+                make_float4(pre[q].x - rowmu[q], pre[q].y - rowmu[q], pre[q].z - rowmu[q], pre[q].w - rowmu[q]);
         __syncthreads();
         if (kc + 1 < Kp / 128) fetch(kc + 1);
         acc_fill_bias<1>(acc, nullptr, 0, w.lane);
