@@ -395,7 +395,8 @@ int pet_profile_reset(void);
 int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int64_t* calls,
                        double* flops, double* bytes, int* n_entries);
 /* Runtime switches used by tests / the benchmark (every setting meets the same parity bar):
- *   "side_stream" 1 = node-feature chain on a second HIP stream (default)
+ *   "side_stream" 1 = node-feature chain on a second HIP stream (default); that stream is created one priority level below the
+ *                 caller's (environment PET_HIP_SIDE_PRIO = same | high overrides; PET_HIP_SIDE = 0 disables the stream)
  *   "trr"         1 = transposed register-resident row kernels on f16x3 split-operand products (default); 0 = the LDS-tile
  *                 kernels for the transformer layers (the one fallback generation, also the transformer-layer path of
  *                 PostLN models). The combination stage has one implementation (the software-pipelined TRR kernel).
