@@ -101,6 +101,8 @@ def main():
                     help="BASELINE configs[3]: 512 x 10 000-atom boxes per step in the whole job (64 per GPU at N = 8), "
                          "micro-batches of 4 = --total-boxes 512 --atoms 10000 --micro 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs that are not `value` (single-term mode, two micro-batches): profiling runs")
     ap.add_argument("--train-bf16", action="store_true",
                     help="pet_config_set('train_bf16', 1): ONE 16-bit MFMA term per product in the second-order and "
                          "weight-gradient GEMMs (BASELINE configs[2]'s 'bf16 MFMA MLPs'; gradients to ~1e-3, not the parity "
@@ -160,30 +162,36 @@ def main():
         micro = min(args.micro, args.boxes) if args.micro > 0 else args.boxes
     else:
         seeds = pdist.box_seeds(args.boxes, rank)
-    batches, n_edges = [], 0
-    for m0 in range(0, args.boxes, micro):
-        pos_l, z_l, cell_l, pair_l, sys_l = [], [], [], [], []
-        for b, seed in enumerate(seeds[m0:m0 + micro]):
-            pos, z, cell = random_box(args.atoms, seed=seed)
-            posd = pos.to(dev)
-            pairs, _ = rt.neighbor_list(posd, cell, [True] * 3, hypers["cutoff"])
-            pairs = pairs.clone()
-            pairs[:, 0:2] += b * args.atoms
-            pos_l.append(posd); z_l.append(z.to(dev)); cell_l.append(cell.to(dev)); pair_l.append(pairs)
-            sys_l.append(torch.full((args.atoms,), b, dtype=torch.int32, device=dev))
-        nb = len(pos_l)
-        pairs = torch.cat(pair_l)
-        graph = rt.HipGraph(model, torch.cat(pos_l), torch.stack(cell_l), pairs[:, 0].contiguous(), pairs[:, 1].contiguous(),
-                            pairs[:, 2:5].contiguous(), torch.cat(z_l), torch.cat(sys_l))
-        per_box = torch.full((nb,), float(args.atoms), device=dev)
-        batches.append(dict(graph=graph, target_energies=(torch.randn(nb, generator=gen) * 0.1).to(dev) * per_box,
-                            n_atoms=per_box, target_gradients=(torch.randn(nb * args.atoms, 3, generator=gen) * 0.1).to(dev)))
-        n_edges += int(graph.n_edges)
+
+    def make_batches(micro):
+        """The step's boxes in micro-batches of `micro`, and ONE training workspace, sized for the largest micro-batch, that
+        all of them walk."""
+        batches = []
+        for m0 in range(0, args.boxes, micro):
+            pos_l, z_l, cell_l, pair_l, sys_l = [], [], [], [], []
+            for b, seed in enumerate(seeds[m0:m0 + micro]):
+                pos, z, cell = random_box(args.atoms, seed=seed)
+                posd = pos.to(dev)
+                pairs, _ = rt.neighbor_list(posd, cell, [True] * 3, hypers["cutoff"])
+                pairs = pairs.clone()
+                pairs[:, 0:2] += b * args.atoms
+                pos_l.append(posd); z_l.append(z.to(dev)); cell_l.append(cell.to(dev)); pair_l.append(pairs)
+                sys_l.append(torch.full((args.atoms,), b, dtype=torch.int32, device=dev))
+            nb = len(pos_l)
+            pairs = torch.cat(pair_l)
+            graph = rt.HipGraph(model, torch.cat(pos_l), torch.stack(cell_l), pairs[:, 0].contiguous(), pairs[:, 1].contiguous(),
+                                pairs[:, 2:5].contiguous(), torch.cat(z_l), torch.cat(sys_l))
+            per_box = torch.full((nb,), float(args.atoms), device=dev)
+            batches.append(dict(graph=graph, target_energies=(torch.randn(nb, generator=gen) * 0.1).to(dev) * per_box,
+                                n_atoms=per_box, target_gradients=(torch.randn(nb * args.atoms, 3, generator=gen) * 0.1).to(dev)))
+        fw = rt.HipForward(model, max(batches, key=lambda b: b["graph"].n_edges)["graph"], train=True)
+        for b in batches:
+            b["fw"] = fw
+        return batches, fw
+
+    batches, fw = make_batches(micro)
+    n_edges = sum(int(b["graph"].n_edges) for b in batches)
     n_atoms = args.boxes * args.atoms
-    # ONE training workspace, sized for the largest micro-batch, walked by all of them
-    fw = rt.HipForward(model, max(batches, key=lambda b: b["graph"].n_edges)["graph"], train=True)
-    for b in batches:
-        b["fw"] = fw
     train = TrainStep(model, {"warmup_fraction": 0.0, "num_epochs": 10**6})
     comm_events = []
 
@@ -213,7 +221,7 @@ def main():
     elapsed = pdist.max_over_ranks(time.perf_counter() - t0, dev)
     train.comm_events = None
     one_term = None
-    if world == 1 and not args.train_bf16:  # not `value`: the same step in the single-term mode (a few more Adam steps)
+    if world == 1 and not args.train_bf16 and not args.no_extras:  # not `value`: the same step in the single-term mode (a few more Adam steps)
         rt.config_set("train_bf16", 1)
         step(graph, fw, target_e, per_box, target_g)
         torch.cuda.synchronize()
@@ -227,6 +235,25 @@ def main():
                     "what": "pet_config_set('train_bf16', 1): ONE 16-bit MFMA term per product in the second-order and "
                             "weight-gradient GEMMs (gradients to ~1e-3: 20-step loss curve in tests/test_gpu_train.py); "
                             "forward and force pass unchanged"}
+    two_micro = None
+    workspace_gb = (fw.nbytes + fw.workspace2.numel()) / 1e9
+    if world == 1 and len(batches) == 1 and args.boxes >= 2 and not args.no_extras and not args.train_bf16:
+        # not `value`: the same step (one Adam step over the same boxes) as TWO micro-batches with gradient accumulation
+        # (TrainStep.microbatched) on a workspace half the size -- what a user short of memory runs
+        gen.manual_seed(1234 + rank)  # (the whole-batch workspace stays allocated: 123 + 62 GB of the 288)
+        mb, fw2 = make_batches((args.boxes + 1) // 2)
+        train.microbatched(mb)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            train.microbatched(mb)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t1) / 3
+        two_micro = {"value": n_atoms / dt2, "unit": "atom-steps/s", "ms_per_step": dt2 * 1e3,
+                     "workspace_gb": (fw2.nbytes + fw2.workspace2.numel()) / 1e9,
+                     "what": f"the same step as 2 micro-batches of {(args.boxes + 1) // 2} boxes (gradient accumulation, one Adam "
+                             "step; --micro): the workspace is sized for one micro-batch"}
+        del mb, fw2
     comm_ms = (sum(a.elapsed_time(b) for a, b in comm_events) / len(comm_events)) if comm_events else 0.0
     if rank == 0:
         ls = [float(x) for x in losses]
@@ -258,7 +285,7 @@ def main():
                 "gradient_all_reduce_ms_per_step": comm_ms,
                 "gradient_all_reduce_backend": backend if world > 1 else None,
                 "loss_first_last": [ls[0], ls[-1]],
-                "workspace_gb": (fw.nbytes + fw.workspace2.numel()) / 1e9,
+                "workspace_gb": workspace_gb,
             },
         }
         # roofline: the stage group with the largest share of the step (instrumented stages only), its algorithmic FLOPs
@@ -287,6 +314,8 @@ def main():
             out["roofline"]["whole_step_algorithmic_tflops"] = 6.0 * fwd / (elapsed / args.steps) / 1e12
         if one_term:
             out["train_bf16"] = one_term
+        if two_micro:
+            out["two_micro_batches"] = two_micro
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(hypers, params)
         print(json.dumps(out), flush=True)

@@ -256,6 +256,7 @@ int tile_mask();
 void set_trr_compress(int v);
 void set_node_planes(int v);  // pet_fwd.hip / pet_bwd.hip: node-row kernels on pre-split fp16 planes (default 1)
 bool node_planes();
+void set_dxf_fused(int v);     // pet_bwd.hip: 1 = dXF formed inside k_comb_bwd_p2 / k_emlp_bwd_p2 instead of by k_dxf (default)
 void set_center_fused(int v);  // pet_fwd.hip: 1 = k_node2 also writes the next layer's centre tokens (default)
 int node_rows(int64_t N);   // rows per workgroup of the node-row kernels (32: two workgroups per CU; 64)
 struct Graph;
@@ -282,13 +283,14 @@ void trr_oproj_bwd(const float* dX1, const float* dOC, const Lin& out, float* dA
 void trr_emlp(const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout, float* VG,
               float* X2, int64_t E, hipStream_t st);
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const float* beta,
-                  const Lin& win, const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg = nullptr);
+                  const Lin& win, const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg = nullptr,
+                  int ldy = 128, const float* dY2 = nullptr, const int* rev2 = nullptr);  // dY2: dY = dY[p] + dY2[rev2[p]], rows of ldy floats
 
 // pet_comb.hip: combination stage and adjoint as TRR kernels (f16x3); false if the split operands are missing
 bool trr_comb(bool first, const float* XF, const Graph& g, const GnnLayerW& G, const float* Min,
               const float* edge_emb, float* CA, float* LNS, float* Mout, int64_t E, hipStream_t st);
 bool trr_comb_bwd(const float* dM, const float* XF, const Graph& g, const GnnLayerW& G, const float* LNS,
-                  const float* CA, float* dcat, int64_t E, float* t_da, hipStream_t st);
+                  const float* CA, float* dcat, int64_t E, float* t_da, hipStream_t st, bool add_dm = false);  // add_dm: dcat[p][:D] += dM[p]
 
 // pet_ablk.hip: the per-atom fused attention block (norm -> QKV -> attention -> output projection in one kernel, the
 // adjoint recomputing Q, K, V); false = not served (an atom of more than 64 tokens, planes missing, switched off)

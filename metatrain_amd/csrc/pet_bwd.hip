@@ -227,7 +227,12 @@ __global__ __launch_bounds__(NTHREADS) void k_head_bwd(const float* __restrict__
     });
 }
 
-// dXF[p] = dM[p] + dcat[p][:D] + dcat[rev[p]][D:]
+static int g_dxf_fused = 1;
+void set_dxf_fused(int v) { g_dxf_fused = v ? 1 : 0; }
+static inline bool dxf_fused_on() { return g_dxf_fused != 0; }
+
+// dXF[p] = dM[p] + dcat[p][:D] + dcat[rev[p]][D:]   (inference graphs on one rank: formed inside k_comb_bwd_p2 / k_emlp_bwd_p2
+// instead -- `dxf_fused` in backward())
 __global__ void k_dxf(const float* __restrict__ dM, const float* __restrict__ dcat, const int* __restrict__ rev,
                       float* __restrict__ dX, int64_t E) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1114,6 +1119,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     const bool trr = use_trr();
     const bool trr_l = trr && m.plain_layers();  // the TRR transformer-layer kernels are PreLN (RMSNorm or LayerNorm)
     const bool fused_attn = trr_l && !tr && ablk_bwd_on(g) && m.gnn[0].attn[0].qkv.bwd2s;
+    // k_dxf folded into its producer and its consumer (pet_config_set("dxf_fused", 0): the separate kernel)
+    const bool dxf_fused = trr_l && !tr && !res && !g.x_fn && m.h.num_attention_layers >= 1 && dxf_fused_on();
     PET_HIP_CHECK(hipMemsetAsync(w.dgeo, 0, E * 4 * sizeof(float), st));
     allow_big_lds(k_swiglu_bwd<256, DNF, false, true>, (BM * LD256 + BM * LD128) * 4);
     allow_big_lds(k_swiglu_bwd<256, DNF, true, true>, (BM * LD256 + BM * LD128) * 4);
@@ -1149,7 +1156,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         } else {
             {
                 ProfScope ps("comb_bwd", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D), fE * 4.0 * (3 * D + 2 * D + 2 * D));  // dM, e, e[rev], CA in; dcat out
-                PET_REQUIRE(trr_comb_bwd(dM, B.XF, g, G, B.LNS, B.CA, w.dcat, E, tr ? w.dCA : nullptr, st), PET_ERR_ARGUMENT,
+                PET_REQUIRE(trr_comb_bwd(dM, B.XF, g, G, B.LNS, B.CA, w.dcat, E, tr ? w.dCA : nullptr, st, dxf_fused), PET_ERR_ARGUMENT,
                             "combination adjoint: the split weight planes are missing (pet_model_finalize)");
                 if (tr) {
                     const std::string gs = std::to_string(gi);
@@ -1161,7 +1168,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                                           "combination_norms." + gs + ".bias", G.ln_b);
                 }
             }
-            {
+            if (!dxf_fused) {
                 ProfScope ps("dxf", st, 0.0);
                 k_dxf<<<cdiv(E * (D / 4), 256), 256, 0, st>>>(dM, w.dcat, g.rev, dX, E);
             }
@@ -1217,7 +1224,12 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 k_rownorm_bwd<<<gR, NTHREADS, lds1, st>>>(dX, dX + E * D, Ab.X1, A.g_attn, ln, dX_alt, E, R);
             } else {
                 ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D), fE * 4.0 * (3 * D + 2 * DFF));  // dY, X1, VG in; dX1 out
-                if (trr_l) {
+                if (dxf_fused && a == m.h.num_attention_layers - 1) {
+                    // dXF[p] = (dM[p] + dcat[p][:D]) + dcat[rev[p]][D:]: the bracket left k_comb_bwd_p2 in dcat's first
+                    // half, the gather is made while this kernel reads its tile
+                    trr_emlp_bwd(w.dcat, Ab.X1, Ab.VG, A.g_mlp, ln ? A.b_mlp : nullptr, A.mlp_in, A.mlp_out, dX_alt, E, st,
+                                 nullptr, 2 * D, w.dcat + D, g.rev);
+                } else if (trr_l) {
                     trr_emlp_bwd(dX, Ab.X1, Ab.VG, A.g_mlp, ln ? A.b_mlp : nullptr, A.mlp_in, A.mlp_out, dX_alt, E, st,
                                  tr ? w.dVG : nullptr);
                 }

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_comb_p2(const float* __restrict__ XF, c
 // rows into the (still empty) park region; the saved pre-activations arrive by LDS-DMA as whole 128-B lines two chunks
 // ahead. LDS per wave: [parked planes 32 KB | CA chunks 2 x 4 KB] = all 160 KB of the CU.
 // ---------------------------------------------------------------------------------
-template <bool TRAIN>
+template <bool TRAIN, bool ADD_DM = false>
 __global__ __launch_bounds__(256) void k_comb_bwd_p2(const float* __restrict__ dM, const float* __restrict__ XF,
                                                       const int* __restrict__ rev, const float* __restrict__ LNS,
                                                       const float* __restrict__ CA, const float* __restrict__ ln_g,
@@ -447,6 +447,8 @@ __global__ __launch_bounds__(256) void k_comb_bwd_p2(const float* __restrict__ d
     acc_to_frag<4>(dl, whi);
     load_rowfrag<16>(xo, XF, row, D, L.h);
     load_rowfrag<16>(xr, XF, (int64_t)rev[row], D, L.h);
+    float4 dm[16];
+    if (ADD_DM) request_rows_addend<16>(dm, L, [&](int r) { return dM + (row0 + r < E ? row0 + r : E - 1) * D; });
     const float mean = LNS[row * 2], rstd = LNS[row * 2 + 1];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -472,7 +474,9 @@ __global__ __launch_bounds__(256) void k_comb_bwd_p2(const float* __restrict__ d
         }
         // the parked chunks are consumed: the wave's park region is its staging tile for full-line stores (trr.h)
         float* otile = reinterpret_cast<float*>(park);
-        store_rows_lines<16>(wlo, otile, L, [&](int r) { return row0 + r < E ? dcat + (row0 + r) * (2 * D) : nullptr; });
+        // ADD_DM: dcat[p][:D] leaves as dM[p] + dcat[p][:D], the first two terms of dXF (k_dxf, pet_bwd.hip) in its order
+        if (ADD_DM) store_rows_lines_add<16>(wlo, dm, otile, L, [&](int r) { return row0 + r < E ? dcat + (row0 + r) * (2 * D) : nullptr; });
+        else store_rows_lines<16>(wlo, otile, L, [&](int r) { return row0 + r < E ? dcat + (row0 + r) * (2 * D) : nullptr; });
         store_rows_lines<16>(whi, otile, L, [&](int r) { return row0 + r < E ? dcat + (row0 + r) * (2 * D) + D : nullptr; });
     }
 }
@@ -503,15 +507,19 @@ bool trr_comb(bool first, const float* XF, const Graph& g, const GnnLayerW& G, c
 }
 
 bool trr_comb_bwd(const float* dM, const float* XF, const Graph& g, const GnnLayerW& G, const float* LNS,
-                  const float* CA, float* dcat, int64_t E, float* t_da, hipStream_t st) {
+                  const float* CA, float* dcat, int64_t E, float* t_da, hipStream_t st, bool add_dm) {
     if (!G.comb0.bwd2 || !G.comb2.bwd2 || E <= 0) return false;
     // bwd2 operands: tiles over k_in, K = n_out
     const W2 w2b = w2_of(G.comb2.bwd2, G.comb2.k_in, G.comb2.n_out), w0b = w2_of(G.comb0.bwd2, G.comb0.k_in, G.comb0.n_out);
     const int grid = cdiv(E, WG_ROWS);
     const size_t lds = (size_t)4 * 40960;  // per wave: parked da planes 32 KB, pre-activation chunks 2 x 4 KB
     if (t_da) {
+        if (add_dm) return false;
         allow_big_lds(k_comb_bwd_p2<true>, lds);
         k_comb_bwd_p2<true><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, t_da);
+    } else if (add_dm) {
+        allow_big_lds(k_comb_bwd_p2<false, true>, lds);
+        k_comb_bwd_p2<false, true><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, nullptr);
     } else {
         allow_big_lds(k_comb_bwd_p2<false>, lds);
         k_comb_bwd_p2<false><<<grid, 256, lds, st>>>(dM, XF, g.rev, LNS, CA, G.ln_g, w2b, w0b, dcat, E, nullptr);

@@ -522,11 +522,12 @@ __global__ __launch_bounds__(256) void k_emlp_p2(const float* __restrict__ X1, c
 // element slices (the next du starts from a literal zero at slot 16). The VG request for chunk hc + 2 sits behind slot 19:
 // behind this iteration's last Win^T request and behind the Wout^T requests that are waited for in this iteration, so
 // the first wait that covers it is the one for the Win^T block of slot 8 of the next iteration.
-template <bool TRAIN, bool LN>
+template <bool TRAIN, bool LN, bool GATHER = false>
 __global__ __launch_bounds__(256) void k_emlp_bwd_p2(const float* __restrict__ dY, const float* __restrict__ X1,
                                                       const float* __restrict__ VG, const float* __restrict__ gamma,
                                                       W2 woutb, W2 winb, float* __restrict__ dX1, int64_t E,
-                                                      float* __restrict__ t_dvg) {
+                                                      float* __restrict__ t_dvg, int ldy, const float* __restrict__ dY2,
+                                                      const int* __restrict__ rev2) {
     extern __shared__ __attribute__((aligned(16))) char ebp_lds[];  // [4 waves][dY / split planes 16 KB | VG chunks 2 x 8 KB, X1 at the end | [dv | dg] 8 KB]
     TRR_PROLOGUE(E);
     constexpr int NC = DFF / 32;
@@ -535,10 +536,19 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_p2(const float* __restrict__ d
     f16x8* const ysp = reinterpret_cast<f16x8*>(my);
     const char* const vgt = my + 16384;  // two chunk buffers [v 4 KB | g 4 KB]; the X1 tile in the last two iterations
     f16x8* const dsp = reinterpret_cast<f16x8*>(my + 32768);  // [4 K blocks x (h, l)][64]
+    float4 y2[16];  // dY2 != nullptr: dY = dY[row] + dY2[rev2[row]] (rows of ldy floats) -- the ji gather of the combination
+                    // adjoint (k_dxf, pet_bwd.hip) made while the tile is read
+    int myrev = 0;  // lane l: rev2 of tile row l & 31
+    if (GATHER) {
+        const int64_t r2 = row0 + (L.lane & 31);
+        myrev = rev2[r2 < E ? r2 : E - 1];
+    }
     {
         const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)my);
-        dma_tile128(dY, row0, E, base, L);
+        dma_tile128(dY, row0, E, base, L, ldy);
     }
+    if (GATHER)  // whole 512-B rows, two per instruction (the line mapping of trr.h request_rows_lines)
+        request_rows_lines(y2, L, [&](int r) { return dY2 + (int64_t)__shfl(myrev, r) * ldy; });
     // VG chunk hc -> buffer: whole 128-B lines (8 lanes per row and half, 8 rows per instruction); row r, 16-B piece p
     // of a half lands at byte 128 r + 16 (p ^ ((r >> 1) & 7)): conflict-free for the per-row reads below
     const unsigned vgbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)vgt);
@@ -584,6 +594,24 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_p2(const float* __restrict__ d
     {
         float4 dy[16];
         tile128_to_frag(dy, my, L);
+        if (GATHER) {  // the gathered rows take the tile's place (same swizzle) and are added as fragments
+            __builtin_amdgcn_wave_barrier();
+            const int rr = L.lane >> 5, pc = L.lane & 31;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int r = 2 * j + rr;
+                *reinterpret_cast<float4*>(my + 512 * r + 16 * (pc ^ (r & 15))) = y2[j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const char* rowp = my + 512 * L.r;
+            const int sw = L.r & 15;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float4 g = *reinterpret_cast<const float4*>(rowp + 16 * ((2 * k + L.h) ^ sw));
+                dy[k] = make_float4(dy[k].x + g.x, dy[k].y + g.y, dy[k].z + g.z, dy[k].w + g.w);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         float sc;
         inv = row_scale_pow2<16>(dy, sc);
         Split2<8> t;
@@ -967,22 +995,27 @@ void trr_emlp(const float* X1, const float* gamma, const float* beta, const Lin&
 }
 template <bool LN>
 static void launch_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const float* beta,
-                            const Lin& win, const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg) {
+                            const Lin& win, const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg, int ldy,
+                            const float* dY2, const int* rev2) {
     const int grid = grid_rows(E);
     const size_t lds = (size_t)4 * 40960;  // per wave: dY tile / split planes 16 KB, VG chunks / X1 tile 16 KB, [dv | dg] 8 KB (all 160 KB of the CU)
-    if (t_dvg) {
+    if (dY2 && !t_dvg) {
+        allow_big_lds(k_emlp_bwd_p2<false, LN, true>, lds);
+        k_emlp_bwd_p2<false, LN, true><<<grid, 256, lds, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, nullptr, ldy, dY2, rev2);
+    } else if (t_dvg) {
         allow_big_lds(k_emlp_bwd_p2<true, LN>, lds);
-        k_emlp_bwd_p2<true, LN><<<grid, 256, lds, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, t_dvg);
+        k_emlp_bwd_p2<true, LN><<<grid, 256, lds, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, t_dvg, ldy, dY2, rev2);
     } else {
         allow_big_lds(k_emlp_bwd_p2<false, LN>, lds);
-        k_emlp_bwd_p2<false, LN><<<grid, 256, lds, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, nullptr);
+        k_emlp_bwd_p2<false, LN><<<grid, 256, lds, st>>>(dY, X1, VG, gamma, w2_bwd(wout), w2_bwd(win), dX1, E, nullptr, ldy, dY2, rev2);
     }
 }
 void trr_emlp_bwd(const float* dY, const float* X1, const float* VG, const float* gamma, const float* beta,
-                  const Lin& win, const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg) {
+                  const Lin& win, const Lin& wout, float* dX1, int64_t E, hipStream_t st, float* t_dvg, int ldy,
+                  const float* dY2, const int* rev2) {
     if (E <= 0) return;
-    if (beta) launch_emlp_bwd<true>(dY, X1, VG, gamma, beta, win, wout, dX1, E, st, t_dvg);
-    else launch_emlp_bwd<false>(dY, X1, VG, gamma, beta, win, wout, dX1, E, st, t_dvg);
+    if (beta) launch_emlp_bwd<true>(dY, X1, VG, gamma, beta, win, wout, dX1, E, st, t_dvg, ldy, dY2, rev2);
+    else launch_emlp_bwd<false>(dY, X1, VG, gamma, beta, win, wout, dX1, E, st, t_dvg, ldy, dY2, rev2);
 }
 
 // ---------------------------------------------------------------------------------

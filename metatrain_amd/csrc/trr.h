@@ -168,6 +168,37 @@ __device__ __forceinline__ void store_rows_lines(const float4 (&y)[KG], float* l
         __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next group
     }
 }
+// The same with an addend that was requested in the line mapping of the stores (request_rows_addend): y + a leaves.
+template <int KG, class RowPtr>
+__device__ __forceinline__ void request_rows_addend(float4 (&a)[KG], const RowLane& L, RowPtr rowptr) {
+    const int rr = L.lane >> 4, cc = 4 * (L.lane & 15);
+#pragma unroll
+    for (int g = 0; g < KG / 8; g++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[8 * g + j] = *reinterpret_cast<const float4*>(rowptr(4 * j + rr) + 64 * g + cc);
+}
+template <int KG, class RowPtr>
+__device__ __forceinline__ void store_rows_lines_add(const float4 (&y)[KG], const float4 (&a)[KG], float* lds, const RowLane& L,
+                                                     RowPtr rowptr) {
+    static_assert(KG % 8 == 0, "whole 64-column groups");
+    float* wr = lds + L.r * TILE_LD + 4 * L.h;
+    const int rr = L.lane >> 4, cc = 4 * (L.lane & 15);
+#pragma unroll
+    for (int g = 0; g < KG / 8; g++) {
+#pragma unroll
+        for (int kg = 0; kg < 8; kg++) *reinterpret_cast<float4*>(wr + 8 * kg) = y[8 * g + kg];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int r = 4 * j + rr;
+            const float4 v = *reinterpret_cast<const float4*>(lds + r * TILE_LD + cc);
+            const float4 b = a[8 * g + j];
+            float* p = rowptr(r);
+            if (p) *reinterpret_cast<float4*>(p + 64 * g + cc) = make_float4(b.x + v.x, b.y + v.y, b.z + v.z, b.w + v.w);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 // rows row0 .. row0 + 31 of a row-major matrix Y (leading dimension ld), rows >= n_rows not written
 __device__ __forceinline__ void store_tile64_lines(const float4 (&y)[8], float* lds, float* __restrict__ Y, int64_t row0,
                                                    int64_t n_rows, int ld, const RowLane& L) {
@@ -492,14 +523,14 @@ __device__ __forceinline__ void glds16_trr(const float* gsrc, unsigned lds_dst) 
 // whole-row LDS-DMA of a [32 x 128] fp32 tile: instruction j brings rows 2j, 2j + 1; row r, 16-B piece p lands at
 // byte 512 r + 16 (p ^ (r & 15)) of the tile
 __device__ __forceinline__ void dma_tile128(const float* __restrict__ X, int64_t row0, int64_t n_rows, unsigned lds_base,
-                                            const RowLane& L) {
+                                            const RowLane& L, int ld = 128) {
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const int r = 2 * j + (L.lane >> 5);
         int64_t rr = row0 + r;
         rr = rr < n_rows ? rr : n_rows - 1;
         const int p = (L.lane & 31) ^ (r & 15);
-        glds16_trr(X + rr * 128 + 4 * p, lds_base + j * 1024);
+        glds16_trr(X + rr * ld + 4 * p, lds_base + j * 1024);
     }
 }
 // row fragment (trr.h) out of such a tile

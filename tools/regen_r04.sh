@@ -2,7 +2,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 bash tools/profile_cmd.sh r04 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/profile_r04.log 2>&1
-bash tools/profile_cmd.sh r04_train python bench_train.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/profile_r04_train.log 2>&1
+bash tools/profile_cmd.sh r04_train python bench_train.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/profile_r04_train.log 2>&1
 bash tools/profile_cmd.sh r04_soap python bench_soap.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/profile_r04_soap.log 2>&1
 python bench.py > gpurun_out/r04_bench.json 2> gpurun_out/r04_bench.err
 python bench_train.py > gpurun_out/r04_bench_train.json 2> gpurun_out/r04_bench_train.err
