@@ -416,6 +416,8 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *   "so_trr"      1 = generic training GEMMs with K = 128 or n_out = 128 as TRR kernels (default); 0 = LDS-tile k_gemm_h
  *   "soap_ps_mfma" 1 = SOAP-BPNN power spectrum and its adjoint on the fp32 matrix core (default); 0 = the VALU kernels
  *   "center_fused" 1 = the node-update kernel also writes the next attention layer's centre tokens (default); 0 = k_center
+ *   "sorted_shortcut" 1 = pet_graph_build reads back whether the neighbour list is already ordered by centre with no edge to
+ *                 drop and skips the radix sort of the edges if so (default); 0 = always sort
  *   "dxf_fused"   1 = inference adjoint on one rank: dXF[p] = dM[p] + dcat[p][:D] + dcat[rev[p]][D:] formed inside the
  *                 combination adjoint (first two terms) and the edge-MLP adjoint (the gather) -- default; 0 = k_dxf launch
  *   "train_bf16"  1 = the GEMMs of the second-order pass and the weight-gradient GEMMs keep ONE 16-bit MFMA term per product

@@ -234,18 +234,26 @@ __global__ void k_species_index(const int* __restrict__ species, const int* __re
     sp[i] = s;
 }
 
+static int g_sorted_shortcut = 1;  // pet_config_set("sorted_shortcut", 0): always run the radix sort of the edges
+void set_sorted_shortcut(int v) { g_sorted_shortcut = v ? 1 : 0; }
+
 // structures.py:206-221 and the non-strict mask of :265-267
 __global__ void k_edge_geometry(const float* __restrict__ pos, const float* __restrict__ cells,
                                 const int* __restrict__ centers, const int* __restrict__ neighbors,
                                 const int* __restrict__ shifts, const int* __restrict__ sys,
                                 float4* __restrict__ vin, int* __restrict__ keep,
                                 int* __restrict__ sort_keys, int* __restrict__ sort_vals,
-                                int n_edges, int n_nodes, float cutoff, int strict, int* __restrict__ n_bad) {
+                                int n_edges, int n_nodes, float cutoff, int strict, int* __restrict__ n_bad,
+                                int* __restrict__ unsorted) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
     int i = centers[e], j = neighbors[e];
+    // *unsorted stays 0 only if every edge is kept and the centres come in non-decreasing order: the sort keys are then
+    // sorted as they stand and graph_build skips the radix sort (a list from pet_nl_build / vesin is ordered like that)
+    if (e > 0 && centers[e - 1] > i) *unsorted = 1;
     if (i < 0 || i >= n_nodes || j < 0 || j >= n_nodes) {  // reported by the host; the edge is dropped
         atomicAdd(n_bad, 1);
+        *unsorted = 1;
         vin[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         keep[e] = 0;
         sort_keys[e] = n_nodes;
@@ -264,6 +272,7 @@ __global__ void k_edge_geometry(const float* __restrict__ pos, const float* __re
     int kp = strict ? 1 : (d0 <= cutoff ? 1 : 0);  // strict == 2: adaptive first pass, every edge
     vin[e] = make_float4(v[0], v[1], v[2], d0);
     keep[e] = kp;
+    if (!kp) *unsorted = 1;
     sort_keys[e] = kp ? i : n_nodes;  // dropped edges sort behind every real centre
     sort_vals[e] = e;
 }
@@ -506,7 +515,7 @@ __global__ void k_csr_fill(const int* __restrict__ perm, const float4* __restric
 }
 
 // nef.py:88-166 restated as a search in row j (rows hold <= a few dozen edges)
-// Four lanes per edge walk row j in strides of four (a row holds ~20 - 30 edges: the one-lane scan was ten dependent loads).
+// Four lanes per edge walk row j in strides of four (a row holds ~20 - 40 edges: the one-lane scan was that many dependent loads).
 __global__ void k_reverse(const int* __restrict__ rowptr, const int* __restrict__ ctr,
                           const int* __restrict__ nbr, const int* __restrict__ shift,
                           int* __restrict__ rev, int* __restrict__ scalars) {
@@ -517,11 +526,19 @@ __global__ void k_reverse(const int* __restrict__ rowptr, const int* __restrict_
     if (live) {
         const int i = ctr[p], j = nbr[p];
         const int sa = -shift[3 * p], sb = -shift[3 * p + 1], sc = -shift[3 * p + 2];
-        for (int q = rowptr[j] + sub; q < rowptr[j + 1]; q += 4)
-            if (nbr[q] == i && shift[3 * q] == sa && shift[3 * q + 1] == sb && shift[3 * q + 2] == sc) {
-                found = q;
-                break;
+        // four candidates per lane in flight (clamped to the row: a repeat of its last entry), then the comparisons: a
+        // row of 40 edges is 3 dependent rounds instead of 10
+        const int b = rowptr[j], e = rowptr[j + 1];
+        for (int q0 = b + sub; q0 < e && found < 0; q0 += 16) {
+            int c[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) c[u] = nbr[min(q0 + 4 * u, e - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int q = q0 + 4 * u;
+                if (q < e && c[u] == i && shift[3 * q] == sa && shift[3 * q + 1] == sb && shift[3 * q + 2] == sc) found = q;
             }
+        }
     }
     found = max(found, __shfl_xor(found, 1));  // at most one lane of the four finds the partner (edges are unique)
     found = max(found, __shfl_xor(found, 2));
@@ -752,11 +769,12 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
                                                         (int)(n_systems > 0 ? n_systems : 1), g.scalars + 7);
     }
     g.adaptive = m.h.num_neighbors_adaptive > 0.f;
+    const int* sorted_keys = g.sort_keys_out;
     if (e0 > 0) {
         k_edge_geometry<<<cdiv(e0, T), T, 0, st>>>(pos, cells, centers, neighbors, shifts, g.sys, g.vin,
                                                    g.keep, g.sort_keys_in, g.sort_vals_in, (int)e0,
                                                    (int)n_nodes, m.h.cutoff, g.adaptive ? 2 : m.h.nl_is_strict,
-                                                   g.scalars + 6);
+                                                   g.scalars + 6, g.scalars + 60);
         size_t sb = g.sort_tmp_bytes, cb = g.scan_tmp_bytes;
         if (g.adaptive) {
             // all-edge CSR -> per-atom cutoffs -> pair mask; then the usual kept-edge CSR below
@@ -787,13 +805,25 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
                                                        g.sort_keys_in, g.sort_vals_in, (int)e0, (int)n_nodes);
             sb = g.sort_tmp_bytes;
         }
-        PET_HIP_CHECK(rocprim::radix_sort_pairs(g.sort_tmp, sb, g.sort_keys_in, g.sort_keys_out,
-                                                g.sort_vals_in, g.perm, (size_t)e0, 0,
-                                                sort_bits(n_nodes), st));
+        // a list that is already ordered by centre with no edge to drop (k_edge_geometry) needs no sort: one 4-byte
+        // read-back (the build ends with one anyway) against three radix passes over the edges
+        int unsorted = 1;
+        if (!g.adaptive && g_sorted_shortcut) {
+            PET_HIP_CHECK(hipMemcpyAsync(&unsorted, g.scalars + 60, sizeof(int), hipMemcpyDeviceToHost, st));
+            PET_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        if (unsorted) {
+            PET_HIP_CHECK(rocprim::radix_sort_pairs(g.sort_tmp, sb, g.sort_keys_in, g.sort_keys_out,
+                                                    g.sort_vals_in, g.perm, (size_t)e0, 0,
+                                                    sort_bits(n_nodes), st));
+        } else {
+            sorted_keys = g.sort_keys_in;
+            g.perm = g.sort_vals_in;  // the identity
+        }
         PET_HIP_CHECK(rocprim::exclusive_scan(g.scan_tmp, cb, g.keep, g.kidx, 0, (size_t)e0,
                                               rocprim::plus<int>(), st));
     }
-    k_rowptr<<<cdiv(n_nodes + 1, T), T, 0, st>>>(g.sort_keys_out, (int)e0, g.rowptr, (int)n_nodes,
+    k_rowptr<<<cdiv(n_nodes + 1, T), T, 0, st>>>(sorted_keys, (int)e0, g.rowptr, (int)n_nodes,
                                                  g.scalars);
     if (n_nodes > 0) k_max_nbr<<<cdiv(n_nodes, T), T, 0, st>>>(g.rowptr, (int)n_nodes, g.scalars);
     if (e0 > 0) {

@@ -294,6 +294,7 @@ bool trr_comb_bwd(const float* dM, const float* XF, const Graph& g, const GnnLay
 
 // pet_ablk.hip: the per-atom fused attention block (norm -> QKV -> attention -> output projection in one kernel, the
 // adjoint recomputing Q, K, V); false = not served (an atom of more than 64 tokens, planes missing, switched off)
+void set_sorted_shortcut(int v);  // graph.hip: 1 = a neighbour list that is ordered by centre skips the radix sort (default)
 void set_attn_fused(int v);
 int attn_fused();
 void ablk_prof_dump();  // debugging aid: per-phase cycle sums of the fused kernels (library built with -DAB_PROFILE)

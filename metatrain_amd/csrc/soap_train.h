@@ -727,7 +727,7 @@ static int soap_train_grads(SoapModel& m, const Graph& g, void* ws, int64_t ws_b
     PET_HIP_CHECK(hipMemsetAsync(t.info, 0, sizeof(SpInfo), st));
     k_sp_count<<<cdiv(N, 256), 256, 0, st>>>(g.sp, d.legacy, N, t.info);
     k_sp_scan<<<1, 1, 0, st>>>(m.n_sets, t.info);
-    k_sp_fill<<<cdiv(N, 256), 256, 0, st>>>(g.sp, d.legacy, N, t.info, t.perm);
+    k_sp_fill<<<cdiv(N, 1024), 1024, 0, st>>>(g.sp, d.legacy, N, t.info, t.perm);
     k_soap_wgrad1<<<dim3(cdiv(d.S, 64), m.n_sets, t.n_chunks), 64, 0, st>>>(d, w.feats, xd, t.perm, t.info, m.sets, t.pack,
                                                                           t.n_chunks, t.part);
     for (int s = 0; s < m.n_sets; s++) {

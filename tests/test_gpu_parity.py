@@ -428,6 +428,48 @@ def test_rotation_and_permutation_consistency(rt, model, dev):
     assert np.abs(g0.sum(0)).max() < 1e-3 * np.abs(g0).max()
 
 
+def test_edge_order_and_the_sort_shortcut(rt, model, dev, golden_dir):
+    """``pet_graph_build`` skips the radix sort of the edges when the list arrives ordered by centre with nothing to drop
+    (one 4-byte read-back decides). The reference list of the 1 000-atom box is ordered: with the shortcut and with
+    ``sorted_shortcut = 0`` the results are bit-identical (the stable sort is the identity); the same list shuffled, and
+    with 40 edges beyond the cutoff appended (dropped by the non-strict filter), takes the sort and must meet the same bar
+    against the reference golden."""
+    g = _load(golden_dir, "pet_default_box1000.npz")
+    assert (np.diff(g["in_centers"]) >= 0).all()
+    t = lambda k: torch.tensor(g[k]).to(dev)  # noqa: E731
+
+    def run(i, j, s):
+        graph = rt.HipGraph(model, t("in_positions").float(), t("in_cells").float(), i, j, s, t("in_species"),
+                            t("in_system_indices").int())
+        fw = rt.HipForward(model, graph)
+        a = fw.forward()
+        return a, fw.backward(torch.ones_like(a)), graph
+
+    a1, g1, graph1 = run(t("in_centers"), t("in_neighbors"), t("in_cell_shifts"))
+    rt.config_set("sorted_shortcut", 0)
+    try:
+        a0, g0, graph0 = run(t("in_centers"), t("in_neighbors"), t("in_cell_shifts"))
+    finally:
+        rt.config_set("sorted_shortcut", 1)
+    assert torch.equal(a0, a1) and torch.equal(g0, g1)
+    for k in ("rowptr", "nbr", "rev"):
+        assert torch.equal(graph0.csr()[k], graph1.csr()[k]), k
+    gen = torch.Generator().manual_seed(3)
+    n_e = len(g["in_centers"])
+    # 40 extra pairs far beyond the cutoff (an atom with its own image 7 cells away, both directions): dropped
+    far = torch.randint(0, 1000, (20,), generator=gen)
+    i = torch.cat([torch.tensor(g["in_centers"]), far, far])
+    j = torch.cat([torch.tensor(g["in_neighbors"]), far, far])
+    sh = torch.zeros(20, 3, dtype=torch.tensor(g["in_cell_shifts"]).dtype)
+    sh[:, 0] = 7
+    s = torch.cat([torch.tensor(g["in_cell_shifts"]), sh, -sh])
+    perm = torch.randperm(n_e + 40, generator=gen)
+    a2, g2, graph2 = run(i[perm].to(dev), j[perm].to(dev), s[perm].to(dev))
+    assert int(graph2.n_edges) == n_e
+    assert relmax(a2.cpu().numpy(), g["atomic_f64"].ravel()) < TOL and relmax(g2.cpu().numpy(), g["grad_f64"]) < TOL
+    assert relmax(a2.cpu().numpy(), a1.cpu().numpy()) < 2e-6
+
+
 def _adaptive_model(rt, dev, method):
     hypers = dict(opet.DEFAULT_HYPERS, num_neighbors_adaptive=12, adaptive_cutoff_method=method,
                   cutoff_width_adaptive=1.0)
