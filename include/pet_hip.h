@@ -415,6 +415,9 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *   "node_planes" 1 = node-row kernels k_node2 / k_node_bwd2 (coalesced tiles, fp16 planes; default), 0 = k_node / k_swiglu_bwd
  *   "so_trr"      1 = generic training GEMMs with K = 128 or n_out = 128 as TRR kernels (default); 0 = LDS-tile k_gemm_h
  *   "soap_ps_mfma" 1 = SOAP-BPNN power spectrum and its adjoint on the fp32 matrix core (default); 0 = the VALU kernels
+ *   "node_split"  1 = graphs of at most 4 096 atoms: the node update and its adjoint run the four hidden chunks of a 32-row
+ *                 tile on four workgroups (partials through a temporary, the last arrival finishes the tile) -- default;
+ *                 0 = one workgroup per tile
  *   "center_fused" 1 = the node-update kernel also writes the next attention layer's centre tokens (default); 0 = k_center
  *   "sorted_shortcut" 1 = pet_graph_build reads back whether the neighbour list is already ordered by centre with no edge to
  *                 drop and skips the radix sort of the edges if so (default); 0 = always sort

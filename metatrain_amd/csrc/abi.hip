@@ -949,6 +949,7 @@ int pet_config_set(const char* key, int value) {
     else if (k == "node_planes") set_node_planes(value);
     else if (k == "center_fused") set_center_fused(value);
     else if (k == "dxf_fused") set_dxf_fused(value);
+    else if (k == "node_split") set_node_split(value);
     else if (k == "sorted_shortcut") set_sorted_shortcut(value);
     else if (k == "so_trr") set_so_trr(value);
     else if (k == "wgrad_bf16") set_wgrad_bf16(value);

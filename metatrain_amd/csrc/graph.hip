@@ -490,10 +490,11 @@ __global__ void k_csr_fill(const int* __restrict__ perm, const float4* __restric
                            int* __restrict__ sp_nbr, float4* __restrict__ geo,
                            float* __restrict__ d0, float* __restrict__ fc, const int* __restrict__ n_kept_dev,
                            float cutoff, float width, int fn, const float* __restrict__ r_atom,
-                           float* __restrict__ pc) {
+                           float* __restrict__ pc, int* __restrict__ rev) {
     // launched over all input edges: the kept count stays on the device until the single read-back of graph_build
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= *n_kept_dev) return;
+    rev[p] = -1;  // "no partner yet" (k_reverse, k_find_pad_src)
     int e = perm[p];
     float4 v = vin[e];
     int j = neighbors[e];
@@ -515,40 +516,43 @@ __global__ void k_csr_fill(const int* __restrict__ perm, const float4* __restric
 }
 
 // nef.py:88-166 restated as a search in row j (rows hold <= a few dozen edges)
-// Four lanes per edge walk row j in strides of four (a row holds ~20 - 40 edges: the one-lane scan was that many dependent loads).
+// Four lanes per edge walk row j in strides of four (a row holds ~20 - 40 edges: the one-lane scan was that many dependent
+// loads). Only the edge of a pair (p: i -> j, S; q: j -> i, -S) with i < j searches and writes both rev[p] = q and rev[q] = p
+// (i == j, an atom's own image: both search); rev arrives filled with -1 (k_csr_fill), and k_find_pad_src turns what is
+// still -1 -- an edge whose partner is missing -- into the error count and a self reference.
 __global__ void k_reverse(const int* __restrict__ rowptr, const int* __restrict__ ctr,
                           const int* __restrict__ nbr, const int* __restrict__ shift,
                           int* __restrict__ rev, int* __restrict__ scalars) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int p = t >> 2, sub = t & 3;
-    const bool live = p < scalars[0];
+    bool live = p < scalars[0];
     int found = -1;
     if (live) {
         const int i = ctr[p], j = nbr[p];
-        const int sa = -shift[3 * p], sb = -shift[3 * p + 1], sc = -shift[3 * p + 2];
-        // four candidates per lane in flight (clamped to the row: a repeat of its last entry), then the comparisons: a
-        // row of 40 edges is 3 dependent rounds instead of 10
-        const int b = rowptr[j], e = rowptr[j + 1];
-        for (int q0 = b + sub; q0 < e && found < 0; q0 += 16) {
-            int c[4];
+        live = i <= j;
+        if (live) {
+            const int sa = -shift[3 * p], sb = -shift[3 * p + 1], sc = -shift[3 * p + 2];
+            // four candidates per lane in flight (clamped to the row: a repeat of its last entry), then the comparisons:
+            // a row of 40 edges is 3 dependent rounds instead of 10
+            const int b = rowptr[j], e = rowptr[j + 1];
+            for (int q0 = b + sub; q0 < e && found < 0; q0 += 16) {
+                int c[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) c[u] = nbr[min(q0 + 4 * u, e - 1)];
+                for (int u = 0; u < 4; u++) c[u] = nbr[min(q0 + 4 * u, e - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int q = q0 + 4 * u;
-                if (q < e && c[u] == i && shift[3 * q] == sa && shift[3 * q + 1] == sb && shift[3 * q + 2] == sc) found = q;
+                for (int u = 0; u < 4; u++) {
+                    const int q = q0 + 4 * u;
+                    if (q < e && c[u] == i && shift[3 * q] == sa && shift[3 * q + 1] == sb && shift[3 * q + 2] == sc) found = q;
+                }
             }
         }
     }
     found = max(found, __shfl_xor(found, 1));  // at most one lane of the four finds the partner (edges are unique)
     found = max(found, __shfl_xor(found, 2));
-    if (!live || sub != 0) return;
-    // an edge without its (j, i, -S) partner makes graph_build fail (PET_ERR_GRAPH); pointing it at itself keeps every
-    // later gather in bounds whatever the caller does with the error
-    rev[p] = found < 0 ? p : found;
-    if (found < 0) atomicAdd(&scalars[2], 1);
+    if (!live || sub != 0 || found < 0) return;
+    rev[p] = found;
+    rev[found] = p;
 }
-
 // reverse edges inside the all-edge CSR (ctr0 = the sorted keys of the first pass)
 __global__ void k_reverse_all(const int* __restrict__ rowptr0, const int* __restrict__ ctr0,
                               const int* __restrict__ nbr0, const int* __restrict__ shift0, int* __restrict__ rev0,
@@ -633,11 +637,17 @@ __global__ void k_export_edges(const int* __restrict__ perm, const int* __restri
 // CSR position of kept edge 0 (the edge every NEF pad aliases)
 __global__ void k_find_pad_src(const int* __restrict__ perm, const int* __restrict__ kidx,
                                const int* __restrict__ keep, const int* __restrict__ n_kept_dev,
-                               int* __restrict__ out) {
+                               int* __restrict__ out, int* __restrict__ rev, int* __restrict__ n_unpaired) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= *n_kept_dev) return;
     int e = perm[p];
     if (keep[e] && kidx[e] == 0) *out = p;
+    // an edge without its (j, i, -S) partner (k_reverse left -1) makes graph_build fail (PET_ERR_GRAPH); pointing it at
+    // itself keeps every later gather in bounds whatever the caller does with the error
+    if (rev[p] < 0) {
+        rev[p] = p;
+        atomicAdd(n_unpaired, 1);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sum_over_atoms(const float* __restrict__ atomic, const int* __restrict__ sys,
@@ -832,9 +842,9 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
         k_csr_fill<<<cdiv(e0, T), T, 0, st>>>(g.perm, g.vin, centers, neighbors, shifts, g.sp, g.ctr,
                                               g.nbr, g.shift, g.sp_nbr, g.geo, g.d0, g.fc, g.scalars,
                                               m.h.cutoff, m.h.cutoff_width, m.h.cutoff_function,
-                                              g.adaptive ? g.r_atom : nullptr, g.pc);
+                                              g.adaptive ? g.r_atom : nullptr, g.pc, g.rev);
         k_reverse<<<cdiv(4 * (int64_t)e0, T), T, 0, st>>>(g.rowptr, g.ctr, g.nbr, g.shift, g.rev, g.scalars);
-        k_find_pad_src<<<cdiv(e0, T), T, 0, st>>>(g.perm, g.kidx, g.keep, g.scalars, g.scalars + 3);
+        k_find_pad_src<<<cdiv(e0, T), T, 0, st>>>(g.perm, g.kidx, g.keep, g.scalars, g.scalars + 3, g.rev, g.scalars + 2);
     }
     // the per-tile-count atom lists and the attention tile plan serve the PET layers only: a model handle without weights
     // (what the SOAP-BPNN path builds its graphs with; a mirror that runs preprocess before its weights are uploaded)

@@ -257,6 +257,8 @@ void set_trr_compress(int v);
 void set_node_planes(int v);  // pet_fwd.hip / pet_bwd.hip: node-row kernels on pre-split fp16 planes (default 1)
 bool node_planes();
 void set_dxf_fused(int v);     // pet_bwd.hip: 1 = dXF formed inside k_comb_bwd_p2 / k_emlp_bwd_p2 instead of by k_dxf (default)
+void set_node_split(int v);    // pet_fwd.hip: 1 = graphs of <= 4 096 atoms: four workgroups per 32-row tile of the node update (default)
+bool node_split_on();
 void set_center_fused(int v);  // pet_fwd.hip: 1 = k_node2 also writes the next layer's centre tokens (default)
 int node_rows(int64_t N);   // rows per workgroup of the node-row kernels (32: two workgroups per CU; 64)
 struct Graph;

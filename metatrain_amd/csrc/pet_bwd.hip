@@ -336,14 +336,20 @@ __global__ __launch_bounds__(NTHREADS) void k_swiglu_bwd(const float* __restrict
 // on the 16-bit matrix cores (the fp32-MFMA form above spends 46 % of its time in the matrix pipe: 64 cycles per 2 k),
 // everything between the two scalings stays in scaled units; the saved pre-activations arrive as float4 rows through
 // wave-private staging tiles. Inference only (no weight-gradient exports).
-template <int RB>  // 32 RB rows per workgroup (see k_node2)
+// SPLIT (RB = 1): the hidden chunks of a row tile on four workgroups as in k_node2 -- partial dn tiles through Pp (device-
+// coherent stores / loads), the workgroup that arrives last at the tile's counter sums them in chunk order (deterministic;
+// not the bits of the unsplit accumulation, whose chunks interleave their two products) and runs the epilogue.
+template <int RB, bool SPLIT = false>  // 32 RB rows per workgroup (see k_node2)
 __global__ __launch_bounds__(NTHREADS) void k_node_bwd2(const float* __restrict__ dY, const float* __restrict__ Xin,
                                                          const float* __restrict__ VG, const float* __restrict__ gamma,
                                                          WX woutb, WX winb, float* __restrict__ dXout, int64_t R, bool ln,
-                                                         const float4* __restrict__ wceb, float* __restrict__ dOC) {
+                                                         const float4* __restrict__ wceb, float* __restrict__ dOC,
+                                                         float* __restrict__ Pp, int* __restrict__ cnt) {
+    static_assert(!SPLIT || RB == 1, "the hidden-chunk split is built for the 32-row workgroups");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = 256, HID = DNF, LDK = lds_ld(K), LDH = plane_ld(K);
     constexpr int ROWS = 32 * RB, NCH = 4 / RB, WC = 256 / NCH, HC = 128 / NCH, NTH = HC / 32, NTO = WC / 32;
+    constexpr int XD = RB == 1 ? 8 : 2;  // weight blocks in flight (tile.h gemm_acc_x)
     float* A = smem;                                                 // [ROWS][260] dY tile; at the end w = gamma * dn
     float* U = smem;                                                 // [ROWS][132] dv / dg chunk (aliases A while A is dead)
     float* stage = smem + ROWS * LD128;                              // 4 staging tiles (behind U, inside A)
@@ -363,15 +369,36 @@ __global__ __launch_bounds__(NTHREADS) void k_node_bwd2(const float* __restrict_
     __syncthreads();  // A is dead until the epilogue
     f32x16 dn[NTO];
     acc_fill_bias<NTO>(dn, nullptr, 0, w.lane);
+    const int hc_lo = SPLIT ? (int)blockIdx.y : 0, hc_hi = SPLIT ? (int)blockIdx.y + 1 : HID / 128;
 #pragma unroll 1
-    for (int hc = 0; hc < HID / 128; hc++) {
+    for (int hc = hc_lo; hc < hc_hi; hc++) {
         f32x16 du[NTH];
         acc_fill_bias<NTH>(du, nullptr, 0, w.lane);
         const int hcol0 = 128 * hc + HC * w.ch;
-        gemm_acc_hs<K, NTH, 8>(Ph + w.rb * 32 * LDH, Pl + w.rb * 32 * LDH, LDH, woutb, K / 8, 0, hcol0 / 32, du, w.lane);
+        // RB == 1 (small graphs, one wave per SIMD, every product starts with an exposed round trip): the K = 128 operands of
+        // this chunk's two dn products and its saved [v | g] rows are requested around the du product instead of after it
+        XRing<NTO, 8> r1, r2;
+        const bool ring = RB == 1 && winb.h != nullptr;
+        float4 vpre[4], gpre[4];
+        if constexpr (RB == 1) {
+            if (ring) xring_request(r1, winb, 2 * HID / 8, 16 * hc, NTO * w.ch, w.lane);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int64_t rr = wrow0 + 8 * j + (w.lane >> 3);
+                const float* p = VG + (rr < R ? rr : R - 1) * (2 * HID) + hcol0 + 4 * (w.lane & 7);
+                vpre[j] = *reinterpret_cast<const float4*>(p);
+                gpre[j] = *reinterpret_cast<const float4*>(p + HID);
+                if (rr >= R) vpre[j] = gpre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        gemm_acc_hs<K, NTH, (RB == 1 ? 4 : 8)>(Ph + w.rb * 32 * LDH, Pl + w.rb * 32 * LDH, LDH, woutb, K / 8, 0, hcol0 / 32, du, w.lane);
+        if (ring) xring_request(r2, winb, 2 * HID / 8, HID / 8 + 16 * hc, NTO * w.ch, w.lane);
         float sg[NTH][16], vv[NTH][16];
         auto vg_rows = [&](int off) {
             return [&, off](int r, int cc, float4& v) {
+                if constexpr (RB == 1) {
+                    v = off ? gpre[r >> 3] : vpre[r >> 3];  // r = 8 j + (lane >> 3), cc = 4 (lane & 7): the mapping of the request
+                } else
                 v = wrow0 + r < R ? *reinterpret_cast<const float4*>(VG + (wrow0 + r) * (2 * HID) + off + hcol0 + cc)
                                   : make_float4(0.f, 0.f, 0.f, 0.f);
             };
@@ -397,7 +424,8 @@ __global__ __launch_bounds__(NTHREADS) void k_node_bwd2(const float* __restrict_
             for (int r = 0; r < 16; r++)
                 U[(w.rb * 32 + acc_row(r, w.lane)) * LD128 + HC * w.ch + 32 * t + (w.lane & 31)] = du[t][r] * sg[t][r];  // dv
         __syncthreads();
-        gemm_acc_x<128, NTO>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, 16 * hc, NTO * w.ch, dn, w.lane);
+        if (ring) gemm_acc_x_ring<NTO, 8>(U + w.rb * 32 * LD128, LD128, r1, dn, w.lane);
+        else gemm_acc_x<128, NTO, XD>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, 16 * hc, NTO * w.ch, dn, w.lane);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < NTH; t++)
@@ -406,9 +434,47 @@ __global__ __launch_bounds__(NTHREADS) void k_node_bwd2(const float* __restrict_
                 U[(w.rb * 32 + acc_row(r, w.lane)) * LD128 + HC * w.ch + 32 * t + (w.lane & 31)] =
                     du[t][r] * vv[t][r] * sigmoid_grad_from(sg[t][r]);  // dg
         __syncthreads();
-        gemm_acc_x<128, NTO>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, HID / 8 + 16 * hc, NTO * w.ch, dn, w.lane);
+        if (ring) gemm_acc_x_ring<NTO, 8>(U + w.rb * 32 * LD128, LD128, r2, dn, w.lane);
+        else gemm_acc_x<128, NTO, XD>(U + w.rb * 32 * LD128, LD128, winb, 2 * HID / 8, HID / 8 + 16 * hc, NTO * w.ch, dn, w.lane);
     }
     __syncthreads();  // everyone is done with U: A takes w = gamma * dn (back in true units)
+    if constexpr (SPLIT) {
+        __shared__ int last_arrival;
+        constexpr int NCHK = HID / 128, IT = ROWS * (K / 4) / NTHREADS;
+        const size_t prows = (size_t)gridDim.x * ROWS;
+#pragma unroll
+        for (int t = 0; t < NTO; t++)
+            wave_rows32(dn[t], my_stage, w.lane, [&](int r, int cc, float4 v) {
+                st4_agent(Pp + ((size_t)blockIdx.y * prows + (wrow0 + r)) * K + WC * w.ch + 32 * t + cc, v);
+            });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the coherent stores are acknowledged (k_node2)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int old = atomicAdd(&cnt[blockIdx.x], 1);
+            last_arrival = old == NCHK - 1;
+            if (last_arrival) cnt[blockIdx.x] = 0;
+        }
+        __syncthreads();
+        if (!last_arrival) return;
+        float4 pk[IT][NCHK];
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int idx = threadIdx.x + it * NTHREADS, r = idx / (K / 4), c = 4 * (idx % (K / 4));
+#pragma unroll
+            for (int k = 0; k < NCHK; k++) pk[it][k] = ld4_agent(Pp + ((size_t)k * prows + row0 + r) * K + c);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int idx = threadIdx.x + it * NTHREADS, r = idx / (K / 4), c = 4 * (idx % (K / 4));
+            float4 sum = pk[it][0];
+#pragma unroll
+            for (int k = 1; k < NCHK; k++)
+                sum = make_float4(sum.x + pk[it][k].x, sum.y + pk[it][k].y, sum.z + pk[it][k].z, sum.w + pk[it][k].w);
+            const float sc = rs[2 * r + 1];
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+            *reinterpret_cast<float4*>(A + r * LDK + c) = make_float4(sum.x * sc * ga.x, sum.y * sc * ga.y, sum.z * sc * ga.z, sum.w * sc * ga.w);
+        }
+    } else
     acc_foreach<NTO>(dn, w.rb, WC * w.ch, w.lane, [&](int r, int c, float v) { A[r * LDK + c] = v * rs[2 * r + 1] * gamma[c]; });
     __syncthreads();
     // dOC = dH1 Wce (k_expand_bwd's GEMM) from the dH1 tile while it is on chip, when the caller passes dOC: one launch less
@@ -1120,6 +1186,7 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     const bool trr_l = trr && m.plain_layers();  // the TRR transformer-layer kernels are PreLN (RMSNorm or LayerNorm)
     const bool fused_attn = trr_l && !tr && ablk_bwd_on(g) && m.gnn[0].attn[0].qkv.bwd2s;
     // k_dxf folded into its producer and its consumer (pet_config_set("dxf_fused", 0): the separate kernel)
+    bool node_cnt_zeroed = false;  // k_node_bwd2 SPLIT: arrival counters zeroed once per adjoint, then they reset themselves
     const bool dxf_fused = trr_l && !tr && !res && !g.x_fn && m.h.num_attention_layers >= 1 && dxf_fused_on();
     PET_HIP_CHECK(hipMemsetAsync(w.dgeo, 0, E * 4 * sizeof(float), st));
     allow_big_lds(k_swiglu_bwd<256, DNF, false, true>, (BM * LD256 + BM * LD128) * 4);
@@ -1189,15 +1256,28 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 if (!tr && node_planes() && wob.h && wib.h) {
                     const int nr = node_rows(N);
                     const size_t lds_nb = (size_t)nr * LD256 * 4 + (size_t)2 * nr * plane_ld(256) * 2 + nr * 8;
-                    if (nr == 32) {  // small graphs: the expansion adjoint in the same launch
+                    // small graphs: four workgroups per row tile (k_node_bwd2, SPLIT); partials and arrival counters in the
+                    // attention-output temporary of the forward pass, which no adjoint kernel touches
+                    const int nt32 = cdiv(N, 32);
+                    const size_t p_floats = (size_t)(DNF / 128) * nt32 * 32 * DN;
+                    const bool split = nr == 32 && node_split_on() && nt32 <= 128 && p_floats + nt32 <= (size_t)R * D;
+                    if (split) {
+                        int* cnt = reinterpret_cast<int*>(w.AO + p_floats);
+                        if (!node_cnt_zeroed) PET_HIP_CHECK(hipMemsetAsync(cnt, 0, nt32 * sizeof(int), s2));
+                        node_cnt_zeroed = true;
+                        allow_big_lds(k_node_bwd2<1, true>, lds_nb);
+                        k_node_bwd2<1, true><<<dim3(nt32, DNF / 128), NTHREADS, lds_nb, s2>>>(
+                            dH, Ab.H1, Ab.VGn, A.g_center, wob, wib, dH_alt, N, ln, A.ce.bwd, w.dOC, w.AO, cnt);
+                        expand_done = true;
+                    } else if (nr == 32) {  // the expansion adjoint in the same launch
                         allow_big_lds(k_node_bwd2<1>, lds_nb);
                         k_node_bwd2<1><<<cdiv(N, 32), NTHREADS, lds_nb, s2>>>(dH, Ab.H1, Ab.VGn, A.g_center, wob, wib, dH_alt, N, ln,
-                                                                             A.ce.bwd, w.dOC);
+                                                                             A.ce.bwd, w.dOC, nullptr, nullptr);
                         expand_done = true;
                     } else {
                         allow_big_lds(k_node_bwd2<2>, lds_nb);
                         k_node_bwd2<2><<<gN, NTHREADS, lds_nb, s2>>>(dH, Ab.H1, Ab.VGn, A.g_center, wob, wib, dH_alt, N, ln,
-                                                                     nullptr, nullptr);
+                                                                     nullptr, nullptr, nullptr, nullptr);
                     }
                 } else
                 PET_LAUNCH_TR(tr, k_swiglu_bwd, PET_TA(256, DNF), gN, (BM * LD256 + BM * LD128) * 4, s2,  dH, Ab.H1,

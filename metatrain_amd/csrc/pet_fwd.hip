@@ -420,7 +420,13 @@ __global__ __launch_bounds__(NTHREADS) void k_node(const float* __restrict__ H, 
 // the four waves own a quarter of the columns each and two workgroups share a CU (67 KB): half the dependent chain per
 // wave and a second workgroup to fill its stalls -- the node chain sits on the critical path of a small box (one
 // k_node2 per attention layer between the output projection and the next layer's centre tokens).
-template <int RB>
+// SPLIT (RB = 1, graphs of at most 128 row tiles): the four 128-unit chunks of the hidden layer go to four workgroups
+// (blockIdx.y) -- a workgroup of a small graph is alone on its CU and its time is the round trips of the 1.8 MB of weights it
+// streams (bytes in flight / latency = 25 GB/s per CU), so four CUs per row tile stream a quarter each. Every workgroup
+// forms h1 and its planes, runs its chunk and leaves a partial [32 x 256] output in Pp; the one that arrives last at the
+// tile's counter (fence + atomic, the counter resets itself) adds bias and partials in chunk order -- the order of the
+// unsplit accumulation, so the same bits whoever is last -- and finishes (Hn, the next layer's centre tokens).
+template <int RB, bool SPLIT = false>
 __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H, const float* __restrict__ OC,
                                                      WX wce, const float* __restrict__ bce,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, WX win,
@@ -428,11 +434,14 @@ __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H,
                                                      const float* __restrict__ bout,
                                                      float* __restrict__ H1, float* __restrict__ VGn,
                                                      float* __restrict__ Hn, int64_t N, WX wcn,
-                                                     const float* __restrict__ bcn, float* __restrict__ Xcn) {
+                                                     const float* __restrict__ bcn, float* __restrict__ Xcn,
+                                                     float* __restrict__ Pp, int* __restrict__ cnt) {
+    static_assert(!SPLIT || RB == 1, "the hidden-chunk split is built for the 32-row workgroups");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 32 * RB, NCH = 4 / RB;      // rows per workgroup, column groups
     constexpr int WC = 256 / NCH, HC = 128 / NCH;    // output columns / hidden columns (per 128-chunk) of one wave
     constexpr int NTH = HC / 32, NTO = WC / 32;
+    constexpr int XD = RB == 1 ? 8 : 2;  // weight blocks in flight in the products that split their A operand on the fly
     constexpr int LDH = plane_ld(256);
     float* Hs = smem;                                                  // [ROWS][260] h, then h1, then dead
     float* U = smem;                                                   // [ROWS][132] SwiGLU chunk (aliases Hs)
@@ -454,27 +463,40 @@ __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H,
         f32x16 acc[2];
         const int col0 = 64 * (NCH * c + w.ch);
         acc_fill_bias<2>(acc, bce, col0, w.lane);
-        gemm_acc_x<128, 2>(OCs + w.rb * 32 * LD128, LD128, wce, 16, 0, col0 / 32, acc, w.lane, rs + 64 * w.rb);
+        gemm_acc_x<128, 2, XD>(OCs + w.rb * 32 * LD128, LD128, wce, 16, 0, col0 / 32, acc, w.lane, rs + 64 * w.rb);
         acc_foreach<2>(acc, w.rb, col0, w.lane, [&](int r, int cc, float v) { Hs[r * LD256 + cc] += v; });  // h1 = h + ...
     }
     __syncthreads();
-    store_rows_from_lds<256, ROWS>(Hs, H1, row0, N, DN);
+    if constexpr (SPLIT) {  // (read again by whichever workgroup finishes the tile)
+        if (blockIdx.y == 0) store_rows_from_lds_agent<256, ROWS>(Hs, H1, row0, N, DN);
+    } else store_rows_from_lds<256, ROWS>(Hs, H1, row0, N, DN);
     __syncthreads();
     norm_rows_inplace<256, ROWS>(Hs, gamma, beta);
     __syncthreads();
     split_tile_planes<256, ROWS>(Hs, LD256, Ph, Pl);
     __syncthreads();  // Hs is dead from here on: U and the staging tiles reuse its memory
     f32x16 out[NTO];  // this wave: 32 rows x WC columns (WC * ch ..)
-    acc_fill_bias<NTO>(out, bout, WC * w.ch, w.lane);
+    acc_fill_bias<NTO>(out, SPLIT ? nullptr : bout, WC * w.ch, w.lane);
     const int64_t wrow0 = row0 + 32 * w.rb;  // first row of this wave's block
+    const int hc_lo = SPLIT ? (int)blockIdx.y : 0, hc_hi = SPLIT ? (int)blockIdx.y + 1 : DNF / 128;
 #pragma unroll 1
-    for (int hc = 0; hc < DNF / 128; hc++) {
+    for (int hc = hc_lo; hc < hc_hi; hc++) {
         f32x16 av[NTH], ag[NTH];
         const int hcol0 = 128 * hc + HC * w.ch;  // hidden columns of this wave
         acc_fill_bias<NTH>(av, bin, hcol0, w.lane);
         acc_fill_bias<NTH>(ag, bin, DNF + hcol0, w.lane);
+        XRing<NTO, 8> ro;  // RB == 1: this chunk's K = 128 operand of the output product, requested before the hidden products
+        const bool ring = RB == 1 && wout.h != nullptr;
+        if (ring) xring_request(ro, wout, DNF / 8, 16 * hc, NTO * w.ch, w.lane);
+        if constexpr (RB == 1) {  // value and gate tile in ONE product (one exposed round trip instead of two); same MFMA order per tile
+            f32x16 vg[2] = {av[0], ag[0]};
+            gemm_acc_hs<256, 2, 4>(Ph + w.rb * 32 * LDH, Pl + w.rb * 32 * LDH, LDH, win, 32, 0, hcol0 / 32, vg, w.lane, DNF / 32);
+            av[0] = vg[0];
+            ag[0] = vg[1];
+        } else {
         gemm_acc_hs<256, NTH, 8>(Ph + w.rb * 32 * LDH, Pl + w.rb * 32 * LDH, LDH, win, 32, 0, hcol0 / 32, av, w.lane);
         gemm_acc_hs<256, NTH, 8>(Ph + w.rb * 32 * LDH, Pl + w.rb * 32 * LDH, LDH, win, 32, 0, (DNF + hcol0) / 32, ag, w.lane);
+        }
         if (VGn) {  // saved for the adjoint: [value | gate] pre-activations, whole float4 rows
             if constexpr (RB == 2) {
                 wave_rows64(av, my_stage, w.lane, [&](int r, int cc, float4 v) {
@@ -499,12 +521,58 @@ __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H,
             for (int r = 0; r < 16; r++)  // transformer.py:42-43: value * sigmoid(gate)
                 U[(w.rb * 32 + acc_row(r, w.lane)) * LD128 + HC * w.ch + 32 * t + (w.lane & 31)] = av[t][r] * sigmoidf_(ag[t][r]);
         __syncthreads();
-        gemm_acc_x<128, NTO>(U + w.rb * 32 * LD128, LD128, wout, DNF / 8, 16 * hc, NTO * w.ch, out, w.lane);
+        if (ring) gemm_acc_x_ring<NTO, 8>(U + w.rb * 32 * LD128, LD128, ro, out, w.lane);
+        else gemm_acc_x<128, NTO, XD>(U + w.rb * 32 * LD128, LD128, wout, DNF / 8, 16 * hc, NTO * w.ch, out, w.lane);
     }
     // Xcn: the NEXT attention layer's centre tokens = center_contraction(Hn) (transformer.py:211-214) from the Hn tile while
     // it is on chip (k_center's arithmetic: power-of-two row scales, the same GEMM) -- one launch and one stream hand-over
     // less per layer on the critical path of a small box
     float* Hn_s = smem + ROWS * LD256;  // [ROWS][260]: over the planes, which nobody reads after the last hidden chunk
+    if constexpr (SPLIT) {
+        __shared__ int last_arrival;
+        const size_t prows = (size_t)gridDim.x * ROWS;  // rows of one partial (whole tiles)
+#pragma unroll
+        for (int t = 0; t < NTO; t++)
+            wave_rows32(out[t], my_stage, w.lane, [&](int r, int cc, float4 v) {
+                st4_agent(Pp + ((size_t)blockIdx.y * prows + (wrow0 + r)) * DN + WC * w.ch + 32 * t + cc, v);
+            });
+        // the partial (and h1) went out as device-coherent stores: once they are acknowledged (the workgroup-scope release
+        // waits for that) the workgroup may be counted -- no L2 write-back fence, which costs 10+ us with a step's dirty lines
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int old = atomicAdd(&cnt[blockIdx.x], 1);
+            last_arrival = old == (int)gridDim.y - 1;
+            if (last_arrival) cnt[blockIdx.x] = 0;  // ready for the next launch on this stream
+        }
+        __syncthreads();
+        if (!last_arrival) return;
+        // every load of the reduction in flight before the first sum (8 positions x (4 partials + h1) per thread)
+        constexpr int IT = ROWS * (DN / 4) / NTHREADS, NCHK = DNF / 128;
+        float4 pk[IT][NCHK], h1v[IT];
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int idx = threadIdx.x + it * NTHREADS, r = idx / (DN / 4), c = 4 * (idx % (DN / 4));
+#pragma unroll
+            for (int k = 0; k < NCHK; k++) pk[it][k] = ld4_agent(Pp + ((size_t)k * prows + row0 + r) * DN + c);
+            h1v[it] = ld4_agent(H1 + (row0 + r < N ? row0 + r : N - 1) * DN + c);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int idx = threadIdx.x + it * NTHREADS, r = idx / (DN / 4), c = 4 * (idx % (DN / 4));
+            float4 sum = *reinterpret_cast<const float4*>(bout + c);
+#pragma unroll
+            for (int k = 0; k < NCHK; k++)  // ((((b + chunk 0) + chunk 1) + chunk 2) + chunk 3): the unsplit order
+                sum = make_float4(sum.x + pk[it][k].x, sum.y + pk[it][k].y, sum.z + pk[it][k].z, sum.w + pk[it][k].w);
+            const int64_t row = row0 + r;
+            float4 hn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < N) {
+                hn = make_float4(h1v[it].x + sum.x, h1v[it].y + sum.y, h1v[it].z + sum.z, h1v[it].w + sum.w);
+                *reinterpret_cast<float4*>(Hn + row * DN + c) = hn;
+            }
+            if (Xcn) *reinterpret_cast<float4*>(Hn_s + r * LD256 + c) = hn;
+        }
+    } else {
     if (Xcn) __syncthreads();
     auto add_h1 = [&](int col) {  // Hn = h1 + MLP
         return [&, col](int r, int cc, float4 v) {
@@ -529,6 +597,7 @@ __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H,
 #pragma unroll
         for (int t = 0; t < NTO; t++) wave_rows32(out[t], my_stage, w.lane, add_h1(WC * w.ch + 32 * t));
     }
+    }
     if (Xcn) {
         constexpr int NTC = RB;  // 128 centre-token columns over the NCH column groups
         __syncthreads();
@@ -536,7 +605,7 @@ __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H,
         __syncthreads();
         f32x16 cacc[NTC];
         acc_fill_bias<NTC>(cacc, bcn, 32 * NTC * w.ch, w.lane);
-        gemm_acc_x<256, NTC>(Hn_s + w.rb * 32 * LD256, LD256, wcn, 32, 0, NTC * w.ch, cacc, w.lane, rs + 64 * w.rb);
+        gemm_acc_x<256, NTC, XD>(Hn_s + w.rb * 32 * LD256, LD256, wcn, 32, 0, NTC * w.ch, cacc, w.lane, rs + 64 * w.rb);
         store_acc<NTC>(cacc, Xcn, row0, N, D, w.rb, 32 * NTC * w.ch, w.lane);
     }
 }
@@ -798,6 +867,9 @@ static void note_workspace(const Graph& g, const void* ws, bool generic) {
     g.fwd_generic = generic;
 }
 
+static int g_node_split = 1;  // pet_config_set("node_split", 0): one workgroup per 32-row tile in k_node2<1> / k_node_bwd2<1>
+void set_node_split(int v) { g_node_split = v ? 1 : 0; }
+bool node_split_on() { return g_node_split != 0; }
 static int g_center_fused = 1;  // pet_config_set("center_fused", 0): the next layer's centre tokens by their own k_center launch
 void set_center_fused(int v) { g_center_fused = v ? 1 : 0; }
 static int g_node_planes = 1;  // k_node2 / k_node_bwd2: A tiles pre-split into fp16 planes (pet_config_set("node_planes", 0): k_node)
@@ -897,6 +969,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
     ss.fork(st);
     launch_center(0, 0);
     side_busy = true;
+    bool node_cnt_zeroed = false;  // k_node2 SPLIT: the arrival counters are zeroed once per forward, then reset themselves
     for (int gi = 0; gi < L; gi++) {
         const GnnLayerW& G = m.gnn[gi];
         GnnBufs& B = w.gnn[gi];
@@ -984,16 +1057,29 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                         wcn = wx_fwd(An.cc, 2);
                         if (wcn.h && Abn.H == Ab.Hn) { bcn = An.cc.b; xcn = Abn.X + E * D; center_done = true; }
                     }
-                    if (nr == 32) {
+                    // small graphs: the hidden chunks of a row tile on four workgroups; partial outputs and the tiles'
+                    // arrival counters live in dQKV, which only the adjoint uses (k_node2, SPLIT)
+                    const int nt32 = cdiv(N, 32);
+                    const size_t p_floats = (size_t)(DNF / 128) * nt32 * 32 * DN;
+                    const bool split = nr == 32 && node_split_on() && nt32 <= 128 && p_floats + nt32 <= (size_t)R * 3 * D;
+                    if (split) {
+                        int* cnt = reinterpret_cast<int*>(w.dQKV + p_floats);
+                        if (!node_cnt_zeroed) PET_HIP_CHECK(hipMemsetAsync(cnt, 0, nt32 * sizeof(int), s2));
+                        node_cnt_zeroed = true;
+                        allow_big_lds(k_node2<1, true>, lds_n2);
+                        k_node2<1, true><<<dim3(nt32, DNF / 128), NTHREADS, lds_n2, s2>>>(
+                            Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci, A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn,
+                            Ab.Hn, N, wcn, bcn, xcn, w.dQKV, cnt);
+                    } else if (nr == 32) {
                         allow_big_lds(k_node2<1>, lds_n2);
                         k_node2<1><<<cdiv(N, 32), NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci,
                                                                          A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N,
-                                                                         wcn, bcn, xcn);
+                                                                         wcn, bcn, xcn, nullptr, nullptr);
                     } else {
                         allow_big_lds(k_node2<2>, lds_n2);
                         k_node2<2><<<gN, NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci,
                                                                  A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N, wcn, bcn,
-                                                                 xcn);
+                                                                 xcn, nullptr, nullptr);
                     }
                 } else
                 k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, s2>>>(

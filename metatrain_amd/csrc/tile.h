@@ -95,7 +95,9 @@ struct WX {
     const f16x8_t* h = nullptr;
     const f16x8_t* l = nullptr;
 };
-template <int KS, int NT>
+// DEPTH weight blocks (K = 16 each) in flight: 2 where many workgroups share a CU; the 32-row kernels of small graphs, where
+// one wave per SIMD has to cover the L2 round trip by itself, take 8 (a whole K = 128 operand requested at once).
+template <int KS, int NT, int DEPTH = 2>
 __device__ __forceinline__ void gemm_acc_x(const float* As, int lda, const WX& w, int kg_total, int kg0, int tile0,
                                            f32x16 (&acc)[NT], int lane, const float* rscale = nullptr) {
     if (w.h == nullptr) {
@@ -103,26 +105,28 @@ __device__ __forceinline__ void gemm_acc_x(const float* As, int lda, const WX& w
         return;
     }
     constexpr int KB = KS / 16;
+    static_assert(KB % DEPTH == 0, "the ring index must be static");
     const int kb_total = kg_total / 2, kb0 = kg0 / 2;
     const float* arow = As + (lane & 31) * lda + (lane >> 5) * 4;
     const float sc = rscale ? rscale[2 * (lane & 31)] : 1.0f;
     size_t base[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) base[t] = ((size_t)(tile0 + t) * kb_total + kb0) * 64 + lane;
-    f16x8_t wh[2][NT], wl[2][NT];
+    f16x8_t wh[DEPTH][NT], wl[DEPTH][NT];
 #pragma unroll
-    for (int s = 0; s < 2; s++)
-        if (s < KB)
+    for (int s = 0; s < DEPTH; s++)
 #pragma unroll
-            for (int t = 0; t < NT; t++) { wh[s][t] = w.h[base[t] + s * 64]; wl[s][t] = w.l[base[t] + s * 64]; }
+        for (int t = 0; t < NT; t++) { wh[s][t] = w.h[base[t] + s * 64]; wl[s][t] = w.l[base[t] + s * 64]; }
     f32x16 ah[NT], al[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) { ah[t][r] = 0.f; al[t][r] = 0.f; }
-#pragma unroll 2
-    for (int kb = 0; kb < KB; kb++) {
-        const int cur = kb & 1;
+#pragma unroll 1
+    for (int kb0i = 0; kb0i < KB; kb0i += DEPTH)
+#pragma unroll
+    for (int cur = 0; cur < DEPTH; cur++) {
+        const int kb = kb0i + cur;
         const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * kb);
         const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * kb + 8);
         const float v[8] = {a0.x * sc, a0.y * sc, a0.z * sc, a0.w * sc, a1.x * sc, a1.y * sc, a1.z * sc, a1.w * sc};
@@ -139,12 +143,68 @@ __device__ __forceinline__ void gemm_acc_x(const float* As, int lda, const WX& w
         for (int t = 0; t < NT; t++) ah[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh[cur][t], ah[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < NT; t++) al[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh[cur][t], al[t], 0, 0, 0);
-        if (kb + 2 < KB)
+        if (kb + DEPTH < KB)
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                wh[cur][t] = w.h[base[t] + (kb + 2) * 64];
-                wl[cur][t] = w.l[base[t] + (kb + 2) * 64];
+                wh[cur][t] = w.h[base[t] + (kb + DEPTH) * 64];
+                wl[cur][t] = w.l[base[t] + (kb + DEPTH) * 64];
             }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float v = ah[t][r] + al[t][r] * (1.0f / 2048.0f);
+            acc[t][r] += rscale ? v * rscale[2 * acc_row(r, lane) + 1] : v;
+        }
+}
+// The same product with the WHOLE weight operand (K = 16 DEPTH) requested ahead of time: a 32-row workgroup of a small graph
+// runs one wave per SIMD, every product starts with an exposed L2 / MALL round trip, and the operand of the NEXT product can
+// be requested before the current one starts (k_node2<1>, k_node_bwd2<1>). Same MFMA order as gemm_acc_x: same bits.
+template <int NT, int DEPTH>
+struct XRing {
+    f16x8_t wh[DEPTH][NT], wl[DEPTH][NT];
+};
+template <int NT, int DEPTH>
+__device__ __forceinline__ void xring_request(XRing<NT, DEPTH>& R, const WX& w, int kg_total, int kg0, int tile0, int lane) {
+    const int kb_total = kg_total / 2, kb0 = kg0 / 2;
+#pragma unroll
+    for (int s = 0; s < DEPTH; s++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const size_t i = ((size_t)(tile0 + t) * kb_total + kb0 + s) * 64 + lane;
+            R.wh[s][t] = w.h[i];
+            R.wl[s][t] = w.l[i];
+        }
+}
+template <int NT, int DEPTH>
+__device__ __forceinline__ void gemm_acc_x_ring(const float* As, int lda, const XRing<NT, DEPTH>& R, f32x16 (&acc)[NT],
+                                                int lane, const float* rscale = nullptr) {
+    const float* arow = As + (lane & 31) * lda + (lane >> 5) * 4;
+    const float sc = rscale ? rscale[2 * (lane & 31)] : 1.0f;
+    f32x16 ah[NT], al[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { ah[t][r] = 0.f; al[t][r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < DEPTH; kb++) {
+        const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * kb);
+        const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * kb + 8);
+        const float v[8] = {a0.x * sc, a0.y * sc, a0.z * sc, a0.w * sc, a1.x * sc, a1.y * sc, a1.z * sc, a1.w * sc};
+        f16x8_t xh, xl;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const _Float16 hj = (_Float16)v[j];
+            xh[j] = hj;
+            xl[j] = (_Float16)((v[j] - (float)hj) * 2048.0f);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) al[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, R.wl[kb][t], al[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) ah[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, R.wh[kb][t], ah[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) al[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, R.wh[kb][t], al[t], 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < NT; t++)
@@ -168,14 +228,14 @@ __device__ __forceinline__ int plane_pos(int k) {
 // covered by this wave's own MFMAs (96 cycles per block and tile).
 template <int KS, int NT, int DEPTH = 2>
 __device__ __forceinline__ void gemm_acc_hs(const _Float16* Ah, const _Float16* Al, int ldh, const WX& w, int kg_total,
-                                            int kg0, int tile0, f32x16 (&acc)[NT], int lane) {
+                                            int kg0, int tile0, f32x16 (&acc)[NT], int lane, int tstride = 1) {
     constexpr int KB = KS / 16;
     static_assert(KB % DEPTH == 0, "the ring index must be static");
     const int kb_total = kg_total / 2, kb0 = kg0 / 2;
     const int roff = (lane & 31) * ldh + (lane >> 5) * 8;
-    size_t base[NT];
+    size_t base[NT];  // output tile t = tile0 + t tstride (tstride != 1: e.g. the value and the gate columns of one hidden tile)
 #pragma unroll
-    for (int t = 0; t < NT; t++) base[t] = ((size_t)(tile0 + t) * kb_total + kb0) * 64 + lane;
+    for (int t = 0; t < NT; t++) base[t] = ((size_t)(tile0 + t * tstride) * kb_total + kb0) * 64 + lane;
     f16x8_t wh[DEPTH][NT], wl[DEPTH][NT];
 #pragma unroll
     for (int s = 0; s < DEPTH; s++)
@@ -302,6 +362,32 @@ __device__ __forceinline__ void store_rows_from_lds(const float* As, float* __re
         const int r = idx / C4, c = idx % C4;
         if (row0 + r < n_rows)
             *reinterpret_cast<float4*>(G + (row0 + r) * ld_g + 4 * c) = *reinterpret_cast<const float4*>(As + r * LDA + 4 * c);
+    }
+}
+
+// Device-coherent accesses (relaxed atomics at agent scope: they pass the per-XCD L2 without a cache write-back / invalidate
+// fence) for data one workgroup hands to another inside a kernel (k_node2 / k_node_bwd2, SPLIT)
+__device__ __forceinline__ void st4_agent(float* p, float4 v) {
+    __hip_atomic_store(p, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 ld4_agent(const float* cp) {
+    float* p = const_cast<float*>(cp);
+    return make_float4(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <int K, int ROWS = BM>
+__device__ __forceinline__ void store_rows_from_lds_agent(const float* As, float* __restrict__ G, int64_t row0, int64_t n_rows,
+                                                          int ld_g) {
+    constexpr int C4 = K / 4;
+    constexpr int LDA = lds_ld(K);
+    for (int idx = threadIdx.x; idx < ROWS * C4; idx += NTHREADS) {
+        const int r = idx / C4, c = idx % C4;
+        if (row0 + r < n_rows) st4_agent(G + (row0 + r) * ld_g + 4 * c, *reinterpret_cast<const float4*>(As + r * LDA + 4 * c));
     }
 }
 

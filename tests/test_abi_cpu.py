@@ -125,5 +125,5 @@ def test_config_switches_of_removed_kernel_generations_are_rejected(lib):
         assert lib.pet_config_set(key, 0) == -3, key
     for key, default in ((b"trr", 1), (b"attn_lds", 3), (b"attn_fused", 3), (b"tile_f16x3", 1), (b"trr_compress", 3),
                          (b"node_planes", 1), (b"so_trr", 1), (b"so_f16x3", 1), (b"wgrad_bf16", 1), (b"side_stream", 1),
-                         (b"center_fused", 1), (b"dxf_fused", 1), (b"sorted_shortcut", 1), (b"train_bf16", 0), (b"soap_ps_mfma", 1)):
+                         (b"center_fused", 1), (b"dxf_fused", 1), (b"node_split", 1), (b"sorted_shortcut", 1), (b"train_bf16", 0), (b"soap_ps_mfma", 1)):
         assert lib.pet_config_set(key, default) == 0, key

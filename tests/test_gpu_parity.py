@@ -470,6 +470,22 @@ def test_edge_order_and_the_sort_shortcut(rt, model, dev, golden_dir):
     assert relmax(a2.cpu().numpy(), a1.cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("drop", ["i<j", "i>j"])
+def test_half_neighbour_list_is_reported(rt, model, dev, golden_dir, drop):
+    """Every kept edge needs its (j, i, -S) partner (nef.py:88-166 has the same precondition). Only the edge of a pair with
+    i <= j searches for it (k_reverse), so both ways of losing partners are covered: three edges with i < j removed leave
+    their i > j partners unpaired, and the other way round; the count in the message is exact."""
+    g = _load(golden_dir, "pet_default_box64.npz")
+    i, j = np.asarray(g["in_centers"]), np.asarray(g["in_neighbors"])
+    pick = np.nonzero(i < j if drop == "i<j" else i > j)[0][[0, 7, 19]]
+    keep = np.ones(len(i), bool)
+    keep[pick] = False
+    t = lambda k: torch.tensor(g[k]).to(dev)  # noqa: E731
+    with pytest.raises(Exception, match="3 kept edges have no reverse edge"):
+        rt.HipGraph(model, t("in_positions").float(), t("in_cells").float(), t("in_centers")[keep], t("in_neighbors")[keep],
+                    t("in_cell_shifts")[keep], t("in_species"), t("in_system_indices").int())
+
+
 def _adaptive_model(rt, dev, method):
     hypers = dict(opet.DEFAULT_HYPERS, num_neighbors_adaptive=12, adaptive_cutoff_method=method,
                   cutoff_width_adaptive=1.0)
@@ -612,14 +628,14 @@ def test_unknown_species_is_an_error_not_an_out_of_bounds_read(rt, model, dev):
 
 
 @pytest.mark.parametrize("switch", ["trr", "attn_fused=0", "attn_lds=1", "side_stream", "tile_f16x3", "trr_compress", "node_planes",
-                                    "node_planes=2", "node_planes=3", "center_fused", "dxf_fused"])
+                                    "node_planes=2", "node_planes=3", "center_fused", "dxf_fused", "node_split"])
 def test_alternative_kernel_paths_agree(rt, model, dev, golden_dir, switch):
     """The fallbacks behind ``pet_config_set``: the LDS-tile kernels (trr=0, also the transformer-layer path of PostLN models;
     on fp32 MFMA with tile_f16x3=0), the three-kernel attention form (attn_fused=0: QKV / attention / projection with Q, K, V
     in HBM -- what the training forward and graphs with many atoms of more than 32 tokens run; with attn_lds=1 its
     per-atom staged adjoint instead of the persistent LDS-DMA one), a single stream (side_stream=0), the node-row kernels
     with 32 / 64 rows per workgroup (node_planes = 2 / 3; by default 32 up to 16 384 atoms), the next layer's centre tokens
-    by their own launch (center_fused = 0), dXF by its own k_dxf launch (dxf_fused = 0) and the A/B switches of the round-2 kernels. Each must meet the same parity bar."""
+    by their own launch (center_fused = 0), dXF by its own k_dxf launch (dxf_fused = 0), one workgroup per node-row tile (node_split = 0) and the A/B switches of the round-2 kernels. Each must meet the same parity bar."""
     g = _load(golden_dir, "pet_default_box64.npz")
     graph = _graph_from_golden(rt, model, g, dev)
     key, _, val = switch.partition("=")

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 RAW=/tmp/prof_gaps
 rm -rf $RAW; mkdir -p $RAW gpurun_out
-rocprofv3 --kernel-trace --output-format csv -d $RAW/trace -o trace -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras $BENCH_ARGS > $RAW/trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $RAW/trace -o trace -- python ${BENCH_PY:-bench.py} --steps 4 --warmup 2 --no-cpu-baseline ${BENCH_EXTRA---no-extras} $BENCH_ARGS > $RAW/trace.log 2>&1
 tail -2 $RAW/trace.log
 f=$(find $RAW -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
