@@ -412,7 +412,8 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *                 (default); 0 = fp32 MFMA. "tile_mask" (debug): bits switch single GEMMs of those kernels back.
  *   "trr_compress" bit mask of f16x3 TRR kernels replacing LDS-tile ones: 1 compress (+adjoint), 2 edge head (+adjoint);
  *                  default 3; 0 = LDS-tile kernels
- *   "node_planes" 1 = node-row kernels k_node2 / k_node_bwd2 (coalesced tiles, fp16 planes; default), 0 = k_node / k_swiglu_bwd
+ *   "node_planes" 1 = node-row kernels k_node2 / k_node2w / k_node_bwd2 (coalesced tiles, fp16 planes; default), 0 = k_node /
+ *                 k_swiglu_bwd; 2 / 3 force 32 / 64 rows per workgroup (3: the 64-row forward with (row block, column half) waves)
  *   "so_trr"      1 = generic training GEMMs with K = 128 or n_out = 128 as TRR kernels (default); 0 = LDS-tile k_gemm_h
  *   "soap_ps_mfma" 1 = SOAP-BPNN power spectrum and its adjoint on the fp32 matrix core (default); 0 = the VALU kernels
  *   "node_split"  1 = graphs of at most 4 096 atoms: the node update and its adjoint run the four hidden chunks of a 32-row

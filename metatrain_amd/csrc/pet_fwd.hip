@@ -610,6 +610,134 @@ __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H,
     }
 }
 
+// k_node2w: the 64-row node update of large graphs with every weight block requested ONCE per workgroup. k_node2<2> runs
+// (row block, column half) waves, so two waves stream the same weights (phase timings at 80 000 atoms, us per launch: tile
+// loads 60, expansion + norm + planes 73, hidden products 234 for 50 us of MFMA work, U exchange + output product 167,
+// epilogue 57). Here a wave owns a column quarter for BOTH 32-row blocks (tile.h gemm_acc_hs_rb2 / gemm_acc_x_ring_rb2): the
+// value and gate tiles of a hidden chunk in one product, the K = 128 operand of the output product requested behind the
+// barriers. 0.52 -> 0.455 ms per launch: the rest is the exposed latency of each phase at one workgroup per CU (133 KB of
+// LDS). Same LDS layout and the same MFMA order per output element as k_node2<2> (pet_config_set("node_planes", 3)).
+__global__ __launch_bounds__(NTHREADS) void k_node2w(const float* __restrict__ H, const float* __restrict__ OC,
+                                                      WX wce, const float* __restrict__ bce,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, WX win,
+                                                      const float* __restrict__ bin, WX wout,
+                                                      const float* __restrict__ bout,
+                                                      float* __restrict__ H1, float* __restrict__ VGn,
+                                                      float* __restrict__ Hn, int64_t N, WX wcn,
+                                                      const float* __restrict__ bcn, float* __restrict__ Xcn) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 64, LDH = plane_ld(256);
+    float* Hs = smem;                                                  // [64][260] h, then h1, then dead
+    float* U = smem;                                                   // [64][132] SwiGLU chunk (aliases Hs)
+    float* stage = smem + ROWS * LD128;                                // 4 staging tiles [32][32] (behind U, inside Hs)
+    _Float16* Ph = reinterpret_cast<_Float16*>(smem + ROWS * LD256);   // [64][264] high pieces of Norm(h1)
+    _Float16* Pl = Ph + ROWS * LDH;
+    float* OCs = smem + ROWS * LD256;                                  // [64][132] OC tile (before the planes exist)
+    float* rs = smem + ROWS * LD256 + ROWS * LDH;                      // [64][2] row scales
+    const int lane = threadIdx.x & 63, ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // column quarter
+    float* my_stage = stage + ch * (32 * 32);
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    load_rows_to_lds<128, ROWS>(OCs, OC, row0, N, D);
+    load_rows_to_lds<256, ROWS>(Hs, H, row0, N, DN);
+    __syncthreads();
+    tile_row_scales<128, ROWS>(OCs, LD128, rs);
+    __syncthreads();
+    {   // h1 = h + center_expansion(OC): this wave's 64 columns, both row blocks
+        XRing<2, 8> rc;
+        xring_request(rc, wce, 16, 0, 2 * ch, lane);
+        f32x16 acc[4];
+        f32x16 b2[2];
+        acc_fill_bias<2>(b2, bce, 64 * ch, lane);
+        acc[0] = acc[2] = b2[0];
+        acc[1] = acc[3] = b2[1];
+        gemm_acc_x_ring_rb2<2, 8>(OCs, LD128, rc, acc, lane, 32 * LD128, rs);
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    Hs[(rb * 32 + acc_row(r, lane)) * LD256 + 64 * ch + 32 * t + (lane & 31)] += acc[rb * 2 + t][r];
+    }
+    __syncthreads();
+    store_rows_from_lds<256, ROWS>(Hs, H1, row0, N, DN);
+    __syncthreads();
+    norm_rows_inplace<256, ROWS>(Hs, gamma, beta);
+    __syncthreads();
+    split_tile_planes<256, ROWS>(Hs, LD256, Ph, Pl);
+    __syncthreads();  // Hs is dead from here on: U and the staging tiles reuse its memory
+    f32x16 out[4];  // [row block][2 tiles]: 64 rows x this wave's 64 columns
+    {
+        f32x16 b2[2];
+        acc_fill_bias<2>(b2, bout, 64 * ch, lane);
+        out[0] = out[2] = b2[0];
+        out[1] = out[3] = b2[1];
+    }
+#pragma unroll 1
+    for (int hc = 0; hc < DNF / 128; hc++) {
+        const int hcol0 = 128 * hc + 32 * ch;  // this wave's 32 hidden units of the chunk
+        f32x16 vg[4];  // [row block][value, gate]
+        {
+            f32x16 bv[1], bg[1];
+            acc_fill_bias<1>(bv, bin, hcol0, lane);
+            acc_fill_bias<1>(bg, bin, DNF + hcol0, lane);
+            vg[0] = vg[2] = bv[0];
+            vg[1] = vg[3] = bg[0];
+        }
+        gemm_acc_hs_rb2<256, 2, 4>(Ph, Pl, LDH, win, 32, 0, hcol0 / 32, vg, lane, DNF / 32, 32 * LDH);
+        if (VGn) {  // saved for the adjoint: [value | gate] pre-activations, whole float4 rows
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+                    wave_rows32(vg[rb * 2 + q], my_stage, lane, [&](int r, int cc, float4 v) {
+                        const int64_t row = row0 + 32 * rb + r;
+                        if (row < N) *reinterpret_cast<float4*>(VGn + row * (2 * DNF) + q * DNF + hcol0 + cc) = v;
+                    });
+        }
+        XRing<2, 8> ro;  // the K = 128 operand of the output product: requested here, it arrives behind the barriers
+        xring_request(ro, wout, DNF / 8, 16 * hc, 2 * ch, lane);
+        __syncthreads();  // previous chunk's readers of U are done
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)  // transformer.py:42-43: value * sigmoid(gate)
+                U[(rb * 32 + acc_row(r, lane)) * LD128 + 32 * ch + (lane & 31)] = vg[rb * 2][r] * sigmoidf_(vg[rb * 2 + 1][r]);
+        __syncthreads();
+        gemm_acc_x_ring_rb2<2, 8>(U, LD128, ro, out, lane, 32 * LD128);
+    }
+    float* Hn_s = smem + ROWS * LD256;  // [64][260]: over the planes, which nobody reads after the last hidden chunk
+    if (Xcn) __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+            wave_rows32(out[rb * 2 + t], my_stage, lane, [&](int r, int cc, float4 v) {  // Hn = h1 + MLP
+                const int64_t row = row0 + 32 * rb + r;
+                const int col = 64 * ch + 32 * t;
+                float4 hn = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < N) {
+                    const int64_t o = row * DN + col + cc;
+                    const float4 h1 = *reinterpret_cast<const float4*>(H1 + o);
+                    hn = make_float4(h1.x + v.x, h1.y + v.y, h1.z + v.z, h1.w + v.w);
+                    *reinterpret_cast<float4*>(Hn + o) = hn;
+                }
+                if (Xcn) *reinterpret_cast<float4*>(Hn_s + (rb * 32 + r) * LD256 + col + cc) = hn;
+            });
+    if (Xcn) {  // the next attention layer's centre tokens (k_node2): this wave's 32 of the 128 columns, both row blocks
+        __syncthreads();
+        tile_row_scales<256, ROWS>(Hn_s, LD256, rs);
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            f32x16 cacc[1];
+            acc_fill_bias<1>(cacc, bcn, 32 * ch, lane);
+            gemm_acc_x<256, 1, 8>(Hn_s + rb * 32 * LD256, LD256, wcn, 32, 0, ch, cacc, lane, rs + 64 * rb);
+            store_acc<1>(cacc, Xcn, row0, N, D, rb, 32 * ch, lane);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // edge MLP: X2 = X1 + SwiGLU_MLP(Norm(X1)); PostLN (NORM = false, transformer.py:246-247): X2 = X1 + SwiGLU_MLP(X1) on
 // already-normalised tokens, centre rows included (E = the row count)
@@ -1075,11 +1203,15 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                         k_node2<1><<<cdiv(N, 32), NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci,
                                                                          A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N,
                                                                          wcn, bcn, xcn, nullptr, nullptr);
-                    } else {
+                    } else if (g_node_planes == 3) {  // A/B: (row block, column half) waves, every weight block fetched twice
                         allow_big_lds(k_node2<2>, lds_n2);
                         k_node2<2><<<gN, NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci,
                                                                  A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N, wcn, bcn,
                                                                  xcn, nullptr, nullptr);
+                    } else {
+                        allow_big_lds(k_node2w, lds_n2);
+                        k_node2w<<<gN, NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci,
+                                                               A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N, wcn, bcn, xcn);
                     }
                 } else
                 k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, s2>>>(

@@ -272,6 +272,102 @@ __device__ __forceinline__ void gemm_acc_hs(const _Float16* Ah, const _Float16* 
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] += ah[t][r] + al[t][r] * (1.0f / 2048.0f);
 }
+// Two row blocks per wave: every weight block is requested ONCE and multiplies the A fragments of both 32-row blocks
+// (acc[rb * NT + t]; row block rb at + rb * rb_stride elements). The 64-row node kernel ran (row block, column half) waves,
+// so two waves of a workgroup streamed the same weights (k_node2w, pet_fwd.hip: - 13 % of the stage at 80 000 atoms).
+// Per output element the MFMA order is that of gemm_acc_hs / _x_ring.
+template <int KS, int NT, int DEPTH>
+__device__ __forceinline__ void gemm_acc_hs_rb2(const _Float16* Ah, const _Float16* Al, int ldh, const WX& w, int kg_total,
+                                                int kg0, int tile0, f32x16 (&acc)[2 * NT], int lane, int tstride,
+                                                int rb_stride) {
+    constexpr int KB = KS / 16;
+    static_assert(KB % DEPTH == 0, "the ring index must be static");
+    const int kb_total = kg_total / 2, kb0 = kg0 / 2;
+    const int roff = (lane & 31) * ldh + (lane >> 5) * 8;
+    size_t base[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) base[t] = ((size_t)(tile0 + t * tstride) * kb_total + kb0) * 64 + lane;
+    f16x8_t wh[DEPTH][NT], wl[DEPTH][NT];
+#pragma unroll
+    for (int s = 0; s < DEPTH; s++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) { wh[s][t] = w.h[base[t] + s * 64]; wl[s][t] = w.l[base[t] + s * 64]; }
+    f32x16 ah[2 * NT], al[2 * NT];
+#pragma unroll
+    for (int t = 0; t < 2 * NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { ah[t][r] = 0.f; al[t][r] = 0.f; }
+#pragma unroll 1
+    for (int kb0i = 0; kb0i < KB; kb0i += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const int kb = kb0i + d;
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+                const f16x8_t xh = *reinterpret_cast<const f16x8_t*>(Ah + rb * rb_stride + roff + 16 * kb);
+                const f16x8_t xl = *reinterpret_cast<const f16x8_t*>(Al + rb * rb_stride + roff + 16 * kb);
+#pragma unroll
+                for (int t = 0; t < NT; t++) al[rb * NT + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl[d][t], al[rb * NT + t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) ah[rb * NT + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh[d][t], ah[rb * NT + t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) al[rb * NT + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh[d][t], al[rb * NT + t], 0, 0, 0);
+            }
+            if (kb + DEPTH < KB)
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    wh[d][t] = w.h[base[t] + (kb + DEPTH) * 64];
+                    wl[d][t] = w.l[base[t] + (kb + DEPTH) * 64];
+                }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2 * NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] += ah[t][r] + al[t][r] * (1.0f / 2048.0f);
+}
+template <int NT, int DEPTH>
+__device__ __forceinline__ void gemm_acc_x_ring_rb2(const float* As, int lda, const XRing<NT, DEPTH>& R, f32x16 (&acc)[2 * NT],
+                                                    int lane, int rb_stride, const float* rscale = nullptr) {
+    f32x16 ah[2 * NT], al[2 * NT];
+#pragma unroll
+    for (int t = 0; t < 2 * NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { ah[t][r] = 0.f; al[t][r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < DEPTH; kb++) {
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            const float* arow = As + rb * rb_stride + (lane & 31) * lda + (lane >> 5) * 4;
+            const float sc = rscale ? rscale[64 * rb + 2 * (lane & 31)] : 1.0f;
+            const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * kb);
+            const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * kb + 8);
+            const float v[8] = {a0.x * sc, a0.y * sc, a0.z * sc, a0.w * sc, a1.x * sc, a1.y * sc, a1.z * sc, a1.w * sc};
+            f16x8_t xh, xl;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const _Float16 hj = (_Float16)v[j];
+                xh[j] = hj;
+                xl[j] = (_Float16)((v[j] - (float)hj) * 2048.0f);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) al[rb * NT + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, R.wl[kb][t], al[rb * NT + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) ah[rb * NT + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, R.wh[kb][t], ah[rb * NT + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) al[rb * NT + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, R.wh[kb][t], al[rb * NT + t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float v = ah[rb * NT + t][r] + al[rb * NT + t][r] * (1.0f / 2048.0f);
+                acc[rb * NT + t][r] += rscale ? v * rscale[64 * rb + 2 * acc_row(r, lane) + 1] : v;
+            }
+}
 // split one value into its two fp16 pieces (high piece, and the remainder scaled by 2^11: trr.h split2)
 __device__ __forceinline__ void split_hl(float v, _Float16& h, _Float16& l) {
     h = (_Float16)v;
