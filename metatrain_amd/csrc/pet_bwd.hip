@@ -497,7 +497,8 @@ __global__ __launch_bounds__(NTHREADS) void k_node_bwd2(const float* __restrict_
         __syncthreads();
         f32x16 acc[NTC];
         acc_fill_bias<NTC>(acc, nullptr, 0, w.lane);
-        gemm_acc<256, NTC>(T + w.rb * 32 * LDK, LDK, wceb, 32, 0, NTC * w.ch, acc, w.lane);
+        if constexpr (RB == 1) gemm_acc_deep<256, NTC, 8>(T + w.rb * 32 * LDK, LDK, wceb, 32, 0, NTC * w.ch, acc, w.lane);
+        else gemm_acc<256, NTC>(T + w.rb * 32 * LDK, LDK, wceb, 32, 0, NTC * w.ch, acc, w.lane);
         acc_foreach<NTC>(acc, w.rb, 32 * NTC * w.ch, w.lane, [&](int r, int c, float v) {
             if (row0 + r < R) dOC[(row0 + r) * D + c] = v;
         });
@@ -524,7 +525,8 @@ __global__ __launch_bounds__(NTHREADS) void k_expand_bwd(const float* __restrict
     });
 }
 
-// dH_in = dH1 + dC Wcc   (centre contraction adjoint)
+// dH_in = dH1 + dC Wcc   (centre contraction adjoint); DEEP (small graphs): eight weight blocks in flight
+template <bool DEEP>
 __global__ __launch_bounds__(NTHREADS) void k_center_bwd(const float* __restrict__ dC, const float* __restrict__ dH1,
                                                           const float4* __restrict__ wccb, float* __restrict__ dHin,
                                                           int64_t N) {
@@ -535,7 +537,8 @@ __global__ __launch_bounds__(NTHREADS) void k_center_bwd(const float* __restrict
     __syncthreads();
     f32x16 acc[4];
     acc_fill_bias<4>(acc, nullptr, 0, w.lane);
-    gemm_acc<128, 4>(smem + w.rb * 32 * LD128, LD128, wccb, 16, 0, 4 * w.ch, acc, w.lane);
+    if constexpr (DEEP) gemm_acc_deep<128, 4, 8>(smem + w.rb * 32 * LD128, LD128, wccb, 16, 0, 4 * w.ch, acc, w.lane);
+    else gemm_acc<128, 4>(smem + w.rb * 32 * LD128, LD128, wccb, 16, 0, 4 * w.ch, acc, w.lane);
     __syncthreads();  // the dC tile is consumed: its memory stages float4 row traffic (tile.h wave_rows64)
     const int64_t wrow0 = row0 + 32 * w.rb;
 #pragma unroll
@@ -1368,7 +1371,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             ss.fork(st);  // centre rows of dX ready
             {
                 ProfScope ps("center_bwd", s2, fN * 2.0 * DN * D);
-                k_center_bwd<<<gN, NTHREADS, lds1, s2>>>(dX + E * D, dH_alt, A.cc.bwd, dH, N);
+                if (N <= 4096) k_center_bwd<true><<<gN, NTHREADS, lds1, s2>>>(dX + E * D, dH_alt, A.cc.bwd, dH, N);
+                else k_center_bwd<false><<<gN, NTHREADS, lds1, s2>>>(dX + E * D, dH_alt, A.cc.bwd, dH, N);
                 if (tr)
                     tr->linear(lp + ".center_contraction", D, DN, {dX + E * D, nullptr, 0, D},
                                {Ab.H, DN, 0, nullptr, nullptr}, 0, N);

@@ -83,6 +83,44 @@ __device__ __forceinline__ void gemm_acc(const float* As, int lda, const float4*
     }
 }
 
+// The same product with DEPTH weight blocks in flight (gemm_acc: one): a small graph runs one workgroup per CU and every
+// block is a dependent round trip to L2 / MALL -- K = 256 is 32 of them (k_node_bwd2<1>'s expansion adjoint, k_center_bwd).
+// Same MFMA order, same bits.
+template <int KS, int NT, int DEPTH>
+__device__ __forceinline__ void gemm_acc_deep(const float* As, int lda, const float4* __restrict__ Wp, int kg_total, int kg0,
+                                              int tile0, f32x16 (&acc)[NT], int lane) {
+    constexpr int KG = KS / 8;
+    static_assert(KG % DEPTH == 0, "the ring index must be static");
+    const float* arow = As + (lane & 31) * lda + (lane >> 5) * 4;
+    const float4* bp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) bp[t] = Wp + ((size_t)(tile0 + t) * kg_total + kg0) * 64 + lane;
+    float4 b[DEPTH][NT];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) b[d][t] = bp[t][d * 64];
+#pragma unroll 1
+    for (int kg0i = 0; kg0i < KG; kg0i += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const int kg = kg0i + d;
+            const float4 a = *reinterpret_cast<const float4*>(arow + kg * 8);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[d][t].x, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[d][t].y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[d][t].z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[d][t].w, acc[t], 0, 0, 0);
+            if (kg + DEPTH < KG)
+#pragma unroll
+                for (int t = 0; t < NT; t++) b[d][t] = bp[t][(kg + DEPTH) * 64];
+        }
+    }
+}
+
 // ---- the same GEMM on the fp16 matrix cores (f16x3, see trr.h): the A tile stays fp32 in LDS and is split on
 // the fly as its fragments are read (two ds_read_b128 and ~30 VALU per K block of 16, against three 32-cycle MFMAs
 // per tile instead of eight 64-cycle ones); the weights come as two fp16 planes (abi.hip k_pack2h).
