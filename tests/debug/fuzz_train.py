@@ -5,6 +5,7 @@ import sys
 import numpy as np
 import torch
 sys.path.insert(0, ".")
+sys.path.insert(0, "tests")  # test_gpu_train imports its sibling _memo
 spec = importlib.util.spec_from_file_location("tgt", "tests/test_gpu_train.py")
 T = importlib.util.module_from_spec(spec); spec.loader.exec_module(T)
 from metatrain_amd import runtime as rt
