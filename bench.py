@@ -204,6 +204,56 @@ def gpu_box1000(model, hypers, dev, reps=200):
     return res
 
 
+def _child_bench(script, argv, timeout=600):
+    """Run one of the sibling benches in a child process and return its JSON line (or the reason there is none)."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, script)] + argv
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": f"{script} timed out after {timeout} s"}
+    for line in reversed(res.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return {"error": f"{script} exit {res.returncode}: {res.stderr.strip()[-400:]}"}
+
+
+def leg_train64x1000(no_cpu):
+    """BASELINE configs[2]: PET training step (forward, dE/dR with its double backward, clip, Adam) on 64 x 1000-atom boxes --
+    `bench_train.py`'s own line, reduced; its parity mode is `value`, the single-term 16-bit mode is `train_bf16`."""
+    r = _child_bench("bench_train.py", ["--steps", "5", "--warmup", "2", "--no-two-micro"] + (["--no-cpu-baseline"] if no_cpu else []))
+    if "error" in r:
+        return r
+    roof = r.get("roofline", {})
+    out = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+           "workspace_gb": r["config"]["workspace_gb"], "workload": r["config"]["workload"],
+           "train_bf16": {k: r["train_bf16"][k] for k in ("value", "ms_per_step")} if "train_bf16" in r else None,
+           "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "stage_ms_per_step",
+                                                 "whole_step_algorithmic_tflops", "step_traffic_bytes")}}
+    if "cpu_baseline" in r:
+        out["cpu_baseline"] = r["cpu_baseline"]
+    return out
+
+
+def leg_soap100k(no_cpu):
+    """BASELINE configs[4] on one GPU: SOAP-BPNN forward + dE/dR of one 100 000-atom box -- `bench_soap.py`'s own line, reduced."""
+    r = _child_bench("bench_soap.py", ["--steps", "10", "--warmup", "3"] + (["--no-cpu-baseline"] if no_cpu else []))
+    if "error" in r:
+        return r
+    roof = r.get("roofline", {})
+    out = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+           "workload": r["config"]["workload"],
+           "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                                 "stages_ms", "step_traffic_bytes", "soap_tail_hbm_frac")}}
+    if "cpu_baseline" in r:
+        out["cpu_baseline"] = r["cpu_baseline"]
+    return out
+
+
 def respawn_under_launcher(n_gpus):
     """`python bench.py --gpus N` without a launcher: start N ranks of this same script under torch.distributed.run
     (one process per GPU, rendezvous on 127.0.0.1) and hand its exit code back."""
@@ -353,13 +403,19 @@ def main():
                   file=sys.stderr)
     step()  # back on two streams before the clock starts
 
-    rt.profile(True, stage=dominant)
+    # `value`: K steps with NO instrumentation in the timed region ...
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         atomic, grad, graph = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    # ... and the dominant stage's launch durations in a SEPARATE pass of the same steps in the same (two-stream)
+    # configuration, HIP events on the stream the stage is launched on
+    rt.profile(True, stage=dominant)
+    for _ in range(min(args.steps, 10)):
+        step()
+    torch.cuda.synchronize()
     dom = [r for r in rt.profile_report() if r["name"] == dominant][0]
     rt.profile(False)
 
@@ -493,6 +549,14 @@ def main():
                             "forward, dE/dR, D2H per-atom energies + gradients"}
         if world == 1 and not strong and not args.no_extras:
             out["box1000"] = gpu_box1000(model, hypers, dev)
+        if world == 1 and not strong and not args.no_extras:
+            # BASELINE configs[2] and configs[4] on this GPU, from their own benches (bench_train.py / bench_soap.py, each a
+            # child process started once this process has released its workspaces): not `value`
+            state.clear()
+            del atomic, grad, graph
+            torch.cuda.empty_cache()
+            out["train64x1000"] = leg_train64x1000(args.no_cpu_baseline)
+            out["soap100k"] = leg_soap100k(args.no_cpu_baseline)
         if not args.no_cpu_baseline and world == 1:  # the reported CPU leg runs at N = 1 only
             out["cpu_baseline"] = cpu_baseline(hypers, params)
         print(json.dumps(out), flush=True)

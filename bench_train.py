@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs that are not `value` (single-term mode, two micro-batches): profiling runs")
+    ap.add_argument("--no-two-micro", action="store_true",
+                    help="skip the two-micro-batch leg (it allocates a second workspace); keeps the train_bf16 leg")
     ap.add_argument("--train-bf16", action="store_true",
                     help="pet_config_set('train_bf16', 1): ONE 16-bit MFMA term per product in the second-order and "
                          "weight-gradient GEMMs (BASELINE configs[2]'s 'bf16 MFMA MLPs'; gradients to ~1e-3, not the parity "
@@ -237,7 +239,7 @@ def main():
                             "forward and force pass unchanged"}
     two_micro = None
     workspace_gb = (fw.nbytes + fw.workspace2.numel()) / 1e9
-    if world == 1 and len(batches) == 1 and args.boxes >= 2 and not args.no_extras and not args.train_bf16:
+    if world == 1 and len(batches) == 1 and args.boxes >= 2 and not args.no_extras and not args.train_bf16 and not args.no_two_micro:
         # not `value`: the same step (one Adam step over the same boxes) as TWO micro-batches with gradient accumulation
         # (TrainStep.microbatched) on a workspace half the size -- what a user short of memory runs
         gen.manual_seed(1234 + rank)  # (the whole-batch workspace stays allocated: 123 + 62 GB of the 288)

@@ -107,8 +107,29 @@ struct Graph {
     int* tsort_tmp = nullptr;  // [ceil(N / 256)][33] per-block counts / first positions of that sort
     int4* tile_desc = nullptr; // [2 N]: the 32-slot tiles first (n_tiles1), then the 64-slot ones (n_tiles2)
     int n_tiles1 = 0, n_tiles2 = 0;  // host copies
-    mutable const void* fwd_ws = nullptr;  // the workspace this graph's last forward wrote, and whether it ran the
-    mutable bool fwd_generic = false;      // size-generic path there (pet_fwd.hip note_workspace)
+    // What this graph's last forward into a given workspace left there (pet_fwd.hip note_workspace): whether it ran the
+    // size-generic path, and whether its attention layers ran the fused per-atom block WITHOUT saving Q, K, V (the adjoint
+    // must then be the fused one). One record per workspace (the last four), so that forwards of the same graph into
+    // different workspaces do not overwrite each other's record.
+    struct FwdRecord {
+        const void* ws = nullptr;
+        bool generic = false;
+        bool attn_unsaved = false;  // some attention layer ran the fused block: its QKV / AO buffers were not written
+    };
+    mutable FwdRecord fwd_rec[4];
+    mutable int fwd_rec_next = 0;
+    const FwdRecord* fwd_record(const void* ws) const {
+        for (const FwdRecord& r : fwd_rec)
+            if (r.ws == ws && ws) return &r;
+        return nullptr;
+    }
+    FwdRecord& fwd_record_new(const void* ws) const {
+        for (FwdRecord& r : fwd_rec)
+            if (r.ws == ws) return r = FwdRecord{ws, false, false};
+        FwdRecord& r = fwd_rec[fwd_rec_next];
+        fwd_rec_next = (fwd_rec_next + 1) % 4;
+        return r = FwdRecord{ws, false, false};
+    }
     bool attn_lists = false;         // atom_order / bucket_start (and the tile plan) exist (graph.hip graph_attention_lists)
     bool tiles_planned = false;      // the graph build made tile_desc (large graphs, or the fused block forced)
     int bucket_start[6] = {0, 0, 0, 0, 0, 0};  // host copy

@@ -456,6 +456,7 @@ __global__ __launch_bounds__(NTHREADS) void k_node_bwd2(const float* __restrict_
         }
         __syncthreads();
         if (!last_arrival) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // consumer side of the hand-over (see k_node2 in pet_fwd.hip)
         float4 pk[IT][NCHK];
 #pragma unroll
         for (int it = 0; it < IT; it++) {
@@ -1188,6 +1189,13 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     const bool trr = use_trr();
     const bool trr_l = trr && m.plain_layers();  // the TRR transformer-layer kernels are PreLN (RMSNorm or LayerNorm)
     const bool fused_attn = trr_l && !tr && ablk_bwd_on(g) && m.gnn[0].attn[0].qkv.bwd2s;
+    // the forward that filled this workspace decided by itself whether Q, K, V were written: if it ran the fused block, the
+    // three-kernel adjoint would read buffers nobody wrote (a switch flipped between the two calls) -- refuse
+    const Graph::FwdRecord* fwd_rec = w.base ? g.fwd_record(w.base) : nullptr;
+    const bool fwd_unsaved = fwd_rec && fwd_rec->attn_unsaved;
+    PET_REQUIRE(!fwd_unsaved || fused_attn, PET_ERR_ARGUMENT,
+                "the forward of this workspace ran the fused attention block (Q, K, V not saved) but the adjoint is "
+                "configured for the three-kernel form: pet_config_set changed between forward and backward");
     // k_dxf folded into its producer and its consumer (pet_config_set("dxf_fused", 0): the separate kernel)
     bool node_cnt_zeroed = false;  // k_node_bwd2 SPLIT: arrival counters zeroed once per adjoint, then they reset themselves
     const bool dxf_fused = trr_l && !tr && !res && !g.x_fn && m.h.num_attention_layers >= 1 && dxf_fused_on();
@@ -1335,6 +1343,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 ProfScope ps("attn_blk_bwd", st, fR * 2.0 * D * 4 * D + 2.0 * 4.0 * D * g_sum_t2(g), fR * 4.0 * 3 * D);  // algorithmic: the adjoint's own products (the Q, K, V recomputation is this design's choice, not counted); X, dX1 in; dX out
                 fusedb = ablk_bwd(m, g, A, Ab.X, dX_alt, w.dOC, dX,
                                   w.dbias_l + ((int64_t)gi * m.h.num_attention_layers + a) * NHEAD * E, scale, st);
+                // (the key-bias reduction below assumes every layer took the same form)
+                PET_REQUIRE(fusedb, PET_ERR_ARGUMENT, "the fused attention adjoint refused a layer (weights not packed for it)");
             }
             if (!fusedb) {
             {

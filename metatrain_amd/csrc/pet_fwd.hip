@@ -547,6 +547,14 @@ __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H,
         }
         __syncthreads();
         if (!last_arrival) return;
+        // Consumer side of the hand-over: an agent-scope ACQUIRE (buffer_inv, no write-back) orders the loads below after the
+        // counter update this workgroup saw. Producer side: the partials are relaxed agent-scope atomic stores (write-through
+        // to the device-coherent level) that the workgroup-scope release above has waited for (s_waitcnt vmcnt(0)); an
+        // agent-scope RELEASE would add the L2 write-back of every dirty line of the step (10+ us) for
+        // data that already went through. That part relies on gfx950's write-through behaviour of sc1 stores rather than on
+        // the formal memory model; tests/test_gpu_stress.py (node_split_stress) runs the hand-over 200 x and demands
+        // bit-identical results.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         // every load of the reduction in flight before the first sum (8 positions x (4 partials + h1) per thread)
         constexpr int IT = ROWS * (DN / 4) / NTHREADS, NCHK = DNF / 128;
         float4 pk[IT][NCHK], h1v[IT];
@@ -989,10 +997,14 @@ bool use_generic(const Model& m, const Graph& g) { return m.generic() || attn_ti
 // compiled size runs on the size-generic path while its inference forward runs on the tuned kernels, and the adjoint calls
 // must follow. Recorded on the graph handle (host side, the caller owns its lifetime): no process-global table, and an
 // adjoint call on a workspace this graph's forward has not written falls back to what (model, graph) say.
-bool generic_workspace(const Graph& g, const void* ws) { return g.fwd_ws == ws && g.fwd_generic; }
-static void note_workspace(const Graph& g, const void* ws, bool generic) {
-    g.fwd_ws = ws;
-    g.fwd_generic = generic;
+bool generic_workspace(const Graph& g, const void* ws) {
+    const Graph::FwdRecord* r = g.fwd_record(ws);
+    return r && r->generic;
+}
+static Graph::FwdRecord& note_workspace(const Graph& g, const void* ws, bool generic) {
+    Graph::FwdRecord& r = g.fwd_record_new(ws);
+    r.generic = generic;
+    return r;
 }
 
 static int g_node_split = 1;  // pet_config_set("node_split", 0): one workgroup per 32-row tile in k_node2<1> / k_node_bwd2<1>
@@ -1042,7 +1054,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                    float* const* node_feats, float* const* edge_feats, int n_layers, hipStream_t st) {
     const bool gen = use_generic(m, g) || (save == 2 && train_generic_for(m, g));
     PET_REQUIRE(!(gen && g.x_fn), PET_ERR_UNSUPPORTED, "the per-layer exchange is built for the tuned path (default model size)");
-    note_workspace(g, ws, gen);
+    Graph::FwdRecord& fwd_rec = note_workspace(g, ws, gen);
     if (gen) return gen_forward_layers(m, g, ws, ws_bytes, save, atomic, node_feats, edge_feats, n_layers, st);
     if (int rcl = graph_attention_lists(g, st)) return rcl;
     Workspace w;
@@ -1129,6 +1141,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
             if (trr_l && save != 2 && E > 0 && (save == 0 || ablk_bwd_on(g))) {
                 ProfScope ps("attn_blk", st, fR * 2.0 * D * 4 * D + attn_flops, fR * 4.0 * 2 * D);  // X in; X1 | OC out
                 fused = ablk_fwd(m, g, A, Ab.X, Ab.X1, Ab.OC, scale, st);
+                if (fused && save) fwd_rec.attn_unsaved = true;  // the adjoint of this workspace must be the fused one
             }
             if (!fused) {
             {

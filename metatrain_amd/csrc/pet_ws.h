@@ -78,10 +78,12 @@ struct Workspace {
     float* partial = nullptr; // split-K partials
     size_t partial_floats = 0;
     size_t bytes = 0;
+    const void* base = nullptr;  // what the caller handed over (key of Graph::fwd_record)
 };
 
 inline void carve_workspace(const Model& m, int64_t N, int64_t E, void* base, Workspace& w, bool train = false) {
     Carver c(base);
+    w.base = base;
     const int64_t R = E + N;
     const int64_t Ea = E > 0 ? E : 1, Na = N > 0 ? N : 1, Ra = R > 0 ? R : 1;
     w.gnn.resize(m.h.num_gnn_layers);

@@ -110,7 +110,9 @@ def slab_partition(positions: torch.Tensor, cell: torch.Tensor, pbc: Sequence[bo
     owned = _owner_of(f, lo_all, width, world) == rank  # the same expression slab_owner uses: every atom has one owner
     below, above = lo - f, f - hi  # > 0 on the respective outside
     if wrap:
-        below, above = torch.remainder(below, 1.0), torch.remainder(above, 1.0)
+        # (an atom within rounding of a slab bound may be owned by the neighbouring rank while lo - f is -1e-17: shifted by
+        # the same 1e-12 as the open branch so that it wraps to ~0 and not to ~1 and lands in this rank's halo)
+        below, above = torch.remainder(below + 1e-12, 1.0) - 1e-12, torch.remainder(above + 1e-12, 1.0) - 1e-12
         near = torch.minimum(below, above) < h
     else:
         near = ((below > -1e-12) & (below < h)) | ((above > -1e-12) & (above < h))

@@ -141,7 +141,7 @@ def energy_and_gradient_exchange(model, positions: torch.Tensor, species: torch.
     dev = positions.device
     n = positions.shape[0]
     n_layers = int(model.hypers["num_gnn_layers"])
-    buf = torch.zeros(3 * n + 1, dtype=torch.float32, device=dev)
+    buf = torch.zeros(3 * n + 2, dtype=torch.float32, device=dev)  # [gradient | energy | run-phase error flag]
     n_rows = n_ghost = 0
     # Every rank must enter the same collectives: 2 x num_gnn_layers all-to-alls and one all-reduce. A rank whose slab
     # (plus halo) is empty has nothing to launch -- the library returns before any layer -- and a rank that fails while
@@ -224,10 +224,15 @@ def energy_and_gradient_exchange(model, positions: torch.Tensor, species: torch.
     for direction in (0, 1):  # keep in step with the peers: an empty slab, or a local failure after the agreement
         while calls[direction] < n_layers:
             exchange(direction)
+    if run_error is not None:
+        buf[3 * n + 1] = 1.0  # every rank learns of it with the reduction it enters anyway
     if all_reduce is not None:
         all_reduce(buf)
     if run_error is not None:
         raise run_error
-    return (buf[3 * n:], buf[: 3 * n].view(n, 3), 0 if index is None else int(index.numel()),
+    if float(buf[3 * n + 1]) > 0:
+        raise RuntimeError("another rank failed during the per-layer exchange step: its contribution to the energy and the "
+                           "gradient is missing; this rank stops with it")
+    return (buf[3 * n:3 * n + 1], buf[: 3 * n].view(n, 3), 0 if index is None else int(index.numel()),
             0 if owned is None else int(owned.sum()), n_rows, n_ghost)
 
