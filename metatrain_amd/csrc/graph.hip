@@ -401,6 +401,7 @@ struct TilePlan {
     short ta[72], tb[72];
     int offa[72], offb[72];
     int binstart[34];
+    int tok0[72];  // tokens of all tiles before the segment (dense per-tile buffers of pet_ablk.hip: tile k starts at tok0 + r * (ta + tb))
 };
 __global__ void k_tile_fill(TilePlan plan, const int* __restrict__ by_t, const int* __restrict__ rowptr,
                             int4* __restrict__ desc) {
@@ -413,7 +414,7 @@ __global__ void k_tile_fill(TilePlan plan, const int* __restrict__ by_t, const i
     const int A = by_t[plan.binstart[ta] + plan.offa[sgm] + r];
     const int B = tb > 0 ? by_t[plan.binstart[tb] + plan.offb[sgm] + r] : 0;
     desc[2 * k] = make_int4(A, rowptr[A], ta, B);
-    desc[2 * k + 1] = make_int4(tb > 0 ? rowptr[B] : 0, tb, 0, 0);
+    desc[2 * k + 1] = make_int4(tb > 0 ? rowptr[B] : 0, tb, plan.tok0[sgm] + r * (ta + tb), 0);
 }
 __global__ void k_tile_fill_big(const int* __restrict__ atoms, int n, const int* __restrict__ rowptr, int4* __restrict__ desc) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -435,9 +436,11 @@ static int plan_attention_tiles(Graph& g, const int* hist, hipStream_t st) {
         off[t] = 0;
         plan.binstart[t + 1] = plan.binstart[t] + hist[t];
     }
-    int nseg = 0, ntile = 0;
+    int nseg = 0, ntile = 0, ntok = 0;
     auto add = [&](int ta, int oa, int tb, int ob, int n) {
         plan.first[nseg] = ntile;
+        plan.tok0[nseg] = ntok;
+        ntok += n * (ta + tb);
         plan.ta[nseg] = (short)ta; plan.tb[nseg] = (short)tb;
         plan.offa[nseg] = oa; plan.offb[nseg] = ob;
         nseg++;

@@ -25,179 +25,9 @@
 // |64 x| must stay inside fp16: |x| < 1023, which holds for normalised rows, weights, Q / K / V (sums of normalised rows
 // times weights), soft-max weights and attention outputs; adjoint rows are scaled per atom by a power of two first.
 // The weight planes are packed by abi.hip (Lin::fwd2s / bwd2s).
-#include "common.h"
-#include "model.h"
-#include "pet_ws.h"
-#include "trr.h"
+#include "ablk.h"
 
 namespace pet {
-
-constexpr float ABS = 64.0f;             // plane scale
-constexpr float ABS_INV = 1.0f / 64.0f;
-constexpr float ABQ = 4096.0f;           // accumulator scale = ABS^2
-constexpr float ABQ_INV = 1.0f / 4096.0f;
-constexpr float AB_LOG2E = 1.4426950408889634f;
-
-union H8 {
-    f16x8 v;
-    h16x2 p[4];
-};
-// the two planes of eight values v = 64 x: hi = fp16(v), lo = fp16(v - hi); the low piece is derived from the PINNED high pair
-// (trr.h split_pair_pinned: otherwise the compiler may convert twice with instructions that round differently)
-__device__ __forceinline__ void ab_split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
-    H8 a, b;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        h16x2 hp, lp;
-        hp[0] = (_Float16)x[2 * j]; hp[1] = (_Float16)x[2 * j + 1];
-        asm volatile("" : "+v"(hp));
-        // x - hi in ONE instruction per value (mixed-precision fma reads the fp16 half directly: no v_cvt_f32_f16 + v_sub)
-        float r0, r1;
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hp), "v"(x[2 * j]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hp), "v"(x[2 * j + 1]));
-        lp[0] = (_Float16)r0;
-        lp[1] = (_Float16)r1;
-        a.p[j] = hp; b.p[j] = lp;
-    }
-    hi = a.v; lo = b.v;
-}
-// acc += 4096 (a b) from the planes of a (A operand) and b (B operand)
-#define AB_MFMA3(acc, aH, aL, bH, bL)          \
-    do {                                       \
-        acc = PET_MFMA_H((aH), (bH), (acc));   \
-        acc = PET_MFMA_H((aL), (bH), (acc));   \
-        acc = PET_MFMA_H((aH), (bL), (acc));   \
-    } while (0)
-
-__device__ __forceinline__ f32x16 ab_zero() {
-    f32x16 z;
-#pragma unroll
-    for (int r = 0; r < 16; r++) z[r] = 0.f;
-    return z;
-}
-// the eight registers 8 kb .. 8 kb + 7 of a C tile (K block kb of the NEXT product) scaled by f
-__device__ __forceinline__ void ab_regs8(const f32x16& a, int kb, float f, float (&o)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) o[j] = a[8 * kb + j] * f;
-}
-__device__ __forceinline__ void ab_regs8(const f32x16& a, int kb, float (&o)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) o[j] = a[8 * kb + j];
-}
-// planes of the two K blocks of a C tile (times f)
-__device__ __forceinline__ void ab_tile_planes(const f32x16& a, float f, f16x8 (&hi)[2], f16x8 (&lo)[2]) {
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-        float t8[8];
-        ab_regs8(a, b, f, t8);
-        ab_split8(t8, hi[b], lo[b]);
-    }
-}
-__device__ __forceinline__ void ab_tile_planes(const f32x16& a, f16x8 (&hi)[2], f16x8 (&lo)[2]) {
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-        float t8[8];
-        ab_regs8(a, b, t8);
-        ab_split8(t8, hi[b], lo[b]);
-    }
-}
-
-#ifdef AB_PROFILE
-// debugging aid (build with -DAB_PROFILE): shader cycles per phase, summed over the waves of every launch
-__device__ unsigned long long ab_prof[32];
-#define AB_T(i)                                                                              \
-    do {                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
-        if (threadIdx.x % 64 == 0) atomicAdd(&ab_prof[(i)], t_ - ab_t0);                     \
-        ab_t0 = __builtin_amdgcn_s_memtime();                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-    } while (0)
-#define AB_T0() unsigned long long ab_t0 = __builtin_amdgcn_s_memtime()
-#else
-#define AB_T(i)
-#define AB_T0()
-#endif
-
-// A tile: 32 NQ token slots holding atom A (slot 0 = its centre token = row E + atom of the token stream, slots 1 .. TA - 1
-// its neighbours = CSR rows startA ..) and, in a 32-slot tile, possibly a second atom B behind it (Graph::tile_desc; the
-// graph build pairs small atoms with partners that fit). Tokens attend within their own atom only. Slots past the last
-// token repeat it (their results are never stored and, as keys, are masked).
-struct AbAtom {
-    int atomA, startA, TA, atomB, startB, TB, T;
-    int64_t E;
-    __device__ __forceinline__ AbAtom(const int4* __restrict__ d, int64_t e) : E(e) {
-        const int4 d0 = d[0], d1 = d[1];
-        atomA = __builtin_amdgcn_readfirstlane(d0.x); startA = __builtin_amdgcn_readfirstlane(d0.y);
-        TA = __builtin_amdgcn_readfirstlane(d0.z); atomB = __builtin_amdgcn_readfirstlane(d0.w);
-        startB = __builtin_amdgcn_readfirstlane(d1.x); TB = __builtin_amdgcn_readfirstlane(d1.y);
-        T = TA + TB;
-    }
-    __device__ __forceinline__ bool centre(int s) const { return s == 0 || s == TA; }
-    __device__ __forceinline__ int atom(int s) const { return s < TA ? atomA : atomB; }
-    __device__ __forceinline__ int64_t edge(int s) const {  // CSR row of a neighbour slot
-        return s < TA ? (int64_t)startA + s - 1 : (int64_t)startB + (s - TA) - 1;
-    }
-    __device__ __forceinline__ int64_t row(int s) const {  // row of the token stream [edges | centre tokens]
-        s = s < T ? s : T - 1;
-        return centre(s) ? E + atom(s) : edge(s);
-    }
-};
-
-// whole-row LDS-DMA of the atom's token rows into the wave's tile(s): tile tq holds slots 32 tq .. 32 tq + 31 in the
-// layout of trr.h dma_tile128 (row r, 16-B piece p at byte 512 r + 16 (p ^ (r & 15)))
-template <int NQ>
-__device__ __forceinline__ void ab_dma_rows(const float* __restrict__ X, const AbAtom& a, unsigned lds_base,
-                                            const RowLane& L) {
-#pragma unroll
-    for (int tq = 0; tq < NQ; tq++)
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int r = 2 * j + (L.lane >> 5);
-            const int p = (L.lane & 31) ^ (r & 15);
-            glds16_trr(X + a.row(32 * tq + r) * D + 4 * p, lds_base + tq * 16384 + j * 1024);
-        }
-}
-
-// planes of a normalised row tile in the wave's LDS: [kb 0..7][plane H, L][lane] f16x8
-__device__ __forceinline__ void ab_park_planes(const float4 (&x)[16], char* tile, const RowLane& L) {
-#pragma unroll
-    for (int kb = 0; kb < 8; kb++) {
-        const float v[8] = {x[2 * kb].x * ABS, x[2 * kb].y * ABS, x[2 * kb].z * ABS, x[2 * kb].w * ABS,
-                            x[2 * kb + 1].x * ABS, x[2 * kb + 1].y * ABS, x[2 * kb + 1].z * ABS, x[2 * kb + 1].w * ABS};
-        f16x8 h, l;
-        ab_split8(v, h, l);
-        *reinterpret_cast<f16x8*>(tile + ((kb * 2 + 0) * 64 + L.lane) * 16) = h;
-        *reinterpret_cast<f16x8*>(tile + ((kb * 2 + 1) * 64 + L.lane) * 16) = l;
-    }
-}
-
-// key bias (log2 of the cutoff factor, transformer.py:109-110) of the keys this lane's S^T registers hold; -inf masks
-// the slots past the last token and the other atom of a paired tile (the lane is a QUERY: its atom decides)
-template <int NQ>
-__device__ __forceinline__ void ab_key_bias(float (&bias)[NQ][16], const AbAtom& a, const float* __restrict__ fc,
-                                            const RowLane& L) {
-    const bool qb = (L.r < a.T ? L.r : a.T - 1) >= a.TA;
-#pragma unroll
-    for (int tk = 0; tk < NQ; tk++)
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int key = 32 * tk + 8 * (i >> 2) + 4 * L.h + (i & 3);
-            float b = -INFINITY;
-            if (key < a.T && (key >= a.TA) == qb)
-                b = a.centre(key) ? 0.f : __builtin_amdgcn_logf(fmaxf(fc[a.edge(key)], 1e-15f));
-            bias[tk][i] = b;
-        }
-}
-
-// accumulators of a token-form tile initialised with 4096 x bias (features 8 j + 4 h .. + 3 of the tile at b)
-__device__ __forceinline__ void ab_bias_tile(f32x16& acc, const float* __restrict__ b, int h) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const float4 v = *reinterpret_cast<const float4*>(b + 8 * j + 4 * h);
-        acc[4 * j] = v.x * ABQ; acc[4 * j + 1] = v.y * ABQ; acc[4 * j + 2] = v.z * ABQ; acc[4 * j + 3] = v.w * ABQ;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // The weight stream, shared by the waves of a workgroup. Every wave needs the same weight fragments at (about) the
@@ -211,15 +41,14 @@ __device__ __forceinline__ void ab_bias_tile(f32x16& acc, const float* __restric
 // barrier count) and store nothing.
 // ---------------------------------------------------------------------------------------------
 constexpr int AB_SLOT = 12288;  // bytes of a ring slot: two QKV K blocks (2 x 6 fragments) or two Wo steps (2 x 4)
-__device__ __forceinline__ void ab_dma_piece(const f16x8* plane, int idx, unsigned lane16, unsigned lds_dst) {
-    const char* base = reinterpret_cast<const char*>(plane + (size_t)idx * 64);
-    glds16_trr(reinterpret_cast<const float*>(base + lane16), lds_dst);
-}
 // forward stages 0 .. 15: QKV blocks (hp = g / 4, kb = 2 (g % 4) + j), pieces j * 6 + {Qh, Ql, Kh, Kl, Vh, Vl};
 // stages 16 .. 23: Wo steps n = 2 (g - 16) + j (c = n / 8, kb = n % 8), pieces j * 4 + {tile 2c h, l, tile 2c + 1 h, l}
 template <int NW>
 __device__ __forceinline__ void ab_fwd_request(int g, const W2& wqkv, const W2& wo, unsigned ring_u, int wave,
                                                unsigned lane16) {
+#ifdef AB_ABL_NODMA  // timing ablation (results are wrong): the weight stream stops after its first stage
+    if (g > 0) return;
+#endif
     const unsigned dst = ring_u + (unsigned)(g & 1) * AB_SLOT;
     if (g < 16) {
         const int hp = g >> 2, kb0 = 2 * (g & 3);
@@ -251,6 +80,9 @@ constexpr int AB_SLOT_B = 16384;
 template <int NW>
 __device__ __forceinline__ void ab_bwd_request(int g, const W2& wqkv, const W2& wot, const W2& wqkvt, unsigned ring_u,
                                                int wave, unsigned lane16) {
+#ifdef AB_ABL_NODMA
+    if (g > 0) return;
+#endif
     const unsigned dst = ring_u + (unsigned)(g & 1) * AB_SLOT_B;
     const int r = g < 4 ? -1 : (g - 4) % 7, hp = g < 4 ? 0 : (g - 4) / 7;
     if (r >= 0 && r < 4) {  // QKV: 12 pieces
@@ -277,11 +109,6 @@ __device__ __forceinline__ void ab_bwd_request(int g, const W2& wqkv, const W2& 
         }
     }
 }
-#define AB_STAGE_SYNC()                                   \
-    do {                                                  \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
-        __syncthreads();                                  \
-    } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // forward
@@ -526,52 +353,6 @@ __global__ __launch_bounds__(NQ == 1 ? 512 : 256) void k_ablk_fwd(
 // rows, so a per-row scale as in the row kernels would not factor out. Slots past the atom's last token get a zero
 // adjoint row, which removes them from every sum over queries.
 // ---------------------------------------------------------------------------------------------
-struct AbSel {
-    f16x8 i0, i1;  // selection matrices of the two K blocks of a 32-wide tile, B-operand form
-};
-__device__ __forceinline__ AbSel ab_selectors(const RowLane& L, float one) {
-    AbSel s;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int f = 8 * (j >> 2) + 4 * L.h + (j & 3);
-        s.i0[j] = (f == L.r) ? (_Float16)one : (_Float16)0.0f;
-        s.i1[j] = (16 + f == L.r) ? (_Float16)one : (_Float16)0.0f;
-    }
-    return s;
-}
-// planes (index = K block of the 32-wide tile) of a tile -> planes of its transpose (times the selector's entry), exactly
-__device__ __forceinline__ void ab_transpose(const f16x8 (&h)[2], const f16x8 (&l)[2], const AbSel& sel,
-                                             f16x8 (&th)[2], f16x8 (&tl)[2]) {
-    f32x16 ch = ab_zero(), cl = ab_zero();
-    ch = PET_MFMA_H(h[0], sel.i0, ch); cl = PET_MFMA_H(l[0], sel.i0, cl);
-    ch = PET_MFMA_H(h[1], sel.i1, ch); cl = PET_MFMA_H(l[1], sel.i1, cl);
-#pragma unroll
-    for (int b = 0; b < 2; b++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            th[b][j] = (_Float16)ch[8 * b + j];
-            tl[b][j] = (_Float16)cl[8 * b + j];
-        }
-}
-// the same, also returning the sum over the registers of the transposed VALUES (h + l): column sums of the tile
-__device__ __forceinline__ float ab_transpose_sum(const f16x8 (&h)[2], const f16x8 (&l)[2], const AbSel& sel,
-                                                  f16x8 (&th)[2], f16x8 (&tl)[2]) {
-    f32x16 ch = ab_zero(), cl = ab_zero();
-    ch = PET_MFMA_H(h[0], sel.i0, ch); cl = PET_MFMA_H(l[0], sel.i0, cl);
-    ch = PET_MFMA_H(h[1], sel.i1, ch); cl = PET_MFMA_H(l[1], sel.i1, cl);
-    float sh = 0.f, sl = 0.f;
-#pragma unroll
-    for (int b = 0; b < 2; b++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            th[b][j] = (_Float16)ch[8 * b + j];
-            tl[b][j] = (_Float16)cl[8 * b + j];
-            sh += ch[8 * b + j];
-            sl += cl[8 * b + j];
-        }
-    return sh + sl;
-}
-
 template <int NQ, bool LN>
 __global__ __launch_bounds__(256) void k_ablk_bwd(
     const float* __restrict__ X, const float* __restrict__ dX1, const float* __restrict__ dOC,
