@@ -332,7 +332,9 @@ __global__ __launch_bounds__(256) void k_emlp_p2(const float* __restrict__ X1, c
     f16x8* const usp = reinterpret_cast<f16x8*>(my + 16384);     // [2 K blocks x (h, l)][64]
     float* const otile = reinterpret_cast<float*>(my + 16384 + 4096);
     float* const bias = reinterpret_cast<float*>(my + 16384 + 4096 + 32 * TILE32_LD * 4);
+#ifndef P2_ABL_NOPROLOG
     dma_tile128(X1, row0, E, __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)my), L);
+#endif
     {   // private copy of the input bias [v 256 | g 256]
         const float4* b4 = reinterpret_cast<const float4*>(bin);
         reinterpret_cast<float4*>(bias)[L.lane] = b4[L.lane];
@@ -545,7 +547,9 @@ __global__ __launch_bounds__(256) void k_emlp_bwd_p2(const float* __restrict__ d
     }
     {
         const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)my);
+#ifndef P2_ABL_NOPROLOG
         dma_tile128(dY, row0, E, base, L, ldy);
+#endif
     }
     if (GATHER)  // whole 512-B rows, two per instruction (the line mapping of trr.h request_rows_lines)
         request_rows_lines(y2, L, [&](int r) { return dY2 + (int64_t)__shfl(myrev, r) * ldy; });
