@@ -225,7 +225,9 @@ def test_exchange_rank_with_an_empty_slab_still_enters_every_collective(rank):
         _ExchangeModel(layers), pos, z, cell, pbc, 4, rank, all_to_all, all_reduce, runtime=_ToyRuntime)
     assert (n_sub, n_owned, n_rows, n_ghost) == (0, 0, 0, 0) and float(e) == 0.0 and float(grad.abs().max()) == 0.0
     assert [c[0] for c in log] == ["ar"] + ["a2a"] * (2 * layers) + ["ar"]
-    assert log[0] == ("ar", 1) and log[-1] == ("ar", 3 * len(pos) + 1)
+    # the final message is [gradient | energy | run-phase error flag] (a rank that failed while it ran says so
+    # in the reduction every rank enters anyway)
+    assert log[0] == ("ar", 1) and log[-1] == ("ar", 3 * len(pos) + 2)
     assert all(c[1] == (0, 4) and c[2] == (0, 4) and c[3] == [0] * 4 and c[4] == [0] * 4 for c in log[1:-1])
 
 
@@ -258,3 +260,22 @@ def test_exchange_setup_failure_reaches_every_rank_before_the_layer_loop():
         partition.energy_and_gradient_exchange(_ExchangeModel(2), pos, z, cell, pbc, 4, 2, all_to_all, flag_sum(1.0),
                                                runtime=_ToyRuntime)
     assert calls == [("ar", 0.0)]
+
+
+def test_exchange_run_phase_failure_of_a_peer_stops_every_rank():
+    """a rank that fails AFTER the set-up agreement tops its collectives up and used to add a partly filled buffer
+    to the final all-reduce: its peers returned a finite but wrong energy. The buffer now carries an error flag; a rank
+    that finds it raised by somebody else stops too."""
+    pos, z, cell, pbc = _clustered()
+    layers = 3
+
+    def all_to_all(out, inp, out_splits, in_splits):
+        pass
+
+    def all_reduce_with_failed_peer(t):
+        if t.numel() > 1:   # the final [gradient | energy | flag] message: a peer raised its flag
+            t[-1] += 1.0
+
+    with pytest.raises(RuntimeError, match="another rank failed during the per-layer exchange"):
+        partition.energy_and_gradient_exchange(_ExchangeModel(layers), pos, z, cell, pbc, 4, 0, all_to_all,
+                                               all_reduce_with_failed_peer, runtime=_ToyRuntime)
