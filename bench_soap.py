@@ -58,9 +58,10 @@ SOAP_STAGE_KERNELS = {"soap_expand": "k_soap_expand_w", "soap_ps": "k_soap_ps_w"
 
 def pmc_traffic(stage, n_pairs):
     """HBM bytes per launch of the stage's kernel and of a whole step from the committed rocprofv3 PMC passes of this bench
-    (profiles/r04_soap_traffic.json: --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, (2 FETCH + WRITE) x 1024); None
+    (profiles/r0N_soap_traffic.json of the newest round: --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, (2 FETCH + WRITE) x 1024); None
     unless the profiled run had the same number of pairs."""
-    path = os.path.join(ROOT, "profiles", "r04_soap_traffic.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_soap_traffic.json") for r in (5, 4)) if os.path.exists(q)),
+                os.path.join(ROOT, "profiles", "r04_soap_traffic.json"))
     if not os.path.exists(path):
         return None, None
     with open(path) as fh:
