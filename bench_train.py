@@ -112,6 +112,8 @@ def main():
                          "mode; the default run reports it next to `value` as `train_bf16`)")
     ap.add_argument("--normalization", default="RMSNorm", choices=["RMSNorm", "LayerNorm"],
                     help="LayerNorm: the legacy-checkpoint norm")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=INT",
+                    help="library switch for A/B runs (pet_config_set), as in bench.py")
     args = ap.parse_args()
     if args.config4:
         args.total_boxes, args.atoms = args.total_boxes or 512, 10000
@@ -152,6 +154,8 @@ def main():
     model = rt.HipModel(hypers, [1, 6, 7, 8])
     model.load({k: v.to(dev) for k, v in params.items()}, "energy")
 
+    for kv in args.set:
+        rt.config_set(kv.split("=")[0], int(kv.split("=")[1]))
     if args.train_bf16:
         rt.config_set("train_bf16", 1)
     gen = torch.Generator().manual_seed(1234 + rank)
