@@ -258,6 +258,8 @@ int finalize(Model& m, hipStream_t st) {
             if ((rc = get(m, lp + ".norm_mlp.weight", D, &A.g_mlp))) return rc;
             if ((rc = get_lin(m, lp + ".mlp.w_in", 2 * DFF, D, A.mlp_in, st))) return rc;
             if ((rc = get_lin(m, lp + ".mlp.w_out", D, DFF, A.mlp_out, st))) return rc;
+            if ((rc = pack_lin_s(m, lp + ".mlp.w_in", A.mlp_in, st))) return rc;   // k_emlp_s (pet_emlp_s.hip)
+            if ((rc = pack_lin_s(m, lp + ".mlp.w_out", A.mlp_out, st))) return rc;
             if (m.layer_norm()) {  // torch.nn.LayerNorm: weight + bias (transformer.py:170-176)
                 if ((rc = get(m, lp + ".norm_attention.bias", D, &A.b_attn))) return rc;
                 if ((rc = get(m, lp + ".norm_mlp.bias", D, &A.b_mlp))) return rc;
@@ -943,6 +945,7 @@ int pet_config_set(const char* key, int value) {
     else if (k == "soap_sorted") set_soap_sorted(value);
     else if (k == "attn_lds") set_attn_lds(value);
     else if (k == "attn_fused") set_attn_fused(value);
+    else if (k == "emlp_s") set_emlp_s(value);
     else if (k == "attn_fused_prof") ablk_prof_dump();
     else if (k == "tile_f16x3") set_tile_f16x3(value);
     else if (k == "trr_compress") set_trr_compress(value);

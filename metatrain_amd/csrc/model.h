@@ -298,6 +298,9 @@ bool trr_comb_bwd(const float* dM, const float* XF, const Graph& g, const GnnLay
 // adjoint recomputing Q, K, V); false = not served (an atom of more than 64 tokens, planes missing, switched off)
 void set_sorted_shortcut(int v);  // graph.hip: 1 = a neighbour list that is ordered by centre skips the radix sort (default)
 void set_attn_fused(int v);
+void set_emlp_s(int v);
+bool emlp_s(const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout, float* VG, float* X2,
+            int64_t E, hipStream_t st);
 int attn_fused();
 void ablk_prof_dump();  // debugging aid: per-phase cycle sums of the fused kernels (library built with -DAB_PROFILE)
 bool ablk_fwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* X, float* X1, float* OC, float scale,

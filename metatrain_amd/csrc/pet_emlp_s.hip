@@ -1,0 +1,233 @@
+// The edge MLP (transformer.py:39-50, 230-232: X2 = X1 + W_out swiglu(W_in RMSNorm(X1))) built like the fused attention
+// forward (pet_ablk.hip) instead of like the one-wave-per-SIMD pipelined row kernel k_emlp_p2 (pet_trr.hip): round 5.
+//
+// k_emlp_p2 keeps two accumulators per product (acc + 2^-11 acl), which costs it the whole register file: one wave per
+// SIMD, and measured (tools/experiments/README.md) that wave spends 20 % of its life waiting for its own 16 KB of rows with
+// nothing else resident, and its matrix and vector work add up instead of overlapping. Here every product is the
+// ONE-accumulator split-operand product of ablk.h (planes H = fp16(s x), L = fp16(s x - H); three MFMAs on one accumulator),
+// so a wave needs ~200 registers and 16 KB of LDS: two workgroups of four waves per CU = two waves per SIMD that are NOT in
+// step with each other (an eight-wave workgroup was tried first: its waves meet at every stage barrier, so the two waves of a
+// SIMD were in their matrix phase or in their vector phase at the same time -- SQ_VALU_MFMA_COEXEC_CYCLES 875 per wave against
+// 5 600 in k_emlp_p2 -- and it ran no faster than k_emlp_p2). The four waves of a workgroup share ONE stream of weight fragments
+// through a four-slot LDS ring (each weight byte is fetched once per four row tiles instead of once per tile), requested
+// three stages ahead (an LDS-DMA request takes ~1 us to land; a stage is 6 MFMAs per wave).
+//
+//   rows      32 per wave, LDS-DMA; residual + output bias = initial value of the out accumulators; RMSNorm / LayerNorm;
+//             planes of 64 xn parked over the rows
+//   chunk hc  (32 hidden units, 8 of them): [v; g] = W_in xn + b (4 stages of 2 K blocks: 48 MFMAs), saved if asked for;
+//             u = v sigmoid(g), planes of u at scale 1 (fp16 range 65504: u is not bounded like a normalised row);
+//             out += W_out[:, chunk] u (2 stages of one K block x 4 tiles: 24 MFMAs)
+//   stores    whole lines through the wave's (dead) plane tile, as in k_ablk_fwd
+// Scales: W planes 64 x, xn planes 64 x -> [v; g] accumulators hold 4096 x; u planes 1 x -> out accumulators hold 64 x.
+#include "ablk.h"
+
+namespace pet {
+
+constexpr int ES_NW = 4;       // waves per workgroup
+constexpr int ES_SLOT = 4096;  // ring slot: 4 fragments, one per wave
+constexpr int ES_NSLOT = 4;
+constexpr int ES_SPC = 12;     // stages per hidden chunk: 8 of W_in, 4 of W_out
+constexpr int ES_NSTAGE = ES_SPC * (DFF / 32);
+
+// stage g = 12 hc + s of the weight stream; wave w brings fragment w of the stage
+//   s < 8:  W_in K block s of tiles v (hc) and g (DFF / 32 + hc): fragments {vh, vl, gh, gl}
+//   s >= 8: W_out K block 2 hc + (s - 8) / 2 of output tiles 2 th, 2 th + 1 (th = (s - 8) % 2): fragments 2 t + plane
+__device__ __forceinline__ void es_request(int hc, int s, const W2& win, const W2& wout, unsigned ring_u, int wave,
+                                           unsigned lane16) {  // s may run past the chunk (s < 2 ES_SPC): the next chunk's stage
+    if (s >= ES_SPC) { s -= ES_SPC; hc += 1; }
+    if (hc >= DFF / 32) { hc = DFF / 32 - 1; s = ES_SPC - 1; }  // past the end: the last stage again (identical bytes; keeps vmcnt uniform)
+#ifdef AB_ABL_NODMA
+    if (hc > 0 || s > 2) return;
+#endif
+    const unsigned dst = ring_u + (unsigned)((ES_SPC * hc + s) & (ES_NSLOT - 1)) * ES_SLOT + wave * 1024;
+    if (s < 8) {
+        const int tile = (wave >> 1) * (DFF / 32) + hc;
+        ab_dma_piece((wave & 1) ? win.l : win.h, tile * (D / 16) + s, lane16, dst);
+    } else {
+        const int kb2 = (s - 8) >> 1, t = 2 * ((s - 8) & 1) + (wave >> 1);
+        ab_dma_piece((wave & 1) ? wout.l : wout.h, t * (DFF / 16) + 2 * hc + kb2, lane16, dst);
+    }
+}
+// this wave's fragment of the stage has landed (everything but its fragments of the two stages requested after it), then
+// the workgroup barrier: the stage is complete for everybody, and everybody is done with the stage before it
+#ifdef AB_ABL_NOBAR
+#define ES_BARRIER()
+#else
+#define ES_BARRIER() __syncthreads()
+#endif
+// (vmcnt retires in order, stores included: behind the chunk's eight [v; g] store instructions -- issued between the requests of stages 12 hc + 10 and 12 hc + 11 -- the
+// count is 2 + 8 for the three stages whose fragments were requested before them and are waited for after them: 12 hc + 8 .. + 10)
+#define ES_STAGE_SYNC(AFTER_STORES)                                           \
+    do {                                                                      \
+        if ((AFTER_STORES) && !full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* a partial tile skips store instructions */ \
+        else if (AFTER_STORES) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        \
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                 \
+        ES_BARRIER();                                                         \
+    } while (0)
+// accumulator tile initialised with 4096 x bias, the bias read through the SCALAR cache (wave-uniform addresses, both halves
+// of a column group, selected by lane half): a vector load here would sit in the in-order vmcnt queue behind the ring requests
+__device__ __forceinline__ void es_bias_tile(f32x16& acc, const float* __restrict__ b, int h) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float lo = b[8 * j + i], hi = b[8 * j + 4 + i];
+            acc[4 * j + i] = (h ? hi : lo) * ABQ;
+        }
+}
+
+template <bool LN>
+__global__ __launch_bounds__(256, 2) void k_emlp_s(const float* __restrict__ X1, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, W2 win, const float* __restrict__ bin, W2 wout,
+                                                const float* __restrict__ bout, float* __restrict__ VG, float* __restrict__ X2,
+                                                int64_t E) {
+    extern __shared__ __attribute__((aligned(16))) char es_smem[];
+    const RowLane L;
+    const unsigned lane16 = (unsigned)L.lane * 16u;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int64_t row0 = ((int64_t)blockIdx.x * ES_NW + wave) * WROWS;
+    const bool live = row0 < E;
+    if (!live) row0 = ((E - 1) / WROWS) * WROWS;  // run along on the last tile (same barriers), store nothing
+    char* tile = es_smem + wave * 16384;
+    const char* ring = es_smem + ES_NW * 16384;
+    const unsigned tile_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile);
+    const unsigned ring_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+    dma_tile128(X1, row0, E, tile_u, L);
+    es_request(0, 0, win, wout, ring_u, wave, lane16);
+    es_request(0, 1, win, wout, ring_u, wave, lane16);
+    es_request(0, 2, win, wout, ring_u, wave, lane16);
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // the rows (the three ring requests may still be in flight)
+    f32x16 out[4];
+    f16x8 xph[8], xpl[8];
+    {
+        float4 x[16];
+        tile128_to_frag(x, tile, L);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {  // 64 (x + b_out): the residual rides in the accumulator
+                const float4 b4 = *reinterpret_cast<const float4*>(bout + 32 * t + 8 * j + 4 * L.h);
+                out[t][4 * j] = (x[4 * t + j].x + b4.x) * ABS; out[t][4 * j + 1] = (x[4 * t + j].y + b4.y) * ABS;
+                out[t][4 * j + 2] = (x[4 * t + j].z + b4.z) * ABS; out[t][4 * j + 3] = (x[4 * t + j].w + b4.w) * ABS;
+            }
+        norm_frag<16, LN>(x, gamma, beta, L.h);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {  // planes of 64 xn, kept in REGISTERS: every hidden chunk reads all of them (an eighth
+            // of the kernel's LDS reads), and the row tile becomes the staging tile of the whole-line [v; g] stores
+            const float v8[8] = {x[2 * kb].x * ABS, x[2 * kb].y * ABS, x[2 * kb].z * ABS, x[2 * kb].w * ABS,
+                                 x[2 * kb + 1].x * ABS, x[2 * kb + 1].y * ABS, x[2 * kb + 1].z * ABS, x[2 * kb + 1].w * ABS};
+            ab_split8(v8, xph[kb], xpl[kb]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    float* const otile = reinterpret_cast<float*>(tile);  // [32][TILE32_LD] staging (trr.h store_tile32_lines)
+    const bool full = row0 + WROWS <= E;        // every row of the tile exists: each store instruction has active lanes
+    const bool stores = VG != nullptr && live;  // wave-uniform: the chunk's eight store instructions are issued
+
+#pragma unroll 1
+    for (int hc = 0; hc < DFF / 32; hc++) {
+        f32x16 va, ga;
+        es_bias_tile(va, bin + 32 * hc, L.h);
+        es_bias_tile(ga, bin + DFF + 32 * hc, L.h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const int g = ES_SPC * hc + s;
+            ES_STAGE_SYNC(false);
+            es_request(hc, s + 3, win, wout, ring_u, wave, lane16);
+            const char* slot = ring + (g & (ES_NSLOT - 1)) * ES_SLOT + lane16;
+            const f16x8 wvh = *reinterpret_cast<const f16x8*>(slot + 0 * 1024);
+            const f16x8 wvl = *reinterpret_cast<const f16x8*>(slot + 1 * 1024);
+            const f16x8 wgh = *reinterpret_cast<const f16x8*>(slot + 2 * 1024);
+            const f16x8 wgl = *reinterpret_cast<const f16x8*>(slot + 3 * 1024);
+            AB_MFMA3(va, wvh, wvl, xph[s], xpl[s]);
+            AB_MFMA3(ga, wgh, wgl, xph[s], xpl[s]);
+        }
+        // pre-activations, saved for the adjoint; u = v sigmoid(g) (transformer.py:42-43) as planes at scale 1
+        f32x16 u;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            va[i] *= ABQ_INV;
+            ga[i] *= ABQ_INV;
+            u[i] = va[i] * sigm_(ga[i]);
+        }
+        if (stores) {  // whole 128-B lines through the staging tile (8 lanes per row)
+            float4 t4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) t4[q] = make_float4(va[4 * q], va[4 * q + 1], va[4 * q + 2], va[4 * q + 3]);
+            store_tile32_lines(t4, otile, VG + 32 * hc, row0, E, 2 * DFF, L);
+#pragma unroll
+            for (int q = 0; q < 4; q++) t4[q] = make_float4(ga[4 * q], ga[4 * q + 1], ga[4 * q + 2], ga[4 * q + 3]);
+            store_tile32_lines(t4, otile, VG + DFF + 32 * hc, row0, E, 2 * DFF, L);
+        }
+        f16x8 uh[2], ul[2];
+        ab_tile_planes(u, uh, ul);
+#pragma unroll
+        for (int s = 8; s < 12; s++) {
+            const int g = ES_SPC * hc + s;
+            ES_STAGE_SYNC(s < 11 && stores);  // (the fragments of stages 8 .. 10 were requested before the stores)
+            es_request(hc, s + 3, win, wout, ring_u, wave, lane16);
+            const char* slot = ring + (g & (ES_NSLOT - 1)) * ES_SLOT + lane16;
+            const int kb2 = (s - 8) >> 1, th = (s - 8) & 1;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(slot + (2 * t) * 1024);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(slot + (2 * t + 1) * 1024);
+                AB_MFMA3(out[2 * th + t], wh, wl, uh[kb2], ul[kb2]);
+            }
+        }
+    }
+    // ---- X2 = out / 64: whole lines through the wave's own tile (the planes are dead)
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    float* stg = reinterpret_cast<float*>(tile);  // [32][TILE_LD]
+    const int rr = L.lane >> 4, cc = 4 * (L.lane & 15);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                *reinterpret_cast<float4*>(stg + L.r * TILE_LD + 8 * (4 * t + j) + 4 * L.h) =
+                    make_float4(out[2 * c + t][4 * j] * ABS_INV, out[2 * c + t][4 * j + 1] * ABS_INV,
+                                out[2 * c + t][4 * j + 2] * ABS_INV, out[2 * c + t][4 * j + 3] * ABS_INV);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int r = 4 * j + rr;
+            if (live && row0 + r < E)
+                *reinterpret_cast<float4*>(X2 + (row0 + r) * D + 64 * c + cc) = *reinterpret_cast<const float4*>(stg + r * TILE_LD + cc);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+static int g_emlp_s = 1;  // pet_config_set("emlp_s", 0): the one-wave-per-SIMD pipelined kernel k_emlp_p2
+void set_emlp_s(int v) { g_emlp_s = v ? 1 : 0; }
+
+static inline W2 es_w2(const void* base, int n_out, int k_in) {
+    const size_t n8 = (size_t)(n_out / 32) * (k_in / 16) * 64;
+    const f16x8* b = reinterpret_cast<const f16x8*>(base);
+    W2 w; w.h = b; w.l = b + n8;
+    return w;
+}
+
+// false = not served (weights not packed for it, or switched off)
+bool emlp_s(const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout, float* VG, float* X2,
+            int64_t E, hipStream_t st) {
+    if (!g_emlp_s || !win.fwd2s || !wout.fwd2s) return false;
+    if (E <= 0) return true;
+    const size_t lds = ES_NW * 16384 + ES_NSLOT * ES_SLOT;
+    const W2 wi = es_w2(win.fwd2s, win.n_out, win.k_in), wo = es_w2(wout.fwd2s, wout.n_out, wout.k_in);
+    const int grid = (int)cdiv(E, ES_NW * WROWS);
+    if (beta) {
+        allow_big_lds(k_emlp_s<true>, lds);
+        k_emlp_s<true><<<grid, 256, lds, st>>>(X1, gamma, beta, wi, win.b, wo, wout.b, VG, X2, E);
+    } else {
+        allow_big_lds(k_emlp_s<false>, lds);
+        k_emlp_s<false><<<grid, 256, lds, st>>>(X1, gamma, beta, wi, win.b, wo, wout.b, VG, X2, E);
+    }
+    return true;
+}
+
+}  // namespace pet
