@@ -1315,7 +1315,16 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 k_rownorm_bwd<<<gR, NTHREADS, lds1, st>>>(dX, dX + E * D, Ab.X1, A.g_attn, ln, dX_alt, E, R);
             } else {
                 ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D), fE * 4.0 * (3 * D + 2 * DFF));  // dY, X1, VG in; dX1 out
-                if (dxf_fused && a == m.h.num_attention_layers - 1) {
+                // the forward of this workspace did not save [v; g] (its record says so; without a record -- a graph handle
+                // made anew for the adjoint call -- the forward followed the same switches as this call does)
+                if (fwd_rec ? fwd_rec->emlp_unsaved : (!tr && trr_l && emlp_recompute_on(A.mlp_in, A.mlp_out, E))) {
+                    const bool gat = dxf_fused && a == m.h.num_attention_layers - 1;
+                    PET_REQUIRE(!tr && trr_l && emlp_bwd_s(gat ? w.dcat : dX, Ab.X1, A.g_mlp, ln ? A.b_mlp : nullptr, A.mlp_in,
+                                                          A.mlp_out, dX_alt, E, st, gat ? 2 * D : D, gat ? w.dcat + D : nullptr,
+                                                          gat ? g.rev : nullptr),
+                                PET_ERR_ARGUMENT, "the forward of this workspace did not save the edge MLP's pre-activations "
+                                "and the recomputing adjoint is switched off: pet_config_set changed between forward and backward");
+                } else if (dxf_fused && a == m.h.num_attention_layers - 1) {
                     // dXF[p] = (dM[p] + dcat[p][:D]) + dcat[rev[p]][D:]: the bracket left k_comb_bwd_p2 in dcat's first
                     // half, the gather is made while this kernel reads its tile
                     trr_emlp_bwd(w.dcat, Ab.X1, Ab.VG, A.g_mlp, ln ? A.b_mlp : nullptr, A.mlp_in, A.mlp_out, dX_alt, E, st,

@@ -202,8 +202,210 @@ __global__ __launch_bounds__(256, 2) void k_emlp_s(const float* __restrict__ X1,
     }
 }
 
-static int g_emlp_s = 1;  // pet_config_set("emlp_s", 0): the one-wave-per-SIMD pipelined kernel k_emlp_p2
+// ---------------------------------------------------------------------------------------------
+// The adjoint in the same form, WITHOUT the saved pre-activations: [v; g] of a hidden chunk is recomputed from the layer
+// input (48 MFMAs per chunk on top of the adjoint's 72), so the forward does not write 2 KB per row and this kernel does not
+// read them -- and nothing but weight fragments is requested between a tile's first and last instruction (an HBM load in
+// the middle of the stream would sit in front of every later fragment wait: vmcnt retires in order).
+//   dX1 = dY + NormAdj(gamma . dxn, x1),  dxn = W_in^T [dv; dg],  dv = du s(g),  dg = du v s(g) (1 - s(g)),  du = W_out^T dY
+// (transformer.py:39-50, 230-232 under autograd; k_emlp_bwd_p2's arithmetic with the recomputation of k_emlp_s in front).
+// Per wave: planes of 64 xn in registers, planes of 64 dY' (dY' = the row times the power of two that puts its largest entry
+// in [1, 2)) in the wave's LDS tile, [dv | dg] as planes at scale 1. Stages of a chunk (four fragments each, one per wave):
+//   0 .. 7    W_in K block s, tiles v / g                     va, ga += W xn           (6 MFMAs)
+//   8 .. 11   W_out^T tile hc, K blocks 2 (s - 8), + 1        du += W^T dY'            (6)
+//   12 .. 19  W_in^T K block kk = (s - 12) / 2 of the chunk (dv 0, 1; dg 0, 1), tiles 2 th, 2 th + 1: dn += W^T [dv | dg]  (6)
+// GATHER: dY = dY[row] + dY2[rev2[row]] (rows of ldy floats), the ji gather of the combination adjoint (pet_bwd.hip).
+// ---------------------------------------------------------------------------------------------
+constexpr int EB_SPC = 20;
+__device__ __forceinline__ void eb_request(int hc, int s, const W2& win, const W2& woutT, const W2& winT, unsigned ring_u, int wave,
+                                           unsigned lane16) {
+    if (s >= EB_SPC) { s -= EB_SPC; hc += 1; }
+    if (hc >= DFF / 32) { hc = DFF / 32 - 1; s = EB_SPC - 1; }
+#ifdef AB_ABL_NODMA
+    if (hc > 0 || s > 2) return;
+#endif
+    const unsigned dst = ring_u + (unsigned)((EB_SPC * hc + s) & (ES_NSLOT - 1)) * ES_SLOT + wave * 1024;
+    const int pl = wave & 1, j = wave >> 1;
+    if (s < 8) {
+        ab_dma_piece(pl ? win.l : win.h, (j * (DFF / 32) + hc) * (D / 16) + s, lane16, dst);
+    } else if (s < 12) {  // W_out^T: tiles over the hidden units (DFF / 32), K = D: fragment (hc, kb)
+        ab_dma_piece(pl ? woutT.l : woutT.h, hc * (D / 16) + 2 * (s - 8) + j, lane16, dst);
+    } else {              // W_in^T: tiles over D (4), K = 2 DFF: K block of the chunk: dv -> 2 hc + b, dg -> DFF / 16 + 2 hc + b
+        const int kk = (s - 12) >> 1, t = 2 * ((s - 12) & 1) + j;
+        const int kb = (kk >> 1) * (DFF / 16) + 2 * hc + (kk & 1);
+        ab_dma_piece(pl ? winT.l : winT.h, t * (2 * DFF / 16) + kb, lane16, dst);
+    }
+}
+
+template <bool LN, bool GATHER>
+__global__ __launch_bounds__(256, 2) void k_emlp_bwd_s(const float* __restrict__ dY, const float* __restrict__ X1,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, W2 win,
+                                                       const float* __restrict__ bin, W2 woutT, W2 winT,
+                                                       float* __restrict__ dX1, int64_t E, int ldy,
+                                                       const float* __restrict__ dY2, const int* __restrict__ rev2) {
+    extern __shared__ __attribute__((aligned(16))) char es_smem[];
+    const RowLane L;
+    const unsigned lane16 = (unsigned)L.lane * 16u;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int64_t row0 = ((int64_t)blockIdx.x * ES_NW + wave) * WROWS;
+    const bool live = row0 < E;
+    if (!live) row0 = ((E - 1) / WROWS) * WROWS;
+    const int64_t row = row0 + L.r < E ? row0 + L.r : E - 1;
+    constexpr bool full = true;  // (ES_STAGE_SYNC: this kernel has no stores between its stages)
+    char* tile = es_smem + wave * 16384;
+    const char* ring = es_smem + ES_NW * 16384;
+    const unsigned tile_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile);
+    const unsigned ring_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+    // the layer input by LDS-DMA, the adjoint rows as row fragments straight into registers, the first ring stages
+    dma_tile128(X1, row0, E, tile_u, L);
+    float4 dy[16];
+    load_rowfrag<16>(dy, dY, row, ldy, L.h);
+    if (GATHER) {
+        float4 d2[16];
+        load_rowfrag<16>(d2, dY2, (int64_t)rev2[row], ldy, L.h);
+#pragma unroll
+        for (int k = 0; k < 16; k++) { dy[k].x += d2[k].x; dy[k].y += d2[k].y; dy[k].z += d2[k].z; dy[k].w += d2[k].w; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    eb_request(0, 0, win, woutT, winT, ring_u, wave, lane16);
+    eb_request(0, 1, win, woutT, winT, ring_u, wave, lane16);
+    eb_request(0, 2, win, woutT, winT, ring_u, wave, lane16);
+    f16x8 xph[8], xpl[8];
+    {
+        float4 x[16];
+        tile128_to_frag(x, tile, L);
+        norm_frag<16, LN>(x, gamma, beta, L.h);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            const float v8[8] = {x[2 * kb].x * ABS, x[2 * kb].y * ABS, x[2 * kb].z * ABS, x[2 * kb].w * ABS,
+                                 x[2 * kb + 1].x * ABS, x[2 * kb + 1].y * ABS, x[2 * kb + 1].z * ABS, x[2 * kb + 1].w * ABS};
+            ab_split8(v8, xph[kb], xpl[kb]);
+        }
+    }
+    float inv;
+    {
+        float sc;
+        inv = row_scale_pow2<16>(dy, sc);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        ab_park_planes(dy, tile, L);  // planes of 64 dY' over the (consumed) input rows
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    f32x16 dn[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) dn[t] = ab_zero();
+
+#pragma unroll 1
+    for (int hc = 0; hc < DFF / 32; hc++) {
+        f32x16 va, ga;
+        es_bias_tile(va, bin + 32 * hc, L.h);
+        es_bias_tile(ga, bin + DFF + 32 * hc, L.h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            ES_STAGE_SYNC(false);
+            eb_request(hc, s + 3, win, woutT, winT, ring_u, wave, lane16);
+            const char* slot = ring + ((EB_SPC * hc + s) & (ES_NSLOT - 1)) * ES_SLOT + lane16;
+            const f16x8 wvh = *reinterpret_cast<const f16x8*>(slot + 0 * 1024);
+            const f16x8 wvl = *reinterpret_cast<const f16x8*>(slot + 1 * 1024);
+            const f16x8 wgh = *reinterpret_cast<const f16x8*>(slot + 2 * 1024);
+            const f16x8 wgl = *reinterpret_cast<const f16x8*>(slot + 3 * 1024);
+            AB_MFMA3(va, wvh, wvl, xph[s], xpl[s]);
+            AB_MFMA3(ga, wgh, wgl, xph[s], xpl[s]);
+        }
+        f32x16 du = ab_zero();
+#pragma unroll
+        for (int s = 8; s < 12; s++) {
+            ES_STAGE_SYNC(false);
+            eb_request(hc, s + 3, win, woutT, winT, ring_u, wave, lane16);
+            const char* slot = ring + ((EB_SPC * hc + s) & (ES_NSLOT - 1)) * ES_SLOT + lane16;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int kb = 2 * (s - 8) + j;
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(slot + (2 * j) * 1024);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(slot + (2 * j + 1) * 1024);
+                const f16x8 yh = *reinterpret_cast<const f16x8*>(tile + ((kb * 2 + 0) * 64 + L.lane) * 16);
+                const f16x8 yl = *reinterpret_cast<const f16x8*>(tile + ((kb * 2 + 1) * 64 + L.lane) * 16);
+                AB_MFMA3(du, wh, wl, yh, yl);
+            }
+        }
+        // SwiGLU adjoint; [dv | dg] as planes at scale 1 (K blocks dv 0, dv 1, dg 0, dg 1)
+        f16x8 dh[4], dl[4];
+        {
+            f32x16 dv, dg;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float d = du[i] * ABQ_INV, v = va[i] * ABQ_INV, sg = sigm_(ga[i] * ABQ_INV);
+                dv[i] = d * sg;
+                dg[i] = d * v * sg * (1.f - sg);
+            }
+            f16x8 h2[2], l2[2];
+            ab_tile_planes(dv, h2, l2);
+            dh[0] = h2[0]; dh[1] = h2[1]; dl[0] = l2[0]; dl[1] = l2[1];
+            ab_tile_planes(dg, h2, l2);
+            dh[2] = h2[0]; dh[3] = h2[1]; dl[2] = l2[0]; dl[3] = l2[1];
+        }
+#pragma unroll
+        for (int s = 12; s < 20; s++) {
+            ES_STAGE_SYNC(false);
+            eb_request(hc, s + 3, win, woutT, winT, ring_u, wave, lane16);
+            const char* slot = ring + ((EB_SPC * hc + s) & (ES_NSLOT - 1)) * ES_SLOT + lane16;
+            const int kk = (s - 12) >> 1, th = (s - 12) & 1;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(slot + (2 * t) * 1024);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(slot + (2 * t + 1) * 1024);
+                AB_MFMA3(dn[2 * th + t], wh, wl, dh[kk], dl[kk]);
+            }
+        }
+    }
+    // ---- epilogue: the residual (dY' from its planes), the layer input once more for the norm adjoint, whole-line stores
+    float4 w[16], r4[16];
+#pragma unroll
+    for (int kb = 0; kb < 8; kb++) {
+        const f16x8 yh = *reinterpret_cast<const f16x8*>(tile + ((kb * 2 + 0) * 64 + L.lane) * 16);
+        const f16x8 yl = *reinterpret_cast<const f16x8*>(tile + ((kb * 2 + 1) * 64 + L.lane) * 16);
+        const float f = inv * ABS_INV;
+        r4[2 * kb] = make_float4(((float)yh[0] + (float)yl[0]) * f, ((float)yh[1] + (float)yl[1]) * f,
+                                 ((float)yh[2] + (float)yl[2]) * f, ((float)yh[3] + (float)yl[3]) * f);
+        r4[2 * kb + 1] = make_float4(((float)yh[4] + (float)yl[4]) * f, ((float)yh[5] + (float)yl[5]) * f,
+                                     ((float)yh[6] + (float)yl[6]) * f, ((float)yh[7] + (float)yl[7]) * f);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    dma_tile128(X1, row0, E, tile_u, L);
+    {
+        const float f = inv * ABS_INV;  // dn holds 64 x (W_in^T planes) of the scaled row
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gamma + 32 * t + 8 * j + 4 * L.h);
+                w[4 * t + j] = make_float4(dn[t][4 * j] * f * g4.x, dn[t][4 * j + 1] * f * g4.y, dn[t][4 * j + 2] * f * g4.z,
+                                           dn[t][4 * j + 3] * f * g4.w);
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        float4 x[16];
+        tile128_to_frag(x, tile, L);
+        norm_bwd_frag<16, LN>(w, x);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { w[k].x += r4[k].x; w[k].y += r4[k].y; w[k].z += r4[k].z; w[k].w += r4[k].w; }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    store_rows_lines<16>(w, reinterpret_cast<float*>(tile), L, [&](int r) { return live && row0 + r < E ? dX1 + (row0 + r) * D : nullptr; });
+}
+
+static int g_emlp_s = 1;  // pet_config_set("emlp_s", 0): the one-wave-per-SIMD pipelined kernels k_emlp_p2 / k_emlp_bwd_p2
 void set_emlp_s(int v) { g_emlp_s = v ? 1 : 0; }
+static int g_emlp_rc = 1;  // pet_config_set("emlp_recompute", 0): the forward saves [v; g] and k_emlp_bwd_p2 reads it
+void set_emlp_recompute(int v) { g_emlp_rc = v ? 1 : 0; }
+constexpr int64_t ES_MIN_ROWS = 16384;  // below: a launch is a few waves per SIMD and the pipelined kernels' shorter chain wins
+bool emlp_recompute_on(const Lin& win, const Lin& wout, int64_t E) {
+    return g_emlp_s && g_emlp_rc && E >= ES_MIN_ROWS && win.fwd2s && win.bwd2s && wout.fwd2s && wout.bwd2s;
+}
 
 static inline W2 es_w2(const void* base, int n_out, int k_in) {
     const size_t n8 = (size_t)(n_out / 32) * (k_in / 16) * 64;
@@ -215,8 +417,7 @@ static inline W2 es_w2(const void* base, int n_out, int k_in) {
 // false = not served (weights not packed for it, or switched off)
 bool emlp_s(const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout, float* VG, float* X2,
             int64_t E, hipStream_t st) {
-    if (!g_emlp_s || !win.fwd2s || !wout.fwd2s) return false;
-    if (E <= 0) return true;
+    if (!g_emlp_s || !win.fwd2s || !wout.fwd2s || E < ES_MIN_ROWS) return false;
     const size_t lds = ES_NW * 16384 + ES_NSLOT * ES_SLOT;
     const W2 wi = es_w2(win.fwd2s, win.n_out, win.k_in), wo = es_w2(wout.fwd2s, wout.n_out, wout.k_in);
     const int grid = (int)cdiv(E, ES_NW * WROWS);
@@ -227,6 +428,26 @@ bool emlp_s(const float* X1, const float* gamma, const float* beta, const Lin& w
         allow_big_lds(k_emlp_s<false>, lds);
         k_emlp_s<false><<<grid, 256, lds, st>>>(X1, gamma, beta, wi, win.b, wo, wout.b, VG, X2, E);
     }
+    return true;
+}
+
+// the adjoint with recomputed pre-activations; false = not served
+bool emlp_bwd_s(const float* dY, const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout,
+                float* dX1, int64_t E, hipStream_t st, int ldy, const float* dY2, const int* rev2) {
+    if (!g_emlp_s || !win.fwd2s || !win.bwd2s || !wout.bwd2s) return false;
+    if (E <= 0) return true;
+    const size_t lds = ES_NW * 16384 + ES_NSLOT * ES_SLOT;
+    const W2 wi = es_w2(win.fwd2s, win.n_out, win.k_in), wot = es_w2(wout.bwd2s, wout.n_out, wout.k_in),
+             wit = es_w2(win.bwd2s, win.n_out, win.k_in);
+    const int grid = (int)cdiv(E, ES_NW * WROWS);
+#define PET_EB(LNF, GF)                                                                                                    \
+    {                                                                                                                      \
+        allow_big_lds(k_emlp_bwd_s<LNF, GF>, lds);                                                                         \
+        k_emlp_bwd_s<LNF, GF><<<grid, 256, lds, st>>>(dY, X1, gamma, beta, wi, win.b, wot, wit, dX1, E, ldy, dY2, rev2);   \
+    }
+    if (beta) { if (dY2) PET_EB(true, true) else PET_EB(true, false) }
+    else { if (dY2) PET_EB(false, true) else PET_EB(false, false) }
+#undef PET_EB
     return true;
 }
 

@@ -1240,7 +1240,11 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
             if (E > 0 && !post) {
                 ProfScope ps("emlp", st, fE * 2.0 * (D * 2 * DFF + DFF * D), fE * 4.0 * (2 * D + 2 * DFF));  // X1 in; VG, X2 out
                 if (trr_l) {
-                    float* vg = save == 0 ? nullptr : Ab.VG;  // [v; g] is stored for the adjoint unless none follows
+                    float* vg = save == 0 ? nullptr : Ab.VG;  // [v; g] is stored for the adjoint unless none follows ...
+                    if (save == 1 && emlp_recompute_on(A.mlp_in, A.mlp_out, E)) {  // ... or the adjoint recomputes it (noted on the graph)
+                        vg = nullptr;
+                        fwd_rec.emlp_unsaved = true;
+                    }
                     trr_emlp(Ab.X1, A.g_mlp, m.layer_norm() ? A.b_mlp : nullptr, A.mlp_in, A.mlp_out, vg, Xnext, E, st);
                 }
                 else k_emlp<true><<<gE, NTHREADS, lds2, st>>>(Ab.X1, A.g_mlp, A.b_mlp, A.mlp_in.fwd, A.mlp_in.b, A.mlp_out.fwd,

@@ -988,7 +988,7 @@ void trr_oproj_bwd(const float* dX1, const float* dOC, const Lin& out, float* dA
 void trr_emlp(const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout, float* VG,
               float* X2, int64_t E, hipStream_t st) {
     if (E <= 0) return;
-    if (E >= 16384 && emlp_s(X1, gamma, beta, win, wout, VG, X2, E, st)) return;  // large graphs: two waves per SIMD (pet_emlp_s.hip)
+    if (emlp_s(X1, gamma, beta, win, wout, VG, X2, E, st)) return;  // large graphs: two waves per SIMD (pet_emlp_s.hip)
     const size_t lds = (size_t)4 * EP2_WAVE_LDS;
     if (beta) {
         allow_big_lds(k_emlp_p2<true>, lds);
