@@ -947,6 +947,7 @@ int pet_config_set(const char* key, int value) {
     else if (k == "attn_fused") set_attn_fused(value);
     else if (k == "emlp_s") set_emlp_s(value);
     else if (k == "emlp_recompute") set_emlp_recompute(value);
+    else if (k == "emlp_s_min") set_emlp_s_min(value);
     else if (k == "attn_fused_prof") ablk_prof_dump();
     else if (k == "tile_f16x3") set_tile_f16x3(value);
     else if (k == "trr_compress") set_trr_compress(value);

@@ -300,6 +300,7 @@ void set_sorted_shortcut(int v);  // graph.hip: 1 = a neighbour list that is ord
 void set_attn_fused(int v);
 void set_emlp_s(int v);
 void set_emlp_recompute(int v);
+void set_emlp_s_min(int v);
 bool emlp_recompute_on(const Lin& win, const Lin& wout, int64_t E);
 bool emlp_bwd_s(const float* dY, const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout,
                 float* dX1, int64_t E, hipStream_t st, int ldy, const float* dY2, const int* rev2);

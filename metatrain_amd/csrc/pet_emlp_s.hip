@@ -402,9 +402,10 @@ static int g_emlp_s = 1;  // pet_config_set("emlp_s", 0): the one-wave-per-SIMD 
 void set_emlp_s(int v) { g_emlp_s = v ? 1 : 0; }
 static int g_emlp_rc = 1;  // pet_config_set("emlp_recompute", 0): the forward saves [v; g] and k_emlp_bwd_p2 reads it
 void set_emlp_recompute(int v) { g_emlp_rc = v ? 1 : 0; }
-constexpr int64_t ES_MIN_ROWS = 16384;  // below: a launch is a few waves per SIMD and the pipelined kernels' shorter chain wins
+static int64_t g_es_min_rows = 16384;  // below: a launch is a few waves per SIMD and the pipelined kernels' shorter chain wins
+void set_emlp_s_min(int v) { g_es_min_rows = v; }  // pet_config_set("emlp_s_min", rows): the tests force the kernels on small graphs
 bool emlp_recompute_on(const Lin& win, const Lin& wout, int64_t E) {
-    return g_emlp_s && g_emlp_rc && E >= ES_MIN_ROWS && win.fwd2s && win.bwd2s && wout.fwd2s && wout.bwd2s;
+    return g_emlp_s && g_emlp_rc && E >= g_es_min_rows && win.fwd2s && win.bwd2s && wout.fwd2s && wout.bwd2s;
 }
 
 static inline W2 es_w2(const void* base, int n_out, int k_in) {
@@ -417,7 +418,7 @@ static inline W2 es_w2(const void* base, int n_out, int k_in) {
 // false = not served (weights not packed for it, or switched off)
 bool emlp_s(const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout, float* VG, float* X2,
             int64_t E, hipStream_t st) {
-    if (!g_emlp_s || !win.fwd2s || !wout.fwd2s || E < ES_MIN_ROWS) return false;
+    if (!g_emlp_s || !win.fwd2s || !wout.fwd2s || E < g_es_min_rows) return false;
     const size_t lds = ES_NW * 16384 + ES_NSLOT * ES_SLOT;
     const W2 wi = es_w2(win.fwd2s, win.n_out, win.k_in), wo = es_w2(wout.fwd2s, wout.n_out, wout.k_in);
     const int grid = (int)cdiv(E, ES_NW * WROWS);
