@@ -946,6 +946,7 @@ int pet_config_set(const char* key, int value) {
     else if (k == "attn_lds") set_attn_lds(value);
     else if (k == "attn_fused") set_attn_fused(value);
     else if (k == "emlp_s") set_emlp_s(value);
+    else if (k == "attn_fwd4") set_ablk_fwd4(value);
     else if (k == "emlp_recompute") set_emlp_recompute(value);
     else if (k == "emlp_s_min") set_emlp_s_min(value);
     else if (k == "attn_fused_prof") ablk_prof_dump();

@@ -298,6 +298,7 @@ bool trr_comb_bwd(const float* dM, const float* XF, const Graph& g, const GnnLay
 // adjoint recomputing Q, K, V); false = not served (an atom of more than 64 tokens, planes missing, switched off)
 void set_sorted_shortcut(int v);  // graph.hip: 1 = a neighbour list that is ordered by centre skips the radix sort (default)
 void set_attn_fused(int v);
+void set_ablk_fwd4(int v);
 void set_emlp_s(int v);
 void set_emlp_recompute(int v);
 void set_emlp_s_min(int v);

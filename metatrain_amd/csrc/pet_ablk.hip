@@ -336,6 +336,222 @@ __global__ __launch_bounds__(NQ == 1 ? 512 : 256) void k_ablk_fwd(
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_ablk_fwd4 (round 5): the same forward for the 32-slot tiles as TWO desynchronised four-wave workgroups per CU instead of
+// one eight-wave workgroup. In k_ablk_fwd the eight waves meet at every stage barrier, so the two waves of a SIMD run their
+// matrix phases and their vector phases at the same time; two independent workgroups drift apart and fill each other's
+// stalls (what made k_emlp_s faster than k_emlp_p2, pet_emlp_s.hip). Each workgroup has its own weight ring: four slots
+// of four fragments (one per wave and stage), requested three stages ahead:
+//   stage g = 12 hp + r (r = 0 .. 11): fragments 4 r .. 4 r + 3 of the head pair's 48 = [K block kb][Qh Ql Kh Kl Vh Vl]
+//                                       (r % 3 = 0: Q, K of kb = 2 (r / 3); 1: V of that kb, Q of the next; 2: K, V of the next)
+//   stage g = 48 + n (n = 0 .. 15):     W_o step n (c = n / 8, kb = n % 8): tiles 2 c, 2 c + 1 x (h, l)
+// Every stage is six MFMAs per wave. Both halves of the output projection are accumulated before anything is stored, so no
+// load or store sits between two stages (vmcnt retires in order: the count at a stage boundary is always the two fragments
+// requested after the one waited for).
+// ---------------------------------------------------------------------------------------------
+constexpr int AB4_SLOT = 4096, AB4_NSLOT = 4, AB4_NSTAGE = 64;
+__device__ __forceinline__ void ab4_request(int g, const W2& wqkv, const W2& wo, unsigned ring_u, int wave, unsigned lane16) {
+    g = g < AB4_NSTAGE ? g : AB4_NSTAGE - 1;  // past the end: the last stage again (identical bytes; keeps vmcnt uniform)
+    const unsigned dst = ring_u + (unsigned)(g & (AB4_NSLOT - 1)) * AB4_SLOT + wave * 1024;
+    if (g < 48) {
+        const int hp = g / 12, pc = 4 * (g % 12) + wave, kb = pc / 6, f = pc % 6;
+        ab_dma_piece((f & 1) ? wqkv.l : wqkv.h, 32 * (f >> 1) + hp * 8 + kb, lane16, dst);
+    } else {
+        const int n = g - 48;
+        ab_dma_piece((wave & 1) ? wo.l : wo.h, (2 * (n >> 3) + (wave >> 1)) * 8 + (n & 7), lane16, dst);
+    }
+}
+#define AB4_STAGE_SYNC()                                  \
+    do {                                                  \
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  \
+        __syncthreads();                                  \
+    } while (0)
+
+template <bool LN>
+__global__ __launch_bounds__(256, 2) void k_ablk_fwd4(
+    const float* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta, W2 wqkv,
+    const float* __restrict__ bqkv, W2 wo, const float* __restrict__ bo, const float* __restrict__ fc,
+    const int4* __restrict__ desc, int n_list, int64_t E, float qscale, float* __restrict__ X1, float* __restrict__ OC) {
+    constexpr int NW = 4;
+    extern __shared__ __attribute__((aligned(16))) char ab_smem[];
+    const RowLane L;
+    const unsigned lane16 = (unsigned)L.lane * 16u;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int li = blockIdx.x * NW + wave;
+    const bool live = li < n_list;
+    li = live ? li : n_list - 1;
+    const AbAtom a(desc + 2 * (size_t)li, E);
+    char* tile = ab_smem + wave * 16384;
+    const char* ring = ab_smem + NW * 16384;
+    const unsigned tile_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile);
+    const unsigned ring_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+    float bias[1][16];
+    ab_key_bias<1>(bias, a, fc, L);  // (its loads are consumed before the requests below: nothing but fragments in the queue)
+    asm volatile("" ::"v"(bias[0][0]), "v"(bias[0][15]));
+    ab_dma_rows<1>(X, a, tile_u, L);
+    ab4_request(0, wqkv, wo, ring_u, wave, lane16);
+    ab4_request(1, wqkv, wo, ring_u, wave, lane16);
+    ab4_request(2, wqkv, wo, ring_u, wave, lane16);
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // the rows
+    {
+        float4 x[16];
+        tile128_to_frag(x, tile, L);
+        norm_frag<16, LN>(x, gamma, beta, L.h);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        ab_park_planes(x, tile, L);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+
+    f16x8 aoh[8], aol[8];  // attention output: planes of the row fragment, K block = head
+#pragma unroll
+    for (int hp = 0; hp < 4; hp++) {
+        f32x16 q, k, v;
+        {
+            const float bv = bqkv[2 * D + 32 * hp + L.r] * ABQ;
+            ab_bias_tile(q, bqkv + 32 * hp, L.h);
+            ab_bias_tile(k, bqkv + D + 32 * hp, L.h);
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = bv;
+        }
+        asm volatile("" ::"v"(q[0]), "v"(k[0]), "v"(v[0]));  // the bias loads are consumed before the stage waits
+        f16x8 xh, xl;
+#pragma unroll
+        for (int r = 0; r < 12; r++) {
+            const int g = 12 * hp + r;
+            AB4_STAGE_SYNC();
+            ab4_request(g + 3, wqkv, wo, ring_u, wave, lane16);
+            const char* slot = ring + (g & (AB4_NSLOT - 1)) * AB4_SLOT + lane16;
+            const f16x8 f0 = *reinterpret_cast<const f16x8*>(slot + 0 * 1024);
+            const f16x8 f1 = *reinterpret_cast<const f16x8*>(slot + 1 * 1024);
+            const f16x8 f2 = *reinterpret_cast<const f16x8*>(slot + 2 * 1024);
+            const f16x8 f3 = *reinterpret_cast<const f16x8*>(slot + 3 * 1024);
+            const int m = r / 3;
+            if (r % 3 == 0) {  // Q, K of K block 2 m
+                xh = *reinterpret_cast<const f16x8*>(tile + (((2 * m) * 2 + 0) * 64 + L.lane) * 16);
+                xl = *reinterpret_cast<const f16x8*>(tile + (((2 * m) * 2 + 1) * 64 + L.lane) * 16);
+                AB_MFMA3(q, f0, f1, xh, xl);
+                AB_MFMA3(k, f2, f3, xh, xl);
+            } else if (r % 3 == 1) {  // V of K block 2 m, Q of 2 m + 1
+                AB_MFMA3(v, xh, xl, f0, f1);
+                xh = *reinterpret_cast<const f16x8*>(tile + (((2 * m + 1) * 2 + 0) * 64 + L.lane) * 16);
+                xl = *reinterpret_cast<const f16x8*>(tile + (((2 * m + 1) * 2 + 1) * 64 + L.lane) * 16);
+                AB_MFMA3(q, f2, f3, xh, xl);
+            } else {  // K, V of K block 2 m + 1
+                AB_MFMA3(k, f0, f1, xh, xl);
+                AB_MFMA3(v, xh, xl, f2, f3);
+            }
+        }
+        // ---- the attention core of the head pair: exactly k_ablk_fwd's
+        f16x8 qh[2], ql[2], kH[2], kL[2], vH[2], vL[2];
+        ab_tile_planes(q, qscale * ABS_INV, qh, ql);
+        ab_tile_planes(k, ABS_INV, kH, kL);
+        ab_tile_planes(v, ABS_INV, vH, vL);
+        f32x16 s[2];
+#pragma unroll
+        for (int hd = 0; hd < 2; hd++) {
+            s[hd] = ab_zero();
+            AB_MFMA3(s[hd], kH[hd], kL[hd], qh[hd], ql[hd]);
+        }
+        float mx[2], sum[2];
+#pragma unroll
+        for (int hd = 0; hd < 2; hd++) {
+            mx[hd] = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                s[hd][i] = fmaf(s[hd][i], ABQ_INV, bias[0][i]);
+                mx[hd] = fmaxf(mx[hd], s[hd][i]);
+            }
+        }
+#pragma unroll
+        for (int hd = 0; hd < 2; hd++) mx[hd] = fmaxf(mx[hd], __shfl_xor(mx[hd], 32)) - 6.0f;  // p comes out as 64 p
+#pragma unroll
+        for (int hd = 0; hd < 2; hd++) {
+            sum[hd] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float pe = __builtin_amdgcn_exp2f(s[hd][i] - mx[hd]);
+                s[hd][i] = pe;
+                sum[hd] += pe;
+            }
+        }
+#pragma unroll
+        for (int hd = 0; hd < 2; hd++) sum[hd] += __shfl_xor(sum[hd], 32);
+        f32x16 o[2];
+#pragma unroll
+        for (int hd = 0; hd < 2; hd++) {
+            o[hd] = ab_zero();
+            f16x8 ph[2], pl[2];
+            ab_tile_planes(s[hd], ph, pl);
+#pragma unroll
+            for (int b = 0; b < 2; b++) AB_MFMA3(o[hd], vH[b], vL[b], ph[b], pl[b]);
+        }
+#pragma unroll
+        for (int hd = 0; hd < 2; hd++) {
+            const float inv = __builtin_amdgcn_rcpf(sum[hd]);
+            float t8[8];
+            ab_regs8(o[hd], hd, inv, t8);
+            ab_split8(t8, aoh[2 * hp + hd], aol[2 * hp + hd]);
+        }
+    }
+    // ---- output projection: both 64-column halves accumulated before the stores
+    f32x16 y[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        ab_bias_tile(y[c][0], bo + 64 * c, L.h);
+        ab_bias_tile(y[c][1], bo + 64 * c + 32, L.h);
+    }
+    asm volatile("" ::"v"(y[0][0][0]), "v"(y[0][1][0]), "v"(y[1][0][0]), "v"(y[1][1][0]));
+#pragma unroll
+    for (int n = 0; n < 16; n++) {
+        const int g = 48 + n, c = n >> 3, kb = n & 7;
+        AB4_STAGE_SYNC();
+        ab4_request(g + 3, wqkv, wo, ring_u, wave, lane16);
+        const char* slot = ring + (g & (AB4_NSLOT - 1)) * AB4_SLOT + lane16;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(slot + (2 * t) * 1024);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(slot + (2 * t + 1) * 1024);
+            AB_MFMA3(y[c][t], wh, wl, aoh[kb], aol[kb]);
+        }
+    }
+    // ---- bias is in, residual, whole-line stores: X1 = X + Wo AO + bo (edge rows); OC = Wo AO + bo (the centre token)
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    float* stg = reinterpret_cast<float*>(tile);  // [32][TILE_LD]
+    const int rr = L.lane >> 4, cc = 4 * (L.lane & 15);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        float4 xr[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int sl = 4 * j + rr;
+            xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sl < a.T && !a.centre(sl)) xr[j] = *reinterpret_cast<const float4*>(X + a.edge(sl) * D + 64 * c + cc);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                *reinterpret_cast<float4*>(stg + L.r * TILE_LD + 8 * (4 * t + j) + 4 * L.h) =
+                    make_float4(y[c][t][4 * j] * ABQ_INV, y[c][t][4 * j + 1] * ABQ_INV, y[c][t][4 * j + 2] * ABQ_INV,
+                                y[c][t][4 * j + 3] * ABQ_INV);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int r = 4 * j + rr;
+            if (live && r < a.T) {
+                float4 o4 = *reinterpret_cast<const float4*>(stg + r * TILE_LD + cc);
+                o4.x += xr[j].x; o4.y += xr[j].y; o4.z += xr[j].z; o4.w += xr[j].w;
+                float* dst = a.centre(r) ? OC + (int64_t)a.atom(r) * D : X1 + a.edge(r) * D;
+                *reinterpret_cast<float4*>(dst + 64 * c + cc) = o4;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // adjoint: (dX1 | dOC) -> dXin, key-bias gradient. Q, K, V are recomputed from the layer input X.
 //
 //   dAO  = dY Wo                                  token form; its feature form by TRANSPOSITION ON THE MATRIX CORE:
@@ -773,6 +989,8 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
 // follows is fused only together with it: the three-kernel adjoint reads the saved Q, K, V), 4 = whatever the graph
 // (by default graphs of fewer than 6 144 tiles, and graphs in which more than 5 % of the atoms have more than 32 tokens,
 // take the three-kernel form: ablk_serves); 0 = the three-kernel form (QKV / attention / projection) everywhere
+static int g_ablk_fwd4 = 1;
+void set_ablk_fwd4(int v) { g_ablk_fwd4 = v ? 1 : 0; }
 static int g_attn_fused = 3;
 void set_attn_fused(int v) { g_attn_fused = v; }
 int attn_fused() { return g_attn_fused; }
@@ -879,7 +1097,18 @@ bool ablk_fwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* 
         if (ln) PET_ABLK_FWD(2, true, g.tile_desc + 2 * (size_t)n1, n2) else PET_ABLK_FWD(2, false, g.tile_desc + 2 * (size_t)n1, n2)
         st = st1;
     }
-    if (n1 > 0) {
+    if (n1 > 0 && g_ablk_fwd4) {  // two four-wave workgroups per CU (pet_config_set("attn_fwd4", 0): the eight-wave form)
+        const size_t lds = (size_t)4 * 16384 + AB4_NSLOT * AB4_SLOT;
+        if (ln) {
+            allow_big_lds(k_ablk_fwd4<true>, lds);
+            k_ablk_fwd4<true><<<cdiv(n1, 4), 256, lds, st>>>(X, A.g_attn, beta, wq, A.qkv.b, wo, A.out.b, g.fc, g.tile_desc, n1,
+                                                             g.n_edges, qscale, X1, OC);
+        } else {
+            allow_big_lds(k_ablk_fwd4<false>, lds);
+            k_ablk_fwd4<false><<<cdiv(n1, 4), 256, lds, st>>>(X, A.g_attn, beta, wq, A.qkv.b, wo, A.out.b, g.fc, g.tile_desc, n1,
+                                                              g.n_edges, qscale, X1, OC);
+        }
+    } else if (n1 > 0) {
         if (ln) PET_ABLK_FWD(1, true, g.tile_desc, n1) else PET_ABLK_FWD(1, false, g.tile_desc, n1)
     }
     tail_join(st1, ts);
