@@ -181,6 +181,33 @@ static int pack_lin(Model& m, const std::string& name, Lin& L, const float* w, c
     return PET_OK;
 }
 
+// W diag(gamma) and b + W beta of a Linear behind a norm (beta == nullptr: RMSNorm), fp64 row sums
+__global__ void k_fold_norm(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, int n_out, int k_in, float* __restrict__ Wg, float* __restrict__ bg) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_out) return;
+    double acc = b[n];
+    for (int k = 0; k < k_in; k++) {
+        const float w = W[(size_t)n * k_in + k];
+        Wg[(size_t)n * k_in + k] = w * gamma[k];
+        if (beta) acc += (double)w * (double)beta[k];
+    }
+    bg[n] = (float)acc;
+}
+static int pack_lin_s(Model& m, const std::string& name, Lin& L, hipStream_t st);
+static int fold_norm_s(Model& m, const std::string& name, const Lin& src, const float* gamma, const float* beta, Lin& out,
+                       hipStream_t st) {
+    if (m.generic()) return PET_OK;
+    float *wg = nullptr, *bg = nullptr;
+    int rc;
+    if ((rc = named_alloc(m, name + ":wg", (void**)&wg, (size_t)src.n_out * src.k_in * sizeof(float))) != PET_OK) return rc;
+    if ((rc = named_alloc(m, name + ":bg", (void**)&bg, (size_t)src.n_out * sizeof(float))) != PET_OK) return rc;
+    k_fold_norm<<<cdiv(src.n_out, 128), 128, 0, st>>>(src.w, src.b, gamma, beta, src.n_out, src.k_in, wg, bg);
+    out = Lin();
+    out.w = wg; out.b = bg; out.n_out = src.n_out; out.k_in = src.k_in;
+    return pack_lin_s(m, name + ":g", out, st);
+}
+
 // "scaled" planes for the single-accumulator products of pet_ablk.hip: H = fp16(64 w), L = fp16(64 w - H)
 static int pack_lin_s(Model& m, const std::string& name, Lin& L, hipStream_t st) {
     if (m.generic()) return PET_OK;
@@ -264,6 +291,7 @@ int finalize(Model& m, hipStream_t st) {
                 if ((rc = get(m, lp + ".norm_attention.bias", D, &A.b_attn))) return rc;
                 if ((rc = get(m, lp + ".norm_mlp.bias", D, &A.b_mlp))) return rc;
             }
+            if ((rc = fold_norm_s(m, lp + ".mlp.w_in", A.mlp_in, A.g_mlp, m.layer_norm() ? A.b_mlp : nullptr, A.mlp_in_g, st))) return rc;
             if (!expanded) continue;  // d_node == d_pet: Identity modules, no parameters (transformer.py:196-201)
             if ((rc = get_lin(m, lp + ".center_contraction", D, DN, A.cc, st))) return rc;
             if ((rc = get_lin(m, lp + ".center_expansion", DN, D, A.ce, st))) return rc;

@@ -35,6 +35,7 @@ struct Lin {
 
 struct AttnLayerW {
     Lin qkv, out, mlp_in, mlp_out, cc, ce, cmlp_in, cmlp_out;
+    Lin mlp_in_g;  // mlp_in with norm_mlp folded in: W diag(gamma), b + W beta (k_emlp_bwd_s works on the un-scaled normalised rows)
     const float *g_attn = nullptr, *g_mlp = nullptr, *g_center = nullptr;
     const float *b_attn = nullptr, *b_mlp = nullptr, *b_center = nullptr;  // LayerNorm biases (nullptr: RMSNorm)
 };
@@ -303,8 +304,8 @@ void set_emlp_s(int v);
 void set_emlp_recompute(int v);
 void set_emlp_s_min(int v);
 bool emlp_recompute_on(const Lin& win, const Lin& wout, int64_t E);
-bool emlp_bwd_s(const float* dY, const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout,
-                float* dX1, int64_t E, hipStream_t st, int ldy, const float* dY2, const int* rev2);
+bool emlp_bwd_s(const float* dY, const float* X1, bool ln, const Lin& win_g, const Lin& wout, float* dX1, int64_t E,
+                hipStream_t st, int ldy, const float* dY2, const int* rev2);
 bool emlp_s(const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout, float* VG, float* X2,
             int64_t E, hipStream_t st);
 int attn_fused();

@@ -1319,9 +1319,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 // made anew for the adjoint call -- the forward followed the same switches as this call does)
                 if (fwd_rec ? fwd_rec->emlp_unsaved : (!tr && trr_l && emlp_recompute_on(A.mlp_in, A.mlp_out, E))) {
                     const bool gat = dxf_fused && a == m.h.num_attention_layers - 1;
-                    PET_REQUIRE(!tr && trr_l && emlp_bwd_s(gat ? w.dcat : dX, Ab.X1, A.g_mlp, ln ? A.b_mlp : nullptr, A.mlp_in,
-                                                          A.mlp_out, dX_alt, E, st, gat ? 2 * D : D, gat ? w.dcat + D : nullptr,
-                                                          gat ? g.rev : nullptr),
+                    PET_REQUIRE(!tr && trr_l && emlp_bwd_s(gat ? w.dcat : dX, Ab.X1, ln, A.mlp_in_g, A.mlp_out, dX_alt, E, st,
+                                                          gat ? 2 * D : D, gat ? w.dcat + D : nullptr, gat ? g.rev : nullptr),
                                 PET_ERR_ARGUMENT, "the forward of this workspace did not save the edge MLP's pre-activations "
                                 "and the recomputing adjoint is switched off: pet_config_set changed between forward and backward");
                 } else if (dxf_fused && a == m.h.num_attention_layers - 1) {

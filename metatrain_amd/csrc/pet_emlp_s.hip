@@ -208,7 +208,9 @@ __global__ __launch_bounds__(256, 2) void k_emlp_s(const float* __restrict__ X1,
 // read them -- and nothing but weight fragments is requested between a tile's first and last instruction (an HBM load in
 // the middle of the stream would sit in front of every later fragment wait: vmcnt retires in order).
 //   dX1 = dY + NormAdj(gamma . dxn, x1),  dxn = W_in^T [dv; dg],  dv = du s(g),  dg = du v s(g) (1 - s(g)),  du = W_out^T dY
-// (transformer.py:39-50, 230-232 under autograd; k_emlp_bwd_p2's arithmetic with the recomputation of k_emlp_s in front).
+// (transformer.py:39-50, 230-232 under autograd; k_emlp_bwd_p2's arithmetic with the recomputation of k_emlp_s in front). The
+// norm's weight and bias are folded into W_in (abi.hip fold_norm_s: W diag(gamma), b + W beta), so xn = W-side and the kernel
+// works on xhat: the recomputation's operand is also the xhat of the norm adjoint, and the layer input is read ONCE.
 // Per wave: planes of 64 xn in registers, planes of 64 dY' (dY' = the row times the power of two that puts its largest entry
 // in [1, 2)) in the wave's LDS tile, [dv | dg] as planes at scale 1. Stages of a chunk (four fragments each, one per wave):
 //   0 .. 7    W_in K block s, tiles v / g                     va, ga += W xn           (6 MFMAs)
@@ -238,8 +240,7 @@ __device__ __forceinline__ void eb_request(int hc, int s, const W2& win, const W
 }
 
 template <bool LN, bool GATHER>
-__global__ __launch_bounds__(256, 2) void k_emlp_bwd_s(const float* __restrict__ dY, const float* __restrict__ X1,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta, W2 win,
+__global__ __launch_bounds__(256, 2) void k_emlp_bwd_s(const float* __restrict__ dY, const float* __restrict__ X1, W2 win,
                                                        const float* __restrict__ bin, W2 woutT, W2 winT,
                                                        float* __restrict__ dX1, int64_t E, int ldy,
                                                        const float* __restrict__ dY2, const int* __restrict__ rev2) {
@@ -270,15 +271,31 @@ __global__ __launch_bounds__(256, 2) void k_emlp_bwd_s(const float* __restrict__
     eb_request(0, 0, win, woutT, winT, ring_u, wave, lane16);
     eb_request(0, 1, win, woutT, winT, ring_u, wave, lane16);
     eb_request(0, 2, win, woutT, winT, ring_u, wave, lane16);
+    // xhat = the normalised row WITHOUT the norm's weight and bias (they are folded into W_in: Model::mlp_in_g), as planes of
+    // 64 xhat in registers: the operand of the recomputation, and -- (H + L) / 64 -- the xhat of the norm adjoint at the end,
+    // which therefore needs neither the layer input again nor gamma
     f16x8 xph[8], xpl[8];
+    float rstd;
     {
         float4 x[16];
         tile128_to_frag(x, tile, L);
-        norm_frag<16, LN>(x, gamma, beta, L.h);
+        if (LN) {
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; k++) sm += (x[k].x + x[k].y) + (x[k].z + x[k].w);
+            const float mean = row_sum(sm) * (1.0f / 128.0f);
+#pragma unroll
+            for (int k = 0; k < 16; k++) { x[k].x -= mean; x[k].y -= mean; x[k].z -= mean; x[k].w -= mean; }
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) ss += x[k].x * x[k].x + x[k].y * x[k].y + x[k].z * x[k].z + x[k].w * x[k].w;
+        rstd = rsqrtf(row_sum(ss) * (1.0f / 128.0f) + (LN ? 1e-5f : 1.1920928955078125e-07f));
+        const float f = rstd * ABS;
 #pragma unroll
         for (int kb = 0; kb < 8; kb++) {
-            const float v8[8] = {x[2 * kb].x * ABS, x[2 * kb].y * ABS, x[2 * kb].z * ABS, x[2 * kb].w * ABS,
-                                 x[2 * kb + 1].x * ABS, x[2 * kb + 1].y * ABS, x[2 * kb + 1].z * ABS, x[2 * kb + 1].w * ABS};
+            const float v8[8] = {x[2 * kb].x * f, x[2 * kb].y * f, x[2 * kb].z * f, x[2 * kb].w * f,
+                                 x[2 * kb + 1].x * f, x[2 * kb + 1].y * f, x[2 * kb + 1].z * f, x[2 * kb + 1].w * f};
             ab_split8(v8, xph[kb], xpl[kb]);
         }
     }
@@ -359,40 +376,50 @@ __global__ __launch_bounds__(256, 2) void k_emlp_bwd_s(const float* __restrict__
             }
         }
     }
-    // ---- epilogue: the residual (dY' from its planes), the layer input once more for the norm adjoint, whole-line stores
-    float4 w[16], r4[16];
+    // ---- epilogue: the norm adjoint on (w = d xhat-space adjoint, xhat from the planes), the residual dY' from ITS planes
+    float4 w[16];
+    {
+        const float f = inv * ABS_INV;  // dn holds 64 x (W_in^T planes) of the scaled row
+        float dot = 0.f, sw = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                w[4 * t + j] = make_float4(dn[t][4 * j] * f, dn[t][4 * j + 1] * f, dn[t][4 * j + 2] * f, dn[t][4 * j + 3] * f);
+        float4 xh4[16];
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            xh4[2 * kb] = make_float4(((float)xph[kb][0] + (float)xpl[kb][0]) * ABS_INV, ((float)xph[kb][1] + (float)xpl[kb][1]) * ABS_INV,
+                                      ((float)xph[kb][2] + (float)xpl[kb][2]) * ABS_INV, ((float)xph[kb][3] + (float)xpl[kb][3]) * ABS_INV);
+            xh4[2 * kb + 1] = make_float4(((float)xph[kb][4] + (float)xpl[kb][4]) * ABS_INV, ((float)xph[kb][5] + (float)xpl[kb][5]) * ABS_INV,
+                                          ((float)xph[kb][6] + (float)xpl[kb][6]) * ABS_INV, ((float)xph[kb][7] + (float)xpl[kb][7]) * ABS_INV);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            dot += xh4[k].x * w[k].x + xh4[k].y * w[k].y + xh4[k].z * w[k].z + xh4[k].w * w[k].w;
+        const float md = row_sum(dot) * (1.0f / 128.0f);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {  // rstd (w - xhat mean(xhat w)); LayerNorm: minus its mean
+            w[k].x = rstd * (w[k].x - xh4[k].x * md); w[k].y = rstd * (w[k].y - xh4[k].y * md);
+            w[k].z = rstd * (w[k].z - xh4[k].z * md); w[k].w = rstd * (w[k].w - xh4[k].w * md);
+            sw += (w[k].x + w[k].y) + (w[k].z + w[k].w);
+        }
+        if (LN) {
+            const float mw = row_sum(sw) * (1.0f / 128.0f);
+#pragma unroll
+            for (int k = 0; k < 16; k++) { w[k].x -= mw; w[k].y -= mw; w[k].z -= mw; w[k].w -= mw; }
+        }
+    }
 #pragma unroll
     for (int kb = 0; kb < 8; kb++) {
         const f16x8 yh = *reinterpret_cast<const f16x8*>(tile + ((kb * 2 + 0) * 64 + L.lane) * 16);
         const f16x8 yl = *reinterpret_cast<const f16x8*>(tile + ((kb * 2 + 1) * 64 + L.lane) * 16);
         const float f = inv * ABS_INV;
-        r4[2 * kb] = make_float4(((float)yh[0] + (float)yl[0]) * f, ((float)yh[1] + (float)yl[1]) * f,
-                                 ((float)yh[2] + (float)yl[2]) * f, ((float)yh[3] + (float)yl[3]) * f);
-        r4[2 * kb + 1] = make_float4(((float)yh[4] + (float)yl[4]) * f, ((float)yh[5] + (float)yl[5]) * f,
-                                     ((float)yh[6] + (float)yl[6]) * f, ((float)yh[7] + (float)yl[7]) * f);
+        w[2 * kb].x += ((float)yh[0] + (float)yl[0]) * f; w[2 * kb].y += ((float)yh[1] + (float)yl[1]) * f;
+        w[2 * kb].z += ((float)yh[2] + (float)yl[2]) * f; w[2 * kb].w += ((float)yh[3] + (float)yl[3]) * f;
+        w[2 * kb + 1].x += ((float)yh[4] + (float)yl[4]) * f; w[2 * kb + 1].y += ((float)yh[5] + (float)yl[5]) * f;
+        w[2 * kb + 1].z += ((float)yh[6] + (float)yl[6]) * f; w[2 * kb + 1].w += ((float)yh[7] + (float)yl[7]) * f;
     }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    dma_tile128(X1, row0, E, tile_u, L);
-    {
-        const float f = inv * ABS_INV;  // dn holds 64 x (W_in^T planes) of the scaled row
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float4 g4 = *reinterpret_cast<const float4*>(gamma + 32 * t + 8 * j + 4 * L.h);
-                w[4 * t + j] = make_float4(dn[t][4 * j] * f * g4.x, dn[t][4 * j + 1] * f * g4.y, dn[t][4 * j + 2] * f * g4.z,
-                                           dn[t][4 * j + 3] * f * g4.w);
-            }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    {
-        float4 x[16];
-        tile128_to_frag(x, tile, L);
-        norm_bwd_frag<16, LN>(w, x);
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) { w[k].x += r4[k].x; w[k].y += r4[k].y; w[k].z += r4[k].z; w[k].w += r4[k].w; }
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
     store_rows_lines<16>(w, reinterpret_cast<float*>(tile), L, [&](int r) { return live && row0 + r < E ? dX1 + (row0 + r) * D : nullptr; });
@@ -405,7 +432,7 @@ void set_emlp_recompute(int v) { g_emlp_rc = v ? 1 : 0; }
 static int64_t g_es_min_rows = 16384;  // below: a launch is a few waves per SIMD and the pipelined kernels' shorter chain wins
 void set_emlp_s_min(int v) { g_es_min_rows = v; }  // pet_config_set("emlp_s_min", rows): the tests force the kernels on small graphs
 bool emlp_recompute_on(const Lin& win, const Lin& wout, int64_t E) {
-    return g_emlp_s && g_emlp_rc && E >= g_es_min_rows && win.fwd2s && win.bwd2s && wout.fwd2s && wout.bwd2s;
+    return g_emlp_s && g_emlp_rc && E >= g_es_min_rows && win.fwd2s && wout.fwd2s && wout.bwd2s;
 }
 
 static inline W2 es_w2(const void* base, int n_out, int k_in) {
@@ -433,20 +460,20 @@ bool emlp_s(const float* X1, const float* gamma, const float* beta, const Lin& w
 }
 
 // the adjoint with recomputed pre-activations; false = not served
-bool emlp_bwd_s(const float* dY, const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout,
-                float* dX1, int64_t E, hipStream_t st, int ldy, const float* dY2, const int* rev2) {
-    if (!g_emlp_s || !win.fwd2s || !win.bwd2s || !wout.bwd2s) return false;
+bool emlp_bwd_s(const float* dY, const float* X1, bool ln, const Lin& win_g, const Lin& wout, float* dX1, int64_t E,
+                hipStream_t st, int ldy, const float* dY2, const int* rev2) {
+    if (!g_emlp_s || !win_g.fwd2s || !win_g.bwd2s || !wout.bwd2s) return false;
     if (E <= 0) return true;
     const size_t lds = ES_NW * 16384 + ES_NSLOT * ES_SLOT;
-    const W2 wi = es_w2(win.fwd2s, win.n_out, win.k_in), wot = es_w2(wout.bwd2s, wout.n_out, wout.k_in),
-             wit = es_w2(win.bwd2s, win.n_out, win.k_in);
+    const W2 wi = es_w2(win_g.fwd2s, win_g.n_out, win_g.k_in), wot = es_w2(wout.bwd2s, wout.n_out, wout.k_in),
+             wit = es_w2(win_g.bwd2s, win_g.n_out, win_g.k_in);
     const int grid = (int)cdiv(E, ES_NW * WROWS);
-#define PET_EB(LNF, GF)                                                                                                    \
-    {                                                                                                                      \
-        allow_big_lds(k_emlp_bwd_s<LNF, GF>, lds);                                                                         \
-        k_emlp_bwd_s<LNF, GF><<<grid, 256, lds, st>>>(dY, X1, gamma, beta, wi, win.b, wot, wit, dX1, E, ldy, dY2, rev2);   \
+#define PET_EB(LNF, GF)                                                                                        \
+    {                                                                                                          \
+        allow_big_lds(k_emlp_bwd_s<LNF, GF>, lds);                                                             \
+        k_emlp_bwd_s<LNF, GF><<<grid, 256, lds, st>>>(dY, X1, wi, win_g.b, wot, wit, dX1, E, ldy, dY2, rev2);  \
     }
-    if (beta) { if (dY2) PET_EB(true, true) else PET_EB(true, false) }
+    if (ln) { if (dY2) PET_EB(true, true) else PET_EB(true, false) }
     else { if (dY2) PET_EB(false, true) else PET_EB(false, false) }
 #undef PET_EB
     return true;
