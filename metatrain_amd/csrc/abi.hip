@@ -292,6 +292,7 @@ int finalize(Model& m, hipStream_t st) {
                 if ((rc = get(m, lp + ".norm_mlp.bias", D, &A.b_mlp))) return rc;
             }
             if ((rc = fold_norm_s(m, lp + ".mlp.w_in", A.mlp_in, A.g_mlp, m.layer_norm() ? A.b_mlp : nullptr, A.mlp_in_g, st))) return rc;
+            if ((rc = fold_norm_s(m, lp + ".attention.input_linear", A.qkv, A.g_attn, m.layer_norm() ? A.b_attn : nullptr, A.qkv_g, st))) return rc;
             if (!expanded) continue;  // d_node == d_pet: Identity modules, no parameters (transformer.py:196-201)
             if ((rc = get_lin(m, lp + ".center_contraction", D, DN, A.cc, st))) return rc;
             if ((rc = get_lin(m, lp + ".center_expansion", DN, D, A.ce, st))) return rc;

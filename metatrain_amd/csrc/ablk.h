@@ -157,6 +157,62 @@ __device__ __forceinline__ void ab_park_planes(const float4 (&x)[16], char* tile
     }
 }
 
+// The normalised row WITHOUT the norm's weight and bias, xhat = (x - mean) rstd (RMSNorm: mean = 0), as planes of 64 xhat
+// parked like ab_park_planes; returns rstd. For kernels whose Linear behind the norm has the norm's affine part folded in
+// (abi.hip fold_norm_s): the planes are the operand of the product AND the xhat of the norm adjoint (ab_norm_adjoint_planes).
+template <bool LN>
+__device__ __forceinline__ float ab_park_xhat(float4 (&x)[16], char* tile, const RowLane& L) {
+    if (LN) {
+        float sm = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) sm += (x[k].x + x[k].y) + (x[k].z + x[k].w);
+        const float mean = row_sum(sm) * (1.0f / 128.0f);
+#pragma unroll
+        for (int k = 0; k < 16; k++) { x[k].x -= mean; x[k].y -= mean; x[k].z -= mean; x[k].w -= mean; }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) ss += x[k].x * x[k].x + x[k].y * x[k].y + x[k].z * x[k].z + x[k].w * x[k].w;
+    const float rstd = rsqrtf(row_sum(ss) * (1.0f / 128.0f) + (LN ? 1e-5f : 1.1920928955078125e-07f));
+#pragma unroll
+    for (int k = 0; k < 16; k++) { x[k].x *= rstd; x[k].y *= rstd; x[k].z *= rstd; x[k].w *= rstd; }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    ab_park_planes(x, tile, L);
+    return rstd;
+}
+// w (the adjoint w.r.t. xhat, a row fragment) -> the adjoint w.r.t. the norm's input, xhat read back from its parked planes:
+//   rstd (w - xhat mean(xhat w))   (LayerNorm: minus its mean)
+template <bool LN>
+__device__ __forceinline__ void ab_norm_adjoint_planes(float4 (&w)[16], const char* tile, float rstd, const RowLane& L) {
+    float4 xh[16];
+    float dot = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 8; kb++) {
+        const f16x8 h = *reinterpret_cast<const f16x8*>(tile + ((kb * 2 + 0) * 64 + L.lane) * 16);
+        const f16x8 l = *reinterpret_cast<const f16x8*>(tile + ((kb * 2 + 1) * 64 + L.lane) * 16);
+        xh[2 * kb] = make_float4(((float)h[0] + (float)l[0]) * ABS_INV, ((float)h[1] + (float)l[1]) * ABS_INV,
+                                 ((float)h[2] + (float)l[2]) * ABS_INV, ((float)h[3] + (float)l[3]) * ABS_INV);
+        xh[2 * kb + 1] = make_float4(((float)h[4] + (float)l[4]) * ABS_INV, ((float)h[5] + (float)l[5]) * ABS_INV,
+                                     ((float)h[6] + (float)l[6]) * ABS_INV, ((float)h[7] + (float)l[7]) * ABS_INV);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) dot += xh[k].x * w[k].x + xh[k].y * w[k].y + xh[k].z * w[k].z + xh[k].w * w[k].w;
+    const float md = row_sum(dot) * (1.0f / 128.0f);
+    float sw = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        w[k].x = rstd * (w[k].x - xh[k].x * md); w[k].y = rstd * (w[k].y - xh[k].y * md);
+        w[k].z = rstd * (w[k].z - xh[k].z * md); w[k].w = rstd * (w[k].w - xh[k].w * md);
+        sw += (w[k].x + w[k].y) + (w[k].z + w[k].w);
+    }
+    if (LN) {
+        const float mw = row_sum(sw) * (1.0f / 128.0f);
+#pragma unroll
+        for (int k = 0; k < 16; k++) { w[k].x -= mw; w[k].y -= mw; w[k].z -= mw; w[k].w -= mw; }
+    }
+}
+
 // key bias (log2 of the cutoff factor, transformer.py:109-110) of the keys this lane's S^T registers hold; -inf masks
 // the slots past the last token and the other atom of a paired tile (the lane is a QUERY: its atom decides)
 template <int NQ>

@@ -35,6 +35,7 @@ struct Lin {
 
 struct AttnLayerW {
     Lin qkv, out, mlp_in, mlp_out, cc, ce, cmlp_in, cmlp_out;
+    Lin qkv_g;     // qkv with norm_attention folded in (k_ablk_bwd)
     Lin mlp_in_g;  // mlp_in with norm_mlp folded in: W diag(gamma), b + W beta (k_emlp_bwd_s works on the un-scaled normalised rows)
     const float *g_attn = nullptr, *g_mlp = nullptr, *g_center = nullptr;
     const float *b_attn = nullptr, *b_mlp = nullptr, *b_center = nullptr;  // LayerNorm biases (nullptr: RMSNorm)

@@ -610,14 +610,14 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
     const AbSel sel1 = ab_selectors(L, 1.0f);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     AB_T(8);
+    // (the norm's weight and bias are folded into W_qkv -- Model::qkv_g, abi.hip fold_norm_s --: the parked planes are xhat,
+    // the operand of the Q, K, V recomputation and, at the end, the xhat of the norm adjoint: the layer input is read ONCE)
+    float rstd[NQ];
 #pragma unroll
     for (int tq = 0; tq < NQ; tq++) {
         float4 x[16];
         tile128_to_frag(x, tile + tq * 16384, L);
-        norm_frag<16, LN>(x, gamma, beta, L.h);
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-        ab_park_planes(x, tile + tq * 16384, L);
+        rstd[tq] = ab_park_xhat<LN>(x, tile + tq * 16384, L);
     }
     AB_T(9);
     // ---- dAO = dY Wo (token form), parked as row fragments [kg][lane] over the rows it came from
@@ -765,11 +765,6 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
                     AB_MFMA3(v[tq], wvh, wvl, xh, xl);
                 }
             }
-        }
-        if (hp == 3) {  // the norm adjoint's input rows come back by LDS-DMA over the row planes, which nobody reads any
-            __builtin_amdgcn_wave_barrier();  // more; the attention work of this pair covers the round trip
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            ab_dma_rows<NQ>(X, a, tile_u, L);
         }
         AB_T(11);
         // ---- operand planes: token form (index = head of the pair) and feature form (index = token K block)
@@ -938,17 +933,14 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
 #pragma unroll
     for (int tq = 0; tq < NQ; tq++) {
         if (32 * tq >= a.T) continue;
-        float4 w[16], x[16];
-        tile128_to_frag(x, tile + tq * 16384, L);  // landed: every stage sync since the request waited for vmcnt(0)
-        const float f = ABQ_INV * inv_sc;
+        float4 w[16];
+        const float f = ABQ_INV * inv_sc;  // (W_qkv^T carries the norm's weight: dxn is the adjoint w.r.t. xhat)
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float4 g = *reinterpret_cast<const float4*>(gamma + 32 * t + 8 * j + 4 * L.h);
-                w[4 * t + j] = make_float4(dxn[tq][t][4 * j] * f * g.x, dxn[tq][t][4 * j + 1] * f * g.y,
-                                           dxn[tq][t][4 * j + 2] * f * g.z, dxn[tq][t][4 * j + 3] * f * g.w);
-            }
+            for (int j = 0; j < 4; j++)
+                w[4 * t + j] = make_float4(dxn[tq][t][4 * j] * f, dxn[tq][t][4 * j + 1] * f, dxn[tq][t][4 * j + 2] * f,
+                                           dxn[tq][t][4 * j + 3] * f);
         const int rr = L.lane >> 4, cc = 4 * (L.lane & 15);
         float4 dr[2][8];  // the residual (dX1 rows) in the store's shape, requested before the norm adjoint's arithmetic
 #pragma unroll
@@ -959,7 +951,7 @@ __global__ __launch_bounds__(256) void k_ablk_bwd(
                 dr[c][j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (s < a.T && !a.centre(s)) dr[c][j] = *reinterpret_cast<const float4*>(dX1 + a.edge(s) * D + 64 * c + cc);
             }
-        norm_bwd_frag<16, LN>(w, x);
+        ab_norm_adjoint_planes<LN>(w, tile + tq * 16384, rstd[tq], L);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
 #pragma unroll
@@ -1119,10 +1111,10 @@ bool ablk_fwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* 
 // dXin [E + N, D] = adjoint of the layer input; dbias [E] = key-bias gradient of this layer summed over the heads
 bool ablk_bwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* X, const float* dX1, const float* dOC,
               float* dXin, float* dbias, float scale, hipStream_t st) {
-    if (!ablk_bwd_on(g) || !A.qkv.fwd2s || !A.qkv.bwd2s || !A.out.bwd2s) return false;
+    if (!ablk_bwd_on(g) || !A.qkv_g.fwd2s || !A.qkv_g.bwd2s || !A.out.bwd2s) return false;
     const bool ln = m.layer_norm();
     const float qscale = scale * AB_LOG2E;
-    const W2 wq = w2s_fwd(A.qkv), wqt = w2s_bwd(A.qkv), wot = w2s_bwd(A.out);
+    const W2 wq = w2s_fwd(A.qkv_g), wqt = w2s_bwd(A.qkv_g), wot = w2s_bwd(A.out);  // (norm_attention folded into W_qkv)
     const float* beta = ln ? A.b_attn : nullptr;
     const int n1 = g.n_tiles1, n2 = g.n_tiles2;
 #define PET_ABLK_BWD(NQ, LNF, LIST, CNT)                                                                             \
@@ -1130,7 +1122,7 @@ bool ablk_bwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* 
         constexpr int WPB = 4 / NQ;                                                                                  \
         const size_t lds = (size_t)WPB * NQ * 32768 + 2 * AB_SLOT_B;                                                 \
         allow_big_lds(k_ablk_bwd<NQ, LNF>, lds);                                                                     \
-        k_ablk_bwd<NQ, LNF><<<cdiv(CNT, WPB), 64 * WPB, lds, st>>>(X, dX1, dOC, A.g_attn, beta, wq, A.qkv.b, wot,    \
+        k_ablk_bwd<NQ, LNF><<<cdiv(CNT, WPB), 64 * WPB, lds, st>>>(X, dX1, dOC, A.g_attn, beta, wq, A.qkv_g.b, wot,  \
                                                                    wqt, g.fc, LIST, CNT, g.n_edges, qscale, scale,   \
                                                                    dXin, dbias);                                     \
     }
