@@ -429,7 +429,7 @@ static int g_emlp_s = 1;  // pet_config_set("emlp_s", 0): the one-wave-per-SIMD 
 void set_emlp_s(int v) { g_emlp_s = v ? 1 : 0; }
 static int g_emlp_rc = 1;  // pet_config_set("emlp_recompute", 0): the forward saves [v; g] and k_emlp_bwd_p2 reads it
 void set_emlp_recompute(int v) { g_emlp_rc = v ? 1 : 0; }
-static int64_t g_es_min_rows = 16384;  // below: a launch is a few waves per SIMD and the pipelined kernels' shorter chain wins
+static int64_t g_es_min_rows = 28672;  // measured crossover (1000 atoms, 19 k rows: pipelined kernels 2 % ahead; 2000 atoms, 38 k rows: these 1 % ahead)
 void set_emlp_s_min(int v) { g_es_min_rows = v; }  // pet_config_set("emlp_s_min", rows): the tests force the kernels on small graphs
 bool emlp_recompute_on(const Lin& win, const Lin& wout, int64_t E) {
     return g_emlp_s && g_emlp_rc && E >= g_es_min_rows && win.fwd2s && wout.fwd2s && wout.bwd2s;
