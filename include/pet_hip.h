@@ -406,10 +406,15 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *                 fewer than 6 144 attention tiles (a few thousand atoms: latency-bound there) and graphs in which more
  *                 than 5 % of the atoms have more than 32 tokens keep the three-kernel form, as do training forwards,
  *                 graphs with an atom of more than 64 tokens and PostLN models. 0 = the three-kernel form everywhere.
+ *   "emlp_s"      the edge MLP and its adjoint as two desynchronised four-wave workgroups per CU on one-accumulator products
+ *                 (csrc/pet_emlp_s.hip; the adjoint RECOMPUTES the SwiGLU pre-activations, so an inference forward does not
+ *                 store them): 1 = for graphs of at least 28 672 edge rows (default), v > 1 = from v rows on, 0 = never
+ *                 (the one-wave-per-SIMD pipelined kernels everywhere). A forward that ran without saving can only be followed
+ *                 by the recomputing adjoint: flipping the switch in between makes pet_backward fail (PET_ERR_ARGUMENT).
  *   "attn_lds"    adjoint of the three-kernel attention form: 1 = staged per atom, 3 = persistent workgroups with LDS-DMA
  *                 prefetch for atoms of at most 32 tokens (default)
  *   "tile_f16x3"  1 = the LDS-tile forward kernels (compress, centre, node update, heads) and the head adjoint on f16x3
- *                 (default); 0 = fp32 MFMA. "tile_mask" (debug): bits switch single GEMMs of those kernels back.
+ *                 (default); 0 = fp32 MFMA. 
  *   "trr_compress" bit mask of f16x3 TRR kernels replacing LDS-tile ones: 1 compress (+adjoint), 2 edge head (+adjoint);
  *                  default 3; 0 = LDS-tile kernels
  *   "node_planes" 1 = node-row kernels k_node2 / k_node2w / k_node_bwd2 (coalesced tiles, fp16 planes; default), 0 = k_node /

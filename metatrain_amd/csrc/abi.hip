@@ -975,9 +975,6 @@ int pet_config_set(const char* key, int value) {
     else if (k == "attn_lds") set_attn_lds(value);
     else if (k == "attn_fused") set_attn_fused(value);
     else if (k == "emlp_s") set_emlp_s(value);
-    else if (k == "attn_fwd4") set_ablk_fwd4(value);
-    else if (k == "emlp_recompute") set_emlp_recompute(value);
-    else if (k == "emlp_s_min") set_emlp_s_min(value);
     else if (k == "attn_fused_prof") ablk_prof_dump();
     else if (k == "tile_f16x3") set_tile_f16x3(value);
     else if (k == "trr_compress") set_trr_compress(value);
@@ -989,7 +986,6 @@ int pet_config_set(const char* key, int value) {
     else if (k == "so_trr") set_so_trr(value);
     else if (k == "wgrad_bf16") set_wgrad_bf16(value);
     else if (k == "train_bf16") set_train_bf16(value);
-    else if (k == "tile_mask") set_tile_mask(value);
     else if (k == "so_f16x3") set_so_f16x3(value);
     else PET_REQUIRE(false, PET_ERR_ARGUMENT, "unknown config key '" + k + "'");
     return PET_OK;

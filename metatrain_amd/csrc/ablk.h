@@ -89,7 +89,7 @@ __device__ __forceinline__ void ab_tile_planes(const f32x16& a, f16x8 (&hi)[2], 
 
 #ifdef AB_PROFILE
 // debugging aid (build with -DAB_PROFILE): shader cycles per phase, summed over the waves of every launch
-__device__ unsigned long long ab_prof[32];
+extern __device__ unsigned long long ab_prof[32];  // defined in pet_ablk.hip
 #define AB_T(i)                                                                              \
     do {                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                   \
@@ -301,5 +301,10 @@ __device__ __forceinline__ float ab_transpose_sum(const f16x8 (&h)[2], const f16
         }
     return sh + sl;
 }
+
+// k_ablk_bwd<1, LN> (pet_ablk_bwd1.hip)
+void ablk_bwd1_launch(bool ln, const float* X, const float* dX1, const float* dOC, const float* gamma, const float* beta, W2 wqkv,
+                      const float* bqkv, W2 wot, W2 wqkvt, const float* fc, const int4* desc, int n_list, int64_t E, float qscale,
+                      float scale, float* dXin, float* dbias, hipStream_t st);
 
 }  // namespace pet

@@ -16,10 +16,10 @@
 #include <string>
 
 #include "gen_common.h"
+#include "cutoff.h"
 
 namespace pet {
 
-float __device__ cutoff_deriv_dev(float d, float rc, float width, int fn);  // graph.hip
 
 namespace {
 

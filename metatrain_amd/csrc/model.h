@@ -253,8 +253,6 @@ void set_soap_ps_mfma(int v);  // soap.hip: 1 = power spectrum and its adjoint o
 void set_soap_fused(int v);  // soap.hip: 1 = power spectrum + LayerNorm + first Linear fused, features never stored (default 0)
 bool use_tile_f16x3();
 void set_tile_f16x3(int v);
-void set_tile_mask(int v);
-int tile_mask();
 void set_trr_compress(int v);
 void set_node_planes(int v);  // pet_fwd.hip / pet_bwd.hip: node-row kernels on pre-split fp16 planes (default 1)
 bool node_planes();
@@ -300,10 +298,7 @@ bool trr_comb_bwd(const float* dM, const float* XF, const Graph& g, const GnnLay
 // adjoint recomputing Q, K, V); false = not served (an atom of more than 64 tokens, planes missing, switched off)
 void set_sorted_shortcut(int v);  // graph.hip: 1 = a neighbour list that is ordered by centre skips the radix sort (default)
 void set_attn_fused(int v);
-void set_ablk_fwd4(int v);
 void set_emlp_s(int v);
-void set_emlp_recompute(int v);
-void set_emlp_s_min(int v);
 bool emlp_recompute_on(const Lin& win, const Lin& wout, int64_t E);
 bool emlp_bwd_s(const float* dY, const float* X1, bool ln, const Lin& win_g, const Lin& wout, float* dX1, int64_t E,
                 hipStream_t st, int ldy, const float* dY2, const int* rev2);

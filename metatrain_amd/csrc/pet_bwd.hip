@@ -9,6 +9,7 @@
 //   * dE/dR_a = sum_{p in row a} (dv[rev[p]] - dv[p])                          (v_p = r_j - r_i + S.cell)
 // so the result is deterministic run to run.
 #include "common.h"
+#include "cutoff.h"
 #include "model.h"
 #include "pet_ws.h"
 #include "train.h"
@@ -19,7 +20,6 @@ namespace pet {
 constexpr int LD128 = lds_ld(128);
 constexpr int LD256 = lds_ld(256);
 
-float __device__ cutoff_deriv_dev(float d, float rc, float width, int fn);
 int attn_tiles(const Graph& g);
 int exchange_backward(const Graph& g, float* dXF, int layer, hipStream_t st);  // pet_fwd.hip
 double g_sum_t2(const Graph& g);

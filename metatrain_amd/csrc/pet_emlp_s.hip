@@ -425,14 +425,17 @@ __global__ __launch_bounds__(256, 2) void k_emlp_bwd_s(const float* __restrict__
     store_rows_lines<16>(w, reinterpret_cast<float*>(tile), L, [&](int r) { return live && row0 + r < E ? dX1 + (row0 + r) * D : nullptr; });
 }
 
-static int g_emlp_s = 1;  // pet_config_set("emlp_s", 0): the one-wave-per-SIMD pipelined kernels k_emlp_p2 / k_emlp_bwd_p2
-void set_emlp_s(int v) { g_emlp_s = v ? 1 : 0; }
-static int g_emlp_rc = 1;  // pet_config_set("emlp_recompute", 0): the forward saves [v; g] and k_emlp_bwd_p2 reads it
-void set_emlp_recompute(int v) { g_emlp_rc = v ? 1 : 0; }
-static int64_t g_es_min_rows = 28672;  // measured crossover (1000 atoms, 19 k rows: pipelined kernels 2 % ahead; 2000 atoms, 38 k rows: these 1 % ahead)
-void set_emlp_s_min(int v) { g_es_min_rows = v; }  // pet_config_set("emlp_s_min", rows): the tests force the kernels on small graphs
+// pet_config_set("emlp_s", v): 0 = the one-wave-per-SIMD pipelined kernels k_emlp_p2 / k_emlp_bwd_p2 everywhere; 1 = these
+// kernels for graphs of at least 28 672 edge rows (default: the measured crossover -- 1 000 atoms, 19 k rows: the pipelined
+// kernels 2 % ahead; 2 000 atoms, 38 k rows: these 1 % ahead); v > 1 = from v rows on (the tests force small graphs through)
+static int g_emlp_s = 1;
+static int64_t g_es_min_rows = 28672;
+void set_emlp_s(int v) {
+    g_emlp_s = v ? 1 : 0;
+    g_es_min_rows = v > 1 ? v : 28672;
+}
 bool emlp_recompute_on(const Lin& win, const Lin& wout, int64_t E) {
-    return g_emlp_s && g_emlp_rc && E >= g_es_min_rows && win.fwd2s && wout.fwd2s && wout.bwd2s;
+    return g_emlp_s && E >= g_es_min_rows && win.fwd2s && wout.fwd2s && wout.bwd2s;
 }
 
 static inline W2 es_w2(const void* base, int n_out, int k_in) {

@@ -1031,10 +1031,10 @@ double g_sum_t2(const Graph& g) {
 }
 
 // both operand forms of a Linear for the LDS-tile kernels: fp16 planes when f16x3 is on and the weight was packed
-static inline WX wx_fwd(const Lin& L, int bit = 0) {
+static inline WX wx_fwd(const Lin& L) {
     WX w;
     w.f = L.fwd;
-    if (use_tile_f16x3() && L.fwd2 && !(tile_mask() & bit)) {
+    if (use_tile_f16x3() && L.fwd2) {
         const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
         w.h = reinterpret_cast<const f16x8_t*>(L.fwd2);
         w.l = w.h + n8;
@@ -1095,7 +1095,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
         if (a == 0 && res && gi > 0)  // backend.py:617: every GNN layer starts from its own node embedding
             k_node_embed<<<cdiv(N * (DN / 4), 256), 256, 0, s2>>>(g.sp, m.node_embs[gi], w.gnn[gi].Hin, (int)N);
         ProfScope ps("center", s2, fN * 2.0 * DN * D);
-        k_center<<<gN, NTHREADS, BM * LD256 * 4 + BM * 8, s2>>>(Ab.H, wx_fwd(A.cc, 2), A.cc.b, Ab.X + E * D, N);
+        k_center<<<gN, NTHREADS, BM * LD256 * 4 + BM * 8, s2>>>(Ab.H, wx_fwd(A.cc), A.cc.b, Ab.X + E * D, N);
     };
     k_node_embed<<<cdiv(N * (DN / 4), 256), 256, 0, st>>>(g.sp, m.node_emb, w.H0, (int)N);
     const bool conditioned = m.h.system_conditioning != 0;
@@ -1120,11 +1120,11 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                 // TRR kernel on f16x3 (pet_trr.hip)
             } else if (gi == 0)
                 k_compress<true><<<gE, NTHREADS, lds1 + BM * 20 + BM * 8, st>>>(g.geo, g.sp_nbr, G.wc, G.tbl, nullptr, WX(),
-                                                                        wx_fwd(G.compress2, 1), G.compress2.b, B.a0,
+                                                                        wx_fwd(G.compress2), G.compress2.b, B.a0,
                                                                         B.attn[0].X, E);
             else
                 k_compress<false><<<gE, NTHREADS, lds_c, st>>>(g.geo, g.sp_nbr, G.wc, G.tbl, Min,
-                                                               wx_fwd(G.compress0_msg, 128), wx_fwd(G.compress2, 256), G.compress2.b,
+                                                               wx_fwd(G.compress0_msg), wx_fwd(G.compress2), G.compress2.b,
                                                                B.a0, B.attn[0].X, E);
         }
         for (int a = 0; a < AL; a++) {
@@ -1185,7 +1185,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                 WX wcn;
                 const float* bcn = nullptr;
                 float* xcn = nullptr;
-                const WX wci = wx_fwd(A.cmlp_in, 8), wce_ = wx_fwd(A.ce, 4), wco = wx_fwd(A.cmlp_out, 16);
+                const WX wci = wx_fwd(A.cmlp_in), wce_ = wx_fwd(A.ce), wco = wx_fwd(A.cmlp_out);
                 if (node_planes() && wci.h && wce_.h && wco.h) {
                     const int nr = node_rows(N);
                     const size_t lds_n2 = (size_t)nr * LD256 * 4 + (size_t)2 * nr * plane_ld(256) * 2 + nr * 8;
@@ -1195,7 +1195,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                     if (has_next && g_center_fused && nr == 32 && !(a + 1 == AL && (conditioned || res))) {  // (large graphs: k_center is quicker)
                         const AttnLayerW& An = a + 1 < AL ? G.attn[a + 1] : m.gnn[gi + 1].attn[0];
                         AttnBufs& Abn = a + 1 < AL ? B.attn[a + 1] : w.gnn[gi + 1].attn[0];
-                        wcn = wx_fwd(An.cc, 2);
+                        wcn = wx_fwd(An.cc);
                         if (wcn.h && Abn.H == Ab.Hn) { bcn = An.cc.b; xcn = Abn.X + E * D; center_done = true; }
                     }
                     // small graphs: the hidden chunks of a row tile on four workgroups; partial outputs and the tiles'
@@ -1228,8 +1228,8 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                     }
                 } else
                 k_node<<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, s2>>>(
-                    Ab.H, Ab.OC, wx_fwd(A.ce, 4), A.ce.b, A.g_center, A.b_center, wx_fwd(A.cmlp_in, 8), A.cmlp_in.b,
-                    wx_fwd(A.cmlp_out, 16), A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
+                    Ab.H, Ab.OC, wx_fwd(A.ce), A.ce.b, A.g_center, A.b_center, wx_fwd(A.cmlp_in), A.cmlp_in.b,
+                    wx_fwd(A.cmlp_out), A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N);
             }
             if (a + 1 == AL && conditioned)  // backend.py:543-545: the node features LEAVING the GNN layer
                 k_add_cond<<<cdiv(N * (DN / 4), 256), 256, 0, s2>>>(Ab.Hn, w.cond, g.sys, g.cond_sys, (int)N);
@@ -1278,12 +1278,12 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
     if (atomic) {
         ProfScope ps("head_node", s2, fN * 2.0 * (DN * DH + DH * DH + DH));
         k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, s2>>>(
-            last.Hout, wx_fwd(m.nh0, 32), m.nh0.b, wx_fwd(m.nh2, 32), m.nh2.b, m.nll_w, m.nll_b, nullptr, nullptr, w.ynode, N);
+            last.Hout, wx_fwd(m.nh0), m.nh0.b, wx_fwd(m.nh2), m.nh2.b, m.nll_w, m.nll_b, nullptr, nullptr, w.ynode, N);
     }
     if (atomic && E > 0) {
         ProfScope ps("head_edge", st, fE * 2.0 * (D * DH + DH * DH + DH));
         if (!(trr && trr_head_edge(m, last.Mout, g.fc, w.ypred_e, w.ye, E, st)))
-        k_head<128><<<gE, NTHREADS, lds2 + BM * 8, st>>>(last.Mout, wx_fwd(m.eh0, 64), m.eh0.b, wx_fwd(m.eh2, 64), m.eh2.b, m.ell_w,
+        k_head<128><<<gE, NTHREADS, lds2 + BM * 8, st>>>(last.Mout, wx_fwd(m.eh0), m.eh0.b, wx_fwd(m.eh2), m.eh2.b, m.ell_w,
                                                 m.ell_b, g.fc, w.ypred_e, w.ye, E);
     }
     ss.join(st);
@@ -1320,10 +1320,10 @@ int aux_outputs(const Model& m, const Graph& g, const float* node_feat, const fl
         float* hid_e = scratch;             // [E, DH] edge-head hidden rows
         float* ytmp = scratch + E * DH;     // [max(E, N)] the heads' scalar predictions, not wanted here
         k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, st>>>(
-            node_feat, wx_fwd(m.nh0, 32), m.nh0.b, wx_fwd(m.nh2, 32), m.nh2.b, m.nll_w, m.nll_b, nullptr, nullptr,
+            node_feat, wx_fwd(m.nh0), m.nh0.b, wx_fwd(m.nh2), m.nh2.b, m.nll_w, m.nll_b, nullptr, nullptr,
             ytmp, N, last_layer, 2 * DH);
         if (E > 0)
-            k_head<128><<<gE, NTHREADS, lds2, st>>>(edge_feat, wx_fwd(m.eh0, 64), m.eh0.b, wx_fwd(m.eh2, 64), m.eh2.b,
+            k_head<128><<<gE, NTHREADS, lds2, st>>>(edge_feat, wx_fwd(m.eh0), m.eh0.b, wx_fwd(m.eh2), m.eh2.b,
                                                     m.ell_w, m.ell_b, nullptr, nullptr, ytmp, E, hid_e, DH);
         k_edge_sum_fc<<<cdiv(N, 4), 256, 0, st>>>(hid_e, g.fc, g.rowptr, last_layer + DH, 2 * DH, (int)N);
     }
@@ -1387,9 +1387,9 @@ int predict(const Model& m, const Graph& g, const HeadW& H, const LastW& Lw, con
     const size_t lds2 = (size_t)(BM * LD128 * 2) * 4 + BM * 8;
     // the heads' own dot-product output is not wanted here (P properties follow): any DH-vector serves as `wl`
     k_head<256><<<gN, NTHREADS, (BM * LD256 + BM * LD128) * 4 + BM * 8, st>>>(
-        node_feat, wx_fwd(H.nh0, 32), H.nh0.b, wx_fwd(H.nh2, 32), H.nh2.b, Lw.nw, 0.f, nullptr, nullptr, ytmp, N, hid_n, DH);
+        node_feat, wx_fwd(H.nh0), H.nh0.b, wx_fwd(H.nh2), H.nh2.b, Lw.nw, 0.f, nullptr, nullptr, ytmp, N, hid_n, DH);
     if (E > 0)
-        k_head<128><<<gE, NTHREADS, lds2, st>>>(edge_feat, wx_fwd(H.eh0, 64), H.eh0.b, wx_fwd(H.eh2, 64), H.eh2.b, Lw.ew,
+        k_head<128><<<gE, NTHREADS, lds2, st>>>(edge_feat, wx_fwd(H.eh0), H.eh0.b, wx_fwd(H.eh2), H.eh2.b, Lw.ew,
                                                 0.f, nullptr, nullptr, ytmp, E, hid_e, DH);
     k_edge_sum_fc<<<cdiv(N, 4), 256, 0, st>>>(hid_e, fc, g.rowptr, sums, DH, (int)N);
     k_fc_sum<<<cdiv(N, 256), 256, 0, st>>>(fc, g.rowptr, csum, (int)N);

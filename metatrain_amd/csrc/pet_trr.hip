@@ -952,9 +952,6 @@ static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
 // pet_fwd.hip / pet_bwd.hip, which are the one fallback (and the path of the LayerNorm / PostLN / residual variants).
 static int g_tile_f16x3 = 1;  // pet_config_set("tile_f16x3", 0): LDS-tile kernels (compress, heads, node chain) on fp32 MFMA
 void set_tile_f16x3(int v) { g_tile_f16x3 = v ? 1 : 0; }
-static int g_tile_mask = 0;  // debugging aid: bits switch individual LDS-tile GEMMs back to fp32 MFMA
-void set_tile_mask(int v) { g_tile_mask = v; }
-int tile_mask() { return g_tile_mask; }
 bool use_tile_f16x3() { return g_tile_f16x3 != 0; }
 // pet_config_set("trr_compress", bits): 1 compress (+adjoint), 2 edge head (+adjoint); 0 = the LDS-tile kernels
 static int g_trr_tilek = 3;

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "common.h"
+#include "cutoff.h"
 #include "model.h"
 #include "pet_ws.h"
 #include "tile.h"
@@ -24,7 +25,6 @@ namespace pet {
 
 constexpr int LD128 = lds_ld(128);
 constexpr float RMS_EPS = 1.1920928955078125e-07f;
-float __device__ cutoff_deriv_dev(float d, float rc, float width, int fn);
 
 // ---------------------------------------------------------------------------------------------
 // generic GEMM:  Y[r][n] (+)= sum_k X[r][k] * cs[k] * W[n][k] + bias[n],  W packed in fragment order

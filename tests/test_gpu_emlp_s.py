@@ -1,7 +1,7 @@
 """GPU parity tests of the two-waves-per-SIMD edge-MLP kernels (csrc/pet_emlp_s.hip: k_emlp_s, and k_emlp_bwd_s, which
 RECOMPUTES the SwiGLU pre-activations instead of reading saved ones; reference: pet/modules/transformer.py:39-50, 230-232)
-at sizes the default policy hands to the pipelined kernels (``pet_config_set("emlp_s_min", 1)`` forces them on any graph; by
-default they serve graphs of at least 16 384 edges, i.e. the at-size tests). Through the C ABI, against goldens generated from
+at sizes the default policy hands to the pipelined kernels (``pet_config_set("emlp_s", 2)`` hands them every graph of at least two edge
+rows; by default they serve graphs of at least 28 672 edges, i.e. the at-size tests). Through the C ABI, against goldens generated from
 the reference and against the fp64 oracle. Bar: 1e-5."""
 import os
 
@@ -27,9 +27,9 @@ def rt():
     assert torch.cuda.is_available(), "these tests need an MI355X"
     from metatrain_amd import runtime
 
-    runtime.config_set("emlp_s_min", 1)
+    runtime.config_set("emlp_s", 2)
     yield runtime
-    runtime.config_set("emlp_s_min", 16384)
+    runtime.config_set("emlp_s", 1)
 
 
 @pytest.fixture(scope="module")
@@ -85,7 +85,7 @@ def test_forced_kernels_against_reference_goldens(rt, dev, golden_dir, name):
         a2 = fw2.forward()
         g2 = fw2.backward(torch.ones_like(a2))
     finally:
-        rt.config_set("emlp_s", 1)
+        rt.config_set("emlp_s", 2)
     assert relmax(atomic.cpu().numpy(), a2.cpu().numpy()) < 2e-6
     assert relmax(grad.cpu().numpy(), g2.cpu().numpy()) < 5e-6
     # run-to-run bit identity (no atomics, fixed summation order)
@@ -191,6 +191,6 @@ def test_adjoint_refuses_a_workspace_without_saved_preactivations_when_recomputa
         with pytest.raises(rt.PetHipError):
             fw.backward(torch.ones_like(atomic))
     finally:
-        rt.config_set("emlp_s", 1)
+        rt.config_set("emlp_s", 2)
     fw.forward()
     assert torch.equal(fw.backward(torch.ones_like(atomic)), ref)

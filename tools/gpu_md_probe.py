@@ -9,7 +9,7 @@ from metatrain_amd.synthetic import random_box, synthetic_params
 
 dev = torch.device("cuda:0")
 hypers = default_hypers()
-for kv in os.environ.get("SET", "").split(","):   # library switches for A/B runs: SET=emlp_s_min=100000,attn_fwd4=0
+for kv in os.environ.get("SET", "").split(","):   # library switches for A/B runs: SET=emlp_s=0,attn_fused=0
     if kv:
         rt.config_set(kv.split("=")[0], int(kv.split("=")[1]))
 model = rt.HipModel(hypers, [1, 6, 7, 8])
