@@ -49,9 +49,9 @@ def synthetic_params(hypers):
 
 # ProfScope stage -> the kernels it launches (base names, template arguments stripped). The attention stages
 # launch one kernel per neighbour-count bucket (NT = 1, 2, 3 ...): their traffic is the sum over the buckets.
-STAGE_KERNELS = {"attn_blk": ("k_ablk_fwd",), "attn_blk_bwd": ("k_ablk_bwd",),
+STAGE_KERNELS = {"attn_blk": ("k_ablk_fwd", "k_ablk_fwd4"), "attn_blk_bwd": ("k_ablk_bwd",),
                  "attn_bwd": ("k_attn_bwd_a", "k_attn_bwd_l"), "attn_fwd": ("k_attn_fwd_p",),
-                 "emlp": ("k_emlp_p2",), "emlp_bwd": ("k_emlp_bwd_p2",), "qkv": ("k_qkv_s",), "qkv_bwd": ("k_qkv_bwd_h",),
+                 "emlp": ("k_emlp_p2", "k_emlp_s"), "emlp_bwd": ("k_emlp_bwd_p2", "k_emlp_bwd_s"), "qkv": ("k_qkv_s",), "qkv_bwd": ("k_qkv_bwd_h",),
                  "comb": ("k_comb_p2",), "comb_bwd": ("k_comb_bwd_p2",)}
 
 

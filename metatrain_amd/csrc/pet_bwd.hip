@@ -1314,10 +1314,11 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                                                                                  A.mlp_in.bwd, dX, R, nullptr, false);
                 k_rownorm_bwd<<<gR, NTHREADS, lds1, st>>>(dX, dX + E * D, Ab.X1, A.g_attn, ln, dX_alt, E, R);
             } else {
-                ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D), fE * 4.0 * (3 * D + 2 * DFF));  // dY, X1, VG in; dX1 out
+                const bool recompute = fwd_rec ? fwd_rec->emlp_unsaved : (!tr && trr_l && emlp_recompute_on(A.mlp_in, A.mlp_out, E));
+                ProfScope ps("emlp_bwd", st, fE * 2.0 * (D * 2 * DFF + DFF * D), fE * 4.0 * (3 * D + (recompute ? 0 : 2 * DFF)));  // dY, X1 (and the saved VG) in; dX1 out
                 // the forward of this workspace did not save [v; g] (its record says so; without a record -- a graph handle
                 // made anew for the adjoint call -- the forward followed the same switches as this call does)
-                if (fwd_rec ? fwd_rec->emlp_unsaved : (!tr && trr_l && emlp_recompute_on(A.mlp_in, A.mlp_out, E))) {
+                if (recompute) {
                     const bool gat = dxf_fused && a == m.h.num_attention_layers - 1;
                     PET_REQUIRE(!tr && trr_l && emlp_bwd_s(gat ? w.dcat : dX, Ab.X1, ln, A.mlp_in_g, A.mlp_out, dX_alt, E, st,
                                                           gat ? 2 * D : D, gat ? w.dcat + D : nullptr, gat ? g.rev : nullptr),

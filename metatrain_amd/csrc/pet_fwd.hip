@@ -1238,7 +1238,8 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
             else if (gi + 1 < L) launch_center(gi + 1, 0);
             side_busy = true;
             if (E > 0 && !post) {
-                ProfScope ps("emlp", st, fE * 2.0 * (D * 2 * DFF + DFF * D), fE * 4.0 * (2 * D + 2 * DFF));  // X1 in; VG, X2 out
+                const bool vg_out = save != 0 && !(trr_l && save == 1 && emlp_recompute_on(A.mlp_in, A.mlp_out, E));
+                ProfScope ps("emlp", st, fE * 2.0 * (D * 2 * DFF + DFF * D), fE * 4.0 * (2 * D + (vg_out ? 2 * DFF : 0)));  // X1 in; X2 (and VG, when it is saved) out
                 if (trr_l) {
                     float* vg = save == 0 ? nullptr : Ab.VG;  // [v; g] is stored for the adjoint unless none follows ...
                     if (save == 1 && emlp_recompute_on(A.mlp_in, A.mlp_out, E)) {  // ... or the adjoint recomputes it (noted on the graph)
