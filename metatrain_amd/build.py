@@ -6,14 +6,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libpet_hip.so")
-SOURCES = ["abi.hip", "graph.hip", "nl.hip", "pet_fwd.hip", "pet_bwd.hip", "pet_trr.hip", "pet_attn.hip", "pet_ablk.hip", "pet_ablk_bwd1.hip", "pet_emlp_s.hip", "pet_comb.hip", "train.hip", "optim.hip", "so.hip", "soap.hip", "gen.hip", "gen_train.hip"]
+SOURCES = ["abi.hip", "graph.hip", "nl.hip", "pet_fwd.hip", "pet_bwd.hip", "pet_trr.hip", "pet_attn.hip", "pet_ablk.hip", "pet_ablk_bwd1.hip", "pet_emlp_s.hip", "pet_comb.hip", "pet_comb_bwd.hip", "train.hip", "optim.hip", "so.hip", "soap.hip", "gen.hip", "gen_train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc"]
 FLAGS += os.environ.get("PET_HIP_EXTRA_FLAGS", "").split()  # debugging builds, e.g. -DAB_PROFILE (pet_ablk.hip)
 # Translation units compiled on their own (no -fgpu-rdc: their device code is generated here, not at the link step) with the
 # matrix products in VGPR form. A kernel at one wave per SIMD otherwise gets the AGPR form of every MFMA and pays 16
 # v_accvgpr_read for every product tile that vector arithmetic consumes (pet_ablk_bwd1.hip has the numbers). Per file, because
 # the option is not a win everywhere (k_comb_p2 loses 5 % with it) and crashes this compiler on some kernels.
-VGPR_FORM = {"pet_ablk_bwd1.hip"} if "-DAB_PROFILE" not in FLAGS else set()
+VGPR_FORM = {"pet_ablk_bwd1.hip", "pet_comb_bwd.hip"} if "-DAB_PROFILE" not in FLAGS else set()
 VGPR_FORM_FLAGS = ["-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 

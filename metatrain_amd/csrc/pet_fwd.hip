@@ -1116,7 +1116,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
         const float* Min = gi == 0 ? nullptr : w.gnn[gi - 1].Mout;
         if (E > 0) {
             ProfScope ps("compress", st, fE * 2.0 * (D * D * (gi == 0 ? 3 : 4) + 4 * D));
-            if (trr && trr_compress(gi == 0, g, G, Min, B.a0, B.attn[0].X, E, st)) {
+            if (trr && trr_compress(gi == 0, g, G, Min, save == 0 ? nullptr : B.a0, B.attn[0].X, E, st)) {  // (no adjoint follows: the pre-activation is not stored)
                 // TRR kernel on f16x3 (pet_trr.hip)
             } else if (gi == 0)
                 k_compress<true><<<gE, NTHREADS, lds1 + BM * 20 + BM * 8, st>>>(g.geo, g.sp_nbr, G.wc, G.tbl, nullptr, WX(),
