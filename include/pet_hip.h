@@ -403,7 +403,7 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *   "attn_fused"  bits: 1 = the per-atom fused attention block in the forward (norm -> QKV -> soft-max attention -> output
  *                 projection in one kernel; Q, K, V and the attention output never reach HBM; csrc/pet_ablk.hip), 2 = its
  *                 adjoint (recomputes Q, K, V from the layer input), 4 = whatever the graph's size; default 3: graphs of
- *                 fewer than 6 144 attention tiles (a few thousand atoms: latency-bound there) and graphs in which more
+ *                 fewer than 3 840 attention tiles (fewer than about 4 700 atoms: latency-bound there) and graphs in which more
  *                 than 5 % of the atoms have more than 32 tokens keep the three-kernel form, as do training forwards,
  *                 graphs with an atom of more than 64 tokens and PostLN models. 0 = the three-kernel form everywhere.
  *   "emlp_s"      the edge MLP and its adjoint as two desynchronised four-wave workgroups per CU on one-accumulator products

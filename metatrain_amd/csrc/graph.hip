@@ -347,8 +347,8 @@ static int bucket_atoms_by_tile_count(Graph& g, hipStream_t st) {  // scalars[8.
     const int T = 256;
     k_bucket_count<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8);
     k_bucket_fill<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8, g.scalars + 13, g.atom_order);
-    // the per-atom attention tiles serve the fused block only (pet_ablk.hip: graphs of at least 6 144 tiles, or forced)
-    g.tiles_planned = g.n_nodes >= 6144 || (attn_fused() & 4);
+    // the per-atom attention tiles serve the fused block only (pet_ablk.hip: graphs of at least ABLK_MIN_TILES tiles, or forced; tiles <= atoms)
+    g.tiles_planned = g.n_nodes >= ABLK_MIN_TILES || (attn_fused() & 4);
     if (!g.tiles_planned) return PET_OK;
     const int nb = cdiv(g.n_nodes, T);
     k_thist<<<nb, T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 24, g.tsort_tmp);

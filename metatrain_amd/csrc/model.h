@@ -305,6 +305,10 @@ bool emlp_bwd_s(const float* dY, const float* X1, bool ln, const Lin& win_g, con
 bool emlp_s(const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout, float* VG, float* X2,
             int64_t E, hipStream_t st);
 int attn_fused();
+// graphs of at least this many 32-slot attention tiles (about 4 700 atoms at 19 neighbours) take the fused per-atom block:
+// measured crossover of one box, graph + forward + dE/dR, fused against three-kernel form -- 3 000 atoms 3.29 / 2.96 ms,
+// 5 000: 4.08 / 4.16, 7 000: 5.21 / 5.51, 10 000: 6.72 / 7.30 (round 5, k_ablk_fwd4 and the VGPR-form adjoint)
+constexpr int ABLK_MIN_TILES = 3840;
 void ablk_prof_dump();  // debugging aid: per-phase cycle sums of the fused kernels (library built with -DAB_PROFILE)
 bool ablk_fwd(const Model& m, const Graph& g, const AttnLayerW& A, const float* X, float* X1, float* OC, float scale,
               hipStream_t st);

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void k_ablk_fwd4(
 // ---------------------------------------------------------------------------------------------
 // pet_config_set("attn_fused", bits): 1 = fused forward, 2 = fused adjoint (the forward of a call sequence whose adjoint
 // follows is fused only together with it: the three-kernel adjoint reads the saved Q, K, V), 4 = whatever the graph
-// (by default graphs of fewer than 6 144 tiles, and graphs in which more than 5 % of the atoms have more than 32 tokens,
+// (by default graphs of fewer than ABLK_MIN_TILES = 3 840 tiles, and graphs in which more than 5 % of the atoms have more than 32 tokens,
 // take the three-kernel form: ablk_serves); 0 = the three-kernel form (QKV / attention / projection) everywhere
 static int g_attn_fused = 3;
 void set_attn_fused(int v) { g_attn_fused = v; }
@@ -597,9 +597,10 @@ static bool ablk_serves(const Graph& g) {
     if (!g.tiles_planned) return false;                       // a small graph built before the block was forced
     if (g_attn_fused & 4) return true;
     // A tile is one wave's serial chain (40 us forward, 100 us adjoint): below a few waves per SIMD the launch costs that
-    // latency whatever its size, and the three row-parallel kernels are quicker (1 000 atoms: 2.5 against 3.1 ms per
-    // step, 3 000: 3.5 / 3.9, 10 000: 7.8 / 7.3). Many 64-slot tiles (the adjoint's instantiation for them spills): likewise.
-    return g.n_tiles1 >= 6144 && (int64_t)g.n_tiles2 * 20 <= g.n_nodes;
+    // latency whatever its size, and the three row-parallel kernels are quicker (one box, three-kernel / fused ms per step:
+    // 1 000 atoms 1.69 / 2.18, 3 000: 2.96 / 3.29, 5 000: 4.16 / 4.08, 10 000: 7.30 / 6.72; model.h ABLK_MIN_TILES). Many
+    // 64-slot tiles (the adjoint's instantiation for them spills): likewise.
+    return g.n_tiles1 >= ABLK_MIN_TILES && (int64_t)g.n_tiles2 * 20 <= g.n_nodes;
 }
 bool ablk_bwd_on(const Graph& g) { return (g_attn_fused & 2) && ablk_serves(g); }
 

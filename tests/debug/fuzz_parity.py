@@ -10,7 +10,7 @@ from oracle import pet as opet
 
 dev = torch.device("cuda:0")
 import os
-if os.environ.get("PET_FUZZ_FUSED"):  # the per-atom fused attention block on every graph (default: graphs of >= 6 144 tiles)
+if os.environ.get("PET_FUZZ_FUSED"):  # the per-atom fused attention block on every graph (default: graphs of >= 3 840 tiles)
     rt.config_set("attn_fused", 7)
 for _kv in filter(None, os.environ.get("PET_FUZZ_SET", "").split(",")):  # e.g. PET_FUZZ_SET=node_split=0,dxf_fused=0
     rt.config_set(_kv.split("=")[0], int(_kv.split("=")[1]))

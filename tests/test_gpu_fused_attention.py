@@ -1,6 +1,6 @@
 """GPU parity tests of the per-atom fused attention block (csrc/pet_ablk.hip; reference: pet/modules/transformer.py:86-152,
 203-234) at sizes the default policy would hand to the three-kernel form (``pet_config_set("attn_fused", 7)`` forces the
-fused kernels on any graph; by default they serve graphs of at least 6 144 attention tiles, i.e. the at-size tests).
+fused kernels on any graph; by default they serve graphs of at least 3 840 attention tiles, i.e. the at-size tests).
 Everything through the C ABI, against goldens generated from the reference and against the fp64 oracle. Bar: 1e-5."""
 import os
 
