@@ -28,7 +28,11 @@ namespace pet {
 template <int NC2, bool UNROLLED = false, int RING = 4, class Epilogue>
 __device__ __forceinline__ void row_gemm128_h(const W2& w, const float* __restrict__ bias, const Split2<8>& xs,
                                               const RowLane& L, float oscale, Epilogue epi) {
+#ifdef H_ABL_W0  // timing ablation (results are wrong): every weight block is block 0 -- the stream comes from the CU's L1
+    auto widx = [&](int b) { return (size_t)(b & 1) * 64 + L.lane; };
+#else
     auto widx = [&](int b) { return ((size_t)(2 * (b >> 3)) * 8 + (b & 7)) * 64 + L.lane; };
+#endif
     WBlk2<2> ring[RING];  // RING (a power of two) weight blocks in flight
 #pragma unroll
     for (int b = 0; b < RING; b++) ld_blk2<2>(ring[b], w, widx(b), 8 * 64);
