@@ -394,6 +394,8 @@ int finalize(Model& m, hipStream_t st) {
         if ((rc = get_lin(m, "node_heads." + tl + ".2", DH, DH, H.nh2, st))) return rc;
         if ((rc = get_lin(m, "edge_heads." + tl + ".0", DH, D, H.eh0, st))) return rc;
         if ((rc = get_lin(m, "edge_heads." + tl + ".2", DH, DH, H.eh2, st))) return rc;
+        if ((rc = pack_lin_s(m, "edge_heads." + tl + ".0", H.eh0, st))) return rc;  // k_head_s / k_head_bwd_s (pet_head_s.hip)
+        if ((rc = pack_lin_s(m, "edge_heads." + tl + ".2", H.eh2, st))) return rc;
     }
     for (const auto& id : last_ids) {
         const std::string key = id.first + "." + id.second;  // <t>.<l>.<block>

@@ -300,6 +300,11 @@ void set_sorted_shortcut(int v);  // graph.hip: 1 = a neighbour list that is ord
 void set_attn_fused(int v);
 void set_emlp_s(int v);
 bool emlp_recompute_on(const Lin& win, const Lin& wout, int64_t E);
+bool emlp_s_serves(int64_t E);
+struct Model;
+bool head_edge_s(const Model& m, const float* Xin, const float* fc, float* ypred, float* yout, int64_t E, hipStream_t st);
+bool head_edge_bwd_s(const Model& m, const float* Xin, const float* gA, const int* ctr, const float* fc, const float* ypred,
+                     float* dfc, float* dXout, int64_t E, hipStream_t st);
 bool emlp_bwd_s(const float* dY, const float* X1, bool ln, const Lin& win_g, const Lin& wout, float* dX1, int64_t E,
                 hipStream_t st, int ldy, const float* dY2, const int* rev2);
 bool emlp_s(const float* X1, const float* gamma, const float* beta, const Lin& win, const Lin& wout, float* VG, float* X2,

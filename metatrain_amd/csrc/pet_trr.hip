@@ -1162,6 +1162,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_h(const float* __restrict__ Xi
 bool trr_head_edge(const Model& m, const float* Xin, const float* fc, float* ypred, float* yout, int64_t E,
                    hipStream_t st) {
     if (!((g_trr_tilek & 2) && m.eh0.fwd2 && m.eh2.fwd2)) return false;
+    if (head_edge_s(m, Xin, fc, ypred, yout, E, st)) return true;  // large graphs: two workgroups per CU, shared weight ring
     k_head_h<<<grid_rows(E), 256, 0, st>>>(Xin, w2_fwd(m.eh0), m.eh0.b, w2_fwd(m.eh2), m.eh2.b, m.ell_w, m.ell_b, fc, ypred,
                                            yout, E);
     return true;
@@ -1170,6 +1171,7 @@ bool trr_head_edge_bwd(const Model& m, const float* Xin, const float* gA, const 
                        const float* ypred, float* dfc, float* dXout, int64_t E, float* t_s1, float* t_da2, float* t_da1,
                        float* t_s2y, hipStream_t st) {
     if (!((g_trr_tilek & 2) && m.eh0.fwd2 && m.eh2.fwd2 && m.eh0.bwd2 && m.eh2.bwd2)) return false;
+    if (!t_s1 && head_edge_bwd_s(m, Xin, gA, ctr, fc, ypred, dfc, dXout, E, st)) return true;  // (inference; pet_head_s.hip)
     const int grid = grid_rows(E);
     if (t_s1)
         k_head_bwd_h<true><<<grid, 256, 0, st>>>(Xin, w2_fwd(m.eh0), m.eh0.b, w2_fwd(m.eh2), m.eh2.b, w2_bwd(m.eh0),

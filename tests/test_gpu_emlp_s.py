@@ -131,9 +131,10 @@ def test_forced_kernels_mixed_systems_against_oracle(rt, dev, normalization, see
     np.testing.assert_allclose(g2.cpu().numpy(), grad.cpu().numpy(), atol=2e-6 * float(grad.abs().max()))
 
 
-@pytest.mark.parametrize("what,factor", [("mlp", 30.0), ("gains", 30.0), ("embeddings", 1e-4)])
+@pytest.mark.parametrize("what,factor", [("mlp", 30.0), ("gains", 30.0), ("embeddings", 1e-4), ("heads", 30.0), ("heads", 0.02)])
 def test_forced_kernels_operand_ranges(rt, dev, what, factor):
-    """The kernels hold weights and normalised rows as fp16 planes of 64 x and the SwiGLU output / its adjoint as planes at
+    """(Forced with the edge MLP's kernels: the edge head's k_head_s / k_head_bwd_s, csrc/pet_head_s.hip.)
+    The kernels hold weights and normalised rows as fp16 planes of 64 x and the SwiGLU output / its adjoint as planes at
     scale 1: large MLP weights (hidden activations of magnitude 1e3), large norm gains and a tiny residual stream must neither
     overflow nor lose the low planes: finite results, within the bar or within 3 x what plain fp32 torch loses on the same
     weights."""
@@ -145,6 +146,10 @@ def test_forced_kernels_operand_ranges(rt, dev, what, factor):
     elif what == "mlp":
         for k in params:
             if ".mlp.w_in." in k:
+                params[k] *= factor
+    elif what == "heads":  # k_head_s / k_head_bwd_s (pet_head_s.hip): un-normalised rows, every operand scaled per row
+        for k in params:
+            if k.startswith("edge_heads.") and k.endswith(".weight"):
                 params[k] *= factor
     else:
         for k in params:
