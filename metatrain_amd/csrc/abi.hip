@@ -194,7 +194,7 @@ __global__ void k_fold_norm(const float* __restrict__ W, const float* __restrict
     }
     bg[n] = (float)acc;
 }
-static int pack_lin_s(Model& m, const std::string& name, Lin& L, hipStream_t st);
+static int pack_lin_s(Model& m, const std::string& name, Lin& L, hipStream_t st, int ld = 0);
 static int fold_norm_s(Model& m, const std::string& name, const Lin& src, const float* gamma, const float* beta, Lin& out,
                        hipStream_t st) {
     if (m.generic()) return PET_OK;
@@ -209,14 +209,16 @@ static int fold_norm_s(Model& m, const std::string& name, const Lin& src, const 
 }
 
 // "scaled" planes for the single-accumulator products of pet_ablk.hip: H = fp16(64 w), L = fp16(64 w - H)
-static int pack_lin_s(Model& m, const std::string& name, Lin& L, hipStream_t st) {
+// (ld: leading dimension of L.w when it is a column block of a wider matrix; 0 = k_in)
+static int pack_lin_s(Model& m, const std::string& name, Lin& L, hipStream_t st, int ld) {
     if (m.generic()) return PET_OK;
+    if (ld == 0) ld = L.k_in;
     const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
     int rc;
     if ((rc = named_alloc(m, name + ":fwd2s", &L.fwd2s, 2 * n8 * 16)) != PET_OK) return rc;
     if ((rc = named_alloc(m, name + ":bwd2s", &L.bwd2s, 2 * n8 * 16)) != PET_OK) return rc;
-    k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(L.w, L.k_in, 1, L.n_out, L.k_in, (_Float16*)L.fwd2s, 64.0f, 64.0f);
-    k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(L.w, 1, L.k_in, L.k_in, L.n_out, (_Float16*)L.bwd2s, 64.0f, 64.0f);
+    k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(L.w, ld, 1, L.n_out, L.k_in, (_Float16*)L.fwd2s, 64.0f, 64.0f);
+    k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(L.w, 1, ld, L.k_in, L.n_out, (_Float16*)L.bwd2s, 64.0f, 64.0f);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
 }
@@ -341,11 +343,15 @@ int finalize(Model& m, hipStream_t st) {
             PET_HIP_CHECK(hipMemsetAsync(G.wcp, 0, 32 * D * sizeof(float), st));
             PET_HIP_CHECK(hipMemcpyAsync(G.wcp, G.wct, 4 * D * sizeof(float), hipMemcpyDeviceToDevice, st));
             k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(G.wcp, D, 1, 32, D, (_Float16*)G.wc2);
+            if ((rc = named_alloc(m, pre + ":wc2s", &G.wc2s, 2 * n8 * 16))) return rc;  // k_compress_bwd_s (pet_compress_s.hip)
+            k_pack2h<<<cdiv(n8, 256), 256, 0, st>>>(G.wcp, D, 1, 32, D, (_Float16*)G.wc2s, 64.0f, 64.0f);
         }
         if (g > 0) {
             if ((rc = pack_lin(m, pre + ".compress.0:msg", G.compress0_msg, w0, nullptr, D, D, kin, 2 * D, st))) return rc;
+            if ((rc = pack_lin_s(m, pre + ".compress.0:msg", G.compress0_msg, st, kin))) return rc;  // k_compress_s / _bwd_s
         }
         if ((rc = get_lin(m, pre + ".compress.2", D, D, G.compress2, st))) return rc;
+        if ((rc = pack_lin_s(m, pre + ".compress.2", G.compress2, st))) return rc;
         const std::string gs = std::to_string(g);
         if (m.residual()) continue;  // backend.py:589-649: no combination modules, messages are averaged
         if ((rc = get(m, "combination_norms." + gs + ".weight", 2 * D, &G.ln_g))) return rc;

@@ -49,6 +49,7 @@ struct GnnLayerW {
     float* wct = nullptr;  // [4, D]  transpose, for the backward dot products
     float* wcp = nullptr;  // [32, D] wct padded with zero rows to one MFMA tile
     void* wc2 = nullptr;   // f16x3 planes of wcp in fragment order (dgeo = da0 Wc as a 32-wide GEMM tile, pet_trr.hip)
+    void* wc2s = nullptr;  // the same as planes of 64 w (single-accumulator products, pet_compress_s.hip)
     float* tbl = nullptr;  // [n_species, D] species part of compress.0 (+ all biases)
     Lin comb0, comb2;
     const float *ln_g = nullptr, *ln_b = nullptr;
@@ -302,6 +303,9 @@ void set_emlp_s(int v);
 bool emlp_recompute_on(const Lin& win, const Lin& wout, int64_t E);
 bool emlp_s_serves(int64_t E);
 struct Model;
+struct GnnLayerW;
+struct Graph;
+bool compress_bwd_s(bool first, const float* dXe, const float* a0, const GnnLayerW& G, float* dgeo, float* dM, int64_t E, hipStream_t st);
 bool head_edge_s(const Model& m, const float* Xin, const float* fc, float* ypred, float* yout, int64_t E, hipStream_t st);
 bool head_edge_bwd_s(const Model& m, const float* Xin, const float* gA, const int* ctr, const float* fc, const float* ypred,
                      float* dfc, float* dXout, int64_t E, hipStream_t st);

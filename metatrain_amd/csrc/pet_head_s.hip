@@ -13,11 +13,9 @@
 //   adjoint   recomputes a1 (parked as fp32 fragments over the consumed row tile), s1, a2;  da2 = gy w_l silu'(a2);
 //             ds1 = W2^T da2;  da1 = ds1 silu'(a1);  dx = W0^T da1  (each operand scaled per row by a power of two first)
 // Inference only (the training adjoint exports s1, da2, da1, s2 y for the weight gradients: k_head_bwd_h<true> keeps doing that).
-#include "ablk.h"
+#include "rows_s.h"
 
 namespace pet {
-
-constexpr int HS_NW = 4, HS_SLOT = 4096, HS_NSLOT = 4;
 
 // stage g of a kernel's weight stream: matrix g / 16, tile pair (g % 16) / 8, K block g % 8; wave w brings tile 2 tp + (w >> 1),
 // plane w & 1. NM matrices in all; past the end: the last stage again (identical bytes; keeps vmcnt uniform)
@@ -37,44 +35,10 @@ __device__ __forceinline__ void hs_request(int g, HS_W, unsigned ring_u, int wav
     else if (mi == 2) ab_dma_piece((wave & 1) ? wc.l : wc.h, idx, lane16, dst);
     else ab_dma_piece((wave & 1) ? wd.l : wd.h, idx, lane16, dst);
 }
-#define HS_STAGE_SYNC()                                   \
-    do {                                                  \
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  \
-        __syncthreads();                                  \
-    } while (0)
-
-// one 128 x 128 product: acc[t] (4 tiles, zero on entry) += W[tile t] planes . x planes; stages g0 .. g0 + 15 of the stream
 template <int NM>
 __device__ __forceinline__ void hs_gemm(f32x16 (&acc)[4], const f16x8 (&xh)[8], const f16x8 (&xl)[8], int g0, HS_W,
                                         const char* ring, unsigned ring_u, int wave, unsigned lane16) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int g = g0 + r, tp = r >> 3, kb = r & 7;
-        HS_STAGE_SYNC();
-        hs_request<NM>(g + 3, HS_WARGS, ring_u, wave, lane16);
-        const char* slot = ring + (g & (HS_NSLOT - 1)) * HS_SLOT + lane16;
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const f16x8 wh = *reinterpret_cast<const f16x8*>(slot + (2 * t) * 1024);
-            const f16x8 wl = *reinterpret_cast<const f16x8*>(slot + (2 * t + 1) * 1024);
-            AB_MFMA3(acc[2 * tp + t], wh, wl, xh[kb], xl[kb]);
-        }
-    }
-}
-// planes of 64 x of a row fragment (already scaled by its power of two)
-__device__ __forceinline__ void hs_planes(const float4 (&x)[16], f16x8 (&xh)[8], f16x8 (&xl)[8]) {
-#pragma unroll
-    for (int kb = 0; kb < 8; kb++) {
-        const float v8[8] = {x[2 * kb].x * ABS, x[2 * kb].y * ABS, x[2 * kb].z * ABS, x[2 * kb].w * ABS,
-                             x[2 * kb + 1].x * ABS, x[2 * kb + 1].y * ABS, x[2 * kb + 1].z * ABS, x[2 * kb + 1].w * ABS};
-        ab_split8(v8, xh[kb], xl[kb]);
-    }
-}
-// the value of a 128-vector at the feature of accumulator register 4 j + i of tile t, read through the SCALAR cache (wave-uniform
-// addresses, both halves of the column group, selected by lane half: a vector load would queue behind the ring requests)
-__device__ __forceinline__ float hs_vec(const float* __restrict__ v, int t, int j, int i, int h) {
-    const float lo = v[32 * t + 8 * j + i], hi = v[32 * t + 8 * j + 4 + i];
-    return h ? hi : lo;
+    hs_gemm_r(acc, xh, xl, g0, [&](int g) { hs_request<NM>(g, HS_WARGS, ring_u, wave, lane16); }, ring, lane16);
 }
 
 __global__ __launch_bounds__(256, 2) void k_head_s(const float* __restrict__ Xin, W2 w0, const float* __restrict__ b0, W2 w2,

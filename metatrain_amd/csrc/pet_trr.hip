@@ -1198,6 +1198,7 @@ bool trr_compress(bool first, const Graph& g, const GnnLayerW& G, const float* M
 bool trr_compress_bwd(bool first, const float* dXe, const float* a0, const GnnLayerW& G, float* dgeo, float* dM,
                       int64_t E, float* t_da0, hipStream_t st) {
     if (!((g_trr_tilek & 1) && G.compress2.bwd2 && G.wc2 && (first || G.compress0_msg.bwd2)) || E <= 0) return false;
+    if (!t_da0 && compress_bwd_s(first, dXe, a0, G, dgeo, dM, E, st)) return true;  // (inference; pet_compress_s.hip)
     const int grid = grid_rows(E);
     if (first) {
         if (t_da0) k_compress_bwd_h<true, true><<<grid, 256, 0, st>>>(dXe, a0, w2_bwd(G.compress2), w2_wc(G), W2(), dgeo, nullptr, E, t_da0);
