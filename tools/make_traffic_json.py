@@ -7,7 +7,7 @@ import sys
 
 src, edges = sys.argv[1], int(sys.argv[2])
 dst = sys.argv[3] if len(sys.argv) > 3 else "profiles/r02_traffic.json"
-step_kernel = sys.argv[4] if len(sys.argv) > 4 else "k_head_h"   # a kernel launched once per step: its calls = steps profiled
+step_kernel = sys.argv[4] if len(sys.argv) > 4 else "k_head<256>"   # a kernel launched once per step: its calls = steps profiled
 command = sys.argv[5] if len(sys.argv) > 5 else "bench.py, default workload"
 text = open(src).read()
 sections = text.split("# counters")
@@ -35,7 +35,7 @@ for name, v in vals.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v and name.startswith("k_"):
         out["kernels"][name] = {"calls": v["calls"], "fetch_kib_raw": v["FETCH_SIZE"], "write_kib_raw": v["WRITE_SIZE"],
                                 "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024}
-# whole-step traffic over ALL kernels; `step_kernel` (PET: the edge head) runs once per step, so its call count is the number of steps profiled
+# whole-step traffic over ALL kernels; `step_kernel` (PET: the node head) runs once per step, so its call count is the number of steps profiled
 steps = max([v["calls"] for k, v in out["kernels"].items() if k.startswith(step_kernel)] or [1])
 out["steps_profiled"] = steps
 out["step_hbm_bytes"] = sum(v["hbm_bytes_per_launch"] * v["calls"] for v in out["kernels"].values()) / steps
