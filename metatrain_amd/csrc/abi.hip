@@ -298,6 +298,8 @@ int finalize(Model& m, hipStream_t st) {
             if (!expanded) continue;  // d_node == d_pet: Identity modules, no parameters (transformer.py:196-201)
             if ((rc = get_lin(m, lp + ".center_contraction", D, DN, A.cc, st))) return rc;
             if ((rc = get_lin(m, lp + ".center_expansion", DN, D, A.ce, st))) return rc;
+            if ((rc = pack_lin_s(m, lp + ".center_contraction", A.cc, st))) return rc;  // k_rowlin_s (pet_center_s.hip)
+            if ((rc = pack_lin_s(m, lp + ".center_expansion", A.ce, st))) return rc;
             if ((rc = get(m, lp + ".norm_center_features.weight", DN, &A.g_center))) return rc;
             if (m.layer_norm() && (rc = get(m, lp + ".norm_center_features.bias", DN, &A.b_center))) return rc;
             if ((rc = get_lin(m, lp + ".center_mlp.w_in", 2 * DNF, DN, A.cmlp_in, st))) return rc;

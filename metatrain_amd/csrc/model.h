@@ -302,10 +302,14 @@ void set_attn_fused(int v);
 void set_emlp_s(int v);
 bool emlp_recompute_on(const Lin& win, const Lin& wout, int64_t E);
 bool emlp_s_serves(int64_t E);
+bool emlp_s_forced();
 struct Model;
 struct GnnLayerW;
 struct Graph;
 bool compress_bwd_s(bool first, const float* dXe, const float* a0, const GnnLayerW& G, float* dgeo, float* dM, int64_t E, hipStream_t st);
+bool center_s(const Lin& cc, const float* H, float* Xc, int64_t N, hipStream_t st);
+bool expand_bwd_s(const Lin& ce, const float* dH1, float* dOC, int64_t N, hipStream_t st);
+bool center_bwd_s(const Lin& cc, const float* dC, const float* dH1, float* dHin, int64_t N, hipStream_t st);
 bool head_edge_s(const Model& m, const float* Xin, const float* fc, float* ypred, float* yout, int64_t E, hipStream_t st);
 bool head_edge_bwd_s(const Model& m, const float* Xin, const float* gA, const int* ctr, const float* fc, const float* ypred,
                      float* dfc, float* dXout, int64_t E, hipStream_t st);

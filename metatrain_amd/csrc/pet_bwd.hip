@@ -1293,7 +1293,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 } else
                 PET_LAUNCH_TR(tr, k_swiglu_bwd, PET_TA(256, DNF), gN, (BM * LD256 + BM * LD128) * 4, s2,  dH, Ab.H1,
                     Ab.VGn, A.g_center, A.cmlp_out.bwd, A.cmlp_in.bwd, dH_alt, N, tr ? w.dVGn : nullptr, ln);
-                if (!expand_done) k_expand_bwd<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(dH_alt, A.ce.bwd, w.dOC, N);
+                if (!expand_done && !(!tr && expand_bwd_s(A.ce, dH_alt, w.dOC, N, s2)))
+                    k_expand_bwd<<<gN, NTHREADS, BM * LD256 * 4, s2>>>(dH_alt, A.ce.bwd, w.dOC, N);
                 if (tr) {
                     tr->linear(lp + ".center_mlp.w_out", DN, DNF, {dH, nullptr, 0, DN},
                                {Ab.VGn, 2 * DNF, DNF, nullptr, nullptr}, 2, N);
@@ -1390,7 +1391,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
             ss.fork(st);  // centre rows of dX ready
             {
                 ProfScope ps("center_bwd", s2, fN * 2.0 * DN * D);
-                if (N <= 4096) k_center_bwd<true><<<gN, NTHREADS, lds1, s2>>>(dX + E * D, dH_alt, A.cc.bwd, dH, N);
+                if (!tr && center_bwd_s(A.cc, dX + E * D, dH_alt, dH, N, s2)) {
+                } else if (N <= 4096) k_center_bwd<true><<<gN, NTHREADS, lds1, s2>>>(dX + E * D, dH_alt, A.cc.bwd, dH, N);
                 else k_center_bwd<false><<<gN, NTHREADS, lds1, s2>>>(dX + E * D, dH_alt, A.cc.bwd, dH, N);
                 if (tr)
                     tr->linear(lp + ".center_contraction", D, DN, {dX + E * D, nullptr, 0, D},

@@ -434,7 +434,8 @@ void set_emlp_s(int v) {
     g_emlp_s = v ? 1 : 0;
     g_es_min_rows = v > 1 ? v : 28672;
 }
-bool emlp_s_serves(int64_t E) { return g_emlp_s && E >= g_es_min_rows; }  // (the edge head's kernels follow the same policy: pet_head_s.hip)
+bool emlp_s_serves(int64_t E) { return g_emlp_s && E >= g_es_min_rows; }
+bool emlp_s_forced() { return g_emlp_s && g_es_min_rows < 28672; }  // pet_config_set("emlp_s", v > 1): the tests' small graphs  // (the edge head's kernels follow the same policy: pet_head_s.hip)
 bool emlp_recompute_on(const Lin& win, const Lin& wout, int64_t E) {
     return g_emlp_s && E >= g_es_min_rows && win.fwd2s && wout.fwd2s && wout.bwd2s;
 }

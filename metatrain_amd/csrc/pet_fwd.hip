@@ -1095,6 +1095,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
         if (a == 0 && res && gi > 0)  // backend.py:617: every GNN layer starts from its own node embedding
             k_node_embed<<<cdiv(N * (DN / 4), 256), 256, 0, s2>>>(g.sp, m.node_embs[gi], w.gnn[gi].Hin, (int)N);
         ProfScope ps("center", s2, fN * 2.0 * DN * D);
+        if (save != 2 && center_s(A.cc, Ab.H, Ab.X + E * D, N, s2)) return;  // large graphs (pet_center_s.hip)
         k_center<<<gN, NTHREADS, BM * LD256 * 4 + BM * 8, s2>>>(Ab.H, wx_fwd(A.cc), A.cc.b, Ab.X + E * D, N);
     };
     k_node_embed<<<cdiv(N * (DN / 4), 256), 256, 0, st>>>(g.sp, m.node_emb, w.H0, (int)N);

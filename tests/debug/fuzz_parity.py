@@ -93,6 +93,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     eg = float((grad - gp).abs().max() / max(float(gp.abs().max()), 1e-30)) if len(i) else 0.0
     worst = (max(worst[0], ea), max(worst[1], eg), max(worst[2], ec))
     flag = "" if ea < 1e-5 and eg < 1e-5 and ec < 1e-5 else f"   <-- ABOVE 1e-5 (cell {ec:.2e})"
+    if ec > 1e-3 and os.environ.get("PET_FUZZ_DUMP"):
+        print("   dE/dcell ours", gcell.numpy().round(8).tolist(), "reference", gc.numpy().round(8).tolist(), "shifts nonzero:", int((s != 0).any(1).sum()))
     if flag:  # yardstick: the same model evaluated by torch in fp32 on the CPU
         q32 = pos.float().requires_grad_(True)
         r32 = opet.pet_atomic_energies(p32, hypers, q32, cells.float(), i, j, s, z, sysidx.long()).ravel()

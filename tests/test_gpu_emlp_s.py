@@ -199,3 +199,36 @@ def test_adjoint_refuses_a_workspace_without_saved_preactivations_when_recomputa
         rt.config_set("emlp_s", 2)
     fw.forward()
     assert torch.equal(fw.backward(torch.ones_like(atomic)), ref)
+
+
+def test_large_graph_round5_kernels_against_the_kernels_they_replace(rt, dev):
+    """A 20 000-atom box (380 k edges, more than 16 384 atoms): the default policy hands the edge MLP, the edge head, the compress
+    adjoint (csrc/pet_emlp_s.hip, pet_head_s.hip, pet_compress_s.hip) and the three node-row Linear layers around the attention
+    block (csrc/pet_center_s.hip: k_rowlin_s) to the two-workgroups-per-CU kernels; ``emlp_s = 0`` runs the kernels they replace.
+    Both are within 1e-5 of the reference at the at-size tests' sizes; here they must agree with each other to 2e-6."""
+    from metatrain_amd.synthetic import random_box
+
+    hypers = dict(opet.DEFAULT_HYPERS)
+    model = _model(rt, dev, hypers, opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32))
+    n = 20000
+    pos, z, cell = random_box(n, 5)
+    pairs, _ = rt.neighbor_list(pos.to(dev), cell, [True] * 3, hypers["cutoff"])
+    graph = rt.HipGraph(model, pos.to(dev), cell.to(dev)[None], pairs[:, 0].contiguous(), pairs[:, 1].contiguous(),
+                        pairs[:, 2:5].contiguous(), z.to(dev), torch.zeros(n, dtype=torch.int32, device=dev))
+    out = {}
+    try:
+        for mode in (0, 1):
+            rt.config_set("emlp_s", mode)
+            fw = rt.HipForward(model, graph)
+            rt.profile(True)
+            a = fw.forward().clone()
+            g = fw.backward(torch.ones_like(a)).clone()
+            torch.cuda.synchronize()
+            rt.profile(False)
+            out[mode] = (a, g)
+    finally:
+        rt.config_set("emlp_s", 2)  # (the module's fixture forces the kernels for the other tests)
+    (a0, g0), (a1, g1) = out[0], out[1]
+    assert torch.isfinite(a1).all() and torch.isfinite(g1).all()
+    assert float((a0 - a1).abs().max() / a0.abs().max()) < 2e-6
+    assert float((g0 - g1).abs().max() / g0.abs().max()) < 2e-6
