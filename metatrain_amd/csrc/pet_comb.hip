@@ -65,7 +65,11 @@ __global__ __launch_bounds__(256) void k_comb_p2(const float* __restrict__ XF, c
     if (FIRST) load_rowfrag<16>(mi, edge_emb, (int64_t)sp_nbr[row], D, L.h);
     else load_rowfrag<16>(mi, Min, row, D, L.h);
     const float4 b0v = reinterpret_cast<const float4*>(b0)[L.lane];
-    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };  // W0 tile hc, K block kb (of 16) at b = 16 hc + kb
+#ifdef C_ABL_W0  // timing ablation (results are wrong): every weight block is one of two: the stream comes from the CU's L1
+    auto aidx = [&](int b) { return (size_t)(b & 1) * 64 + L.lane; };
+#else
+    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
+#endif  // W0 tile hc, K block kb (of 16) at b = 16 hc + kb
     constexpr int RD = 4;  // W0 ring: K blocks kb .. kb + 3 (eight spill into the store regions of the loop)
     WBlk2<1> ra[RD];
 #pragma unroll
@@ -128,7 +132,11 @@ __global__ __launch_bounds__(256) void k_comb_p2(const float* __restrict__ XF, c
     // W2 fragments of one chunk, one (K block, tile) pair per slot of the out GEMM: ring entry s = 4 kb2 + tile
     f16x8 roh[8], rol[8];
     auto ld_w2 = [&](int c, int s) {
+#ifdef C_ABL_W0
+        const size_t i = (size_t)(s & 1) * 64 + L.lane;
+#else
         const size_t i = ((size_t)(s & 3) * 16 + 2 * c + (s >> 2)) * 64 + L.lane;
+#endif
         roh[s] = w2.h[i];
         rol[s] = w2.l[i];
     };

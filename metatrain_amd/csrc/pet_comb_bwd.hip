@@ -60,9 +60,17 @@ __global__ __launch_bounds__(256) void k_comb_bwd_p2(const float* __restrict__ d
     };
     dma_ca(0, 0);
     dma_ca(1, 1);
-    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };  // W2^T tile hc, K block kb: b = 8 hc + kb
+#ifdef C_ABL_W0  // timing ablation (results are wrong): every weight block is one of two: the stream comes from the CU's L1
+    auto aidx = [&](int b) { return (size_t)(b & 1) * 64 + L.lane; };
+#else
+    auto aidx = [&](int b) { return (size_t)b * 64 + L.lane; };
+#endif  // W2^T tile hc, K block kb: b = 8 hc + kb
     // W0^T stream position p = 0 .. 31: K block p & 15 of output half p >> 4 (tile t at + t * 16 * 64)
+#ifdef C_ABL_W0
+    auto bidx = [&](int p) { return (size_t)(p & 1) * 64 + L.lane; };
+#else
     auto bidx = [&](int p) { return ((size_t)(4 * (p >> 4)) * 16 + (p & 15)) * 64 + L.lane; };
+#endif
     constexpr int RA = 4;
     WBlk2<1> ra[RA];
     WBlk2<4> rb[2];
