@@ -406,8 +406,10 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *                 fewer than 3 840 attention tiles (fewer than about 4 700 atoms: latency-bound there) and graphs in which more
  *                 than 5 % of the atoms have more than 32 tokens keep the three-kernel form, as do training forwards,
  *                 graphs with an atom of more than 64 tokens and PostLN models. 0 = the three-kernel form everywhere.
- *   "emlp_s"      the edge MLP and its adjoint -- and the edge head and its inference adjoint, csrc/pet_head_s.hip -- as two
- *                 desynchronised four-wave workgroups per CU on one-accumulator products (csrc/pet_emlp_s.hip; the adjoint RECOMPUTES the SwiGLU pre-activations, so an inference forward does not
+ *   "emlp_s"      the edge MLP and its adjoint -- and, in inference, the edge head and its adjoint (csrc/pet_head_s.hip), the compress
+ *                 adjoint (pet_compress_s.hip) and, from 16 384 atoms on, the node-row Linear layers around the attention block
+ *                 (pet_center_s.hip) -- as two desynchronised four-wave workgroups per CU on one-accumulator products
+ *                 with a workgroup-shared weight ring (csrc/pet_emlp_s.hip, rows_s.h; the adjoint RECOMPUTES the SwiGLU pre-activations, so an inference forward does not
  *                 store them): 1 = for graphs of at least 28 672 edge rows (default), v > 1 = from v rows on, 0 = never
  *                 (the one-wave-per-SIMD pipelined kernels everywhere). A forward that ran without saving can only be followed
  *                 by the recomputing adjoint: flipping the switch in between makes pet_backward fail (PET_ERR_ARGUMENT).
