@@ -226,6 +226,10 @@ def test_large_graph_round5_kernels_against_the_kernels_they_replace(rt, dev):
             torch.cuda.synchronize()
             rt.profile(False)
             out[mode] = (a, g)
+            if mode == 1:  # run-to-run bit determinism of the large-graph kernels (no atomics, fixed reduction orders)
+                a2 = fw.forward().clone()
+                g2 = fw.backward(torch.ones_like(a2)).clone()
+                assert torch.equal(a, a2) and torch.equal(g, g2)
     finally:
         rt.config_set("emlp_s", 2)  # (the module's fixture forces the kernels for the other tests)
     (a0, g0), (a1, g1) = out[0], out[1]
