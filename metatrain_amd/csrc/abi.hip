@@ -360,6 +360,8 @@ int finalize(Model& m, hipStream_t st) {
         if ((rc = get(m, "combination_norms." + gs + ".bias", 2 * D, &G.ln_b))) return rc;
         if ((rc = get_lin(m, "combination_mlps." + gs + ".0", 2 * D, 2 * D, G.comb0, st))) return rc;
         if ((rc = get_lin(m, "combination_mlps." + gs + ".2", D, 2 * D, G.comb2, st))) return rc;
+        if ((rc = fold_norm_s(m, "combination_mlps." + gs + ".0", G.comb0, G.ln_g, G.ln_b, G.comb0_g, st))) return rc;  // k_comb_s
+        if ((rc = pack_lin_s(m, "combination_mlps." + gs + ".2", G.comb2, st))) return rc;
     }
     m.node_embs.assign(m.residual() ? h.num_gnn_layers : 1, nullptr);  // backend.py:93-119: one per readout layer
     for (size_t l = 0; l < m.node_embs.size(); l++)

@@ -52,6 +52,7 @@ struct GnnLayerW {
     void* wc2s = nullptr;  // the same as planes of 64 w (single-accumulator products, pet_compress_s.hip)
     float* tbl = nullptr;  // [n_species, D] species part of compress.0 (+ all biases)
     Lin comb0, comb2;
+    Lin comb0_g;  // comb0 with the combination LayerNorm's weight and bias folded in (k_comb_s, pet_comb_s.hip)
     const float *ln_g = nullptr, *ln_b = nullptr;
     // raw forms for the size-generic path (gen.hip): edge_embedder (4 -> d_pet), compress.0 as uploaded, neighbor_embedder
     Lin eemb, c0;
@@ -310,6 +311,8 @@ bool compress_bwd_s(bool first, const float* dXe, const float* a0, const GnnLaye
 bool center_s(const Lin& cc, const float* H, float* Xc, int64_t N, hipStream_t st);
 bool expand_bwd_s(const Lin& ce, const float* dH1, float* dOC, int64_t N, hipStream_t st);
 bool center_bwd_s(const Lin& cc, const float* dC, const float* dH1, float* dHin, int64_t N, hipStream_t st);
+bool comb_s(bool first, const float* XF, const int* rev, const Lin& c0g, const Lin& c2, const float* Min, const float* edge_emb,
+            const int* sp_nbr, float* CA, float* LNS, float* Mout, int64_t E, hipStream_t st);
 bool head_edge_s(const Model& m, const float* Xin, const float* fc, float* ypred, float* yout, int64_t E, hipStream_t st);
 bool head_edge_bwd_s(const Model& m, const float* Xin, const float* gA, const int* ctr, const float* fc, const float* ypred,
                      float* dfc, float* dXout, int64_t E, hipStream_t st);

@@ -44,8 +44,10 @@ __global__ __launch_bounds__(256, 2) void k_rowlin_s(const float* __restrict__ X
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = xa[k];
         if (KIN == 256) {
+            // the reads must have RETURNED before the tile is requested again (an L2-warm LDS-DMA lands after 250-400 cycles, sooner
+            // than sixteen queued ds_read_b128 of a busy CU are served; the copies above are no instructions, so nothing else waits)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
             dma_tile128(X + 128, row0, N, tile_u, L, KIN);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             tile128_to_frag(xa, tile, L);

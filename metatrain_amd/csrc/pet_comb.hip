@@ -264,6 +264,7 @@ static inline W2 w2_of(const void* base, int n_tiles_dim, int k_dim) {
 bool trr_comb(bool first, const float* XF, const Graph& g, const GnnLayerW& G, const float* Min,
               const float* edge_emb, float* CA, float* LNS, float* Mout, int64_t E, hipStream_t st) {
     if (!G.comb0.fwd2 || !G.comb2.fwd2 || E <= 0) return false;
+    if (comb_s(first, XF, g.rev, G.comb0_g, G.comb2, Min, edge_emb, g.sp_nbr, CA, LNS, Mout, E, st)) return true;  // large graphs (pet_comb_s.hip)
     const W2 w0 = w2_of(G.comb0.fwd2, G.comb0.n_out, G.comb0.k_in), w2 = w2_of(G.comb2.fwd2, G.comb2.n_out, G.comb2.k_in);
     const int grid = cdiv(E, WG_ROWS);
     const size_t lds = (size_t)4 * 32768;  // per wave: e tile (then operands / staging / bias), e[rev] tile (then its planes)

@@ -72,3 +72,29 @@ def test_adjoint_refuses_a_workspace_whose_forward_did_not_save_qkv(rt):
         assert torch.equal(fw.backward(ones), ref)
     finally:
         rt.config_set("attn_fused", 3)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_large_batch_kernels_are_bit_stable(rt, train):
+    """Run-to-run bit determinism of forward and adjoint on a batch that hands every stage to the large-graph kernels (32 x 1 000
+    atoms: 600 k edge rows, 32 000 atoms: csrc/pet_emlp_s.hip, pet_head_s.hip, pet_compress_s.hip, pet_center_s.hip,
+    pet_comb_s.hip). The first versions of k_comb_s and k_rowlin_s re-requested their row tile by LDS-DMA while the ds_read_b128 of
+    its previous contents had been issued but not returned: an L2-warm DMA lands sooner than sixteen queued reads of a busy CU are
+    served, and about one launch in seventy came out different (tools/debug/comb_det.py runs the longer version)."""
+    from metatrain_amd import data
+    from metatrain_amd.pet import default_hypers
+    from metatrain_amd.synthetic import random_box, synthetic_params
+
+    dev = torch.device("cuda:0")
+    hypers = default_hypers()
+    model = rt.HipModel(hypers, [1, 6, 7, 8])
+    model.load({k: v.to(dev) for k, v in synthetic_params(hypers, [1, 6, 7, 8], {"energy": 1}, 0).items()}, "energy")
+    boxes = [random_box(1000, 300 + b) for b in range(32)]
+    g = data.graph_of(model, data.collate([(p.to(dev), z.to(dev), c.to(dev), (True, True, True)) for p, z, c in boxes], 4.5))
+    fw = rt.HipForward(model, g, train=train)
+    a0 = fw.forward().clone()
+    ones = torch.ones_like(a0)
+    g0 = fw.backward(ones).clone()
+    for _ in range(25):
+        assert torch.equal(fw.forward(), a0)
+        assert torch.equal(fw.backward(ones), g0)
