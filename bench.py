@@ -52,7 +52,7 @@ def synthetic_params(hypers):
 STAGE_KERNELS = {"attn_blk": ("k_ablk_fwd", "k_ablk_fwd4"), "attn_blk_bwd": ("k_ablk_bwd",),
                  "attn_bwd": ("k_attn_bwd_a", "k_attn_bwd_l"), "attn_fwd": ("k_attn_fwd_p",),
                  "emlp": ("k_emlp_p2", "k_emlp_s"), "emlp_bwd": ("k_emlp_bwd_p2", "k_emlp_bwd_s"), "qkv": ("k_qkv_s",), "qkv_bwd": ("k_qkv_bwd_h",),
-                 "comb": ("k_comb_p2",), "comb_bwd": ("k_comb_bwd_p2",)}
+                 "comb": ("k_comb_p2", "k_comb_s"), "comb_bwd": ("k_comb_bwd_p2",)}
 
 
 SPLIT_MFMA_STAGES = {"attn_blk", "attn_blk_bwd", "emlp", "emlp_bwd", "qkv", "qkv_bwd", "oproj", "oproj_bwd", "comb", "comb_bwd", "compress",
