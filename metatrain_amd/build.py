@@ -28,6 +28,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "pet_hip.h"))
     hdr_time = max(os.path.getmtime(h) for h in headers)
+    # the flag set is part of an object's identity: a stamp file in the object directory forces a full rebuild when it changes
+    # (PET_HIP_EXTRA_FLAGS = -DAB_PROFILE also switches VGPR_FORM off: objects of the other setting must not be linked)
+    stamp = os.path.join(objdir, "flags.stamp")
+    flag_id = " ".join(FLAGS) + " | " + " ".join(sorted(VGPR_FORM)) + " | " + " ".join(VGPR_FORM_FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != flag_id:
+        have_objects = any(f.endswith(".o") for f in os.listdir(objdir))
+        force = force or os.path.exists(stamp) or (have_objects and bool(os.environ.get("PET_HIP_EXTRA_FLAGS")))
+        with open(stamp, "w") as fh:
+            fh.write(flag_id)
     procs, objs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -116,6 +116,7 @@ struct Graph {
         bool generic = false;
         bool attn_unsaved = false;  // some attention layer ran the fused block: its QKV / AO buffers were not written
         bool emlp_unsaved = false;  // the edge MLPs did not write [v; g]: the adjoint recomputes them (pet_emlp_s.hip)
+        int save = -1;              // the forward's save level (0 = nothing kept for an adjoint: pet_backward must refuse)
     };
     mutable FwdRecord fwd_rec[4];
     mutable int fwd_rec_next = 0;
@@ -126,10 +127,10 @@ struct Graph {
     }
     FwdRecord& fwd_record_new(const void* ws) const {
         for (FwdRecord& r : fwd_rec)
-            if (r.ws == ws) return r = FwdRecord{ws, false, false, false};
+            if (r.ws == ws) return r = FwdRecord{ws, false, false, false, -1};
         FwdRecord& r = fwd_rec[fwd_rec_next];
         fwd_rec_next = (fwd_rec_next + 1) % 4;
-        return r = FwdRecord{ws, false, false, false};
+        return r = FwdRecord{ws, false, false, false, -1};
     }
     bool attn_lists = false;         // atom_order / bucket_start (and the tile plan) exist (graph.hip graph_attention_lists)
     bool tiles_planned = false;      // the graph build made tile_desc (large graphs, or the fused block forced)

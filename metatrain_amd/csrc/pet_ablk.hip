@@ -324,7 +324,7 @@ __device__ __forceinline__ void ab4_request(int g, const W2& wqkv, const W2& wo,
 }
 #define AB4_STAGE_SYNC()                                  \
     do {                                                  \
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  \
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");  \
         __syncthreads();                                  \
     } while (0)
 

@@ -1193,6 +1193,10 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
     // three-kernel adjoint would read buffers nobody wrote (a switch flipped between the two calls) -- refuse
     const Graph::FwdRecord* fwd_rec = w.base ? g.fwd_record(w.base) : nullptr;
     const bool fwd_unsaved = fwd_rec && fwd_rec->attn_unsaved;
+    // a forward that kept nothing (save_for_backward = 0) wrote neither [v; g] nor the compress pre-activations: no adjoint
+    // can follow it, whatever the switches say
+    PET_REQUIRE(!fwd_rec || fwd_rec->save != 0, PET_ERR_ARGUMENT,
+                "the last forward into this workspace ran with save_for_backward = 0: nothing was kept for an adjoint");
     PET_REQUIRE(!fwd_unsaved || fused_attn, PET_ERR_ARGUMENT,
                 "the forward of this workspace ran the fused attention block (Q, K, V not saved) but the adjoint is "
                 "configured for the three-kernel form: pet_config_set changed between forward and backward");

@@ -121,7 +121,7 @@ static inline W2 ns_w2(const void* base, int tiles, int kbs) {
     return w;
 }
 // the node chain takes this form from 16 384 atoms on (below: the 32-row node kernels fuse these layers, pet_fwd.hip node_rows)
-static bool center_s_serves(int64_t N) { return emlp_s_serves((int64_t)1 << 40) && (N > 16384 || emlp_s_forced()); }
+static bool center_s_serves(int64_t N) { return emlp_s_serves((int64_t)1 << 40) && (N >= 16384 || emlp_s_forced()); }
 
 template <int KIN, int NOUT, bool ADD>
 static void rowlin_s_launch(const float* X, W2 w, const float* bias, const float* addend, float* Y, int64_t N, hipStream_t st) {

@@ -34,9 +34,9 @@ __device__ __forceinline__ void cb_request(int hc, int s, const W2& w0, const W2
 // stages 12 hc + 10 and + 11, so the count is 2 + 4 for the stages 12 hc + 8 .. + 10; a partial tile skips store instructions)
 #define CB_STAGE_SYNC(AFTER_STORES)                                                          \
     do {                                                                                     \
-        if ((AFTER_STORES) && !full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        \
-        else if (AFTER_STORES) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");              \
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                \
+        if ((AFTER_STORES) && !full) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
+        else if (AFTER_STORES) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");              \
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                \
         __syncthreads();                                                                     \
     } while (0)
 

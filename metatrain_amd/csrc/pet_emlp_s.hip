@@ -59,9 +59,9 @@ __device__ __forceinline__ void es_request(int hc, int s, const W2& win, const W
 // count is 2 + 8 for the three stages whose fragments were requested before them and are waited for after them: 12 hc + 8 .. + 10)
 #define ES_STAGE_SYNC(AFTER_STORES)                                           \
     do {                                                                      \
-        if ((AFTER_STORES) && !full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* a partial tile skips store instructions */ \
-        else if (AFTER_STORES) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        \
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                 \
+        if ((AFTER_STORES) && !full) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   /* a partial tile skips store instructions */ \
+        else if (AFTER_STORES) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");        \
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                 \
         ES_BARRIER();                                                         \
     } while (0)
 // accumulator tile initialised with 4096 x bias, the bias read through the SCALAR cache (wave-uniform addresses, both halves
@@ -377,6 +377,8 @@ __global__ __launch_bounds__(256, 2) void k_emlp_bwd_s(const float* __restrict__
         }
     }
     // ---- epilogue: the norm adjoint on (w = d xhat-space adjoint, xhat from the planes), the residual dY' from ITS planes
+    // (hi + lo keeps 22 bits of the pass-through adjoint: 2.4e-7 of the row's largest entry per layer, linear in the depth;
+    // the fp32 rows would cost 64 registers the kernel does not have. tests/test_gpu_emlp_s.py runs a 3 x 3-layer model.)
     float4 w[16];
     {
         const float f = inv * ABS_INV;  // dn holds 64 x (W_in^T planes) of the scaled row

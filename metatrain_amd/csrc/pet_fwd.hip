@@ -1055,6 +1055,7 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
     const bool gen = use_generic(m, g) || (save == 2 && train_generic_for(m, g));
     PET_REQUIRE(!(gen && g.x_fn), PET_ERR_UNSUPPORTED, "the per-layer exchange is built for the tuned path (default model size)");
     Graph::FwdRecord& fwd_rec = note_workspace(g, ws, gen);
+    fwd_rec.save = save;
     if (gen) return gen_forward_layers(m, g, ws, ws_bytes, save, atomic, node_feats, edge_feats, n_layers, st);
     if (int rcl = graph_attention_lists(g, st)) return rcl;
     Workspace w;

@@ -15,7 +15,7 @@ constexpr int HS_NW = 4, HS_SLOT = 4096, HS_NSLOT = 4;
 // workgroup barrier: the stage is complete for everybody, and everybody is done with the stage before it
 #define HS_STAGE_SYNC()                                   \
     do {                                                  \
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  \
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");  \
         __syncthreads();                                  \
     } while (0)
 

@@ -97,9 +97,13 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
         print("   dE/dcell ours", gcell.numpy().round(8).tolist(), "reference", gc.numpy().round(8).tolist(), "shifts nonzero:", int((s != 0).any(1).sum()))
     if flag:  # yardstick: the same model evaluated by torch in fp32 on the CPU
         q32 = pos.float().requires_grad_(True)
-        r32 = opet.pet_atomic_energies(p32, hypers, q32, cells.float(), i, j, s, z, sysidx.long()).ravel()
-        (g32,) = torch.autograd.grad((r32 * w.float()).sum(), q32)
+        c32 = cells.float().requires_grad_(True)
+        r32 = opet.pet_atomic_energies(p32, hypers, q32, c32, i, j, s, z, sysidx.long()).ravel()
+        g32, gc32 = torch.autograd.grad((r32 * w.float()).sum(), [q32, c32], allow_unused=True)
+        gc32 = torch.zeros_like(c32) if gc32 is None else gc32
+        yc = float((gc32.double() - gc).abs().max() / max(float(gc.abs().max()), 1e-30))
         flag += f" (torch fp32: E {float((r32.detach().double() - ref.detach()).abs().max() / ref.detach().abs().max()):.2e}" \
-                f" grad {float((g32.double() - gp).abs().max() / gp.abs().max()):.2e}; max|grad| {float(gp.abs().max()):.3e})"
+                f" grad {float((g32.double() - gp).abs().max() / gp.abs().max()):.2e} cell {yc:.2e}; max|grad| {float(gp.abs().max()):.3e}" \
+                f" max|dE/dcell| {float(gc.abs().max()):.3e})"
     print(f"trial {trial:3d} systems {desc} edges {len(i)}: E {ea:.2e} grad {eg:.2e}{flag}", flush=True)
 print("worst", worst)

@@ -236,3 +236,52 @@ def test_large_graph_round5_kernels_against_the_kernels_they_replace(rt, dev):
     assert torch.isfinite(a1).all() and torch.isfinite(g1).all()
     assert float((a0 - a1).abs().max() / a0.abs().max()) < 2e-6
     assert float((g0 - g1).abs().max() / g0.abs().max()) < 2e-6
+
+
+def test_backward_after_a_forward_that_saved_nothing_is_refused(rt, dev, golden_dir):
+    """``pet_forward(save_for_backward = 0)`` writes neither [v; g] nor the compress pre-activations; the workspace's
+    forward record carries the save level and ``pet_backward`` on that workspace fails with PET_ERR_ARGUMENT instead of
+    consuming unwritten buffers. A saving forward into the same workspace makes the adjoint valid again."""
+    from metatrain_amd.runtime import PetHipError, _ptr, _stream, check
+
+    g = dict(np.load(os.path.join(golden_dir, "pet_default_box64.npz")))
+    t = lambda k: torch.tensor(g[k])  # noqa: E731
+    hypers = dict(opet.DEFAULT_HYPERS)
+    model = _model(rt, dev, hypers, opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32))
+    graph = _graph(rt, model, dev, t("in_positions"), t("in_cells"), g["in_centers"], g["in_neighbors"], g["in_cell_shifts"],
+                   t("in_species"), t("in_system_indices"))
+    fw = rt.HipForward(model, graph)
+    atomic = torch.empty((graph.n_nodes,), dtype=torch.float32, device=dev)
+    check(fw.lib.pet_forward(model.handle, graph.handle, _ptr(fw.workspace), fw.nbytes, 0, _ptr(atomic), None, None, _stream()))
+    assert relmax(atomic.cpu().numpy(), g["atomic_f64"].ravel()) < TOL
+    with pytest.raises(PetHipError, match="save_for_backward = 0"):
+        fw.backward(torch.ones_like(atomic))
+    a2 = fw.forward()
+    grad = fw.backward(torch.ones_like(a2))
+    assert relmax(grad.cpu().numpy(), g["grad_f64"]) < TOL
+
+
+def test_forced_kernels_on_a_deeper_model(rt, dev):
+    """``k_emlp_bwd_s`` rebuilds the pass-through adjoint dY of the residual branch from its two fp16 planes (22 bits)
+    instead of the fp32 rows, about 2.4e-7 of the row's largest entry per layer; the loss grows linearly with the depth. A model
+    of 3 GNN x 3 attention layers (nine edge-MLP adjoints in a chain, against four of the default model) stays inside the same
+    1e-5 bar against the fp64 oracle, with the fused attention adjoint forced as well."""
+    hypers = dict(opet.DEFAULT_HYPERS, num_gnn_layers=3, num_attention_layers=3)
+    params = opet.synthetic_params(hypers, TYPES, {"energy": 1}, 0, torch.float32)
+    model = _model(rt, dev, hypers, params)
+    pos, z, cell = opet.random_box(150, seed=77)
+    i, j, s, _ = onl.neighbor_list(pos.numpy(), cell.numpy(), [True] * 3, hypers["cutoff"])
+    sysidx = torch.zeros(150, dtype=torch.long)
+    rt.config_set("attn_fused", 7)
+    try:
+        graph = _graph(rt, model, dev, pos, cell[None], i, j, s, z, sysidx)
+        fw = rt.HipForward(model, graph)
+        atomic, grad, stages = _stages(rt, fw, None)
+    finally:
+        rt.config_set("attn_fused", 3)
+    assert {"emlp", "emlp_bwd"} <= stages
+    p64 = {k: (v.double() if v.is_floating_point() else v) for k, v in params.items()}
+    _, g_ref, a_ref = opet.energy_and_gradient(p64, hypers, pos.double(), cell[None].double(), torch.tensor(i), torch.tensor(j),
+                                               torch.tensor(s).long(), z, sysidx)
+    assert relmax(atomic.cpu().numpy(), a_ref.numpy().ravel()) < TOL
+    assert relmax(grad.cpu().numpy(), g_ref.numpy()) < TOL
