@@ -43,8 +43,14 @@ struct SoapDims {
     int n_per_l[MAXL + 1], rad_off[MAXL + 1], coef_off[MAXL + 2], feat_off[MAXL + 2];
     int kp_off[MAXL + 2];  // fused ps+tail kernels: feature (l, a, b) sits at K index kp_off[l] + 32 a + b
     int ncmax;             // largest n_per_l[l] * C
+    // packed power spectrum (round 6): p_l[a][b] = p_l[b][a], so the inference path stores the upper triangle a <= b of every
+    // l block only -- Sp = sum_l nc (nc + 1) / 2 floats per atom instead of S = sum_l nc^2 (2 360 against 4 544 for the default
+    // basis) -- at pfeat_off[l] + a nc - a (a - 1) / 2 + (b - a); the first Linear and the LayerNorm are folded accordingly
+    // (k_soap_prep_wallp). Halves the feature traffic of the four kernels that stream [N][S].
+    int Sp, pfeat_off[MAXL + 2];
     float rc, width, inv_h;
 };
+__host__ __device__ __forceinline__ int soap_tri(int nc, int lo, int hi) { return lo * nc - lo * (lo - 1) / 2 + (hi - lo); }
 
 constexpr int MAXNH = 8;  // hidden layers of the tail (soap_bpnn/documentation.py: num_hidden_layers, default 2)
 struct SoapSet {  // weights of one (centre-species) set
@@ -81,6 +87,14 @@ struct SoapModel {
     int Kp2 = 0;
     float *wall2 = nullptr, *wall2t = nullptr;
     float4 *wall2_fwd = nullptr, *wall2_bwd = nullptr, *wall2t_bwd = nullptr;
+    // packed power spectrum (SoapDims::Sp): the first Linear of every network over the upper-triangle layout,
+    // W'[j][(a, b)] = gamma W1[j][(a, b)] + gamma W1[j][(b, a)] (a < b), for the adjoint with the diagonal doubled
+    int Kpp = 0;
+    float *wallp = nullptr, *wallpb = nullptr;
+    float4 *wallp_fwd_set = nullptr, *wallp_bwd_set = nullptr;
+    // which layout the last forward into a workspace left in its feature buffer (true = packed); soap_bwd and the training
+    // pass follow it (the training pass rebuilds the full layout from the stored expansion coefficients)
+    mutable std::map<const void*, bool> ws_packed;
     bool finalized = false;
 };
 
@@ -388,6 +402,32 @@ __global__ void k_soap_prep_rows(SoapDims d, const SoapSet* __restrict__ sets, i
     bs[o] = (float)b;
 }
 
+// The first Linear over the packed (upper-triangle) feature layout, one network after the other: [n_sets * H][Kpp].
+// diag2: the adjoint's copy -- its GEMM output is G[a][b] = dx[a][b] + dx[b][a], which on the diagonal is TWICE dx[a][a].
+__global__ void k_soap_prep_wallp(SoapDims d, const SoapSet* __restrict__ sets, int n_sets, int Kpp, int diag2,
+                                  float* __restrict__ wallp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n_sets * d.H * Kpp) return;
+    const int o = (int)(idx / Kpp), t = (int)(idx % Kpp);
+    float v = 0.f;
+    if (t < d.Sp) {
+        int l = 0;
+        while (t >= d.pfeat_off[l + 1]) l++;
+        const int nc = d.n_per_l[l] * d.C;
+        int q = t - d.pfeat_off[l], a = 0;
+        while (q >= nc - a) { q -= nc - a; a++; }
+        const int b = a + q;
+        const SoapSet W = sets[o / d.H];
+        const float* w1 = W.W1 + (size_t)(o % d.H) * d.S + d.feat_off[l];
+        const float* lw = W.ln_w + d.feat_off[l];
+        const int k1 = a * nc + b, k2 = b * nc + a;
+        v = w1[k1] * (d.layernorm ? lw[k1] : 1.f);
+        if (a != b) v += w1[k2] * (d.layernorm ? lw[k2] : 1.f);
+        else if (diag2) v *= 2.f;
+    }
+    wallp[idx] = v;
+}
+
 template <int NT>
 __global__ __launch_bounds__(NTHREADS) void k_soap_tail_fwd_mfma(SoapDims d, const float* __restrict__ feats,
                                                                  const int* __restrict__ sp,
@@ -590,6 +630,9 @@ __global__ __launch_bounds__(256) void k_soap_ps_w(SoapDims d, const float* __re
 // operands are the SAME register -- lane (a = lane & 31, m = 2 s + (lane >> 5)) holds c[l][m][a] as A[a][m] and as B[m][a] --
 // so an l block costs ceil((2l+1) / 2) v_mfma_f32_32x32x2_f32 and as many ds_read_b32 (exact fp32 products, fp32 sums, as
 // the scalar loop). One wave per atom; the 32 x 32 tile leaves as rows of nc consecutive floats; LayerNorm statistics in fp64.
+// PACKED: only the upper triangle a <= b leaves (SoapDims::Sp floats per atom); the LayerNorm statistics count an
+// off-diagonal entry twice, so mean and rstd are those of the full S-vector.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_soap_ps_m(SoapDims d, const float* __restrict__ Cf, const int* __restrict__ sp,
                                                    const float* __restrict__ enc, float* __restrict__ feats,
                                                    float* __restrict__ tail, int N) {
@@ -601,7 +644,7 @@ __global__ __launch_bounds__(256) void k_soap_ps_m(SoapDims d, const float* __re
     for (int k = lane; k < d.NCOEF; k += 64) cs[k] = Cf[(size_t)i * d.NCOEF + k];
     __builtin_amdgcn_wave_barrier();
     const float* e = enc ? enc + (size_t)sp[i] * d.S : nullptr;
-    float* out = feats + (size_t)i * d.S;
+    float* out = feats + (size_t)i * (PACKED ? d.Sp : d.S);
     const int a = lane & 31, mh = lane >> 5;
     double s1 = 0.0, s2 = 0.0;
     for (int l = 0; l <= d.L; l++) {
@@ -620,7 +663,15 @@ __global__ __launch_bounds__(256) void k_soap_ps_m(SoapDims d, const float* __re
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int p1 = (r & 3) + 8 * (r >> 2) + 4 * mh;
-                if (p1 < nc) {
+                if (PACKED) {
+                    if (p1 <= a) {  // row p1 of the triangle: nc - p1 consecutive floats across the lanes
+                        const float v = acc[r];
+                        out[d.pfeat_off[l] + soap_tri(nc, p1, a)] = v;
+                        const double wv = p1 == a ? (double)v : 2.0 * (double)v;
+                        s1 += wv;
+                        s2 += wv * (double)v;
+                    }
+                } else if (p1 < nc) {
                     const int idx = f0 + p1 * nc + a;
                     float v = acc[r];
                     if (e) v *= e[idx];
@@ -677,16 +728,20 @@ __global__ __launch_bounds__(256) void k_soap_ps_bwd_s(SoapDims d, const float* 
 // is at most 2 L + 1 = 13 .. 17 rows: the 32-row tile would waste more than half of itself), two MFMAs per K step -- one
 // with dF[b][a], one with dF[a][b] -- instead of a symmetrisation pass over the staged row; the workgroup's four waves take
 // the l blocks in turn. fp32 products and sums (the scalar kernel summed its 28 terms in fp64).
+// PACKED: dF arrives as the symmetrised upper triangle G[a][b] = dx[a][b] + dx[b][a] (k_soap_tail_bwd_set with the packed
+// weights): one MFMA per K step, half the staged row.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_soap_ps_bwd_m(SoapDims d, const float* __restrict__ Cf,
                                                        const float* __restrict__ dF, float* __restrict__ dCf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cs = smem;             // [NCOEF]
-    float* G = smem + d.NCOEF;    // [S]
+    float* G = smem + d.NCOEF;    // [S] (PACKED: [Sp])
     const int i = blockIdx.x;
+    const int SF = PACKED ? d.Sp : d.S;
     for (int k = threadIdx.x; k < d.NCOEF; k += 256) cs[k] = Cf[(size_t)i * d.NCOEF + k];
-    for (int k = threadIdx.x; k < d.S / 4; k += 256)
-        reinterpret_cast<float4*>(G)[k] = reinterpret_cast<const float4*>(dF + (size_t)i * d.S)[k];
+    for (int k = threadIdx.x; k < SF / 4; k += 256)
+        reinterpret_cast<float4*>(G)[k] = reinterpret_cast<const float4*>(dF + (size_t)i * SF)[k];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -694,7 +749,7 @@ __global__ __launch_bounds__(256) void k_soap_ps_bwd_m(SoapDims d, const float* 
     for (int l = wave; l <= d.L; l += 4) {
         const int nc = d.n_per_l[l] * d.C, M = 2 * l + 1;
         const float* c = cs + d.coef_off[l];
-        const float* g = G + d.feat_off[l];
+        const float* g = G + (PACKED ? d.pfeat_off[l] : d.feat_off[l]);
         for (int m0 = 0; m0 < M; m0 += 16)
             for (int a0 = 0; a0 < nc; a0 += 16) {
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -703,9 +758,14 @@ __global__ __launch_bounds__(256) void k_soap_ps_bwd_m(SoapDims d, const float* 
                     const int b = b0 + kq;
                     const float av = (mi < M && b < nc) ? c[mi * nc + b] : 0.f;
                     const bool ok = aj < nc && b < nc;
-                    const float bv = ok ? g[b * nc + aj] : 0.f, bt = ok ? g[aj * nc + b] : 0.f;  // dF[b][a], dF[a][b]
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bt, acc, 0, 0, 0);
+                    if (PACKED) {
+                        const float bv = ok ? g[soap_tri(nc, b < aj ? b : aj, b < aj ? aj : b)] : 0.f;  // G[a][b] = G[b][a]
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                    } else {
+                        const float bv = ok ? g[b * nc + aj] : 0.f, bt = ok ? g[aj * nc + b] : 0.f;  // dF[b][a], dF[a][b]
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bt, acc, 0, 0, 0);
+                    }
                 }
                 if (aj < nc) {
 #pragma unroll
@@ -1241,9 +1301,14 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_set(SoapDims d, cons
                                                                 const float* __restrict__ enc,
                                                                 const float* __restrict__ tail,
                                                                 const float* __restrict__ gA, float* __restrict__ dF,
-                                                                const float* __restrict__ da2x) {
+                                                                const float* __restrict__ da2x, int packed) {
+    // packed != 0: feats / dF rows are the upper-triangle layout (SoapDims::Sp floats), Wpbs the packed weights with the
+    // diagonal doubled; the output is G[a][b] = dx[a][b] + dx[b][a] = rstd (g'_t - 2 (m1 + xhat_t m2)): the two LayerNorm means
+    // (over the FULL S-vector, as before) enter twice
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int H = 32, LDD = lds_ld(H), TS = 2 + 2 * H;
+    const int SR = packed ? d.Sp : d.S;   // row pitch and length of feats / dF
+    const float pm = packed ? 2.f : 1.f;
     float* Ds = smem;                 // [64][36] d a1
     float* d2 = Ds + BM * LDD;        // [64][32] d a2
     float* st = d2 + BM * H;          // [64][4] mean, rstd, m1, m2
@@ -1289,8 +1354,8 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_set(SoapDims d, cons
         for (int o = 16; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
         if (j == 0) {
             st[r * 4] = mu; st[r * 4 + 1] = rstd;
-            st[r * 4 + 2] = t1 / d.S;          // m1 = mean(dxn gamma)
-            st[r * 4 + 3] = rstd * t2 / d.S;   // m2 = mean(dxn gamma xhat)
+            st[r * 4 + 2] = pm * t1 / d.S;          // m1 = mean(dxn gamma)
+            st[r * 4 + 3] = pm * rstd * t2 / d.S;   // m2 = mean(dxn gamma xhat)
         }
     }
     __syncthreads();
@@ -1298,14 +1363,14 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_set(SoapDims d, cons
     const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
     int64_t rowoff[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) rowoff[q] = rows[r0 + 8 * q] >= 0 ? (int64_t)rows[r0 + 8 * q] * d.S : -1;
+    for (int q = 0; q < 8; q++) rowoff[q] = rows[r0 + 8 * q] >= 0 ? (int64_t)rows[r0 + 8 * q] * SR : -1;
     float4 xpre[8];
     auto fetch = [&](int nblk) {
         const int k = 128 * nblk + 4 * c4;
 #pragma unroll
         for (int q = 0; q < 8; q++)
-            xpre[q] = d.layernorm && rowoff[q] >= 0 && k < d.S ? *reinterpret_cast<const float4*>(feats + rowoff[q] + k)
-                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            xpre[q] = d.layernorm && rowoff[q] >= 0 && k < SR ? *reinterpret_cast<const float4*>(feats + rowoff[q] + k)
+                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     fetch(0);
     for (int nblk = 0; nblk < Kp / 128; nblk++) {
@@ -1323,7 +1388,7 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_set(SoapDims d, cons
         for (int q = 0; q < 8; q++) {
             const int r = r0 + 8 * q, k = 128 * nblk + 4 * c4;
             const int at = rows[r];
-            if (at < 0 || k >= d.S) continue;
+            if (at < 0 || k >= SR) continue;
             float4 v = *reinterpret_cast<const float4*>(ot + r * lds_ld(128) + 4 * c4);
             if (d.layernorm) {
                 const float4 x = xcur[q];
@@ -1337,7 +1402,7 @@ __global__ __launch_bounds__(NTHREADS) void k_soap_tail_bwd_set(SoapDims d, cons
                 const float4 e = *reinterpret_cast<const float4*>(enc + (size_t)sp[at] * d.S + k);
                 v.x *= e.x; v.y *= e.y; v.z *= e.z; v.w *= e.w;
             }
-            *reinterpret_cast<float4*>(dF + (size_t)at * d.S + k) = v;
+            *reinterpret_cast<float4*>(dF + (size_t)at * SR + k) = v;
         }
     }
 }
@@ -1901,6 +1966,25 @@ static int soap_finalize(SoapModel& m, hipStream_t st) {
                 k_pack<<<cdiv(per, 256), 256, 0, st>>>(ws, 1, Kp, Kp, d.H, m.wall_bwd_set + sset * per);
             }
         }
+        if (d.ncmax <= 32 && d.Sp % 4 == 0) {  // packed power spectrum: the networks' first Linear over the upper-triangle layout
+            const int Kpp = (d.Sp + 127) / 128 * 128;
+            const size_t per = (size_t)(Kpp / 8) * 64, nw = (size_t)m.n_sets * d.H * Kpp;
+            if (!m.wallp || m.Kpp != Kpp) {
+                if ((rc = salloc(m, (void**)&m.wallp, nw * 4))) return rc;
+                if ((rc = salloc(m, (void**)&m.wallpb, nw * 4))) return rc;
+                if ((rc = salloc(m, (void**)&m.wallp_fwd_set, m.n_sets * per * sizeof(float4)))) return rc;
+                if ((rc = salloc(m, (void**)&m.wallp_bwd_set, m.n_sets * per * sizeof(float4)))) return rc;
+            }
+            m.Kpp = Kpp;
+            k_soap_prep_wallp<<<cdiv((int64_t)nw, 256), 256, 0, st>>>(d, m.sets, m.n_sets, Kpp, 0, m.wallp);
+            k_soap_prep_wallp<<<cdiv((int64_t)nw, 256), 256, 0, st>>>(d, m.sets, m.n_sets, Kpp, 1, m.wallpb);
+            for (int sset = 0; sset < m.n_sets; sset++) {
+                k_pack<<<cdiv(per, 256), 256, 0, st>>>(m.wallp + (size_t)sset * d.H * Kpp, Kpp, 1, d.H, Kpp,
+                                                        m.wallp_fwd_set + sset * per);
+                k_pack<<<cdiv(per, 256), 256, 0, st>>>(m.wallpb + (size_t)sset * d.H * Kpp, 1, Kpp, Kpp, d.H,
+                                                        m.wallp_bwd_set + sset * per);
+            }
+        }
         if (d.ncmax <= 32) {  // fused power-spectrum + tail kernels: W1 over the padded K layout, and its transpose
             const int Kp2 = d.kp_off[d.L + 1];
             const size_t n42 = (size_t)NOUTP * Kp2 / 4;
@@ -1933,6 +2017,22 @@ static int g_soap_sorted = 1;
 void set_soap_sorted(int v) { g_soap_sorted = v ? 1 : 0; }
 static bool soap_sorted_ok(const SoapModel& m) {
     return g_soap_sorted && g_soap_mfma && m.NT > 0 && m.wall_fwd_set != nullptr && m.n_sets <= SP_MAXSETS;
+}
+// pet_config_set("soap_packed", 0): the full [N][S] feature layout in inference too (the layout the training pass, the
+// feature output and the Alchemical centre encoding use)
+static int g_soap_packed = 1;
+void set_soap_packed(int v) { g_soap_packed = v ? 1 : 0; }
+static bool soap_packed_ok(const SoapModel& m) {
+    return g_soap_packed && g_soap_pair && g_soap_ps_mfma && m.enc == nullptr && m.wallp_fwd_set != nullptr &&
+           m.d.ncmax <= 32 && (size_t)(m.d.NCOEF + m.d.Sp) * 4 <= 64 * 1024;
+}
+static void soap_note_layout(const SoapModel& m, const void* ws, bool packed) {
+    if (m.ws_packed.size() > 64) m.ws_packed.clear();
+    m.ws_packed[ws] = packed;
+}
+static bool soap_ws_packed(const SoapModel& m, const void* ws) {
+    auto it = m.ws_packed.find(ws);
+    return it != m.ws_packed.end() && it->second;
 }
 static bool soap_fused_ok(const SoapModel& m) {
     return g_soap_fused && g_soap_mfma && m.NT > 0 && m.wall2_fwd != nullptr && m.d.ncmax <= 32 && m.d.L <= MAXL;
@@ -1974,6 +2074,8 @@ static int soap_fwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
                                                          m.species_w, w.Cf);
         }
     }
+    const bool packed = !soap_fused_ok(m) && soap_sorted_ok(m) && soap_packed_ok(m) && features == nullptr;
+    soap_note_layout(m, ws, packed);
     if (soap_fused_ok(m)) {
         ProfScope ps("soap_ps_tail", st, 2.0 * (double)N * d.S * (d.L + 1 + d.H), (double)N * d.NCOEF * 4);
         const int cld = soap_cld(d), grid = cdiv(N, BM);
@@ -1990,10 +2092,13 @@ static int soap_fwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
 #undef SOAP_FUSED_FWD
     } else {
     {
-            ProfScope ps("soap_ps", st, 2.0 * (double)N * d.S * (d.L + 1), (double)N * (d.NCOEF + d.S) * 4);
-            if (g_soap_pair && g_soap_ps_mfma && d.ncmax <= 32) {
-                allow_big_lds(k_soap_ps_m, (size_t)4 * d.NCOEF * 4);
-                k_soap_ps_m<<<cdiv(N, 4), 256, (size_t)4 * d.NCOEF * 4, st>>>(d, w.Cf, g.sp, m.enc, w.feats, w.tail, N);
+            ProfScope ps("soap_ps", st, 2.0 * (double)N * d.S * (d.L + 1), (double)N * (d.NCOEF + (packed ? d.Sp : d.S)) * 4);
+            if (packed) {
+                allow_big_lds(k_soap_ps_m<true>, (size_t)4 * d.NCOEF * 4);
+                k_soap_ps_m<true><<<cdiv(N, 4), 256, (size_t)4 * d.NCOEF * 4, st>>>(d, w.Cf, g.sp, nullptr, w.feats, w.tail, N);
+            } else if (g_soap_pair && g_soap_ps_mfma && d.ncmax <= 32) {
+                allow_big_lds(k_soap_ps_m<false>, (size_t)4 * d.NCOEF * 4);
+                k_soap_ps_m<false><<<cdiv(N, 4), 256, (size_t)4 * d.NCOEF * 4, st>>>(d, w.Cf, g.sp, m.enc, w.feats, w.tail, N);
             } else if (g_soap_pair && d.ncmax < 128 && d.NCOEF < 65536) {
                 allow_big_lds(k_soap_ps_w, (size_t)4 * d.NCOEF * 4);
                 k_soap_ps_w<<<cdiv(N, 4), 256, (size_t)4 * d.NCOEF * 4, st>>>(d, w.Cf, g.sp, m.enc, m.feat_lut, w.feats,
@@ -2003,16 +2108,18 @@ static int soap_fwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
             }
         }
         {
-            ProfScope ps("soap_tail", st, 2.0 * (double)N * d.S * d.H, (double)N * d.S * 4);
+            ProfScope ps("soap_tail", st, 2.0 * (double)N * d.S * d.H, (double)N * (packed ? d.Sp : d.S) * 4);
             if (soap_sorted_ok(m)) {
                 PET_HIP_CHECK(hipMemsetAsync(w.info, 0, sizeof(SpInfo), st));
                 k_sp_count<<<cdiv(N, 256), 256, 0, st>>>(g.sp, d.legacy, N, w.info);
                 k_sp_scan<<<1, 1, 0, st>>>(m.n_sets, w.info);
                 k_sp_fill<<<cdiv(N, 1024), 1024, 0, st>>>(g.sp, d.legacy, N, w.info, w.perm);
                 const size_t lds = ((size_t)BM * lds_ld(128) + BM * 32 + BM) * 4;
+                SoapDims dt = d;
+                if (packed) dt.S = d.Sp;  // (the kernel uses S as the row pitch / length of the feature rows only)
                 k_soap_tail_fwd_set<<<cdiv(N, BM) + m.n_sets, NTHREADS, lds, st>>>(
-                    d, w.feats, w.perm, w.info, m.n_sets, m.sets, m.wall_fwd_set, m.Kp, m.wall_rs, m.wall_b, w.tail,
-                    atomic);
+                    dt, w.feats, w.perm, w.info, m.n_sets, m.sets, packed ? m.wallp_fwd_set : m.wall_fwd_set,
+                    packed ? m.Kpp : m.Kp, m.wall_rs, m.wall_b, w.tail, atomic);
             } else if (m.NT > 0 && g_soap_mfma) {
                 const int NOUTP = m.NOUTP, lda = lds_ld(128);
                 const size_t lds = ((size_t)BM * (NOUTP + 1 > lda ? NOUTP + 1 : lda) + BM * 32) * 4;
@@ -2056,6 +2163,10 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
         k_soap_tail_extra_bwd<<<cdiv(N, 4), 256, 0, st>>>(d, g.sp, m.sets, w.tail, w.tail_ext, gA, w.da2, N);
         da2x = w.da2;
     }
+    const bool packed = soap_ws_packed(m, ws);  // what the forward into this workspace stored
+    PET_REQUIRE(!packed || (soap_sorted_ok(m) && soap_packed_ok(m) && !soap_fused_ok(m)), PET_ERR_ARGUMENT,
+                "the forward of this workspace stored the packed power spectrum but the adjoint is configured for the full "
+                "layout: pet_config_set changed between soap_forward and soap_backward");
     if (soap_fused_ok(m)) {
         ProfScope ps("soap_ps_tail_bwd", st, 4.0 * (double)N * d.S * (d.L + 1 + d.H), (double)N * d.NCOEF * 8);
         const int cld = soap_cld(d), grid = cdiv(N, BMB);
@@ -2072,12 +2183,12 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
 #undef SOAP_FUSED_BWD
     } else {
     {
-        ProfScope ps("soap_tail_bwd", st, 2.0 * (double)N * d.S * d.H, (double)N * d.S * 8);
+        ProfScope ps("soap_tail_bwd", st, 2.0 * (double)N * d.S * d.H, (double)N * (packed ? d.Sp : d.S) * 8);
         if (soap_sorted_ok(m)) {  // perm / info were filled by the forward pass on this workspace
             const size_t lds = ((size_t)BM * lds_ld(32) + BM * 32 + BM * 4 + BM * lds_ld(128) + BM) * 4;
             k_soap_tail_bwd_set<<<cdiv(N, BM) + m.n_sets, NTHREADS, lds, st>>>(
-                d, w.feats, w.perm, w.info, m.n_sets, g.sp, m.sets, m.wall_bwd_set, m.Kp, m.wall_rs, m.wall_b, m.enc,
-                w.tail, gA, w.dF, da2x);
+                d, w.feats, w.perm, w.info, m.n_sets, g.sp, m.sets, packed ? m.wallp_bwd_set : m.wall_bwd_set,
+                packed ? m.Kpp : m.Kp, m.wall_rs, m.wall_b, m.enc, w.tail, gA, w.dF, da2x, packed ? 1 : 0);
         } else if (m.NT > 0 && g_soap_mfma) {
             const size_t lds = ((size_t)BM * lds_ld(m.NOUTP) + BM * 32 + BM * 4 + BM * lds_ld(128)) * 4;
             const int grid = cdiv(N, BM);
@@ -2095,9 +2206,11 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
         }
     }
     {
-        ProfScope ps("soap_ps_bwd", st, 4.0 * (double)N * d.S * (d.L + 1), (double)N * (2 * d.NCOEF + d.S) * 4);
-        if (g_soap_pair && g_soap_ps_mfma && d.S % 4 == 0 && (size_t)(d.NCOEF + d.S) * 4 <= 64 * 1024) {
-            k_soap_ps_bwd_m<<<N, 256, (size_t)(d.NCOEF + d.S) * 4, st>>>(d, w.Cf, w.dF, w.dCf);
+        ProfScope ps("soap_ps_bwd", st, 4.0 * (double)N * d.S * (d.L + 1), (double)N * (2 * d.NCOEF + (packed ? d.Sp : d.S)) * 4);
+        if (packed) {
+            k_soap_ps_bwd_m<true><<<N, 256, (size_t)(d.NCOEF + d.Sp) * 4, st>>>(d, w.Cf, w.dF, w.dCf);
+        } else if (g_soap_pair && g_soap_ps_mfma && d.S % 4 == 0 && (size_t)(d.NCOEF + d.S) * 4 <= 64 * 1024) {
+            k_soap_ps_bwd_m<false><<<N, 256, (size_t)(d.NCOEF + d.S) * 4, st>>>(d, w.Cf, w.dF, w.dCf);
         } else if (g_soap_pair && d.S % 4 == 0 && d.NCOEF < 65536 && (size_t)(d.NCOEF + d.S) * 4 <= 64 * 1024) {
             k_soap_ps_bwd_s<<<N, 256, (size_t)(d.NCOEF + d.S) * 4, st>>>(d, w.Cf, w.dF, m.out_lut, w.dCf);
         } else {
@@ -2168,16 +2281,18 @@ int soap_model_create(const soap_hypers_t* h, soap_model_t** out) {
     d.L = h->max_angular; d.C = h->n_channels; d.ns = h->n_species; d.legacy = h->legacy; d.layernorm = h->layernorm;
     d.H = h->num_neurons_per_layer; d.NH = h->num_hidden_layers; d.rc = h->cutoff; d.width = h->cutoff_width;
     d.NLM = (d.L + 1) * (d.L + 1);
-    int f = 0, co = 0, fo = 0, items = 0;
+    int f = 0, co = 0, fo = 0, items = 0, pfo = 0;
     for (int l = 0; l <= d.L; l++) {
         const int n = h->n_per_l[l];
         if (n < 0 || n > 64) { delete sm; set_error("bad n_per_l"); return PET_ERR_ARGUMENT; }
         d.n_per_l[l] = n; d.rad_off[l] = f; d.coef_off[l] = co; d.feat_off[l] = fo;
         d.kp_off[l] = l == 0 ? 0 : d.kp_off[l - 1] + (d.n_per_l[l - 1] * d.C + 7) / 8 * 8 * 32;
         if (n * d.C > d.ncmax) d.ncmax = n * d.C;
+        d.pfeat_off[l] = pfo;
         f += n; co += (2 * l + 1) * n * d.C; fo += (n * d.C) * (n * d.C); items += (2 * l + 1) * n;
+        pfo += (n * d.C) * (n * d.C + 1) / 2;
     }
-    d.coef_off[d.L + 1] = co; d.feat_off[d.L + 1] = fo;
+    d.coef_off[d.L + 1] = co; d.feat_off[d.L + 1] = fo; d.pfeat_off[d.L + 1] = pfo; d.Sp = pfo;
     d.kp_off[d.L + 1] = d.kp_off[d.L] + (d.n_per_l[d.L] * d.C + 7) / 8 * 8 * 32;
     d.F = f; d.NCOEF = co; d.S = fo; d.ITEMS = items;
     m.n_sets = h->legacy ? h->n_species : 1;

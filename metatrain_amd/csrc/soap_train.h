@@ -705,6 +705,12 @@ static int soap_train_grads(SoapModel& m, const Graph& g, void* ws, int64_t ws_b
     PET_REQUIRE((int64_t)t.bytes <= tws_bytes, PET_ERR_ARGUMENT, "soap training workspace too small");
     const int N = (int)g.n_nodes;
     if (N == 0) return PET_OK;
+    if (soap_ws_packed(m, ws)) {  // the inference forward stored the packed power spectrum: this pass reads the full layout,
+        // rebuilt from the expansion coefficients the same forward left in the workspace (the LayerNorm statistics stay)
+        allow_big_lds(k_soap_ps_m<false>, (size_t)4 * d.NCOEF * 4);
+        k_soap_ps_m<false><<<cdiv(N, 4), 256, (size_t)4 * d.NCOEF * 4, st>>>(d, w.Cf, g.sp, m.enc, w.feats, w.tail, N);
+        soap_note_layout(m, ws, false);
+    }
     const bool tangent = u != nullptr && g.n_edges > 0;
     if (!tangent && !d.legacy) {   // the front-of-the-tail pass reads the tangents: zeros for an energy-only loss
         PET_HIP_CHECK(hipMemsetAsync(t.vd, 0, (size_t)(g.n_edges > 0 ? g.n_edges : 1) * sizeof(float4), st));

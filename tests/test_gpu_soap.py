@@ -362,3 +362,91 @@ def test_power_spectrum_features_against_the_reference_module(legacy):
         table[torch.tensor(types)] = torch.arange(4)
         ref = ref * params["center_encoding.weight"].double().numpy()[table[z.long()].numpy()]
     assert _relmax(feats.cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("layernorm,layers", [(True, 2), (False, 2), (True, 1), (True, 4)])
+def test_packed_power_spectrum_layout_against_the_full_layout_and_the_oracle(layernorm, layers):
+    """Round 6: p_l[a][b] = p_l[b][a], so an inference step of the legacy (per-species networks) model stores the upper
+    triangle of every l block only (2 360 floats per atom instead of 4 544), with the LayerNorm statistics weighted and the
+    first Linear folded accordingly (``soap.hip k_soap_prep_wallp``). Per-atom energies and dE/dR -- incl. dE/dcell -- against
+    the fp64 oracle at the 1e-5 bar and against the full layout (``pet_config_set("soap_packed", 0)``); seed linearity of the
+    packed adjoint; an Alchemical model (per-feature centre encoding) keeps the full layout and is unaffected by the switch."""
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.soap_bpnn import SoapBpnnHip
+
+    dev = torch.device("cuda:0")
+    types = [1, 6, 7, 8]
+    hypers = dict(osoap.DEFAULT_HYPERS, legacy=True)
+    hypers["bpnn"] = dict(hypers["bpnn"], layernorm=layernorm, num_hidden_layers=layers)
+    n_per_l = osoap.basis(hypers)[0]
+    params = osoap.synthetic_params(hypers, 4, n_per_l, 0, torch.float32)
+    gen = torch.Generator().manual_seed(3)
+    for k in params:  # random LayerNorm weights / biases: the folding W' = gamma_ab W_ab + gamma_ba W_ba must be exercised
+        if k.startswith("layernorm."):
+            params[k] = params[k] + 0.3 * torch.randn(params[k].shape, generator=gen)
+    pos, z, cells, ci, cj, cs, sysidx = _box(200, seed=9)
+    p64 = {k: v.double() for k, v in params.items()}
+    w = torch.rand(200, generator=gen, dtype=torch.float64) + 0.5
+    r = pos.clone().requires_grad_(True)
+    c64 = cells.clone().requires_grad_(True)
+    a_ref = osoap.soap_bpnn_atomic_energies(p64, hypers, types, r, c64, ci, cj, cs, z, sysidx)
+    g_ref, gc_ref = torch.autograd.grad((a_ref * w).sum(), [r, c64])
+
+    model = SoapBpnnHip(hypers, types)
+    model.load({k: v.to(dev) for k, v in params.items()})
+    g = model.graph(pos.float().to(dev), cells.float().to(dev), ci.to(dev), cj.to(dev), cs.to(dev), z.to(dev),
+                    sysidx.int().to(dev))
+    out = {}
+    try:
+        for mode in (1, 0):
+            rt.config_set("soap_packed", mode)
+            atomic = model.forward(g)
+            grad, gcell = model.backward(g, w.float().to(dev), want_cell_grad=True)
+            out[mode] = (atomic.cpu().numpy(), grad.cpu().numpy(), gcell.cpu().numpy())
+            if mode == 1:
+                g2 = model.backward(g, (0.25 * w).float().to(dev)) + model.backward(g, (0.75 * w).float().to(dev))
+                np.testing.assert_allclose(g2.cpu().numpy(), out[1][1], atol=2e-6 * float(np.abs(out[1][1]).max()))
+                assert torch.equal(model.forward(g), atomic)  # run-to-run bit identity
+    finally:
+        rt.config_set("soap_packed", 1)
+    for mode in (1, 0):
+        assert _relmax(out[mode][0], a_ref.detach().numpy()) < TOL
+        assert _relmax(out[mode][1], g_ref.numpy()) < TOL
+        assert _relmax(out[mode][2], gc_ref.numpy()) < TOL
+    assert _relmax(out[1][0], out[0][0]) < 2e-6 and _relmax(out[1][1], out[0][1]) < 4e-6
+
+
+def test_training_gradients_after_a_packed_forward():
+    """``soap_train_gradients`` reads the FULL power spectrum of the workspace ``soap_forward`` ran on; after a packed inference
+    forward it rebuilds that layout from the stored expansion coefficients. Parameter gradients and the force tangent are the
+    ones of a full-layout forward, and a ``soap_backward`` behind the training pass follows the rebuilt layout."""
+    from metatrain_amd import runtime as rt
+    from metatrain_amd.soap_bpnn import SoapBpnnHip
+
+    dev = torch.device("cuda:0")
+    types = [1, 6, 7, 8]
+    hypers = dict(osoap.DEFAULT_HYPERS, legacy=True)
+    params = osoap.synthetic_params(hypers, 4, osoap.basis(hypers)[0], 0, torch.float32)
+    pos, z, cells, ci, cj, cs, sysidx = _box(120, seed=4)
+    gen = torch.Generator().manual_seed(8)
+    gA = (torch.rand(120, generator=gen) + 0.5).to(dev)
+    u = (torch.randn(120, 3, generator=gen) * 0.1).to(dev)
+    res = {}
+    try:
+        for mode in (1, 0):
+            rt.config_set("soap_packed", mode)
+            model = SoapBpnnHip(hypers, types)
+            model.load({k: v.to(dev) for k, v in params.items()})
+            g = model.graph(pos.float().to(dev), cells.float().to(dev), ci.to(dev), cj.to(dev), cs.to(dev), z.to(dev),
+                            sysidx.int().to(dev))
+            model.forward(g)
+            model.zero_grad()
+            tangent = model.train_gradients(g, gA, u)
+            grad_after = model.backward(g, gA)
+            res[mode] = ({k: v.cpu().numpy() for k, v in model.grads().items()}, tangent.cpu().numpy(),
+                         grad_after.cpu().numpy())
+    finally:
+        rt.config_set("soap_packed", 1)
+    for k in res[0][0]:
+        assert _relmax(res[1][0][k], res[0][0][k]) < 2e-6, k
+    assert _relmax(res[1][1], res[0][1]) < 2e-6 and _relmax(res[1][2], res[0][2]) < 2e-6
