@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="with --partition on ONE GPU: time every rank's share of a W-rank partition one after the other "
                          "and report the busiest rank (a W-GPU step without its 1.2 MB all-reduce)")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=INT",
+                    help="library switch for A/B runs (pet_config_set), e.g. --set soap_packed=0")
     args = ap.parse_args()
 
     from metatrain_amd import distributed as pdist
@@ -117,6 +119,8 @@ def main():
     from metatrain_amd.soap_bpnn import SoapBpnnHip, default_hypers
     from metatrain_amd.synthetic import random_box
 
+    for kv in args.set:
+        rt.config_set(kv.split("=")[0], int(kv.split("=")[1]))
     hypers = default_hypers()
     hypers["legacy"] = not args.alchemical
     model = SoapBpnnHip(hypers, [1, 6, 7, 8])

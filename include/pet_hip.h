@@ -439,7 +439,10 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *   (removed in round 4 with the kernels they selected: "emlp_pipe", "emlp_bwd_pipe", "comb_pipe", "comb_bwd_pipe",
  *   "emlp_recompute", "line_stores", "lds_w")
  *   "soap_mfma"   1 = SOAP-BPNN LayerNorm + MLP tail on MFMA (default)
- *   "soap_fused"  1 = SOAP power spectrum + LayerNorm + first Linear in one kernel, features never stored (default 0: slower, saves memory)
+ *   "soap_packed" 1 = SOAP-BPNN inference (legacy / per-species networks) stores the upper triangle of every power-spectrum block
+ *                 only (p_l[a][b] = p_l[b][a]: 2 360 instead of 4 544 floats per atom for the default basis), LayerNorm statistics
+ *                 weighted and the first Linear folded accordingly -- default; 0 = the full [N][S] layout (what the feature output,
+ *                 the Alchemical centre encoding and the training pass use in any case)
  *   "soap_sorted" 1 = SOAP-BPNN tail GEMM on species-sorted atom tiles, one network per tile (default)
  *   "soap_pair"   1 = SOAP expansion one wave per atom, its adjoint one lane per pair (default); 0 = first generation
  * Unknown keys return PET_ERR_ARGUMENT. */

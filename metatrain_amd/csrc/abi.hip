@@ -981,7 +981,6 @@ int pet_config_set(const char* key, int value) {
     else if (k == "trr") set_use_trr(value);
     else if (k == "soap_mfma") set_soap_mfma(value);
     else if (k == "soap_pair") set_soap_pair(value);
-    else if (k == "soap_fused") set_soap_fused(value);
     else if (k == "soap_packed") set_soap_packed(value);
     else if (k == "soap_ps_mfma") set_soap_ps_mfma(value);
     else if (k == "soap_sorted") set_soap_sorted(value);

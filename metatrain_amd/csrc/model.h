@@ -253,7 +253,6 @@ void set_attn_lds(int v);   // pet_attn.hip: 1 = LDS-staged attention (default),
 void set_soap_mfma(int v);  // soap.hip: 1 = MFMA tail (default), 0 = per-atom tail kernels
 void set_soap_ps_mfma(int v);  // soap.hip: 1 = power spectrum and its adjoint on the fp32 matrix core (default)
 void set_soap_packed(int v); // soap.hip: 1 = inference stores the upper triangle of every power-spectrum block only (default)
-void set_soap_fused(int v);  // soap.hip: 1 = power spectrum + LayerNorm + first Linear fused, features never stored (default 0)
 bool use_tile_f16x3();
 void set_tile_f16x3(int v);
 void set_trr_compress(int v);

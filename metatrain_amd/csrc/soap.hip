@@ -41,7 +41,6 @@ constexpr int PC = 32;  // pairs per LDS chunk
 struct SoapDims {
     int L, C, F, NLM, NCOEF, ITEMS, S, H, NH, ns, legacy, layernorm, n_grid;
     int n_per_l[MAXL + 1], rad_off[MAXL + 1], coef_off[MAXL + 2], feat_off[MAXL + 2];
-    int kp_off[MAXL + 2];  // fused ps+tail kernels: feature (l, a, b) sits at K index kp_off[l] + 32 a + b
     int ncmax;             // largest n_per_l[l] * C
     // packed power spectrum (round 6): p_l[a][b] = p_l[b][a], so the inference path stores the upper triangle a <= b of every
     // l block only -- Sp = sum_l nc (nc + 1) / 2 floats per atom instead of S = sum_l nc^2 (2 360 against 4 544 for the default
@@ -82,11 +81,6 @@ struct SoapModel {
     float4 *wall_fwd = nullptr, *wall_bwd = nullptr;
     float *wall_rs = nullptr, *wall_b = nullptr;  // [NOUTP] row sums, W1 beta
     float4 *wall_fwd_set = nullptr, *wall_bwd_set = nullptr;  // per network: [n_sets][1][Kp/8][64], [n_sets][Kp/32][4][64]
-    // fused power-spectrum + tail kernels: the same matrix over the padded K layout (SoapDims::kp_off), and its
-    // (a, b) <-> (b, a) transpose for the symmetrised power-spectrum adjoint
-    int Kp2 = 0;
-    float *wall2 = nullptr, *wall2t = nullptr;
-    float4 *wall2_fwd = nullptr, *wall2_bwd = nullptr, *wall2t_bwd = nullptr;
     // packed power spectrum (SoapDims::Sp): the first Linear of every network over the upper-triangle layout,
     // W'[j][(a, b)] = gamma W1[j][(a, b)] + gamma W1[j][(b, a)] (a < b), for the adjoint with the diagonal doubled
     int Kpp = 0;
@@ -778,320 +772,11 @@ __global__ __launch_bounds__(256) void k_soap_ps_bwd_m(SoapDims d, const float* 
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// a17 + a18 fused: power spectrum, LayerNorm and the first Linear in one kernel, and their adjoints in another.
-// The feature tensor ([N][S], 1.8 GB at 100 k atoms) is never written: a workgroup holds the expansion
-// coefficients of its atoms for one l in LDS, forms 4 (forward) / 8 (adjoint) rows a of p_l[a][b] = sum_m c[m][a]
-// c[m][b] at a time as the A tile of the MFMA GEMM against W1 (K laid out as kp_off[l] + 32 a + b, zero weights in
-// the padding), and accumulates the LayerNorm statistics on the way (fp64 sums). The adjoint needs dF[a][b] AND
-// dF[b][a] for dC[m][a] = sum_b (dF[a][b] + dF[b][a]) c[m][b]; it gets the second one from a GEMM against the
-// (a, b) <-> (b, a) transposed copy of W1, so that the thread that owns (atom, a) sums over b in registers:
-// no scatter, no atomics, bit-deterministic. The LayerNorm reductions of the adjoint come from the saved a1
-// (sum_f dy_f xhat_f = sum_j da1_j (a1_j - b_j)), as in k_soap_tail_bwd_mfma.
-// ---------------------------------------------------------------------------------------------
-// Measured on the 100 k-atom bench (legacy, four stacked per-species networks): fused forward 4.3 ms against
-// 2.0 + 1.6 for k_soap_ps + k_soap_tail_fwd_mfma, fused adjoint 7.0 ms against 2.2 + 1.3. The GEMM is the same 118
-// GFLOP of fp32 MFMA either way (+35 % K padding here, and twice in the adjoint), and with the feature formation in
-// the same one-wave-per-SIMD workgroup nothing overlaps it. So this path is OFF by default
-// (pet_config_set("soap_fused", 1) selects it; parity-tested); it wins memory (no [N][S] tensors), not time.
-static int g_soap_fused = 0;
-void set_soap_fused(int v) { g_soap_fused = v ? 1 : 0; }
+// (The first-generation fused power-spectrum + tail kernels -- k_soap_ps_tail_fwd / _bwd behind pet_config_set("soap_fused", 1):
+// features never stored, but 4.3 + 7.0 ms against 0.5 + 0.6 + 0.9 + 0.7 for the separate kernels -- were removed in round 6:
+// the packed power spectrum halves the feature traffic at no cost in time.)
 static int g_soap_ps_mfma = 1;  // pet_config_set("soap_ps_mfma", 0): the power spectrum (and its adjoint) on the VALU kernels
 void set_soap_ps_mfma(int v) { g_soap_ps_mfma = v ? 1 : 0; }
-
-__global__ void k_soap_prep_wall2(SoapDims d, const SoapSet* __restrict__ sets, int n_sets, int NOUTP, int Kp2,
-                                  int transpose, float* __restrict__ wall2) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)NOUTP * Kp2) return;
-    const int o = (int)(idx / Kp2), kp = (int)(idx % Kp2);
-    int l = 0;
-    while (kp >= d.kp_off[l + 1]) l++;
-    const int q = kp - d.kp_off[l], a = q >> 5, b = q & 31, nc = d.n_per_l[l] * d.C;
-    float v = 0.f;
-    if (o < n_sets * d.H && a < nc && b < nc) {
-        const SoapSet W = sets[o / d.H];
-        const int k = d.feat_off[l] + (transpose ? b * nc + a : a * nc + b);
-        v = W.W1[(size_t)(o % d.H) * d.S + k];
-        if (d.layernorm) v *= W.ln_w[k];
-    }
-    wall2[idx] = v;
-}
-
-// p[b] = sum_m c[m][a] c[m][b] for one (atom, a): M = 2l + 1 unrolled, c[.][a] in registers
-template <int M>
-__device__ __forceinline__ void ps_row_fwd(const float* __restrict__ crow, int nc, int a, const float* __restrict__ e,
-                                           float* __restrict__ arow, double& s1, double& s2,
-                                           float* __restrict__ fout) {
-    float ca[M];
-#pragma unroll
-    for (int m = 0; m < M; m++) ca[m] = crow[m * nc + a];
-    for (int b = 0; b < 32; b++) {
-        float v = 0.f;
-        if (b < nc) {
-#pragma unroll
-            for (int m = 0; m < M; m++) v += ca[m] * crow[m * nc + b];
-            if (e) v *= e[a * nc + b];
-            s1 += (double)v;
-            s2 += (double)v * (double)v;
-            if (fout) fout[a * nc + b] = v;
-        }
-        arow[b] = v;
-    }
-}
-
-template <int NT>
-__global__ __launch_bounds__(NTHREADS) void k_soap_ps_tail_fwd(SoapDims d, int cld, const float* __restrict__ Cf,
-                                                               const int* __restrict__ sp,
-                                                               const float* __restrict__ enc,
-                                                               const SoapSet* __restrict__ sets,
-                                                               const float4* __restrict__ Wp2, int Kp2,
-                                                               const float* __restrict__ rs,
-                                                               const float* __restrict__ bs, float* __restrict__ tail,
-                                                               float* __restrict__ atomic, float* __restrict__ feats,
-                                                               int N) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NOUTP = 64 * NT, LDO = NOUTP + 1, LDA = lds_ld(128);
-    float* As = smem;                                   // [64][132] A tile, later out [64][NOUTP + 1]
-    float* out = smem;
-    float* a1s = As + BM * (LDO > LDA ? LDO : LDA);     // [64][32] silu(a1)
-    double* stat = reinterpret_cast<double*>(a1s + BM * 32);  // [4][64][2] partial sums, then [64][2] mean / rstd
-    float* Cs = reinterpret_cast<float*>(stat + 4 * BM * 2);  // [64][cld] coefficients of the current l
-    const WaveId w;
-    const int row0 = blockIdx.x * BM;
-    const int r = threadIdx.x & 63, as = threadIdx.x >> 6, atom = row0 + r;
-    const bool live = atom < N;
-    f32x16 acc[NT];
-    acc_fill_bias<NT>(acc, nullptr, 0, w.lane);
-    double s1 = 0.0, s2 = 0.0;
-    for (int l = 0; l <= d.L; l++) {
-        const int nc = d.n_per_l[l] * d.C, clw = (2 * l + 1) * nc;
-        __syncthreads();
-        for (int rr = w.wave; rr < BM; rr += 4)
-            for (int c = w.lane; c < clw; c += 64)
-                Cs[rr * cld + c] = row0 + rr < N ? Cf[(size_t)(row0 + rr) * d.NCOEF + d.coef_off[l] + c] : 0.f;
-        __syncthreads();
-        const float* crow = Cs + r * cld;
-        const float* e = enc && live ? enc + (size_t)sp[atom] * d.S + d.feat_off[l] : nullptr;
-        float* fo = feats && live ? feats + (size_t)atom * d.S + d.feat_off[l] : nullptr;
-        const int nchunk = (nc + 7) / 8 * 2;  // chunks of 4 rows a (128 K columns); blocks are padded to 8 rows
-        for (int kc = 0; kc < nchunk; kc++) {
-            const int a = 4 * kc + as;
-            float* arow = As + r * LDA + 32 * as;
-            if (a < nc) {
-                switch (l) {
-#define PS_CASE(LV) case LV: ps_row_fwd<2 * LV + 1>(crow, nc, a, e, arow, s1, s2, fo); break;
-                    PS_CASE(0) PS_CASE(1) PS_CASE(2) PS_CASE(3) PS_CASE(4) PS_CASE(5) PS_CASE(6) PS_CASE(7) PS_CASE(8)
-#undef PS_CASE
-                }
-            } else {
-                for (int b = 0; b < 32; b++) arow[b] = 0.f;
-            }
-            __syncthreads();
-            gemm_acc<128, NT>(As + w.rb * 32 * LDA, LDA, Wp2, Kp2 / 8, (d.kp_off[l] + 128 * kc) / 8, NT * w.ch, acc,
-                              w.lane);
-            __syncthreads();
-        }
-    }
-    // LayerNorm statistics: partial sums of the four a-slots of a row
-    stat[(as * BM + r) * 2] = s1;
-    stat[(as * BM + r) * 2 + 1] = s2;
-    __syncthreads();
-    const int H = 32, TS = 2 + 2 * H;
-    if (threadIdx.x < BM) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int q = 0; q < 4; q++) { t1 += stat[(q * BM + r) * 2]; t2 += stat[(q * BM + r) * 2 + 1]; }
-        const double mean = t1 / d.S, var = t2 / d.S - mean * mean;
-        const float mu = d.layernorm ? (float)mean : 0.f;
-        const float rstd = d.layernorm ? (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + 1e-5)) : 1.f;
-        a1s[r] = mu;       // borrowed until the a1 pass below overwrites it
-        a1s[BM + r] = rstd;
-        if (live && d.layernorm) {
-            tail[(size_t)atom * TS] = mu;
-            tail[(size_t)atom * TS + 1] = rstd;
-        }
-    }
-    acc_foreach<NT>(acc, w.rb, 32 * NT * w.ch, w.lane, [&](int rr, int c, float v) { out[rr * LDO + c] = v; });
-    __syncthreads();
-    float a1v[BM * H / NTHREADS];
-#pragma unroll
-    for (int it = 0; it < BM * H / NTHREADS; it++) {
-        const int item = threadIdx.x + it * NTHREADS;
-        const int rr = item >> 5, j = item & 31, at = row0 + rr;
-        float a1 = 0.f;
-        if (at < N) {
-            const int sidx = d.legacy ? sp[at] : 0;
-            a1 = a1s[BM + rr] * (out[rr * LDO + sidx * H + j] - a1s[rr] * rs[sidx * H + j]) + bs[sidx * H + j];
-            tail[(size_t)at * TS + 2 + j] = a1;
-        }
-        a1v[it] = a1;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < BM * H / NTHREADS; it++) {
-        const int item = threadIdx.x + it * NTHREADS;
-        a1s[(item >> 5) * H + (item & 31)] = silu(a1v[it]);
-    }
-    __syncthreads();
-    for (int item = threadIdx.x; item < BM * H; item += NTHREADS) {
-        const int rr = item >> 5, j = item & 31, at = row0 + rr;
-        float e = 0.f;
-        if (at < N) {
-            const SoapSet W = sets[d.legacy ? sp[at] : 0];
-            if (d.NH > 1) {
-                float a2 = 0.f;
-                for (int q = 0; q < H; q++) a2 += W.W2[j * H + q] * a1s[rr * H + q];
-                tail[(size_t)at * TS + 2 + H + j] = a2;
-                e = W.w3[j] * silu(a2);
-            } else {
-                e = W.w3[j] * a1s[rr * H + j];
-            }
-        }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) e += __shfl_xor(e, o);
-        if (j == 0 && at < N) atomic[at] = e;
-    }
-}
-
-// one (atom, a) of the adjoint: accm[m] += dF(a, b) c[m][b] over b, dF from the staged GEMM output `orow`
-template <int M>
-__device__ __forceinline__ void ps_row_bwd(const float* __restrict__ crow, int nc, int a, const float* __restrict__ e,
-                                           bool transposed, const float* __restrict__ orow, bool layernorm, float mu,
-                                           float rstd, float m1, float m2, float (&accm)[2 * MAXL + 1]) {
-    float ca[M];
-#pragma unroll
-    for (int m = 0; m < M; m++) ca[m] = crow[m * nc + a];
-    for (int b = 0; b < nc; b++) {
-        float cb[M], p = 0.f;
-#pragma unroll
-        for (int m = 0; m < M; m++) { cb[m] = crow[m * nc + b]; p += ca[m] * cb[m]; }
-        const float ee = e ? (transposed ? e[b * nc + a] : e[a * nc + b]) : 1.f;
-        float v = orow[b];
-        if (layernorm) v = rstd * (v - m1 - (p * ee - mu) * rstd * m2);
-        v *= ee;
-#pragma unroll
-        for (int m = 0; m < M; m++) accm[m] += v * cb[m];
-    }
-}
-
-constexpr int BMB = 32;  // atoms per workgroup in the fused adjoint
-template <int NT>
-__global__ __launch_bounds__(NTHREADS) void k_soap_ps_tail_bwd(SoapDims d, int cld, const float* __restrict__ Cf,
-                                                               const int* __restrict__ sp,
-                                                               const SoapSet* __restrict__ sets,
-                                                               const float4* __restrict__ Wpb2,
-                                                               const float4* __restrict__ Wpb2t,
-                                                               const float* __restrict__ rs,
-                                                               const float* __restrict__ bs,
-                                                               const float* __restrict__ enc,
-                                                               const float* __restrict__ tail,
-                                                               const float* __restrict__ gA, float* __restrict__ dCf,
-                                                               int N, const float* __restrict__ da2x) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NOUTP = 64 * NT, LDD = lds_ld(NOUTP), LDT = lds_ld(256);
-    float* Ds = smem;                 // [32][NOUTP + 4] d a1, zero outside the atom's own set
-    float* d2 = Ds + BMB * LDD;       // [32][32] d a2
-    float* st = d2 + BMB * 32;        // [32][4] mean, rstd, m1, m2
-    float* ot = st + BMB * 4;         // [32][260] GEMM output of the current chunk
-    float* Cs = ot + BMB * LDT;       // [32][cld] coefficients of the current l
-    float* dCs = Cs + BMB * cld;      // [32][cld] their gradients
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int row0 = blockIdx.x * BMB;
-    const int H = 32, TS = 2 + 2 * H;
-    for (int idx = threadIdx.x; idx < BMB * LDD; idx += NTHREADS) Ds[idx] = 0.f;
-    for (int item = threadIdx.x; item < BMB * H; item += NTHREADS) {
-        const int rr = item >> 5, j = item & 31, at = row0 + rr;
-        float v = 0.f;
-        if (at < N && d.NH > 1) {
-            const SoapSet W = sets[d.legacy ? sp[at] : 0];
-            v = da2x ? da2x[(size_t)at * H + j] : gA[at] * W.w3[j] * dsilu(tail[(size_t)at * TS + 2 + H + j]);
-        }
-        d2[rr * H + j] = v;
-    }
-    __syncthreads();
-    for (int item = threadIdx.x; item < BMB * H; item += NTHREADS) {
-        const int rr = item >> 5, j = item & 31, at = row0 + rr;
-        float da1 = 0.f, t1 = 0.f, t2 = 0.f;
-        float mu = 0.f, rstd = 1.f;
-        if (at < N) {
-            const int sidx = d.legacy ? sp[at] : 0;
-            const SoapSet W = sets[sidx];
-            const float a1 = tail[(size_t)at * TS + 2 + j];
-            if (d.NH > 1) {
-                float acc = 0.f;
-                for (int q = 0; q < H; q++) acc += W.W2[q * H + j] * d2[rr * H + q];
-                da1 = acc * dsilu(a1);
-            } else {
-                da1 = gA[at] * W.w3[j] * dsilu(a1);
-            }
-            Ds[rr * LDD + sidx * H + j] = da1;
-            if (d.layernorm) {
-                mu = tail[(size_t)at * TS];
-                rstd = tail[(size_t)at * TS + 1];
-                const float rsj = rs[sidx * H + j];
-                const float raw = (a1 - bs[sidx * H + j]) / rstd + mu * rsj;  // Wall_s[j] . x
-                t1 = da1 * rsj;
-                t2 = da1 * raw;
-            }
-        }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
-        if (j == 0) {
-            st[rr * 4] = mu; st[rr * 4 + 1] = rstd;
-            st[rr * 4 + 2] = t1 / d.S;                        // m1 = mean(dxn gamma)
-            st[rr * 4 + 3] = rstd * (t2 - mu * t1) / d.S;     // m2 = mean(dxn gamma xhat)
-        }
-    }
-    const int r = threadIdx.x & 31, as = threadIdx.x >> 5, atom = row0 + r;
-    const bool live = atom < N;
-    for (int l = 0; l <= d.L; l++) {
-        const int nc = d.n_per_l[l] * d.C, clw = (2 * l + 1) * nc;
-        __syncthreads();
-        for (int rr = wave; rr < BMB; rr += 4)
-            for (int c = lane; c < clw; c += 64)
-                Cs[rr * cld + c] = row0 + rr < N ? Cf[(size_t)(row0 + rr) * d.NCOEF + d.coef_off[l] + c] : 0.f;
-        __syncthreads();
-        const float* crow = Cs + r * cld;
-        const float* e = enc && live ? enc + (size_t)sp[atom] * d.S + d.feat_off[l] : nullptr;
-        const float mu = st[r * 4], rstd = st[r * 4 + 1], m1 = st[r * 4 + 2], m2 = st[r * 4 + 3];
-        const int nchunk = (nc + 7) / 8;  // chunks of 8 rows a (256 K columns)
-        for (int kc = 0; kc < nchunk; kc++) {
-            const int a = 8 * kc + as;
-            float accm[2 * MAXL + 1];
-#pragma unroll
-            for (int m = 0; m < 2 * MAXL + 1; m++) accm[m] = 0.f;
-            for (int pass = 0; pass < 2; pass++) {
-                f32x16 acc2[2];
-                acc_fill_bias<2>(acc2, nullptr, 0, lane);
-                gemm_acc<NOUTP, 2>(Ds, LDD, pass ? Wpb2t : Wpb2, NOUTP / 8, 0, (d.kp_off[l] + 256 * kc) / 32 + 2 * wave,
-                                   acc2, lane);
-                __syncthreads();  // the previous output tile has been consumed
-                acc_foreach<2>(acc2, 0, 64 * wave, lane, [&](int rr, int c, float v) { ot[rr * LDT + c] = v; });
-                __syncthreads();
-                if (a < nc && live) {
-                    const float* orow = ot + r * LDT + 32 * as;
-                    switch (l) {
-#define PS_CASE(LV)                                                                                              \
-    case LV:                                                                                                      \
-        ps_row_bwd<2 * LV + 1>(crow, nc, a, e, pass != 0, orow, d.layernorm != 0, mu, rstd, m1, m2, accm);        \
-        break;
-                        PS_CASE(0) PS_CASE(1) PS_CASE(2) PS_CASE(3) PS_CASE(4) PS_CASE(5) PS_CASE(6) PS_CASE(7) PS_CASE(8)
-#undef PS_CASE
-                    }
-                }
-            }
-            if (a < nc) {
-#pragma unroll
-                for (int m = 0; m < 2 * MAXL + 1; m++)
-                    if (m < 2 * l + 1) dCs[r * cld + m * nc + a] = accm[m];
-            }
-        }
-        __syncthreads();
-        for (int rr = wave; rr < BMB; rr += 4)
-            if (row0 + rr < N)
-                for (int c = lane; c < clw; c += 64)
-                    dCf[(size_t)(row0 + rr) * d.NCOEF + d.coef_off[l] + c] = dCs[rr * cld + c];
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // a18, species-sorted tiles (pet_config_set("soap_sorted", 1), default): in legacy mode every atom uses ONE of the
@@ -1809,6 +1494,8 @@ __global__ __launch_bounds__(256) void k_soap_expand_bwd_p(SoapDims d, const flo
         const float* dCl = dC + d.coef_off[l];
         for (int n = 0; n < nl; n++) {
             float R, dR;
+            // (requesting the spline nodes of function n + 1 before evaluating function n was measured in round 6: 1.04 - 1.08
+            // against 0.97 - 0.98 ms; three waves per SIMD at 168 registers and 52 KB of staging: 1.07 ms)
             radial_one(d, table, d.rad_off[l] + n, r, fc, dfc, &R, &dR);
             float ay_ = 0.f;  // sum over m of A Y in fp32 (at most 2 l + 1 terms), then one fp64 add per radial function
 #pragma unroll
@@ -1985,24 +1672,6 @@ static int soap_finalize(SoapModel& m, hipStream_t st) {
                                                         m.wallp_bwd_set + sset * per);
             }
         }
-        if (d.ncmax <= 32) {  // fused power-spectrum + tail kernels: W1 over the padded K layout, and its transpose
-            const int Kp2 = d.kp_off[d.L + 1];
-            const size_t n42 = (size_t)NOUTP * Kp2 / 4;
-            if (!m.wall2 || m.Kp2 != Kp2) {
-                if ((rc = salloc(m, (void**)&m.wall2, (size_t)NOUTP * Kp2 * 4))) return rc;
-                if ((rc = salloc(m, (void**)&m.wall2t, (size_t)NOUTP * Kp2 * 4))) return rc;
-                if ((rc = salloc(m, (void**)&m.wall2_fwd, n42 * sizeof(float4)))) return rc;
-                if ((rc = salloc(m, (void**)&m.wall2_bwd, n42 * sizeof(float4)))) return rc;
-                if ((rc = salloc(m, (void**)&m.wall2t_bwd, n42 * sizeof(float4)))) return rc;
-            }
-            m.Kp2 = Kp2;
-            const int g2 = (int)cdiv((int64_t)NOUTP * Kp2, 256);
-            k_soap_prep_wall2<<<g2, 256, 0, st>>>(d, m.sets, m.n_sets, NOUTP, Kp2, 0, m.wall2);
-            k_soap_prep_wall2<<<g2, 256, 0, st>>>(d, m.sets, m.n_sets, NOUTP, Kp2, 1, m.wall2t);
-            k_pack<<<cdiv(n42, 256), 256, 0, st>>>(m.wall2, Kp2, 1, NOUTP, Kp2, m.wall2_fwd);
-            k_pack<<<cdiv(n42, 256), 256, 0, st>>>(m.wall2, 1, Kp2, Kp2, NOUTP, m.wall2_bwd);
-            k_pack<<<cdiv(n42, 256), 256, 0, st>>>(m.wall2t, 1, Kp2, Kp2, NOUTP, m.wall2t_bwd);
-        }
         PET_HIP_CHECK(hipGetLastError());
     }
     PET_HIP_CHECK(hipStreamSynchronize(st));  // host vectors go out of scope
@@ -2033,14 +1702,6 @@ static void soap_note_layout(const SoapModel& m, const void* ws, bool packed) {
 static bool soap_ws_packed(const SoapModel& m, const void* ws) {
     auto it = m.ws_packed.find(ws);
     return it != m.ws_packed.end() && it->second;
-}
-static bool soap_fused_ok(const SoapModel& m) {
-    return g_soap_fused && g_soap_mfma && m.NT > 0 && m.wall2_fwd != nullptr && m.d.ncmax <= 32 && m.d.L <= MAXL;
-}
-static int soap_cld(const SoapDims& d) {
-    int w = 1;
-    for (int l = 0; l <= d.L; l++) w = std::max(w, (2 * l + 1) * d.n_per_l[l] * d.C);
-    return w | 1;  // odd row pitch: lanes = atoms read the same column without bank conflicts
 }
 static size_t lds_expand(const SoapDims& d) { return (size_t)PC * (d.NLM + d.F + 8 + 1) * 4; }
 static size_t lds_expand_bwd(const SoapDims& d) {
@@ -2074,23 +1735,9 @@ static int soap_fwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
                                                          m.species_w, w.Cf);
         }
     }
-    const bool packed = !soap_fused_ok(m) && soap_sorted_ok(m) && soap_packed_ok(m) && features == nullptr;
+    const bool packed = soap_sorted_ok(m) && soap_packed_ok(m) && features == nullptr;
     soap_note_layout(m, ws, packed);
-    if (soap_fused_ok(m)) {
-        ProfScope ps("soap_ps_tail", st, 2.0 * (double)N * d.S * (d.L + 1 + d.H), (double)N * d.NCOEF * 4);
-        const int cld = soap_cld(d), grid = cdiv(N, BM);
-#define SOAP_FUSED_FWD(NTV)                                                                                       \
-    case NTV: {                                                                                                   \
-        constexpr int LDO = 64 * NTV + 1, LDA = lds_ld(128);                                                      \
-        const size_t lds = ((size_t)BM * (LDO > LDA ? LDO : LDA) + BM * 32 + (size_t)BM * cld) * 4 + 4 * BM * 2 * 8; \
-        allow_big_lds(k_soap_ps_tail_fwd<NTV>, lds);                                                              \
-        k_soap_ps_tail_fwd<NTV><<<grid, NTHREADS, lds, st>>>(d, cld, w.Cf, g.sp, m.enc, m.sets, m.wall2_fwd, m.Kp2, \
-                                                             m.wall_rs, m.wall_b, w.tail, atomic,                 \
-                                                             features ? w.feats : nullptr, N);                    \
-    } break;
-        switch (m.NT) { SOAP_FUSED_FWD(1) SOAP_FUSED_FWD(2) SOAP_FUSED_FWD(3) SOAP_FUSED_FWD(4) }
-#undef SOAP_FUSED_FWD
-    } else {
+    {
     {
             ProfScope ps("soap_ps", st, 2.0 * (double)N * d.S * (d.L + 1), (double)N * (d.NCOEF + (packed ? d.Sp : d.S)) * 4);
             if (packed) {
@@ -2164,24 +1811,10 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
         da2x = w.da2;
     }
     const bool packed = soap_ws_packed(m, ws);  // what the forward into this workspace stored
-    PET_REQUIRE(!packed || (soap_sorted_ok(m) && soap_packed_ok(m) && !soap_fused_ok(m)), PET_ERR_ARGUMENT,
+    PET_REQUIRE(!packed || (soap_sorted_ok(m) && soap_packed_ok(m)), PET_ERR_ARGUMENT,
                 "the forward of this workspace stored the packed power spectrum but the adjoint is configured for the full "
                 "layout: pet_config_set changed between soap_forward and soap_backward");
-    if (soap_fused_ok(m)) {
-        ProfScope ps("soap_ps_tail_bwd", st, 4.0 * (double)N * d.S * (d.L + 1 + d.H), (double)N * d.NCOEF * 8);
-        const int cld = soap_cld(d), grid = cdiv(N, BMB);
-#define SOAP_FUSED_BWD(NTV)                                                                                       \
-    case NTV: {                                                                                                   \
-        const size_t lds = ((size_t)BMB * lds_ld(64 * NTV) + BMB * 32 + BMB * 4 + BMB * lds_ld(256) +             \
-                            (size_t)2 * BMB * cld) * 4;                                                           \
-        allow_big_lds(k_soap_ps_tail_bwd<NTV>, lds);                                                              \
-        k_soap_ps_tail_bwd<NTV><<<grid, NTHREADS, lds, st>>>(d, cld, w.Cf, g.sp, m.sets, m.wall2_bwd, m.wall2t_bwd, \
-                                                             m.wall_rs, m.wall_b, m.enc, w.tail, gA, w.dCf, N,    \
-                                                             da2x);                                               \
-    } break;
-        switch (m.NT) { SOAP_FUSED_BWD(1) SOAP_FUSED_BWD(2) SOAP_FUSED_BWD(3) SOAP_FUSED_BWD(4) }
-#undef SOAP_FUSED_BWD
-    } else {
+    {
     {
         ProfScope ps("soap_tail_bwd", st, 2.0 * (double)N * d.S * d.H, (double)N * (packed ? d.Sp : d.S) * 8);
         if (soap_sorted_ok(m)) {  // perm / info were filled by the forward pass on this workspace
@@ -2223,7 +1856,7 @@ static int soap_bwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
                      (double)g.n_edges * 36 + (double)N * d.NCOEF * 4);
         if (soap_pair_ok(d)) {
             const int grid = (int)cdiv(g.n_edges, 256);
-            const int lds_floats = (d.NCOEF % 4 == 0) ? 16 * 1024 : 0;  // 64 KB: the rows of up to ~11 centres of the default basis
+            const int lds_floats = (d.NCOEF % 4 == 0) ? 16 * 1024 : 0;  // 64 KB: the rows of up to ~14 centres of the default basis
             if (d.L <= 6) {
                 allow_big_lds(k_soap_expand_bwd_p<6>, (size_t)lds_floats * 4);
                 k_soap_expand_bwd_p<6><<<grid, 256, (size_t)lds_floats * 4, st>>>(d, g.geo, g.ctr, g.sp_nbr, m.table, m.shnorm,
@@ -2286,14 +1919,12 @@ int soap_model_create(const soap_hypers_t* h, soap_model_t** out) {
         const int n = h->n_per_l[l];
         if (n < 0 || n > 64) { delete sm; set_error("bad n_per_l"); return PET_ERR_ARGUMENT; }
         d.n_per_l[l] = n; d.rad_off[l] = f; d.coef_off[l] = co; d.feat_off[l] = fo;
-        d.kp_off[l] = l == 0 ? 0 : d.kp_off[l - 1] + (d.n_per_l[l - 1] * d.C + 7) / 8 * 8 * 32;
         if (n * d.C > d.ncmax) d.ncmax = n * d.C;
         d.pfeat_off[l] = pfo;
         f += n; co += (2 * l + 1) * n * d.C; fo += (n * d.C) * (n * d.C); items += (2 * l + 1) * n;
         pfo += (n * d.C) * (n * d.C + 1) / 2;
     }
     d.coef_off[d.L + 1] = co; d.feat_off[d.L + 1] = fo; d.pfeat_off[d.L + 1] = pfo; d.Sp = pfo;
-    d.kp_off[d.L + 1] = d.kp_off[d.L] + (d.n_per_l[d.L] * d.C + 7) / 8 * 8 * 32;
     d.F = f; d.NCOEF = co; d.S = fo; d.ITEMS = items;
     m.n_sets = h->legacy ? h->n_species : 1;
     if (d.F > 255 || d.NLM > 255 || d.NCOEF > 256 * MAXK || d.NCOEF >= 65536) {

@@ -695,8 +695,6 @@ static int soap_train_grads(SoapModel& m, const Graph& g, void* ws, int64_t ws_b
     PET_REQUIRE(d.legacy || d.ns * d.C <= 256, PET_ERR_UNSUPPORTED, "more than 64 species with the Alchemical embedding");
     PET_REQUIRE(d.H <= MAXH && d.NH <= MAXNH, PET_ERR_UNSUPPORTED, "tail size outside the compiled limits");
     PET_REQUIRE(!m.grad.empty(), PET_ERR_ARGUMENT, "soap_model_zero_grad has not been called");
-    PET_REQUIRE(!soap_fused_ok(m), PET_ERR_UNSUPPORTED,
-                "training reads the stored power spectrum: switch pet_config_set(\"soap_fused\", 0)");
     SoapWs w;
     carve_soap(d, g.n_nodes, g.n_edges, ws, w);
     PET_REQUIRE((int64_t)w.bytes <= ws_bytes, PET_ERR_ARGUMENT, "soap workspace too small");

@@ -24,16 +24,14 @@ def _relmax(a, b):
     return np.abs(a - b).max() / np.abs(b).max()
 
 
-@pytest.mark.parametrize("mfma_tail,pair_kernels,fused,sorted_tiles",
-                         [(1, 1, 0, 1), (1, 1, 0, 0), (1, 1, 1, 0), (0, 1, 0, 0), (1, 0, 0, 1)])
+@pytest.mark.parametrize("mfma_tail,pair_kernels,sorted_tiles", [(1, 1, 1), (1, 1, 0), (0, 1, 0), (1, 0, 1)])
 @pytest.mark.parametrize("legacy", [True, False])
-def test_soap_bpnn_energy_features_and_forces(legacy, mfma_tail, pair_kernels, fused, sorted_tiles):
+def test_soap_bpnn_energy_features_and_forces(legacy, mfma_tail, pair_kernels, sorted_tiles):
     from metatrain_amd import runtime as rt
     from metatrain_amd.soap_bpnn import SoapBpnnHip
 
     rt.config_set("soap_mfma", mfma_tail)  # both tail implementations: MFMA GEMM over 64 atoms / per-atom kernels
     rt.config_set("soap_pair", pair_kernels)  # wave-per-atom expansion + lane-per-pair adjoint / first generation
-    rt.config_set("soap_fused", fused)  # power spectrum + LayerNorm + first Linear in one kernel / separate kernels
     rt.config_set("soap_sorted", sorted_tiles)  # tail GEMM per network on species-sorted tiles / all networks stacked
 
     dev = torch.device("cuda:0")
@@ -64,7 +62,6 @@ def test_soap_bpnn_energy_features_and_forces(legacy, mfma_tail, pair_kernels, f
     assert float(grad.sum(0).abs().max()) < 1e-4 * float(grad.abs().max())
     rt.config_set("soap_mfma", 1)
     rt.config_set("soap_pair", 1)
-    rt.config_set("soap_fused", 0)
     rt.config_set("soap_sorted", 1)
 
 
@@ -101,16 +98,15 @@ def test_power_spectrum_on_the_matrix_core_and_on_the_valu_agree(legacy):
     assert not np.array_equal(out[1][1], out[0][1])  # the switch did select other kernels (other summation order)
 
 
-@pytest.mark.parametrize("mfma_tail,fused,sorted_tiles", [(1, 0, 1), (1, 0, 0), (1, 1, 0), (0, 0, 0)])
+@pytest.mark.parametrize("mfma_tail,sorted_tiles", [(1, 1), (1, 0), (0, 0)])
 @pytest.mark.parametrize("legacy,layers", [(True, 3), (False, 4), (True, 8)])
-def test_more_than_two_hidden_layers(legacy, layers, mfma_tail, fused, sorted_tiles):
+def test_more_than_two_hidden_layers(legacy, layers, mfma_tail, sorted_tiles):
     """``bpnn.num_hidden_layers`` > 2 (soap_bpnn/documentation.py: any depth; VERDICT r2 missing #9): every tail path keeps
     its first two layers and hands over to the per-atom continuation kernels."""
     from metatrain_amd import runtime as rt
     from metatrain_amd.soap_bpnn import SoapBpnnHip
 
     rt.config_set("soap_mfma", mfma_tail)
-    rt.config_set("soap_fused", fused)
     rt.config_set("soap_sorted", sorted_tiles)
     try:
         dev = torch.device("cuda:0")
@@ -139,8 +135,7 @@ def test_more_than_two_hidden_layers(legacy, layers, mfma_tail, fused, sorted_ti
         np.testing.assert_allclose(g2.cpu().numpy(), grad.cpu().numpy(), atol=2e-6 * float(grad.abs().max()))
     finally:
         rt.config_set("soap_mfma", 1)
-        rt.config_set("soap_fused", 0)
-        rt.config_set("soap_sorted", 1)
+            rt.config_set("soap_sorted", 1)
 
 
 @pytest.mark.parametrize("legacy,neurons,layers", [(True, 48, 2), (False, 64, 3), (True, 7, 1), (False, 16, 2)])
