@@ -155,25 +155,51 @@ def sum_over_ranks(value: float, device: torch.device) -> float:
     return float(t.item())
 
 
-def all_reduce_gradients(model, timing: Optional[list] = None) -> None:
-    """Mean of the gradient slots over ranks, as ONE collective on the flat bucket (2 903 298 fp32 =
-    11.6 MB: a single ring all-reduce is per-link bound on xGMI, and one bucket keeps it at one
-    launch). ``model`` exposes ``flat_grad()`` / ``set_flat_grad(t)`` (runtime.HipModel). RCCL takes the mean itself
-    (``ReduceOp.AVG``); gloo (CPU tests, debugging) sums and divides. ``timing``: a list that receives a pair of
-    recorded events around copy-out + collective + copy-in (the benches read ``elapsed_time`` after the step)."""
+class GradientReduce:
+    """An in-flight mean all-reduce of the flat gradient bucket (``all_reduce_gradients_async``). ``wait()`` makes the
+    CURRENT stream wait for the collective (RCCL: a stream dependency, the host does not block; gloo: the host waits),
+    finishes the mean and writes the bucket back into the model's gradient slots."""
+
+    def __init__(self, model, flat=None, work=None, divide: int = 1, events=None, timing=None):
+        self.model, self.flat, self.work, self.divide, self.events, self.timing = model, flat, work, divide, events, timing
+
+    def wait(self) -> None:
+        if self.flat is None:
+            return
+        if self.work is not None:
+            self.work.wait()
+        if self.divide > 1:
+            self.flat /= self.divide
+        self.model.set_flat_grad(self.flat)
+        if self.events is not None:
+            self.events[1].record()
+            self.timing.append(self.events)
+        self.flat = self.work = None
+
+
+def all_reduce_gradients_async(model, timing: Optional[list] = None) -> GradientReduce:
+    """Start the mean of the gradient slots over ranks as ONE collective on the flat bucket (2 903 298 fp32 = 11.6 MB: a
+    single ring all-reduce is per-link bound on xGMI, and one bucket keeps it at one launch) and return at once: the
+    bucket is copied out on the current stream, the collective is issued with ``async_op=True`` -- ProcessGroupNCCL (= RCCL)
+    runs it on ITS OWN stream behind an event of the current one --, and the caller's stream stays free for whatever does
+    not need the reduced gradients (the next batch's neighbour lists and graph build: ``pet/trainer.py TrainStep.begin`` /
+    ``.end``) until ``wait()``. ``model`` exposes ``flat_grad()`` / ``set_flat_grad(t)`` (runtime.HipModel). RCCL takes the mean
+    itself (``ReduceOp.AVG``); gloo (CPU tests, debugging) sums and ``wait()`` divides. ``timing``: a list that receives a pair
+    of recorded events around copy-out ... copy-in (the benches read ``elapsed_time`` after the step)."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
-        return
+        return GradientReduce(model)
     ev = None
     if timing is not None and torch.cuda.is_available():
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     flat = model.flat_grad()
     if dist.get_backend() == "nccl":
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat /= dist.get_world_size()
-    model.set_flat_grad(flat)
-    if ev is not None:
-        ev[1].record()
-        timing.append(ev)
+        work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True)
+        return GradientReduce(model, flat, work, 1, ev, timing)
+    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    return GradientReduce(model, flat, work, dist.get_world_size(), ev, timing)
+
+
+def all_reduce_gradients(model, timing: Optional[list] = None) -> None:
+    """``all_reduce_gradients_async(model, timing).wait()``: the blocking form (same collective, same result)."""
+    all_reduce_gradients_async(model, timing).wait()

@@ -135,9 +135,30 @@ class TrainStep:
         norm = self._finish()
         return {"loss": loss, "grad_norm": norm, "energies": torch.cat(energies)}
 
+    def begin(self, graph: HipGraph, fw: HipForward, target_energies: torch.Tensor, n_atoms: torch.Tensor,
+              target_gradients: Optional[torch.Tensor] = None, target_strain_gradients: Optional[torch.Tensor] = None,
+              positions: Optional[torch.Tensor] = None, cells: Optional[torch.Tensor] = None) -> None:
+        """First half of :meth:`__call__`: the three sweeps of the batch, then the gradient all-reduce is STARTED
+        (``distributed.all_reduce_gradients_async``: RCCL runs it on its own stream). Whatever the caller launches before
+        :meth:`end` -- the next batch's neighbour lists and graph build, as the reference's DataLoader workers do beside
+        ``loss.backward()`` (``pet/trainer.py:417-472``) -- overlaps the collective."""
+        self.model.zero_grad()
+        self._pending = self._accumulate(graph, fw, target_energies, n_atoms, target_gradients, target_strain_gradients,
+                                         positions, cells, 1.0, 1.0, 1.0)
+        self._reduce = D.all_reduce_gradients_async(self.model, self.comm_events)
+
+    def end(self) -> Dict[str, torch.Tensor]:
+        """Second half: wait for the reduced gradients (a stream dependency under RCCL), clip + AdamW + schedule."""
+        loss, energies = self._pending
+        norm = self._finish()
+        self._pending = None
+        return {"loss": loss, "grad_norm": norm, "energies": energies}
+
     def _finish(self) -> torch.Tensor:
         m = self.model
-        D.all_reduce_gradients(m, self.comm_events)
+        reduce = getattr(self, "_reduce", None) or D.all_reduce_gradients_async(m, self.comm_events)
+        self._reduce = None
+        reduce.wait()
         norm = m.adam_step(self.current_lr(), self.step_index + 1, weight_decay=self.hypers["weight_decay"],
                            max_grad_norm=self.hypers["grad_clip_norm"] or 0.0)
         self.step_index += 1

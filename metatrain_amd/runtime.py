@@ -198,7 +198,7 @@ class HipModel:
         _require_cuda(flat)
         flat = flat.to(torch.float32).contiguous()
         check(self.lib.pet_model_flat_grad(self._handle, _ptr(flat), flat.numel(), 1, _stream()))
-        torch.cuda.current_stream().synchronize()  # `flat` may be a temporary
+        self._flat_keepalive = flat  # `flat` may be a temporary: it must outlive the copy queued on the stream (no host sync)
 
     def optimizer_state(self) -> Dict[str, torch.Tensor]:
         """Adam's moments as flat buffers in upload order (``pet_optimizer_state``): what a checkpoint keeps."""

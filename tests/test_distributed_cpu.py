@@ -102,6 +102,49 @@ def test_two_rank_gradient_all_reduce_is_the_mean_of_one_flat_bucket():
         assert mid == 1.5
 
 
+def _grad_async_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from metatrain_amd import distributed as d
+
+    d.init("gloo")
+    n = 2903298
+    gen = torch.Generator().manual_seed(7 + rank)
+    g = torch.randn(n, generator=gen)
+    blocking = _FakeModel(g.clone())
+    d.all_reduce_gradients(blocking)
+    model = _FakeModel(g.clone())
+    handle = d.all_reduce_gradients_async(model)
+    # work that does not need the reduced gradients runs between the start of the collective and wait() (the next batch's
+    # graph build in TrainStep.begin / .end); the model's slots still hold the local gradient until wait()
+    busy = float((torch.arange(1000.0) ** 0.5).sum())
+    untouched = bool(torch.equal(model.flat, g))
+    handle.wait()
+    handle.wait()  # idempotent
+    out.put((rank, untouched, bool(torch.equal(model.flat, blocking.flat)), float(model.flat[:16].double().sum()), busy > 0))
+    d.barrier(torch.device("cpu"))
+    torch.distributed.destroy_process_group()
+
+
+def test_async_gradient_all_reduce_equals_the_blocking_one():
+    """the gradient all-reduce is issued as soon as the flat bucket is final and waited for just before the
+    optimizer step (``distributed.all_reduce_gradients_async`` -> ``GradientReduce.wait``; under RCCL the collective runs on
+    the process group's own stream): same collective, bit-identical result to the blocking call, on both ranks."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_async_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] and r[4] for r in res)
+    assert res[0][3] == res[1][3]  # the same mean on both ranks
+
+
 def test_lr_schedule_matches_reference_formula():
     """Linear warm-up then cosine (pet/trainer.py:56-86): known points of the closed form."""
     from metatrain_amd.pet.trainer import lr_lambda
