@@ -135,7 +135,7 @@ def test_more_than_two_hidden_layers(legacy, layers, mfma_tail, sorted_tiles):
         np.testing.assert_allclose(g2.cpu().numpy(), grad.cpu().numpy(), atol=2e-6 * float(grad.abs().max()))
     finally:
         rt.config_set("soap_mfma", 1)
-            rt.config_set("soap_sorted", 1)
+        rt.config_set("soap_sorted", 1)
 
 
 @pytest.mark.parametrize("legacy,neurons,layers", [(True, 48, 2), (False, 64, 3), (True, 7, 1), (False, 16, 2)])
