@@ -64,7 +64,7 @@ SURVEY_8D_BYTES_PER_ATOM = 150e3  # forward + forces with a
 
 
 def _traffic_file():
-    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # newest round first
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # newest round first
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as fh:
@@ -94,7 +94,7 @@ def pmc_traffic(stage, n_edges):
 def pmc_mfma_busy(stage):
     """SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE of the stage's largest kernel from the committed SQ pass of this bench
     (profiles/r0N_sq_counters_table.txt of the newest round, column mfma_util), or None."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_sq_counters_table.txt") for r in (5, 4)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_sq_counters_table.txt") for r in (6, 5, 4)) if os.path.exists(q)), None)
     if stage not in STAGE_KERNELS or path is None:
         return None
     best = None
@@ -287,7 +287,7 @@ def main():
     ap.add_argument("--normalization", default="RMSNorm", choices=["RMSNorm", "LayerNorm"],
                     help="side runs only: the legacy-checkpoint norm; the headline metric is the default (RMSNorm)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=INT",
-                    help="library switch for A/B runs, e.g. --set attn_lds=1 (pet_config_set)")
+                    help="library switch for A/B runs, e.g. --set side_stream=0 (pet_config_set)")
     args = ap.parse_args()
 
     from metatrain_amd import distributed as pdist

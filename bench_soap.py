@@ -51,8 +51,8 @@ def cpu_baseline(hypers, n=10000):
 
 
 
-SOAP_STAGE_KERNELS = {"soap_expand": "k_soap_expand_w", "soap_ps": "k_soap_ps_w", "soap_tail": "k_soap_tail_fwd_set",
-                      "soap_tail_bwd": "k_soap_tail_bwd_set", "soap_ps_bwd": "k_soap_ps_bwd_s",
+SOAP_STAGE_KERNELS = {"soap_expand": "k_soap_expand_w", "soap_ps": "k_soap_ps_m", "soap_tail": "k_soap_tail_fwd_set",
+                      "soap_tail_bwd": "k_soap_tail_bwd_set", "soap_ps_bwd": "k_soap_ps_bwd_m",
                       "soap_expand_bwd": "k_soap_expand_bwd_p"}
 
 
@@ -60,7 +60,7 @@ def pmc_traffic(stage, n_pairs):
     """HBM bytes per launch of the stage's kernel and of a whole step from the committed rocprofv3 PMC passes of this bench
     (profiles/r0N_soap_traffic.json of the newest round: --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, (2 FETCH + WRITE) x 1024); None
     unless the profiled run had the same number of pairs."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_soap_traffic.json") for r in (5, 4)) if os.path.exists(q)),
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_soap_traffic.json") for r in (6, 5, 4)) if os.path.exists(q)),
                 os.path.join(ROOT, "profiles", "r04_soap_traffic.json"))
     if not os.path.exists(path):
         return None, None
@@ -188,6 +188,9 @@ def main():
                             f"{'alchemical (4 pseudo-species)' if args.alchemical else 'legacy (per-species heads)'}",
                 "pairs_per_gpu_per_step": int(g.n_edges),
                 "total_energy_rank0": float(atomic.double().sum()),
+                "power_spectrum_storage": ("full [N][S]" if args.alchemical or ("soap_packed=0" in args.set) else
+                                           "upper triangle of every l block (p_l[a][b] = p_l[b][a]): "
+                                           f"{sum((k * 4) * (k * 4 + 1) // 2 for k in model.n_per_l)} of {S} floats per atom"),
             },
             "roofline": {"bound": "hbm", "kernel": dominant["name"], "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": dominant["total_ms"],

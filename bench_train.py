@@ -71,7 +71,7 @@ def pmc_traffic(stage, n_edges):
     """HBM bytes PER STEP of the stage group's kernels and of the whole step from the committed rocprofv3 PMC passes of this
     bench (profiles/r0N_train_traffic.json of the newest round: --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, (2 FETCH + WRITE) x 1024);
     None unless the profiled run had the same number of edges."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_train_traffic.json") for r in (5, 4)) if os.path.exists(q)),
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_train_traffic.json") for r in (6, 5, 4)) if os.path.exists(q)),
                 os.path.join(ROOT, "profiles", "r04_train_traffic.json"))
     if not os.path.exists(path):
         return None, None

@@ -413,14 +413,10 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *                 store them): 1 = for graphs of at least 28 672 edge rows (default), v > 1 = from v rows on, 0 = never
  *                 (the one-wave-per-SIMD pipelined kernels everywhere). A forward that ran without saving can only be followed
  *                 by the recomputing adjoint: flipping the switch in between makes pet_backward fail (PET_ERR_ARGUMENT).
- *   "attn_lds"    adjoint of the three-kernel attention form: 1 = staged per atom, 3 = persistent workgroups with LDS-DMA
- *                 prefetch for atoms of at most 32 tokens (default)
- *   "tile_f16x3"  1 = the LDS-tile forward kernels (compress, centre, node update, heads) and the head adjoint on f16x3
- *                 (default); 0 = fp32 MFMA. 
  *   "trr_compress" bit mask of f16x3 TRR kernels replacing LDS-tile ones: 1 compress (+adjoint), 2 edge head (+adjoint);
  *                  default 3; 0 = LDS-tile kernels
  *   "node_planes" 1 = node-row kernels k_node2 / k_node2w / k_node_bwd2 (coalesced tiles, fp16 planes; default), 0 = k_node /
- *                 k_swiglu_bwd; 2 / 3 force 32 / 64 rows per workgroup (3: the 64-row forward with (row block, column half) waves)
+ *                 k_swiglu_bwd; 2 forces 32 rows per workgroup (by default up to 16 384 atoms)
  *   "so_trr"      1 = generic training GEMMs with K = 128 or n_out = 128 as TRR kernels (default); 0 = LDS-tile k_gemm_h
  *   "soap_ps_mfma" 1 = SOAP-BPNN power spectrum and its adjoint on the fp32 matrix core (default); 0 = the VALU kernels
  *   "node_split"  1 = graphs of at most 4 096 atoms: the node update and its adjoint run the four hidden chunks of a 32-row
@@ -437,7 +433,9 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *   "wgrad_bf16"  1 = weight-gradient GEMMs of the training passes as bf16x3 split-operand products (default); 0 = fp32 MFMA
  *   "so_f16x3"    1 = generic GEMMs of the second-order (training) pass as f16x3 (default); 0 = fp32 MFMA
  *   (removed in round 4 with the kernels they selected: "emlp_pipe", "emlp_bwd_pipe", "comb_pipe", "comb_bwd_pipe",
- *   "emlp_recompute", "line_stores", "lds_w")
+ *   "emlp_recompute", "line_stores", "lds_w"; in round 6: "attn_lds" with the two staged-adjoint instantiations only it reached,
+ *   "tile_f16x3" (the fp32 fallback of the LDS-tile kernels remains for weights without fp16 planes), "soap_fused" with the
+ *   first-generation fused SOAP kernels, the A/B value 3 of "node_planes" with its kernel)
  *   "soap_mfma"   1 = SOAP-BPNN LayerNorm + MLP tail on MFMA (default)
  *   "soap_packed" 1 = SOAP-BPNN inference (legacy / per-species networks) stores the upper triangle of every power-spectrum block
  *                 only (p_l[a][b] = p_l[b][a]: 2 360 instead of 4 544 floats per atom for the default basis), LayerNorm statistics

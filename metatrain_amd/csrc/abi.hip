@@ -984,11 +984,9 @@ int pet_config_set(const char* key, int value) {
     else if (k == "soap_packed") set_soap_packed(value);
     else if (k == "soap_ps_mfma") set_soap_ps_mfma(value);
     else if (k == "soap_sorted") set_soap_sorted(value);
-    else if (k == "attn_lds") set_attn_lds(value);
     else if (k == "attn_fused") set_attn_fused(value);
     else if (k == "emlp_s") set_emlp_s(value);
     else if (k == "attn_fused_prof") ablk_prof_dump();
-    else if (k == "tile_f16x3") set_tile_f16x3(value);
     else if (k == "trr_compress") set_trr_compress(value);
     else if (k == "node_planes") set_node_planes(value);
     else if (k == "center_fused") set_center_fused(value);

@@ -249,12 +249,9 @@ void set_train_bf16(int v);  // so.hip / train.hip: 1 = ONE 16-bit MFMA term per
 int train_bf16();
 void set_wgrad_bf16(int v);  // train.hip: 1 = weight gradients as bf16x3 products on the 16-bit matrix cores (default)
 void set_so_trr(int v);     // so.hip: 1 = K = 128 / n_out = 128 generic GEMMs as TRR kernels (default)
-void set_attn_lds(int v);   // pet_attn.hip: 1 = LDS-staged attention (default), 0 = wave-per-head from global
 void set_soap_mfma(int v);  // soap.hip: 1 = MFMA tail (default), 0 = per-atom tail kernels
 void set_soap_ps_mfma(int v);  // soap.hip: 1 = power spectrum and its adjoint on the fp32 matrix core (default)
 void set_soap_packed(int v); // soap.hip: 1 = inference stores the upper triangle of every power-spectrum block only (default)
-bool use_tile_f16x3();
-void set_tile_f16x3(int v);
 void set_trr_compress(int v);
 void set_node_planes(int v);  // pet_fwd.hip / pet_bwd.hip: node-row kernels on pre-split fp16 planes (default 1)
 bool node_planes();

@@ -827,16 +827,11 @@ __global__ __launch_bounds__(512) void k_attn_bwd_a(const float* __restrict__ QK
     }
 }
 
-// pet_config_set("attn_lds", v) selects the attention adjoint (the forward is always k_attn_fwd_p, one wave per
-// (atom, head) straight from global memory):
-//   1 = staged through LDS per atom for every atom (k_attn_bwd_l)
-//   3 (default) = persistent kernel with LDS-DMA prefetch (k_attn_bwd_a) for atoms of at most 32 tokens, k_attn_bwd_l
-//       for the rest
-// (0 and 2 of round 1 -- a two-pass global-memory adjoint and an LDS-staged forward -- were slower and were removed:
-// measured per launch on 8 x 10k-atom boxes: adjoint 3.2 (two-pass) / 2.5 (1) / 1.8 ms (3); forward 1.0 / 1.2 (staged).)
+// The attention adjoint of the three-kernel form (the forward is always k_attn_fwd_p, one wave per (atom, head) straight from global
+// memory): a persistent kernel with LDS-DMA prefetch (k_attn_bwd_a) for atoms of at most 32 tokens, the per-atom LDS-staged k_attn_bwd_l
+// for the rest. (Rounds 1 - 5 kept a switch, "attn_lds", that sent every atom through k_attn_bwd_l; measured per launch on 8 x 10k-atom
+// boxes: 2.5 ms against 1.8 ms. Removed in round 6 with the two instantiations only it reached.)
 // The generic wave-per-head kernels of pet_fwd.hip / pet_bwd.hip serve more than 64 tokens per atom and trr = 0.
-static int g_attn_lds = 3;
-void set_attn_lds(int v) { g_attn_lds = v >= 2 ? 3 : 1; }
 
 // Atoms are served by the instantiation that matches their own tile count (registers / LDS, hence waves in
 // flight, scale with NT): one launch per tile count, over the graph's list of the atoms that have it.
@@ -874,8 +869,8 @@ bool attn_bwd_preload(int nt, const float* QKV, const float* dAO, const Graph& g
                       float scale, hipStream_t st) {
     if (nt > 4) return false;
     const int N = (int)g.n_nodes;
-    int first = 1;
-    if (g_attn_lds == 3) {  // persistent LDS-DMA kernel for every atom with at most `cap` tokens (tile counts 1 and 2)
+    constexpr int first = 3;
+    {  // persistent LDS-DMA kernel for every atom with at most `cap` tokens (tile counts 1 and 2)
         constexpr int cap = 32;
         static int n_cu = 0;
         if (!n_cu) {
@@ -891,7 +886,6 @@ bool attn_bwd_preload(int nt, const float* QKV, const float* dAO, const Graph& g
             k_attn_bwd_a<2><<<grid, 512, lds, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h, g.n_edges, N, scale, cap,
                                                     g.atom_order, n_list);
         }
-        first = 3;
     }
 #define PET_ATTN_BWD_L(K)                                                                                      \
     if (nt >= K && K >= first && bucket_count(g, K) > 0) {                                                     \
@@ -900,7 +894,7 @@ bool attn_bwd_preload(int nt, const float* QKV, const float* dAO, const Graph& g
         k_attn_bwd_l<K><<<bucket_count(g, K), 512, lds, st>>>(QKV, dAO, g.rowptr, g.fc, dQKV, dbias_h,         \
                                                               g.n_edges, N, scale, bucket_atoms(g, K));        \
     }
-    PET_ATTN_BWD_L(1) PET_ATTN_BWD_L(2) PET_ATTN_BWD_L(3) PET_ATTN_BWD_L(4)
+    PET_ATTN_BWD_L(3) PET_ATTN_BWD_L(4)
 #undef PET_ATTN_BWD_L
     return true;
 }

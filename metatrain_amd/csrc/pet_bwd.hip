@@ -1106,7 +1106,7 @@ static void launch_attn_bwd(const float* QKV, const float* dAO, const Graph& g, 
 static inline WX wx_f(const Lin& L) {
     WX w;
     w.f = L.fwd;
-    if (use_tile_f16x3() && L.fwd2) {
+    if (L.fwd2) {
         const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
         w.h = reinterpret_cast<const f16x8_t*>(L.fwd2);
         w.l = w.h + n8;
@@ -1116,7 +1116,7 @@ static inline WX wx_f(const Lin& L) {
 static inline WX wx_b(const Lin& L) {
     WX w;
     w.f = L.bwd;
-    if (use_tile_f16x3() && L.bwd2) {
+    if (L.bwd2) {
         const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
         w.h = reinterpret_cast<const f16x8_t*>(L.bwd2);
         w.l = w.h + n8;

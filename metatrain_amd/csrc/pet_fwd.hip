@@ -624,7 +624,7 @@ __global__ __launch_bounds__(NTHREADS) void k_node2(const float* __restrict__ H,
 // epilogue 57). Here a wave owns a column quarter for BOTH 32-row blocks (tile.h gemm_acc_hs_rb2 / gemm_acc_x_ring_rb2): the
 // value and gate tiles of a hidden chunk in one product, the K = 128 operand of the output product requested behind the
 // barriers. 0.52 -> 0.455 ms per launch: the rest is the exposed latency of each phase at one workgroup per CU (133 KB of
-// LDS). Same LDS layout and the same MFMA order per output element as k_node2<2> (pet_config_set("node_planes", 3)).
+// LDS). Same LDS layout and the same MFMA order per output element as k_node2<2> (the A/B kernel of rounds 3 - 5; its forward instantiation is no longer launched).
 __global__ __launch_bounds__(NTHREADS) void k_node2w(const float* __restrict__ H, const float* __restrict__ OC,
                                                       WX wce, const float* __restrict__ bce,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, WX win,
@@ -1013,13 +1013,12 @@ bool node_split_on() { return g_node_split != 0; }
 static int g_center_fused = 1;  // pet_config_set("center_fused", 0): the next layer's centre tokens by their own k_center launch
 void set_center_fused(int v) { g_center_fused = v ? 1 : 0; }
 static int g_node_planes = 1;  // k_node2 / k_node_bwd2: A tiles pre-split into fp16 planes (pet_config_set("node_planes", 0): k_node)
-void set_node_planes(int v) { g_node_planes = v; }
+void set_node_planes(int v) { g_node_planes = v > 2 ? 2 : v; }
 bool node_planes() { return g_node_planes != 0; }
-// rows per workgroup of k_node2 / k_node_bwd2: node_planes = 2 / 3 force 32 / 64, 1 chooses by the number of atoms
+// rows per workgroup of k_node2 / k_node_bwd2: node_planes = 2 forces 32 (the tests' route to the 32-row kernels), 1 chooses by the number of atoms
 static int g_node_rows_threshold = 16384;  // measured: 1 000 / 3 000 / 10 000 atoms gain 14 / 8 / 2 %, 80 000 lose 8 % of the stage
 int node_rows(int64_t N) {
     if (g_node_planes == 2) return 32;
-    if (g_node_planes == 3) return 64;
     return N <= g_node_rows_threshold ? 32 : 64;
 }
 
@@ -1034,7 +1033,7 @@ double g_sum_t2(const Graph& g) {
 static inline WX wx_fwd(const Lin& L) {
     WX w;
     w.f = L.fwd;
-    if (use_tile_f16x3() && L.fwd2) {
+    if (L.fwd2) {
         const size_t n8 = (size_t)(L.n_out / 32) * (L.k_in / 16) * 64;
         w.h = reinterpret_cast<const f16x8_t*>(L.fwd2);
         w.l = w.h + n8;
@@ -1218,11 +1217,6 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                         k_node2<1><<<cdiv(N, 32), NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci,
                                                                          A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N,
                                                                          wcn, bcn, xcn, nullptr, nullptr);
-                    } else if (g_node_planes == 3) {  // A/B: (row block, column half) waves, every weight block fetched twice
-                        allow_big_lds(k_node2<2>, lds_n2);
-                        k_node2<2><<<gN, NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci,
-                                                                 A.cmlp_in.b, wco, A.cmlp_out.b, Ab.H1, Ab.VGn, Ab.Hn, N, wcn, bcn,
-                                                                 xcn, nullptr, nullptr);
                     } else {
                         allow_big_lds(k_node2w, lds_n2);
                         k_node2w<<<gN, NTHREADS, lds_n2, s2>>>(Ab.H, Ab.OC, wce_, A.ce.b, A.g_center, A.b_center, wci,

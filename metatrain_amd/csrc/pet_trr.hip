@@ -954,9 +954,6 @@ static inline int grid_rows(int64_t rows) { return cdiv(rows, WG_ROWS); }
 // MFMAs per K block; 1.7e-7 product error against fp64, tools/ubench). The fp32-MFMA and 3-way bf16 (bf16x6)
 // generations of round 1 were removed in round 2; pet_config_set("trr", 0) selects the LDS-tile kernels of
 // pet_fwd.hip / pet_bwd.hip, which are the one fallback (and the path of the LayerNorm / PostLN / residual variants).
-static int g_tile_f16x3 = 1;  // pet_config_set("tile_f16x3", 0): LDS-tile kernels (compress, heads, node chain) on fp32 MFMA
-void set_tile_f16x3(int v) { g_tile_f16x3 = v ? 1 : 0; }
-bool use_tile_f16x3() { return g_tile_f16x3 != 0; }
 // pet_config_set("trr_compress", bits): 1 compress (+adjoint), 2 edge head (+adjoint); 0 = the LDS-tile kernels
 static int g_trr_tilek = 3;
 void set_trr_compress(int v) { g_trr_tilek = v; }

@@ -122,9 +122,9 @@ def test_config_switches_of_removed_kernel_generations_are_rejected(lib):
     (PET_ERR_ARGUMENT), the documented ones (include/pet_hip.h) are accepted."""
     for key in (b"bf16x6", b"f16x3", b"trr_persist", b"so_bf16x6", b"emlp_pipe", b"emlp_bwd_pipe", b"comb_pipe",
                 b"comb_bwd_pipe", b"emlp_recompute", b"line_stores", b"lds_w", b"attn_fwd4", b"emlp_s_min", b"tile_mask",
-                b"no_such_switch"):
+                b"attn_lds", b"tile_f16x3", b"soap_fused", b"no_such_switch"):
         assert lib.pet_config_set(key, 0) == -3, key
-    for key, default in ((b"trr", 1), (b"attn_lds", 3), (b"attn_fused", 3), (b"tile_f16x3", 1), (b"trr_compress", 3),
+    for key, default in ((b"trr", 1), (b"attn_fused", 3), (b"trr_compress", 3), (b"soap_packed", 1),
                          (b"node_planes", 1), (b"so_trr", 1), (b"so_f16x3", 1), (b"wgrad_bf16", 1), (b"side_stream", 1),
                          (b"center_fused", 1), (b"dxf_fused", 1), (b"node_split", 1), (b"sorted_shortcut", 1), (b"train_bf16", 0), (b"soap_ps_mfma", 1), (b"emlp_s", 1)):
         assert lib.pet_config_set(key, default) == 0, key

@@ -627,19 +627,18 @@ def test_unknown_species_is_an_error_not_an_out_of_bounds_read(rt, model, dev):
                     torch.zeros(32, dtype=torch.int32, device=dev))
 
 
-@pytest.mark.parametrize("switch", ["trr", "attn_fused=0", "attn_lds=1", "side_stream", "tile_f16x3", "trr_compress", "node_planes",
-                                    "node_planes=2", "node_planes=3", "center_fused", "dxf_fused", "node_split"])
+@pytest.mark.parametrize("switch", ["trr", "attn_fused=0", "side_stream", "trr_compress", "node_planes",
+                                    "node_planes=2", "center_fused", "dxf_fused", "node_split"])
 def test_alternative_kernel_paths_agree(rt, model, dev, golden_dir, switch):
     """The fallbacks behind ``pet_config_set``: the LDS-tile kernels (trr=0, also the transformer-layer path of PostLN models;
-    on fp32 MFMA with tile_f16x3=0), the three-kernel attention form (attn_fused=0: QKV / attention / projection with Q, K, V
-    in HBM -- what the training forward and graphs with many atoms of more than 32 tokens run; with attn_lds=1 its
-    per-atom staged adjoint instead of the persistent LDS-DMA one), a single stream (side_stream=0), the node-row kernels
-    with 32 / 64 rows per workgroup (node_planes = 2 / 3; by default 32 up to 16 384 atoms), the next layer's centre tokens
+    ), the three-kernel attention form (attn_fused=0: QKV / attention / projection with Q, K, V
+    in HBM -- what the training forward and graphs with many atoms of more than 32 tokens run), a single stream
+    (side_stream=0), the node-row kernels with 32 rows per workgroup (node_planes = 2; the default up to 16 384 atoms), the next layer's centre tokens
     by their own launch (center_fused = 0), dXF by its own k_dxf launch (dxf_fused = 0), one workgroup per node-row tile (node_split = 0) and the A/B switches of the round-2 kernels. Each must meet the same parity bar."""
     g = _load(golden_dir, "pet_default_box64.npz")
     graph = _graph_from_golden(rt, model, g, dev)
     key, _, val = switch.partition("=")
-    default = {"attn_lds": 3, "trr_compress": 3, "attn_fused": 3}.get(key, 1)
+    default = {"trr_compress": 3, "attn_fused": 3}.get(key, 1)
     rt.config_set(key, int(val or 0))
     try:
         fw = rt.HipForward(model, graph)

@@ -13,3 +13,7 @@ python tools/gpu_md_probe.py 1000 3000 10000 2>/dev/null | grep "^{" > gpurun_ou
 #   python tools/make_traffic_json.py profiles/r06_rocprofv3_summary.txt 1528404 profiles/r06_traffic.json
 #   python tools/make_traffic_json.py profiles/r06_train_rocprofv3_summary.txt 1220632 profiles/r06_train_traffic.json "k_compress_h<f" "bench_train.py ..."
 #   python tools/make_traffic_json.py profiles/r06_soap_rocprofv3_summary.txt 2617156 profiles/r06_soap_traffic.json k_soap_tail_fwd_set "bench_soap.py ..."
+# one box over eight ranks, every rank's share timed one after the other on this GPU
+python bench_pet_box.py --emulate-world 8 --steps 5 --warmup 2 2>/dev/null | grep "^{" > gpurun_out/r06_box_emul8.json
+python bench_pet_box.py --emulate-world 8 --exchange --steps 5 --warmup 2 2>/dev/null | grep "^{" > gpurun_out/r06_box_emul8_exchange.json
+python bench_soap.py --partition --emulate-world 8 --steps 5 --warmup 2 2>/dev/null | grep "^{" > gpurun_out/r06_soap_box_emul8.json
