@@ -647,10 +647,18 @@ __global__ __launch_bounds__(256) void k_soap_ps_m(SoapDims d, const float* __re
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
-        for (int m0 = 0; m0 < M; m0 += 2) {
-            const int m = m0 + mh;
-            const float v = (m < M && a < nc) ? c[m * nc + a] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, v, acc, 0, 0, 0);
+        {   // (at most MAXL + 1 K steps: unrolled, the LDS reads of a block in flight together)
+            float cv[MAXL + 1];
+#pragma unroll
+            for (int s9 = 0; s9 <= MAXL; s9++) {
+                const int m = 2 * s9 + mh;
+                const bool ok = m < M && a < nc;
+                const float t = c[ok ? m * nc + a : 0];
+                cv[s9] = ok ? t : 0.f;
+            }
+#pragma unroll
+            for (int s9 = 0; s9 <= MAXL; s9++)
+                if (2 * s9 < M) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv[s9], cv[s9], acc, 0, 0, 0);
         }
         if (a < nc) {  // this lane: column b = a of rows p1(r)
             const int f0 = d.feat_off[l];
@@ -748,6 +756,23 @@ __global__ __launch_bounds__(256) void k_soap_ps_bwd_m(SoapDims d, const float* 
             for (int a0 = 0; a0 < nc; a0 += 16) {
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
                 const int mi = m0 + li, aj = a0 + li;
+                if (PACKED) {
+                    // (ncmax <= 32: eight K steps, unrolled with clamped addresses and zeroed operands past the block, so that the
+                    // sixteen LDS reads are in flight together; the rolled loop waited for two dependent reads per MFMA)
+                    float av[8], bv[8];
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; s8++) {
+                        const int b = 4 * s8 + kq;
+                        const bool oka = mi < M && b < nc, okb = aj < nc && b < nc;
+                        const float ta = c[oka ? mi * nc + b : 0];
+                        const float tb = g[okb ? soap_tri(nc, b < aj ? b : aj, b < aj ? aj : b) : 0];  // G[a][b] = G[b][a]
+                        av[s8] = oka ? ta : 0.f;
+                        bv[s8] = okb ? tb : 0.f;
+                    }
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; s8++)
+                        if (4 * s8 < nc) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8], bv[s8], acc, 0, 0, 0);
+                } else
                 for (int b0 = 0; b0 < nc; b0 += 4) {
                     const int b = b0 + kq;
                     const float av = (mi < M && b < nc) ? c[mi * nc + b] : 0.f;
