@@ -35,7 +35,19 @@ class SoapBpnnHip:
         h.n_channels = ns if self.legacy else 4
         h.legacy = int(self.legacy)
         h.layernorm = int(bool(hypers["bpnn"]["layernorm"]))
-        h.num_hidden_layers = hypers["bpnn"]["num_hidden_layers"]
+        # heads: {"energy": "mlp"} (soap_bpnn/documentation.py:117-122; model.py:117-135, 671-672, 1110-1133): one bias-free
+        # Linear(H, H) + SiLU per centre species between the BPNN and the last layer -- the same shape as one more hidden layer
+        # of the BPNN (model.py:50-93: [Linear(bias=False), SiLU] x num_hidden_layers), so the native model runs it as layer
+        # num_hidden_layers + 1 and ``load`` / ``trainable`` map the key ``heads.energy.<s>.0.weight`` onto that layer. Omitted
+        # or "linear": no extra layer (the reference's Identity).
+        head = (hypers.get("heads") or {}).get("energy", "linear")
+        if head not in ("linear", "mlp"):
+            raise ValueError(f"Unsupported head type {head} for target energy")
+        self.mlp_head = head == "mlp"
+        self._nh = int(hypers["bpnn"]["num_hidden_layers"])
+        if self.mlp_head and self._nh + 1 > 8:
+            raise PetHipError("an mlp head on top of 8 hidden layers: the tail kernels hold at most 8 layers")
+        h.num_hidden_layers = self._nh + (1 if self.mlp_head else 0)
         h.num_neurons_per_layer = hypers["bpnn"]["num_neurons_per_layer"]
         self._handle = c_void_p()
         check(self.lib.soap_model_create(byref(h), byref(self._handle)))
@@ -59,8 +71,15 @@ class SoapBpnnHip:
         except Exception:
             pass
 
+    def _native_key(self, key: str) -> str:
+        """``heads.energy.<s>.0.weight`` -> the native tail's extra hidden layer ``bpnn.<s>.<2 NH>.weight``."""
+        if self.mlp_head and key.startswith("heads.energy.") and key.endswith(".0.weight"):
+            return f"bpnn.{key.split('.')[2]}.{2 * self._nh}.weight"
+        return key
+
     def load(self, params: Dict[str, torch.Tensor]) -> None:
         for key, t in params.items():
+            key = self._native_key(key)
             rt._require_cuda(t)
             src = t.detach().to(torch.float32).contiguous()
             check(self.lib.soap_model_set_param(self._handle, key.encode(), rt._ptr(src), src.numel(), rt._stream()))
@@ -127,7 +146,7 @@ class SoapBpnnHip:
         out = {}
         for key, shape in keys_shapes:
             t = torch.empty(shape, dtype=torch.float32, device="cuda")
-            check(fn(self._handle, key.encode(), rt._ptr(t), t.numel(), rt._stream()))
+            check(fn(self._handle, self._native_key(key).encode(), rt._ptr(t), t.numel(), rt._stream()))
             out[key] = t
         return out
 
@@ -143,6 +162,8 @@ class SoapBpnnHip:
             if self.hypers["bpnn"]["layernorm"]:
                 out += [(f"layernorm.{s}.weight", (size,)), (f"layernorm.{s}.bias", (size,))]
             out += [(f"bpnn.{s}.{2 * k}.weight", (nn_, size if k == 0 else nn_)) for k in range(nh)]
+            if self.mlp_head:
+                out.append((f"heads.energy.{s}.0.weight", (nn_, nn_)))
             out.append((f"last_layers.energy.{s}.weight", (1, nn_)))
         return out
 

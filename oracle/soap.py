@@ -177,6 +177,8 @@ def state_dict_schema(hypers: dict, n_species: int, n_per_l: List[int]):
             out.append((f"layernorm.{s}.bias", (size,), "norm_b"))
         for k in range(nh):
             out.append((f"bpnn.{s}.{2 * k}.weight", (nn, size if k == 0 else nn), "linear_w"))
+        if (hypers.get("heads") or {}).get("energy") == "mlp":  # MLPHeadMap (soap_bpnn/model.py:117-135): Linear(nn, nn, bias=False) + SiLU
+            out.append((f"heads.energy.{s}.0.weight", (nn, nn), "linear_w"))
         out.append((f"last_layers.energy.{s}.weight", (1, nn if nh > 0 else size), "linear_w"))
     return out
 
@@ -243,7 +245,10 @@ def power_spectrum(expansion: List[torch.Tensor]) -> torch.Tensor:
 
 def soap_bpnn_atomic_energies(params, hypers, atomic_types, positions, cells, centers, neighbors, cell_shifts,
                               species, system_indices, return_features=False):
-    """Per-atom energies ``[N]`` of SOAP-BPNN for a scalar target with the default linear head."""
+    """Per-atom energies ``[N]`` of SOAP-BPNN for a scalar target: the default (linear = Identity) head, or with
+    ``hypers["heads"] = {"energy": "mlp"}`` the reference's MLP head between the BPNN and the last layer
+    (soap_bpnn/model.py:117-135 ``MLPHeadMap``: one bias-free Linear(H, H) + SiLU per centre species; applied at
+    model.py:671-672, selected at model.py:1110-1133)."""
     legacy = bool(hypers["legacy"])
     ns = len(atomic_types)
     table = torch.full((max(atomic_types) + 1,), -1, dtype=torch.long)
@@ -272,6 +277,8 @@ def soap_bpnn_atomic_energies(params, hypers, atomic_types, positions, cells, ce
                                                params[f"layernorm.{s}.bias"], 1e-5)
         for k in range(nh):
             x = torch.nn.functional.silu(x @ params[f"bpnn.{s}.{2 * k}.weight"].T)
+        if (hypers.get("heads") or {}).get("energy") == "mlp":
+            x = torch.nn.functional.silu(x @ params[f"heads.energy.{s}.0.weight"].T)
         e = (x @ params[f"last_layers.energy.{s}.weight"].T)[:, 0]
         energies = energies.index_add(0, idx, e)
     if return_features:

@@ -445,3 +445,46 @@ def test_training_gradients_after_a_packed_forward():
     for k in res[0][0]:
         assert _relmax(res[1][0][k], res[0][0][k]) < 2e-6, k
     assert _relmax(res[1][1], res[0][1]) < 2e-6 and _relmax(res[1][2], res[0][2]) < 2e-6
+
+
+@pytest.mark.parametrize("legacy,layers", [(True, 2), (False, 1), (True, 3)])
+def test_mlp_head(legacy, layers):
+    """``heads: {energy: mlp}`` (soap_bpnn/documentation.py:117-122): one bias-free Linear(H, H) + SiLU per centre species between
+    the BPNN and the last layer (soap_bpnn/model.py:117-135, 671-672, 1110-1133). The native tail runs it as one more hidden layer
+    (``SoapBpnnHip._native_key``); energies and dE/dR against the oracle, which applies the head explicitly; "linear" (the reference's
+    Identity) is the model without the key."""
+    from metatrain_amd.soap_bpnn import SoapBpnnHip
+
+    dev = torch.device("cuda:0")
+    types = [1, 6, 7, 8]
+    hypers = dict(osoap.DEFAULT_HYPERS, legacy=legacy, heads={"energy": "mlp"})
+    hypers["bpnn"] = dict(hypers["bpnn"], num_hidden_layers=layers)
+    n_per_l = osoap.basis(hypers)[0]
+    params = osoap.synthetic_params(hypers, 4, n_per_l, 5, torch.float32)
+    assert any(k.startswith("heads.energy.") for k in params)
+    for k in params:
+        if k.startswith(("bpnn.", "heads.")) and not k.endswith(".0.weight") or k.startswith("heads."):
+            params[k] = params[k] * 3.0   # (deep SiLU stacks shrink the signal: keep the energies O(1))
+    pos, z, cells, ci, cj, cs, sysidx = _box(90, seed=12)
+    p64 = {k: v.double() for k, v in params.items()}
+    e_ref, g_ref, a_ref = osoap.energy_and_gradient(p64, hypers, types, pos, cells, ci, cj, cs, z, sysidx)
+    # the head matters: without it the energies differ
+    h0 = dict(hypers, heads={"energy": "linear"})
+    _, _, a_lin = osoap.energy_and_gradient({k: v for k, v in p64.items() if not k.startswith("heads.")}, h0, types, pos, cells,
+                                            ci, cj, cs, z, sysidx)
+    assert _relmax(a_lin.numpy(), a_ref.numpy()) > 1e-2
+    model = SoapBpnnHip(hypers, types)
+    model.load({k: v.to(dev) for k, v in params.items()})
+    g = model.graph(pos.float().to(dev), cells.float().to(dev), ci.to(dev), cj.to(dev), cs.to(dev), z.to(dev),
+                    sysidx.int().to(dev))
+    atomic = model.forward(g)
+    grad = model.backward(g, torch.ones_like(atomic))
+    assert _relmax(atomic.cpu().numpy(), a_ref.numpy()) < TOL
+    assert _relmax(grad.cpu().numpy(), g_ref.numpy()) < TOL
+    # the trainable-parameter view names the head by the reference's key and returns what was loaded
+    back = model.params()
+    for k in params:
+        if k.startswith("heads.energy."):
+            assert torch.equal(back[k].cpu(), params[k])
+    with pytest.raises(ValueError, match="Unsupported head type"):
+        SoapBpnnHip(dict(hypers, heads={"energy": "quadratic"}), types)

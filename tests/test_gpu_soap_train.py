@@ -117,7 +117,7 @@ def test_ethanol_frames_energy_and_forces():
 
 @pytest.mark.parametrize("case", ["ethanol", "boxes", "boxes_no_layernorm", "boxes_one_hidden_layer",
                                   "boxes_four_hidden_layers", "boxes_48_neurons", "energy_only", "alchemical", "alchemical_ethanol",
-                                  "alchemical_no_layernorm", "alchemical_energy_only"])
+                                  "alchemical_no_layernorm", "alchemical_energy_only", "boxes_mlp_head", "alchemical_mlp_head"])
 def test_training_gradients_against_the_oracles_double_backward(case):
     dev = torch.device("cuda:0")
     hypers = dict(osoap.DEFAULT_HYPERS)
@@ -131,6 +131,8 @@ def test_training_gradients_against_the_oracles_double_backward(case):
         hypers["legacy"] = False
     if case == "alchemical_no_layernorm":
         hypers["bpnn"] = dict(hypers["bpnn"], layernorm=False)
+    if case.endswith("mlp_head"):  # heads: {energy: mlp} (soap_bpnn/model.py:117-135): trained as the native tail's extra layer
+        hypers["heads"] = {"energy": "mlp"}
     if case == "boxes_48_neurons":
         hypers["bpnn"] = dict(hypers["bpnn"], num_hidden_layers=3, num_neurons_per_layer=48)
     types = [1, 6, 8] if case.endswith("ethanol") else [1, 6, 7, 8]
