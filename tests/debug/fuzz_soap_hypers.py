@@ -20,8 +20,10 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 16):
     hy["legacy"] = bool(rng.random() < 0.5)
     hy["bpnn"]["num_hidden_layers"] = int(rng.integers(1, 7))
     hy["bpnn"]["layernorm"] = bool(rng.random() < 0.7)
+    if rng.random() < 0.3:  # round 6: the mlp head (one more bias-free Linear + SiLU per centre species)
+        hy["heads"] = {"energy": "mlp"}
     tag = f"L={hy['soap']['max_angular']} N={hy['soap']['max_radial']} rc={hy['soap']['cutoff']} legacy={hy['legacy']} " \
-          f"hidden={hy['bpnn']['num_hidden_layers']} ln={hy['bpnn']['layernorm']}"
+          f"hidden={hy['bpnn']['num_hidden_layers']} ln={hy['bpnn']['layernorm']} heads={hy.get('heads')}"
     try:
         params = osoap.synthetic_params(hy, 4, osoap.basis(hy)[0], 0, torch.float32)
         model = SoapBpnnHip(hy, types)
