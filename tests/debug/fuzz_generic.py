@@ -12,6 +12,9 @@ from oracle import nl as onl
 from oracle import pet as opet
 
 dev = torch.device("cuda:0")
+import os
+for _kv in filter(None, os.environ.get("PET_FUZZ_SET", "").split(",")):  # e.g. PET_FUZZ_SET=gen_f16x3=0
+    rt.config_set(_kv.split("=")[0], int(_kv.split("=")[1]))
 seed0, ntrial = int(sys.argv[1]), int(sys.argv[2])
 types = [1, 6, 7, 8]
 bad = 0
