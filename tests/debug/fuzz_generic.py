@@ -18,7 +18,11 @@ for _kv in filter(None, os.environ.get("PET_FUZZ_SET", "").split(",")):  # e.g. 
 seed0, ntrial = int(sys.argv[1]), int(sys.argv[2])
 types = [1, 6, 7, 8]
 bad = 0
+only = os.environ.get("PET_FUZZ_ONLY")            # run this trial index only
+dhead_override = os.environ.get("PET_FUZZ_DHEAD")  # ... with this d_head instead of the drawn one (debugging)
 for trial in range(ntrial):
+    if only is not None and trial != int(only):
+        continue
     rng = np.random.default_rng(seed0 * 1000 + trial)
     heads = int(rng.choice([1, 1, 2, 4, 8]))
     hd = int(rng.choice([1, 2, 3, 4, 8, 16, 20]))
@@ -34,6 +38,8 @@ for trial in range(ntrial):
               cutoff_function=str(rng.choice(["Bump", "Cosine"])), cutoff=float(rng.choice([3.5, 4.5, 5.5])),
               cutoff_width=float(rng.choice([0.2, 0.5, 1.0])), attention_temperature=float(rng.choice([0.5, 1.0, 2.0])),
               system_conditioning=bool(rng.random() < 0.35))
+    if dhead_override:
+        hy["d_head"] = int(dhead_override)
     adaptive = rng.random() < 0.3
     if adaptive:
         hy.update(num_neighbors_adaptive=float(rng.choice([4.0, 8.0])), adaptive_cutoff_method=str(rng.choice(["solver", "grid"])))
@@ -95,7 +101,7 @@ for trial in range(ntrial):
             err = float((got.cpu().double() - ref).abs().max()) / (sc if sc > 1e-12 else 1.0)
             if not err < tol:
                 e32 = float((ref32.double() - ref).abs().max()) / (sc if sc > 1e-12 else 1.0)
-                msgs.append(f"{name} {err:.2e} (torch fp32 {e32:.2e})")
+                msgs.append(f"{name} {err:.2e} (torch fp32 {e32:.2e}; max|ref| {sc:.3e}, numel {ref.numel()})")
                 if err > 5 * max(e32, 2e-6):
                     nonlocal_bad = 1
             return nonlocal_bad
