@@ -634,7 +634,12 @@ __global__ __launch_bounds__(256) void k_soap_ps_m(SoapDims d, const float* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wave;
     if (i >= N) return;
-    float* cs = smem + (size_t)wave * d.NCOEF;
+    // PACKED: behind the coefficients a staging tile for one l block's triangle (528 floats for nc = 32): the triangle's rows are
+    // nc - p1 floats long, so storing them from the accumulator layout is 16 partial-line store instructions per block; through
+    // the tile the block leaves as whole 8-byte-per-lane stores (every block starts at an even float: nc is a multiple of C = 4)
+    const int stg_len = PACKED ? (d.ncmax * (d.ncmax + 1) / 2 + 3) & ~3 : 0;
+    float* cs = smem + (size_t)wave * (d.NCOEF + stg_len);
+    float* stg = cs + d.NCOEF;
     for (int k = lane; k < d.NCOEF; k += 64) cs[k] = Cf[(size_t)i * d.NCOEF + k];
     __builtin_amdgcn_wave_barrier();
     const float* e = enc ? enc + (size_t)sp[i] * d.S : nullptr;
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(256) void k_soap_ps_m(SoapDims d, const float* __re
                 if (PACKED) {
                     if (p1 <= a) {  // row p1 of the triangle: nc - p1 consecutive floats across the lanes
                         const float v = acc[r];
-                        out[d.pfeat_off[l] + soap_tri(nc, p1, a)] = v;
+                        stg[soap_tri(nc, p1, a)] = v;
                         const double wv = p1 == a ? (double)v : 2.0 * (double)v;
                         s1 += wv;
                         s2 += wv * (double)v;
@@ -682,6 +687,13 @@ __global__ __launch_bounds__(256) void k_soap_ps_m(SoapDims d, const float* __re
                     s2 += (double)v * (double)v;
                 }
             }
+        }
+        if (PACKED) {
+            __builtin_amdgcn_wave_barrier();
+            const int n2 = nc * (nc + 1) / 4;  // float2 per block (nc (nc + 1) / 2 is even)
+            float2* dst = reinterpret_cast<float2*>(out + d.pfeat_off[l]);
+            for (int k = lane; k < n2; k += 64) dst[k] = reinterpret_cast<const float2*>(stg)[k];
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if (!d.layernorm) return;
@@ -747,6 +759,8 @@ __global__ __launch_bounds__(256) void k_soap_ps_bwd_m(SoapDims d, const float* 
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
+    // (collecting the result in LDS and storing it as whole lines behind a workgroup barrier was measured in round 6: 0.63 against
+    // 0.56 ms -- the four waves' own 64-byte row pieces overlap with the slower waves' products)
     float* out = dCf + (size_t)i * d.NCOEF;
     for (int l = wave; l <= d.L; l += 4) {
         const int nc = d.n_per_l[l] * d.C, M = 2 * l + 1;
@@ -796,6 +810,7 @@ __global__ __launch_bounds__(256) void k_soap_ps_bwd_m(SoapDims d, const float* 
             }
     }
 }
+
 
 // (The first-generation fused power-spectrum + tail kernels -- k_soap_ps_tail_fwd / _bwd behind pet_config_set("soap_fused", 1):
 // features never stored, but 4.3 + 7.0 ms against 0.5 + 0.6 + 0.9 + 0.7 for the separate kernels -- were removed in round 6:
@@ -1717,6 +1732,10 @@ static bool soap_sorted_ok(const SoapModel& m) {
 static int g_soap_packed = 1;
 void set_soap_packed(int v) { g_soap_packed = v ? 1 : 0; }
 static bool soap_packed_ok(const SoapModel& m) {
+    for (int l = 0; l <= m.d.L; l++) {  // every block's triangle an even number of floats (k_soap_ps_m<true> stores 8 bytes per lane)
+        const int nc = m.d.n_per_l[l] * m.d.C;
+        if ((nc * (nc + 1) / 2) % 2) return false;
+    }
     return g_soap_packed && g_soap_pair && g_soap_ps_mfma && m.enc == nullptr && m.wallp_fwd_set != nullptr &&
            m.d.ncmax <= 32 && (size_t)(m.d.NCOEF + m.d.Sp) * 4 <= 64 * 1024;
 }
@@ -1766,8 +1785,9 @@ static int soap_fwd(const SoapModel& m, const Graph& g, void* ws, int64_t ws_byt
     {
             ProfScope ps("soap_ps", st, 2.0 * (double)N * d.S * (d.L + 1), (double)N * (d.NCOEF + (packed ? d.Sp : d.S)) * 4);
             if (packed) {
-                allow_big_lds(k_soap_ps_m<true>, (size_t)4 * d.NCOEF * 4);
-                k_soap_ps_m<true><<<cdiv(N, 4), 256, (size_t)4 * d.NCOEF * 4, st>>>(d, w.Cf, g.sp, nullptr, w.feats, w.tail, N);
+                const size_t lds_ps = (size_t)4 * (d.NCOEF + ((d.ncmax * (d.ncmax + 1) / 2 + 3) & ~3)) * 4;
+                allow_big_lds(k_soap_ps_m<true>, lds_ps);
+                k_soap_ps_m<true><<<cdiv(N, 4), 256, lds_ps, st>>>(d, w.Cf, g.sp, nullptr, w.feats, w.tail, N);
             } else if (g_soap_pair && g_soap_ps_mfma && d.ncmax <= 32) {
                 allow_big_lds(k_soap_ps_m<false>, (size_t)4 * d.NCOEF * 4);
                 k_soap_ps_m<false><<<cdiv(N, 4), 256, (size_t)4 * d.NCOEF * 4, st>>>(d, w.Cf, g.sp, m.enc, w.feats, w.tail, N);
