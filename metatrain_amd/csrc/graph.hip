@@ -8,10 +8,65 @@
 #include "model.h"
 #include "cutoff.h"
 
+#include <atomic>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
 namespace pet {
+
+// ----------------------------------------------------------------------------------
+// A few device integers to the host, on the critical path of a small box's step (the graph build cannot size its launches
+// before it knows the kept edge count; the neighbour list cannot return before it knows the pair count). hipMemcpyAsync to
+// a stack variable + hipStreamSynchronize costs 27 us per read-back on this stack (pageable destination; 16 us into pinned
+// memory); a one-wave kernel that writes the values and then a sequence word into coherent pinned host memory that the host
+// polls costs under 10 us, launch included (tools/debug/readback_latency.hip). One mailbox per host thread.
+// ----------------------------------------------------------------------------------
+__global__ void k_publish(const int* __restrict__ a, int na, const int* __restrict__ b, int nb, volatile int* host, int seq) {
+    const int t = threadIdx.x;
+    if (t < na) host[t] = a[t];
+    else if (t < na + nb) host[t] = b[t - na];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) host[MAILBOX_INTS - 1] = seq;
+}
+
+namespace {
+struct Mailbox {
+    int* p = nullptr;
+    int seq = 0;
+    ~Mailbox() { if (p) (void)hipHostFree(p); }
+};
+thread_local Mailbox t_mailbox;
+}  // namespace
+
+int read_back(const int* d_a, int na, const int* d_b, int nb, int* out, hipStream_t st) {
+    PET_REQUIRE(na >= 0 && nb >= 0 && na + nb <= MAILBOX_INTS - 1, PET_ERR_ARGUMENT, "read_back: too many integers");
+    Mailbox& mb = t_mailbox;
+    if (!mb.p) {
+        PET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&mb.p), MAILBOX_INTS * sizeof(int),
+                                    hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable));
+        std::memset(mb.p, 0, MAILBOX_INTS * sizeof(int));
+    }
+    const int seq = ++mb.seq == 0 ? ++mb.seq : mb.seq;  // 0 is the word's initial value
+    k_publish<<<1, MAILBOX_INTS, 0, st>>>(d_a, na, d_b, nb, mb.p, seq);
+    PET_HIP_CHECK(hipGetLastError());
+    for (uint64_t spins = 1;; spins++) {
+        if (__atomic_load_n(&mb.p[MAILBOX_INTS - 1], __ATOMIC_ACQUIRE) == seq) break;
+        __builtin_ia32_pause();
+        if ((spins & 0x3FFFF) == 0) {  // every few ms: a stream that failed, or drained without the word (not seen so far), ends the wait
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) {
+                PET_HIP_CHECK(hipStreamSynchronize(st));
+                PET_REQUIRE(__atomic_load_n(&mb.p[MAILBOX_INTS - 1], __ATOMIC_ACQUIRE) == seq, PET_ERR_HIP,
+                            "read_back: the stream drained without the mailbox word arriving");
+                break;
+            }
+            if (q != hipErrorNotReady) PET_HIP_CHECK(q);
+        }
+    }
+    for (int k = 0; k < na + nb; k++) out[k] = mb.p[k];
+    return PET_OK;
+}
 
 // ----------------------------------------------------------------------------------
 // adaptive cutoff (pet/modules/adaptive_cutoff.py:46-229, "solver" method)
@@ -247,11 +302,15 @@ __global__ void k_edge_geometry(const float* __restrict__ pos, const float* __re
 }
 
 // rowptr[i] = first sorted position whose key >= i
+// veto (graph_build, a list ASSUMED to be sorted): if the word is set the keys are not sorted after all -- every row is left
+// empty, so that the kernels behind this one (which take their counts from rowptr / scalars[0]) touch nothing before the host
+// sees the word and builds again with the sort
 __global__ void k_rowptr(const int* __restrict__ sorted_keys, int n_edges, int* __restrict__ rowptr,
-                         int n_nodes, int* __restrict__ scalars) {
+                         int n_nodes, int* __restrict__ scalars, const int* __restrict__ veto = nullptr) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_nodes) return;
     int lo = 0, hi = n_edges;
+    if (veto && *veto) hi = 0;
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
         if (sorted_keys[mid] < i) lo = mid + 1; else hi = mid;
@@ -724,18 +783,25 @@ int graph_attention_lists(const Graph& gc, hipStream_t st) {
     if (g.attn_lists || g.n_nodes <= 0) return PET_OK;
     if (int rcb = bucket_atoms_by_tile_count(g, st)) return rcb;
     int host_scalars[57] = {0};
-    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 57 * sizeof(int), hipMemcpyDeviceToHost, st));
-    PET_HIP_CHECK(hipStreamSynchronize(st));
+    if (int rcr = read_back(g.scalars, 57, nullptr, 0, host_scalars, st)) return rcr;
     set_bucket_starts(g, host_scalars + 8);
     if (int rcp = plan_attention_tiles(g, host_scalars + 24, st)) return rcp;
     g.attn_lists = true;
     return PET_OK;
 }
 
-int graph_build(const Model& m, const float* pos, const float* cells, const int* centers,
-                const int* neighbors, const int* shifts, const int* species, const int* sys,
-                int64_t n_nodes, int64_t e0, int64_t n_systems, void* ws, int64_t ws_bytes,
-                Graph& g, hipStream_t st) {
+// The sorted shortcut (below) needs to know whether the list is ordered by centre before it can skip the sort: asked of the
+// device that is a read-back in the middle of the build. A molecular-dynamics driver hands over a list of the same kind
+// every step, so the build ASSUMES what the previous build found: "sorted" skips the sort unasked, and the build's one
+// read-back at the end carries the word that says whether that was right (if not: k_rowptr has left the graph empty, and
+// the build runs again with the sort); "unsorted" sorts unasked, which is right for either kind of list.
+enum SortMode { SORT_ASK, SORT_ALWAYS, SORT_ASSUME_SORTED };
+static std::atomic<int> g_list_was_sorted{-1};  // the previous build's list (-1: no build yet)
+
+static int graph_build_once(const Model& m, const float* pos, const float* cells, const int* centers,
+                            const int* neighbors, const int* shifts, const int* species, const int* sys,
+                            int64_t n_nodes, int64_t e0, int64_t n_systems, void* ws, int64_t ws_bytes,
+                            Graph& g, hipStream_t st, SortMode mode, bool* wrong_guess) {
     size_t need = 0;
     int rc = carve_graph(g, ws, n_nodes, e0 > 0 ? e0 : 1, &need);
     if (rc != PET_OK) return rc;
@@ -790,10 +856,11 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
         // a list that is already ordered by centre with no edge to drop (k_edge_geometry) needs no sort: one 4-byte
         // read-back (the build ends with one anyway) against three radix passes over the edges
         int unsorted = 1;
-        if (!g.adaptive && g_sorted_shortcut) {
-            PET_HIP_CHECK(hipMemcpyAsync(&unsorted, g.scalars + 60, sizeof(int), hipMemcpyDeviceToHost, st));
-            PET_HIP_CHECK(hipStreamSynchronize(st));
-        }
+        if (g.adaptive || !g_sorted_shortcut) mode = SORT_ALWAYS;
+        if (mode == SORT_ASK) {
+            if (int rcr = read_back(g.scalars + 60, 1, nullptr, 0, &unsorted, st)) return rcr;
+        } else if (mode == SORT_ASSUME_SORTED)
+            unsorted = 0;
         if (unsorted) {
             PET_HIP_CHECK(rocprim::radix_sort_pairs(g.sort_tmp, sb, g.sort_keys_in, g.sort_keys_out,
                                                     g.sort_vals_in, g.perm, (size_t)e0, 0,
@@ -805,8 +872,8 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
         PET_HIP_CHECK(rocprim::exclusive_scan(g.scan_tmp, cb, g.keep, g.kidx, 0, (size_t)e0,
                                               rocprim::plus<int>(), st));
     }
-    k_rowptr<<<cdiv(n_nodes + 1, T), T, 0, st>>>(sorted_keys, (int)e0, g.rowptr, (int)n_nodes,
-                                                 g.scalars);
+    k_rowptr<<<cdiv(n_nodes + 1, T), T, 0, st>>>(sorted_keys, (int)e0, g.rowptr, (int)n_nodes, g.scalars,
+                                                 e0 > 0 && mode == SORT_ASSUME_SORTED ? g.scalars + 60 : nullptr);
     if (n_nodes > 0) k_max_nbr<<<cdiv(n_nodes, T), T, 0, st>>>(g.rowptr, (int)n_nodes, g.scalars);
     if (e0 > 0) {
         // sized by the input edge count; the kernels read the kept count from the device (scalars[0]), so the whole
@@ -824,9 +891,15 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
     g.attn_lists = m.finalized;
     if (g.attn_lists)
         if (int rcb = bucket_atoms_by_tile_count(g, st)) return rcb;
-    int host_scalars[57] = {0};
-    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 57 * sizeof(int), hipMemcpyDeviceToHost, st));
-    PET_HIP_CHECK(hipStreamSynchronize(st));
+    int host_scalars[61] = {0};
+    if (int rcr = read_back(g.scalars, 61, nullptr, 0, host_scalars, st)) return rcr;
+    if (e0 > 0 && !g.adaptive && g_sorted_shortcut) {
+        g_list_was_sorted.store(host_scalars[60] ? 0 : 1, std::memory_order_relaxed);
+        if (mode == SORT_ASSUME_SORTED && host_scalars[60]) {
+            *wrong_guess = true;
+            return PET_OK;
+        }
+    }
     g.n_edges = host_scalars[0];
     g.max_nbr = host_scalars[1];
     if (g.attn_lists) {
@@ -848,10 +921,24 @@ int graph_build(const Model& m, const float* pos, const float* cells, const int*
     return PET_OK;
 }
 
+int graph_build(const Model& m, const float* pos, const float* cells, const int* centers,
+                const int* neighbors, const int* shifts, const int* species, const int* sys,
+                int64_t n_nodes, int64_t e0, int64_t n_systems, void* ws, int64_t ws_bytes,
+                Graph& g, hipStream_t st) {
+    const int last = g_list_was_sorted.load(std::memory_order_relaxed);
+    const SortMode mode = last < 0 ? SORT_ASK : last ? SORT_ASSUME_SORTED : SORT_ALWAYS;
+    bool wrong_guess = false;
+    int rc = graph_build_once(m, pos, cells, centers, neighbors, shifts, species, sys, n_nodes, e0, n_systems, ws, ws_bytes,
+                              g, st, mode, &wrong_guess);
+    if (rc == PET_OK && wrong_guess)
+        rc = graph_build_once(m, pos, cells, centers, neighbors, shifts, species, sys, n_nodes, e0, n_systems, ws, ws_bytes,
+                              g, st, SORT_ALWAYS, &wrong_guess);
+    return rc;
+}
+
 int graph_check_reverse(Graph& g, hipStream_t st) {
     int bad = 0;
-    PET_HIP_CHECK(hipMemcpyAsync(&bad, g.scalars + 2, sizeof(int), hipMemcpyDeviceToHost, st));
-    PET_HIP_CHECK(hipStreamSynchronize(st));
+    if (int rcr = read_back(g.scalars + 2, 1, nullptr, 0, &bad, st)) return rcr;
     PET_REQUIRE(bad == 0, PET_ERR_GRAPH,
                 "neighbour list is not a full list: " + std::to_string(bad) +
                     " edges have no reverse edge (j, i, -S)");
@@ -868,8 +955,7 @@ int graph_export(const Graph& g, float cutoff, int64_t* el_nodes, int64_t* el_nb
     int64_t cells = g.n_nodes * (int64_t)g.max_nbr;
     if (cells > 0) {
         int pad_src = -1;
-        PET_HIP_CHECK(hipMemcpyAsync(&pad_src, g.scalars + 3, sizeof(int), hipMemcpyDeviceToHost, st));
-        PET_HIP_CHECK(hipStreamSynchronize(st));
+        if (int rcr = read_back(g.scalars + 3, 1, nullptr, 0, &pad_src, st)) return rcr;
         k_export_nef<<<cdiv(cells, T), T, 0, st>>>(g.rowptr, g.nbr, g.rev, g.sp_nbr, g.geo, g.fc, g.perm,
                                                    g.kidx, el_nbr, ev, ed, mask, rni, cf, (int)g.n_nodes,
                                                    g.max_nbr, pad_src);
@@ -998,12 +1084,9 @@ int graph_from_batch(const int64_t* el_nodes, const int64_t* el_nbr, const float
                                                           g.nbr, g.rev, g.sp, g.sp_nbr, g.geo, g.fc, g.scalars);
     g.attn_lists = true;
     if (int rcb = bucket_atoms_by_tile_count(g, st)) return rcb;
-    int host_scalars[57] = {0};
-    int n_edges = 0;
-    PET_HIP_CHECK(hipMemcpyAsync(host_scalars, g.scalars, 57 * sizeof(int), hipMemcpyDeviceToHost, st));
-    PET_HIP_CHECK(hipMemcpyAsync(&n_edges, g.rowptr + n_nodes, sizeof(int), hipMemcpyDeviceToHost, st));
-    PET_HIP_CHECK(hipStreamSynchronize(st));
-    g.n_edges = n_edges;
+    int host_scalars[58] = {0};
+    if (int rcr = read_back(g.scalars, 57, g.rowptr + n_nodes, 1, host_scalars, st)) return rcr;
+    g.n_edges = host_scalars[57];
     g.max_nbr = host_scalars[1];
     set_bucket_starts(g, host_scalars + 8);
     if (int rcp = plan_attention_tiles(g, host_scalars + 24, st)) return rcp;

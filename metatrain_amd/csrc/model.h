@@ -137,6 +137,10 @@ int tie_halves(Model& m, const std::string& key);
 int optimizer_state(Model& m, float* d_m, float* d_v, int64_t numel, int direction, hipStream_t st);
 
 // graph.hip
+// na + nb <= MAILBOX_INTS - 1 device integers (two sources, either may be empty) to `out` on the host, ordered after
+// everything issued on `st` so far: a one-wave kernel into the calling thread's pinned mailbox, which the host polls
+constexpr int MAILBOX_INTS = 64;
+int read_back(const int* d_a, int na, const int* d_b, int nb, int* out, hipStream_t st);
 int64_t graph_workspace_bytes(int64_t n_nodes, int64_t e0);
 int graph_attention_lists(const Graph& g, hipStream_t st);  // graph.hip: lazily, for a graph built before pet_model_finalize
 int graph_build(const Model& m, const float* pos, const float* cells, const int* centers,

@@ -468,8 +468,12 @@ int nl_build_batch(const float* d_pos, const float* h_cells, const int* h_pbc, c
         PET_HIP_CHECK(hipMemcpyAsync(w.prms, prm.data(), n_sys * sizeof(NlParams), hipMemcpyHostToDevice, st));
         k_nlb_bbox<<<cdiv(n, T), T, 0, st>>>(d_pos, (int)n, w.prms, w.first_atom, (int)n_sys, w.bbox);
         std::vector<int> enc(6 * n_sys);
-        PET_HIP_CHECK(hipMemcpyAsync(enc.data(), w.bbox, enc.size() * sizeof(int), hipMemcpyDeviceToHost, st));
-        PET_HIP_CHECK(hipStreamSynchronize(st));
+        if ((int)enc.size() < MAILBOX_INTS) {
+            if (int rcr = read_back(w.bbox, (int)enc.size(), nullptr, 0, enc.data(), st)) return rcr;
+        } else {
+            PET_HIP_CHECK(hipMemcpyAsync(enc.data(), w.bbox, enc.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+            PET_HIP_CHECK(hipStreamSynchronize(st));
+        }
         for (size_t k = 0; k < enc.size(); k++) h_bbox[k] = unord_f(enc[k]);
     }
     int64_t total_bins = 0;
@@ -499,11 +503,8 @@ int nl_build_batch(const float* d_pos, const float* h_cells, const int* h_pbc, c
                                                         (int)total_bins, w.counts, nullptr, nullptr, nullptr);
     tb = w.tmp_bytes;
     PET_HIP_CHECK(rocprim::exclusive_scan(w.tmp, tb, w.counts, w.offsets, 0, (size_t)n + 1, rocprim::plus<int>(), st));
-    if (d_pairs)  // optimistic: fill straight away (rows beyond `capacity` are never written: checked below)
-        ;
     int total = 0;
-    PET_HIP_CHECK(hipMemcpyAsync(&total, w.offsets + n, sizeof(int), hipMemcpyDeviceToHost, st));
-    PET_HIP_CHECK(hipStreamSynchronize(st));
+    if (int rcr = read_back(w.offsets + n, 1, nullptr, 0, &total, st)) return rcr;
     *n_pairs = total;
     if (!d_pairs) return PET_OK;
     PET_REQUIRE(capacity >= total, PET_ERR_ARGUMENT,

@@ -429,8 +429,12 @@ def test_rotation_and_permutation_consistency(rt, model, dev):
 
 
 def test_edge_order_and_the_sort_shortcut(rt, model, dev, golden_dir):
-    """``pet_graph_build`` skips the radix sort of the edges when the list arrives ordered by centre with nothing to drop
-    (one 4-byte read-back decides). The reference list of the 1 000-atom box is ordered: with the shortcut and with
+    """``pet_graph_build`` skips the radix sort of the edges when the list arrives ordered by centre with nothing to drop.
+    The first build of a process asks the device (a 4-byte read-back); later builds assume what the build before them found
+    and learn from their final read-back whether that was right -- a wrong "sorted" guess leaves the graph empty on the
+    device and builds again with the sort. The calls below walk through every transition: sorted after sorted (guess
+    right), shuffled after sorted (guess wrong, rebuilt), sorted after shuffled (sorted although it need not be), sorted
+    again (guess right). The reference list of the 1 000-atom box is ordered: with the shortcut and with
     ``sorted_shortcut = 0`` the results are bit-identical (the stable sort is the identity); the same list shuffled, and
     with 40 edges beyond the cutoff appended (dropped by the non-strict filter), takes the sort and must meet the same bar
     against the reference golden."""
@@ -468,6 +472,13 @@ def test_edge_order_and_the_sort_shortcut(rt, model, dev, golden_dir):
     assert int(graph2.n_edges) == n_e
     assert relmax(a2.cpu().numpy(), g["atomic_f64"].ravel()) < TOL and relmax(g2.cpu().numpy(), g["grad_f64"]) < TOL
     assert relmax(a2.cpu().numpy(), a1.cpu().numpy()) < 2e-6
+    for _ in range(2):  # the sorted list again: through the sort (the guess is now "unsorted"), then through the shortcut
+        a3, g3, graph3 = run(t("in_centers"), t("in_neighbors"), t("in_cell_shifts"))
+        assert torch.equal(a3, a1) and torch.equal(g3, g1)
+        for k in ("rowptr", "nbr", "rev"):
+            assert torch.equal(graph3.csr()[k], graph1.csr()[k]), k
+    a4, g4, graph4 = run(i[perm].to(dev), j[perm].to(dev), s[perm].to(dev))  # and the wrong guess once more
+    assert int(graph4.n_edges) == n_e and torch.equal(a4, a2) and torch.equal(g4, g2)
 
 
 @pytest.mark.parametrize("drop", ["i<j", "i>j"])
