@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libpet_hip.so")
-SOURCES = ["abi.hip", "graph.hip", "nl.hip", "pet_fwd.hip", "pet_bwd.hip", "pet_trr.hip", "pet_attn.hip", "pet_ablk.hip", "pet_ablk_bwd1.hip", "pet_emlp_s.hip", "pet_head_s.hip", "pet_compress_s.hip", "pet_center_s.hip", "pet_comb.hip", "pet_comb_s.hip", "pet_comb_bwd.hip", "train.hip", "optim.hip", "so.hip", "soap.hip", "gen.hip", "gen_train.hip"]
+SOURCES = ["abi.hip", "graph.hip", "nl.hip", "pet_fwd.hip", "pet_bwd.hip", "pet_trr.hip", "pet_attn.hip", "pet_ablk.hip", "pet_ablk_bwd1.hip", "pet_emlp_s.hip", "pet_head_s.hip", "pet_compress_s.hip", "pet_center_s.hip", "pet_comb.hip", "pet_comb_s.hip", "pet_comb_bwd.hip", "train.hip", "optim.hip", "so.hip", "so_rows_s.hip", "soap.hip", "gen.hip", "gen_train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc"]
 FLAGS += os.environ.get("PET_HIP_EXTRA_FLAGS", "").split()  # debugging builds, e.g. -DAB_PROFILE (pet_ablk.hip)
 # Translation units compiled on their own (no -fgpu-rdc: their device code is generated here, not at the link step) with the

@@ -304,6 +304,8 @@ int finalize(Model& m, hipStream_t st) {
             if (m.layer_norm() && (rc = get(m, lp + ".norm_center_features.bias", DN, &A.b_center))) return rc;
             if ((rc = get_lin(m, lp + ".center_mlp.w_in", 2 * DNF, DN, A.cmlp_in, st))) return rc;
             if ((rc = get_lin(m, lp + ".center_mlp.w_out", DN, DNF, A.cmlp_out, st))) return rc;
+            if ((rc = pack_lin_s(m, lp + ".center_mlp.w_in", A.cmlp_in, st))) return rc;  // k_rowgemm_s (so_rows_s.hip)
+            if ((rc = pack_lin_s(m, lp + ".center_mlp.w_out", A.cmlp_out, st))) return rc;
         }
         // ---- compress.0 decomposition (transformer.py:499-521) -------------------
         // tokens = [edge_embedder([v, d]) ; (g>0: neighbor_embedder[species]) ; message]
@@ -362,6 +364,7 @@ int finalize(Model& m, hipStream_t st) {
         if ((rc = get_lin(m, "combination_mlps." + gs + ".2", D, 2 * D, G.comb2, st))) return rc;
         if ((rc = fold_norm_s(m, "combination_mlps." + gs + ".0", G.comb0, G.ln_g, G.ln_b, G.comb0_g, st))) return rc;  // k_comb_s
         if ((rc = pack_lin_s(m, "combination_mlps." + gs + ".2", G.comb2, st))) return rc;
+        if ((rc = pack_lin_s(m, "combination_mlps." + gs + ".0", G.comb0, st))) return rc;  // k_rowgemm_s (so_rows_s.hip)
     }
     m.node_embs.assign(m.residual() ? h.num_gnn_layers : 1, nullptr);  // backend.py:93-119: one per readout layer
     for (size_t l = 0; l < m.node_embs.size(); l++)

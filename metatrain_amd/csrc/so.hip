@@ -410,7 +410,9 @@ static void mm_fwd(const Ctx& c, const Lin& L, const float* X, float* Y, int64_t
                    bool acc = false) {
     if (R <= 0) return;
     ProfScope ps("so_gemm", c.st, 2.0 * (double)R * L.k_in * L.n_out, 4.0 * (double)R * (L.k_in + L.n_out));
-    if (g_so_f16x3 && L.fwd2 &&
+    if (g_so_f16x3 && !g_train_bf16 && g_so_trr &&
+        rowgemm_s(c.st, X, L.k_in, cs, L.fwd2s, bias ? L.b : nullptr, Y, L.n_out, R, acc)) {  // large row counts (so_rows_s.hip)
+    } else if (g_so_f16x3 && L.fwd2 &&
         rowgemm_trr(c.st, X, L.k_in, cs, w2_at(L.fwd2, L.n_out, L.k_in), bias ? L.b : nullptr, Y, L.n_out, R, acc)) {
     } else if (g_so_f16x3 && L.fwd2)
         k_gemm_h<<<cdiv(R, BM), NTHREADS, 2 * BM * LDB16 * 2 + BM * 4, c.st>>>(X, L.k_in, L.k_in, cs,
@@ -425,7 +427,8 @@ static void mm_fwd(const Ctx& c, const Lin& L, const float* X, float* Y, int64_t
 static void mm_bwd(const Ctx& c, const Lin& L, const float* Yadj, float* Xadj, int64_t R, bool acc = false) {
     if (R <= 0) return;
     ProfScope ps("so_gemm", c.st, 2.0 * (double)R * L.k_in * L.n_out, 4.0 * (double)R * (L.k_in + L.n_out));
-    if (g_so_f16x3 && L.bwd2 &&
+    if (g_so_f16x3 && !g_train_bf16 && g_so_trr && rowgemm_s(c.st, Yadj, L.n_out, nullptr, L.bwd2s, nullptr, Xadj, L.k_in, R, acc)) {
+    } else if (g_so_f16x3 && L.bwd2 &&
         rowgemm_trr(c.st, Yadj, L.n_out, nullptr, w2_at(L.bwd2, L.k_in, L.n_out), nullptr, Xadj, L.k_in, R, acc)) {
     } else if (g_so_f16x3 && L.bwd2)  // the transposed operand: tiles over k_in, K = n_out
         k_gemm_h<<<cdiv(R, BM), NTHREADS, 2 * BM * LDB16 * 2 + BM * 4, c.st>>>(Yadj, L.n_out, L.n_out, nullptr,

@@ -190,16 +190,20 @@ def _oracle_second_order(params, hypers, inp, nu, u):
     return {k: (torch.zeros_like(p64[k]) if gr is None else gr) for k, gr in zip(keys, grads)}, tan, g.detach()
 
 
-@pytest.mark.parametrize("case,so_trr,wgrad_bf16", [("pet_default_box64.npz", 1, 1), ("batch_two_systems.npz", 1, 1),
-                                                    ("batch_two_systems.npz", 0, 1), ("batch_two_systems.npz", 1, 0)])
-def test_force_loss_parameter_gradients_match_oracle_double_backward(golden_dir, case, so_trr, wgrad_bf16):
+@pytest.mark.parametrize("case,so_trr,wgrad_bf16,emlp_s", [("pet_default_box64.npz", 1, 1, 1), ("batch_two_systems.npz", 1, 1, 1),
+                                                           ("batch_two_systems.npz", 0, 1, 1), ("batch_two_systems.npz", 1, 0, 1),
+                                                           ("pet_default_box64.npz", 1, 1, 2), ("batch_two_systems.npz", 1, 1, 2)])
+def test_force_loss_parameter_gradients_match_oracle_double_backward(golden_dir, case, so_trr, wgrad_bf16, emlp_s):
     """The second-order pass (loss on dE/dR) against torch's double backward through the fp64 oracle; with the
-    generic GEMMs on the TRR kernels (default) and on the LDS-tile kernel (so_trr = 0), and with the weight-gradient
-    GEMMs as bf16x3 products (default) and on the fp32 MFMA (wgrad_bf16 = 0)."""
+    generic GEMMs on the TRR kernels (the default for graphs of this size), on the LDS-tile kernel (so_trr = 0) and on the
+    shared-ring kernel that serves large row counts (so_rows_s.hip: emlp_s = 2 sends these small graphs there -- every shape
+    of the pass, both orientations, with and without bias / column scales / accumulation, partial last tiles), and with the
+    weight-gradient GEMMs as bf16x3 products (default) and on the fp32 MFMA (wgrad_bf16 = 0)."""
     from metatrain_amd import runtime as rt
 
     rt.config_set("so_trr", so_trr)
     rt.config_set("wgrad_bf16", wgrad_bf16)
+    rt.config_set("emlp_s", emlp_s)
     dev = torch.device("cuda:0")
     hypers = dict(opet.DEFAULT_HYPERS)
     types = [1, 6, 7, 8]
@@ -238,6 +242,7 @@ def test_force_loss_parameter_gradients_match_oracle_double_backward(golden_dir,
         print(f"{v:.3e}  {k}")
     rt.config_set("so_trr", 1)
     rt.config_set("wgrad_bf16", 1)
+    rt.config_set("emlp_s", 1)
     bad = {k: v for k, v in worst.items() if not v < TOL}  # measured worst 6e-6
     assert not bad, f"second-order parameter gradients off: {bad}"
 
@@ -659,9 +664,10 @@ def _oracle_param_grads_cond(params, hypers, inp, seed_w):
     return {k: (torch.zeros_like(p64[k]) if g is None else g) for k, g in zip(keys, grads)}
 
 
-@pytest.mark.parametrize("activation,wgrad_bf16,trr", [("SwiGLU", 1, 1), ("SiLU", 1, 1), ("SwiGLU", 0, 1), ("SiLU", 0, 0),
-                                                       ("SwiGLU", 1, 0)])
-def test_training_gradients_of_a_layernorm_model(golden_dir, activation, wgrad_bf16, trr):
+@pytest.mark.parametrize("activation,wgrad_bf16,trr,emlp_s", [("SwiGLU", 1, 1, 1), ("SiLU", 1, 1, 1), ("SwiGLU", 0, 1, 1),
+                                                              ("SiLU", 0, 0, 1), ("SwiGLU", 1, 0, 1), ("SwiGLU", 1, 1, 2),
+                                                              ("SiLU", 1, 1, 2)])
+def test_training_gradients_of_a_layernorm_model(golden_dir, activation, wgrad_bf16, trr, emlp_s):
     """normalization = LayerNorm (modules/transformer.py:181-186, PreLN, feed-forward featuriser): the energy-loss and the
     force-loss parameter gradients -- norm weights AND biases -- against autograd / double backward through the fp64
     oracle. LayerNorm-hat is the RMSNorm-hat of the centred row, which is how the second-order kernels compute it. With
@@ -687,6 +693,7 @@ def test_training_gradients_of_a_layernorm_model(golden_dir, activation, wgrad_b
 
     rt.config_set("wgrad_bf16", wgrad_bf16)
     rt.config_set("trr", trr)
+    rt.config_set("emlp_s", emlp_s)  # 2: the row kernels with the shared weight ring (so_rows_s.hip among them) on this small graph
     try:
         model = rt.HipModel(hypers, types)
         model.load({k: v.to(dev) for k, v in params.items()}, "energy")
@@ -707,6 +714,7 @@ def test_training_gradients_of_a_layernorm_model(golden_dir, activation, wgrad_b
     finally:
         rt.config_set("wgrad_bf16", 1)
         rt.config_set("trr", 1)
+        rt.config_set("emlp_s", 1)
     assert np.abs(tan.cpu().numpy() - tan_ref.numpy()).max() / np.abs(tan_ref.numpy()).max() < TOL
     for name, ref, got in (("energy loss", ref1, got1), ("force loss", ref2, got2)):
         assert set(got) == set(ref)
