@@ -19,7 +19,7 @@ namespace pet {
 // before it knows the kept edge count; the neighbour list cannot return before it knows the pair count). hipMemcpyAsync to
 // a stack variable + hipStreamSynchronize costs 27 us per read-back on this stack (pageable destination; 16 us into pinned
 // memory); a one-wave kernel that writes the values and then a sequence word into coherent pinned host memory that the host
-// polls costs under 10 us, launch included (tools/debug/readback_latency.hip). One mailbox per host thread.
+// polls costs under 10 us, launch included (tools/ubench/readback_latency.hip). One mailbox per host thread.
 // ----------------------------------------------------------------------------------
 __global__ void k_publish(const int* __restrict__ a, int na, const int* __restrict__ b, int nb, volatile int* host, int seq) {
     const int t = threadIdx.x;

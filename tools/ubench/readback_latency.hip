@@ -1,6 +1,6 @@
 // Host read-back of a few device integers after a kernel: hipMemcpyAsync + hipStreamSynchronize against a kernel that
 // writes them to coherent pinned host memory and a host that polls a sequence word. Build + run:
-//   hipcc --offload-arch=gfx950 -O2 tools/debug/readback_latency.hip -o /tmp/readback_latency && /tmp/readback_latency
+//   hipcc --offload-arch=gfx950 -O2 tools/ubench/readback_latency.hip -o tools/ubench/readback_latency && tools/ubench/readback_latency
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
