@@ -62,7 +62,7 @@ def cpu_baseline(hypers, params, n=1000):
 
 
 
-TRAIN_STAGE_KERNELS = {"so_gemm": ("k_rowgemm_n128", "k_rowgemm_k128", "k_gemm_h"), "wgrad": ("k_wgrad_b", "k_wgrad<"),
+TRAIN_STAGE_KERNELS = {"so_gemm": ("k_rowgemm_s", "k_rowgemm_n128", "k_rowgemm_k128", "k_gemm_h"), "wgrad": ("k_wgrad_b", "k_wgrad<"),
                        "so_attn_rev": ("k_attn_rev_p",), "so_attn_jvp": ("k_attn_jvp_p",), "emlp": ("k_emlp_p2", "k_emlp_s"),
                        "emlp_bwd": ("k_emlp_bwd_p2",), "attn_blk_bwd": ("k_ablk_bwd",), "attn_blk": ("k_ablk_fwd",)}
 
