@@ -141,7 +141,12 @@ int64_t pet_graph_workspace_bytes(int64_t n_nodes, int64_t n_edges_in);
  * d_species [N] int32 atomic numbers, d_system_indices [N] int32.
  * ONE device->host read-back (kept edges, max neighbours, validation counters) happens
  * here, like the reference's int(torch.max(num_neighbors)) (structures.py:292); nothing
- * downstream (forward, reverse passes) synchronises with the host.
+ * downstream (forward, reverse passes) synchronises with the host. The read-back is a one-wave
+ * kernel into a pinned mailbox that the calling thread polls (under 10 us against 27 us for
+ * hipMemcpyAsync + hipStreamSynchronize: it sits on the critical path of a small box's MD step).
+ * A list that arrives ordered by centre with nothing to drop skips the radix sort: the first build
+ * of a process asks the device, later builds assume what the build before them found and verify
+ * it with the read-back above (a wrong guess costs a second build, never a wrong graph).
  * Errors: PET_ERR_GRAPH if a kept edge (i, j, S) has no partner (j, i, -S) -- every consumer
  * gathers through the ij->ji map, the reference's get_corresponding_edges (nef.py:88-166)
  * has the same precondition; PET_ERR_ARGUMENT for indices outside [0, N), atomic numbers
