@@ -304,6 +304,9 @@ void set_attn_fused(int v);
 void set_emlp_s(int v);
 bool emlp_recompute_on(const Lin& win, const Lin& wout, int64_t E);
 bool emlp_s_serves(int64_t E);
+// pet_comb_bwd_s.hip: the inference adjoint of the combination stage with a workgroup-shared weight ring; false = not served
+bool comb_bwd_s(const float* dM, const float* XF, const int* rev, const float* LNS, const float* CA, const Lin& c0g, const Lin& c2,
+                float* dcat, int64_t E, bool add_dm, hipStream_t st);
 // so_rows_s.hip: the generic row GEMM of the training passes with a workgroup-shared weight ring; false = not served
 bool rowgemm_s(hipStream_t st, const float* X, int K, const float* cs, const void* planes, const float* bias, float* Y, int n_out,
                int64_t R, bool acc);

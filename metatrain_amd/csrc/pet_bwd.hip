@@ -1238,6 +1238,8 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
         } else {
             {
                 ProfScope ps("comb_bwd", st, fE * 2.0 * (2 * D * 2 * D + 2 * D * D), fE * 4.0 * (3 * D + 2 * D + 2 * D));  // dM, e, e[rev], CA in; dcat out
+                if (!tr && comb_bwd_s(dM, B.XF, g.rev, B.LNS, B.CA, G.comb0_g, G.comb2, w.dcat, E, dxf_fused, st)) {  // large graphs (pet_comb_bwd_s.hip)
+                } else
                 PET_REQUIRE(trr_comb_bwd(dM, B.XF, g, G, B.LNS, B.CA, w.dcat, E, tr ? w.dCA : nullptr, st, dxf_fused), PET_ERR_ARGUMENT,
                             "combination adjoint: the split weight planes are missing (pet_model_finalize)");
                 if (tr) {
