@@ -412,8 +412,9 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *                 than 5 % of the atoms have more than 32 tokens keep the three-kernel form, as do training forwards,
  *                 graphs with an atom of more than 64 tokens and PostLN models. 0 = the three-kernel form everywhere.
  *   "emlp_s"      the edge MLP and its adjoint -- and, in inference, the edge head and its adjoint (csrc/pet_head_s.hip), the compress
- *                 adjoint (pet_compress_s.hip) and, from 16 384 atoms on, the node-row Linear layers around the attention block
- *                 (pet_center_s.hip) -- as two desynchronised four-wave workgroups per CU on one-accumulator products
+ *                 adjoint (pet_compress_s.hip), the combination stage and its adjoint (pet_comb_s.hip, pet_comb_bwd_s.hip), from
+ *                 16 384 atoms on the node-row Linear layers around the attention block (pet_center_s.hip), and in training the
+ *                 generic GEMMs of the second-order pass (so_rows_s.hip) -- as two desynchronised four-wave workgroups per CU on one-accumulator products
  *                 with a workgroup-shared weight ring (csrc/pet_emlp_s.hip, rows_s.h; the adjoint RECOMPUTES the SwiGLU pre-activations, so an inference forward does not
  *                 store them): 1 = for graphs of at least 28 672 edge rows (default), v > 1 = from v rows on, 0 = never
  *                 (the one-wave-per-SIMD pipelined kernels everywhere). A forward that ran without saving can only be followed
@@ -428,8 +429,9 @@ int pet_profile_report(int max_entries, char (*names)[64], double* total_ms, int
  *                 tile on four workgroups (partials through a temporary, the last arrival finishes the tile) -- default;
  *                 0 = one workgroup per tile
  *   "center_fused" 1 = the node-update kernel also writes the next attention layer's centre tokens (default); 0 = k_center
- *   "sorted_shortcut" 1 = pet_graph_build reads back whether the neighbour list is already ordered by centre with no edge to
- *                 drop and skips the radix sort of the edges if so (default); 0 = always sort
+ *   "sorted_shortcut" 1 = pet_graph_build skips the radix sort of the edges when the neighbour list is already ordered by centre
+ *                 with no edge to drop (the first build asks the device, later ones assume the previous build's answer and verify
+ *                 it with the build's one read-back; default); 0 = always sort
  *   "dxf_fused"   1 = inference adjoint on one rank: dXF[p] = dM[p] + dcat[p][:D] + dcat[rev[p]][D:] formed inside the
  *                 combination adjoint (first two terms) and the edge-MLP adjoint (the gather) -- default; 0 = k_dxf launch
  *   "train_bf16"  1 = the GEMMs of the second-order pass and the weight-gradient GEMMs keep ONE 16-bit MFMA term per product
