@@ -8,5 +8,7 @@ timeout 400 python tests/debug/fuzz_generic.py 61 12 2>&1 | grep -v Warning | ta
 timeout 400 python tests/debug/fuzz_soap.py 61 40 2>&1 | grep -v Warning | tail -10 > gpurun_out/fz6_soap.log
 timeout 600 python tests/debug/fuzz_soap_hypers.py 61 30 2>&1 | grep -v Warning | tail -34 > gpurun_out/fz6_soap_hypers.log
 timeout 300 python tests/debug/fuzz_train.py 61 4 2>&1 | grep -v Warning | tail -6 > gpurun_out/fz6_train.log
+# the same with the shared-ring row kernels forced on the small random batches (so_rows_s.hip serves every generic GEMM of the second-order pass)
+PET_FUZZ_SET=emlp_s=2 timeout 300 python tests/debug/fuzz_train.py 61 4 2>&1 | grep -v Warning | tail -6 > gpurun_out/fz6_train_forced.log
 for f in gpurun_out/fz6_*.log; do echo "== $f"; tail -n 3 $f; echo "   batches flagged above 1e-5 (any of the three): $(grep -c ABOVE $f)"; done > gpurun_out/r06_fuzz_summary.txt
 cat gpurun_out/r06_fuzz_summary.txt
