@@ -304,19 +304,44 @@ __global__ void k_edge_geometry(const float* __restrict__ pos, const float* __re
 // rowptr[i] = first sorted position whose key >= i
 // veto (graph_build, a list ASSUMED to be sorted): if the word is set the keys are not sorted after all -- every row is left
 // empty, so that the kernels behind this one (which take their counts from rowptr / scalars[0]) touch nothing before the host
-// sees the word and builds again with the sort
-__global__ void k_rowptr(const int* __restrict__ sorted_keys, int n_edges, int* __restrict__ rowptr,
-                         int n_nodes, int* __restrict__ scalars, const int* __restrict__ veto = nullptr) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n_nodes) return;
-    int lo = 0, hi = n_edges;
-    if (veto && *veto) hi = 0;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (sorted_keys[mid] < i) lo = mid + 1; else hi = mid;
+// sees the word and builds again with the sort.
+// max_out (the kept-edge CSR): the largest row length as well -- rowptr[i + 1] comes from the neighbouring thread through LDS (the
+// block's last thread searches for it), one atomicMax per block; this was a launch of its own (k_max_nbr: 5 us of a small box's
+// 70-us graph build, 20 us at 100 000 atoms, where its one atomic per wave serialised).
+__global__ __launch_bounds__(256) void k_rowptr(const int* __restrict__ sorted_keys, int n_edges, int* __restrict__ rowptr,
+                                                int n_nodes, int* __restrict__ scalars, const int* __restrict__ veto = nullptr,
+                                                int* __restrict__ max_out = nullptr) {
+    __shared__ int lo_s[257];
+    __shared__ int wmax[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_hi = (veto && *veto) ? 0 : n_edges;
+    auto lower = [&](int key) {
+        int lo = 0, hi = n_hi;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sorted_keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    int lo = 0;
+    if (i <= n_nodes) {
+        lo = lower(i);
+        rowptr[i] = lo;
+        if (i == n_nodes) scalars[0] = lo;
     }
-    rowptr[i] = lo;
-    if (i == n_nodes) scalars[0] = lo;
+    if (!max_out) return;
+    lo_s[threadIdx.x] = lo;
+    if (threadIdx.x == blockDim.x - 1) lo_s[blockDim.x] = i + 1 <= n_nodes ? lower(i + 1) : lo;
+    __syncthreads();
+    int v = i < n_nodes ? lo_s[threadIdx.x + 1] - lo : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (v > 0) atomicMax(max_out, v);
+    }
 }
 
 // Atoms by attention tile count (bucket b = min(ceil((deg + 1) / 16), 5) - 1): counts, then a fill whose order inside a
@@ -504,14 +529,6 @@ static int plan_attention_tiles(Graph& g, const int* hist, hipStream_t st) {
                                                                g.tile_desc + 2 * (size_t)ntile);
     PET_HIP_CHECK(hipGetLastError());
     return PET_OK;
-}
-
-__global__ void k_max_nbr(const int* __restrict__ rowptr, int n_nodes, int* __restrict__ scalars) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int v = (i < n_nodes) ? rowptr[i + 1] - rowptr[i] : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(&scalars[1], v);
 }
 
 __global__ void k_csr_fill(const int* __restrict__ perm, const float4* __restrict__ vin,
@@ -873,8 +890,7 @@ static int graph_build_once(const Model& m, const float* pos, const float* cells
                                               rocprim::plus<int>(), st));
     }
     k_rowptr<<<cdiv(n_nodes + 1, T), T, 0, st>>>(sorted_keys, (int)e0, g.rowptr, (int)n_nodes, g.scalars,
-                                                 e0 > 0 && mode == SORT_ASSUME_SORTED ? g.scalars + 60 : nullptr);
-    if (n_nodes > 0) k_max_nbr<<<cdiv(n_nodes, T), T, 0, st>>>(g.rowptr, (int)n_nodes, g.scalars);
+                                                 e0 > 0 && mode == SORT_ASSUME_SORTED ? g.scalars + 60 : nullptr, g.scalars + 1);
     if (e0 > 0) {
         // sized by the input edge count; the kernels read the kept count from the device (scalars[0]), so the whole
         // build needs ONE device -> host read-back (below), like the reference's int(torch.max(num_neighbors))
