@@ -268,9 +268,10 @@ __global__ void k_edge_geometry(const float* __restrict__ pos, const float* __re
                                 float4* __restrict__ vin, int* __restrict__ keep,
                                 int* __restrict__ sort_keys, int* __restrict__ sort_vals,
                                 int n_edges, int n_nodes, float cutoff, int strict, int* __restrict__ n_bad,
-                                int* __restrict__ unsorted) {
+                                int* __restrict__ unsorted, int* __restrict__ kidx_iota = nullptr) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
+    if (kidx_iota) kidx_iota[e] = e;  // a list assumed sorted with nothing to drop: edge e is kept edge e (graph_build)
     int i = centers[e], j = neighbors[e];
     // *unsorted stays 0 only if every edge is kept and the centres come in non-decreasing order: the sort keys are then
     // sorted as they stand and graph_build skips the radix sort (a list from pet_nl_build / vesin is ordered like that)
@@ -307,10 +308,10 @@ __global__ void k_edge_geometry(const float* __restrict__ pos, const float* __re
 // sees the word and builds again with the sort.
 // max_out (the kept-edge CSR): the largest row length as well -- rowptr[i + 1] comes from the neighbouring thread through LDS (the
 // block's last thread searches for it), one atomicMax per block; this was a launch of its own (k_max_nbr: 5 us of a small box's
-// 70-us graph build, 20 us at 100 000 atoms, where its one atomic per wave serialised).
+// 70-us graph build, 20 us at 100 000 atoms, where its one atomic per wave serialised). bucket_counts: k_bucket_count's histogram too.
 __global__ __launch_bounds__(256) void k_rowptr(const int* __restrict__ sorted_keys, int n_edges, int* __restrict__ rowptr,
                                                 int n_nodes, int* __restrict__ scalars, const int* __restrict__ veto = nullptr,
-                                                int* __restrict__ max_out = nullptr) {
+                                                int* __restrict__ max_out = nullptr, int* __restrict__ bucket_counts = nullptr) {
     __shared__ int lo_s[257];
     __shared__ int wmax[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -334,6 +335,14 @@ __global__ __launch_bounds__(256) void k_rowptr(const int* __restrict__ sorted_k
     if (threadIdx.x == blockDim.x - 1) lo_s[blockDim.x] = i + 1 <= n_nodes ? lower(i + 1) : lo;
     __syncthreads();
     int v = i < n_nodes ? lo_s[threadIdx.x + 1] - lo : 0;
+    if (bucket_counts) {  // k_bucket_count's histogram of the atoms by attention tile count, from the row length at hand
+        const int b = i < n_nodes ? min((v + 1 + 15) >> 4, 5) - 1 : -1;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const unsigned long long m = __ballot(b == k);
+            if ((threadIdx.x & 63) == 0 && m) atomicAdd(&bucket_counts[k], __popcll(m));
+        }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = v;
@@ -426,10 +435,11 @@ __global__ void k_tsort(const int* __restrict__ rowptr, int n_nodes, const int* 
         out[base + rank] = i;
     }
 }
-static int bucket_atoms_by_tile_count(Graph& g, hipStream_t st) {  // scalars[8..17] were zeroed with the rest
+static int bucket_atoms_by_tile_count(Graph& g, hipStream_t st, bool counted = false) {  // scalars[8..17] were zeroed with the rest
     if (g.n_nodes <= 0) return PET_OK;
     const int T = 256;
-    k_bucket_count<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8);
+    if (!counted)  // (graph_build: k_rowptr has filled the histogram)
+        k_bucket_count<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8);
     k_bucket_fill<<<cdiv(g.n_nodes, T), T, 0, st>>>(g.rowptr, (int)g.n_nodes, g.scalars + 8, g.scalars + 13, g.atom_order);
     // the per-atom attention tiles serve the fused block only (pet_ablk.hip: graphs of at least ABLK_MIN_TILES tiles, or forced; tiles <= atoms)
     g.tiles_planned = g.n_nodes >= ABLK_MIN_TILES || (attn_fused() & 4);
@@ -835,11 +845,12 @@ static int graph_build_once(const Model& m, const float* pos, const float* cells
     }
     g.adaptive = m.h.num_neighbors_adaptive > 0.f;
     const int* sorted_keys = g.sort_keys_out;
+    if (g.adaptive || !g_sorted_shortcut) mode = SORT_ALWAYS;
     if (e0 > 0) {
         k_edge_geometry<<<cdiv(e0, T), T, 0, st>>>(pos, cells, centers, neighbors, shifts, g.sys, g.vin,
                                                    g.keep, g.sort_keys_in, g.sort_vals_in, (int)e0,
                                                    (int)n_nodes, m.h.cutoff, g.adaptive ? 2 : m.h.nl_is_strict,
-                                                   g.scalars + 6, g.scalars + 60);
+                                                   g.scalars + 6, g.scalars + 60, mode == SORT_ASSUME_SORTED ? g.kidx : nullptr);
         size_t sb = g.sort_tmp_bytes, cb = g.scan_tmp_bytes;
         if (g.adaptive) {
             // all-edge CSR -> per-atom cutoffs -> pair mask; then the usual kept-edge CSR below
@@ -873,7 +884,6 @@ static int graph_build_once(const Model& m, const float* pos, const float* cells
         // a list that is already ordered by centre with no edge to drop (k_edge_geometry) needs no sort: one 4-byte
         // read-back (the build ends with one anyway) against three radix passes over the edges
         int unsorted = 1;
-        if (g.adaptive || !g_sorted_shortcut) mode = SORT_ALWAYS;
         if (mode == SORT_ASK) {
             if (int rcr = read_back(g.scalars + 60, 1, nullptr, 0, &unsorted, st)) return rcr;
         } else if (mode == SORT_ASSUME_SORTED)
@@ -886,11 +896,15 @@ static int graph_build_once(const Model& m, const float* pos, const float* cells
             sorted_keys = g.sort_keys_in;
             g.perm = g.sort_vals_in;  // the identity
         }
-        PET_HIP_CHECK(rocprim::exclusive_scan(g.scan_tmp, cb, g.keep, g.kidx, 0, (size_t)e0,
-                                              rocprim::plus<int>(), st));
+        // kidx = position among the kept edges; a list assumed sorted keeps every edge (k_edge_geometry has written the identity)
+        if (mode != SORT_ASSUME_SORTED)
+            PET_HIP_CHECK(rocprim::exclusive_scan(g.scan_tmp, cb, g.keep, g.kidx, 0, (size_t)e0,
+                                                  rocprim::plus<int>(), st));
     }
+    g.attn_lists = m.finalized;
     k_rowptr<<<cdiv(n_nodes + 1, T), T, 0, st>>>(sorted_keys, (int)e0, g.rowptr, (int)n_nodes, g.scalars,
-                                                 e0 > 0 && mode == SORT_ASSUME_SORTED ? g.scalars + 60 : nullptr, g.scalars + 1);
+                                                 e0 > 0 && mode == SORT_ASSUME_SORTED ? g.scalars + 60 : nullptr, g.scalars + 1,
+                                                 g.attn_lists && n_nodes > 0 ? g.scalars + 8 : nullptr);
     if (e0 > 0) {
         // sized by the input edge count; the kernels read the kept count from the device (scalars[0]), so the whole
         // build needs ONE device -> host read-back (below), like the reference's int(torch.max(num_neighbors))
@@ -904,9 +918,8 @@ static int graph_build_once(const Model& m, const float* pos, const float* cells
     // the per-tile-count atom lists and the attention tile plan serve the PET layers only: a model handle without weights
     // (what the SOAP-BPNN path builds its graphs with; a mirror that runs preprocess before its weights are uploaded)
     // skips them here, and the first tuned forward on the graph makes them (graph_attention_lists)
-    g.attn_lists = m.finalized;
     if (g.attn_lists)
-        if (int rcb = bucket_atoms_by_tile_count(g, st)) return rcb;
+        if (int rcb = bucket_atoms_by_tile_count(g, st, true)) return rcb;
     int host_scalars[61] = {0};
     if (int rcr = read_back(g.scalars, 61, nullptr, 0, host_scalars, st)) return rcr;
     if (e0 > 0 && !g.adaptive && g_sorted_shortcut) {
