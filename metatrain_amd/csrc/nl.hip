@@ -11,6 +11,7 @@
 #include "common.h"
 #include "model.h"
 
+#include <algorithm>
 #include <math.h>
 #include <string.h>
 #include <cstring>
@@ -49,24 +50,14 @@ __device__ __forceinline__ void frac_of(const float* pos, int i, const NlParams&
     for (int a = 0; a < 3; a++) fr[a] = x * prm.inv[a] + y * prm.inv[3 + a] + z * prm.inv[6 + a];
 }
 
-__global__ void k_nl_bin_start(const int* __restrict__ sorted_keys, int n, int nbins, int* __restrict__ bin_start) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > nbins) return;
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (sorted_keys[mid] < b) lo = mid + 1; else hi = mid;
-    }
-    bin_start[b] = lo;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Batched build: every system of a batch in ONE set of launches, one wave per occupied bin.
 //   k_nlb_bin      thread per atom: its system (binary search in first_atom), wrap into the cell, bin key
 //                  (system's bin base + bin)
 //   radix sort     atoms by key -> bins are contiguous runs of the sorted array, systems are contiguous blocks of bins
-//   k_nlb_gather   sorted SoA tile source: spos[q] = (wrapped x, y, z, atom id) so that a wave reads a bin's atoms as
-//                  ONE coalesced 16 B-per-lane load
+//   k_nlb_post_sort  bin starts, the bins' systems, and the sorted SoA tile source: spos[q] = (wrapped x, y, z, atom id) so that
+//                  a wave reads a bin's atoms as ONE coalesced 16 B-per-lane load
 //   k_nlb_pairs    one WAVE per bin. It stages the atoms of the (2 reach + 1)^3 surrounding bins -- periodic images
 //                  included -- as one dense candidate tile in wave-private LDS (position, atom id, image number), then
 //                  for every centre of its bin all 64 lanes test 64 candidates at a time; hits are compacted with a
@@ -113,13 +104,6 @@ __global__ void k_nlb_bin(const float* __restrict__ pos, int n, const NlParams* 
         wpos[3 * i + k] = pos[3 * i + k] - (wr[0] * prm.cell[k] + wr[1] * prm.cell[3 + k] + wr[2] * prm.cell[6 + k]);
 }
 
-__global__ void k_nlb_gather(const int* __restrict__ sorted_atoms, const float* __restrict__ wpos, int n,
-                             float4* __restrict__ spos) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    const int j = sorted_atoms[q];
-    spos[q] = make_float4(wpos[3 * j], wpos[3 * j + 1], wpos[3 * j + 2], __int_as_float(j));
-}
 
 // bounding boxes of the open systems (fractional coordinates along the completed lattice)
 __global__ void k_nlb_bbox(const float* __restrict__ pos, int n, const NlParams* __restrict__ prms,
@@ -421,15 +405,36 @@ static int64_t bin_params(NlParams& prm, const double height[3], const float* h_
     return total_bins;
 }
 
-__global__ void k_nlb_bin_sys(const int* __restrict__ bin_base, int n_sys, int total_bins, int* __restrict__ bin_sys) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= total_bins) return;
-    int lo = 0, hi = n_sys;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (bin_base[mid] <= b) lo = mid; else hi = mid;
+
+// What follows the sort of the bin keys, in one launch (three tiny launches and a memset before: a small box's neighbour list is
+// launch-bound): thread t < nbins + 1: first sorted position of bin t; t < nbins: the bin's system;
+// t < n: the wrapped position of the t-th atom in bin order (spos, below); thread 0: the pair counts' terminator.
+__global__ void k_nlb_post_sort(const int* __restrict__ sorted_keys, const int* __restrict__ sorted_atoms,
+                                const float* __restrict__ wpos, const int* __restrict__ bin_base, int n, int n_sys, int nbins,
+                                int* __restrict__ bin_start, int* __restrict__ bin_sys, float4* __restrict__ spos,
+                                int* __restrict__ counts_end) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) *counts_end = 0;
+    if (t <= nbins) {
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sorted_keys[mid] < t) lo = mid + 1; else hi = mid;
+        }
+        bin_start[t] = lo;
     }
-    bin_sys[b] = lo;
+    if (t < nbins) {
+        int lo = 0, hi = n_sys;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (bin_base[mid] <= t) lo = mid; else hi = mid;
+        }
+        bin_sys[t] = lo;
+    }
+    if (t < n) {
+        const int j = sorted_atoms[t];
+        spos[t] = make_float4(wpos[3 * j], wpos[3 * j + 1], wpos[3 * j + 2], __int_as_float(j));
+    }
 }
 
 int nl_build_batch(const float* d_pos, const float* h_cells, const int* h_pbc, const int64_t* h_first_atom, int64_t n_sys,
@@ -456,7 +461,10 @@ int nl_build_batch(const float* d_pos, const float* h_cells, const int* h_pbc, c
     }
     first[n_sys] = (int)n;
     const int T = 256;
-    PET_HIP_CHECK(hipMemcpyAsync(w.first_atom, first.data(), (n_sys + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    // first_atom, bin_base, (bbox), prms sit one behind the other in the workspace (carve_nl): when no system is open nothing on
+    // the device is needed to fill them, and they travel in ONE copy below (three before: each a launch on a small box's critical path)
+    if (any_open)
+        PET_HIP_CHECK(hipMemcpyAsync(w.first_atom, first.data(), (n_sys + 1) * sizeof(int), hipMemcpyHostToDevice, st));
     std::vector<float> h_bbox(6 * n_sys);
     for (int64_t s = 0; s < n_sys; s++)
         for (int k = 0; k < 6; k++) h_bbox[6 * s + k] = k < 3 ? 0.f : 1.f;
@@ -486,8 +494,19 @@ int nl_build_batch(const float* d_pos, const float* h_cells, const int* h_pbc, c
     }
     base[n_sys] = (int)total_bins;
     PET_REQUIRE(tile_ok, PET_ERR_UNSUPPORTED, "a cell is more than 100 times thinner than the cutoff");
-    PET_HIP_CHECK(hipMemcpyAsync(w.prms, prm.data(), n_sys * sizeof(NlParams), hipMemcpyHostToDevice, st));
-    PET_HIP_CHECK(hipMemcpyAsync(w.bin_base, base.data(), (n_sys + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    if (any_open) {
+        PET_HIP_CHECK(hipMemcpyAsync(w.prms, prm.data(), n_sys * sizeof(NlParams), hipMemcpyHostToDevice, st));
+        PET_HIP_CHECK(hipMemcpyAsync(w.bin_base, base.data(), (n_sys + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    } else {
+        char* const d0 = reinterpret_cast<char*>(w.first_atom);
+        const size_t span = (size_t)(reinterpret_cast<char*>(w.prms) - d0) + n_sys * sizeof(NlParams);
+        static thread_local std::vector<char> block;  // (the copy is asynchronous: its source outlives the call)
+        block.assign(span, 0);
+        std::memcpy(block.data(), first.data(), (n_sys + 1) * sizeof(int));
+        std::memcpy(block.data() + (reinterpret_cast<char*>(w.bin_base) - d0), base.data(), (n_sys + 1) * sizeof(int));
+        std::memcpy(block.data() + (reinterpret_cast<char*>(w.prms) - d0), prm.data(), n_sys * sizeof(NlParams));
+        PET_HIP_CHECK(hipMemcpyAsync(d0, block.data(), span, hipMemcpyHostToDevice, st));
+    }
     k_nlb_bin<<<cdiv(n, T), T, 0, st>>>(d_pos, (int)n, w.prms, w.first_atom, w.bin_base, (int)n_sys, w.bin_key, w.atom_id,
                                         w.wrap, w.wpos, w.sys_of);
     int bits = 1;
@@ -495,10 +514,9 @@ int nl_build_batch(const float* d_pos, const float* h_cells, const int* h_pbc, c
     size_t tb = w.tmp_bytes;
     PET_HIP_CHECK(rocprim::radix_sort_pairs(w.tmp, tb, w.bin_key, w.bin_key_sorted, w.atom_id, w.sorted_atoms, (size_t)n, 0,
                                             bits, st));
-    k_nl_bin_start<<<cdiv(total_bins + 1, T), T, 0, st>>>(w.bin_key_sorted, (int)n, (int)total_bins, w.bin_start);
-    k_nlb_bin_sys<<<cdiv(total_bins, T), T, 0, st>>>(w.bin_base, (int)n_sys, (int)total_bins, w.bin_sys);
-    k_nlb_gather<<<cdiv(n, T), T, 0, st>>>(w.sorted_atoms, w.wpos, (int)n, w.spos);
-    PET_HIP_CHECK(hipMemsetAsync(w.counts + n, 0, sizeof(int), st));
+    k_nlb_post_sort<<<cdiv(std::max<int64_t>(total_bins + 1, n), T), T, 0, st>>>(w.bin_key_sorted, w.sorted_atoms, w.wpos, w.bin_base,
+                                                                               (int)n, (int)n_sys, (int)total_bins, w.bin_start,
+                                                                               w.bin_sys, w.spos, w.counts + n);
     k_nlb_pairs<0><<<cdiv(total_bins, 4), 256, 0, st>>>(d_pos, w.spos, w.wrap, w.bin_start, w.prms, w.bin_base, w.bin_sys,
                                                         (int)total_bins, w.counts, nullptr, nullptr, nullptr);
     tb = w.tmp_bytes;
