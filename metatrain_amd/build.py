@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libpet_hip.so")
-SOURCES = ["abi.hip", "graph.hip", "nl.hip", "pet_fwd.hip", "pet_bwd.hip", "pet_trr.hip", "pet_attn.hip", "pet_ablk.hip", "pet_ablk_bwd1.hip", "pet_emlp_s.hip", "pet_head_s.hip", "pet_compress_s.hip", "pet_center_s.hip", "pet_comb.hip", "pet_comb_s.hip", "pet_comb_bwd.hip", "pet_comb_bwd_s.hip", "train.hip", "optim.hip", "so.hip", "so_rows_s.hip", "soap.hip", "gen.hip", "gen_train.hip"]
+SOURCES = ["abi.hip", "graph.hip", "nl.hip", "pet_fwd.hip", "pet_bwd.hip", "pet_trr.hip", "pet_attn.hip", "pet_ablk.hip", "pet_ablk_bwd1.hip", "pet_emlp_s.hip", "pet_head_s.hip", "pet_compress_s.hip", "pet_center_s.hip", "pet_comb.hip", "pet_comb_s.hip", "pet_comb_bwd.hip", "pet_comb_bwd_s.hip", "train.hip", "optim.hip", "so.hip", "so_rows_s.hip", "pet_node_s.hip", "soap.hip", "gen.hip", "gen_train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc"]
 FLAGS += os.environ.get("PET_HIP_EXTRA_FLAGS", "").split()  # debugging builds, e.g. -DAB_PROFILE (pet_ablk.hip)
 # Translation units compiled on their own (no -fgpu-rdc: their device code is generated here, not at the link step) with the
@@ -18,7 +18,7 @@ VGPR_FORM_FLAGS = ["-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 # Translation units whose device code is generated per file, not at the link step (-fgpu-rdc generates it there, over all files, and
 # its register allocation of k_comb_bwd_s came out at 256 registers + 4 spilled -- scratch loads inside the ring's vmcnt window --
 # where the per-file code generation needs 229 and none)
-NO_RDC = {"pet_comb_bwd_s.hip"}
+NO_RDC = {"pet_comb_bwd_s.hip", "so_rows_s.hip"}
 
 
 def _newer(a, b):

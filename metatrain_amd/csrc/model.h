@@ -307,9 +307,17 @@ bool emlp_s_serves(int64_t E);
 // pet_comb_bwd_s.hip: the inference adjoint of the combination stage with a workgroup-shared weight ring; false = not served
 bool comb_bwd_s(const float* dM, const float* XF, const int* rev, const float* LNS, const float* CA, const Lin& c0g, const Lin& c2,
                 float* dcat, int64_t E, bool add_dm, hipStream_t st);
+// pet_node_s.hip: the node update of large graphs as three shared-ring row GEMMs (every kernel fits beside an edge kernel's workgroup)
+bool node_fwd_s(const AttnLayerW& A, const float* H, const float* OC, float* H1, float* VGn, float* Hn, float* tmp, int64_t N,
+                hipStream_t st);
+bool node_bwd_s(const AttnLayerW& A, const float* dHn, const float* H1, const float* VGn, float* dH1, float* tmp, int64_t N, bool ln,
+                hipStream_t st);
 // so_rows_s.hip: the generic row GEMM of the training passes with a workgroup-shared weight ring; false = not served
 bool rowgemm_s(hipStream_t st, const float* X, int K, const float* cs, const void* planes, const float* bias, float* Y, int n_out,
                int64_t R, bool acc);
+// the same with an addend A (may be Y) and, for K == 256, a RMSNorm (norm 1) / LayerNorm (2) of the rows in front (weight cs, bias cb)
+bool rowgemm_s_ex(hipStream_t st, const float* X, int K, const float* cs, const void* planes, const float* bias, const float* A,
+                  float* Y, int n_out, int64_t R, int norm, const float* cb);
 bool emlp_s_forced();
 struct Model;
 struct GnnLayerW;

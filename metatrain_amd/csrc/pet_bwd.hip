@@ -1270,6 +1270,11 @@ int backward_features(const Model& m, const Graph& g, Workspace& w, hipStream_t 
                 ProfScope ps("node_bwd", s2, fN * 2.0 * (D * DN + DN * 2 * DNF + DNF * DN));
                 const WX wob = wx_b(A.cmlp_out), wib = wx_b(A.cmlp_in);
                 bool expand_done = false;
+                // large graphs: two shared-ring GEMMs and two row-wise kernels that can run BESIDE the edge kernels (pet_node_s.hip);
+                // scratch: the attention-output temporary of the forward pass, which no adjoint kernel touches
+                if (!tr && node_planes() && (size_t)N * 3 * DNF <= (size_t)R * D &&
+                    node_bwd_s(A, dH, Ab.H1, Ab.VGn, dH_alt, w.AO, N, ln, s2)) {
+                } else
                 if (!tr && node_planes() && wob.h && wib.h) {
                     const int nr = node_rows(N);
                     const size_t lds_nb = (size_t)nr * LD256 * 4 + (size_t)2 * nr * plane_ld(256) * 2 + nr * 8;

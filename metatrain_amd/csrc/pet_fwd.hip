@@ -1187,6 +1187,11 @@ int forward_layers(const Model& m, const Graph& g, void* ws, int64_t ws_bytes, i
                 const float* bcn = nullptr;
                 float* xcn = nullptr;
                 const WX wci = wx_fwd(A.cmlp_in), wce_ = wx_fwd(A.ce), wco = wx_fwd(A.cmlp_out);
+                // large graphs: three shared-ring GEMMs that can run BESIDE the edge MLP (pet_node_s.hip); its scratch lives in
+                // dQKV, which only the adjoint uses
+                if (node_planes() && (size_t)N * DNF <= (size_t)R * 3 * D &&
+                    node_fwd_s(A, Ab.H, Ab.OC, Ab.H1, Ab.VGn, Ab.Hn, w.dQKV, N, s2)) {
+                } else
                 if (node_planes() && wci.h && wce_.h && wco.h) {
                     const int nr = node_rows(N);
                     const size_t lds_n2 = (size_t)nr * LD256 * 4 + (size_t)2 * nr * plane_ld(256) * 2 + nr * 8;

@@ -75,7 +75,7 @@ __device__ __forceinline__ void rs_gemm(f32x16 (&acc)[4], const f16x8 (&xh)[8], 
 // w: planes of 64 W (k_pack2h with both scales 64: Lin::fwd2s / bwd2s), fragments [(tile * (K / 16) + kb) * 64 + lane]
 __global__ __launch_bounds__(256, 2) void k_rowgemm_s(const float* __restrict__ X, int ldx, int nk, const float* __restrict__ cs,
                                                      W2 w, const float* __restrict__ bias, float* __restrict__ Y, int ldy, int nn,
-                                                     int64_t R, int accumulate) {
+                                                     int64_t R, const float* __restrict__ A /* addend rows (ld = ldy), may be Y; or null */) {
     extern __shared__ __attribute__((aligned(16))) char rs_smem[];
     const RowLane L;
     const unsigned lane16 = (unsigned)L.lane * 16u;
@@ -188,9 +188,9 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_s(const float* __restrict__ 
             asm volatile("" : "+s"(r0));
             auto out = [&](int r) { return live && r0 + r < R ? Y + (r0 + r) * ldy + col : nullptr; };
             __builtin_amdgcn_wave_barrier();
-            if (accumulate) {
+            if (A) {
                 float4 old[8];
-                request_rows_addend<8>(old, Lp, [&](int r) { return Y + (r0 + r < R ? r0 + r : R - 1) * ldy + col; });
+                request_rows_addend<8>(old, Lp, [&](int r) { return A + (r0 + r < R ? r0 + r : R - 1) * ldy + col; });
                 store_rows_lines_add<8>(y, old, reinterpret_cast<float*>(tile), Lp, out);
             } else
                 store_rows_lines<8>(y, reinterpret_cast<float*>(tile), Lp, out);
@@ -206,18 +206,285 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_s(const float* __restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Two shapes get kernels of their own, because the generic one re-reads the rows of the input once per column block when
+// BOTH K and the output are wider than 128 (the slice it needs next lands with its full latency exposed, once per block):
+//   k_rowgemm_s_k2   K = 256, any width of output: the planes of both slices stay in registers across the column blocks (128
+//                    registers), the column blocks leave 32 columns at a time; optionally the rows are normalised first
+//                    (NORM 1: RMSNorm, 2: LayerNorm, with weight cs and bias cb -- the node update's norm_center_features)
+//   k_rowgemm_s_n2   256 output columns, any K: the K slices are the OUTER loop and both column blocks accumulate at once
+//                    (128 accumulator registers), every slice is read once
+// Both take an addend (Y = A + ...; A == Y accumulates in place). Same stream order convention as above: product p of the
+// stream = (column block, K slice) in the order the kernel consumes them.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define RS_SETUP()                                                                                       \
+    extern __shared__ __attribute__((aligned(16))) char rs_smem[];                                       \
+    const RowLane L;                                                                                     \
+    const unsigned lane16 = (unsigned)L.lane * 16u;                                                      \
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                                   \
+    int64_t row0 = ((int64_t)blockIdx.x * HS_NW + wave) * WROWS;                                         \
+    const bool live = row0 < R;                                                                          \
+    if (!live) row0 = ((R - 1) / WROWS) * WROWS;                                                         \
+    const bool full = live && row0 + WROWS <= R; /* every store instruction of the tile is issued */     \
+    char* tile = rs_smem + wave * 16384;                                                                 \
+    const char* ring = rs_smem + HS_NW * 16384;                                                          \
+    const unsigned tile_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile);                   \
+    const unsigned ring_u = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);                   \
+    const f16x8* plane = (wave & 1) ? w.l : w.h
+#define RS_LANE(Lx)                            \
+    RowLane Lx = L;                            \
+    asm volatile("" : "+v"(Lx.lane));          \
+    Lx.r = Lx.lane & 31;                       \
+    Lx.h = Lx.lane >> 5
+#define RS_ROW0(rx) int64_t rx = row0; asm volatile("" : "+s"(rx))
+
+// one 128-column block of results: scale back, bias, addend, 32 columns at a time as whole 128-B lines through the tile
+// (4 x 4 store instructions; the addend's row-fragment loads are consumed before the stores are issued)
+__device__ __forceinline__ void rs_store_block(const f32x16 (&acc)[4], float f, const float* __restrict__ bv, const float* __restrict__ A,
+                                               float* __restrict__ Y, int ldy, int col, int64_t r0, int64_t R, bool live, char* tile,
+                                               const RowLane& Lq) {
+    const int64_t row = r0 + Lq.r < R ? r0 + Lq.r : R - 1;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        float4 y[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) y[j] = make_float4(acc[t][4 * j] * f, acc[t][4 * j + 1] * f, acc[t][4 * j + 2] * f, acc[t][4 * j + 3] * f);
+        if (bv) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bv + 32 * t + 8 * j + 4 * Lq.h);
+                y[j].x += b4.x; y[j].y += b4.y; y[j].z += b4.z; y[j].w += b4.w;
+            }
+        }
+        if (A) {
+            float4 a4[4];
+            load_rowfrag<4>(a4, A + col + 32 * t, row, ldy, Lq.h);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { y[j].x += a4[j].x; y[j].y += a4[j].y; y[j].z += a4[j].z; y[j].w += a4[j].w; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        store_tile32_lines(y, reinterpret_cast<float*>(tile), Y + col + 32 * t, r0, live ? R : 0, ldy, Lq);
+    }
+}
+
+template <int NORM>
+__global__ __launch_bounds__(256, 2) void k_rowgemm_s_k2(const float* __restrict__ X, int ldx, const float* __restrict__ cs,
+                                                        const float* __restrict__ cb, W2 w, const float* __restrict__ bias,
+                                                        const float* __restrict__ A, float* __restrict__ Y, int ldy, int nn, int64_t R) {
+    RS_SETUP();
+    constexpr int nk = 2, kbt = 16;
+    auto piece = [=](int nb, int ks, int s, int slot) {
+        const unsigned dst = ring_u + (unsigned)slot * HS_SLOT + wave * 1024;
+        ab_dma_piece(plane, (4 * nb + 2 * (s >> 3) + (wave >> 1)) * kbt + 8 * ks + (s & 7), lane16, dst);
+    };
+    rs_dma_tile(X, row0, R, ldx, tile_u, L);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f16x8 xh[2][8], xl[2][8];
+    float inv;
+    {
+        float4 x0[16], x1[16];
+        tile128_to_frag(x0, tile, L);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have returned before the tile is requested again
+        __builtin_amdgcn_wave_barrier();
+        rs_dma_tile(X + 128, row0, R, ldx, tile_u, L);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tile128_to_frag(x1, tile, L);
+        if (NORM) {  // RMSNorm (eps 2^-23) or torch.nn.LayerNorm (eps 1e-5) over the 256 columns, then weight (and bias)
+            float mean = 0.f;
+            if (NORM == 2) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; k++) s1 += (x0[k].x + x0[k].y) + (x0[k].z + x0[k].w) + (x1[k].x + x1[k].y) + (x1[k].z + x1[k].w);
+                mean = row_sum(s1) * (1.0f / 256.0f);
+            }
+            float s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (NORM == 2) {
+                    x0[k].x -= mean; x0[k].y -= mean; x0[k].z -= mean; x0[k].w -= mean;
+                    x1[k].x -= mean; x1[k].y -= mean; x1[k].z -= mean; x1[k].w -= mean;
+                }
+                s2 += x0[k].x * x0[k].x + x0[k].y * x0[k].y + x0[k].z * x0[k].z + x0[k].w * x0[k].w;
+                s2 += x1[k].x * x1[k].x + x1[k].y * x1[k].y + x1[k].z * x1[k].z + x1[k].w * x1[k].w;
+            }
+            const float rstd = rsqrtf(row_sum(s2) * (1.0f / 256.0f) + (NORM == 2 ? 1e-5f : 1.1920928955078125e-07f));
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float4 g0 = *reinterpret_cast<const float4*>(cs + 8 * k + 4 * L.h);
+                const float4 g1 = *reinterpret_cast<const float4*>(cs + 128 + 8 * k + 4 * L.h);
+                x0[k] = make_float4(x0[k].x * rstd * g0.x, x0[k].y * rstd * g0.y, x0[k].z * rstd * g0.z, x0[k].w * rstd * g0.w);
+                x1[k] = make_float4(x1[k].x * rstd * g1.x, x1[k].y * rstd * g1.y, x1[k].z * rstd * g1.z, x1[k].w * rstd * g1.w);
+                if (NORM == 2) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(cb + 8 * k + 4 * L.h);
+                    const float4 b1 = *reinterpret_cast<const float4*>(cb + 128 + 8 * k + 4 * L.h);
+                    x0[k].x += b0.x; x0[k].y += b0.y; x0[k].z += b0.z; x0[k].w += b0.w;
+                    x1[k].x += b1.x; x1[k].y += b1.y; x1[k].z += b1.z; x1[k].w += b1.w;
+                }
+            }
+        } else if (cs) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float4 g0 = *reinterpret_cast<const float4*>(cs + 8 * k + 4 * L.h);
+                const float4 g1 = *reinterpret_cast<const float4*>(cs + 128 + 8 * k + 4 * L.h);
+                x0[k].x *= g0.x; x0[k].y *= g0.y; x0[k].z *= g0.z; x0[k].w *= g0.w;
+                x1[k].x *= g1.x; x1[k].y *= g1.y; x1[k].z *= g1.z; x1[k].w *= g1.w;
+            }
+        }
+        float sc0, sc1;
+        const float iv0 = row_pow2<16>(x0, sc0), iv1 = row_pow2<16>(x1, sc1);
+        const float sc = sc0 < sc1 ? sc0 : sc1;  // one power of two for the row: the larger slice decides
+        inv = sc0 < sc1 ? iv0 : iv1;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { x0[k].x *= sc; x0[k].y *= sc; x0[k].z *= sc; x0[k].w *= sc; }
+        hs_planes(x0, xh[0], xl[0]);
+#pragma unroll
+        for (int k = 0; k < 16; k++) { x1[k].x *= sc; x1[k].y *= sc; x1[k].z *= sc; x1[k].w *= sc; }
+        hs_planes(x1, xh[1], xl[1]);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the norm's weight loads: nothing but fragments in the queue from here on)
+    piece(0, 0, 0, 0);
+    piece(0, 0, 1, 1);
+    piece(0, 0, 2, 2);
+    const float f = inv * ABQ_INV;
+#pragma unroll 1
+    for (int nb = 0; nb < nn; nb++) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = ab_zero();
+        const bool last = nb + 1 == nn;
+        // (16 store instructions of the previous block may be in flight over the first three stages -- if all of them were issued)
+        if (nb > 0 && !full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a partial tile skips store instructions: drained instead of counted)
+        rs_gemm(acc, xh[0], xl[0], nb > 0 && full, [=](int s, int slot) {
+            if (s < 16) piece(nb, 0, s, slot); else piece(nb, 1, s - 16, slot);
+        }, ring, lane16);
+        rs_gemm(acc, xh[1], xl[1], false, [=](int s, int slot) {
+            if (s < 16) piece(nb, 1, s, slot);
+            else if (last) piece(nb, 1, 15, slot);
+            else piece(nb + 1, 0, s - 16, slot);
+        }, ring, lane16);
+        RS_LANE(Lq);
+        RS_ROW0(r0);
+        rs_store_block(acc, f, bias ? bias + 128 * nb : nullptr, A, Y, ldy, 128 * nb, r0, R, live, tile, Lq);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_rowgemm_s_n2(const float* __restrict__ X, int ldx, int nk, W2 w,
+                                                        const float* __restrict__ bias, const float* __restrict__ A,
+                                                        float* __restrict__ Y, int ldy, int64_t R) {
+    RS_SETUP();
+    (void)full;
+    const int kbt = 8 * nk;
+    auto piece = [=](int nb, int ks, int s, int slot) {
+        const unsigned dst = ring_u + (unsigned)slot * HS_SLOT + wave * 1024;
+        ab_dma_piece(plane, (4 * nb + 2 * (s >> 3) + (wave >> 1)) * kbt + 8 * ks + (s & 7), lane16, dst);
+    };
+    rs_dma_tile(X, row0, R, ldx, tile_u, L);
+    piece(0, 0, 0, 0);
+    piece(0, 0, 1, 1);
+    piece(0, 0, 2, 2);
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    f32x16 acc0[4], acc1[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { acc0[t] = ab_zero(); acc1[t] = ab_zero(); }
+    f16x8 xh[8], xl[8];
+    float scale = 0.f, inv = 0.f;
+#pragma unroll 1
+    for (int ks = 0; ks < nk; ks++) {
+        RS_LANE(Lp);
+        RS_ROW0(r0);
+        {   // the slice: its largest entry first (one pass over the tile), then planes eight fragments at a time (registers)
+            const char* rowp = tile + 512 * Lp.r;
+            const int sw = Lp.r & 15;
+            float m = 0.f;
+#pragma unroll
+            for (int kg = 0; kg < 16; kg++) {
+                const float4 v = *reinterpret_cast<const float4*>(rowp + 16 * ((2 * kg + Lp.h) ^ sw));
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            int e = (__float_as_int(m) >> 23) & 0xff;
+            e = e > 253 ? 253 : e;
+            const float sc = __int_as_float((254 - e) << 23), iv = __int_as_float(e << 23);  // trr.h row_pow2
+            const bool shrink = ks == 0 || sc < scale;
+            const float sc_eff = shrink ? sc : scale;
+            if (ks > 0) {
+                const float g = sc_eff * inv;  // 1 unless this slice is larger than everything before it
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++) { acc0[t][i] *= g; acc1[t][i] *= g; }
+            }
+            scale = sc_eff;
+            inv = shrink ? iv : inv;
+            const float fs = sc_eff;  // (times ABS in a second step: an all-zero row's scale is 2^127, and 0 x (2^127 x 64) is not 0)
+#pragma unroll
+            for (int kb = 0; kb < 8; kb++) {
+                const float4 a = *reinterpret_cast<const float4*>(rowp + 16 * ((4 * kb + Lp.h) ^ sw));
+                const float4 b = *reinterpret_cast<const float4*>(rowp + 16 * ((4 * kb + 2 + Lp.h) ^ sw));
+                const float v8[8] = {a.x * fs * ABS, a.y * fs * ABS, a.z * fs * ABS, a.w * fs * ABS,
+                                     b.x * fs * ABS, b.y * fs * ABS, b.z * fs * ABS, b.w * fs * ABS};
+                ab_split8(v8, xh[kb], xl[kb]);
+            }
+        }
+        const bool more = ks + 1 < nk;
+        if (more) {  // the next slice into the tile while this slice's two products run
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            rs_dma_tile(X + 128 * (ks + 1), r0, R, ldx, tile_u, Lp);
+        }
+        rs_gemm(acc0, xh, xl, more, [=](int s, int slot) {
+            if (s < 16) piece(0, ks, s, slot); else piece(1, ks, s - 16, slot);
+        }, ring, lane16);
+        rs_gemm(acc1, xh, xl, false, [=](int s, int slot) {
+            if (s < 16) piece(1, ks, s, slot);
+            else if (!more) piece(1, ks, 15, slot);
+            else piece(0, ks + 1, s - 16, slot);
+        }, ring, lane16);
+    }
+    const float f = inv * ABQ_INV;
+    RS_LANE(Lq);
+    RS_ROW0(r0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    rs_store_block(acc0, f, bias, A, Y, ldy, 0, r0, R, live, tile, Lq);
+    rs_store_block(acc1, f, bias ? bias + 128 : nullptr, A, Y, ldy, 128, r0, R, live, tile, Lq);
+}
+
 // false = not served: planes missing, shape not a multiple of 128 both ways, a small matrix of rows, or the row kernels'
-// switch is off (pet_config_set("emlp_s", 0); "emlp_s" = 2 serves the tests' small graphs too)
-bool rowgemm_s(hipStream_t st, const float* X, int K, const float* cs, const void* planes, const float* bias, float* Y, int n_out,
-               int64_t R, bool acc) {
+// switch is off (pet_config_set("emlp_s", 0); "emlp_s" = 2 serves the tests' small graphs too).
+// Y = [A +] (norm(X) | X * cs) W^T [+ bias]; A may be Y (accumulate in place); norm 1 / 2: RMSNorm / LayerNorm of the 256-wide rows
+// with weight cs (and bias cb) before the product (K == 256 only)
+bool rowgemm_s_ex(hipStream_t st, const float* X, int K, const float* cs, const void* planes, const float* bias, const float* A,
+                  float* Y, int n_out, int64_t R, int norm, const float* cb) {
     if (!planes || K % 128 || n_out % 128 || K > 1024 || n_out > 1024 || !emlp_s_serves(R)) return false;
+    if (norm && (K != 256 || !cs || (norm == 2 && !cb))) return false;
     const size_t n8 = (size_t)(n_out / 32) * (K / 16) * 64;
     const f16x8* b = reinterpret_cast<const f16x8*>(planes);
     W2 w; w.h = b; w.l = b + n8;
     const size_t lds = HS_NW * 16384 + HS_NSLOT * HS_SLOT;
-    allow_big_lds(k_rowgemm_s, lds);
-    k_rowgemm_s<<<(int)cdiv(R, HS_NW * WROWS), 256, lds, st>>>(X, K, K / 128, cs, w, bias, Y, n_out, n_out / 128, R, acc ? 1 : 0);
+    const int grid = (int)cdiv(R, HS_NW * WROWS);
+    if (norm == 1) {
+        allow_big_lds(k_rowgemm_s_k2<1>, lds);
+        k_rowgemm_s_k2<1><<<grid, 256, lds, st>>>(X, K, cs, cb, w, bias, A, Y, n_out, n_out / 128, R);
+    } else if (norm == 2) {
+        allow_big_lds(k_rowgemm_s_k2<2>, lds);
+        k_rowgemm_s_k2<2><<<grid, 256, lds, st>>>(X, K, cs, cb, w, bias, A, Y, n_out, n_out / 128, R);
+    } else if (K == 256 && n_out >= 256) {
+        allow_big_lds(k_rowgemm_s_k2<0>, lds);
+        k_rowgemm_s_k2<0><<<grid, 256, lds, st>>>(X, K, cs, nullptr, w, bias, A, Y, n_out, n_out / 128, R);
+    } else if (n_out == 256 && K >= 256 && !cs) {
+        allow_big_lds(k_rowgemm_s_n2, lds);
+        k_rowgemm_s_n2<<<grid, 256, lds, st>>>(X, K, K / 128, w, bias, A, Y, n_out, R);
+    } else {
+        allow_big_lds(k_rowgemm_s, lds);
+        k_rowgemm_s<<<grid, 256, lds, st>>>(X, K, K / 128, cs, w, bias, Y, n_out, n_out / 128, R, A);
+    }
     return true;
+}
+bool rowgemm_s(hipStream_t st, const float* X, int K, const float* cs, const void* planes, const float* bias, float* Y, int n_out,
+               int64_t R, bool acc) {
+    return rowgemm_s_ex(st, X, K, cs, planes, bias, acc ? Y : nullptr, Y, n_out, R, 0, nullptr);
 }
 
 }  // namespace pet
