@@ -318,6 +318,9 @@ bool rowgemm_s(hipStream_t st, const float* X, int K, const float* cs, const voi
 // the same with an addend A (may be Y) and, for K == 256, a RMSNorm (norm 1) / LayerNorm (2) of the rows in front (weight cs, bias cb)
 bool rowgemm_s_ex(hipStream_t st, const float* X, int K, const float* cs, const void* planes, const float* bias, const float* A,
                   float* Y, int n_out, int64_t R, int norm, const float* cb);
+bool rowgemm_s_swiglu_bwd(hipStream_t st, const float* X, const void* planes, const float* VG, float* dVG, int hid, int64_t R);
+bool rowgemm_s_norm_bwd(hipStream_t st, const float* X, int K, const void* planes, const float* xn, const float* gamma, int ln,
+                        const float* dres, float* out, int64_t R);
 bool emlp_s_forced();
 struct Model;
 struct GnnLayerW;

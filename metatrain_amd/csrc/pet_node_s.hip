@@ -27,53 +27,6 @@ __global__ __launch_bounds__(256) void k_node_swiglu(const float* __restrict__ V
         make_float4(v.x * sigmoidf_(g.x), v.y * sigmoidf_(g.y), v.z * sigmoidf_(g.z), v.w * sigmoidf_(g.w));
 }
 
-// (dv, dg) = (du sigmoid(g), du v sigmoid'(g)) of u = v sigmoid(g): [N, DNF] and the saved [value | gate] -> [N, 2 DNF]
-__global__ __launch_bounds__(256) void k_node_swiglu_bwd(const float* __restrict__ VG, const float* __restrict__ dU,
-                                                         float* __restrict__ dVG, int64_t n4) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    const int64_t row = i / (DNF / 4);
-    const int c = (int)(i % (DNF / 4)) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(VG + row * (2 * DNF) + c);
-    const float4 g = *reinterpret_cast<const float4*>(VG + row * (2 * DNF) + DNF + c);
-    const float4 d = *reinterpret_cast<const float4*>(dU + row * DNF + c);
-    const float sx = sigmoidf_(g.x), sy = sigmoidf_(g.y), sz = sigmoidf_(g.z), sw = sigmoidf_(g.w);
-    *reinterpret_cast<float4*>(dVG + row * (2 * DNF) + c) = make_float4(d.x * sx, d.y * sy, d.z * sz, d.w * sw);
-    *reinterpret_cast<float4*>(dVG + row * (2 * DNF) + DNF + c) =
-        make_float4(d.x * v.x * sx * (1.f - sx), d.y * v.y * sy * (1.f - sy), d.z * v.z * sz * (1.f - sz), d.w * v.w * sw * (1.f - sw));
-}
-
-// out = dres + (adjoint of y = norm(x) gamma (+ beta) applied to dy): RMSNorm (ln == 0; eps 2^-23) or LayerNorm (eps 1e-5) of rows of
-// DN = 256; one wave per row. dx = rstd (dyh - [mean(dyh)] - xh mean(dyh xh)), dyh = dy gamma, xh = the normalised row
-__global__ __launch_bounds__(256) void k_node_norm_bwd(const float* __restrict__ dy, const float* __restrict__ x,
-                                                       const float* __restrict__ gamma, int ln, const float* __restrict__ dres,
-                                                       float* __restrict__ out, int64_t N) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= N) return;
-    const int l = threadIdx.x & 63;
-    auto wave_sum = [](float s) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        return s;
-    };
-    float4 v = *reinterpret_cast<const float4*>(x + row * DN + 4 * l);
-    if (ln) {
-        const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / DN);
-        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-    }
-    const float rstd = rsqrtf(wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / DN) + (ln ? 1e-5f : 1.1920928955078125e-07f));
-    v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
-    const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * l);
-    float4 d = *reinterpret_cast<const float4*>(dy + row * DN + 4 * l);
-    d.x *= g.x; d.y *= g.y; d.z *= g.z; d.w *= g.w;
-    const float m1 = ln ? wave_sum((d.x + d.y) + (d.z + d.w)) * (1.0f / DN) : 0.f;
-    const float m2 = wave_sum(d.x * v.x + d.y * v.y + d.z * v.z + d.w * v.w) * (1.0f / DN);
-    const float4 r = *reinterpret_cast<const float4*>(dres + row * DN + 4 * l);
-    *reinterpret_cast<float4*>(out + row * DN + 4 * l) =
-        make_float4(r.x + rstd * (d.x - m1 - v.x * m2), r.y + rstd * (d.y - m1 - v.y * m2), r.z + rstd * (d.z - m1 - v.z * m2),
-                    r.w + rstd * (d.w - m1 - v.w * m2));
-}
-
 // false = not served (fewer atoms than the row kernels' threshold, planes missing, or pet_config_set("emlp_s", 0)); nothing has been
 // launched in that case. tmp: [N, DNF] floats of scratch (the SwiGLU output)
 bool node_fwd_s(const AttnLayerW& A, const float* H, const float* OC, float* H1, float* VGn, float* Hn, float* tmp, int64_t N,
@@ -88,20 +41,17 @@ bool node_fwd_s(const AttnLayerW& A, const float* H, const float* OC, float* H1,
 }
 
 // The adjoint of the same update (inference): dH1 = dHn + norm^T(W_in^T swiglu'(W_out^T dHn)). tmp: [N, 3 DNF] floats of scratch.
-//   du  = dHn Wout                             k_rowgemm_s_k2<0>  (256 -> 512)
-//   dvg = swiglu'(saved vg) du                 k_node_swiglu_bwd
-//   dy  = dvg Win                              k_rowgemm_s_n2     (1024 -> 256)
-//   dH1 = dHn + norm^T(dy; h1)                 k_node_norm_bwd
+//   dvg = swiglu'(saved vg) (dHn Wout)         k_rowgemm_s_k2<0, 1>  (256 -> 512, the SwiGLU adjoint in the epilogue)
+//   dH1 = dHn + norm^T(dvg Win; h1)            k_rowgemm_s_n2<1>     (1024 -> 256, the norm adjoint and the residual in the epilogue)
+// (the first form of this chain ran the two row-wise steps as kernels of their own: four links instead of two, 42.98 against 42.82 ms)
 bool node_bwd_s(const AttnLayerW& A, const float* dHn, const float* H1, const float* VGn, float* dH1, float* tmp, int64_t N, bool ln,
                 hipStream_t st) {
     if (!emlp_s_serves(N) || !A.cmlp_in.bwd2s || !A.cmlp_out.bwd2s || N <= 0) return false;
-    float* dU = tmp;            // [N, DNF]; dead after the SwiGLU adjoint: dy reuses it
-    float* dVG = tmp + N * DNF;  // [N, 2 DNF]
-    float* dY = tmp;
-    if (!rowgemm_s_ex(st, dHn, DN, nullptr, A.cmlp_out.bwd2s, nullptr, nullptr, dU, DNF, N, 0, nullptr)) return false;
-    k_node_swiglu_bwd<<<(int)cdiv(N * (DNF / 4), 256), 256, 0, st>>>(VGn, dU, dVG, N * (DNF / 4));
-    rowgemm_s_ex(st, dVG, 2 * DNF, nullptr, A.cmlp_in.bwd2s, nullptr, nullptr, dY, DN, N, 0, nullptr);
-    k_node_norm_bwd<<<(int)cdiv(N, 4), 256, 0, st>>>(dY, H1, A.g_center, ln ? 1 : 0, dHn, dH1, N);
+    float* dVG = tmp;  // [N, 2 DNF]
+    // the SwiGLU adjoint is the first GEMM's epilogue, the norm adjoint and the residual the second one's (so_rows_s.hip): two
+    // launches in the dependent chain beside the edge kernels instead of four
+    if (!rowgemm_s_swiglu_bwd(st, dHn, A.cmlp_out.bwd2s, VGn, dVG, DNF, N)) return false;
+    rowgemm_s_norm_bwd(st, dVG, 2 * DNF, A.cmlp_in.bwd2s, H1, A.g_center, ln ? 1 : 0, dHn, dH1, N);
     return true;
 }
 

@@ -19,6 +19,7 @@
 //     column block is requested behind them and waited for in full -- one exposed round trip per column block.
 // Row scaling as in k_rowgemm_n128: one power of two per row and K slice, a running scale that only shrinks (exact).
 #include "rows_s.h"
+#include "tile.h"
 
 namespace pet {
 
@@ -268,7 +269,86 @@ __device__ __forceinline__ void rs_store_block(const f32x16 (&acc)[4], float f, 
     }
 }
 
-template <int NORM>
+// The node update's adjoint, two epilogues (pet_node_s.hip): each removes a row-wise kernel -- and a link of the dependent chain that
+// runs beside the edge kernels -- and the round trip of its input through HBM.
+// (a) du (this 128-column block of the 512) -> (dv, dg) = (du sigmoid(g), du v sigmoid'(g)) with the saved [value | gate] rows:
+//     two 32-column tiles leave per accumulator tile (8 x 4 store instructions per block)
+__device__ __forceinline__ void rs_store_block_swiglu_bwd(const f32x16 (&acc)[4], float f, const float* __restrict__ VG,
+                                                          float* __restrict__ dVG, int hid, int col, int64_t r0, int64_t R, bool live,
+                                                          char* tile, const RowLane& Lq) {
+    const int64_t row = r0 + Lq.r < R ? r0 + Lq.r : R - 1;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        float4 v4[4], g4[4], dv[4], dg[4];
+        load_rowfrag<4>(v4, VG + col + 32 * t, row, 2 * hid, Lq.h);
+        load_rowfrag<4>(g4, VG + hid + col + 32 * t, row, 2 * hid, Lq.h);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float du[4] = {acc[t][4 * j] * f, acc[t][4 * j + 1] * f, acc[t][4 * j + 2] * f, acc[t][4 * j + 3] * f};
+            const float sx = sigmoidf_(g4[j].x), sy = sigmoidf_(g4[j].y), sz = sigmoidf_(g4[j].z), sw = sigmoidf_(g4[j].w);
+            dv[j] = make_float4(du[0] * sx, du[1] * sy, du[2] * sz, du[3] * sw);
+            dg[j] = make_float4(du[0] * v4[j].x * sx * (1.f - sx), du[1] * v4[j].y * sy * (1.f - sy), du[2] * v4[j].z * sz * (1.f - sz),
+                                du[3] * v4[j].w * sw * (1.f - sw));
+        }
+        __builtin_amdgcn_wave_barrier();
+        store_tile32_lines(dv, reinterpret_cast<float*>(tile), dVG + col + 32 * t, r0, live ? R : 0, 2 * hid, Lq);
+        store_tile32_lines(dg, reinterpret_cast<float*>(tile), dVG + hid + col + 32 * t, r0, live ? R : 0, 2 * hid, Lq);
+    }
+}
+// (b) dy (both 128-column blocks of the 256-wide row, in the accumulators) -> out = dres + norm^T(dy; x): RMSNorm (ln == 0; eps
+//     2^-23) or LayerNorm (eps 1e-5) with weight gamma: dx = rstd (dyh - [mean(dyh)] - xh mean(dyh xh)), dyh = dy gamma. The row x
+//     is read twice (statistics, then the result), 32 columns at a time: the second read comes from L2.
+__device__ __forceinline__ void rs_store_norm_bwd(f32x16 (&a0)[4], f32x16 (&a1)[4], float f, const float* __restrict__ x,
+                                                  const float* __restrict__ gamma, int ln, const float* __restrict__ dres,
+                                                  float* __restrict__ out, int64_t r0, int64_t R, bool live, char* tile,
+                                                  const RowLane& Lq) {
+    const int64_t row = r0 + Lq.r < R ? r0 + Lq.r : R - 1;
+    float s1 = 0.f, s2 = 0.f, sx = 0.f, sxx = 0.f;  // sum dyh, sum dyh x, sum x, sum x^2 (LayerNorm: centred below)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            f32x16& a = b ? a1[t] : a0[t];
+            float4 x4[4];
+            load_rowfrag<4>(x4, x + 128 * b + 32 * t, row, 256, Lq.h);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + 128 * b + 32 * t + 8 * j + 4 * Lq.h);
+                const float xv[4] = {x4[j].x, x4[j].y, x4[j].z, x4[j].w}, gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float d = a[4 * j + i] * f * gv[i];
+                    a[4 * j + i] = d;  // dyh from here on
+                    s1 += d; s2 = fmaf(d, xv[i], s2); sx += xv[i]; sxx = fmaf(xv[i], xv[i], sxx);
+                }
+            }
+        }
+    s1 = row_sum(s1); s2 = row_sum(s2); sx = row_sum(sx); sxx = row_sum(sxx);
+    const float mean = ln ? sx * (1.0f / 256.0f) : 0.f;
+    const float var = sxx * (1.0f / 256.0f) - mean * mean;
+    const float rstd = rsqrtf(var + (ln ? 1e-5f : 1.1920928955078125e-07f));
+    const float m1 = ln ? s1 * (1.0f / 256.0f) : 0.f;
+    const float m2 = (s2 - mean * s1) * rstd * (1.0f / 256.0f);  // mean(dyh xh), xh = (x - mean) rstd
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const f32x16& a = b ? a1[t] : a0[t];
+            float4 x4[4], r4[4], y[4];
+            load_rowfrag<4>(x4, x + 128 * b + 32 * t, row, 256, Lq.h);
+            load_rowfrag<4>(r4, dres + 128 * b + 32 * t, row, 256, Lq.h);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                y[j] = make_float4(r4[j].x + rstd * (a[4 * j] - m1 - (x4[j].x - mean) * rstd * m2),
+                                   r4[j].y + rstd * (a[4 * j + 1] - m1 - (x4[j].y - mean) * rstd * m2),
+                                   r4[j].z + rstd * (a[4 * j + 2] - m1 - (x4[j].z - mean) * rstd * m2),
+                                   r4[j].w + rstd * (a[4 * j + 3] - m1 - (x4[j].w - mean) * rstd * m2));
+            __builtin_amdgcn_wave_barrier();
+            store_tile32_lines(y, reinterpret_cast<float*>(tile), out + 128 * b + 32 * t, r0, live ? R : 0, 256, Lq);
+        }
+}
+
+template <int NORM, int EPI = 0>  // EPI 1: the SwiGLU adjoint as the epilogue (A = the saved [value | gate] rows, Y = [N, 2 x 128 nn])
 __global__ __launch_bounds__(256, 2) void k_rowgemm_s_k2(const float* __restrict__ X, int ldx, const float* __restrict__ cs,
                                                         const float* __restrict__ cb, W2 w, const float* __restrict__ bias,
                                                         const float* __restrict__ A, float* __restrict__ Y, int ldy, int nn, int64_t R) {
@@ -355,7 +435,8 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_s_k2(const float* __restrict
         const bool last = nb + 1 == nn;
         // (16 store instructions of the previous block may be in flight over the first three stages -- if all of them were issued)
         if (nb > 0 && !full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a partial tile skips store instructions: drained instead of counted)
-        rs_gemm(acc, xh[0], xl[0], nb > 0 && full, [=](int s, int slot) {
+        if (EPI == 1 && nb > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (32 stores per block there: drained, not budgeted)
+        rs_gemm(acc, xh[0], xl[0], EPI == 0 && nb > 0 && full, [=](int s, int slot) {
             if (s < 16) piece(nb, 0, s, slot); else piece(nb, 1, s - 16, slot);
         }, ring, lane16);
         rs_gemm(acc, xh[1], xl[1], false, [=](int s, int slot) {
@@ -365,13 +446,16 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_s_k2(const float* __restrict
         }, ring, lane16);
         RS_LANE(Lq);
         RS_ROW0(r0);
-        rs_store_block(acc, f, bias ? bias + 128 * nb : nullptr, A, Y, ldy, 128 * nb, r0, R, live, tile, Lq);
+        if (EPI == 1) rs_store_block_swiglu_bwd(acc, f, A, Y, 128 * nn, 128 * nb, r0, R, live, tile, Lq);
+        else rs_store_block(acc, f, bias ? bias + 128 * nb : nullptr, A, Y, ldy, 128 * nb, r0, R, live, tile, Lq);
     }
 }
 
+template <int EPI = 0>  // EPI 1: the norm adjoint as the epilogue (bias = the norm's weight, A = the residual's adjoint, xn = the normalised rows' source)
 __global__ __launch_bounds__(256, 2) void k_rowgemm_s_n2(const float* __restrict__ X, int ldx, int nk, W2 w,
                                                         const float* __restrict__ bias, const float* __restrict__ A,
-                                                        float* __restrict__ Y, int ldy, int64_t R) {
+                                                        float* __restrict__ Y, int ldy, int64_t R,
+                                                        const float* __restrict__ xn = nullptr, int ln = 0) {
     RS_SETUP();
     (void)full;
     const int kbt = 8 * nk;
@@ -447,6 +531,10 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_s_n2(const float* __restrict
     RS_ROW0(r0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    if (EPI == 1) {
+        rs_store_norm_bwd(acc0, acc1, f, xn, bias, ln, A, Y, r0, R, live, tile, Lq);
+        return;
+    }
     rs_store_block(acc0, f, bias, A, Y, ldy, 0, r0, R, live, tile, Lq);
     rs_store_block(acc1, f, bias ? bias + 128 : nullptr, A, Y, ldy, 128, r0, R, live, tile, Lq);
 }
@@ -474,12 +562,33 @@ bool rowgemm_s_ex(hipStream_t st, const float* X, int K, const float* cs, const 
         allow_big_lds(k_rowgemm_s_k2<0>, lds);
         k_rowgemm_s_k2<0><<<grid, 256, lds, st>>>(X, K, cs, nullptr, w, bias, A, Y, n_out, n_out / 128, R);
     } else if (n_out == 256 && K >= 256 && !cs) {
-        allow_big_lds(k_rowgemm_s_n2, lds);
-        k_rowgemm_s_n2<<<grid, 256, lds, st>>>(X, K, K / 128, w, bias, A, Y, n_out, R);
+        allow_big_lds(k_rowgemm_s_n2<0>, lds);
+        k_rowgemm_s_n2<0><<<grid, 256, lds, st>>>(X, K, K / 128, w, bias, A, Y, n_out, R);
     } else {
         allow_big_lds(k_rowgemm_s, lds);
         k_rowgemm_s<<<grid, 256, lds, st>>>(X, K, K / 128, cs, w, bias, Y, n_out, n_out / 128, R, A);
     }
+    return true;
+}
+// dVG[R, 2 hid] = swiglu'(VG) ((X[R, 256]) W^T): the node update's adjoint, first half (hid a multiple of 128)
+bool rowgemm_s_swiglu_bwd(hipStream_t st, const float* X, const void* planes, const float* VG, float* dVG, int hid, int64_t R) {
+    if (!planes || hid % 128 || hid > 1024 || !emlp_s_serves(R)) return false;
+    const f16x8* b = reinterpret_cast<const f16x8*>(planes);
+    W2 w; w.h = b; w.l = b + (size_t)(hid / 32) * (256 / 16) * 64;
+    const size_t lds = HS_NW * 16384 + HS_NSLOT * HS_SLOT;
+    allow_big_lds(k_rowgemm_s_k2<0, 1>, lds);
+    k_rowgemm_s_k2<0, 1><<<(int)cdiv(R, HS_NW * WROWS), 256, lds, st>>>(X, 256, nullptr, nullptr, w, nullptr, VG, dVG, 2 * hid, hid / 128, R);
+    return true;
+}
+// out[R, 256] = dres + norm^T((X[R, K]) W^T; xn): the node update's adjoint, second half (gamma: the norm's weight; ln: LayerNorm)
+bool rowgemm_s_norm_bwd(hipStream_t st, const float* X, int K, const void* planes, const float* xn, const float* gamma, int ln,
+                        const float* dres, float* out, int64_t R) {
+    if (!planes || K % 128 || K < 256 || K > 1024 || !emlp_s_serves(R)) return false;
+    const f16x8* b = reinterpret_cast<const f16x8*>(planes);
+    W2 w; w.h = b; w.l = b + (size_t)(256 / 32) * (K / 16) * 64;
+    const size_t lds = HS_NW * 16384 + HS_NSLOT * HS_SLOT;
+    allow_big_lds(k_rowgemm_s_n2<1>, lds);
+    k_rowgemm_s_n2<1><<<(int)cdiv(R, HS_NW * WROWS), 256, lds, st>>>(X, K, K / 128, w, gamma, dres, out, 256, R, xn, ln);
     return true;
 }
 bool rowgemm_s(hipStream_t st, const float* X, int K, const float* cs, const void* planes, const float* bias, float* Y, int n_out,
